@@ -1,0 +1,238 @@
+"""Deterministic synthetic radiosonde captures (test + bench input generator).
+
+The reference ships no sample captures; parity is pinned by
+running the compiled reference next to the engine on captures made here.
+Everything is seeded numpy -> identical bytes in this container and on the GPU box.
+
+RS41 frame layout follows the block map in the reference
+(demod/mod/rs41mod.c:336-392, header bytes :172, whitening mask :175-182,
+RS(255,231) interleave :1729-1732, CRC-16/CCITT-FALSE :284-304).
+Modulation: 4800 Bd GFSK, BT 0.5, +-2400 Hz deviation.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# GF(2^8), primitive polynomial 0x11D, alpha = 2  (bch_ecc_mod.h:83-89)
+# --------------------------------------------------------------------------
+_GF_EXP = np.zeros(512, dtype=np.int32)
+_GF_LOG = np.zeros(256, dtype=np.int32)
+
+
+def _gf_init() -> None:
+    x = 1
+    for i in range(255):
+        _GF_EXP[i] = x
+        _GF_LOG[x] = i
+        x <<= 1
+        if x & 0x100:
+            x ^= 0x11D
+    _GF_EXP[255:510] = _GF_EXP[0:255]
+
+
+_gf_init()
+
+
+def gf_mul(a: int, b: int) -> int:
+    if a == 0 or b == 0:
+        return 0
+    return int(_GF_EXP[_GF_LOG[a] + _GF_LOG[b]])
+
+
+def _rs_generator(nroots: int = 24) -> list[int]:
+    # g(x) = prod_{i=0}^{23} (x - alpha^i), coefficient list low->high (b = 0)
+    g = [1]
+    for i in range(nroots):
+        root = int(_GF_EXP[i])
+        ng = [0] * (len(g) + 1)
+        for j, c in enumerate(g):
+            ng[j] ^= gf_mul(c, root)
+            ng[j + 1] ^= c
+        g = ng
+    return g
+
+
+_RS_G = _rs_generator()
+
+
+def rs255_231_parity(msg231: bytes | np.ndarray) -> np.ndarray:
+    """Parity p[0..23] so that cw = [p, msg] (cw[i] = coeff of x^i) is a codeword."""
+    msg = [int(v) for v in msg231]
+    assert len(msg) == 231
+    rem = [0] * 24 + msg  # m(x) * 1 with zero low coefficients
+    for d in range(254, 23, -1):  # long division by monic g, high -> low
+        c = rem[d]
+        if c:
+            for j in range(25):
+                rem[d - 24 + j] ^= gf_mul(_RS_G[j], c)
+    return np.array(rem[:24], dtype=np.uint8)
+
+
+def crc16_ccitt_false(data: bytes | np.ndarray) -> int:
+    rem = 0xFFFF
+    for b in bytes(data):
+        rem ^= b << 8
+        for _ in range(8):
+            rem = ((rem << 1) ^ 0x1021) & 0xFFFF if rem & 0x8000 else (rem << 1) & 0xFFFF
+    return rem
+
+
+RS41_HEADER_BYTES = bytes([0x86, 0x35, 0xF4, 0x40, 0x93, 0xDF, 0x1A, 0x60])
+RS41_MASK = bytes([
+    0x96, 0x83, 0x3E, 0x51, 0xB1, 0x49, 0x08, 0x98, 0x32, 0x05, 0x59, 0x0E, 0xF9, 0x44, 0xC6, 0x26,
+    0x21, 0x60, 0xC2, 0xEA, 0x79, 0x5D, 0x6D, 0xA1, 0x54, 0x69, 0x47, 0x0C, 0xDC, 0xE8, 0x5C, 0xF1,
+    0xF7, 0x76, 0x82, 0x7F, 0x07, 0x99, 0xA2, 0x2C, 0x93, 0x7C, 0x30, 0x63, 0xF5, 0x10, 0x2E, 0x61,
+    0xD0, 0xBC, 0xB4, 0xB6, 0x06, 0xAA, 0xF4, 0x23, 0x78, 0x6E, 0x3B, 0xAE, 0xBF, 0x7B, 0x4C, 0xC1])
+RS41_FRAME_LEN = 320
+
+
+def _put_block(frame: bytearray, pos: int, blk_id: int, payload: bytes) -> None:
+    frame[pos] = blk_id
+    frame[pos + 1] = len(payload)
+    frame[pos + 2:pos + 2 + len(payload)] = payload
+    crc = crc16_ccitt_false(payload)
+    frame[pos + 2 + len(payload)] = crc & 0xFF
+    frame[pos + 3 + len(payload)] = crc >> 8
+
+
+def rs41_frame(frame_no: int, sonde_id: str = "S1234567", *, week: int = 2280,
+               itow_ms: int | None = None, ecef_cm=(412345600, 61234500, 480123400),
+               vel_cms=(123, -45, 510), nsats: int = 9, batt_dV: int = 27,
+               rng: np.random.Generator | None = None) -> bytes:
+    """One valid standard (320-byte) RS41 frame with CRCs and RS parity."""
+    rng = rng or np.random.default_rng(frame_no)
+    f = bytearray(RS41_FRAME_LEN)
+    f[0:8] = RS41_HEADER_BYTES
+    f[0x38] = 0x0F
+    # 0x79 FRAME block, 0x28 bytes
+    p = bytearray(0x28)
+    p[0:2] = int(frame_no & 0xFFFF).to_bytes(2, "little")
+    p[2:10] = sonde_id.encode("ascii")[:8].ljust(8, b"0")
+    p[10] = batt_dV
+    calidx = frame_no % 51
+    p[0x52 - 0x3B] = calidx
+    p[0x53 - 0x3B:0x63 - 0x3B] = bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+    _put_block(f, 0x39, 0x79, bytes(p))
+    # 0x7A PTU block, 0x2A bytes (opaque measurement counts)
+    _put_block(f, 0x65, 0x7A, bytes(rng.integers(0, 256, 0x2A, dtype=np.uint8)))
+    # 0x7C GPS1, 0x1E bytes: week, iTOW, sats
+    p = bytearray(rng.integers(0, 256, 0x1E, dtype=np.uint8).tobytes())
+    p[0:2] = int(week).to_bytes(2, "little")
+    if itow_ms is None:
+        itow_ms = 1000 * (100000 + frame_no)
+    p[2:6] = int(itow_ms).to_bytes(4, "little")
+    _put_block(f, 0x93, 0x7C, bytes(p))
+    # 0x7D GPS2, 0x59 bytes
+    _put_block(f, 0xB5, 0x7D, bytes(rng.integers(0, 256, 0x59, dtype=np.uint8)))
+    # 0x7B GPS3, 0x15 bytes: ECEF pos (cm), vel (cm/s), nSV
+    p = bytearray(0x15)
+    for i in range(3):
+        p[4 * i:4 * i + 4] = int(ecef_cm[i]).to_bytes(4, "little", signed=True)
+        p[12 + 2 * i:14 + 2 * i] = int(vel_cms[i]).to_bytes(2, "little", signed=True)
+    p[18] = nsats
+    p[19] = 10
+    p[20] = 12
+    _put_block(f, 0x112, 0x7B, bytes(p))
+    # 0x76 zero block, 0x11 bytes
+    _put_block(f, 0x12B, 0x76, bytes(0x11))
+    assert 0x12B + 2 + 0x11 + 2 == RS41_FRAME_LEN
+    # two interleaved RS(255,231) codewords, message zero-padded beyond byte 320
+    msg1 = np.zeros(231, dtype=np.uint8)
+    msg2 = np.zeros(231, dtype=np.uint8)
+    body = np.frombuffer(bytes(f[56:]), dtype=np.uint8)
+    msg1[:len(body[0::2])] = body[0::2]
+    msg2[:len(body[1::2])] = body[1::2]
+    f[8:32] = rs255_231_parity(msg1).tobytes()
+    f[32:56] = rs255_231_parity(msg2).tobytes()
+    return bytes(f)
+
+
+def rs41_onair_bits(frame: bytes, preamble_bytes: int = 40) -> np.ndarray:
+    """Whitened, LSB-first bit stream with 0101.. preamble in front."""
+    fr = np.frombuffer(frame, dtype=np.uint8)
+    mask = np.frombuffer(RS41_MASK, dtype=np.uint8)
+    x = fr ^ mask[np.arange(len(fr)) % 64]
+    bits = np.unpackbits(x, bitorder="little")
+    pre = np.tile(np.array([0, 1], dtype=np.uint8), preamble_bytes * 4)
+    return np.concatenate([pre, bits])
+
+
+# --------------------------------------------------------------------------
+# GFSK modulator
+# --------------------------------------------------------------------------
+def _gauss_taps(sps: float, bt: float, span: int = 4) -> np.ndarray:
+    n = int(round(span * sps)) | 1
+    t = (np.arange(n) - (n - 1) / 2) / sps
+    sigma = np.sqrt(np.log(2.0)) / (2 * np.pi * bt)
+    g = np.exp(-0.5 * (t / sigma) ** 2)
+    return g / g.sum()
+
+
+def gfsk_baseband(bits: np.ndarray, sr: int, baud: float, dev_hz: float, bt: float = 0.5,
+                  manchester: bool = False) -> np.ndarray:
+    """Complex unit-amplitude GFSK burst at baseband (bit 1 -> +dev)."""
+    from scipy.signal import oaconvolve
+    if manchester:  # 1 -> 10, 0 -> 01 (caller passes symbols if it wants another map)
+        sym = np.empty(2 * len(bits), dtype=np.uint8)
+        sym[0::2] = bits
+        sym[1::2] = 1 - bits
+        bits = sym
+    nrz = 2.0 * bits.astype(np.float64) - 1.0
+    sps = sr / baud
+    nsamp = int(round(len(bits) * sps))
+    idx = np.minimum((np.arange(nsamp) / sps).astype(np.int64), len(bits) - 1)
+    f = oaconvolve(nrz[idx], _gauss_taps(sps, bt), mode="same") * dev_hz
+    phase = 2 * np.pi * np.cumsum(f) / sr
+    return np.exp(1j * phase)
+
+
+def rs41_capture(sr: int = 2_400_000, seconds: float = 2.2, fq: float = 0.1, *, n_frames: int | None = None,
+                 first_frame_no: int = 1234, sonde_id: str = "S1234567", t_first: float = 0.15,
+                 amp: float = 0.5, noise_sigma: float = 0.01, dc: complex = 0.0, seed: int = 1,
+                 bit_errors: int = 0, dev_hz: float = 2400.0, f_offset_hz: float = 0.0,
+                 return_frames: bool = False):
+    """Interleaved int16 IQ capture: one RS41 frame per second at carrier fq*sr (+f_offset_hz).
+
+    bit_errors: number of random on-air bit flips per frame (inside the 320 data bytes) to
+    exercise the RS decoder.  Returns int16 array of shape [2*N] (and the clean frames).
+    """
+    rng = np.random.default_rng(seed)
+    n = int(round(sr * seconds))
+    x = np.zeros(n, dtype=np.complex128)
+    frames = []
+    k = 0
+    while True:
+        t0 = t_first + k * 1.0
+        if n_frames is not None and k >= n_frames:
+            break
+        frm = rs41_frame(first_frame_no + k, sonde_id, rng=np.random.default_rng(seed * 1000 + k))
+        bits = rs41_onair_bits(frm)
+        if bit_errors:
+            pos = rng.choice(np.arange(40 * 8 + 64, len(bits)), size=bit_errors, replace=False)
+            bits = bits.copy()
+            bits[pos] ^= 1
+        burst = gfsk_baseband(bits, sr, 4800.0, dev_hz)
+        s0 = int(round(t0 * sr))
+        if s0 + len(burst) > n:
+            break
+        x[s0:s0 + len(burst)] += amp * burst
+        frames.append(frm)
+        k += 1
+    if fq != 0.0 or f_offset_hz != 0.0:
+        x *= np.exp(2j * np.pi * (fq + f_offset_hz / sr) * np.arange(n))
+    x += dc
+    x += noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    if return_frames:
+        return out, frames
+    return out
+
+
+def snap_fq(fq: float, sr: int) -> float:
+    """Snap a normalised carrier to a multiple of 16 Hz (the LUT periodicity of
+    demod_mod.c:1265-1288) so the reference mixes with exactly this frequency."""
+    hz = int(round(fq * sr / 16.0)) * 16
+    return hz / sr
