@@ -1,0 +1,172 @@
+"""ctypes bindings for the CPU oracle (liboracle.so) and the compiled reference (oracle/_ref).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg — never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(HERE, "_ref")
+
+RS41_HDR = b"0000100001101101010100111000100001000100011010010100100000011111"
+CONST_NAMES = ("N", "M", "L", "K", "delay", "dectaps", "decM", "lut_len", "lpiq_taps", "lpfm_taps", "if_sr")
+
+
+def build(ref: bool | None = None) -> None:
+    """Compile liboracle.so (always) and oracle/_ref (only where /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+    if ref is None:
+        ref = os.path.isdir("/root/reference/demod/mod")
+    if ref:
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        _lib = C.CDLL(path)
+        _lib.ora_rs41_decode.restype = C.c_int
+        _lib.ora_streams.restype = C.c_int
+    return _lib
+
+
+def _buf(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ora_rs41_decode(iq: np.ndarray, sr: int, *, bps: int = 16, iq_mode: int = 5, fq: float = 0.0,
+                    lp_iq: bool = True, lp_fm: bool = False, afc: bool = False, ecc: int = 2,
+                    thres: float = 0.7, max_frames: int = 64, want_soft: bool = True):
+    """Oracle equivalent of `rs41mod -r --ecc<ecc> --IQ fq [--lpIQ] [--dc] - sr bps`."""
+    raw = np.ascontiguousarray(iq)
+    frames = np.zeros((max_frames, 518), np.uint8)
+    flen = np.zeros(max_frames, np.int32)
+    ec = np.zeros(max_frames, np.int32)
+    meta = np.zeros((max_frames, 4), np.float64)
+    soft = np.zeros((max_frames, 4080), np.float32) if want_soft else None
+    pre = np.zeros((max_frames, 518), np.float32)
+    n = lib().ora_rs41_decode(_buf(raw), C.c_size_t(raw.nbytes), sr, bps, iq_mode, C.c_double(fq),
+                              (1 if lp_iq else 0) | (2 if lp_fm else 0), int(afc), ecc, C.c_float(thres),
+                              max_frames, _buf(frames), _buf(flen), _buf(ec), _buf(meta),
+                              _buf(soft) if want_soft else None, _buf(pre))
+    if n < 0:
+        raise RuntimeError("ora_rs41_decode failed")
+    lines = []
+    out = C.create_string_buffer(2 * 518 + 32)
+    for i in range(n):
+        k = lib().ora_rs41_rawline(_buf(frames[i]), int(flen[i]), int(ec[i]), out)
+        lines.append(out.raw[:k].decode())
+    return dict(n=n, frames=frames[:n], flen=flen[:n], ecc=ec[:n], mv=meta[:n, 0], mv_pos=meta[:n, 1].astype(np.int64),
+                s_in_after=meta[:n, 2].astype(np.int64), soft=None if soft is None else soft[:n],
+                pre_ecc=pre[:n].astype(np.uint8), lines=lines)
+
+
+def _streams(fn, cfgargs, iq, max_if, want_iq):
+    raw = np.ascontiguousarray(iq)
+    iqo = np.zeros((max_if, 2), np.float32) if want_iq else None
+    fm = np.zeros(max_if, np.float32)
+    bufs = np.zeros(max_if, np.float32)
+    consts = np.zeros(11, np.int32)
+    n = fn(raw, cfgargs, max_if, iqo, fm, bufs, consts)
+    if n < 0:
+        raise RuntimeError("streams failed: %d" % n)
+    return dict(n=n, iq=None if iqo is None else iqo[:n], fm=fm[:n], bufs=bufs[:n],
+                consts=dict(zip(CONST_NAMES, (int(v) for v in consts))))
+
+
+def ora_streams(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False, afc=False, baud=4800.0,
+                bt=0.5, h=0.6, lpiq_bw=7400, lpfm_bw=6000, hdr=RS41_HDR, symlen=1, symhd=1,
+                max_if=None, want_iq=True):
+    if max_if is None:
+        max_if = len(iq) // 2 + 16
+    mask = (1 if lp_iq else 0) | (2 if lp_fm else 0)
+
+    def call(raw, _, max_if, iqo, fm, bufs, consts):
+        return lib().ora_streams(_buf(raw), C.c_size_t(raw.nbytes), sr, bps, iq_mode, C.c_double(-fq), mask,
+                                 int(afc), C.c_float(baud), C.c_float(bt), C.c_float(h), lpiq_bw, lpfm_bw,
+                                 C.c_char_p(hdr), symlen, symhd, max_if,
+                                 None if iqo is None else _buf(iqo), _buf(fm), _buf(bufs), _buf(consts))
+    return _streams(call, None, iq, max_if, want_iq)
+
+
+# ----------------------------------------------------------------------------- compiled reference
+class RefCfg(C.Structure):
+    _fields_ = [("sr", C.c_int), ("bps", C.c_int), ("opt_iq", C.c_int), ("opt_lp", C.c_int),
+                ("opt_dc", C.c_int), ("opt_iqdc", C.c_int), ("opt_min", C.c_int), ("opt_nolut", C.c_int),
+                ("xlt_fq", C.c_double), ("baud", C.c_float), ("symlen", C.c_int), ("symhd", C.c_int),
+                ("BT", C.c_float), ("h", C.c_float), ("lpIQ_bw", C.c_int), ("lpFM_bw", C.c_int),
+                ("hdr", C.c_char_p)]
+
+
+def have_ref() -> bool:
+    return os.path.exists(os.path.join(REFDIR, "libref_demod.so")) and os.path.exists(os.path.join(REFDIR, "rs41mod"))
+
+
+_reflibs: dict = {}
+
+
+def reflib(name: str = "libref_demod.so") -> C.CDLL:
+    if name not in _reflibs:
+        _reflibs[name] = C.CDLL(os.path.join(REFDIR, name))
+    return _reflibs[name]
+
+
+def _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm, afc, baud, bt, h, lpiq_bw, lpfm_bw, hdr, symlen, symhd):
+    return RefCfg(sr, bps, iq_mode, (1 if lp_iq else 0) | (2 if lp_fm else 0), int(afc), 0, 0, 0, -fq, baud,
+                  symlen, symhd, bt, h, lpiq_bw, lpfm_bw, hdr)
+
+
+def ref_streams(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False, afc=False, baud=4800.0,
+                bt=0.5, h=0.6, lpiq_bw=7400, lpfm_bw=6000, hdr=RS41_HDR, symlen=1, symhd=1,
+                max_if=None, want_iq=True, libname="libref_demod.so"):
+    if max_if is None:
+        max_if = len(iq) // 2 + 16
+    cfg = _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm, afc, baud, bt, h, lpiq_bw, lpfm_bw, hdr, symlen, symhd)
+    L = reflib(libname)
+    L.ref_streams.restype = C.c_int
+
+    def call(raw, _, max_if, iqo, fm, bufs, consts):
+        return L.ref_streams(C.byref(cfg), _buf(raw), C.c_size_t(raw.nbytes), max_if,
+                             None if iqo is None else _buf(iqo), _buf(fm), _buf(bufs), _buf(consts))
+    return _streams(call, None, iq, max_if, want_iq)
+
+
+def ref_softframes(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False, afc=False, baud=4800.0,
+                   bt=0.5, h=0.6, lpiq_bw=7400, lpfm_bw=6000, hdr=RS41_HDR, symlen=1, symhd=1,
+                   thres=0.7, hdmax=4, bitofs=2, l=2.0, nbits=4080, max_hits=64, libname="libref_demod.so"):
+    raw = np.ascontiguousarray(iq)
+    cfg = _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm or (afc and iq_mode == 5), afc, baud, bt, h, lpiq_bw,
+                  lpfm_bw, hdr, symlen, symhd)
+    hits = np.zeros((max_hits, 4), np.float64)
+    sb = np.zeros((max_hits, nbits), np.float32)
+    sb1 = np.zeros((max_hits, nbits), np.float32)
+    consts = np.zeros(11, np.int32)
+    L = reflib(libname)
+    L.ref_softframes.restype = C.c_int
+    n = L.ref_softframes(C.byref(cfg), _buf(raw), C.c_size_t(raw.nbytes), C.c_float(thres), hdmax, bitofs,
+                         C.c_float(l), nbits, max_hits, _buf(hits), _buf(sb), _buf(sb1), _buf(consts))
+    if n < 0:
+        raise RuntimeError("ref_softframes failed")
+    return dict(n=n, mv=hits[:n, 0], mv_pos=hits[:n, 1].astype(np.int64), nbits=hits[:n, 2].astype(np.int64),
+                s_in_after=hits[:n, 3].astype(np.int64), soft=sb[:n], soft1=sb1[:n],
+                consts=dict(zip(CONST_NAMES, (int(v) for v in consts))))
+
+
+def ref_run(binary: str, args: list[str], data: bytes | np.ndarray, timeout: float = 120.0):
+    """Run a compiled reference binary with `data` on stdin -> (stdout, stderr, returncode)."""
+    if isinstance(data, np.ndarray):
+        data = data.tobytes()
+    r = subprocess.run([os.path.join(REFDIR, binary)] + list(args), input=data, capture_output=True, timeout=timeout)
+    return r.stdout.decode(errors="replace"), r.stderr.decode(errors="replace"), r.returncode

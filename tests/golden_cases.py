@@ -1,0 +1,28 @@
+"""Shared access to tests/golden (fixtures generated from the compiled reference by tools/make_golden.py)."""
+import functools, json, os, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_golden  # noqa: E402  (only CASES + capture(); does not touch oracle/_ref on import)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NAMES = list(make_golden.CASES)
+
+
+@functools.lru_cache(maxsize=None)
+def load(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    g["consts"] = json.loads(str(g["consts"]))
+    g["lines"] = [str(s) for s in g["lines"]]
+    return g
+
+
+@functools.lru_cache(maxsize=4)
+def capture(name):
+    x, fq = make_golden.capture(make_golden.CASES[name])
+    return x, fq, make_golden.CASES[name]["sr"]
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64))))) if np.size(a) else 0.0

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref, built from /root/reference).
+
+Run in the build container only (needs oracle/_ref).  The captures are re-created from seeds by
+radiosonde_auto_rx_amd.synth, so only the reference's outputs are stored:
+  lines      stdout of `rs41mod -r --ecc2 --crc --IQ fq --lpIQ - sr 16`   (shipping -Ofast build)
+  mv, mv_pos header score / position of every hit                          (harness on demod_mod.o)
+  soft       4080 soft bits per hit (-O2 build of the same source = strict IEEE evaluation)
+  iq/fm/bufs per-IF-sample streams, window [w0, w1)                        (-O2 build)
+  floor_*    RMS(-Ofast minus -O2) of the same quantity: the reference's own fast-math self-noise
+"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import bind
+from radiosonde_auto_rx_amd import synth
+
+CASES = {
+    # name: capture kwargs (+ window of IF samples kept for the stream fixtures)
+    "rs41_2400k_clean": dict(sr=2_400_000, seconds=2.2, fq=0.1, noise_sigma=0.01, seed=1, win=(8000, 24000)),
+    "rs41_2400k_noisy_be14": dict(sr=2_400_000, seconds=2.2, fq=-0.2371, noise_sigma=0.12, bit_errors=14, seed=7, win=(8000, 16000)),
+    "rs41_480k_clean": dict(sr=480_000, seconds=3.2, fq=0.05, noise_sigma=0.01, seed=3, win=(0, 40000)),
+    "rs41_480k_be30": dict(sr=480_000, seconds=3.2, fq=0.31, noise_sigma=0.05, bit_errors=30, seed=4, win=(0, 0)),
+    "rs41_96k_off300": dict(sr=96_000, seconds=3.2, fq=0.0, f_offset_hz=300.0, noise_sigma=0.02, seed=5, win=(0, 0)),
+}
+
+
+def rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64))))) if np.size(a) else 0.0
+
+
+def capture(kw):
+    kw = dict(kw); kw.pop("win")
+    sr = kw["sr"]
+    kw["fq"] = synth.snap_fq(kw["fq"], sr)
+    return synth.rs41_capture(**kw), kw["fq"]
+
+
+def main():
+    outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for name, kw in CASES.items():
+        x, fq = capture(kw)
+        sr = kw["sr"]
+        out, err, rc = bind.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], x)
+        lines = out.splitlines()
+        fast = bind.ref_softframes(x, sr, fq=fq)
+        strict = bind.ref_softframes(x, sr, fq=fq, libname="libref_demod_O2.so")
+        assert fast["n"] == strict["n"] == len(lines), (name, fast["n"], strict["n"], len(lines))
+        w0, w1 = kw["win"]
+        d = dict(lines=np.array(lines), mv=strict["mv"], mv_pos=strict["mv_pos"], soft=strict["soft"],
+                 mv_fast=fast["mv"], floor_soft=rms(fast["soft"] - strict["soft"]),
+                 consts=json.dumps(strict["consts"]), fq=fq, win=np.array([w0, w1]))
+        if w1 > w0:
+            sf = bind.ref_streams(x, sr, fq=fq)
+            ss = bind.ref_streams(x, sr, fq=fq, libname="libref_demod_O2.so")
+            for k in ("iq", "fm", "bufs"):
+                d[k] = ss[k][w0:w1]
+                d["floor_" + k] = rms(sf[k] - ss[k])
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
+        print(name, "frames", len(lines), [l[-10:] for l in lines], "mv", strict["mv"], "floor_soft", d["floor_soft"])
+
+
+if __name__ == "__main__":
+    main()
