@@ -1,0 +1,141 @@
+/*
+ * sonde_hip.h — C ABI of libsonde_hip.so, the MI355X-native radiosonde IQ demodulation engine.
+ *
+ * Plain C, plain pointers and sizes.  The reference has no in-process FFI for this path: its
+ * "operator API" is (i) the per-sonde CLI contract and (ii) the function seam of
+ * demod/mod/demod_mod.h:179-192 under it.  This header is the batched (many
+ * channels per call) equivalent of that seam; each entry point names the reference code it replaces.
+ * Host programs (host/rs41mod.c ...) keep the CLI contract on top of it; INTEGRATION.md shows the bindings.
+ *
+ * Threading: an engine is owned by one host thread.  No global state; several engines (one per GPU)
+ * may live in one process.  All functions return 0 / a non-negative count on success and a negative
+ * SONDE_E_* code on error (the reference convention: negative int, message on stderr by the caller —
+ * sonde_strerror() supplies the text).
+ */
+#ifndef SONDE_HIP_H
+#define SONDE_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SONDE_ABI_VERSION 1
+
+/* error codes */
+#define SONDE_E_ARG      (-1)   /* bad argument / unsupported option combination          */
+#define SONDE_E_NOGPU    (-2)   /* no HIP device / HIP runtime failure (never falls back) */
+#define SONDE_E_NOMEM    (-3)
+#define SONDE_E_RANGE    (-4)   /* chunk larger than max_chunk / not a multiple of decM   */
+#define SONDE_E_OVERFLOW (-5)   /* frame queue overflow (frames were dropped)             */
+
+/* sonde types (dsp.hdr / baud / BT / h presets of the reference callers) */
+#define SONDE_RS41  41          /* rs41mod.c:2812-2836: 4800 Bd, BT 0.5, h 0.6, 64-bit header, thres 0.7, hdmax 4 */
+
+/* opt_lp bits, as demod_mod.h:12-14 */
+#define SONDE_LP_IQ 1
+#define SONDE_LP_FM 2
+
+/* stream taps for parity testing (what the reference keeps in rot_iqbuf / fm_buffer / bufs,
+ * demod_mod.c:775,849,852; CORR is the un-normalised matched-filter output of getCorrDFT :190-192) */
+#define SONDE_TAP_DECIM 0       /* decimated IQ before the IF low-pass  (cf32) */
+#define SONDE_TAP_IFIQ  1       /* IF-filtered IQ = rot_iqbuf          (cf32) */
+#define SONDE_TAP_FM    2       /* fm_buffer                            (f32)  */
+#define SONDE_TAP_BUFS  3       /* bufs (sliced stream)                 (f32)  */
+#define SONDE_TAP_CORR  4       /* header correlation per end-sample    (f32)  */
+
+typedef struct sonde_engine sonde_engine_t;
+
+/* Engine configuration: the fields the reference callers set in dsp_t (rs41mod.c:2816-2836) plus batching. */
+typedef struct {
+    int32_t abi_version;     /* SONDE_ABI_VERSION                                             */
+    int32_t device;          /* HIP device ordinal                                            */
+    int32_t n_channels;      /* independent channels (one reference process each)             */
+    int32_t sample_rate;     /* input rate of every channel ("- <sr> <bs>" argv)              */
+    int32_t bits;            /* 16 (cs16); 8/32 not yet                                        */
+    int32_t sonde_type;      /* SONDE_RS41                                                    */
+    int32_t opt_lp;          /* SONDE_LP_IQ (--lpIQ) | SONDE_LP_FM (--lpFM)                    */
+    int32_t opt_dc;          /* --dc (AFC); not yet supported -> SONDE_E_ARG                   */
+    int32_t opt_min;         /* --min (IF 32 kHz)                                             */
+    int32_t lpiq_bw;         /* --lpbw in Hz, 0 = type default (7400 for RS41)                */
+    int32_t ecc_level;       /* 0 none, 1 --ecc, 2 --ecc2                                     */
+    float   thres;           /* --ths, header score threshold (0 = type default)              */
+    int32_t max_chunk;       /* largest n_samples per process call (per channel)              */
+    int32_t max_frames;      /* frame queue capacity between two fetches (0 = 4*n_channels)   */
+    int32_t keep_soft;       /* keep per-frame soft bits for the soft-bit fetch call (testing)       */
+    int32_t reserved[5];
+} sonde_cfg_t;
+
+/* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */
+typedef struct {
+    int32_t  channel;
+    int32_t  len;            /* 320 or 518 (frametype, rs41mod.c:407-415)                      */
+    int32_t  ecc;            /* rs41_ecc() return: >=0 corrected symbols, -1/-2/-3 failed cw   */
+    uint32_t mv_pos;         /* IF-sample index of the last header sample (dsp.mv_pos)         */
+    float    mv;             /* header correlation score (dsp.mv)                              */
+    int32_t  nbytes;         /* bytes actually sliced (518 unless stream ended)                */
+    uint8_t  frame[518];     /* de-whitened, ECC-corrected frame bytes                         */
+    uint8_t  pad[2];
+} sonde_frame_t;
+
+/* Derived constants of init_buffers() (demod_mod.c:1208-1474), for callers and tests. */
+typedef struct {
+    int32_t if_sr, decM, dectaps, lut_len, lpiq_taps, lpfm_taps;
+    int32_t L, M, K, N, delay;
+    float   sps;
+    int32_t ring_len;        /* per-channel IF ring length (samples)                           */
+    int32_t reserved[3];
+} sonde_info_t;
+
+/* replaces init_buffers() (demod_mod.c:1208) for n_channels channels; fq[c] is the --IQ <fq> argument
+ * of channel c (-0.5..0.5, rs41mod.c:2678-2687). */
+int  sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out);
+/* replaces free_buffers() (demod_mod.c:1476) */
+void sonde_engine_destroy(sonde_engine_t *e);
+int  sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info);
+
+/* Push n_samples new complex samples per channel.  Replaces the pull loop
+ * find_header()/read_softbit2p() -> f32buf_sample() -> f32read_cblock() (demod_mod.c:1533,1087,722,463).
+ * iq: interleaved I,Q little-endian int16, channel c at iq + 2*c*ch_stride (ch_stride in complex samples).
+ * n_samples must be a multiple of decM and <= max_chunk.  The *_device form takes a device pointer and
+ * only enqueues work on the engine's HIP stream; the *_host form copies first (PCIe-inclusive). */
+int  sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples);
+int  sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples);
+/* wait for all enqueued work */
+int  sonde_engine_sync(sonde_engine_t *e);
+
+/* Collect frames completed so far (syncs).  Runs the RS(255,231) pass(es) of rs41_ecc()
+ * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
+ * Returns the number of frames written (<= max). */
+int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
+/* soft bits (hsbit_t.sb of read_softbit2p) of the frames returned by the last fetch; soft: [n][4080] */
+int  sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames);
+
+/* Testing tap: copy `count` IF-rate samples starting at absolute IF index `first` of one channel
+ * (must still be inside the ring).  out: count floats (x2 for the cf32 taps). */
+int  sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64_t first, int32_t count, float *out);
+
+/* HIP stream the engine enqueues on (hipStream_t), for event timing by the caller */
+void *sonde_engine_stream(sonde_engine_t *e);
+/* average GPU time (ms) of the named kernel since the last reset, measured with HIP events on the
+ * engine stream when profiling is enabled; names: "mix_decimate","if_chain","header_corr","framesync" */
+int  sonde_engine_profile(sonde_engine_t *e, int enable);
+int  sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches);
+
+/* Raw text line of `rs41mod -r` for one frame (rs41mod.c:2530-2545); returns strlen. buf >= 1100 bytes */
+int  sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen);
+
+/* RS(255,231) codec of bch_ecc_mod.c (rs_encode :860, rs_decode :962) — exposed for tests/tools */
+int  sonde_rs255_encode(uint8_t cw[255]);
+int  sonde_rs255_decode(uint8_t cw[255]);
+/* CRC-16/CCITT-FALSE of rs41mod.c:284 */
+int  sonde_crc16(const uint8_t *data, int len);
+
+const char *sonde_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,67 @@
+// sonde_dev.h — structs shared by the HIP kernels (sonde_kernels.hip) and the host engine (sonde_engine.cpp).
+#ifndef SONDE_DEV_H
+#define SONDE_DEV_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct MixDecArgs {
+    const int16_t *iq;        // [n_ch][ch_stride] complex int16
+    long long ch_stride;      // complex samples between channels
+    int n_ch, nblocks;        // blocks (= IF samples) in this chunk
+    int D, Q, KS, n4, nrem;   // decM, ceil(taps/D), k-steps, 16-sample super-steps, single k-steps
+    int G;                    // 16-block tiles per wave
+    int wgs_per_ch;           // filled by the launcher
+    const float *Bop;         // [KS][64] MFMA B operands
+    const float2 *lut;        // [n_ch][lut_stride] mixer tables (padded)
+    int lut_len, lut_stride;
+    uint32_t lut_phase;       // table index of the chunk's first sample
+    const float2 *dc_avg;     // [n_ch] IQ-DC mean in effect
+    long long *dc_sums;       // [n_ch][2] integer sums of the running DC segment
+    const float2 *ptail_in;   // [n_ch][8][8] P rows of the Q-1 blocks before the chunk
+    float2 *ptail_out;
+    float2 *y;                // [n_ch][ring_len] decimated IQ ring
+    int ring_len;
+    uint32_t m0;              // IF index of the chunk's first output
+};
+
+struct IfArgs {
+    const float2 *y; float2 *tap_ifiq; float *fm; float *bufs;
+    int n_ch, ring_len, n; uint32_t m0;
+    int lpiq_on, lpiq_taps, lpfm_on, lpfm_taps, tone_on, nwin;
+    const float *w_iq, *w_fm;
+    double rho;               // tone phase advance per IF sample, revolutions
+    float sps;
+};
+
+struct CorrArgs {
+    const float *bufs; float *corr; const float *match;
+    int n_ch, ring_len, n, L; uint32_t m0;
+};
+
+struct SyncState {
+    uint32_t s_in, k, mv_pos, mode;
+    float mv; uint32_t pad[3];
+};
+
+struct FrameRec {
+    int32_t channel, len, nbytes; uint32_t mv_pos; float mv;
+    uint8_t synd[48];
+    uint8_t frame[520];
+};
+
+struct SyncArgs {
+    const float *bufs, *corr; SyncState *state; FrameRec *frames; unsigned *frame_count; float *soft;
+    const uint8_t *hdr, *hdr_bytes, *mask, *gf_exp, *gf_log;
+    int n_ch, ring_len, max_frames; uint32_t avail;
+    int K, L, delay, hdrlen, symhd, symlen, hdmax, bitofs, nbits; uint32_t frame_samples;
+    float sps, thres, l_win;
+};
+
+extern "C" {
+void sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);
+void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
+void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
+void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s);
+void sonde_launch_framesync(const SyncArgs *a, hipStream_t s);
+}
+#endif

@@ -1,0 +1,389 @@
+// sonde_engine.cpp — host side of libsonde_hip: engine object behind the C ABI of include/sonde_hip.h.
+//
+// Push model of the reference's pull loop: every sonde_engine_process_* call hands
+// n_samples new complex samples of every channel to the GPU and enqueues, on one HIP stream,
+//   k_mix_decimate (per IQ-DC segment)  ->  k_if_chain  ->  k_header_corr  ->  k_framesync
+// Sequential per-channel state of the reference and where it lives here:
+//   IQ-DC running mean (demod_mod.c:407-417,495-504)   host schedule + k_dc_update, exact integer sums
+//   FIR histories (decXbuffer, lpIQ_buf, lpFM_buf)     P-tail of the decimator + IF-rate rings in HBM
+//   mixer table position (sample_decM)                 lut_phase (host counter, same for all channels)
+//   find_header / read_softbit2p counters              SyncState per channel in HBM
+// Not supported yet (returns SONDE_E_ARG): --dc (AFC feedback), 8-bit / float input.
+#include "../../include/sonde_hip.h"
+#include "sonde_dev.h"
+#include "sonde_host.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace sonde;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libsonde_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return SONDE_E_NOGPU; } } while (0)
+
+struct KernelStat { double ms = 0; int64_t n = 0; };
+struct PendingEvt { hipEvent_t a, b; const char *name; };
+
+struct sonde_engine {
+    sonde_cfg_t cfg{};
+    sonde_info_t info{};
+    hipStream_t stream = nullptr;
+    // design
+    Decimator dec; int Q = 0, KS = 0, n4 = 0, nrem = 0, G = 8;
+    std::vector<float> w_iq, w_fm, match;
+    float sps = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;
+    int symlen = 1, symhd = 1, hdmax = 0, bitofs = 0, nbits = 0, hdrlen = 0;
+    uint32_t frame_samples = 0;
+    double rho = 0;
+    // device
+    float *d_Bop = nullptr; float2 *d_lut = nullptr; int lut_len = 0, lut_stride = 0;
+    float2 *d_dcavg = nullptr; long long *d_dcsums = nullptr;
+    float2 *d_ptail[2] = { nullptr, nullptr }; int ptail_cur = 0;
+    float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr;
+    float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
+    SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr;
+    uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
+    int16_t *d_stage = nullptr; size_t stage_bytes = 0;
+    int ring_len = 0, max_frames = 0;
+    // stream position
+    uint64_t samples_in = 0;       // base-rate samples consumed per channel
+    uint32_t m_out = 0;            // IF samples produced per channel
+    uint32_t dc_cnt = 0, dc_max = 0, dc_lim = 0;
+    // results of the last fetch
+    std::vector<float> last_soft; int last_n = 0;
+    bool overflow = false;
+    // profiling
+    bool prof = false; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
+};
+
+template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+    return 0;
+}
+
+static void prof_begin(sonde_engine *e, const char *name) {
+    if (!e->prof) return;
+    PendingEvt p; p.name = name;
+    hipEventCreate(&p.a); hipEventCreate(&p.b);
+    hipEventRecord(p.a, e->stream);
+    e->pend.push_back(p);
+}
+static void prof_end(sonde_engine *e) { if (e->prof) hipEventRecord(e->pend.back().b, e->stream); }
+static void prof_collect(sonde_engine *e) {
+    for (auto &p : e->pend) {
+        float ms = 0; hipEventSynchronize(p.b); hipEventElapsedTime(&ms, p.a, p.b);
+        auto &s = e->stats[p.name]; s.ms += ms; s.n += 1;
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    e->pend.clear();
+}
+
+extern "C" {
+
+const char *sonde_strerror(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case SONDE_E_ARG: return "bad argument or unsupported option";
+        case SONDE_E_NOGPU: return "HIP device/runtime error";
+        case SONDE_E_NOMEM: return "out of memory";
+        case SONDE_E_RANGE: return "chunk size out of range or not a multiple of the decimation";
+        case SONDE_E_OVERFLOW: return "frame queue overflow";
+        default: return "unknown error";
+    }
+}
+
+int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
+    if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || cfg->bits != 16) return SONDE_E_ARG;
+    if (cfg->sonde_type != SONDE_RS41 || cfg->opt_dc) return SONDE_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
+        fprintf(stderr, "libsonde_hip: no usable HIP device (the engine has no CPU fallback)\n");
+        return SONDE_E_NOGPU;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    sonde_engine *e = new sonde_engine();
+    e->cfg = *cfg;
+    const int C = cfg->n_channels;
+
+    // ---- sonde preset (rs41mod.c:2591-2597,2812-2836,2882,2920-2923)
+    e->baud = 4800.f; e->bt = 0.5f; e->hmod = 0.6f; e->symlen = 1; e->symhd = 1; e->hdmax = 4; e->bitofs = 2;
+    e->nbits = 510 * 8; e->hdrlen = 64; e->l_win = 2.0f;
+    e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
+    const int lpiq_bw = cfg->lpiq_bw > 0 ? cfg->lpiq_bw : 7400, lpfm_bw = 6000;
+
+    // ---- init_buffers() arithmetic (demod_mod.c:1208-1474)
+    e->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);
+    const int D = e->dec.decM, sr = e->dec.if_sr;
+    if (D == 1) e->dec.taps.assign(1, 1.0f);                   // reference bypasses the FIR for decM == 1 (:751)
+    const int T = (int)e->dec.taps.size();
+    e->sps = (float)cfg->sample_rate / e->baud;
+    e->sps /= (float)D;
+    e->Q = (T + D - 1) / D;
+    e->n4 = D / 16; e->nrem = (D - 16 * e->n4 + 3) / 4; e->KS = 4 * e->n4 + e->nrem;
+    if (e->n4 > 4 || e->nrem > 4 || e->Q > 8) { delete e; return SONDE_E_ARG; }
+    if (cfg->opt_lp & SONDE_LP_IQ) {
+        float f_lp = (float)(24e3 / (float)sr / 2.0);
+        if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
+        int taps = (int)(4 * sr / 4e3); if (taps % 2 == 0) taps++;
+        e->w_iq = design_lowpass(f_lp, taps);                  // locked filter; the 1.5x acquisition filter is --dc only
+    }
+    if (cfg->opt_lp & SONDE_LP_FM) {
+        float f_lp = (float)(10e3 / (float)sr);
+        if (lpfm_bw > 0) f_lp = lpfm_bw / (float)sr;
+        int taps = (int)(4 * sr / 2e3); if (taps % 2 == 0) taps++;
+        e->w_fm = design_lowpass(f_lp, taps);
+    }
+    e->match = design_match(std::string(kRs41Header), e->sps, e->bt);
+    const int L = (int)e->match.size();
+    int M = 3 * L, p2 = 1;
+    const int delay = L / 16;
+    while (p2 < M) p2 <<= 1;
+    while (p2 < 0x2000) p2 <<= 1;
+    M = p2;
+    const int K = M - L - delay;
+    { const float nh = -e->hmod; const float hs = nh * sr; const double f1 = hs / (2.0 * e->sps); e->rho = -f1 / (double)sr; }
+    { uint32_t q0, q1; double mid; bit_window(e->nbits - 1, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1; }
+
+    const int max_if = (cfg->max_chunk + D - 1) / D;
+    int ring = 1; while (ring < max_if + 65536 || ring < 4 * M) ring <<= 1;
+    e->ring_len = ring;
+    e->max_frames = cfg->max_frames > 0 ? cfg->max_frames : 4 * C;
+
+    sonde_info_t &I = e->info;
+    I.if_sr = sr; I.decM = D; I.dectaps = (D == 1) ? 0 : T; I.lpiq_taps = (int)e->w_iq.size(); I.lpfm_taps = (int)e->w_fm.size();
+    I.L = L; I.M = M; I.K = K; I.N = M; I.delay = delay; I.sps = e->sps; I.ring_len = ring;
+
+    // ---- B operand of the MFMA decimator: front-padded taps in the kernel's K order
+    {
+        const int pad = e->Q * D - T;
+        std::vector<float> wpad((size_t)e->Q * D, 0.f);
+        for (int k = 0; k < T; k++) wpad[pad + k] = e->dec.taps[k];
+        std::vector<float> B((size_t)e->KS * 64, 0.f);
+        for (int s = 0; s < e->KS; s++) for (int lane = 0; lane < 64; lane++) {
+            const int kk = lane >> 4, q = lane & 15;
+            const int r = (s < 4 * e->n4) ? 16 * (s / 4) + 4 * kk + (s % 4) : 16 * e->n4 + 4 * (s - 4 * e->n4) + kk;
+            if (q < e->Q && r < D) B[(size_t)s * 64 + lane] = wpad[(size_t)D * q + r];
+        }
+        if (dalloc(&e->d_Bop, B.size(), false)) { delete e; return SONDE_E_NOMEM; }
+        HIPCHK(hipMemcpy(e->d_Bop, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // ---- mixer tables, one per channel (xlt_fq = -fq, rs41mod.c:2685), padded so 16-byte reads may run past the end
+    {
+        std::vector<std::complex<float>> first = design_lut(-std::max(-0.5, std::min(0.5, fq[0])), cfg->sample_rate);
+        e->lut_len = (int)first.size(); e->lut_stride = e->lut_len + 64;
+        I.lut_len = e->lut_len;
+        if (dalloc(&e->d_lut, (size_t)C * e->lut_stride, false)) { delete e; return SONDE_E_NOMEM; }
+        std::vector<std::complex<float>> row((size_t)e->lut_stride);
+        for (int c = 0; c < C; c++) {
+            const double f = std::max(-0.5, std::min(0.5, fq[c]));
+            std::vector<std::complex<float>> ex = (c == 0) ? first : design_lut(-f, cfg->sample_rate);
+            for (int n = 0; n < e->lut_stride; n++) row[n] = ex[n % e->lut_len];
+            HIPCHK(hipMemcpy(e->d_lut + (size_t)c * e->lut_stride, row.data(), row.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
+    }
+    int bad = 0;
+    bad |= dalloc(&e->d_dcavg, C); bad |= dalloc(&e->d_dcsums, 2 * (size_t)C);
+    bad |= dalloc(&e->d_ptail[0], (size_t)C * 64); bad |= dalloc(&e->d_ptail[1], (size_t)C * 64);
+    bad |= dalloc(&e->d_y, (size_t)C * ring); bad |= dalloc(&e->d_ifiq, (size_t)C * ring);
+    bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring);
+    bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1);
+    if (cfg->keep_soft) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
+    bad |= dalloc(&e->d_match, L, false);
+    if (!e->w_iq.empty()) bad |= dalloc(&e->d_wiq, e->w_iq.size(), false);
+    if (!e->w_fm.empty()) bad |= dalloc(&e->d_wfm, e->w_fm.size(), false);
+    bad |= dalloc(&e->d_consts, 1024, true);
+    if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+    HIPCHK(hipMemcpy(e->d_match, e->match.data(), L * sizeof(float), hipMemcpyHostToDevice));
+    if (e->d_wiq) HIPCHK(hipMemcpy(e->d_wiq, e->w_iq.data(), e->w_iq.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (e->d_wfm) HIPCHK(hipMemcpy(e->d_wfm, e->w_fm.data(), e->w_fm.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        uint8_t cb[1024]; memset(cb, 0, sizeof cb);
+        memcpy(cb, kRs41Header, 64); memcpy(cb + 64, kRs41HeaderBytes, 8); memcpy(cb + 72, kRs41Mask, 64);
+        memcpy(cb + 136, gf_exp_table(), 512); memcpy(cb + 648, gf_log_table(), 256);
+        HIPCHK(hipMemcpy(e->d_consts, cb, sizeof cb, hipMemcpyHostToDevice));
+    }
+    // IQ-DC segment schedule (demod_mod.c:1351-1357)
+    e->dc_lim = (uint32_t)sr; e->dc_max = e->dc_lim / 32;
+    if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
+    if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
+    HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    *out = e;
+    return 0;
+}
+
+void sonde_engine_destroy(sonde_engine_t *e) {
+    if (!e) return;
+    if (e->stream) { hipStreamSynchronize(e->stream); prof_collect(e); hipStreamDestroy(e->stream); }
+    void *ptrs[] = { e->d_Bop, e->d_lut, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
+                     e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
+                     e->d_consts, e->d_stage };
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete e;
+}
+
+int sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info) {
+    if (!e || !info) return SONDE_E_ARG;
+    *info = e->info;
+    return 0;
+}
+
+void *sonde_engine_stream(sonde_engine_t *e) { return e ? (void *)e->stream : nullptr; }
+
+int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples) {
+    if (!e || !d_iq) return SONDE_E_ARG;
+    const int D = e->info.decM, C = e->cfg.n_channels;
+    if (n_samples <= 0 || n_samples > e->cfg.max_chunk || n_samples % D || ch_stride < n_samples) return SONDE_E_RANGE;
+    const uint32_t m_first = e->m_out;
+    int done = 0;
+    while (done < n_samples) {
+        // never straddle an IQ-DC segment: the mean of segment s-1 is subtracted throughout segment s
+        const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt);
+        MixDecArgs a{};
+        a.iq = (const int16_t *)d_iq + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
+        a.D = D; a.Q = e->Q; a.KS = e->KS; a.n4 = e->n4; a.nrem = e->nrem; a.G = e->G;
+        a.Bop = e->d_Bop; a.lut = e->d_lut; a.lut_len = e->lut_len; a.lut_stride = e->lut_stride;
+        a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
+        a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums;
+        a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];
+        a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
+        prof_begin(e, "mix_decimate"); sonde_launch_mix_decimate(&a, e->stream); prof_end(e);
+        e->ptail_cur ^= 1;
+        e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
+        if (e->dc_cnt == e->dc_max) {
+            sonde_launch_dc_update(C, e->d_dcsums, e->d_dcavg, (float)e->dc_max, e->stream);
+            e->dc_cnt = 0;
+            if (e->dc_max < e->dc_lim) e->dc_max *= 2;
+        }
+    }
+    const int n_if = n_samples / D;
+    IfArgs b{};
+    b.y = e->d_y; b.tap_ifiq = e->d_ifiq; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
+    b.n = n_if; b.m0 = m_first;
+    b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
+    b.tone_on = 1; b.nwin = (int)e->sps; b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
+    prof_begin(e, "if_chain"); sonde_launch_if_chain(&b, e->stream); prof_end(e);
+    CorrArgs c{};
+    c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
+    prof_begin(e, "header_corr"); sonde_launch_header_corr(&c, e->stream); prof_end(e);
+    SyncArgs s{};
+    s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft;
+    s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
+    s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
+    s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
+    s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
+    s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
+    prof_begin(e, "framesync"); sonde_launch_framesync(&s, e->stream); prof_end(e);
+    if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
+    return 0;
+}
+
+int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples) {
+    if (!e || !h_iq) return SONDE_E_ARG;
+    const int C = e->cfg.n_channels;
+    if (n_samples <= 0 || n_samples > e->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
+    const size_t need = (size_t)C * n_samples * 4;
+    if (need > e->stage_bytes) {
+        if (e->d_stage) { hipStreamSynchronize(e->stream); hipFree(e->d_stage); e->d_stage = nullptr; }
+        HIPCHK(hipMalloc((void **)&e->d_stage, need)); e->stage_bytes = need;
+    }
+    HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)n_samples * 4, h_iq, (size_t)ch_stride * 4, (size_t)n_samples * 4, C,
+                            hipMemcpyHostToDevice, e->stream));
+    return sonde_engine_process_device(e, e->d_stage, n_samples, n_samples);
+}
+
+int sonde_engine_sync(sonde_engine_t *e) {
+    if (!e) return SONDE_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    return 0;
+}
+
+int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
+    if (!e || !out || max < 0) return SONDE_E_ARG;
+    unsigned cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, e->d_fcount, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    if (cnt > (unsigned)e->max_frames) { e->overflow = true; cnt = (unsigned)e->max_frames; }
+    const int n = (int)std::min<unsigned>(cnt, (unsigned)max);
+    std::vector<FrameRec> recs((size_t)n);
+    if (n) HIPCHK(hipMemcpy(recs.data(), e->d_frames, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
+    if (e->d_soft) {
+        e->last_soft.resize((size_t)n * e->nbits);
+        if (n) HIPCHK(hipMemcpy(e->last_soft.data(), e->d_soft, e->last_soft.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemsetAsync(e->d_fcount, 0, sizeof(unsigned), e->stream));
+    for (int i = 0; i < n; i++) {
+        const FrameRec &r = recs[i];
+        sonde_frame_t &f = out[i];
+        memset(&f, 0, sizeof f);
+        f.channel = r.channel; f.len = r.len; f.mv = r.mv; f.mv_pos = r.mv_pos; f.nbytes = r.nbytes;
+        memcpy(f.frame, r.frame, 518);
+        f.ecc = 0;
+        if (e->cfg.ecc_level > 0) {
+            bool clean = true;
+            for (int k = 0; k < 48; k++) clean &= (r.synd[k] == 0);
+            if (clean) { for (int k = f.len; k < 518; k++) f.frame[k] = 0; }
+            else f.ecc = rs41_ecc(f.frame, f.len, e->cfg.ecc_level, r.synd);
+        }
+    }
+    e->last_n = n;
+    const bool ovf = e->overflow; e->overflow = false;
+    return ovf ? SONDE_E_OVERFLOW : n;
+}
+
+int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) {
+    if (!e || !soft || !e->d_soft) return SONDE_E_ARG;
+    const int n = std::min(e->last_n, (int)max_frames);
+    memcpy(soft, e->last_soft.data(), (size_t)n * e->nbits * sizeof(float));
+    return n;
+}
+
+int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64_t first, int32_t count, float *out) {
+    if (!e || !out || channel < 0 || channel >= e->cfg.n_channels || count < 0 || count > e->ring_len || first < 0) return SONDE_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    const void *base; size_t esz;
+    switch (tap) {
+        case SONDE_TAP_DECIM: base = e->d_y; esz = 8; break;
+        case SONDE_TAP_IFIQ:  base = e->d_ifiq; esz = 8; break;
+        case SONDE_TAP_FM:    base = e->d_fm; esz = 4; break;
+        case SONDE_TAP_BUFS:  base = e->d_bufs; esz = 4; break;
+        case SONDE_TAP_CORR:  base = e->d_corr; esz = 4; break;
+        default: return SONDE_E_ARG;
+    }
+    const char *row = (const char *)base + (size_t)channel * e->ring_len * esz;
+    const uint32_t mask = (uint32_t)e->ring_len - 1;
+    int32_t done = 0;
+    while (done < count) {
+        const uint32_t idx = (uint32_t)(first + done) & mask;
+        const int32_t run = std::min<int32_t>(count - done, (int32_t)(e->ring_len - idx));
+        HIPCHK(hipMemcpy((char *)out + (size_t)done * esz, row + (size_t)idx * esz, (size_t)run * esz, hipMemcpyDeviceToHost));
+        done += run;
+    }
+    return count;
+}
+
+int sonde_engine_profile(sonde_engine_t *e, int enable) {
+    if (!e) return SONDE_E_ARG;
+    hipStreamSynchronize(e->stream); prof_collect(e);
+    e->prof = enable != 0; e->stats.clear();
+    return 0;
+}
+
+int sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches) {
+    if (!e || !kernel) return SONDE_E_ARG;
+    hipStreamSynchronize(e->stream); prof_collect(e);
+    auto it = e->stats.find(kernel);
+    if (it == e->stats.end() || it->second.n == 0) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return 0; }
+    if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;
+    if (launches) *launches = it->second.n;
+    return 0;
+}
+
+}  // extern "C"

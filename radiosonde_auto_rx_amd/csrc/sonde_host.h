@@ -1,0 +1,36 @@
+// sonde_host.h — internal host-side declarations of libsonde_hip (design math, RS41 framing/ECC).
+#ifndef SONDE_HOST_H
+#define SONDE_HOST_H
+#include <complex>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace sonde {
+
+struct Decimator { int if_sr = 0, decM = 1; std::vector<float> taps; };
+
+std::vector<float> design_lowpass(float f, int taps);
+Decimator design_decimator(int sr_base, bool if_min);
+std::vector<std::complex<float>> design_lut(double xlt_fq, int sr_base);
+std::vector<float> design_match(const std::string &hdr, float sps, float bt);
+void bit_window(int pos, int half, int symlen, float sps, uint32_t &q0, uint32_t &q1, double &mid);
+
+// GF(2^8)/0x11D, alpha = 2
+const uint8_t *gf_exp_table();   // 512 entries
+const uint8_t *gf_log_table();   // 256 entries
+int  rs255_syndromes(const uint8_t cw[255], uint8_t S[24]);     // returns 1 if any non-zero
+int  rs255_decode_syn(uint8_t cw[255], const uint8_t S[24]);    // errors-only, Euclid; <0 on failure
+int  rs255_decode(uint8_t cw[255]);
+void rs255_encode(uint8_t cw[255]);
+int  crc16(const uint8_t *p, int len);
+
+extern const char    kRs41Header[65];
+extern const uint8_t kRs41HeaderBytes[8];
+extern const uint8_t kRs41Mask[64];
+int  rs41_frametype(const uint8_t *frame);
+// rs41_ecc() of the reference for ecc levels 1/2; synd = device syndromes of the first pass or nullptr
+int  rs41_ecc(uint8_t frame[518], int frmlen, int level, const uint8_t *synd);
+
+}  // namespace sonde
+#endif

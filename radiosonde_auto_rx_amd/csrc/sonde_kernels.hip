@@ -1,0 +1,538 @@
+// sonde_kernels.hip — CDNA4 (gfx950) kernels of the radiosonde IQ demodulation engine.
+//
+//   k_mix_decimate   cs16 -> (x - dc) * exp-LUT -> decM:1 Blackman-sinc FIR -> cf32 @ IF rate
+//                    (reference: f32read_cblock + LUT mixer + lowpass, demod_mod.c:463-508,737-754,639-648)
+//                    The decimating FIR is evaluated on the matrix cores: with D = decM and Q = ceil(taps/D)
+//                    y[m] = sum_q P[m-(Q-1)+q][q],  P[j][q] = sum_r W_q[r] * z[D*j + r]
+//                    i.e. a [blocks x D] x [D x Q] product per channel -> v_mfma_f32_16x16x4_f32
+//                    (exact f32 FMA chains), 16 blocks per tile, re and im as two accumulators.
+//   k_if_chain       IF low-pass, conj-product FM discriminator, two-tone sliding correlator, FM low-pass
+//                    (demod_mod.c:765-808,843-852)
+//   k_header_corr    matched-filter header correlation for every end sample (getCorrDFT, demod_mod.c:148-222,
+//                    evaluated in the time domain instead of per-window FFTs)
+//   k_framesync      per-channel find_header / headcmp / read_softbit2p state machine + RS41 byte framing
+//                    + RS(255,231) syndromes (demod_mod.c:1533-1617,870-938,1087-1175; rs41mod.c:2900-2962)
+//   k_dc_update      running IQ-DC mean hand-over at segment boundaries (demod_mod.c:495-504)
+//
+// One wave = 64 lanes everywhere.  No CUDA compatibility paths.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sonde_dev.h"
+
+typedef float  f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// k_mix_decimate
+// ------------------------------------------------------------------------------------------------
+// K ordering inside one D-sample block (host builds the B operand with the same map, sonde_engine.cpp
+// mixdec_k_map): lane (i = lane&15, kk = lane>>4) owns, for super-step ss < n4, the 4 consecutive
+// samples r = 16*ss + 4*kk + u (one 16-byte load), consumed in k-steps s = 4*ss + u; the remaining
+// samples r = 16*n4 + 4*(s - 4*n4) + kk are single-dword loads.
+#define MD_N4MAX  4
+#define MD_REMMAX 4
+#define MD_TILE   16          // blocks (rows) per MFMA tile
+#define MD_PROWS  (MD_TILE + 8)
+
+struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) f32x4_u { float x, y, z, w; };
+
+__device__ __forceinline__ void md_mac(uint32_t raw, float lr, float li, float ax, float ay, float bop,
+                                       f32x4 &acc_re, f32x4 &acc_im, int &sx, int &sy, bool count) {
+    const int xi = (int)(short)(raw & 0xffffu);
+    const int yi = ((int)raw) >> 16;
+    if (count) { sx += xi; sy += yi; }
+    // x = b/32768.0 is exact, so one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
+    const float ur = fmaf((float)xi, 3.0517578125e-05f, -ax);
+    const float ui = fmaf((float)yi, 3.0517578125e-05f, -ay);
+    const float zr = ur * lr - ui * li;           // z = u * ex[n]  (demod_mod.c:744)
+    const float zi = ur * li + ui * lr;
+    acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr, bop, acc_re, 0, 0, 0);
+    acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bop, acc_im, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256)
+void k_mix_decimate(const MixDecArgs a) {
+    extern __shared__ float smem[];
+    float *sB = smem;                                   // [KS][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *sP = smem + a.KS * 64 + wave * (2 * MD_PROWS * 16);   // per wave: re[24][16], im[24][16]
+    float *sPre = sP, *sPim = sP + MD_PROWS * 16;
+
+    for (int i = threadIdx.x; i < a.KS * 64; i += blockDim.x) sB[i] = a.Bop[i];
+    __syncthreads();
+
+    // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; keep a channel on one XCD
+    // so its mixer table stays in that XCD's L2.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
+    const int wg = slot % a.wgs_per_ch;
+    if (ch >= a.n_ch) return;
+
+    const int seg = wg * 4 + wave;
+    const int blocks_per_seg = MD_TILE * a.G;
+    const int jb = seg * blocks_per_seg;
+    if (jb >= a.nblocks) return;
+    const int je = min(a.nblocks, jb + blocks_per_seg);
+
+    const int i = lane & 15, kk = lane >> 4;
+    const int D = a.D, Q = a.Q, H = a.Q - 1;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const float2 *lut = a.lut + (size_t)ch * a.lut_stride;
+    const float2 avg = a.dc_avg[ch];
+    float2 *yout = a.y + (size_t)ch * a.ring_len;
+
+    // history rows of P (partial sums of the Q-1 blocks before this segment)
+    if (seg == 0) {
+        for (int k = lane; k < H * 16; k += WAVE) {
+            const int r = k >> 4, n = k & 15;
+            float2 v = make_float2(0.f, 0.f);
+            if (n < 8) v = a.ptail_in[((size_t)ch * 8 + r) * 8 + n];
+            sPre[r * 16 + n] = v.x; sPim[r * 16 + n] = v.y;
+        }
+    }
+    int sx = 0, sy = 0;
+
+    for (int jt = (seg == 0 ? jb : jb - MD_TILE); jt < je; jt += MD_TILE) {
+        const bool halo = jt < jb;
+        const int j = min(jt + i, a.nblocks - 1);               // clamp rows past the chunk (results unused)
+        const bool rowvalid = (jt + i) < je && !halo;
+        const size_t n0 = (size_t)j * D;
+        uint32_t lidx = (a.lut_phase + (uint32_t)n0) % (uint32_t)a.lut_len;
+
+        u32x4_u raw4[MD_N4MAX]; f32x4_u la[MD_N4MAX], lb[MD_N4MAX];
+        uint32_t raw1[MD_REMMAX]; float2 l1[MD_REMMAX];
+#pragma unroll
+        for (int ss = 0; ss < MD_N4MAX; ss++) {
+            if (ss < a.n4) {
+                const int r0 = 16 * ss + 4 * kk;
+                raw4[ss] = *reinterpret_cast<const u32x4_u *>(iq + n0 + r0);
+                uint32_t li = lidx + r0; if (li >= (uint32_t)a.lut_len) li -= a.lut_len;
+                la[ss] = *reinterpret_cast<const f32x4_u *>(lut + li);
+                lb[ss] = *reinterpret_cast<const f32x4_u *>(lut + li + 2);
+            }
+        }
+#pragma unroll
+        for (int rs = 0; rs < MD_REMMAX; rs++) {
+            if (rs < a.nrem) {
+                int r = 16 * a.n4 + 4 * rs + kk; if (r >= D) r = D - 1;      // B is zero there
+                raw1[rs] = iq[n0 + r];
+                uint32_t li = lidx + r; if (li >= (uint32_t)a.lut_len) li -= a.lut_len;
+                l1[rs] = lut[li];
+            }
+        }
+
+        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < MD_N4MAX; ss++) {
+            if (ss < a.n4) {
+                const float *bp = sB + (4 * ss) * 64 + lane;
+                md_mac(raw4[ss].x, la[ss].x, la[ss].y, avg.x, avg.y, bp[0],   acc_re, acc_im, sx, sy, rowvalid);
+                md_mac(raw4[ss].y, la[ss].z, la[ss].w, avg.x, avg.y, bp[64],  acc_re, acc_im, sx, sy, rowvalid);
+                md_mac(raw4[ss].z, lb[ss].x, lb[ss].y, avg.x, avg.y, bp[128], acc_re, acc_im, sx, sy, rowvalid);
+                md_mac(raw4[ss].w, lb[ss].z, lb[ss].w, avg.x, avg.y, bp[192], acc_re, acc_im, sx, sy, rowvalid);
+            }
+        }
+#pragma unroll
+        for (int rs = 0; rs < MD_REMMAX; rs++) {
+            if (rs < a.nrem) {
+                const int r = 16 * a.n4 + 4 * rs + kk;
+                md_mac(raw1[rs], l1[rs].x, l1[rs].y, avg.x, avg.y, sB[(4 * a.n4 + rs) * 64 + lane],
+                       acc_re, acc_im, sx, sy, rowvalid && r < D);
+            }
+        }
+
+        // C/D layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = H + 4 * kk + rg;
+            sPre[row * 16 + i] = acc_re[rg];
+            sPim[row * 16 + i] = acc_im[rg];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!halo && lane < 16 && jt + lane < je) {
+            float yr = 0.f, yi = 0.f;
+            for (int q = 0; q < Q; q++) { yr += sPre[(lane + q) * 16 + q]; yi += sPim[(lane + q) * 16 + q]; }
+            const uint32_t m = a.m0 + (uint32_t)(jt + lane);
+            yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
+        }
+        // P rows of the last Q-1 blocks of the chunk go to the next call
+        if (jt + MD_TILE >= a.nblocks && !halo) {
+            const int base = a.nblocks - jt;                 // row index of block (nblocks - H)
+            for (int k = lane; k < H * 8; k += WAVE) {
+                const int r = k >> 3, n = k & 7;
+                a.ptail_out[((size_t)ch * 8 + r) * 8 + n] = make_float2(sPre[(base + r) * 16 + n], sPim[(base + r) * 16 + n]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // slide history: rows [16, 16+H) -> [0, H)
+        for (int k = lane; k < H * 16; k += WAVE) {
+            const float vr = sPre[(MD_TILE + (k >> 4)) * 16 + (k & 15)], vi = sPim[(MD_TILE + (k >> 4)) * 16 + (k & 15)];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            sPre[k] = vr; sPim[k] = vi;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // running IQ-DC sums of this segment (exact integer arithmetic == the reference's double sums)
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
+    if (lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch), (unsigned long long)(long long)sx);
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch + 1), (unsigned long long)(long long)sy);
+    }
+}
+
+// avg = (float)(sum / (float)maxcnt) with sum = S/32768 exact in double (demod_mod.c:498-503)
+__global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float maxcnt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    const double sx = (double)dc_sums[2 * c] / 32768.0, sy = (double)dc_sums[2 * c + 1] / 32768.0;
+    dc_avg[c] = make_float2((float)(sx / (double)maxcnt), (float)(sy / (double)maxcnt));
+    dc_sums[2 * c] = 0; dc_sums[2 * c + 1] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_if_chain: one workgroup = IF_TILE output samples of one channel
+// ------------------------------------------------------------------------------------------------
+#define IF_TILE 512
+#define IF_THREADS 256
+
+__global__ __launch_bounds__(IF_THREADS)
+void k_if_chain(const IfArgs a) {
+    extern __shared__ float smem[];
+    const int ch = blockIdx.y;
+    const uint32_t t0 = a.m0 + (uint32_t)blockIdx.x * IF_TILE;        // first output sample (absolute)
+    const int nout = min(IF_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
+    if (nout <= 0) return;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const int T1 = a.lpiq_on ? a.lpiq_taps : 1;       // IF low-pass taps
+    const int T2 = a.lpfm_on ? a.lpfm_taps : 1;       // FM low-pass taps
+    const int nwin = a.nwin;                          // tone window = (int)sps
+    // sample ranges (relative to t0): s_fm needed on [-(T2-1), nout); z' on [-(T2-1)-max(1,nwin-1)..]
+    const int hz = (T2 - 1) + max(1, nwin - 1);       // history of z' needed
+    const int nz = hz + nout;                         // z' count
+    const int ny = nz + (T1 - 1);                     // y count
+    float2 *sy = reinterpret_cast<float2 *>(smem);            // [ny]
+    float2 *sz = sy + ny;                                      // [nz]   z'[t0 - hz + k]
+    float2 *sx = sz + nz;                                      // [nz]   tone phasor e^{+i 2 pi m rho}
+    float  *sf = reinterpret_cast<float *>(sx + nz);           // [T2-1+nout] raw s_fm
+    float  *wq = sf + (T2 - 1 + nout);                         // [T1]
+    float  *wf = wq + T1;                                      // [T2]
+
+    const float2 *yr = a.y + (size_t)ch * a.ring_len;
+    for (int k = threadIdx.x; k < ny; k += IF_THREADS) {
+        const int64_t m = (int64_t)t0 - hz - (T1 - 1) + k;     // absolute IF index, may be < 0 at stream start
+        sy[k] = (m >= 0) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
+    }
+    for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? a.w_iq[k] : 1.0f;
+    for (int k = threadIdx.x; k < T2; k += IF_THREADS) wf[k] = a.lpfm_on ? a.w_fm[k] : 1.0f;
+    __syncthreads();
+
+    // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648)
+    for (int k = threadIdx.x; k < nz; k += IF_THREADS) {
+        float re = 0.f, im = 0.f;
+        for (int t = 0; t < T1; t++) { const float2 v = sy[k + t]; re = fmaf(v.x, wq[t], re); im = fmaf(v.y, wq[t], im); }
+        const int64_t m = (int64_t)t0 - hz + k;
+        if (m < 0) { re = 0.f; im = 0.f; }
+        sz[k] = make_float2(re, im);
+        // tone mixer e^{-i t w1}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
+        const double rev = (double)m * a.rho;
+        const float fr = (float)(rev - floor(rev));
+        float sn, cs; sincospif(2.0f * fr, &sn, &cs);
+        // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470)
+        sx[k] = make_float2(cs, sn);
+        if (a.tap_ifiq && m >= (int64_t)t0) a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
+    }
+    __syncthreads();
+
+    // FM discriminator on [-(T2-1), nout): s_fm = 0.8 * arg(z[m] * conj(z[m-1])) / pi   (demod_mod.c:771-773)
+    for (int k = threadIdx.x; k < T2 - 1 + nout; k += IF_THREADS) {
+        const int zi = k + (hz - (T2 - 1));            // index into sz of sample m
+        const float2 z1 = sz[zi], z0 = sz[zi - 1];
+        const float wr = z1.x * z0.x + z1.y * z0.y, wi = z1.y * z0.x - z1.x * z0.y;
+        sf[k] = 0.8f * atan2f(wi, wr) * 0.31830988618379067f;
+    }
+    __syncthreads();
+
+    float *bufs = a.bufs + (size_t)ch * a.ring_len;
+    float *fmb = a.fm + (size_t)ch * a.ring_len;
+    for (int k = threadIdx.x; k < nout; k += IF_THREADS) {
+        const uint32_t m = t0 + (uint32_t)k;
+        // two-tone correlator: windowed sums over the last nwin samples (the reference keeps them as
+        // recursive sliding sums, demod_mod.c:796-803 — same value up to its float drift)
+        float f1r = 0.f, f1i = 0.f, f2r = 0.f, f2i = 0.f;
+        if (a.tone_on) {
+            for (int j = nwin - 1; j >= 0; j--) {
+                const float2 z = sz[hz + k - j], e = sx[hz + k - j];
+                f1r += z.x * e.x - z.y * e.y;  f1i += z.x * e.y + z.y * e.x;     // z * (cs + i sn)
+                f2r += z.x * e.x + z.y * e.y;  f2i += z.y * e.x - z.x * e.y;     // z * (cs - i sn)
+            }
+        }
+        float s_fm = sf[T2 - 1 + k];
+        if (a.lpfm_on) {
+            float acc = 0.f;
+            for (int t = 0; t < T2; t++) acc = fmaf(sf[k + t], wf[t], acc);
+            s_fm = acc;
+        }
+        float s = s_fm;
+        if (a.tone_on) s = (sqrtf(f2r * f2r + f2i * f2i) - sqrtf(f1r * f1r + f1i * f1i)) / a.sps;
+        fmb[m & mask] = s_fm;
+        bufs[m & mask] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_header_corr: c[p] = sum_u match[u] * bufs[p-(L-1)+u]   for p in [m0, m0+n)
+// ------------------------------------------------------------------------------------------------
+#define HC_TILE 1024
+#define HC_THREADS 256
+
+__global__ __launch_bounds__(HC_THREADS)
+void k_header_corr(const CorrArgs a) {
+    extern __shared__ float smem[];
+    const int ch = blockIdx.y, L = a.L;
+    const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HC_TILE;
+    const int nout = min(HC_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
+    if (nout <= 0) return;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    float *sx = smem;                 // [HC_TILE + L - 1]
+    float *sm = smem + HC_TILE + L;   // [L]
+    const float *bufs = a.bufs + (size_t)ch * a.ring_len;
+    for (int k = threadIdx.x; k < HC_TILE + L - 1; k += HC_THREADS) {
+        const int64_t m = (int64_t)p0 - (L - 1) + k;
+        sx[k] = (m >= 0 && k < nout + L - 1) ? bufs[(uint32_t)m & mask] : 0.f;
+    }
+    for (int k = threadIdx.x; k < L; k += HC_THREADS) sm[k] = a.match[k];
+    __syncthreads();
+    float acc[HC_TILE / HC_THREADS];
+#pragma unroll
+    for (int j = 0; j < HC_TILE / HC_THREADS; j++) acc[j] = 0.f;
+    for (int u = 0; u < L; u++) {
+        const float mu = sm[u];
+#pragma unroll
+        for (int j = 0; j < HC_TILE / HC_THREADS; j++) acc[j] = fmaf(mu, sx[threadIdx.x + j * HC_THREADS + u], acc[j]);
+    }
+    float *corr = a.corr + (size_t)ch * a.ring_len;
+#pragma unroll
+    for (int j = 0; j < HC_TILE / HC_THREADS; j++) {
+        const int k = threadIdx.x + j * HC_THREADS;
+        if (k < nout) corr[(p0 + (uint32_t)k) & mask] = acc[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_framesync: one wave per channel
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Consumed-sample window [q0, q1) and centre `mid` of one symbol half of bit `pos`
+// (read_softbit2p, demod_mod.c:1098-1161).  The reference walks an integer counter sc against double
+// edges: bg = (float)(pos*symlen)*sps (0 for pos 0); per half: mid = bg + (sps-1)/2, bg += sps,
+// do {..; sc++} while (sc < bg).  With sps >= 1 every loop ends at sc = ceil(bg), so each half's
+// window is a closed form of pos and the bits can be sliced in parallel.
+__device__ __forceinline__ void bit_window(int pos, int half, int symlen, float sps,
+                                           uint32_t &q0, uint32_t &q1, double &mid) {
+    double bg = (pos == 0) ? 0.0 : (double)((float)(pos * symlen) * sps);
+    double prev;                                    // edge at which the previous do-while stopped
+    if (half == 0) {
+        if (pos == 0) prev = 0.0;
+        else {
+            prev = (pos == 1) ? 0.0 : (double)((float)((pos - 1) * symlen) * sps);
+            prev += (double)sps;
+            if (symlen == 2) prev += (double)sps;
+        }
+    } else {
+        bg += (double)sps;
+        prev = bg;
+    }
+    q0 = (uint32_t)ceil(prev);
+    mid = bg + (double)(sps - 1.0f) / 2.0;
+    q1 = (uint32_t)ceil(bg + (double)sps);
+    if (q1 <= q0) q1 = q0 + 1;
+}
+
+__global__ __launch_bounds__(WAVE)
+void k_framesync(const SyncArgs a) {
+    __shared__ uint8_t s_frame[520];
+    __shared__ uint8_t s_exp[512];
+    __shared__ uint8_t s_log[256];
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= a.n_ch) return;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const float *bufs = a.bufs + (size_t)ch * a.ring_len;
+    const float *corr = a.corr + (size_t)ch * a.ring_len;
+    SyncState st = a.state[ch];
+    const uint32_t avail = a.avail;            // IF samples [0, avail) exist
+    const int K = a.K, L = a.L;
+
+    for (int k = lane; k < 512; k += WAVE) s_exp[k] = a.gf_exp[k];
+    for (int k = lane; k < 256; k += WAVE) s_log[k] = a.gf_log[k];
+    __syncthreads();
+
+    for (int guard = 0; guard < 64; guard++) {
+        if (st.mode == 0) {
+            // ---- find_header: next correlation once K-4 new samples were consumed (demod_mod.c:1540-1548)
+            const uint32_t need = (uint32_t)(K - 4) - st.k;
+            const uint32_t s_in_w = st.s_in + need;
+            if ((int32_t)(avail - s_in_w) < 0) { st.k += avail - st.s_in; st.s_in = avail; break; }
+            st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
+            const uint32_t pos = s_in_w - 1 - (uint32_t)a.delay;      // sample_out
+            if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
+            // arg-max of c^2 over end positions p = pos-K .. pos, first maximum wins (demod_mod.c:200-208)
+            float best = 0.f; int bidx = -1;
+            for (int t = lane; t <= K; t += WAVE) {
+                const int64_t p = (int64_t)pos - K + t;
+                const float c = (p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
+                const float c2 = c * c;
+                if (c2 > best) { best = c2; bidx = t; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
+                if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+            }
+            if (bidx == 0 || bidx == K) continue;                      // edge value -> -4, mv = 0
+            if (bidx < 0) continue;
+            const uint32_t mpos = pos - (uint32_t)K + (uint32_t)bidx;
+            float e = 0.f;
+            for (int t = lane; t < L; t += WAVE) {
+                const int64_t p = (int64_t)mpos - t;
+                const float v = (p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
+                e = fmaf(v, v, e);
+            }
+            e = wave_sum(e);
+            const float mv = corr[mpos & mask] / sqrtf(e);
+            const uint32_t prev = st.mv_pos;
+            st.mv = mv; st.mv_pos = mpos;
+            if (!(mv > a.thres || mv < -a.thres)) continue;
+            if (!(mpos > prev)) continue;
+            // ---- headcmp (demod_mod.c:870-938): hard-slice the header from the ring, count mismatches
+            int errs = 0;
+            const int nsym = a.hdrlen / a.symhd;
+            const uint32_t mvp = mpos + 1 - (uint32_t)L;
+            for (int p = lane; p < ((nsym + WAVE - 1) / WAVE) * WAVE; p += WAVE) {
+                int e1 = 0;
+                if (p < nsym) {
+                    double edge = (double)((float)(p * a.symhd) * a.sps);
+                    uint32_t cnt = (uint32_t)ceil(edge);
+                    double sum = 0.0;
+                    edge += (double)a.sps;
+                    do { sum += (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
+                    if (a.symhd == 2) {
+                        edge += (double)a.sps;
+                        do { sum -= (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
+                    }
+                    const int sign = mv < 0 ? 1 : 0;
+                    if (a.symhd == 1) {
+                        const int bit = (sum >= 0) ? 1 : 0;
+                        e1 = ((bit ^ sign) != (a.hdr[p] & 1));
+                    } else {
+                        const int b0 = (sum >= 0) ? 1 : 0, b1 = 1 - b0;
+                        e1 = ((b0 ^ sign) != (a.hdr[2 * p] & 1)) + ((b1 ^ sign) != (a.hdr[2 * p + 1] & 1));
+                    }
+                }
+                errs += e1;
+            }
+            for (int off = 32; off > 0; off >>= 1) errs += __shfl_xor(errs, off);
+            if (errs > a.hdmax) continue;
+            if (mv < 0.f) continue;                     // rs41mod.c:2888-2891 without -i / --auto
+            st.mode = 1;
+        } else {
+            // ---- frame: nbits soft bits from sample mv_pos+1+ofs on (read_softbit2p, demod_mod.c:1087-1175)
+            const uint32_t s_in_after = st.mv_pos + (uint32_t)a.delay + 1 + a.frame_samples;
+            if ((int32_t)(avail - s_in_after) < 0) break;              // wait for the next chunk
+            const uint32_t base = st.mv_pos + 1 + (uint32_t)a.bitofs;
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(a.frame_count, 1u);
+            slot = __shfl(slot, 0);
+            const bool keep = slot < (unsigned)a.max_frames;
+            FrameRec *rec = a.frames + (keep ? slot : 0);
+            for (int k = lane; k < 520; k += WAVE) s_frame[k] = (k < 8) ? a.hdr_bytes[k] : 0;
+            __syncthreads();
+            for (int it = 0; it * WAVE < a.nbits; it++) {
+                const int bp = it * WAVE + lane;
+                double sum = 0.0;
+                if (bp < a.nbits) {
+                    if (a.symlen == 2) {
+                        uint32_t q0, q1; double mid;
+                        bit_window(bp, 0, 2, a.sps, q0, q1, mid);
+                        for (uint32_t q = q0; q < q1; q++)
+                            if (a.l_win < 0.f || (mid - (double)a.l_win < (double)q && (double)q < mid + (double)a.l_win))
+                                sum -= (double)bufs[(base + q) & mask];
+                    }
+                    uint32_t q0, q1; double mid;
+                    bit_window(bp, a.symlen - 1, a.symlen, a.sps, q0, q1, mid);
+                    for (uint32_t q = q0; q < q1; q++)
+                        if (a.l_win < 0.f || (mid - (double)a.l_win < (double)q && (double)q < mid + (double)a.l_win))
+                            sum += (double)bufs[(base + q) & mask];
+                }
+                const int hb = (bp < a.nbits) && (sum >= 0.0);
+                const unsigned long long bal = __ballot(hb);
+                if (keep && a.soft && bp < a.nbits) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
+                if (lane < 8) {
+                    const int bi = 8 + it * 8 + lane;                  // frame byte index (LSB-first bits, rs41mod.c:224)
+                    if (bi < 518 && (it * 8 + lane) * 8 < a.nbits)
+                        s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
+                }
+            }
+            __syncthreads();
+            // frame length from the type byte (rs41mod.c:407-415,2488-2490)
+            int ft = 0; { const uint8_t b = s_frame[0x38]; for (int q = 0; q < 4; q++) ft += ((b >> q) & 1) - ((b >> (q + 4)) & 1); }
+            const int flen = (ft >= 0) ? 320 : 518;
+            // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732)
+            uint8_t syn = 0;
+            if (lane < 48) {
+                const int cw = lane / 24, jx = lane % 24;
+                const uint8_t x = s_exp[jx];
+                // Horner from the highest coefficient: cw[254] ... cw[24] (message), cw[23..0] (parity)
+                for (int n = 254; n >= 0; n--) {
+                    int fi = (n >= 24) ? 56 + 2 * (n - 24) + cw : 8 + 24 * cw + n;
+                    uint8_t v = (fi < flen) ? s_frame[fi] : 0;
+                    uint8_t prod = (syn && x) ? s_exp[s_log[syn] + s_log[x]] : 0;
+                    syn = prod ^ v;
+                }
+            }
+            if (keep) {
+                for (int k = lane; k < 518; k += WAVE) rec->frame[k] = s_frame[k];
+                if (lane < 48) rec->synd[lane] = syn;
+                if (lane == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = flen; rec->nbytes = 518; }
+            }
+            __syncthreads();
+            st.s_in = s_in_after; st.k = 0; st.mode = 0;
+        }
+    }
+    if (lane == 0) a.state[ch] = st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (called from sonde_engine.cpp)
+// ------------------------------------------------------------------------------------------------
+extern "C" void sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
+    const int blocks_per_wg = 4 * MD_TILE * a->G;
+    const int wgs_per_ch = (a->nblocks + blocks_per_wg - 1) / blocks_per_wg;
+    MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
+    const int chg = (a->n_ch + 7) / 8;
+    const size_t lds = (size_t)(a->KS * 64 + 4 * 2 * MD_PROWS * 16) * sizeof(float);
+    hipLaunchKernelGGL(k_mix_decimate, dim3(chg * 8 * wgs_per_ch), dim3(256), lds, s, b);
+}
+extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
+}
+extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
+    const int T1 = a->lpiq_on ? a->lpiq_taps : 1, T2 = a->lpfm_on ? a->lpfm_taps : 1;
+    const int hz = (T2 - 1) + (a->nwin - 1 > 1 ? a->nwin - 1 : 1);
+    const int nz = hz + IF_TILE, ny = nz + T1 - 1;
+    const size_t lds = (size_t)ny * 8 + (size_t)nz * 8 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)nz * 8 + (size_t)(T1 + T2) * 4;
+    hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
+}
+extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
+    const size_t lds = (size_t)(HC_TILE + 2 * a->L + 8) * sizeof(float);
+    hipLaunchKernelGGL(k_header_corr, dim3((a->n + HC_TILE - 1) / HC_TILE, a->n_ch), dim3(HC_THREADS), lds, s, *a);
+}
+extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
+    hipLaunchKernelGGL(k_framesync, dim3(a->n_ch), dim3(WAVE), 0, s, *a);
+}

@@ -1,0 +1,166 @@
+"""ctypes binding of libsonde_hip.so (include/sonde_hip.h) — the Python host side used by tests and bench.py.
+
+There is no CPU fallback: if the in-tree HIP library is missing or no GPU is present the constructor raises.
+PyTorch is only plumbing here (device buffers for resident input, torch.distributed in bench.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsonde_hip.so")
+
+SONDE_RS41 = 41
+LP_IQ, LP_FM = 1, 2
+TAP_DECIM, TAP_IFIQ, TAP_FM, TAP_BUFS, TAP_CORR = range(5)
+ABI_VERSION = 1
+
+
+class SondeCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "device", "n_channels", "sample_rate", "bits", "sonde_type",
+                                         "opt_lp", "opt_dc", "opt_min", "lpiq_bw", "ecc_level")] + \
+               [("thres", C.c_float), ("max_chunk", C.c_int32), ("max_frames", C.c_int32), ("keep_soft", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class SondeFrame(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("len", C.c_int32), ("ecc", C.c_int32), ("mv_pos", C.c_uint32),
+                ("mv", C.c_float), ("nbytes", C.c_int32), ("frame", C.c_uint8 * 518), ("pad", C.c_uint8 * 2)]
+
+
+class SondeInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("if_sr", "decM", "dectaps", "lut_len", "lpiq_taps", "lpfm_taps",
+                                         "L", "M", "K", "N", "delay")] + \
+               [("sps", C.c_float), ("ring_len", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the in-tree library (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", src])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the engine has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.sonde_strerror.restype = C.c_char_p
+        L.sonde_engine_stream.restype = C.c_void_p
+        L.sonde_engine_create.argtypes = [C.POINTER(SondeCfg), C.POINTER(C.c_double), C.POINTER(C.c_void_p)]
+        L.sonde_engine_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_engine_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_engine_fetch_frames.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
+        L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.sonde_engine_read_tap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
+        L.sonde_engine_sync.argtypes = [C.c_void_p]
+        L.sonde_engine_destroy.argtypes = [C.c_void_p]
+        L.sonde_engine_info.argtypes = [C.c_void_p, C.POINTER(SondeInfo)]
+        L.sonde_engine_profile.argtypes = [C.c_void_p, C.c_int]
+        L.sonde_engine_kernel_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.sonde_engine_stream.argtypes = [C.c_void_p]
+        L.sonde_rs41_rawline.argtypes = [C.POINTER(SondeFrame), C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+class SondeError(RuntimeError):
+    pass
+
+
+def _chk(rc: int) -> int:
+    if rc < 0:
+        raise SondeError(f"libsonde_hip: {lib().sonde_strerror(rc).decode()} ({rc})")
+    return rc
+
+
+class Engine:
+    """Batched equivalent of `rs41mod --IQ <fq> [--lpIQ] - <sr> 16` for n channels on one GPU."""
+
+    def __init__(self, fq, sample_rate: int, *, device: int = 0, lp_iq: bool = True, lp_fm: bool = False,
+                 ecc: int = 2, thres: float = 0.0, max_chunk: int | None = None, max_frames: int = 0,
+                 keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False):
+        fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
+        self.n_channels = len(fq)
+        self.sample_rate = sample_rate
+        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, 16, SONDE_RS41,
+                       (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
+                       thres, max_chunk or sample_rate, max_frames, int(keep_soft))
+        h = C.c_void_p()
+        _chk(lib().sonde_engine_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
+        self._h = h
+        info = SondeInfo()
+        _chk(lib().sonde_engine_info(h, C.byref(info)))
+        self.info = {n: getattr(info, n) for n, _ in SondeInfo._fields_ if n != "reserved"}
+        self.nbits = 4080
+        self._max_frames = max_frames or 4 * self.n_channels
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sonde_engine_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- input -------------------------------------------------------------------------------
+    def process_host(self, iq: np.ndarray, n_samples: int | None = None):
+        """iq: int16 array [n_channels, 2*stride] (or [2*stride] for one channel)."""
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(self.n_channels, -1)
+        stride = iq.shape[1] // 2
+        _chk(lib().sonde_engine_process_host(self._h, iq.ctypes.data_as(C.c_void_p), stride, n_samples or stride))
+
+    def process_device(self, ptr: int, ch_stride: int, n_samples: int):
+        _chk(lib().sonde_engine_process_device(self._h, C.c_void_p(ptr), ch_stride, n_samples))
+
+    def sync(self):
+        _chk(lib().sonde_engine_sync(self._h))
+
+    # -- output ------------------------------------------------------------------------------
+    def fetch_frames(self, max_frames: int | None = None, with_soft: bool = False):
+        n = max_frames or self._max_frames
+        buf = (SondeFrame * n)()
+        k = _chk(lib().sonde_engine_fetch_frames(self._h, buf, n))
+        frames = []
+        line = C.create_string_buffer(1200)
+        for i in range(k):
+            f = buf[i]
+            ll = lib().sonde_rs41_rawline(C.byref(f), line, 1200)
+            frames.append(dict(channel=f.channel, len=f.len, ecc=f.ecc, mv=f.mv, mv_pos=f.mv_pos,
+                               frame=bytes(f.frame), line=line.raw[:ll].decode()))
+        if with_soft:
+            soft = np.zeros((max(k, 1), self.nbits), np.float32)
+            _chk(lib().sonde_engine_fetch_soft(self._h, soft.ctypes.data_as(C.c_void_p), k))
+            for i in range(k):
+                frames[i]["soft"] = soft[i].copy()
+        return frames
+
+    def read_tap(self, channel: int, tap: int, first: int, count: int) -> np.ndarray:
+        width = 2 if tap in (TAP_DECIM, TAP_IFIQ) else 1
+        out = np.zeros((count, width), np.float32)
+        _chk(lib().sonde_engine_read_tap(self._h, channel, tap, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out if width == 2 else out[:, 0]
+
+    # -- profiling ---------------------------------------------------------------------------
+    def profile(self, enable: bool = True):
+        _chk(lib().sonde_engine_profile(self._h, int(enable)))
+
+    def kernel_ms(self, name: str):
+        ms, n = C.c_double(), C.c_int64()
+        _chk(lib().sonde_engine_kernel_ms(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    @property
+    def stream(self) -> int:
+        return lib().sonde_engine_stream(self._h)
