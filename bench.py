@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the RS41 `--IQ fq --lpIQ` hot path on MI355X (BASELINE.json metric).
+
+One step = one pass of the whole hot path (mix+decimate -> IF chain -> header correlation -> framesync ->
+frame fetch + RS ECC) over one batch of synthetic input: CHANNELS channels x 1 s of 2.4 Msps cs16 IQ per GPU,
+already resident in HBM.  Workload = BASELINE.json configs[1] (single RS41 channel, 2.4 Msps cs16) batched to
+the per-GPU share of configs[4] (4096 channels / 8 GPUs = 512 per GPU).  Channels shard across ranks with no
+data-path collective; one small all_gather of per-channel detection summaries per step.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR = 2_400_000
+BANK = 8                 # unique synthetic captures tiled over the channels
+
+
+def make_bank(seconds: float = 1.0):
+    from radiosonde_auto_rx_amd import synth
+    rng = np.random.default_rng(2024)
+    fqs, caps = [], []
+    for b in range(BANK):
+        fq = synth.snap_fq(float(rng.uniform(-0.4, 0.4)), SR)
+        caps.append(synth.rs41_capture(sr=SR, seconds=seconds, fq=fq, n_frames=1, t_first=0.15, seed=100 + b,
+                                       first_frame_no=1000 * (b + 1), sonde_id="T%07d" % b, noise_sigma=0.01))
+        fqs.append(fq)
+    return fqs, caps
+
+
+def cpu_baseline(fqs, caps, budget_s: float = 15.0):
+    """Reference rs41mod (oracle/_ref, built from /root/reference) timed on this host's cores; falls back to the
+    single-threaded CPU restatement (oracle/liboracle.so) when the compiled reference is absent."""
+    from oracle import bind
+    ncores = max(1, min(os.cpu_count() or 1, 8))
+    secs = 20
+    if bind.have_ref():
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for b in range(min(BANK, ncores)):
+                p = os.path.join(td, f"c{b}.cs16")
+                with open(p, "wb") as f:
+                    for _ in range(secs):
+                        f.write(caps[b].tobytes())
+                paths.append(p)
+            exe = os.path.join(bind.REFDIR, "rs41mod")
+            for p in paths:                      # page cache
+                open(p, "rb").read()
+            reps, t0, total, frames = 0, time.perf_counter(), 0, 0
+            while time.perf_counter() - t0 < budget_s:
+                procs = []
+                for k in range(ncores):
+                    b = k % len(paths)
+                    procs.append(subprocess.Popen([exe, "-r", "--ecc2", "--crc", "--IQ", repr(fqs[b]), "--lpIQ", "-", str(SR), "16"],
+                                                  stdin=open(paths[b], "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+                for pr in procs:
+                    out, _ = pr.communicate()
+                    frames += out.count(b"[OK]")
+                total += ncores * secs * SR
+                reps += 1
+            dt = time.perf_counter() - t0
+        return dict(value=total / dt / 1e6, unit="Msamples/s", cores=ncores, kind="reference",
+                    per_core=total / dt / 1e6 / ncores, frames_ok=frames,
+                    sample=f"{ncores} concurrent reference rs41mod processes (-O3, demod_mod.o -Ofast) x {reps} passes over "
+                           f"{secs} s of the same 2.4 Msps cs16 RS41 captures")
+    t0 = time.perf_counter()
+    n, total = 0, 0
+    while time.perf_counter() - t0 < budget_s:
+        o = bind.ora_rs41_decode(caps[n % BANK], SR, fq=fqs[n % BANK], want_soft=False)
+        total += len(caps[n % BANK]) // 2
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=total / dt / 1e6, unit="Msamples/s", cores=1, kind="port", per_core=total / dt / 1e6,
+                sample=f"{n} x 1 s 2.4 Msps cs16 RS41 captures through the single-threaded CPU restatement (oracle/)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=int(os.environ.get("SONDE_BENCH_CHANNELS", "512")), help="channels per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libsonde_hip has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from radiosonde_auto_rx_amd.engine import Engine
+    from radiosonde_auto_rx_amd import shard
+    C = args.channels
+    fqs, caps = make_bank()
+    ch_fq = [fqs[(c + rank) % BANK] for c in range(C)]
+    bank_t = torch.from_numpy(np.stack(caps)).to(dev)                     # [BANK, 2*SR] int16
+    idx = torch.tensor([(c + rank) % BANK for c in range(C)], device=dev)
+    iq = bank_t.index_select(0, idx).contiguous()                         # [C, 2*SR] resident input
+    del bank_t
+    torch.cuda.synchronize()
+
+    eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C)
+    summary = torch.zeros(C, 4, device=dev)
+
+    def step():
+        eng.process_device(iq.data_ptr(), SR, SR)
+        frames = eng.fetch_frames_np()                                    # sync + D2H of frame records + host RS ECC
+        if world > 1:                                                     # per-channel detection summaries over RCCL
+            summary.copy_(torch.from_numpy(shard.summarize(frames, C)))
+            shard.gather_summaries(dist, summary, world)
+        return frames
+
+    for _ in range(args.warmup):
+        step()
+    eng.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nframes, nok = 0, 0
+    for _ in range(args.steps):
+        fr = step()
+        nframes += len(fr)
+        nok += int((fr["ecc"] >= 0).sum())
+    eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = shard.max_over_ranks(dist, dt, dev)
+        cnt = torch.tensor([nframes, nok], device=dev, dtype=torch.int64)
+        dist.all_reduce(cnt)
+        nframes, nok = int(cnt[0]), int(cnt[1])
+
+    md_ms, md_n = eng.kernel_ms("mix_decimate")
+    kern = {k: eng.kernel_ms(k) for k in ("mix_decimate", "if_chain", "header_corr", "framesync")}
+    total_samples = world * C * SR * args.steps
+    value = total_samples / dt / 1e6
+    # dominant kernel = k_mix_decimate: algorithmic bytes = 4 B per complex cs16 sample;
+    # per-step launches differ in size (IQ-DC segment edges) so the rate is (bytes of all launches)/(time of all launches)
+    md_total_s = md_ms * md_n / 1e3
+    achieved = (C * SR * args.steps * 4) / md_total_s / 1e9 if md_total_s > 0 else 0.0
+    if rank == 0:
+        out = {
+            "metric": "IQ Msamples/s (RS41 --IQ --lpIQ demod + framesync + ECC), concurrent real-time 2.4 Msps channels = value/2.4",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RS41 2.4 Msps cs16 IQ, rs41mod --ecc2 --IQ fq --lpIQ (BASELINE configs[1]) x %d channels per GPU "
+                                   "(per-GPU share of configs[4]), 1 s of signal per channel per step" % C,
+                       "channels_per_gpu": C, "samples_per_channel_per_step": SR, "realtime_channels": round(value / 2.4, 1),
+                       "frames_decoded": nframes, "frames_ecc_ok": nok,
+                       "kernel_ms_avg": {k: round(v[0], 4) for k, v in kern.items()},
+                       "kernel_launches": {k: v[1] for k, v in kern.items()}},
+            "roofline": {"bound": "hbm", "kernel": "k_mix_decimate", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "note": "achieved = 4 B x complex samples of all timed k_mix_decimate launches / their HIP-event time on the engine stream"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fqs, caps)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+/*
+ * host/rs41mod.c — `rs41mod` command-line front end on top of libsonde_hip (C, like the reference's tools).
+ *
+ * Keeps the reference's process contract for the IQ form (reference demod/mod/rs41mod.c:2617-2744):
+ *     rs41mod [-r] [--ecc|--ecc2] [--crc] [--ths x] --IQ <fq> [--lpIQ | --lpbw kHz] [--min] - <sr> 16
+ * stdin : interleaved little-endian int16 I/Q at <sr>            (rs41mod.c:2719-2734)
+ * stdout: one raw line per frame, `<hex bytes> [OK]|[NO] (n)`     (rs41mod.c:2530-2545), unbuffered (:2612)
+ * stderr: `IF: <rate>` / `dec: <M>`                               (demod_mod.c:1257-1258)
+ * exit  : 0 on EOF, 255 on argument / init errors                 (rs41mod.c:2663,2739,2846)
+ * Field decode / JSON (print_position) is the next tier — without -r this build refuses.
+ * The DSP runs on the GPU; there is no CPU fallback: without a HIP device the program exits 255.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "sonde_hip.h"
+
+int main(int argc, char **argv) {
+    sonde_cfg_t cfg;
+    double fq = 0.0;
+    int have_iq = 0, raw = 0, have_pcm = 0;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = SONDE_ABI_VERSION;
+    cfg.sonde_type = SONDE_RS41;
+    cfg.ecc_level = 1;                               /* rs41mod.c:2757: ecc < 2 -> 1 */
+    setbuf(stdout, NULL);
+
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
+        else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
+        else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
+        else if (!strcmp(a, "--crc")) { /* CRC is evaluated by field decode only */ }
+        else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
+        else if (!strcmp(a, "--IQ")) {
+            if (++i >= argc) return -1;
+            fq = atof(argv[i]);
+            if (fq < -0.5) fq = -0.5;
+            if (fq > 0.5) fq = 0.5;
+            have_iq = 1;
+        }
+        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
+        else if (!strcmp(a, "--lpbw")) {
+            if (++i >= argc) return -1;
+            double bw = atof(argv[i]);
+            if (bw > 4.6 && bw < 24.0) cfg.lpiq_bw = (int)(bw * 1e3);
+            cfg.opt_lp |= SONDE_LP_IQ;
+        }
+        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
+        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
+        else if (!strcmp(a, "-")) {
+            if (i + 2 >= argc) return -1;
+            cfg.sample_rate = atoi(argv[++i]);
+            cfg.bits = atoi(argv[++i]);
+            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
+            have_pcm = 1;
+        }
+        else { fprintf(stderr, "rs41mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
+    }
+    if (!have_iq || !have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
+    if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+
+    /* 0.1 s of input per GPU call keeps latency well below one frame */
+    cfg.n_channels = 1;
+    cfg.max_chunk = cfg.sample_rate;
+    sonde_engine_t *eng = NULL;
+    int rc = sonde_engine_create(&cfg, &fq, &eng);
+    if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+    sonde_info_t info;
+    sonde_engine_info(eng, &info);
+    fprintf(stderr, "IF: %d\n", info.if_sr);
+    fprintf(stderr, "dec: %d\n", info.decM);
+
+    int chunk = cfg.sample_rate / 10;
+    chunk -= chunk % info.decM;
+    if (chunk < info.decM) chunk = info.decM;
+    int16_t *buf = (int16_t *)malloc((size_t)chunk * 4);
+    sonde_frame_t frames[8];
+    char line[1200];
+    size_t have = 0;
+    for (;;) {
+        size_t got = fread((char *)buf + have, 1, (size_t)chunk * 4 - have, stdin);
+        have += got;
+        int n = (int)(have / 4);
+        n -= n % info.decM;
+        if (n > 0) {
+            rc = sonde_engine_process_host(eng, buf, n, n);
+            if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
+            int k = sonde_engine_fetch_frames(eng, frames, 8);
+            for (int i = 0; i < k; i++) { sonde_rs41_rawline(&frames[i], line, sizeof line); fprintf(stdout, "%s\n", line); }
+            memmove(buf, (char *)buf + (size_t)n * 4, have - (size_t)n * 4);
+            have -= (size_t)n * 4;
+        }
+        if (got == 0) break;                        /* EOF */
+    }
+    {   /* EOF: the reference still prints a frame it was in the middle of (rs41mod.c:2931,2965) */
+        int k = sonde_engine_finish(eng, frames, 8);
+        for (int i = 0; i < k; i++) { sonde_rs41_rawline(&frames[i], line, sizeof line); fprintf(stdout, "%s\n", line); }
+    }
+    sonde_engine_destroy(eng);
+    free(buf);
+    return 0;
+}

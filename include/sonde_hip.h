@@ -110,6 +110,9 @@ int  sonde_engine_sync(sonde_engine_t *e);
  * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
  * Returns the number of frames written (<= max). */
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
+/* End of input (stdin EOF of the reference): emit the frame each channel was in the middle of, with the bits that
+ * exist (rs41mod.c:2931 breaks the bit loop on EOF and still calls print_frame :2965), then fetch as above. */
+int  sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
 /* soft bits (hsbit_t.sb of read_softbit2p) of the frames returned by the last fetch; soft: [n][4080] */
 int  sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames);
 

@@ -36,6 +36,11 @@ struct IfArgs {
 struct CorrArgs {
     const float *bufs; float *corr; const float *match;
     int n_ch, ring_len, n, L; uint32_t m0;
+    // factorised form (integer samples/symbol): ntypes == 0 selects the direct L-tap kernel
+    int ntypes, isps, nsym;
+    const float *shapes;      // [ntypes][isps]
+    const int *sym_type;      // [nsym]
+    const float *sym_sign;    // [nsym]
 };
 
 struct SyncState {
@@ -55,10 +60,11 @@ struct SyncArgs {
     int n_ch, ring_len, max_frames; uint32_t avail;
     int K, L, delay, hdrlen, symhd, symlen, hdmax, bitofs, nbits; uint32_t frame_samples;
     float sps, thres, l_win;
+    int eof;                  // end of stream: emit the frame in progress with the bits that exist
 };
 
 extern "C" {
-void sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);
+int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s);

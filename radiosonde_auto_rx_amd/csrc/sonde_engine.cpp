@@ -44,6 +44,7 @@ struct sonde_engine {
     float2 *d_ptail[2] = { nullptr, nullptr }; int ptail_cur = 0;
     float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr;
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
+    int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr;
     uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
     int16_t *d_stage = nullptr; size_t stage_bytes = 0;
@@ -54,6 +55,7 @@ struct sonde_engine {
     uint32_t dc_cnt = 0, dc_max = 0, dc_lim = 0;
     // results of the last fetch
     std::vector<float> last_soft; int last_n = 0;
+    std::vector<uint8_t> last_frame;   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
     // profiling
     bool prof = false; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
@@ -81,6 +83,9 @@ static void prof_collect(sonde_engine *e) {
     }
     e->pend.clear();
 }
+
+static void launch_framesync_impl(sonde_engine *e, int eof);
+static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); }
 
 extern "C" {
 
@@ -125,7 +130,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->sps /= (float)D;
     e->Q = (T + D - 1) / D;
     e->n4 = D / 16; e->nrem = (D - 16 * e->n4 + 3) / 4; e->KS = 4 * e->n4 + e->nrem;
-    if (e->n4 > 4 || e->nrem > 4 || e->Q > 8) { delete e; return SONDE_E_ARG; }
+    if (e->n4 > 4 || e->nrem > 4 || e->n4 * 4 + e->nrem > 16 || (e->n4 == 4 && e->nrem) || e->Q > 8) { delete e; return SONDE_E_ARG; }
     if (cfg->opt_lp & SONDE_LP_IQ) {
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
@@ -207,10 +212,45 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         memcpy(cb + 136, gf_exp_table(), 512); memcpy(cb + 648, gf_log_table(), 256);
         HIPCHK(hipMemcpy(e->d_consts, cb, sizeof cb, hipMemcpyHostToDevice));
     }
+    // ---- factorised header correlation tables (integer samples/symbol only; else the direct L-tap kernel runs)
+    {
+        const int isps = (int)e->sps, nsym = e->hdrlen / e->symhd;
+        if ((float)isps == e->sps && e->symhd == 1 && isps * nsym == L && isps >= 2) {
+            std::vector<float> shapes; std::vector<int> type(nsym); std::vector<float> sign(nsym);
+            std::vector<int> key;                                     // (left, right) neighbour relative to the own bit
+            bool ok = true;
+            for (int k = 0; k < nsym && ok; k++) {
+                const int b = (kRs41Header[k] & 1) ? 1 : -1;
+                const int l = (k > 0) ? ((kRs41Header[k - 1] & 1) ? 1 : -1) * b : 0;
+                const int r = (k < nsym - 1) ? ((kRs41Header[k + 1] & 1) ? 1 : -1) * b : 0;
+                const int ky = (l + 1) * 3 + (r + 1);
+                int t = -1;
+                for (size_t q = 0; q < key.size(); q++) if (key[q] == ky) t = (int)q;
+                if (t < 0) {
+                    t = (int)key.size(); key.push_back(ky);
+                    for (int d = 0; d < isps; d++) shapes.push_back((float)b * e->match[(size_t)isps * k + d]);
+                } else {
+                    for (int d = 0; d < isps; d++) ok &= (shapes[(size_t)t * isps + d] == (float)b * e->match[(size_t)isps * k + d]);
+                }
+                type[k] = t; sign[k] = (float)b;
+            }
+            if (ok && key.size() <= 9) {
+                e->corr_types = (int)key.size(); e->corr_isps = isps;
+                bad = 0;
+                bad |= dalloc(&e->d_shapes, shapes.size(), false); bad |= dalloc(&e->d_symtype, nsym, false); bad |= dalloc(&e->d_symsign, nsym, false);
+                if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+                HIPCHK(hipMemcpy(e->d_shapes, shapes.data(), shapes.size() * sizeof(float), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_symtype, type.data(), nsym * sizeof(int), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(e->d_symsign, sign.data(), nsym * sizeof(float), hipMemcpyHostToDevice));
+            }
+        }
+    }
     // IQ-DC segment schedule (demod_mod.c:1351-1357)
     e->dc_lim = (uint32_t)sr; e->dc_max = e->dc_lim / 32;
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
+    e->last_frame.assign((size_t)C * 518, 0);
+    for (int c = 0; c < C; c++) memcpy(e->last_frame.data() + (size_t)c * 518, kRs41HeaderBytes, 8);
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     *out = e;
     return 0;
@@ -221,7 +261,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->stream) { hipStreamSynchronize(e->stream); prof_collect(e); hipStreamDestroy(e->stream); }
     void *ptrs[] = { e->d_Bop, e->d_lut, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
-                     e->d_consts, e->d_stage };
+                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -251,7 +291,10 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums;
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];
         a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
-        prof_begin(e, "mix_decimate"); sonde_launch_mix_decimate(&a, e->stream); prof_end(e);
+        // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
+        { long long tiles = (long long)C * ((a.nblocks + 15) / 16); int G = (int)(tiles / 24576); a.G = G < 1 ? 1 : (G > 32 ? 32 : G); }
+        prof_begin(e, "mix_decimate"); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e);
+        if (lrc < 0) return SONDE_E_ARG;
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
         if (e->dc_cnt == e->dc_max) {
@@ -269,8 +312,17 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     prof_begin(e, "if_chain"); sonde_launch_if_chain(&b, e->stream); prof_end(e);
     CorrArgs c{};
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
+    c.ntypes = e->corr_types; c.isps = e->corr_isps; c.nsym = e->hdrlen / e->symhd; c.shapes = e->d_shapes; c.sym_type = e->d_symtype; c.sym_sign = e->d_symsign;
     prof_begin(e, "header_corr"); sonde_launch_header_corr(&c, e->stream); prof_end(e);
+    launch_framesync(e, 0);
+    if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
+    return 0;
+}
+
+static void launch_framesync_impl(sonde_engine *e, int eof) {
+    const int C = e->cfg.n_channels;
     SyncArgs s{};
+    s.eof = eof;
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
@@ -278,8 +330,6 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
     s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
     prof_begin(e, "framesync"); sonde_launch_framesync(&s, e->stream); prof_end(e);
-    if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
-    return 0;
 }
 
 int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples) {
@@ -323,18 +373,36 @@ int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max
         sonde_frame_t &f = out[i];
         memset(&f, 0, sizeof f);
         f.channel = r.channel; f.len = r.len; f.mv = r.mv; f.mv_pos = r.mv_pos; f.nbytes = r.nbytes;
-        memcpy(f.frame, r.frame, 518);
-        f.ecc = 0;
-        if (e->cfg.ecc_level > 0) {
-            bool clean = true;
-            for (int k = 0; k < 48; k++) clean &= (r.synd[k] == 0);
-            if (clean) { for (int k = f.len; k < 518; k++) f.frame[k] = 0; }
-            else f.ecc = rs41_ecc(f.frame, f.len, e->cfg.ecc_level, r.synd);
+        uint8_t *keepf = e->last_frame.data() + (size_t)r.channel * 518;
+        if (r.nbytes >= 518) {
+            memcpy(f.frame, r.frame, 518);
+            f.ecc = 0;
+            if (e->cfg.ecc_level > 0) {
+                bool clean = true;
+                for (int k = 0; k < 48; k++) clean &= (r.synd[k] == 0);
+                if (clean) { for (int k = f.len; k < 518; k++) f.frame[k] = 0; }
+                else f.ecc = rs41_ecc(f.frame, f.len, e->cfg.ecc_level, r.synd);
+            }
+        } else {
+            // end-of-stream frame: bytes not read keep the previous frame's content unless fewer than
+            // pos_GPS1 = 0x93 bytes exist, then they are zeroed (print_frame, rs41mod.c:2479-2490)
+            memcpy(f.frame, keepf, 518);
+            memcpy(f.frame, r.frame, (size_t)r.nbytes);
+            if (r.nbytes < 0x93) for (int k = r.nbytes; k < 518; k++) f.frame[k] = 0;
+            f.len = (rs41_frametype(f.frame) >= 0) ? 320 : 518;
+            f.ecc = e->cfg.ecc_level > 0 ? rs41_ecc(f.frame, f.len, e->cfg.ecc_level, nullptr) : 0;
         }
+        memcpy(keepf, f.frame, 518);
     }
     e->last_n = n;
     const bool ovf = e->overflow; e->overflow = false;
     return ovf ? SONDE_E_OVERFLOW : n;
+}
+
+int sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
+    if (!e || !out) return SONDE_E_ARG;
+    launch_framesync(e, 1);
+    return sonde_engine_fetch_frames(e, out, max);
 }
 
 int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) {
@@ -371,14 +439,14 @@ int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64
 
 int sonde_engine_profile(sonde_engine_t *e, int enable) {
     if (!e) return SONDE_E_ARG;
-    hipStreamSynchronize(e->stream); prof_collect(e);
+    (void)hipStreamSynchronize(e->stream); prof_collect(e);
     e->prof = enable != 0; e->stats.clear();
     return 0;
 }
 
 int sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches) {
     if (!e || !kernel) return SONDE_E_ARG;
-    hipStreamSynchronize(e->stream); prof_collect(e);
+    (void)hipStreamSynchronize(e->stream); prof_collect(e);
     auto it = e->stats.find(kernel);
     if (it == e->stats.end() || it->second.n == 0) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return 0; }
     if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;

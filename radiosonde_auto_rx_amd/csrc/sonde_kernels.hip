@@ -33,7 +33,6 @@ typedef float  f32x4 __attribute__((ext_vector_type(4)));
 #define MD_N4MAX  4
 #define MD_REMMAX 4
 #define MD_TILE   16          // blocks (rows) per MFMA tile
-#define MD_PROWS  (MD_TILE + 8)
 
 struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) f32x4_u { float x, y, z, w; };
@@ -52,16 +51,45 @@ __device__ __forceinline__ void md_mac(uint32_t raw, float lr, float li, float a
     acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bop, acc_im, 0, 0, 0);
 }
 
+// P rows live in a 32-row circular LDS buffer per wave, transposed: Pt[part][q][row & 31] (row = block index
+// relative to the segment start), so the 4 accumulator rows of a lane are one 16-byte store and the
+// diagonal sum y[o] = sum_q P[o-(Q-1)+q][q] reads conflict-free columns.  Tiles alternate between the two
+// 16-row halves, which keeps the Q-1 history rows of the previous tile without copying.
+#define MD_PT_FLOATS (2 * 8 * 32)
+
+template <int N4, int NREM>
+struct MdTile {
+    u32x4_u raw4[N4 > 0 ? N4 : 1]; f32x4_u la[N4 > 0 ? N4 : 1], lb[N4 > 0 ? N4 : 1];
+    uint32_t raw1[NREM > 0 ? NREM : 1]; float2 l1[NREM > 0 ? NREM : 1];
+};
+
+template <int N4, int NREM>
+__device__ __forceinline__ void md_load(MdTile<N4, NREM> &t, const uint32_t *iq, const float2 *lut, int D, int lut_len,
+                                        size_t n0, uint32_t lidx, int kk) {
+#pragma unroll
+    for (int ss = 0; ss < N4; ss++) {
+        const int r0 = 16 * ss + 4 * kk;
+        t.raw4[ss] = *reinterpret_cast<const u32x4_u *>(iq + n0 + r0);
+        uint32_t li = lidx + r0; if (li >= (uint32_t)lut_len) li -= lut_len;
+        t.la[ss] = *reinterpret_cast<const f32x4_u *>(lut + li);
+        t.lb[ss] = *reinterpret_cast<const f32x4_u *>(lut + li + 2);
+    }
+#pragma unroll
+    for (int rs = 0; rs < NREM; rs++) {
+        int r = 16 * N4 + 4 * rs + kk; if (r >= D) r = D - 1;               // B is zero there
+        t.raw1[rs] = iq[n0 + r];
+        uint32_t li = lidx + r; if (li >= (uint32_t)lut_len) li -= lut_len;
+        t.l1[rs] = lut[li];
+    }
+}
+
+template <int N4, int NREM>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ float smem[];
-    float *sB = smem;                                   // [KS][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *sP = smem + a.KS * 64 + wave * (2 * MD_PROWS * 16);   // per wave: re[24][16], im[24][16]
-    float *sPre = sP, *sPim = sP + MD_PROWS * 16;
-
-    for (int i = threadIdx.x; i < a.KS * 64; i += blockDim.x) sB[i] = a.Bop[i];
-    __syncthreads();
+    float *sPt = smem + wave * MD_PT_FLOATS;                 // [part][q][32]
+    constexpr int KS = 4 * N4 + NREM;
 
     // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; keep a channel on one XCD
     // so its mixer table stays in that XCD's L2.
@@ -70,7 +98,6 @@ void k_mix_decimate(const MixDecArgs a) {
     const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
     const int wg = slot % a.wgs_per_ch;
     if (ch >= a.n_ch) return;
-
     const int seg = wg * 4 + wave;
     const int blocks_per_seg = MD_TILE * a.G;
     const int jb = seg * blocks_per_seg;
@@ -84,96 +111,87 @@ void k_mix_decimate(const MixDecArgs a) {
     const float2 avg = a.dc_avg[ch];
     float2 *yout = a.y + (size_t)ch * a.ring_len;
 
-    // history rows of P (partial sums of the Q-1 blocks before this segment)
-    if (seg == 0) {
-        for (int k = lane; k < H * 16; k += WAVE) {
-            const int r = k >> 4, n = k & 15;
-            float2 v = make_float2(0.f, 0.f);
-            if (n < 8) v = a.ptail_in[((size_t)ch * 8 + r) * 8 + n];
-            sPre[r * 16 + n] = v.x; sPim[r * 16 + n] = v.y;
+    float bop[KS];                                           // B operand: taps in the kernel's K order
+#pragma unroll
+    for (int s = 0; s < KS; s++) bop[s] = a.Bop[s * 64 + lane];
+
+    if (seg == 0) {                                          // P rows of the Q-1 blocks before the chunk
+        for (int k = lane; k < H * 8; k += WAVE) {
+            const int r = k >> 3, q = k & 7;
+            const float2 v = a.ptail_in[((size_t)ch * 8 + r) * 8 + q];
+            const int row = (r - H) & 31;
+            sPt[q * 32 + row] = v.x; sPt[256 + q * 32 + row] = v.y;
         }
     }
     int sx = 0, sy = 0;
+    const int jt0 = (seg == 0) ? jb : jb - MD_TILE;          // one halo tile rebuilds the history of later segments
+    // mixer-table index of this lane's row in the first tile, then advanced by 16*D per tile
+    const uint32_t step = (uint32_t)((16u * (uint32_t)D) % (uint32_t)a.lut_len);
+    uint32_t lidx = (a.lut_phase + (uint32_t)(min(jt0 + i, a.nblocks - 1)) * (uint32_t)D) % (uint32_t)a.lut_len;
 
-    for (int jt = (seg == 0 ? jb : jb - MD_TILE); jt < je; jt += MD_TILE) {
+    MdTile<N4, NREM> T[2];
+    {
+        const int j = min(jt0 + i, a.nblocks - 1);
+        md_load<N4, NREM>(T[0], iq, lut, D, a.lut_len, (size_t)j * D, lidx, kk);
+    }
+    int cur = 0;
+#pragma unroll 2
+    for (int jt = jt0; jt < je; jt += MD_TILE, cur ^= 1) {
         const bool halo = jt < jb;
-        const int j = min(jt + i, a.nblocks - 1);               // clamp rows past the chunk (results unused)
         const bool rowvalid = (jt + i) < je && !halo;
-        const size_t n0 = (size_t)j * D;
-        uint32_t lidx = (a.lut_phase + (uint32_t)n0) % (uint32_t)a.lut_len;
-
-        u32x4_u raw4[MD_N4MAX]; f32x4_u la[MD_N4MAX], lb[MD_N4MAX];
-        uint32_t raw1[MD_REMMAX]; float2 l1[MD_REMMAX];
-#pragma unroll
-        for (int ss = 0; ss < MD_N4MAX; ss++) {
-            if (ss < a.n4) {
-                const int r0 = 16 * ss + 4 * kk;
-                raw4[ss] = *reinterpret_cast<const u32x4_u *>(iq + n0 + r0);
-                uint32_t li = lidx + r0; if (li >= (uint32_t)a.lut_len) li -= a.lut_len;
-                la[ss] = *reinterpret_cast<const f32x4_u *>(lut + li);
-                lb[ss] = *reinterpret_cast<const f32x4_u *>(lut + li + 2);
-            }
+        if (jt + MD_TILE < je) {                             // prefetch the next tile while this one is on the matrix cores
+            const int jn = jt + MD_TILE + i;
+            const int j = min(jn, a.nblocks - 1);
+            uint32_t ln = lidx + step; if (ln >= (uint32_t)a.lut_len) ln -= a.lut_len;
+            if (jn > a.nblocks - 1) ln = (a.lut_phase + (uint32_t)j * (uint32_t)D) % (uint32_t)a.lut_len;   // clamped rows
+            lidx = ln;
+            md_load<N4, NREM>(T[cur ^ 1], iq, lut, D, a.lut_len, (size_t)j * D, ln, kk);
         }
-#pragma unroll
-        for (int rs = 0; rs < MD_REMMAX; rs++) {
-            if (rs < a.nrem) {
-                int r = 16 * a.n4 + 4 * rs + kk; if (r >= D) r = D - 1;      // B is zero there
-                raw1[rs] = iq[n0 + r];
-                uint32_t li = lidx + r; if (li >= (uint32_t)a.lut_len) li -= a.lut_len;
-                l1[rs] = lut[li];
-            }
-        }
-
+        const MdTile<N4, NREM> &t = T[cur];
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ss = 0; ss < MD_N4MAX; ss++) {
-            if (ss < a.n4) {
-                const float *bp = sB + (4 * ss) * 64 + lane;
-                md_mac(raw4[ss].x, la[ss].x, la[ss].y, avg.x, avg.y, bp[0],   acc_re, acc_im, sx, sy, rowvalid);
-                md_mac(raw4[ss].y, la[ss].z, la[ss].w, avg.x, avg.y, bp[64],  acc_re, acc_im, sx, sy, rowvalid);
-                md_mac(raw4[ss].z, lb[ss].x, lb[ss].y, avg.x, avg.y, bp[128], acc_re, acc_im, sx, sy, rowvalid);
-                md_mac(raw4[ss].w, lb[ss].z, lb[ss].w, avg.x, avg.y, bp[192], acc_re, acc_im, sx, sy, rowvalid);
-            }
+        for (int ss = 0; ss < N4; ss++) {
+            md_mac(t.raw4[ss].x, t.la[ss].x, t.la[ss].y, avg.x, avg.y, bop[4 * ss + 0], acc_re, acc_im, sx, sy, rowvalid);
+            md_mac(t.raw4[ss].y, t.la[ss].z, t.la[ss].w, avg.x, avg.y, bop[4 * ss + 1], acc_re, acc_im, sx, sy, rowvalid);
+            md_mac(t.raw4[ss].z, t.lb[ss].x, t.lb[ss].y, avg.x, avg.y, bop[4 * ss + 2], acc_re, acc_im, sx, sy, rowvalid);
+            md_mac(t.raw4[ss].w, t.lb[ss].z, t.lb[ss].w, avg.x, avg.y, bop[4 * ss + 3], acc_re, acc_im, sx, sy, rowvalid);
         }
 #pragma unroll
-        for (int rs = 0; rs < MD_REMMAX; rs++) {
-            if (rs < a.nrem) {
-                const int r = 16 * a.n4 + 4 * rs + kk;
-                md_mac(raw1[rs], l1[rs].x, l1[rs].y, avg.x, avg.y, sB[(4 * a.n4 + rs) * 64 + lane],
-                       acc_re, acc_im, sx, sy, rowvalid && r < D);
-            }
+        for (int rs = 0; rs < NREM; rs++) {
+            const int r = 16 * N4 + 4 * rs + kk;
+            md_mac(t.raw1[rs], t.l1[rs].x, t.l1[rs].y, avg.x, avg.y, bop[4 * N4 + rs], acc_re, acc_im, sx, sy, rowvalid && r < D);
         }
 
-        // C/D layout of 16x16x4: col = lane&15, row = 4*(lane>>4) + reg
-#pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-            const int row = H + 4 * kk + rg;
-            sPre[row * 16 + i] = acc_re[rg];
-            sPim[row * 16 + i] = acc_im[rg];
+        // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
+        const int rbase = (jt - jb) & 31;                    // row of the tile's first block (0 or 16)
+        if (i < 8) {
+            *reinterpret_cast<f32x4 *>(sPt + i * 32 + rbase + 4 * kk) = acc_re;
+            *reinterpret_cast<f32x4 *>(sPt + 256 + i * 32 + rbase + 4 * kk) = acc_im;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!halo && lane < 16 && jt + lane < je) {
-            float yr = 0.f, yi = 0.f;
-            for (int q = 0; q < Q; q++) { yr += sPre[(lane + q) * 16 + q]; yi += sPim[(lane + q) * 16 + q]; }
-            const uint32_t m = a.m0 + (uint32_t)(jt + lane);
-            yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
-        }
-        // P rows of the last Q-1 blocks of the chunk go to the next call
-        if (jt + MD_TILE >= a.nblocks && !halo) {
-            const int base = a.nblocks - jt;                 // row index of block (nblocks - H)
-            for (int k = lane; k < H * 8; k += WAVE) {
-                const int r = k >> 3, n = k & 7;
-                a.ptail_out[((size_t)ch * 8 + r) * 8 + n] = make_float2(sPre[(base + r) * 16 + n], sPim[(base + r) * 16 + n]);
+        if (!halo) {
+            // lane = (half, part, o): 4 of the Q diagonal terms each, combined with two cross-lane adds
+            const int o = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
+            float v = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const int q = 4 * half + qq;
+                if (q < Q) v += sPt[part * 256 + q * 32 + ((rbase + o - H + q) & 31)];
+            }
+            v += __shfl_xor(v, 32);
+            const float vim = __shfl_xor(v, 16);
+            if (lane < 16 && jt + lane < je) {
+                const uint32_t m = a.m0 + (uint32_t)(jt + lane);
+                yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
+            }
+            if (jt + MD_TILE >= a.nblocks) {                 // P rows of the last Q-1 blocks go to the next call
+                for (int k = lane; k < H * 8; k += WAVE) {
+                    const int r = k >> 3, q = k & 7;
+                    const int row = (a.nblocks - H + r - jb) & 31;
+                    a.ptail_out[((size_t)ch * 8 + r) * 8 + q] = make_float2(sPt[q * 32 + row], sPt[256 + q * 32 + row]);
+                }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // slide history: rows [16, 16+H) -> [0, H)
-        for (int k = lane; k < H * 16; k += WAVE) {
-            const float vr = sPre[(MD_TILE + (k >> 4)) * 16 + (k & 15)], vi = sPim[(MD_TILE + (k >> 4)) * 16 + (k & 15)];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            sPre[k] = vr; sPim[k] = vi;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 
     // running IQ-DC sums of this segment (exact integer arithmetic == the reference's double sums)
@@ -322,6 +340,59 @@ void k_header_corr(const CorrArgs a) {
     }
 }
 
+// Factorised form for integer samples/symbol (sps): the template is, symbol by symbol, one of a few
+// `shapes` (own bit +-1 and the two neighbour bits, demod_mod.c:1398-1416), so
+//   c[p] = sum_k sign_k * F_{type_k}[p-(L-1)+sps*k],   F_t[n] = sum_{d<sps} shape_t[d] * bufs[n+d]
+// ~ (types*sps + symbols) operations per sample instead of L.  The shapes are taken from the very same
+// match[] floats, so the result differs from the direct sum only by float association.
+#define HCF_TILE 1024
+#define HCF_THREADS 256
+#define HCF_MAXTYPES 9
+
+__global__ __launch_bounds__(HCF_THREADS)
+void k_header_corr_fact(const CorrArgs a) {
+    extern __shared__ float smem[];
+    const int ch = blockIdx.y, L = a.L, sps = a.isps, nsym = a.nsym, nt = a.ntypes;
+    const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HCF_TILE;
+    const int nout = min(HCF_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
+    if (nout <= 0) return;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const int nx = HCF_TILE + L - 1;                 // samples p0-(L-1) .. p0+HCF_TILE-1
+    const int nf = HCF_TILE + sps * (nsym - 1);      // F entries per type
+    float *sx = smem;                                // [nx]
+    float *sF = smem + ((nx + 3) & ~3);              // [nt][nf]
+    const float *bufs = a.bufs + (size_t)ch * a.ring_len;
+    for (int k = threadIdx.x; k < nx; k += HCF_THREADS) {
+        const int64_t m = (int64_t)p0 - (L - 1) + k;
+        sx[k] = (m >= 0 && k < nout + L - 1) ? bufs[(uint32_t)m & mask] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nt * nf; idx += HCF_THREADS) {
+        const int t = idx / nf, n = idx - t * nf;
+        const float *sh = a.shapes + t * sps;
+        float acc = 0.f;
+        for (int d = 0; d < sps; d++) acc = fmaf(sh[d], sx[n + d], acc);
+        sF[idx] = acc;
+    }
+    __syncthreads();
+    float acc[HCF_TILE / HCF_THREADS];
+#pragma unroll
+    for (int j = 0; j < HCF_TILE / HCF_THREADS; j++) acc[j] = 0.f;
+    for (int k = 0; k < nsym; k++) {
+        const int ty = a.sym_type[k];                // uniform: scalar loads
+        const float sg = a.sym_sign[k];
+        const float *f = sF + ty * nf + sps * k + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < HCF_TILE / HCF_THREADS; j++) acc[j] = fmaf(sg, f[j * HCF_THREADS], acc[j]);
+    }
+    float *corr = a.corr + (size_t)ch * a.ring_len;
+#pragma unroll
+    for (int j = 0; j < HCF_TILE / HCF_THREADS; j++) {
+        const int k = threadIdx.x + j * HCF_THREADS;
+        if (k < nout) corr[(p0 + (uint32_t)k) & mask] = acc[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_framesync: one wave per channel
 // ------------------------------------------------------------------------------------------------
@@ -375,6 +446,7 @@ void k_framesync(const SyncArgs a) {
     __syncthreads();
 
     for (int guard = 0; guard < 64; guard++) {
+        if (st.mode == 2) break;                       // stream finished
         if (st.mode == 0) {
             // ---- find_header: next correlation once K-4 new samples were consumed (demod_mod.c:1540-1548)
             const uint32_t need = (uint32_t)(K - 4) - st.k;
@@ -444,7 +516,11 @@ void k_framesync(const SyncArgs a) {
         } else {
             // ---- frame: nbits soft bits from sample mv_pos+1+ofs on (read_softbit2p, demod_mod.c:1087-1175)
             const uint32_t s_in_after = st.mv_pos + (uint32_t)a.delay + 1 + a.frame_samples;
-            if ((int32_t)(avail - s_in_after) < 0) break;              // wait for the next chunk
+            const bool enough = (int32_t)(avail - s_in_after) >= 0;
+            if (!enough && !a.eof) break;                              // wait for the next chunk
+            // at end of stream the reference slices until f32buf_sample() hits EOF (rs41mod.c:2931): consumption q
+            // needs IF sample mv_pos+delay+1+q, so only bits ending at q1 <= q_lim exist
+            const int32_t q_lim = enough ? (int32_t)a.frame_samples : (int32_t)(avail - (st.mv_pos + (uint32_t)a.delay + 1));
             const uint32_t base = st.mv_pos + 1 + (uint32_t)a.bitofs;
             unsigned slot = 0;
             if (lane == 0) slot = atomicAdd(a.frame_count, 1u);
@@ -453,10 +529,12 @@ void k_framesync(const SyncArgs a) {
             FrameRec *rec = a.frames + (keep ? slot : 0);
             for (int k = lane; k < 520; k += WAVE) s_frame[k] = (k < 8) ? a.hdr_bytes[k] : 0;
             __syncthreads();
+            int nbytes_ok = 0;
             for (int it = 0; it * WAVE < a.nbits; it++) {
                 const int bp = it * WAVE + lane;
                 double sum = 0.0;
-                if (bp < a.nbits) {
+                bool valid = bp < a.nbits;
+                if (valid) {
                     if (a.symlen == 2) {
                         uint32_t q0, q1; double mid;
                         bit_window(bp, 0, 2, a.sps, q0, q1, mid);
@@ -466,16 +544,19 @@ void k_framesync(const SyncArgs a) {
                     }
                     uint32_t q0, q1; double mid;
                     bit_window(bp, a.symlen - 1, a.symlen, a.sps, q0, q1, mid);
-                    for (uint32_t q = q0; q < q1; q++)
-                        if (a.l_win < 0.f || (mid - (double)a.l_win < (double)q && (double)q < mid + (double)a.l_win))
-                            sum += (double)bufs[(base + q) & mask];
+                    valid = (int32_t)q1 <= q_lim;
+                    if (valid)
+                        for (uint32_t q = q0; q < q1; q++)
+                            if (a.l_win < 0.f || (mid - (double)a.l_win < (double)q && (double)q < mid + (double)a.l_win))
+                                sum += (double)bufs[(base + q) & mask];
                 }
-                const int hb = (bp < a.nbits) && (sum >= 0.0);
-                const unsigned long long bal = __ballot(hb);
-                if (keep && a.soft && bp < a.nbits) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
+                const int hb = valid && (sum >= 0.0);
+                const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
+                if (keep && a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
+                nbytes_ok += __popcll(vm & 0x8080808080808080ULL);
                 if (lane < 8) {
                     const int bi = 8 + it * 8 + lane;                  // frame byte index (LSB-first bits, rs41mod.c:224)
-                    if (bi < 518 && (it * 8 + lane) * 8 < a.nbits)
+                    if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
                         s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
                 }
             }
@@ -499,9 +580,10 @@ void k_framesync(const SyncArgs a) {
             if (keep) {
                 for (int k = lane; k < 518; k += WAVE) rec->frame[k] = s_frame[k];
                 if (lane < 48) rec->synd[lane] = syn;
-                if (lane == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = flen; rec->nbytes = 518; }
+                if (lane == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = flen; rec->nbytes = 8 + nbytes_ok; }
             }
             __syncthreads();
+            if (!enough) { st.mode = 2; st.s_in = avail; break; }
             st.s_in = s_in_after; st.k = 0; st.mode = 0;
         }
     }
@@ -511,13 +593,21 @@ void k_framesync(const SyncArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from sonde_engine.cpp)
 // ------------------------------------------------------------------------------------------------
-extern "C" void sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
+template <int N4, int NREM>
+static void md_launch(const MixDecArgs &b, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_mix_decimate<N4, NREM>), dim3(grid), dim3(256), 4 * MD_PT_FLOATS * sizeof(float), s, b);
+}
+extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     const int blocks_per_wg = 4 * MD_TILE * a->G;
     const int wgs_per_ch = (a->nblocks + blocks_per_wg - 1) / blocks_per_wg;
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
-    const int chg = (a->n_ch + 7) / 8;
-    const size_t lds = (size_t)(a->KS * 64 + 4 * 2 * MD_PROWS * 16) * sizeof(float);
-    hipLaunchKernelGGL(k_mix_decimate, dim3(chg * 8 * wgs_per_ch), dim3(256), lds, s, b);
+    const int grid = ((a->n_ch + 7) / 8) * 8 * wgs_per_ch;
+    // (n4, nrem) = (decM/16, ceil((decM%16)/4)): one straight-line instantiation per pair
+#define MD_CASE(N4_, NR_) if (a->n4 == N4_ && a->nrem == NR_) { md_launch<N4_, NR_>(b, grid, s); return 0; }
+    MD_CASE(3, 1) MD_CASE(0, 1) MD_CASE(0, 2) MD_CASE(0, 3) MD_CASE(0, 4) MD_CASE(1, 0) MD_CASE(1, 1) MD_CASE(1, 2) MD_CASE(1, 3)
+    MD_CASE(2, 0) MD_CASE(2, 1) MD_CASE(2, 2) MD_CASE(2, 3) MD_CASE(3, 0) MD_CASE(3, 2) MD_CASE(3, 3) MD_CASE(4, 0)
+#undef MD_CASE
+    return -1;
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
@@ -530,6 +620,12 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
+    if (a->ntypes > 0) {
+        const int nx = HCF_TILE + a->L - 1, nf = HCF_TILE + a->isps * (a->nsym - 1);
+        const size_t lds = (size_t)(((nx + 3) & ~3) + a->ntypes * nf) * sizeof(float);
+        hipLaunchKernelGGL(k_header_corr_fact, dim3((a->n + HCF_TILE - 1) / HCF_TILE, a->n_ch), dim3(HCF_THREADS), lds, s, *a);
+        return;
+    }
     const size_t lds = (size_t)(HC_TILE + 2 * a->L + 8) * sizeof(float);
     hipLaunchKernelGGL(k_header_corr, dim3((a->n + HC_TILE - 1) / HC_TILE, a->n_ch), dim3(HC_THREADS), lds, s, *a);
 }

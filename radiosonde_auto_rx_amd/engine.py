@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         L.sonde_engine_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_engine_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_engine_fetch_frames.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
+        L.sonde_engine_finish.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
         L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_engine_read_tap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
         L.sonde_engine_sync.argtypes = [C.c_void_p]
@@ -128,16 +129,18 @@ class Engine:
         _chk(lib().sonde_engine_sync(self._h))
 
     # -- output ------------------------------------------------------------------------------
-    def fetch_frames(self, max_frames: int | None = None, with_soft: bool = False):
+    def fetch_frames(self, max_frames: int | None = None, with_soft: bool = False, finish: bool = False):
+        """Frames completed so far; finish=True = end of input (also emits the frame in progress, like the reference at EOF)."""
         n = max_frames or self._max_frames
         buf = (SondeFrame * n)()
-        k = _chk(lib().sonde_engine_fetch_frames(self._h, buf, n))
+        fn = lib().sonde_engine_finish if finish else lib().sonde_engine_fetch_frames
+        k = _chk(fn(self._h, buf, n))
         frames = []
         line = C.create_string_buffer(1200)
         for i in range(k):
             f = buf[i]
             ll = lib().sonde_rs41_rawline(C.byref(f), line, 1200)
-            frames.append(dict(channel=f.channel, len=f.len, ecc=f.ecc, mv=f.mv, mv_pos=f.mv_pos,
+            frames.append(dict(channel=f.channel, len=f.len, ecc=f.ecc, mv=f.mv, mv_pos=f.mv_pos, nbytes=f.nbytes,
                                frame=bytes(f.frame), line=line.raw[:ll].decode()))
         if with_soft:
             soft = np.zeros((max(k, 1), self.nbits), np.float32)
@@ -145,6 +148,17 @@ class Engine:
             for i in range(k):
                 frames[i]["soft"] = soft[i].copy()
         return frames
+
+    FRAME_DTYPE = np.dtype([("channel", "<i4"), ("len", "<i4"), ("ecc", "<i4"), ("mv_pos", "<u4"), ("mv", "<f4"),
+                            ("nbytes", "<i4"), ("frame", "u1", (518,)), ("pad", "u1", (2,))])
+
+    def fetch_frames_np(self, max_frames: int | None = None) -> np.ndarray:
+        """Frames completed so far as one structured array (layout of sonde_frame_t); no per-frame Python work."""
+        n = max_frames or self._max_frames
+        if getattr(self, "_fbuf", None) is None or len(self._fbuf) < n:
+            self._fbuf = np.zeros(n, self.FRAME_DTYPE)
+        k = _chk(lib().sonde_engine_fetch_frames(self._h, self._fbuf.ctypes.data_as(C.POINTER(SondeFrame)), n))
+        return self._fbuf[:k]
 
     def read_tap(self, channel: int, tap: int, first: int, count: int) -> np.ndarray:
         width = 2 if tap in (TAP_DECIM, TAP_IFIQ) else 1

@@ -42,15 +42,15 @@ def test_frames_match_golden_and_oracle(oracle, name):
     x, fq, sr = capture(name)
     eng = _engine([fq], sr, max_chunk=sr)
     frames, used = _run(eng, x, sr)          # 1-second chunks
+    frames += eng.fetch_frames(with_soft=True, finish=True)   # EOF: the reference also prints the frame in progress
     o = oracle.ora_rs41_decode(x[:2 * used], sr, fq=fq)
-    # the engine only emits complete frames; the reference also prints a partial frame at EOF
-    full = [i for i in range(o["n"]) if o["s_in_after"][i] <= used // eng.info["decM"]]
-    assert len(frames) == len(full)
-    for f, i in zip(frames, full):
+    assert len(frames) == o["n"] == len(g["lines"])
+    for i, f in enumerate(frames):
         assert f["line"] == o["lines"][i] == g["lines"][i]
         assert f["mv_pos"] == o["mv_pos"][i] == g["mv_pos"][i]
-        assert abs(f["mv"] - o["mv"][i]) < 2e-5
-        d = rms(f["soft"] - o["soft"][i])
+        assert abs(f["mv"] - o["mv"][i]) < 1e-4          # score only gates the 0.7 threshold; reference FFT error ~4e-5
+        nb = (f["nbytes"] - 8) * 8
+        d = rms(f["soft"][:nb] - o["soft"][i][:nb])
         assert d < 3e-5 and d <= 3 * float(g["floor_soft"]) + 1e-6, d
     eng.close()
 
@@ -125,3 +125,18 @@ def test_no_gpu_fallback_symbols():
     """The product library exports every symbol of include/sonde_hip.h (also checked without a GPU)."""
     import test_capi_symbols
     test_capi_symbols.test_exports()
+
+
+def test_cli_rs41mod_matches_reference_lines():
+    """host/bin/rs41mod (C front end over the C ABI) prints the same stdout as the reference binary did (golden)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "host")])
+    for name in ("rs41_480k_be30", "rs41_480k_trunc2600", "rs41_96k_off300"):
+        g = load(name)
+        x, fq, sr = capture(name)
+        r = subprocess.run([os.path.join(root, "host", "bin", "rs41mod"), "-r", "--ecc2", "--crc", "--IQ", repr(fq), "--lpIQ",
+                            "-", str(sr), "16"], input=x.tobytes(), capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode().splitlines() == g["lines"], name
+        assert r.stderr.decode().splitlines()[:2] == ["IF: %d" % g["consts"]["if_sr"], "dec: %d" % g["consts"]["decM"]]

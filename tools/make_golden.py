@@ -22,6 +22,9 @@ CASES = {
     "rs41_480k_clean": dict(sr=480_000, seconds=3.2, fq=0.05, noise_sigma=0.01, seed=3, win=(0, 40000)),
     "rs41_480k_be30": dict(sr=480_000, seconds=3.2, fq=0.31, noise_sigma=0.05, bit_errors=30, seed=4, win=(0, 0)),
     "rs41_96k_off300": dict(sr=96_000, seconds=3.2, fq=0.0, f_offset_hz=300.0, noise_sigma=0.02, seed=5, win=(0, 0)),
+    # input ends inside the third frame: < 0x93 bytes read (tail zeroed) / more (tail keeps the previous frame)
+    "rs41_480k_trunc2500": dict(sr=480_000, seconds=3.2, fq=0.05, noise_sigma=0.01, seed=3, win=(0, 0), trunc=1_200_000),
+    "rs41_480k_trunc2600": dict(sr=480_000, seconds=3.2, fq=0.05, noise_sigma=0.01, seed=3, win=(0, 0), trunc=1_248_000),
 }
 
 
@@ -31,9 +34,13 @@ def rms(a):
 
 def capture(kw):
     kw = dict(kw); kw.pop("win")
+    trunc = kw.pop("trunc", None)
     sr = kw["sr"]
     kw["fq"] = synth.snap_fq(kw["fq"], sr)
-    return synth.rs41_capture(**kw), kw["fq"]
+    x = synth.rs41_capture(**kw)
+    if trunc:
+        x = x[:2 * trunc]
+    return x, kw["fq"]
 
 
 def main():
