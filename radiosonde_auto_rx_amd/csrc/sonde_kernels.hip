@@ -57,26 +57,29 @@ __device__ __forceinline__ void md_mac(uint32_t raw, float lr, float li, float a
 // 16-row halves, which keeps the Q-1 history rows of the previous tile without copying.
 #define MD_PT_FLOATS (2 * 8 * 32)
 
-template <int N4, int NREM>
-struct MdTile {
-    u32x4_u raw4[N4 > 0 ? N4 : 1]; f32x4_u la[N4 > 0 ? N4 : 1], lb[N4 > 0 ? N4 : 1];
-    uint32_t raw1[NREM > 0 ? NREM : 1]; float2 l1[NREM > 0 ? NREM : 1];
+// One tile's samples are loaded in two phases (A: the first ceil(N4/2) 16-sample super-steps, B: the rest) so
+// that a phase is always in flight while the other one is on the matrix cores, at half the register cost of
+// prefetching whole tiles.
+template <int NS, int NR>
+struct MdPhase {
+    u32x4_u raw4[NS > 0 ? NS : 1]; f32x4_u la[NS > 0 ? NS : 1], lb[NS > 0 ? NS : 1];
+    uint32_t raw1[NR > 0 ? NR : 1]; float2 l1[NR > 0 ? NR : 1];
 };
 
-template <int N4, int NREM>
-__device__ __forceinline__ void md_load(MdTile<N4, NREM> &t, const uint32_t *iq, const float2 *lut, int D, int lut_len,
+template <int S0, int NS, int NR>
+__device__ __forceinline__ void md_load(MdPhase<NS, NR> &t, const uint32_t *iq, const float2 *lut, int D, int lut_len,
                                         size_t n0, uint32_t lidx, int kk) {
 #pragma unroll
-    for (int ss = 0; ss < N4; ss++) {
-        const int r0 = 16 * ss + 4 * kk;
+    for (int ss = 0; ss < NS; ss++) {
+        const int r0 = 16 * (S0 + ss) + 4 * kk;
         t.raw4[ss] = *reinterpret_cast<const u32x4_u *>(iq + n0 + r0);
         uint32_t li = lidx + r0; if (li >= (uint32_t)lut_len) li -= lut_len;
         t.la[ss] = *reinterpret_cast<const f32x4_u *>(lut + li);
         t.lb[ss] = *reinterpret_cast<const f32x4_u *>(lut + li + 2);
     }
 #pragma unroll
-    for (int rs = 0; rs < NREM; rs++) {
-        int r = 16 * N4 + 4 * rs + kk; if (r >= D) r = D - 1;               // B is zero there
+    for (int rs = 0; rs < NR; rs++) {
+        int r = 16 * (S0 + NS) + 4 * rs + kk; if (r >= D) r = D - 1;         // B is zero there
         t.raw1[rs] = iq[n0 + r];
         uint32_t li = lidx + r; if (li >= (uint32_t)lut_len) li -= lut_len;
         t.l1[rs] = lut[li];
@@ -84,7 +87,86 @@ __device__ __forceinline__ void md_load(MdTile<N4, NREM> &t, const uint32_t *iq,
 }
 
 template <int N4, int NREM>
-__global__ __launch_bounds__(256)
+struct MdCtx {
+    const MixDecArgs &a; const uint32_t *iq; const float2 *lut; float2 *yout; float *sPt; const float *bop; float2 avg;
+    int lane, i, kk, ch, jb, je, D, Q, H; uint32_t step, lidx; int sx, sy;
+    f32x4 acc_re, acc_im;
+};
+
+// row (block) and mixer-table index of this lane for the tile starting at jt; advances c.lidx tile by tile
+template <int N4, int NREM>
+__device__ __forceinline__ size_t md_row(MdCtx<N4, NREM> &c, int jt, bool first, uint32_t &lidx) {
+    const int jn = jt + c.i;
+    const int j = min(jn, c.a.nblocks - 1);
+    if (!first) {
+        uint32_t ln = c.lidx + c.step; if (ln >= (uint32_t)c.a.lut_len) ln -= c.a.lut_len;
+        if (jn > c.a.nblocks - 1) ln = (c.a.lut_phase + (uint32_t)j * (uint32_t)c.D) % (uint32_t)c.a.lut_len;   // clamped rows
+        c.lidx = ln;
+    }
+    lidx = c.lidx;
+    return (size_t)j * c.D;
+}
+
+template <int N4, int NREM, int S0, int NS, int NR>
+__device__ __forceinline__ void md_phase_mac(MdCtx<N4, NREM> &c, const MdPhase<NS, NR> &t, int jt) {
+    const bool rowvalid = (jt + c.i) < c.je && jt >= c.jb;
+#pragma unroll
+    for (int ss = 0; ss < NS; ss++) {
+        const int s0 = 4 * (S0 + ss);
+        md_mac(t.raw4[ss].x, t.la[ss].x, t.la[ss].y, c.avg.x, c.avg.y, c.bop[s0 + 0], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
+        md_mac(t.raw4[ss].y, t.la[ss].z, t.la[ss].w, c.avg.x, c.avg.y, c.bop[s0 + 1], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
+        md_mac(t.raw4[ss].z, t.lb[ss].x, t.lb[ss].y, c.avg.x, c.avg.y, c.bop[s0 + 2], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
+        md_mac(t.raw4[ss].w, t.lb[ss].z, t.lb[ss].w, c.avg.x, c.avg.y, c.bop[s0 + 3], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
+    }
+#pragma unroll
+    for (int rs = 0; rs < NR; rs++) {
+        const int r = 16 * (S0 + NS) + 4 * rs + c.kk;
+        md_mac(t.raw1[rs], t.l1[rs].x, t.l1[rs].y, c.avg.x, c.avg.y, c.bop[4 * (S0 + NS) + rs], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid && r < c.D);
+    }
+}
+
+template <int N4, int NREM>
+__device__ __forceinline__ void md_epilogue(MdCtx<N4, NREM> &c, int jt) {
+    const MixDecArgs &a = c.a;
+    const int lane = c.lane, i = c.i, kk = c.kk, jb = c.jb, je = c.je, Q = c.Q, H = c.H;
+    float *sPt = c.sPt;
+    const bool halo = jt < jb;
+    // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
+    const int rbase = (jt - jb) & 31;                    // row of the tile's first block (0 or 16)
+    if (i < 8) {
+        *reinterpret_cast<f32x4 *>(sPt + i * 32 + rbase + 4 * kk) = c.acc_re;
+        *reinterpret_cast<f32x4 *>(sPt + 256 + i * 32 + rbase + 4 * kk) = c.acc_im;
+    }
+    c.acc_re = (f32x4){0.f, 0.f, 0.f, 0.f}; c.acc_im = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!halo) {
+        // lane = (half, part, o): 4 of the Q diagonal terms each, combined with two cross-lane adds
+        const int o = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
+        float v = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const int q = 4 * half + qq;
+            if (q < Q) v += sPt[part * 256 + q * 32 + ((rbase + o - H + q) & 31)];
+        }
+        v += __shfl_xor(v, 32);
+        const float vim = __shfl_xor(v, 16);
+        if (lane < 16 && jt + lane < je) {
+            const uint32_t m = a.m0 + (uint32_t)(jt + lane);
+            c.yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
+        }
+        if (jt + MD_TILE >= a.nblocks) {                 // P rows of the last Q-1 blocks go to the next call
+            for (int k = lane; k < H * 8; k += WAVE) {
+                const int r = k >> 3, q = k & 7;
+                const int row = (a.nblocks - H + r - jb) & 31;
+                a.ptail_out[((size_t)c.ch * 8 + r) * 8 + q] = make_float2(sPt[q * 32 + row], sPt[256 + q * 32 + row]);
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+template <int N4, int NREM>
+__global__ __launch_bounds__(256, 4)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,76 +205,30 @@ void k_mix_decimate(const MixDecArgs a) {
             sPt[q * 32 + row] = v.x; sPt[256 + q * 32 + row] = v.y;
         }
     }
-    int sx = 0, sy = 0;
     const int jt0 = (seg == 0) ? jb : jb - MD_TILE;          // one halo tile rebuilds the history of later segments
     // mixer-table index of this lane's row in the first tile, then advanced by 16*D per tile
     const uint32_t step = (uint32_t)((16u * (uint32_t)D) % (uint32_t)a.lut_len);
     uint32_t lidx = (a.lut_phase + (uint32_t)(min(jt0 + i, a.nblocks - 1)) * (uint32_t)D) % (uint32_t)a.lut_len;
 
-    MdTile<N4, NREM> T[2];
-    {
-        const int j = min(jt0 + i, a.nblocks - 1);
-        md_load<N4, NREM>(T[0], iq, lut, D, a.lut_len, (size_t)j * D, lidx, kk);
+    // software pipeline over half tiles: phase B of tile t and phase A of tile t+1 are in flight while the
+    // other phase is on the matrix cores
+    constexpr int NA = (N4 + 1) / 2, NB = N4 - NA;
+    MdCtx<N4, NREM> c = { a, iq, lut, yout, sPt, bop, avg, lane, i, kk, ch, jb, je, D, Q, H, step, lidx, 0, 0,
+                          {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f} };
+    MdPhase<NA, 0> PA; MdPhase<NB, NREM> PB;
+    uint32_t li; size_t n0 = md_row<N4, NREM>(c, jt0, true, li);
+    md_load<0, NA, 0>(PA, iq, lut, D, a.lut_len, n0, li, kk);
+    for (int jt = jt0; jt < je; jt += MD_TILE) {
+        md_load<NA, NB, NREM>(PB, iq, lut, D, a.lut_len, n0, li, kk);
+        md_phase_mac<N4, NREM, 0, NA, 0>(c, PA, jt);
+        if (jt + MD_TILE < je) {
+            n0 = md_row<N4, NREM>(c, jt + MD_TILE, false, li);
+            md_load<0, NA, 0>(PA, iq, lut, D, a.lut_len, n0, li, kk);
+        }
+        md_phase_mac<N4, NREM, NA, NB, NREM>(c, PB, jt);
+        md_epilogue<N4, NREM>(c, jt);
     }
-    int cur = 0;
-#pragma unroll 2
-    for (int jt = jt0; jt < je; jt += MD_TILE, cur ^= 1) {
-        const bool halo = jt < jb;
-        const bool rowvalid = (jt + i) < je && !halo;
-        if (jt + MD_TILE < je) {                             // prefetch the next tile while this one is on the matrix cores
-            const int jn = jt + MD_TILE + i;
-            const int j = min(jn, a.nblocks - 1);
-            uint32_t ln = lidx + step; if (ln >= (uint32_t)a.lut_len) ln -= a.lut_len;
-            if (jn > a.nblocks - 1) ln = (a.lut_phase + (uint32_t)j * (uint32_t)D) % (uint32_t)a.lut_len;   // clamped rows
-            lidx = ln;
-            md_load<N4, NREM>(T[cur ^ 1], iq, lut, D, a.lut_len, (size_t)j * D, ln, kk);
-        }
-        const MdTile<N4, NREM> &t = T[cur];
-        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ss = 0; ss < N4; ss++) {
-            md_mac(t.raw4[ss].x, t.la[ss].x, t.la[ss].y, avg.x, avg.y, bop[4 * ss + 0], acc_re, acc_im, sx, sy, rowvalid);
-            md_mac(t.raw4[ss].y, t.la[ss].z, t.la[ss].w, avg.x, avg.y, bop[4 * ss + 1], acc_re, acc_im, sx, sy, rowvalid);
-            md_mac(t.raw4[ss].z, t.lb[ss].x, t.lb[ss].y, avg.x, avg.y, bop[4 * ss + 2], acc_re, acc_im, sx, sy, rowvalid);
-            md_mac(t.raw4[ss].w, t.lb[ss].z, t.lb[ss].w, avg.x, avg.y, bop[4 * ss + 3], acc_re, acc_im, sx, sy, rowvalid);
-        }
-#pragma unroll
-        for (int rs = 0; rs < NREM; rs++) {
-            const int r = 16 * N4 + 4 * rs + kk;
-            md_mac(t.raw1[rs], t.l1[rs].x, t.l1[rs].y, avg.x, avg.y, bop[4 * N4 + rs], acc_re, acc_im, sx, sy, rowvalid && r < D);
-        }
-
-        // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
-        const int rbase = (jt - jb) & 31;                    // row of the tile's first block (0 or 16)
-        if (i < 8) {
-            *reinterpret_cast<f32x4 *>(sPt + i * 32 + rbase + 4 * kk) = acc_re;
-            *reinterpret_cast<f32x4 *>(sPt + 256 + i * 32 + rbase + 4 * kk) = acc_im;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!halo) {
-            // lane = (half, part, o): 4 of the Q diagonal terms each, combined with two cross-lane adds
-            const int o = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
-            float v = 0.f;
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const int q = 4 * half + qq;
-                if (q < Q) v += sPt[part * 256 + q * 32 + ((rbase + o - H + q) & 31)];
-            }
-            v += __shfl_xor(v, 32);
-            const float vim = __shfl_xor(v, 16);
-            if (lane < 16 && jt + lane < je) {
-                const uint32_t m = a.m0 + (uint32_t)(jt + lane);
-                yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
-            }
-            if (jt + MD_TILE >= a.nblocks) {                 // P rows of the last Q-1 blocks go to the next call
-                for (int k = lane; k < H * 8; k += WAVE) {
-                    const int r = k >> 3, q = k & 7;
-                    const int row = (a.nblocks - H + r - jb) & 31;
-                    a.ptail_out[((size_t)ch * 8 + r) * 8 + q] = make_float2(sPt[q * 32 + row], sPt[256 + q * 32 + row]);
-                }
-            }
-        }
-    }
+    int sx = c.sx, sy = c.sy;
 
     // running IQ-DC sums of this segment (exact integer arithmetic == the reference's double sums)
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
