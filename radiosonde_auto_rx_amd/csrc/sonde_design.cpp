@@ -5,7 +5,7 @@
 // GPU kernels must share with the reference to stay inside the soft-bit tolerance:
 //   design_lowpass   Blackman x sinc, 1-norm, float accumulate            demod_mod.c:555-587
 //   design_decimator IF rate / decM / tap count                            demod_mod.c:1222-1259
-//   design_lut       16-Hz-snapped mixer table with float32 phase argument demod_mod.c:1262-1296
+//   design_mixer     16-Hz-snapped mixer frequency + table period           demod_mod.c:1262-1296
 //   design_match     Gaussian-pulse header template, 2-norm                demod_mod.c:1190-1195,1398-1421
 #include "sonde_host.h"
 #include <cmath>
@@ -54,7 +54,10 @@ Decimator design_decimator(int sr_base, bool if_min) {
     return d;
 }
 
-std::vector<std::complex<float>> design_lut(double xlt_fq, int sr_base) {
+// Mixer: the reference snaps the frequency to a multiple of d Hz (d = largest divisor <= 16 of the sample rate)
+// and tabulates ex[n] = cexp(2 pi i * fl32(f0*n)) over one period lut_len = sr/d.  The kernels evaluate the
+// same expression on the fly, so only (f0, lut_len) are needed.
+Mixer design_mixer(double xlt_fq, int sr_base) {
     const int W = 16;
     int d;
     const int freq = (int)(xlt_fq * (double)sr_base + 0.5);
@@ -65,15 +68,10 @@ std::vector<std::complex<float>> design_lut(double xlt_fq, int sr_base) {
         if ((freq + k) % d == 0) { freq0 = freq + k; break; }
         if ((freq - k) % d == 0) { freq0 = freq - k; break; }
     }
-    const int len = sr_base / d;
-    const double f0 = freq0 / (double)sr_base;
-    std::vector<std::complex<float>> ex(len);
-    for (int n = 0; n < len; n++) {
-        const float t = (float)(f0 * (double)n);
-        const double ph = t * kTwoPi;
-        ex[n] = std::complex<float>((float)std::cos(ph), (float)std::sin(ph));
-    }
-    return ex;
+    Mixer m;
+    m.lut_len = sr_base / d;
+    m.f0 = freq0 / (double)sr_base;
+    return m;
 }
 
 static double gauss_q(double x) { return 0.5 - 0.5 * std::erf(x / 1.4142135624); }

@@ -8,12 +8,12 @@ struct MixDecArgs {
     const int16_t *iq;        // [n_ch][ch_stride] complex int16
     long long ch_stride;      // complex samples between channels
     int n_ch, nblocks;        // blocks (= IF samples) in this chunk
-    int D, Q, KS, n4, nrem;   // decM, ceil(taps/D), k-steps, 16-sample super-steps, single k-steps
+    int D, Q, KS;             // decM, ceil(taps/D), k-steps = ceil(D/4)
     int G;                    // 16-block tiles per wave
     int wgs_per_ch;           // filled by the launcher
     const float *Bop;         // [KS][64] MFMA B operands
-    const float2 *lut;        // [n_ch][lut_stride] mixer tables (padded)
-    int lut_len, lut_stride;
+    const double *chan_f0;    // [n_ch] snapped mixer frequency / sample rate (demod_mod.c:1288)
+    int lut_len;              // period of the reference's mixer table (sr_base / d)
     uint32_t lut_phase;       // table index of the chunk's first sample
     const float2 *dc_avg;     // [n_ch] IQ-DC mean in effect
     long long *dc_sums;       // [n_ch][2] integer sums of the running DC segment

@@ -32,14 +32,14 @@ struct sonde_engine {
     sonde_info_t info{};
     hipStream_t stream = nullptr;
     // design
-    Decimator dec; int Q = 0, KS = 0, n4 = 0, nrem = 0, G = 8;
+    Decimator dec; int Q = 0, KS = 0, G = 8;
     std::vector<float> w_iq, w_fm, match;
     float sps = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;
     int symlen = 1, symhd = 1, hdmax = 0, bitofs = 0, nbits = 0, hdrlen = 0;
     uint32_t frame_samples = 0;
     double rho = 0;
     // device
-    float *d_Bop = nullptr; float2 *d_lut = nullptr; int lut_len = 0, lut_stride = 0;
+    float *d_Bop = nullptr; double *d_chanf0 = nullptr; int lut_len = 0;
     float2 *d_dcavg = nullptr; long long *d_dcsums = nullptr;
     float2 *d_ptail[2] = { nullptr, nullptr }; int ptail_cur = 0;
     float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr;
@@ -129,8 +129,8 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->sps = (float)cfg->sample_rate / e->baud;
     e->sps /= (float)D;
     e->Q = (T + D - 1) / D;
-    e->n4 = D / 16; e->nrem = (D - 16 * e->n4 + 3) / 4; e->KS = 4 * e->n4 + e->nrem;
-    if (e->n4 > 4 || e->nrem > 4 || e->n4 * 4 + e->nrem > 16 || (e->n4 == 4 && e->nrem) || e->Q > 8) { delete e; return SONDE_E_ARG; }
+    e->KS = (D + 3) / 4;
+    if (e->KS > 16 || e->Q > 8) { delete e; return SONDE_E_ARG; }   // decM <= 64 (input rate <= 3.07 Msps at IF 48 kHz)
     if (cfg->opt_lp & SONDE_LP_IQ) {
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
@@ -171,25 +171,22 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         std::vector<float> B((size_t)e->KS * 64, 0.f);
         for (int s = 0; s < e->KS; s++) for (int lane = 0; lane < 64; lane++) {
             const int kk = lane >> 4, q = lane & 15;
-            const int r = (s < 4 * e->n4) ? 16 * (s / 4) + 4 * kk + (s % 4) : 16 * e->n4 + 4 * (s - 4 * e->n4) + kk;
+            const int r = 4 * s + kk;                                  // k-step s, lane group kk handles sample r of its row
             if (q < e->Q && r < D) B[(size_t)s * 64 + lane] = wpad[(size_t)D * q + r];
         }
         if (dalloc(&e->d_Bop, B.size(), false)) { delete e; return SONDE_E_NOMEM; }
         HIPCHK(hipMemcpy(e->d_Bop, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    // ---- mixer tables, one per channel (xlt_fq = -fq, rs41mod.c:2685), padded so 16-byte reads may run past the end
+    // ---- mixer: snapped frequency per channel (xlt_fq = -fq, rs41mod.c:2685); the table period is common
     {
-        std::vector<std::complex<float>> first = design_lut(-std::max(-0.5, std::min(0.5, fq[0])), cfg->sample_rate);
-        e->lut_len = (int)first.size(); e->lut_stride = e->lut_len + 64;
-        I.lut_len = e->lut_len;
-        if (dalloc(&e->d_lut, (size_t)C * e->lut_stride, false)) { delete e; return SONDE_E_NOMEM; }
-        std::vector<std::complex<float>> row((size_t)e->lut_stride);
+        std::vector<double> f0s(C);
         for (int c = 0; c < C; c++) {
-            const double f = std::max(-0.5, std::min(0.5, fq[c]));
-            std::vector<std::complex<float>> ex = (c == 0) ? first : design_lut(-f, cfg->sample_rate);
-            for (int n = 0; n < e->lut_stride; n++) row[n] = ex[n % e->lut_len];
-            HIPCHK(hipMemcpy(e->d_lut + (size_t)c * e->lut_stride, row.data(), row.size() * sizeof(float2), hipMemcpyHostToDevice));
+            const Mixer m = design_mixer(-std::max(-0.5, std::min(0.5, fq[c])), cfg->sample_rate);
+            f0s[c] = m.f0; e->lut_len = m.lut_len;
         }
+        I.lut_len = e->lut_len;
+        if (dalloc(&e->d_chanf0, (size_t)C, false)) { delete e; return SONDE_E_NOMEM; }
+        HIPCHK(hipMemcpy(e->d_chanf0, f0s.data(), f0s.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     int bad = 0;
     bad |= dalloc(&e->d_dcavg, C); bad |= dalloc(&e->d_dcsums, 2 * (size_t)C);
@@ -259,7 +256,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
 void sonde_engine_destroy(sonde_engine_t *e) {
     if (!e) return;
     if (e->stream) { hipStreamSynchronize(e->stream); prof_collect(e); hipStreamDestroy(e->stream); }
-    void *ptrs[] = { e->d_Bop, e->d_lut, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
+    void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -285,8 +282,8 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt);
         MixDecArgs a{};
         a.iq = (const int16_t *)d_iq + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
-        a.D = D; a.Q = e->Q; a.KS = e->KS; a.n4 = e->n4; a.nrem = e->nrem; a.G = e->G;
-        a.Bop = e->d_Bop; a.lut = e->d_lut; a.lut_len = e->lut_len; a.lut_stride = e->lut_stride;
+        a.D = D; a.Q = e->Q; a.KS = e->KS; a.G = e->G;
+        a.Bop = e->d_Bop; a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len;
         a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
         a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums;
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];

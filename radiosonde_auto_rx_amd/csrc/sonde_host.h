@@ -12,7 +12,8 @@ struct Decimator { int if_sr = 0, decM = 1; std::vector<float> taps; };
 
 std::vector<float> design_lowpass(float f, int taps);
 Decimator design_decimator(int sr_base, bool if_min);
-std::vector<std::complex<float>> design_lut(double xlt_fq, int sr_base);
+struct Mixer { double f0 = 0; int lut_len = 1; };
+Mixer design_mixer(double xlt_fq, int sr_base);
 std::vector<float> design_match(const std::string &hdr, float sps, float bt);
 void bit_window(int pos, int half, int symlen, float sps, uint32_t &q0, uint32_t &q1, double &mid);
 

@@ -26,155 +26,45 @@ typedef float  f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // k_mix_decimate
 // ------------------------------------------------------------------------------------------------
-// K ordering inside one D-sample block (host builds the B operand with the same map, sonde_engine.cpp
-// mixdec_k_map): lane (i = lane&15, kk = lane>>4) owns, for super-step ss < n4, the 4 consecutive
-// samples r = 16*ss + 4*kk + u (one 16-byte load), consumed in k-steps s = 4*ss + u; the remaining
-// samples r = 16*n4 + 4*(s - 4*n4) + kk are single-dword loads.
-#define MD_N4MAX  4
-#define MD_REMMAX 4
+// Work decomposition: one wave owns 16*G consecutive D-sample blocks of one channel and walks them in tiles of
+// 16 blocks (the 16 rows of an MFMA tile).  Per tile:
+//   1. the 64*D raw bytes of the tile were fetched with fully coalesced 16-byte-per-lane loads one tile ahead
+//      (registers) and are parked in the wave's private LDS slice (no workgroup barrier anywhere);
+//   2. k-step s: lane (i = lane&15, kk = lane>>4) reads its sample r = 4s+kk of row i from LDS (stride-D dword
+//      reads are bank-conflict free), converts, removes the IQ-DC mean, and multiplies by the mixer phasor
+//      ex[n] = cexp(2 pi i * fl32(f0*n)) — the reference's float32-phase table (demod_mod.c:1292-1295) evaluated
+//      on the fly: fl32(f0*n) is reproduced bit-exactly in f64, the sin/cos by the hardware revolutions-input
+//      units (max abs error 2e-7 vs the table, tools/probes/sincos_probe.hip) — so no 8 B/sample table traffic;
+//   3. two v_mfma_f32_16x16x4_f32 accumulate P[row][q] += z * W_q[r] for re and im;
+//   4. the diagonal sum y[m] = sum_q P[m-(Q-1)+q][q] goes through a 32-row circular, transposed LDS buffer.
 #define MD_TILE   16          // blocks (rows) per MFMA tile
-
-struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(4))) f32x4_u { float x, y, z, w; };
-
-__device__ __forceinline__ void md_mac(uint32_t raw, float lr, float li, float ax, float ay, float bop,
-                                       f32x4 &acc_re, f32x4 &acc_im, int &sx, int &sy, bool count) {
-    const int xi = (int)(short)(raw & 0xffffu);
-    const int yi = ((int)raw) >> 16;
-    if (count) { sx += xi; sy += yi; }
-    // x = b/32768.0 is exact, so one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
-    const float ur = fmaf((float)xi, 3.0517578125e-05f, -ax);
-    const float ui = fmaf((float)yi, 3.0517578125e-05f, -ay);
-    const float zr = ur * lr - ui * li;           // z = u * ex[n]  (demod_mod.c:744)
-    const float zi = ur * li + ui * lr;
-    acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr, bop, acc_re, 0, 0, 0);
-    acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bop, acc_im, 0, 0, 0);
-}
-
-// P rows live in a 32-row circular LDS buffer per wave, transposed: Pt[part][q][row & 31] (row = block index
-// relative to the segment start), so the 4 accumulator rows of a lane are one 16-byte store and the
-// diagonal sum y[o] = sum_q P[o-(Q-1)+q][q] reads conflict-free columns.  Tiles alternate between the two
-// 16-row halves, which keeps the Q-1 history rows of the previous tile without copying.
+#define MD_KSMAX  16          // D <= 64
+#ifndef MD_UNROLL
+#define MD_UNROLL 1
+#endif
 #define MD_PT_FLOATS (2 * 8 * 32)
 
-// One tile's samples are loaded in two phases (A: the first ceil(N4/2) 16-sample super-steps, B: the rest) so
-// that a phase is always in flight while the other one is on the matrix cores, at half the register cost of
-// prefetching whole tiles.
-template <int NS, int NR>
-struct MdPhase {
-    u32x4_u raw4[NS > 0 ? NS : 1]; f32x4_u la[NS > 0 ? NS : 1], lb[NS > 0 ? NS : 1];
-    uint32_t raw1[NR > 0 ? NR : 1]; float2 l1[NR > 0 ? NR : 1];
-};
+struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 
-template <int S0, int NS, int NR>
-__device__ __forceinline__ void md_load(MdPhase<NS, NR> &t, const uint32_t *iq, const float2 *lut, int D, int lut_len,
-                                        size_t n0, uint32_t lidx, int kk) {
-#pragma unroll
-    for (int ss = 0; ss < NS; ss++) {
-        const int r0 = 16 * (S0 + ss) + 4 * kk;
-        t.raw4[ss] = *reinterpret_cast<const u32x4_u *>(iq + n0 + r0);
-        uint32_t li = lidx + r0; if (li >= (uint32_t)lut_len) li -= lut_len;
-        t.la[ss] = *reinterpret_cast<const f32x4_u *>(lut + li);
-        t.lb[ss] = *reinterpret_cast<const f32x4_u *>(lut + li + 2);
-    }
-#pragma unroll
-    for (int rs = 0; rs < NR; rs++) {
-        int r = 16 * (S0 + NS) + 4 * rs + kk; if (r >= D) r = D - 1;         // B is zero there
-        t.raw1[rs] = iq[n0 + r];
-        uint32_t li = lidx + r; if (li >= (uint32_t)lut_len) li -= lut_len;
-        t.l1[rs] = lut[li];
-    }
-}
-
-template <int N4, int NREM>
-struct MdCtx {
-    const MixDecArgs &a; const uint32_t *iq; const float2 *lut; float2 *yout; float *sPt; const float *bop; float2 avg;
-    int lane, i, kk, ch, jb, je, D, Q, H; uint32_t step, lidx; int sx, sy;
-    f32x4 acc_re, acc_im;
-};
-
-// row (block) and mixer-table index of this lane for the tile starting at jt; advances c.lidx tile by tile
-template <int N4, int NREM>
-__device__ __forceinline__ size_t md_row(MdCtx<N4, NREM> &c, int jt, bool first, uint32_t &lidx) {
-    const int jn = jt + c.i;
-    const int j = min(jn, c.a.nblocks - 1);
-    if (!first) {
-        uint32_t ln = c.lidx + c.step; if (ln >= (uint32_t)c.a.lut_len) ln -= c.a.lut_len;
-        if (jn > c.a.nblocks - 1) ln = (c.a.lut_phase + (uint32_t)j * (uint32_t)c.D) % (uint32_t)c.a.lut_len;   // clamped rows
-        c.lidx = ln;
-    }
-    lidx = c.lidx;
-    return (size_t)j * c.D;
-}
-
-template <int N4, int NREM, int S0, int NS, int NR>
-__device__ __forceinline__ void md_phase_mac(MdCtx<N4, NREM> &c, const MdPhase<NS, NR> &t, int jt) {
-    const bool rowvalid = (jt + c.i) < c.je && jt >= c.jb;
-#pragma unroll
-    for (int ss = 0; ss < NS; ss++) {
-        const int s0 = 4 * (S0 + ss);
-        md_mac(t.raw4[ss].x, t.la[ss].x, t.la[ss].y, c.avg.x, c.avg.y, c.bop[s0 + 0], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
-        md_mac(t.raw4[ss].y, t.la[ss].z, t.la[ss].w, c.avg.x, c.avg.y, c.bop[s0 + 1], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
-        md_mac(t.raw4[ss].z, t.lb[ss].x, t.lb[ss].y, c.avg.x, c.avg.y, c.bop[s0 + 2], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
-        md_mac(t.raw4[ss].w, t.lb[ss].z, t.lb[ss].w, c.avg.x, c.avg.y, c.bop[s0 + 3], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid);
-    }
-#pragma unroll
-    for (int rs = 0; rs < NR; rs++) {
-        const int r = 16 * (S0 + NS) + 4 * rs + c.kk;
-        md_mac(t.raw1[rs], t.l1[rs].x, t.l1[rs].y, c.avg.x, c.avg.y, c.bop[4 * (S0 + NS) + rs], c.acc_re, c.acc_im, c.sx, c.sy, rowvalid && r < c.D);
-    }
-}
-
-template <int N4, int NREM>
-__device__ __forceinline__ void md_epilogue(MdCtx<N4, NREM> &c, int jt) {
-    const MixDecArgs &a = c.a;
-    const int lane = c.lane, i = c.i, kk = c.kk, jb = c.jb, je = c.je, Q = c.Q, H = c.H;
-    float *sPt = c.sPt;
-    const bool halo = jt < jb;
-    // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
-    const int rbase = (jt - jb) & 31;                    // row of the tile's first block (0 or 16)
-    if (i < 8) {
-        *reinterpret_cast<f32x4 *>(sPt + i * 32 + rbase + 4 * kk) = c.acc_re;
-        *reinterpret_cast<f32x4 *>(sPt + 256 + i * 32 + rbase + 4 * kk) = c.acc_im;
-    }
-    c.acc_re = (f32x4){0.f, 0.f, 0.f, 0.f}; c.acc_im = (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!halo) {
-        // lane = (half, part, o): 4 of the Q diagonal terms each, combined with two cross-lane adds
-        const int o = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
-        float v = 0.f;
-#pragma unroll
-        for (int qq = 0; qq < 4; qq++) {
-            const int q = 4 * half + qq;
-            if (q < Q) v += sPt[part * 256 + q * 32 + ((rbase + o - H + q) & 31)];
-        }
-        v += __shfl_xor(v, 32);
-        const float vim = __shfl_xor(v, 16);
-        if (lane < 16 && jt + lane < je) {
-            const uint32_t m = a.m0 + (uint32_t)(jt + lane);
-            c.yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
-        }
-        if (jt + MD_TILE >= a.nblocks) {                 // P rows of the last Q-1 blocks go to the next call
-            for (int k = lane; k < H * 8; k += WAVE) {
-                const int r = k >> 3, q = k & 7;
-                const int row = (a.nblocks - H + r - jb) & 31;
-                a.ptail_out[((size_t)c.ch * 8 + r) * 8 + q] = make_float2(sPt[q * 32 + row], sPt[256 + q * 32 + row]);
-            }
-        }
-    }
-    asm volatile("" ::: "memory");
-}
-
-template <int N4, int NREM>
-__global__ __launch_bounds__(256, 4)
+template <int KS_T>
+__global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *sPt = smem + wave * MD_PT_FLOATS;                 // [part][q][32]
-    constexpr int KS = 4 * N4 + NREM;
+    const int D = a.D, Q = a.Q, H = a.Q - 1;
+    const int KS = KS_T ? KS_T : a.KS;
+    const int tile_dw = 16 * D;                               // dwords (= complex int16 samples) per tile
+    const int wave_dw = MD_PT_FLOATS + ((tile_dw + 3) & ~3) + 4;   // +4: k-step padding may read past the last row
+    float *sPt = smem + wave * wave_dw;                       // [part][q][32]
+    uint32_t *sRaw = reinterpret_cast<uint32_t *>(sPt + MD_PT_FLOATS);   // [16][D] raw samples of the current tile
+    float *sB = smem + 4 * wave_dw;                           // [KS][64] (runtime-KS variant only)
 
-    // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; keep a channel on one XCD
-    // so its mixer table stays in that XCD's L2.
+    if (KS_T == 0) {
+        for (int k = threadIdx.x; k < KS * 64; k += blockDim.x) sB[k] = a.Bop[k];
+        __syncthreads();
+    }
+
+    // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; a channel stays on one XCD
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
@@ -187,17 +77,19 @@ void k_mix_decimate(const MixDecArgs a) {
     const int je = min(a.nblocks, jb + blocks_per_seg);
 
     const int i = lane & 15, kk = lane >> 4;
-    const int D = a.D, Q = a.Q, H = a.Q - 1;
     const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
-    const float2 *lut = a.lut + (size_t)ch * a.lut_stride;
     const float2 avg = a.dc_avg[ch];
+    const double f0 = a.chan_f0[ch];
+    const uint32_t L = (uint32_t)a.lut_len;
     float2 *yout = a.y + (size_t)ch * a.ring_len;
 
-    float bop[KS];                                           // B operand: taps in the kernel's K order
+    float bop[KS_T ? KS_T : 1];
+    if (KS_T) {
 #pragma unroll
-    for (int s = 0; s < KS; s++) bop[s] = a.Bop[s * 64 + lane];
+        for (int s = 0; s < KS_T; s++) bop[s] = a.Bop[s * 64 + lane];
+    }
 
-    if (seg == 0) {                                          // P rows of the Q-1 blocks before the chunk
+    if (seg == 0) {                                           // P rows of the Q-1 blocks before the chunk
         for (int k = lane; k < H * 8; k += WAVE) {
             const int r = k >> 3, q = k & 7;
             const float2 v = a.ptail_in[((size_t)ch * 8 + r) * 8 + q];
@@ -205,30 +97,108 @@ void k_mix_decimate(const MixDecArgs a) {
             sPt[q * 32 + row] = v.x; sPt[256 + q * 32 + row] = v.y;
         }
     }
-    const int jt0 = (seg == 0) ? jb : jb - MD_TILE;          // one halo tile rebuilds the history of later segments
-    // mixer-table index of this lane's row in the first tile, then advanced by 16*D per tile
-    const uint32_t step = (uint32_t)((16u * (uint32_t)D) % (uint32_t)a.lut_len);
-    uint32_t lidx = (a.lut_phase + (uint32_t)(min(jt0 + i, a.nblocks - 1)) * (uint32_t)D) % (uint32_t)a.lut_len;
 
-    // software pipeline over half tiles: phase B of tile t and phase A of tile t+1 are in flight while the
-    // other phase is on the matrix cores
-    constexpr int NA = (N4 + 1) / 2, NB = N4 - NA;
-    MdCtx<N4, NREM> c = { a, iq, lut, yout, sPt, bop, avg, lane, i, kk, ch, jb, je, D, Q, H, step, lidx, 0, 0,
-                          {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f} };
-    MdPhase<NA, 0> PA; MdPhase<NB, NREM> PB;
-    uint32_t li; size_t n0 = md_row<N4, NREM>(c, jt0, true, li);
-    md_load<0, NA, 0>(PA, iq, lut, D, a.lut_len, n0, li, kk);
-    for (int jt = jt0; jt < je; jt += MD_TILE) {
-        md_load<NA, NB, NREM>(PB, iq, lut, D, a.lut_len, n0, li, kk);
-        md_phase_mac<N4, NREM, 0, NA, 0>(c, PA, jt);
-        if (jt + MD_TILE < je) {
-            n0 = md_row<N4, NREM>(c, jt + MD_TILE, false, li);
-            md_load<0, NA, 0>(PA, iq, lut, D, a.lut_len, n0, li, kk);
+    const int jt0 = (seg == 0) ? jb : jb - MD_TILE;           // one halo tile rebuilds the history of later segments
+    const int nv = (tile_dw + 255) / 256;                     // 16-byte loads per lane per tile
+    const int total_dw = a.nblocks * D;
+    u32x4_u pre[4];
+    auto fetch = [&](int jt) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (v < nv) {
+                int off = jt * D + 256 * v + 4 * lane;         // dword offset in the chunk
+                if (256 * v + 4 * lane >= tile_dw || off + 4 > total_dw) off = jt * D;   // tail: any valid address
+                pre[v] = *reinterpret_cast<const u32x4_u *>(iq + off);
+            }
         }
-        md_phase_mac<N4, NREM, NA, NB, NREM>(c, PB, jt);
-        md_epilogue<N4, NREM>(c, jt);
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            if (v < nv && 256 * v + 4 * lane < tile_dw)
+                *reinterpret_cast<uint4 *>(sRaw + 256 * v + 4 * lane) = make_uint4(pre[v].x, pre[v].y, pre[v].z, pre[v].w);
+        }
+    };
+    fetch(jt0);
+    park();
+
+    // mixer-table index of this lane's row: n = (lut_phase + D*row) mod lut_len, advanced by 16*D per tile
+    const uint32_t step = (uint32_t)((16u * (uint32_t)D) % L);
+    uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)(jt0 + i) * (uint64_t)D) % L);
+    int sx = 0, sy = 0;
+
+    for (int jt = jt0; jt < je; jt += MD_TILE) {
+        const bool halo = jt < jb;
+        const bool more = jt + MD_TILE < je;
+        if (more) fetch(jt + MD_TILE);                        // next tile's bytes are in flight during the MFMAs
+        const bool rowvalid = (jt + i) < je && !halo;
+        const uint32_t *row = sRaw + i * D;
+        const uint32_t towrap = L - rown;                     // samples of this row before the table index wraps
+
+        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t raws[KS_T ? KS_T : 1];
+        if (KS_T) {                                           // all LDS reads of the tile up front, then one k-step at a time
+#pragma unroll
+            for (int s = 0; s < KS_T; s++) raws[s] = row[4 * s + kk];      // r >= D reads a neighbour's sample, its tap is 0
+        }
+#pragma unroll MD_UNROLL
+        for (int s = 0; s < (KS_T ? KS_T : KS); s++) {
+            const int r = 4 * s + kk;
+            const bool rv = r < D;
+            const uint32_t raw = KS_T ? raws[KS_T ? s : 0] : row[r];
+            const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
+            const bool cnt = rowvalid && rv;
+            sx += cnt ? xi : 0; sy += cnt ? yi : 0;
+            // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
+            const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
+            const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
+            // ex[n]: t = fl32(f0 * n) exactly as the table was built, phase = fract(t) revolutions
+            const uint32_t n = rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u);
+            const float t = (float)(f0 * (double)n);
+            const float fr = __builtin_amdgcn_fractf(t);
+            const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
+            const float zr = ur * lr - ui * li;               // z = u * ex[n]  (demod_mod.c:744)
+            const float zi = ur * li + ui * lr;
+            const float bw = KS_T ? bop[KS_T ? s : 0] : sB[s * 64 + lane];
+            acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr, bw, acc_re, 0, 0, 0);
+            acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bw, acc_im, 0, 0, 0);
+            if (KS_T) __builtin_amdgcn_sched_barrier(0);      // keep the k-steps sequential: short live ranges
+        }
+
+        // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
+        const int rbase = (jt - jb) & 31;                     // row of the tile's first block (0 or 16)
+        if (i < 8) {
+            *reinterpret_cast<f32x4 *>(sPt + i * 32 + rbase + 4 * kk) = acc_re;
+            *reinterpret_cast<f32x4 *>(sPt + 256 + i * 32 + rbase + 4 * kk) = acc_im;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!halo) {
+            // lane = (half, part, o): 4 of the Q diagonal terms each, combined with two cross-lane adds
+            const int o = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
+            float v = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const int q = 4 * half + qq;
+                if (q < Q) v += sPt[part * 256 + q * 32 + ((rbase + o - H + q) & 31)];
+            }
+            v += __shfl_xor(v, 32);
+            const float vim = __shfl_xor(v, 16);
+            if (lane < 16 && jt + lane < je) {
+                const uint32_t m = a.m0 + (uint32_t)(jt + lane);
+                yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
+            }
+            if (jt + MD_TILE >= a.nblocks) {                  // P rows of the last Q-1 blocks go to the next call
+                for (int k = lane; k < H * 8; k += WAVE) {
+                    const int r = k >> 3, q = k & 7;
+                    const int prow = (a.nblocks - H + r - jb) & 31;
+                    a.ptail_out[((size_t)ch * 8 + r) * 8 + q] = make_float2(sPt[q * 32 + prow], sPt[256 + q * 32 + prow]);
+                }
+            }
+        }
+        if (more) park();                                     // all reads of the old tile were issued above (in-order DS)
+        rown += step; if (rown >= L) rown -= L;
     }
-    int sx = c.sx, sy = c.sy;
 
     // running IQ-DC sums of this segment (exact integer arithmetic == the reference's double sums)
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
@@ -629,21 +599,15 @@ void k_framesync(const SyncArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from sonde_engine.cpp)
 // ------------------------------------------------------------------------------------------------
-template <int N4, int NREM>
-static void md_launch(const MixDecArgs &b, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_mix_decimate<N4, NREM>), dim3(grid), dim3(256), 4 * MD_PT_FLOATS * sizeof(float), s, b);
-}
 extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
+    if (a->KS < 1 || a->KS > MD_KSMAX || a->Q > 8) return -1;
     const int blocks_per_wg = 4 * MD_TILE * a->G;
     const int wgs_per_ch = (a->nblocks + blocks_per_wg - 1) / blocks_per_wg;
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
     const int grid = ((a->n_ch + 7) / 8) * 8 * wgs_per_ch;
-    // (n4, nrem) = (decM/16, ceil((decM%16)/4)): one straight-line instantiation per pair
-#define MD_CASE(N4_, NR_) if (a->n4 == N4_ && a->nrem == NR_) { md_launch<N4_, NR_>(b, grid, s); return 0; }
-    MD_CASE(3, 1) MD_CASE(0, 1) MD_CASE(0, 2) MD_CASE(0, 3) MD_CASE(0, 4) MD_CASE(1, 0) MD_CASE(1, 1) MD_CASE(1, 2) MD_CASE(1, 3)
-    MD_CASE(2, 0) MD_CASE(2, 1) MD_CASE(2, 2) MD_CASE(2, 3) MD_CASE(3, 0) MD_CASE(3, 2) MD_CASE(3, 3) MD_CASE(4, 0)
-#undef MD_CASE
-    return -1;
+    const int wave_dw = MD_PT_FLOATS + ((16 * a->D + 3) & ~3) + 4;
+    hipLaunchKernelGGL((k_mix_decimate<0>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
+    return 0;
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
