@@ -46,12 +46,12 @@ typedef float  f32x4 __attribute__((ext_vector_type(4)));
 
 struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 
-template <int KS_T>
+template <int KS_T, int D_T>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int D = a.D, Q = a.Q, H = a.Q - 1;
+    const int D = D_T ? D_T : a.D, Q = a.Q, H = a.Q - 1;
     const int KS = KS_T ? KS_T : a.KS;
     const int tile_dw = 16 * D;                               // dwords (= complex int16 samples) per tile
     const int wave_dw = MD_PT_FLOATS + ((tile_dw + 3) & ~3) + 4;   // +4: k-step padding may read past the last row
@@ -90,6 +90,7 @@ void k_mix_decimate(const MixDecArgs a) {
     }
 
     if (seg == 0) {                                           // P rows of the Q-1 blocks before the chunk
+#pragma unroll 1
         for (int k = lane; k < H * 8; k += WAVE) {
             const int r = k >> 3, q = k & 7;
             const float2 v = a.ptail_in[((size_t)ch * 8 + r) * 8 + q];
@@ -137,33 +138,70 @@ void k_mix_decimate(const MixDecArgs a) {
 
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        uint32_t raws[KS_T ? KS_T : 1];
-        if (KS_T) {                                           // all LDS reads of the tile up front, then one k-step at a time
+        if (KS_T) {
+            // compile-time KS: k-steps in groups of 4 — the group's LDS reads and its four independent
+            // int->f64->f32->sin/cos chains overlap, then 8 MFMAs; the next group's reads are issued first
+            constexpr int GS = 4, NG = (KS_T + GS - 1) / GS;
+            uint32_t rawn[GS];
 #pragma unroll
-            for (int s = 0; s < KS_T; s++) raws[s] = row[4 * s + kk];      // r >= D reads a neighbour's sample, its tap is 0
-        }
-#pragma unroll MD_UNROLL
-        for (int s = 0; s < (KS_T ? KS_T : KS); s++) {
-            const int r = 4 * s + kk;
-            const bool rv = r < D;
-            const uint32_t raw = KS_T ? raws[KS_T ? s : 0] : row[r];
-            const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
-            const bool cnt = rowvalid && rv;
-            sx += cnt ? xi : 0; sy += cnt ? yi : 0;
-            // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
-            const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
-            const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
-            // ex[n]: t = fl32(f0 * n) exactly as the table was built, phase = fract(t) revolutions
-            const uint32_t n = rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u);
-            const float t = (float)(f0 * (double)n);
-            const float fr = __builtin_amdgcn_fractf(t);
-            const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
-            const float zr = ur * lr - ui * li;               // z = u * ex[n]  (demod_mod.c:744)
-            const float zi = ur * li + ui * lr;
-            const float bw = KS_T ? bop[KS_T ? s : 0] : sB[s * 64 + lane];
-            acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr, bw, acc_re, 0, 0, 0);
-            acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bw, acc_im, 0, 0, 0);
-            if (KS_T) __builtin_amdgcn_sched_barrier(0);      // keep the k-steps sequential: short live ranges
+            for (int u = 0; u < GS; u++) rawn[u] = row[4 * u + kk];
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                uint32_t raw[GS];
+#pragma unroll
+                for (int u = 0; u < GS; u++) raw[u] = rawn[u];
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int u = 0; u < GS; u++) if ((g + 1) * GS + u < KS_T) rawn[u] = row[4 * ((g + 1) * GS + u) + kk];
+                }
+                float zr[GS], zi[GS];
+#pragma unroll
+                for (int u = 0; u < GS; u++) {
+                    const int s = g * GS + u;
+                    if (s < KS_T) {
+                        const int r = 4 * s + kk;
+                        const int xi = (int)(short)(raw[u] & 0xffffu), yi = ((int)raw[u]) >> 16;
+                        const bool cnt = rowvalid && r < D;
+                        sx += cnt ? xi : 0; sy += cnt ? yi : 0;
+                        const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
+                        const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
+                        const uint32_t n = rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u);
+                        const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
+                        const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
+                        zr[u] = ur * lr - ui * li;
+                        zi[u] = ur * li + ui * lr;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GS; u++) {
+                    const int s = g * GS + u;
+                    if (s < KS_T) {
+                        acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[u], bop[KS_T ? s : 0], acc_re, 0, 0, 0);
+                        acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi[u], bop[KS_T ? s : 0], acc_im, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int s = 0; s < KS; s++) {
+                const int r = 4 * s + kk;
+                const uint32_t raw = row[r];                  // r >= D reads a neighbour's sample, its tap is 0
+                const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
+                const bool cnt = rowvalid && r < D;
+                sx += cnt ? xi : 0; sy += cnt ? yi : 0;
+                // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
+                const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
+                const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
+                // ex[n]: t = fl32(f0 * n) exactly as the table was built, phase = fract(t) revolutions
+                const uint32_t n = rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u);
+                const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
+                const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
+                const float zr = ur * lr - ui * li;           // z = u * ex[n]  (demod_mod.c:744)
+                const float zi = ur * li + ui * lr;
+                const float bw = sB[s * 64 + lane];
+                acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr, bw, acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bw, acc_im, 0, 0, 0);
+            }
         }
 
         // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
@@ -189,6 +227,7 @@ void k_mix_decimate(const MixDecArgs a) {
                 yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
             }
             if (jt + MD_TILE >= a.nblocks) {                  // P rows of the last Q-1 blocks go to the next call
+#pragma unroll 1
                 for (int k = lane; k < H * 8; k += WAVE) {
                     const int r = k >> 3, q = k & 7;
                     const int prow = (a.nblocks - H + r - jb) & 31;
@@ -606,7 +645,10 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
     const int grid = ((a->n_ch + 7) / 8) * 8 * wgs_per_ch;
     const int wave_dw = MD_PT_FLOATS + ((16 * a->D + 3) & ~3) + 4;
-    hipLaunchKernelGGL((k_mix_decimate<0>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
+    if (a->D == 50)       // 2.4 Msps -> 48 kHz: compile-time geometry, unrolled k-steps, taps in registers
+        hipLaunchKernelGGL((k_mix_decimate<13, 50>), dim3(grid), dim3(256), (size_t)4 * wave_dw * sizeof(float), s, b);
+    else
+        hipLaunchKernelGGL((k_mix_decimate<0, 0>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
     return 0;
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
