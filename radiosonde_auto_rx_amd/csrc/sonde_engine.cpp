@@ -212,7 +212,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     // ---- factorised header correlation tables (integer samples/symbol only; else the direct L-tap kernel runs)
     {
         const int isps = (int)e->sps, nsym = e->hdrlen / e->symhd;
-        if ((float)isps == e->sps && e->symhd == 1 && isps * nsym == L && isps >= 2) {
+        if ((float)isps == e->sps && e->symhd == 1 && isps * nsym == L && isps >= 2 && isps <= 16 && isps % 2 == 0) {
             std::vector<float> shapes; std::vector<int> type(nsym); std::vector<float> sign(nsym);
             std::vector<int> key;                                     // (left, right) neighbour relative to the own bit
             bool ok = true;
@@ -289,7 +289,8 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];
         a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
-        { long long tiles = (long long)C * ((a.nblocks + 15) / 16); int G = (int)(tiles / 24576); a.G = G < 1 ? 1 : (G > 32 ? 32 : G); }
+        { long long tiles = (long long)C * ((a.nblocks + 15) / 16); int G = (int)(tiles / 16384); a.G = G < 8 ? 8 : (G > 32 ? 32 : G);
+          if (C * ((a.nblocks + 16 * a.G - 1) / (16 * a.G)) < 2048) { G = (int)(tiles / 2048); a.G = G < 1 ? 1 : (G > 32 ? 32 : G); } }
         prof_begin(e, "mix_decimate"); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e);
         if (lrc < 0) return SONDE_E_ARG;
         e->ptail_cur ^= 1;

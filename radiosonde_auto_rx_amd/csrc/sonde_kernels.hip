@@ -20,6 +20,7 @@
 #include "sonde_dev.h"
 
 typedef float  f32x4 __attribute__((ext_vector_type(4)));
+typedef short  short2v __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
 
@@ -42,7 +43,9 @@ typedef float  f32x4 __attribute__((ext_vector_type(4)));
 #ifndef MD_UNROLL
 #define MD_UNROLL 1
 #endif
-#define MD_PT_FLOATS (2 * 8 * 32)
+#define MD_PT_QS 36          // q stride of the transposed P buffer (32 rows + 4 pad: conflict-free 16-byte stores)
+#define MD_PT_PS (8 * MD_PT_QS)
+#define MD_PT_FLOATS (2 * MD_PT_PS)
 
 struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 
@@ -95,7 +98,7 @@ void k_mix_decimate(const MixDecArgs a) {
             const int r = k >> 3, q = k & 7;
             const float2 v = a.ptail_in[((size_t)ch * 8 + r) * 8 + q];
             const int row = (r - H) & 31;
-            sPt[q * 32 + row] = v.x; sPt[256 + q * 32 + row] = v.y;
+            sPt[q * MD_PT_QS + row] = v.x; sPt[MD_PT_PS + q * MD_PT_QS + row] = v.y;
         }
     }
 
@@ -135,6 +138,8 @@ void k_mix_decimate(const MixDecArgs a) {
         const bool rowvalid = (jt + i) < je && !halo;
         const uint32_t *row = sRaw + i * D;
         const uint32_t towrap = L - rown;                     // samples of this row before the table index wraps
+        const bool nowrap = __builtin_amdgcn_ballot_w64(towrap < (uint32_t)(4 * KS)) == 0;   // wave-uniform
+        const double nd0 = (double)(rown + (uint32_t)kk);
 
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -161,12 +166,18 @@ void k_mix_decimate(const MixDecArgs a) {
                     if (s < KS_T) {
                         const int r = 4 * s + kk;
                         const int xi = (int)(short)(raw[u] & 0xffffu), yi = ((int)raw[u]) >> 16;
-                        const bool cnt = rowvalid && r < D;
-                        sx += cnt ? xi : 0; sy += cnt ? yi : 0;
+                        // IQ-DC sums: x and y halves by one dot2 each; the multiplier is 0 for rows/samples outside the chunk
+                        const int mx = (rowvalid && r < D) ? 0x00000001 : 0, my = (rowvalid && r < D) ? 0x00010000 : 0;
+                        sx = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, mx), sx, false);
+                        sy = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, my), sy, false);
                         const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
                         const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
-                        const uint32_t n = rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u);
-                        const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
+                        // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the table was built.  No wrap inside the
+                        // row (all but 1 in L/D rows): n as a double is nd0 + 4s exactly; else the integer form.
+                        double nd;
+                        if (nowrap) nd = nd0 + (double)(4 * s);
+                        else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
+                        const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
                         const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
                         zr[u] = ur * lr - ui * li;
                         zi[u] = ur * li + ui * lr;
@@ -207,8 +218,8 @@ void k_mix_decimate(const MixDecArgs a) {
         // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
         const int rbase = (jt - jb) & 31;                     // row of the tile's first block (0 or 16)
         if (i < 8) {
-            *reinterpret_cast<f32x4 *>(sPt + i * 32 + rbase + 4 * kk) = acc_re;
-            *reinterpret_cast<f32x4 *>(sPt + 256 + i * 32 + rbase + 4 * kk) = acc_im;
+            *reinterpret_cast<f32x4 *>(sPt + i * MD_PT_QS + rbase + 4 * kk) = acc_re;
+            *reinterpret_cast<f32x4 *>(sPt + MD_PT_PS + i * MD_PT_QS + rbase + 4 * kk) = acc_im;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!halo) {
@@ -218,7 +229,7 @@ void k_mix_decimate(const MixDecArgs a) {
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
                 const int q = 4 * half + qq;
-                if (q < Q) v += sPt[part * 256 + q * 32 + ((rbase + o - H + q) & 31)];
+                if (q < Q) v += sPt[part * MD_PT_PS + q * MD_PT_QS + ((rbase + o - H + q) & 31)];
             }
             v += __shfl_xor(v, 32);
             const float vim = __shfl_xor(v, 16);
@@ -231,7 +242,7 @@ void k_mix_decimate(const MixDecArgs a) {
                 for (int k = lane; k < H * 8; k += WAVE) {
                     const int r = k >> 3, q = k & 7;
                     const int prow = (a.nblocks - H + r - jb) & 31;
-                    a.ptail_out[((size_t)ch * 8 + r) * 8 + q] = make_float2(sPt[q * 32 + prow], sPt[256 + q * 32 + prow]);
+                    a.ptail_out[((size_t)ch * 8 + r) * 8 + q] = make_float2(sPt[q * MD_PT_QS + prow], sPt[MD_PT_PS + q * MD_PT_QS + prow]);
                 }
             }
         }
@@ -296,7 +307,8 @@ void k_if_chain(const IfArgs a) {
     // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648)
     for (int k = threadIdx.x; k < nz; k += IF_THREADS) {
         float re = 0.f, im = 0.f;
-        for (int t = 0; t < T1; t++) { const float2 v = sy[k + t]; re = fmaf(v.x, wq[t], re); im = fmaf(v.y, wq[t], im); }
+#pragma unroll 7
+        for (int t = 0; t < T1; t++) { const float2 v = sy[k + t]; const float w = wq[t]; re = fmaf(v.x, w, re); im = fmaf(v.y, w, im); }
         const int64_t m = (int64_t)t0 - hz + k;
         if (m < 0) { re = 0.f; im = 0.f; }
         sz[k] = make_float2(re, im);
@@ -403,39 +415,55 @@ void k_header_corr_fact(const CorrArgs a) {
     if (nout <= 0) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const int nx = HCF_TILE + L - 1;                 // samples p0-(L-1) .. p0+HCF_TILE-1
-    const int nf = HCF_TILE + sps * (nsym - 1);      // F entries per type
-    float *sx = smem;                                // [nx]
-    float *sF = smem + ((nx + 3) & ~3);              // [nt][nf]
+    const int nf = (HCF_TILE + sps * (nsym - 1) + 3) & ~3;   // F entries per type (multiple of 4)
+    const int nxp = (nf + sps + 3 + 3) & ~3;
+    float *sx = smem;                                // [nxp]
+    float *sF = smem + nxp;                          // [nt][nf]
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
-    for (int k = threadIdx.x; k < nx; k += HCF_THREADS) {
+    for (int k = threadIdx.x; k < nxp; k += HCF_THREADS) {
         const int64_t m = (int64_t)p0 - (L - 1) + k;
-        sx[k] = (m >= 0 && k < nout + L - 1) ? bufs[(uint32_t)m & mask] : 0.f;
+        sx[k] = (m >= 0 && k < nout + L - 1 && k < nx) ? bufs[(uint32_t)m & mask] : 0.f;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nt * nf; idx += HCF_THREADS) {
-        const int t = idx / nf, n = idx - t * nf;
-        const float *sh = a.shapes + t * sps;
-        float acc = 0.f;
-        for (int d = 0; d < sps; d++) acc = fmaf(sh[d], sx[n + d], acc);
-        sF[idx] = acc;
-    }
-    __syncthreads();
-    float acc[HCF_TILE / HCF_THREADS];
+    // F_t[n] = sum_d shape_t[d] * x[n+d]: 4 consecutive n per thread from 16-byte LDS reads, all types at once
+    for (int n4 = threadIdx.x * 4; n4 < nf; n4 += HCF_THREADS * 4) {
+        float xv[4 + 16];                            // sps <= 16
+        const int nload = (sps + 3 + 3) / 4;         // float4 chunks covering x[n4 .. n4+sps+2]
 #pragma unroll
-    for (int j = 0; j < HCF_TILE / HCF_THREADS; j++) acc[j] = 0.f;
+        for (int c = 0; c < 5; c++) {
+            if (c < nload) {
+                const float4 v = *reinterpret_cast<const float4 *>(sx + n4 + 4 * c);
+                xv[4 * c] = v.x; xv[4 * c + 1] = v.y; xv[4 * c + 2] = v.z; xv[4 * c + 3] = v.w;
+            }
+        }
+        for (int t = 0; t < nt; t++) {
+            const float *sh = a.shapes + t * sps;    // uniform -> scalar loads
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                if (d < sps) {
+                    const float w = sh[d];
+                    f0 = fmaf(w, xv[d], f0); f1 = fmaf(w, xv[d + 1], f1); f2 = fmaf(w, xv[d + 2], f2); f3 = fmaf(w, xv[d + 3], f3);
+                }
+            }
+            *reinterpret_cast<float4 *>(sF + t * nf + n4) = make_float4(f0, f1, f2, f3);
+        }
+    }
+    __syncthreads();
+    // c[o] = sum_k sign_k * F_{type_k}[o + sps*k]: 4 consecutive outputs per thread
+    const int o4 = threadIdx.x * 4;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
     for (int k = 0; k < nsym; k++) {
         const int ty = a.sym_type[k];                // uniform: scalar loads
         const float sg = a.sym_sign[k];
-        const float *f = sF + ty * nf + sps * k + threadIdx.x;
-#pragma unroll
-        for (int j = 0; j < HCF_TILE / HCF_THREADS; j++) acc[j] = fmaf(sg, f[j * HCF_THREADS], acc[j]);
+        const float *f = sF + ty * nf + sps * k + o4;
+        const float2 u = *reinterpret_cast<const float2 *>(f), v = *reinterpret_cast<const float2 *>(f + 2);   // sps*k may be 2 mod 4
+        c0 = fmaf(sg, u.x, c0); c1 = fmaf(sg, u.y, c1); c2 = fmaf(sg, v.x, c2); c3 = fmaf(sg, v.y, c3);
     }
     float *corr = a.corr + (size_t)ch * a.ring_len;
+    const float cc[4] = { c0, c1, c2, c3 };
 #pragma unroll
-    for (int j = 0; j < HCF_TILE / HCF_THREADS; j++) {
-        const int k = threadIdx.x + j * HCF_THREADS;
-        if (k < nout) corr[(p0 + (uint32_t)k) & mask] = acc[j];
-    }
+    for (int j = 0; j < 4; j++) if (o4 + j < nout) corr[(p0 + (uint32_t)(o4 + j)) & mask] = cc[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -502,11 +530,19 @@ void k_framesync(const SyncArgs a) {
             if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
             // arg-max of c^2 over end positions p = pos-K .. pos, first maximum wins (demod_mod.c:200-208)
             float best = 0.f; int bidx = -1;
-            for (int t = lane; t <= K; t += WAVE) {
-                const int64_t p = (int64_t)pos - K + t;
-                const float c = (p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
-                const float c2 = c * c;
-                if (c2 > best) { best = c2; bidx = t; }
+            for (int t0 = lane; t0 <= K; t0 += 8 * WAVE) {
+                float cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int t = t0 + u * WAVE;
+                    const int64_t p = (int64_t)pos - K + t;
+                    cv[u] = (t <= K && p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float c2 = cv[u] * cv[u];
+                    if (c2 > best) { best = c2; bidx = t0 + u * WAVE; }
+                }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
@@ -663,8 +699,8 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
 }
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
     if (a->ntypes > 0) {
-        const int nx = HCF_TILE + a->L - 1, nf = HCF_TILE + a->isps * (a->nsym - 1);
-        const size_t lds = (size_t)(((nx + 3) & ~3) + a->ntypes * nf) * sizeof(float);
+        const int nf = (HCF_TILE + a->isps * (a->nsym - 1) + 3) & ~3, nxp = (nf + a->isps + 3 + 3) & ~3;
+        const size_t lds = (size_t)(nxp + a->ntypes * nf) * sizeof(float);
         hipLaunchKernelGGL(k_header_corr_fact, dim3((a->n + HCF_TILE - 1) / HCF_TILE, a->n_ch), dim3(HCF_THREADS), lds, s, *a);
         return;
     }
