@@ -40,8 +40,8 @@ typedef short  short2v __attribute__((ext_vector_type(2)));
 //   4. the diagonal sum y[m] = sum_q P[m-(Q-1)+q][q] goes through a 32-row circular, transposed LDS buffer.
 #define MD_TILE   16          // blocks (rows) per MFMA tile
 #define MD_KSMAX  16          // D <= 64
-#ifndef MD_UNROLL
-#define MD_UNROLL 1
+#ifndef MD_MINWAVES
+#define MD_MINWAVES 4      // waves per SIMD the register allocation is held to (VALU/MFMA overlap needs waves)
 #endif
 #define MD_PT_QS 36          // q stride of the transposed P buffer (32 rows + 4 pad: conflict-free 16-byte stores)
 #define MD_PT_PS (8 * MD_PT_QS)
@@ -49,8 +49,66 @@ typedef short  short2v __attribute__((ext_vector_type(2)));
 
 struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 
+// All k-steps of one tile with compile-time KS: groups of 4 — the group's LDS reads and its four independent
+// int->f64->f32->sin/cos chains overlap, then 8 MFMAs; the next group's reads are issued first.
+// WRAP = the mixer-table index wraps inside some row of this tile (1 tile in ~L/(16*D)): integer index path.
+template <int KS_T, bool WRAP>
+__device__ __forceinline__ void md_ksteps(const uint32_t *row, int kk, int D, bool rowvalid, float2 avg, double f0,
+                                          uint32_t rown, uint32_t towrap, uint32_t L, const float *bop,
+                                          f32x4 &acc_re, f32x4 &acc_im, int &sx, int &sy) {
+    constexpr int GS = 4, NG = (KS_T + GS - 1) / GS;
+    const double nd0 = (double)(rown + (uint32_t)kk);
+    uint32_t rawn[GS];
+#pragma unroll
+    for (int u = 0; u < GS; u++) rawn[u] = row[4 * u + kk];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        uint32_t raw[GS];
+#pragma unroll
+        for (int u = 0; u < GS; u++) raw[u] = rawn[u];
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int u = 0; u < GS; u++) if ((g + 1) * GS + u < KS_T) rawn[u] = row[4 * ((g + 1) * GS + u) + kk];
+        }
+        float zr[GS], zi[GS];
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            const int s = g * GS + u;
+            if (s < KS_T) {
+                const int r = 4 * s + kk;
+                const int xi = (int)(short)(raw[u] & 0xffffu), yi = ((int)raw[u]) >> 16;
+                // IQ-DC sums: x and y halves by one dot2 each; the multiplier is 0 for rows/samples outside the chunk
+                const bool cnt = rowvalid && r < D;
+                const int mx = cnt ? 0x00000001 : 0, my = cnt ? 0x00010000 : 0;
+                sx = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, mx), sx, false);
+                sy = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, my), sy, false);
+                // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
+                const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
+                const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
+                // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
+                double nd;
+                if (!WRAP) nd = nd0 + (double)(4 * s);       // exact: small integers
+                else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
+                const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
+                const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
+                zr[u] = ur * lr - ui * li;                   // z = u * ex[n]  (demod_mod.c:744)
+                zi[u] = ur * li + ui * lr;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            const int s = g * GS + u;
+            if (s < KS_T) {
+                acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[u], bop[s], acc_re, 0, 0, 0);
+                acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi[u], bop[s], acc_im, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int KS_T, int D_T>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, MD_MINWAVES)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,12 +118,10 @@ void k_mix_decimate(const MixDecArgs a) {
     const int wave_dw = MD_PT_FLOATS + ((tile_dw + 3) & ~3) + 4;   // +4: k-step padding may read past the last row
     float *sPt = smem + wave * wave_dw;                       // [part][q][32]
     uint32_t *sRaw = reinterpret_cast<uint32_t *>(sPt + MD_PT_FLOATS);   // [16][D] raw samples of the current tile
-    float *sB = smem + 4 * wave_dw;                           // [KS][64] (runtime-KS variant only)
+    float *sB = smem + 4 * wave_dw;                           // [KS][64] taps in MFMA B-operand order
 
-    if (KS_T == 0) {
-        for (int k = threadIdx.x; k < KS * 64; k += blockDim.x) sB[k] = a.Bop[k];
-        __syncthreads();
-    }
+    for (int k = threadIdx.x; k < KS * 64; k += blockDim.x) sB[k] = a.Bop[k];
+    __syncthreads();
 
     // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; a channel stays on one XCD
     const int b = blockIdx.x;
@@ -86,10 +142,11 @@ void k_mix_decimate(const MixDecArgs a) {
     const uint32_t L = (uint32_t)a.lut_len;
     float2 *yout = a.y + (size_t)ch * a.ring_len;
 
-    float bop[KS_T ? KS_T : 1];
+
+    float bop[KS_T ? KS_T : 1];                               // compile-time variant: taps in registers
     if (KS_T) {
 #pragma unroll
-        for (int s = 0; s < KS_T; s++) bop[s] = a.Bop[s * 64 + lane];
+        for (int s = 0; s < KS_T; s++) bop[s] = sB[s * 64 + lane];
     }
 
     if (seg == 0) {                                           // P rows of the Q-1 blocks before the chunk
@@ -139,60 +196,12 @@ void k_mix_decimate(const MixDecArgs a) {
         const uint32_t *row = sRaw + i * D;
         const uint32_t towrap = L - rown;                     // samples of this row before the table index wraps
         const bool nowrap = __builtin_amdgcn_ballot_w64(towrap < (uint32_t)(4 * KS)) == 0;   // wave-uniform
-        const double nd0 = (double)(rown + (uint32_t)kk);
 
         f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (KS_T) {
-            // compile-time KS: k-steps in groups of 4 — the group's LDS reads and its four independent
-            // int->f64->f32->sin/cos chains overlap, then 8 MFMAs; the next group's reads are issued first
-            constexpr int GS = 4, NG = (KS_T + GS - 1) / GS;
-            uint32_t rawn[GS];
-#pragma unroll
-            for (int u = 0; u < GS; u++) rawn[u] = row[4 * u + kk];
-#pragma unroll
-            for (int g = 0; g < NG; g++) {
-                uint32_t raw[GS];
-#pragma unroll
-                for (int u = 0; u < GS; u++) raw[u] = rawn[u];
-                if (g + 1 < NG) {
-#pragma unroll
-                    for (int u = 0; u < GS; u++) if ((g + 1) * GS + u < KS_T) rawn[u] = row[4 * ((g + 1) * GS + u) + kk];
-                }
-                float zr[GS], zi[GS];
-#pragma unroll
-                for (int u = 0; u < GS; u++) {
-                    const int s = g * GS + u;
-                    if (s < KS_T) {
-                        const int r = 4 * s + kk;
-                        const int xi = (int)(short)(raw[u] & 0xffffu), yi = ((int)raw[u]) >> 16;
-                        // IQ-DC sums: x and y halves by one dot2 each; the multiplier is 0 for rows/samples outside the chunk
-                        const int mx = (rowvalid && r < D) ? 0x00000001 : 0, my = (rowvalid && r < D) ? 0x00010000 : 0;
-                        sx = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, mx), sx, false);
-                        sy = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, my), sy, false);
-                        const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
-                        const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
-                        // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the table was built.  No wrap inside the
-                        // row (all but 1 in L/D rows): n as a double is nd0 + 4s exactly; else the integer form.
-                        double nd;
-                        if (nowrap) nd = nd0 + (double)(4 * s);
-                        else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
-                        const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
-                        const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
-                        zr[u] = ur * lr - ui * li;
-                        zi[u] = ur * li + ui * lr;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < GS; u++) {
-                    const int s = g * GS + u;
-                    if (s < KS_T) {
-                        acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[u], bop[KS_T ? s : 0], acc_re, 0, 0, 0);
-                        acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi[u], bop[KS_T ? s : 0], acc_im, 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if (nowrap) md_ksteps<KS_T, false>(row, kk, D, rowvalid, avg, f0, rown, towrap, L, bop, acc_re, acc_im, sx, sy);
+            else        md_ksteps<KS_T, true>(row, kk, D, rowvalid, avg, f0, rown, towrap, L, bop, acc_re, acc_im, sx, sy);
         } else {
             for (int s = 0; s < KS; s++) {
                 const int r = 4 * s + kk;
@@ -682,7 +691,7 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     const int grid = ((a->n_ch + 7) / 8) * 8 * wgs_per_ch;
     const int wave_dw = MD_PT_FLOATS + ((16 * a->D + 3) & ~3) + 4;
     if (a->D == 50)       // 2.4 Msps -> 48 kHz: compile-time geometry, unrolled k-steps, taps in registers
-        hipLaunchKernelGGL((k_mix_decimate<13, 50>), dim3(grid), dim3(256), (size_t)4 * wave_dw * sizeof(float), s, b);
+        hipLaunchKernelGGL((k_mix_decimate<13, 50>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
     else
         hipLaunchKernelGGL((k_mix_decimate<0, 0>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
     return 0;
