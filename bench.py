@@ -125,6 +125,15 @@ def main():
     eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C)
     summary = torch.zeros(C, 4, device=dev)
 
+    # Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): one
+    # untimed lead-in call up to the last short boundary, after which every 1 s step is exactly one segment.
+    lead = 0
+    while eng.samples_to_dc_boundary() < SR:
+        n = eng.samples_to_dc_boundary()
+        eng.process_device(iq.data_ptr(), SR, n)
+        lead += n
+    eng.fetch_frames_np()
+
     def step():
         eng.process_device(iq.data_ptr(), SR, SR)
         frames = eng.fetch_frames_np()                                    # sync + D2H of frame records + host RS ECC

@@ -103,6 +103,10 @@ int  sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info);
  * only enqueues work on the engine's HIP stream; the *_host form copies first (PCIe-inclusive). */
 int  sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples);
 int  sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples);
+/* Samples until the next IQ-DC segment boundary of the reference (demod_mod.c:498-504: 1/32 s doubling up to 1 s).
+ * A process call that ends exactly there (and later calls of one full segment) needs a single decimator launch;
+ * any other chunking is split internally at the boundary with identical results. */
+int64_t sonde_engine_samples_to_dc_boundary(const sonde_engine_t *e);
 /* wait for all enqueued work */
 int  sonde_engine_sync(sonde_engine_t *e);
 

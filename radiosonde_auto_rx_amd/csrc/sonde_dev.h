@@ -8,10 +8,10 @@ struct MixDecArgs {
     const int16_t *iq;        // [n_ch][ch_stride] complex int16
     long long ch_stride;      // complex samples between channels
     int n_ch, nblocks;        // blocks (= IF samples) in this chunk
-    int D, Q, KS;             // decM, ceil(taps/D), k-steps = ceil(D/4)
-    int G;                    // 16-block tiles per wave
+    int D, Q;                 // decM, ceil(taps/D)
+    int G;                    // 64-row tiles per wave
     int wgs_per_ch;           // filled by the launcher
-    const float *Bop;         // [KS][64] MFMA B operands
+    float wtab[64 * 8];       // [D][8]: wtab[r][q] = front-padded tap D*q + r; in the kernarg segment -> scalar loads
     const double *chan_f0;    // [n_ch] snapped mixer frequency / sample rate (demod_mod.c:1288)
     int lut_len;              // period of the reference's mixer table (sr_base / d)
     uint32_t lut_phase;       // table index of the chunk's first sample

@@ -32,8 +32,8 @@ struct sonde_engine {
     sonde_info_t info{};
     hipStream_t stream = nullptr;
     // design
-    Decimator dec; int Q = 0, KS = 0, G = 8;
-    std::vector<float> w_iq, w_fm, match;
+    Decimator dec; int Q = 0, G = 8;
+    std::vector<float> w_iq, w_fm, match, wtab;
     float sps = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;
     int symlen = 1, symhd = 1, hdmax = 0, bitofs = 0, nbits = 0, hdrlen = 0;
     uint32_t frame_samples = 0;
@@ -129,8 +129,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->sps = (float)cfg->sample_rate / e->baud;
     e->sps /= (float)D;
     e->Q = (T + D - 1) / D;
-    e->KS = (D + 3) / 4;
-    if (e->KS > 16 || e->Q > 8) { delete e; return SONDE_E_ARG; }   // decM <= 64 (input rate <= 3.07 Msps at IF 48 kHz)
+    if (D > 64 || e->Q > 8) { delete e; return SONDE_E_ARG; }       // decM <= 64 (input rate <= 3.07 Msps at IF 48 kHz)
     if (cfg->opt_lp & SONDE_LP_IQ) {
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
@@ -163,19 +162,13 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     I.if_sr = sr; I.decM = D; I.dectaps = (D == 1) ? 0 : T; I.lpiq_taps = (int)e->w_iq.size(); I.lpfm_taps = (int)e->w_fm.size();
     I.L = L; I.M = M; I.K = K; I.N = M; I.delay = delay; I.sps = e->sps; I.ring_len = ring;
 
-    // ---- B operand of the MFMA decimator: front-padded taps in the kernel's K order
+    // ---- decimator taps, front-padded to Q*D and laid out [r][q] so that step r loads its Q taps with one scalar load
     {
         const int pad = e->Q * D - T;
         std::vector<float> wpad((size_t)e->Q * D, 0.f);
         for (int k = 0; k < T; k++) wpad[pad + k] = e->dec.taps[k];
-        std::vector<float> B((size_t)e->KS * 64, 0.f);
-        for (int s = 0; s < e->KS; s++) for (int lane = 0; lane < 64; lane++) {
-            const int kk = lane >> 4, q = lane & 15;
-            const int r = 4 * s + kk;                                  // k-step s, lane group kk handles sample r of its row
-            if (q < e->Q && r < D) B[(size_t)s * 64 + lane] = wpad[(size_t)D * q + r];
-        }
-        if (dalloc(&e->d_Bop, B.size(), false)) { delete e; return SONDE_E_NOMEM; }
-        HIPCHK(hipMemcpy(e->d_Bop, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
+        e->wtab.assign(64 * 8, 0.f);
+        for (int r = 0; r < D; r++) for (int q = 0; q < e->Q; q++) e->wtab[(size_t)r * 8 + q] = wpad[(size_t)D * q + r];
     }
     // ---- mixer: snapped frequency per channel (xlt_fq = -fq, rs41mod.c:2685); the table period is common
     {
@@ -269,6 +262,10 @@ int sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info) {
     return 0;
 }
 
+int64_t sonde_engine_samples_to_dc_boundary(const sonde_engine_t *e) {
+    return e ? (int64_t)(e->dc_max - e->dc_cnt) : SONDE_E_ARG;
+}
+
 void *sonde_engine_stream(sonde_engine_t *e) { return e ? (void *)e->stream : nullptr; }
 
 int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples) {
@@ -282,15 +279,14 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt);
         MixDecArgs a{};
         a.iq = (const int16_t *)d_iq + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
-        a.D = D; a.Q = e->Q; a.KS = e->KS; a.G = e->G;
-        a.Bop = e->d_Bop; a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len;
+        a.D = D; a.Q = e->Q; a.G = e->G;
+        memcpy(a.wtab, e->wtab.data(), sizeof a.wtab); a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len;
         a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
         a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums;
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];
         a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
-        { long long tiles = (long long)C * ((a.nblocks + 15) / 16); int G = (int)(tiles / 16384); a.G = G < 8 ? 8 : (G > 32 ? 32 : G);
-          if (C * ((a.nblocks + 16 * a.G - 1) / (16 * a.G)) < 2048) { G = (int)(tiles / 2048); a.G = G < 1 ? 1 : (G > 32 ? 32 : G); } }
+        { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
         prof_begin(e, "mix_decimate"); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e);
         if (lrc < 0) return SONDE_E_ARG;
         e->ptail_cur ^= 1;

@@ -19,7 +19,6 @@
 #include <stdint.h>
 #include "sonde_dev.h"
 
-typedef float  f32x4 __attribute__((ext_vector_type(4)));
 typedef short  short2v __attribute__((ext_vector_type(2)));
 
 #define WAVE 64
@@ -27,101 +26,75 @@ typedef short  short2v __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // k_mix_decimate
 // ------------------------------------------------------------------------------------------------
-// Work decomposition: one wave owns 16*G consecutive D-sample blocks of one channel and walks them in tiles of
-// 16 blocks (the 16 rows of an MFMA tile).  Per tile:
-//   1. the 64*D raw bytes of the tile were fetched with fully coalesced 16-byte-per-lane loads one tile ahead
-//      (registers) and are parked in the wave's private LDS slice (no workgroup barrier anywhere);
-//   2. k-step s: lane (i = lane&15, kk = lane>>4) reads its sample r = 4s+kk of row i from LDS (stride-D dword
-//      reads are bank-conflict free), converts, removes the IQ-DC mean, and multiplies by the mixer phasor
-//      ex[n] = cexp(2 pi i * fl32(f0*n)) — the reference's float32-phase table (demod_mod.c:1292-1295) evaluated
-//      on the fly: fl32(f0*n) is reproduced bit-exactly in f64, the sin/cos by the hardware revolutions-input
-//      units (max abs error 2e-7 vs the table, tools/probes/sincos_probe.hip) — so no 8 B/sample table traffic;
-//   3. two v_mfma_f32_16x16x4_f32 accumulate P[row][q] += z * W_q[r] for re and im;
-//   4. the diagonal sum y[m] = sum_q P[m-(Q-1)+q][q] goes through a 32-row circular, transposed LDS buffer.
-#define MD_TILE   16          // blocks (rows) per MFMA tile
-#define MD_KSMAX  16          // D <= 64
-#ifndef MD_MINWAVES
-#define MD_MINWAVES 4      // waves per SIMD the register allocation is held to (VALU/MFMA overlap needs waves)
-#endif
-#define MD_PT_QS 36          // q stride of the transposed P buffer (32 rows + 4 pad: conflict-free 16-byte stores)
-#define MD_PT_PS (8 * MD_PT_QS)
-#define MD_PT_FLOATS (2 * MD_PT_PS)
+// y[m] = sum_k w[k] z[D(m+1)-T+k],  z[n] = (x[n]-dc) * ex[n].  With Q = ceil(T/D) and the taps front-padded to
+// Q*D:  y[m] = sum_q P[m-(Q-1)+q][q],  P[j][q] = sum_{r<D} W_q[r] z[D j + r]   (block j = D input samples).
+//
+// One LANE owns one block j ("row"); a wave walks its 64 rows through r = 0..D-1 in lock step, so
+//   * the tap W_q[r] is wave-uniform -> scalar operand, no LDS traffic, no cross-lane reduction;
+//   * each lane keeps its 2*Q partial sums P[j][0..Q-1] (re, im) in registers: 2*Q FMAs per sample;
+//   * the diagonal sum over q is Q-1 lane shifts (ds_bpermute) with a carry from the previous tile.
+// (A first version ran P as an f32 MFMA block product; on gfx950 v_mfma_f32_16x16x4_f32 executes on the same
+//  fp32 ALUs as the VALU — tools/probes/mfma_valu_overlap.hip: MFMA 0.64 ms + VALU 0.64 ms = 1.45 ms when
+//  mixed — and only Q = 7 of its 16 columns carried work, so the plain FMA form is 2.3x cheaper.)
+// The 64*D*4 bytes of a tile are fetched with fully coalesced 16-byte-per-lane loads one tile ahead (registers)
+// and parked in the wave's private LDS slice (stride-D reads are at most 2-way bank conflicted); no workgroup
+// barrier anywhere.  The mixer phasor ex[n] = cexp(2 pi i fl32(f0 n)) of the reference's float32-phase table
+// (demod_mod.c:1292-1295) is evaluated on the fly: fl32(f0*n) bit-exactly in f64, sin/cos by the hardware
+// revolutions-input units (max abs error 2e-7 vs the table, tools/probes/sincos_probe.hip).
+#define MD_ROWS   64          // blocks per tile = lanes
+#define MD_NVMAX  16          // 16-byte loads per lane per tile = ceil(D/4); D <= 64
 
 struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 
-// All k-steps of one tile with compile-time KS: groups of 4 — the group's LDS reads and its four independent
-// int->f64->f32->sin/cos chains overlap, then 8 MFMAs; the next group's reads are issued first.
-// WRAP = the mixer-table index wraps inside some row of this tile (1 tile in ~L/(16*D)): integer index path.
-template <int KS_T, bool WRAP>
-__device__ __forceinline__ void md_ksteps(const uint32_t *row, int kk, int D, bool rowvalid, float2 avg, double f0,
-                                          uint32_t rown, uint32_t towrap, uint32_t L, const float *bop,
-                                          f32x4 &acc_re, f32x4 &acc_im, int &sx, int &sy) {
-    constexpr int GS = 4, NG = (KS_T + GS - 1) / GS;
-    const double nd0 = (double)(rown + (uint32_t)kk);
-    uint32_t rawn[GS];
+template <int Q_T, bool WRAP>
+__device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float *wt, float2 avg, double f0,
+                                        uint32_t rown, uint32_t L, int dcmask_x, int dcmask_y,
+                                        float (&pr)[Q_T], float (&pi)[Q_T], int &sx, int &sy) {
+    const uint32_t towrap = L - rown;
+    const double nd0 = (double)rown;
+    float wn[Q_T];                                            // taps of the next step: scalar loads issued one step ahead
 #pragma unroll
-    for (int u = 0; u < GS; u++) rawn[u] = row[4 * u + kk];
+    for (int q = 0; q < Q_T; q++) wn[q] = wt[q];
+#pragma unroll 2
+    for (int r = 0; r < D; r++) {
+        float w[Q_T];
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        uint32_t raw[GS];
+        for (int q = 0; q < Q_T; q++) w[q] = wn[q];
+        {
+            const float *wp = wt + 8 * (r + 1 < D ? r + 1 : r);
 #pragma unroll
-        for (int u = 0; u < GS; u++) raw[u] = rawn[u];
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int u = 0; u < GS; u++) if ((g + 1) * GS + u < KS_T) rawn[u] = row[4 * ((g + 1) * GS + u) + kk];
+            for (int q = 0; q < Q_T; q++) wn[q] = wp[q];
         }
-        float zr[GS], zi[GS];
+        const uint32_t raw = row[r];
+        const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
+        // IQ-DC sums (exact integers == the reference's double sums); mask is 0 for rows outside the chunk
+        sx = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw), __builtin_bit_cast(short2v, dcmask_x), sx, false);
+        sy = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw), __builtin_bit_cast(short2v, dcmask_y), sy, false);
+        // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
+        const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
+        const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
+        // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
+        double nd;
+        if (!WRAP) nd = nd0 + (double)r;
+        else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
+        const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
+        const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
+        const float zr = ur * lr - ui * li;                   // z = u * ex[n]  (demod_mod.c:744)
+        const float zi = ur * li + ui * lr;
 #pragma unroll
-        for (int u = 0; u < GS; u++) {
-            const int s = g * GS + u;
-            if (s < KS_T) {
-                const int r = 4 * s + kk;
-                const int xi = (int)(short)(raw[u] & 0xffffu), yi = ((int)raw[u]) >> 16;
-                // IQ-DC sums: x and y halves by one dot2 each; the multiplier is 0 for rows/samples outside the chunk
-                const bool cnt = rowvalid && r < D;
-                const int mx = cnt ? 0x00000001 : 0, my = cnt ? 0x00010000 : 0;
-                sx = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, mx), sx, false);
-                sy = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw[u]), __builtin_bit_cast(short2v, my), sy, false);
-                // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
-                const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
-                const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
-                // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
-                double nd;
-                if (!WRAP) nd = nd0 + (double)(4 * s);       // exact: small integers
-                else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
-                const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
-                const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
-                zr[u] = ur * lr - ui * li;                   // z = u * ex[n]  (demod_mod.c:744)
-                zi[u] = ur * li + ui * lr;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < GS; u++) {
-            const int s = g * GS + u;
-            if (s < KS_T) {
-                acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr[u], bop[s], acc_re, 0, 0, 0);
-                acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi[u], bop[s], acc_im, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < Q_T; q++) { pr[q] = fmaf(w[q], zr, pr[q]); pi[q] = fmaf(w[q], zi, pi[q]); }
     }
 }
 
-template <int KS_T, int D_T>
-__global__ __launch_bounds__(256, MD_MINWAVES)
+template <int Q_T>
+__global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
-    extern __shared__ float smem[];
+    extern __shared__ uint32_t smem_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int D = D_T ? D_T : a.D, Q = a.Q, H = a.Q - 1;
-    const int KS = KS_T ? KS_T : a.KS;
-    const int tile_dw = 16 * D;                               // dwords (= complex int16 samples) per tile
-    const int wave_dw = MD_PT_FLOATS + ((tile_dw + 3) & ~3) + 4;   // +4: k-step padding may read past the last row
-    float *sPt = smem + wave * wave_dw;                       // [part][q][32]
-    uint32_t *sRaw = reinterpret_cast<uint32_t *>(sPt + MD_PT_FLOATS);   // [16][D] raw samples of the current tile
-    float *sB = smem + 4 * wave_dw;                           // [KS][64] taps in MFMA B-operand order
-
-    for (int k = threadIdx.x; k < KS * 64; k += blockDim.x) sB[k] = a.Bop[k];
-    __syncthreads();
+    const int D = a.D;
+    constexpr int H = Q_T - 1;
+    const int tile_dw = MD_ROWS * D;
+    uint32_t *sRaw = smem_u + wave * (tile_dw + 4);
 
     // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; a channel stays on one XCD
     const int b = blockIdx.x;
@@ -130,136 +103,99 @@ void k_mix_decimate(const MixDecArgs a) {
     const int wg = slot % a.wgs_per_ch;
     if (ch >= a.n_ch) return;
     const int seg = wg * 4 + wave;
-    const int blocks_per_seg = MD_TILE * a.G;
-    const int jb = seg * blocks_per_seg;
+    const int rows_per_seg = MD_ROWS * a.G - H;               // later segments start H rows early: exactly G full tiles
+    const int jb = seg * rows_per_seg;
     if (jb >= a.nblocks) return;
-    const int je = min(a.nblocks, jb + blocks_per_seg);
+    const int je = min(a.nblocks, jb + rows_per_seg);
 
-    const int i = lane & 15, kk = lane >> 4;
     const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
     const float2 avg = a.dc_avg[ch];
     const double f0 = a.chan_f0[ch];
     const uint32_t L = (uint32_t)a.lut_len;
     float2 *yout = a.y + (size_t)ch * a.ring_len;
+    const int total_dw = a.nblocks * D;
+    const int nv = (D + 3) >> 2;                              // 16-byte loads per lane per tile
 
-
-    float bop[KS_T ? KS_T : 1];                               // compile-time variant: taps in registers
-    if (KS_T) {
+    // P of the previous tile (carry for the diagonal sum).  Segment 0 continues the previous call (P tail),
+    // later segments start Q-1 rows early instead (those rows produce no output).
+    float pvr[Q_T], pvi[Q_T];
 #pragma unroll
-        for (int s = 0; s < KS_T; s++) bop[s] = sB[s * 64 + lane];
-    }
-
-    if (seg == 0) {                                           // P rows of the Q-1 blocks before the chunk
-#pragma unroll 1
-        for (int k = lane; k < H * 8; k += WAVE) {
-            const int r = k >> 3, q = k & 7;
-            const float2 v = a.ptail_in[((size_t)ch * 8 + r) * 8 + q];
-            const int row = (r - H) & 31;
-            sPt[q * MD_PT_QS + row] = v.x; sPt[MD_PT_PS + q * MD_PT_QS + row] = v.y;
+    for (int q = 0; q < Q_T; q++) { pvr[q] = 0.f; pvi[q] = 0.f; }
+    if (seg == 0 && lane >= MD_ROWS - H) {
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) {
+            const float2 v = a.ptail_in[((size_t)ch * 8 + (lane - (MD_ROWS - H))) * 8 + q];
+            pvr[q] = v.x; pvi[q] = v.y;
         }
     }
+    if (seg == 0 && a.nblocks < H && lane < H - a.nblocks) {  // chunk shorter than the history: old tail rows survive
+        for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + lane) * 8 + q] = a.ptail_in[((size_t)ch * 8 + lane + a.nblocks) * 8 + q];
+    }
 
-    const int jt0 = (seg == 0) ? jb : jb - MD_TILE;           // one halo tile rebuilds the history of later segments
-    const int nv = (tile_dw + 255) / 256;                     // 16-byte loads per lane per tile
-    const int total_dw = a.nblocks * D;
-    u32x4_u pre[4];
+    const int jt0 = (seg == 0) ? jb : jb - H;
+    u32x4_u pre[MD_NVMAX];
     auto fetch = [&](int jt) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
+        for (int v = 0; v < MD_NVMAX; v++) {
             if (v < nv) {
-                int off = jt * D + 256 * v + 4 * lane;         // dword offset in the chunk
-                if (256 * v + 4 * lane >= tile_dw || off + 4 > total_dw) off = jt * D;   // tail: any valid address
+                const int c = 64 * v + lane;                  // 16-byte chunk of the tile
+                int off = jt * D + 4 * c;                     // dword offset in the chunk
+                if (4 * c >= tile_dw || off + 4 > total_dw) off = jt * D;   // beyond the tile / the chunk: any valid address
                 pre[v] = *reinterpret_cast<const u32x4_u *>(iq + off);
             }
         }
     };
     auto park = [&]() {
 #pragma unroll
-        for (int v = 0; v < 4; v++) {
-            if (v < nv && 256 * v + 4 * lane < tile_dw)
-                *reinterpret_cast<uint4 *>(sRaw + 256 * v + 4 * lane) = make_uint4(pre[v].x, pre[v].y, pre[v].z, pre[v].w);
+        for (int v = 0; v < MD_NVMAX; v++) {
+            if (v < nv) {
+                const int c = 64 * v + lane;
+                if (4 * c < tile_dw) *reinterpret_cast<uint4 *>(sRaw + 4 * c) = make_uint4(pre[v].x, pre[v].y, pre[v].z, pre[v].w);
+            }
         }
     };
     fetch(jt0);
     park();
 
-    // mixer-table index of this lane's row: n = (lut_phase + D*row) mod lut_len, advanced by 16*D per tile
-    const uint32_t step = (uint32_t)((16u * (uint32_t)D) % L);
-    uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)(jt0 + i) * (uint64_t)D) % L);
     int sx = 0, sy = 0;
+    const uint32_t step = (uint32_t)(((uint64_t)MD_ROWS * (uint64_t)D) % L);
+    uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)(jt0 + lane) * (uint64_t)D) % L);
 
-    for (int jt = jt0; jt < je; jt += MD_TILE) {
-        const bool halo = jt < jb;
-        const bool more = jt + MD_TILE < je;
-        if (more) fetch(jt + MD_TILE);                        // next tile's bytes are in flight during the MFMAs
-        const bool rowvalid = (jt + i) < je && !halo;
-        const uint32_t *row = sRaw + i * D;
-        const uint32_t towrap = L - rown;                     // samples of this row before the table index wraps
-        const bool nowrap = __builtin_amdgcn_ballot_w64(towrap < (uint32_t)(4 * KS)) == 0;   // wave-uniform
-
-        f32x4 acc_re = {0.f, 0.f, 0.f, 0.f}, acc_im = {0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (KS_T) {
-            if (nowrap) md_ksteps<KS_T, false>(row, kk, D, rowvalid, avg, f0, rown, towrap, L, bop, acc_re, acc_im, sx, sy);
-            else        md_ksteps<KS_T, true>(row, kk, D, rowvalid, avg, f0, rown, towrap, L, bop, acc_re, acc_im, sx, sy);
-        } else {
-            for (int s = 0; s < KS; s++) {
-                const int r = 4 * s + kk;
-                const uint32_t raw = row[r];                  // r >= D reads a neighbour's sample, its tap is 0
-                const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
-                const bool cnt = rowvalid && r < D;
-                sx += cnt ? xi : 0; sy += cnt ? yi : 0;
-                // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
-                const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
-                const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
-                // ex[n]: t = fl32(f0 * n) exactly as the table was built, phase = fract(t) revolutions
-                const uint32_t n = rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u);
-                const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
-                const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
-                const float zr = ur * lr - ui * li;           // z = u * ex[n]  (demod_mod.c:744)
-                const float zi = ur * li + ui * lr;
-                const float bw = sB[s * 64 + lane];
-                acc_re = __builtin_amdgcn_mfma_f32_16x16x4f32(zr, bw, acc_re, 0, 0, 0);
-                acc_im = __builtin_amdgcn_mfma_f32_16x16x4f32(zi, bw, acc_im, 0, 0, 0);
-            }
-        }
-
-        // C/D layout of 16x16x4: col = lane&15 (= q), rows 4*(lane>>4) .. +3 in the 4 accumulator registers
-        const int rbase = (jt - jb) & 31;                     // row of the tile's first block (0 or 16)
-        if (i < 8) {
-            *reinterpret_cast<f32x4 *>(sPt + i * MD_PT_QS + rbase + 4 * kk) = acc_re;
-            *reinterpret_cast<f32x4 *>(sPt + MD_PT_PS + i * MD_PT_QS + rbase + 4 * kk) = acc_im;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!halo) {
-            // lane = (half, part, o): 4 of the Q diagonal terms each, combined with two cross-lane adds
-            const int o = lane & 15, part = (lane >> 4) & 1, half = lane >> 5;
-            float v = 0.f;
+    for (int jt = jt0; jt < je; jt += MD_ROWS) {
+        const bool more = jt + MD_ROWS < je;
+        if (more) fetch(jt + MD_ROWS);                        // next tile's bytes fly while this one is computed
+        const int j = jt + lane;
+        const bool outrow = j >= jb && j < je;
+        const int mx = outrow ? 0x00000001 : 0, my = outrow ? 0x00010000 : 0;
+        float pr[Q_T], pi[Q_T];
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const int q = 4 * half + qq;
-                if (q < Q) v += sPt[part * MD_PT_PS + q * MD_PT_QS + ((rbase + o - H + q) & 31)];
-            }
-            v += __shfl_xor(v, 32);
-            const float vim = __shfl_xor(v, 16);
-            if (lane < 16 && jt + lane < je) {
-                const uint32_t m = a.m0 + (uint32_t)(jt + lane);
-                yout[m & (uint32_t)(a.ring_len - 1)] = make_float2(v, vim);
-            }
-            if (jt + MD_TILE >= a.nblocks) {                  // P rows of the last Q-1 blocks go to the next call
-#pragma unroll 1
-                for (int k = lane; k < H * 8; k += WAVE) {
-                    const int r = k >> 3, q = k & 7;
-                    const int prow = (a.nblocks - H + r - jb) & 31;
-                    a.ptail_out[((size_t)ch * 8 + r) * 8 + q] = make_float2(sPt[q * MD_PT_QS + prow], sPt[MD_PT_PS + q * MD_PT_QS + prow]);
-                }
-            }
+        for (int q = 0; q < Q_T; q++) { pr[q] = 0.f; pi[q] = 0.f; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
+        if (nowrap) md_rows<Q_T, false>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, mx, my, pr, pi, sx, sy);
+        else        md_rows<Q_T, true>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, mx, my, pr, pi, sx, sy);
+
+        // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
+        float yr = pr[H], yi = pi[H];
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int k = H - q, src = (lane - k) & 63;
+            const float cr = __shfl(pr[q], src), ci = __shfl(pi[q], src);
+            const float or_ = __shfl(pvr[q], src), oi = __shfl(pvi[q], src);
+            yr += (lane >= k) ? cr : or_;
+            yi += (lane >= k) ? ci : oi;
         }
-        if (more) park();                                     // all reads of the old tile were issued above (in-order DS)
+        if (outrow) yout[(a.m0 + (uint32_t)j) & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
+        if (j >= a.nblocks - H && j < a.nblocks) {            // P rows of the last Q-1 blocks go to the next call
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(pr[q], pi[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) { pvr[q] = pr[q]; pvi[q] = pi[q]; }
+        if (more) park();                                     // LDS reads of the old tile are done (in-order DS)
         rown += step; if (rown >= L) rown -= L;
     }
 
-    // running IQ-DC sums of this segment (exact integer arithmetic == the reference's double sums)
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
     if (lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch), (unsigned long long)(long long)sx);
@@ -684,16 +620,22 @@ void k_framesync(const SyncArgs a) {
 // launch wrappers (called from sonde_engine.cpp)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
-    if (a->KS < 1 || a->KS > MD_KSMAX || a->Q > 8) return -1;
-    const int blocks_per_wg = 4 * MD_TILE * a->G;
-    const int wgs_per_ch = (a->nblocks + blocks_per_wg - 1) / blocks_per_wg;
+    if (a->D < 1 || a->D > 64 || a->Q < 1 || a->Q > 8) return -1;
+    const int rows_per_wg = 4 * (MD_ROWS * a->G - (a->Q - 1));
+    const int wgs_per_ch = (a->nblocks + rows_per_wg - 1) / rows_per_wg;
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
-    const int grid = ((a->n_ch + 7) / 8) * 8 * wgs_per_ch;
-    const int wave_dw = MD_PT_FLOATS + ((16 * a->D + 3) & ~3) + 4;
-    if (a->D == 50)       // 2.4 Msps -> 48 kHz: compile-time geometry, unrolled k-steps, taps in registers
-        hipLaunchKernelGGL((k_mix_decimate<13, 50>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
-    else
-        hipLaunchKernelGGL((k_mix_decimate<0, 0>), dim3(grid), dim3(256), (size_t)(4 * wave_dw + a->KS * 64) * sizeof(float), s, b);
+    const dim3 grid(((a->n_ch + 7) / 8) * 8 * wgs_per_ch), blk(256);
+    const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
+    switch (a->Q) {
+        case 1: hipLaunchKernelGGL((k_mix_decimate<1>), grid, blk, lds, s, b); break;
+        case 2: hipLaunchKernelGGL((k_mix_decimate<2>), grid, blk, lds, s, b); break;
+        case 3: hipLaunchKernelGGL((k_mix_decimate<3>), grid, blk, lds, s, b); break;
+        case 4: hipLaunchKernelGGL((k_mix_decimate<4>), grid, blk, lds, s, b); break;
+        case 5: hipLaunchKernelGGL((k_mix_decimate<5>), grid, blk, lds, s, b); break;
+        case 6: hipLaunchKernelGGL((k_mix_decimate<6>), grid, blk, lds, s, b); break;
+        case 7: hipLaunchKernelGGL((k_mix_decimate<7>), grid, blk, lds, s, b); break;
+        default: hipLaunchKernelGGL((k_mix_decimate<8>), grid, blk, lds, s, b); break;
+    }
     return 0;
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {

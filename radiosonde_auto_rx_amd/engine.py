@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
         L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_engine_read_tap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
         L.sonde_engine_sync.argtypes = [C.c_void_p]
+        L.sonde_engine_samples_to_dc_boundary.argtypes = [C.c_void_p]
+        L.sonde_engine_samples_to_dc_boundary.restype = C.c_int64
         L.sonde_engine_destroy.argtypes = [C.c_void_p]
         L.sonde_engine_info.argtypes = [C.c_void_p, C.POINTER(SondeInfo)]
         L.sonde_engine_profile.argtypes = [C.c_void_p, C.c_int]
@@ -124,6 +126,9 @@ class Engine:
 
     def process_device(self, ptr: int, ch_stride: int, n_samples: int):
         _chk(lib().sonde_engine_process_device(self._h, C.c_void_p(ptr), ch_stride, n_samples))
+
+    def samples_to_dc_boundary(self) -> int:
+        return int(lib().sonde_engine_samples_to_dc_boundary(self._h))
 
     def sync(self):
         _chk(lib().sonde_engine_sync(self._h))

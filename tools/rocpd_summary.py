@@ -18,7 +18,7 @@ def kernel_stats(path):
     print("\n-- per launch geometry (kernels of this repo)")
     print(f"{'kernel':28s} {'grid':>22s} {'wg':>5s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>7s}")
     for r in db.execute("select name, grid_x, grid_y, workgroup_x, count(*), avg(duration)/1e3, min(duration)/1e3, vgpr_count, accum_vgpr_count, "
-                        "sgpr_count, lds_size from kernels where name like '%k\_%' escape '\' group by name, grid_x, grid_y order by name, grid_x desc"):
+                        "sgpr_count, lds_size from kernels where name like '%k!_%' escape '!' group by name, grid_x, grid_y order by name, grid_x desc"):
         print(f"{r[0].split('(')[0]:28s} {str(r[1])+'x'+str(r[2]):>22s} {r[3]:5d} {r[4]:6d} {r[5]:10.1f} {r[6]:10.1f} {r[7]:5d} {r[8]:5d} {r[9]:5d} {r[10]:7d}")
 
 
@@ -27,7 +27,7 @@ def pmc_stats(path):
     print(f"\n== PMC: {path}")
     print(f"{'kernel':28s} {'grid':>14s} {'counter':>14s} {'calls':>6s} {'avg':>16s} {'max':>16s}")
     for r in db.execute("select kernel_name, grid_size, counter_name, count(*), avg(value), max(value) from counters_collection "
-                        "where kernel_name like '%k\_%' escape '\' group by kernel_name, grid_size, counter_name order by kernel_name, grid_size desc"):
+                        "where kernel_name like '%k!_%' escape '!' group by kernel_name, grid_size, counter_name order by kernel_name, grid_size desc"):
         print(f"{r[0].split('(')[0]:28s} {r[1]:14d} {r[2]:>14s} {r[3]:6d} {r[4]:16.1f} {r[5]:16.1f}")
 
 
