@@ -46,12 +46,19 @@ typedef short  short2v __attribute__((ext_vector_type(2)));
 
 struct __attribute__((packed, aligned(4))) u32x4_u { uint32_t x, y, z, w; };
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// One tile: every lane walks the D samples of its row.  Measured issue costs on gfx950 (tools/probes/valu_rates.hip,
+// cycles per wave64 instruction): v_fma_f32 3.2, v_pk_fma_f32 5.2, v_mul/add_f64 4.7, v_sin/cos_f32 10.1 — the
+// kernel is VALU-bound, so the FIR uses packed FMAs on (re, im) pairs and everything else is kept to the minimum
+// number of instructions.
 template <int Q_T, bool WRAP>
 __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float *wt, float2 avg, double f0,
-                                        uint32_t rown, uint32_t L, int dcmask_x, int dcmask_y,
-                                        float (&pr)[Q_T], float (&pi)[Q_T], int &sx, int &sy) {
+                                        uint32_t rown, uint32_t L, float dcmask,
+                                        float2v (&acc)[Q_T], float2v &dcs) {
     const uint32_t towrap = L - rown;
     const double nd0 = (double)rown;
+    const float2v navg = { -avg.x, -avg.y }, scale = { 3.0517578125e-05f, 3.0517578125e-05f }, msk = { dcmask, dcmask };
     float wn[Q_T];                                            // taps of the next step: scalar loads issued one step ahead
 #pragma unroll
     for (int q = 0; q < Q_T; q++) wn[q] = wt[q];
@@ -66,23 +73,25 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
             for (int q = 0; q < Q_T; q++) wn[q] = wp[q];
         }
         const uint32_t raw = row[r];
-        const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
-        // IQ-DC sums (exact integers == the reference's double sums); mask is 0 for rows outside the chunk
-        sx = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw), __builtin_bit_cast(short2v, dcmask_x), sx, false);
-        sy = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, raw), __builtin_bit_cast(short2v, dcmask_y), sy, false);
+        const float2v xf = { (float)(int)(short)(raw & 0xffffu), (float)(((int)raw) >> 16) };
+        // IQ-DC sums: int16 values are exact in f32 and a tile row sums to < 2^24, so the float sum is exact
+        dcs = __builtin_elementwise_fma(xf, msk, dcs);
         // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
-        const float ur = fmaf((float)xi, 3.0517578125e-05f, -avg.x);
-        const float ui = fmaf((float)yi, 3.0517578125e-05f, -avg.y);
+        const float2v u = __builtin_elementwise_fma(xf, scale, navg);
         // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
         double nd;
         if (!WRAP) nd = nd0 + (double)r;
         else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
         const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
         const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
-        const float zr = ur * lr - ui * li;                   // z = u * ex[n]  (demod_mod.c:744)
-        const float zi = ur * li + ui * lr;
+        // z = u * ex[n]  (demod_mod.c:744), 4 scalar ops
+        const float t1 = u.y * li, t2 = u.y * lr;
+        const float2v z = { __builtin_fmaf(u.x, lr, -t1), __builtin_fmaf(u.x, li, t2) };
 #pragma unroll
-        for (int q = 0; q < Q_T; q++) { pr[q] = fmaf(w[q], zr, pr[q]); pi[q] = fmaf(w[q], zi, pi[q]); }
+        for (int q = 0; q < Q_T; q++) {                      // P[row][q] += W_q[r] * z: one packed FMA per tap
+            const float2v wq = { w[q], w[q] };
+            acc[q] = __builtin_elementwise_fma(wq, z, acc[q]);
+        }
     }
 }
 
@@ -118,14 +127,14 @@ void k_mix_decimate(const MixDecArgs a) {
 
     // P of the previous tile (carry for the diagonal sum).  Segment 0 continues the previous call (P tail),
     // later segments start Q-1 rows early instead (those rows produce no output).
-    float pvr[Q_T], pvi[Q_T];
+    float2v pv[Q_T];
 #pragma unroll
-    for (int q = 0; q < Q_T; q++) { pvr[q] = 0.f; pvi[q] = 0.f; }
+    for (int q = 0; q < Q_T; q++) pv[q] = (float2v){0.f, 0.f};
     if (seg == 0 && lane >= MD_ROWS - H) {
 #pragma unroll
         for (int q = 0; q < Q_T; q++) {
             const float2 v = a.ptail_in[((size_t)ch * 8 + (lane - (MD_ROWS - H))) * 8 + q];
-            pvr[q] = v.x; pvi[q] = v.y;
+            pv[q] = (float2v){v.x, v.y};
         }
     }
     if (seg == 0 && a.nblocks < H && lane < H - a.nblocks) {  // chunk shorter than the history: old tail rows survive
@@ -166,32 +175,33 @@ void k_mix_decimate(const MixDecArgs a) {
         if (more) fetch(jt + MD_ROWS);                        // next tile's bytes fly while this one is computed
         const int j = jt + lane;
         const bool outrow = j >= jb && j < je;
-        const int mx = outrow ? 0x00000001 : 0, my = outrow ? 0x00010000 : 0;
-        float pr[Q_T], pi[Q_T];
+        float2v acc[Q_T];
 #pragma unroll
-        for (int q = 0; q < Q_T; q++) { pr[q] = 0.f; pi[q] = 0.f; }
+        for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
+        float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if (nowrap) md_rows<Q_T, false>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, mx, my, pr, pi, sx, sy);
-        else        md_rows<Q_T, true>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, mx, my, pr, pi, sx, sy);
+        if (nowrap) md_rows<Q_T, false>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        else        md_rows<Q_T, true>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        sx += (int)dcs.x; sy += (int)dcs.y;
 
         // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
-        float yr = pr[H], yi = pi[H];
+        float yr = acc[H].x, yi = acc[H].y;
 #pragma unroll
         for (int q = 0; q < H; q++) {
             const int k = H - q, src = (lane - k) & 63;
-            const float cr = __shfl(pr[q], src), ci = __shfl(pi[q], src);
-            const float or_ = __shfl(pvr[q], src), oi = __shfl(pvi[q], src);
+            const float cr = __shfl(acc[q].x, src), ci = __shfl(acc[q].y, src);
+            const float or_ = __shfl(pv[q].x, src), oi = __shfl(pv[q].y, src);
             yr += (lane >= k) ? cr : or_;
             yi += (lane >= k) ? ci : oi;
         }
         if (outrow) yout[(a.m0 + (uint32_t)j) & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
         if (j >= a.nblocks - H && j < a.nblocks) {            // P rows of the last Q-1 blocks go to the next call
 #pragma unroll
-            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(pr[q], pi[q]);
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
         }
 #pragma unroll
-        for (int q = 0; q < Q_T; q++) { pvr[q] = pr[q]; pvi[q] = pi[q]; }
+        for (int q = 0; q < Q_T; q++) pv[q] = acc[q];
         if (more) park();                                     // LDS reads of the old tile are done (in-order DS)
         rown += step; if (rown >= L) rown -= L;
     }
