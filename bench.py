@@ -173,6 +173,16 @@ def main():
     # per-step launches differ in size (IQ-DC segment edges) so the rate is (bytes of all launches)/(time of all launches)
     md_total_s = md_ms * md_n / 1e3
     achieved = (C * SR * args.steps * 4) / md_total_s / 1e9 if md_total_s > 0 else 0.0
+    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes of this same command (it cannot be sampled from
+    # inside the process); the committed summary is quoted when it was taken on the same launch geometry.
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_mix_decimate_traffic.json")))
+        if tj["algorithmic_bytes"] == C * SR * 4:
+            traffic = round(tj["traffic_bytes"] / 1e9, 3)
+            traffic_src = "GB per launch, (2 x FETCH_SIZE + WRITE_SIZE) from profiles/r1_mix_decimate_traffic.json (rocprofv3 --pmc)"
+    except Exception:
+        pass
     if rank == 0:
         out = {
             "metric": "IQ Msamples/s (RS41 --IQ --lpIQ demod + framesync + ECC), concurrent real-time 2.4 Msps channels = value/2.4",
@@ -186,7 +196,8 @@ def main():
                        "kernel_ms_avg": {k: round(v[0], 4) for k, v in kern.items()},
                        "kernel_launches": {k: v[1] for k, v in kern.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_mix_decimate", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_src,
+                         "algorithmic_gb_per_launch": round(C * SR * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4),
                          "note": "achieved = 4 B x complex samples of all timed k_mix_decimate launches / their HIP-event time on the engine stream"},
         }
         if world == 1 and not args.no_cpu_baseline:
