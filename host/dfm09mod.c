@@ -1,0 +1,96 @@
+/*
+ * host/dfm09mod.c — `dfm09mod` command-line front end on top of libsonde_hip (C).
+ *
+ * Reference contract kept for the IQ + raw form (reference demod/mod/dfm09mod.c:1338-1500 argv, :1198-1236 output):
+ *     dfm09mod -r [--ecc|--ecc2] [--ths x] --IQ <fq> [--lpIQ | --lpbw kHz] [--min] - <sr> 16
+ * stdout: per frame `<7 nibbles> [OK]   <13 nibbles> [OK]   <13 nibbles> [OK] ` ([KO] = corrected, [NO] = uncorrectable)
+ * stderr: `IF:` / `dec:`; exit 0 at EOF, 255 on argument / init errors.  Field decode / JSON is the next tier.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "sonde_hip.h"
+
+int main(int argc, char **argv) {
+    sonde_cfg_t cfg;
+    double fq = 0.0;
+    int have_iq = 0, raw = 0, have_pcm = 0;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = SONDE_ABI_VERSION;
+    cfg.sonde_type = SONDE_DFM09;
+    setbuf(stdout, NULL);
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
+        else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
+        else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
+        else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
+        else if (!strcmp(a, "--IQ")) {
+            if (++i >= argc) return -1;
+            fq = atof(argv[i]);
+            if (fq < -0.5) fq = -0.5;
+            if (fq > 0.5) fq = 0.5;
+            have_iq = 1;
+        }
+        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
+        else if (!strcmp(a, "--lpbw")) {
+            if (++i >= argc) return -1;
+            double bw = atof(argv[i]);
+            if (bw > 4.6 && bw < 32.0) cfg.lpiq_bw = (int)(bw * 1e3);
+            cfg.opt_lp |= SONDE_LP_IQ;
+        }
+        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
+        else if (!strcmp(a, "-")) {
+            if (i + 2 >= argc) return -1;
+            cfg.sample_rate = atoi(argv[++i]);
+            cfg.bits = atoi(argv[++i]);
+            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
+            have_pcm = 1;
+        }
+        else { fprintf(stderr, "dfm09mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
+    }
+    if (!have_iq || !have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
+    if (!raw) { fprintf(stderr, "dfm09mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+
+    cfg.n_channels = 1;
+    cfg.max_chunk = cfg.sample_rate;
+    cfg.max_frames = 16;
+    sonde_engine_t *eng = NULL;
+    int rc = sonde_engine_create(&cfg, &fq, &eng);
+    if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+    sonde_info_t info;
+    sonde_engine_info(eng, &info);
+    fprintf(stderr, "IF: %d\n", info.if_sr);
+    fprintf(stderr, "dec: %d\n", info.decM);
+
+    int chunk = cfg.sample_rate / 10;
+    chunk -= chunk % info.decM;
+    if (chunk < info.decM) chunk = info.decM;
+    int16_t *buf = (int16_t *)malloc((size_t)chunk * 4);
+    sonde_dfm_frame_t frames[128];
+    char line[128];
+    size_t have = 0;
+    for (;;) {
+        size_t got = fread((char *)buf + have, 1, (size_t)chunk * 4 - have, stdin);
+        have += got;
+        int n = (int)(have / 4);
+        n -= n % info.decM;
+        if (n > 0) {
+            rc = sonde_engine_process_host(eng, buf, n, n);
+            if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
+            int k = sonde_engine_fetch_dfm(eng, frames, 128, 0);
+            for (int i = 0; i < k; i++) { sonde_dfm_rawline(&frames[i], cfg.ecc_level, line, sizeof line); fprintf(stdout, "%s\n", line); }
+            memmove(buf, (char *)buf + (size_t)n * 4, have - (size_t)n * 4);
+            have -= (size_t)n * 4;
+        }
+        if (got == 0) break;
+    }
+    {
+        int k = sonde_engine_fetch_dfm(eng, frames, 128, 1);
+        for (int i = 0; i < k; i++) { sonde_dfm_rawline(&frames[i], cfg.ecc_level, line, sizeof line); fprintf(stdout, "%s\n", line); }
+    }
+    sonde_engine_destroy(eng);
+    free(buf);
+    return 0;
+}

@@ -33,6 +33,8 @@ extern "C" {
 
 /* sonde types (dsp.hdr / baud / BT / h presets of the reference callers) */
 #define SONDE_RS41  41          /* rs41mod.c:2812-2836: 4800 Bd, BT 0.5, h 0.6, 64-bit header, thres 0.7, hdmax 4 */
+#define SONDE_DFM09  9          /* dfm09mod.c:1309,1560-1582: 2500 Bd Manchester, BT 0.5, h 1.8, 32-symbol raw header,
+                                 * thres 0.65, hdmax 2, lpIQ 12 kHz, 8 x 280-bit frames sliced per header hit       */
 
 /* opt_lp bits, as demod_mod.h:12-14 */
 #define SONDE_LP_IQ 1
@@ -80,6 +82,17 @@ typedef struct {
     uint8_t  pad[2];
 } sonde_frame_t;
 
+/* One DFM frame = what dfm09mod's print_frame() sees after de-interleave + Hamming(8,4) (dfm09mod.c:1153-1236). */
+typedef struct {
+    int32_t  channel;
+    int32_t  frame_in_hit;   /* 0..7: frames are sliced back-to-back after one header hit (nfrms = 8)   */
+    int32_t  ecc[3];         /* hamming() return per block conf/dat1/dat2: 0 ok, >0 fixed-codeword mask, <0 uncorrectable */
+    uint32_t mv_pos;
+    float    mv;
+    uint8_t  conf[7], dat1[13], dat2[13];   /* data nibbles */
+    uint8_t  pad[3];
+} sonde_dfm_frame_t;
+
 /* Derived constants of init_buffers() (demod_mod.c:1208-1474), for callers and tests. */
 typedef struct {
     int32_t if_sr, decM, dectaps, lut_len, lpiq_taps, lpfm_taps;
@@ -114,6 +127,13 @@ int  sonde_engine_sync(sonde_engine_t *e);
  * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
  * Returns the number of frames written (<= max). */
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
+/* DFM engines: frames completed so far (syncs; Hamming decode of dfm09mod.c:240-345 on the host).  cfg.ecc_level 0/1/2
+ * = none / --ecc / --ecc2 (soft 2-bit pass).  finish != 0: end of input, also emits the complete frames of a hit
+ * in progress (a partial frame is dropped like dfm09mod.c:1713). */
+int  sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish);
+/* Raw text line of `dfm09mod -r [--ecc]` (dfm09mod.c:1198-1236); returns strlen. buf >= 96 bytes */
+int  sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, size_t buflen);
+
 /* End of input (stdin EOF of the reference): emit the frame each channel was in the middle of, with the bits that
  * exist (rs41mod.c:2931 breaks the bit loop on EOF and still calls print_frame :2965), then fetch as above. */
 int  sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max);

@@ -170,3 +170,26 @@ def ref_run(binary: str, args: list[str], data: bytes | np.ndarray, timeout: flo
         data = data.tobytes()
     r = subprocess.run([os.path.join(REFDIR, binary)] + list(args), input=data, capture_output=True, timeout=timeout)
     return r.stdout.decode(errors="replace"), r.stderr.decode(errors="replace"), r.returncode
+
+
+DFM_RAWHDR = b"10011010100110010101101001010101"
+
+
+def ora_dfm_decode(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, ecc=1, thres=0.65, max_lines=256, max_hits=64,
+                   want_soft=True):
+    """Oracle equivalent of `dfm09mod -r --ecc[2] --IQ fq [--lpIQ] - sr bps`: text lines + per-hit meta/soft bits."""
+    raw = np.ascontiguousarray(iq)
+    lines = C.create_string_buffer(max_lines * 96)
+    meta = np.zeros((max_hits, 4), np.float64)
+    soft = np.zeros((max_hits, 2224), np.float32) if want_soft else None
+    nh = C.c_int(0)
+    L = lib()
+    L.ora_dfm_decode.restype = C.c_int
+    n = L.ora_dfm_decode(_buf(raw), C.c_size_t(raw.nbytes), sr, bps, iq_mode, C.c_double(fq), 1 if lp_iq else 0, ecc,
+                         C.c_float(thres), max_lines, lines, max_hits, _buf(meta), _buf(soft) if want_soft else None, C.byref(nh))
+    if n < 0:
+        raise RuntimeError("ora_dfm_decode failed")
+    out = [lines.raw[i * 96:(i + 1) * 96].split(b"\0")[0].decode() for i in range(n)]
+    h = nh.value
+    return dict(n=n, lines=out, nhits=h, mv=meta[:h, 0], mv_pos=meta[:h, 1].astype(np.int64), nbits=meta[:h, 2].astype(np.int64),
+                s_in_after=meta[:h, 3].astype(np.int64), soft=None if soft is None else soft[:h])

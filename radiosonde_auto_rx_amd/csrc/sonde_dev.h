@@ -60,6 +60,7 @@ struct SyncArgs {
     int n_ch, ring_len, max_frames; uint32_t avail;
     int K, L, delay, hdrlen, symhd, symlen, hdmax, bitofs, nbits; uint32_t frame_samples;
     float sps, thres, l_win;
+    int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
 };
 

@@ -104,7 +104,7 @@ const char *sonde_strerror(int code) {
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || cfg->bits != 16) return SONDE_E_ARG;
-    if (cfg->sonde_type != SONDE_RS41 || cfg->opt_dc) return SONDE_E_ARG;
+    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09) || cfg->opt_dc) return SONDE_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
         fprintf(stderr, "libsonde_hip: no usable HIP device (the engine has no CPU fallback)\n");
@@ -116,10 +116,19 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     const int C = cfg->n_channels;
 
     // ---- sonde preset (rs41mod.c:2591-2597,2812-2836,2882,2920-2923)
-    e->baud = 4800.f; e->bt = 0.5f; e->hmod = 0.6f; e->symlen = 1; e->symhd = 1; e->hdmax = 4; e->bitofs = 2;
-    e->nbits = 510 * 8; e->hdrlen = 64; e->l_win = 2.0f;
-    e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
-    const int lpiq_bw = cfg->lpiq_bw > 0 ? cfg->lpiq_bw : 7400, lpfm_bw = 6000;
+    std::string header;
+    int lpiq_def, lpfm_bw;
+    if (cfg->sonde_type == SONDE_RS41) {
+        e->baud = 4800.f; e->bt = 0.5f; e->hmod = 0.6f; e->symlen = 1; e->symhd = 1; e->hdmax = 4; e->bitofs = 2;
+        e->nbits = 510 * 8; e->l_win = 2.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
+        header = kRs41Header; lpiq_def = 7400; lpfm_bw = 6000;
+    } else {   // DFM06/09 (dfm09mod.c:1309-1312,1560-1582,1690-1694): 264 + 7*280 Manchester bits per header hit
+        e->baud = 2500.f; e->bt = 0.5f; e->hmod = 1.8f; e->symlen = 2; e->symhd = 2; e->hdmax = 2; e->bitofs = 2;
+        e->nbits = 264 + 7 * 280; e->l_win = 4.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.65f;
+        header = kDfmRawHeader; lpiq_def = 12000; lpfm_bw = 4000;
+    }
+    e->hdrlen = (int)header.size();
+    const int lpiq_bw = cfg->lpiq_bw > 0 ? cfg->lpiq_bw : lpiq_def;
 
     // ---- init_buffers() arithmetic (demod_mod.c:1208-1474)
     e->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);
@@ -142,7 +151,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         int taps = (int)(4 * sr / 2e3); if (taps % 2 == 0) taps++;
         e->w_fm = design_lowpass(f_lp, taps);
     }
-    e->match = design_match(std::string(kRs41Header), e->sps, e->bt);
+    e->match = design_match(header, e->sps, e->bt);
     const int L = (int)e->match.size();
     int M = 3 * L, p2 = 1;
     const int delay = L / 16;
@@ -154,7 +163,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     { uint32_t q0, q1; double mid; bit_window(e->nbits - 1, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1; }
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
-    int ring = 1; while (ring < max_if + 65536 || ring < 4 * M) ring <<= 1;
+    int ring = 1; while (ring < max_if + (int)e->frame_samples + 2 * M + 4096 || ring < 4 * M) ring <<= 1;
     e->ring_len = ring;
     e->max_frames = cfg->max_frames > 0 ? cfg->max_frames : 4 * C;
 
@@ -187,7 +196,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     bad |= dalloc(&e->d_y, (size_t)C * ring); bad |= dalloc(&e->d_ifiq, (size_t)C * ring);
     bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring);
     bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1);
-    if (cfg->keep_soft) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
+    if (cfg->keep_soft || cfg->sonde_type != SONDE_RS41) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
     bad |= dalloc(&e->d_match, L, false);
     if (!e->w_iq.empty()) bad |= dalloc(&e->d_wiq, e->w_iq.size(), false);
     if (!e->w_fm.empty()) bad |= dalloc(&e->d_wfm, e->w_fm.size(), false);
@@ -198,7 +207,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (e->d_wfm) HIPCHK(hipMemcpy(e->d_wfm, e->w_fm.data(), e->w_fm.size() * sizeof(float), hipMemcpyHostToDevice));
     {
         uint8_t cb[1024]; memset(cb, 0, sizeof cb);
-        memcpy(cb, kRs41Header, 64); memcpy(cb + 64, kRs41HeaderBytes, 8); memcpy(cb + 72, kRs41Mask, 64);
+        memcpy(cb, header.data(), header.size()); memcpy(cb + 64, kRs41HeaderBytes, 8); memcpy(cb + 72, kRs41Mask, 64);
         memcpy(cb + 136, gf_exp_table(), 512); memcpy(cb + 648, gf_log_table(), 256);
         HIPCHK(hipMemcpy(e->d_consts, cb, sizeof cb, hipMemcpyHostToDevice));
     }
@@ -210,9 +219,9 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
             std::vector<int> key;                                     // (left, right) neighbour relative to the own bit
             bool ok = true;
             for (int k = 0; k < nsym && ok; k++) {
-                const int b = (kRs41Header[k] & 1) ? 1 : -1;
-                const int l = (k > 0) ? ((kRs41Header[k - 1] & 1) ? 1 : -1) * b : 0;
-                const int r = (k < nsym - 1) ? ((kRs41Header[k + 1] & 1) ? 1 : -1) * b : 0;
+                const int b = (header[k] & 1) ? 1 : -1;
+                const int l = (k > 0) ? ((header[k - 1] & 1) ? 1 : -1) * b : 0;
+                const int r = (k < nsym - 1) ? ((header[k + 1] & 1) ? 1 : -1) * b : 0;
                 const int ky = (l + 1) * 3 + (r + 1);
                 int t = -1;
                 for (size_t q = 0; q < key.size(); q++) if (key[q] == ky) t = (int)q;
@@ -316,7 +325,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
 static void launch_framesync_impl(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
-    s.eof = eof;
+    s.eof = eof; s.rs41 = (e->cfg.sonde_type == SONDE_RS41);
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
@@ -348,7 +357,7 @@ int sonde_engine_sync(sonde_engine_t *e) {
 }
 
 int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
-    if (!e || !out || max < 0) return SONDE_E_ARG;
+    if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_RS41) return SONDE_E_ARG;
     unsigned cnt = 0;
     HIPCHK(hipMemcpyAsync(&cnt, e->d_fcount, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -389,6 +398,49 @@ int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max
         memcpy(keepf, f.frame, 518);
     }
     e->last_n = n;
+    const bool ovf = e->overflow; e->overflow = false;
+    return ovf ? SONDE_E_OVERFLOW : n;
+}
+
+int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish) {
+    if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_DFM09) return SONDE_E_ARG;
+    if (finish) launch_framesync(e, 1);
+    unsigned cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, e->d_fcount, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    if (cnt > (unsigned)e->max_frames) { e->overflow = true; cnt = (unsigned)e->max_frames; }
+    const int nh = (int)cnt;
+    std::vector<FrameRec> recs((size_t)nh);
+    std::vector<float> soft((size_t)nh * e->nbits);
+    if (nh) {
+        HIPCHK(hipMemcpy(recs.data(), e->d_frames, (size_t)nh * sizeof(FrameRec), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(soft.data(), e->d_soft, soft.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemsetAsync(e->d_fcount, 0, sizeof(unsigned), e->stream));
+    e->last_soft = soft; e->last_n = nh;
+    int n = 0;
+    for (int h = 0; h < nh; h++) {
+        const FrameRec &r = recs[h];
+        const float *sb = soft.data() + (size_t)h * e->nbits;
+        // frame 0 of a hit holds bits 16..279 (the header was consumed by the correlator), then 7 x 280 (dfm09mod.c:1652-1717)
+        for (int f = 0; f < 8 && n < max; f++) {
+            const int first = f == 0 ? 0 : 264 + 280 * (f - 1), skip = f == 0 ? 16 : 0;
+            if (first + (280 - skip) > r.nbytes) break;           // nbytes = valid bits of the hit; partial frame is dropped
+            uint8_t hb[280]; float sf[280];
+            memset(hb, 0, sizeof hb); memset(sf, 0, sizeof sf);
+            for (int i = skip; i < 280; i++) {
+                const int b = first + i - skip;
+                hb[i] = (r.frame[b >> 3] >> (b & 7)) & 1; sf[i] = sb[b];
+            }
+            sonde_dfm_frame_t &o = out[n++];
+            memset(&o, 0, sizeof o);
+            o.channel = r.channel; o.frame_in_hit = f; o.mv = r.mv; o.mv_pos = r.mv_pos;
+            o.ecc[0] = dfm_block(e->cfg.ecc_level, hb + 16, sf + 16, 7, o.conf);
+            o.ecc[1] = dfm_block(e->cfg.ecc_level, hb + 72, sf + 72, 13, o.dat1);
+            o.ecc[2] = dfm_block(e->cfg.ecc_level, hb + 176, sf + 176, 13, o.dat2);
+        }
+    }
     const bool ovf = e->overflow; e->overflow = false;
     return ovf ? SONDE_E_OVERFLOW : n;
 }

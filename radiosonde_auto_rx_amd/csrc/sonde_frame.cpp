@@ -179,9 +179,72 @@ int rs41_ecc(uint8_t frame[518], int frmlen, int level, const uint8_t *synd) {
     return e1 + e2;
 }
 
+
+// ---- DFM: Hamming(8,4), systematic generator / parity check of dfm09mod.c:181-195; de-interleave :231
+const char kDfmRawHeader[33] = "10011010100110010101101001010101";
+
+static void dfm_codeword(int n, uint8_t *c) {
+    const uint8_t d[4] = { (uint8_t)((n >> 3) & 1), (uint8_t)((n >> 2) & 1), (uint8_t)((n >> 1) & 1), (uint8_t)(n & 1) };
+    c[0] = d[0]; c[1] = d[1]; c[2] = d[2]; c[3] = d[3];
+    c[4] = d[1] ^ d[2] ^ d[3]; c[5] = d[0] ^ d[2] ^ d[3]; c[6] = d[0] ^ d[1] ^ d[3]; c[7] = d[0] ^ d[1] ^ d[2];
+}
+
+// one 8-bit codeword: returns 0 clean, j+1 = bit j fixed, -1 uncorrectable (then ecc level 2 picks, among the
+// codewords at distance 2, the one best correlated with the soft bits — dfm09mod.c:262-307)
+static int dfm_check(int level, uint8_t hb[8], const float sb[8]) {
+    static const uint8_t Hm[4][8] = { {0,1,1,1,1,0,0,0}, {1,0,1,1,0,1,0,0}, {1,1,0,1,0,0,1,0}, {1,1,1,0,0,0,0,1} };
+    static const uint8_t He[8] = { 0x7, 0xB, 0xD, 0xE, 0x8, 0x4, 0x2, 0x1 };
+    unsigned syn = 0;
+    for (int i = 0; i < 4; i++) { uint8_t s = 0; for (int j = 0; j < 8; j++) s ^= Hm[i][j] & hb[j]; syn = (syn << 1) | s; }
+    if (!syn) return 0;
+    for (int j = 0; j < 8; j++) if (syn == He[j]) { hb[j] ^= 1; return j + 1; }
+    if (level == 2) {
+        int best = -1; float bestsum = 0.0f;
+        for (int n = 0; n < 16; n++) {
+            uint8_t c[8]; int d = 0;
+            dfm_codeword(n, c);
+            for (int i = 0; i < 8; i++) d += (hb[i] != c[i]);
+            if (d != 2) continue;
+            float sum = 0.0f;
+            for (int i = 0; i < 8; i++) sum += (2 * c[i] - 1) * sb[i];
+            if (sum >= bestsum) { bestsum = sum; best = n; }
+        }
+        if (best >= 0) dfm_codeword(best, hb);
+    }
+    return -1;
+}
+
+// str: L*8 interleaved bits of one block (hard + soft) -> L nibbles; return value as hamming() of the reference
+int dfm_block(int level, const uint8_t *hb, const float *sb, int L, uint8_t *nib) {
+    int ret = 0;
+    for (int i = 0; i < L; i++) {
+        uint8_t c[8]; float s[8];
+        for (int j = 0; j < 8; j++) { c[j] = hb[L * j + i]; s[j] = sb[L * j + i]; }
+        if (level) {
+            const int e = dfm_check(level, c, s);
+            if (e > 0) ret |= (1 << i);
+            if (e < 0) ret |= e;
+        }
+        nib[i] = (uint8_t)((c[0] << 3) | (c[1] << 2) | (c[2] << 1) | c[3]);
+    }
+    return ret;
+}
+
 }  // namespace sonde
 
 extern "C" {
+int sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, size_t buflen) {
+    if (!f || !buf || buflen < 96) return SONDE_E_ARG;
+    const uint8_t *blk[3] = { f->conf, f->dat1, f->dat2 };
+    const int len[3] = { 7, 13, 13 };
+    int n = 0;
+    for (int b = 0; b < 3; b++) {
+        if (b) n += snprintf(buf + n, buflen - n, "  ");
+        for (int i = 0; i < len[b]; i++) n += snprintf(buf + n, buflen - n, "%01X", blk[b][i]);
+        if (ecc_level) n += snprintf(buf + n, buflen - n, f->ecc[b] == 0 ? " [OK] " : f->ecc[b] > 0 ? " [KO] " : " [NO] ");
+    }
+    return n;
+}
 int sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen) {
     if (!f || !buf || buflen < (size_t)(2 * f->len + 16)) return SONDE_E_ARG;
     int n = 0;

@@ -33,5 +33,8 @@ int  rs41_frametype(const uint8_t *frame);
 // rs41_ecc() of the reference for ecc levels 1/2; synd = device syndromes of the first pass or nullptr
 int  rs41_ecc(uint8_t frame[518], int frmlen, int level, const uint8_t *synd);
 
+extern const char kDfmRawHeader[33];
+int  dfm_block(int level, const uint8_t *hb, const float *sb, int L, uint8_t *nib);
+
 }  // namespace sonde
 #endif

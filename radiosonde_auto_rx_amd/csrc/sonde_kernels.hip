@@ -563,9 +563,9 @@ void k_framesync(const SyncArgs a) {
             slot = __shfl(slot, 0);
             const bool keep = slot < (unsigned)a.max_frames;
             FrameRec *rec = a.frames + (keep ? slot : 0);
-            for (int k = lane; k < 520; k += WAVE) s_frame[k] = (k < 8) ? a.hdr_bytes[k] : 0;
+            for (int k = lane; k < 520; k += WAVE) s_frame[k] = (a.rs41 && k < 8) ? a.hdr_bytes[k] : 0;
             __syncthreads();
-            int nbytes_ok = 0;
+            int nbytes_ok = 0, nbits_ok = 0;
             for (int it = 0; it * WAVE < a.nbits; it++) {
                 const int bp = it * WAVE + lane;
                 double sum = 0.0;
@@ -591,10 +591,16 @@ void k_framesync(const SyncArgs a) {
                 if (keep && a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
                 nbytes_ok += __popcll(vm & 0x8080808080808080ULL);
                 if (lane < 8) {
-                    const int bi = 8 + it * 8 + lane;                  // frame byte index (LSB-first bits, rs41mod.c:224)
-                    if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
-                        s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
+                    if (a.rs41) {
+                        const int bi = 8 + it * 8 + lane;              // frame byte index (LSB-first bits, rs41mod.c:224)
+                        if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
+                            s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
+                    } else {
+                        const int bi = it * 8 + lane;                  // other sondes: hard bits packed LSB-first, framed on the host
+                        if (bi < 520) s_frame[bi] = (uint8_t)(((bal & vm) >> (8 * lane)) & 0xff);
+                    }
                 }
+                nbits_ok += __popcll(vm);
             }
             __syncthreads();
             // frame length from the type byte (rs41mod.c:407-415,2488-2490)
@@ -602,7 +608,7 @@ void k_framesync(const SyncArgs a) {
             const int flen = (ft >= 0) ? 320 : 518;
             // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732)
             uint8_t syn = 0;
-            if (lane < 48) {
+            if (a.rs41 && lane < 48) {
                 const int cw = lane / 24, jx = lane % 24;
                 const uint8_t x = s_exp[jx];
                 // Horner from the highest coefficient: cw[254] ... cw[24] (message), cw[23..0] (parity)
@@ -616,7 +622,7 @@ void k_framesync(const SyncArgs a) {
             if (keep) {
                 for (int k = lane; k < 518; k += WAVE) rec->frame[k] = s_frame[k];
                 if (lane < 48) rec->synd[lane] = syn;
-                if (lane == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = flen; rec->nbytes = 8 + nbytes_ok; }
+                if (lane == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok; }
             }
             __syncthreads();
             if (!enough) { st.mode = 2; st.s_in = avail; break; }

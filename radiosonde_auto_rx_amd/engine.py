@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsonde_hip.so")
 
 SONDE_RS41 = 41
+SONDE_DFM09 = 9
 LP_IQ, LP_FM = 1, 2
 TAP_DECIM, TAP_IFIQ, TAP_FM, TAP_BUFS, TAP_CORR = range(5)
 ABI_VERSION = 1
@@ -30,6 +31,11 @@ class SondeCfg(C.Structure):
 class SondeFrame(C.Structure):
     _fields_ = [("channel", C.c_int32), ("len", C.c_int32), ("ecc", C.c_int32), ("mv_pos", C.c_uint32),
                 ("mv", C.c_float), ("nbytes", C.c_int32), ("frame", C.c_uint8 * 518), ("pad", C.c_uint8 * 2)]
+
+
+class SondeDfmFrame(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("frame_in_hit", C.c_int32), ("ecc", C.c_int32 * 3), ("mv_pos", C.c_uint32),
+                ("mv", C.c_float), ("conf", C.c_uint8 * 7), ("dat1", C.c_uint8 * 13), ("dat2", C.c_uint8 * 13), ("pad", C.c_uint8 * 3)]
 
 
 class SondeInfo(C.Structure):
@@ -65,6 +71,8 @@ def lib() -> C.CDLL:
         L.sonde_engine_fetch_frames.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
         L.sonde_engine_finish.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
         L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.sonde_engine_fetch_dfm.argtypes = [C.c_void_p, C.POINTER(SondeDfmFrame), C.c_int32, C.c_int32]
+        L.sonde_dfm_rawline.argtypes = [C.POINTER(SondeDfmFrame), C.c_int, C.c_char_p, C.c_size_t]
         L.sonde_engine_read_tap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
         L.sonde_engine_sync.argtypes = [C.c_void_p]
         L.sonde_engine_samples_to_dc_boundary.argtypes = [C.c_void_p]
@@ -94,11 +102,14 @@ class Engine:
 
     def __init__(self, fq, sample_rate: int, *, device: int = 0, lp_iq: bool = True, lp_fm: bool = False,
                  ecc: int = 2, thres: float = 0.0, max_chunk: int | None = None, max_frames: int = 0,
-                 keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False):
+                 keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False,
+                 sonde: str = "rs41"):
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
         self.n_channels = len(fq)
         self.sample_rate = sample_rate
-        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, 16, SONDE_RS41,
+        self.sonde = sonde
+        self.ecc = ecc
+        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, 16, SONDE_RS41 if sonde == "rs41" else SONDE_DFM09,
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft))
         h = C.c_void_p()
@@ -107,7 +118,7 @@ class Engine:
         info = SondeInfo()
         _chk(lib().sonde_engine_info(h, C.byref(info)))
         self.info = {n: getattr(info, n) for n, _ in SondeInfo._fields_ if n != "reserved"}
-        self.nbits = 4080
+        self.nbits = 4080 if sonde == "rs41" else 2224
         self._max_frames = max_frames or 4 * self.n_channels
 
     def close(self):
@@ -152,6 +163,24 @@ class Engine:
             _chk(lib().sonde_engine_fetch_soft(self._h, soft.ctypes.data_as(C.c_void_p), k))
             for i in range(k):
                 frames[i]["soft"] = soft[i].copy()
+        return frames
+
+    def fetch_dfm(self, finish: bool = False, with_soft: bool = False):
+        """DFM engines: decoded frames (dicts with the `dfm09mod -r` text line); with_soft adds per-hit soft bits."""
+        n = 8 * self._max_frames
+        buf = (SondeDfmFrame * n)()
+        k = _chk(lib().sonde_engine_fetch_dfm(self._h, buf, n, int(finish)))
+        line = C.create_string_buffer(128)
+        frames = []
+        for i in range(k):
+            f = buf[i]
+            ll = lib().sonde_dfm_rawline(C.byref(f), self.ecc, line, 128)
+            frames.append(dict(channel=f.channel, frame_in_hit=f.frame_in_hit, ecc=list(f.ecc), mv=f.mv, mv_pos=f.mv_pos,
+                               line=line.raw[:ll].decode()))
+        if with_soft:
+            soft = np.zeros((self._max_frames, self.nbits), np.float32)
+            nh = _chk(lib().sonde_engine_fetch_soft(self._h, soft.ctypes.data_as(C.c_void_p), self._max_frames))
+            return frames, soft[:nh]
         return frames
 
     FRAME_DTYPE = np.dtype([("channel", "<i4"), ("len", "<i4"), ("ecc", "<i4"), ("mv_pos", "<u4"), ("mv", "<f4"),

@@ -236,3 +236,70 @@ def snap_fq(fq: float, sr: int) -> float:
     demod_mod.c:1265-1288) so the reference mixes with exactly this frequency."""
     hz = int(round(fq * sr / 16.0)) * 16
     return hz / sr
+
+
+# --------------------------------------------------------------------------
+# DFM09: 2500 Bd Manchester GFSK, 280-bit frames (16 header + 56 conf + 2 x 104 data), Hamming(8,4),
+# bit-interleaved blocks (reference demod/mod/dfm09mod.c:141-142 header, :181-195 G/H, :231 deinterleave)
+# --------------------------------------------------------------------------
+DFM_HEADER_BITS = "0100010111001111"       # 0x45CF
+
+
+def _hamming84(nib: int) -> list[int]:
+    d = [(nib >> 3) & 1, (nib >> 2) & 1, (nib >> 1) & 1, nib & 1]          # big endian nibble
+    return d + [d[1] ^ d[2] ^ d[3], d[0] ^ d[2] ^ d[3], d[0] ^ d[1] ^ d[3], d[0] ^ d[1] ^ d[2]]
+
+
+def _dfm_block(nibbles) -> list[int]:
+    L = len(nibbles)
+    cw = [_hamming84(n) for n in nibbles]
+    out = [0] * (8 * L)
+    for j in range(8):                      # transmitted order: str[L*j + i] = bit j of codeword i
+        for i in range(L):
+            out[L * j + i] = cw[i][j]
+    return out
+
+
+def dfm_frame_bits(conf_nibbles, dat1_nibbles, dat2_nibbles) -> np.ndarray:
+    assert len(conf_nibbles) == 7 and len(dat1_nibbles) == 13 and len(dat2_nibbles) == 13
+    bits = [int(c) for c in DFM_HEADER_BITS] + _dfm_block(conf_nibbles) + _dfm_block(dat1_nibbles) + _dfm_block(dat2_nibbles)
+    return np.array(bits, dtype=np.uint8)
+
+
+def dfm_capture(sr: int = 480_000, seconds: float = 3.0, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.01,
+                seed: int = 1, bit_errors_per_frame: int = 0, dev_hz: float = 2400.0, t_first: float = 0.1,
+                return_frames: bool = False):
+    """Continuous DFM09 transmission starting at t_first: back-to-back 280-bit frames, Manchester (1 -> 01, 0 -> 10)."""
+    rng = np.random.default_rng(seed)
+    n = int(round(sr * seconds))
+    nfr = int((seconds - t_first) * 2500.0 / 560.0)
+    frames, allbits = [], []
+    for k in range(nfr):
+        conf = [int(v) for v in rng.integers(0, 16, 7)]
+        d1 = [int(v) for v in rng.integers(0, 16, 13)]
+        d2 = [int(v) for v in rng.integers(0, 16, 13)]
+        d1[12] = k % 9                       # data block id nibble
+        fb = dfm_frame_bits(conf, d1, d2)
+        if bit_errors_per_frame:
+            pos = rng.choice(np.arange(16, 280), size=bit_errors_per_frame, replace=False)
+            fb = fb.copy(); fb[pos] ^= 1
+        frames.append((conf, d1, d2))
+        allbits.append(fb)
+    bits = np.concatenate(allbits)
+    sym = np.empty(2 * len(bits), dtype=np.uint8)
+    sym[0::2] = 1 - bits                     # bit 1 -> symbols 0,1 ; bit 0 -> symbols 1,0
+    sym[1::2] = bits
+    burst = gfsk_baseband(sym, sr, 2500.0, dev_hz, bt=0.5)
+    x = np.zeros(n, dtype=np.complex128)
+    s0 = int(round(t_first * sr))
+    m = min(len(burst), n - s0)
+    x[s0:s0 + m] = amp * burst[:m]
+    if fq != 0.0:
+        x *= np.exp(2j * np.pi * fq * np.arange(n))
+    x += noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    if return_frames:
+        return out, frames
+    return out

@@ -26,3 +26,12 @@ def capture(name):
 
 def rms(a):
     return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64))))) if np.size(a) else 0.0
+
+
+DFM_NAMES = list(make_golden.DFM_CASES)
+
+
+@functools.lru_cache(maxsize=4)
+def dfm_capture(name):
+    x, fq, ecc = make_golden.dfm_capture(make_golden.DFM_CASES[name])
+    return x, fq, make_golden.DFM_CASES[name]["sr"], ecc

@@ -10,7 +10,7 @@ Tolerances (stated per SURVEY.md §7/§8c and BASELINE.json):
 """
 import numpy as np
 import pytest
-from golden_cases import NAMES, load, capture, rms
+from golden_cases import NAMES, DFM_NAMES, load, capture, dfm_capture, rms
 
 pytestmark = pytest.mark.gpu
 
@@ -140,3 +140,45 @@ def test_cli_rs41mod_matches_reference_lines():
         assert r.returncode == 0, r.stderr
         assert r.stdout.decode().splitlines() == g["lines"], name
         assert r.stderr.decode().splitlines()[:2] == ["IF: %d" % g["consts"]["if_sr"], "dec: %d" % g["consts"]["decM"]]
+
+
+@pytest.mark.parametrize("name", DFM_NAMES)
+def test_dfm_frames_match_golden_and_oracle(oracle, name):
+    """DFM09 (`dfm09mod -r --ecc[2] --IQ fq --lpIQ`): same GPU front-end, Manchester slicing, host Hamming decode."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    g = load(name)
+    x, fq, sr, ecc = dfm_capture(name)
+    eng = Engine([fq], sr, sonde="dfm", ecc=ecc, max_chunk=sr, max_frames=16)
+    D = eng.info["decM"]
+    n = len(x) // 2
+    lines, hits_soft, hit_pos = [], [], []
+    for pos in range(0, n, sr):
+        take = min(sr, n - pos) // D * D
+        if take <= 0:
+            break
+        eng.process_host(x[2 * pos:2 * (pos + take)])
+        fr, soft = eng.fetch_dfm(with_soft=True, finish=(pos + take >= n - D))
+        lines += [f["line"] for f in fr]
+        hit_pos += sorted(set(f["mv_pos"] for f in fr))
+        hits_soft += list(soft)
+    o = oracle.ora_dfm_decode(x, sr, fq=fq, ecc=ecc)
+    assert [l.rstrip() for l in lines] == [l.rstrip() for l in o["lines"]] == [l.rstrip() for l in g["lines"]]
+    assert hit_pos == [int(v) for v in g["mv_pos"]]
+    for h, s in enumerate(hits_soft):
+        nb = int(o["nbits"][h])
+        d = rms(s[:nb] - o["soft"][h][:nb])
+        assert d < 1e-4 and d <= 3 * float(g["floor_soft"]) + 1e-6, d
+    eng.close()
+
+
+def test_cli_dfm09mod_matches_reference_lines():
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "host")])
+    for name in DFM_NAMES:
+        g = load(name)
+        x, fq, sr, ecc = dfm_capture(name)
+        r = subprocess.run([os.path.join(root, "host", "bin", "dfm09mod"), "-r", "--ecc2" if ecc == 2 else "--ecc", "--IQ", repr(fq),
+                            "--lpIQ", "-", str(sr), "16"], input=x.tobytes(), capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert [l.rstrip() for l in r.stdout.decode().splitlines()] == [l.rstrip() for l in g["lines"]], name

@@ -8,7 +8,7 @@ and with the shipping -Ofast build at 3x that build's own fast-math self-noise (
 """
 import numpy as np
 import pytest
-from golden_cases import NAMES, load, capture, rms
+from golden_cases import NAMES, DFM_NAMES, load, capture, dfm_capture, rms
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -79,3 +79,16 @@ def test_crc_kat(oracle):
     # std zero block 76 11 00x17 -> CRC EC C7 (rs41mod.c:1752-1756)
     p = (C.c_ubyte * 17)(*([0] * 17))
     assert oracle.lib().ora_crc16(p, 17) == 0xC7EC
+
+
+@pytest.mark.parametrize("name", DFM_NAMES)
+def test_oracle_dfm_matches_golden(oracle, name):
+    """DFM09 framer (Manchester slicer, de-interleave, Hamming(8,4) incl. soft 2-bit pass) vs reference dfm09mod."""
+    g = load(name)
+    x, fq, sr, ecc = dfm_capture(name)
+    o = oracle.ora_dfm_decode(x, sr, fq=fq, ecc=ecc)
+    assert [l.rstrip() for l in o["lines"]] == [l.rstrip() for l in g["lines"]]
+    assert list(o["mv_pos"]) == list(g["mv_pos"]) and list(o["nbits"]) == list(g["nbits"])
+    for h in range(o["nhits"]):
+        nb = int(o["nbits"][h])
+        assert rms(o["soft"][h][:nb] - g["soft"][h][:nb]) < 1e-7

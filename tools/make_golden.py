@@ -28,6 +28,20 @@ CASES = {
 }
 
 
+DFM_CASES = {
+    "dfm_480k_clean": dict(sr=480_000, seconds=3.0, fq=0.05, noise_sigma=0.01, seed=5, ecc=1),
+    "dfm_2400k_be3": dict(sr=2_400_000, seconds=2.6, fq=-0.17, noise_sigma=0.08, bit_errors_per_frame=3, seed=6, ecc=1),
+    "dfm_480k_be6_ecc2": dict(sr=480_000, seconds=4.2, fq=0.21, noise_sigma=0.05, bit_errors_per_frame=6, seed=7, ecc=2),
+}
+
+
+def dfm_capture(kw):
+    kw = dict(kw); ecc = kw.pop("ecc")
+    sr = kw["sr"]
+    kw["fq"] = synth.snap_fq(kw["fq"], sr)
+    return synth.dfm_capture(**kw), kw["fq"], ecc
+
+
 def rms(a):
     return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64))))) if np.size(a) else 0.0
 
@@ -66,6 +80,19 @@ def main():
                 d["floor_" + k] = rms(sf[k] - ss[k])
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "frames", len(lines), [l[-10:] for l in lines], "mv", strict["mv"], "floor_soft", d["floor_soft"])
+    for name, kw in DFM_CASES.items():
+        x, fq, ecc = dfm_capture(kw)
+        sr = kw["sr"]
+        out, err, rc = bind.ref_run("dfm09mod", ["-r", "--ecc2" if ecc == 2 else "--ecc", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], x)
+        lines = out.splitlines()
+        par = dict(fq=fq, baud=2500.0, h=1.8, lpiq_bw=12000, lpfm_bw=4000, hdr=bind.DFM_RAWHDR, symlen=2, symhd=2,
+                   thres=0.65, hdmax=2, bitofs=2, l=4.0, nbits=2224)
+        fast = bind.ref_softframes(x, sr, **par)
+        strict = bind.ref_softframes(x, sr, libname="libref_demod_O2.so", **par)
+        d = dict(lines=np.array(lines), mv=strict["mv"], mv_pos=strict["mv_pos"], nbits=strict["nbits"], soft=strict["soft"],
+                 floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]), fq=fq, ecc=ecc)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
+        print(name, "lines", len(lines), "hits", strict["n"], strict["mv_pos"], strict["nbits"], "floor_soft", d["floor_soft"])
 
 
 if __name__ == "__main__":
