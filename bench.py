@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=int(os.environ.get("SONDE_BENCH_CHANNELS", "512")), help="channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lag", type=int, default=0, help="1 = pipelined frame fetch (see step())")
     args = ap.parse_args()
 
     import torch
@@ -134,9 +135,12 @@ def main():
         lead += n
     eng.fetch_frames_np()
 
-    def step():
+    def step(lag=args.lag):
+        # lag = 0: every step waits for its own frames (kernel times below are then un-overlapped and the roofline
+        # figure of k_mix_decimate is clean).  lag = 1 pipelines: the IF-rate kernels of call k (stream B) overlap the
+        # decimator of call k+1 (stream A) — ~4 % more throughput, but per-kernel event times include the overlap.
         eng.process_device(iq.data_ptr(), SR, SR)
-        frames = eng.fetch_frames_np()                                    # sync + D2H of frame records + host RS ECC
+        frames = eng.fetch_frames_np(lag=lag)                             # D2H of frame records + host RS ECC
         if world > 1:                                                     # per-channel detection summaries over RCCL
             summary.copy_(torch.from_numpy(shard.summarize(frames, C)))
             shard.gather_summaries(dist, summary, world)
@@ -144,6 +148,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    eng.fetch_frames_np(lag=0)
     eng.profile(True)
     if world > 1:
         dist.barrier()
@@ -154,6 +159,9 @@ def main():
         fr = step()
         nframes += len(fr)
         nok += int((fr["ecc"] >= 0).sum())
+    fr = eng.fetch_frames_np(lag=0)                                       # drain: all work of the K steps is inside the timed region
+    nframes += len(fr)
+    nok += int((fr["ecc"] >= 0).sum())
     eng.sync()
     torch.cuda.synchronize()
     if world > 1:

@@ -127,6 +127,11 @@ int  sonde_engine_sync(sonde_engine_t *e);
  * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
  * Returns the number of frames written (<= max). */
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
+/* Pipelined variant: return only the frames of process calls issued at least `lag` calls ago and wait only for those.
+ * With lag = 1 the IF-rate kernels of call k (stream B) overlap the decimator of call k+1 (stream A); lag = 0 is
+ * sonde_engine_fetch_frames().  Frames are never lost: what is not returned stays queued. */
+int  sonde_engine_fetch_frames_lagged(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int32_t lag);
+
 /* DFM engines: frames completed so far (syncs; Hamming decode of dfm09mod.c:240-345 on the host).  cfg.ecc_level 0/1/2
  * = none / --ecc / --ecc2 (soft 2-bit pass).  finish != 0: end of input, also emits the complete frames of a hit
  * in progress (a partial frame is dropped like dfm09mod.c:1713). */

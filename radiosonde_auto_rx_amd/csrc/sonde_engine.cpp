@@ -30,7 +30,12 @@ struct PendingEvt { hipEvent_t a, b; const char *name; };
 struct sonde_engine {
     sonde_cfg_t cfg{};
     sonde_info_t info{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // A: input staging, k_mix_decimate, k_dc_update
+    hipStream_t stream_b = nullptr;    // B: IF chain, header correlation, framesync (may overlap the next call's A work)
+    hipEvent_t ev_a[4] = {}, ev_b[4] = {};
+    unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
+    int64_t call = 0;                  // process calls issued
+    unsigned read_idx = 0;             // frames already handed to the caller (monotonic)
     // design
     Decimator dec; int Q = 0, G = 8;
     std::vector<float> w_iq, w_fm, match, wtab;
@@ -67,14 +72,14 @@ template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
     return 0;
 }
 
-static void prof_begin(sonde_engine *e, const char *name) {
+static void prof_begin(sonde_engine *e, const char *name, hipStream_t s) {
     if (!e->prof) return;
     PendingEvt p; p.name = name;
     hipEventCreate(&p.a); hipEventCreate(&p.b);
-    hipEventRecord(p.a, e->stream);
+    hipEventRecord(p.a, s);
     e->pend.push_back(p);
 }
-static void prof_end(sonde_engine *e) { if (e->prof) hipEventRecord(e->pend.back().b, e->stream); }
+static void prof_end(sonde_engine *e, hipStream_t s) { if (e->prof) hipEventRecord(e->pend.back().b, s); }
 static void prof_collect(sonde_engine *e) {
     for (auto &p : e->pend) {
         float ms = 0; hipEventSynchronize(p.b); hipEventElapsedTime(&ms, p.a, p.b);
@@ -82,6 +87,38 @@ static void prof_collect(sonde_engine *e) {
         hipEventDestroy(p.a); hipEventDestroy(p.b);
     }
     e->pend.clear();
+}
+
+// Hit records completed up to `lag` process calls ago (0 = everything enqueued so far; syncs stream B fully).
+// The device frame counter is monotonic; records live in a ring of max_frames entries.
+static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs, std::vector<float> *soft, int max_take) {
+    unsigned count = 0;
+    if (lag > 0) {
+        const int64_t target = e->call - 1 - lag;
+        if (target < 0) { recs.clear(); if (soft) soft->clear(); return 0; }
+        if (hipEventSynchronize(e->ev_b[target & 3]) != hipSuccess) return SONDE_E_NOGPU;
+        count = e->h_count[target & 3];
+    } else {
+        if (hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        if (hipMemcpy(&count, e->d_fcount, sizeof count, hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        prof_collect(e);
+    }
+    unsigned n = count - e->read_idx;
+    if (n > (unsigned)e->max_frames) { e->overflow = true; e->read_idx = count - (unsigned)e->max_frames; n = (unsigned)e->max_frames; }
+    if (max_take >= 0 && n > (unsigned)max_take) n = (unsigned)max_take;     // the rest stays queued for the next fetch
+    recs.resize(n);
+    if (soft) soft->resize((size_t)n * e->nbits);
+    unsigned done = 0;
+    while (done < n) {
+        const unsigned idx = (e->read_idx + done) % (unsigned)e->max_frames;
+        const unsigned run = std::min<unsigned>(n - done, (unsigned)e->max_frames - idx);
+        if (hipMemcpy(recs.data() + done, e->d_frames + idx, (size_t)run * sizeof(FrameRec), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        if (soft && e->d_soft && hipMemcpy(soft->data() + (size_t)done * e->nbits, e->d_soft + (size_t)idx * e->nbits,
+                                           (size_t)run * e->nbits * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        done += run;
+    }
+    e->read_idx += n;
+    return (int)n;
 }
 
 static void launch_framesync_impl(sonde_engine *e, int eof);
@@ -251,13 +288,23 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->last_frame.assign((size_t)C * 518, 0);
     for (int c = 0; c < C; c++) memcpy(e->last_frame.data() + (size_t)c * 518, kRs41HeaderBytes, 8);
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
+    HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocDefault));
+    memset(e->h_count, 0, 4 * sizeof(unsigned));
     *out = e;
     return 0;
 }
 
 void sonde_engine_destroy(sonde_engine_t *e) {
     if (!e) return;
-    if (e->stream) { hipStreamSynchronize(e->stream); prof_collect(e); hipStreamDestroy(e->stream); }
+    if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream_b) hipStreamSynchronize(e->stream_b);
+    prof_collect(e);
+    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->stream_b) hipStreamDestroy(e->stream_b);
+    for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); }
+    if (e->h_count) hipHostFree(e->h_count);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign };
@@ -296,7 +343,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
         { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
-        prof_begin(e, "mix_decimate"); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e);
+        prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);
         if (lrc < 0) return SONDE_E_ARG;
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
@@ -312,12 +359,19 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     b.n = n_if; b.m0 = m_first;
     b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
     b.tone_on = 1; b.nwin = (int)e->sps; b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
-    prof_begin(e, "if_chain"); sonde_launch_if_chain(&b, e->stream); prof_end(e);
+    // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
+    const int slot = (int)(e->call & 3);
+    hipEventRecord(e->ev_a[slot], e->stream);
+    hipStreamWaitEvent(e->stream_b, e->ev_a[slot], 0);
+    prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b);
     CorrArgs c{};
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
     c.ntypes = e->corr_types; c.isps = e->corr_isps; c.nsym = e->hdrlen / e->symhd; c.shapes = e->d_shapes; c.sym_type = e->d_symtype; c.sym_sign = e->d_symsign;
-    prof_begin(e, "header_corr"); sonde_launch_header_corr(&c, e->stream); prof_end(e);
+    prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
     launch_framesync(e, 0);
+    hipMemcpyAsync(e->h_count + slot, e->d_fcount, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream_b);
+    hipEventRecord(e->ev_b[slot], e->stream_b);
+    e->call += 1;
     if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
     return 0;
 }
@@ -332,7 +386,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
     s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
-    prof_begin(e, "framesync"); sonde_launch_framesync(&s, e->stream); prof_end(e);
+    prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }
 
 int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples) {
@@ -352,25 +406,16 @@ int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_st
 int sonde_engine_sync(sonde_engine_t *e) {
     if (!e) return SONDE_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream_b));
     prof_collect(e);
     return 0;
 }
 
-int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
+static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int lag) {
     if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_RS41) return SONDE_E_ARG;
-    unsigned cnt = 0;
-    HIPCHK(hipMemcpyAsync(&cnt, e->d_fcount, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    prof_collect(e);
-    if (cnt > (unsigned)e->max_frames) { e->overflow = true; cnt = (unsigned)e->max_frames; }
-    const int n = (int)std::min<unsigned>(cnt, (unsigned)max);
-    std::vector<FrameRec> recs((size_t)n);
-    if (n) HIPCHK(hipMemcpy(recs.data(), e->d_frames, (size_t)n * sizeof(FrameRec), hipMemcpyDeviceToHost));
-    if (e->d_soft) {
-        e->last_soft.resize((size_t)n * e->nbits);
-        if (n) HIPCHK(hipMemcpy(e->last_soft.data(), e->d_soft, e->last_soft.size() * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    HIPCHK(hipMemsetAsync(e->d_fcount, 0, sizeof(unsigned), e->stream));
+    std::vector<FrameRec> recs;
+    const int n = collect_records(e, lag, recs, e->d_soft ? &e->last_soft : nullptr, max);
+    if (n < 0) return n;
     for (int i = 0; i < n; i++) {
         const FrameRec &r = recs[i];
         sonde_frame_t &f = out[i];
@@ -402,22 +447,19 @@ int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max
     return ovf ? SONDE_E_OVERFLOW : n;
 }
 
+int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) { return fetch_rs41(e, out, max, 0); }
+
+int sonde_engine_fetch_frames_lagged(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int32_t lag) {
+    return fetch_rs41(e, out, max, lag < 0 ? 0 : lag);
+}
+
 int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish) {
     if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_DFM09) return SONDE_E_ARG;
     if (finish) launch_framesync(e, 1);
-    unsigned cnt = 0;
-    HIPCHK(hipMemcpyAsync(&cnt, e->d_fcount, sizeof cnt, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
-    prof_collect(e);
-    if (cnt > (unsigned)e->max_frames) { e->overflow = true; cnt = (unsigned)e->max_frames; }
-    const int nh = (int)cnt;
-    std::vector<FrameRec> recs((size_t)nh);
-    std::vector<float> soft((size_t)nh * e->nbits);
-    if (nh) {
-        HIPCHK(hipMemcpy(recs.data(), e->d_frames, (size_t)nh * sizeof(FrameRec), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(soft.data(), e->d_soft, soft.size() * sizeof(float), hipMemcpyDeviceToHost));
-    }
-    HIPCHK(hipMemsetAsync(e->d_fcount, 0, sizeof(unsigned), e->stream));
+    std::vector<FrameRec> recs;
+    std::vector<float> soft;
+    const int nh = collect_records(e, 0, recs, &soft, max / 8);
+    if (nh < 0) return nh;
     e->last_soft = soft; e->last_n = nh;
     int n = 0;
     for (int h = 0; h < nh; h++) {
@@ -461,6 +503,7 @@ int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) 
 int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64_t first, int32_t count, float *out) {
     if (!e || !out || channel < 0 || channel >= e->cfg.n_channels || count < 0 || count > e->ring_len || first < 0) return SONDE_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream_b));
     prof_collect(e);
     const void *base; size_t esz;
     switch (tap) {
@@ -485,14 +528,14 @@ int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64
 
 int sonde_engine_profile(sonde_engine_t *e, int enable) {
     if (!e) return SONDE_E_ARG;
-    (void)hipStreamSynchronize(e->stream); prof_collect(e);
+    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); prof_collect(e);
     e->prof = enable != 0; e->stats.clear();
     return 0;
 }
 
 int sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches) {
     if (!e || !kernel) return SONDE_E_ARG;
-    (void)hipStreamSynchronize(e->stream); prof_collect(e);
+    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); prof_collect(e);
     auto it = e->stats.find(kernel);
     if (it == e->stats.end() || it->second.n == 0) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return 0; }
     if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;

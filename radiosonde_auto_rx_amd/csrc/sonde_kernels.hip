@@ -561,8 +561,9 @@ void k_framesync(const SyncArgs a) {
             unsigned slot = 0;
             if (lane == 0) slot = atomicAdd(a.frame_count, 1u);
             slot = __shfl(slot, 0);
-            const bool keep = slot < (unsigned)a.max_frames;
-            FrameRec *rec = a.frames + (keep ? slot : 0);
+            slot %= (unsigned)a.max_frames;                            // monotonic counter, ring of records (host tracks its read index)
+            const bool keep = true;
+            FrameRec *rec = a.frames + slot;
             for (int k = lane; k < 520; k += WAVE) s_frame[k] = (a.rs41 && k < 8) ? a.hdr_bytes[k] : 0;
             __syncthreads();
             int nbytes_ok = 0, nbits_ok = 0;

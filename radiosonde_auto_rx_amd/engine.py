@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
         L.sonde_engine_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_engine_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_engine_fetch_frames.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
+        L.sonde_engine_fetch_frames_lagged.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32, C.c_int32]
         L.sonde_engine_finish.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_int32]
         L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_engine_fetch_dfm.argtypes = [C.c_void_p, C.POINTER(SondeDfmFrame), C.c_int32, C.c_int32]
@@ -186,13 +187,14 @@ class Engine:
     FRAME_DTYPE = np.dtype([("channel", "<i4"), ("len", "<i4"), ("ecc", "<i4"), ("mv_pos", "<u4"), ("mv", "<f4"),
                             ("nbytes", "<i4"), ("frame", "u1", (518,)), ("pad", "u1", (2,))])
 
-    def fetch_frames_np(self, max_frames: int | None = None) -> np.ndarray:
-        """Frames completed so far as one structured array (layout of sonde_frame_t); no per-frame Python work."""
+    def fetch_frames_np(self, max_frames: int | None = None, lag: int = 0) -> np.ndarray:
+        """Frames completed so far as one structured array (layout of sonde_frame_t); no per-frame Python work.
+        lag = 1: only frames of calls before the latest one (lets the latest call's GPU work keep running)."""
         n = max_frames or self._max_frames
         if getattr(self, "_fbuf", None) is None or len(self._fbuf) < n:
             self._fbuf = np.zeros(n, self.FRAME_DTYPE)
-        k = _chk(lib().sonde_engine_fetch_frames(self._h, self._fbuf.ctypes.data_as(C.POINTER(SondeFrame)), n))
-        return self._fbuf[:k]
+        k = _chk(lib().sonde_engine_fetch_frames_lagged(self._h, self._fbuf.ctypes.data_as(C.POINTER(SondeFrame)), n, lag))
+        return self._fbuf[:k].copy()
 
     def read_tap(self, channel: int, tap: int, first: int, count: int) -> np.ndarray:
         width = 2 if tap in (TAP_DECIM, TAP_IFIQ) else 1
