@@ -123,7 +123,7 @@ def main():
     del bank_t
     torch.cuda.synchronize()
 
-    eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C)
+    eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=args.lag > 0)
     summary = torch.zeros(C, 4, device=dev)
 
     # Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): one

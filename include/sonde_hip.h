@@ -67,7 +67,9 @@ typedef struct {
     int32_t max_chunk;       /* largest n_samples per process call (per channel)              */
     int32_t max_frames;      /* frame queue capacity between two fetches (0 = 4*n_channels)   */
     int32_t keep_soft;       /* keep per-frame soft bits for the soft-bit fetch call (testing)       */
-    int32_t reserved[5];
+    int32_t pipeline;        /* 1: IF-rate kernels on a second HIP stream so that sonde_engine_fetch_frames_lagged(lag=1)
+                              * overlaps them with the next call's decimator; 0: one in-order stream             */
+    int32_t reserved[4];
 } sonde_cfg_t;
 
 /* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */

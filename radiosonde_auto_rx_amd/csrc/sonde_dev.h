@@ -33,19 +33,21 @@ struct IfArgs {
     float sps;
 };
 
+struct SyncState {
+    uint32_t s_in, k, mv_pos, mode;
+    float mv; uint32_t pad[3];
+};
+
 struct CorrArgs {
     const float *bufs; float *corr; const float *match;
+    const SyncState *state;   // per-channel sync state for skipping tiles no window can reach (nullptr = compute all)
+    int delay; uint32_t frame_samples;
     int n_ch, ring_len, n, L; uint32_t m0;
     // factorised form (integer samples/symbol): ntypes == 0 selects the direct L-tap kernel
     int ntypes, isps, nsym;
     const float *shapes;      // [ntypes][isps]
     const int *sym_type;      // [nsym]
     const float *sym_sign;    // [nsym]
-};
-
-struct SyncState {
-    uint32_t s_in, k, mv_pos, mode;
-    float mv; uint32_t pad[3];
 };
 
 struct FrameRec {

@@ -34,8 +34,10 @@ struct sonde_engine {
     hipStream_t stream_b = nullptr;    // B: IF chain, header correlation, framesync (may overlap the next call's A work)
     hipEvent_t ev_a[4] = {}, ev_b[4] = {};
     unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
+    FrameRec *h_recs = nullptr;        // pinned staging for record fetches
     int64_t call = 0;                  // process calls issued
     unsigned read_idx = 0;             // frames already handed to the caller (monotonic)
+    bool eof_pending = false;          // an end-of-stream framesync ran after the last counter snapshot
     // design
     Decimator dec; int Q = 0, G = 8;
     std::vector<float> w_iq, w_fm, match, wtab;
@@ -100,7 +102,9 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
         count = e->h_count[target & 3];
     } else {
         if (hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
-        if (hipMemcpy(&count, e->d_fcount, sizeof count, hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        if (e->call > 0 && !e->eof_pending) count = e->h_count[(e->call - 1) & 3];       // snapshot taken by the last process call
+        else if (hipMemcpy(&count, e->d_fcount, sizeof count, hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        e->eof_pending = false;
         prof_collect(e);
     }
     unsigned n = count - e->read_idx;
@@ -112,17 +116,19 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
     while (done < n) {
         const unsigned idx = (e->read_idx + done) % (unsigned)e->max_frames;
         const unsigned run = std::min<unsigned>(n - done, (unsigned)e->max_frames - idx);
-        if (hipMemcpy(recs.data() + done, e->d_frames + idx, (size_t)run * sizeof(FrameRec), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
-        if (soft && e->d_soft && hipMemcpy(soft->data() + (size_t)done * e->nbits, e->d_soft + (size_t)idx * e->nbits,
-                                           (size_t)run * e->nbits * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        if (hipMemcpyAsync(e->h_recs + done, e->d_frames + idx, (size_t)run * sizeof(FrameRec), hipMemcpyDeviceToHost, e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        if (soft && e->d_soft && hipMemcpyAsync(soft->data() + (size_t)done * e->nbits, e->d_soft + (size_t)idx * e->nbits,
+                                                (size_t)run * e->nbits * sizeof(float), hipMemcpyDeviceToHost, e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
         done += run;
     }
+    if (n && hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+    if (n) memcpy(recs.data(), e->h_recs, (size_t)n * sizeof(FrameRec));
     e->read_idx += n;
     return (int)n;
 }
 
 static void launch_framesync_impl(sonde_engine *e, int eof);
-static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); }
+static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); if (eof) e->eof_pending = true; }
 
 extern "C" {
 
@@ -288,10 +294,12 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->last_frame.assign((size_t)C * 518, 0);
     for (int c = 0; c < C; c++) memcpy(e->last_frame.data() + (size_t)c * 518, kRs41HeaderBytes, 8);
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+    if (cfg->pipeline) HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+    else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
     for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
     HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocDefault));
     memset(e->h_count, 0, 4 * sizeof(unsigned));
+    HIPCHK(hipHostMalloc((void **)&e->h_recs, (size_t)e->max_frames * sizeof(FrameRec), hipHostMallocDefault));
     *out = e;
     return 0;
 }
@@ -301,10 +309,11 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_b) hipStreamSynchronize(e->stream_b);
     prof_collect(e);
-    if (e->stream) hipStreamDestroy(e->stream);
-    if (e->stream_b) hipStreamDestroy(e->stream_b);
+    { hipStream_t sa = e->stream; if (sa) hipStreamDestroy(sa); }
+    if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
     for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); }
     if (e->h_count) hipHostFree(e->h_count);
+    if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign };
@@ -361,11 +370,14 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     b.tone_on = 1; b.nwin = (int)e->sps; b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);
-    hipEventRecord(e->ev_a[slot], e->stream);
-    hipStreamWaitEvent(e->stream_b, e->ev_a[slot], 0);
+    if (e->stream_b != e->stream) {
+        hipEventRecord(e->ev_a[slot], e->stream);
+        hipStreamWaitEvent(e->stream_b, e->ev_a[slot], 0);
+    }
     prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b);
     CorrArgs c{};
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
+    c.state = e->d_state; c.delay = e->info.delay; c.frame_samples = e->frame_samples;
     c.ntypes = e->corr_types; c.isps = e->corr_isps; c.nsym = e->hdrlen / e->symhd; c.shapes = e->d_shapes; c.sym_type = e->d_symtype; c.sym_sign = e->d_symsign;
     prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
     launch_framesync(e, 0);

@@ -316,6 +316,20 @@ void k_if_chain(const IfArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_header_corr: c[p] = sum_u match[u] * bufs[p-(L-1)+u]   for p in [m0, m0+n)
 // ------------------------------------------------------------------------------------------------
+// The reference correlates only while find_header() runs: not during the nbits a framer slices after a hit, and a
+// window only reaches back K+delay samples.  The channel's sync state (left by the previous k_framesync) gives the
+// first end position any future window can examine; correlation tiles entirely below it are skipped.
+__device__ __forceinline__ bool corr_tile_unused(const CorrArgs &a, int ch, uint32_t tile_end) {
+    if (!a.state) return false;
+    const SyncState st = a.state[ch];
+    uint32_t first;                                           // earliest candidate end position of the next window
+    if (st.mode == 1) first = st.mv_pos + 1 + a.frame_samples;                  // s_in_after - delay (frame in progress)
+    else if (st.mode == 0) first = st.s_in - st.k;                              // window start of the running search
+    else return true;                                                           // stream finished
+    first -= (uint32_t)(a.delay + 16);
+    return (int32_t)(tile_end - first) <= 0;
+}
+
 #define HC_TILE 1024
 #define HC_THREADS 256
 
@@ -326,6 +340,7 @@ void k_header_corr(const CorrArgs a) {
     const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HC_TILE;
     const int nout = min(HC_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
     if (nout <= 0) return;
+    if (corr_tile_unused(a, ch, p0 + (uint32_t)nout)) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     float *sx = smem;                 // [HC_TILE + L - 1]
     float *sm = smem + HC_TILE + L;   // [L]
@@ -368,6 +383,7 @@ void k_header_corr_fact(const CorrArgs a) {
     const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HCF_TILE;
     const int nout = min(HCF_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
     if (nout <= 0) return;
+    if (corr_tile_unused(a, ch, p0 + (uint32_t)nout)) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const int nx = HCF_TILE + L - 1;                 // samples p0-(L-1) .. p0+HCF_TILE-1
     const int nf = (HCF_TILE + sps * (nsym - 1) + 3) & ~3;   // F entries per type (multiple of 4)
