@@ -66,7 +66,7 @@ typedef struct {
     float   thres;           /* --ths, header score threshold (0 = type default)              */
     int32_t max_chunk;       /* largest n_samples per process call (per channel)              */
     int32_t max_frames;      /* frame queue capacity between two fetches (0 = 4*n_channels)   */
-    int32_t keep_soft;       /* keep per-frame soft bits for the soft-bit fetch call (testing)       */
+    int32_t keep_soft;       /* testing: keep per-frame soft bits (soft-bit fetch call) and the IFIQ / FM tap streams */
     int32_t pipeline;        /* 1: IF-rate kernels on a second HIP stream so that sonde_engine_fetch_frames_lagged(lag=1)
                               * overlaps them with the next call's decimator; 0: one in-order stream             */
     int32_t reserved[4];

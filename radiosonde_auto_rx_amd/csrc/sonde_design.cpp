@@ -126,4 +126,17 @@ void bit_window(int pos, int half, int symlen, float sps, uint32_t &q0, uint32_t
     if (q1 <= q0) q1 = q0 + 1;
 }
 
+// Range [qa, qb) of consumed-sample counts a symbol half actually sums: q in [q0, q1) with mid-l < q < mid+l
+// (everything for l < 0) — the `if (l < 0 || (mid-l < dsp->sc && dsp->sc < mid+l))` of read_softbit2p.
+void slice_range(uint32_t q0, uint32_t q1, double mid, float l, uint32_t &qa, uint32_t &qb) {
+    qa = q0; qb = q1;
+    if (!(l < 0.f)) {
+        const double lo = mid - (double)l, hi = mid + (double)l;
+        const double fa = std::floor(lo) + 1.0, fb = std::ceil(hi);      // smallest q > lo, smallest q >= hi
+        if (fa > (double)qa) qa = (uint32_t)fa;
+        if (fb < (double)qb) qb = (fb > 0.0) ? (uint32_t)fb : 0u;
+    }
+    if (qb < qa) qb = qa;
+}
+
 }  // namespace sonde

@@ -28,6 +28,7 @@ struct IfArgs {
     const float2 *y; float2 *tap_ifiq; float *fm; float *bufs;
     int n_ch, ring_len, n; uint32_t m0;
     int lpiq_on, lpiq_taps, lpfm_on, lpfm_taps, tone_on, nwin;
+    int fm_on;                // FM discriminator stream wanted (sliced stream of FM modes, --lpFM, taps); off = tone path only
     const float *w_iq, *w_fm;
     double rho;               // tone phase advance per IF sample, revolutions
     float sps;
@@ -59,6 +60,8 @@ struct FrameRec {
 struct SyncArgs {
     const float *bufs, *corr; SyncState *state; FrameRec *frames; unsigned *frame_count; float *soft;
     const uint8_t *hdr, *hdr_bytes, *mask, *gf_exp, *gf_log;
+    const uint4 *bitwin;      // [nbits] consumed-sample ranges of every bit: {first half (Manchester) qa,qb, main half qa,qb}
+    const uint32_t *bitend;   // [nbits] consumed samples after the bit
     int n_ch, ring_len, max_frames; uint32_t avail;
     int K, L, delay, hdrlen, symhd, symlen, hdmax, bitofs, nbits; uint32_t frame_samples;
     float sps, thres, l_win;

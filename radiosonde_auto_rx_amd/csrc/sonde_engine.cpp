@@ -53,6 +53,7 @@ struct sonde_engine {
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr;
+    uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
     uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
     int16_t *d_stage = nullptr; size_t stage_bytes = 0;
     int ring_len = 0, max_frames = 0;
@@ -287,6 +288,24 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
             }
         }
     }
+    // ---- per-bit slicing ranges (position independent): read_softbit2p's double-edge / integer-counter walk, tabulated
+    {
+        std::vector<uint32_t> win((size_t)e->nbits * 4), end(e->nbits);
+        for (int bp = 0; bp < e->nbits; bp++) {
+            uint32_t q0, q1, qa, qb; double mid;
+            if (e->symlen == 2) { bit_window(bp, 0, 2, e->sps, q0, q1, mid); slice_range(q0, q1, mid, e->l_win, qa, qb); }
+            else { qa = qb = 0; }
+            win[4 * bp] = qa; win[4 * bp + 1] = qb;
+            bit_window(bp, e->symlen - 1, e->symlen, e->sps, q0, q1, mid);
+            slice_range(q0, q1, mid, e->l_win, qa, qb);
+            win[4 * bp + 2] = qa; win[4 * bp + 3] = qb; end[bp] = q1;
+        }
+        bad = 0;
+        bad |= dalloc(&e->d_bitwin, (size_t)e->nbits, false); bad |= dalloc(&e->d_bitend, (size_t)e->nbits, false);
+        if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+        HIPCHK(hipMemcpy(e->d_bitwin, win.data(), win.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_bitend, end.data(), end.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     // IQ-DC segment schedule (demod_mod.c:1351-1357)
     e->dc_lim = (uint32_t)sr; e->dc_max = e->dc_lim / 32;
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
@@ -316,7 +335,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
-                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign };
+                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -364,10 +383,12 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     }
     const int n_if = n_samples / D;
     IfArgs b{};
-    b.y = e->d_y; b.tap_ifiq = e->d_ifiq; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
+    b.y = e->d_y; b.tap_ifiq = e->cfg.keep_soft ? e->d_ifiq : nullptr; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
     b.n = n_if; b.m0 = m_first;
     b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
-    b.tone_on = 1; b.nwin = (int)e->sps; b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
+    b.tone_on = 1; b.nwin = (int)e->sps;
+    b.fm_on = (e->cfg.keep_soft || !e->w_fm.empty()) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
+    b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);
     if (e->stream_b != e->stream) {
@@ -394,6 +415,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.eof = eof; s.rs41 = (e->cfg.sonde_type == SONDE_RS41);
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
+    s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
     s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;

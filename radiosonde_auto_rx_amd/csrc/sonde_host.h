@@ -16,6 +16,7 @@ struct Mixer { double f0 = 0; int lut_len = 1; };
 Mixer design_mixer(double xlt_fq, int sr_base);
 std::vector<float> design_match(const std::string &hdr, float sps, float bt);
 void bit_window(int pos, int half, int symlen, float sps, uint32_t &q0, uint32_t &q1, double &mid);
+void slice_range(uint32_t q0, uint32_t q1, double mid, float l, uint32_t &qa, uint32_t &qb);
 
 // GF(2^8)/0x11D, alpha = 2
 const uint8_t *gf_exp_table();   // 512 entries

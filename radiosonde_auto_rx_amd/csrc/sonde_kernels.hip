@@ -243,41 +243,70 @@ void k_if_chain(const IfArgs a) {
     const int hz = (T2 - 1) + max(1, nwin - 1);       // history of z' needed
     const int nz = hz + nout;                         // z' count
     const int ny = nz + (T1 - 1);                     // y count
-    float2 *sy = reinterpret_cast<float2 *>(smem);            // [ny]
-    float2 *sz = sy + ny;                                      // [nz]   z'[t0 - hz + k]
-    float2 *sx = sz + nz;                                      // [nz]   tone phasor e^{+i 2 pi m rho}
-    float  *sf = reinterpret_cast<float *>(sx + nz);           // [T2-1+nout] raw s_fm
+    const int nyp = (ny + 8 + 1) & ~1;                         // padded: the 4-output groups read a little past ny
+    float2 *sy = reinterpret_cast<float2 *>(smem);            // [nyp]
+    float2 *sz = sy + nyp;                                     // [nz]   z'[t0 - hz + k]
+    float2 *sx = sz + nz;                                      // [nz]   X1 = z' * e^{+i 2 pi m rho}
+    float2 *sx2 = sx + nz;                                     // [nz]   X2 = z' * e^{-i 2 pi m rho}
+    float  *sf = reinterpret_cast<float *>(sx2 + nz);          // [T2-1+nout] raw s_fm
     float  *wq = sf + (T2 - 1 + nout);                         // [T1]
     float  *wf = wq + T1;                                      // [T2]
 
     const float2 *yr = a.y + (size_t)ch * a.ring_len;
-    for (int k = threadIdx.x; k < ny; k += IF_THREADS) {
+    for (int k = threadIdx.x; k < nyp; k += IF_THREADS) {
         const int64_t m = (int64_t)t0 - hz - (T1 - 1) + k;     // absolute IF index, may be < 0 at stream start
-        sy[k] = (m >= 0) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
+        sy[k] = (m >= 0 && k < ny) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
     }
     for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? a.w_iq[k] : 1.0f;
     for (int k = threadIdx.x; k < T2; k += IF_THREADS) wf[k] = a.lpfm_on ? a.w_fm[k] : 1.0f;
     __syncthreads();
 
-    // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648)
-    for (int k = threadIdx.x; k < nz; k += IF_THREADS) {
-        float re = 0.f, im = 0.f;
-#pragma unroll 7
-        for (int t = 0; t < T1; t++) { const float2 v = sy[k + t]; const float w = wq[t]; re = fmaf(v.x, w, re); im = fmaf(v.y, w, im); }
-        const int64_t m = (int64_t)t0 - hz + k;
-        if (m < 0) { re = 0.f; im = 0.f; }
-        sz[k] = make_float2(re, im);
-        // tone mixer e^{-i t w1}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
-        const double rev = (double)m * a.rho;
-        const float fr = (float)(rev - floor(rev));
-        float sn, cs; sincospif(2.0f * fr, &sn, &cs);
-        // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470)
-        sx[k] = make_float2(cs, sn);
-        if (a.tap_ifiq && m >= (int64_t)t0) a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
+    // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648).
+    // 4 consecutive outputs per thread with a sliding register window: one 16-byte LDS read per 2 taps;
+    // the tone phasors e^{+-i 2 pi m rho} are applied once per sample here (X1, X2), not once per window term.
+    for (int k0 = 4 * threadIdx.x; k0 < nz; k0 += 4 * IF_THREADS) {
+        float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
+        float2 win[6];
+        { const float4 v0 = *reinterpret_cast<const float4 *>(sy + k0), v1 = *reinterpret_cast<const float4 *>(sy + k0 + 2);
+          win[0] = make_float2(v0.x, v0.y); win[1] = make_float2(v0.z, v0.w); win[2] = make_float2(v1.x, v1.y); win[3] = make_float2(v1.z, v1.w); }
+        for (int t = 0; t + 1 < T1; t += 2) {
+            const float4 nv = *reinterpret_cast<const float4 *>(sy + k0 + t + 4);
+            win[4] = make_float2(nv.x, nv.y); win[5] = make_float2(nv.z, nv.w);
+            const float w0 = wq[t], w1 = wq[t + 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]);
+                ar[j] = fmaf(win[j + 1].x, w1, ar[j]); ai[j] = fmaf(win[j + 1].y, w1, ai[j]);
+            }
+            win[0] = win[2]; win[1] = win[3]; win[2] = win[4]; win[3] = win[5];
+        }
+        if (T1 & 1) {
+            const float w0 = wq[T1 - 1];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = k0 + j;
+            if (k >= nz) break;
+            float re = ar[j], im = ai[j];
+            const int64_t m = (int64_t)t0 - hz + k;
+            if (m < 0) { re = 0.f; im = 0.f; }
+            sz[k] = make_float2(re, im);
+            // tone mixer e^{-i t w}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
+            const double rev = (double)m * a.rho;
+            const float fr = (float)(rev - floor(rev));
+            const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
+            // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470)
+            sx[k] = make_float2(re * cs - im * sn, re * sn + im * cs);
+            sx2[k] = make_float2(re * cs + im * sn, im * cs - re * sn);
+            if (a.tap_ifiq && m >= (int64_t)t0) a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
+        }
     }
     __syncthreads();
 
     // FM discriminator on [-(T2-1), nout): s_fm = 0.8 * arg(z[m] * conj(z[m-1])) / pi   (demod_mod.c:771-773)
+    if (a.fm_on)
     for (int k = threadIdx.x; k < T2 - 1 + nout; k += IF_THREADS) {
         const int zi = k + (hz - (T2 - 1));            // index into sz of sample m
         const float2 z1 = sz[zi], z0 = sz[zi - 1];
@@ -295,20 +324,22 @@ void k_if_chain(const IfArgs a) {
         float f1r = 0.f, f1i = 0.f, f2r = 0.f, f2i = 0.f;
         if (a.tone_on) {
             for (int j = nwin - 1; j >= 0; j--) {
-                const float2 z = sz[hz + k - j], e = sx[hz + k - j];
-                f1r += z.x * e.x - z.y * e.y;  f1i += z.x * e.y + z.y * e.x;     // z * (cs + i sn)
-                f2r += z.x * e.x + z.y * e.y;  f2i += z.y * e.x - z.x * e.y;     // z * (cs - i sn)
+                const float2 x1 = sx[hz + k - j], x2 = sx2[hz + k - j];
+                f1r += x1.x; f1i += x1.y; f2r += x2.x; f2i += x2.y;
             }
         }
-        float s_fm = sf[T2 - 1 + k];
-        if (a.lpfm_on) {
-            float acc = 0.f;
-            for (int t = 0; t < T2; t++) acc = fmaf(sf[k + t], wf[t], acc);
-            s_fm = acc;
+        float s_fm = 0.f;
+        if (a.fm_on) {
+            s_fm = sf[T2 - 1 + k];
+            if (a.lpfm_on) {
+                float acc = 0.f;
+                for (int t = 0; t < T2; t++) acc = fmaf(sf[k + t], wf[t], acc);
+                s_fm = acc;
+            }
+            fmb[m & mask] = s_fm;
         }
         float s = s_fm;
         if (a.tone_on) s = (sqrtf(f2r * f2r + f2i * f2i) - sqrtf(f1r * f1r + f1i * f1i)) / a.sps;
-        fmb[m & mask] = s_fm;
         bufs[m & mask] = s;
     }
 }
@@ -471,6 +502,22 @@ __device__ __forceinline__ void bit_window(int pos, int half, int symlen, float 
     if (q1 <= q0) q1 = q0 + 1;
 }
 
+// Sum of the ring samples the slicer selects inside one symbol half, consumed counts q in [qa, qb), added in
+// ascending q as doubles (read_softbit2p, demod_mod.c:1139-1161).  The ranges are position independent, so the
+// host tabulates them once per engine with the reference's float/double edge arithmetic (sonde_design.cpp
+// bit_window / slice_range); all loads of a range are issued up front.
+#define SLICE_MAXW 24
+__device__ __forceinline__ double window_sum(const float *bufs, uint32_t base, uint32_t mask, uint32_t qa, uint32_t qb) {
+    float v[SLICE_MAXW];
+#pragma unroll
+    for (int j = 0; j < SLICE_MAXW; j++) v[j] = (qa + (uint32_t)j < qb) ? bufs[(base + qa + (uint32_t)j) & mask] : 0.f;
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < SLICE_MAXW; j++) if (qa + (uint32_t)j < qb) sum += (double)v[j];
+    for (uint32_t q = qa + SLICE_MAXW; q < qb; q++) sum += (double)bufs[(base + q) & mask];    // very wide symbols
+    return sum;
+}
+
 __global__ __launch_bounds__(WAVE)
 void k_framesync(const SyncArgs a) {
     __shared__ uint8_t s_frame[520];
@@ -583,41 +630,49 @@ void k_framesync(const SyncArgs a) {
             for (int k = lane; k < 520; k += WAVE) s_frame[k] = (a.rs41 && k < 8) ? a.hdr_bytes[k] : 0;
             __syncthreads();
             int nbytes_ok = 0, nbits_ok = 0;
-            for (int it = 0; it * WAVE < a.nbits; it++) {
-                const int bp = it * WAVE + lane;
-                double sum = 0.0;
-                bool valid = bp < a.nbits;
-                if (valid) {
-                    if (a.symlen == 2) {
-                        uint32_t q0, q1; double mid;
-                        bit_window(bp, 0, 2, a.sps, q0, q1, mid);
-                        for (uint32_t q = q0; q < q1; q++)
-                            if (a.l_win < 0.f || (mid - (double)a.l_win < (double)q && (double)q < mid + (double)a.l_win))
-                                sum -= (double)bufs[(base + q) & mask];
+            // 8 bit-groups (512 bits) per pass: all their ring loads are issued before the first sum is needed
+#ifdef FS_SKIP_SLICE
+            for (int it0 = 0; it0 * WAVE < 512; it0 += 8) {
+#else
+            for (int it0 = 0; it0 * WAVE < a.nbits; it0 += 8) {
+#endif
+                double sums[8]; bool valids[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int bp = (it0 + u) * WAVE + lane;
+                    double sum = 0.0;
+                    bool valid = bp < a.nbits;
+                    if (valid) {
+                        const uint4 w = a.bitwin[bp];                  // {qa-, qb-, qa+, qb+}
+                        valid = (int32_t)a.bitend[bp] <= q_lim;
+                        if (valid) {
+                            if (w.y > w.x) sum = 0.0 - window_sum(bufs, base, mask, w.x, w.y);
+                            sum += window_sum(bufs, base, mask, w.z, w.w);
+                        }
                     }
-                    uint32_t q0, q1; double mid;
-                    bit_window(bp, a.symlen - 1, a.symlen, a.sps, q0, q1, mid);
-                    valid = (int32_t)q1 <= q_lim;
-                    if (valid)
-                        for (uint32_t q = q0; q < q1; q++)
-                            if (a.l_win < 0.f || (mid - (double)a.l_win < (double)q && (double)q < mid + (double)a.l_win))
-                                sum += (double)bufs[(base + q) & mask];
+                    sums[u] = sum; valids[u] = valid;
                 }
-                const int hb = valid && (sum >= 0.0);
-                const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
-                if (keep && a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
-                nbytes_ok += __popcll(vm & 0x8080808080808080ULL);
-                if (lane < 8) {
-                    if (a.rs41) {
-                        const int bi = 8 + it * 8 + lane;              // frame byte index (LSB-first bits, rs41mod.c:224)
-                        if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
-                            s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
-                    } else {
-                        const int bi = it * 8 + lane;                  // other sondes: hard bits packed LSB-first, framed on the host
-                        if (bi < 520) s_frame[bi] = (uint8_t)(((bal & vm) >> (8 * lane)) & 0xff);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int it = it0 + u;
+                    const int bp = it * WAVE + lane;
+                    const bool valid = valids[u];
+                    const int hb = valid && (sums[u] >= 0.0);
+                    const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
+                    if (keep && a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sums[u];
+                    nbytes_ok += __popcll(vm & 0x8080808080808080ULL);
+                    if (lane < 8) {
+                        if (a.rs41) {
+                            const int bi = 8 + it * 8 + lane;          // frame byte index (LSB-first bits, rs41mod.c:224)
+                            if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
+                                s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
+                        } else {
+                            const int bi = it * 8 + lane;              // other sondes: hard bits packed LSB-first, framed on the host
+                            if (bi < 520) s_frame[bi] = (uint8_t)(((bal & vm) >> (8 * lane)) & 0xff);
+                        }
                     }
+                    nbits_ok += __popcll(vm);
                 }
-                nbits_ok += __popcll(vm);
             }
             __syncthreads();
             // frame length from the type byte (rs41mod.c:407-415,2488-2490)
@@ -625,6 +680,7 @@ void k_framesync(const SyncArgs a) {
             const int flen = (ft >= 0) ? 320 : 518;
             // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732)
             uint8_t syn = 0;
+#ifndef FS_SKIP_SYND
             if (a.rs41 && lane < 48) {
                 const int cw = lane / 24, jx = lane % 24;
                 const uint8_t x = s_exp[jx];
@@ -636,6 +692,7 @@ void k_framesync(const SyncArgs a) {
                     syn = prod ^ v;
                 }
             }
+#endif
             if (keep) {
                 for (int k = lane; k < 518; k += WAVE) rec->frame[k] = s_frame[k];
                 if (lane < 48) rec->synd[lane] = syn;
@@ -678,7 +735,7 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     const int T1 = a->lpiq_on ? a->lpiq_taps : 1, T2 = a->lpfm_on ? a->lpfm_taps : 1;
     const int hz = (T2 - 1) + (a->nwin - 1 > 1 ? a->nwin - 1 : 1);
     const int nz = hz + IF_TILE, ny = nz + T1 - 1;
-    const size_t lds = (size_t)ny * 8 + (size_t)nz * 8 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)nz * 8 + (size_t)(T1 + T2) * 4;
+    const size_t lds = (size_t)((ny + 8 + 1) & ~1) * 8 + (size_t)nz * 8 * 3 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)(T1 + T2) * 4;
     hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
