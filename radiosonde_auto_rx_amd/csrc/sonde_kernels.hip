@@ -518,12 +518,24 @@ __device__ __forceinline__ double window_sum(const float *bufs, uint32_t base, u
     return sum;
 }
 
-__global__ __launch_bounds__(WAVE)
+#define FS_THREADS 1024
+#define FS_WAVES (FS_THREADS / WAVE)
+
+// One workgroup of 16 waves per channel.  The state machine is evaluated redundantly by every thread (all
+// decisions depend only on workgroup-uniform values); the data-parallel parts — window arg-max (K+1 candidates),
+// L-sample energy, header bit check, the nbits soft bits, RS syndromes — are spread over the 1024 threads so that
+// each phase costs about one memory round trip instead of a chain of them.
+__global__ __launch_bounds__(FS_THREADS)
 void k_framesync(const SyncArgs a) {
     __shared__ uint8_t s_frame[520];
     __shared__ uint8_t s_exp[512];
     __shared__ uint8_t s_log[256];
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    __shared__ float s_rf[FS_WAVES];
+    __shared__ int s_ri[FS_WAVES];
+    __shared__ int s_cnt[2];
+    __shared__ unsigned s_slot;
+    __shared__ uint8_t s_syn[FS_WAVES][48];
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= a.n_ch) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
@@ -532,8 +544,8 @@ void k_framesync(const SyncArgs a) {
     const uint32_t avail = a.avail;            // IF samples [0, avail) exist
     const int K = a.K, L = a.L;
 
-    for (int k = lane; k < 512; k += WAVE) s_exp[k] = a.gf_exp[k];
-    for (int k = lane; k < 256; k += WAVE) s_log[k] = a.gf_log[k];
+    if (tid < 512) s_exp[tid] = a.gf_exp[tid];
+    if (tid < 256) s_log[tid] = a.gf_log[tid];
     __syncthreads();
 
     for (int guard = 0; guard < 64; guard++) {
@@ -548,34 +560,52 @@ void k_framesync(const SyncArgs a) {
             if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
             // arg-max of c^2 over end positions p = pos-K .. pos, first maximum wins (demod_mod.c:200-208)
             float best = 0.f; int bidx = -1;
-            for (int t0 = lane; t0 <= K; t0 += 8 * WAVE) {
+            {
                 float cv[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int t = t0 + u * WAVE;
+                    const int t = tid + u * FS_THREADS;
                     const int64_t p = (int64_t)pos - K + t;
                     cv[u] = (t <= K && p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const float c2 = cv[u] * cv[u];
-                    if (c2 > best) { best = c2; bidx = t0 + u * WAVE; }
+                    if (c2 > best) { best = c2; bidx = tid + u * FS_THREADS; }
+                }
+                for (int t = tid + 8 * FS_THREADS; t <= K; t += FS_THREADS) {      // K > 8191 only
+                    const int64_t p = (int64_t)pos - K + t;
+                    const float c = (p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
+                    if (c * c > best) { best = c * c; bidx = t; }
                 }
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
                 if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
             }
+            if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
+            __syncthreads();
+            best = 0.f; bidx = -1;
+            for (int w = 0; w < FS_WAVES; w++) {
+                const float ob = s_rf[w]; const int oi = s_ri[w];
+                if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+            }
+            __syncthreads();
             if (bidx == 0 || bidx == K) continue;                      // edge value -> -4, mv = 0
             if (bidx < 0) continue;
             const uint32_t mpos = pos - (uint32_t)K + (uint32_t)bidx;
             float e = 0.f;
-            for (int t = lane; t < L; t += WAVE) {
+            for (int t = tid; t < L; t += FS_THREADS) {
                 const int64_t p = (int64_t)mpos - t;
                 const float v = (p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
                 e = fmaf(v, v, e);
             }
             e = wave_sum(e);
+            if (lane == 0) s_rf[wave] = e;
+            __syncthreads();
+            e = 0.f;
+            for (int w = 0; w < FS_WAVES; w++) e += s_rf[w];
+            __syncthreads();
             const float mv = corr[mpos & mask] / sqrtf(e);
             const uint32_t prev = st.mv_pos;
             st.mv = mv; st.mv_pos = mpos;
@@ -585,30 +615,31 @@ void k_framesync(const SyncArgs a) {
             int errs = 0;
             const int nsym = a.hdrlen / a.symhd;
             const uint32_t mvp = mpos + 1 - (uint32_t)L;
-            for (int p = lane; p < ((nsym + WAVE - 1) / WAVE) * WAVE; p += WAVE) {
-                int e1 = 0;
-                if (p < nsym) {
-                    double edge = (double)((float)(p * a.symhd) * a.sps);
-                    uint32_t cnt = (uint32_t)ceil(edge);
-                    double sum = 0.0;
+            for (int p = tid; p < nsym; p += FS_THREADS) {
+                double edge = (double)((float)(p * a.symhd) * a.sps);
+                uint32_t cnt = (uint32_t)ceil(edge);
+                double sum = 0.0;
+                edge += (double)a.sps;
+                do { sum += (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
+                if (a.symhd == 2) {
                     edge += (double)a.sps;
-                    do { sum += (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
-                    if (a.symhd == 2) {
-                        edge += (double)a.sps;
-                        do { sum -= (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
-                    }
-                    const int sign = mv < 0 ? 1 : 0;
-                    if (a.symhd == 1) {
-                        const int bit = (sum >= 0) ? 1 : 0;
-                        e1 = ((bit ^ sign) != (a.hdr[p] & 1));
-                    } else {
-                        const int b0 = (sum >= 0) ? 1 : 0, b1 = 1 - b0;
-                        e1 = ((b0 ^ sign) != (a.hdr[2 * p] & 1)) + ((b1 ^ sign) != (a.hdr[2 * p + 1] & 1));
-                    }
+                    do { sum -= (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
                 }
-                errs += e1;
+                const int sign = mv < 0 ? 1 : 0;
+                if (a.symhd == 1) {
+                    const int bit = (sum >= 0) ? 1 : 0;
+                    errs += ((bit ^ sign) != (a.hdr[p] & 1));
+                } else {
+                    const int b0 = (sum >= 0) ? 1 : 0, b1 = 1 - b0;
+                    errs += ((b0 ^ sign) != (a.hdr[2 * p] & 1)) + ((b1 ^ sign) != (a.hdr[2 * p + 1] & 1));
+                }
             }
             for (int off = 32; off > 0; off >>= 1) errs += __shfl_xor(errs, off);
+            if (lane == 0) s_ri[wave] = errs;
+            __syncthreads();
+            errs = 0;
+            for (int w = 0; w < FS_WAVES; w++) errs += s_ri[w];
+            __syncthreads();
             if (errs > a.hdmax) continue;
             if (mv < 0.f) continue;                     // rs41mod.c:2888-2891 without -i / --auto
             st.mode = 1;
@@ -621,89 +652,73 @@ void k_framesync(const SyncArgs a) {
             // needs IF sample mv_pos+delay+1+q, so only bits ending at q1 <= q_lim exist
             const int32_t q_lim = enough ? (int32_t)a.frame_samples : (int32_t)(avail - (st.mv_pos + (uint32_t)a.delay + 1));
             const uint32_t base = st.mv_pos + 1 + (uint32_t)a.bitofs;
-            unsigned slot = 0;
-            if (lane == 0) slot = atomicAdd(a.frame_count, 1u);
-            slot = __shfl(slot, 0);
-            slot %= (unsigned)a.max_frames;                            // monotonic counter, ring of records (host tracks its read index)
-            const bool keep = true;
-            FrameRec *rec = a.frames + slot;
-            for (int k = lane; k < 520; k += WAVE) s_frame[k] = (a.rs41 && k < 8) ? a.hdr_bytes[k] : 0;
+            if (tid == 0) { s_slot = atomicAdd(a.frame_count, 1u) % (unsigned)a.max_frames; s_cnt[0] = 0; s_cnt[1] = 0; }
+            if (tid < 520) s_frame[tid] = (a.rs41 && tid < 8) ? a.hdr_bytes[tid] : 0;
             __syncthreads();
-            int nbytes_ok = 0, nbits_ok = 0;
-            // 8 bit-groups (512 bits) per pass: all their ring loads are issued before the first sum is needed
-#ifdef FS_SKIP_SLICE
-            for (int it0 = 0; it0 * WAVE < 512; it0 += 8) {
-#else
-            for (int it0 = 0; it0 * WAVE < a.nbits; it0 += 8) {
-#endif
-                double sums[8]; bool valids[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int bp = (it0 + u) * WAVE + lane;
-                    double sum = 0.0;
-                    bool valid = bp < a.nbits;
+            const unsigned slot = s_slot;                              // monotonic counter, ring of records
+            FrameRec *rec = a.frames + slot;
+            for (int p0 = 0; p0 < a.nbits; p0 += FS_THREADS) {
+                const int bp = p0 + tid;
+                double sum = 0.0;
+                bool valid = bp < a.nbits;
+                if (valid) {
+                    const uint4 w = a.bitwin[bp];                      // {qa-, qb-, qa+, qb+}
+                    valid = (int32_t)a.bitend[bp] <= q_lim;
                     if (valid) {
-                        const uint4 w = a.bitwin[bp];                  // {qa-, qb-, qa+, qb+}
-                        valid = (int32_t)a.bitend[bp] <= q_lim;
-                        if (valid) {
-                            if (w.y > w.x) sum = 0.0 - window_sum(bufs, base, mask, w.x, w.y);
-                            sum += window_sum(bufs, base, mask, w.z, w.w);
-                        }
+                        if (w.y > w.x) sum = 0.0 - window_sum(bufs, base, mask, w.x, w.y);
+                        sum += window_sum(bufs, base, mask, w.z, w.w);
                     }
-                    sums[u] = sum; valids[u] = valid;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int it = it0 + u;
-                    const int bp = it * WAVE + lane;
-                    const bool valid = valids[u];
-                    const int hb = valid && (sums[u] >= 0.0);
-                    const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
-                    if (keep && a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sums[u];
-                    nbytes_ok += __popcll(vm & 0x8080808080808080ULL);
-                    if (lane < 8) {
-                        if (a.rs41) {
-                            const int bi = 8 + it * 8 + lane;          // frame byte index (LSB-first bits, rs41mod.c:224)
-                            if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
-                                s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
-                        } else {
-                            const int bi = it * 8 + lane;              // other sondes: hard bits packed LSB-first, framed on the host
-                            if (bi < 520) s_frame[bi] = (uint8_t)(((bal & vm) >> (8 * lane)) & 0xff);
-                        }
+                const int hb = valid && (sum >= 0.0);
+                const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
+                if (a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
+                const int it = (p0 >> 6) + wave;                       // 64-bit group index = 8 frame bytes
+                if (lane < 8) {
+                    if (a.rs41) {
+                        const int bi = 8 + it * 8 + lane;              // frame byte index (LSB-first bits, rs41mod.c:224)
+                        if (bi < 518 && ((vm >> (8 * lane + 7)) & 1ULL))
+                            s_frame[bi] = (uint8_t)((bal >> (8 * lane)) & 0xff) ^ a.mask[bi & 63];
+                    } else {
+                        const int bi = it * 8 + lane;                  // other sondes: hard bits packed LSB-first, framed on the host
+                        if (bi < 520) s_frame[bi] = (uint8_t)(((bal & vm) >> (8 * lane)) & 0xff);
                     }
-                    nbits_ok += __popcll(vm);
                 }
+                if (lane == 0) { atomicAdd(&s_cnt[0], __popcll(vm & 0x8080808080808080ULL)); atomicAdd(&s_cnt[1], __popcll(vm)); }
             }
             __syncthreads();
+            const int nbytes_ok = s_cnt[0], nbits_ok = s_cnt[1];
             // frame length from the type byte (rs41mod.c:407-415,2488-2490)
             int ft = 0; { const uint8_t b = s_frame[0x38]; for (int q = 0; q < 4; q++) ft += ((b >> q) & 1) - ((b >> (q + 4)) & 1); }
             const int flen = (ft >= 0) ? 320 : 518;
-            // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732)
-            uint8_t syn = 0;
-#ifndef FS_SKIP_SYND
+            // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732):
+            // wave c evaluates coefficients 16c..16c+15 by Horner and scales by alpha^(16 c j); XOR over the waves
             if (a.rs41 && lane < 48) {
                 const int cw = lane / 24, jx = lane % 24;
                 const uint8_t x = s_exp[jx];
-                // Horner from the highest coefficient: cw[254] ... cw[24] (message), cw[23..0] (parity)
-                for (int n = 254; n >= 0; n--) {
-                    int fi = (n >= 24) ? 56 + 2 * (n - 24) + cw : 8 + 24 * cw + n;
-                    uint8_t v = (fi < flen) ? s_frame[fi] : 0;
-                    uint8_t prod = (syn && x) ? s_exp[s_log[syn] + s_log[x]] : 0;
-                    syn = prod ^ v;
+                uint8_t hsum = 0;
+                for (int i = 15; i >= 0; i--) {
+                    const int n = 16 * wave + i;
+                    uint8_t v = 0;
+                    if (n < 255) {
+                        const int fi = (n >= 24) ? 56 + 2 * (n - 24) + cw : 8 + 24 * cw + n;
+                        v = (fi < flen) ? s_frame[fi] : 0;
+                    }
+                    const uint8_t prod = (hsum && x) ? s_exp[s_log[hsum] + s_log[x]] : 0;
+                    hsum = prod ^ v;
                 }
+                const int sh = (jx * 16 * wave) % 255;                 // alpha^(j*16c)
+                s_syn[wave][lane] = hsum ? s_exp[(s_log[hsum] + sh) % 255] : 0;
             }
-#endif
-            if (keep) {
-                for (int k = lane; k < 518; k += WAVE) rec->frame[k] = s_frame[k];
-                if (lane < 48) rec->synd[lane] = syn;
-                if (lane == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok; }
-            }
+            __syncthreads();
+            if (tid < 518) rec->frame[tid] = s_frame[tid];
+            if (a.rs41 && tid < 48) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][tid]; rec->synd[tid] = syn; }
+            if (tid == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok; }
             __syncthreads();
             if (!enough) { st.mode = 2; st.s_in = avail; break; }
             st.s_in = s_in_after; st.k = 0; st.mode = 0;
         }
     }
-    if (lane == 0) a.state[ch] = st;
+    if (tid == 0) a.state[ch] = st;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -749,5 +764,5 @@ extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
     hipLaunchKernelGGL(k_header_corr, dim3((a->n + HC_TILE - 1) / HC_TILE, a->n_ch), dim3(HC_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
-    hipLaunchKernelGGL(k_framesync, dim3(a->n_ch), dim3(WAVE), 0, s, *a);
+    hipLaunchKernelGGL(k_framesync, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
 }
