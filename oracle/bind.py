@@ -193,3 +193,52 @@ def ora_dfm_decode(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, ecc=1, thre
     h = nh.value
     return dict(n=n, lines=out, nhits=h, mv=meta[:h, 0], mv_pos=meta[:h, 1].astype(np.int64), nbits=meta[:h, 2].astype(np.int64),
                 s_in_after=meta[:h, 3].astype(np.int64), soft=None if soft is None else soft[:h])
+
+
+# ----------------------------------------------------------------------------- scanner (scan/dft_detect.c)
+class RefScanCfg(C.Structure):
+    _fields_ = [("sr", C.c_int), ("bps", C.c_int), ("opt_iq", C.c_int), ("opt_dc", C.c_int), ("opt_min", C.c_int),
+                ("fq", C.c_double), ("bw_khz", C.c_double), ("nch", C.c_int)]
+
+
+SCAN_TYPES = ("DFM9", "RS41", "RS92", "LMS6", "IMET5", "MK2LMS", "M10", "MEISEI", "RD94RD41", "MRZ", "MTS01",
+              "C34C50", "WXR301", "WXRPN9", "IMET1AB", "IMETafsk")
+
+
+def ref_scan_windows(raw, sr, *, bps=16, iq_mode=5, fq=0.0, dc=False, opt_min=False, bw_khz=0.0, max_win=256,
+                     want_fm=0):
+    """Per-window score/position/dc of every template from the reference's own getCorrDFT (dft_detect.c:357).
+
+    dft_detect.c keeps its state in file statics, so every call loads a private copy of the harness."""
+    import shutil
+    import tempfile
+    raw = np.ascontiguousarray(raw)
+    src = os.path.join(REFDIR, "libref_scan.so")
+    with tempfile.NamedTemporaryFile(suffix=".so", delete=False) as t:
+        tmp = t.name
+    shutil.copyfile(src, tmp)
+    try:
+        L = C.CDLL(tmp)
+        L.ref_scan_windows.restype = C.c_int
+        cfg = RefScanCfg(sr, bps, iq_mode, int(dc), int(opt_min), fq, bw_khz, 1)
+        mv = np.zeros((max_win, 16), np.float32)
+        mpos = np.zeros((max_win, 16), np.uint32)
+        mp = np.zeros((max_win, 16), np.int32)
+        dcs = np.zeros((max_win, 16), np.float32)
+        herrs = np.zeros((max_win, 16), np.int32)
+        m10 = np.zeros((max_win, 16), np.uint32)
+        pos = np.zeros(max_win, np.uint32)
+        consts = np.zeros(32, np.int32)
+        fm = np.zeros((4, want_fm), np.float32) if want_fm else None
+        n = L.ref_scan_windows(C.byref(cfg), _buf(raw), C.c_size_t(raw.nbytes), max_win, _buf(mv), _buf(mpos), _buf(mp),
+                               _buf(dcs), _buf(herrs), _buf(m10), _buf(pos), _buf(consts),
+                               _buf(fm) if want_fm else None, want_fm)
+    finally:
+        os.unlink(tmp)
+    if n < 0:
+        raise RuntimeError("ref_scan_windows failed: %d" % n)
+    names = ("K", "N", "delay", "M", "sr_if", "decM", "lpfm_taps", "lpiq_taps", "ntpl")
+    cd = dict(zip(names, (int(v) for v in consts[:9])))
+    cd["L"] = [int(v) for v in consts[9:25]]
+    return dict(n=n, mv=mv[:n], mpos=mpos[:n], mp=mp[:n], dc=dcs[:n], herrs=herrs[:n], m10=m10[:n], pos=pos[:n],
+                consts=cd, fm=fm)

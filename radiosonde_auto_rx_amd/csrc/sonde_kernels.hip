@@ -52,7 +52,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // cycles per wave64 instruction): v_fma_f32 3.2, v_pk_fma_f32 5.2, v_mul/add_f64 4.7, v_sin/cos_f32 10.1 — the
 // kernel is VALU-bound, so the FIR uses packed FMAs on (re, im) pairs and everything else is kept to the minimum
 // number of instructions.
-template <int Q_T, bool WRAP>
+template <int Q_T, bool WRAP, bool PH64>
 __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float *wt, float2 avg, double f0,
                                         uint32_t rown, uint32_t L, float dcmask,
                                         float2v (&acc)[Q_T], float2v &dcs) {
@@ -82,7 +82,10 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
         double nd;
         if (!WRAP) nd = nd0 + (double)r;
         else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
-        const float fr = __builtin_amdgcn_fractf((float)(f0 * nd));
+        // demod_mod.c keeps the table phase in a float (t = fl32(f0*n)); dft_detect.c:1090-1093 keeps it in a double
+        float fr;
+        if (PH64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
+        else      fr = __builtin_amdgcn_fractf((float)(f0 * nd));
         const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
         // z = u * ex[n]  (demod_mod.c:744), 4 scalar ops
         const float t1 = u.y * li, t2 = u.y * lr;
@@ -95,7 +98,7 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
     }
 }
 
-template <int Q_T>
+template <int Q_T, bool PH64>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ uint32_t smem_u[];
@@ -181,8 +184,8 @@ void k_mix_decimate(const MixDecArgs a) {
         float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if (nowrap) md_rows<Q_T, false>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
-        else        md_rows<Q_T, true>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        if (nowrap) md_rows<Q_T, false, PH64>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        else        md_rows<Q_T, true, PH64>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
         sx += (int)dcs.x; sy += (int)dcs.y;
 
         // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
@@ -731,16 +734,19 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
     const dim3 grid(((a->n_ch + 7) / 8) * 8 * wgs_per_ch), blk(256);
     const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
+#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true>), grid, blk, lds, s, b); \
+                         else hipLaunchKernelGGL((k_mix_decimate<QT, false>), grid, blk, lds, s, b); } while (0)
     switch (a->Q) {
-        case 1: hipLaunchKernelGGL((k_mix_decimate<1>), grid, blk, lds, s, b); break;
-        case 2: hipLaunchKernelGGL((k_mix_decimate<2>), grid, blk, lds, s, b); break;
-        case 3: hipLaunchKernelGGL((k_mix_decimate<3>), grid, blk, lds, s, b); break;
-        case 4: hipLaunchKernelGGL((k_mix_decimate<4>), grid, blk, lds, s, b); break;
-        case 5: hipLaunchKernelGGL((k_mix_decimate<5>), grid, blk, lds, s, b); break;
-        case 6: hipLaunchKernelGGL((k_mix_decimate<6>), grid, blk, lds, s, b); break;
-        case 7: hipLaunchKernelGGL((k_mix_decimate<7>), grid, blk, lds, s, b); break;
-        default: hipLaunchKernelGGL((k_mix_decimate<8>), grid, blk, lds, s, b); break;
+        case 1: MD_LAUNCH(1); break;
+        case 2: MD_LAUNCH(2); break;
+        case 3: MD_LAUNCH(3); break;
+        case 4: MD_LAUNCH(4); break;
+        case 5: MD_LAUNCH(5); break;
+        case 6: MD_LAUNCH(6); break;
+        case 7: MD_LAUNCH(7); break;
+        default: MD_LAUNCH(8); break;
     }
+#undef MD_LAUNCH
     return 0;
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {

@@ -1,0 +1,588 @@
+// sonde_scan.cpp — host side of the batched scanner behind include/sonde_scan.h (the reference's scan/dft_detect.c).
+//
+// Per process call, on one HIP stream:
+//   front-end (k_mix_decimate per IQ-DC segment | k_iq_convert | k_audio_convert)  ->  k_scan_if (4 FM streams)
+//   ->  k_scan_corr over the list of correlation windows that became complete  ->  decision logic on the host.
+// Sequential state of the reference and where it lives here:
+//   IQ-DC mean, fixed window sr_if/32 [* decM]  (dft_detect.c:1152-1156)   host schedule + k_dc_update
+//   FIR histories, z0 of the discriminators                                  IF-rate rings in HBM (absolute indices)
+//   k / sample_in / sample_out window counter (main, :1483-1505)             next_sin per channel
+//   mv[], mv_pos[], mv0_pos[], mv_max, j_max, rs_detect2[], mutable type/tn   Chan (host)
+// Not implemented: the IMETafsk post-processing (1 s spectrum, :1533-1607) — an IMET preamble hit is dropped like the
+// reference's "IMET1AB?" branch; N_DFT other than 8192 (IF rate above ~51 kHz, i.e. --bw > 48).
+#include "../../include/sonde_scan.h"
+#include "sonde_dev.h"
+#include "sonde_host.h"
+#include "sonde_scan_dev.h"
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace sonde;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libsonde_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return SONDE_E_NOGPU; } } while (0)
+
+namespace {
+
+struct TplDef { int baud; const char *hdr; float bt; float thres; int herrs; const char *type; int tn; int lpfm; int lpiq; };
+
+// rs_hdr[] of the reference (dft_detect.c:172-191); the header strings are the on-air sync patterns (:43-134)
+const int kNrs = 18, kIdxImetAfsk = 15;      // rows 16/17 (IMET1RS, IMET4) are only reached from the IMETafsk post-processing
+const TplDef kTpl[kNrs] = {
+    { 2500, "10011010100110010101101001010101", 1.0f, 0.65f, 2, "DFM9", 2, 0, 1 },
+    { 4800, "0000100001101101010100111000100001000100011010010100100000011111", 0.5f, 0.70f, 2, "RS41", 3, 0, 1 },
+    { 4800, "10100110011001101001" "10100110011001101001" "1010011001100110100110101010100110101001", 0.5f, 0.70f, 3, "RS92", 4, 0, 1 },
+    { 4800, "0101011000001000" "0001110010010111" "0001101010100111" "0011110100111110", 1.0f, 0.60f, 8, "LMS6", 8, 0, 1 },
+    { 4800, "0000000001" "0101010101" "0001001001" "0001001001", 0.5f, 0.80f, 2, "IMET5", 24, 0, 1 },
+    { 9616, "0010100111" "0010100111" "0001001001" "0010010101", 1.0f, 0.70f, 2, "MK2LMS", 18, 1, 2 },
+    { 9608, "1001100110010100110010011001" "1010", 1.0f, 0.76f, 2, "M10", 5, 1, 2 },
+    { 2400, "110011001101001101001101010100101010110010101010", 1.0f, 0.70f, 2, "MEISEI", 9, 0, 2 },
+    { 4800, "10100110010110101001" "10010101011010010101" "10101001010101010101" "10011001010110101001", 1.0f, 0.70f, 2, "RD94RD41", 10, 0, 1 },
+    { 2400, "1001100110011001" "1001101010101010", 1.5f, 0.80f, 2, "MRZ", 12, 0, 1 },
+    { 1200, "10101010" "10101010" "10110100" "00101011", 1.0f, 0.65f, 2, "MTS01", 13, 0, 0 },
+    { 5800, "01010101010101010101010101010101", 1.5f, 0.80f, 2, "C34C50", 15, 0, 2 },
+    { 4800, "10101010" "10101010" "10101010" "00101101" "11010100", 1.0f, 0.65f, 2, "WXR301", 16, 0, 3 },
+    { 5000, "10101010" "10101010" "10101010" "11000001" "10010100", 1.0f, 0.65f, 2, "WXRPN9", 17, 0, 3 },
+    { 9600, "0000" "11110000111100001111000011110000" "1111" "0000" "10101100110010101100101010101100" "1111", 1.0f, 0.80f, 2, "IMET1AB", 29, 1, 3 },
+    { 9600, "11110000111100001111000011110000" "11110000111100001111000011110000", 0.5f, 0.80f, 4, "IMETafsk", 25, 1, 1 },
+    { 9600, "0000" "1111" "0000" "1111" "0000" "1111" "0000" "1111", 0.5f, 0.80f, 2, "IMET1RS", 28, 0, 3 },
+    { 9600, "0000" "1111" "0000" "1111" "0000" "1111" "0000" "1111", 0.5f, 0.80f, 2, "IMET4", 26, 1, 1 },
+};
+const uint32_t kDefaultDisable = (1u << 11) | (1u << 14);       // -DNOC34C50 -DNOIMET1AB (scan/Makefile:1)
+
+// The reference's own transform (dft_raw, dft_detect.c:285-322): radix-2 decimation in time with the stage twiddle
+// advanced by a float recurrence w1 *= cexp(-i pi/2^s).  Its drift (up to ~2e-4 in the last stage) is part of every
+// score the reference prints, so the template / low-pass spectra and the device kernels use the very same table.
+std::vector<float2> ref_twiddles() {
+    std::vector<float2> tws(SC_N - 1);
+    for (int s = 0; s < SC_LOG2N; s++) {
+        const int l2 = 1 << s;
+        const std::complex<double> e = std::exp(std::complex<double>(0.0, -M_PI / (double)(float)l2));
+        const float w2r = (float)e.real(), w2i = (float)e.imag();
+        float w1r = 1.0f, w1i = 0.0f;
+        for (int j = 0; j < l2; j++) {
+            tws[(size_t)l2 - 1 + j] = make_float2(w1r, w1i);
+            const float nr = w1r * w2r - w1i * w2i, ni = w1r * w2i + w1i * w2r;
+            w1r = nr; w1i = ni;
+        }
+    }
+    return tws;
+}
+
+void dft_ref_host(std::vector<float2> &z, const std::vector<float2> &tws) {
+    const int n = SC_N;
+    for (int i = 1, j = 0; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(z[i], z[j]);
+    }
+    for (int s = 0; s < SC_LOG2N; s++) {
+        const int l2 = 1 << s, l = l2 << 1;
+        for (int j = 0; j < l2; j++) {
+            const float2 w = tws[(size_t)l2 - 1 + j];
+            for (int i = j; i < n; i += l) {
+                const int k = i + l2;
+                const float tr = z[k].x * w.x - z[k].y * w.y, ti = z[k].x * w.y + z[k].y * w.x;
+                z[k] = make_float2(z[i].x - tr, z[i].y - ti);
+                z[i] = make_float2(z[i].x + tr, z[i].y + ti);
+            }
+        }
+    }
+}
+
+double gq(double x) { return 0.5 - 0.5 * std::erf(x / 1.4142135624); }
+double gpulse(double t, double sigma) { return gq((t - 0.5) / sigma) - gq((t + 0.5) / sigma); }
+
+// header template of dft_detect.c:1227-1258 (double t, float storage, 2-norm).  hLen is the *longest* header of all
+// active templates there (:1166-1173), so a shorter header sees its string terminator as a following 0 bit.
+std::vector<float> scan_match(const char *bits, int hLen, float spb, float bt, int L) {
+    std::vector<float> m(L);
+    const double sigma = std::sqrt(std::log(2)) / (2 * M_PI * bt);
+    for (int i = 0; i < L; i++) {
+        const int pos = (int)(i / spb);
+        const double t = (i - pos * spb) / spb - 0.5;
+        const double b1 = ((bits[pos] & 1) - 0.5) * 2.0;
+        double b = b1 * gpulse(t, sigma);
+        if (pos > 0) b += ((bits[pos - 1] & 1) - 0.5) * 2.0 * gpulse(t + 1, sigma);
+        if (pos < hLen - 1) b += ((bits[pos + 1] & 1) - 0.5) * 2.0 * gpulse(t - 1, sigma);
+        m[i] = (float)b;
+    }
+    double n2 = 0; for (int i = 0; i < L; i++) { const double x = m[i]; n2 += x * x; }
+    const float nm = (float)std::sqrt(n2);
+    for (int i = 0; i < L; i++) m[i] /= nm;
+    return m;
+}
+
+// read_bufbit's float bit clock (dft_detect.c:821-864): rbitgrenze += spb; do { ...; rcount++ } while (rcount < rbitgrenze)
+void bit_boundaries(float spb, int nhalf, std::vector<int> &out) {
+    unsigned rcount = 0; float grenze = 0.f;
+    for (int k = 0; k < nhalf; k++) {
+        grenze += spb;
+        do { rcount++; } while ((float)rcount < grenze);
+        out.push_back((int)rcount);
+    }
+}
+
+struct Chan {
+    float mv[kNrs]; uint32_t mv_pos[kNrs], mv0_pos[kNrs]; int mp[kNrs]; float dc[kNrs], df[kNrs];
+    const char *type[kNrs]; int tn[kNrs]; int detect2[kNrs];
+    int j_max = 0; float mv_max = 0.f; int d2_tn = kNrs; bool done = false;
+    uint32_t next_sin = 0;
+};
+
+struct KStat { double ms = 0; int64_t n = 0; };
+
+}  // namespace
+
+struct sonde_scan {
+    sonde_scan_cfg_t cfg{};
+    sonde_scan_info_t info{};
+    hipStream_t stream = nullptr;
+    // design
+    Decimator dec; int Q = 0; int lut_len = 1;
+    std::vector<float> wtab;
+    ScanTpl tpl[SC_NTPL]; float thres[kNrs]; uint32_t disabled = 0;
+    int K = 0, delay = 0, nstreams = 0, nfilt = 0, filt_stream[3] = {0, 0, 0}, raw_stream = 0, lpiq_taps = 0, lpfm_taps = 0;
+    // device
+    double *d_chanf0 = nullptr; float2 *d_dcavg = nullptr; long long *d_dcsums = nullptr; float2 *d_ptail[2] = {nullptr, nullptr}; int ptail_cur = 0;
+    float2 *d_y = nullptr; float *d_fm = nullptr; float *d_wiq = nullptr; float2 *d_G = nullptr, *d_tw = nullptr, *d_WS = nullptr;
+    uint8_t *d_hdr = nullptr; int *d_bnd = nullptr; ScanItem *d_items = nullptr; ScanRes *d_res = nullptr;
+    ScanItem *h_items = nullptr; ScanRes *h_res = nullptr; int item_cap = 0;
+    void *d_stage = nullptr; size_t stage_bytes = 0;
+    int ring_len = 0;
+    // stream position
+    uint64_t samples_in = 0; uint32_t m_out = 0; uint32_t dc_cnt = 0, dc_max = 0;
+    std::vector<Chan> chan;
+    std::vector<sonde_detection_t> queue;
+    std::vector<sonde_scan_window_t> last_windows;
+    std::map<std::string, KStat> stats;
+};
+
+static void timed(sonde_scan *s, const char *name, hipEvent_t a, hipEvent_t b) {
+    float ms = 0; if (hipEventElapsedTime(&ms, a, b) == hipSuccess) { auto &k = s->stats[name]; k.ms += ms; k.n += 1; }
+}
+
+template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+    return 0;
+}
+template <class T> static int dupload(T **p, const std::vector<T> &v) {
+    if (dalloc(p, v.size() ? v.size() : 1, false)) return SONDE_E_NOMEM;
+    if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" {
+
+int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_t **out) {
+    if (!cfg || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || cfg->bits != 16 || cfg->max_chunk < 1) return SONDE_E_ARG;
+    if (cfg->iq_mode != SONDE_SCAN_AUDIO && cfg->iq_mode != SONDE_SCAN_IFIQ && cfg->iq_mode != SONDE_SCAN_BBIQ) return SONDE_E_ARG;
+    if (cfg->iq_mode == SONDE_SCAN_BBIQ && !fq) return SONDE_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
+        fprintf(stderr, "libsonde_hip: no usable HIP device (the scanner has no CPU fallback)\n");
+        return SONDE_E_NOGPU;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    sonde_scan *s = new sonde_scan();
+    s->cfg = *cfg;
+    const int C = cfg->n_channels;
+    const bool iq = cfg->iq_mode != SONDE_SCAN_AUDIO;
+    const float set_lpIQ = cfg->bw_khz < 1.0f ? 0.f : (float)((double)cfg->bw_khz * 1e3);
+    s->disabled = cfg->disable_mask ? cfg->disable_mask : kDefaultDisable;
+
+    // ---- init_buffers() (dft_detect.c:995-1285)
+    int sr = cfg->sample_rate, D = 1;
+    if (cfg->iq_mode == SONDE_SCAN_BBIQ) {
+        if (set_lpIQ > 48000.f) { delete s; return SONDE_E_ARG; }          // wide IF (:1024-1041) needs N_DFT > 8192
+        s->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);     // same arithmetic as demod_mod.c:1222-1259
+        D = s->dec.decM; sr = s->dec.if_sr;
+        if (D == 1) s->dec.taps.assign(1, 1.0f);
+        const int T = (int)s->dec.taps.size();
+        s->Q = (T + D - 1) / D;
+        if (D > 64 || s->Q > 8) { delete s; return SONDE_E_ARG; }
+        const int pad = s->Q * D - T;
+        std::vector<float> wpad((size_t)s->Q * D, 0.f);
+        for (int k = 0; k < T; k++) wpad[pad + k] = s->dec.taps[k];
+        s->wtab.assign(64 * 8, 0.f);
+        for (int r = 0; r < D; r++) for (int q = 0; q < s->Q; q++) s->wtab[(size_t)r * 8 + q] = wpad[(size_t)D * q + r];
+        std::vector<double> f0s(C);
+        for (int c = 0; c < C; c++) {
+            const Mixer m = design_mixer(-std::max(-0.5, std::min(0.5, fq[c])), cfg->sample_rate);
+            f0s[c] = m.f0; s->lut_len = m.lut_len;
+        }
+        if (dupload(&s->d_chanf0, f0s)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
+    }
+    std::vector<float> w_iq, w_lp;
+    if (iq) {
+        int taps = (int)(4 * sr / 2e3); if (taps % 2 == 0) taps++;                 // FM low-pass, 2 kHz transition (:1106-1117)
+        float lpfm_bw[2] = { 4e3f, 10e3f };
+        for (int j = 0; j < 2; j++) { const std::vector<float> w = design_lowpass(lpfm_bw[j] / (float)sr, taps); w_lp.insert(w_lp.end(), w.begin(), w.end()); s->lpfm_taps = (int)w.size(); }
+        float lpiq_bw[3] = { 6e3f, 12e3f, 22e3f };
+        if (cfg->opt_lband) { lpiq_bw[0] = 20e3f; lpiq_bw[1] = 32e3f; lpiq_bw[2] = 200e3f; }
+        s->nfilt = 3;
+        if (set_lpIQ > 100.0f) { lpiq_bw[0] = set_lpIQ; s->nfilt = 1; }             // --bw: option_singleLpIQ (:1121-1126)
+        taps = (int)(4 * sr / 4e3); if (taps % 2 == 0) taps++;
+        for (int b = 0; b < s->nfilt; b++) {
+            const float f_lp = (float)(lpiq_bw[b] / (float)sr / 2.0);
+            const std::vector<float> w = design_lowpass(f_lp, taps); w_iq.insert(w_iq.end(), w.begin(), w.end()); s->lpiq_taps = (int)w.size();
+        }
+        if (s->nfilt == 3) { s->filt_stream[0] = 0; s->filt_stream[1] = 1; s->filt_stream[2] = 2; s->raw_stream = 3; s->nstreams = 4; }
+        else { s->filt_stream[0] = 0; s->raw_stream = 1; s->nstreams = 2; }
+    } else s->nstreams = 1;
+    auto phys_stream = [&](int lpiq) { if (!iq) return 0; if (lpiq == 3) return s->raw_stream; return s->nfilt == 3 ? lpiq : 0; };
+
+    int Lmax = 0, hLenMax = 0;
+    std::vector<int> Ls(kNrs); std::vector<float> spbs(kNrs);
+    for (int j = 0; j < kNrs; j++) {
+        spbs[j] = sr / (float)kTpl[j].baud;
+        const int hLen = (int)strlen(kTpl[j].hdr);
+        Ls[j] = (int)(hLen * spbs[j] + 0.5);
+        if (!((s->disabled >> j) & 1u) && Ls[j] > Lmax) Lmax = Ls[j];
+        if (!((s->disabled >> j) & 1u) && hLen > hLenMax) hLenMax = hLen;
+        s->thres[j] = cfg->ths > 0.f ? cfg->ths : kTpl[j].thres;
+    }
+    const int L2 = 2 * Lmax;
+    int p2 = 1; while (p2 < 3 * L2) p2 <<= 1; while (p2 < 0x2000) p2 <<= 1;
+    if (p2 != SC_N) { delete s; return SONDE_E_ARG; }
+    s->K = SC_N - L2; s->delay = L2 / 16;
+
+    const std::vector<float2> tws = ref_twiddles();
+    std::vector<float2> G((size_t)SC_NTPL * SC_N, make_float2(0.f, 0.f));
+    std::vector<uint8_t> hdrbits; std::vector<int> bnd;
+    std::vector<std::vector<float2>> WS(2);
+    if (iq) for (int j = 0; j < 2; j++) {                     // WS[j] = dft(FM low-pass taps) (dft_detect.c:1269-1278)
+        WS[j].assign(SC_N, make_float2(0.f, 0.f));
+        for (int i = 0; i < s->lpfm_taps; i++) WS[j][i].x = w_lp[(size_t)j * s->lpfm_taps + i];
+        dft_ref_host(WS[j], tws);
+    }
+    for (int j = 0; j < SC_NTPL; j++) {
+        ScanTpl &t = s->tpl[j];
+        memset(&t, 0, sizeof t);
+        t.L = Ls[j]; t.hLen = (int)strlen(kTpl[j].hdr); t.lpfm = kTpl[j].lpfm; t.stream = phys_stream(kTpl[j].lpiq);
+        t.active = !((s->disabled >> j) & 1u) && (s->K + t.L <= SC_N);
+        t.is_m10 = strncmp(kTpl[j].type, "M10", 3) == 0;
+        t.spb = spbs[j]; t.thres = s->thres[j]; t.herrs = kTpl[j].herrs;
+        t.hdr_off = (int)hdrbits.size(); hdrbits.insert(hdrbits.end(), kTpl[j].hdr, kTpl[j].hdr + t.hLen);
+        t.bnd_off = (int)bnd.size(); bit_boundaries(t.spb, t.hLen, bnd);
+        if (t.is_m10) bit_boundaries(t.spb, 28, bnd);
+        s->info.L[j] = t.L;
+        // Fm = dft of the time-reversed template (m[L-1-i] = match[i], dft_detect.c:1260-1262); G = WS[lpFM] * Fm
+        const std::vector<float> match = scan_match(kTpl[j].hdr, hLenMax, t.spb, kTpl[j].bt, t.L);
+        std::vector<float2> F(SC_N, make_float2(0.f, 0.f));
+        for (int i = 0; i < t.L; i++) F[t.L - 1 - i].x = match[i];
+        dft_ref_host(F, tws);
+        for (int k = 0; k < SC_N; k++) {
+            float2 g = F[k];
+            if (iq) { const float2 w = WS[t.lpfm][k]; g = make_float2(w.x * F[k].x - w.y * F[k].y, w.x * F[k].y + w.y * F[k].x); }
+            G[(size_t)j * SC_N + k] = g;
+        }
+    }
+
+    const int max_if = (cfg->max_chunk + D - 1) / D;
+    int ring = 1; while (ring < max_if + 2 * SC_N + 4096) ring <<= 1;
+    s->ring_len = ring;
+    sonde_scan_info_t &I = s->info;
+    I.if_sr = sr; I.decM = D; I.dectaps = (D == 1) ? 0 : (int)s->dec.taps.size(); I.lpiq_taps = s->lpiq_taps; I.lpfm_taps = s->lpfm_taps;
+    I.K = s->K; I.N = SC_N; I.delay = s->delay; I.L2 = L2; I.ring_len = ring;
+
+    int bad = 0;
+    bad |= dalloc(&s->d_dcavg, C); bad |= dalloc(&s->d_dcsums, 2 * (size_t)C);
+    if (cfg->iq_mode == SONDE_SCAN_BBIQ) { bad |= dalloc(&s->d_ptail[0], (size_t)C * 64); bad |= dalloc(&s->d_ptail[1], (size_t)C * 64); }
+    if (iq) bad |= dalloc(&s->d_y, (size_t)C * ring);
+    bad |= dalloc(&s->d_fm, (size_t)s->nstreams * C * ring);
+    bad |= dupload(&s->d_G, G); bad |= dupload(&s->d_tw, tws); bad |= dupload(&s->d_hdr, hdrbits); bad |= dupload(&s->d_bnd, bnd);
+    if (iq) { bad |= dupload(&s->d_wiq, w_iq); std::vector<float2> ws2(WS[0]); ws2.insert(ws2.end(), WS[1].begin(), WS[1].end()); bad |= dupload(&s->d_WS, ws2); }
+    s->item_cap = C * (max_if / (s->K - 4) + 2);
+    bad |= dalloc(&s->d_items, (size_t)s->item_cap, false); bad |= dalloc(&s->d_res, (size_t)s->item_cap * SC_NTPL, false);
+    if (bad) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
+    HIPCHK(hipHostMalloc((void **)&s->h_items, (size_t)s->item_cap * sizeof(ScanItem), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_res, (size_t)s->item_cap * SC_NTPL * sizeof(ScanRes), hipHostMallocDefault));
+    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+
+    // IQ-DC: always on, fixed window (dft_detect.c:1152-1156)
+    s->dc_max = (uint32_t)(sr / 32); if (D > 1) s->dc_max *= (uint32_t)D;
+    if (iq && (s->dc_max == 0 || s->dc_max % D)) { sonde_scan_destroy(s); return SONDE_E_ARG; }
+    s->chan.resize(C);
+    for (auto &c : s->chan) {
+        for (int j = 0; j < kNrs; j++) { c.mv[j] = 0; c.mv_pos[j] = 0; c.mv0_pos[j] = 0; c.mp[j] = 0; c.dc[j] = 0; c.df[j] = 0; c.type[j] = kTpl[j].type; c.tn[j] = kTpl[j].tn; c.detect2[j] = 0; }
+        c.next_sin = (uint32_t)(s->K - 4);
+    }
+    *out = s;
+    return 0;
+}
+
+void sonde_scan_destroy(sonde_scan_t *s) {
+    if (!s) return;
+    if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    if (s->h_items) hipHostFree(s->h_items);
+    if (s->h_res) hipHostFree(s->h_res);
+    void *ptrs[] = { s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage };
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete s;
+}
+
+int sonde_scan_info(const sonde_scan_t *s, sonde_scan_info_t *info) {
+    if (!s || !info) return SONDE_E_ARG;
+    *info = s->info;
+    return 0;
+}
+
+// decision logic of main() for one window of one channel (dft_detect.c:1494-1649)
+static void decide(sonde_scan *s, int ch, const ScanRes *res) {
+    Chan &c = s->chan[ch];
+    const bool iq = s->cfg.iq_mode != SONDE_SCAN_AUDIO;
+    for (int j = 0; j <= kIdxImetAfsk; j++) {
+        if (!s->tpl[j].active) continue;
+        c.mv0_pos[j] = c.mv_pos[j];
+        c.mp[j] = res[j].mp;
+        c.dc[j] = res[j].dc;
+        if (res[j].mp > 0) {                                   // getCorrDFT ran to its end
+            c.mv[j] = res[j].mv; c.mv_pos[j] = res[j].mpos;
+            if (s->cfg.opt_dc) c.df[j] = (float)(c.dc[j] / (2.0 * 0.8 * s->info.decM));
+        }
+    }
+    int header_found = 0;
+    uint32_t frm2 = 0;
+    for (int j0 = 0; j0 <= kIdxImetAfsk; j0++) {
+        int j = j0;
+        if (!s->tpl[j].active) continue;
+        if (!(c.mp[j] > 0 && (c.mv[j] > s->thres[j] || c.mv[j] < -s->thres[j]))) continue;
+        if (!(c.mv_pos[j] > c.mv0_pos[j])) continue;
+        if (!(res[j].herrs >= 0 && res[j].herrs < kTpl[j].herrs)) continue;
+        if (s->tpl[j].is_m10) {
+            // frm_M10 (:932-977): differential Manchester over 2 header symbols + 14 sliced ones -> 2 bytes
+            const int inv = c.mv[j] < 0;
+            const char *hdr = kTpl[j].hdr;
+            const int ofs = ((int)strlen(hdr) - 28) / 2;
+            char bit0 = (char)(0x30 + inv), frmbit[17];
+            for (int p = 0; p < 16; p++) {
+                char mb0;
+                if (p < ofs) mb0 = (char)(hdr[28 + 2 * p] ^ inv);
+                else mb0 = ((res[j].m10 >> (p - ofs)) & 1u) ? '1' : '0';
+                frmbit[p] = (char)(0x31 ^ (bit0 ^ mb0));
+                bit0 = mb0;
+            }
+            uint32_t bytes = 0;
+            for (int p = 0; p < 16; p++) bytes = (bytes << 1) | (uint32_t)(frmbit[p] == '1');
+            int h = 0; for (int q = 0; q < 4; q++) h += (bytes >> q) & 1u;
+            if (h < 2 || (h == 2 && (bytes & 0xF0) == 0x20)) { c.type[j] = "M20"; c.tn[j] = 6; }
+            else { c.type[j] = "M10"; c.tn[j] = 5; }
+            frm2 = bytes;
+        }
+        if (j == kIdxImetAfsk) {
+            c.mv[j] = 0.0f;                                    // post-processing not implemented: no IMET1RS/IMET4 decision
+        } else header_found = 1;
+        if (header_found) {
+            int printed = 0;
+            if (c.mv[j] > s->thres[j] || c.mv[j] < -s->thres[j]) {
+                if (s->cfg.opt_d2) {
+                    c.detect2[j] += 1;
+                    int tn = 0; for (tn = 0; tn < kNrs; tn++) if (c.detect2[tn] > 1) break;
+                    c.d2_tn = tn;
+                    if (c.d2_tn == kNrs) header_found = 0;
+                }
+                if (!s->cfg.opt_d2 || j == c.d2_tn) printed = 1;
+                sonde_detection_t d; memset(&d, 0, sizeof d);
+                d.channel = ch; d.tpl = j; d.tn = c.tn[j]; snprintf(d.type, sizeof d.type, "%s", c.type[j]);
+                d.score = c.mv[j]; d.sample = c.mv_pos[j]; d.printed = printed;
+                if (s->tpl[j].is_m10) { d.m10_bytes = frm2 & 0xFFFF; frm2 = 0; }
+                if (s->cfg.opt_dc && iq) { d.df = c.df[j]; d.freq_hz = c.df[j] * (float)s->cfg.sample_rate; }
+                s->queue.push_back(d);
+            }
+            if (std::fabs(c.mv_max) < std::fabs(c.mv[j])) { c.mv_max = c.mv[j]; c.j_max = j; }
+        }
+    }
+    if ((header_found && !s->cfg.opt_cont) || c.d2_tn < kNrs) c.done = true;
+    for (int j = 0; j < kNrs; j++) c.mv[j] = 0.0f;
+}
+
+int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stride, int32_t n_samples) {
+    if (!s || !d_in) return SONDE_E_ARG;
+    const int C = s->cfg.n_channels, D = s->info.decM, mode = s->cfg.iq_mode;
+    if (n_samples <= 0 || n_samples > s->cfg.max_chunk || n_samples % D || ch_stride < n_samples) return SONDE_E_RANGE;
+    hipEvent_t ev[4]; for (auto &e : ev) hipEventCreate(&e);
+    const uint32_t m_first = s->m_out;
+    hipEventRecord(ev[0], s->stream);
+    if (mode == SONDE_SCAN_AUDIO) {
+        AudioConvArgs a{}; a.pcm = (const int16_t *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.n = n_samples;
+        a.nch = std::max(1, s->cfg.audio_channels); a.sel = std::min(std::max(0, s->cfg.audio_select), a.nch - 1);
+        a.fm = s->d_fm; a.ring_len = s->ring_len; a.m0 = s->m_out;
+        sonde_launch_audio_convert(&a, s->stream);
+        s->m_out += (uint32_t)n_samples; s->samples_in += (uint64_t)n_samples;
+    } else {
+        int done = 0;
+        while (done < n_samples) {
+            const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), s->dc_max - s->dc_cnt);
+            if (mode == SONDE_SCAN_BBIQ) {
+                MixDecArgs a{};
+                a.iq = (const int16_t *)d_in + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
+                a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
+                a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
+                a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums;
+                a.ptail_in = s->d_ptail[s->ptail_cur]; a.ptail_out = s->d_ptail[s->ptail_cur ^ 1];
+                a.y = s->d_y; a.ring_len = s->ring_len; a.m0 = s->m_out; a.phase_f64 = 1;
+                { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
+                if (sonde_launch_mix_decimate(&a, s->stream) < 0) return SONDE_E_ARG;
+                s->ptail_cur ^= 1;
+            } else {
+                IqConvArgs a{}; a.iq = (const int16_t *)d_in + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.n = take;
+                a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums; a.y = s->d_y; a.ring_len = s->ring_len; a.m0 = s->m_out;
+                sonde_launch_iq_convert(&a, s->stream);
+            }
+            s->samples_in += (uint64_t)take; s->m_out += (uint32_t)(take / D); s->dc_cnt += (uint32_t)take; done += take;
+            if (s->dc_cnt == s->dc_max) { sonde_launch_dc_update(C, s->d_dcsums, s->d_dcavg, (float)s->dc_max, s->stream); s->dc_cnt = 0; }
+        }
+        hipEventRecord(ev[1], s->stream);
+        ScanIfArgs b{};
+        b.y = s->d_y; b.fm = s->d_fm; b.n_ch = C; b.ring_len = s->ring_len; b.n = n_samples / D; b.m0 = m_first;
+        b.taps = s->lpiq_taps; b.nfilt = s->nfilt; b.w = s->d_wiq;
+        for (int k = 0; k < 3; k++) b.filt_stream[k] = s->filt_stream[k];
+        b.raw_stream = s->raw_stream;
+        sonde_launch_scan_if(&b, s->stream);
+    }
+    hipEventRecord(ev[2], s->stream);
+
+    // ---- windows that became complete: sample_in = k (K-4), pos = sample_out = sample_in - 1 - delay (:1483-1505,811-813)
+    const float tl = s->cfg.time_limit;
+    const float limit = (tl + 1.0f) * (float)s->info.if_sr;
+    int n_items = 0;
+    std::vector<int> first_item(C + 1, 0);
+    for (int c = 0; c < C; c++) {
+        first_item[c] = n_items;
+        Chan &cs = s->chan[c];
+        uint32_t sin = cs.next_sin;
+        while (!cs.done && sin <= s->m_out && n_items < s->item_cap) {
+            if (tl > 0 && (float)sin > limit) break;
+            s->h_items[n_items].ch = c; s->h_items[n_items].pos = sin - 1u - (uint32_t)s->delay; n_items++;
+            sin += (uint32_t)(s->K - 4);
+        }
+    }
+    first_item[C] = n_items;
+    if (n_items) {
+        HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+        ScanCorrArgs a{};
+        a.fm = s->d_fm; a.n_ch = C; a.ring_len = s->ring_len; a.items = s->d_items; a.n_items = n_items;
+        memcpy(a.tpl, s->tpl, sizeof a.tpl);
+        a.G = s->d_G; a.WS = s->d_WS; a.lpfm_taps = s->lpfm_taps; a.tws = s->d_tw; a.K = s->K; a.opt_dc = s->cfg.opt_dc;
+        a.opt_iq = (mode != SONDE_SCAN_AUDIO); a.hdrbits = s->d_hdr; a.bnd = s->d_bnd; a.out = s->d_res;
+        if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
+        HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
+    }
+    hipEventRecord(ev[3], s->stream);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (mode != SONDE_SCAN_AUDIO) { timed(s, "front_end", ev[0], ev[1]); timed(s, "scan_if", ev[1], ev[2]); }
+    if (n_items) timed(s, "scan_corr", ev[2], ev[3]);
+    for (auto &e : ev) hipEventDestroy(e);
+
+    s->last_windows.clear();
+    for (int c = 0; c < C; c++) {
+        Chan &cs = s->chan[c];
+        for (int i = first_item[c]; i < first_item[c + 1]; i++) {
+            if (cs.done) break;
+            const ScanRes *r = s->h_res + (size_t)i * SC_NTPL;
+            sonde_scan_window_t w; memset(&w, 0, sizeof w);
+            w.channel = c; w.pos = s->h_items[i].pos;
+            for (int j = 0; j < SC_NTPL; j++) { w.mp[j] = r[j].mp; w.mv[j] = r[j].mv; w.mpos[j] = r[j].mpos; w.dc[j] = r[j].dc; w.herrs[j] = r[j].herrs; w.m10[j] = r[j].m10; }
+            s->last_windows.push_back(w);
+            cs.next_sin += (uint32_t)(s->K - 4);
+            decide(s, c, r);
+        }
+        if (!cs.done && tl > 0 && (float)cs.next_sin > limit && (float)s->m_out > limit) cs.done = true;   // -t: the sample loop broke
+    }
+    return 0;
+}
+
+int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples) {
+    if (!s || !h_in) return SONDE_E_ARG;
+    const int C = s->cfg.n_channels;
+    if (n_samples <= 0 || n_samples > s->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
+    const size_t unit = s->cfg.iq_mode == SONDE_SCAN_AUDIO ? 2 * (size_t)std::max(1, s->cfg.audio_channels) : 4;
+    const size_t need = (size_t)C * n_samples * unit;
+    if (need > s->stage_bytes) {
+        if (s->d_stage) { hipStreamSynchronize(s->stream); hipFree(s->d_stage); s->d_stage = nullptr; }
+        HIPCHK(hipMalloc(&s->d_stage, need)); s->stage_bytes = need;
+    }
+    HIPCHK(hipMemcpy2DAsync(s->d_stage, (size_t)n_samples * unit, h_in, (size_t)ch_stride * unit, (size_t)n_samples * unit, C,
+                            hipMemcpyHostToDevice, s->stream));
+    return sonde_scan_process_device(s, s->d_stage, n_samples, n_samples);
+}
+
+int sonde_scan_fetch(sonde_scan_t *s, sonde_detection_t *out, int32_t max) {
+    if (!s || !out || max < 0) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->queue.size(), (size_t)max);
+    for (int i = 0; i < n; i++) out[i] = s->queue[i];
+    s->queue.erase(s->queue.begin(), s->queue.begin() + n);
+    return n;
+}
+
+int sonde_scan_channel_done(const sonde_scan_t *s, int32_t channel) {
+    if (!s || channel < 0 || channel >= s->cfg.n_channels) return SONDE_E_ARG;
+    return s->chan[channel].done ? 1 : 0;
+}
+
+int sonde_scan_result(const sonde_scan_t *s, int32_t channel, int32_t *code) {
+    if (!s || !code || channel < 0 || channel >= s->cfg.n_channels) return SONDE_E_ARG;
+    const Chan &c = s->chan[channel];
+    int header_found = 0;
+    if (c.mv_max != 0.f) header_found = (c.mv_max < 0 && c.j_max < 3) ? -1 : 1;        // dft_detect.c:1656-1666
+    *code = header_found * c.tn[c.j_max];
+    return 0;
+}
+
+int sonde_scan_line(const sonde_scan_t *s, const sonde_detection_t *d, int verbose, char *buf, size_t buflen) {
+    if (!s || !d || !buf) return SONDE_E_ARG;
+    std::string o;
+    char t[96];
+    if (verbose) { snprintf(t, sizeof t, "sample: %d\n", (int)d->sample); o += t; }
+    snprintf(t, sizeof t, "%s: %.4f", d->type, d->score); o += t;
+    if (strncmp(d->type, "M10", 3) == 0 || strncmp(d->type, "M20", 3) == 0) { if (verbose) { snprintf(t, sizeof t, " [%04X]", d->m10_bytes & 0xFFFF); o += t; } }
+    if (s->cfg.opt_dc && s->cfg.iq_mode != SONDE_SCAN_AUDIO) {
+        snprintf(t, sizeof t, " , %+.1fHz", d->df * (float)s->cfg.sample_rate); o += t;
+        if (verbose) { snprintf(t, sizeof t, "   [ fq-ofs: %+.6f", d->df); o += t; snprintf(t, sizeof t, " = %+.1fHz ]", d->df * (float)s->cfg.sample_rate); o += t; }
+    }
+    snprintf(buf, buflen, "%s", o.c_str());
+    return (int)std::min(o.size(), buflen ? buflen - 1 : 0);
+}
+
+int sonde_scan_last_windows(const sonde_scan_t *s, sonde_scan_window_t *out, int32_t max) {
+    if (!s || (!out && max > 0)) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->last_windows.size(), (size_t)std::max(0, max));
+    for (int i = 0; i < n; i++) out[i] = s->last_windows[i];
+    return (int)s->last_windows.size();
+}
+
+int sonde_scan_read_fm(sonde_scan_t *s, int32_t channel, int32_t stream, int64_t first, int32_t count, float *out) {
+    if (!s || !out || channel < 0 || channel >= s->cfg.n_channels || stream < 0 || stream > 3 || count < 0) return SONDE_E_ARG;
+    int phys = 0;
+    if (s->cfg.iq_mode != SONDE_SCAN_AUDIO) phys = (stream == 3) ? s->raw_stream : (s->nfilt == 3 ? stream : 0);
+    if (first < 0 || first + count > (int64_t)s->m_out || (int64_t)s->m_out - first > s->ring_len) return SONDE_E_RANGE;
+    const float *base = s->d_fm + ((size_t)phys * s->cfg.n_channels + channel) * s->ring_len;
+    for (int32_t done = 0; done < count;) {
+        const uint32_t idx = (uint32_t)(first + done) & (uint32_t)(s->ring_len - 1);
+        const int run = (int)std::min<int64_t>(count - done, s->ring_len - idx);
+        HIPCHK(hipMemcpy(out + done, base + idx, (size_t)run * sizeof(float), hipMemcpyDeviceToHost));
+        done += run;
+    }
+    return 0;
+}
+
+int sonde_scan_kernel_ms(sonde_scan_t *s, const char *kernel, double *avg_ms, int64_t *launches) {
+    if (!s || !kernel) return SONDE_E_ARG;
+    auto it = s->stats.find(kernel);
+    if (it == s->stats.end() || it->second.n == 0) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return 0; }
+    if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;
+    if (launches) *launches = it->second.n;
+    return 0;
+}
+
+}  // extern "C"

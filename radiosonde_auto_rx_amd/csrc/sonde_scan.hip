@@ -1,0 +1,341 @@
+// sonde_scan.hip — gfx950 kernels of the scanner (the reference's scan/dft_detect.c).
+//
+//   k_iq_convert    --iq input: cs16 -> (x/32768 - mean) into the IF ring, exact integer IQ-DC sums   dft_detect.c:539-573
+//   k_audio_convert FM-audio input: s16 -> b/32768 into FM stream 0                                   dft_detect.c:505-533
+//   k_scan_if       3 IF low-passes on one delay line + 4 FM discriminators -> buf_fm[4]              dft_detect.c:737-819
+//   k_scan_corr     one workgroup = one correlation window x one template:
+//                   window -> FFT-8192 -> (dc, FM low-pass, matched filter) in the frequency domain -> FFT of the
+//                   conjugate -> peak, norm, header bit check, M10 type bits                          dft_detect.c:357-443,866-977
+//
+// k_scan_corr keeps the reference's structure (circular correlation by two radix-2 DIT transforms) *and its
+// twiddle factors*: the 8192-point data and the stage twiddles live in 128 KB of LDS, three butterfly stages per
+// pass are held in registers.
+#include "sonde_scan_dev.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+
+// ------------------------------------------------------------------------------------------------
+// input converters
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_iq_convert(const IqConvArgs a) {
+    const int ch = blockIdx.y;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const float2 avg = a.dc_avg[ch];
+    float2 *y = a.y + (size_t)ch * a.ring_len;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    long long sx = 0, sy = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        const uint32_t raw = iq[i];
+        const int xi = (int)(short)(raw & 0xffffu), yi = ((int)raw) >> 16;
+        sx += xi; sy += yi;
+        // x = b/32768.0 exact; z = (x - avg) rounded once (dft_detect.c:554-560)
+        y[(a.m0 + (uint32_t)i) & mask] = make_float2(__builtin_fmaf((float)xi, 3.0517578125e-05f, -avg.x),
+                                                     __builtin_fmaf((float)yi, 3.0517578125e-05f, -avg.y));
+    }
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch), (unsigned long long)sx);
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch + 1), (unsigned long long)sy);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_audio_convert(const AudioConvArgs a) {
+    const int ch = blockIdx.y;
+    const int16_t *pcm = a.pcm + (size_t)ch * a.ch_stride * a.nch;
+    float *fm = a.fm + (size_t)ch * a.ring_len;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+        fm[(a.m0 + (uint32_t)i) & mask] = (float)pcm[(size_t)i * a.nch + a.sel] * 3.0517578125e-05f;     // b/128.0/256.0, exact
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_if: 256 IF samples of one channel per workgroup
+// ------------------------------------------------------------------------------------------------
+#define SI_TILE 256
+
+__global__ __launch_bounds__(SI_TILE)
+void k_scan_if(const ScanIfArgs a) {
+    extern __shared__ float2 smem2[];
+    const int ch = blockIdx.y, T = a.taps, tid = threadIdx.x;
+    const uint32_t t0 = a.m0 + (uint32_t)blockIdx.x * SI_TILE;
+    const int nout = min(SI_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
+    if (nout <= 0) return;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    float2 *sy = smem2;                          // y[t0 - T + k], k < SI_TILE + T   (one sample more than the FIR history: z[t0-1])
+    float2 *sz = sy + SI_TILE + T;               // [3][SI_TILE + 1] z_b[t0 - 1 + k]
+    float  *sw = reinterpret_cast<float *>(sz + 3 * (SI_TILE + 1));   // [nfilt][T]
+    const float2 *yr = a.y + (size_t)ch * a.ring_len;
+    for (int k = tid; k < SI_TILE + T; k += SI_TILE) {
+        const int64_t m = (int64_t)t0 - T + k;
+        sy[k] = (m >= 0 && k < nout + T) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
+    }
+    for (int k = tid; k < a.nfilt * T; k += SI_TILE) sw[k] = a.w[k];
+    __syncthreads();
+    // z_b[m] = sum_k w_b[k] * y[m-(T-1)+k] for m = t0-1 .. t0+nout-1 (oldest sample pairs with tap 0, dft_detect.c:696-705)
+    for (int o = tid; o < nout + 1; o += SI_TILE) {
+        float2 acc[3] = { {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f} };
+        const float2 *yy = sy + o;               // y[t0 - 1 + o - (T-1)] = sy[o]
+        for (int k = 0; k < T; k++) {
+            const float2 v = yy[k];
+#pragma unroll
+            for (int b = 0; b < 3; b++) if (b < a.nfilt) {
+                const float w = sw[b * T + k];
+                acc[b].x = fmaf(w, v.x, acc[b].x); acc[b].y = fmaf(w, v.y, acc[b].y);
+            }
+        }
+        const bool before = (int64_t)t0 - 1 + o < 0;          // z[-1] = 0: static z0 of f32buf_sample starts at 0
+#pragma unroll
+        for (int b = 0; b < 3; b++) if (b < a.nfilt) sz[b * (SI_TILE + 1) + o] = before ? make_float2(0.f, 0.f) : acc[b];
+    }
+    __syncthreads();
+    if (tid < nout) {
+        const uint32_t m = (t0 + (uint32_t)tid) & mask;
+        const size_t cs = (size_t)a.n_ch * a.ring_len, co = (size_t)ch * a.ring_len + m;
+        // s = 0.8 * carg(z * conj(z_prev)) / pi   (dft_detect.c:776-803)
+#pragma unroll
+        for (int b = 0; b < 3; b++) if (b < a.nfilt) {
+            const float2 z1 = sz[b * (SI_TILE + 1) + tid + 1], z0 = sz[b * (SI_TILE + 1) + tid];
+            const float2 w = cmulc(z1, z0);
+            a.fm[(size_t)a.filt_stream[b] * cs + co] = (float)(0.8 * (double)atan2f(w.y, w.x) / 3.14159265358979323846);
+        }
+        const float2 y1 = sy[T + tid], y0 = ((int64_t)t0 + tid - 1 < 0) ? make_float2(0.f, 0.f) : sy[T + tid - 1];
+        const float2 w = cmulc(y1, y0);
+        a.fm[(size_t)a.raw_stream * cs + co] = (float)(0.8 * (double)atan2f(w.y, w.x) / 3.14159265358979323846);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_corr
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int brev13(int k) { return (int)(__brev((unsigned)k) >> (32 - SC_LOG2N)); }
+
+// R merged radix-2 decimation-in-time stages starting at stage t0 (bit-reversed in -> natural out), groups of 2^R
+// elements held in registers.  The twiddles are the reference's own: stage t uses w_t[j] = w_t[j-1] * cexp(-i pi/2^t)
+// accumulated in float (dft_raw, dft_detect.c:306-319), tabulated by the host at tws[2^t - 1 + j].  The recurrence
+// drifts by up to ~2e-4 in the last stages, and the reference's scores carry that drift; using its table reproduces
+// them instead of the exact DFT.
+template <int R>
+__device__ __forceinline__ void dit_pass(float2 *x, const float2 *tws, const int t0, const int tid) {
+    constexpr int E = 1 << R;
+    const int p_lo = t0;
+    for (int g = tid; g < (SC_N >> R); g += SC_THREADS) {
+        const int low = g & ((1 << p_lo) - 1), high = g >> p_lo;
+        const int base = (high << (p_lo + R)) | low;
+        float2 v[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] = x[base + (e << p_lo)];
+#pragma unroll
+        for (int s = 0; s < R; s++) {
+            const int t = t0 + s, bit = 1 << s;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (e & bit) continue;
+                const int idx = base + (e << p_lo);
+                const float2 w = tws[((1 << t) - 1) + (idx & ((1 << t) - 1))];
+                const float2 p = v[e], r = cmul(v[e | bit], w);
+                v[e] = make_float2(p.x + r.x, p.y + r.y);
+                v[e | bit] = make_float2(p.x - r.x, p.y - r.y);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) x[base + (e << p_lo)] = v[e];
+    }
+    __syncthreads();
+}
+
+// input already bit-reversed; stages 0..11 take their twiddles from LDS, the last one from the global table
+__device__ __forceinline__ void dft_ref(float2 *x, const float2 *tws, const float2 *tws_g, const int tid) {
+    dit_pass<3>(x, tws, 0, tid);
+    dit_pass<3>(x, tws, 3, tid);
+    dit_pass<3>(x, tws, 6, tid);
+    dit_pass<3>(x, tws, 9, tid);
+    dit_pass<1>(x, tws_g, 12, tid);
+}
+
+__device__ __forceinline__ float wsumf(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+__device__ __forceinline__ double wsumd(double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+
+// one workgroup = one correlation window x one template (getCorrDFT, dft_detect.c:357-443)
+__global__ __launch_bounds__(SC_THREADS)
+void k_scan_corr(const ScanCorrArgs a) {
+    extern __shared__ float2 smem2[];
+    float2 *x = smem2;                           // [SC_N]
+    float2 *tws = smem2 + SC_N;                  // [SC_N/2] twiddles of stages 0..11
+    float *xnl = reinterpret_cast<float *>(smem2 + SC_N + SC_N / 2);   // [SC_N] filtered window (norm)
+    __shared__ float s_rf[SC_THREADS / WAVE];
+    __shared__ int s_ri[SC_THREADS / WAVE];
+    __shared__ double s_rd[SC_THREADS / WAVE];
+    const int item = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ScanItem it = a.items[item];
+    const int K = a.K, N = SC_N;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const ScanTpl tp = a.tpl[j];
+    ScanRes *out = a.out + (size_t)item * SC_NTPL + j;
+    if (!tp.active) {
+        if (tid == 0) *out = ScanRes{ 0, 0.f, 0u, 0.f, -1, 0u };
+        return;
+    }
+    const float *str = a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len;
+    const int L = tp.L, wl = K + L;
+    const int64_t start = (int64_t)it.pos - (wl - 1);
+    for (int k = tid; k < N / 2 - 1; k += SC_THREADS) tws[k] = a.tws[k];
+    float dc = 0.f;
+    // xn[i] = stream[pos - (K+L-1) + i], i < K+L, zero padded (dft_detect.c:378-379); stored bit-reversed for the DIT network
+    auto load_window = [&](bool want_dc) {
+        float dcp = 0.f;
+        for (int i = tid; i < N; i += SC_THREADS) {
+            const int64_t p = start + i;
+            const float v = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
+            if (i >= K - L && i < wl) dcp += v;                        // last 2L samples (dft_detect.c:389)
+            x[brev13(i)] = make_float2(v, 0.f);
+        }
+        if (want_dc) {
+            const float sw = wsumf(dcp); if (lane == 0) s_rf[wave] = sw;
+            __syncthreads();
+            float sum = 0.f;
+            for (int w = 0; w < SC_THREADS / WAVE; w++) sum += s_rf[w];
+            dc = (float)((double)sum / (2.0 * (double)(float)L));
+        }
+        __syncthreads();
+    };
+    // Z = X * H with X[0] -= N*dc*0.98 for --dc (dft_detect.c:387-403); Nidft() transforms conj(Z): conjugate and swap
+    // into bit-reversed order for the next pass of the same network.  H == nullptr: Z = X.
+    auto spectrum_step = [&](const float2 *H) {
+        const float dcsub = a.opt_dc ? (float)((double)((float)N * dc) * 0.98) : 0.f;
+        for (int i = tid; i < N; i += SC_THREADS) {
+            const int r = brev13(i);
+            if (r < i) continue;
+            float2 xi = x[i], xr = x[r];
+            if (i == 0) { xi.x -= dcsub; xr.x -= dcsub; }             // i = r = 0
+            const float2 zi = H ? cmul(xi, H[i]) : xi, zr = H ? cmul(xr, H[r]) : xr;
+            x[r] = make_float2(zi.x, -zi.y);
+            x[i] = make_float2(zr.x, -zr.y);
+        }
+        __syncthreads();
+    };
+    // xn <- filtered window: real part of Nidft(X * WS[lpFM]) / N (dft_detect.c:394-402); it only feeds the norm
+    const bool filt = a.opt_dc || a.opt_iq;
+    if (filt) {
+        load_window(a.opt_dc != 0);
+        dft_ref(x, tws, a.tws, tid);
+        spectrum_step(a.opt_iq ? a.WS + (size_t)tp.lpfm * N : nullptr);
+        dft_ref(x, tws, a.tws, tid);
+        for (int i = tid; i < N; i += SC_THREADS) xnl[i] = x[i].x / (float)N;
+        __syncthreads();
+    }
+    load_window(false);
+    if (!filt) { for (int i = tid; i < N; i += SC_THREADS) xnl[brev13(i)] = x[i].x; __syncthreads(); }     // raw window, natural order
+    dft_ref(x, tws, a.tws, tid);                                         // X = dft(xn)
+    spectrum_step(a.G + (size_t)j * N);                                  // G = WS * Fm (Fm alone for FM-audio input)
+    dft_ref(x, tws, a.tws, tid);                                         // cx = Nidft(Z), real part used
+
+    // arg-max of cx^2 over i in [L-1, K+L), first maximum wins (dft_detect.c:415-423)
+    float best = 0.f; int bidx = -1;
+    for (int i = tid; i < N; i += SC_THREADS) {
+        if (i >= L - 1 && i < wl) { const float c = x[i].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
+        if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
+    __syncthreads();
+    int mp = -1;
+    {
+        float b = 0.f;
+        for (int w = 0; w < SC_THREADS / WAVE; w++) {
+            const float ob = s_rf[w]; const int oi = s_ri[w];
+            if (ob > b || (ob == b && oi >= 0 && (mp < 0 || oi < mp))) { b = ob; mp = oi; }
+        }
+    }
+    const float mx = (mp >= 0) ? x[mp].x : 0.f;
+    // norm over the L filtered window samples under the peak (dft_detect.c:431-433)
+    double e2 = 0.0;
+    if (mp >= 0) for (int k = tid; k < L; k += SC_THREADS) { const float v = xnl[mp - k]; e2 += (double)(v * v); }
+    { const double sw = wsumd(e2); if (lane == 0) s_rd[wave] = sw; }
+    __syncthreads();
+
+    if (wave == 0) {
+        ScanRes r{ 0, 0.f, 0u, dc, -1, 0u };
+        if (mp < 0) r.mp = -1;
+        else if (mp == L - 1 || mp == K + L - 1) r.mp = -4;                          // edge value
+        else {
+            double e = 0.0;
+            for (int w = 0; w < SC_THREADS / WAVE; w++) e += s_rd[w];
+            const double xnorm = sqrt(e);
+            r.mp = mp;
+            r.mv = (float)((double)mx / (xnorm * (double)N));
+            r.mpos = it.pos - (uint32_t)(K + L - 1) + (uint32_t)mp;
+            if (a.opt_iq) r.mpos -= (uint32_t)(a.lpfm_taps / 2);                       // low-pass delay
+            if (r.mv > tp.thres || r.mv < -tp.thres) {
+                const float dcv = a.opt_dc ? dc : 0.f;
+                const int sign = r.mv < 0.f ? 1 : 0;
+                // headcmp (dft_detect.c:866-905): hard bits of the header from the raw stream
+                const uint32_t mvp = r.mpos + 1u - (uint32_t)(int)((float)tp.hLen * tp.spb);
+                const int *bnd = a.bnd + tp.bnd_off;
+                int errs = 0;
+                for (int b0 = 0; b0 < tp.hLen; b0 += WAVE) {
+                    const int b = b0 + lane;
+                    int bad = 0;
+                    if (b < tp.hLen) {
+                        const int q0 = b ? bnd[b - 1] : 0, q1 = bnd[b];
+                        double sum = 0.0;
+                        for (int q = q0; q < q1; q++) {
+                            const int64_t p = (int64_t)(int32_t)(mvp + (uint32_t)q);
+                            const float v = (p >= 0) ? str[(uint32_t)p & mask] : 0.f;
+                            sum += (double)(v - dcv);
+                        }
+                        const int bit = sum >= 0.0 ? 1 : 0;
+                        bad = ((bit ^ sign) != (a.hdrbits[tp.hdr_off + b] & 1));
+                    }
+                    errs += __popcll(__ballot(bad));
+                }
+                r.herrs = errs;
+                if (tp.is_m10) {
+                    // frm_M10 (dft_detect.c:932-977): 14 Manchester symbols behind the header, first half minus second
+                    const int *bm = bnd + tp.hLen;
+                    int one = 0;
+                    if (lane < 14) {
+                        const int q0 = lane ? bm[2 * lane - 1] : 0, q1 = bm[2 * lane], q2 = bm[2 * lane + 1];
+                        double sum = 0.0;
+                        for (int q = q0; q < q1; q++) sum += (double)(str[(r.mpos + (uint32_t)q) & mask] - dcv);
+                        for (int q = q1; q < q2; q++) sum -= (double)(str[(r.mpos + (uint32_t)q) & mask] - dcv);
+                        one = sum >= 0.0;
+                    }
+                    r.m10 = (uint32_t)(__ballot(one) & 0x3fffULL);
+                }
+            }
+        }
+        if (lane == 0) *out = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s) {
+    const size_t lds = (size_t)(SI_TILE + a->taps + 3 * (SI_TILE + 1)) * sizeof(float2) + (size_t)a->nfilt * a->taps * sizeof(float);
+    hipLaunchKernelGGL(k_scan_if, dim3((a->n + SI_TILE - 1) / SI_TILE, a->n_ch), dim3(SI_TILE), lds, s, *a);
+}
+extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * SC_N) * sizeof(float2);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_corr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    if (a->n_items <= 0) return 0;
+    hipLaunchKernelGGL(k_scan_corr, dim3(a->n_items, SC_NTPL), dim3(SC_THREADS), lds, s, *a);
+    return 0;
+}
+extern "C" void sonde_launch_iq_convert(const IqConvArgs *a, hipStream_t s) {
+    int gx = (a->n + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_iq_convert, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
+}
+extern "C" void sonde_launch_audio_convert(const AudioConvArgs *a, hipStream_t s) {
+    int gx = (a->n + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_audio_convert, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
+}

@@ -1,0 +1,73 @@
+// sonde_scan_dev.h — structs shared by the scanner kernels (sonde_scan.hip) and the scanner engine (sonde_scan.cpp).
+// Scanner = the reference's scan/dft_detect.c: one IF front-end, 4 FM streams, 16 header templates correlated per window.
+#ifndef SONDE_SCAN_DEV_H
+#define SONDE_SCAN_DEV_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SC_N       8192      // N_DFT (dft_detect.c:1207-1211; fixed for IF rates up to ~51 kHz)
+#define SC_LOG2N   13
+#define SC_NTPL    16        // templates 0..idxIMETafsk (dft_detect.c:172-191)
+#define SC_THREADS 1024
+
+struct ScanTpl {              // one header template (rs_hdr[] row + derived sizes, dft_detect.c:1166-1175)
+    int   L;                  // samples of the header
+    int   hLen;               // header bits
+    int   lpfm;               // FM low-pass variant 0/1 (4 kHz / 10 kHz)
+    int   stream;             // physical FM stream the template reads
+    int   active;             // 0: compiled out in the reference build (NOC34C50, NOIMET1AB) or disabled
+    int   is_m10;             // M10/M20 type bytes are sliced behind the header
+    int   hdr_off;            // offset of the header bits in ScanCorrArgs.hdrbits
+    int   bnd_off;            // offset of the bit-boundary table in ScanCorrArgs.bnd
+    float spb;                // samples per bit
+    float thres;
+    int   herrs;              // headcmp limit (exclusive)
+    int   pad;
+};
+
+struct ScanItem { int ch; uint32_t pos; };                    // one correlation window: channel, sample_out at the window
+struct ScanRes  { int mp; float mv; uint32_t mpos; float dc; int herrs; uint32_t m10; };   // per (window, template)
+
+struct ScanCorrArgs {
+    const float *fm;          // [streams][n_ch][ring_len]
+    int n_ch, ring_len;
+    const ScanItem *items; int n_items;
+    ScanTpl tpl[SC_NTPL];
+    const float2 *G;          // [SC_NTPL][SC_N] reference-transform spectrum of (FM low-pass x) time-reversed template
+    const float2 *WS;         // [2][SC_N] reference-transform spectrum of the FM low-pass taps
+    int lpfm_taps;
+    const float2 *tws;        // [SC_N-1] stage twiddles of the reference's dft_raw: stage t at 2^t - 1 + j
+    int K, opt_dc, opt_iq;
+    const uint8_t *hdrbits;
+    const int *bnd;           // bit boundaries in samples (float accumulation of the reference tabulated on the host)
+    ScanRes *out;             // [n_items][SC_NTPL]
+};
+
+struct ScanIfArgs {
+    const float2 *y;          // [n_ch][ring_len] IF-rate IQ
+    float *fm;                // [streams][n_ch][ring_len]
+    int n_ch, ring_len, n; uint32_t m0;
+    int taps, nfilt;          // IF low-pass taps, number of distinct filters (3, or 1 with --bw)
+    const float *w;           // [nfilt][taps]
+    int filt_stream[3];       // physical stream of filter b
+    int raw_stream;           // physical stream of the unfiltered discriminator
+};
+
+struct IqConvArgs {           // --iq: IF-rate IQ in, IQ-DC removed (f32read_csample, dft_detect.c:539-573)
+    const int16_t *iq; long long ch_stride; int n_ch, n;
+    const float2 *dc_avg; long long *dc_sums;
+    float2 *y; int ring_len; uint32_t m0;
+};
+
+struct AudioConvArgs {        // FM audio in (f32read_sample, dft_detect.c:505-533): int16, one of nch interleaved channels
+    const int16_t *pcm; long long ch_stride; int n_ch, n, nch, sel;
+    float *fm; int ring_len; uint32_t m0;
+};
+
+extern "C" {
+void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s);
+int  sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s);
+void sonde_launch_iq_convert(const IqConvArgs *a, hipStream_t s);
+void sonde_launch_audio_convert(const AudioConvArgs *a, hipStream_t s);
+}
+#endif
