@@ -337,6 +337,22 @@ int sonde_scan_info(const sonde_scan_t *s, sonde_scan_info_t *info) {
     return 0;
 }
 
+// frm_M10 (dft_detect.c:932-977): differential Manchester over 2 header symbols + the 14 symbols sliced on the device
+static uint32_t m10_bytes(const char *hdr, uint32_t mask, int inv) {
+    const int ofs = ((int)strlen(hdr) - 28) / 2;
+    char bit0 = (char)(0x30 + inv), frmbit[17];
+    for (int p = 0; p < 16; p++) {
+        char mb0;
+        if (p < ofs) mb0 = (char)(hdr[28 + 2 * p] ^ inv);
+        else mb0 = ((mask >> (p - ofs)) & 1u) ? '1' : '0';
+        frmbit[p] = (char)(0x31 ^ (bit0 ^ mb0));
+        bit0 = mb0;
+    }
+    uint32_t bytes = 0;
+    for (int p = 0; p < 16; p++) bytes = (bytes << 1) | (uint32_t)(frmbit[p] == '1');
+    return bytes;
+}
+
 // decision logic of main() for one window of one channel (dft_detect.c:1494-1649)
 static void decide(sonde_scan *s, int ch, const ScanRes *res) {
     Chan &c = s->chan[ch];
@@ -360,20 +376,7 @@ static void decide(sonde_scan *s, int ch, const ScanRes *res) {
         if (!(c.mv_pos[j] > c.mv0_pos[j])) continue;
         if (!(res[j].herrs >= 0 && res[j].herrs < kTpl[j].herrs)) continue;
         if (s->tpl[j].is_m10) {
-            // frm_M10 (:932-977): differential Manchester over 2 header symbols + 14 sliced ones -> 2 bytes
-            const int inv = c.mv[j] < 0;
-            const char *hdr = kTpl[j].hdr;
-            const int ofs = ((int)strlen(hdr) - 28) / 2;
-            char bit0 = (char)(0x30 + inv), frmbit[17];
-            for (int p = 0; p < 16; p++) {
-                char mb0;
-                if (p < ofs) mb0 = (char)(hdr[28 + 2 * p] ^ inv);
-                else mb0 = ((res[j].m10 >> (p - ofs)) & 1u) ? '1' : '0';
-                frmbit[p] = (char)(0x31 ^ (bit0 ^ mb0));
-                bit0 = mb0;
-            }
-            uint32_t bytes = 0;
-            for (int p = 0; p < 16; p++) bytes = (bytes << 1) | (uint32_t)(frmbit[p] == '1');
+            const uint32_t bytes = m10_bytes(kTpl[j].hdr, res[j].m10, c.mv[j] < 0);
             int h = 0; for (int q = 0; q < 4; q++) h += (bytes >> q) & 1u;
             if (h < 2 || (h == 2 && (bytes & 0xF0) == 0x20)) { c.type[j] = "M20"; c.tn[j] = 6; }
             else { c.type[j] = "M10"; c.tn[j] = 5; }
@@ -492,7 +495,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
             const ScanRes *r = s->h_res + (size_t)i * SC_NTPL;
             sonde_scan_window_t w; memset(&w, 0, sizeof w);
             w.channel = c; w.pos = s->h_items[i].pos;
-            for (int j = 0; j < SC_NTPL; j++) { w.mp[j] = r[j].mp; w.mv[j] = r[j].mv; w.mpos[j] = r[j].mpos; w.dc[j] = r[j].dc; w.herrs[j] = r[j].herrs; w.m10[j] = r[j].m10; }
+            for (int j = 0; j < SC_NTPL; j++) { w.mp[j] = r[j].mp; w.mv[j] = r[j].mv; w.mpos[j] = r[j].mpos; w.dc[j] = r[j].dc; w.herrs[j] = r[j].herrs; w.m10[j] = (s->tpl[j].is_m10 && r[j].herrs >= 0) ? m10_bytes(kTpl[j].hdr, r[j].m10, r[j].mv < 0) : 0u; }
             s->last_windows.push_back(w);
             cs.next_sin += (uint32_t)(s->K - 4);
             decide(s, c, r);

@@ -303,3 +303,70 @@ def dfm_capture(sr: int = 480_000, seconds: float = 3.0, fq: float = 0.0, *, amp
     if return_frames:
         return out, frames
     return out
+
+
+# --------------------------------------------------------------------------
+# M10 / M20 (scanner tests): raw-symbol header + differential-Manchester type bytes
+# --------------------------------------------------------------------------
+M10_RAWHEADER = "1001100110010100110010011001" "1010"   # scan/dft_detect.c:72-74, last 4 symbols = first two frame bits
+
+
+def m10_symbols(type_bytes=(0x64, 0x9F), n_payload_bytes: int = 99, rng=None) -> np.ndarray:
+    """Raw 2-FSK symbols of one M10-style frame: 1001.. preamble, the 32-symbol header, then the frame bytes as
+    Manchester pairs whose first symbol repeats the previous pair's for a 1 and flips for a 0 (what frm_M10 of
+    dft_detect.c:932-977 undoes).  The header's last two pairs already carry the first two bits of byte 0."""
+    rng = rng or np.random.default_rng(0)
+    data = bytes(type_bytes) + bytes(int(v) for v in rng.integers(0, 256, n_payload_bytes))
+    bits = np.unpackbits(np.frombuffer(data, dtype=np.uint8))          # MSB first
+    sym = [int(c) for c in "1001" * 12] + [int(c) for c in M10_RAWHEADER]
+    prev = int(M10_RAWHEADER[30])
+    for b in bits[2:]:
+        s = prev if b else 1 - prev
+        sym += [s, 1 - s]
+        prev = s
+    return np.array(sym, dtype=np.uint8)
+
+
+def m10_capture(sr: int = 48_000, seconds: float = 3.0, fq: float = 0.0, *, type_bytes=(0x64, 0x9F), baud: float = 9616.0,
+                amp: float = 0.5, noise_sigma: float = 0.01, seed: int = 1, dev_hz: float = 3300.0, t_first: float = 0.35,
+                period: float = 1.0, f_offset_hz: float = 0.0) -> np.ndarray:
+    """Interleaved int16 IQ: continuous carrier, one M10/M20-style frame per `period` seconds, 1001.. idle pattern between."""
+    rng = np.random.default_rng(seed)
+    n = int(round(sr * seconds))
+    nsym = int(seconds * baud) + 8
+    sym = np.tile(np.array([1, 0, 0, 1], dtype=np.uint8), nsym // 4 + 1)[:nsym]
+    k = 0
+    while True:
+        s0 = int(round((t_first + k * period) * baud)) // 4 * 4
+        fr = m10_symbols(type_bytes, rng=np.random.default_rng(seed * 77 + k))
+        if s0 + len(fr) > nsym:
+            break
+        sym[s0:s0 + len(fr)] = fr
+        k += 1
+    x = amp * gfsk_baseband(sym, sr, baud, dev_hz, bt=1.0)[:n]
+    if len(x) < n:
+        x = np.concatenate([x, np.zeros(n - len(x))])
+    if fq != 0.0 or f_offset_hz != 0.0:
+        x = x * np.exp(2j * np.pi * (fq + f_offset_hz / sr) * np.arange(n))
+    x = x + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    return out
+
+
+def fm_audio(iq: np.ndarray, gain: float = 0.25) -> np.ndarray:
+    """FM-discriminator audio (int16 mono) of an interleaved int16 IQ capture at the same rate — the kind of input
+    the reference's FM chain feeds to the decoders / dft_detect as WAV."""
+    z = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    w = z[1:] * np.conj(z[:-1])
+    s = np.concatenate([[0.0], np.angle(w) / np.pi])
+    return np.clip(np.round(s * gain * 32767 * 4), -32768, 32767).astype(np.int16)
+
+
+def wav_bytes(pcm: np.ndarray, sr: int, nch: int = 1) -> bytes:
+    """Minimal RIFF/WAVE container (16-bit PCM) around interleaved samples."""
+    import struct
+    data = np.ascontiguousarray(pcm, dtype="<i2").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, nch, sr, sr * nch * 2, nch * 2, 16)
+    return hdr + b"data" + struct.pack("<I", len(data)) + data

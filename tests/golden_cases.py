@@ -35,3 +35,23 @@ DFM_NAMES = list(make_golden.DFM_CASES)
 def dfm_capture(name):
     x, fq, ecc = make_golden.dfm_capture(make_golden.DFM_CASES[name])
     return x, fq, make_golden.DFM_CASES[name]["sr"], ecc
+
+
+SCAN_NAMES = list(make_golden.SCAN_CASES)
+
+
+@functools.lru_cache(maxsize=None)
+def load_scan(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    g["consts"] = json.loads(str(g["consts"]))
+    g["stdout"] = str(g["stdout"])
+    g["rc"] = int(g["rc"])
+    return g
+
+
+@functools.lru_cache(maxsize=4)
+def scan_capture(name):
+    """-> (int16 samples, fq, CLI stdin bytes, case dict)"""
+    case = make_golden.SCAN_CASES[name]
+    x, fq, stdin = make_golden.scan_capture(case)
+    return x, fq, stdin, case

@@ -35,6 +35,64 @@ DFM_CASES = {
 }
 
 
+# scanner (scan/dft_detect.c): gen = capture generator, mode 5 = --IQ fq, 1 = --iq, 0 = FM audio (WAV)
+SCAN_CASES = {
+    "scan_rs41_2400k_dc": dict(gen="rs41", cap=dict(sr=2_400_000, seconds=1.5, fq=0.1, n_frames=1, t_first=0.3, noise_sigma=0.01, seed=5, f_offset_hz=-400.0),
+                               mode=5, dc=True, bw=0.0, cli=["-v", "-c"]),
+    "scan_rs41_48k_bw15_dc": dict(gen="rs41", cap=dict(sr=48_000, seconds=3.0, fq=0.0, n_frames=2, t_first=0.4, noise_sigma=0.02, seed=7, f_offset_hz=900.0),
+                                  mode=1, dc=True, bw=15.0, cli=["-v", "-c"]),
+    "scan_rs41_48k_inv": dict(gen="rs41", cap=dict(sr=48_000, seconds=3.0, fq=0.0, n_frames=2, t_first=0.4, noise_sigma=0.02, seed=7, dev_hz=-2400.0),
+                              mode=1, dc=True, bw=15.0, cli=["-v"]),
+    "scan_dfm_2400k": dict(gen="dfm", cap=dict(sr=2_400_000, seconds=1.0, fq=-0.2, noise_sigma=0.01, seed=3), mode=5, dc=False, bw=0.0, cli=["-v", "-c"]),
+    "scan_m10_48k": dict(gen="m10", cap=dict(sr=48_000, seconds=2.5, type_bytes=(0x64, 0x9F), noise_sigma=0.02, seed=3, f_offset_hz=500.0),
+                         mode=1, dc=True, bw=0.0, cli=["-v", "-c"]),
+    "scan_m20_2400k": dict(gen="m10", cap=dict(sr=2_400_000, seconds=1.6, fq=0.15, type_bytes=(0x45, 0x20), noise_sigma=0.02, seed=4, f_offset_hz=-300.0),
+                           mode=5, dc=True, bw=0.0, cli=["-v"]),
+    "scan_none_48k_t2": dict(gen="noise", cap=dict(sr=48_000, seconds=4.0, seed=9), mode=1, dc=True, bw=15.0, cli=["-t", "2"]),
+    "scan_rs41_audio": dict(gen="rs41_audio", cap=dict(sr=48_000, seconds=3.0, fq=0.0, n_frames=2, t_first=0.4, noise_sigma=0.02, seed=7), mode=0, dc=False, bw=0.0, cli=["-v", "-c"]),
+}
+
+
+def scan_capture(case):
+    """-> (samples int16, fq, stdin bytes for the CLI)"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    if "fq" in cap and case["mode"] == 5:
+        cap["fq"] = synth.snap_fq(cap["fq"], sr)
+    fq = cap.get("fq", 0.0)
+    g = case["gen"]
+    if g == "rs41":
+        x = synth.rs41_capture(**cap)
+    elif g == "dfm":
+        x = synth.dfm_capture(**cap)
+    elif g == "m10":
+        x = synth.m10_capture(**cap)
+    elif g == "noise":
+        rng = np.random.default_rng(cap["seed"]); n = int(sr * cap["seconds"])
+        x = np.clip(np.round(rng.standard_normal(2 * n) * 0.05 * 32767), -32768, 32767).astype(np.int16)
+    elif g == "rs41_audio":
+        x = synth.fm_audio(synth.rs41_capture(**cap))
+        return x, fq, synth.wav_bytes(x, sr)
+    else:
+        raise ValueError(g)
+    return x, fq, x.tobytes()
+
+
+def scan_cli_args(case, fq):
+    sr = case["cap"]["sr"]
+    a = list(case["cli"])
+    if case["mode"] == 5:
+        a += ["--IQ", repr(fq)]
+    elif case["mode"] == 1:
+        a += ["--iq"]
+    if case["bw"]:
+        a += ["--bw", repr(case["bw"])]
+    if case["dc"]:
+        a += ["--dc"]
+    if case["mode"] != 0:
+        a += ["-", str(sr), "16"]
+    return a
+
+
 def dfm_capture(kw):
     kw = dict(kw); ecc = kw.pop("ecc")
     sr = kw["sr"]
@@ -93,6 +151,16 @@ def main():
                  floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]), fq=fq, ecc=ecc)
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "lines", len(lines), "hits", strict["n"], strict["mv_pos"], strict["nbits"], "floor_soft", d["floor_soft"])
+    for name, case in SCAN_CASES.items():
+        x, fq, stdin = scan_capture(case)
+        sr = case["cap"]["sr"]
+        out, err, rc = bind.ref_run("dft_detect", scan_cli_args(case, fq), stdin)
+        r = bind.ref_scan_windows(x, sr, iq_mode=case["mode"], fq=fq, dc=case["dc"], bw_khz=case["bw"], max_win=512)
+        d = dict(stdout=np.array(out), rc=rc, fq=fq, consts=json.dumps(r["consts"]))
+        for k in ("mv", "mpos", "mp", "dc", "herrs", "m10", "pos"):
+            d[k] = r[k]
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
+        print(name, "windows", r["n"], "rc", rc, repr(out))
 
 
 if __name__ == "__main__":
