@@ -159,6 +159,14 @@ def main():
         d = dict(stdout=np.array(out), rc=rc, fq=fq, consts=json.dumps(r["consts"]))
         for k in ("mv", "mpos", "mp", "dc", "herrs", "m10", "pos"):
             d[k] = r[k]
+        # FM-stream segment under the first window with an accepted header: input of the numpy restatement (oracle/ora_scan.py)
+        hits = np.argwhere(r["herrs"] >= 0)
+        if len(hits) and case["mode"] != 0:
+            w, j = (int(v) for v in hits[0])
+            stream = [1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 0, 2, 3, 3, 3, 1][j]                  # rs_hdr[j].lpIQ
+            first = max(0, int(r["pos"][w]) - 7300); last = int(r["pos"][w]) + 200
+            rr = bind.ref_scan_windows(x, sr, iq_mode=case["mode"], fq=fq, dc=case["dc"], bw_khz=case["bw"], max_win=512, want_fm=last)
+            d.update(tap_w=w, tap_j=j, tap_stream=stream, tap_first=first, tap_fm=rr["fm"][stream][first:last])
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "windows", r["n"], "rc", rc, repr(out))
 
