@@ -1,0 +1,82 @@
+/*
+ * sonde_fsk.h — C ABI of the batched 2-FSK modem in libsonde_hip.so.
+ *
+ * Replaces the reference's utils/fsk.c demodulator (the codec2 "fsk_demod" auto_rx pipes IQ into,
+ * auto_rx/autorx/decode.py:901,976,1067,1120) for many channels at once.  The reference seam is
+ * fsk_create_hbr / fsk_set_freq_est_limits / fsk_set_freq_est_alg / fsk_nin / fsk_demod_sd / fsk_get_demod_stats /
+ * fsk_destroy (utils/fsk.h:115-205) over struct FSK (fsk.h:47-95); every channel here is one such struct.
+ * host/fsk_demod.c keeps the CLI (utils/fsk_demod.c) on top of it.  Conventions as sonde_hip.h.
+ */
+#ifndef SONDE_FSK_H
+#define SONDE_FSK_H
+
+#include "sonde_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* input sample formats (fsk_demod.c:103-110,283-311) */
+#define SONDE_FSK_S16   1       /* real int16,  x/1000           */
+#define SONDE_FSK_CS16  2       /* --cs16: complex int16, x/1000 */
+#define SONDE_FSK_CU8   3       /* --cu8: complex uint8, (u-127)/128 */
+
+typedef struct sonde_fsk sonde_fsk_t;
+
+typedef struct {
+    int32_t abi_version;     /* SONDE_ABI_VERSION                                            */
+    int32_t device;
+    int32_t n_channels;
+    int32_t Fs, Rs;          /* sample / symbol rate; Fs % Rs == 0 (fsk.c:127)               */
+    int32_t M;               /* 2 (4-FSK is not implemented)                                 */
+    int32_t P;               /* -p: timing oversampling, (Fs/Rs) % P == 0 (fsk.c:129)        */
+    int32_t nsym;            /* --nsym: symbols per modem frame                              */
+    int32_t format;          /* SONDE_FSK_*                                                  */
+    int32_t fsk_lower, fsk_upper;   /* -b / -u estimator limits in Hz (fsk_set_freq_est_limits) */
+    int32_t mask;            /* --mask given: mask estimator (fsk_set_freq_est_alg)          */
+    int32_t tone_spacing;    /* --mask <Hz> (tx_tone_separation, default 100)                */
+    int32_t max_chunk;       /* largest n_samples per process call                           */
+    int32_t reserved[4];
+} sonde_fsk_cfg_t;
+
+/* struct FSK constants (fsk_create_core, fsk.c:114-201) */
+typedef struct {
+    int32_t Ts, N, Ndft, Nmem, Nbits;
+    float   tc;
+    int32_t reserved[4];
+} sonde_fsk_info_t;
+
+/* per modem frame: what fsk_demod_core leaves in struct FSK / MODEM_STATS (fsk.c:593-915) */
+typedef struct {
+    int32_t nin;             /* samples this frame consumed                                  */
+    int32_t nin_next;        /* fsk_nin() after the frame                                    */
+    float   f_est[2];        /* tone estimates used by the demod (peak or mask estimator)    */
+    float   norm_rx_timing;
+    float   ppm;
+    float   EbNodB;
+    float   snr_est;         /* MODEM_STATS.snr_est (the "EbNodB" of the stats JSON)         */
+} sonde_fsk_frame_t;
+
+int  sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out);     /* fsk_create_hbr + limits + estimator */
+void sonde_fsk_destroy(sonde_fsk_t *f);                                   /* fsk_destroy                          */
+int  sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info);
+
+/* Push n_samples per channel (channel c at in + c*ch_stride samples); runs every modem frame for which fsk_nin()
+ * samples are available (the `while (fread(.., fsk_nin(fsk), ..))` loop of fsk_demod.c:279) — samples left over stay
+ * queued.  Synchronous. */
+int  sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples);
+int  sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
+
+/* Soft decisions (fsk_demod_sd: one float per bit, >0 = the lower tone) produced by the last process call for one
+ * channel; returns the number of floats written (<= max). frames (optional, may be NULL): per-frame records,
+ * max_frames entries; *n_frames receives the count. */
+int  sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames,
+                     int32_t *n_frames);
+/* fsk_get_demod_stats + Sf: smoothed magnitude spectrum (Ndft floats, DC at Ndft/2) and samples consumed so far */
+int  sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, float *Sf, int64_t *samples);
+int  sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

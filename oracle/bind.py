@@ -242,3 +242,39 @@ def ref_scan_windows(raw, sr, *, bps=16, iq_mode=5, fq=0.0, dc=False, opt_min=Fa
     cd["L"] = [int(v) for v in consts[9:25]]
     return dict(n=n, mv=mv[:n], mpos=mpos[:n], mp=mp[:n], dc=dcs[:n], herrs=herrs[:n], m10=m10[:n], pos=pos[:n],
                 consts=cd, fm=fm)
+
+
+# ----------------------------------------------------------------------------- 2-FSK modem (utils/fsk.c)
+class RefFskCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("Fs", "Rs", "P", "nsym", "format", "lower", "upper", "mask", "tone_spacing")]
+
+
+class RefFskFrame(C.Structure):
+    _fields_ = [("nin", C.c_int), ("nin_next", C.c_int), ("f_est", C.c_float * 2), ("norm_rx_timing", C.c_float),
+                ("ppm", C.c_float), ("EbNodB", C.c_float), ("snr_est", C.c_float)]
+
+
+def ref_fsk_run(raw, Fs, Rs, *, P=8, nsym=50, fmt=2, lower=None, upper=None, mask=0, tone_spacing=100, max_frames=4096):
+    """Per-frame internals + soft decisions of the reference modem (fsk_demod_sd) on an in-memory capture."""
+    raw = np.ascontiguousarray(raw)
+    ns = raw.size // (2 if fmt != 1 else 1)
+    if lower is None:
+        lower = -Fs // 2 if fmt != 1 else 0
+    if upper is None:
+        upper = Fs // 2
+    L = reflib("libref_fsk.so")
+    L.ref_fsk_run.restype = C.c_int
+    cfg = RefFskCfg(Fs, Rs, P, nsym, fmt, lower, upper, int(bool(mask)), tone_spacing)
+    sd = np.zeros(max_frames * nsym, np.float32)
+    fr = (RefFskFrame * max_frames)()
+    Sf = np.zeros(1024, np.float32)
+    consts = np.zeros(4, np.int32)
+    n = L.ref_fsk_run(C.byref(cfg), _buf(raw), C.c_size_t(ns), max_frames, _buf(sd), fr, _buf(Sf), _buf(consts))
+    if n < 0:
+        raise RuntimeError("ref_fsk_run failed")
+    keys = ("nin", "nin_next", "norm_rx_timing", "ppm", "EbNodB", "snr_est")
+    out = {k: np.array([getattr(fr[i], k) for i in range(n)]) for k in keys}
+    out["f_est"] = np.array([[fr[i].f_est[0], fr[i].f_est[1]] for i in range(n)], np.float32).reshape(n, 2)
+    Ts, N, Ndft, Nmem = (int(v) for v in consts)
+    out.update(n=n, sd=sd[:n * nsym].reshape(n, nsym), Sf=Sf[:Ndft].copy(), consts=dict(Ts=Ts, N=N, Ndft=Ndft, Nmem=Nmem))
+    return out

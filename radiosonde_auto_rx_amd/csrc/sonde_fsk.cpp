@@ -1,0 +1,221 @@
+// sonde_fsk.cpp — host side of the batched 2-FSK modem behind include/sonde_fsk.h (the reference's utils/fsk.c).
+//
+// fsk_create_core()'s constants and every data-independent table are computed here with the host libm — the same
+// cosf/sinf the reference binary calls — so the device never evaluates a transcendental the reference evaluates on
+// the CPU: Hann window (fsk.c:91-98), the per-sample oscillator step comp_exp_j(2 pi f / Fs) for every frequency the
+// two estimators can return (fsk.c:643), and the timing oscillator's float recurrence (fsk.c:682-703).
+#include "../../include/sonde_fsk.h"
+#include "sonde_fsk_dev.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libsonde_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return SONDE_E_NOGPU; } } while (0)
+
+struct sonde_fsk {
+    sonde_fsk_cfg_t cfg{};
+    sonde_fsk_info_t info{};
+    FskArgs args{};
+    hipStream_t stream = nullptr;
+    void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr;
+    float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
+    FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr;
+    std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
+    size_t unit = 4;
+    uint32_t wr = 0;
+    double ms = 0; int64_t launches = 0;
+};
+
+template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
+    HIPCHK(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    if (zero) HIPCHK(hipMemset(*p, 0, (n ? n : 1) * sizeof(T)));
+    return 0;
+}
+template <class T> static int dupload(T **p, const std::vector<T> &v) {
+    if (dalloc(p, v.size(), false)) return SONDE_E_NOMEM;
+    if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static float2 exp_j(float phi) { return make_float2(cosf(phi), sinf(phi)); }       // comp_exp_j (comp_prim.h:95)
+
+extern "C" {
+
+int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
+    if (!cfg || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->Fs < 1 || cfg->Rs < 1 || cfg->P < 1 || cfg->nsym < 1 || cfg->max_chunk < 1) return SONDE_E_ARG;
+    if (cfg->M != 2) return SONDE_E_ARG;                                              // 4-FSK: not implemented
+    if (cfg->Fs % cfg->Rs || (cfg->Fs / cfg->Rs) % cfg->P) return SONDE_E_ARG;          // the reference asserts (fsk.c:127-129)
+    if (cfg->format != SONDE_FSK_S16 && cfg->format != SONDE_FSK_CS16 && cfg->format != SONDE_FSK_CU8) return SONDE_E_ARG;
+    if (cfg->fsk_lower < -cfg->Fs / 2 || cfg->fsk_upper > cfg->Fs / 2 || cfg->fsk_upper <= cfg->fsk_lower) return SONDE_E_ARG;   // fsk.c:1019-1022
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
+        fprintf(stderr, "libsonde_hip: no usable HIP device (the modem has no CPU fallback)\n");
+        return SONDE_E_NOGPU;
+    }
+    HIPCHK(hipSetDevice(cfg->device));
+    sonde_fsk *f = new sonde_fsk();
+    f->cfg = *cfg;
+    const int C = cfg->n_channels, Fs = cfg->Fs, Rs = cfg->Rs, P = cfg->P, nsym = cfg->nsym;
+
+    // ---- fsk_create_core (fsk.c:114-201)
+    const float bin_width_Hz = 0.1 * Rs;
+    float Ndft_f = (float)Fs / bin_width_Hz;
+    Ndft_f = pow(2.0, ceil(log2(Ndft_f)));
+    const int Ndft = (int)Ndft_f, Ts = Fs / Rs, N = Ts * nsym, Nmem = N + 2 * Ts;
+    int lg = 0; while ((1 << lg) < Ndft) lg++;
+    if (Ndft > 1024 || Ndft < 8 || (1 << lg) != Ndft) { delete f; return SONDE_E_ARG; }
+    FskArgs &a = f->args;
+    a.format = cfg->format; a.n_ch = C; a.Fs = Fs; a.Rs = Rs; a.Ts = Ts; a.P = P; a.nsym = nsym; a.N = N; a.Ndft = Ndft; a.log2Ndft = lg;
+    a.Nmem = Nmem; a.NT = 2 * Ts + Ts / 2;
+    a.tc = 0.95 * Ndft_f / Fs;
+    const int est_space = 0.75 * Rs, fs_tx = cfg->mask ? cfg->tone_spacing : 100;
+    a.fs_tx = fs_tx; a.est_type = cfg->mask ? 1 : 0;
+    // fsk_demod_freq_est's bin limits (fsk.c:464-469), integer arithmetic
+    a.st = (cfg->fsk_lower * Ndft) / Fs + Ndft / 2; if (a.st < 0) a.st = 0;
+    a.en = (cfg->fsk_upper * Ndft) / Fs + Ndft / 2; if (a.en > Ndft) a.en = Ndft;
+    a.f_zero = (est_space * Ndft) / Fs;
+    {   // mask of the second estimator (fsk.c:553-560): ones at 0..2 and at bin..bin+2, bin = round(fs_tx Ndft / Fs) - 1
+        std::vector<char> mask(Ndft + 8, 0);
+        for (int i = 0; i < 3; i++) mask[i] = 1;
+        const int bin = (int)round((float)1 * fs_tx * Ndft / Fs) - 1;
+        if (bin < 0 || bin + 2 >= Ndft) { if (cfg->mask) { delete f; return SONDE_E_ARG; } }
+        else for (int i = bin; i <= bin + 2; i++) mask[i] = 1;
+        a.len_mask = bin + 2 + 1; a.n_mask = 0;
+        for (int i = 0; i < Ndft && a.n_mask < 6; i++) if (mask[i]) a.mask_idx[a.n_mask++] = i;
+    }
+    f->info.Ts = Ts; f->info.N = N; f->info.Ndft = Ndft; f->info.Nmem = Nmem; f->info.Nbits = nsym; f->info.tc = a.tc;
+    a.max_fft = (N + Ts / 2) / (Ndft / 2) - 1; if (a.max_fft < 1) a.max_fft = 1;
+
+    // ---- tables
+    std::vector<float> hann(Ndft), fmask((size_t)Ndft * 2);
+    std::vector<float2> tw(Ndft / 2), dpeak(Ndft), dmask((size_t)Ndft * 2), phift((size_t)(nsym + 1) * P);
+    for (int i = 0; i < Ndft; i++) hann[i] = 0.5 - 0.5 * cosf(2.0 * M_PI * (float)i / (float)(Ndft - 1));
+    for (int k = 0; k < Ndft / 2; k++) { const double ang = -2.0 * M_PI * k / Ndft; tw[k] = make_float2((float)cos(ang), (float)sin(ang)); }
+    for (int k = 0; k < Ndft; k++) {
+        const float fp = (float)(k - Ndft / 2) * ((float)Fs / (float)Ndft);             // peak estimator (fsk.c:544-546)
+        dpeak[k] = exp_j(2 * M_PI * ((fp) / (float)(Fs)));
+        const float foff = (k - Ndft / 2) * Fs / Ndft;                                  // mask estimator (fsk.c:575-578), integer division
+        for (int m = 0; m < 2; m++) { const float fm = foff + m * fs_tx; fmask[2 * k + m] = fm; dmask[2 * k + m] = exp_j(2 * M_PI * ((fm) / (float)(Fs))); }
+    }
+    {   // timing oscillator: phi_ft = 1; used, then phi_ft *= dphift (fsk.c:682-703)
+        const float2 d = exp_j(2 * M_PI * ((float)(Rs) / (float)(P * Rs)));
+        float2 ph = make_float2(1.f, 0.f);
+        for (size_t i = 0; i < phift.size(); i++) {
+            phift[i] = ph;
+            const float nr = ph.x * d.x - ph.y * d.y, ni = ph.x * d.y + ph.y * d.x;
+            ph = make_float2(nr, ni);
+        }
+    }
+    const int max_frames = cfg->max_chunk / std::max(1, N - Ts / 2) + 2;
+    a.rec_cap = max_frames; a.sd_cap = max_frames * nsym;
+    uint32_t ring = 1; while (ring < (uint32_t)(cfg->max_chunk + N + Ts + 16)) ring <<= 1;
+    a.ring = ring;
+    f->unit = cfg->format == SONDE_FSK_CS16 ? 4 : 2;
+    int bad = 0;
+    bad |= dalloc((char **)&f->d_in, (size_t)C * ring * f->unit);
+    bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
+    bad |= dupload(&f->d_fmask, fmask); bad |= dupload(&f->d_phift, phift);
+    bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * 2 * a.NT);
+    bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
+    if (bad) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
+    f->h_chan.resize(C);
+    for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); c.phi_c[0] = c.phi_c[1] = exp_j(0); c.nin = N; }
+    HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
+    a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
+    a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.tail = f->d_tail; a.sd = f->d_sd; a.recs = f->d_recs;
+    f->h_sd.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
+    HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    *out = f;
+    return 0;
+}
+
+void sonde_fsk_destroy(sonde_fsk_t *f) {
+    if (!f) return;
+    if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs };
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete f;
+}
+
+int sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info) {
+    if (!f || !info) return SONDE_E_ARG;
+    *info = f->info;
+    return 0;
+}
+
+static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hipMemcpyKind kind) {
+    const int C = f->cfg.n_channels;
+    if (n <= 0 || n > f->cfg.max_chunk || ch_stride < n) return SONDE_E_RANGE;
+    FskArgs &a = f->args;
+    // append to the per-channel rings (two pieces when the write position wraps)
+    const uint32_t w0 = f->wr & (a.ring - 1);
+    const uint32_t first = std::min<uint32_t>((uint32_t)n, a.ring - w0);
+    char *dst = (char *)f->d_in;
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)w0 * f->unit, (size_t)a.ring * f->unit, src, (size_t)ch_stride * f->unit, (size_t)first * f->unit, C, kind, f->stream));
+    if (first < (uint32_t)n)
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)a.ring * f->unit, (const char *)src + (size_t)first * f->unit, (size_t)ch_stride * f->unit,
+                                (size_t)(n - first) * f->unit, C, kind, f->stream));
+    f->wr += (uint32_t)n;
+    a.wr = f->wr;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, f->stream);
+    const int lrc = sonde_launch_fsk(&a, f->stream);
+    hipEventRecord(e1, f->stream);
+    if (lrc < 0) { hipEventDestroy(e0); hipEventDestroy(e1); return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU; }
+    HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { f->ms += ms; f->launches++; }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
+
+int sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples) {
+    if (!f || !h_in) return SONDE_E_ARG;
+    return run(f, h_in, ch_stride, n_samples, hipMemcpyHostToDevice);
+}
+int sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples) {
+    if (!f || !d_in) return SONDE_E_ARG;
+    return run(f, d_in, ch_stride, n_samples, hipMemcpyDeviceToDevice);
+}
+
+int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames, int32_t *n_frames) {
+    if (!f || channel < 0 || channel >= f->cfg.n_channels || (!sd && max > 0)) return SONDE_E_ARG;
+    const FskChan &c = f->h_chan[channel];
+    const int nf = c.frames, nb = std::min<int>(nf * f->cfg.nsym, max);
+    if (nb > 0) memcpy(sd, f->h_sd.data() + (size_t)channel * f->args.sd_cap, (size_t)nb * sizeof(float));
+    if (frames) for (int i = 0; i < std::min(nf, max_frames); i++) {
+        const FskFrameRec &r = f->h_recs[(size_t)channel * f->args.rec_cap + i];
+        sonde_fsk_frame_t &o = frames[i];
+        o.nin = r.nin; o.nin_next = r.nin_next; o.f_est[0] = r.f_est[0]; o.f_est[1] = r.f_est[1];
+        o.norm_rx_timing = r.norm_rx_timing; o.ppm = r.ppm; o.EbNodB = r.EbNodB; o.snr_est = r.snr_est;
+    }
+    if (n_frames) *n_frames = nf;
+    return nb;
+}
+
+int sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, float *Sf, int64_t *samples) {
+    if (!f || channel < 0 || channel >= f->cfg.n_channels) return SONDE_E_ARG;
+    const FskChan &c = f->h_chan[channel];
+    if (last) {
+        memset(last, 0, sizeof *last);
+        last->nin_next = c.nin; last->f_est[0] = c.f_est[0]; last->f_est[1] = c.f_est[1]; last->norm_rx_timing = c.norm_rx_timing;
+        last->ppm = c.ppm; last->EbNodB = c.EbNodB; last->snr_est = c.snr_est;
+    }
+    if (Sf) HIPCHK(hipMemcpy(Sf, f->d_Sf + (size_t)channel * f->info.Ndft, (size_t)f->info.Ndft * sizeof(float), hipMemcpyDeviceToHost));
+    if (samples) *samples = c.samples;
+    return 0;
+}
+
+int sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches) {
+    if (!f) return SONDE_E_ARG;
+    if (avg_ms) *avg_ms = f->launches ? f->ms / (double)f->launches : 0.0;
+    if (launches) *launches = f->launches;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,268 @@
+// sonde_fsk.hip — gfx950 kernel of the batched 2-FSK modem (the reference's utils/fsk.c fsk_demod_core).
+//
+// One workgroup per channel walks the modem frames that fit into the samples queued for that channel — the frame loop
+// is sequential in the reference too (nin, the smoothed spectrum Sf and the oscillator phases feed the next frame).
+// Inside a frame everything that is data-parallel runs on 256 threads out of LDS:
+//   frequency estimator   half-overlapped Hann-windowed FFTs (one wave per block), magnitude, per-bin exponential
+//                         smoothing in block order, peak / mask search                              fsk.c:438-590
+//   down-conversion       f_dc = in * conj(phi_c), phi_c advanced by the reference's float recurrence — kept serial on
+//                         one lane per tone because its rounding drift (~2e-4 over a frame) is part of the output
+//   integrate             (nsym+1) P sliding sums of Ts samples per tone                              fsk.c:659-668
+//   fine timing           |f_int|^2 against the tabulated spectral-line oscillator, atan2             fsk.c:682-731
+//   soft decisions        linear interpolation of the integrators, |t0| - |t1|                        fsk.c:751-805
+// Floating-point contraction is off in this file: the reference is plain C on x86-64 (separately rounded mul/add),
+// and the serial sums keep its order, so f_dc / f_int / soft decisions reproduce it up to libm (atan2f, log10f).
+#pragma clang fp contract(off)
+#include "sonde_fsk_dev.h"
+#include <limits.h>
+
+#define WAVE 64
+#define FMT_S16  1
+#define FMT_CS16 2
+#define FMT_CU8  3
+
+__device__ __forceinline__ float2 cmult(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+
+// first index of the maximum of v[lo..hi) with the reference's `if (v > max)` scan from max = 0; dflt if nothing is > 0
+__device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_rf, int *s_ri) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = 0.f; int bi = INT_MAX;
+    for (int i = lo + tid; i < hi; i += FSK_THREADS) { const float x = v[i]; if (x > best) { best = x; bi = i; } }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    __syncthreads();                                  // s_rf / s_ri may still be read from a previous call
+    if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bi; }
+    __syncthreads();
+    best = 0.f; bi = INT_MAX;
+    for (int w = 0; w < FSK_THREADS / WAVE; w++) { const float ob = s_rf[w]; const int oi = s_ri[w]; if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; } }
+    return bi == INT_MAX ? dflt : bi;
+}
+
+__global__ __launch_bounds__(FSK_THREADS)
+void k_fsk_demod(const FskArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float s_Sf[1024], s_Sc[1024];
+    __shared__ float s_rf[FSK_THREADS / WAVE]; __shared__ int s_ri[FSK_THREADS / WAVE];
+    __shared__ float2 s_phi[2]; __shared__ float s_tc[2], s_eb[2];
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT;
+    const int W = (nsym + 1) * P;
+    const int n_in = max(N + Ts / 2, W);
+    float2 *s_in  = reinterpret_cast<float2 *>(lds);                       // [n_in]  input frame; later ft1 * phi_ft
+    float2 *s_fdc = s_in + n_in;                                           // [max(2 Nmem, 4 Ndft)]  FFT scratch, then f_dc[2][Nmem]
+    float  *s_u   = reinterpret_cast<float *>(s_fdc + max(2 * Nmem, 4 * Ndft));   // mag[max_fft][Ndft] | f_int[2][W] + eb[nsym]
+    float2 *s_fint = reinterpret_cast<float2 *>(s_u);
+    float  *s_ebv = s_u + 4 * W;
+    FskChan st = a.chan[ch];
+    float *Sf_g = a.Sf + (size_t)ch * Ndft;
+    float2 *tail_g = a.tail + (size_t)ch * 2 * NT;
+    int frames = 0;
+
+    for (;;) {
+        const int nin = st.nin;
+        if ((int32_t)(a.wr - st.rd) < nin) break;
+        if (frames >= a.rec_cap || (frames + 1) * nsym > a.sd_cap) break;
+        // ---- input conversion (fsk_demod.c:283-311)
+        for (int i = tid; i < nin; i += FSK_THREADS) {
+            const uint32_t p = (st.rd + (uint32_t)i) & (a.ring - 1);
+            float2 v;
+            if (a.format == FMT_CS16) {
+                const uint32_t raw = reinterpret_cast<const uint32_t *>(a.in)[(size_t)ch * a.ring + p];
+                v = make_float2((float)(short)(raw & 0xffffu) / 1000.f, (float)(((int)raw) >> 16) / 1000.f);
+            } else if (a.format == FMT_S16) {
+                v = make_float2((float)reinterpret_cast<const int16_t *>(a.in)[(size_t)ch * a.ring + p] / 1000.f, 0.f);
+            } else {
+                const uint16_t raw = reinterpret_cast<const uint16_t *>(a.in)[(size_t)ch * a.ring + p];
+                v = make_float2(((float)(raw & 0xffu) - 127.0f) / 128.0f, ((float)(raw >> 8) - 127.0f) / 128.0f);
+            }
+            s_in[i] = v;
+        }
+        __syncthreads();
+
+        // ---- frequency estimator (fsk_demod_freq_est): numffts half-overlapped windowed FFTs, one wave each
+        const int numffts = nin / (Ndft / 2) - 1;
+        for (int j0 = 0; j0 < numffts; j0 += FSK_THREADS / WAVE) {
+            const int j = j0 + wave;
+            const bool act = j < numffts;
+            float2 *buf = s_fdc + wave * Ndft;
+            if (act) for (int i = lane; i < Ndft; i += WAVE) {
+                const float h = a.hann[i]; const float2 x = s_in[i + j * (Ndft / 2)];
+                buf[(int)(__brev((unsigned)i) >> (32 - a.log2Ndft))] = make_float2(h * x.x, h * x.y);
+            }
+            __syncthreads();
+            for (int s = 0; s < a.log2Ndft; s++) {
+                const int half = 1 << s;
+                if (act) for (int b = lane; b < Ndft / 2; b += WAVE) {
+                    const int i = ((b >> s) << (s + 1)) | (b & (half - 1)), k = i + half;
+                    const float2 t = cmult(buf[k], a.tw[(b & (half - 1)) << (a.log2Ndft - 1 - s)]);
+                    const float2 u = buf[i];
+                    buf[k] = make_float2(u.x - t.x, u.y - t.y);
+                    buf[i] = make_float2(u.x + t.x, u.y + t.y);
+                }
+                __syncthreads();
+            }
+            // fftshift (DC at Ndft/2) and magnitude
+            if (act) for (int k = lane; k < Ndft; k += WAVE) {
+                const float2 X = buf[k];
+                s_u[j * Ndft + ((k + Ndft / 2) & (Ndft - 1))] = sqrtf((X.x * X.x) + (X.y * X.y));
+            }
+            __syncthreads();
+        }
+        // Sf = Sf (1 - tc) + |X| tc, block after block (fsk.c:497-503)
+        for (int k = tid; k < Ndft; k += FSK_THREADS) {
+            float sf = Sf_g[k];
+            const float tc = a.tc, omt = 1 - tc;
+            for (int j = 0; j < numffts; j++) sf = (sf * omt) + (s_u[j * Ndft + k] * tc);
+            Sf_g[k] = sf; s_Sf[k] = sf; s_Sc[k] = sf;
+        }
+        __syncthreads();
+        // peak estimator: the two largest bins in [st, en), +-f_zero blanked after the first (fsk.c:508-546)
+        float f_est[2]; float2 dphi[2];
+        {
+            int freqi[2];
+            for (int m = 0; m < 2; m++) {
+                const int imax = block_argmax(s_Sc, a.st, a.en, 0, s_rf, s_ri);
+                const int f_min = max(imax - a.f_zero, 0), f_max = min(imax + a.f_zero, Ndft);
+                __syncthreads();
+                for (int k = f_min + tid; k < f_max; k += FSK_THREADS) s_Sc[k] = 0.f;
+                __syncthreads();
+                freqi[m] = imax - Ndft / 2;
+            }
+            if (freqi[1] < freqi[0]) { const int t = freqi[0]; freqi[0] = freqi[1]; freqi[1] = t; }
+            for (int m = 0; m < 2; m++) { f_est[m] = (float)freqi[m] * ((float)a.Fs / (float)Ndft); dphi[m] = a.dphi_peak[freqi[m] + Ndft / 2]; }
+        }
+        // mask estimator: two 3-bin groups fs_tx apart dragged over Sf (fsk.c:551-581)
+        if (a.est_type) {
+            for (int b = a.st + tid; b < a.en - a.len_mask; b += FSK_THREADS) {
+                float corr = 0.0f;
+                for (int i = 0; i < a.n_mask; i++) corr += s_Sf[b + a.mask_idx[i]];      // the non-zero mask entries, ascending
+                s_Sc[b] = corr;
+            }
+            __syncthreads();
+            const int b_max = block_argmax(s_Sc, a.st, a.en - a.len_mask, a.st, s_rf, s_ri);
+            for (int m = 0; m < 2; m++) { f_est[m] = a.f_mask[2 * b_max + m]; dphi[m] = a.dphi_mask[2 * b_max + m]; }
+        }
+        __syncthreads();
+
+        // ---- down-conversion with continuous phase (fsk.c:633-656); the oscillator recurrence stays serial
+        const int nold = Nmem - nin;
+        if (wave == 0 && lane < 2) {
+            float2 phi = lane ? st.phi_c[1] : st.phi_c[0]; const float2 d = lane ? dphi[1] : dphi[0];
+            float2 *o = s_fdc + lane * Nmem + nold;
+            for (int j = 0; j < nin; j++) { phi = cmult(phi, d); o[j] = phi; }
+            const float av = sqrtf((phi.x * phi.x) + (phi.y * phi.y));
+            s_phi[lane] = make_float2(phi.x / av, phi.y / av);
+        } else if (tid >= WAVE) {
+            for (int k = tid - WAVE; k < 2 * nold; k += FSK_THREADS - WAVE) {
+                const int m = k / nold, i = k - m * nold;
+                s_fdc[m * Nmem + i] = tail_g[m * NT + (NT - nold) + i];
+            }
+        }
+        __syncthreads();
+        st.phi_c[0] = s_phi[0]; st.phi_c[1] = s_phi[1];
+        for (int k = tid; k < 2 * nin; k += FSK_THREADS) {
+            const int m = k / nin, j = k - m * nin;
+            const float2 p = s_fdc[m * Nmem + nold + j], x = s_in[j];
+            s_fdc[m * Nmem + nold + j] = cmult(x, make_float2(p.x, -p.y));
+        }
+        __syncthreads();
+        for (int k = tid; k < 2 * NT; k += FSK_THREADS) { const int m = k / NT, i = k - m * NT; tail_g[m * NT + i] = s_fdc[m * Nmem + (Nmem - NT) + i]; }
+
+        // ---- integrate over a symbol period at (nsym+1) P offsets (fsk.c:659-668)
+        for (int k = tid; k < 2 * W; k += FSK_THREADS) {
+            const int m = k / W, i = k - m * W;
+            const float2 *f = s_fdc + m * Nmem + i * Ts / P;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int j = 0; j < Ts; j++) acc = cadd(acc, f[j]);
+            s_fint[k] = acc;
+        }
+        __syncthreads();
+        // ---- fine timing: sum_i (|f_int0|^2 + |f_int1|^2) phi_ft[i]  (fsk.c:682-703)
+        for (int i = tid; i < W; i += FSK_THREADS) {
+            float ft1 = 0;
+            for (int m = 0; m < 2; m++) { const float2 v = s_fint[m * W + i]; ft1 += (v.x * v.x) + (v.y * v.y); }
+            const float2 ph = a.phi_ft[i];
+            s_in[i] = make_float2(ft1 * ph.x, ft1 * ph.y);
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 2) {
+            const float *pp = reinterpret_cast<const float *>(s_in) + lane;
+            float t = 0;
+            for (int i = 0; i < W; i++) t = t + pp[2 * i];
+            s_tc[lane] = t;
+        }
+        __syncthreads();
+        const float norm_rx_timing = (float)((double)(float)atan2((double)s_tc[1], (double)s_tc[0]) / (2 * 3.14159265358979323846));
+        const float rx_timing = norm_rx_timing * (float)P;
+        const float d_norm = norm_rx_timing - st.norm_rx_timing;
+        st.norm_rx_timing = norm_rx_timing;
+        if (fabsf(d_norm) < .2) {
+            const float appm = (float)(1e6 * d_norm / (float)nsym);
+            st.ppm = (float)(.9 * st.ppm + .1 * appm);
+        }
+        int nin_next = N;
+        if (norm_rx_timing > 0.25) nin_next = N + Ts / 2;
+        else if (norm_rx_timing < -0.25) nin_next = N - Ts / 2;
+
+        // ---- soft decisions: integrators resampled by linear interpolation (fsk.c:733-805)
+        const int low = (int)floorf(rx_timing), high = (int)ceilf(rx_timing);
+        const float fract = rx_timing - (float)low, omf = 1 - fract;
+        float *sd = a.sd + (size_t)ch * a.sd_cap + (size_t)frames * nsym;
+        for (int i = tid; i < nsym; i += FSK_THREADS) {
+            const int sp = (i + 1) * P;
+            float tmax[2];
+            for (int m = 0; m < 2; m++) {
+                const float2 lo = s_fint[m * W + sp + low], hi = s_fint[m * W + sp + high];
+                const float2 t = cadd(make_float2(omf * lo.x, omf * lo.y), make_float2(fract * hi.x, fract * hi.y));
+                tmax[m] = (t.x * t.x) + (t.y * t.y);
+            }
+            s_ebv[i] = tmax[1] > tmax[0] ? tmax[1] : tmax[0];
+            sd[i] = sqrtf(tmax[0]) - sqrtf(tmax[1]);
+        }
+        __syncthreads();
+        // EbNo estimate (fsk.c:807-836): serial sums in symbol order
+        if (wave == 0 && lane < 2) {
+            float acc = 0;
+            if (lane == 0) for (int i = 0; i < nsym; i++) acc += s_ebv[i];
+            else           for (int i = 0; i < nsym; i++) acc += sqrtf(s_ebv[i]);
+            s_eb[lane] = acc;
+        }
+        __syncthreads();
+        {
+            const float meanebno = s_eb[1] / (float)nsym;
+            float stdebno = (s_eb[0] / (float)nsym) - (meanebno * meanebno);
+            if (stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
+            st.EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
+            st.snr_est = (float)(.5 * st.snr_est + .5 * st.EbNodB);
+        }
+        st.f_est[0] = f_est[0]; st.f_est[1] = f_est[1];
+        if (tid == 0) {
+            FskFrameRec r; r.nin = nin; r.nin_next = nin_next; r.f_est[0] = f_est[0]; r.f_est[1] = f_est[1];
+            r.norm_rx_timing = norm_rx_timing; r.ppm = st.ppm; r.EbNodB = st.EbNodB; r.snr_est = st.snr_est;
+            a.recs[(size_t)ch * a.rec_cap + frames] = r;
+        }
+        st.rd += (uint32_t)nin; st.samples += nin; st.nin = nin_next;
+        frames++;
+        __syncthreads();
+    }
+    if (tid == 0) { st.frames = frames; a.chan[ch] = st; }
+}
+
+extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
+    const int W = (a->nsym + 1) * a->P;
+    const int n_in = (a->N + a->Ts / 2) > W ? (a->N + a->Ts / 2) : W;
+    const int n_fdc = 2 * a->Nmem > 4 * a->Ndft ? 2 * a->Nmem : 4 * a->Ndft;
+    const size_t u1 = (size_t)a->max_fft * a->Ndft * sizeof(float), u2 = (size_t)(4 * W + a->nsym) * sizeof(float);
+    const size_t lds = (size_t)(n_in + n_fdc) * sizeof(float2) + (u1 > u2 ? u1 : u2);
+    if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fsk_demod), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(k_fsk_demod, dim3(a->n_ch), dim3(FSK_THREADS), lds, s, *a);
+    return 0;
+}

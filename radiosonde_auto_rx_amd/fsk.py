@@ -1,0 +1,111 @@
+"""ctypes binding of the batched 2-FSK modem in libsonde_hip.so (include/sonde_fsk.h).
+
+Python mirror of the reference's `fsk_demod` (utils/fsk_demod.c, the codec2 modem auto_rx pipes IQ into) for many
+channels at once.  No CPU fallback: the constructor raises without the in-tree HIP library / a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .engine import ABI_VERSION, _chk, lib
+
+S16, CS16, CU8 = 1, 2, 3
+
+
+class FskCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "device", "n_channels", "Fs", "Rs", "M", "P", "nsym", "format",
+                                         "fsk_lower", "fsk_upper", "mask", "tone_spacing", "max_chunk")] + \
+               [("reserved", C.c_int32 * 4)]
+
+
+class FskInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("Ts", "N", "Ndft", "Nmem", "Nbits")] + [("tc", C.c_float), ("reserved", C.c_int32 * 4)]
+
+
+class FskFrame(C.Structure):
+    _fields_ = [("nin", C.c_int32), ("nin_next", C.c_int32), ("f_est", C.c_float * 2), ("norm_rx_timing", C.c_float),
+                ("ppm", C.c_float), ("EbNodB", C.c_float), ("snr_est", C.c_float)]
+
+
+_proto = False
+
+
+def _lib():
+    global _proto
+    L = lib()
+    if not _proto:
+        L.sonde_fsk_create.argtypes = [C.POINTER(FskCfg), C.POINTER(C.c_void_p)]
+        L.sonde_fsk_destroy.argtypes = [C.c_void_p]
+        L.sonde_fsk_info.argtypes = [C.c_void_p, C.POINTER(FskInfo)]
+        L.sonde_fsk_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_fsk_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_fsk_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_int32, C.POINTER(C.c_int32)]
+        L.sonde_fsk_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_void_p, C.POINTER(C.c_int64)]
+        L.sonde_fsk_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        _proto = True
+    return L
+
+
+class FskModem:
+    """Batched `fsk_demod [--cs16|--cu8] -s [-b lo] [-u hi] [--mask S] [--nsym N] [-p P] 2 Fs Rs - -` for n channels."""
+
+    def __init__(self, Fs: int, Rs: int, *, n_channels: int = 1, P: int = 8, nsym: int = 50, fmt: int = CS16,
+                 lower: int | None = None, upper: int | None = None, mask: int = 0, max_chunk: int | None = None, device: int = 0):
+        self.n_channels, self.Fs, self.Rs, self.nsym, self.fmt = n_channels, Fs, Rs, nsym, fmt
+        if lower is None:
+            lower = -Fs // 2 if fmt != S16 else 0
+        if upper is None:
+            upper = Fs // 2
+        cfg = FskCfg(ABI_VERSION, device, n_channels, Fs, Rs, 2, P, nsym, fmt, lower, upper, int(mask > 0), mask if mask else 100,
+                     max_chunk or Fs)
+        h = C.c_void_p()
+        _chk(_lib().sonde_fsk_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        info = FskInfo()
+        _chk(_lib().sonde_fsk_info(h, C.byref(info)))
+        self.info = {n: getattr(info, n) for n, _ in FskInfo._fields_ if n != "reserved"}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().sonde_fsk_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def process_host(self, x: np.ndarray):
+        """x: [n_channels, n*k] int16 (k = 2 for cs16) or uint8 pairs (cu8)."""
+        x = np.ascontiguousarray(x)
+        if x.ndim == 1:
+            x = x[None, :]
+        per = 1 if self.fmt == S16 else 2
+        n = x.shape[1] // per
+        _chk(_lib().sonde_fsk_process_host(self._h, x.ctypes.data_as(C.c_void_p), n, n))
+
+    def process_device(self, ptr: int, ch_stride: int, n: int):
+        _chk(_lib().sonde_fsk_process_device(self._h, C.c_void_p(ptr), ch_stride, n))
+
+    def fetch(self, ch: int = 0):
+        """-> (soft decisions [frames, nsym], list of per-frame dicts) of the last process call."""
+        cap = 4096
+        fr = (FskFrame * cap)()
+        nf = C.c_int32(0)
+        sd = np.zeros(cap * self.nsym, np.float32)
+        nb = _chk(_lib().sonde_fsk_fetch(self._h, ch, sd.ctypes.data_as(C.c_void_p), len(sd), fr, cap, C.byref(nf)))
+        recs = [dict(nin=fr[i].nin, nin_next=fr[i].nin_next, f_est=(fr[i].f_est[0], fr[i].f_est[1]), norm_rx_timing=fr[i].norm_rx_timing,
+                     ppm=fr[i].ppm, EbNodB=fr[i].EbNodB, snr_est=fr[i].snr_est) for i in range(nf.value)]
+        return sd[:nb].reshape(-1, self.nsym), recs
+
+    def stats(self, ch: int = 0):
+        last = FskFrame()
+        Sf = np.zeros(self.info["Ndft"], np.float32)
+        n = C.c_int64(0)
+        _chk(_lib().sonde_fsk_stats(self._h, ch, C.byref(last), Sf.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return dict(f_est=(last.f_est[0], last.f_est[1]), ppm=last.ppm, EbNodB=last.EbNodB, snr_est=last.snr_est,
+                    norm_rx_timing=last.norm_rx_timing, nin=last.nin_next, Sf=Sf, samples=n.value)
+
+    def kernel_ms(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _chk(_lib().sonde_fsk_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -55,3 +55,21 @@ def scan_capture(name):
     case = make_golden.SCAN_CASES[name]
     x, fq, stdin = make_golden.scan_capture(case)
     return x, fq, stdin, case
+
+
+FSK_NAMES = list(make_golden.FSK_CASES)
+
+
+@functools.lru_cache(maxsize=None)
+def load_fsk(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    g["consts"] = json.loads(str(g["consts"]))
+    if "rs41_lines" in g:
+        g["rs41_lines"] = [str(s) for s in g["rs41_lines"]]
+    return g
+
+
+@functools.lru_cache(maxsize=4)
+def fsk_capture(name):
+    case = make_golden.FSK_CASES[name]
+    return make_golden.fsk_capture(case), case

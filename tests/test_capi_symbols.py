@@ -18,9 +18,9 @@ def _lib():
 
 
 def test_exports():
-    hdr = open(os.path.join(ROOT, "include", "sonde_hip.h")).read() + open(os.path.join(ROOT, "include", "sonde_scan.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("sonde_hip.h", "sonde_scan.h", "sonde_fsk.h"))
     names = set(re.findall(r"\b(sonde_[a-z0-9_]+)\s*\(", hdr))
-    assert len(names) >= 27 and "sonde_scan_create" in names
+    assert len(names) >= 35 and "sonde_scan_create" in names and "sonde_fsk_create" in names
     L = _lib()
     for n in sorted(names):
         assert hasattr(L, n), n
@@ -43,6 +43,16 @@ def test_scanner_without_gpu_fails_loudly():
     from radiosonde_auto_rx_amd.scan import Scanner
     with pytest.raises(SondeError):
         Scanner(48000, n_channels=1, iq_mode=1)
+
+
+def test_modem_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from radiosonde_auto_rx_amd.engine import SondeError
+    from radiosonde_auto_rx_amd.fsk import FskModem
+    with pytest.raises(SondeError):
+        FskModem(48000, 4800)
 
 
 def test_host_rs_codec_matches_oracle(oracle):
