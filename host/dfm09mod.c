@@ -11,11 +11,13 @@
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "wav_header.h"
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, raw = 0, have_pcm = 0;
+    int have_iq = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1;
+    FILE *fp = stdin;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_DFM09;
@@ -48,9 +50,21 @@ int main(int argc, char **argv) {
             if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
             have_pcm = 1;
         }
+        else if (!strcmp(a, "--ch2")) wav_ch = 1;
+        else if (a[0] != '-') {                      /* WAV file instead of stdin (dfm09mod.c wavloaded) */
+            fp = fopen(a, "rb");
+            if (fp == NULL) { fprintf(stderr, "error: open %s\n", a); return -1; }
+        }
         else { fprintf(stderr, "dfm09mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (!have_iq || !have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
+    if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
+    if (have_iq && !have_pcm) { fprintf(stderr, "dfm09mod (sonde_hip): --IQ needs raw input (- <sr> <bits>)\n"); return -1; }
+    if (!have_iq) {                                  /* FM audio: WAV on stdin or from a file (opt_iq = 0) */
+        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
+        if (cfg.bits != 16) { fprintf(stderr, "dfm09mod (sonde_hip): only 16-bit input is implemented\n"); return -1; }
+        cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
+        cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
+    }
     if (!raw) { fprintf(stderr, "dfm09mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
 
     cfg.n_channels = 1;
@@ -61,28 +75,31 @@ int main(int argc, char **argv) {
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
     sonde_info_t info;
     sonde_engine_info(eng, &info);
-    fprintf(stderr, "IF: %d\n", info.if_sr);
-    fprintf(stderr, "dec: %d\n", info.decM);
+    if (have_iq) {
+        fprintf(stderr, "IF: %d\n", info.if_sr);
+        fprintf(stderr, "dec: %d\n", info.decM);
+    }
+    const size_t unit = have_iq ? 4 : 2 * (size_t)cfg.audio_channels;      /* bytes per input sample / audio frame */
 
     int chunk = cfg.sample_rate / 10;
     chunk -= chunk % info.decM;
     if (chunk < info.decM) chunk = info.decM;
-    int16_t *buf = (int16_t *)malloc((size_t)chunk * 4);
+    int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
     sonde_dfm_frame_t frames[128];
     char line[128];
     size_t have = 0;
     for (;;) {
-        size_t got = fread((char *)buf + have, 1, (size_t)chunk * 4 - have, stdin);
+        size_t got = fread((char *)buf + have, 1, (size_t)chunk * unit - have, fp);
         have += got;
-        int n = (int)(have / 4);
+        int n = (int)(have / unit);
         n -= n % info.decM;
         if (n > 0) {
             rc = sonde_engine_process_host(eng, buf, n, n);
             if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
             int k = sonde_engine_fetch_dfm(eng, frames, 128, 0);
             for (int i = 0; i < k; i++) { sonde_dfm_rawline(&frames[i], cfg.ecc_level, line, sizeof line); fprintf(stdout, "%s\n", line); }
-            memmove(buf, (char *)buf + (size_t)n * 4, have - (size_t)n * 4);
-            have -= (size_t)n * 4;
+            memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
+            have -= (size_t)n * unit;
         }
         if (got == 0) break;
     }

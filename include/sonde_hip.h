@@ -36,6 +36,10 @@ extern "C" {
 #define SONDE_DFM09  9          /* dfm09mod.c:1309,1560-1582: 2500 Bd Manchester, BT 0.5, h 1.8, 32-symbol raw header,
                                  * thres 0.65, hdmax 2, lpIQ 12 kHz, 8 x 280-bit frames sliced per header hit       */
 
+/* input forms (dsp.opt_iq of demod_mod.h:62; rs41mod.c:2674-2687,2786-2803) */
+#define SONDE_IN_IQ    0        /* baseband IQ, mixed by -fq and decimated to the IF rate (opt_iq = 5)        */
+#define SONDE_IN_AUDIO 1        /* FM-demodulated audio, one real sample per input frame (opt_iq = 0)         */
+
 /* opt_lp bits, as demod_mod.h:12-14 */
 #define SONDE_LP_IQ 1
 #define SONDE_LP_FM 2
@@ -69,7 +73,11 @@ typedef struct {
     int32_t keep_soft;       /* testing: keep per-frame soft bits (soft-bit fetch call) and the IFIQ / FM tap streams */
     int32_t pipeline;        /* 1: IF-rate kernels on a second HIP stream so that sonde_engine_fetch_frames_lagged(lag=1)
                               * overlaps them with the next call's decimator; 0: one in-order stream             */
-    int32_t reserved[4];
+    int32_t input;           /* SONDE_IN_IQ (--IQ fq, cs16) or SONDE_IN_AUDIO (FM audio: WAV payload, real int16;
+                              * dsp.opt_iq = 0, the reference's CPU-runnable configuration)                      */
+    int32_t audio_channels;  /* SONDE_IN_AUDIO: interleaved channels per frame (1 or 2) and which one (--ch2 = 1) */
+    int32_t audio_select;
+    int32_t reserved[1];
 } sonde_cfg_t;
 
 /* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */

@@ -35,6 +35,11 @@ struct IfArgs {
     float sps;
 };
 
+struct AudioChainArgs {       // FM-audio input: raw ring -> (FM low-pass) -> fm, bufs
+    const float *raw; float *fm, *bufs; const float *w;
+    int n_ch, ring_len, n, taps; uint32_t m0;
+};
+
 struct SyncState {
     uint32_t s_in, k, mv_pos, mode;
     float mv; uint32_t pad[3];
@@ -74,6 +79,7 @@ extern "C" {
 int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
+void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s);
 void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s);
 void sonde_launch_framesync(const SyncArgs *a, hipStream_t s);
 }

@@ -12,6 +12,7 @@
 #include "../../include/sonde_hip.h"
 #include "sonde_dev.h"
 #include "sonde_host.h"
+#include "sonde_scan_dev.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -49,7 +50,7 @@ struct sonde_engine {
     float *d_Bop = nullptr; double *d_chanf0 = nullptr; int lut_len = 0;
     float2 *d_dcavg = nullptr; long long *d_dcsums = nullptr;
     float2 *d_ptail[2] = { nullptr, nullptr }; int ptail_cur = 0;
-    float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr;
+    float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr, *d_raw = nullptr;
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr;
@@ -175,7 +176,9 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     const int lpiq_bw = cfg->lpiq_bw > 0 ? cfg->lpiq_bw : lpiq_def;
 
     // ---- init_buffers() arithmetic (demod_mod.c:1208-1474)
-    e->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);
+    const bool audio = cfg->input == SONDE_IN_AUDIO;
+    if (audio) { e->dec.if_sr = cfg->sample_rate; e->dec.decM = 1; e->l_win = -1.0f; }     // opt_iq = 0: no front-end, whole-bit slicing (rs41mod.c:2920)
+    else e->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);
     const int D = e->dec.decM, sr = e->dec.if_sr;
     if (D == 1) e->dec.taps.assign(1, 1.0f);                   // reference bypasses the FIR for decM == 1 (:751)
     const int T = (int)e->dec.taps.size();
@@ -183,7 +186,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->sps /= (float)D;
     e->Q = (T + D - 1) / D;
     if (D > 64 || e->Q > 8) { delete e; return SONDE_E_ARG; }       // decM <= 64 (input rate <= 3.07 Msps at IF 48 kHz)
-    if (cfg->opt_lp & SONDE_LP_IQ) {
+    if ((cfg->opt_lp & SONDE_LP_IQ) && !audio) {
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
         int taps = (int)(4 * sr / 4e3); if (taps % 2 == 0) taps++;
@@ -237,7 +240,8 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     int bad = 0;
     bad |= dalloc(&e->d_dcavg, C); bad |= dalloc(&e->d_dcsums, 2 * (size_t)C);
     bad |= dalloc(&e->d_ptail[0], (size_t)C * 64); bad |= dalloc(&e->d_ptail[1], (size_t)C * 64);
-    bad |= dalloc(&e->d_y, (size_t)C * ring); bad |= dalloc(&e->d_ifiq, (size_t)C * ring);
+    if (audio) bad |= dalloc(&e->d_raw, (size_t)C * ring);
+    else { bad |= dalloc(&e->d_y, (size_t)C * ring); bad |= dalloc(&e->d_ifiq, (size_t)C * ring); }
     bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring);
     bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1);
     if (cfg->keep_soft || cfg->sonde_type != SONDE_RS41) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
@@ -335,7 +339,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
-                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend };
+                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -358,6 +362,17 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     if (n_samples <= 0 || n_samples > e->cfg.max_chunk || n_samples % D || ch_stride < n_samples) return SONDE_E_RANGE;
     const uint32_t m_first = e->m_out;
     int done = 0;
+    if (e->cfg.input == SONDE_IN_AUDIO) {
+        // f32read_sample (demod_mod.c:379-405): b/128/256 of the selected channel; then FM low-pass / bufs
+        AudioConvArgs c0{}; c0.pcm = (const int16_t *)d_iq; c0.ch_stride = ch_stride; c0.n_ch = C; c0.n = n_samples;
+        c0.nch = std::max(1, e->cfg.audio_channels); c0.sel = std::min(std::max(0, e->cfg.audio_select), c0.nch - 1);
+        c0.fm = e->d_raw; c0.ring_len = e->ring_len; c0.m0 = e->m_out;
+        sonde_launch_audio_convert(&c0, e->stream);
+        AudioChainArgs c1{}; c1.raw = e->d_raw; c1.fm = e->d_fm; c1.bufs = e->d_bufs; c1.w = e->d_wfm; c1.n_ch = C; c1.ring_len = e->ring_len;
+        c1.n = n_samples; c1.taps = (int)e->w_fm.size(); c1.m0 = e->m_out;
+        prof_begin(e, "if_chain", e->stream); sonde_launch_audio_chain(&c1, e->stream); prof_end(e, e->stream);
+        e->samples_in += (uint64_t)n_samples; e->m_out += (uint32_t)n_samples; done = n_samples;
+    }
     while (done < n_samples) {
         // never straddle an IQ-DC segment: the mean of segment s-1 is subtracted throughout segment s
         const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt);
@@ -395,7 +410,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         hipEventRecord(e->ev_a[slot], e->stream);
         hipStreamWaitEvent(e->stream_b, e->ev_a[slot], 0);
     }
-    prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b);
+    if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
     CorrArgs c{};
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
     c.state = e->d_state; c.delay = e->info.delay; c.frame_samples = e->frame_samples;
@@ -427,12 +442,13 @@ int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_st
     if (!e || !h_iq) return SONDE_E_ARG;
     const int C = e->cfg.n_channels;
     if (n_samples <= 0 || n_samples > e->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
-    const size_t need = (size_t)C * n_samples * 4;
+    const size_t unit = e->cfg.input == SONDE_IN_AUDIO ? 2 * (size_t)std::max(1, e->cfg.audio_channels) : 4;
+    const size_t need = (size_t)C * n_samples * unit;
     if (need > e->stage_bytes) {
         if (e->d_stage) { hipStreamSynchronize(e->stream); hipFree(e->d_stage); e->d_stage = nullptr; }
         HIPCHK(hipMalloc((void **)&e->d_stage, need)); e->stage_bytes = need;
     }
-    HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)n_samples * 4, h_iq, (size_t)ch_stride * 4, (size_t)n_samples * 4, C,
+    HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)n_samples * unit, h_iq, (size_t)ch_stride * unit, (size_t)n_samples * unit, C,
                             hipMemcpyHostToDevice, e->stream));
     return sonde_engine_process_device(e, e->d_stage, n_samples, n_samples);
 }

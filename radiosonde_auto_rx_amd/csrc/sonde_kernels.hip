@@ -226,6 +226,29 @@ __global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_audio_chain: FM-audio input (dsp.opt_iq = 0): optional FM low-pass, then fm_buffer and bufs (demod_mod.c:836-852)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_audio_chain(const AudioChainArgs a) {
+    const int ch = blockIdx.y;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const float *raw = a.raw + (size_t)ch * a.ring_len;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        const uint32_t m = a.m0 + (uint32_t)i;
+        float s;
+        if (a.taps > 0) {                       // s_fm = sum_k w[k] * raw[m-(T-1)+k], zero history before the stream (re_lowpass :711-719)
+            s = 0.f;
+            for (int k = 0; k < a.taps; k++) {
+                const int64_t p = (int64_t)m - (a.taps - 1) + k;
+                s = fmaf(a.w[k], p >= 0 ? raw[(uint32_t)p & mask] : 0.f, s);
+            }
+        } else s = raw[m & mask];
+        a.fm[(size_t)ch * a.ring_len + (m & mask)] = s;
+        a.bufs[(size_t)ch * a.ring_len + (m & mask)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_if_chain: one workgroup = IF_TILE output samples of one channel
 // ------------------------------------------------------------------------------------------------
 #define IF_TILE 512
@@ -751,6 +774,10 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
+}
+extern "C" void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s) {
+    int gx = (a->n + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_audio_chain, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
 }
 extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     const int T1 = a->lpiq_on ? a->lpiq_taps : 1, T2 = a->lpfm_on ? a->lpfm_taps : 1;

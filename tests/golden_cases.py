@@ -73,3 +73,13 @@ def load_fsk(name):
 def fsk_capture(name):
     case = make_golden.FSK_CASES[name]
     return make_golden.fsk_capture(case), case
+
+
+AUDIO_NAMES = list(make_golden.AUDIO_CASES)
+
+
+@functools.lru_cache(maxsize=4)
+def audio_capture(name):
+    case = make_golden.AUDIO_CASES[name]
+    pcm, wav = make_golden.audio_capture(case)
+    return pcm, wav, case

@@ -35,6 +35,27 @@ DFM_CASES = {
 }
 
 
+# FM-audio input (WAV, dsp.opt_iq = 0): BASELINE config 1, the reference's own CPU-runnable form
+AUDIO_CASES = {
+    "rs41_audio_48k_be10": dict(gen="rs41", cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=11, bit_errors=10), lpfm=False),
+    "rs41_audio_48k_lpfm": dict(gen="rs41", cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.05, seed=12, bit_errors=4), lpfm=True),
+    "dfm_audio_48k": dict(gen="dfm", cap=dict(sr=48_000, seconds=3.0, fq=0.0, noise_sigma=0.03, seed=12), lpfm=False),
+}
+
+
+def audio_capture(case):
+    """-> (mono int16 FM audio, WAV bytes)"""
+    x = synth.rs41_capture(**case["cap"]) if case["gen"] == "rs41" else synth.dfm_capture(**case["cap"])
+    pcm = synth.fm_audio(x)
+    return pcm, synth.wav_bytes(pcm, case["cap"]["sr"])
+
+
+def audio_cli(case):
+    if case["gen"] == "rs41":
+        return "rs41mod", ["-r", "--ecc2", "--crc"] + (["--lpFM"] if case["lpfm"] else [])
+    return "dfm09mod", ["-r", "--ecc"]
+
+
 # scanner (scan/dft_detect.c): gen = capture generator, mode 5 = --IQ fq, 1 = --iq, 0 = FM audio (WAV)
 SCAN_CASES = {
     "scan_rs41_2400k_dc": dict(gen="rs41", cap=dict(sr=2_400_000, seconds=1.5, fq=0.1, n_frames=1, t_first=0.3, noise_sigma=0.01, seed=5, f_offset_hz=-400.0),
@@ -194,6 +215,21 @@ def main():
                  floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]), fq=fq, ecc=ecc)
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "lines", len(lines), "hits", strict["n"], strict["mv_pos"], strict["nbits"], "floor_soft", d["floor_soft"])
+    for name, case in AUDIO_CASES.items():
+        pcm, wav = audio_capture(case)
+        sr = case["cap"]["sr"]
+        binary, args = audio_cli(case)
+        out, err, rc = bind.ref_run(binary, args, wav)
+        lines = out.splitlines()
+        par = dict(iq_mode=0, lp_iq=False, lp_fm=case["lpfm"], l=-1.0)
+        if case["gen"] == "dfm":
+            par.update(baud=2500.0, h=1.8, lpfm_bw=4000, hdr=bind.DFM_RAWHDR, symlen=2, symhd=2, thres=0.65, hdmax=2, nbits=2224)
+        fast = bind.ref_softframes(pcm, sr, **par)
+        strict = bind.ref_softframes(pcm, sr, libname="libref_demod_O2.so", **par)
+        d = dict(lines=np.array(lines), mv=strict["mv"], mv_pos=strict["mv_pos"], soft=strict["soft"], nbits=strict["nbits"],
+                 floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]))
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
+        print(name, "lines", len(lines), "hits", strict["n"], strict["mv"], "floor_soft", d["floor_soft"])
     for name, case in SCAN_CASES.items():
         x, fq, stdin = scan_capture(case)
         sr = case["cap"]["sr"]
