@@ -52,13 +52,51 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // cycles per wave64 instruction): v_fma_f32 3.2, v_pk_fma_f32 5.2, v_mul/add_f64 4.7, v_sin/cos_f32 10.1 — the
 // kernel is VALU-bound, so the FIR uses packed FMAs on (re, im) pairs and everything else is kept to the minimum
 // number of instructions.
+// z = u * (c + i s) as two packed ops: t = (-u.y s, u.y c); z = (u.x c, u.x s) + t.  op_sel / neg_lo pick and negate the
+// halves, so no register shuffling is needed (the compiler's own lowering costs two extra moves per sample).
+__device__ __forceinline__ float2v cmul_pk(float2v u, float2v cs) {
+    float2v t, z;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(u), "v"(cs));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(z) : "v"(u), "v"(cs), "v"(t));
+    return z;
+}
+
+// one input sample of a row: IQ-DC sums, DC removal, mixer phasor, Q packed tap FMAs
 template <int Q_T, bool WRAP, bool PH64>
+__device__ __forceinline__ void md_step(const uint32_t raw, const int r, const float *w, const float2v navg, const float2v msk,
+                                        const double f0, double &ndrun, const uint32_t rown, const uint32_t towrap, const uint32_t L,
+                                        float2v (&acc)[Q_T], float2v &dcs) {
+    const float2v scale = { 3.0517578125e-05f, 3.0517578125e-05f };
+    const float2v xf = { (float)(int)(short)(raw & 0xffffu), (float)(((int)raw) >> 16) };
+    // IQ-DC sums: int16 values are exact in f32 and a tile row sums to < 2^24, so the float sum is exact
+    dcs = __builtin_elementwise_fma(xf, msk, dcs);
+    // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
+    const float2v u = __builtin_elementwise_fma(xf, scale, navg);
+    // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
+    double nd;
+    if (!WRAP) { nd = ndrun; ndrun += 1.0; }                  // running index: integers stay exact in f64, one add per sample
+    else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
+    // demod_mod.c keeps the table phase in a float (t = fl32(f0*n)); dft_detect.c:1090-1093 keeps it in a double
+    float fr;
+    if (PH64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
+    else      fr = __builtin_amdgcn_fractf((float)(f0 * nd));
+    const float2v cs = { __builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr) };
+    const float2v z = cmul_pk(u, cs);                         // z = u * ex[n]  (demod_mod.c:744)
+#pragma unroll
+    for (int q = 0; q < Q_T; q++) {                           // P[row][q] += W_q[r] * z: one packed FMA per tap
+        const float2v wq = { w[q], w[q] };
+        acc[q] = __builtin_elementwise_fma(wq, z, acc[q]);
+    }
+}
+
+template <int Q_T, bool WRAP, bool PH64, int D_T>
 __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float *wt, float2 avg, double f0,
                                         uint32_t rown, uint32_t L, float dcmask,
                                         float2v (&acc)[Q_T], float2v &dcs) {
     const uint32_t towrap = L - rown;
-    const double nd0 = (double)rown;
-    const float2v navg = { -avg.x, -avg.y }, scale = { 3.0517578125e-05f, 3.0517578125e-05f }, msk = { dcmask, dcmask };
+    double nd0 = (double)rown;
+    const float2v navg = { -avg.x, -avg.y }, msk = { dcmask, dcmask };
+    if (D_T > 0) D = D_T;                                     // compile-time trip count
     float wn[Q_T];                                            // taps of the next step: scalar loads issued one step ahead
 #pragma unroll
     for (int q = 0; q < Q_T; q++) wn[q] = wt[q];
@@ -72,38 +110,16 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
 #pragma unroll
             for (int q = 0; q < Q_T; q++) wn[q] = wp[q];
         }
-        const uint32_t raw = row[r];
-        const float2v xf = { (float)(int)(short)(raw & 0xffffu), (float)(((int)raw) >> 16) };
-        // IQ-DC sums: int16 values are exact in f32 and a tile row sums to < 2^24, so the float sum is exact
-        dcs = __builtin_elementwise_fma(xf, msk, dcs);
-        // x = b/32768.0 is exact -> one rounding for (x - avg) as in the reference (demod_mod.c:484-493)
-        const float2v u = __builtin_elementwise_fma(xf, scale, navg);
-        // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
-        double nd;
-        if (!WRAP) nd = nd0 + (double)r;
-        else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
-        // demod_mod.c keeps the table phase in a float (t = fl32(f0*n)); dft_detect.c:1090-1093 keeps it in a double
-        float fr;
-        if (PH64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
-        else      fr = __builtin_amdgcn_fractf((float)(f0 * nd));
-        const float lr = __builtin_amdgcn_cosf(fr), li = __builtin_amdgcn_sinf(fr);
-        // z = u * ex[n]  (demod_mod.c:744), 4 scalar ops
-        const float t1 = u.y * li, t2 = u.y * lr;
-        const float2v z = { __builtin_fmaf(u.x, lr, -t1), __builtin_fmaf(u.x, li, t2) };
-#pragma unroll
-        for (int q = 0; q < Q_T; q++) {                      // P[row][q] += W_q[r] * z: one packed FMA per tap
-            const float2v wq = { w[q], w[q] };
-            acc[q] = __builtin_elementwise_fma(wq, z, acc[q]);
-        }
+        md_step<Q_T, WRAP, PH64>(row[r], r, w, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
     }
 }
 
-template <int Q_T, bool PH64>
+template <int Q_T, bool PH64, int D_T>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ uint32_t smem_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int D = a.D;
+    const int D = D_T > 0 ? D_T : a.D;
     constexpr int H = Q_T - 1;
     const int tile_dw = MD_ROWS * D;
     uint32_t *sRaw = smem_u + wave * (tile_dw + 4);
@@ -127,6 +143,7 @@ void k_mix_decimate(const MixDecArgs a) {
     float2 *yout = a.y + (size_t)ch * a.ring_len;
     const int total_dw = a.nblocks * D;
     const int nv = (D + 3) >> 2;                              // 16-byte loads per lane per tile
+    constexpr int NV_T = D_T > 0 ? (D_T + 3) / 4 : MD_NVMAX;
 
     // P of the previous tile (carry for the diagonal sum).  Segment 0 continues the previous call (P tail),
     // later segments start Q-1 rows early instead (those rows produce no output).
@@ -145,10 +162,21 @@ void k_mix_decimate(const MixDecArgs a) {
     }
 
     const int jt0 = (seg == 0) ? jb : jb - H;
-    u32x4_u pre[MD_NVMAX];
+    u32x4_u pre[NV_T];
+    // tile bytes -> registers: 16 bytes per lane per load, 64 lanes = 1 KB per load instruction.  A tile that lies
+    // completely inside the chunk takes the unchecked path (immediate offsets from one base address).
     auto fetch = [&](int jt) {
+        if (D_T > 0 && jt + MD_ROWS <= a.nblocks) {
+            const uint32_t *p = iq + (size_t)jt * D + 4 * lane;
 #pragma unroll
-        for (int v = 0; v < MD_NVMAX; v++) {
+            for (int v = 0; v < NV_T; v++) {
+                if (4 * (64 * v) + 3 < MD_ROWS * D_T)           // load v exists for lane 0; the last one only for the low lanes
+                    pre[v] = *reinterpret_cast<const u32x4_u *>((4 * (64 * v + 63) < MD_ROWS * D_T || 4 * (64 * v + lane) < MD_ROWS * D_T) ? p + 256 * v : p);
+            }
+            return;
+        }
+#pragma unroll
+        for (int v = 0; v < NV_T; v++) {
             if (v < nv) {
                 const int c = 64 * v + lane;                  // 16-byte chunk of the tile
                 int off = jt * D + 4 * c;                     // dword offset in the chunk
@@ -159,7 +187,7 @@ void k_mix_decimate(const MixDecArgs a) {
     };
     auto park = [&]() {
 #pragma unroll
-        for (int v = 0; v < MD_NVMAX; v++) {
+        for (int v = 0; v < NV_T; v++) {
             if (v < nv) {
                 const int c = 64 * v + lane;
                 if (4 * c < tile_dw) *reinterpret_cast<uint4 *>(sRaw + 4 * c) = make_uint4(pre[v].x, pre[v].y, pre[v].z, pre[v].w);
@@ -184,8 +212,8 @@ void k_mix_decimate(const MixDecArgs a) {
         float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if (nowrap) md_rows<Q_T, false, PH64>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
-        else        md_rows<Q_T, true, PH64>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
         sx += (int)dcs.x; sy += (int)dcs.y;
 
         // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
@@ -757,8 +785,13 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
     const dim3 grid(((a->n_ch + 7) / 8) * 8 * wgs_per_ch), blk(256);
     const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
-#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true>), grid, blk, lds, s, b); \
-                         else hipLaunchKernelGGL((k_mix_decimate<QT, false>), grid, blk, lds, s, b); } while (0)
+#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0>), grid, blk, lds, s, b); \
+                         else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0>), grid, blk, lds, s, b); } while (0)
+    if (a->Q == 7 && a->D == 50) {            // 2.4 Msps -> 48 kHz: decimation known at compile time
+        if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50>), grid, blk, lds, s, b);
+        else hipLaunchKernelGGL((k_mix_decimate<7, false, 50>), grid, blk, lds, s, b);
+        return 0;
+    }
     switch (a->Q) {
         case 1: MD_LAUNCH(1); break;
         case 2: MD_LAUNCH(2); break;
