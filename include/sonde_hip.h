@@ -33,6 +33,8 @@ extern "C" {
 
 /* sonde types (dsp.hdr / baud / BT / h presets of the reference callers) */
 #define SONDE_RS41  41          /* rs41mod.c:2812-2836: 4800 Bd, BT 0.5, h 0.6, 64-bit header, thres 0.7, hdmax 4 */
+#define SONDE_FRONTEND 0        /* no sonde: front-end only = the reference's demod/mod/iq_dec.c (mixer, decimator, optional
+                                 * IF low-pass / FM discriminator / FM low-pass); results are read with sonde_engine_read_tap */
 #define SONDE_DFM09  9          /* dfm09mod.c:1309,1560-1582: 2500 Bd Manchester, BT 0.5, h 1.8, 32-symbol raw header,
                                  * thres 0.65, hdmax 2, lpIQ 12 kHz, 8 x 280-bit frames sliced per header hit       */
 
@@ -77,7 +79,8 @@ typedef struct {
                               * dsp.opt_iq = 0, the reference's CPU-runnable configuration)                      */
     int32_t audio_channels;  /* SONDE_IN_AUDIO: interleaved channels per frame (1 or 2) and which one (--ch2 = 1) */
     int32_t audio_select;
-    int32_t reserved[1];
+    int32_t if_rate;         /* SONDE_FRONTEND: designated IF rate in Hz (iq_dec --IFbw k -> 1000 k, default 48000;
+                              * iq_dec.c:632-651); 0 elsewhere (48000, or 32000 with opt_min)                     */
 } sonde_cfg_t;
 
 /* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */

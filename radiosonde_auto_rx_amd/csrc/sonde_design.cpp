@@ -54,6 +54,28 @@ Decimator design_decimator(int sr_base, bool if_min) {
     return d;
 }
 
+// iq_dec's variant (iq_dec.c:632-666): the IF rate is a parameter (--IFbw), --min only narrows the transition band
+Decimator design_decimator_if(int sr_base, int if_target, bool narrow) {
+    Decimator d;
+    int if_sr = if_target;
+    d.decM = 1;
+    if (if_sr > sr_base) if_sr = sr_base;
+    if (if_sr < sr_base) {
+        while (sr_base % if_sr) if_sr += 1;
+        d.decM = sr_base / if_sr;
+    }
+    const float f_lp = (float)((if_sr + 20e3) / (4.0 * sr_base));
+    float t_bw = (float)(if_sr - 20e3);
+    if (narrow) t_bw = (float)(if_sr - 12e3);
+    if (t_bw < 0) t_bw = 10e3f;
+    t_bw /= sr_base;
+    int taps = (int)(4.0 / t_bw);
+    if (taps % 2 == 0) taps++;
+    d.if_sr = if_sr;
+    d.taps = design_lowpass(f_lp, taps);
+    return d;
+}
+
 // Mixer: the reference snaps the frequency to a multiple of d Hz (d = largest divisor <= 16 of the sample rate)
 // and tabulates ex[n] = cexp(2 pi i * fl32(f0*n)) over one period lut_len = sr/d.  The kernels evaluate the
 // same expression on the fly, so only (f0, lut_len) are needed.

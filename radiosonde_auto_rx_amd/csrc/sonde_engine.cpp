@@ -149,7 +149,8 @@ const char *sonde_strerror(int code) {
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || cfg->bits != 16) return SONDE_E_ARG;
-    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09) || cfg->opt_dc) return SONDE_E_ARG;
+    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) || cfg->opt_dc) return SONDE_E_ARG;
+    if (cfg->sonde_type == SONDE_FRONTEND && cfg->input == SONDE_IN_AUDIO) return SONDE_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
         fprintf(stderr, "libsonde_hip: no usable HIP device (the engine has no CPU fallback)\n");
@@ -163,7 +164,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     // ---- sonde preset (rs41mod.c:2591-2597,2812-2836,2882,2920-2923)
     std::string header;
     int lpiq_def, lpfm_bw;
-    if (cfg->sonde_type == SONDE_RS41) {
+    if (cfg->sonde_type == SONDE_RS41 || cfg->sonde_type == SONDE_FRONTEND) {   // front-end only: the sync preset is never used
         e->baud = 4800.f; e->bt = 0.5f; e->hmod = 0.6f; e->symlen = 1; e->symhd = 1; e->hdmax = 4; e->bitofs = 2;
         e->nbits = 510 * 8; e->l_win = 2.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
         header = kRs41Header; lpiq_def = 7400; lpfm_bw = 6000;
@@ -178,6 +179,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     // ---- init_buffers() arithmetic (demod_mod.c:1208-1474)
     const bool audio = cfg->input == SONDE_IN_AUDIO;
     if (audio) { e->dec.if_sr = cfg->sample_rate; e->dec.decM = 1; e->l_win = -1.0f; }     // opt_iq = 0: no front-end, whole-bit slicing (rs41mod.c:2920)
+    else if (cfg->sonde_type == SONDE_FRONTEND) e->dec = design_decimator_if(cfg->sample_rate, cfg->if_rate > 0 ? cfg->if_rate : 48000, cfg->opt_min != 0);
     else e->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);
     const int D = e->dec.decM, sr = e->dec.if_sr;
     if (D == 1) e->dec.taps.assign(1, 1.0f);                   // reference bypasses the FIR for decM == 1 (:751)
@@ -384,6 +386,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums;
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];
         a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
+        a.phase_f64 = (e->cfg.sonde_type == SONDE_FRONTEND);     // iq_dec.c:690 builds its table from a double phase
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
         { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
         prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);
@@ -398,11 +401,12 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     }
     const int n_if = n_samples / D;
     IfArgs b{};
-    b.y = e->d_y; b.tap_ifiq = e->cfg.keep_soft ? e->d_ifiq : nullptr; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
+    const bool fe = e->cfg.sonde_type == SONDE_FRONTEND;
+    b.y = e->d_y; b.tap_ifiq = (e->cfg.keep_soft || fe) ? e->d_ifiq : nullptr; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
     b.n = n_if; b.m0 = m_first;
     b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
     b.tone_on = 1; b.nwin = (int)e->sps;
-    b.fm_on = (e->cfg.keep_soft || !e->w_fm.empty()) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
+    b.fm_on = (e->cfg.keep_soft || fe || !e->w_fm.empty()) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
     b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);
@@ -415,8 +419,10 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
     c.state = e->d_state; c.delay = e->info.delay; c.frame_samples = e->frame_samples;
     c.ntypes = e->corr_types; c.isps = e->corr_isps; c.nsym = e->hdrlen / e->symhd; c.shapes = e->d_shapes; c.sym_type = e->d_symtype; c.sym_sign = e->d_symsign;
-    prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
-    launch_framesync(e, 0);
+    if (!fe) {
+        prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
+        launch_framesync(e, 0);
+    }
     hipMemcpyAsync(e->h_count + slot, e->d_fcount, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream_b);
     hipEventRecord(e->ev_b[slot], e->stream_b);
     e->call += 1;

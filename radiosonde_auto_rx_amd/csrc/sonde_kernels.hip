@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sonde_dev.h"
+#include <cstdlib>
 
 typedef short  short2v __attribute__((ext_vector_type(2)));
 
@@ -56,8 +57,11 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // halves, so no register shuffling is needed (the compiler's own lowering costs two extra moves per sample).
 __device__ __forceinline__ float2v cmul_pk(float2v u, float2v cs) {
     float2v t, z;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(u), "v"(cs));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(z) : "v"(u), "v"(cs), "v"(t));
+    // early-clobber outputs: a packed op whose op_sel crosses halves must not write a register pair it still reads.
+    // s_nop: cs comes straight from v_cos/v_sin, and gfx940+ needs one wait state between a transcendental result and
+    // its first VALU use — the compiler's hazard recognizer does not look into inline asm (seen as a corrupted real part).
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=&v"(t) : "v"(u), "v"(cs));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=&v"(z) : "v"(u), "v"(cs), "v"(t));
     return z;
 }
 
@@ -179,9 +183,15 @@ void k_mix_decimate(const MixDecArgs a) {
         for (int v = 0; v < NV_T; v++) {
             if (v < nv) {
                 const int c = 64 * v + lane;                  // 16-byte chunk of the tile
-                int off = jt * D + 4 * c;                     // dword offset in the chunk
-                if (4 * c >= tile_dw || off + 4 > total_dw) off = jt * D;   // beyond the tile / the chunk: any valid address
-                pre[v] = *reinterpret_cast<const u32x4_u *>(iq + off);
+                const int off = jt * D + 4 * c;               // dword offset in the chunk
+                if (4 * c < tile_dw && off + 4 <= total_dw) pre[v] = *reinterpret_cast<const u32x4_u *>(iq + off);
+                else if (4 * c < tile_dw && off < total_dw) { // the chunk ends inside this 16-byte piece: keep the samples that exist
+                    pre[v].x = iq[off];
+                    pre[v].y = off + 1 < total_dw ? iq[off + 1] : 0u;
+                    pre[v].z = off + 2 < total_dw ? iq[off + 2] : 0u;
+                    pre[v].w = 0u;
+                }
+                else pre[v] = u32x4_u{0u, 0u, 0u, 0u};          // beyond the tile / the chunk
             }
         }
     };
@@ -787,7 +797,8 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
 #define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0>), grid, blk, lds, s, b); \
                          else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0>), grid, blk, lds, s, b); } while (0)
-    if (a->Q == 7 && a->D == 50) {            // 2.4 Msps -> 48 kHz: decimation known at compile time
+    static const bool no_dt = getenv("SONDE_NO_DT") != nullptr;      // debugging aid: force the runtime-D variant
+    if (a->Q == 7 && a->D == 50 && !no_dt) {            // 2.4 Msps -> 48 kHz: decimation known at compile time
         if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50>), grid, blk, lds, s, b);
         else hipLaunchKernelGGL((k_mix_decimate<7, false, 50>), grid, blk, lds, s, b);
         return 0;

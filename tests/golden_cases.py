@@ -83,3 +83,13 @@ def audio_capture(name):
     case = make_golden.AUDIO_CASES[name]
     pcm, wav = make_golden.audio_capture(case)
     return pcm, wav, case
+
+
+IQDEC_NAMES = list(make_golden.IQDEC_CASES)
+
+
+@functools.lru_cache(maxsize=None)
+def load_iqdec(name):
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    g["stderr"] = str(g["stderr"])
+    return g

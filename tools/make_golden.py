@@ -56,6 +56,26 @@ def audio_cli(case):
     return "dfm09mod", ["-r", "--ecc"]
 
 
+# front end only (demod/mod/iq_dec.c): args in front of `- sr 16`; out = dtype of stdout after the optional WAV header
+IQDEC_CASES = {
+    "iqdec_2400k_bo16": dict(cap=dict(sr=2_400_000, seconds=0.5, fq=0.1, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=21, dc=0.01 + 0.02j), args=["--bo", "16"], out="i2"),
+    "iqdec_2400k_iq_lpIQ_f32": dict(cap=dict(sr=2_400_000, seconds=0.5, fq=-0.17, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=22), args=["--iq", "FQ", "--lpIQ"], out="f4"),
+    "iqdec_2400k_fm_wav": dict(cap=dict(sr=2_400_000, seconds=0.5, fq=0.0, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=23),
+                               args=["--FM", "--IFbw", "48", "--lpFM", "--wav", "--iq", "0.0"], out="f4", wav=46),
+    "iqdec_48k_passthrough": dict(cap=dict(sr=48_000, seconds=1.0, fq=0.0, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=24, dc=-0.03 + 0.01j), args=["--bo", "16"], out="i2"),
+    "iqdec_2400k_ifbw96_fm_dec": dict(cap=dict(sr=2_400_000, seconds=0.4, fq=0.05, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=25),
+                                      args=["--iq", "FQ", "--IFbw", "96", "--decFM", "--bo", "16"], out="i2"),
+}
+
+
+def iqdec_capture(case):
+    cap = dict(case["cap"]); sr = cap["sr"]
+    cap["fq"] = synth.snap_fq(cap["fq"], sr)
+    x = synth.rs41_capture(**cap)
+    args = [repr(cap["fq"]) if a == "FQ" else a for a in case["args"]] + ["-", str(sr), "16"]
+    return x, args
+
+
 # scanner (scan/dft_detect.c): gen = capture generator, mode 5 = --IQ fq, 1 = --iq, 0 = FM audio (WAV)
 SCAN_CASES = {
     "scan_rs41_2400k_dc": dict(gen="rs41", cap=dict(sr=2_400_000, seconds=1.5, fq=0.1, n_frames=1, t_first=0.3, noise_sigma=0.01, seed=5, f_offset_hz=-400.0),
@@ -215,6 +235,13 @@ def main():
                  floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]), fq=fq, ecc=ecc)
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "lines", len(lines), "hits", strict["n"], strict["mv_pos"], strict["nbits"], "floor_soft", d["floor_soft"])
+    for name, case in IQDEC_CASES.items():
+        x, args = iqdec_capture(case)
+        r = subprocess.run([os.path.join(bind.REFDIR, "iq_dec")] + args, input=x.tobytes(), capture_output=True)
+        hdr = case.get("wav", 0)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), header=np.frombuffer(r.stdout[:hdr], np.uint8),
+                            out=np.frombuffer(r.stdout[hdr:], "<" + case["out"]), stderr=np.array(r.stderr.decode()))
+        print(name, len(r.stdout), r.stderr.decode().split())
     for name, case in AUDIO_CASES.items():
         pcm, wav = audio_capture(case)
         sr = case["cap"]["sr"]
