@@ -101,21 +101,25 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
     double nd0 = (double)rown;
     const float2v navg = { -avg.x, -avg.y }, msk = { dcmask, dcmask };
     if (D_T > 0) D = D_T;                                     // compile-time trip count
-    float wn[Q_T];                                            // taps of the next step: scalar loads issued one step ahead
+    // two samples per iteration (written out: the inline asm of the complex multiply counts as convergent, which
+    // forbids a compiler-generated remainder loop); the taps of the next pair are fetched one iteration ahead
+    float wa[Q_T], wb[Q_T];
 #pragma unroll
-    for (int q = 0; q < Q_T; q++) wn[q] = wt[q];
-#pragma unroll 2
-    for (int r = 0; r < D; r++) {
-        float w[Q_T];
+    for (int q = 0; q < Q_T; q++) { wa[q] = wt[q]; wb[q] = wt[8 * (D > 1 ? 1 : 0) + q]; }
+    int r = 0;
+    for (; r + 1 < D; r += 2) {
+        float w0[Q_T], w1[Q_T];
 #pragma unroll
-        for (int q = 0; q < Q_T; q++) w[q] = wn[q];
+        for (int q = 0; q < Q_T; q++) { w0[q] = wa[q]; w1[q] = wb[q]; }
         {
-            const float *wp = wt + 8 * (r + 1 < D ? r + 1 : r);
+            const float *pa = wt + 8 * (r + 2 < D ? r + 2 : D - 1), *pb = wt + 8 * (r + 3 < D ? r + 3 : D - 1);
 #pragma unroll
-            for (int q = 0; q < Q_T; q++) wn[q] = wp[q];
+            for (int q = 0; q < Q_T; q++) { wa[q] = pa[q]; wb[q] = pb[q]; }
         }
-        md_step<Q_T, WRAP, PH64>(row[r], r, w, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
+        md_step<Q_T, WRAP, PH64>(row[r], r, w0, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
+        md_step<Q_T, WRAP, PH64>(row[r + 1], r + 1, w1, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
     }
+    if (r < D) md_step<Q_T, WRAP, PH64>(row[r], r, wa, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
 }
 
 template <int Q_T, bool PH64, int D_T>
