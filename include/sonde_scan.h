@@ -90,7 +90,8 @@ int  sonde_scan_info(const sonde_scan_t *s, sonde_scan_info_t *info);
 
 /* Push n_samples per channel (complex int16 pairs for the IQ forms, audio frames for SONDE_SCAN_AUDIO); replaces the
  * `while (f32buf_sample(fp) != EOF)` loop of main (dft_detect.c:1483-1651).  Runs every correlation window that is
- * complete, then the reference's decision logic per channel.  Synchronous.  BBIQ: n_samples % decM == 0. */
+ * complete, then the reference's decision logic per channel.  Synchronous.  BBIQ: n_samples % decM == 0.
+ * ch_stride == 0: one wideband stream shared by all channels (each mixes its own fq out of it) — the channelizer form. */
 int  sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stride, int32_t n_samples);
 

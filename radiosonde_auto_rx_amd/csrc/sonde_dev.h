@@ -22,6 +22,8 @@ struct MixDecArgs {
     float2 *y;                // [n_ch][ring_len] decimated IQ ring
     int ring_len;
     uint32_t m0;              // IF index of the chunk's first output
+    const float *wtab_g;      // D > 64: [D][8] tap table in global memory, and the piece length DS (divides D, <= 64)
+    int DS;
     int phase_f64;            // mixer phase f0*n kept in double (dft_detect.c:1090) instead of the float of demod_mod.c:1290
 };
 

@@ -40,7 +40,7 @@ struct sonde_engine {
     unsigned read_idx = 0;             // frames already handed to the caller (monotonic)
     bool eof_pending = false;          // an end-of-stream framesync ran after the last counter snapshot
     // design
-    Decimator dec; int Q = 0, G = 8;
+    Decimator dec; int Q = 0, G = 8, DS = 0; float *d_wtab = nullptr;
     std::vector<float> w_iq, w_fm, match, wtab;
     float sps = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;
     int symlen = 1, symhd = 1, hdmax = 0, bitofs = 0, nbits = 0, hdrlen = 0;
@@ -187,7 +187,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->sps = (float)cfg->sample_rate / e->baud;
     e->sps /= (float)D;
     e->Q = (T + D - 1) / D;
-    if (D > 64 || e->Q > 8) { delete e; return SONDE_E_ARG; }       // decM <= 64 (input rate <= 3.07 Msps at IF 48 kHz)
+    if (e->Q > 8 || D > 1024) { delete e; return SONDE_E_ARG; }
     if ((cfg->opt_lp & SONDE_LP_IQ) && !audio) {
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
@@ -225,8 +225,14 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         const int pad = e->Q * D - T;
         std::vector<float> wpad((size_t)e->Q * D, 0.f);
         for (int k = 0; k < T; k++) wpad[pad + k] = e->dec.taps[k];
-        e->wtab.assign(64 * 8, 0.f);
+        e->wtab.assign((size_t)std::max(64, D) * 8, 0.f);
         for (int r = 0; r < D; r++) for (int q = 0; q < e->Q; q++) e->wtab[(size_t)r * 8 + q] = wpad[(size_t)D * q + r];
+        if (D > 64) {                                         // wide decimation (k_mix_decimate_wide): taps in global memory
+            for (int k = 64; k >= 4; k--) if (D % k == 0) { e->DS = k; break; }
+            if (!e->DS || e->Q < 5) { delete e; return SONDE_E_ARG; }
+            if (dalloc(&e->d_wtab, e->wtab.size(), false)) { delete e; return SONDE_E_NOMEM; }
+            HIPCHK(hipMemcpy(e->d_wtab, e->wtab.data(), e->wtab.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     // ---- mixer: snapped frequency per channel (xlt_fq = -fq, rs41mod.c:2685); the table period is common
     {
@@ -341,7 +347,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
-                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw };
+                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -381,7 +387,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         MixDecArgs a{};
         a.iq = (const int16_t *)d_iq + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
         a.D = D; a.Q = e->Q; a.G = e->G;
-        memcpy(a.wtab, e->wtab.data(), sizeof a.wtab); a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len;
+        memcpy(a.wtab, e->wtab.data(), sizeof a.wtab); a.wtab_g = e->d_wtab; a.DS = e->DS; a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len;
         a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
         a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums;
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];

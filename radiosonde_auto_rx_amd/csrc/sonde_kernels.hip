@@ -258,6 +258,100 @@ void k_mix_decimate(const MixDecArgs a) {
     }
 }
 
+// Decimation factors above 64 (input rates above ~3 Msps, e.g. a 10 Msps wideband stream): same lane-per-block scheme,
+// but a block's D samples are walked in NS = D/DS pieces of DS <= 64 samples.  Each lane stages its own piece in LDS
+// (16-byte loads along its row), so there is no cross-lane traffic at all; the taps come from a global table.  Not
+// software-pipelined — this variant serves the wideband scanner, not the headline path.
+template <int Q_T, bool PH64>
+__global__ __launch_bounds__(256)
+void k_mix_decimate_wide(const MixDecArgs a) {
+    extern __shared__ uint32_t smem_u[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.D, DS = a.DS, NS = D / DS, pitch = (DS + 3) & ~3;
+    constexpr int H = Q_T - 1;
+    uint32_t *sRow = smem_u + (wave * MD_ROWS + lane) * pitch;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
+    const int wg = slot % a.wgs_per_ch;
+    if (ch >= a.n_ch) return;
+    const int seg = wg * 4 + wave;
+    const int rows_per_seg = MD_ROWS * a.G - H;
+    const int jb = seg * rows_per_seg;
+    if (jb >= a.nblocks) return;
+    const int je = min(a.nblocks, jb + rows_per_seg);
+
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const float2 avg = a.dc_avg[ch];
+    const double f0 = a.chan_f0[ch];
+    const uint32_t L = (uint32_t)a.lut_len;
+    float2 *yout = a.y + (size_t)ch * a.ring_len;
+    const long long total_dw = (long long)a.nblocks * D;
+
+    float2v pv[Q_T];
+#pragma unroll
+    for (int q = 0; q < Q_T; q++) pv[q] = (float2v){0.f, 0.f};
+    if (seg == 0 && lane >= MD_ROWS - H) {
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) {
+            const float2 v = a.ptail_in[((size_t)ch * 8 + (lane - (MD_ROWS - H))) * 8 + q];
+            pv[q] = (float2v){v.x, v.y};
+        }
+    }
+    if (seg == 0 && a.nblocks < H && lane < H - a.nblocks) {
+        for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + lane) * 8 + q] = a.ptail_in[((size_t)ch * 8 + lane + a.nblocks) * 8 + q];
+    }
+    const int jt0 = (seg == 0) ? jb : jb - H;
+    int sx = 0, sy = 0;
+    for (int jt = jt0; jt < je; jt += MD_ROWS) {
+        const int j = jt + lane;
+        const bool outrow = j >= jb && j < je;
+        float2v acc[Q_T];
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
+        float2v dcs = {0.f, 0.f};
+        const uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)j * (uint64_t)D) % L);
+        for (int sub = 0; sub < NS; sub++) {
+            const long long o0 = (long long)j * D + (long long)sub * DS;
+            for (int v = 0; v < pitch / 4; v++) {
+                const long long o = o0 + 4 * v;
+                uint4 w = make_uint4(0u, 0u, 0u, 0u);
+                if (j < a.nblocks) {
+                    if (o + 4 <= total_dw) { const u32x4_u t = *reinterpret_cast<const u32x4_u *>(iq + o); w = make_uint4(t.x, t.y, t.z, t.w); }
+                    else { if (o < total_dw) w.x = iq[o]; if (o + 1 < total_dw) w.y = iq[o + 1]; if (o + 2 < total_dw) w.z = iq[o + 2]; }
+                }
+                *reinterpret_cast<uint4 *>(sRow + 4 * v) = w;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            uint32_t rs = rown + (uint32_t)(sub * DS); if (rs >= L) rs -= L;
+            md_rows<Q_T, true, PH64, 0>(sRow, DS, a.wtab_g + 8 * sub * DS, avg, f0, rs, L, outrow ? 1.f : 0.f, acc, dcs);
+            sx += (int)dcs.x; sy += (int)dcs.y; dcs = (float2v){0.f, 0.f};
+        }
+        float yr = acc[H].x, yi = acc[H].y;
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int k = H - q, src = (lane - k) & 63;
+            const float cr = __shfl(acc[q].x, src), ci = __shfl(acc[q].y, src);
+            const float or_ = __shfl(pv[q].x, src), oi = __shfl(pv[q].y, src);
+            yr += (lane >= k) ? cr : or_;
+            yi += (lane >= k) ? ci : oi;
+        }
+        if (outrow) yout[(a.m0 + (uint32_t)j) & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
+        if (j >= a.nblocks - H && j < a.nblocks) {
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) pv[q] = acc[q];
+    }
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
+    if (lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch), (unsigned long long)(long long)sx);
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch + 1), (unsigned long long)(long long)sy);
+    }
+}
+
 // avg = (float)(sum / (float)maxcnt) with sum = S/32768 exact in double (demod_mod.c:498-503)
 __global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float maxcnt) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -793,11 +887,26 @@ void k_framesync(const SyncArgs a) {
 // launch wrappers (called from sonde_engine.cpp)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
-    if (a->D < 1 || a->D > 64 || a->Q < 1 || a->Q > 8) return -1;
+    if (a->D < 1 || a->Q < 1 || a->Q > 8) return -1;
     const int rows_per_wg = 4 * (MD_ROWS * a->G - (a->Q - 1));
     const int wgs_per_ch = (a->nblocks + rows_per_wg - 1) / rows_per_wg;
     MixDecArgs b = *a; b.wgs_per_ch = wgs_per_ch;
     const dim3 grid(((a->n_ch + 7) / 8) * 8 * wgs_per_ch), blk(256);
+    if (a->D > 64) {                           // wide variant: D walked in pieces of DS samples, taps from a.wtab_g
+        if (!a->wtab_g || a->DS < 1 || a->DS > 64 || a->D % a->DS) return -1;
+        const size_t ldsw = (size_t)4 * MD_ROWS * ((a->DS + 3) & ~3) * sizeof(uint32_t);
+#define MDW_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate_wide<QT, true>), grid, blk, ldsw, s, b); \
+                          else hipLaunchKernelGGL((k_mix_decimate_wide<QT, false>), grid, blk, ldsw, s, b); } while (0)
+        switch (a->Q) {
+            case 5: MDW_LAUNCH(5); break;
+            case 6: MDW_LAUNCH(6); break;
+            case 7: MDW_LAUNCH(7); break;
+            case 8: MDW_LAUNCH(8); break;
+            default: return -1;
+        }
+#undef MDW_LAUNCH
+        return 0;
+    }
     const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
 #define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0>), grid, blk, lds, s, b); \
                          else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0>), grid, blk, lds, s, b); } while (0)

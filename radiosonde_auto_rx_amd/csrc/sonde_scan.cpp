@@ -145,7 +145,7 @@ struct sonde_scan {
     sonde_scan_info_t info{};
     hipStream_t stream = nullptr;
     // design
-    Decimator dec; int Q = 0; int lut_len = 1;
+    Decimator dec; int Q = 0; int lut_len = 1; int DS = 0; float *d_wtab = nullptr;
     std::vector<float> wtab;
     ScanTpl tpl[SC_NTPL]; float thres[kNrs]; uint32_t disabled = 0;
     int K = 0, delay = 0, nstreams = 0, nfilt = 0, filt_stream[3] = {0, 0, 0}, raw_stream = 0, lpiq_taps = 0, lpfm_taps = 0;
@@ -208,12 +208,17 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
         if (D == 1) s->dec.taps.assign(1, 1.0f);
         const int T = (int)s->dec.taps.size();
         s->Q = (T + D - 1) / D;
-        if (D > 64 || s->Q > 8) { delete s; return SONDE_E_ARG; }
+        if (s->Q > 8 || D > 1024) { delete s; return SONDE_E_ARG; }
         const int pad = s->Q * D - T;
         std::vector<float> wpad((size_t)s->Q * D, 0.f);
         for (int k = 0; k < T; k++) wpad[pad + k] = s->dec.taps[k];
-        s->wtab.assign(64 * 8, 0.f);
+        s->wtab.assign((size_t)std::max(64, D) * 8, 0.f);
         for (int r = 0; r < D; r++) for (int q = 0; q < s->Q; q++) s->wtab[(size_t)r * 8 + q] = wpad[(size_t)D * q + r];
+        if (D > 64) {                                         // wide decimation: taps in global memory, D walked in pieces of DS
+            for (int k = 64; k >= 4; k--) if (D % k == 0) { s->DS = k; break; }
+            if (!s->DS || s->Q < 5) { delete s; return SONDE_E_ARG; }
+            if (dupload(&s->d_wtab, s->wtab)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
+        }
         std::vector<double> f0s(C);
         for (int c = 0; c < C; c++) {
             const Mixer m = design_mixer(-std::max(-0.5, std::min(0.5, fq[c])), cfg->sample_rate);
@@ -326,7 +331,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_items) hipHostFree(s->h_items);
     if (s->h_res) hipHostFree(s->h_res);
     void *ptrs[] = { s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -412,7 +417,7 @@ static void decide(sonde_scan *s, int ch, const ScanRes *res) {
 int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stride, int32_t n_samples) {
     if (!s || !d_in) return SONDE_E_ARG;
     const int C = s->cfg.n_channels, D = s->info.decM, mode = s->cfg.iq_mode;
-    if (n_samples <= 0 || n_samples > s->cfg.max_chunk || n_samples % D || ch_stride < n_samples) return SONDE_E_RANGE;
+    if (n_samples <= 0 || n_samples > s->cfg.max_chunk || n_samples % D || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;   // stride 0: one wideband stream shared by all channels
     hipEvent_t ev[4]; for (auto &e : ev) hipEventCreate(&e);
     const uint32_t m_first = s->m_out;
     hipEventRecord(ev[0], s->stream);
@@ -429,7 +434,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
             if (mode == SONDE_SCAN_BBIQ) {
                 MixDecArgs a{};
                 a.iq = (const int16_t *)d_in + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
-                a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
+                a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.DS = s->DS; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
                 a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
                 a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums;
                 a.ptail_in = s->d_ptail[s->ptail_cur]; a.ptail_out = s->d_ptail[s->ptail_cur ^ 1];
@@ -508,8 +513,17 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
 int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples) {
     if (!s || !h_in) return SONDE_E_ARG;
     const int C = s->cfg.n_channels;
-    if (n_samples <= 0 || n_samples > s->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
+    if (n_samples <= 0 || n_samples > s->cfg.max_chunk || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;
     const size_t unit = s->cfg.iq_mode == SONDE_SCAN_AUDIO ? 2 * (size_t)std::max(1, s->cfg.audio_channels) : 4;
+    if (ch_stride == 0) {                                  // one wideband stream: staged once, every channel mixes its own fq out of it
+        const size_t need1 = (size_t)n_samples * unit;
+        if (need1 > s->stage_bytes) {
+            if (s->d_stage) { hipStreamSynchronize(s->stream); hipFree(s->d_stage); s->d_stage = nullptr; }
+            HIPCHK(hipMalloc(&s->d_stage, need1)); s->stage_bytes = need1;
+        }
+        HIPCHK(hipMemcpyAsync(s->d_stage, h_in, need1, hipMemcpyHostToDevice, s->stream));
+        return sonde_scan_process_device(s, s->d_stage, 0, n_samples);
+    }
     const size_t need = (size_t)C * n_samples * unit;
     if (need > s->stage_bytes) {
         if (s->d_stage) { hipStreamSynchronize(s->stream); hipFree(s->d_stage); s->d_stage = nullptr; }

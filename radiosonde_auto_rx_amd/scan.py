@@ -95,15 +95,16 @@ class Scanner:
 
     __del__ = close
 
-    def process_host(self, x: np.ndarray):
-        """x: int16 [n_channels, 2*n] (IQ forms) or [n_channels, n*audio_channels] (FM audio)."""
+    def process_host(self, x: np.ndarray, shared: bool = False):
+        """x: int16 [n_channels, 2*n] (IQ forms) or [n_channels, n*audio_channels] (FM audio).
+        shared=True: x is ONE wideband stream [2*n] that every channel mixes its own fq out of (channel stride 0)."""
         x = np.ascontiguousarray(x, dtype=np.int16)
         if x.ndim == 1:
             x = x[None, :]
-        assert x.shape[0] == self.n_channels
+        assert shared or x.shape[0] == self.n_channels
         per = 2 if self.iq_mode != AUDIO else self.audio_channels
         n = x.shape[1] // per
-        _chk(_lib().sonde_scan_process_host(self._h, x.ctypes.data_as(C.c_void_p), n, n))
+        _chk(_lib().sonde_scan_process_host(self._h, x.ctypes.data_as(C.c_void_p), 0 if shared else n, n))
 
     def process_device(self, ptr: int, ch_stride: int, n: int):
         _chk(_lib().sonde_scan_process_device(self._h, C.c_void_p(ptr), ch_stride, n))

@@ -370,3 +370,37 @@ def wav_bytes(pcm: np.ndarray, sr: int, nch: int = 1) -> bytes:
     data = np.ascontiguousarray(pcm, dtype="<i2").tobytes()
     hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, nch, sr, sr * nch * 2, nch * 2, 16)
     return hdr + b"data" + struct.pack("<I", len(data)) + data
+
+
+def wideband_capture(sr: int, seconds: float, signals, *, noise_sigma: float = 0.01, seed: int = 1) -> np.ndarray:
+    """One wideband int16 IQ stream carrying several sondes (BASELINE config 3): signals = list of dicts
+    {kind: "rs41"|"dfm"|"m10", fq, t_first, amp, ...}; each burst is generated at baseband and shifted to fq*sr."""
+    rng = np.random.default_rng(seed)
+    n = int(round(sr * seconds))
+    x = np.zeros(n, dtype=np.complex128)
+    for k, sg in enumerate(signals):
+        kind, fq, t0, amp = sg["kind"], sg["fq"], sg.get("t_first", 0.05), sg.get("amp", 0.1)
+        if kind == "rs41":
+            bits = rs41_onair_bits(rs41_frame(1000 + k, "W%07d" % k, rng=np.random.default_rng(seed * 31 + k)))
+            b = gfsk_baseband(bits, sr, 4800.0, sg.get("dev_hz", 2400.0))
+        elif kind == "dfm":
+            r2 = np.random.default_rng(seed * 37 + k)
+            fb = np.concatenate([dfm_frame_bits([int(v) for v in r2.integers(0, 16, 7)], [int(v) for v in r2.integers(0, 16, 13)],
+                                                [int(v) for v in r2.integers(0, 16, 13)]) for _ in range(int(seconds * 2500 / 560) + 1)])
+            sym = np.empty(2 * len(fb), dtype=np.uint8); sym[0::2] = 1 - fb; sym[1::2] = fb
+            b = gfsk_baseband(sym, sr, 2500.0, 2400.0, bt=0.5)
+        else:
+            nsym = int((seconds - t0) * 9616.0)
+            sym = np.tile(np.array([1, 0, 0, 1], dtype=np.uint8), nsym // 4 + 1)[:nsym]
+            fr = m10_symbols(sg.get("type_bytes", (0x64, 0x9F)), rng=np.random.default_rng(seed * 41 + k))
+            s0 = int(0.02 * 9616) // 4 * 4
+            sym[s0:s0 + len(fr)] = fr[:max(0, nsym - s0)]
+            b = gfsk_baseband(sym, sr, 9616.0, 3300.0, bt=1.0)
+        s0 = int(round(t0 * sr))
+        m = min(len(b), n - s0)
+        x[s0:s0 + m] += amp * b[:m] * np.exp(2j * np.pi * fq * np.arange(s0, s0 + m))
+    x += noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    return out

@@ -134,3 +134,35 @@ def test_cli_dft_detect_matches_reference(name):
     assert r.returncode == g["rc"]
     if case["mode"] == 5:
         assert r.stderr.decode().splitlines()[:2] == ["IF: %d" % g["consts"]["sr_if"], "dec: %d" % g["consts"]["decM"]]
+
+
+def test_scan_wideband_shared_stream_10msps():
+    """BASELINE config 3 in small: one 10 Msps stream, five channels mixed out of it by one engine (channel stride 0,
+    decimation 200 -> the wide decimator variant), each compared with `dft_detect --IQ fq --dc` of the reference."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    from radiosonde_auto_rx_amd.scan import Scanner, BBIQ
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "scan_wide_10M.npz"), allow_pickle=False))
+    x, fqs = make_golden.wide_capture()
+    assert np.allclose(fqs, g["fqs"])
+    sr = make_golden.WIDE_CASE["sr"]
+    sc = Scanner(sr, fq=fqs, iq_mode=BBIQ, dc=True, cont=True, max_chunk=2_000_000)
+    consts = json.loads(str(g["consts"]))
+    assert sc.info["decM"] == consts["decM"] == 200 and sc.info["K"] == consts["K"] and sc.info["L"] == consts["L"]
+    wins = {c: [] for c in range(len(fqs))}
+    dets = {c: [] for c in range(len(fqs))}
+    n = len(x) // 2
+    for s0 in range(0, n, 2_000_000):
+        sc.process_host(x[2 * s0:2 * min(n, s0 + 2_000_000)], shared=True)
+        for w in sc.last_windows():
+            wins[w["channel"]].append(w)
+        for d in sc.fetch(verbose=True):
+            dets[d["channel"]].append(d)
+    for c in range(len(fqs)):
+        gc = {k: g["%s%d" % (k, c)] for k in ("mv", "mpos", "mp", "dc", "herrs", "m10", "pos")}
+        assert len(wins[c]) == len(gc["pos"])
+        _check_windows(wins[c], gc)
+        assert "".join(d["line"] + "\n" for d in dets[c]) == str(g["stdout%d" % c])
+        assert sc.result(c) % 256 == int(g["rc%d" % c])

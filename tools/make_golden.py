@@ -94,6 +94,21 @@ SCAN_CASES = {
 }
 
 
+# one wideband stream, several channels mixed out of it (BASELINE config 3): dft_detect --IQ fq --dc on each
+WIDE_CASE = dict(sr=10_000_000, seconds=0.4, seed=5, noise_sigma=0.01,
+                 signals=[dict(kind="rs41", fq=0.12, t_first=0.04, amp=0.12), dict(kind="dfm", fq=-0.2, t_first=0.0, amp=0.1),
+                          dict(kind="m10", fq=0.31, t_first=0.03, amp=0.1)],
+                 extra_fq=[0.0, -0.35])
+
+
+def wide_capture():
+    c = WIDE_CASE; sr = c["sr"]
+    sig = [dict(s, fq=synth.snap_fq(s["fq"], sr)) for s in c["signals"]]
+    x = synth.wideband_capture(sr, c["seconds"], sig, noise_sigma=c["noise_sigma"], seed=c["seed"])
+    fqs = [s["fq"] for s in sig] + [synth.snap_fq(f, sr) for f in c["extra_fq"]]
+    return x, fqs
+
+
 def scan_capture(case):
     """-> (samples int16, fq, stdin bytes for the CLI)"""
     cap = dict(case["cap"]); sr = cap["sr"]
@@ -257,6 +272,16 @@ def main():
                  floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]))
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "lines", len(lines), "hits", strict["n"], strict["mv"], "floor_soft", d["floor_soft"])
+    x, fqs = wide_capture()
+    d = dict(fqs=np.array(fqs))
+    for c, fq in enumerate(fqs):
+        out, err, rc = bind.ref_run("dft_detect", ["-v", "-c", "--IQ", repr(fq), "--dc", "-", str(WIDE_CASE["sr"]), "16"], x)
+        r = bind.ref_scan_windows(x, WIDE_CASE["sr"], iq_mode=5, fq=fq, dc=True, max_win=64)
+        d["stdout%d" % c] = np.array(out); d["rc%d" % c] = rc; d["consts"] = json.dumps(r["consts"])
+        for k in ("mv", "mpos", "mp", "dc", "herrs", "m10", "pos"):
+            d["%s%d" % (k, c)] = r[k]
+        print("scan_wide_10M ch", c, fq, "rc", rc, repr(out))
+    np.savez_compressed(os.path.join(outdir, "scan_wide_10M.npz"), **d)
     for name, case in SCAN_CASES.items():
         x, fq, stdin = scan_capture(case)
         sr = case["cap"]["sr"]
