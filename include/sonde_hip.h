@@ -169,6 +169,16 @@ void *sonde_engine_stream(sonde_engine_t *e);
 int  sonde_engine_profile(sonde_engine_t *e, int enable);
 int  sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches);
 
+/* Soft-bit input (`rs41mod --softin [-i]` behind `fsk_demod -s`, decode.py:901-909): float32 soft bits in, frames out.
+ * find_softbinhead / corr_softhdb (demod_mod.c:1692-1762) + the bit loop of rs41mod.c:2893-2968; host side (bit-rate work).
+ * invert_stream = --softinv (f32soft_read inv), opt_inv = -i (gpx.option.inv), opt_auto = --auto. */
+typedef struct sonde_softin sonde_softin_t;
+int  sonde_softin_create(int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto, sonde_softin_t **out);
+void sonde_softin_destroy(sonde_softin_t *s);
+int  sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n);
+int  sonde_softin_finish(sonde_softin_t *s);               /* EOF: emit the frame in progress (rs41mod.c:2931,2965) */
+int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
+
 /* Raw text line of `rs41mod -r` for one frame (rs41mod.c:2530-2545); returns strlen. buf >= 1100 bytes */
 int  sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen);
 

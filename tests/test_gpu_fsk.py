@@ -120,6 +120,10 @@ def test_cli_fsk_demod_matches_reference_and_decodes():
         if "rs41_lines" in g and os.path.exists(ref):
             dec = subprocess.run([ref, "--softin", "-i", "-r", "--ecc2"], input=r.stdout, capture_output=True, timeout=60)
             assert dec.stdout.decode().splitlines() == g["rs41_lines"]
+        if "rs41_lines" in g:                                   # and through this repo's own soft-input framer
+            dec = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "-i", "-r", "--ecc2"], input=r.stdout,
+                                 capture_output=True, timeout=60)
+            assert dec.stdout.decode().splitlines() == g["rs41_lines"]
     # hard-decision output: one byte per bit
     g = load_fsk("fsk_rs41_48k_peak")
     x, case = fsk_capture("fsk_rs41_48k_peak")

@@ -1,0 +1,46 @@
+"""Soft-bit input framing (`rs41mod --softin -i`, the consumer of `fsk_demod -s` in auto_rx's decode.py:901-909).
+
+Host-side bit-rate logic of libsonde_hip (sonde_softin_*), no GPU involved: the reference's fsk_demod soft decisions stored
+in the modem fixtures must frame and decode to exactly the lines the reference's own `rs41mod --softin -i -r --ecc2` printed."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from golden_cases import load_fsk
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["fsk_rs41_48k_mask", "fsk_rs41_48k_peak"])
+def test_softin_cli_matches_reference_lines(name):
+    from radiosonde_auto_rx_amd import engine
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    g = load_fsk(name)
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "-i", "-r", "--ecc2"],
+                       input=g["sd"].astype("<f4").tobytes(), capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.decode().splitlines() == g["rs41_lines"]
+    # wrong polarity without -i: the header correlates negatively and is rejected (rs41mod.c:2888-2891)
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "-r", "--ecc2"],
+                       input=g["sd"].astype("<f4").tobytes(), capture_output=True, timeout=60)
+    assert r.stdout == b""
+    # --softinv negates the stream instead
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softinv", "-r", "--ecc2"],
+                       input=g["sd"].astype("<f4").tobytes(), capture_output=True, timeout=60)
+    assert r.stdout.decode().splitlines() == g["rs41_lines"]
+
+
+def test_softin_truncated_stream_emits_partial_frame():
+    """EOF inside a frame: the reference prints the frame with the bytes read so far (rs41mod.c:2931,2965)."""
+    g = load_fsk("fsk_rs41_48k_mask")
+    sd = g["sd"].astype("<f4").ravel()
+    ref = os.path.join(ROOT, "oracle", "_ref", "rs41mod")
+    if not os.path.exists(ref):
+        pytest.skip("compiled reference not present")
+    cut = sd[:len(sd) * 55 // 100]
+    a = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "-i", "-r", "--ecc2"], input=cut.tobytes(), capture_output=True)
+    b = subprocess.run([ref, "--softin", "-i", "-r", "--ecc2"], input=cut.tobytes(), capture_output=True)
+    assert a.stdout == b.stdout and a.stdout
