@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=int(os.environ.get("SONDE_BENCH_CHANNELS", "512")), help="channels per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lag", type=int, default=0, help="1 = pipelined frame fetch (see step())")
+    ap.add_argument("--lag", type=int, default=0, help="1 = frame fetch one step behind (see step())")
+    ap.add_argument("--two-streams", action="store_true", help="with --lag 1: IF-rate kernels on a second HIP stream")
     args = ap.parse_args()
 
     import torch
@@ -123,7 +124,7 @@ def main():
     del bank_t
     torch.cuda.synchronize()
 
-    eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=args.lag > 0)
+    eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=(args.lag > 0 and args.two_streams))
     summary = torch.zeros(C, 4, device=dev)
 
     # Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): one
@@ -149,7 +150,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.fetch_frames_np(lag=0)
-    eng.profile(True)
+    eng.profile(int(os.environ.get("SONDE_BENCH_PROF", "2")))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -165,7 +165,8 @@ int  sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int6
 /* HIP stream the engine enqueues on (hipStream_t), for event timing by the caller */
 void *sonde_engine_stream(sonde_engine_t *e);
 /* average GPU time (ms) of the named kernel since the last reset, measured with HIP events on the
- * engine stream when profiling is enabled; names: "mix_decimate","if_chain","header_corr","framesync" */
+ * engine stream when profiling is enabled; names: "mix_decimate","if_chain","header_corr","framesync".
+ * enable = 1 brackets only the dominant kernel (k_mix_decimate), 2 every kernel, 0 none */
 int  sonde_engine_profile(sonde_engine_t *e, int enable);
 int  sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches);
 
@@ -178,6 +179,8 @@ void sonde_softin_destroy(sonde_softin_t *s);
 int  sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n);
 int  sonde_softin_finish(sonde_softin_t *s);               /* EOF: emit the frame in progress (rs41mod.c:2931,2965) */
 int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
+/* SONDE_DFM09 framers (dfm09mod --softin, dfm09mod.c:1604-1720: two soft symbols per bit, 8 frames per header hit) */
+int  sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max);
 
 /* Raw text line of `rs41mod -r` for one frame (rs41mod.c:2530-2545); returns strlen. buf >= 1100 bytes */
 int  sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen);

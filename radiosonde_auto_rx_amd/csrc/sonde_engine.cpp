@@ -67,7 +67,7 @@ struct sonde_engine {
     std::vector<uint8_t> last_frame;   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
     // profiling
-    bool prof = false; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
+    bool prof = false, prof_skip = false; int prof_level = 2; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
 };
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
@@ -77,13 +77,14 @@ template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
 }
 
 static void prof_begin(sonde_engine *e, const char *name, hipStream_t s) {
-    if (!e->prof) return;
+    if (!e->prof || (e->prof_level == 1 && strcmp(name, "mix_decimate") != 0)) { e->prof_skip = true; return; }
+    e->prof_skip = false;
     PendingEvt p; p.name = name;
     hipEventCreate(&p.a); hipEventCreate(&p.b);
     hipEventRecord(p.a, s);
     e->pend.push_back(p);
 }
-static void prof_end(sonde_engine *e, hipStream_t s) { if (e->prof) hipEventRecord(e->pend.back().b, s); }
+static void prof_end(sonde_engine *e, hipStream_t s) { if (e->prof && !e->prof_skip) hipEventRecord(e->pend.back().b, s); }
 static void prof_collect(sonde_engine *e) {
     for (auto &p : e->pend) {
         float ms = 0; hipEventSynchronize(p.b); hipEventElapsedTime(&ms, p.a, p.b);
@@ -591,7 +592,7 @@ int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64
 int sonde_engine_profile(sonde_engine_t *e, int enable) {
     if (!e) return SONDE_E_ARG;
     (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); prof_collect(e);
-    e->prof = enable != 0; e->stats.clear();
+    e->prof = enable != 0; e->prof_level = enable == 1 ? 1 : 2; e->stats.clear();    // 1: dominant kernel only (2 events per launch), 2: every kernel
     return 0;
 }
 

@@ -112,6 +112,10 @@ void k_scan_if(const ScanIfArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_scan_corr
 // ------------------------------------------------------------------------------------------------
+// LDS index of element i: one pad element per 8 keeps the stride-8 and stride-64 element accesses of the first two
+// register passes (and the bit-reversed store) off the same banks: position i + (i >> 3)
+#define XI(i) ((i) + ((i) >> 3))
+
 __device__ __forceinline__ int brev13(int k) { return (int)(__brev((unsigned)k) >> (32 - SC_LOG2N)); }
 
 // R merged radix-2 decimation-in-time stages starting at stage t0 (bit-reversed in -> natural out), groups of 2^R
@@ -128,7 +132,7 @@ __device__ __forceinline__ void dit_pass(float2 *x, const float2 *tws, const int
         const int base = (high << (p_lo + R)) | low;
         float2 v[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) v[e] = x[base + (e << p_lo)];
+        for (int e = 0; e < E; e++) v[e] = x[XI(base + (e << p_lo))];
 #pragma unroll
         for (int s = 0; s < R; s++) {
             const int t = t0 + s, bit = 1 << s;
@@ -143,7 +147,7 @@ __device__ __forceinline__ void dit_pass(float2 *x, const float2 *tws, const int
             }
         }
 #pragma unroll
-        for (int e = 0; e < E; e++) x[base + (e << p_lo)] = v[e];
+        for (int e = 0; e < E; e++) x[XI(base + (e << p_lo))] = v[e];
     }
     __syncthreads();
 }
@@ -164,9 +168,9 @@ __device__ __forceinline__ double wsumd(double v) { for (int off = 32; off > 0; 
 __global__ __launch_bounds__(SC_THREADS)
 void k_scan_corr(const ScanCorrArgs a) {
     extern __shared__ float2 smem2[];
-    float2 *x = smem2;                           // [SC_N]
-    float2 *tws = smem2 + SC_N;                  // [SC_N/2] twiddles of stages 0..11
-    float *xnl = reinterpret_cast<float *>(smem2 + SC_N + SC_N / 2);   // [SC_N] filtered window (norm)
+    float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
+    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_N/2] twiddles of stages 0..11
+    float *xnl = reinterpret_cast<float *>(tws + SC_N / 2);   // [SC_N] filtered window (norm)
     __shared__ float s_rf[SC_THREADS / WAVE];
     __shared__ int s_ri[SC_THREADS / WAVE];
     __shared__ double s_rd[SC_THREADS / WAVE];
@@ -192,7 +196,7 @@ void k_scan_corr(const ScanCorrArgs a) {
             const int64_t p = start + i;
             const float v = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
             if (i >= K - L && i < wl) dcp += v;                        // last 2L samples (dft_detect.c:389)
-            x[brev13(i)] = make_float2(v, 0.f);
+            x[XI(brev13(i))] = make_float2(v, 0.f);
         }
         if (want_dc) {
             const float sw = wsumf(dcp); if (lane == 0) s_rf[wave] = sw;
@@ -210,11 +214,11 @@ void k_scan_corr(const ScanCorrArgs a) {
         for (int i = tid; i < N; i += SC_THREADS) {
             const int r = brev13(i);
             if (r < i) continue;
-            float2 xi = x[i], xr = x[r];
+            float2 xi = x[XI(i)], xr = x[XI(r)];
             if (i == 0) { xi.x -= dcsub; xr.x -= dcsub; }             // i = r = 0
             const float2 zi = H ? cmul(xi, H[i]) : xi, zr = H ? cmul(xr, H[r]) : xr;
-            x[r] = make_float2(zi.x, -zi.y);
-            x[i] = make_float2(zr.x, -zr.y);
+            x[XI(r)] = make_float2(zi.x, -zi.y);
+            x[XI(i)] = make_float2(zr.x, -zr.y);
         }
         __syncthreads();
     };
@@ -225,11 +229,11 @@ void k_scan_corr(const ScanCorrArgs a) {
         dft_ref(x, tws, a.tws, tid);
         spectrum_step(a.opt_iq ? a.WS + (size_t)tp.lpfm * N : nullptr);
         dft_ref(x, tws, a.tws, tid);
-        for (int i = tid; i < N; i += SC_THREADS) xnl[i] = x[i].x / (float)N;
+        for (int i = tid; i < N; i += SC_THREADS) xnl[i] = x[XI(i)].x / (float)N;
         __syncthreads();
     }
     load_window(false);
-    if (!filt) { for (int i = tid; i < N; i += SC_THREADS) xnl[brev13(i)] = x[i].x; __syncthreads(); }     // raw window, natural order
+    if (!filt) { for (int i = tid; i < N; i += SC_THREADS) xnl[brev13(i)] = x[XI(i)].x; __syncthreads(); }     // raw window, natural order
     dft_ref(x, tws, a.tws, tid);                                         // X = dft(xn)
     spectrum_step(a.G + (size_t)j * N);                                  // G = WS * Fm (Fm alone for FM-audio input)
     dft_ref(x, tws, a.tws, tid);                                         // cx = Nidft(Z), real part used
@@ -237,7 +241,7 @@ void k_scan_corr(const ScanCorrArgs a) {
     // arg-max of cx^2 over i in [L-1, K+L), first maximum wins (dft_detect.c:415-423)
     float best = 0.f; int bidx = -1;
     for (int i = tid; i < N; i += SC_THREADS) {
-        if (i >= L - 1 && i < wl) { const float c = x[i].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
+        if (i >= L - 1 && i < wl) { const float c = x[XI(i)].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
@@ -253,7 +257,7 @@ void k_scan_corr(const ScanCorrArgs a) {
             if (ob > b || (ob == b && oi >= 0 && (mp < 0 || oi < mp))) { b = ob; mp = oi; }
         }
     }
-    const float mx = (mp >= 0) ? x[mp].x : 0.f;
+    const float mx = (mp >= 0) ? x[XI(mp)].x : 0.f;
     // norm over the L filtered window samples under the peak (dft_detect.c:431-433)
     double e2 = 0.0;
     if (mp >= 0) for (int k = tid; k < L; k += SC_THREADS) { const float v = xnl[mp - k]; e2 += (double)(v * v); }
@@ -322,7 +326,7 @@ extern "C" void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s) {
 }
 extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(2 * SC_N) * sizeof(float2);
+    const size_t lds = (size_t)(2 * SC_N + SC_N / 8) * sizeof(float2);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_corr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set = true;

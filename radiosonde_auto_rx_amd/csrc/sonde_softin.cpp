@@ -15,6 +15,11 @@
 using namespace sonde;
 
 struct sonde_softin {
+    int type = SONDE_RS41;
+    // DFM (dfm09mod.c:1604-1720): 32 raw header symbols, then two soft symbols per bit (s = s2 - s1), 8 frames of 280 bits per hit
+    float dsb[32]; int dpos = 16, dfrm = 0, dhalf = 0; float ds1 = 0.f;
+    uint8_t dhb[280]; float dsf[280];
+    std::vector<sonde_dfm_frame_t> dqueue;
     int ecc_level = 1, inv_in = 0;            // inv_in: --softinv / -i applied to the stream (f32soft_read inv)
     int opt_inv = 0, opt_auto = 0;            // gpx.option.inv / .aut (rs41mod.c:2888-2891)
     float ths = 0.7f;
@@ -42,8 +47,10 @@ static void emit(sonde_softin *s, int nbytes) {           // print_frame(gpx, by
 extern "C" {
 
 int sonde_softin_create(int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto, sonde_softin_t **out) {
-    if (!out || sonde_type != SONDE_RS41) return SONDE_E_ARG;
+    if (!out || (sonde_type != SONDE_RS41 && sonde_type != SONDE_DFM09)) return SONDE_E_ARG;
     sonde_softin *s = new sonde_softin();
+    s->type = sonde_type;
+    memset(s->dsb, 0, sizeof s->dsb); memset(s->dhb, 0, sizeof s->dhb); memset(s->dsf, 0, sizeof s->dsf);
     s->ecc_level = ecc_level; s->inv_in = invert_stream ? 1 : 0; s->opt_inv = opt_inv ? 1 : 0; s->opt_auto = opt_auto ? 1 : 0;
     memset(s->sbuf, 0, sizeof s->sbuf); memset(s->frame, 0, sizeof s->frame);
     memcpy(s->frame, kRs41HeaderBytes, 8);
@@ -55,6 +62,53 @@ void sonde_softin_destroy(sonde_softin_t *s) { delete s; }
 
 int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
     if (!s || (!soft && n > 0) || n < 0) return SONDE_E_ARG;
+    if (s->type == SONDE_DFM09) {
+        for (int32_t i = 0; i < n; i++) {
+            float sb = soft[i];
+            if (s->inv_in) sb = -sb;
+            s->bits_in++;
+            if (s->state == 0) {
+                s->bufpos = (s->bufpos + 1) % 32;
+                s->dsb[s->bufpos] = sb;
+                double sum = 0.0, normx = 0.0, normy = 0.0;
+                int j = s->bufpos + 1;
+                for (int k = 0; k < 32; k++) {
+                    if (j >= 32) j = 0;
+                    const float x = s->dsb[j];
+                    const float y = (float)(2.0 * (kDfmRawHeader[k] & 0x1) - 1.0);
+                    sum += (double)y * (double)s->dsb[j];
+                    normx += x * x;
+                    normy += y * y;
+                    j++;
+                }
+                sum /= std::sqrt(normx * normy);
+                const float mv = (float)sum;
+                if (std::fabs(mv) > s->ths) {
+                    int found = 1;
+                    if (mv * (0.5 - s->opt_inv) < 0) { if (!s->opt_auto) found = 0; else s->opt_inv ^= 1; }
+                    if (found) { s->state = 1; s->dpos = 16; s->dfrm = 0; s->dhalf = 0; s->mv = mv; s->hdr_bit = s->bits_in; }
+                }
+            } else {
+                if (!s->dhalf) { s->ds1 = sb; s->dhalf = 1; continue; }
+                s->dhalf = 0;
+                float v = sb - s->ds1;                          // integrate both Manchester symbols (dfm09mod.c:1684)
+                int hb = v >= 0.0f;
+                if (s->opt_inv) { hb ^= 1; v = -v; }
+                s->dhb[s->dpos] = (uint8_t)hb; s->dsf[s->dpos] = v;
+                if (++s->dpos == 280) {
+                    sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
+                    o.channel = 0; o.frame_in_hit = s->dfrm; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+                    o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
+                    o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
+                    o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);
+                    s->dqueue.push_back(o);
+                    s->dpos = 0;
+                    if (++s->dfrm == 8) s->state = 0;           // nfrms frames per header hit, then search again (:1656,1718)
+                }
+            }
+        }
+        return 0;
+    }
     for (int32_t i = 0; i < n; i++) {
         float sb = soft[i];
         if (s->inv_in) sb = -sb;
@@ -100,8 +154,17 @@ int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
 
 int sonde_softin_finish(sonde_softin_t *s) {               // EOF inside a frame: print_frame with the bytes that exist
     if (!s) return SONDE_E_ARG;
+    if (s->type == SONDE_DFM09) { s->state = 0; return 0; }          // a partial DFM frame is dropped (dfm09mod.c:1702,1713)
     if (s->state == 1) { emit(s, s->byte_count); s->state = 0; }
     return 0;
+}
+
+int sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max) {
+    if (!s || (!out && max > 0) || max < 0) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->dqueue.size(), (size_t)max);
+    for (int i = 0; i < n; i++) out[i] = s->dqueue[i];
+    s->dqueue.erase(s->dqueue.begin(), s->dqueue.begin() + n);
+    return n;
 }
 
 int sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max) {

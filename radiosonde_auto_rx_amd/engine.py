@@ -206,8 +206,9 @@ class Engine:
         return out if width == 2 else out[:, 0]
 
     # -- profiling ---------------------------------------------------------------------------
-    def profile(self, enable: bool = True):
-        _chk(lib().sonde_engine_profile(self._h, int(enable)))
+    def profile(self, enable: bool | int = True):
+        """True / 2: HIP events around every kernel; 1: around the dominant kernel only; False: none."""
+        _chk(lib().sonde_engine_profile(self._h, 2 if enable is True else int(enable)))
 
     def kernel_ms(self, name: str):
         ms, n = C.c_double(), C.c_int64()

@@ -44,3 +44,14 @@ def test_softin_truncated_stream_emits_partial_frame():
     a = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "-i", "-r", "--ecc2"], input=cut.tobytes(), capture_output=True)
     b = subprocess.run([ref, "--softin", "-i", "-r", "--ecc2"], input=cut.tobytes(), capture_output=True)
     assert a.stdout == b.stdout and a.stdout
+
+
+def test_dfm_softin_cli_matches_reference_lines():
+    """`dfm09mod --softin [-i] -r --ecc`: two soft symbols per bit, 8 frames per header hit (dfm09mod.c:1604-1720)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    g = load_fsk("fsk_dfm_50k")
+    sd = g["sd"].astype("<f4").tobytes()
+    for key, args in (("dfm_lines", ["--softin", "-i", "-r", "--ecc"]), ("dfm_lines_noinv", ["--softin", "-r", "--ecc"])):
+        r = subprocess.run([os.path.join(ROOT, "host", "bin", "dfm09mod")] + args, input=sd, capture_output=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        assert [l.rstrip() for l in r.stdout.decode().splitlines()] == [str(l).rstrip() for l in g[key]] and len(g[key]) > 0

@@ -313,6 +313,10 @@ def main():
         if case["gen"] == "rs41" and case["fmt"] == 2:                   # end to end: soft bits into the reference's rs41mod --softin
             dec = subprocess.run([os.path.join(bind.REFDIR, "rs41mod"), "--softin", "-i", "-r", "--ecc2"], input=cli.stdout, capture_output=True)
             d["rs41_lines"] = np.array(dec.stdout.decode().splitlines())
+        if case["gen"] == "dfm":                                          # ... and into dfm09mod --softin (two soft symbols per bit)
+            for key, args in (("dfm_lines", ["--softin", "-i", "-r", "--ecc"]), ("dfm_lines_noinv", ["--softin", "-r", "--ecc"])):
+                dec = subprocess.run([os.path.join(bind.REFDIR, "dfm09mod")] + args, input=cli.stdout, capture_output=True)
+                d[key] = np.array(dec.stdout.decode().splitlines())
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "frames", r["n"], "nin set", sorted(set(r["nin"].tolist())), "f_est", r["f_est"][-1], d.get("rs41_lines", np.array([])).shape)
 
