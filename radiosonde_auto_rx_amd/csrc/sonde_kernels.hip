@@ -387,8 +387,9 @@ void k_audio_chain(const AudioChainArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_if_chain: one workgroup = IF_TILE output samples of one channel
 // ------------------------------------------------------------------------------------------------
-#define IF_TILE 512
-#define IF_THREADS 256
+#define IF_TILE 960
+#define IF_THREADS 512
+#define IF_NB 2
 
 __global__ __launch_bounds__(IF_THREADS)
 void k_if_chain(const IfArgs a) {
@@ -424,31 +425,38 @@ void k_if_chain(const IfArgs a) {
     __syncthreads();
 
     // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648).
-    // 4 consecutive outputs per thread with a sliding register window: one 16-byte LDS read per 2 taps;
+    // IF_NB consecutive outputs per thread with a sliding register window: one 16-byte LDS read per 2 taps;
     // the tone phasors e^{+-i 2 pi m rho} are applied once per sample here (X1, X2), not once per window term.
-    for (int k0 = 4 * threadIdx.x; k0 < nz; k0 += 4 * IF_THREADS) {
-        float ar[4] = {0.f, 0.f, 0.f, 0.f}, ai[4] = {0.f, 0.f, 0.f, 0.f};
-        float2 win[6];
-        { const float4 v0 = *reinterpret_cast<const float4 *>(sy + k0), v1 = *reinterpret_cast<const float4 *>(sy + k0 + 2);
-          win[0] = make_float2(v0.x, v0.y); win[1] = make_float2(v0.z, v0.w); win[2] = make_float2(v1.x, v1.y); win[3] = make_float2(v1.z, v1.w); }
+    // (IF_NB = 2 keeps all 512 threads of a 960-sample tile busy; the per-output tap order does not depend on it.)
+    for (int k0 = IF_NB * threadIdx.x; k0 < nz; k0 += IF_NB * IF_THREADS) {
+        float ar[IF_NB], ai[IF_NB];
+#pragma unroll
+        for (int j = 0; j < IF_NB; j++) { ar[j] = 0.f; ai[j] = 0.f; }
+        float2 win[IF_NB + 2];
+#pragma unroll
+        for (int j = 0; j < IF_NB; j += 2) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(sy + k0 + j);
+            win[j] = make_float2(v0.x, v0.y); win[j + 1] = make_float2(v0.z, v0.w);
+        }
         for (int t = 0; t + 1 < T1; t += 2) {
-            const float4 nv = *reinterpret_cast<const float4 *>(sy + k0 + t + 4);
-            win[4] = make_float2(nv.x, nv.y); win[5] = make_float2(nv.z, nv.w);
+            const float4 nv = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB);
+            win[IF_NB] = make_float2(nv.x, nv.y); win[IF_NB + 1] = make_float2(nv.z, nv.w);
             const float w0 = wq[t], w1 = wq[t + 1];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < IF_NB; j++) {
                 ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]);
                 ar[j] = fmaf(win[j + 1].x, w1, ar[j]); ai[j] = fmaf(win[j + 1].y, w1, ai[j]);
             }
-            win[0] = win[2]; win[1] = win[3]; win[2] = win[4]; win[3] = win[5];
+#pragma unroll
+            for (int j = 0; j < IF_NB; j++) win[j] = win[j + 2];
         }
         if (T1 & 1) {
             const float w0 = wq[T1 - 1];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]); }
+            for (int j = 0; j < IF_NB; j++) { ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]); }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < IF_NB; j++) {
             const int k = k0 + j;
             if (k >= nz) break;
             float re = ar[j], im = ai[j];
@@ -566,7 +574,7 @@ void k_header_corr(const CorrArgs a) {
 // ~ (types*sps + symbols) operations per sample instead of L.  The shapes are taken from the very same
 // match[] floats, so the result differs from the direct sum only by float association.
 #define HCF_TILE 1024
-#define HCF_THREADS 256
+#define HCF_THREADS 512
 #define HCF_MAXTYPES 9
 
 __global__ __launch_bounds__(HCF_THREADS)
@@ -614,20 +622,29 @@ void k_header_corr_fact(const CorrArgs a) {
         }
     }
     __syncthreads();
-    // c[o] = sum_k sign_k * F_{type_k}[o + sps*k]: 4 consecutive outputs per thread
-    const int o4 = threadIdx.x * 4;
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-    for (int k = 0; k < nsym; k++) {
-        const int ty = a.sym_type[k];                // uniform: scalar loads
-        const float sg = a.sym_sign[k];
-        const float *f = sF + ty * nf + sps * k + o4;
-        const float2 u = *reinterpret_cast<const float2 *>(f), v = *reinterpret_cast<const float2 *>(f + 2);   // sps*k may be 2 mod 4
-        c0 = fmaf(sg, u.x, c0); c1 = fmaf(sg, u.y, c1); c2 = fmaf(sg, v.x, c2); c3 = fmaf(sg, v.y, c3);
-    }
+    // c[o] = sum_k sign_k * F_{type_k}[o + sps*k]: 2 consecutive outputs per thread and pass — lanes then read
+    // consecutive 8-byte words (no LDS bank conflicts; 4 outputs per thread made every read 2-way conflicted)
     float *corr = a.corr + (size_t)ch * a.ring_len;
-    const float cc[4] = { c0, c1, c2, c3 };
-#pragma unroll
-    for (int j = 0; j < 4; j++) if (o4 + j < nout) corr[(p0 + (uint32_t)(o4 + j)) & mask] = cc[j];
+#if HCF_TILE / HCF_THREADS >= 2
+    for (int o2 = threadIdx.x * 2; o2 < HCF_TILE; o2 += 2 * HCF_THREADS) {
+        float c0 = 0.f, c1 = 0.f;
+        for (int k = 0; k < nsym; k++) {
+            const int ty = a.sym_type[k];                // uniform: scalar loads
+            const float sg = a.sym_sign[k];
+            const float2 u = *reinterpret_cast<const float2 *>(sF + ty * nf + sps * k + o2);     // sps even -> 8-byte aligned
+            c0 = fmaf(sg, u.x, c0); c1 = fmaf(sg, u.y, c1);
+        }
+        if (o2 < nout) corr[(p0 + (uint32_t)o2) & mask] = c0;
+        if (o2 + 1 < nout) corr[(p0 + (uint32_t)(o2 + 1)) & mask] = c1;
+    }
+#else
+    {
+        const int o = threadIdx.x;
+        float c0 = 0.f;
+        for (int k = 0; k < nsym; k++) c0 = fmaf(a.sym_sign[k], sF[a.sym_type[k] * nf + sps * k + o], c0);
+        if (o < nout) corr[(p0 + (uint32_t)o) & mask] = c0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
