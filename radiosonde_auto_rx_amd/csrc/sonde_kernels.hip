@@ -234,11 +234,12 @@ void k_mix_decimate(const MixDecArgs a) {
         float yr = acc[H].x, yi = acc[H].y;
 #pragma unroll
         for (int q = 0; q < H; q++) {
+            // lane l takes row l-k: this tile's for l >= k, the previous tile's row l-k+64 otherwise — one rotation of
+            // the vector that holds the previous tile in its last k lanes
             const int k = H - q, src = (lane - k) & 63;
-            const float cr = __shfl(acc[q].x, src), ci = __shfl(acc[q].y, src);
-            const float or_ = __shfl(pv[q].x, src), oi = __shfl(pv[q].y, src);
-            yr += (lane >= k) ? cr : or_;
-            yi += (lane >= k) ? ci : oi;
+            const bool old = lane >= MD_ROWS - k;
+            yr += __shfl(old ? pv[q].x : acc[q].x, src);
+            yi += __shfl(old ? pv[q].y : acc[q].y, src);
         }
         if (outrow) yout[(a.m0 + (uint32_t)j) & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
         if (j >= a.nblocks - H && j < a.nblocks) {            // P rows of the last Q-1 blocks go to the next call

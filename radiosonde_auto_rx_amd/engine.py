@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsonde_hip.so")
+LIB_PATH = os.environ.get("SONDE_HIP_LIB", os.path.join(_HERE, "libsonde_hip.so"))     # override: A/B experiments with another build
 
 SONDE_RS41 = 41
 SONDE_DFM09 = 9
