@@ -156,6 +156,12 @@ int main(int argc, char **argv) {
         if (sonde_scan_channel_done(sc, 0) == 1) break;
         if (got < (size_t)chunk) break;
     }
+    sonde_scan_finish(sc);
+    {
+        sonde_detection_t det[16]; int n;
+        while ((n = sonde_scan_fetch(sc, det, 16)) > 0)
+            for (int k = 0; k < n; k++) { char line[256]; if (silent || !det[k].printed) continue; sonde_scan_line(sc, &det[k], verbose, line, sizeof line); fprintf(stdout, "%s\n", line); }
+    }
     int32_t code = 0;
     sonde_scan_result(sc, 0, &code);
     sonde_scan_destroy(sc);

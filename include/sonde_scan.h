@@ -95,6 +95,10 @@ int  sonde_scan_info(const sonde_scan_t *s, sonde_scan_info_t *info);
 int  sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stride, int32_t n_samples);
 
+/* End of input: a channel parked in the IMET AFSK check (one more second of samples, dft_detect.c:1533-1607) is decided
+ * with the samples that exist, like the reference at EOF. */
+int  sonde_scan_finish(sonde_scan_t *s);
+
 /* Detections found since the last fetch, in the order the reference would print them per channel. */
 int  sonde_scan_fetch(sonde_scan_t *s, sonde_detection_t *out, int32_t max);
 /* 1 once a channel has stopped (detection without -c, -d2 satisfied, or -t exceeded) */

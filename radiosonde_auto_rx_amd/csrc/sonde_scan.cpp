@@ -8,8 +8,7 @@
 //   FIR histories, z0 of the discriminators                                  IF-rate rings in HBM (absolute indices)
 //   k / sample_in / sample_out window counter (main, :1483-1505)             next_sin per channel
 //   mv[], mv_pos[], mv0_pos[], mv_max, j_max, rs_detect2[], mutable type/tn   Chan (host)
-// Not implemented: the IMETafsk post-processing (1 s spectrum, :1533-1607) — an IMET preamble hit is dropped like the
-// reference's "IMET1AB?" branch; N_DFT other than 8192 (IF rate above ~51 kHz, i.e. --bw > 48).
+// Not implemented: N_DFT other than 8192 (IF rate above ~51 kHz, i.e. --IQ with --bw > 48).
 #include "../../include/sonde_scan.h"
 #include "sonde_dev.h"
 #include "sonde_host.h"
@@ -134,6 +133,8 @@ struct Chan {
     const char *type[kNrs]; int tn[kNrs]; int detect2[kNrs];
     int j_max = 0; float mv_max = 0.f; int d2_tn = kNrs; bool done = false;
     uint32_t next_sin = 0;
+    // IMET AFSK post-processing in progress (dft_detect.c:1533-1607): the window's decision waits for one more second of the FM stream
+    bool imet_hold = false; uint32_t imet_sin = 0; int imet_hf = 0;
 };
 
 struct KStat { double ms = 0; int64_t n = 0; };
@@ -293,7 +294,7 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
     }
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
-    int ring = 1; while (ring < max_if + 2 * SC_N + 4096) ring <<= 1;
+    int ring = 1; while (ring < max_if + sr + 2 * SC_N + 4096) ring <<= 1;        // + one second: the IMET check re-reads it (imet_resolve)
     s->ring_len = ring;
     sonde_scan_info_t &I = s->info;
     I.if_sr = sr; I.decM = D; I.dectaps = (D == 1) ? 0 : (int)s->dec.taps.size(); I.lpiq_taps = s->lpiq_taps; I.lpfm_taps = s->lpfm_taps;
@@ -359,9 +360,38 @@ static uint32_t m10_bytes(const char *hdr, uint32_t mask, int inv) {
 }
 
 // decision logic of main() for one window of one channel (dft_detect.c:1494-1649)
-static void decide(sonde_scan *s, int ch, const ScanRes *res) {
+// print / bookkeeping of one accepted header (the `if (header_found)` block of main, dft_detect.c:1609-1643)
+static void report(sonde_scan *s, int ch, int j, int &header_found, uint32_t &frm2) {
     Chan &c = s->chan[ch];
     const bool iq = s->cfg.iq_mode != SONDE_SCAN_AUDIO;
+    if (!header_found) return;
+    int printed = 0;
+    if (c.mv[j] > s->thres[j] || c.mv[j] < -s->thres[j]) {
+        if (s->cfg.opt_d2) {
+            c.detect2[j] += 1;
+            int tn = 0; for (tn = 0; tn < kNrs; tn++) if (c.detect2[tn] > 1) break;
+            c.d2_tn = tn;
+            if (c.d2_tn == kNrs) header_found = 0;
+        }
+        if (!s->cfg.opt_d2 || j == c.d2_tn) printed = 1;
+        sonde_detection_t d; memset(&d, 0, sizeof d);
+        d.channel = ch; d.tpl = j; d.tn = c.tn[j]; snprintf(d.type, sizeof d.type, "%s", c.type[j]);
+        d.score = c.mv[j]; d.sample = c.mv_pos[j]; d.printed = printed;
+        if (j < SC_NTPL && s->tpl[j].is_m10) { d.m10_bytes = frm2 & 0xFFFF; frm2 = 0; }
+        if (s->cfg.opt_dc && iq) { d.df = c.df[j]; d.freq_hz = c.df[j] * (float)s->cfg.sample_rate; }
+        s->queue.push_back(d);
+    }
+    if (std::fabs(c.mv_max) < std::fabs(c.mv[j])) { c.mv_max = c.mv[j]; c.j_max = j; }
+}
+
+static void end_window(sonde_scan *s, int ch, int header_found) {       // dft_detect.c:1647-1650
+    Chan &c = s->chan[ch];
+    if ((header_found && !s->cfg.opt_cont) || c.d2_tn < kNrs) c.done = true;
+    for (int j = 0; j < kNrs; j++) c.mv[j] = 0.0f;
+}
+
+static void decide(sonde_scan *s, int ch, const ScanRes *res, uint32_t win_sin) {
+    Chan &c = s->chan[ch];
     for (int j = 0; j <= kIdxImetAfsk; j++) {
         if (!s->tpl[j].active) continue;
         c.mv0_pos[j] = c.mv_pos[j];
@@ -388,30 +418,129 @@ static void decide(sonde_scan *s, int ch, const ScanRes *res) {
             frm2 = bytes;
         }
         if (j == kIdxImetAfsk) {
-            c.mv[j] = 0.0f;                                    // post-processing not implemented: no IMET1RS/IMET4 decision
-        } else header_found = 1;
-        if (header_found) {
-            int printed = 0;
-            if (c.mv[j] > s->thres[j] || c.mv[j] < -s->thres[j]) {
-                if (s->cfg.opt_d2) {
-                    c.detect2[j] += 1;
-                    int tn = 0; for (tn = 0; tn < kNrs; tn++) if (c.detect2[tn] > 1) break;
-                    c.d2_tn = tn;
-                    if (c.d2_tn == kNrs) header_found = 0;
-                }
-                if (!s->cfg.opt_d2 || j == c.d2_tn) printed = 1;
-                sonde_detection_t d; memset(&d, 0, sizeof d);
-                d.channel = ch; d.tpl = j; d.tn = c.tn[j]; snprintf(d.type, sizeof d.type, "%s", c.type[j]);
-                d.score = c.mv[j]; d.sample = c.mv_pos[j]; d.printed = printed;
-                if (s->tpl[j].is_m10) { d.m10_bytes = frm2 & 0xFFFF; frm2 = 0; }
-                if (s->cfg.opt_dc && iq) { d.df = c.df[j]; d.freq_hz = c.df[j] * (float)s->cfg.sample_rate; }
-                s->queue.push_back(d);
+            // the reference now reads one more second of samples inside this window's decision; park the channel until
+            // they exist (imet_resolve), everything decided so far in this window is kept
+            c.imet_hold = true; c.imet_sin = win_sin; c.imet_hf = header_found;
+            return;
+        }
+        header_found = 1;
+        report(s, ch, j, header_found, frm2);
+    }
+    end_window(s, ch, header_found);
+}
+
+static int read_fm_phys(sonde_scan *s, int channel, int phys, int64_t first, int32_t count, float *out) {
+    const float *base = s->d_fm + ((size_t)phys * s->cfg.n_channels + channel) * s->ring_len;
+    for (int32_t done = 0; done < count;) {
+        const uint32_t idx = (uint32_t)(first + done) & (uint32_t)(s->ring_len - 1);
+        const int run = (int)std::min<int64_t>(count - done, s->ring_len - idx);
+        HIPCHK(hipMemcpy(out + done, base + idx, (size_t)run * sizeof(float), hipMemcpyDeviceToHost));
+        done += run;
+    }
+    return 0;
+}
+
+// IMET AFSK check (dft_detect.c:1533-1607): after an IMET preamble hit the reference reads one more second, sums the
+// magnitude spectra of 4093-sample blocks of the FM stream and decides between IMET4 / IMET1RS (2200 Hz space tone present,
+// stronger than 2400 Hz and 800 Hz) and nothing.  Rare and bit-rate-scale work: host side, with the reference's transform.
+// Returns 1 when the held window was completed, 0 if the second of samples is not there yet.
+static int imet_resolve(sonde_scan *s, int ch, bool eof) {
+    Chan &c = s->chan[ch];
+    const int sr = s->info.if_sr, N = SC_N, Dn = N / 2 - 3, j0 = kIdxImetAfsk;
+    const uint32_t S = c.imet_sin;
+    const uint32_t avail = s->m_out - S;
+    if (!eof && avail < (uint32_t)sr) return 0;
+    const int n_read = (int)std::min<uint32_t>((uint32_t)sr, avail);
+    const int nb = n_read / Dn;
+    std::vector<float> blk((size_t)std::max(1, nb) * Dn), db(N, 0.f);
+    if (nb > 0 && read_fm_phys(s, ch, s->tpl[j0].stream, (int64_t)S - s->delay, nb * Dn, blk.data()) < 0) return SONDE_E_NOGPU;
+    static const std::vector<float2> tws = ref_twiddles();
+    for (int b = 0; b < nb; b++) {
+        std::vector<float2> X(N, make_float2(0.f, 0.f));
+        for (int i = 0; i < Dn; i++) X[i].x = blk[(size_t)b * Dn + i];
+        dft_ref_host(X, tws);
+        for (int m = 0; m < N; m++) db[m] = (float)((double)db[m] + std::hypot((double)X[m].x, (double)X[m].y));
+    }
+    int header_found = c.imet_hf, j = j0;
+    uint32_t frm2 = 0;
+    const float df = (1 / (float)N) * sr;                                   // bin2freq(1)
+    int m = (int)(50.0 / df); if (m < 1) m = 1;
+    auto f2b = [&](int f) { return (float)(f * N) / (float)sr; };
+    if (f2b(2500) > N / 2) { c.imet_hold = false; c.done = true; return 1; } // `goto ende`: the reference stops here
+    auto band = [&](int f) { const int bin = (int)f2b(f); float p = 0.f; for (int n = 0; n < m; n++) p += db[bin - m / 4 + n]; return p; };
+    const float pow2200 = band(2200), pow2400 = band(2400);
+    c.mv[j0] = std::fabs(c.mv[j0]);
+    if (pow2200 > pow2400) {
+        const float pow800 = band(800);
+        if (pow2200 > pow800) {                                             // IMET -> IMET1RS / IMET4
+            const bool iq = s->cfg.iq_mode != SONDE_SCAN_AUDIO;
+            j = (iq && (double)s->cfg.bw_khz * 1e3 > 50e3) ? 16 : 17;
+            c.mv[j] = c.mv[j0]; c.mv_pos[j] = c.mv_pos[j0]; c.dc[j] = c.dc[j0]; c.df[j] = c.df[j0];
+            c.mv[j0] = 0.0f;
+            header_found = 1;
+        } else c.mv[j0] = 0.0f;
+    } else c.mv[j0] = 0.0f;
+    report(s, ch, j, header_found, frm2);
+    end_window(s, ch, header_found);
+    c.imet_hold = false;
+    c.next_sin = S + (uint32_t)n_read + (uint32_t)(s->K - 4);               // k restarts after the extra second (:1505,1544)
+    return 1;
+}
+
+// Evaluate every correlation window that is complete (sample_in = k (K-4), pos = sample_out = sample_in - 1 - delay;
+// dft_detect.c:1483-1505,811-813) and apply the decision logic, channel by channel in stream order.  A channel parked by
+// the IMET check resumes with a shifted window phase, so the evaluation runs in rounds until nothing new is due.
+static int run_windows(sonde_scan *s) {
+    const int C = s->cfg.n_channels, mode = s->cfg.iq_mode;
+    const float tl = s->cfg.time_limit;
+    const float limit = (tl + 1.0f) * (float)s->info.if_sr;
+    for (int round = 0; round < 64; round++) {
+        for (int c = 0; c < C; c++) if (s->chan[c].imet_hold && !s->chan[c].done) { const int r = imet_resolve(s, c, false); if (r < 0) return r; }
+        int n_items = 0;
+        std::vector<int> first_item(C + 1, 0);
+        for (int c = 0; c < C; c++) {
+            first_item[c] = n_items;
+            Chan &cs = s->chan[c];
+            if (!cs.done && !cs.imet_hold && tl > 0 && (float)cs.next_sin > limit && (float)s->m_out > limit) cs.done = true;   // -t: the sample loop broke
+            uint32_t sin = cs.next_sin;
+            while (!cs.done && !cs.imet_hold && sin <= s->m_out && n_items < s->item_cap) {
+                if (tl > 0 && (float)sin > limit) break;
+                s->h_items[n_items].ch = c; s->h_items[n_items].pos = sin - 1u - (uint32_t)s->delay; n_items++;
+                sin += (uint32_t)(s->K - 4);
             }
-            if (std::fabs(c.mv_max) < std::fabs(c.mv[j])) { c.mv_max = c.mv[j]; c.j_max = j; }
+        }
+        first_item[C] = n_items;
+        if (!n_items) break;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, s->stream);
+        HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+        ScanCorrArgs a{};
+        a.fm = s->d_fm; a.n_ch = C; a.ring_len = s->ring_len; a.items = s->d_items; a.n_items = n_items;
+        memcpy(a.tpl, s->tpl, sizeof a.tpl);
+        a.G = s->d_G; a.WS = s->d_WS; a.lpfm_taps = s->lpfm_taps; a.tws = s->d_tw; a.K = s->K; a.opt_dc = s->cfg.opt_dc;
+        a.opt_iq = (mode != SONDE_SCAN_AUDIO); a.hdrbits = s->d_hdr; a.bnd = s->d_bnd; a.out = s->d_res;
+        if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
+        HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
+        hipEventRecord(e1, s->stream);
+        HIPCHK(hipStreamSynchronize(s->stream));
+        timed(s, "scan_corr", e0, e1);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        for (int c = 0; c < C; c++) {
+            Chan &cs = s->chan[c];
+            for (int i = first_item[c]; i < first_item[c + 1]; i++) {
+                if (cs.done || cs.imet_hold) break;
+                const ScanRes *r = s->h_res + (size_t)i * SC_NTPL;
+                sonde_scan_window_t w; memset(&w, 0, sizeof w);
+                w.channel = c; w.pos = s->h_items[i].pos;
+                for (int j = 0; j < SC_NTPL; j++) { w.mp[j] = r[j].mp; w.mv[j] = r[j].mv; w.mpos[j] = r[j].mpos; w.dc[j] = r[j].dc; w.herrs[j] = r[j].herrs; w.m10[j] = (s->tpl[j].is_m10 && r[j].herrs >= 0) ? m10_bytes(kTpl[j].hdr, r[j].m10, r[j].mv < 0) : 0u; }
+                s->last_windows.push_back(w);
+                const uint32_t win_sin = cs.next_sin;
+                cs.next_sin += (uint32_t)(s->K - 4);
+                decide(s, c, r, win_sin);
+            }
         }
     }
-    if ((header_found && !s->cfg.opt_cont) || c.d2_tn < kNrs) c.done = true;
-    for (int j = 0; j < kNrs; j++) c.mv[j] = 0.0f;
+    return 0;
 }
 
 int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stride, int32_t n_samples) {
@@ -460,54 +589,12 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
     }
     hipEventRecord(ev[2], s->stream);
 
-    // ---- windows that became complete: sample_in = k (K-4), pos = sample_out = sample_in - 1 - delay (:1483-1505,811-813)
-    const float tl = s->cfg.time_limit;
-    const float limit = (tl + 1.0f) * (float)s->info.if_sr;
-    int n_items = 0;
-    std::vector<int> first_item(C + 1, 0);
-    for (int c = 0; c < C; c++) {
-        first_item[c] = n_items;
-        Chan &cs = s->chan[c];
-        uint32_t sin = cs.next_sin;
-        while (!cs.done && sin <= s->m_out && n_items < s->item_cap) {
-            if (tl > 0 && (float)sin > limit) break;
-            s->h_items[n_items].ch = c; s->h_items[n_items].pos = sin - 1u - (uint32_t)s->delay; n_items++;
-            sin += (uint32_t)(s->K - 4);
-        }
-    }
-    first_item[C] = n_items;
-    if (n_items) {
-        HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
-        ScanCorrArgs a{};
-        a.fm = s->d_fm; a.n_ch = C; a.ring_len = s->ring_len; a.items = s->d_items; a.n_items = n_items;
-        memcpy(a.tpl, s->tpl, sizeof a.tpl);
-        a.G = s->d_G; a.WS = s->d_WS; a.lpfm_taps = s->lpfm_taps; a.tws = s->d_tw; a.K = s->K; a.opt_dc = s->cfg.opt_dc;
-        a.opt_iq = (mode != SONDE_SCAN_AUDIO); a.hdrbits = s->d_hdr; a.bnd = s->d_bnd; a.out = s->d_res;
-        if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
-        HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
-    }
     hipEventRecord(ev[3], s->stream);
     HIPCHK(hipStreamSynchronize(s->stream));
     if (mode != SONDE_SCAN_AUDIO) { timed(s, "front_end", ev[0], ev[1]); timed(s, "scan_if", ev[1], ev[2]); }
-    if (n_items) timed(s, "scan_corr", ev[2], ev[3]);
     for (auto &e : ev) hipEventDestroy(e);
-
     s->last_windows.clear();
-    for (int c = 0; c < C; c++) {
-        Chan &cs = s->chan[c];
-        for (int i = first_item[c]; i < first_item[c + 1]; i++) {
-            if (cs.done) break;
-            const ScanRes *r = s->h_res + (size_t)i * SC_NTPL;
-            sonde_scan_window_t w; memset(&w, 0, sizeof w);
-            w.channel = c; w.pos = s->h_items[i].pos;
-            for (int j = 0; j < SC_NTPL; j++) { w.mp[j] = r[j].mp; w.mv[j] = r[j].mv; w.mpos[j] = r[j].mpos; w.dc[j] = r[j].dc; w.herrs[j] = r[j].herrs; w.m10[j] = (s->tpl[j].is_m10 && r[j].herrs >= 0) ? m10_bytes(kTpl[j].hdr, r[j].m10, r[j].mv < 0) : 0u; }
-            s->last_windows.push_back(w);
-            cs.next_sin += (uint32_t)(s->K - 4);
-            decide(s, c, r);
-        }
-        if (!cs.done && tl > 0 && (float)cs.next_sin > limit && (float)s->m_out > limit) cs.done = true;   // -t: the sample loop broke
-    }
-    return 0;
+    return run_windows(s);
 }
 
 int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples) {
@@ -532,6 +619,13 @@ int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride
     HIPCHK(hipMemcpy2DAsync(s->d_stage, (size_t)n_samples * unit, h_in, (size_t)ch_stride * unit, (size_t)n_samples * unit, C,
                             hipMemcpyHostToDevice, s->stream));
     return sonde_scan_process_device(s, s->d_stage, n_samples, n_samples);
+}
+
+int sonde_scan_finish(sonde_scan_t *s) {                     // end of input: complete a pending IMET check with the samples that exist
+    if (!s) return SONDE_E_ARG;
+    for (int c = 0; c < s->cfg.n_channels; c++)
+        if (s->chan[c].imet_hold && !s->chan[c].done) { const int r = imet_resolve(s, c, true); if (r < 0) return r; s->chan[c].done = true; }
+    return 0;
 }
 
 int sonde_scan_fetch(sonde_scan_t *s, sonde_detection_t *out, int32_t max) {

@@ -53,6 +53,7 @@ def _lib():
         L.sonde_scan_info.argtypes = [C.c_void_p, C.POINTER(ScanInfo)]
         L.sonde_scan_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_scan_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_scan_finish.argtypes = [C.c_void_p]
         L.sonde_scan_fetch.argtypes = [C.c_void_p, C.POINTER(Detection), C.c_int32]
         L.sonde_scan_channel_done.argtypes = [C.c_void_p, C.c_int32]
         L.sonde_scan_result.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -108,6 +109,10 @@ class Scanner:
 
     def process_device(self, ptr: int, ch_stride: int, n: int):
         _chk(_lib().sonde_scan_process_device(self._h, C.c_void_p(ptr), ch_stride, n))
+
+    def finish(self):
+        """End of input: decide a pending IMET check with the samples that exist."""
+        _chk(_lib().sonde_scan_finish(self._h))
 
     def fetch(self, verbose: bool = False):
         out = []

@@ -404,3 +404,28 @@ def wideband_capture(sr: int, seconds: float, signals, *, noise_sigma: float = 0
     out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
     out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
     return out
+
+
+def imet_capture(sr: int = 48_000, seconds: float = 3.0, *, f_offset_hz: float = 0.0, amp: float = 0.5, noise_sigma: float = 0.02,
+                 seed: int = 1, dev_hz: float = 3000.0, t_first: float = 0.3, space_hz: float = 2200.0) -> np.ndarray:
+    """iMet-style AFSK on FM (Bell 202: mark 1200 Hz, space `space_hz`): carrier with a 1200 Hz preamble tone, then 1200 Bd
+    data alternating between mark and space tones.  What dft_detect's IMETafsk template + spectrum check look for
+    (scan/dft_detect.c:103-107,1533-1607)."""
+    rng = np.random.default_rng(seed)
+    n = int(round(sr * seconds))
+    t = np.arange(n) / sr
+    tone = np.full(n, 1200.0)
+    s0 = int(round(t_first * sr))
+    bits = rng.integers(0, 2, int((seconds - t_first - 0.25) * 1200))
+    pre = int(0.25 * sr)                                   # 0.25 s of mark tone (preamble), then data
+    spb = sr / 1200.0
+    idx = np.minimum(((np.arange(n - s0 - pre)) / spb).astype(int), len(bits) - 1)
+    tone[s0 + pre:] = np.where(bits[idx] == 1, 1200.0, space_hz)
+    audio = np.sign(np.sin(2 * np.pi * np.cumsum(tone) / sr))          # square-ish AFSK audio as the FM modulator
+    audio[:s0] = 0.0
+    phase = 2 * np.pi * np.cumsum(dev_hz * audio + f_offset_hz) / sr
+    x = amp * np.exp(1j * phase) + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    return out

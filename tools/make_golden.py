@@ -90,6 +90,10 @@ SCAN_CASES = {
     "scan_m20_2400k": dict(gen="m10", cap=dict(sr=2_400_000, seconds=1.6, fq=0.15, type_bytes=(0x45, 0x20), noise_sigma=0.02, seed=4, f_offset_hz=-300.0),
                            mode=5, dc=True, bw=0.0, cli=["-v"]),
     "scan_none_48k_t2": dict(gen="noise", cap=dict(sr=48_000, seconds=4.0, seed=9), mode=1, dc=True, bw=15.0, cli=["-t", "2"]),
+    "scan_imet4_48k": dict(gen="imet", cap=dict(sr=48_000, seconds=3.0, noise_sigma=0.02, seed=1), mode=1, dc=True, bw=15.0, cli=["-v", "-c"]),
+    "scan_imet1rs_48k_bw60": dict(gen="imet", cap=dict(sr=48_000, seconds=3.0, noise_sigma=0.02, seed=2, f_offset_hz=600.0), mode=1, dc=True, bw=60.0, cli=["-v"]),
+    "scan_imet_rejected_48k": dict(gen="imet", cap=dict(sr=48_000, seconds=3.0, noise_sigma=0.02, seed=3, space_hz=2400.0), mode=1, dc=True, bw=0.0, cli=["-v", "-c"]),
+    "scan_imet4_48k_eof": dict(gen="imet", cap=dict(sr=48_000, seconds=0.95, noise_sigma=0.02, seed=4, t_first=0.1), mode=1, dc=True, bw=15.0, cli=["-v", "-c"]),
     "scan_rs41_audio": dict(gen="rs41_audio", cap=dict(sr=48_000, seconds=3.0, fq=0.0, n_frames=2, t_first=0.4, noise_sigma=0.02, seed=7), mode=0, dc=False, bw=0.0, cli=["-v", "-c"]),
 }
 
@@ -122,6 +126,8 @@ def scan_capture(case):
         x = synth.dfm_capture(**cap)
     elif g == "m10":
         x = synth.m10_capture(**cap)
+    elif g == "imet":
+        x = synth.imet_capture(**cap)
     elif g == "noise":
         rng = np.random.default_rng(cap["seed"]); n = int(sr * cap["seconds"])
         x = np.clip(np.round(rng.standard_normal(2 * n) * 0.05 * 32767), -32768, 32767).astype(np.int16)
