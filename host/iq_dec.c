@@ -70,7 +70,8 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "iq_dec (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (!have_pcm || cfg.bits != 16) { fprintf(stderr, "iq_dec (sonde_hip): raw 16-bit IQ input (- <sr> 16) only\n"); return -1; }
+    if (!have_pcm || (cfg.bits != 16 && cfg.bits != 8)) { fprintf(stderr, "iq_dec (sonde_hip): raw 8 / 16-bit IQ input (- <sr> <8|16>) only\n"); return -1; }
+    const size_t unit = 2 * (size_t)(cfg.bits / 8);
     cfg.n_channels = 1; cfg.if_rate = if_min;
     cfg.max_chunk = cfg.sample_rate / 4 + 4096;
     sonde_engine_t *eng = NULL;
@@ -90,7 +91,7 @@ int main(int argc, char **argv) {
     int64_t m_done = 0;                                   /* IF samples written so far */
     const int tap = opt_fm ? SONDE_TAP_FM : ((cfg.opt_lp & SONDE_LP_IQ) ? SONDE_TAP_IFIQ : SONDE_TAP_DECIM);
     for (;;) {
-        size_t got = fread(buf, 4, (size_t)chunk, stdin);
+        size_t got = fread(buf, unit, (size_t)chunk, stdin);
         got -= got % (size_t)(info.decM * decFM);                      /* whole output samples only (if_fm returns EOF mid-block) */
         if (got == 0) break;
         if (sonde_engine_process_host(eng, buf, (int64_t)got, (int32_t)got) < 0) break;

@@ -91,7 +91,7 @@ int main(int argc, char **argv) {
     if (have_iq && !have_pcm) { fprintf(stderr, "rs41mod (sonde_hip): --IQ needs raw input (- <sr> <bits>)\n"); return -1; }
     if (!have_iq) {                                  /* FM audio: WAV on stdin or from a file (opt_iq = 0) */
         if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-        if (cfg.bits != 16) { fprintf(stderr, "rs41mod (sonde_hip): only 16-bit input is implemented\n"); return -1; }
+        if (cfg.bits != 16 && cfg.bits != 8) { fprintf(stderr, "rs41mod (sonde_hip): 8 / 16-bit input only\n"); return -1; }
         cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
         cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
     }
@@ -109,7 +109,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
     }
-    const size_t unit = have_iq ? 4 : 2 * (size_t)cfg.audio_channels;      /* bytes per input sample / audio frame */
+    if (cfg.bits != 16 && cfg.bits != 8) { fprintf(stderr, "%s (sonde_hip): 8 / 16-bit input only\n", argv[0]); return -1; }
+    const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);  /* bytes per input sample / audio frame */
 
     int chunk = cfg.sample_rate / 10;
     chunk -= chunk % info.decM;

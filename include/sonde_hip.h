@@ -62,7 +62,7 @@ typedef struct {
     int32_t device;          /* HIP device ordinal                                            */
     int32_t n_channels;      /* independent channels (one reference process each)             */
     int32_t sample_rate;     /* input rate of every channel ("- <sr> <bs>" argv)              */
-    int32_t bits;            /* 16 (cs16); 8/32 not yet                                        */
+    int32_t bits;            /* 16 (cs16 / s16) or 8 (unsigned: rtl_sdr cu8, 8-bit WAV); 32 (float) not yet */
     int32_t sonde_type;      /* SONDE_RS41                                                    */
     int32_t opt_lp;          /* SONDE_LP_IQ (--lpIQ) | SONDE_LP_FM (--lpFM)                    */
     int32_t opt_dc;          /* --dc (AFC); not yet supported -> SONDE_E_ARG                   */
@@ -138,7 +138,8 @@ int  sonde_engine_sync(sonde_engine_t *e);
 
 /* Collect frames completed so far (syncs).  Runs the RS(255,231) pass(es) of rs41_ecc()
  * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
- * Returns the number of frames written (<= max). */
+ * Returns the number of frames written (<= max).  Frames of one channel come in stream order; the order between
+ * channels that completed a frame in the same process call is unspecified (sonde_frame_t.channel tells them apart). */
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
 /* Pipelined variant: return only the frames of process calls issued at least `lag` calls ago and wait only for those.
  * With lag = 1 the IF-rate kernels of call k (stream B) overlap the decimator of call k+1 (stream A); lag = 0 is

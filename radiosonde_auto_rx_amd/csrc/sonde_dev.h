@@ -82,6 +82,8 @@ int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: dec
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s);
+// 8-bit unsigned IQ -> the int16 form with identical sample values; n complex samples per channel, n even
+void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s);
 void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s);
 void sonde_launch_framesync(const SyncArgs *a, hipStream_t s);
 }

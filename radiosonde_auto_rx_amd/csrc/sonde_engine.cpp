@@ -57,6 +57,8 @@ struct sonde_engine {
     uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
     uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
     int16_t *d_stage = nullptr; size_t stage_bytes = 0;
+    hipEvent_t ev_copy = nullptr;                  // end of the host -> staging copy of process_host
+    int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy [C][max_chunk]
     int ring_len = 0, max_frames = 0;
     // stream position
     uint64_t samples_in = 0;       // base-rate samples consumed per channel
@@ -149,7 +151,7 @@ const char *sonde_strerror(int code) {
 
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
-    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || cfg->bits != 16) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8)) return SONDE_E_ARG;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) || cfg->opt_dc) return SONDE_E_ARG;
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input == SONDE_IN_AUDIO) return SONDE_E_ARG;
     int ndev = 0;
@@ -329,6 +331,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (cfg->pipeline) HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
     else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
     for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocDefault));
     memset(e->h_count, 0, 4 * sizeof(unsigned));
     HIPCHK(hipHostMalloc((void **)&e->h_recs, (size_t)e->max_frames * sizeof(FrameRec), hipHostMallocDefault));
@@ -344,11 +347,12 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     { hipStream_t sa = e->stream; if (sa) hipStreamDestroy(sa); }
     if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
     for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); }
+    if (e->ev_copy) hipEventDestroy(e->ev_copy);
     if (e->h_count) hipHostFree(e->h_count);
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
-                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab };
+                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -369,6 +373,12 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     if (!e || !d_iq) return SONDE_E_ARG;
     const int D = e->info.decM, C = e->cfg.n_channels;
     if (n_samples <= 0 || n_samples > e->cfg.max_chunk || n_samples % D || ch_stride < n_samples) return SONDE_E_RANGE;
+    if (e->cfg.bits == 8) {                        // cu8: (u-128)/128 == ((u-128)*256)/32768 -> feed the 16-bit path
+        const int epf = e->cfg.input == SONDE_IN_AUDIO ? std::max(1, e->cfg.audio_channels) : 2;    // bytes per sample / audio frame
+        if (!e->d_conv) HIPCHK(hipMalloc((void **)&e->d_conv, (size_t)C * e->cfg.max_chunk * epf * 2));
+        sonde_launch_u8_to_s16((const uint8_t *)d_iq, ch_stride * epf, e->d_conv, (long long)n_samples * epf, C, n_samples * epf, e->stream);
+        d_iq = e->d_conv; ch_stride = n_samples;
+    }
     const uint32_t m_first = e->m_out;
     int done = 0;
     if (e->cfg.input == SONDE_IN_AUDIO) {
@@ -455,7 +465,7 @@ int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_st
     if (!e || !h_iq) return SONDE_E_ARG;
     const int C = e->cfg.n_channels;
     if (n_samples <= 0 || n_samples > e->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
-    const size_t unit = e->cfg.input == SONDE_IN_AUDIO ? 2 * (size_t)std::max(1, e->cfg.audio_channels) : 4;
+    const size_t unit = (e->cfg.input == SONDE_IN_AUDIO ? (size_t)std::max(1, e->cfg.audio_channels) : 2) * (e->cfg.bits == 8 ? 1 : 2);
     const size_t need = (size_t)C * n_samples * unit;
     if (need > e->stage_bytes) {
         if (e->d_stage) { hipStreamSynchronize(e->stream); hipFree(e->d_stage); e->d_stage = nullptr; }
@@ -463,6 +473,10 @@ int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_st
     }
     HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)n_samples * unit, h_iq, (size_t)ch_stride * unit, (size_t)n_samples * unit, C,
                             hipMemcpyHostToDevice, e->stream));
+    // the caller may free or overwrite h_iq as soon as this returns; a pageable source can be pinned in place and read by the
+    // copy engine after hipMemcpy2DAsync has returned, so wait for the copy itself (not for the kernels queued behind it)
+    HIPCHK(hipEventRecord(e->ev_copy, e->stream));
+    HIPCHK(hipEventSynchronize(e->ev_copy));
     return sonde_engine_process_device(e, e->d_stage, n_samples, n_samples);
 }
 

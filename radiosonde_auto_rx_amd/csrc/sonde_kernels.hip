@@ -363,6 +363,35 @@ __global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_u8_to_s16: 8-bit unsigned input (rtl_sdr's native IQ format, 8-bit WAV).  The reference reads x = (u - 128) / 128.0
+// (demod_mod.c:397-398,438-439,480-481, dft_detect.c:534-535,575-576,607-608); v = (u - 128) * 256 as int16 gives
+// v / 32768 = exactly that x, so the 16-bit path then produces bit-identical samples and IQ-DC sums.
+// Strides: bytes per channel in the input, int16 elements per channel in the output.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_bytes) {
+    const int ch = blockIdx.y;
+    const uint8_t *srcb = in + (size_t)ch * in_stride;
+    int16_t *dsts = out + (size_t)ch * out_stride;
+    const int n_words = n_bytes >> 2;
+    if (((reinterpret_cast<uintptr_t>(srcb) & 3) | (reinterpret_cast<uintptr_t>(dsts) & 7)) == 0) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(srcb);
+        uint2 *dst = reinterpret_cast<uint2 *>(dsts);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) {
+            const uint32_t w = src[i] ^ 0x80808080u;                                                // u - 128 as signed bytes
+            dst[i] = make_uint2(((w & 0xffu) << 8) | ((w & 0xff00u) << 16), ((w >> 8) & 0xff00u) | (w & 0xff000000u));
+        }
+    } else {                                                                                        // odd strides: bytewise
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * n_words; i += gridDim.x * blockDim.x)
+            dsts[i] = (int16_t)(((int)srcb[i] - 128) * 256);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_bytes & 3)) {
+        const int i = 4 * n_words + threadIdx.x;
+        dsts[i] = (int16_t)(((int)srcb[i] - 128) * 256);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_audio_chain: FM-audio input (dsp.opt_iq = 0): optional FM low-pass, then fm_buffer and bufs (demod_mod.c:836-852)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
@@ -949,6 +978,10 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
+}
+extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s) {
+    int gx = (n_bytes / 4 + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_u8_to_s16, dim3(gx, n_ch), dim3(256), 0, s, in, in_stride, out, out_stride, n_bytes);
 }
 extern "C" void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s) {
     int gx = (a->n + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;

@@ -156,6 +156,7 @@ struct sonde_scan {
     uint8_t *d_hdr = nullptr; int *d_bnd = nullptr; ScanItem *d_items = nullptr; ScanRes *d_res = nullptr;
     ScanItem *h_items = nullptr; ScanRes *h_res = nullptr; int item_cap = 0;
     void *d_stage = nullptr; size_t stage_bytes = 0;
+    int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy
     int ring_len = 0;
     // stream position
     uint64_t samples_in = 0; uint32_t m_out = 0; uint32_t dc_cnt = 0, dc_max = 0;
@@ -184,7 +185,7 @@ extern "C" {
 
 int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_t **out) {
     if (!cfg || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
-    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || cfg->bits != 16 || cfg->max_chunk < 1) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8) || cfg->max_chunk < 1) return SONDE_E_ARG;
     if (cfg->iq_mode != SONDE_SCAN_AUDIO && cfg->iq_mode != SONDE_SCAN_IFIQ && cfg->iq_mode != SONDE_SCAN_BBIQ) return SONDE_E_ARG;
     if (cfg->iq_mode == SONDE_SCAN_BBIQ && !fq) return SONDE_E_ARG;
     int ndev = 0;
@@ -332,7 +333,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_items) hipHostFree(s->h_items);
     if (s->h_res) hipHostFree(s->h_res);
     void *ptrs[] = { s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -547,6 +548,13 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
     if (!s || !d_in) return SONDE_E_ARG;
     const int C = s->cfg.n_channels, D = s->info.decM, mode = s->cfg.iq_mode;
     if (n_samples <= 0 || n_samples > s->cfg.max_chunk || n_samples % D || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;   // stride 0: one wideband stream shared by all channels
+    if (s->cfg.bits == 8) {                        // cu8: (u-128)/128 == ((u-128)*256)/32768 -> feed the 16-bit path
+        const int nc = ch_stride == 0 ? 1 : C;
+        const int epf = mode == SONDE_SCAN_AUDIO ? std::max(1, s->cfg.audio_channels) : 2;          // bytes per sample / audio frame
+        if (!s->d_conv) HIPCHK(hipMalloc((void **)&s->d_conv, (size_t)C * s->cfg.max_chunk * epf * 2));
+        sonde_launch_u8_to_s16((const uint8_t *)d_in, ch_stride * epf, s->d_conv, (long long)n_samples * epf, nc, n_samples * epf, s->stream);
+        d_in = s->d_conv; if (ch_stride != 0) ch_stride = n_samples;
+    }
     hipEvent_t ev[4]; for (auto &e : ev) hipEventCreate(&e);
     const uint32_t m_first = s->m_out;
     hipEventRecord(ev[0], s->stream);
@@ -601,7 +609,7 @@ int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride
     if (!s || !h_in) return SONDE_E_ARG;
     const int C = s->cfg.n_channels;
     if (n_samples <= 0 || n_samples > s->cfg.max_chunk || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;
-    const size_t unit = s->cfg.iq_mode == SONDE_SCAN_AUDIO ? 2 * (size_t)std::max(1, s->cfg.audio_channels) : 4;
+    const size_t unit = (s->cfg.iq_mode == SONDE_SCAN_AUDIO ? (size_t)std::max(1, s->cfg.audio_channels) : 2) * (s->cfg.bits == 8 ? 1 : 2);
     if (ch_stride == 0) {                                  // one wideband stream: staged once, every channel mixes its own fq out of it
         const size_t need1 = (size_t)n_samples * unit;
         if (need1 > s->stage_bytes) {
@@ -609,6 +617,7 @@ int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride
             HIPCHK(hipMalloc(&s->d_stage, need1)); s->stage_bytes = need1;
         }
         HIPCHK(hipMemcpyAsync(s->d_stage, h_in, need1, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));     // h_in belongs to the caller again when this returns
         return sonde_scan_process_device(s, s->d_stage, 0, n_samples);
     }
     const size_t need = (size_t)C * n_samples * unit;
@@ -618,6 +627,7 @@ int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride
     }
     HIPCHK(hipMemcpy2DAsync(s->d_stage, (size_t)n_samples * unit, h_in, (size_t)ch_stride * unit, (size_t)n_samples * unit, C,
                             hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));         // h_in belongs to the caller again when this returns
     return sonde_scan_process_device(s, s->d_stage, n_samples, n_samples);
 }
 

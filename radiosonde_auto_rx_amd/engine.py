@@ -106,14 +106,15 @@ class Engine:
                  ecc: int = 2, thres: float = 0.0, max_chunk: int | None = None, max_frames: int = 0,
                  keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False,
                  sonde: str = "rs41", pipeline: bool = False, audio: bool = False, audio_channels: int = 1, audio_select: int = 0,
-                 if_rate: int = 0):
+                 if_rate: int = 0, bits: int = 16):
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
         self.n_channels = len(fq)
         self.sample_rate = sample_rate
         self.sonde = sonde
         self.ecc = ecc
-        self._per_sample = audio_channels if audio else 2      # int16 words per input sample
-        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, 16, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "frontend": 0}[sonde],
+        self._per_sample = audio_channels if audio else 2      # input words (int16, or uint8 for bits=8) per sample
+        self._dtype = np.uint8 if bits == 8 else np.int16
+        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "frontend": 0}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline), int(audio), audio_channels, audio_select, if_rate)
         h = C.c_void_p()
@@ -134,8 +135,8 @@ class Engine:
 
     # -- input -------------------------------------------------------------------------------
     def process_host(self, iq: np.ndarray, n_samples: int | None = None):
-        """iq: int16 array [n_channels, 2*stride] (or [2*stride] for one channel)."""
-        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(self.n_channels, -1)
+        """iq: int16 (bits=8: uint8) array [n_channels, 2*stride] (or [2*stride] for one channel)."""
+        iq = np.ascontiguousarray(iq, dtype=self._dtype).reshape(self.n_channels, -1)
         stride = iq.shape[1] // (self._per_sample)
         _chk(lib().sonde_engine_process_host(self._h, iq.ctypes.data_as(C.c_void_p), stride, n_samples or stride))
 

@@ -71,7 +71,7 @@ class Scanner:
     def __init__(self, sample_rate: int, *, fq=None, n_channels: int | None = None, iq_mode: int = BBIQ, dc: bool = False,
                  bw_khz: float = 0.0, opt_min: bool = False, cont: bool = False, d2: bool = False, lband: bool = False,
                  ths: float = 0.0, time_limit: float = 0.0, max_chunk: int | None = None, device: int = 0,
-                 audio_channels: int = 1, audio_select: int = 0, disable_mask: int = 0):
+                 audio_channels: int = 1, audio_select: int = 0, disable_mask: int = 0, bits: int = 16):
         if fq is None:
             fq = np.zeros(n_channels or 1)
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
@@ -79,7 +79,8 @@ class Scanner:
         self.sample_rate = sample_rate
         self.iq_mode = iq_mode
         self.audio_channels = audio_channels
-        cfg = ScanCfg(ABI_VERSION, device, self.n_channels, sample_rate, 16, iq_mode, int(dc), int(opt_min), int(cont), int(d2),
+        self._dtype = np.uint8 if bits == 8 else np.int16
+        cfg = ScanCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, iq_mode, int(dc), int(opt_min), int(cont), int(d2),
                       int(lband), audio_channels, audio_select, max_chunk or sample_rate, bw_khz, ths, time_limit, disable_mask)
         h = C.c_void_p()
         _chk(_lib().sonde_scan_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
@@ -97,9 +98,9 @@ class Scanner:
     __del__ = close
 
     def process_host(self, x: np.ndarray, shared: bool = False):
-        """x: int16 [n_channels, 2*n] (IQ forms) or [n_channels, n*audio_channels] (FM audio).
+        """x: int16 (bits=8: uint8) [n_channels, 2*n] (IQ forms) or [n_channels, n*audio_channels] (FM audio).
         shared=True: x is ONE wideband stream [2*n] that every channel mixes its own fq out of (channel stride 0)."""
-        x = np.ascontiguousarray(x, dtype=np.int16)
+        x = np.ascontiguousarray(x, dtype=self._dtype)
         if x.ndim == 1:
             x = x[None, :]
         assert shared or x.shape[0] == self.n_channels

@@ -364,11 +364,16 @@ def fm_audio(iq: np.ndarray, gain: float = 0.25) -> np.ndarray:
     return np.clip(np.round(s * gain * 32767 * 4), -32768, 32767).astype(np.int16)
 
 
-def wav_bytes(pcm: np.ndarray, sr: int, nch: int = 1) -> bytes:
-    """Minimal RIFF/WAVE container (16-bit PCM) around interleaved samples."""
+def to_u8(x: np.ndarray) -> np.ndarray:
+    """int16 samples -> 8-bit unsigned (rtl_sdr's cu8 / 8-bit WAV): the top byte around 128."""
+    return np.clip((np.asarray(x).astype(np.int32) >> 8) + 128, 0, 255).astype(np.uint8)
+
+
+def wav_bytes(pcm: np.ndarray, sr: int, nch: int = 1, bits: int = 16) -> bytes:
+    """Minimal RIFF/WAVE container (16-bit PCM, or 8-bit unsigned from uint8 samples) around interleaved samples."""
     import struct
-    data = np.ascontiguousarray(pcm, dtype="<i2").tobytes()
-    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, nch, sr, sr * nch * 2, nch * 2, 16)
+    data = np.ascontiguousarray(pcm, dtype="<i2" if bits == 16 else np.uint8).tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, nch, sr, sr * nch * bits // 8, nch * bits // 8, bits)
     return hdr + b"data" + struct.pack("<I", len(data)) + data
 
 

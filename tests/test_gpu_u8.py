@@ -1,0 +1,106 @@
+"""GPU parity of 8-bit unsigned input (`- <sr> 8`, rtl_sdr's cu8; 8-bit WAV) through every host CLI.
+
+The reference reads (u - 128) / 128.0 (demod_mod.c:397-398,438-439,480-481; dft_detect.c:534-535,575-576,607-608);
+the device converts to (u - 128) * 256 as int16, whose / 32768 is exactly that value, so everything downstream is the
+16-bit path.  Golden = stdout / stderr / exit code of the compiled reference on the same bytes (tools/make_golden.py
+U8_CASES).  Text output (frames, detections, scores to %.4f) and exit codes are exact; the iq_dec float stream is held
+to the same 1e-6 RMS / 2e-5 max as tests/test_gpu_iqdec.py."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_golden  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _rms(a):
+    return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64))))) if np.size(a) else 0.0
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.U8_CASES))
+def test_cli_u8_matches_reference(name):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    case = make_golden.U8_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    stdin, args = make_golden.u8_capture(case)
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", case["binary"])] + args, input=stdin, capture_output=True, timeout=180)
+    assert r.returncode == int(g["rc"]), (r.returncode, r.stderr)
+    assert r.stderr.decode() == str(g["stderr"])
+    ref = g["stdout"].tobytes()
+    if "out" in case:
+        out, want = np.frombuffer(r.stdout, "<" + case["out"]), np.frombuffer(ref, "<" + case["out"])
+        assert out.shape == want.shape
+        assert _rms(out - want) < 1e-6 and np.abs(out - want).max() < 2e-5
+    else:
+        assert [l.rstrip() for l in r.stdout.decode().splitlines()] == [l.rstrip() for l in ref.decode().splitlines()]
+        assert len(ref) > 0
+
+
+def test_u8_equals_widened_s16_engine():
+    """Engine level: cu8 input and the same samples widened on the host to (u-128)*256 int16 give identical taps, frames and
+    soft bits."""
+    from radiosonde_auto_rx_amd.engine import Engine, TAP_DECIM, TAP_FM
+    from radiosonde_auto_rx_amd import synth
+    sr = 2_400_000
+    fqs = [synth.snap_fq(0.1, sr), synth.snap_fq(-0.2, sr), synth.snap_fq(0.03, sr)]
+    caps = [synth.to_u8(synth.rs41_capture(sr=sr, seconds=0.9, fq=fq, n_frames=1, t_first=0.05, noise_sigma=0.02, seed=40 + k)) for k, fq in enumerate(fqs)]
+    u8 = np.stack(caps)
+    s16 = ((u8.astype(np.int32) - 128) * 256).astype(np.int16)
+    res = []
+    for x, bits in ((u8, 8), (s16, 16)):
+        eng = Engine(fqs, sr, keep_soft=True, max_chunk=sr, max_frames=8, bits=bits)
+        n = x.shape[1] // 2
+        pos = 0
+        for take in (50 * 4001, 50 * 777, n):                # uneven chunks
+            take = min(take, n - pos) // 50 * 50
+            if take <= 0:
+                break
+            eng.process_host(np.ascontiguousarray(x[:, 2 * pos:2 * (pos + take)]))
+            pos += take
+        fr = sorted(eng.fetch_frames(with_soft=True, finish=True), key=lambda f: f["channel"])
+        taps = [(eng.read_tap(c, TAP_DECIM, pos // 50 - 4000, 4000), eng.read_tap(c, TAP_FM, pos // 50 - 4000, 4000)) for c in range(3)]
+        res.append((fr, taps))
+        eng.close()
+    (fa, ta), (fb, tb) = res
+    assert len(fa) == len(fb) == 3
+    for a, b in zip(fa, fb):
+        assert a["channel"] == b["channel"] and a["line"] == b["line"] and a["mv_pos"] == b["mv_pos"] and a["mv"] == b["mv"] and np.array_equal(a["soft"], b["soft"])
+    for (da, ma), (db, mb) in zip(ta, tb):
+        assert np.array_equal(da, db) and np.array_equal(ma, mb)
+
+
+def test_u8_equals_widened_s16_audio_odd_chunks():
+    """8-bit FM audio, two engine channels, odd chunk lengths: channel 1 starts on an odd byte (bytewise path of the converter)
+    and every chunk leaves a 1..3 byte tail."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from radiosonde_auto_rx_amd import synth
+    sr = 48_000
+    pcm = [synth.to_u8(synth.fm_audio(synth.rs41_capture(sr=sr, seconds=2.4, fq=0.0, n_frames=2, t_first=0.1, noise_sigma=0.03, seed=50 + k))) for k in range(2)]
+    u8 = np.stack(pcm)
+    s16 = ((u8.astype(np.int32) - 128) * 256).astype(np.int16)
+    res = []
+    for x, bits in ((u8, 8), (s16, 16)):
+        eng = Engine([0.0, 0.0], sr, lp_iq=False, audio=True, keep_soft=True, max_chunk=x.shape[1], max_frames=8, bits=bits)
+        fr = []
+        pos, n = 0, x.shape[1]
+        for take in (4801, 12347, 1, 3, 20001, n):
+            take = min(take, n - pos)
+            if take <= 0:
+                break
+            eng.process_host(np.ascontiguousarray(x[:, pos:pos + take]))
+            pos += take
+            fr += eng.fetch_frames(with_soft=True)
+        fr += eng.fetch_frames(with_soft=True, finish=True)
+        res.append(sorted(fr, key=lambda f: (f["channel"], f["mv_pos"])))
+        eng.close()
+    fa, fb = res
+    assert len(fa) == len(fb) and len(fa) >= 2, (len(fa), len(fb))
+    for a, b in zip(fa, fb):
+        assert a["channel"] == b["channel"] and a["line"] == b["line"] and a["mv_pos"] == b["mv_pos"] and np.array_equal(a["soft"], b["soft"])

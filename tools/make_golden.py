@@ -76,6 +76,36 @@ def iqdec_capture(case):
     return x, args
 
 
+# 8-bit unsigned input through each CLI (`- sr 8`, 8-bit WAV): stdout / stderr / exit code of the compiled reference
+U8_CASES = {
+    "u8_rs41mod_2400k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=2_400_000, seconds=1.3, fq=0.1, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=31),
+                             args=["-r", "--ecc2", "--crc", "--IQ", "FQ", "--lpIQ", "-", "SR", "8"]),
+    "u8_dfm09mod_2400k": dict(binary="dfm09mod", gen="dfm", cap=dict(sr=2_400_000, seconds=1.2, fq=-0.13, noise_sigma=0.02, seed=32),
+                              args=["-r", "--ecc", "--IQ", "FQ", "--lpIQ", "-", "SR", "8"]),
+    "u8_dft_detect_2400k": dict(binary="dft_detect", gen="rs41", cap=dict(sr=2_400_000, seconds=1.2, fq=0.07, n_frames=1, t_first=0.3, noise_sigma=0.02, seed=33, dc=0.02 - 0.01j),
+                                args=["-v", "--IQ", "FQ", "--dc", "-", "SR", "8"]),
+    "u8_dft_detect_if48k": dict(binary="dft_detect", gen="dfm", cap=dict(sr=48_000, seconds=2.0, fq=0.0, noise_sigma=0.02, seed=34),
+                                args=["-v", "--iq", "--bw", "20", "-", "SR", "8"]),
+    "u8_iq_dec_2400k": dict(binary="iq_dec", gen="rs41", cap=dict(sr=2_400_000, seconds=0.4, fq=0.1, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=35),
+                            args=["--iq", "FQ", "--lpIQ", "-", "SR", "8"], out="f4"),
+    "u8_rs41mod_wav8": dict(binary="rs41mod", gen="rs41", audio=True, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=36, bit_errors=6),
+                            args=["-r", "--ecc2", "--crc"]),
+    "u8_dft_detect_wav8": dict(binary="dft_detect", gen="rs41", audio=True, cap=dict(sr=48_000, seconds=2.0, fq=0.0, n_frames=1, t_first=0.4, noise_sigma=0.03, seed=37),
+                               args=["-v"]),
+}
+
+
+def u8_capture(case):
+    """-> (stdin bytes, argv)"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    cap["fq"] = synth.snap_fq(cap["fq"], sr)
+    x = synth.rs41_capture(**cap) if case["gen"] == "rs41" else synth.dfm_capture(**cap)
+    args = [repr(cap["fq"]) if a == "FQ" else str(sr) if a == "SR" else a for a in case["args"]]
+    if case.get("audio"):
+        return synth.wav_bytes(synth.to_u8(synth.fm_audio(x)), sr, bits=8), args
+    return synth.to_u8(x).tobytes(), args
+
+
 # scanner (scan/dft_detect.c): gen = capture generator, mode 5 = --IQ fq, 1 = --iq, 0 = FM audio (WAV)
 SCAN_CASES = {
     "scan_rs41_2400k_dc": dict(gen="rs41", cap=dict(sr=2_400_000, seconds=1.5, fq=0.1, n_frames=1, t_first=0.3, noise_sigma=0.01, seed=5, f_offset_hz=-400.0),
@@ -263,6 +293,12 @@ def main():
         np.savez_compressed(os.path.join(outdir, name + ".npz"), header=np.frombuffer(r.stdout[:hdr], np.uint8),
                             out=np.frombuffer(r.stdout[hdr:], "<" + case["out"]), stderr=np.array(r.stderr.decode()))
         print(name, len(r.stdout), r.stderr.decode().split())
+    for name, case in U8_CASES.items():
+        stdin, args = u8_capture(case)
+        r = subprocess.run([os.path.join(bind.REFDIR, case["binary"])] + args, input=stdin, capture_output=True)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), stdout=np.frombuffer(r.stdout, np.uint8), stderr=np.array(r.stderr.decode()),
+                            rc=r.returncode)
+        print(name, "rc", r.returncode, len(r.stdout), r.stdout[:60] if "out" not in case else "", r.stderr.decode().split())
     for name, case in AUDIO_CASES.items():
         pcm, wav = audio_capture(case)
         sr = case["cap"]["sr"]
