@@ -16,7 +16,7 @@
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0;
     FILE *fp = stdin;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
@@ -33,8 +33,12 @@ int main(int argc, char **argv) {
             fq = atof(argv[i]);
             if (fq < -0.5) fq = -0.5;
             if (fq > 0.5) fq = 0.5;
-            have_iq = 1;
+            have_iq = 1; iq_mode = 5;
         }
+        else if (!strcmp(a, "--iq0")) { have_iq = 1; iq_mode = 1; }      /* IF-rate IQ, FM discriminator */
+        else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }      /* IF-rate IQ, tone correlator  */
+        else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
+        else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
         else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
         else if (!strcmp(a, "--lpbw")) {
             if (++i >= argc) return -1;
@@ -80,7 +84,11 @@ int main(int argc, char **argv) {
     }
     if (opt_inv || opt_auto) { fprintf(stderr, "dfm09mod (sonde_hip): -i / --auto are implemented for --softin only\n"); return -1; }
     if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
-    if (have_iq && !have_pcm) { fprintf(stderr, "dfm09mod (sonde_hip): --IQ needs raw input (- <sr> <bits>)\n"); return -1; }
+    if (have_iq && !have_pcm) {                      /* IQ in a 2-channel WAV: header, then the same sample pairs */
+        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
+        if (nch != 2) { fprintf(stderr, "dfm09mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
+    }
+    if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
     if (!have_iq) {                                  /* FM audio: WAV on stdin or from a file (opt_iq = 0) */
         if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
         if (cfg.bits != 16 && cfg.bits != 8) { fprintf(stderr, "dfm09mod (sonde_hip): 8 / 16-bit input only\n"); return -1; }
@@ -97,7 +105,7 @@ int main(int argc, char **argv) {
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
     sonde_info_t info;
     sonde_engine_info(eng, &info);
-    if (have_iq) {
+    if (iq_mode == 5) {
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
     }

@@ -41,6 +41,9 @@ extern "C" {
 /* input forms (dsp.opt_iq of demod_mod.h:62; rs41mod.c:2674-2687,2786-2803) */
 #define SONDE_IN_IQ    0        /* baseband IQ, mixed by -fq and decimated to the IF rate (opt_iq = 5)        */
 #define SONDE_IN_AUDIO 1        /* FM-demodulated audio, one real sample per input frame (opt_iq = 0)         */
+#define SONDE_IN_IFIQ0 2        /* --iq0: IF-rate IQ (no mixer / decimator), FM discriminator sliced (opt_iq = 1) */
+#define SONDE_IN_IFIQ2 3        /* --iq2: IF-rate IQ, two-tone correlator sliced over whole bits (opt_iq = 2) */
+#define SONDE_IN_IFIQ3 4        /* --iq3: as --iq2 with the centre window of --IQ (opt_iq = 3, rs41mod.c:2921) */
 
 /* opt_lp bits, as demod_mod.h:12-14 */
 #define SONDE_LP_IQ 1
@@ -75,12 +78,14 @@ typedef struct {
     int32_t keep_soft;       /* testing: keep per-frame soft bits (soft-bit fetch call) and the IFIQ / FM tap streams */
     int32_t pipeline;        /* 1: IF-rate kernels on a second HIP stream so that sonde_engine_fetch_frames_lagged(lag=1)
                               * overlaps them with the next call's decimator; 0: one in-order stream             */
-    int32_t input;           /* SONDE_IN_IQ (--IQ fq, cs16) or SONDE_IN_AUDIO (FM audio: WAV payload, real int16;
-                              * dsp.opt_iq = 0, the reference's CPU-runnable configuration)                      */
+    int32_t input;           /* SONDE_IN_IQ (--IQ fq, cs16), SONDE_IN_AUDIO (FM audio: WAV payload, real int16; dsp.opt_iq = 0,
+                              * the reference's CPU-runnable configuration) or SONDE_IN_IFIQ0/2/3 (--iq0/2/3)     */
     int32_t audio_channels;  /* SONDE_IN_AUDIO: interleaved channels per frame (1 or 2) and which one (--ch2 = 1) */
     int32_t audio_select;
     int32_t if_rate;         /* SONDE_FRONTEND: designated IF rate in Hz (iq_dec --IFbw k -> 1000 k, default 48000;
                               * iq_dec.c:632-651); 0 elsewhere (48000, or 32000 with opt_min)                     */
+    int32_t opt_iqdc;        /* --iqdc: running-mean IQ-DC removal for SONDE_IN_IFIQ* (f32read_csample, demod_mod.c:444-458);
+                              * SONDE_IN_IQ always removes it (f32read_cblock :492)                              */
 } sonde_cfg_t;
 
 /* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */

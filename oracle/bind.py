@@ -123,8 +123,8 @@ def reflib(name: str = "libref_demod.so") -> C.CDLL:
     return _reflibs[name]
 
 
-def _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm, afc, baud, bt, h, lpiq_bw, lpfm_bw, hdr, symlen, symhd):
-    return RefCfg(sr, bps, iq_mode, (1 if lp_iq else 0) | (2 if lp_fm else 0), int(afc), 0, 0, 0, -fq, baud,
+def _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm, afc, baud, bt, h, lpiq_bw, lpfm_bw, hdr, symlen, symhd, iqdc=False):
+    return RefCfg(sr, bps, iq_mode, (1 if lp_iq else 0) | (2 if lp_fm else 0), int(afc), int(iqdc), 0, 0, -fq, baud,
                   symlen, symhd, bt, h, lpiq_bw, lpfm_bw, hdr)
 
 
@@ -145,10 +145,10 @@ def ref_streams(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False, a
 
 def ref_softframes(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False, afc=False, baud=4800.0,
                    bt=0.5, h=0.6, lpiq_bw=7400, lpfm_bw=6000, hdr=RS41_HDR, symlen=1, symhd=1,
-                   thres=0.7, hdmax=4, bitofs=2, l=2.0, nbits=4080, max_hits=64, libname="libref_demod.so"):
+                   thres=0.7, hdmax=4, bitofs=2, l=2.0, nbits=4080, max_hits=64, libname="libref_demod.so", iqdc=False):
     raw = np.ascontiguousarray(iq)
     cfg = _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm or (afc and iq_mode == 5), afc, baud, bt, h, lpiq_bw,
-                  lpfm_bw, hdr, symlen, symhd)
+                  lpfm_bw, hdr, symlen, symhd, iqdc)
     hits = np.zeros((max_hits, 4), np.float64)
     sb = np.zeros((max_hits, nbits), np.float32)
     sb1 = np.zeros((max_hits, nbits), np.float32)

@@ -57,6 +57,7 @@ struct sonde_engine {
     uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
     uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
     int16_t *d_stage = nullptr; size_t stage_bytes = 0;
+    bool ifiq = false;                             // --iq0/2/3 input
     hipEvent_t ev_copy = nullptr;                  // end of the host -> staging copy of process_host
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy [C][max_chunk]
     int ring_len = 0, max_frames = 0;
@@ -153,7 +154,8 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8)) return SONDE_E_ARG;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) || cfg->opt_dc) return SONDE_E_ARG;
-    if (cfg->sonde_type == SONDE_FRONTEND && cfg->input == SONDE_IN_AUDIO) return SONDE_E_ARG;
+    if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
+    if (cfg->input < SONDE_IN_IQ || cfg->input > SONDE_IN_IFIQ3) return SONDE_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
         fprintf(stderr, "libsonde_hip: no usable HIP device (the engine has no CPU fallback)\n");
@@ -181,7 +183,9 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
 
     // ---- init_buffers() arithmetic (demod_mod.c:1208-1474)
     const bool audio = cfg->input == SONDE_IN_AUDIO;
+    const bool ifiq = cfg->input >= SONDE_IN_IFIQ0;           // --iq0/2/3: the input already is the IF-rate stream (f32read_csample)
     if (audio) { e->dec.if_sr = cfg->sample_rate; e->dec.decM = 1; e->l_win = -1.0f; }     // opt_iq = 0: no front-end, whole-bit slicing (rs41mod.c:2920)
+    else if (ifiq) { e->dec.if_sr = cfg->sample_rate; e->dec.decM = 1; if (cfg->input != SONDE_IN_IFIQ3) e->l_win = -1.0f; }   // centre window only for opt_iq > 2
     else if (cfg->sonde_type == SONDE_FRONTEND) e->dec = design_decimator_if(cfg->sample_rate, cfg->if_rate > 0 ? cfg->if_rate : 48000, cfg->opt_min != 0);
     else e->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);
     const int D = e->dec.decM, sr = e->dec.if_sr;
@@ -325,6 +329,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     e->dc_lim = (uint32_t)sr; e->dc_max = e->dc_lim / 32;
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
+    e->ifiq = ifiq;
     e->last_frame.assign((size_t)C * 518, 0);
     for (int c = 0; c < C; c++) memcpy(e->last_frame.data() + (size_t)c * 518, kRs41HeaderBytes, 8);
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -392,6 +397,23 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         prof_begin(e, "if_chain", e->stream); sonde_launch_audio_chain(&c1, e->stream); prof_end(e, e->stream);
         e->samples_in += (uint64_t)n_samples; e->m_out += (uint32_t)n_samples; done = n_samples;
     }
+    while (done < n_samples && e->ifiq) {
+        // --iq0/2/3 (f32read_csample, demod_mod.c:419-461): convert, optionally minus the running mean of the previous segment
+        const bool dc = e->cfg.opt_iqdc != 0;
+        const int take = dc ? (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt) : n_samples - done;
+        IqConvArgs a{}; a.iq = (const int16_t *)d_iq + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.n = take;
+        a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums; a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
+        prof_begin(e, "iq_convert", e->stream); sonde_launch_iq_convert(&a, e->stream); prof_end(e, e->stream);
+        e->samples_in += (uint64_t)take; e->m_out += (uint32_t)take; done += take;
+        if (dc) {
+            e->dc_cnt += (uint32_t)take;
+            if (e->dc_cnt == e->dc_max) {
+                sonde_launch_dc_update(C, e->d_dcsums, e->d_dcavg, (float)e->dc_max, e->stream);
+                e->dc_cnt = 0;
+                if (e->dc_max < e->dc_lim) e->dc_max *= 2;
+            }
+        }
+    }
     while (done < n_samples) {
         // never straddle an IQ-DC segment: the mean of segment s-1 is subtracted throughout segment s
         const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt);
@@ -422,8 +444,8 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     b.y = e->d_y; b.tap_ifiq = (e->cfg.keep_soft || fe) ? e->d_ifiq : nullptr; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
     b.n = n_if; b.m0 = m_first;
     b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
-    b.tone_on = 1; b.nwin = (int)e->sps;
-    b.fm_on = (e->cfg.keep_soft || fe || !e->w_fm.empty()) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
+    b.tone_on = (e->cfg.input != SONDE_IN_IFIQ0); b.nwin = (int)e->sps;           // --iq0 slices the FM stream (opt_iq = 1)
+    b.fm_on = (e->cfg.keep_soft || fe || !e->w_fm.empty() || !b.tone_on) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
     b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);

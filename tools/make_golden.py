@@ -76,6 +76,46 @@ def iqdec_capture(case):
     return x, args
 
 
+# IF-rate IQ input of the demodulators (--iq0 / --iq2 / --iq3 [--iqdc], f32read_csample): args in front of `- sr bits`
+IFIQ_CASES = {
+    "ifiq_rs41_iq2_lpIQ": dict(gen="rs41", mode=2, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=61, f_offset_hz=350.0, bit_errors=6),
+                               lp_iq=True, lp_fm=False, iqdc=False),
+    "ifiq_rs41_iq0_lpFM": dict(gen="rs41", mode=1, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=62, f_offset_hz=-200.0),
+                               lp_iq=False, lp_fm=True, iqdc=False),
+    "ifiq_rs41_iq3_iqdc": dict(gen="rs41", mode=3, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=63, dc=0.03 - 0.02j),
+                               lp_iq=True, lp_fm=False, iqdc=True),
+    "ifiq_rs41_iq0_iqdc_u8": dict(gen="rs41", mode=1, cap=dict(sr=48_000, seconds=2.2, fq=0.0, n_frames=2, t_first=0.15, noise_sigma=0.02, seed=64, dc=0.05 + 0.04j),
+                                  lp_iq=True, lp_fm=False, iqdc=True, bits=8),
+    "ifiq_dfm_iq2_50k": dict(gen="dfm", mode=2, cap=dict(sr=50_000, seconds=2.5, fq=0.0, noise_sigma=0.03, seed=65), lp_iq=True, lp_fm=False, iqdc=False),
+    "ifiq_dfm_iq3_48k": dict(gen="dfm", mode=3, cap=dict(sr=48_000, seconds=2.5, fq=0.0, noise_sigma=0.03, seed=66), lp_iq=False, lp_fm=False, iqdc=False),
+}
+
+
+def ifiq_capture(case):
+    """-> (samples (int16 or uint8 pairs), binary, argv)"""
+    cap = dict(case["cap"])
+    x = synth.rs41_capture(**cap) if case["gen"] == "rs41" else synth.dfm_capture(**cap)
+    bits = case.get("bits", 16)
+    if bits == 8:
+        x = synth.to_u8(x)
+    binary = "rs41mod" if case["gen"] == "rs41" else "dfm09mod"
+    args = ["-r"] + (["--ecc2", "--crc"] if case["gen"] == "rs41" else ["--ecc"]) + ["--iq%d" % {1: 0, 2: 2, 3: 3}[case["mode"]]]
+    args += (["--lpIQ"] if case["lp_iq"] else []) + (["--lpFM"] if case["lp_fm"] else []) + (["--iqdc"] if case["iqdc"] else [])
+    return x, binary, args + ["-", str(cap["sr"]), str(bits)]
+
+
+def ifiq_softpar(case):
+    """ref_softframes keywords of a case (the slicing parameters the CLIs use, rs41mod.c:2920-2923, dfm09mod.c:1692-1695)"""
+    m = case["mode"]
+    par = dict(iq_mode=m, lp_iq=case["lp_iq"], lp_fm=case["lp_fm"], iqdc=case["iqdc"], bps=case.get("bits", 16))
+    if case["gen"] == "rs41":
+        par.update(l=2.0 if m > 2 else -1.0)
+    else:
+        par.update(baud=2500.0, h=1.8, lpiq_bw=12000, lpfm_bw=4000, hdr=bind.DFM_RAWHDR, symlen=2, symhd=2, thres=0.65, hdmax=2, nbits=2224,
+                   l=4.0 if m > 2 else -1.0)
+    return par
+
+
 # 8-bit unsigned input through each CLI (`- sr 8`, 8-bit WAV): stdout / stderr / exit code of the compiled reference
 U8_CASES = {
     "u8_rs41mod_2400k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=2_400_000, seconds=1.3, fq=0.1, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=31),
@@ -293,6 +333,16 @@ def main():
         np.savez_compressed(os.path.join(outdir, name + ".npz"), header=np.frombuffer(r.stdout[:hdr], np.uint8),
                             out=np.frombuffer(r.stdout[hdr:], "<" + case["out"]), stderr=np.array(r.stderr.decode()))
         print(name, len(r.stdout), r.stderr.decode().split())
+    for name, case in IFIQ_CASES.items():
+        x, binary, args = ifiq_capture(case)
+        out, err, rc = bind.ref_run(binary, args, x)
+        par = ifiq_softpar(case)
+        fast = bind.ref_softframes(x, case["cap"]["sr"], **par)
+        strict = bind.ref_softframes(x, case["cap"]["sr"], libname="libref_demod_O2.so", **par)
+        d = dict(lines=np.array(out.splitlines()), stderr=np.array(err), rc=rc, mv=strict["mv"], mv_pos=strict["mv_pos"], nbits=strict["nbits"],
+                 soft=strict["soft"], floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]))
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
+        print(name, "rc", rc, "lines", len(d["lines"]), "hits", strict["n"], strict["mv"], strict["mv_pos"], "floor_soft", d["floor_soft"], repr(err))
     for name, case in U8_CASES.items():
         stdin, args = u8_capture(case)
         r = subprocess.run([os.path.join(bind.REFDIR, case["binary"])] + args, input=stdin, capture_output=True)
