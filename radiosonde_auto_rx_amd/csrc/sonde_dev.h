@@ -27,8 +27,24 @@ struct MixDecArgs {
     int phase_f64;            // mixer phase f0*n kept in double (dft_detect.c:1090) instead of the float of demod_mod.c:1290
 };
 
+// --dc (AFC) per-channel state: what find_header keeps in dsp.Df / dsp.locked / dsp.dc (demod_mod.c:1555-1600, 280-298)
+struct AfcState {
+    double Df;                // accumulated frequency correction, Hz
+    double dc;                // FM mean under the last header (dsp.dc)
+    int locked;               // 1: nominal IF filter, 0: 1.5x acquisition filter
+    uint32_t pad;
+};
+
+struct AfcRotArgs {           // z *= cexp(-t 2 pi Df) at IF rate, t = m / sr in double (demod_mod.c:758-761)
+    const float2 *y; float2 *yrot; const AfcState *afc; const uint32_t *start;
+    int n_ch, ring_len, sr; uint32_t m_end;
+};
+
 struct IfArgs {
     const float2 *y; float2 *tap_ifiq; float *fm; float *bufs;
+    // --dc: per-channel restart.  Outputs are produced for m >= start[ch] only; older z' / raw FM samples come from the
+    // rings (tap_ifiq = rot_iqbuf, whose tail find_header may have rotated in place; fmraw = lpFM_buf).  nullptr = off.
+    const AfcState *afc; const uint32_t *start; float *fmraw; const float *w_iq0;
     int n_ch, ring_len, n; uint32_t m0;
     int lpiq_on, lpiq_taps, lpfm_on, lpfm_taps, tone_on, nwin;
     int fm_on;                // FM discriminator stream wanted (sliced stream of FM modes, --lpFM, taps); off = tone path only
@@ -50,6 +66,7 @@ struct SyncState {
 struct CorrArgs {
     const float *bufs; float *corr; const float *match;
     const SyncState *state;   // per-channel sync state for skipping tiles no window can reach (nullptr = compute all)
+    const uint32_t *start;    // --dc restart: positions below start[ch] are unchanged (nullptr = off)
     int delay; uint32_t frame_samples;
     int n_ch, ring_len, n, L; uint32_t m0;
     // factorised form (integer samples/symbol): ntypes == 0 selects the direct L-tap kernel
@@ -75,12 +92,19 @@ struct SyncArgs {
     float sps, thres, l_win;
     int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
+    // --dc (demod_mod.c:174-188,227-298,1555-1600): zero-mean windows, FM-stream fallback correlation, header dc, AFC events
+    int opt_dc, opt_iq, lpiq_on, lpfm_taps, N, sr;
+    float match_sum;
+    const float *fm, *corr2; float2 *ifiq;
+    AfcState *afc; uint32_t *start; unsigned *pending;
 };
 
 extern "C" {
 int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
+void sonde_launch_afc_rotate(const AfcRotArgs *a, hipStream_t s, int n_max);
+void sonde_launch_fill_u32(uint32_t *p, uint32_t v, int n, hipStream_t s);
 void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s);
 // 8-bit unsigned IQ -> the int16 form with identical sample values; n complex samples per channel, n even
 void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s);

@@ -58,6 +58,11 @@ struct sonde_engine {
     uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
     int16_t *d_stage = nullptr; size_t stage_bytes = 0;
     bool ifiq = false;                             // --iq0/2/3 input
+    // --dc: AFC state and the rings a restart needs (rotated pre-filter stream, raw FM, FM-stream correlation)
+    int opt_iq = 5; float match_sum = 0.f;
+    std::vector<float> w_iq0; float *d_wiq0 = nullptr;
+    float2 *d_yrot = nullptr; float *d_fmraw = nullptr, *d_corr2 = nullptr;
+    AfcState *d_afc = nullptr; uint32_t *d_start = nullptr; unsigned *d_pending = nullptr, *h_pending = nullptr;
     hipEvent_t ev_copy = nullptr;                  // end of the host -> staging copy of process_host
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy [C][max_chunk]
     int ring_len = 0, max_frames = 0;
@@ -153,7 +158,8 @@ const char *sonde_strerror(int code) {
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8)) return SONDE_E_ARG;
-    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) || cfg->opt_dc) return SONDE_E_ARG;
+    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
+    if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
     if (cfg->input < SONDE_IN_IQ || cfg->input > SONDE_IN_IFIQ3) return SONDE_E_ARG;
     int ndev = 0;
@@ -199,7 +205,8 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
         int taps = (int)(4 * sr / 4e3); if (taps % 2 == 0) taps++;
-        e->w_iq = design_lowpass(f_lp, taps);                  // locked filter; the 1.5x acquisition filter is --dc only
+        e->w_iq = design_lowpass(f_lp, taps);                  // locked filter
+        if (cfg->opt_dc) e->w_iq0 = design_lowpass((float)(1.5 * f_lp), taps);       // coarse acquisition (demod_mod.c:1312)
     }
     if (cfg->opt_lp & SONDE_LP_FM) {
         float f_lp = (float)(10e3 / (float)sr);
@@ -330,6 +337,18 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
     e->ifiq = ifiq;
+    e->opt_iq = audio ? 0 : ifiq ? (cfg->input == SONDE_IN_IFIQ0 ? 1 : cfg->input == SONDE_IN_IFIQ2 ? 2 : 3) : 5;
+    { double sm = 0.0; for (float v : e->match) sm += (double)v; e->match_sum = (float)sm; }
+    if (cfg->opt_dc) {
+        bad = 0;
+        bad |= dalloc(&e->d_afc, C); bad |= dalloc(&e->d_start, C); bad |= dalloc(&e->d_pending, 1);
+        if (!audio) { bad |= dalloc(&e->d_yrot, (size_t)C * ring); bad |= dalloc(&e->d_fmraw, (size_t)C * ring); }
+        if (e->opt_iq >= 2) bad |= dalloc(&e->d_corr2, (size_t)C * ring);
+        if (!e->w_iq0.empty()) bad |= dalloc(&e->d_wiq0, e->w_iq0.size(), false);
+        if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+        if (e->d_wiq0) HIPCHK(hipMemcpy(e->d_wiq0, e->w_iq0.data(), e->w_iq0.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipHostMalloc((void **)&e->h_pending, sizeof(unsigned), hipHostMallocDefault));
+    }
     e->last_frame.assign((size_t)C * 518, 0);
     for (int c = 0; c < C; c++) memcpy(e->last_frame.data() + (size_t)c * 518, kRs41HeaderBytes, 8);
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -353,11 +372,13 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
     for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); }
     if (e->ev_copy) hipEventDestroy(e->ev_copy);
+    if (e->h_pending) hipHostFree(e->h_pending);
     if (e->h_count) hipHostFree(e->h_count);
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
-                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv };
+                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
+                     e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -453,14 +474,37 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         hipEventRecord(e->ev_a[slot], e->stream);
         hipStreamWaitEvent(e->stream_b, e->ev_a[slot], 0);
     }
-    if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
     CorrArgs c{};
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
     c.state = e->d_state; c.delay = e->info.delay; c.frame_samples = e->frame_samples;
     c.ntypes = e->corr_types; c.isps = e->corr_isps; c.nsym = e->hdrlen / e->symhd; c.shapes = e->d_shapes; c.sym_type = e->d_symtype; c.sym_sign = e->d_symsign;
-    if (!fe) {
-        prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
-        launch_framesync(e, 0);
+    if (e->cfg.opt_dc && e->cfg.input != SONDE_IN_AUDIO) {
+        // --dc with IQ input: a header detection may change Df / the IF filter from its sample on (find_header,
+        // demod_mod.c:1553-1600).  The chunk is processed optimistically; k_framesync stops a channel at such an event and
+        // reports the sample, and everything IF-rate is redone from there with the new state until no channel reports one.
+        hipStream_t sb = e->stream_b;
+        sonde_launch_fill_u32(e->d_start, m_first, C, sb);
+        b.y = e->d_yrot; b.tap_ifiq = e->d_ifiq; b.afc = e->d_afc; b.start = e->d_start; b.fmraw = e->d_fmraw; b.w_iq0 = e->d_wiq0; b.fm_on = 1;
+        c.start = e->d_start;
+        AfcRotArgs r{}; r.y = e->d_y; r.yrot = e->d_yrot; r.afc = e->d_afc; r.start = e->d_start; r.n_ch = C; r.ring_len = e->ring_len;
+        r.sr = e->info.if_sr; r.m_end = e->m_out;
+        for (int it = 0; it < n_if / std::max(1, e->info.K - 4) + 4; it++) {
+            hipMemsetAsync(e->d_pending, 0, sizeof(unsigned), sb);
+            sonde_launch_afc_rotate(&r, sb, n_if);
+            prof_begin(e, "if_chain", sb); sonde_launch_if_chain(&b, sb); prof_end(e, sb);
+            prof_begin(e, "header_corr", sb); sonde_launch_header_corr(&c, sb); prof_end(e, sb);
+            if (e->opt_iq >= 2) { CorrArgs c2 = c; c2.bufs = e->d_fm; c2.corr = e->d_corr2; sonde_launch_header_corr(&c2, sb); }
+            launch_framesync(e, 0);
+            hipMemcpyAsync(e->h_pending, e->d_pending, sizeof(unsigned), hipMemcpyDeviceToHost, sb);
+            HIPCHK(hipStreamSynchronize(sb));
+            if (*e->h_pending == 0) break;
+        }
+    } else {
+        if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
+        if (!fe) {
+            prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
+            launch_framesync(e, 0);
+        }
     }
     hipMemcpyAsync(e->h_count + slot, e->d_fcount, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream_b);
     hipEventRecord(e->ev_b[slot], e->stream_b);
@@ -480,6 +524,8 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
     s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
+    s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
+    s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }
 

@@ -415,6 +415,41 @@ void k_audio_chain(const AudioChainArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_afc_rotate (--dc): yrot[m] = y[m] * cexp(-t 2 pi Df), t = m / sr, for m in [start[ch], m_end)   (demod_mod.c:758-761)
+// The reference multiplies the float sample by a double phasor and rounds once; Df is piecewise constant in time (it
+// changes at header detections), so the rotated stream is kept in its own ring = the IF filter's delay line lpIQ_buf.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_afc_rotate(const AfcRotArgs a) {
+    const int ch = blockIdx.y;
+    const uint32_t start = a.start[ch];
+    const int n = (int32_t)(a.m_end - start);
+    if (n <= 0) return;
+    const double Df = a.afc[ch].Df;
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const float2 *y = a.y + (size_t)ch * a.ring_len;
+    float2 *yr = a.yrot + (size_t)ch * a.ring_len;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t m = start + (uint32_t)i;
+        const float2 z = y[m & mask];
+        float2 r = z;
+        if (Df != 0.0) {
+            const double t = (double)m / (double)a.sr;
+            const double ph = -t * 6.2831853071795864769 * Df;
+            double sn, cs;
+            sincos(ph, &sn, &cs);
+            r = make_float2((float)((double)z.x * cs - (double)z.y * sn), (float)((double)z.x * sn + (double)z.y * cs));
+        }
+        yr[m & mask] = r;
+    }
+}
+
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_if_chain: one workgroup = IF_TILE output samples of one channel
 // ------------------------------------------------------------------------------------------------
 #define IF_TILE 960
@@ -428,6 +463,9 @@ void k_if_chain(const IfArgs a) {
     const uint32_t t0 = a.m0 + (uint32_t)blockIdx.x * IF_TILE;        // first output sample (absolute)
     const int nout = min(IF_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
     if (nout <= 0) return;
+    const bool afc = a.afc != nullptr;
+    const uint32_t start = afc ? a.start[ch] : t0;    // --dc restart: nothing below start[ch] is recomputed
+    if (afc && (int32_t)(t0 + (uint32_t)nout - start) <= 0) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const int T1 = a.lpiq_on ? a.lpiq_taps : 1;       // IF low-pass taps
     const int T2 = a.lpfm_on ? a.lpfm_taps : 1;       // FM low-pass taps
@@ -450,7 +488,8 @@ void k_if_chain(const IfArgs a) {
         const int64_t m = (int64_t)t0 - hz - (T1 - 1) + k;     // absolute IF index, may be < 0 at stream start
         sy[k] = (m >= 0 && k < ny) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
     }
-    for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? a.w_iq[k] : 1.0f;
+    const float *w_iq = (afc && !a.afc[ch].locked) ? a.w_iq0 : a.w_iq;          // acquisition / locked tap set (demod_mod.c:1577-1590)
+    for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? w_iq[k] : 1.0f;
     for (int k = threadIdx.x; k < T2; k += IF_THREADS) wf[k] = a.lpfm_on ? a.w_fm[k] : 1.0f;
     __syncthreads();
 
@@ -492,6 +531,10 @@ void k_if_chain(const IfArgs a) {
             float re = ar[j], im = ai[j];
             const int64_t m = (int64_t)t0 - hz + k;
             if (m < 0) { re = 0.f; im = 0.f; }
+            else if (afc && (int32_t)((uint32_t)m - start) < 0) {          // older than the restart: rot_iqbuf as it stands
+                const float2 zo = a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)];
+                re = zo.x; im = zo.y;
+            }
             sz[k] = make_float2(re, im);
             // tone mixer e^{-i t w}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
             const double rev = (double)m * a.rho;
@@ -500,7 +543,8 @@ void k_if_chain(const IfArgs a) {
             // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470)
             sx[k] = make_float2(re * cs - im * sn, re * sn + im * cs);
             sx2[k] = make_float2(re * cs + im * sn, im * cs - re * sn);
-            if (a.tap_ifiq && m >= (int64_t)t0) a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
+            if (a.tap_ifiq && m >= (int64_t)t0 && (int32_t)((uint32_t)m - start) >= 0)
+                a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
         }
     }
     __syncthreads();
@@ -511,7 +555,14 @@ void k_if_chain(const IfArgs a) {
         const int zi = k + (hz - (T2 - 1));            // index into sz of sample m
         const float2 z1 = sz[zi], z0 = sz[zi - 1];
         const float wr = z1.x * z0.x + z1.y * z0.y, wi = z1.y * z0.x - z1.x * z0.y;
-        sf[k] = 0.8f * atan2f(wi, wr) * 0.31830988618379067f;
+        float v = 0.8f * atan2f(wi, wr) * 0.31830988618379067f;
+        if (afc) {                                     // raw FM samples older than the restart come from lpFM_buf's ring
+            const int64_t m = (int64_t)t0 - (T2 - 1) + k;
+            float *fr = a.fmraw + (size_t)ch * a.ring_len;
+            if (m >= 0 && (int32_t)((uint32_t)m - start) < 0) v = fr[(uint32_t)m & mask];
+            else if (m >= (int64_t)t0) fr[(uint32_t)m & mask] = v;
+        }
+        sf[k] = v;
     }
     __syncthreads();
 
@@ -519,6 +570,7 @@ void k_if_chain(const IfArgs a) {
     float *fmb = a.fm + (size_t)ch * a.ring_len;
     for (int k = threadIdx.x; k < nout; k += IF_THREADS) {
         const uint32_t m = t0 + (uint32_t)k;
+        if (afc && (int32_t)(m - start) < 0) continue;
         // two-tone correlator: windowed sums over the last nwin samples (the reference keeps them as
         // recursive sliding sums, demod_mod.c:796-803 — same value up to its float drift)
         float f1r = 0.f, f1i = 0.f, f2r = 0.f, f2i = 0.f;
@@ -551,6 +603,7 @@ void k_if_chain(const IfArgs a) {
 // window only reaches back K+delay samples.  The channel's sync state (left by the previous k_framesync) gives the
 // first end position any future window can examine; correlation tiles entirely below it are skipped.
 __device__ __forceinline__ bool corr_tile_unused(const CorrArgs &a, int ch, uint32_t tile_end) {
+    if (a.start && (int32_t)(tile_end - a.start[ch]) <= 0) return true;        // --dc restart: bufs below start[ch] did not change
     if (!a.state) return false;
     const SyncState st = a.state[ch];
     uint32_t first;                                           // earliest candidate end position of the next window
@@ -716,24 +769,110 @@ __device__ __forceinline__ void bit_window(int pos, int half, int symlen, float 
 // host tabulates them once per engine with the reference's float/double edge arithmetic (sonde_design.cpp
 // bit_window / slice_range); all loads of a range are issued up front.
 #define SLICE_MAXW 24
-__device__ __forceinline__ double window_sum(const float *bufs, uint32_t base, uint32_t mask, uint32_t qa, uint32_t qb) {
+// DCSUB (--dc with an FM-sliced stream): sample = (float)(sample - dc) before it is added (demod_mod.c:1150).
+template <bool DCSUB>
+__device__ __forceinline__ double window_sum(const float *bufs, uint32_t base, uint32_t mask, uint32_t qa, uint32_t qb, double dc) {
     float v[SLICE_MAXW];
 #pragma unroll
     for (int j = 0; j < SLICE_MAXW; j++) v[j] = (qa + (uint32_t)j < qb) ? bufs[(base + qa + (uint32_t)j) & mask] : 0.f;
     double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < SLICE_MAXW; j++) if (qa + (uint32_t)j < qb) sum += (double)v[j];
-    for (uint32_t q = qa + SLICE_MAXW; q < qb; q++) sum += (double)bufs[(base + q) & mask];    // very wide symbols
+    for (int j = 0; j < SLICE_MAXW; j++) if (qa + (uint32_t)j < qb) sum += DCSUB ? (double)(float)((double)v[j] - dc) : (double)v[j];
+    for (uint32_t q = qa + SLICE_MAXW; q < qb; q++) {                                           // very wide symbols
+        const float s = bufs[(base + q) & mask];
+        sum += DCSUB ? (double)(float)((double)s - dc) : (double)s;
+    }
     return sum;
 }
 
 #define FS_THREADS 1024
 #define FS_WAVES (FS_THREADS / WAVE)
 
+// One correlation window of getCorrDFT (demod_mod.c:148-225) evaluated from the precomputed correlation ring: arg-max of
+// c^2 over the K+1 end positions p = pos-K .. pos (first maximum wins), edge rejection, L-sample norm.
+// DC (--dc, :174-188): the reference zeroes bin 0 of the zero-padded N-point transform, i.e. subtracts mu = sum(window)/N
+// from every sample including the padding; the circular correlation then drops by mu * sum(match) at every lag and
+// the norm runs over (x - mu).  Returns the peak index 0..K, or -4 (edge / empty window); mv, mpos only when >= 0.
+template <bool DC>
+__device__ __forceinline__ int fs_window(const float *x, const float *corr, uint32_t mask, uint32_t pos, int K, int L, int N,
+                                         float match_sum, int tid, int lane, int wave, float *s_rf, int *s_ri,
+                                         float &mv, uint32_t &mpos) {
+    float mu = 0.f;
+    if (DC) {
+        float s = 0.f;
+        for (int t = tid; t < K + L; t += FS_THREADS) {
+            const int64_t p = (int64_t)pos - (K + L - 1) + t;
+            if (p >= 0) s += x[(uint32_t)p & mask];
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_rf[wave] = s;
+        __syncthreads();
+        s = 0.f;
+        for (int w = 0; w < FS_WAVES; w++) s += s_rf[w];
+        __syncthreads();
+        mu = s / (float)N;
+    }
+    const float off = mu * match_sum;
+    float best = 0.f; int bidx = -1;
+    {
+        float cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int t = tid + u * FS_THREADS;
+            const int64_t p = (int64_t)pos - K + t;
+            cv[u] = (t <= K && p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
+            if (DC) cv[u] = (t <= K) ? cv[u] - off : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float c2 = cv[u] * cv[u];
+            if (c2 > best) { best = c2; bidx = tid + u * FS_THREADS; }
+        }
+        for (int t = tid + 8 * FS_THREADS; t <= K; t += FS_THREADS) {      // K > 8191 only
+            const int64_t p = (int64_t)pos - K + t;
+            float c = (p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
+            if (DC) c -= off;
+            if (c * c > best) { best = c * c; bidx = t; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bidx, o);
+        if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
+    __syncthreads();
+    best = 0.f; bidx = -1;
+    for (int w = 0; w < FS_WAVES; w++) {
+        const float ob = s_rf[w]; const int oi = s_ri[w];
+        if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+    }
+    __syncthreads();
+    if (bidx <= 0 || bidx == K) return -4;                         // edge value -> -4 (mv stays 0)
+    mpos = pos - (uint32_t)K + (uint32_t)bidx;
+    float e = 0.f;
+    for (int t = tid; t < L; t += FS_THREADS) {
+        const int64_t p = (int64_t)mpos - t;
+        float v = (p >= 0) ? x[(uint32_t)p & mask] : 0.f;
+        if (DC) v -= mu;
+        e = fmaf(v, v, e);
+    }
+    e = wave_sum(e);
+    if (lane == 0) s_rf[wave] = e;
+    __syncthreads();
+    e = 0.f;
+    for (int w = 0; w < FS_WAVES; w++) e += s_rf[w];
+    __syncthreads();
+    float c = corr[mpos & mask];
+    if (DC) c -= off;
+    mv = c / sqrtf(e);
+    return bidx;
+}
+
 // One workgroup of 16 waves per channel.  The state machine is evaluated redundantly by every thread (all
 // decisions depend only on workgroup-uniform values); the data-parallel parts — window arg-max (K+1 candidates),
 // L-sample energy, header bit check, the nbits soft bits, RS syndromes — are spread over the 1024 threads so that
 // each phase costs about one memory round trip instead of a chain of them.
+template <bool DC>
 __global__ __launch_bounds__(FS_THREADS)
 void k_framesync(const SyncArgs a) {
     __shared__ uint8_t s_frame[520];
@@ -744,13 +883,17 @@ void k_framesync(const SyncArgs a) {
     __shared__ int s_cnt[2];
     __shared__ unsigned s_slot;
     __shared__ uint8_t s_syn[FS_WAVES][48];
+    __shared__ double s_rd[FS_WAVES];
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= a.n_ch) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
     const float *corr = a.corr + (size_t)ch * a.ring_len;
     SyncState st = a.state[ch];
-    const uint32_t avail = a.avail;            // IF samples [0, avail) exist
+    uint32_t avail = a.avail;                  // IF samples [0, avail) exist (--dc: cut at an AFC event, the rest is recomputed)
+    AfcState af{};                             // --dc only
+    if (DC) af = a.afc[ch];
+    bool afc_event = false;
     const int K = a.K, L = a.L;
 
     if (tid < 512) s_exp[tid] = a.gf_exp[tid];
@@ -767,72 +910,73 @@ void k_framesync(const SyncArgs a) {
             st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
             const uint32_t pos = s_in_w - 1 - (uint32_t)a.delay;      // sample_out
             if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
-            // arg-max of c^2 over end positions p = pos-K .. pos, first maximum wins (demod_mod.c:200-208)
-            float best = 0.f; int bidx = -1;
-            {
-                float cv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int t = tid + u * FS_THREADS;
-                    const int64_t p = (int64_t)pos - K + t;
-                    cv[u] = (t <= K && p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const float c2 = cv[u] * cv[u];
-                    if (c2 > best) { best = c2; bidx = tid + u * FS_THREADS; }
-                }
-                for (int t = tid + 8 * FS_THREADS; t <= K; t += FS_THREADS) {      // K > 8191 only
-                    const int64_t p = (int64_t)pos - K + t;
-                    const float c = (p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
-                    if (c * c > best) { best = c * c; bidx = t; }
-                }
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
-                if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
-            }
-            if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
-            __syncthreads();
-            best = 0.f; bidx = -1;
-            for (int w = 0; w < FS_WAVES; w++) {
-                const float ob = s_rf[w]; const int oi = s_ri[w];
-                if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
-            }
-            __syncthreads();
-            if (bidx == 0 || bidx == K) continue;                      // edge value -> -4, mv = 0
-            if (bidx < 0) continue;
-            const uint32_t mpos = pos - (uint32_t)K + (uint32_t)bidx;
-            float e = 0.f;
-            for (int t = tid; t < L; t += FS_THREADS) {
-                const int64_t p = (int64_t)mpos - t;
-                const float v = (p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
-                e = fmaf(v, v, e);
-            }
-            e = wave_sum(e);
-            if (lane == 0) s_rf[wave] = e;
-            __syncthreads();
-            e = 0.f;
-            for (int w = 0; w < FS_WAVES; w++) e += s_rf[w];
-            __syncthreads();
-            const float mv = corr[mpos & mask] / sqrtf(e);
+            float mv; uint32_t mpos;
+            if (fs_window<DC>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
             const uint32_t prev = st.mv_pos;
             st.mv = mv; st.mv_pos = mpos;
+            if (DC) {
+                // FM-stream fallback (opt_iq >= 2 and the tone stream missed, demod_mod.c:230-277), header dc (:280-292), dDf (:298)
+                const float *fm = a.fm + (size_t)ch * a.ring_len;
+                const float hofs = ((float)a.lpfm_taps - (a.sps - 1.0f)) / 2.0f;
+                uint32_t dpos = mpos, mv2_pos = 0;
+                if (a.opt_iq >= 2 && fabsf(mv) < a.thres) {
+                    float mv2; uint32_t mpos2;
+                    if (fs_window<true>(fm, a.corr2 + (size_t)ch * a.ring_len, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv2, mpos2) < 0) continue;
+                    mv2_pos = (uint32_t)((float)mpos2 - hofs);
+                    dpos = mpos2;
+                    if (mv2 > a.thres || mv2 < -a.thres) { st.mv = mv2; st.mv_pos = mv2_pos; }
+                }
+                const int mp_ofs = (a.opt_iq >= 2 && mv2_pos == 0) ? (int)hofs : 0;
+                double dsum = 0.0;
+                for (int t = tid; t < L; t += FS_THREADS) dsum += (double)fm[((uint32_t)mp_ofs + dpos - (uint32_t)t) & mask];
+                for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+                if (lane == 0) s_rd[wave] = dsum;
+                __syncthreads();
+                dsum = 0.0;
+                for (int w = 0; w < FS_WAVES; w++) dsum += s_rd[w];
+                __syncthreads();
+                af.dc = dsum / (double)(float)L;
+                mv = st.mv; mpos = st.mv_pos;
+            }
             if (!(mv > a.thres || mv < -a.thres)) continue;
+            if (DC && a.opt_iq) {
+                // AFC (find_header, demod_mod.c:1553-1600): 60 % of the remaining offset once it exceeds 100 Hz; IF filter
+                // locked below 1 kHz.  Everything from sample_in = st.s_in on is recomputed by the host loop.
+                const double dDf = (double)a.sr * af.dc / (2.0 * 0.8);
+                bool ev = false;
+                if (fabs(dDf) > 100.0) {
+                    const double diff = dDf * 0.6;
+                    const int nn = (int)a.sps;
+                    if (a.opt_iq >= 2 && tid < nn) {               // rot_iqbuf tail: the tone window straddling the change (:1562-1575)
+                        const uint32_t m = st.s_in - (uint32_t)(tid + 1);
+                        const double tn = (double)m / (double)a.sr;
+                        double sn, cs;
+                        sincos(-tn * 6.2831853071795864769 * diff, &sn, &cs);
+                        float2 *zp = a.ifiq + (size_t)ch * a.ring_len + (m & mask);
+                        const float2 z = *zp;
+                        *zp = make_float2((float)((double)z.x * cs - (double)z.y * sn), (float)((double)z.x * sn + (double)z.y * cs));
+                    }
+                    af.Df += diff; ev = true;
+                }
+                if (fabs(dDf) > 1e3) { if (af.locked) { af.locked = 0; ev |= (a.lpiq_on != 0); } }
+                else { if (!af.locked) { af.locked = 1; ev |= (a.lpiq_on != 0); } }
+                if (ev) { afc_event = true; avail = st.s_in; }
+            }
             if (!(mpos > prev)) continue;
             // ---- headcmp (demod_mod.c:870-938): hard-slice the header from the ring, count mismatches
             int errs = 0;
             const int nsym = a.hdrlen / a.symhd;
             const uint32_t mvp = mpos + 1 - (uint32_t)L;
+            const double hdc = (DC && a.opt_iq < 2) ? af.dc : 0.0;     // read_bufbit: bufs - dc for the FM-sliced forms (demod_mod.c:879)
             for (int p = tid; p < nsym; p += FS_THREADS) {
                 double edge = (double)((float)(p * a.symhd) * a.sps);
                 uint32_t cnt = (uint32_t)ceil(edge);
                 double sum = 0.0;
                 edge += (double)a.sps;
-                do { sum += (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
+                do { sum += (double)bufs[(cnt + mvp) & mask] - hdc; cnt++; } while ((double)cnt < edge);
                 if (a.symhd == 2) {
                     edge += (double)a.sps;
-                    do { sum -= (double)bufs[(cnt + mvp) & mask]; cnt++; } while ((double)cnt < edge);
+                    do { sum -= (double)bufs[(cnt + mvp) & mask] - hdc; cnt++; } while ((double)cnt < edge);
                 }
                 const int sign = mv < 0 ? 1 : 0;
                 if (a.symhd == 1) {
@@ -874,8 +1018,13 @@ void k_framesync(const SyncArgs a) {
                     const uint4 w = a.bitwin[bp];                      // {qa-, qb-, qa+, qb+}
                     valid = (int32_t)a.bitend[bp] <= q_lim;
                     if (valid) {
-                        if (w.y > w.x) sum = 0.0 - window_sum(bufs, base, mask, w.x, w.y);
-                        sum += window_sum(bufs, base, mask, w.z, w.w);
+                        if (DC && a.opt_iq < 2) {
+                            if (w.y > w.x) sum = 0.0 - window_sum<true>(bufs, base, mask, w.x, w.y, af.dc);
+                            sum += window_sum<true>(bufs, base, mask, w.z, w.w, af.dc);
+                        } else {
+                            if (w.y > w.x) sum = 0.0 - window_sum<false>(bufs, base, mask, w.x, w.y, 0.0);
+                            sum += window_sum<false>(bufs, base, mask, w.z, w.w, 0.0);
+                        }
                     }
                 }
                 const int hb = valid && (sum >= 0.0);
@@ -928,6 +1077,11 @@ void k_framesync(const SyncArgs a) {
         }
     }
     if (tid == 0) a.state[ch] = st;
+    if (DC && tid == 0) {
+        a.afc[ch] = af;
+        a.start[ch] = afc_event ? avail : a.avail;      // first IF sample the host loop has to recompute for this channel
+        if (afc_event) atomicAdd(a.pending, 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -983,6 +1137,13 @@ extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, i
     int gx = (n_bytes / 4 + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_u8_to_s16, dim3(gx, n_ch), dim3(256), 0, s, in, in_stride, out, out_stride, n_bytes);
 }
+extern "C" void sonde_launch_afc_rotate(const AfcRotArgs *a, hipStream_t s, int n_max) {
+    int gx = (n_max + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_afc_rotate, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
+}
+extern "C" void sonde_launch_fill_u32(uint32_t *p, uint32_t v, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_u32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+}
 extern "C" void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s) {
     int gx = (a->n + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_audio_chain, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
@@ -1005,5 +1166,6 @@ extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
     hipLaunchKernelGGL(k_header_corr, dim3((a->n + HC_TILE - 1) / HC_TILE, a->n_ch), dim3(HC_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
-    hipLaunchKernelGGL(k_framesync, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
+    if (a->opt_dc) hipLaunchKernelGGL(k_framesync<true>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
+    else hipLaunchKernelGGL(k_framesync<false>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
 }

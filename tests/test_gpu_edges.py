@@ -34,7 +34,7 @@ def test_cli_empty_and_short_inputs():
     # argument errors: 255 like the reference's `return -1`
     r = _run([os.path.join(BIN, "rs41mod"), "-r", "--IQ", "0.1", "-", "0", "16"])
     assert r.returncode == 255
-    r = _run([os.path.join(BIN, "rs41mod"), "-r", "--dc", "--IQ", "0.1", "-", "2400000", "16"])
+    r = _run([os.path.join(BIN, "rs41mod"), "-r", "--noLUT", "--IQ", "0.1", "-", "2400000", "16"])
     assert r.returncode == 255 and b"not supported" in r.stderr          # refused, not approximated
 
 
@@ -75,7 +75,7 @@ def test_engine_rejects_bad_requests():
     assert eng.fetch_frames() == []
     eng.close()
     with pytest.raises(SondeError):
-        Engine([0.1], 2_400_000, opt_dc=True)                           # --dc (AFC) is not implemented: refused
+        Engine([0.1], 2_400_000, bits=32)                               # float input is not implemented: refused
     from radiosonde_auto_rx_amd.fsk import FskModem
     with pytest.raises(SondeError):
         FskModem(48000, 4799)                                           # Fs % Rs != 0 (the reference asserts)

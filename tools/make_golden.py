@@ -116,6 +116,51 @@ def ifiq_softpar(case):
     return par
 
 
+# --dc: header dc / AFC feedback (find_header + getCorrDFT dc branches).  off = carrier offset in Hz the decoder is not told about.
+DC_CASES = {
+    "dc_rs41_2400k_off3200": dict(gen="rs41", mode=5, off=3200.0, cap=dict(sr=2_400_000, seconds=4.2, fq=0.1, n_frames=4, t_first=0.1, noise_sigma=0.02, seed=71), lp_iq=True),
+    "dc_rs41_2400k_off450": dict(gen="rs41", mode=5, off=-450.0, cap=dict(sr=2_400_000, seconds=3.2, fq=-0.21, n_frames=3, t_first=0.1, noise_sigma=0.02, seed=72), lp_iq=True),
+    "dc_rs41_2400k_nolp_off1500": dict(gen="rs41", mode=5, off=1500.0, cap=dict(sr=2_400_000, seconds=3.2, fq=0.05, n_frames=3, t_first=0.1, noise_sigma=0.01, seed=73), lp_iq=False),
+    "dc_rs41_iq2_48k_off1800": dict(gen="rs41", mode=2, off=1800.0, cap=dict(sr=48_000, seconds=4.2, fq=0.0, n_frames=4, t_first=0.15, noise_sigma=0.03, seed=74), lp_iq=True),
+    "dc_rs41_iq0_48k_off900": dict(gen="rs41", mode=1, off=900.0, cap=dict(sr=48_000, seconds=4.2, fq=0.0, n_frames=4, t_first=0.15, noise_sigma=0.03, seed=75), lp_iq=True),
+    "dc_rs41_audio_48k": dict(gen="rs41", mode=0, off=700.0, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=76), lp_iq=False),
+    "dc_dfm_2400k_off2500": dict(gen="dfm", mode=5, off=2500.0, cap=dict(sr=2_400_000, seconds=2.6, fq=0.12, noise_sigma=0.02, seed=77), lp_iq=True),
+    "dc_dfm_iq3_48k_off600": dict(gen="dfm", mode=3, off=-600.0, cap=dict(sr=48_000, seconds=2.6, fq=0.0, noise_sigma=0.03, seed=78), lp_iq=True),
+}
+
+
+def dc_capture(case):
+    """-> (samples for ref_softframes, stdin bytes, binary, argv, fq the decoder is given)"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    fq = synth.snap_fq(cap["fq"], sr)
+    if case["gen"] == "rs41":
+        cap["fq"] = fq
+        x = synth.rs41_capture(f_offset_hz=case["off"], **cap)
+    else:
+        cap["fq"] = fq + case["off"] / sr
+        x = synth.dfm_capture(**cap)
+    binary = "rs41mod" if case["gen"] == "rs41" else "dfm09mod"
+    args = ["-r"] + (["--ecc2", "--crc"] if case["gen"] == "rs41" else ["--ecc"]) + ["--dc"]
+    m = case["mode"]
+    if m == 0:
+        pcm = synth.fm_audio(x)
+        return pcm, synth.wav_bytes(pcm, sr), binary, args, fq
+    args += ["--IQ", repr(fq)] if m == 5 else ["--iq%d" % {1: 0, 2: 2, 3: 3}[m]]
+    args += ["--lpIQ"] if case["lp_iq"] else []
+    return x, x.tobytes(), binary, args + ["-", str(sr), "16"], fq
+
+
+def dc_softpar(case, fq):
+    m = case["mode"]
+    par = dict(iq_mode=m, fq=fq, lp_iq=case["lp_iq"] and m != 0, lp_fm=False, afc=True)     # afc: ref_softframes adds LP_FM for mode 5 like the CLIs
+    if case["gen"] == "rs41":
+        par.update(l=2.0 if m > 2 else -1.0)
+    else:
+        par.update(baud=2500.0, h=1.8, lpiq_bw=12000, lpfm_bw=4000, hdr=bind.DFM_RAWHDR, symlen=2, symhd=2, thres=0.65, hdmax=2, nbits=2224,
+                   l=4.0 if m > 2 else -1.0)
+    return par
+
+
 # 8-bit unsigned input through each CLI (`- sr 8`, 8-bit WAV): stdout / stderr / exit code of the compiled reference
 U8_CASES = {
     "u8_rs41mod_2400k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=2_400_000, seconds=1.3, fq=0.1, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=31),
@@ -290,6 +335,20 @@ def capture(kw):
     return x, kw["fq"]
 
 
+def gen_dc_case(name, case, outdir):
+    x, stdin, binary, args, fq = dc_capture(case)
+    out, err, rc = bind.ref_run(binary, args, stdin)
+    par = dc_softpar(case, fq)
+    fast = bind.ref_softframes(x, case["cap"]["sr"], **par)
+    strict = bind.ref_softframes(x, case["cap"]["sr"], libname="libref_demod_O2.so", **par)
+    same = fast["n"] == strict["n"] and np.array_equal(fast["mv_pos"], strict["mv_pos"])
+    d = dict(lines=np.array(out.splitlines()), stderr=np.array(err), rc=rc, mv=strict["mv"], mv_pos=strict["mv_pos"], nbits=strict["nbits"],
+             soft=strict["soft"], floor_soft=rms(fast["soft"] - strict["soft"]) if same else -1.0, consts=json.dumps(strict["consts"]))
+    np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
+    print(name, "rc", rc, "lines", len(d["lines"]), [l[-10:] for l in d["lines"]][:4], "hits", strict["n"], strict["mv"], strict["mv_pos"],
+          "fast hits", fast["n"], fast["mv_pos"], "floor_soft", d["floor_soft"])
+
+
 def main():
     outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -343,6 +402,8 @@ def main():
                  soft=strict["soft"], floor_soft=rms(fast["soft"] - strict["soft"]), consts=json.dumps(strict["consts"]))
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "rc", rc, "lines", len(d["lines"]), "hits", strict["n"], strict["mv"], strict["mv_pos"], "floor_soft", d["floor_soft"], repr(err))
+    for name, case in DC_CASES.items():
+        gen_dc_case(name, case, outdir)
     for name, case in U8_CASES.items():
         stdin, args = u8_capture(case)
         r = subprocess.run([os.path.join(bind.REFDIR, case["binary"])] + args, input=stdin, capture_output=True)
