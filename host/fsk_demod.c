@@ -8,7 +8,7 @@
  * stderr: `Setting estimator limits to a to b Hz.` and, with --stats, one JSON line every 1/(r*loop_time) frames carrying
  *         samples / EbNodB / ppm / f1_est / f2_est / samp_fft (:365-411; what auto_rx/autorx/fsk_demod.py:23 requires).
  * exit 0 at EOF / SIGTERM, 1 on usage errors.  Like the reference, each iteration reads exactly fsk_nin() samples.
- * Not implemented: 4-FSK, --testframes, the eye-diagram samples of the stats line (printed as an empty list).
+ * Not implemented: 4-FSK, --testframes.
  */
 #include <getopt.h>
 #include <signal.h>
@@ -103,7 +103,19 @@ int main(int argc, char *argv[]) {
                 fprintf(stderr, "{");
                 fprintf(stderr, "\"samples\": %ld, \"EbNodB\": %5.1f, \"ppm\": %4d,", (long)samples, last.snr_est, (int)last.ppm);
                 fprintf(stderr, " \"f1_est\":%.1f, \"f2_est\":%.1f", last.f_est[0], last.f_est[1]);
-                fprintf(stderr, ",\t\"eye_diagram\":[],");
+                {   /* eye diagram (fsk_demod.c:387-398) */
+                    static float eye[8 * 160];
+                    int32_t ntr = 0, nes = 0;
+                    fprintf(stderr, ",\t\"eye_diagram\":[");
+                    if (sonde_fsk_eye(fsk, 0, eye, &ntr, &nes) > 0)
+                        for (int i = 0; i < ntr; i++) {
+                            fprintf(stderr, "[");
+                            for (int j = 0; j < nes; j++) { fprintf(stderr, "%f ", eye[i * nes + j]); if (j < nes - 1) fprintf(stderr, ","); }
+                            fprintf(stderr, "]");
+                            if (i < ntr - 1) fprintf(stderr, ",");
+                        }
+                    fprintf(stderr, "],");
+                }
                 fprintf(stderr, "\"samp_fft\":[");
                 for (int i = 0; i < info.Ndft / 2; i++) { fprintf(stderr, "%f ", Sf[i]); if (i < info.Ndft / 2 - 1) fprintf(stderr, ","); }
                 fprintf(stderr, "]}\n");

@@ -74,6 +74,10 @@ int  sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, so
                      int32_t *n_frames);
 /* fsk_get_demod_stats + Sf: smoothed magnitude spectrum (Ndft floats, DC at Ndft/2) and samples consumed so far */
 int  sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, float *Sf, int64_t *samples);
+/* Eye diagram of the last modem frame as fsk_get_demod_stats() returns it (rx_eye, fsk.c:857-903; modem_stats.h:63-65):
+ * neyetr = 8 traces (4 per tone, interleaved lower / upper) of neyesamp = 2P/ceil(2P/160) integrator magnitudes, normalised
+ * to the largest.  eye receives neyetr * neyesamp floats (row-major; at most 8 * 160); returns that count. */
+int  sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr, int32_t *neyesamp);
 int  sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches);
 
 #ifdef __cplusplus

@@ -19,7 +19,7 @@ struct sonde_fsk {
     sonde_fsk_info_t info{};
     FskArgs args{};
     hipStream_t stream = nullptr;
-    void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr;
+    void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr, *d_eye = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
     FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr;
     std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
@@ -118,14 +118,14 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     bad |= dalloc((char **)&f->d_in, (size_t)C * ring * f->unit);
     bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
     bad |= dupload(&f->d_fmask, fmask); bad |= dupload(&f->d_phift, phift);
-    bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * 2 * a.NT);
+    bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * 2 * a.NT);
     bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
     if (bad) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
     f->h_chan.resize(C);
     for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); c.phi_c[0] = c.phi_c[1] = exp_j(0); c.nin = N; }
     HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
     a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
-    a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.tail = f->d_tail; a.sd = f->d_sd; a.recs = f->d_recs;
+    a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.recs = f->d_recs;
     f->h_sd.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
     HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     *out = f;
@@ -135,7 +135,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -209,6 +209,20 @@ int sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, fl
     if (Sf) HIPCHK(hipMemcpy(Sf, f->d_Sf + (size_t)channel * f->info.Ndft, (size_t)f->info.Ndft * sizeof(float), hipMemcpyDeviceToHost));
     if (samples) *samples = c.samples;
     return 0;
+}
+
+int sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr, int32_t *neyesamp) {
+    if (!f || !eye || channel < 0 || channel >= f->cfg.n_channels) return SONDE_E_ARG;
+    const int P = f->cfg.P;
+    const int dec = (int)ceil(((float)P * 2) / 160.0f), nes = (P * 2) / dec, ntr = 8;      // MODEM_STATS_EYE_IND_MAX 160, ET_MAX 8
+    std::vector<float> raw(8 * 160);
+    HIPCHK(hipMemcpy(raw.data(), f->d_eye + (size_t)channel * 8 * 160, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+    float eye_max = 0;                                        // normalise_eye = 1 (fsk.c:198,892-903)
+    for (int i = 0; i < ntr; i++) for (int j = 0; j < nes; j++) if (fabsf(raw[i * 160 + j]) > eye_max) eye_max = fabsf(raw[i * 160 + j]);
+    for (int i = 0; i < ntr; i++) for (int j = 0; j < nes; j++) eye[i * nes + j] = raw[i * 160 + j] / eye_max;
+    if (neyetr) *neyetr = ntr;
+    if (neyesamp) *neyesamp = nes;
+    return ntr * nes;
 }
 
 int sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches) {

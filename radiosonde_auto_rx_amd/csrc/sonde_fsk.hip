@@ -222,6 +222,20 @@ void k_fsk_demod(const FskArgs a) {
             s_ebv[i] = tmax[1] > tmax[0] ? tmax[1] : tmax[0];
             sd[i] = sqrtf(tmax[0]) - sqrtf(tmax[1]);
         }
+        // eye diagram samples (fsk.c:857-889): 4 traces of two symbols per tone, |f_int[m][2 P i + high + 1 + j dec]|; the
+        // reference overwrites them every frame, normalisation happens when the stats are read
+        if (a.eye) {
+            const int dec = (int)ceilf(((float)P * 2) / 160.0f), nes = (P * 2) / dec;
+            float *eye = a.eye + (size_t)ch * 8 * 160;
+            for (int q = tid; q < 8 * nes; q += FSK_THREADS) {
+                const int row = q / nes, j = q - row * nes, i = row >> 1, m = row & 1;
+                const int ind = 2 * P * i + high + 1 + j * dec;
+                // high + 1 can be -1 (rx_timing in [-P/2, -2]): the reference then reads f_int[m][-1], i.e. the last integrator of
+                // the other tone for m = 1 and memory in front of the array for m = 0 (undefined there; 0 here)
+                const float2 v = (ind < W && m * W + ind >= 0) ? s_fint[m * W + ind] : make_float2(0.f, 0.f);
+                eye[row * 160 + j] = sqrtf((v.x * v.x) + (v.y * v.y));
+            }
+        }
         __syncthreads();
         // EbNo estimate (fsk.c:807-836): serial sums in symbol order
         if (wave == 0 && lane < 2) {

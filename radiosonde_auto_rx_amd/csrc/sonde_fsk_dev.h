@@ -39,6 +39,7 @@ struct FskArgs {
     float *sd; int sd_cap;            // [n_ch][sd_cap] soft decisions of this launch
     FskFrameRec *recs; int rec_cap;   // [n_ch][rec_cap]
     int max_fft;                      // most FFT blocks a frame can have
+    float *eye;                       // [n_ch][8][160] |f_int| samples of the last frame for the eye diagram (fsk.c:857-889), may be nullptr
 };
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s);

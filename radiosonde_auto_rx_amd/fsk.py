@@ -44,6 +44,7 @@ def _lib():
         L.sonde_fsk_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_int32, C.POINTER(C.c_int32)]
         L.sonde_fsk_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_void_p, C.POINTER(C.c_int64)]
         L.sonde_fsk_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.sonde_fsk_eye.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         _proto = True
     return L
 
@@ -104,6 +105,13 @@ class FskModem:
         _chk(_lib().sonde_fsk_stats(self._h, ch, C.byref(last), Sf.ctypes.data_as(C.c_void_p), C.byref(n)))
         return dict(f_est=(last.f_est[0], last.f_est[1]), ppm=last.ppm, EbNodB=last.EbNodB, snr_est=last.snr_est,
                     norm_rx_timing=last.norm_rx_timing, nin=last.nin_next, Sf=Sf, samples=n.value)
+
+    def eye(self, ch: int = 0) -> np.ndarray:
+        """Eye diagram of the last modem frame: [8 traces, 2P/ceil(2P/160) samples], normalised (MODEM_STATS.rx_eye)."""
+        buf = np.zeros(8 * 160, np.float32)
+        ntr, nes = C.c_int32(0), C.c_int32(0)
+        n = _chk(_lib().sonde_fsk_eye(self._h, ch, buf.ctypes.data_as(C.c_void_p), C.byref(ntr), C.byref(nes)))
+        return buf[:n].reshape(ntr.value, nes.value)
 
     def kernel_ms(self):
         ms, n = C.c_double(0), C.c_int64(0)

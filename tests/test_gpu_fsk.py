@@ -130,3 +130,49 @@ def test_cli_fsk_demod_matches_reference_and_decodes():
     r = subprocess.run([os.path.join(ROOT, "host", "bin", "fsk_demod")] + make_golden.fsk_cli_args(case, soft=False), input=x.tobytes(),
                        capture_output=True, timeout=120)
     assert np.array_equal(np.frombuffer(r.stdout, np.uint8).reshape(-1, case["nsym"]), (g["sd"] < 0).astype(np.uint8))
+
+
+def _parse_stats(text):
+    """stats lines of fsk_demod --stats -> list of dicts; the eye may hold nan (not JSON): parsed leniently."""
+    import json
+    import re
+    out = []
+    for l in text.splitlines():
+        if not l.startswith("{"):
+            continue
+        out.append(json.loads(re.sub(r"-?nan", "NaN", l)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["fsk_rs41_48k_mask", "fsk_rs41_48k_peak", "fsk_dfm_50k", "fsk_m10_48080", "fsk_rs41_48k_cu8", "fsk_rs41_48k_real"])
+def test_cli_stats_lines_match_reference(name):
+    """`fsk_demod --stats=5`: every stats line of the reference (fsk_demod.c:365-411) — sample count, EbNodB, ppm, tone
+    estimates, eye diagram (8 traces x 2P samples, %f) and the smoothed spectrum — at the same frames.  Tolerances: integers and
+    the %.1f fields exact; eye / spectrum within 2e-6 + 1e-5 relative (printed with 6 decimals).  Lines where the reference read
+    in front of its integrator array (high_sample + 1 < 0, fsk.c:869,884: garbage in trace 0, which then also scales the whole
+    normalised eye) are compared without the eye."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    case = make_golden.FSK_CASES[name]
+    x = make_golden.fsk_capture(case)
+    ref = str(np.load(os.path.join(ROOT, "tests", "golden", name + "_stats.npz"))["stderr"])
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", "fsk_demod")] + ["--stats=5"] + make_golden.fsk_cli_args(case),
+                       input=x.tobytes(), capture_output=True, timeout=120)
+    assert r.returncode == 0
+    got, want = _parse_stats(r.stderr.decode()), _parse_stats(ref)
+    assert len(got) == len(want) and len(want) >= 3
+    n_eye = 0
+    for a, b in zip(got, want):
+        assert a["samples"] == b["samples"] and a["ppm"] == b["ppm"]
+        assert a["EbNodB"] == b["EbNodB"] and a["f1_est"] == b["f1_est"] and a["f2_est"] == b["f2_est"]
+        fa, fb = np.array(a["samp_fft"]), np.array(b["samp_fft"])
+        assert fa.shape == fb.shape and np.all(np.abs(fa - fb) <= 2e-6 + 1e-5 * np.abs(fb))
+        ea, eb = np.array(a["eye_diagram"], float), np.array(b["eye_diagram"], float)
+        assert ea.shape == eb.shape == (8, 2 * case["P"])
+        oob = np.isnan(eb).any() or np.abs(eb[2:]).max() < 1e-3 or not np.isclose(np.nanmax(eb), 1.0)
+        if not oob:
+            assert np.all(np.abs(ea - eb) <= 2e-6 + 1e-5 * np.abs(eb)), (np.abs(ea - eb).max())
+            n_eye += 1
+    assert n_eye >= len(want) // 2

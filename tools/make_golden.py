@@ -470,6 +470,9 @@ def main():
             for key, args in (("dfm_lines", ["--softin", "-i", "-r", "--ecc"]), ("dfm_lines_noinv", ["--softin", "-r", "--ecc"])):
                 dec = subprocess.run([os.path.join(bind.REFDIR, "dfm09mod")] + args, input=cli.stdout, capture_output=True)
                 d[key] = np.array(dec.stdout.decode().splitlines())
+        # stats lines of the reference CLI (--stats=5: JSON on stderr incl. the eye diagram, fsk_demod.c:365-411)
+        st = subprocess.run([os.path.join(bind.REFDIR, "fsk_demod"), "--stats=5"] + fsk_cli_args(case), input=x.tobytes(), capture_output=True)
+        np.savez_compressed(os.path.join(outdir, name + "_stats.npz"), stderr=np.array(st.stderr.decode()))
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **d)
         print(name, "frames", r["n"], "nin set", sorted(set(r["nin"].tolist())), "f_est", r["f_est"][-1], d.get("rs41_lines", np.array([])).shape)
 
