@@ -91,7 +91,7 @@ int main(int argc, char **argv) {
         sonde_softin_destroy(si);
         return 0;
     }
-    if (opt_inv || opt_auto) { fprintf(stderr, "rs41mod (sonde_hip): -i / --auto are implemented for --softin only\n"); return -1; }
+    cfg.opt_inv = opt_inv; cfg.opt_auto = opt_auto;
     if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
     if (have_iq && !have_pcm) {                      /* IQ in a 2-channel WAV: header, then the same sample pairs */
         if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }

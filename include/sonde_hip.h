@@ -86,6 +86,9 @@ typedef struct {
                               * iq_dec.c:632-651); 0 elsewhere (48000, or 32000 with opt_min)                     */
     int32_t opt_iqdc;        /* --iqdc: running-mean IQ-DC removal for SONDE_IN_IFIQ* (f32read_csample, demod_mod.c:444-458);
                               * SONDE_IN_IQ always removes it (f32read_cblock :492)                              */
+    int32_t opt_inv;         /* -i: inverted polarity expected — headers with a negative score are taken, bits flipped
+                              * (rs41mod.c:2887-2891,2933-2937; dfm09mod.c:1642-1645,1702-1705)                  */
+    int32_t opt_auto;        /* --auto: a header of the opposite polarity flips the channel's polarity instead of being skipped */
 } sonde_cfg_t;
 
 /* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */

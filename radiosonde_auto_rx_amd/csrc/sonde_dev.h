@@ -60,7 +60,8 @@ struct AudioChainArgs {       // FM-audio input: raw ring -> (FM low-pass) -> fm
 
 struct SyncState {
     uint32_t s_in, k, mv_pos, mode;
-    float mv; uint32_t pad[3];
+    float mv; uint32_t inv;   // inv: current polarity of the channel (-i, flipped by --auto)
+    uint32_t pad[2];
 };
 
 struct CorrArgs {
@@ -92,6 +93,7 @@ struct SyncArgs {
     float sps, thres, l_win;
     int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
+    int opt_auto;             // --auto: opposite-polarity header flips SyncState.inv instead of being skipped
     // --dc (demod_mod.c:174-188,227-298,1555-1600): zero-mean windows, FM-stream fallback correlation, header dc, AFC events
     int opt_dc, opt_iq, lpiq_on, lpfm_taps, N, sr;
     float match_sum;

@@ -337,6 +337,10 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
     e->ifiq = ifiq;
+    if (cfg->opt_inv) {                                       // -i: every channel starts with inverted polarity
+        std::vector<SyncState> st0(C); for (auto &q : st0) { memset(&q, 0, sizeof q); q.inv = 1; }
+        HIPCHK(hipMemcpy(e->d_state, st0.data(), st0.size() * sizeof(SyncState), hipMemcpyHostToDevice));
+    }
     e->opt_iq = audio ? 0 : ifiq ? (cfg->input == SONDE_IN_IFIQ0 ? 1 : cfg->input == SONDE_IN_IFIQ2 ? 2 : 3) : 5;
     { double sm = 0.0; for (float v : e->match) sm += (double)v; e->match_sum = (float)sm; }
     if (cfg->opt_dc) {
@@ -524,6 +528,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
     s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
+    s.opt_auto = e->cfg.opt_auto != 0;
     s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);

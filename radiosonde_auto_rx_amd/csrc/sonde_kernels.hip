@@ -994,7 +994,10 @@ void k_framesync(const SyncArgs a) {
             for (int w = 0; w < FS_WAVES; w++) errs += s_ri[w];
             __syncthreads();
             if (errs > a.hdmax) continue;
-            if (mv < 0.f) continue;                     // rs41mod.c:2888-2891 without -i / --auto
+            if (mv * (0.5f - (float)st.inv) < 0.f) {    // polarity mismatch (rs41mod.c:2887-2891): skipped, or flips the channel with --auto
+                if (!a.opt_auto) continue;
+                st.inv ^= 1u;
+            }
             st.mode = 1;
         } else {
             // ---- frame: nbits soft bits from sample mv_pos+1+ofs on (read_softbit2p, demod_mod.c:1087-1175)
@@ -1027,7 +1030,8 @@ void k_framesync(const SyncArgs a) {
                         }
                     }
                 }
-                const int hb = valid && (sum >= 0.0);
+                if (st.inv) sum = -sum;                                // -i / --auto: bit ^= 1, sb = -sb (rs41mod.c:2933-2937)
+                const int hb = valid && (st.inv ? !(-sum >= 0.0) : (sum >= 0.0));
                 const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
                 if (a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
                 const int it = (p0 >> 6) + wave;                       // 64-bit group index = 8 frame bytes

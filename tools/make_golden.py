@@ -161,6 +161,37 @@ def dc_softpar(case, fq):
     return par
 
 
+# polarity: -i / --auto on captures whose spectrum is mirrored (Q negated, fq -> -fq) or whose FM audio is negated
+INV_CASES = {
+    "inv_rs41_2400k_i": dict(gen="rs41", flags=["-i"], inverted=True, cap=dict(sr=2_400_000, seconds=2.2, fq=0.1, n_frames=2, t_first=0.1, noise_sigma=0.02, seed=81)),
+    "inv_rs41_2400k_auto": dict(gen="rs41", flags=["--auto"], inverted=True, cap=dict(sr=2_400_000, seconds=3.2, fq=-0.15, n_frames=3, t_first=0.1, noise_sigma=0.02, seed=82)),
+    "inv_rs41_2400k_i_on_normal": dict(gen="rs41", flags=["-i"], inverted=False, cap=dict(sr=2_400_000, seconds=2.2, fq=0.1, n_frames=2, t_first=0.1, noise_sigma=0.02, seed=83)),
+    "inv_rs41_2400k_none_on_inverted": dict(gen="rs41", flags=[], inverted=True, cap=dict(sr=2_400_000, seconds=2.2, fq=0.1, n_frames=2, t_first=0.1, noise_sigma=0.02, seed=84)),
+    "inv_dfm_2400k_auto": dict(gen="dfm", flags=["--auto"], inverted=True, cap=dict(sr=2_400_000, seconds=2.2, fq=0.08, noise_sigma=0.02, seed=85)),
+    "inv_dfm_2400k_i": dict(gen="dfm", flags=["-i"], inverted=True, cap=dict(sr=2_400_000, seconds=2.2, fq=-0.05, noise_sigma=0.02, seed=86)),
+    "inv_rs41_audio_auto": dict(gen="rs41", flags=["--auto"], inverted=True, audio=True, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=87)),
+}
+
+
+def inv_capture(case):
+    """-> (int16 samples, stdin bytes, binary, argv, fq given to the decoder)"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    fq = synth.snap_fq(cap["fq"], sr)
+    cap["fq"] = fq
+    x = synth.rs41_capture(**cap) if case["gen"] == "rs41" else synth.dfm_capture(**cap)
+    binary = "rs41mod" if case["gen"] == "rs41" else "dfm09mod"
+    args = ["-r"] + (["--ecc2", "--crc"] if case["gen"] == "rs41" else ["--ecc"]) + case["flags"]
+    if case.get("audio"):
+        pcm = synth.fm_audio(x)
+        if case["inverted"]:
+            pcm = np.clip(-pcm.astype(np.int32), -32768, 32767).astype(np.int16)
+        return pcm, synth.wav_bytes(pcm, sr), binary, args, 0.0
+    if case["inverted"]:
+        x = x.copy(); x[1::2] = np.clip(-x[1::2].astype(np.int32), -32768, 32767).astype(np.int16)
+        fq = -fq
+    return x, x.tobytes(), binary, args + ["--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], fq
+
+
 # 8-bit unsigned input through each CLI (`- sr 8`, 8-bit WAV): stdout / stderr / exit code of the compiled reference
 U8_CASES = {
     "u8_rs41mod_2400k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=2_400_000, seconds=1.3, fq=0.1, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=31),
@@ -404,6 +435,11 @@ def main():
         print(name, "rc", rc, "lines", len(d["lines"]), "hits", strict["n"], strict["mv"], strict["mv_pos"], "floor_soft", d["floor_soft"], repr(err))
     for name, case in DC_CASES.items():
         gen_dc_case(name, case, outdir)
+    for name, case in INV_CASES.items():
+        _, stdin, binary, args, _ = inv_capture(case)
+        out, err, rc = bind.ref_run(binary, args, stdin)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), lines=np.array(out.splitlines()), stderr=np.array(err), rc=rc)
+        print(name, "rc", rc, "lines", len(out.splitlines()))
     for name, case in U8_CASES.items():
         stdin, args = u8_capture(case)
         r = subprocess.run([os.path.join(bind.REFDIR, case["binary"])] + args, input=stdin, capture_output=True)
