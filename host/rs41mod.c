@@ -20,7 +20,7 @@
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0;
     FILE *fp = stdin;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--ch2")) wav_ch = 1;
         else if (!strcmp(a, "--softin")) softin = 1;
         else if (!strcmp(a, "--softinv")) softin = 2;
+        else if (!strcmp(a, "--bin")) opt_bin = 1;                       /* one byte per hard bit */
         else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) opt_inv = 1;
         else if (!strcmp(a, "--auto")) opt_auto = 1;
         else if (a[0] != '-') {                      /* WAV file instead of stdin (rs41mod.c wavloaded) */
@@ -74,14 +75,19 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "rs41mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (softin) {                                    /* float32 soft bits on stdin (rs41mod.c:2655-2656,2878-2917) */
+    if (softin || opt_bin) {                                    /* float32 soft bits on stdin (rs41mod.c:2655-2656,2878-2917) */
         if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
         sonde_softin_t *si = NULL;
         if (sonde_softin_create(SONDE_RS41, cfg.ecc_level, softin == 2, opt_inv, opt_auto, &si) < 0) return -1;
         float sb[1024]; sonde_frame_t fr[4]; char ln[1200]; size_t got;
         for (;;) {
-            got = fread(sb, 4, 1024, fp);
-            if (got) sonde_softin_push(si, sb, (int32_t)got);
+            if (opt_bin && !softin) {                    /* --bin: one byte per bit (--softin wins if both are given) */
+                got = fread(sb, 1, 1024, fp);
+                if (got) sonde_softin_push_bits(si, (const uint8_t *)sb, (int32_t)got);
+            } else {
+                got = fread(sb, 4, 1024, fp);
+                if (got) sonde_softin_push(si, sb, (int32_t)got);
+            }
             if (got < 1024) sonde_softin_finish(si);
             int k;
             while ((k = sonde_softin_fetch(si, fr, 4)) > 0)

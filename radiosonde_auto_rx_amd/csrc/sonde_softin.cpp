@@ -24,6 +24,7 @@ struct sonde_softin {
     int opt_inv = 0, opt_auto = 0;            // gpx.option.inv / .aut (rs41mod.c:2888-2891)
     float ths = 0.7f;
     float sbuf[64]; int bufpos = -1;
+    char hbuf[64];                            // --bin: last header-length hard bits as '0'/'1' (hdb.buf, demod_mod.c:1668-1690)
     int state = 0;                            // 0 searching, 1 in frame
     int byte_count = 8, b8pos = 0; uint8_t bitbuf[8];
     uint8_t frame[518];                       // gpx.frame persists across frames like the reference's
@@ -52,7 +53,7 @@ int sonde_softin_create(int32_t sonde_type, int32_t ecc_level, int32_t invert_st
     s->type = sonde_type;
     memset(s->dsb, 0, sizeof s->dsb); memset(s->dhb, 0, sizeof s->dhb); memset(s->dsf, 0, sizeof s->dsf);
     s->ecc_level = ecc_level; s->inv_in = invert_stream ? 1 : 0; s->opt_inv = opt_inv ? 1 : 0; s->opt_auto = opt_auto ? 1 : 0;
-    memset(s->sbuf, 0, sizeof s->sbuf); memset(s->frame, 0, sizeof s->frame);
+    memset(s->sbuf, 0, sizeof s->sbuf); memset(s->frame, 0, sizeof s->frame); memset(s->hbuf, 0, sizeof s->hbuf);
     memcpy(s->frame, kRs41HeaderBytes, 8);
     *out = s;
     return 0;
@@ -142,6 +143,73 @@ int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
             if (s->b8pos == 8) {
                 uint8_t byte = 0;
                 for (int k = 0; k < 8; k++) byte |= (uint8_t)(s->bitbuf[k] << k);          // bits2byte, LSB first (rs41mod.c:224)
+                s->frame[s->byte_count] = byte ^ kRs41Mask[s->byte_count % 64];
+                s->b8pos = 0;
+                s->byte_count++;
+                if (s->byte_count == 518) { emit(s, 518); s->state = 0; }
+            }
+        }
+    }
+    return 0;
+}
+
+// cmp_hdb (demod_mod.c:1639-1666): header bit errors of the circular buffer in both polarities, as a +-score
+static float hdr_bit_score(const char *buf, int bufpos, const char *hdr, int len) {
+    int e1 = 0, e2 = 0;
+    for (int i = 0, j = bufpos; i < len; i++, j--) {
+        if (j < 0) j = len - 1;
+        if (buf[j] != hdr[len - 1 - i]) e1++;
+        if ((buf[j] ^ 0x01) != hdr[len - 1 - i]) e2++;
+    }
+    return e2 < e1 ? (float)(-len + e2) / (float)len : (float)(len - e1) / (float)len;
+}
+
+// --bin: one byte per hard bit (`fsk_demod` without -s), find_binhead + the bit loops (rs41mod.c:2875,2899-2906; dfm09mod.c:1665-1676)
+int sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n) {
+    if (!s || (!bits && n > 0) || n < 0) return SONDE_E_ARG;
+    const bool dfm = s->type == SONDE_DFM09;
+    const int hl = dfm ? 32 : 64;
+    const char *hdr = dfm ? kDfmRawHeader : kRs41Header;
+    const float thb = (float)(1.0 - (dfm ? 2.1 : 3.1) / (float)hl);
+    for (int32_t i = 0; i < n; i++) {
+        const int b = bits[i] & 1;
+        s->bits_in++;
+        if (s->state == 0) {
+            s->bufpos = (s->bufpos + 1) % hl;
+            s->hbuf[s->bufpos] = (char)(0x30 | b);
+            const float mv = hdr_bit_score(s->hbuf, s->bufpos, hdr, hl);
+            if (std::fabs(mv) > thb) {
+                int found = 1;
+                if (mv * (0.5 - s->opt_inv) < 0) { if (!s->opt_auto) found = 0; else s->opt_inv ^= 1; }
+                if (found) {
+                    s->state = 1; s->mv = mv; s->hdr_bit = s->bits_in;
+                    s->byte_count = 8; s->b8pos = 0;
+                    s->dpos = 16; s->dfrm = 0; s->dhalf = 0;
+                }
+            }
+        } else if (dfm) {
+            if (!s->dhalf) { s->dhalf = 1; continue; }              // first Manchester symbol is read and dropped
+            s->dhalf = 0;
+            int hb = b; float v = (float)(2 * hb - 1);
+            if (s->opt_inv) { hb ^= 1; v = -v; }
+            s->dhb[s->dpos] = (uint8_t)hb; s->dsf[s->dpos] = v;
+            if (++s->dpos == 280) {
+                sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
+                o.channel = 0; o.frame_in_hit = s->dfrm; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+                o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
+                o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
+                o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);
+                s->dqueue.push_back(o);
+                s->dpos = 0;
+                if (++s->dfrm == 8) s->state = 0;
+            }
+        } else {
+            int bit = b;
+            if (s->opt_inv) bit ^= 1;
+            s->bitbuf[s->b8pos++] = (uint8_t)bit;
+            if (s->b8pos == 8) {
+                uint8_t byte = 0;
+                for (int k = 0; k < 8; k++) byte |= (uint8_t)(s->bitbuf[k] << k);
                 s->frame[s->byte_count] = byte ^ kRs41Mask[s->byte_count % 64];
                 s->b8pos = 0;
                 s->byte_count++;

@@ -55,3 +55,24 @@ def test_dfm_softin_cli_matches_reference_lines():
         r = subprocess.run([os.path.join(ROOT, "host", "bin", "dfm09mod")] + args, input=sd, capture_output=True, timeout=60)
         assert r.returncode == 0, r.stderr
         assert [l.rstrip() for l in r.stdout.decode().splitlines()] == [str(l).rstrip() for l in g[key]] and len(g[key]) > 0
+
+
+def test_bin_cli_matches_reference_lines():
+    """`rs41mod|dfm09mod --bin [-i|--auto] -r`: one byte per hard bit (fsk_demod without -s), header found by bit errors in either
+    polarity (find_binhead / cmp_hdb, demod_mod.c:1639-1690).  Golden = the reference decoders on the same bytes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    from radiosonde_auto_rx_amd import engine
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "bin_lines.npz"))
+    some = 0
+    for name, binary, extra, flags in make_golden.BIN_RUNS:
+        bits = (load_fsk(name)["sd"].ravel() < 0).astype(np.uint8).tobytes()
+        r = subprocess.run([os.path.join(ROOT, "host", "bin", binary), "--bin", "-r"] + extra + flags, input=bits, capture_output=True, timeout=60)
+        want = [str(l).rstrip() for l in gold["|".join([name, binary] + flags)]]
+        assert r.returncode == 0 and [l.rstrip() for l in r.stdout.decode().splitlines()] == want, (name, flags)
+        some += len(want)
+    assert some > 10

@@ -380,6 +380,23 @@ def gen_dc_case(name, case, outdir):
           "fast hits", fast["n"], fast["mv_pos"], "floor_soft", d["floor_soft"])
 
 
+BIN_RUNS = [(name, binary, extra, flags) for name, binary, extra in (("fsk_rs41_48k_mask", "rs41mod", ["--ecc2"]), ("fsk_rs41_48k_peak", "rs41mod", ["--ecc2"]),
+                                                                     ("fsk_dfm_50k", "dfm09mod", ["--ecc"]))
+            for flags in ([], ["-i"], ["--auto"])]
+
+
+def gen_bin_lines(outdir):
+    """--bin (one byte per hard bit = fsk_demod without -s): the reference decoders' lines on the hard decisions of the modem fixtures"""
+    d = {}
+    for name, binary, extra, flags in BIN_RUNS:
+        sd = np.load(os.path.join(outdir, name + ".npz"))["sd"]
+        bits = (sd.ravel() < 0).astype(np.uint8).tobytes()
+        out, err, rc = bind.ref_run(binary, ["--bin", "-r"] + extra + flags, bits)
+        d["|".join([name, binary] + flags)] = np.array(out.splitlines())
+    np.savez_compressed(os.path.join(outdir, "bin_lines.npz"), **d)
+    print("bin_lines", {k: len(v) for k, v in d.items()})
+
+
 def main():
     outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -435,6 +452,7 @@ def main():
         print(name, "rc", rc, "lines", len(d["lines"]), "hits", strict["n"], strict["mv"], strict["mv_pos"], "floor_soft", d["floor_soft"], repr(err))
     for name, case in DC_CASES.items():
         gen_dc_case(name, case, outdir)
+    gen_bin_lines(outdir)
     for name, case in INV_CASES.items():
         _, stdin, binary, args, _ = inv_capture(case)
         out, err, rc = bind.ref_run(binary, args, stdin)
