@@ -191,7 +191,7 @@ def rs41_capture(sr: int = 2_400_000, seconds: float = 2.2, fq: float = 0.1, *, 
                  first_frame_no: int = 1234, sonde_id: str = "S1234567", t_first: float = 0.15,
                  amp: float = 0.5, noise_sigma: float = 0.01, dc: complex = 0.0, seed: int = 1,
                  bit_errors: int = 0, dev_hz: float = 2400.0, f_offset_hz: float = 0.0,
-                 return_frames: bool = False):
+                 return_frames: bool = False, frame_kw: dict | None = None):
     """Interleaved int16 IQ capture: one RS41 frame per second at carrier fq*sr (+f_offset_hz).
 
     bit_errors: number of random on-air bit flips per frame (inside the 320 data bytes) to
@@ -206,7 +206,7 @@ def rs41_capture(sr: int = 2_400_000, seconds: float = 2.2, fq: float = 0.1, *, 
         t0 = t_first + k * 1.0
         if n_frames is not None and k >= n_frames:
             break
-        frm = rs41_frame(first_frame_no + k, sonde_id, rng=np.random.default_rng(seed * 1000 + k))
+        frm = rs41_frame(first_frame_no + k, sonde_id, rng=np.random.default_rng(seed * 1000 + k), **(frame_kw or {}))
         bits = rs41_onair_bits(frm)
         if bit_errors:
             pos = rng.choice(np.arange(40 * 8 + 64, len(bits)), size=bit_errors, replace=False)

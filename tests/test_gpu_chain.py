@@ -1,0 +1,82 @@
+"""End-to-end drop-in check of the production auto_rx chains (auto_rx/autorx/decode.py:895-909,1060-1085;
+sdr_wrappers.py:315-323):
+
+    <48 kHz cs16 IQ> | iq_dec --bo 16 - 48000 16 | fsk_demod --cs16 -b lo -u hi -s --mask 5000 --nsym=300 -p 5 --stats=5 2 48000 4800 - -
+                     | rs41mod --ptu2 --json --jsnsubfrm1 --softin -i
+
+with the sample-rate stages (iq_dec, fsk_demod) taken from this repo (GPU) and the bit-level decoder + JSON from the compiled
+reference, against the same pipe built entirely from the reference's binaries.  The decoded telemetry (text + JSON lines on
+stdout) must be identical: the stages this repo replaces are interchangeable in front of the reference's own decoders.
+oracle/_ref (compiled reference, test infrastructure) travels with the snapshot; skipped when it is absent."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+BIN = os.path.join(ROOT, "host", "bin")
+
+
+# a position the reference accepts (its altitude plausibility window is -1 .. 80 km, rs41mod.c:1069): 48.1 N 11.6 E, 12.3 km
+ECEF_OK = dict(ecef_cm=(418833319, 85974133, 473346430))
+
+
+def _pipe(stages, data):
+    for argv in stages:
+        r = subprocess.run(argv, input=data, capture_output=True, timeout=180)
+        assert r.returncode == 0, (argv[0], r.stderr[-300:])
+        data = r.stdout
+    return data
+
+
+def _chains(front, decoder):
+    """the same pipe with the front stages from `ours` / from the reference, decoder always the reference's"""
+    out = []
+    for d in (BIN, REF):
+        out.append([[os.path.join(d, a[0])] + a[1:] for a in front] + [[os.path.join(REF, decoder[0])] + decoder[1:]])
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "rs41mod")), reason="compiled reference not present")
+def test_rs41_production_chain_json_identical():
+    from radiosonde_auto_rx_amd import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    x = synth.rs41_capture(sr=48_000, seconds=6.3, fq=0.0, n_frames=6, t_first=0.2, noise_sigma=0.03, seed=101, f_offset_hz=1200.0, dc=0.02 - 0.03j, frame_kw=ECEF_OK)
+    front = [["iq_dec", "--bo", "16", "-", "48000", "16"],
+             ["fsk_demod", "--cs16", "-b", "-20000", "-u", "20000", "-s", "--mask", "5000", "--nsym=300", "-p", "5", "--stats=5", "2", "48000", "4800", "-", "-"]]
+    ours, ref = _chains(front, ["rs41mod", "--ptu2", "--json", "--jsnsubfrm1", "--softin", "-i"])
+    a, b = _pipe(ours, x.tobytes()), _pipe(ref, x.tobytes())
+    assert a == b
+    lines = a.decode().splitlines()
+    js = [l for l in lines if l.startswith("{")]
+    assert len(js) >= 4 and all('"type": "RS41"' in l and '"lat"' in l for l in js)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "dfm09mod")), reason="compiled reference not present")
+def test_dfm_production_chain_identical():
+    from radiosonde_auto_rx_amd import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    x = synth.dfm_capture(sr=50_000, seconds=4.0, fq=0.01, noise_sigma=0.03, seed=102)
+    front = [["iq_dec", "--bo", "16", "-", "50000", "16"],
+             ["fsk_demod", "--cs16", "-b", "-15000", "-u", "15000", "-s", "-p", "10", "--stats=5", "2", "50000", "2500", "-", "-"]]
+    ours, ref = _chains(front, ["dfm09mod", "-r", "--ecc", "--auto", "--softin", "-i"])      # synthetic DFM payload is random: raw lines
+    a, b = _pipe(ours, x.tobytes()), _pipe(ref, x.tobytes())
+    assert a == b and len(a.splitlines()) >= 8
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "rs41mod")), reason="compiled reference not present")
+def test_rs41_fm_chain_identical():
+    """FM chain (decode.py:417 form): baseband IQ -> iq_dec --FM --wav (this repo) -> reference rs41mod --ptu2 --json on the WAV."""
+    from radiosonde_auto_rx_amd import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sr = 2_400_000
+    fq = synth.snap_fq(0.0, sr)
+    x = synth.rs41_capture(sr=sr, seconds=4.3, fq=fq, n_frames=4, t_first=0.15, noise_sigma=0.02, seed=103, frame_kw=ECEF_OK)
+    front = [["iq_dec", "--FM", "--IFbw", "48", "--lpFM", "--wav", "--iq", "0.0", "-", str(sr), "16"]]
+    ours, ref = _chains(front, ["rs41mod", "--ptu2", "--json", "--jsnsubfrm1"])
+    a, b = _pipe(ours, x.tobytes()), _pipe(ref, x.tobytes())
+    assert a == b
+    assert sum(l.startswith("{") for l in a.decode().splitlines()) >= 3
