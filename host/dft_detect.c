@@ -9,7 +9,7 @@
  * stdout: one line per detection `TYPE: %.4f[ , %+.1fHz]` (-v: `sample: n` before it, `[hhhh]` for M10/M20);
  * stderr: `IF:`/`dec:` (--IQ) or the WAV header summary; exit code = header_found * type number (negative for
  * inverted DFM/RS41/RS92), -50 on errors — all modulo 256 as seen by the shell.
- * 8-bit unsigned and 16-bit signed input; float input exits with an error instead of decoding differently.
+ * 8-bit unsigned, 16-bit signed and 32-bit float input.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -115,7 +115,6 @@ int main(int argc, char **argv) {
         if (read_wav_header(fp, &cfg.sample_rate, &cfg.bits, &channels) < 0) { fclose(fp); fprintf(stderr, "error: wav header\n"); return -50; }
     }
     if (cfg.iq_mode != SONDE_SCAN_AUDIO && channels < 2) { fprintf(stderr, "error: iq channels < 2\n"); return -50; }
-    if (cfg.bits != 16 && cfg.bits != 8) { fprintf(stderr, "dft_detect (sonde_hip): 8 / 16-bit input only\n"); return -50; }
     if (channels < 1) channels = 1;
     cfg.audio_channels = channels;
     cfg.audio_select = (wav_channel >= 0 && wav_channel < channels) ? wav_channel : 0;

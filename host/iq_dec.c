@@ -70,7 +70,7 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "iq_dec (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (!have_pcm || (cfg.bits != 16 && cfg.bits != 8)) { fprintf(stderr, "iq_dec (sonde_hip): raw 8 / 16-bit IQ input (- <sr> <8|16>) only\n"); return -1; }
+    if (!have_pcm) { fprintf(stderr, "iq_dec (sonde_hip): raw IQ input (- <sr> <8|16|32>) only\n"); return -1; }
     const size_t unit = 2 * (size_t)(cfg.bits / 8);
     cfg.n_channels = 1; cfg.if_rate = if_min;
     cfg.max_chunk = cfg.sample_rate / 4 + 4096;
@@ -86,7 +86,7 @@ int main(int argc, char **argv) {
     if (opt_wav) write_wav_header(opt_fm ? info.if_sr / decFM : info.if_sr, bps_out, opt_fm ? 1 : 2);
 
     int chunk = cfg.sample_rate / 4; chunk -= chunk % (info.decM * decFM); if (chunk < info.decM * decFM) chunk = info.decM * decFM;
-    int16_t *buf = (int16_t *)malloc((size_t)chunk * 4);
+    int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
     float *out = (float *)malloc((size_t)(chunk / info.decM + 8) * 8);
     int64_t m_done = 0;                                   /* IF samples written so far */
     const int tap = opt_fm ? SONDE_TAP_FM : ((cfg.opt_lp & SONDE_LP_IQ) ? SONDE_TAP_IFIQ : SONDE_TAP_DECIM);

@@ -107,7 +107,6 @@ int main(int argc, char **argv) {
     if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
     if (!have_iq) {                                  /* FM audio: WAV on stdin or from a file (opt_iq = 0) */
         if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-        if (cfg.bits != 16 && cfg.bits != 8) { fprintf(stderr, "rs41mod (sonde_hip): 8 / 16-bit input only\n"); return -1; }
         cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
         cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
     }
@@ -125,7 +124,6 @@ int main(int argc, char **argv) {
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
     }
-    if (cfg.bits != 16 && cfg.bits != 8) { fprintf(stderr, "%s (sonde_hip): 8 / 16-bit input only\n", argv[0]); return -1; }
     const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);  /* bytes per input sample / audio frame */
 
     int chunk = cfg.sample_rate / 10;

@@ -65,7 +65,7 @@ typedef struct {
     int32_t device;          /* HIP device ordinal                                            */
     int32_t n_channels;      /* independent channels (one reference process each)             */
     int32_t sample_rate;     /* input rate of every channel ("- <sr> <bs>" argv)              */
-    int32_t bits;            /* 16 (cs16 / s16) or 8 (unsigned: rtl_sdr cu8, 8-bit WAV); 32 (float) not yet */
+    int32_t bits;            /* 16 (cs16 / s16), 8 (unsigned: rtl_sdr cu8, 8-bit WAV) or 32 (float32: cf32 / float WAV) */
     int32_t sonde_type;      /* SONDE_RS41                                                    */
     int32_t opt_lp;          /* SONDE_LP_IQ (--lpIQ) | SONDE_LP_FM (--lpFM)                    */
     int32_t opt_dc;          /* --dc (AFC); not yet supported -> SONDE_E_ARG                   */

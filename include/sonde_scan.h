@@ -30,7 +30,7 @@ typedef struct {
     int32_t device;
     int32_t n_channels;
     int32_t sample_rate;     /* input rate ("- <sr> <bits>" or the WAV header)                      */
-    int32_t bits;            /* 16, or 8 (unsigned)                                                 */
+    int32_t bits;            /* 16, 8 (unsigned) or 32 (float32)                                    */
     int32_t iq_mode;         /* SONDE_SCAN_AUDIO / _IFIQ / _BBIQ                                    */
     int32_t opt_dc;          /* --dc  (dft_detect.c:1397)                                           */
     int32_t opt_min;         /* --min (IF 32 kHz, :1398)                                            */

@@ -35,6 +35,22 @@ struct AfcState {
     uint32_t pad;
 };
 
+// float32 input (`- <sr> 32`, cf32): no tuned path — two plain kernels.  k_mix_f32 writes z = (x - avg) * ex[n] into a ring of
+// mixed base-rate samples (the decimator's delay line decXbuffer, demod_mod.c:737-750) and accumulates the IQ-DC sums in double
+// like the reference; k_decimate_f32 runs the FIR over that ring, one output per thread, taps in time order.
+struct MixF32Args {
+    const float2 *x; long long ch_stride; int n_ch, n;         // n complex samples per channel in this launch
+    const double *chan_f0; int lut_len; uint32_t lut_phase; int phase_f64;
+    const float2 *dc_avg; double *dc_sums;                      // [n_ch][2]
+    float2 *z; uint32_t zmask; uint64_t n0;                     // ring [n_ch][zmask+1], absolute base-rate index of the first sample
+    int mix;                                                    // 0: no mixer (IF-rate input, --iq0/2/3): z = x - avg
+};
+struct DecF32Args {
+    const float2 *z; uint32_t zmask; uint64_t n0;               // ring and the absolute index of the first input sample of output 0
+    const float *taps; int T, D, n_ch, nblocks;
+    float2 *y; int ring_len; uint32_t m0;
+};
+
 struct AfcRotArgs {           // z *= cexp(-t 2 pi Df) at IF rate, t = m / sr in double (demod_mod.c:758-761)
     const float2 *y; float2 *yrot; const AfcState *afc; const uint32_t *start;
     int n_ch, ring_len, sr; uint32_t m_end;
@@ -105,6 +121,9 @@ extern "C" {
 int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
+void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s);
+void sonde_launch_decimate_f32(const DecF32Args *a, hipStream_t s);
+void sonde_launch_dc_update_f64(int n_ch, double *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_afc_rotate(const AfcRotArgs *a, hipStream_t s, int n_max);
 void sonde_launch_fill_u32(uint32_t *p, uint32_t v, int n, hipStream_t s);
 void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s);

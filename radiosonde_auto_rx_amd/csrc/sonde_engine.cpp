@@ -63,6 +63,8 @@ struct sonde_engine {
     std::vector<float> w_iq0; float *d_wiq0 = nullptr;
     float2 *d_yrot = nullptr; float *d_fmraw = nullptr, *d_corr2 = nullptr;
     AfcState *d_afc = nullptr; uint32_t *d_start = nullptr; unsigned *d_pending = nullptr, *h_pending = nullptr;
+    // float32 input: IQ-DC sums in double, ring of mixed base-rate samples, taps in time order
+    double *d_dcsums_f = nullptr; float2 *d_zring = nullptr; float *d_taps_f = nullptr; uint32_t zmask = 0;
     hipEvent_t ev_copy = nullptr;                  // end of the host -> staging copy of process_host
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy [C][max_chunk]
     int ring_len = 0, max_frames = 0;
@@ -157,7 +159,7 @@ const char *sonde_strerror(int code) {
 
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
-    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8)) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
@@ -337,6 +339,16 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
     e->ifiq = ifiq;
+    if (cfg->bits == 32) {
+        bad = dalloc(&e->d_dcsums_f, 2 * (size_t)C);
+        if (!audio && !ifiq) {
+            uint32_t zl = 1; while (zl < (uint32_t)cfg->max_chunk + (uint32_t)T + (uint32_t)D + 64u) zl <<= 1;
+            e->zmask = zl - 1;
+            bad |= dalloc(&e->d_zring, (size_t)C * zl); bad |= dalloc(&e->d_taps_f, (size_t)T, false);
+            if (!bad) HIPCHK(hipMemcpy(e->d_taps_f, e->dec.taps.data(), (size_t)T * sizeof(float), hipMemcpyHostToDevice));
+        }
+        if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+    }
     if (cfg->opt_inv) {                                       // -i: every channel starts with inverted polarity
         std::vector<SyncState> st0(C); for (auto &q : st0) { memset(&q, 0, sizeof q); q.inv = 1; }
         HIPCHK(hipMemcpy(e->d_state, st0.data(), st0.size() * sizeof(SyncState), hipMemcpyHostToDevice));
@@ -382,7 +394,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
-                     e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending };
+                     e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -415,12 +427,39 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         // f32read_sample (demod_mod.c:379-405): b/128/256 of the selected channel; then FM low-pass / bufs
         AudioConvArgs c0{}; c0.pcm = (const int16_t *)d_iq; c0.ch_stride = ch_stride; c0.n_ch = C; c0.n = n_samples;
         c0.nch = std::max(1, e->cfg.audio_channels); c0.sel = std::min(std::max(0, e->cfg.audio_select), c0.nch - 1);
-        c0.fm = e->d_raw; c0.ring_len = e->ring_len; c0.m0 = e->m_out;
+        c0.fm = e->d_raw; c0.ring_len = e->ring_len; c0.m0 = e->m_out; c0.f32 = (e->cfg.bits == 32);
         sonde_launch_audio_convert(&c0, e->stream);
         AudioChainArgs c1{}; c1.raw = e->d_raw; c1.fm = e->d_fm; c1.bufs = e->d_bufs; c1.w = e->d_wfm; c1.n_ch = C; c1.ring_len = e->ring_len;
         c1.n = n_samples; c1.taps = (int)e->w_fm.size(); c1.m0 = e->m_out;
         prof_begin(e, "if_chain", e->stream); sonde_launch_audio_chain(&c1, e->stream); prof_end(e, e->stream);
         e->samples_in += (uint64_t)n_samples; e->m_out += (uint32_t)n_samples; done = n_samples;
+    }
+    while (done < n_samples && e->cfg.bits == 32 && e->cfg.input != SONDE_IN_AUDIO) {
+        // float32 IQ (cf32): plain mixer + FIR kernels (MixF32Args); the IQ-DC schedule is the same, sums in double like the reference
+        const bool dc = !e->ifiq || e->cfg.opt_iqdc != 0;
+        const int take = dc ? (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt) : n_samples - done;
+        MixF32Args a{}; a.x = (const float2 *)d_iq + (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.n = take;
+        a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len; a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
+        a.phase_f64 = (e->cfg.sonde_type == SONDE_FRONTEND); a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums_f;
+        if (e->ifiq) { a.mix = 0; a.z = e->d_y; a.zmask = (uint32_t)e->ring_len - 1; a.n0 = e->m_out; }
+        else { a.mix = 1; a.z = e->d_zring; a.zmask = e->zmask; a.n0 = e->samples_in; }
+        prof_begin(e, "mix_decimate", e->stream);
+        sonde_launch_mix_f32(&a, e->stream);
+        if (!e->ifiq) {
+            DecF32Args d{}; d.z = e->d_zring; d.zmask = e->zmask; d.n0 = e->samples_in; d.taps = e->d_taps_f; d.T = (int)e->dec.taps.size(); d.D = D;
+            d.n_ch = C; d.nblocks = take / D; d.y = e->d_y; d.ring_len = e->ring_len; d.m0 = e->m_out;
+            sonde_launch_decimate_f32(&d, e->stream);
+        }
+        prof_end(e, e->stream);
+        e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); done += take;
+        if (dc) {
+            e->dc_cnt += (uint32_t)take;
+            if (e->dc_cnt == e->dc_max) {
+                sonde_launch_dc_update_f64(C, e->d_dcsums_f, e->d_dcavg, (float)e->dc_max, e->stream);
+                e->dc_cnt = 0;
+                if (e->dc_max < e->dc_lim) e->dc_max *= 2;
+            }
+        }
     }
     while (done < n_samples && e->ifiq) {
         // --iq0/2/3 (f32read_csample, demod_mod.c:419-461): convert, optionally minus the running mean of the previous segment
@@ -538,7 +577,7 @@ int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_st
     if (!e || !h_iq) return SONDE_E_ARG;
     const int C = e->cfg.n_channels;
     if (n_samples <= 0 || n_samples > e->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
-    const size_t unit = (e->cfg.input == SONDE_IN_AUDIO ? (size_t)std::max(1, e->cfg.audio_channels) : 2) * (e->cfg.bits == 8 ? 1 : 2);
+    const size_t unit = (e->cfg.input == SONDE_IN_AUDIO ? (size_t)std::max(1, e->cfg.audio_channels) : 2) * (size_t)(e->cfg.bits / 8);
     const size_t need = (size_t)C * n_samples * unit;
     if (need > e->stage_bytes) {
         if (e->d_stage) { hipStreamSynchronize(e->stream); hipFree(e->d_stage); e->d_stage = nullptr; }

@@ -415,6 +415,64 @@ void k_audio_chain(const AudioChainArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// float32 input: k_mix_f32 / k_decimate_f32 / k_dc_update_f64 (see MixF32Args).  Correct-by-construction, not tuned: cf32 is
+// 8 B per sample and rare (the reference's usual sources are cs16 and cu8).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_mix_f32(const MixF32Args a) {
+    const int ch = blockIdx.y;
+    const float2 *x = a.x + (size_t)ch * a.ch_stride;
+    float2 *z = a.z + (size_t)ch * ((size_t)a.zmask + 1);
+    const float2 avg = a.dc_avg[ch];
+    const double f0 = a.mix ? a.chan_f0[ch] : 0.0;
+    const uint32_t L = (uint32_t)a.lut_len;
+    double sx = 0.0, sy = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+        const float2 v = x[i];
+        sx += (double)v.x; sy += (double)v.y;
+        float2 u = make_float2(v.x - avg.x, v.y - avg.y);
+        if (a.mix) {
+            const uint32_t k = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)i) % L);         // table index (demod_mod.c:746)
+            const double nd = (double)k;
+            float fr;
+            if (a.phase_f64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
+            else             fr = __builtin_amdgcn_fractf((float)(f0 * nd));
+            const float c = __builtin_amdgcn_cosf(fr), s = __builtin_amdgcn_sinf(fr);
+            u = make_float2(u.x * c - u.y * s, u.x * s + u.y * c);
+        }
+        z[(uint32_t)(a.n0 + (uint64_t)i) & a.zmask] = u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(a.dc_sums + 2 * (size_t)ch, sx); atomicAdd(a.dc_sums + 2 * (size_t)ch + 1, sy); }
+}
+
+__global__ __launch_bounds__(256)
+void k_decimate_f32(const DecF32Args a) {
+    const int ch = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.nblocks) return;
+    const float2 *z = a.z + (size_t)ch * ((size_t)a.zmask + 1);
+    // y[m] = sum_k w[k] z[D (m+1) - T + k]; samples before the stream are zero (calloc'ed delay line)
+    const int64_t first = (int64_t)a.n0 + (int64_t)a.D * (j + 1) - a.T;
+    float re = 0.f, im = 0.f;
+    for (int k = 0; k < a.T; k++) {
+        const int64_t n = first + k;
+        if (n < 0) continue;
+        const float2 v = z[(uint32_t)n & a.zmask];
+        const float w = a.taps[k];
+        re = fmaf(w, v.x, re); im = fmaf(w, v.y, im);
+    }
+    a.y[(size_t)ch * a.ring_len + ((a.m0 + (uint32_t)j) & ((uint32_t)a.ring_len - 1))] = make_float2(re, im);
+}
+
+__global__ void k_dc_update_f64(int n_ch, double *dc_sums, float2 *dc_avg, float maxcnt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    dc_avg[c] = make_float2((float)(dc_sums[2 * c] / (double)maxcnt), (float)(dc_sums[2 * c + 1] / (double)maxcnt));   // sumIQx/(float)maxcnt
+    dc_sums[2 * c] = 0.0; dc_sums[2 * c + 1] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_afc_rotate (--dc): yrot[m] = y[m] * cexp(-t 2 pi Df), t = m / sr, for m in [start[ch], m_end)   (demod_mod.c:758-761)
 // The reference multiplies the float sample by a double phasor and rounds once; Df is piecewise constant in time (it
 // changes at header detections), so the rotated stream is kept in its own ring = the IF filter's delay line lpIQ_buf.
@@ -1140,6 +1198,17 @@ extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, f
 extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s) {
     int gx = (n_bytes / 4 + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_u8_to_s16, dim3(gx, n_ch), dim3(256), 0, s, in, in_stride, out, out_stride, n_bytes);
+}
+extern "C" void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s) {
+    int gx = (a->n + 255) / 256; if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_mix_f32, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
+}
+extern "C" void sonde_launch_decimate_f32(const DecF32Args *a, hipStream_t s) {
+    if (a->nblocks <= 0) return;
+    hipLaunchKernelGGL(k_decimate_f32, dim3((a->nblocks + 255) / 256, a->n_ch), dim3(256), 0, s, *a);
+}
+extern "C" void sonde_launch_dc_update_f64(int n_ch, double *sums, float2 *avg, float maxcnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_dc_update_f64, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
 }
 extern "C" void sonde_launch_afc_rotate(const AfcRotArgs *a, hipStream_t s, int n_max) {
     int gx = (n_max + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;

@@ -157,6 +157,7 @@ struct sonde_scan {
     ScanItem *h_items = nullptr; ScanRes *h_res = nullptr; int item_cap = 0;
     void *d_stage = nullptr; size_t stage_bytes = 0;
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy
+    double *d_dcsums_f = nullptr; float2 *d_zring = nullptr; float *d_taps_f = nullptr; uint32_t zmask = 0;   // float32 input (MixF32Args)
     int ring_len = 0;
     // stream position
     uint64_t samples_in = 0; uint32_t m_out = 0; uint32_t dc_cnt = 0, dc_max = 0;
@@ -185,7 +186,7 @@ extern "C" {
 
 int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_t **out) {
     if (!cfg || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
-    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8) || cfg->max_chunk < 1) return SONDE_E_ARG;
+    if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32) || cfg->max_chunk < 1) return SONDE_E_ARG;
     if (cfg->iq_mode != SONDE_SCAN_AUDIO && cfg->iq_mode != SONDE_SCAN_IFIQ && cfg->iq_mode != SONDE_SCAN_BBIQ) return SONDE_E_ARG;
     if (cfg->iq_mode == SONDE_SCAN_BBIQ && !fq) return SONDE_E_ARG;
     int ndev = 0;
@@ -333,7 +334,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_items) hipHostFree(s->h_items);
     if (s->h_res) hipHostFree(s->h_res);
     void *ptrs[] = { s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -561,13 +562,39 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
     if (mode == SONDE_SCAN_AUDIO) {
         AudioConvArgs a{}; a.pcm = (const int16_t *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.n = n_samples;
         a.nch = std::max(1, s->cfg.audio_channels); a.sel = std::min(std::max(0, s->cfg.audio_select), a.nch - 1);
-        a.fm = s->d_fm; a.ring_len = s->ring_len; a.m0 = s->m_out;
+        a.fm = s->d_fm; a.ring_len = s->ring_len; a.m0 = s->m_out; a.f32 = (s->cfg.bits == 32);
         sonde_launch_audio_convert(&a, s->stream);
         s->m_out += (uint32_t)n_samples; s->samples_in += (uint64_t)n_samples;
     } else {
         int done = 0;
         while (done < n_samples) {
             const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), s->dc_max - s->dc_cnt);
+            if (s->cfg.bits == 32) {                         // float32 IQ: plain mixer / FIR kernels, IQ-DC sums in double
+                if (!s->d_dcsums_f) {
+                    HIPCHK(hipMalloc((void **)&s->d_dcsums_f, 2 * (size_t)C * sizeof(double))); HIPCHK(hipMemset(s->d_dcsums_f, 0, 2 * (size_t)C * sizeof(double)));
+                    if (mode == SONDE_SCAN_BBIQ) {
+                        uint32_t zl = 1; while (zl < (uint32_t)s->cfg.max_chunk + (uint32_t)s->dec.taps.size() + (uint32_t)D + 64u) zl <<= 1;
+                        s->zmask = zl - 1;
+                        HIPCHK(hipMalloc((void **)&s->d_zring, (size_t)C * zl * sizeof(float2))); HIPCHK(hipMemset(s->d_zring, 0, (size_t)C * zl * sizeof(float2)));
+                        HIPCHK(hipMalloc((void **)&s->d_taps_f, s->dec.taps.size() * sizeof(float)));
+                        HIPCHK(hipMemcpy(s->d_taps_f, s->dec.taps.data(), s->dec.taps.size() * sizeof(float), hipMemcpyHostToDevice));
+                    }
+                }
+                MixF32Args a{}; a.x = (const float2 *)d_in + (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.n = take;
+                a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len; a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)std::max(1, s->lut_len));
+                a.phase_f64 = 1; a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums_f;
+                if (mode == SONDE_SCAN_BBIQ) { a.mix = 1; a.z = s->d_zring; a.zmask = s->zmask; a.n0 = s->samples_in; }
+                else { a.mix = 0; a.z = s->d_y; a.zmask = (uint32_t)s->ring_len - 1; a.n0 = s->m_out; }
+                sonde_launch_mix_f32(&a, s->stream);
+                if (mode == SONDE_SCAN_BBIQ) {
+                    DecF32Args d{}; d.z = s->d_zring; d.zmask = s->zmask; d.n0 = s->samples_in; d.taps = s->d_taps_f; d.T = (int)s->dec.taps.size(); d.D = D;
+                    d.n_ch = C; d.nblocks = take / D; d.y = s->d_y; d.ring_len = s->ring_len; d.m0 = s->m_out;
+                    sonde_launch_decimate_f32(&d, s->stream);
+                }
+                s->samples_in += (uint64_t)take; s->m_out += (uint32_t)(take / D); s->dc_cnt += (uint32_t)take; done += take;
+                if (s->dc_cnt == s->dc_max) { sonde_launch_dc_update_f64(C, s->d_dcsums_f, s->d_dcavg, (float)s->dc_max, s->stream); s->dc_cnt = 0; }
+                continue;
+            }
             if (mode == SONDE_SCAN_BBIQ) {
                 MixDecArgs a{};
                 a.iq = (const int16_t *)d_in + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
@@ -609,7 +636,7 @@ int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride
     if (!s || !h_in) return SONDE_E_ARG;
     const int C = s->cfg.n_channels;
     if (n_samples <= 0 || n_samples > s->cfg.max_chunk || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;
-    const size_t unit = (s->cfg.iq_mode == SONDE_SCAN_AUDIO ? (size_t)std::max(1, s->cfg.audio_channels) : 2) * (s->cfg.bits == 8 ? 1 : 2);
+    const size_t unit = (s->cfg.iq_mode == SONDE_SCAN_AUDIO ? (size_t)std::max(1, s->cfg.audio_channels) : 2) * (size_t)(s->cfg.bits / 8);
     if (ch_stride == 0) {                                  // one wideband stream: staged once, every channel mixes its own fq out of it
         const size_t need1 = (size_t)n_samples * unit;
         if (need1 > s->stage_bytes) {

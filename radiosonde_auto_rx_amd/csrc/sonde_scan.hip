@@ -49,6 +49,12 @@ void k_audio_convert(const AudioConvArgs a) {
     const int16_t *pcm = a.pcm + (size_t)ch * a.ch_stride * a.nch;
     float *fm = a.fm + (size_t)ch * a.ring_len;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
+    if (a.f32) {
+        const float *pf = reinterpret_cast<const float *>(a.pcm) + (size_t)ch * a.ch_stride * a.nch;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+            fm[(a.m0 + (uint32_t)i) & mask] = pf[(size_t)i * a.nch + a.sel];
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
         fm[(a.m0 + (uint32_t)i) & mask] = (float)pcm[(size_t)i * a.nch + a.sel] * 3.0517578125e-05f;     // b/128.0/256.0, exact
 }

@@ -62,6 +62,7 @@ struct IqConvArgs {           // --iq: IF-rate IQ in, IQ-DC removed (f32read_csa
 struct AudioConvArgs {        // FM audio in (f32read_sample, dft_detect.c:505-533): int16, one of nch interleaved channels
     const int16_t *pcm; long long ch_stride; int n_ch, n, nch, sel;
     float *fm; int ring_len; uint32_t m0;
+    int f32;                  // samples are float32 (32-bit WAV / `- sr 32`): taken as they are (*s = *f)
 };
 
 extern "C" {

@@ -115,7 +115,7 @@ class Engine:
         self.sonde = sonde
         self.ecc = ecc
         self._per_sample = audio_channels if audio else 2      # input words (int16, or uint8 for bits=8) per sample
-        self._dtype = np.uint8 if bits == 8 else np.int16
+        self._dtype = {8: np.uint8, 16: np.int16, 32: np.float32}[bits]
         cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "frontend": 0}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline),

@@ -369,10 +369,15 @@ def to_u8(x: np.ndarray) -> np.ndarray:
     return np.clip((np.asarray(x).astype(np.int32) >> 8) + 128, 0, 255).astype(np.uint8)
 
 
+def to_f32(x: np.ndarray, scale: float = 0.73) -> np.ndarray:
+    """int16 samples -> float32 in [-1, 1) times a factor that makes the values non-representable as int16 / 32768."""
+    return (np.asarray(x).astype(np.float32) * np.float32(scale / 32768.0)).astype(np.float32)
+
+
 def wav_bytes(pcm: np.ndarray, sr: int, nch: int = 1, bits: int = 16) -> bytes:
     """Minimal RIFF/WAVE container (16-bit PCM, or 8-bit unsigned from uint8 samples) around interleaved samples."""
     import struct
-    data = np.ascontiguousarray(pcm, dtype="<i2" if bits == 16 else np.uint8).tobytes()
+    data = np.ascontiguousarray(pcm, dtype={8: np.uint8, 16: "<i2", 32: "<f4"}[bits]).tobytes()
     hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, nch, sr, sr * nch * bits // 8, nch * bits // 8, bits)
     return hdr + b"data" + struct.pack("<I", len(data)) + data
 

@@ -75,7 +75,7 @@ def test_engine_rejects_bad_requests():
     assert eng.fetch_frames() == []
     eng.close()
     with pytest.raises(SondeError):
-        Engine([0.1], 2_400_000, bits=32)                               # float input is not implemented: refused
+        Engine([0.1], 2_400_000, bits=24)                               # only 8 / 16 / 32-bit samples exist
     from radiosonde_auto_rx_amd.fsk import FskModem
     with pytest.raises(SondeError):
         FskModem(48000, 4799)                                           # Fs % Rs != 0 (the reference asserts)

@@ -211,6 +211,47 @@ U8_CASES = {
 }
 
 
+# float32 input (`- sr 32`, float WAV) through each CLI
+F32_CASES = {
+    "f32_rs41mod_2400k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=2_400_000, seconds=1.3, fq=0.1, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=111, dc=0.01 - 0.02j),
+                              args=["-r", "--ecc2", "--crc", "--IQ", "FQ", "--lpIQ", "-", "SR", "32"]),
+    "f32_dfm09mod_iq2_48k": dict(binary="dfm09mod", gen="dfm", cap=dict(sr=48_000, seconds=2.5, fq=0.0, noise_sigma=0.03, seed=112),
+                                 args=["-r", "--ecc", "--iq2", "--lpIQ", "-", "SR", "32"]),
+    "f32_rs41mod_iq0_iqdc_48k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=48_000, seconds=2.2, fq=0.0, n_frames=2, t_first=0.15, noise_sigma=0.02, seed=113, dc=0.04 + 0.03j),
+                                     args=["-r", "--ecc2", "--iq0", "--iqdc", "--lpIQ", "-", "SR", "32"]),
+    "f32_dft_detect_2400k": dict(binary="dft_detect", gen="rs41", cap=dict(sr=2_400_000, seconds=1.2, fq=0.07, n_frames=1, t_first=0.3, noise_sigma=0.02, seed=114, dc=0.02 - 0.01j),
+                                 args=["-v", "--IQ", "FQ", "--dc", "-", "SR", "32"]),
+    "f32_dft_detect_if48k": dict(binary="dft_detect", gen="dfm", cap=dict(sr=48_000, seconds=2.0, fq=0.0, noise_sigma=0.02, seed=115),
+                                 args=["-v", "--iq", "--bw", "20", "-", "SR", "32"]),
+    "f32_iq_dec_2400k": dict(binary="iq_dec", gen="rs41", cap=dict(sr=2_400_000, seconds=0.4, fq=0.1, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=116),
+                             args=["--iq", "FQ", "--lpIQ", "-", "SR", "32"], out="f4"),
+    "f32_rs41mod_wav32": dict(binary="rs41mod", gen="rs41", audio=True, cap=dict(sr=48_000, seconds=3.2, fq=0.0, n_frames=3, t_first=0.15, noise_sigma=0.03, seed=117, bit_errors=6),
+                              args=["-r", "--ecc2", "--crc"]),
+    "f32_dft_detect_wav32": dict(binary="dft_detect", gen="rs41", audio=True, cap=dict(sr=48_000, seconds=2.0, fq=0.0, n_frames=1, t_first=0.4, noise_sigma=0.03, seed=118),
+                                 args=["-v"]),
+}
+
+
+def f32_capture(case):
+    """-> (stdin bytes, argv)"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    cap["fq"] = synth.snap_fq(cap["fq"], sr)
+    x = synth.rs41_capture(**cap) if case["gen"] == "rs41" else synth.dfm_capture(**cap)
+    args = [repr(cap["fq"]) if a == "FQ" else str(sr) if a == "SR" else a for a in case["args"]]
+    if case.get("audio"):
+        return synth.wav_bytes(synth.to_f32(synth.fm_audio(x)), sr, bits=32), args
+    return synth.to_f32(x).tobytes(), args
+
+
+def gen_cli_cases(cases, capture, outdir):
+    for name, case in cases.items():
+        stdin, args = capture(case)
+        r = subprocess.run([os.path.join(bind.REFDIR, case["binary"])] + args, input=stdin, capture_output=True)
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), stdout=np.frombuffer(r.stdout, np.uint8), stderr=np.array(r.stderr.decode()),
+                            rc=r.returncode)
+        print(name, "rc", r.returncode, len(r.stdout), r.stdout[:70] if "out" not in case else "", r.stderr.decode().split())
+
+
 def u8_capture(case):
     """-> (stdin bytes, argv)"""
     cap = dict(case["cap"]); sr = cap["sr"]
@@ -453,6 +494,7 @@ def main():
     for name, case in DC_CASES.items():
         gen_dc_case(name, case, outdir)
     gen_bin_lines(outdir)
+    gen_cli_cases(F32_CASES, f32_capture, outdir)
     for name, case in INV_CASES.items():
         _, stdin, binary, args, _ = inv_capture(case)
         out, err, rc = bind.ref_run(binary, args, stdin)
