@@ -39,6 +39,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }      /* IF-rate IQ, tone correlator  */
         else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
         else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
+        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;               /* --IQ only, like the reference */
         else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;                     /* header dc / AFC */
         else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
         else if (!strcmp(a, "--lpbw")) {
@@ -96,6 +97,7 @@ int main(int argc, char **argv) {
         if (nch != 2) { fprintf(stderr, "dfm09mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
     }
     if (iq_mode == 5 && cfg.opt_dc) cfg.opt_lp |= SONDE_LP_FM;          /* as the reference (dfm09mod.c: option_iq == 5 && option_dc) */
+    if (iq_mode != 5) cfg.opt_nolut = 0;
     if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
     if (!have_iq) {                                  /* FM audio: WAV on stdin or from a file (opt_iq = 0) */
         if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }

@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--iq")) { if (++i >= argc) return -1; fq = atof(argv[i]); if (fq < -0.5) fq = -0.5; if (fq > 0.5) fq = 0.5; }
         else if (!strcmp(a, "--IFbw")) { if (++i >= argc) return -1; int k = atoi(argv[i]); if (k * 1000 >= 32000) if_min = k * 1000; }
         else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
+        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;
         else if (!strcmp(a, "--lpbw")) { if (++i >= argc) return -1; double bw = atof(argv[i]); if (bw > 1.0) cfg.lpiq_bw = (int)(bw * 1e3); cfg.opt_lp |= SONDE_LP_IQ; }
         else if (!strcmp(a, "--FM")) opt_fm = 1;
         else if (!strcmp(a, "--lpFM")) { cfg.opt_lp |= SONDE_LP_FM; opt_fm = 1; }

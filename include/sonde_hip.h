@@ -88,6 +88,8 @@ typedef struct {
                               * SONDE_IN_IQ always removes it (f32read_cblock :492)                              */
     int32_t opt_inv;         /* -i: inverted polarity expected — headers with a negative score are taken, bits flipped
                               * (rs41mod.c:2887-2891,2933-2937; dfm09mod.c:1642-1645,1702-1705)                  */
+    int32_t opt_nolut;       /* --noLUT (SONDE_IN_IQ): mixer phasor from the exact fq and the absolute sample index in double instead
+                              * of the periodic float-phase table of the snapped fq (demod_mod.c:738-742); not with opt_dc   */
     int32_t opt_auto;        /* --auto: a header of the opposite polarity flips the channel's polarity instead of being skipped */
 } sonde_cfg_t;
 

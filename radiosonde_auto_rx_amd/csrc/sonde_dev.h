@@ -25,6 +25,7 @@ struct MixDecArgs {
     const float *wtab_g;      // D > 64: [D][8] tap table in global memory, and the piece length DS (divides D, <= 64)
     int DS;
     int phase_f64;            // mixer phase f0*n kept in double (dft_detect.c:1090) instead of the float of demod_mod.c:1290
+    double nd_base;           // --noLUT: absolute index of the launch's first sample (phase = f0 * absolute index, no table period); else 0
 };
 
 // --dc (AFC) per-channel state: what find_header keeps in dsp.Df / dsp.locked / dsp.dc (demod_mod.c:1555-1600, 280-298)
@@ -40,7 +41,7 @@ struct AfcState {
 // like the reference; k_decimate_f32 runs the FIR over that ring, one output per thread, taps in time order.
 struct MixF32Args {
     const float2 *x; long long ch_stride; int n_ch, n;         // n complex samples per channel in this launch
-    const double *chan_f0; int lut_len; uint32_t lut_phase; int phase_f64;
+    const double *chan_f0; int lut_len; uint32_t lut_phase; int phase_f64; double nd_base;
     const float2 *dc_avg; double *dc_sums;                      // [n_ch][2]
     float2 *z; uint32_t zmask; uint64_t n0;                     // ring [n_ch][zmask+1], absolute base-rate index of the first sample
     int mix;                                                    // 0: no mixer (IF-rate input, --iq0/2/3): z = x - avg

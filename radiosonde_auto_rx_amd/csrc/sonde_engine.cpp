@@ -162,6 +162,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    if (cfg->opt_nolut && (cfg->opt_dc || cfg->input != SONDE_IN_IQ)) return SONDE_E_ARG;     // --noLUT folds Df into the base-rate mixer: not with --dc here
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
     if (cfg->input < SONDE_IN_IQ || cfg->input > SONDE_IN_IFIQ3) return SONDE_E_ARG;
     int ndev = 0;
@@ -256,6 +257,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         for (int c = 0; c < C; c++) {
             const Mixer m = design_mixer(-std::max(-0.5, std::min(0.5, fq[c])), cfg->sample_rate);
             f0s[c] = m.f0; e->lut_len = m.lut_len;
+            if (cfg->opt_nolut) f0s[c] = -std::max(-0.5, std::min(0.5, fq[c]));          // xlt_fq itself, not the table's snapped value
         }
         I.lut_len = e->lut_len;
         if (dalloc(&e->d_chanf0, (size_t)C, false)) { delete e; return SONDE_E_NOMEM; }
@@ -441,6 +443,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         MixF32Args a{}; a.x = (const float2 *)d_iq + (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.n = take;
         a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len; a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
         a.phase_f64 = (e->cfg.sonde_type == SONDE_FRONTEND); a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums_f;
+        if (e->cfg.opt_nolut) { a.phase_f64 = 1; a.lut_len = 1 << 30; a.lut_phase = 0; a.nd_base = (double)e->samples_in; }
         if (e->ifiq) { a.mix = 0; a.z = e->d_y; a.zmask = (uint32_t)e->ring_len - 1; a.n0 = e->m_out; }
         else { a.mix = 1; a.z = e->d_zring; a.zmask = e->zmask; a.n0 = e->samples_in; }
         prof_begin(e, "mix_decimate", e->stream);
@@ -490,6 +493,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.ptail_in = e->d_ptail[e->ptail_cur]; a.ptail_out = e->d_ptail[e->ptail_cur ^ 1];
         a.y = e->d_y; a.ring_len = e->ring_len; a.m0 = e->m_out;
         a.phase_f64 = (e->cfg.sonde_type == SONDE_FRONTEND);     // iq_dec.c:690 builds its table from a double phase
+        if (e->cfg.opt_nolut) { a.phase_f64 = 1; a.lut_len = 1 << 30; a.lut_phase = 0; a.nd_base = (double)e->samples_in; }
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
         { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
         prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);

@@ -79,7 +79,7 @@ __device__ __forceinline__ void md_step(const uint32_t raw, const int r, const f
     // ex[n], n = rown + r (mod L): t = fl32(f0*n) exactly as the reference's table was built
     double nd;
     if (!WRAP) { nd = ndrun; ndrun += 1.0; }                  // running index: integers stay exact in f64, one add per sample
-    else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u));
+    else nd = (double)(rown + (uint32_t)r - (((uint32_t)r >= towrap) ? L : 0u)) + ndrun;      // (WRAP: ndrun carries nd_base)
     // demod_mod.c keeps the table phase in a float (t = fl32(f0*n)); dft_detect.c:1090-1093 keeps it in a double
     float fr;
     if (PH64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
@@ -95,10 +95,10 @@ __device__ __forceinline__ void md_step(const uint32_t raw, const int r, const f
 
 template <int Q_T, bool WRAP, bool PH64, int D_T>
 __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float *wt, float2 avg, double f0,
-                                        uint32_t rown, uint32_t L, float dcmask,
+                                        uint32_t rown, uint32_t L, float dcmask, double nd_base,
                                         float2v (&acc)[Q_T], float2v &dcs) {
     const uint32_t towrap = L - rown;
-    double nd0 = (double)rown;
+    double nd0 = WRAP ? nd_base : (double)rown + nd_base;
     const float2v navg = { -avg.x, -avg.y }, msk = { dcmask, dcmask };
     if (D_T > 0) D = D_T;                                     // compile-time trip count
     // two samples per iteration (written out: the inline asm of the complex multiply counts as convergent, which
@@ -226,8 +226,8 @@ void k_mix_decimate(const MixDecArgs a) {
         float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
-        else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, acc, dcs);
+        if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+        else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
         sx += (int)dcs.x; sy += (int)dcs.y;
 
         // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
@@ -326,7 +326,7 @@ void k_mix_decimate_wide(const MixDecArgs a) {
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             uint32_t rs = rown + (uint32_t)(sub * DS); if (rs >= L) rs -= L;
-            md_rows<Q_T, true, PH64, 0>(sRow, DS, a.wtab_g + 8 * sub * DS, avg, f0, rs, L, outrow ? 1.f : 0.f, acc, dcs);
+            md_rows<Q_T, true, PH64, 0>(sRow, DS, a.wtab_g + 8 * sub * DS, avg, f0, rs, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
             sx += (int)dcs.x; sy += (int)dcs.y; dcs = (float2v){0.f, 0.f};
         }
         float yr = acc[H].x, yi = acc[H].y;
@@ -433,7 +433,7 @@ void k_mix_f32(const MixF32Args a) {
         float2 u = make_float2(v.x - avg.x, v.y - avg.y);
         if (a.mix) {
             const uint32_t k = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)i) % L);         // table index (demod_mod.c:746)
-            const double nd = (double)k;
+            const double nd = (double)k + a.nd_base;
             float fr;
             if (a.phase_f64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
             else             fr = __builtin_amdgcn_fractf((float)(f0 * nd));

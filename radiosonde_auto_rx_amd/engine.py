@@ -26,7 +26,7 @@ class SondeCfg(C.Structure):
                                          "opt_lp", "opt_dc", "opt_min", "lpiq_bw", "ecc_level")] + \
                [("thres", C.c_float), ("max_chunk", C.c_int32), ("max_frames", C.c_int32), ("keep_soft", C.c_int32),
                 ("pipeline", C.c_int32), ("input", C.c_int32), ("audio_channels", C.c_int32), ("audio_select", C.c_int32),
-                ("if_rate", C.c_int32), ("opt_iqdc", C.c_int32), ("opt_inv", C.c_int32), ("opt_auto", C.c_int32)]
+                ("if_rate", C.c_int32), ("opt_iqdc", C.c_int32), ("opt_inv", C.c_int32), ("opt_nolut", C.c_int32), ("opt_auto", C.c_int32)]
 
 
 class SondeFrame(C.Structure):
@@ -108,18 +108,18 @@ class Engine:
                  ecc: int = 2, thres: float = 0.0, max_chunk: int | None = None, max_frames: int = 0,
                  keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False,
                  sonde: str = "rs41", pipeline: bool = False, audio: bool = False, audio_channels: int = 1, audio_select: int = 0,
-                 if_rate: int = 0, bits: int = 16, iq_mode: int = 5, iqdc: bool = False, inv: bool = False, auto: bool = False):
+                 if_rate: int = 0, bits: int = 16, iq_mode: int = 5, iqdc: bool = False, inv: bool = False, auto: bool = False, nolut: bool = False):
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
         self.n_channels = len(fq)
         self.sample_rate = sample_rate
         self.sonde = sonde
         self.ecc = ecc
         self._per_sample = audio_channels if audio else 2      # input words (int16, or uint8 for bits=8) per sample
-        self._dtype = {8: np.uint8, 16: np.int16, 32: np.float32}[bits]
+        self._dtype = {8: np.uint8, 32: np.float32}.get(bits, np.int16)
         cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "frontend": 0}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline),
-                       1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(auto))
+                       1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), int(auto))
         h = C.c_void_p()
         _chk(lib().sonde_engine_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
         self._h = h

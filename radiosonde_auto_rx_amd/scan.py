@@ -79,7 +79,7 @@ class Scanner:
         self.sample_rate = sample_rate
         self.iq_mode = iq_mode
         self.audio_channels = audio_channels
-        self._dtype = {8: np.uint8, 16: np.int16, 32: np.float32}[bits]
+        self._dtype = {8: np.uint8, 32: np.float32}.get(bits, np.int16)
         cfg = ScanCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, iq_mode, int(dc), int(opt_min), int(cont), int(d2),
                       int(lband), audio_channels, audio_select, max_chunk or sample_rate, bw_khz, ths, time_limit, disable_mask)
         h = C.c_void_p()

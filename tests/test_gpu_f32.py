@@ -1,4 +1,4 @@
-"""GPU parity of float32 input (`- <sr> 32` cf32, 32-bit float WAV) through every host CLI: rs41mod / dfm09mod (--IQ, --iq0/2
+"""GPU parity of float32 input and of --noLUT (`- <sr> 32` cf32, 32-bit float WAV) through every host CLI: rs41mod / dfm09mod (--IQ, --iq0/2
 with --iqdc, FM audio), dft_detect (--IQ --dc, --iq, WAV), iq_dec.  The reference takes the floats as they are (demod_mod.c:
 393,434-436,487-489; dft_detect.c:530,571-573,610-612) and keeps the IQ-DC sums in double; the device does the same with
 plain (untuned) mixer / FIR kernels.  Sample values are scaled so that they are not multiples of 1/32768.
@@ -23,12 +23,16 @@ def _rms(a):
     return float(np.sqrt(np.mean(np.square(np.asarray(a, np.float64))))) if np.size(a) else 0.0
 
 
-@pytest.mark.parametrize("name", sorted(make_golden.F32_CASES))
+ALL = {**{k: (v, make_golden.f32_capture) for k, v in make_golden.F32_CASES.items()},
+       **{k: (v, make_golden.nolut_capture) for k, v in make_golden.NOLUT_CASES.items()}}     # --noLUT: exact fq, absolute-index phasor
+
+
+@pytest.mark.parametrize("name", sorted(ALL))
 def test_cli_f32_matches_reference(name):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
-    case = make_golden.F32_CASES[name]
+    case, capture = ALL[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    stdin, args = make_golden.f32_capture(case)
+    stdin, args = capture(case)
     r = subprocess.run([os.path.join(ROOT, "host", "bin", case["binary"])] + args, input=stdin, capture_output=True, timeout=180)
     assert r.returncode == int(g["rc"]), (r.returncode, r.stderr)
     assert r.stderr.decode() == str(g["stderr"])

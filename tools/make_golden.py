@@ -243,6 +243,27 @@ def f32_capture(case):
     return synth.to_f32(x).tobytes(), args
 
 
+# --noLUT: mixer phasor from the exact (unsnapped) fq and the absolute sample index (demod_mod.c:738-742, iq_dec.c:566-570)
+NOLUT_CASES = {
+    "nolut_rs41mod_2400k": dict(binary="rs41mod", gen="rs41", cap=dict(sr=2_400_000, seconds=2.3, fq=0.1000123, n_frames=2, t_first=0.1, noise_sigma=0.02, seed=131),
+                                args=["-r", "--ecc2", "--crc", "--noLUT", "--IQ", "FQ", "--lpIQ", "-", "SR", "16"]),
+    "nolut_dfm09mod_2400k": dict(binary="dfm09mod", gen="dfm", cap=dict(sr=2_400_000, seconds=1.4, fq=-0.1300071, noise_sigma=0.02, seed=132),
+                                 args=["-r", "--ecc", "--noLUT", "--IQ", "FQ", "--lpIQ", "-", "SR", "16"]),
+    "nolut_iq_dec_2400k": dict(binary="iq_dec", gen="rs41", cap=dict(sr=2_400_000, seconds=0.6, fq=0.0700031, n_frames=1, t_first=0.02, noise_sigma=0.02, seed=133),
+                               args=["--noLUT", "--iq", "FQ", "--lpIQ", "-", "SR", "16"], out="f4"),
+    "nolut_rs41mod_2400k_f32": dict(binary="rs41mod", gen="rs41", f32=True, cap=dict(sr=2_400_000, seconds=1.3, fq=-0.2000377, n_frames=1, t_first=0.1, noise_sigma=0.02, seed=134),
+                                    args=["-r", "--ecc2", "--crc", "--noLUT", "--IQ", "FQ", "--lpIQ", "-", "SR", "32"]),
+}
+
+
+def nolut_capture(case):
+    """-> (stdin bytes, argv); fq is NOT snapped to the table raster here"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    x = synth.rs41_capture(**cap) if case["gen"] == "rs41" else synth.dfm_capture(**cap)
+    args = [repr(cap["fq"]) if a == "FQ" else str(sr) if a == "SR" else a for a in case["args"]]
+    return (synth.to_f32(x) if case.get("f32") else x).tobytes(), args
+
+
 def gen_cli_cases(cases, capture, outdir):
     for name, case in cases.items():
         stdin, args = capture(case)
@@ -495,6 +516,7 @@ def main():
         gen_dc_case(name, case, outdir)
     gen_bin_lines(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
+    gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
     for name, case in INV_CASES.items():
         _, stdin, binary, args, _ = inv_capture(case)
         out, err, rc = bind.ref_run(binary, args, stdin)
