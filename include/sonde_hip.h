@@ -135,7 +135,8 @@ int  sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info);
 /* Push n_samples new complex samples per channel.  Replaces the pull loop
  * find_header()/read_softbit2p() -> f32buf_sample() -> f32read_cblock() (demod_mod.c:1533,1087,722,463).
  * iq: interleaved I,Q little-endian int16, channel c at iq + 2*c*ch_stride (ch_stride in complex samples).
- * n_samples must be a multiple of decM and <= max_chunk.  The *_device form takes a device pointer and
+ * ch_stride == 0: ONE wideband stream shared by all channels — each channel mixes its own fq out of it (the channelizer
+ * form: one SDR stream, N sondes, no N processes).  n_samples must be a multiple of decM and <= max_chunk.  The *_device form takes a device pointer and
  * only enqueues work on the engine's HIP stream; the *_host form copies first (PCIe-inclusive). */
 int  sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples);
 int  sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples);

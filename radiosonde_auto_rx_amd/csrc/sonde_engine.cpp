@@ -416,12 +416,13 @@ void *sonde_engine_stream(sonde_engine_t *e) { return e ? (void *)e->stream : nu
 int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples) {
     if (!e || !d_iq) return SONDE_E_ARG;
     const int D = e->info.decM, C = e->cfg.n_channels;
-    if (n_samples <= 0 || n_samples > e->cfg.max_chunk || n_samples % D || ch_stride < n_samples) return SONDE_E_RANGE;
+    // ch_stride == 0: one wideband stream shared by all channels (each mixes its own fq out of it)
+    if (n_samples <= 0 || n_samples > e->cfg.max_chunk || n_samples % D || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;
     if (e->cfg.bits == 8) {                        // cu8: (u-128)/128 == ((u-128)*256)/32768 -> feed the 16-bit path
         const int epf = e->cfg.input == SONDE_IN_AUDIO ? std::max(1, e->cfg.audio_channels) : 2;    // bytes per sample / audio frame
         if (!e->d_conv) HIPCHK(hipMalloc((void **)&e->d_conv, (size_t)C * e->cfg.max_chunk * epf * 2));
-        sonde_launch_u8_to_s16((const uint8_t *)d_iq, ch_stride * epf, e->d_conv, (long long)n_samples * epf, C, n_samples * epf, e->stream);
-        d_iq = e->d_conv; ch_stride = n_samples;
+        sonde_launch_u8_to_s16((const uint8_t *)d_iq, ch_stride * epf, e->d_conv, (long long)n_samples * epf, ch_stride == 0 ? 1 : C, n_samples * epf, e->stream);
+        d_iq = e->d_conv; if (ch_stride != 0) ch_stride = n_samples;
     }
     const uint32_t m_first = e->m_out;
     int done = 0;
@@ -580,20 +581,21 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
 int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_stride, int32_t n_samples) {
     if (!e || !h_iq) return SONDE_E_ARG;
     const int C = e->cfg.n_channels;
-    if (n_samples <= 0 || n_samples > e->cfg.max_chunk || ch_stride < n_samples) return SONDE_E_RANGE;
+    if (n_samples <= 0 || n_samples > e->cfg.max_chunk || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;
     const size_t unit = (e->cfg.input == SONDE_IN_AUDIO ? (size_t)std::max(1, e->cfg.audio_channels) : 2) * (size_t)(e->cfg.bits / 8);
-    const size_t need = (size_t)C * n_samples * unit;
+    const int rows = ch_stride == 0 ? 1 : C;                   // shared wideband stream: staged once
+    const size_t need = (size_t)rows * n_samples * unit;
     if (need > e->stage_bytes) {
         if (e->d_stage) { hipStreamSynchronize(e->stream); hipFree(e->d_stage); e->d_stage = nullptr; }
         HIPCHK(hipMalloc((void **)&e->d_stage, need)); e->stage_bytes = need;
     }
-    HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)n_samples * unit, h_iq, (size_t)ch_stride * unit, (size_t)n_samples * unit, C,
+    HIPCHK(hipMemcpy2DAsync(e->d_stage, (size_t)n_samples * unit, h_iq, (size_t)std::max<int64_t>(ch_stride, n_samples) * unit, (size_t)n_samples * unit, rows,
                             hipMemcpyHostToDevice, e->stream));
     // the caller may free or overwrite h_iq as soon as this returns; a pageable source can be pinned in place and read by the
     // copy engine after hipMemcpy2DAsync has returned, so wait for the copy itself (not for the kernels queued behind it)
     HIPCHK(hipEventRecord(e->ev_copy, e->stream));
     HIPCHK(hipEventSynchronize(e->ev_copy));
-    return sonde_engine_process_device(e, e->d_stage, n_samples, n_samples);
+    return sonde_engine_process_device(e, e->d_stage, ch_stride == 0 ? 0 : n_samples, n_samples);
 }
 
 int sonde_engine_sync(sonde_engine_t *e) {

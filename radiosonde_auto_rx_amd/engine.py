@@ -137,8 +137,14 @@ class Engine:
     __del__ = close
 
     # -- input -------------------------------------------------------------------------------
-    def process_host(self, iq: np.ndarray, n_samples: int | None = None):
-        """iq: int16 (bits=8: uint8) array [n_channels, 2*stride] (or [2*stride] for one channel)."""
+    def process_host(self, iq: np.ndarray, n_samples: int | None = None, shared: bool = False):
+        """iq: int16 (bits=8: uint8, 32: float32) array [n_channels, 2*stride] (or [2*stride] for one channel).
+        shared=True: iq is ONE wideband stream [2*n] that every channel mixes its own fq out of (channel stride 0)."""
+        if shared:
+            iq = np.ascontiguousarray(iq, dtype=self._dtype).reshape(-1)
+            n = iq.shape[0] // self._per_sample
+            _chk(lib().sonde_engine_process_host(self._h, iq.ctypes.data_as(C.c_void_p), 0, n_samples or n))
+            return
         iq = np.ascontiguousarray(iq, dtype=self._dtype).reshape(self.n_channels, -1)
         stride = iq.shape[1] // (self._per_sample)
         _chk(lib().sonde_engine_process_host(self._h, iq.ctypes.data_as(C.c_void_p), stride, n_samples or stride))

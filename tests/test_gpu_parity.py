@@ -182,3 +182,33 @@ def test_cli_dfm09mod_matches_reference_lines():
                             "--lpIQ", "-", str(sr), "16"], input=x.tobytes(), capture_output=True, timeout=120)
         assert r.returncode == 0, r.stderr
         assert [l.rstrip() for l in r.stdout.decode().splitlines()] == [l.rstrip() for l in g["lines"]], name
+
+
+def test_wideband_shared_stream_demod_matches_reference():
+    """BASELINE config 3 through the demodulator: ONE 10 Msps stream, four channels (three RS41 at different offsets, one empty)
+    mixed out of it by one engine (channel stride 0, wide decimator D = 200) — frames per channel identical to one reference
+    `rs41mod --IQ fq --lpIQ - 10000000 16` process per channel on the same stream."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_golden
+    from radiosonde_auto_rx_amd.engine import Engine
+    g = np.load(os.path.join(root, "tests", "golden", "demod_wide_10M.npz"))
+    x, fqs = make_golden.wide_demod_capture()
+    sr = make_golden.WIDE_DEMOD_CASE["sr"]
+    eng = Engine(fqs, sr, max_chunk=2_000_000, max_frames=16)
+    D = eng.info["decM"]
+    assert (eng.info["if_sr"], D) == (50000, 200)
+    n = len(x) // 2
+    frames = []
+    for s0 in range(0, n - n % D, 2_000_000):
+        s1 = min(n - n % D, s0 + 2_000_000)
+        eng.process_host(x[2 * s0:2 * s1], shared=True)
+        frames += eng.fetch_frames()
+    frames += eng.fetch_frames(finish=True)
+    eng.close()
+    for c in range(len(fqs)):
+        got = [f["line"].rstrip() for f in frames if f["channel"] == c]
+        assert got == [str(l).rstrip() for l in g["lines%d" % c]], c
+    assert sum(len(g["lines%d" % c]) for c in range(len(fqs))) == 3

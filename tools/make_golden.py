@@ -264,6 +264,30 @@ def nolut_capture(case):
     return (synth.to_f32(x) if case.get("f32") else x).tobytes(), args
 
 
+# one wideband stream, several sondes (BASELINE config 3) through the demodulator: reference = one rs41mod process per channel
+WIDE_DEMOD_CASE = dict(sr=10_000_000, seconds=1.25, seed=6, noise_sigma=0.01,
+                       signals=[dict(kind="rs41", fq=0.12, t_first=0.05, amp=0.12), dict(kind="rs41", fq=-0.231, t_first=0.31, amp=0.1),
+                                dict(kind="rs41", fq=0.4, t_first=0.12, amp=0.08)],
+                       extra_fq=[0.05])
+
+
+def wide_demod_capture():
+    c = WIDE_DEMOD_CASE; sr = c["sr"]
+    sig = [dict(s, fq=synth.snap_fq(s["fq"], sr)) for s in c["signals"]]
+    x = synth.wideband_capture(sr, c["seconds"], sig, noise_sigma=c["noise_sigma"], seed=c["seed"])
+    return x, [s["fq"] for s in sig] + [synth.snap_fq(f, sr) for f in c["extra_fq"]]
+
+
+def gen_wide_demod(outdir):
+    x, fqs = wide_demod_capture()
+    d = dict(fqs=np.array(fqs))
+    for c, fq in enumerate(fqs):
+        out, err, rc = bind.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "--IQ", repr(fq), "--lpIQ", "-", str(WIDE_DEMOD_CASE["sr"]), "16"], x)
+        d["lines%d" % c] = np.array(out.splitlines()); d["stderr%d" % c] = np.array(err)
+        print("demod_wide_10M ch", c, fq, len(out.splitlines()), err.split())
+    np.savez_compressed(os.path.join(outdir, "demod_wide_10M.npz"), **d)
+
+
 def gen_cli_cases(cases, capture, outdir):
     for name, case in cases.items():
         stdin, args = capture(case)
@@ -516,6 +540,7 @@ def main():
         gen_dc_case(name, case, outdir)
     gen_bin_lines(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
+    gen_wide_demod(outdir)
     gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
     for name, case in INV_CASES.items():
         _, stdin, binary, args, _ = inv_capture(case)
