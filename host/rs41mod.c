@@ -20,7 +20,7 @@
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0, rawhex = 0, xorhex = 0;
     FILE *fp = stdin;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
@@ -68,6 +68,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--softin")) softin = 1;
         else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "--bin")) opt_bin = 1;                       /* one byte per hard bit */
+        else if (!strcmp(a, "--rawhex")) rawhex = 1;                     /* frames as hex lines */
+        else if (!strcmp(a, "--xorhex")) { rawhex = 1; xorhex = 1; }
         else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) opt_inv = 1;
         else if (!strcmp(a, "--auto")) opt_auto = 1;
         else if (a[0] != '-') {                      /* WAV file instead of stdin (rs41mod.c wavloaded) */
@@ -75,6 +77,24 @@ int main(int argc, char **argv) {
             if (fp == NULL) { fprintf(stderr, "error: open %s\n", a); return -1; }
         }
         else { fprintf(stderr, "rs41mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
+    }
+    if (rawhex) {                                    /* rs41mod.c:2976-3002: hex up to the first blank, frames longer than the ID block */
+        if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+        sonde_softin_t *si = NULL;
+        if (sonde_softin_create(SONDE_RS41, cfg.ecc_level, 0, 0, 0, &si) < 0) return -1;
+        char lb[2 * 518 + 12], ln[1200]; uint8_t fb[518]; sonde_frame_t fr;
+        while (fgets(lb, sizeof lb, fp)) {
+            lb[2 * 518] = 0;
+            char *sp = strchr(lb, ' ');
+            if (sp) *sp = 0;
+            int len = (int)(strlen(lb) / 2);
+            if (len <= 0x3D + 10) continue;
+            for (int i = 0; i < len; i++) { unsigned v = 0; sscanf(lb + 2 * i, "%2x", &v); fb[i] = (uint8_t)v; }
+            sonde_softin_push_frame(si, fb, len, xorhex);
+            while (sonde_softin_fetch(si, &fr, 1) > 0) { sonde_rs41_rawline(&fr, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
+        }
+        sonde_softin_destroy(si);
+        return 0;
     }
     if (softin || opt_bin) {                                    /* float32 soft bits on stdin (rs41mod.c:2655-2656,2878-2917) */
         if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }

@@ -192,6 +192,8 @@ int  sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n);
 /* --bin: one byte per hard bit (LSB used; `fsk_demod` without -s): find_binhead / cmp_hdb (demod_mod.c:1639-1690), header
  * accepted at <= 3 (RS41) / 2 (DFM) bit errors in either polarity; then the same framers */
 int  sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n);
+/* --rawhex / --xorhex (rs41mod.c:2976-3002): one frame given as bytes (xorhex: still whitened), handed to print_frame() */
+int  sonde_softin_push_frame(sonde_softin_t *s, const uint8_t *bytes, int32_t len, int32_t xorhex);
 int  sonde_softin_finish(sonde_softin_t *s);               /* EOF: emit the frame in progress (rs41mod.c:2931,2965) */
 int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
 /* SONDE_DFM09 framers (dfm09mod --softin, dfm09mod.c:1604-1720: two soft symbols per bit, 8 frames per header hit) */

@@ -220,6 +220,15 @@ int sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n) {
     return 0;
 }
 
+// --rawhex / --xorhex (rs41mod.c:2976-3002): frame bytes given directly; gpx.frame persists between lines
+int sonde_softin_push_frame(sonde_softin_t *s, const uint8_t *bytes, int32_t len, int32_t xorhex) {
+    if (!s || !bytes || len < 0 || len > 518 || s->type != SONDE_RS41) return SONDE_E_ARG;
+    for (int i = 0; i < len; i++) s->frame[i] = xorhex ? (uint8_t)(bytes[i] ^ kRs41Mask[i % 64]) : bytes[i];
+    s->mv = 0.f; s->hdr_bit = 0;
+    emit(s, len);
+    return 0;
+}
+
 int sonde_softin_finish(sonde_softin_t *s) {               // EOF inside a frame: print_frame with the bytes that exist
     if (!s) return SONDE_E_ARG;
     if (s->type == SONDE_DFM09) { s->state = 0; return 0; }          // a partial DFM frame is dropped (dfm09mod.c:1702,1713)

@@ -76,3 +76,15 @@ def test_bin_cli_matches_reference_lines():
         assert r.returncode == 0 and [l.rstrip() for l in r.stdout.decode().splitlines()] == want, (name, flags)
         some += len(want)
     assert some > 10
+
+
+def test_rawhex_cli_matches_reference_lines():
+    """`rs41mod --rawhex -r [--ecc|--ecc2]`: frames as hex lines (rs41mod.c:2976-3002) — clean, correctable, uncorrectable,
+    too short (skipped) and truncated lines; the frame buffer persists between lines like the reference's."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rawhex_lines.npz"))
+    for key, flags in (("ecc2", ["--ecc2"]), ("ecc", ["--ecc"]), ("none", [])):
+        r = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--rawhex", "-r"] + flags, input=str(g["input"]).encode(),
+                           capture_output=True, timeout=60)
+        assert r.returncode == 0
+        assert r.stdout.decode().splitlines() == [str(l) for l in g[key]] and len(g[key]) == 5

@@ -483,6 +483,25 @@ def gen_bin_lines(outdir):
     print("bin_lines", {k: len(v) for k, v in d.items()})
 
 
+def gen_rawhex(outdir):
+    """--rawhex: frames as hex lines (clean, correctable, uncorrectable, short, truncated) through the reference's rs41mod"""
+    lines = [str(l).split(" ")[0] for l in np.load(os.path.join(outdir, "fsk_rs41_48k_mask.npz"))["rs41_lines"]]
+    rng = np.random.default_rng(3)
+
+    def corrupt(h, n):
+        b = bytearray(bytes.fromhex(h))
+        for p in rng.choice(np.arange(60, len(b)), n, replace=False):
+            b[p] ^= int(rng.integers(1, 256))
+        return b.hex()
+    inp = "\n".join([lines[0], corrupt(lines[0], 8) + " [NO] junk", corrupt(lines[1], 30), lines[1][:200], corrupt(lines[1], 20)[:600]]) + "\n"
+    d = dict(input=np.array(inp))
+    for key, flags in (("ecc2", ["--ecc2"]), ("ecc", ["--ecc"]), ("none", [])):
+        out, err, rc = bind.ref_run("rs41mod", ["--rawhex", "-r"] + flags, inp.encode())
+        d[key] = np.array(out.splitlines())
+    np.savez_compressed(os.path.join(outdir, "rawhex_lines.npz"), **d)
+    print("rawhex", {k: len(v) for k, v in d.items() if k != "input"})
+
+
 def main():
     outdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -539,6 +558,7 @@ def main():
     for name, case in DC_CASES.items():
         gen_dc_case(name, case, outdir)
     gen_bin_lines(outdir)
+    gen_rawhex(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_wide_demod(outdir)
     gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
