@@ -7,7 +7,8 @@
  * stdout: one raw line per frame, `<hex bytes> [OK]|[NO] (n)`     (rs41mod.c:2530-2545), unbuffered (:2612)
  * stderr: `IF: <rate>` / `dec: <M>`                               (demod_mod.c:1257-1258)
  * exit  : 0 on EOF, 255 on argument / init errors                 (rs41mod.c:2663,2739,2846)
- * Field decode / JSON (print_position) is the next tier — without -r this build refuses.
+ * Without -r the telemetry text line (and with --json the JSON object auto_rx parses) of print_position() is printed
+ * (include/sonde_rs41.h; -v, --ptu, --ptu2, --dewp, --json, --jsnsubfrm1/2, --jsn_cfq, --silent).
  * The DSP runs on the GPU; there is no CPU fallback: without a HIP device the program exits 255.
  */
 #include <stdio.h>
@@ -15,13 +16,41 @@
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "sonde_rs41.h"
 #include "wav_header.h"
+
+static sonde_rs41_dec_t *g_dec = NULL;
+static int g_raw = 0;
+
+/* print_frame() (rs41mod.c:2472-2553): raw line with -r (then JSON only, if asked for), else the decoded text */
+/* the decoder behind the text / JSON output; version = what the reference compiles in as VER_JSN_STR */
+static int make_decoder(sonde_rs41_opts_t *o, int raw, int khz) {
+    const char *ver = getenv("SONDE_JSN_VERSION");
+    g_raw = raw;
+    if (raw && o->json) o->silent = 1;                  /* rs41mod.c:2754 */
+    if (raw && !o->json) return 0;
+    o->jsn_freq_khz = khz;
+#ifdef VER_JSN_STR
+    if (!ver) ver = VER_JSN_STR;
+#endif
+    if (ver) { strncpy(o->version, ver, sizeof o->version - 1); o->version[sizeof o->version - 1] = 0; }
+    return sonde_rs41_dec_create(o, &g_dec);
+}
+
+static void emit_frame(const sonde_frame_t *f) {
+    static char ln[1200], tx[8192];
+    if (g_raw) { sonde_rs41_rawline(f, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
+    if (g_dec && sonde_rs41_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
+}
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
     int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0, rawhex = 0, xorhex = 0;
     FILE *fp = stdin;
+    sonde_rs41_opts_t dopt;
+    int json_ecc = 0, cfreq = -1;
+    memset(&dopt, 0, sizeof dopt);
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_RS41;
@@ -33,7 +62,16 @@ int main(int argc, char **argv) {
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
         else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
-        else if (!strcmp(a, "--crc")) { /* CRC is evaluated by field decode only */ }
+        else if (!strcmp(a, "--crc")) { /* block CRCs are always evaluated by the field decode */ }
+        else if (!strcmp(a, "-v")) dopt.verbose = 1;
+        else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
+        else if (!strcmp(a, "--ptu2")) dopt.ptu = 2;
+        else if (!strcmp(a, "--dewp")) dopt.dewp = 1;
+        else if (!strcmp(a, "--silent")) dopt.silent = 1;
+        else if (!strcmp(a, "--json")) { dopt.json = 1; json_ecc = 1; }
+        else if (!strcmp(a, "--jsnsubfrm1")) { dopt.jsn_subfrm = 1; dopt.json = 1; json_ecc = 1; }
+        else if (!strcmp(a, "--jsnsubfrm2")) { dopt.jsn_subfrm = 2; dopt.json = 1; json_ecc = 1; }
+        else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
         else if (!strcmp(a, "--IQ")) {
             if (++i >= argc) return -1;
@@ -78,11 +116,12 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "rs41mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
+    if (json_ecc) cfg.ecc_level = 2;                 /* --json / --jsnsubfrm: ecc = 2, crc (rs41mod.c:2703-2707,2770-2774) */
+    if (rawhex || softin || opt_bin) { if (make_decoder(&dopt, raw, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1; }
     if (rawhex) {                                    /* rs41mod.c:2976-3002: hex up to the first blank, frames longer than the ID block */
-        if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
         sonde_softin_t *si = NULL;
         if (sonde_softin_create(SONDE_RS41, cfg.ecc_level, 0, 0, 0, &si) < 0) return -1;
-        char lb[2 * 518 + 12], ln[1200]; uint8_t fb[518]; sonde_frame_t fr;
+        char lb[2 * 518 + 12]; uint8_t fb[518]; sonde_frame_t fr;
         while (fgets(lb, sizeof lb, fp)) {
             lb[2 * 518] = 0;
             char *sp = strchr(lb, ' ');
@@ -91,16 +130,15 @@ int main(int argc, char **argv) {
             if (len <= 0x3D + 10) continue;
             for (int i = 0; i < len; i++) { unsigned v = 0; sscanf(lb + 2 * i, "%2x", &v); fb[i] = (uint8_t)v; }
             sonde_softin_push_frame(si, fb, len, xorhex);
-            while (sonde_softin_fetch(si, &fr, 1) > 0) { sonde_rs41_rawline(&fr, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
+            while (sonde_softin_fetch(si, &fr, 1) > 0) emit_frame(&fr);
         }
         sonde_softin_destroy(si);
         return 0;
     }
     if (softin || opt_bin) {                                    /* float32 soft bits on stdin (rs41mod.c:2655-2656,2878-2917) */
-        if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
         sonde_softin_t *si = NULL;
         if (sonde_softin_create(SONDE_RS41, cfg.ecc_level, softin == 2, opt_inv, opt_auto, &si) < 0) return -1;
-        float sb[1024]; sonde_frame_t fr[4]; char ln[1200]; size_t got;
+        float sb[1024]; sonde_frame_t fr[4]; size_t got;
         for (;;) {
             if (opt_bin && !softin) {                    /* --bin: one byte per bit (--softin wins if both are given) */
                 got = fread(sb, 1, 1024, fp);
@@ -112,7 +150,7 @@ int main(int argc, char **argv) {
             if (got < 1024) sonde_softin_finish(si);
             int k;
             while ((k = sonde_softin_fetch(si, fr, 4)) > 0)
-                for (int i = 0; i < k; i++) { sonde_rs41_rawline(&fr[i], ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
+                for (int i = 0; i < k; i++) emit_frame(&fr[i]);
             if (got < 1024) break;
         }
         sonde_softin_destroy(si);
@@ -132,8 +170,12 @@ int main(int argc, char **argv) {
         cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
         cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
     }
-    if (!raw) { fprintf(stderr, "rs41mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
 
+    {   /* "freq" of the JSON: (cfreq - xlt_fq * sr + 500) / 1e3 with xlt_fq = -fq for --IQ (rs41mod.c:2806-2809) */
+        const double xlt = (iq_mode == 5) ? -fq : 0.0;
+        const int khz = cfreq > 0 ? (int)((cfreq - xlt * cfg.sample_rate + 500) / 1e3) : 0;
+        if (make_decoder(&dopt, raw, khz) < 0) { fprintf(stderr, "error: telemetry options\n"); return -1; }
+    }
     /* 0.1 s of input per GPU call keeps latency well below one frame */
     cfg.n_channels = 1;
     cfg.max_chunk = cfg.sample_rate;
@@ -153,7 +195,6 @@ int main(int argc, char **argv) {
     if (chunk < info.decM) chunk = info.decM;
     int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
     sonde_frame_t frames[8];
-    char line[1200];
     size_t have = 0;
     for (;;) {
         size_t got = fread((char *)buf + have, 1, (size_t)chunk * unit - have, fp);
@@ -164,7 +205,7 @@ int main(int argc, char **argv) {
             rc = sonde_engine_process_host(eng, buf, n, n);
             if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
             int k = sonde_engine_fetch_frames(eng, frames, 8);
-            for (int i = 0; i < k; i++) { sonde_rs41_rawline(&frames[i], line, sizeof line); fprintf(stdout, "%s\n", line); }
+            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
             memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
             have -= (size_t)n * unit;
         }
@@ -172,7 +213,7 @@ int main(int argc, char **argv) {
     }
     {   /* EOF: the reference still prints a frame it was in the middle of (rs41mod.c:2931,2965) */
         int k = sonde_engine_finish(eng, frames, 8);
-        for (int i = 0; i < k; i++) { sonde_rs41_rawline(&frames[i], line, sizeof line); fprintf(stdout, "%s\n", line); }
+        for (int i = 0; i < k; i++) emit_frame(&frames[i]);
     }
     sonde_engine_destroy(eng);
     free(buf);

@@ -96,15 +96,81 @@ def _put_block(frame: bytearray, pos: int, blk_id: int, payload: bytes) -> None:
     frame[pos + 3 + len(payload)] = crc >> 8
 
 
+def rs41_cal_table(seed: int = 1, typ: str = "RS41-SGP", rsm: str = "RSM421", freq_khz: int = 403010, fw: int = 0x4EF5,
+                   burst_kill: int = 0, kill_timer: int = 0xFFFF, burst_timer: int = 0x7788) -> bytes:
+    """A plausible 51 x 16 byte calibration / configuration table (the subframes an RS41 cycles through, one per frame):
+    PTU coefficients as little-endian floats at the offsets the decoders read them from, frequency, firmware, timers,
+    type strings, CRC-16 of bytes 2..799 in front.  Values are made up but sane (T around -40..+30 C, RH 0..100 %)."""
+    import struct
+    rng = np.random.default_rng(seed)
+    c = bytearray(rng.integers(0, 256, 51 * 16, dtype=np.uint8).tobytes())
+
+    def put(ofs, *vals):
+        for k, v in enumerate(vals):
+            c[ofs + 4 * k:ofs + 4 * k + 4] = struct.pack("<f", v)
+    put(61, 750.0, 1100.0)                                   # reference resistors
+    put(69, 0.0, 47.0)                                       # reference capacitors
+    put(77, -243.911, 0.187654, 8.2e-06)                     # platinum polynomial, sensor 1
+    put(89, 1.00312, -0.0213, 0.00021)                       # calibration T1
+    put(117, 44.93, 5.02)                                    # humidity capacitance calibration
+    put(125, *[float(v) for v in (rng.standard_normal(42) * np.repeat(10.0 ** -np.arange(7), 6) * 20.0)])
+    put(293, -243.911, 0.187654, 8.2e-06)                    # platinum polynomial, humidity-sensor temperature
+    put(305, 1.00177, 0.0153, -0.00013)
+    put(606, *[float(v) for v in (rng.standard_normal(18) * 0.3)])
+    put(630, 1.45)                                           # calP[24]: scale of the pressure ratio
+    put(678, 0.021, -0.0042, 0.0011)                         # pressure correction of the humidity capacitance
+    put(698, *[float(v) for v in (rng.standard_normal(12) * 0.05)])
+    c[2] = (((freq_khz - 400000) % 40) // 10) << 6           # 10 kHz steps in the two top bits, 40 kHz steps in the next byte
+    c[3] = (freq_khz - 400000) // 40
+    c[0x10 + 5:0x10 + 7] = int(fw).to_bytes(2, "little")
+    c[0x20 + 11] = burst_kill
+    c[0x20 + 7:0x20 + 9] = int(kill_timer).to_bytes(2, "little")
+    t9 = typ.encode("ascii")[:9].ljust(9, b"\0")
+    c[0x210 + 8:0x210 + 16] = t9[:8]
+    c[0x220] = t9[8]
+    c[0x221] = 0
+    c[0x222:0x22A] = rsm.encode("ascii")[:8].ljust(8, b"\0")
+    c[0x310 + 6:0x310 + 8] = int(burst_timer).to_bytes(2, "little")
+    c[0x320:0x322] = (0xFFFF).to_bytes(2, "little")          # countdown (variable subframe, outside the CRC)
+    c[0:2] = crc16_ccitt_false(bytes(c[2:800])).to_bytes(2, "little")
+    return bytes(c)
+
+
+def rs41_ptu_counts(rng: np.random.Generator) -> bytes:
+    """0x2A bytes of the measurement block: four sensors x (measurement, reference 1, reference 2) 24-bit counts, then the
+    pressure-sensor temperature (int16, 1/100 C) and padding — in ranges that give finite physical values."""
+    m = []
+    for lo, hi in ((131000, 189000), (520000, 570000), (131000, 189000), (300000, 420000)):
+        f1, f2 = 130000 + int(rng.integers(0, 500)), 190000 + int(rng.integers(0, 500))
+        if lo >= 300000:
+            f1, f2 = 290000 + int(rng.integers(0, 500)), 430000 + int(rng.integers(0, 500))
+        if lo >= 500000:
+            f1, f2 = 480000 + int(rng.integers(0, 500)), 560000 + int(rng.integers(0, 500))
+        m += [int(rng.integers(lo, hi)), f1, f2]
+    b = bytearray(0x2A)
+    for k, v in enumerate(m):
+        b[3 * k:3 * k + 3] = int(v).to_bytes(3, "little")
+    b[36:38] = bytes(rng.integers(0, 256, 2, dtype=np.uint8))
+    b[38:40] = int(rng.integers(-6000, 3000)).to_bytes(2, "little", signed=True)
+    b[40:42] = bytes(rng.integers(0, 256, 2, dtype=np.uint8))
+    return bytes(b)
+
+
 def rs41_frame(frame_no: int, sonde_id: str = "S1234567", *, week: int = 2280,
                itow_ms: int | None = None, ecef_cm=(412345600, 61234500, 480123400),
                vel_cms=(123, -45, 510), nsats: int = 9, batt_dV: int = 27,
-               rng: np.random.Generator | None = None) -> bytes:
-    """One valid standard (320-byte) RS41 frame with CRCs and RS parity."""
+               rng: np.random.Generator | None = None, cal_table: bytes | None = None, ptu_counts: bool = False,
+               xdata: list | None = None, gnss2: bool = False, corrupt_crc: int | None = None) -> bytes:
+    """One valid RS41 frame with CRCs and RS parity: standard 320 bytes, or 518 bytes when xdata (list of ASCII strings, one
+    0x7E block each) is given.  cal_table: the 51 x 16 table whose subframe (frame_no mod 51) the status block carries
+    (default: random bytes); ptu_counts: physical measurement counts instead of random bytes in the PTU block;
+    gnss2: the newer block layout (0x8226 position + UTC date/time, 0x8329 satellites) instead of the three u-blox 6 blocks;
+    corrupt_crc: block id whose CRC is broken BEFORE the RS parity is computed (ECC passes, the block CRC does not)."""
     rng = rng or np.random.default_rng(frame_no)
-    f = bytearray(RS41_FRAME_LEN)
+    flen = 518 if xdata is not None else RS41_FRAME_LEN
+    f = bytearray(flen)
     f[0:8] = RS41_HEADER_BYTES
-    f[0x38] = 0x0F
+    f[0x38] = 0xF0 if xdata is not None else 0x0F
     # 0x79 FRAME block, 0x28 bytes
     p = bytearray(0x28)
     p[0:2] = int(frame_no & 0xFFFF).to_bytes(2, "little")
@@ -112,10 +178,28 @@ def rs41_frame(frame_no: int, sonde_id: str = "S1234567", *, week: int = 2280,
     p[10] = batt_dV
     calidx = frame_no % 51
     p[0x52 - 0x3B] = calidx
-    p[0x53 - 0x3B:0x63 - 0x3B] = bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+    sub = bytes(rng.integers(0, 256, 16, dtype=np.uint8))
+    p[0x53 - 0x3B:0x63 - 0x3B] = sub if cal_table is None else cal_table[16 * calidx:16 * calidx + 16]
     _put_block(f, 0x39, 0x79, bytes(p))
-    # 0x7A PTU block, 0x2A bytes (opaque measurement counts)
-    _put_block(f, 0x65, 0x7A, bytes(rng.integers(0, 256, 0x2A, dtype=np.uint8)))
+    # 0x7A PTU block, 0x2A bytes (opaque measurement counts unless ptu_counts)
+    rnd = bytes(rng.integers(0, 256, 0x2A, dtype=np.uint8))
+    _put_block(f, 0x65, 0x7A, rs41_ptu_counts(rng) if ptu_counts else rnd)
+    if gnss2:
+        import datetime
+        t = datetime.datetime(2024, 5, 17, 11, 42, 7) + datetime.timedelta(seconds=frame_no)
+        p = bytearray(0x26)
+        for i in range(3):
+            p[4 * i:4 * i + 4] = int(ecef_cm[i]).to_bytes(4, "little", signed=True)
+            p[12 + 2 * i:14 + 2 * i] = int(vel_cms[i]).to_bytes(2, "little", signed=True)
+        p[18:20] = t.year.to_bytes(2, "little"); p[20] = t.month; p[21] = t.day; p[22] = t.hour; p[23] = t.minute; p[24] = t.second
+        p[25] = (7 * frame_no) % 100
+        p[26:] = bytes(rng.integers(0, 256, 0x26 - 26, dtype=np.uint8))
+        _put_block(f, 0x93, 0x82, bytes(p))
+        q = bytearray(rng.integers(0, 256, 0x29, dtype=np.uint8).tobytes())
+        q[4 + 21:4 + 21 + 16] = bytes([0x37 if k < 5 else 0x00 for k in range(16)])     # 10 satellites with a status nibble
+        _put_block(f, 0xBD, 0x83, bytes(q))
+        _put_block(f, 0xEA, 0x76, bytes(320 - 0xEA - 4))
+        return _rs41_finish(f, corrupt_crc)
     # 0x7C GPS1, 0x1E bytes: week, iTOW, sats
     p = bytearray(rng.integers(0, 256, 0x1E, dtype=np.uint8).tobytes())
     p[0:2] = int(week).to_bytes(2, "little")
@@ -134,9 +218,29 @@ def rs41_frame(frame_no: int, sonde_id: str = "S1234567", *, week: int = 2280,
     p[19] = 10
     p[20] = 12
     _put_block(f, 0x112, 0x7B, bytes(p))
-    # 0x76 zero block, 0x11 bytes
-    _put_block(f, 0x12B, 0x76, bytes(0x11))
-    assert 0x12B + 2 + 0x11 + 2 == RS41_FRAME_LEN
+    if xdata is None:
+        # 0x76 zero block, 0x11 bytes
+        _put_block(f, 0x12B, 0x76, bytes(0x11))
+        assert 0x12B + 2 + 0x11 + 2 == RS41_FRAME_LEN
+    else:
+        pos = 0x12B
+        for k, xs in enumerate(xdata):                        # 0x7E blocks: instrument byte + ASCII payload
+            pl = bytes([k]) + xs.encode("ascii")
+            _put_block(f, pos, 0x7E, pl)
+            pos += 2 + len(pl) + 2
+        _put_block(f, pos, 0x76, bytes(518 - pos - 4))        # zero block up to the end of the long frame
+    return _rs41_finish(f, corrupt_crc)
+
+
+def _rs41_finish(f: bytearray, corrupt_crc: int | None = None) -> bytes:
+    if corrupt_crc is not None:
+        pos = 0x39
+        while pos < len(f) - 4:
+            ln = f[pos + 1]
+            if f[pos] == corrupt_crc:
+                f[pos + 2 + ln] ^= 0x5A
+                break
+            pos += ln + 4
     # two interleaved RS(255,231) codewords, message zero-padded beyond byte 320
     msg1 = np.zeros(231, dtype=np.uint8)
     msg2 = np.zeros(231, dtype=np.uint8)

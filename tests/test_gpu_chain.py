@@ -80,3 +80,35 @@ def test_rs41_fm_chain_identical():
     a, b = _pipe(ours, x.tobytes()), _pipe(ref, x.tobytes())
     assert a == b
     assert sum(l.startswith("{") for l in a.decode().splitlines()) >= 3
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "rs41mod")), reason="compiled reference not present")
+def test_all_own_chains_json_identical():
+    """Everything from this repo, including the telemetry / JSON tier (include/sonde_rs41.h): the soft chain
+    iq_dec | fsk_demod | rs41mod --json --softin -i, and the direct IQ form rs41mod --ptu2 --json --IQ fq --lpIQ, against the same
+    commands built from the reference."""
+    from radiosonde_auto_rx_amd import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    table = synth.rs41_cal_table(seed=5, typ="RS41-SGP")
+    fk = dict(ECEF_OK, cal_table=table, ptu_counts=True)
+    x = synth.rs41_capture(sr=48_000, seconds=8.3, fq=0.0, n_frames=8, t_first=0.2, noise_sigma=0.03, seed=104, f_offset_hz=-800.0, first_frame_no=3, frame_kw=fk)
+    front = [["iq_dec", "--bo", "16", "-", "48000", "16"],
+             ["fsk_demod", "--cs16", "-b", "-20000", "-u", "20000", "-s", "--mask", "5000", "--nsym=300", "-p", "5", "2", "48000", "4800", "-", "-"],
+             ["rs41mod", "--ptu2", "--json", "--jsnsubfrm1", "--softin", "-i"]]
+    outs = []
+    for d in (BIN, REF):
+        data = x.tobytes()
+        for a in front:
+            r = subprocess.run([os.path.join(d, a[0])] + a[1:], input=data, capture_output=True, timeout=180, env=env)
+            assert r.returncode == 0, (a[0], r.stderr[-300:])
+            data = r.stdout
+        outs.append(data)
+    assert outs[0] == outs[1] and outs[0].count(b'"type": "RS41"') >= 6 and b'"temp"' in outs[0]
+    sr = 2_400_000
+    fq = synth.snap_fq(0.15, sr)
+    x = synth.rs41_capture(sr=sr, seconds=5.3, fq=fq, n_frames=5, t_first=0.15, noise_sigma=0.02, seed=105, first_frame_no=3, frame_kw=fk)
+    args = ["--ptu2", "--json", "--jsn_cfq", "403000000", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"]
+    a = subprocess.run([os.path.join(BIN, "rs41mod")] + args, input=x.tobytes(), capture_output=True, timeout=180, env=env)
+    b = subprocess.run([os.path.join(REF, "rs41mod")] + args, input=x.tobytes(), capture_output=True, timeout=180)
+    assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b'"freq": ') >= 4

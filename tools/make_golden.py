@@ -483,6 +483,59 @@ def gen_bin_lines(outdir):
     print("bin_lines", {k: len(v) for k, v in d.items()})
 
 
+# RS41 telemetry text / JSON (print_position): frame streams at the soft-bit level (no modulation involved), option sets
+FIELD_SCENARIOS = {
+    "fields_sgp_70": dict(n=70, typ="RS41-SGP", ptu=True),                         # full calibration cycle, pressure sensor
+    "fields_sg_60_newid": dict(n=60, typ="RS41-SG", ptu=True, new_id_at=55),        # no pressure sensor (barometric estimate); ID change
+    "fields_xdata_12": dict(n=12, typ="RS41-SG", ptu=True, xdata=["0501AB2C440F31", "0803Z9"]),   # 518-byte frames with two xdata blocks
+    "fields_gnss2_10": dict(n=10, typ="RS41-SGM", ptu=True, gnss2=True),             # 0x8226 / 0x8329 block layout
+    "fields_damaged_16": dict(n=16, typ="RS41-SG", ptu=True, damage=True),          # bad block CRCs under good ECC; frames beyond the ECC
+    "fields_random_8": dict(n=8, typ=None, ptu=False),                              # random subframes / PTU bytes (the other fixtures' frames)
+}
+FIELD_ARGS = [[], ["-v"], ["--ptu"], ["-v", "--ptu2", "--dewp"], ["--ptu2", "--json", "--jsnsubfrm1"], ["--json", "--jsnsubfrm2", "--jsn_cfq", "403000000"],
+              ["--ptu", "--json", "--silent"], ["-r", "--json"], ["--ecc", "--ptu"]]
+
+
+def fields_softbits(sc):
+    """float32 soft bits (+-1, a little noise) of a scenario's frame stream"""
+    rng = np.random.default_rng(7)
+    kw = dict(ecef_cm=(418833319, 85974133, 473346430))
+    table = synth.rs41_cal_table(seed=3, typ=sc["typ"]) if sc["typ"] else None
+    out = []
+    for k in range(sc["n"]):
+        sid = "T7654321" if sc.get("new_id_at") and k >= sc["new_id_at"] else "S1234567"
+        extra = {}
+        if sc.get("damage"):
+            extra["corrupt_crc"] = {3: 0x79, 5: 0x7A, 7: 0x7C, 9: 0x7B, 11: 0x7D, 13: 0x76}.get(k)
+        fr = synth.rs41_frame(1000 + k, sid, cal_table=table, ptu_counts=sc["ptu"], xdata=sc.get("xdata"), gnss2=sc.get("gnss2", False),
+                              vel_cms=(123 + 7 * k, -45 - 3 * k, 510 - 11 * k), rng=np.random.default_rng(900 + k), **kw, **extra)
+        bits = synth.rs41_onair_bits(fr).copy()
+        if sc.get("damage") and k in (4, 8, 12, 14):                       # beyond the ECC: one / the other / both codewords / everything
+            base = 40 * 8                                                  # bit index of frame byte 0
+            if k == 14:
+                idx = rng.choice(np.arange(base + 64, len(bits)), size=900, replace=False)
+            else:                                                          # 14 byte errors per codeword, inside the GPS2 block only
+                byts = np.arange(0xB8, 0x110)
+                par = [0] if k == 4 else [1] if k == 8 else [0, 1]
+                sel = np.concatenate([rng.choice(byts[byts % 2 == q], size=14, replace=False) for q in par])
+                idx = base + 8 * sel + rng.integers(0, 8, len(sel))
+            bits[idx] ^= 1
+        out.append(bits); out.append(np.zeros(4800 - len(bits), np.uint8))       # one frame per second at 4800 bit/s
+    b = np.concatenate(out)
+    return ((2.0 * b - 1.0) + 0.05 * rng.standard_normal(len(b))).astype("<f4")
+
+
+def gen_fields(outdir):
+    d = {}
+    for name, sc in FIELD_SCENARIOS.items():
+        soft = fields_softbits(sc)
+        for k, args in enumerate(FIELD_ARGS):
+            out, err, rc = bind.ref_run("rs41mod", args + ["--softin"], soft.tobytes())
+            d["%s|%d" % (name, k)] = np.frombuffer(out.encode(), np.uint8)
+        print(name, len(soft), [len(d["%s|%d" % (name, k)]) for k in range(len(FIELD_ARGS))])
+    np.savez_compressed(os.path.join(outdir, "rs41_fields.npz"), **d)
+
+
 def gen_rawhex(outdir):
     """--rawhex: frames as hex lines (clean, correctable, uncorrectable, short, truncated) through the reference's rs41mod"""
     lines = [str(l).split(" ")[0] for l in np.load(os.path.join(outdir, "fsk_rs41_48k_mask.npz"))["rs41_lines"]]
@@ -559,6 +612,7 @@ def main():
         gen_dc_case(name, case, outdir)
     gen_bin_lines(outdir)
     gen_rawhex(outdir)
+    gen_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_wide_demod(outdir)
     gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
