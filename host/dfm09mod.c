@@ -4,20 +4,47 @@
  * Reference contract kept for the IQ + raw form (reference demod/mod/dfm09mod.c:1338-1500 argv, :1198-1236 output):
  *     dfm09mod -r [--ecc|--ecc2] [--ths x] --IQ <fq> [--lpIQ | --lpbw kHz] [--min] - <sr> 16
  * stdout: per frame `<7 nibbles> [OK]   <13 nibbles> [OK]   <13 nibbles> [OK] ` ([KO] = corrected, [NO] = uncorrectable)
- * stderr: `IF:` / `dec:`; exit 0 at EOF, 255 on argument / init errors.  Field decode / JSON is the next tier.
+ * stderr: `IF:` / `dec:`; exit 0 at EOF, 255 on argument / init errors.  Without -r: the telemetry text line once per nine
+ * data packets and, with --json, the JSON object auto_rx parses (include/sonde_dfm.h; -v, -vv, --ptu, --dist, --json, --jsn_cfq, --sat).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "sonde_dfm.h"
 #include "wav_header.h"
+
+static sonde_dfm_dec_t *g_dec = NULL;
+static int g_raw = 0, g_ecc = 0;
+
+static int make_decoder(sonde_dfm_opts_t *o, int raw, int ecc, int opt_auto, int khz) {
+    const char *ver = getenv("SONDE_JSN_VERSION");
+    g_raw = raw; g_ecc = ecc;
+    if (raw && !o->json) return 0;
+    o->raw = raw; o->ecc = ecc; o->opt_auto = opt_auto; o->jsn_freq_khz = khz;
+#ifdef VER_JSN_STR
+    if (!ver) ver = VER_JSN_STR;
+#endif
+    if (ver) { strncpy(o->version, ver, sizeof o->version - 1); o->version[sizeof o->version - 1] = 0; }
+    return sonde_dfm_dec_create(o, &g_dec);
+}
+
+/* print_frame() (dfm09mod.c:1153-1262): raw line with -r, then what conf_out / dat_out / print_gpx print */
+static void emit_frame(const sonde_dfm_frame_t *f) {
+    static char ln[128], tx[4096];
+    if (g_raw) { sonde_dfm_rawline(f, g_ecc, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
+    if (g_dec && sonde_dfm_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
+}
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
     int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0;
     FILE *fp = stdin;
+    sonde_dfm_opts_t dopt;
+    int force_ecc = 0, cfreq = -1;
+    memset(&dopt, 0, sizeof dopt);
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_DFM09;
@@ -27,6 +54,13 @@ int main(int argc, char **argv) {
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
         else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
+        else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) dopt.verbose = 1;
+        else if (!strcmp(a, "-vv")) dopt.verbose = 2;
+        else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
+        else if (!strcmp(a, "--sat")) dopt.sat = 1;
+        else if (!strcmp(a, "--dist")) { dopt.dist = 1; force_ecc = 1; }
+        else if (!strcmp(a, "--json")) { dopt.json = 1; force_ecc = 1; }
+        else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
         else if (!strcmp(a, "--IQ")) {
             if (++i >= argc) return -1;
@@ -68,11 +102,12 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "dfm09mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
+    if (force_ecc) cfg.ecc_level = 1;               /* --dist / --json: option_ecc = 1 (dfm09mod.c:1487) */
     if (softin || opt_bin) {                                    /* float32 soft symbols on stdin (dfm09mod.c:1604-1720) */
-        if (!raw) { fprintf(stderr, "dfm09mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+        if (make_decoder(&dopt, raw, cfg.ecc_level, opt_auto, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;
         sonde_softin_t *si = NULL;
         if (sonde_softin_create(SONDE_DFM09, cfg.ecc_level, softin == 2, opt_inv, opt_auto, &si) < 0) return -1;
-        float sb[1024]; sonde_dfm_frame_t fr[8]; char ln[128]; size_t got;
+        float sb[1024]; sonde_dfm_frame_t fr[8]; size_t got;
         for (;;) {
             if (opt_bin && !softin) {                    /* --bin: one byte per bit (--softin wins if both are given) */
                 got = fread(sb, 1, 1024, fp);
@@ -84,7 +119,7 @@ int main(int argc, char **argv) {
             if (got < 1024) sonde_softin_finish(si);
             int k;
             while ((k = sonde_softin_fetch_dfm(si, fr, 8)) > 0)
-                for (int i = 0; i < k; i++) { sonde_dfm_rawline(&fr[i], cfg.ecc_level, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
+                for (int i = 0; i < k; i++) emit_frame(&fr[i]);
             if (got < 1024) break;
         }
         sonde_softin_destroy(si);
@@ -104,7 +139,10 @@ int main(int argc, char **argv) {
         cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
         cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
     }
-    if (!raw) { fprintf(stderr, "dfm09mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+    {   /* "freq" of the JSON: (cfreq - xlt_fq * sr + 500) / 1e3 (dfm09mod.c:1554-1557) */
+        const double xlt = (iq_mode == 5) ? -fq : 0.0;
+        if (make_decoder(&dopt, raw, cfg.ecc_level, opt_auto, cfreq > 0 ? (int)((cfreq - xlt * cfg.sample_rate + 500) / 1e3) : 0) < 0) return -1;
+    }
 
     cfg.n_channels = 1;
     cfg.max_chunk = cfg.sample_rate;
@@ -125,7 +163,6 @@ int main(int argc, char **argv) {
     if (chunk < info.decM) chunk = info.decM;
     int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
     sonde_dfm_frame_t frames[128];
-    char line[128];
     size_t have = 0;
     for (;;) {
         size_t got = fread((char *)buf + have, 1, (size_t)chunk * unit - have, fp);
@@ -136,7 +173,7 @@ int main(int argc, char **argv) {
             rc = sonde_engine_process_host(eng, buf, n, n);
             if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
             int k = sonde_engine_fetch_dfm(eng, frames, 128, 0);
-            for (int i = 0; i < k; i++) { sonde_dfm_rawline(&frames[i], cfg.ecc_level, line, sizeof line); fprintf(stdout, "%s\n", line); }
+            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
             memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
             have -= (size_t)n * unit;
         }
@@ -144,7 +181,7 @@ int main(int argc, char **argv) {
     }
     {
         int k = sonde_engine_fetch_dfm(eng, frames, 128, 1);
-        for (int i = 0; i < k; i++) { sonde_dfm_rawline(&frames[i], cfg.ecc_level, line, sizeof line); fprintf(stdout, "%s\n", line); }
+        for (int i = 0; i < k; i++) emit_frame(&frames[i]);
     }
     sonde_engine_destroy(eng);
     free(buf);

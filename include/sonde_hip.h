@@ -114,6 +114,9 @@ typedef struct {
     float    mv;
     uint8_t  conf[7], dat1[13], dat2[13];   /* data nibbles */
     uint8_t  pad[3];
+    float    frm_count;      /* gpx._frmcnt: mv_pos / (2 sps 280) + frame_in_hit, or headers seen * 8 + frame_in_hit for
+                              * soft / hard bit input (dfm09mod.c:1658-1663) — the time stamp of the telemetry decoder */
+    int32_t  inv;            /* polarity in effect for this frame (gpx.option.inv after -i / --auto)        */
 } sonde_dfm_frame_t;
 
 /* Derived constants of init_buffers() (demod_mod.c:1208-1474), for callers and tests. */

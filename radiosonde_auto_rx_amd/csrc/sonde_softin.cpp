@@ -29,6 +29,7 @@ struct sonde_softin {
     int byte_count = 8, b8pos = 0; uint8_t bitbuf[8];
     uint8_t frame[518];                       // gpx.frame persists across frames like the reference's
     float mv = 0.f; uint64_t bits_in = 0, hdr_bit = 0;
+    uint32_t hdrcnt = 0;                      // DFM: 8 per header seen (dfm09mod.c:1628,1632), base of the frame time stamp
     std::vector<sonde_frame_t> queue;
 };
 
@@ -86,6 +87,7 @@ int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
                 const float mv = (float)sum;
                 if (std::fabs(mv) > s->ths) {
                     int found = 1;
+                    s->hdrcnt += 8;
                     if (mv * (0.5 - s->opt_inv) < 0) { if (!s->opt_auto) found = 0; else s->opt_inv ^= 1; }
                     if (found) { s->state = 1; s->dpos = 16; s->dfrm = 0; s->dhalf = 0; s->mv = mv; s->hdr_bit = s->bits_in; }
                 }
@@ -99,6 +101,7 @@ int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
                 if (++s->dpos == 280) {
                     sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
                     o.channel = 0; o.frame_in_hit = s->dfrm; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+                    o.frm_count = (float)(s->hdrcnt + (uint32_t)s->dfrm); o.inv = s->opt_inv;
                     o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
                     o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
                     o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);
@@ -180,6 +183,7 @@ int sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n) {
             const float mv = hdr_bit_score(s->hbuf, s->bufpos, hdr, hl);
             if (std::fabs(mv) > thb) {
                 int found = 1;
+                s->hdrcnt += 8;
                 if (mv * (0.5 - s->opt_inv) < 0) { if (!s->opt_auto) found = 0; else s->opt_inv ^= 1; }
                 if (found) {
                     s->state = 1; s->mv = mv; s->hdr_bit = s->bits_in;
@@ -196,6 +200,7 @@ int sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n) {
             if (++s->dpos == 280) {
                 sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
                 o.channel = 0; o.frame_in_hit = s->dfrm; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+                o.frm_count = (float)(s->hdrcnt + (uint32_t)s->dfrm); o.inv = s->opt_inv;
                 o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
                 o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
                 o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);

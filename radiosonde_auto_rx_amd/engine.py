@@ -36,7 +36,8 @@ class SondeFrame(C.Structure):
 
 class SondeDfmFrame(C.Structure):
     _fields_ = [("channel", C.c_int32), ("frame_in_hit", C.c_int32), ("ecc", C.c_int32 * 3), ("mv_pos", C.c_uint32),
-                ("mv", C.c_float), ("conf", C.c_uint8 * 7), ("dat1", C.c_uint8 * 13), ("dat2", C.c_uint8 * 13), ("pad", C.c_uint8 * 3)]
+                ("mv", C.c_float), ("conf", C.c_uint8 * 7), ("dat1", C.c_uint8 * 13), ("dat2", C.c_uint8 * 13), ("pad", C.c_uint8 * 3),
+                ("frm_count", C.c_float), ("inv", C.c_int32)]
 
 
 class SondeInfo(C.Structure):

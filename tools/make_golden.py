@@ -536,6 +536,120 @@ def gen_fields(outdir):
     np.savez_compressed(os.path.join(outdir, "rs41_fields.npz"), **d)
 
 
+# DFM telemetry text / JSON (conf_out / dat_out / print_gpx): packet streams at the symbol level through `dfm09mod --softin`
+DFM_FIELD_SCENARIOS = {
+    "dfmf_09_40": dict(kind="09", n=40, sn=18012345),
+    "dfmf_17_40_inv": dict(kind="17", n=40, sn=23045678, inverted=True),
+    "dfmf_06_36": dict(kind="06", n=36, sn6=0x712345),
+    "dfmf_09p_44_errors": dict(kind="09P", n=44, sn=19054321, errors=True),
+    "dfmf_09_mode3_30": dict(kind="09", n=30, sn=18000111, mode=3),
+}
+DFM_FIELD_ARGS = [[], ["-v"], ["-vv", "--ecc", "--ptu"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["--json", "--ptu", "--jsn_cfq", "404500000"],
+                  ["-r", "--json", "--auto"], ["--ecc2", "-v", "--sat", "--auto"], ["--dist", "--ptu", "-i"]]
+
+
+def _f24(x):
+    """value -> the 24-bit code of a DFM measurement channel (4-bit exponent, 20-bit mantissa; value = mantissa / 2^exponent)"""
+    e = 0
+    while e < 15 and x * (1 << (e + 1)) < (1 << 20):
+        e += 1
+    return (e << 20) | (int(round(x * (1 << e))) & 0xFFFFF)
+
+
+def dfm_field_symbols(sc):
+    """float32 soft symbols (two per bit) of a DFM packet stream: configuration channels cycle, data packets 0..8 cycle"""
+    rng = np.random.default_rng(11)
+    kind, n, mode = sc["kind"], sc["n"], sc.get("mode", 2)
+
+    def nibs(val, cnt):
+        return [(val >> (4 * (cnt - 1 - i))) & 0xF for i in range(cnt)]
+    # configuration cycle
+    meas = {"09": [30000 + 9 * 7, 41000.5, 52000.25, 20000.0, 220000.0], "17": [45000.0, 41000.5, 52000.25, 20000.0, 332000.0],
+            "06": [24000.0 * 16, 300.5 * 16, 410.25 * 16, 10000.0 * 16, 220000.0 / 2 * 16, 777.0],
+            "09P": [61000.0, 33000 + 5.5, 52000.25, 1234.5, 4321.0, 20000.0, 220000.0, 3.0]}[kind]
+    conf = []
+    if kind == "06":
+        for c, v in enumerate(meas):
+            conf.append([c] + nibs(_f24(v), 6))
+        conf[5] = [5, 0xA, 0, 0, 0, 0, 0]                                   # the empty channel that marks a DFM-06
+        conf.append([6] + nibs(sc["sn6"], 6))
+    else:
+        top = {"09": 0xA, "17": 0xB, "09P": 0xC}[kind]
+        vals = list(meas)
+        if kind != "09P":
+            vals += [3.3 * 1000 / 16.0 * 0 + 0, 0]                          # placeholders replaced below
+        chans = []
+        for c in range(top - 1):
+            v = vals[c] if c < len(meas) else 0.0
+            chans.append([c] + nibs(_f24(v) if c < len(meas) else 0, 6))
+        ofs = 2 if kind == "09P" else 0
+        chans[5 + ofs] = [5 + ofs, 0] + nibs(3950, 4) + [0]                  # battery mV in the inner 16 bits
+        chans[6 + ofs] = [6 + ofs, 0] + nibs(29815, 4) + [0]                 # MCU temperature, 1/100 K
+        if 7 + ofs < top - 1:
+            chans[7 + ofs] = [7 + ofs, 0] + nibs(1234, 4) + [0]
+        chans.append([top - 1, 0, 0, 0, 0, 0, 0])                            # empty channel below the serial-number channel
+        conf = chans
+        sn = sc["sn"]
+        conf_sn = [[top, 0xC] + nibs(sn >> 16, 4) + [0], [top, 0xC] + nibs(sn & 0xFFFF, 4) + [1]]
+    frames = []
+    pk = 0
+    t0 = 11 * 3600 + 42 * 60 + 7
+    cyc = 0
+    for k in range(n):
+        if kind == "06":
+            cf = conf[k % len(conf)]
+        else:
+            m = k % (len(conf) + 1)
+            cf = conf[m] if m < len(conf) else conf_sn[(k // (len(conf) + 1)) % 2]
+        dats = []
+        for _ in range(2):
+            sec = t0 + cyc
+            lat, lon, alt = int((48.1 + 1e-4 * cyc) * 1e7), int((11.6 - 2e-4 * cyc) * 1e7), int((1234.5 + 5.1 * cyc) * 100)
+            d = [0] * 12
+            if mode == 2:
+                body = {0: (0 << 32) | (mode << 24) | ((cyc + 40) & 0xFF) << 16, 1: (0x00A4C213 << 16) | ((sec % 60) * 1000 + 250),
+                        2: (lat << 16) | 1234, 3: (lon << 16) | 27150, 4: (alt << 16) | ((-321) & 0xFFFF), 5: ((-4712) & 0xFFFF) << 32,
+                        6: int(rng.integers(0, 1 << 48)), 7: int(rng.integers(0, 1 << 48))}
+            else:
+                body = {0: (((sec % 60) * 1000 + 250) << 32) | (mode << 24) | (((cyc + 40) & 0xFF) << 16) | 1234,
+                        1: (lat << 16) | 27150, 2: (lon << 16) | ((-321) & 0xFFFF), 3: (alt << 16), 4: int(rng.integers(0, 1 << 48)),
+                        5: (lat << 16) | 1200, 6: (lon << 16) | 27000, 7: (alt << 16) | ((-300) & 0xFFFF)}
+            if pk == 8:
+                hh, mm = (sec // 3600) % 24, (sec // 60) % 60
+                v = (2024 << 36) | (5 << 32) | (17 << 27) | (hh << 22) | (mm << 16) | (9 << 8)
+            else:
+                v = body[pk] & ((1 << 48) - 1)
+            dats.append(nibs(v, 12) + [pk])
+            pk += 1
+            if pk == 9:
+                pk = 0; cyc += 1
+        frames.append(synth.dfm_frame_bits(cf, dats[0], dats[1]))
+    bits = np.concatenate(frames)
+    if sc.get("errors"):
+        for k in range(6, n, 5):                                             # single errors (corrected), doubles (uncorrectable), bursts
+            lo = 280 * k
+            idx = lo + rng.choice(np.arange(16, 280), size=[1, 2, 9, 30][(k // 5) % 4], replace=False)
+            bits[idx] ^= 1
+    sym = np.empty(2 * len(bits), np.uint8)
+    sym[0::2] = 1 - bits; sym[1::2] = bits                                   # Manchester: 1 -> 01, 0 -> 10
+    pre = np.tile(np.array([1, 0], np.uint8), 40)
+    s = 2.0 * np.concatenate([pre, sym, pre]) - 1.0
+    if sc.get("inverted"):
+        s = -s
+    return (s + 0.05 * rng.standard_normal(len(s))).astype("<f4")
+
+
+def gen_dfm_fields(outdir):
+    d = {}
+    for name, sc in DFM_FIELD_SCENARIOS.items():
+        soft = dfm_field_symbols(sc)
+        for k, args in enumerate(DFM_FIELD_ARGS):
+            out, err, rc = bind.ref_run("dfm09mod", args + ["--softin"], soft.tobytes())
+            d["%s|%d" % (name, k)] = np.frombuffer(out.encode(), np.uint8)
+        print(name, len(soft), [len(d["%s|%d" % (name, k)]) for k in range(len(DFM_FIELD_ARGS))])
+    np.savez_compressed(os.path.join(outdir, "dfm_fields.npz"), **d)
+
+
 def gen_rawhex(outdir):
     """--rawhex: frames as hex lines (clean, correctable, uncorrectable, short, truncated) through the reference's rs41mod"""
     lines = [str(l).split(" ")[0] for l in np.load(os.path.join(outdir, "fsk_rs41_48k_mask.npz"))["rs41_lines"]]
@@ -613,6 +727,7 @@ def main():
     gen_bin_lines(outdir)
     gen_rawhex(outdir)
     gen_fields(outdir)
+    gen_dfm_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_wide_demod(outdir)
     gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
