@@ -1,0 +1,51 @@
+"""ctypes bindings of the telemetry tier (include/sonde_rs41.h, include/sonde_dfm.h): frames -> the reference's text / JSON.
+
+Host-side, no GPU involved.  `Rs41Telemetry.decode(frame_dict)` takes what Engine.fetch_frames() returns and gives back the
+characters `rs41mod` prints for that frame; `.json(frame_dict)` parses the JSON object out of them (None if the frame did not
+qualify for one — block CRCs of ID, time and position must be good, like the reference)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+from .engine import SondeFrame, SondeError, lib
+
+
+class Rs41Opts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("verbose", "ptu", "dewp", "json", "jsn_subfrm", "silent", "jsn_freq_khz")] + \
+               [("version", C.c_char * 32), ("reserved", C.c_int32 * 4)]
+
+
+class Rs41Telemetry:
+    def __init__(self, *, ptu: int = 2, verbose: int = 0, jsn_subfrm: int = 0, freq_khz: int = 0, version: str = "sonde_hip", silent: bool = False):
+        L = lib()
+        L.sonde_rs41_dec_create.argtypes = [C.POINTER(Rs41Opts), C.POINTER(C.c_void_p)]
+        L.sonde_rs41_dec_frame.argtypes = [C.c_void_p, C.POINTER(SondeFrame), C.c_char_p, C.c_size_t]
+        L.sonde_rs41_dec_destroy.argtypes = [C.c_void_p]
+        o = Rs41Opts(verbose=verbose, ptu=ptu, json=1, jsn_subfrm=jsn_subfrm, silent=int(silent), jsn_freq_khz=freq_khz, version=version.encode())
+        self._h = C.c_void_p()
+        if L.sonde_rs41_dec_create(C.byref(o), C.byref(self._h)) < 0:
+            raise SondeError("sonde_rs41_dec_create: unsupported options")
+        self._buf = C.create_string_buffer(16384)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sonde_rs41_dec_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def decode(self, frame: dict) -> str:
+        f = SondeFrame(channel=frame["channel"], len=frame["len"], ecc=frame["ecc"], mv_pos=frame["mv_pos"], mv=frame["mv"], nbytes=frame["nbytes"])
+        raw = bytes(frame["frame"])
+        C.memmove(f.frame, raw + bytes(518 - len(raw)), 518)
+        n = lib().sonde_rs41_dec_frame(self._h, C.byref(f), self._buf, len(self._buf))
+        if n < 0:
+            raise SondeError("sonde_rs41_dec_frame failed")
+        return self._buf.value.decode(errors="replace")
+
+    def json(self, frame: dict):
+        for line in self.decode(frame).splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return None

@@ -1,0 +1,105 @@
+"""One wideband IQ stream -> every RS41 in it, in one process on one GPU.
+
+The reference handles a wideband source by starting one detector process per candidate peak (auto_rx/autorx/scan.py:413-656:
+rtl_power peaks -> `dft_detect` per peak) and then one decoder pipeline per sonde (decode.py).  Here the same two steps run
+batched over a frequency raster: a Scanner whose channels all mix their own fq out of the shared stream (`dft_detect --IQ fq
+--dc` per raster point, channel stride 0), and one demodulator Engine per detected sonde fed from the same chunks, followed by the
+telemetry tier.  Everything sample-rate runs on the GPU; this module is the orchestration auto_rx does in Python.
+
+    python -m radiosonde_auto_rx_amd.wideband --cfreq 403000000 --raster 10000 - 2400000 16 < capture.cs16
+
+prints one JSON object per decoded frame (the reference's `rs41mod --json` object, "freq" = channel frequency in kHz).
+"""
+from __future__ import annotations
+
+import json
+import sys
+
+import numpy as np
+
+from .engine import Engine
+from .scan import Scanner
+from .synth import snap_fq
+from .telemetry import Rs41Telemetry
+
+
+class WidebandReceiver:
+    def __init__(self, sample_rate: int, *, cfreq_hz: int = 0, raster_hz: int = 10_000, span: float = 0.45, chunk: int | None = None,
+                 merge_hz: float = 6_000.0, version: str = "sonde_hip"):
+        self.sr, self.cfreq, self.merge_hz, self.version = sample_rate, cfreq_hz, merge_hz, version
+        kmax = int(span * sample_rate / raster_hz)
+        self.raster = [snap_fq(k * raster_hz / sample_rate, sample_rate) for k in range(-kmax, kmax + 1)]
+        self.chunk = chunk or sample_rate // 4
+        self.scanner = Scanner(sample_rate, fq=self.raster, dc=True, cont=True, max_chunk=self.chunk)
+        D = self.scanner.info["decM"]
+        self.chunk -= self.chunk % D
+        self.sondes: list[dict] = []           # {fq, engine, telemetry, type, frames}
+        self.log: list[dict] = []
+
+    def _start(self, fq: float, typ: str):
+        for s in self.sondes:
+            if abs(s["fq"] - fq) * self.sr < self.merge_hz:
+                return
+        fq = snap_fq(fq, self.sr)
+        khz = int(round((self.cfreq + fq * self.sr) / 1000.0)) if self.cfreq else 0
+        eng = Engine([fq], self.sr, max_chunk=self.chunk, max_frames=8)
+        self.sondes.append(dict(fq=fq, type=typ, engine=eng, telemetry=Rs41Telemetry(freq_khz=khz, version=self.version), frames=0, khz=khz))
+        self.log.append(dict(event="detected", type=typ, fq=fq, freq_khz=khz))
+
+    def push(self, iq: np.ndarray, finish: bool = False):
+        """iq: interleaved int16 I/Q, a whole number of chunks is not required; returns the JSON objects of this call."""
+        out = []
+        n = len(iq) // 2
+        D = self.scanner.info["decM"]
+        for s0 in range(0, n - n % D, self.chunk):
+            x = iq[2 * s0:2 * min(n - n % D, s0 + self.chunk)]
+            self.scanner.process_host(x, shared=True)
+            for d in self.scanner.fetch():
+                if d["type"] == "RS41" and d["score"] > 0:
+                    self._start(self.raster[d["channel"]] + d["df"], "RS41")
+            for s in self.sondes:
+                s["engine"].process_host(x)
+                for fr in s["engine"].fetch_frames():
+                    js = s["telemetry"].json(fr)
+                    s["frames"] += 1
+                    if js is not None:
+                        out.append(js)
+        if finish:
+            for s in self.sondes:
+                for fr in s["engine"].fetch_frames(finish=True):
+                    js = s["telemetry"].json(fr)
+                    if js is not None:
+                        out.append(js)
+        return out
+
+    def close(self):
+        self.scanner.close()
+        for s in self.sondes:
+            s["engine"].close(); s["telemetry"].close()
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--cfreq", type=int, default=0, help="centre frequency of the stream in Hz (for the JSON freq field)")
+    ap.add_argument("--raster", type=int, default=10_000, help="scanner raster in Hz")
+    ap.add_argument("dash"); ap.add_argument("sr", type=int); ap.add_argument("bits", type=int)
+    a = ap.parse_args(argv)
+    if a.dash != "-" or a.bits != 16:
+        ap.error("input is `- <sr> 16` (cs16 on stdin)")
+    rx = WidebandReceiver(a.sr, cfreq_hz=a.cfreq, raster_hz=a.raster)
+    inp = sys.stdin.buffer
+    while True:
+        buf = inp.read(rx.chunk * 4)
+        if not buf:
+            break
+        last = len(buf) < rx.chunk * 4
+        for js in rx.push(np.frombuffer(buf[:len(buf) // 4 * 4], np.int16), finish=last):
+            print(json.dumps(js), flush=True)
+        if last:
+            break
+    rx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,3 +112,42 @@ def test_all_own_chains_json_identical():
     a = subprocess.run([os.path.join(BIN, "rs41mod")] + args, input=x.tobytes(), capture_output=True, timeout=180, env=env)
     b = subprocess.run([os.path.join(REF, "rs41mod")] + args, input=x.tobytes(), capture_output=True, timeout=180)
     assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b'"freq": ') >= 4
+
+
+def test_wideband_receiver_finds_and_decodes_all_sondes():
+    """One 2.4 Msps stream with three RS41 (different IDs, offsets off the raster, one starting late) and nothing else told to the
+    receiver: the raster scanner finds each, a demodulator is started per sonde, every later frame comes out as the telemetry JSON
+    with the right ID / frequency; positions are what the frames carry."""
+    from radiosonde_auto_rx_amd import synth
+    from radiosonde_auto_rx_amd.wideband import WidebandReceiver
+    sr = 2_400_000
+    cf = 403_000_000
+    sig = [dict(id="A1111111", hz=+203_400.0, t=0.2, amp=0.25, lat=(418833319, 85974133, 473346430)),
+           dict(id="B2222222", hz=-512_900.0, t=0.5, amp=0.2, lat=(418833319, 85974133, 473346430)),
+           dict(id="C3333333", hz=+861_000.0, t=2.3, amp=0.15, lat=(418833319, 85974133, 473346430))]
+    secs = 7.3
+    n = int(sr * secs)
+    x = np.zeros(n, np.complex128)
+    rng = np.random.default_rng(5)
+    for k, s in enumerate(sig):
+        cap = synth.rs41_capture(sr=sr, seconds=secs, fq=0.0, n_frames=int(secs - s["t"]), t_first=s["t"], noise_sigma=0.0, amp=s["amp"], seed=200 + k,
+                                 sonde_id=s["id"], first_frame_no=100 * (k + 1),
+                                 frame_kw=dict(ecef_cm=s["lat"], cal_table=synth.rs41_cal_table(seed=k, freq_khz=int(round((cf + s["hz"]) / 10000.0)) * 10)))
+        z = (cap[0::2].astype(np.float64) + 1j * cap[1::2].astype(np.float64)) / (32767 * 0.9)
+        x += z * np.exp(2j * np.pi * s["hz"] / sr * np.arange(n))
+    x += 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767); iq[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767)
+    rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000)
+    out = rx.push(iq, finish=True)
+    found = {s["khz"] for s in rx.sondes}
+    rx.close()
+    assert len(rx.sondes) == 3, rx.log
+    for s in sig:
+        want_khz = int(round((cf + s["hz"]) / 1000.0))
+        assert any(abs(k - want_khz) <= 2 for k in found), (want_khz, found)
+        mine = [j for j in out if j["id"] == s["id"]]
+        assert len(mine) >= int(secs - s["t"]) - 3, (s["id"], len(mine))
+        # "freq" is the channel frequency until the sonde's own configuration subframe 0 has been seen, then the transmitted one (10 kHz steps)
+        assert all(abs(j["freq"] - want_khz) <= 6 and abs(j["lat"] - 48.1) < 1e-4 and abs(j["alt"] - 12300) < 1 for j in mine), mine[:2]
+        assert [j["frame"] for j in mine] == sorted(j["frame"] for j in mine)
