@@ -37,6 +37,9 @@ extern "C" {
                                  * IF low-pass / FM discriminator / FM low-pass); results are read with sonde_engine_read_tap */
 #define SONDE_DFM09  9          /* dfm09mod.c:1309,1560-1582: 2500 Bd Manchester, BT 0.5, h 1.8, 32-symbol raw header,
                                  * thres 0.65, hdmax 2, lpIQ 12 kHz, 8 x 280-bit frames sliced per header hit       */
+#define SONDE_M10    10         /* m10mod.c:55,76,1370-1390,1436-1510: 9615 Bd Manchester, BT 1.8, h 0.9, 32-symbol raw header compared
+                                 * per symbol, thres 0.76, hdmax 2; 968 differentially coded bits per frame, then the rest of the
+                                 * second (5 x 808 bits) is skipped; either polarity */
 
 /* input forms (dsp.opt_iq of demod_mod.h:62; rs41mod.c:2674-2687,2786-2803) */
 #define SONDE_IN_IQ    0        /* baseband IQ, mixed by -fq and decimated to the IF rate (opt_iq = 5)        */
@@ -164,6 +167,23 @@ int  sonde_engine_fetch_frames_lagged(sonde_engine_t *e, sonde_frame_t *out, int
  * = none / --ecc / --ecc2 (soft 2-bit pass).  finish != 0: end of input, also emits the complete frames of a hit
  * in progress (a partial frame is dropped like dfm09mod.c:1713). */
 int  sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish);
+/* One M10 / M10+ / M2K2 frame = what m10mod's print_frame() sees after differential decoding (m10mod.c:1049-1070,1484). */
+typedef struct {
+    int32_t  channel;
+    int32_t  nbits;          /* bits sliced (968 unless the stream ended inside the frame)                  */
+    int32_t  len;            /* 101 + aux length (frame byte 0 - 0x64 when that is 1..20)                   */
+    int32_t  cs_ok;          /* transmitted checksum == computed one                                        */
+    uint32_t cs_calc;        /* checkM10() over len - 2 bytes (m10mod.c:594-628)                            */
+    uint32_t mv_pos;
+    float    mv;
+    uint8_t  frame[124];     /* 101 + 20 bytes, big-endian bits                                             */
+} sonde_m10_frame_t;
+/* SONDE_M10 engines: frames completed so far; finish != 0 = end of input (a frame in progress is emitted with the bits that
+ * exist, m10mod.c:1486-1490). */
+int  sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish);
+/* Raw text line of `m10mod -r [-v]` (m10mod.c:1112-1123): hex bytes, with verbose " # <checksum> [OK]|[NO]"; buf >= 280 */
+int  sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen);
+
 /* Raw text line of `dfm09mod -r [--ecc]` (dfm09mod.c:1198-1236); returns strlen. buf >= 96 bytes */
 int  sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, size_t buflen);
 

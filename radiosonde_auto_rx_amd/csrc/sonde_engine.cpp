@@ -74,7 +74,8 @@ struct sonde_engine {
     uint32_t dc_cnt = 0, dc_max = 0, dc_lim = 0;
     // results of the last fetch
     std::vector<float> last_soft; int last_n = 0;
-    std::vector<uint8_t> last_frame;   // [n_ch][518] gpx.frame of the reference persists across frames
+    std::vector<uint8_t> last_frame;
+    std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
     // profiling
     bool prof = false, prof_skip = false; int prof_level = 2; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
@@ -160,7 +161,7 @@ const char *sonde_strerror(int code) {
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
-    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
+    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->opt_nolut && (cfg->opt_dc || cfg->input != SONDE_IN_IQ)) return SONDE_E_ARG;     // --noLUT folds Df into the base-rate mixer: not with --dc here
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
@@ -182,6 +183,10 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
         e->baud = 4800.f; e->bt = 0.5f; e->hmod = 0.6f; e->symlen = 1; e->symhd = 1; e->hdmax = 4; e->bitofs = 2;
         e->nbits = 510 * 8; e->l_win = 2.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
         header = kRs41Header; lpiq_def = 7400; lpfm_bw = 6000;
+    } else if (cfg->sonde_type == SONDE_M10) {   // m10mod.c:55,76,1178-1181,1370-1390,1454-1476: Manchester bits, header compared per symbol
+        e->baud = 9615.f; e->bt = 1.8f; e->hmod = 0.9f; e->symlen = 2; e->symhd = 1; e->hdmax = 2; e->bitofs = 0;      // m10mod.c:1184: bitofs 0
+        e->nbits = (101 + 20) * 8; e->l_win = 4.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.76f;
+        header = kM10RawHeader; lpiq_def = 24000; lpfm_bw = 10000;
     } else {   // DFM06/09 (dfm09mod.c:1309-1312,1560-1582,1690-1694): 264 + 7*280 Manchester bits per header hit
         e->baud = 2500.f; e->bt = 0.5f; e->hmod = 1.8f; e->symlen = 2; e->symhd = 2; e->hdmax = 2; e->bitofs = 2;
         e->nbits = 264 + 7 * 280; e->l_win = 4.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.65f;
@@ -226,7 +231,11 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     M = p2;
     const int K = M - L - delay;
     { const float nh = -e->hmod; const float hs = nh * sr; const double f1 = hs / (2.0 * e->sps); e->rho = -f1 / (double)sr; }
-    { uint32_t q0, q1; double mid; bit_window(e->nbits - 1, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1; }
+    {   // samples the framer consumes behind a header before the search resumes: all nbits — M10: the rest of the second as well
+        // (bits up to 5 x 808 are read and dropped, m10mod.c:1494-1507)
+        const int last = cfg->sonde_type == SONDE_M10 ? 5 * 808 - 1 : e->nbits - 1;
+        uint32_t q0, q1; double mid; bit_window(last, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1;
+    }
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
     int ring = 1; while (ring < max_if + (int)e->frame_samples + 2 * M + 4096 || ring < 4 * M) ring <<= 1;
@@ -572,7 +581,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
     s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
-    s.opt_auto = e->cfg.opt_auto != 0;
+    s.opt_auto = e->cfg.opt_auto != 0 || e->cfg.sonde_type == SONDE_M10;      // M10: either polarity (differential coding)
     s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
@@ -679,6 +688,40 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
             o.ecc[1] = dfm_block(e->cfg.ecc_level, hb + 72, sf + 72, 13, o.dat1);
             o.ecc[2] = dfm_block(e->cfg.ecc_level, hb + 176, sf + 176, 13, o.dat2);
         }
+    }
+    const bool ovf = e->overflow; e->overflow = false;
+    return ovf ? SONDE_E_OVERFLOW : n;
+}
+
+int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish) {
+    if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_M10) return SONDE_E_ARG;
+    if (finish) launch_framesync(e, 1);
+    std::vector<FrameRec> recs;
+    std::vector<float> soft;
+    const int n = collect_records(e, 0, recs, &soft, max);
+    if (n < 0) return n;
+    e->last_soft = soft; e->last_n = n;
+    const int NB = (101 + 20) * 8;
+    if (e->m10_bits.empty()) e->m10_bits.assign((size_t)e->cfg.n_channels * (NB + 8), 0);
+    for (int h = 0; h < n; h++) {
+        const FrameRec &r = recs[h];
+        sonde_m10_frame_t &o = out[h];
+        memset(&o, 0, sizeof o);
+        char *fb = e->m10_bits.data() + (size_t)r.channel * (NB + 8);
+        const int nv = std::min(r.nbytes, NB);                      // nbytes = valid bits of the hit
+        int bit0 = '0';                                             // differential decoding: 1 = same as the previous bit (m10mod.c:1484)
+        for (int p = 0; p < nv; p++) { const int bit = (r.frame[p >> 3] >> (p & 7)) & 1; fb[p] = (char)(0x31 ^ (bit0 ^ bit)); bit0 = bit; }
+        fb[nv] = 0;
+        for (int i = 0; i < 121; i++) {                             // bits2bytes, big endian; anything but '1' counts as 0 (m10mod.c:141-166)
+            int v = 0;
+            for (int k = 0; k < 8; k++) if (fb[8 * i + 7 - k] == '1') v |= 1 << k;
+            o.frame[i] = (uint8_t)v;
+        }
+        int aux = o.frame[0] - 0x64;
+        if (aux < 0 || aux > 20) aux = 0;
+        o.channel = r.channel; o.nbits = nv; o.len = 101 + aux; o.mv = r.mv; o.mv_pos = r.mv_pos;
+        o.cs_calc = (uint32_t)m10_checksum(o.frame, 99 + aux);
+        o.cs_ok = ((uint32_t)((o.frame[99 + aux] << 8) | o.frame[100 + aux]) == o.cs_calc);
     }
     const bool ovf = e->overflow; e->overflow = false;
     return ovf ? SONDE_E_OVERFLOW : n;

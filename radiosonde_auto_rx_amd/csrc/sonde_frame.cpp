@@ -182,6 +182,24 @@ int rs41_ecc(uint8_t frame[518], int frmlen, int level, const uint8_t *synd) {
 
 // ---- DFM: Hamming(8,4), systematic generator / parity check of dfm09mod.c:181-195; de-interleave :231
 const char kDfmRawHeader[33] = "10011010100110010101101001010101";
+const char kM10RawHeader[33] = "10011001100110010100110010011001";       // m10mod.c:76
+
+// M10 frame checksum: a 16-bit register stepped once per byte; the low byte mixes the rotated-and-folded input byte with two
+// parity folds of the old register, the old low byte moves up (m10mod.c:594-628).
+int m10_checksum(const uint8_t *msg, int len) {
+    int c = 0;
+    for (int i = 0; i < len; i++) {
+        uint8_t b = msg[i];
+        b = (uint8_t)((b >> 1) | ((b & 1) << 7));
+        b ^= (b >> 2) & 0xFF;
+        const int t6 = (c & 1) ^ ((c >> 2) & 1) ^ ((c >> 4) & 1), t7 = ((c >> 1) & 1) ^ ((c >> 3) & 1) ^ ((c >> 5) & 1);
+        const int t = (c & 0x3F) | (t6 << 6) | (t7 << 7);
+        int sreg = (c >> 7) & 0xFF;
+        sreg ^= (sreg >> 2) & 0xFF;
+        c = (((c & 0xFF) << 8) | ((b ^ t ^ sreg) & 0xFF)) & 0xFFFF;
+    }
+    return c & 0xFFFF;
+}
 
 static void dfm_codeword(int n, uint8_t *c) {
     const uint8_t d[4] = { (uint8_t)((n >> 3) & 1), (uint8_t)((n >> 2) & 1), (uint8_t)((n >> 1) & 1), (uint8_t)(n & 1) };
@@ -243,6 +261,13 @@ int sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, size
         for (int i = 0; i < len[b]; i++) n += snprintf(buf + n, buflen - n, "%01X", blk[b][i]);
         if (ecc_level) n += snprintf(buf + n, buflen - n, f->ecc[b] == 0 ? " [OK] " : f->ecc[b] > 0 ? " [KO] " : " [NO] ");
     }
+    return n;
+}
+int sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen) {
+    if (!f || !buf || f->len < 101 || f->len > 121 || buflen < (size_t)(2 * f->len + 20)) return SONDE_E_ARG;
+    int n = 0;
+    for (int i = 0; i < f->len; i++) n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
+    if (verbose) n += snprintf(buf + n, buflen - n, " # %04x%s", f->cs_calc, f->cs_ok ? " [OK]" : " [NO]");
     return n;
 }
 int sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen) {

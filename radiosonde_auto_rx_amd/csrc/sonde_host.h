@@ -36,6 +36,8 @@ int  rs41_frametype(const uint8_t *frame);
 int  rs41_ecc(uint8_t frame[518], int frmlen, int level, const uint8_t *synd);
 
 extern const char kDfmRawHeader[33];
+extern const char kM10RawHeader[33];
+int  m10_checksum(const uint8_t *msg, int len);          // checkM10 (m10mod.c:594-628)
 int  dfm_block(int level, const uint8_t *hb, const float *sb, int L, uint8_t *nib);
 
 }  // namespace sonde

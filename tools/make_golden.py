@@ -288,6 +288,33 @@ def gen_wide_demod(outdir):
     np.savez_compressed(os.path.join(outdir, "demod_wide_10M.npz"), **d)
 
 
+# M10 through the demodulator (m10mod -r -v): reference stdout / stderr / exit code per input form
+M10_CASES = {
+    "m10_48k_IQ": dict(cap=dict(sr=48_000, seconds=4.2, noise_sigma=0.02, seed=3, f_offset_hz=300.0), args=["-r", "-v", "--IQ", "0.0", "--lpIQ", "-", "SR", "16"]),
+    "m10_48k_iq2": dict(cap=dict(sr=48_000, seconds=3.2, noise_sigma=0.03, seed=4, f_offset_hz=-500.0), args=["-r", "-v", "--iq2", "-", "SR", "16"]),
+    "m10_48k_iq0_lpIQ": dict(cap=dict(sr=48_000, seconds=3.2, noise_sigma=0.03, seed=5), args=["-r", "--iq0", "--lpIQ", "-", "SR", "16"]),
+    "m10_2400k_IQ": dict(cap=dict(sr=2_400_000, seconds=2.5, fq=0.11, noise_sigma=0.02, seed=6, f_offset_hz=200.0), args=["-r", "-v", "--IQ", "FQ", "--lpIQ", "-", "SR", "16"]),
+    "m10_2400k_IQ_dc": dict(cap=dict(sr=2_400_000, seconds=3.4, fq=-0.2, noise_sigma=0.02, seed=7, f_offset_hz=1500.0), args=["-r", "-v", "--IQ", "FQ", "--lpIQ", "--dc", "-", "SR", "16"]),
+    "m10_48k_audio": dict(cap=dict(sr=48_000, seconds=3.2, noise_sigma=0.02, seed=8), audio=True, args=["-r", "-v"]),
+    "m10_48k_IQ_trunc": dict(cap=dict(sr=48_000, seconds=2.2, noise_sigma=0.02, seed=9), trunc=0.45 + 0.06, args=["-r", "-v", "--IQ", "0.0", "--lpIQ", "-", "SR", "16"]),
+    "m10_aux_48k_IQ": dict(cap=dict(sr=48_000, seconds=3.2, noise_sigma=0.02, seed=10, type_bytes=(0x76, 0x9F)), args=["-r", "-v", "--IQ", "0.0", "-", "SR", "16"]),
+}
+
+
+def m10_capture_cli(case):
+    """-> (stdin bytes, argv)"""
+    cap = dict(case["cap"]); sr = cap["sr"]
+    if "fq" in cap:
+        cap["fq"] = synth.snap_fq(cap["fq"], sr)
+    x = synth.m10_capture(**cap)
+    if case.get("trunc"):
+        x = x[:2 * int(case["trunc"] * sr)]
+    args = [repr(cap.get("fq", 0.0)) if a == "FQ" else str(sr) if a == "SR" else a for a in case["args"]]
+    if case.get("audio"):
+        return synth.wav_bytes(synth.fm_audio(x), sr), args
+    return x.tobytes(), args
+
+
 def gen_cli_cases(cases, capture, outdir):
     for name, case in cases.items():
         stdin, args = capture(case)
@@ -729,6 +756,7 @@ def main():
     gen_fields(outdir)
     gen_dfm_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
+    gen_cli_cases({k: dict(v, binary="m10mod") for k, v in M10_CASES.items()}, m10_capture_cli, outdir)
     gen_wide_demod(outdir)
     gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
     for name, case in INV_CASES.items():
