@@ -151,3 +151,30 @@ def test_wideband_receiver_finds_and_decodes_all_sondes():
         # "freq" is the channel frequency until the sonde's own configuration subframe 0 has been seen, then the transmitted one (10 kHz steps)
         assert all(abs(j["freq"] - want_khz) <= 6 and abs(j["lat"] - 48.1) < 1e-4 and abs(j["alt"] - 12300) < 1 for j in mine), mine[:2]
         assert [j["frame"] for j in mine] == sorted(j["frame"] for j in mine)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "dfm09mod")), reason="compiled reference not present")
+def test_dfm_iq_json_identical():
+    """DFM09 telemetry packet stream, GFSK-modulated at 2.4 Msps: this repo's `dfm09mod -vv --ecc --json --dist --auto --IQ fq --lpIQ` (GPU
+    demodulator + host framer + DFM telemetry tier) prints what the reference prints on the same samples — text lines, JSON, the
+    frame time stamps derived from the header sample positions included."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    from radiosonde_auto_rx_amd import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sym = (make_golden.dfm_field_symbols(dict(kind="09", n=26, sn=18012345)) > 0).astype(np.uint8)
+    sr = 2_400_000
+    fq = synth.snap_fq(-0.12, sr)
+    z = 0.4 * synth.gfsk_baseband(sym, sr, 2500.0, 2400.0)
+    n = len(z)
+    rng = np.random.default_rng(9)
+    z = z * np.exp(2j * np.pi * fq * np.arange(n)) + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.round(z.real * 32767 * 0.9), -32768, 32767); iq[1::2] = np.clip(np.round(z.imag * 32767 * 0.9), -32768, 32767)
+    args = ["-vv", "--ecc", "--json", "--dist", "--auto", "--ptu", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"]
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    a = subprocess.run([os.path.join(BIN, "dfm09mod")] + args, input=iq.tobytes(), capture_output=True, timeout=180, env=env)
+    b = subprocess.run([os.path.join(REF, "dfm09mod")] + args, input=iq.tobytes(), capture_output=True, timeout=180)
+    assert a.returncode == 0 and a.stdout == b.stdout
+    assert a.stdout.count(b'"type": "DFM"') >= 2 and b"DFM-18012345" in a.stdout
