@@ -191,6 +191,7 @@ class Engine:
             f = buf[i]
             ll = lib().sonde_dfm_rawline(C.byref(f), self.ecc, line, 128)
             frames.append(dict(channel=f.channel, frame_in_hit=f.frame_in_hit, ecc=list(f.ecc), mv=f.mv, mv_pos=f.mv_pos,
+                               conf=bytes(f.conf), dat1=bytes(f.dat1), dat2=bytes(f.dat2), frm_count=f.frm_count, inv=f.inv,
                                line=line.raw[:ll].decode()))
         if with_soft:
             soft = np.zeros((self._max_frames, self.nbits), np.float32)

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 
-from .engine import SondeFrame, SondeError, lib
+from .engine import SondeDfmFrame, SondeFrame, SondeError, lib
 
 
 class Rs41Opts(C.Structure):
@@ -42,6 +42,50 @@ class Rs41Telemetry:
         n = lib().sonde_rs41_dec_frame(self._h, C.byref(f), self._buf, len(self._buf))
         if n < 0:
             raise SondeError("sonde_rs41_dec_frame failed")
+        return self._buf.value.decode(errors="replace")
+
+    def json(self, frame: dict):
+        for line in self.decode(frame).splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return None
+
+
+class DfmOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("verbose", "ptu", "ecc", "dist", "json", "sat", "raw", "opt_auto", "jsn_freq_khz")] + \
+               [("version", C.c_char * 32), ("reserved", C.c_int32 * 4)]
+
+
+class DfmTelemetry:
+    """`dfm09mod -vv --ecc --json --dist --auto` behind Engine(sonde="dfm").fetch_dfm(): feed EVERY frame dict in order (a DFM
+    spreads one fix over nine packets); decode() returns the text of that frame (mostly empty), json() the parsed object or None."""
+
+    def __init__(self, *, verbose: int = 2, ptu: int = 1, dist: bool = True, freq_khz: int = 0, version: str = "sonde_hip"):
+        L = lib()
+        L.sonde_dfm_dec_create.argtypes = [C.POINTER(DfmOpts), C.POINTER(C.c_void_p)]
+        L.sonde_dfm_dec_frame.argtypes = [C.c_void_p, C.POINTER(SondeDfmFrame), C.c_char_p, C.c_size_t]
+        L.sonde_dfm_dec_destroy.argtypes = [C.c_void_p]
+        o = DfmOpts(verbose=verbose, ptu=ptu, ecc=1, dist=int(dist), json=1, opt_auto=1, jsn_freq_khz=freq_khz, version=version.encode())
+        self._h = C.c_void_p()
+        if L.sonde_dfm_dec_create(C.byref(o), C.byref(self._h)) < 0:
+            raise SondeError("sonde_dfm_dec_create: unsupported options")
+        self._buf = C.create_string_buffer(8192)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sonde_dfm_dec_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def decode(self, frame: dict) -> str:
+        f = SondeDfmFrame(channel=frame["channel"], frame_in_hit=frame["frame_in_hit"], mv_pos=frame["mv_pos"], mv=frame["mv"],
+                          frm_count=frame["frm_count"], inv=frame["inv"])
+        for i, v in enumerate(frame["ecc"]):
+            f.ecc[i] = v
+        C.memmove(f.conf, frame["conf"], 7); C.memmove(f.dat1, frame["dat1"], 13); C.memmove(f.dat2, frame["dat2"], 13)
+        if lib().sonde_dfm_dec_frame(self._h, C.byref(f), self._buf, len(self._buf)) < 0:
+            raise SondeError("sonde_dfm_dec_frame failed")
         return self._buf.value.decode(errors="replace")
 
     def json(self, frame: dict):

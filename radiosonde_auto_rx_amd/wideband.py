@@ -1,4 +1,4 @@
-"""One wideband IQ stream -> every RS41 in it, in one process on one GPU.
+"""One wideband IQ stream -> every RS41 and DFM in it, in one process on one GPU.
 
 The reference handles a wideband source by starting one detector process per candidate peak (auto_rx/autorx/scan.py:413-656:
 rtl_power peaks -> `dft_detect` per peak) and then one decoder pipeline per sonde (decode.py).  Here the same two steps run
@@ -20,7 +20,7 @@ import numpy as np
 from .engine import Engine
 from .scan import Scanner
 from .synth import snap_fq
-from .telemetry import Rs41Telemetry
+from .telemetry import DfmTelemetry, Rs41Telemetry
 
 
 class WidebandReceiver:
@@ -42,8 +42,13 @@ class WidebandReceiver:
                 return
         fq = snap_fq(fq, self.sr)
         khz = int(round((self.cfreq + fq * self.sr) / 1000.0)) if self.cfreq else 0
-        eng = Engine([fq], self.sr, max_chunk=self.chunk, max_frames=8)
-        self.sondes.append(dict(fq=fq, type=typ, engine=eng, telemetry=Rs41Telemetry(freq_khz=khz, version=self.version), frames=0, khz=khz))
+        if typ == "DFM":
+            eng = Engine([fq], self.sr, sonde="dfm", ecc=1, auto=True, max_chunk=self.chunk, max_frames=8)
+            tel = DfmTelemetry(freq_khz=khz, version=self.version)
+        else:
+            eng = Engine([fq], self.sr, max_chunk=self.chunk, max_frames=8)
+            tel = Rs41Telemetry(freq_khz=khz, version=self.version)
+        self.sondes.append(dict(fq=fq, type=typ, engine=eng, telemetry=tel, frames=0, khz=khz))
         self.log.append(dict(event="detected", type=typ, fq=fq, freq_khz=khz))
 
     def push(self, iq: np.ndarray, finish: bool = False):
@@ -57,19 +62,25 @@ class WidebandReceiver:
             for d in self.scanner.fetch():
                 if d["type"] == "RS41" and d["score"] > 0:
                     self._start(self.raster[d["channel"]] + d["df"], "RS41")
+                elif d["type"] == "DFM9":                                   # either polarity: the decoder runs with --auto
+                    self._start(self.raster[d["channel"]] + d["df"], "DFM")
             for s in self.sondes:
                 s["engine"].process_host(x)
-                for fr in s["engine"].fetch_frames():
-                    js = s["telemetry"].json(fr)
-                    s["frames"] += 1
-                    if js is not None:
-                        out.append(js)
+                out += self._drain(s, False)
         if finish:
             for s in self.sondes:
-                for fr in s["engine"].fetch_frames(finish=True):
-                    js = s["telemetry"].json(fr)
-                    if js is not None:
-                        out.append(js)
+                out += self._drain(s, True)
+        return out
+
+    @staticmethod
+    def _drain(s, finish):
+        frames = s["engine"].fetch_dfm(finish=finish) if s["type"] == "DFM" else s["engine"].fetch_frames(finish=finish)
+        out = []
+        for fr in frames:
+            js = s["telemetry"].json(fr)
+            s["frames"] += 1
+            if js is not None:
+                out.append(js)
         return out
 
     def close(self):

@@ -115,7 +115,7 @@ def test_all_own_chains_json_identical():
 
 
 def test_wideband_receiver_finds_and_decodes_all_sondes():
-    """One 2.4 Msps stream with three RS41 (different IDs, offsets off the raster, one starting late) and nothing else told to the
+    """One 2.4 Msps stream with three RS41 (different IDs, offsets off the raster, one starting late), one DFM09, and nothing else told to the
     receiver: the raster scanner finds each, a demodulator is started per sonde, every later frame comes out as the telemetry JSON
     with the right ID / frequency; positions are what the frames carry."""
     from radiosonde_auto_rx_amd import synth
@@ -135,6 +135,13 @@ def test_wideband_receiver_finds_and_decodes_all_sondes():
                                  frame_kw=dict(ecef_cm=s["lat"], cal_table=synth.rs41_cal_table(seed=k, freq_khz=int(round((cf + s["hz"]) / 10000.0)) * 10)))
         z = (cap[0::2].astype(np.float64) + 1j * cap[1::2].astype(np.float64)) / (32767 * 0.9)
         x += z * np.exp(2j * np.pi * s["hz"] / sr * np.arange(n))
+    # ... and one DFM09 telemetry stream (continuous transmission) at -700.6 kHz
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    dsym = (make_golden.dfm_field_symbols(dict(kind="09", n=60, sn=18012345)) > 0).astype(np.uint8)
+    dz = 0.2 * synth.gfsk_baseband(dsym, sr, 2500.0, 2400.0)[:n]
+    x[:len(dz)] += dz * np.exp(2j * np.pi * (-700_600.0) / sr * np.arange(len(dz)))
     x += 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     iq = np.empty(2 * n, np.int16)
     iq[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767); iq[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767)
@@ -142,7 +149,11 @@ def test_wideband_receiver_finds_and_decodes_all_sondes():
     out = rx.push(iq, finish=True)
     found = {s["khz"] for s in rx.sondes}
     rx.close()
-    assert len(rx.sondes) == 3, rx.log
+    assert len(rx.sondes) == 4, rx.log
+    dfm = [j for j in out if j["type"] == "DFM"]
+    assert len(dfm) >= 3 and all(j["id"] in ("DFM-18012345", "DFM-xxxxxxxx") and abs(j["freq"] - (cf - 700_600) // 1000) <= 2 for j in dfm), dfm[:2]
+    assert any(j["id"] == "DFM-18012345" and j.get("subtype") == "0xA:DFM09" for j in dfm)
+    out = [j for j in out if j["type"] == "RS41"]
     for s in sig:
         want_khz = int(round((cf + s["hz"]) / 1000.0))
         assert any(abs(k - want_khz) <= 2 for k in found), (want_khz, found)
