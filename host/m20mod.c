@@ -1,0 +1,133 @@
+/*
+ * host/m20mod.c — `m20mod` command-line front end on top of libsonde_hip (C).
+ *
+ * Reference contract kept for the sample-input forms with raw output (reference demod/mod/m20mod.c:1196-1300 argv, :1112-1123
+ * output, :1436-1510 frame loop):
+ *     m20mod -r [-v] [--ths x] ( --IQ <fq> | --iq0 | --iq2 | --iq3 [--iqdc] ) [--lpIQ | --lpbw kHz] [--lpFM] [--dc] [--min] - <sr> <bits>
+ *     m20mod -r [-v] [--ch2] [file.wav]                                  FM audio
+ * stdout: one line of hex per frame (frame byte 0 + 1 bytes), with -v ` # <checksum> [(ok)|(oo)|(no)] [OK]|[NO]` (block check for firmware < 7)
+ * stderr: `note: sample rate low`, `IF:` / `dec:`; exit 0 at EOF, 255 on argument / init errors.
+ * The position / PTU decode of M20 frames (print_pos) is not part of this build: without -r the program refuses.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "sonde_hip.h"
+#include "wav_header.h"
+
+static int g_verbose = 0;
+
+static void emit_frame(const sonde_m20_frame_t *f) {
+    static char ln[420];
+    if (sonde_m20_rawline(f, g_verbose, ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
+}
+
+int main(int argc, char **argv) {
+    sonde_cfg_t cfg;
+    double fq = 0.0;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1;
+    FILE *fp = stdin;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = SONDE_ABI_VERSION;
+    cfg.sonde_type = SONDE_M20;
+    setbuf(stdout, NULL);
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
+        else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) g_verbose = 1;
+        else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) { /* irrelevant for the differential code (m20mod.c:1447) */ }
+        else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
+        else if (!strcmp(a, "--IQ")) {
+            if (++i >= argc) return -1;
+            fq = atof(argv[i]);
+            if (fq < -0.5) fq = -0.5;
+            if (fq > 0.5) fq = 0.5;
+            have_iq = 1; iq_mode = 5;
+        }
+        else if (!strcmp(a, "--iq0")) { have_iq = 1; iq_mode = 1; }
+        else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }
+        else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
+        else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
+        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;
+        else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;
+        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
+        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
+        else if (!strcmp(a, "--lpbw")) {
+            if (++i >= argc) return -1;
+            double bw = atof(argv[i]);
+            if (bw > 4.6 && bw < 48.0) cfg.lpiq_bw = (int)(bw * 1e3);
+            cfg.opt_lp |= SONDE_LP_IQ;
+        }
+        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
+        else if (!strcmp(a, "--ch2")) wav_ch = 1;
+        else if (!strcmp(a, "-")) {
+            if (i + 2 >= argc) return -1;
+            cfg.sample_rate = atoi(argv[++i]);
+            cfg.bits = atoi(argv[++i]);
+            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
+            have_pcm = 1;
+        }
+        else if (a[0] != '-') {
+            fp = fopen(a, "rb");
+            if (fp == NULL) { fprintf(stderr, "error: open %s\n", a); return -1; }
+        }
+        else { fprintf(stderr, "m20mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
+    }
+    if (!raw) { fprintf(stderr, "m20mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+    if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
+    if (have_iq && !have_pcm) {
+        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
+        if (nch != 2) { fprintf(stderr, "m20mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
+    }
+    if (iq_mode == 5 && cfg.opt_dc) cfg.opt_lp |= SONDE_LP_FM;
+    if (iq_mode != 5) cfg.opt_nolut = 0;
+    if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
+    if (!have_iq) {
+        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
+        cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
+        cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
+    }
+    if ((float)cfg.sample_rate / 9600.0f < 8) fprintf(stderr, "note: sample rate low (%.1f sps)\n", (float)cfg.sample_rate / 9600.0f);   /* m20mod.c:1392 */
+    cfg.n_channels = 1;
+    cfg.max_chunk = cfg.sample_rate;
+    cfg.max_frames = 16;
+    sonde_engine_t *eng = NULL;
+    int rc = sonde_engine_create(&cfg, &fq, &eng);
+    if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+    sonde_info_t info;
+    sonde_engine_info(eng, &info);
+    if (iq_mode == 5) {                              /* init_buffers prints these first (demod_mod.c:1257-1258) */
+        fprintf(stderr, "IF: %d\n", info.if_sr);
+        fprintf(stderr, "dec: %d\n", info.decM);
+    }
+    const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);
+    int chunk = cfg.sample_rate / 10;
+    chunk -= chunk % info.decM;
+    if (chunk < info.decM) chunk = info.decM;
+    int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
+    sonde_m20_frame_t frames[16];
+    size_t have = 0;
+    for (;;) {
+        size_t got = fread((char *)buf + have, 1, (size_t)chunk * unit - have, fp);
+        have += got;
+        int n = (int)(have / unit);
+        n -= n % info.decM;
+        if (n > 0) {
+            rc = sonde_engine_process_host(eng, buf, n, n);
+            if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
+            int k = sonde_engine_fetch_m20(eng, frames, 16, 0);
+            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
+            have -= (size_t)n * unit;
+        }
+        if (got == 0) break;
+    }
+    {
+        int k = sonde_engine_fetch_m20(eng, frames, 16, 1);
+        for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+    }
+    sonde_engine_destroy(eng);
+    free(buf);
+    return 0;
+}

@@ -40,6 +40,7 @@ extern "C" {
 #define SONDE_M10    10         /* m10mod.c:55,76,1370-1390,1436-1510: 9615 Bd Manchester, BT 1.8, h 0.9, 32-symbol raw header compared
                                  * per symbol, thres 0.76, hdmax 2; 968 differentially coded bits per frame, then the rest of the
                                  * second (5 x 808 bits) is skipped; either polarity */
+#define SONDE_M20    20         /* m20mod.c:60,86,1034-1040,1238-1251,1321-1365: as M10 with 9600 Bd and up to 64 aux bytes (1320 bits) */
 
 /* input forms (dsp.opt_iq of demod_mod.h:62; rs41mod.c:2674-2687,2786-2803) */
 #define SONDE_IN_IQ    0        /* baseband IQ, mixed by -fq and decimated to the IF rate (opt_iq = 5)        */
@@ -183,6 +184,24 @@ typedef struct {
 int  sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish);
 /* Raw text line of `m10mod -r [-v]` (m10mod.c:1112-1123): hex bytes, with verbose " # <checksum> [OK]|[NO]"; buf >= 280 */
 int  sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen);
+
+/* One M20 frame (m20mod.c:870-911): frame byte 0 = length; checksum over the first len-1 bytes; older firmware (< 0x07) also carries a
+ * checksum of the essential block (bytes 0x02..0x17). */
+typedef struct {
+    int32_t  channel;
+    int32_t  nbits;          /* bits sliced (1320 unless the stream ended inside the frame)                 */
+    int32_t  len;            /* bytes printed: frame[0] + 1, at most 0x45 + 64 + 1                          */
+    int32_t  cs_ok;
+    uint32_t cs_calc;
+    int32_t  blk_ok;         /* 1 block checksum good, -1 transmitted as 0, 0 bad                           */
+    int32_t  fw;             /* firmware byte (0 when implausible); the block verdict is printed for fw < 7 */
+    uint32_t mv_pos;
+    float    mv;
+    uint8_t  frame[172];
+} sonde_m20_frame_t;
+int  sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t max, int32_t finish);
+/* Raw text line of `m20mod -r [-v]` (m20mod.c:959-973); buf >= 400 */
+int  sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen);
 
 /* Raw text line of `dfm09mod -r [--ecc]` (dfm09mod.c:1198-1236); returns strlen. buf >= 96 bytes */
 int  sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, size_t buflen);

@@ -161,7 +161,7 @@ const char *sonde_strerror(int code) {
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
-    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
+    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->opt_nolut && (cfg->opt_dc || cfg->input != SONDE_IN_IQ)) return SONDE_E_ARG;     // --noLUT folds Df into the base-rate mixer: not with --dc here
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
@@ -186,6 +186,10 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     } else if (cfg->sonde_type == SONDE_M10) {   // m10mod.c:55,76,1178-1181,1370-1390,1454-1476: Manchester bits, header compared per symbol
         e->baud = 9615.f; e->bt = 1.8f; e->hmod = 0.9f; e->symlen = 2; e->symhd = 1; e->hdmax = 2; e->bitofs = 0;      // m10mod.c:1184: bitofs 0
         e->nbits = (101 + 20) * 8; e->l_win = 4.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.76f;
+        header = kM10RawHeader; lpiq_def = 24000; lpfm_bw = 10000;
+    } else if (cfg->sonde_type == SONDE_M20) {   // m20mod.c:60,81,86,1034-1040,1238-1251: the M10 scheme at 9600 Bd with a longer aux part
+        e->baud = 9600.f; e->bt = 1.8f; e->hmod = 0.9f; e->symlen = 2; e->symhd = 1; e->hdmax = 2; e->bitofs = 0;
+        e->nbits = (101 + 64) * 8; e->l_win = 4.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.76f;
         header = kM10RawHeader; lpiq_def = 24000; lpfm_bw = 10000;
     } else {   // DFM06/09 (dfm09mod.c:1309-1312,1560-1582,1690-1694): 264 + 7*280 Manchester bits per header hit
         e->baud = 2500.f; e->bt = 0.5f; e->hmod = 1.8f; e->symlen = 2; e->symhd = 2; e->hdmax = 2; e->bitofs = 2;
@@ -233,7 +237,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     { const float nh = -e->hmod; const float hs = nh * sr; const double f1 = hs / (2.0 * e->sps); e->rho = -f1 / (double)sr; }
     {   // samples the framer consumes behind a header before the search resumes: all nbits — M10: the rest of the second as well
         // (bits up to 5 x 808 are read and dropped, m10mod.c:1494-1507)
-        const int last = cfg->sonde_type == SONDE_M10 ? 5 * 808 - 1 : e->nbits - 1;
+        const int last = (cfg->sonde_type == SONDE_M10 || cfg->sonde_type == SONDE_M20) ? 5 * 808 - 1 : e->nbits - 1;
         uint32_t q0, q1; double mid; bit_window(last, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1;
     }
 
@@ -581,7 +585,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;
     s.sps = e->sps; s.thres = e->thres; s.l_win = e->l_win;
-    s.opt_auto = e->cfg.opt_auto != 0 || e->cfg.sonde_type == SONDE_M10;      // M10: either polarity (differential coding)
+    s.opt_auto = e->cfg.opt_auto != 0 || e->cfg.sonde_type == SONDE_M10 || e->cfg.sonde_type == SONDE_M20;      // M10: either polarity (differential coding)
     s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
@@ -693,6 +697,56 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
     return ovf ? SONDE_E_OVERFLOW : n;
 }
 
+// M10 / M20: sliced Manchester bits -> differentially decoded frame bytes.  The bit characters persist per channel like the
+// reference's gpx.frame_bits: a frame cut short by the end of the stream keeps the tail of the previous one behind the terminator.
+static int mxx_bytes(sonde_engine *e, const FrameRec &r, int nbytes_max, uint8_t *frame) {
+    const int NB = nbytes_max * 8;
+    if (e->m10_bits.empty()) e->m10_bits.assign((size_t)e->cfg.n_channels * (NB + 8), 0);
+    char *fb = e->m10_bits.data() + (size_t)r.channel * (NB + 8);
+    const int nv = std::min(r.nbytes, NB);                          // nbytes = valid bits of the hit
+    int bit0 = '0';                                                 // differential decoding: 1 = same as the previous bit (m10mod.c:1484)
+    for (int p = 0; p < nv; p++) { const int bit = (r.frame[p >> 3] >> (p & 7)) & 1; fb[p] = (char)(0x31 ^ (bit0 ^ bit)); bit0 = bit; }
+    fb[nv] = 0;
+    for (int i = 0; i < nbytes_max; i++) {                          // bits2bytes, big endian; anything but '1' counts as 0 (m10mod.c:141-166)
+        int v = 0;
+        for (int k = 0; k < 8; k++) if (fb[8 * i + 7 - k] == '1') v |= 1 << k;
+        frame[i] = (uint8_t)v;
+    }
+    return nv;
+}
+
+int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t max, int32_t finish) {
+    if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_M20) return SONDE_E_ARG;
+    if (finish) launch_framesync(e, 1);
+    std::vector<FrameRec> recs;
+    std::vector<float> soft;
+    const int n = collect_records(e, 0, recs, &soft, max);
+    if (n < 0) return n;
+    e->last_soft = soft; e->last_n = n;
+    for (int h = 0; h < n; h++) {
+        const FrameRec &r = recs[h];
+        sonde_m20_frame_t &o = out[h];
+        memset(&o, 0, sizeof o);
+        o.nbits = mxx_bytes(e, r, 101 + 64, o.frame);
+        int flen = o.frame[0], pos_fw = 0x43;                       // m20mod.c:875-899
+        if (flen < 0x45) pos_fw = flen - 2;
+        else if (flen - 0x45 > 64) flen = 0x45 + 64;
+        const int pos_check = flen - 1;
+        o.fw = (pos_fw >= 0) ? o.frame[pos_fw] : 0;
+        if (o.fw > 0x20) o.fw = 0;
+        o.channel = r.channel; o.len = flen + 1; o.mv = r.mv; o.mv_pos = r.mv_pos;
+        o.cs_calc = pos_check >= 0 ? (uint32_t)m10_checksum(o.frame, pos_check) : 0;
+        o.cs_ok = pos_check >= 0 && ((uint32_t)((o.frame[pos_check] << 8) | o.frame[pos_check + 1]) == o.cs_calc);
+        {   // block checksum: the length byte 0x16, then frame[2 .. 2+0x14) (blk_checkM10, m20mod.c:548-560)
+            uint8_t blk[0x16]; blk[0] = 0x16; memcpy(blk + 1, o.frame + 2, 0x14);
+            const int bc2 = m10_checksum(blk, 0x15), bc1 = (o.frame[0x16] << 8) | o.frame[0x17];
+            o.blk_ok = bc1 == bc2 ? 1 : bc1 == 0 ? -1 : 0;
+        }
+    }
+    const bool ovf = e->overflow; e->overflow = false;
+    return ovf ? SONDE_E_OVERFLOW : n;
+}
+
 int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish) {
     if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_M10) return SONDE_E_ARG;
     if (finish) launch_framesync(e, 1);
@@ -701,22 +755,11 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
     const int n = collect_records(e, 0, recs, &soft, max);
     if (n < 0) return n;
     e->last_soft = soft; e->last_n = n;
-    const int NB = (101 + 20) * 8;
-    if (e->m10_bits.empty()) e->m10_bits.assign((size_t)e->cfg.n_channels * (NB + 8), 0);
     for (int h = 0; h < n; h++) {
         const FrameRec &r = recs[h];
         sonde_m10_frame_t &o = out[h];
         memset(&o, 0, sizeof o);
-        char *fb = e->m10_bits.data() + (size_t)r.channel * (NB + 8);
-        const int nv = std::min(r.nbytes, NB);                      // nbytes = valid bits of the hit
-        int bit0 = '0';                                             // differential decoding: 1 = same as the previous bit (m10mod.c:1484)
-        for (int p = 0; p < nv; p++) { const int bit = (r.frame[p >> 3] >> (p & 7)) & 1; fb[p] = (char)(0x31 ^ (bit0 ^ bit)); bit0 = bit; }
-        fb[nv] = 0;
-        for (int i = 0; i < 121; i++) {                             // bits2bytes, big endian; anything but '1' counts as 0 (m10mod.c:141-166)
-            int v = 0;
-            for (int k = 0; k < 8; k++) if (fb[8 * i + 7 - k] == '1') v |= 1 << k;
-            o.frame[i] = (uint8_t)v;
-        }
+        const int nv = mxx_bytes(e, r, 101 + 20, o.frame);
         int aux = o.frame[0] - 0x64;
         if (aux < 0 || aux > 20) aux = 0;
         o.channel = r.channel; o.nbits = nv; o.len = 101 + aux; o.mv = r.mv; o.mv_pos = r.mv_pos;

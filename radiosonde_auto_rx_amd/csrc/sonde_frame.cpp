@@ -270,6 +270,17 @@ int sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t
     if (verbose) n += snprintf(buf + n, buflen - n, " # %04x%s", f->cs_calc, f->cs_ok ? " [OK]" : " [NO]");
     return n;
 }
+int sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen) {
+    if (!f || !buf || f->len < 1 || f->len > 0x45 + 64 + 1 || buflen < (size_t)(2 * f->len + 32)) return SONDE_E_ARG;
+    int n = 0;
+    for (int i = 0; i < f->len; i++) n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
+    if (verbose) {
+        n += snprintf(buf + n, buflen - n, " # %04x", f->cs_calc);
+        if (f->fw < 0x07) n += snprintf(buf + n, buflen - n, f->blk_ok > 0 ? " (ok)" : f->blk_ok < 0 ? " (oo)" : " (no)");
+        n += snprintf(buf + n, buflen - n, f->cs_ok ? " [OK]" : " [NO]");
+    }
+    return n;
+}
 int sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen) {
     if (!f || !buf || buflen < (size_t)(2 * f->len + 16)) return SONDE_E_ARG;
     int n = 0;

@@ -19,13 +19,17 @@ import make_golden  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-@pytest.mark.parametrize("name", sorted(make_golden.M10_CASES))
+ALL = {**{k: (v, "m10mod") for k, v in make_golden.M10_CASES.items()}, **{k: (v, "m20mod") for k, v in make_golden.M20_CASES.items()}}
+
+
+@pytest.mark.parametrize("name", sorted(ALL))
 def test_cli_m10_matches_reference(name):
+    """M10 (m10mod) and M20 (m20mod: 9600 Bd, length byte 0x45 / shorter / longer with aux bytes, block checksum verdict)"""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
-    case = make_golden.M10_CASES[name]
+    case, binary = ALL[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
     stdin, args = make_golden.m10_capture_cli(case)
-    r = subprocess.run([os.path.join(ROOT, "host", "bin", "m10mod")] + args, input=stdin, capture_output=True, timeout=180)
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", binary)] + args, input=stdin, capture_output=True, timeout=180)
     assert r.returncode == int(g["rc"]), (r.returncode, r.stderr)
     assert r.stderr.decode() == str(g["stderr"])
     want = g["stdout"].tobytes().decode().splitlines()

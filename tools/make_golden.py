@@ -301,6 +301,15 @@ M10_CASES = {
 }
 
 
+# M20 (m20mod -r -v): same modulation scheme at 9600 Bd, frame length byte 0x45
+M20_CASES = {
+    "m20_48k_IQ": dict(cap=dict(sr=48_000, seconds=4.2, noise_sigma=0.02, seed=13, f_offset_hz=-250.0, type_bytes=(0x45, 0x20), baud=9600.0), args=["-r", "-v", "--IQ", "0.0", "--lpIQ", "-", "SR", "16"]),
+    "m20_2400k_IQ": dict(cap=dict(sr=2_400_000, seconds=2.5, fq=-0.31, noise_sigma=0.02, seed=14, type_bytes=(0x45, 0x20), baud=9600.0), args=["-r", "-v", "--IQ", "FQ", "--lpIQ", "-", "SR", "16"]),
+    "m20_48k_iq2_long": dict(cap=dict(sr=48_000, seconds=3.2, noise_sigma=0.03, seed=15, type_bytes=(0x6F, 0x20), baud=9600.0), args=["-r", "-v", "--iq2", "-", "SR", "16"]),
+    "m20_48k_audio_short": dict(cap=dict(sr=48_000, seconds=3.2, noise_sigma=0.02, seed=16, type_bytes=(0x43, 0x20), baud=9600.0), audio=True, args=["-r", "-v"]),
+}
+
+
 def m10_capture_cli(case):
     """-> (stdin bytes, argv)"""
     cap = dict(case["cap"]); sr = cap["sr"]
@@ -757,6 +766,7 @@ def main():
     gen_dfm_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_cli_cases({k: dict(v, binary="m10mod") for k, v in M10_CASES.items()}, m10_capture_cli, outdir)
+    gen_cli_cases({k: dict(v, binary="m20mod") for k, v in M20_CASES.items()}, m10_capture_cli, outdir)
     gen_wide_demod(outdir)
     gen_cli_cases(NOLUT_CASES, nolut_capture, outdir)
     for name, case in INV_CASES.items():
