@@ -94,6 +94,7 @@ typedef struct {
                               * (rs41mod.c:2887-2891,2933-2937; dfm09mod.c:1642-1645,1702-1705)                  */
     int32_t opt_nolut;       /* --noLUT (SONDE_IN_IQ): mixer phasor from the exact fq and the absolute sample index in double instead
                               * of the periodic float-phase table of the snapped fq (demod_mod.c:738-742); not with opt_dc   */
+    int32_t m10_noskip;      /* SONDE_M10 / M20 with -vvv: do not drop the rest of the second after a frame (m10mod.c:1493) */
     int32_t opt_auto;        /* --auto: a header of the opposite polarity flips the channel's polarity instead of being skipped */
 } sonde_cfg_t;
 
@@ -240,6 +241,12 @@ int  sonde_softin_finish(sonde_softin_t *s);               /* EOF: emit the fram
 int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
 /* SONDE_DFM09 framers (dfm09mod --softin, dfm09mod.c:1604-1720: two soft symbols per bit, 8 frames per header hit) */
 int  sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max);
+/* SONDE_M10 / SONDE_M20 framers (m10mod / m20mod --softin, m10mod.c:1405-1510: header threshold 0.8, two soft symbols per bit,
+ * differential decoding, the rest of the second dropped) */
+int  sonde_softin_fetch_m10(sonde_softin_t *s, sonde_m10_frame_t *out, int32_t max);
+int  sonde_softin_fetch_m20(sonde_softin_t *s, sonde_m20_frame_t *out, int32_t max);
+/* -vvv: the reference then searches the next header right behind a frame instead of dropping the rest of the second */
+int  sonde_softin_set_m10_skip(sonde_softin_t *s, int32_t skip);
 
 /* Raw text line of `rs41mod -r` for one frame (rs41mod.c:2530-2545); returns strlen. buf >= 1100 bytes */
 int  sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen);

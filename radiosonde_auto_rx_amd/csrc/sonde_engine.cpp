@@ -237,7 +237,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     { const float nh = -e->hmod; const float hs = nh * sr; const double f1 = hs / (2.0 * e->sps); e->rho = -f1 / (double)sr; }
     {   // samples the framer consumes behind a header before the search resumes: all nbits — M10: the rest of the second as well
         // (bits up to 5 x 808 are read and dropped, m10mod.c:1494-1507)
-        const int last = (cfg->sonde_type == SONDE_M10 || cfg->sonde_type == SONDE_M20) ? 5 * 808 - 1 : e->nbits - 1;
+        const int last = ((cfg->sonde_type == SONDE_M10 || cfg->sonde_type == SONDE_M20) && !cfg->m10_noskip) ? 5 * 808 - 1 : e->nbits - 1;
         uint32_t q0, q1; double mid; bit_window(last, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1;
     }
 

@@ -31,7 +31,43 @@ struct sonde_softin {
     float mv = 0.f; uint64_t bits_in = 0, hdr_bit = 0;
     uint32_t hdrcnt = 0;                      // DFM: 8 per header seen (dfm09mod.c:1628,1632), base of the frame time stamp
     std::vector<sonde_frame_t> queue;
+    // M10 / M20 (m10mod.c:1405-1510): 32-symbol header at threshold 0.8, two soft symbols per bit (s2 - s1), differential decoding,
+    // then ONE symbol per counted bit is dropped until 5 x 808 (the reference's skip loop reads a single float per step)
+    int mpos = 0, mhalf = 0, mbit0 = '0', mskip = 0, mdoskip = 1; float ms1 = 0.f;
+    char mbits[(101 + 64) * 8 + 8];
+    std::vector<sonde_m10_frame_t> q10; std::vector<sonde_m20_frame_t> q20;
 };
+
+static void mxx_emit(sonde_softin *s, int pos) {
+    const bool m20 = s->type == SONDE_M20;
+    const int nb = m20 ? 101 + 64 : 101 + 20;
+    uint8_t fr[172]; memset(fr, 0, sizeof fr);
+    s->mbits[pos] = 0;
+    for (int i = 0; i < nb; i++) { int v = 0; for (int k = 0; k < 8; k++) if (s->mbits[8 * i + 7 - k] == '1') v |= 1 << k; fr[i] = (uint8_t)v; }
+    if (!m20) {
+        sonde_m10_frame_t o; memset(&o, 0, sizeof o);
+        memcpy(o.frame, fr, 121);
+        int aux = fr[0] - 0x64; if (aux < 0 || aux > 20) aux = 0;
+        o.nbits = pos; o.len = 101 + aux; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+        o.cs_calc = (uint32_t)m10_checksum(fr, 99 + aux);
+        o.cs_ok = ((uint32_t)((fr[99 + aux] << 8) | fr[100 + aux]) == o.cs_calc);
+        s->q10.push_back(o);
+    } else {
+        sonde_m20_frame_t o; memset(&o, 0, sizeof o);
+        memcpy(o.frame, fr, 165);
+        int flen = fr[0], pos_fw = 0x43;
+        if (flen < 0x45) pos_fw = flen - 2; else if (flen - 0x45 > 64) flen = 0x45 + 64;
+        const int pc = flen - 1;
+        o.fw = pos_fw >= 0 ? fr[pos_fw] : 0; if (o.fw > 0x20) o.fw = 0;
+        o.nbits = pos; o.len = flen + 1; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+        o.cs_calc = pc >= 0 ? (uint32_t)m10_checksum(fr, pc) : 0;
+        o.cs_ok = pc >= 0 && ((uint32_t)((fr[pc] << 8) | fr[pc + 1]) == o.cs_calc);
+        uint8_t blk[0x16]; blk[0] = 0x16; memcpy(blk + 1, fr + 2, 0x14);
+        const int bc2 = m10_checksum(blk, 0x15), bc1 = (fr[0x16] << 8) | fr[0x17];
+        o.blk_ok = bc1 == bc2 ? 1 : bc1 == 0 ? -1 : 0;
+        s->q20.push_back(o);
+    }
+}
 
 static void emit(sonde_softin *s, int nbytes) {           // print_frame(gpx, byte_count) (rs41mod.c:2472-2490)
     sonde_frame_t f; memset(&f, 0, sizeof f);
@@ -49,13 +85,15 @@ static void emit(sonde_softin *s, int nbytes) {           // print_frame(gpx, by
 extern "C" {
 
 int sonde_softin_create(int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto, sonde_softin_t **out) {
-    if (!out || (sonde_type != SONDE_RS41 && sonde_type != SONDE_DFM09)) return SONDE_E_ARG;
+    if (!out || (sonde_type != SONDE_RS41 && sonde_type != SONDE_DFM09 && sonde_type != SONDE_M10 && sonde_type != SONDE_M20)) return SONDE_E_ARG;
     sonde_softin *s = new sonde_softin();
     s->type = sonde_type;
     memset(s->dsb, 0, sizeof s->dsb); memset(s->dhb, 0, sizeof s->dhb); memset(s->dsf, 0, sizeof s->dsf);
     s->ecc_level = ecc_level; s->inv_in = invert_stream ? 1 : 0; s->opt_inv = opt_inv ? 1 : 0; s->opt_auto = opt_auto ? 1 : 0;
     memset(s->sbuf, 0, sizeof s->sbuf); memset(s->frame, 0, sizeof s->frame); memset(s->hbuf, 0, sizeof s->hbuf);
     memcpy(s->frame, kRs41HeaderBytes, 8);
+    memset(s->mbits, 0, sizeof s->mbits);
+    if (sonde_type == SONDE_M10 || sonde_type == SONDE_M20) s->ths = 0.8f;
     *out = s;
     return 0;
 }
@@ -64,6 +102,44 @@ void sonde_softin_destroy(sonde_softin_t *s) { delete s; }
 
 int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
     if (!s || (!soft && n > 0) || n < 0) return SONDE_E_ARG;
+    if (s->type == SONDE_M10 || s->type == SONDE_M20) {
+        const int nbits = (s->type == SONDE_M20 ? 101 + 64 : 101 + 20) * 8;
+        for (int32_t i = 0; i < n; i++) {
+            float sb = soft[i];
+            if (s->inv_in) sb = -sb;
+            s->bits_in++;
+            if (s->state == 0) {                                   // header search on the symbol stream
+                s->bufpos = (s->bufpos + 1) % 32;
+                s->dsb[s->bufpos] = sb;
+                double sum = 0.0, normx = 0.0, normy = 0.0;
+                int j = s->bufpos + 1;
+                for (int k = 0; k < 32; k++) {
+                    if (j >= 32) j = 0;
+                    const float x = s->dsb[j];
+                    const float y = (float)(2.0 * (kM10RawHeader[k] & 0x1) - 1.0);
+                    sum += (double)y * (double)s->dsb[j];
+                    normx += x * x; normy += y * y;
+                    j++;
+                }
+                sum /= std::sqrt(normx * normy);
+                const float mv = (float)sum;
+                if (std::fabs(mv) > s->ths) {
+                    if (mv * (0.5 - s->opt_inv) < 0) s->opt_inv ^= 1;          // irrelevant for the differential code (m10mod.c:1447)
+                    s->state = 1; s->mpos = 0; s->mhalf = 0; s->mbit0 = '0'; s->mv = mv; s->hdr_bit = s->bits_in;
+                }
+            } else if (s->state == 1) {                            // frame bits: two symbols each
+                if (!s->mhalf) { s->ms1 = sb; s->mhalf = 1; continue; }
+                s->mhalf = 0;
+                const int bit = (sb - s->ms1) >= 0.0f;
+                s->mbits[s->mpos++] = (char)(0x31 ^ (s->mbit0 ^ bit));
+                s->mbit0 = bit;
+                if (s->mpos == nbits) { mxx_emit(s, s->mpos); s->state = s->mdoskip ? 2 : 0; s->mskip = nbits; }
+            } else {                                               // rest of the second: one symbol per counted bit up to 5 x 808
+                if (++s->mskip >= 5 * 808) s->state = 0;
+            }
+        }
+        return 0;
+    }
     if (s->type == SONDE_DFM09) {
         for (int32_t i = 0; i < n; i++) {
             float sb = soft[i];
@@ -237,8 +313,30 @@ int sonde_softin_push_frame(sonde_softin_t *s, const uint8_t *bytes, int32_t len
 int sonde_softin_finish(sonde_softin_t *s) {               // EOF inside a frame: print_frame with the bytes that exist
     if (!s) return SONDE_E_ARG;
     if (s->type == SONDE_DFM09) { s->state = 0; return 0; }          // a partial DFM frame is dropped (dfm09mod.c:1702,1713)
+    if (s->type == SONDE_M10 || s->type == SONDE_M20) {               // EOF inside a frame: printed with the bits that exist (m10mod.c:1486-1490)
+        if (s->state == 1) mxx_emit(s, s->mpos);
+        s->state = 0;
+        return 0;
+    }
     if (s->state == 1) { emit(s, s->byte_count); s->state = 0; }
     return 0;
+}
+
+int sonde_softin_set_m10_skip(sonde_softin_t *s, int32_t skip) { if (!s) return SONDE_E_ARG; s->mdoskip = skip != 0; return 0; }
+
+int sonde_softin_fetch_m10(sonde_softin_t *s, sonde_m10_frame_t *out, int32_t max) {
+    if (!s || (!out && max > 0) || max < 0) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->q10.size(), (size_t)max);
+    for (int i = 0; i < n; i++) out[i] = s->q10[i];
+    s->q10.erase(s->q10.begin(), s->q10.begin() + n);
+    return n;
+}
+int sonde_softin_fetch_m20(sonde_softin_t *s, sonde_m20_frame_t *out, int32_t max) {
+    if (!s || (!out && max > 0) || max < 0) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->q20.size(), (size_t)max);
+    for (int i = 0; i < n; i++) out[i] = s->q20[i];
+    s->q20.erase(s->q20.begin(), s->q20.begin() + n);
+    return n;
 }
 
 int sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max) {

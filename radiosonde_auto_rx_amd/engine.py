@@ -26,7 +26,7 @@ class SondeCfg(C.Structure):
                                          "opt_lp", "opt_dc", "opt_min", "lpiq_bw", "ecc_level")] + \
                [("thres", C.c_float), ("max_chunk", C.c_int32), ("max_frames", C.c_int32), ("keep_soft", C.c_int32),
                 ("pipeline", C.c_int32), ("input", C.c_int32), ("audio_channels", C.c_int32), ("audio_select", C.c_int32),
-                ("if_rate", C.c_int32), ("opt_iqdc", C.c_int32), ("opt_inv", C.c_int32), ("opt_nolut", C.c_int32), ("opt_auto", C.c_int32)]
+                ("if_rate", C.c_int32), ("opt_iqdc", C.c_int32), ("opt_inv", C.c_int32), ("opt_nolut", C.c_int32), ("m10_noskip", C.c_int32), ("opt_auto", C.c_int32)]
 
 
 class SondeFrame(C.Structure):
@@ -120,7 +120,7 @@ class Engine:
         cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "frontend": 0}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline),
-                       1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), int(auto))
+                       1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), 0, int(auto))
         h = C.c_void_p()
         _chk(lib().sonde_engine_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
         self._h = h

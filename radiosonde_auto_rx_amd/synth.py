@@ -415,12 +415,69 @@ def dfm_capture(sr: int = 480_000, seconds: float = 3.0, fq: float = 0.0, *, amp
 M10_RAWHEADER = "1001100110010100110010011001" "1010"   # scan/dft_detect.c:72-74, last 4 symbols = first two frame bits
 
 
-def m10_symbols(type_bytes=(0x64, 0x9F), n_payload_bytes: int = 99, rng=None) -> np.ndarray:
+def m10_checksum(data: bytes) -> int:
+    """checkM10 of the M10 / M20 frames: 16-bit register, one step per byte"""
+    c = 0
+    for b in data:
+        b = ((b >> 1) | ((b & 1) << 7)) & 0xFF
+        b ^= (b >> 2) & 0xFF
+        t6 = (c & 1) ^ ((c >> 2) & 1) ^ ((c >> 4) & 1)
+        t7 = ((c >> 1) & 1) ^ ((c >> 3) & 1) ^ ((c >> 5) & 1)
+        t = (c & 0x3F) | (t6 << 6) | (t7 << 7)
+        sreg = (c >> 7) & 0xFF
+        sreg ^= (sreg >> 2) & 0xFF
+        c = (((c & 0xFF) << 8) | ((b ^ t ^ sreg) & 0xFF)) & 0xFFFF
+    return c
+
+
+def m10_frame(k: int = 0, *, gtop: bool = False, lat=48.1, lon=11.6, alt_m=1234.5, sn=(0x84, 0x12, 0x3A, 0x45, 0x67), rng=None,
+              good_checksum: bool = True) -> bytes:
+    """One 101-byte M10 (Trimble GPS, type 0x9F) or M10+ (Gtop GPS, 0xAF) frame with plausible sensor words and a valid checksum."""
+    rng = rng or np.random.default_rng(k)
+    f = bytearray(rng.integers(0, 256, 101, dtype=np.uint8).tobytes())
+    f[0] = 0x64; f[1] = 0xAF if gtop else 0x9F
+    if gtop:
+        f[0x04:0x08] = int(round((lat + 1e-4 * k) * 1e6)).to_bytes(4, "big", signed=True)
+        f[0x08:0x0C] = int(round((lon - 2e-4 * k) * 1e6)).to_bytes(4, "big", signed=True)
+        f[0x0C:0x0F] = (int(round((alt_m + 5.2 * k) * 100)) & 0xFFFFFF).to_bytes(3, "big")
+        for p, v in ((0x0F, 321 + k), (0x11, -1234 + 3 * k), (0x13, 498)):
+            f[p:p + 2] = int(v).to_bytes(2, "big", signed=True)
+        f[0x15:0x18] = (114207 + k).to_bytes(3, "big")
+        f[0x18:0x1B] = (170524).to_bytes(3, "big")
+    else:
+        f[2] = 0x20
+        for p, v in ((0x04, 640 + 5 * k), (0x06, -2468 + 7 * k), (0x08, 996)):
+            f[p:p + 2] = int(v).to_bytes(2, "big", signed=True)
+        f[0x0A:0x0E] = (4 * 86400_000 + 42_127_250 + 1000 * k).to_bytes(4, "big")
+        unit = (1 << 30) / 90.0
+        f[0x0E:0x12] = int(round((lat + 1e-4 * k) * unit)).to_bytes(4, "big", signed=True)
+        f[0x12:0x16] = int(round((lon - 2e-4 * k) * unit)).to_bytes(4, "big", signed=True)
+        f[0x16:0x1A] = int(round((alt_m + 5.2 * k) * 1000)).to_bytes(4, "big", signed=True)
+        f[0x1E] = 9; f[0x1F] = 18
+        f[0x20:0x22] = (2314 - 2048).to_bytes(2, "big")             # week number after the 10-bit rollovers
+    f[0x32:0x35] = (14_100_000 + 1000 * k).to_bytes(3, "little")    # reference capacitance count x 1000
+    f[0x35:0x38] = (13_500_000 + 9000 * k).to_bytes(3, "little")    # humidity capacitance count x 1000
+    f[0x3E] = k % 3                                                  # thermistor range
+    f[0x3F:0x41] = (0xA000 | (900 + 310 * (k % 9))).to_bytes(2, "little")
+    f[0x45:0x47] = (655 + k % 5).to_bytes(2, "little")              # battery ADC
+    f[0x48:0x4A] = (2790 + 3 * k).to_bytes(2, "little")             # MCU temperature diode
+    f[0x59:0x5B] = (1500 + 40 * (k % 7)).to_bytes(2, "little")      # second NTC
+    f[0x5D:0x62] = bytes(sn)
+    f[0x62] = k & 0xFF
+    cs = m10_checksum(bytes(f[:99]))
+    if not good_checksum:
+        cs ^= 0x0101
+    f[99] = cs >> 8; f[100] = cs & 0xFF
+    return bytes(f)
+
+
+def m10_symbols(type_bytes=(0x64, 0x9F), n_payload_bytes: int = 99, rng=None, data: bytes | None = None) -> np.ndarray:
     """Raw 2-FSK symbols of one M10-style frame: 1001.. preamble, the 32-symbol header, then the frame bytes as
     Manchester pairs whose first symbol repeats the previous pair's for a 1 and flips for a 0 (what frm_M10 of
     dft_detect.c:932-977 undoes).  The header's last two pairs already carry the first two bits of byte 0."""
     rng = rng or np.random.default_rng(0)
-    data = bytes(type_bytes) + bytes(int(v) for v in rng.integers(0, 256, n_payload_bytes))
+    if data is None:
+        data = bytes(type_bytes) + bytes(int(v) for v in rng.integers(0, 256, n_payload_bytes))
     bits = np.unpackbits(np.frombuffer(data, dtype=np.uint8))          # MSB first
     sym = [int(c) for c in "1001" * 12] + [int(c) for c in M10_RAWHEADER]
     prev = int(M10_RAWHEADER[30])
@@ -433,8 +490,9 @@ def m10_symbols(type_bytes=(0x64, 0x9F), n_payload_bytes: int = 99, rng=None) ->
 
 def m10_capture(sr: int = 48_000, seconds: float = 3.0, fq: float = 0.0, *, type_bytes=(0x64, 0x9F), baud: float = 9616.0,
                 amp: float = 0.5, noise_sigma: float = 0.01, seed: int = 1, dev_hz: float = 3300.0, t_first: float = 0.35,
-                period: float = 1.0, f_offset_hz: float = 0.0) -> np.ndarray:
-    """Interleaved int16 IQ: continuous carrier, one M10/M20-style frame per `period` seconds, 1001.. idle pattern between."""
+                period: float = 1.0, f_offset_hz: float = 0.0, frame_fn=None) -> np.ndarray:
+    """Interleaved int16 IQ: continuous carrier, one M10/M20-style frame per `period` seconds, 1001.. idle pattern between.
+    frame_fn(k) -> frame bytes of the k-th frame (default: random payload behind type_bytes)."""
     rng = np.random.default_rng(seed)
     n = int(round(sr * seconds))
     nsym = int(seconds * baud) + 8
@@ -442,7 +500,7 @@ def m10_capture(sr: int = 48_000, seconds: float = 3.0, fq: float = 0.0, *, type
     k = 0
     while True:
         s0 = int(round((t_first + k * period) * baud)) // 4 * 4
-        fr = m10_symbols(type_bytes, rng=np.random.default_rng(seed * 77 + k))
+        fr = m10_symbols(type_bytes, rng=np.random.default_rng(seed * 77 + k), data=frame_fn(k) if frame_fn else None)
         if s0 + len(fr) > nsym:
             break
         sym[s0:s0 + len(fr)] = fr

@@ -686,6 +686,42 @@ def gen_dfm_fields(outdir):
     np.savez_compressed(os.path.join(outdir, "dfm_fields.npz"), **d)
 
 
+# M10 telemetry text / JSON (print_pos): frame streams at the symbol level through `m10mod --softin`
+M10_FIELD_SCENARIOS = {
+    "m10f_trimble_12": dict(n=12, gtop=False),
+    "m10f_gtop_8": dict(n=8, gtop=True),
+    "m10f_mixed_bad_10": dict(n=10, gtop=False, bad={3, 7}, week_bad={5}),
+}
+M10_FIELD_ARGS = [[], ["-v", "--ptu"], ["-vv", "--ptu"], ["--json", "--ptu", "-vvv"], ["--json", "--jsn_cfq", "405100000"], ["-r", "-v", "--json", "--ptu", "-vv"], ["-r", "-v"]]
+
+
+def m10_field_symbols(sc):
+    """float32 soft symbols: per second 1001.. idle pattern, header, one differentially Manchester-coded frame"""
+    rng = np.random.default_rng(17)
+    out = []
+    for k in range(sc["n"]):
+        fr = bytearray(synth.m10_frame(k, gtop=sc["gtop"], rng=np.random.default_rng(300 + k), good_checksum=k not in sc.get("bad", ())))
+        if k in sc.get("week_bad", ()):
+            fr[0x20:0x22] = (5000).to_bytes(2, "big")              # implausible week: the frame is dropped by the decoder
+            cs = synth.m10_checksum(bytes(fr[:99])); fr[99] = cs >> 8; fr[100] = cs & 0xFF
+        sym = synth.m10_symbols(data=bytes(fr))
+        out.append(sym)
+        out.append(np.tile(np.array([1, 0, 0, 1], np.uint8), (9616 - len(sym)) // 4))
+    s = 2.0 * np.concatenate(out) - 1.0
+    return (s + 0.05 * rng.standard_normal(len(s))).astype("<f4")
+
+
+def gen_m10_fields(outdir):
+    d = {}
+    for name, sc in M10_FIELD_SCENARIOS.items():
+        soft = m10_field_symbols(sc)
+        for k, args in enumerate(M10_FIELD_ARGS):
+            out, err, rc = bind.ref_run("m10mod", args + ["--softin"], soft.tobytes())
+            d["%s|%d" % (name, k)] = np.frombuffer(out.encode(), np.uint8)
+        print(name, len(soft), [len(d["%s|%d" % (name, k)]) for k in range(len(M10_FIELD_ARGS))])
+    np.savez_compressed(os.path.join(outdir, "m10_fields.npz"), **d)
+
+
 def gen_rawhex(outdir):
     """--rawhex: frames as hex lines (clean, correctable, uncorrectable, short, truncated) through the reference's rs41mod"""
     lines = [str(l).split(" ")[0] for l in np.load(os.path.join(outdir, "fsk_rs41_48k_mask.npz"))["rs41_lines"]]
@@ -764,6 +800,7 @@ def main():
     gen_rawhex(outdir)
     gen_fields(outdir)
     gen_dfm_fields(outdir)
+    gen_m10_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_cli_cases({k: dict(v, binary="m10mod") for k, v in M10_CASES.items()}, m10_capture_cli, outdir)
     gen_cli_cases({k: dict(v, binary="m20mod") for k, v in M20_CASES.items()}, m10_capture_cli, outdir)
