@@ -1,33 +1,52 @@
 /*
  * host/m20mod.c — `m20mod` command-line front end on top of libsonde_hip (C).
  *
- * Reference contract kept for the sample-input forms with raw output (reference demod/mod/m20mod.c:1196-1300 argv, :1112-1123
- * output, :1436-1510 frame loop):
+ * Reference contract kept for the sample-input forms with raw output (reference demod/mod/m20mod.c:1055-1200 argv, :918-990
+ * output, :1300-1420 frame loop):
  *     m20mod -r [-v] [--ths x] ( --IQ <fq> | --iq0 | --iq2 | --iq3 [--iqdc] ) [--lpIQ | --lpbw kHz] [--lpFM] [--dc] [--min] - <sr> <bits>
  *     m20mod -r [-v] [--ch2] [file.wav]                                  FM audio
  * stdout: one line of hex per frame (frame byte 0 + 1 bytes), with -v ` # <checksum> [(ok)|(oo)|(no)] [OK]|[NO]` (block check for firmware < 7)
  * stderr: `note: sample rate low`, `IF:` / `dec:`; exit 0 at EOF, 255 on argument / init errors.
- * The position / PTU decode of M20 frames (print_pos) is not part of this build: without -r the program refuses.
+ * Without -r: the position / PTU text line and, with --json, the JSON object (include/sonde_m20.h; -v, -vv, -vvv, --ptu, --json,
+ * --jsn_cfq, --silent); --softin / --softinv take the soft symbols of fsk_demod -s.
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "sonde_m20.h"
 #include "wav_header.h"
 
-static int g_verbose = 0;
+static int g_verbose = 0, g_raw = 0;
+static sonde_m20_dec_t *g_dec = NULL;
 
+/* print_frame() (m20mod.c:870-1003): raw line with -r, else (or with -r --json: silently) the decoded position line / JSON */
 static void emit_frame(const sonde_m20_frame_t *f) {
-    static char ln[420];
-    if (sonde_m20_rawline(f, g_verbose, ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
+    static char ln[420], tx[4096];
+    if (g_raw && sonde_m20_rawline(f, g_verbose, ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
+    if (g_dec && sonde_m20_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
+}
+
+static int make_decoder(sonde_m20_opts_t *o, int raw, int khz) {
+    const char *ver = getenv("SONDE_JSN_VERSION");
+    g_raw = raw;
+    o->raw = raw; o->verbose = g_verbose; o->jsn_freq_khz = khz;
+    if (raw && !o->json && !o->silent) return 0;
+#ifdef VER_JSN_STR
+    if (!ver) ver = VER_JSN_STR;
+#endif
+    if (ver) { strncpy(o->version, ver, sizeof o->version - 1); o->version[sizeof o->version - 1] = 0; }
+    return sonde_m20_dec_create(o, &g_dec);
 }
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, cfreq = -1;
     FILE *fp = stdin;
+    sonde_m20_opts_t dopt;
+    memset(&dopt, 0, sizeof dopt);
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_M20;
@@ -36,6 +55,14 @@ int main(int argc, char **argv) {
         const char *a = argv[i];
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) g_verbose = 1;
+        else if (!strcmp(a, "-vv")) g_verbose = 2;
+        else if (!strcmp(a, "-vvv")) g_verbose = 3;
+        else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
+        else if (!strcmp(a, "--json")) dopt.json = 1;
+        else if (!strcmp(a, "--silent")) dopt.silent = 1;
+        else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
+        else if (!strcmp(a, "--softin")) softin = 1;
+        else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) { /* irrelevant for the differential code (m20mod.c:1447) */ }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
         else if (!strcmp(a, "--IQ")) {
@@ -74,7 +101,23 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "m20mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (!raw) { fprintf(stderr, "m20mod (sonde_hip): only raw output (-r) is implemented\n"); return -1; }
+    if (softin) {                                    /* float32 soft symbols on stdin (m20mod.c:1405-1510) */
+        if (make_decoder(&dopt, raw, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;
+        sonde_softin_t *si = NULL;
+        if (sonde_softin_create(SONDE_M20, 0, softin == 2, 0, 1, &si) < 0) return -1;
+        sonde_softin_set_m10_skip(si, g_verbose < 3);
+        float sb[1024]; sonde_m20_frame_t fr[4]; size_t got;
+        for (;;) {
+            got = fread(sb, 4, 1024, fp);
+            if (got) sonde_softin_push(si, sb, (int32_t)got);
+            if (got < 1024) sonde_softin_finish(si);
+            int k;
+            while ((k = sonde_softin_fetch_m20(si, fr, 4)) > 0) for (int i = 0; i < k; i++) emit_frame(&fr[i]);
+            if (got < 1024) break;
+        }
+        sonde_softin_destroy(si);
+        return 0;
+    }
     if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
     if (have_iq && !have_pcm) {
         if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
@@ -89,6 +132,11 @@ int main(int argc, char **argv) {
         cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
     }
     if ((float)cfg.sample_rate / 9600.0f < 8) fprintf(stderr, "note: sample rate low (%.1f sps)\n", (float)cfg.sample_rate / 9600.0f);   /* m20mod.c:1392 */
+    {
+        const double xlt = (iq_mode == 5) ? -fq : 0.0;
+        if (make_decoder(&dopt, raw, cfreq > 0 ? (int)((cfreq - xlt * cfg.sample_rate + 500) / 1e3) : 0) < 0) return -1;
+    }
+    cfg.m10_noskip = g_verbose >= 3;
     cfg.n_channels = 1;
     cfg.max_chunk = cfg.sample_rate;
     cfg.max_frames = 16;

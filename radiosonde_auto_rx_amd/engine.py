@@ -40,6 +40,16 @@ class SondeDfmFrame(C.Structure):
                 ("frm_count", C.c_float), ("inv", C.c_int32)]
 
 
+class SondeM10Frame(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("nbits", C.c_int32), ("len", C.c_int32), ("cs_ok", C.c_int32), ("cs_calc", C.c_uint32),
+                ("mv_pos", C.c_uint32), ("mv", C.c_float), ("frame", C.c_uint8 * 124)]
+
+
+class SondeM20Frame(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("nbits", C.c_int32), ("len", C.c_int32), ("cs_ok", C.c_int32), ("cs_calc", C.c_uint32),
+                ("blk_ok", C.c_int32), ("fw", C.c_int32), ("mv_pos", C.c_uint32), ("mv", C.c_float), ("frame", C.c_uint8 * 172)]
+
+
 class SondeInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("if_sr", "decM", "dectaps", "lut_len", "lpiq_taps", "lpfm_taps",
                                          "L", "M", "K", "N", "delay")] + \
@@ -76,6 +86,10 @@ def lib() -> C.CDLL:
         L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_engine_fetch_dfm.argtypes = [C.c_void_p, C.POINTER(SondeDfmFrame), C.c_int32, C.c_int32]
         L.sonde_dfm_rawline.argtypes = [C.POINTER(SondeDfmFrame), C.c_int, C.c_char_p, C.c_size_t]
+        L.sonde_engine_fetch_m10.argtypes = [C.c_void_p, C.POINTER(SondeM10Frame), C.c_int32, C.c_int32]
+        L.sonde_engine_fetch_m20.argtypes = [C.c_void_p, C.POINTER(SondeM20Frame), C.c_int32, C.c_int32]
+        L.sonde_m10_rawline.argtypes = [C.POINTER(SondeM10Frame), C.c_int, C.c_char_p, C.c_size_t]
+        L.sonde_m20_rawline.argtypes = [C.POINTER(SondeM20Frame), C.c_int, C.c_char_p, C.c_size_t]
         L.sonde_engine_read_tap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]
         L.sonde_engine_sync.argtypes = [C.c_void_p]
         L.sonde_engine_samples_to_dc_boundary.argtypes = [C.c_void_p]
@@ -117,7 +131,7 @@ class Engine:
         self.ecc = ecc
         self._per_sample = audio_channels if audio else 2      # input words (int16, or uint8 for bits=8) per sample
         self._dtype = {8: np.uint8, 32: np.float32}.get(bits, np.int16)
-        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "frontend": 0}[sonde],
+        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "m10": 10, "m20": 20, "frontend": 0}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline),
                        1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), 0, int(auto))
@@ -197,6 +211,25 @@ class Engine:
             soft = np.zeros((self._max_frames, self.nbits), np.float32)
             nh = _chk(lib().sonde_engine_fetch_soft(self._h, soft.ctypes.data_as(C.c_void_p), self._max_frames))
             return frames, soft[:nh]
+        return frames
+
+    def fetch_mxx(self, finish: bool = False, verbose: int = 1):
+        """M10 / M20 engines: frames as dicts (bytes, checksum verdicts, the `m10mod -r [-v]` / `m20mod -r [-v]` text line)."""
+        m20 = self.sonde == "m20"
+        n = 4 * self._max_frames
+        buf = ((SondeM20Frame if m20 else SondeM10Frame) * n)()
+        L = lib()
+        k = _chk((L.sonde_engine_fetch_m20 if m20 else L.sonde_engine_fetch_m10)(self._h, buf, n, int(finish)))
+        line = C.create_string_buffer(420)
+        frames = []
+        for i in range(k):
+            f = buf[i]
+            ll = (L.sonde_m20_rawline if m20 else L.sonde_m10_rawline)(C.byref(f), verbose, line, 420)
+            d = dict(channel=f.channel, nbits=f.nbits, len=f.len, cs_ok=f.cs_ok, cs_calc=f.cs_calc, mv=f.mv, mv_pos=f.mv_pos,
+                     frame=bytes(f.frame), line=line.raw[:max(ll, 0)].decode())
+            if m20:
+                d.update(blk_ok=f.blk_ok, fw=f.fw)
+            frames.append(d)
         return frames
 
     FRAME_DTYPE = np.dtype([("channel", "<i4"), ("len", "<i4"), ("ecc", "<i4"), ("mv_pos", "<u4"), ("mv", "<f4"),

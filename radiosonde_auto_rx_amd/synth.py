@@ -471,6 +471,45 @@ def m10_frame(k: int = 0, *, gtop: bool = False, lat=48.1, lon=11.6, alt_m=1234.
     return bytes(f)
 
 
+def m20_frame(k: int = 0, *, fw: int = 6, lat=52.2, lon=-4.3, alt_m=2345.6, sn24: int = (1 << 23) | (4321 << 10) | (2 << 7) | 101,
+              rng=None, good_checksum: bool = True, blk: str = "ok", week: int = 2314, pressure_hpa: float = 0.0) -> bytes:
+    """One 70-byte M20 frame (type 0x20): sensor words, the 0x16-byte block with its own check word (blk = "ok" | "zero" | "bad";
+    firmware >= 7 reuses the low check byte as pressure LSB) and the frame checksum over bytes 0..0x43."""
+    rng = rng or np.random.default_rng(k)
+    f = bytearray(rng.integers(0, 256, 70, dtype=np.uint8).tobytes())
+    f[0] = 0x45; f[1] = 0x20
+    f[0x02:0x04] = (30100 + 850 * (k % 11)).to_bytes(2, "little")    # humidity capacitance word
+    f[0x04:0x06] = ((k % 3) * 4096 + 700 + 290 * (k % 10)).to_bytes(2, "little")   # thermistor ADC incl. range bits
+    f[0x06:0x08] = (1400 + 55 * (k % 13)).to_bytes(2, "little")      # NTC on the humidity sensor
+    f[0x08:0x0B] = (int(round((alt_m + 4.7 * k) * 100)) & 0xFFFFFF).to_bytes(3, "big")
+    for p, v in ((0x0B, 512 + 9 * k), (0x0D, -1777 + 5 * k), (0x18, 503 - k)):
+        f[p:p + 2] = int(v).to_bytes(2, "big", signed=True)
+    f[0x0F:0x12] = (3 * 86400 + 51_723 + k).to_bytes(3, "big")
+    f[0x12:0x15] = int(sn24).to_bytes(3, "little")
+    f[0x15] = (17 + k) & 0xFF
+    f[0x1A:0x1C] = int(week).to_bytes(2, "big")                      # < 1304 gets one 10-bit rollover added by the decoder
+    f[0x1C:0x20] = int(round((lat + 1e-4 * k) * 1e6)).to_bytes(4, "big", signed=True)
+    f[0x20:0x24] = int(round((lon - 2e-4 * k) * 1e6)).to_bytes(4, "big", signed=True)
+    pv = int(round(pressure_hpa * 4096))
+    f[0x24:0x26] = ((pv >> 8) & 0xFFFF).to_bytes(2, "little")
+    f[0x26] = 198 + k % 20                                           # battery
+    f[0x2F:0x31] = (31000 + 3 * k).to_bytes(2, "little")             # humidity calibration word
+    f[0x43] = fw
+    bc = m10_checksum(bytes([0x16]) + bytes(f[2:2 + 0x14]))
+    if blk == "zero":
+        bc = 0
+    elif blk == "bad":
+        bc ^= 0x1010
+    f[0x16] = bc >> 8; f[0x17] = bc & 0xFF
+    if fw >= 7:
+        f[0x16] = pv & 0xFF
+    cs = m10_checksum(bytes(f[:0x44]))
+    if not good_checksum:
+        cs ^= 0x0101
+    f[0x44] = cs >> 8; f[0x45] = cs & 0xFF
+    return bytes(f)
+
+
 def m10_symbols(type_bytes=(0x64, 0x9F), n_payload_bytes: int = 99, rng=None, data: bytes | None = None) -> np.ndarray:
     """Raw 2-FSK symbols of one M10-style frame: 1001.. preamble, the 32-symbol header, then the frame bytes as
     Manchester pairs whose first symbol repeats the previous pair's for a 1 and flips for a 0 (what frm_M10 of

@@ -1,4 +1,4 @@
-"""ctypes bindings of the telemetry tier (include/sonde_rs41.h, include/sonde_dfm.h): frames -> the reference's text / JSON.
+"""ctypes bindings of the telemetry tier (include/sonde_rs41.h, sonde_dfm.h, sonde_m10.h, sonde_m20.h): frames -> the reference's text / JSON.
 
 Host-side, no GPU involved.  `Rs41Telemetry.decode(frame_dict)` takes what Engine.fetch_frames() returns and gives back the
 characters `rs41mod` prints for that frame; `.json(frame_dict)` parses the JSON object out of them (None if the frame did not
@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 
-from .engine import SondeDfmFrame, SondeFrame, SondeError, lib
+from .engine import SondeDfmFrame, SondeFrame, SondeM10Frame, SondeM20Frame, SondeError, lib
 
 
 class Rs41Opts(C.Structure):
@@ -93,3 +93,55 @@ class DfmTelemetry:
             if line.startswith("{"):
                 return json.loads(line)
         return None
+
+
+class MxxOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("verbose", "ptu", "json", "silent", "raw", "jsn_freq_khz")] + \
+               [("version", C.c_char * 32), ("reserved", C.c_int32 * 4)]
+
+
+class _MxxTelemetry:
+    _name, _frame, _flen = "", None, 0
+
+    def __init__(self, *, verbose: int = 1, ptu: bool = True, freq_khz: int = 0, version: str = "sonde_hip", silent: bool = False):
+        L = lib()
+        self._create, self._dec, self._destroy = (getattr(L, "sonde_%s_dec_%s" % (self._name, n)) for n in ("create", "frame", "destroy"))
+        self._create.argtypes = [C.POINTER(MxxOpts), C.POINTER(C.c_void_p)]
+        self._dec.argtypes = [C.c_void_p, C.POINTER(self._frame), C.c_char_p, C.c_size_t]
+        self._destroy.argtypes = [C.c_void_p]
+        o = MxxOpts(verbose=verbose, ptu=int(ptu), json=1, silent=int(silent), jsn_freq_khz=freq_khz, version=version.encode())
+        self._h = C.c_void_p()
+        if self._create(C.byref(o), C.byref(self._h)) < 0:
+            raise SondeError("sonde_%s_dec_create: unsupported options" % self._name)
+        self._buf = C.create_string_buffer(8192)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def decode(self, frame: dict) -> str:
+        f = self._frame(**{k: frame[k] for k, _ in self._frame._fields_ if k != "frame"})
+        raw = bytes(frame["frame"])
+        C.memmove(f.frame, raw + bytes(self._flen - len(raw)), self._flen)
+        if self._dec(self._h, C.byref(f), self._buf, len(self._buf)) < 0:
+            raise SondeError("sonde_%s_dec_frame failed" % self._name)
+        return self._buf.value.decode(errors="replace")
+
+    def json(self, frame: dict):
+        for line in self.decode(frame).splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return None
+
+
+class M10Telemetry(_MxxTelemetry):
+    """`m10mod -v --ptu --json` behind Engine(sonde="m10").fetch_mxx()"""
+    _name, _frame, _flen = "m10", SondeM10Frame, 124
+
+
+class M20Telemetry(_MxxTelemetry):
+    """`m20mod -v --ptu --json` behind Engine(sonde="m20").fetch_mxx()"""
+    _name, _frame, _flen = "m20", SondeM20Frame, 172

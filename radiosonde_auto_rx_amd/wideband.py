@@ -1,4 +1,4 @@
-"""One wideband IQ stream -> every RS41 and DFM in it, in one process on one GPU.
+"""One wideband IQ stream -> every RS41, DFM, M10 and M20 in it, in one process on one GPU.
 
 The reference handles a wideband source by starting one detector process per candidate peak (auto_rx/autorx/scan.py:413-656:
 rtl_power peaks -> `dft_detect` per peak) and then one decoder pipeline per sonde (decode.py).  Here the same two steps run
@@ -20,7 +20,7 @@ import numpy as np
 from .engine import Engine
 from .scan import Scanner
 from .synth import snap_fq
-from .telemetry import DfmTelemetry, Rs41Telemetry
+from .telemetry import DfmTelemetry, M10Telemetry, M20Telemetry, Rs41Telemetry
 
 
 class WidebandReceiver:
@@ -38,13 +38,16 @@ class WidebandReceiver:
 
     def _start(self, fq: float, typ: str):
         for s in self.sondes:
-            if abs(s["fq"] - fq) * self.sr < self.merge_hz:
+            if abs(s["fq"] - fq) * self.sr < self.merge_hz * (3 if typ in ("M10", "M20") else 1):    # 9.6 kBd: seen from neighbouring raster points too
                 return
         fq = snap_fq(fq, self.sr)
         khz = int(round((self.cfreq + fq * self.sr) / 1000.0)) if self.cfreq else 0
         if typ == "DFM":
             eng = Engine([fq], self.sr, sonde="dfm", ecc=1, auto=True, max_chunk=self.chunk, max_frames=8)
             tel = DfmTelemetry(freq_khz=khz, version=self.version)
+        elif typ in ("M10", "M20"):
+            eng = Engine([fq], self.sr, sonde=typ.lower(), max_chunk=self.chunk, max_frames=8)
+            tel = (M10Telemetry if typ == "M10" else M20Telemetry)(freq_khz=khz, version=self.version)
         else:
             eng = Engine([fq], self.sr, max_chunk=self.chunk, max_frames=8)
             tel = Rs41Telemetry(freq_khz=khz, version=self.version)
@@ -64,6 +67,8 @@ class WidebandReceiver:
                     self._start(self.raster[d["channel"]] + d["df"], "RS41")
                 elif d["type"] == "DFM9":                                   # either polarity: the decoder runs with --auto
                     self._start(self.raster[d["channel"]] + d["df"], "DFM")
+                elif d["type"] in ("M10", "M20"):                           # differential code: polarity does not matter
+                    self._start(self.raster[d["channel"]] + d["df"], d["type"])
             for s in self.sondes:
                 s["engine"].process_host(x)
                 out += self._drain(s, False)
@@ -74,7 +79,8 @@ class WidebandReceiver:
 
     @staticmethod
     def _drain(s, finish):
-        frames = s["engine"].fetch_dfm(finish=finish) if s["type"] == "DFM" else s["engine"].fetch_frames(finish=finish)
+        e = s["engine"]
+        frames = e.fetch_dfm(finish=finish) if s["type"] == "DFM" else e.fetch_mxx(finish=finish) if s["type"] in ("M10", "M20") else e.fetch_frames(finish=finish)
         out = []
         for fr in frames:
             js = s["telemetry"].json(fr)

@@ -189,3 +189,37 @@ def test_dfm_iq_json_identical():
     b = subprocess.run([os.path.join(REF, "dfm09mod")] + args, input=iq.tobytes(), capture_output=True, timeout=180)
     assert a.returncode == 0 and a.stdout == b.stdout
     assert a.stdout.count(b'"type": "DFM"') >= 2 and b"DFM-18012345" in a.stdout
+
+
+def test_wideband_receiver_m10_m20():
+    """One 2.4 Msps stream with an M10 (Trimble), an M20 and an RS41: the scanner tells M10 from M20 by the first frame bytes, the
+    receiver starts the matching 9615 / 9600 Bd demodulator and every frame with a good checksum comes out as JSON."""
+    from radiosonde_auto_rx_amd import synth
+    from radiosonde_auto_rx_amd.wideband import WidebandReceiver
+    sr, cf, secs = 2_400_000, 404_000_000, 6.3
+    n = int(sr * secs)
+    x = np.zeros(n, np.complex128)
+
+    def add(cap, hz, amp):
+        z = (cap[0::2].astype(np.float64) + 1j * cap[1::2].astype(np.float64)) / (32767 * 0.9)
+        x[:len(z)] += (amp / 0.5) * z[:n] * np.exp(2j * np.pi * hz / sr * np.arange(min(n, len(z))))
+
+    add(synth.m10_capture(sr=sr, seconds=secs, noise_sigma=0.0, seed=41, frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(900 + k))), +301_700.0, 0.25)
+    add(synth.m10_capture(sr=sr, seconds=secs, noise_sigma=0.0, seed=42, baud=9600.0, t_first=0.6,
+                          frame_fn=lambda k: synth.m20_frame(k, fw=8, pressure_hpa=455.5, rng=np.random.default_rng(950 + k))), -608_300.0, 0.25)
+    add(synth.rs41_capture(sr=sr, seconds=secs, fq=0.0, n_frames=5, t_first=0.4, noise_sigma=0.0, amp=0.5, seed=43, sonde_id="D4444444",
+                           frame_kw=dict(ecef_cm=(418833319, 85974133, 473346430))), +55_000.0, 0.2)
+    rng = np.random.default_rng(6)
+    x += 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767); iq[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767)
+    rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000)
+    out = rx.push(iq, finish=True)
+    kinds = sorted((s["type"], s["khz"]) for s in rx.sondes)
+    rx.close()
+    assert [k for k, _ in kinds] == ["M10", "M20", "RS41"], rx.log
+    m10 = [j for j in out if j["type"] == "M10"]
+    m20 = [j for j in out if j["type"] == "M20"]
+    assert len(m10) >= 4 and all(abs(j["freq"] - 404_302) <= 3 and abs(j["lat"] - 48.1) < 0.01 and "temp" in j for j in m10), m10[:1]
+    assert len(m20) >= 3 and all(abs(j["freq"] - 403_392) <= 3 and j["id"] == "M20-806-3-14321" and abs(j["pressure"] - 455.5) < 0.01 for j in m20), m20[:1]
+    assert len([j for j in out if j["type"] == "RS41" and j["id"] == "D4444444"]) >= 3

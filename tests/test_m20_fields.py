@@ -1,0 +1,36 @@
+"""M20 telemetry text / JSON (the reference's m20mod print_pos(), m20mod.c:742-868) — include/sonde_m20.h — and the soft-symbol
+framer behind `m20mod --softin`, host side, no GPU.
+
+Frame streams at the symbol level: firmware 6 frames with a good / zero / wrong block check, firmware 8 frames with the pressure
+word in all three print precisions (and none / out of range), frames with a bad checksum, an implausible week, a week before
+the rollover repair, an all-zero serial — each through seven option sets (-v / -vv / -vvv, --ptu, --json, --jsn_cfq, -r).
+Golden = stdout of the compiled reference on the same symbols (tools/make_golden.py gen_m20_fields); byte for byte."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.M20_FIELD_SCENARIOS))
+def test_cli_m20_telemetry_matches_reference(name):
+    from radiosonde_auto_rx_amd import engine
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "m20_fields.npz"))
+    soft = make_golden.m20_field_symbols(make_golden.M20_FIELD_SCENARIOS[name]).tobytes()
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    total = 0
+    for k, args in enumerate(make_golden.M20_FIELD_ARGS):
+        r = subprocess.run([os.path.join(ROOT, "host", "bin", "m20mod")] + args + ["--softin"], input=soft, capture_output=True, env=env, timeout=120)
+        want = gold["%s|%d" % (name, k)].tobytes()
+        assert r.returncode == 0
+        assert r.stdout == want, (name, args)
+        total += len(want)
+    assert total > 5000

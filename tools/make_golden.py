@@ -722,6 +722,46 @@ def gen_m10_fields(outdir):
     np.savez_compressed(os.path.join(outdir, "m10_fields.npz"), **d)
 
 
+# M20 telemetry text / JSON (print_pos): frame streams at the symbol level through `m20mod --softin`
+M20_FIELD_SCENARIOS = {
+    "m20f_fw6_12": dict(n=12, fw=6, blk={4: "zero", 9: "bad"}),
+    "m20f_fw8_press_10": dict(n=10, fw=8, pressure=[873.26, 91.337, 7.0625, 0.0, 2600.0, 500.0, 12.5, 300.25, 1013.25, 99.99]),
+    "m20f_mixed_bad_10": dict(n=10, fw=6, bad={2, 6}, week_bad={5}, sn0={7, 8}, week_lo={3}),
+}
+M20_FIELD_ARGS = [[], ["-v", "--ptu"], ["-vv", "--ptu"], ["--json", "--ptu", "-vvv"], ["--json", "--jsn_cfq", "403010000"], ["-r", "-v", "--json", "--ptu", "-vv"], ["-r", "-v"]]
+
+
+def m20_field_symbols(sc):
+    rng = np.random.default_rng(19)
+    out = []
+    for k in range(sc["n"]):
+        kw = dict(fw=sc["fw"], rng=np.random.default_rng(500 + k), good_checksum=k not in sc.get("bad", ()), blk=sc.get("blk", {}).get(k, "ok"))
+        if "pressure" in sc:
+            kw["pressure_hpa"] = sc["pressure"][k]
+        if k in sc.get("week_bad", ()):
+            kw["week"] = 4500                                       # implausible week: the frame is dropped by the decoder
+        if k in sc.get("week_lo", ()):
+            kw["week"] = 2314 - 2048                                # before the rollover repair
+        if k in sc.get("sn0", ()):
+            kw["sn24"] = 0
+        sym = synth.m10_symbols(data=synth.m20_frame(k, **kw))
+        out.append(sym)
+        out.append(np.tile(np.array([1, 0, 0, 1], np.uint8), (9600 - len(sym)) // 4))
+    s = 2.0 * np.concatenate(out) - 1.0
+    return (s + 0.05 * rng.standard_normal(len(s))).astype("<f4")
+
+
+def gen_m20_fields(outdir):
+    d = {}
+    for name, sc in M20_FIELD_SCENARIOS.items():
+        soft = m20_field_symbols(sc)
+        for k, args in enumerate(M20_FIELD_ARGS):
+            out, err, rc = bind.ref_run("m20mod", args + ["--softin"], soft.tobytes())
+            d["%s|%d" % (name, k)] = np.frombuffer(out.encode(), np.uint8)
+        print(name, len(soft), [len(d["%s|%d" % (name, k)]) for k in range(len(M20_FIELD_ARGS))])
+    np.savez_compressed(os.path.join(outdir, "m20_fields.npz"), **d)
+
+
 def gen_rawhex(outdir):
     """--rawhex: frames as hex lines (clean, correctable, uncorrectable, short, truncated) through the reference's rs41mod"""
     lines = [str(l).split(" ")[0] for l in np.load(os.path.join(outdir, "fsk_rs41_48k_mask.npz"))["rs41_lines"]]
@@ -801,6 +841,7 @@ def main():
     gen_fields(outdir)
     gen_dfm_fields(outdir)
     gen_m10_fields(outdir)
+    gen_m20_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_cli_cases({k: dict(v, binary="m10mod") for k, v in M10_CASES.items()}, m10_capture_cli, outdir)
     gen_cli_cases({k: dict(v, binary="m20mod") for k, v in M20_CASES.items()}, m10_capture_cli, outdir)
