@@ -1,0 +1,247 @@
+/*
+ * host/seam/demod_mod_hip.c — the reference's function-level seam (demod/mod/demod_mod.h:179-192) on top of libsonde_hip.
+ *
+ * Drop this file into the reference's demod/mod/ in place of demod_mod.c (it includes the reference's own demod_mod.h, which is not
+ * shipped here) and link the decoders against libsonde_hip:
+ *
+ *     gcc -O2 -I<repo>/include -I<repo>/host rs41mod.c bch_ecc_mod.c demod_mod_hip.c -L<repo>/radiosonde_auto_rx_amd -lsonde_hip -lm -o rs41mod
+ *
+ * The reference's own main() then drives the GPU engine: every option, every print_frame() / print_position() of rs41mod.c,
+ * dfm09mod.c, m10mod.c, m20mod.c stays the reference's code; only the sample-rate work behind find_header() / read_softbit*()
+ * runs on the MI355X.  oracle/Makefile builds exactly that (the *_seam binaries under oracle/_ref) and tests/test_gpu_seam.py compares it with the
+ * all-CPU reference binaries.
+ *
+ *   init_buffers()   demod_mod.c:1208   -> sonde_engine_create() from the dsp_t fields the caller filled in (rs41mod.c:2816-2836);
+ *                                          writes back sr / sps / _spb / decM / dectaps / L / M / K / delay, prints IF: / dec:
+ *   find_header()    :1533              -> pull: read a block from dsp->fp, sonde_engine_process_host(), sonde_engine_fetch_hits();
+ *                                          sets dsp->mv / mv_pos, returns 1 per header (either polarity: the caller decides), EOF at the end
+ *   read_softbit2p() :1087, read_softbit() :1012, read_slbit() :942  -> soft bit `pos` of the current hit (raw polarity)
+ *   free_buffers()   :1476              -> sonde_engine_destroy()
+ *   read_wav_header() :313, f32soft_read() :1718, find_softbinhead() :1740, find_binhead() :1668  -> host code, no GPU
+ *
+ * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs
+ * of the sonde type's preset are used except `thres` (taken from the first find_header call); a header of the wrong polarity that the
+ * caller skips still has its frame consumed; the second soft bit of read_softbit2p (one sample earlier, used by --ecc3) equals the first;
+ * f32buf_sample() is not available (EOF).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "demod_mod.h"          /* the reference's header */
+#include "sonde_hip.h"
+#include "wav_header.h"
+
+#define SEAM_MAXHITS 16
+
+static struct {
+    sonde_engine_t *eng;
+    sonde_info_t info;
+    int nbits;                  /* soft bits per hit of this sonde type */
+    size_t unit;                /* bytes per input sample */
+    int chunk;
+    char *buf; size_t have;
+    int eof, started;
+    sonde_hit_t hit[SEAM_MAXHITS];
+    float *soft;
+    int qn, qi;
+    const float *cur; int cur_nbits, cur_inv;
+} S;
+
+static int seam_type(const dsp_t *dsp) {
+    const int br = (int)(dsp->br + 0.5f);
+    if (dsp->hdrlen == 64 && br == 4800) return SONDE_RS41;
+    if (dsp->hdrlen == 32 && br == 2500) return SONDE_DFM09;
+    if (dsp->hdrlen == 32 && (br == 9615 || br == 9616)) return SONDE_M10;
+    if (dsp->hdrlen == 32 && br == 9600) return SONDE_M20;
+    return -1;
+}
+
+int init_buffers(dsp_t *dsp) {
+    sonde_cfg_t cfg;
+    double fq = -dsp->xlt_fq;
+    const int type = seam_type(dsp);
+    if (S.eng) { fprintf(stderr, "demod_mod_hip: one dsp_t at a time\n"); return -1; }
+    if (type < 0) { fprintf(stderr, "demod_mod_hip: sonde type (baud %.0f, header %d) not supported\n", dsp->br, dsp->hdrlen); return -1; }
+    memset(&cfg, 0, sizeof cfg);
+    cfg.abi_version = SONDE_ABI_VERSION;
+    cfg.n_channels = 1;
+    cfg.sample_rate = dsp->sr;
+    cfg.bits = dsp->bps;
+    cfg.sonde_type = type;
+    cfg.opt_lp = dsp->opt_lp & (SONDE_LP_IQ | SONDE_LP_FM);
+    cfg.opt_dc = dsp->opt_dc != 0;
+    cfg.opt_min = dsp->opt_IFmin != 0;
+    cfg.lpiq_bw = dsp->lpIQ_bw;
+    cfg.opt_iqdc = dsp->opt_iqdc != 0;
+    cfg.opt_nolut = dsp->opt_nolut != 0;
+    cfg.opt_auto = 1;                               /* headers of both polarities are reported; the caller skips or flips */
+    cfg.keep_soft = 1;
+    cfg.max_frames = SEAM_MAXHITS;
+    cfg.max_chunk = dsp->sr;
+    switch (dsp->opt_iq) {
+        case 0: cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = dsp->nch < 1 ? 1 : dsp->nch;
+                cfg.audio_select = (dsp->ch >= 0 && dsp->ch < cfg.audio_channels) ? dsp->ch : 0; break;
+        case 1: cfg.input = SONDE_IN_IFIQ0; break;
+        case 2: cfg.input = SONDE_IN_IFIQ2; break;
+        case 3: cfg.input = SONDE_IN_IFIQ3; break;
+        case 5: cfg.input = SONDE_IN_IQ; break;
+        default: return -1;
+    }
+    if (dsp->opt_iq && dsp->nch != 2) return -1;
+    int rc = sonde_engine_create(&cfg, &fq, &S.eng);
+    if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); S.eng = NULL; return -1; }
+    sonde_engine_info(S.eng, &S.info);
+    if (dsp->opt_iq == 5) {
+        dsp->sr_base = (ui32_t)dsp->sr;
+        dsp->sr = S.info.if_sr;
+        dsp->sps /= (float)S.info.decM;
+        dsp->_spb /= (float)S.info.decM;
+        dsp->decM = S.info.decM;
+        dsp->dectaps = (ui32_t)S.info.dectaps;
+        fprintf(stderr, "IF: %d\n", S.info.if_sr);
+        fprintf(stderr, "dec: %d\n", S.info.decM);
+    }
+    dsp->L = S.info.L; dsp->M = S.info.M; dsp->K = S.info.K; dsp->delay = (ui32_t)S.info.delay;
+    S.nbits = type == SONDE_RS41 ? 510 * 8 : type == SONDE_DFM09 ? 264 + 7 * 280 : type == SONDE_M10 ? (101 + 20) * 8 : (101 + 64) * 8;
+    S.unit = (size_t)(dsp->opt_iq ? 2 : cfg.audio_channels) * (size_t)(dsp->bps / 8);
+    S.chunk = cfg.sample_rate / 10;
+    S.chunk -= S.chunk % S.info.decM;
+    if (S.chunk < S.info.decM) S.chunk = S.info.decM;
+    S.buf = (char *)malloc((size_t)S.chunk * S.unit);
+    S.soft = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
+    S.have = 0; S.eof = 0; S.started = 0; S.qn = S.qi = 0; S.cur = NULL; S.cur_nbits = 0;
+    if (!S.buf || !S.soft) return -1;
+    return S.info.K;
+}
+
+int free_buffers(dsp_t *dsp) {
+    (void)dsp;
+    if (S.eng) sonde_engine_destroy(S.eng);
+    free(S.buf); free(S.soft);
+    memset(&S, 0, sizeof S);
+    return 0;
+}
+
+int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
+    (void)hdmax; (void)bitofs; (void)opt_dc;
+    if (!S.eng) return EOF;
+    if (!S.started) { sonde_engine_set_threshold(S.eng, thres); S.started = 1; }
+    for (;;) {
+        if (S.qi < S.qn) {
+            const sonde_hit_t *h = &S.hit[S.qi];
+            S.cur = S.soft + (size_t)S.qi * S.nbits;
+            S.cur_nbits = h->nbits; S.cur_inv = h->mv < 0.f;
+            S.qi++;
+            dsp->mv = h->mv; dsp->mv_pos = h->mv_pos;
+            return 1;
+        }
+        S.cur = NULL; S.cur_nbits = 0;
+        if (S.eof) return EOF;
+        size_t got = fread(S.buf + S.have, 1, (size_t)S.chunk * S.unit - S.have, dsp->fp);
+        S.have += got;
+        int n = (int)(S.have / S.unit);
+        n -= n % S.info.decM;
+        if (n > 0) {
+            int rc = sonde_engine_process_host(S.eng, S.buf, n, n);
+            if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); return EOF; }
+            memmove(S.buf, S.buf + (size_t)n * S.unit, S.have - (size_t)n * S.unit);
+            S.have -= (size_t)n * S.unit;
+        }
+        if (got == 0) S.eof = 1;
+        S.qn = sonde_engine_fetch_hits(S.eng, S.hit, SEAM_MAXHITS, S.eof);
+        if (S.qn < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(S.qn)); S.qn = 0; return EOF; }
+        if (S.qn > 0) sonde_engine_fetch_soft(S.eng, S.soft, S.qn);
+        S.qi = 0;
+    }
+}
+
+static int seam_bit(int inv, int pos, float *sb) {
+    if (!S.cur || pos < 0 || pos >= S.cur_nbits) return EOF;
+    float s = S.cur[pos];
+    if (S.cur_inv) s = -s;                          /* the engine stores the bits in the polarity in effect; the reference returns them raw */
+    if (inv) s = -s;
+    *sb = s;
+    return 0;
+}
+
+int read_softbit2p(dsp_t *dsp, hsbit_t *shb, int inv, int ofs, int pos, float l, int spike, hsbit_t *shb1) {
+    float s;
+    (void)dsp; (void)ofs; (void)l; (void)spike;
+    if (seam_bit(inv, pos, &s) == EOF) return EOF;
+    shb->sb = s; shb->hb = (s >= 0.f);
+    if (shb1) *shb1 = *shb;
+    return 0;
+}
+
+int read_softbit(dsp_t *dsp, hsbit_t *shb, int inv, int ofs, int pos, float l, int spike) {
+    return read_softbit2p(dsp, shb, inv, ofs, pos, l, spike, NULL);
+}
+
+/* hard bit; behind the end of a hit (the M10 / M20 "rest of the second") the engine has already skipped: 0 until the stream is over */
+int read_slbit(dsp_t *dsp, int *bit, int inv, int ofs, int pos, float l, int spike) {
+    float s;
+    (void)dsp; (void)ofs; (void)l; (void)spike;
+    if (seam_bit(inv, pos, &s) == 0) { *bit = (s >= 0.f); return 0; }
+    if (S.eof && S.qi >= S.qn) return EOF;
+    *bit = 0;
+    return 0;
+}
+
+int f32buf_sample(dsp_t *dsp, int inv) { (void)dsp; (void)inv; return EOF; }
+
+/* ---------------------------------------------------------------- host-only helpers of demod_mod.c the decoders link against */
+
+int read_wav_header(pcm_t *pcm, FILE *fp) {
+    int sr = 0, bits = 0, nch = 0;
+    if (wav_read_header(fp, &sr, &bits, &nch) < 0) return -1;
+    pcm->sr = sr; pcm->bps = bits; pcm->nch = nch;
+    if (pcm->sel_ch < 0 || pcm->sel_ch >= nch) pcm->sel_ch = 0;
+    return 0;
+}
+
+int f32soft_read(FILE *fp, float *s, int inv) {
+    float v;
+    if (fread(&v, 4, 1, fp) != 1) return EOF;
+    *s = inv ? -v : v;
+    return 0;
+}
+
+/* share of header bits the last hdb->len bits agree with, signed by polarity (cmp_hdb, demod_mod.c:1639-1666) */
+int find_binhead(FILE *fp, hdb_t *hdb, float *score) {
+    const int n = hdb->len;
+    int c;
+    while ((c = fgetc(fp)) != EOF) {
+        int e1 = 0;
+        hdb->bufpos = (hdb->bufpos + 1) % n;
+        hdb->buf[hdb->bufpos] = (char)(0x30 | (c & 1));
+        for (int i = 0, j = hdb->bufpos; i < n; i++, j--) {
+            if (j < 0) j = n - 1;
+            if (hdb->buf[j] != hdb->hdr[n - 1 - i]) e1++;
+        }
+        const int e2 = n - e1;                       /* errors against the inverted header */
+        const float mv = e2 < e1 ? (float)(-n + e2) / (float)n : (float)(n - e1) / (float)n;
+        if (mv > hdb->thb || -mv > hdb->thb) { *score = mv; return 1; }
+    }
+    return EOF;
+}
+
+/* normalised correlation of the last hdb->len soft bits with the +-1 header (corr_softhdb, demod_mod.c:1692-1716) */
+int find_softbinhead(FILE *fp, hdb_t *hdb, float *score, int inv) {
+    const int n = hdb->len;
+    float sbit;
+    while (f32soft_read(fp, &sbit, inv) != EOF) {
+        double sum = 0.0, nx = 0.0, ny = 0.0;
+        hdb->bufpos = (hdb->bufpos + 1) % n;
+        hdb->sbuf[hdb->bufpos] = sbit;
+        for (int i = 0, j = hdb->bufpos + 1; i < n; i++, j++) {
+            if (j >= n) j = 0;
+            const float x = hdb->sbuf[j], y = (float)(2.0 * (hdb->hdr[i] & 1) - 1.0);
+            sum += y * hdb->sbuf[j]; nx += x * x; ny += y * y;
+        }
+        sum /= sqrt(nx * ny);
+        const float mv = (float)sum;
+        if (mv > hdb->ths || -mv > hdb->ths) { *score = mv; return 1; }
+    }
+    return EOF;
+}

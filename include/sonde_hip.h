@@ -165,6 +165,20 @@ int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t ma
  * sonde_engine_fetch_frames().  Frames are never lost: what is not returned stays queued. */
 int  sonde_engine_fetch_frames_lagged(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int32_t lag);
 
+/* Function-level seam: one header hit the way the reference's own main() sees it between find_header() and
+ * read_softbit2p() (demod_mod.h:179-192) — score, position and how many soft bits were sliced behind it.  Any sonde type; needs
+ * cfg.keep_soft.  The soft bits (hsbit_t.sb, in the polarity in effect) of the hits returned by the last call come from
+ * sonde_engine_fetch_soft().  No ECC / framing is run.  host/seam/demod_mod_hip.c builds the reference's pull API on this. */
+typedef struct {
+    int32_t  channel;
+    int32_t  nbits;          /* soft bits sliced for this hit (type's frame length unless the stream ended) */
+    uint32_t mv_pos;
+    float    mv;             /* negative: header of inverted polarity (the stored soft bits are already flipped) */
+} sonde_hit_t;
+int  sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, int32_t finish);
+/* find_header()'s threshold argument (demod_mod.c:1533) for the following process calls */
+int  sonde_engine_set_threshold(sonde_engine_t *e, float thres);
+
 /* DFM engines: frames completed so far (syncs; Hamming decode of dfm09mod.c:240-345 on the host).  cfg.ecc_level 0/1/2
  * = none / --ecc / --ecc2 (soft 2-bit pass).  finish != 0: end of input, also emits the complete frames of a hit
  * in progress (a partial frame is dropped like dfm09mod.c:1713). */

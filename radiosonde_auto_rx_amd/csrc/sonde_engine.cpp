@@ -770,6 +770,29 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
     return ovf ? SONDE_E_OVERFLOW : n;
 }
 
+int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, int32_t finish) {
+    if (!e || !out || max < 0 || !e->d_soft || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    if (finish) launch_framesync(e, 1);
+    std::vector<FrameRec> recs;
+    std::vector<float> soft;
+    const int n = collect_records(e, 0, recs, &soft, max);
+    if (n < 0) return n;
+    e->last_soft = soft; e->last_n = n;
+    for (int i = 0; i < n; i++) {
+        const FrameRec &r = recs[i];
+        out[i].channel = r.channel; out[i].mv = r.mv; out[i].mv_pos = r.mv_pos;
+        out[i].nbits = e->cfg.sonde_type == SONDE_RS41 ? 8 * (r.nbytes - 8) : r.nbytes;      // RS41 records count bytes incl. the 8 header bytes
+    }
+    const bool ovf = e->overflow; e->overflow = false;
+    return ovf ? SONDE_E_OVERFLOW : n;
+}
+
+int sonde_engine_set_threshold(sonde_engine_t *e, float thres) {
+    if (!e || !(thres > 0.f) || thres >= 1.f) return SONDE_E_ARG;
+    e->thres = thres;
+    return 0;
+}
+
 int sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
     if (!e || !out) return SONDE_E_ARG;
     launch_framesync(e, 1);

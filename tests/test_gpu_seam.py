@@ -1,0 +1,93 @@
+"""The function-level seam: the reference's OWN decoders — their main(), option handling, framing, ECC, telemetry
+and JSON code, compiled from the sources where they lie — linked against host/seam/demod_mod_hip.c instead of demod_mod.c, so that
+init_buffers() / find_header() / read_softbit*() run on the GPU engine.  oracle/Makefile builds them (oracle/_ref/*_seam); here they
+run next to the all-CPU reference binaries on the same input and must print the same stdout, byte for byte.
+
+Covers the argv auto_rx uses (decode.py:417,517,544) on --IQ input, FM-audio WAV, IF-rate IQ, --dc, inverted polarity with -i / --auto,
+8-bit input, and end of input inside a frame."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_golden  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+REF = os.path.join(ROOT, "oracle", "_ref")
+ECEF = dict(ecef_cm=(418833319, 85974133, 473346430))
+
+
+def _both(binary, args, stdin):
+    seam, ref = os.path.join(REF, binary + "_seam"), os.path.join(REF, binary)
+    if not (os.path.exists(seam) and os.path.exists(ref)):
+        pytest.skip("oracle/_ref seam binaries not built (make -C oracle ref)")
+    a = subprocess.run([seam] + args, input=stdin, capture_output=True, timeout=300)
+    b = subprocess.run([ref] + args, input=stdin, capture_output=True, timeout=300)
+    assert a.returncode == b.returncode == 0, (a.returncode, a.stderr[-400:])
+    assert a.stdout == b.stdout, (binary, args, a.stdout[:300], b.stdout[:300])
+    return a.stdout
+
+
+def _rs41(sr, secs, fq, **kw):
+    from radiosonde_auto_rx_amd import synth
+    fq = synth.snap_fq(fq, sr)
+    return synth.rs41_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.02, frame_kw=ECEF, **kw), fq
+
+
+@pytest.mark.parametrize("args", [["--ptu2", "--json", "--jsnsubfrm1"], ["-r", "--ecc2", "--crc"], ["-v", "--ecc", "--dc", "--json"]])
+def test_seam_rs41_iq(args):
+    x, fq = _rs41(2_400_000, 4.3, 0.12, n_frames=4, t_first=0.1, seed=91, bit_errors=3)
+    out = _both("rs41mod", args + ["--IQ", repr(fq), "--lpIQ", "-", "2400000", "16"], x.tobytes())
+    assert len(out.splitlines()) >= 4
+
+
+def test_seam_rs41_eof_inside_frame_and_8bit():
+    from radiosonde_auto_rx_amd import synth
+    x, fq = _rs41(2_400_000, 3.3, -0.2, n_frames=3, t_first=0.1, seed=92)
+    x = x[:2 * int(2_400_000 * 2.4)]                                           # third frame cut by the end of the stream
+    out = _both("rs41mod", ["-r", "--ecc2", "--IQ", repr(fq), "--lpIQ", "-", "2400000", "16"], x.tobytes())
+    assert len(out.splitlines()) == 3 and out.splitlines()[2].endswith(b"[NO] (--)")
+    _both("rs41mod", ["-r", "--ecc2", "--IQ", repr(fq), "--lpIQ", "-", "2400000", "8"], synth.to_u8(x).tobytes())
+
+
+def test_seam_rs41_audio_wav_and_ifiq():
+    from radiosonde_auto_rx_amd import synth
+    x, _ = _rs41(48_000, 4.3, 0.0, n_frames=4, t_first=0.15, seed=93)
+    out = _both("rs41mod", ["--ptu2", "--json", "--jsnsubfrm1"], synth.wav_bytes(synth.fm_audio(x), 48_000))
+    assert out.count(b'"type": "RS41"') >= 3
+    _both("rs41mod", ["-r", "--ecc2", "--iq2", "--lpIQ", "-", "48000", "16"], x.tobytes())
+    _both("rs41mod", ["-r", "--ecc2", "--iq0", "--iqdc", "-", "48000", "16"], x.tobytes())
+
+
+@pytest.mark.parametrize("name", ["inv_rs41_2400k_i", "inv_rs41_2400k_auto", "inv_rs41_2400k_i_on_normal", "inv_dfm_2400k_auto", "inv_dfm_2400k_i"])
+def test_seam_polarity(name):
+    _, stdin, binary, args, _ = make_golden.inv_capture(make_golden.INV_CASES[name])
+    _both(binary, args, stdin)
+
+
+def test_seam_dfm_autorx_args():
+    from radiosonde_auto_rx_amd import synth
+    sym = (make_golden.dfm_field_symbols(dict(kind="09", n=40, sn=18012345)) > 0).astype(np.uint8)
+    sr = 48_000
+    z = 0.5 * synth.gfsk_baseband(sym, sr, 2500.0, 2400.0)
+    rng = np.random.default_rng(7)
+    z = z * np.exp(2j * np.pi * 300.0 / sr * np.arange(len(z))) + 0.02 * (rng.standard_normal(len(z)) + 1j * rng.standard_normal(len(z)))
+    x = np.empty(2 * len(z), np.int16)
+    x[0::2] = np.round(z.real * 32767 * 0.9); x[1::2] = np.round(z.imag * 32767 * 0.9)
+    out = _both("dfm09mod", ["-vv", "--ecc", "--json", "--dist", "--auto", "--IQ", "0.0", "--lpIQ", "-", str(sr), "16"], x.tobytes())
+    assert out.count(b'"type": "DFM"') >= 3
+
+
+@pytest.mark.parametrize("binary,baud", [("m10mod", 9616.0), ("m20mod", 9600.0)])
+def test_seam_m10_m20(binary, baud):
+    from radiosonde_auto_rx_amd import synth
+    fn = (lambda k: synth.m10_frame(k, rng=np.random.default_rng(40 + k))) if binary == "m10mod" else \
+         (lambda k: synth.m20_frame(k, fw=8, pressure_hpa=700.0 - k, rng=np.random.default_rng(60 + k)))
+    x = synth.m10_capture(sr=48_000, seconds=5.3, noise_sigma=0.02, seed=95, f_offset_hz=200.0, baud=baud, frame_fn=fn)
+    out = _both(binary, ["--json", "--ptu", "-vv", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], x.tobytes())
+    assert out.count(b'"type"') >= 4
+    _both(binary, ["-r", "-v", "--iq2", "-", "48000", "16"], x.tobytes())
