@@ -19,6 +19,9 @@
  *   free_buffers()   :1476              -> sonde_engine_destroy()
  *   read_wav_header() :313, f32soft_read() :1718, find_softbinhead() :1740, find_binhead() :1668  -> host code, no GPU
  *
+ * Decoders: rs41mod, dfm09mod, m10mod, m20mod (the engine's own presets) and, through the engine's generic sonde description filled from the
+ * caller's dsp_t, rs92mod, imet54mod, mp3h1mod, mts01mod, meisei100mod (kFamily below).  Not lms6Xmod (it changes the baud rate between frames).
+ *
  * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs
  * of the sonde type's preset are used except `thres` (taken from the first find_header call); a header of the wrong polarity that the
  * caller skips still has its frame consumed; the second soft bit of read_softbit2p (one sample earlier, used by --ecc3) equals the first;
@@ -46,21 +49,37 @@ static struct {
     float *soft;
     int qn, qi;
     const float *cur; int cur_nbits, cur_inv;
+    sonde_cfg_t cfg; sonde_generic_t gen; double fq; int generic;
 } S;
 
-static int seam_type(const dsp_t *dsp) {
+/* How the bit loop of each other decoder of the family consumes a header hit (what demod_mod.c learns one call at a time, the batched
+ * engine has to know up front): bits read per hit, the centre window it passes for opt_iq > 2, and the hdmax / bitofs defaults of its
+ * find_header() call (replaced by the real arguments at the first call). */
+static const struct { const char *name; int br, hdrlen, symlen, nbits, hdmax, bitofs; float l; } kFamily[] = {
+    { "rs92mod",      4800, 60, 2, (240 - 6) * 10, 3, 2, 4.0f },      /* rs92mod.c:1992,2010-2040: 234 bytes of 10 bits, read_slbit            */
+    { "imet54mod",    4798, 40, 1, 220 * 10,       4, 1, 2.0f },      /* imet54mod.c:1013,1029-1060                                            */
+    { "mp3h1mod",     2399, 44, 2, 51 * 8 - 22,    2, 2, 2.0f },      /* mp3h1mod.c:1181,1196-1235: bitfrm_len (45+6)*8 from pos 22            */
+    { "mts01mod",     1200, 32, 1, 8 * 131,        2, 0, 2.0f },      /* mts01mod.c:572,588-612                                                */
+    { "meisei100mod", 2400, 48, 1, 1200 - 48,      1, 0, -1.0f },     /* meisei100mod.c:691,704-718: 2*600-48 raw bits, read_slbit             */
+};
+
+static int seam_type(const dsp_t *dsp, int *fam) {
     const int br = (int)(dsp->br + 0.5f);
-    if (dsp->hdrlen == 64 && br == 4800) return SONDE_RS41;
+    *fam = -1;
+    if (dsp->hdrlen == 64 && br == 4800 && dsp->symlen == 1) return SONDE_RS41;
     if (dsp->hdrlen == 32 && br == 2500) return SONDE_DFM09;
     if (dsp->hdrlen == 32 && (br == 9615 || br == 9616)) return SONDE_M10;
     if (dsp->hdrlen == 32 && br == 9600) return SONDE_M20;
+    for (int i = 0; i < (int)(sizeof kFamily / sizeof kFamily[0]); i++)
+        if (br == kFamily[i].br && dsp->hdrlen == kFamily[i].hdrlen && dsp->symlen == kFamily[i].symlen) { *fam = i; return SONDE_GENERIC; }
     return -1;
 }
 
 int init_buffers(dsp_t *dsp) {
     sonde_cfg_t cfg;
     double fq = -dsp->xlt_fq;
-    const int type = seam_type(dsp);
+    int fam;
+    const int type = seam_type(dsp, &fam);
     if (S.eng) { fprintf(stderr, "demod_mod_hip: one dsp_t at a time\n"); return -1; }
     if (type < 0) { fprintf(stderr, "demod_mod_hip: sonde type (baud %.0f, header %d) not supported\n", dsp->br, dsp->hdrlen); return -1; }
     memset(&cfg, 0, sizeof cfg);
@@ -89,7 +108,17 @@ int init_buffers(dsp_t *dsp) {
         default: return -1;
     }
     if (dsp->opt_iq && dsp->nch != 2) return -1;
-    int rc = sonde_engine_create(&cfg, &fq, &S.eng);
+    memset(&S.gen, 0, sizeof S.gen);
+    if (type == SONDE_GENERIC) {
+        if (dsp->hdrlen > 64) return -1;
+        memcpy(S.gen.header, dsp->hdr, (size_t)dsp->hdrlen);
+        S.gen.baud = dsp->br; S.gen.bt = dsp->BT; S.gen.h = dsp->h; S.gen.symlen = dsp->symlen; S.gen.symhd = dsp->symhd;
+        S.gen.hdmax = kFamily[fam].hdmax; S.gen.bitofs = kFamily[fam].bitofs; S.gen.nbits = kFamily[fam].nbits; S.gen.l_win = kFamily[fam].l;
+        S.gen.lpiq_bw = dsp->lpIQ_bw; S.gen.lpfm_bw = dsp->lpFM_bw;
+        cfg.lpiq_bw = 0;
+    }
+    S.generic = type == SONDE_GENERIC; S.cfg = cfg; S.fq = fq;
+    int rc = S.generic ? sonde_engine_create_generic(&cfg, &fq, &S.gen, &S.eng) : sonde_engine_create(&cfg, &fq, &S.eng);
     if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); S.eng = NULL; return -1; }
     sonde_engine_info(S.eng, &S.info);
     if (dsp->opt_iq == 5) {
@@ -103,7 +132,7 @@ int init_buffers(dsp_t *dsp) {
         fprintf(stderr, "dec: %d\n", S.info.decM);
     }
     dsp->L = S.info.L; dsp->M = S.info.M; dsp->K = S.info.K; dsp->delay = (ui32_t)S.info.delay;
-    S.nbits = type == SONDE_RS41 ? 510 * 8 : type == SONDE_DFM09 ? 264 + 7 * 280 : type == SONDE_M10 ? (101 + 20) * 8 : (101 + 64) * 8;
+    S.nbits = type == SONDE_GENERIC ? S.gen.nbits : type == SONDE_RS41 ? 510 * 8 : type == SONDE_DFM09 ? 264 + 7 * 280 : type == SONDE_M10 ? (101 + 20) * 8 : (101 + 64) * 8;
     S.unit = (size_t)(dsp->opt_iq ? 2 : cfg.audio_channels) * (size_t)(dsp->bps / 8);
     S.chunk = cfg.sample_rate / 10;
     S.chunk -= S.chunk % S.info.decM;
@@ -124,9 +153,16 @@ int free_buffers(dsp_t *dsp) {
 }
 
 int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
-    (void)hdmax; (void)bitofs; (void)opt_dc;
+    (void)opt_dc;
     if (!S.eng) return EOF;
-    if (!S.started) { sonde_engine_set_threshold(S.eng, thres); S.started = 1; }
+    if (!S.started) {
+        if (S.generic && (hdmax != S.gen.hdmax || bitofs != S.gen.bitofs)) {      /* e.g. the decoder's -d <shift> option: nothing processed yet, start over */
+            sonde_engine_destroy(S.eng); S.eng = NULL;
+            S.gen.hdmax = hdmax; S.gen.bitofs = bitofs;
+            if (sonde_engine_create_generic(&S.cfg, &S.fq, &S.gen, &S.eng) < 0) { S.eng = NULL; return EOF; }
+        }
+        sonde_engine_set_threshold(S.eng, thres); S.started = 1;
+    }
     for (;;) {
         if (S.qi < S.qn) {
             const sonde_hit_t *h = &S.hit[S.qi];

@@ -42,6 +42,9 @@ extern "C" {
                                  * second (5 x 808 bits) is skipped; either polarity */
 #define SONDE_M20    20         /* m20mod.c:60,86,1034-1040,1238-1251,1321-1365: as M10 with 9600 Bd and up to 64 aux bytes (1320 bits) */
 
+#define SONDE_GENERIC 99        /* any other 2-FSK sonde of the reference's demod/mod family, described by sonde_generic_t (sonde_engine_create_generic);
+                                 * header hits + soft bits only (sonde_engine_fetch_hits), framing stays with the caller */
+
 /* input forms (dsp.opt_iq of demod_mod.h:62; rs41mod.c:2674-2687,2786-2803) */
 #define SONDE_IN_IQ    0        /* baseband IQ, mixed by -fq and decimated to the IF rate (opt_iq = 5)        */
 #define SONDE_IN_AUDIO 1        /* FM-demodulated audio, one real sample per input frame (opt_iq = 0)         */
@@ -136,6 +139,21 @@ typedef struct {
 /* replaces init_buffers() (demod_mod.c:1208) for n_channels channels; fq[c] is the --IQ <fq> argument
  * of channel c (-0.5..0.5, rs41mod.c:2678-2687). */
 int  sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out);
+/* cfg->sonde_type == SONDE_GENERIC: the fields a decoder of the reference puts into dsp_t (e.g. rs92mod.c:1924-1939: br, symlen, symhd, hdr,
+ * BT, h, lpIQ_bw, lpFM_bw), the find_header() arguments hdmax / bitofs, and how its bit loop consumes a hit: nbits soft bits (<= 4144), then
+ * — if skip_bits > nbits — bits up to skip_bits dropped before the header search resumes.  l_win: the centre window `l` it passes to
+ * read_softbit*() for opt_iq > 2 (0 = whole bits).  Threshold: cfg->thres (0 = 0.7).  Needs cfg->keep_soft; results through sonde_engine_fetch_hits(). */
+typedef struct {
+    char    header[68];      /* '0' / '1' characters, 8..64, NUL-terminated                     */
+    float   baud, bt, h;
+    int32_t symlen, symhd;   /* symbols per bit in the frame / in the header (1 or 2)           */
+    int32_t hdmax, bitofs;
+    int32_t nbits, skip_bits;
+    float   l_win;
+    int32_t lpiq_bw, lpfm_bw;   /* Hz */
+    int32_t reserved[4];
+} sonde_generic_t;
+int  sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out);
 /* replaces free_buffers() (demod_mod.c:1476) */
 void sonde_engine_destroy(sonde_engine_t *e);
 int  sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info);

@@ -158,10 +158,18 @@ const char *sonde_strerror(int code) {
     }
 }
 
-int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) {
+int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) { return sonde_engine_create_generic(cfg, fq, nullptr, out); }
+
+int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
+    if ((cfg->sonde_type == SONDE_GENERIC) != (gen != nullptr)) return SONDE_E_ARG;
+    if (gen) {
+        const size_t hl = strnlen(gen->header, sizeof gen->header);
+        if (hl < 8 || hl > 64 || !(gen->baud > 0.f) || !(gen->bt > 0.f) || !(gen->h > 0.f) || gen->symlen < 1 || gen->symlen > 2 || gen->symhd < 1 || gen->symhd > gen->symlen ||
+            hl % gen->symhd || gen->hdmax < 0 || gen->bitofs < 0 || gen->nbits < 1 || gen->nbits > 518 * 8 || gen->skip_bits < 0) return SONDE_E_ARG;
+    }
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
-    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND) ) return SONDE_E_ARG;
+    if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND && cfg->sonde_type != SONDE_GENERIC) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->opt_nolut && (cfg->opt_dc || cfg->input != SONDE_IN_IQ)) return SONDE_E_ARG;     // --noLUT folds Df into the base-rate mixer: not with --dc here
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
@@ -179,7 +187,13 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     // ---- sonde preset (rs41mod.c:2591-2597,2812-2836,2882,2920-2923)
     std::string header;
     int lpiq_def, lpfm_bw;
-    if (cfg->sonde_type == SONDE_RS41 || cfg->sonde_type == SONDE_FRONTEND) {   // front-end only: the sync preset is never used
+    int skip_last = -1;
+    if (gen) {                                   // any other 2-FSK sonde of the reference's demod/mod family: what its main() puts into dsp_t / passes to find_header()
+        e->baud = gen->baud; e->bt = gen->bt; e->hmod = gen->h; e->symlen = gen->symlen; e->symhd = gen->symhd; e->hdmax = gen->hdmax; e->bitofs = gen->bitofs;
+        e->nbits = gen->nbits; e->l_win = gen->l_win > 0.f ? gen->l_win : -1.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
+        header = std::string(gen->header, strnlen(gen->header, sizeof gen->header)); lpiq_def = gen->lpiq_bw; lpfm_bw = gen->lpfm_bw;
+        if (gen->skip_bits > gen->nbits) skip_last = gen->skip_bits - 1;
+    } else if (cfg->sonde_type == SONDE_RS41 || cfg->sonde_type == SONDE_FRONTEND) {   // front-end only: the sync preset is never used
         e->baud = 4800.f; e->bt = 0.5f; e->hmod = 0.6f; e->symlen = 1; e->symhd = 1; e->hdmax = 4; e->bitofs = 2;
         e->nbits = 510 * 8; e->l_win = 2.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.7f;
         header = kRs41Header; lpiq_def = 7400; lpfm_bw = 6000;
@@ -237,7 +251,7 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
     { const float nh = -e->hmod; const float hs = nh * sr; const double f1 = hs / (2.0 * e->sps); e->rho = -f1 / (double)sr; }
     {   // samples the framer consumes behind a header before the search resumes: all nbits — M10: the rest of the second as well
         // (bits up to 5 x 808 are read and dropped, m10mod.c:1494-1507)
-        const int last = ((cfg->sonde_type == SONDE_M10 || cfg->sonde_type == SONDE_M20) && !cfg->m10_noskip) ? 5 * 808 - 1 : e->nbits - 1;
+        const int last = skip_last >= 0 ? skip_last : ((cfg->sonde_type == SONDE_M10 || cfg->sonde_type == SONDE_M20) && !cfg->m10_noskip) ? 5 * 808 - 1 : e->nbits - 1;
         uint32_t q0, q1; double mid; bit_window(last, e->symlen - 1, e->symlen, e->sps, q0, q1, mid); e->frame_samples = q1;
     }
 

@@ -556,6 +556,56 @@ def m10_capture(sr: int = 48_000, seconds: float = 3.0, fq: float = 0.0, *, type
     return out
 
 
+# Other frame-based 2-FSK sondes of the reference's demod/mod family (seam tests): raw header + random payload.  `header` is the raw-symbol
+# string the decoder hands to the demodulator (rs92mod.c:88-92, imet54mod.c:90-95, mp3h1mod.c:118, mts01mod.c:49-50, meisei100mod.c:200-201).
+FAMILY = {
+    "rs92mod": dict(baud=4800.0, dev_hz=2400.0, bt=0.5, manchester=True, nbits=2340,
+                    header="10100110011001101001" "1010011001100110100110101010100110101001"),
+    "imet54mod": dict(baud=4798.0, dev_hz=2000.0, bt=1.0, manchester=False, nbits=2200, header="0000000001" "0101010101" "0001001001" "0001001001"),
+    "mp3h1mod": dict(baud=2399.0, dev_hz=2400.0, bt=1.0, manchester=True, nbits=386, header="100110011001100110011001100110011001" "10101010"),
+    "mts01mod": dict(baud=1200.0, dev_hz=640.0, bt=1.5, manchester=False, nbits=1048, header="10101010" "10101010" "10110100" "00101011"),
+    "meisei100mod": dict(baud=2400.0, dev_hz=2900.0, bt=1.2, manchester=False, nbits=1152, header="101010101011010100101011001101001100101011001101"),
+}
+
+
+def family_capture(name: str, sr: int = 48_000, seconds: float = 4.3, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1,
+                   t_first: float = 0.3, period: float = 1.0, f_offset_hz: float = 0.0, invert: bool = False) -> np.ndarray:
+    """Interleaved int16 IQ: carrier with an alternating idle pattern, every `period` seconds the decoder's raw header followed by random
+    payload bits (Manchester pairs where the sonde uses them).  The payload is not a valid frame: the decoders' raw output prints it anyway."""
+    f = FAMILY[name]
+    rng = np.random.default_rng(seed)
+    baud = f["baud"]
+    n = int(round(sr * seconds))
+    nsym = int(seconds * baud) + 8
+    sym = np.tile(np.array([1, 0], dtype=np.uint8), nsym // 2 + 1)[:nsym]
+    hdr = np.array([int(c) for c in f["header"]], dtype=np.uint8)
+    k = 0
+    while True:
+        s0 = int(round((t_first + k * period) * baud)) // 2 * 2
+        bits = rng.integers(0, 2, f["nbits"] + 40, dtype=np.uint8)
+        if f["manchester"]:
+            pay = np.empty(2 * len(bits), np.uint8); pay[0::2] = bits; pay[1::2] = 1 - bits
+        else:
+            pay = bits
+        fr = np.concatenate([hdr, pay])
+        if s0 + len(fr) > nsym:
+            break
+        sym[s0:s0 + len(fr)] = fr
+        k += 1
+    if invert:
+        sym = 1 - sym
+    x = amp * gfsk_baseband(sym, sr, baud, f["dev_hz"], bt=f["bt"])[:n]
+    if len(x) < n:
+        x = np.concatenate([x, np.zeros(n - len(x))])
+    if fq != 0.0 or f_offset_hz != 0.0:
+        x = x * np.exp(2j * np.pi * (fq + f_offset_hz / sr) * np.arange(n))
+    x = x + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    return out
+
+
 def fm_audio(iq: np.ndarray, gain: float = 0.25) -> np.ndarray:
     """FM-discriminator audio (int16 mono) of an interleaved int16 IQ capture at the same rate — the kind of input
     the reference's FM chain feeds to the decoders / dft_detect as WAV."""

@@ -91,3 +91,22 @@ def test_seam_m10_m20(binary, baud):
     out = _both(binary, ["--json", "--ptu", "-vv", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], x.tobytes())
     assert out.count(b'"type"') >= 4
     _both(binary, ["-r", "-v", "--iq2", "-", "48000", "16"], x.tobytes())
+
+
+@pytest.mark.parametrize("binary", ["rs92mod", "imet54mod", "mp3h1mod", "mts01mod", "meisei100mod"])
+def test_seam_family_generic(binary):
+    """The frame-based rest of the reference's demod/mod family through the engine's generic sonde description (baud, header, BT, h, symbol
+    layout taken from the decoder's own dsp_t; bits per hit from the seam's table): raw output on baseband IQ at 2.4 Msps (mixer +
+    decimator), IF-rate IQ with the tone correlator (--iq3: centre window), FM-sliced (--iq0), and an inverted signal."""
+    from radiosonde_auto_rx_amd import synth
+    sr = 2_400_000
+    fq = synth.snap_fq(0.07, sr)
+    x = synth.family_capture(binary, sr=sr, seconds=3.4, fq=fq, seed=11, f_offset_hz=150.0)
+    out = _both(binary, ["-r", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], x.tobytes())
+    assert len(out.splitlines()) >= 2
+    y = synth.family_capture(binary, sr=48_000, seconds=4.4, seed=12)
+    _both(binary, ["-r", "--iq3", "--lpIQ", "-", "48000", "16"], y.tobytes())
+    _both(binary, ["-r", "--iq0", "-", "48000", "16"], y.tobytes())
+    _both(binary, ["-r", "--IQ", "0.0", "--lpIQ", "--dc", "-", "48000", "16"], y.tobytes())
+    z = synth.family_capture(binary, sr=48_000, seconds=3.4, seed=13, invert=True)
+    _both(binary, ["-r", "-i", "--IQ", "0.0", "-", "48000", "16"], z.tobytes())
