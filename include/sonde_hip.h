@@ -42,7 +42,7 @@ extern "C" {
                                  * second (5 x 808 bits) is skipped; either polarity */
 #define SONDE_M20    20         /* m20mod.c:60,86,1034-1040,1238-1251,1321-1365: as M10 with 9600 Bd and up to 64 aux bytes (1320 bits) */
 
-#define SONDE_GENERIC 99        /* any other 2-FSK sonde of the reference's demod/mod family, described by sonde_generic_t (sonde_engine_create_generic);
+#define SONDE_GENERIC 99        /* any other 2-FSK sonde of the reference's demod/mod family, described by a sonde_generic_t given to sonde_engine_create_generic;
                                  * header hits + soft bits only (sonde_engine_fetch_hits), framing stays with the caller */
 
 /* input forms (dsp.opt_iq of demod_mod.h:62; rs41mod.c:2674-2687,2786-2803) */

@@ -18,7 +18,7 @@ def _lib():
 
 
 def test_exports():
-    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("sonde_hip.h", "sonde_scan.h", "sonde_fsk.h"))
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h"))
     names = set(re.findall(r"\b(sonde_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 35 and "sonde_scan_create" in names and "sonde_fsk_create" in names
     L = _lib()
