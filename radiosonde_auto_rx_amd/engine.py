@@ -50,6 +50,16 @@ class SondeM20Frame(C.Structure):
                 ("blk_ok", C.c_int32), ("fw", C.c_int32), ("mv_pos", C.c_uint32), ("mv", C.c_float), ("frame", C.c_uint8 * 172)]
 
 
+class SondeHit(C.Structure):
+    _fields_ = [("channel", C.c_int32), ("nbits", C.c_int32), ("mv_pos", C.c_uint32), ("mv", C.c_float)]
+
+
+class SondeGeneric(C.Structure):
+    _fields_ = [("header", C.c_char * 68), ("baud", C.c_float), ("bt", C.c_float), ("h", C.c_float), ("symlen", C.c_int32), ("symhd", C.c_int32),
+                ("hdmax", C.c_int32), ("bitofs", C.c_int32), ("nbits", C.c_int32), ("skip_bits", C.c_int32), ("l_win", C.c_float),
+                ("lpiq_bw", C.c_int32), ("lpfm_bw", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
 class SondeInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("if_sr", "decM", "dectaps", "lut_len", "lpiq_taps", "lpfm_taps",
                                          "L", "M", "K", "N", "delay")] + \
@@ -86,6 +96,9 @@ def lib() -> C.CDLL:
         L.sonde_engine_fetch_soft.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_engine_fetch_dfm.argtypes = [C.c_void_p, C.POINTER(SondeDfmFrame), C.c_int32, C.c_int32]
         L.sonde_dfm_rawline.argtypes = [C.POINTER(SondeDfmFrame), C.c_int, C.c_char_p, C.c_size_t]
+        L.sonde_engine_create_generic.argtypes = [C.POINTER(SondeCfg), C.POINTER(C.c_double), C.POINTER(SondeGeneric), C.POINTER(C.c_void_p)]
+        L.sonde_engine_fetch_hits.argtypes = [C.c_void_p, C.POINTER(SondeHit), C.c_int32, C.c_int32]
+        L.sonde_engine_set_threshold.argtypes = [C.c_void_p, C.c_float]
         L.sonde_engine_fetch_m10.argtypes = [C.c_void_p, C.POINTER(SondeM10Frame), C.c_int32, C.c_int32]
         L.sonde_engine_fetch_m20.argtypes = [C.c_void_p, C.POINTER(SondeM20Frame), C.c_int32, C.c_int32]
         L.sonde_m10_rawline.argtypes = [C.POINTER(SondeM10Frame), C.c_int, C.c_char_p, C.c_size_t]
@@ -123,7 +136,8 @@ class Engine:
                  ecc: int = 2, thres: float = 0.0, max_chunk: int | None = None, max_frames: int = 0,
                  keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False,
                  sonde: str = "rs41", pipeline: bool = False, audio: bool = False, audio_channels: int = 1, audio_select: int = 0,
-                 if_rate: int = 0, bits: int = 16, iq_mode: int = 5, iqdc: bool = False, inv: bool = False, auto: bool = False, nolut: bool = False):
+                 if_rate: int = 0, bits: int = 16, iq_mode: int = 5, iqdc: bool = False, inv: bool = False, auto: bool = False, nolut: bool = False,
+                 generic: dict | None = None):
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
         self.n_channels = len(fq)
         self.sample_rate = sample_rate
@@ -131,17 +145,22 @@ class Engine:
         self.ecc = ecc
         self._per_sample = audio_channels if audio else 2      # input words (int16, or uint8 for bits=8) per sample
         self._dtype = {8: np.uint8, 32: np.float32}.get(bits, np.int16)
-        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "m10": 10, "m20": 20, "frontend": 0}[sonde],
+        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "m10": 10, "m20": 20, "frontend": 0, "generic": 99}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline),
                        1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), 0, int(auto))
         h = C.c_void_p()
-        _chk(lib().sonde_engine_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
+        if sonde == "generic":      # any other 2-FSK sonde: generic = dict(header=, baud=, bt=, h=, symlen=, symhd=, hdmax=, bitofs=, nbits=, ...) (sonde_generic_t)
+            g = SondeGeneric(**{k: (v.encode() if k == "header" else v) for k, v in (generic or {}).items()})
+            cfg.keep_soft = 1
+            _chk(lib().sonde_engine_create_generic(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(g), C.byref(h)))
+        else:
+            _chk(lib().sonde_engine_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
         self._h = h
         info = SondeInfo()
         _chk(lib().sonde_engine_info(h, C.byref(info)))
         self.info = {n: getattr(info, n) for n, _ in SondeInfo._fields_ if n != "reserved"}
-        self.nbits = 4080 if sonde == "rs41" else 2224
+        self.nbits = 4080 if sonde == "rs41" else generic["nbits"] if sonde == "generic" else {"m10": 968, "m20": 1320}.get(sonde, 2224)
         self._max_frames = max_frames or 4 * self.n_channels
 
     def close(self):
@@ -212,6 +231,16 @@ class Engine:
             nh = _chk(lib().sonde_engine_fetch_soft(self._h, soft.ctypes.data_as(C.c_void_p), self._max_frames))
             return frames, soft[:nh]
         return frames
+
+    def fetch_hits(self, finish: bool = False):
+        """Function-level seam: header hits (score, position, polarity) with their soft bits, any sonde type (needs keep_soft)."""
+        n = self._max_frames
+        buf = (SondeHit * n)()
+        k = _chk(lib().sonde_engine_fetch_hits(self._h, buf, n, int(finish)))
+        soft = np.zeros((max(k, 1), self.nbits), np.float32)
+        if k:
+            _chk(lib().sonde_engine_fetch_soft(self._h, soft.ctypes.data_as(C.c_void_p), k))
+        return [dict(channel=buf[i].channel, nbits=buf[i].nbits, mv=buf[i].mv, mv_pos=buf[i].mv_pos, soft=soft[i, :buf[i].nbits].copy()) for i in range(k)]
 
     def fetch_mxx(self, finish: bool = False, verbose: int = 1):
         """M10 / M20 engines: frames as dicts (bytes, checksum verdicts, the `m10mod -r [-v]` / `m20mod -r [-v]` text line)."""

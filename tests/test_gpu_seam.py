@@ -110,3 +110,46 @@ def test_seam_family_generic(binary):
     _both(binary, ["-r", "--IQ", "0.0", "--lpIQ", "--dc", "-", "48000", "16"], y.tobytes())
     z = synth.family_capture(binary, sr=48_000, seconds=3.4, seed=13, invert=True)
     _both(binary, ["-r", "-i", "--IQ", "0.0", "-", "48000", "16"], z.tobytes())
+
+
+@pytest.mark.parametrize("sr", [250_000, 1_000_000, 1_200_000, 2_048_000, 3_200_000, 6_000_000])
+def test_seam_rs41_sample_rates(sr):
+    """SDR rates off the benchmark's 2.4 Msps: other decimation factors / tap counts (decM 5 .. 125: the runtime-D and the wide
+    decimator variants), a designated IF above 48 kHz where 48000 does not divide the rate (2.048 Msps -> 51.2 kHz)."""
+    from radiosonde_auto_rx_amd import synth
+    fq = synth.snap_fq(-0.11, sr)
+    x = synth.rs41_capture(sr=sr, seconds=3.3, fq=fq, noise_sigma=0.02, frame_kw=ECEF, n_frames=3, t_first=0.1, seed=97, bit_errors=2)
+    out = _both("rs41mod", ["-r", "--ecc2", "--crc", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], x.tobytes())
+    assert len(out.splitlines()) == 3 and out.count(b"[OK]") == 3
+
+
+def test_generic_engine_batched_channels_python():
+    """Engine(sonde="generic") from Python: three MTS01-style channels (1200 Bd, 32-symbol header) at different carriers in one engine give
+    the same hits and soft bits as three single-channel engines — the batched form of what the seam does for one decoder process."""
+    from radiosonde_auto_rx_amd import synth
+    from radiosonde_auto_rx_amd.engine import Engine
+    sr = 480_000
+    f = synth.FAMILY["mts01mod"]
+    gen = dict(header=f["header"], baud=f["baud"], bt=1.5, h=0.9, symlen=1, symhd=1, hdmax=2, bitofs=0, nbits=f["nbits"], l_win=2.0, lpiq_bw=4000, lpfm_bw=4000)
+    fqs = [synth.snap_fq(v, sr) for v in (0.1, -0.23, 0.31)]
+    caps = np.stack([synth.family_capture("mts01mod", sr=sr, seconds=3.2, fq=fq, seed=70 + k, t_first=0.2 + 0.1 * k) for k, fq in enumerate(fqs)])
+
+    def run(fq_list, x):
+        eng = Engine(fq_list, sr, sonde="generic", generic=gen, thres=0.76, max_chunk=sr, max_frames=16)
+        hits = []
+        n = x.shape[1] // 2
+        for s0 in range(0, n, sr // 2):
+            s1 = min(n, s0 + sr // 2)
+            eng.process_host(np.ascontiguousarray(x[:, 2 * s0:2 * s1]))
+            hits += eng.fetch_hits(finish=s1 >= n)
+        eng.close()
+        return hits
+
+    allh = run(fqs, caps)
+    for c, fq in enumerate(fqs):
+        one = run([fq], caps[c:c + 1])
+        mine = [h for h in allh if h["channel"] == c]
+        assert len(one) == len(mine) >= 2
+        for a, b in zip(mine, one):
+            assert a["mv_pos"] == b["mv_pos"] and a["nbits"] == b["nbits"] == f["nbits"] and abs(a["mv"]) > 0.76
+            assert np.array_equal(a["soft"], b["soft"])
