@@ -7,14 +7,15 @@
  *     iq_dec [--iq <fq>] [--IFbw kHz] [--lpIQ | --lpbw kHz] [--FM] [--lpFM] [--decFM] [--dc] [--min] [--wav] [--bo 8|16|32] - <sr> 16
  * stdin : interleaved int16 I/Q;  stdout: decimated IQ (cf32 / cs16 / cu8) or the FM discriminator stream
  *         (f32 / s16 / u8), optionally behind a streaming WAV header (iq_dec.c:206-248);  stderr: `IF:` / `dec:`.
- * Sample conversion on output as iq_dec.c:798-936 (x*128[*256], C truncation).  Not implemented: --noLUT, WAV input,
- * 8-bit / float input.
+ * Sample conversion on output as iq_dec.c:798-936 (x*128[*256], C truncation).  Input: raw IQ (`- <sr> <8|16|32>`) or a 2-channel WAV,
+ * on stdin or from a file (iq_dec.c:1051-1080).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "wav_header.h"
 
 static void write_wav_header(int sr, int bps, int nch) {
     uint32_t data = 0;
@@ -42,6 +43,7 @@ static void put_samples(const float *x, int n, int bps) {            /* fwrite_c
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
+    FILE *fp = stdin;
     int have_pcm = 0, opt_fm = 0, opt_decfm = 0, opt_wav = 0, bps_out = 32, if_min = 48000;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
@@ -69,9 +71,18 @@ int main(int argc, char **argv) {
             if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
             have_pcm = 1;
         }
+        else if (a[0] != '-') {                                       /* input file instead of stdin (iq_dec.c:1051-1058) */
+            fp = fopen(a, "rb");
+            if (fp == NULL) { fprintf(stderr, "error: open %s\n", a); return -1; }
+        }
         else { fprintf(stderr, "iq_dec (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (!have_pcm) { fprintf(stderr, "iq_dec (sonde_hip): raw IQ input (- <sr> <8|16|32>) only\n"); return -1; }
+    if (!have_pcm) {                                                  /* WAV: IQ as 2 channels (iq_dec.c:1072-1079, :761) */
+        int nch = 0;
+        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
+        if (nch < 2) { fprintf(stderr, "error: init buffers\n"); return -1; }
+        if (nch != 2) { fprintf(stderr, "iq_dec (sonde_hip): WAV input needs 2 channels\n"); return -1; }
+    }
     const size_t unit = 2 * (size_t)(cfg.bits / 8);
     cfg.n_channels = 1; cfg.if_rate = if_min;
     cfg.max_chunk = cfg.sample_rate / 4 + 4096;
@@ -92,7 +103,7 @@ int main(int argc, char **argv) {
     int64_t m_done = 0;                                   /* IF samples written so far */
     const int tap = opt_fm ? SONDE_TAP_FM : ((cfg.opt_lp & SONDE_LP_IQ) ? SONDE_TAP_IFIQ : SONDE_TAP_DECIM);
     for (;;) {
-        size_t got = fread(buf, unit, (size_t)chunk, stdin);
+        size_t got = fread(buf, unit, (size_t)chunk, fp);
         got -= got % (size_t)(info.decM * decFM);                      /* whole output samples only (if_fm returns EOF mid-block) */
         if (got == 0) break;
         if (sonde_engine_process_host(eng, buf, (int64_t)got, (int32_t)got) < 0) break;

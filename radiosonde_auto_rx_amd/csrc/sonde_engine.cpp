@@ -8,7 +8,8 @@
 //   FIR histories (decXbuffer, lpIQ_buf, lpFM_buf)     P-tail of the decimator + IF-rate rings in HBM
 //   mixer table position (sample_decM)                 lut_phase (host counter, same for all channels)
 //   find_header / read_softbit2p counters              SyncState per channel in HBM
-// Not supported yet (returns SONDE_E_ARG): --dc (AFC feedback), 8-bit / float input.
+//   AFC of --dc (dsp.Df / locked / dc, demod_mod.c:1553-1600)   AfcState per channel; optimistic chunk + per-channel restart loop (process_device)
+// Returns SONDE_E_ARG for what is not mirrored: --ecc3/4, --noLUT together with --dc, decimation factors whose tap count needs Q > 8.
 #include "../../include/sonde_hip.h"
 #include "sonde_dev.h"
 #include "sonde_host.h"
