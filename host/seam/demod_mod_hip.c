@@ -24,8 +24,7 @@
  *
  * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs
  * of the sonde type's preset are used except `thres` (taken from the first find_header call); a header of the wrong polarity that the
- * caller skips still has its frame consumed; the second soft bit of read_softbit2p (one sample earlier, used by --ecc3) equals the first;
- * f32buf_sample() is not available (EOF).
+ * caller skips still has its frame consumed; --spike is ignored; f32buf_sample() is not available (EOF).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,9 +45,9 @@ static struct {
     char *buf; size_t have;
     int eof, started;
     sonde_hit_t hit[SEAM_MAXHITS];
-    float *soft;
+    float *soft, *soft1;
     int qn, qi;
-    const float *cur; int cur_nbits, cur_inv;
+    const float *cur, *cur1; int cur_nbits, cur_inv;
     sonde_cfg_t cfg; sonde_generic_t gen; double fq; int generic;
 } S;
 
@@ -95,7 +94,7 @@ int init_buffers(dsp_t *dsp) {
     cfg.opt_iqdc = dsp->opt_iqdc != 0;
     cfg.opt_nolut = dsp->opt_nolut != 0;
     cfg.opt_auto = 1;                               /* headers of both polarities are reported; the caller skips or flips */
-    cfg.keep_soft = 1;
+    cfg.keep_soft = 2;                              /* both soft bits of read_softbit2p */
     cfg.max_frames = SEAM_MAXHITS;
     cfg.max_chunk = dsp->sr;
     switch (dsp->opt_iq) {
@@ -139,15 +138,16 @@ int init_buffers(dsp_t *dsp) {
     if (S.chunk < S.info.decM) S.chunk = S.info.decM;
     S.buf = (char *)malloc((size_t)S.chunk * S.unit);
     S.soft = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
+    S.soft1 = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
     S.have = 0; S.eof = 0; S.started = 0; S.qn = S.qi = 0; S.cur = NULL; S.cur_nbits = 0;
-    if (!S.buf || !S.soft) return -1;
+    if (!S.buf || !S.soft || !S.soft1) return -1;
     return S.info.K;
 }
 
 int free_buffers(dsp_t *dsp) {
     (void)dsp;
     if (S.eng) sonde_engine_destroy(S.eng);
-    free(S.buf); free(S.soft);
+    free(S.buf); free(S.soft); free(S.soft1);
     memset(&S, 0, sizeof S);
     return 0;
 }
@@ -166,13 +166,13 @@ int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
     for (;;) {
         if (S.qi < S.qn) {
             const sonde_hit_t *h = &S.hit[S.qi];
-            S.cur = S.soft + (size_t)S.qi * S.nbits;
+            S.cur = S.soft + (size_t)S.qi * S.nbits; S.cur1 = S.soft1 + (size_t)S.qi * S.nbits;
             S.cur_nbits = h->nbits; S.cur_inv = h->mv < 0.f;
             S.qi++;
             dsp->mv = h->mv; dsp->mv_pos = h->mv_pos;
             return 1;
         }
-        S.cur = NULL; S.cur_nbits = 0;
+        S.cur = S.cur1 = NULL; S.cur_nbits = 0;
         if (S.eof) return EOF;
         size_t got = fread(S.buf + S.have, 1, (size_t)S.chunk * S.unit - S.have, dsp->fp);
         S.have += got;
@@ -187,26 +187,26 @@ int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
         if (got == 0) S.eof = 1;
         S.qn = sonde_engine_fetch_hits(S.eng, S.hit, SEAM_MAXHITS, S.eof);
         if (S.qn < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(S.qn)); S.qn = 0; return EOF; }
-        if (S.qn > 0) sonde_engine_fetch_soft(S.eng, S.soft, S.qn);
+        if (S.qn > 0) { sonde_engine_fetch_soft(S.eng, S.soft, S.qn); sonde_engine_fetch_soft1(S.eng, S.soft1, S.qn); }
         S.qi = 0;
     }
 }
 
-static int seam_bit(int inv, int pos, float *sb) {
+static int seam_bit(int inv, int pos, float *sb, float *sb1) {
     if (!S.cur || pos < 0 || pos >= S.cur_nbits) return EOF;
-    float s = S.cur[pos];
-    if (S.cur_inv) s = -s;                          /* the engine stores the bits in the polarity in effect; the reference returns them raw */
-    if (inv) s = -s;
-    *sb = s;
+    float s = S.cur[pos], s1 = S.cur1[pos];
+    if (S.cur_inv) { s = -s; s1 = -s1; }            /* the engine stores the bits in the polarity in effect; the reference returns them raw */
+    if (inv) { s = -s; s1 = -s1; }
+    *sb = s; *sb1 = s1;
     return 0;
 }
 
 int read_softbit2p(dsp_t *dsp, hsbit_t *shb, int inv, int ofs, int pos, float l, int spike, hsbit_t *shb1) {
-    float s;
+    float s, s1;
     (void)dsp; (void)ofs; (void)l; (void)spike;
-    if (seam_bit(inv, pos, &s) == EOF) return EOF;
+    if (seam_bit(inv, pos, &s, &s1) == EOF) return EOF;
     shb->sb = s; shb->hb = (s >= 0.f);
-    if (shb1) *shb1 = *shb;
+    if (shb1) { shb1->sb = s1; shb1->hb = (s1 >= 0.f); }
     return 0;
 }
 
@@ -216,9 +216,9 @@ int read_softbit(dsp_t *dsp, hsbit_t *shb, int inv, int ofs, int pos, float l, i
 
 /* hard bit; behind the end of a hit (the M10 / M20 "rest of the second") the engine has already skipped: 0 until the stream is over */
 int read_slbit(dsp_t *dsp, int *bit, int inv, int ofs, int pos, float l, int spike) {
-    float s;
+    float s, s1;
     (void)dsp; (void)ofs; (void)l; (void)spike;
-    if (seam_bit(inv, pos, &s) == 0) { *bit = (s >= 0.f); return 0; }
+    if (seam_bit(inv, pos, &s, &s1) == 0) { *bit = (s >= 0.f); return 0; }
     if (S.eof && S.qi >= S.qn) return EOF;
     *bit = 0;
     return 0;

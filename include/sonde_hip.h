@@ -82,7 +82,7 @@ typedef struct {
     float   thres;           /* --ths, header score threshold (0 = type default)              */
     int32_t max_chunk;       /* largest n_samples per process call (per channel)              */
     int32_t max_frames;      /* frame queue capacity between two fetches (0 = 4*n_channels)   */
-    int32_t keep_soft;       /* testing: keep per-frame soft bits (soft-bit fetch call) and the IFIQ / FM tap streams */
+    int32_t keep_soft;       /* keep per-frame soft bits (soft-bit fetch call) and the IFIQ / FM tap streams; 2: also the second soft bit (fetch_soft1) */
     int32_t pipeline;        /* 1: IF-rate kernels on a second HIP stream so that sonde_engine_fetch_frames_lagged(lag=1)
                               * overlaps them with the next call's decimator; 0: one in-order stream             */
     int32_t input;           /* SONDE_IN_IQ (--IQ fq, cs16), SONDE_IN_AUDIO (FM audio: WAV payload, real int16; dsp.opt_iq = 0,
@@ -194,6 +194,9 @@ typedef struct {
     float    mv;             /* negative: header of inverted polarity (the stored soft bits are already flipped) */
 } sonde_hit_t;
 int  sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, int32_t finish);
+/* cfg.keep_soft == 2: the second soft bit of read_softbit2p() (hsbit1: the same bit sums taken one IF sample earlier, demod_mod.c:1120,1145 —
+ * what --ecc3 adds to the first before slicing, rs41mod.c:2925) of the hits returned by the last sonde_engine_fetch_hits() */
+int  sonde_engine_fetch_soft1(sonde_engine_t *e, float *soft, int32_t max_frames);
 /* find_header()'s threshold argument (demod_mod.c:1533) for the following process calls */
 int  sonde_engine_set_threshold(sonde_engine_t *e, float thres);
 

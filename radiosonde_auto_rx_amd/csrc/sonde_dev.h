@@ -102,6 +102,7 @@ struct FrameRec {
 
 struct SyncArgs {
     const float *bufs, *corr; SyncState *state; FrameRec *frames; unsigned *frame_count; float *soft;
+    float *soft1;             // optional: the same bit sums one IF sample earlier (hsbit1 of read_softbit2p, demod_mod.c:1120,1145)
     const uint8_t *hdr, *hdr_bytes, *mask, *gf_exp, *gf_log;
     const uint4 *bitwin;      // [nbits] consumed-sample ranges of every bit: {first half (Manchester) qa,qb, main half qa,qb}
     const uint32_t *bitend;   // [nbits] consumed samples after the bit

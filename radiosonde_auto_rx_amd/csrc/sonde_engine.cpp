@@ -54,7 +54,7 @@ struct sonde_engine {
     float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr, *d_raw = nullptr;
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
-    SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr;
+    SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr, *d_soft1 = nullptr;
     uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
     uint8_t *d_consts = nullptr;   // hdr[64] | hdr_bytes[8] | mask[64] | gf_exp[512] | gf_log[256]
     int16_t *d_stage = nullptr; size_t stage_bytes = 0;
@@ -74,7 +74,7 @@ struct sonde_engine {
     uint32_t m_out = 0;            // IF samples produced per channel
     uint32_t dc_cnt = 0, dc_max = 0, dc_lim = 0;
     // results of the last fetch
-    std::vector<float> last_soft; int last_n = 0;
+    std::vector<float> last_soft, last_soft1; int last_n = 0;
     std::vector<uint8_t> last_frame;
     std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
@@ -299,6 +299,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring);
     bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1);
     if (cfg->keep_soft || cfg->sonde_type != SONDE_RS41) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
+    if (cfg->keep_soft == 2) bad |= dalloc(&e->d_soft1, (size_t)e->max_frames * e->nbits);
     bad |= dalloc(&e->d_match, L, false);
     if (!e->w_iq.empty()) bad |= dalloc(&e->d_wiq, e->w_iq.size(), false);
     if (!e->w_fm.empty()) bad |= dalloc(&e->d_wfm, e->w_fm.size(), false);
@@ -422,7 +423,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_count) hipHostFree(e->h_count);
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
-                     e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft,
+                     e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -593,7 +594,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
     s.eof = eof; s.rs41 = (e->cfg.sonde_type == SONDE_RS41);
-    s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft;
+    s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft; s.soft1 = e->d_soft1;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
     s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
@@ -790,9 +791,19 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
     if (finish) launch_framesync(e, 1);
     std::vector<FrameRec> recs;
     std::vector<float> soft;
+    const unsigned first = e->read_idx;
     const int n = collect_records(e, 0, recs, &soft, max);
     if (n < 0) return n;
     e->last_soft = soft; e->last_n = n;
+    if (e->d_soft1) {                                          // the same ring slots of the second soft-bit array
+        const unsigned start = e->read_idx - (unsigned)n;       // (an overflow moves read_idx forward before the records are taken)
+        (void)first;
+        e->last_soft1.resize((size_t)n * e->nbits);
+        for (int i = 0; i < n; i++) {
+            const unsigned idx = (start + (unsigned)i) % (unsigned)e->max_frames;
+            if (hipMemcpy(e->last_soft1.data() + (size_t)i * e->nbits, e->d_soft1 + (size_t)idx * e->nbits, (size_t)e->nbits * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        }
+    }
     for (int i = 0; i < n; i++) {
         const FrameRec &r = recs[i];
         out[i].channel = r.channel; out[i].mv = r.mv; out[i].mv_pos = r.mv_pos;
@@ -818,6 +829,13 @@ int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) 
     if (!e || !soft || !e->d_soft) return SONDE_E_ARG;
     const int n = std::min(e->last_n, (int)max_frames);
     memcpy(soft, e->last_soft.data(), (size_t)n * e->nbits * sizeof(float));
+    return n;
+}
+
+int sonde_engine_fetch_soft1(sonde_engine_t *e, float *soft, int32_t max_frames) {
+    if (!e || !soft || !e->d_soft1) return SONDE_E_ARG;
+    const int n = std::min({e->last_n, (int)max_frames, (int)(e->last_soft1.size() / (size_t)e->nbits)});
+    memcpy(soft, e->last_soft1.data(), (size_t)n * e->nbits * sizeof(float));
     return n;
 }
 

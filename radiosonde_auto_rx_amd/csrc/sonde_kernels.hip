@@ -1092,6 +1092,19 @@ void k_framesync(const SyncArgs a) {
                 const int hb = valid && (st.inv ? !(-sum >= 0.0) : (sum >= 0.0));
                 const unsigned long long bal = __ballot(hb), vm = __ballot(valid);
                 if (a.soft && valid) a.soft[(size_t)slot * a.nbits + bp] = (float)sum;
+                if (a.soft1 && valid) {                                // sample1 = bufs[.. + ofs - 1]: same windows, one sample earlier
+                    const uint4 w = a.bitwin[bp];
+                    const double d1 = (DC && a.opt_iq < 2) ? af.dc : 0.0;
+                    double s1 = 0.0;
+                    if (DC && a.opt_iq < 2) {
+                        if (w.y > w.x) s1 = 0.0 - window_sum<true>(bufs, base - 1u, mask, w.x, w.y, d1);
+                        s1 += window_sum<true>(bufs, base - 1u, mask, w.z, w.w, d1);
+                    } else {
+                        if (w.y > w.x) s1 = 0.0 - window_sum<false>(bufs, base - 1u, mask, w.x, w.y, 0.0);
+                        s1 += window_sum<false>(bufs, base - 1u, mask, w.z, w.w, 0.0);
+                    }
+                    a.soft1[(size_t)slot * a.nbits + bp] = (float)(st.inv ? -s1 : s1);
+                }
                 const int it = (p0 >> 6) + wave;                       // 64-bit group index = 8 frame bytes
                 if (lane < 8) {
                     if (a.rs41) {

@@ -153,3 +153,20 @@ def test_generic_engine_batched_channels_python():
         for a, b in zip(mine, one):
             assert a["mv_pos"] == b["mv_pos"] and a["nbits"] == b["nbits"] == f["nbits"] and abs(a["mv"]) > 0.76
             assert np.array_equal(a["soft"], b["soft"])
+
+
+@pytest.mark.parametrize("ecc", ["--ecc3", "--ecc4"])
+def test_seam_rs41_ecc3_second_soft_bit(ecc):
+    """--ecc3 / --ecc4 (rs41mod.c:2925, :1881-1950) slice every bit from the sum of read_softbit2p()'s two soft bits — the second one is the
+    same window one IF sample earlier (cfg.keep_soft = 2, sonde_engine_fetch_soft1) — and use byte scores for erasure / bit-toggle
+    decoding: at a noise level where that changes the correction counts, the reference's decoder on the seam prints what it prints on
+    demod_mod.c."""
+    from radiosonde_auto_rx_amd import synth
+    outs = []
+    for ns, seed in ((0.38, 55), (0.44, 56)):
+        x = synth.rs41_capture(sr=48_000, seconds=8.3, fq=0.0, noise_sigma=ns, frame_kw=ECEF, n_frames=8, t_first=0.15, seed=seed)
+        outs.append(_both("rs41mod", ["-r", ecc, "--crc", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], x.tobytes()))
+        plain = subprocess.run([os.path.join(REF, "rs41mod"), "-r", "--ecc2", "--crc", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], input=x.tobytes(),
+                               capture_output=True, timeout=300).stdout
+        assert plain != outs[-1]                                   # the second soft bit matters at this noise level
+    assert outs[0].count(b"[OK]") >= 5
