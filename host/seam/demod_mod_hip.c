@@ -22,8 +22,8 @@
  * Decoders: rs41mod, dfm09mod, m10mod, m20mod (the engine's own presets) and, through the engine's generic sonde description filled from the
  * caller's dsp_t, rs92mod, imet54mod, mp3h1mod, mts01mod, meisei100mod (kFamily below).  Not lms6Xmod (it changes the baud rate between frames).
  *
- * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs
- * of the sonde type's preset are used except `thres` (taken from the first find_header call); a header of the wrong polarity that the
+ * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs are
+ * taken from the first find_header call; a header of the wrong polarity that the
  * caller skips still has its frame consumed; --spike is ignored; f32buf_sample() is not available (EOF).
  */
 #include <stdio.h>
@@ -155,13 +155,10 @@ int free_buffers(dsp_t *dsp) {
 int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
     (void)opt_dc;
     if (!S.eng) return EOF;
-    if (!S.started) {
-        if (S.generic && (hdmax != S.gen.hdmax || bitofs != S.gen.bitofs)) {      /* e.g. the decoder's -d <shift> option: nothing processed yet, start over */
-            sonde_engine_destroy(S.eng); S.eng = NULL;
-            S.gen.hdmax = hdmax; S.gen.bitofs = bitofs;
-            if (sonde_engine_create_generic(&S.cfg, &S.fq, &S.gen, &S.eng) < 0) { S.eng = NULL; return EOF; }
-        }
-        sonde_engine_set_threshold(S.eng, thres); S.started = 1;
+    if (!S.started) {                                  /* the caller's threshold, accepted header errors and bit offset (e.g. -d <shift>) */
+        sonde_engine_set_threshold(S.eng, thres);
+        if (sonde_engine_set_sync(S.eng, hdmax, bitofs) < 0) { fprintf(stderr, "demod_mod_hip: hdmax %d / bitofs %d out of range\n", hdmax, bitofs); return EOF; }
+        S.started = 1;
     }
     for (;;) {
         if (S.qi < S.qn) {

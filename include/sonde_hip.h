@@ -194,6 +194,9 @@ typedef struct {
     float    mv;             /* negative: header of inverted polarity (the stored soft bits are already flipped) */
 } sonde_hit_t;
 int  sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, int32_t finish);
+/* find_header()'s hdmax / bitofs arguments (accepted header bit errors; sample offset of the bit windows, e.g. the decoders' -d <shift>)
+ * instead of the sonde type's defaults; before the first process call */
+int  sonde_engine_set_sync(sonde_engine_t *e, int32_t hdmax, int32_t bitofs);
 /* cfg.keep_soft == 2: the second soft bit of read_softbit2p() (hsbit1: the same bit sums taken one IF sample earlier, demod_mod.c:1120,1145 —
  * what --ecc3 adds to the first before slicing, rs41mod.c:2925) of the hits returned by the last sonde_engine_fetch_hits() */
 int  sonde_engine_fetch_soft1(sonde_engine_t *e, float *soft, int32_t max_frames);

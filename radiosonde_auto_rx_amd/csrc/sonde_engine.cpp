@@ -813,6 +813,12 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
     return ovf ? SONDE_E_OVERFLOW : n;
 }
 
+int sonde_engine_set_sync(sonde_engine_t *e, int32_t hdmax, int32_t bitofs) {
+    if (!e || hdmax < 0 || hdmax > 64 || bitofs < -8 || bitofs > 64 || e->call > 0) return SONDE_E_ARG;      // before the first process call only
+    e->hdmax = hdmax; e->bitofs = bitofs;
+    return 0;
+}
+
 int sonde_engine_set_threshold(sonde_engine_t *e, float thres) {
     if (!e || !(thres > 0.f) || thres >= 1.f) return SONDE_E_ARG;
     e->thres = thres;

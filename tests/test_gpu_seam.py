@@ -170,3 +170,22 @@ def test_seam_rs41_ecc3_second_soft_bit(ecc):
                                capture_output=True, timeout=300).stdout
         assert plain != outs[-1]                                   # the second soft bit matters at this noise level
     assert outs[0].count(b"[OK]") >= 5
+
+
+@pytest.mark.parametrize("binary,shift", [("rs41mod", "1"), ("rs41mod", "-2"), ("dfm09mod", "-1"), ("m10mod", "2")])
+def test_seam_bit_offset_option(binary, shift):
+    """-d <shift>: the decoders add it to the bitofs they pass to find_header() / read_softbit*(); the seam hands it to the engine
+    (sonde_engine_set_sync) — soft bits move by whole IF samples, so correction counts / scores printed by the reference change with it."""
+    from radiosonde_auto_rx_amd import synth
+    if binary == "rs41mod":
+        x = synth.rs41_capture(sr=48_000, seconds=4.3, fq=0.0, noise_sigma=0.3, frame_kw=ECEF, n_frames=4, t_first=0.15, seed=61)
+        args = ["-r", "--ecc2", "--crc"]
+    elif binary == "dfm09mod":
+        x = synth.dfm_capture(sr=48_000, seconds=3.2, fq=0.0, noise_sigma=0.15, seed=62)
+        args = ["-r", "--ecc2"]
+    else:
+        x = synth.m10_capture(sr=48_000, seconds=4.3, noise_sigma=0.1, seed=63, frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(80 + k)))
+        args = ["-r", "-v"]
+    tail = ["--IQ", "0.0", "--lpIQ", "-", "48000", "16"]
+    out = _both(binary, args + ["-d", shift] + tail, x.tobytes())
+    assert len(out.splitlines()) >= 2
