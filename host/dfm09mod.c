@@ -17,6 +17,7 @@
 
 static sonde_dfm_dec_t *g_dec = NULL;
 static int g_raw = 0, g_ecc = 0;
+static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (dfm09mod.c:1321,1398-1404) */
 
 static int make_decoder(sonde_dfm_opts_t *o, int raw, int ecc, int opt_auto, int khz) {
     const char *ver = getenv("SONDE_JSN_VERSION");
@@ -62,6 +63,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--json")) { dopt.json = 1; force_ecc = 1; }
         else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
+        else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; g_shift = atoi(argv[i]); if (g_shift > 4) g_shift = 4; if (g_shift < -4) g_shift = -4; }
         else if (!strcmp(a, "--IQ")) {
             if (++i >= argc) return -1;
             fq = atof(argv[i]);
@@ -149,6 +151,7 @@ int main(int argc, char **argv) {
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
     int rc = sonde_engine_create(&cfg, &fq, &eng);
+    if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 2 + g_shift);
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
     sonde_info_t info;
     sonde_engine_info(eng, &info);

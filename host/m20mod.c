@@ -18,6 +18,7 @@
 #include "sonde_m20.h"
 #include "wav_header.h"
 
+static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (m20mod.c:1040,1108-1114) */
 static int g_verbose = 0, g_raw = 0;
 static sonde_m20_dec_t *g_dec = NULL;
 
@@ -65,6 +66,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) { /* irrelevant for the differential code (m20mod.c:1447) */ }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
+        else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; g_shift = atoi(argv[i]); if (g_shift > 4) g_shift = 4; if (g_shift < -4) g_shift = -4; }
         else if (!strcmp(a, "--IQ")) {
             if (++i >= argc) return -1;
             fq = atof(argv[i]);
@@ -142,6 +144,7 @@ int main(int argc, char **argv) {
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
     int rc = sonde_engine_create(&cfg, &fq, &eng);
+    if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 0 + g_shift);
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
     sonde_info_t info;
     sonde_engine_info(eng, &info);

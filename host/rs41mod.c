@@ -21,6 +21,7 @@
 
 static sonde_rs41_dec_t *g_dec = NULL;
 static int g_raw = 0;
+static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (rs41mod.c:2597-2598,2664-2671,2850) */
 
 /* print_frame() (rs41mod.c:2472-2553): raw line with -r (then JSON only, if asked for), else the decoded text */
 /* the decoder behind the text / JSON output; version = what the reference compiles in as VER_JSN_STR */
@@ -73,6 +74,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--jsnsubfrm2")) { dopt.jsn_subfrm = 2; dopt.json = 1; json_ecc = 1; }
         else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
+        else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; g_shift = atoi(argv[i]); if (g_shift > 4) g_shift = 4; if (g_shift < -4) g_shift = -4; }
         else if (!strcmp(a, "--IQ")) {
             if (++i >= argc) return -1;
             fq = atof(argv[i]);
@@ -181,6 +183,7 @@ int main(int argc, char **argv) {
     cfg.max_chunk = cfg.sample_rate;
     sonde_engine_t *eng = NULL;
     int rc = sonde_engine_create(&cfg, &fq, &eng);
+    if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 4, 2 + g_shift);
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
     sonde_info_t info;
     sonde_engine_info(eng, &info);
