@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;               /* --IQ only, like the reference */
         else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;                     /* header dc / AFC */
         else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
+        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
         else if (!strcmp(a, "--lpbw")) {
             if (++i >= argc) return -1;
             double bw = atof(argv[i]);

@@ -44,7 +44,7 @@ static int make_decoder(sonde_m20_opts_t *o, int raw, int khz) {
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, cfreq = -1;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, rawhex = 0, cfreq = -1;
     FILE *fp = stdin;
     sonde_m20_opts_t dopt;
     memset(&dopt, 0, sizeof dopt);
@@ -62,6 +62,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--json")) dopt.json = 1;
         else if (!strcmp(a, "--silent")) dopt.silent = 1;
         else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
+        else if (!strcmp(a, "--rawhex")) rawhex = 1;
         else if (!strcmp(a, "--softin")) softin = 1;
         else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) { /* irrelevant for the differential code (m20mod.c:1447) */ }
@@ -102,6 +103,25 @@ int main(int argc, char **argv) {
             if (fp == NULL) { fprintf(stderr, "error: open %s\n", a); return -1; }
         }
         else { fprintf(stderr, "m20mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
+    }
+    if (rawhex) {                                    /* frames as hex lines, e.g. the output of -r (m20mod.c:1384-1412): bytes up to the first blank,
+                                                      * lines longer than the week field; bytes not given keep the previous line's */
+        if (make_decoder(&dopt, raw, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;
+        static char lb[2 * 165 + 12];
+        static sonde_m20_frame_t fr;
+        while (fgets(lb, sizeof lb, fp)) {
+            lb[2 * 165] = 0;
+            char *sp = strchr(lb, ' ');
+            if (sp) *sp = 0;
+            sp = strchr(lb, '\n'); if (sp) *sp = 0;
+            const int len = (int)(strlen(lb) / 2);
+            if (len <= 0x1A + 2) continue;
+            for (int i = 0; i < len; i++) { unsigned v = 0; sscanf(lb + 2 * i, "%2x", &v); fr.frame[i] = (uint8_t)v; }
+            fr.nbits = len * 8;
+            sonde_m20_frame_finish(&fr);
+            emit_frame(&fr);
+        }
+        return 0;
     }
     if (softin) {                                    /* float32 soft symbols on stdin (m20mod.c:1405-1510) */
         if (make_decoder(&dopt, raw, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;

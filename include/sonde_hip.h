@@ -239,6 +239,10 @@ typedef struct {
     uint8_t  frame[172];
 } sonde_m20_frame_t;
 int  sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t max, int32_t finish);
+/* Fill len / cs_ok / cs_calc (/ blk_ok / fw) from f->frame: what print_frame() derives before printing (m10mod.c:1049-1070, m20mod.c:875-907).
+ * For frames that do not come from an engine or soft-symbol framer, e.g. --rawhex input. */
+int  sonde_m10_frame_finish(sonde_m10_frame_t *f);
+int  sonde_m20_frame_finish(sonde_m20_frame_t *f);
 /* Raw text line of `m20mod -r [-v]` (m20mod.c:959-973); buf >= 400 */
 int  sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen);
 

@@ -744,20 +744,8 @@ int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t ma
         sonde_m20_frame_t &o = out[h];
         memset(&o, 0, sizeof o);
         o.nbits = mxx_bytes(e, r, 101 + 64, o.frame);
-        int flen = o.frame[0], pos_fw = 0x43;                       // m20mod.c:875-899
-        if (flen < 0x45) pos_fw = flen - 2;
-        else if (flen - 0x45 > 64) flen = 0x45 + 64;
-        const int pos_check = flen - 1;
-        o.fw = (pos_fw >= 0) ? o.frame[pos_fw] : 0;
-        if (o.fw > 0x20) o.fw = 0;
-        o.channel = r.channel; o.len = flen + 1; o.mv = r.mv; o.mv_pos = r.mv_pos;
-        o.cs_calc = pos_check >= 0 ? (uint32_t)m10_checksum(o.frame, pos_check) : 0;
-        o.cs_ok = pos_check >= 0 && ((uint32_t)((o.frame[pos_check] << 8) | o.frame[pos_check + 1]) == o.cs_calc);
-        {   // block checksum: the length byte 0x16, then frame[2 .. 2+0x14) (blk_checkM10, m20mod.c:548-560)
-            uint8_t blk[0x16]; blk[0] = 0x16; memcpy(blk + 1, o.frame + 2, 0x14);
-            const int bc2 = m10_checksum(blk, 0x15), bc1 = (o.frame[0x16] << 8) | o.frame[0x17];
-            o.blk_ok = bc1 == bc2 ? 1 : bc1 == 0 ? -1 : 0;
-        }
+        o.channel = r.channel; o.mv = r.mv; o.mv_pos = r.mv_pos;
+        sonde_m20_frame_finish(&o);                                 // length, firmware byte, checksums (m20mod.c:875-907)
     }
     const bool ovf = e->overflow; e->overflow = false;
     return ovf ? SONDE_E_OVERFLOW : n;
@@ -776,11 +764,8 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
         sonde_m10_frame_t &o = out[h];
         memset(&o, 0, sizeof o);
         const int nv = mxx_bytes(e, r, 101 + 20, o.frame);
-        int aux = o.frame[0] - 0x64;
-        if (aux < 0 || aux > 20) aux = 0;
-        o.channel = r.channel; o.nbits = nv; o.len = 101 + aux; o.mv = r.mv; o.mv_pos = r.mv_pos;
-        o.cs_calc = (uint32_t)m10_checksum(o.frame, 99 + aux);
-        o.cs_ok = ((uint32_t)((o.frame[99 + aux] << 8) | o.frame[100 + aux]) == o.cs_calc);
+        o.channel = r.channel; o.nbits = nv; o.mv = r.mv; o.mv_pos = r.mv_pos;
+        sonde_m10_frame_finish(&o);
     }
     const bool ovf = e->overflow; e->overflow = false;
     return ovf ? SONDE_E_OVERFLOW : n;

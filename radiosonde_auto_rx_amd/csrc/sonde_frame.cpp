@@ -281,6 +281,33 @@ int sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t
     }
     return n;
 }
+// what print_frame() derives from the frame bytes before printing (m10mod.c:1049-1070; m20mod.c:875-907)
+int sonde_m10_frame_finish(sonde_m10_frame_t *f) {
+    if (!f) return SONDE_E_ARG;
+    int aux = f->frame[0] - 0x64;
+    if (aux < 0 || aux > 20) aux = 0;
+    f->len = 101 + aux;
+    f->cs_calc = (uint32_t)sonde::m10_checksum(f->frame, 99 + aux);
+    f->cs_ok = ((uint32_t)((f->frame[99 + aux] << 8) | f->frame[100 + aux]) == f->cs_calc);
+    return 0;
+}
+int sonde_m20_frame_finish(sonde_m20_frame_t *f) {
+    if (!f) return SONDE_E_ARG;
+    int flen = f->frame[0], pos_fw = 0x43;
+    if (flen < 0x45) pos_fw = flen - 2;
+    else if (flen - 0x45 > 64) flen = 0x45 + 64;
+    const int pc = flen - 1;
+    f->fw = pos_fw >= 0 ? f->frame[pos_fw] : 0;
+    if (f->fw > 0x20) f->fw = 0;
+    f->len = flen + 1;
+    f->cs_calc = pc >= 0 ? (uint32_t)sonde::m10_checksum(f->frame, pc) : 0;
+    f->cs_ok = pc >= 0 && ((uint32_t)((f->frame[pc] << 8) | f->frame[pc + 1]) == f->cs_calc);
+    uint8_t blk[0x16]; blk[0] = 0x16; memcpy(blk + 1, f->frame + 2, 0x14);       // blk_checkM10 (m20mod.c:548-560): length byte, then the block
+    const int bc2 = sonde::m10_checksum(blk, 0x15), bc1 = (f->frame[0x16] << 8) | f->frame[0x17];
+    f->blk_ok = bc1 == bc2 ? 1 : bc1 == 0 ? -1 : 0;
+    return 0;
+}
+
 int sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen) {
     if (!f || !buf || buflen < (size_t)(2 * f->len + 16)) return SONDE_E_ARG;
     int n = 0;

@@ -47,24 +47,14 @@ static void mxx_emit(sonde_softin *s, int pos) {
     if (!m20) {
         sonde_m10_frame_t o; memset(&o, 0, sizeof o);
         memcpy(o.frame, fr, 121);
-        int aux = fr[0] - 0x64; if (aux < 0 || aux > 20) aux = 0;
-        o.nbits = pos; o.len = 101 + aux; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
-        o.cs_calc = (uint32_t)m10_checksum(fr, 99 + aux);
-        o.cs_ok = ((uint32_t)((fr[99 + aux] << 8) | fr[100 + aux]) == o.cs_calc);
+        o.nbits = pos; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+        sonde_m10_frame_finish(&o);
         s->q10.push_back(o);
     } else {
         sonde_m20_frame_t o; memset(&o, 0, sizeof o);
         memcpy(o.frame, fr, 165);
-        int flen = fr[0], pos_fw = 0x43;
-        if (flen < 0x45) pos_fw = flen - 2; else if (flen - 0x45 > 64) flen = 0x45 + 64;
-        const int pc = flen - 1;
-        o.fw = pos_fw >= 0 ? fr[pos_fw] : 0; if (o.fw > 0x20) o.fw = 0;
-        o.nbits = pos; o.len = flen + 1; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
-        o.cs_calc = pc >= 0 ? (uint32_t)m10_checksum(fr, pc) : 0;
-        o.cs_ok = pc >= 0 && ((uint32_t)((fr[pc] << 8) | fr[pc + 1]) == o.cs_calc);
-        uint8_t blk[0x16]; blk[0] = 0x16; memcpy(blk + 1, fr + 2, 0x14);
-        const int bc2 = m10_checksum(blk, 0x15), bc1 = (fr[0x16] << 8) | fr[0x17];
-        o.blk_ok = bc1 == bc2 ? 1 : bc1 == 0 ? -1 : 0;
+        o.nbits = pos; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
+        sonde_m20_frame_finish(&o);
         s->q20.push_back(o);
     }
 }

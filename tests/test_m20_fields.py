@@ -34,3 +34,24 @@ def test_cli_m20_telemetry_matches_reference(name):
         assert r.stdout == want, (name, args)
         total += len(want)
     assert total > 5000
+
+
+@pytest.mark.parametrize("binary", ["m10mod", "m20mod"])
+def test_cli_rawhex_input_matches_reference(binary):
+    """--rawhex: the hex lines of `-r` fed back in (re-decoding a log): telemetry text / JSON / raw lines as the compiled reference prints them"""
+    from radiosonde_auto_rx_amd import engine
+    ref = os.path.join(ROOT, "oracle", "_ref", binary)
+    if not os.path.exists(ref):
+        pytest.skip("compiled reference not present")
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build_library()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    soft = (make_golden.m10_field_symbols(make_golden.M10_FIELD_SCENARIOS["m10f_mixed_bad_10"]) if binary == "m10mod"
+            else make_golden.m20_field_symbols(make_golden.M20_FIELD_SCENARIOS["m20f_mixed_bad_10"])).tobytes()
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    raw = subprocess.run([os.path.join(ROOT, "host", "bin", binary), "-r", "--softin"], input=soft, capture_output=True, env=env, timeout=120).stdout
+    assert len(raw.splitlines()) >= 8
+    for args in (["--json", "--ptu", "-vv"], ["-r", "-v"], ["-r", "--json"], ["-vvv", "--ptu"]):
+        a = subprocess.run([os.path.join(ROOT, "host", "bin", binary)] + args + ["--rawhex"], input=raw, capture_output=True, env=env, timeout=120)
+        b = subprocess.run([ref] + args + ["--rawhex"], input=raw, capture_output=True, timeout=120)
+        assert a.returncode == 0 and a.stdout == b.stdout and len(b.stdout) > 500, (binary, args)
