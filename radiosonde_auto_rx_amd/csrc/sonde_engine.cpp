@@ -776,13 +776,11 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
     if (finish) launch_framesync(e, 1);
     std::vector<FrameRec> recs;
     std::vector<float> soft;
-    const unsigned first = e->read_idx;
     const int n = collect_records(e, 0, recs, &soft, max);
     if (n < 0) return n;
     e->last_soft = soft; e->last_n = n;
     if (e->d_soft1) {                                          // the same ring slots of the second soft-bit array
-        const unsigned start = e->read_idx - (unsigned)n;       // (an overflow moves read_idx forward before the records are taken)
-        (void)first;
+        const unsigned start = e->read_idx - (unsigned)n;       // first ring slot of the records just taken (read_idx is already behind them)
         e->last_soft1.resize((size_t)n * e->nbits);
         for (int i = 0; i < n; i++) {
             const unsigned idx = (start + (unsigned)i) % (unsigned)e->max_frames;
