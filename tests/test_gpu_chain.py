@@ -223,3 +223,19 @@ def test_wideband_receiver_m10_m20():
     assert len(m10) >= 4 and all(abs(j["freq"] - 404_302) <= 3 and abs(j["lat"] - 48.1) < 0.01 and "temp" in j for j in m10), m10[:1]
     assert len(m20) >= 3 and all(abs(j["freq"] - 403_392) <= 3 and j["id"] == "M20-806-3-14321" and abs(j["pressure"] - 455.5) < 0.01 for j in m20), m20[:1]
     assert len([j for j in out if j["type"] == "RS41" and j["id"] == "D4444444"]) >= 3
+
+
+def test_wideband_module_cli():
+    """`python -m radiosonde_auto_rx_amd.wideband --cfreq Hz - 2400000 16 < capture`: one JSON object per decoded frame on stdout"""
+    import json
+    import subprocess
+    import sys
+    from radiosonde_auto_rx_amd import synth
+    sr, cf = 2_400_000, 402_500_000
+    cap = synth.rs41_capture(sr=sr, seconds=5.3, fq=synth.snap_fq(0.125, sr), n_frames=5, t_first=0.3, noise_sigma=0.01, seed=77, sonde_id="E5555555",
+                             frame_kw=dict(ecef_cm=(418833319, 85974133, 473346430)))
+    r = subprocess.run([sys.executable, "-m", "radiosonde_auto_rx_amd.wideband", "--cfreq", str(cf), "-", str(sr), "16"], input=cap.tobytes(),
+                       capture_output=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-400:]
+    objs = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(objs) >= 3 and all(o["type"] == "RS41" and o["id"] == "E5555555" and abs(o["freq"] - (cf + 300_000) // 1000) <= 3 for o in objs), objs[:1]
