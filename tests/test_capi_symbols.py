@@ -77,3 +77,34 @@ def test_host_rs_codec_matches_oracle(oracle):
 def test_host_crc_kat():
     p = (C.c_ubyte * 17)(*([0] * 17))
     assert _lib().sonde_crc16(p, 17) == 0xC7EC
+
+
+def test_generic_descriptor_is_validated_before_the_device_is_touched():
+    """sonde_engine_create_generic: malformed descriptors are SONDE_E_ARG (no GPU needed to find out); a well-formed one gets as far as the
+    device check (SONDE_E_NOGPU here) — the generic path has no CPU fallback either."""
+    from radiosonde_auto_rx_amd.engine import SondeCfg, SondeGeneric, ABI_VERSION
+    import torch
+    E_ARG, E_NOGPU = -1, -2                                # SONDE_E_ARG, SONDE_E_NOGPU (include/sonde_hip.h)
+    L = _lib()
+    L.sonde_engine_create_generic.argtypes = [C.POINTER(SondeCfg), C.POINTER(C.c_double), C.POINTER(SondeGeneric), C.POINTER(C.c_void_p)]
+    fq = (C.c_double * 1)(0.0)
+
+    def create(sonde_type=99, gen=True, **kw):
+        cfg = SondeCfg(abi_version=ABI_VERSION, n_channels=1, sample_rate=48000, bits=16, sonde_type=sonde_type, opt_lp=1, max_chunk=48000, keep_soft=1)
+        d = dict(header=b"10101010101101001010110011010011", baud=2400.0, bt=1.2, h=2.4, symlen=1, symhd=1, hdmax=1, bitofs=0, nbits=1152)
+        d.update(kw)
+        g = SondeGeneric(**d)
+        h = C.c_void_p()
+        return L.sonde_engine_create_generic(C.byref(cfg), fq, C.byref(g) if gen else None, C.byref(h))
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert create() == E_NOGPU
+    assert create(gen=False) == E_ARG                      # SONDE_GENERIC without a descriptor
+    assert create(sonde_type=41) == E_ARG                  # a descriptor with a preset type
+    assert create(header=b"1010") == E_ARG                 # header shorter than 8 symbols
+    assert create(baud=0.0) == E_ARG
+    assert create(symlen=3) == E_ARG
+    assert create(symlen=1, symhd=2) == E_ARG              # header symbols per bit cannot exceed the frame's
+    assert create(nbits=5000) == E_ARG                     # more than a frame record holds
+    assert create(nbits=0) == E_ARG
