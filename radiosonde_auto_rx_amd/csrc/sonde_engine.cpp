@@ -275,9 +275,10 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
         if (D > 64) {                                         // wide decimation (k_mix_decimate_wide): taps in global memory
             for (int k = 64; k >= 4; k--) if (D % k == 0) { e->DS = k; break; }
             if (!e->DS || e->Q < 5) { delete e; return SONDE_E_ARG; }
-            if (dalloc(&e->d_wtab, e->wtab.size(), false)) { delete e; return SONDE_E_NOMEM; }
-            HIPCHK(hipMemcpy(e->d_wtab, e->wtab.data(), e->wtab.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        // the tap rows in global memory too: the wide variant and the hand-scheduled D = 50 stream fetch them with scalar loads
+        if (dalloc(&e->d_wtab, e->wtab.size(), false)) { delete e; return SONDE_E_NOMEM; }
+        HIPCHK(hipMemcpy(e->d_wtab, e->wtab.data(), e->wtab.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ---- mixer: snapped frequency per channel (xlt_fq = -fq, rs41mod.c:2685); the table period is common
     {

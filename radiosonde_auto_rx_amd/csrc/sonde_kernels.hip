@@ -2,10 +2,9 @@
 //
 //   k_mix_decimate   cs16 -> (x - dc) * exp-LUT -> decM:1 Blackman-sinc FIR -> cf32 @ IF rate
 //                    (reference: f32read_cblock + LUT mixer + lowpass, demod_mod.c:463-508,737-754,639-648)
-//                    The decimating FIR is evaluated on the matrix cores: with D = decM and Q = ceil(taps/D)
-//                    y[m] = sum_q P[m-(Q-1)+q][q],  P[j][q] = sum_r W_q[r] * z[D*j + r]
-//                    i.e. a [blocks x D] x [D x Q] product per channel -> v_mfma_f32_16x16x4_f32
-//                    (exact f32 FMA chains), 16 blocks per tile, re and im as two accumulators.
+//                    With D = decM and Q = ceil(taps/D):  y[m] = sum_q P[m-(Q-1)+q][q],  P[j][q] = sum_r W_q[r] * z[D*j + r];
+//                    one lane owns one block j and walks its D samples with packed f32 FMAs on (re, im); the 2.4 Msps -> 48 kHz
+//                    case runs a generated, hand-scheduled instruction stream (md_fast_body.inc, tools/gen_md_fast.py).
 //   k_if_chain       IF low-pass, conj-product FM discriminator, two-tone sliding correlator, FM low-pass
 //                    (demod_mod.c:765-808,843-852)
 //   k_header_corr    matched-filter header correlation for every end sample (getCorrDFT, demod_mod.c:148-222,
@@ -122,7 +121,25 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
     if (r < D) md_step<Q_T, WRAP, PH64>(row[r], r, wa, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
 }
 
-template <int Q_T, bool PH64, int D_T>
+// Hand-scheduled walk of one 64-row tile for D = 50, Q = 7 (tools/gen_md_fast.py has the schedule and the reasons).  Same
+// arithmetic per sample as md_step<7, false, false> except that the mixer phase advances by T += f0 in double from the exact
+// product f0*n of the row's first sample (<= 49 additions: the float rounding of t differs from fl32(f0*n) for about one
+// sample in 1e7, far inside the 1e-6 stream tolerance — tests/test_gpu_parity.py::test_streams_match_oracle).
+// row_lds: byte address of the lane's row in LDS; wt: [50][8] tap rows in global memory (scalar loads).
+__device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, float2v navg, float2v msk,
+                                             float2v (&acc)[7], float2v &dcs) {
+    const uint64_t scale = 0x3800000038000000ull;            // (2^-15, 2^-15): x = b / 32768 (demod_mod.c:484-493)
+    asm volatile(
+#include "md_fast_body.inc"
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
+          [a6] "+v"(acc[6]), [dcs] "+v"(dcs), [T] "+v"(T)
+        : [row] "v"(row_lds), [f0] "s"(f0), [msk] "v"(msk), [navg] "v"(navg), [scale] "s"(scale), [wt] "s"(wt)
+        :
+#include "md_fast_clobbers.inc"
+    );
+}
+
+template <int Q_T, bool PH64, int D_T, bool FAST>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ uint32_t smem_u[];
@@ -131,6 +148,8 @@ void k_mix_decimate(const MixDecArgs a) {
     constexpr int H = Q_T - 1;
     const int tile_dw = MD_ROWS * D;
     uint32_t *sRaw = smem_u + wave * (tile_dw + 4);
+    // LDS byte address of the lane's row (the low half of a flat LDS address is the LDS offset)
+    const uint32_t row_lds = (uint32_t)reinterpret_cast<uintptr_t>(sRaw + lane * D);
 
     // XCD-aware mapping: consecutive block ids round-robin over the 8 XCDs; a channel stays on one XCD
     const int b = blockIdx.x;
@@ -226,8 +245,13 @@ void k_mix_decimate(const MixDecArgs a) {
         float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
-        else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+        if constexpr (FAST) {
+            if (nowrap) {
+                const float m = outrow ? 1.f : 0.f;
+                md_fast_tile(row_lds, a.wtab_g, f0, f0 * (double)rown, (float2v){-avg.x, -avg.y}, (float2v){m, m}, acc, dcs);
+            }
+        } else if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+        if (!nowrap) md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
         sx += (int)dcs.x; sy += (int)dcs.y;
 
         // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
@@ -1184,12 +1208,14 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
         return 0;
     }
     const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
-#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0>), grid, blk, lds, s, b); \
-                         else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0>), grid, blk, lds, s, b); } while (0)
+#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0, false>), grid, blk, lds, s, b); \
+                         else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0, false>), grid, blk, lds, s, b); } while (0)
     static const bool no_dt = getenv("SONDE_NO_DT") != nullptr;      // debugging aid: force the runtime-D variant
     if (a->Q == 7 && a->D == 50 && !no_dt) {            // 2.4 Msps -> 48 kHz: decimation known at compile time
-        if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50>), grid, blk, lds, s, b);
-        else hipLaunchKernelGGL((k_mix_decimate<7, false, 50>), grid, blk, lds, s, b);
+        static const bool no_fast = getenv("SONDE_MD_NOFAST") != nullptr;     // A/B aid: the compiler-scheduled sample loop
+        if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, false>), grid, blk, lds, s, b);
+        else if (a->wtab_g && a->nd_base == 0.0 && !no_fast) hipLaunchKernelGGL((k_mix_decimate<7, false, 50, true>), grid, blk, lds, s, b);
+        else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, false>), grid, blk, lds, s, b);
         return 0;
     }
     switch (a->Q) {
