@@ -277,8 +277,13 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
             if (!e->DS || e->Q < 5) { delete e; return SONDE_E_ARG; }
         }
         // the tap rows in global memory too: the wide variant and the hand-scheduled D = 50 stream fetch them with scalar loads
-        if (dalloc(&e->d_wtab, e->wtab.size(), false)) { delete e; return SONDE_E_NOMEM; }
-        HIPCHK(hipMemcpy(e->d_wtab, e->wtab.data(), e->wtab.size() * sizeof(float), hipMemcpyHostToDevice));
+        // (for D <= 64 a second copy follows, scaled by 2^-15 — exact — which takes over the 1/32768 of the int16 samples)
+        {
+            std::vector<float> both(e->wtab);
+            if (D <= 64) for (size_t i = 0; i < e->wtab.size(); i++) both.push_back(e->wtab[i] * 3.0517578125e-05f);
+            if (dalloc(&e->d_wtab, both.size(), false)) { delete e; return SONDE_E_NOMEM; }
+            HIPCHK(hipMemcpy(e->d_wtab, both.data(), both.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     // ---- mixer: snapped frequency per channel (xlt_fq = -fq, rs41mod.c:2685); the table period is common
     {

@@ -4,7 +4,7 @@
 //                    (reference: f32read_cblock + LUT mixer + lowpass, demod_mod.c:463-508,737-754,639-648)
 //                    With D = decM and Q = ceil(taps/D):  y[m] = sum_q P[m-(Q-1)+q][q],  P[j][q] = sum_r W_q[r] * z[D*j + r];
 //                    one lane owns one block j and walks its D samples with packed f32 FMAs on (re, im); the 2.4 Msps -> 48 kHz
-//                    case runs a generated, hand-scheduled instruction stream (md_fast_body.inc, tools/gen_md_fast.py).
+//                    case runs a generated, hand-scheduled instruction stream (md_fast_gen.h, tools/gen_md_fast.py).
 //   k_if_chain       IF low-pass, conj-product FM discriminator, two-tone sliding correlator, FM low-pass
 //                    (demod_mod.c:765-808,843-852)
 //   k_header_corr    matched-filter header correlation for every end sample (getCorrDFT, demod_mod.c:148-222,
@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sonde_dev.h"
+#include "md_fast_gen.h"
 #include <cstdlib>
 
 typedef short  short2v __attribute__((ext_vector_type(2)));
@@ -125,21 +126,161 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
 // arithmetic per sample as md_step<7, false, false> except that the mixer phase advances by T += f0 in double from the exact
 // product f0*n of the row's first sample (<= 49 additions: the float rounding of t differs from fl32(f0*n) for about one
 // sample in 1e7, far inside the 1e-6 stream tolerance — tests/test_gpu_parity.py::test_streams_match_oracle).
-// row_lds: byte address of the lane's row in LDS; wt: [50][8] tap rows in global memory (scalar loads).
-__device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, float2v navg, float2v msk,
+// row_lds: byte address of the lane's row in LDS; wt: [50][8] tap rows * 2^-15 in global memory (scalar loads);
+// navg: -32768 * avg (wave-uniform, SGPR pair).
+#define MD_FAST_CLOBBERS "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
+        "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
+        "v116", "v117", "v118", "memory"
+#define MD_FAST_ASM(BODY) asm volatile(BODY \
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]), \
+          [a6] "+v"(acc[6]), [dcs] "+v"(dcs), [T] "+v"(T) \
+        : [row] "v"(row_lds), [f0] "s"(f0), [msk] "v"(msk), [navg] "s"(navg), [wt] "s"(wt) \
+        : MD_FAST_CLOBBERS)
+template <int VAR>
+__device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, uint64_t navg, float2v msk,
                                              float2v (&acc)[7], float2v &dcs) {
-    const uint64_t scale = 0x3800000038000000ull;            // (2^-15, 2^-15): x = b / 32768 (demod_mod.c:484-493)
-    asm volatile(
-#include "md_fast_body.inc"
-        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
-          [a6] "+v"(acc[6]), [dcs] "+v"(dcs), [T] "+v"(T)
-        : [row] "v"(row_lds), [f0] "s"(f0), [msk] "v"(msk), [navg] "v"(navg), [scale] "s"(scale), [wt] "s"(wt)
-        :
-#include "md_fast_clobbers.inc"
-    );
+    if constexpr (VAR == 1) { MD_FAST_ASM(MD_FAST_BODY_1); }
+}
+// -32768 * avg as an SGPR pair (avg is per channel, i.e. wave-uniform)
+__device__ __forceinline__ uint64_t md_navg_sgpr(float2 avg) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(__float_as_uint(-32768.f * avg.x));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(__float_as_uint(-32768.f * avg.y));
+    return ((uint64_t)hi << 32) | lo;
 }
 
-template <int Q_T, bool PH64, int D_T, bool FAST>
+// ------------------------------------------------------------------------------------------------
+// k_mix_decimate50: the 2.4 Msps -> 48 kHz decimator (D = 50, Q = 7, float table phase) with everything around the sample
+// loop arranged for the memory system.  Measured on the plain kernel (tools/ab_variants.sh, empty sample loop): with ONE tile
+// (12.8 KB) per wave in flight, 12 waves per CU, the launch takes 0.9 ms without any arithmetic — 154 KB per CU in flight
+// against a loaded HBM latency of ~7 us caps the stream at 5.3 TB/s (a pure read of the same bytes in the same pattern:
+// 6.3 TB/s, 6.8 with non-temporal loads; tools/probes/read_bw.hip).  So here
+//   * TWO tiles per wave are in flight: two staging sets of 12 x 16 B + 8 B per lane (100 VGPRs), filled by non-temporal
+//     loads whose address is an SGPR base + one lane offset (no address arithmetic per tile), waited for with vmcnt counts;
+//   * the previous tile's contribution to the first Q-1 outputs of a tile is ONE carry value per lane (the rotation that
+//     forms the diagonal sum delivers both this tile's terms and the next tile's carry) instead of a copy of all P rows;
+//   * -32768*avg and the mixer frequency are SGPRs, the 2^-15 of the int16 scale sits in the tap table.
+// That only fits 3 waves per SIMD (168 VGPRs) with every register placed by hand, so a wave's whole run of full tiles is ONE
+// generated statement (MD50_LOOP_*, tools/gen_md_fast.py); C++ does the set-up, a tile that sticks out of the chunk, the P tail
+// and the IQ-DC sums.  Requires nblocks even (every 16-byte piece of a tile is then either inside or outside the chunk) and
+// >= 64, and rows aligned with the mixer table (lut_len % 50 == 0, lut_phase % 50 == 0: no row wraps around the table end).
+// ------------------------------------------------------------------------------------------------
+#define MD50_CLOBBERS MD50_S36_81, MD50_V28_167, "memory", "vcc", "scc"
+#define MD50_S36_81 "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", \
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81"
+#define MD50_V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+#define MD50_V28_167 "v28", "v29", MD50_V10(3), MD50_V10(4), MD50_V10(5), MD50_V10(6), MD50_V10(7), MD50_V10(8), MD50_V10(9), MD50_V10(10), \
+        MD50_V10(11), MD50_V10(12), MD50_V10(13), MD50_V10(14), MD50_V10(15), "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+#define MD50_ASM(BODY) asm volatile(BODY \
+        : [o0] "=v"(acc[0]), [o1] "=v"(acc[1]), [o2] "=v"(acc[2]), [o3] "=v"(acc[3]), [o4] "=v"(acc[4]), [o5] "=v"(acc[5]), [o6] "=v"(acc[6]), \
+          [carry] "+v"(carry), [rown] "+v"(rown), [sx] "+v"(sx), [sy] "+v"(sy) \
+        : [row] "v"(row_lds), [voff16] "v"(voff16), [voff8] "v"(voff8), [ldsw16] "v"(ldsw16), [ldsw8] "v"(ldsw8), [lane4] "v"(lane4), \
+          [tb] "s"(tb), [f0] "s"(f0), [navg] "s"(navg), [wt] "s"(wt_s), [yout] "s"(yout), [jm] "s"(jm), [rmask] "s"(rmask), [L] "s"(L), \
+          [step] "s"(step), [nfull] "s"(nfull), [outmask] "s"(outmask) \
+        : MD50_CLOBBERS)
+
+template <int VAR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_mix_decimate50(const MixDecArgs a) {
+    extern __shared__ uint32_t smem_u[];
+    constexpr int Q_T = 7, H = 6, D = 50, TILE_DW = MD_ROWS * D;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *sRaw = smem_u + wave * (TILE_DW + 4);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(sRaw);     // LDS byte address (low half of the flat address)
+    const uint32_t row_lds = lds0 + 4u * D * lane, ldsw16 = lds0 + 16u * lane, ldsw8 = lds0 + 8u * lane;
+    const uint32_t voff16 = 16u * lane, voff8 = 8u * lane, lane4 = 4u * lane;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
+    const int wg = slot % a.wgs_per_ch;
+    if (ch >= a.n_ch) return;
+    const int seg = wg * 4 + wave;
+    const int rows_per_seg = MD_ROWS * a.G - H;
+    const int jb = seg * rows_per_seg;
+    if (jb >= a.nblocks) return;
+    const int je = min(a.nblocks, jb + rows_per_seg);
+    const int jt0 = (seg == 0) ? jb : jb - H;
+    const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
+    const int nfull = min(ntiles, (a.nblocks - jt0) / MD_ROWS);        // leading tiles that lie completely inside the chunk
+
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const float2 avg = a.dc_avg[ch];
+    const uint64_t navg = md_navg_sgpr(avg);
+    const double f0 = a.chan_f0[ch];
+    const uint32_t L = (uint32_t)a.lut_len;
+    float2 *yout = a.y + (size_t)ch * a.ring_len;
+    const float *wt_s = a.wtab_g + 64 * 8;                     // tap rows * 2^-15
+    const uint32_t rmask = (uint32_t)a.ring_len - 1;
+
+    // carry: what the P rows before this tile add to its first H outputs (lane l < H: sum over q of P[l-(H-q)][q], rows < 0)
+    float2v carry = {0.f, 0.f};
+    if (seg == 0 && lane < H) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int i = lane + q;                            // row l - (H-q) of the chunk = row l + q of the P tail (blocks -H .. -1)
+            if (i < H) { const float2 v = a.ptail_in[((size_t)ch * 8 + i) * 8 + q]; carry += (float2v){v.x, v.y}; }
+        }
+    }
+    int sx = 0, sy = 0;
+    const uint32_t step = (uint32_t)(((uint64_t)MD_ROWS * (uint64_t)D) % L);
+    uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)(jt0 + lane) * (uint64_t)D) % L);
+    float2v acc[Q_T];
+
+    if (nfull > 0) {
+        const uint32_t *tb = iq + (size_t)jt0 * D;
+        const uint32_t jm = a.m0 + (uint32_t)jt0;
+        const uint64_t outmask = (seg == 0) ? ~0ull : ~0ull << H;           // the H halo rows of a later segment produce no output
+        if constexpr (VAR == 1) { MD50_ASM(MD50_LOOP_1); }
+#ifdef SONDE_MD_EXPERIMENTS                                  // timing experiments (tools/ab_variants.sh): results are garbage
+        if constexpr (VAR == 2) { MD50_ASM(MD50_LOOP_2); }
+        if constexpr (VAR == 3) { MD50_ASM(MD50_LOOP_3); }
+#endif
+        const int j = jt0 + (nfull - 1) * MD_ROWS + lane;      // rows of the last tile walked above
+        if (j >= a.nblocks - H && j < a.nblocks) {             // P rows of the last Q-1 blocks go to the next call
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+    }
+    if (ntiles > nfull) {                                     // the wave's last tile sticks out of the chunk: checked loads, no staging
+        const int jt = jt0 + nfull * MD_ROWS, total_dw = a.nblocks * D;
+#pragma unroll 1
+        for (int v = 0; v < 13; v++) {
+            const int c = 64 * v + lane, off = jt * D + 4 * c;
+            u32x4_u w = {0u, 0u, 0u, 0u};
+            if (4 * c < TILE_DW && off + 4 <= total_dw) w = *reinterpret_cast<const u32x4_u *>(iq + off);
+            if (4 * c < TILE_DW) *reinterpret_cast<uint4 *>(sRaw + 4 * c) = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        const int j = jt + lane;
+        const bool outrow = j >= jb && j < je;
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
+        float2v dcs = {0.f, 0.f};
+        const float m = outrow ? 1.f : 0.f;
+        md_fast_tile<1>(row_lds, wt_s, f0, f0 * (double)rown, navg, (float2v){m, m}, acc, dcs);
+        sx += (int)dcs.x; sy += (int)dcs.y;
+        float2v y = acc[H] + carry;
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int k = H - q, src = (lane - k) & 63;
+            const float2v r = { __shfl(acc[q].x, src), __shfl(acc[q].y, src) };
+            if (lane >= k) y += r;
+        }
+        if (outrow) yout[(a.m0 + (uint32_t)j) & rmask] = make_float2(y.x, y.y);
+        if (j >= a.nblocks - H && j < a.nblocks) {
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
+    if (lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch), (unsigned long long)(long long)sx);
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch + 1), (unsigned long long)(long long)sy);
+    }
+}
+
+template <int Q_T, bool PH64, int D_T, int FAST>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
     extern __shared__ uint32_t smem_u[];
@@ -197,8 +338,12 @@ void k_mix_decimate(const MixDecArgs a) {
             const uint32_t *p = iq + (size_t)jt * D + 4 * lane;
 #pragma unroll
             for (int v = 0; v < NV_T; v++) {
-                if (4 * (64 * v) + 3 < MD_ROWS * D_T)           // load v exists for lane 0; the last one only for the low lanes
-                    pre[v] = *reinterpret_cast<const u32x4_u *>((4 * (64 * v + 63) < MD_ROWS * D_T || 4 * (64 * v + lane) < MD_ROWS * D_T) ? p + 256 * v : p);
+                if (4 * (64 * v) + 3 < MD_ROWS * D_T) {         // load v exists for lane 0; the last one only for the low lanes
+                    const uint32_t *q = (4 * (64 * v + 63) < MD_ROWS * D_T || 4 * (64 * v + lane) < MD_ROWS * D_T) ? p + 256 * v : p;
+                    // read-once stream: non-temporal (tools/probes/read_bw.hip: 6.3 -> 6.8 TB/s on this access pattern)
+                    pre[v].x = __builtin_nontemporal_load(q); pre[v].y = __builtin_nontemporal_load(q + 1);
+                    pre[v].z = __builtin_nontemporal_load(q + 2); pre[v].w = __builtin_nontemporal_load(q + 3);
+                }
             }
             return;
         }
@@ -245,10 +390,10 @@ void k_mix_decimate(const MixDecArgs a) {
         float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if constexpr (FAST) {
+        if constexpr (FAST > 0) {
             if (nowrap) {
                 const float m = outrow ? 1.f : 0.f;
-                md_fast_tile(row_lds, a.wtab_g, f0, f0 * (double)rown, (float2v){-avg.x, -avg.y}, (float2v){m, m}, acc, dcs);
+                md_fast_tile<1>(row_lds, a.wtab_g + 64 * 8, f0, f0 * (double)rown, md_navg_sgpr(avg), (float2v){m, m}, acc, dcs);
             }
         } else if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
         if (!nowrap) md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
@@ -1208,14 +1353,28 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
         return 0;
     }
     const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
-#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0, false>), grid, blk, lds, s, b); \
-                         else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0, false>), grid, blk, lds, s, b); } while (0)
+#define MD_LAUNCH(QT) do { if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<QT, true, 0, 0>), grid, blk, lds, s, b); \
+                         else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0, 0>), grid, blk, lds, s, b); } while (0)
     static const bool no_dt = getenv("SONDE_NO_DT") != nullptr;      // debugging aid: force the runtime-D variant
     if (a->Q == 7 && a->D == 50 && !no_dt) {            // 2.4 Msps -> 48 kHz: decimation known at compile time
-        static const bool no_fast = getenv("SONDE_MD_NOFAST") != nullptr;     // A/B aid: the compiler-scheduled sample loop
-        if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, false>), grid, blk, lds, s, b);
-        else if (a->wtab_g && a->nd_base == 0.0 && !no_fast) hipLaunchKernelGGL((k_mix_decimate<7, false, 50, true>), grid, blk, lds, s, b);
-        else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, false>), grid, blk, lds, s, b);
+        static const bool no_fast = getenv("SONDE_MD_NOFAST") != nullptr;     // A/B aids: the compiler-scheduled sample loop,
+        static const bool no_k50 = getenv("SONDE_MD_NO50") != nullptr;        // the one-tile-in-flight kernel around the asm loop
+        if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, 0>), grid, blk, lds, s, b);
+        else if (a->wtab_g && a->nd_base == 0.0 && !no_fast) {
+            if (a->nblocks >= 64 && a->nblocks % 2 == 0 && a->lut_len % 50 == 0 && a->lut_phase % 50 == 0 && !no_k50) {
+#ifdef SONDE_MD_EXPERIMENTS
+                static const int var = getenv("SONDE_MD_VARIANT") ? atoi(getenv("SONDE_MD_VARIANT")) : 1;
+                switch (var) {
+                    case 2: hipLaunchKernelGGL((k_mix_decimate50<2>), grid, blk, lds, s, b); return 0;
+                    case 3: hipLaunchKernelGGL((k_mix_decimate50<3>), grid, blk, lds, s, b); return 0;
+                    default: break;
+                }
+#endif
+                hipLaunchKernelGGL((k_mix_decimate50<1>), grid, blk, lds, s, b);
+            }
+            else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, 1>), grid, blk, lds, s, b);
+        }
+        else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, 0>), grid, blk, lds, s, b);
         return 0;
     }
     switch (a->Q) {

@@ -1,107 +1,240 @@
 #!/usr/bin/env python3
-"""Generates radiosonde_auto_rx_amd/csrc/md_fast_body.inc: the hand-scheduled gfx950 instruction stream that walks one
-64-row tile of k_mix_decimate (one lane = one block of D input samples, Q = 7 tap columns).
+"""Generates radiosonde_auto_rx_amd/csrc/md_fast_gen.h: the hand-scheduled gfx950 instruction streams of the 2.4 Msps -> 48 kHz
+decimator (D = 50 input samples per output, Q = 7 tap columns; one lane = one block of D input samples, 64 rows per tile).
 
-Why a generated stream and not C++: the sample loop is VALU-issue-bound, and what the compiler makes of it loses cycles in
-three places that only an explicit schedule removes —
+MD_FAST_BODY_1   the walk over the 50 samples of one tile, registers of the accumulators / phase chosen by the compiler
+                 (operands) — used where single tiles are processed from C++ (chunk ends, odd launch geometries).
+MD50_LOOP_1      a wave's whole sequence of full tiles as ONE statement with hand-allocated registers: non-temporal loads of
+                 tile t+2 into one of two staging sets (2 x 50 VGPRs), the sample walk of tile t out of LDS, the diagonal sum
+                 with a one-value carry, the store of the 64 outputs, then vmcnt-counted wait + park of tile t+1 into LDS.
+
+Why generated streams and not C++:
   * SMEM (taps) and LDS (raw samples) share lgkmcnt and SMEM returns out of order, so every wait is lgkmcnt(0): the loads of
     the NEXT pair of samples must be issued right AFTER the wait for the current pair, never before it, or the wave sleeps
     for a scalar-cache round trip per pair (the compiler's loop did exactly that);
   * v_pk_fma_f32 takes its wave-uniform tap from an aligned SGPR pair; op_sel picks the odd tap of a pair, so a tap row
     loaded with one s_load_dwordx8 is used in place (the compiler copied 16 SGPRs per pair of samples);
   * the mixer phase t = fl32(f0*n) advances by one v_add_f64 per sample (re-seeded with the exact product per row and tile)
-    instead of index-add + v_mul_f64.
+    instead of index-add + v_mul_f64;
+  * with one 12.8 KB tile per wave in flight (12 waves per CU) the launch is bound by bytes in flight, not by arithmetic
+    (an EMPTY sample loop still took 0.9 ms per 4.9 GB): two tiles per wave must be in flight, which only fits the 168
+    registers of a 3-waves-per-SIMD kernel when every register is placed by hand (the compiler spilled and — fatal for
+    loads it cannot see — copied staging registers before their data had landed).
 
 Per sample r (reference: demod_mod.c:484-493 IQ-DC, :737-750 mixer, :639-648/753 FIR):
-  S1(r): x = cvt(raw); dcs += x*msk; u = x*2^-15 - avg; t = fl32(T); T += f0; (c, s) = cos/sin(2 pi fract(t))
-  S2(r): z = u * (c + i s); acc[q] += W_q[r] * z, q = 0..6
+  S1(r): x = cvt(raw); dcs += x; u = x - 32768*avg; t = fl32(T); T += f0; (c, s) = cos/sin(2 pi fract(t))
+  S2(r): z = u * (c + i s); acc[q] += (2^-15 W_q[r]) * z, q = 0..6
+(the 2^-15 of x = b/32768 sits in the tap table: scaling by a power of two commutes with every rounding, so the sums are
+bit-identical to (x/32768 - avg) * ex * W, and -32768*avg is wave-uniform -> one SGPR pair, no VGPRs for scale / avg)
 Block B_r = S2(r-1) interleaved with S1(r), r = 0..D.  Before every even block: s_waitcnt lgkmcnt(0), then the loads
 for the blocks after the next wait (raw pair p+1, tap rows 2p+1 and 2p+2).  Four tap-row register sets, two raw pairs.
 """
+import os
 import sys
 
 D = 50
 Q = 7
+H = Q - 1
 TAPSET = [36, 44, 52, 60]          # s[36:67]: four 8-dword tap rows
-V0 = 100                           # v[100:118] scratch
-RAW = [f"v[{V0}:{V0 + 1}]", f"v[{V0 + 2}:{V0 + 3}]"]
-RAWC = [[f"v{V0}", f"v{V0 + 1}"], [f"v{V0 + 2}", f"v{V0 + 3}"]]
-X = f"v[{V0 + 4}:{V0 + 5}]"; XR = f"v{V0 + 4}"; XI = f"v{V0 + 5}"
-U = [f"v[{V0 + 6}:{V0 + 7}]", f"v[{V0 + 8}:{V0 + 9}]"]
-CS = [f"v[{V0 + 10}:{V0 + 11}]", f"v[{V0 + 12}:{V0 + 13}]"]
-C = [f"v{V0 + 10}", f"v{V0 + 12}"]; S = [f"v{V0 + 11}", f"v{V0 + 13}"]
-TT = f"v[{V0 + 14}:{V0 + 15}]"
-Z = f"v[{V0 + 16}:{V0 + 17}]"
-TP = f"v{V0 + 18}"
-NV = 19
 
 
-def tap_fma(q, row):
+def pair(n):
+    return f"v[{n}:{n + 1}]"
+
+
+class Regs:
+    """Register names of one instance of the sample walk.  v0 = first of 19 scratch VGPRs."""
+
+    def __init__(self, v0, acc, dcs, T, row, f0, navg, wt, msk=None):
+        self.RAW = [pair(v0), pair(v0 + 2)]
+        self.RAWC = [[f"v{v0}", f"v{v0 + 1}"], [f"v{v0 + 2}", f"v{v0 + 3}"]]
+        self.X, self.XR, self.XI = pair(v0 + 4), f"v{v0 + 4}", f"v{v0 + 5}"
+        self.U = [pair(v0 + 6), pair(v0 + 8)]
+        self.CS = [pair(v0 + 10), pair(v0 + 12)]
+        self.C = [f"v{v0 + 10}", f"v{v0 + 12}"]
+        self.S = [f"v{v0 + 11}", f"v{v0 + 13}"]
+        self.TT, self.Z, self.TP = pair(v0 + 14), pair(v0 + 16), f"v{v0 + 18}"
+        self.acc, self.dcs, self.T, self.row, self.f0, self.navg, self.wt, self.msk = acc, dcs, T, row, f0, navg, wt, msk
+
+
+EXP = ""      # experiment variants (tools/ab_variants.sh): timing only, results are garbage
+
+
+def tap_fma(R, q, row):
     b = TAPSET[row % 4] + (q & ~1)
     sel = "op_sel:[1,0,0] op_sel_hi:[1,1,1]" if q & 1 else "op_sel_hi:[0,1,1]"
-    return f"v_pk_fma_f32 %[a{q}], s[{b}:{b + 1}], {Z}, %[a{q}] {sel}"
+    return f"v_pk_fma_f32 {R.acc[q]}, s[{b}:{b + 1}], {R.Z}, {R.acc[q]} {sel}"
 
 
-def loads_after_wait(p):
+def loads_after_wait(R, p):
     out = []
     if p + 1 <= (D - 1) // 2:
-        out.append(f"ds_read_b64 {RAW[(p + 1) & 1]}, %[row] offset:{8 * (p + 1)}")
+        out.append(f"ds_read_b64 {R.RAW[(p + 1) & 1]}, {R.row} offset:{8 * (p + 1)}")
     for k in (2 * p + 1, 2 * p + 2):
         if k <= D - 1:
             b = TAPSET[k % 4]
-            out.append(f"s_load_dwordx8 s[{b}:{b + 7}], %[wt], 0x{32 * k:x}")
+            out.append(f"s_load_dwordx8 s[{b}:{b + 7}], {R.wt}, 0x{32 * k:x}")
     return out
 
 
-def block(r):
+def block(R, r):
     s1 = r <= D - 1
     s2 = r >= 1
     e, o = r & 1, (r - 1) & 1
-    raw = RAWC[(r >> 1) & 1][r & 1] if s1 else None
+    raw = R.RAWC[(r >> 1) & 1][r & 1] if s1 else None
     L = []
-    if s1: L.append(f"v_cvt_f32_f64 {TP}, %[T]")
-    if s2: L.append(f"v_pk_mul_f32 {TT}, {U[o]}, {CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]")
-    if s1: L.append(f"v_add_f64 %[T], %[T], %[f0]")
-    if s1: L.append(f"v_fract_f32 {TP}, {TP}")
-    if s2: L.append(f"v_pk_fma_f32 {Z}, {U[o]}, {CS[o]}, {TT} op_sel_hi:[0,1,1]")
-    if s1: L.append(f"v_cvt_f32_i32_sdwa {XR}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0")
-    if s1: L.append(f"v_cos_f32 {C[e]}, {TP}")
-    if s2: L.append(tap_fma(0, r - 1))
-    if s1: L.append(f"v_cvt_f32_i32_sdwa {XI}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
-    if s1: L.append(f"v_sin_f32 {S[e]}, {TP}")
-    if s2: L.append(tap_fma(1, r - 1))
-    if s2: L.append(tap_fma(2, r - 1))
-    if s1: L.append(f"v_pk_fma_f32 %[dcs], {X}, %[msk], %[dcs]")
-    if s2: L.append(tap_fma(3, r - 1))
-    if s1: L.append(f"v_pk_fma_f32 {U[e]}, {X}, %[scale], %[navg] op_sel_hi:[1,0,1]")
+    if s1: L.append(f"v_cvt_f32_f64 {R.TP}, {R.T}")
+    if s2: L.append(f"v_pk_mul_f32 {R.TT}, {R.U[o]}, {R.CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]")
+    if s1: L.append(f"v_add_f64 {R.T}, {R.T}, {R.f0}")
+    if s1: L.append(f"v_fract_f32 {R.TP}, {R.TP}")
+    if s2: L.append(f"v_pk_fma_f32 {R.Z}, {R.U[o]}, {R.CS[o]}, {R.TT} op_sel_hi:[0,1,1]")
+    if s1: L.append(f"v_cvt_f32_i32_sdwa {R.XR}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0")
+    if s1: L.append(f"v_cos_f32 {R.C[e]}, {R.TP}")
+    if s2: L.append(tap_fma(R, 0, r - 1))
+    if s1: L.append(f"v_cvt_f32_i32_sdwa {R.XI}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+    if s1: L.append(f"v_sin_f32 {R.S[e]}, {R.TP}")
+    if s2: L.append(tap_fma(R, 1, r - 1))
+    if s2: L.append(tap_fma(R, 2, r - 1))
+    if s1: L.append(f"v_pk_fma_f32 {R.dcs}, {R.X}, {R.msk}, {R.dcs}" if R.msk else f"v_pk_add_f32 {R.dcs}, {R.X}, {R.dcs}")
+    if s2: L.append(tap_fma(R, 3, r - 1))
+    if s1: L.append(f"v_pk_add_f32 {R.U[e]}, {R.X}, {R.navg}")
     if s2:
-        for q in range(4, Q): L.append(tap_fma(q, r - 1))
+        for q in range(4, Q): L.append(tap_fma(R, q, r - 1))
+    if "nosincos" in EXP:
+        L = [l.replace("v_cos_f32", "v_mov_b32").replace("v_sin_f32", "v_mov_b32") for l in L]
+    if "nof64" in EXP:
+        L = [l for l in L if not l.startswith("v_add_f64")]
+        L = [f"v_mov_b32 {R.TP}, {R.XR}" if l.startswith("v_cvt_f32_f64") else l for l in L]
+    if "nofir" in EXP:
+        L = [l for l in L if not any(l.startswith(f"v_pk_fma_f32 {R.acc[q]},") for q in range(1, Q))]
     return L
 
 
-def generate():
-    L = [f"ds_read_b64 {RAW[0]}, %[row]", f"s_load_dwordx8 s[{TAPSET[0]}:{TAPSET[0] + 7}], %[wt], 0x0"]
+def walk(R):
+    """the 50 samples of one tile; ends with every LDS / SMEM access complete"""
+    if "empty" in EXP:
+        return ["s_waitcnt lgkmcnt(0)"]
+    L = [f"ds_read_b64 {R.RAW[0]}, {R.row}", f"s_load_dwordx8 s[{TAPSET[0]}:{TAPSET[0] + 7}], {R.wt}, 0x0"]
     for r in range(D + 1):
         if r % 2 == 0:
             L.append("s_waitcnt lgkmcnt(0)")
-            L += loads_after_wait(r // 2)
-        L += block(r)
+            L += loads_after_wait(R, r // 2)
+        L += block(R, r)
+    if "noloads" in EXP:
+        L = [l for l in L if not (l.startswith("ds_read") or l.startswith("s_load") or l.startswith("s_waitcnt"))]
     return L
 
 
+# ---- the operand form (md_fast_tile in sonde_kernels.hip) -----------------------------------------------------------------
+def body_operands():
+    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[navg]", "%[wt]", msk="%[msk]")
+    return walk(R)
+
+
+# ---- the whole tile loop of k_mix_decimate50 -------------------------------------------------------------------------------
+# VGPRs v28..v167 belong to the statement (clobbers, MD50_CLOBBERS in sonde_kernels.hip); the compiler keeps its operands below.
+ACC0 = 28                          # v[28:41]  P[row][0..6] (re, im)
+CARRY = 42                         # v[42:43]  what earlier rows add to the first H outputs of the next tile
+STAGE = [44, 94]                   # two staging sets: 12 x 4 + 2 VGPRs each
+SCR = 144                          # v[144:162] scratch of the sample walk; reused by the diagonal sum
+DCS = 164                          # v[164:165]
+TREG = 166                         # v[166:167]
+S_B1, S_B2, S_B3, S_TB = 68, 70, 72, 74      # tile base + 4096 / 8192 / 12288 bytes, tile base
+S_T, S_TMP, S_OUT, S_JM = 76, 77, 78, 80     # tile counter, scratch, s[78:79] lanes whose outputs count, ring index of the tile
+TILE_BYTES = 64 * D * 4
+ACC = [pair(ACC0 + 2 * q) for q in range(Q)]
+
+
+def fetch(st):
+    """13 non-temporal loads of the tile at s[S_TB] into staging set st; advances s[S_TB] by one tile"""
+    L = []
+    for b, o in ((S_B1, 0x1000), (S_B2, 0x2000), (S_B3, 0x3000)):
+        L += [f"s_add_u32 s{b}, s{S_TB}, 0x{o:x}", f"s_addc_u32 s{b + 1}, s{S_TB + 1}, 0"]
+    for i in range(12):
+        base = (S_TB, S_B1, S_B2)[i // 4]
+        L.append(f"global_load_dwordx4 v[{st + 4 * i}:{st + 4 * i + 3}], %[voff16], s[{base}:{base + 1}] offset:{1024 * (i % 4)} nt")
+    L.append(f"global_load_dwordx2 v[{st + 48}:{st + 49}], %[voff8], s[{S_B3}:{S_B3 + 1}] nt")
+    L += [f"s_add_u32 s{S_TB}, s{S_TB}, 0x{TILE_BYTES:x}", f"s_addc_u32 s{S_TB + 1}, s{S_TB + 1}, 0"]
+    return L
+
+
+def park(st):
+    L = [f"ds_write_b128 %[ldsw16], v[{st + 4 * i}:{st + 4 * i + 3}]" + (f" offset:{1024 * i}" if i else "") for i in range(12)]
+    L.append(f"ds_write_b64 %[ldsw8], v[{st + 48}:{st + 49}] offset:12288")
+    return L
+
+
+def tile():
+    R = Regs(SCR, ACC, pair(DCS), pair(TREG), "%[row]", "%[f0]", "%[navg]", "%[wt]")
+    L = [f"v_mov_b64 {a}, 0" for a in ACC] + [f"v_mov_b64 {pair(DCS)}, 0",
+         f"v_cvt_f64_u32 {pair(TREG)}, %[rown]", f"v_mul_f64 {pair(TREG)}, {pair(TREG)}, %[f0]"]
+    L += walk(R)
+    Rq = [SCR + 2 * q for q in range(H)]                       # rotated columns
+    Y, T1, A, B = SCR + 12, SCR + 14, SCR + 15, SCR + 16
+    # table row of the lane's block in the next tile: rown = (rown + 64 D) mod L
+    L += [f"v_add_u32 %[rown], %[step], %[rown]", f"v_subrev_u32 v{T1}, %[L], %[rown]", f"v_min_u32 %[rown], v{T1}, %[rown]"]
+    L += [f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}"]
+    # y[j] = P[j][H] + sum_{q<H} P[j-(H-q)][q]: rotate column q down by k = H-q lanes (bpermute address 4*lane + 256 - 4k)
+    for q in range(H):
+        k = H - q
+        L += [f"ds_bpermute_b32 v{Rq[q]}, %[lane4], v{ACC0 + 2 * q} offset:{256 - 4 * k}",
+              f"ds_bpermute_b32 v{Rq[q] + 1}, %[lane4], v{ACC0 + 2 * q + 1} offset:{256 - 4 * k}"]
+    L += [f"v_pk_add_f32 {pair(Y)}, {ACC[H]}, {pair(CARRY)}", f"v_mov_b64 {pair(CARRY)}, 0",
+          f"v_lshrrev_b32 v{T1}, 2, %[lane4]", f"v_add_u32 v{T1}, s{S_JM}, v{T1}", f"v_and_b32 v{T1}, %[rmask], v{T1}",
+          f"v_lshlrev_b32 v{T1}, 3, v{T1}",
+          f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}",
+          "s_mov_b64 exec, -1", "s_waitcnt lgkmcnt(0)"]
+    for q in range(H):                                         # lanes >= k: a row of this tile -> its term of y
+        L += [f"s_mov_b32 exec_lo, 0x{(0xffffffff << (H - q)) & 0xffffffff:x}", f"v_pk_add_f32 {pair(Y)}, {pair(Y)}, {pair(Rq[q])}"]
+    for q in range(H):                                         # lanes < k: rows 64-k+l of this tile -> the next tile's carry
+        L += [f"s_mov_b64 exec, {(1 << (H - q)) - 1}", f"v_pk_add_f32 {pair(CARRY)}, {pair(CARRY)}, {pair(Rq[q])}"]
+    L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
+          "s_mov_b64 exec, -1", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], -1", f"s_add_i32 s{S_JM}, s{S_JM}, 64"]
+    return L
+
+
+def gen_loop():
+    L = [f"s_mov_b64 s[{S_TB}:{S_TB + 1}], %[tb]", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[outmask]", f"s_mov_b32 s{S_JM}, %[jm]",
+         f"s_mov_b32 s{S_T}, 0", f"v_mov_b64 {pair(CARRY)}, %[carry]"]
+    # tile 0 -> LDS (the wave's only exposed load latency); tile 1 on its way
+    L += fetch(STAGE[0])
+    L += ["s_cmp_gt_i32 %[nfull], 1", "s_cbranch_scc0 10f"]
+    L += fetch(STAGE[1])
+    L += ["s_waitcnt vmcnt(13)", "s_branch 11f", "10:", "s_waitcnt vmcnt(0)", "11:"]
+    L += park(STAGE[0])
+    for half in (0, 1):                                        # tile t even: fetch t+2 -> set 0, park t+1 from set 1; odd: swapped
+        lab = 20 + 10 * half
+        L += [f"{lab}:", f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 1}f"]
+        L += fetch(STAGE[half])
+        L += [f"{lab + 1}:"]
+        L += tile()
+        L += [f"s_add_i32 s{S_T}, s{S_T}, 1", f"s_cmp_ge_i32 s{S_T}, %[nfull]", "s_cbranch_scc1 90f"]
+        # the loads of tile t+1 are followed by its predecessor's store, 13 loads of tile t+2 (if issued) and this tile's store
+        L += [f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f",
+              "s_waitcnt vmcnt(14)", f"s_branch {lab + 3}f", f"{lab + 2}:", "s_waitcnt vmcnt(0)", f"{lab + 3}:"]
+        L += park(STAGE[1 - half])
+    L += ["s_branch 20b", "90:"]
+    L += [f"v_mov_b64 %[o{q}], {ACC[q]}" for q in range(Q)] + [f"v_mov_b64 %[carry], {pair(CARRY)}", "s_nop 1"]
+    return L
+
+
+def as_macro(name, lines):
+    return f"#define {name} \\\n" + " \\\n".join(f'    "{l}\\n\\t"' for l in lines) + "\n"
+
+
 def main():
-    lines = generate()
-    out = ["// generated by tools/gen_md_fast.py — do not edit (tests/test_generated_sources.py checks it is in sync)"]
-    out += [f'"{l}\\n\\t"' for l in lines]
-    clob = [f'"s{i}"' for i in range(TAPSET[0], TAPSET[-1] + 8)] + [f'"v{i}"' for i in range(V0, V0 + NV)] + ['"memory"']
-    text = "\n".join(out) + "\n"
-    clobtext = "// generated by tools/gen_md_fast.py — clobber list of md_fast_body.inc\n" + ", ".join(clob) + "\n"
+    """md_fast_gen.h: MD_FAST_BODY_1 / MD50_LOOP_1 = production; with --experiments <spec>... also _2.. (timing only)"""
+    global EXP
+    text = "// generated by tools/gen_md_fast.py — do not edit (tests/test_generated_sources.py checks it is in sync)\n"
+    text += as_macro("MD_FAST_BODY_1", body_operands()) + as_macro("MD50_LOOP_1", gen_loop())
+    if len(sys.argv) > 1 and sys.argv[1] == "--experiments":
+        for k, e in enumerate(sys.argv[2:], 2):
+            EXP = e
+            text += f"// experiment {k}: {e}\n" + as_macro(f"MD50_LOOP_{k}", gen_loop())
     if len(sys.argv) > 1 and sys.argv[1] == "--print":
         sys.stdout.write(text); return
-    import os
     base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "radiosonde_auto_rx_amd", "csrc")
-    open(os.path.join(base, "md_fast_body.inc"), "w").write(text)
-    open(os.path.join(base, "md_fast_clobbers.inc"), "w").write(clobtext)
+    open(os.path.join(base, "md_fast_gen.h"), "w").write(text)
 
 
 if __name__ == "__main__":
