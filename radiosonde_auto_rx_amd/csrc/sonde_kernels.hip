@@ -233,9 +233,18 @@ void k_mix_decimate50(const MixDecArgs a) {
         const uint32_t jm = a.m0 + (uint32_t)jt0;
         const uint64_t outmask = (seg == 0) ? ~0ull : ~0ull << H;           // the H halo rows of a later segment produce no output
         if constexpr (VAR == 1) { MD50_ASM(MD50_LOOP_1); }
-#ifdef SONDE_MD_EXPERIMENTS                                  // timing experiments (tools/ab_variants.sh): results are garbage
+        // timing experiments (tools/ab_variants.sh; streams from `gen_md_fast.py --experiments ...`): results may be garbage
+#ifdef MD50_LOOP_2
         if constexpr (VAR == 2) { MD50_ASM(MD50_LOOP_2); }
+#endif
+#ifdef MD50_LOOP_3
         if constexpr (VAR == 3) { MD50_ASM(MD50_LOOP_3); }
+#endif
+#ifdef MD50_LOOP_4
+        if constexpr (VAR == 4) { MD50_ASM(MD50_LOOP_4); }
+#endif
+#ifdef MD50_LOOP_5
+        if constexpr (VAR == 5) { MD50_ASM(MD50_LOOP_5); }
 #endif
         const int j = jt0 + (nfull - 1) * MD_ROWS + lane;      // rows of the last tile walked above
         if (j >= a.nblocks - H && j < a.nblocks) {             // P rows of the last Q-1 blocks go to the next call
@@ -1362,13 +1371,18 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
         if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, 0>), grid, blk, lds, s, b);
         else if (a->wtab_g && a->nd_base == 0.0 && !no_fast) {
             if (a->nblocks >= 64 && a->nblocks % 2 == 0 && a->lut_len % 50 == 0 && a->lut_phase % 50 == 0 && !no_k50) {
-#ifdef SONDE_MD_EXPERIMENTS
                 static const int var = getenv("SONDE_MD_VARIANT") ? atoi(getenv("SONDE_MD_VARIANT")) : 1;
-                switch (var) {
-                    case 2: hipLaunchKernelGGL((k_mix_decimate50<2>), grid, blk, lds, s, b); return 0;
-                    case 3: hipLaunchKernelGGL((k_mix_decimate50<3>), grid, blk, lds, s, b); return 0;
-                    default: break;
-                }
+#ifdef MD50_LOOP_2
+                if (var == 2) { hipLaunchKernelGGL((k_mix_decimate50<2>), grid, blk, lds, s, b); return 0; }
+#endif
+#ifdef MD50_LOOP_3
+                if (var == 3) { hipLaunchKernelGGL((k_mix_decimate50<3>), grid, blk, lds, s, b); return 0; }
+#endif
+#ifdef MD50_LOOP_4
+                if (var == 4) { hipLaunchKernelGGL((k_mix_decimate50<4>), grid, blk, lds, s, b); return 0; }
+#endif
+#ifdef MD50_LOOP_5
+                if (var == 5) { hipLaunchKernelGGL((k_mix_decimate50<5>), grid, blk, lds, s, b); return 0; }
 #endif
                 hipLaunchKernelGGL((k_mix_decimate50<1>), grid, blk, lds, s, b);
             }

@@ -60,8 +60,11 @@ class Regs:
 EXP = ""      # experiment variants (tools/ab_variants.sh): timing only, results are garbage
 
 
-def tap_fma(R, q, row):
+def tap_fma(R, q, row, init=False):
     b = TAPSET[row % 4] + (q & ~1)
+    if init:                                                  # first sample of a tile: acc = w * z (no zeroing of the accumulators)
+        sel = "op_sel:[1,0] op_sel_hi:[1,1]" if q & 1 else "op_sel_hi:[0,1]"
+        return f"v_pk_mul_f32 {R.acc[q]}, s[{b}:{b + 1}], {R.Z} {sel}"
     sel = "op_sel:[1,0,0] op_sel_hi:[1,1,1]" if q & 1 else "op_sel_hi:[0,1,1]"
     return f"v_pk_fma_f32 {R.acc[q]}, s[{b}:{b + 1}], {R.Z}, {R.acc[q]} {sel}"
 
@@ -77,49 +80,57 @@ def loads_after_wait(R, p):
     return out
 
 
-def block(R, r):
+def block(R, r, init=False):
     s1 = r <= D - 1
     s2 = r >= 1
     e, o = r & 1, (r - 1) & 1
     raw = R.RAWC[(r >> 1) & 1][r & 1] if s1 else None
-    L = []
-    if s1: L.append(f"v_cvt_f32_f64 {R.TP}, {R.T}")
-    if s2: L.append(f"v_pk_mul_f32 {R.TT}, {R.U[o]}, {R.CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]")
-    if s1: L.append(f"v_add_f64 {R.T}, {R.T}, {R.f0}")
-    if s1: L.append(f"v_fract_f32 {R.TP}, {R.TP}")
-    if s2: L.append(f"v_pk_fma_f32 {R.Z}, {R.U[o]}, {R.CS[o]}, {R.TT} op_sel_hi:[0,1,1]")
-    if s1: L.append(f"v_cvt_f32_i32_sdwa {R.XR}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0")
-    if s1: L.append(f"v_cos_f32 {R.C[e]}, {R.TP}")
-    if s2: L.append(tap_fma(R, 0, r - 1))
-    if s1: L.append(f"v_cvt_f32_i32_sdwa {R.XI}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
-    if s1: L.append(f"v_sin_f32 {R.S[e]}, {R.TP}")
-    if s2: L.append(tap_fma(R, 1, r - 1))
-    if s2: L.append(tap_fma(R, 2, r - 1))
-    if s1: L.append(f"v_pk_fma_f32 {R.dcs}, {R.X}, {R.msk}, {R.dcs}" if R.msk else f"v_pk_add_f32 {R.dcs}, {R.X}, {R.dcs}")
-    if s2: L.append(tap_fma(R, 3, r - 1))
-    if s1: L.append(f"v_pk_add_f32 {R.U[e]}, {R.X}, {R.navg}")
+    I = {}                                                    # the instructions of the block by name
+    if s1:
+        I["cvt64"] = f"v_cvt_f32_f64 {R.TP}, {R.T}"
+        I["add64"] = f"v_add_f64 {R.T}, {R.T}, {R.f0}"
+        I["fract"] = f"v_fract_f32 {R.TP}, {R.TP}"
+        I["xr"] = f"v_cvt_f32_i32_sdwa {R.XR}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
+        I["xi"] = f"v_cvt_f32_i32_sdwa {R.XI}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+        I["cos"] = f"v_cos_f32 {R.C[e]}, {R.TP}"
+        I["sin"] = f"v_sin_f32 {R.S[e]}, {R.TP}"
+        I["dcs"] = f"v_pk_fma_f32 {R.dcs}, {R.X}, {R.msk}, {R.dcs}" if R.msk else f"v_pk_add_f32 {R.dcs}, {R.X}, {R.dcs}"
+        if init and r == 0: I["dcs"] = f"v_mov_b64 {R.dcs}, {R.X}"
+        I["u"] = f"v_pk_add_f32 {R.U[e]}, {R.X}, {R.navg}"
     if s2:
-        for q in range(4, Q): L.append(tap_fma(R, q, r - 1))
+        I["tt"] = f"v_pk_mul_f32 {R.TT}, {R.U[o]}, {R.CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        I["z"] = f"v_pk_fma_f32 {R.Z}, {R.U[o]}, {R.CS[o]}, {R.TT} op_sel_hi:[0,1,1]"
+        for q in range(Q): I[f"a{q}"] = tap_fma(R, q, r - 1, init and r == 1)
+    order = "cvt64 tt add64 fract z xr cos a0 xi sin a1 a2 dcs a3 u a4 a5 a6"
+    if "schedA" in EXP: order = "cvt64 tt add64 z fract xr cos a0 a1 xi a2 sin a3 dcs a4 u a5 a6"
+    if "schedB" in EXP: order = "cvt64 tt add64 fract z xr xi cos sin a0 a1 a2 dcs a3 u a4 a5 a6"
+    if "schedC" in EXP: order = "cvt64 tt xr z fract a0 cos xi a1 add64 a2 sin a3 dcs a4 u a5 a6"
+    if "nodc" in EXP: order = order.replace(" dcs", "").replace(" u ", " ")
+    if "nocmul" in EXP: order = order.replace(" tt ", " ").replace(" z ", " ")
+    L = [I[k] for k in order.split() if k in I]
     if "nosincos" in EXP:
         L = [l.replace("v_cos_f32", "v_mov_b32").replace("v_sin_f32", "v_mov_b32") for l in L]
     if "nof64" in EXP:
         L = [l for l in L if not l.startswith("v_add_f64")]
         L = [f"v_mov_b32 {R.TP}, {R.XR}" if l.startswith("v_cvt_f32_f64") else l for l in L]
     if "nofir" in EXP:
-        L = [l for l in L if not any(l.startswith(f"v_pk_fma_f32 {R.acc[q]},") for q in range(1, Q))]
+        L = [l for l in L if not any(l.startswith(f"v_pk_fma_f32 {R.acc[q]},") or l.startswith(f"v_pk_mul_f32 {R.acc[q]},") for q in range(1, Q))]
     return L
 
 
-def walk(R):
-    """the 50 samples of one tile; ends with every LDS / SMEM access complete"""
+def walk(R, init=False, hook=()):
+    """the 50 samples of one tile; ends with every LDS / SMEM access complete.  init: the accumulators and the DC sum start
+    from the first sample instead of from their old values.  hook: instructions placed behind the first wait (by then every
+    LDS operation issued before the walk has completed as well)"""
     if "empty" in EXP:
-        return ["s_waitcnt lgkmcnt(0)"]
+        return ["s_waitcnt lgkmcnt(0)"] + list(hook)
     L = [f"ds_read_b64 {R.RAW[0]}, {R.row}", f"s_load_dwordx8 s[{TAPSET[0]}:{TAPSET[0] + 7}], {R.wt}, 0x0"]
     for r in range(D + 1):
         if r % 2 == 0:
             L.append("s_waitcnt lgkmcnt(0)")
             L += loads_after_wait(R, r // 2)
-        L += block(R, r)
+            if r == 0: L += list(hook)
+        L += block(R, r, init)
     if "noloads" in EXP:
         L = [l for l in L if not (l.startswith("ds_read") or l.startswith("s_load") or l.startswith("s_waitcnt"))]
     return L
@@ -164,36 +175,37 @@ def park(st):
     return L
 
 
-def tile():
-    R = Regs(SCR, ACC, pair(DCS), pair(TREG), "%[row]", "%[f0]", "%[navg]", "%[wt]")
-    L = [f"v_mov_b64 {a}, 0" for a in ACC] + [f"v_mov_b64 {pair(DCS)}, 0",
-         f"v_cvt_f64_u32 {pair(TREG)}, %[rown]", f"v_mul_f64 {pair(TREG)}, {pair(TREG)}, %[f0]"]
-    L += walk(R)
-    Rq = [SCR + 2 * q for q in range(H)]                       # rotated columns
-    Y, T1, A, B = SCR + 12, SCR + 14, SCR + 15, SCR + 16
-    # table row of the lane's block in the next tile: rown = (rown + 64 D) mod L
-    L += [f"v_add_u32 %[rown], %[step], %[rown]", f"v_subrev_u32 v{T1}, %[L], %[rown]", f"v_min_u32 %[rown], v{T1}, %[rown]"]
-    L += [f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}"]
-    # y[j] = P[j][H] + sum_{q<H} P[j-(H-q)][q]: rotate column q down by k = H-q lanes (bpermute address 4*lane + 256 - 4k)
+def diag_issue(rb):
+    """rotations of the P columns into v[rb..rb+11], y = P[.][H] + carry into v[rb+12:rb+13], byte offset of the lane's output in the
+    ring into v[rb+14]; the carry restarts from zero.  y[j] = P[j][H] + sum_{q<H} P[j-(H-q)][q]: column q goes down by k = H-q lanes
+    (bpermute address 4*lane + 256 - 4k; the LDS unit reads the source registers when the instruction issues)"""
+    L = []
     for q in range(H):
         k = H - q
-        L += [f"ds_bpermute_b32 v{Rq[q]}, %[lane4], v{ACC0 + 2 * q} offset:{256 - 4 * k}",
-              f"ds_bpermute_b32 v{Rq[q] + 1}, %[lane4], v{ACC0 + 2 * q + 1} offset:{256 - 4 * k}"]
+        L += [f"ds_bpermute_b32 v{rb + 2 * q}, %[lane4], v{ACC0 + 2 * q} offset:{256 - 4 * k}",
+              f"ds_bpermute_b32 v{rb + 2 * q + 1}, %[lane4], v{ACC0 + 2 * q + 1} offset:{256 - 4 * k}"]
+    Y, T1 = rb + 12, rb + 14
     L += [f"v_pk_add_f32 {pair(Y)}, {ACC[H]}, {pair(CARRY)}", f"v_mov_b64 {pair(CARRY)}, 0",
           f"v_lshrrev_b32 v{T1}, 2, %[lane4]", f"v_add_u32 v{T1}, s{S_JM}, v{T1}", f"v_and_b32 v{T1}, %[rmask], v{T1}",
-          f"v_lshlrev_b32 v{T1}, 3, v{T1}",
-          f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}",
-          "s_mov_b64 exec, -1", "s_waitcnt lgkmcnt(0)"]
-    for q in range(H):                                         # lanes >= k: a row of this tile -> its term of y
-        L += [f"s_mov_b32 exec_lo, 0x{(0xffffffff << (H - q)) & 0xffffffff:x}", f"v_pk_add_f32 {pair(Y)}, {pair(Y)}, {pair(Rq[q])}"]
-    for q in range(H):                                         # lanes < k: rows 64-k+l of this tile -> the next tile's carry
-        L += [f"s_mov_b64 exec, {(1 << (H - q)) - 1}", f"v_pk_add_f32 {pair(CARRY)}, {pair(CARRY)}, {pair(Rq[q])}"]
+          f"v_lshlrev_b32 v{T1}, 3, v{T1}", f"s_add_i32 s{S_JM}, s{S_JM}, 64"]
+    return L
+
+
+def diag_finish(rb):
+    """(after lgkmcnt(0)) lanes >= k hold a row of the same tile -> its term of y; lanes < k hold rows 64-k+l -> the next tile's carry"""
+    Y, T1, L = rb + 12, rb + 14, []
+    for q in range(H):
+        L += [f"s_mov_b32 exec_lo, 0x{(0xffffffff << (H - q)) & 0xffffffff:x}", f"v_pk_add_f32 {pair(Y)}, {pair(Y)}, {pair(rb + 2 * q)}"]
+    for q in range(H):
+        L += [f"s_mov_b64 exec, {(1 << (H - q)) - 1}", f"v_pk_add_f32 {pair(CARRY)}, {pair(CARRY)}, {pair(rb + 2 * q)}"]
     L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
-          "s_mov_b64 exec, -1", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], -1", f"s_add_i32 s{S_JM}, s{S_JM}, 64"]
+          "s_mov_b64 exec, -1", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], -1"]
     return L
 
 
 def gen_loop():
+    R = Regs(SCR, ACC, pair(DCS), pair(TREG), "%[row]", "%[f0]", "%[navg]", "%[wt]")
+    T1, A, B = SCR + 14, SCR + 15, SCR + 16
     L = [f"s_mov_b64 s[{S_TB}:{S_TB + 1}], %[tb]", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[outmask]", f"s_mov_b32 s{S_JM}, %[jm]",
          f"s_mov_b32 s{S_T}, 0", f"v_mov_b64 {pair(CARRY)}, %[carry]"]
     # tile 0 -> LDS (the wave's only exposed load latency); tile 1 on its way
@@ -202,18 +214,29 @@ def gen_loop():
     L += fetch(STAGE[1])
     L += ["s_waitcnt vmcnt(13)", "s_branch 11f", "10:", "s_waitcnt vmcnt(0)", "11:"]
     L += park(STAGE[0])
-    for half in (0, 1):                                        # tile t even: fetch t+2 -> set 0, park t+1 from set 1; odd: swapped
-        lab = 20 + 10 * half
-        L += [f"{lab}:", f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 1}f"]
-        L += fetch(STAGE[half])
-        L += [f"{lab + 1}:"]
-        L += tile()
+    # Tile t lives in staging set t & 1 until it is parked.  Half h of the loop walks a tile with t & 1 == h: set h has just been
+    # parked, so its registers take the rotated columns of the PREVIOUS tile; those sums and the store of its outputs sit behind
+    # the walk's first wait (one LDS round trip per tile instead of three), then tile t+2 is requested into set h.
+    for h in (0, 1):
+        lab = 20 + 10 * h
+        hook = [f"s_cmp_eq_u32 s{S_T}, 0", f"s_cbranch_scc1 {lab + 1}f"] + diag_finish(STAGE[h]) + [f"{lab + 1}:"]
+        hook += [f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f"]
+        hook += fetch(STAGE[h]) + [f"{lab + 2}:"]
+        L += [f"{lab}:", f"v_cvt_f64_u32 {pair(TREG)}, %[rown]", f"v_mul_f64 {pair(TREG)}, {pair(TREG)}, %[f0]"]
+        L += walk(R, init=True, hook=hook)
+        # table row of the lane's block in the next tile: rown = (rown + 64 D) mod L; IQ-DC sums of the rows that count
+        L += [f"v_add_u32 %[rown], %[step], %[rown]", f"v_subrev_u32 v{T1}, %[L], %[rown]", f"v_min_u32 %[rown], v{T1}, %[rown]",
+              f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
+              f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1"]
         L += [f"s_add_i32 s{S_T}, s{S_T}, 1", f"s_cmp_ge_i32 s{S_T}, %[nfull]", "s_cbranch_scc1 90f"]
-        # the loads of tile t+1 are followed by its predecessor's store, 13 loads of tile t+2 (if issued) and this tile's store
-        L += [f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f",
-              "s_waitcnt vmcnt(14)", f"s_branch {lab + 3}f", f"{lab + 2}:", "s_waitcnt vmcnt(0)", f"{lab + 3}:"]
-        L += park(STAGE[1 - half])
+        # tile t+1: its loads are followed by 13 loads of tile t+2 (if requested) — and by the store of tile t-1, which is older than those
+        L += [f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 3}f",
+              "s_waitcnt vmcnt(13)", f"s_branch {lab + 4}f", f"{lab + 3}:", "s_waitcnt vmcnt(0)", f"{lab + 4}:"]
+        L += park(STAGE[1 - h])
+        L += diag_issue(STAGE[1 - h])
     L += ["s_branch 20b", "90:"]
+    # the wave's last full tile: nothing follows, the walk's scratch registers take the rotations
+    L += diag_issue(SCR) + ["s_waitcnt lgkmcnt(0)"] + diag_finish(SCR)
     L += [f"v_mov_b64 %[o{q}], {ACC[q]}" for q in range(Q)] + [f"v_mov_b64 %[carry], {pair(CARRY)}", "s_nop 1"]
     return L
 

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_stride(const uint4 *p, size_t n16, uint
 
 // (b) the decimator's pattern: channel -> XCD, 4 waves per WG, each wave walks `tiles` tiles of 12800 bytes (13 x 16 B per lane,
 // the last load only in the low lanes), next tile in flight while the current one is "used"
-template <bool NT, int DEPTH, bool PARK = false, bool HALO = false, bool STORE = false>
+template <bool NT, int DEPTH, bool PARK = false, bool HALO = false, int STORE = 0>
 __global__ __launch_bounds__(256) void k_tiles(const uint32_t *base, long long ch_stride_dw, int n_ch, int wgs_per_ch, int tiles, int n_waves, uint32_t *out, float2 *y = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
@@ -45,7 +45,12 @@ __global__ __launch_bounds__(256) void k_tiles(const uint32_t *base, long long c
 #pragma unroll
         for (int s = 0; s < DEPTH; s++) {
             if (t + s + DEPTH - 1 < tiles) fetch(t + s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
-            if (STORE) y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)] = make_float2((float)acc, 1.f);
+            if (STORE == 1) y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)] = make_float2((float)acc, 1.f);
+            if (STORE == 2) { float2 *q = &y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)]; __builtin_nontemporal_store((float)acc, &q->x); __builtin_nontemporal_store(1.f, &q->y); }
+            if (STORE == 3 && ((t + s) & 3) == 3) {          // four tiles' outputs at once: 2 KB per wave
+                float4 *q = reinterpret_cast<float4 *>(&y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s - 3) * 64) & 131071)]);
+                q[lane] = make_float4((float)acc, 1.f, 2.f, 3.f); q[64 + lane] = make_float4((float)acc, 1.f, 2.f, 3.f);
+            }
             if (PARK) {
 #pragma unroll
                 for (int v = 0; v < 13; v++) { if (v < 12 || lane < 32) *reinterpret_cast<uint4 *>(sRaw + 256 * v + 4 * lane) = make_uint4(buf[s][v].x, buf[s][v].y, buf[s][v].z, buf[s][v].w); }
@@ -95,8 +100,10 @@ int main() {
     }
     float2 *y; (void)hipMalloc(&y, (size_t)C * 131072 * 8);
     timeit("12 waves/CU, nt, park, halo segments", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, true>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
-    timeit("12 waves/CU, nt, park, stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, true>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
-    timeit("12 waves/CU, nt, park, halo + stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, true, true>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
-    timeit("12 waves/CU, plain loads, park, halo + stores", [&] { hipLaunchKernelGGL((k_tiles<false, 2, true, true, true>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, nt, park, stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 1>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, nt, park, halo + stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, true, 1>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, plain loads, park, halo + stores", [&] { hipLaunchKernelGGL((k_tiles<false, 2, true, true, 1>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, nt, park, nt stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 2>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, nt, park, 2 KB stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 3>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
     return 0;
 }
