@@ -26,6 +26,11 @@ struct MixDecArgs {
     int DS;
     int phase_f64;            // mixer phase f0*n kept in double (dft_detect.c:1090) instead of the float of demod_mod.c:1290
     double nd_base;           // --noLUT: absolute index of the launch's first sample (phase = f0 * absolute index, no table period); else 0
+    // fast / fold mode (D = 50, Q = 7, float table phase, lut_len % D == 0): E[ch][etab_len] = the decimator's response to the bare mixer
+    // table, etab_len = lut_len / D.  Set for every launch of such an engine or for none: the P tail then holds sums without the IQ-DC term.
+    const float2 *etab; int etab_len;
+    const float2 *dc_avg_prev; // fold mode, launches within Q-1 blocks after a change of the IQ-DC mean: the mean before (md_dc_boundary); else nullptr
+    int dc_since;             // blocks between that change and this launch
 };
 
 // --dc (AFC) per-channel state: what find_header keeps in dsp.Df / dsp.locked / dsp.dc (demod_mod.c:1555-1600, 280-298)
@@ -122,6 +127,7 @@ struct SyncArgs {
 extern "C" {
 int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
+void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s);
 void sonde_launch_decimate_f32(const DecF32Args *a, hipStream_t s);

@@ -42,6 +42,7 @@ struct sonde_engine {
     bool eof_pending = false;          // an end-of-stream framesync ran after the last counter snapshot
     // design
     Decimator dec; int Q = 0, G = 8, DS = 0; float *d_wtab = nullptr;
+    float2 *d_etab = nullptr, *d_dcavg_prev = nullptr; int etab_len = 0; int dc_since = 1 << 20;      // fold mode of the decimator (MixDecArgs.etab)
     std::vector<float> w_iq, w_fm, match, wtab;
     float sps = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;
     int symlen = 1, symhd = 1, hdmax = 0, bitofs = 0, nbits = 0, hdrlen = 0;
@@ -297,6 +298,18 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
         if (dalloc(&e->d_chanf0, (size_t)C, false)) { delete e; return SONDE_E_NOMEM; }
         HIPCHK(hipMemcpy(e->d_chanf0, f0s.data(), f0s.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    // ---- 2.4 Msps -> 48 kHz class (D = 50, Q = 7, float table phase, rows aligned with the mixer table): the hand-scheduled
+    // decimator, which subtracts the IQ-DC mean per output as avg * E — E tabulated here, once (k_md_etable)
+    {
+        static const bool no_fast = getenv("SONDE_MD_NOFAST") != nullptr;       // A/B aid: the compiler-scheduled kernels
+        if (D == 50 && e->Q == 7 && !audio && cfg->bits != 32 && cfg->sonde_type != SONDE_FRONTEND && !cfg->opt_nolut && e->lut_len % D == 0 && !no_fast
+            && cfg->input == SONDE_IN_IQ) {
+            e->etab_len = e->lut_len / D;
+            if (dalloc(&e->d_etab, (size_t)C * e->etab_len, false) || dalloc(&e->d_dcavg_prev, C)) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+            sonde_launch_md_etable(e->d_chanf0, e->d_wtab, D, e->Q, e->etab_len, C, e->d_etab, nullptr);
+            HIPCHK(hipDeviceSynchronize());
+        }
+    }
     int bad = 0;
     bad |= dalloc(&e->d_dcavg, C); bad |= dalloc(&e->d_dcsums, 2 * (size_t)C);
     bad |= dalloc(&e->d_ptail[0], (size_t)C * 64); bad |= dalloc(&e->d_ptail[1], (size_t)C * 64);
@@ -431,7 +444,8 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
-                     e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending };
+                     e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
+                     e->d_etab, e->d_dcavg_prev };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -532,11 +546,15 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         if (e->cfg.opt_nolut) { a.phase_f64 = 1; a.lut_len = 1 << 30; a.lut_phase = 0; a.nd_base = (double)e->samples_in; }
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
         { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
+        a.etab = e->d_etab; a.etab_len = e->etab_len;
+        a.dc_avg_prev = (e->d_etab && e->dc_since < e->Q - 1) ? e->d_dcavg_prev : nullptr; a.dc_since = e->dc_since;
+        if (e->dc_since < (1 << 20)) e->dc_since += take / D;
         prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);
         if (lrc < 0) return SONDE_E_ARG;
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
         if (e->dc_cnt == e->dc_max) {
+            if (e->d_etab) { hipMemcpyAsync(e->d_dcavg_prev, e->d_dcavg, (size_t)C * sizeof(float2), hipMemcpyDeviceToDevice, e->stream); e->dc_since = 0; }
             sonde_launch_dc_update(C, e->d_dcsums, e->d_dcavg, (float)e->dc_max, e->stream);
             e->dc_cnt = 0;
             if (e->dc_max < e->dc_lim) e->dc_max *= 2;

@@ -122,31 +122,86 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
     if (r < D) md_step<Q_T, WRAP, PH64>(row[r], r, wa, navg, msk, f0, nd0, rown, towrap, L, acc, dcs);
 }
 
-// Hand-scheduled walk of one 64-row tile for D = 50, Q = 7 (tools/gen_md_fast.py has the schedule and the reasons).  Same
-// arithmetic per sample as md_step<7, false, false> except that the mixer phase advances by T += f0 in double from the exact
-// product f0*n of the row's first sample (<= 49 additions: the float rounding of t differs from fl32(f0*n) for about one
-// sample in 1e7, far inside the 1e-6 stream tolerance — tests/test_gpu_parity.py::test_streams_match_oracle).
-// row_lds: byte address of the lane's row in LDS; wt: [50][8] tap rows * 2^-15 in global memory (scalar loads);
-// navg: -32768 * avg (wave-uniform, SGPR pair).
+// Hand-scheduled walk of one 64-row tile for D = 50, Q = 7 (tools/gen_md_fast.py has the schedule and the reasons).  Differences
+// to md_step<7, false, false>:
+//   * the mixer phase advances by T += f0 in double from the exact product f0*n of the row's first sample (<= 49 additions: the
+//     float rounding of t differs from fl32(f0*n) for about one sample in 1e7, far inside the 1e-6 stream tolerance);
+//   * the IQ-DC mean is not subtracted per sample: P'[j][q] = sum_r W_q[r] x ex, and the caller subtracts avg * E[m] per OUTPUT
+//     (E = the filter's response to the bare mixer table, k_md_etable; md_dc_correct below).  The P tail between calls holds P'.
+// row_lds: byte address of the lane's row in LDS; wt: [50][8] tap rows * 2^-15 in global memory (scalar loads).
 #define MD_FAST_CLOBBERS "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
         "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
         "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
-        "v116", "v117", "v118", "memory"
+        "v116", "memory"
 #define MD_FAST_ASM(BODY) asm volatile(BODY \
         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]), \
           [a6] "+v"(acc[6]), [dcs] "+v"(dcs), [T] "+v"(T) \
-        : [row] "v"(row_lds), [f0] "s"(f0), [msk] "v"(msk), [navg] "s"(navg), [wt] "s"(wt) \
+        : [row] "v"(row_lds), [f0] "s"(f0), [msk] "v"(msk), [wt] "s"(wt) \
         : MD_FAST_CLOBBERS)
-template <int VAR>
-__device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, uint64_t navg, float2v msk,
-                                             float2v (&acc)[7], float2v &dcs) {
-    if constexpr (VAR == 1) { MD_FAST_ASM(MD_FAST_BODY_1); }
+__device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, float2v msk, float2v (&acc)[7], float2v &dcs) {
+    MD_FAST_ASM(MD_FAST_BODY_1);
 }
-// -32768 * avg as an SGPR pair (avg is per channel, i.e. wave-uniform)
+// y -= avg * E (complex)
+__device__ __forceinline__ float2v md_dc_correct(float2v y, float2 avg, float2 E) {
+    y.x = fmaf(-avg.x, E.x, y.x); y.y = fmaf(-avg.x, E.y, y.y);
+    y.x = fmaf(avg.y, E.y, y.x);  y.y = fmaf(-avg.y, E.x, y.y);
+    return y;
+}
+// -avg as an SGPR pair (avg is per channel, i.e. wave-uniform)
 __device__ __forceinline__ uint64_t md_navg_sgpr(float2 avg) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(__float_as_uint(-32768.f * avg.x));
-    const uint32_t hi = __builtin_amdgcn_readfirstlane(__float_as_uint(-32768.f * avg.y));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(__float_as_uint(-avg.x));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(__float_as_uint(-avg.y));
     return ((uint64_t)hi << 32) | lo;
+}
+
+// mixer phasor of table index n as the decimator evaluates it: ex[n] = cexp(2 pi i fl32(f0 n))  (demod_mod.c:1290-1295)
+__device__ __forceinline__ float2 md_phasor(double f0, uint32_t n) {
+    const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
+    return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
+}
+// k_md_etable: E[ch][i] = sum_{q<Q} sum_{r<D} W_q[r] ex[D ((i-(Q-1)+q) mod P) + r], i < P = lut_len / D: the decimator's output for
+// the input x = 1 when the block that completes the output is block i of the mixer table's period.  Once per engine.
+__global__ __launch_bounds__(256)
+void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, float2 *etab) {
+    const int ch = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const double f0 = chan_f0[ch];
+    float er = 0.f, ei = 0.f;
+    for (int q = 0; q < Q; q++) {
+        const uint32_t n0 = (uint32_t)D * (uint32_t)((i - (Q - 1) + q + P) % P);
+        for (int r = 0; r < D; r++) {
+            const float2 e = md_phasor(f0, n0 + (uint32_t)r);
+            const float w = wtab[8 * r + q];
+            er = fmaf(w, e.x, er); ei = fmaf(w, e.y, ei);
+        }
+    }
+    etab[(size_t)ch * P + i] = make_float2(er, ei);
+}
+// The launch that follows a change of the IQ-DC mean (avg_old -> avg_new) subtracts avg_new * E from all of its outputs, but the
+// blocks BEFORE the launch — which reach into its first Q-1 outputs — were mixed while avg_old was in effect (demod_mod.c:495-504:
+// the mean changes at a sample).  Output j < Q-1 of the launch therefore gets  + (avg_new - avg_old) * S_j,
+// S_j = sum over q with j-(Q-1-q) < 0 of G_q[block j-(Q-1-q)],  G_q[b] = sum_r W_q[r] ex[D b + r]  (complex product).
+// Evaluated by the first Q-1 lanes of the wave that owns the launch's first rows; a.dc_avg_prev == nullptr: no change within reach.
+// (A launch shorter than Q-1 blocks leaves part of that reach to the next one: dc_since.)
+__device__ __forceinline__ float2v md_dc_boundary(const MixDecArgs &a, int ch, double f0, int j) {
+    float2v t = {0.f, 0.f};
+    if (a.dc_avg_prev && j < a.Q - 1 - a.dc_since) {          // dc_since: blocks between the change of the mean and this launch
+        const int H = a.Q - 1, P = a.etab_len;
+        const int i0 = (int)((a.lut_phase / (uint32_t)a.D) % (uint32_t)P);
+        float sr = 0.f, si = 0.f;
+        for (int q = 0; q < H - j - a.dc_since; q++) {        // block b = j - (H - q) of the launch lies before the change
+            const uint32_t n0 = (uint32_t)a.D * (uint32_t)((i0 + j - (H - q) + P) % P);
+            for (int r = 0; r < a.D; r++) {
+                const float2 e = md_phasor(f0, n0 + (uint32_t)r);
+                const float w = a.wtab_g[8 * r + q];
+                sr = fmaf(w, e.x, sr); si = fmaf(w, e.y, si);
+            }
+        }
+        const float2 an = a.dc_avg[ch], ao = a.dc_avg_prev[ch];
+        const float dx = an.x - ao.x, dy = an.y - ao.y;
+        t = (float2v){dx * sr - dy * si, dx * si + dy * sr};
+    }
+    return t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,7 +214,7 @@ __device__ __forceinline__ uint64_t md_navg_sgpr(float2 avg) {
 //     loads whose address is an SGPR base + one lane offset (no address arithmetic per tile), waited for with vmcnt counts;
 //   * the previous tile's contribution to the first Q-1 outputs of a tile is ONE carry value per lane (the rotation that
 //     forms the diagonal sum delivers both this tile's terms and the next tile's carry) instead of a copy of all P rows;
-//   * -32768*avg and the mixer frequency are SGPRs, the 2^-15 of the int16 scale sits in the tap table.
+//   * the IQ-DC mean is subtracted per output (avg * E, see md_fast_tile); the 2^-15 of the int16 scale sits in the tap table.
 // That only fits 3 waves per SIMD (168 VGPRs) with every register placed by hand, so a wave's whole run of full tiles is ONE
 // generated statement (MD50_LOOP_*, tools/gen_md_fast.py); C++ does the set-up, a tile that sticks out of the chunk, the P tail
 // and the IQ-DC sums.  Requires nblocks even (every 16-byte piece of a tile is then either inside or outside the chunk) and
@@ -174,10 +229,10 @@ __device__ __forceinline__ uint64_t md_navg_sgpr(float2 avg) {
         MD50_V10(11), MD50_V10(12), MD50_V10(13), MD50_V10(14), MD50_V10(15), "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
 #define MD50_ASM(BODY) asm volatile(BODY \
         : [o0] "=v"(acc[0]), [o1] "=v"(acc[1]), [o2] "=v"(acc[2]), [o3] "=v"(acc[3]), [o4] "=v"(acc[4]), [o5] "=v"(acc[5]), [o6] "=v"(acc[6]), \
-          [carry] "+v"(carry), [rown] "+v"(rown), [sx] "+v"(sx), [sy] "+v"(sy) \
+          [carry] "+v"(carry), [e] "+v"(eidx), [sx] "+v"(sx), [sy] "+v"(sy) \
         : [row] "v"(row_lds), [voff16] "v"(voff16), [voff8] "v"(voff8), [ldsw16] "v"(ldsw16), [ldsw8] "v"(ldsw8), [lane4] "v"(lane4), \
-          [tb] "s"(tb), [f0] "s"(f0), [navg] "s"(navg), [wt] "s"(wt_s), [yout] "s"(yout), [jm] "s"(jm), [rmask] "s"(rmask), [L] "s"(L), \
-          [step] "s"(step), [nfull] "s"(nfull), [outmask] "s"(outmask) \
+          [tb] "s"(tb), [f0] "s"(f0), [navg] "s"(navg), [wt] "s"(wt_s), [yout] "s"(yout), [jm] "s"(jm), [rmask] "s"(rmask), [P] "s"(P), \
+          [etab] "s"(etab), [nfull] "s"(nfull), [outmask] "s"(outmask) \
         : MD50_CLOBBERS)
 
 template <int VAR>
@@ -209,10 +264,11 @@ void k_mix_decimate50(const MixDecArgs a) {
     const float2 avg = a.dc_avg[ch];
     const uint64_t navg = md_navg_sgpr(avg);
     const double f0 = a.chan_f0[ch];
-    const uint32_t L = (uint32_t)a.lut_len;
     float2 *yout = a.y + (size_t)ch * a.ring_len;
     const float *wt_s = a.wtab_g + 64 * 8;                     // tap rows * 2^-15
     const uint32_t rmask = (uint32_t)a.ring_len - 1;
+    const uint32_t P = (uint32_t)a.etab_len;                   // blocks per period of the mixer table
+    const float2 *etab = a.etab + (size_t)ch * P;
 
     // carry: what the P rows before this tile add to its first H outputs (lane l < H: sum over q of P[l-(H-q)][q], rows < 0)
     float2v carry = {0.f, 0.f};
@@ -223,9 +279,10 @@ void k_mix_decimate50(const MixDecArgs a) {
             if (i < H) { const float2 v = a.ptail_in[((size_t)ch * 8 + i) * 8 + q]; carry += (float2v){v.x, v.y}; }
         }
     }
+    if (seg == 0 && lane < H) carry += md_dc_boundary(a, ch, f0, lane);
     int sx = 0, sy = 0;
-    const uint32_t step = (uint32_t)(((uint64_t)MD_ROWS * (uint64_t)D) % L);
-    uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)(jt0 + lane) * (uint64_t)D) % L);
+    // the lane's block as an index into the period of the mixer table (table index = D * eidx): phase seed and E index
+    uint32_t eidx = (uint32_t)(((uint64_t)(a.lut_phase / D) + (uint64_t)(jt0 + lane)) % P);
     float2v acc[Q_T];
 
     if (nfull > 0) {
@@ -267,7 +324,7 @@ void k_mix_decimate50(const MixDecArgs a) {
         for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
         float2v dcs = {0.f, 0.f};
         const float m = outrow ? 1.f : 0.f;
-        md_fast_tile<1>(row_lds, wt_s, f0, f0 * (double)rown, navg, (float2v){m, m}, acc, dcs);
+        md_fast_tile(row_lds, wt_s, f0, f0 * (double)(eidx * (uint32_t)D), (float2v){m, m}, acc, dcs);
         sx += (int)dcs.x; sy += (int)dcs.y;
         float2v y = acc[H] + carry;
 #pragma unroll
@@ -276,6 +333,7 @@ void k_mix_decimate50(const MixDecArgs a) {
             const float2v r = { __shfl(acc[q].x, src), __shfl(acc[q].y, src) };
             if (lane >= k) y += r;
         }
+        y = md_dc_correct(y, avg, etab[eidx]);
         if (outrow) yout[(a.m0 + (uint32_t)j) & rmask] = make_float2(y.x, y.y);
         if (j >= a.nblocks - H && j < a.nblocks) {
 #pragma unroll
@@ -399,13 +457,13 @@ void k_mix_decimate(const MixDecArgs a) {
         float2v dcs = {0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool nowrap = __builtin_amdgcn_ballot_w64(L - rown < (uint32_t)D) == 0;     // wave-uniform
-        if constexpr (FAST > 0) {
-            if (nowrap) {
-                const float m = outrow ? 1.f : 0.f;
-                md_fast_tile<1>(row_lds, a.wtab_g + 64 * 8, f0, f0 * (double)rown, md_navg_sgpr(avg), (float2v){m, m}, acc, dcs);
-            }
-        } else if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
-        if (!nowrap) md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+        if constexpr (FAST > 0) {                             // rows are aligned with the mixer table here (launcher): none wraps
+            const float m = outrow ? 1.f : 0.f;
+            md_fast_tile(row_lds, a.wtab_g + 64 * 8, f0, f0 * (double)rown, (float2v){m, m}, acc, dcs);
+        } else {
+            if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+            else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+        }
         sx += (int)dcs.x; sy += (int)dcs.y;
 
         // y[j] = sum_q P[j-(H-q)][q]: shift column q down by H-q lanes, the first lanes take the previous tile's rows
@@ -418,6 +476,13 @@ void k_mix_decimate(const MixDecArgs a) {
             const bool old = lane >= MD_ROWS - k;
             yr += __shfl(old ? pv[q].x : acc[q].x, src);
             yi += __shfl(old ? pv[q].y : acc[q].y, src);
+        }
+        if constexpr (FAST > 0) {                             // the IQ-DC mean, per output: y -= avg * E (md_fast_tile)
+            if (outrow) {
+                float2v yc = md_dc_correct((float2v){yr, yi}, avg, a.etab[(size_t)ch * a.etab_len + (rown / (uint32_t)D)]);
+                if (j < H) yc += md_dc_boundary(a, ch, f0, j);
+                yr = yc.x; yi = yc.y;
+            }
         }
         if (outrow) yout[(a.m0 + (uint32_t)j) & (uint32_t)(a.ring_len - 1)] = make_float2(yr, yi);
         if (j >= a.nblocks - H && j < a.nblocks) {            // P rows of the last Q-1 blocks go to the next call
@@ -1366,11 +1431,11 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
                          else hipLaunchKernelGGL((k_mix_decimate<QT, false, 0, 0>), grid, blk, lds, s, b); } while (0)
     static const bool no_dt = getenv("SONDE_NO_DT") != nullptr;      // debugging aid: force the runtime-D variant
     if (a->Q == 7 && a->D == 50 && !no_dt) {            // 2.4 Msps -> 48 kHz: decimation known at compile time
-        static const bool no_fast = getenv("SONDE_MD_NOFAST") != nullptr;     // A/B aids: the compiler-scheduled sample loop,
-        static const bool no_k50 = getenv("SONDE_MD_NO50") != nullptr;        // the one-tile-in-flight kernel around the asm loop
-        if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, 0>), grid, blk, lds, s, b);
-        else if (a->wtab_g && a->nd_base == 0.0 && !no_fast) {
-            if (a->nblocks >= 64 && a->nblocks % 2 == 0 && a->lut_len % 50 == 0 && a->lut_phase % 50 == 0 && !no_k50) {
+        // fast / fold mode is a property of the ENGINE (a->etab set): the P tail between calls then holds sums without the IQ-DC
+        // term, so every launch of such an engine goes through one of the two kernels that subtract avg * E per output
+        static const bool no_k50 = getenv("SONDE_MD_NO50") != nullptr;        // A/B aid: the kernel with one tile in flight
+        if (a->etab && !a->phase_f64 && a->nd_base == 0.0 && a->lut_phase % 50 == 0) {
+            if (a->nblocks >= 64 && a->nblocks % 2 == 0 && !no_k50) {
                 static const int var = getenv("SONDE_MD_VARIANT") ? atoi(getenv("SONDE_MD_VARIANT")) : 1;
 #ifdef MD50_LOOP_2
                 if (var == 2) { hipLaunchKernelGGL((k_mix_decimate50<2>), grid, blk, lds, s, b); return 0; }
@@ -1384,10 +1449,13 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
 #ifdef MD50_LOOP_5
                 if (var == 5) { hipLaunchKernelGGL((k_mix_decimate50<5>), grid, blk, lds, s, b); return 0; }
 #endif
+                (void)var;
                 hipLaunchKernelGGL((k_mix_decimate50<1>), grid, blk, lds, s, b);
             }
             else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, 1>), grid, blk, lds, s, b);
         }
+        else if (a->etab) return -1;                          // a fold-mode engine must never fall back to sums with the IQ-DC term
+        else if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, 0>), grid, blk, lds, s, b);
         else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, 0>), grid, blk, lds, s, b);
         return 0;
     }
@@ -1406,6 +1474,9 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
+}
+extern "C" void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s) {
+    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab);
 }
 extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s) {
     int gx = (n_bytes / 4 + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;

@@ -83,6 +83,37 @@ def test_streams_match_oracle(oracle, name):
     eng.close()
 
 
+@pytest.mark.parametrize("chunk", [2_400_000, 240_000, 75_050, 90_100])
+def test_iq_dc_offset_streams_match_oracle(oracle, chunk):
+    """A strong IQ-DC offset (the decimator subtracts the running mean per OUTPUT as avg * E, k_md_etable / md_dc_boundary, instead of
+    per sample): the IF-rate streams still match the reference's to 1e-6 across every change of the mean (segments of 75000 * 2^k
+    samples, demod_mod.c:495-504) and for every way the calls cut the stream — whole seconds (one launch per segment, two tiles in
+    flight), 0.1 s blocks, and odd block counts (the single-tile kernel) whose call edges fall between the segment edges."""
+    from radiosonde_auto_rx_amd import engine as E
+    x, fq, sr = capture("rs41_2400k_clean")
+    x = x.astype(np.int32)
+    x[0::2] += 2100
+    x[1::2] -= 1300
+    x = np.clip(x, -32768, 32767).astype(np.int16)
+    eng = _engine([fq], sr, max_chunk=sr)
+    D = eng.info["decM"]
+    n = min((len(x) // 2 // D) * D, sr)
+    pos = 0
+    while pos < n:
+        take = min(chunk, n - pos)
+        take -= take % D
+        eng.process_host(x[2 * pos:2 * (pos + take)])
+        pos += take
+    nif = n // D
+    s = oracle.ora_streams(x[:2 * n], sr, fq=fq)
+    iq = eng.read_tap(0, E.TAP_IFIQ, 0, nif)
+    bufs = eng.read_tap(0, E.TAP_BUFS, 0, nif)
+    assert rms(iq - s["iq"]) < 1e-6
+    assert float(np.max(np.abs(iq - s["iq"]))) < 2e-5          # no outlier at a segment edge
+    assert rms(bufs - s["bufs"]) < 1e-5
+    eng.close()
+
+
 def test_chunking_invariance(oracle):
     """Any chunking of the stream (down to one decM block per DC segment edge) gives the same frames."""
     x, fq, sr = capture("rs41_480k_clean")

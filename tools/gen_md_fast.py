@@ -22,10 +22,14 @@ Why generated streams and not C++:
     loads it cannot see — copied staging registers before their data had landed).
 
 Per sample r (reference: demod_mod.c:484-493 IQ-DC, :737-750 mixer, :639-648/753 FIR):
-  S1(r): x = cvt(raw); dcs += x; u = x - 32768*avg; t = fl32(T); T += f0; (c, s) = cos/sin(2 pi fract(t))
-  S2(r): z = u * (c + i s); acc[q] += (2^-15 W_q[r]) * z, q = 0..6
-(the 2^-15 of x = b/32768 sits in the tap table: scaling by a power of two commutes with every rounding, so the sums are
-bit-identical to (x/32768 - avg) * ex * W, and -32768*avg is wave-uniform -> one SGPR pair, no VGPRs for scale / avg)
+  S1(r): x = cvt(raw); dcs += x; t = fl32(T); T += f0; (c, s) = cos/sin(2 pi fract(t))
+  S2(r): z = x * (c + i s); acc[q] += (2^-15 W_q[r]) * z, q = 0..6
+The 2^-15 of x = b/32768 sits in the tap table (scaling by a power of two commutes with every rounding).  The IQ-DC mean is
+NOT subtracted per sample: the filter is linear, so y = sum W (x - avg) ex = sum W x ex - avg * E, where E[m] = sum_k w[k] ex[.]
+is the filter's response to the bare mixer table — it depends on the channel's frequency only, has the table's period
+(lut_len / D outputs) and is tabulated once per engine (k_md_etable); one complex multiply per OUTPUT replaces one packed
+add per INPUT sample.  (avg is constant within a launch; the few outputs whose window straddles a change of avg between two
+launches are corrected by md_dc_boundary.)  The difference to subtracting per sample is rounding noise of the order 1e-8.
 Block B_r = S2(r-1) interleaved with S1(r), r = 0..D.  Before every even block: s_waitcnt lgkmcnt(0), then the loads
 for the blocks after the next wait (raw pair p+1, tap rows 2p+1 and 2p+2).  Four tap-row register sets, two raw pairs.
 """
@@ -43,18 +47,19 @@ def pair(n):
 
 
 class Regs:
-    """Register names of one instance of the sample walk.  v0 = first of 19 scratch VGPRs."""
+    """Register names of one instance of the sample walk.  v0 = first of 17 scratch VGPRs."""
 
-    def __init__(self, v0, acc, dcs, T, row, f0, navg, wt, msk=None):
+    def __init__(self, v0, acc, dcs, T, row, f0, wt, msk=None):
         self.RAW = [pair(v0), pair(v0 + 2)]
         self.RAWC = [[f"v{v0}", f"v{v0 + 1}"], [f"v{v0 + 2}", f"v{v0 + 3}"]]
-        self.X, self.XR, self.XI = pair(v0 + 4), f"v{v0 + 4}", f"v{v0 + 5}"
-        self.U = [pair(v0 + 6), pair(v0 + 8)]
-        self.CS = [pair(v0 + 10), pair(v0 + 12)]
-        self.C = [f"v{v0 + 10}", f"v{v0 + 12}"]
-        self.S = [f"v{v0 + 11}", f"v{v0 + 13}"]
-        self.TT, self.Z, self.TP = pair(v0 + 14), pair(v0 + 16), f"v{v0 + 18}"
-        self.acc, self.dcs, self.T, self.row, self.f0, self.navg, self.wt, self.msk = acc, dcs, T, row, f0, navg, wt, msk
+        self.X = [pair(v0 + 4), pair(v0 + 6)]
+        self.XR = [f"v{v0 + 4}", f"v{v0 + 6}"]
+        self.XI = [f"v{v0 + 5}", f"v{v0 + 7}"]
+        self.CS = [pair(v0 + 8), pair(v0 + 10)]
+        self.C = [f"v{v0 + 8}", f"v{v0 + 10}"]
+        self.S = [f"v{v0 + 9}", f"v{v0 + 11}"]
+        self.TT, self.Z, self.TP = pair(v0 + 12), pair(v0 + 14), f"v{v0 + 16}"
+        self.acc, self.dcs, self.T, self.row, self.f0, self.wt, self.msk = acc, dcs, T, row, f0, wt, msk
 
 
 EXP = ""      # experiment variants (tools/ab_variants.sh): timing only, results are garbage
@@ -90,29 +95,25 @@ def block(R, r, init=False):
         I["cvt64"] = f"v_cvt_f32_f64 {R.TP}, {R.T}"
         I["add64"] = f"v_add_f64 {R.T}, {R.T}, {R.f0}"
         I["fract"] = f"v_fract_f32 {R.TP}, {R.TP}"
-        I["xr"] = f"v_cvt_f32_i32_sdwa {R.XR}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
-        I["xi"] = f"v_cvt_f32_i32_sdwa {R.XI}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+        I["xr"] = f"v_cvt_f32_i32_sdwa {R.XR[e]}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
+        I["xi"] = f"v_cvt_f32_i32_sdwa {R.XI[e]}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
         I["cos"] = f"v_cos_f32 {R.C[e]}, {R.TP}"
         I["sin"] = f"v_sin_f32 {R.S[e]}, {R.TP}"
-        I["dcs"] = f"v_pk_fma_f32 {R.dcs}, {R.X}, {R.msk}, {R.dcs}" if R.msk else f"v_pk_add_f32 {R.dcs}, {R.X}, {R.dcs}"
-        if init and r == 0: I["dcs"] = f"v_mov_b64 {R.dcs}, {R.X}"
-        I["u"] = f"v_pk_add_f32 {R.U[e]}, {R.X}, {R.navg}"
+        I["dcs"] = f"v_pk_fma_f32 {R.dcs}, {R.X[e]}, {R.msk}, {R.dcs}" if R.msk else f"v_pk_add_f32 {R.dcs}, {R.X[e]}, {R.dcs}"
+        if init and r == 0: I["dcs"] = f"v_mov_b64 {R.dcs}, {R.X[e]}"
     if s2:
-        I["tt"] = f"v_pk_mul_f32 {R.TT}, {R.U[o]}, {R.CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
-        I["z"] = f"v_pk_fma_f32 {R.Z}, {R.U[o]}, {R.CS[o]}, {R.TT} op_sel_hi:[0,1,1]"
+        I["tt"] = f"v_pk_mul_f32 {R.TT}, {R.X[o]}, {R.CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        I["z"] = f"v_pk_fma_f32 {R.Z}, {R.X[o]}, {R.CS[o]}, {R.TT} op_sel_hi:[0,1,1]"
         for q in range(Q): I[f"a{q}"] = tap_fma(R, q, r - 1, init and r == 1)
-    order = "cvt64 tt add64 fract z xr cos a0 xi sin a1 a2 dcs a3 u a4 a5 a6"
-    if "schedA" in EXP: order = "cvt64 tt add64 z fract xr cos a0 a1 xi a2 sin a3 dcs a4 u a5 a6"
-    if "schedB" in EXP: order = "cvt64 tt add64 fract z xr xi cos sin a0 a1 a2 dcs a3 u a4 a5 a6"
-    if "schedC" in EXP: order = "cvt64 tt xr z fract a0 cos xi a1 add64 a2 sin a3 dcs a4 u a5 a6"
-    if "nodc" in EXP: order = order.replace(" dcs", "").replace(" u ", " ")
+    order = "cvt64 tt add64 fract z xr cos a0 xi sin a1 a2 dcs a3 a4 a5 a6"
+    if "nodc" in EXP: order = order.replace(" dcs", "")
     if "nocmul" in EXP: order = order.replace(" tt ", " ").replace(" z ", " ")
     L = [I[k] for k in order.split() if k in I]
     if "nosincos" in EXP:
         L = [l.replace("v_cos_f32", "v_mov_b32").replace("v_sin_f32", "v_mov_b32") for l in L]
     if "nof64" in EXP:
         L = [l for l in L if not l.startswith("v_add_f64")]
-        L = [f"v_mov_b32 {R.TP}, {R.XR}" if l.startswith("v_cvt_f32_f64") else l for l in L]
+        L = [f"v_mov_b32 {R.TP}, {R.XR[0]}" if l.startswith("v_cvt_f32_f64") else l for l in L]
     if "nofir" in EXP:
         L = [l for l in L if not any(l.startswith(f"v_pk_fma_f32 {R.acc[q]},") or l.startswith(f"v_pk_mul_f32 {R.acc[q]},") for q in range(1, Q))]
     return L
@@ -138,7 +139,7 @@ def walk(R, init=False, hook=()):
 
 # ---- the operand form (md_fast_tile in sonde_kernels.hip) -----------------------------------------------------------------
 def body_operands():
-    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[navg]", "%[wt]", msk="%[msk]")
+    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[wt]", msk="%[msk]")
     return walk(R)
 
 
@@ -147,7 +148,8 @@ def body_operands():
 ACC0 = 28                          # v[28:41]  P[row][0..6] (re, im)
 CARRY = 42                         # v[42:43]  what earlier rows add to the first H outputs of the next tile
 STAGE = [44, 94]                   # two staging sets: 12 x 4 + 2 VGPRs each
-SCR = 144                          # v[144:162] scratch of the sample walk; reused by the diagonal sum
+SCR = 144                          # v[144:160] scratch of the sample walk; reused by the last tile's diagonal sum
+EREG = 162                         # v[162:163] E of the tile being walked (requested at its start, used with its deferred sum)
 DCS = 164                          # v[164:165]
 TREG = 166                         # v[166:167]
 S_B1, S_B2, S_B3, S_TB = 68, 70, 72, 74      # tile base + 4096 / 8192 / 12288 bytes, tile base
@@ -184,6 +186,7 @@ def diag_issue(rb):
         k = H - q
         L += [f"ds_bpermute_b32 v{rb + 2 * q}, %[lane4], v{ACC0 + 2 * q} offset:{256 - 4 * k}",
               f"ds_bpermute_b32 v{rb + 2 * q + 1}, %[lane4], v{ACC0 + 2 * q + 1} offset:{256 - 4 * k}"]
+    if "nodiag" in EXP: L = []
     Y, T1 = rb + 12, rb + 14
     L += [f"v_pk_add_f32 {pair(Y)}, {ACC[H]}, {pair(CARRY)}", f"v_mov_b64 {pair(CARRY)}, 0",
           f"v_lshrrev_b32 v{T1}, 2, %[lane4]", f"v_add_u32 v{T1}, s{S_JM}, v{T1}", f"v_and_b32 v{T1}, %[rmask], v{T1}",
@@ -192,19 +195,24 @@ def diag_issue(rb):
 
 
 def diag_finish(rb):
-    """(after lgkmcnt(0)) lanes >= k hold a row of the same tile -> its term of y; lanes < k hold rows 64-k+l -> the next tile's carry"""
+    """(after lgkmcnt(0), E landed) lanes >= k hold a row of the same tile -> its term of y; lanes < k hold rows 64-k+l -> the next
+    tile's carry; then y -= avg * E (complex; %[navg] = (-avg.re, -avg.im)) and the store of the 64 outputs"""
     Y, T1, L = rb + 12, rb + 14, []
     for q in range(H):
         L += [f"s_mov_b32 exec_lo, 0x{(0xffffffff << (H - q)) & 0xffffffff:x}", f"v_pk_add_f32 {pair(Y)}, {pair(Y)}, {pair(rb + 2 * q)}"]
     for q in range(H):
         L += [f"s_mov_b64 exec, {(1 << (H - q)) - 1}", f"v_pk_add_f32 {pair(CARRY)}, {pair(CARRY)}, {pair(rb + 2 * q)}"]
-    L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
+    L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]",
+          f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel_hi:[1,0,1]",
+          f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]",
+          f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
           "s_mov_b64 exec, -1", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], -1"]
+    if "nostore" in EXP: L = [l for l in L if not l.startswith("global_store")]
     return L
 
 
 def gen_loop():
-    R = Regs(SCR, ACC, pair(DCS), pair(TREG), "%[row]", "%[f0]", "%[navg]", "%[wt]")
+    R = Regs(SCR, ACC, pair(DCS), pair(TREG), "%[row]", "%[f0]", "%[wt]")
     T1, A, B = SCR + 14, SCR + 15, SCR + 16
     L = [f"s_mov_b64 s[{S_TB}:{S_TB + 1}], %[tb]", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[outmask]", f"s_mov_b32 s{S_JM}, %[jm]",
          f"s_mov_b32 s{S_T}, 0", f"v_mov_b64 {pair(CARRY)}, %[carry]"]
@@ -216,27 +224,34 @@ def gen_loop():
     L += park(STAGE[0])
     # Tile t lives in staging set t & 1 until it is parked.  Half h of the loop walks a tile with t & 1 == h: set h has just been
     # parked, so its registers take the rotated columns of the PREVIOUS tile; those sums and the store of its outputs sit behind
-    # the walk's first wait (one LDS round trip per tile instead of three), then tile t+2 is requested into set h.
+    # the walk's first wait (one LDS round trip per tile instead of three), then this tile's E and tile t+2 (into set h) are requested.
+    # %[e] = the lane's block as an index into the mixer table's period (table index = 50 e): phase seed and E index.
     for h in (0, 1):
         lab = 20 + 10 * h
-        hook = [f"s_cmp_eq_u32 s{S_T}, 0", f"s_cbranch_scc1 {lab + 1}f"] + diag_finish(STAGE[h]) + [f"{lab + 1}:"]
-        hook += [f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f"]
-        hook += fetch(STAGE[h]) + [f"{lab + 2}:"]
-        L += [f"{lab}:", f"v_cvt_f64_u32 {pair(TREG)}, %[rown]", f"v_mul_f64 {pair(TREG)}, {pair(TREG)}, %[f0]"]
+        hook = [f"s_cmp_eq_u32 s{S_T}, 0", f"s_cbranch_scc1 {lab + 1}f",
+                # E of the previous tile: younger than it are only the 13 loads of tile t+1 — if those were requested
+                f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 5}f",
+                "s_waitcnt vmcnt(13)", f"s_branch {lab + 6}f", f"{lab + 5}:", "s_waitcnt vmcnt(0)", f"{lab + 6}:"]
+        hook += diag_finish(STAGE[h]) + [f"{lab + 1}:"]
+        if "noE" not in EXP: hook += [f"v_lshlrev_b32 v{T1}, 3, %[e]", f"global_load_dwordx2 {pair(EREG)}, v{T1}, %[etab]"]
+        fe = [f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f"] + fetch(STAGE[h]) + [f"{lab + 2}:"]
+        if "latefetch" not in EXP: hook += fe
+        L += [f"{lab}:", f"v_mul_u32_u24 v{T1}, 50, %[e]", f"v_cvt_f64_u32 {pair(TREG)}, v{T1}", f"v_mul_f64 {pair(TREG)}, {pair(TREG)}, %[f0]"]
         L += walk(R, init=True, hook=hook)
-        # table row of the lane's block in the next tile: rown = (rown + 64 D) mod L; IQ-DC sums of the rows that count
-        L += [f"v_add_u32 %[rown], %[step], %[rown]", f"v_subrev_u32 v{T1}, %[L], %[rown]", f"v_min_u32 %[rown], v{T1}, %[rown]",
+        if "latefetch" in EXP: L += fe
+        # the lane's block in the next tile: e = (e + 64) mod P; IQ-DC sums of the rows that count
+        L += [f"v_add_u32 %[e], 64, %[e]", f"v_subrev_u32 v{T1}, %[P], %[e]", f"v_min_u32 %[e], v{T1}, %[e]",
               f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
               f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1"]
         L += [f"s_add_i32 s{S_T}, s{S_T}, 1", f"s_cmp_ge_i32 s{S_T}, %[nfull]", "s_cbranch_scc1 90f"]
-        # tile t+1: its loads are followed by 13 loads of tile t+2 (if requested) — and by the store of tile t-1, which is older than those
+        # tile t+1: its loads are followed by this tile's E load and 13 loads of tile t+2 (if requested)
         L += [f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 3}f",
               "s_waitcnt vmcnt(13)", f"s_branch {lab + 4}f", f"{lab + 3}:", "s_waitcnt vmcnt(0)", f"{lab + 4}:"]
         L += park(STAGE[1 - h])
         L += diag_issue(STAGE[1 - h])
     L += ["s_branch 20b", "90:"]
     # the wave's last full tile: nothing follows, the walk's scratch registers take the rotations
-    L += diag_issue(SCR) + ["s_waitcnt lgkmcnt(0)"] + diag_finish(SCR)
+    L += diag_issue(SCR) + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + diag_finish(SCR)
     L += [f"v_mov_b64 %[o{q}], {ACC[q]}" for q in range(Q)] + [f"v_mov_b64 %[carry], {pair(CARRY)}", "s_nop 1"]
     return L
 

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_stride(const uint4 *p, size_t n16, uint
 
 // (b) the decimator's pattern: channel -> XCD, 4 waves per WG, each wave walks `tiles` tiles of 12800 bytes (13 x 16 B per lane,
 // the last load only in the low lanes), next tile in flight while the current one is "used"
-template <bool NT, int DEPTH, bool PARK = false, bool HALO = false, int STORE = 0>
+template <bool NT, int DEPTH, bool PARK = false, bool HALO = false, int STORE = 0, int YSTRIDE = 131072>
 __global__ __launch_bounds__(256) void k_tiles(const uint32_t *base, long long ch_stride_dw, int n_ch, int wgs_per_ch, int tiles, int n_waves, uint32_t *out, float2 *y = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
@@ -45,7 +45,17 @@ __global__ __launch_bounds__(256) void k_tiles(const uint32_t *base, long long c
 #pragma unroll
         for (int s = 0; s < DEPTH; s++) {
             if (t + s + DEPTH - 1 < tiles) fetch(t + s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
-            if (STORE == 1) y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)] = make_float2((float)acc, 1.f);
+            if (STORE == 1) y[(size_t)ch * YSTRIDE + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)] = make_float2((float)acc, 1.f);
+            if (STORE >= 10) {
+                float2 *q = &y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)];
+                const float2 v = make_float2((float)acc, 1.f);
+                if (STORE == 10) asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(q), "v"(v) : "memory");
+                if (STORE == 11) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+                if (STORE == 12) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");
+                if (STORE == 13) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" :: "v"(q), "v"(v) : "memory");
+                if (STORE == 14) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" :: "v"(q), "v"(v) : "memory");
+                if (STORE == 15) asm volatile("global_store_dwordx2 %0, %1, off sc0 nt" :: "v"(q), "v"(v) : "memory");
+            }
             if (STORE == 2) { float2 *q = &y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s) * 64 + lane) & 131071)]; __builtin_nontemporal_store((float)acc, &q->x); __builtin_nontemporal_store(1.f, &q->y); }
             if (STORE == 3 && ((t + s) & 3) == 3) {          // four tiles' outputs at once: 2 KB per wave
                 float4 *q = reinterpret_cast<float4 *>(&y[(size_t)ch * 131072 + ((row0 + (size_t)(t + s - 3) * 64) & 131071)]);
@@ -103,6 +113,16 @@ int main() {
     timeit("12 waves/CU, nt, park, stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 1>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
     timeit("12 waves/CU, nt, park, halo + stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, true, 1>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
     timeit("12 waves/CU, plain loads, park, halo + stores", [&] { hipLaunchKernelGGL((k_tiles<false, 2, true, true, 1>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    (void)hipFree(y); (void)hipMalloc(&y, (size_t)C * (131072 + 4096) * 8);
+    timeit("12 waves/CU, nt, park, stores, ring stride +32", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 1, 131072 + 32>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, nt, park, stores, ring stride +544", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 1, 131072 + 544>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("12 waves/CU, nt, park, stores, ring stride +2080", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 1, 131072 + 2080>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("stores sc0", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 10>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("stores sc1", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 11>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("stores sc0 sc1", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 12>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("stores sc0 sc1 nt", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 13>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("stores sc1 nt", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 14>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
+    timeit("stores sc0 nt", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 15>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
     timeit("12 waves/CU, nt, park, nt stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 2>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
     timeit("12 waves/CU, nt, park, 2 KB stores", [&] { hipLaunchKernelGGL((k_tiles<true, 2, true, false, 3>), dim3(C * 12), dim3(256), 51264, 0, d, SR, C, 12, 16, 47, out, y); });
     return 0;
