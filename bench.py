@@ -30,7 +30,7 @@ BANK = 8                 # unique synthetic captures tiled over the channels
 
 
 def make_bank(seconds: float = 1.0):
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     rng = np.random.default_rng(2024)
     fqs, caps = [], []
     for b in range(BANK):

@@ -29,7 +29,7 @@ extern "C" {
 #define SONDE_E_NOGPU    (-2)   /* no HIP device / HIP runtime failure (never falls back) */
 #define SONDE_E_NOMEM    (-3)
 #define SONDE_E_RANGE    (-4)   /* chunk larger than max_chunk / not a multiple of decM   */
-#define SONDE_E_OVERFLOW (-5)   /* frame queue overflow (frames were dropped)             */
+#define SONDE_E_OVERFLOW (-5)   /* (reserved; queue overflow is reported by sonde_engine_overflowed()) */
 
 /* sonde types (dsp.hdr / baud / BT / h presets of the reference callers) */
 #define SONDE_RS41  41          /* rs41mod.c:2812-2836: 4800 Bd, BT 0.5, h 0.6, 64-bit header, thres 0.7, hdmax 4 */
@@ -178,6 +178,9 @@ int  sonde_engine_sync(sonde_engine_t *e);
  * Returns the number of frames written (<= max).  Frames of one channel come in stream order; the order between
  * channels that completed a frame in the same process call is unspecified (sonde_frame_t.channel tells them apart). */
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
+/* 1 if the device-side frame queue (cfg.max_frames) overflowed since the last call of this function — the oldest frames were then
+ * overwritten before a fetch could read them; the fetch functions themselves return the number of frames they delivered. */
+int  sonde_engine_overflowed(sonde_engine_t *e);
 /* Pipelined variant: return only the frames of process calls issued at least `lag` calls ago and wait only for those.
  * With lag = 1 the IF-rate kernels of call k (stream B) overlap the decimator of call k+1 (stream A); lag = 0 is
  * sonde_engine_fetch_frames().  Frames are never lost: what is not returned stays queued. */

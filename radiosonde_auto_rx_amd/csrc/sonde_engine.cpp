@@ -258,7 +258,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     }
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
-    int ring = 1; while (ring < max_if + (int)e->frame_samples + 2 * M + 4096 || ring < 4 * M) ring <<= 1;
+    int ring = 1; while (ring < max_if + (int)e->frame_samples + 2 * M + 4096 || ring < 4 * M || (cfg->pipeline && ring < 2 * max_if + 4096)) ring <<= 1;
     e->ring_len = ring;
     e->max_frames = cfg->max_frames > 0 ? cfg->max_frames : 4 * C;
 
@@ -418,6 +418,9 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     e->last_frame.assign((size_t)C * 518, 0);
     for (int c = 0; c < C; c++) memcpy(e->last_frame.data() + (size_t)c * 518, kRs41HeaderBytes, 8);
     HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // pipeline: stream A (staging, decimator) may run ONE call ahead of stream B (IF-rate kernels); the rings hold that (see
+    // process_device).  The FM-audio path writes the rings B reads from on stream A, so it does not pipeline.
+    if (cfg->pipeline && audio) { sonde_engine_destroy(e); return SONDE_E_ARG; }
     if (cfg->pipeline) HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
     else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
     for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
@@ -475,6 +478,9 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     }
     const uint32_t m_first = e->m_out;
     int done = 0;
+    // two streams: this call's decimator overwrites the part of the y ring that call-2 occupied (ring_len >= 2 * max_if + history),
+    // so it must not start before the IF-rate kernels of call-2 have read it; one call of overlap remains
+    if (e->stream_b != e->stream && e->call >= 2) hipStreamWaitEvent(e->stream, e->ev_b[(e->call - 2) & 3], 0);
     if (e->cfg.input == SONDE_IN_AUDIO) {
         // f32read_sample (demod_mod.c:379-405): b/128/256 of the selected channel; then FM low-pass / bufs
         AudioConvArgs c0{}; c0.pcm = (const int16_t *)d_iq; c0.ch_stride = ch_stride; c0.n_ch = C; c0.n = n_samples;
@@ -691,8 +697,13 @@ static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int la
         memcpy(keepf, f.frame, 518);
     }
     e->last_n = n;
+    return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
+}
+
+int sonde_engine_overflowed(sonde_engine_t *e) {
+    if (!e) return SONDE_E_ARG;
     const bool ovf = e->overflow; e->overflow = false;
-    return ovf ? SONDE_E_OVERFLOW : n;
+    return ovf ? 1 : 0;
 }
 
 int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) { return fetch_rs41(e, out, max, 0); }
@@ -733,8 +744,7 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
             o.ecc[2] = dfm_block(e->cfg.ecc_level, hb + 176, sf + 176, 13, o.dat2);
         }
     }
-    const bool ovf = e->overflow; e->overflow = false;
-    return ovf ? SONDE_E_OVERFLOW : n;
+    return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
 }
 
 // M10 / M20: sliced Manchester bits -> differentially decoded frame bytes.  The bit characters persist per channel like the
@@ -771,8 +781,7 @@ int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t ma
         o.channel = r.channel; o.mv = r.mv; o.mv_pos = r.mv_pos;
         sonde_m20_frame_finish(&o);                                 // length, firmware byte, checksums (m20mod.c:875-907)
     }
-    const bool ovf = e->overflow; e->overflow = false;
-    return ovf ? SONDE_E_OVERFLOW : n;
+    return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
 }
 
 int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish) {
@@ -791,8 +800,7 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
         o.channel = r.channel; o.nbits = nv; o.mv = r.mv; o.mv_pos = r.mv_pos;
         sonde_m10_frame_finish(&o);
     }
-    const bool ovf = e->overflow; e->overflow = false;
-    return ovf ? SONDE_E_OVERFLOW : n;
+    return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
 }
 
 int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, int32_t finish) {
@@ -816,8 +824,7 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
         out[i].channel = r.channel; out[i].mv = r.mv; out[i].mv_pos = r.mv_pos;
         out[i].nbits = e->cfg.sonde_type == SONDE_RS41 ? 8 * (r.nbytes - 8) : r.nbytes;      // RS41 records count bytes incl. the 8 header bytes
     }
-    const bool ovf = e->overflow; e->overflow = false;
-    return ovf ? SONDE_E_OVERFLOW : n;
+    return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
 }
 
 int sonde_engine_set_sync(sonde_engine_t *e, int32_t hdmax, int32_t bitofs) {

@@ -1201,7 +1201,8 @@ void k_framesync(const SyncArgs a) {
     if (tid < 256) s_log[tid] = a.gf_log[tid];
     __syncthreads();
 
-    for (int guard = 0; guard < 64; guard++) {
+    // every pass consumes a window (K-4 samples) or a frame, or ends at `avail`: the bound only guards against a corrupted state
+    for (int guard = 0; guard < (1 << 20); guard++) {
         if (st.mode == 2) break;                       // stream finished
         if (st.mode == 0) {
             // ---- find_header: next correlation once K-4 new samples were consumed (demod_mod.c:1540-1548)

@@ -361,11 +361,13 @@ struct sonde_rs41_dec {
         int n = 0, last = 0, cnt = 0;
         xd[0] = 0;
         if (frametype() <= 0) {
-            while (pos < FL && fr[pos] == 0x7E) {
+            // (the reference appends without a bound, rs41mod.c get_Aux; frames come off the air, so the text stops where xd[] ends)
+            const int cap = (int)sizeof xd - 2;
+            while (pos + 1 < FL && fr[pos] == 0x7E) {
                 const int len = fr[pos + 1];
                 if (pos + len + 4 <= FL && (int)(fr[pos + 2 + len] | fr[pos + 3 + len] << 8) == crc16(fr + pos + 2, len)) {
-                    if (cnt) xd[n++] = '#';
-                    for (int i = 1; i < len; i++) { const uint8_t ch = fr[pos + 2 + i]; if (ch > 0x1E && ch < 0x7F) xd[n++] = (char)ch; }
+                    if (cnt && n < cap) xd[n++] = '#';
+                    for (int i = 1; i < len; i++) { const uint8_t ch = fr[pos + 2 + i]; if (ch > 0x1E && ch < 0x7F && n < cap) xd[n++] = (char)ch; }
                     cnt++; last = pos; pos += 2 + len + 2;
                 } else { pos = FL; crc |= F_AUX; }
             }

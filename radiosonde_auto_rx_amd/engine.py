@@ -121,6 +121,12 @@ class SondeError(RuntimeError):
     pass
 
 
+def snap_fq(fq: float, sr: int) -> float:
+    """The carrier the reference's mixer table really mixes with: fq snapped to a multiple of 16 Hz (demod_mod.c:1265-1288,
+    valid where 16 divides the sample rate); the engine applies the same rule itself (design_mixer in sonde_design.cpp)."""
+    return int(round(fq * sr / 16.0)) * 16 / sr
+
+
 def _chk(rc: int) -> int:
     if rc < 0:
         raise SondeError(f"libsonde_hip: {lib().sonde_strerror(rc).decode()} ({rc})")
@@ -193,6 +199,11 @@ class Engine:
         _chk(lib().sonde_engine_sync(self._h))
 
     # -- output ------------------------------------------------------------------------------
+    def overflowed(self) -> bool:
+        """True if the device-side frame queue overflowed since the last call (oldest frames overwritten before a fetch read them);
+        the fetch_* methods return what they could read either way"""
+        return bool(_chk(lib().sonde_engine_overflowed(self._h)))
+
     def fetch_frames(self, max_frames: int | None = None, with_soft: bool = False, finish: bool = False):
         """Frames completed so far; finish=True = end of input (also emits the frame in progress, like the reference at EOF)."""
         n = max_frames or self._max_frames

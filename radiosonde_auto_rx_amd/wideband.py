@@ -17,9 +17,8 @@ import sys
 
 import numpy as np
 
-from .engine import Engine
+from .engine import Engine, snap_fq
 from .scan import Scanner
-from .synth import snap_fq
 from .telemetry import DfmTelemetry, M10Telemetry, M20Telemetry, Rs41Telemetry
 
 
@@ -31,7 +30,13 @@ class WidebandReceiver:
         self.raster = [snap_fq(k * raster_hz / sample_rate, sample_rate) for k in range(-kmax, kmax + 1)]
         self.chunk = chunk or sample_rate // 4
         self.scanner = Scanner(sample_rate, fq=self.raster, dc=True, cont=True, max_chunk=self.chunk)
-        D = self.scanner.info["decM"]
+        # the demodulators decimate to the reference's IF rate (48 kHz, raised until it divides the sample rate, demod_mod.c:1229-1236);
+        # pushes are cut at multiples of both decimation factors, the rest of a push waits for the next one
+        if_sr = min(48000, sample_rate)
+        while sample_rate % if_sr:
+            if_sr += 1
+        D = int(np.lcm(self.scanner.info["decM"], sample_rate // if_sr))
+        self.align, self._rest = D, None
         self.chunk -= self.chunk % D
         self.sondes: list[dict] = []           # {fq, engine, telemetry, type, frames}
         self.log: list[dict] = []
@@ -57,8 +62,11 @@ class WidebandReceiver:
     def push(self, iq: np.ndarray, finish: bool = False):
         """iq: interleaved int16 I/Q, a whole number of chunks is not required; returns the JSON objects of this call."""
         out = []
+        if self._rest is not None and len(self._rest):       # samples that did not fill a decimation block last time
+            iq = np.concatenate([self._rest, np.asarray(iq, np.int16)])
         n = len(iq) // 2
-        D = self.scanner.info["decM"]
+        D = self.align                                        # lcm of the scanner's and the demodulators' decimation factors
+        self._rest = np.array(iq[2 * (n - n % D):2 * n], np.int16)
         for s0 in range(0, n - n % D, self.chunk):
             x = iq[2 * s0:2 * min(n - n % D, s0 + self.chunk)]
             self.scanner.process_host(x, shared=True)
@@ -108,9 +116,7 @@ def main(argv=None):
     inp = sys.stdin.buffer
     while True:
         buf = inp.read(rx.chunk * 4)
-        if not buf:
-            break
-        last = len(buf) < rx.chunk * 4
+        last = len(buf) < rx.chunk * 4                        # also an EMPTY read: the frame in progress at EOF is still due
         for js in rx.push(np.frombuffer(buf[:len(buf) // 4 * 4], np.int16), finish=last):
             print(json.dumps(js), flush=True)
         if last:

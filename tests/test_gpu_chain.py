@@ -42,7 +42,7 @@ def _chains(front, decoder):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "rs41mod")), reason="compiled reference not present")
 def test_rs41_production_chain_json_identical():
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     x = synth.rs41_capture(sr=48_000, seconds=6.3, fq=0.0, n_frames=6, t_first=0.2, noise_sigma=0.03, seed=101, f_offset_hz=1200.0, dc=0.02 - 0.03j, frame_kw=ECEF_OK)
     front = [["iq_dec", "--bo", "16", "-", "48000", "16"],
@@ -57,7 +57,7 @@ def test_rs41_production_chain_json_identical():
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "dfm09mod")), reason="compiled reference not present")
 def test_dfm_production_chain_identical():
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     x = synth.dfm_capture(sr=50_000, seconds=4.0, fq=0.01, noise_sigma=0.03, seed=102)
     front = [["iq_dec", "--bo", "16", "-", "50000", "16"],
@@ -70,7 +70,7 @@ def test_dfm_production_chain_identical():
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF, "rs41mod")), reason="compiled reference not present")
 def test_rs41_fm_chain_identical():
     """FM chain (decode.py:417 form): baseband IQ -> iq_dec --FM --wav (this repo) -> reference rs41mod --ptu2 --json on the WAV."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     sr = 2_400_000
     fq = synth.snap_fq(0.0, sr)
@@ -87,7 +87,7 @@ def test_all_own_chains_json_identical():
     """Everything from this repo, including the telemetry / JSON tier (include/sonde_rs41.h): the soft chain
     iq_dec | fsk_demod | rs41mod --json --softin -i, and the direct IQ form rs41mod --ptu2 --json --IQ fq --lpIQ, against the same
     commands built from the reference."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     env = dict(os.environ, SONDE_JSN_VERSION="oracle")
     table = synth.rs41_cal_table(seed=5, typ="RS41-SGP")
@@ -118,7 +118,7 @@ def test_wideband_receiver_finds_and_decodes_all_sondes():
     """One 2.4 Msps stream with three RS41 (different IDs, offsets off the raster, one starting late), one DFM09, and nothing else told to the
     receiver: the raster scanner finds each, a demodulator is started per sonde, every later frame comes out as the telemetry JSON
     with the right ID / frequency; positions are what the frames carry."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     from radiosonde_auto_rx_amd.wideband import WidebandReceiver
     sr = 2_400_000
     cf = 403_000_000
@@ -172,7 +172,7 @@ def test_dfm_iq_json_identical():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_golden
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     sym = (make_golden.dfm_field_symbols(dict(kind="09", n=26, sn=18012345)) > 0).astype(np.uint8)
     sr = 2_400_000
@@ -194,7 +194,7 @@ def test_dfm_iq_json_identical():
 def test_wideband_receiver_m10_m20():
     """One 2.4 Msps stream with an M10 (Trimble), an M20 and an RS41: the scanner tells M10 from M20 by the first frame bytes, the
     receiver starts the matching 9615 / 9600 Bd demodulator and every frame with a good checksum comes out as JSON."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     from radiosonde_auto_rx_amd.wideband import WidebandReceiver
     sr, cf, secs = 2_400_000, 404_000_000, 6.3
     n = int(sr * secs)
@@ -230,7 +230,7 @@ def test_wideband_module_cli():
     import json
     import subprocess
     import sys
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr, cf = 2_400_000, 402_500_000
     cap = synth.rs41_capture(sr=sr, seconds=5.3, fq=synth.snap_fq(0.125, sr), n_frames=5, t_first=0.3, noise_sigma=0.01, seed=77, sonde_id="E5555555",
                              frame_kw=dict(ecef_cm=(418833319, 85974133, 473346430)))

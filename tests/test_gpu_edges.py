@@ -84,3 +84,68 @@ def test_engine_rejects_bad_requests():
     from radiosonde_auto_rx_amd.scan import Scanner
     with pytest.raises(SondeError):
         Scanner(2_400_000, fq=[0.1], bw_khz=96.0)                       # wide IF needs N_DFT > 8192: refused
+
+
+def test_two_stream_pipeline_matches_single_stream():
+    """pipeline=1 (IF-rate kernels on a second stream, frames fetched one call late) gives the frames of the plain engine: the
+    decimator of call k+1 may overlap the IF-rate kernels of call k, but must not run two calls ahead of them (ring reuse)."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    x, fq, sr = capture("rs41_480k_be30")
+    n = len(x) // 2
+    D = 10
+    out = {}
+    for pipe in (False, True):
+        eng = Engine([fq] * 3, sr, max_chunk=48_000, keep_soft=False, pipeline=pipe, max_frames=64)
+        xb = np.stack([x, x, x])
+        frames = []
+        for pos in range(0, n - n % D, 48_000):                       # 0.1 s calls: the streams really overlap
+            take = min(48_000, n - n % D - pos)
+            eng.process_host(np.ascontiguousarray(xb[:, 2 * pos:2 * (pos + take)]))
+            fr = eng.fetch_frames_np(lag=1 if pipe else 0)
+            frames += [(int(f["channel"]), int(f["mv_pos"]), bytes(f["frame"])) for f in fr]
+        fr = eng.fetch_frames_np(lag=0)
+        frames += [(int(f["channel"]), int(f["mv_pos"]), bytes(f["frame"])) for f in fr]
+        out[pipe] = sorted(frames)
+        eng.close()
+    assert out[True] == out[False] and len(out[False]) >= 3
+    with pytest.raises(Exception):                                      # FM audio writes the rings of stream B on stream A: refused
+        Engine([0.0], 48000, audio=True, pipeline=True)
+
+
+def test_long_chunk_is_fully_consumed():
+    """A call much longer than 64 correlation windows (K - 4 = 7508 IF samples each): the frame sync keeps going until the samples
+    are used up — all frames of a 12 s capture come out of ONE call."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    sr = 480_000
+    fq = synth.snap_fq(0.07, sr)
+    x = synth.rs41_capture(sr=sr, seconds=12.3, fq=fq, seed=5, noise_sigma=0.02)
+    n = (len(x) // 2 // 10) * 10
+    ref = Engine([fq], sr, max_chunk=sr, max_frames=32)
+    want = []
+    for pos in range(0, n, sr):
+        take = min(sr, n - pos)
+        ref.process_host(x[2 * pos:2 * (pos + take)])
+        want += [f["line"] for f in ref.fetch_frames()]
+    ref.close()
+    eng = Engine([fq], sr, max_chunk=n, max_frames=32)
+    eng.process_host(x[:2 * n])
+    got = [f["line"] for f in eng.fetch_frames()]
+    eng.close()
+    assert len(want) >= 11 and got == want
+
+
+def test_queue_overflow_is_reported_not_returned_as_error():
+    """max_frames smaller than what one call produces: the fetch returns the frames that survived, overflowed() says that older ones
+    were overwritten (and clears)."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    sr = 480_000
+    fq = synth.snap_fq(-0.11, sr)
+    x = synth.rs41_capture(sr=sr, seconds=5.3, fq=fq, seed=9, noise_sigma=0.02)
+    n = (len(x) // 2 // 10) * 10
+    eng = Engine([fq], sr, max_chunk=n, max_frames=2)
+    eng.process_host(x[:2 * n])
+    fr = eng.fetch_frames()
+    assert len(fr) == 2 and eng.overflowed() is True and eng.overflowed() is False
+    eng.close()

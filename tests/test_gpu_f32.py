@@ -50,7 +50,7 @@ def test_f32_of_int16_values_equals_s16_engine():
     """cf32 samples that are exactly b/32768 must give the streams of the tuned 16-bit path within float summation noise, the same
     frames and header positions: the plain float kernels and the packed-FMA decimator implement one filter."""
     from radiosonde_auto_rx_amd.engine import Engine, TAP_DECIM, TAP_BUFS
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 2_400_000
     fqs = [synth.snap_fq(0.1, sr), synth.snap_fq(-0.2, sr)]
     s16 = np.stack([synth.rs41_capture(sr=sr, seconds=1.3, fq=fq, n_frames=1, t_first=0.05, noise_sigma=0.02, seed=120 + k, dc=0.01j) for k, fq in enumerate(fqs)])

@@ -83,7 +83,7 @@ def test_cli_ifiq_matches_reference(name):
 
 def test_cli_iq_in_stereo_wav():
     """IQ pairs inside a 2-channel WAV (no `- sr bits`): header summary on stderr, then the same frames."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     name = "ifiq_rs41_iq2_lpIQ"
     case = make_golden.IFIQ_CASES[name]

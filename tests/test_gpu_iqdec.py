@@ -74,7 +74,7 @@ def test_cli_iq_dec_wav_input_equals_raw_input():
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_golden
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     x, _ = make_golden.iqdec_capture(make_golden.IQDEC_CASES["iqdec_2400k_bo16"])
     x = x[:2 * 600_000]

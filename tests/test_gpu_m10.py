@@ -41,7 +41,7 @@ def test_m10_engine_many_channels():
     """Batched form: 6 channels of one engine, each its own capture and carrier; frames per channel equal the single-channel CLI
     goldens' frame bytes for the matching capture."""
     from radiosonde_auto_rx_amd.engine import Engine
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 2_400_000
     fqs = [synth.snap_fq(f, sr) for f in (0.11, -0.2, 0.3, -0.05, 0.01, 0.4)]
     caps = [synth.m10_capture(sr=sr, seconds=1.6, fq=fq, noise_sigma=0.02, seed=20 + k, t_first=0.2 + 0.03 * k) for k, fq in enumerate(fqs)]
@@ -65,7 +65,7 @@ def test_m10_engine_many_channels():
 def test_m10_telemetry_on_iq_matches_reference(args):
     """Telemetry frames (valid GPS / sensor words / checksum) modulated at 48 kHz: `m10mod <args> --IQ 0.0 --lpIQ - 48000 16` from this repo
     (GPU demodulator + host framer + telemetry tier; -vvv = no skipping behind a frame) against the compiled reference."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     ref = os.path.join(ROOT, "oracle", "_ref", "m10mod")
     if not os.path.exists(ref):
         pytest.skip("compiled reference not present")
@@ -83,7 +83,7 @@ def test_m10_telemetry_on_iq_matches_reference(args):
 @pytest.mark.parametrize("args", [["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-r", "-v", "--json"]])
 def test_m20_telemetry_on_iq_matches_reference(args):
     """M20 telemetry frames (firmware 8 with pressure, one bad checksum) at 9600 Bd: `m20mod <args> --IQ 0.0 --lpIQ - 48000 16`"""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     ref = os.path.join(ROOT, "oracle", "_ref", "m20mod")
     if not os.path.exists(ref):
         pytest.skip("compiled reference not present")
@@ -102,7 +102,7 @@ def test_m20_telemetry_on_iq_matches_reference(args):
 @pytest.mark.parametrize("binary,shift", [("rs41mod", "1"), ("rs41mod", "-3"), ("dfm09mod", "-1"), ("m10mod", "2"), ("m20mod", "1")])
 def test_cli_bit_offset_option_matches_reference(binary, shift):
     """-d <shift> of the native front ends (sonde_engine_set_sync behind it) against the compiled reference"""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     ref = os.path.join(ROOT, "oracle", "_ref", binary)
     if not os.path.exists(ref):
         pytest.skip("compiled reference not present")

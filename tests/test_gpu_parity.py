@@ -131,7 +131,7 @@ def test_chunking_invariance(oracle):
 
 def test_multichannel_independent(oracle):
     """Channels are independent: a batch gives per-channel results identical to single-channel runs."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 480_000
     fqs = [synth.snap_fq(f, sr) for f in (0.05, -0.21, 0.33, 0.0, -0.4, 0.12, 0.27, -0.08, 0.41)]
     caps = [synth.rs41_capture(sr=sr, seconds=2.2, fq=f, seed=20 + i, first_frame_no=100 * i, noise_sigma=0.03,

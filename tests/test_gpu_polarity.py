@@ -34,7 +34,7 @@ def test_engine_polarity_is_per_channel():
     """Two channels of one engine, one mirrored: with --auto each channel settles on its own polarity and both decode; the soft
     bits of the mirrored channel equal those of the same capture decoded with -i."""
     from radiosonde_auto_rx_amd.engine import Engine
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 2_400_000
     fq = synth.snap_fq(0.1, sr)
     x = synth.rs41_capture(sr=sr, seconds=2.2, fq=fq, n_frames=2, t_first=0.1, noise_sigma=0.02, seed=91)

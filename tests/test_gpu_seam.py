@@ -33,7 +33,7 @@ def _both(binary, args, stdin):
 
 
 def _rs41(sr, secs, fq, **kw):
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     fq = synth.snap_fq(fq, sr)
     return synth.rs41_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.02, frame_kw=ECEF, **kw), fq
 
@@ -46,7 +46,7 @@ def test_seam_rs41_iq(args):
 
 
 def test_seam_rs41_eof_inside_frame_and_8bit():
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     x, fq = _rs41(2_400_000, 3.3, -0.2, n_frames=3, t_first=0.1, seed=92)
     x = x[:2 * int(2_400_000 * 2.4)]                                           # third frame cut by the end of the stream
     out = _both("rs41mod", ["-r", "--ecc2", "--IQ", repr(fq), "--lpIQ", "-", "2400000", "16"], x.tobytes())
@@ -55,7 +55,7 @@ def test_seam_rs41_eof_inside_frame_and_8bit():
 
 
 def test_seam_rs41_audio_wav_and_ifiq():
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     x, _ = _rs41(48_000, 4.3, 0.0, n_frames=4, t_first=0.15, seed=93)
     out = _both("rs41mod", ["--ptu2", "--json", "--jsnsubfrm1"], synth.wav_bytes(synth.fm_audio(x), 48_000))
     assert out.count(b'"type": "RS41"') >= 3
@@ -70,7 +70,7 @@ def test_seam_polarity(name):
 
 
 def test_seam_dfm_autorx_args():
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sym = (make_golden.dfm_field_symbols(dict(kind="09", n=40, sn=18012345)) > 0).astype(np.uint8)
     sr = 48_000
     z = 0.5 * synth.gfsk_baseband(sym, sr, 2500.0, 2400.0)
@@ -84,7 +84,7 @@ def test_seam_dfm_autorx_args():
 
 @pytest.mark.parametrize("binary,baud", [("m10mod", 9616.0), ("m20mod", 9600.0)])
 def test_seam_m10_m20(binary, baud):
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     fn = (lambda k: synth.m10_frame(k, rng=np.random.default_rng(40 + k))) if binary == "m10mod" else \
          (lambda k: synth.m20_frame(k, fw=8, pressure_hpa=700.0 - k, rng=np.random.default_rng(60 + k)))
     x = synth.m10_capture(sr=48_000, seconds=5.3, noise_sigma=0.02, seed=95, f_offset_hz=200.0, baud=baud, frame_fn=fn)
@@ -98,7 +98,7 @@ def test_seam_family_generic(binary):
     """The frame-based rest of the reference's demod/mod family through the engine's generic sonde description (baud, header, BT, h, symbol
     layout taken from the decoder's own dsp_t; bits per hit from the seam's table): raw output on baseband IQ at 2.4 Msps (mixer +
     decimator), IF-rate IQ with the tone correlator (--iq3: centre window), FM-sliced (--iq0), and an inverted signal."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 2_400_000
     fq = synth.snap_fq(0.07, sr)
     x = synth.family_capture(binary, sr=sr, seconds=3.4, fq=fq, seed=11, f_offset_hz=150.0)
@@ -116,7 +116,7 @@ def test_seam_family_generic(binary):
 def test_seam_rs41_sample_rates(sr):
     """SDR rates off the benchmark's 2.4 Msps: other decimation factors / tap counts (decM 5 .. 125: the runtime-D and the wide
     decimator variants), a designated IF above 48 kHz where 48000 does not divide the rate (2.048 Msps -> 51.2 kHz)."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     fq = synth.snap_fq(-0.11, sr)
     x = synth.rs41_capture(sr=sr, seconds=3.3, fq=fq, noise_sigma=0.02, frame_kw=ECEF, n_frames=3, t_first=0.1, seed=97, bit_errors=2)
     out = _both("rs41mod", ["-r", "--ecc2", "--crc", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], x.tobytes())
@@ -126,7 +126,7 @@ def test_seam_rs41_sample_rates(sr):
 def test_generic_engine_batched_channels_python():
     """Engine(sonde="generic") from Python: three MTS01-style channels (1200 Bd, 32-symbol header) at different carriers in one engine give
     the same hits and soft bits as three single-channel engines — the batched form of what the seam does for one decoder process."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     from radiosonde_auto_rx_amd.engine import Engine
     sr = 480_000
     f = synth.FAMILY["mts01mod"]
@@ -161,7 +161,7 @@ def test_seam_rs41_ecc3_second_soft_bit(ecc):
     same window one IF sample earlier (cfg.keep_soft = 2, sonde_engine_fetch_soft1) — and use byte scores for erasure / bit-toggle
     decoding: at a noise level where that changes the correction counts, the reference's decoder on the seam prints what it prints on
     demod_mod.c."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     outs = []
     for ns, seed in ((0.38, 55), (0.44, 56)):
         x = synth.rs41_capture(sr=48_000, seconds=8.3, fq=0.0, noise_sigma=ns, frame_kw=ECEF, n_frames=8, t_first=0.15, seed=seed)
@@ -176,7 +176,7 @@ def test_seam_rs41_ecc3_second_soft_bit(ecc):
 def test_seam_bit_offset_option(binary, shift):
     """-d <shift>: the decoders add it to the bitofs they pass to find_header() / read_softbit*(); the seam hands it to the engine
     (sonde_engine_set_sync) — soft bits move by whole IF samples, so correction counts / scores printed by the reference change with it."""
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     if binary == "rs41mod":
         x = synth.rs41_capture(sr=48_000, seconds=4.3, fq=0.0, noise_sigma=0.3, frame_kw=ECEF, n_frames=4, t_first=0.15, seed=61)
         args = ["-r", "--ecc2", "--crc"]

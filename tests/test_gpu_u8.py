@@ -47,7 +47,7 @@ def test_u8_equals_widened_s16_engine():
     """Engine level: cu8 input and the same samples widened on the host to (u-128)*256 int16 give identical taps, frames and
     soft bits."""
     from radiosonde_auto_rx_amd.engine import Engine, TAP_DECIM, TAP_FM
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 2_400_000
     fqs = [synth.snap_fq(0.1, sr), synth.snap_fq(-0.2, sr), synth.snap_fq(0.03, sr)]
     caps = [synth.to_u8(synth.rs41_capture(sr=sr, seconds=0.9, fq=fq, n_frames=1, t_first=0.05, noise_sigma=0.02, seed=40 + k)) for k, fq in enumerate(fqs)]
@@ -80,7 +80,7 @@ def test_u8_equals_widened_s16_audio_odd_chunks():
     """8-bit FM audio, two engine channels, odd chunk lengths: channel 1 starts on an odd byte (bytewise path of the converter)
     and every chunk leaves a 1..3 byte tail."""
     from radiosonde_auto_rx_amd.engine import Engine
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 48_000
     pcm = [synth.to_u8(synth.fm_audio(synth.rs41_capture(sr=sr, seconds=2.4, fq=0.0, n_frames=2, t_first=0.1, noise_sigma=0.03, seed=50 + k))) for k in range(2)]
     u8 = np.stack(pcm)

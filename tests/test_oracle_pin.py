@@ -31,7 +31,7 @@ def test_oracle_matches_golden(oracle, name):
 def test_oracle_vs_live_reference(oracle):
     if not oracle.have_ref():
         pytest.skip("oracle/_ref not built (no /root/reference here)")
-    from radiosonde_auto_rx_amd import synth
+    from tools import synth
     sr = 240_000
     fq = synth.snap_fq(-0.123, sr)
     x = synth.rs41_capture(sr=sr, seconds=4.2, fq=fq, noise_sigma=0.08, bit_errors=9, seed=11)

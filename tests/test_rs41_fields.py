@@ -44,7 +44,8 @@ def test_cli_telemetry_matches_reference(built, name):
 def test_decoder_api_fields():
     """C ABI through ctypes: frames in, text out, numeric fields readable; option validation."""
     import ctypes as C
-    from radiosonde_auto_rx_amd import engine, synth
+    from radiosonde_auto_rx_amd import engine
+    from tools import synth
     if not os.path.exists(engine.LIB_PATH):
         engine.build_library()
     L = C.CDLL(engine.LIB_PATH)

@@ -2,7 +2,7 @@
 the first stdout line and to exit, for a 3.3 s 48 kHz IQ capture piped in at once.  Run from the repo root: python tools/cli_latency.py"""
 import sys, subprocess, time, os
 sys.path.insert(0, os.getcwd())
-from radiosonde_auto_rx_amd import synth
+from tools import synth
 x = synth.rs41_capture(sr=48000, seconds=3.3, fq=0.0, n_frames=3, t_first=0.15, seed=5).tobytes()
 for name, cmd in (("rs41mod 48k IQ", ["host/bin/rs41mod", "--ptu2", "--json", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"]),
                   ("dft_detect 48k IQ", ["host/bin/dft_detect", "-t", "2", "--iq", "--bw", "15", "--dc", "-", "48000", "16"])):

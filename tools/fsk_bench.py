@@ -3,7 +3,7 @@ import sys, time
 import numpy as np
 import torch
 sys.path.insert(0, ".")
-from radiosonde_auto_rx_amd import synth
+from tools import synth
 from radiosonde_auto_rx_amd.fsk import FskModem
 from radiosonde_auto_rx_amd.scan import Scanner, IFIQ
 

@@ -208,6 +208,8 @@ def diag_finish(rb):
           f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
           "s_mov_b64 exec, -1", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], -1"]
     if "nostore" in EXP: L = [l for l in L if not l.startswith("global_store")]
+    if "sc1store" in EXP: L = [l + " sc1" if l.startswith("global_store") else l for l in L]
+    if "sc01store" in EXP: L = [l + " sc0 sc1" if l.startswith("global_store") else l for l in L]
     return L
 
 

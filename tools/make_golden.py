@@ -13,7 +13,7 @@ import json, os, subprocess, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import bind
-from radiosonde_auto_rx_amd import synth
+from tools import synth
 
 CASES = {
     # name: capture kwargs (+ window of IF samples kept for the stream fixtures)

@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 sys.path.insert(0, ".")
-from radiosonde_auto_rx_amd import synth
+from tools import synth
 from radiosonde_auto_rx_amd.scan import Scanner, BBIQ, IFIQ, TYPES
 from oracle import bind
 
