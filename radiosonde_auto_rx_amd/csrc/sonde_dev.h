@@ -91,6 +91,7 @@ struct CorrArgs {
     const SyncState *state;   // per-channel sync state for skipping tiles no window can reach (nullptr = compute all)
     const uint32_t *start;    // --dc restart: positions below start[ch] are unchanged (nullptr = off)
     int delay; uint32_t frame_samples;
+    uint32_t limit;           // != 0: only end positions less than `limit` behind the first one the sync can examine (pass 1 of two)
     int n_ch, ring_len, n, L; uint32_t m0;
     // factorised form (integer samples/symbol): ntypes == 0 selects the direct L-tap kernel
     int ntypes, isps, nsym;
@@ -122,6 +123,7 @@ struct SyncArgs {
     float match_sum;
     const float *fm, *corr2; float2 *ifiq;
     AfcState *afc; uint32_t *start; unsigned *pending;
+    uint32_t corr_limit;      // != 0: pass 1 of two — `corr` holds CorrArgs.limit end positions behind the state's first one; stop there
 };
 
 extern "C" {

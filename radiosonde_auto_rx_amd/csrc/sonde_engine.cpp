@@ -54,6 +54,7 @@ struct sonde_engine {
     float2 *d_ptail[2] = { nullptr, nullptr }; int ptail_cur = 0;
     float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr, *d_raw = nullptr;
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
+    uint32_t corr_limit = 0;                       // pass 1 of the two correlation / sync passes of a call
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr, *d_soft1 = nullptr;
     uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
@@ -609,6 +610,16 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     } else {
         if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
         if (!fe) {
+            // two passes (corr_tile_unused in sonde_kernels.hip): correlate what two search windows can reach, sync up to there, then the
+            // rest with the state that is known by then — nothing at all for a channel whose new frame covers the rest of the call
+            static const bool one_pass = getenv("SONDE_CORR_ONEPASS") != nullptr;         // A/B aid
+            const uint32_t lim = (!one_pass && n_if > 3 * e->info.K) ? (uint32_t)(2 * e->info.K + 64) : 0u;
+            if (lim) {
+                c.limit = lim; e->corr_limit = lim;
+                prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
+                launch_framesync(e, 0);
+                c.limit = 0; e->corr_limit = 0;
+            }
             prof_begin(e, "header_corr", e->stream_b); sonde_launch_header_corr(&c, e->stream_b); prof_end(e, e->stream_b);
             launch_framesync(e, 0);
         }
@@ -634,6 +645,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.opt_auto = e->cfg.opt_auto != 0 || e->cfg.sonde_type == SONDE_M10 || e->cfg.sonde_type == SONDE_M20;      // M10: either polarity (differential coding)
     s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
+    s.corr_limit = e->corr_limit;
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }
 

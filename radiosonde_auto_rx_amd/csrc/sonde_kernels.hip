@@ -903,15 +903,24 @@ void k_if_chain(const IfArgs a) {
 // The reference correlates only while find_header() runs: not during the nbits a framer slices after a hit, and a
 // window only reaches back K+delay samples.  The channel's sync state (left by the previous k_framesync) gives the
 // first end position any future window can examine; correlation tiles entirely below it are skipped.
-__device__ __forceinline__ bool corr_tile_unused(const CorrArgs &a, int ch, uint32_t tile_end) {
+// Two passes per call (sonde_engine.cpp): a sonde that is being received spends 85 % of the time inside a frame, where no window is
+// examined — but WHERE the next frame starts is only known once the sync has run.  Pass 1 correlates the `limit` samples behind
+// `first` (two windows) and the sync stops at that horizon (sync_corr_horizon); pass 2 repeats both with the state pass 1 left: for a
+// channel that found its header, everything up to the end of the new frame is now skipped; a channel that is still searching gets
+// the rest of the call.  Same decisions as one pass (the sync is resumable at any sample — it is how calls are chained anyway).
+__device__ __forceinline__ uint32_t sync_first_pos(const SyncState &st, uint32_t frame_samples, int delay) {
+    uint32_t first;                                           // earliest candidate end position of the next window
+    if (st.mode == 1) first = st.mv_pos + 1 + frame_samples;                    // s_in_after - delay (frame in progress)
+    else first = st.s_in - st.k;                                                // window start of the running search
+    return first - (uint32_t)(delay + 16);
+}
+__device__ __forceinline__ bool corr_tile_unused(const CorrArgs &a, int ch, uint32_t tile_start, uint32_t tile_end) {
     if (a.start && (int32_t)(tile_end - a.start[ch]) <= 0) return true;        // --dc restart: bufs below start[ch] did not change
     if (!a.state) return false;
     const SyncState st = a.state[ch];
-    uint32_t first;                                           // earliest candidate end position of the next window
-    if (st.mode == 1) first = st.mv_pos + 1 + a.frame_samples;                  // s_in_after - delay (frame in progress)
-    else if (st.mode == 0) first = st.s_in - st.k;                              // window start of the running search
-    else return true;                                                           // stream finished
-    first -= (uint32_t)(a.delay + 16);
+    if (st.mode != 0 && st.mode != 1) return true;                              // stream finished
+    const uint32_t first = sync_first_pos(st, a.frame_samples, a.delay);
+    if (a.limit && (int32_t)(tile_start - (first + a.limit)) >= 0) return true; // pass 1: beyond the horizon
     return (int32_t)(tile_end - first) <= 0;
 }
 
@@ -925,7 +934,7 @@ void k_header_corr(const CorrArgs a) {
     const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HC_TILE;
     const int nout = min(HC_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
     if (nout <= 0) return;
-    if (corr_tile_unused(a, ch, p0 + (uint32_t)nout)) return;
+    if (corr_tile_unused(a, ch, p0, p0 + (uint32_t)nout)) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     float *sx = smem;                 // [HC_TILE + L - 1]
     float *sm = smem + HC_TILE + L;   // [L]
@@ -968,7 +977,7 @@ void k_header_corr_fact(const CorrArgs a) {
     const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HCF_TILE;
     const int nout = min(HCF_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
     if (nout <= 0) return;
-    if (corr_tile_unused(a, ch, p0 + (uint32_t)nout)) return;
+    if (corr_tile_unused(a, ch, p0, p0 + (uint32_t)nout)) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const int nx = HCF_TILE + L - 1;                 // samples p0-(L-1) .. p0+HCF_TILE-1
     const int nf = (HCF_TILE + sps * (nsym - 1) + 3) & ~3;   // F entries per type (multiple of 4)
@@ -1200,6 +1209,9 @@ void k_framesync(const SyncArgs a) {
     if (tid < 512) s_exp[tid] = a.gf_exp[tid];
     if (tid < 256) s_log[tid] = a.gf_log[tid];
     __syncthreads();
+    // pass 1 of two: the correlation ring is valid below this end position only (corr_tile_unused with the same state and limit)
+    const bool horizon_on = a.corr_limit != 0 && (st.mode == 0 || st.mode == 1);
+    const uint32_t horizon = horizon_on ? sync_first_pos(st, a.frame_samples, a.delay) + a.corr_limit : 0u;
 
     // every pass consumes a window (K-4 samples) or a frame, or ends at `avail`: the bound only guards against a corrupted state
     for (int guard = 0; guard < (1 << 20); guard++) {
@@ -1209,6 +1221,7 @@ void k_framesync(const SyncArgs a) {
             const uint32_t need = (uint32_t)(K - 4) - st.k;
             const uint32_t s_in_w = st.s_in + need;
             if ((int32_t)(avail - s_in_w) < 0) { st.k += avail - st.s_in; st.s_in = avail; break; }
+            if (horizon_on && (int32_t)(s_in_w - 1 - (uint32_t)a.delay - horizon) >= 0) break;      // this window is pass 2's
             st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
             const uint32_t pos = s_in_w - 1 - (uint32_t)a.delay;      // sample_out
             if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
