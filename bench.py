@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the RS41 `--IQ fq --lpIQ` hot path on MI355X (BASELINE.json metric).
+"""bench.py — throughput of the radiosonde hot path on MI355X (BASELINE.json metric), one JSON line per run.
 
-One step = one pass of the whole hot path (mix+decimate -> IF chain -> header correlation -> framesync ->
-frame fetch + RS ECC) over one batch of synthetic input: CHANNELS channels x 1 s of 2.4 Msps cs16 IQ per GPU,
-already resident in HBM.  Workload = BASELINE.json configs[1] (single RS41 channel, 2.4 Msps cs16) batched to
-the per-GPU share of configs[4] (4096 channels / 8 GPUs = 512 per GPU).  Channels shard across ranks with no
-data-path collective; one small all_gather of per-channel detection summaries per step.
+  --config demod (default, the headline; BASELINE configs[1] batched to the per-GPU share of configs[4])
+      One step = the whole RS41 `--IQ fq --lpIQ` path (mix + decimate -> IF chain -> header correlation -> frame sync -> frame fetch
+      + RS ECC) over CHANNELS channels x 1 s of 2.4 Msps cs16 IQ per GPU, resident in HBM.  Channels shard across ranks with no
+      data-path collective; the per-channel detection summaries (32 B, written by the frame-sync kernel) are all_gathered from device
+      memory once per step.  Extra objects: `detect` (the dft_detect scanner over the same channels, not part of
+      `value`), `pcie_inclusive` (the same steps fed from pinned host memory, never `value`).
+  --config scan_wide (BASELINE configs[2]): 256 channels out of ONE 10 Msps stream -> dft_detect scanner, per 0.2 s of stream.
+  --config fsk_mixed (BASELINE configs[3]): 1024 mixed RS41 / DFM09 / M10 channels through the 2-FSK modem (fsk_demod path).
 
-  python bench.py --gpus 1 --steps 10 --warmup 3
+  python bench.py --gpus 1 [--config demod] [--steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 from __future__ import annotations
@@ -27,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 SR = 2_400_000
 BANK = 8                 # unique synthetic captures tiled over the channels
+PROFILE_TAG = "r2"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
 
 
 def make_bank(seconds: float = 1.0):
@@ -41,7 +45,23 @@ def make_bank(seconds: float = 1.0):
     return fqs, caps
 
 
-def cpu_baseline(fqs, caps, budget_s: float = 15.0):
+def _time_reference(cmds, inputs, units_per_pass, unit, what, budget_s=15.0):
+    """ncores concurrent reference processes (oracle/_ref) fed from files, repeated for ~budget_s"""
+    ncores = len(cmds)
+    reps, t0, total, out_bytes = 0, time.perf_counter(), 0.0, 0
+    while time.perf_counter() - t0 < budget_s:
+        procs = [subprocess.Popen(c, stdin=open(i, "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for c, i in zip(cmds, inputs)]
+        for pr in procs:
+            out, _ = pr.communicate()
+            out_bytes += len(out)
+        total += ncores * units_per_pass
+        reps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=total / dt / 1e6, unit=unit, cores=ncores, kind="reference", per_core=total / dt / 1e6 / ncores,
+                sample=f"{ncores} concurrent reference {what} x {reps} passes", stdout_bytes=out_bytes)
+
+
+def cpu_baseline_demod(fqs, caps, budget_s: float = 15.0):
     """Reference rs41mod (oracle/_ref, built from /root/reference) timed on this host's cores; falls back to the
     single-threaded CPU restatement (oracle/liboracle.so) when the compiled reference is absent."""
     from oracle import bind
@@ -59,27 +79,14 @@ def cpu_baseline(fqs, caps, budget_s: float = 15.0):
             exe = os.path.join(bind.REFDIR, "rs41mod")
             for p in paths:                      # page cache
                 open(p, "rb").read()
-            reps, t0, total, frames = 0, time.perf_counter(), 0, 0
-            while time.perf_counter() - t0 < budget_s:
-                procs = []
-                for k in range(ncores):
-                    b = k % len(paths)
-                    procs.append(subprocess.Popen([exe, "-r", "--ecc2", "--crc", "--IQ", repr(fqs[b]), "--lpIQ", "-", str(SR), "16"],
-                                                  stdin=open(paths[b], "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
-                for pr in procs:
-                    out, _ = pr.communicate()
-                    frames += out.count(b"[OK]")
-                total += ncores * secs * SR
-                reps += 1
-            dt = time.perf_counter() - t0
-        return dict(value=total / dt / 1e6, unit="Msamples/s", cores=ncores, kind="reference",
-                    per_core=total / dt / 1e6 / ncores, frames_ok=frames,
-                    sample=f"{ncores} concurrent reference rs41mod processes (-O3, demod_mod.o -Ofast) x {reps} passes over "
-                           f"{secs} s of the same 2.4 Msps cs16 RS41 captures")
+            cmds = [[exe, "-r", "--ecc2", "--crc", "--IQ", repr(fqs[k % len(paths)]), "--lpIQ", "-", str(SR), "16"] for k in range(ncores)]
+            r = _time_reference(cmds, [paths[k % len(paths)] for k in range(ncores)], secs * SR, "Msamples/s",
+                                f"rs41mod processes (-O3, demod_mod.o -Ofast) over {secs} s of the same 2.4 Msps cs16 RS41 captures", budget_s)
+        return r
     t0 = time.perf_counter()
     n, total = 0, 0
     while time.perf_counter() - t0 < budget_s:
-        o = bind.ora_rs41_decode(caps[n % BANK], SR, fq=fqs[n % BANK], want_soft=False)
+        bind.ora_rs41_decode(caps[n % BANK], SR, fq=fqs[n % BANK], want_soft=False)
         total += len(caps[n % BANK]) // 2
         n += 1
     dt = time.perf_counter() - t0
@@ -87,76 +94,106 @@ def cpu_baseline(fqs, caps, budget_s: float = 15.0):
                 sample=f"{n} x 1 s 2.4 Msps cs16 RS41 captures through the single-threaded CPU restatement (oracle/)")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=int(os.environ.get("SONDE_BENCH_CHANNELS", "512")), help="channels per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lag", type=int, default=0, help="1 = frame fetch one step behind (see step())")
-    ap.add_argument("--two-streams", action="store_true", help="with --lag 1: IF-rate kernels on a second HIP stream")
-    args = ap.parse_args()
+def _traffic(name, algorithmic_bytes):
+    """HBM traffic of the dominant kernel: it cannot be sampled from inside the process — quoted from the committed rocprofv3 --pmc
+    summary of this same command (tools/profile_round.sh) when that was taken on the same launch geometry"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}_traffic.json")))
+        if tj["algorithmic_bytes"] == algorithmic_bytes:
+            return round(tj["traffic_bytes"] / 1e9, 3), f"GB per launch, (2 x FETCH_SIZE + WRITE_SIZE) from profiles/{PROFILE_TAG}_{name}_traffic.json (rocprofv3 --pmc)"
+    except Exception:
+        pass
+    return None, None
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libsonde_hip has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
+class Dist:
+    """torch.distributed as the driver launches it (one rank per GPU, RCCL), or a single process"""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (libsonde_hip has no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def finish_times(self, dt):
+        """(max over ranks, per-rank list)"""
+        from radiosonde_auto_rx_amd import shard
+        if not self.dist:
+            return dt, [dt]
+        per = shard.gather_floats(self.dist, dt, self.world, self.dev)
+        return max(per), per
+
+    def sum_ints(self, *vals):
+        if not self.dist:
+            return vals
+        t = self.torch.tensor(list(vals), device=self.dev, dtype=self.torch.int64)
+        self.dist.all_reduce(t)
+        return tuple(int(v) for v in t)
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def bench_demod(args, D: Dist):
+    torch = D.torch
     from radiosonde_auto_rx_amd.engine import Engine
     from radiosonde_auto_rx_amd import shard
-    C = args.channels
+    C = args.channels or int(os.environ.get("SONDE_BENCH_CHANNELS", "512"))
+    steps = args.steps or 1200                                              # ~2 s of GPU time: long enough for the driver's busy sampler
+    warmup = 3 if args.warmup is None else args.warmup
     fqs, caps = make_bank()
-    ch_fq = [fqs[(c + rank) % BANK] for c in range(C)]
-    bank_t = torch.from_numpy(np.stack(caps)).to(dev)                     # [BANK, 2*SR] int16
-    idx = torch.tensor([(c + rank) % BANK for c in range(C)], device=dev)
+    ch_fq = [fqs[(c + D.rank) % BANK] for c in range(C)]
+    bank_t = torch.from_numpy(np.stack(caps)).to(D.dev)                     # [BANK, 2*SR] int16
+    idx = torch.tensor([(c + D.rank) % BANK for c in range(C)], device=D.dev)
     iq = bank_t.index_select(0, idx).contiguous()                         # [C, 2*SR] resident input
     del bank_t
     torch.cuda.synchronize()
 
-    eng = Engine(ch_fq, SR, device=local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=(args.lag > 0 and args.two_streams))
-    summary = torch.zeros(C, 4, device=dev)
+    eng = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=(args.lag > 0 and args.two_streams))
+    summary = shard.summary_buffer(C, D.dev)                              # written by the frame-sync kernel, gathered from device memory
+    eng.set_summary(summary.data_ptr(), D.rank * C)
+    gathered = [torch.empty_like(summary) for _ in range(D.world)] if D.dist else None
 
     # Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): one
     # untimed lead-in call up to the last short boundary, after which every 1 s step is exactly one segment.
-    lead = 0
     while eng.samples_to_dc_boundary() < SR:
-        n = eng.samples_to_dc_boundary()
-        eng.process_device(iq.data_ptr(), SR, n)
-        lead += n
+        eng.process_device(iq.data_ptr(), SR, eng.samples_to_dc_boundary())
     eng.fetch_frames_np()
 
     def step(lag=args.lag):
-        # lag = 0: every step waits for its own frames (kernel times below are then un-overlapped and the roofline
-        # figure of k_mix_decimate is clean).  lag = 1 pipelines: the IF-rate kernels of call k (stream B) overlap the
-        # decimator of call k+1 (stream A) — ~4 % more throughput, but per-kernel event times include the overlap.
+        # lag = 0: every step waits for its own frames (kernel times are then un-overlapped and the roofline figure of
+        # k_mix_decimate is clean).  lag = 1 pipelines: the IF-rate kernels of call k (stream B) overlap the decimator of call k+1.
         eng.process_device(iq.data_ptr(), SR, SR)
         frames = eng.fetch_frames_np(lag=lag)                             # D2H of frame records + host RS ECC
-        if world > 1:                                                     # per-channel detection summaries over RCCL
-            summary.copy_(torch.from_numpy(shard.summarize(frames, C)))
-            shard.gather_summaries(dist, summary, world)
+        if D.dist:
+            shard.gather_summaries(D.dist, summary, D.world, gathered)    # 32 B per channel over RCCL, device to device
         return frames
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     eng.fetch_frames_np(lag=0)
-    eng.profile(int(os.environ.get("SONDE_BENCH_PROF", "2")))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    eng.profile(1)                      # timed region: HIP events around the dominant kernel only (2 events per step)
+    D.barrier()
     t0 = time.perf_counter()
     nframes, nok = 0, 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         fr = step()
         nframes += len(fr)
         nok += int((fr["ecc"] >= 0).sum())
@@ -164,57 +201,129 @@ def main():
     nframes += len(fr)
     nok += int((fr["ecc"] >= 0).sum())
     eng.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        dt = shard.max_over_ranks(dist, dt, dev)
-        cnt = torch.tensor([nframes, nok], device=dev, dtype=torch.int64)
-        dist.all_reduce(cnt)
-        nframes, nok = int(cnt[0]), int(cnt[1])
-
+    D.barrier()
+    dt_local = time.perf_counter() - t0
+    dt, per_rank = D.finish_times(dt_local)
+    nframes, nok = D.sum_ints(nframes, nok)
     md_ms, md_n = eng.kernel_ms("mix_decimate")
-    kern = {k: eng.kernel_ms(k) for k in ("mix_decimate", "if_chain", "header_corr", "framesync")}
-    total_samples = world * C * SR * args.steps
+
+    # untimed: per-kernel table of a step (events around every kernel cost ~0.1 ms of host time per step, so not in the timed region)
+    eng.profile(2)
+    nprof = 5
+    for _ in range(nprof):
+        step(lag=0)
+    kern = {}
+    for k in ("mix_decimate", "if_chain", "header_corr", "framesync"):
+        ms, n = eng.kernel_ms(k)
+        kern[k] = dict(ms_per_step=round(ms * n / nprof, 4), launches_per_step=n / nprof)
+    eng.profile(0)
+    rec = shard.decode_summaries(summary)
+    total_samples = D.world * C * SR * steps
     value = total_samples / dt / 1e6
     # dominant kernel = k_mix_decimate: algorithmic bytes = 4 B per complex cs16 sample;
-    # per-step launches differ in size (IQ-DC segment edges) so the rate is (bytes of all launches)/(time of all launches)
+    # per-step launches may differ in size (IQ-DC segment edges) so the rate is (bytes of all launches)/(time of all launches)
     md_total_s = md_ms * md_n / 1e3
-    achieved = (C * SR * args.steps * 4) / md_total_s / 1e9 if md_total_s > 0 else 0.0
-    # HBM traffic of the dominant kernel comes from rocprofv3 PMC passes of this same command (it cannot be sampled from
-    # inside the process); the committed summary is quoted when it was taken on the same launch geometry.
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_mix_decimate_traffic.json")))
-        if tj["algorithmic_bytes"] == C * SR * 4:
-            traffic = round(tj["traffic_bytes"] / 1e9, 3)
-            traffic_src = "GB per launch, (2 x FETCH_SIZE + WRITE_SIZE) from profiles/r1_mix_decimate_traffic.json (rocprofv3 --pmc)"
-    except Exception:
-        pass
-    if rank == 0:
+    achieved = (C * SR * steps * 4) / md_total_s / 1e9 if md_total_s > 0 else 0.0
+    traffic, traffic_src = _traffic("mix_decimate", C * SR * 4)
+    out = None
+    if D.rank == 0:
         out = {
             "metric": "IQ Msamples/s (RS41 --IQ --lpIQ demod + framesync + ECC), concurrent real-time 2.4 Msps channels = value/2.4",
-            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RS41 2.4 Msps cs16 IQ, rs41mod --ecc2 --IQ fq --lpIQ (BASELINE configs[1]) x %d channels per GPU "
                                    "(per-GPU share of configs[4]), 1 s of signal per channel per step" % C,
                        "channels_per_gpu": C, "samples_per_channel_per_step": SR, "realtime_channels": round(value / 2.4, 1),
-                       "frames_decoded": nframes, "frames_ecc_ok": nok,
-                       "kernel_ms_avg": {k: round(v[0], 4) for k, v in kern.items()},
-                       "kernel_launches": {k: v[1] for k, v in kern.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_mix_decimate", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                       "frames_decoded": nframes, "frames_ecc_ok": nok, "timed_seconds": round(dt, 3),
+                       "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank],
+                       "summary_records": {"bytes_per_channel": shard.SUMMARY_BYTES, "channels_with_frames": int((rec["frames"] > 0).sum()),
+                                           "frames_clean_on_device": int(rec["frames_clean"].sum())},
+                       "kernels": kern},
+            "roofline": {"bound": "hbm", "kernel": "k_mix_decimate50", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_src,
-                         "algorithmic_gb_per_launch": round(C * SR * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4),
-                         "note": "achieved = 4 B x complex samples of all timed k_mix_decimate launches / their HIP-event time on the engine stream"},
+                         "algorithmic_gb_per_launch": round(C * SR * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4), "launches": md_n,
+                         "note": "achieved = 4 B x complex samples of all timed k_mix_decimate50 launches / their HIP-event time on the engine stream"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fqs, caps)
-        print(json.dumps(out), flush=True)
+    # ---- extras on one GPU (never part of `value`)
+    if D.world == 1 and not args.no_extras:
+        out["detect"] = detect_extra(D, iq, ch_fq, C)
+        out["pcie_inclusive"] = pcie_extra(D, eng, iq, C)
+    eng.set_summary(0)
     eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+    if D.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_demod(fqs, caps)
+    return out
+
+
+def detect_extra(D: Dist, iq, ch_fq, C):
+    """The scanner (the reference's dft_detect, `--IQ fq --dc`) over the first second of every channel of the demodulator batch:
+    what the detect stage of configs[4] costs when it runs.  In auto_rx a channel is scanned BEFORE a decoder is started for it, not
+    beside the decoder (scan.py vs decode.py), so this is a separate figure, not a term of the step."""
+    torch = D.torch
+    from radiosonde_auto_rx_amd.scan import Scanner
+    nch = min(C, 256)
+    sc = Scanner(SR, fq=ch_fq[:nch], dc=True, cont=True, max_chunk=SR, device=D.local_rank)
+    sub = iq[:nch].contiguous()
+    sc.process_device(sub.data_ptr(), SR, SR)
+    sc.fetch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    found = 0
+    for _ in range(reps):
+        sc.process_device(sub.data_ptr(), SR, SR)
+        found += sum(1 for d in sc.fetch() if d["type"] == "RS41")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    sc.close()
+    return dict(channels=nch, ms_per_channel_second=round(dt * 1e3 / nch, 4), msamples_per_s=round(nch * SR / dt / 1e6, 1),
+                rs41_detections_per_pass=found / reps,
+                note="dft_detect scanner (front end + 14 templates) over 1 s of each channel; scanned before decoding starts, not per step")
+
+
+def pcie_extra(D: Dist, eng, iq, C):
+    """the same step fed from pinned host memory (process_host: H2D copy, then the kernels): bounded by PCIe, never `value`"""
+    torch = D.torch
+    nch = C
+    host = torch.empty((nch, 2 * SR), dtype=torch.int16).pin_memory()
+    host.copy_(iq[:nch])
+    arr = host.numpy()
+    eng.process_host(arr)
+    eng.fetch_frames_np()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        eng.process_host(arr)
+        eng.fetch_frames_np()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=round(nch * SR / dt / 1e6, 1), unit="Msamples/s", ms_per_step=round(dt * 1e3, 3), realtime_channels=round(nch * SR / dt / 2.4e6, 1),
+                note="process_host from pinned memory, copy and kernels of one call in sequence (no double buffering)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="demod", choices=["demod", "scan_wide", "fsk_mixed"])
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (0 = the configuration's own)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="demod: skip the detect / PCIe-inclusive extras")
+    ap.add_argument("--lag", type=int, default=0, help="demod: 1 = frame fetch one step behind")
+    ap.add_argument("--two-streams", action="store_true", help="demod, with --lag 1: IF-rate kernels on a second HIP stream")
+    args = ap.parse_args()
+    D = Dist()
+    if args.config == "demod":
+        out = bench_demod(args, D)
+    else:
+        import bench_configs
+        out = bench_configs.run(args, D)
+    if D.rank == 0:
+        print(json.dumps(out), flush=True)
+    D.close()
 
 
 if __name__ == "__main__":

@@ -177,6 +177,26 @@ int  sonde_engine_sync(sonde_engine_t *e);
  * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
  * Returns the number of frames written (<= max).  Frames of one channel come in stream order; the order between
  * channels that completed a frame in the same process call is unspecified (sonde_frame_t.channel tells them apart). */
+/* Per-channel detection summary: the ONLY data that crosses GPUs when channels are sharded over a node — 32 bytes per
+ * channel, written by the frame-sync kernel at every frame it emits and left in device memory, so the all_gather (RCCL over xGMI) runs
+ * on the device buffer without a host round trip.  sample_pos = IF-rate sample index of the header's last sample (64 bit).  frames /
+ * frames_clean are cumulative: frames emitted and, of those, frames whose RS syndromes were all zero on the device (no host ECC
+ * needed; RS41 only).  reference: the per-sonde process of auto_rx prints this information per frame (rs41mod.c:2530-2545). */
+typedef struct {
+    uint32_t channel_id;     /* global channel number: summary_base + channel within the engine                  */
+    uint8_t  type;           /* SONDE_RS41 / SONDE_DFM09 / ... (cfg.sonde_type)                                   */
+    uint8_t  inverted;       /* header found with negative polarity                                               */
+    uint16_t reserved;
+    float    score;          /* header correlation of the last frame (mv, demod_mod.c:222)                        */
+    float    freq_offset_hz; /* --dc: accumulated AFC offset Df; else 0                                          */
+    uint64_t sample_pos;
+    uint32_t frames;
+    uint32_t frames_clean;
+} sonde_summary_t;
+/* The engine writes its channels' records to `d_summary` (device memory, n_channels records, zeroed by the caller) from now on;
+ * channel_id starts at `channel_base`.  NULL switches the records off. */
+int  sonde_engine_set_summary(sonde_engine_t *e, void *d_summary, uint32_t channel_base);
+
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
 /* 1 if the device-side frame queue (cfg.max_frames) overflowed since the last call of this function — the oldest frames were then
  * overwritten before a fetch could read them; the fetch functions themselves return the number of frames they delivered. */

@@ -3,6 +3,7 @@
 #define SONDE_DEV_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/sonde_hip.h"
 
 struct MixDecArgs {
     const int16_t *iq;        // [n_ch][ch_stride] complex int16
@@ -123,6 +124,7 @@ struct SyncArgs {
     float match_sum;
     const float *fm, *corr2; float2 *ifiq;
     AfcState *afc; uint32_t *start; unsigned *pending;
+    sonde_summary_t *summary; uint32_t summary_base; int summary_type; uint64_t summary_epoch;      // nullable: per-channel summary records
     uint32_t corr_limit;      // != 0: pass 1 of two — `corr` holds CorrArgs.limit end positions behind the state's first one; stop there
 };
 

@@ -55,6 +55,7 @@ struct sonde_engine {
     float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr, *d_raw = nullptr;
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
     uint32_t corr_limit = 0;                       // pass 1 of the two correlation / sync passes of a call
+    sonde_summary_t *d_summary = nullptr; uint32_t summary_base = 0;      // caller-owned device buffer (sonde_engine_set_summary)
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr, *d_soft1 = nullptr;
     uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
@@ -646,6 +647,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     s.corr_limit = e->corr_limit;
+    s.summary = e->d_summary; s.summary_base = e->summary_base; s.summary_type = e->cfg.sonde_type; s.summary_epoch = e->samples_in / (uint64_t)std::max(1, e->info.decM);     // IF samples produced so far, 64 bit
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }
 
@@ -710,6 +712,12 @@ static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int la
     }
     e->last_n = n;
     return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
+}
+
+int sonde_engine_set_summary(sonde_engine_t *e, void *d_summary, uint32_t channel_base) {
+    if (!e) return SONDE_E_ARG;
+    e->d_summary = (sonde_summary_t *)d_summary; e->summary_base = channel_base;
+    return 0;
 }
 
 int sonde_engine_overflowed(sonde_engine_t *e) {

@@ -1403,6 +1403,15 @@ void k_framesync(const SyncArgs a) {
             if (tid < 518) rec->frame[tid] = s_frame[tid];
             if (a.rs41 && tid < 48) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][tid]; rec->synd[tid] = syn; }
             if (tid == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok; }
+            if (a.summary && tid == 0) {                              // per-channel detection summary, stays on the device
+                bool clean = a.rs41 != 0;
+                if (a.rs41) for (int k = 0; k < 48; k++) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][k]; clean &= (syn == 0); }
+                sonde_summary_t *sm = a.summary + ch;
+                sm->channel_id = a.summary_base + (uint32_t)ch; sm->type = (uint8_t)a.summary_type; sm->inverted = (uint8_t)(st.mv < 0.f);
+                sm->score = st.mv; sm->freq_offset_hz = DC ? (float)af.Df : 0.f;
+                sm->sample_pos = a.summary_epoch - (uint64_t)(uint32_t)((uint32_t)a.summary_epoch - st.mv_pos);     // mv_pos is the low half of a 64-bit index
+                sm->frames += 1; sm->frames_clean += clean ? 1u : 0u;
+            }
             __syncthreads();
             if (!enough) { st.mode = 2; st.s_in = avail; break; }
             st.s_in = s_in_after; st.k = 0; st.mode = 0;

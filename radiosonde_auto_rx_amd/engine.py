@@ -199,6 +199,11 @@ class Engine:
         _chk(lib().sonde_engine_sync(self._h))
 
     # -- output ------------------------------------------------------------------------------
+    def set_summary(self, device_ptr: int, channel_base: int = 0):
+        """Per-channel detection summaries (sonde_summary_t, 32 B each) are written into this device buffer from now on
+        (radiosonde_auto_rx_amd.shard.summary_buffer); 0 switches them off."""
+        _chk(lib().sonde_engine_set_summary(self._h, C.c_void_p(device_ptr), channel_base))
+
     def overflowed(self) -> bool:
         """True if the device-side frame queue overflowed since the last call (oldest frames overwritten before a fetch read them);
         the fetch_* methods return what they could read either way"""

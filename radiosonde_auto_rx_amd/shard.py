@@ -1,16 +1,20 @@
 """Channel sharding across the GPUs of one node.
 
-Channels are independent (no cross-channel state anywhere in demod_mod.c / fsk.c / dft_detect.c), so rank r of
-world w simply owns a contiguous block of channels and runs the whole detect -> demod -> sync -> ECC path for
-them.  The only exchange is a fixed-size per-channel detection summary per step, all-gathered over
-torch.distributed (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests): <= 4096 x 16 B,
-latency-bound.  No data-path collective exists.
+Channels are independent (no cross-channel state anywhere in demod_mod.c / fsk.c / dft_detect.c), so rank r of world w owns a
+contiguous block of channels and runs the whole detect -> demod -> sync -> ECC path for them.  The only exchange is the fixed-size
+per-channel detection summary (sonde_summary_t, 32 bytes, include/sonde_hip.h): the frame-sync kernel writes the records into a
+device buffer of the caller — here a torch tensor — and one all_gather per step over torch.distributed moves them (backend "nccl" =
+RCCL over xGMI on the GPU node, "gloo" in the CPU tests): <= 4096 x 32 B, latency-bound, no host round trip.  No data-path
+collective exists.
 """
 from __future__ import annotations
 
 import numpy as np
 
-SUMMARY_FIELDS = ("detected", "score", "pos_lo16", "ecc")   # float32 x 4 per channel
+SUMMARY_BYTES = 32
+SUMMARY_DTYPE = np.dtype([("channel_id", "<u4"), ("type", "u1"), ("inverted", "u1"), ("reserved", "<u2"), ("score", "<f4"),
+                          ("freq_offset_hz", "<f4"), ("sample_pos", "<u8"), ("frames", "<u4"), ("frames_clean", "<u4")])
+assert SUMMARY_DTYPE.itemsize == SUMMARY_BYTES
 
 
 def channel_block(n_total: int, rank: int, world: int) -> range:
@@ -20,22 +24,25 @@ def channel_block(n_total: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
-def summarize(frames: np.ndarray, n_local: int) -> np.ndarray:
-    """[n_local, 4] float32 summary from a structured sonde_frame_t array (last frame of a channel wins)."""
-    s = np.zeros((n_local, 4), np.float32)
-    if len(frames):
-        ch = frames["channel"]
-        s[ch, 0] = 1.0
-        s[ch, 1] = frames["mv"]
-        s[ch, 2] = (frames["mv_pos"] % 65536).astype(np.float32)
-        s[ch, 3] = frames["ecc"]
-    return s
-
-
-def gather_summaries(dist, local, world: int):
-    """all_gather of equal-sized per-rank summary tensors -> list ordered by rank (global channel order)."""
+def summary_buffer(n_local: int, device):
+    """Zeroed [n_local, 32] uint8 tensor for Engine.set_summary(): the frame-sync kernel fills it in place."""
     import torch
-    out = [torch.zeros_like(local) for _ in range(world)]
+    return torch.zeros(n_local, SUMMARY_BYTES, dtype=torch.uint8, device=device)
+
+
+def decode_summaries(t) -> np.ndarray:
+    """tensor(s) of records -> structured numpy array (host copy; for checks and reports, not part of the data path)"""
+    import torch
+    if isinstance(t, (list, tuple)):
+        t = torch.cat(list(t), 0)
+    return t.detach().cpu().numpy().reshape(-1, SUMMARY_BYTES).view(SUMMARY_DTYPE).reshape(-1)
+
+
+def gather_summaries(dist, local, world: int, out=None):
+    """all_gather of equal-sized per-rank summary tensors (device resident) -> list ordered by rank = global channel order."""
+    import torch
+    if out is None:
+        out = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(out, local)
     return out
 
@@ -45,3 +52,11 @@ def max_over_ranks(dist, value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(dist, value: float, world: int, device) -> list:
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
