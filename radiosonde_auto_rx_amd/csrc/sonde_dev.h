@@ -87,6 +87,27 @@ struct SyncState {
     uint32_t pad[2];
 };
 
+// Header search with the reference's own transform (getCorrDFT, demod_mod.c:148-225) instead of a time-domain correlation ring:
+// k_sync_plan lists, per channel, the next windows its sync state will examine; k_sync_window_fft evaluates each one exactly as
+// the reference does (window -> dft_raw -> X * Fm -> dft_raw of the conjugate -> first maximum of re^2 -> norm); k_framesync
+// consumes the results in order and stops where they end.  The twiddle recurrence of dft_raw drifts by ~1e-4, and which of two
+// almost equal neighbouring maxima wins depends on that drift: only the same arithmetic reproduces the reference's mv_pos.
+struct WinItem {
+    uint32_t pos;             // sample_out of the window
+    int32_t  state;           // 0 unused, 1 planned, 2 evaluated
+    int32_t  rc;              // peak index (>= 0) or -4 (edge value)
+    float    mv; uint32_t mpos;
+    uint32_t pad[3];
+};
+struct WinPlanArgs {
+    const SyncState *state; WinItem *items;
+    int n_ch, stride, W, K, L, delay; uint32_t frame_samples, avail;    // table of `stride` slots per channel, this round fills the first W
+};
+struct WinFftArgs {
+    const float *bufs; WinItem *items; const float2 *Fm, *tws;
+    int n_ch, stride, W, K, L, ring_len;
+};
+
 struct CorrArgs {
     const float *bufs; float *corr; const float *match;
     const SyncState *state;   // per-channel sync state for skipping tiles no window can reach (nullptr = compute all)
@@ -125,6 +146,7 @@ struct SyncArgs {
     const float *fm, *corr2; float2 *ifiq;
     AfcState *afc; uint32_t *start; unsigned *pending;
     sonde_summary_t *summary; uint32_t summary_base; int summary_type; uint64_t summary_epoch;      // nullable: per-channel summary records
+    const WinItem *win; int win_W;                             // != nullptr: header windows precomputed by k_sync_window_fft (W per channel)
     uint32_t corr_limit;      // != 0: pass 1 of two — `corr` holds CorrArgs.limit end positions behind the state's first one; stop there
 };
 
@@ -142,6 +164,8 @@ void sonde_launch_audio_chain(const AudioChainArgs *a, hipStream_t s);
 // 8-bit unsigned IQ -> the int16 form with identical sample values; n complex samples per channel, n even
 void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s);
 void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s);
+void sonde_launch_sync_plan(const WinPlanArgs *a, hipStream_t s);
+void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s);
 void sonde_launch_framesync(const SyncArgs *a, hipStream_t s);
 }
 #endif

@@ -55,6 +55,8 @@ struct sonde_engine {
     float2 *d_y = nullptr, *d_ifiq = nullptr; float *d_fm = nullptr, *d_bufs = nullptr, *d_corr = nullptr, *d_raw = nullptr;
     float *d_wiq = nullptr, *d_wfm = nullptr, *d_match = nullptr;
     uint32_t corr_limit = 0;                       // pass 1 of the two correlation / sync passes of a call
+    // header search with the reference's transform (k_sync_plan / k_sync_window_fft): per channel win_W planned windows
+    WinItem *d_win = nullptr; float2 *d_Fm = nullptr, *d_tws = nullptr; int win_W = 0;
     sonde_summary_t *d_summary = nullptr; uint32_t summary_base = 0;      // caller-owned device buffer (sonde_engine_set_summary)
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr, *d_soft1 = nullptr;
@@ -147,6 +149,7 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
 
 static void launch_framesync_impl(sonde_engine *e, int eof);
 static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); if (eof) e->eof_pending = true; }
+static void sync_round(sonde_engine *e, int W);
 
 extern "C" {
 
@@ -327,6 +330,19 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     bad |= dalloc(&e->d_consts, 1024, true);
     if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
     HIPCHK(hipMemcpy(e->d_match, e->match.data(), L * sizeof(float), hipMemcpyHostToDevice));
+    {   // Fm = rdft(time-reversed match) with the reference's transform (init_buffers, demod_mod.c:1446-1449); N = 8192 only
+        static const bool no_fft = getenv("SONDE_NO_FFTSYNC") != nullptr;        // A/B aid: time-domain correlation ring
+        if (!cfg->opt_dc && M == 8192 && K + L <= M && !no_fft) {
+            std::vector<float> m(2 * (size_t)M, 0.f);
+            for (int i = 0; i < L; i++) m[2 * (size_t)(L - 1 - i)] = e->match[i];
+            ref_dft_8192(m);
+            const std::vector<float> tw = ref_twiddle_table();
+            e->win_W = 8;
+            if (dalloc(&e->d_Fm, (size_t)M, false) || dalloc(&e->d_tws, tw.size() / 2, false) || dalloc(&e->d_win, (size_t)C * e->win_W)) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+            HIPCHK(hipMemcpy(e->d_Fm, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_tws, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     if (e->d_wiq) HIPCHK(hipMemcpy(e->d_wiq, e->w_iq.data(), e->w_iq.size() * sizeof(float), hipMemcpyHostToDevice));
     if (e->d_wfm) HIPCHK(hipMemcpy(e->d_wfm, e->w_fm.data(), e->w_fm.size() * sizeof(float), hipMemcpyHostToDevice));
     {
@@ -450,7 +466,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
                      e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
-                     e->d_etab, e->d_dcavg_prev };
+                     e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -610,7 +626,16 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         }
     } else {
         if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
-        if (!fe) {
+        if (!fe && e->d_win) {
+            // header search with the reference's own transform: rounds of plan -> evaluate -> sync; the sync stops where the planned
+            // windows end and the next round plans from the state it left.  First round: the two windows a received sonde needs.
+            // A round ends when the planned windows are used up or a hit's frame has been sliced (the search then resumes at a place the
+            // plan could not know), so it covers at least min(W windows, one window + one frame) samples: two rounds for a call of up to
+            // about a second, more for longer ones.
+            const int kw = std::max(1, e->info.K - 4);
+            const int rounds = 2 + n_if / (kw + (int)e->frame_samples) + n_if / (e->win_W * kw);
+            for (int round = 0; round < rounds; round++) sync_round(e, round == 0 ? 2 : e->win_W);
+        } else if (!fe) {
             // two passes (corr_tile_unused in sonde_kernels.hip): correlate what two search windows can reach, sync up to there, then the
             // rest with the state that is known by then — nothing at all for a channel whose new frame covers the rest of the call
             static const bool one_pass = getenv("SONDE_CORR_ONEPASS") != nullptr;         // A/B aid
@@ -632,6 +657,21 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     return 0;
 }
 
+static void sync_round(sonde_engine *e, int W) {
+    // the item table has win_W slots per channel; this round plans and evaluates the first W of them (the others are cleared)
+    const int C = e->cfg.n_channels;
+    hipStream_t sb = e->stream_b;
+    WinPlanArgs p{}; p.state = e->d_state; p.items = e->d_win; p.n_ch = C; p.stride = e->win_W; p.W = W; p.K = e->info.K; p.L = e->info.L;
+    p.delay = e->info.delay; p.frame_samples = e->frame_samples; p.avail = e->m_out;
+    WinFftArgs f{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
+    f.K = e->info.K; f.L = e->info.L; f.ring_len = e->ring_len;
+    prof_begin(e, "header_corr", sb);
+    sonde_launch_sync_plan(&p, sb);
+    sonde_launch_sync_window_fft(&f, sb);
+    prof_end(e, sb);
+    launch_framesync(e, 0);
+}
+
 static void launch_framesync_impl(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
@@ -647,6 +687,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.opt_dc = e->cfg.opt_dc != 0; s.opt_iq = e->opt_iq; s.lpiq_on = !e->w_iq.empty(); s.lpfm_taps = (int)e->w_fm.size(); s.N = e->info.N; s.sr = e->info.if_sr;
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     s.corr_limit = e->corr_limit;
+    s.win = e->d_win; s.win_W = e->win_W;
     s.summary = e->d_summary; s.summary_base = e->summary_base; s.summary_type = e->cfg.sonde_type; s.summary_epoch = e->samples_in / (uint64_t)std::max(1, e->info.decM);     // IF samples produced so far, 64 bit
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }

@@ -28,6 +28,11 @@ int  rs255_decode(uint8_t cw[255]);
 void rs255_encode(uint8_t cw[255]);
 int  crc16(const uint8_t *p, int len);
 
+// the reference's 8192-point transform (dft_raw with its float twiddle recurrence; sonde_scan.cpp): in place on 8192 (re, im) pairs,
+// and the stage twiddle table the device kernels use (stage t at 2^t - 1 + j, (re, im) pairs)
+void ref_dft_8192(std::vector<float> &re_im);
+std::vector<float> ref_twiddle_table();
+
 extern const char    kRs41Header[65];
 extern const uint8_t kRs41HeaderBytes[8];
 extern const uint8_t kRs41Mask[64];

@@ -1222,11 +1222,17 @@ void k_framesync(const SyncArgs a) {
             const uint32_t s_in_w = st.s_in + need;
             if ((int32_t)(avail - s_in_w) < 0) { st.k += avail - st.s_in; st.s_in = avail; break; }
             if (horizon_on && (int32_t)(s_in_w - 1 - (uint32_t)a.delay - horizon) >= 0) break;      // this window is pass 2's
-            st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
             const uint32_t pos = s_in_w - 1 - (uint32_t)a.delay;      // sample_out
+            const WinItem *wi = nullptr;
+            if (!DC && a.win && pos >= (uint32_t)L) {                  // precomputed with the reference's transform (k_sync_window_fft)
+                for (int w = 0; w < a.win_W; w++) { const WinItem *c = a.win + (size_t)ch * a.win_W + w; if (c->state == 2 && c->pos == pos) { wi = c; break; } }
+                if (!wi) break;                                        // planned windows used up: the next round continues here
+            }
+            st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
             if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
             float mv; uint32_t mpos;
-            if (fs_window<DC>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
+            if (wi) { if (wi->rc < 0) continue; mv = wi->mv; mpos = wi->mpos; }
+            else if (fs_window<DC>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
             const uint32_t prev = st.mv_pos;
             st.mv = mv; st.mv_pos = mpos;
             if (DC) {
@@ -1426,6 +1432,111 @@ void k_framesync(const SyncArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sync_plan / k_sync_window_fft: the header search of find_header with the reference's transform (WinItem in sonde_dev.h)
+// ------------------------------------------------------------------------------------------------
+// the windows the frame sync will ask for, in order, assuming none of them finds a header (those behind a hit are not consumed)
+__global__ void k_sync_plan(const WinPlanArgs a) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.n_ch) return;
+    const SyncState st = a.state[ch];
+    WinItem *it = a.items + (size_t)ch * a.stride;
+    uint32_t s_in = st.s_in, k = st.k;
+    bool on = st.mode == 0;
+    if (st.mode == 1) {                                       // frame in progress: the search resumes behind it, if it ends in this call
+        const uint32_t s_after = st.mv_pos + (uint32_t)a.delay + 1 + a.frame_samples;
+        if ((int32_t)(a.avail - s_after) >= 0) { s_in = s_after; k = 0; on = true; }
+    }
+    int n = 0;
+    while (on && n < a.W) {
+        const uint32_t s_in_w = s_in + ((uint32_t)(a.K - 4) - k);
+        if ((int32_t)(a.avail - s_in_w) < 0) break;
+        const uint32_t pos = s_in_w - 1 - (uint32_t)a.delay;
+        if (pos >= (uint32_t)a.L) { it[n].pos = pos; it[n].state = 1; it[n].rc = -1; it[n].mv = 0.f; it[n].mpos = 0; n++; }     // else getCorrDFT returns -2: nothing to evaluate
+        s_in = s_in_w; k = 0;
+    }
+    for (; n < a.stride; n++) { it[n].pos = 0xffffffffu; it[n].state = 0; }
+}
+
+// The reference is plain C on x86-64: separately rounded multiplies and adds (no fused multiply-add) in the butterflies and products.
+#pragma clang fp contract(off)
+#include "sonde_fft_dev.h"
+// one workgroup = one planned window (getCorrDFT without --dc, demod_mod.c:148-225)
+__global__ __launch_bounds__(SC_THREADS)
+void k_sync_window_fft(const WinFftArgs a) {
+    extern __shared__ float2 smem2[];
+    float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
+    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_N/2] twiddles of stages 0..11
+    float *xnl = reinterpret_cast<float *>(tws + SC_N / 2);   // [SC_N] the window in natural order (norm)
+    __shared__ float s_rf[SC_THREADS / WAVE];
+    __shared__ int s_ri[SC_THREADS / WAVE];
+    const int ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WinItem *it = a.items + (size_t)ch * a.stride + blockIdx.x;
+    if (it->state != 1) return;
+    const int K = a.K, L = a.L, N = SC_N, wl = K + L;
+    const uint32_t pos = it->pos, mask = (uint32_t)a.ring_len - 1;
+    const float *bufs = a.bufs + (size_t)ch * a.ring_len;
+    const int64_t start = (int64_t)pos - (wl - 1);
+    for (int k = tid; k < N / 2 - 1; k += SC_THREADS) tws[k] = a.tws[k];
+    // xn[i] = bufs[pos - (K+L-1) + i], i < K+L, zero padded (:168-169); bit-reversed for the DIT network, natural order for the norm
+    for (int i = tid; i < N; i += SC_THREADS) {
+        const int64_t p = start + i;
+        const float v = (i < wl && p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
+        x[XI(brev13(i))] = make_float2(v, 0.f);
+        xnl[i] = v;
+    }
+    __syncthreads();
+    dft_ref(x, tws, a.tws, tid);                                         // X = rdft(xn)
+    // Z = X * Fm (:190); Nidft() transforms conj(Z) (:78-80): conjugate and swap into bit-reversed order for the same network
+    for (int i = tid; i < N; i += SC_THREADS) {
+        const int r = brev13(i);
+        if (r < i) continue;
+        const float2 zi = cmul(x[XI(i)], a.Fm[i]), zr = cmul(x[XI(r)], a.Fm[r]);
+        x[XI(r)] = make_float2(zi.x, -zi.y);
+        x[XI(i)] = make_float2(zr.x, -zr.y);
+    }
+    __syncthreads();
+    dft_ref(x, tws, a.tws, tid);                                         // cx = Nidft(Z), real part used
+    // arg-max of re(cx)^2 over i in [L-1, K+L), first maximum wins (:200-207)
+    float best = 0.f; int bidx = -1;
+    for (int i = tid; i < N; i += SC_THREADS) {
+        if (i >= L - 1 && i < wl) { const float c = x[XI(i)].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
+        if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
+    __syncthreads();
+    int mp = -1;
+    {
+        float b = 0.f;
+        for (int w = 0; w < SC_THREADS / WAVE; w++) {
+            const float ob = s_rf[w]; const int oi = s_ri[w];
+            if (ob > b || (ob == b && oi >= 0 && (mp < 0 || oi < mp))) { b = ob; mp = oi; }
+        }
+    }
+    __syncthreads();
+    if (mp < 0 || mp == L - 1 || mp == wl - 1) {                          // nothing above zero / edge value: -4 (:208)
+        if (tid == 0) { it->rc = -4; it->mv = 0.f; it->mpos = 0; __threadfence(); it->state = 2; }
+        return;
+    }
+    // xnorm = sqrt(sum_{i<L} xn[mp-i]^2) (:215-217); mx /= xnorm * N
+    float e = 0.f;
+    for (int k = tid; k < L; k += SC_THREADS) { const float v = xnl[mp - k]; e += v * v; }
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+    if (lane == 0) s_rf[wave] = e;
+    __syncthreads();
+    if (tid == 0) {
+        float es = 0.f;
+        for (int w = 0; w < SC_THREADS / WAVE; w++) es += s_rf[w];
+        const float xnorm = sqrtf(es);
+        it->rc = mp; it->mv = x[XI(mp)].x / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
+        __threadfence(); it->state = 2;
+    }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers (called from sonde_engine.cpp)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
@@ -1543,6 +1654,13 @@ extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
     }
     const size_t lds = (size_t)(HC_TILE + 2 * a->L + 8) * sizeof(float);
     hipLaunchKernelGGL(k_header_corr, dim3((a->n + HC_TILE - 1) / HC_TILE, a->n_ch), dim3(HC_THREADS), lds, s, *a);
+}
+extern "C" void sonde_launch_sync_plan(const WinPlanArgs *a, hipStream_t s) {
+    hipLaunchKernelGGL(k_sync_plan, dim3((a->n_ch + 255) / 256), dim3(256), 0, s, *a);
+}
+extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s) {
+    const size_t lds = (size_t)(2 * SC_N + SC_N / 8) * sizeof(float2);
+    hipLaunchKernelGGL(k_sync_window_fft, dim3(a->W, a->n_ch), dim3(SC_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
     if (a->opt_dc) hipLaunchKernelGGL(k_framesync<true>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);

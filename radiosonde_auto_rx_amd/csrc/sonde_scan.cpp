@@ -141,6 +141,23 @@ struct KStat { double ms = 0; int64_t n = 0; };
 
 }  // namespace
 
+// the same transform for the demodulators' header search (sonde_engine.cpp: match spectrum Fm, twiddle table), plain float pairs
+namespace sonde {
+std::vector<float> ref_twiddle_table() {
+    const std::vector<float2> t = ref_twiddles();
+    std::vector<float> o(2 * t.size());
+    for (size_t k = 0; k < t.size(); k++) { o[2 * k] = t[k].x; o[2 * k + 1] = t[k].y; }
+    return o;
+}
+void ref_dft_8192(std::vector<float> &re_im) {
+    static const std::vector<float2> tws = ref_twiddles();
+    std::vector<float2> z(SC_N);
+    for (int k = 0; k < SC_N; k++) z[k] = make_float2(re_im[2 * k], re_im[2 * k + 1]);
+    dft_ref_host(z, tws);
+    for (int k = 0; k < SC_N; k++) { re_im[2 * k] = z[k].x; re_im[2 * k + 1] = z[k].y; }
+}
+}  // namespace sonde
+
 struct sonde_scan {
     sonde_scan_cfg_t cfg{};
     sonde_scan_info_t info{};

@@ -48,10 +48,10 @@ def test_frames_match_golden_and_oracle(oracle, name):
     for i, f in enumerate(frames):
         assert f["line"] == o["lines"][i] == g["lines"][i]
         assert f["mv_pos"] == o["mv_pos"][i] == g["mv_pos"][i]
-        assert abs(f["mv"] - o["mv"][i]) < 1e-4          # score only gates the 0.7 threshold; reference FFT error ~4e-5
+        assert abs(f["mv"] - o["mv"][i]) < 5e-6          # the header search runs the reference's own transform (k_sync_window_fft): same score up to the norm's rounding
         nb = (f["nbytes"] - 8) * 8
         d = rms(f["soft"][:nb] - o["soft"][i][:nb])
-        assert d < 3e-5 and d <= 3 * float(g["floor_soft"]) + 1e-6, d
+        assert d < 1e-5 and d <= 3 * float(g["floor_soft"]) + 1e-6, d      # north_star: soft bits within 1e-5 RMS (observed 3-8e-6)
     eng.close()
 
 
