@@ -29,3 +29,25 @@ void ref_rs255_tables(ui8_t exp_a[256], ui8_t log_a[256], ui8_t g[25]) {
     ensure();
     memcpy(exp_a, g_rs.GF.exp_a, 256); memcpy(log_a, g_rs.GF.log_a, 256); memcpy(g, g_rs.g, 25);
 }
+
+/* every code of bch_ecc_mod.h:98-103 (1 RS(255,231), 2 RS(255,223) CCSDS, 3 BCH(63,51), 4 RS(15,11)) for tests/test_ecc_codes.py */
+static RS_t g_codes[5];
+static int g_codes_init[5];
+static RS_t *code(int k) {
+    if (k < 1 || k > 4) return 0;
+    if (!g_codes_init[k]) {
+        if (k == 1) rs_init_RS255(&g_codes[k]);
+        if (k == 2) rs_init_RS255ccsds(&g_codes[k]);
+        if (k == 3) rs_init_BCH64(&g_codes[k]);
+        if (k == 4) rs_init_RS15ccsds(&g_codes[k]);
+        g_codes_init[k] = 1;
+    }
+    return &g_codes[k];
+}
+int ref_ecc_params(int k, int *N, int *t, int *R, int *K) { RS_t *r = code(k); if (!r) return -1; *N = r->N; *t = r->t; *R = r->R; *K = r->K; return 0; }
+int ref_ecc_encode(int k, ui8_t *cw) { RS_t *r = code(k); return r ? rs_encode(r, cw) : -9; }
+int ref_ecc_decode(int k, ui8_t *cw, ui8_t *err_pos, ui8_t *err_val) { RS_t *r = code(k); return r ? rs_decode(r, cw, err_pos, err_val) : -9; }
+int ref_ecc_decode_era(int k, ui8_t *cw, int nera, ui8_t *era_pos, ui8_t *err_pos, ui8_t *err_val) {
+    RS_t *r = code(k); return r ? rs_decode_ErrEra(r, cw, nera, era_pos, err_pos, err_val) : -9;
+}
+int ref_ecc_decode_bch(int k, ui8_t *cw, ui8_t *err_pos, ui8_t *err_val) { RS_t *r = code(k); return r ? rs_decode_bch_gf2t2(r, cw, err_pos, err_val) : -9; }
