@@ -2,7 +2,7 @@
  * host/rs41mod.c — `rs41mod` command-line front end on top of libsonde_hip (C, like the reference's tools).
  *
  * Keeps the reference's process contract for the IQ form (reference demod/mod/rs41mod.c:2617-2744):
- *     rs41mod [-r] [--ecc|--ecc2] [--crc] [--ths x] --IQ <fq> [--lpIQ | --lpbw kHz] [--min] - <sr> 16
+ *     rs41mod [-r] [--ecc|--ecc2|--ecc3|--ecc4] [--crc] [--ths x] --IQ <fq> [--lpIQ | --lpbw kHz] [--min] - <sr> 16
  * stdin : interleaved little-endian int16 I/Q at <sr>            (rs41mod.c:2719-2734)
  * stdout: one raw line per frame, `<hex bytes> [OK]|[NO] (n)`     (rs41mod.c:2530-2545), unbuffered (:2612)
  * stderr: `IF: <rate>` / `dec: <M>`                               (demod_mod.c:1257-1258)
@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <math.h>
 #include "sonde_hip.h"
 #include "sonde_rs41.h"
 #include "wav_header.h"
@@ -44,6 +45,29 @@ static void emit_frame(const sonde_frame_t *f) {
     if (g_dec && sonde_rs41_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
 }
 
+/* --ecc3 / --ecc4: header hits with both soft bits of every bit (read_softbit2p's hsbit / hsbit1) -> sonde_rs41_dec_ecc() */
+static sonde_rs41_dec_t *g_ecc_only = NULL;
+static sonde_rs41_dec_t *ecc_ctx(void) {            /* -r without --json: the ECC state still lives in a decoder object (never printed from) */
+    if (g_dec) return g_dec;
+    if (!g_ecc_only) { sonde_rs41_opts_t q; memset(&q, 0, sizeof q); q.silent = 1; if (sonde_rs41_dec_create(&q, &g_ecc_only) < 0) return NULL; }
+    return g_ecc_only;
+}
+static void emit_hits(sonde_engine_t *eng, int level, int if_sr, int finish) {
+    static sonde_hit_t hits[8];
+    static float s0[8 * 4080], s1[8 * 4080];
+    int k = sonde_engine_fetch_hits(eng, hits, 8, finish);
+    if (k <= 0) return;
+    sonde_engine_fetch_soft(eng, s0, k); sonde_engine_fetch_soft1(eng, s1, k);
+    for (int i = 0; i < k; i++) {
+        sonde_frame_t f; memset(&f, 0, sizeof f);
+        f.channel = hits[i].channel; f.mv = hits[i].mv; f.mv_pos = hits[i].mv_pos;
+        /* the soft bits come in the polarity in effect: no further inversion here */
+        sonde_rs41_dec_ecc(ecc_ctx(), level, 0, s0 + (size_t)i * 4080, s1 + (size_t)i * 4080, hits[i].nbits,
+                           (float)hits[i].mv_pos / (float)if_sr, &f);
+        emit_frame(&f);
+    }
+}
+
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
@@ -63,6 +87,8 @@ int main(int argc, char **argv) {
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
         else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
+        else if (!strcmp(a, "--ecc3")) cfg.ecc_level = 3;               /* erasures + bit toggling from the soft bits (rs41mod.c:1861-1941) */
+        else if (!strcmp(a, "--ecc4")) cfg.ecc_level = 4;               /* + bytes known from earlier frames (rs41mod.c:1764-1849) */
         else if (!strcmp(a, "--crc")) { /* block CRCs are always evaluated by the field decode */ }
         else if (!strcmp(a, "-v")) dopt.verbose = 1;
         else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
@@ -118,8 +144,14 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "rs41mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (json_ecc) cfg.ecc_level = 2;                 /* --json / --jsnsubfrm: ecc = 2, crc (rs41mod.c:2703-2707,2770-2774) */
-    if (rawhex || softin || opt_bin) { if (make_decoder(&dopt, raw, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1; }
+    if (json_ecc && cfg.ecc_level < 2) cfg.ecc_level = 2;   /* --json / --jsnsubfrm: ecc = 2, crc (rs41mod.c:2703-2707,2770-2774) */
+    const int ecc34 = cfg.ecc_level >= 3 ? cfg.ecc_level : 0;
+    if (ecc34 && (rawhex || (opt_bin && !softin))) { fprintf(stderr, "rs41mod (sonde_hip): --ecc3/--ecc4 need soft bits (samples or --softin)\n"); return -1; }
+    if (ecc34 && !softin) { cfg.ecc_level = 2; cfg.keep_soft = 2; }      /* the engine hands out both soft bits per bit; the list decoding runs in sonde_rs41_dec_ecc() */
+    if (rawhex || softin || opt_bin) {
+        if (make_decoder(&dopt, raw, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;
+        if (ecc34 && ecc_ctx() == NULL) return -1;
+    }
     if (rawhex) {                                    /* rs41mod.c:2976-3002: hex up to the first blank, frames longer than the ID block */
         sonde_softin_t *si = NULL;
         if (sonde_softin_create(SONDE_RS41, cfg.ecc_level, 0, 0, 0, &si) < 0) return -1;
@@ -151,8 +183,14 @@ int main(int argc, char **argv) {
             }
             if (got < 1024) sonde_softin_finish(si);
             int k;
-            while ((k = sonde_softin_fetch(si, fr, 4)) > 0)
+            while ((k = sonde_softin_fetch(si, fr, 4)) > 0) {
+                if (ecc34) {                             /* ts = dsp.mv_pos / dsp.sr with an untouched dsp (rs41mod.c:2601,2963): 0 / 0 */
+                    static float sv[4 * 4080]; int32_t nb[4], iv[4];
+                    sonde_softin_fetch_soft(si, sv, nb, iv, k);
+                    for (int i = 0; i < k; i++) sonde_rs41_dec_ecc(ecc_ctx(), ecc34, iv[i], sv + (size_t)i * 4080, NULL, nb[i], nanf(""), &fr[i]);
+                }
                 for (int i = 0; i < k; i++) emit_frame(&fr[i]);
+            }
             if (got < 1024) break;
         }
         sonde_softin_destroy(si);
@@ -177,6 +215,7 @@ int main(int argc, char **argv) {
         const double xlt = (iq_mode == 5) ? -fq : 0.0;
         const int khz = cfreq > 0 ? (int)((cfreq - xlt * cfg.sample_rate + 500) / 1e3) : 0;
         if (make_decoder(&dopt, raw, khz) < 0) { fprintf(stderr, "error: telemetry options\n"); return -1; }
+        if (ecc34 && ecc_ctx() == NULL) return -1;
     }
     /* 0.1 s of input per GPU call keeps latency well below one frame */
     cfg.n_channels = 1;
@@ -207,16 +246,22 @@ int main(int argc, char **argv) {
         if (n > 0) {
             rc = sonde_engine_process_host(eng, buf, n, n);
             if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
-            int k = sonde_engine_fetch_frames(eng, frames, 8);
-            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            if (ecc34) emit_hits(eng, ecc34, info.if_sr, 0);
+            else {
+                int k = sonde_engine_fetch_frames(eng, frames, 8);
+                for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            }
             memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
             have -= (size_t)n * unit;
         }
         if (got == 0) break;                        /* EOF */
     }
     {   /* EOF: the reference still prints a frame it was in the middle of (rs41mod.c:2931,2965) */
-        int k = sonde_engine_finish(eng, frames, 8);
-        for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+        if (ecc34) emit_hits(eng, ecc34, info.if_sr, 1);
+        else {
+            int k = sonde_engine_finish(eng, frames, 8);
+            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+        }
     }
     sonde_engine_destroy(eng);
     free(buf);

@@ -304,6 +304,9 @@ int  sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n);
 int  sonde_softin_push_frame(sonde_softin_t *s, const uint8_t *bytes, int32_t len, int32_t xorhex);
 int  sonde_softin_finish(sonde_softin_t *s);               /* EOF: emit the frame in progress (rs41mod.c:2931,2965) */
 int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
+/* ecc_level 3 / 4 (rs41mod --softin --ecc3): frames come out uncorrected; the soft values of the frames of the last fetch
+ * ([n][4080], nbits[i] of them, inv[i] = polarity in effect) go to sonde_rs41_dec_ecc() (sonde_rs41.h) with soft1 = NULL. */
+int  sonde_softin_fetch_soft(sonde_softin_t *s, float *soft, int32_t *nbits, int32_t *inv, int32_t max);
 /* SONDE_DFM09 framers (dfm09mod --softin, dfm09mod.c:1604-1720: two soft symbols per bit, 8 frames per header hit) */
 int  sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max);
 /* SONDE_M10 / SONDE_M20 framers (m10mod / m20mod --softin, m10mod.c:1405-1510: header threshold 0.8, two soft symbols per bit,

@@ -45,6 +45,15 @@ void sonde_rs41_dec_destroy(sonde_rs41_dec_t *d);
  * fit (4 KiB always do). */
 int  sonde_rs41_dec_frame(sonde_rs41_dec_t *d, const sonde_frame_t *f, char *out, size_t outlen);
 
+/* rs41_ecc() for --ecc3 / --ecc4 (levels 1 / 2 work too), from the soft bits of one frame: soft0 / soft1 = the two soft values
+ * read_softbit2p() returns per bit (sonde_engine_fetch_frames(.. keep_soft = 2): soft and soft1 of the frame; soft1 == NULL = one
+ * soft value per bit, the --softin case), nbits of them behind the 64 header bits, ts = mv_pos / sr of the frame.  The bits are re-sliced from both values
+ * ((s0 + s1) >= 0, rs41mod.c:2930), the least reliable byte positions become erasure candidates and their weakest bit a toggle
+ * candidate (:1861-1941), and --ecc4 first restores bytes that are known from earlier frames of the same sonde — ID, calibration
+ * subframe, frame counter (:1764-1849) — which is why this lives in the decoder object: call it BEFORE sonde_rs41_dec_frame()
+ * for every frame, in order.  Fills f->frame (518 bytes after ECC), f->len (320 / 518), f->nbytes (bytes read) and f->ecc. */
+int  sonde_rs41_dec_ecc(sonde_rs41_dec_t *d, int level, int inv, const float *soft0, const float *soft1, int nbits, float ts, sonde_frame_t *f);
+
 /* Fields of the last decoded frame, for callers that want numbers instead of text. */
 typedef struct {
     int32_t frame_nr; char id[12];

@@ -19,6 +19,7 @@
 // Arithmetic keeps the reference's types step by step (float where it computes in float, double where C promotes), because
 // the printed digits are compared with the reference's.
 #include "../../include/sonde_rs41.h"
+#include "../../include/sonde_ecc.h"
 #include "sonde_host.h"
 #include <cmath>
 #include <cstdarg>
@@ -74,6 +75,11 @@ struct sonde_rs41_dec {
     // PTU coefficients (get_CalData)
     float Rf1, Rf2, co1[3], calT1[3], co2[3], calT2[3], calH[2], mtxH[42], corHp[3], corHt[12], Cf1, Cf2, calP[25];
     int have_id = 0, have_time = 0, have_pos = 0;
+    // --ecc3 / --ecc4 (ecdat_t, rs41mod.c:91-100): time stamps of the last good frame number / calibration subframe, and the frame
+    // image that persists from frame to frame (gpx->frame: bytes a short read does not reach keep their old content)
+    float ec_ts = 0.f, ec_last_frnb_ts = 0.f, ec_last_calfrm_ts = 0.f; uint16_t ec_last_frnb = 0; uint8_t ec_last_calfrm = 0;
+    uint8_t ec_frame[FL]; bool ec_frame_init = false;
+    float ec_score[FL + 8]; uint8_t ec_bitscore[FL];        // gpx.ecdat.frm_bytescore / gpx.dfrm_bitscore: bytes not read keep the last frame's
 
     int block_crc(int pos, int kind) const {                 // 0 ok, 1 mismatch, -1 not that block / does not fit
         if (((kind >> 8) & 0xFF) != fr[pos]) return -1;
@@ -97,12 +103,15 @@ struct sonde_rs41_dec {
                 lat = lon = alt = vH = vD = vV = 0.0; numSV = 0; isUTC = 0;
                 T = -273.15f; RH = -1.0f; P = -1.0f; RH2 = -1.0f;
                 memcpy(id, nid, 9);
+                ec_last_frnb = 0;                             // (get_SondeID :503)
             }
         }
         frnr = (int)le16(fr + P_FRNR + ofs);
+        if (bad == 0) { ec_last_frnb = (uint16_t)frnr; ec_last_frnb_ts = ec_ts; }           // (get_FrameNb :432-435)
         batt = (float)((uint16_t)fr[P_BATT + ofs] / 10.0);
         if (bad == 0) {
             const int k = fr[P_CAL + ofs];
+            ec_last_calfrm = (uint8_t)k; ec_last_calfrm_ts = ec_ts;                         // (get_FrameConf :533-534)
             if (k < 51 && !have[k]) { memcpy(cal + 16 * k, fr + P_CAL + ofs + 1, 16); have[k] = 1; }
             if (!cal_complete) {
                 int n = 0; for (int i = 0; i < 51; i++) n += have[i];
@@ -495,6 +504,169 @@ struct sonde_rs41_dec {
         have_time = !err1 || !err13; have_pos = !err3 || !err13;
     }
 
+    // ---- --ecc3 / --ecc4: the frame from both soft bits of every bit, byte scores, and the list decoding of rs41_ecc -----------
+    // (bit loop rs41mod.c:2918-2962, score sorting in print_frame :2490-2522, rs41_ecc :1703-1974)
+    int ecc34(int level, int inv, const float *s0, const float *s1, int nbits, float ts, uint8_t *frame_out, int *len_out, int *nbytes_out) {
+        static sonde_ecc_t *rs = sonde_ecc_create(SONDE_ECC_RS255);
+        enum { FS = 8, PAR = 8, MSG = 56, RR = 24, KK = 231, NDATA = 320, P_ZSTD = 0x12B };
+        if (!ec_frame_init) {
+            memset(ec_frame, 0, FL); memcpy(ec_frame, kRs41HeaderBytes, 8); ec_frame_init = true;
+            memset(ec_bitscore, 0, sizeof ec_bitscore);
+            for (int i = 0; i < FL + 8; i++) ec_score[i] = 0.f;
+        }
+        uint8_t *F = ec_frame;
+        float *score = ec_score; uint8_t *bitscore = ec_bitscore;
+        int bc = FS;
+        for (; bc < FL && 8 * (bc - FS + 1) <= nbits; bc++) {
+            const float *a = s0 + 8 * (bc - FS), *b = s1 + 8 * (bc - FS);
+            unsigned byte = 0; float sb[8];
+            for (int j = 0; j < 8; j++) {
+                int bit = level >= 3 ? ((a[j] + b[j]) >= 0) : (a[j] >= 0);
+                sb[j] = a[j];
+                if (inv) { bit ^= 1; sb[j] = -sb[j]; }
+                byte |= (unsigned)bit << j;                   // bits2byte: LSB first
+            }
+            int j0 = 0; float m = sb[0];
+            for (int j = 1; j < 8; j++) if (fabsf(sb[j]) < fabsf(m)) { m = sb[j]; j0 = j; }
+            score[bc] = m; bitscore[bc] = (uint8_t)(1 << j0);
+            F[bc] = (uint8_t)(byte ^ kRs41Mask[bc % 64]);
+        }
+        ec_ts = ts;
+        int len = bc;
+        if (len < 0x93) for (int i = len; i < FL; i++) F[i] = 0;              // print_frame :2479-2482
+        { int t = 0; const uint8_t b = F[0x38]; for (int i = 0; i < 4; i++) t += ((b >> i) & 1) - ((b >> (i + 4)) & 1); len = t >= 0 ? NDATA : FL; }
+        float mm = 0.f;
+        for (int i = FS; i < len; i++) if (fabsf(score[i]) > mm) mm = fabsf(score[i]);
+        mm = floorf(mm + 1.5f);
+        if (level > 2) {
+            for (int i = 0; i < FS; i++) score[i] = mm * 2.0f;
+            for (int i = len; i < FL; i++) score[i] = mm;
+        }
+        int order[FL], idx1[FL], idx2[FL];
+        for (int i = 0; i < FL; i++) { order[i] = i; idx1[i] = i; idx2[i] = i; }
+        if (level > 2) {
+            for (int i = 0; i < FL; i++)                                       // the reference's bubble sort: stable, ascending |score|
+                for (int j = 0; j < FL - 1; j++)
+                    if (fabsf(score[order[j + 1]]) < fabsf(score[order[j]])) { const int t = order[j + 1]; order[j + 1] = order[j]; order[j] = t; }
+            int j1 = 0, j2 = 0;
+            for (int i = 0; i < FL; i++) {
+                const int k = order[i];
+                if (k >= PAR && k < PAR + RR) idx1[j1++] = k;
+                else if (k >= PAR + RR && k < PAR + 2 * RR) idx2[j2++] = k;
+                else if (k >= MSG && k % 2 == 0) idx1[j1++] = k;
+                else if (k >= MSG && k % 2 == 1) idx2[j2++] = k;
+            }
+        }
+        // ---- rs41_ecc
+        int frmlen = len;
+        for (int i = frmlen; i < FL; i++) F[i] = 0;
+        uint8_t cw1[255], cw2[255], ep1[RR], ev1[RR], ep2[RR], ev2[RR], era[RR];
+        memset(cw1, 0, 255); memset(cw2, 0, 255);
+        for (int i = 0; i < RR; i++) { cw1[i] = F[PAR + i]; cw2[i] = F[PAR + RR + i]; }
+        auto msg1 = [&] { for (int i = 0; i < KK; i++) cw1[RR + i] = F[MSG + 2 * i]; };
+        auto msg2 = [&] { for (int i = 0; i < KK; i++) cw2[RR + i] = F[MSG + 2 * i + 1]; };
+        msg1(); msg2();
+        int e1 = sonde_ecc_decode(rs, cw1, ep1, ev1), e2 = sonde_ecc_decode(rs, cw2, ep2, ev2);
+        auto ftype = [&] { int t = 0; const uint8_t b = F[0x38]; for (int i = 0; i < 4; i++) t += ((b >> i) & 1) - ((b >> (i + 4)) & 1); return t; };
+        if (level >= 2 && (e1 < 0 || e2 < 0)) {                                // 2nd pass: block ids, zero tail (:1736-1761)
+            static const int pos[5] = { P_STATUS, P_PTU, P_GPS1, P_GPS2, P_GPS3 };
+            static const int pck[5] = { K_STATUS, K_PTU, K_GPS1, K_GPS2, K_GPS3 };
+            for (int k = 0; k < 5; k++) { F[pos[k]] = (uint8_t)(pck[k] >> 8); F[pos[k] + 1] = (uint8_t)(pck[k] & 0xFF); }
+            if (ftype() < -2) { for (int i = NDATA + 7; i < FL - 2; i++) F[i] = 0; }
+            else {
+                for (int i = NDATA; i < FL; i++) F[i] = 0;
+                F[P_ZSTD] = 0x76; F[P_ZSTD + 1] = 0x11;
+                for (int i = P_ZSTD + 2; i < NDATA - 2; i++) F[i] = 0;
+                F[NDATA - 2] = 0xEC; F[NDATA - 1] = 0xC7;
+            }
+            msg1(); msg2();
+            e1 = sonde_ecc_decode(rs, cw1, ep1, ev1); e2 = sonde_ecc_decode(rs, cw2, ep2, ev2);
+        }
+        int frmset[FL], setcnt = 0;
+        auto chk = [&](int pos_, int kind) {                                    // check_CRC on the working frame (:307-319)
+            if (((kind >> 8) & 0xFF) != F[pos_]) return -1;
+            const int n = F[pos_ + 1];
+            if (pos_ + n + 4 > FL) return -1;
+            return (int)le16(F + pos_ + 2 + n) != crc16(F + pos_ + 2, n) ? 1 : 0;
+        };
+        auto set_bytes = [&](int pos_, const uint8_t *src, int n, int subcw) {  // (:1667-1679): only the bytes of that codeword
+            const int rem = subcw == 2 ? 1 : 0;
+            int *pset = frmset + setcnt;
+            for (int i = 0; i < n; i++) if ((pos_ + i) % 2 == rem) { F[pos_ + i] = src[i]; *pset++ = pos_ + i; }
+        };
+        if (level == 4) {                                                      // known bytes of the same sonde (:1764-1849)
+            const float frnb_ts = ec_ts - ec_last_frnb_ts + 0.5f;
+            const int frnb = ec_last_frnb + (int)(unsigned)frnb_ts;
+            const float calfr_ts = ec_ts - ec_last_calfrm_ts + 0.5f;
+            const int calfr = (ec_last_calfrm + (int)(unsigned)calfr_ts) % 51;
+            for (int cwn = 1; cwn <= 2; cwn++) {
+                int &e = cwn == 1 ? e1 : e2;
+                if (e >= 0) continue;
+                int c = chk(P_STATUS, K_STATUS);
+                if (c) {
+                    if (id[0] && strncmp((const char *)F + P_ID, id, 8) != 0) { set_bytes(P_ID, (const uint8_t *)id, 8, cwn); setcnt += 8 / 2; }
+                    c = chk(P_STATUS, K_STATUS);
+                    if (c && have[calfr]) {
+                        if (F[P_CAL] == calfr) { set_bytes(P_CAL + 1, cal + calfr * 16, 16, cwn); setcnt += 16 / 2; }
+                    }
+                    c = chk(P_STATUS, K_STATUS);
+                    if (cwn == 1) { if (c && ((frnb >> 8) & 0xFF) != F[P_FRNR + 1]) { if (ec_last_frnb > 0) { F[P_FRNR + 1] = (uint8_t)((frnb >> 8) & 0xFF); frmset[setcnt++] = P_FRNR + 1; } } }
+                    else          { if (c && (frnb & 0xFF) != F[P_FRNR]) { if (ec_last_frnb > 0) { F[P_FRNR] = (uint8_t)(frnb & 0xFF); frmset[setcnt++] = P_FRNR; } } }
+                }
+                if (cwn == 1) { msg1(); e1 = sonde_ecc_decode(rs, cw1, ep1, ev1); } else { msg2(); e2 = sonde_ecc_decode(rs, cw2, ep2, ev2); }
+            }
+        }
+        auto in_fixed = [&](int idx) {                                          // (:1684-1697)
+            static const int fx[5] = { P_STATUS, P_PTU, P_GPS1, P_GPS2, P_GPS3 };
+            for (int j = 0; j < 5; j++) if (idx == fx[j] || idx == fx[j] + 1) return true;
+            if (ftype() >= -2) { if (idx >= P_ZSTD && idx < NDATA) return true; }
+            for (int j = 0; j < setcnt; j++) if (idx == frmset[j]) return true;
+            return false;
+        };
+        if (level > 2) {                                                       // 3rd pass: 2 erasures + toggled low-score bits (:1861-1941)
+            const int Era_max = 12;
+            for (int cwn = 1; cwn <= 2; cwn++) {
+                int &e = cwn == 1 ? e1 : e2;
+                if (e >= 0) continue;
+                const int *sidx = cwn == 1 ? idx1 : idx2;
+                uint8_t *cw = cwn == 1 ? cw1 : cw2; uint8_t *ep = cwn == 1 ? ep1 : ep2, *ev = cwn == 1 ? ev1 : ev2;
+                auto cwpos = [&](int pf) { return pf < MSG ? pf - PAR - (cwn == 2 ? RR : 0) : RR + (pf - MSG) / 2; };
+                for (int i = 1; i < Era_max; i++) {
+                    int pf = sidx[i];
+                    if (in_fixed(pf)) continue;
+                    int pc = cwpos(pf);
+                    if (pc < 0 || pc > 254) continue;
+                    era[0] = (uint8_t)pc;
+                    for (int j = 0; j < i; j++) {
+                        pf = sidx[j];
+                        if (in_fixed(pf)) continue;
+                        pc = cwpos(pf);
+                        if (pc < 0 || pc > 254) continue;
+                        era[1] = (uint8_t)pc;
+                        for (int k = -1; k < j; k++) {
+                            if (k >= 0) {
+                                pf = sidx[k];
+                                if (in_fixed(pf)) continue;
+                                pc = cwpos(pf);
+                                if (pc < 0 || pc > 254) continue;
+                                cw[pc] ^= bitscore[pf];                       // toggled bits stay toggled (the reference does not undo them)
+                            }
+                            e = sonde_ecc_decode_errera(rs, cw, 2, era, ep, ev);
+                            if (e >= 0) { j = 256; i = 256; k = 256; }
+                        }
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < RR; i++) { F[PAR + i] = cw1[i]; F[PAR + RR + i] = cw2[i]; }
+        for (int i = 0; i < KK; i++) { F[MSG + 2 * i] = cw1[RR + i]; F[MSG + 1 + 2 * i] = cw2[RR + i]; }
+        int ret = e1 + e2;
+        if (e1 < 0 || e2 < 0) ret = -((e1 < 0 ? 1 : 0) | (e2 < 0 ? 2 : 0));
+        memcpy(frame_out, F, FL);
+        *len_out = len; *nbytes_out = bc;
+        return ret;
+    }
+
     // ---- frames whose ECC failed: what still has a good block CRC --------------------------------------------------------
     void run_failed(Out &w, int ec) {
         if (o.silent) return;
@@ -557,6 +729,14 @@ int sonde_rs41_dec_frame(sonde_rs41_dec_t *d, const sonde_frame_t *f, char *out,
     if (w.s.size() + 1 > outlen) return SONDE_E_ARG;
     memcpy(out, w.s.c_str(), w.s.size() + 1);
     return (int)w.s.size();
+}
+
+int sonde_rs41_dec_ecc(sonde_rs41_dec_t *d, int level, int inv, const float *soft0, const float *soft1, int nbits, float ts, sonde_frame_t *f) {
+    if (!d || !f || !soft0 || level < 1 || level > 4 || nbits < 0) return SONDE_E_ARG;
+    int len = 0, nb = 0;
+    f->ecc = d->ecc34(level, inv, soft0, soft1 ? soft1 : soft0, nbits, ts, f->frame, &len, &nb);
+    f->len = len; f->nbytes = nb;
+    return 0;
 }
 
 int sonde_rs41_dec_fields(const sonde_rs41_dec_t *d, sonde_rs41_fields_t *o) {

@@ -31,6 +31,9 @@ struct sonde_softin {
     float mv = 0.f; uint64_t bits_in = 0, hdr_bit = 0;
     uint32_t hdrcnt = 0;                      // DFM: 8 per header seen (dfm09mod.c:1628,1632), base of the frame time stamp
     std::vector<sonde_frame_t> queue;
+    // --ecc3 / --ecc4 behind soft input: the soft value of every frame bit travels with the frame (rs41mod.c:2910-2916,2941)
+    float fsoft[4080]; int nsoft = 0;
+    std::vector<std::vector<float>> qsoft, last_soft;
     // M10 / M20 (m10mod.c:1405-1510): 32-symbol header at threshold 0.8, two soft symbols per bit (s2 - s1), differential decoding,
     // then ONE symbol per counted bit is dropped until 5 x 808 (the reference's skip loop reads a single float per step)
     int mpos = 0, mhalf = 0, mbit0 = '0', mskip = 0, mdoskip = 1; float ms1 = 0.f;
@@ -66,9 +69,14 @@ static void emit(sonde_softin *s, int nbytes) {           // print_frame(gpx, by
     f.channel = 0; f.nbytes = nbytes; f.mv = s->mv; f.mv_pos = (uint32_t)s->hdr_bit;
     f.len = (rs41_frametype(s->frame) >= 0) ? 320 : 518;
     memcpy(f.frame, s->frame, 518);
-    f.ecc = s->ecc_level > 0 ? rs41_ecc(f.frame, f.len, s->ecc_level, nullptr) : 0;
-    if (s->ecc_level == 0) for (int k = 0; k < 0; k++) {}
-    memcpy(s->frame, f.frame, 518);
+    if (s->ecc_level >= 3) {                               // list decoding needs the decoder's state: sonde_rs41_dec_ecc() by the caller
+        f.ecc = 0;
+        s->qsoft.emplace_back(s->fsoft, s->fsoft + s->nsoft);
+        s->qsoft.back().push_back((float)s->opt_inv);      // last element: polarity in effect for this frame
+    } else {
+        f.ecc = s->ecc_level > 0 ? rs41_ecc(f.frame, f.len, s->ecc_level, nullptr) : 0;
+        memcpy(s->frame, f.frame, 518);
+    }
     s->queue.push_back(f);
 }
 
@@ -203,10 +211,11 @@ int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
             if (std::fabs(mv) > s->ths) {
                 int found = 1;
                 if (mv * (0.5 - s->opt_inv) < 0) { if (!s->opt_auto) found = 0; else s->opt_inv ^= 1; }
-                if (found) { s->state = 1; s->byte_count = 8; s->b8pos = 0; s->mv = mv; s->hdr_bit = s->bits_in; }
+                if (found) { s->state = 1; s->byte_count = 8; s->b8pos = 0; s->mv = mv; s->hdr_bit = s->bits_in; s->nsoft = 0; }
             }
         } else {
             int bit = sb >= 0.0f;
+            if (s->nsoft < 4080) s->fsoft[s->nsoft++] = sb;
             if (s->opt_inv) bit ^= 1;
             s->bitbuf[s->b8pos++] = (uint8_t)bit;
             if (s->b8pos == 8) {
@@ -342,6 +351,21 @@ int sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max) {
     const int n = (int)std::min<size_t>(s->queue.size(), (size_t)max);
     for (int i = 0; i < n; i++) out[i] = s->queue[i];
     s->queue.erase(s->queue.begin(), s->queue.begin() + n);
+    if (s->ecc_level >= 3) {
+        s->last_soft.assign(s->qsoft.begin(), s->qsoft.begin() + std::min<size_t>((size_t)n, s->qsoft.size()));
+        s->qsoft.erase(s->qsoft.begin(), s->qsoft.begin() + (long)s->last_soft.size());
+    }
+    return n;
+}
+
+int sonde_softin_fetch_soft(sonde_softin_t *s, float *soft, int32_t *nbits, int32_t *inv, int32_t max) {
+    if (!s || max < 0 || (max > 0 && (!soft || !nbits || !inv))) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->last_soft.size(), (size_t)max);
+    for (int i = 0; i < n; i++) {
+        const std::vector<float> &v = s->last_soft[i];
+        nbits[i] = (int32_t)v.size() - 1; inv[i] = v.back() != 0.f;
+        memcpy(soft + (size_t)i * 4080, v.data(), (v.size() - 1) * sizeof(float));
+    }
     return n;
 }
 

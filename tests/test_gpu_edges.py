@@ -34,8 +34,10 @@ def test_cli_empty_and_short_inputs():
     # argument errors: 255 like the reference's `return -1`
     r = _run([os.path.join(BIN, "rs41mod"), "-r", "--IQ", "0.1", "-", "0", "16"])
     assert r.returncode == 255
-    r = _run([os.path.join(BIN, "rs41mod"), "-r", "--ecc3", "--IQ", "0.1", "-", "2400000", "16"])
-    assert r.returncode == 255 and b"not supported" in r.stderr          # refused, not approximated
+    r = _run([os.path.join(BIN, "rs41mod"), "-r", "--ecc5", "--IQ", "0.1", "-", "2400000", "16"])
+    assert r.returncode == 255 and b"not supported" in r.stderr          # unknown options: refused, not ignored
+    r = _run([os.path.join(BIN, "rs41mod"), "-r", "--ecc3", "--rawhex", "-"])
+    assert r.returncode == 255                                           # --ecc3/4 work on the demodulator's soft bits only
     r = _run([os.path.join(BIN, "rs41mod"), "-r", "--noLUT", "--dc", "--IQ", "0.1", "-", "2400000", "16"])
     assert r.returncode == 255                                           # --noLUT with --dc (Df inside the base-rate mixer): refused
 

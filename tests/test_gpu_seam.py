@@ -172,6 +172,31 @@ def test_seam_rs41_ecc3_second_soft_bit(ecc):
     assert outs[0].count(b"[OK]") >= 5
 
 
+@pytest.mark.parametrize("ecc", ["--ecc3", "--ecc4"])
+def test_native_rs41_ecc3_ecc4_match_reference(ecc):
+    """host/bin/rs41mod --ecc3 / --ecc4: the list decoding (erasures from the byte scores, bit toggling, bytes known from earlier
+    frames — rs41mod.c:1703-1974, :2490-2522, :2918-2962) runs in sonde_rs41_dec_ecc() over the library's own RS(255,231) codec
+    (sonde_ecc.h), not in the reference's code: same stdout as the reference binary, raw and decoded, at noise levels where the
+    plain --ecc2 output differs."""
+    from tools import synth
+    native = os.path.join(ROOT, "host", "bin", "rs41mod")
+    ref = os.path.join(REF, "rs41mod")
+    if not (os.path.exists(native) and os.path.exists(ref)):
+        pytest.skip("host/bin or oracle/_ref not built")
+    tail = ["--IQ", "0.0", "--lpIQ", "-", "48000", "16"]
+    changed = 0
+    for ns, seed in ((0.38, 55), (0.44, 56), (0.47, 57)):
+        x = synth.rs41_capture(sr=48_000, seconds=12.3, fq=0.0, noise_sigma=ns, frame_kw=ECEF, n_frames=12, t_first=0.15, seed=seed).tobytes()
+        for mode in (["-r", ecc, "--crc"], ["-vx", ecc, "--crc", "--ptu"], ["--json", ecc]):
+            a = subprocess.run([native] + mode + tail, input=x, capture_output=True, timeout=300)
+            b = subprocess.run([ref] + mode + tail, input=x, capture_output=True, timeout=300)
+            assert a.returncode == b.returncode == 0, a.stderr[-300:]
+            assert a.stdout == b.stdout, (mode, ns, a.stdout[:400], b.stdout[:400])
+        plain = subprocess.run([ref, "-r", "--ecc2", "--crc"] + tail, input=x, capture_output=True, timeout=300).stdout
+        changed += plain != subprocess.run([ref, "-r", ecc, "--crc"] + tail, input=x, capture_output=True, timeout=300).stdout
+    assert changed >= 2
+
+
 @pytest.mark.parametrize("binary,shift", [("rs41mod", "1"), ("rs41mod", "-2"), ("dfm09mod", "-1"), ("m10mod", "2")])
 def test_seam_bit_offset_option(binary, shift):
     """-d <shift>: the decoders add it to the bitofs they pass to find_header() / read_softbit*(); the seam hands it to the engine
