@@ -1,11 +1,12 @@
 /*
- * sonde_fsk.h — C ABI of the batched 2-FSK modem in libsonde_hip.so.
+ * sonde_fsk.h — C ABI of the batched 2-/4-FSK modem in libsonde_hip.so.
  *
  * Replaces the reference's utils/fsk.c demodulator (the codec2 "fsk_demod" auto_rx pipes IQ into,
  * auto_rx/autorx/decode.py:901,976,1067,1120) for many channels at once.  The reference seam is
  * fsk_create_hbr / fsk_set_freq_est_limits / fsk_set_freq_est_alg / fsk_nin / fsk_demod_sd / fsk_get_demod_stats /
  * fsk_destroy (utils/fsk.h:115-205) over struct FSK (fsk.h:47-95); every channel here is one such struct.
- * host/fsk_demod.c keeps the CLI (utils/fsk_demod.c) on top of it.  Conventions as sonde_hip.h.
+ * host/fsk_demod.c keeps the CLI (utils/fsk_demod.c) on top of it; host/seam/fsk_hip.c is the fsk.h function seam itself (the
+ * reference's fsk_demod.c links against it unchanged).  Conventions as sonde_hip.h.
  */
 #ifndef SONDE_FSK_H
 #define SONDE_FSK_H
@@ -20,6 +21,7 @@ extern "C" {
 #define SONDE_FSK_S16   1       /* real int16,  x/1000           */
 #define SONDE_FSK_CS16  2       /* --cs16: complex int16, x/1000 */
 #define SONDE_FSK_CU8   3       /* --cu8: complex uint8, (u-127)/128 */
+#define SONDE_FSK_CF32  4       /* complex float32 as is: the COMP fsk_in[] of fsk_demod() / fsk_demod_sd() (fsk.h:176,186) */
 
 typedef struct sonde_fsk sonde_fsk_t;
 
@@ -28,7 +30,7 @@ typedef struct {
     int32_t device;
     int32_t n_channels;
     int32_t Fs, Rs;          /* sample / symbol rate; Fs % Rs == 0 (fsk.c:127)               */
-    int32_t M;               /* 2 (4-FSK is not implemented)                                 */
+    int32_t M;               /* 2 or 4 tones (fsk.c:130); 4-FSK yields two soft bits per symbol */
     int32_t P;               /* -p: timing oversampling, (Fs/Rs) % P == 0 (fsk.c:129)        */
     int32_t nsym;            /* --nsym: symbols per modem frame                              */
     int32_t format;          /* SONDE_FSK_*                                                  */
@@ -36,7 +38,9 @@ typedef struct {
     int32_t mask;            /* --mask given: mask estimator (fsk_set_freq_est_alg)          */
     int32_t tone_spacing;    /* --mask <Hz> (tx_tone_separation, default 100)                */
     int32_t max_chunk;       /* largest n_samples per process call                           */
-    int32_t reserved[4];
+    int32_t burst_mode;      /* fsk_enable_burst_mode: nin never adjusted (fsk.c:724,976)    */
+    int32_t raw_eye;         /* fsk_stats_normalise_eye(fsk, 0): eye traces not normalised   */
+    int32_t reserved[2];
 } sonde_fsk_cfg_t;
 
 /* struct FSK constants (fsk_create_core, fsk.c:114-201) */
@@ -50,7 +54,7 @@ typedef struct {
 typedef struct {
     int32_t nin;             /* samples this frame consumed                                  */
     int32_t nin_next;        /* fsk_nin() after the frame                                    */
-    float   f_est[2];        /* tone estimates used by the demod (peak or mask estimator)    */
+    float   f_est[4];        /* tone estimates used by the demod (peak or mask estimator), M of them */
     float   norm_rx_timing;
     float   ppm;
     float   EbNodB;
@@ -67,17 +71,20 @@ int  sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info);
 int  sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
 
-/* Soft decisions (fsk_demod_sd: one float per bit, >0 = the lower tone) produced by the last process call for one
+/* Soft decisions (fsk_demod_sd: one float per bit — 2-FSK: >0 = the lower tone; 4-FSK: two per symbol, fsk.c:793-802) produced by the last process call for one
  * channel; returns the number of floats written (<= max). frames (optional, may be NULL): per-frame records,
  * max_frames entries; *n_frames receives the count. */
 int  sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames,
                      int32_t *n_frames);
+/* Hard decisions of the same frames (rx_bits of fsk_demod(): the strictly largest tone, first wins; fsk.c:760-778), one byte per bit */
+int  sonde_fsk_fetch_bits(sonde_fsk_t *f, int32_t channel, uint8_t *bits, int32_t max);
 /* fsk_get_demod_stats + Sf: smoothed magnitude spectrum (Ndft floats, DC at Ndft/2) and samples consumed so far */
 int  sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, float *Sf, int64_t *samples);
 /* Eye diagram of the last modem frame as fsk_get_demod_stats() returns it (rx_eye, fsk.c:857-903; modem_stats.h:63-65):
- * neyetr = 8 traces (4 per tone, interleaved lower / upper) of neyesamp = 2P/ceil(2P/160) integrator magnitudes, normalised
+ * neyetr = 8 traces (8/M per tone, interleaved by tone) of neyesamp = 2P/ceil(2P/160) integrator magnitudes, normalised
  * to the largest.  eye receives neyetr * neyesamp floats (row-major; at most 8 * 160); returns that count. */
 int  sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr, int32_t *neyesamp);
+int  sonde_fsk_clear_estimators(sonde_fsk_t *f);                          /* fsk_clear_estimators (fsk.c:981)     */
 int  sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches);
 
 #ifdef __cplusplus

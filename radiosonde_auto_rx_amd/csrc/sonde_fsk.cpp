@@ -21,7 +21,7 @@ struct sonde_fsk {
     hipStream_t stream = nullptr;
     void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr, *d_eye = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
-    FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr;
+    FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; std::vector<uint8_t> h_hb;
     std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
     size_t unit = 4;
     uint32_t wr = 0;
@@ -46,9 +46,9 @@ extern "C" {
 int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     if (!cfg || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->n_channels < 1 || cfg->Fs < 1 || cfg->Rs < 1 || cfg->P < 1 || cfg->nsym < 1 || cfg->max_chunk < 1) return SONDE_E_ARG;
-    if (cfg->M != 2) return SONDE_E_ARG;                                              // 4-FSK: not implemented
+    if (cfg->M != 2 && cfg->M != 4) return SONDE_E_ARG;                               // fsk.c:130
     if (cfg->Fs % cfg->Rs || (cfg->Fs / cfg->Rs) % cfg->P) return SONDE_E_ARG;          // the reference asserts (fsk.c:127-129)
-    if (cfg->format != SONDE_FSK_S16 && cfg->format != SONDE_FSK_CS16 && cfg->format != SONDE_FSK_CU8) return SONDE_E_ARG;
+    if (cfg->format != SONDE_FSK_S16 && cfg->format != SONDE_FSK_CS16 && cfg->format != SONDE_FSK_CU8 && cfg->format != SONDE_FSK_CF32) return SONDE_E_ARG;
     if (cfg->fsk_lower < -cfg->Fs / 2 || cfg->fsk_upper > cfg->Fs / 2 || cfg->fsk_upper <= cfg->fsk_lower) return SONDE_E_ARG;   // fsk.c:1019-1022
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device >= ndev) {
@@ -58,7 +58,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     HIPCHK(hipSetDevice(cfg->device));
     sonde_fsk *f = new sonde_fsk();
     f->cfg = *cfg;
-    const int C = cfg->n_channels, Fs = cfg->Fs, Rs = cfg->Rs, P = cfg->P, nsym = cfg->nsym;
+    const int C = cfg->n_channels, Fs = cfg->Fs, Rs = cfg->Rs, P = cfg->P, nsym = cfg->nsym, M = cfg->M;
 
     // ---- fsk_create_core (fsk.c:114-201)
     const float bin_width_Hz = 0.1 * Rs;
@@ -68,7 +68,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     int lg = 0; while ((1 << lg) < Ndft) lg++;
     if (Ndft > 1024 || Ndft < 8 || (1 << lg) != Ndft) { delete f; return SONDE_E_ARG; }
     FskArgs &a = f->args;
-    a.format = cfg->format; a.n_ch = C; a.Fs = Fs; a.Rs = Rs; a.Ts = Ts; a.P = P; a.nsym = nsym; a.N = N; a.Ndft = Ndft; a.log2Ndft = lg;
+    a.format = cfg->format; a.M = M; a.burst = cfg->burst_mode ? 1 : 0; a.n_ch = C; a.Fs = Fs; a.Rs = Rs; a.Ts = Ts; a.P = P; a.nsym = nsym; a.N = N; a.Ndft = Ndft; a.log2Ndft = lg;
     a.Nmem = Nmem; a.NT = 2 * Ts + Ts / 2;
     a.tc = 0.95 * Ndft_f / Fs;
     const int est_space = 0.75 * Rs, fs_tx = cfg->mask ? cfg->tone_spacing : 100;
@@ -77,28 +77,32 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     a.st = (cfg->fsk_lower * Ndft) / Fs + Ndft / 2; if (a.st < 0) a.st = 0;
     a.en = (cfg->fsk_upper * Ndft) / Fs + Ndft / 2; if (a.en > Ndft) a.en = Ndft;
     a.f_zero = (est_space * Ndft) / Fs;
-    {   // mask of the second estimator (fsk.c:553-560): ones at 0..2 and at bin..bin+2, bin = round(fs_tx Ndft / Fs) - 1
+    {   // mask of the second estimator (fsk.c:553-560): ones at 0..2 and at bin_m..bin_m+2, bin_m = round(m fs_tx Ndft / Fs) - 1, m = 1..M-1
         std::vector<char> mask(Ndft + 8, 0);
         for (int i = 0; i < 3; i++) mask[i] = 1;
-        const int bin = (int)round((float)1 * fs_tx * Ndft / Fs) - 1;
-        if (bin < 0 || bin + 2 >= Ndft) { if (cfg->mask) { delete f; return SONDE_E_ARG; } }
-        else for (int i = bin; i <= bin + 2; i++) mask[i] = 1;
+        int bin = 0; bool fits = true;
+        for (int m = 1; m <= M - 1; m++) {
+            bin = (int)round((float)m * fs_tx * Ndft / Fs) - 1;
+            if (bin < 0 || bin + 2 >= Ndft) { fits = false; break; }
+            for (int i = bin; i <= bin + 2; i++) mask[i] = 1;
+        }
+        if (!fits && cfg->mask) { delete f; return SONDE_E_ARG; }
         a.len_mask = bin + 2 + 1; a.n_mask = 0;
-        for (int i = 0; i < Ndft && a.n_mask < 6; i++) if (mask[i]) a.mask_idx[a.n_mask++] = i;
+        for (int i = 0; i < Ndft && a.n_mask < 12; i++) if (mask[i]) a.mask_idx[a.n_mask++] = i;
     }
-    f->info.Ts = Ts; f->info.N = N; f->info.Ndft = Ndft; f->info.Nmem = Nmem; f->info.Nbits = nsym; f->info.tc = a.tc;
+    f->info.Ts = Ts; f->info.N = N; f->info.Ndft = Ndft; f->info.Nmem = Nmem; f->info.Nbits = nsym * (M / 2); f->info.tc = a.tc;
     a.max_fft = (N + Ts / 2) / (Ndft / 2) - 1; if (a.max_fft < 1) a.max_fft = 1;
 
     // ---- tables
-    std::vector<float> hann(Ndft), fmask((size_t)Ndft * 2);
-    std::vector<float2> tw(Ndft / 2), dpeak(Ndft), dmask((size_t)Ndft * 2), phift((size_t)(nsym + 1) * P);
+    std::vector<float> hann(Ndft), fmask((size_t)Ndft * M);
+    std::vector<float2> tw(Ndft / 2), dpeak(Ndft), dmask((size_t)Ndft * M), phift((size_t)(nsym + 1) * P);
     for (int i = 0; i < Ndft; i++) hann[i] = 0.5 - 0.5 * cosf(2.0 * M_PI * (float)i / (float)(Ndft - 1));
     for (int k = 0; k < Ndft / 2; k++) { const double ang = -2.0 * M_PI * k / Ndft; tw[k] = make_float2((float)cos(ang), (float)sin(ang)); }
     for (int k = 0; k < Ndft; k++) {
         const float fp = (float)(k - Ndft / 2) * ((float)Fs / (float)Ndft);             // peak estimator (fsk.c:544-546)
         dpeak[k] = exp_j(2 * M_PI * ((fp) / (float)(Fs)));
         const float foff = (k - Ndft / 2) * Fs / Ndft;                                  // mask estimator (fsk.c:575-578), integer division
-        for (int m = 0; m < 2; m++) { const float fm = foff + m * fs_tx; fmask[2 * k + m] = fm; dmask[2 * k + m] = exp_j(2 * M_PI * ((fm) / (float)(Fs))); }
+        for (int m = 0; m < M; m++) { const float fm = foff + m * fs_tx; fmask[M * k + m] = fm; dmask[M * k + m] = exp_j(2 * M_PI * ((fm) / (float)(Fs))); }
     }
     {   // timing oscillator: phi_ft = 1; used, then phi_ft *= dphift (fsk.c:682-703)
         const float2 d = exp_j(2 * M_PI * ((float)(Rs) / (float)(P * Rs)));
@@ -110,23 +114,23 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
         }
     }
     const int max_frames = cfg->max_chunk / std::max(1, N - Ts / 2) + 2;
-    a.rec_cap = max_frames; a.sd_cap = max_frames * nsym;
+    a.rec_cap = max_frames; a.sd_cap = max_frames * nsym * (M / 2);
     uint32_t ring = 1; while (ring < (uint32_t)(cfg->max_chunk + N + Ts + 16)) ring <<= 1;
     a.ring = ring;
-    f->unit = cfg->format == SONDE_FSK_CS16 ? 4 : 2;
+    f->unit = cfg->format == SONDE_FSK_CF32 ? 8 : cfg->format == SONDE_FSK_CS16 ? 4 : 2;
     int bad = 0;
     bad |= dalloc((char **)&f->d_in, (size_t)C * ring * f->unit);
     bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
     bad |= dupload(&f->d_fmask, fmask); bad |= dupload(&f->d_phift, phift);
-    bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * 2 * a.NT);
-    bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
+    bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * M * a.NT);
+    bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_hb, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
     if (bad) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
     f->h_chan.resize(C);
-    for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); c.phi_c[0] = c.phi_c[1] = exp_j(0); c.nin = N; }
+    for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); for (int m = 0; m < 4; m++) c.phi_c[m] = exp_j(0); c.nin = N; }
     HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
     a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
-    a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.recs = f->d_recs;
-    f->h_sd.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
+    a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.hb = f->d_hb; a.recs = f->d_recs;
+    f->h_sd.resize((size_t)C * a.sd_cap); f->h_hb.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
     HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     *out = f;
     return 0;
@@ -135,7 +139,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -167,6 +171,7 @@ static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hi
     if (lrc < 0) { hipEventDestroy(e0); hipEventDestroy(e1); return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU; }
     HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_hb.data(), f->d_hb, f->h_hb.size(), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
     float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { f->ms += ms; f->launches++; }
@@ -186,15 +191,22 @@ int sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride
 int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames, int32_t *n_frames) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels || (!sd && max > 0)) return SONDE_E_ARG;
     const FskChan &c = f->h_chan[channel];
-    const int nf = c.frames, nb = std::min<int>(nf * f->cfg.nsym, max);
+    const int nf = c.frames, nb = std::min<int>(nf * f->info.Nbits, max);
     if (nb > 0) memcpy(sd, f->h_sd.data() + (size_t)channel * f->args.sd_cap, (size_t)nb * sizeof(float));
     if (frames) for (int i = 0; i < std::min(nf, max_frames); i++) {
         const FskFrameRec &r = f->h_recs[(size_t)channel * f->args.rec_cap + i];
         sonde_fsk_frame_t &o = frames[i];
-        o.nin = r.nin; o.nin_next = r.nin_next; o.f_est[0] = r.f_est[0]; o.f_est[1] = r.f_est[1];
+        o.nin = r.nin; o.nin_next = r.nin_next; for (int m = 0; m < 4; m++) o.f_est[m] = r.f_est[m];
         o.norm_rx_timing = r.norm_rx_timing; o.ppm = r.ppm; o.EbNodB = r.EbNodB; o.snr_est = r.snr_est;
     }
     if (n_frames) *n_frames = nf;
+    return nb;
+}
+
+int sonde_fsk_fetch_bits(sonde_fsk_t *f, int32_t channel, uint8_t *bits, int32_t max) {
+    if (!f || channel < 0 || channel >= f->cfg.n_channels || (!bits && max > 0)) return SONDE_E_ARG;
+    const int nb = std::min<int>(f->h_chan[channel].frames * f->info.Nbits, max);
+    if (nb > 0) memcpy(bits, f->h_hb.data() + (size_t)channel * f->args.sd_cap, (size_t)nb);
     return nb;
 }
 
@@ -203,7 +215,7 @@ int sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, fl
     const FskChan &c = f->h_chan[channel];
     if (last) {
         memset(last, 0, sizeof *last);
-        last->nin_next = c.nin; last->f_est[0] = c.f_est[0]; last->f_est[1] = c.f_est[1]; last->norm_rx_timing = c.norm_rx_timing;
+        last->nin_next = c.nin; for (int m = 0; m < f->cfg.M; m++) last->f_est[m] = c.f_est[m]; last->norm_rx_timing = c.norm_rx_timing;
         last->ppm = c.ppm; last->EbNodB = c.EbNodB; last->snr_est = c.snr_est;
     }
     if (Sf) HIPCHK(hipMemcpy(Sf, f->d_Sf + (size_t)channel * f->info.Ndft, (size_t)f->info.Ndft * sizeof(float), hipMemcpyDeviceToHost));
@@ -217,12 +229,26 @@ int sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr, 
     const int dec = (int)ceil(((float)P * 2) / 160.0f), nes = (P * 2) / dec, ntr = 8;      // MODEM_STATS_EYE_IND_MAX 160, ET_MAX 8
     std::vector<float> raw(8 * 160);
     HIPCHK(hipMemcpy(raw.data(), f->d_eye + (size_t)channel * 8 * 160, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
-    float eye_max = 0;                                        // normalise_eye = 1 (fsk.c:198,892-903)
-    for (int i = 0; i < ntr; i++) for (int j = 0; j < nes; j++) if (fabsf(raw[i * 160 + j]) > eye_max) eye_max = fabsf(raw[i * 160 + j]);
+    float eye_max = 1.f;
+    if (!f->cfg.raw_eye) {                                    // normalise_eye = 1 unless fsk_stats_normalise_eye(.., 0) (fsk.c:198,892-903)
+        eye_max = 0;
+        for (int i = 0; i < ntr; i++) for (int j = 0; j < nes; j++) if (fabsf(raw[i * 160 + j]) > eye_max) eye_max = fabsf(raw[i * 160 + j]);
+    }
     for (int i = 0; i < ntr; i++) for (int j = 0; j < nes; j++) eye[i * nes + j] = raw[i * 160 + j] / eye_max;
     if (neyetr) *neyetr = ntr;
     if (neyesamp) *neyesamp = nes;
     return ntr * nes;
+}
+
+int sonde_fsk_clear_estimators(sonde_fsk_t *f) {               // fsk_clear_estimators (fsk.c:981-989): Sf = 0, nin = N
+    if (!f) return SONDE_E_ARG;
+    const int C = f->cfg.n_channels;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    HIPCHK(hipMemset(f->d_Sf, 0, (size_t)C * f->info.Ndft * sizeof(float)));
+    HIPCHK(hipMemcpy(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost));
+    for (auto &c : f->h_chan) c.nin = f->info.N;
+    HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
+    return 0;
 }
 
 int sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches) {

@@ -1,4 +1,4 @@
-// sonde_fsk.hip — gfx950 kernel of the batched 2-FSK modem (the reference's utils/fsk.c fsk_demod_core).
+// sonde_fsk.hip — gfx950 kernel of the batched 2-/4-FSK modem (the reference's utils/fsk.c fsk_demod_core).
 //
 // One workgroup per channel walks the modem frames that fit into the samples queued for that channel — the frame loop
 // is sequential in the reference too (nin, the smoothed spectrum Sf and the oscillator phases feed the next frame).
@@ -20,6 +20,7 @@
 #define FMT_S16  1
 #define FMT_CS16 2
 #define FMT_CU8  3
+#define FMT_CF32 4
 
 __device__ __forceinline__ float2 cmult(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -41,30 +42,31 @@ __device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_r
     return bi == INT_MAX ? dflt : bi;
 }
 
+template <int M>
 __global__ __launch_bounds__(FSK_THREADS)
 void k_fsk_demod(const FskArgs a) {
     extern __shared__ float lds[];
     __shared__ float s_Sf[1024], s_Sc[1024];
     __shared__ float s_rf[FSK_THREADS / WAVE]; __shared__ int s_ri[FSK_THREADS / WAVE];
-    __shared__ float2 s_phi[2]; __shared__ float s_tc[2], s_eb[2];
+    __shared__ float2 s_phi[4]; __shared__ float s_tc[2], s_eb[2];
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT;
     const int W = (nsym + 1) * P;
     const int n_in = max(N + Ts / 2, W);
     float2 *s_in  = reinterpret_cast<float2 *>(lds);                       // [n_in]  input frame; later ft1 * phi_ft
-    float2 *s_fdc = s_in + n_in;                                           // [max(2 Nmem, 4 Ndft)]  FFT scratch, then f_dc[2][Nmem]
-    float  *s_u   = reinterpret_cast<float *>(s_fdc + max(2 * Nmem, 4 * Ndft));   // mag[max_fft][Ndft] | f_int[2][W] + eb[nsym]
+    float2 *s_fdc = s_in + n_in;                                           // [max(M Nmem, 4 Ndft)]  FFT scratch, then f_dc[M][Nmem]
+    float  *s_u   = reinterpret_cast<float *>(s_fdc + max(M * Nmem, 4 * Ndft));   // mag[max_fft][Ndft] | f_int[M][W] + eb[nsym]
     float2 *s_fint = reinterpret_cast<float2 *>(s_u);
-    float  *s_ebv = s_u + 4 * W;
+    float  *s_ebv = s_u + 2 * M * W;
     FskChan st = a.chan[ch];
     float *Sf_g = a.Sf + (size_t)ch * Ndft;
-    float2 *tail_g = a.tail + (size_t)ch * 2 * NT;
+    float2 *tail_g = a.tail + (size_t)ch * M * NT;
     int frames = 0;
 
     for (;;) {
         const int nin = st.nin;
         if ((int32_t)(a.wr - st.rd) < nin) break;
-        if (frames >= a.rec_cap || (frames + 1) * nsym > a.sd_cap) break;
+        if (frames >= a.rec_cap || (frames + 1) * nsym * (M / 2) > a.sd_cap) break;
         // ---- input conversion (fsk_demod.c:283-311)
         for (int i = tid; i < nin; i += FSK_THREADS) {
             const uint32_t p = (st.rd + (uint32_t)i) & (a.ring - 1);
@@ -72,6 +74,8 @@ void k_fsk_demod(const FskArgs a) {
             if (a.format == FMT_CS16) {
                 const uint32_t raw = reinterpret_cast<const uint32_t *>(a.in)[(size_t)ch * a.ring + p];
                 v = make_float2((float)(short)(raw & 0xffffu) / 1000.f, (float)(((int)raw) >> 16) / 1000.f);
+            } else if (a.format == FMT_CF32) {                                // the fsk.h seam: COMP samples as the caller scaled them
+                v = reinterpret_cast<const float2 *>(a.in)[(size_t)ch * a.ring + p];
             } else if (a.format == FMT_S16) {
                 v = make_float2((float)reinterpret_cast<const int16_t *>(a.in)[(size_t)ch * a.ring + p] / 1000.f, 0.f);
             } else {
@@ -119,11 +123,11 @@ void k_fsk_demod(const FskArgs a) {
             Sf_g[k] = sf; s_Sf[k] = sf; s_Sc[k] = sf;
         }
         __syncthreads();
-        // peak estimator: the two largest bins in [st, en), +-f_zero blanked after the first (fsk.c:508-546)
-        float f_est[2]; float2 dphi[2];
+        // peak estimator: the M largest bins in [st, en), +-f_zero blanked after each, ascending (fsk.c:508-546)
+        float f_est[4]; float2 dphi[4];
         {
-            int freqi[2];
-            for (int m = 0; m < 2; m++) {
+            int freqi[4];
+            for (int m = 0; m < M; m++) {
                 const int imax = block_argmax(s_Sc, a.st, a.en, 0, s_rf, s_ri);
                 const int f_min = max(imax - a.f_zero, 0), f_max = min(imax + a.f_zero, Ndft);
                 __syncthreads();
@@ -131,10 +135,11 @@ void k_fsk_demod(const FskArgs a) {
                 __syncthreads();
                 freqi[m] = imax - Ndft / 2;
             }
-            if (freqi[1] < freqi[0]) { const int t = freqi[0]; freqi[0] = freqi[1]; freqi[1] = t; }
-            for (int m = 0; m < 2; m++) { f_est[m] = (float)freqi[m] * ((float)a.Fs / (float)Ndft); dphi[m] = a.dphi_peak[freqi[m] + Ndft / 2]; }
+            for (int i = 1; i < M; i++)                                     // the reference's gnome sort: ascending
+                for (int j = i; j > 0 && freqi[j] < freqi[j - 1]; j--) { const int t = freqi[j]; freqi[j] = freqi[j - 1]; freqi[j - 1] = t; }
+            for (int m = 0; m < M; m++) { f_est[m] = (float)freqi[m] * ((float)a.Fs / (float)Ndft); dphi[m] = a.dphi_peak[freqi[m] + Ndft / 2]; }
         }
-        // mask estimator: two 3-bin groups fs_tx apart dragged over Sf (fsk.c:551-581)
+        // mask estimator: M 3-bin groups fs_tx apart dragged over Sf (fsk.c:551-581)
         if (a.est_type) {
             for (int b = a.st + tid; b < a.en - a.len_mask; b += FSK_THREADS) {
                 float corr = 0.0f;
@@ -143,36 +148,37 @@ void k_fsk_demod(const FskArgs a) {
             }
             __syncthreads();
             const int b_max = block_argmax(s_Sc, a.st, a.en - a.len_mask, a.st, s_rf, s_ri);
-            for (int m = 0; m < 2; m++) { f_est[m] = a.f_mask[2 * b_max + m]; dphi[m] = a.dphi_mask[2 * b_max + m]; }
+            for (int m = 0; m < M; m++) { f_est[m] = a.f_mask[M * b_max + m]; dphi[m] = a.dphi_mask[M * b_max + m]; }
         }
         __syncthreads();
 
         // ---- down-conversion with continuous phase (fsk.c:633-656); the oscillator recurrence stays serial
         const int nold = Nmem - nin;
-        if (wave == 0 && lane < 2) {
-            float2 phi = lane ? st.phi_c[1] : st.phi_c[0]; const float2 d = lane ? dphi[1] : dphi[0];
+        if (wave == 0 && lane < M) {
+            float2 phi = st.phi_c[0], d = dphi[0];
+            for (int m = 1; m < M; m++) if (lane == m) { phi = st.phi_c[m]; d = dphi[m]; }
             float2 *o = s_fdc + lane * Nmem + nold;
             for (int j = 0; j < nin; j++) { phi = cmult(phi, d); o[j] = phi; }
             const float av = sqrtf((phi.x * phi.x) + (phi.y * phi.y));
             s_phi[lane] = make_float2(phi.x / av, phi.y / av);
         } else if (tid >= WAVE) {
-            for (int k = tid - WAVE; k < 2 * nold; k += FSK_THREADS - WAVE) {
+            for (int k = tid - WAVE; k < M * nold; k += FSK_THREADS - WAVE) {
                 const int m = k / nold, i = k - m * nold;
                 s_fdc[m * Nmem + i] = tail_g[m * NT + (NT - nold) + i];
             }
         }
         __syncthreads();
-        st.phi_c[0] = s_phi[0]; st.phi_c[1] = s_phi[1];
-        for (int k = tid; k < 2 * nin; k += FSK_THREADS) {
+        for (int m = 0; m < M; m++) st.phi_c[m] = s_phi[m];
+        for (int k = tid; k < M * nin; k += FSK_THREADS) {
             const int m = k / nin, j = k - m * nin;
             const float2 p = s_fdc[m * Nmem + nold + j], x = s_in[j];
             s_fdc[m * Nmem + nold + j] = cmult(x, make_float2(p.x, -p.y));
         }
         __syncthreads();
-        for (int k = tid; k < 2 * NT; k += FSK_THREADS) { const int m = k / NT, i = k - m * NT; tail_g[m * NT + i] = s_fdc[m * Nmem + (Nmem - NT) + i]; }
+        for (int k = tid; k < M * NT; k += FSK_THREADS) { const int m = k / NT, i = k - m * NT; tail_g[m * NT + i] = s_fdc[m * Nmem + (Nmem - NT) + i]; }
 
         // ---- integrate over a symbol period at (nsym+1) P offsets (fsk.c:659-668)
-        for (int k = tid; k < 2 * W; k += FSK_THREADS) {
+        for (int k = tid; k < M * W; k += FSK_THREADS) {
             const int m = k / W, i = k - m * W;
             const float2 *f = s_fdc + m * Nmem + i * Ts / P;
             float2 acc = make_float2(0.f, 0.f);
@@ -180,10 +186,10 @@ void k_fsk_demod(const FskArgs a) {
             s_fint[k] = acc;
         }
         __syncthreads();
-        // ---- fine timing: sum_i (|f_int0|^2 + |f_int1|^2) phi_ft[i]  (fsk.c:682-703)
+        // ---- fine timing: sum_i (sum_m |f_int[m]|^2) phi_ft[i]  (fsk.c:682-703)
         for (int i = tid; i < W; i += FSK_THREADS) {
             float ft1 = 0;
-            for (int m = 0; m < 2; m++) { const float2 v = s_fint[m * W + i]; ft1 += (v.x * v.x) + (v.y * v.y); }
+            for (int m = 0; m < M; m++) { const float2 v = s_fint[m * W + i]; ft1 += (v.x * v.x) + (v.y * v.y); }
             const float2 ph = a.phi_ft[i];
             s_in[i] = make_float2(ft1 * ph.x, ft1 * ph.y);
         }
@@ -204,23 +210,37 @@ void k_fsk_demod(const FskArgs a) {
             st.ppm = (float)(.9 * st.ppm + .1 * appm);
         }
         int nin_next = N;
-        if (norm_rx_timing > 0.25) nin_next = N + Ts / 2;
-        else if (norm_rx_timing < -0.25) nin_next = N - Ts / 2;
+        if (!a.burst) {
+            if (norm_rx_timing > 0.25) nin_next = N + Ts / 2;
+            else if (norm_rx_timing < -0.25) nin_next = N - Ts / 2;
+        }
 
         // ---- soft decisions: integrators resampled by linear interpolation (fsk.c:733-805)
         const int low = (int)floorf(rx_timing), high = (int)ceilf(rx_timing);
         const float fract = rx_timing - (float)low, omf = 1 - fract;
-        float *sd = a.sd + (size_t)ch * a.sd_cap + (size_t)frames * nsym;
+        float *sd = a.sd + (size_t)ch * a.sd_cap + (size_t)frames * nsym * (M / 2);
+        uint8_t *hb = a.hb + (size_t)ch * a.sd_cap + (size_t)frames * nsym * (M / 2);
         for (int i = tid; i < nsym; i += FSK_THREADS) {
             const int sp = (i + 1) * P;
-            float tmax[2];
-            for (int m = 0; m < 2; m++) {
+            float tmax[4];
+            for (int m = 0; m < M; m++) {
                 const float2 lo = s_fint[m * W + sp + low], hi = s_fint[m * W + sp + high];
                 const float2 t = cadd(make_float2(omf * lo.x, omf * lo.y), make_float2(fract * hi.x, fract * hi.y));
                 tmax[m] = (t.x * t.x) + (t.y * t.y);
             }
-            s_ebv[i] = tmax[1] > tmax[0] ? tmax[1] : tmax[0];
-            sd[i] = sqrtf(tmax[0]) - sqrtf(tmax[1]);
+            float mx = tmax[0]; int sym = 0;                                // first maximum wins (fsk.c:760-768)
+            for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+            s_ebv[i] = mx;
+            if (M == 2) { sd[i] = sqrtf(tmax[0]) - sqrtf(tmax[1]); hb[i] = (uint8_t)(sym == 1); }
+            else {
+                hb[2 * i + 1] = (uint8_t)(sym & 1); hb[2 * i] = (uint8_t)((sym & 2) >> 1);                                                          // 4-FSK: two soft bits per symbol, summed in the reference's order (fsk.c:793-802)
+                const float t0 = sqrtf(tmax[0]), t1 = sqrtf(tmax[1]), t2 = sqrtf(tmax[2]), t3 = sqrtf(tmax[3]);
+                float lsb = -t0, msb = -t0;
+                lsb += t1; msb += -t1;
+                lsb += -t2; msb += t2;
+                lsb += t3; msb += t3;
+                sd[2 * i + 1] = lsb; sd[2 * i] = msb;
+            }
         }
         // eye diagram samples (fsk.c:857-889): 4 traces of two symbols per tone, |f_int[m][2 P i + high + 1 + j dec]|; the
         // reference overwrites them every frame, normalisation happens when the stats are read
@@ -228,10 +248,10 @@ void k_fsk_demod(const FskArgs a) {
             const int dec = (int)ceilf(((float)P * 2) / 160.0f), nes = (P * 2) / dec;
             float *eye = a.eye + (size_t)ch * 8 * 160;
             for (int q = tid; q < 8 * nes; q += FSK_THREADS) {
-                const int row = q / nes, j = q - row * nes, i = row >> 1, m = row & 1;
+                const int row = q / nes, j = q - row * nes, i = row / M, m = row - i * M;
                 const int ind = 2 * P * i + high + 1 + j * dec;
                 // high + 1 can be -1 (rx_timing in [-P/2, -2]): the reference then reads f_int[m][-1], i.e. the last integrator of
-                // the other tone for m = 1 and memory in front of the array for m = 0 (undefined there; 0 here)
+                // the previous tone for m > 0 and memory in front of the array for m = 0 (undefined there; 0 here)
                 const float2 v = (ind < W && m * W + ind >= 0) ? s_fint[m * W + ind] : make_float2(0.f, 0.f);
                 eye[row * 160 + j] = sqrtf((v.x * v.x) + (v.y * v.y));
             }
@@ -252,9 +272,9 @@ void k_fsk_demod(const FskArgs a) {
             st.EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
             st.snr_est = (float)(.5 * st.snr_est + .5 * st.EbNodB);
         }
-        st.f_est[0] = f_est[0]; st.f_est[1] = f_est[1];
+        for (int m = 0; m < M; m++) st.f_est[m] = f_est[m];
         if (tid == 0) {
-            FskFrameRec r; r.nin = nin; r.nin_next = nin_next; r.f_est[0] = f_est[0]; r.f_est[1] = f_est[1];
+            FskFrameRec r; r.nin = nin; r.nin_next = nin_next; for (int m = 0; m < 4; m++) r.f_est[m] = m < M ? f_est[m] : 0.f;
             r.norm_rx_timing = norm_rx_timing; r.ppm = st.ppm; r.EbNodB = st.EbNodB; r.snr_est = st.snr_est;
             a.recs[(size_t)ch * a.rec_cap + frames] = r;
         }
@@ -268,15 +288,18 @@ void k_fsk_demod(const FskArgs a) {
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     const int W = (a->nsym + 1) * a->P;
     const int n_in = (a->N + a->Ts / 2) > W ? (a->N + a->Ts / 2) : W;
-    const int n_fdc = 2 * a->Nmem > 4 * a->Ndft ? 2 * a->Nmem : 4 * a->Ndft;
-    const size_t u1 = (size_t)a->max_fft * a->Ndft * sizeof(float), u2 = (size_t)(4 * W + a->nsym) * sizeof(float);
+    const int n_fdc = a->M * a->Nmem > 4 * a->Ndft ? a->M * a->Nmem : 4 * a->Ndft;
+    const size_t u1 = (size_t)a->max_fft * a->Ndft * sizeof(float), u2 = (size_t)(2 * a->M * W + a->nsym) * sizeof(float);
     const size_t lds = (size_t)(n_in + n_fdc) * sizeof(float2) + (u1 > u2 ? u1 : u2);
     if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
-    static size_t attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fsk_demod), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr = lds;
+    if (a->M != 2 && a->M != 4) return -1;
+    static size_t attr[2] = { 0, 0 };
+    const void *fn = a->M == 2 ? reinterpret_cast<const void *>(k_fsk_demod<2>) : reinterpret_cast<const void *>(k_fsk_demod<4>);
+    if (lds > attr[a->M == 4]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        attr[a->M == 4] = lds;
     }
-    hipLaunchKernelGGL(k_fsk_demod, dim3(a->n_ch), dim3(FSK_THREADS), lds, s, *a);
+    if (a->M == 2) hipLaunchKernelGGL(k_fsk_demod<2>, dim3(a->n_ch), dim3(FSK_THREADS), lds, s, *a);
+    else           hipLaunchKernelGGL(k_fsk_demod<4>, dim3(a->n_ch), dim3(FSK_THREADS), lds, s, *a);
     return 0;
 }

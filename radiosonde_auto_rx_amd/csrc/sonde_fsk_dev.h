@@ -1,4 +1,4 @@
-// sonde_fsk_dev.h — structs shared by the 2-FSK modem kernel (sonde_fsk.hip) and its host engine (sonde_fsk.cpp).
+// sonde_fsk_dev.h — structs shared by the 2-/4-FSK modem kernel (sonde_fsk.hip) and its host engine (sonde_fsk.cpp).
 #ifndef SONDE_FSK_DEV_H
 #define SONDE_FSK_DEV_H
 #include <hip/hip_runtime.h>
@@ -7,39 +7,42 @@
 #define FSK_THREADS 256
 
 struct FskChan {                      // per-channel struct FSK state (utils/fsk.h:47-95) that survives a modem frame
-    float2 phi_c[2];                  // demod local oscillators
+    float2 phi_c[4];                  // demod local oscillators (M of them)
     int    nin;                       // samples the next frame wants
     float  norm_rx_timing, ppm, EbNodB, snr_est;
-    float  f_est[2];                  // estimates used by the last frame
+    float  f_est[4];                  // estimates used by the last frame
     uint32_t rd;                      // absolute index of the next unread input sample
     long long samples;                // sample_count of fsk_demod.c
     int    frames;                    // frames produced by the current launch
     int    pad;
 };
 
-struct FskFrameRec { int nin, nin_next; float f_est[2]; float norm_rx_timing, ppm, EbNodB, snr_est; };
+struct FskFrameRec { int nin, nin_next; float f_est[4]; float norm_rx_timing, ppm, EbNodB, snr_est; };
 
 struct FskArgs {
     const void *in;                   // [n_ch][ring] raw samples (int16 / int16x2 / uint8x2)
     int format;                       // SONDE_FSK_*
+    int M;                            // tones: 2 or 4 (fsk.h:40, MODE_2FSK / MODE_4FSK)
+    int burst;                        // fsk_enable_burst_mode: nin stays N (fsk.c:724)
     int n_ch; uint32_t ring; uint32_t wr;          // absolute write index: samples [rd, wr) are available
     int Fs, Rs, Ts, P, nsym, N, Ndft, log2Ndft, Nmem, NT;   // NT = 2 Ts + Ts/2 tail samples kept per tone
     int st, en, f_zero, len_mask, est_type, fs_tx;
-    int n_mask, mask_idx[6];          // positions of the ones in the mask estimator's mask (fsk.c:553-560)
+    int n_mask, mask_idx[12];         // positions of the ones in the mask estimator's mask (fsk.c:553-560): 3 per tone
     float tc;
     const float *hann;                // [Ndft]
     const float2 *tw;                 // [Ndft/2] exp(-2 pi i k / Ndft)
     const float2 *dphi_peak;          // [Ndft]    comp_exp_j(2 pi f/Fs) for f = (k - Ndft/2) Fs/Ndft
-    const float2 *dphi_mask;          // [Ndft][2] same for the mask estimator's f2_est
-    const float *f_mask;              // [Ndft][2] f2_est values
+    const float2 *dphi_mask;          // [Ndft][M] same for the mask estimator's f2_est
+    const float *f_mask;              // [Ndft][M] f2_est values
     const float2 *phi_ft;             // [(nsym+1) P] timing oscillator sequence
     FskChan *chan;                    // [n_ch]
     float *Sf;                        // [n_ch][Ndft]
-    float2 *tail;                     // [n_ch][2][NT]
-    float *sd; int sd_cap;            // [n_ch][sd_cap] soft decisions of this launch
+    float2 *tail;                     // [n_ch][M][NT]
+    float *sd; int sd_cap;            // [n_ch][sd_cap] soft decisions of this launch (nsym per frame, 2 nsym for 4-FSK)
+    uint8_t *hb;                      // [n_ch][sd_cap] hard bits (rx_bits of fsk_demod, fsk.c:770-778)
     FskFrameRec *recs; int rec_cap;   // [n_ch][rec_cap]
     int max_fft;                      // most FFT blocks a frame can have
-    float *eye;                       // [n_ch][8][160] |f_int| samples of the last frame for the eye diagram (fsk.c:857-889), may be nullptr
+    float *eye;                       // [n_ch][8][160] |f_int| samples of the last frame for the eye diagram (fsk.c:857-889; row = trace * M + tone), may be nullptr
 };
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s);

@@ -11,13 +11,13 @@ import numpy as np
 
 from .engine import ABI_VERSION, _chk, lib
 
-S16, CS16, CU8 = 1, 2, 3
+S16, CS16, CU8, CF32 = 1, 2, 3, 4
 
 
 class FskCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "device", "n_channels", "Fs", "Rs", "M", "P", "nsym", "format",
                                          "fsk_lower", "fsk_upper", "mask", "tone_spacing", "max_chunk")] + \
-               [("reserved", C.c_int32 * 4)]
+               [("burst_mode", C.c_int32), ("raw_eye", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class FskInfo(C.Structure):
@@ -25,7 +25,7 @@ class FskInfo(C.Structure):
 
 
 class FskFrame(C.Structure):
-    _fields_ = [("nin", C.c_int32), ("nin_next", C.c_int32), ("f_est", C.c_float * 2), ("norm_rx_timing", C.c_float),
+    _fields_ = [("nin", C.c_int32), ("nin_next", C.c_int32), ("f_est", C.c_float * 4), ("norm_rx_timing", C.c_float),
                 ("ppm", C.c_float), ("EbNodB", C.c_float), ("snr_est", C.c_float)]
 
 
@@ -50,16 +50,16 @@ def _lib():
 
 
 class FskModem:
-    """Batched `fsk_demod [--cs16|--cu8] -s [-b lo] [-u hi] [--mask S] [--nsym N] [-p P] 2 Fs Rs - -` for n channels."""
+    """Batched `fsk_demod [--cs16|--cu8] -s [-b lo] [-u hi] [--mask S] [--nsym N] [-p P] (2|4) Fs Rs - -` for n channels."""
 
     def __init__(self, Fs: int, Rs: int, *, n_channels: int = 1, P: int = 8, nsym: int = 50, fmt: int = CS16,
-                 lower: int | None = None, upper: int | None = None, mask: int = 0, max_chunk: int | None = None, device: int = 0):
-        self.n_channels, self.Fs, self.Rs, self.nsym, self.fmt = n_channels, Fs, Rs, nsym, fmt
+                 lower: int | None = None, upper: int | None = None, mask: int = 0, max_chunk: int | None = None, device: int = 0, M: int = 2):
+        self.n_channels, self.Fs, self.Rs, self.nsym, self.fmt, self.M = n_channels, Fs, Rs, nsym, fmt, M
         if lower is None:
             lower = -Fs // 2 if fmt != S16 else 0
         if upper is None:
             upper = Fs // 2
-        cfg = FskCfg(ABI_VERSION, device, n_channels, Fs, Rs, 2, P, nsym, fmt, lower, upper, int(mask > 0), mask if mask else 100,
+        cfg = FskCfg(ABI_VERSION, device, n_channels, Fs, Rs, M, P, nsym, fmt, lower, upper, int(mask > 0), mask if mask else 100,
                      max_chunk or Fs)
         h = C.c_void_p()
         _chk(_lib().sonde_fsk_create(C.byref(cfg), C.byref(h)))
@@ -88,22 +88,23 @@ class FskModem:
         _chk(_lib().sonde_fsk_process_device(self._h, C.c_void_p(ptr), ch_stride, n))
 
     def fetch(self, ch: int = 0):
-        """-> (soft decisions [frames, nsym], list of per-frame dicts) of the last process call."""
+        """-> (soft decisions [frames, Nbits], list of per-frame dicts) of the last process call."""
         cap = 4096
         fr = (FskFrame * cap)()
         nf = C.c_int32(0)
-        sd = np.zeros(cap * self.nsym, np.float32)
+        nbits = self.info["Nbits"]
+        sd = np.zeros(cap * nbits, np.float32)
         nb = _chk(_lib().sonde_fsk_fetch(self._h, ch, sd.ctypes.data_as(C.c_void_p), len(sd), fr, cap, C.byref(nf)))
-        recs = [dict(nin=fr[i].nin, nin_next=fr[i].nin_next, f_est=(fr[i].f_est[0], fr[i].f_est[1]), norm_rx_timing=fr[i].norm_rx_timing,
+        recs = [dict(nin=fr[i].nin, nin_next=fr[i].nin_next, f_est=tuple(fr[i].f_est[m] for m in range(self.M)), norm_rx_timing=fr[i].norm_rx_timing,
                      ppm=fr[i].ppm, EbNodB=fr[i].EbNodB, snr_est=fr[i].snr_est) for i in range(nf.value)]
-        return sd[:nb].reshape(-1, self.nsym), recs
+        return sd[:nb].reshape(-1, nbits), recs
 
     def stats(self, ch: int = 0):
         last = FskFrame()
         Sf = np.zeros(self.info["Ndft"], np.float32)
         n = C.c_int64(0)
         _chk(_lib().sonde_fsk_stats(self._h, ch, C.byref(last), Sf.ctypes.data_as(C.c_void_p), C.byref(n)))
-        return dict(f_est=(last.f_est[0], last.f_est[1]), ppm=last.ppm, EbNodB=last.EbNodB, snr_est=last.snr_est,
+        return dict(f_est=tuple(last.f_est[m] for m in range(self.M)), ppm=last.ppm, EbNodB=last.EbNodB, snr_est=last.snr_est,
                     norm_rx_timing=last.norm_rx_timing, nin=last.nin_next, Sf=Sf, samples=n.value)
 
     def eye(self, ch: int = 0) -> np.ndarray:

@@ -176,3 +176,96 @@ def test_cli_stats_lines_match_reference(name):
             assert np.all(np.abs(ea - eb) <= 2e-6 + 1e-5 * np.abs(eb)), (np.abs(ea - eb).max())
             n_eye += 1
     assert n_eye >= len(want) // 2
+
+
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "fsk_demod")
+SEAMBIN = os.path.join(ROOT, "oracle", "_ref", "fsk_demod_seam")
+NATIVE = os.path.join(ROOT, "host", "bin", "fsk_demod")
+
+
+def _run3(args, data, which=("native", "seam", "ref")):
+    """-> {name: CompletedProcess} of this repo's CLI, the reference's fsk_demod.c on the fsk.h seam, and the all-CPU reference"""
+    if not (os.path.exists(REFBIN) and os.path.exists(SEAMBIN)):
+        pytest.skip("oracle/_ref fsk_demod / fsk_demod_seam not built (make -C oracle ref)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    bins = dict(native=NATIVE, seam=SEAMBIN, ref=REFBIN)
+    out = {k: subprocess.run([bins[k]] + args, input=data, capture_output=True, timeout=300) for k in which}
+    for k, r in out.items():
+        assert r.returncode == 0, (k, r.stderr[-400:])
+    return out
+
+
+def _sd_close(a: bytes, b: bytes):
+    x, y = np.frombuffer(a, np.float32), np.frombuffer(b, np.float32)
+    rms = float(np.sqrt(np.mean(y.astype(np.float64) ** 2)))
+    assert x.shape == y.shape and len(y) > 0
+    assert np.abs(x - y).max() < 1e-5 * rms and np.array_equal(x < 0, y < 0)
+
+
+@pytest.mark.parametrize("name", ["fsk_rs41_48k_mask", "fsk_dfm_50k", "fsk_rs41_48k_peak"])
+def test_fsk_h_seam_reference_main_on_gpu_modem(name):
+    """The reference's own utils/fsk_demod.c linked against host/seam/fsk_hip.c (fsk.h:115-205 over libsonde_hip) instead of fsk.c:
+    soft decisions, hard decisions and --stats lines like the all-CPU binary."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    x, case = fsk_capture(name)
+    o = _run3(["--stats=5"] + make_golden.fsk_cli_args(case), x.tobytes(), which=("seam", "ref"))
+    _sd_close(o["seam"].stdout, o["ref"].stdout)
+    got, want = _parse_stats(o["seam"].stderr.decode()), _parse_stats(o["ref"].stderr.decode())
+    assert o["seam"].stderr.decode().splitlines()[0] == o["ref"].stderr.decode().splitlines()[0]
+    assert len(got) == len(want) >= 3
+    for a, b in zip(got, want):
+        assert a["samples"] == b["samples"] and a["ppm"] == b["ppm"] and a["EbNodB"] == b["EbNodB"]
+        assert a["f1_est"] == b["f1_est"] and a["f2_est"] == b["f2_est"]
+        fa, fb = np.array(a["samp_fft"]), np.array(b["samp_fft"])
+        assert fa.shape == fb.shape and np.all(np.abs(fa - fb) <= 2e-6 + 1e-5 * np.abs(fb))
+    o = _run3(make_golden.fsk_cli_args(case, soft=False), x.tobytes(), which=("seam", "ref"))
+    assert o["seam"].stdout == o["ref"].stdout and len(o["ref"].stdout) > 0
+
+
+@pytest.mark.parametrize("mask", [0, 2400])
+def test_4fsk_matches_reference(mask):
+    """4-FSK (fsk.c: M = 4 — four tone estimates, four down-converters / integrators, two soft bits per symbol :793-802): this repo's
+    CLI and the seam against the compiled reference on a synthetic 4-tone signal; hard bits recover what was sent."""
+    from tools import synth
+    rng = np.random.default_rng(4)
+    bits = rng.integers(0, 2, 2 * 50 * 200)
+    x = synth.mfsk_capture(bits, 48000, 2400, 4, f_low=-3600.0, shift=2400.0, noise_sigma=0.12, seed=9)
+    base = ["--cs16", "-p", "5", "--stats=4"] + (["--mask", str(mask)] if mask else [])
+    o = _run3(base + ["-s", "4", "48000", "2400", "-", "-"], x.tobytes())
+    _sd_close(o["native"].stdout, o["ref"].stdout)
+    _sd_close(o["seam"].stdout, o["ref"].stdout)
+    want = _parse_stats(o["ref"].stderr.decode())
+    for k in ("native", "seam"):
+        got = _parse_stats(o[k].stderr.decode())
+        assert len(got) == len(want) >= 3
+        for a, b in zip(got, want):
+            assert all(a[f] == b[f] for f in ("samples", "ppm", "EbNodB", "f1_est", "f2_est", "f3_est", "f4_est"))
+    h = _run3(base + ["4", "48000", "2400", "-", "-"], x.tobytes())
+    assert h["native"].stdout == h["ref"].stdout == h["seam"].stdout
+    rx = np.frombuffer(h["ref"].stdout, np.uint8)
+    # the demodulated stream is the sent one after the modem's start-up delay
+    best = max(int(np.sum(rx[d:d + 10000] == bits[:10000])) for d in range(0, 400, 2))
+    assert best >= 9990
+
+
+def test_testframes_ber_lines_match_reference():
+    """--testframes (fsk_demod.c:239-256,319-357): the sliding 100-bit comparison against the srand(158324) frame — every `errs:` line
+    of the reference, and the frames / bits / errs fields of the --stats variant."""
+    from tools import synth
+    bits = synth.fsk_test_frame_bits(60)
+    x = synth.mfsk_capture(bits, 48000, 4800, 2, f_low=-2400.0, shift=4800.0, noise_sigma=0.4, seed=3)
+    o = _run3(["--cs16", "--testframes", "2", "48000", "4800", "-", "-"], x.tobytes())
+    want = o["ref"].stderr.decode().splitlines()
+    assert len([l for l in want if l.startswith("errs:")]) >= 20
+    assert o["native"].stderr.decode().splitlines() == want and o["seam"].stderr.decode().splitlines() == want
+    o = _run3(["--cs16", "-s", "--testframes", "--stats=10", "2", "48000", "4800", "-", "-"], x.tobytes())
+    want = o["ref"].stderr.decode().splitlines()[1:]
+    import json
+    for k in ("native", "seam"):
+        got = o[k].stderr.decode().splitlines()[1:]
+        assert len(got) == len(want) >= 20
+        for a, b in zip(got, want):
+            a, b = json.loads(a), json.loads(b)
+            assert all(a[f] == b[f] for f in ("samples", "frames", "bits", "errs", "ppm", "f1_est", "f2_est")) and "eye_diagram" not in a

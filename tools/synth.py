@@ -690,3 +690,34 @@ def imet_capture(sr: int = 48_000, seconds: float = 3.0, *, f_offset_hz: float =
     out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
     out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
     return out
+
+
+def mfsk_capture(bits: np.ndarray, sr: int, baud: int, M: int = 2, *, f_low: float = 1500.0, shift: float = 400.0, amp: float = 0.4,
+                 noise_sigma: float = 0.02, seed: int = 1) -> np.ndarray:
+    """Continuous-phase M-FSK (M = 2 or 4) as interleaved complex int16: symbol m = tone f_low + m * shift, MSB first for 4-FSK
+    (the bit order of the reference's fsk_mod, utils/fsk.c:302-312)."""
+    bits = np.asarray(bits, dtype=np.int64)
+    if M == 4:
+        sym = 2 * bits[0::2][:len(bits) // 2] + bits[1::2][:len(bits) // 2]
+    else:
+        sym = bits
+    sps = sr // baud
+    f = np.repeat(f_low + shift * sym, sps).astype(np.float64)
+    ph = 2 * np.pi * np.cumsum(f) / sr
+    rng = np.random.default_rng(seed)
+    z = amp * np.exp(1j * ph) + noise_sigma * (rng.standard_normal(len(ph)) + 1j * rng.standard_normal(len(ph)))
+    out = np.empty(2 * len(z), np.int16)
+    out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
+    out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
+    return out
+
+
+def fsk_test_frame_bits(n_frames: int) -> np.ndarray:
+    """The 100-bit test frame of the reference's fsk_demod --testframes (utils/fsk_demod.c:30,247-251: srand(158324), rand() & 1 from
+    the C library), repeated."""
+    import ctypes
+    import ctypes.util
+    libc = ctypes.CDLL(ctypes.util.find_library("c") or "libc.so.6")
+    libc.srand(158324)
+    frame = np.array([libc.rand() & 1 for _ in range(100)], dtype=np.int64)
+    return np.tile(frame, n_frames)
