@@ -24,7 +24,12 @@
  *
  * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs are
  * taken from the first find_header call; a header of the wrong polarity that the
- * caller skips still has its frame consumed; --spike is ignored; f32buf_sample() is not available (EOF).
+ * caller skips still has its frame consumed; f32buf_sample() is not available (EOF).
+ * The bit readers take per-call arguments the batched engine fixed when the hit was sliced: `ofs` must be the bitofs given to find_header() and
+ * `l` the window this decoder always passes (-1, or its centre window for opt_iq > 2) — every decoder of the family does exactly that; any other
+ * value, and spike != 0, ends the program with a message instead of returning bits that were sliced differently.  (spike: the reference's
+ * clipping compares against a local `avg` that is read before it is ever written, demod_mod.c:945,975 / :1016,1046 / :1092,1121 — its output
+ * depends on what the compiler left in that register, so there is nothing well defined to mirror.)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +53,7 @@ static struct {
     float *soft, *soft1;
     int qn, qi;
     const float *cur, *cur1; int cur_nbits, cur_inv;
+    int bitofs; float l_win;      /* what the hits were sliced with: find_header()'s bitofs, the decoder's window */
     sonde_cfg_t cfg; sonde_generic_t gen; double fq; int generic;
 } S;
 
@@ -117,6 +123,8 @@ int init_buffers(dsp_t *dsp) {
         cfg.lpiq_bw = 0;
     }
     S.generic = type == SONDE_GENERIC; S.cfg = cfg; S.fq = fq;
+    /* centre window only for opt_iq > 2 (rs41mod.c:2920-2921, dfm09mod.c:1692-1694, m10mod.c:1470-1472, ...), whole symbols otherwise */
+    S.l_win = dsp->opt_iq > 2 ? (type == SONDE_GENERIC ? kFamily[fam].l : type == SONDE_RS41 ? 2.0f : 4.0f) : -1.0f;
     int rc = S.generic ? sonde_engine_create_generic(&cfg, &fq, &S.gen, &S.eng) : sonde_engine_create(&cfg, &fq, &S.eng);
     if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); S.eng = NULL; return -1; }
     sonde_engine_info(S.eng, &S.info);
@@ -158,6 +166,7 @@ int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
     if (!S.started) {                                  /* the caller's threshold, accepted header errors and bit offset (e.g. -d <shift>) */
         sonde_engine_set_threshold(S.eng, thres);
         if (sonde_engine_set_sync(S.eng, hdmax, bitofs) < 0) { fprintf(stderr, "demod_mod_hip: hdmax %d / bitofs %d out of range\n", hdmax, bitofs); return EOF; }
+        S.bitofs = bitofs;
         S.started = 1;
     }
     for (;;) {
@@ -189,8 +198,16 @@ int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
     }
 }
 
-static int seam_bit(int inv, int pos, float *sb, float *sb1) {
+static void seam_reject(const char *what, double got, double want) {
+    fprintf(stderr, "demod_mod_hip: %s = %g is not what the hit was sliced with (%g); the GPU engine cannot re-slice per call\n", what, got, want);
+    exit(2);
+}
+
+static int seam_bit(int inv, int ofs, float l, int spike, int pos, float *sb, float *sb1) {
     if (!S.cur || pos < 0 || pos >= S.cur_nbits) return EOF;
+    if (spike) { fprintf(stderr, "demod_mod_hip: spike clipping is not supported (undefined in the reference: demod_mod.c:945,975)\n"); exit(2); }
+    if (ofs != S.bitofs) seam_reject("ofs", ofs, S.bitofs);
+    if ((l < 0) != (S.l_win < 0) || (l >= 0 && l != S.l_win)) seam_reject("l", l, S.l_win);
     float s = S.cur[pos], s1 = S.cur1[pos];
     if (S.cur_inv) { s = -s; s1 = -s1; }            /* the engine stores the bits in the polarity in effect; the reference returns them raw */
     if (inv) { s = -s; s1 = -s1; }
@@ -200,8 +217,8 @@ static int seam_bit(int inv, int pos, float *sb, float *sb1) {
 
 int read_softbit2p(dsp_t *dsp, hsbit_t *shb, int inv, int ofs, int pos, float l, int spike, hsbit_t *shb1) {
     float s, s1;
-    (void)dsp; (void)ofs; (void)l; (void)spike;
-    if (seam_bit(inv, pos, &s, &s1) == EOF) return EOF;
+    (void)dsp;
+    if (seam_bit(inv, ofs, l, spike, pos, &s, &s1) == EOF) return EOF;
     shb->sb = s; shb->hb = (s >= 0.f);
     if (shb1) { shb1->sb = s1; shb1->hb = (s1 >= 0.f); }
     return 0;
@@ -214,8 +231,8 @@ int read_softbit(dsp_t *dsp, hsbit_t *shb, int inv, int ofs, int pos, float l, i
 /* hard bit; behind the end of a hit (the M10 / M20 "rest of the second") the engine has already skipped: 0 until the stream is over */
 int read_slbit(dsp_t *dsp, int *bit, int inv, int ofs, int pos, float l, int spike) {
     float s, s1;
-    (void)dsp; (void)ofs; (void)l; (void)spike;
-    if (seam_bit(inv, pos, &s, &s1) == 0) { *bit = (s >= 0.f); return 0; }
+    (void)dsp;
+    if (seam_bit(inv, ofs, l, spike, pos, &s, &s1) == 0) { *bit = (s >= 0.f); return 0; }
     if (S.eof && S.qi >= S.qn) return EOF;
     *bit = 0;
     return 0;

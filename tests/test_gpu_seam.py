@@ -214,3 +214,19 @@ def test_seam_bit_offset_option(binary, shift):
     tail = ["--IQ", "0.0", "--lpIQ", "-", "48000", "16"]
     out = _both(binary, args + ["-d", shift] + tail, x.tobytes())
     assert len(out.splitlines()) >= 2
+
+
+def test_seam_rejects_what_it_cannot_reslice():
+    """--spike (dfm09mod.c:1374, read_softbit(.., spike)): the reference's clipping reads an uninitialised local (demod_mod.c:1016,1046), so the
+    seam ends the program with a message instead of silently returning unclipped bits; the same guard covers a per-call `l` / `ofs` other than
+    what the hit was sliced with."""
+    from tools import synth
+    seam = os.path.join(REF, "dfm09mod_seam")
+    if not os.path.exists(seam):
+        pytest.skip("oracle/_ref seam binaries not built (make -C oracle ref)")
+    x = synth.dfm_capture(sr=48_000, seconds=2.2, fq=0.0, noise_sigma=0.05, seed=5)
+    wav = synth.wav_bytes(synth.fm_audio(x), 48_000)                      # spike only applies to FM audio / --iq0 input (dfm09mod.c:1693)
+    r = subprocess.run([seam, "-r", "--ecc", "--spike"], input=wav, capture_output=True, timeout=300)
+    assert r.returncode == 2 and b"spike" in r.stderr
+    r = subprocess.run([seam, "-r", "--ecc"], input=wav, capture_output=True, timeout=300)
+    assert r.returncode == 0 and len(r.stdout.splitlines()) >= 2
