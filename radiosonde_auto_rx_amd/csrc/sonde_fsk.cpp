@@ -20,6 +20,7 @@ struct sonde_fsk {
     FskArgs args{};
     hipStream_t stream = nullptr;
     void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr, *d_eye = nullptr;
+    uint16_t *d_perm = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
     FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; std::vector<uint8_t> h_hb;
     std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
@@ -95,9 +96,26 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 
     // ---- tables
     std::vector<float> hann(Ndft), fmask((size_t)Ndft * M);
-    std::vector<float2> tw(Ndft / 2), dpeak(Ndft), dmask((size_t)Ndft * M), phift((size_t)(nsym + 1) * P);
+    std::vector<float2> tw(Ndft), dpeak(Ndft), dmask((size_t)Ndft * M), phift((size_t)(nsym + 1) * P);
     for (int i = 0; i < Ndft; i++) hann[i] = 0.5 - 0.5 * cosf(2.0 * M_PI * (float)i / (float)(Ndft - 1));
-    for (int k = 0; k < Ndft / 2; k++) { const double ang = -2.0 * M_PI * k / Ndft; tw[k] = make_float2((float)cos(ang), (float)sin(ang)); }
+    std::vector<uint16_t> perm(Ndft);
+    {   // kiss_fft_alloc / kf_factor / kf_work (kiss_fft.c:340-366, :304-331, :238-300): twiddles from cosf / sinf of the float phase,
+        // factors 4,4,..(,2); output slot sum_s k_s m_s holds input sum_s k_s fstride_s; stages run innermost first
+        for (int k = 0; k < Ndft; k++) {
+            const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
+            const double phase = -2 * pi * k / Ndft;
+            tw[k] = make_float2(cosf(phase), sinf(phase));
+        }
+        int fp[8], fm[8], ffs[8], L = 0, n = Ndft, stride = 1;
+        while (n > 1) { const int p = (n % 4 == 0) ? 4 : 2; n /= p; fp[L] = p; fm[L] = n; ffs[L] = stride; stride *= p; L++; }
+        for (int o = 0; o < Ndft; o++) {
+            int rem = o, in = 0;
+            for (int s = 0; s < L; s++) { const int k = rem / fm[s]; rem -= k * fm[s]; in += k * ffs[s]; }
+            perm[in] = (uint16_t)o;
+        }
+        a.n_stage = L;
+        for (int s = 0; s < L; s++) { a.st_p[s] = fp[L - 1 - s]; a.st_m[s] = fm[L - 1 - s]; a.st_fs[s] = ffs[L - 1 - s]; }
+    }
     for (int k = 0; k < Ndft; k++) {
         const float fp = (float)(k - Ndft / 2) * ((float)Fs / (float)Ndft);             // peak estimator (fsk.c:544-546)
         dpeak[k] = exp_j(2 * M_PI * ((fp) / (float)(Fs)));
@@ -120,7 +138,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     f->unit = cfg->format == SONDE_FSK_CF32 ? 8 : cfg->format == SONDE_FSK_CS16 ? 4 : 2;
     int bad = 0;
     bad |= dalloc((char **)&f->d_in, (size_t)C * ring * f->unit);
-    bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
+    bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_perm, perm); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
     bad |= dupload(&f->d_fmask, fmask); bad |= dupload(&f->d_phift, phift);
     bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * M * a.NT);
     bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_hb, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
@@ -128,7 +146,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     f->h_chan.resize(C);
     for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); for (int m = 0; m < 4; m++) c.phi_c[m] = exp_j(0); c.nin = N; }
     HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
-    a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
+    a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.perm = f->d_perm; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
     a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.hb = f->d_hb; a.recs = f->d_recs;
     f->h_sd.resize((size_t)C * a.sd_cap); f->h_hb.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
     HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
@@ -139,7 +157,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }

@@ -94,17 +94,32 @@ void k_fsk_demod(const FskArgs a) {
             float2 *buf = s_fdc + wave * Ndft;
             if (act) for (int i = lane; i < Ndft; i += WAVE) {
                 const float h = a.hann[i]; const float2 x = s_in[i + j * (Ndft / 2)];
-                buf[(int)(__brev((unsigned)i) >> (32 - a.log2Ndft))] = make_float2(h * x.x, h * x.y);
+                buf[a.perm[i]] = make_float2(h * x.x, h * x.y);
             }
             __syncthreads();
-            for (int s = 0; s < a.log2Ndft; s++) {
-                const int half = 1 << s;
-                if (act) for (int b = lane; b < Ndft / 2; b += WAVE) {
-                    const int i = ((b >> s) << (s + 1)) | (b & (half - 1)), k = i + half;
-                    const float2 t = cmult(buf[k], a.tw[(b & (half - 1)) << (a.log2Ndft - 1 - s)]);
-                    const float2 u = buf[i];
-                    buf[k] = make_float2(u.x - t.x, u.y - t.y);
-                    buf[i] = make_float2(u.x + t.x, u.y + t.y);
+            // the reference's transform, butterfly for butterfly (kiss_fft.c kf_work / kf_bfly4 / kf_bfly2: radix-4 stages, one radix-2
+            // stage when log2 Ndft is odd, innermost factor first, separately rounded mul / add) so that Sf and with it every estimator
+            // decision is the reference's bit for bit
+            for (int s = 0; s < a.n_stage; s++) {
+                const int p = a.st_p[s], m = a.st_m[s], fs = a.st_fs[s];
+                if (act) for (int b = lane; b < Ndft / p; b += WAVE) {
+                    const int blk = b / m, u = b - blk * m;
+                    float2 *F = buf + blk * p * m + u;
+                    if (p == 4) {
+                        const float2 s0 = cmult(F[m], a.tw[u * fs]), s1 = cmult(F[2 * m], a.tw[2 * u * fs]), s2 = cmult(F[3 * m], a.tw[3 * u * fs]);
+                        float2 f0 = F[0];
+                        const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
+                        f0 = cadd(f0, s1);
+                        const float2 s3 = cadd(s0, s2), s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
+                        F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
+                        F[0] = cadd(f0, s3);
+                        F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
+                        F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
+                    } else {
+                        const float2 t = cmult(F[m], a.tw[u * fs]), f0 = F[0];
+                        F[m] = make_float2(f0.x - t.x, f0.y - t.y);
+                        F[0] = cadd(f0, t);
+                    }
                 }
                 __syncthreads();
             }

@@ -30,7 +30,9 @@ struct FskArgs {
     int n_mask, mask_idx[12];         // positions of the ones in the mask estimator's mask (fsk.c:553-560): 3 per tone
     float tc;
     const float *hann;                // [Ndft]
-    const float2 *tw;                 // [Ndft/2] exp(-2 pi i k / Ndft)
+    const float2 *tw;                 // [Ndft] kiss_fft's twiddles: (cosf, sinf) of (float)(-2 pi k / Ndft) (kiss_fft.c:356-362)
+    const uint16_t *perm;             // [Ndft] where input sample i sits before the first butterfly stage (kf_work's decimation)
+    int n_stage, st_p[8], st_m[8], st_fs[8];   // butterfly stages in execution order: radix, sub-transform length, twiddle stride
     const float2 *dphi_peak;          // [Ndft]    comp_exp_j(2 pi f/Fs) for f = (k - Ndft/2) Fs/Ndft
     const float2 *dphi_mask;          // [Ndft][M] same for the mask estimator's f2_est
     const float *f_mask;              // [Ndft][M] f2_est values

@@ -1,4 +1,4 @@
-"""GPU parity of the batched 2-FSK modem (include/sonde_fsk.h) against the reference's utils/fsk.c.
+"""GPU parity of the batched 2-/4-FSK modem (include/sonde_fsk.h) against the reference's utils/fsk.c.
 
 Golden values come from the compiled reference (tools/make_golden.py: oracle/ref_fsk_harness.c drives fsk_demod_sd the
 way utils/fsk_demod.c does; its soft decisions are asserted equal to the reference CLI's stdout when the fixture is made).
@@ -6,7 +6,8 @@ Tolerances:
   nin sequence, tone estimates (quantised to FFT bins), hard decisions, frame count ............. exact
   soft decisions: the kernel keeps the reference's operation order without fused multiply-adds;
   what is left is libm (atan2f in the timing estimate) .......................................... 1e-6 of the RMS, max 1e-5 of it
-  norm_rx_timing 2e-7 abs, ppm 1e-3, Eb/N0 (log10f) 5e-3 dB, smoothed spectrum Sf 1e-5 relative
+  norm_rx_timing 2e-7 abs, ppm 1e-3, Eb/N0 (log10f) 5e-3 dB; smoothed spectrum Sf exact (the kernel mirrors kiss_fft's radix-4/2
+  butterfly network and twiddles, so estimator decisions cannot flip on near ties)
 """
 import os
 import subprocess
@@ -61,7 +62,7 @@ def test_fsk_frames_match_reference(name):
     sd, recs = _feed(md, x, case["cap"]["sr"], per)
     _check(sd, recs, g)
     st = md.stats(0)
-    assert np.abs(st["Sf"] - g["Sf"]).max() <= 1e-5 * g["Sf"].max()
+    assert np.array_equal(st["Sf"], g["Sf"])                  # the kernel runs kiss_fft's own butterfly network: bit for bit
     assert st["samples"] == int(g["nin"].sum())
 
 
