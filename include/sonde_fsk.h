@@ -71,6 +71,14 @@ int  sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info);
 int  sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
 
+/* Channels fed independently (the resident broker, host/sonde_broker.c: every client reads exactly fsk_nin() samples of its own
+ * stream per frame, and nin differs between channels): channel c gets n_samples[c] samples from h_in[c] (0 = nothing this time).
+ * An engine is fed either this way or through sonde_fsk_process_host / _device, not both. */
+int  sonde_fsk_process_host_var(sonde_fsk_t *f, const void *const *h_in, const int32_t *n_samples);
+/* Back to the state fsk_create_hbr() leaves (oscillators, timing, Sf, nin = N) for one channel; samples queued for it are dropped.
+ * The next samples fed to the channel are the first of a new stream. */
+int  sonde_fsk_reset_channel(sonde_fsk_t *f, int32_t channel);
+
 /* Soft decisions (fsk_demod_sd: one float per bit — 2-FSK: >0 = the lower tone; 4-FSK: two per symbol, fsk.c:793-802) produced by the last process call for one
  * channel; returns the number of floats written (<= max). frames (optional, may be NULL): per-frame records,
  * max_frames entries; *n_frames receives the count. */

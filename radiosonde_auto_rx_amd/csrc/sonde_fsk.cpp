@@ -26,6 +26,7 @@ struct sonde_fsk {
     std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
     size_t unit = 4;
     uint32_t wr = 0;
+    std::vector<uint32_t> wr_ch; uint32_t *d_wr = nullptr;    // per-channel write positions once sonde_fsk_process_host_var is used
     double ms = 0; int64_t launches = 0;
 };
 
@@ -157,7 +158,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_wr };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -168,20 +169,9 @@ int sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info) {
     return 0;
 }
 
-static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hipMemcpyKind kind) {
+static int launch_and_collect(sonde_fsk_t *f) {
     const int C = f->cfg.n_channels;
-    if (n <= 0 || n > f->cfg.max_chunk || ch_stride < n) return SONDE_E_RANGE;
     FskArgs &a = f->args;
-    // append to the per-channel rings (two pieces when the write position wraps)
-    const uint32_t w0 = f->wr & (a.ring - 1);
-    const uint32_t first = std::min<uint32_t>((uint32_t)n, a.ring - w0);
-    char *dst = (char *)f->d_in;
-    HIPCHK(hipMemcpy2DAsync(dst + (size_t)w0 * f->unit, (size_t)a.ring * f->unit, src, (size_t)ch_stride * f->unit, (size_t)first * f->unit, C, kind, f->stream));
-    if (first < (uint32_t)n)
-        HIPCHK(hipMemcpy2DAsync(dst, (size_t)a.ring * f->unit, (const char *)src + (size_t)first * f->unit, (size_t)ch_stride * f->unit,
-                                (size_t)(n - first) * f->unit, C, kind, f->stream));
-    f->wr += (uint32_t)n;
-    a.wr = f->wr;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, f->stream);
     const int lrc = sonde_launch_fsk(&a, f->stream);
@@ -197,6 +187,34 @@ static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hi
     return 0;
 }
 
+// append n samples of one channel to its ring at absolute position w (two pieces when it wraps)
+static int ring_write(sonde_fsk_t *f, int ch, uint32_t w, const char *src, int32_t n, hipMemcpyKind kind) {
+    const FskArgs &a = f->args;
+    const uint32_t w0 = w & (a.ring - 1), first = std::min<uint32_t>((uint32_t)n, a.ring - w0);
+    char *dst = (char *)f->d_in + (size_t)ch * a.ring * f->unit;
+    HIPCHK(hipMemcpyAsync(dst + (size_t)w0 * f->unit, src, (size_t)first * f->unit, kind, f->stream));
+    if (first < (uint32_t)n) HIPCHK(hipMemcpyAsync(dst, src + (size_t)first * f->unit, (size_t)(n - first) * f->unit, kind, f->stream));
+    return 0;
+}
+
+static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hipMemcpyKind kind) {
+    const int C = f->cfg.n_channels;
+    if (n <= 0 || n > f->cfg.max_chunk || ch_stride < n) return SONDE_E_RANGE;
+    if (!f->wr_ch.empty()) return SONDE_E_ARG;                  // the engine was switched to per-channel feeding
+    FskArgs &a = f->args;
+    // append to the per-channel rings (two pieces when the write position wraps)
+    const uint32_t w0 = f->wr & (a.ring - 1);
+    const uint32_t first = std::min<uint32_t>((uint32_t)n, a.ring - w0);
+    char *dst = (char *)f->d_in;
+    HIPCHK(hipMemcpy2DAsync(dst + (size_t)w0 * f->unit, (size_t)a.ring * f->unit, src, (size_t)ch_stride * f->unit, (size_t)first * f->unit, C, kind, f->stream));
+    if (first < (uint32_t)n)
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)a.ring * f->unit, (const char *)src + (size_t)first * f->unit, (size_t)ch_stride * f->unit,
+                                (size_t)(n - first) * f->unit, C, kind, f->stream));
+    f->wr += (uint32_t)n;
+    a.wr = f->wr;
+    return launch_and_collect(f);
+}
+
 int sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples) {
     if (!f || !h_in) return SONDE_E_ARG;
     return run(f, h_in, ch_stride, n_samples, hipMemcpyHostToDevice);
@@ -204,6 +222,41 @@ int sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, 
 int sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples) {
     if (!f || !d_in) return SONDE_E_ARG;
     return run(f, d_in, ch_stride, n_samples, hipMemcpyDeviceToDevice);
+}
+
+int sonde_fsk_process_host_var(sonde_fsk_t *f, const void *const *h_in, const int32_t *n_samples) {
+    if (!f || !h_in || !n_samples) return SONDE_E_ARG;
+    const int C = f->cfg.n_channels;
+    if (f->wr_ch.empty()) {
+        if (f->wr != 0) return SONDE_E_ARG;                     // one feeding mode per engine
+        f->wr_ch.assign(C, 0);
+        if (dalloc(&f->d_wr, (size_t)C)) return SONDE_E_NOMEM;
+        f->args.wr_ch = f->d_wr;
+    }
+    for (int c = 0; c < C; c++) if (n_samples[c] < 0 || n_samples[c] > f->cfg.max_chunk || (n_samples[c] > 0 && !h_in[c])) return SONDE_E_RANGE;
+    for (int c = 0; c < C; c++) {
+        if (n_samples[c] == 0) continue;
+        if (ring_write(f, c, f->wr_ch[c], (const char *)h_in[c], n_samples[c], hipMemcpyHostToDevice)) return SONDE_E_NOGPU;
+        f->wr_ch[c] += (uint32_t)n_samples[c];
+    }
+    HIPCHK(hipMemcpyAsync(f->d_wr, f->wr_ch.data(), (size_t)C * sizeof(uint32_t), hipMemcpyHostToDevice, f->stream));
+    return launch_and_collect(f);
+}
+
+int sonde_fsk_reset_channel(sonde_fsk_t *f, int32_t channel) {
+    if (!f || channel < 0 || channel >= f->cfg.n_channels) return SONDE_E_ARG;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    const FskArgs &a = f->args;
+    FskChan c; memset(&c, 0, sizeof c);
+    for (int m = 0; m < 4; m++) c.phi_c[m] = exp_j(0);
+    c.nin = f->info.N;
+    c.rd = f->wr_ch.empty() ? f->wr : f->wr_ch[channel];        // nothing queued: the next sample fed is this stream's first
+    f->h_chan[channel] = c;
+    HIPCHK(hipMemcpy(f->d_chan + channel, &c, sizeof c, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(f->d_Sf + (size_t)channel * f->info.Ndft, 0, (size_t)f->info.Ndft * sizeof(float)));
+    HIPCHK(hipMemset(f->d_tail + (size_t)channel * a.M * a.NT, 0, (size_t)a.M * a.NT * sizeof(float2)));
+    HIPCHK(hipMemset(f->d_eye + (size_t)channel * 8 * 160, 0, 8 * 160 * sizeof(float)));
+    return 0;
 }
 
 int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames, int32_t *n_frames) {

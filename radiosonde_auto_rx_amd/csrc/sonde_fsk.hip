@@ -62,10 +62,11 @@ void k_fsk_demod(const FskArgs a) {
     float *Sf_g = a.Sf + (size_t)ch * Ndft;
     float2 *tail_g = a.tail + (size_t)ch * M * NT;
     int frames = 0;
+    const uint32_t wr = a.wr_ch ? a.wr_ch[ch] : a.wr;
 
     for (;;) {
         const int nin = st.nin;
-        if ((int32_t)(a.wr - st.rd) < nin) break;
+        if ((int32_t)(wr - st.rd) < nin) break;
         if (frames >= a.rec_cap || (frames + 1) * nsym * (M / 2) > a.sd_cap) break;
         // ---- input conversion (fsk_demod.c:283-311)
         for (int i = tid; i < nin; i += FSK_THREADS) {

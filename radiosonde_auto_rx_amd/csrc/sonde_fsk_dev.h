@@ -25,6 +25,7 @@ struct FskArgs {
     int M;                            // tones: 2 or 4 (fsk.h:40, MODE_2FSK / MODE_4FSK)
     int burst;                        // fsk_enable_burst_mode: nin stays N (fsk.c:724)
     int n_ch; uint32_t ring; uint32_t wr;          // absolute write index: samples [rd, wr) are available
+    const uint32_t *wr_ch;            // per-channel write index instead of wr (channels fed different counts, sonde_fsk_process_host_var); may be nullptr
     int Fs, Rs, Ts, P, nsym, N, Ndft, log2Ndft, Nmem, NT;   // NT = 2 Ts + Ts/2 tail samples kept per tone
     int st, en, f_zero, len_mask, est_type, fs_tx;
     int n_mask, mask_idx[12];         // positions of the ones in the mask estimator's mask (fsk.c:553-560): 3 per tone
