@@ -20,7 +20,10 @@
  *   read_wav_header() :313, f32soft_read() :1718, find_softbinhead() :1740, find_binhead() :1668  -> host code, no GPU
  *
  * Decoders: rs41mod, dfm09mod, m10mod, m20mod (the engine's own presets) and, through the engine's generic sonde description filled from the
- * caller's dsp_t, rs92mod, imet54mod, mp3h1mod, mts01mod, meisei100mod (kFamily below).  Not lms6Xmod (it changes the baud rate between frames).
+ * caller's dsp_t, rs92mod, imet54mod, mp3h1mod, mts01mod, meisei100mod, lms6Xmod (kFamily below).  lms6Xmod rewrites dsp.br / dsp.sps after
+ * init_buffers() (lms6Xmod.c:1336-1348 for --lms6 / --lmsX): the seam picks the value up at the first find_header() call and re-creates the engine with that
+ * symbol rate for the bit clock and slicers (sonde_generic_t.slice_baud), 4096 raw bits per block for LMS6, 4720 for LMS-X.  A change of dsp.sps later in the
+ * stream (auto detection switching between LMS6 and LMS-X, :1436-1462) ends the program with a message: samples already demodulated would need another scale.
  *
  * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs are
  * taken from the first find_header call; a header of the wrong polarity that the
@@ -54,29 +57,34 @@ static struct {
     int qn, qi;
     const float *cur, *cur1; int cur_nbits, cur_inv;
     int bitofs; float l_win;      /* what the hits were sliced with: find_header()'s bitofs, the decoder's window */
+    float sps_cur; int fam;       /* dsp->sps the engine slices with; index into kFamily or -1 */
     sonde_cfg_t cfg; sonde_generic_t gen; double fq; int generic;
 } S;
 
 /* How the bit loop of each other decoder of the family consumes a header hit (what demod_mod.c learns one call at a time, the batched
  * engine has to know up front): bits read per hit, the centre window it passes for opt_iq > 2, and the hdmax / bitofs defaults of its
  * find_header() call (replaced by the real arguments at the first call). */
-static const struct { const char *name; int br, hdrlen, symlen, nbits, hdmax, bitofs; float l; } kFamily[] = {
+static const struct { const char *name; int br, hdrlen, symlen, nbits, hdmax, bitofs; float l; const char *hdr16; } kFamily[] = {
     { "rs92mod",      4800, 60, 2, (240 - 6) * 10, 3, 2, 4.0f },      /* rs92mod.c:1992,2010-2040: 234 bytes of 10 bits, read_slbit            */
     { "imet54mod",    4798, 40, 1, 220 * 10,       4, 1, 2.0f },      /* imet54mod.c:1013,1029-1060                                            */
     { "mp3h1mod",     2399, 44, 2, 51 * 8 - 22,    2, 2, 2.0f },      /* mp3h1mod.c:1181,1196-1235: bitfrm_len (45+6)*8 from pos 22            */
     { "mts01mod",     1200, 32, 1, 8 * 131,        2, 0, 2.0f },      /* mts01mod.c:572,588-612                                                */
     { "meisei100mod", 2400, 48, 1, 1200 - 48,      1, 0, -1.0f },     /* meisei100mod.c:691,704-718: 2*600-48 raw bits, read_slbit             */
+    { "lms6Xmod",     4800, 64, 1, 261 * 16 - 80, 10, 0, -1.0f, "0101011000001000" },   /* lms6Xmod.c:89-92,101,1358,1394: RAWBITBLOCK_LEN_6 - BLOCKSTART bits */
 };
 
 static int seam_type(const dsp_t *dsp, int *fam) {
     const int br = (int)(dsp->br + 0.5f);
     *fam = -1;
+    for (int i = 0; i < (int)(sizeof kFamily / sizeof kFamily[0]); i++)          /* same rates as another type: told apart by the header itself */
+        if (kFamily[i].hdr16 && br == kFamily[i].br && dsp->hdrlen == kFamily[i].hdrlen && dsp->symlen == kFamily[i].symlen &&
+            dsp->hdr && strncmp(dsp->hdr, kFamily[i].hdr16, 16) == 0) { *fam = i; return SONDE_GENERIC; }
     if (dsp->hdrlen == 64 && br == 4800 && dsp->symlen == 1) return SONDE_RS41;
     if (dsp->hdrlen == 32 && br == 2500) return SONDE_DFM09;
     if (dsp->hdrlen == 32 && (br == 9615 || br == 9616)) return SONDE_M10;
     if (dsp->hdrlen == 32 && br == 9600) return SONDE_M20;
     for (int i = 0; i < (int)(sizeof kFamily / sizeof kFamily[0]); i++)
-        if (br == kFamily[i].br && dsp->hdrlen == kFamily[i].hdrlen && dsp->symlen == kFamily[i].symlen) { *fam = i; return SONDE_GENERIC; }
+        if (!kFamily[i].hdr16 && br == kFamily[i].br && dsp->hdrlen == kFamily[i].hdrlen && dsp->symlen == kFamily[i].symlen) { *fam = i; return SONDE_GENERIC; }
     return -1;
 }
 
@@ -148,6 +156,7 @@ int init_buffers(dsp_t *dsp) {
     S.soft = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
     S.soft1 = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
     S.have = 0; S.eof = 0; S.started = 0; S.qn = S.qi = 0; S.cur = NULL; S.cur_nbits = 0;
+    S.sps_cur = dsp->sps; S.fam = fam;
     if (!S.buf || !S.soft || !S.soft1) return -1;
     return S.info.K;
 }
@@ -163,6 +172,24 @@ int free_buffers(dsp_t *dsp) {
 int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
     (void)opt_dc;
     if (!S.eng) return EOF;
+    if (!S.started && S.generic && dsp->sps != S.sps_cur) {
+        /* the caller changed dsp.br / dsp.sps after init_buffers() (lms6Xmod.c:1336-1348): same filters and header template, new bit clock */
+        sonde_engine_destroy(S.eng); S.eng = NULL;
+        S.gen.slice_baud = dsp->br;
+        if (S.fam >= 0 && kFamily[S.fam].hdr16 && !(dsp->br > 4799.9f && dsp->br < 4800.1f)) S.gen.nbits = 300 * 16 - 80;      /* LMS-X: RAWBITBLOCK_LEN - BLOCKSTART */
+        double fq = S.fq;
+        const int rc = sonde_engine_create_generic(&S.cfg, &fq, &S.gen, &S.eng);
+        if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); S.eng = NULL; return EOF; }
+        S.nbits = S.gen.nbits; S.sps_cur = dsp->sps;
+        free(S.soft); free(S.soft1);
+        S.soft = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
+        S.soft1 = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
+        if (!S.soft || !S.soft1) return EOF;
+    }
+    if (dsp->sps != S.sps_cur) {
+        fprintf(stderr, "demod_mod_hip: dsp.sps changed from %g to %g in mid-stream; the engine cannot re-scale samples it has already demodulated\n", S.sps_cur, dsp->sps);
+        exit(2);
+    }
     if (!S.started) {                                  /* the caller's threshold, accepted header errors and bit offset (e.g. -d <shift>) */
         sonde_engine_set_threshold(S.eng, thres);
         if (sonde_engine_set_sync(S.eng, hdmax, bitofs) < 0) { fprintf(stderr, "demod_mod_hip: hdmax %d / bitofs %d out of range\n", hdmax, bitofs); return EOF; }

@@ -140,7 +140,7 @@ typedef struct {
  * of channel c (-0.5..0.5, rs41mod.c:2678-2687). */
 int  sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out);
 /* cfg->sonde_type == SONDE_GENERIC: the fields a decoder of the reference puts into dsp_t (e.g. rs92mod.c:1924-1939: br, symlen, symhd, hdr,
- * BT, h, lpIQ_bw, lpFM_bw), the find_header() arguments hdmax / bitofs, and how its bit loop consumes a hit: nbits soft bits (<= 4144), then
+ * BT, h, lpIQ_bw, lpFM_bw), the find_header() arguments hdmax / bitofs, and how its bit loop consumes a hit: nbits soft bits (<= 8192), then
  * — if skip_bits > nbits — bits up to skip_bits dropped before the header search resumes.  l_win: the centre window `l` it passes to
  * read_softbit*() for opt_iq > 2 (0 = whole bits).  Threshold: cfg->thres (0 = 0.7).  Needs cfg->keep_soft; results through sonde_engine_fetch_hits(). */
 typedef struct {
@@ -151,7 +151,8 @@ typedef struct {
     int32_t nbits, skip_bits;
     float   l_win;
     int32_t lpiq_bw, lpfm_bw;   /* Hz */
-    int32_t reserved[4];
+    float   slice_baud;      /* > 0: dsp.br the decoder sets AFTER init_buffers() (lms6Xmod.c:1343-1347): bit clock / slicers only */
+    int32_t reserved[3];
 } sonde_generic_t;
 int  sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out);
 /* replaces free_buffers() (demod_mod.c:1476) */

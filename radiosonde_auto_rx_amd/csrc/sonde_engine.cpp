@@ -44,7 +44,7 @@ struct sonde_engine {
     Decimator dec; int Q = 0, G = 8, DS = 0; float *d_wtab = nullptr;
     float2 *d_etab = nullptr, *d_dcavg_prev = nullptr; int etab_len = 0; int dc_since = 1 << 20;      // fold mode of the decimator (MixDecArgs.etab)
     std::vector<float> w_iq, w_fm, match, wtab;
-    float sps = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;
+    float sps = 0, sps_design = 0, baud = 0, bt = 0, hmod = 0, thres = 0, l_win = -1;   // sps: what the slicers / header bit clock use; sps_design: what init_buffers() saw
     int symlen = 1, symhd = 1, hdmax = 0, bitofs = 0, nbits = 0, hdrlen = 0;
     uint32_t frame_samples = 0;
     double rho = 0;
@@ -173,7 +173,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     if (gen) {
         const size_t hl = strnlen(gen->header, sizeof gen->header);
         if (hl < 8 || hl > 64 || !(gen->baud > 0.f) || !(gen->bt > 0.f) || !(gen->h > 0.f) || gen->symlen < 1 || gen->symlen > 2 || gen->symhd < 1 || gen->symhd > gen->symlen ||
-            hl % gen->symhd || gen->hdmax < 0 || gen->bitofs < 0 || gen->nbits < 1 || gen->nbits > 518 * 8 || gen->skip_bits < 0) return SONDE_E_ARG;
+            hl % gen->symhd || gen->hdmax < 0 || gen->bitofs < 0 || gen->nbits < 1 || gen->nbits > 8192 || gen->skip_bits < 0 || gen->slice_baud < 0.f) return SONDE_E_ARG;
     }
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND && cfg->sonde_type != SONDE_GENERIC) ) return SONDE_E_ARG;
@@ -256,6 +256,10 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     M = p2;
     const int K = M - L - delay;
     { const float nh = -e->hmod; const float hs = nh * sr; const double f1 = hs / (2.0 * e->sps); e->rho = -f1 / (double)sr; }
+    e->sps_design = e->sps;
+    if (gen && gen->slice_baud > 0.f) {          // a decoder that changes dsp.br / dsp.sps after init_buffers() (lms6Xmod.c:1343-1347: LMS-X at 4797.8 Bd behind
+        e->sps = (float)sr / gen->slice_baud;    // filters and a header template designed for 4800): `dsp.sps = (float)dsp.sr / dsp.br` with the IF rate — bit
+    }                                            // clock, slicer windows and the tone correlator's 1/sps scale follow it, everything designed above stays
     {   // samples the framer consumes behind a header before the search resumes: all nbits — M10: the rest of the second as well
         // (bits up to 5 x 808 are read and dropped, m10mod.c:1494-1507)
         const int last = skip_last >= 0 ? skip_last : ((cfg->sonde_type == SONDE_M10 || cfg->sonde_type == SONDE_M20) && !cfg->m10_noskip) ? 5 * 808 - 1 : e->nbits - 1;
@@ -269,7 +273,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
 
     sonde_info_t &I = e->info;
     I.if_sr = sr; I.decM = D; I.dectaps = (D == 1) ? 0 : T; I.lpiq_taps = (int)e->w_iq.size(); I.lpfm_taps = (int)e->w_fm.size();
-    I.L = L; I.M = M; I.K = K; I.N = M; I.delay = delay; I.sps = e->sps; I.ring_len = ring;
+    I.L = L; I.M = M; I.K = K; I.N = M; I.delay = delay; I.sps = e->sps_design; I.ring_len = ring;
 
     // ---- decimator taps, front-padded to Q*D and laid out [r][q] so that step r loads its Q taps with one scalar load
     {
@@ -353,8 +357,8 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     }
     // ---- factorised header correlation tables (integer samples/symbol only; else the direct L-tap kernel runs)
     {
-        const int isps = (int)e->sps, nsym = e->hdrlen / e->symhd;
-        if ((float)isps == e->sps && e->symhd == 1 && isps * nsym == L && isps >= 2 && isps <= 16 && isps % 2 == 0) {
+        const int isps = (int)e->sps_design, nsym = e->hdrlen / e->symhd;
+        if ((float)isps == e->sps_design && e->symhd == 1 && isps * nsym == L && isps >= 2 && isps <= 16 && isps % 2 == 0) {
             std::vector<float> shapes; std::vector<int> type(nsym); std::vector<float> sign(nsym);
             std::vector<int> key;                                     // (left, right) neighbour relative to the own bit
             bool ok = true;

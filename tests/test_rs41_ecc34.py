@@ -32,7 +32,7 @@ def _pair(args, data):
     if not os.path.exists(engine.LIB_PATH):
         engine.build_library()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
-    a = subprocess.run([NATIVE] + args, input=data, capture_output=True, timeout=120)
+    a = subprocess.run([NATIVE] + args, input=data, capture_output=True, timeout=120, env=dict(os.environ, SONDE_JSN_VERSION="oracle"))
     b = subprocess.run([REF] + args, input=data, capture_output=True, timeout=120)
     assert a.returncode == b.returncode == 0, a.stderr[-300:]
     assert a.stdout == b.stdout, (args, a.stdout[:300], b.stdout[:300])

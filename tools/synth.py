@@ -721,3 +721,108 @@ def fsk_test_frame_bits(n_frames: int) -> np.ndarray:
     libc.srand(158324)
     frame = np.array([libc.rand() & 1 for _ in range(100)], dtype=np.int64)
     return np.tile(frame, n_frames)
+
+
+# ---------------------------------------------------------------- LMS6 (CCSDS-style: RS(255,223) blocks behind a K = 7 rate-1/2 convolutional code)
+_GF187 = None
+
+
+def _gf187():
+    """GF(2^8) / 0x187 exp / log tables (the CCSDS field of the reference's RS(255,223), bch_ecc_mod.h:99)"""
+    global _GF187
+    if _GF187 is None:
+        exp, log = [0] * 512, [0] * 256
+        x = 1
+        for i in range(255):
+            exp[i] = x; log[x] = i
+            x <<= 1
+            if x & 0x100:
+                x ^= 0x187
+        for i in range(255, 512):
+            exp[i] = exp[i - 255]
+        _GF187 = (exp, log)
+    return _GF187
+
+
+def rs255_223_ccsds_parity(msg223) -> np.ndarray:
+    """32 parity bytes of the reference's RS(255,223) (generator roots alpha^(11 (112 + i)), i = 0..31; codeword = parity[0..31] | message[0..222],
+    lowest degree first, like rs_encode in bch_ecc_mod.c:832)"""
+    exp, log = _gf187()
+
+    def mul(a, b):
+        return 0 if a == 0 or b == 0 else exp[log[a] + log[b]]
+    g = [1]
+    for i in range(32):
+        root = exp[(11 * (112 + i)) % 255]
+        ng = [0] * (len(g) + 1)
+        for k, c in enumerate(g):                # g(x) * (x + root), coefficients lowest degree first
+            ng[k] ^= mul(c, root)
+            ng[k + 1] ^= c
+        g = ng
+    rem = [0] * 32                               # remainder of x^32 m(x) mod g(x), highest message coefficient first
+    for m in reversed([int(v) for v in msg223]):
+        fb = m ^ rem[31]
+        rem = [0] + rem[:31]
+        if fb:
+            for k in range(32):
+                rem[k] ^= mul(fb, g[k])
+    return np.array(rem, dtype=np.uint8)
+
+
+def lms6_frame(k: int = 0, *, sn: int = 8123456, lat=47.5, lon=8.7, alt_m=12345.6, tow_ms: int = 3 * 86400_000 + 12 * 3600_000) -> bytes:
+    """One 223-byte LMS6 data frame (lms6Xmod.c:446-460 field map: 24 54 00 00 | SN u32 | frame nr u16 | GPS tow ms u32 | .. lat / lon i32 deg 2^31/180..
+    | alt i32 mm | vE vN vU i24 | .. | CRC16 (poly 0x1021, init 0) over the first 221 bytes, big endian)"""
+    f = bytearray(223)
+    f[0:4] = bytes([0x24, 0x54, 0x00, 0x00])
+    f[4:8] = int(sn).to_bytes(4, "big")
+    f[8:10] = int(100 + k).to_bytes(2, "big")
+    f[10:14] = int(tow_ms + 1000 * k).to_bytes(4, "big")
+    f[18:22] = int(round(lat * (2 ** 31) / 180.0)).to_bytes(4, "big", signed=True)
+    f[22:26] = int(round(lon * (2 ** 31) / 180.0)).to_bytes(4, "big", signed=True)
+    f[26:30] = int(round((alt_m + 5.0 * k) * 1000)).to_bytes(4, "big", signed=True)
+    for j, v in enumerate((310, -120, 480)):
+        f[30 + 3 * j:33 + 3 * j] = int(v).to_bytes(3, "big", signed=True)
+    rng = np.random.default_rng(1000 + k)
+    f[39:221] = rng.integers(0, 256, 221 - 39, dtype=np.uint8).tobytes()
+    crc = 0
+    for b in f[:221]:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    f[221:223] = crc.to_bytes(2, "big")
+    return bytes(f)
+
+
+def lms6_onair_bits(n_blocks: int) -> np.ndarray:
+    """Raw channel bits of n_blocks consecutive LMS6 blocks: [00 58 f3 3f b8 | 223-byte frame | 32 RS parity] bytes, LSB first, through the
+    K = 7 rate-1/2 code of lms6Xmod.c:116-117 (c0 from 1001111, c1 from 1101101, oldest bit first), every second channel bit inverted."""
+    data = []
+    for k in range(n_blocks):
+        fr = np.frombuffer(lms6_frame(k), np.uint8)
+        par = rs255_223_ccsds_parity(fr[::-1])          # rs_cw[254 - j] = block byte j: the first frame byte is the highest coefficient
+        data += [0x00, 0x58, 0xF3, 0x3F, 0xB8] + list(fr) + list(par[::-1])
+    bits = np.unpackbits(np.array(data, np.uint8)[:, None], axis=1, bitorder="little").ravel().astype(np.int64)
+    pa = np.array([1, 0, 0, 1, 1, 1, 1]); pb = np.array([1, 1, 0, 1, 1, 0, 1])
+    hist = np.concatenate([np.zeros(6, np.int64), bits])
+    win = np.lib.stride_tricks.sliding_window_view(hist, 7)          # win[n] = bits n-6 .. n, oldest first
+    c0 = (win @ pa) & 1
+    c1 = ((win @ pb) & 1) ^ 1
+    return np.stack([c0, c1], axis=1).ravel().astype(np.uint8)
+
+
+def lms6_capture(sr: int = 48_000, seconds: float = 4.0, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1,
+                 baud: float = 4800.0) -> np.ndarray:
+    """LMS6-403 GFSK capture (h = 0.9, BT = 1.2 as the decoder assumes, lms6Xmod.c:1274-1275), continuous blocks from t = 0."""
+    n_blocks = int(seconds * baud / (260 * 16)) + 2
+    bits = lms6_onair_bits(n_blocks)
+    n = int(seconds * sr)
+    z = gfsk_baseband(bits, sr, baud, dev_hz=0.9 * baud / 2, bt=1.2)[:n]
+    if len(z) < n:
+        z = np.concatenate([z, np.zeros(n - len(z), z.dtype)])
+    t = np.arange(n)
+    rng = np.random.default_rng(seed)
+    z = amp * z * np.exp(2j * np.pi * fq * t) + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, np.int16)
+    out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
+    out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
+    return out
