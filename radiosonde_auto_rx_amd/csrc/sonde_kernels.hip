@@ -754,8 +754,9 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
 // k_if_chain: one workgroup = IF_TILE output samples of one channel
 // ------------------------------------------------------------------------------------------------
 #define IF_TILE 960
-#define IF_THREADS 512
-#define IF_NB 2
+#define IF_THREADS 256
+#define IF_NB 4
+#define IF_RUN 4
 
 __global__ __launch_bounds__(IF_THREADS)
 void k_if_chain(const IfArgs a) {
@@ -778,58 +779,58 @@ void k_if_chain(const IfArgs a) {
     const int nyp = (ny + 8 + 1) & ~1;                         // padded: the 4-output groups read a little past ny
     float2 *sy = reinterpret_cast<float2 *>(smem);            // [nyp]
     float2 *sz = sy + nyp;                                     // [nz]   z'[t0 - hz + k]
-    float2 *sx = sz + nz;                                      // [nz]   X1 = z' * e^{+i 2 pi m rho}
-    float2 *sx2 = sx + nz;                                     // [nz]   X2 = z' * e^{-i 2 pi m rho}
-    float  *sf = reinterpret_cast<float *>(sx2 + nz);          // [T2-1+nout] raw s_fm
-    float  *wq = sf + (T2 - 1 + nout);                         // [T1]
-    float  *wf = wq + T1;                                      // [T2]
+    float4 *sx4 = reinterpret_cast<float4 *>(sz + nz + (nz & 1));   // [nz]   (X1, X2): X1 = z' * e^{+i 2 pi m rho}, X2 = z' * e^{-i 2 pi m rho}
+    float  *sf = reinterpret_cast<float *>(sx4 + nz);          // [T2-1+nout] raw s_fm
+    float  *wf = sf + (T2 - 1 + nout);                         // [T2]
 
     const float2 *yr = a.y + (size_t)ch * a.ring_len;
     for (int k = threadIdx.x; k < nyp; k += IF_THREADS) {
         const int64_t m = (int64_t)t0 - hz - (T1 - 1) + k;     // absolute IF index, may be < 0 at stream start
         sy[k] = (m >= 0 && k < ny) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
     }
-    const float *w_iq = (afc && !a.afc[ch].locked) ? a.w_iq0 : a.w_iq;          // acquisition / locked tap set (demod_mod.c:1577-1590)
-    for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? w_iq[k] : 1.0f;
+    // acquisition / locked tap set (demod_mod.c:1577-1590); the choice is per channel = per workgroup: kept in a scalar register so that the taps load as scalars
+    const int acq = __builtin_amdgcn_readfirstlane((afc && !a.afc[ch].locked) ? 1 : 0);
+    const float *w_iq = acq ? a.w_iq0 : a.w_iq;
     for (int k = threadIdx.x; k < T2; k += IF_THREADS) wf[k] = a.lpfm_on ? a.w_fm[k] : 1.0f;
     __syncthreads();
 
     // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648).
-    // IF_NB consecutive outputs per thread with a sliding register window: one 16-byte LDS read per 2 taps;
-    // the tone phasors e^{+-i 2 pi m rho} are applied once per sample here (X1, X2), not once per window term.
-    // (IF_NB = 2 keeps all 512 threads of a 960-sample tile busy; the per-output tap order does not depend on it.)
+    // IF_NB consecutive outputs per thread with a sliding register window: one 16-byte LDS read per 2 taps and IF_NB outputs; the taps are
+    // wave-uniform and come through scalar loads; (re, im) pairs accumulate with packed FMAs — per component the same fused multiply-adds in the
+    // same tap order as before.  The tone phasors e^{+-i 2 pi m rho} are applied once per sample here (X1, X2), not once per window term.
+    typedef float v2f __attribute__((ext_vector_type(2)));
     for (int k0 = IF_NB * threadIdx.x; k0 < nz; k0 += IF_NB * IF_THREADS) {
-        float ar[IF_NB], ai[IF_NB];
+        v2f acc[IF_NB];
 #pragma unroll
-        for (int j = 0; j < IF_NB; j++) { ar[j] = 0.f; ai[j] = 0.f; }
-        float2 win[IF_NB + 2];
+        for (int j = 0; j < IF_NB; j++) acc[j] = v2f{0.f, 0.f};
+        v2f win[IF_NB + 2];
 #pragma unroll
         for (int j = 0; j < IF_NB; j += 2) {
             const float4 v0 = *reinterpret_cast<const float4 *>(sy + k0 + j);
-            win[j] = make_float2(v0.x, v0.y); win[j + 1] = make_float2(v0.z, v0.w);
+            win[j] = v2f{v0.x, v0.y}; win[j + 1] = v2f{v0.z, v0.w};
         }
         for (int t = 0; t + 1 < T1; t += 2) {
             const float4 nv = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB);
-            win[IF_NB] = make_float2(nv.x, nv.y); win[IF_NB + 1] = make_float2(nv.z, nv.w);
-            const float w0 = wq[t], w1 = wq[t + 1];
+            win[IF_NB] = v2f{nv.x, nv.y}; win[IF_NB + 1] = v2f{nv.z, nv.w};
+            const float w0 = w_iq[t], w1 = w_iq[t + 1];           // T1 > 1 only with the low-pass on
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) {
-                ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]);
-                ar[j] = fmaf(win[j + 1].x, w1, ar[j]); ai[j] = fmaf(win[j + 1].y, w1, ai[j]);
+                acc[j] = __builtin_elementwise_fma(win[j], v2f{w0, w0}, acc[j]);
+                acc[j] = __builtin_elementwise_fma(win[j + 1], v2f{w1, w1}, acc[j]);
             }
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) win[j] = win[j + 2];
         }
         if (T1 & 1) {
-            const float w0 = wq[T1 - 1];
+            const float w0 = a.lpiq_on ? w_iq[T1 - 1] : 1.0f;
 #pragma unroll
-            for (int j = 0; j < IF_NB; j++) { ar[j] = fmaf(win[j].x, w0, ar[j]); ai[j] = fmaf(win[j].y, w0, ai[j]); }
+            for (int j = 0; j < IF_NB; j++) acc[j] = __builtin_elementwise_fma(win[j], v2f{w0, w0}, acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < IF_NB; j++) {
             const int k = k0 + j;
             if (k >= nz) break;
-            float re = ar[j], im = ai[j];
+            float re = acc[j].x, im = acc[j].y;
             const int64_t m = (int64_t)t0 - hz + k;
             if (m < 0) { re = 0.f; im = 0.f; }
             else if (afc && (int32_t)((uint32_t)m - start) < 0) {          // older than the restart: rot_iqbuf as it stands
@@ -841,9 +842,8 @@ void k_if_chain(const IfArgs a) {
             const double rev = (double)m * a.rho;
             const float fr = (float)(rev - floor(rev));
             const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
-            // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470)
-            sx[k] = make_float2(re * cs - im * sn, re * sn + im * cs);
-            sx2[k] = make_float2(re * cs + im * sn, im * cs - re * sn);
+            // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470); stored side by side
+            sx4[k] = make_float4(re * cs - im * sn, re * sn + im * cs, re * cs + im * sn, im * cs - re * sn);
             if (a.tap_ifiq && m >= (int64_t)t0 && (int32_t)((uint32_t)m - start) >= 0)
                 a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
         }
@@ -869,31 +869,39 @@ void k_if_chain(const IfArgs a) {
 
     float *bufs = a.bufs + (size_t)ch * a.ring_len;
     float *fmb = a.fm + (size_t)ch * a.ring_len;
-    for (int k = threadIdx.x; k < nout; k += IF_THREADS) {
-        const uint32_t m = t0 + (uint32_t)k;
-        if (afc && (int32_t)(m - start) < 0) continue;
-        // two-tone correlator: windowed sums over the last nwin samples (the reference keeps them as
-        // recursive sliding sums, demod_mod.c:796-803 — same value up to its float drift)
-        float f1r = 0.f, f1i = 0.f, f2r = 0.f, f2i = 0.f;
-        if (a.tone_on) {
-            for (int j = nwin - 1; j >= 0; j--) {
-                const float2 x1 = sx[hz + k - j], x2 = sx2[hz + k - j];
-                f1r += x1.x; f1i += x1.y; f2r += x2.x; f2i += x2.y;
+    // two-tone correlator: windowed sums over the last nwin samples (the reference keeps them as recursive sliding sums over the whole stream,
+    // demod_mod.c:796-803 — same value up to its float drift).  Each thread takes IF_RUN consecutive outputs: a full window sum for the first,
+    // then + newest - oldest for the next IF_RUN - 1 (the run is short, so no drift builds up: <= 2 (IF_RUN - 1) roundings on top of the sum's own).
+    for (int k0 = IF_RUN * threadIdx.x; k0 < nout; k0 += IF_RUN * IF_THREADS) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < IF_RUN; r++) {
+            const int k = k0 + r;
+            if (k >= nout) break;
+            const uint32_t m = t0 + (uint32_t)k;
+            if (a.tone_on) {
+                if (r == 0) {
+                    for (int j = nwin - 1; j >= 0; j--) { const float4 x = sx4[hz + k - j]; f.x += x.x; f.y += x.y; f.z += x.z; f.w += x.w; }
+                } else {
+                    const float4 xn = sx4[hz + k], xo = sx4[hz + k - nwin];
+                    f.x += xn.x - xo.x; f.y += xn.y - xo.y; f.z += xn.z - xo.z; f.w += xn.w - xo.w;
+                }
             }
-        }
-        float s_fm = 0.f;
-        if (a.fm_on) {
-            s_fm = sf[T2 - 1 + k];
-            if (a.lpfm_on) {
-                float acc = 0.f;
-                for (int t = 0; t < T2; t++) acc = fmaf(sf[k + t], wf[t], acc);
-                s_fm = acc;
+            if (afc && (int32_t)(m - start) < 0) continue;
+            float s_fm = 0.f;
+            if (a.fm_on) {
+                s_fm = sf[T2 - 1 + k];
+                if (a.lpfm_on) {
+                    float acc = 0.f;
+                    for (int t = 0; t < T2; t++) acc = fmaf(sf[k + t], wf[t], acc);
+                    s_fm = acc;
+                }
+                fmb[m & mask] = s_fm;
             }
-            fmb[m & mask] = s_fm;
+            float s = s_fm;
+            if (a.tone_on) s = (sqrtf(f.z * f.z + f.w * f.w) - sqrtf(f.x * f.x + f.y * f.y)) / a.sps;
+            bufs[m & mask] = s;
         }
-        float s = s_fm;
-        if (a.tone_on) s = (sqrtf(f2r * f2r + f2i * f2i) - sqrtf(f1r * f1r + f1i * f1i)) / a.sps;
-        bufs[m & mask] = s;
     }
 }
 
@@ -1642,7 +1650,7 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     const int T1 = a->lpiq_on ? a->lpiq_taps : 1, T2 = a->lpfm_on ? a->lpfm_taps : 1;
     const int hz = (T2 - 1) + (a->nwin - 1 > 1 ? a->nwin - 1 : 1);
     const int nz = hz + IF_TILE, ny = nz + T1 - 1;
-    const size_t lds = (size_t)((ny + 8 + 1) & ~1) * 8 + (size_t)nz * 8 * 3 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)(T1 + T2) * 4;
+    const size_t lds = (size_t)((ny + 8 + 1) & ~1) * 8 + (size_t)(nz + 1) * 8 + (size_t)nz * 16 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)T2 * 4 + 16;
     hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
