@@ -753,7 +753,9 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
 // ------------------------------------------------------------------------------------------------
 // k_if_chain: one workgroup = IF_TILE output samples of one channel
 // ------------------------------------------------------------------------------------------------
+#ifndef IF_TILE
 #define IF_TILE 960
+#endif
 #define IF_THREADS 256
 #define IF_NB 4
 #define IF_RUN 4
@@ -782,6 +784,7 @@ void k_if_chain(const IfArgs a) {
     float4 *sx4 = reinterpret_cast<float4 *>(sz + nz + (nz & 1));   // [nz]   (X1, X2): X1 = z' * e^{+i 2 pi m rho}, X2 = z' * e^{-i 2 pi m rho}
     float  *sf = reinterpret_cast<float *>(sx4 + nz);          // [T2-1+nout] raw s_fm
     float  *wf = sf + (T2 - 1 + nout);                         // [T2]
+    float  *wq = sf + ((T2 - 1 + nout + T2 + 3) & ~3);         // [T1] IF low-pass taps, 16-byte aligned (sf is): read 4 at a time
 
     const float2 *yr = a.y + (size_t)ch * a.ring_len;
     for (int k = threadIdx.x; k < nyp; k += IF_THREADS) {
@@ -792,11 +795,12 @@ void k_if_chain(const IfArgs a) {
     const int acq = __builtin_amdgcn_readfirstlane((afc && !a.afc[ch].locked) ? 1 : 0);
     const float *w_iq = acq ? a.w_iq0 : a.w_iq;
     for (int k = threadIdx.x; k < T2; k += IF_THREADS) wf[k] = a.lpfm_on ? a.w_fm[k] : 1.0f;
+    for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? w_iq[k] : 1.0f;
     __syncthreads();
 
     // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648).
     // IF_NB consecutive outputs per thread with a sliding register window: one 16-byte LDS read per 2 taps and IF_NB outputs; the taps are
-    // wave-uniform and come through scalar loads; (re, im) pairs accumulate with packed FMAs — per component the same fused multiply-adds in the
+    // wave-uniform: four at a time as one broadcast LDS read; (re, im) pairs accumulate with packed FMAs — per component the same fused multiply-adds in the
     // same tap order as before.  The tone phasors e^{+-i 2 pi m rho} are applied once per sample here (X1, X2), not once per window term.
     typedef float v2f __attribute__((ext_vector_type(2)));
     for (int k0 = IF_NB * threadIdx.x; k0 < nz; k0 += IF_NB * IF_THREADS) {
@@ -809,10 +813,31 @@ void k_if_chain(const IfArgs a) {
             const float4 v0 = *reinterpret_cast<const float4 *>(sy + k0 + j);
             win[j] = v2f{v0.x, v0.y}; win[j + 1] = v2f{v0.z, v0.w};
         }
-        for (int t = 0; t + 1 < T1; t += 2) {
+        int t = 0;
+        for (; t + 3 < T1; t += 4) {                                   // 4 taps: two 16-byte sample reads, one 16-byte (broadcast) tap read
+            const float4 n0 = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB), n1 = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB + 2);
+            const float4 w4 = *reinterpret_cast<const float4 *>(wq + t);
+            win[IF_NB] = v2f{n0.x, n0.y}; win[IF_NB + 1] = v2f{n0.z, n0.w};
+#pragma unroll
+            for (int j = 0; j < IF_NB; j++) {
+                acc[j] = __builtin_elementwise_fma(win[j], v2f{w4.x, w4.x}, acc[j]);
+                acc[j] = __builtin_elementwise_fma(win[j + 1], v2f{w4.y, w4.y}, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < IF_NB; j++) win[j] = win[j + 2];
+            win[IF_NB] = v2f{n1.x, n1.y}; win[IF_NB + 1] = v2f{n1.z, n1.w};
+#pragma unroll
+            for (int j = 0; j < IF_NB; j++) {
+                acc[j] = __builtin_elementwise_fma(win[j], v2f{w4.z, w4.z}, acc[j]);
+                acc[j] = __builtin_elementwise_fma(win[j + 1], v2f{w4.w, w4.w}, acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < IF_NB; j++) win[j] = win[j + 2];
+        }
+        for (; t + 1 < T1; t += 2) {
             const float4 nv = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB);
             win[IF_NB] = v2f{nv.x, nv.y}; win[IF_NB + 1] = v2f{nv.z, nv.w};
-            const float w0 = w_iq[t], w1 = w_iq[t + 1];           // T1 > 1 only with the low-pass on
+            const float w0 = wq[t], w1 = wq[t + 1];
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) {
                 acc[j] = __builtin_elementwise_fma(win[j], v2f{w0, w0}, acc[j]);
@@ -822,7 +847,7 @@ void k_if_chain(const IfArgs a) {
             for (int j = 0; j < IF_NB; j++) win[j] = win[j + 2];
         }
         if (T1 & 1) {
-            const float w0 = a.lpiq_on ? w_iq[T1 - 1] : 1.0f;
+            const float w0 = wq[T1 - 1];
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) acc[j] = __builtin_elementwise_fma(win[j], v2f{w0, w0}, acc[j]);
         }
@@ -839,8 +864,7 @@ void k_if_chain(const IfArgs a) {
             }
             sz[k] = make_float2(re, im);
             // tone mixer e^{-i t w}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
-            const double rev = (double)m * a.rho;
-            const float fr = (float)(rev - floor(rev));
+            const float fr = (float)__builtin_amdgcn_fract((double)m * a.rho);
             const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
             // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470); stored side by side
             sx4[k] = make_float4(re * cs - im * sn, re * sn + im * cs, re * cs + im * sn, im * cs - re * sn);
@@ -872,6 +896,7 @@ void k_if_chain(const IfArgs a) {
     // two-tone correlator: windowed sums over the last nwin samples (the reference keeps them as recursive sliding sums over the whole stream,
     // demod_mod.c:796-803 — same value up to its float drift).  Each thread takes IF_RUN consecutive outputs: a full window sum for the first,
     // then + newest - oldest for the next IF_RUN - 1 (the run is short, so no drift builds up: <= 2 (IF_RUN - 1) roundings on top of the sum's own).
+    const float inv_sps = 1.0f / a.sps;
     for (int k0 = IF_RUN * threadIdx.x; k0 < nout; k0 += IF_RUN * IF_THREADS) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -899,7 +924,9 @@ void k_if_chain(const IfArgs a) {
                 fmb[m & mask] = s_fm;
             }
             float s = s_fm;
-            if (a.tone_on) s = (sqrtf(f.z * f.z + f.w * f.w) - sqrtf(f.x * f.x + f.y * f.y)) / a.sps;
+            // |F2| - |F1| scaled by 1/sps: hardware square root and a reciprocal multiply (1 ulp each — the reference itself evaluates this in
+            // double from drifting float sums; the tolerance of the stream is 1e-5 RMS, tests/test_gpu_parity.py)
+            if (a.tone_on) s = (__builtin_amdgcn_sqrtf(f.z * f.z + f.w * f.w) - __builtin_amdgcn_sqrtf(f.x * f.x + f.y * f.y)) * inv_sps;
             bufs[m & mask] = s;
         }
     }
@@ -1650,7 +1677,7 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     const int T1 = a->lpiq_on ? a->lpiq_taps : 1, T2 = a->lpfm_on ? a->lpfm_taps : 1;
     const int hz = (T2 - 1) + (a->nwin - 1 > 1 ? a->nwin - 1 : 1);
     const int nz = hz + IF_TILE, ny = nz + T1 - 1;
-    const size_t lds = (size_t)((ny + 8 + 1) & ~1) * 8 + (size_t)(nz + 1) * 8 + (size_t)nz * 16 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)T2 * 4 + 16;
+    const size_t lds = (size_t)((ny + 8 + 1) & ~1) * 8 + (size_t)(nz + 1) * 8 + (size_t)nz * 16 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)(T1 + T2) * 4 + 32;
     hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
