@@ -57,7 +57,7 @@ class SondeHit(C.Structure):
 class SondeGeneric(C.Structure):
     _fields_ = [("header", C.c_char * 68), ("baud", C.c_float), ("bt", C.c_float), ("h", C.c_float), ("symlen", C.c_int32), ("symhd", C.c_int32),
                 ("hdmax", C.c_int32), ("bitofs", C.c_int32), ("nbits", C.c_int32), ("skip_bits", C.c_int32), ("l_win", C.c_float),
-                ("lpiq_bw", C.c_int32), ("lpfm_bw", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("lpiq_bw", C.c_int32), ("lpfm_bw", C.c_int32), ("slice_baud", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
 class SondeInfo(C.Structure):

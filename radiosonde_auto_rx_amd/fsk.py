@@ -45,6 +45,9 @@ def _lib():
         L.sonde_fsk_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_void_p, C.POINTER(C.c_int64)]
         L.sonde_fsk_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.sonde_fsk_eye.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.sonde_fsk_process_host_var.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.sonde_fsk_reset_channel.argtypes = [C.c_void_p, C.c_int32]
+        L.sonde_fsk_fetch_bits.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         _proto = True
     return L
 
@@ -83,6 +86,25 @@ class FskModem:
         per = 1 if self.fmt == S16 else 2
         n = x.shape[1] // per
         _chk(_lib().sonde_fsk_process_host(self._h, x.ctypes.data_as(C.c_void_p), n, n))
+
+    def process_host_var(self, chunks):
+        """Channels fed independently (what the broker does): chunks[c] = samples of channel c for this call (None / empty = nothing)."""
+        per = 1 if self.fmt == S16 else 2
+        ptrs = (C.c_void_p * self.n_channels)()
+        ns = (C.c_int32 * self.n_channels)()
+        keep = []
+        for c in range(self.n_channels):
+            x = chunks[c] if c < len(chunks) else None
+            if x is None or len(x) == 0:
+                ptrs[c] = None; ns[c] = 0
+                continue
+            x = np.ascontiguousarray(x); keep.append(x)
+            ptrs[c] = x.ctypes.data; ns[c] = x.shape[-1] // per
+        _chk(_lib().sonde_fsk_process_host_var(self._h, ptrs, ns))
+
+    def reset_channel(self, ch: int):
+        """Back to the fsk_create_hbr() state for one channel (a new stream starts on it)."""
+        _chk(_lib().sonde_fsk_reset_channel(self._h, ch))
 
     def process_device(self, ptr: int, ch_stride: int, n: int):
         _chk(_lib().sonde_fsk_process_device(self._h, C.c_void_p(ptr), ch_stride, n))

@@ -106,5 +106,5 @@ def test_generic_descriptor_is_validated_before_the_device_is_touched():
     assert create(baud=0.0) == E_ARG
     assert create(symlen=3) == E_ARG
     assert create(symlen=1, symhd=2) == E_ARG              # header symbols per bit cannot exceed the frame's
-    assert create(nbits=5000) == E_ARG                     # more than a frame record holds
+    assert create(nbits=9000) == E_ARG                     # more than the soft-bit buffers are sized for
     assert create(nbits=0) == E_ARG

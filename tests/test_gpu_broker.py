@@ -57,12 +57,21 @@ def test_64_concurrent_shims_share_one_engine(tmp_path):
             assert p.returncode == 0, err[-300:]
             assert out == alone[k].stdout
             assert err == alone[k].stderr
+        # a second wave on the same broker: the channels freed by the first are reset and handed out again
+        procs = []
+        for i in range(16):
+            k = (3 * i) % 8
+            a = list(streams[k][0]); a[-2] = files[k]
+            procs.append((k, subprocess.Popen([os.path.join(BIN, "fsk_demod")] + a, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)))
+        for k, p in procs:
+            out, err = p.communicate(timeout=300)
+            assert p.returncode == 0 and out == alone[k].stdout and err == alone[k].stderr
     finally:
         broker.send_signal(signal.SIGTERM)
         _, berr = broker.communicate(timeout=30)
     line = [l for l in berr.decode().splitlines() if l.startswith("broker: groups")][-1].split()
     st = {line[i]: int(line[i + 1]) for i in range(1, len(line), 2)}
-    assert st["groups"] == 2 and st["clients"] == 72
+    assert st["groups"] == 2 and st["clients"] == 72 + 16
     assert st["max_batch"] >= 48 and st["frames"] >= 8 * st["steps"], st          # one launch sequence per block of (nearly) all clients
 
 

@@ -179,6 +179,43 @@ def test_cli_stats_lines_match_reference(name):
     assert n_eye >= len(want) // 2
 
 
+def test_fsk_channels_fed_independently_and_reset():
+    """sonde_fsk_process_host_var / sonde_fsk_reset_channel (what the resident broker needs): every channel is fed exactly its own fsk_nin()
+    samples per call — the counts differ between channels and calls — and a channel that is reset and fed the same stream again repeats its
+    output bit for bit while its neighbour carries on."""
+    ga = load_fsk("fsk_rs41_48k_mask")
+    xa, case = fsk_capture("fsk_rs41_48k_mask")
+    md = _modem(case, n_channels=2, max_chunk=4096)
+    N = md.info["N"]
+
+    def run(streams, frames):
+        pos = [0, 0]; nin = [N, N]; out = [[], []]
+        for _ in range(frames):
+            chunks = []
+            for c in range(2):
+                x = streams[c]
+                chunks.append(None if x is None or 2 * (pos[c] + nin[c]) > len(x) else x[2 * pos[c]:2 * (pos[c] + nin[c])])
+            md.process_host_var(chunks)
+            for c in range(2):
+                if chunks[c] is None:
+                    continue
+                sd, recs = md.fetch(c)
+                assert len(recs) == 1 and recs[0]["nin"] == nin[c]
+                pos[c] += nin[c]; nin[c] = recs[0]["nin_next"]; out[c].append(sd[0])
+        return [np.array(o) for o in out]
+
+    nfr = len(ga["nin"])
+    shifted = xa[2 * 777:]                                       # channel 1: the same capture 777 samples later -> other nin decisions
+    first = run([xa, shifted], nfr)
+    assert np.array_equal(first[0][:nfr] < 0, ga["sd"][:len(first[0])] < 0) and len(first[0]) == nfr
+    rms = float(np.sqrt(np.mean(ga["sd"].astype(np.float64) ** 2)))
+    assert np.abs(first[0] - ga["sd"]).max() < 1e-5 * rms
+    md.reset_channel(0)
+    again = run([xa, None], nfr)
+    assert np.array_equal(again[0], first[0])                    # bit for bit: the reset channel starts from the fsk_create_hbr() state
+    md.close()
+
+
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "fsk_demod")
 SEAMBIN = os.path.join(ROOT, "oracle", "_ref", "fsk_demod_seam")
 NATIVE = os.path.join(ROOT, "host", "bin", "fsk_demod")
