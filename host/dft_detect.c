@@ -10,6 +10,12 @@
  * stderr: `IF:`/`dec:` (--IQ) or the WAV header summary; exit code = header_found * type number (negative for
  * inverted DFM/RS41/RS92), -50 on errors — all modulo 256 as seen by the shell.
  * 8-bit unsigned, 16-bit signed and 32-bit float input.
+ *
+ * Batch form (not in the reference; what auto_rx's detect_sonde() loop over the peaks of one scan step, scan.py:378-760, can call once):
+ *     dft_detect [...] --IQ <fq1>,<fq2>,... - <sr> <bits>
+ * scans every listed offset of the ONE stream on stdin in the same launches (scanner channels on a shared stream).  stdout: the reference's
+ * line prefixed by `<index> <fq> ` per detection and, at the end, `# <index> <fq> <code>` with the exit code the single run would return;
+ * the process exits 0.  A single <fq> behaves exactly like the reference.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,10 +60,29 @@ static int read_wav_header(FILE *fp, int *sr, int *bits, int *nch) {
     return 0;
 }
 
+static void print_detections(sonde_scan_t *sc, int verbose, int silent, int batch, const double *fqs) {
+    sonde_detection_t det[16];
+    int n;
+    while ((n = sonde_scan_fetch(sc, det, 16)) > 0)
+        for (int k = 0; k < n; k++) {
+            char line[256];
+            if (silent || !det[k].printed) continue;
+            sonde_scan_line(sc, &det[k], verbose, line, sizeof line);
+            if (!batch) { fprintf(stdout, "%s\n", line); continue; }
+            for (char *l = line; l; ) {                          /* -v: two physical lines per detection; each gets the prefix */
+                char *nl = strchr(l, '\n');
+                if (nl) *nl = 0;
+                fprintf(stdout, "%d %.6f %s\n", det[k].channel, fqs[det[k].channel], l);
+                l = nl ? nl + 1 : NULL;
+            }
+        }
+}
+
 int main(int argc, char **argv) {
     sonde_scan_cfg_t cfg;
     FILE *fp = stdin;
     double fq = 0.0;
+    double fqs[256]; int nfq = 0;                        /* --IQ fq1,fq2,...: batch form */
     int verbose = 0, silent = 0, pcmraw = 0, wavloaded = 0, wav_channel = 0, channels = 0;
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
@@ -76,9 +101,16 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--iq")) cfg.iq_mode = SONDE_SCAN_IFIQ;
         else if (!strcmp(a, "--IQ")) {
             if (++i >= argc) return -1;
-            fq = atof(argv[i]);
-            if (fq < -0.5) fq = -0.5;
-            if (fq > 0.5) fq = 0.5;
+            for (const char *q = argv[i]; q && *q && nfq < 256; ) {
+                double v = atof(q);
+                if (v < -0.5) v = -0.5;
+                if (v > 0.5) v = 0.5;
+                fqs[nfq++] = v;
+                q = strchr(q, ',');
+                if (q) q++;
+            }
+            if (nfq < 1) return -1;
+            fq = fqs[0];
             cfg.iq_mode = SONDE_SCAN_BBIQ;
         }
         else if (!strcmp(a, "--bw")) {
@@ -118,7 +150,8 @@ int main(int argc, char **argv) {
     if (channels < 1) channels = 1;
     cfg.audio_channels = channels;
     cfg.audio_select = (wav_channel >= 0 && wav_channel < channels) ? wav_channel : 0;
-    cfg.n_channels = 1;
+    cfg.n_channels = nfq > 1 ? nfq : 1;
+    const int batch = nfq > 1;
 
     /* a quarter second per call keeps the reaction time of the blocking reference; multiples of decM for --IQ */
     int chunk = cfg.sample_rate / 4;
@@ -126,7 +159,7 @@ int main(int argc, char **argv) {
     chunk -= chunk % 64;
     cfg.max_chunk = chunk + 64;
     sonde_scan_t *sc = NULL;
-    int rc = sonde_scan_create(&cfg, &fq, &sc);
+    int rc = sonde_scan_create(&cfg, batch ? fqs : &fq, &sc);
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -50; }
     sonde_scan_info_t info;
     sonde_scan_info(sc, &info);
@@ -140,26 +173,20 @@ int main(int argc, char **argv) {
         size_t got = fread(buf, unit, (size_t)chunk, fp);
         got -= got % (size_t)info.decM;
         if (got == 0) break;
-        rc = sonde_scan_process_host(sc, buf, (int64_t)got, (int32_t)got);
+        rc = sonde_scan_process_host(sc, buf, batch ? 0 : (int64_t)got, (int32_t)got);      /* stride 0: all channels read the one stream */
         if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); break; }
-        sonde_detection_t det[16];
-        int n;
-        while ((n = sonde_scan_fetch(sc, det, 16)) > 0) {
-            for (int k = 0; k < n; k++) {
-                char line[256];
-                if (silent || !det[k].printed) continue;
-                sonde_scan_line(sc, &det[k], verbose, line, sizeof line);
-                fprintf(stdout, "%s\n", line);
-            }
-        }
-        if (sonde_scan_channel_done(sc, 0) == 1) break;
+        print_detections(sc, verbose, silent, batch, fqs);
+        int all_done = 1;
+        for (int c = 0; c < cfg.n_channels; c++) all_done &= sonde_scan_channel_done(sc, c) == 1;
+        if (all_done) break;
         if (got < (size_t)chunk) break;
     }
     sonde_scan_finish(sc);
-    {
-        sonde_detection_t det[16]; int n;
-        while ((n = sonde_scan_fetch(sc, det, 16)) > 0)
-            for (int k = 0; k < n; k++) { char line[256]; if (silent || !det[k].printed) continue; sonde_scan_line(sc, &det[k], verbose, line, sizeof line); fprintf(stdout, "%s\n", line); }
+    print_detections(sc, verbose, silent, batch, fqs);
+    if (batch) {
+        for (int c = 0; c < cfg.n_channels; c++) { int32_t code = 0; sonde_scan_result(sc, c, &code); fprintf(stdout, "# %d %.6f %d\n", c, fqs[c], (int)code); }
+        sonde_scan_destroy(sc); free(buf); fclose(fp);
+        return 0;
     }
     int32_t code = 0;
     sonde_scan_result(sc, 0, &code);

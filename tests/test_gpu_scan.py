@@ -168,6 +168,33 @@ def test_scan_wideband_shared_stream_10msps():
         assert sc.result(c) % 256 == int(g["rc%d" % c])
 
 
+def test_cli_dft_detect_batch_form():
+    """`dft_detect -v -c --dc --IQ fq1,fq2,... - 10000000 16`: every listed offset of ONE stream scanned in the same launches — per channel the lines
+    and the exit code the reference prints / returns when it is run once per offset (what auto_rx's detect_sonde() loop does, scan.py:541-547)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "scan_wide_10M.npz"), allow_pickle=False))
+    x, fqs = make_golden.wide_capture()
+    r = subprocess.run([os.path.join(ROOT, "host", "bin", "dft_detect"), "-v", "-c", "--dc", "--IQ", ",".join(repr(f) for f in fqs), "-",
+                        str(make_golden.WIDE_CASE["sr"]), "16"], input=x.tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-300:]
+    lines = {c: "" for c in range(len(fqs))}
+    codes = {}
+    for l in r.stdout.decode().splitlines():
+        if l.startswith("# "):
+            _, c, fq, code = l.split()
+            codes[int(c)] = int(code)
+            assert abs(float(fq) - fqs[int(c)]) < 1e-6
+        else:
+            c, fq, rest = l.split(" ", 2)
+            lines[int(c)] += rest + "\n"
+    for c in range(len(fqs)):
+        assert lines[c] == str(g["stdout%d" % c])
+        assert codes[c] % 256 == int(g["rc%d" % c])
+
+
 @pytest.mark.parametrize("name", [n for n in SCAN_NAMES if "imet" in n])
 def test_scan_imet_afsk_check(name):
     """IMET preamble hits trigger the reference's extra second of spectrum analysis (IMET4 / IMET1RS / rejected), which
