@@ -163,6 +163,11 @@ def bench_demod(args, D: Dist):
     bank_t = torch.from_numpy(np.stack(caps)).to(D.dev)                     # [BANK, 2*SR] int16
     idx = torch.tensor([(c + D.rank) % BANK for c in range(C)], device=D.dev)
     iq = bank_t.index_select(0, idx).contiguous()                         # [C, 2*SR] resident input
+    STRIDE = SR + int(os.environ.get("SONDE_BENCH_PAD", "0"))              # experiments: channel rows padded apart (samples)
+    if STRIDE != SR:
+        padded = torch.zeros((C, 2 * STRIDE), dtype=iq.dtype, device=D.dev)
+        padded[:, :2 * SR] = iq
+        iq = padded
     del bank_t
     torch.cuda.synchronize()
 
@@ -174,13 +179,13 @@ def bench_demod(args, D: Dist):
     # Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): one
     # untimed lead-in call up to the last short boundary, after which every 1 s step is exactly one segment.
     while eng.samples_to_dc_boundary() < SR:
-        eng.process_device(iq.data_ptr(), SR, eng.samples_to_dc_boundary())
+        eng.process_device(iq.data_ptr(), STRIDE, eng.samples_to_dc_boundary())
     eng.fetch_frames_np()
 
     def step(lag=args.lag):
         # lag = 0: every step waits for its own frames (kernel times are then un-overlapped and the roofline figure of
         # k_mix_decimate is clean).  lag = 1 pipelines: the IF-rate kernels of call k (stream B) overlap the decimator of call k+1.
-        eng.process_device(iq.data_ptr(), SR, SR)
+        eng.process_device(iq.data_ptr(), STRIDE, SR)
         frames = eng.fetch_frames_np(lag=lag)                             # D2H of frame records + host RS ECC
         if D.dist:
             shard.gather_summaries(D.dist, summary, D.world, gathered)    # 32 B per channel over RCCL, device to device

@@ -46,18 +46,25 @@ template <int M>
 __global__ __launch_bounds__(FSK_THREADS)
 void k_fsk_demod(const FskArgs a) {
     extern __shared__ float lds[];
-    __shared__ float s_Sf[1024], s_Sc[1024];
     __shared__ float s_rf[FSK_THREADS / WAVE]; __shared__ int s_ri[FSK_THREADS / WAVE];
     __shared__ float2 s_phi[4]; __shared__ float s_tc[2], s_eb[2];
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT;
     const int W = (nsym + 1) * P;
     const int n_in = max(N + Ts / 2, W);
-    float2 *s_in  = reinterpret_cast<float2 *>(lds);                       // [n_in]  input frame; later ft1 * phi_ft
-    float2 *s_fdc = s_in + n_in;                                           // [max(M Nmem, 4 Ndft)]  FFT scratch, then f_dc[M][Nmem]
-    float  *s_u   = reinterpret_cast<float *>(s_fdc + max(M * Nmem, 4 * Ndft));   // mag[max_fft][Ndft] | f_int[M][W] + eb[nsym]
-    float2 *s_fint = reinterpret_cast<float2 *>(s_u);
-    float  *s_ebv = s_u + 2 * M * W;
+    // LDS regions (two workgroups per CU must fit: a 300-symbol RS41 frame needs 73 KB this way, 97 KB with one region per array):
+    //   A  [nA]  the input frame s_in until the down-conversion has consumed it, then the integrators f_int[M][W] and the Eb/N0 terms
+    //   B  [nB]  during the estimator: FFT scratch [4 Ndft] + block magnitudes mag[max_fft][Ndft]; then f_dc[M][Nmem]; then ft1 * phi_ft [W]
+    //   Sf, Sc   smoothed spectrum and its search copy [Ndft] each
+    const int nA = max(n_in, M * W + (nsym + 1) / 2);
+    const int nB = max(max(M * Nmem, 4 * Ndft + (a.max_fft * Ndft + 1) / 2), W);
+    float2 *s_in  = reinterpret_cast<float2 *>(lds);
+    float2 *s_fint = s_in;
+    float  *s_ebv = reinterpret_cast<float *>(s_fint + M * W);
+    float2 *s_fdc = s_in + nA;
+    float  *s_mag = reinterpret_cast<float *>(s_fdc + 4 * Ndft);
+    float2 *s_ft  = s_fdc;
+    float  *s_Sf = reinterpret_cast<float *>(s_fdc + nB), *s_Sc = s_Sf + Ndft;
     FskChan st = a.chan[ch];
     float *Sf_g = a.Sf + (size_t)ch * Ndft;
     float2 *tail_g = a.tail + (size_t)ch * M * NT;
@@ -127,7 +134,7 @@ void k_fsk_demod(const FskArgs a) {
             // fftshift (DC at Ndft/2) and magnitude
             if (act) for (int k = lane; k < Ndft; k += WAVE) {
                 const float2 X = buf[k];
-                s_u[j * Ndft + ((k + Ndft / 2) & (Ndft - 1))] = sqrtf((X.x * X.x) + (X.y * X.y));
+                s_mag[j * Ndft + ((k + Ndft / 2) & (Ndft - 1))] = sqrtf((X.x * X.x) + (X.y * X.y));
             }
             __syncthreads();
         }
@@ -135,7 +142,7 @@ void k_fsk_demod(const FskArgs a) {
         for (int k = tid; k < Ndft; k += FSK_THREADS) {
             float sf = Sf_g[k];
             const float tc = a.tc, omt = 1 - tc;
-            for (int j = 0; j < numffts; j++) sf = (sf * omt) + (s_u[j * Ndft + k] * tc);
+            for (int j = 0; j < numffts; j++) sf = (sf * omt) + (s_mag[j * Ndft + k] * tc);
             Sf_g[k] = sf; s_Sf[k] = sf; s_Sc[k] = sf;
         }
         __syncthreads();
@@ -207,11 +214,11 @@ void k_fsk_demod(const FskArgs a) {
             float ft1 = 0;
             for (int m = 0; m < M; m++) { const float2 v = s_fint[m * W + i]; ft1 += (v.x * v.x) + (v.y * v.y); }
             const float2 ph = a.phi_ft[i];
-            s_in[i] = make_float2(ft1 * ph.x, ft1 * ph.y);
+            s_ft[i] = make_float2(ft1 * ph.x, ft1 * ph.y);
         }
         __syncthreads();
         if (wave == 0 && lane < 2) {
-            const float *pp = reinterpret_cast<const float *>(s_in) + lane;
+            const float *pp = reinterpret_cast<const float *>(s_ft) + lane;
             float t = 0;
             for (int i = 0; i < W; i++) t = t + pp[2 * i];
             s_tc[lane] = t;
@@ -302,11 +309,13 @@ void k_fsk_demod(const FskArgs a) {
 }
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
-    const int W = (a->nsym + 1) * a->P;
+    const int W = (a->nsym + 1) * a->P, M = a->M;
     const int n_in = (a->N + a->Ts / 2) > W ? (a->N + a->Ts / 2) : W;
-    const int n_fdc = a->M * a->Nmem > 4 * a->Ndft ? a->M * a->Nmem : 4 * a->Ndft;
-    const size_t u1 = (size_t)a->max_fft * a->Ndft * sizeof(float), u2 = (size_t)(2 * a->M * W + a->nsym) * sizeof(float);
-    const size_t lds = (size_t)(n_in + n_fdc) * sizeof(float2) + (u1 > u2 ? u1 : u2);
+    const int nA = n_in > M * W + (a->nsym + 1) / 2 ? n_in : M * W + (a->nsym + 1) / 2;
+    int nB = M * a->Nmem;
+    if (4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2 > nB) nB = 4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2;
+    if (W > nB) nB = W;
+    const size_t lds = (size_t)(nA + nB) * sizeof(float2) + (size_t)2 * a->Ndft * sizeof(float);
     if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
     if (a->M != 2 && a->M != 4) return -1;
     static size_t attr[2] = { 0, 0 };
