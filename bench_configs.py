@@ -52,6 +52,7 @@ def bench_scan_wide(args, D):
     ch = Channelizer(sr, M, Dd, P, max_chunk=sr, device=D.local_rank)
     if_sr = int(ch.out_rate)
     out = torch.zeros(M, ch.max_frames, 2, dtype=torch.float32, device=D.dev)
+    torch.cuda.synchronize()                     # torch's fill must be over before another stream writes the buffer
     sc = Scanner(if_sr, n_channels=M, iq_mode=IFIQ, dc=True, cont=True, max_chunk=ch.max_frames, device=D.local_rank, bits=32)
     found = []
 

@@ -48,7 +48,8 @@ void sonde_chan_destroy(sonde_chan_t *c);
 int  sonde_chan_info(const sonde_chan_t *c, sonde_chan_info_t *info);
 /* n_samples complex int16 samples of the stream (device / host memory) -> d_out[k * out_stride + j] (complex float32, device),
  * j = 0 .. returned count - 1: the output samples this call completes (the filter state carries over between calls).
- * Returns the count (>= 0) or SONDE_E_*.  Work is queued on the channelizer's stream; sonde_chan_sync() waits for it. */
+ * Returns the count (>= 0) or SONDE_E_*.  Work is queued on the channelizer's stream; sonde_chan_sync() waits for it.  The stream does not
+ * wait for any other stream: whatever prepared d_iq / d_out elsewhere (an allocator's fill, a copy) must have completed before the call. */
 int  sonde_chan_process_device(sonde_chan_t *c, const void *d_iq, int32_t n_samples, void *d_out, int64_t out_stride);
 int  sonde_chan_process_host(sonde_chan_t *c, const void *h_iq, int32_t n_samples, void *d_out, int64_t out_stride);
 int  sonde_chan_sync(sonde_chan_t *c);

@@ -46,6 +46,7 @@ def test_channelizer_matches_defining_sum(M, D, P):
     x = (xi[0::2].astype(np.float64) + 1j * xi[1::2]) / 32768.0
     ch = Channelizer(1_000_000, M, D, P, max_chunk=n)
     out = torch.zeros(M, ch.max_frames, 2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                     # the fill runs on torch's stream, the channelizer on its own: order them
     # the stream in three uneven calls: the filter state carries over
     got, pos = 0, 0
     for take in (12_345, 77, n - 12_345 - 77):
@@ -94,6 +95,7 @@ def test_wideband_stream_channels_detect_and_decode_like_reference():
     ch = Channelizer(sr, M, D, 16, max_chunk=sr)
     if_sr = int(ch.out_rate)
     out = torch.zeros(M, 3 * ch.max_frames, 2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     got = 0
     n = len(x) // 2
     for pos in range(0, n, sr):
