@@ -27,7 +27,10 @@ def channel_block(n_total: int, rank: int, world: int) -> range:
 def summary_buffer(n_local: int, device):
     """Zeroed [n_local, 32] uint8 tensor for Engine.set_summary(): the frame-sync kernel fills it in place."""
     import torch
-    return torch.zeros(n_local, SUMMARY_BYTES, dtype=torch.uint8, device=device)
+    t = torch.zeros(n_local, SUMMARY_BYTES, dtype=torch.uint8, device=device)
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)         # the fill runs on torch's stream; the engine writes the records on its own
+    return t
 
 
 def decode_summaries(t) -> np.ndarray:
