@@ -276,6 +276,15 @@ int  sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, siz
 /* End of input (stdin EOF of the reference): emit the frame each channel was in the middle of, with the bits that
  * exist (rs41mod.c:2931 breaks the bit loop on EOF and still calls print_frame :2965), then fetch as above. */
 int  sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
+/* Channels that come and go in a running engine (the resident broker: one channel per decoder process).
+ * finish_channel: end of ONE channel's stream — the frame in progress on it is emitted with the bits that exist, like sonde_engine_finish()
+ * does for all channels (rs41mod.c:2931,2965); fetch as usual afterwards.
+ * restart_channel: a new stream starts on the channel with the next samples fed.  Everything the channel has seen is forgotten (its rings read
+ * as silence, sync state as created) and header positions count from here, so the channel behaves like channel 0 of a fresh engine.  Only for
+ * engines without the base-rate front end (decM == 1: FM audio and IF-rate IQ input) — channels of an engine share the base-rate sample clock
+ * (mixer table phase, IQ-DC schedule) — and not with --dc / --iqdc / pipeline: SONDE_E_ARG otherwise. */
+int  sonde_engine_finish_channel(sonde_engine_t *e, int32_t channel);
+int  sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel);
 /* soft bits (hsbit_t.sb of read_softbit2p) of the frames returned by the last fetch; soft: [n][4080] */
 int  sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames);
 

@@ -74,6 +74,7 @@ struct IfArgs {
     const float *w_iq, *w_fm;
     double rho;               // tone phase advance per IF sample, revolutions
     float sps;
+    const uint32_t *epoch;    // per-channel stream start: the tone phase counts from there; nullptr = 0
 };
 
 struct AudioChainArgs {       // FM-audio input: raw ring -> (FM low-pass) -> fm, bufs
@@ -102,6 +103,7 @@ struct WinItem {
 struct WinPlanArgs {
     const SyncState *state; WinItem *items;
     int n_ch, stride, W, K, L, delay; uint32_t frame_samples, avail;    // table of `stride` slots per channel, this round fills the first W
+    const uint32_t *epoch;    // per-channel stream start (sonde_engine_restart_channel), nullptr = 0 everywhere
 };
 struct WinFftArgs {
     const float *bufs; WinItem *items; const float2 *Fm, *tws;
@@ -139,6 +141,8 @@ struct SyncArgs {
     float sps, thres, l_win;
     int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
+    int eof_ch;               // with eof: only this channel (-1 = all)
+    const uint32_t *epoch;    // per-channel stream start, nullptr = 0
     int opt_auto;             // --auto: opposite-polarity header flips SyncState.inv instead of being skipped
     // --dc (demod_mod.c:174-188,227-298,1555-1600): zero-mean windows, FM-stream fallback correlation, header dc, AFC events
     int opt_dc, opt_iq, lpiq_on, lpfm_taps, N, sr;

@@ -83,6 +83,8 @@ struct sonde_engine {
     std::vector<uint8_t> last_frame;
     std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
+    // channels restarted in mid-stream (sonde_engine_restart_channel): per-channel stream start in IF samples
+    std::vector<uint32_t> epoch; uint32_t *d_epoch = nullptr; int eof_ch = -1;
     // profiling
     bool prof = false, prof_skip = false; int prof_level = 2; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
 };
@@ -148,6 +150,8 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
 }
 
 static void launch_framesync_impl(sonde_engine *e, int eof);
+// header position as the caller's stream counts it: from the channel's own start
+static inline uint32_t rel_pos(const sonde_engine *e, const FrameRec &r) { return e->epoch.empty() ? r.mv_pos : r.mv_pos - e->epoch[r.channel]; }
 static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); if (eof) e->eof_pending = true; }
 static void sync_round(sonde_engine *e, int W);
 
@@ -468,7 +472,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
-                     e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
+                     e->d_epoch, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
                      e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -596,7 +600,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
     b.tone_on = (e->cfg.input != SONDE_IN_IFIQ0); b.nwin = (int)e->sps;           // --iq0 slices the FM stream (opt_iq = 1)
     b.fm_on = (e->cfg.keep_soft || fe || !e->w_fm.empty() || !b.tone_on) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
-    b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps;
+    b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps; b.epoch = e->d_epoch;
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);
     if (e->stream_b != e->stream) {
@@ -666,7 +670,7 @@ static void sync_round(sonde_engine *e, int W) {
     const int C = e->cfg.n_channels;
     hipStream_t sb = e->stream_b;
     WinPlanArgs p{}; p.state = e->d_state; p.items = e->d_win; p.n_ch = C; p.stride = e->win_W; p.W = W; p.K = e->info.K; p.L = e->info.L;
-    p.delay = e->info.delay; p.frame_samples = e->frame_samples; p.avail = e->m_out;
+    p.delay = e->info.delay; p.frame_samples = e->frame_samples; p.avail = e->m_out; p.epoch = e->d_epoch;
     WinFftArgs f{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
     f.K = e->info.K; f.L = e->info.L; f.ring_len = e->ring_len;
     prof_begin(e, "header_corr", sb);
@@ -679,7 +683,7 @@ static void sync_round(sonde_engine *e, int W) {
 static void launch_framesync_impl(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
-    s.eof = eof; s.rs41 = (e->cfg.sonde_type == SONDE_RS41);
+    s.eof = eof; s.eof_ch = e->eof_ch; s.epoch = e->d_epoch; s.rs41 = (e->cfg.sonde_type == SONDE_RS41);
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft; s.soft1 = e->d_soft1;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
@@ -733,7 +737,7 @@ static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int la
         const FrameRec &r = recs[i];
         sonde_frame_t &f = out[i];
         memset(&f, 0, sizeof f);
-        f.channel = r.channel; f.len = r.len; f.mv = r.mv; f.mv_pos = r.mv_pos; f.nbytes = r.nbytes;
+        f.channel = r.channel; f.len = r.len; f.mv = r.mv; f.mv_pos = rel_pos(e, r); f.nbytes = r.nbytes;
         uint8_t *keepf = e->last_frame.data() + (size_t)r.channel * 518;
         if (r.nbytes >= 518) {
             memcpy(f.frame, r.frame, 518);
@@ -801,8 +805,8 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
             }
             sonde_dfm_frame_t &o = out[n++];
             memset(&o, 0, sizeof o);
-            o.channel = r.channel; o.frame_in_hit = f; o.mv = r.mv; o.mv_pos = r.mv_pos;
-            o.frm_count = (float)(r.mv_pos / (2.0 * e->sps * 280) + f);   // gpx._frmcnt (dfm09mod.c:1662)
+            o.channel = r.channel; o.frame_in_hit = f; o.mv = r.mv; o.mv_pos = rel_pos(e, r);
+            o.frm_count = (float)(rel_pos(e, r) / (2.0 * e->sps * 280) + f);   // gpx._frmcnt (dfm09mod.c:1662)
             o.inv = r.mv < 0.f;                                            // an accepted header has the sign of the polarity in effect
             o.ecc[0] = dfm_block(e->cfg.ecc_level, hb + 16, sf + 16, 7, o.conf);
             o.ecc[1] = dfm_block(e->cfg.ecc_level, hb + 72, sf + 72, 13, o.dat1);
@@ -843,7 +847,7 @@ int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t ma
         sonde_m20_frame_t &o = out[h];
         memset(&o, 0, sizeof o);
         o.nbits = mxx_bytes(e, r, 101 + 64, o.frame);
-        o.channel = r.channel; o.mv = r.mv; o.mv_pos = r.mv_pos;
+        o.channel = r.channel; o.mv = r.mv; o.mv_pos = rel_pos(e, r);
         sonde_m20_frame_finish(&o);                                 // length, firmware byte, checksums (m20mod.c:875-907)
     }
     return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
@@ -862,7 +866,7 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
         sonde_m10_frame_t &o = out[h];
         memset(&o, 0, sizeof o);
         const int nv = mxx_bytes(e, r, 101 + 20, o.frame);
-        o.channel = r.channel; o.nbits = nv; o.mv = r.mv; o.mv_pos = r.mv_pos;
+        o.channel = r.channel; o.nbits = nv; o.mv = r.mv; o.mv_pos = rel_pos(e, r);
         sonde_m10_frame_finish(&o);
     }
     return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
@@ -886,7 +890,7 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
     }
     for (int i = 0; i < n; i++) {
         const FrameRec &r = recs[i];
-        out[i].channel = r.channel; out[i].mv = r.mv; out[i].mv_pos = r.mv_pos;
+        out[i].channel = r.channel; out[i].mv = r.mv; out[i].mv_pos = rel_pos(e, r);
         out[i].nbits = e->cfg.sonde_type == SONDE_RS41 ? 8 * (r.nbytes - 8) : r.nbytes;      // RS41 records count bytes incl. the 8 header bytes
     }
     return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
@@ -908,6 +912,44 @@ int sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
     if (!e || !out) return SONDE_E_ARG;
     launch_framesync(e, 1);
     return sonde_engine_fetch_frames(e, out, max);
+}
+
+int sonde_engine_finish_channel(sonde_engine_t *e, int32_t channel) {
+    if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
+    e->eof_ch = channel;
+    launch_framesync(e, 1);
+    e->eof_ch = -1;
+    return 0;
+}
+
+int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
+    if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
+    // channels of an engine share the base-rate sample clock (mixer table phase, IQ-DC segment schedule): only engines without that
+    // front end can give one channel a new origin; the AFC loop of --dc and the pipelined streams are left out as well
+    if (e->info.decM != 1 || e->cfg.opt_dc || e->cfg.opt_iqdc || e->cfg.pipeline || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream_b));
+    const int C = e->cfg.n_channels;
+    const size_t ring = (size_t)e->ring_len, row = (size_t)channel * ring;
+    // history older than the new origin reads as silence, like the reference's freshly allocated buffers
+    if (e->d_y)    HIPCHK(hipMemset(e->d_y + row, 0, ring * sizeof(float2)));
+    if (e->d_ifiq) HIPCHK(hipMemset(e->d_ifiq + row, 0, ring * sizeof(float2)));
+    if (e->d_fm)   HIPCHK(hipMemset(e->d_fm + row, 0, ring * sizeof(float)));
+    if (e->d_bufs) HIPCHK(hipMemset(e->d_bufs + row, 0, ring * sizeof(float)));
+    if (e->d_corr) HIPCHK(hipMemset(e->d_corr + row, 0, ring * sizeof(float)));
+    if (e->d_raw)  HIPCHK(hipMemset(e->d_raw + row, 0, ring * sizeof(float)));
+    if (e->epoch.empty()) {
+        e->epoch.assign((size_t)C, 0u);
+        if (dalloc(&e->d_epoch, (size_t)C)) return SONDE_E_NOMEM;
+    }
+    e->epoch[channel] = e->m_out;
+    HIPCHK(hipMemcpy(e->d_epoch, e->epoch.data(), (size_t)C * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SyncState st; memset(&st, 0, sizeof st);
+    st.s_in = e->m_out; st.mv_pos = e->m_out; st.inv = e->cfg.opt_inv ? 1u : 0u;
+    HIPCHK(hipMemcpy(e->d_state + channel, &st, sizeof st, hipMemcpyHostToDevice));
+    if (!e->last_frame.empty()) { memset(e->last_frame.data() + (size_t)channel * 518, 0, 518); memcpy(e->last_frame.data() + (size_t)channel * 518, kRs41HeaderBytes, 8); }
+    if (!e->m10_bits.empty()) { const size_t per = e->m10_bits.size() / (size_t)C; memset(e->m10_bits.data() + (size_t)channel * per, 0, per); }
+    return 0;
 }
 
 int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) {

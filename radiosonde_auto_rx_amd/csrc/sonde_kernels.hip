@@ -774,6 +774,7 @@ void k_if_chain(const IfArgs a) {
     const int T1 = a.lpiq_on ? a.lpiq_taps : 1;       // IF low-pass taps
     const int T2 = a.lpfm_on ? a.lpfm_taps : 1;       // FM low-pass taps
     const int nwin = a.nwin;                          // tone window = (int)sps
+    const int64_t ep = a.epoch ? (int64_t)a.epoch[ch] : 0;   // this channel's stream start: phase origin of the tone mixer (history before it is zeroed by the host)
     // sample ranges (relative to t0): s_fm needed on [-(T2-1), nout); z' on [-(T2-1)-max(1,nwin-1)..]
     const int hz = (T2 - 1) + max(1, nwin - 1);       // history of z' needed
     const int nz = hz + nout;                         // z' count
@@ -864,7 +865,7 @@ void k_if_chain(const IfArgs a) {
             }
             sz[k] = make_float2(re, im);
             // tone mixer e^{-i t w}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
-            const float fr = (float)__builtin_amdgcn_fract((double)m * a.rho);
+            const float fr = (float)__builtin_amdgcn_fract((double)(m - ep) * a.rho);
             const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
             // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470); stored side by side
             sx4[k] = make_float4(re * cs - im * sn, re * sn + im * cs, re * cs + im * sn, im * cs - re * sn);
@@ -1235,6 +1236,7 @@ void k_framesync(const SyncArgs a) {
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
     const float *corr = a.corr + (size_t)ch * a.ring_len;
     SyncState st = a.state[ch];
+    const uint32_t ep = a.epoch ? a.epoch[ch] : 0u;      // this channel's stream start (0 unless the channel was restarted)
     uint32_t avail = a.avail;                  // IF samples [0, avail) exist (--dc: cut at an AFC event, the rest is recomputed)
     AfcState af{};                             // --dc only
     if (DC) af = a.afc[ch];
@@ -1264,7 +1266,7 @@ void k_framesync(const SyncArgs a) {
                 if (!wi) break;                                        // planned windows used up: the next round continues here
             }
             st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
-            if (pos < (uint32_t)L) continue;                           // getCorrDFT returns -2
+            if (pos - ep < (uint32_t)L) continue;                      // getCorrDFT returns -2 (position counted from the channel's stream start)
             float mv; uint32_t mpos;
             if (wi) { if (wi->rc < 0) continue; mv = wi->mv; mpos = wi->mpos; }
             else if (fs_window<DC>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
@@ -1359,7 +1361,7 @@ void k_framesync(const SyncArgs a) {
             // ---- frame: nbits soft bits from sample mv_pos+1+ofs on (read_softbit2p, demod_mod.c:1087-1175)
             const uint32_t s_in_after = st.mv_pos + (uint32_t)a.delay + 1 + a.frame_samples;
             const bool enough = (int32_t)(avail - s_in_after) >= 0;
-            if (!enough && !a.eof) break;                              // wait for the next chunk
+            if (!enough && !(a.eof && (a.eof_ch < 0 || a.eof_ch == ch))) break;      // wait for the next chunk
             // at end of stream the reference slices until f32buf_sample() hits EOF (rs41mod.c:2931): consumption q
             // needs IF sample mv_pos+delay+1+q, so only bits ending at q1 <= q_lim exist
             const int32_t q_lim = enough ? (int32_t)a.frame_samples : (int32_t)(avail - (st.mv_pos + (uint32_t)a.delay + 1));
@@ -1476,6 +1478,7 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
     const SyncState st = a.state[ch];
     WinItem *it = a.items + (size_t)ch * a.stride;
     uint32_t s_in = st.s_in, k = st.k;
+    const uint32_t ep = a.epoch ? a.epoch[ch] : 0u;
     bool on = st.mode == 0;
     if (st.mode == 1) {                                       // frame in progress: the search resumes behind it, if it ends in this call
         const uint32_t s_after = st.mv_pos + (uint32_t)a.delay + 1 + a.frame_samples;
@@ -1486,7 +1489,7 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
         const uint32_t s_in_w = s_in + ((uint32_t)(a.K - 4) - k);
         if ((int32_t)(a.avail - s_in_w) < 0) break;
         const uint32_t pos = s_in_w - 1 - (uint32_t)a.delay;
-        if (pos >= (uint32_t)a.L) { it[n].pos = pos; it[n].state = 1; it[n].rc = -1; it[n].mv = 0.f; it[n].mpos = 0; n++; }     // else getCorrDFT returns -2: nothing to evaluate
+        if (pos - ep >= (uint32_t)a.L) { it[n].pos = pos; it[n].state = 1; it[n].rc = -1; it[n].mv = 0.f; it[n].mpos = 0; n++; }     // else getCorrDFT returns -2: nothing to evaluate
         s_in = s_in_w; k = 0;
     }
     for (; n < a.stride; n++) { it[n].pos = 0xffffffffu; it[n].state = 0; }

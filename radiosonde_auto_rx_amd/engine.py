@@ -192,6 +192,14 @@ class Engine:
     def process_device(self, ptr: int, ch_stride: int, n_samples: int):
         _chk(lib().sonde_engine_process_device(self._h, C.c_void_p(ptr), ch_stride, n_samples))
 
+    def finish_channel(self, ch: int):
+        """End of one channel's stream: the frame in progress on it is emitted with the bits that exist (fetch afterwards)."""
+        _chk(lib().sonde_engine_finish_channel(self._h, ch))
+
+    def restart_channel(self, ch: int):
+        """A new stream starts on the channel with the next samples (IF-rate / FM-audio engines only; include/sonde_hip.h)."""
+        _chk(lib().sonde_engine_restart_channel(self._h, ch))
+
     def samples_to_dc_boundary(self) -> int:
         return int(lib().sonde_engine_samples_to_dc_boundary(self._h))
 

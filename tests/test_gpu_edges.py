@@ -151,3 +151,80 @@ def test_queue_overflow_is_reported_not_returned_as_error():
     fr = eng.fetch_frames()
     assert len(fr) == 2 and eng.overflowed() is True and eng.overflowed() is False
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["audio", "iq2"])
+def test_channel_restart_behaves_like_a_fresh_engine(form):
+    """sonde_engine_finish_channel / sonde_engine_restart_channel (what the resident broker needs for decoder processes that come and go):
+    a channel that has carried one stream is ended — its frame in progress comes out with the bits that exist — and restarted in the middle of
+    the engine's life; the second stream decodes to exactly what a fresh one-channel engine gives (frame bytes, ECC, header positions counted
+    from the stream's own start), while the neighbouring channel carries on undisturbed."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    ecef = dict(ecef_cm=(418833319, 85974133, 473346430))
+    sr = 48_000
+    caps = [synth.rs41_capture(sr=sr, seconds=5.4, fq=0.0, noise_sigma=0.03, frame_kw=ecef, n_frames=5, t_first=0.2, seed=71),
+            synth.rs41_capture(sr=sr, seconds=3.1, fq=0.0, noise_sigma=0.05, frame_kw=ecef, n_frames=3, t_first=0.31, seed=72, first_frame_no=77),
+            synth.rs41_capture(sr=sr, seconds=2.6, fq=0.0, noise_sigma=0.04, frame_kw=ecef, n_frames=2, t_first=0.12, seed=73, first_frame_no=990)]
+    if form == "audio":
+        caps = [np.ascontiguousarray(synth.fm_audio(c)) for c in caps]
+        kw = dict(audio=True, lp_iq=False); per = 1
+    else:
+        kw = dict(iq_mode=2, lp_iq=True); per = 2
+
+    def alone(x):
+        e = Engine([0.0], sr, max_chunk=sr, **kw)
+        n = len(x) // per
+        out = []
+        for s0 in range(0, n, 4800):
+            e.process_host(x[per * s0:per * min(n, s0 + 4800)][None, :])
+            out += e.fetch_frames(finish=(s0 + 4800 >= n))
+        e.close()
+        return out
+
+    want = [alone(c) for c in caps]
+    assert all(len(w) >= 2 for w in want)
+    eng = Engine([0.0, 0.0], sr, max_chunk=sr, **kw)
+    blk = 4800
+    got = {0: [], 1: []}
+    # channel 0: stream 0 all the way; channel 1: stream 1 from the start, ended early, then stream 2 after a restart
+    plan1 = [(caps[1], len(caps[1]) // per - 9000), (caps[2], len(caps[2]) // per)]        # (stream, samples to feed): stream 1 is cut inside its last frame
+    seg, pos1 = 0, 0
+    n0 = len(caps[0]) // per
+    sil = np.zeros(per * blk, np.int16)
+    out_seg = {0: [], 1: []}
+    for s0 in range(0, n0, blk):
+        a = caps[0][per * s0:per * (s0 + blk)]
+        if len(a) < per * blk:
+            a = np.concatenate([a, sil[:per * blk - len(a)]])
+        x1, n1 = plan1[seg] if seg < len(plan1) else (None, 0)
+        b = sil
+        if x1 is not None:
+            b = x1[per * pos1:per * min(n1, pos1 + blk)]
+            if len(b) < per * blk:                        # the stream ends inside this block: silence behind it until the restart
+                b = np.concatenate([b, sil[:per * blk - len(b)]])
+            pos1 += blk
+        eng.process_host(np.stack([a, b]))
+        for f in eng.fetch_frames():
+            (got[0] if f["channel"] == 0 else out_seg[seg if seg < len(plan1) else len(plan1) - 1]).append(f)
+        if x1 is not None and pos1 >= n1:                 # end of this stream on channel 1
+            eng.finish_channel(1)
+            for f in eng.fetch_frames():
+                (got[0] if f["channel"] == 0 else out_seg[seg]).append(f)
+            eng.restart_channel(1)
+            seg += 1; pos1 = 0
+    for f in eng.fetch_frames(finish=True):
+        (got[0] if f["channel"] == 0 else out_seg[min(seg, len(plan1) - 1)]).append(f)
+    eng.close()
+
+    def same(a, b, full=True):
+        assert len(a) == len(b), (len(a), len(b))
+        for u, v in zip(a, b):
+            assert u["mv_pos"] == v["mv_pos"] and u["ecc"] == v["ecc"] and u["len"] == v["len"]
+            assert bytes(u["frame"]) == bytes(v["frame"])
+    same(got[0], want[0])
+    same(out_seg[1], want[2])                             # the restarted channel: like a fresh engine
+    assert len(out_seg[0]) >= 2                           # the first stream on channel 1 up to its cut: the complete frames are the stand-alone ones
+    for u, v in zip(out_seg[0][:-1], want[1]):
+        assert u["mv_pos"] == v["mv_pos"] and bytes(u["frame"]) == bytes(v["frame"])
