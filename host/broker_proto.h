@@ -11,6 +11,14 @@
  *                                                                            [stats: Ndft float Sf, brk_eye_t] }   or ERROR
  *   close = the slot is free again.
  * DATA carries exactly fsk_nin() samples — the frame loop of utils/fsk_demod.c:281 stays in the client.
+ *
+ * Decoder shims (BRK_KIND_DEMOD: rs41mod / dfm09mod / m10mod / m20mod on FM audio or IF-rate IQ — the forms auto_rx pipes into them,
+ * decode.py:375-417; not the base-rate --IQ form, whose channels share one sample clock inside an engine):
+ *   client: HELLO  { brk_hello_demod_t }                    broker: INFO   { sonde_info_t }            or ERROR { text }
+ *   client: DATA   { brk_data_t, n_samples * unit bytes }   broker: RESULT { brk_dresult_t, count records of rec_size bytes }
+ * A DATA message is one read of the client's input loop (any length up to one second); want_stats bit 1 (BRK_FINISH) marks the end of the
+ * stream: the broker flushes the frame in progress on that channel.  Records are what the client's own fetch call would return
+ * (sonde_frame_t, sonde_dfm_frame_t, sonde_m10_frame_t, sonde_m20_frame_t — chosen by cfg.sonde_type), with channel = 0.
  */
 #ifndef BROKER_PROTO_H
 #define BROKER_PROTO_H
@@ -19,7 +27,9 @@
 
 #define BRK_MAGIC 0x42444e53u            /* "SNDB" */
 enum { BRK_HELLO = 1, BRK_INFO = 2, BRK_DATA = 3, BRK_RESULT = 4, BRK_ERROR = 5 };
-enum { BRK_KIND_FSK = 1 };
+enum { BRK_KIND_FSK = 1, BRK_KIND_DEMOD = 2 };
+#define BRK_WANT_STATS 1u
+#define BRK_FINISH     2u
 
 typedef struct { uint32_t magic, type, length; } brk_hdr_t;      /* length = payload bytes that follow */
 
@@ -38,5 +48,15 @@ typedef struct {
 } brk_result_t;
 
 typedef struct { int32_t neyetr, neyesamp; float eye[8 * 160]; } brk_eye_t;
+
+typedef struct {
+    uint32_t kind;                       /* BRK_KIND_DEMOD */
+    uint32_t reserved;
+    sonde_cfg_t cfg;                     /* n_channels / device / max_chunk / max_frames / pipeline are the broker's business and ignored */
+    int32_t set_sync, hdmax, bitofs;     /* set_sync != 0: sonde_engine_set_sync(hdmax, bitofs) (the decoders' -d <shift>) */
+    int32_t reserved2;
+} brk_hello_demod_t;
+
+typedef struct { uint32_t count, rec_size; } brk_dresult_t;
 
 #endif

@@ -12,6 +12,7 @@
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "broker_client.h"
 #include "sonde_dfm.h"
 #include "wav_header.h"
 
@@ -37,6 +38,8 @@ static void emit_frame(const sonde_dfm_frame_t *f) {
     if (g_raw) { sonde_dfm_rawline(f, g_ecc, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
     if (g_dec && sonde_dfm_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
 }
+
+static void emit_rec(const void *r) { emit_frame((const sonde_dfm_frame_t *)r); }      /* records from the resident broker */
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
@@ -151,11 +154,19 @@ int main(int argc, char **argv) {
     cfg.max_chunk = cfg.sample_rate;
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
-    int rc = sonde_engine_create(&cfg, &fq, &eng);
-    if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 2 + g_shift);
-    if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+    brk_demod_t brk; brk.fd = -1;
+    const int use_broker = brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
+    int rc = 0;
     sonde_info_t info;
-    sonde_engine_info(eng, &info);
+    if (use_broker) {
+        if (brk_demod_open(&brk, &cfg, g_shift != 0, 2, 2 + g_shift) < 0) return -1;
+        info = brk.info;
+    } else {
+        rc = sonde_engine_create(&cfg, &fq, &eng);
+        if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 2 + g_shift);
+        if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+        sonde_engine_info(eng, &info);
+    }
     if (iq_mode == 5) {
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
@@ -174,20 +185,26 @@ int main(int argc, char **argv) {
         int n = (int)(have / unit);
         n -= n % info.decM;
         if (n > 0) {
-            rc = sonde_engine_process_host(eng, buf, n, n);
-            if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
-            int k = sonde_engine_fetch_dfm(eng, frames, 128, 0);
-            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            if (use_broker) {
+                if (brk_demod_feed(&brk, buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
+            } else {
+                rc = sonde_engine_process_host(eng, buf, n, n);
+                if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
+                int k = sonde_engine_fetch_dfm(eng, frames, 128, 0);
+                for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            }
             memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
             have -= (size_t)n * unit;
         }
         if (got == 0) break;
     }
-    {
+    if (use_broker) brk_demod_feed(&brk, NULL, 0, unit, 1, sizeof frames[0], emit_rec);
+    else {
         int k = sonde_engine_fetch_dfm(eng, frames, 128, 1);
         for (int i = 0; i < k; i++) emit_frame(&frames[i]);
     }
-    sonde_engine_destroy(eng);
+    if (eng) sonde_engine_destroy(eng);
+    brk_demod_close(&brk);
     free(buf);
     return 0;
 }

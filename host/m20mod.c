@@ -15,6 +15,7 @@
 #include <string.h>
 #include <stdint.h>
 #include "sonde_hip.h"
+#include "broker_client.h"
 #include "sonde_m20.h"
 #include "wav_header.h"
 
@@ -40,6 +41,8 @@ static int make_decoder(sonde_m20_opts_t *o, int raw, int khz) {
     if (ver) { strncpy(o->version, ver, sizeof o->version - 1); o->version[sizeof o->version - 1] = 0; }
     return sonde_m20_dec_create(o, &g_dec);
 }
+
+static void emit_rec(const void *r) { emit_frame((const sonde_m20_frame_t *)r); }      /* records from the resident broker */
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
@@ -163,11 +166,19 @@ int main(int argc, char **argv) {
     cfg.max_chunk = cfg.sample_rate;
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
-    int rc = sonde_engine_create(&cfg, &fq, &eng);
-    if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 0 + g_shift);
-    if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+    brk_demod_t brk; brk.fd = -1;
+    const int use_broker = brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
+    int rc = 0;
     sonde_info_t info;
-    sonde_engine_info(eng, &info);
+    if (use_broker) {
+        if (brk_demod_open(&brk, &cfg, g_shift != 0, 2, 0 + g_shift) < 0) return -1;
+        info = brk.info;
+    } else {
+        rc = sonde_engine_create(&cfg, &fq, &eng);
+        if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 0 + g_shift);
+        if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+        sonde_engine_info(eng, &info);
+    }
     if (iq_mode == 5) {                              /* init_buffers prints these first (demod_mod.c:1257-1258) */
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
@@ -185,20 +196,26 @@ int main(int argc, char **argv) {
         int n = (int)(have / unit);
         n -= n % info.decM;
         if (n > 0) {
-            rc = sonde_engine_process_host(eng, buf, n, n);
-            if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
-            int k = sonde_engine_fetch_m20(eng, frames, 16, 0);
-            for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            if (use_broker) {
+                if (brk_demod_feed(&brk, buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
+            } else {
+                rc = sonde_engine_process_host(eng, buf, n, n);
+                if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
+                int k = sonde_engine_fetch_m20(eng, frames, 16, 0);
+                for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            }
             memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
             have -= (size_t)n * unit;
         }
         if (got == 0) break;
     }
-    {
+    if (use_broker) brk_demod_feed(&brk, NULL, 0, unit, 1, sizeof frames[0], emit_rec);
+    else {
         int k = sonde_engine_fetch_m20(eng, frames, 16, 1);
         for (int i = 0; i < k; i++) emit_frame(&frames[i]);
     }
-    sonde_engine_destroy(eng);
+    if (eng) sonde_engine_destroy(eng);
+    brk_demod_close(&brk);
     free(buf);
     return 0;
 }

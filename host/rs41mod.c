@@ -18,6 +18,7 @@
 #include <math.h>
 #include "sonde_hip.h"
 #include "sonde_rs41.h"
+#include "broker_client.h"
 #include "wav_header.h"
 
 static sonde_rs41_dec_t *g_dec = NULL;
@@ -44,6 +45,8 @@ static void emit_frame(const sonde_frame_t *f) {
     if (g_raw) { sonde_rs41_rawline(f, ln, sizeof ln); fprintf(stdout, "%s\n", ln); }
     if (g_dec && sonde_rs41_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
 }
+
+static void emit_rec(const void *r) { emit_frame((const sonde_frame_t *)r); }      /* records from the resident broker */
 
 /* --ecc3 / --ecc4: header hits with both soft bits of every bit (read_softbit2p's hsbit / hsbit1) -> sonde_rs41_dec_ecc() */
 static sonde_rs41_dec_t *g_ecc_only = NULL;
@@ -221,11 +224,19 @@ int main(int argc, char **argv) {
     cfg.n_channels = 1;
     cfg.max_chunk = cfg.sample_rate;
     sonde_engine_t *eng = NULL;
-    int rc = sonde_engine_create(&cfg, &fq, &eng);
-    if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 4, 2 + g_shift);
-    if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+    brk_demod_t brk; brk.fd = -1;
+    const int use_broker = brk_demod_wanted(&cfg) && !ecc34;      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
+    int rc = 0;
     sonde_info_t info;
-    sonde_engine_info(eng, &info);
+    if (use_broker) {
+        if (brk_demod_open(&brk, &cfg, g_shift != 0, 4, 2 + g_shift) < 0) return -1;
+        info = brk.info;
+    } else {
+        rc = sonde_engine_create(&cfg, &fq, &eng);
+        if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 4, 2 + g_shift);
+        if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
+        sonde_engine_info(eng, &info);
+    }
     if (iq_mode == 5) {
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
@@ -244,12 +255,16 @@ int main(int argc, char **argv) {
         int n = (int)(have / unit);
         n -= n % info.decM;
         if (n > 0) {
-            rc = sonde_engine_process_host(eng, buf, n, n);
-            if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
-            if (ecc34) emit_hits(eng, ecc34, info.if_sr, 0);
-            else {
-                int k = sonde_engine_fetch_frames(eng, frames, 8);
-                for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+            if (use_broker) {
+                if (brk_demod_feed(&brk, buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
+            } else {
+                rc = sonde_engine_process_host(eng, buf, n, n);
+                if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
+                if (ecc34) emit_hits(eng, ecc34, info.if_sr, 0);
+                else {
+                    int k = sonde_engine_fetch_frames(eng, frames, 8);
+                    for (int i = 0; i < k; i++) emit_frame(&frames[i]);
+                }
             }
             memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
             have -= (size_t)n * unit;
@@ -257,13 +272,15 @@ int main(int argc, char **argv) {
         if (got == 0) break;                        /* EOF */
     }
     {   /* EOF: the reference still prints a frame it was in the middle of (rs41mod.c:2931,2965) */
-        if (ecc34) emit_hits(eng, ecc34, info.if_sr, 1);
+        if (use_broker) brk_demod_feed(&brk, NULL, 0, unit, 1, sizeof frames[0], emit_rec);
+        else if (ecc34) emit_hits(eng, ecc34, info.if_sr, 1);
         else {
             int k = sonde_engine_finish(eng, frames, 8);
             for (int i = 0; i < k; i++) emit_frame(&frames[i]);
         }
     }
-    sonde_engine_destroy(eng);
+    if (eng) sonde_engine_destroy(eng);
+    brk_demod_close(&brk);
     free(buf);
     return 0;
 }

@@ -10,7 +10,12 @@
  *
  *     sonde_broker --socket /run/sonde.sock [--slots 64] [--device 0] [--window-us 2000] [--idle-exit]
  *
- * Step policy of a group: run as soon as every connected client has a frame pending; otherwise when the oldest pending frame has
+ * The decoder shims themselves (rs41mod / dfm09mod / m10mod / m20mod on FM audio or IF-rate IQ: what decode.py:375-417 pipes into them) work
+ * the same way: a group is an engine configuration, a client owns a channel, every step feeds all channels the same number of samples of
+ * their pending input blocks in one sonde_engine_process_host() call and routes the frame records back.  A channel is ended with
+ * sonde_engine_finish_channel() when its client reaches EOF and re-armed with sonde_engine_restart_channel() for the next client.
+ *
+ * Step policy of a modem group: run as soon as every connected client has a frame pending; otherwise when the oldest pending frame has
  * waited --window-us (clients whose frame is not there yet simply sit the step out: their channel is fed 0 samples).  A slot freed by
  * a disconnect is reset to the fsk_create_hbr() state before it is handed out again.  SIGTERM / SIGINT: statistics line on stderr
  * (`broker: groups G clients C steps S frames F max_batch B`), socket removed, exit 0.
@@ -28,16 +33,21 @@
 #include <sys/socket.h>
 #include <sys/un.h>
 #include "broker_proto.h"
+#include "sonde_hip.h"
 
 #define MAX_CLIENTS 1024
 #define MAX_GROUPS  16
 
 typedef struct {
     int fd;                              /* -1 = unused */
+    int kind;                            /* BRK_KIND_FSK / BRK_KIND_DEMOD once HELLO has been seen */
     int group, slot;                     /* -1 until HELLO */
     unsigned char *rx; size_t rx_len, rx_cap;
     int pending;                         /* a complete DATA message sits at the head of rx */
     int64_t pending_since_us;
+    /* decoder shims: progress inside the pending block and the records collected for the reply */
+    uint32_t blk_off;
+    unsigned char *out; size_t out_len, out_cap; uint32_t out_count;
 } client_t;
 
 typedef struct {
@@ -52,8 +62,24 @@ typedef struct {
     float *sd; uint8_t *bits; float *Sf;
 } group_t;
 
+typedef struct {                         /* one engine configuration of decoder shims */
+    int used;
+    brk_hello_demod_t key;
+    sonde_engine_t *eng;
+    sonde_info_t info;
+    size_t unit, rec_size;               /* bytes per input sample (all components) / per frame record */
+    int max_chunk;
+    int *slot_client, *slot_dirty;
+    int n_clients;
+    long calls;                          /* process calls so far: 0 = the engine is still at its origin */
+    unsigned char *stage;                /* [slots][max_chunk] samples of one step */
+    unsigned char *recs;                 /* fetch buffer */
+} dgroup_t;
+
 static client_t g_cl[MAX_CLIENTS];
 static group_t g_gr[MAX_GROUPS];
+static dgroup_t g_dg[MAX_GROUPS];
+static long g_dsteps = 0, g_drecs = 0; static int g_dmax_batch = 0;
 static int g_slots = 64, g_device = 0, g_idle_exit = 0;
 static int64_t g_window_us = 2000;
 static volatile sig_atomic_t g_stop = 0;
@@ -82,11 +108,16 @@ static void drop_client(int ci) {
     client_t *c = &g_cl[ci];
     if (c->fd < 0) return;
     close(c->fd); c->fd = -1;
-    if (c->group >= 0) {
+    if (c->group >= 0 && c->kind == BRK_KIND_FSK) {
         group_t *g = &g_gr[c->group];
         g->slot_client[c->slot] = -1; g->slot_dirty[c->slot] = 1; g->n_clients--;
     }
-    free(c->rx); c->rx = NULL; c->rx_len = c->rx_cap = 0; c->pending = 0; c->group = c->slot = -1;
+    if (c->group >= 0 && c->kind == BRK_KIND_DEMOD) {
+        dgroup_t *g = &g_dg[c->group];
+        g->slot_client[c->slot] = -1; g->slot_dirty[c->slot] = 1; g->n_clients--;
+    }
+    free(c->rx); c->rx = NULL; c->rx_len = c->rx_cap = 0; c->pending = 0; c->group = c->slot = -1; c->kind = 0;
+    free(c->out); c->out = NULL; c->out_len = c->out_cap = 0; c->out_count = 0; c->blk_off = 0;
 }
 
 /* the fields that make two clients batchable */
@@ -124,9 +155,160 @@ static int join_group(int ci, const sonde_fsk_cfg_t *want) {
     if (slot < 0) { send_error(g_cl[ci].fd, "broker: all channels of this configuration are taken"); return -1; }
     if (g->slot_dirty[slot]) { sonde_fsk_reset_channel(g->eng, slot); g->slot_dirty[slot] = 0; }
     g->slot_client[slot] = ci; g->n_clients++;
-    g_cl[ci].group = gi; g_cl[ci].slot = slot;
+    g_cl[ci].group = gi; g_cl[ci].slot = slot; g_cl[ci].kind = BRK_KIND_FSK;
     g_served++;
     return send_msg(g_cl[ci].fd, BRK_INFO, &g->info, sizeof g->info, NULL, 0, NULL, 0, NULL, 0);
+}
+
+static void consume(client_t *c, size_t n);
+
+/* ---- decoder shims ---------------------------------------------------------------------------------------------------------- */
+
+static size_t demod_rec_size(int type) {
+    return type == SONDE_RS41 ? sizeof(sonde_frame_t) : type == SONDE_DFM09 ? sizeof(sonde_dfm_frame_t) : type == SONDE_M10 ? sizeof(sonde_m10_frame_t) :
+           type == SONDE_M20 ? sizeof(sonde_m20_frame_t) : 0;
+}
+
+static int same_demod(const brk_hello_demod_t *a, const brk_hello_demod_t *b) {
+    const sonde_cfg_t *x = &a->cfg, *y = &b->cfg;
+    return x->sample_rate == y->sample_rate && x->bits == y->bits && x->sonde_type == y->sonde_type && x->opt_lp == y->opt_lp && x->opt_min == y->opt_min &&
+           x->lpiq_bw == y->lpiq_bw && x->ecc_level == y->ecc_level && x->thres == y->thres && x->input == y->input && x->audio_channels == y->audio_channels &&
+           x->audio_select == y->audio_select && x->opt_inv == y->opt_inv && x->m10_noskip == y->m10_noskip && x->opt_auto == y->opt_auto &&
+           a->set_sync == b->set_sync && (!a->set_sync || (a->hdmax == b->hdmax && a->bitofs == b->bitofs));
+}
+
+static int join_dgroup(int ci, const brk_hello_demod_t *want) {
+    const sonde_cfg_t *w = &want->cfg;
+    const size_t rs = demod_rec_size(w->sonde_type);
+    if (!rs || w->input == SONDE_IN_IQ || w->opt_dc || w->opt_iqdc || w->opt_nolut || w->keep_soft || w->sample_rate < 1000 || w->sample_rate > 4000000) {
+        send_error(g_cl[ci].fd, "broker: this decoder configuration is not served (FM audio / IF-rate IQ of rs41mod, dfm09mod, m10mod, m20mod without --dc / --iqdc)");
+        return -1;
+    }
+    int gi = -1;
+    for (int i = 0; i < MAX_GROUPS; i++) if (g_dg[i].used && same_demod(&g_dg[i].key, want)) { gi = i; break; }
+    if (gi < 0) {
+        for (int i = 0; i < MAX_GROUPS; i++) if (!g_dg[i].used) { gi = i; break; }
+        if (gi < 0) { send_error(g_cl[ci].fd, "broker: too many decoder configurations"); return -1; }
+        dgroup_t *g = &g_dg[gi];
+        memset(g, 0, sizeof *g);
+        g->key = *want;
+        sonde_cfg_t *c = &g->key.cfg;
+        c->abi_version = SONDE_ABI_VERSION; c->device = g_device; c->n_channels = g_slots; c->max_chunk = c->sample_rate; c->max_frames = 16 * g_slots;
+        c->pipeline = 0; c->keep_soft = 0;
+        double *fq = (double *)calloc((size_t)g_slots, sizeof(double));
+        int rc = sonde_engine_create(c, fq, &g->eng);
+        free(fq);
+        if (rc >= 0 && want->set_sync) rc = sonde_engine_set_sync(g->eng, want->hdmax, want->bitofs);
+        if (rc < 0) { if (g->eng) sonde_engine_destroy(g->eng); send_error(g_cl[ci].fd, sonde_strerror(rc)); return -1; }
+        sonde_engine_info(g->eng, &g->info);
+        g->unit = (size_t)(c->input == SONDE_IN_AUDIO ? c->audio_channels : 2) * (size_t)(c->bits / 8);
+        g->rec_size = rs; g->max_chunk = c->max_chunk;
+        g->slot_client = (int *)malloc(sizeof(int) * (size_t)g_slots); g->slot_dirty = (int *)calloc((size_t)g_slots, sizeof(int));
+        for (int s2 = 0; s2 < g_slots; s2++) g->slot_client[s2] = -1;
+        g->stage = (unsigned char *)calloc((size_t)g_slots * (size_t)g->max_chunk, g->unit);
+        g->recs = (unsigned char *)malloc(rs * 256);
+        g->used = 1;
+    }
+    dgroup_t *g = &g_dg[gi];
+    int slot = -1;
+    for (int s2 = 0; s2 < g_slots; s2++) if (g->slot_client[s2] < 0) { slot = s2; break; }
+    if (slot < 0) { send_error(g_cl[ci].fd, "broker: all channels of this configuration are taken"); return -1; }
+    /* a channel that carried another stream, or sat idle while the engine ran, starts over: from here on it is channel 0 of a fresh engine */
+    if (g->slot_dirty[slot] || g->calls > 0) {
+        const int rc = sonde_engine_restart_channel(g->eng, slot);
+        if (rc < 0) { send_error(g_cl[ci].fd, sonde_strerror(rc)); return -1; }
+        g->slot_dirty[slot] = 0;
+    }
+    g->slot_client[slot] = ci; g->n_clients++;
+    g_cl[ci].group = gi; g_cl[ci].slot = slot; g_cl[ci].kind = BRK_KIND_DEMOD; g_cl[ci].blk_off = 0;
+    g_served++;
+    return send_msg(g_cl[ci].fd, BRK_INFO, &g->info, sizeof g->info, NULL, 0, NULL, 0, NULL, 0);
+}
+
+/* frame records the engine has ready -> the outboxes of the clients that own the channels */
+static void route_records(dgroup_t *g) {
+    for (;;) {
+        int k;
+        const int t = g->key.cfg.sonde_type;
+        if (t == SONDE_RS41) k = sonde_engine_fetch_frames(g->eng, (sonde_frame_t *)g->recs, 256);
+        else if (t == SONDE_DFM09) k = sonde_engine_fetch_dfm(g->eng, (sonde_dfm_frame_t *)g->recs, 256, 0);
+        else if (t == SONDE_M10) k = sonde_engine_fetch_m10(g->eng, (sonde_m10_frame_t *)g->recs, 256, 0);
+        else k = sonde_engine_fetch_m20(g->eng, (sonde_m20_frame_t *)g->recs, 256, 0);
+        if (k <= 0) return;
+        for (int i = 0; i < k; i++) {
+            unsigned char *r = g->recs + (size_t)i * g->rec_size;
+            int32_t ch; memcpy(&ch, r, sizeof ch);
+            if (ch < 0 || ch >= g_slots || g->slot_client[ch] < 0) continue;          /* a channel nobody owns (silence): nothing to report */
+            client_t *c = &g_cl[g->slot_client[ch]];
+            const int32_t zero = 0; memcpy(r, &zero, sizeof zero);                     /* the client sees itself as channel 0 */
+            if (c->out_cap - c->out_len < g->rec_size) { c->out_cap = c->out_cap ? 2 * c->out_cap : 16 * g->rec_size; c->out = (unsigned char *)realloc(c->out, c->out_cap); }
+            memcpy(c->out + c->out_len, r, g->rec_size); c->out_len += g->rec_size; c->out_count++; g_drecs++;
+        }
+        if (k < 256) return;
+    }
+}
+
+static void parse_client(int ci);
+
+/* the pending block of a client has been consumed: end its stream if it said so, send the records collected for it, look at its next message */
+static void reply_dclient(dgroup_t *g, int s2) {
+    const int ci = g->slot_client[s2];
+    client_t *c = &g_cl[ci];
+    brk_hdr_t h; brk_data_t d;
+    memcpy(&h, c->rx, sizeof h); memcpy(&d, c->rx + sizeof h, sizeof d);
+    if (d.want_stats & BRK_FINISH) { sonde_engine_finish_channel(g->eng, s2); route_records(g); g->slot_dirty[s2] = 1; }
+    brk_dresult_t r = { c->out_count, (uint32_t)g->rec_size };
+    const int bad = send_msg(c->fd, BRK_RESULT, &r, sizeof r, c->out, c->out_len, NULL, 0, NULL, 0);
+    c->out_len = 0; c->out_count = 0; c->blk_off = 0; c->pending = 0;
+    consume(c, sizeof h + h.length);
+    if (bad) { drop_client(ci); return; }
+    parse_client(ci);
+}
+
+/* one process call for the pending blocks of all clients of the group: n = what every one of them still has */
+static void step_dgroup(dgroup_t *g) {
+    /* a client with nothing left in its block (an empty end-of-stream message) is answered first: its channel must not see the
+     * samples — silence — of a call made for the others */
+    for (int s2 = 0; s2 < g_slots; s2++) {
+        const int ci = g->slot_client[s2];
+        if (ci < 0 || !g_cl[ci].pending) continue;
+        brk_data_t d; memcpy(&d, g_cl[ci].rx + sizeof(brk_hdr_t), sizeof d);
+        if (d.n_samples == g_cl[ci].blk_off) reply_dclient(g, s2);
+    }
+    uint32_t n = 0; int batch = 0, active = 0;
+    for (int s2 = 0; s2 < g_slots; s2++) {
+        const int ci = g->slot_client[s2];
+        if (ci < 0) continue;
+        active++;
+        if (!g_cl[ci].pending) continue;
+        brk_data_t d; memcpy(&d, g_cl[ci].rx + sizeof(brk_hdr_t), sizeof d);
+        const uint32_t left = d.n_samples - g_cl[ci].blk_off;
+        if (left == 0) continue;
+        if (!batch || left < n) n = left;
+        batch++;
+    }
+    if (!batch || batch != active) return;                   /* somebody's next block is not here yet */
+    const size_t row = (size_t)g->max_chunk * g->unit;
+    for (int s2 = 0; s2 < g_slots; s2++) {
+        unsigned char *dst = g->stage + (size_t)s2 * row;
+        const int ci = g->slot_client[s2];
+        if (ci >= 0) memcpy(dst, g_cl[ci].rx + sizeof(brk_hdr_t) + sizeof(brk_data_t) + (size_t)g_cl[ci].blk_off * g->unit, (size_t)n * g->unit);
+        else memset(dst, 0, (size_t)n * g->unit);             /* nobody there: silence */
+    }
+    const int rc = sonde_engine_process_host(g->eng, g->stage, g->max_chunk, (int32_t)n);
+    g_dsteps++; g->calls++; if (batch > g_dmax_batch) g_dmax_batch = batch;
+    if (rc < 0) {
+        for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0) { send_error(g_cl[ci].fd, sonde_strerror(rc)); drop_client(ci); } }
+        return;
+    }
+    route_records(g);
+    for (int s2 = 0; s2 < g_slots; s2++) {
+        const int ci = g->slot_client[s2];
+        if (ci < 0) continue;
+        g_cl[ci].blk_off += n;
+        brk_data_t d; memcpy(&d, g_cl[ci].rx + sizeof(brk_hdr_t), sizeof d);
+        if (g_cl[ci].blk_off >= d.n_samples) reply_dclient(g, s2);   /* otherwise the rest of its block goes into the next call */
+    }
 }
 
 /* 1 = a complete message is at the head of rx */
@@ -142,12 +324,22 @@ static void parse_client(int ci) {
     brk_hdr_t h;
     while (c->fd >= 0 && !c->pending && have_message(c, &h)) {
         if (h.magic != BRK_MAGIC) { drop_client(ci); return; }
-        if (h.type == BRK_HELLO && c->group < 0 && h.length == sizeof(brk_hello_t)) {
+        uint32_t hello_kind = 0;
+        if (h.type == BRK_HELLO && h.length >= sizeof hello_kind) memcpy(&hello_kind, c->rx + sizeof h, sizeof hello_kind);
+        if (h.type == BRK_HELLO && c->group < 0 && hello_kind == BRK_KIND_FSK && h.length == sizeof(brk_hello_t)) {
             brk_hello_t hello; memcpy(&hello, c->rx + sizeof h, sizeof hello);
             consume(c, sizeof h + h.length);
-            if (hello.kind != BRK_KIND_FSK) { send_error(c->fd, "broker: unknown client kind"); drop_client(ci); return; }
             if (join_group(ci, &hello.fsk) < 0) { drop_client(ci); return; }
-        } else if (h.type == BRK_DATA && c->group >= 0 && h.length >= sizeof(brk_data_t)) {
+        } else if (h.type == BRK_HELLO && c->group < 0 && hello_kind == BRK_KIND_DEMOD && h.length == sizeof(brk_hello_demod_t)) {
+            brk_hello_demod_t hello; memcpy(&hello, c->rx + sizeof h, sizeof hello);
+            consume(c, sizeof h + h.length);
+            if (join_dgroup(ci, &hello) < 0) { drop_client(ci); return; }
+        } else if (h.type == BRK_DATA && c->group >= 0 && c->kind == BRK_KIND_DEMOD && h.length >= sizeof(brk_data_t)) {
+            brk_data_t d; memcpy(&d, c->rx + sizeof h, sizeof d);
+            const dgroup_t *g = &g_dg[c->group];
+            if (h.length != sizeof d + (size_t)d.n_samples * g->unit || (int)d.n_samples > g->max_chunk) { send_error(c->fd, "broker: malformed DATA"); drop_client(ci); return; }
+            c->pending = 1; c->pending_since_us = now_us(); c->blk_off = 0;
+        } else if (h.type == BRK_DATA && c->group >= 0 && c->kind == BRK_KIND_FSK && h.length >= sizeof(brk_data_t)) {
             brk_data_t d; memcpy(&d, c->rx + sizeof h, sizeof d);
             const group_t *g = &g_gr[c->group];
             if (h.length != sizeof d + (size_t)d.n_samples * g->unit || (int)d.n_samples > g->key.max_chunk) { send_error(c->fd, "broker: malformed DATA"); drop_client(ci); return; }
@@ -260,7 +452,7 @@ int main(int argc, char **argv) {
                     int ci = -1;
                     for (int i = 0; i < MAX_CLIENTS; i++) if (g_cl[i].fd < 0) { ci = i; break; }
                     if (ci < 0) { send_error(fd, "broker: too many clients"); close(fd); }
-                    else { g_cl[ci].fd = fd; g_cl[ci].group = g_cl[ci].slot = -1; g_cl[ci].pending = 0; g_cl[ci].rx = NULL; g_cl[ci].rx_len = g_cl[ci].rx_cap = 0; }
+                    else { memset(&g_cl[ci], 0, sizeof g_cl[ci]); g_cl[ci].fd = fd; g_cl[ci].group = g_cl[ci].slot = -1; }
                 }
             }
             for (int k = 1; k < np; k++) if (pf[k].revents & (POLLIN | POLLHUP | POLLERR)) read_client(map[k]);
@@ -279,10 +471,39 @@ int main(int argc, char **argv) {
             }
             if (pend && (pend == g->n_clients || t - oldest >= g_window_us)) step_group(g);
         }
+        /* decoder groups feed every channel the same number of samples per call: they step when all their clients have input pending; a client
+         * that has sent nothing for 5 s while others wait is dropped so that it cannot stall them */
+        for (int gi = 0; gi < MAX_GROUPS; gi++) {
+            dgroup_t *g = &g_dg[gi];
+            if (!g->used || !g->n_clients) continue;
+            int pend = 0; int64_t oldest = -1;
+            for (int s2 = 0; s2 < g_slots; s2++) {
+                const int ci = g->slot_client[s2];
+                if (ci < 0 || !g_cl[ci].pending) continue;
+                pend++;
+                if (oldest < 0 || g_cl[ci].pending_since_us < oldest) oldest = g_cl[ci].pending_since_us;
+            }
+            if (pend && pend < g->n_clients && t - oldest >= 5000000)
+                for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && !g_cl[ci].pending) { send_error(g_cl[ci].fd, "broker: no input for 5 s"); drop_client(ci); } }
+            for (int guard = 0; guard < 64 && g->n_clients > 0; guard++) {             /* blocks of unequal length take more than one call */
+                int p2 = 0;
+                for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && g_cl[ci].pending) p2++; }
+                if (p2 != g->n_clients) break;
+                const long before = g->calls; const long served = g_drecs + g_served;
+                step_dgroup(g);
+                if (g->calls == before && g_drecs + g_served == served) {
+                    int p3 = 0;
+                    for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && g_cl[ci].pending) p3++; }
+                    if (p3 == p2) break;                                               /* nothing moved */
+                }
+            }
+        }
     }
-    int groups = 0;
+    int groups = 0, dgroups = 0;
     for (int gi = 0; gi < MAX_GROUPS; gi++) if (g_gr[gi].used) { groups++; sonde_fsk_destroy(g_gr[gi].eng); }
+    for (int gi = 0; gi < MAX_GROUPS; gi++) if (g_dg[gi].used) { dgroups++; sonde_engine_destroy(g_dg[gi].eng); }
     fprintf(stderr, "broker: groups %d clients %ld steps %ld frames %ld max_batch %d\n", groups, g_served, g_steps, g_frames, g_max_batch);
+    if (dgroups) fprintf(stderr, "broker: decoder_groups %d calls %ld records %ld max_batch %d\n", dgroups, g_dsteps, g_drecs, g_dmax_batch);
     for (int i = 0; i < MAX_CLIENTS; i++) if (g_cl[i].fd >= 0) close(g_cl[i].fd);
     close(lfd); unlink(path);
     return 0;

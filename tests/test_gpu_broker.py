@@ -96,3 +96,63 @@ def test_broker_without_gpu_reports_the_error_to_the_client(tmp_path):
         broker.send_signal(signal.SIGTERM)
         _, berr = broker.communicate(timeout=30)
     assert b"broker: groups 0" in berr
+
+
+def _decoder_streams():
+    from tools import synth
+    ecef = dict(ecef_cm=(418833319, 85974133, 473346430))
+    out = []
+    for k in range(4):            # RS41 on FM audio (WAV): what auto_rx's classic chain pipes into rs41mod (decode.py:375-417)
+        x = synth.rs41_capture(sr=48_000, seconds=4.3, fq=0.0, noise_sigma=0.02 + 0.02 * k, frame_kw=ecef, n_frames=4, t_first=0.1 + 0.07 * k, seed=500 + k,
+                               first_frame_no=200 + 10 * k)
+        out.append(("rs41mod", ["--ptu2", "--json", "--jsnsubfrm1"], synth.wav_bytes(synth.fm_audio(x), 48_000)))
+    for k in range(2):            # RS41 on IF-rate IQ, raw lines
+        x = synth.rs41_capture(sr=48_000, seconds=3.3, fq=0.0, noise_sigma=0.05 + 0.05 * k, frame_kw=ecef, n_frames=3, t_first=0.2, seed=510 + k)
+        out.append(("rs41mod", ["-r", "--ecc2", "--crc", "--iq2", "--lpIQ", "-", "48000", "16"], x.tobytes()))
+    for k in range(2):            # DFM on FM audio, raw frames with the polarity found automatically
+        x = synth.dfm_capture(sr=48_000, seconds=3.2, fq=0.0, noise_sigma=0.03 + 0.03 * k, seed=520 + k)
+        out.append(("dfm09mod", ["-r", "--ecc", "--auto"], synth.wav_bytes(synth.fm_audio(x), 48_000)))
+    for k in range(2):            # M10 on FM audio with auto_rx's options (decode.py:544)
+        x = synth.m10_capture(sr=48_000, seconds=4.3, noise_sigma=0.03 + 0.02 * k, seed=530 + k, frame_fn=lambda j, k=k: synth.m10_frame(j, rng=np.random.default_rng(40 + 7 * k + j)))
+        out.append(("m10mod", ["--json", "--ptu", "-vvv"], synth.wav_bytes(synth.fm_audio(x), 48_000)))
+    return out
+
+
+@pytest.mark.gpu
+def test_decoder_shims_share_one_engine_per_configuration(tmp_path):
+    """rs41mod / dfm09mod / m10mod on FM audio and IF-rate IQ behind the broker: every process owns a channel of one engine per configuration
+    (sonde_engine_restart_channel / finish_channel), all channels advance in the same process call, and every process prints what it prints
+    on its own — including a second wave of processes that reuses the channels of the first."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    streams = _decoder_streams()
+    env0 = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    alone = [subprocess.run([os.path.join(BIN, b)] + a, input=x, capture_output=True, timeout=120, env=env0) for b, a, x in streams]
+    assert all(r.returncode == 0 and len(r.stdout) > 0 for r in alone), [r.stderr[-200:] for r in alone]
+    sock = str(tmp_path / "broker.sock")
+    broker = subprocess.Popen([os.path.join(BIN, "sonde_broker"), "--socket", sock, "--slots", "32"], stderr=subprocess.PIPE)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        env = dict(env0, SONDE_BROKER=sock)
+        files = []
+        for i, (b, a, x) in enumerate(streams):
+            p = tmp_path / ("dec%d.bin" % i)
+            p.write_bytes(x)
+            files.append(str(p))
+        for wave in range(2):
+            procs = []
+            for rep in range(3 if wave == 0 else 2):
+                for k, (b, a, x) in enumerate(streams):
+                    procs.append((k, subprocess.Popen([os.path.join(BIN, b)] + a, env=env, stdin=open(files[k], "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)))
+            for k, p in procs:
+                out, err = p.communicate(timeout=300)
+                assert p.returncode == 0, (streams[k][0], err[-300:])
+                assert out == alone[k].stdout, (wave, streams[k][0], streams[k][1], out[:200], alone[k].stdout[:200])
+    finally:
+        broker.send_signal(signal.SIGTERM)
+        _, berr = broker.communicate(timeout=30)
+    line = [l for l in berr.decode().splitlines() if l.startswith("broker: decoder_groups")][-1].split()
+    st = {line[i]: int(line[i + 1]) for i in range(1, len(line), 2)}
+    assert st["decoder_groups"] == 4 and st["max_batch"] >= 6 and st["records"] > 0, st
