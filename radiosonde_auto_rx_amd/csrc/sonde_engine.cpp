@@ -926,7 +926,7 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
     if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
     // channels of an engine share the base-rate sample clock (mixer table phase, IQ-DC segment schedule): only engines without that
     // front end can give one channel a new origin; the AFC loop of --dc and the pipelined streams are left out as well
-    if (e->info.decM != 1 || e->cfg.opt_dc || e->cfg.opt_iqdc || e->cfg.pipeline || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    if (e->info.decM != 1 || e->cfg.input == SONDE_IN_IQ || e->cfg.opt_dc || e->cfg.opt_iqdc || e->cfg.pipeline || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
     const int C = e->cfg.n_channels;

@@ -115,6 +115,9 @@ def _decoder_streams():
     for k in range(2):            # M10 on FM audio with auto_rx's options (decode.py:544)
         x = synth.m10_capture(sr=48_000, seconds=4.3, noise_sigma=0.03 + 0.02 * k, seed=530 + k, frame_fn=lambda j, k=k: synth.m10_frame(j, rng=np.random.default_rng(40 + 7 * k + j)))
         out.append(("m10mod", ["--json", "--ptu", "-vvv"], synth.wav_bytes(synth.fm_audio(x), 48_000)))
+    x = synth.m10_capture(sr=48_000, seconds=4.3, noise_sigma=0.03, seed=540, baud=9600.0,       # M20 on IF-rate IQ
+                          frame_fn=lambda j: synth.m20_frame(j, fw=8, pressure_hpa=700.0 - j, rng=np.random.default_rng(60 + j)))
+    out.append(("m20mod", ["--json", "--ptu", "-vv", "--iq2", "-", "48000", "16"], x.tobytes()))
     return out
 
 
@@ -155,4 +158,4 @@ def test_decoder_shims_share_one_engine_per_configuration(tmp_path):
         _, berr = broker.communicate(timeout=30)
     line = [l for l in berr.decode().splitlines() if l.startswith("broker: decoder_groups")][-1].split()
     st = {line[i]: int(line[i + 1]) for i in range(1, len(line), 2)}
-    assert st["decoder_groups"] == 4 and st["max_batch"] >= 6 and st["records"] > 0, st
+    assert st["decoder_groups"] == 5 and st["max_batch"] >= 6 and st["records"] > 0, st
