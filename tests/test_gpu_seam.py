@@ -131,6 +131,14 @@ def test_seam_lms6():
     z = synth.lms6_capture(sr=48_000, seconds=5.0, noise_sigma=0.01, seed=23)
     assert _both("lms6Xmod", ["-r", "--iq0", "-", "48000", "16"], z.tobytes()).count(b"[OK]") >= 3
     _both("lms6Xmod", ["--lmsX", "-r", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], y.tobytes())        # forced 4797.8 Bd bit clock on the same samples
+    # an LMS-X signal (300-byte blocks at 4797.8 Bd): with --lmsX the decoder sets dsp.br after init_buffers() and the seam follows (4720 raw bits per hit)
+    w = synth.lms6_capture(sr=48_000, seconds=6.0, noise_sigma=0.05, seed=31, baud=4797.8, lmsx=True)
+    out = _both("lms6Xmod", ["--lmsX", "-r", "--ecc", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], w.tobytes())
+    assert out.count(b"[OK]") >= 5 and out.startswith(b"24 46 05 00")
+    assert _both("lms6Xmod", ["--lmsX", "--vit", "--ecc", "--json", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], w.tobytes()).count(b'"id": "LMSX-') >= 5
+    # without --lmsX the decoder recognises the type from the first block and switches the symbol rate in mid-stream: the seam says so and stops
+    r = subprocess.run([os.path.join(REF, "lms6Xmod_seam"), "-r", "--ecc", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], input=w.tobytes(), capture_output=True, timeout=300)
+    assert r.returncode == 2 and b"dsp.sps changed" in r.stderr
 
 
 @pytest.mark.parametrize("sr", [250_000, 1_000_000, 1_200_000, 2_048_000, 3_200_000, 6_000_000])

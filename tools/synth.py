@@ -793,14 +793,29 @@ def lms6_frame(k: int = 0, *, sn: int = 8123456, lat=47.5, lon=8.7, alt_m=12345.
     return bytes(f)
 
 
-def lms6_onair_bits(n_blocks: int) -> np.ndarray:
+def lmsx_frame(k: int = 0, **kw) -> bytes:
+    """LMS-X variant of lms6_frame(): frame sync 24 46 05 00 (lms6Xmod.c:109), same CRC position"""
+    f = bytearray(lms6_frame(k, **kw))
+    f[0:4] = bytes([0x24, 0x46, 0x05, 0x00])
+    crc = 0
+    for b in f[:221]:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    f[221:223] = crc.to_bytes(2, "big")
+    return bytes(f)
+
+
+def lms6_onair_bits(n_blocks: int, lmsx: bool = False) -> np.ndarray:
     """Raw channel bits of n_blocks consecutive LMS6 blocks: [00 58 f3 3f b8 | 223-byte frame | 32 RS parity] bytes, LSB first, through the
     K = 7 rate-1/2 code of lms6Xmod.c:116-117 (c0 from 1001111, c1 from 1101101, oldest bit first), every second channel bit inverted."""
     data = []
     for k in range(n_blocks):
-        fr = np.frombuffer(lms6_frame(k), np.uint8)
+        fr = np.frombuffer(lmsx_frame(k) if lmsx else lms6_frame(k), np.uint8)
         par = rs255_223_ccsds_parity(fr[::-1])          # rs_cw[254 - j] = block byte j: the first frame byte is the highest coefficient
         data += [0x00, 0x58, 0xF3, 0x3F, 0xB8] + list(fr) + list(par[::-1])
+        if lmsx:
+            data += [0] * 40                            # LMS-X: one block per 300 bytes (RAWBITBLOCK_LEN, lms6Xmod.c:91)
     bits = np.unpackbits(np.array(data, np.uint8)[:, None], axis=1, bitorder="little").ravel().astype(np.int64)
     pa = np.array([1, 0, 0, 1, 1, 1, 1]); pb = np.array([1, 1, 0, 1, 1, 0, 1])
     hist = np.concatenate([np.zeros(6, np.int64), bits])
@@ -811,10 +826,11 @@ def lms6_onair_bits(n_blocks: int) -> np.ndarray:
 
 
 def lms6_capture(sr: int = 48_000, seconds: float = 4.0, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1,
-                 baud: float = 4800.0) -> np.ndarray:
-    """LMS6-403 GFSK capture (h = 0.9, BT = 1.2 as the decoder assumes, lms6Xmod.c:1274-1275), continuous blocks from t = 0."""
-    n_blocks = int(seconds * baud / (260 * 16)) + 2
-    bits = lms6_onair_bits(n_blocks)
+                 baud: float = 4800.0, lmsx: bool = False) -> np.ndarray:
+    """LMS6-403 GFSK capture (h = 0.9, BT = 1.2 as the decoder assumes, lms6Xmod.c:1274-1275), continuous blocks from t = 0.
+    lmsx: 300-byte blocks with the LMS-X frame sync (give baud = 4797.8)."""
+    n_blocks = int(seconds * baud / ((300 if lmsx else 260) * 16)) + 2
+    bits = lms6_onair_bits(n_blocks, lmsx)
     n = int(seconds * sr)
     z = gfsk_baseband(bits, sr, baud, dev_hz=0.9 * baud / 2, bt=1.2)[:n]
     if len(z) < n:
