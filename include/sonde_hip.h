@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SONDE_ABI_VERSION 1
+#define SONDE_ABI_VERSION 2          /* 2: sonde_cfg_t.if_tune, sonde_generic_t.slice_baud, sonde_fsk_frame_t.f_est[4] */
 
 /* error codes */
 #define SONDE_E_ARG      (-1)   /* bad argument / unsupported option combination          */
@@ -99,6 +99,9 @@ typedef struct {
                               * of the periodic float-phase table of the snapped fq (demod_mod.c:738-742); not with opt_dc   */
     int32_t m10_noskip;      /* SONDE_M10 / M20 with -vvv: do not drop the rest of the second after a frame (m10mod.c:1493) */
     int32_t opt_auto;        /* --auto: a header of the opposite polarity flips the channel's polarity instead of being skipped */
+    int32_t if_tune;         /* SONDE_IN_IFIQ* with float32 samples (bits = 32): rotate channel c by -fq[c] (cycles per IF sample, exact double phase
+                              * from the channel's own sample count) before the IF low-pass — the fine tuning a channelizer output needs (the sonde sits
+                              * anywhere inside its channel); 0 = the reference's --iq0/2/3, which ignore fq                               */
 } sonde_cfg_t;
 
 /* One decoded frame = what rs41mod's print_frame() sees (rs41mod.c:2472-2553). */
@@ -284,6 +287,9 @@ int  sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
  * engines without the base-rate front end (decM == 1: FM audio and IF-rate IQ input) — channels of an engine share the base-rate sample clock
  * (mixer table phase, IQ-DC schedule) — and not with --dc / --iqdc / pipeline: SONDE_E_ARG otherwise. */
 int  sonde_engine_finish_channel(sonde_engine_t *e, int32_t channel);
+/* cfg.if_tune engines: new fine-tuning offset fq (cycles per IF sample) for one channel, normally together with restart_channel when a
+ * channel is given to another signal of a channelized stream. */
+int  sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq);
 int  sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel);
 /* soft bits (hsbit_t.sb of read_softbit2p) of the frames returned by the last fetch; soft: [n][4080] */
 int  sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames);

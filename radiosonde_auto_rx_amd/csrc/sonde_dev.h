@@ -51,6 +51,7 @@ struct MixF32Args {
     const float2 *dc_avg; double *dc_sums;                      // [n_ch][2]
     float2 *z; uint32_t zmask; uint64_t n0;                     // ring [n_ch][zmask+1], absolute base-rate index of the first sample
     int mix;                                                    // 0: no mixer (IF-rate input, --iq0/2/3): z = x - avg
+    const uint32_t *epoch;                                      // phase_f64 with IF-rate input (if_tune): per-channel stream start the phase counts from; nullptr = 0
 };
 struct DecF32Args {
     const float2 *z; uint32_t zmask; uint64_t n0;               // ring and the absolute index of the first input sample of output 0

@@ -183,6 +183,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND && cfg->sonde_type != SONDE_GENERIC) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->opt_nolut && (cfg->opt_dc || cfg->input != SONDE_IN_IQ)) return SONDE_E_ARG;     // --noLUT folds Df into the base-rate mixer: not with --dc here
+    if (cfg->if_tune && (cfg->input < SONDE_IN_IFIQ0 || cfg->bits != 32 || cfg->opt_dc)) return SONDE_E_ARG;   // fine tuning: float32 IF-rate IQ only
     if (cfg->sonde_type == SONDE_FRONTEND && cfg->input != SONDE_IN_IQ) return SONDE_E_ARG;
     if (cfg->input < SONDE_IN_IQ || cfg->input > SONDE_IN_IFIQ3) return SONDE_E_ARG;
     int ndev = 0;
@@ -305,7 +306,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
         for (int c = 0; c < C; c++) {
             const Mixer m = design_mixer(-std::max(-0.5, std::min(0.5, fq[c])), cfg->sample_rate);
             f0s[c] = m.f0; e->lut_len = m.lut_len;
-            if (cfg->opt_nolut) f0s[c] = -std::max(-0.5, std::min(0.5, fq[c]));          // xlt_fq itself, not the table's snapped value
+            if (cfg->opt_nolut || cfg->if_tune) f0s[c] = -std::max(-0.5, std::min(0.5, fq[c]));   // xlt_fq itself, not the table's snapped value
         }
         I.lut_len = e->lut_len;
         if (dalloc(&e->d_chanf0, (size_t)C, false)) { delete e; return SONDE_E_NOMEM; }
@@ -526,7 +527,12 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.chan_f0 = e->d_chanf0; a.lut_len = e->lut_len; a.lut_phase = (uint32_t)(e->samples_in % (uint64_t)e->lut_len);
         a.phase_f64 = (e->cfg.sonde_type == SONDE_FRONTEND); a.dc_avg = e->d_dcavg; a.dc_sums = e->d_dcsums_f;
         if (e->cfg.opt_nolut) { a.phase_f64 = 1; a.lut_len = 1 << 30; a.lut_phase = 0; a.nd_base = (double)e->samples_in; }
-        if (e->ifiq) { a.mix = 0; a.z = e->d_y; a.zmask = (uint32_t)e->ring_len - 1; a.n0 = e->m_out; }
+        if (e->ifiq) {
+            a.mix = 0; a.z = e->d_y; a.zmask = (uint32_t)e->ring_len - 1; a.n0 = e->m_out;
+            if (e->cfg.if_tune) {                    // channelizer output: rotate by -fq[c] with the exact phase of the channel's own sample count
+                a.mix = 1; a.phase_f64 = 1; a.lut_len = 1 << 30; a.lut_phase = 0; a.nd_base = (double)e->samples_in; a.epoch = e->d_epoch;
+            }
+        }
         else { a.mix = 1; a.z = e->d_zring; a.zmask = e->zmask; a.n0 = e->samples_in; }
         prof_begin(e, "mix_decimate", e->stream);
         sonde_launch_mix_f32(&a, e->stream);
@@ -949,6 +955,14 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
     HIPCHK(hipMemcpy(e->d_state + channel, &st, sizeof st, hipMemcpyHostToDevice));
     if (!e->last_frame.empty()) { memset(e->last_frame.data() + (size_t)channel * 518, 0, 518); memcpy(e->last_frame.data() + (size_t)channel * 518, kRs41HeaderBytes, 8); }
     if (!e->m10_bits.empty()) { const size_t per = e->m10_bits.size() / (size_t)C; memset(e->m10_bits.data() + (size_t)channel * per, 0, per); }
+    return 0;
+}
+
+int sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq) {
+    if (!e || channel < 0 || channel >= e->cfg.n_channels || !e->cfg.if_tune || !(fq >= -0.5 && fq <= 0.5)) return SONDE_E_ARG;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double f0 = -fq;
+    HIPCHK(hipMemcpy(e->d_chanf0 + channel, &f0, sizeof f0, hipMemcpyHostToDevice));
     return 0;
 }
 

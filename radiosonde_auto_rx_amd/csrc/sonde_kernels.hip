@@ -676,7 +676,7 @@ void k_mix_f32(const MixF32Args a) {
         float2 u = make_float2(v.x - avg.x, v.y - avg.y);
         if (a.mix) {
             const uint32_t k = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)i) % L);         // table index (demod_mod.c:746)
-            const double nd = (double)k + a.nd_base;
+            const double nd = (double)k + a.nd_base - (a.epoch ? (double)a.epoch[ch] : 0.0);
             float fr;
             if (a.phase_f64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
             else             fr = __builtin_amdgcn_fractf((float)(f0 * nd));

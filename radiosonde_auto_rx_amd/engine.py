@@ -18,7 +18,7 @@ SONDE_RS41 = 41
 SONDE_DFM09 = 9
 LP_IQ, LP_FM = 1, 2
 TAP_DECIM, TAP_IFIQ, TAP_FM, TAP_BUFS, TAP_CORR = range(5)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SondeCfg(C.Structure):
@@ -26,7 +26,7 @@ class SondeCfg(C.Structure):
                                          "opt_lp", "opt_dc", "opt_min", "lpiq_bw", "ecc_level")] + \
                [("thres", C.c_float), ("max_chunk", C.c_int32), ("max_frames", C.c_int32), ("keep_soft", C.c_int32),
                 ("pipeline", C.c_int32), ("input", C.c_int32), ("audio_channels", C.c_int32), ("audio_select", C.c_int32),
-                ("if_rate", C.c_int32), ("opt_iqdc", C.c_int32), ("opt_inv", C.c_int32), ("opt_nolut", C.c_int32), ("m10_noskip", C.c_int32), ("opt_auto", C.c_int32)]
+                ("if_rate", C.c_int32), ("opt_iqdc", C.c_int32), ("opt_inv", C.c_int32), ("opt_nolut", C.c_int32), ("m10_noskip", C.c_int32), ("opt_auto", C.c_int32), ("if_tune", C.c_int32)]
 
 
 class SondeFrame(C.Structure):
@@ -143,7 +143,7 @@ class Engine:
                  keep_soft: bool = False, opt_min: bool = False, lpiq_bw: int = 0, opt_dc: bool = False,
                  sonde: str = "rs41", pipeline: bool = False, audio: bool = False, audio_channels: int = 1, audio_select: int = 0,
                  if_rate: int = 0, bits: int = 16, iq_mode: int = 5, iqdc: bool = False, inv: bool = False, auto: bool = False, nolut: bool = False,
-                 generic: dict | None = None):
+                 generic: dict | None = None, if_tune: bool = False):
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
         self.n_channels = len(fq)
         self.sample_rate = sample_rate
@@ -154,7 +154,7 @@ class Engine:
         cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "m10": 10, "m20": 20, "frontend": 0, "generic": 99}[sonde],
                        (LP_IQ if lp_iq else 0) | (LP_FM if lp_fm else 0), int(opt_dc), int(opt_min), lpiq_bw, ecc,
                        thres, max_chunk or sample_rate, max_frames, int(keep_soft), int(pipeline),
-                       1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), 0, int(auto))
+                       1 if audio else {5: 0, 1: 2, 2: 3, 3: 4}[iq_mode], audio_channels, audio_select, if_rate, int(iqdc), int(inv), int(nolut), 0, int(auto), int(if_tune))
         h = C.c_void_p()
         if sonde == "generic":      # any other 2-FSK sonde: generic = dict(header=, baud=, bt=, h=, symlen=, symhd=, hdmax=, bitofs=, nbits=, ...) (sonde_generic_t)
             g = SondeGeneric(**{k: (v.encode() if k == "header" else v) for k, v in (generic or {}).items()})
@@ -199,6 +199,11 @@ class Engine:
     def restart_channel(self, ch: int):
         """A new stream starts on the channel with the next samples (IF-rate / FM-audio engines only; include/sonde_hip.h)."""
         _chk(lib().sonde_engine_restart_channel(self._h, ch))
+
+    def tune_channel(self, ch: int, fq: float):
+        """if_tune engines: fine-tuning offset (cycles per IF sample) of one channel"""
+        lib().sonde_engine_tune_channel.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+        _chk(lib().sonde_engine_tune_channel(self._h, ch, float(fq)))
 
     def samples_to_dc_boundary(self) -> int:
         return int(lib().sonde_engine_samples_to_dc_boundary(self._h))

@@ -103,16 +103,136 @@ class WidebandReceiver:
             s["engine"].close(); s["telemetry"].close()
 
 
+class ChannelizedReceiver:
+    """The same job for wide streams (BASELINE configs[2]: 10 Msps and 256 channels) without re-reading the stream once per channel:
+
+        stream -> polyphase channelizer (chan.py: M channels at sr / D, one pass) -> Scanner on all M channels (`dft_detect --iq --dc` each)
+               -> per sonde type ONE demodulator engine whose channels are handed out at run time: a detection takes a free channel
+                  (sonde_engine_restart_channel), is fine-tuned to the offset the scanner measured inside its channelizer channel
+                  (cfg.if_tune / sonde_engine_tune_channel) and is fed that channel's samples from then on -> telemetry JSON.
+
+    Every block costs one channelizer launch, one scanner step and one launch sequence per sonde type, whatever the number of sondes."""
+
+    TYPES = {"RS41": ("rs41", Rs41Telemetry), "DFM": ("dfm", DfmTelemetry), "M10": ("m10", M10Telemetry), "M20": ("m20", M20Telemetry)}
+
+    def __init__(self, sample_rate: int, *, M: int = 256, D: int = 200, P: int = 16, cfreq_hz: int = 0, slots: int = 16, chunk: int | None = None,
+                 version: str = "sonde_hip", device: int = 0):
+        import torch
+        from .chan import Channelizer
+        from .scan import IFIQ
+        self.torch, self.sr, self.cfreq, self.version, self.slots, self.device = torch, sample_rate, cfreq_hz, version, slots, device
+        self.chunk = chunk or sample_rate // 4
+        self.chunk -= self.chunk % D
+        self.ch = Channelizer(sample_rate, M, D, P, max_chunk=self.chunk, device=device)
+        self.M, self.if_sr, self.nmax = M, int(self.ch.out_rate), self.ch.max_frames
+        dev = torch.device("cuda", device)
+        self.out = torch.zeros(M, self.nmax, 2, dtype=torch.float32, device=dev)
+        self.scanner = Scanner(self.if_sr, n_channels=M, iq_mode=IFIQ, dc=True, cont=True, max_chunk=self.nmax, device=device, bits=32)
+        self.groups: dict[str, dict] = {}       # type -> {engine, stage, owner[slot] = sonde dict or None}
+        self.sondes: list[dict] = []
+        self.log: list[dict] = []
+        self._rest = None
+        torch.cuda.synchronize(dev)
+
+    def _group(self, typ: str):
+        g = self.groups.get(typ)
+        if g is None:
+            sonde, _ = self.TYPES[typ]
+            kw = dict(sonde=sonde, bits=32, iq_mode=3, if_tune=True, lp_iq=True, max_chunk=self.nmax, max_frames=8 * self.slots, device=self.device)
+            if typ == "DFM":
+                kw.update(ecc=1, auto=True)
+            eng = Engine([0.0] * self.slots, self.if_sr, **kw)
+            stage = self.torch.zeros(self.slots, self.nmax, 2, dtype=self.torch.float32, device=self.out.device)
+            self.torch.cuda.synchronize(self.out.device)
+            g = self.groups[typ] = dict(engine=eng, stage=stage, owner=[None] * self.slots, calls=0)
+        return g
+
+    def _start(self, k: int, typ: str, df: float):
+        f_hz = self.ch.channel_freq(k) + df * self.if_sr
+        for s in self.sondes:                                    # the neighbouring channel sees a strong signal too
+            if s["type"] == typ and abs(s["f_hz"] - f_hz) < (20_000.0 if typ in ("M10", "M20") else 8_000.0):
+                return
+        g = self._group(typ)
+        if None not in g["owner"]:
+            self.log.append(dict(event="no free channel", type=typ, f_hz=f_hz))
+            return
+        slot = g["owner"].index(None)
+        if g["calls"]:
+            g["engine"].restart_channel(slot)
+        g["engine"].tune_channel(slot, df)
+        khz = int(round((self.cfreq + f_hz) / 1000.0)) if self.cfreq else 0
+        s = dict(type=typ, f_hz=f_hz, chan=k, slot=slot, telemetry=self.TYPES[typ][1](freq_khz=khz, version=self.version), frames=0, khz=khz)
+        g["owner"][slot] = s
+        self.sondes.append(s)
+        self.log.append(dict(event="detected", type=typ, f_hz=f_hz, channel=k, slot=slot, freq_khz=khz))
+
+    def push(self, iq: np.ndarray, finish: bool = False):
+        """iq: interleaved int16 I/Q of the wide stream; returns the JSON objects of this call."""
+        torch = self.torch
+        out = []
+        if self._rest is not None and len(self._rest):
+            iq = np.concatenate([self._rest, np.asarray(iq, np.int16)])
+        n = len(iq) // 2
+        D = self.sr // self.if_sr
+        self._rest = np.array(iq[2 * (n - n % D):2 * n], np.int16)
+        for s0 in range(0, n - n % D, self.chunk):
+            x = np.ascontiguousarray(iq[2 * s0:2 * min(n - n % D, s0 + self.chunk)])
+            m = self.ch.process_host(x, self.out.data_ptr(), self.nmax)           # m IF samples per channel
+            self.ch.sync()
+            self.scanner.process_device(self.out.data_ptr(), self.nmax, m)
+            for d in self.scanner.fetch():
+                if d["type"] == "RS41" and d["score"] > 0:
+                    self._start(d["channel"], "RS41", d["df"])
+                elif d["type"] == "DFM9":
+                    self._start(d["channel"], "DFM", d["df"])
+                elif d["type"] in ("M10", "M20"):
+                    self._start(d["channel"], d["type"], d["df"])
+            for typ, g in self.groups.items():
+                for slot, s in enumerate(g["owner"]):
+                    if s is not None:
+                        g["stage"][slot, :m] = self.out[s["chan"], :m]
+                torch.cuda.synchronize(self.out.device)                           # the copies ran on torch's stream, the engine has its own
+                g["engine"].process_device(g["stage"].data_ptr(), self.nmax, m)
+                g["calls"] += 1
+                out += self._drain(typ, g, False)
+        if finish:
+            for typ, g in self.groups.items():
+                out += self._drain(typ, g, True)
+        return out
+
+    def _drain(self, typ, g, finish):
+        e = g["engine"]
+        frames = e.fetch_dfm(finish=finish) if typ == "DFM" else e.fetch_mxx(finish=finish) if typ in ("M10", "M20") else e.fetch_frames(finish=finish)
+        out = []
+        for fr in frames:
+            s = g["owner"][fr["channel"]]
+            if s is None:
+                continue
+            js = s["telemetry"].json(fr)
+            s["frames"] += 1
+            if js is not None:
+                out.append(js)
+        return out
+
+    def close(self):
+        self.scanner.close(); self.ch.close()
+        for g in self.groups.values():
+            g["engine"].close()
+        for s in self.sondes:
+            s["telemetry"].close()
+
+
 def main(argv=None):
     import argparse
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--cfreq", type=int, default=0, help="centre frequency of the stream in Hz (for the JSON freq field)")
     ap.add_argument("--raster", type=int, default=10_000, help="scanner raster in Hz")
+    ap.add_argument("--channelize", action="store_true", help="polyphase channelizer front end (256 channels at sr / 200): for streams of several Msps")
     ap.add_argument("dash"); ap.add_argument("sr", type=int); ap.add_argument("bits", type=int)
     a = ap.parse_args(argv)
     if a.dash != "-" or a.bits != 16:
         ap.error("input is `- <sr> 16` (cs16 on stdin)")
-    rx = WidebandReceiver(a.sr, cfreq_hz=a.cfreq, raster_hz=a.raster)
+    rx = ChannelizedReceiver(a.sr, cfreq_hz=a.cfreq) if a.channelize else WidebandReceiver(a.sr, cfreq_hz=a.cfreq, raster_hz=a.raster)
     inp = sys.stdin.buffer
     while True:
         buf = inp.read(rx.chunk * 4)
