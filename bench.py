@@ -156,7 +156,7 @@ def bench_demod(args, D: Dist):
     from radiosonde_auto_rx_amd.engine import Engine
     from radiosonde_auto_rx_amd import shard
     C = args.channels or int(os.environ.get("SONDE_BENCH_CHANNELS", "512"))
-    steps = args.steps or 1200                                              # ~2 s of GPU time: long enough for the driver's busy sampler
+    steps = args.steps or 1500                                              # ~2 s of GPU time: long enough for the driver's busy sampler
     warmup = 3 if args.warmup is None else args.warmup
     fqs, caps = make_bank()
     ch_fq = [fqs[(c + D.rank) % BANK] for c in range(C)]

@@ -105,10 +105,12 @@ struct WinPlanArgs {
     const SyncState *state; WinItem *items;
     int n_ch, stride, W, K, L, delay; uint32_t frame_samples, avail;    // table of `stride` slots per channel, this round fills the first W
     const uint32_t *epoch;    // per-channel stream start (sonde_engine_restart_channel), nullptr = 0 everywhere
+    uint32_t *work, *work_count; int round_parity;     // compact list of planned items (ch * stride + slot) for k_sync_window_fft; counters [2], alternating per round
 };
 struct WinFftArgs {
     const float *bufs; WinItem *items; const float2 *Fm, *tws;
     int n_ch, stride, W, K, L, ring_len;
+    const uint32_t *work, *work_count; int round_parity;
 };
 
 struct CorrArgs {

@@ -57,6 +57,7 @@ struct sonde_engine {
     uint32_t corr_limit = 0;                       // pass 1 of the two correlation / sync passes of a call
     // header search with the reference's transform (k_sync_plan / k_sync_window_fft): per channel win_W planned windows
     WinItem *d_win = nullptr; float2 *d_Fm = nullptr, *d_tws = nullptr; int win_W = 0;
+    uint32_t *d_work = nullptr, *d_work_count = nullptr; int sync_rounds = 0;      // compact window list of the round, counters [2]
     sonde_summary_t *d_summary = nullptr; uint32_t summary_base = 0;      // caller-owned device buffer (sonde_engine_set_summary)
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr, *d_soft1 = nullptr;
@@ -347,7 +348,8 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
             ref_dft_8192(m);
             const std::vector<float> tw = ref_twiddle_table();
             e->win_W = 8;
-            if (dalloc(&e->d_Fm, (size_t)M, false) || dalloc(&e->d_tws, tw.size() / 2, false) || dalloc(&e->d_win, (size_t)C * e->win_W)) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+            if (dalloc(&e->d_Fm, (size_t)M, false) || dalloc(&e->d_tws, tw.size() / 2, false) || dalloc(&e->d_win, (size_t)C * e->win_W) ||
+                dalloc(&e->d_work, (size_t)C * e->win_W) || dalloc(&e->d_work_count, 2)) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
             HIPCHK(hipMemcpy(e->d_Fm, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_tws, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
         }
@@ -473,7 +475,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
-                     e->d_epoch, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
+                     e->d_epoch, e->d_work, e->d_work_count, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
                      e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -677,8 +679,11 @@ static void sync_round(sonde_engine *e, int W) {
     hipStream_t sb = e->stream_b;
     WinPlanArgs p{}; p.state = e->d_state; p.items = e->d_win; p.n_ch = C; p.stride = e->win_W; p.W = W; p.K = e->info.K; p.L = e->info.L;
     p.delay = e->info.delay; p.frame_samples = e->frame_samples; p.avail = e->m_out; p.epoch = e->d_epoch;
+    p.work = e->d_work; p.work_count = e->d_work_count; p.round_parity = e->sync_rounds & 1;
     WinFftArgs f{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
     f.K = e->info.K; f.L = e->info.L; f.ring_len = e->ring_len;
+    f.work = e->d_work; f.work_count = e->d_work_count; f.round_parity = e->sync_rounds & 1;
+    e->sync_rounds++;
     prof_begin(e, "header_corr", sb);
     sonde_launch_sync_plan(&p, sb);
     sonde_launch_sync_window_fft(&f, sb);

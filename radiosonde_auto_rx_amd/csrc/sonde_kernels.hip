@@ -1492,29 +1492,25 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
         if (pos - ep >= (uint32_t)a.L) { it[n].pos = pos; it[n].state = 1; it[n].rc = -1; it[n].mv = 0.f; it[n].mpos = 0; n++; }     // else getCorrDFT returns -2: nothing to evaluate
         s_in = s_in_w; k = 0;
     }
+    if (a.work && n > 0) {                                      // compact list of the windows to evaluate this round (no empty workgroups)
+        const uint32_t at = atomicAdd(a.work_count + a.round_parity, (uint32_t)n);
+        for (int i = 0; i < n; i++) a.work[at + (uint32_t)i] = (uint32_t)(ch * a.stride + i);
+    }
+    if (a.work && ch == 0) a.work_count[a.round_parity ^ 1] = 0;            // the other round's counter: its consumer ran before this kernel
     for (; n < a.stride; n++) { it[n].pos = 0xffffffffu; it[n].state = 0; }
 }
 
 // The reference is plain C on x86-64: separately rounded multiplies and adds (no fused multiply-add) in the butterflies and products.
 #pragma clang fp contract(off)
 #include "sonde_fft_dev.h"
-// one workgroup = one planned window (getCorrDFT without --dc, demod_mod.c:148-225)
-__global__ __launch_bounds__(SC_THREADS)
-void k_sync_window_fft(const WinFftArgs a) {
-    extern __shared__ float2 smem2[];
-    float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
-    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_N/2] twiddles of stages 0..11
-    float *xnl = reinterpret_cast<float *>(tws + SC_N / 2);   // [SC_N] the window in natural order (norm)
-    __shared__ float s_rf[SC_THREADS / WAVE];
-    __shared__ int s_ri[SC_THREADS / WAVE];
-    const int ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    WinItem *it = a.items + (size_t)ch * a.stride + blockIdx.x;
+// one planned window (getCorrDFT without --dc, demod_mod.c:148-225), evaluated by one workgroup
+__device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int ch, WinItem *it, float2 *x, float2 *tws, float *xnl, float *s_rf, int *s_ri) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (it->state != 1) return;
     const int K = a.K, L = a.L, N = SC_N, wl = K + L;
     const uint32_t pos = it->pos, mask = (uint32_t)a.ring_len - 1;
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
     const int64_t start = (int64_t)pos - (wl - 1);
-    for (int k = tid; k < N / 2 - 1; k += SC_THREADS) tws[k] = a.tws[k];
     // xn[i] = bufs[pos - (K+L-1) + i], i < K+L, zero padded (:168-169); bit-reversed for the DIT network, natural order for the norm
     for (int i = tid; i < N; i += SC_THREADS) {
         const int64_t p = start + i;
@@ -1570,6 +1566,26 @@ void k_sync_window_fft(const WinFftArgs a) {
         const float xnorm = sqrtf(es);
         it->rc = mp; it->mv = x[XI(mp)].x / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
         __threadfence(); it->state = 2;
+    }
+}
+
+// Workgroups walk the compact list k_sync_plan wrote (a.work): the grid does not depend on how many windows a round planned, and a round in
+// which almost every channel is inside a frame costs a handful of workgroups instead of stride x channels empty ones.
+__global__ __launch_bounds__(SC_THREADS)
+void k_sync_window_fft(const WinFftArgs a) {
+    extern __shared__ float2 smem2[];
+    float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
+    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_N/2] twiddles of stages 0..11
+    float *xnl = reinterpret_cast<float *>(tws + SC_N / 2);   // [SC_N] the window in natural order (norm)
+    __shared__ float s_rf[SC_THREADS / WAVE];
+    __shared__ int s_ri[SC_THREADS / WAVE];
+    const uint32_t count = a.work_count[a.round_parity];
+    if (blockIdx.x >= count) return;
+    for (int k = threadIdx.x; k < SC_N / 2 - 1; k += SC_THREADS) tws[k] = a.tws[k];
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint32_t item = a.work[w];
+        __syncthreads();                         // the previous window's last reads of x / xnl / s_rf are over
+        sync_eval_window(a, (int)(item / (uint32_t)a.stride), a.items + item, x, tws, xnl, s_rf, s_ri);
     }
 }
 #pragma clang fp contract(fast)
@@ -1698,7 +1714,8 @@ extern "C" void sonde_launch_sync_plan(const WinPlanArgs *a, hipStream_t s) {
 }
 extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s) {
     const size_t lds = (size_t)(2 * SC_N + SC_N / 8) * sizeof(float2);
-    hipLaunchKernelGGL(k_sync_window_fft, dim3(a->W, a->n_ch), dim3(SC_THREADS), lds, s, *a);
+    int grid = a->W * a->n_ch; if (grid > 512) grid = 512;      // two waves of workgroups on 256 CUs at most; the kernel strides over the list
+    hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(SC_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
     if (a->opt_dc) hipLaunchKernelGGL(k_framesync<true>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
