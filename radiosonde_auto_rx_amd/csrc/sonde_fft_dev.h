@@ -47,12 +47,15 @@ __device__ __forceinline__ void dit_pass(float2 *x, const float2 *tws, const int
     __syncthreads();
 }
 
-// input already bit-reversed; stages 0..11 take their twiddles from LDS, the last one from the global table
+// input already bit-reversed; stages 0..8 take their twiddles from an LDS copy (SC_TW_LDS = 2^9 - 1 entries), the last four from the global table
+// (L2-resident, 32 KB, shared by every workgroup): the data array and 4 KB of twiddles are all the LDS a transform needs, so two workgroups of
+// 1024 threads fit on a CU
+#define SC_TW_LDS 511
 __device__ __forceinline__ void dft_ref(float2 *x, const float2 *tws, const float2 *tws_g, const int tid) {
     dit_pass<3>(x, tws, 0, tid);
     dit_pass<3>(x, tws, 3, tid);
     dit_pass<3>(x, tws, 6, tid);
-    dit_pass<3>(x, tws, 9, tid);
+    dit_pass<3>(x, tws_g, 9, tid);
     dit_pass<1>(x, tws_g, 12, tid);
 }
 

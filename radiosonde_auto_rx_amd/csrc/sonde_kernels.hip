@@ -1504,7 +1504,7 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
 #pragma clang fp contract(off)
 #include "sonde_fft_dev.h"
 // one planned window (getCorrDFT without --dc, demod_mod.c:148-225), evaluated by one workgroup
-__device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int ch, WinItem *it, float2 *x, float2 *tws, float *xnl, float *s_rf, int *s_ri) {
+__device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int ch, WinItem *it, float2 *x, float2 *tws, float *s_rf, int *s_ri) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (it->state != 1) return;
     const int K = a.K, L = a.L, N = SC_N, wl = K + L;
@@ -1516,7 +1516,6 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
         const int64_t p = start + i;
         const float v = (i < wl && p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
         x[XI(brev13(i))] = make_float2(v, 0.f);
-        xnl[i] = v;
     }
     __syncthreads();
     dft_ref(x, tws, a.tws, tid);                                         // X = rdft(xn)
@@ -1556,7 +1555,11 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
     }
     // xnorm = sqrt(sum_{i<L} xn[mp-i]^2) (:215-217); mx /= xnorm * N
     float e = 0.f;
-    for (int k = tid; k < L; k += SC_THREADS) { const float v = xnl[mp - k]; e += v * v; }
+    for (int k = tid; k < L; k += SC_THREADS) {                          // xn[mp - k], read again from the ring (it is not kept in LDS)
+        const int i = mp - k; const int64_t p2 = start + i;
+        const float v = (i < wl && p2 >= 0) ? bufs[(uint32_t)p2 & mask] : 0.f;
+        e += v * v;
+    }
     for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
     if (lane == 0) s_rf[wave] = e;
     __syncthreads();
@@ -1571,21 +1574,22 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
 
 // Workgroups walk the compact list k_sync_plan wrote (a.work): the grid does not depend on how many windows a round planned, and a round in
 // which almost every channel is inside a frame costs a handful of workgroups instead of stride x channels empty ones.
+// (the scanner's k_scan_corr runs two such workgroups per CU at 64 VGPRs; here the ~1000 windows of a round gain nothing from that and the
+// spills cost 10 %, measured: one workgroup per CU with the registers the compiler wants)
 __global__ __launch_bounds__(SC_THREADS)
 void k_sync_window_fft(const WinFftArgs a) {
     extern __shared__ float2 smem2[];
     float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
-    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_N/2] twiddles of stages 0..11
-    float *xnl = reinterpret_cast<float *>(tws + SC_N / 2);   // [SC_N] the window in natural order (norm)
+    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_TW_LDS + 1] twiddles of stages 0..8
     __shared__ float s_rf[SC_THREADS / WAVE];
     __shared__ int s_ri[SC_THREADS / WAVE];
     const uint32_t count = a.work_count[a.round_parity];
     if (blockIdx.x >= count) return;
-    for (int k = threadIdx.x; k < SC_N / 2 - 1; k += SC_THREADS) tws[k] = a.tws[k];
+    for (int k = threadIdx.x; k < SC_TW_LDS; k += SC_THREADS) tws[k] = a.tws[k];
     for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
         const uint32_t item = a.work[w];
-        __syncthreads();                         // the previous window's last reads of x / xnl / s_rf are over
-        sync_eval_window(a, (int)(item / (uint32_t)a.stride), a.items + item, x, tws, xnl, s_rf, s_ri);
+        __syncthreads();                         // the previous window's last reads of x / s_rf are over
+        sync_eval_window(a, (int)(item / (uint32_t)a.stride), a.items + item, x, tws, s_rf, s_ri);
     }
 }
 #pragma clang fp contract(fast)
@@ -1713,7 +1717,7 @@ extern "C" void sonde_launch_sync_plan(const WinPlanArgs *a, hipStream_t s) {
     hipLaunchKernelGGL(k_sync_plan, dim3((a->n_ch + 255) / 256), dim3(256), 0, s, *a);
 }
 extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s) {
-    const size_t lds = (size_t)(2 * SC_N + SC_N / 8) * sizeof(float2);
+    const size_t lds = (size_t)(SC_N + SC_N / 8 + SC_TW_LDS + 1) * sizeof(float2);
     int grid = a->W * a->n_ch; if (grid > 512) grid = 512;      // two waves of workgroups on 256 CUs at most; the kernel strides over the list
     hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(SC_THREADS), lds, s, *a);
 }

@@ -123,12 +123,11 @@ __device__ __forceinline__ float wsumf(float v) { for (int off = 32; off > 0; of
 __device__ __forceinline__ double wsumd(double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
 // one workgroup = one correlation window x one template (getCorrDFT, dft_detect.c:357-443)
-__global__ __launch_bounds__(SC_THREADS)
+__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two workgroups per CU: 78 KB of LDS, 64 VGPRs
 void k_scan_corr(const ScanCorrArgs a) {
     extern __shared__ float2 smem2[];
     float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
-    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_N/2] twiddles of stages 0..11
-    float *xnl = reinterpret_cast<float *>(tws + SC_N / 2);   // [SC_N] filtered window (norm)
+    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_TW_LDS + 1] twiddles of stages 0..8
     __shared__ float s_rf[SC_THREADS / WAVE];
     __shared__ int s_ri[SC_THREADS / WAVE];
     __shared__ double s_rd[SC_THREADS / WAVE];
@@ -145,7 +144,7 @@ void k_scan_corr(const ScanCorrArgs a) {
     const float *str = a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len;
     const int L = tp.L, wl = K + L;
     const int64_t start = (int64_t)it.pos - (wl - 1);
-    for (int k = tid; k < N / 2 - 1; k += SC_THREADS) tws[k] = a.tws[k];
+    for (int k = tid; k < SC_TW_LDS; k += SC_THREADS) tws[k] = a.tws[k];
     float dc = 0.f;
     // xn[i] = stream[pos - (K+L-1) + i], i < K+L, zero padded (dft_detect.c:378-379); stored bit-reversed for the DIT network
     auto load_window = [&](bool want_dc) {
@@ -180,18 +179,11 @@ void k_scan_corr(const ScanCorrArgs a) {
         }
         __syncthreads();
     };
-    // xn <- filtered window: real part of Nidft(X * WS[lpFM]) / N (dft_detect.c:394-402); it only feeds the norm
+    // The reference filters the window first (X * WS[lpFM] -> Nidft -> xn, dft_detect.c:394-402: it only feeds the norm) and correlates then.  The
+    // two computations are independent, so the correlation runs first here and the filtered window is left in `x` when the norm is taken: no
+    // second copy of the window in LDS, which is what lets two workgroups share a CU.
     const bool filt = a.opt_dc || a.opt_iq;
-    if (filt) {
-        load_window(a.opt_dc != 0);
-        dft_ref(x, tws, a.tws, tid);
-        spectrum_step(a.opt_iq ? a.WS + (size_t)tp.lpfm * N : nullptr);
-        dft_ref(x, tws, a.tws, tid);
-        for (int i = tid; i < N; i += SC_THREADS) xnl[i] = x[XI(i)].x / (float)N;
-        __syncthreads();
-    }
-    load_window(false);
-    if (!filt) { for (int i = tid; i < N; i += SC_THREADS) xnl[brev13(i)] = x[XI(i)].x; __syncthreads(); }     // raw window, natural order
+    load_window(a.opt_dc != 0);
     dft_ref(x, tws, a.tws, tid);                                         // X = dft(xn)
     spectrum_step(a.G + (size_t)j * N);                                  // G = WS * Fm (Fm alone for FM-audio input)
     dft_ref(x, tws, a.tws, tid);                                         // cx = Nidft(Z), real part used
@@ -216,9 +208,22 @@ void k_scan_corr(const ScanCorrArgs a) {
         }
     }
     const float mx = (mp >= 0) ? x[XI(mp)].x : 0.f;
-    // norm over the L filtered window samples under the peak (dft_detect.c:431-433)
+    __syncthreads();                                                     // everybody has mx before x is reused
+    // norm over the L (filtered) window samples under the peak (dft_detect.c:431-433)
     double e2 = 0.0;
-    if (mp >= 0) for (int k = tid; k < L; k += SC_THREADS) { const float v = xnl[mp - k]; e2 += (double)(v * v); }
+    if (filt) {
+        load_window(false);
+        dft_ref(x, tws, a.tws, tid);
+        spectrum_step(a.opt_iq ? a.WS + (size_t)tp.lpfm * N : nullptr);
+        dft_ref(x, tws, a.tws, tid);                                     // x[i].x / N = filtered xn[i]
+        if (mp >= 0) for (int k = tid; k < L; k += SC_THREADS) { const float v = x[XI(mp - k)].x / (float)N; e2 += (double)(v * v); }
+    } else if (mp >= 0) {
+        for (int k = tid; k < L; k += SC_THREADS) {                      // raw window, read again from the stream
+            const int i = mp - k; const int64_t p = start + i;
+            const float v = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
+            e2 += (double)(v * v);
+        }
+    }
     { const double sw = wsumd(e2); if (lane == 0) s_rd[wave] = sw; }
     __syncthreads();
 
@@ -284,7 +289,7 @@ extern "C" void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s) {
 }
 extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(2 * SC_N + SC_N / 8) * sizeof(float2);
+    const size_t lds = (size_t)(SC_N + SC_N / 8 + SC_TW_LDS + 1) * sizeof(float2);
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_corr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set = true;
