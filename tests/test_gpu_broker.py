@@ -92,6 +92,14 @@ def test_broker_without_gpu_reports_the_error_to_the_client(tmp_path):
         r = subprocess.run([os.path.join(BIN, "fsk_demod"), "--cs16", "-s", "2", "48000", "4800", "-", "-"], input=b"\0" * 8000,
                            env=dict(os.environ, SONDE_BROKER=sock), capture_output=True, timeout=60)
         assert r.returncode == 1 and b"Couldn't open files" in r.stderr and r.stdout == b""
+        # a decoder shim on IF-rate IQ: the same protocol, the decoder's own error line and exit code (255 like the reference's `return -1`)
+        r = subprocess.run([os.path.join(BIN, "rs41mod"), "-r", "--iq2", "--lpIQ", "-", "48000", "16"], input=b"\0" * 8000,
+                           env=dict(os.environ, SONDE_BROKER=sock), capture_output=True, timeout=60)
+        assert r.returncode == 255 and b"error: init buffers" in r.stderr and r.stdout == b""
+        # the base-rate form is not served by the broker: the shim opens the GPU itself (and fails the same way without one)
+        r = subprocess.run([os.path.join(BIN, "rs41mod"), "-r", "--IQ", "0.1", "-", "2400000", "16"], input=b"\0" * 8000,
+                           env=dict(os.environ, SONDE_BROKER=sock), capture_output=True, timeout=60)
+        assert r.returncode == 255 and b"error: init buffers" in r.stderr
     finally:
         broker.send_signal(signal.SIGTERM)
         _, berr = broker.communicate(timeout=30)
