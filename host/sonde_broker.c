@@ -354,6 +354,10 @@ static void read_client(int ci) {
     const ssize_t k = recv(c->fd, c->rx + c->rx_len, c->rx_cap - c->rx_len, MSG_DONTWAIT);
     if (k == 0 || (k < 0 && errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) { drop_client(ci); return; }
     if (k > 0) c->rx_len += (size_t)k;
+    if (c->rx_len >= sizeof(brk_hdr_t)) {                    /* a header that cannot be ours, or a message no client sends: do not buffer it */
+        brk_hdr_t h; memcpy(&h, c->rx, sizeof h);
+        if (h.magic != BRK_MAGIC || h.length > (48u << 20)) { drop_client(ci); return; }
+    }
     parse_client(ci);
 }
 
