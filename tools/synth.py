@@ -842,3 +842,145 @@ def lms6_capture(sr: int = 48_000, seconds: float = 4.0, fq: float = 0.0, *, amp
     out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
     out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- Meisei iMS-100 / RS-11G
+def _bch46(msg34) -> list:
+    """46 transmitted bits of one block: 34 message bits + 12 check bits of the BCH(63,51) code shortened to (46,34), generator
+    x^12+x^10+x^8+x^5+x^4+x^3+1 (meisei100mod.c:96-98); transmitted bit j is the coefficient of x^(45-j) (:738)."""
+    g = 0b1010100111001                                  # x^12 .. x^0
+    r = 0
+    for b in msg34:                                      # long division of m(x) x^12, highest power first
+        r = (r << 1) | int(b)
+        if r & (1 << 12):
+            r ^= g
+    for _ in range(12):
+        r <<= 1
+        if r & (1 << 12):
+            r ^= g
+    return [int(b) for b in msg34] + [(r >> (11 - k)) & 1 for k in range(12)]
+
+
+def _meisei_subframe(hdr24: int, words12) -> list:
+    """24 header bits + 6 blocks of (16 bits, parity, 16 bits, parity, 12 check bits); parity = 1 when the 16 bits hold an even number of ones"""
+    bits = [(hdr24 >> (23 - k)) & 1 for k in range(24)]
+    for blk in range(6):
+        m = []
+        for w in (words12[2 * blk], words12[2 * blk + 1]):
+            wb = [(int(w) >> (15 - k)) & 1 for k in range(16)]
+            m += wb + [1 ^ (sum(wb) & 1)]
+        bits += _bch46(m)
+    return bits
+
+
+def _f32_words(x: float):
+    w = int(np.frombuffer(np.float32(x).tobytes(), np.uint32)[0])
+    return w & 0xFFFF, w >> 16
+
+
+def meisei_config(variant: str = "ims100", sn: float = 4123456.0) -> list:
+    """the 64 configuration floats a sonde cycles through: serial number at 0 / 16 / 32 / 48, transmit frequency at 15, temperature table at
+    17.., resistance table, humidity polynomial 49..52 and the resistance polynomial (meisei100mod.c:841-848 RS-11G, :1092-1102 iMS-100)"""
+    c = [0.0] * 64
+    for k in (0, 16, 32, 48):
+        c[k] = sn
+    c[15] = 42.5 if variant == "ims100" else 13.0         # 400e3 + 100 c kHz / 403700 + 100 c kHz
+    if variant == "ims100":
+        for j in range(12):
+            c[17 + j] = 40.0 - 10.0 * j
+            c[33 + j] = 5.0 * 1.6 ** j
+        c[53:57] = [0.5, 30.0, 2.0, 0.1]
+    else:
+        for j in range(11):
+            c[17 + j] = 40.0 - 10.0 * j
+            c[37 + j] = 5.0 * 1.6 ** j
+        c[33:37] = [0.5, 30.0, 2.0, 0.1]
+    c[49:53] = [-5.0, 40.0, 3.0, -0.2]
+    return c
+
+
+def meisei_frame_bits(counter: int, variant: str = "ims100", cfg=None) -> list:
+    """600 bits of one half-second frame (two subframes, headers 0x049DCE / 0xFB6230) in the layout meisei100mod.c:24-86 documents and decodes"""
+    cfg = cfg or meisei_config(variant)
+    k = counter
+    c = cfg[k % 64]
+    ms = (1000 * (k // 2)) % 60000
+    hh, mi = 12, (k // 120) % 60
+    if variant == "ims100":
+        lo, hi = _f32_words(c)
+        w = [0] * 12
+        w[0] = k & 0xFFFF
+        w[1] = 32768                                     # reference frequency (read at counter % 4 == 0)
+        w[2], w[3] = lo, hi
+        w[5] = 9500 + 7 * (k % 50)                        # thermistor count
+        w[6] = 32768 if k % 4 == 3 else 8000 + 11 * (k % 40)      # reference again / humidity count
+        w[7] = 0x30C1 + ((k & 1) << 8)
+        w[10] = ms if k % 2 == 0 else (0x400 + k) & 0xFFFF
+        w[11] = (hh << 8) | mi
+        v = [0] * 12
+        if k % 2 == 0:
+            v[0] = 15 * 1000 + 6 * 10 + 4                  # day 15, month 6, year digit 4
+            lat = 3512_3456 + 3 * k; lon = 13945_6789 - 2 * k; alt = 1234567 + 250 * k      # NMEA ddmm.mmmm * 1e4, cm
+            v[1], v[2] = lat >> 16, lat & 0xFFFF
+            v[3], v[4] = lon >> 16, lon & 0xFFFF
+            v[5], v[6] = (alt >> 8) & 0xFFFF, (alt & 0xFF) << 8
+            v[9] = 23456                                  # course 234.56
+            v[10] = 1944                                  # 10 m/s in 1/194.384 knots
+        else:
+            v[1] = 97                                     # 5 m/s
+            v[2] = 0x1200
+        v[11] = (w[10] + w[11] + sum(v[:11])) & 0xFFFF
+    else:
+        w32 = int(np.frombuffer(np.float32(c * 4.0).tobytes(), np.uint32)[0])
+        e2 = ((w32 >> 31) << 23) | (((w32 >> 23) & 0xFF) << 24) | (w32 & 0x7FFFFF)         # inverse of f32e2 (:163-191)
+        lo, hi = e2 & 0xFFFF, e2 >> 16
+        sw = lambda x: ((x & 0xFF) << 8) | (x >> 8)
+        w = [0] * 12
+        w[0] = k & 0xFFFF
+        w[1] = 32768
+        w[2], w[3] = sw(lo), sw(hi)
+        w[5] = 9500 + 7 * (k % 50)
+        w[6] = 8000 + 11 * (k % 40)
+        w[7] = 0x30A2 + ((k & 1) << 8)
+        if k % 2 == 1:
+            w[10] = sw(ms)
+            w[11] = (hh << 8) | mi
+        v = [0] * 12
+        if k % 2 == 0:
+            lat = int(35.123456 * 1e7) + 30 * k; lon = int(139.456789 * 1e7) - 20 * k; alt = 1234567 + 250 * k
+            v[1], v[2] = lat >> 16, lat & 0xFFFF
+            v[3], v[4] = lon >> 16, lon & 0xFFFF
+            v[5], v[6] = alt >> 16, alt & 0xFFFF
+            v[7], v[8], v[9] = 1000, 23456, 500
+            v[10] = 2024 - 0x0700                          # year = low byte + 0x700
+            v[11] = (6 << 8) | 15
+    return _meisei_subframe(0x049DCE, w) + _meisei_subframe(0xFB6230, v)
+
+
+def meisei_symbols(n_frames: int, variant: str = "ims100", k0: int = 0, cfg=None) -> np.ndarray:
+    """half symbols (0 / 1, 2400 Bd) of n_frames back-to-back frames in biphase-S: a transition at every bit boundary, one more in the middle of a 0"""
+    out, level = [], 0
+    for k in range(k0, k0 + n_frames):
+        for b in meisei_frame_bits(k, variant, cfg):
+            level ^= 1
+            out.append(level)
+            if not b:
+                level ^= 1
+            out.append(level)
+    return np.array(out, dtype=np.uint8)
+
+
+def meisei_capture(sr: int = 48_000, seconds: float = 6.0, fq: float = 0.0, *, variant: str = "ims100", amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1,
+                   k0: int = 0) -> np.ndarray:
+    """Meisei GFSK capture (2400 Bd half symbols, h = 2.4, BT 1.2 as the decoder assumes, meisei100mod.c:640-641), continuous frames from t = 0"""
+    sym = meisei_symbols(int(seconds * 2) + 2, variant, k0)
+    n = int(seconds * sr)
+    z = gfsk_baseband(sym, sr, 2400.0, dev_hz=2.4 * 2400.0 / 2, bt=1.2)[:n]
+    if len(z) < n:
+        z = np.concatenate([z, np.zeros(n - len(z), z.dtype)])
+    rng = np.random.default_rng(seed)
+    z = amp * z * np.exp(2j * np.pi * fq * np.arange(n)) + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, np.int16)
+    out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
+    out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
+    return out
