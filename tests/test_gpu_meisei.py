@@ -42,7 +42,8 @@ def test_native_meisei_on_samples(tmp_path):
     out = _both(["--ecc", "--json", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], z.tobytes())
     assert out.count(b"(ok)[OK]") >= 4
     # FM audio from a file: starts as iMS-100 (a file name without -r / --rs11g), RS-11G signal -> switches by itself
-    c = y.astype(np.float64)[0::2] + 1j * y.astype(np.float64)[1::2]
+    q = synth.meisei_capture(sr=48_000, seconds=6.0, noise_sigma=0.01, seed=44, variant="rs11g").astype(np.float64)
+    c = q[0::2] + 1j * q[1::2]
     fm = np.angle(c[1:] * np.conj(c[:-1])) / np.pi
     pcm = np.clip(np.round(fm * 40000), -32768, 32767).astype(np.int16)
     p = tmp_path / "meisei.wav"
