@@ -984,3 +984,44 @@ def meisei_capture(sr: int = 48_000, seconds: float = 6.0, fq: float = 0.0, *, v
     out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
     out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- Meteosis MTS01
+def mts01_frame_bits(k: int = 0, *, sn: str = "A2031234", lat=39.912345, lon=32.854321, alt=1234.0) -> np.ndarray:
+    """1048 bits behind the header: 0x80, 128 bytes of comma-separated ASCII telemetry (zero padded; field order as mts01mod.c:180-230 reads
+    it), CRC-16 poly 0x8005 init 0xFFFF bit-reversed, low byte first (:76-99,:159-161); bytes MSB first (:112)"""
+    sec = k % 60
+    txt = f"{sn},0,{k + 1},2406151200{sec:02d},{7412 - k},{lat + 1e-5 * k:.6f},{lon - 1e-5 * k:.6f},{alt + 5 * k:.1f},{123.4 + k:.1f},{12.3:.1f},0,{20.0 + 0.5 * k:.2f},{20.0 + 0.5 * k:.2f},{40 + k},0,0"
+    dat = txt.encode("ascii")[:128].ljust(128, b"\0")
+    rem = 0xFFFF
+    for b in dat:
+        rem ^= b << 8
+        for _ in range(8):
+            rem = ((rem << 1) ^ 0x8005) & 0xFFFF if rem & 0x8000 else (rem << 1) & 0xFFFF
+    re = int(f"{rem:016b}"[::-1], 2)
+    fr = bytes([0x80]) + dat + bytes([re & 0xFF, re >> 8])
+    return np.unpackbits(np.frombuffer(fr, np.uint8))
+
+
+def mts01_onair_bits(n_frames: int, gap_bits: int = 152) -> np.ndarray:
+    """n_frames frames, one per second at 1200 Bd: preamble AA AA, sync B4 2B, the frame, idle 0101.. up to the next"""
+    hdr = np.array([int(c) for c in FAMILY["mts01mod"]["header"]], np.uint8)
+    idle = np.tile(np.array([1, 0], np.uint8), gap_bits // 2 - 16)
+    return np.concatenate([np.concatenate([idle, hdr, mts01_frame_bits(k)]) for k in range(n_frames)])
+
+
+def mts01_capture(sr: int = 48_000, seconds: float = 6.0, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1, invert: bool = False) -> np.ndarray:
+    """MTS01 GFSK capture (1200 Bd, h = 0.9, BT 1.5 as the decoder assumes, mts01mod.c:526-527)"""
+    bits = mts01_onair_bits(int(seconds) + 2)
+    if invert:
+        bits = 1 - bits
+    n = int(seconds * sr)
+    z = gfsk_baseband(bits, sr, 1200.0, dev_hz=0.9 * 1200.0 / 2, bt=1.5)[:n]
+    if len(z) < n:
+        z = np.concatenate([z, np.zeros(n - len(z), z.dtype)])
+    rng = np.random.default_rng(seed)
+    z = amp * z * np.exp(2j * np.pi * fq * np.arange(n)) + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, np.int16)
+    out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
+    out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
+    return out
