@@ -1025,3 +1025,125 @@ def mts01_capture(sr: int = 48_000, seconds: float = 6.0, fq: float = 0.0, *, am
     out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
     out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- InterMet iMet-54
+_IMET54_HAM = [0x00, 0x87, 0x99, 0x1E, 0xAA, 0x2D, 0x33, 0xB4, 0x4B, 0xCC, 0xD2, 0x55, 0xE1, 0x66, 0x78, 0xFF]        # imet54mod.c:196-197
+
+
+def _imet54_check_words(b: bytearray):
+    """the reference's 32-bit frame check (imet54mod.c:229-284) run forward: returns (crc0, crc1) of the data positions"""
+    poly0, poly1 = 0x0EDB, 0x8260
+    n, bit = 104, 0
+    c0, c1 = 0x48EB, 0x1ACA
+    nx0, nx1 = c0, c1
+    crc0 = crc1 = 0
+    while n >= 0:
+        if n < 100 or 101 < n < 106:
+            if (b[n] >> bit) & 1:
+                crc0 ^= c0; crc1 ^= c1
+        if c1 & 0x8000:
+            nx0 ^= poly0; nx1 ^= poly1
+        nx0 <<= 1; nx1 <<= 1
+        if c1 & 0x8000:
+            nx0 |= 1
+        if (c1 ^ c0) & 0x8000:
+            nx1 |= 1
+        nx0 &= 0xFFFF
+        nx1 &= 0xFFFFFFFF
+        c0, c1 = nx0, nx1
+        if bit < 7:
+            bit += 1
+        else:
+            bit = 0
+            n = n - 7 if n % 4 == 3 else n + 1
+    return crc0, crc1
+
+
+def imet54_frame(k: int = 0, *, sn: int = 54012345, lat=52.123456, lon=13.654321, alt_m=2345.6, check: str = "std", imet50: bool = False) -> bytes:
+    """108 frame bytes (field map imet54mod.c:330-345): SN, GPS time hhmmssmmm, lat / lon as ddmm.mmmm * 1e4, alt dm, PTU floats, status,
+    0xF8 marker; check = "std": the 32-bit check of the standard frame (:229-284), "cont": CRC-32 at 0x34 (:350-360), "none": neither"""
+    f = bytearray(108)
+    f[0:4] = int(sn).to_bytes(4, "big")
+    sec = k % 60
+    f[4:8] = int(((12 * 100 + 34) * 100 + sec) * 1000 + 250).to_bytes(4, "big")
+
+    def nmea(x):
+        d = int(abs(x)); m = (abs(x) - d) * 60.0
+        v = int(round((d * 100 + m) * 1e4))
+        return -v if x < 0 else v
+    f[8:12] = nmea(lat + 1e-4 * k).to_bytes(4, "big", signed=True)
+    f[12:16] = nmea(lon - 1e-4 * k).to_bytes(4, "big", signed=True)
+    f[16:20] = int(round((alt_m + 5.0 * k) * 10)).to_bytes(4, "big", signed=True)
+    if imet50:
+        for p in (0x1C, 0x20, 0x24):
+            f[p:p + 4] = bytes.fromhex("4E6E6B28")
+        f[0x2A:0x2C] = bytes([0x00, 0x30])
+    else:
+        f[0x1C:0x20] = np.float32(-12.5 - 0.1 * k).tobytes()[::-1]
+        f[0x20:0x24] = np.float32(55.0 + k).tobytes()[::-1]
+        f[0x24:0x28] = np.float32(-10.0 - 0.1 * k).tobytes()[::-1]
+        f[0x2A:0x2C] = bytes([0x00, 0x3E])
+        rng = np.random.default_rng(500 + k)
+        f[0x38:0x52] = rng.integers(0, 256, 0x52 - 0x38, dtype=np.uint8).tobytes()
+    f[0x52] = 0xF8
+    f[0x5E] = k & 0xFF
+    if check == "cont":
+        m4 = bytearray(0x34)
+        for i in range(0x34 // 4):
+            for j in range(4):
+                m4[4 * i + j] = f[4 * i + 3 - j]
+        rem = 0
+        for byte in m4:
+            rem ^= byte << 24
+            for _ in range(8):
+                rem = ((rem << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if rem & 0x80000000 else (rem << 1) & 0xFFFFFFFF
+        f[0x34:0x38] = (rem ^ 0x63D60875).to_bytes(4, "big")
+    elif check == "std":
+        c0, c1 = _imet54_check_words(f)
+        f[100:102] = (((c0 ^ 0x5000) & 0xF000) | 0x0ABC & 0x0FFF).to_bytes(2, "big")
+        f[106:108] = ((c1 ^ 0x1DAD) & 0xFFFF).to_bytes(2, "big")
+    return bytes(f)
+
+
+def imet54_frame_bits(frame108: bytes) -> np.ndarray:
+    """2200 bits behind the header: 8N1 characters (start 0, 8 bits, stop 1) of 0x24 0x24 0x42 and of the 64-bit interleaved Hamming(8,4)
+    codewords of the 216 nibbles, one more character at the end (imet54mod.c:626-646 backwards)"""
+    cw = []
+    for b in frame108:
+        for nib in (b >> 4, b & 0xF):
+            cw += [(_IMET54_HAM[nib] >> j) & 1 for j in range(8)]
+    cw = np.array(cw, np.uint8).reshape(-1, 8, 8)
+    inter = cw.transpose(0, 2, 1).reshape(-1)                         # out[8 j + i] = in[8 i + j], its own inverse
+    sync = np.unpackbits(np.array([0x24, 0x24, 0x42], np.uint8))
+    data = np.concatenate([sync, inter, np.zeros(8, np.uint8)])
+    chars = data.reshape(-1, 8)
+    out = np.zeros((len(chars), 10), np.uint8)
+    out[:, 1:9] = chars
+    out[:, 9] = 1
+    return out.reshape(-1)
+
+
+def imet54_onair_bits(n_frames: int, **kw) -> np.ndarray:
+    """n_frames frames, one per second at 4798 Bd: preamble 0x00 0xAA x 9, the header characters 0x00 0xAA 0x24 0x24, the frame, idle ones"""
+    pre = np.array([int(c) for c in ("0000000001" "0101010101") * 9], np.uint8)
+    hdr = np.array([int(c) for c in FAMILY["imet54mod"]["header"]], np.uint8)
+    idle = np.ones(4798 - len(pre) - len(hdr) - 2200, np.uint8)
+    return np.concatenate([np.concatenate([pre, hdr, imet54_frame_bits(imet54_frame(k, **kw)), idle]) for k in range(n_frames)])
+
+
+def imet54_capture(sr: int = 48_000, seconds: float = 5.0, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1, invert: bool = False, **kw) -> np.ndarray:
+    """iMet-54 GFSK capture (4798 Bd, h = 0.8, BT 1.0 as the decoder assumes, imet54mod.c:953-954)"""
+    bits = imet54_onair_bits(int(seconds) + 2, **kw)
+    if invert:
+        bits = 1 - bits
+    n = int(seconds * sr)
+    z = gfsk_baseband(bits, sr, 4798.0, dev_hz=0.8 * 4798.0 / 2, bt=1.0)[:n]
+    if len(z) < n:
+        z = np.concatenate([z, np.zeros(n - len(z), z.dtype)])
+    rng = np.random.default_rng(seed)
+    z = amp * z * np.exp(2j * np.pi * fq * np.arange(n)) + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, np.int16)
+    out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
+    out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
+    return out
