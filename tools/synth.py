@@ -1147,3 +1147,92 @@ def imet54_capture(sr: int = 48_000, seconds: float = 5.0, fq: float = 0.0, *, a
     out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
     out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- Meteo-Radiy MRZ (MP3-H1)
+def mrz_config() -> list:
+    """the 16 configuration words a sonde cycles through (mp3h1mod.c:541-616): NTC A/B/C, ADC polynomials, serial numbers, dates"""
+    f = lambda x: int(np.frombuffer(np.float32(x).tobytes(), np.uint32)[0])
+    return [f(0.012), f(3450.0), f(1.5), f(1e-6), f(0.9), f(120.0), f(2e-6), f(0.8), f(50.0), 0x1234, 0x5678, 0, 21043, 18765, 150323, 150624]
+
+
+def mrz_frame(k: int = 0, *, latlon: bool = False, lat=55.751244, lon=37.618423, alt_m=3456.7) -> bytes:
+    """frame bytes AA BF 35 .. CRC (50 bytes ECEF, 47 lat / lon; field map mp3h1mod.c:246-275): sub-frame counter k % 16 with its configuration
+    word, time, position (ECEF cm + velocities cm/s, or lat / lon 1e-6 deg + alt cm), PTU, CRC-16 0xA001 reflected, init 0xFFFF, low byte first"""
+    cfgw = mrz_config()
+    sub = k % 16
+    sec = (k // 1) % 60
+    f = bytearray(50 if not latlon else 47)
+    f[0:3] = bytes([0xAA, 0xBF, 0x35])
+    f[3] = 0x80 | sub
+    f[4:7] = bytes([12, 34, sec])
+    o = -3 if latlon else 0
+    if latlon:
+        f[7:11] = int(round((lat + 1e-4 * k) * 1e6)).to_bytes(4, "little", signed=True)
+        f[11:15] = int(round((lon - 1e-4 * k) * 1e6)).to_bytes(4, "little", signed=True)
+        f[15:19] = int(round((alt_m + 5 * k) * 100)).to_bytes(4, "little", signed=True)
+        f[19:21] = int(1234).to_bytes(2, "little")
+        f[21:23] = int(23456).to_bytes(2, "little")
+        f[23] = 9
+        f[30:32] = b"\xff\xff"
+    else:
+        a, e2 = 6378137.0, 6.69437999014e-3
+        ph, la, h = np.radians(lat + 1e-4 * k), np.radians(lon - 1e-4 * k), alt_m + 5 * k
+        N = a / np.sqrt(1 - e2 * np.sin(ph) ** 2)
+        xyz = ((N + h) * np.cos(ph) * np.cos(la), (N + h) * np.cos(ph) * np.sin(la), (N * (1 - e2) + h) * np.sin(ph))
+        for j, v in enumerate(xyz):
+            f[8 + 4 * j:12 + 4 * j] = int(round(v * 100)).to_bytes(4, "little", signed=True)
+        for j, v in enumerate((310, -420, 530)):
+            f[20 + 2 * j:22 + 2 * j] = int(v).to_bytes(2, "little", signed=True)
+        f[26] = 11
+        f[33:35] = b"\x12\x34"
+    f[29 + o:31 + o] = int(-1234 - k).to_bytes(2, "little", signed=True)
+    f[31 + o:33 + o] = int(5678 + k).to_bytes(2, "little", signed=True)
+    f[35 + o:39 + o] = int(1_500_000 + 100 * k).to_bytes(4, "little")
+    f[39 + o:43 + o] = int(900_000 + 100 * k).to_bytes(4, "little")
+    f[43 + o] = sub + 1
+    f[44 + o:48 + o] = int(cfgw[sub]).to_bytes(4, "little")
+    n = 42 if latlon else 45
+    rem = 0xFFFF
+    for b in f[3:3 + n]:
+        rem ^= b
+        for _ in range(8):
+            rem = (rem >> 1) ^ 0xA001 if rem & 1 else rem >> 1
+    f[3 + n:5 + n] = rem.to_bytes(2, "little")
+    return bytes(f)
+
+
+def mrz_symbols(n_seconds: int, repeats: int = 2, **kw) -> np.ndarray:
+    """half symbols at 2399 Bd: per second `repeats` copies of the frame back to back, each as AA + frame bytes MSB first in Manchester (1 -> 10,
+    0 -> 01, mp3h1mod.c:133-135), then AA AA and random idle symbols"""
+    out = []
+    for k in range(n_seconds):
+        fr = mrz_frame(k, **kw)
+        bits = []
+        for _ in range(repeats):
+            bits += list(np.unpackbits(np.frombuffer(bytes([0xAA]) + fr, np.uint8)))
+        bits += [1, 0, 1, 0, 1, 0, 1, 0] * 2
+        sym = []
+        for b in bits:
+            sym += [1, 0] if b else [0, 1]
+        pad = max(0, 2399 - len(sym))
+        sym += list(np.random.default_rng(7000 + k).integers(0, 2, pad))        # idle: anything that does not resemble the 1001 preamble
+        out += sym
+    return np.array(out, np.uint8)
+
+
+def mrz_capture(sr: int = 48_000, seconds: float = 5.0, fq: float = 0.0, *, amp: float = 0.5, noise_sigma: float = 0.02, seed: int = 1, invert: bool = False, **kw) -> np.ndarray:
+    """MRZ GFSK capture (2399 Bd half symbols, h = 2.0, BT 1.0 as the decoder assumes, mp3h1mod.c:1122-1123)"""
+    sym = mrz_symbols(int(seconds) + 2, **kw)
+    if invert:
+        sym = 1 - sym
+    n = int(seconds * sr)
+    z = gfsk_baseband(sym, sr, 2399.0, dev_hz=2.0 * 2399.0 / 2, bt=1.0)[:n]
+    if len(z) < n:
+        z = np.concatenate([z, np.zeros(n - len(z), z.dtype)])
+    rng = np.random.default_rng(seed)
+    z = amp * z * np.exp(2j * np.pi * fq * np.arange(n)) + noise_sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    out = np.empty(2 * n, np.int16)
+    out[0::2] = np.clip(np.round(z.real * 32767), -32768, 32767)
+    out[1::2] = np.clip(np.round(z.imag * 32767), -32768, 32767)
+    return out
