@@ -1331,10 +1331,14 @@ void k_framesync(const SyncArgs a) {
                 uint32_t cnt = (uint32_t)ceil(edge);
                 double sum = 0.0;
                 edge += (double)a.sps;
-                do { sum += (double)bufs[(cnt + mvp) & mask] - hdc; cnt++; } while ((double)cnt < edge);
+                // the reference's ring holds M = N samples (bufs[sample_in % M], demod_mod.c:850): a header position taken from the FM-stream
+                // fallback lies up to (lpFMtaps - sps + 1) / 2 samples before the window (:268), and what it reads there has already been
+                // overwritten by the newest samples — index + M
+                const uint32_t ring_first = st.s_in - (uint32_t)a.N;
+                do { uint32_t ix = cnt + mvp; if ((int32_t)(ix - ring_first) < 0) ix += (uint32_t)a.N; sum += (double)bufs[ix & mask] - hdc; cnt++; } while ((double)cnt < edge);
                 if (a.symhd == 2) {
                     edge += (double)a.sps;
-                    do { sum -= (double)bufs[(cnt + mvp) & mask] - hdc; cnt++; } while ((double)cnt < edge);
+                    do { uint32_t ix = cnt + mvp; if ((int32_t)(ix - ring_first) < 0) ix += (uint32_t)a.N; sum -= (double)bufs[ix & mask] - hdc; cnt++; } while ((double)cnt < edge);
                 }
                 const int sign = mv < 0 ? 1 : 0;
                 if (a.symhd == 1) {

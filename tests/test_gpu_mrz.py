@@ -34,10 +34,10 @@ def test_native_mrz_on_samples(tmp_path):
     assert out.count(b"[OK]") >= 20 and out.count(b'"type": "MRZ"') >= 2
     y = synth.mrz_capture(sr=48_000, seconds=6.5, noise_sigma=0.15, seed=72)
     _both(["-vv", "--ptu", "--IQ", "0.0", "--lpIQ", "-", "48000", "16"], y.tobytes())
-    # --dc: the frames decoded are the same, but one partial preamble match (a header taken 2 bits early, printed [NO]) is accepted by the engine
-    # and not by the reference on this capture — the reference-linked seam build behaves like the native one; cause not traced yet
-    a, b = _both(["-vv", "--ptu", "--IQ", "0.0", "--lpIQ", "--dc", "-", "48000", "16"], x[:2 * 48_000 * 7].tobytes(), exact=False)
-    assert [l for l in a.splitlines() if b"[OK]" in l] == [l for l in b.splitlines() if b"[OK]" in l] and a.count(b"[OK]") >= 6
+    # --dc: the FM-stream fallback puts a header up to (lpFMtaps - sps + 1) / 2 samples before the window; the reference's header check then reads
+    # ring slots that already hold the newest samples (demod_mod.c:268,850) — the engine reads the same samples (k_framesync)
+    _both(["-vv", "--ptu", "--IQ", "0.0", "--lpIQ", "--dc", "-", "48000", "16"], x[:2 * 48_000 * 7].tobytes())
+    _both(["-r", "--IQ", "0.0", "--lpIQ", "--dc", "-", "48000", "16"], y.tobytes())
     _both(["-r", "--iq3", "--lpIQ", "-", "48000", "16"], y.tobytes())
     _both(["-r", "--iq2", "-d", "1", "--br", "2399.5", "-", "48000", "16"], y.tobytes())
     _both(["-R", "--iq0", "-", "48000", "16"], y.tobytes())
