@@ -19,6 +19,7 @@ import numpy as np
 
 from .engine import Engine, snap_fq
 from .scan import Scanner
+from .family import FAMILY, FamilyDecoder
 from .telemetry import DfmTelemetry, M10Telemetry, M20Telemetry, Rs41Telemetry
 
 
@@ -114,6 +115,7 @@ class ChannelizedReceiver:
     Every block costs one channelizer launch, one scanner step and one launch sequence per sonde type, whatever the number of sondes."""
 
     TYPES = {"RS41": ("rs41", Rs41Telemetry), "DFM": ("dfm", DfmTelemetry), "M10": ("m10", M10Telemetry), "M20": ("m20", M20Telemetry)}
+    # + the scanner's LMS6 / MEISEI / IMET5 / MRZ / MTS01: generic sonde descriptions and the bit-rate tiers of family.py
 
     def __init__(self, sample_rate: int, *, M: int = 256, D: int = 200, P: int = 16, cfreq_hz: int = 0, slots: int = 16, chunk: int | None = None,
                  version: str = "sonde_hip", device: int = 0):
@@ -137,8 +139,12 @@ class ChannelizedReceiver:
     def _group(self, typ: str):
         g = self.groups.get(typ)
         if g is None:
-            sonde, _ = self.TYPES[typ]
-            kw = dict(sonde=sonde, bits=32, iq_mode=3, if_tune=True, lp_iq=True, max_chunk=self.nmax, max_frames=8 * self.slots, device=self.device)
+            kw = dict(bits=32, iq_mode=3, if_tune=True, lp_iq=True, max_chunk=self.nmax, max_frames=8 * self.slots, device=self.device)
+            if typ in FAMILY:
+                f = FAMILY[typ]
+                kw.update(sonde="generic", generic=f["generic"], thres=f["thres"], auto=f["auto"], keep_soft=True)
+            else:
+                kw.update(sonde=self.TYPES[typ][0])
             if typ == "DFM":
                 kw.update(ecc=1, auto=True)
             eng = Engine([0.0] * self.slots, self.if_sr, **kw)
@@ -150,7 +156,7 @@ class ChannelizedReceiver:
     def _start(self, k: int, typ: str, df: float):
         f_hz = self.ch.channel_freq(k) + df * self.if_sr
         for s in self.sondes:                                    # the neighbouring channel sees a strong signal too
-            if s["type"] == typ and abs(s["f_hz"] - f_hz) < (20_000.0 if typ in ("M10", "M20") else 8_000.0):
+            if s["type"] == typ and abs(s["f_hz"] - f_hz) < (FAMILY[typ]["sep_hz"] if typ in FAMILY else 20_000.0 if typ in ("M10", "M20") else 8_000.0):
                 return
         g = self._group(typ)
         if None not in g["owner"]:
@@ -161,7 +167,8 @@ class ChannelizedReceiver:
             g["engine"].restart_channel(slot)
         g["engine"].tune_channel(slot, df)
         khz = int(round((self.cfreq + f_hz) / 1000.0)) if self.cfreq else 0
-        s = dict(type=typ, f_hz=f_hz, chan=k, slot=slot, telemetry=self.TYPES[typ][1](freq_khz=khz, version=self.version), frames=0, khz=khz)
+        tel = FamilyDecoder(typ, freq_khz=khz, version=self.version) if typ in FAMILY else self.TYPES[typ][1](freq_khz=khz, version=self.version)
+        s = dict(type=typ, f_hz=f_hz, chan=k, slot=slot, telemetry=tel, frames=0, khz=khz)
         g["owner"][slot] = s
         self.sondes.append(s)
         self.log.append(dict(event="detected", type=typ, f_hz=f_hz, channel=k, slot=slot, freq_khz=khz))
@@ -187,6 +194,8 @@ class ChannelizedReceiver:
                     self._start(d["channel"], "DFM", d["df"])
                 elif d["type"] in ("M10", "M20"):
                     self._start(d["channel"], d["type"], d["df"])
+                elif d["type"] in FAMILY and (d["score"] > 0 or FAMILY[d["type"]]["auto"]):
+                    self._start(d["channel"], d["type"], d["df"])
             for typ, g in self.groups.items():
                 for slot, s in enumerate(g["owner"]):
                     if s is not None:
@@ -202,6 +211,15 @@ class ChannelizedReceiver:
 
     def _drain(self, typ, g, finish):
         e = g["engine"]
+        if typ in FAMILY:                                          # header hits -> the type's bit-rate tier (family.py), one decoder object per sonde
+            out = []
+            for h in e.fetch_hits(finish=finish):
+                s = g["owner"][h["channel"]]
+                if s is None:
+                    continue
+                s["frames"] += 1
+                out += FamilyDecoder.json_objects(s["telemetry"].hit(h, self.if_sr))
+            return out
         frames = e.fetch_dfm(finish=finish) if typ == "DFM" else e.fetch_mxx(finish=finish) if typ in ("M10", "M20") else e.fetch_frames(finish=finish)
         out = []
         for fr in frames:

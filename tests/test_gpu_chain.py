@@ -316,3 +316,40 @@ def test_channelized_receiver_assigns_decoder_channels_at_run_time():
                 if key in w:
                     assert j.get(key) == w[key], (key, j, w)
     ch.close()
+
+
+def test_channelized_receiver_decodes_the_generic_family():
+    """the same receiver with sondes of the generic family in the 10 Msps stream: the scanner names LMS6 / IMET5 / MEISEI, each type gets one
+    generic-description engine whose channels are handed out at run time, and every header hit goes through that sonde's own bit-rate tier
+    (radiosonde_auto_rx_amd/family.py) — ids, positions and frame counts as sent"""
+    from tools import synth
+    from radiosonde_auto_rx_amd.wideband import ChannelizedReceiver
+    sr, M, D = 10_000_000, 256, 200
+    spacing = sr / M
+    secs = 4.6
+    n = int(sr * secs)
+    sondes = [("LMS6", 40 * spacing + 900.0, lambda fq: synth.lms6_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.0, amp=0.2, seed=91)),
+              ("IMET5", -60 * spacing - 1200.0, lambda fq: synth.imet54_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.0, amp=0.2, seed=92)),
+              ("MEISEI", 100 * spacing + 300.0, lambda fq: synth.meisei_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.0, amp=0.2, seed=93))]
+    acc = np.zeros(2 * n, np.float64)
+    for typ, f_hz, make in sondes:
+        x = make(f_hz / sr)
+        acc[:len(x)] += x[:2 * n]
+    acc += np.random.default_rng(97).normal(0.0, 60.0, size=2 * n)
+    iq = np.clip(np.round(acc), -32768, 32767).astype(np.int16)
+    del acc
+    rx = ChannelizedReceiver(sr, M=M, D=D, cfreq_hz=403_000_000, slots=2, version="oracle")
+    out = []
+    for s0 in range(0, n, rx.chunk):
+        out += rx.push(iq[2 * s0:2 * min(n, s0 + rx.chunk)], finish=(s0 + rx.chunk >= n))
+    log = list(rx.log)
+    found = [(s["type"], s["f_hz"]) for s in rx.sondes]
+    rx.close()
+    for typ, f_hz, _ in sondes:
+        assert any(t == typ and abs(f - f_hz) < 800.0 for t, f in found), (typ, f_hz, found, log)
+    lms = [j for j in out if j["type"] == "LMS"]
+    assert len(lms) >= 2 and all(j["id"] == "LMS6-8123456" and abs(j["lat"] - 47.5) < 1e-3 and abs(j["freq"] - 404_563) <= 3 for j in lms), lms[:1]
+    im = [j for j in out if j["type"] == "IMET5"]
+    assert len(im) >= 2 and all(j["id"] == "IMET5-54012345" and abs(j["lat"] - 52.1236) < 1e-3 for j in im), im[:1]
+    me = [j for j in out if j["type"] == "MEISEI"]
+    assert len(me) >= 1 and all(j["subtype"] == "IMS100" and abs(j["lat"] - 35.2058) < 1e-3 for j in me), me[:1]      # one object per second once a frame pair is in
