@@ -69,7 +69,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "       -i, --invert\n");
             return 0;
         }
-        else if (!strcmp(a, "--ofs")) { if (++i >= argc) return -1; o.bits_ofs = atoi(argv[i]); }
+        else if (!strcmp(a, "--ofs")) { if (++i >= argc) return -1; o.bits_ofs = atoi(argv[i]); o.bits_ofs_given = 1; }
         else if (!strcmp(a, "--dbg")) o.dbg = 1;
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) o.verbose = 1;
         else if (!strcmp(a, "-vv")) o.verbose = 2;

@@ -11,8 +11,8 @@
  * Mirrors print_frame imet54mod.c:618-707, print_position :494-616, de8n1 :107-118, deinter64 :120-133, check / hamming :162-227, crc32ok
  * :229-284, crc32_802 :286-303, crc32ok_cont :350-360, get_GPS :368-406, vaporSatP :409-422, get_PTU :424-475, the bit loop of main
  * :1008-1061, the --rawhex reader :1086-1112 and, for soft input, find_softbinhead / corr_softhdb (demod_mod.c:1692-1762; threshold 0.8, :998).
- * Deviation: for a frame cut short by the end of the stream the reference sums Hamming results it never computed (stack garbage, :632,:651);
- * here those entries are 0.
+ * For a frame cut short by the end of the stream the reference sums Hamming results it never computed (locals that are not cleared, :623-624,:651):
+ * in the compiled reference they hold what the previous frame left there, and so they do here (kept in the decoder object).
  */
 #ifndef SONDE_IMET54_H
 #define SONDE_IMET54_H

@@ -36,10 +36,11 @@ typedef struct {
     int32_t color;           /* -c                                                                                      */
     int32_t json;            /* --json                                                                                  */
     int32_t inv, aut;        /* -i, --auto: polarity handling of the soft-input framer (:1186-1189)                      */
-    int32_t bits_ofs;        /* --ofs: first frame bit, 0 = the default 8                                               */
+    int32_t bits_ofs;        /* --ofs n: first frame bit (0..64); used when bits_ofs_given != 0, else the default 8      */
     int32_t jsn_freq_khz;    /* "freq" of the JSON when > 0                                                             */
     char    version[32];     /* "version" of the JSON; "" = omit                                                        */
-    int32_t reserved[4];
+    int32_t bits_ofs_given;
+    int32_t reserved[3];
 } sonde_mrz_opts_t;
 
 int  sonde_mrz_dec_create(const sonde_mrz_opts_t *opts, sonde_mrz_dec_t **out);

@@ -100,6 +100,9 @@ struct sonde_imet54_dec {
     uint16_t status = 0;
     uint8_t frame[FRAME_LEN + 4];
     uint8_t frame_bits[BITFRAME_LEN + 8];
+    // print_frame's nib[] / ec[] (:623-624) are locals the reference never clears; a frame cut short sums entries it did not compute (:651).  In the
+    // compiled reference they keep what the previous frame left there (print_frame is inlined into main's frame), which is what members do.
+    uint8_t nib[FRAME_LEN] = { 0 }, ec[FRAME_LEN] = { 0 };
     int inv = 0;
     float sbuf[40]; int bufpos = -1, in_frame = 0, pos = 0;
 
@@ -207,9 +210,9 @@ struct sonde_imet54_dec {
     void print_frame(Out &w, int len, int b2B) {
         int ecc_frm = 0, ecc_std = 0, ecc_tlm = 0;
         if (b2B) {
-            static thread_local uint8_t bits8n1[BITFRAME_LEN + 10], bits[BITFRAME_LEN], nib[FRAME_LEN], ec[FRAME_LEN];
+            static thread_local uint8_t bits8n1[BITFRAME_LEN + 10], bits[BITFRAME_LEN];
             for (int i = len; i < BITFRAME_LEN; i++) frame_bits[i] = 0;
-            memset(bits8n1, 0, sizeof bits8n1); memset(bits, 0, sizeof bits); memset(ec, 0, sizeof ec); memset(nib, 0, sizeof nib);
+            memset(bits8n1, 0, sizeof bits8n1); memset(bits, 0, sizeof bits);      // nib[] / ec[] are not cleared: see the members' comment
             uint8_t *q = bits8n1;
             for (int n = 0; n < len; n++) if (n % 10 > 0 && n % 10 < 9) *q++ = frame_bits[n];          // de8n1
             len = (8 * len) / 10;

@@ -291,7 +291,7 @@ int sonde_mrz_dec_create(const sonde_mrz_opts_t *opts, sonde_mrz_dec_t **out) {
     sonde_mrz_dec *d = new sonde_mrz_dec();
     d->o = *opts;
     d->o.version[sizeof d->o.version - 1] = 0;
-    d->bits_ofs = opts->bits_ofs ? opts->bits_ofs : 8;
+    d->bits_ofs = opts->bits_ofs_given ? opts->bits_ofs : 8;
     d->inv = opts->inv != 0;
     memset(d->frame, 0, sizeof d->frame); memset(d->frame_bits, 0, sizeof d->frame_bits); memset(d->cfg, 0, sizeof d->cfg); memset(d->sbuf, 0, sizeof d->sbuf);
     for (int i = 0; i < HEADLEN / 2; i++) d->frame_bits[i] = (kHeader[2 * i] == '1' && kHeader[2 * i + 1] == '0') ? '1' : '0';      // manchester1(mrz_header) (:1173)

@@ -33,7 +33,8 @@ class Imet54Opts(C.Structure):
 
 
 class MrzOpts(C.Structure):
-    _fields_ = _opts(("raw", "verbose", "dbg", "ptu", "uniq", "color", "json", "inv", "aut", "bits_ofs", "jsn_freq_khz"))
+    _fields_ = [(n, _I) for n in ("raw", "verbose", "dbg", "ptu", "uniq", "color", "json", "inv", "aut", "bits_ofs", "jsn_freq_khz")] + \
+               [("version", C.c_char * 32), ("bits_ofs_given", _I), ("reserved", _I * 3)]
 
 
 class Mts01Opts(C.Structure):

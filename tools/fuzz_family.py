@@ -1,0 +1,74 @@
+"""Differential fuzzing of the five native bit-rate tiers against the compiled reference decoders (oracle/_ref): random frame streams from tools/synth.py,
+damaged in random ways (noise, sign bursts, scaling, zeros, inversion, truncation, a torn last float), random option sets, soft-bit input.
+    python tools/fuzz_family.py <seed> <iterations>       -> prints every mismatch, exit code = number of mismatches (capped at 255)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
+from tools import synth  # noqa: E402
+
+env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+def both(dec, args, data):
+    a = subprocess.run(["host/bin/" + dec] + args, input=data, capture_output=True, env=env, timeout=60)
+    b = subprocess.run(["oracle/_ref/" + dec] + args, input=data, capture_output=True, timeout=60)
+    return a.returncode == b.returncode and a.stdout == b.stdout, a, b
+streams = {
+ "lms6Xmod": lambda: np.concatenate([synth.lms6_onair_bits(3, lmsx=bool(rng.integers(2))) for _ in range(rng.integers(1, 3))]),
+ "meisei100mod": lambda: synth.meisei_symbols(int(rng.integers(4, 40)), "ims100" if rng.integers(2) else "rs11g", k0=int(rng.integers(0, 200))),
+ "imet54mod": lambda: synth.imet54_onair_bits(int(rng.integers(1, 4)), check=["std", "cont", "none"][rng.integers(3)], imet50=bool(rng.integers(2))),
+ "mp3h1mod": lambda: synth.mrz_symbols(int(rng.integers(2, 20)), latlon=bool(rng.integers(2))),
+ "mts01mod": lambda: synth.mts01_onair_bits(int(rng.integers(1, 5))),
+}
+opts = {
+ "lms6Xmod": [[], ["-r"], ["--ecc"], ["--vit"], ["--vit2", "--ecc"], ["--json"], ["--json", "--vit2"], ["--lms6", "--ecc"], ["--lmsX", "--ecc", "--vit"], ["--ecc3", "--vit2"], ["--gpsweek", "2290", "--json"]],
+ "meisei100mod": [[], ["-r"], ["--ecc"], ["--ecc", "-v", "--ptu"], ["--json", "--ptu"], ["-r", "--ecc", "-v"], ["--dbg"], ["--rs11g", "--ecc", "--ptu"], ["--ims100", "--json"], ["--year", "2035", "--json"]],
+ "imet54mod": [[], ["-r"], ["--ecc"], ["--ecc", "-v", "--ptu"], ["--json", "--ptu"], ["-r4", "--ecc"], ["--auto", "--ecc"], ["-i", "--ecc"], ["-r", "--json"], ["--silent", "--json"]],
+ "mp3h1mod": [[], ["-r"], ["-R"], ["-v"], ["-vv", "--ptu", "--dbg"], ["--json", "--ptu"], ["--auto", "--json"], ["-i"], ["--uniq", "--json"], ["-c"], ["--ofs", "9"], ["--ofs", "0", "-r"]],
+ "mts01mod": [[], ["-r"], ["-R"], ["-v"], ["--json"], ["-v", "--json"]],
+}
+
+
+def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
+  global rng
+  rng = np.random.default_rng(seed)
+  bad = 0
+  for it in range(iterations):
+      dec = list(streams)[it % 5]
+      s = 2.0 * streams[dec]().astype(np.float64) - 1.0
+      lead = 2.0 * rng.integers(0, 2, int(rng.integers(0, 200))) - 1.0
+      s = np.concatenate([lead, s])
+      mode = rng.integers(4)
+      if mode == 0: s = s + rng.normal(0, rng.uniform(0, 1.2), len(s))
+      elif mode == 1:                                    # bursts
+          for _ in range(rng.integers(1, 6)):
+              p = rng.integers(0, len(s)); s[p:p + rng.integers(1, 300)] *= -1
+      elif mode == 2: s = s * rng.uniform(0.01, 100.0) + rng.normal(0, 0.3, len(s))
+      else: s[rng.integers(0, len(s), rng.integers(0, 50))] = 0.0
+      if rng.integers(3) == 0: s = -s
+      if rng.integers(3) == 0: s = s[:rng.integers(1, len(s))]
+      data = s.astype(np.float32).tobytes()
+      if rng.integers(8) == 0: data = data[:-int(rng.integers(1, 4))]
+      a = opts[dec][rng.integers(len(opts[dec]))]
+      args = ["--softinv" if rng.integers(4) == 0 else "--softin"] + a
+      ok, ra, rb = both(dec, args, data)
+      if not ok:
+          bad += 1
+          print("MISMATCH", dec, args, len(data), ra.returncode, rb.returncode)
+          if keep_dir:
+            open(os.path.join(keep_dir, f"fail_{dec}_{seed}_{it}.f32"), "wb").write(data)
+          la, lb = ra.stdout.splitlines(), rb.stdout.splitlines()
+          for x, y in zip(la, lb):
+              if x != y: print(" OUR:", x[:200]); print(" REF:", y[:200]); break
+          else: print(" line counts", len(la), len(lb))
+  return bad
+
+
+if __name__ == "__main__":
+    n = run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 60, sys.argv[3] if len(sys.argv) > 3 else None)
+    print("done, mismatches:", n)
+    sys.exit(min(n, 255))
