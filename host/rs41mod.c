@@ -8,7 +8,7 @@
  * stderr: `IF: <rate>` / `dec: <M>`                               (demod_mod.c:1257-1258)
  * exit  : 0 on EOF, 255 on argument / init errors                 (rs41mod.c:2663,2739,2846)
  * Without -r the telemetry text line (and with --json the JSON object auto_rx parses) of print_position() is printed
- * (include/sonde_rs41.h; -v, --ptu, --ptu2, --dewp, --json, --jsnsubfrm1/2, --jsn_cfq, --silent).
+ * (include/sonde_rs41.h; -v, --ptu, --ptu2, --dewp, --sat, --json, --jsnsubfrm1/2, --jsn_cfq, --silent).
  * The DSP runs on the GPU; there is no CPU fallback: without a HIP device the program exits 255.
  */
 #include <stdio.h>
@@ -97,8 +97,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
         else if (!strcmp(a, "--ptu2")) dopt.ptu = 2;
         else if (!strcmp(a, "--dewp")) dopt.dewp = 1;
+        else if (!strcmp(a, "--sat")) dopt.sat = 1;
         else if (!strcmp(a, "--silent")) dopt.silent = 1;
-        else if (!strcmp(a, "--json")) { dopt.json = 1; json_ecc = 1; }
+        else if (!strcmp(a, "--json")) { dopt.json = 1; cfg.ecc_level = 2; }      /* at this point of the argument list: a later --ecc wins (rs41mod.c:2703-2707) */
         else if (!strcmp(a, "--jsnsubfrm1")) { dopt.jsn_subfrm = 1; dopt.json = 1; json_ecc = 1; }
         else if (!strcmp(a, "--jsnsubfrm2")) { dopt.jsn_subfrm = 2; dopt.json = 1; json_ecc = 1; }
         else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
@@ -147,7 +148,7 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "rs41mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    if (json_ecc && cfg.ecc_level < 2) cfg.ecc_level = 2;   /* --json / --jsnsubfrm: ecc = 2, crc (rs41mod.c:2703-2707,2770-2774) */
+    if (json_ecc) cfg.ecc_level = 2;                        /* --jsnsubfrm1/2: ecc = 2 after the arguments, whatever they said (rs41mod.c:2769-2773) */
     const int ecc34 = cfg.ecc_level >= 3 ? cfg.ecc_level : 0;
     if (ecc34 && (rawhex || (opt_bin && !softin))) { fprintf(stderr, "rs41mod (sonde_hip): --ecc3/--ecc4 need soft bits (samples or --softin)\n"); return -1; }
     if (ecc34 && !softin) { cfg.ecc_level = 2; cfg.keep_soft = 2; }      /* the engine hands out both soft bits per bit; the list decoding runs in sonde_rs41_dec_ecc() */

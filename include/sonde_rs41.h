@@ -33,7 +33,8 @@ typedef struct {
     int32_t silent;         /* --silent, or -r together with --json: no text line, JSON only (rs41mod.c:2754)         */
     int32_t jsn_freq_khz;   /* "freq" of the JSON when > 0: (--jsn_cfq Hz - xlt_fq * sr + 500) / 1000 (rs41mod.c:2806-2809) */
     char    version[32];    /* "version" of the JSON — the reference compiles it in (VER_JSN_STR); "" = omit          */
-    int32_t reserved[4];
+    int32_t sat;            /* --sat: raw GPS block contents behind the time / position pieces (prn_sat1/2/3, rs41mod.c:2052-2111) */
+    int32_t reserved[3];
 } sonde_rs41_opts_t;
 
 int  sonde_rs41_dec_create(const sonde_rs41_opts_t *opts, sonde_rs41_dec_t **out);

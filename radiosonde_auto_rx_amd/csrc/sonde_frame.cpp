@@ -300,8 +300,10 @@ int sonde_m20_frame_finish(sonde_m20_frame_t *f) {
     f->fw = pos_fw >= 0 ? f->frame[pos_fw] : 0;
     if (f->fw > 0x20) f->fw = 0;
     f->len = flen + 1;
+    // length byte 0: the reference then reads the two bytes in FRONT of its frame buffer (m20mod.c:897-901: frame_bytes[-2], [-1] = two bytes of the
+    // previous frame's serial number, gpx_t :112-113); they are taken as 0 here, which is what they are until a frame has been printed
     f->cs_calc = pc >= 0 ? (uint32_t)sonde::m10_checksum(f->frame, pc) : 0;
-    f->cs_ok = pc >= 0 && ((uint32_t)((f->frame[pc] << 8) | f->frame[pc + 1]) == f->cs_calc);
+    f->cs_ok = pc >= 0 ? ((uint32_t)((f->frame[pc] << 8) | f->frame[pc + 1]) == f->cs_calc) : (f->frame[0] == 0);
     uint8_t blk[0x16]; blk[0] = 0x16; memcpy(blk + 1, f->frame + 2, 0x14);       // blk_checkM10 (m20mod.c:548-560): length byte, then the block
     const int bc2 = sonde::m10_checksum(blk, 0x15), bc1 = (f->frame[0x16] << 8) | f->frame[0x17];
     f->blk_ok = bc1 == bc2 ? 1 : bc1 == 0 ? -1 : 0;

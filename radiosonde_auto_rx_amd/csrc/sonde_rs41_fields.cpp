@@ -199,12 +199,36 @@ struct sonde_rs41_dec {
         isUTC = 1;
         return e;
     }
+    uint8_t sv_id[32], sv_status[32]; int n_sv168 = 0, n_svstatus = 0;      // gnss_sv[], gnss_numSVb168, gnss_nSVstatus (for --sat)
     int gnss_sats(int pos) {
+        memset(sv_id, 0, sizeof sv_id); memset(sv_status, 0, sizeof sv_status); n_sv168 = 0; n_svstatus = 0;
         if (block_crc(pos, K_SATS)) { crc |= F_GPS2; return 1; }
+        int c = 0;
+        for (int j = 0; j < 21; j++) for (int k = 0; k < 8; k++) if ((fr[pos + 2 + 4 + j] >> k) & 1) { if (c < 32) sv_id[c] = (uint8_t)(j * 8 + k + 1); c++; }
+        n_sv168 = c;
         int n = 0;
-        for (int j = 0; j < 16; j++) { const uint8_t b = fr[pos + 2 + 4 + 21 + j]; if (b & 0xF) n++; if ((b >> 4) & 0xF) n++; }
+        for (int j = 0; j < 16; j++) {
+            const uint8_t b = fr[pos + 2 + 4 + 21 + j];
+            sv_status[2 * j] = b & 0xF; sv_status[2 * j + 1] = (b >> 4) & 0xF;
+            if (b & 0xF) n++; if ((b >> 4) & 0xF) n++;
+        }
+        n_svstatus = n;
         numSV = n;
         return 0;
+    }
+    void t_gnss_sat2(Out &w) {                                  // prn_gnss_sat2 (:1221-1260)
+        w.f("\n"); w.f("  numSV168 : %2d", n_sv168); w.f("  nSVstatus: %2d", n_svstatus); w.f("\n"); w.f("  SVids: ");
+        for (int n = 0; n < 32; n++) { if (n < n_sv168) w.f(" %3d", sv_id[n]); if (n < n_svstatus) w.f(":%X", sv_status[n]); }
+        w.f("\n");
+        for (int n = 0; n < 32; n++) {
+            if (!(n < n_sv168 || n < n_svstatus)) continue;
+            if (sv_id[n] < 33) { if (n == 0) w.f("  GPS: "); w.f(" PRN%02d", sv_id[n]); }
+            else if (sv_id[n] < 33 + 36) {
+                if (n == 0 || sv_id[n - 1] < 33) { if (n > 0) w.f("\n"); w.f("  GAL: "); }
+                w.f(" E%02d", sv_id[n] - 32);
+            }
+        }
+        w.f("\n");
     }
 
     // ---- PTU ---------------------------------------------------------------------------------------------------------
@@ -456,10 +480,40 @@ struct sonde_rs41_dec {
         w.f("\n");
     }
 
+    // ---- --sat: raw contents of the three GPS blocks (prn_sat1/2/3, :2052-2111) ------------------------------------------------------
+    static uint32_t le4(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+    static int le2(const uint8_t *p) { return p[0] | (p[1] << 8); }
+    void t_sat1(Out &w, int ofs) { w.f("\n"); w.f("iTOW: 0x%08X", le4(fr + 0x097 + ofs)); w.f("  week: 0x%04X", le2(fr + 0x095 + ofs)); }
+    void t_sat2(Out &w, int ofs) {
+        const double c = 299.792458e6, L1 = 1575.42e6;
+        w.f("\n");
+        const uint32_t minPR = le4(fr + 0x0B7 + ofs);
+        w.f("minPR: %d", (int)minPR); w.f("\n");
+        for (int i = 0; i < 12; i++) {
+            const int sv = fr[0x09B + ofs + 2 * i];
+            if (sv == 0xFF) break;
+            const uint8_t *p = fr + 0x0BC + ofs + 7 * i;
+            int d24 = p[4] | (p[5] << 8) | (p[6] << 16);
+            if (d24 & 0x800000) d24 -= 0x1000000;
+            w.f("    SV: %2d ", sv); w.f("#  ");
+            w.f("prMes: %.1f", le4(p) / 100.0 + minPR); w.f("  ");
+            w.f("doMes: %.1f", -d24 / 100.0 * L1 / c); w.f("\n");
+        }
+    }
+    void t_sat3(Out &w, int ofs) {
+        w.f("\n");
+        w.f("ECEF-POS: (%d,%d,%d)\n", (int32_t)le4(fr + 0x114 + ofs), (int32_t)le4(fr + 0x118 + ofs), (int32_t)le4(fr + 0x11C + ofs));
+        w.f("ECEF-VEL: (%d,%d,%d)\n", (int16_t)le2(fr + 0x120 + ofs), (int16_t)le2(fr + 0x122 + ofs), (int16_t)le2(fr + 0x124 + ofs));
+        double sAcc = fr[0x127 + ofs] / 10.0, pDOP = fr[0x128 + ofs] / 10.0;
+        if (fr[0x127 + ofs] == 0xFF) sAcc = -1.0;
+        if (fr[0x128 + ofs] == 0xFF) pDOP = -1.0;
+        w.f("numSatsFix: %2d  sAcc: %.1f  pDOP: %.1f\n", fr[0x126 + ofs], sAcc, pDOP);
+    }
+
     // ---- frames whose ECC passed ---------------------------------------------------------------------------------------
     void run_good(Out &w, int ec) {
         const int out = !o.silent;
-        int err = 1, err0 = 1, err1 = 1, err3 = 1, err13 = 1, encrypted = 0, pos_aux = 0, ofs_ptu = 0, kind_ptu = 0, ofs_cal = 0;
+        int err = 1, err0 = 1, err1 = 1, err3 = 1, err13 = 1, encrypted = 0, pos_aux = 0, ofs_ptu = 0, kind_ptu = 0, ofs_cal = 0, err2g = 1, is_gnss2 = 0;
         int flen = NDATA;
         if (frametype() < 0) flen += 198;
         int frm_end = NDATA - 2;
@@ -474,30 +528,31 @@ struct sonde_rs41_dec {
             const int blk = fr[pos], len = fr[pos + 1], kind = (blk << 8) | len;
             if (block_crc(pos, blk << 8) != 0) { w.f(" [ERROR]\n"); break; }
             switch (kind) {
-                case K_STATUS: ofs_cal = pos - P_STATUS; err = status_block(ofs_cal); have_id = !err; if (!err && out) t_frame(w); break;
+                case K_STATUS: ofs_cal = pos - P_STATUS; err = status_block(ofs_cal); have_id = !err; if (!err && (out || o.sat)) t_frame(w); break;
                 case K_PTU: ofs_ptu = pos - P_PTU; kind_ptu = K_PTU; break;
-                case K_GPS1: err1 = gps_time(pos - P_GPS1); if (!err1) { gps_date(); if (out) t_time(w); } break;
-                case K_GPS2: if (block_crc(P_GPS2 + (pos - P_GPS2), K_GPS2)) crc |= F_GPS2; break;
-                case K_GPS3: err3 = gps_pos(pos - P_GPS3); if (!err3 && out) t_pos(w); break;
+                case K_GPS1: err1 = gps_time(pos - P_GPS1); if (!err1) { gps_date(); if (out) t_time(w); if (o.sat) t_sat1(w, pos - P_GPS1); } break;
+                case K_GPS2: if (block_crc(P_GPS2 + (pos - P_GPS2), K_GPS2)) crc |= F_GPS2; else if (o.sat) t_sat2(w, pos - P_GPS2); break;
+                case K_GPS3: err3 = gps_pos(pos - P_GPS3); if (!err3) { if (out) t_pos(w); if (o.sat) t_sat3(w, pos - P_GPS3); } break;
                 case K_XTU: ofs_ptu = pos - P_PTU; kind_ptu = kind; break;
                 case K_CRYPT: encrypted = 1; if (out) w.f(" [%04X] (RS41-SGM) ", K_CRYPT); break;
                 case K_960A: break;
                 case K_POSDT: err13 = pos_datetime(pos); if (!err13 && out) t_posdt(w); break;
-                case K_SATS: gnss_sats(pos); break;
+                case K_SATS: err2g = gnss_sats(pos); is_gnss2 = 1; break;
                 default:
                     if (blk == 0x7E) { if (!pos_aux) pos_aux = pos; }
                     if (blk != 0x76 && blk != 0x7E) { if (out) w.f(" [%04X] ", kind); }
             }
             pos += 2 + len + 2;
             if (pos > frm_end) {                               // end of the (sub)frame: PTU, configuration, trailer, JSON
-                if (o.ptu && !encrypted && kind_ptu > 0) { err0 = ptu(ofs_ptu, kind_ptu, !err3); if (!err0 && out) t_ptu(w); }
+                if (o.ptu && !o.sat && !encrypted && kind_ptu > 0) { err0 = ptu(ofs_ptu, kind_ptu, !err3); if (!err0 && out) t_ptu(w); }
                 kind_ptu = 0;
                 conf_subframe(w, out, ofs_cal);
                 if (out && ec > 0 && pos > flen - 1) w.f(" (%d)", ec);
                 if (pos_aux) aux = xdata(pos_aux);
                 crc = 0;
                 frm_end = FL - 2;
-                if (out) w.f("\n");
+                if (is_gnss2 && o.sat && !err2g) t_gnss_sat2(w);
+                if (out || o.sat) w.f("\n");
                 if (o.json && !err && ((!err1 && !err3) || !err13 || encrypted)) json(w, err0, encrypted);
             }
         }

@@ -17,14 +17,56 @@ def both(dec, args, data):
     a = subprocess.run(["host/bin/" + dec] + args, input=data, capture_output=True, env=env, timeout=60)
     b = subprocess.run(["oracle/_ref/" + dec] + args, input=data, capture_output=True, timeout=60)
     return a.returncode == b.returncode and a.stdout == b.stdout, a, b
+
+
+def _rs41_stream():
+    out = []
+    for k in range(int(rng.integers(1, 5))):
+        fr = synth.rs41_frame(100 + k, "F%07d" % int(rng.integers(0, 9999999)), week=2280, extended=bool(rng.integers(4) == 0)) if _has_ext else synth.rs41_frame(100 + k)
+        out += [synth.rs41_onair_bits(fr, preamble_bytes=int(rng.integers(4, 40))), rng.integers(0, 2, int(rng.integers(0, 400))).astype(np.uint8)]
+    return np.concatenate(out)
+
+
+def _dfm_stream():
+    bits = []
+    for k in range(int(rng.integers(2, 30))):
+        d1 = [int(v) for v in rng.integers(0, 16, 13)]; d1[12] = k % 9
+        d2 = [int(v) for v in rng.integers(0, 16, 13)]; d2[12] = int(rng.integers(0, 9))
+        bits.append(synth.dfm_frame_bits([int(v) for v in rng.integers(0, 16, 7)], d1, d2))
+    b = np.concatenate(bits)
+    sym = np.empty(2 * len(b), np.uint8); sym[0::2] = 1 - b; sym[1::2] = b
+    return sym
+
+
+def _mxx_stream(m20):
+    out = []
+    for k in range(int(rng.integers(1, 5))):
+        fr = synth.m20_frame(k) if m20 else synth.m10_frame(k, gtop=bool(rng.integers(2)), rng=np.random.default_rng(int(rng.integers(1 << 30))))
+        out += [synth.m10_symbols(data=fr), np.tile(np.array([1, 0, 0, 1], np.uint8), int(rng.integers(0, 300)))]
+    return np.concatenate(out)
+
+
+import inspect  # noqa: E402
+_has_ext = "extended" in inspect.signature(synth.rs41_frame).parameters
+
 streams = {
+ "rs41mod": _rs41_stream,
+ "dfm09mod": _dfm_stream,
+ "m10mod": lambda: _mxx_stream(False),
+ "m20mod": lambda: _mxx_stream(True),
  "lms6Xmod": lambda: np.concatenate([synth.lms6_onair_bits(3, lmsx=bool(rng.integers(2))) for _ in range(rng.integers(1, 3))]),
  "meisei100mod": lambda: synth.meisei_symbols(int(rng.integers(4, 40)), "ims100" if rng.integers(2) else "rs11g", k0=int(rng.integers(0, 200))),
  "imet54mod": lambda: synth.imet54_onair_bits(int(rng.integers(1, 4)), check=["std", "cont", "none"][rng.integers(3)], imet50=bool(rng.integers(2))),
  "mp3h1mod": lambda: synth.mrz_symbols(int(rng.integers(2, 20)), latlon=bool(rng.integers(2))),
  "mts01mod": lambda: synth.mts01_onair_bits(int(rng.integers(1, 5))),
 }
+HEXIN = {"rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
 opts = {
+ "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
+             ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
+ "dfm09mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["-i", "-r", "--ecc"], ["--ecc", "--ptu"], ["-v", "--ecc2", "--json"], ["--ecc", "-vv"]],
+ "m10mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
+ "m20mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
  "lms6Xmod": [[], ["-r"], ["--ecc"], ["--vit"], ["--vit2", "--ecc"], ["--json"], ["--json", "--vit2"], ["--lms6", "--ecc"], ["--lmsX", "--ecc", "--vit"], ["--ecc3", "--vit2"], ["--gpsweek", "2290", "--json"]],
  "meisei100mod": [[], ["-r"], ["--ecc"], ["--ecc", "-v", "--ptu"], ["--json", "--ptu"], ["-r", "--ecc", "-v"], ["--dbg"], ["--rs11g", "--ecc", "--ptu"], ["--ims100", "--json"], ["--year", "2035", "--json"]],
  "imet54mod": [[], ["-r"], ["--ecc"], ["--ecc", "-v", "--ptu"], ["--json", "--ptu"], ["-r4", "--ecc"], ["--auto", "--ecc"], ["-i", "--ecc"], ["-r", "--json"], ["--silent", "--json"]],
@@ -38,7 +80,7 @@ def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
   rng = np.random.default_rng(seed)
   bad = 0
   for it in range(iterations):
-      dec = list(streams)[it % 5]
+      dec = list(streams)[it % len(streams)]
       s = 2.0 * streams[dec]().astype(np.float64) - 1.0
       lead = 2.0 * rng.integers(0, 2, int(rng.integers(0, 200))) - 1.0
       s = np.concatenate([lead, s])
