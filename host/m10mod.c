@@ -116,10 +116,10 @@ int main(int argc, char **argv) {
             lb[2 * 121] = 0;
             char *sp = strchr(lb, ' ');
             if (sp) *sp = 0;
-            sp = strchr(lb, '\n'); if (sp) *sp = 0;
             const int len = (int)(strlen(lb) / 2);
             if (len <= 0x20 + 2) continue;
-            for (int i = 0; i < len; i++) { unsigned v = 0; sscanf(lb + 2 * i, "%2x", &v); fr.frame[i] = (uint8_t)v; }
+            static unsigned char frmbyte;                        /* keeps its value over pairs that are not hex, as the reference's does */
+            for (int i = 0; i < len; i++) { sscanf(lb + 2 * i, "%2hhx", &frmbyte); fr.frame[i] = frmbyte; }
             fr.nbits = len * 8;
             sonde_m10_frame_finish(&fr);
             emit_frame(&fr);

@@ -159,15 +159,9 @@ int main(int argc, char **argv) {
     if (rawhex) {                                    /* rs41mod.c:2976-3002: hex up to the first blank, frames longer than the ID block */
         sonde_softin_t *si = NULL;
         if (sonde_softin_create(SONDE_RS41, cfg.ecc_level, 0, 0, 0, &si) < 0) return -1;
-        char lb[2 * 518 + 12]; uint8_t fb[518]; sonde_frame_t fr;
+        char lb[2 * 518 + 12]; sonde_frame_t fr;
         while (fgets(lb, sizeof lb, fp)) {
-            lb[2 * 518] = 0;
-            char *sp = strchr(lb, ' ');
-            if (sp) *sp = 0;
-            int len = (int)(strlen(lb) / 2);
-            if (len <= 0x3D + 10) continue;
-            for (int i = 0; i < len; i++) { unsigned v = 0; sscanf(lb + 2 * i, "%2x", &v); fb[i] = (uint8_t)v; }
-            sonde_softin_push_frame(si, fb, len, xorhex);
+            sonde_softin_push_hexline(si, lb, xorhex);
             while (sonde_softin_fetch(si, &fr, 1) > 0) emit_frame(&fr);
         }
         sonde_softin_destroy(si);

@@ -318,6 +318,9 @@ int  sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n);
 int  sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n);
 /* --rawhex / --xorhex (rs41mod.c:2976-3002): one frame given as bytes (xorhex: still whitened), handed to print_frame() */
 int  sonde_softin_push_frame(sonde_softin_t *s, const uint8_t *bytes, int32_t len, int32_t xorhex);
+/* the same from the text line itself: cut at 2 * 518 characters and at the first blank, lines of 0x3D + 10 bytes or less ignored, pairs read with
+ * sscanf "%2hhx" — a pair that is not hex keeps the previous byte (after its de-whitening with --xorhex), across lines too (:2980-2999) */
+int  sonde_softin_push_hexline(sonde_softin_t *s, const char *line, int32_t xorhex);
 int  sonde_softin_finish(sonde_softin_t *s);               /* EOF: emit the frame in progress (rs41mod.c:2931,2965) */
 int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
 /* ecc_level 3 / 4 (rs41mod --softin --ecc3): frames come out uncorrected; the soft values of the frames of the last fetch

@@ -9,6 +9,7 @@
 #include "../../include/sonde_hip.h"
 #include "sonde_host.h"
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct sonde_softin {
     std::vector<sonde_dfm_frame_t> dqueue;
     int ecc_level = 1, inv_in = 0;            // inv_in: --softinv / -i applied to the stream (f32soft_read inv)
     int opt_inv = 0, opt_auto = 0;            // gpx.option.inv / .aut (rs41mod.c:2888-2891)
+    unsigned char hexbyte = 0;                // frmbyte of the --rawhex reader (:2980): keeps its value over pairs that are not hex
     float ths = 0.7f;
     float sbuf[64]; int bufpos = -1;
     char hbuf[64];                            // --bin: last header-length hard bits as '0'/'1' (hdb.buf, demod_mod.c:1668-1690)
@@ -307,6 +309,25 @@ int sonde_softin_push_frame(sonde_softin_t *s, const uint8_t *bytes, int32_t len
     s->mv = 0.f; s->hdr_bit = 0;
     emit(s, len);
     return 0;
+}
+
+int sonde_softin_push_hexline(sonde_softin_t *s, const char *line, int32_t xorhex) {
+    if (!s || !line || s->type != SONDE_RS41) return SONDE_E_ARG;
+    static thread_local char buf[2 * 518 + 12];
+    strncpy(buf, line, sizeof buf - 1); buf[sizeof buf - 1] = 0;
+    buf[2 * 518] = '\0';
+    char *sp = strchr(buf, ' ');
+    if (sp) *sp = '\0';
+    const int len = (int)strlen(buf) / 2;
+    if (len <= 0x3D + 10) return 0;
+    for (int i = 0; i < len; i++) {
+        sscanf(buf + 2 * i, "%2hhx", &s->hexbyte);
+        if (xorhex) s->hexbyte ^= kRs41Mask[i % 64];
+        s->frame[i] = s->hexbyte;
+    }
+    s->mv = 0.f; s->hdr_bit = 0;
+    emit(s, len);
+    return 1;
 }
 
 int sonde_softin_finish(sonde_softin_t *s) {               // EOF inside a frame: print_frame with the bytes that exist

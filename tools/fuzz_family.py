@@ -75,39 +75,77 @@ opts = {
 }
 
 
+def _report(dec, args, data, ra, rb, keep_dir, tag):
+    print("MISMATCH", dec, args, len(data), ra.returncode, rb.returncode)
+    if keep_dir:
+        open(os.path.join(keep_dir, f"fail_{dec}_{tag}"), "wb").write(data)
+    la, lb = ra.stdout.splitlines(), rb.stdout.splitlines()
+    for x, y in zip(la, lb):
+        if x != y:
+            print(" OUR:", x[:200]); print(" REF:", y[:200])
+            break
+    else:
+        print(" line counts", len(la), len(lb))
+
+
 def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
-  global rng
-  rng = np.random.default_rng(seed)
-  bad = 0
-  for it in range(iterations):
-      dec = list(streams)[it % len(streams)]
-      s = 2.0 * streams[dec]().astype(np.float64) - 1.0
-      lead = 2.0 * rng.integers(0, 2, int(rng.integers(0, 200))) - 1.0
-      s = np.concatenate([lead, s])
-      mode = rng.integers(4)
-      if mode == 0: s = s + rng.normal(0, rng.uniform(0, 1.2), len(s))
-      elif mode == 1:                                    # bursts
-          for _ in range(rng.integers(1, 6)):
-              p = rng.integers(0, len(s)); s[p:p + rng.integers(1, 300)] *= -1
-      elif mode == 2: s = s * rng.uniform(0.01, 100.0) + rng.normal(0, 0.3, len(s))
-      else: s[rng.integers(0, len(s), rng.integers(0, 50))] = 0.0
-      if rng.integers(3) == 0: s = -s
-      if rng.integers(3) == 0: s = s[:rng.integers(1, len(s))]
-      data = s.astype(np.float32).tobytes()
-      if rng.integers(8) == 0: data = data[:-int(rng.integers(1, 4))]
-      a = opts[dec][rng.integers(len(opts[dec]))]
-      args = ["--softinv" if rng.integers(4) == 0 else "--softin"] + a
-      ok, ra, rb = both(dec, args, data)
-      if not ok:
-          bad += 1
-          print("MISMATCH", dec, args, len(data), ra.returncode, rb.returncode)
-          if keep_dir:
-            open(os.path.join(keep_dir, f"fail_{dec}_{seed}_{it}.f32"), "wb").write(data)
-          la, lb = ra.stdout.splitlines(), rb.stdout.splitlines()
-          for x, y in zip(la, lb):
-              if x != y: print(" OUR:", x[:200]); print(" REF:", y[:200]); break
-          else: print(" line counts", len(la), len(lb))
-  return bad
+    global rng
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for it in range(iterations):
+        dec = list(streams)[it % len(streams)]
+        s = 2.0 * streams[dec]().astype(np.float64) - 1.0
+        lead = 2.0 * rng.integers(0, 2, int(rng.integers(0, 200))) - 1.0
+        s = np.concatenate([lead, s])
+        mode = rng.integers(4)
+        if mode == 0:
+            s = s + rng.normal(0, rng.uniform(0, 1.2), len(s))
+        elif mode == 1:                                    # bursts
+            for _ in range(rng.integers(1, 6)):
+                p = rng.integers(0, len(s)); s[p:p + rng.integers(1, 300)] *= -1
+        elif mode == 2:
+            s = s * rng.uniform(0.01, 100.0) + rng.normal(0, 0.3, len(s))
+        else:
+            s[rng.integers(0, len(s), rng.integers(0, 50))] = 0.0
+        if rng.integers(3) == 0:
+            s = -s
+        if rng.integers(3) == 0:
+            s = s[:rng.integers(1, len(s))]
+        data = s.astype(np.float32).tobytes()
+        if rng.integers(8) == 0:
+            data = data[:-int(rng.integers(1, 4))]
+        a = opts[dec][rng.integers(len(opts[dec]))]
+        args = ["--softinv" if rng.integers(4) == 0 else "--softin"] + a
+        form = rng.integers(4)
+        if form == 0 and dec in HEXIN:                     # hex-line input: the reference's own -r output of this stream, then damaged as text
+            raw = subprocess.run(["oracle/_ref/" + dec, "--softin"] + HEXIN[dec], input=data, capture_output=True, timeout=60).stdout
+            t = bytearray(raw)
+            for _ in range(int(rng.integers(0, 12))):
+                if not t:
+                    break
+                q = int(rng.integers(0, len(t)))
+                k = int(rng.integers(4))
+                if k == 0:
+                    t[q] = int(rng.integers(32, 127))
+                elif k == 1:
+                    del t[q:q + int(rng.integers(1, 40))]
+                elif k == 2:
+                    t[q:q] = bytes(rng.integers(32, 127, int(rng.integers(1, 30))).astype(np.uint8))
+                else:
+                    t[q:q] = b"\n"
+            data = bytes(t)
+            args = ["--rawhex"] + [x for x in a if x not in ("-i", "--auto", "--ecc3", "--ecc4")]
+        elif form == 1 and dec in ("rs41mod", "dfm09mod"):   # one byte per hard bit (fsk_demod without -s)
+            hard = (np.frombuffer(data[:len(data) // 4 * 4], np.float32) < 0).astype(np.uint8)
+            if rng.integers(3) == 0:
+                hard = hard ^ (rng.random(len(hard)) < 0.01).astype(np.uint8)
+            data = hard.tobytes()
+            args = ["--bin"] + [x for x in a if x not in ("--ecc3", "--ecc4")]
+        ok, ra, rb = both(dec, args, data)
+        if not ok:
+            bad += 1
+            _report(dec, args, data, ra, rb, keep_dir, f"{seed}_{it}.bin")
+    return bad
 
 
 if __name__ == "__main__":
