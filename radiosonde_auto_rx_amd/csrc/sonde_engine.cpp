@@ -178,7 +178,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     if (gen) {
         const size_t hl = strnlen(gen->header, sizeof gen->header);
         if (hl < 8 || hl > 64 || !(gen->baud > 0.f) || !(gen->bt > 0.f) || !(gen->h > 0.f) || gen->symlen < 1 || gen->symlen > 2 || gen->symhd < 1 || gen->symhd > gen->symlen ||
-            hl % gen->symhd || gen->hdmax < 0 || gen->bitofs < 0 || gen->nbits < 1 || gen->nbits > 8192 || gen->skip_bits < 0 || gen->slice_baud < 0.f) return SONDE_E_ARG;
+            hl % gen->symhd || gen->hdmax < 0 || gen->bitofs < -8 || gen->bitofs > 64 || gen->nbits < 1 || gen->nbits > 8192 || gen->skip_bits < 0 || gen->slice_baud < 0.f) return SONDE_E_ARG;
     }
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND && cfg->sonde_type != SONDE_GENERIC) ) return SONDE_E_ARG;
