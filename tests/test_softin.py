@@ -88,3 +88,56 @@ def test_rawhex_cli_matches_reference_lines():
                            capture_output=True, timeout=60)
         assert r.returncode == 0
         assert r.stdout.decode().splitlines() == [str(l) for l in g[key]] and len(g[key]) == 5
+
+
+def _ref_or_skip(name):
+    p = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(p):
+        pytest.skip("compiled reference not present")
+    return p
+
+
+def test_rs41_sat_and_argument_order_match_reference():
+    """`--sat` (raw GPS block contents, no PTU then: rs41mod.c:2052-2111,2279) and the order dependence of `--json` / `--ecc` (`--json` sets ecc = 2
+    where it stands, a later `--ecc` wins, :2703-2707; `--jsnsubfrm1` forces 2 afterwards, :2769-2773) — found by tools/fuzz_family.py"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    ref = _ref_or_skip("rs41mod")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    rng = np.random.default_rng(5)
+    bits = np.concatenate([synth.rs41_onair_bits(synth.rs41_frame(100 + k, ecef_cm=(418833319, 85974133, 473346430))) for k in range(3)])
+    clean = (2.0 * bits - 1.0).astype(np.float32)
+    hurt = clean.copy()
+    pos = rng.choice(np.arange(2000, len(hurt)), 55, replace=False)          # more byte errors than --ecc corrects in one of the code words
+    hurt[pos] *= -1
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    for args in (["--softin", "--sat", "-v", "--ecc2"], ["--softin", "--sat", "--ptu", "--ecc"], ["--softin", "--sat", "--silent", "--ecc2"],
+                 ["--softin", "--json", "--ecc"], ["--softin", "--ecc", "--json"], ["--softin", "--ecc3", "--jsnsubfrm1"], ["--softin", "--json", "--ecc3"]):
+        for data in (clean, hurt):
+            a = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod")] + args, input=data.tobytes(), capture_output=True, timeout=60, env=env)
+            b = subprocess.run([ref] + args, input=data.tobytes(), capture_output=True, timeout=60)
+            assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (args, a.stdout[:300], b.stdout[:300])
+    out = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "--sat", "-v", "--ecc2"], input=clean.tobytes(), capture_output=True).stdout
+    assert out.count(b"iTOW: 0x") >= 2 and out.count(b"ECEF-POS: (") >= 2 and b"prMes:" in out
+
+
+@pytest.mark.parametrize("dec,opts", [("rs41mod", ["-r", "--ecc2"]), ("rs41mod", ["--xorhex", "-r", "--ecc"]), ("m10mod", ["-r", "-v"]), ("m20mod", ["-vv"])])
+def test_rawhex_lines_with_non_hex_characters(dec, opts):
+    """a pair of characters that is not hex keeps the previous byte (the reference's sscanf leaves its variable alone, rs41mod.c:2995, m10mod.c:1539,
+    m20mod.c:1405), also across lines; odd lengths, blanks, text behind the frame — found by tools/fuzz_family.py"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    ref = _ref_or_skip(dec)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    if dec == "rs41mod":
+        h = synth.rs41_frame(7).hex()
+    else:
+        h = (synth.m10_frame(3, rng=np.random.default_rng(3)) if dec == "m10mod" else synth.m20_frame(3)).hex()
+    lines = [h, h[:60] + "zz" + h[62:], h[:61], "xy" + h[2:200] + " [OK] tail", h[:100] + "g" + h[101:] + "\n" + "q" * 80, h[:2 * 40] + "  " + h[2 * 41:], "", "#" * 300]
+    data = ("\n".join(lines) + "\n").encode()
+    args = ([] if "--xorhex" in opts else ["--rawhex"]) + opts
+    a = subprocess.run([os.path.join(ROOT, "host", "bin", dec)] + args, input=data, capture_output=True, timeout=60)
+    b = subprocess.run([ref] + args, input=data, capture_output=True, timeout=60)
+    assert a.returncode == b.returncode == 0 and a.stdout == b.stdout and a.stdout, (a.stdout[:300], b.stdout[:300])
