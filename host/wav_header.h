@@ -39,6 +39,7 @@ static int wav_read_header(FILE *fp, int *sr, int *bits, int *nch) {
     fprintf(stderr, "bits       : %d\n", *bits);
     fprintf(stderr, "channels   : %d\n", *nch);
     if (*bits != 8 && *bits != 16 && *bits != 32) return -1;
+    if (*sr == 900001) *sr -= 1;                    /* demod_mod.c:369 (printed as read, used as 900000) */
     return 0;
 }
 #endif
