@@ -1,4 +1,4 @@
-"""One wideband IQ stream -> every RS41, DFM, M10 and M20 in it, in one process on one GPU.
+"""One wideband IQ stream -> every RS41, DFM, M10, M20 (and LMS6, iMet-54, Meisei, MRZ, MTS01) in it, in one process on one GPU.
 
 The reference handles a wideband source by starting one detector process per candidate peak (auto_rx/autorx/scan.py:413-656:
 rtl_power peaks -> `dft_detect` per peak) and then one decoder pipeline per sonde (decode.py).  Here the same two steps run
@@ -48,7 +48,12 @@ class WidebandReceiver:
                 return
         fq = snap_fq(fq, self.sr)
         khz = int(round((self.cfreq + fq * self.sr) / 1000.0)) if self.cfreq else 0
-        if typ == "DFM":
+        if typ in FAMILY:                                      # generic sonde description + the type's bit-rate tier (family.py)
+            f = FAMILY[typ]
+            eng = Engine([fq], self.sr, sonde="generic", generic=f["generic"], thres=f["thres"], auto=f["auto"], keep_soft=True, lp_iq=True,
+                         max_chunk=self.chunk, max_frames=8)
+            tel = FamilyDecoder(typ, freq_khz=khz, version=self.version)
+        elif typ == "DFM":
             eng = Engine([fq], self.sr, sonde="dfm", ecc=1, auto=True, max_chunk=self.chunk, max_frames=8)
             tel = DfmTelemetry(freq_khz=khz, version=self.version)
         elif typ in ("M10", "M20"):
@@ -78,6 +83,8 @@ class WidebandReceiver:
                     self._start(self.raster[d["channel"]] + d["df"], "DFM")
                 elif d["type"] in ("M10", "M20"):                           # differential code: polarity does not matter
                     self._start(self.raster[d["channel"]] + d["df"], d["type"])
+                elif d["type"] in FAMILY and (d["score"] > 0 or FAMILY[d["type"]]["auto"]):
+                    self._start(self.raster[d["channel"]] + d["df"], d["type"])
             for s in self.sondes:
                 s["engine"].process_host(x)
                 out += self._drain(s, False)
@@ -89,6 +96,12 @@ class WidebandReceiver:
     @staticmethod
     def _drain(s, finish):
         e = s["engine"]
+        if s["type"] in FAMILY:
+            out = []
+            for h in e.fetch_hits(finish=finish):
+                s["frames"] += 1
+                out += FamilyDecoder.json_objects(s["telemetry"].hit(h, e.info["if_sr"]))
+            return out
         frames = e.fetch_dfm(finish=finish) if s["type"] == "DFM" else e.fetch_mxx(finish=finish) if s["type"] in ("M10", "M20") else e.fetch_frames(finish=finish)
         out = []
         for fr in frames:

@@ -353,3 +353,26 @@ def test_channelized_receiver_decodes_the_generic_family():
     assert len(im) >= 2 and all(j["id"] == "IMET5-54012345" and abs(j["lat"] - 52.1236) < 1e-3 for j in im), im[:1]
     me = [j for j in out if j["type"] == "MEISEI"]
     assert len(me) >= 1 and all(j["subtype"] == "IMS100" and abs(j["lat"] - 35.2058) < 1e-3 for j in me), me[:1]      # one object per second once a frame pair is in
+
+
+def test_wideband_receiver_decodes_the_generic_family():
+    """the raster receiver (SDR-rate stream, one `--IQ fq` engine per sonde) with an LMS6 and an iMet-54 in a 2.4 Msps stream"""
+    from tools import synth
+    from radiosonde_auto_rx_amd.wideband import WidebandReceiver
+    sr, cf, secs = 2_400_000, 403_000_000, 4.4
+    n = int(sr * secs)
+    fa, fb = synth.snap_fq(0.125, sr), synth.snap_fq(-0.2, sr)
+    acc = synth.lms6_capture(sr=sr, seconds=secs, fq=fa, noise_sigma=0.0, amp=0.25, seed=95).astype(np.float64)[:2 * n]
+    acc = acc + synth.imet54_capture(sr=sr, seconds=secs, fq=fb, noise_sigma=0.0, amp=0.25, seed=96).astype(np.float64)[:2 * n]
+    acc += np.random.default_rng(94).normal(0.0, 80.0, size=2 * n)
+    iq = np.clip(np.round(acc), -32768, 32767).astype(np.int16)
+    rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000)
+    out = rx.push(iq, finish=True)
+    kinds = sorted(s["type"] for s in rx.sondes)
+    log = list(rx.log)
+    rx.close()
+    assert "LMS6" in kinds and "IMET5" in kinds, log
+    lms = [j for j in out if j["type"] == "LMS"]
+    im = [j for j in out if j["type"] == "IMET5"]
+    assert len(lms) >= 2 and all(j["id"] == "LMS6-8123456" and abs(j["freq"] - 403_300) <= 3 for j in lms), lms[:1]
+    assert len(im) >= 2 and all(j["id"] == "IMET5-54012345" and abs(j["freq"] - 402_520) <= 3 for j in im), im[:1]
