@@ -232,7 +232,7 @@ struct sonde_dfm_dec {
 
         if (!o.raw || o.json) {
             to_gps_week(year, month, day, hour, minute, (int)(sec + 0.5), &week, &tow);
-            sec_gps = (uint32_t)(week * 604800 + tow);
+            sec_gps = (uint32_t)week * 604800u + (uint32_t)tow;      // the reference's int product wraps for garbage dates; the same bits without the overflow
             if (contgps) {
                 int diff = (int)(uint8_t)sec_gps - frnr;
                 if (diff < 0) diff += 256;

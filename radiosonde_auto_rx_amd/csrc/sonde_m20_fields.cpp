@@ -43,7 +43,7 @@ struct sonde_m20_dec {
     int gps() {
         int err = 0;
         int t = fb[0x0F] << 16 | fb[0x10] << 8 | fb[0x11];
-        tow_ms = t * 1000;
+        tow_ms = (int)((uint32_t)t * 1000u);             // 24-bit seconds * 1000 wraps in the reference's int for garbage frames; same bits, defined
         gpssec = t;
         const int d = t / 86400;
         if (d < 0 || d > 6) err = -1;
@@ -85,7 +85,9 @@ struct sonde_m20_dec {
         month = (int)(M + 2 - 12 * J);
         year = (int)(100 * (C - 49) + Y + J);
     }
+    uint8_t snraw[3] = { 0, 0, 0 };            // gpx_t.SNraw: sits directly in front of frame_bytes in the reference (m20mod.c:112-113)
     void serial() {
+        snraw[0] = fb[0x12]; snraw[1] = fb[0x13]; snraw[2] = fb[0x14];
         const uint32_t sn = (uint32_t)(fb[0x14] << 16 | fb[0x13] << 8 | fb[0x12]);
         const unsigned ym = sn & 0x7F, y = (ym / 12) & 0xFF, m = ((ym % 12) + 1) & 0xFF;
         for (int i = 0; i < 11; i++) SN[i] = ' ';
@@ -213,9 +215,14 @@ int sonde_m20_dec_frame(sonde_m20_dec_t *d, const sonde_m20_frame_t *f, char *ou
     if (!d || !f || !out || outlen < 1) return SONDE_E_ARG;
     d->fb = f->frame;
     d->fw = f->fw;
+    int cs_ok = f->cs_ok;
+    if (f->frame[0] == 0) {                    // length byte 0: check word and firmware byte are read from in front of the frame buffer (:897-901) =
+        cs_ok = d->snraw[2] == 0;              // the serial number bytes of the last frame that was printed
+        d->fw = d->snraw[1] > 0x20 ? 0 : d->snraw[1];
+    }
     switch (f->frame[1]) { case 0x8F: d->type = 0x8F; break; case 0x9F: d->type = 0x9F; break; case 0xAF: d->type = 0xAF; break; case 0x20: d->type = 0x20; break; default: d->type = 0x9F; }
     Out w;
-    if (!d->o.raw || d->o.silent) d->print(w, f->blk_ok, f->cs_ok);
+    if (!d->o.raw || d->o.silent) d->print(w, f->blk_ok, cs_ok);
     if (w.s.size() + 1 > outlen) return SONDE_E_ARG;
     memcpy(out, w.s.c_str(), w.s.size() + 1);
     return (int)w.s.size();

@@ -12,11 +12,17 @@ sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402
 
-env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+env = dict(os.environ, SONDE_JSN_VERSION="oracle", ASAN_OPTIONS="detect_leaks=0")
+BIN = os.environ.get("FUZZ_BIN_DIR", "host/bin")       # e.g. an AddressSanitizer / UBSan build of the front ends and the host-only library sources
+
+
 def both(dec, args, data):
-    a = subprocess.run(["host/bin/" + dec] + args, input=data, capture_output=True, env=env, timeout=60)
+    a = subprocess.run([os.path.join(BIN, dec)] + args, input=data, capture_output=True, env=env, timeout=120)
     b = subprocess.run(["oracle/_ref/" + dec] + args, input=data, capture_output=True, timeout=60)
-    return a.returncode == b.returncode and a.stdout == b.stdout, a, b
+    clean = b"Sanitizer" not in a.stderr and b"runtime error" not in a.stderr
+    if not clean:
+        print(a.stderr.decode(errors="replace")[:1500])
+    return a.returncode == b.returncode and a.stdout == b.stdout and clean, a, b
 
 
 def _rs41_stream():
@@ -123,7 +129,7 @@ def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
             for _ in range(int(rng.integers(0, 12))):
                 if not t:
                     break
-                q = int(rng.integers(0, len(t)))
+                q = int(rng.integers(2, max(3, len(t))))           # not the very first pair: the reference's byte variable starts uninitialised
                 k = int(rng.integers(4))
                 if k == 0:
                     t[q] = int(rng.integers(32, 127))
