@@ -93,7 +93,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--ecc3")) cfg.ecc_level = 3;               /* erasures + bit toggling from the soft bits (rs41mod.c:1861-1941) */
         else if (!strcmp(a, "--ecc4")) cfg.ecc_level = 4;               /* + bytes known from earlier frames (rs41mod.c:1764-1849) */
         else if (!strcmp(a, "--crc")) { /* block CRCs are always evaluated by the field decode */ }
-        else if (!strcmp(a, "-v")) dopt.verbose = 1;
+        else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) dopt.verbose = 1;
+        else if (!strcmp(a, "-vx")) dopt.verbose = 2;                   /* + the xdata text */
+        else if (!strcmp(a, "-vv")) dopt.verbose = 3;                   /* + battery, week, sats, every subframe's bytes */
         else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
         else if (!strcmp(a, "--ptu2")) dopt.ptu = 2;
         else if (!strcmp(a, "--dewp")) dopt.dewp = 1;

@@ -25,7 +25,7 @@ extern "C" {
 typedef struct sonde_rs41_dec sonde_rs41_dec_t;
 
 typedef struct {
-    int32_t verbose;        /* 0, or 1 for -v (frequency / firmware / sub-type / timers as their subframes arrive)   */
+    int32_t verbose;        /* 0, 1 = -v (frequency / firmware / sub-type / timers as their subframes arrive), 2 = -vx (+ xdata text), 3 = -vv (+ battery, week, sats, subframe bytes) */
     int32_t ptu;            /* 0, 1 = --ptu, 2 = --ptu2 (rs41mod.c:2650-2651)                                         */
     int32_t dewp;           /* --dewp: dew point next to the PTU values (rs41mod.c:2000-2010)                         */
     int32_t json;           /* --json                                                                                 */

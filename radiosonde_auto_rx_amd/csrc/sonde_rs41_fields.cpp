@@ -352,8 +352,13 @@ struct sonde_rs41_dec {
     void conf_subframe(Out &w, int out, int ofs) {
         subfrm_pos = P_CAL + ofs;
         const int k = fr[P_CAL + ofs];
-        if (block_crc(P_STATUS + ofs, K_STATUS)) return;
         const uint8_t *c = fr + P_CAL + ofs;                   // c[0] = subframe number, c[1..16] = its bytes
+        if (out && o.verbose == 3) {                           // -vv: the subframe bytes, before the CRC is looked at (:1565-1578)
+            w.f("\n"); w.f("[%5d] ", frnr); w.f(" 0x%02x: ", k);
+            for (int i = 0; i < 16; i++) w.f("%02x ", c[1 + i]);
+            w.f(" ");
+        }
+        if (block_crc(P_STATUS + ofs, K_STATUS)) return;
         if (k == 0x00) {
             const int f0 = ((c[3] & 0xC0) * 10) / 64, f1 = 40 * c[4];
             freq = 400000 + f1 + f0;
@@ -367,15 +372,19 @@ struct sonde_rs41_dec {
         }
         if (k == 0x31) {
             bt = (uint16_t)(c[7] + (c[8] << 8));
-            if (out && bt != 0 && o.verbose && bk) w.f(": bt %.1fmin ", bt / 60.0);
+            if (out && bt != 0 && (o.verbose == 3 || (o.verbose && bk))) w.f(": bt %.1fmin ", bt / 60.0);
         }
         if (k == 0x32) {
             cd = (uint16_t)(c[1] + (c[2] << 8));
-            if (out && cd != 0xFFFF && o.verbose && (bk || kt != 0xFFFF)) w.f(": cd %.1fmin ", cd / 60.0);
+            if (out && cd != 0xFFFF && (o.verbose == 3 || (o.verbose && (bk || kt != 0xFFFF)))) w.f(": cd %.1fmin ", cd / 60.0);
         }
         if (k == 0x21) {
             memset(rstmp, 0, sizeof rstmp);
             for (int i = 0; i < 8; i++) { const uint8_t b = c[9 + i]; if (b >= 0x20 && b < 0x7F) rstmp[i] = (char)b; else if (b == 0) rstmp[i] = 0; }
+            if (out && o.verbose == 3) {                       // station pressure; read at the standard position, without the block offset (:1634-1635)
+                float q1, q2; memcpy(&q1, fr + P_CAL + 1, 4); memcpy(&q2, fr + P_CAL + 5, 4);
+                if (q1 > 0.0 || q2 > 0.0) { w.f(" "); if (q1 > 0.0) w.f("QFE1:%.1fhPa ", q1); if (q2 > 0.0) w.f("QFE2:%.1fhPa ", q2); }
+            }
         }
         if (k == 0x22) {
             const uint8_t b = c[1];
@@ -390,7 +399,7 @@ struct sonde_rs41_dec {
     }
 
     // ---- xdata -------------------------------------------------------------------------------------------------------
-    int xdata(int pos) {
+    int xdata(int pos, Out *w = nullptr) {                     // w: -vx / -vv print the text as it is collected (:1492-1506)
         int n = 0, last = 0, cnt = 0;
         xd[0] = 0;
         if (frametype() <= 0) {
@@ -399,8 +408,9 @@ struct sonde_rs41_dec {
             while (pos + 1 < FL && fr[pos] == 0x7E) {
                 const int len = fr[pos + 1];
                 if (pos + len + 4 <= FL && (int)(fr[pos + 2 + len] | fr[pos + 3 + len] << 8) == crc16(fr + pos + 2, len)) {
-                    if (cnt && n < cap) xd[n++] = '#';
-                    for (int i = 1; i < len; i++) { const uint8_t ch = fr[pos + 2 + i]; if (ch > 0x1E && ch < 0x7F && n < cap) xd[n++] = (char)ch; }
+                    if (!cnt) { if (w) w->f("\n # xdata = "); }
+                    else { if (w) w->f(" # "); if (n < cap) xd[n++] = '#'; }
+                    for (int i = 1; i < len; i++) { const uint8_t ch = fr[pos + 2 + i]; if (ch > 0x1E && ch < 0x7F) { if (w) w->f("%c", ch); if (n < cap) xd[n++] = (char)ch; } }
                     cnt++; last = pos; pos += 2 + len + 2;
                 } else { pos = FL; crc |= F_AUX; }
             }
@@ -411,15 +421,17 @@ struct sonde_rs41_dec {
     }
 
     // ---- text pieces (prn_frm / prn_gpstime / prn_gpspos / prn_posdatetime / prn_ptu, :1978-2050) ----------------------
-    void t_frame(Out &w) const { w.f("[%5d] ", frnr); w.f("(%s) ", id); w.f(" "); }
+    void t_frame(Out &w) const { w.f("[%5d] ", frnr); w.f("(%s) ", id); if (o.verbose == 3) w.f("(%.1f V) ", batt); w.f(" "); }
     void t_time(Out &w) const {
         w.f("%s ", kDay[((wday % 7) + 7) % 7]);
         w.f("%04d-%02d-%02d %02d:%02d:%06.3f", year, month, day, hour, minute, sec);
+        if (o.verbose == 3) w.f(" (W %d)", week);
         w.f(" ");
     }
     void t_pos(Out &w) const {
         w.f(" lat: %.5f ", lat); w.f(" lon: %.5f ", lon); w.f(" alt: %.2f ", alt);
         w.f("  vH: %4.1f  D: %5.1f  vV: %3.1f ", vH, vD, vV);
+        if (o.verbose == 3) w.f(" sats: %02d ", numSV);
     }
     void t_posdt(Out &w) const {
         w.f("%04d-%02d-%02d %02d:%02d:%05.2f", year, month, day, hour, minute, sec);
@@ -548,7 +560,7 @@ struct sonde_rs41_dec {
                 kind_ptu = 0;
                 conf_subframe(w, out, ofs_cal);
                 if (out && ec > 0 && pos > flen - 1) w.f(" (%d)", ec);
-                if (pos_aux) aux = xdata(pos_aux);
+                if (pos_aux) aux = xdata(pos_aux, (out && o.verbose > 1) ? &w : nullptr);
                 crc = 0;
                 frm_end = FL - 2;
                 if (is_gnss2 && o.sat && !err2g) t_gnss_sat2(w);
@@ -757,7 +769,7 @@ struct sonde_rs41_dec {
 extern "C" {
 
 int sonde_rs41_dec_create(const sonde_rs41_opts_t *opts, sonde_rs41_dec_t **out) {
-    if (!opts || !out || opts->verbose < 0 || opts->verbose > 1 || opts->ptu < 0 || opts->ptu > 2 || opts->jsn_subfrm < 0 || opts->jsn_subfrm > 2)
+    if (!opts || !out || opts->verbose < 0 || opts->verbose > 3 || opts->ptu < 0 || opts->ptu > 2 || opts->jsn_subfrm < 0 || opts->jsn_subfrm > 2)
         return SONDE_E_ARG;
     sonde_rs41_dec *d = new sonde_rs41_dec();
     d->o = *opts;

@@ -98,7 +98,8 @@ def _ref_or_skip(name):
 
 
 def test_rs41_sat_and_argument_order_match_reference():
-    """`--sat` (raw GPS block contents, no PTU then: rs41mod.c:2052-2111,2279) and the order dependence of `--json` / `--ecc` (`--json` sets ecc = 2
+    """`--sat` (raw GPS block contents incl. the newer GNSS block, no PTU then: rs41mod.c:2052-2111,1221-1260,2279), `-vx` / `-vv` (xdata text, battery,
+    week, sats, subframe bytes, QFE: :1565-1578,1981,2018,2029,1492-1506) and the order dependence of `--json` / `--ecc` (`--json` sets ecc = 2
     where it stands, a later `--ecc` wins, :2703-2707; `--jsnsubfrm1` forces 2 afterwards, :2769-2773) — found by tools/fuzz_family.py"""
     import sys
     sys.path.insert(0, ROOT)
@@ -106,20 +107,23 @@ def test_rs41_sat_and_argument_order_match_reference():
     ref = _ref_or_skip("rs41mod")
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     rng = np.random.default_rng(5)
-    bits = np.concatenate([synth.rs41_onair_bits(synth.rs41_frame(100 + k, ecef_cm=(418833319, 85974133, 473346430))) for k in range(3)])
+    cal = synth.rs41_cal_table(3)
+    bits = np.concatenate([synth.rs41_onair_bits(synth.rs41_frame(k, cal_table=cal, ptu_counts=True, xdata=["0511AABB", "01OZONE"] if k % 2 else None, gnss2=(k > 33),
+                                                                  ecef_cm=(418833319, 85974133, 473346430))) for k in (0, 1, 2, 33, 34, 49, 50)])
     clean = (2.0 * bits - 1.0).astype(np.float32)
     hurt = clean.copy()
     pos = rng.choice(np.arange(2000, len(hurt)), 55, replace=False)          # more byte errors than --ecc corrects in one of the code words
     hurt[pos] *= -1
     env = dict(os.environ, SONDE_JSN_VERSION="oracle")
     for args in (["--softin", "--sat", "-v", "--ecc2"], ["--softin", "--sat", "--ptu", "--ecc"], ["--softin", "--sat", "--silent", "--ecc2"],
+                 ["--softin", "-vv", "--ecc2", "--ptu"], ["--softin", "-vx", "--ecc2"], ["--softin", "-vv", "--sat", "--ecc2"],
                  ["--softin", "--json", "--ecc"], ["--softin", "--ecc", "--json"], ["--softin", "--ecc3", "--jsnsubfrm1"], ["--softin", "--json", "--ecc3"]):
         for data in (clean, hurt):
             a = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod")] + args, input=data.tobytes(), capture_output=True, timeout=60, env=env)
             b = subprocess.run([ref] + args, input=data.tobytes(), capture_output=True, timeout=60)
             assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (args, a.stdout[:300], b.stdout[:300])
     out = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod"), "--softin", "--sat", "-v", "--ecc2"], input=clean.tobytes(), capture_output=True).stdout
-    assert out.count(b"iTOW: 0x") >= 2 and out.count(b"ECEF-POS: (") >= 2 and b"prMes:" in out
+    assert out.count(b"iTOW: 0x") >= 2 and out.count(b"ECEF-POS: (") >= 2 and b"prMes:" in out and b"numSV168" in out
 
 
 @pytest.mark.parametrize("dec,opts", [("rs41mod", ["-r", "--ecc2"]), ("rs41mod", ["--xorhex", "-r", "--ecc"]), ("m10mod", ["-r", "-v"]), ("m20mod", ["-vv"])])

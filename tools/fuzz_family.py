@@ -26,9 +26,19 @@ def both(dec, args, data):
 
 
 def _rs41_stream():
+    """a few frames of one sonde: calibration table cycling through its subframes, physical PTU counts, sometimes xdata blocks (518-byte frames),
+    sometimes the newer GNSS block layout"""
     out = []
-    for k in range(int(rng.integers(1, 5))):
-        fr = synth.rs41_frame(100 + k, "F%07d" % int(rng.integers(0, 9999999)), week=2280, extended=bool(rng.integers(4) == 0)) if _has_ext else synth.rs41_frame(100 + k)
+    cal = synth.rs41_cal_table(int(rng.integers(1, 1000)))
+    sid = "F%07d" % int(rng.integers(0, 9999999))
+    k0 = int(rng.integers(0, 5000))
+    gnss2 = bool(rng.integers(4) == 0)
+    for k in range(int(rng.integers(1, 6))):
+        xd = None
+        if rng.integers(4) == 0:
+            xd = ["%02X%s" % (int(rng.integers(1, 9)), "".join(chr(int(c)) for c in rng.integers(0x30, 0x5A, int(rng.integers(4, 30))))) for _ in range(int(rng.integers(1, 4)))]
+        fr = synth.rs41_frame(k0 + k, sid, cal_table=cal, ptu_counts=True, xdata=xd, gnss2=gnss2, ecef_cm=(418833319, 85974133, 473346430) if rng.integers(4) else (0, 0, 0),
+                              rng=np.random.default_rng(int(rng.integers(1 << 30))))
         out += [synth.rs41_onair_bits(fr, preamble_bytes=int(rng.integers(4, 40))), rng.integers(0, 2, int(rng.integers(0, 400))).astype(np.uint8)]
     return np.concatenate(out)
 
@@ -52,9 +62,6 @@ def _mxx_stream(m20):
     return np.concatenate(out)
 
 
-import inspect  # noqa: E402
-_has_ext = "extended" in inspect.signature(synth.rs41_frame).parameters
-
 streams = {
  "rs41mod": _rs41_stream,
  "dfm09mod": _dfm_stream,
@@ -69,7 +76,7 @@ streams = {
 HEXIN = {"rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
 opts = {
  "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
-             ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
+             ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
  "dfm09mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["-i", "-r", "--ecc"], ["--ecc", "--ptu"], ["-v", "--ecc2", "--json"], ["--ecc", "-vv"]],
  "m10mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
  "m20mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
