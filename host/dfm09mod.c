@@ -22,8 +22,8 @@ static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slice
 
 static int make_decoder(sonde_dfm_opts_t *o, int raw, int ecc, int opt_auto, int khz) {
     const char *ver = getenv("SONDE_JSN_VERSION");
-    g_raw = raw; g_ecc = ecc;
-    if (raw && !o->json) return 0;
+    g_raw = raw == 1; g_ecc = ecc;
+    if (raw == 1 && !o->json) return 0;
     o->raw = raw; o->ecc = ecc; o->opt_auto = opt_auto; o->jsn_freq_khz = khz;
 #ifdef VER_JSN_STR
     if (!ver) ver = VER_JSN_STR;
@@ -56,6 +56,8 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
+        else if (!strcmp(a, "-R") || !strcmp(a, "--RAW")) raw = 2;          /* data packets as hex (dfm09mod.c:972-981) */
+        else if (!strcmp(a, "--rawecc")) raw = 9;                          /* frame bits before the Hamming decoder (:1177-1196; decode.py:1078) */
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
         else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) dopt.verbose = 1;

@@ -28,7 +28,8 @@ typedef struct {
     int32_t dist;           /* --dist: output only when packets 0,1,2,3,4,8 of the last 6 frames are all good         */
     int32_t json;           /* --json                                                                                 */
     int32_t sat;            /* --sat: geoid separation / satellites line                                              */
-    int32_t raw;            /* -r given as well: the caller prints the raw line, the text line is suppressed          */
+    int32_t raw;            /* 1 = -r given as well: the caller prints the raw line (sonde_dfm_rawline), the text line is suppressed;
+                             * 2 = -R: the nine data packets as hex instead of the text line; 9 = --rawecc: the frame bits as sliced, as hex  */
     int32_t opt_auto;       /* --auto (only changes the "<+> " / "<-> " prefix of -vv)                                */
     int32_t jsn_freq_khz;   /* (--jsn_cfq + 500) / 1000, 0 = none (dfm09mod.c:1516)                                   */
     char    version[32];    /* "version" of the JSON (VER_JSN_STR of the reference build); "" = omit                  */

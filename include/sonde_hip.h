@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SONDE_ABI_VERSION 2          /* 2: sonde_cfg_t.if_tune, sonde_generic_t.slice_baud, sonde_fsk_frame_t.f_est[4] */
+#define SONDE_ABI_VERSION 3          /* 2: sonde_cfg_t.if_tune, sonde_generic_t.slice_baud, sonde_fsk_frame_t.f_est[4]; 3: sonde_dfm_frame_t.rawbits */
 
 /* error codes */
 #define SONDE_E_ARG      (-1)   /* bad argument / unsupported option combination          */
@@ -128,6 +128,10 @@ typedef struct {
     float    frm_count;      /* gpx._frmcnt: mv_pos / (2 sps 280) + frame_in_hit, or headers seen * 8 + frame_in_hit for
                               * soft / hard bit input (dfm09mod.c:1658-1663) — the time stamp of the telemetry decoder */
     int32_t  inv;            /* polarity in effect for this frame (gpx.option.inv after -i / --auto)        */
+    uint8_t  rawbits[35];    /* the 280 hard bits of the frame as sliced (bit i = rawbits[i >> 3] >> (i & 7)), before the Hamming decoder —
+                              * what `--rawecc` prints (dfm09mod.c:1177-1196); bits 0..15 of frame 0 of a hit are not sliced (the header
+                              * was consumed by the correlator): 0 here, the telemetry decoder keeps the previous frame's like the reference */
+    uint8_t  pad2;
 } sonde_dfm_frame_t;
 
 /* Derived constants of init_buffers() (demod_mod.c:1208-1474), for callers and tests. */

@@ -62,12 +62,17 @@ struct sonde_dfm_dec {
     struct { uint32_t prn; float dMSL; uint8_t nSV, nPRN; } gps = {0, 0.f, 0, 0};
     int prev_cntsec_diff = 0, prev_manpol = 0;
 
+    char dat_str[9][14] = {};
+    uint8_t hdr_bits[16] = { 0, 1, 0, 0, 0, 1, 0, 1, 1, 1, 0, 0, 1, 1, 1, 1 };      // gpx.frame[0..15]: the header to begin with (:1503-1506); not read for frame 0 of a hit, so there they are the previous frame's (:1649-1650,1710)
+
     void reset_cfg() { memset(have24, 0, sizeof have24); cfgchk = 0; ptu_out = 0; SN_out[0] = 0; T = -273.15f; }
 
     // ---- data packets ------------------------------------------------------------------------------------------------------
     int data_packet(const uint8_t *b, int ec) {
         const int id = (int)field(b + 48, 4);
         if (id >= 0 && id <= 8) {
+            for (int i = 0; i < 13; i++) { const unsigned nb = field(b + 4 * i, 4); dat_str[id][i] = (char)(nb < 0xA ? 0x30 + nb : 0x41 + nb - 0xA); }      // -R (:360-365)
+            dat_str[id][13] = 0;
             pck[id].ts = frmcnt;
             if (o.ecc) {
                 pck[id].ec = ec;
@@ -247,6 +252,11 @@ struct sonde_dfm_dec {
             }
         }
         if (output & 0xF000) {
+            if (o.raw == 2) {                                  // -R: the nine data packets as hex (:972-981)
+                for (int i = 0; i < 9; i++) { w.f(" %s", dat_str[i]); if (o.ecc) w.f(" (%1X) ", pck[i].ec & 0xF); }
+                for (int i = 0; i < 9; i++) for (int j = 0; j < 13; j++) dat_str[i][j] = ' ';
+                w.f("\n");
+            }
             if (!o.raw) {
                 if (o.opt_auto && o.verbose >= 2) w.f("<%c> ", inv ? '-' : '+');
                 w.f("[%3d] ", frnr);
@@ -334,6 +344,31 @@ int sonde_dfm_dec_frame(sonde_dfm_dec_t *d, const sonde_dfm_frame_t *f, char *ou
     d->frmcnt = f->frm_count;
     d->inv = f->inv ? 1 : 0;
     Out w;
+    {   // --rawecc (:1177-1196): the frame's bits as sliced, as hex nibbles (LSB first), if its 16 header bits are intact
+        static const char kHdr[] = "0100010111001111";
+        uint8_t fb[280];
+        for (int i = 0; i < 280; i++) fb[i] = (f->rawbits[i >> 3] >> (i & 7)) & 1;
+        if (f->frame_in_hit == 0) memcpy(fb, d->hdr_bits, 16); else memcpy(d->hdr_bits, fb, 16);
+        if (d->o.raw == 9) {
+            int diff = 0;
+            for (int i = 0; i < 16; i++) diff += (fb[i] != (kHdr[i] & 1));
+            if (diff == 0) {
+                unsigned nb = 0;
+                w.f("%c", d->inv ? '-' : '+'); w.f("<%7.1f>  ", d->frmcnt);
+                for (int i = 16; i < 280; i++) {
+                    if (i == 72 || i == 176) w.f(" ");
+                    nb |= (unsigned)fb[i] << (i % 4);
+                    if (i % 4 == 3) { w.f("%1X", nb & 0xF); nb = 0; }
+                }
+                w.f("\n");
+            }
+        }
+    }
+    if ((d->o.raw & 1) == 1 && !d->o.json) {                    // -r / --rawecc without --json: no telemetry tier (:1239)
+        if (w.s.size() + 1 > outlen) return SONDE_E_ARG;
+        memcpy(out, w.s.c_str(), w.s.size() + 1);
+        return (int)w.s.size();
+    }
     const auto take = [&](int ret) { return !d->o.ecc || ret >= 0 || d->o.ecc == 2; };      // uncorrectable packets are skipped unless --ecc2
     if (take(f->ecc[0])) d->conf_packet(conf, f->ecc[0]);
     for (int k = 0; k < 2; k++)

@@ -819,6 +819,7 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
             o.channel = r.channel; o.frame_in_hit = f; o.mv = r.mv; o.mv_pos = rel_pos(e, r);
             o.frm_count = (float)(rel_pos(e, r) / (2.0 * e->sps * 280) + f);   // gpx._frmcnt (dfm09mod.c:1662)
             o.inv = r.mv < 0.f;                                            // an accepted header has the sign of the polarity in effect
+            for (int i = 0; i < 280; i++) o.rawbits[i >> 3] |= (uint8_t)(hb[i] << (i & 7));
             o.ecc[0] = dfm_block(e->cfg.ecc_level, hb + 16, sf + 16, 7, o.conf);
             o.ecc[1] = dfm_block(e->cfg.ecc_level, hb + 72, sf + 72, 13, o.dat1);
             o.ecc[2] = dfm_block(e->cfg.ecc_level, hb + 176, sf + 176, 13, o.dat2);

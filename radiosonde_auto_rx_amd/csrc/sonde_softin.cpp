@@ -89,6 +89,7 @@ int sonde_softin_create(int32_t sonde_type, int32_t ecc_level, int32_t invert_st
     sonde_softin *s = new sonde_softin();
     s->type = sonde_type;
     memset(s->dsb, 0, sizeof s->dsb); memset(s->dhb, 0, sizeof s->dhb); memset(s->dsf, 0, sizeof s->dsf);
+    { static const char kDfmHdr[] = "0100010111001111"; for (int i = 0; i < 16; i++) s->dhb[i] = (uint8_t)(kDfmHdr[i] & 1); }      // dfm09mod.c:1503-1506
     s->ecc_level = ecc_level; s->inv_in = invert_stream ? 1 : 0; s->opt_inv = opt_inv ? 1 : 0; s->opt_auto = opt_auto ? 1 : 0;
     memset(s->sbuf, 0, sizeof s->sbuf); memset(s->frame, 0, sizeof s->frame); memset(s->hbuf, 0, sizeof s->hbuf);
     memcpy(s->frame, kRs41HeaderBytes, 8);
@@ -178,6 +179,7 @@ int sonde_softin_push(sonde_softin_t *s, const float *soft, int32_t n) {
                     sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
                     o.channel = 0; o.frame_in_hit = s->dfrm; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
                     o.frm_count = (float)(s->hdrcnt + (uint32_t)s->dfrm); o.inv = s->opt_inv;
+                    for (int i = 0; i < 280; i++) o.rawbits[i >> 3] |= (uint8_t)((s->dhb[i] & 1) << (i & 7));
                     o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
                     o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
                     o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);
@@ -278,6 +280,7 @@ int sonde_softin_push_bits(sonde_softin_t *s, const uint8_t *bits, int32_t n) {
                 sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
                 o.channel = 0; o.frame_in_hit = s->dfrm; o.mv = s->mv; o.mv_pos = (uint32_t)s->hdr_bit;
                 o.frm_count = (float)(s->hdrcnt + (uint32_t)s->dfrm); o.inv = s->opt_inv;
+                for (int i = 0; i < 280; i++) o.rawbits[i >> 3] |= (uint8_t)((s->dhb[i] & 1) << (i & 7));
                 o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
                 o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
                 o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);

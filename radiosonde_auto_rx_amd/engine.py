@@ -18,7 +18,7 @@ SONDE_RS41 = 41
 SONDE_DFM09 = 9
 LP_IQ, LP_FM = 1, 2
 TAP_DECIM, TAP_IFIQ, TAP_FM, TAP_BUFS, TAP_CORR = range(5)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SondeCfg(C.Structure):
@@ -37,7 +37,7 @@ class SondeFrame(C.Structure):
 class SondeDfmFrame(C.Structure):
     _fields_ = [("channel", C.c_int32), ("frame_in_hit", C.c_int32), ("ecc", C.c_int32 * 3), ("mv_pos", C.c_uint32),
                 ("mv", C.c_float), ("conf", C.c_uint8 * 7), ("dat1", C.c_uint8 * 13), ("dat2", C.c_uint8 * 13), ("pad", C.c_uint8 * 3),
-                ("frm_count", C.c_float), ("inv", C.c_int32)]
+                ("frm_count", C.c_float), ("inv", C.c_int32), ("rawbits", C.c_uint8 * 35), ("pad2", C.c_uint8)]
 
 
 class SondeM10Frame(C.Structure):

@@ -145,3 +145,22 @@ def test_rawhex_lines_with_non_hex_characters(dec, opts):
     a = subprocess.run([os.path.join(ROOT, "host", "bin", dec)] + args, input=data, capture_output=True, timeout=60)
     b = subprocess.run([ref] + args, input=data, capture_output=True, timeout=60)
     assert a.returncode == b.returncode == 0 and a.stdout == b.stdout and a.stdout, (a.stdout[:300], b.stdout[:300])
+
+
+def test_dfm_rawecc_and_packet_hex_match_reference():
+    """`dfm09mod --rawecc` (the frame's bits before the Hamming decoder as hex — what auto_rx asks for when it saves raw frames, decode.py:1078) and
+    `-R` (the nine data packets as hex, dfm09mod.c:972-981) on soft symbols, clean and damaged"""
+    ref = _ref_or_skip("dfm09mod")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sd = load_fsk("fsk_dfm_50k")["sd"].astype("<f4").ravel()
+    rng = np.random.default_rng(9)
+    hurt = sd + rng.normal(0, 0.6 * np.abs(sd).mean(), len(sd)).astype(np.float32)
+    some = 0
+    for args in (["--softin", "-i", "--rawecc"], ["-vv", "--ecc", "--json", "--dist", "--auto", "--softin", "--rawecc"], ["--softin", "-i", "-R", "--ecc"], ["--softin", "-R"],
+                 ["--softin", "--auto", "--rawecc", "--ecc2", "--json"]):
+        for data in (sd, hurt, sd[:len(sd) // 3]):
+            a = subprocess.run([os.path.join(ROOT, "host", "bin", "dfm09mod")] + args, input=data.tobytes(), capture_output=True, timeout=60, env=dict(os.environ, SONDE_JSN_VERSION="oracle"))
+            b = subprocess.run([ref] + args, input=data.tobytes(), capture_output=True, timeout=60)
+            assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (args, a.stdout[:300], b.stdout[:300])
+            some += len(a.stdout)
+    assert some > 2000
