@@ -44,7 +44,7 @@ static void emit_rec(const void *r) { emit_frame((const sonde_dfm_frame_t *)r); 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0;
+    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0, rawhex = 0;
     FILE *fp = stdin;
     sonde_dfm_opts_t dopt;
     int force_ecc = 0, cfreq = -1;
@@ -57,6 +57,7 @@ int main(int argc, char **argv) {
         const char *a = argv[i];
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "-R") || !strcmp(a, "--RAW")) raw = 2;          /* data packets as hex (dfm09mod.c:972-981) */
+        else if (!strcmp(a, "--rawhex")) rawhex = 1;                        /* the lines of --rawecc as input (:1730-1787) */
         else if (!strcmp(a, "--rawecc")) raw = 9;                          /* frame bits before the Hamming decoder (:1177-1196; decode.py:1078) */
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
         else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
@@ -111,6 +112,20 @@ int main(int argc, char **argv) {
         else { fprintf(stderr, "dfm09mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
     if (force_ecc) cfg.ecc_level = 1;               /* --dist / --json: option_ecc = 1 (dfm09mod.c:1487) */
+    if (rawhex) {
+        if (make_decoder(&dopt, raw, cfg.ecc_level, opt_auto, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;
+        sonde_softin_t *si = NULL;
+        if (sonde_softin_create(SONDE_DFM09, cfg.ecc_level, 0, opt_inv, opt_auto, &si) < 0) return -1;
+        char tb[1024]; sonde_dfm_frame_t fr[8]; size_t got;
+        while ((got = fread(tb, 1, sizeof tb, fp)) > 0) {
+            sonde_softin_push_dfm_rawhex(si, tb, (int32_t)got);
+            int k;
+            while ((k = sonde_softin_fetch_dfm(si, fr, 8)) > 0)
+                for (int i = 0; i < k; i++) emit_frame(&fr[i]);
+        }
+        sonde_softin_destroy(si);
+        return 0;
+    }
     if (softin || opt_bin) {                                    /* float32 soft symbols on stdin (dfm09mod.c:1604-1720) */
         if (make_decoder(&dopt, raw, cfg.ecc_level, opt_auto, cfreq > 0 ? (cfreq + 500) / 1000 : 0) < 0) return -1;
         sonde_softin_t *si = NULL;

@@ -332,6 +332,9 @@ int  sonde_softin_fetch(sonde_softin_t *s, sonde_frame_t *out, int32_t max);
 int  sonde_softin_fetch_soft(sonde_softin_t *s, float *soft, int32_t *nbits, int32_t *inv, int32_t max);
 /* SONDE_DFM09 framers (dfm09mod --softin, dfm09mod.c:1604-1720: two soft symbols per bit, 8 frames per header hit) */
 int  sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max);
+/* dfm09mod --rawhex (dfm09mod.c:1730-1787): the text `--rawecc` wrote — `+|-<frame count>  hex nibbles` per line, blanks skipped, other
+ * characters dropped, 66 nibbles = the 264 bits behind the header, LSB first — back into frames (hard bits, soft = +-1) */
+int  sonde_softin_push_dfm_rawhex(sonde_softin_t *s, const char *text, int32_t n);
 /* SONDE_M10 / SONDE_M20 framers (m10mod / m20mod --softin, m10mod.c:1405-1510: header threshold 0.8, two soft symbols per bit,
  * differential decoding, the rest of the second dropped) */
 int  sonde_softin_fetch_m10(sonde_softin_t *s, sonde_m10_frame_t *out, int32_t max);

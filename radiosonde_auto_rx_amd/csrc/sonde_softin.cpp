@@ -31,6 +31,7 @@ struct sonde_softin {
     int byte_count = 8, b8pos = 0; uint8_t bitbuf[8];
     uint8_t frame[518];                       // gpx.frame persists across frames like the reference's
     float mv = 0.f; uint64_t bits_in = 0, hdr_bit = 0;
+    char rawbuf[280 / 4 + 12 + 1] = {}; int rawpos = 0; float rawcnt = -1.0f;      // --rawhex reader of dfm09mod (:1732-1740)
     uint32_t hdrcnt = 0;                      // DFM: 8 per header seen (dfm09mod.c:1628,1632), base of the frame time stamp
     std::vector<sonde_frame_t> queue;
     // --ecc3 / --ecc4 behind soft input: the soft value of every frame bit travels with the frame (rs41mod.c:2910-2916,2941)
@@ -360,6 +361,44 @@ int sonde_softin_fetch_m20(sonde_softin_t *s, sonde_m20_frame_t *out, int32_t ma
     for (int i = 0; i < n; i++) out[i] = s->q20[i];
     s->q20.erase(s->q20.begin(), s->q20.begin() + n);
     return n;
+}
+
+int sonde_softin_push_dfm_rawhex(sonde_softin_t *s, const char *text, int32_t n) {
+    if (!s || n < 0 || (n > 0 && !text) || s->type != SONDE_DFM09) return SONDE_E_ARG;
+    const int BUFLEN = 280 / 4 + 12;
+    for (int t = 0; t < n; t++) {
+        const int ch = (unsigned char)text[t];
+        if (ch == ' ') continue;
+        if (ch != '\n') {
+            const bool keep = (ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'f') || (ch >= 'A' && ch <= 'F') || ch == '+' || ch == '-' || ch == '<' || ch == '.' || ch == '>';
+            if (keep && s->rawpos < BUFLEN) s->rawbuf[s->rawpos++] = (char)ch;
+            continue;
+        }
+        s->rawbuf[s->rawpos] = '\0';
+        s->opt_inv = s->rawbuf[0] == '-' ? 1 : 0;
+        sscanf(s->rawbuf + 1, "<%f>", &s->rawcnt);
+        const char *p = strchr(s->rawbuf, '>');
+        if (p) {
+            p++;
+            const int len = (int)strlen(p);
+            if (len * 4 == 280 - 16) {
+                for (int i = 0; i < len; i++) {
+                    unsigned char nib = 0xFF;
+                    sscanf(p + i, "%1hhx", &nib);
+                    for (int j = 0; j < 4; j++) { s->dhb[16 + 4 * i + j] = (nib >> j) & 1; s->dsf[16 + 4 * i + j] = (float)(2 * s->dhb[16 + 4 * i + j] - 1); }
+                }
+                sonde_dfm_frame_t o; memset(&o, 0, sizeof o);
+                o.frame_in_hit = 1; o.frm_count = s->rawcnt; o.inv = s->opt_inv;
+                for (int i = 0; i < 280; i++) o.rawbits[i >> 3] |= (uint8_t)((s->dhb[i] & 1) << (i & 7));
+                o.ecc[0] = dfm_block(s->ecc_level, s->dhb + 16, s->dsf + 16, 7, o.conf);
+                o.ecc[1] = dfm_block(s->ecc_level, s->dhb + 72, s->dsf + 72, 13, o.dat1);
+                o.ecc[2] = dfm_block(s->ecc_level, s->dhb + 176, s->dsf + 176, 13, o.dat2);
+                s->dqueue.push_back(o);
+            }
+        }
+        s->rawpos = 0;
+    }
+    return 0;
 }
 
 int sonde_softin_fetch_dfm(sonde_softin_t *s, sonde_dfm_frame_t *out, int32_t max) {

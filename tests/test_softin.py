@@ -164,3 +164,13 @@ def test_dfm_rawecc_and_packet_hex_match_reference():
             assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (args, a.stdout[:300], b.stdout[:300])
             some += len(a.stdout)
     assert some > 2000
+    # --rawhex: the --rawecc text back in (dfm09mod.c:1730-1787), also with blanks, other characters, wrong lengths
+    raw = subprocess.run([ref, "--softin", "--auto", "--rawecc"], input=hurt.tobytes(), capture_output=True, timeout=60).stdout
+    assert raw.count(b"\n") > 20
+    lines = raw.split(b"\n")
+    dirty = b"\n".join(lines[:5] + [lines[5][:40] + b"zz" + lines[5][40:], lines[6][:-3], b"+<12.5>" + lines[7][11:], b"garbage", lines[8].replace(b" ", b"   ")] + lines[9:])
+    for args in (["--rawhex", "-vv", "--ecc", "--json", "--dist"], ["--rawhex", "-r", "--ecc"], ["--rawhex", "--rawecc"], ["--rawhex", "-R", "--ecc2"], ["--rawhex", "--ptu"]):
+        for data in (raw, dirty):
+            a = subprocess.run([os.path.join(ROOT, "host", "bin", "dfm09mod")] + args, input=data, capture_output=True, timeout=60, env=dict(os.environ, SONDE_JSN_VERSION="oracle"))
+            b = subprocess.run([ref] + args, input=data, capture_output=True, timeout=60)
+            assert a.returncode == b.returncode == 0 and a.stdout == b.stdout, (args, a.stdout[:300], b.stdout[:300])

@@ -73,7 +73,7 @@ streams = {
  "mp3h1mod": lambda: synth.mrz_symbols(int(rng.integers(2, 20)), latlon=bool(rng.integers(2))),
  "mts01mod": lambda: synth.mts01_onair_bits(int(rng.integers(1, 5))),
 }
-HEXIN = {"rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
+HEXIN = {"dfm09mod": ["--rawecc", "--auto"], "rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
 opts = {
  "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
              ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
