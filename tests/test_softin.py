@@ -165,8 +165,19 @@ def test_dfm_rawecc_and_packet_hex_match_reference():
             some += len(a.stdout)
     assert some > 2000
     # --rawhex: the --rawecc text back in (dfm09mod.c:1730-1787), also with blanks, other characters, wrong lengths
-    raw = subprocess.run([ref, "--softin", "--auto", "--rawecc"], input=hurt.tobytes(), capture_output=True, timeout=60).stdout
-    assert raw.count(b"\n") > 20
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    bits = []
+    for k in range(24):
+        d1 = [int(v) for v in rng.integers(0, 16, 13)]; d1[12] = k % 9
+        d2 = [int(v) for v in rng.integers(0, 16, 13)]; d2[12] = (k + 4) % 9
+        bits.append(synth.dfm_frame_bits([int(v) for v in rng.integers(0, 16, 7)], d1, d2))
+    b = np.concatenate(bits)
+    sym = np.empty(2 * len(b), np.float32); sym[0::2] = 1.0 - 2.0 * b; sym[1::2] = 2.0 * b - 1.0         # bit 1 -> symbols 0, 1
+    sym += rng.normal(0, 0.35, len(sym)).astype(np.float32)
+    raw = subprocess.run([ref, "--softin", "--auto", "--rawecc"], input=sym.tobytes(), capture_output=True, timeout=60).stdout
+    assert raw.count(b"\n") >= 12
     lines = raw.split(b"\n")
     dirty = b"\n".join(lines[:5] + [lines[5][:40] + b"zz" + lines[5][40:], lines[6][:-3], b"+<12.5>" + lines[7][11:], b"garbage", lines[8].replace(b" ", b"   ")] + lines[9:])
     for args in (["--rawhex", "-vv", "--ecc", "--json", "--dist"], ["--rawhex", "-r", "--ecc"], ["--rawhex", "--rawecc"], ["--rawhex", "-R", "--ecc2"], ["--rawhex", "--ptu"]):
