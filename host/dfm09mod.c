@@ -57,6 +57,8 @@ int main(int argc, char **argv) {
         const char *a = argv[i];
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "-R") || !strcmp(a, "--RAW")) raw = 2;          /* data packets as hex (dfm09mod.c:972-981) */
+        else if (!strcmp(a, "-vvv")) dopt.verbose = 3;
+        else if (!strcmp(a, "--dbg")) dopt.dbg = 1;
         else if (!strcmp(a, "--rawhex")) rawhex = 1;                        /* the lines of --rawecc as input (:1730-1787) */
         else if (!strcmp(a, "--rawecc")) raw = 9;                          /* frame bits before the Hamming decoder (:1177-1196; decode.py:1078) */
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;

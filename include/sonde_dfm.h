@@ -22,7 +22,7 @@ extern "C" {
 typedef struct sonde_dfm_dec sonde_dfm_dec_t;
 
 typedef struct {
-    int32_t verbose;        /* 0, 1 (-v), 2 (-vv)                                                                     */
+    int32_t verbose;        /* 0, 1 (-v), 2 (-vv), 3 (-vvv: sensor type / polarity, battery, internal temperature, on-time) */
     int32_t ptu;            /* --ptu: temperature                                                                     */
     int32_t ecc;            /* 0, 1 (--ecc; forced by --dist / --json), 2 (--ecc2)                                     */
     int32_t dist;           /* --dist: output only when packets 0,1,2,3,4,8 of the last 6 frames are all good         */
@@ -33,7 +33,8 @@ typedef struct {
     int32_t opt_auto;       /* --auto (only changes the "<+> " / "<-> " prefix of -vv)                                */
     int32_t jsn_freq_khz;   /* (--jsn_cfq + 500) / 1000, 0 = none (dfm09mod.c:1516)                                   */
     char    version[32];    /* "version" of the JSON (VER_JSN_STR of the reference build); "" = omit                  */
-    int32_t reserved[4];
+    int32_t dbg;            /* --dbg: the measurement channels and two alternative thermistor evaluations (dfm09mod.c:1004-1026) */
+    int32_t reserved[3];
 } sonde_dfm_opts_t;
 
 int  sonde_dfm_dec_create(const sonde_dfm_opts_t *opts, sonde_dfm_dec_t **out);

@@ -217,6 +217,33 @@ struct sonde_dfm_dec {
         return (float)(Tk - 273.15);
     }
 
+    // --dbg: the two alternative thermistor evaluations (get_Temp2 :593-636, get_Temp4 :638-688); w: -vvv --ptu adds the resistor estimates
+    bool alt_channels() const { return (ptu_out >= 0xC && meas24[6] < 220e3) || sonde_id[3] == '8'; }
+    float temperature2(Out *w) const {
+        float f = meas24[0], f1 = meas24[3], f2 = meas24[4];
+        if (alt_channels()) { f = meas24[1]; f1 = meas24[5]; f2 = meas24[6]; }
+        const float B0 = 3260.0, T0 = 25 + 273.15, R0 = 5.0e3, Rf2 = 220e3;
+        const float g_o = f2 / Rf2, Rs_o = f1 / g_o;
+        float Rf1 = Rs_o, g, Rb, R, Tk = 0;
+        if (8e3 < Rs_o && Rs_o < 12e3) Rf1 = 10e3;
+        else if (18e3 < Rs_o && Rs_o < 22e3) Rf1 = 20e3;
+        g = (f2 - f1) / (Rf2 - Rf1);
+        Rb = (f1 * Rf2 - f2 * Rf1) / (f2 - f1);
+        R = (f - f1) / g;
+        if (R > 0) Tk = (float)(1 / (1 / T0 + 1 / B0 * log(R / R0)));
+        if (w) w->f("  (Rso: %.1f , Rb: %.1f)", Rs_o / 1e3, Rb / 1e3);
+        return (float)(Tk - 273.15);
+    }
+    float temperature4() const {
+        const float p0 = 1.09698417e-03, p1 = 2.39564629e-04, p2 = 2.48821437e-06, p3 = 5.84354921e-08;
+        float f = meas24[0], f1 = meas24[3], f2 = meas24[4];
+        if (alt_channels()) { f = meas24[1]; f1 = meas24[5]; f2 = meas24[6]; }
+        const float Rf4 = 220e3, g = f2 / Rf4, R = (f - f1) / g;
+        float Tk = 0;
+        if (R > 0) Tk = (float)(1 / (p0 + p1 * log(R) + p2 * log(R) * log(R) + p3 * log(R) * log(R) * log(R)));
+        return (float)(Tk - 273.15);
+    }
+
     static void to_gps_week(int yy, int mm, int dd, int hr, int mi, int se, int *wk, int *tw) {
         if (mm < 3) { yy -= 1; mm += 12; }
         const int days = (int)(365.25 * yy) + (int)(30.6001 * (mm + 1.0)) + dd - 723263;
@@ -271,7 +298,29 @@ struct sonde_dfm_dec {
                 w.f(" vH: %5.2f ", horiV);
                 w.f(" D: %5.1f ", dir);
                 w.f(" vV: %5.2f ", vertV);
-                if (cfgchk && o.ptu && ptu_out && T > -270.0f) w.f("  T=%.1fC ", T);
+                if (cfgchk) {
+                    if (o.ptu && ptu_out) {
+                        if (T > -270.0f) {
+                            w.f("  T=%.1fC ", T);
+                            if (o.verbose == 3) w.f(" (0x%X:%c%c) ", sonde_typ & 0xF, sensortyp, inv ? '-' : '+');
+                        }
+                        if (o.dbg) {
+                            const float t2 = temperature2(o.verbose == 3 ? &w : nullptr), t4 = temperature4();
+                            if (t2 > -270.0f) w.f("  T2=%.1fC ", t2);
+                            if (t4 > -270.0f) w.f(" T4=%.1fC  ", t4);
+                        }
+                    }
+                    if (o.verbose == 3 && ptu_out >= 0xA) {
+                        if (status[0] > 0.0) w.f("  U: %.2fV ", status[0]);
+                        if (status[1] > 0.0) w.f("  Ti: %.1fK ", status[1]);
+                        if (status[2] > 0.0) w.f("  sec: %.0f ", status[2]);
+                    }
+                }
+                if (o.dbg) {
+                    for (int j = 0; j < 5; j++) w.f(" f%d:%.1f", j, meas24[j]);
+                    if (ptu_out >= 0xA || sonde_id[3] == '8') { w.f(" f5:%.1f", meas24[5]); w.f(" f6:%.1f", meas24[6]); }
+                    w.f(" ");
+                }
                 if (o.verbose && (sonde_typ & SNBIT)) {
                     w.f(" (%s", sonde_id);
                     if (o.verbose > 1 && *kTypes[dfmtyp]) w.f(":%s", kTypes[dfmtyp]);
@@ -324,7 +373,7 @@ struct sonde_dfm_dec {
 extern "C" {
 
 int sonde_dfm_dec_create(const sonde_dfm_opts_t *opts, sonde_dfm_dec_t **out) {
-    if (!opts || !out || opts->verbose < 0 || opts->verbose > 2 || opts->ecc < 0 || opts->ecc > 2) return SONDE_E_ARG;
+    if (!opts || !out || opts->verbose < 0 || opts->verbose > 3 || opts->ecc < 0 || opts->ecc > 2) return SONDE_E_ARG;
     sonde_dfm_dec *d = new sonde_dfm_dec();
     d->o = *opts;
     d->o.version[sizeof d->o.version - 1] = 0;

@@ -53,7 +53,7 @@ class Rs41Telemetry:
 
 class DfmOpts(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("verbose", "ptu", "ecc", "dist", "json", "sat", "raw", "opt_auto", "jsn_freq_khz")] + \
-               [("version", C.c_char * 32), ("reserved", C.c_int32 * 4)]
+               [("version", C.c_char * 32), ("dbg", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class DfmTelemetry:

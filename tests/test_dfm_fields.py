@@ -35,3 +35,30 @@ def test_cli_dfm_telemetry_matches_reference(name):
         assert r.stdout == want, (name, args)
         total += len(want)
     assert total > 5000
+
+
+NEW_ARGS = [["-vvv", "--ptu", "--dbg", "--ecc", "--auto"], ["-vvv", "--ecc", "--ptu", "-i"], ["--dbg", "--ptu", "-v"], ["--rawecc", "--auto"], ["--rawecc", "--json", "--auto", "--ecc"],
+            ["-R", "--ecc", "--auto"], ["-R", "-i"], ["-vvv", "--dbg", "--ptu", "--ecc2", "--sat", "--auto"]]
+
+
+@pytest.mark.parametrize("name", sorted(make_golden.DFM_FIELD_SCENARIOS))
+def test_cli_dfm_verbose3_dbg_rawecc_match_compiled_reference(name):
+    """-vvv (sensor type / polarity, battery, internal temperature, on-time), --dbg (measurement channels, the two alternative thermistor
+    evaluations, resistor estimates), --rawecc and -R on the same scenarios: stdout of the compiled reference, byte for byte"""
+    ref = os.path.join(ROOT, "oracle", "_ref", "dfm09mod")
+    if not os.path.exists(ref):
+        pytest.skip("compiled reference not present")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    soft = make_golden.dfm_field_symbols(make_golden.DFM_FIELD_SCENARIOS[name]).tobytes()
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    total = 0
+    for args in NEW_ARGS:
+        a = subprocess.run([os.path.join(ROOT, "host", "bin", "dfm09mod")] + args + ["--softin"], input=soft, capture_output=True, env=env, timeout=120)
+        b = subprocess.run([ref] + args + ["--softin"], input=soft, capture_output=True, timeout=120)
+        assert a.returncode == b.returncode == 0
+        if a.stdout != b.stdout:
+            for x, y in zip(a.stdout.splitlines(), b.stdout.splitlines()):
+                assert x == y, (name, args, x, y)
+        assert a.stdout == b.stdout, (name, args)
+        total += len(a.stdout)
+    assert total > 3000

@@ -77,7 +77,7 @@ HEXIN = {"dfm09mod": ["--rawecc", "--auto"], "rs41mod": ["-r"], "m10mod": ["-r"]
 opts = {
  "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
              ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
- "dfm09mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["-i", "-r", "--ecc"], ["--ecc", "--ptu"], ["-v", "--ecc2", "--json"], ["--ecc", "-vv"], ["--rawecc"], ["--rawecc", "--ecc", "--json", "--auto"], ["-R", "--ecc"], ["-R"], ["-vv", "--ecc", "--json", "--dist", "--auto", "--rawecc"]],
+ "dfm09mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["-i", "-r", "--ecc"], ["--ecc", "--ptu"], ["-v", "--ecc2", "--json"], ["--ecc", "-vv"], ["--rawecc"], ["--rawecc", "--ecc", "--json", "--auto"], ["-vvv", "--ecc", "--ptu", "--dbg", "--auto"], ["-vvv", "--ptu"], ["--dbg", "--ptu", "-v"], ["-R", "--ecc"], ["-R"], ["-vv", "--ecc", "--json", "--dist", "--auto", "--rawecc"]],
  "m10mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
  "m20mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
  "lms6Xmod": [[], ["-r"], ["--ecc"], ["--vit"], ["--vit2", "--ecc"], ["--json"], ["--json", "--vit2"], ["--lms6", "--ecc"], ["--lmsX", "--ecc", "--vit"], ["--ecc3", "--vit2"], ["--gpsweek", "2290", "--json"]],
