@@ -55,6 +55,17 @@ int main(int argc, char **argv) {
     setbuf(stdout, NULL);
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
+        if (!strcmp(a, "-h") || !strcmp(a, "--help")) {
+            fprintf(stderr, "%s [options] audio.wav\n", argv[0]);
+            fprintf(stderr, "  options:\n");
+            fprintf(stderr, "       -v, -vv\n");
+            fprintf(stderr, "       -r, --raw\n");
+            fprintf(stderr, "       -i, --invert\n");
+            fprintf(stderr, "       --ecc        (Hamming ECC)\n");
+            fprintf(stderr, "       --ths <x>    (peak threshold; default=0.65)\n");
+            fprintf(stderr, "       --json       (JSON output)\n");
+            return 0;
+        }
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "-R") || !strcmp(a, "--RAW")) raw = 2;          /* data packets as hex (dfm09mod.c:972-981) */
         else if (!strcmp(a, "-vvv")) dopt.verbose = 3;

@@ -61,6 +61,15 @@ int main(int argc, char **argv) {
     setbuf(stdout, NULL);
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
+        if (!strcmp(a, "-h") || !strcmp(a, "--help")) {
+            fprintf(stderr, "%s [options] audio.wav\n", argv[0]);
+            fprintf(stderr, "  options:\n");
+            fprintf(stderr, "       -v, --verbose\n");
+            fprintf(stderr, "       -r, --raw\n");
+            fprintf(stderr, "       --vit        (Viterbi)\n");
+            fprintf(stderr, "       --ecc        (Reed-Solomon)\n");
+            return 0;
+        }
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) o.raw = 1;
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) { /* no output depends on it */ }
         else if (!strcmp(a, "--lms6")) o.typ = 6;

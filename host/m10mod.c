@@ -57,6 +57,15 @@ int main(int argc, char **argv) {
     setbuf(stdout, NULL);
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
+        if (!strcmp(a, "-h") || !strcmp(a, "--help")) {
+            fprintf(stderr, "%s [options] audio.wav\n", argv[0]);
+            fprintf(stderr, "  options:\n");
+            fprintf(stderr, "       -v, -vv, -vvv\n");
+            fprintf(stderr, "       -r, --raw\n");
+            fprintf(stderr, "       --ptu\n");
+            fprintf(stderr, "       --json\n");
+            return 0;
+        }
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) g_verbose = 1;
         else if (!strcmp(a, "-vv")) g_verbose = 2;

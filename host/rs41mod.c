@@ -87,6 +87,18 @@ int main(int argc, char **argv) {
 
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
+        if (!strcmp(a, "-h") || !strcmp(a, "--help")) {
+            fprintf(stderr, "%s [options] audio.wav\n", argv[0]);
+            fprintf(stderr, "  options:\n");
+            fprintf(stderr, "       -v, -vx, -vv  (info, aux, info/conf)\n");
+            fprintf(stderr, "       -r, --raw\n");
+            fprintf(stderr, "       -i, --invert\n");
+            fprintf(stderr, "       --crc        (check CRC)\n");
+            fprintf(stderr, "       --ecc        (Reed-Solomon)\n");
+            fprintf(stderr, "       --ths <x>    (peak threshold; default=0.7)\n");
+            fprintf(stderr, "       --iq0,2,3    (IQ data)\n");
+            return 0;
+        }
         if (!strcmp(a, "-r") || !strcmp(a, "--raw")) raw = 1;
         else if (!strcmp(a, "--ecc")) cfg.ecc_level = 1;
         else if (!strcmp(a, "--ecc2")) cfg.ecc_level = 2;
