@@ -112,6 +112,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--ptu2")) dopt.ptu = 2;
         else if (!strcmp(a, "--dewp")) dopt.dewp = 1;
         else if (!strcmp(a, "--sat")) dopt.sat = 1;
+        else if (!strcmp(a, "--aux")) dopt.aux = 1;
         else if (!strcmp(a, "--silent")) dopt.silent = 1;
         else if (!strcmp(a, "--json")) { dopt.json = 1; cfg.ecc_level = 2; }      /* at this point of the argument list: a later --ecc wins (rs41mod.c:2703-2707) */
         else if (!strcmp(a, "--jsnsubfrm1")) { dopt.jsn_subfrm = 1; dopt.json = 1; json_ecc = 1; }

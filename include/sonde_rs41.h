@@ -34,7 +34,8 @@ typedef struct {
     int32_t jsn_freq_khz;   /* "freq" of the JSON when > 0: (--jsn_cfq Hz - xlt_fq * sr + 500) / 1000 (rs41mod.c:2806-2809) */
     char    version[32];    /* "version" of the JSON — the reference compiles it in (VER_JSN_STR); "" = omit          */
     int32_t sat;            /* --sat: raw GPS block contents behind the time / position pieces (prn_sat1/2/3, rs41mod.c:2052-2111) */
-    int32_t reserved[3];
+    int32_t aux;            /* --aux: ozone / frost-point instruments decoded from the xdata text (implies verbose >= 2, rs41mod.c:2763)   */
+    int32_t reserved[2];
 } sonde_rs41_opts_t;
 
 int  sonde_rs41_dec_create(const sonde_rs41_opts_t *opts, sonde_rs41_dec_t **out);

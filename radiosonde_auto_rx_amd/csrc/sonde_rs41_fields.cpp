@@ -399,6 +399,66 @@ struct sonde_rs41_dec {
     }
 
     // ---- xdata -------------------------------------------------------------------------------------------------------
+    // ---- --aux: the ozone / frost-point instruments in the xdata text (hex2uint :1263-1278, prn_aux_IDx01 / 05 / 08 :1280-1452) -------------------
+    static int hex2uint(const char *str, int nibs) {
+        int erg = 0;
+        if (nibs > 7) return -2;
+        for (int i = 0; i < nibs; i++) {
+            int h;
+            if (str[i] >= '0' && str[i] <= '9') h = str[i] - '0';
+            else if (str[i] >= 'a' && str[i] <= 'f') h = str[i] - 'a' + 0xA;
+            else if (str[i] >= 'A' && str[i] <= 'F') h = str[i] - 'A' + 0xA;
+            else return -1;
+            erg = (erg << 4) | (h & 0xF);
+        }
+        return erg;
+    }
+    static const char *aux_at(const char *x, const char *id, const char *hash_id, size_t need) {
+        const char *px = x;
+        if (!*px) return nullptr;
+        if (strncmp(px, id, 2) != 0) { px = strstr(x, hash_id); if (!px) return nullptr; px += 1; }
+        return strlen(px) < need ? nullptr : px;
+    }
+    static void aux_ecc(Out &w, const char *x) {                // ID 0x01: ECC ozone sonde
+        const char *px = aux_at(x, "01", "#01", 16);
+        if (!px) return;
+        w.f(" ID=0x01 ECC ");
+        int v = hex2uint(px + 2, 2); if (v < 0) return; const uint8_t num = (uint8_t)v;
+        v = hex2uint(px + 4, 4); if (v < 0) return; const uint16_t icell = (uint16_t)v;
+        v = hex2uint(px + 8, 4); if (v < 0) return; const int16_t tpump = (int16_t)v;
+        v = hex2uint(px + 12, 2); if (v < 0) return; const uint8_t ipump = (uint8_t)v;
+        v = hex2uint(px + 14, 2); if (v < 0) return; const uint8_t vbat = (uint8_t)v;
+        w.f(" No.%d ", num); w.f(" Icell:%.3fuA ", icell / 1000.0); w.f(" Tpump:%.2fC ", tpump / 100.0); w.f(" Ipump:%dmA ", ipump); w.f(" Vbat:%.1fV ", vbat / 10.0);
+    }
+    static void aux_oif411(Out &w, const char *x) {             // ID 0x05: OIF411 ozone interface
+        const char *px = aux_at(x, "05", "#05", 20);
+        if (!px) return;
+        w.f(" ID=0x05 OIF411 ");
+        int v = hex2uint(px + 2, 2); if (v < 0) return;
+        w.f(" No.%d ", (uint8_t)v);
+        if (px[20] == 'I') {
+            char sn[9]; strncpy(sn, px + 4, 8); sn[8] = 0;
+            v = hex2uint(px + 12, 4); if (v < 0) return; const uint16_t dw = (uint16_t)v;
+            v = hex2uint(px + 16, 4); if (v < 0) return; const uint16_t sw = (uint16_t)v;
+            w.f(" SN:%s ", sn); w.f(" DW:%04X ", dw); w.f(" SW:%.2f ", sw / 100.0);
+        } else {
+            v = hex2uint(px + 4, 4); if (v < 0) return; const int16_t tpump = (int16_t)v;
+            v = hex2uint(px + 8, 5); if (v < 0) return; const uint32_t icell = (uint32_t)v & 0xFFFFF;
+            v = hex2uint(px + 13, 2); if (v < 0) return; const uint8_t vbat = (uint8_t)v;
+            v = hex2uint(px + 15, 3); if (v < 0) return; const uint16_t ipump = (uint16_t)(v & 0xFFF);
+            v = hex2uint(px + 18, 2); if (v < 0) return; const uint8_t vext = (uint8_t)v;
+            w.f(" Tpump:%.2fC ", tpump / 100.0); w.f(" Icell:%.4fuA ", icell / 10000.0); w.f(" Vbat:%.1fV ", vbat / 10.0); w.f(" Ipump:%dmA ", ipump); w.f(" Vext:%.1fV ", vext / 10.0);
+        }
+    }
+    static void aux_cfh(Out &w, const char *x) {                // ID 0x08: CFH frost-point hygrometer
+        const char *px = aux_at(x, "08", "#08", 24);
+        if (!px) return;
+        w.f(" ID=0x08 CFH ");
+        const int v = hex2uint(px + 2, 2); if (v < 0) return;
+        w.f(" No.%d ", (uint8_t)v);
+        w.f(" Tmir:0x%.6s ", px + 4); w.f(" Vopt:0x%.6s ", px + 10); w.f(" Topt:0x%.4s ", px + 16); w.f(" Vbat:0x%.4s ", px + 20);
+    }
+
     int xdata(int pos, Out *w = nullptr) {                     // w: -vx / -vv print the text as it is collected (:1492-1506)
         int n = 0, last = 0, cnt = 0;
         xd[0] = 0;
@@ -416,6 +476,23 @@ struct sonde_rs41_dec {
             }
         }
         xd[n] = 0;
+        if (w && o.aux && xd[0]) {                             // get_Aux :1512-1540
+            const char *paux = xd;
+            for (int i = 0; i < cnt; i++) {
+                if (paux > xd) { while (*paux && *paux != '#') paux++; paux++; }
+                if (strlen(paux) > 2) {
+                    const int v = hex2uint(paux, 2);
+                    if (v < 0) { paux += 2; continue; }
+                    switch (v & 0xFF) {
+                        case 0x01: w->f("\n"); aux_ecc(*w, paux); break;
+                        case 0x05: w->f("\n"); aux_oif411(*w, paux); break;
+                        case 0x08: w->f("\n"); aux_cfh(*w, paux); break;
+                    }
+                    paux++;
+                } else break;
+            }
+            if (!o.json) w->f("\n");
+        }
         if (pos < FL - 3 ? block_crc(pos, 0x7600) : -1) crc |= F_ZERO;
         return last;
     }
@@ -775,6 +852,7 @@ int sonde_rs41_dec_create(const sonde_rs41_opts_t *opts, sonde_rs41_dec_t **out)
     d->o = *opts;
     d->o.version[sizeof d->o.version - 1] = 0;
     if (d->o.jsn_subfrm) d->o.json = 1;
+    if (d->o.aux) d->o.verbose = 2;                            // rs41mod.c:2763
     memset(d->fr, 0, sizeof d->fr); memset(d->cal, 0, sizeof d->cal); memset(d->have, 0, sizeof d->have);
     memset(d->rstyp, 0, sizeof d->rstyp); memset(d->rstmp, 0, sizeof d->rstmp); memset(d->rsm, 0, sizeof d->rsm); memset(d->xd, 0, sizeof d->xd);
     d->Rf1 = d->Rf2 = d->Cf1 = d->Cf2 = 0.f;

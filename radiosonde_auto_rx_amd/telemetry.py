@@ -13,7 +13,7 @@ from .engine import SondeDfmFrame, SondeFrame, SondeM10Frame, SondeM20Frame, Son
 
 class Rs41Opts(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("verbose", "ptu", "dewp", "json", "jsn_subfrm", "silent", "jsn_freq_khz")] + \
-               [("version", C.c_char * 32), ("sat", C.c_int32), ("reserved", C.c_int32 * 3)]
+               [("version", C.c_char * 32), ("sat", C.c_int32), ("aux", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Rs41Telemetry:

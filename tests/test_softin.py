@@ -99,7 +99,7 @@ def _ref_or_skip(name):
 
 def test_rs41_sat_and_argument_order_match_reference():
     """`--sat` (raw GPS block contents incl. the newer GNSS block, no PTU then: rs41mod.c:2052-2111,1221-1260,2279), `-vx` / `-vv` (xdata text, battery,
-    week, sats, subframe bytes, QFE: :1565-1578,1981,2018,2029,1492-1506) and the order dependence of `--json` / `--ecc` (`--json` sets ecc = 2
+    week, sats, subframe bytes, QFE: :1565-1578,1981,2018,2029,1492-1506), `--aux` (ECC / OIF411 / CFH instrument records in the xdata text, :1280-1452) and the order dependence of `--json` / `--ecc` (`--json` sets ecc = 2
     where it stands, a later `--ecc` wins, :2703-2707; `--jsnsubfrm1` forces 2 afterwards, :2769-2773) — found by tools/fuzz_family.py"""
     import sys
     sys.path.insert(0, ROOT)
@@ -108,7 +108,7 @@ def test_rs41_sat_and_argument_order_match_reference():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
     rng = np.random.default_rng(5)
     cal = synth.rs41_cal_table(3)
-    bits = np.concatenate([synth.rs41_onair_bits(synth.rs41_frame(k, cal_table=cal, ptu_counts=True, xdata=["0511AABB", "01OZONE"] if k % 2 else None, gnss2=(k > 33),
+    bits = np.concatenate([synth.rs41_onair_bits(synth.rs41_frame(k, cal_table=cal, ptu_counts=True, xdata=[["0103123407D02D78"], ["05011B5801F4A782640A", "0501N1234567003C0123I"], ["08011234567890ABCDEF1234", "0102", "zz"]][k % 3] if k % 2 else None, gnss2=(k > 33),
                                                                   ecef_cm=(418833319, 85974133, 473346430))) for k in (0, 1, 2, 33, 34, 49, 50)])
     clean = (2.0 * bits - 1.0).astype(np.float32)
     hurt = clean.copy()
@@ -116,7 +116,8 @@ def test_rs41_sat_and_argument_order_match_reference():
     hurt[pos] *= -1
     env = dict(os.environ, SONDE_JSN_VERSION="oracle")
     for args in (["--softin", "--sat", "-v", "--ecc2"], ["--softin", "--sat", "--ptu", "--ecc"], ["--softin", "--sat", "--silent", "--ecc2"],
-                 ["--softin", "-vv", "--ecc2", "--ptu"], ["--softin", "-vx", "--ecc2"], ["--softin", "-vv", "--sat", "--ecc2"],
+                 ["--softin", "-vv", "--ecc2", "--ptu"], ["--softin", "-vx", "--ecc2"], ["--softin", "-vv", "--sat", "--ecc2"], ["--softin", "--aux", "--ecc2"],
+                 ["--softin", "--aux", "--json", "--ptu"],
                  ["--softin", "--json", "--ecc"], ["--softin", "--ecc", "--json"], ["--softin", "--ecc3", "--jsnsubfrm1"], ["--softin", "--json", "--ecc3"]):
         for data in (clean, hurt):
             a = subprocess.run([os.path.join(ROOT, "host", "bin", "rs41mod")] + args, input=data.tobytes(), capture_output=True, timeout=60, env=env)

@@ -36,7 +36,7 @@ def _rs41_stream():
     for k in range(int(rng.integers(1, 6))):
         xd = None
         if rng.integers(4) == 0:
-            xd = ["%02X%s" % (int(rng.integers(1, 9)), "".join(chr(int(c)) for c in rng.integers(0x30, 0x5A, int(rng.integers(4, 30))))) for _ in range(int(rng.integers(1, 4)))]
+            xd = ["%02X%s" % (int([1, 5, 8, 5, 2][rng.integers(5)]), "".join("0123456789ABCDEFI"[int(c)] for c in rng.integers(0, 17, int(rng.integers(4, 30))))) for _ in range(int(rng.integers(1, 4)))]
         fr = synth.rs41_frame(k0 + k, sid, cal_table=cal, ptu_counts=True, xdata=xd, gnss2=gnss2, ecef_cm=(418833319, 85974133, 473346430) if rng.integers(4) else (0, 0, 0),
                               rng=np.random.default_rng(int(rng.integers(1 << 30))))
         out += [synth.rs41_onair_bits(fr, preamble_bytes=int(rng.integers(4, 40))), rng.integers(0, 2, int(rng.integers(0, 400))).astype(np.uint8)]
@@ -76,7 +76,7 @@ streams = {
 HEXIN = {"dfm09mod": ["--rawecc", "--auto"], "rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
 opts = {
  "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
-             ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
+             ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--aux", "--ecc2"], ["--aux", "--json", "--ptu"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
  "dfm09mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["-i", "-r", "--ecc"], ["--ecc", "--ptu"], ["-v", "--ecc2", "--json"], ["--ecc", "-vv"], ["--rawecc"], ["--rawecc", "--ecc", "--json", "--auto"], ["-vvv", "--ecc", "--ptu", "--dbg", "--auto"], ["-vvv", "--ptu"], ["--dbg", "--ptu", "-v"], ["-R", "--ecc"], ["-R"], ["-vv", "--ecc", "--json", "--dist", "--auto", "--rawecc"]],
  "m10mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
  "m20mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
