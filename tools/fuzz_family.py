@@ -146,7 +146,8 @@ def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
                     t[q:q] = bytes(rng.integers(32, 127, int(rng.integers(1, 30))).astype(np.uint8))
                 else:
                     t[q:q] = b"\n"
-            data = bytes(t)
+            first = raw.split(b"\n", 1)[0] + b"\n" if raw else b""      # an intact first line: the reference's byte variable starts uninitialised,
+            data = first + bytes(t)                                       # its value before the first good pair is whatever the stack held
             args = ["--rawhex"] + [x for x in a if x not in ("-i", "--auto", "--ecc3", "--ecc4")]
         elif form == 1 and dec in ("rs41mod", "dfm09mod"):   # one byte per hard bit (fsk_demod without -s)
             hard = (np.frombuffer(data[:len(data) // 4 * 4], np.float32) < 0).astype(np.uint8)
