@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_dfm_raw_forms_on_samples_match_reference():
-    from test_gpu_parity import DFM_NAMES, dfm_capture
+    from golden_cases import DFM_NAMES, dfm_capture
     ref = os.path.join(ROOT, "oracle", "_ref", "dfm09mod")
     if not os.path.exists(ref):
         pytest.skip("compiled reference not present")
