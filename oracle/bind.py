@@ -164,6 +164,23 @@ def ref_softframes(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False
                 consts=dict(zip(CONST_NAMES, (int(v) for v in consts))))
 
 
+def ora_softframes(iq, sr, *, bps=16, iq_mode=5, fq=0.0, lp_iq=True, lp_fm=False, afc=False, baud=4800.0,
+                   bt=0.5, h=0.6, lpiq_bw=7400, lpfm_bw=6000, hdr=RS41_HDR, symlen=1, symhd=1,
+                   thres=0.7, hdmax=4, bitofs=2, l=2.0, nbits=4080, max_hits=64, iqdc=False):
+    """the CPU restatement with the arguments (and the result layout) of ref_softframes(): any sonde of the family"""
+    raw = np.ascontiguousarray(iq)
+    cfg = _refcfg(sr, bps, iq_mode, fq, lp_iq, lp_fm or (afc and iq_mode == 5), afc, baud, bt, h, lpiq_bw, lpfm_bw, hdr, symlen, symhd, iqdc)
+    hits = np.zeros((max_hits, 4), np.float64)
+    sb = np.zeros((max_hits, nbits), np.float32)
+    sb1 = np.zeros((max_hits, nbits), np.float32)
+    L = lib()
+    L.ora_softframes.restype = C.c_int
+    n = L.ora_softframes(C.byref(cfg), _buf(raw), C.c_size_t(raw.nbytes), C.c_float(thres), hdmax, bitofs, C.c_float(l), nbits, max_hits, _buf(hits), _buf(sb), _buf(sb1))
+    if n < 0:
+        raise RuntimeError("ora_softframes failed")
+    return dict(n=n, mv=hits[:n, 0], mv_pos=hits[:n, 1].astype(np.int64), nbits=hits[:n, 2].astype(np.int64), s_in_after=hits[:n, 3].astype(np.int64), soft=sb[:n], soft1=sb1[:n])
+
+
 def ref_run(binary: str, args: list[str], data: bytes | np.ndarray, timeout: float = 120.0):
     """Run a compiled reference binary with `data` on stdin -> (stdout, stderr, returncode)."""
     if isinstance(data, np.ndarray):

@@ -289,3 +289,39 @@ int ora_streams(const void *data, size_t nbytes, int sr, int bps, int iq_mode, d
     ora_free(&d);
     return n;
 }
+
+/* Any sonde of the family through the restatement: header hits (score, position) and their soft bits — the same contract as
+ * ref_softframes() of oracle/ref_harness.c (which drives the reference's own demod_mod.o), so that tests can hand both the same configuration.
+ * Polarity as rs41mod without -i / --auto: hits with a negative score are skipped (rs41mod.c:2888-2891). */
+typedef struct {
+    int sr, bps, opt_iq, opt_lp, opt_dc, opt_iqdc, opt_min, opt_nolut;
+    double xlt_fq; float baud; int symlen, symhd; float BT, h; int lpIQ_bw, lpFM_bw; const char *hdr;
+} ora_cfg_t;
+
+int ora_softframes(const ora_cfg_t *c, const void *data, size_t nbytes, float thres, int hdmax, int bitofs, float l, int nbits, int max_hits,
+                   double *hits, float *sb, float *sb1) {
+    ora_dsp d; memset(&d, 0, sizeof(d));
+    d.src = (const uint8_t *)data; d.src_len = nbytes; d.src_pos = 0;
+    d.sr_in = c->sr; d.bps = c->bps; d.iq_mode = c->opt_iq; d.lp_mask = c->opt_lp; d.afc = c->opt_dc; d.iqdc = c->opt_iqdc; d.if_min = c->opt_min;
+    d.xlt_fq = c->xlt_fq; d.baud = c->baud; d.symlen = c->symlen; d.symhd = c->symhd; d.bt = c->BT; d.h = c->h;
+    d.lpiq_bw = c->lpIQ_bw; d.lpfm_bw = c->lpFM_bw; d.hdr = c->hdr; d.hdrlen = (int)strlen(c->hdr);
+    if (ora_init(&d) < 0) return -1;
+    int nh = 0;
+    while (nh < max_hits) {
+        if (ora_find_header(&d, thres, hdmax) < 0) break;
+        if (d.mv * 0.5f < 0) continue;
+        hits[4 * nh] = d.mv; hits[4 * nh + 1] = d.mv_pos;
+        int i, q = 0;
+        for (i = 0; i < nbits; i++) {
+            ora_bit a, b;
+            q = ora_softbit2p(&d, &a, 0, bitofs, i, l, 0, &b);
+            if (q < 0) break;
+            sb[(size_t)nh * nbits + i] = a.sb; sb1[(size_t)nh * nbits + i] = b.sb;
+        }
+        hits[4 * nh + 2] = i; hits[4 * nh + 3] = d.s_in;
+        nh++;
+        if (q < 0) break;
+    }
+    ora_free(&d);
+    return nh;
+}
