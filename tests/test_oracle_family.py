@@ -17,6 +17,12 @@ FAM = {
     "imet54": dict(cap=lambda: synth.imet54_capture(sr=48_000, seconds=4.5, noise_sigma=0.08, seed=62),
                    kw=dict(baud=4798.0, bt=1.0, h=0.8, lpiq_bw=7400, lpfm_bw=6000, hdr=b"0000000001" b"0101010101" b"0001001001" b"0001001001", symlen=1, symhd=1,
                            thres=0.7, hdmax=4, bitofs=1, l=2.0, nbits=2200)),
+    "meisei": dict(cap=lambda: synth.meisei_capture(sr=48_000, seconds=5.0, noise_sigma=0.1, seed=41),
+                   kw=dict(baud=2400.0, bt=1.2, h=2.4, lpiq_bw=16000, lpfm_bw=4000, hdr=b"101010101011010100101011001101001100101011001101", symlen=1, symhd=1,
+                           thres=0.7, hdmax=1, bitofs=0, l=-1.0, nbits=1152)),
+    "mts01": dict(cap=lambda: synth.mts01_capture(sr=48_000, seconds=5.5, noise_sigma=0.1, seed=51),
+                  kw=dict(baud=1200.0, bt=1.5, h=0.9, lpiq_bw=4000, lpfm_bw=4000, hdr=b"10101010" b"10101010" b"10110100" b"00101011", symlen=1, symhd=1,
+                          thres=0.76, hdmax=2, bitofs=0, l=2.0, nbits=1048)),
 }
 
 
