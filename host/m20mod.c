@@ -20,13 +20,13 @@
 #include "wav_header.h"
 
 static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (m20mod.c:1040,1108-1114) */
-static int g_verbose = 0, g_raw = 0;
+static int g_verbose = 0, g_raw = 0, g_color = 0;
 static sonde_m20_dec_t *g_dec = NULL;
 
 /* print_frame() (m20mod.c:870-1003): raw line with -r, else (or with -r --json: silently) the decoded position line / JSON */
 static void emit_frame(const sonde_m20_frame_t *f) {
-    static char ln[420], tx[4096];
-    if (g_raw && sonde_m20_rawline(f, g_verbose, ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
+    static char ln[4096], tx[4096];
+    if (g_raw && sonde_m20_rawline(f, g_verbose | (g_color ? SONDE_M20_COLOR : 0), ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
     if (g_dec && sonde_m20_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
 }
 
@@ -71,6 +71,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-vv")) g_verbose = 2;
         else if (!strcmp(a, "-vvv")) g_verbose = 3;
         else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
+        else if (!strcmp(a, "-c") || !strcmp(a, "--color")) { g_color = 1; dopt.color = 1; }
         else if (!strcmp(a, "--json")) dopt.json = 1;
         else if (!strcmp(a, "--silent")) dopt.silent = 1;
         else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }

@@ -275,6 +275,7 @@ int  sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t m
 int  sonde_m10_frame_finish(sonde_m10_frame_t *f);
 int  sonde_m20_frame_finish(sonde_m20_frame_t *f);
 /* Raw text line of `m20mod -r [-v]` (m20mod.c:959-973); buf >= 400 */
+#define SONDE_M20_COLOR 0x100    /* or'ed into `verbose`: -c, ANSI colours around the fields of the raw line (m20mod.c:918-958) */
 int  sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen);
 
 /* Raw text line of `dfm09mod -r [--ecc]` (dfm09mod.c:1198-1236); returns strlen. buf >= 96 bytes */

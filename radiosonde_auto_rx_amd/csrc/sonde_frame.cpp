@@ -271,14 +271,52 @@ int sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t
     return n;
 }
 int sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen) {
-    if (!f || !buf || f->len < 1 || f->len > 0x45 + 64 + 1 || buflen < (size_t)(2 * f->len + 32)) return SONDE_E_ARG;
+    const bool col = (verbose & SONDE_M20_COLOR) != 0;
+    verbose &= 0xFF;
+    if (!f || !buf || f->len < 1 || f->len > 0x45 + 64 + 1 || buflen < (size_t)((col ? 26 : 2) * f->len + 96)) return SONDE_E_ARG;
     int n = 0;
-    for (int i = 0; i < f->len; i++) n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
-    if (verbose) {
-        n += snprintf(buf + n, buflen - n, " # %04x", f->cs_calc);
-        if (f->fw < 0x07) n += snprintf(buf + n, buflen - n, f->blk_ok > 0 ? " (ok)" : f->blk_ok < 0 ? " (oo)" : " (no)");
-        n += snprintf(buf + n, buflen - n, f->cs_ok ? " [OK]" : " [NO]");
+    if (!col) {
+        for (int i = 0; i < f->len; i++) n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
+        if (verbose) {
+            n += snprintf(buf + n, buflen - n, " # %04x", f->cs_calc);
+            if (f->fw < 0x07) n += snprintf(buf + n, buflen - n, f->blk_ok > 0 ? " (ok)" : f->blk_ok < 0 ? " (oo)" : " (no)");
+            n += snprintf(buf + n, buflen - n, f->cs_ok ? " [OK]" : " [NO]");
+        }
+        return n;
     }
+    // -c: a colour in front of every byte of a field, the text colour behind every byte (m20mod.c:918-958)
+    const char *FR = "\x1b[38;5;244m", *TXT = FR;
+    const int pc = f->len - 2;                                       // pos_check = flen - 1, len = flen + 1
+    n += snprintf(buf + n, buflen - n, "%s", FR);
+    for (int i = 0; i < f->len; i++) {
+        const auto put = [&](const char *c) { n += snprintf(buf + n, buflen - n, "%s", c); };
+        if (i == 1) put("\x1b[38;5;250m");
+        if (i >= 0x0F && i < 0x0F + 3) put("\x1b[38;5;27m");
+        if (i >= 0x1C && i < 0x1C + 4) put("\x1b[38;5;34m");
+        if (i >= 0x20 && i < 0x20 + 4) put("\x1b[38;5;70m");
+        if (i >= 0x08 && i < 0x08 + 3) put("\x1b[38;5;82m");
+        if (i >= 0x1A && i < 0x1A + 2) put("\x1b[38;5;20m");
+        if (i >= 0x0B && i < 0x0B + 2) put("\x1b[38;5;36m");
+        if (i >= 0x0D && i < 0x0D + 2) put("\x1b[38;5;36m");
+        if (i >= 0x18 && i < 0x18 + 2) put("\x1b[38;5;36m");
+        if (i >= 0x12 && i < 0x12 + 3) put("\x1b[38;5;58m");
+        if (i == 0x15) put("\x1b[38;5;172m");
+        if (f->fw < 0x07) { if (i >= 0x16 && i < 0x16 + 2) put("\x1b[38;5;11m"); }
+        else { if (i >= 0x16 + 1 && i < 0x16 + 2) put("\x1b[38;5;11m"); }
+        if (i >= 0x02 && i <= 0x03) put("\x1b[38;5;120m");
+        if (i >= 0x04 && i <= 0x05) put("\x1b[38;5;110m");
+        if (i >= 0x06 && i <= 0x07) put("\x1b[38;5;115m");
+        if ((i == 0x16 && f->fw >= 0x07) || (i >= 0x24 && i <= 0x25)) put("\x1b[38;5;180m");
+        if (i >= pc && i < pc + 2) put("\x1b[38;5;11m");
+        n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
+        put(FR);
+    }
+    if (verbose) {
+        n += snprintf(buf + n, buflen - n, " # %s%04x%s", "\x1b[38;5;11m", f->cs_calc, FR);
+        if (f->fw < 0x07) n += snprintf(buf + n, buflen - n, " %s%s%s", f->blk_ok > 0 ? "\x1b[38;5;2m" : f->blk_ok < 0 ? "\x1b[38;5;220m" : "\x1b[38;5;1m", f->blk_ok > 0 ? "(ok)" : f->blk_ok < 0 ? "(oo)" : "(no)", TXT);
+        n += snprintf(buf + n, buflen - n, " %s%s%s", f->cs_ok ? "\x1b[38;5;2m" : "\x1b[38;5;1m", f->cs_ok ? "[OK]" : "[NO]", TXT);
+    }
+    n += snprintf(buf + n, buflen - n, "%s", "\x1b[0m");
     return n;
 }
 // what print_frame() derives from the frame bytes before printing (m10mod.c:1049-1070; m20mod.c:875-907)

@@ -151,16 +151,22 @@ struct sonde_m20_dec {
         if (o.ptu && csOK) { T = temp(); TH = temp_rh_sensor(); RH = humidity(); P = pressure(); }
         batV = fb[0x26] * (3.3f / 255);
         if (!o.silent) {
-            if (o.verbose >= 3) { w.f("[%3d]", fb[0x15]); w.f(" (W %d) ", week); }
-            w.f("%s ", kDay[wday]);
-            w.f("%04d-%02d-%02d %02d:%02d:%06.3f ", year, month, day, hour, minute, sec);
-            w.f(" lat: %.5f ", lat); w.f(" lon: %.5f ", lon); w.f(" alt: %.2f ", alt);
-            w.f("  vH: %4.1f  D: %5.1f  vV: %3.1f ", vH, vD, vV);
-            if (o.verbose >= 1 && (bcOK || csOK)) w.f("  SN: %s", SN);
+            // -c: ANSI colours around the fields (COLOPT, m20mod.c:239-267); empty strings without it
+            const bool c = o.color != 0;
+            const char *TXT = c ? "\x1b[38;5;244m" : "", *WK = c ? "\x1b[38;5;20m" : "", *TOW = c ? "\x1b[38;5;27m" : "", *DAT = c ? "\x1b[38;5;94m" : "";
+            const char *LAT = c ? "\x1b[38;5;34m" : "", *LON = c ? "\x1b[38;5;70m" : "", *ALT = c ? "\x1b[38;5;82m" : "", *VEL = c ? "\x1b[38;5;36m" : "", *SNC = c ? "\x1b[38;5;58m" : "";
+            const char *OKC = c ? "\x1b[38;5;2m" : "", *OOC = c ? "\x1b[38;5;220m" : "", *NOC = c ? "\x1b[38;5;1m" : "", *RST = c ? "\x1b[0m" : "";
+            w.f("%s", TXT);
+            if (o.verbose >= 3) { w.f("[%3d]", fb[0x15]); w.f(" (W %s%d%s) ", WK, week, TXT); }
+            w.f("%s%s%s ", TOW, kDay[wday], TXT);
+            w.f("%s%04d-%02d-%02d%s %s%02d:%02d:%06.3f%s ", DAT, year, month, day, TXT, TOW, hour, minute, sec, TXT);
+            w.f(" lat: %s%.5f%s ", LAT, lat, TXT); w.f(" lon: %s%.5f%s ", LON, lon, TXT); w.f(" alt: %s%.2f%s ", ALT, alt, TXT);
+            w.f("  vH: %s%4.1f%s  D: %s%5.1f%s  vV: %s%3.1f%s ", VEL, vH, TXT, VEL, vD, TXT, VEL, vV, TXT);
+            if (o.verbose >= 1 && (bcOK || csOK)) w.f("  SN: %s%s%s", SNC, SN, TXT);
             if (o.verbose >= 1) {
                 w.f("  # ");
-                if (fw < 0x07) w.f(bcOK > 0 ? " (ok)" : bcOK < 0 ? " (oo)" : " (no)");
-                w.f(csOK ? " [OK]" : " [NO]");
+                if (fw < 0x07) { if (bcOK > 0) w.f(" %s(ok)%s", OKC, TXT); else if (bcOK < 0) w.f(" %s(oo)%s", OOC, TXT); else w.f(" %s(no)%s", NOC, TXT); }
+                if (csOK) w.f(" %s[OK]%s", OKC, TXT); else w.f(" %s[NO]%s", NOC, TXT);
             }
             if (o.ptu && csOK) {
                 w.f(" ");
@@ -170,6 +176,7 @@ struct sonde_m20_dec {
                 if (P > 0.0f) { if (P < 10.0f) w.f(" P=%.3fhPa ", P); else if (P < 100.0f) w.f(" P=%.2fhPa ", P); else w.f(" P=%.1fhPa ", P); }
             }
             if (o.verbose >= 3 && csOK) w.f(" (bat:%.2fV)", batV);
+            w.f("%s", RST);
             w.f("\n");
         }
         if (o.json && csOK) {
