@@ -20,13 +20,13 @@
 #include "wav_header.h"
 
 static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (m10mod.c:1184,1245-1251,1436) */
-static int g_verbose = 0, g_raw = 0;
+static int g_verbose = 0, g_raw = 0, g_color = 0;
 static sonde_m10_dec_t *g_dec = NULL;
 
 /* print_frame() (m10mod.c:1049-1140): raw line with -r, else (or with -r --json: silently) the decoded position line / JSON */
 static void emit_frame(const sonde_m10_frame_t *f) {
-    static char ln[320], tx[4096];
-    if (g_raw && sonde_m10_rawline(f, g_verbose, ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
+    static char ln[4096], tx[4096];
+    if (g_raw && sonde_m10_rawline(f, g_verbose | (g_color ? SONDE_M10_COLOR : 0), ln, sizeof ln) > 0) fprintf(stdout, "%s\n", ln);
     if (g_dec && sonde_m10_dec_frame(g_dec, f, tx, sizeof tx) > 0) fputs(tx, stdout);
 }
 
@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) g_verbose = 1;
         else if (!strcmp(a, "-vv")) g_verbose = 2;
         else if (!strcmp(a, "-vvv")) g_verbose = 3;
+        else if (!strcmp(a, "-c") || !strcmp(a, "--color")) { g_color = 1; dopt.color = 1; }
         else if (!strcmp(a, "--ptu")) dopt.ptu = 1;
         else if (!strcmp(a, "--json")) dopt.json = 1;
         else if (!strcmp(a, "--silent")) dopt.silent = 1;

@@ -253,6 +253,7 @@ typedef struct {
  * exist, m10mod.c:1486-1490). */
 int  sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish);
 /* Raw text line of `m10mod -r [-v]` (m10mod.c:1112-1123): hex bytes, with verbose " # <checksum> [OK]|[NO]"; buf >= 280 */
+#define SONDE_M10_COLOR 0x100    /* or'ed into `verbose`: -c, ANSI colours around the fields (m10mod.c:1078-1110; M10 / M10+ frames only); buf >= 4096 */
 int  sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen);
 
 /* One M20 frame (m20mod.c:870-911): frame byte 0 = length; checksum over the first len-1 bytes; older firmware (< 0x07) also carries a

@@ -25,7 +25,8 @@ typedef struct {
     int32_t raw;            /* -r: the caller prints the raw line; print_pos only runs when silent (m10mod.c:1123)     */
     int32_t jsn_freq_khz;   /* "freq" of the JSON when > 0                                                             */
     char    version[32];    /* "version" of the JSON (VER_JSN_STR of the reference build); "" = omit                   */
-    int32_t reserved[4];
+    int32_t color;          /* -c: ANSI colours around the fields of the position line (m10mod.c:253-277,886-923)       */
+    int32_t reserved[3];
 } sonde_m10_opts_t;
 
 int  sonde_m10_dec_create(const sonde_m10_opts_t *opts, sonde_m10_dec_t **out);

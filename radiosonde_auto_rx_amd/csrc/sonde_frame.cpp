@@ -264,10 +264,50 @@ int sonde_dfm_rawline(const sonde_dfm_frame_t *f, int ecc_level, char *buf, size
     return n;
 }
 int sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen) {
-    if (!f || !buf || f->len < 101 || f->len > 121 || buflen < (size_t)(2 * f->len + 20)) return SONDE_E_ARG;
+    bool col = (verbose & SONDE_M10_COLOR) != 0;
+    verbose &= 0xFF;
+    if (!f || !buf || f->len < 101 || f->len > 121 || buflen < (size_t)((col ? 26 : 2) * f->len + 96)) return SONDE_E_ARG;
+    const int typ = f->frame[1];
+    if (typ == 0x49 || !(typ == 0x9F || typ == 0xAF || !(typ == 0x8F || typ == 0x20))) col = false;      // coloured for t_M10 / t_M10plus (unknown types count as M10, :1066-1072)
     int n = 0;
-    for (int i = 0; i < f->len; i++) n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
-    if (verbose) n += snprintf(buf + n, buflen - n, " # %04x%s", f->cs_calc, f->cs_ok ? " [OK]" : " [NO]");
+    if (!col) {
+        for (int i = 0; i < f->len; i++) n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
+        if (verbose) n += snprintf(buf + n, buflen - n, " # %04x%s", f->cs_calc, f->cs_ok ? " [OK]" : " [NO]");
+        return n;
+    }
+    const char *FR = "\x1b[38;5;244m";
+    const bool m10 = typ != 0xAF;
+    const int aux = f->len - 101, pc = 0x63 + aux;
+    n += snprintf(buf + n, buflen - n, "%s", FR);
+    for (int i = 0; i < f->len; i++) {
+        const auto put = [&](const char *c) { n += snprintf(buf + n, buflen - n, "%s", c); };
+        if (i == 1) put("\x1b[38;5;250m");
+        if (m10) {
+            if (i >= 0x0A && i < 0x0A + 4) put("\x1b[38;5;27m");
+            if (i >= 0x0E && i < 0x0E + 4) put("\x1b[38;5;34m");
+            if (i >= 0x12 && i < 0x12 + 4) put("\x1b[38;5;70m");
+            if (i >= 0x16 && i < 0x16 + 4) put("\x1b[38;5;82m");
+            if (i >= 0x20 && i < 0x20 + 2) put("\x1b[38;5;20m");
+            if (i >= 0x04 && i < 0x04 + 6) put("\x1b[38;5;36m");
+        } else {
+            if (i >= 0x04 && i < 0x04 + 4) put("\x1b[38;5;34m");
+            if (i >= 0x08 && i < 0x08 + 4) put("\x1b[38;5;70m");
+            if (i >= 0x0C && i < 0x0C + 3) put("\x1b[38;5;82m");
+            if (i >= 0x0F && i < 0x0F + 6) put("\x1b[38;5;36m");
+            if (i >= 0x15 && i < 0x15 + 3) put("\x1b[38;5;27m");
+            if (i >= 0x18 && i < 0x18 + 3) put("\x1b[38;5;20m");
+        }
+        if (i >= 0x5D && i < 0x5D + 5) put("\x1b[38;5;58m");
+        if (i == 0x62) put("\x1b[38;5;172m");
+        if (i >= pc && i < pc + 2) put("\x1b[38;5;11m");
+        n += snprintf(buf + n, buflen - n, "%02x", f->frame[i]);
+        put(FR);
+    }
+    if (verbose) {
+        n += snprintf(buf + n, buflen - n, " # %s%04x%s", "\x1b[38;5;11m", f->cs_calc, FR);
+        n += snprintf(buf + n, buflen - n, " %s%s%s", f->cs_ok ? "\x1b[38;5;2m" : "\x1b[38;5;1m", f->cs_ok ? "[OK]" : "[NO]", FR);
+    }
+    n += snprintf(buf + n, buflen - n, "%s", "\x1b[0m");
     return n;
 }
 int sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen) {

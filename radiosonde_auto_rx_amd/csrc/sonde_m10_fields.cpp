@@ -175,15 +175,21 @@ struct sonde_m10_dec {
         T = temp(); RH = humidity(); Ti = int_temp(); batV = battery();
         serial();
         if (!o.silent) {
+            // -c: the same line with ANSI colours around the fields (m10mod.c:253-277,886-923); empty strings without it
+            const bool c = o.color != 0;
+            const char *TXT = c ? "\x1b[38;5;244m" : "", *WK = c ? "\x1b[38;5;20m" : "", *TOW = c ? "\x1b[38;5;27m" : "", *DAT = c ? "\x1b[38;5;94m" : "";
+            const char *LAT = c ? "\x1b[38;5;34m" : "", *LON = c ? "\x1b[38;5;70m" : "", *ALT = c ? "\x1b[38;5;82m" : "", *VEL = c ? "\x1b[38;5;36m" : "", *SNC = c ? "\x1b[38;5;58m" : "";
+            const char *OKC = c ? "\x1b[38;5;2m" : "", *NOC = c ? "\x1b[38;5;1m" : "";
+            w.f("%s", TXT);
             if (type == 0x9F) {
-                if (o.verbose >= 3) w.f(" (W %d) ", week);
-                w.f("%s ", kDay[wday]);
+                if (o.verbose >= 3) w.f(" (W %s%d%s) ", WK, week, TXT);
+                w.f("%s%s%s ", TOW, kDay[wday], TXT);
             }
-            w.f("%04d-%02d-%02d %02d:%02d:%06.3f ", year, month, day, hour, minute, sec);
-            w.f(" lat: %.5f ", lat); w.f(" lon: %.5f ", lon); w.f(" alt: %.2f ", alt);
-            if (!err2) w.f("  vH: %.1f  D: %.1f  vV: %.1f ", vH, vD, vV);
-            if (o.verbose >= 2) w.f("  SN: %s", SN);
-            if (o.verbose >= 2) { w.f("  # "); w.f(csOK ? " [OK]" : " [NO]"); }
+            w.f("%s%04d-%02d-%02d%s %s%02d:%02d:%06.3f%s ", DAT, year, month, day, TXT, TOW, hour, minute, sec, TXT);
+            w.f(" lat: %s%.5f%s ", LAT, lat, TXT); w.f(" lon: %s%.5f%s ", LON, lon, TXT); w.f(" alt: %s%.2f%s ", ALT, alt, TXT);
+            if (!err2) w.f("  vH: %s%.1f%s  D: %s%.1f%s  vV: %s%.1f%s ", VEL, vH, TXT, VEL, vD, TXT, VEL, vV, TXT);
+            if (o.verbose >= 2) w.f("  SN: %s%s%s", SNC, SN, TXT);
+            if (o.verbose >= 2) { w.f("  # "); if (csOK) w.f(" %s[OK]%s", OKC, TXT); else w.f(" %s[NO]%s", NOC, TXT); }
             if (o.ptu && csOK) {
                 if (T > -270.0) w.f("  T=%.1fC", T);
                 if (o.verbose >= 2 && RH > -0.5) w.f(" _RH=%.0f%%", RH);
@@ -195,6 +201,7 @@ struct sonde_m10_dec {
                 }
             }
             if (o.verbose >= 3 && csOK) w.f(" (bat:%.2fV)", batV);
+            if (c) w.f("\x1b[0m");
             w.f("\n");
         }
         if (o.json && csOK) {

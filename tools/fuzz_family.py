@@ -78,7 +78,7 @@ opts = {
  "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
              ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--aux", "--ecc2"], ["--aux", "--json", "--ptu"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
  "dfm09mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2"], ["-vv", "--ecc", "--json", "--dist", "--auto"], ["-i", "-r", "--ecc"], ["--ecc", "--ptu"], ["-v", "--ecc2", "--json"], ["--ecc", "-vv"], ["--rawecc"], ["--rawecc", "--ecc", "--json", "--auto"], ["-vvv", "--ecc", "--ptu", "--dbg", "--auto"], ["-vvv", "--ptu"], ["--dbg", "--ptu", "-v"], ["-R", "--ecc"], ["-R"], ["-vv", "--ecc", "--json", "--dist", "--auto", "--rawecc"]],
- "m10mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"]],
+ "m10mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"], ["-c", "-vvv", "--ptu"], ["-c", "-r", "-v"], ["-c", "-vv"], ["-c", "-r", "--json"]],
  "m20mod": [["-r"], ["-r", "-v"], ["--json", "--ptu", "-vvv"], ["-v", "--ptu"], ["-vv"], ["--json", "--jsn_cfq", "404000000"], ["-c", "-vvv", "--ptu"], ["-c", "-r", "-v"], ["-c"], ["-c", "-r", "--json"]],
  "lms6Xmod": [[], ["-r"], ["--ecc"], ["--vit"], ["--vit2", "--ecc"], ["--json"], ["--json", "--vit2"], ["--lms6", "--ecc"], ["--lmsX", "--ecc", "--vit"], ["--ecc3", "--vit2"], ["--gpsweek", "2290", "--json"]],
  "meisei100mod": [[], ["-r"], ["--ecc"], ["--ecc", "-v", "--ptu"], ["--json", "--ptu"], ["-r", "--ecc", "-v"], ["--dbg"], ["--rs11g", "--ecc", "--ptu"], ["--ims100", "--json"], ["--year", "2035", "--json"]],
