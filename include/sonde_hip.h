@@ -252,7 +252,7 @@ typedef struct {
 /* SONDE_M10 engines: frames completed so far; finish != 0 = end of input (a frame in progress is emitted with the bits that
  * exist, m10mod.c:1486-1490). */
 int  sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish);
-/* Raw text line of `m10mod -r [-v]` (m10mod.c:1112-1123): hex bytes, with verbose " # <checksum> [OK]|[NO]"; buf >= 280 */
+/* Raw text line of `m10mod -r [-v]` (m10mod.c:1112-1123): hex bytes, with verbose " # <checksum> [OK]|[NO]"; buf >= 2 * len + 96 (340 at most) */
 #define SONDE_M10_COLOR 0x100    /* or'ed into `verbose`: -c, ANSI colours around the fields (m10mod.c:1078-1110; M10 / M10+ frames only); buf >= 4096 */
 int  sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen);
 
@@ -275,7 +275,7 @@ int  sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t m
  * For frames that do not come from an engine or soft-symbol framer, e.g. --rawhex input. */
 int  sonde_m10_frame_finish(sonde_m10_frame_t *f);
 int  sonde_m20_frame_finish(sonde_m20_frame_t *f);
-/* Raw text line of `m20mod -r [-v]` (m20mod.c:959-973); buf >= 400 */
+/* Raw text line of `m20mod -r [-v]` (m20mod.c:959-973); buf >= 2 * len + 96 (400 is enough), 4096 with SONDE_M20_COLOR */
 #define SONDE_M20_COLOR 0x100    /* or'ed into `verbose`: -c, ANSI colours around the fields of the raw line (m20mod.c:918-958) */
 int  sonde_m20_rawline(const sonde_m20_frame_t *f, int verbose, char *buf, size_t buflen);
 
