@@ -5,8 +5,11 @@
       One step = the whole RS41 `--IQ fq --lpIQ` path (mix + decimate -> IF chain -> header correlation -> frame sync -> frame fetch
       + RS ECC) over CHANNELS channels x 1 s of 2.4 Msps cs16 IQ per GPU, resident in HBM.  Channels shard across ranks with no
       data-path collective; the per-channel detection summaries (32 B, written by the frame-sync kernel) are all_gathered from device
-      memory once per step.  Extra objects: `detect` (the dft_detect scanner over the same channels, not part of
-      `value`), `pcie_inclusive` (the same steps fed from pinned host memory, never `value`).
+      memory once per step.  After the timed loop every channel's last frame is compared with the CPU oracle's frame for
+      the stream that channel saw (`config.verified_channels`).  Extra objects of the default single-GPU run, none of them part of `value`:
+      `detect_in_step` (BASELINE configs[4]: the same steps with the dft_detect scanner re-scanning a rotating 1/16 of the channels inside
+      every step), `pcie_inclusive` (the same steps fed from pinned host memory), `scan_wide` and `fsk_mixed` (BASELINE configs[2] and
+      configs[3], each with its own ms_per_step / roofline / cpu_baseline — the objects `--config scan_wide|fsk_mixed` print on their own).
   --config scan_wide (BASELINE configs[2]): 256 channels out of ONE 10 Msps stream -> dft_detect scanner, per 0.2 s of stream.
   --config fsk_mixed (BASELINE configs[3]): 1024 mixed RS41 / DFM09 / M10 channels through the 2-FSK modem (fsk_demod path).
 
@@ -30,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 SR = 2_400_000
 BANK = 8                 # unique synthetic captures tiled over the channels
-PROFILE_TAG = "r2"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
+PROFILE_TAG = "r3"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
 
 
 def make_bank(seconds: float = 1.0):
@@ -118,12 +121,20 @@ class Dist:
         self.dist = None
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (libsonde_hip has no CPU fallback)")
+        # SONDE_DIST_BACKEND=gloo: the multi-rank code path on a box with fewer GPUs than ranks (tests/test_gpu_multirank.py): ranks share
+        # the devices round robin and the collectives go through host memory; the driver's runs use nccl (= RCCL), one rank per GPU
+        self.backend = os.environ.get("SONDE_DIST_BACKEND", "nccl")
+        if self.backend != "nccl":
+            self.local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
             self.dist = dist
 
     def barrier(self):
@@ -142,7 +153,7 @@ class Dist:
     def sum_ints(self, *vals):
         if not self.dist:
             return vals
-        t = self.torch.tensor(list(vals), device=self.dev, dtype=self.torch.int64)
+        t = self.torch.tensor(list(vals), device=self.dev if self.backend == "nccl" else "cpu", dtype=self.torch.int64)
         self.dist.all_reduce(t)
         return tuple(int(v) for v in t)
 
@@ -151,17 +162,44 @@ class Dist:
             self.dist.destroy_process_group()
 
 
+def _lead_in(eng, ptr, stride):
+    """Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): untimed lead-in calls up
+    to the last short boundary, after which every 1 s step is exactly one segment.  Returns the lengths fed (each from the row start)."""
+    fed = []
+    while eng.samples_to_dc_boundary() < SR:
+        n = eng.samples_to_dc_boundary()
+        eng.process_device(ptr, stride, n)
+        fed.append(n)
+    eng.fetch_frames_np()
+    return fed
+
+
+def _oracle_last_frames(fqs, caps, fed):
+    """What the CPU oracle (oracle/, the checker) decodes last from the stream a channel of bank b saw: the lead-in pieces, then whole
+    seconds of the capture until the IQ-DC mean, the filter histories and the sync state repeat (4 s).  -> per bank (frame bytes, len, ecc)"""
+    from oracle import bind
+    out = []
+    for b in range(BANK):
+        cap = caps[b]
+        x = np.concatenate([cap[:2 * n] for n in fed] + [cap] * 4)
+        o = bind.ora_rs41_decode(x, SR, fq=fqs[b], want_soft=False)
+        # [-1] is the frame in progress at the end of the oracle's input (emitted with the bits that exist); [-2] is the last whole one
+        out.append((bytes(o["frames"][-2]), int(o["flen"][-2]), int(o["ecc"][-2])) if o["n"] >= 2 else None)
+    return out
+
+
 def bench_demod(args, D: Dist):
     torch = D.torch
     from radiosonde_auto_rx_amd.engine import Engine
     from radiosonde_auto_rx_amd import shard
     C = args.channels or int(os.environ.get("SONDE_BENCH_CHANNELS", "512"))
-    steps = args.steps or 1500                                              # ~2 s of GPU time: long enough for the driver's busy sampler
-    warmup = 3 if args.warmup is None else args.warmup
+    steps = args.steps or 400
+    warmup = 5 if args.warmup is None else args.warmup
     fqs, caps = make_bank()
-    ch_fq = [fqs[(c + D.rank) % BANK] for c in range(C)]
+    ch_bank = [(c + D.rank) % BANK for c in range(C)]
+    ch_fq = [fqs[b] for b in ch_bank]
     bank_t = torch.from_numpy(np.stack(caps)).to(D.dev)                     # [BANK, 2*SR] int16
-    idx = torch.tensor([(c + D.rank) % BANK for c in range(C)], device=D.dev)
+    idx = torch.tensor(ch_bank, device=D.dev)
     iq = bank_t.index_select(0, idx).contiguous()                         # [C, 2*SR] resident input
     STRIDE = SR + int(os.environ.get("SONDE_BENCH_PAD", "0"))              # experiments: channel rows padded apart (samples)
     if STRIDE != SR:
@@ -171,46 +209,75 @@ def bench_demod(args, D: Dist):
     del bank_t
     torch.cuda.synchronize()
 
-    eng = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=(args.lag > 0 and args.two_streams))
+    lag = args.lag
+    eng = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=(lag > 0 and args.two_streams))
     summary = shard.summary_buffer(C, D.dev)                              # written by the frame-sync kernel, gathered from device memory
     eng.set_summary(summary.data_ptr(), D.rank * C)
+    # pipelined steps (lag 1): the all_gather of step k reads the snapshot the engine took at the end of call k-1 while call k runs
+    snaps = shard.summary_buffer(2 * C, D.dev).view(2, C, shard.SUMMARY_BYTES) if (D.dist and lag) else None
+    snap_next = eng.set_summary_snapshots(snaps.data_ptr()) if snaps is not None else 0
     gathered = [torch.empty_like(summary) for _ in range(D.world)] if D.dist else None
+    fed = _lead_in(eng, iq.data_ptr(), STRIDE)
+    calls = [0]
+    last = {}                                                             # channel -> its most recent frame record (verification, untimed)
 
-    # Align the call boundaries with the reference's IQ-DC segments (75000 * 2^k samples, then every 2.4 M): one
-    # untimed lead-in call up to the last short boundary, after which every 1 s step is exactly one segment.
-    while eng.samples_to_dc_boundary() < SR:
-        eng.process_device(iq.data_ptr(), STRIDE, eng.samples_to_dc_boundary())
-    eng.fetch_frames_np()
-
-    def step(lag=args.lag):
-        # lag = 0: every step waits for its own frames (kernel times are then un-overlapped and the roofline figure of
-        # k_mix_decimate is clean).  lag = 1 pipelines: the IF-rate kernels of call k (stream B) overlap the decimator of call k+1.
+    def step(lag=lag):
+        # lag = 0: every step waits for its own frames.  lag = 1: the frames of call k-1 are fetched (D2H of the records, host RS ECC) while
+        # call k runs — the host work leaves the critical path; kernels of one engine stream still run one after the other, so the HIP-event
+        # time of k_mix_decimate50 is that kernel alone.  --two-streams: the IF-rate kernels of call k-1 also overlap the decimator of call k.
         eng.process_device(iq.data_ptr(), STRIDE, SR)
-        frames = eng.fetch_frames_np(lag=lag)                             # D2H of frame records + host RS ECC
-        if D.dist:
-            shard.gather_summaries(D.dist, summary, D.world, gathered)    # 32 B per channel over RCCL, device to device
+        calls[0] += 1
+        frames = eng.fetch_frames_np(lag=lag)
+        if D.dist:                                                        # 32 B per channel over RCCL, device to device
+            src = summary if snaps is None else snaps[(snap_next + calls[0] - 2) & 1]
+            if snaps is None or calls[0] >= 2:
+                shard.gather_summaries(D.dist, src, D.world, gathered)
         return frames
 
+    t_w = time.perf_counter()
     for _ in range(warmup):
         step()
     eng.fetch_frames_np(lag=0)
+    t_w = (time.perf_counter() - t_w) / max(1, warmup)
+    # at least ~1.2 s of timed work whatever K is (the driver's GPU-busy sampler needs to see the run): the K steps are repeated R times
+    # and every figure below is over all K x R steps
+    est = max(t_w, 1e-4)
+    repeats = 1 if os.environ.get("SONDE_BENCH_NO_REPEAT") else max(1, int(np.ceil(1.2 / (est * steps))))
+    total_steps = steps * repeats
     eng.profile(1)                      # timed region: HIP events around the dominant kernel only (2 events per step)
     D.barrier()
     t0 = time.perf_counter()
     nframes, nok = 0, 0
-    for _ in range(steps):
+    fr_tail = [None, None, None]                                          # the last fetches (every channel ends a frame once per step)
+    for k in range(total_steps):
         fr = step()
+        fr_tail[k % 3] = fr
         nframes += len(fr)
         nok += int((fr["ecc"] >= 0).sum())
-    fr = eng.fetch_frames_np(lag=0)                                       # drain: all work of the K steps is inside the timed region
-    nframes += len(fr)
-    nok += int((fr["ecc"] >= 0).sum())
+    fr_tail = [fr_tail[(total_steps + i) % 3] for i in range(3)] + [eng.fetch_frames_np(lag=0)]     # oldest first; drain: all work is inside the timed region
+    nframes += len(fr_tail[-1])
+    nok += int((fr_tail[-1]["ecc"] >= 0).sum())
     eng.sync()
     D.barrier()
     dt_local = time.perf_counter() - t0
     dt, per_rank = D.finish_times(dt_local)
     nframes, nok = D.sum_ints(nframes, nok)
     md_ms, md_n = eng.kernel_ms("mix_decimate")
+
+    # untimed: every channel's last frame against the CPU oracle's last frame of the same stream (frame bytes, length, ECC verdict)
+    for arr in fr_tail:
+        for f in (arr if arr is not None else ()):
+            last[int(f["channel"])] = f
+    verified, mismatched = 0, []
+    want = _oracle_last_frames(fqs, caps, fed) if not args.no_verify else None
+    if want is not None:
+        for c in range(C):
+            f, w = last.get(c), want[ch_bank[c]]
+            ok = f is not None and w is not None and int(f["len"]) == w[1] and int(f["ecc"]) == w[2] and bytes(f["frame"][:w[1]]) == w[0][:w[1]]
+            verified += int(ok)
+            if not ok and len(mismatched) < 8:
+                mismatched.append(c)
+        verified, = D.sum_ints(verified)
 
     # untimed: per-kernel table of a step (events around every kernel cost ~0.1 ms of host time per step, so not in the timed region)
     eng.profile(2)
@@ -223,68 +290,105 @@ def bench_demod(args, D: Dist):
         kern[k] = dict(ms_per_step=round(ms * n / nprof, 4), launches_per_step=n / nprof)
     eng.profile(0)
     rec = shard.decode_summaries(summary)
-    total_samples = D.world * C * SR * steps
+    total_samples = D.world * C * SR * total_steps
     value = total_samples / dt / 1e6
     # dominant kernel = k_mix_decimate: algorithmic bytes = 4 B per complex cs16 sample;
     # per-step launches may differ in size (IQ-DC segment edges) so the rate is (bytes of all launches)/(time of all launches)
     md_total_s = md_ms * md_n / 1e3
-    achieved = (C * SR * steps * 4) / md_total_s / 1e9 if md_total_s > 0 else 0.0
+    achieved = (C * SR * total_steps * 4) / md_total_s / 1e9 if md_total_s > 0 else 0.0
     traffic, traffic_src = _traffic("mix_decimate", C * SR * 4)
     out = None
     if D.rank == 0:
         out = {
             "metric": "IQ Msamples/s (RS41 --IQ --lpIQ demod + framesync + ECC), concurrent real-time 2.4 Msps channels = value/2.4",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / total_steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RS41 2.4 Msps cs16 IQ, rs41mod --ecc2 --IQ fq --lpIQ (BASELINE configs[1]) x %d channels per GPU "
-                                   "(per-GPU share of configs[4]), 1 s of signal per channel per step" % C,
+                                   "(per-GPU share of configs[4]), 1 s of signal per channel per step, input resident in HBM" % C,
                        "channels_per_gpu": C, "samples_per_channel_per_step": SR, "realtime_channels": round(value / 2.4, 1),
-                       "frames_decoded": nframes, "frames_ecc_ok": nok, "timed_seconds": round(dt, 3),
-                       "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank],
+                       "repeats": repeats, "timed_steps": total_steps, "timed_seconds": round(dt, 3),
+                       "frame_fetch_lag": lag, "two_streams": bool(lag > 0 and args.two_streams),
+                       "frames_decoded": nframes, "frames_ecc_ok": nok,
+                       "verified_channels": verified if want is not None else None, "verify_mismatch_channels": mismatched,
+                       "verify_note": "untimed, after the loop: the last frame of every channel (bytes, length, ECC verdict) equals the CPU oracle's last frame "
+                                      "of the stream that channel saw (oracle/ora_rs41_decode on lead-in + 4 s of its capture)",
+                       "rank_ms_per_step": [round(t / total_steps * 1e3, 3) for t in per_rank],
                        "summary_records": {"bytes_per_channel": shard.SUMMARY_BYTES, "channels_with_frames": int((rec["frames"] > 0).sum()),
                                            "frames_clean_on_device": int(rec["frames_clean"].sum())},
                        "kernels": kern},
             "roofline": {"bound": "hbm", "kernel": "k_mix_decimate50", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_src,
                          "algorithmic_gb_per_launch": round(C * SR * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4), "launches": md_n,
-                         "note": "achieved = 4 B x complex samples of all timed k_mix_decimate50 launches / their HIP-event time on the engine stream"},
+                         "step_frac": round(C * SR * 4 / (dt / total_steps) / 8e12, 4),
+                         "note": "achieved = 4 B x complex samples of all timed k_mix_decimate50 launches / their HIP-event time on the engine stream; "
+                                 "step_frac = the same bytes over the whole step time (all kernels + host)"},
         }
+        if want is not None and verified != D.world * C:
+            out["config"]["verify_failed"] = True
     # ---- extras on one GPU (never part of `value`)
     if D.world == 1 and not args.no_extras:
-        out["detect"] = detect_extra(D, iq, ch_fq, C)
+        out["detect_in_step"] = detect_in_step_extra(D, eng, iq, ch_fq, C, STRIDE, lag)
         out["pcie_inclusive"] = pcie_extra(D, eng, iq, C)
     eng.set_summary(0)
     eng.close()
+    del iq
+    torch.cuda.empty_cache()
     if D.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_demod(fqs, caps)
+    if D.world == 1 and not args.no_extras and not args.no_configs:
+        import bench_configs
+        for name in ("scan_wide", "fsk_mixed"):                           # BASELINE configs[2] and [3] in the same line (short runs)
+            sub = argparse.Namespace(**vars(args))
+            sub.config, sub.steps, sub.warmup, sub.channels, sub.cpu_budget = name, None, None, 0, 6.0
+            try:
+                out[name] = bench_configs.run(sub, D, short=True)
+            except Exception as exc:                                      # the headline must survive a failure beside it — and say so
+                out[name] = {"error": repr(exc)}
     return out
 
 
-def detect_extra(D: Dist, iq, ch_fq, C):
-    """The scanner (the reference's dft_detect, `--IQ fq --dc`) over the first second of every channel of the demodulator batch:
-    what the detect stage of configs[4] costs when it runs.  In auto_rx a channel is scanned BEFORE a decoder is started for it, not
-    beside the decoder (scan.py vs decode.py), so this is a separate figure, not a term of the step."""
+def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
+    """BASELINE configs[4] "full detect -> demod -> ECC" as one step: the demodulator step over all C channels with the dft_detect scanner
+    (`--IQ fq --dc`, front end + 14 templates) re-scanning a rotating 1/16 of the channels over the same second, inside the step — the
+    auto_rx duty cycle: decoders run on the channels that were found while the scanner keeps sweeping (scan.py:948, decode.py:869-913).
+    The scanner works on its own stream beside the engine's (its call returns when its windows are decided, the engine's call is asynchronous);
+    its detections are fetched inside the step.  Not part of `value`."""
     torch = D.torch
     from radiosonde_auto_rx_amd.scan import Scanner
-    nch = min(C, 256)
-    sc = Scanner(SR, fq=ch_fq[:nch], dc=True, cont=True, max_chunk=SR, device=D.local_rank)
-    sub = iq[:nch].contiguous()
-    sc.process_device(sub.data_ptr(), SR, SR)
-    sc.fetch()
+    groups = 16
+    per = max(1, C // groups)
+    scs = [Scanner(SR, fq=ch_fq[g * per:(g + 1) * per], dc=True, cont=True, max_chunk=SR, device=D.local_rank) for g in range(groups)]
+    found = [0]
+
+    def step(k):
+        g = k % groups
+        sc = scs[g]
+        eng.process_device(iq.data_ptr(), STRIDE, SR)                              # asynchronous on the engine's stream(s)
+        sc.process_device(iq.data_ptr() + 4 * STRIDE * g * per, STRIDE, SR)          # scanner stream; returns when its windows are decided
+        fr = eng.fetch_frames_np(lag=lag)
+        found[0] += sum(1 for d in sc.fetch() if d["type"] == "RS41")
+        return fr
+
+    for k in range(groups):                                               # every scanner has seen a second (allocations, first windows)
+        step(k)
+    eng.fetch_frames_np(lag=0)
     torch.cuda.synchronize()
+    found[0] = 0
+    n = 4 * groups
     t0 = time.perf_counter()
-    reps = 3
-    found = 0
-    for _ in range(reps):
-        sc.process_device(sub.data_ptr(), SR, SR)
-        found += sum(1 for d in sc.fetch() if d["type"] == "RS41")
+    for k in range(n):
+        step(k)
+    eng.fetch_frames_np(lag=0)
+    eng.sync()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    sc.close()
-    return dict(channels=nch, ms_per_channel_second=round(dt * 1e3 / nch, 4), msamples_per_s=round(nch * SR / dt / 1e6, 1),
-                rs41_detections_per_pass=found / reps,
-                note="dft_detect scanner (front end + 14 templates) over 1 s of each channel; scanned before decoding starts, not per step")
+    dt = (time.perf_counter() - t0) / n
+    for sc in scs:
+        sc.close()
+    return dict(ms_per_step=round(dt * 1e3, 3), value=round(C * SR / dt / 1e6, 1), unit="Msamples/s", realtime_channels=round(C * SR / dt / 2.4e6, 1),
+                channels_scanned_per_step=per, scan_duty="1/%d of the channels per step, rotating" % groups, steps=n,
+                rs41_detections_per_scanned_channel=round(found[0] / float(n * per), 3),
+                note="demodulator step over all channels + dft_detect scanner (front end, 14 templates) over 1 s of a rotating 1/16 of them, inside the step")
 
 
 def pcie_extra(D: Dist, eng, iq, C):
@@ -317,7 +421,9 @@ def main():
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (0 = the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="demod: skip the detect / PCIe-inclusive extras")
-    ap.add_argument("--lag", type=int, default=0, help="demod: 1 = frame fetch one step behind")
+    ap.add_argument("--no-configs", action="store_true", help="demod: skip the scan_wide / fsk_mixed objects")
+    ap.add_argument("--no-verify", action="store_true", help="demod: skip the oracle check of every channel's last frame")
+    ap.add_argument("--lag", type=int, default=1, help="demod: 1 = frame fetch one step behind (default), 0 = every step waits for its own frames")
     ap.add_argument("--two-streams", action="store_true", help="demod, with --lag 1: IF-rate kernels on a second HIP stream")
     args = ap.parse_args()
     D = Dist()

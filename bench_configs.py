@@ -34,14 +34,14 @@ def _timed_steps(D, step, steps, warmup):
     return dt, per
 
 
-def bench_scan_wide(args, D):
+def bench_scan_wide(args, D, short=False):
     torch = D.torch
     from tools import synth
     from radiosonde_auto_rx_amd.chan import Channelizer
     from radiosonde_auto_rx_amd.scan import Scanner, IFIQ, BBIQ
     from bench import _time_reference, _traffic
     sr, M, Dd, P = 10_000_000, 256, 200, 16
-    steps = args.steps or 40
+    steps = args.steps or (12 if short else 40)
     warmup = 2 if args.warmup is None else args.warmup
     spacing = sr / M
     # a stream with a dozen sondes on the channel raster (+- a few kHz), 1 s, repeated every step
@@ -113,20 +113,20 @@ def bench_scan_wide(args, D):
                     exe = os.path.join(bind.REFDIR, "dft_detect")
                     cmds = [[exe, "--IQ", repr(ch.channel_freq(10 * k + 3) / sr), "--dc", "-t", "1", "-", str(sr), "16"] for k in range(ncores)]
                     r = _time_reference(cmds, [p] * ncores, 2_000_000, "Msamples/s",
-                                        "dft_detect --IQ fq processes, one channel each, over 0.2 s of the 10 Msps stream (channel-samples/s: x1)", 12.0)
+                                        "dft_detect --IQ fq processes, one channel each, over 0.2 s of the 10 Msps stream (channel-samples/s: x1)", getattr(args, "cpu_budget", 12.0))
                 r["note"] = "channel-samples per second: one process handles ONE of the 256 channels; divide by 256 for stream samples/s"
                 out_json["cpu_baseline"] = r
     sc.close(); ch.close()
     return out_json
 
 
-def bench_fsk_mixed(args, D):
+def bench_fsk_mixed(args, D, short=False):
     torch = D.torch
     from tools import synth
     from radiosonde_auto_rx_amd.fsk import FskModem
     from bench import _time_reference
     C = args.channels or 1024
-    steps = args.steps or 100
+    steps = args.steps or (25 if short else 100)
     warmup = 2 if args.warmup is None else args.warmup
     groups = [("rs41", 48000, 4800, 5), ("dfm", 50000, 2500, 5), ("m10", 48080, 9616, 5)]
     engines = []
@@ -198,7 +198,7 @@ def bench_fsk_mixed(args, D):
                         cmds.append([exe, "--cs16", "-b", "-20000", "-u", "20000", "-s"] + (["--mask", "5000", "--nsym=300"] if kind == "rs41" else ["--nsym=150"]) +
                                     ["-p", "5", "2", str(Fs), str(Rs), "-", "-"])
                         inputs.append(p); units += 20 * (len(cap) // 2)
-                    r = _time_reference(cmds, inputs, units / ncores, "Msamples/s", "fsk_demod processes (RS41 / DFM / M10 settings in turn) over 20 s of IF-rate cs16", 12.0)
+                    r = _time_reference(cmds, inputs, units / ncores, "Msamples/s", "fsk_demod processes (RS41 / DFM / M10 settings in turn) over 20 s of IF-rate cs16", getattr(args, "cpu_budget", 12.0))
                 out["cpu_baseline"] = r
     pool.shutdown()
     for e in engines:
@@ -206,5 +206,6 @@ def bench_fsk_mixed(args, D):
     return out
 
 
-def run(args, D):
-    return bench_scan_wide(args, D) if args.config == "scan_wide" else bench_fsk_mixed(args, D)
+def run(args, D, short=False):
+    """short: the reduced runs the default `bench.py` line carries as its `scan_wide` / `fsk_mixed` objects"""
+    return bench_scan_wide(args, D, short) if args.config == "scan_wide" else bench_fsk_mixed(args, D, short)

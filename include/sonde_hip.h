@@ -204,6 +204,12 @@ typedef struct {
 /* The engine writes its channels' records to `d_summary` (device memory, n_channels records, zeroed by the caller) from now on;
  * channel_id starts at `channel_base`.  NULL switches the records off. */
 int  sonde_engine_set_summary(sonde_engine_t *e, void *d_summary, uint32_t channel_base);
+/* Pipelined callers (frames fetched with a lag, the next call already running): `d_snap` = device memory for 2 x n_channels records.
+ * Every process call ends with a device-to-device copy of the live records into half (call number & 1), ordered behind the call's frame
+ * sync on the engine's stream; once sonde_engine_fetch_frames_lagged(.., lag = 1) has returned, the half of the call BEFORE the latest one
+ * is complete and stable — that half is what an all_gather may read while the latest call still runs.  Returns the index (0 / 1) of the
+ * half the NEXT process call will fill; NULL switches the copies off. */
+int  sonde_engine_set_summary_snapshots(sonde_engine_t *e, void *d_snap);
 
 int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
 /* 1 if the device-side frame queue (cfg.max_frames) overflowed since the last call of this function — the oldest frames were then

@@ -59,6 +59,7 @@ struct sonde_engine {
     WinItem *d_win = nullptr; float2 *d_Fm = nullptr, *d_tws = nullptr; int win_W = 0;
     uint32_t *d_work = nullptr, *d_work_count = nullptr; int sync_rounds = 0;      // compact window list of the round, counters [2]
     sonde_summary_t *d_summary = nullptr; uint32_t summary_base = 0;      // caller-owned device buffer (sonde_engine_set_summary)
+    sonde_summary_t *d_summary_snap = nullptr;                            // caller-owned, 2 x n_channels records (sonde_engine_set_summary_snapshots)
     int corr_types = 0, corr_isps = 0; float *d_shapes = nullptr, *d_symsign = nullptr; int *d_symtype = nullptr;
     SyncState *d_state = nullptr; FrameRec *d_frames = nullptr; unsigned *d_fcount = nullptr; float *d_soft = nullptr, *d_soft1 = nullptr;
     uint4 *d_bitwin = nullptr; uint32_t *d_bitend = nullptr;
@@ -586,6 +587,9 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         if (e->cfg.opt_nolut) { a.phase_f64 = 1; a.lut_len = 1 << 30; a.lut_phase = 0; a.nd_base = (double)e->samples_in; }
         // enough waves to fill the chip, few enough that the one-tile halo per wave stays small
         { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
+        {   // test aid: tiles per wave of a large batch (512 channels x 1 s: G = 16) on a batch small enough for a parity test (tests/test_gpu_batch.py)
+            const char *g = getenv("SONDE_MD_G"); const int gv = g ? atoi(g) : 0; if (gv >= 1 && gv <= 16) a.G = gv;
+        }
         a.etab = e->d_etab; a.etab_len = e->etab_len;
         a.dc_avg_prev = (e->d_etab && e->dc_since < e->Q - 1) ? e->d_dcavg_prev : nullptr; a.dc_since = e->dc_since;
         if (e->dc_since < (1 << 20)) e->dc_since += take / D;
@@ -667,6 +671,8 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         }
     }
     hipMemcpyAsync(e->h_count + slot, e->d_fcount, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream_b);
+    if (e->d_summary && e->d_summary_snap)
+        hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
     hipEventRecord(e->ev_b[slot], e->stream_b);
     e->call += 1;
     if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
@@ -778,6 +784,12 @@ int sonde_engine_set_summary(sonde_engine_t *e, void *d_summary, uint32_t channe
     if (!e) return SONDE_E_ARG;
     e->d_summary = (sonde_summary_t *)d_summary; e->summary_base = channel_base;
     return 0;
+}
+
+int sonde_engine_set_summary_snapshots(sonde_engine_t *e, void *d_snap) {
+    if (!e) return SONDE_E_ARG;
+    e->d_summary_snap = (sonde_summary_t *)d_snap;
+    return (int)(e->call & 1);
 }
 
 int sonde_engine_overflowed(sonde_engine_t *e) {

@@ -217,6 +217,11 @@ class Engine:
         (radiosonde_auto_rx_amd.shard.summary_buffer); 0 switches them off."""
         _chk(lib().sonde_engine_set_summary(self._h, C.c_void_p(device_ptr), channel_base))
 
+    def set_summary_snapshots(self, device_ptr: int) -> int:
+        """device memory for 2 x n_channels records: every process call leaves a copy of the summaries in half (call & 1), stable once a
+        lagged fetch has waited for that call (include/sonde_hip.h).  Returns the half the next call fills."""
+        return _chk(lib().sonde_engine_set_summary_snapshots(self._h, C.c_void_p(device_ptr)))
+
     def overflowed(self) -> bool:
         """True if the device-side frame queue overflowed since the last call (oldest frames overwritten before a fetch read them);
         the fetch_* methods return what they could read either way"""

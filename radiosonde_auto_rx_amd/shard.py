@@ -41,25 +41,36 @@ def decode_summaries(t) -> np.ndarray:
     return t.detach().cpu().numpy().reshape(-1, SUMMARY_BYTES).view(SUMMARY_DTYPE).reshape(-1)
 
 
+def _host_staged(dist, t) -> bool:
+    """gloo has no all_gather on device tensors: stage through host memory (single-GPU readiness tests; RCCL takes the device tensors)"""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
 def gather_summaries(dist, local, world: int, out=None):
     """all_gather of equal-sized per-rank summary tensors (device resident) -> list ordered by rank = global channel order."""
     import torch
     if out is None:
         out = [torch.empty_like(local) for _ in range(world)]
+    if _host_staged(dist, local):
+        host = [torch.empty(local.shape, dtype=local.dtype) for _ in range(world)]
+        dist.all_gather(host, local.cpu())
+        for o, h in zip(out, host):
+            o.copy_(h)
+        return out
     dist.all_gather(out, local)
     return out
 
 
 def max_over_ranks(dist, value: float, device) -> float:
     import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def gather_floats(dist, value: float, world: int, device) -> list:
     import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     return [float(o.item()) for o in out]

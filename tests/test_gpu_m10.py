@@ -38,27 +38,37 @@ def test_cli_m10_matches_reference(name):
 
 
 def test_m10_engine_many_channels():
-    """Batched form: 6 channels of one engine, each its own capture and carrier; frames per channel equal the single-channel CLI
-    goldens' frame bytes for the matching capture."""
+    """Batched form: 11 channels of one 2.4 Msps engine (the hand-scheduled decimator with its channel -> XCD mapping), each its own
+    capture, carrier, offset, noise and start time, fed from device memory; per channel every text line equals the stdout of the compiled
+    reference `m10mod -r -v --IQ fq --lpIQ - 2400000 16` on that capture."""
+    import torch
     from radiosonde_auto_rx_amd.engine import Engine
     from tools import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "m10mod")
+    if not os.path.exists(ref):
+        pytest.skip("compiled reference not present")
     sr = 2_400_000
-    fqs = [synth.snap_fq(f, sr) for f in (0.11, -0.2, 0.3, -0.05, 0.01, 0.4)]
-    caps = [synth.m10_capture(sr=sr, seconds=1.6, fq=fq, noise_sigma=0.02, seed=20 + k, t_first=0.2 + 0.03 * k) for k, fq in enumerate(fqs)]
+    fqs = [synth.snap_fq(f, sr) for f in (0.11, -0.2, 0.3, -0.05, 0.01, 0.4, -0.33, 0.22, -0.44, 0.17, -0.12)]
+    caps = [synth.m10_capture(sr=sr, seconds=2.3, fq=fq, noise_sigma=(0.02, 0.05, 0.1)[k % 3], seed=20 + k, t_first=0.2 + 0.03 * k, f_offset_hz=150.0 * (k - 5),
+                              frame_fn=lambda j, k=k: synth.m10_frame(j, rng=np.random.default_rng(40 * k + j), good_checksum=(j + k) % 4 != 3))
+            for k, fq in enumerate(fqs)]
     x = np.stack(caps)
-    eng = Engine(fqs, sr, sonde="m10", max_chunk=sr, max_frames=32)
+    dev = torch.from_numpy(x).to("cuda:0")
+    eng = Engine(fqs, sr, sonde="m10", max_chunk=sr, max_frames=64)
     n = x.shape[1] // 2
+    n -= n % 50
     got = {}
-    for s0 in range(0, n, sr // 2):
-        s1 = min(n, s0 + sr // 2)
-        eng.process_host(np.ascontiguousarray(x[:, 2 * s0:2 * s1]))
+    for s0 in range(0, n, sr):
+        s1 = min(n, s0 + sr)
+        eng.process_device(dev.data_ptr() + 4 * s0, x.shape[1] // 2, s1 - s0)
         for f in eng.fetch_mxx(finish=s1 >= n):
-            got.setdefault(f["channel"], []).append(f["frame"][:f["len"]])
-            assert f["line"].startswith(f["frame"][:f["len"]].hex())
+            got.setdefault(f["channel"], []).append(f["line"].rstrip())
     eng.close()
     assert sorted(got) == list(range(len(fqs)))
-    for c in range(len(fqs)):
-        assert len(got[c]) >= 1 and all(f[:2] == bytes([0x64, 0x9F]) and len(f) == 101 for f in got[c][:1])
+    for c, fq in enumerate(fqs):
+        r = subprocess.run([ref, "-r", "-v", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], input=x[c, :2 * n].tobytes(), capture_output=True, timeout=180)
+        want = [l.rstrip() for l in r.stdout.decode().splitlines()]
+        assert got[c] == want and len(want) >= 2, c
 
 
 @pytest.mark.parametrize("args", [["--json", "--ptu", "-vvv"], ["-vv", "--ptu"], ["-r", "-v", "--json"]])

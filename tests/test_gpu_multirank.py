@@ -1,0 +1,35 @@
+"""Multi-rank readiness on ONE GPU: `bench.py --gpus 2` launched the way the driver launches it (torch.distributed.run, one process per
+rank), with SONDE_DIST_BACKEND=gloo so that both ranks may share device 0 — exercises Dist, the per-rank engines, the per-step summary
+all_gather (pipelined: from the engine's snapshots), rank_ms_per_step, sum_ints and the per-rank oracle verification end to end.  No
+scaling figure is taken from this; the driver measures N = 1, 2, 4, 8 over RCCL itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("lag", [1, 0])
+def test_bench_two_ranks_on_one_device(lag):
+    env = dict(os.environ, SONDE_DIST_BACKEND="gloo", SONDE_BENCH_NO_REPEAT="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() + lag) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--channels", "40", "--lag", str(lag)]
+    r = subprocess.run(cmd, capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints, nobody else
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and cfg["channels_per_gpu"] == 40
+    assert len(cfg["rank_ms_per_step"]) == 2 and all(t > 0 for t in cfg["rank_ms_per_step"])
+    assert abs(d["ms_per_step"] - max(cfg["rank_ms_per_step"])) < 1e-3                 # max over ranks
+    assert abs(d["value"] - 2 * 40 * 2.4e6 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]        # whole-job samples / max time
+    assert cfg["frames_decoded"] >= 2 * 40 * 5 and cfg["frames_ecc_ok"] == cfg["frames_decoded"]          # summed over ranks
+    assert cfg["verified_channels"] == 80 and not cfg.get("verify_failed")                                # both ranks' channels against the oracle
+    assert cfg["frame_fetch_lag"] == lag
+    assert "cpu_baseline" not in d and "detect_in_step" not in d                                          # single-GPU extras stay out of N > 1 lines

@@ -6,7 +6,7 @@ Tolerances (stated per SURVEY.md §7/§8c and BASELINE.json):
                                                            own -Ofast self-noise on these is ~4e-8 / 1.5e-7)
   tone-correlator stream `bufs` (the sliced stream) ...... 1e-5 RMS abs, and <= 3x the reference's own
                                                            -Ofast-vs-O2 floor stored in the fixture (~3e-6)
-  soft bits (sum of 4 centre samples) .................... 3e-5 RMS abs and <= 3x the fixture's floor_soft (~1e-5)
+  soft bits (RS41: sum of 4 centre samples; DFM halves) .. 1e-5 RMS abs and <= 3x the fixture's floor_soft (~1e-5)
 """
 import numpy as np
 import pytest
@@ -198,7 +198,7 @@ def test_dfm_frames_match_golden_and_oracle(oracle, name):
     for h, s in enumerate(hits_soft):
         nb = int(o["nbits"][h])
         d = rms(s[:nb] - o["soft"][h][:nb])
-        assert d < 1e-4 and d <= 3 * float(g["floor_soft"]) + 1e-6, d
+        assert d < 1e-5 and d <= 3 * float(g["floor_soft"]) + 1e-6, d      # north_star: 1e-5 RMS (the reference's own -Ofast floor here: 1.3-2.6e-5)
     eng.close()
 
 

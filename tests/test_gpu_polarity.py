@@ -31,8 +31,10 @@ def test_cli_polarity_matches_reference(name):
 
 
 def test_engine_polarity_is_per_channel():
-    """Two channels of one engine, one mirrored: with --auto each channel settles on its own polarity and both decode; the soft
-    bits of the mirrored channel equal those of the same capture decoded with -i."""
+    """Two channels of one engine, one mirrored: with --auto each channel settles on its own polarity and both decode.  Checked
+    against the compiled reference per channel (`rs41mod -r --ecc2 --crc --auto --IQ fq --lpIQ` on the upright capture, the same with -fq on
+    the mirrored one: identical stdout) and against the reference's soft bits of the mirrored capture sliced with inverted polarity."""
+    from oracle import bind
     from radiosonde_auto_rx_amd.engine import Engine
     from tools import synth
     sr = 2_400_000
@@ -52,6 +54,11 @@ def test_engine_polarity_is_per_channel():
     assert len(by[0]) == 2 and len(by[1]) == 2
     assert [f["line"] for f in by[0]] == [f["line"] for f in by[1]]
     assert all(f["mv"] > 0 for f in by[0]) and all(f["mv"] < 0 for f in by[1])
+    if bind.have_ref():
+        for c, (cap, f0) in enumerate(((x, fq), (xm, -fq))):
+            out, _, rc = bind.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "--auto", "--IQ", repr(f0), "--lpIQ", "-", str(sr), "16"], cap)
+            assert rc == 0 and [l.rstrip() for l in out.splitlines()] == [f["line"].rstrip() for f in by[c]], c
+    # the same mirrored capture with -i on a one-channel engine: same positions and bit-identical soft values
     eng = Engine([-fq], sr, inv=True, keep_soft=True, max_chunk=sr, max_frames=8)
     fi = []
     for s0 in range(0, n, sr // 2):
@@ -63,3 +70,6 @@ def test_engine_polarity_is_per_channel():
     assert len(fi) == 2
     for a, b in zip(by[1], fi):
         assert a["mv_pos"] == b["mv_pos"] and np.array_equal(a["soft"], b["soft"])
+    if bind.have_ref():
+        out, _, rc = bind.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "-i", "--IQ", repr(-fq), "--lpIQ", "-", str(sr), "16"], xm)
+        assert rc == 0 and [l.rstrip() for l in out.splitlines()] == [f["line"].rstrip() for f in fi]
