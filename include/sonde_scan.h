@@ -44,7 +44,11 @@ typedef struct {
     float   ths;             /* --ths x (all templates), 0 = per-type defaults                      */
     float   time_limit;      /* -t seconds, <= 0: none                                              */
     uint32_t disable_mask;   /* bit j: skip template j; 0 = as the reference build (C34C50, IMET1AB off, scan/Makefile:1) */
-    int32_t reserved[4];
+    int32_t opt_exact;       /* 0: every (window, template) is scored by the matrix-core prefilter, and those within 0.03 of their
+                              *    threshold — plus the same template's window before them — by the reference's own transform network;
+                              *    detections, scores, positions and exit codes are the same as with 1.
+                              * 1: the transform network for every pair (testing tap: per-window parity of every template)  */
+    int32_t reserved[3];
 } sonde_scan_cfg_t;
 
 /* One printed detection = one stdout line of dft_detect (dft_detect.c:1612-1634). */
@@ -78,7 +82,8 @@ typedef struct {
     float    mv[SONDE_SCAN_NTPL];
     uint32_t mpos[SONDE_SCAN_NTPL];
     float    dc[SONDE_SCAN_NTPL];
-    int32_t  herrs[SONDE_SCAN_NTPL];         /* -1: threshold not reached, header not compared       */
+    int32_t  herrs[SONDE_SCAN_NTPL];         /* -1: threshold not reached, header not compared; -2: prefilter only — |mv| is at least
+                                              *  0.03 below the threshold, mp / mv / mpos are the prefilter's (mv within ~1e-3)        */
     uint32_t m10[SONDE_SCAN_NTPL];
 } sonde_scan_window_t;
 

@@ -160,6 +160,8 @@ struct SyncArgs {
 extern "C" {
 int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
+void sonde_launch_dc_update_keep(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, float maxcnt, hipStream_t s);
+void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapped, hipStream_t s);
 void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s);

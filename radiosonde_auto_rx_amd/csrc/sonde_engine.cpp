@@ -36,6 +36,7 @@ struct sonde_engine {
     hipStream_t stream_b = nullptr;    // B: IF chain, header correlation, framesync (may overlap the next call's A work)
     hipEvent_t ev_a[4] = {}, ev_b[4] = {};
     unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
+    unsigned *h_count_dev = nullptr;   // the same words as the device addresses them (k_publish_u32 writes them)
     FrameRec *h_recs = nullptr;        // pinned staging for record fetches
     int64_t call = 0;                  // process calls issued
     unsigned read_idx = 0;             // frames already handed to the caller (monotonic)
@@ -455,8 +456,9 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
     for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming));
-    HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocMapped));
     memset(e->h_count, 0, 4 * sizeof(unsigned));
+    HIPCHK(hipHostGetDevicePointer((void **)&e->h_count_dev, e->h_count, 0));
     HIPCHK(hipHostMalloc((void **)&e->h_recs, (size_t)e->max_frames * sizeof(FrameRec), hipHostMallocDefault));
     *out = e;
     return 0;
@@ -598,8 +600,8 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
         if (e->dc_cnt == e->dc_max) {
-            if (e->d_etab) { hipMemcpyAsync(e->d_dcavg_prev, e->d_dcavg, (size_t)C * sizeof(float2), hipMemcpyDeviceToDevice, e->stream); e->dc_since = 0; }
-            sonde_launch_dc_update(C, e->d_dcsums, e->d_dcavg, (float)e->dc_max, e->stream);
+            if (e->d_etab) e->dc_since = 0;
+            sonde_launch_dc_update_keep(C, e->d_dcsums, e->d_dcavg, e->d_etab ? e->d_dcavg_prev : nullptr, (float)e->dc_max, e->stream);
             e->dc_cnt = 0;
             if (e->dc_max < e->dc_lim) e->dc_max *= 2;
         }
@@ -670,7 +672,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
             launch_framesync(e, 0);
         }
     }
-    hipMemcpyAsync(e->h_count + slot, e->d_fcount, sizeof(unsigned), hipMemcpyDeviceToHost, e->stream_b);
+    sonde_launch_publish_u32(e->d_fcount, e->h_count_dev + slot, e->stream_b);
     if (e->d_summary && e->d_summary_snap)
         hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
     hipEventRecord(e->ev_b[slot], e->stream_b);

@@ -597,13 +597,18 @@ void k_mix_decimate_wide(const MixDecArgs a) {
 }
 
 // avg = (float)(sum / (float)maxcnt) with sum = S/32768 exact in double (demod_mod.c:498-503)
-__global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float maxcnt) {
+// dc_avg_prev (optional): keeps the mean that was in effect up to here (md_dc_boundary corrects the outputs whose taps straddle the change)
+__global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float2 *dc_avg_prev, float maxcnt) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_ch) return;
     const double sx = (double)dc_sums[2 * c] / 32768.0, sy = (double)dc_sums[2 * c + 1] / 32768.0;
+    if (dc_avg_prev) dc_avg_prev[c] = dc_avg[c];
     dc_avg[c] = make_float2((float)(sx / (double)maxcnt), (float)(sy / (double)maxcnt));
     dc_sums[2 * c] = 0; dc_sums[2 * c + 1] = 0;
 }
+// one word of device memory -> pinned host memory (the frame counter after a call's frame sync): a one-lane kernel on the same queue instead of
+// a copy-engine round trip at the end of every call
+__global__ void k_publish_u32(const unsigned *src, unsigned *dst) { if (threadIdx.x == 0) *dst = *src; }
 
 // ------------------------------------------------------------------------------------------------
 // k_u8_to_s16: 8-bit unsigned input (rtl_sdr's native IQ format, 8-bit WAV).  The reference reads x = (u - 128) / 128.0
@@ -1669,7 +1674,13 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     return 0;
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
+    hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, (float2 *)nullptr, maxcnt);
+}
+extern "C" void sonde_launch_dc_update_keep(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, float maxcnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, avg_prev, maxcnt);
+}
+extern "C" void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapped, hipStream_t s) {
+    hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(64), 0, s, src, dst_mapped);
 }
 extern "C" void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s) {
     hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab);

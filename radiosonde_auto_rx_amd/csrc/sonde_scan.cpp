@@ -133,6 +133,9 @@ struct Chan {
     const char *type[kNrs]; int tn[kNrs]; int detect2[kNrs];
     int j_max = 0; float mv_max = 0.f; int d2_tn = kNrs; bool done = false;
     uint32_t next_sin = 0;
+    // prefilter bookkeeping: the most recent decided window and which of its templates were evaluated by the exact kernel (a candidate in the
+    // NEXT window needs this one's exact peak position for `mv_pos > mv0_pos`, dft_detect.c:1521)
+    bool last_valid = false; uint32_t last_pos = 0; uint32_t last_exact = 0;
     // IMET AFSK post-processing in progress (dft_detect.c:1533-1607): the window's decision waits for one more second of the FM stream
     bool imet_hold = false; uint32_t imet_sin = 0; int imet_hf = 0;
 };
@@ -172,6 +175,9 @@ struct sonde_scan {
     float2 *d_y = nullptr; float *d_fm = nullptr; float *d_wiq = nullptr; float2 *d_G = nullptr, *d_tw = nullptr, *d_WS = nullptr;
     uint8_t *d_hdr = nullptr; int *d_bnd = nullptr; ScanItem *d_items = nullptr; ScanRes *d_res = nullptr;
     ScanItem *h_items = nullptr; ScanRes *h_res = nullptr; int item_cap = 0;
+    // prefilter (k_scan_pre): A fragments of the templates / FM low-passes, per-pair results, work list of the exact kernel
+    uint16_t *d_amatch = nullptr, *d_aws = nullptr; float *d_wstail = nullptr; int a_off[SC_NTPL] = {0}, nc2[SC_NTPL] = {0}, nc1 = 0, ws_pad = 0;
+    ScanPre *d_pre = nullptr, *h_pre = nullptr; ScanWork *d_work = nullptr, *h_work = nullptr; bool use_pre = false;
     void *d_stage = nullptr; size_t stage_bytes = 0;
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy
     double *d_dcsums_f = nullptr; float2 *d_zring = nullptr; float *d_taps_f = nullptr; uint32_t zmask = 0;   // float32 input (MixF32Args)
@@ -198,6 +204,21 @@ template <class T> static int dupload(T **p, const std::vector<T> &v) {
     if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
+
+// ---- prefilter tables (k_scan_pre, sonde_scan_pre.hip)
+static uint16_t f16_bits(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, sizeof u); return u; }
+// A fragments of the Toeplitz product out[i] = sum_u h[u] x[i+u]: step c, lane (b = lane & 15, g = lane >> 4), element r  <-  h[16 c + 8 g + r - b]
+static int toeplitz_frags(const std::vector<float> &h, std::vector<uint16_t> &out) {
+    const int U = (int)h.size(), nc = (U - 1 + 15) / 16 + 1;
+    for (int c = 0; c < nc; c++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int r = 0; r < 8; r++) {
+                const int u = 16 * c + 8 * (lane >> 4) + r - (lane & 15);
+                out.push_back((u >= 0 && u < U) ? f16_bits(h[u]) : (uint16_t)0);
+            }
+    return nc;
+}
+static const float kPreMargin = 0.03f;      // candidates: smax > thres - margin; the prefilter's own error is ~1e-4 (tests/test_scan_prefilter_model.py)
 
 extern "C" {
 
@@ -289,6 +310,7 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
         for (int i = 0; i < s->lpfm_taps; i++) WS[j][i].x = w_lp[(size_t)j * s->lpfm_taps + i];
         dft_ref_host(WS[j], tws);
     }
+    std::vector<uint16_t> a_match, a_ws;
     for (int j = 0; j < SC_NTPL; j++) {
         ScanTpl &t = s->tpl[j];
         memset(&t, 0, sizeof t);
@@ -302,6 +324,7 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
         s->info.L[j] = t.L;
         // Fm = dft of the time-reversed template (m[L-1-i] = match[i], dft_detect.c:1260-1262); G = WS[lpFM] * Fm
         const std::vector<float> match = scan_match(kTpl[j].hdr, hLenMax, t.spb, kTpl[j].bt, t.L);
+        s->a_off[j] = (int)a_match.size(); s->nc2[j] = toeplitz_frags(match, a_match);        // c'[p'] = sum_k match[k] xf[p' + k]
         std::vector<float2> F(SC_N, make_float2(0.f, 0.f));
         for (int i = 0; i < t.L; i++) F[t.L - 1 - i].x = match[i];
         dft_ref_host(F, tws);
@@ -311,6 +334,21 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
             G[(size_t)j * SC_N + k] = g;
         }
     }
+
+    // FM low-pass as a Toeplitz product on the window stored behind ws_pad zeros: xf[i] = sum_t ws[t] xn[i-t] = sum_u h[u] xh[i+u],
+    // h[u] = ws[taps-1-(u-front)], front = padding that makes ws_pad = taps-1+front a multiple of 8 (aligned 16-byte LDS reads)
+    std::vector<float> ws_tail;
+    if (iq) {
+        const int taps = s->lpfm_taps, front = (8 - (taps - 1) % 8) % 8;
+        s->ws_pad = taps - 1 + front;
+        for (int lp = 0; lp < 2; lp++) {
+            std::vector<float> h((size_t)front + taps, 0.f);
+            for (int t = 0; t < taps; t++) h[(size_t)front + (taps - 1 - t)] = w_lp[(size_t)lp * taps + t];
+            s->nc1 = toeplitz_frags(h, a_ws);
+            for (int i = 0; i < taps; i++) { double acc = 0; for (int t = i + 1; t < taps; t++) acc += (double)w_lp[(size_t)lp * taps + t]; ws_tail.push_back((float)acc); }
+        }
+    }
+    s->use_pre = cfg->opt_exact == 0;
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
     int ring = 1; while (ring < max_if + sr + 2 * SC_N + 4096) ring <<= 1;        // + one second: the IMET check re-reads it (imet_resolve)
@@ -327,10 +365,15 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
     bad |= dupload(&s->d_G, G); bad |= dupload(&s->d_tw, tws); bad |= dupload(&s->d_hdr, hdrbits); bad |= dupload(&s->d_bnd, bnd);
     if (iq) { bad |= dupload(&s->d_wiq, w_iq); std::vector<float2> ws2(WS[0]); ws2.insert(ws2.end(), WS[1].begin(), WS[1].end()); bad |= dupload(&s->d_WS, ws2); }
     s->item_cap = C * (max_if / (s->K - 4) + 2);
-    bad |= dalloc(&s->d_items, (size_t)s->item_cap, false); bad |= dalloc(&s->d_res, (size_t)s->item_cap * SC_NTPL, false);
+    const size_t icap = (size_t)s->item_cap + C;           // + one re-evaluated window of the previous call per channel (prefilter)
+    bad |= dalloc(&s->d_items, icap, false); bad |= dalloc(&s->d_res, icap * SC_NTPL, false);
+    bad |= dupload(&s->d_amatch, a_match); bad |= dupload(&s->d_aws, a_ws); bad |= dupload(&s->d_wstail, ws_tail);
+    bad |= dalloc(&s->d_pre, icap * SC_NTPL, false); bad |= dalloc(&s->d_work, icap * SC_NTPL, false);
     if (bad) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
-    HIPCHK(hipHostMalloc((void **)&s->h_items, (size_t)s->item_cap * sizeof(ScanItem), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&s->h_res, (size_t)s->item_cap * SC_NTPL * sizeof(ScanRes), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_items, icap * sizeof(ScanItem), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_res, icap * SC_NTPL * sizeof(ScanRes), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_pre, icap * SC_NTPL * sizeof(ScanPre), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s->h_work, icap * SC_NTPL * sizeof(ScanWork), hipHostMallocDefault));
     HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
 
     // IQ-DC: always on, fixed window (dft_detect.c:1152-1156)
@@ -350,7 +393,9 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
     if (s->h_items) hipHostFree(s->h_items);
     if (s->h_res) hipHostFree(s->h_res);
-    void *ptrs[] = { s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
+    if (s->h_pre) hipHostFree(s->h_pre);
+    if (s->h_work) hipHostFree(s->h_work);
+    void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
                      s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
@@ -530,20 +575,90 @@ static int run_windows(sonde_scan *s) {
         }
         first_item[C] = n_items;
         if (!n_items) break;
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, s->stream);
-        HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+        hipEvent_t e0, e1, e2; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
         ScanCorrArgs a{};
         a.fm = s->d_fm; a.n_ch = C; a.ring_len = s->ring_len; a.items = s->d_items; a.n_items = n_items;
         memcpy(a.tpl, s->tpl, sizeof a.tpl);
         a.G = s->d_G; a.WS = s->d_WS; a.lpfm_taps = s->lpfm_taps; a.tws = s->d_tw; a.K = s->K; a.opt_dc = s->cfg.opt_dc;
         a.opt_iq = (mode != SONDE_SCAN_AUDIO); a.hdrbits = s->d_hdr; a.bnd = s->d_bnd; a.out = s->d_res;
-        if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
-        HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
-        hipEventRecord(e1, s->stream);
-        HIPCHK(hipStreamSynchronize(s->stream));
-        timed(s, "scan_corr", e0, e1);
-        hipEventDestroy(e0); hipEventDestroy(e1);
+        std::vector<uint32_t> exact((size_t)n_items + C, 0u);                 // per window: templates evaluated by the exact kernel
+        int n_all = n_items;                                                  // + re-evaluated last windows of the previous call
+        std::vector<int> aux_of(C, -1);
+        if (!s->use_pre) {
+            hipEventRecord(e0, s->stream);
+            HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+            hipEventRecord(e1, s->stream);
+            if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
+            HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
+            hipEventRecord(e2, s->stream);
+            HIPCHK(hipStreamSynchronize(s->stream));
+            timed(s, "scan_corr", e1, e2);
+            for (int i = 0; i < n_items; i++) exact[i] = 0xffffu;
+        } else {
+            // pass 1: the prefilter over every (window, template)
+            ScanPreArgs pa{};
+            pa.fm = s->d_fm; pa.n_ch = C; pa.ring_len = s->ring_len; pa.items = s->d_items; pa.n_items = n_items;
+            memcpy(pa.tpl, s->tpl, sizeof pa.tpl);
+            pa.a_match = s->d_amatch; memcpy(pa.a_off, s->a_off, sizeof pa.a_off); memcpy(pa.nc2, s->nc2, sizeof pa.nc2);
+            pa.a_ws = s->d_aws; pa.nc1 = s->nc1; pa.taps = s->lpfm_taps; pa.ws_pad = s->ws_pad; pa.ws_tail = s->d_wstail;
+            pa.K = s->K; pa.opt_dc = s->cfg.opt_dc; pa.opt_iq = a.opt_iq; pa.lpfm_taps = s->lpfm_taps; pa.out = s->d_pre;
+            hipEventRecord(e0, s->stream);
+            HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+            if (sonde_launch_scan_pre(&pa, s->stream) < 0) return SONDE_E_NOGPU;
+            HIPCHK(hipMemcpyAsync(s->h_pre, s->d_pre, (size_t)n_items * SC_NTPL * sizeof(ScanPre), hipMemcpyDeviceToHost, s->stream));
+            hipEventRecord(e1, s->stream);
+            HIPCHK(hipStreamSynchronize(s->stream));
+            timed(s, "scan_pre", e0, e1);
+            // candidates, and for each the same template in the window before it (this call's, or the last one of the previous call)
+            int n_work = 0;
+            auto add = [&](int item, int j) { if (!((exact[item] >> j) & 1u)) { exact[item] |= 1u << j; s->h_work[n_work].item = item; s->h_work[n_work].tpl = j; n_work++; } };
+            for (int c = 0; c < C; c++) {
+                Chan &cs = s->chan[c];
+                for (int i = first_item[c]; i < first_item[c + 1]; i++)
+                    for (int j = 0; j < SC_NTPL; j++) {
+                        if (!s->tpl[j].active || !(s->h_pre[(size_t)i * SC_NTPL + j].smax > s->thres[j] - kPreMargin)) continue;
+                        add(i, j);
+                        if (i > first_item[c]) add(i - 1, j);
+                        else if (cs.last_valid && !((cs.last_exact >> j) & 1u)) {
+                            if (aux_of[c] < 0) { aux_of[c] = n_all; s->h_items[n_all].ch = c; s->h_items[n_all].pos = cs.last_pos; n_all++; }
+                            add(aux_of[c], j);
+                        }
+                    }
+            }
+            { auto &k = s->stats["exact_pairs"]; k.ms += n_work; k.n += 1; }          // counters read through sonde_scan_kernel_ms: average pairs per round
+            { int act = 0; for (int j = 0; j < SC_NTPL; j++) act += s->tpl[j].active; auto &k = s->stats["pre_pairs"]; k.ms += (double)n_items * act; k.n += 1; }
+            // pass 2: the reference's transform network for the listed pairs
+            if (n_work > 0) {
+                hipEventRecord(e1, s->stream);
+                a.n_items = n_all; a.work = s->d_work; a.n_work = n_work;
+                if (n_all > n_items) HIPCHK(hipMemcpyAsync(s->d_items + n_items, s->h_items + n_items, (size_t)(n_all - n_items) * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+                HIPCHK(hipMemcpyAsync(s->d_work, s->h_work, (size_t)n_work * sizeof(ScanWork), hipMemcpyHostToDevice, s->stream));
+                if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
+                HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_all * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
+                hipEventRecord(e2, s->stream);
+                HIPCHK(hipStreamSynchronize(s->stream));
+                timed(s, "scan_corr", e1, e2);
+            }
+            // everything else keeps the prefilter's values: below the threshold by more than the margin, header not compared (herrs = -2)
+            for (int i = 0; i < n_items; i++)
+                for (int j = 0; j < SC_NTPL; j++) {
+                    if ((exact[i] >> j) & 1u) continue;
+                    const ScanPre &q = s->h_pre[(size_t)i * SC_NTPL + j];
+                    s->h_res[(size_t)i * SC_NTPL + j] = ScanRes{ s->tpl[j].active ? q.mp : 0, q.mv, q.mpos, q.dc, s->tpl[j].active ? -2 : -1, 0u };
+                }
+            // a re-evaluated last window of the previous call: its exact verdict replaces what the prefilter left in mv_pos (decide() kept the
+            // value from before that window in mv0_pos)
+            for (int c = 0; c < C; c++) {
+                if (aux_of[c] < 0) continue;
+                Chan &cs = s->chan[c];
+                for (int j = 0; j < SC_NTPL; j++) {
+                    if (!((exact[aux_of[c]] >> j) & 1u)) continue;
+                    const ScanRes &r = s->h_res[(size_t)aux_of[c] * SC_NTPL + j];
+                    cs.mv_pos[j] = (r.mp > 0) ? r.mpos : cs.mv0_pos[j];
+                }
+            }
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
         for (int c = 0; c < C; c++) {
             Chan &cs = s->chan[c];
             for (int i = first_item[c]; i < first_item[c + 1]; i++) {
@@ -555,6 +670,7 @@ static int run_windows(sonde_scan *s) {
                 s->last_windows.push_back(w);
                 const uint32_t win_sin = cs.next_sin;
                 cs.next_sin += (uint32_t)(s->K - 4);
+                cs.last_valid = true; cs.last_pos = s->h_items[i].pos; cs.last_exact = exact[i];
                 decide(s, c, r, win_sin);
             }
         }

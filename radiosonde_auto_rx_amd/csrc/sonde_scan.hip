@@ -131,7 +131,9 @@ void k_scan_corr(const ScanCorrArgs a) {
     __shared__ float s_rf[SC_THREADS / WAVE];
     __shared__ int s_ri[SC_THREADS / WAVE];
     __shared__ double s_rd[SC_THREADS / WAVE];
-    const int item = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int item = blockIdx.x, j = blockIdx.y;
+    if (a.work) { const ScanWork w = a.work[blockIdx.x]; item = w.item; j = w.tpl; }      // listed pairs only (behind the prefilter)
     const ScanItem it = a.items[item];
     const int K = a.K, N = SC_N;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
@@ -294,6 +296,7 @@ extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_corr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set = true;
     }
+    if (a->work) { if (a->n_work > 0) hipLaunchKernelGGL(k_scan_corr, dim3(a->n_work, 1), dim3(SC_THREADS), lds, s, *a); return 0; }
     if (a->n_items <= 0) return 0;
     hipLaunchKernelGGL(k_scan_corr, dim3(a->n_items, SC_NTPL), dim3(SC_THREADS), lds, s, *a);
     return 0;

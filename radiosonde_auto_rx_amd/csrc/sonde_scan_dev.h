@@ -41,8 +41,27 @@ struct ScanCorrArgs {
     const uint8_t *hdrbits;
     const int *bnd;           // bit boundaries in samples (float accumulation of the reference tabulated on the host)
     ScanRes *out;             // [n_items][SC_NTPL]
+    const struct ScanWork *work; int n_work;      // work list: one workgroup per listed (window, template) pair (nullptr: the full n_items x SC_NTPL grid)
 };
+struct ScanWork { int item, tpl; };
 
+// Prefilter (k_scan_pre, sonde_scan_pre.hip): every (window, template) is first scored in the time domain on the matrix cores (f16 inputs,
+// f32 accumulation) — FM low-pass and header correlation as Toeplitz products, energy under the template from prefix sums.  smax is an UPPER
+// bound (up to the f16 rounding, ~1e-4) of |mv| as getCorrDFT would return it: the reference normalises the correlation at its arg-max, smax
+// takes the maximum of the normalised value over all positions.  Only pairs with smax > thres - margin go to the exact transform network.
+struct ScanPre { float smax; float mv; int mp; uint32_t mpos; float dc; int pad; };
+struct ScanPreArgs {
+    const float *fm; int n_ch, ring_len;
+    const ScanItem *items; int n_items;
+    ScanTpl tpl[SC_NTPL];
+    const uint16_t *a_match;  // f16 A fragments of the header templates: template j at a_off[j] (halves), nc2[j] steps of 64 lanes x 8 halves
+    int a_off[SC_NTPL], nc2[SC_NTPL];
+    const uint16_t *a_ws;     // f16 A fragments of the two FM low-passes: [2][nc1][64][8]
+    int nc1, taps, ws_pad;    // ws_pad = taps - 1 + front padding of the tap vector, a multiple of 8 (16-byte aligned LDS reads)
+    const float *ws_tail;     // [2][taps]: sum of the taps behind tap i (what a constant loses in the filter's first taps-1 outputs)
+    int K, opt_dc, opt_iq, lpfm_taps;
+    ScanPre *out;             // [n_items][SC_NTPL]
+};
 struct ScanIfArgs {
     const float2 *y;          // [n_ch][ring_len] IF-rate IQ
     float *fm;                // [streams][n_ch][ring_len]
@@ -68,6 +87,7 @@ struct AudioConvArgs {        // FM audio in (f32read_sample, dft_detect.c:505-5
 extern "C" {
 void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s);
 int  sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s);
+int  sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s);
 void sonde_launch_iq_convert(const IqConvArgs *a, hipStream_t s);
 void sonde_launch_audio_convert(const AudioConvArgs *a, hipStream_t s);
 }

@@ -1,0 +1,226 @@
+// sonde_scan_pre.hip — k_scan_pre: the scanner's prefilter on the matrix cores (gfx950, v_mfma_f32_16x16x32_f16).
+//
+// getCorrDFT (scan/dft_detect.c:357-443) scores a header template against a window as
+//     mv = c[mp] / sqrt(e[mp]),  c[p] = sum_k match[k] xf[p-L+1+k],  e[p] = sum_{i<L} xf[p-i]^2,  mp = argmax_p c[p]^2,
+// where xf is the window (K+L samples ending at sample_out, zeros before and behind it) after `X[0] -= N dc 0.98` (a constant 0.98 dc taken off
+// every sample) and the FM low-pass — all evaluated through its own drifting radix-2 transform, which is what k_scan_corr mirrors at 3-4
+// transforms per (window, template).  Almost every pair is far below its threshold (noise: |mv| < 0.35 against 0.6 ... 0.8), so this kernel
+// evaluates the SAME quantities in the time domain with f16 operands and f32 accumulation — within ~1e-4 of the reference's values — and
+// reports an upper bound smax = max_p |c[p]| / sqrt(e[p]) >= |mv|; only pairs with smax > thres - margin (margin 0.03 = 300 times the rounding)
+// are handed to the exact kernel, together with the same template's window before them (its exact peak position feeds the reference's
+// `mv_pos > mv0_pos` test).  Decisions, printed scores and positions therefore still come from the reference's own transform network.
+//
+// Both the low-pass and the correlation are Toeplitz products out[i] = sum_u h[u] x[i+u]; with i = 16 a + b, u = 16 c + e - b:
+//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] X[e][a + c],   A_c[b][e] = h[16 c + e - b],  X[e][a'] = x[16 a' + e]
+// i.e. per step c one 16x16x32 MFMA: A_c is a constant fragment (tabulated by the host, 1 KB per step), the B fragment of lane (n = lane & 15,
+// g = lane >> 4) is the 8 consecutive halves x[16 (a0+n+c) + 8 g ...] — one 16-byte LDS read.  The D fragment of a lane is out[16 (a0+n) + 4 g + r],
+// r < 4.  (A and B use the same k order within a lane, so the products pair up whatever the hardware's internal k numbering is.)
+// One workgroup (4 waves) = one (window, template); LDS: window f16 + filtered window f16 + prefix sums of its squares = 67 KB, two per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sonde_scan_dev.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SP_THREADS 256
+#define SP_WAVES 4
+#define SP_MAXT 8                      // 256-sample tiles per wave (8192 samples / 256 / 4 waves)
+#define SP_PI(i) ((i) + ((i) >> 5))    // prefix sums are stored with one pad word per 32: a thread's run of 32 stays off its neighbours' banks
+
+__device__ __forceinline__ float sp_wsum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
+
+// acc[t] += A_c x B(tile t, step c) for the wave's tiles; x: f16 array in LDS whose element 0 pairs with h[0] of output 0
+template <int NT>
+__device__ __forceinline__ void sp_toeplitz(const _Float16 *x, const uint16_t *afrag, int nc, int wave, int ntiles, int lane, f32x4 (&acc)[NT]) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nc; c++) {
+        const half8 A = *reinterpret_cast<const half8 *>(afrag + ((size_t)c * 64 + lane) * 8);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int tile = wave + SP_WAVES * t;
+            if (tile < ntiles) {                                   // wave-uniform
+                const half8 B = *reinterpret_cast<const half8 *>(x + 16 * (16 * tile + n + c) + 8 * g);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SP_THREADS, 2)
+void k_scan_pre(const ScanPreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    const int item = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ScanTpl tp = a.tpl[j];
+    ScanPre *out = a.out + (size_t)item * SC_NTPL + j;
+    if (!tp.active) { if (tid == 0) *out = ScanPre{0.f, 0.f, 0, 0u, 0.f, 0}; return; }
+    const ScanItem it = a.items[item];
+    const int K = a.K, L = tp.L, wl = K + L;
+    const int nT1 = (wl + 255) >> 8, nT2 = (K + 1 + 255) >> 8, nc2 = a.nc2[j];
+    const int padL = a.opt_iq ? a.ws_pad : 0;
+    // LDS carve-up (halves / floats); every array starts on a 16-byte boundary
+    const int NXH = (256 * nT1 + 16 * a.nc1 + 48 + 7) & ~7;
+    int NXF = 256 * nT2 + 16 * nc2 + 48; if (NXF < 256 * nT1) NXF = 256 * nT1; NXF = (NXF + 7) & ~7;
+    _Float16 *xh = reinterpret_cast<_Float16 *>(sp_smem);                 // padL zeros, the window minus 0.98 dc, zeros
+    _Float16 *xfh = xh + (a.opt_iq ? NXH : 0);                             // the filtered window, zeros behind it
+    float *P = reinterpret_cast<float *>(xfh + NXF);                       // P[SP_PI(i)] = sum_{q<i} xf[q]^2, i <= 256 nT1
+    __shared__ float s_f[2 * SP_WAVES];
+    __shared__ int s_i[SP_WAVES];
+    __shared__ float s_dc;
+
+    // ---- the window: xn[i] = stream[pos - (K+L-1) + i], i < K+L (dft_detect.c:378-379); dc over its last 2L samples (:389-391)
+    const uint32_t mask = (uint32_t)a.ring_len - 1;
+    const float *str = a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len;
+    const int64_t start = (int64_t)it.pos - (wl - 1);
+    float v[32];
+    float dcp = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int i = tid + SP_THREADS * r;
+        const int64_t p = start + i;
+        v[r] = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
+        if (i >= K - L && i < wl) dcp += v[r];
+    }
+    float dc = 0.f;
+    if (a.opt_dc) {
+        const float sw = sp_wsum(dcp);
+        if (lane == 0) s_f[wave] = sw;
+        __syncthreads();
+        if (tid == 0) { float s = 0.f; for (int w = 0; w < SP_WAVES; w++) s += s_f[w]; s_dc = (float)((double)s / (2.0 * (double)(float)L)); }
+        __syncthreads();
+        dc = s_dc;
+    }
+    const float dcs = 0.98f * dc;
+    _Float16 *dst = a.opt_iq ? xh + padL : xfh;
+    const int ndst = (a.opt_iq ? NXH - padL : NXF);
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const int i = tid + SP_THREADS * r;
+        if (i < ndst) dst[i] = (_Float16)((i < wl) ? v[r] - dcs : 0.f);
+    }
+    for (int i = 32 * SP_THREADS + tid; i < ndst; i += SP_THREADS) dst[i] = (_Float16)0.f;
+    if (a.opt_iq) for (int i = tid; i < padL; i += SP_THREADS) xh[i] = (_Float16)0.f;
+    __syncthreads();
+
+    const int n = lane & 15, g = lane >> 4;
+    // ---- FM low-pass (X *= WS[lpFM], dft_detect.c:396-399): xf[i] = sum_t ws[t] xn'[i-t]; the constant -0.98 dc reaches every sample of the
+    // reference's (circular, zero padded) array, so the first taps-1 outputs get the part of it the filter has not seen yet (ws_tail)
+    if (a.opt_iq) {
+        f32x4 acc[SP_MAXT];
+        sp_toeplitz<SP_MAXT>(xh, a.a_ws + (size_t)tp.lpfm * a.nc1 * 512, a.nc1, wave, nT1, lane, acc);
+        const float *tail = a.ws_tail + tp.lpfm * a.taps;
+#pragma unroll
+        for (int t = 0; t < SP_MAXT; t++) {
+            const int tile = wave + SP_WAVES * t;
+            if (tile < nT1) {
+                const int i0 = 256 * tile + 16 * n + 4 * g;
+                half4 h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = i0 + r;
+                    float x = acc[t][r];
+                    if (i < a.taps - 1) x -= dcs * tail[i];
+                    h[r] = (_Float16)((i < wl) ? x : 0.f);
+                }
+                *reinterpret_cast<half4 *>(xfh + i0) = h;
+            }
+        }
+        for (int i = 256 * nT1 + tid; i < NXF; i += SP_THREADS) xfh[i] = (_Float16)0.f;
+        __syncthreads();
+    }
+
+    // ---- prefix sums of xf^2 (the 2-norm under the template, dft_detect.c:431-433): thread t owns samples [32 t, 32 t + 32)
+    {
+        float run[32];
+        float s = 0.f;
+        const half8 *src = reinterpret_cast<const half8 *>(xfh + 32 * tid);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const half8 h = (32 * tid + 8 * q < 256 * nT1) ? src[q] : (half8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 8; r++) { run[8 * q + r] = s; const float x = (float)h[r]; s += x * x; }
+        }
+        float inc = s;                                            // inclusive scan of the per-thread totals
+        for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        if (lane == 63) s_f[SP_WAVES + wave] = inc;
+        __syncthreads();
+        float base = inc - s;
+        for (int w = 0; w < wave; w++) base += s_f[SP_WAVES + w];
+#pragma unroll
+        for (int q = 0; q < 32; q++) P[SP_PI(32 * tid + q)] = base + run[q];
+        if (tid == SP_THREADS - 1) P[SP_PI(32 * SP_THREADS)] = base + s;
+        __syncthreads();
+    }
+
+    // ---- header correlation c'[p'] = sum_k match[k] xf[p'+k], p' = p - (L-1) in [0, K] (Z = X Fm, Nidft; arg-max range dft_detect.c:415)
+    float bc = -1.f, bs = 0.f; int bp = 0x7fffffff; float bcv = 0.f;
+    {
+        f32x4 acc[SP_MAXT];
+        sp_toeplitz<SP_MAXT>(xfh, a.a_match + a.a_off[j], nc2, wave, nT2, lane, acc);
+#pragma unroll
+        for (int t = 0; t < SP_MAXT; t++) {
+            const int tile = wave + SP_WAVES * t;
+            if (tile < nT2) {
+                const int p0 = 256 * tile + 16 * n + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int p = p0 + r;
+                    if (p <= K) {
+                        const float c = acc[t][r], ac = fabsf(c);
+                        const float e = P[SP_PI(p + L)] - P[SP_PI(p)];
+                        const float sc = e > 0.f ? ac * __builtin_amdgcn_rsqf(e) : 0.f;
+                        if (sc > bs) bs = sc;
+                        if (ac > bc || (ac == bc && p < bp)) { bc = ac; bp = p; bcv = c; }
+                    }
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(bc, off), ov = __shfl_xor(bcv, off), os = __shfl_xor(bs, off); const int op = __shfl_xor(bp, off);
+        if (oc > bc || (oc == bc && op < bp)) { bc = oc; bp = op; bcv = ov; }
+        if (os > bs) bs = os;
+    }
+    __syncthreads();
+    if (lane == 0) { s_f[wave] = bc; s_f[SP_WAVES + wave] = bs; s_i[wave] = bp; }
+    __shared__ float s_cv[SP_WAVES];
+    if (lane == 0) s_cv[wave] = bcv;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < SP_WAVES; w++) {
+            if (s_f[w] > bc || (s_f[w] == bc && s_i[w] < bp)) { bc = s_f[w]; bp = s_i[w]; bcv = s_cv[w]; }
+            if (s_f[SP_WAVES + w] > bs) bs = s_f[SP_WAVES + w];
+        }
+        ScanPre r{bs, 0.f, -1, 0u, dc, 0};
+        if (bp <= K && bc >= 0.f) {
+            const float e = P[SP_PI(bp + L)] - P[SP_PI(bp)];
+            r.mv = e > 0.f ? bcv / sqrtf(e) : 0.f;
+            const int mp = bp + L - 1;
+            r.mp = (bp == 0 || bp == K) ? -4 : mp;                                 // edge value (dft_detect.c:424)
+            r.mpos = it.pos - (uint32_t)(K + L - 1) + (uint32_t)mp;
+            if (a.opt_iq) r.mpos -= (uint32_t)(a.lpfm_taps / 2);
+        }
+        *out = r;
+    }
+}
+
+extern "C" int sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s) {
+    if (a->n_items <= 0) return 0;
+    int maxL = 0, maxc2 = 0;
+    for (int j = 0; j < SC_NTPL; j++) if (a->tpl[j].active) { if (a->tpl[j].L > maxL) maxL = a->tpl[j].L; if (a->nc2[j] > maxc2) maxc2 = a->nc2[j]; }
+    const int wl = a->K + maxL, nT1 = (wl + 255) >> 8, nT2 = (a->K + 1 + 255) >> 8;
+    if (nT1 > SP_WAVES * SP_MAXT || 256 * nT1 > 32 * SP_THREADS) return -1;          // window longer than 8192 samples
+    const size_t nxh = a->opt_iq ? (size_t)((256 * nT1 + 16 * a->nc1 + 48 + 7) & ~7) : 0;
+    size_t nxf = (size_t)256 * nT2 + 16 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1) nxf = (size_t)256 * nT1; nxf = (nxf + 7) & ~(size_t)7;
+    const size_t lds = 2 * (nxh + nxf) + 4 * (size_t)(SP_PI(256 * nT1) + 8);
+    static size_t attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pre), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(k_scan_pre, dim3(a->n_items, SC_NTPL), dim3(SP_THREADS), lds, s, *a);
+    return 0;
+}

@@ -22,7 +22,7 @@ class ScanCfg(C.Structure):
                                          "opt_min", "opt_cont", "opt_d2", "opt_lband", "audio_channels", "audio_select",
                                          "max_chunk")] + \
                [("bw_khz", C.c_float), ("ths", C.c_float), ("time_limit", C.c_float), ("disable_mask", C.c_uint32),
-                ("reserved", C.c_int32 * 4)]
+                ("opt_exact", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Detection(C.Structure):
@@ -71,7 +71,9 @@ class Scanner:
     def __init__(self, sample_rate: int, *, fq=None, n_channels: int | None = None, iq_mode: int = BBIQ, dc: bool = False,
                  bw_khz: float = 0.0, opt_min: bool = False, cont: bool = False, d2: bool = False, lband: bool = False,
                  ths: float = 0.0, time_limit: float = 0.0, max_chunk: int | None = None, device: int = 0,
-                 audio_channels: int = 1, audio_select: int = 0, disable_mask: int = 0, bits: int = 16):
+                 audio_channels: int = 1, audio_select: int = 0, disable_mask: int = 0, bits: int = 16, exact: bool = False):
+        """exact=True: every (window, template) goes through the reference's transform network (per-window parity taps); the default scores
+        them on the matrix cores first and runs the network for those within 0.03 of their threshold — same detections, scores, exit codes."""
         if fq is None:
             fq = np.zeros(n_channels or 1)
         fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
@@ -81,7 +83,7 @@ class Scanner:
         self.audio_channels = audio_channels
         self._dtype = {8: np.uint8, 32: np.float32}.get(bits, np.int16)
         cfg = ScanCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, iq_mode, int(dc), int(opt_min), int(cont), int(d2),
-                      int(lband), audio_channels, audio_select, max_chunk or sample_rate, bw_khz, ths, time_limit, disable_mask)
+                      int(lband), audio_channels, audio_select, max_chunk or sample_rate, bw_khz, ths, time_limit, disable_mask, int(exact))
         h = C.c_void_p()
         _chk(_lib().sonde_scan_create(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
         self._h = h

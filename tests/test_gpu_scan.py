@@ -7,6 +7,10 @@ Tolerances:
   text lines (`TYPE: %.4f , %+.1fHz`) ............................................................ identical
   scores mv (the kernels reproduce the reference's radix-2 transform incl. its twiddle recurrence) . 2e-5 abs
   dc (mean of the last 2L window samples) .......................................................... 1e-6 abs
+Two modes: `exact=True` runs the reference's transform network for every (window, template) — the per-window parity tests; the default
+(what the CLIs and the receivers use) scores every pair with the matrix-core prefilter first and runs the network only where the
+prefilter's upper bound comes within 0.03 of the threshold (and for the same template's window before such a pair).  The prefilter tests
+below check that this changes nothing that is printed or returned and that every pair it skipped is indeed below its threshold.
 """
 import os
 import subprocess
@@ -62,7 +66,7 @@ def test_scan_windows_and_lines_match_reference(name):
     g = load_scan(name)
     x, fq, _, case = scan_capture(name)
     sr = case["cap"]["sr"]
-    sc = _scanner(case, fq, max_chunk=sr)
+    sc = _scanner(case, fq, max_chunk=sr, exact=True)
     assert sc.info["K"] == g["consts"]["K"] and sc.info["delay"] == g["consts"]["delay"] and sc.info["L"] == g["consts"]["L"]
     wins, dets = _feed(sc, x, sr // 2, 2 if case["mode"] else 1)
     # without -c / with -t the reference stops early; the harness behind the fixture always runs to the end
@@ -74,6 +78,69 @@ def test_scan_windows_and_lines_match_reference(name):
     assert text == g["stdout"]
     code = sc.result(0)
     assert code % 256 == g["rc"]
+
+
+THRES = [0.65, 0.70, 0.70, 0.60, 0.80, 0.70, 0.76, 0.70, 0.70, 0.80, 0.65, 0.80, 0.65, 0.65, 0.80, 0.80]      # rs_hdr[].thres (dft_detect.c:172-191)
+MARGIN = 0.03
+
+
+def _check_windows_prefiltered(wins, g):
+    """default mode: pairs the exact kernel saw (herrs != -2) equal the reference; pairs left to the prefilter are below the threshold by
+    more than half the margin in the REFERENCE's own values, and the prefilter's score is close to the reference's"""
+    n_pre = n_exact = 0
+    for w, r in enumerate(wins):
+        assert r["pos"] == g["pos"][w]
+        for j in range(16):
+            gm = g["mp"][w][j]
+            if r["herrs"][j] == -2:
+                n_pre += 1
+                if gm > 0:
+                    assert abs(g["mv"][w][j]) < THRES[j] - MARGIN / 2, (w, j, g["mv"][w][j])
+                    if r["mp"][j] == gm:
+                        assert abs(r["mv"][j] - g["mv"][w][j]) < 2e-3, (w, j, r["mv"][j], g["mv"][w][j])
+                continue
+            if gm == 0 and r["mp"][j] == 0:
+                continue
+            n_exact += 1
+            assert r["mp"][j] == gm, (w, j)
+            assert abs(r["dc"][j] - g["dc"][w][j]) < 1e-6
+            if gm > 0:
+                assert r["mpos"][j] == g["mpos"][w][j] and abs(r["mv"][j] - g["mv"][w][j]) < 2e-5
+                assert r["herrs"][j] == g["herrs"][w][j] and r["m10"][j] == g["m10"][w][j]
+    return n_pre, n_exact
+
+
+@pytest.mark.parametrize("name", [n for n in SCAN_NAMES if "imet" not in n])
+def test_scan_prefilter_changes_nothing_that_is_printed(name):
+    """The default mode on the captures of the per-window tests: same text lines and exit code as the reference; the exact kernel ran for a
+    small part of the pairs only, and for every hit and its predecessor window."""
+    g = load_scan(name)
+    x, fq, _, case = scan_capture(name)
+    sr = case["cap"]["sr"]
+    sc = _scanner(case, fq, max_chunk=sr)
+    wins, dets = _feed(sc, x, sr // 2, 2 if case["mode"] else 1)
+    n_pre, n_exact = _check_windows_prefiltered(wins, g)
+    assert n_pre > 4 * n_exact                               # the point of it
+    v = "-v" in case["cli"]
+    text = "".join((d["line"] if v else d["line"].split("\n")[-1]) + "\n" for d in dets if d["printed"])
+    assert text == g["stdout"]
+    assert sc.result(0) % 256 == g["rc"]
+    for d in dets:                                           # every detection came from an exactly evaluated pair, and so did its predecessor
+        ws = [k for k, w in enumerate(wins) if w["mpos"][d["tpl"]] == d["sample"] and w["herrs"][d["tpl"]] >= 0]
+        assert ws and all(k == 0 or wins[k - 1]["herrs"][d["tpl"]] != -2 for k in ws)
+
+
+def test_scan_prefilter_chunk_edges():
+    """Windows whose predecessor belongs to the previous call: odd chunk sizes put call edges between a header's two windows"""
+    name = "scan_rs41_2400k_dc"
+    g = load_scan(name)
+    x, fq, _, case = scan_capture(name)
+    for chunk in (350 * 50 * 7, 2_400_000 // 5 + 50 * 13):
+        sc = _scanner(case, fq, max_chunk=2_400_000)
+        wins, dets = _feed(sc, x, chunk, 2)
+        _check_windows_prefiltered(wins, g)
+        assert len(wins) == len(g["pos"])
+        assert "".join(d["line"] + "\n" for d in dets) == g["stdout"]
 
 
 def test_scan_time_limit_stops_windows():
@@ -91,7 +158,7 @@ def test_scan_chunking_invariance():
     name = "scan_rs41_2400k_dc"
     g = load_scan(name)
     x, fq, _, case = scan_capture(name)
-    sc = _scanner(case, fq, max_chunk=2_400_000)
+    sc = _scanner(case, fq, max_chunk=2_400_000, exact=True)
     D = sc.info["decM"]
     wins, dets = _feed(sc, x, 77 * 1000 * D // D * 1 + 350 * D, 2)
     _check_windows(wins, g)
@@ -148,7 +215,7 @@ def test_scan_wideband_shared_stream_10msps():
     x, fqs = make_golden.wide_capture()
     assert np.allclose(fqs, g["fqs"])
     sr = make_golden.WIDE_CASE["sr"]
-    sc = Scanner(sr, fq=fqs, iq_mode=BBIQ, dc=True, cont=True, max_chunk=2_000_000)
+    sc = Scanner(sr, fq=fqs, iq_mode=BBIQ, dc=True, cont=True, max_chunk=2_000_000, exact=True)
     consts = json.loads(str(g["consts"]))
     assert sc.info["decM"] == consts["decM"] == 200 and sc.info["K"] == consts["K"] and sc.info["L"] == consts["L"]
     wins = {c: [] for c in range(len(fqs))}

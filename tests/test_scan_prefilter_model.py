@@ -1,0 +1,55 @@
+"""CPU: the prefilter's obligation (tests/scan_pre_model.py = k_scan_pre's arithmetic in numpy) against the pinned restatement of the
+reference's getCorrDFT (oracle/ora_scan.py): on FM streams with headers of several types, both polarities, a dc offset, noise and a header
+cut by the window edge, every (window, template) whose reference score comes within 0.01 of its threshold is a prefilter candidate
+(smax > thres - 0.03), the prefilter's own score is within 1e-3 of the reference's wherever both pick the same peak, and the prefilter
+is selective (a few per cent of the pairs are candidates)."""
+import numpy as np
+import pytest
+
+from scan_pre_model import PrefilterModel, MARGIN
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle import ora_scan
+    d = ora_scan.ScanDesign(48000, iq=True)
+    return ora_scan, d, PrefilterModel(d)
+
+
+def _stream(pre, rng, n, dc, noise, plants):
+    s = (noise * rng.standard_normal(n)).astype(np.float32) + np.float32(dc)
+    for j, at, sgn, amp in plants:
+        w = pre.match[j] / np.abs(pre.match[j]).max() * amp
+        seg = s[at:at + len(w)]
+        seg += (sgn * w[:len(seg)]).astype(np.float32)
+    return s
+
+
+@pytest.mark.parametrize("opt_dc,dc,noise", [(1, 0.11, 0.02), (0, 0.0, 0.02), (1, -0.3, 0.05), (0, 0.02, 0.08)])
+def test_prefilter_is_a_superset_and_close(setup, opt_dc, dc, noise):
+    ora_scan, d, pre = setup
+    rng = np.random.default_rng(int(1000 * abs(dc)) + opt_dc)
+    n = 46000
+    K = d.K
+    first = K - 4 - d.delay - 1
+    plants = [(1, 9000, 1, 0.08), (0, 25000, -1, 0.08), (6, 40000, 1, 0.06), (9, 30500, 1, 0.03),
+              (1, first + (K - 4) - 300, -1, 0.08)]                                   # the last one straddles a window's end
+    stream = _stream(pre, rng, n, dc, noise, plants)
+    worst, ncand, nall, hits = 0.0, 0, 0, 0
+    for pos in range(first, n, K - 4):
+        for j in d.active:
+            ex = d.corr(j, stream, pos, opt_dc)
+            pr = pre.run(j, stream, pos, opt_dc)
+            thres = ora_scan.TEMPLATES[j][3]
+            cand = pr["smax"] > thres - MARGIN
+            nall += 1
+            ncand += cand
+            if ex["mp"] > 0:
+                assert pr["smax"] > abs(ex["mv"]) - 1e-3, (pos, j, ex, pr)               # upper bound up to the f16 rounding
+                if abs(ex["mv"]) > thres - 0.01:
+                    assert cand, (pos, j, ex, pr)
+                    hits += abs(ex["mv"]) > thres
+                if ex["mp"] == pr["mp"]:
+                    worst = max(worst, abs(ex["mv"] - pr["mv"]))
+            assert abs(ex["dc"] - pr["dc"]) < 1e-5
+    assert hits >= 3 and worst < 1e-3 and ncand < 0.1 * nall, (hits, worst, ncand, nall)
