@@ -150,8 +150,8 @@ void k_scan_pre(const ScanPreArgs a) {
         float base = inc - s;
         for (int w = 0; w < wave; w++) base += s_f[SP_WAVES + w];
 #pragma unroll
-        for (int q = 0; q < 32; q++) P[SP_PI(32 * tid + q)] = base + run[q];
-        if (tid == SP_THREADS - 1) P[SP_PI(32 * SP_THREADS)] = base + s;
+        for (int q = 0; q < 32; q++) if (32 * tid + q <= 256 * nT1) P[SP_PI(32 * tid + q)] = base + run[q];     // P holds 256 nT1 + 1 sums
+        if (tid == SP_THREADS - 1 && 256 * nT1 == 32 * SP_THREADS) P[SP_PI(32 * SP_THREADS)] = base + s;
         __syncthreads();
     }
 
