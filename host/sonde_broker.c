@@ -8,12 +8,15 @@
  * pending frame of all its clients in one launch.  The shims keep their whole command-line contract — option parsing, the fsk_nin()
  * read loop, --stats / --testframes output stay in the client — so stdout / stderr are byte for byte those of a stand-alone run.
  *
- *     sonde_broker --socket /run/sonde.sock [--slots 64] [--device 0] [--window-us 2000] [--idle-exit]
+ *     sonde_broker --socket /run/sonde.sock [--slots 64] [--device 0] [--window-us 2000] [--stall-ms 1000] [--idle-exit]
  *
  * The decoder shims themselves (rs41mod / dfm09mod / m10mod / m20mod on FM audio or IF-rate IQ: what decode.py:375-417 pipes into them) work
  * the same way: a group is an engine configuration, a client owns a channel, every step feeds all channels the same number of samples of
  * their pending input blocks in one sonde_engine_process_host() call and routes the frame records back.  A channel is ended with
  * sonde_engine_finish_channel() when its client reaches EOF and re-armed with sonde_engine_restart_channel() for the next client.
+ * A decoder group steps when all its clients have a block pending.  A client whose input pauses for longer than --stall-ms (1000) while
+ * others wait is parked, not dropped: its channel is ended like at EOF (the frame in progress is delivered with the bits that exist) and
+ * starts over with its next block, so one SDR hiccup neither stalls the other decoders nor ends that sonde's decoder process.
  *
  * Step policy of a modem group: run as soon as every connected client has a frame pending; otherwise when the oldest pending frame has
  * waited --window-us (clients whose frame is not there yet simply sit the step out: their channel is fed 0 samples).  A slot freed by
@@ -48,6 +51,8 @@ typedef struct {
     /* decoder shims: progress inside the pending block and the records collected for the reply */
     uint32_t blk_off;
     unsigned char *out; size_t out_len, out_cap; uint32_t out_count;
+    int parked;                          /* decoder shim whose input paused while its peers waited: its channel has been ended (finish_channel) and
+                                          * is restarted with its next block; the group steps without it meanwhile */
 } client_t;
 
 typedef struct {
@@ -79,9 +84,9 @@ typedef struct {                         /* one engine configuration of decoder 
 static client_t g_cl[MAX_CLIENTS];
 static group_t g_gr[MAX_GROUPS];
 static dgroup_t g_dg[MAX_GROUPS];
-static long g_dsteps = 0, g_drecs = 0; static int g_dmax_batch = 0;
+static long g_dsteps = 0, g_drecs = 0, g_parked = 0; static int g_dmax_batch = 0;
 static int g_slots = 64, g_device = 0, g_idle_exit = 0;
-static int64_t g_window_us = 2000;
+static int64_t g_window_us = 2000, g_stall_us = 1000000;
 static volatile sig_atomic_t g_stop = 0;
 static long g_steps = 0, g_frames = 0, g_served = 0; static int g_max_batch = 0;
 
@@ -117,7 +122,7 @@ static void drop_client(int ci) {
         g->slot_client[c->slot] = -1; g->slot_dirty[c->slot] = 1; g->n_clients--;
     }
     free(c->rx); c->rx = NULL; c->rx_len = c->rx_cap = 0; c->pending = 0; c->group = c->slot = -1; c->kind = 0;
-    free(c->out); c->out = NULL; c->out_len = c->out_cap = 0; c->out_count = 0; c->blk_off = 0;
+    free(c->out); c->out = NULL; c->out_len = c->out_cap = 0; c->out_count = 0; c->blk_off = 0; c->parked = 0;
 }
 
 /* the fields that make two clients batchable */
@@ -130,6 +135,7 @@ static int same_cfg(const sonde_fsk_cfg_t *a, const sonde_fsk_cfg_t *b) {
 static int join_group(int ci, const sonde_fsk_cfg_t *want) {
     int gi = -1;
     for (int i = 0; i < MAX_GROUPS; i++) if (g_gr[i].used && same_cfg(&g_gr[i].key, want)) { gi = i; break; }
+    if (want->abi_version != SONDE_ABI_VERSION) { send_error(g_cl[ci].fd, "broker: the shim was built against another ABI version of libsonde_hip"); return -1; }
     if (gi < 0) {
         for (int i = 0; i < MAX_GROUPS; i++) if (!g_gr[i].used) { gi = i; break; }
         if (gi < 0) { send_error(g_cl[ci].fd, "broker: too many modem configurations"); return -1; }
@@ -144,9 +150,13 @@ static int join_group(int ci, const sonde_fsk_cfg_t *want) {
         sonde_fsk_info(g->eng, &g->info);
         g->unit = want->format == SONDE_FSK_CF32 ? 8 : want->format == SONDE_FSK_CS16 ? 4 : 2;
         g->slot_client = (int *)malloc(sizeof(int) * (size_t)g_slots); g->slot_dirty = (int *)calloc((size_t)g_slots, sizeof(int));
-        for (int s = 0; s < g_slots; s++) g->slot_client[s] = -1;
         g->sd = (float *)malloc(sizeof(float) * (size_t)g->info.Nbits); g->bits = (uint8_t *)malloc((size_t)g->info.Nbits);
         g->Sf = (float *)malloc(sizeof(float) * (size_t)g->info.Ndft);
+        if (!g->slot_client || !g->slot_dirty || !g->sd || !g->bits || !g->Sf) {
+            free(g->slot_client); free(g->slot_dirty); free(g->sd); free(g->bits); free(g->Sf); sonde_fsk_destroy(g->eng); memset(g, 0, sizeof *g);
+            send_error(g_cl[ci].fd, "broker: out of memory"); return -1;
+        }
+        for (int s = 0; s < g_slots; s++) g->slot_client[s] = -1;
         g->used = 1;
     }
     group_t *g = &g_gr[gi];
@@ -174,12 +184,18 @@ static int same_demod(const brk_hello_demod_t *a, const brk_hello_demod_t *b) {
     return x->sample_rate == y->sample_rate && x->bits == y->bits && x->sonde_type == y->sonde_type && x->opt_lp == y->opt_lp && x->opt_min == y->opt_min &&
            x->lpiq_bw == y->lpiq_bw && x->ecc_level == y->ecc_level && x->thres == y->thres && x->input == y->input && x->audio_channels == y->audio_channels &&
            x->audio_select == y->audio_select && x->opt_inv == y->opt_inv && x->m10_noskip == y->m10_noskip && x->opt_auto == y->opt_auto &&
+           x->if_rate == y->if_rate && x->if_tune == y->if_tune &&
            a->set_sync == b->set_sync && (!a->set_sync || (a->hdmax == b->hdmax && a->bitofs == b->bitofs));
 }
 
 static int join_dgroup(int ci, const brk_hello_demod_t *want) {
     const sonde_cfg_t *w = &want->cfg;
     const size_t rs = demod_rec_size(w->sonde_type);
+    if (w->abi_version != SONDE_ABI_VERSION) { send_error(g_cl[ci].fd, "broker: the shim was built against another ABI version of libsonde_hip"); return -1; }
+    if ((w->bits != 8 && w->bits != 16 && w->bits != 32) || (w->input == SONDE_IN_AUDIO && w->audio_channels != 1 && w->audio_channels != 2) ||
+        (w->input == SONDE_IN_AUDIO && (w->audio_select < 0 || w->audio_select >= w->audio_channels))) {
+        send_error(g_cl[ci].fd, "broker: invalid sample format (bits 8 / 16 / 32, one or two audio channels)"); return -1;
+    }
     if (!rs || w->input == SONDE_IN_IQ || w->opt_dc || w->opt_iqdc || w->opt_nolut || w->keep_soft || w->sample_rate < 1000 || w->sample_rate > 4000000) {
         send_error(g_cl[ci].fd, "broker: this decoder configuration is not served (FM audio / IF-rate IQ of rs41mod, dfm09mod, m10mod, m20mod without --dc / --iqdc)");
         return -1;
@@ -196,6 +212,7 @@ static int join_dgroup(int ci, const brk_hello_demod_t *want) {
         c->abi_version = SONDE_ABI_VERSION; c->device = g_device; c->n_channels = g_slots; c->max_chunk = c->sample_rate; c->max_frames = 16 * g_slots;
         c->pipeline = 0; c->keep_soft = 0;
         double *fq = (double *)calloc((size_t)g_slots, sizeof(double));
+        if (!fq) { send_error(g_cl[ci].fd, "broker: out of memory"); return -1; }
         int rc = sonde_engine_create(c, fq, &g->eng);
         free(fq);
         if (rc >= 0 && want->set_sync) rc = sonde_engine_set_sync(g->eng, want->hdmax, want->bitofs);
@@ -204,9 +221,13 @@ static int join_dgroup(int ci, const brk_hello_demod_t *want) {
         g->unit = (size_t)(c->input == SONDE_IN_AUDIO ? c->audio_channels : 2) * (size_t)(c->bits / 8);
         g->rec_size = rs; g->max_chunk = c->max_chunk;
         g->slot_client = (int *)malloc(sizeof(int) * (size_t)g_slots); g->slot_dirty = (int *)calloc((size_t)g_slots, sizeof(int));
-        for (int s2 = 0; s2 < g_slots; s2++) g->slot_client[s2] = -1;
         g->stage = (unsigned char *)calloc((size_t)g_slots * (size_t)g->max_chunk, g->unit);
         g->recs = (unsigned char *)malloc(rs * 256);
+        if (!g->slot_client || !g->slot_dirty || !g->stage || !g->recs || !g->unit) {
+            free(g->slot_client); free(g->slot_dirty); free(g->stage); free(g->recs); sonde_engine_destroy(g->eng); memset(g, 0, sizeof *g);
+            send_error(g_cl[ci].fd, "broker: out of memory"); return -1;
+        }
+        for (int s2 = 0; s2 < g_slots; s2++) g->slot_client[s2] = -1;
         g->used = 1;
     }
     dgroup_t *g = &g_dg[gi];
@@ -241,10 +262,16 @@ static void route_records(dgroup_t *g) {
             if (ch < 0 || ch >= g_slots || g->slot_client[ch] < 0) continue;          /* a channel nobody owns (silence): nothing to report */
             client_t *c = &g_cl[g->slot_client[ch]];
             const int32_t zero = 0; memcpy(r, &zero, sizeof zero);                     /* the client sees itself as channel 0 */
-            if (c->out_cap - c->out_len < g->rec_size) { c->out_cap = c->out_cap ? 2 * c->out_cap : 16 * g->rec_size; c->out = (unsigned char *)realloc(c->out, c->out_cap); }
+            if (c->out_cap - c->out_len < g->rec_size) {
+                const size_t cap = c->out_cap ? 2 * c->out_cap : 16 * g->rec_size;
+                unsigned char *p = (unsigned char *)realloc(c->out, cap);
+                if (!p) continue;                                                     /* out of memory: this record is lost, the client stays */
+                c->out = p; c->out_cap = cap;
+            }
             memcpy(c->out + c->out_len, r, g->rec_size); c->out_len += g->rec_size; c->out_count++; g_drecs++;
         }
-        if (k < 256) return;
+        /* a short batch does not mean an empty queue (the DFM fetch takes at most 32 hits per call and a partial hit has fewer than 8 frames):
+         * go on until a fetch returns nothing */
     }
 }
 
@@ -266,19 +293,23 @@ static void reply_dclient(dgroup_t *g, int s2) {
 }
 
 /* one process call for the pending blocks of all clients of the group: n = what every one of them still has */
-static void step_dgroup(dgroup_t *g) {
-    /* a client with nothing left in its block (an empty end-of-stream message) is answered first: its channel must not see the
-     * samples — silence — of a call made for the others */
+/* a client with nothing left in its block (an empty end-of-stream message) is answered at once, whatever its peers are doing: its channel must
+ * not see the samples — silence — of a call made for the others, and its decoder must not wait for them */
+static void answer_empty_blocks(dgroup_t *g) {
     for (int s2 = 0; s2 < g_slots; s2++) {
         const int ci = g->slot_client[s2];
         if (ci < 0 || !g_cl[ci].pending) continue;
         brk_data_t d; memcpy(&d, g_cl[ci].rx + sizeof(brk_hdr_t), sizeof d);
         if (d.n_samples == g_cl[ci].blk_off) reply_dclient(g, s2);
     }
+}
+
+static void step_dgroup(dgroup_t *g) {
+    answer_empty_blocks(g);
     uint32_t n = 0; int batch = 0, active = 0;
     for (int s2 = 0; s2 < g_slots; s2++) {
         const int ci = g->slot_client[s2];
-        if (ci < 0) continue;
+        if (ci < 0 || g_cl[ci].parked) continue;
         active++;
         if (!g_cl[ci].pending) continue;
         brk_data_t d; memcpy(&d, g_cl[ci].rx + sizeof(brk_hdr_t), sizeof d);
@@ -292,8 +323,8 @@ static void step_dgroup(dgroup_t *g) {
     for (int s2 = 0; s2 < g_slots; s2++) {
         unsigned char *dst = g->stage + (size_t)s2 * row;
         const int ci = g->slot_client[s2];
-        if (ci >= 0) memcpy(dst, g_cl[ci].rx + sizeof(brk_hdr_t) + sizeof(brk_data_t) + (size_t)g_cl[ci].blk_off * g->unit, (size_t)n * g->unit);
-        else memset(dst, 0, (size_t)n * g->unit);             /* nobody there: silence */
+        if (ci >= 0 && !g_cl[ci].parked) memcpy(dst, g_cl[ci].rx + sizeof(brk_hdr_t) + sizeof(brk_data_t) + (size_t)g_cl[ci].blk_off * g->unit, (size_t)n * g->unit);
+        else memset(dst, 0, (size_t)n * g->unit);             /* nobody there, or a parked (ended) channel: silence */
     }
     const int rc = sonde_engine_process_host(g->eng, g->stage, g->max_chunk, (int32_t)n);
     g_dsteps++; g->calls++; if (batch > g_dmax_batch) g_dmax_batch = batch;
@@ -304,7 +335,7 @@ static void step_dgroup(dgroup_t *g) {
     route_records(g);
     for (int s2 = 0; s2 < g_slots; s2++) {
         const int ci = g->slot_client[s2];
-        if (ci < 0) continue;
+        if (ci < 0 || g_cl[ci].parked) continue;
         g_cl[ci].blk_off += n;
         brk_data_t d; memcpy(&d, g_cl[ci].rx + sizeof(brk_hdr_t), sizeof d);
         if (g_cl[ci].blk_off >= d.n_samples) reply_dclient(g, s2);   /* otherwise the rest of its block goes into the next call */
@@ -338,6 +369,11 @@ static void parse_client(int ci) {
             brk_data_t d; memcpy(&d, c->rx + sizeof h, sizeof d);
             const dgroup_t *g = &g_dg[c->group];
             if (h.length != sizeof d + (size_t)d.n_samples * g->unit || (int)d.n_samples > g->max_chunk) { send_error(c->fd, "broker: malformed DATA"); drop_client(ci); return; }
+            if (c->parked) {                                  /* its input is back: the channel starts over with this block */
+                const int rc = sonde_engine_restart_channel(g->eng, c->slot);
+                if (rc < 0) { send_error(c->fd, sonde_strerror(rc)); drop_client(ci); return; }
+                c->parked = 0;
+            }
             c->pending = 1; c->pending_since_us = now_us(); c->blk_off = 0;
         } else if (h.type == BRK_DATA && c->group >= 0 && c->kind == BRK_KIND_FSK && h.length >= sizeof(brk_data_t)) {
             brk_data_t d; memcpy(&d, c->rx + sizeof h, sizeof d);
@@ -350,7 +386,12 @@ static void parse_client(int ci) {
 
 static void read_client(int ci) {
     client_t *c = &g_cl[ci];
-    if (c->rx_cap - c->rx_len < 65536) { c->rx_cap = c->rx_cap ? c->rx_cap * 2 : 262144; c->rx = (unsigned char *)realloc(c->rx, c->rx_cap); }
+    if (c->rx_cap - c->rx_len < 65536) {
+        const size_t cap = c->rx_cap ? c->rx_cap * 2 : 262144;
+        unsigned char *p = (unsigned char *)realloc(c->rx, cap);
+        if (!p) { send_error(c->fd, "broker: out of memory"); drop_client(ci); return; }
+        c->rx = p; c->rx_cap = cap;
+    }
     const ssize_t k = recv(c->fd, c->rx + c->rx_len, c->rx_cap - c->rx_len, MSG_DONTWAIT);
     if (k == 0 || (k < 0 && errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) { drop_client(ci); return; }
     if (k > 0) c->rx_len += (size_t)k;
@@ -415,8 +456,9 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--slots") && i + 1 < argc) g_slots = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) g_device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--window-us") && i + 1 < argc) g_window_us = atoll(argv[++i]);
+        else if (!strcmp(argv[i], "--stall-ms") && i + 1 < argc) g_stall_us = 1000 * atoll(argv[++i]);
         else if (!strcmp(argv[i], "--idle-exit")) g_idle_exit = 1;
-        else { fprintf(stderr, "usage: %s --socket <path> [--slots 64] [--device 0] [--window-us 2000] [--idle-exit]\n", argv[0]); return 1; }
+        else { fprintf(stderr, "usage: %s --socket <path> [--slots 64] [--device 0] [--window-us 2000] [--stall-ms 1000] [--idle-exit]\n", argv[0]); return 1; }
     }
     if (!path || g_slots < 1 || g_slots > 4096) { fprintf(stderr, "sonde_broker: --socket <path> and 1 <= --slots <= 4096 required\n"); return 1; }
     for (int i = 0; i < MAX_CLIENTS; i++) { g_cl[i].fd = -1; g_cl[i].group = g_cl[i].slot = -1; }
@@ -440,7 +482,13 @@ int main(int argc, char **argv) {
         for (int i = 0; i < MAX_CLIENTS; i++) {
             if (g_cl[i].fd < 0) continue;
             live++;
-            if (g_cl[i].pending) { const int64_t dl = g_cl[i].pending_since_us + g_window_us; if (deadline < 0 || dl < deadline) deadline = dl; continue; }
+            if (g_cl[i].pending) {
+                /* modem frames wait at most --window-us for their peers; a decoder block waits for its peers' sockets to become readable
+                 * (poll blocks) and at most --stall-ms before the late ones are parked */
+                const int64_t dl = g_cl[i].pending_since_us + (g_cl[i].kind == BRK_KIND_FSK ? g_window_us : g_stall_us);
+                if (deadline < 0 || dl < deadline) deadline = dl;
+                continue;
+            }
             pf[np].fd = g_cl[i].fd; pf[np].events = POLLIN; map[np++] = i;
         }
         if (live) had_clients = 1;
@@ -475,29 +523,38 @@ int main(int argc, char **argv) {
             }
             if (pend && (pend == g->n_clients || t - oldest >= g_window_us)) step_group(g);
         }
-        /* decoder groups feed every channel the same number of samples per call: they step when all their clients have input pending; a client
-         * that has sent nothing for 5 s while others wait is dropped so that it cannot stall them */
+        /* decoder groups feed every channel the same number of samples per call: they step when all their (not parked) clients have input
+         * pending.  A client that has sent nothing for --stall-ms while others wait is parked: its channel is ended as at EOF (the frame in
+         * progress goes out with the bits that exist, with its next reply) and starts over when its next block arrives — the others go on */
         for (int gi = 0; gi < MAX_GROUPS; gi++) {
             dgroup_t *g = &g_dg[gi];
             if (!g->used || !g->n_clients) continue;
-            int pend = 0; int64_t oldest = -1;
+            answer_empty_blocks(g);
+            int pend = 0, need = 0; int64_t oldest = -1;
             for (int s2 = 0; s2 < g_slots; s2++) {
                 const int ci = g->slot_client[s2];
-                if (ci < 0 || !g_cl[ci].pending) continue;
+                if (ci < 0 || g_cl[ci].parked) continue;
+                need++;
+                if (!g_cl[ci].pending) continue;
                 pend++;
                 if (oldest < 0 || g_cl[ci].pending_since_us < oldest) oldest = g_cl[ci].pending_since_us;
             }
-            if (pend && pend < g->n_clients && t - oldest >= 5000000)
-                for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && !g_cl[ci].pending) { send_error(g_cl[ci].fd, "broker: no input for 5 s"); drop_client(ci); } }
+            if (pend && pend < need && t - oldest >= g_stall_us)
+                for (int s2 = 0; s2 < g_slots; s2++) {
+                    const int ci = g->slot_client[s2];
+                    if (ci < 0 || g_cl[ci].pending || g_cl[ci].parked) continue;
+                    sonde_engine_finish_channel(g->eng, s2); route_records(g);
+                    g_cl[ci].parked = 1; g_parked++;
+                }
             for (int guard = 0; guard < 64 && g->n_clients > 0; guard++) {             /* blocks of unequal length take more than one call */
-                int p2 = 0;
-                for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && g_cl[ci].pending) p2++; }
-                if (p2 != g->n_clients) break;
+                int p2 = 0, n2 = 0;
+                for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && !g_cl[ci].parked) { n2++; if (g_cl[ci].pending) p2++; } }
+                if (!n2 || p2 != n2) break;
                 const long before = g->calls; const long served = g_drecs + g_served;
                 step_dgroup(g);
                 if (g->calls == before && g_drecs + g_served == served) {
                     int p3 = 0;
-                    for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && g_cl[ci].pending) p3++; }
+                    for (int s2 = 0; s2 < g_slots; s2++) { const int ci = g->slot_client[s2]; if (ci >= 0 && !g_cl[ci].parked && g_cl[ci].pending) p3++; }
                     if (p3 == p2) break;                                               /* nothing moved */
                 }
             }
@@ -507,7 +564,7 @@ int main(int argc, char **argv) {
     for (int gi = 0; gi < MAX_GROUPS; gi++) if (g_gr[gi].used) { groups++; sonde_fsk_destroy(g_gr[gi].eng); }
     for (int gi = 0; gi < MAX_GROUPS; gi++) if (g_dg[gi].used) { dgroups++; sonde_engine_destroy(g_dg[gi].eng); }
     fprintf(stderr, "broker: groups %d clients %ld steps %ld frames %ld max_batch %d\n", groups, g_served, g_steps, g_frames, g_max_batch);
-    if (dgroups) fprintf(stderr, "broker: decoder_groups %d calls %ld records %ld max_batch %d\n", dgroups, g_dsteps, g_drecs, g_dmax_batch);
+    if (dgroups) fprintf(stderr, "broker: decoder_groups %d calls %ld records %ld max_batch %d parked %ld\n", dgroups, g_dsteps, g_drecs, g_dmax_batch, g_parked);
     for (int i = 0; i < MAX_CLIENTS; i++) if (g_cl[i].fd >= 0) close(g_cl[i].fd);
     close(lfd); unlink(path);
     return 0;

@@ -118,6 +118,9 @@ int  sonde_scan_line(const sonde_scan_t *s, const sonde_detection_t *d, int verb
 int  sonde_scan_last_windows(const sonde_scan_t *s, sonde_scan_window_t *out, int32_t max);
 int  sonde_scan_read_fm(sonde_scan_t *s, int32_t channel, int32_t stream, int64_t first, int32_t count, float *out);
 int  sonde_scan_kernel_ms(sonde_scan_t *s, const char *kernel, double *avg_ms, int64_t *launches);
+/* testing tap of the prefilter (host only, no GPU): out[i] = sum_u h[u] x[i+u], i < n_out, evaluated from the SAME f16 fragment tables and in the
+ * same contraction the matrix-core kernel uses (x beyond n_x reads as 0); returns the number of 16x16x32 steps per output tile */
+int  sonde_scan_toeplitz_model(const float *h, int32_t n_taps, const float *x, int32_t n_x, float *out, int32_t n_out);
 
 #ifdef __cplusplus
 }

@@ -207,14 +207,17 @@ template <class T> static int dupload(T **p, const std::vector<T> &v) {
 
 // ---- prefilter tables (k_scan_pre, sonde_scan_pre.hip)
 static uint16_t f16_bits(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, sizeof u); return u; }
-// A fragments of the Toeplitz product out[i] = sum_u h[u] x[i+u]: step c, lane (b = lane & 15, g = lane >> 4), element r  <-  h[16 c + 8 g + r - b]
+// A fragments of the Toeplitz product out[i] = sum_u h[u] x[i+u].  With i = 16 a + b and u = 16 c + d, d in [0, 16):
+//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] x[16 (a+c) + e],   A_c[b][e] = h[16 c + (e - b)] where 0 <= e - b < 16, else 0
+// (each tap belongs to exactly one step c; half of every 16x32 fragment is zero).  Fragment element: step c, lane (b = lane & 15, g = lane >> 4),
+// r < 8  <-  A_c[b][8 g + r].
 static int toeplitz_frags(const std::vector<float> &h, std::vector<uint16_t> &out) {
-    const int U = (int)h.size(), nc = (U - 1 + 15) / 16 + 1;
+    const int U = (int)h.size(), nc = (U + 15) / 16;
     for (int c = 0; c < nc; c++)
         for (int lane = 0; lane < 64; lane++)
             for (int r = 0; r < 8; r++) {
-                const int u = 16 * c + 8 * (lane >> 4) + r - (lane & 15);
-                out.push_back((u >= 0 && u < U) ? f16_bits(h[u]) : (uint16_t)0);
+                const int d = 8 * (lane >> 4) + r - (lane & 15), u = 16 * c + d;
+                out.push_back((d >= 0 && d < 16 && u < U) ? f16_bits(h[u]) : (uint16_t)0);
             }
     return nc;
 }
@@ -833,6 +836,26 @@ int sonde_scan_line(const sonde_scan_t *s, const sonde_detection_t *d, int verbo
     }
     snprintf(buf, buflen, "%s", o.c_str());
     return (int)std::min(o.size(), buflen ? buflen - 1 : 0);
+}
+
+int sonde_scan_toeplitz_model(const float *h, int32_t n_taps, const float *x, int32_t n_x, float *out, int32_t n_out) {
+    if (!h || !x || !out || n_taps < 1 || n_out < 0) return SONDE_E_ARG;
+    std::vector<uint16_t> fr;
+    const int nc = toeplitz_frags(std::vector<float>(h, h + n_taps), fr);
+    auto f16 = [](uint16_t u) { _Float16 v; memcpy(&v, &u, sizeof v); return (float)v; };
+    for (int i = 0; i < n_out; i++) {
+        const int a = i >> 4, b = i & 15;
+        float acc = 0.f;
+        for (int c = 0; c < nc; c++)
+            for (int g = 0; g < 4; g++)
+                for (int r = 0; r < 8; r++) {                       // D[b][n] += A[b][k] B[k][n], k = 8 g + r, lane of A = b + 16 g
+                    const int idx = 16 * (a + c) + 8 * g + r;
+                    const float xv = idx < n_x ? (float)(_Float16)x[idx] : 0.f;
+                    acc += f16(fr[((size_t)c * 64 + (size_t)(b + 16 * g)) * 8 + r]) * xv;
+                }
+        out[i] = acc;
+    }
+    return nc;
 }
 
 int sonde_scan_last_windows(const sonde_scan_t *s, sonde_scan_window_t *out, int32_t max) {

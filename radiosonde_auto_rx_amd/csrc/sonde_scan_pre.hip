@@ -11,11 +11,11 @@
 // `mv_pos > mv0_pos` test).  Decisions, printed scores and positions therefore still come from the reference's own transform network.
 //
 // Both the low-pass and the correlation are Toeplitz products out[i] = sum_u h[u] x[i+u]; with i = 16 a + b, u = 16 c + e - b:
-//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] X[e][a + c],   A_c[b][e] = h[16 c + e - b],  X[e][a'] = x[16 a' + e]
-// i.e. per step c one 16x16x32 MFMA: A_c is a constant fragment (tabulated by the host, 1 KB per step), the B fragment of lane (n = lane & 15,
+//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] X[e][a + c],   A_c[b][e] = h[16 c + e - b] for 0 <= e - b < 16 (else 0),  X[e][a'] = x[16 a' + e]
+// i.e. per step c (16 taps) one 16x16x32 MFMA: A_c is a constant fragment (tabulated by the host, 1 KB per step), the B fragment of lane (n = lane & 15,
 // g = lane >> 4) is the 8 consecutive halves x[16 (a0+n+c) + 8 g ...] — one 16-byte LDS read.  The D fragment of a lane is out[16 (a0+n) + 4 g + r],
 // r < 4.  (A and B use the same k order within a lane, so the products pair up whatever the hardware's internal k numbering is.)
-// One workgroup (4 waves) = one (window, template); LDS: window f16 + filtered window f16 + prefix sums of its squares = 67 KB, two per CU.
+// One workgroup (8 waves) = one (window, template); LDS: window f16 + filtered window f16 + prefix sums of its squares = 69 KB, two per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sonde_scan_dev.h"
@@ -24,10 +24,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define SP_THREADS 256
-#define SP_WAVES 4
-#define SP_MAXT 8                      // 256-sample tiles per wave (8192 samples / 256 / 4 waves)
-#define SP_PI(i) ((i) + ((i) >> 5))    // prefix sums are stored with one pad word per 32: a thread's run of 32 stays off its neighbours' banks
+#define SP_THREADS 512
+#define SP_WAVES 8
+#define SP_MAXT 4                      // 256-sample tiles per wave (8192 samples / 256 / 8 waves)
+#define SP_CH 16                       // samples per thread in the load and prefix phases (8192 / 512)
+#define SP_PI(i) ((i) + ((i) >> 4))    // prefix sums are stored with one pad word per 16: a thread's run of 16 stays off its neighbours' banks
 
 __device__ __forceinline__ float sp_wsum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
@@ -37,20 +38,28 @@ __device__ __forceinline__ void sp_toeplitz(const _Float16 *x, const uint16_t *a
     const int n = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A_c comes from global memory (the tables of all templates do not fit beside the window in LDS): the fragment of step c+1 is requested
+    // before the MFMAs of step c so that its latency is covered; the B fragments of a step are independent LDS reads
+    const half8 *af = reinterpret_cast<const half8 *>(afrag) + lane;
+    half8 A = af[0];
     for (int c = 0; c < nc; c++) {
-        const half8 A = *reinterpret_cast<const half8 *>(afrag + ((size_t)c * 64 + lane) * 8);
+        const half8 An = af[(size_t)64 * (c + 1 < nc ? c + 1 : c)];
+        half8 B[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int tile = wave + SP_WAVES * t;
-            if (tile < ntiles) {                                   // wave-uniform
-                const half8 B = *reinterpret_cast<const half8 *>(x + 16 * (16 * tile + n + c) + 8 * g);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, acc[t], 0, 0, 0);
-            }
+            if (tile < ntiles) B[t] = *reinterpret_cast<const half8 *>(x + 16 * (16 * tile + n + c) + 8 * g);
         }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int tile = wave + SP_WAVES * t;
+            if (tile < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B[t], acc[t], 0, 0, 0);      // wave-uniform branch
+        }
+        A = An;
     }
 }
 
-__global__ __launch_bounds__(SP_THREADS, 2)
+__global__ __launch_bounds__(SP_THREADS, 4)
 void k_scan_pre(const ScanPreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     const int item = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,10 +84,10 @@ void k_scan_pre(const ScanPreArgs a) {
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const float *str = a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len;
     const int64_t start = (int64_t)it.pos - (wl - 1);
-    float v[32];
+    float v[SP_CH];
     float dcp = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
+    for (int r = 0; r < SP_CH; r++) {
         const int i = tid + SP_THREADS * r;
         const int64_t p = start + i;
         v[r] = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
@@ -97,11 +106,11 @@ void k_scan_pre(const ScanPreArgs a) {
     _Float16 *dst = a.opt_iq ? xh + padL : xfh;
     const int ndst = (a.opt_iq ? NXH - padL : NXF);
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
+    for (int r = 0; r < SP_CH; r++) {
         const int i = tid + SP_THREADS * r;
         if (i < ndst) dst[i] = (_Float16)((i < wl) ? v[r] - dcs : 0.f);
     }
-    for (int i = 32 * SP_THREADS + tid; i < ndst; i += SP_THREADS) dst[i] = (_Float16)0.f;
+    for (int i = SP_CH * SP_THREADS + tid; i < ndst; i += SP_THREADS) dst[i] = (_Float16)0.f;
     if (a.opt_iq) for (int i = tid; i < padL; i += SP_THREADS) xh[i] = (_Float16)0.f;
     __syncthreads();
 
@@ -132,14 +141,14 @@ void k_scan_pre(const ScanPreArgs a) {
         __syncthreads();
     }
 
-    // ---- prefix sums of xf^2 (the 2-norm under the template, dft_detect.c:431-433): thread t owns samples [32 t, 32 t + 32)
+    // ---- prefix sums of xf^2 (the 2-norm under the template, dft_detect.c:431-433): thread t owns samples [16 t, 16 t + 16)
     {
-        float run[32];
+        float run[SP_CH];
         float s = 0.f;
-        const half8 *src = reinterpret_cast<const half8 *>(xfh + 32 * tid);
+        const half8 *src = reinterpret_cast<const half8 *>(xfh + SP_CH * tid);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const half8 h = (32 * tid + 8 * q < 256 * nT1) ? src[q] : (half8){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < SP_CH / 8; q++) {
+            const half8 h = (SP_CH * tid + 8 * q < 256 * nT1) ? src[q] : (half8){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < 8; r++) { run[8 * q + r] = s; const float x = (float)h[r]; s += x * x; }
         }
@@ -150,8 +159,8 @@ void k_scan_pre(const ScanPreArgs a) {
         float base = inc - s;
         for (int w = 0; w < wave; w++) base += s_f[SP_WAVES + w];
 #pragma unroll
-        for (int q = 0; q < 32; q++) if (32 * tid + q <= 256 * nT1) P[SP_PI(32 * tid + q)] = base + run[q];     // P holds 256 nT1 + 1 sums
-        if (tid == SP_THREADS - 1 && 256 * nT1 == 32 * SP_THREADS) P[SP_PI(32 * SP_THREADS)] = base + s;
+        for (int q = 0; q < SP_CH; q++) if (SP_CH * tid + q <= 256 * nT1) P[SP_PI(SP_CH * tid + q)] = base + run[q];     // P holds 256 nT1 + 1 sums
+        if (tid == SP_THREADS - 1 && 256 * nT1 == SP_CH * SP_THREADS) P[SP_PI(SP_CH * SP_THREADS)] = base + s;
         __syncthreads();
     }
 
@@ -212,7 +221,7 @@ extern "C" int sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s) {
     int maxL = 0, maxc2 = 0;
     for (int j = 0; j < SC_NTPL; j++) if (a->tpl[j].active) { if (a->tpl[j].L > maxL) maxL = a->tpl[j].L; if (a->nc2[j] > maxc2) maxc2 = a->nc2[j]; }
     const int wl = a->K + maxL, nT1 = (wl + 255) >> 8, nT2 = (a->K + 1 + 255) >> 8;
-    if (nT1 > SP_WAVES * SP_MAXT || 256 * nT1 > 32 * SP_THREADS) return -1;          // window longer than 8192 samples
+    if (nT1 > SP_WAVES * SP_MAXT || 256 * nT1 > SP_CH * SP_THREADS) return -1;       // window longer than 8192 samples
     const size_t nxh = a->opt_iq ? (size_t)((256 * nT1 + 16 * a->nc1 + 48 + 7) & ~7) : 0;
     size_t nxf = (size_t)256 * nT2 + 16 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1) nxf = (size_t)256 * nT1; nxf = (nxf + 7) & ~(size_t)7;
     const size_t lds = 2 * (nxh + nxf) + 4 * (size_t)(SP_PI(256 * nT1) + 8);

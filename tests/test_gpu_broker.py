@@ -167,3 +167,48 @@ def test_decoder_shims_share_one_engine_per_configuration(tmp_path):
     line = [l for l in berr.decode().splitlines() if l.startswith("broker: decoder_groups")][-1].split()
     st = {line[i]: int(line[i + 1]) for i in range(1, len(line), 2)}
     assert st["decoder_groups"] == 5 and st["max_batch"] >= 6 and st["records"] > 0, st
+
+
+@pytest.mark.gpu
+def test_a_paused_decoder_neither_stalls_its_peers_nor_dies(tmp_path):
+    """Two rs41mod shims of one configuration behind the broker.  One of them gets its input in two parts with a pause longer than --stall-ms in
+    between (an SDR hiccup): the other one still prints exactly what it prints on its own and ends long before the pause is over; the paused one
+    is parked (its channel ended and re-armed), keeps running, decodes the frames behind the pause and exits 0 — it is not dropped."""
+    from tools import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    args = ["-r", "--ecc2", "--crc", "--iq2", "--lpIQ", "-", "48000", "16"]
+    xa = synth.rs41_capture(sr=48_000, seconds=3.3, fq=0.0, noise_sigma=0.05, n_frames=3, t_first=0.2, seed=610).tobytes()
+    xb = synth.rs41_capture(sr=48_000, seconds=5.3, fq=0.0, noise_sigma=0.05, n_frames=5, t_first=0.2, seed=611).tobytes()
+    alone_a = subprocess.run([os.path.join(BIN, "rs41mod")] + args, input=xa, capture_output=True, timeout=120)
+    alone_b = subprocess.run([os.path.join(BIN, "rs41mod")] + args, input=xb, capture_output=True, timeout=120)
+    assert alone_a.returncode == 0 and len(alone_a.stdout.splitlines()) == 3 and len(alone_b.stdout.splitlines()) == 5
+    sock = str(tmp_path / "broker.sock")
+    broker = subprocess.Popen([os.path.join(BIN, "sonde_broker"), "--socket", sock, "--slots", "4", "--stall-ms", "300"], stderr=subprocess.PIPE)
+    try:
+        for _ in range(200):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.05)
+        env = dict(os.environ, SONDE_BROKER=sock)
+        pb = subprocess.Popen([os.path.join(BIN, "rs41mod")] + args, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        cut = 4 * 103200                                     # 2.15 s of the 5.3 s: the second frame is complete (2.12 s), the third starts at 2.2 s
+        pb.stdin.write(xb[:cut]); pb.stdin.flush()
+        time.sleep(0.5)                                      # b is connected and has delivered what it has
+        t0 = time.time()
+        ra = subprocess.run([os.path.join(BIN, "rs41mod")] + args, env=env, input=xa, capture_output=True, timeout=120)
+        ta = time.time() - t0
+        assert ra.returncode == 0 and ra.stdout == alone_a.stdout, ra.stderr[-300:]
+        assert ta < 10.0                                     # it waited for b at most --stall-ms, not for b's input to come back
+        time.sleep(1.0)
+        pb.stdin.write(xb[cut:]); pb.stdin.close()
+        out_b = pb.stdout.read(); err_b = pb.stderr.read()
+        assert pb.wait(timeout=120) == 0, err_b[-300:]
+        lines_b, want_b = out_b.decode().splitlines(), alone_b.stdout.decode().splitlines()
+        assert lines_b[:2] == want_b[:2]                     # the frames before the pause
+        assert lines_b[-2:] == want_b[-2:]                   # the channel started over: the frames well behind the pause are decoded again
+    finally:
+        broker.send_signal(signal.SIGTERM)
+        _, berr = broker.communicate(timeout=30)
+    line = [l for l in berr.decode().splitlines() if l.startswith("broker: decoder_groups")][-1].split()
+    st = {line[i]: int(line[i + 1]) for i in range(1, len(line), 2)}
+    assert st["parked"] >= 1, st

@@ -53,3 +53,22 @@ def test_prefilter_is_a_superset_and_close(setup, opt_dc, dc, noise):
                     worst = max(worst, abs(ex["mv"] - pr["mv"]))
             assert abs(ex["dc"] - pr["dc"]) < 1e-5
     assert hits >= 3 and worst < 1e-3 and ncand < 0.1 * nall, (hits, worst, ncand, nall)
+
+
+@pytest.mark.parametrize("n_taps,n_out", [(97, 700), (640, 1200), (1, 40), (16, 64), (17, 33), (1280, 300)])
+def test_toeplitz_fragment_tables(n_taps, n_out):
+    """The f16 A-fragment tables the matrix-core kernel multiplies with (sonde_scan.cpp toeplitz_frags), contracted on the host exactly the way
+    v_mfma_f32_16x16x32_f16 pairs them with the window (lane = row + 16 g, k = 8 g + r), give out[i] = sum_u h[u] x[i + u]: every tap once."""
+    import ctypes as C
+    from radiosonde_auto_rx_amd.engine import lib
+    L = lib()
+    L.sonde_scan_toeplitz_model.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    rng = np.random.default_rng(n_taps)
+    h = rng.standard_normal(n_taps).astype(np.float32) * 0.1
+    x = rng.standard_normal(n_out + n_taps + 40).astype(np.float32)
+    out = np.zeros(n_out, np.float32)
+    nc = L.sonde_scan_toeplitz_model(h.ctypes.data, n_taps, x.ctypes.data, len(x), out.ctypes.data, n_out)
+    assert nc == (n_taps + 15) // 16
+    h16, x16 = h.astype(np.float16).astype(np.float64), x.astype(np.float16).astype(np.float64)
+    want = np.array([np.dot(h16, x16[i:i + n_taps]) for i in range(n_out)])
+    assert np.abs(out - want).max() < 2e-5 * max(1.0, np.abs(want).max())
