@@ -51,6 +51,8 @@ typedef struct {
     /* decoder shims: progress inside the pending block and the records collected for the reply */
     uint32_t blk_off;
     unsigned char *out; size_t out_len, out_cap; uint32_t out_count;
+    int64_t active_us;                   /* last time the client sent something or was answered */
+    int got_data;                        /* decoder shim: it has delivered samples since it took (or re-took) its channel */
     int parked;                          /* decoder shim whose input paused while its peers waited: its channel has been ended (finish_channel) and
                                           * is restarted with its next block; the group steps without it meanwhile */
 } client_t;
@@ -286,7 +288,7 @@ static void reply_dclient(dgroup_t *g, int s2) {
     if (d.want_stats & BRK_FINISH) { sonde_engine_finish_channel(g->eng, s2); route_records(g); g->slot_dirty[s2] = 1; }
     brk_dresult_t r = { c->out_count, (uint32_t)g->rec_size };
     const int bad = send_msg(c->fd, BRK_RESULT, &r, sizeof r, c->out, c->out_len, NULL, 0, NULL, 0);
-    c->out_len = 0; c->out_count = 0; c->blk_off = 0; c->pending = 0;
+    c->out_len = 0; c->out_count = 0; c->blk_off = 0; c->pending = 0; c->active_us = now_us();
     consume(c, sizeof h + h.length);
     if (bad) { drop_client(ci); return; }
     parse_client(ci);
@@ -355,6 +357,7 @@ static void parse_client(int ci) {
     brk_hdr_t h;
     while (c->fd >= 0 && !c->pending && have_message(c, &h)) {
         if (h.magic != BRK_MAGIC) { drop_client(ci); return; }
+        c->active_us = now_us();
         uint32_t hello_kind = 0;
         if (h.type == BRK_HELLO && h.length >= sizeof hello_kind) memcpy(&hello_kind, c->rx + sizeof h, sizeof hello_kind);
         if (h.type == BRK_HELLO && c->group < 0 && hello_kind == BRK_KIND_FSK && h.length == sizeof(brk_hello_t)) {
@@ -374,6 +377,7 @@ static void parse_client(int ci) {
                 if (rc < 0) { send_error(c->fd, sonde_strerror(rc)); drop_client(ci); return; }
                 c->parked = 0;
             }
+            if (d.n_samples) c->got_data = 1;
             c->pending = 1; c->pending_since_us = now_us(); c->blk_off = 0;
         } else if (h.type == BRK_DATA && c->group >= 0 && c->kind == BRK_KIND_FSK && h.length >= sizeof(brk_data_t)) {
             brk_data_t d; memcpy(&d, c->rx + sizeof h, sizeof d);
@@ -504,7 +508,7 @@ int main(int argc, char **argv) {
                     int ci = -1;
                     for (int i = 0; i < MAX_CLIENTS; i++) if (g_cl[i].fd < 0) { ci = i; break; }
                     if (ci < 0) { send_error(fd, "broker: too many clients"); close(fd); }
-                    else { memset(&g_cl[ci], 0, sizeof g_cl[ci]); g_cl[ci].fd = fd; g_cl[ci].group = g_cl[ci].slot = -1; }
+                    else { memset(&g_cl[ci], 0, sizeof g_cl[ci]); g_cl[ci].fd = fd; g_cl[ci].group = g_cl[ci].slot = -1; g_cl[ci].active_us = now_us(); }
                 }
             }
             for (int k = 1; k < np; k++) if (pf[k].revents & (POLLIN | POLLHUP | POLLERR)) read_client(map[k]);
@@ -543,8 +547,10 @@ int main(int argc, char **argv) {
                 for (int s2 = 0; s2 < g_slots; s2++) {
                     const int ci = g->slot_client[s2];
                     if (ci < 0 || g_cl[ci].pending || g_cl[ci].parked) continue;
-                    sonde_engine_finish_channel(g->eng, s2); route_records(g);
-                    g_cl[ci].parked = 1; g_parked++;
+                    if (t - g_cl[ci].active_us < g_stall_us) continue;                 /* it is the broker that was busy, not the client that is late */
+                    /* a channel that has carried samples ends like at EOF; one that has not seen any yet just sits out until its first block */
+                    if (g_cl[ci].got_data) { sonde_engine_finish_channel(g->eng, s2); route_records(g); }
+                    g_cl[ci].parked = 1; g_cl[ci].got_data = 0; g_parked++;
                 }
             for (int guard = 0; guard < 64 && g->n_clients > 0; guard++) {             /* blocks of unequal length take more than one call */
                 int p2 = 0, n2 = 0;

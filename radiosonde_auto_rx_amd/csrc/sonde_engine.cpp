@@ -132,6 +132,9 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
         e->eof_pending = false;
         prof_collect(e);
     }
+    // the per-call snapshot is older than records an end-of-stream frame sync (finish / finish_channel) has added and a fetch has already
+    // taken: never step back behind what has been read
+    if ((int32_t)(count - e->read_idx) < 0) count = e->read_idx;
     unsigned n = count - e->read_idx;
     if (n > (unsigned)e->max_frames) { e->overflow = true; e->read_idx = count - (unsigned)e->max_frames; n = (unsigned)e->max_frames; }
     if (max_take >= 0 && n > (unsigned)max_take) n = (unsigned)max_take;     // the rest stays queued for the next fetch

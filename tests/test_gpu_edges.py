@@ -228,3 +228,28 @@ def test_channel_restart_behaves_like_a_fresh_engine(form):
     assert len(out_seg[0]) >= 2                           # the first stream on channel 1 up to its cut: the complete frames are the stand-alone ones
     for u, v in zip(out_seg[0][:-1], want[1]):
         assert u["mv_pos"] == v["mv_pos"] and bytes(u["frame"]) == bytes(v["frame"])
+
+
+@pytest.mark.gpu
+def test_fetching_again_behind_an_ended_channel_returns_nothing():
+    """A fetch, sonde_engine_finish_channel, a fetch that takes the frame in progress, and ANOTHER fetch with no process call in between (the
+    broker drains a channel's queue until a fetch comes back empty): the last one returns no frame and reports no overflow — the frame counter
+    snapshot of the last process call is older than what the end-of-stream frame sync added, and must not pull the read index back."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    sr = 48_000
+    x = synth.rs41_capture(sr=sr, seconds=2.0, fq=0.0, noise_sigma=0.03, n_frames=2, t_first=0.2, seed=81)       # the second frame is cut by the end
+    eng = Engine([0.0, 0.0], sr, max_chunk=sr, iq_mode=2, lp_iq=True, max_frames=8)
+    n = len(x) // 2
+    frames = []
+    for s0 in range(0, n, 9600):
+        blk = x[2 * s0:2 * min(n, s0 + 9600)]
+        eng.process_host(np.stack([blk, np.zeros_like(blk)]))
+        frames += eng.fetch_frames()
+    assert len(frames) == 1
+    eng.finish_channel(0)
+    tail = eng.fetch_frames()
+    assert len(tail) == 1 and tail[0]["channel"] == 0 and tail[0]["mv_pos"] > frames[0]["mv_pos"]
+    assert eng.fetch_frames() == [] and eng.fetch_frames() == []
+    assert eng.overflowed() is False
+    eng.close()

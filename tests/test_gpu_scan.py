@@ -125,9 +125,10 @@ def test_scan_prefilter_changes_nothing_that_is_printed(name):
     text = "".join((d["line"] if v else d["line"].split("\n")[-1]) + "\n" for d in dets if d["printed"])
     assert text == g["stdout"]
     assert sc.result(0) % 256 == g["rc"]
-    for d in dets:                                           # every detection came from an exactly evaluated pair, and so did its predecessor
-        ws = [k for k, w in enumerate(wins) if w["mpos"][d["tpl"]] == d["sample"] and w["herrs"][d["tpl"]] >= 0]
-        assert ws and all(k == 0 or wins[k - 1]["herrs"][d["tpl"]] != -2 for k in ws)
+    for d in dets:                                           # every detection came from a pair the exact kernel evaluated (header compared: herrs >= 0)
+        assert any(w["mpos"][d["tpl"]] == d["sample"] and w["herrs"][d["tpl"]] >= 0 for w in wins)
+    # (the window before a hit is re-evaluated exactly as well; when it belongs to the previous call its record has already been handed out, so
+    # that is checked through what it decides: the text lines above and test_scan_prefilter_chunk_edges)
 
 
 def test_scan_prefilter_chunk_edges():
