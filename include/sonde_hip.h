@@ -295,12 +295,16 @@ int  sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max);
  * finish_channel: end of ONE channel's stream — the frame in progress on it is emitted with the bits that exist, like sonde_engine_finish()
  * does for all channels (rs41mod.c:2931,2965); fetch as usual afterwards.
  * restart_channel: a new stream starts on the channel with the next samples fed.  Everything the channel has seen is forgotten (its rings read
- * as silence, sync state as created) and header positions count from here, so the channel behaves like channel 0 of a fresh engine.  Only for
- * engines without the base-rate front end (decM == 1: FM audio and IF-rate IQ input) — channels of an engine share the base-rate sample clock
- * (mixer table phase, IQ-DC schedule) — and not with --dc / --iqdc / pipeline: SONDE_E_ARG otherwise. */
+ * as silence, sync state as created) and header positions count from here, so the channel behaves like channel 0 of a fresh engine.
+ * Base-rate engines (`--IQ fq`, int16 / uint8 input through the mixer table) give the channel its own sample clock as well: the mixer table
+ * phase, the IQ-DC mean and its segment schedule (75000 * 2^k samples, demod_mod.c:495-504) and the decimator history start over; from then on
+ * process calls are cut at every channel's own segment edges (sonde_engine_samples_to_dc_boundary() = the nearest one).
+ * Not with --dc / --iqdc / --noLUT / float32 base-rate input / pipeline: SONDE_E_ARG. */
 int  sonde_engine_finish_channel(sonde_engine_t *e, int32_t channel);
-/* cfg.if_tune engines: new fine-tuning offset fq (cycles per IF sample) for one channel, normally together with restart_channel when a
- * channel is given to another signal of a channelized stream. */
+/* A new carrier for one channel, normally together with restart_channel when the channel is given to another signal of the stream.
+ * cfg.if_tune engines: fine-tuning offset fq in cycles per IF sample.  Base-rate engines (`--IQ fq`): fq in cycles per input sample, snapped to
+ * the mixer table's raster like the --IQ argument itself (demod_mod.c:1265-1288); the table period must not change (always true: it depends on
+ * the sample rate only). */
 int  sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq);
 int  sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel);
 /* soft bits (hsbit_t.sb of read_softbit2p) of the frames returned by the last fetch; soft: [n][4080] */

@@ -32,6 +32,10 @@ struct MixDecArgs {
     const float2 *etab; int etab_len;
     const float2 *dc_avg_prev; // fold mode, launches within Q-1 blocks after a change of the IQ-DC mean: the mean before (md_dc_boundary); else nullptr
     int dc_since;             // blocks between that change and this launch
+    // channels restarted at run time (sonde_engine_restart_channel on a base-rate engine) have their own sample clock: the mixer table phase
+    // and the IQ-DC segment schedule count from the channel's start.  nullptr = all channels started with the engine.
+    const uint32_t *epoch_phase;   // [n_ch] (base-rate index of the channel's first sample) mod lut_len
+    const int32_t *dc_since_ch;    // [n_ch] blocks since the channel's mean last changed (replaces dc_since; dc_avg_prev is then always set)
 };
 
 // --dc (AFC) per-channel state: what find_header keeps in dsp.Df / dsp.locked / dsp.dc (demod_mod.c:1555-1600, 280-298)
@@ -162,6 +166,10 @@ int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: dec
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_dc_update_keep(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, float maxcnt, hipStream_t s);
 void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapped, hipStream_t s);
+// per-channel IQ-DC schedule (restarted channels): cnt += n_samples; a channel that reaches its segment length hands its mean over
+// (avg_prev = avg, avg = sums / max, sums = 0, since = 0, cnt = 0, max doubles up to lim); the others get since += nblocks
+void sonde_launch_dc_update_pcs(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, uint32_t *cnt, uint32_t *max, uint32_t lim, int32_t *since,
+                                uint32_t n_samples, int nblocks, hipStream_t s);
 void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s);

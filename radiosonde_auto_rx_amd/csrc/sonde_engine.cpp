@@ -81,6 +81,10 @@ struct sonde_engine {
     uint64_t samples_in = 0;       // base-rate samples consumed per channel
     uint32_t m_out = 0;            // IF samples produced per channel
     uint32_t dc_cnt = 0, dc_max = 0, dc_lim = 0;
+    // base-rate engines whose channels were restarted at run time: every channel has its own sample clock (pcs = per-channel schedule):
+    // mixer table phase origin, IQ-DC segment counters (host mirror + device copy kept by k_dc_update_pcs)
+    bool pcs = false; std::vector<uint32_t> pcs_cnt, pcs_max; uint32_t dc_max0 = 0;
+    uint32_t *d_epoch_phase = nullptr, *d_pcs_cnt = nullptr, *d_pcs_max = nullptr; int32_t *d_pcs_since = nullptr;
     // results of the last fetch
     std::vector<float> last_soft, last_soft1; int last_n = 0;
     std::vector<uint8_t> last_frame;
@@ -422,6 +426,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     e->dc_lim = (uint32_t)sr; e->dc_max = e->dc_lim / 32;
     if (D > 1) { e->dc_lim *= D; e->dc_max *= D; }
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
+    e->dc_max0 = e->dc_max;
     e->ifiq = ifiq;
     if (cfg->bits == 32) {
         bad = dalloc(&e->d_dcsums_f, 2 * (size_t)C);
@@ -483,7 +488,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
                      e->d_epoch, e->d_work, e->d_work_count, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
-                     e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws };
+                     e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws, e->d_epoch_phase, e->d_pcs_cnt, e->d_pcs_max, e->d_pcs_since };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -494,8 +499,14 @@ int sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info) {
     return 0;
 }
 
+static uint32_t pcs_room(const sonde_engine *e) {             // samples until the first channel reaches the end of its IQ-DC segment
+    uint32_t r = 0xffffffffu;
+    for (size_t c = 0; c < e->pcs_cnt.size(); c++) r = std::min(r, e->pcs_max[c] - e->pcs_cnt[c]);
+    return r;
+}
 int64_t sonde_engine_samples_to_dc_boundary(const sonde_engine_t *e) {
-    return e ? (int64_t)(e->dc_max - e->dc_cnt) : SONDE_E_ARG;
+    if (!e) return SONDE_E_ARG;
+    return e->pcs ? (int64_t)pcs_room(e) : (int64_t)(e->dc_max - e->dc_cnt);
 }
 
 void *sonde_engine_stream(sonde_engine_t *e) { return e ? (void *)e->stream : nullptr; }
@@ -579,7 +590,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     }
     while (done < n_samples) {
         // never straddle an IQ-DC segment: the mean of segment s-1 is subtracted throughout segment s
-        const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt);
+        const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->pcs ? pcs_room(e) : e->dc_max - e->dc_cnt);
         MixDecArgs a{};
         a.iq = (const int16_t *)d_iq + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
         a.D = D; a.Q = e->Q; a.G = e->G;
@@ -598,10 +609,20 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         a.etab = e->d_etab; a.etab_len = e->etab_len;
         a.dc_avg_prev = (e->d_etab && e->dc_since < e->Q - 1) ? e->d_dcavg_prev : nullptr; a.dc_since = e->dc_since;
         if (e->dc_since < (1 << 20)) e->dc_since += take / D;
+        if (e->pcs) { a.epoch_phase = e->d_epoch_phase; a.dc_since_ch = e->d_pcs_since; a.dc_avg_prev = e->d_etab ? e->d_dcavg_prev : nullptr; }
         prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);
         if (lrc < 0) return SONDE_E_ARG;
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
+        if (e->pcs) {                                    // per-channel segment edges: the device keeps the counters, the host mirrors them
+            sonde_launch_dc_update_pcs(C, e->d_dcsums, e->d_dcavg, e->d_dcavg_prev, e->d_pcs_cnt, e->d_pcs_max, e->dc_lim, e->d_pcs_since, (uint32_t)take, take / D, e->stream);
+            for (int c2 = 0; c2 < C; c2++) {
+                e->pcs_cnt[c2] += (uint32_t)take;
+                if (e->pcs_cnt[c2] >= e->pcs_max[c2]) { e->pcs_cnt[c2] = 0; if (e->pcs_max[c2] < e->dc_lim) e->pcs_max[c2] *= 2; }
+            }
+            e->dc_cnt = 0;
+            continue;
+        }
         if (e->dc_cnt == e->dc_max) {
             if (e->d_etab) e->dc_since = 0;
             sonde_launch_dc_update_keep(C, e->d_dcsums, e->d_dcavg, e->d_etab ? e->d_dcavg_prev : nullptr, (float)e->dc_max, e->stream);
@@ -955,10 +976,35 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
     if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
     // channels of an engine share the base-rate sample clock (mixer table phase, IQ-DC segment schedule): only engines without that
     // front end can give one channel a new origin; the AFC loop of --dc and the pipelined streams are left out as well
-    if (e->info.decM != 1 || e->cfg.input == SONDE_IN_IQ || e->cfg.opt_dc || e->cfg.opt_iqdc || e->cfg.pipeline || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    const bool base = e->cfg.input == SONDE_IN_IQ;            // --IQ fq: mixer + decimator in front of the IF-rate chain
+    if ((!base && e->info.decM != 1) || e->cfg.opt_dc || e->cfg.opt_iqdc || e->cfg.pipeline || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    if (base && (e->cfg.bits == 32 || e->cfg.opt_nolut || e->lut_len <= 0 || e->lut_len % e->info.decM)) return SONDE_E_ARG;   // int16 / uint8 input through the mixer table only
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
     const int C = e->cfg.n_channels;
+    if (base) {
+        // the channel's own sample clock starts here: mixer table phase 0, IQ-DC mean 0 with the first (shortest) segment, empty decimator history
+        if (!e->pcs) {
+            e->pcs_cnt.assign((size_t)C, e->dc_cnt); e->pcs_max.assign((size_t)C, e->dc_max);
+            std::vector<uint32_t> zero((size_t)C, 0u); std::vector<int32_t> since((size_t)C, e->dc_since);
+            if (dalloc(&e->d_epoch_phase, (size_t)C) || dalloc(&e->d_pcs_cnt, (size_t)C) || dalloc(&e->d_pcs_max, (size_t)C) || dalloc(&e->d_pcs_since, (size_t)C)) return SONDE_E_NOMEM;
+            HIPCHK(hipMemcpy(e->d_pcs_cnt, e->pcs_cnt.data(), (size_t)C * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_pcs_max, e->pcs_max.data(), (size_t)C * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(e->d_pcs_since, since.data(), (size_t)C * sizeof(int32_t), hipMemcpyHostToDevice));
+            if (e->d_etab && !e->d_dcavg_prev) return SONDE_E_ARG;
+            e->pcs = true;
+        }
+        const uint32_t ph = (uint32_t)(e->samples_in % (uint64_t)e->lut_len), zero = 0u, m0 = e->dc_max0; const int32_t far = 1 << 20;
+        HIPCHK(hipMemcpy(e->d_epoch_phase + channel, &ph, sizeof ph, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_pcs_cnt + channel, &zero, sizeof zero, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_pcs_max + channel, &m0, sizeof m0, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_pcs_since + channel, &far, sizeof far, hipMemcpyHostToDevice));
+        e->pcs_cnt[channel] = 0; e->pcs_max[channel] = m0;
+        HIPCHK(hipMemset(e->d_dcavg + channel, 0, sizeof(float2)));
+        if (e->d_dcavg_prev) HIPCHK(hipMemset(e->d_dcavg_prev + channel, 0, sizeof(float2)));
+        HIPCHK(hipMemset(e->d_dcsums + 2 * (size_t)channel, 0, 2 * sizeof(long long)));
+        for (int k = 0; k < 2; k++) if (e->d_ptail[k]) HIPCHK(hipMemset(e->d_ptail[k] + (size_t)channel * 64, 0, 64 * sizeof(float2)));
+    }
     const size_t ring = (size_t)e->ring_len, row = (size_t)channel * ring;
     // history older than the new origin reads as silence, like the reference's freshly allocated buffers
     if (e->d_y)    HIPCHK(hipMemset(e->d_y + row, 0, ring * sizeof(float2)));
@@ -982,7 +1028,21 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
 }
 
 int sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq) {
-    if (!e || channel < 0 || channel >= e->cfg.n_channels || !e->cfg.if_tune || !(fq >= -0.5 && fq <= 0.5)) return SONDE_E_ARG;
+    if (!e || channel < 0 || channel >= e->cfg.n_channels || !(fq >= -0.5 && fq <= 0.5)) return SONDE_E_ARG;
+    if (e->cfg.input == SONDE_IN_IQ && !e->ifiq && e->cfg.bits != 32 && !e->cfg.opt_nolut) {
+        // base-rate engine: the channel's mixer table is that of `--IQ fq` (carrier snapped to the table's raster, demod_mod.c:1265-1288) and, in fold
+        // mode, its row of the E table; meant to be followed by sonde_engine_restart_channel() — the samples the channel has seen were mixed with the old carrier
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const Mixer m = design_mixer(-fq, e->cfg.sample_rate);
+        if (m.lut_len != e->lut_len) return SONDE_E_ARG;
+        HIPCHK(hipMemcpy(e->d_chanf0 + channel, &m.f0, sizeof m.f0, hipMemcpyHostToDevice));
+        if (e->d_etab) {
+            sonde_launch_md_etable(e->d_chanf0 + channel, e->d_wtab, e->info.decM, e->Q, e->etab_len, 1, e->d_etab + (size_t)channel * e->etab_len, e->stream);
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+        return 0;
+    }
+    if (!e->cfg.if_tune) return SONDE_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     const double f0 = -fq;
     HIPCHK(hipMemcpy(e->d_chanf0 + channel, &f0, sizeof f0, hipMemcpyHostToDevice));

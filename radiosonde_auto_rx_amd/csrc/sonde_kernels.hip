@@ -159,6 +159,14 @@ __device__ __forceinline__ float2 md_phasor(double f0, uint32_t n) {
     const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
     return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
 }
+// table index of the launch's first sample / blocks since the last change of the IQ-DC mean, for a channel that may have been restarted at run time
+__device__ __forceinline__ uint32_t md_lut_phase(const MixDecArgs &a, int ch) {
+    if (!a.epoch_phase) return a.lut_phase;
+    const uint32_t L = (uint32_t)a.lut_len;
+    return (a.lut_phase + L - a.epoch_phase[ch]) % L;
+}
+__device__ __forceinline__ int md_dc_since(const MixDecArgs &a, int ch) { return a.dc_since_ch ? a.dc_since_ch[ch] : a.dc_since; }
+
 // k_md_etable: E[ch][i] = sum_{q<Q} sum_{r<D} W_q[r] ex[D ((i-(Q-1)+q) mod P) + r], i < P = lut_len / D: the decimator's output for
 // the input x = 1 when the block that completes the output is block i of the mixer table's period.  Once per engine.
 __global__ __launch_bounds__(256)
@@ -185,11 +193,12 @@ void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, 
 // (A launch shorter than Q-1 blocks leaves part of that reach to the next one: dc_since.)
 __device__ __forceinline__ float2v md_dc_boundary(const MixDecArgs &a, int ch, double f0, int j) {
     float2v t = {0.f, 0.f};
-    if (a.dc_avg_prev && j < a.Q - 1 - a.dc_since) {          // dc_since: blocks between the change of the mean and this launch
+    const int since = md_dc_since(a, ch);                     // blocks between the change of the mean and this launch
+    if (a.dc_avg_prev && j < a.Q - 1 - since) {
         const int H = a.Q - 1, P = a.etab_len;
-        const int i0 = (int)((a.lut_phase / (uint32_t)a.D) % (uint32_t)P);
+        const int i0 = (int)((md_lut_phase(a, ch) / (uint32_t)a.D) % (uint32_t)P);
         float sr = 0.f, si = 0.f;
-        for (int q = 0; q < H - j - a.dc_since; q++) {        // block b = j - (H - q) of the launch lies before the change
+        for (int q = 0; q < H - j - since; q++) {             // block b = j - (H - q) of the launch lies before the change
             const uint32_t n0 = (uint32_t)a.D * (uint32_t)((i0 + j - (H - q) + P) % P);
             for (int r = 0; r < a.D; r++) {
                 const float2 e = md_phasor(f0, n0 + (uint32_t)r);
@@ -282,7 +291,7 @@ void k_mix_decimate50(const MixDecArgs a) {
     if (seg == 0 && lane < H) carry += md_dc_boundary(a, ch, f0, lane);
     int sx = 0, sy = 0;
     // the lane's block as an index into the period of the mixer table (table index = D * eidx): phase seed and E index
-    uint32_t eidx = (uint32_t)(((uint64_t)(a.lut_phase / D) + (uint64_t)(jt0 + lane)) % P);
+    uint32_t eidx = (uint32_t)(((uint64_t)(md_lut_phase(a, ch) / D) + (uint64_t)(jt0 + lane)) % P);
     float2v acc[Q_T];
 
     if (nfull > 0) {
@@ -444,7 +453,7 @@ void k_mix_decimate(const MixDecArgs a) {
 
     int sx = 0, sy = 0;
     const uint32_t step = (uint32_t)(((uint64_t)MD_ROWS * (uint64_t)D) % L);
-    uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)(jt0 + lane) * (uint64_t)D) % L);
+    uint32_t rown = (uint32_t)(((uint64_t)md_lut_phase(a, ch) + (uint64_t)(jt0 + lane) * (uint64_t)D) % L);
 
     for (int jt = jt0; jt < je; jt += MD_ROWS) {
         const bool more = jt + MD_ROWS < je;
@@ -555,7 +564,7 @@ void k_mix_decimate_wide(const MixDecArgs a) {
 #pragma unroll
         for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
         float2v dcs = {0.f, 0.f};
-        const uint32_t rown = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)j * (uint64_t)D) % L);
+        const uint32_t rown = (uint32_t)(((uint64_t)md_lut_phase(a, ch) + (uint64_t)j * (uint64_t)D) % L);
         for (int sub = 0; sub < NS; sub++) {
             const long long o0 = (long long)j * D + (long long)sub * DS;
             for (int v = 0; v < pitch / 4; v++) {
@@ -605,6 +614,24 @@ __global__ void k_dc_update(int n_ch, long long *dc_sums, float2 *dc_avg, float2
     if (dc_avg_prev) dc_avg_prev[c] = dc_avg[c];
     dc_avg[c] = make_float2((float)(sx / (double)maxcnt), (float)(sy / (double)maxcnt));
     dc_sums[2 * c] = 0; dc_sums[2 * c + 1] = 0;
+}
+__global__ void k_dc_update_pcs(int n_ch, long long *dc_sums, float2 *dc_avg, float2 *dc_avg_prev, uint32_t *cnt, uint32_t *mx, uint32_t lim, int32_t *since,
+                                uint32_t n_samples, int nblocks) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    const uint32_t k = cnt[c] + n_samples, m = mx[c];
+    if (k >= m) {                                             // the host never lets a launch run past a channel's segment edge: k == m
+        const double sx = (double)dc_sums[2 * c] / 32768.0, sy = (double)dc_sums[2 * c + 1] / 32768.0;
+        if (dc_avg_prev) dc_avg_prev[c] = dc_avg[c];
+        dc_avg[c] = make_float2((float)(sx / (double)(float)m), (float)(sy / (double)(float)m));
+        dc_sums[2 * c] = 0; dc_sums[2 * c + 1] = 0;
+        cnt[c] = 0; if (m < lim) mx[c] = 2 * m;
+        since[c] = 0;
+    } else {
+        cnt[c] = k;
+        const int sn = since[c];
+        since[c] = sn < (1 << 20) ? sn + nblocks : sn;
+    }
 }
 // one word of device memory -> pinned host memory (the frame counter after a call's frame sync): a one-lane kernel on the same queue instead of
 // a copy-engine round trip at the end of every call
@@ -1678,6 +1705,10 @@ extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, f
 }
 extern "C" void sonde_launch_dc_update_keep(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, avg_prev, maxcnt);
+}
+extern "C" void sonde_launch_dc_update_pcs(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, uint32_t *cnt, uint32_t *max, uint32_t lim, int32_t *since,
+                                           uint32_t n_samples, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_dc_update_pcs, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, avg_prev, cnt, max, lim, since, n_samples, nblocks);
 }
 extern "C" void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapped, hipStream_t s) {
     hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(64), 0, s, src, dst_mapped);

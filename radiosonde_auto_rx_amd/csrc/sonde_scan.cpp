@@ -212,7 +212,7 @@ static uint16_t f16_bits(float x) { const _Float16 h = (_Float16)x; uint16_t u; 
 // (each tap belongs to exactly one step c; half of every 16x32 fragment is zero).  Fragment element: step c, lane (b = lane & 15, g = lane >> 4),
 // r < 8  <-  A_c[b][8 g + r].
 static int toeplitz_frags(const std::vector<float> &h, std::vector<uint16_t> &out) {
-    const int U = (int)h.size(), nc = (U + 15) / 16;
+    const int U = (int)h.size(), nc = ((U + 15) / 16 + 3) & ~3;      // whole blocks of 4 steps (k_scan_pre prefetches the fragments block-wise); the padding is zeros
     for (int c = 0; c < nc; c++)
         for (int lane = 0; lane < 64; lane++)
             for (int r = 0; r < 8; r++) {

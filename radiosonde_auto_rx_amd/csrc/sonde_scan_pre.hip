@@ -27,36 +27,60 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SP_THREADS 512
 #define SP_WAVES 8
 #define SP_MAXT 4                      // 256-sample tiles per wave (8192 samples / 256 / 8 waves)
+#define SP_CK 4                        // Toeplitz steps per block of prefetched A fragments (the host pads every table to a multiple)
 #define SP_CH 16                       // samples per thread in the load and prefix phases (8192 / 512)
 #define SP_PI(i) ((i) + ((i) >> 4))    // prefix sums are stored with one pad word per 16: a thread's run of 16 stays off its neighbours' banks
 
 __device__ __forceinline__ float sp_wsum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
-// acc[t] += A_c x B(tile t, step c) for the wave's tiles; x: f16 array in LDS whose element 0 pairs with h[0] of output 0
+// acc[t] = sum_c A_c x B(tile t, step c) for the NT tiles of this wave (tile = wave + SP_WAVES t); x: f16 array in LDS whose element 0 pairs with
+// h[0] of output 0.  NT is a template parameter so that the step loop has no branches: the B fragments of a step are NT independent 16-byte
+// LDS reads at a fixed distance, followed by NT MFMAs.  A_c comes from global memory (the tables of all templates do not fit beside the
+// window in LDS); the fragment of step c+1 is requested before the MFMAs of step c so that its latency is covered.
 template <int NT>
-__device__ __forceinline__ void sp_toeplitz(const _Float16 *x, const uint16_t *afrag, int nc, int wave, int ntiles, int lane, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void sp_toeplitz_nt(const _Float16 *x, const uint16_t *afrag, int nc, int wave, int lane, f32x4 *acc) {
     const int n = lane & 15, g = lane >> 4;
+    f32x4 r[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A_c comes from global memory (the tables of all templates do not fit beside the window in LDS): the fragment of step c+1 is requested
-    // before the MFMAs of step c so that its latency is covered; the B fragments of a step are independent LDS reads
+    for (int t = 0; t < NT; t++) r[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const half8 *af = reinterpret_cast<const half8 *>(afrag) + lane;
-    half8 A = af[0];
-    for (int c = 0; c < nc; c++) {
-        const half8 An = af[(size_t)64 * (c + 1 < nc ? c + 1 : c)];
-        half8 B[NT];
+    const _Float16 *xb = x + 16 * (16 * wave + n) + 8 * g;           // tile t adds 16 * 16 * SP_WAVES * t halves, step c adds 16
+    // nc is a multiple of SP_CK (the host pads the table with zero steps).  The A fragments of the NEXT block of SP_CK steps are requested before
+    // the MFMAs of the current block (the scheduling barrier keeps the requests there), so one global-memory latency is paid per wave, not per step.
+    half8 cur[SP_CK], nxt[SP_CK];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int tile = wave + SP_WAVES * t;
-            if (tile < ntiles) B[t] = *reinterpret_cast<const half8 *>(x + 16 * (16 * tile + n + c) + 8 * g);
-        }
+    for (int k = 0; k < SP_CK; k++) cur[k] = af[(size_t)64 * k];
+    for (int c0 = 0; c0 < nc; c0 += SP_CK) {
+        const int cn = c0 + SP_CK < nc ? c0 + SP_CK : c0;             // the last block re-reads itself (unused)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int tile = wave + SP_WAVES * t;
-            if (tile < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B[t], acc[t], 0, 0, 0);      // wave-uniform branch
+        for (int k = 0; k < SP_CK; k++) nxt[k] = af[(size_t)64 * (cn + k)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < SP_CK; k++) {
+            half8 B[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) B[t] = *reinterpret_cast<const half8 *>(xb + 256 * SP_WAVES * t + 16 * k);
+#pragma unroll
+            for (int t = 0; t < NT; t++) r[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[k], B[t], r[t], 0, 0, 0);
         }
-        A = An;
+        xb += 16 * SP_CK;
+#pragma unroll
+        for (int k = 0; k < SP_CK; k++) cur[k] = nxt[k];
     }
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = r[t];
+}
+// number of tiles of this wave (wave-uniform) and the dispatch on it
+__device__ __forceinline__ int sp_toeplitz(const _Float16 *x, const uint16_t *afrag, int nc, int wave, int ntiles, int lane, f32x4 (&acc)[SP_MAXT]) {
+    const int cnt = ntiles > wave ? (ntiles - wave + SP_WAVES - 1) / SP_WAVES : 0;
+    switch (cnt) {
+        case 1: sp_toeplitz_nt<1>(x, afrag, nc, wave, lane, acc); break;
+        case 2: sp_toeplitz_nt<2>(x, afrag, nc, wave, lane, acc); break;
+        case 3: sp_toeplitz_nt<3>(x, afrag, nc, wave, lane, acc); break;
+        case 4: sp_toeplitz_nt<4>(x, afrag, nc, wave, lane, acc); break;
+        default: break;
+    }
+    return cnt;
 }
 
 __global__ __launch_bounds__(SP_THREADS, 4)
@@ -119,7 +143,7 @@ void k_scan_pre(const ScanPreArgs a) {
     // reference's (circular, zero padded) array, so the first taps-1 outputs get the part of it the filter has not seen yet (ws_tail)
     if (a.opt_iq) {
         f32x4 acc[SP_MAXT];
-        sp_toeplitz<SP_MAXT>(xh, a.a_ws + (size_t)tp.lpfm * a.nc1 * 512, a.nc1, wave, nT1, lane, acc);
+        sp_toeplitz(xh, a.a_ws + (size_t)tp.lpfm * a.nc1 * 512, a.nc1, wave, nT1, lane, acc);
         const float *tail = a.ws_tail + tp.lpfm * a.taps;
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) {
@@ -168,7 +192,7 @@ void k_scan_pre(const ScanPreArgs a) {
     float bc = -1.f, bs = 0.f; int bp = 0x7fffffff; float bcv = 0.f;
     {
         f32x4 acc[SP_MAXT];
-        sp_toeplitz<SP_MAXT>(xfh, a.a_match + a.a_off[j], nc2, wave, nT2, lane, acc);
+        sp_toeplitz(xfh, a.a_match + a.a_off[j], nc2, wave, nT2, lane, acc);
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) {
             const int tile = wave + SP_WAVES * t;

@@ -225,6 +225,61 @@ def test_wideband_receiver_m10_m20():
     assert len([j for j in out if j["type"] == "RS41" and j["id"] == "D4444444"]) >= 3
 
 
+def test_wideband_c_entry_matches_the_decoders_started_by_hand():
+    """host/bin/sonde_wideband (C, §8f-3): one 2.4 Msps stream with an RS41, an M10 and an M20 at off-raster offsets.  Nobody tells it where they
+    are: the raster scanner finds them, each gets a channel of its type's `--IQ` engine at run time (sonde_engine_tune_channel + restart_channel on a
+    base-rate engine) and the telemetry tier prints one JSON object per frame.  Checked against the REFERENCE decoders started by hand on the same
+    stream with the carrier the receiver reports (what auto_rx would have started: `rs41mod --json --IQ fq --lpIQ`, `m10mod --json`, `m20mod --json`):
+    every JSON object the reference prints for a frame that starts after the detection is printed by the receiver too, field by field."""
+    import json
+    from tools import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    if not os.path.exists(os.path.join(REF, "rs41mod")):
+        pytest.skip("compiled reference not present")
+    sr, cf, secs = 2_400_000, 404_000_000, 7.3
+    n = int(sr * secs)
+    x = np.zeros(n, np.complex128)
+
+    def add(cap, hz, amp):
+        z = (cap[0::2].astype(np.float64) + 1j * cap[1::2].astype(np.float64)) / (32767 * 0.9)
+        x[:len(z)] += (amp / 0.5) * z[:n] * np.exp(2j * np.pi * hz / sr * np.arange(min(n, len(z))))
+
+    add(synth.m10_capture(sr=sr, seconds=secs, noise_sigma=0.0, seed=41, frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(900 + k))), +301_700.0, 0.25)
+    add(synth.m10_capture(sr=sr, seconds=secs, noise_sigma=0.0, seed=42, baud=9600.0, t_first=0.6,
+                          frame_fn=lambda k: synth.m20_frame(k, fw=8, pressure_hpa=455.5, rng=np.random.default_rng(950 + k))), -608_300.0, 0.25)
+    add(synth.rs41_capture(sr=sr, seconds=secs, fq=0.0, n_frames=6, t_first=0.4, noise_sigma=0.0, amp=0.5, seed=43, sonde_id="D4444444",
+                           frame_kw=dict(ecef_cm=(418833319, 85974133, 473346430))), +55_000.0, 0.2)
+    rng = np.random.default_rng(6)
+    x += 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767); iq[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767)
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    r = subprocess.run([os.path.join(BIN, "sonde_wideband"), "-v", "--cfreq", str(cf), "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    objs = [json.loads(l) for l in r.stdout.decode().splitlines()]
+    det = {}
+    for l in r.stderr.decode().splitlines():                 # "detected: RS41 +55008 Hz (404055 kHz) -> channel 0"
+        if l.startswith("detected: "):
+            w = l.split()
+            det[w[1]] = int(w[2]) / sr
+    assert sorted(det) == ["M10", "M20", "RS41"], r.stderr.decode()
+    assert abs(det["RS41"] * sr - 55_000) < 1500 and abs(det["M10"] * sr - 301_700) < 3000 and abs(det["M20"] * sr + 608_300) < 3000
+    for typ, binary, args in (("RS41", "rs41mod", ["--ptu2", "--json"]), ("M10", "m10mod", ["-v", "--ptu", "--json"]), ("M20", "m20mod", ["-v", "--ptu", "--json"])):
+        ref = subprocess.run([os.path.join(REF, binary)] + args + ["--IQ", repr(det[typ]), "--lpIQ", "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600)
+        want = [json.loads(l) for l in ref.stdout.decode().splitlines() if l.startswith("{")]
+        mine = {o["frame"]: o for o in objs if o["type"] == typ}
+        assert len(want) >= 4 and len(mine) >= len(want) - 2, (typ, len(want), len(mine))
+        first = min(mine)
+        for o in want:
+            if o["frame"] < first:
+                continue                                     # before the scanner had seen the sonde
+            m = dict(mine[o["frame"]])
+            o = dict(o)
+            for k in ("freq", "version", "tx_frequency"):     # the receiver adds the channel frequency; the reference build has no --jsn_cfq here
+                m.pop(k, None); o.pop(k, None)
+            assert m == o, (typ, o["frame"], m, o)
+
+
 def test_wideband_module_cli():
     """`python -m radiosonde_auto_rx_amd.wideband --cfreq Hz - 2400000 16 < capture`: one JSON object per decoded frame on stdout"""
     import json

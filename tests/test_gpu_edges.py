@@ -154,6 +154,73 @@ def test_queue_overflow_is_reported_not_returned_as_error():
 
 
 @pytest.mark.gpu
+def test_base_rate_channel_restart_behaves_like_a_fresh_engine():
+    """The same for a 2.4 Msps `--IQ fq` engine (mixer + decimator in front of the IF-rate chain; the hand-scheduled decimator): channel 1
+    carries a first sonde, is ended, gets ANOTHER carrier (sonde_engine_tune_channel) and is restarted in the middle of the engine's life — the
+    mixer table phase, the IQ-DC mean with its segment schedule and the decimator history of that channel start over, calls are cut at every
+    channel's own segment edges from then on.  The second stream decodes to exactly what a fresh one-channel engine gives (frame bytes, ECC
+    verdict, header positions counted from the stream's own start, soft bits within 1e-5), channel 0 carries on undisturbed."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    sr, blk = 2_400_000, 240_000
+    fqs = [synth.snap_fq(f, sr) for f in (0.11, -0.23, 0.31)]
+    caps = [synth.rs41_capture(sr=sr, seconds=5.4, fq=fqs[0], noise_sigma=0.03, n_frames=5, t_first=0.2, seed=171, dc=0.01 - 0.02j),
+            synth.rs41_capture(sr=sr, seconds=2.3, fq=fqs[1], noise_sigma=0.05, n_frames=2, t_first=0.31, seed=172, first_frame_no=77),
+            synth.rs41_capture(sr=sr, seconds=2.7, fq=fqs[2], noise_sigma=0.04, n_frames=2, t_first=0.12, seed=173, first_frame_no=990, dc=-0.02 + 0.01j)]
+
+    def alone(x, fq):
+        e = Engine([fq], sr, max_chunk=sr, keep_soft=True)
+        n = len(x) // 2 // 50 * 50
+        out = []
+        for s0 in range(0, n, blk):
+            e.process_host(x[2 * s0:2 * min(n, s0 + blk)][None, :])
+            out += e.fetch_frames(with_soft=True, finish=(s0 + blk >= n))
+        e.close()
+        return out
+
+    want = [alone(c, f) for c, f in zip(caps, fqs)]
+    assert [len(w) for w in want] == [5, 2, 2]
+    eng = Engine([fqs[0], fqs[1]], sr, max_chunk=sr, keep_soft=True)
+    n0 = len(caps[0]) // 2 // 50 * 50
+    n1 = len(caps[1]) // 2 // 50 * 50
+    n2 = len(caps[2]) // 2 // 50 * 50
+    got0, got1, got2 = [], [], []
+    seg, pos1 = 1, 0
+    for s0 in range(0, n0, blk):
+        a = caps[0][2 * s0:2 * min(n0, s0 + blk)]
+        take = len(a) // 2
+        src, nsrc = (caps[1], n1) if seg == 1 else (caps[2], n2)
+        b = src[2 * pos1:2 * min(nsrc, pos1 + take)]
+        if len(b) < len(a):
+            b = np.concatenate([b, np.zeros(len(a) - len(b), np.int16)])
+        pos1 += take
+        eng.process_host(np.stack([a, b]))
+        for f in eng.fetch_frames(with_soft=True):
+            (got0 if f["channel"] == 0 else got1 if seg == 1 else got2).append(f)
+        if seg == 1 and pos1 >= n1:                           # end of the first sonde on channel 1: its frame in progress, then the new carrier
+            eng.finish_channel(1)
+            for f in eng.fetch_frames(with_soft=True):
+                (got0 if f["channel"] == 0 else got1).append(f)
+            eng.tune_channel(1, fqs[2])
+            eng.restart_channel(1)
+            seg, pos1 = 2, 0
+    for f in eng.fetch_frames(with_soft=True, finish=True):
+        (got0 if f["channel"] == 0 else got2).append(f)
+    eng.close()
+
+    def same(a, b):
+        assert len(a) == len(b), (len(a), len(b))
+        for u, v in zip(a, b):
+            assert u["mv_pos"] == v["mv_pos"] and u["ecc"] == v["ecc"] and u["len"] == v["len"] and bytes(u["frame"]) == bytes(v["frame"])
+            nb = (u["nbytes"] - 8) * 8
+            assert float(np.sqrt(np.mean((u["soft"][:nb] - v["soft"][:nb]) ** 2))) < 1e-5
+    same(got0, want[0])
+    same(got2, want[2][:len(got2)])
+    assert len(got2) >= 1 and got2[0]["mv_pos"] == want[2][0]["mv_pos"]
+    assert len(got1) >= 1 and bytes(got1[0]["frame"]) == bytes(want[1][0]["frame"]) and got1[0]["mv_pos"] == want[1][0]["mv_pos"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["audio", "iq2"])
 def test_channel_restart_behaves_like_a_fresh_engine(form):
     """sonde_engine_finish_channel / sonde_engine_restart_channel (what the resident broker needs for decoder processes that come and go):
