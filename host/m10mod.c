@@ -20,6 +20,7 @@
 #include "wav_header.h"
 
 static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (m10mod.c:1184,1245-1251,1436) */
+static int g_chk3 = 0;                       /* --chk3 */
 static int g_verbose = 0, g_raw = 0, g_color = 0;
 static sonde_m10_dec_t *g_dec = NULL;
 
@@ -102,6 +103,7 @@ int main(int argc, char **argv) {
             if (bw > 4.6 && bw < 48.0) cfg.lpiq_bw = (int)(bw * 1e3);
             cfg.opt_lp |= SONDE_LP_IQ;
         }
+        else if (!strcmp(a, "--chk3")) g_chk3 = 1;       /* bits re-decided from both soft values (m10mod.c:1233,1476-1479; IQ forms only) */
         else if (!strcmp(a, "--min")) cfg.opt_min = 1;
         else if (!strcmp(a, "--ch2")) wav_ch = 1;
         else if (!strcmp(a, "-")) {
@@ -177,14 +179,16 @@ int main(int argc, char **argv) {
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
     brk_demod_t brk; brk.fd = -1;
-    const int use_broker = brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
+    const int use_broker = (g_chk3 && have_iq) ? 0 : brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
     int rc = 0;
     sonde_info_t info;
     if (use_broker) {
         if (brk_demod_open(&brk, &cfg, g_shift != 0, 2, 0 + g_shift) < 0) return -1;
         info = brk.info;
     } else {
+        if (g_chk3 && have_iq) cfg.keep_soft = 2;
         rc = sonde_engine_create(&cfg, &fq, &eng);
+        if (rc >= 0 && g_chk3 && have_iq) rc = sonde_engine_set_m10_chk3(eng, 1);
         if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 0 + g_shift);
         if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
         sonde_engine_info(eng, &info);

@@ -20,6 +20,7 @@
 #include "wav_header.h"
 
 static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (m20mod.c:1040,1108-1114) */
+static double g_baud = -1;                   /* --br */
 static int g_verbose = 0, g_raw = 0, g_color = 0;
 static sonde_m20_dec_t *g_dec = NULL;
 
@@ -102,6 +103,11 @@ int main(int argc, char **argv) {
             if (bw > 4.6 && bw < 48.0) cfg.lpiq_bw = (int)(bw * 1e3);
             cfg.opt_lp |= SONDE_LP_IQ;
         }
+        else if (!strcmp(a, "--br")) {                   /* symbol rate; out of range = the default (m20mod.c) */
+            if (++i >= argc) return -1;
+            g_baud = atof(argv[i]);
+            if (g_baud < 9000 || g_baud > 10000) g_baud = 9600.0;
+        }
         else if (!strcmp(a, "--min")) cfg.opt_min = 1;
         else if (!strcmp(a, "--ch2")) wav_ch = 1;
         else if (!strcmp(a, "-")) {
@@ -177,14 +183,18 @@ int main(int argc, char **argv) {
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
     brk_demod_t brk; brk.fd = -1;
-    const int use_broker = brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
+    const int use_broker = g_baud > 0 ? 0 : brk_demod_wanted(&cfg);     /* SONDE_BROKER: a channel of the resident engine instead of one of our own; --br: our own (the broker's groups run the preset rate) */
     int rc = 0;
     sonde_info_t info;
+    if (g_baud > 0) fprintf(stderr, "sps corr: %.4f\n", (float)cfg.sample_rate / (float)g_baud);        /* before init_buffers()' own lines */
     if (use_broker) {
         if (brk_demod_open(&brk, &cfg, g_shift != 0, 2, 0 + g_shift) < 0) return -1;
         info = brk.info;
     } else {
-        rc = sonde_engine_create(&cfg, &fq, &eng);
+        if (g_baud > 0) {                            /* --br: dsp.br / dsp.sps replaced before init_buffers() */
+            sonde_generic_t gb; memset(&gb, 0, sizeof gb); gb.baud = (float)g_baud;
+            rc = sonde_engine_create_generic(&cfg, &fq, &gb, &eng);
+        } else rc = sonde_engine_create(&cfg, &fq, &eng);
         if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 0 + g_shift);
         if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
         sonde_engine_info(eng, &info);

@@ -162,6 +162,8 @@ typedef struct {
     int32_t reserved[3];
 } sonde_generic_t;
 int  sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out);
+/* With a PRESET cfg->sonde_type (SONDE_RS41 / DFM09 / M10 / M20) a non-NULL `gen` carries one thing only: gen->baud replaces the preset's symbol
+ * rate before the design — the decoders' --br option (dfm09mod.c:1436-1443,1590-1594; m20mod.c:1082-1089).  Everything else of `gen` is ignored. */
 /* replaces free_buffers() (demod_mod.c:1476) */
 void sonde_engine_destroy(sonde_engine_t *e);
 int  sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info);
@@ -258,6 +260,9 @@ typedef struct {
 /* SONDE_M10 engines: frames completed so far; finish != 0 = end of input (a frame in progress is emitted with the bits that
  * exist, m10mod.c:1486-1490). */
 int  sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish);
+/* m10mod --chk3 (m10mod.c:1233,1476-1479; IQ input forms): every bit is re-decided from both soft values of read_softbit2p, (sb + 0.25 sb1) >= 0.
+ * Needs cfg.keep_soft = 2 (the engine then keeps the second soft value per bit); SONDE_E_ARG otherwise. */
+int  sonde_engine_set_m10_chk3(sonde_engine_t *e, int32_t on);
 /* Raw text line of `m10mod -r [-v]` (m10mod.c:1112-1123): hex bytes, with verbose " # <checksum> [OK]|[NO]"; buf >= 2 * len + 96 (340 at most) */
 #define SONDE_M10_COLOR 0x100    /* or'ed into `verbose`: -c, ANSI colours around the fields (m10mod.c:1078-1110; M10 / M10+ frames only); buf >= 4096 */
 int  sonde_m10_rawline(const sonde_m10_frame_t *f, int verbose, char *buf, size_t buflen);

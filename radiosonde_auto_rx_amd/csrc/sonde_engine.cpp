@@ -90,6 +90,7 @@ struct sonde_engine {
     std::vector<uint8_t> last_frame;
     std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
+    bool m10_chk3 = false;                         // m10mod --chk3 (sonde_engine_set_m10_chk3)
     // channels restarted in mid-stream (sonde_engine_restart_channel): per-channel stream start in IF samples
     std::vector<uint32_t> epoch; uint32_t *d_epoch = nullptr; int eof_ch = -1;
     // profiling
@@ -183,7 +184,11 @@ int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t
 
 int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
-    if ((cfg->sonde_type == SONDE_GENERIC) != (gen != nullptr)) return SONDE_E_ARG;
+    if (cfg->sonde_type == SONDE_GENERIC && !gen) return SONDE_E_ARG;
+    // a description next to a PRESET type (DFM09 / M10 / M20 / RS41): only its baud is read — the decoders' --br option (dfm09mod.c:1436-1443,
+    // 1590-1594; m20mod.c:1082-1089): dsp.br / dsp.sps are replaced before init_buffers(), so filters, template and slicers all follow
+    float baud_override = 0.f;
+    if (gen && cfg->sonde_type != SONDE_GENERIC) { if (!(gen->baud > 0.f)) return SONDE_E_ARG; baud_override = gen->baud; gen = nullptr; }
     if (gen) {
         const size_t hl = strnlen(gen->header, sizeof gen->header);
         if (hl < 8 || hl > 64 || !(gen->baud > 0.f) || !(gen->bt > 0.f) || !(gen->h > 0.f) || gen->symlen < 1 || gen->symlen > 2 || gen->symhd < 1 || gen->symhd > gen->symlen ||
@@ -232,6 +237,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
         e->nbits = 264 + 7 * 280; e->l_win = 4.0f; e->thres = cfg->thres > 0 ? cfg->thres : 0.65f;
         header = kDfmRawHeader; lpiq_def = 12000; lpfm_bw = 4000;
     }
+    if (baud_override > 0.f) e->baud = baud_override;
     e->hdrlen = (int)header.size();
     const int lpiq_bw = cfg->lpiq_bw > 0 ? cfg->lpiq_bw : lpiq_def;
 
@@ -911,6 +917,21 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
     const int n = collect_records(e, 0, recs, &soft, max);
     if (n < 0) return n;
     e->last_soft = soft; e->last_n = n;
+    if (e->m10_chk3 && e->d_soft1 && !soft.empty()) {
+        // --chk3 (m10mod.c:1476-1479): the bit is re-decided from both soft values of read_softbit2p, (sb + 0.25 sb1) >= 0, before the differential decoding
+        const unsigned start = e->read_idx - (unsigned)n;
+        std::vector<float> s1((size_t)e->nbits);
+        for (int h = 0; h < n; h++) {
+            const unsigned idx = (start + (unsigned)h) % (unsigned)e->max_frames;
+            if (hipMemcpy(s1.data(), e->d_soft1 + (size_t)idx * e->nbits, (size_t)e->nbits * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+            FrameRec &r = recs[h];
+            const int nv = std::min(r.nbytes, e->nbits);
+            for (int p = 0; p < nv; p++) {
+                const int bit = ((double)soft[(size_t)h * e->nbits + p] + 0.25 * (double)s1[p]) >= 0.0;
+                r.frame[p >> 3] = (uint8_t)((r.frame[p >> 3] & ~(1u << (p & 7))) | ((unsigned)bit << (p & 7)));
+            }
+        }
+    }
     for (int h = 0; h < n; h++) {
         const FrameRec &r = recs[h];
         sonde_m10_frame_t &o = out[h];
@@ -944,6 +965,12 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
         out[i].nbits = e->cfg.sonde_type == SONDE_RS41 ? 8 * (r.nbytes - 8) : r.nbytes;      // RS41 records count bytes incl. the 8 header bytes
     }
     return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
+}
+
+int sonde_engine_set_m10_chk3(sonde_engine_t *e, int32_t on) {
+    if (!e || e->cfg.sonde_type != SONDE_M10 || (on && (!e->d_soft1 || e->cfg.input == SONDE_IN_AUDIO))) return SONDE_E_ARG;   // needs keep_soft = 2; IQ forms only
+    e->m10_chk3 = on != 0;
+    return 0;
 }
 
 int sonde_engine_set_sync(sonde_engine_t *e, int32_t hdmax, int32_t bitofs) {

@@ -131,3 +131,30 @@ def test_cli_bit_offset_option_matches_reference(binary, shift):
     a = subprocess.run([os.path.join(ROOT, "host", "bin", binary)] + args + tail, input=x.tobytes(), capture_output=True, timeout=180)
     b = subprocess.run([ref] + args + tail, input=x.tobytes(), capture_output=True, timeout=180)
     assert a.returncode == 0 and a.stdout == b.stdout and len(b.stdout.splitlines()) >= 2
+
+
+@pytest.mark.parametrize("binary,extra", [("dfm09mod", ["--br", "2497.5"]), ("dfm09mod", ["--br", "3100"]), ("m20mod", ["--br", "9616"]), ("m20mod", ["--br", "12"]),
+                                          ("m10mod", ["--chk3"]), ("m10mod", ["--chk3", "--iq2"])])
+def test_cli_br_and_chk3_match_reference(binary, extra):
+    """`dfm09mod --br x` / `m20mod --br x` (symbol rate replaced before the design: dfm09mod.c:1436-1443,1590-1594; m20mod.c:1082-1089; out of range
+    = default) and `m10mod --chk3` (bits from both soft values of read_softbit2p, m10mod.c:1476-1479) on noisy captures whose symbol clock is off
+    the nominal one: stdout and the stderr preamble of the compiled reference."""
+    from tools import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", binary)
+    if not os.path.exists(ref):
+        pytest.skip("compiled reference not present")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    if binary == "dfm09mod":
+        x = synth.dfm_capture(sr=48_000, seconds=4.2, fq=0.0, noise_sigma=0.12, seed=162)
+        args = ["-r", "--ecc2"]
+    elif binary == "m20mod":
+        x = synth.m10_capture(sr=48_000, seconds=4.3, noise_sigma=0.12, seed=163, baud=9616.0, frame_fn=lambda k: synth.m20_frame(k, rng=np.random.default_rng(190 + k)))
+        args = ["-r", "-v"]
+    else:
+        x = synth.m10_capture(sr=48_000, seconds=5.3, noise_sigma=0.15, seed=164, frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(180 + k)))
+        args = ["-r", "-v"]
+    tail = ["-", "48000", "16"] if "--iq2" in extra else ["--IQ", "0.0", "--lpIQ", "-", "48000", "16"]
+    a = subprocess.run([os.path.join(ROOT, "host", "bin", binary)] + args + extra + tail, input=x.tobytes(), capture_output=True, timeout=180)
+    b = subprocess.run([ref] + args + extra + tail, input=x.tobytes(), capture_output=True, timeout=180)
+    assert a.returncode == 0 and a.stdout == b.stdout and len(b.stdout.splitlines()) >= 2
+    assert a.stderr.decode().splitlines()[:3] == b.stderr.decode().splitlines()[:3]
