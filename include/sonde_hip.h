@@ -162,7 +162,7 @@ typedef struct {
     int32_t reserved[3];
 } sonde_generic_t;
 int  sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out);
-/* With a PRESET cfg->sonde_type (SONDE_RS41 / DFM09 / M10 / M20) a non-NULL `gen` carries one thing only: gen->baud replaces the preset's symbol
+/* With a preset type in cfg (SONDE_RS41 / DFM09 / M10 / M20) a non-NULL `gen` carries one thing only: gen->baud replaces the preset's symbol
  * rate before the design — the decoders' --br option (dfm09mod.c:1436-1443,1590-1594; m20mod.c:1082-1089).  Everything else of `gen` is ignored. */
 /* replaces free_buffers() (demod_mod.c:1476) */
 void sonde_engine_destroy(sonde_engine_t *e);

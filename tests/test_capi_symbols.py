@@ -101,7 +101,8 @@ def test_generic_descriptor_is_validated_before_the_device_is_touched():
         pytest.skip("GPU present")
     assert create() == E_NOGPU
     assert create(gen=False) == E_ARG                      # SONDE_GENERIC without a descriptor
-    assert create(sonde_type=41) == E_ARG                  # a descriptor with a preset type
+    assert create(sonde_type=9) == E_NOGPU                 # a descriptor with a PRESET type: its baud replaces the preset's (--br); everything else is ignored
+    assert create(sonde_type=9, baud=0.0) == E_ARG         # ... and must be a rate
     assert create(header=b"1010") == E_ARG                 # header shorter than 8 symbols
     assert create(baud=0.0) == E_ARG
     assert create(symlen=3) == E_ARG
