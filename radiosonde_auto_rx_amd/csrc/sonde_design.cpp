@@ -54,6 +54,33 @@ Decimator design_decimator(int sr_base, bool if_min) {
     return d;
 }
 
+// dft_detect's variant (dft_detect.c:1021-1067): --bw above 48 kHz raises the IF rate to that bandwidth; an IF above 60 kHz ("wideIF") gets a wider
+// pass band and transition (IF + 60 kHz, IF - 60 kHz)
+Decimator design_decimator_scan(int sr_base, bool if_min, float set_lpIQ) {
+    Decimator d;
+    int if_sr = 48000;
+    if (set_lpIQ > (float)if_sr) if_sr = (int)set_lpIQ;
+    const bool wide = if_sr > 60e3;
+    if (if_min) if_sr = 32000;
+    d.decM = 1;
+    if (if_sr > sr_base) if_sr = sr_base;
+    if (if_sr < sr_base) {
+        while (sr_base % if_sr) if_sr += 1;
+        d.decM = sr_base / if_sr;
+    }
+    float f_lp = (float)((if_sr + 20e3) / (4.0 * sr_base));
+    float t_bw = (float)(if_sr - 20e3);
+    if (wide) { f_lp = (float)((if_sr + 60e3) / (4.0 * sr_base)); t_bw = (float)(if_sr - 60e3); }
+    else if (if_min) t_bw = (float)(if_sr - 12e3);
+    if (t_bw < 0) t_bw = 10e3f;
+    t_bw /= sr_base;
+    int taps = (int)(4.0 / t_bw);
+    if (taps % 2 == 0) taps++;
+    d.if_sr = if_sr;
+    d.taps = design_lowpass(f_lp, taps);
+    return d;
+}
+
 // iq_dec's variant (iq_dec.c:632-666): the IF rate is a parameter (--IFbw), --min only narrows the transition band
 Decimator design_decimator_if(int sr_base, int if_target, bool narrow) {
     Decimator d;

@@ -12,6 +12,7 @@ struct Decimator { int if_sr = 0, decM = 1; std::vector<float> taps; };
 
 std::vector<float> design_lowpass(float f, int taps);
 Decimator design_decimator(int sr_base, bool if_min);
+Decimator design_decimator_scan(int sr_base, bool if_min, float set_lpIQ);
 Decimator design_decimator_if(int sr_base, int if_target, bool narrow);
 struct Mixer { double f0 = 0; int lut_len = 1; };
 Mixer design_mixer(double xlt_fq, int sr_base);

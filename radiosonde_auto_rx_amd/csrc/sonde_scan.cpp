@@ -8,7 +8,8 @@
 //   FIR histories, z0 of the discriminators                                  IF-rate rings in HBM (absolute indices)
 //   k / sample_in / sample_out window counter (main, :1483-1505)             next_sin per channel
 //   mv[], mv_pos[], mv0_pos[], mv_max, j_max, rs_detect2[], mutable type/tn   Chan (host)
-// Not implemented: N_DFT other than 8192 (IF rate above ~51 kHz, i.e. --IQ with --bw > 48).
+// N_DFT is 8192 up to an IF rate of ~51 kHz; above it (--IQ with --bw > 48, --iq input at 96 / 192 kHz) 16384 / 32768: those windows skip the
+// prefilter and every pair runs the reference's transform network on an array in global memory (k_scan_corr_t<true>) — rare, exactness over speed.
 #include "../../include/sonde_scan.h"
 #include "sonde_dev.h"
 #include "sonde_host.h"
@@ -57,9 +58,9 @@ const uint32_t kDefaultDisable = (1u << 11) | (1u << 14);       // -DNOC34C50 -D
 // The reference's own transform (dft_raw, dft_detect.c:285-322): radix-2 decimation in time with the stage twiddle
 // advanced by a float recurrence w1 *= cexp(-i pi/2^s).  Its drift (up to ~2e-4 in the last stage) is part of every
 // score the reference prints, so the template / low-pass spectra and the device kernels use the very same table.
-std::vector<float2> ref_twiddles() {
-    std::vector<float2> tws(SC_N - 1);
-    for (int s = 0; s < SC_LOG2N; s++) {
+std::vector<float2> ref_twiddles(int log2n = SC_LOG2N) {
+    std::vector<float2> tws(((size_t)1 << log2n) - 1);
+    for (int s = 0; s < log2n; s++) {
         const int l2 = 1 << s;
         const std::complex<double> e = std::exp(std::complex<double>(0.0, -M_PI / (double)(float)l2));
         const float w2r = (float)e.real(), w2i = (float)e.imag();
@@ -74,14 +75,15 @@ std::vector<float2> ref_twiddles() {
 }
 
 void dft_ref_host(std::vector<float2> &z, const std::vector<float2> &tws) {
-    const int n = SC_N;
+    const int n = (int)z.size();                 // a power of two; tws = ref_twiddles(log2 n)
+    int log2n = 0; while ((1 << log2n) < n) log2n++;
     for (int i = 1, j = 0; i < n; i++) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
         j ^= bit;
         if (i < j) std::swap(z[i], z[j]);
     }
-    for (int s = 0; s < SC_LOG2N; s++) {
+    for (int s = 0; s < log2n; s++) {
         const int l2 = 1 << s, l = l2 << 1;
         for (int j = 0; j < l2; j++) {
             const float2 w = tws[(size_t)l2 - 1 + j];
@@ -170,6 +172,9 @@ struct sonde_scan {
     std::vector<float> wtab;
     ScanTpl tpl[SC_NTPL]; float thres[kNrs]; uint32_t disabled = 0;
     int K = 0, delay = 0, nstreams = 0, nfilt = 0, filt_stream[3] = {0, 0, 0}, raw_stream = 0, lpiq_taps = 0, lpfm_taps = 0;
+    int N = SC_N, log2n = SC_LOG2N;                // N_DFT (dft_detect.c:1196-1202): 8192, or 16384 / 32768 for IF rates above ~51 kHz
+    float2 *d_scratch = nullptr; int scratch_pairs = 0;       // N_DFT > 8192: transform arrays of the exact kernel in global memory
+    bool wide_fe = false; float2 *d_f32in = nullptr;           // decimator longer than 8 blocks (wide IF): int16 input goes through the float32 mixer / FIR kernels
     // device
     double *d_chanf0 = nullptr; float2 *d_dcavg = nullptr; long long *d_dcsums = nullptr; float2 *d_ptail[2] = {nullptr, nullptr}; int ptail_cur = 0;
     float2 *d_y = nullptr; float *d_fm = nullptr; float *d_wiq = nullptr; float2 *d_G = nullptr, *d_tw = nullptr, *d_WS = nullptr;
@@ -246,19 +251,21 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
     // ---- init_buffers() (dft_detect.c:995-1285)
     int sr = cfg->sample_rate, D = 1;
     if (cfg->iq_mode == SONDE_SCAN_BBIQ) {
-        if (set_lpIQ > 48000.f) { delete s; return SONDE_E_ARG; }          // wide IF (:1024-1041) needs N_DFT > 8192
-        s->dec = design_decimator(cfg->sample_rate, cfg->opt_min != 0);     // same arithmetic as demod_mod.c:1222-1259
+        s->dec = design_decimator_scan(cfg->sample_rate, cfg->opt_min != 0, set_lpIQ);     // dft_detect.c:1021-1067 (= demod_mod.c:1222-1259 up to 48 kHz)
         D = s->dec.decM; sr = s->dec.if_sr;
         if (D == 1) s->dec.taps.assign(1, 1.0f);
         const int T = (int)s->dec.taps.size();
         s->Q = (T + D - 1) / D;
-        if (s->Q > 8 || D > 1024) { delete s; return SONDE_E_ARG; }
-        const int pad = s->Q * D - T;
-        std::vector<float> wpad((size_t)s->Q * D, 0.f);
-        for (int k = 0; k < T; k++) wpad[pad + k] = s->dec.taps[k];
+        if (D > 1024) { delete s; return SONDE_E_ARG; }
+        if (s->Q > 8) { s->wide_fe = true; s->Q = 8; }         // (wide IF: 267 taps over D = 25) -> the plain float32 mixer / FIR kernels, any tap count
         s->wtab.assign((size_t)std::max(64, D) * 8, 0.f);
-        for (int r = 0; r < D; r++) for (int q = 0; q < s->Q; q++) s->wtab[(size_t)r * 8 + q] = wpad[(size_t)D * q + r];
-        if (D > 64) {                                         // wide decimation: taps in global memory, D walked in pieces of DS
+        if (!s->wide_fe) {
+            const int pad = s->Q * D - T;
+            std::vector<float> wpad((size_t)s->Q * D, 0.f);
+            for (int k = 0; k < T; k++) wpad[pad + k] = s->dec.taps[k];
+            for (int r = 0; r < D; r++) for (int q = 0; q < s->Q; q++) s->wtab[(size_t)r * 8 + q] = wpad[(size_t)D * q + r];
+        }
+        if (D > 64 && !s->wide_fe) {                                         // wide decimation: taps in global memory, D walked in pieces of DS
             for (int k = 64; k >= 4; k--) if (D % k == 0) { s->DS = k; break; }
             if (!s->DS || s->Q < 5) { delete s; return SONDE_E_ARG; }
             if (dupload(&s->d_wtab, s->wtab)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
@@ -301,15 +308,17 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
     }
     const int L2 = 2 * Lmax;
     int p2 = 1; while (p2 < 3 * L2) p2 <<= 1; while (p2 < 0x2000) p2 <<= 1;
-    if (p2 != SC_N) { delete s; return SONDE_E_ARG; }
-    s->K = SC_N - L2; s->delay = L2 / 16;
+    if (p2 != 8192 && p2 != 16384 && p2 != 32768) { delete s; return SONDE_E_ARG; }
+    s->N = p2; s->log2n = 13 + (p2 > 8192) + (p2 > 16384);
+    const int N = s->N;
+    s->K = N - L2; s->delay = L2 / 16;
 
-    const std::vector<float2> tws = ref_twiddles();
-    std::vector<float2> G((size_t)SC_NTPL * SC_N, make_float2(0.f, 0.f));
+    const std::vector<float2> tws = ref_twiddles(s->log2n);
+    std::vector<float2> G((size_t)SC_NTPL * N, make_float2(0.f, 0.f));
     std::vector<uint8_t> hdrbits; std::vector<int> bnd;
     std::vector<std::vector<float2>> WS(2);
     if (iq) for (int j = 0; j < 2; j++) {                     // WS[j] = dft(FM low-pass taps) (dft_detect.c:1269-1278)
-        WS[j].assign(SC_N, make_float2(0.f, 0.f));
+        WS[j].assign(N, make_float2(0.f, 0.f));
         for (int i = 0; i < s->lpfm_taps; i++) WS[j][i].x = w_lp[(size_t)j * s->lpfm_taps + i];
         dft_ref_host(WS[j], tws);
     }
@@ -318,7 +327,7 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
         ScanTpl &t = s->tpl[j];
         memset(&t, 0, sizeof t);
         t.L = Ls[j]; t.hLen = (int)strlen(kTpl[j].hdr); t.lpfm = kTpl[j].lpfm; t.stream = phys_stream(kTpl[j].lpiq);
-        t.active = !((s->disabled >> j) & 1u) && (s->K + t.L <= SC_N);
+        t.active = !((s->disabled >> j) & 1u) && (s->K + t.L <= N);
         t.is_m10 = strncmp(kTpl[j].type, "M10", 3) == 0;
         t.spb = spbs[j]; t.thres = s->thres[j]; t.herrs = kTpl[j].herrs;
         t.hdr_off = (int)hdrbits.size(); hdrbits.insert(hdrbits.end(), kTpl[j].hdr, kTpl[j].hdr + t.hLen);
@@ -328,13 +337,13 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
         // Fm = dft of the time-reversed template (m[L-1-i] = match[i], dft_detect.c:1260-1262); G = WS[lpFM] * Fm
         const std::vector<float> match = scan_match(kTpl[j].hdr, hLenMax, t.spb, kTpl[j].bt, t.L);
         s->a_off[j] = (int)a_match.size(); s->nc2[j] = toeplitz_frags(match, a_match);        // c'[p'] = sum_k match[k] xf[p' + k]
-        std::vector<float2> F(SC_N, make_float2(0.f, 0.f));
+        std::vector<float2> F(N, make_float2(0.f, 0.f));
         for (int i = 0; i < t.L; i++) F[t.L - 1 - i].x = match[i];
         dft_ref_host(F, tws);
-        for (int k = 0; k < SC_N; k++) {
+        for (int k = 0; k < N; k++) {
             float2 g = F[k];
             if (iq) { const float2 w = WS[t.lpfm][k]; g = make_float2(w.x * F[k].x - w.y * F[k].y, w.x * F[k].y + w.y * F[k].x); }
-            G[(size_t)j * SC_N + k] = g;
+            G[(size_t)j * N + k] = g;
         }
     }
 
@@ -351,14 +360,14 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
             for (int i = 0; i < taps; i++) { double acc = 0; for (int t = i + 1; t < taps; t++) acc += (double)w_lp[(size_t)lp * taps + t]; ws_tail.push_back((float)acc); }
         }
     }
-    s->use_pre = cfg->opt_exact == 0;
+    s->use_pre = cfg->opt_exact == 0 && N == SC_N;             // windows beyond 8192 samples: the exact kernel for every pair (rare: wide --bw / wide --iq input)
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
-    int ring = 1; while (ring < max_if + sr + 2 * SC_N + 4096) ring <<= 1;        // + one second: the IMET check re-reads it (imet_resolve)
+    int ring = 1; while (ring < max_if + sr + 2 * N + 4096) ring <<= 1;        // + one second: the IMET check re-reads it (imet_resolve)
     s->ring_len = ring;
     sonde_scan_info_t &I = s->info;
     I.if_sr = sr; I.decM = D; I.dectaps = (D == 1) ? 0 : (int)s->dec.taps.size(); I.lpiq_taps = s->lpiq_taps; I.lpfm_taps = s->lpfm_taps;
-    I.K = s->K; I.N = SC_N; I.delay = s->delay; I.L2 = L2; I.ring_len = ring;
+    I.K = s->K; I.N = N; I.delay = s->delay; I.L2 = L2; I.ring_len = ring;
 
     int bad = 0;
     bad |= dalloc(&s->d_dcavg, C); bad |= dalloc(&s->d_dcsums, 2 * (size_t)C);
@@ -398,7 +407,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_res) hipHostFree(s->h_res);
     if (s->h_pre) hipHostFree(s->h_pre);
     if (s->h_work) hipHostFree(s->h_work);
-    void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
+    void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_scratch, s->d_f32in, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
                      s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
@@ -513,7 +522,7 @@ static int read_fm_phys(sonde_scan *s, int channel, int phys, int64_t first, int
 // Returns 1 when the held window was completed, 0 if the second of samples is not there yet.
 static int imet_resolve(sonde_scan *s, int ch, bool eof) {
     Chan &c = s->chan[ch];
-    const int sr = s->info.if_sr, N = SC_N, Dn = N / 2 - 3, j0 = kIdxImetAfsk;
+    const int sr = s->info.if_sr, N = s->N, Dn = N / 2 - 3, j0 = kIdxImetAfsk;
     const uint32_t S = c.imet_sin;
     const uint32_t avail = s->m_out - S;
     if (!eof && avail < (uint32_t)sr) return 0;
@@ -521,7 +530,7 @@ static int imet_resolve(sonde_scan *s, int ch, bool eof) {
     const int nb = n_read / Dn;
     std::vector<float> blk((size_t)std::max(1, nb) * Dn), db(N, 0.f);
     if (nb > 0 && read_fm_phys(s, ch, s->tpl[j0].stream, (int64_t)S - s->delay, nb * Dn, blk.data()) < 0) return SONDE_E_NOGPU;
-    static const std::vector<float2> tws = ref_twiddles();
+    const std::vector<float2> tws = ref_twiddles(s->log2n);
     for (int b = 0; b < nb; b++) {
         std::vector<float2> X(N, make_float2(0.f, 0.f));
         for (int i = 0; i < Dn; i++) X[i].x = blk[(size_t)b * Dn + i];
@@ -587,7 +596,33 @@ static int run_windows(sonde_scan *s) {
         std::vector<uint32_t> exact((size_t)n_items + C, 0u);                 // per window: templates evaluated by the exact kernel
         int n_all = n_items;                                                  // + re-evaluated last windows of the previous call
         std::vector<int> aux_of(C, -1);
-        if (!s->use_pre) {
+        if (!s->use_pre && s->N > SC_N) {
+            // N_DFT 16384 / 32768: every pair through the global-memory form of the exact kernel, in batches that share the scratch arrays
+            hipEventRecord(e0, s->stream);
+            HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+            hipEventRecord(e1, s->stream);
+            int n_work = 0;
+            for (int i = 0; i < n_items; i++) for (int j = 0; j < SC_NTPL; j++) {
+                if (s->tpl[j].active) { s->h_work[n_work].item = i; s->h_work[n_work].tpl = j; n_work++; }
+                else s->h_res[(size_t)i * SC_NTPL + j] = ScanRes{ 0, 0.f, 0u, 0.f, -1, 0u };
+            }
+            const int batch = 256;
+            if (!s->d_scratch) { HIPCHK(hipMalloc((void **)&s->d_scratch, (size_t)batch * s->N * sizeof(float2))); s->scratch_pairs = batch; }
+            HIPCHK(hipMemcpyAsync(s->d_work, s->h_work, (size_t)n_work * sizeof(ScanWork), hipMemcpyHostToDevice, s->stream));
+            HIPCHK(hipMemsetAsync(s->d_res, 0, (size_t)n_items * SC_NTPL * sizeof(ScanRes), s->stream));
+            a.N = s->N; a.log2n = s->log2n; a.scratch = s->d_scratch;
+            for (int w0 = 0; w0 < n_work; w0 += batch) {
+                a.work = s->d_work + w0; a.n_work = std::min(batch, n_work - w0);
+                if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
+            }
+            std::vector<ScanRes> keep(s->h_res, s->h_res + (size_t)n_items * SC_NTPL);
+            HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
+            hipEventRecord(e2, s->stream);
+            HIPCHK(hipStreamSynchronize(s->stream));
+            for (int i = 0; i < n_items; i++) for (int j = 0; j < SC_NTPL; j++) if (!s->tpl[j].active) s->h_res[(size_t)i * SC_NTPL + j] = keep[(size_t)i * SC_NTPL + j];
+            timed(s, "scan_corr", e1, e2);
+            for (int i = 0; i < n_items; i++) exact[i] = 0xffffu;
+        } else if (!s->use_pre) {
             hipEventRecord(e0, s->stream);
             HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
             hipEventRecord(e1, s->stream);
@@ -692,6 +727,14 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         sonde_launch_u8_to_s16((const uint8_t *)d_in, ch_stride * epf, s->d_conv, (long long)n_samples * epf, nc, n_samples * epf, s->stream);
         d_in = s->d_conv; if (ch_stride != 0) ch_stride = n_samples;
     }
+    bool f32in = s->cfg.bits == 32;
+    if (s->wide_fe && !f32in) {                    // wide IF: the decimator has more than 8 blocks of taps -> float32 copy (x / 32768, exact) for the plain kernels
+        const int nc = ch_stride == 0 ? 1 : C;
+        if (!s->d_f32in) HIPCHK(hipMalloc((void **)&s->d_f32in, (size_t)C * s->cfg.max_chunk * sizeof(float2)));
+        sonde_launch_s16_to_f32((const int16_t *)d_in, ch_stride, s->d_f32in, n_samples, nc, n_samples, s->stream);
+        d_in = s->d_f32in; if (ch_stride != 0) ch_stride = n_samples;
+        f32in = true;
+    }
     hipEvent_t ev[4]; for (auto &e : ev) hipEventCreate(&e);
     const uint32_t m_first = s->m_out;
     hipEventRecord(ev[0], s->stream);
@@ -705,7 +748,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         int done = 0;
         while (done < n_samples) {
             const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), s->dc_max - s->dc_cnt);
-            if (s->cfg.bits == 32) {                         // float32 IQ: plain mixer / FIR kernels, IQ-DC sums in double
+            if (f32in) {                                     // float32 IQ (or the wide-IF copy): plain mixer / FIR kernels, IQ-DC sums in double
                 if (!s->d_dcsums_f) {
                     HIPCHK(hipMalloc((void **)&s->d_dcsums_f, 2 * (size_t)C * sizeof(double))); HIPCHK(hipMemset(s->d_dcsums_f, 0, 2 * (size_t)C * sizeof(double)));
                     if (mode == SONDE_SCAN_BBIQ) {

@@ -123,11 +123,34 @@ __device__ __forceinline__ float wsumf(float v) { for (int off = 32; off > 0; of
 __device__ __forceinline__ double wsumd(double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
 // one workgroup = one correlation window x one template (getCorrDFT, dft_detect.c:357-443)
+// BIG = false: N_DFT = 8192, the data array and the first stages' twiddles in LDS (sonde_fft_dev.h).  BIG = true: N_DFT = 16384 / 32768 (IF rates above
+// ~51 kHz, dft_detect.c:1196-1202): the same network stage by stage on a per-workgroup array in global memory — rare (wide --bw, wide --iq input),
+// exactness over speed.
+// dft_big: the reference's dft_raw on a bit-reversed array in global memory, one radix-2 stage per pass; twiddle of butterfly column j of stage s = tws[2^s - 1 + j]
+__device__ __forceinline__ void dft_big(float2 *x, const float2 *tws, int log2n, int tid) {
+    const int half = 1 << (log2n - 1);
+    for (int s = 0; s < log2n; s++) {
+        const int l2 = 1 << s;
+        for (int bfly = tid; bfly < half; bfly += SC_THREADS) {
+            const int j = bfly & (l2 - 1), i = ((bfly >> s) << (s + 1)) | j, k = i + l2;
+            const float2 t = cmul(x[k], tws[(l2 - 1) + j]), u = x[i];
+            x[k] = make_float2(u.x - t.x, u.y - t.y);
+            x[i] = make_float2(u.x + t.x, u.y + t.y);
+        }
+        __syncthreads();
+    }
+}
+
+template <bool BIG>
 __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two workgroups per CU: 78 KB of LDS, 64 VGPRs
-void k_scan_corr(const ScanCorrArgs a) {
+void k_scan_corr_t(const ScanCorrArgs a) {
     extern __shared__ float2 smem2[];
-    float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
-    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_TW_LDS + 1] twiddles of stages 0..8
+    float2 *x = BIG ? a.scratch + (size_t)blockIdx.x * a.N : smem2;      // [SC_N + SC_N/8] padded in LDS, or the [N] global array of this workgroup
+    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_TW_LDS + 1] twiddles of stages 0..8 (LDS form only)
+    const int log2n = BIG ? a.log2n : SC_LOG2N;
+    auto XP = [&](int i) -> int { return BIG ? i : XI(i); };
+    auto BR = [&](int k) -> int { return (int)(__brev((unsigned)k) >> (32 - log2n)); };
+    auto DFT = [&](int tid_) { if (BIG) dft_big(x, a.tws, log2n, tid_); else dft_ref(x, tws, a.tws, tid_); };
     __shared__ float s_rf[SC_THREADS / WAVE];
     __shared__ int s_ri[SC_THREADS / WAVE];
     __shared__ double s_rd[SC_THREADS / WAVE];
@@ -135,7 +158,7 @@ void k_scan_corr(const ScanCorrArgs a) {
     int item = blockIdx.x, j = blockIdx.y;
     if (a.work) { const ScanWork w = a.work[blockIdx.x]; item = w.item; j = w.tpl; }      // listed pairs only (behind the prefilter)
     const ScanItem it = a.items[item];
-    const int K = a.K, N = SC_N;
+    const int K = a.K, N = BIG ? a.N : SC_N;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const ScanTpl tp = a.tpl[j];
     ScanRes *out = a.out + (size_t)item * SC_NTPL + j;
@@ -146,7 +169,7 @@ void k_scan_corr(const ScanCorrArgs a) {
     const float *str = a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len;
     const int L = tp.L, wl = K + L;
     const int64_t start = (int64_t)it.pos - (wl - 1);
-    for (int k = tid; k < SC_TW_LDS; k += SC_THREADS) tws[k] = a.tws[k];
+    if (!BIG) for (int k = tid; k < SC_TW_LDS; k += SC_THREADS) tws[k] = a.tws[k];
     float dc = 0.f;
     // xn[i] = stream[pos - (K+L-1) + i], i < K+L, zero padded (dft_detect.c:378-379); stored bit-reversed for the DIT network
     auto load_window = [&](bool want_dc) {
@@ -155,7 +178,7 @@ void k_scan_corr(const ScanCorrArgs a) {
             const int64_t p = start + i;
             const float v = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
             if (i >= K - L && i < wl) dcp += v;                        // last 2L samples (dft_detect.c:389)
-            x[XI(brev13(i))] = make_float2(v, 0.f);
+            x[XP(BR(i))] = make_float2(v, 0.f);
         }
         if (want_dc) {
             const float sw = wsumf(dcp); if (lane == 0) s_rf[wave] = sw;
@@ -171,13 +194,13 @@ void k_scan_corr(const ScanCorrArgs a) {
     auto spectrum_step = [&](const float2 *H) {
         const float dcsub = a.opt_dc ? (float)((double)((float)N * dc) * 0.98) : 0.f;
         for (int i = tid; i < N; i += SC_THREADS) {
-            const int r = brev13(i);
+            const int r = BR(i);
             if (r < i) continue;
-            float2 xi = x[XI(i)], xr = x[XI(r)];
+            float2 xi = x[XP(i)], xr = x[XP(r)];
             if (i == 0) { xi.x -= dcsub; xr.x -= dcsub; }             // i = r = 0
             const float2 zi = H ? cmul(xi, H[i]) : xi, zr = H ? cmul(xr, H[r]) : xr;
-            x[XI(r)] = make_float2(zi.x, -zi.y);
-            x[XI(i)] = make_float2(zr.x, -zr.y);
+            x[XP(r)] = make_float2(zi.x, -zi.y);
+            x[XP(i)] = make_float2(zr.x, -zr.y);
         }
         __syncthreads();
     };
@@ -186,14 +209,14 @@ void k_scan_corr(const ScanCorrArgs a) {
     // second copy of the window in LDS, which is what lets two workgroups share a CU.
     const bool filt = a.opt_dc || a.opt_iq;
     load_window(a.opt_dc != 0);
-    dft_ref(x, tws, a.tws, tid);                                         // X = dft(xn)
+    DFT(tid);                                         // X = dft(xn)
     spectrum_step(a.G + (size_t)j * N);                                  // G = WS * Fm (Fm alone for FM-audio input)
-    dft_ref(x, tws, a.tws, tid);                                         // cx = Nidft(Z), real part used
+    DFT(tid);                                         // cx = Nidft(Z), real part used
 
     // arg-max of cx^2 over i in [L-1, K+L), first maximum wins (dft_detect.c:415-423)
     float best = 0.f; int bidx = -1;
     for (int i = tid; i < N; i += SC_THREADS) {
-        if (i >= L - 1 && i < wl) { const float c = x[XI(i)].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
+        if (i >= L - 1 && i < wl) { const float c = x[XP(i)].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
     }
     for (int off = 32; off > 0; off >>= 1) {
         const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
@@ -209,16 +232,16 @@ void k_scan_corr(const ScanCorrArgs a) {
             if (ob > b || (ob == b && oi >= 0 && (mp < 0 || oi < mp))) { b = ob; mp = oi; }
         }
     }
-    const float mx = (mp >= 0) ? x[XI(mp)].x : 0.f;
+    const float mx = (mp >= 0) ? x[XP(mp)].x : 0.f;
     __syncthreads();                                                     // everybody has mx before x is reused
     // norm over the L (filtered) window samples under the peak (dft_detect.c:431-433)
     double e2 = 0.0;
     if (filt) {
         load_window(false);
-        dft_ref(x, tws, a.tws, tid);
+        DFT(tid);
         spectrum_step(a.opt_iq ? a.WS + (size_t)tp.lpfm * N : nullptr);
-        dft_ref(x, tws, a.tws, tid);                                     // x[i].x / N = filtered xn[i]
-        if (mp >= 0) for (int k = tid; k < L; k += SC_THREADS) { const float v = x[XI(mp - k)].x / (float)N; e2 += (double)(v * v); }
+        DFT(tid);                                     // x[i].x / N = filtered xn[i]
+        if (mp >= 0) for (int k = tid; k < L; k += SC_THREADS) { const float v = x[XP(mp - k)].x / (float)N; e2 += (double)(v * v); }
     } else if (mp >= 0) {
         for (int k = tid; k < L; k += SC_THREADS) {                      // raw window, read again from the stream
             const int i = mp - k; const int64_t p = start + i;
@@ -292,14 +315,33 @@ extern "C" void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s) {
 extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = (size_t)(SC_N + SC_N / 8 + SC_TW_LDS + 1) * sizeof(float2);
+    if (a->N > SC_N) {                                     // the global-memory form: the caller lists the pairs and owns the scratch arrays
+        if (!a->work || !a->scratch || (1 << a->log2n) != a->N) return -1;
+        if (a->n_work > 0) hipLaunchKernelGGL(k_scan_corr_t<true>, dim3(a->n_work, 1), dim3(SC_THREADS), 0, s, *a);
+        return 0;
+    }
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_corr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_corr_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set = true;
     }
-    if (a->work) { if (a->n_work > 0) hipLaunchKernelGGL(k_scan_corr, dim3(a->n_work, 1), dim3(SC_THREADS), lds, s, *a); return 0; }
+    if (a->work) { if (a->n_work > 0) hipLaunchKernelGGL(k_scan_corr_t<false>, dim3(a->n_work, 1), dim3(SC_THREADS), lds, s, *a); return 0; }      // listed pairs only (behind the prefilter)
     if (a->n_items <= 0) return 0;
-    hipLaunchKernelGGL(k_scan_corr, dim3(a->n_items, SC_NTPL), dim3(SC_THREADS), lds, s, *a);
+    hipLaunchKernelGGL(k_scan_corr_t<false>, dim3(a->n_items, SC_NTPL), dim3(SC_THREADS), lds, s, *a);
     return 0;
+}
+// cs16 -> cf32 (x / 32768, exact) for front ends that only exist in float32 form (decimators longer than 8 blocks: wide IF)
+__global__ __launch_bounds__(256)
+void k_s16_to_f32(const int16_t *in, long long in_stride, float2 *out, long long out_stride, int n) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(in) + (size_t)blockIdx.y * in_stride;
+    float2 *q = out + (size_t)blockIdx.y * out_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t w = p[i];
+        q[i] = make_float2((float)(int16_t)(w & 0xffffu) / 32768.0f, (float)(int16_t)(w >> 16) / 32768.0f);
+    }
+}
+extern "C" void sonde_launch_s16_to_f32(const int16_t *in, long long in_stride, float2 *out, long long out_stride, int n_ch, int n, hipStream_t s) {
+    int gx = (n + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_s16_to_f32, dim3(gx, n_ch), dim3(256), 0, s, in, in_stride, out, out_stride, n);
 }
 extern "C" void sonde_launch_iq_convert(const IqConvArgs *a, hipStream_t s) {
     int gx = (a->n + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;

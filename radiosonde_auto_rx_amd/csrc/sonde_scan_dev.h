@@ -42,6 +42,8 @@ struct ScanCorrArgs {
     const int *bnd;           // bit boundaries in samples (float accumulation of the reference tabulated on the host)
     ScanRes *out;             // [n_items][SC_NTPL]
     const struct ScanWork *work; int n_work;      // work list: one workgroup per listed (window, template) pair (nullptr: the full n_items x SC_NTPL grid)
+    int N, log2n;             // N_DFT: 0 / SC_N, or 16384 / 32768 with the work-list form and `scratch`
+    float2 *scratch;          // N_DFT > SC_N: [n_work][N] transform arrays in global memory
 };
 struct ScanWork { int item, tpl; };
 
@@ -89,6 +91,7 @@ void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s);
 int  sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s);
 int  sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s);
 void sonde_launch_iq_convert(const IqConvArgs *a, hipStream_t s);
+void sonde_launch_s16_to_f32(const int16_t *in, long long in_stride, float2 *out, long long out_stride, int n_ch, int n, hipStream_t s);
 void sonde_launch_audio_convert(const AudioConvArgs *a, hipStream_t s);
 }
 #endif

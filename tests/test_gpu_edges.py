@@ -84,8 +84,11 @@ def test_engine_rejects_bad_requests():
     with pytest.raises(SondeError):
         FskModem(48000, 4799)                                           # Fs % Rs != 0 (the reference asserts)
     from radiosonde_auto_rx_amd.scan import Scanner
+    sc = Scanner(2_400_000, fq=[0.1], bw_khz=96.0)                      # wide IF: N_DFT = 16384 (the global-memory form of the exact kernel)
+    assert sc.info["N"] == 16384 and sc.info["if_sr"] == 96000 and sc.info["decM"] == 25
+    sc.close()
     with pytest.raises(SondeError):
-        Scanner(2_400_000, fq=[0.1], bw_khz=96.0)                       # wide IF needs N_DFT > 8192: refused
+        Scanner(1_000_000, n_channels=1, iq_mode=1)                     # an IF rate that would need N_DFT = 65536
 
 
 def test_two_stream_pipeline_matches_single_stream():

@@ -363,6 +363,12 @@ SCAN_CASES = {
     "scan_imet_rejected_48k": dict(gen="imet", cap=dict(sr=48_000, seconds=3.0, noise_sigma=0.02, seed=3, space_hz=2400.0), mode=1, dc=True, bw=0.0, cli=["-v", "-c"]),
     "scan_imet4_48k_eof": dict(gen="imet", cap=dict(sr=48_000, seconds=0.95, noise_sigma=0.02, seed=4, t_first=0.1), mode=1, dc=True, bw=15.0, cli=["-v", "-c"]),
     "scan_rs41_audio": dict(gen="rs41_audio", cap=dict(sr=48_000, seconds=3.0, fq=0.0, n_frames=2, t_first=0.4, noise_sigma=0.02, seed=7), mode=0, dc=False, bw=0.0, cli=["-v", "-c"]),
+    # IF rates above ~51 kHz: N_DFT = 16384 / 32768 (dft_detect.c:1196-1202); big = no FM-stream tap for the 8192-point numpy restatement
+    "scan_rs41_96k_iq_dc": dict(gen="rs41", cap=dict(sr=96_000, seconds=2.6, fq=0.0, n_frames=2, t_first=0.5, noise_sigma=0.02, seed=11, f_offset_hz=700.0),
+                                mode=1, dc=True, bw=0.0, cli=["-v", "-c"], big=True),
+    "scan_m10_2400k_bw96_dc": dict(gen="m10", cap=dict(sr=2_400_000, seconds=1.7, fq=-0.12, type_bytes=(0x64, 0x9F), noise_sigma=0.02, seed=12, f_offset_hz=-350.0),
+                                   mode=5, dc=True, bw=96.0, cli=["-v", "-c"], big=True),
+    "scan_dfm_192k_iq": dict(gen="dfm", cap=dict(sr=192_000, seconds=2.2, fq=0.0, noise_sigma=0.02, seed=13), mode=1, dc=False, bw=0.0, cli=["-v", "-c"], big=True),
 }
 
 
@@ -893,7 +899,7 @@ def main():
             d[k] = r[k]
         # FM-stream segment under the first window with an accepted header: input of the numpy restatement (oracle/ora_scan.py)
         hits = np.argwhere(r["herrs"] >= 0)
-        if len(hits) and case["mode"] != 0:
+        if len(hits) and case["mode"] != 0 and not case.get("big"):
             w, j = (int(v) for v in hits[0])
             stream = [1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 0, 2, 3, 3, 3, 1][j]                  # rs_hdr[j].lpIQ
             first = max(0, int(r["pos"][w]) - 7300); last = int(r["pos"][w]) + 200
