@@ -20,6 +20,7 @@ struct sonde_fsk {
     FskArgs args{};
     hipStream_t stream = nullptr;
     void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr, *d_eye = nullptr;
+    unsigned long long *d_prof = nullptr;          // SONDE_FSK_PROF
     uint16_t *d_perm = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
     FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; std::vector<uint8_t> h_hb;
@@ -158,6 +159,17 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
+    if (f->d_prof) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, f->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *nm[9] = { "input", "fft", "Sf+estimators", "oscillator", "downconv+tail", "integrate", "timing", "soft", "ebno+record" };
+            unsigned long long tot = 0; for (int k = 0; k < 9; k++) tot += h[k];
+            fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, %% of %llu cycles):", f->cfg.Rs, f->cfg.nsym, tot);
+            for (int k = 0; k < 9; k++) fprintf(stderr, " %s %.1f", nm[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
+            fprintf(stderr, "\n");
+        }
+        hipFree(f->d_prof);
+    }
     void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_wr };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
@@ -174,6 +186,9 @@ static int launch_and_collect(sonde_fsk_t *f) {
     FskArgs &a = f->args;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, f->stream);
+    static const bool want_prof = getenv("SONDE_FSK_PROF") != nullptr;            // profiling aid: cycles per phase of channel 0, printed when the modem is destroyed
+    if (want_prof && !f->d_prof) { if (hipMalloc((void **)&f->d_prof, 16 * sizeof(unsigned long long)) == hipSuccess) hipMemset(f->d_prof, 0, 16 * sizeof(unsigned long long)); }
+    a.prof = f->d_prof;
     const int lrc = sonde_launch_fsk(&a, f->stream);
     hipEventRecord(e1, f->stream);
     if (lrc < 0) { hipEventDestroy(e0); hipEventDestroy(e1); return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU; }

