@@ -101,11 +101,15 @@ void k_fsk_demod(const FskArgs a) {
 
         // ---- frequency estimator (fsk_demod_freq_est): numffts half-overlapped windowed FFTs, one wave each
         const int numffts = nin / (Ndft / 2) - 1;
-        for (int j0 = 0; j0 < numffts; j0 += FSK_THREADS / WAVE) {
-            const int j = j0 + wave;
+        // threads per transform: one wave each while there are four blocks to do at a time, more when a frame has fewer (a 150-symbol M10 frame
+        // has ONE block: all 256 threads work on it) — the stages are separated by workgroup barriers either way, so any split is the same arithmetic
+        const int TPF = numffts >= 4 ? WAVE : numffts >= 2 ? 2 * WAVE : FSK_THREADS, par = FSK_THREADS / TPF;
+        const int sub = tid / TPF, lt = tid - sub * TPF;
+        for (int j0 = 0; j0 < numffts; j0 += par) {
+            const int j = j0 + sub;
             const bool act = j < numffts;
-            float2 *buf = s_fdc + wave * Ndft;
-            if (act) for (int i = lane; i < Ndft; i += WAVE) {
+            float2 *buf = s_fdc + sub * Ndft;
+            if (act) for (int i = lt; i < Ndft; i += TPF) {
                 const float h = a.hann[i]; const float2 x = s_in[i + j * (Ndft / 2)];
                 buf[a.perm[i]] = make_float2(h * x.x, h * x.y);
             }
@@ -114,9 +118,9 @@ void k_fsk_demod(const FskArgs a) {
             // stage when log2 Ndft is odd, innermost factor first, separately rounded mul / add) so that Sf and with it every estimator
             // decision is the reference's bit for bit
             for (int s = 0; s < a.n_stage; s++) {
-                const int p = a.st_p[s], m = a.st_m[s], fs = a.st_fs[s];
-                if (act) for (int b = lane; b < Ndft / p; b += WAVE) {
-                    const int blk = b / m, u = b - blk * m;
+                const int p = a.st_p[s], m = a.st_m[s], fs = a.st_fs[s], lm = __builtin_ctz((unsigned)m);      // m is a power of two (Ndft is)
+                if (act) for (int b = lt; b < Ndft / p; b += TPF) {
+                    const int blk = b >> lm, u = b & (m - 1);
                     float2 *F = buf + blk * p * m + u;
                     if (p == 4) {
                         const float2 s0 = cmult(F[m], a.tw[u * fs]), s1 = cmult(F[2 * m], a.tw[2 * u * fs]), s2 = cmult(F[3 * m], a.tw[3 * u * fs]);
@@ -137,7 +141,7 @@ void k_fsk_demod(const FskArgs a) {
                 __syncthreads();
             }
             // fftshift (DC at Ndft/2) and magnitude
-            if (act) for (int k = lane; k < Ndft; k += WAVE) {
+            if (act) for (int k = lt; k < Ndft; k += TPF) {
                 const float2 X = buf[k];
                 s_mag[j * Ndft + ((k + Ndft / 2) & (Ndft - 1))] = sqrtf((X.x * X.x) + (X.y * X.y));
             }
@@ -188,34 +192,38 @@ void k_fsk_demod(const FskArgs a) {
             float2 phi = st.phi_c[0], d = dphi[0];
             for (int m = 1; m < M; m++) if (lane == m) { phi = st.phi_c[m]; d = dphi[m]; }
             float2 *o = s_fdc + lane * Nmem + nold;
+            // one dependent complex multiply per sample (the chain cannot be shortened: every product is rounded); unrolled so that the loop's
+            // scalar bookkeeping and the LDS stores stay out of its way
+#pragma unroll 8
             for (int j = 0; j < nin; j++) { phi = cmult(phi, d); o[j] = phi; }
             const float av = sqrtf((phi.x * phi.x) + (phi.y * phi.y));
             s_phi[lane] = make_float2(phi.x / av, phi.y / av);
         } else if (tid >= WAVE) {
-            for (int k = tid - WAVE; k < M * nold; k += FSK_THREADS - WAVE) {
-                const int m = k / nold, i = k - m * nold;
-                s_fdc[m * Nmem + i] = tail_g[m * NT + (NT - nold) + i];
-            }
+            for (int m = 0; m < M; m++)
+                for (int i = tid - WAVE; i < nold; i += FSK_THREADS - WAVE) s_fdc[m * Nmem + i] = tail_g[m * NT + (NT - nold) + i];
         }
         __syncthreads();
         FSK_MARK(3);
         for (int m = 0; m < M; m++) st.phi_c[m] = s_phi[m];
-        for (int k = tid; k < M * nin; k += FSK_THREADS) {
-            const int m = k / nin, j = k - m * nin;
-            const float2 p = s_fdc[m * Nmem + nold + j], x = s_in[j];
-            s_fdc[m * Nmem + nold + j] = cmult(x, make_float2(p.x, -p.y));
+        for (int j = tid; j < nin; j += FSK_THREADS) {
+            const float2 x = s_in[j];
+#pragma unroll
+            for (int m = 0; m < M; m++) { const float2 p = s_fdc[m * Nmem + nold + j]; s_fdc[m * Nmem + nold + j] = cmult(x, make_float2(p.x, -p.y)); }
         }
         __syncthreads();
-        for (int k = tid; k < M * NT; k += FSK_THREADS) { const int m = k / NT, i = k - m * NT; tail_g[m * NT + i] = s_fdc[m * Nmem + (Nmem - NT) + i]; }
+        for (int m = 0; m < M; m++) for (int i = tid; i < NT; i += FSK_THREADS) tail_g[m * NT + i] = s_fdc[m * Nmem + (Nmem - NT) + i];
 
         FSK_MARK(4);
         // ---- integrate over a symbol period at (nsym+1) P offsets (fsk.c:659-668)
-        for (int k = tid; k < M * W; k += FSK_THREADS) {
-            const int m = k / W, i = k - m * W;
-            const float2 *f = s_fdc + m * Nmem + i * Ts / P;
-            float2 acc = make_float2(0.f, 0.f);
-            for (int j = 0; j < Ts; j++) acc = cadd(acc, f[j]);
-            s_fint[k] = acc;
+        {
+            const int step = Ts / P;                           // P divides Ts (fsk.c:129), so i * Ts / P = i * step
+            for (int m = 0; m < M; m++)
+                for (int i = tid; i < W; i += FSK_THREADS) {
+                    const float2 *f = s_fdc + m * Nmem + i * step;
+                    float2 acc = make_float2(0.f, 0.f);
+                    for (int j = 0; j < Ts; j++) acc = cadd(acc, f[j]);
+                    s_fint[m * W + i] = acc;
+                }
         }
         __syncthreads();
         FSK_MARK(5);
@@ -229,7 +237,8 @@ void k_fsk_demod(const FskArgs a) {
         __syncthreads();
         if (wave == 0 && lane < 2) {
             const float *pp = reinterpret_cast<const float *>(s_ft) + lane;
-            float t = 0;
+            float t = 0;                                // serial sum in the reference's order; unrolled: the LDS reads of a batch are issued together
+#pragma unroll 16
             for (int i = 0; i < W; i++) t = t + pp[2 * i];
             s_tc[lane] = t;
         }
@@ -295,8 +304,13 @@ void k_fsk_demod(const FskArgs a) {
         // EbNo estimate (fsk.c:807-836): serial sums in symbol order
         if (wave == 0 && lane < 2) {
             float acc = 0;
-            if (lane == 0) for (int i = 0; i < nsym; i++) acc += s_ebv[i];
-            else           for (int i = 0; i < nsym; i++) acc += sqrtf(s_ebv[i]);
+            if (lane == 0) {
+#pragma unroll 16
+                for (int i = 0; i < nsym; i++) acc += s_ebv[i];
+            } else {
+#pragma unroll 16
+                for (int i = 0; i < nsym; i++) acc += sqrtf(s_ebv[i]);
+            }
             s_eb[lane] = acc;
         }
         __syncthreads();
