@@ -42,6 +42,11 @@ __device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_r
     return bi == INT_MAX ? dflt : bi;
 }
 
+// one step of the local oscillator phi *= d on (%0, %1) with temporaries %2..%5, d = (%6, %7); the result goes to LDS at %8 + 8 k
+#define FSK_OSC1(k) "v_mul_f32 %2, %0, %6\n\tv_mul_f32 %3, %1, %7\n\tv_mul_f32 %4, %0, %7\n\tv_mul_f32 %5, %1, %6\n\t" \
+                    "v_sub_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5\n\tds_write2_b32 %8, %0, %1 offset0:" #k "*2 offset1:" #k "*2+1\n\t"
+#define FSK_OSC8 FSK_OSC1(0) FSK_OSC1(1) FSK_OSC1(2) FSK_OSC1(3) FSK_OSC1(4) FSK_OSC1(5) FSK_OSC1(6) FSK_OSC1(7)
+
 // profiling aid: thread 0 of channel 0 adds the shader-clock cycles since the previous mark to phase k
 #define FSK_MARK(k) do { if (a.prof && ch == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
@@ -192,10 +197,20 @@ void k_fsk_demod(const FskArgs a) {
             float2 phi = st.phi_c[0], d = dphi[0];
             for (int m = 1; m < M; m++) if (lane == m) { phi = st.phi_c[m]; d = dphi[m]; }
             float2 *o = s_fdc + lane * Nmem + nold;
-            // one dependent complex multiply per sample (the chain cannot be shortened: every product is rounded); unrolled so that the loop's
-            // scalar bookkeeping and the LDS stores stay out of its way
-#pragma unroll 8
-            for (int j = 0; j < nin; j++) { phi = cmult(phi, d); o[j] = phi; }
+            // one dependent complex multiply per sample — the chain cannot be shortened: every product and sum is rounded like the reference's
+            // (cmult: x = a.x b.x - a.y b.y, y = a.x b.y + a.y b.x, no contraction).  Eight steps per statement as plain v_mul / v_sub / v_add: the
+            // compiler's own version packs the four products into v_pk_mul_f32 + register moves, which triples the latency of every link
+            float pr = phi.x, pi = phi.y;
+            const float dr = d.x, di = d.y;
+            uint32_t oaddr = (uint32_t)reinterpret_cast<uintptr_t>(o);
+            int j = 0;
+            for (; j + 8 <= nin; j += 8) {
+                float t0, t1, t2, t3;
+                asm volatile(FSK_OSC8 : "+v"(pr), "+v"(pi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(dr), "v"(di), "v"(oaddr) : "memory");
+                oaddr += 64;
+            }
+            phi = make_float2(pr, pi);
+            for (; j < nin; j++) { phi = cmult(phi, d); o[j] = phi; }
             const float av = sqrtf((phi.x * phi.x) + (phi.y * phi.y));
             s_phi[lane] = make_float2(phi.x / av, phi.y / av);
         } else if (tid >= WAVE) {
@@ -237,9 +252,16 @@ void k_fsk_demod(const FskArgs a) {
         __syncthreads();
         if (wave == 0 && lane < 2) {
             const float *pp = reinterpret_cast<const float *>(s_ft) + lane;
-            float t = 0;                                // serial sum in the reference's order; unrolled: the LDS reads of a batch are issued together
-#pragma unroll 16
-            for (int i = 0; i < W; i++) t = t + pp[2 * i];
+            float t = 0;                                // serial sum in the reference's order; a batch of LDS reads first, then the dependent adds
+            int i = 0;
+            for (; i + 16 <= W; i += 16) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = pp[2 * (i + k)];
+#pragma unroll
+                for (int k = 0; k < 16; k++) t = t + v[k];
+            }
+            for (; i < W; i++) t = t + pp[2 * i];
             s_tc[lane] = t;
         }
         __syncthreads();
@@ -304,13 +326,15 @@ void k_fsk_demod(const FskArgs a) {
         // EbNo estimate (fsk.c:807-836): serial sums in symbol order
         if (wave == 0 && lane < 2) {
             float acc = 0;
-            if (lane == 0) {
-#pragma unroll 16
-                for (int i = 0; i < nsym; i++) acc += s_ebv[i];
-            } else {
-#pragma unroll 16
-                for (int i = 0; i < nsym; i++) acc += sqrtf(s_ebv[i]);
+            int i = 0;                                   // lane 0: sum of the squares' maxima, lane 1: of their roots — same order as the reference, reads batched
+            for (; i + 16 <= nsym; i += 16) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const float x = s_ebv[i + k]; v[k] = lane ? sqrtf(x) : x; }
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc += v[k];
             }
+            for (; i < nsym; i++) { const float x = s_ebv[i]; acc += lane ? sqrtf(x) : x; }
             s_eb[lane] = acc;
         }
         __syncthreads();
