@@ -42,9 +42,11 @@ __device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_r
     return bi == INT_MAX ? dflt : bi;
 }
 
-// one step of the local oscillator phi *= d on (%0, %1) with temporaries %2..%5, d = (%6, %7); the result goes to LDS at %8 + 8 k
-#define FSK_OSC1(k) "v_mul_f32 %2, %0, %6\n\tv_mul_f32 %3, %1, %7\n\tv_mul_f32 %4, %0, %7\n\tv_mul_f32 %5, %1, %6\n\t" \
-                    "v_sub_f32 %0, %2, %3\n\tv_add_f32 %1, %4, %5\n\tds_write2_b32 %8, %0, %1 offset0:" #k "*2 offset1:" #k "*2+1\n\t"
+// one step of the local oscillator phi *= d on the register pair %0 with temporaries %1, %2 and d = %3; the result goes to LDS at %4 + 8 k.
+// A lone wave issues an instruction every ~8 cycles whatever it depends on, so the step is three packed instructions instead of six plain ones:
+//   A = phi.x (d.x, d.y),  B = phi.y (d.y, d.x),  phi = (A.x - B.x, A.y + B.y)     — the four products and two sums of cmult(), each rounded once
+#define FSK_OSC1(k) "v_pk_mul_f32 %1, %0, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\tv_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t" \
+                    "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]\n\tds_write_b64 %4, %0 offset:" #k "*8\n\t"
 #define FSK_OSC8 FSK_OSC1(0) FSK_OSC1(1) FSK_OSC1(2) FSK_OSC1(3) FSK_OSC1(4) FSK_OSC1(5) FSK_OSC1(6) FSK_OSC1(7)
 
 // profiling aid: thread 0 of channel 0 adds the shader-clock cycles since the previous mark to phase k
@@ -198,17 +200,18 @@ void k_fsk_demod(const FskArgs a) {
             for (int m = 1; m < M; m++) if (lane == m) { phi = st.phi_c[m]; d = dphi[m]; }
             float2 *o = s_fdc + lane * Nmem + nold;
             // one dependent complex multiply per sample — the chain cannot be shortened: every product and sum is rounded like the reference's
-            // (cmult: x = a.x b.x - a.y b.y, y = a.x b.y + a.y b.x, no contraction).  Eight steps per statement as plain v_mul / v_sub / v_add: the
-            // compiler's own version packs the four products into v_pk_mul_f32 + register moves, which triples the latency of every link
-            float pr = phi.x, pi = phi.y;
-            const float dr = d.x, di = d.y;
+            // (cmult: x = a.x b.x - a.y b.y, y = a.x b.y + a.y b.x, no contraction); eight steps per statement (FSK_OSC1)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f ph = {phi.x, phi.y};
+            const v2f dd = {d.x, d.y};
             uint32_t oaddr = (uint32_t)reinterpret_cast<uintptr_t>(o);
             int j = 0;
             for (; j + 8 <= nin; j += 8) {
-                float t0, t1, t2, t3;
-                asm volatile(FSK_OSC8 : "+v"(pr), "+v"(pi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(dr), "v"(di), "v"(oaddr) : "memory");
+                v2f ta, tb;
+                asm volatile(FSK_OSC8 : "+v"(ph), "=&v"(ta), "=&v"(tb) : "v"(dd), "v"(oaddr) : "memory");
                 oaddr += 64;
             }
+            const float pr = ph.x, pi = ph.y;
             phi = make_float2(pr, pi);
             for (; j < nin; j++) { phi = cmult(phi, d); o[j] = phi; }
             const float av = sqrtf((phi.x * phi.x) + (phi.y * phi.y));
