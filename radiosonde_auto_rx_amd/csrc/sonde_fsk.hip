@@ -66,7 +66,7 @@ void k_fsk_demod(const FskArgs a) {
     //   A  [nA]  the input frame s_in until the down-conversion has consumed it, then the integrators f_int[M][W] and the Eb/N0 terms
     //   B  [nB]  during the estimator: FFT scratch [4 Ndft] + block magnitudes mag[max_fft][Ndft]; then f_dc[M][Nmem]; then ft1 * phi_ft [W]
     //   Sf, Sc   smoothed spectrum and its search copy [Ndft] each
-    const int nA = max(n_in, M * W + (nsym + 1) / 2);
+    const int nA = max(n_in, M * W + (nsym + 1));           // f_int[M][W] + the two Eb/N0 term arrays (nsym floats each)
     const int nB = max(max(M * Nmem, 4 * Ndft + (a.max_fft * Ndft + 1) / 2), W);
     float2 *s_in  = reinterpret_cast<float2 *>(lds);
     float2 *s_fint = s_in;
@@ -298,7 +298,7 @@ void k_fsk_demod(const FskArgs a) {
             }
             float mx = tmax[0]; int sym = 0;                                // first maximum wins (fsk.c:760-768)
             for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
-            s_ebv[i] = mx;
+            s_ebv[i] = mx; s_ebv[nsym + i] = sqrtf(mx);          // both Eb/N0 terms of the symbol (the roots are taken here, in parallel; the sums stay serial)
             if (M == 2) { sd[i] = sqrtf(tmax[0]) - sqrtf(tmax[1]); hb[i] = (uint8_t)(sym == 1); }
             else {
                 hb[2 * i + 1] = (uint8_t)(sym & 1); hb[2 * i] = (uint8_t)((sym & 2) >> 1);                                                          // 4-FSK: two soft bits per symbol, summed in the reference's order (fsk.c:793-802)
@@ -329,15 +329,15 @@ void k_fsk_demod(const FskArgs a) {
         // EbNo estimate (fsk.c:807-836): serial sums in symbol order
         if (wave == 0 && lane < 2) {
             float acc = 0;
-            int i = 0;                                   // lane 0: sum of the squares' maxima, lane 1: of their roots — same order as the reference, reads batched
+            int i = 0;                                   // lane 0: sum of the largest |t|^2 per symbol, lane 1: of their roots — the reference's order, reads batched
             for (; i + 16 <= nsym; i += 16) {
                 float v[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) { const float x = s_ebv[i + k]; v[k] = lane ? sqrtf(x) : x; }
+                for (int k = 0; k < 16; k++) v[k] = s_ebv[lane * nsym + i + k];
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc += v[k];
             }
-            for (; i < nsym; i++) { const float x = s_ebv[i]; acc += lane ? sqrtf(x) : x; }
+            for (; i < nsym; i++) acc += s_ebv[lane * nsym + i];
             s_eb[lane] = acc;
         }
         __syncthreads();
@@ -365,7 +365,7 @@ void k_fsk_demod(const FskArgs a) {
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     const int W = (a->nsym + 1) * a->P, M = a->M;
     const int n_in = (a->N + a->Ts / 2) > W ? (a->N + a->Ts / 2) : W;
-    const int nA = n_in > M * W + (a->nsym + 1) / 2 ? n_in : M * W + (a->nsym + 1) / 2;
+    const int nA = n_in > M * W + (a->nsym + 1) ? n_in : M * W + (a->nsym + 1);
     int nB = M * a->Nmem;
     if (4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2 > nB) nB = 4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2;
     if (W > nB) nB = W;

@@ -5,27 +5,28 @@
 #   scan_wide, fsk_mixed   bench line + kernel trace each
 # everything lands in gpurun_out/prof/ as <tag>_*; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 400 python bench.py 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/t" -o t -- python "$ROOT/bench.py" --steps 200 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/f" -o f -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/w" -o w -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/t" -o t -- python "$ROOT/bench.py" --steps 200 --no-cpu-baseline --no-extras --no-verify 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/f" -o f -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-verify > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/w" -o w -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-verify > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE \
-    -d "$OUT/a" -o a -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+    -d "$OUT/a" -o a -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-verify > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
-    -d "$OUT/b" -o b -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+    -d "$OUT/b" -o b -- python "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-verify > /dev/null 2>&1
 cd "$ROOT"
 db() { find "$OUT/$1" -name '*results.db' | head -1; }
 python tools/rocpd_summary.py "$(db t)" "$(db f)" "$(db w)" > "$OUT/${TAG}_bench_rocprofv3.txt" 2>&1
 python tools/rocpd_summary.py "$(db a)" "$(db a)" "$(db b)" > "$OUT/${TAG}_mix_decimate_sq.txt" 2>&1
 python tools/traffic_json.py "$(db f)" "$(db w)" k_mix_decimate50 1572864 4915200000 > "$OUT/${TAG}_mix_decimate_traffic.json" 2>/dev/null
 for cfg in scan_wide fsk_mixed; do
-  timeout 300 python bench.py --config $cfg 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_${cfg}.json"
+  SONDE_FSK_PROF=1 timeout 300 python bench.py --config $cfg 2> "$OUT/${TAG}_bench_${cfg}.err" | tail -1 > "$OUT/${TAG}_bench_${cfg}.json"
+  grep "fsk prof" "$OUT/${TAG}_bench_${cfg}.err" > "$OUT/${TAG}_fsk_phases.txt" 2>/dev/null; rm -f "$OUT/${TAG}_bench_${cfg}.err"
   cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/k_$cfg" -o k -- python "$ROOT/bench.py" --config $cfg --steps 5 --no-cpu-baseline > /dev/null 2>&1
   cd "$ROOT"
