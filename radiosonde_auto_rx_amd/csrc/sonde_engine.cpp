@@ -34,6 +34,7 @@ struct sonde_engine {
     sonde_info_t info{};
     hipStream_t stream = nullptr;      // A: input staging, k_mix_decimate, k_dc_update
     hipStream_t stream_b = nullptr;    // B: IF chain, header correlation, framesync (may overlap the next call's A work)
+    hipStream_t stream_c = nullptr;    // C: record copies of a lagged fetch (on B they would queue behind the call that is still running)
     hipEvent_t ev_a[4] = {}, ev_b[4] = {};
     unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
     unsigned *h_count_dev = nullptr;   // the same words as the device addresses them (k_publish_u32 writes them)
@@ -140,6 +141,9 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
     // the per-call snapshot is older than records an end-of-stream frame sync (finish / finish_channel) has added and a fetch has already
     // taken: never step back behind what has been read
     if ((int32_t)(count - e->read_idx) < 0) count = e->read_idx;
+    // a lagged fetch copies on its own stream: on B the copy would sit behind the kernels of the latest call and waiting for it would wait for
+    // that call, so the host could never run ahead of the GPU.  Records up to `count` are complete (their call's event has been waited for).
+    hipStream_t cs = (lag > 0 && e->stream_c) ? e->stream_c : e->stream_b;
     unsigned n = count - e->read_idx;
     if (n > (unsigned)e->max_frames) { e->overflow = true; e->read_idx = count - (unsigned)e->max_frames; n = (unsigned)e->max_frames; }
     if (max_take >= 0 && n > (unsigned)max_take) n = (unsigned)max_take;     // the rest stays queued for the next fetch
@@ -149,12 +153,12 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
     while (done < n) {
         const unsigned idx = (e->read_idx + done) % (unsigned)e->max_frames;
         const unsigned run = std::min<unsigned>(n - done, (unsigned)e->max_frames - idx);
-        if (hipMemcpyAsync(e->h_recs + done, e->d_frames + idx, (size_t)run * sizeof(FrameRec), hipMemcpyDeviceToHost, e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        if (hipMemcpyAsync(e->h_recs + done, e->d_frames + idx, (size_t)run * sizeof(FrameRec), hipMemcpyDeviceToHost, cs) != hipSuccess) return SONDE_E_NOGPU;
         if (soft && e->d_soft && hipMemcpyAsync(soft->data() + (size_t)done * e->nbits, e->d_soft + (size_t)idx * e->nbits,
-                                                (size_t)run * e->nbits * sizeof(float), hipMemcpyDeviceToHost, e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+                                                (size_t)run * e->nbits * sizeof(float), hipMemcpyDeviceToHost, cs) != hipSuccess) return SONDE_E_NOGPU;
         done += run;
     }
-    if (n && hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+    if (n && hipStreamSynchronize(cs) != hipSuccess) return SONDE_E_NOGPU;
     if (n) memcpy(recs.data(), e->h_recs, (size_t)n * sizeof(FrameRec));
     e->read_idx += n;
     return (int)n;
@@ -468,6 +472,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     if (cfg->pipeline && audio) { sonde_engine_destroy(e); return SONDE_E_ARG; }
     if (cfg->pipeline) HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
     else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
+    HIPCHK(hipStreamCreateWithFlags(&e->stream_c, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocMapped));
@@ -485,6 +490,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     prof_collect(e);
     { hipStream_t sa = e->stream; if (sa) hipStreamDestroy(sa); }
     if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
+    if (e->stream_c) hipStreamDestroy(e->stream_c);
     for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); }
     if (e->ev_copy) hipEventDestroy(e->ev_copy);
     if (e->h_pending) hipHostFree(e->h_pending);

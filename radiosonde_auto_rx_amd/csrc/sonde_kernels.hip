@@ -789,8 +789,13 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
 #define IF_TILE 960
 #endif
 #define IF_THREADS 256
+#ifndef IF_NB
 #define IF_NB 4
+#endif
 #define IF_RUN 4
+#ifndef IF_LD
+#define IF_LD 5
+#endif
 
 __global__ __launch_bounds__(IF_THREADS)
 void k_if_chain(const IfArgs a) {
@@ -811,18 +816,28 @@ void k_if_chain(const IfArgs a) {
     const int hz = (T2 - 1) + max(1, nwin - 1);       // history of z' needed
     const int nz = hz + nout;                         // z' count
     const int ny = nz + (T1 - 1);                     // y count
-    const int nyp = (ny + 8 + 1) & ~1;                         // padded: the 4-output groups read a little past ny
+    const int nyp = (ny + 2 * IF_NB + 1) & ~1;                 // padded: the IF_NB-output groups read a little past ny
     float2 *sy = reinterpret_cast<float2 *>(smem);            // [nyp]
+    const int nzs = a.fm_on ? nz + (nz & 1) : 0;               // z' is kept for the discriminator only
     float2 *sz = sy + nyp;                                     // [nz]   z'[t0 - hz + k]
-    float4 *sx4 = reinterpret_cast<float4 *>(sz + nz + (nz & 1));   // [nz]   (X1, X2): X1 = z' * e^{+i 2 pi m rho}, X2 = z' * e^{-i 2 pi m rho}
-    float  *sf = reinterpret_cast<float *>(sx4 + nz);          // [T2-1+nout] raw s_fm
-    float  *wf = sf + (T2 - 1 + nout);                         // [T2]
-    float  *wq = sf + ((T2 - 1 + nout + T2 + 3) & ~3);         // [T1] IF low-pass taps, 16-byte aligned (sf is): read 4 at a time
+    float4 *sx4 = reinterpret_cast<float4 *>(sz + nzs);        // [nz]   (X1, X2): X1 = z' * e^{+i 2 pi m rho}, X2 = z' * e^{-i 2 pi m rho}
+    float  *sf = reinterpret_cast<float *>(sx4 + (a.tone_on ? nz : 0));   // [T2-1+nout] raw s_fm (the tone products exist with the tone correlator only)
+    const int nsf = a.fm_on ? T2 - 1 + nout : 0;
+    float  *wf = sf + nsf;                                     // [T2]
+    float  *wq = sf + ((nsf + T2 + 3) & ~3);                   // [T1] IF low-pass taps, 16-byte aligned (sf is): read 4 at a time
 
     const float2 *yr = a.y + (size_t)ch * a.ring_len;
-    for (int k = threadIdx.x; k < nyp; k += IF_THREADS) {
-        const int64_t m = (int64_t)t0 - hz - (T1 - 1) + k;     // absolute IF index, may be < 0 at stream start
-        sy[k] = (m >= 0 && k < ny) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
+    // the tile's y samples: IF_LD loads per thread in flight before the first is parked (a workgroup has nothing else to do until they are there)
+    for (int kb = threadIdx.x; kb < nyp; kb += IF_LD * IF_THREADS) {
+        float2 v[IF_LD];
+#pragma unroll
+        for (int u = 0; u < IF_LD; u++) {
+            const int k = kb + u * IF_THREADS;
+            const int64_t m = (int64_t)t0 - hz - (T1 - 1) + k;     // absolute IF index, may be < 0 at stream start
+            v[u] = (m >= 0 && k < ny) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < IF_LD; u++) { const int k = kb + u * IF_THREADS; if (k < nyp) sy[k] = v[u]; }
     }
     // acquisition / locked tap set (demod_mod.c:1577-1590); the choice is per channel = per workgroup: kept in a scalar register so that the taps load as scalars
     const int acq = __builtin_amdgcn_readfirstlane((afc && !a.afc[ch].locked) ? 1 : 0);
@@ -847,6 +862,9 @@ void k_if_chain(const IfArgs a) {
             win[j] = v2f{v0.x, v0.y}; win[j + 1] = v2f{v0.z, v0.w};
         }
         int t = 0;
+#ifdef IF_EXP_NOFIR
+        t = T1 & ~3;
+#endif
         for (; t + 3 < T1; t += 4) {                                   // 4 taps: two 16-byte sample reads, one 16-byte (broadcast) tap read
             const float4 n0 = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB), n1 = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB + 2);
             const float4 w4 = *reinterpret_cast<const float4 *>(wq + t);
@@ -895,12 +913,18 @@ void k_if_chain(const IfArgs a) {
                 const float2 zo = a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)];
                 re = zo.x; im = zo.y;
             }
-            sz[k] = make_float2(re, im);
-            // tone mixer e^{-i t w}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
-            const float fr = (float)__builtin_amdgcn_fract((double)(m - ep) * a.rho);
-            const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
-            // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470); stored side by side
-            sx4[k] = make_float4(re * cs - im * sn, re * sn + im * cs, re * cs + im * sn, im * cs - re * sn);
+            if (a.fm_on) sz[k] = make_float2(re, im);
+            if (a.tone_on) {
+                // tone mixer e^{-i t w}, t = m/sr: phase in revolutions = m * rho (double), reduced before the f32 sincos
+#ifdef IF_EXP_NOTONE
+                const float sn = 0.f, cs = 1.f;
+#else
+                const float fr = (float)__builtin_amdgcn_fract((double)(m - ep) * a.rho);
+                const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
+#endif
+                // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470); stored side by side
+                sx4[k] = make_float4(re * cs - im * sn, re * sn + im * cs, re * cs + im * sn, im * cs - re * sn);
+            }
             if (a.tap_ifiq && m >= (int64_t)t0 && (int32_t)((uint32_t)m - start) >= 0)
                 a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
         }
@@ -913,7 +937,11 @@ void k_if_chain(const IfArgs a) {
         const int zi = k + (hz - (T2 - 1));            // index into sz of sample m
         const float2 z1 = sz[zi], z0 = sz[zi - 1];
         const float wr = z1.x * z0.x + z1.y * z0.y, wi = z1.y * z0.x - z1.x * z0.y;
+#ifdef IF_EXP_NOATAN
+        float v = wi + wr;
+#else
         float v = 0.8f * atan2f(wi, wr) * 0.31830988618379067f;
+#endif
         if (afc) {                                     // raw FM samples older than the restart come from lpFM_buf's ring
             const int64_t m = (int64_t)t0 - (T2 - 1) + k;
             float *fr = a.fmraw + (size_t)ch * a.ring_len;
@@ -932,12 +960,19 @@ void k_if_chain(const IfArgs a) {
     const float inv_sps = 1.0f / a.sps;
     for (int k0 = IF_RUN * threadIdx.x; k0 < nout; k0 += IF_RUN * IF_THREADS) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        float so[IF_RUN], sfm[IF_RUN];
+        // a full run at a 16-byte boundary of the ring leaves as one store per stream (the ring length is a power of two >= IF_RUN: no wrap inside it)
+        const bool vec = !afc && k0 + IF_RUN <= nout && ((t0 + (uint32_t)k0) & (IF_RUN - 1)) == 0;
 #pragma unroll
         for (int r = 0; r < IF_RUN; r++) {
             const int k = k0 + r;
+            so[r] = 0.f; sfm[r] = 0.f;
             if (k >= nout) break;
             const uint32_t m = t0 + (uint32_t)k;
             if (a.tone_on) {
+#ifdef IF_EXP_NOWIN
+                if (1) { f = sx4[hz + k]; } else
+#endif
                 if (r == 0) {
                     for (int j = nwin - 1; j >= 0; j--) { const float4 x = sx4[hz + k - j]; f.x += x.x; f.y += x.y; f.z += x.z; f.w += x.w; }
                 } else {
@@ -954,13 +989,20 @@ void k_if_chain(const IfArgs a) {
                     for (int t = 0; t < T2; t++) acc = fmaf(sf[k + t], wf[t], acc);
                     s_fm = acc;
                 }
-                fmb[m & mask] = s_fm;
+                if (!vec) fmb[m & mask] = s_fm;
             }
             float s = s_fm;
             // |F2| - |F1| scaled by 1/sps: hardware square root and a reciprocal multiply (1 ulp each — the reference itself evaluates this in
             // double from drifting float sums; the tolerance of the stream is 1e-5 RMS, tests/test_gpu_parity.py)
             if (a.tone_on) s = (__builtin_amdgcn_sqrtf(f.z * f.z + f.w * f.w) - __builtin_amdgcn_sqrtf(f.x * f.x + f.y * f.y)) * inv_sps;
-            bufs[m & mask] = s;
+            if (!vec) bufs[m & mask] = s;
+            so[r] = s; sfm[r] = s_fm;
+        }
+        if (vec) {
+            const uint32_t mi = (t0 + (uint32_t)k0) & mask;
+            static_assert(IF_RUN == 4, "the vector store below writes four outputs");
+            *reinterpret_cast<float4 *>(bufs + mi) = make_float4(so[0], so[1], so[2], so[3]);
+            if (a.fm_on) *reinterpret_cast<float4 *>(fmb + mi) = make_float4(sfm[0], sfm[1], sfm[2], sfm[3]);
         }
     }
 }
@@ -1746,7 +1788,7 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     const int T1 = a->lpiq_on ? a->lpiq_taps : 1, T2 = a->lpfm_on ? a->lpfm_taps : 1;
     const int hz = (T2 - 1) + (a->nwin - 1 > 1 ? a->nwin - 1 : 1);
     const int nz = hz + IF_TILE, ny = nz + T1 - 1;
-    const size_t lds = (size_t)((ny + 8 + 1) & ~1) * 8 + (size_t)(nz + 1) * 8 + (size_t)nz * 16 + (size_t)(T2 - 1 + IF_TILE) * 4 + (size_t)(T1 + T2) * 4 + 32;
+    const size_t lds = (size_t)((ny + 2 * IF_NB + 1) & ~1) * 8 + (size_t)(a->fm_on ? nz + 1 : 0) * 8 + (size_t)(a->tone_on ? nz : 0) * 16 + (size_t)(a->fm_on ? T2 - 1 + IF_TILE : 0) * 4 + (size_t)(T1 + T2) * 4 + 32;
     hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
