@@ -115,6 +115,7 @@ struct WinFftArgs {
     const float *bufs; WinItem *items; const float2 *Fm, *tws;
     int n_ch, stride, W, K, L, ring_len;
     const uint32_t *work, *work_count; int round_parity;
+    unsigned long long *prof; // SONDE_WF_PROF: cycles per phase of workgroup 0 (nullptr = off)
 };
 
 struct CorrArgs {
@@ -159,6 +160,7 @@ struct SyncArgs {
     sonde_summary_t *summary; uint32_t summary_base; int summary_type; uint64_t summary_epoch;      // nullable: per-channel summary records
     const WinItem *win; int win_W;                             // != nullptr: header windows precomputed by k_sync_window_fft (W per channel)
     uint32_t corr_limit;      // != 0: pass 1 of two — `corr` holds CorrArgs.limit end positions behind the state's first one; stop there
+    unsigned long long *prof; // SONDE_WF_PROF: cycles per phase of channel 0 (nullptr = off)
 };
 
 extern "C" {

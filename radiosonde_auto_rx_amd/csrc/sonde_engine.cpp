@@ -34,6 +34,7 @@ struct sonde_engine {
     sonde_info_t info{};
     hipStream_t stream = nullptr;      // A: input staging, k_mix_decimate, k_dc_update
     hipStream_t stream_b = nullptr;    // B: IF chain, header correlation, framesync (may overlap the next call's A work)
+    unsigned long long *d_wfprof = nullptr;        // SONDE_WF_PROF
     hipStream_t stream_c = nullptr;    // C: record copies of a lagged fetch (on B they would queue behind the call that is still running)
     hipEvent_t ev_a[4] = {}, ev_b[4] = {};
     unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
@@ -367,7 +368,12 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
             ref_dft_8192(m);
             const std::vector<float> tw = ref_twiddle_table();
             e->win_W = 8;
-            if (dalloc(&e->d_Fm, (size_t)M, false) || dalloc(&e->d_tws, tw.size() / 2, false) || dalloc(&e->d_win, (size_t)C * e->win_W) ||
+            m.resize(4 * (size_t)M);                          // behind the table its bit-reversed copy (the conjugate-and-swap pass reads both coalesced)
+            for (int i = 0; i < M; i++) {
+                int r = 0; for (int b = 0; b < 13; b++) if (i >> b & 1) r |= 1 << (12 - b);
+                m[2 * (size_t)(M + i)] = m[2 * (size_t)r]; m[2 * (size_t)(M + i) + 1] = m[2 * (size_t)r + 1];
+            }
+            if (dalloc(&e->d_Fm, 2 * (size_t)M, false) || dalloc(&e->d_tws, tw.size() / 2, false) || dalloc(&e->d_win, (size_t)C * e->win_W) ||
                 dalloc(&e->d_work, (size_t)C * e->win_W) || dalloc(&e->d_work_count, 2)) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
             HIPCHK(hipMemcpy(e->d_Fm, m.data(), m.size() * sizeof(float), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(e->d_tws, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -488,6 +494,24 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_b) hipStreamSynchronize(e->stream_b);
     prof_collect(e);
+    if (e->d_wfprof) {
+        unsigned long long h[32] = {0};
+        if (hipMemcpy(h, e->d_wfprof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[31]) {
+            static const char *nm[7] = {"setup", "search", "headcmp", "slot", "slice", "syndromes+record", "exit"};
+            unsigned long long tot = 0; for (int i = 0; i < 7; i++) tot += h[16 + i];
+            fprintf(stderr, "framesync prof (channel 0, %llu launches, %llu frames, %.0f cycles per launch):", h[31], h[30], (double)tot / (double)h[31]);
+            for (int i = 0; i < 7; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h[16 + i] / (double)std::max(1ull, tot));
+            fprintf(stderr, "\n");
+        }
+        if (h[15]) {
+            static const char *nm[6] = {"load", "fft1", "mul", "fft2", "argmax", "norm"};
+            unsigned long long tot = 0; for (int i = 0; i < 6; i++) tot += h[i];
+            fprintf(stderr, "window fft prof (workgroup 0, %llu windows, %.0f cycles each):", h[15], (double)tot / (double)h[15]);
+            for (int i = 0; i < 6; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h[i] / (double)std::max(1ull, tot));
+            fprintf(stderr, "\n");
+        }
+        hipFree(e->d_wfprof);
+    }
     { hipStream_t sa = e->stream; if (sa) hipStreamDestroy(sa); }
     if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
     if (e->stream_c) hipStreamDestroy(e->stream_c);
@@ -727,6 +751,9 @@ static void sync_round(sonde_engine *e, int W) {
     WinFftArgs f{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
     f.K = e->info.K; f.L = e->info.L; f.ring_len = e->ring_len;
     f.work = e->d_work; f.work_count = e->d_work_count; f.round_parity = e->sync_rounds & 1;
+    static const bool want_prof = getenv("SONDE_WF_PROF") != nullptr;          // profiling aid: cycles per phase of workgroup 0, printed when the engine is destroyed
+    if (want_prof && !e->d_wfprof) { if (hipMalloc((void **)&e->d_wfprof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(e->d_wfprof, 0, 32 * sizeof(unsigned long long)); }
+    f.prof = e->d_wfprof;
     e->sync_rounds++;
     prof_begin(e, "header_corr", sb);
     sonde_launch_sync_plan(&p, sb);
@@ -751,6 +778,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.match_sum = e->match_sum; s.fm = e->d_fm; s.corr2 = e->d_corr2; s.ifiq = e->d_ifiq; s.afc = e->d_afc; s.start = e->d_start; s.pending = e->d_pending;
     s.corr_limit = e->corr_limit;
     s.win = e->d_win; s.win_W = e->win_W;
+    s.prof = e->d_wfprof ? e->d_wfprof + 16 : nullptr;
     s.summary = e->d_summary; s.summary_base = e->summary_base; s.summary_type = e->cfg.sonde_type; s.summary_epoch = e->samples_in / (uint64_t)std::max(1, e->info.decM);     // IF samples produced so far, 64 bit
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }

@@ -4,12 +4,19 @@
 #ifndef SONDE_FFT_DEV_H
 #define SONDE_FFT_DEV_H
 #include "sonde_scan_dev.h"
+#ifndef FFT_THREADS
+#define FFT_THREADS SC_THREADS      // threads of the workgroup that runs a transform (the including file may choose)
+#endif
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-// LDS index of element i: one pad element per 8 keeps the stride-8 and stride-64 element accesses of the first two
-// register passes (and the bit-reversed store) off the same banks: position i + (i >> 3)
-#define XI(i) ((i) + ((i) >> 3))
+// LDS index of element i: position i + (i >> 4) + (i >> 8).  With it every access pattern of the transform spreads evenly over the banks
+// (tools/probes/lds_banks.py: each aligned group of 32 lanes touches every 8-byte bank slot exactly twice): the element strides 1, 8, 64, 512
+// and 4096 of the register passes AND the bit-reversed order — lanes i..i+63 go to brev13(i) = base + 128 * brev6(lane) — in which the
+// input is stored and the spectra are conjugated and swapped.  (One pad per 8 elements served the passes but put all 64 lanes of a
+// bit-reversed access into one slot.)
+#define XI(i) ((i) + ((i) >> 4) + ((i) >> 8))
+#define SC_XN (SC_N + SC_N / 16 + SC_N / 256)     // elements of the padded array
 
 __device__ __forceinline__ int brev13(int k) { return (int)(__brev((unsigned)k) >> (32 - SC_LOG2N)); }
 
@@ -22,7 +29,8 @@ template <int R>
 __device__ __forceinline__ void dit_pass(float2 *x, const float2 *tws, const int t0, const int tid) {
     constexpr int E = 1 << R;
     const int p_lo = t0;
-    for (int g = tid; g < (SC_N >> R); g += SC_THREADS) {
+#pragma unroll 1
+    for (int g = tid; g < (SC_N >> R); g += FFT_THREADS) {
         const int low = g & ((1 << p_lo) - 1), high = g >> p_lo;
         const int base = (high << (p_lo + R)) | low;
         float2 v[E];
@@ -51,11 +59,15 @@ __device__ __forceinline__ void dit_pass(float2 *x, const float2 *tws, const int
 // (L2-resident, 32 KB, shared by every workgroup): the data array and 4 KB of twiddles are all the LDS a transform needs, so two workgroups of
 // 1024 threads fit on a CU
 #define SC_TW_LDS 511
-__device__ __forceinline__ void dft_ref(float2 *x, const float2 *tws, const float2 *tws_g, const int tid) {
+// stages 0..11; the caller runs the last stage (12) itself when it wants the outputs in registers
+__device__ __forceinline__ void dft_ref_head(float2 *x, const float2 *tws, const float2 *tws_g, const int tid) {
     dit_pass<3>(x, tws, 0, tid);
     dit_pass<3>(x, tws, 3, tid);
     dit_pass<3>(x, tws, 6, tid);
     dit_pass<3>(x, tws_g, 9, tid);
+}
+__device__ __forceinline__ void dft_ref(float2 *x, const float2 *tws, const float2 *tws_g, const int tid) {
+    dft_ref_head(x, tws, tws_g, tid);
     dit_pass<1>(x, tws_g, 12, tid);
 }
 

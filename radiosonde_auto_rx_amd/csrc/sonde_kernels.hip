@@ -788,7 +788,9 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
 #ifndef IF_TILE
 #define IF_TILE 960
 #endif
+#ifndef IF_THREADS
 #define IF_THREADS 256
+#endif
 #ifndef IF_NB
 #define IF_NB 4
 #endif
@@ -1317,9 +1319,13 @@ void k_framesync(const SyncArgs a) {
     bool afc_event = false;
     const int K = a.K, L = a.L;
 
+    // profiling aid (SONDE_WF_PROF): thread 0 of channel 0 adds the shader-clock cycles since the previous mark to phase k
+#define FS_MARK(k) do { if (a.prof && ch == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
+    unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
     if (tid < 512) s_exp[tid] = a.gf_exp[tid];
     if (tid < 256) s_log[tid] = a.gf_log[tid];
     __syncthreads();
+    FS_MARK(0);
     // pass 1 of two: the correlation ring is valid below this end position only (corr_tile_unused with the same state and limit)
     const bool horizon_on = a.corr_limit != 0 && (st.mode == 0 || st.mode == 1);
     const uint32_t horizon = horizon_on ? sync_first_pos(st, a.frame_samples, a.delay) + a.corr_limit : 0u;
@@ -1395,6 +1401,7 @@ void k_framesync(const SyncArgs a) {
                 if (ev) { afc_event = true; avail = st.s_in; }
             }
             if (!(mpos > prev)) continue;
+            FS_MARK(1);
             // ---- headcmp (demod_mod.c:870-938): hard-slice the header from the ring, count mismatches
             int errs = 0;
             const int nsym = a.hdrlen / a.symhd;
@@ -1429,6 +1436,7 @@ void k_framesync(const SyncArgs a) {
             errs = 0;
             for (int w = 0; w < FS_WAVES; w++) errs += s_ri[w];
             __syncthreads();
+            FS_MARK(2);
             if (errs > a.hdmax) continue;
             if (mv * (0.5f - (float)st.inv) < 0.f) {    // polarity mismatch (rs41mod.c:2887-2891): skipped, or flips the channel with --auto
                 if (!a.opt_auto) continue;
@@ -1449,6 +1457,7 @@ void k_framesync(const SyncArgs a) {
             __syncthreads();
             const unsigned slot = s_slot;                              // monotonic counter, ring of records
             FrameRec *rec = a.frames + slot;
+            FS_MARK(3);
             for (int p0 = 0; p0 < a.nbits; p0 += FS_THREADS) {
                 const int bp = p0 + tid;
                 double sum = 0.0;
@@ -1497,6 +1506,7 @@ void k_framesync(const SyncArgs a) {
                 if (lane == 0) { atomicAdd(&s_cnt[0], __popcll(vm & 0x8080808080808080ULL)); atomicAdd(&s_cnt[1], __popcll(vm)); }
             }
             __syncthreads();
+            FS_MARK(4);
             const int nbytes_ok = s_cnt[0], nbits_ok = s_cnt[1];
             // frame length from the type byte (rs41mod.c:407-415,2488-2490)
             int ft = 0; { const uint8_t b = s_frame[0x38]; for (int q = 0; q < 4; q++) ft += ((b >> q) & 1) - ((b >> (q + 4)) & 1); }
@@ -1534,11 +1544,15 @@ void k_framesync(const SyncArgs a) {
                 sm->frames += 1; sm->frames_clean += clean ? 1u : 0u;
             }
             __syncthreads();
+            FS_MARK(5);
+            if (a.prof && ch == 0 && tid == 0) a.prof[14] += 1;
             if (!enough) { st.mode = 2; st.s_in = avail; break; }
             st.s_in = s_in_after; st.k = 0; st.mode = 0;
         }
     }
     if (tid == 0) a.state[ch] = st;
+    FS_MARK(6);
+    if (a.prof && ch == 0 && tid == 0) a.prof[15] += 1;
     if (DC && tid == 0) {
         a.afc[ch] = af;
         a.start[ch] = afc_event ? avail : a.avail;      // first IF sample the host loop has to recompute for this channel
@@ -1580,90 +1594,145 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
 
 // The reference is plain C on x86-64: separately rounded multiplies and adds (no fused multiply-add) in the butterflies and products.
 #pragma clang fp contract(off)
+// threads per window workgroup: two workgroups of 512 share a CU (74 KB of LDS each, up to 128 registers per thread) — while one waits at a
+// barrier or for memory the other one computes; a single 1024-thread workgroup per CU left the CU idle in every such wait
+#ifndef WF_THREADS
+#define WF_THREADS 512
+#endif
+#define FFT_THREADS WF_THREADS
 #include "sonde_fft_dev.h"
 // one planned window (getCorrDFT without --dc, demod_mod.c:148-225), evaluated by one workgroup
+#ifndef WF_MB
+#define WF_MB 4               // table entries fetched together in the conjugate-and-swap pass
+#endif
+#ifndef WF_LU
+#define WF_LU 1
+#endif
+// profiling aid (SONDE_WF_PROF): thread 0 of workgroup 0 adds the shader-clock cycles since the previous mark to phase k
+#define WF_MARK(k) do { if (a.prof && blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
 __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int ch, WinItem *it, float2 *x, float2 *tws, float *s_rf, int *s_ri) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (it->state != 1) return;
+    unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
     const int K = a.K, L = a.L, N = SC_N, wl = K + L;
     const uint32_t pos = it->pos, mask = (uint32_t)a.ring_len - 1;
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
     const int64_t start = (int64_t)pos - (wl - 1);
     // xn[i] = bufs[pos - (K+L-1) + i], i < K+L, zero padded (:168-169); bit-reversed for the DIT network, natural order for the norm
-    for (int i = tid; i < N; i += SC_THREADS) {
+    for (int i = tid; i < N; i += WF_THREADS) {
         const int64_t p = start + i;
         const float v = (i < wl && p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
         x[XI(brev13(i))] = make_float2(v, 0.f);
     }
     __syncthreads();
+    WF_MARK(0);
     dft_ref(x, tws, a.tws, tid);                                         // X = rdft(xn)
-    // Z = X * Fm (:190); Nidft() transforms conj(Z) (:78-80): conjugate and swap into bit-reversed order for the same network
-    for (int i = tid; i < N; i += SC_THREADS) {
-        const int r = brev13(i);
-        if (r < i) continue;
-        const float2 zi = cmul(x[XI(i)], a.Fm[i]), zr = cmul(x[XI(r)], a.Fm[r]);
-        x[XI(r)] = make_float2(zi.x, -zi.y);
-        x[XI(i)] = make_float2(zr.x, -zr.y);
+    WF_MARK(1);
+    // Z = X * Fm (:190); Nidft() transforms conj(Z) (:78-80): conjugate and swap into bit-reversed order for the same network.
+    // Pairs (i, r = brev(i)), r >= i; Fm[r] comes from the bit-reversed copy of the table behind it (a.Fm + N) — coalesced like Fm[i]
+    {
+        const float2 *FmR = a.Fm + N;
+#pragma unroll 1
+        for (int h = 0; h < N / WF_THREADS; h += WF_MB) {
+            float2 fi[WF_MB], fr[WF_MB];
+#pragma unroll
+            for (int u = 0; u < WF_MB; u++) {
+                const int i = tid + (h + u) * WF_THREADS;
+                const bool on = brev13(i) >= i;
+                fi[u] = on ? a.Fm[i] : make_float2(0.f, 0.f);
+                fr[u] = on ? FmR[i] : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < WF_MB; u++) {
+                const int i = tid + (h + u) * WF_THREADS, r = brev13(i);
+                if (r < i) continue;
+                const float2 zi = cmul(x[XI(i)], fi[u]), zr = cmul(x[XI(r)], fr[u]);
+                x[XI(r)] = make_float2(zi.x, -zi.y);
+                x[XI(i)] = make_float2(zr.x, -zr.y);
+            }
+        }
     }
     __syncthreads();
-    dft_ref(x, tws, a.tws, tid);                                         // cx = Nidft(Z), real part used
-    // arg-max of re(cx)^2 over i in [L-1, K+L), first maximum wins (:200-207)
-    float best = 0.f; int bidx = -1;
-    for (int i = tid; i < N; i += SC_THREADS) {
-        if (i >= L - 1 && i < wl) { const float c = x[XI(i)].x, c2 = c * c; if (c2 > best) { best = c2; bidx = i; } }
+    WF_MARK(2);
+    dft_ref_head(x, tws, a.tws, tid);                                    // cx = Nidft(Z), real part used
+    // last stage (dit_pass<1> at t = 12) in registers: only re(cx) is looked at, so nothing is stored — the arg-max of re(cx)^2 over
+    // i in [L-1, K+L), first maximum wins (:200-207), is taken from the butterfly outputs as they come
+    float best = 0.f, bestc = 0.f; int bidx = -1;
+#pragma unroll WF_LU
+    for (int u = 0; u < SC_N / 2 / WF_THREADS; u++) {
+        const int g = tid + u * WF_THREADS;
+        const float2 w = a.tws[((1 << 12) - 1) + g];
+        const float2 p = x[XI(g)], r = cmul(x[XI(g + (1 << 12))], w);
+        const float c0 = p.x + r.x, c1 = p.x - r.x;
+        const int i0 = g, i1 = g + (1 << 12);
+        if (i0 >= L - 1 && i0 < wl) { const float c2 = c0 * c0; if (c2 > best || (c2 == best && bidx >= 0 && i0 < bidx)) { best = c2; bidx = i0; bestc = c0; } }
+        if (i1 >= L - 1 && i1 < wl) { const float c2 = c1 * c1; if (c2 > best || (c2 == best && bidx >= 0 && i1 < bidx)) { best = c2; bidx = i1; bestc = c1; } }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bidx, off);
-        if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
+    WF_MARK(3);
+    {
+        float rb = best; int ri = bidx;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(rb, off); const int oi = __shfl_xor(ri, off);
+            if (ob > rb || (ob == rb && oi >= 0 && (ri < 0 || oi < ri))) { rb = ob; ri = oi; }
+        }
+        if (lane == 0) { s_rf[wave] = rb; s_ri[wave] = ri; }
     }
-    if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
     __syncthreads();
     int mp = -1;
     {
         float b = 0.f;
-        for (int w = 0; w < SC_THREADS / WAVE; w++) {
+        for (int w = 0; w < WF_THREADS / WAVE; w++) {
             const float ob = s_rf[w]; const int oi = s_ri[w];
             if (ob > b || (ob == b && oi >= 0 && (mp < 0 || oi < mp))) { b = ob; mp = oi; }
         }
     }
     __syncthreads();
+    WF_MARK(4);
     if (mp < 0 || mp == L - 1 || mp == wl - 1) {                          // nothing above zero / edge value: -4 (:208)
         if (tid == 0) { it->rc = -4; it->mv = 0.f; it->mpos = 0; __threadfence(); it->state = 2; }
         return;
     }
     // xnorm = sqrt(sum_{i<L} xn[mp-i]^2) (:215-217); mx /= xnorm * N
     float e = 0.f;
-    for (int k = tid; k < L; k += SC_THREADS) {                          // xn[mp - k], read again from the ring (it is not kept in LDS)
+    for (int k = tid; k < L; k += WF_THREADS) {                          // xn[mp - k], read again from the ring (it is not kept in LDS)
         const int i = mp - k; const int64_t p2 = start + i;
         const float v = (i < wl && p2 >= 0) ? bufs[(uint32_t)p2 & mask] : 0.f;
         e += v * v;
     }
     for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
     if (lane == 0) s_rf[wave] = e;
+    if (bidx == mp) s_rf[WF_THREADS / WAVE] = bestc;                     // re(cx[mp]) from the thread whose butterfly produced it
     __syncthreads();
     if (tid == 0) {
         float es = 0.f;
-        for (int w = 0; w < SC_THREADS / WAVE; w++) es += s_rf[w];
+        for (int w = 0; w < WF_THREADS / WAVE; w++) es += s_rf[w];
         const float xnorm = sqrtf(es);
-        it->rc = mp; it->mv = x[XI(mp)].x / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
+        it->rc = mp; it->mv = s_rf[WF_THREADS / WAVE] / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
         __threadfence(); it->state = 2;
     }
+    WF_MARK(5);
+    if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[15] += 1;
 }
 
 // Workgroups walk the compact list k_sync_plan wrote (a.work): the grid does not depend on how many windows a round planned, and a round in
 // which almost every channel is inside a frame costs a handful of workgroups instead of stride x channels empty ones.
 // (the scanner's k_scan_corr runs two such workgroups per CU at 64 VGPRs; here the ~1000 windows of a round gain nothing from that and the
 // spills cost 10 %, measured: one workgroup per CU with the registers the compiler wants)
-__global__ __launch_bounds__(SC_THREADS)
+#if WF_THREADS <= 512
+#define WF_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2 * WF_THREADS / 256, 2 * WF_THREADS / 256)))      // two workgroups per CU
+#else
+#define WF_WAVES_ATTR
+#endif
+__global__ __launch_bounds__(WF_THREADS) WF_WAVES_ATTR
 void k_sync_window_fft(const WinFftArgs a) {
     extern __shared__ float2 smem2[];
-    float2 *x = smem2;                           // [SC_N + SC_N/8] padded (XI)
-    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_TW_LDS + 1] twiddles of stages 0..8
-    __shared__ float s_rf[SC_THREADS / WAVE];
-    __shared__ int s_ri[SC_THREADS / WAVE];
+    float2 *x = smem2;                           // [SC_XN] padded (XI)
+    float2 *tws = smem2 + SC_XN;       // [SC_TW_LDS + 1] twiddles of stages 0..8
+    __shared__ float s_rf[WF_THREADS / WAVE + 1];
+    __shared__ int s_ri[WF_THREADS / WAVE];
     const uint32_t count = a.work_count[a.round_parity];
     if (blockIdx.x >= count) return;
-    for (int k = threadIdx.x; k < SC_TW_LDS; k += SC_THREADS) tws[k] = a.tws[k];
+    for (int k = threadIdx.x; k < SC_TW_LDS; k += WF_THREADS) tws[k] = a.tws[k];
     for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
         const uint32_t item = a.work[w];
         __syncthreads();                         // the previous window's last reads of x / s_rf are over
@@ -1805,9 +1874,9 @@ extern "C" void sonde_launch_sync_plan(const WinPlanArgs *a, hipStream_t s) {
     hipLaunchKernelGGL(k_sync_plan, dim3((a->n_ch + 255) / 256), dim3(256), 0, s, *a);
 }
 extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s) {
-    const size_t lds = (size_t)(SC_N + SC_N / 8 + SC_TW_LDS + 1) * sizeof(float2);
+    const size_t lds = (size_t)(SC_XN + SC_TW_LDS + 1) * sizeof(float2);
     int grid = a->W * a->n_ch; if (grid > 512) grid = 512;      // two waves of workgroups on 256 CUs at most; the kernel strides over the list
-    hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(SC_THREADS), lds, s, *a);
+    hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(WF_THREADS), lds, s, *a);
 }
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
     if (a->opt_dc) hipLaunchKernelGGL(k_framesync<true>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);

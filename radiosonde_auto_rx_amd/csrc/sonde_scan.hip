@@ -145,8 +145,8 @@ template <bool BIG>
 __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two workgroups per CU: 78 KB of LDS, 64 VGPRs
 void k_scan_corr_t(const ScanCorrArgs a) {
     extern __shared__ float2 smem2[];
-    float2 *x = BIG ? a.scratch + (size_t)blockIdx.x * a.N : smem2;      // [SC_N + SC_N/8] padded in LDS, or the [N] global array of this workgroup
-    float2 *tws = smem2 + SC_N + SC_N / 8;       // [SC_TW_LDS + 1] twiddles of stages 0..8 (LDS form only)
+    float2 *x = BIG ? a.scratch + (size_t)blockIdx.x * a.N : smem2;      // [SC_XN] padded in LDS, or the [N] global array of this workgroup
+    float2 *tws = smem2 + SC_XN;       // [SC_TW_LDS + 1] twiddles of stages 0..8 (LDS form only)
     const int log2n = BIG ? a.log2n : SC_LOG2N;
     auto XP = [&](int i) -> int { return BIG ? i : XI(i); };
     auto BR = [&](int k) -> int { return (int)(__brev((unsigned)k) >> (32 - log2n)); };
@@ -314,7 +314,7 @@ extern "C" void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s) {
 }
 extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(SC_N + SC_N / 8 + SC_TW_LDS + 1) * sizeof(float2);
+    const size_t lds = (size_t)(SC_XN + SC_TW_LDS + 1) * sizeof(float2);
     if (a->N > SC_N) {                                     // the global-memory form: the caller lists the pairs and owns the scratch arrays
         if (!a->work || !a->scratch || (1 << a->log2n) != a->N) return -1;
         if (a->n_work > 0) hipLaunchKernelGGL(k_scan_corr_t<true>, dim3(a->n_work, 1), dim3(SC_THREADS), 0, s, *a);
