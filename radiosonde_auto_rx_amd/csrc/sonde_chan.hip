@@ -34,7 +34,7 @@ struct ChanArgs {
 
 __global__ __launch_bounds__(CH_THREADS)
 void k_channelize(const ChanArgs a) {
-    extern __shared__ uint32_t smem_c[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_c[];
     const int M = a.M, D = a.D, T = a.T, tid = threadIdx.x;
     const int f0 = blockIdx.x * CH_F, nf = min(CH_F, a.n_frames - f0);
     if (nf <= 0) return;

@@ -15,6 +15,7 @@
 #pragma clang fp contract(off)
 #include "sonde_fsk_dev.h"
 #include <limits.h>
+#include <cstdlib>
 
 #define WAVE 64
 #define FMT_S16  1
@@ -42,6 +43,168 @@ __device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_r
     return bi == INT_MAX ? dflt : bi;
 }
 
+// the same search on one wave (no workgroup barrier): the next frame's estimator runs on a single wave beside the oscillator
+__device__ __forceinline__ int wave_argmax(const float *v, int lo, int hi, int dflt, int lane) {
+    float best = 0.f; int bi = INT_MAX;
+    for (int i = lo + lane; i < hi; i += WAVE) { const float x = v[i]; if (x > best) { best = x; bi = i; } }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    return bi == INT_MAX ? dflt : bi;
+}
+
+// x / 1000.f for an integer-valued x of 16 bits, correctly rounded, in three instructions instead of the division's dozen: q = x r with
+// r = fl(1/1000), then one Newton step on the exact residual, q + (x - 1000 q) r.  Checked against the division for all 65536 inputs
+// (tests/test_fsk_div1000.py); the conversion runs for every sample in the frame's input pass and again, twice, in the estimator blocks.
+__device__ __forceinline__ float div1000(const float x) {
+    const float r = 1.0f / 1000.0f;
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 1000.0f, x), r, q);
+}
+// input sample p of channel ch as the modem sees it (fsk_demod.c:283-311)
+__device__ __forceinline__ float2 fsk_sample(const FskArgs &a, int ch, uint32_t p) {
+    if (a.format == FMT_CS16) {
+        const uint32_t raw = reinterpret_cast<const uint32_t *>(a.in)[(size_t)ch * a.ring + p];
+        return make_float2(div1000((float)(short)(raw & 0xffffu)), div1000((float)(((int)raw) >> 16)));
+    }
+    if (a.format == FMT_CF32) return reinterpret_cast<const float2 *>(a.in)[(size_t)ch * a.ring + p];      // the fsk.h seam: COMP samples as the caller scaled them
+    if (a.format == FMT_S16) return make_float2(div1000((float)reinterpret_cast<const int16_t *>(a.in)[(size_t)ch * a.ring + p]), 0.f);
+    const uint16_t raw = reinterpret_cast<const uint16_t *>(a.in)[(size_t)ch * a.ring + p];
+    return make_float2(((float)(raw & 0xffu) - 127.0f) / 128.0f, ((float)(raw >> 8) - 127.0f) / 128.0f);
+}
+
+// one butterfly stage of the reference's transform on buf[Ndft], butterflies lt, lt + TPF, ...  (kiss_fft.c kf_bfly4 / kf_bfly2: separately
+// rounded mul / add, so that Sf and with it every estimator decision is the reference's bit for bit)
+__device__ __forceinline__ void fsk_stage(float2 *buf, const float2 *tw, const int p, const int m, const int fs, const int Ndft, const int lt, const int TPF) {
+    const int lm = __builtin_ctz((unsigned)m);               // m is a power of two (Ndft is)
+    for (int b = lt; b < Ndft / p; b += TPF) {
+        const int blk = b >> lm, u = b & (m - 1);
+        float2 *F = buf + blk * p * m + u;
+        if (p == 4) {
+            const float2 s0 = cmult(F[m], tw[u * fs]), s1 = cmult(F[2 * m], tw[2 * u * fs]), s2 = cmult(F[3 * m], tw[3 * u * fs]);
+            float2 f0 = F[0];
+            const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
+            f0 = cadd(f0, s1);
+            const float2 s3 = cadd(s0, s2), s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
+            F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
+            F[0] = cadd(f0, s3);
+            F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
+            F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
+        } else {
+            const float2 t = cmult(F[m], tw[u * fs]), f0 = F[0];
+            F[m] = make_float2(f0.x - t.x, f0.y - t.y);
+            F[0] = cadd(f0, t);
+        }
+    }
+}
+
+#define FSK_AE 4               // transform bins per lane the ahead-estimator holds in registers: Ndft <= 256 (sondes: 64, 128, 256)
+// barrier of the `n` estimator waves only (wave 0 is inside the oscillator walk and takes no part): a counter in LDS that only grows —
+// every wave adds one and waits until the count says all have arrived for this `phase` (1, 2, ...).  DS operations of a wave execute in
+// order, so what a wave wrote before its add is visible to whoever sees the count; all waves of a workgroup are resident, so the wait ends.
+__device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned n, unsigned &phase, const int lane) {
+    phase++;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        atomicAdd(cnt, 1u);
+        while (*reinterpret_cast<volatile unsigned *>(cnt) < n * phase) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The frequency estimator of the frame that starts at input sample rd (fsk_demod_freq_est, fsk.c:438-590), run AHEAD on waves 1..NG while
+// wave 0 walks the oscillator of the frame before — that walk is one lane per tone for thousands of dependent steps, and the estimator of the
+// next frame needs nothing from it (only the samples and the smoothed spectrum).  Rounds of NG blocks, one per wave: window, transform,
+// magnitude (left in the wave's scratch); then the waves share the BINS and apply the round's magnitudes to Sf in block order — the same
+// arithmetic in the same order as the workgroup-wide form in the kernel, so either may produce a frame's estimate.
+template <int M>
+__device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_t rd, const int numffts, float2 *s_fb, const float2 *s_tw,
+                                   float *s_Sf, float *s_Sc, float *Sf_g, float *o_fest, float2 *o_dphi, const int gw, const int NG, const int lane,
+                                   unsigned *s_bar) {
+    const int Ndft = a.Ndft;
+    const float tc = a.tc, omt = 1 - tc;
+    // a wave takes BPW blocks at a time, one per group of GL lanes, FSK_AE transform elements per lane: short transforms (Ndft 64 / 128) would
+    // leave most lanes of a wave without a butterfly otherwise
+    const int BPW = (FSK_AE * WAVE) / Ndft, GL = WAVE / BPW, sub = lane / GL, lt = lane - sub * GL;
+    const int slot = gw * BPW + sub, RB = NG * BPW;               // this lane group's block within a round; blocks per round
+    float2 *buf = s_fb + slot * Ndft;
+    float *mag = reinterpret_cast<float *>(buf);                // the block's magnitudes, fftshifted, over the first half of its scratch
+    const int gt = gw * WAVE + lane, GT = NG * WAVE;             // thread index / count of the group
+    unsigned phase = 0;
+    // window, permutation and the samples of the group's NEXT block live in registers: a round then waits for LDS only
+    float hn[FSK_AE]; int pm[FSK_AE]; float2 xs[FSK_AE];
+#pragma unroll
+    for (int e = 0; e < FSK_AE; e++) { const int i = lt + e * GL; hn[e] = a.hann[i]; pm[e] = a.perm[i]; xs[e] = make_float2(0.f, 0.f); }
+    auto fetch = [&](const int j) {
+#pragma unroll
+        for (int e = 0; e < FSK_AE; e++) {
+            const int i = lt + e * GL;
+            if (j < numffts) xs[e] = fsk_sample(a, ch, (rd + (uint32_t)(i + j * (Ndft / 2))) & (a.ring - 1));
+        }
+    };
+    fetch(slot);
+    for (int j0 = 0; j0 < numffts; j0 += RB) {
+        const int j = j0 + slot;
+        // (a wave whose groups have no block left in the last round still walks the stages: its lanes are masked by `act`)
+        const bool act = j < numffts;
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < FSK_AE; e++) buf[pm[e]] = make_float2(hn[e] * xs[e].x, hn[e] * xs[e].y);
+        }
+        fetch(j + RB);                                         // in flight during the transform
+        __builtin_amdgcn_wave_barrier();
+        for (int s = 0; s < a.n_stage; s++) { if (act) fsk_stage(buf, s_tw, a.st_p[s], a.st_m[s], a.st_fs[s], Ndft, lt, GL); __builtin_amdgcn_wave_barrier(); }
+        // magnitudes in place: every lane reads its bins first, then the wave writes (mag[q] overlays buf[q / 2])
+        float mg[FSK_AE];
+#pragma unroll
+        for (int e = 0; e < FSK_AE; e++) { mg[e] = 0.f; if (act) { const float2 X = buf[lt + e * GL]; mg[e] = sqrtf((X.x * X.x) + (X.y * X.y)); } }
+        __builtin_amdgcn_wave_barrier();
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < FSK_AE; e++) mag[(lt + e * GL + Ndft / 2) & (Ndft - 1)] = mg[e];
+        }
+        fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
+        const int nb = min(RB, numffts - j0);
+        for (int k = gt; k < Ndft; k += GT) {                  // Sf = Sf (1 - tc) + |X| tc, block after block (fsk.c:497-503)
+            float sf = s_Sf[k];
+            for (int g = 0; g < nb; g++) sf = (sf * omt) + (reinterpret_cast<const float *>(s_fb + g * Ndft)[k] * tc);
+            s_Sf[k] = sf;
+        }
+        fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
+    }
+    if (gw != 0) return;
+    // the searches are short: one wave
+    for (int k = lane; k < Ndft; k += WAVE) { const float sf = s_Sf[k]; Sf_g[k] = sf; s_Sc[k] = sf; }
+    __builtin_amdgcn_wave_barrier();
+    float f_est[4]; float2 dphi[4];
+    {
+        int freqi[4];
+        for (int m = 0; m < M; m++) {
+            const int imax = wave_argmax(s_Sc, a.st, a.en, 0, lane);
+            const int f_min = max(imax - a.f_zero, 0), f_max = min(imax + a.f_zero, Ndft);
+            __builtin_amdgcn_wave_barrier();
+            for (int k = f_min + lane; k < f_max; k += WAVE) s_Sc[k] = 0.f;
+            __builtin_amdgcn_wave_barrier();
+            freqi[m] = imax - Ndft / 2;
+        }
+        for (int i = 1; i < M; i++)
+            for (int j = i; j > 0 && freqi[j] < freqi[j - 1]; j--) { const int t = freqi[j]; freqi[j] = freqi[j - 1]; freqi[j - 1] = t; }
+        for (int m = 0; m < M; m++) { f_est[m] = (float)freqi[m] * ((float)a.Fs / (float)Ndft); dphi[m] = a.dphi_peak[freqi[m] + Ndft / 2]; }
+    }
+    if (a.est_type) {
+        for (int b = a.st + lane; b < a.en - a.len_mask; b += WAVE) {
+            float corr = 0.0f;
+            for (int i = 0; i < a.n_mask; i++) corr += s_Sf[b + a.mask_idx[i]];
+            s_Sc[b] = corr;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int b_max = wave_argmax(s_Sc, a.st, a.en - a.len_mask, a.st, lane);
+        for (int m = 0; m < M; m++) { f_est[m] = a.f_mask[M * b_max + m]; dphi[m] = a.dphi_mask[M * b_max + m]; }
+    }
+    if (lane == 0) for (int m = 0; m < M; m++) { o_fest[m] = f_est[m]; o_dphi[m] = dphi[m]; }
+}
+
 // one step of the local oscillator phi *= d on the register pair %0 with temporaries %1, %2 and d = %3; the result goes to LDS at %4 + 8 k.
 // A lone wave issues an instruction every ~8 cycles whatever it depends on, so the step is three packed instructions instead of six plain ones:
 //   A = phi.x (d.x, d.y),  B = phi.y (d.y, d.x),  phi = (A.x - B.x, A.y + B.y)     — the four products and two sums of cmult(), each rounded once
@@ -55,9 +218,11 @@ __device__ int block_argmax(const float *v, int lo, int hi, int dflt, float *s_r
 template <int M>
 __global__ __launch_bounds__(FSK_THREADS)
 void k_fsk_demod(const FskArgs a) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 16-byte base whatever the static arrays in front of it add up to (float2 / b64 accesses everywhere)
     __shared__ float s_rf[FSK_THREADS / WAVE]; __shared__ int s_ri[FSK_THREADS / WAVE];
     __shared__ float2 s_phi[4]; __shared__ float s_tc[2], s_eb[2];
+    __shared__ float s_nfest[4]; __shared__ float2 s_ndphi[4];            // the next frame's estimate, when it was made ahead
+    __shared__ unsigned s_bar;                                              // arrival count of the estimator waves (fsk_group_barrier)
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT;
     const int W = (nsym + 1) * P;
@@ -75,37 +240,32 @@ void k_fsk_demod(const FskArgs a) {
     float  *s_mag = reinterpret_cast<float *>(s_fdc + 4 * Ndft);
     float2 *s_ft  = s_fdc;
     float  *s_Sf = reinterpret_cast<float *>(s_fdc + nB), *s_Sc = s_Sf + Ndft;
+    float2 *s_tw = reinterpret_cast<float2 *>(s_Sc + Ndft), *s_fb = s_tw + Ndft;      // twiddles; transform scratch of the estimator that runs ahead
     FskChan st = a.chan[ch];
     float *Sf_g = a.Sf + (size_t)ch * Ndft;
     float2 *tail_g = a.tail + (size_t)ch * M * NT;
     int frames = 0;
     const uint32_t wr = a.wr_ch ? a.wr_ch[ch] : a.wr;
     unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
+    for (int k = tid; k < Ndft; k += FSK_THREADS) s_tw[k] = a.tw[k];
+    bool have_est = false;                    // this frame's estimate was made while the previous frame's oscillator ran
+    // frames whose length may differ by +-Ts/2 have the same estimator blocks when all three lengths give the same block count
+    const bool same_blocks = a.burst || ((N - Ts / 2) / (Ndft / 2) == (N + Ts / 2) / (Ndft / 2));
 
     for (;;) {
         const int nin = st.nin;
         if ((int32_t)(wr - st.rd) < nin) break;
         if (frames >= a.rec_cap || (frames + 1) * nsym * (M / 2) > a.sd_cap) break;
         // ---- input conversion (fsk_demod.c:283-311)
-        for (int i = tid; i < nin; i += FSK_THREADS) {
-            const uint32_t p = (st.rd + (uint32_t)i) & (a.ring - 1);
-            float2 v;
-            if (a.format == FMT_CS16) {
-                const uint32_t raw = reinterpret_cast<const uint32_t *>(a.in)[(size_t)ch * a.ring + p];
-                v = make_float2((float)(short)(raw & 0xffffu) / 1000.f, (float)(((int)raw) >> 16) / 1000.f);
-            } else if (a.format == FMT_CF32) {                                // the fsk.h seam: COMP samples as the caller scaled them
-                v = reinterpret_cast<const float2 *>(a.in)[(size_t)ch * a.ring + p];
-            } else if (a.format == FMT_S16) {
-                v = make_float2((float)reinterpret_cast<const int16_t *>(a.in)[(size_t)ch * a.ring + p] / 1000.f, 0.f);
-            } else {
-                const uint16_t raw = reinterpret_cast<const uint16_t *>(a.in)[(size_t)ch * a.ring + p];
-                v = make_float2(((float)(raw & 0xffu) - 127.0f) / 128.0f, ((float)(raw >> 8) - 127.0f) / 128.0f);
-            }
-            s_in[i] = v;
-        }
+        for (int i = tid; i < nin; i += FSK_THREADS) s_in[i] = fsk_sample(a, ch, (st.rd + (uint32_t)i) & (a.ring - 1));
+        if (tid == 0) s_bar = 0;
         __syncthreads();
         FSK_MARK(0);
 
+        float f_est[4]; float2 dphi[4];
+        if (have_est) {
+            for (int m = 0; m < M; m++) { f_est[m] = s_nfest[m]; dphi[m] = s_ndphi[m]; }
+        } else {
         // ---- frequency estimator (fsk_demod_freq_est): numffts half-overlapped windowed FFTs, one wave each
         const int numffts = nin / (Ndft / 2) - 1;
         // threads per transform: one wave each while there are four blocks to do at a time, more when a frame has fewer (a 150-symbol M10 frame
@@ -124,29 +284,7 @@ void k_fsk_demod(const FskArgs a) {
             // the reference's transform, butterfly for butterfly (kiss_fft.c kf_work / kf_bfly4 / kf_bfly2: radix-4 stages, one radix-2
             // stage when log2 Ndft is odd, innermost factor first, separately rounded mul / add) so that Sf and with it every estimator
             // decision is the reference's bit for bit
-            for (int s = 0; s < a.n_stage; s++) {
-                const int p = a.st_p[s], m = a.st_m[s], fs = a.st_fs[s], lm = __builtin_ctz((unsigned)m);      // m is a power of two (Ndft is)
-                if (act) for (int b = lt; b < Ndft / p; b += TPF) {
-                    const int blk = b >> lm, u = b & (m - 1);
-                    float2 *F = buf + blk * p * m + u;
-                    if (p == 4) {
-                        const float2 s0 = cmult(F[m], a.tw[u * fs]), s1 = cmult(F[2 * m], a.tw[2 * u * fs]), s2 = cmult(F[3 * m], a.tw[3 * u * fs]);
-                        float2 f0 = F[0];
-                        const float2 s5 = make_float2(f0.x - s1.x, f0.y - s1.y);
-                        f0 = cadd(f0, s1);
-                        const float2 s3 = cadd(s0, s2), s4 = make_float2(s0.x - s2.x, s0.y - s2.y);
-                        F[2 * m] = make_float2(f0.x - s3.x, f0.y - s3.y);
-                        F[0] = cadd(f0, s3);
-                        F[m] = make_float2(s5.x + s4.y, s5.y - s4.x);
-                        F[3 * m] = make_float2(s5.x - s4.y, s5.y + s4.x);
-                    } else {
-                        const float2 t = cmult(F[m], a.tw[u * fs]), f0 = F[0];
-                        F[m] = make_float2(f0.x - t.x, f0.y - t.y);
-                        F[0] = cadd(f0, t);
-                    }
-                }
-                __syncthreads();
-            }
+            for (int s = 0; s < a.n_stage; s++) { if (act) fsk_stage(buf, s_tw, a.st_p[s], a.st_m[s], a.st_fs[s], Ndft, lt, TPF); __syncthreads(); }
             // fftshift (DC at Ndft/2) and magnitude
             if (act) for (int k = lt; k < Ndft; k += TPF) {
                 const float2 X = buf[k];
@@ -164,7 +302,6 @@ void k_fsk_demod(const FskArgs a) {
         }
         __syncthreads();
         // peak estimator: the M largest bins in [st, en), +-f_zero blanked after each, ascending (fsk.c:508-546)
-        float f_est[4]; float2 dphi[4];
         {
             int freqi[4];
             for (int m = 0; m < M; m++) {
@@ -192,9 +329,16 @@ void k_fsk_demod(const FskArgs a) {
         }
         __syncthreads();
 
+        }
         FSK_MARK(2);
         // ---- down-conversion with continuous phase (fsk.c:633-656); the oscillator recurrence stays serial
         const int nold = Nmem - nin;
+        // the next frame's estimate is made now, on wave 1, if that frame is certain to be demodulated by this launch (samples queued for its
+        // longest form, room for its outputs) and its blocks do not depend on the length this frame's timing will choose for it
+        const uint32_t rd_next = st.rd + (uint32_t)nin;
+        const int NG = a.est_waves;                         // waves 1..NG (0: no room in LDS for their scratch — every frame estimates for itself)
+        const bool est_ahead = NG > 0 && same_blocks && (int32_t)(wr - rd_next) >= (a.burst ? N : N + Ts / 2)
+                               && frames + 1 < a.rec_cap && (frames + 2) * nsym * (M / 2) <= a.sd_cap;
         if (wave == 0 && lane < M) {
             float2 phi = st.phi_c[0], d = dphi[0];
             for (int m = 1; m < M; m++) if (lane == m) { phi = st.phi_c[m]; d = dphi[m]; }
@@ -219,8 +363,11 @@ void k_fsk_demod(const FskArgs a) {
         } else if (tid >= WAVE) {
             for (int m = 0; m < M; m++)
                 for (int i = tid - WAVE; i < nold; i += FSK_THREADS - WAVE) s_fdc[m * Nmem + i] = tail_g[m * NT + (NT - nold) + i];
+            if (est_ahead && wave <= NG)
+                fsk_estimate_ahead<M>(a, ch, rd_next, N / (Ndft / 2) - 1, s_fb, s_tw, s_Sf, s_Sc, Sf_g, s_nfest, s_ndphi, wave - 1, NG, lane, &s_bar);
         }
         __syncthreads();
+        have_est = est_ahead;
         FSK_MARK(3);
         for (int m = 0; m < M; m++) st.phi_c[m] = s_phi[m];
         for (int j = tid; j < nin; j += FSK_THREADS) {
@@ -369,8 +516,19 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     int nB = M * a->Nmem;
     if (4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2 > nB) nB = 4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2;
     if (W > nB) nB = W;
-    const size_t lds = (size_t)(nA + nB) * sizeof(float2) + (size_t)2 * a->Ndft * sizeof(float);
+    // regions A and B, Sf and its search copy, the twiddles — and the scratch of the waves that estimate the next frame ahead: as many of
+    // the three as fit without costing the second workgroup of a CU its place (80 KB each, 256 B of static data)
+    const size_t base = (size_t)(nA + nB) * sizeof(float2) + (size_t)2 * a->Ndft * sizeof(float) + (size_t)a->Ndft * sizeof(float2);
+    const size_t cap = base + 256 <= 80 * 1024 ? (size_t)80 * 1024 - 256 : (size_t)150 * 1024;
+    int ng = 3;
+    static const char *ng_env = getenv("SONDE_FSK_AHEAD");               // A/B aid: 0 = every frame estimates for itself
+    if (ng_env) { ng = atoi(ng_env); if (ng < 0) ng = 0; if (ng > 3) ng = 3; }
+    const size_t per_wave = (size_t)FSK_AE * 64 * sizeof(float2);        // (FSK_AE * 64 / Ndft) blocks of Ndft elements
+    while (ng > 0 && base + (size_t)ng * per_wave > cap) ng--;
+    if (a->Ndft > FSK_AE * 64 || a->Ndft < FSK_AE) ng = 0;                // a lane holds FSK_AE elements of its block
+    const size_t lds = base + (size_t)ng * per_wave;
     if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
+    FskArgs b = *a; b.est_waves = ng; a = &b;
     if (a->M != 2 && a->M != 4) return -1;
     static size_t attr[2] = { 0, 0 };
     const void *fn = a->M == 2 ? reinterpret_cast<const void *>(k_fsk_demod<2>) : reinterpret_cast<const void *>(k_fsk_demod<4>);

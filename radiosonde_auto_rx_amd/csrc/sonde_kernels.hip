@@ -247,7 +247,7 @@ __device__ __forceinline__ float2v md_dc_boundary(const MixDecArgs &a, int ch, d
 template <int VAR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_mix_decimate50(const MixDecArgs a) {
-    extern __shared__ uint32_t smem_u[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
     constexpr int Q_T = 7, H = 6, D = 50, TILE_DW = MD_ROWS * D;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *sRaw = smem_u + wave * (TILE_DW + 4);
@@ -359,7 +359,7 @@ void k_mix_decimate50(const MixDecArgs a) {
 template <int Q_T, bool PH64, int D_T, int FAST>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
-    extern __shared__ uint32_t smem_u[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = D_T > 0 ? D_T : a.D;
     constexpr int H = Q_T - 1;
@@ -518,7 +518,7 @@ void k_mix_decimate(const MixDecArgs a) {
 template <int Q_T, bool PH64>
 __global__ __launch_bounds__(256)
 void k_mix_decimate_wide(const MixDecArgs a) {
-    extern __shared__ uint32_t smem_u[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = a.D, DS = a.DS, NS = D / DS, pitch = (DS + 3) & ~3;
     constexpr int H = Q_T - 1;
@@ -801,7 +801,7 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
 
 __global__ __launch_bounds__(IF_THREADS)
 void k_if_chain(const IfArgs a) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ch = blockIdx.y;
     const uint32_t t0 = a.m0 + (uint32_t)blockIdx.x * IF_TILE;        // first output sample (absolute)
     const int nout = min(IF_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ bool corr_tile_unused(const CorrArgs &a, int ch, uint
 
 __global__ __launch_bounds__(HC_THREADS)
 void k_header_corr(const CorrArgs a) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ch = blockIdx.y, L = a.L;
     const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HC_TILE;
     const int nout = min(HC_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
@@ -1084,7 +1084,7 @@ void k_header_corr(const CorrArgs a) {
 
 __global__ __launch_bounds__(HCF_THREADS)
 void k_header_corr_fact(const CorrArgs a) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ch = blockIdx.y, L = a.L, sps = a.isps, nsym = a.nsym, nt = a.ntypes;
     const uint32_t p0 = a.m0 + (uint32_t)blockIdx.x * HCF_TILE;
     const int nout = min(HCF_TILE, (int)(a.m0 + (uint32_t)a.n - p0));
@@ -1725,7 +1725,7 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
 #endif
 __global__ __launch_bounds__(WF_THREADS) WF_WAVES_ATTR
 void k_sync_window_fft(const WinFftArgs a) {
-    extern __shared__ float2 smem2[];
+    extern __shared__ __attribute__((aligned(16))) float2 smem2[];
     float2 *x = smem2;                           // [SC_XN] padded (XI)
     float2 *tws = smem2 + SC_XN;       // [SC_TW_LDS + 1] twiddles of stages 0..8
     __shared__ float s_rf[WF_THREADS / WAVE + 1];

@@ -65,7 +65,7 @@ void k_audio_convert(const AudioConvArgs a) {
 
 __global__ __launch_bounds__(SI_TILE)
 void k_scan_if(const ScanIfArgs a) {
-    extern __shared__ float2 smem2[];
+    extern __shared__ __attribute__((aligned(16))) float2 smem2[];
     const int ch = blockIdx.y, T = a.taps, tid = threadIdx.x;
     const uint32_t t0 = a.m0 + (uint32_t)blockIdx.x * SI_TILE;
     const int nout = min(SI_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
@@ -144,7 +144,7 @@ __device__ __forceinline__ void dft_big(float2 *x, const float2 *tws, int log2n,
 template <bool BIG>
 __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))      // two workgroups per CU: 78 KB of LDS, 64 VGPRs
 void k_scan_corr_t(const ScanCorrArgs a) {
-    extern __shared__ float2 smem2[];
+    extern __shared__ __attribute__((aligned(16))) float2 smem2[];
     float2 *x = BIG ? a.scratch + (size_t)blockIdx.x * a.N : smem2;      // [SC_XN] padded in LDS, or the [N] global array of this workgroup
     float2 *tws = smem2 + SC_XN;       // [SC_TW_LDS + 1] twiddles of stages 0..8 (LDS form only)
     const int log2n = BIG ? a.log2n : SC_LOG2N;
