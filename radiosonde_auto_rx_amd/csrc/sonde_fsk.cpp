@@ -163,10 +163,17 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         unsigned long long h[16];
         if (hipMemcpy(h, f->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
             static const char *nm[9] = { "input", "fft", "Sf+estimators", "oscillator", "downconv+tail", "integrate", "timing", "soft", "ebno+record" };
-            unsigned long long tot = 0; for (int k = 0; k < 9; k++) tot += h[k];
-            fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, %% of %llu cycles):", f->cfg.Rs, f->cfg.nsym, tot);
-            for (int k = 0; k < 9; k++) fprintf(stderr, " %s %.1f", nm[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
-            fprintf(stderr, "\n");
+            if (h[15]) {          // the pipelined kernel: cycles of channel 0's waves, all of it and what they spent waiting
+                fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, pipelined kernel): producer %.0f kcycles (waits: estimate %.1f%% ring %.1f%% length %.1f%%), "
+                                "consumer %.0f (waits for samples %.1f%%, frame tail %.1f%%), estimators %.0f (waits %.1f%%)\n", f->cfg.Rs, f->cfg.nsym,
+                        h[0] / 1e3, 100.0 * h[1] / std::max(1ull, h[0]), 100.0 * h[2] / std::max(1ull, h[0]), 100.0 * h[3] / std::max(1ull, h[0]),
+                        h[4] / 1e3, 100.0 * h[5] / std::max(1ull, h[4]), 100.0 * h[6] / std::max(1ull, h[4]), h[8] / 1e3, 100.0 * h[9] / std::max(1ull, h[8]));
+            } else {
+                unsigned long long tot = 0; for (int k = 0; k < 9; k++) tot += h[k];
+                fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, %% of %llu cycles):", f->cfg.Rs, f->cfg.nsym, tot);
+                for (int k = 0; k < 9; k++) fprintf(stderr, " %s %.1f", nm[k], tot ? 100.0 * (double)h[k] / (double)tot : 0.0);
+                fprintf(stderr, "\n");
+            }
         }
         hipFree(f->d_prof);
     }
@@ -199,6 +206,7 @@ static int launch_and_collect(sonde_fsk_t *f) {
     HIPCHK(hipStreamSynchronize(f->stream));
     float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { f->ms += ms; f->launches++; }
     hipEventDestroy(e0); hipEventDestroy(e1);
+    for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) { fprintf(stderr, "libsonde_hip: fsk modem pipeline of channel %d stalled\n", c); return SONDE_E_NOGPU; }
     return 0;
 }
 

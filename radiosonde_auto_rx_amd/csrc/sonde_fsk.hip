@@ -99,6 +99,7 @@ __device__ __forceinline__ void fsk_stage(float2 *buf, const float2 *tw, const i
     }
 }
 
+#define FSK_SPIN_MAX (1u << 21)   // iterations of a wait loop (64 clocks of sleep each, ~60 ms) after which a wave gives up
 #define FSK_AE 4               // transform bins per lane the ahead-estimator holds in registers: Ndft <= 256 (sondes: 64, 128, 256)
 // barrier of the `n` estimator waves only (wave 0 is inside the oscillator walk and takes no part): a counter in LDS that only grows —
 // every wave adds one and waits until the count says all have arrived for this `phase` (1, 2, ...).  DS operations of a wave execute in
@@ -108,7 +109,8 @@ __device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned 
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         atomicAdd(cnt, 1u);
-        while (*reinterpret_cast<volatile unsigned *>(cnt) < n * phase) __builtin_amdgcn_s_sleep(1);
+        unsigned spins = 0;                                       // a wait that long means a bug: give up instead of hanging the device
+        while (*reinterpret_cast<volatile unsigned *>(cnt) < n * phase && ++spins < FSK_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -121,7 +123,7 @@ __device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned 
 template <int M>
 __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_t rd, const int numffts, float2 *s_fb, const float2 *s_tw,
                                    float *s_Sf, float *s_Sc, float *Sf_g, float *o_fest, float2 *o_dphi, const int gw, const int NG, const int lane,
-                                   unsigned *s_bar) {
+                                   unsigned *s_bar, unsigned &phase) {
     const int Ndft = a.Ndft;
     const float tc = a.tc, omt = 1 - tc;
     // a wave takes BPW blocks at a time, one per group of GL lanes, FSK_AE transform elements per lane: short transforms (Ndft 64 / 128) would
@@ -131,7 +133,6 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
     float2 *buf = s_fb + slot * Ndft;
     float *mag = reinterpret_cast<float *>(buf);                // the block's magnitudes, fftshifted, over the first half of its scratch
     const int gt = gw * WAVE + lane, GT = NG * WAVE;             // thread index / count of the group
-    unsigned phase = 0;
     // window, permutation and the samples of the group's NEXT block live in registers: a round then waits for LDS only
     float hn[FSK_AE]; int pm[FSK_AE]; float2 xs[FSK_AE];
 #pragma unroll
@@ -363,8 +364,10 @@ void k_fsk_demod(const FskArgs a) {
         } else if (tid >= WAVE) {
             for (int m = 0; m < M; m++)
                 for (int i = tid - WAVE; i < nold; i += FSK_THREADS - WAVE) s_fdc[m * Nmem + i] = tail_g[m * NT + (NT - nold) + i];
-            if (est_ahead && wave <= NG)
-                fsk_estimate_ahead<M>(a, ch, rd_next, N / (Ndft / 2) - 1, s_fb, s_tw, s_Sf, s_Sc, Sf_g, s_nfest, s_ndphi, wave - 1, NG, lane, &s_bar);
+            if (est_ahead && wave <= NG) {
+                unsigned phase = 0;                                 // (s_bar was cleared at the top of the frame)
+                fsk_estimate_ahead<M>(a, ch, rd_next, N / (Ndft / 2) - 1, s_fb, s_tw, s_Sf, s_Sc, Sf_g, s_nfest, s_ndphi, wave - 1, NG, lane, &s_bar, phase);
+            }
         }
         __syncthreads();
         have_est = est_ahead;
@@ -509,8 +512,426 @@ void k_fsk_demod(const FskArgs a) {
     if (tid == 0) { st.frames = frames; a.chan[ch] = st; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fsk_stream: the same modem as a pipeline of the workgroup's four waves
+// ------------------------------------------------------------------------------------------------
+// k_fsk_demod spends most of a frame in the oscillator walk — one lane per tone, a dependent complex multiply per sample — with the other
+// 250 threads idle, and keeps f_dc[M][Nmem] in LDS for it (48 KB of the 76 KB a 300-symbol RS41 frame takes: two channels per CU).  Here
+// the walk never stops: every other step of the modem runs beside it, on what it has produced so far.
+//   producer   (one wave, a lane per tone)  phi *= d for every sample of every frame of the launch, into a RING of R samples per tone;
+//              a frame's length is only needed when the walk has done the shortest form of the frame (the fine timing of the frame before
+//              decides it, long before), its frequency estimate when the frame starts (made ahead, below)
+//   consumer   (one wave)  pieces of up to 64 samples as they appear: f_dc = in conj(phi) in place in the ring, the integrator windows that
+//              are complete by then (a lane per window, Ts sequential adds each), their fine-timing products summed serially in window order;
+//              behind a frame's last window: timing -> the next frame's length (published at once), soft decisions, Eb/N0, the frame record
+//   estimators (two waves)  fsk_estimate_ahead for the next frame as soon as its start is known
+// They meet through counters in LDS that only grow (FskPipe): samples produced, lowest sample still needed, frames whose length / estimate
+// has been published.  A wave's DS operations execute in order, so data written before a counter is bumped is visible to whoever has seen
+// the bump.  Every sum and product is the same operation in the same order as in k_fsk_demod (and in the reference), only the schedule
+// differs; the windows read the f_dc stream where the frame-at-a-time form reads its copy of it.
+// LDS: f_int[M][W] + ring + a few KB — 37 KB for RS41 instead of 76, so FOUR channels per CU are resident.
+struct FskPipe {
+    unsigned prod_pos;                 // stream samples the producer has written (0 = first new sample of the launch)
+    int      cons_free;                // stream position below which the consumer needs nothing any more
+    unsigned nin_seq;                  // frames whose length has been published: frame k when nin_seq > k; length 0 = the stream stops in front of k
+    unsigned est_seq;                  // frames whose estimate has been published
+    unsigned bar;                      // fsk_group_barrier of the estimator waves
+    unsigned prod_done;
+    unsigned abort;                    // a wave waited too long: everybody leaves, the channel reports frames = -1
+    int      nin[2];                   // by frame parity
+    float    f_est[2][4]; float2 dphi[2][4];
+    float2   phi_end[4];
+    float    tc[2], eb[2];
+};
+// (every lane reads the same word: the value is handed on as a scalar, so that the loops steered by it stay on the scalar unit)
+__device__ __forceinline__ unsigned pipe_ld(const unsigned *p) { return (unsigned)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(p, __ATOMIC_RELAXED)); }
+__device__ __forceinline__ int pipe_ldi(const int *p) { return __builtin_amdgcn_readfirstlane(__atomic_load_n(p, __ATOMIC_RELAXED)); }
+// false: another wave gave up, or this wait took so long that something is wrong — the caller leaves (the launch reports an error, no hang)
+__device__ __forceinline__ bool pipe_wait_ge(const unsigned *p, const unsigned v, unsigned *abort_flag) {
+    unsigned spins = 0;
+    while ((int)(pipe_ld(p) - v) < 0) {
+        if (++spins > FSK_SPIN_MAX || pipe_ld(abort_flag)) { __atomic_store_n(abort_flag, 1u, __ATOMIC_RELAXED); return false; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+__device__ __forceinline__ void pipe_publish(unsigned *p, const unsigned v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __atomic_store_n(p, v, __ATOMIC_RELAXED);
+}
+
+// profiling aid (SONDE_FSK_PROF): cycles channel 0's waves spend in all / waiting; slot k of a.prof
+#define PIPE_T0() (a.prof && ch == 0 ? __builtin_readcyclecounter() : 0ull)
+#define PIPE_ADD(k, t0) do { if (a.prof && ch == 0 && lane == 0) a.prof[k] += __builtin_readcyclecounter() - (t0); } while (0)
+template <int M>
+__global__ __launch_bounds__(FSK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_fsk_stream(const FskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ FskPipe pp;
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT, R = a.R;
+    const int W = (nsym + 1) * P, step = Ts / P;
+    float2 *s_ring = reinterpret_cast<float2 *>(lds);                      // [M][R]
+    float2 *s_fint = s_ring + M * R;                                       // [M][W]
+    float  *s_ebv  = reinterpret_cast<float *>(s_fint + M * W);            // [2][nsym] (+ pad to an even count)
+    float2 *s_ftp  = reinterpret_cast<float2 *>(s_ebv + ((2 * nsym + 1) & ~1));   // [64] fine-timing products of a batch of windows
+    float  *s_Sf   = reinterpret_cast<float *>(s_ftp + WAVE), *s_Sc = s_Sf + Ndft;
+    float2 *s_tw   = reinterpret_cast<float2 *>(s_Sc + Ndft), *s_fb = s_tw + Ndft;
+    FskChan st = a.chan[ch];
+    float *Sf_g = a.Sf + (size_t)ch * Ndft;
+    float2 *tail_g = a.tail + (size_t)ch * M * NT;
+    const uint32_t wr = a.wr_ch ? a.wr_ch[ch] : a.wr, rd0 = st.rd;
+    const uint32_t rmask = (uint32_t)R - 1;
+    // a frame k exists if its samples are queued and its outputs have room (the loop conditions of k_fsk_demod)
+    auto frame_fits = [&](const int k, const uint32_t S, const int nin) -> bool {
+        return (int32_t)(wr - (rd0 + S)) >= nin && k < a.rec_cap && (k + 1) * nsym * (M / 2) <= a.sd_cap;
+    };
+
+    for (int k = tid; k < Ndft; k += FSK_THREADS) { s_tw[k] = a.tw[k]; s_Sf[k] = Sf_g[k]; }
+    for (int m = 0; m < M; m++) for (int i = tid; i < NT; i += FSK_THREADS) s_ring[m * R + ((uint32_t)(i - NT) & rmask)] = tail_g[m * NT + i];
+    if (tid == 0) {
+        pp.prod_pos = 0; pp.cons_free = -NT; pp.est_seq = 0; pp.bar = 0; pp.prod_done = 0; pp.abort = 0;
+        pp.nin[0] = frame_fits(0, 0u, st.nin) ? st.nin : 0; pp.nin[1] = 0; pp.nin_seq = 1;
+    }
+    __syncthreads();
+    // the roles rotate with the channel, so that the producers of the channels sharing a CU do not all sit on the same SIMD
+    const int role = (wave + ch) & 3;
+
+    if (role == 0) {
+        // ---- producer: the oscillator walk (fsk.c:633-656), one lane per tone
+        if (lane < M) {
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            float2 phi = st.phi_c[0];
+            for (int m = 1; m < M; m++) if (lane == m) phi = st.phi_c[m];
+            float2 *ring = s_ring + lane * R;
+            uint32_t pos = 0;
+            const unsigned long long tp0 = PIPE_T0();
+            for (int k = 0;; k++) {
+                bool stop = false;
+                const unsigned long long tw0 = PIPE_T0();
+                for (unsigned spins = 0;; ) {                           // the frame's estimate — or the word that the stream ends here
+                    if ((int)(pipe_ld(&pp.est_seq) - (unsigned)(k + 1)) >= 0) break;
+                    if ((int)(pipe_ld(&pp.nin_seq) - (unsigned)(k + 1)) >= 0 && pipe_ldi(&pp.nin[k & 1]) == 0) { stop = true; break; }
+                    if (++spins > FSK_SPIN_MAX || pipe_ld(&pp.abort)) { __atomic_store_n(&pp.abort, 1u, __ATOMIC_RELAXED); stop = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                PIPE_ADD(1, tw0);
+                if (stop) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float2 d = pp.dphi[k & 1][0];
+                for (int m = 1; m < M; m++) if (lane == m) d = pp.dphi[k & 1][m];
+                v2f ph = {phi.x, phi.y};
+                const v2f dd = {d.x, d.y};
+                int remaining = a.burst ? N : N - Ts / 2;               // the shortest form of the frame; its real length is known by the time this is done
+                bool have_nin = false;
+                // (pos, remaining and everything that steers this loop are wave-uniform scalars; a vector compare per step would cost as much as the step)
+                for (;;) {
+                    while (remaining > 0) {
+                        if ((pos & 63u) == 0) {                         // every 64 samples: say how far the walk is, make sure the ring has room for the next 64
+                            pipe_publish(&pp.prod_pos, pos);
+                            unsigned spins = 0;
+                            const unsigned long long tw1 = PIPE_T0();
+                            while ((int)(pos + 64u - (uint32_t)R) - pipe_ldi(&pp.cons_free) > 0) {
+                                if (++spins > FSK_SPIN_MAX || pipe_ld(&pp.abort)) { __atomic_store_n(&pp.abort, 1u, __ATOMIC_RELAXED); break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            PIPE_ADD(2, tw1);
+                            if (pipe_ld(&pp.abort)) { remaining = 0; have_nin = true; break; }
+                        }
+                        if ((pos & 7u) == 0 && remaining >= 8) {
+                            // groups of eight steps up to the next multiple of 64 (a ring of R samples, R a multiple of 64, does not wrap inside)
+                            const int g = min((int)((64u - (pos & 63u)) >> 3), remaining >> 3);
+                            uint32_t oaddr = (uint32_t)reinterpret_cast<uintptr_t>(ring + (pos & rmask));
+                            for (int u = 0; u < g; u++) {
+                                v2f ta, tb;
+                                asm volatile(FSK_OSC8 : "+v"(ph), "=&v"(ta), "=&v"(tb) : "v"(dd), "v"(oaddr) : "memory");
+                                oaddr += 64;
+                            }
+                            pos += 8u * (uint32_t)g; remaining -= 8 * g;
+                        } else {
+                            const float pr = ph.x, pi = ph.y;
+                            const float2 q = cmult(make_float2(pr, pi), d);
+                            ring[pos & rmask] = q;
+                            ph.x = q.x; ph.y = q.y;
+                            pos += 1; remaining -= 1;
+                        }
+                    }
+                    if (have_nin) break;
+                    const unsigned long long tw2 = PIPE_T0();
+                    if (!pipe_wait_ge(&pp.nin_seq, (unsigned)(k + 1), &pp.abort)) break;
+                    PIPE_ADD(3, tw2);
+                    remaining = pipe_ldi(&pp.nin[k & 1]) - (a.burst ? N : N - Ts / 2);
+                    have_nin = true;
+                }
+                if (pipe_ld(&pp.abort)) break;
+                {   // end of the frame: phi /= |phi| (fsk.c:654-656)
+                    const float pr = ph.x, pi = ph.y;
+                    const float av = sqrtf((pr * pr) + (pi * pi));
+                    phi = make_float2(pr / av, pi / av);
+                }
+                pipe_publish(&pp.prod_pos, pos);
+            }
+            pp.phi_end[lane] = phi;
+            PIPE_ADD(0, tp0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) pipe_publish(&pp.prod_done, 1u);
+        return;
+    }
+
+    if (role >= 2) {
+        // ---- estimators: the frequency estimate of every frame, as early as its start is known
+        const int gw = role - 2;
+        uint32_t S = 0;
+        unsigned phase = 0;
+        const bool same_blocks = a.burst || ((N - Ts / 2) / (Ndft / 2) == (N + Ts / 2) / (Ndft / 2));
+        const unsigned long long te0 = PIPE_T0();
+        for (int k = 0;; k++) {
+            const unsigned long long tw0 = PIPE_T0();
+            if (k > 0) {
+                if (!pipe_wait_ge(&pp.nin_seq, (unsigned)k, &pp.abort)) break;
+                const int prev = pipe_ldi(&pp.nin[(k - 1) & 1]);
+                if (prev == 0) break;
+                S += (uint32_t)prev;
+            }
+            // ahead of the frame's length: when it is certain to be demodulated whatever length the timing gives it, and its blocks are the same for all three
+            const bool ahead = k > 0 && same_blocks && frame_fits(k, S, a.burst ? N : N + Ts / 2);
+            int numffts = N / (Ndft / 2) - 1;
+            if (!ahead) {
+                if (!pipe_wait_ge(&pp.nin_seq, (unsigned)(k + 1), &pp.abort)) break;
+                const int nin = pipe_ldi(&pp.nin[k & 1]);
+                if (nin == 0) break;
+                numffts = nin / (Ndft / 2) - 1;
+            }
+            if (gw == 0) PIPE_ADD(9, tw0);
+            fsk_estimate_ahead<M>(a, ch, rd0 + S, numffts, s_fb, s_tw, s_Sf, s_Sc, Sf_g, pp.f_est[k & 1], pp.dphi[k & 1], gw, 2, lane, &pp.bar, phase);
+            if (pipe_ld(&pp.abort)) break;
+            if (gw == 0 && lane == 0) pipe_publish(&pp.est_seq, (unsigned)(k + 1));
+        }
+        if (gw == 0) PIPE_ADD(8, te0);
+        return;
+    }
+
+    // ---- consumer
+    {
+        uint32_t S = 0;
+        int frames = 0;
+        int nin = pipe_ldi(&pp.nin[0]);
+        uint32_t E_last = 0;
+        constexpr int WB = WAVE / M;                                    // integrator windows per pass
+        const unsigned long long tc0_ = PIPE_T0();
+        for (int k = 0; nin != 0; k++) {
+            const uint32_t E = S + (uint32_t)nin;
+            const int32_t wbase = (int32_t)E - Nmem;                    // stream position of f_dc[.][0] of this frame
+            int i_done = 0;
+            float t = 0;                                                // lanes 0 / 1: the timing sum (re / im)
+            for (uint32_t c = S; c != E; ) {
+                uint32_t ce = (c | 63u) + 1u; if ((int32_t)(ce - E) > 0) ce = E;      // pieces end where the producer reports (multiples of 64, frame ends)
+                const int cl = (int)(ce - c);
+                float2 x = make_float2(0.f, 0.f);
+                if (lane < cl) x = fsk_sample(a, ch, (rd0 + c + (uint32_t)lane) & (a.ring - 1));
+                // (both global reads of the piece are issued before the wait for the producer: the input sample and the timing phasor of the lane's next window)
+                const float2 ph_next = (i_done + lane / M < W) ? a.phi_ft[i_done + lane / M] : make_float2(0.f, 0.f);
+                const unsigned long long tw0 = PIPE_T0();
+                if (!pipe_wait_ge(&pp.prod_pos, ce, &pp.abort)) { nin = 0; break; }
+                PIPE_ADD(5, tw0);
+                if (lane < cl) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) { float2 *q = s_ring + m * R + ((c + (uint32_t)lane) & rmask); const float2 p = *q; *q = cmult(x, make_float2(p.x, -p.y)); }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // integrator windows complete by now (fsk.c:659-668): window i reads f_dc[i step .. i step + Ts)
+                int i_new = ((int32_t)ce - wbase - Ts) / step + 1;
+                if ((int32_t)ce - wbase - Ts < 0) i_new = 0;
+                if (i_new > W) i_new = W;
+                // a lane per (window, tone): WB windows at a time.  The Ts samples of a window are summed in order; they are contiguous in the ring
+                // unless the window straddles its end
+                for (int ib = i_done; ib < i_new; ib += WB) {
+                    const int wl = lane / M, m = lane - wl * M, i = ib + wl;
+                    if (i < i_new) {
+                        const float2 *rg = s_ring + m * R;
+                        const uint32_t q0 = (uint32_t)(wbase + i * step) & rmask;
+                        float2 acc = make_float2(0.f, 0.f);
+                        if (q0 + (uint32_t)Ts <= (uint32_t)R) {
+                            const float2 *src = rg + q0;
+                            int j = 0;
+                            for (; j + 5 <= Ts; j += 5) {                // (Ts is 5, 10 or 20 for the sondes)
+                                const float2 v0 = src[j], v1 = src[j + 1], v2 = src[j + 2], v3 = src[j + 3], v4 = src[j + 4];
+                                acc = cadd(acc, v0); acc = cadd(acc, v1); acc = cadd(acc, v2); acc = cadd(acc, v3); acc = cadd(acc, v4);
+                            }
+                            for (; j < Ts; j++) acc = cadd(acc, src[j]);
+                        } else {
+                            for (int j = 0; j < Ts; j++) acc = cadd(acc, rg[(q0 + (uint32_t)j) & rmask]);
+                        }
+                        s_fint[m * W + i] = acc;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < i_new && m == 0) {                          // fine timing: sum_i (sum_m |f_int[m]|^2) phi_ft[i]  (fsk.c:682-703)
+                        float ft1 = 0;
+#pragma unroll
+                        for (int m2 = 0; m2 < M; m2++) { const float2 v = s_fint[m2 * W + i]; ft1 += (v.x * v.x) + (v.y * v.y); }
+                        const float2 ph = (ib == i_done) ? ph_next : a.phi_ft[i];
+                        s_ftp[wl] = make_float2(ft1 * ph.x, ft1 * ph.y);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int nb = min(WB, i_new - ib);
+                    if (lane < 2) {
+                        const float *pq = reinterpret_cast<const float *>(s_ftp) + lane;
+                        int q = 0;
+                        for (; q + 16 <= nb; q += 16) {
+                            float v[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) v[u] = pq[2 * (q + u)];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) t = t + v[u];
+                        }
+                        for (; q < nb; q++) t = t + pq[2 * q];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (i_new > i_done) i_done = i_new;
+                // what the producer may overwrite: everything below the first incomplete window — but never the last NT samples of the frame,
+                // the history of the next one
+                if (lane == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __atomic_store_n(&pp.cons_free, min(wbase + i_done * step, (int32_t)E - NT), __ATOMIC_RELAXED); }
+                c = ce;
+            }
+            if (nin == 0) break;                                        // gave up waiting
+            const unsigned long long tt0 = PIPE_T0();
+            if (lane < 2) pp.tc[lane] = t;
+            __builtin_amdgcn_wave_barrier();
+            const float tc0 = pp.tc[0], tc1 = pp.tc[1];
+            const float norm_rx_timing = (float)((double)(float)atan2((double)tc1, (double)tc0) / (2 * 3.14159265358979323846));
+            const float rx_timing = norm_rx_timing * (float)P;
+            const float d_norm = norm_rx_timing - st.norm_rx_timing;
+            st.norm_rx_timing = norm_rx_timing;
+            if (fabsf(d_norm) < .2) {
+                const float appm = (float)(1e6 * d_norm / (float)nsym);
+                st.ppm = (float)(.9 * st.ppm + .1 * appm);
+            }
+            int nin_next = N;
+            if (!a.burst) {
+                if (norm_rx_timing > 0.25) nin_next = N + Ts / 2;
+                else if (norm_rx_timing < -0.25) nin_next = N - Ts / 2;
+            }
+            float f_est[4];
+            for (int m = 0; m < M; m++) f_est[m] = pp.f_est[k & 1][m];    // (published before the producer started this frame)
+            // the next frame: its length, or 0 if it does not fit into this launch — the other waves go on (or stop) from here
+            const bool more = frame_fits(k + 1, E, nin_next);
+            if (lane == 0) {
+                __atomic_store_n(&pp.nin[(k + 1) & 1], more ? nin_next : 0, __ATOMIC_RELAXED);
+                __atomic_store_n(&pp.cons_free, (int32_t)E - NT, __ATOMIC_RELAXED);
+                pipe_publish(&pp.nin_seq, (unsigned)(k + 2));
+            }
+            // ---- soft decisions: integrators resampled by linear interpolation (fsk.c:733-805)
+            const int low = (int)floorf(rx_timing), high = (int)ceilf(rx_timing);
+            const float fract = rx_timing - (float)low, omf = 1 - fract;
+            float *sd = a.sd + (size_t)ch * a.sd_cap + (size_t)frames * nsym * (M / 2);
+            uint8_t *hb = a.hb + (size_t)ch * a.sd_cap + (size_t)frames * nsym * (M / 2);
+            for (int i = lane; i < nsym; i += WAVE) {
+                const int sp = (i + 1) * P;
+                float tmax[4];
+                for (int m = 0; m < M; m++) {
+                    const float2 lo = s_fint[m * W + sp + low], hi = s_fint[m * W + sp + high];
+                    const float2 tt = cadd(make_float2(omf * lo.x, omf * lo.y), make_float2(fract * hi.x, fract * hi.y));
+                    tmax[m] = (tt.x * tt.x) + (tt.y * tt.y);
+                }
+                float mx = tmax[0]; int sym = 0;                                // first maximum wins (fsk.c:760-768)
+                for (int m = 1; m < M; m++) if (tmax[m] > mx) { mx = tmax[m]; sym = m; }
+                s_ebv[i] = mx; s_ebv[nsym + i] = sqrtf(mx);
+                if (M == 2) { sd[i] = sqrtf(tmax[0]) - sqrtf(tmax[1]); hb[i] = (uint8_t)(sym == 1); }
+                else {
+                    hb[2 * i + 1] = (uint8_t)(sym & 1); hb[2 * i] = (uint8_t)((sym & 2) >> 1);
+                    const float t0 = sqrtf(tmax[0]), t1 = sqrtf(tmax[1]), t2 = sqrtf(tmax[2]), t3 = sqrtf(tmax[3]);
+                    float lsb = -t0, msb = -t0;
+                    lsb += t1; msb += -t1;
+                    lsb += -t2; msb += t2;
+                    lsb += t3; msb += t3;
+                    sd[2 * i + 1] = lsb; sd[2 * i] = msb;
+                }
+            }
+            if (a.eye) {                                                // eye diagram samples (fsk.c:857-889), see k_fsk_demod
+                const int dec = (int)ceilf(((float)P * 2) / 160.0f), nes = (P * 2) / dec;
+                float *eye = a.eye + (size_t)ch * 8 * 160;
+                for (int q = lane; q < 8 * nes; q += WAVE) {
+                    const int row = q / nes, j = q - row * nes, i = row / M, m = row - i * M;
+                    const int ind = 2 * P * i + high + 1 + j * dec;
+                    const float2 v = (ind < W && m * W + ind >= 0) ? s_fint[m * W + ind] : make_float2(0.f, 0.f);
+                    eye[row * 160 + j] = sqrtf((v.x * v.x) + (v.y * v.y));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // EbNo estimate (fsk.c:807-836): serial sums in symbol order
+            if (lane < 2) {
+                float acc = 0;
+                int i = 0;
+                for (; i + 16 <= nsym; i += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) v[u] = s_ebv[lane * nsym + i + u];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) acc += v[u];
+                }
+                for (; i < nsym; i++) acc += s_ebv[lane * nsym + i];
+                pp.eb[lane] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+                const float meanebno = pp.eb[1] / (float)nsym;
+                float stdebno = (pp.eb[0] / (float)nsym) - (meanebno * meanebno);
+                if (stdebno > 0.0) stdebno = (float)sqrt((double)stdebno); else stdebno = 0.0f;
+                st.EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
+                st.snr_est = (float)(.5 * st.snr_est + .5 * st.EbNodB);
+            }
+            for (int m = 0; m < M; m++) st.f_est[m] = f_est[m];
+            if (lane == 0) {
+                FskFrameRec r; r.nin = nin; r.nin_next = nin_next; for (int m = 0; m < 4; m++) r.f_est[m] = m < M ? f_est[m] : 0.f;
+                r.norm_rx_timing = norm_rx_timing; r.ppm = st.ppm; r.EbNodB = st.EbNodB; r.snr_est = st.snr_est;
+                a.recs[(size_t)ch * a.rec_cap + frames] = r;
+            }
+            __builtin_amdgcn_wave_barrier();                            // s_fint / s_ebv / pp.tc are rewritten by the next frame
+            PIPE_ADD(6, tt0);
+            st.rd += (uint32_t)nin; st.samples += nin; st.nin = nin_next;
+            frames++;
+            S = E; E_last = E;
+            nin = more ? nin_next : 0;
+        }
+        PIPE_ADD(4, tc0_);
+        if (a.prof && ch == 0 && lane == 0) a.prof[15] = 1;             // (this kernel's slots, not k_fsk_demod's phases)
+        // the launch is over for this channel: oscillator phases, the last NT f_dc samples, the channel state
+        if (!pipe_wait_ge(&pp.prod_done, 1u, &pp.abort) || pipe_ld(&pp.abort)) {
+            if (lane == 0) a.chan[ch].frames = -1;                      // the host turns this into an error
+            return;
+        }
+        if (frames > 0) {
+            for (int m = 0; m < M; m++) st.phi_c[m] = pp.phi_end[m];
+            for (int m = 0; m < M; m++) for (int i = lane; i < NT; i += WAVE) tail_g[m * NT + i] = s_ring[m * R + ((E_last - (uint32_t)NT + (uint32_t)i) & rmask)];
+        }
+        if (lane == 0) { st.frames = frames; a.chan[ch] = st; }
+    }
+}
+
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     const int W = (a->nsym + 1) * a->P, M = a->M;
+    if (a->M != 2 && a->M != 4) return -1;
+    {   // the pipelined kernel, where its estimator fits (Ndft <= 256: every sonde configuration)
+        static const char *st_env = getenv("SONDE_FSK_STREAM");          // A/B aid: 0 = the frame-at-a-time kernel
+        int R = 256; while (R < a->NT + 128) R <<= 1;
+        const size_t lds_s = (size_t)M * R * sizeof(float2) + (size_t)M * W * sizeof(float2) + (size_t)((2 * a->nsym + 1) & ~1) * sizeof(float) + 64 * sizeof(float2)
+                           + (size_t)2 * a->Ndft * sizeof(float) + (size_t)a->Ndft * sizeof(float2) + (size_t)2 * FSK_AE * 64 * sizeof(float2);
+        if (!(st_env && atoi(st_env) == 0) && a->Ndft <= FSK_AE * 64 && a->Ndft >= FSK_AE && a->P >= 1 && a->Ts % a->P == 0 && lds_s <= 150 * 1024) {
+            static size_t attr_s[2] = { 0, 0 };
+            const void *fn = M == 2 ? reinterpret_cast<const void *>(k_fsk_stream<2>) : reinterpret_cast<const void *>(k_fsk_stream<4>);
+            if (lds_s > attr_s[M == 4]) {
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess) return -2;
+                attr_s[M == 4] = lds_s;
+            }
+            FskArgs b = *a; b.R = R;
+            if (M == 2) hipLaunchKernelGGL(k_fsk_stream<2>, dim3(a->n_ch), dim3(FSK_THREADS), lds_s, s, b);
+            else        hipLaunchKernelGGL(k_fsk_stream<4>, dim3(a->n_ch), dim3(FSK_THREADS), lds_s, s, b);
+            return 0;
+        }
+    }
     const int n_in = (a->N + a->Ts / 2) > W ? (a->N + a->Ts / 2) : W;
     const int nA = n_in > M * W + (a->nsym + 1) ? n_in : M * W + (a->nsym + 1);
     int nB = M * a->Nmem;

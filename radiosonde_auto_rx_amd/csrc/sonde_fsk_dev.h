@@ -46,6 +46,7 @@ struct FskArgs {
     FskFrameRec *recs; int rec_cap;   // [n_ch][rec_cap]
     int max_fft;                      // most FFT blocks a frame can have
     float *eye;                       // [n_ch][8][160] |f_int| samples of the last frame for the eye diagram (fsk.c:857-889; row = trace * M + tone), may be nullptr
+    int R;                            // set by the launcher: ring length (samples per tone) of the pipelined kernel, a power of two
     int est_waves;                    // set by the launcher: waves that estimate the next frame while the oscillator of the current one runs (0..3)
     unsigned long long *prof;         // profiling aid (SONDE_FSK_PROF): [16] shader-clock cycles per phase of channel 0's frames, summed; nullptr = off
 };
