@@ -155,7 +155,7 @@ def bench_fsk_mixed(args, D, short=False):
         total_samples += n * (L // 2)
 
     # the three modem configurations are three engines with a stream each: driven from three host threads (the C calls release the GIL) their
-    # launches overlap on the GPU — one workgroup per channel, ~100 KB of LDS each, so a launch of ~340 channels alone leaves CUs idle
+    # launches overlap on the GPU — one workgroup per channel (23-37 KB of LDS), four to five of them resident per CU
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=len(engines))
 
@@ -170,7 +170,7 @@ def bench_fsk_mixed(args, D, short=False):
     dt, per = _timed_steps(D, step, steps, warmup)
     value = D.world * total_samples * steps / dt / 1e6
     kern = {kind: md.kernel_ms() for kind, _, _, _, _, md, _ in engines}
-    # dominant kernel k_fsk_demod: algorithmic bytes = 4 B per complex cs16 input sample (soft decisions out: 4 B per symbol)
+    # dominant kernel k_fsk_stream: algorithmic bytes = 4 B per complex cs16 input sample (soft decisions out: 4 B per symbol)
     # the three launches overlap: the rate follows from the step time, not from the sum of the kernels' own durations
     achieved = total_samples * 4 / (dt / steps) / 1e9
     out = None
@@ -184,9 +184,10 @@ def bench_fsk_mixed(args, D, short=False):
                        "channels_per_gpu": C, "realtime_channels": round(value * 1e6 / D.world / (total_samples / C), 1) if total_samples else 0,
                        "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per],
                        "kernel_ms_per_launch": {k: round(v[0], 4) for k, v in kern.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_fsk_demod", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                         "traffic": None, "note": "4 B per complex input sample over the sum of the three (overlapping) launches; one workgroup per channel walks its modem "
-                                                  "frames in order (timing loop and oscillator recurrences are serial in the reference too): latency-bound, see DESIGN.md"},
+            "roofline": {"bound": "hbm", "kernel": "k_fsk_stream", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                         "traffic": None, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel, its four waves a pipeline around the "
+                                                  "serial oscillator recurrence (one dependent complex multiply per sample, as in the reference): bound by that chain and by "
+                                                  "instruction issue, not by memory, see DESIGN.md"},
         }
         if D.world == 1 and not args.no_cpu_baseline:
             from oracle import bind

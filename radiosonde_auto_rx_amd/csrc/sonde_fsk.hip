@@ -565,7 +565,10 @@ __device__ __forceinline__ void pipe_publish(unsigned *p, const unsigned v) {
 #define PIPE_T0() (a.prof && ch == 0 ? __builtin_readcyclecounter() : 0ull)
 #define PIPE_ADD(k, t0) do { if (a.prof && ch == 0 && lane == 0) a.prof[k] += __builtin_readcyclecounter() - (t0); } while (0)
 template <int M>
-__global__ __launch_bounds__(FSK_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef FSK_STREAM_WPE
+#define FSK_STREAM_WPE 5      // waves per SIMD = workgroups per CU the registers allow: a thousand channels are exactly four per CU, and the
+#endif                        // dispatcher does not spread three kernels that evenly — without a fifth place the last workgroups wait for a whole round
+__global__ __launch_bounds__(FSK_THREADS) __attribute__((amdgpu_waves_per_eu(FSK_STREAM_WPE, FSK_STREAM_WPE)))
 void k_fsk_stream(const FskArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ FskPipe pp;
