@@ -24,6 +24,8 @@ db() { find "$OUT/$1" -name '*results.db' | head -1; }
 python tools/rocpd_summary.py "$(db t)" "$(db f)" "$(db w)" > "$OUT/${TAG}_bench_rocprofv3.txt" 2>&1
 python tools/rocpd_summary.py "$(db a)" "$(db a)" "$(db b)" > "$OUT/${TAG}_mix_decimate_sq.txt" 2>&1
 python tools/traffic_json.py "$(db f)" "$(db w)" k_mix_decimate50 1572864 4915200000 > "$OUT/${TAG}_mix_decimate_traffic.json" 2>/dev/null
+# phase profile of the two sync kernels (cycles of workgroup 0 / channel 0 per phase)
+SONDE_WF_PROF=1 SONDE_BENCH_NO_REPEAT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-configs --no-verify 2>&1 >/dev/null | grep " prof " > "$OUT/${TAG}_sync_phases.txt"
 for cfg in scan_wide fsk_mixed; do
   SONDE_FSK_PROF=1 timeout 300 python bench.py --config $cfg 2> "$OUT/${TAG}_bench_${cfg}.err" | tail -1 > "$OUT/${TAG}_bench_${cfg}.json"
   grep "fsk prof" "$OUT/${TAG}_bench_${cfg}.err" > "$OUT/${TAG}_fsk_phases.txt" 2>/dev/null; rm -f "$OUT/${TAG}_bench_${cfg}.err"
