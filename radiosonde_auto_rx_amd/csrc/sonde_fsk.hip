@@ -1,6 +1,10 @@
-// sonde_fsk.hip — gfx950 kernel of the batched 2-/4-FSK modem (the reference's utils/fsk.c fsk_demod_core).
+// sonde_fsk.hip — gfx950 kernels of the batched 2-/4-FSK modem (the reference's utils/fsk.c fsk_demod_core).
 //
-// One workgroup per channel walks the modem frames that fit into the samples queued for that channel — the frame loop
+// Two schedules of the same arithmetic:
+//   k_fsk_stream   the workgroup's four waves as a pipeline around the serial oscillator walk (producer / consumer / two estimators,
+//                  further down) — the one that runs for every sonde configuration (Ndft <= 256)
+//   k_fsk_demod    frame at a time, every stage on all 256 threads with workgroup barriers between them — for longer transforms
+// k_fsk_demod: one workgroup per channel walks the modem frames that fit into the samples queued for that channel — the frame loop
 // is sequential in the reference too (nin, the smoothed spectrum Sf and the oscillator phases feed the next frame).
 // Inside a frame everything that is data-parallel runs on 256 threads out of LDS:
 //   frequency estimator   half-overlapped Hann-windowed FFTs (one wave per block), magnitude, per-bin exponential

@@ -7,8 +7,10 @@
 //                    case runs a generated, hand-scheduled instruction stream (md_fast_gen.h, tools/gen_md_fast.py).
 //   k_if_chain       IF low-pass, conj-product FM discriminator, two-tone sliding correlator, FM low-pass
 //                    (demod_mod.c:765-808,843-852)
-//   k_header_corr    matched-filter header correlation for every end sample (getCorrDFT, demod_mod.c:148-222,
-//                    evaluated in the time domain instead of per-window FFTs)
+//   k_sync_plan,     the header search of find_header with the reference's own 8192-point transform per window (getCorrDFT,
+//   k_sync_window_fft demod_mod.c:148-225): the windows the sync will ask for are planned, then evaluated one workgroup each
+//   k_header_corr    the same correlation in the time domain for every end sample — used by --dc engines only (zero-mean
+//                    windows and the FM-stream fallback are evaluated from the correlation ring)
 //   k_framesync      per-channel find_header / headcmp / read_softbit2p state machine + RS41 byte framing
 //                    + RS(255,231) syndromes (demod_mod.c:1533-1617,870-938,1087-1175; rs41mod.c:2900-2962)
 //   k_dc_update      running IQ-DC mean hand-over at segment boundaries (demod_mod.c:495-504)
