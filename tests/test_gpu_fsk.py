@@ -76,6 +76,29 @@ def test_fsk_chunking_invariance():
     _check(sd, recs, g)
 
 
+@pytest.mark.parametrize("name", ["fsk_rs41_48k_mask", "fsk_dfm_50k", "fsk_m10_48080", "fsk_rs41_48k_cu8"])
+def test_fsk_random_chunks_give_the_same_frames(name):
+    """Calls of random length — from a few samples (launches that cannot produce a frame) to several frames — leave the same stream as
+    one-second calls: the pipelined kernel carries its oscillator phases, the last f_dc samples, the smoothed spectrum and the pending
+    frame length from launch to launch, and decides per launch which frames it can finish."""
+    g = load_fsk(name)
+    x, case = fsk_capture(name)
+    per = 1 if case["fmt"] == 1 else 2
+    n = x.shape[-1] // per
+    rng = np.random.default_rng(11)
+    N = case["cap"]["sr"] // case["Rs"] * case["nsym"]
+    md = _modem(case, max_chunk=4 * N)
+    sds, recs, s0 = [], [], 0
+    while s0 < n:
+        c = int(rng.choice([7, 33, N // 3, N - 1, N, N + 1, 2 * N + 5, 3 * N + 17]))
+        md.process_host(x[..., per * s0:per * min(n, s0 + c)])
+        sd, rc = md.fetch(0)
+        sds.append(sd); recs += rc
+        s0 += c
+    _check(np.concatenate(sds), recs, g)
+    assert np.array_equal(md.stats(0)["Sf"], g["Sf"])
+
+
 def test_fsk_multichannel_batch():
     """Two channels in one engine keep their single-channel results (independent nin / phase / spectrum state)."""
     ga, gb = load_fsk("fsk_rs41_48k_mask"), load_fsk("fsk_rs41_48k_cu8")
