@@ -25,6 +25,7 @@ struct sonde_fsk {
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
     FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; std::vector<uint8_t> h_hb;
     std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
+    bool pinned = false;
     size_t unit = 4;
     uint32_t wr = 0;
     std::vector<uint32_t> wr_ch; uint32_t *d_wr = nullptr;    // per-channel write positions once sonde_fsk_process_host_var is used
@@ -151,6 +152,13 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.perm = f->d_perm; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
     a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.hb = f->d_hb; a.recs = f->d_recs;
     f->h_sd.resize((size_t)C * a.sd_cap); f->h_hb.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
+    // the per-launch results come back into these (never resized again): page-locked, so that the copies are real asynchronous DMA and not staged through
+    // a bounce buffer — with the pipelined kernel the copies of a thousand channels were a fifth of a step
+    f->pinned = hipHostRegister(f->h_sd.data(), f->h_sd.size() * sizeof(float), hipHostRegisterDefault) == hipSuccess
+             && hipHostRegister(f->h_hb.data(), f->h_hb.size(), hipHostRegisterDefault) == hipSuccess
+             && hipHostRegister(f->h_recs.data(), f->h_recs.size() * sizeof(FskFrameRec), hipHostRegisterDefault) == hipSuccess
+             && hipHostRegister(f->h_chan.data(), f->h_chan.size() * sizeof(FskChan), hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();                          // (registration is an optimisation: pageable buffers work too)
     HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     *out = f;
     return 0;
@@ -177,6 +185,7 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         }
         hipFree(f->d_prof);
     }
+    if (!f->h_sd.empty()) { hipHostUnregister(f->h_sd.data()); hipHostUnregister(f->h_hb.data()); hipHostUnregister(f->h_recs.data()); hipHostUnregister(f->h_chan.data()); (void)hipGetLastError(); }
     void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_wr };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;

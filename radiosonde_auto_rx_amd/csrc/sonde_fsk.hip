@@ -78,6 +78,18 @@ __device__ __forceinline__ float2 fsk_sample(const FskArgs &a, int ch, uint32_t 
     return make_float2(((float)(raw & 0xffu) - 127.0f) / 128.0f, ((float)(raw >> 8) - 127.0f) / 128.0f);
 }
 
+// the same with the channel's ring base already formed (the consumer's inner loop)
+__device__ __forceinline__ float2 fsk_sample_at(const FskArgs &a, const void *base, uint32_t p) {
+    if (a.format == FMT_CS16) {
+        const uint32_t raw = reinterpret_cast<const uint32_t *>(base)[p];
+        return make_float2(div1000((float)(short)(raw & 0xffffu)), div1000((float)(((int)raw) >> 16)));
+    }
+    if (a.format == FMT_CF32) return reinterpret_cast<const float2 *>(base)[p];
+    if (a.format == FMT_S16) return make_float2(div1000((float)reinterpret_cast<const int16_t *>(base)[p]), 0.f);
+    const uint16_t raw = reinterpret_cast<const uint16_t *>(base)[p];
+    return make_float2(((float)(raw & 0xffu) - 127.0f) / 128.0f, ((float)(raw >> 8) - 127.0f) / 128.0f);
+}
+
 // one butterfly stage of the reference's transform on buf[Ndft], butterflies lt, lt + TPF, ...  (kiss_fft.c kf_bfly4 / kf_bfly2: separately
 // rounded mul / add, so that Sf and with it every estimator decision is the reference's bit for bit)
 __device__ __forceinline__ void fsk_stage(float2 *buf, const float2 *tw, const int p, const int m, const int fs, const int Ndft, const int lt, const int TPF) {
@@ -103,6 +115,9 @@ __device__ __forceinline__ void fsk_stage(float2 *buf, const float2 *tw, const i
     }
 }
 
+#ifndef FSK_NAP
+#define FSK_NAP 1               // s_sleep argument of the wait loops (64 clocks each)
+#endif
 #define FSK_SPIN_MAX (1u << 21)   // iterations of a wait loop (64 clocks of sleep each, ~60 ms) after which a wave gives up
 #define FSK_AE 4               // transform bins per lane the ahead-estimator holds in registers: Ndft <= 256 (sondes: 64, 128, 256)
 // barrier of the `n` estimator waves only (wave 0 is inside the oscillator walk and takes no part): a counter in LDS that only grows —
@@ -114,7 +129,7 @@ __device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned 
     if (lane == 0) {
         atomicAdd(cnt, 1u);
         unsigned spins = 0;                                       // a wait that long means a bug: give up instead of hanging the device
-        while (*reinterpret_cast<volatile unsigned *>(cnt) < n * phase && ++spins < FSK_SPIN_MAX) __builtin_amdgcn_s_sleep(1);
+        while (*reinterpret_cast<volatile unsigned *>(cnt) < n * phase && ++spins < FSK_SPIN_MAX) __builtin_amdgcn_s_sleep(FSK_NAP);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -132,7 +147,9 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
     const float tc = a.tc, omt = 1 - tc;
     // a wave takes BPW blocks at a time, one per group of GL lanes, FSK_AE transform elements per lane: short transforms (Ndft 64 / 128) would
     // leave most lanes of a wave without a butterfly otherwise
-    const int BPW = (FSK_AE * WAVE) / Ndft, GL = WAVE / BPW, sub = lane / GL, lt = lane - sub * GL;
+    // (a.est_bpw: the launcher may allow fewer blocks per wave than the lanes could take, when the scratch has to be small)
+    const int BPW = min(a.est_bpw > 0 ? a.est_bpw : 64, (FSK_AE * WAVE) / Ndft), GL = WAVE / BPW, sub = lane / GL, lt = lane - sub * GL;
+    const int EPL = Ndft / GL;                                     // transform elements per lane, <= FSK_AE
     const int slot = gw * BPW + sub, RB = NG * BPW;               // this lane group's block within a round; blocks per round
     float2 *buf = s_fb + slot * Ndft;
     float *mag = reinterpret_cast<float *>(buf);                // the block's magnitudes, fftshifted, over the first half of its scratch
@@ -140,12 +157,12 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
     // window, permutation and the samples of the group's NEXT block live in registers: a round then waits for LDS only
     float hn[FSK_AE]; int pm[FSK_AE]; float2 xs[FSK_AE];
 #pragma unroll
-    for (int e = 0; e < FSK_AE; e++) { const int i = lt + e * GL; hn[e] = a.hann[i]; pm[e] = a.perm[i]; xs[e] = make_float2(0.f, 0.f); }
+    for (int e = 0; e < FSK_AE; e++) { const int i = lt + e * GL; hn[e] = 0.f; pm[e] = 0; xs[e] = make_float2(0.f, 0.f); if (e < EPL) { hn[e] = a.hann[i]; pm[e] = a.perm[i]; } }
     auto fetch = [&](const int j) {
 #pragma unroll
         for (int e = 0; e < FSK_AE; e++) {
             const int i = lt + e * GL;
-            if (j < numffts) xs[e] = fsk_sample(a, ch, (rd + (uint32_t)(i + j * (Ndft / 2))) & (a.ring - 1));
+            if (e < EPL && j < numffts) xs[e] = fsk_sample(a, ch, (rd + (uint32_t)(i + j * (Ndft / 2))) & (a.ring - 1));
         }
     };
     fetch(slot);
@@ -155,7 +172,7 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
         const bool act = j < numffts;
         if (act) {
 #pragma unroll
-            for (int e = 0; e < FSK_AE; e++) buf[pm[e]] = make_float2(hn[e] * xs[e].x, hn[e] * xs[e].y);
+            for (int e = 0; e < FSK_AE; e++) if (e < EPL) buf[pm[e]] = make_float2(hn[e] * xs[e].x, hn[e] * xs[e].y);
         }
         fetch(j + RB);                                         // in flight during the transform
         __builtin_amdgcn_wave_barrier();
@@ -163,11 +180,11 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
         // magnitudes in place: every lane reads its bins first, then the wave writes (mag[q] overlays buf[q / 2])
         float mg[FSK_AE];
 #pragma unroll
-        for (int e = 0; e < FSK_AE; e++) { mg[e] = 0.f; if (act) { const float2 X = buf[lt + e * GL]; mg[e] = sqrtf((X.x * X.x) + (X.y * X.y)); } }
+        for (int e = 0; e < FSK_AE; e++) { mg[e] = 0.f; if (act && e < EPL) { const float2 X = buf[lt + e * GL]; mg[e] = sqrtf((X.x * X.x) + (X.y * X.y)); } }
         __builtin_amdgcn_wave_barrier();
         if (act) {
 #pragma unroll
-            for (int e = 0; e < FSK_AE; e++) mag[(lt + e * GL + Ndft / 2) & (Ndft - 1)] = mg[e];
+            for (int e = 0; e < FSK_AE; e++) if (e < EPL) mag[(lt + e * GL + Ndft / 2) & (Ndft - 1)] = mg[e];
         }
         fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
         const int nb = min(RB, numffts - j0);
@@ -555,7 +572,7 @@ __device__ __forceinline__ bool pipe_wait_ge(const unsigned *p, const unsigned v
     unsigned spins = 0;
     while ((int)(pipe_ld(p) - v) < 0) {
         if (++spins > FSK_SPIN_MAX || pipe_ld(abort_flag)) { __atomic_store_n(abort_flag, 1u, __ATOMIC_RELAXED); return false; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(FSK_NAP);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return true;
@@ -621,7 +638,7 @@ void k_fsk_stream(const FskArgs a) {
                     if ((int)(pipe_ld(&pp.est_seq) - (unsigned)(k + 1)) >= 0) break;
                     if ((int)(pipe_ld(&pp.nin_seq) - (unsigned)(k + 1)) >= 0 && pipe_ldi(&pp.nin[k & 1]) == 0) { stop = true; break; }
                     if (++spins > FSK_SPIN_MAX || pipe_ld(&pp.abort)) { __atomic_store_n(&pp.abort, 1u, __ATOMIC_RELAXED); stop = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(FSK_NAP);
                 }
                 PIPE_ADD(1, tw0);
                 if (stop) break;
@@ -641,7 +658,7 @@ void k_fsk_stream(const FskArgs a) {
                             const unsigned long long tw1 = PIPE_T0();
                             while ((int)(pos + 64u - (uint32_t)R) - pipe_ldi(&pp.cons_free) > 0) {
                                 if (++spins > FSK_SPIN_MAX || pipe_ld(&pp.abort)) { __atomic_store_n(&pp.abort, 1u, __ATOMIC_RELAXED); break; }
-                                __builtin_amdgcn_s_sleep(1);
+                                __builtin_amdgcn_s_sleep(FSK_NAP);
                             }
                             PIPE_ADD(2, tw1);
                             if (pipe_ld(&pp.abort)) { remaining = 0; have_nin = true; break; }
@@ -727,6 +744,10 @@ void k_fsk_stream(const FskArgs a) {
         int nin = pipe_ldi(&pp.nin[0]);
         uint32_t E_last = 0;
         constexpr int WB = WAVE / M;                                    // integrator windows per pass
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const int unit = a.format == FMT_CS16 ? 4 : a.format == FMT_CF32 ? 8 : 2;
+        const char *in_ch = reinterpret_cast<const char *>(a.in) + (size_t)ch * a.ring * unit;
+        const int sshift = (step & (step - 1)) == 0 ? __builtin_ctz((unsigned)step) : -1;      // Ts / P is 1, 2 or 4 for the sondes
         const unsigned long long tc0_ = PIPE_T0();
         for (int k = 0; nin != 0; k++) {
             const uint32_t E = S + (uint32_t)nin;
@@ -737,41 +758,48 @@ void k_fsk_stream(const FskArgs a) {
                 uint32_t ce = (c | 63u) + 1u; if ((int32_t)(ce - E) > 0) ce = E;      // pieces end where the producer reports (multiples of 64, frame ends)
                 const int cl = (int)(ce - c);
                 float2 x = make_float2(0.f, 0.f);
-                if (lane < cl) x = fsk_sample(a, ch, (rd0 + c + (uint32_t)lane) & (a.ring - 1));
+                if (lane < cl) x = fsk_sample_at(a, in_ch, (rd0 + c + (uint32_t)lane) & (a.ring - 1));
                 // (both global reads of the piece are issued before the wait for the producer: the input sample and the timing phasor of the lane's next window)
                 const float2 ph_next = (i_done + lane / M < W) ? a.phi_ft[i_done + lane / M] : make_float2(0.f, 0.f);
                 const unsigned long long tw0 = PIPE_T0();
                 if (!pipe_wait_ge(&pp.prod_pos, ce, &pp.abort)) { nin = 0; break; }
                 PIPE_ADD(5, tw0);
                 if (lane < cl) {
+                    // x conj(p): the products x.x p.x, x.y p.y and x.y p.x, x.x p.y as two packed multiplies, then one add and one subtract —
+                    // cmult(x, (p.x, -p.y)) value for value (negating a factor negates the rounded product)
+                    const v2f xv = {x.x, x.y}, xs = {x.y, x.x};
 #pragma unroll
-                    for (int m = 0; m < M; m++) { float2 *q = s_ring + m * R + ((c + (uint32_t)lane) & rmask); const float2 p = *q; *q = cmult(x, make_float2(p.x, -p.y)); }
+                    for (int m = 0; m < M; m++) {
+                        v2f *q = reinterpret_cast<v2f *>(s_ring + m * R + ((c + (uint32_t)lane) & rmask));
+                        const v2f p = *q, aa = xv * p, bb = xs * p;
+                        *q = v2f{aa.x + aa.y, bb.x - bb.y};
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 // integrator windows complete by now (fsk.c:659-668): window i reads f_dc[i step .. i step + Ts)
-                int i_new = ((int32_t)ce - wbase - Ts) / step + 1;
-                if ((int32_t)ce - wbase - Ts < 0) i_new = 0;
+                const int32_t span = (int32_t)ce - wbase - Ts;
+                int i_new = span < 0 ? 0 : (sshift >= 0 ? (span >> sshift) : span / step) + 1;
                 if (i_new > W) i_new = W;
                 // a lane per (window, tone): WB windows at a time.  The Ts samples of a window are summed in order; they are contiguous in the ring
                 // unless the window straddles its end
                 for (int ib = i_done; ib < i_new; ib += WB) {
                     const int wl = lane / M, m = lane - wl * M, i = ib + wl;
                     if (i < i_new) {
-                        const float2 *rg = s_ring + m * R;
+                        const v2f *rg = reinterpret_cast<const v2f *>(s_ring + m * R);
                         const uint32_t q0 = (uint32_t)(wbase + i * step) & rmask;
-                        float2 acc = make_float2(0.f, 0.f);
+                        v2f acc = {0.f, 0.f};                           // (re, im) advance together: one packed add per sample, each component rounded as before
                         if (q0 + (uint32_t)Ts <= (uint32_t)R) {
-                            const float2 *src = rg + q0;
+                            const v2f *src = rg + q0;
                             int j = 0;
                             for (; j + 5 <= Ts; j += 5) {                // (Ts is 5, 10 or 20 for the sondes)
-                                const float2 v0 = src[j], v1 = src[j + 1], v2 = src[j + 2], v3 = src[j + 3], v4 = src[j + 4];
-                                acc = cadd(acc, v0); acc = cadd(acc, v1); acc = cadd(acc, v2); acc = cadd(acc, v3); acc = cadd(acc, v4);
+                                const v2f v0 = src[j], v1 = src[j + 1], v2 = src[j + 2], v3 = src[j + 3], v4 = src[j + 4];
+                                acc += v0; acc += v1; acc += v2; acc += v3; acc += v4;
                             }
-                            for (; j < Ts; j++) acc = cadd(acc, src[j]);
+                            for (; j < Ts; j++) acc += src[j];
                         } else {
-                            for (int j = 0; j < Ts; j++) acc = cadd(acc, rg[(q0 + (uint32_t)j) & rmask]);
+                            for (int j = 0; j < Ts; j++) acc += rg[(q0 + (uint32_t)j) & rmask];
                         }
-                        s_fint[m * W + i] = acc;
+                        s_fint[m * W + i] = make_float2(acc.x, acc.y);
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (i < i_new && m == 0) {                          // fine timing: sum_i (sum_m |f_int[m]|^2) phi_ft[i]  (fsk.c:682-703)
@@ -923,9 +951,24 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     if (a->M != 2 && a->M != 4) return -1;
     {   // the pipelined kernel, where its estimator fits (Ndft <= 256: every sonde configuration)
         static const char *st_env = getenv("SONDE_FSK_STREAM");          // A/B aid: 0 = the frame-at-a-time kernel
-        int R = 256; while (R < a->NT + 128) R <<= 1;
-        const size_t lds_s = (size_t)M * R * sizeof(float2) + (size_t)M * W * sizeof(float2) + (size_t)((2 * a->nsym + 1) & ~1) * sizeof(float) + 64 * sizeof(float2)
-                           + (size_t)2 * a->Ndft * sizeof(float) + (size_t)a->Ndft * sizeof(float2) + (size_t)2 * FSK_AE * 64 * sizeof(float2);
+        // LDS of a channel: f_int, the Eb/N0 terms, the timing products, Sf + search copy, twiddles — fixed — plus the ring (R samples per tone) and the
+        // scratch of the two estimator waves (bpw blocks of Ndft each).  A longer ring lets the oscillator run on while the consumer is busy with a frame's
+        // soft decisions (R = 256: it stood still 17-40 % of the time); it is taken as long as the channel stays in its bracket of workgroups per CU
+        // (160 KB / 5 or / 4).  (Giving up estimator blocks per wave for a longer ring was tried for RS41: the estimators then became what the oscillator waits for.)
+        const size_t fixed = (size_t)M * W * sizeof(float2) + (size_t)((2 * a->nsym + 1) & ~1) * sizeof(float) + 64 * sizeof(float2)
+                           + (size_t)2 * a->Ndft * sizeof(float) + (size_t)a->Ndft * sizeof(float2);
+        int Rmin = 256; while (Rmin < a->NT + 128) Rmin <<= 1;
+        const int bpw_max = (FSK_AE * 64) / a->Ndft > 0 ? (FSK_AE * 64) / a->Ndft : 1;
+        auto total = [&](int R, int bpw) { return fixed + (size_t)M * R * sizeof(float2) + (size_t)2 * bpw * a->Ndft * sizeof(float2); };
+        const size_t small = total(Rmin, bpw_max);
+        const size_t bracket = small <= 160 * 1024 / 5 - 512 ? 160 * 1024 / 5 - 512 : small <= 160 * 1024 / 4 - 512 ? 160 * 1024 / 4 - 512 : small;
+        int R = Rmin, bpw = bpw_max;
+        static const char *r_env = getenv("SONDE_FSK_RING");                 // A/B aid: ring length
+        if (r_env && atoi(r_env) >= Rmin) { R = atoi(r_env); while (R & (R - 1)) R++; }
+        else {
+            for (int cand = 2 * Rmin; cand > Rmin; cand >>= 1) if (total(cand, bpw_max) <= bracket) { R = cand; break; }
+        }
+        const size_t lds_s = total(R, bpw);
         if (!(st_env && atoi(st_env) == 0) && a->Ndft <= FSK_AE * 64 && a->Ndft >= FSK_AE && a->P >= 1 && a->Ts % a->P == 0 && lds_s <= 150 * 1024) {
             static size_t attr_s[2] = { 0, 0 };
             const void *fn = M == 2 ? reinterpret_cast<const void *>(k_fsk_stream<2>) : reinterpret_cast<const void *>(k_fsk_stream<4>);
@@ -933,7 +976,7 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess) return -2;
                 attr_s[M == 4] = lds_s;
             }
-            FskArgs b = *a; b.R = R;
+            FskArgs b = *a; b.R = R; b.est_bpw = bpw;
             if (M == 2) hipLaunchKernelGGL(k_fsk_stream<2>, dim3(a->n_ch), dim3(FSK_THREADS), lds_s, s, b);
             else        hipLaunchKernelGGL(k_fsk_stream<4>, dim3(a->n_ch), dim3(FSK_THREADS), lds_s, s, b);
             return 0;
@@ -956,7 +999,7 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     if (a->Ndft > FSK_AE * 64 || a->Ndft < FSK_AE) ng = 0;                // a lane holds FSK_AE elements of its block
     const size_t lds = base + (size_t)ng * per_wave;
     if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
-    FskArgs b = *a; b.est_waves = ng; a = &b;
+    FskArgs b = *a; b.est_waves = ng; b.est_bpw = 0; a = &b;
     if (a->M != 2 && a->M != 4) return -1;
     static size_t attr[2] = { 0, 0 };
     const void *fn = a->M == 2 ? reinterpret_cast<const void *>(k_fsk_demod<2>) : reinterpret_cast<const void *>(k_fsk_demod<4>);

@@ -47,6 +47,7 @@ struct FskArgs {
     int max_fft;                      // most FFT blocks a frame can have
     float *eye;                       // [n_ch][8][160] |f_int| samples of the last frame for the eye diagram (fsk.c:857-889; row = trace * M + tone), may be nullptr
     int R;                            // set by the launcher: ring length (samples per tone) of the pipelined kernel, a power of two
+    int est_bpw;                      // set by the launcher: transform blocks a wave of the ahead-estimator takes at a time (0 = as many as its lanes hold)
     int est_waves;                    // set by the launcher: waves that estimate the next frame while the oscillator of the current one runs (0..3)
     unsigned long long *prof;         // profiling aid (SONDE_FSK_PROF): [16] shader-clock cycles per phase of channel 0's frames, summed; nullptr = off
 };
