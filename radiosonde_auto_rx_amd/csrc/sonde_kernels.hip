@@ -1610,6 +1610,9 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
 #ifndef WF_LU
 #define WF_LU 1
 #endif
+#ifndef WF_LB
+#define WF_LB 4               // window samples a thread fetches together (8: no faster, more spills)
+#endif
 // profiling aid (SONDE_WF_PROF): thread 0 of workgroup 0 adds the shader-clock cycles since the previous mark to phase k
 #define WF_MARK(k) do { if (a.prof && blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
 __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int ch, WinItem *it, float2 *x, float2 *tws, float *s_rf, int *s_ri) {
@@ -1621,10 +1624,21 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
     const int64_t start = (int64_t)pos - (wl - 1);
     // xn[i] = bufs[pos - (K+L-1) + i], i < K+L, zero padded (:168-169); bit-reversed for the DIT network, natural order for the norm
-    for (int i = tid; i < N; i += WF_THREADS) {
-        const int64_t p = start + i;
-        const float v = (i < wl && p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
-        x[XI(brev13(i))] = make_float2(v, 0.f);
+    // (all loads of a thread are issued before the first store: one memory round trip for the window instead of one per element)
+    {
+        constexpr int NL = SC_N / WF_THREADS;
+#pragma unroll 1
+        for (int h = 0; h < NL; h += WF_LB) {
+            float v[WF_LB];
+#pragma unroll
+            for (int u = 0; u < WF_LB; u++) {
+                const int i = tid + (h + u) * WF_THREADS;
+                const int64_t p = start + i;
+                v[u] = (i < wl && p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < WF_LB; u++) x[XI(brev13(tid + (h + u) * WF_THREADS))] = make_float2(v[u], 0.f);
+        }
     }
     __syncthreads();
     WF_MARK(0);
