@@ -14,7 +14,7 @@
 #include "sonde_hip.h"
 #include "broker_client.h"
 #include "sonde_dfm.h"
-#include "wav_header.h"
+#include "cli_common.h"
 
 static sonde_dfm_dec_t *g_dec = NULL;
 static int g_raw = 0, g_ecc = 0;
@@ -44,13 +44,14 @@ static void emit_rec(const void *r) { emit_frame((const sonde_dfm_frame_t *)r); 
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
-    double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0, rawhex = 0;
+    cli_in_t in;
+    int raw = 0, softin = 0, opt_inv = 0, opt_auto = 0, opt_bin = 0, rawhex = 0, oc;
     FILE *fp = stdin;
     sonde_dfm_opts_t dopt;
     int force_ecc = 0, cfreq = -1;
     memset(&dopt, 0, sizeof dopt);
     memset(&cfg, 0, sizeof cfg);
+    cli_in_init(&in, 0, 32.0);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_DFM09;
     setbuf(stdout, NULL);
@@ -84,41 +85,12 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--jsn_cfq")) { if (++i >= argc) return -1; cfreq = atoi(argv[i]); if (cfreq < 300000000) cfreq = -1; }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
         else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; g_shift = atoi(argv[i]); if (g_shift > 4) g_shift = 4; if (g_shift < -4) g_shift = -4; }
-        else if (!strcmp(a, "--IQ")) {
-            if (++i >= argc) return -1;
-            fq = atof(argv[i]);
-            if (fq < -0.5) fq = -0.5;
-            if (fq > 0.5) fq = 0.5;
-            have_iq = 1; iq_mode = 5;
-        }
-        else if (!strcmp(a, "--iq0")) { have_iq = 1; iq_mode = 1; }      /* IF-rate IQ, FM discriminator */
-        else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }      /* IF-rate IQ, tone correlator  */
-        else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
-        else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
-        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;               /* --IQ only, like the reference */
-        else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;                     /* header dc / AFC */
-        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
-        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
-        else if (!strcmp(a, "--lpbw")) {
-            if (++i >= argc) return -1;
-            double bw = atof(argv[i]);
-            if (bw > 4.6 && bw < 32.0) cfg.lpiq_bw = (int)(bw * 1e3);
-            cfg.opt_lp |= SONDE_LP_IQ;
-        }
+        else if ((oc = cli_input_option(argc, argv, &i, &cfg, &in)) != 0) { if (oc < 0) return -1; }      /* --IQ, --iq0/2/3, --iqdc, --noLUT, --dc, --lpIQ, --lpFM, --lpbw, --min, --ch2, "- <sr> <bits>" */
         else if (!strcmp(a, "--br")) {                   /* symbol rate; out of range = the default (dfm09mod.c) */
             if (++i >= argc) return -1;
             g_baud = atof(argv[i]);
             if (g_baud < 2200 || g_baud > 2800) g_baud = 2500.0;
         }
-        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
-        else if (!strcmp(a, "-")) {
-            if (i + 2 >= argc) return -1;
-            cfg.sample_rate = atoi(argv[++i]);
-            cfg.bits = atoi(argv[++i]);
-            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
-            have_pcm = 1;
-        }
-        else if (!strcmp(a, "--ch2")) wav_ch = 1;
         else if (!strcmp(a, "--softin")) softin = 1;
         else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "--bin")) opt_bin = 1;                       /* one byte per hard bit */
@@ -168,21 +140,10 @@ int main(int argc, char **argv) {
         return 0;
     }
     cfg.opt_inv = opt_inv; cfg.opt_auto = opt_auto;
-    if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
-    if (have_iq && !have_pcm) {                      /* IQ in a 2-channel WAV: header, then the same sample pairs */
-        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-        if (nch != 2) { fprintf(stderr, "dfm09mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
-    }
-    if (iq_mode == 5 && cfg.opt_dc) cfg.opt_lp |= SONDE_LP_FM;          /* as the reference (dfm09mod.c: option_iq == 5 && option_dc) */
-    if (iq_mode != 5) cfg.opt_nolut = 0;
-    if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
-    if (!have_iq) {                                  /* FM audio: WAV on stdin or from a file (opt_iq = 0) */
-        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-        cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
-        cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
-    }
+    if (cli_input_setup("dfm09mod", fp, &cfg, &in) < 0) return -1;      /* raw data must be IQ; WAV header; --dc with --IQ implies --lpFM; cfg.input */
+    cfg.lpiq_bw = in.lpiq_bw;                         /* 0 = the sonde type's own */
     {   /* "freq" of the JSON: (cfreq - xlt_fq * sr + 500) / 1e3 (dfm09mod.c:1554-1557) */
-        const double xlt = (iq_mode == 5) ? -fq : 0.0;
+        const double xlt = (in.iq_mode == 5) ? -in.fq : 0.0;
         if (make_decoder(&dopt, raw, cfg.ecc_level, opt_auto, cfreq > 0 ? (int)((cfreq - xlt * cfg.sample_rate + 500) / 1e3) : 0) < 0) return -1;
     }
 
@@ -201,40 +162,33 @@ int main(int argc, char **argv) {
     } else {
         if (g_baud > 0) {                            /* --br: dsp.br / dsp.sps replaced before init_buffers() */
             sonde_generic_t gb; memset(&gb, 0, sizeof gb); gb.baud = (float)g_baud;
-            rc = sonde_engine_create_generic(&cfg, &fq, &gb, &eng);
-        } else rc = sonde_engine_create(&cfg, &fq, &eng);
+            rc = sonde_engine_create_generic(&cfg, &in.fq, &gb, &eng);
+        } else rc = sonde_engine_create(&cfg, &in.fq, &eng);
         if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 2 + g_shift);
         if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
         sonde_engine_info(eng, &info);
     }
-    if (iq_mode == 5) {
+    if (in.iq_mode == 5) {
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
     }
-    const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);  /* bytes per input sample / audio frame */
-
-    int chunk = cfg.sample_rate / 10;
-    chunk -= chunk % info.decM;
-    if (chunk < info.decM) chunk = info.decM;
-    int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
+    const size_t unit = cli_sample_bytes(&cfg, &in);  /* bytes per input sample / audio frame */
+    cli_reader_t rd;
+    if (cli_reader_init(&rd, unit, cfg.sample_rate, info.decM) < 0) return -1;
     sonde_dfm_frame_t frames[128];
-    size_t have = 0;
     for (;;) {
-        size_t got = fread((char *)buf + have, 1, (size_t)chunk * unit - have, fp);
-        have += got;
-        int n = (int)(have / unit);
-        n -= n % info.decM;
+        int n;
+        const size_t got = cli_reader_fill(&rd, fp, &n);
         if (n > 0) {
             if (use_broker) {
-                if (brk_demod_feed(&brk, buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
+                if (brk_demod_feed(&brk, rd.buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
             } else {
-                rc = sonde_engine_process_host(eng, buf, n, n);
+                rc = sonde_engine_process_host(eng, rd.buf, n, n);
                 if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
                 int k = sonde_engine_fetch_dfm(eng, frames, 128, 0);
                 for (int i = 0; i < k; i++) emit_frame(&frames[i]);
             }
-            memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
-            have -= (size_t)n * unit;
+            cli_reader_consume(&rd, n);
         }
         if (got == 0) break;
     }
@@ -245,6 +199,6 @@ int main(int argc, char **argv) {
     }
     if (eng) sonde_engine_destroy(eng);
     brk_demod_close(&brk);
-    free(buf);
+    cli_reader_free(&rd);
     return 0;
 }

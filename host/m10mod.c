@@ -17,7 +17,7 @@
 #include "sonde_hip.h"
 #include "broker_client.h"
 #include "sonde_m10.h"
-#include "wav_header.h"
+#include "cli_common.h"
 
 static int g_shift = 0;      /* -d <shift>: added to the bit offset of the slicer (m10mod.c:1184,1245-1251,1436) */
 static int g_chk3 = 0;                       /* --chk3 */
@@ -47,11 +47,12 @@ static void emit_rec(const void *r) { emit_frame((const sonde_m10_frame_t *)r); 
 
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
-    double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, raw = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, rawhex = 0, cfreq = -1;
+    cli_in_t in;
+    int raw = 0, softin = 0, rawhex = 0, cfreq = -1, oc;
     FILE *fp = stdin;
     sonde_m10_opts_t dopt;
     memset(&dopt, 0, sizeof dopt);
+    cli_in_init(&in, 0, 48.0);
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_M10;
@@ -82,37 +83,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-i") || !strcmp(a, "--invert")) { /* irrelevant for the differential code (m10mod.c:1447) */ }
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; cfg.thres = (float)atof(argv[i]); }
         else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; g_shift = atoi(argv[i]); if (g_shift > 4) g_shift = 4; if (g_shift < -4) g_shift = -4; }
-        else if (!strcmp(a, "--IQ")) {
-            if (++i >= argc) return -1;
-            fq = atof(argv[i]);
-            if (fq < -0.5) fq = -0.5;
-            if (fq > 0.5) fq = 0.5;
-            have_iq = 1; iq_mode = 5;
-        }
-        else if (!strcmp(a, "--iq0")) { have_iq = 1; iq_mode = 1; }
-        else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }
-        else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
-        else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
-        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;
-        else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;
-        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
-        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
-        else if (!strcmp(a, "--lpbw")) {
-            if (++i >= argc) return -1;
-            double bw = atof(argv[i]);
-            if (bw > 4.6 && bw < 48.0) cfg.lpiq_bw = (int)(bw * 1e3);
-            cfg.opt_lp |= SONDE_LP_IQ;
-        }
+        else if ((oc = cli_input_option(argc, argv, &i, &cfg, &in)) != 0) { if (oc < 0) return -1; }      /* --IQ, --iq0/2/3, --iqdc, --noLUT, --dc, --lpIQ, --lpFM, --lpbw, --min, --ch2, "- <sr> <bits>" */
         else if (!strcmp(a, "--chk3")) g_chk3 = 1;       /* bits re-decided from both soft values (m10mod.c:1233,1476-1479; IQ forms only) */
-        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
-        else if (!strcmp(a, "--ch2")) wav_ch = 1;
-        else if (!strcmp(a, "-")) {
-            if (i + 2 >= argc) return -1;
-            cfg.sample_rate = atoi(argv[++i]);
-            cfg.bits = atoi(argv[++i]);
-            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
-            have_pcm = 1;
-        }
         else if (a[0] != '-') {
             fp = fopen(a, "rb");
             if (fp == NULL) { fprintf(stderr, "error: open %s\n", a); return -1; }
@@ -155,22 +127,11 @@ int main(int argc, char **argv) {
         sonde_softin_destroy(si);
         return 0;
     }
-    if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
-    if (have_iq && !have_pcm) {
-        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-        if (nch != 2) { fprintf(stderr, "m10mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
-    }
-    if (iq_mode == 5 && cfg.opt_dc) cfg.opt_lp |= SONDE_LP_FM;
-    if (iq_mode != 5) cfg.opt_nolut = 0;
-    if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
-    if (!have_iq) {
-        if (wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-        cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
-        cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
-    }
+    if (cli_input_setup("m10mod", fp, &cfg, &in) < 0) return -1;
+    cfg.lpiq_bw = in.lpiq_bw;                         /* 0 = the sonde type's own */
     if ((float)cfg.sample_rate / 9615.0f < 8) fprintf(stderr, "note: sample rate low (%.1f sps)\n", (float)cfg.sample_rate / 9615.0f);   /* m10mod.c:1392 */
     {
-        const double xlt = (iq_mode == 5) ? -fq : 0.0;
+        const double xlt = (in.iq_mode == 5) ? -in.fq : 0.0;
         if (make_decoder(&dopt, raw, cfreq > 0 ? (int)((cfreq - xlt * cfg.sample_rate + 500) / 1e3) : 0) < 0) return -1;
     }
     cfg.m10_noskip = g_verbose >= 3;
@@ -179,47 +140,41 @@ int main(int argc, char **argv) {
     cfg.max_frames = 16;
     sonde_engine_t *eng = NULL;
     brk_demod_t brk; brk.fd = -1;
-    const int use_broker = (g_chk3 && have_iq) ? 0 : brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
+    const int use_broker = (g_chk3 && in.have_iq) ? 0 : brk_demod_wanted(&cfg);      /* SONDE_BROKER: a channel of the resident engine instead of one of our own */
     int rc = 0;
     sonde_info_t info;
     if (use_broker) {
         if (brk_demod_open(&brk, &cfg, g_shift != 0, 2, 0 + g_shift) < 0) return -1;
         info = brk.info;
     } else {
-        if (g_chk3 && have_iq) cfg.keep_soft = 2;
-        rc = sonde_engine_create(&cfg, &fq, &eng);
-        if (rc >= 0 && g_chk3 && have_iq) rc = sonde_engine_set_m10_chk3(eng, 1);
+        if (g_chk3 && in.have_iq) cfg.keep_soft = 2;
+        rc = sonde_engine_create(&cfg, &in.fq, &eng);
+        if (rc >= 0 && g_chk3 && in.have_iq) rc = sonde_engine_set_m10_chk3(eng, 1);
         if (rc >= 0 && g_shift) rc = sonde_engine_set_sync(eng, 2, 0 + g_shift);
         if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
         sonde_engine_info(eng, &info);
     }
-    if (iq_mode == 5) {                              /* init_buffers prints these first (demod_mod.c:1257-1258) */
+    if (in.iq_mode == 5) {                              /* init_buffers prints these first (demod_mod.c:1257-1258) */
         fprintf(stderr, "IF: %d\n", info.if_sr);
         fprintf(stderr, "dec: %d\n", info.decM);
     }
-    const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);
-    int chunk = cfg.sample_rate / 10;
-    chunk -= chunk % info.decM;
-    if (chunk < info.decM) chunk = info.decM;
-    int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
+    const size_t unit = cli_sample_bytes(&cfg, &in);
+    cli_reader_t rd;
+    if (cli_reader_init(&rd, unit, cfg.sample_rate, info.decM) < 0) return -1;
     sonde_m10_frame_t frames[16];
-    size_t have = 0;
     for (;;) {
-        size_t got = fread((char *)buf + have, 1, (size_t)chunk * unit - have, fp);
-        have += got;
-        int n = (int)(have / unit);
-        n -= n % info.decM;
+        int n;
+        const size_t got = cli_reader_fill(&rd, fp, &n);
         if (n > 0) {
             if (use_broker) {
-                if (brk_demod_feed(&brk, buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
+                if (brk_demod_feed(&brk, rd.buf, n, unit, 0, sizeof frames[0], emit_rec) < 0) { fprintf(stderr, "error: broker\n"); return -1; }
             } else {
-                rc = sonde_engine_process_host(eng, buf, n, n);
+                rc = sonde_engine_process_host(eng, rd.buf, n, n);
                 if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
                 int k = sonde_engine_fetch_m10(eng, frames, 16, 0);
                 for (int i = 0; i < k; i++) emit_frame(&frames[i]);
             }
-            memmove(buf, (char *)buf + (size_t)n * unit, have - (size_t)n * unit);
-            have -= (size_t)n * unit;
+            cli_reader_consume(&rd, n);
         }
         if (got == 0) break;
     }
@@ -230,6 +185,6 @@ int main(int argc, char **argv) {
     }
     if (eng) sonde_engine_destroy(eng);
     brk_demod_close(&brk);
-    free(buf);
+    cli_reader_free(&rd);
     return 0;
 }

@@ -20,7 +20,7 @@
 #include <stdint.h>
 #include "sonde_hip.h"
 #include "sonde_meisei.h"
-#include "wav_header.h"
+#include "cli_common.h"
 
 #define MAXHITS 8
 static const char kHeader[] = "101010101011010100101011001101001100101011001101";      /* meisei100mod.c:200-201 */
@@ -28,12 +28,13 @@ static const char kHeader[] = "101010101011010100101011001101001100101011001101"
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     sonde_meisei_opts_t o;
-    double fq = 0.0;
-    int have_iq = 0, iq_mode = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, cfreq = -1, shift = 0, lpiq_bw = 16000, rs11g = 0;
+    cli_in_t in;
+    int softin = 0, cfreq = -1, shift = 0, rs11g = 0, oc;
     float thres = 0.7f, baudrate = -1.f;
     FILE *fp = stdin;
     static char out[1 << 16];
     memset(&o, 0, sizeof o);
+    cli_in_init(&in, 16000, 32.0);
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_GENERIC;
@@ -64,36 +65,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "--ths")) { if (++i >= argc) return -1; thres = (float)atof(argv[i]); }
         else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; shift = atoi(argv[i]); if (shift > 4) shift = 4; if (shift < -4) shift = -4; }
-        else if (!strcmp(a, "--IQ")) {
-            if (++i >= argc) return -1;
-            fq = atof(argv[i]);
-            if (fq < -0.5) fq = -0.5;
-            if (fq > 0.5) fq = 0.5;
-            have_iq = 1; iq_mode = 5;
-        }
-        else if (!strcmp(a, "--iq0")) { have_iq = 1; iq_mode = 1; }
-        else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }
-        else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
-        else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
-        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;
-        else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;
-        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
-        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
-        else if (!strcmp(a, "--lpbw")) {
-            if (++i >= argc) return -1;
-            double bw = atof(argv[i]);
-            if (bw > 4.6 && bw < 32.0) lpiq_bw = (int)(bw * 1e3);
-            cfg.opt_lp |= SONDE_LP_IQ;
-        }
-        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
-        else if (!strcmp(a, "--ch2")) wav_ch = 1;
-        else if (!strcmp(a, "-")) {
-            if (i + 2 >= argc) return -1;
-            cfg.sample_rate = atoi(argv[++i]);
-            cfg.bits = atoi(argv[++i]);
-            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
-            have_pcm = 1;
-        }
+        else if ((oc = cli_input_option(argc, argv, &i, &cfg, &in)) != 0) { if (oc < 0) return -1; }      /* --IQ, --iq0/2/3, --iqdc, --noLUT, --dc, --lpIQ, --lpFM, --lpbw, --min, --ch2, "- <sr> <bits>" */
         else if (a[0] != '-') {
             if (rs11g && o.ims100) goto help_out;
             if (!o.raw && !rs11g && !o.ims100) o.ims100 = 1;
@@ -103,13 +75,7 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "meisei100mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    {
-        const char *ver = getenv("SONDE_JSN_VERSION");
-#ifdef VER_JSN_STR
-        if (!ver) ver = VER_JSN_STR;
-#endif
-        if (ver) { strncpy(o.version, ver, sizeof o.version - 1); o.version[sizeof o.version - 1] = 0; }
-    }
+    cli_json_version(o.version, sizeof o.version);
     sonde_meisei_dec_t *dec = NULL;
 
     if (softin) {
@@ -126,19 +92,10 @@ int main(int argc, char **argv) {
         return 0;
     }
 
-    if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
-    if (!have_pcm && wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-    if (have_iq && !have_pcm && nch != 2) { fprintf(stderr, "meisei100mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
-    if (iq_mode == 5 && cfg.opt_dc) cfg.opt_lp |= SONDE_LP_FM;
-    if (iq_mode != 5) cfg.opt_nolut = 0;
-    if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
-    else {
-        cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
-        cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
-    }
+    if (cli_input_setup("meisei100mod", fp, &cfg, &in) < 0) return -1;
     if ((float)cfg.sample_rate / 2400.0f < 8) fprintf(stderr, "note: sample rate low (%.1f sps)\n", (float)cfg.sample_rate / 2400.0f);
     if (baudrate > 0) fprintf(stderr, "sps corr: %.4f\n", (float)cfg.sample_rate / baudrate);
-    o.jsn_freq_khz = cfreq > 0 ? (int)((cfreq - (iq_mode == 5 ? -fq : 0.0) * cfg.sample_rate + 500) / 1e3) : 0;
+    o.jsn_freq_khz = cfreq > 0 ? (int)((cfreq - (in.iq_mode == 5 ? -in.fq : 0.0) * cfg.sample_rate + 500) / 1e3) : 0;
     if (sonde_meisei_dec_create(&o, &dec) < 0) return -1;
     cfg.n_channels = 1;
     cfg.max_chunk = cfg.sample_rate;
@@ -153,36 +110,27 @@ int main(int argc, char **argv) {
     g.hdmax = 1; g.bitofs = shift;                                                                    /* :690 */
     g.nbits = SONDE_MEISEI_FRAME_SYMBOLS;
     g.l_win = -1.0f;                                                                                   /* read_slbit(..., -1, 0) :713 */
-    g.lpiq_bw = lpiq_bw; g.lpfm_bw = 4000;
+    g.lpiq_bw = in.lpiq_bw; g.lpfm_bw = 4000;
     sonde_engine_t *eng = NULL;
-    int rc = sonde_engine_create_generic(&cfg, &fq, &g, &eng);
+    int rc = sonde_engine_create_generic(&cfg, &in.fq, &g, &eng);
     if (rc >= 0) rc = sonde_engine_set_threshold(eng, thres);
     if (rc < 0) { fprintf(stderr, "error: init buffers (%s)\n", sonde_strerror(rc)); return -1; }
     sonde_info_t info;
     sonde_engine_info(eng, &info);
-    if (iq_mode == 5) { fprintf(stderr, "IF: %d\n", info.if_sr); fprintf(stderr, "dec: %d\n", info.decM); }
+    if (in.iq_mode == 5) { fprintf(stderr, "IF: %d\n", info.if_sr); fprintf(stderr, "dec: %d\n", info.decM); }
 
-    const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);
-    int chunk = cfg.sample_rate / 10;
-    chunk -= chunk % info.decM;
-    if (chunk < info.decM) chunk = info.decM;
-    char *buf = (char *)malloc((size_t)chunk * unit);
+    cli_reader_t rd;
     static float s0[MAXHITS * SONDE_MEISEI_FRAME_SYMBOLS];
     static sonde_hit_t hits[MAXHITS];
-    size_t have = 0;
     int eof = 0;
-    if (!buf) return -1;
+    if (cli_reader_init(&rd, cli_sample_bytes(&cfg, &in), cfg.sample_rate, info.decM) < 0) return -1;
     while (!eof) {
-        const size_t got = fread(buf + have, 1, (size_t)chunk * unit - have, fp);
-        have += got;
-        if (got == 0) eof = 1;
-        int n = (int)(have / unit);
-        n -= n % info.decM;
+        int n;
+        if (cli_reader_fill(&rd, fp, &n) == 0) eof = 1;
         if (n > 0) {
-            rc = sonde_engine_process_host(eng, buf, n, n);
+            rc = sonde_engine_process_host(eng, rd.buf, n, n);
             if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); return -1; }
-            memmove(buf, buf + (size_t)n * unit, have - (size_t)n * unit);
-            have -= (size_t)n * unit;
+            cli_reader_consume(&rd, n);
         }
         if (n <= 0 && !eof) continue;
         const int k = sonde_engine_fetch_hits(eng, hits, MAXHITS, eof);
@@ -198,6 +146,6 @@ int main(int argc, char **argv) {
     printf("\n");                                                /* :1320 */
     sonde_engine_destroy(eng);
     sonde_meisei_dec_destroy(dec);
-    free(buf);
+    cli_reader_free(&rd);
     return 0;
 }

@@ -23,7 +23,7 @@
 #include <math.h>
 #include "sonde_hip.h"
 #include "sonde_mrz.h"
-#include "wav_header.h"
+#include "cli_common.h"
 
 #define MAXHITS 8
 #define MAXBITS SONDE_MRZ_MAX_BITS
@@ -49,12 +49,13 @@ static sonde_engine_t *make_engine(const sonde_cfg_t *cfg, double fq, int lpiq_b
 int main(int argc, char **argv) {
     sonde_cfg_t cfg;
     sonde_mrz_opts_t o;
-    double fq = 0.0;
-    int rawhex = 0, have_iq = 0, iq_mode = 0, have_pcm = 0, wav_ch = 0, nch = 1, softin = 0, cfreq = -1, shift = 0, lpiq_bw = 9000;
+    cli_in_t in;
+    int rawhex = 0, softin = 0, cfreq = -1, shift = 0, oc;
     float thres = 0.76f, baudrate = -1.f;
     FILE *fp = stdin;
     static char out[1 << 16];
     memset(&o, 0, sizeof o);
+    cli_in_init(&in, 9000, 32.0);
     memset(&cfg, 0, sizeof cfg);
     cfg.abi_version = SONDE_ABI_VERSION;
     cfg.sonde_type = SONDE_GENERIC;
@@ -88,36 +89,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "--softin")) softin = 1;
         else if (!strcmp(a, "--softinv")) softin = 2;
         else if (!strcmp(a, "-d")) { if (++i >= argc) return -1; shift = atoi(argv[i]); if (shift > 4) shift = 4; if (shift < -4) shift = -4; }
-        else if (!strcmp(a, "--IQ")) {
-            if (++i >= argc) return -1;
-            fq = atof(argv[i]);
-            if (fq < -0.5) fq = -0.5;
-            if (fq > 0.5) fq = 0.5;
-            have_iq = 1; iq_mode = 5;
-        }
-        else if (!strcmp(a, "--iq0")) { have_iq = 1; iq_mode = 1; }
-        else if (!strcmp(a, "--iq2")) { have_iq = 1; iq_mode = 2; }
-        else if (!strcmp(a, "--iq3")) { have_iq = 1; iq_mode = 3; }
-        else if (!strcmp(a, "--iqdc")) cfg.opt_iqdc = 1;
-        else if (!strcmp(a, "--noLUT")) cfg.opt_nolut = 1;
-        else if (!strcmp(a, "--dc")) cfg.opt_dc = 1;
-        else if (!strcmp(a, "--lpIQ")) cfg.opt_lp |= SONDE_LP_IQ;
-        else if (!strcmp(a, "--lpFM")) cfg.opt_lp |= SONDE_LP_FM;
-        else if (!strcmp(a, "--lpbw")) {
-            if (++i >= argc) return -1;
-            double bw = atof(argv[i]);
-            if (bw > 4.6 && bw < 32.0) lpiq_bw = (int)(bw * 1e3);
-            cfg.opt_lp |= SONDE_LP_IQ;
-        }
-        else if (!strcmp(a, "--min")) cfg.opt_min = 1;
-        else if (!strcmp(a, "--ch2")) wav_ch = 1;
-        else if (!strcmp(a, "-")) {
-            if (i + 2 >= argc) return -1;
-            cfg.sample_rate = atoi(argv[++i]);
-            cfg.bits = atoi(argv[++i]);
-            if (cfg.sample_rate < 1 || (cfg.bits != 8 && cfg.bits != 16 && cfg.bits != 32)) { fprintf(stderr, "- <sr> <bs>\n"); return -1; }
-            have_pcm = 1;
-        }
+        else if ((oc = cli_input_option(argc, argv, &i, &cfg, &in)) != 0) { if (oc < 0) return -1; }      /* --IQ, --iq0/2/3, --iqdc, --noLUT, --dc, --lpIQ, --lpFM, --lpbw, --min, --ch2, "- <sr> <bits>" */
         else if (a[0] != '-') {
             fp = fopen(a, "rb");
             if (fp == NULL) { fprintf(stderr, "error open %s\n", a); return -1; }
@@ -125,13 +97,7 @@ int main(int argc, char **argv) {
         }
         else { fprintf(stderr, "mp3h1mod (sonde_hip): option %s not supported by this build\n", a); return -1; }
     }
-    {
-        const char *ver = getenv("SONDE_JSN_VERSION");
-#ifdef VER_JSN_STR
-        if (!ver) ver = VER_JSN_STR;
-#endif
-        if (ver) { strncpy(o.version, ver, sizeof o.version - 1); o.version[sizeof o.version - 1] = 0; }
-    }
+    cli_json_version(o.version, sizeof o.version);
     sonde_mrz_dec_t *dec = NULL;
 
     if (rawhex) {                                                /* :1249-1276 */
@@ -159,20 +125,11 @@ int main(int argc, char **argv) {
         return 0;
     }
 
-    if (!have_iq && have_pcm) { fprintf(stderr, "error: raw data not IQ\n"); return -1; }
-    if (!have_pcm && wav_read_header(fp, &cfg.sample_rate, &cfg.bits, &nch) < 0) { fprintf(stderr, "error: wav header\n"); return -1; }
-    if (have_iq && !have_pcm && nch != 2) { fprintf(stderr, "mp3h1mod (sonde_hip): IQ input needs 2 channels\n"); return -1; }
-    if (iq_mode == 5 && cfg.opt_dc) cfg.opt_lp |= SONDE_LP_FM;
-    if (iq_mode != 5) cfg.opt_nolut = 0;
-    if (have_iq) cfg.input = iq_mode == 5 ? SONDE_IN_IQ : iq_mode == 1 ? SONDE_IN_IFIQ0 : iq_mode == 2 ? SONDE_IN_IFIQ2 : SONDE_IN_IFIQ3;
-    else {
-        cfg.input = SONDE_IN_AUDIO; cfg.audio_channels = nch < 1 ? 1 : nch;
-        cfg.audio_select = (wav_ch < cfg.audio_channels) ? wav_ch : 0;
-    }
+    if (cli_input_setup("mp3h1mod", fp, &cfg, &in) < 0) return -1;
     if ((float)cfg.sample_rate / 2399.0f < 5) fprintf(stderr, "note: sample rate low (%.1f sps)\n", (float)cfg.sample_rate / 2399.0f);
     if (baudrate > 0) fprintf(stderr, "sps corr: %.4f\n", (float)cfg.sample_rate / baudrate);
     const float baud = baudrate > 0 ? baudrate : 2399.0f;
-    o.jsn_freq_khz = cfreq > 0 ? (int)((cfreq - (iq_mode == 5 ? -fq : 0.0) * cfg.sample_rate + 500) / 1e3) : 0;
+    o.jsn_freq_khz = cfreq > 0 ? (int)((cfreq - (in.iq_mode == 5 ? -in.fq : 0.0) * cfg.sample_rate + 500) / 1e3) : 0;
     if (sonde_mrz_dec_create(&o, &dec) < 0) return -1;
     cfg.n_channels = 1;
     cfg.max_chunk = cfg.sample_rate;
@@ -182,11 +139,11 @@ int main(int argc, char **argv) {
 
     sonde_info_t info;
     int nb = sonde_mrz_dec_frame_bits(dec);
-    sonde_engine_t *eng = make_engine(&cfg, fq, lpiq_bw, nb, baud, thres, shift, &info);
+    sonde_engine_t *eng = make_engine(&cfg, in.fq, in.lpiq_bw, nb, baud, thres, shift, &info);
     if (!eng) return -1;
-    if (iq_mode == 5) { fprintf(stderr, "IF: %d\n", info.if_sr); fprintf(stderr, "dec: %d\n", info.decM); }
+    if (in.iq_mode == 5) { fprintf(stderr, "IF: %d\n", info.if_sr); fprintf(stderr, "dec: %d\n", info.decM); }
 
-    const size_t unit = (have_iq ? 2 : (size_t)cfg.audio_channels) * (size_t)(cfg.bits / 8);
+    const size_t unit = cli_sample_bytes(&cfg, &in);
     int chunk = cfg.sample_rate / 10;
     chunk -= chunk % info.decM;
     if (chunk < info.decM) chunk = info.decM;
@@ -245,7 +202,7 @@ int main(int argc, char **argv) {
                     if (from > fed) from = fed;
                     sonde_engine_destroy(eng);
                     nb = want;
-                    eng = make_engine(&cfg, fq, lpiq_bw, nb, baud, thres, shift, &info);
+                    eng = make_engine(&cfg, in.fq, in.lpiq_bw, nb, baud, thres, shift, &info);
                     if (!eng) return -1;
                     eng0 = from; fed = from; skip_before = (int64_t)frame_end;
                     restarted = 1;

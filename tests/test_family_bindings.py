@@ -50,4 +50,4 @@ def test_descriptors_match_the_c_front_ends():
         assert re.search(r"g\.bt = %sf" % g["bt"], src) and re.search(r"g\.h = %sf" % g["h"], src), typ
         assert re.search(r"g\.hdmax = %d;" % g["hdmax"], src), typ
         assert re.search(r"g\.symlen = %d; g\.symhd = %d;" % (g["symlen"], g["symhd"]), src), typ
-        assert re.search(r"lpfm_bw = %d;" % g["lpfm_bw"], src) and re.search(r"lpiq_bw = %d[;,]" % g["lpiq_bw"], src), typ
+        assert re.search(r"lpfm_bw = %d;" % g["lpfm_bw"], src) and re.search(r"cli_in_init\(&in, %d," % g["lpiq_bw"], src), typ
