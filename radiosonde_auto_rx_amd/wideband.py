@@ -25,8 +25,11 @@ from .telemetry import DfmTelemetry, M10Telemetry, M20Telemetry, Rs41Telemetry
 
 class WidebandReceiver:
     def __init__(self, sample_rate: int, *, cfreq_hz: int = 0, raster_hz: int = 10_000, span: float = 0.45, chunk: int | None = None,
-                 merge_hz: float = 6_000.0, version: str = "sonde_hip"):
-        self.sr, self.cfreq, self.merge_hz, self.version = sample_rate, cfreq_hz, merge_hz, version
+                 merge_hz: float = 6_000.0, version: str = "sonde_hip", idle_s: float = 30.0):
+        """idle_s: a decoder that has produced no frame for that long (a false detection, a sonde that has landed) is closed and its engine
+        freed; the scanner starts a new one if the signal comes back."""
+        self.sr, self.cfreq, self.merge_hz, self.version, self.idle_s = sample_rate, cfreq_hz, merge_hz, version, idle_s
+        self.t = 0.0                           # stream time in seconds
         kmax = int(span * sample_rate / raster_hz)
         self.raster = [snap_fq(k * raster_hz / sample_rate, sample_rate) for k in range(-kmax, kmax + 1)]
         self.chunk = chunk or sample_rate // 4
@@ -62,7 +65,7 @@ class WidebandReceiver:
         else:
             eng = Engine([fq], self.sr, max_chunk=self.chunk, max_frames=8)
             tel = Rs41Telemetry(freq_khz=khz, version=self.version)
-        self.sondes.append(dict(fq=fq, type=typ, engine=eng, telemetry=tel, frames=0, khz=khz))
+        self.sondes.append(dict(fq=fq, type=typ, engine=eng, telemetry=tel, frames=0, khz=khz, t_last=self.t))
         self.log.append(dict(event="detected", type=typ, fq=fq, freq_khz=khz))
 
     def push(self, iq: np.ndarray, finish: bool = False):
@@ -85,9 +88,18 @@ class WidebandReceiver:
                     self._start(self.raster[d["channel"]] + d["df"], d["type"])
                 elif d["type"] in FAMILY and (d["score"] > 0 or FAMILY[d["type"]]["auto"]):
                     self._start(self.raster[d["channel"]] + d["df"], d["type"])
-            for s in self.sondes:
+            self.t += (len(x) // 2) / self.sr
+            for s in list(self.sondes):
                 s["engine"].process_host(x)
+                before = s["frames"]
                 out += self._drain(s, False)
+                if s["frames"] != before:
+                    s["t_last"] = self.t
+                elif self.t - s["t_last"] > self.idle_s:      # silent for too long: give the engine back
+                    out += self._drain(s, True)
+                    s["engine"].close(); s["telemetry"].close()
+                    self.sondes.remove(s)
+                    self.log.append(dict(event="released", type=s["type"], fq=s["fq"], freq_khz=s["khz"], frames=s["frames"]))
         if finish:
             for s in self.sondes:
                 out += self._drain(s, True)
@@ -131,8 +143,11 @@ class ChannelizedReceiver:
     # + the scanner's LMS6 / MEISEI / IMET5 / MRZ / MTS01: generic sonde descriptions and the bit-rate tiers of family.py
 
     def __init__(self, sample_rate: int, *, M: int = 256, D: int = 200, P: int = 16, cfreq_hz: int = 0, slots: int = 16, chunk: int | None = None,
-                 version: str = "sonde_hip", device: int = 0):
+                 version: str = "sonde_hip", device: int = 0, idle_s: float = 30.0):
+        """idle_s: a decoder channel that has produced no frame for that long (a false detection, a sonde that has landed) is ended
+        (sonde_engine_finish_channel) and handed to the next detection of its type."""
         import torch
+        self.idle_s, self.t = idle_s, 0.0
         from .chan import Channelizer
         from .scan import IFIQ
         self.torch, self.sr, self.cfreq, self.version, self.slots, self.device = torch, sample_rate, cfreq_hz, version, slots, device
@@ -181,7 +196,7 @@ class ChannelizedReceiver:
         g["engine"].tune_channel(slot, df)
         khz = int(round((self.cfreq + f_hz) / 1000.0)) if self.cfreq else 0
         tel = FamilyDecoder(typ, freq_khz=khz, version=self.version) if typ in FAMILY else self.TYPES[typ][1](freq_khz=khz, version=self.version)
-        s = dict(type=typ, f_hz=f_hz, chan=k, slot=slot, telemetry=tel, frames=0, khz=khz)
+        s = dict(type=typ, f_hz=f_hz, chan=k, slot=slot, telemetry=tel, frames=0, khz=khz, t_last=self.t, seen=0)
         g["owner"][slot] = s
         self.sondes.append(s)
         self.log.append(dict(event="detected", type=typ, f_hz=f_hz, channel=k, slot=slot, freq_khz=khz))
@@ -217,6 +232,19 @@ class ChannelizedReceiver:
                 g["engine"].process_device(g["stage"].data_ptr(), self.nmax, m)
                 g["calls"] += 1
                 out += self._drain(typ, g, False)
+                for slot, s in enumerate(g["owner"]):                             # channels that have gone silent go back to the pool
+                    if s is None:
+                        continue
+                    if s["frames"] != s["seen"]:
+                        s["seen"], s["t_last"] = s["frames"], self.t
+                    elif self.t - s["t_last"] > self.idle_s:
+                        g["engine"].finish_channel(slot)
+                        out += self._drain(typ, g, False)                         # what the end of its stream still gave
+                        g["owner"][slot] = None
+                        s["telemetry"].close()
+                        self.sondes.remove(s)
+                        self.log.append(dict(event="released", type=typ, f_hz=s["f_hz"], slot=slot, frames=s["frames"]))
+            self.t += m / self.if_sr
         if finish:
             for typ, g in self.groups.items():
                 out += self._drain(typ, g, True)

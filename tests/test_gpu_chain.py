@@ -431,3 +431,36 @@ def test_wideband_receiver_decodes_the_generic_family():
     im = [j for j in out if j["type"] == "IMET5"]
     assert len(lms) >= 2 and all(j["id"] == "LMS6-8123456" and abs(j["freq"] - 403_300) <= 3 for j in lms), lms[:1]
     assert len(im) >= 2 and all(j["id"] == "IMET5-54012345" and abs(j["freq"] - 402_520) <= 3 for j in im), im[:1]
+
+
+def test_wideband_receiver_gives_a_silent_sondes_decoder_back():
+    """A sonde that stops transmitting (landed, or a false detection): after idle_s without a frame its decoder is closed and logged as released;
+    when a signal appears there again the scanner starts a new one (the receivers never released a slot)."""
+    from tools import synth
+    from radiosonde_auto_rx_amd.wideband import WidebandReceiver
+    sr, cf, hz = 2_400_000, 403_000_000, +203_400.0
+    rng = np.random.default_rng(7)
+
+    def burst(secs, frames, seed, frame_no):
+        n = int(sr * secs)
+        z = np.zeros(n, np.complex128)
+        if frames:
+            cap = synth.rs41_capture(sr=sr, seconds=secs, fq=0.0, n_frames=frames, t_first=0.2, noise_sigma=0.0, amp=0.25, seed=seed, sonde_id="A1111111",
+                                     first_frame_no=frame_no, frame_kw=dict(ecef_cm=(418833319, 85974133, 473346430)))
+            z = (cap[0::2].astype(np.float64) + 1j * cap[1::2].astype(np.float64)) / (32767 * 0.9)
+        return z
+
+    z = np.concatenate([burst(3.3, 3, 1, 100), burst(2.6, 0, 0, 0), burst(3.3, 3, 2, 200)])
+    n = len(z)
+    x = z * np.exp(2j * np.pi * hz / sr * np.arange(n)) + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq = np.empty(2 * n, np.int16)
+    iq[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767); iq[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767)
+    rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000, idle_s=1.5)
+    out = rx.push(iq, finish=True)
+    ev = [(e["event"], e.get("frames")) for e in rx.log]
+    rx.close()
+    kinds = [e for e, _ in ev]
+    assert kinds.count("detected") == 2 and kinds.count("released") >= 1 and kinds.index("released") > kinds.index("detected"), ev
+    assert kinds[-1] == "detected" or kinds[-1] == "released", ev
+    nos = sorted(o["frame"] for o in out if o.get("id") == "A1111111")
+    assert any(f < 150 for f in nos) and any(f >= 200 for f in nos), nos       # frames of both transmissions came out
