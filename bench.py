@@ -352,8 +352,8 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
     """BASELINE configs[4] "full detect -> demod -> ECC" as one step: the demodulator step over all C channels with the dft_detect scanner
     (`--IQ fq --dc`, front end + 14 templates) re-scanning a rotating 1/16 of the channels over the same second, inside the step — the
     auto_rx duty cycle: decoders run on the channels that were found while the scanner keeps sweeping (scan.py:948, decode.py:869-913).
-    The scanner works on its own stream beside the engine's (its call returns when its windows are decided, the engine's call is asynchronous);
-    its detections are fetched inside the step.  Not part of `value`."""
+    The scanner works on its own (high-priority) stream beside the engine's and is driven from a host thread of its own; the step ends when the
+    engine's frames of the previous call AND the scanner's detections of this one have been fetched.  Not part of `value`."""
     torch = D.torch
     from radiosonde_auto_rx_amd.scan import Scanner
     groups = 16
@@ -361,13 +361,19 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
     scs = [Scanner(SR, fq=ch_fq[g * per:(g + 1) * per], dc=True, cont=True, max_chunk=SR, device=D.local_rank) for g in range(groups)]
     found = [0]
 
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+
+    def scan(g):                                                          # on a host thread of its own (the C call releases the GIL): the scanner's
+        sc = scs[g]                                                       # call waits for its kernels between stages, on its own high-priority stream
+        sc.process_device(iq.data_ptr() + 4 * STRIDE * g * per, STRIDE, SR)
+        return sum(1 for d in sc.fetch() if d["type"] == "RS41")
+
     def step(k):
-        g = k % groups
-        sc = scs[g]
+        job = pool.submit(scan, k % groups)
         eng.process_device(iq.data_ptr(), STRIDE, SR)                              # asynchronous on the engine's stream(s)
-        sc.process_device(iq.data_ptr() + 4 * STRIDE * g * per, STRIDE, SR)          # scanner stream; returns when its windows are decided
         fr = eng.fetch_frames_np(lag=lag)
-        found[0] += sum(1 for d in sc.fetch() if d["type"] == "RS41")
+        found[0] += job.result()                                                    # the step is over when both are
         return fr
 
     for k in range(groups):                                               # every scanner has seen a second (allocations, first windows)
@@ -383,6 +389,7 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
     eng.sync()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    pool.shutdown()
     for sc in scs:
         sc.close()
     return dict(ms_per_step=round(dt * 1e3, 3), value=round(C * SR / dt / 1e6, 1), unit="Msamples/s", realtime_channels=round(C * SR / dt / 2.4e6, 1),

@@ -386,7 +386,12 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
     HIPCHK(hipHostMalloc((void **)&s->h_res, icap * SC_NTPL * sizeof(ScanRes), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&s->h_pre, icap * SC_NTPL * sizeof(ScanPre), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&s->h_work, icap * SC_NTPL * sizeof(ScanWork), hipHostMallocDefault));
-    HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    {   // the scanner's kernels are short and its call waits for them between stages: on a device that also runs a demodulator engine they must not
+        // queue behind a millisecond of decimator workgroups — highest stream priority (the engine's streams have the default one)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
+        HIPCHK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, hi));
+    }
 
     // IQ-DC: always on, fixed window (dft_detect.c:1152-1156)
     s->dc_max = (uint32_t)(sr / 32); if (D > 1) s->dc_max *= (uint32_t)D;
