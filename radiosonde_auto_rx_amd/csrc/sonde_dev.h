@@ -36,7 +36,13 @@ struct MixDecArgs {
     // and the IQ-DC segment schedule count from the channel's start.  nullptr = all channels started with the engine.
     const uint32_t *epoch_phase;   // [n_ch] (base-rate index of the channel's first sample) mod lut_len
     const int32_t *dc_since_ch;    // [n_ch] blocks since the channel's mean last changed (replaces dc_since; dc_avg_prev is then always set)
+    // a launch that spans several IQ-DC windows (the scanner's are 1/32 s, dft_detect.c:539-573: a launch per window would be 64 launches per second of
+    // signal): dc_seg[ch][k] = the mean in effect for the k-th window the launch touches, block j lies in window (j + dc_seg_off) / dc_seg_blocks.
+    // nullptr = one mean for the whole launch (dc_avg).  Generic kernel only; the kernel then leaves dc_sums alone (k_dc_seg_* own them).
+    const float2 *dc_seg; int dc_seg_n, dc_seg_off, dc_seg_blocks;
 };
+extern "C" void sonde_launch_dc_segments(const int16_t *iq, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,
+                                         long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n, hipStream_t s);
 
 // --dc (AFC) per-channel state: what find_header keeps in dsp.Df / dsp.locked / dsp.dc (demod_mod.c:1555-1600, 280-298)
 struct AfcState {

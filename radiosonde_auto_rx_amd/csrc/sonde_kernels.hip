@@ -472,8 +472,10 @@ void k_mix_decimate(const MixDecArgs a) {
             const float m = outrow ? 1.f : 0.f;
             md_fast_tile(row_lds, a.wtab_g + 64 * 8, f0, f0 * (double)rown, (float2v){m, m}, acc, dcs);
         } else {
-            if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
-            else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, avg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+            float2 ravg = avg;                                // the mean of the IQ-DC window the row lies in, when the launch spans several
+            if (a.dc_seg) { int k = (j + a.dc_seg_off) / a.dc_seg_blocks; k = k < a.dc_seg_n ? k : a.dc_seg_n - 1; ravg = a.dc_seg[(size_t)ch * a.dc_seg_n + k]; }
+            if (nowrap) md_rows<Q_T, false, PH64, D_T>(sRaw + lane * D, D, a.wtab, ravg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
+            else        md_rows<Q_T, true, PH64, 0>(sRaw + lane * D, D, a.wtab, ravg, f0, rown, L, outrow ? 1.f : 0.f, a.nd_base, acc, dcs);
         }
         sx += (int)dcs.x; sy += (int)dcs.y;
 
@@ -507,10 +509,56 @@ void k_mix_decimate(const MixDecArgs a) {
     }
 
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
-    if (lane == 0) {
+    if (lane == 0 && !a.dc_seg) {
         atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch), (unsigned long long)(long long)sx);
         atomicAdd(reinterpret_cast<unsigned long long *>(a.dc_sums + 2 * (size_t)ch + 1), (unsigned long long)(long long)sy);
     }
+}
+
+// IQ-DC windows of a launch that spans several (MixDecArgs.dc_seg): k_dc_seg_sums adds up the raw samples of every window the call touches,
+// k_dc_seg_means turns them into the table of means — window k runs under the mean of window k-1 (the first under the one carried in dc_avg), the
+// trailing incomplete window's sum is carried to the next call in dc_sums — exactly what one launch per window plus k_dc_update did.
+__global__ __launch_bounds__(256)
+void k_dc_seg_sums(const int16_t *iq, long long ch_stride, int n_samples, unsigned dc_cnt0, unsigned dc_max, long long *seg_sums, int nseg) {
+    const int k = blockIdx.x, ch = blockIdx.y;
+    const long long lo = (long long)k * dc_max - dc_cnt0, hi = lo + dc_max;
+    const int s0 = (int)(lo < 0 ? 0 : lo), s1 = (int)(hi > n_samples ? n_samples : hi);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)ch * ch_stride;
+    int sx = 0, sy = 0;                                       // a thread sees (window / 256) samples: no overflow below 2^16 samples per thread
+    long long lx = 0, ly = 0;
+    int cnt = 0;
+    for (int i = s0 + (int)threadIdx.x; i < s1; i += 256) {
+        const uint32_t raw = p[i];
+        sx += (int)(short)(raw & 0xffffu); sy += ((int)raw) >> 16;
+        if (++cnt == 32768) { lx += sx; ly += sy; sx = sy = 0; cnt = 0; }
+    }
+    lx += sx; ly += sy;
+    for (int off = 32; off > 0; off >>= 1) { lx += __shfl_down(lx, off); ly += __shfl_down(ly, off); }
+    __shared__ long long s_l[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_l[2 * wave] = lx; s_l[2 * wave + 1] = ly; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tx = 0, ty = 0;
+        for (int w = 0; w < 4; w++) { tx += s_l[2 * w]; ty += s_l[2 * w + 1]; }
+        seg_sums[((size_t)ch * nseg + k) * 2] = tx; seg_sums[((size_t)ch * nseg + k) * 2 + 1] = ty;
+    }
+}
+__global__ void k_dc_seg_means(int n_ch, int nseg, int ncomplete, float maxcnt, const long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    float2 mean = dc_avg[c];
+    long long cx = dc_sums[2 * c], cy = dc_sums[2 * c + 1];   // what the window in progress had collected before this call
+    for (int k = 0; k < dc_seg_n; k++) {
+        dc_seg[(size_t)c * dc_seg_n + k] = mean;
+        if (k >= nseg) continue;
+        cx += seg_sums[((size_t)c * nseg + k) * 2]; cy += seg_sums[((size_t)c * nseg + k) * 2 + 1];
+        if (k < ncomplete) {                                  // avg = (float)(sum / (float)maxcnt), sum = S / 32768 exact in double (k_dc_update)
+            mean = make_float2((float)(((double)cx / 32768.0) / (double)maxcnt), (float)(((double)cy / 32768.0) / (double)maxcnt));
+            cx = 0; cy = 0;
+        }
+    }
+    dc_avg[c] = mean; dc_sums[2 * c] = cx; dc_sums[2 * c + 1] = cy;
 }
 
 // Decimation factors above 64 (input rates above ~3 Msps, e.g. a 10 Msps wideband stream): same lane-per-block scheme,
@@ -1826,6 +1874,13 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
     }
 #undef MD_LAUNCH
     return 0;
+}
+extern "C" void sonde_launch_dc_segments(const int16_t *iq, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,
+                                         long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
+    const int nseg = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples + dc_max - 1) / dc_max);
+    const int ncomplete = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples) / dc_max);
+    hipLaunchKernelGGL(k_dc_seg_sums, dim3(nseg, n_ch), dim3(256), 0, s, iq, ch_stride, n_samples, dc_cnt0, dc_max, seg_sums, nseg);
+    hipLaunchKernelGGL(k_dc_seg_means, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, (float)dc_max, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n);
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, (float2 *)nullptr, maxcnt);

@@ -189,6 +189,7 @@ struct sonde_scan {
     int ring_len = 0;
     // stream position
     uint64_t samples_in = 0; uint32_t m_out = 0; uint32_t dc_cnt = 0, dc_max = 0;
+    long long *d_segsums = nullptr; float2 *d_dcseg = nullptr;      // IQ-DC windows of a call: sums, table of means (MixDecArgs.dc_seg)
     std::vector<Chan> chan;
     std::vector<sonde_detection_t> queue;
     std::vector<sonde_scan_window_t> last_windows;
@@ -413,7 +414,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_pre) hipHostFree(s->h_pre);
     if (s->h_work) hipHostFree(s->h_work);
     void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_scratch, s->d_f32in, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -751,6 +752,33 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         s->m_out += (uint32_t)n_samples; s->samples_in += (uint64_t)n_samples;
     } else {
         int done = 0;
+        // int16 base-rate input with a decimation the lane-per-block kernel takes in one piece: ONE decimator launch for the whole call, the IQ-DC
+        // windows it spans (1/32 s each: 32 per second of signal) handled by a table of means (MixDecArgs.dc_seg) that two small kernels fill first —
+        // a launch per window made the front end launch-bound (64 launches of ~9 us per second of signal)
+        static const bool no_segtab = getenv("SONDE_SCAN_NO_SEGTAB") != nullptr;      // A/B aid
+        if (mode == SONDE_SCAN_BBIQ && !f32in && D <= 64 && n_samples % D == 0 && s->dc_cnt % (uint32_t)D == 0 && !no_segtab) {
+            const int nseg_cap = s->cfg.max_chunk / (int)s->dc_max + 2;
+            if (!s->d_segsums) {
+                HIPCHK(hipMalloc((void **)&s->d_segsums, (size_t)C * nseg_cap * 2 * sizeof(long long)));
+                HIPCHK(hipMalloc((void **)&s->d_dcseg, (size_t)C * (nseg_cap + 1) * sizeof(float2)));
+            }
+            sonde_launch_dc_segments((const int16_t *)d_in, ch_stride, C, n_samples, s->dc_cnt, s->dc_max, s->d_segsums, s->d_dcsums, s->d_dcavg,
+                                     s->d_dcseg, nseg_cap + 1, s->stream);
+            MixDecArgs a{};
+            a.iq = (const int16_t *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = n_samples / D;
+            a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.DS = s->DS; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
+            a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
+            a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums;
+            a.dc_seg = s->d_dcseg; a.dc_seg_n = nseg_cap + 1; a.dc_seg_off = (int)(s->dc_cnt / (uint32_t)D); a.dc_seg_blocks = (int)(s->dc_max / (uint32_t)D);
+            a.ptail_in = s->d_ptail[s->ptail_cur]; a.ptail_out = s->d_ptail[s->ptail_cur ^ 1];
+            a.y = s->d_y; a.ring_len = s->ring_len; a.m0 = s->m_out; a.phase_f64 = 1;
+            { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
+            if (sonde_launch_mix_decimate(&a, s->stream) < 0) return SONDE_E_ARG;
+            s->ptail_cur ^= 1;
+            s->samples_in += (uint64_t)n_samples; s->m_out += (uint32_t)(n_samples / D);
+            s->dc_cnt = (uint32_t)(((uint64_t)s->dc_cnt + (uint64_t)n_samples) % s->dc_max);
+            done = n_samples;
+        }
         while (done < n_samples) {
             const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), s->dc_max - s->dc_cnt);
             if (f32in) {                                     // float32 IQ (or the wide-IF copy): plain mixer / FIR kernels, IQ-DC sums in double
