@@ -524,15 +524,29 @@ void k_dc_seg_sums(const int16_t *iq, long long ch_stride, int n_samples, unsign
     const long long lo = (long long)k * dc_max - dc_cnt0, hi = lo + dc_max;
     const int s0 = (int)(lo < 0 ? 0 : lo), s1 = (int)(hi > n_samples ? n_samples : hi);
     const uint32_t *p = reinterpret_cast<const uint32_t *>(iq) + (size_t)ch * ch_stride;
-    int sx = 0, sy = 0;                                       // a thread sees (window / 256) samples: no overflow below 2^16 samples per thread
     long long lx = 0, ly = 0;
-    int cnt = 0;
-    for (int i = s0 + (int)threadIdx.x; i < s1; i += 256) {
-        const uint32_t raw = p[i];
-        sx += (int)(short)(raw & 0xffffu); sy += ((int)raw) >> 16;
-        if (++cnt == 32768) { lx += sx; ly += sy; sx = sy = 0; cnt = 0; }
+    // 16-byte loads over the part of the window that is 16-byte aligned (the channel rows are), four of them in flight per thread; the few
+    // samples in front of and behind it one by one.  An int accumulates at most 2^15 samples of 16 bits before it is folded into the long sums.
+    const int a0 = min(s1, (s0 + 3) & ~3), a1 = max(a0, s1 & ~3);
+    for (int i = s0 + (int)threadIdx.x; i < a0; i += 256) { const uint32_t raw = p[i]; lx += (int)(short)(raw & 0xffffu); ly += ((int)raw) >> 16; }
+    for (int i = a1 + (int)threadIdx.x; i < s1; i += 256) { const uint32_t raw = p[i]; lx += (int)(short)(raw & 0xffffu); ly += ((int)raw) >> 16; }
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + a0);
+        const int nq = (a1 - a0) >> 2;
+        int sx = 0, sy = 0, cnt = 0;
+        auto add = [&](const uint4 v) {
+            sx += (int)(short)(v.x & 0xffffu) + (int)(short)(v.y & 0xffffu) + (int)(short)(v.z & 0xffffu) + (int)(short)(v.w & 0xffffu);
+            sy += (((int)v.x) >> 16) + (((int)v.y) >> 16) + (((int)v.z) >> 16) + (((int)v.w) >> 16);
+        };
+        int i = (int)threadIdx.x;
+        for (; i + 3 * 256 < nq; i += 4 * 256) {
+            const uint4 v0 = q[i], v1 = q[i + 256], v2 = q[i + 512], v3 = q[i + 768];
+            add(v0); add(v1); add(v2); add(v3);
+            if ((cnt += 16) >= 32768 - 16) { lx += sx; ly += sy; sx = sy = 0; cnt = 0; }
+        }
+        for (; i < nq; i += 256) add(q[i]);
+        lx += sx; ly += sy;
     }
-    lx += sx; ly += sy;
     for (int off = 32; off > 0; off >>= 1) { lx += __shfl_down(lx, off); ly += __shfl_down(ly, off); }
     __shared__ long long s_l[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
