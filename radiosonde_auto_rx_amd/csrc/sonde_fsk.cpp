@@ -176,6 +176,8 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
                                 "consumer %.0f (waits for samples %.1f%%, frame tail %.1f%%), estimators %.0f (waits %.1f%%)\n", f->cfg.Rs, f->cfg.nsym,
                         h[0] / 1e3, 100.0 * h[1] / std::max(1ull, h[0]), 100.0 * h[2] / std::max(1ull, h[0]), 100.0 * h[3] / std::max(1ull, h[0]),
                         h[4] / 1e3, 100.0 * h[5] / std::max(1ull, h[4]), 100.0 * h[6] / std::max(1ull, h[4]), h[8] / 1e3, 100.0 * h[9] / std::max(1ull, h[8]));
+                fprintf(stderr, "fsk prof   estimator wave 0, kcycles: window %.0f stages %.0f magnitudes+Sf %.0f group barriers %.0f searches %.0f\n",
+                        h[10] / 1e3, h[11] / 1e3, h[12] / 1e3, h[13] / 1e3, h[14] / 1e3);
             } else {
                 unsigned long long tot = 0; for (int k = 0; k < 9; k++) tot += h[k];
                 fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, %% of %llu cycles):", f->cfg.Rs, f->cfg.nsym, tot);

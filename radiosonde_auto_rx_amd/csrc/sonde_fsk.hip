@@ -166,6 +166,8 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
         }
     };
     fetch(slot);
+#define EST_MARK(k) do { if (a.prof && ch == 0 && gw == 0 && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - te_; te_ = t_; } } while (0)
+    unsigned long long te_ = (a.prof && ch == 0) ? __builtin_readcyclecounter() : 0ull;
     for (int j0 = 0; j0 < numffts; j0 += RB) {
         const int j = j0 + slot;
         // (a wave whose groups have no block left in the last round still walks the stages: its lanes are masked by `act`)
@@ -176,7 +178,9 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
         }
         fetch(j + RB);                                         // in flight during the transform
         __builtin_amdgcn_wave_barrier();
+        EST_MARK(10);
         for (int s = 0; s < a.n_stage; s++) { if (act) fsk_stage(buf, s_tw, a.st_p[s], a.st_m[s], a.st_fs[s], Ndft, lt, GL); __builtin_amdgcn_wave_barrier(); }
+        EST_MARK(11);
         // magnitudes in place: every lane reads its bins first, then the wave writes (mag[q] overlays buf[q / 2])
         float mg[FSK_AE];
 #pragma unroll
@@ -186,14 +190,18 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
 #pragma unroll
             for (int e = 0; e < FSK_AE; e++) if (e < EPL) mag[(lt + e * GL + Ndft / 2) & (Ndft - 1)] = mg[e];
         }
+        EST_MARK(12);
         fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
+        EST_MARK(13);
         const int nb = min(RB, numffts - j0);
         for (int k = gt; k < Ndft; k += GT) {                  // Sf = Sf (1 - tc) + |X| tc, block after block (fsk.c:497-503)
             float sf = s_Sf[k];
             for (int g = 0; g < nb; g++) sf = (sf * omt) + (reinterpret_cast<const float *>(s_fb + g * Ndft)[k] * tc);
             s_Sf[k] = sf;
         }
+        EST_MARK(12);
         fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
+        EST_MARK(13);
     }
     if (gw != 0) return;
     // the searches are short: one wave
@@ -225,6 +233,7 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
         for (int m = 0; m < M; m++) { f_est[m] = a.f_mask[M * b_max + m]; dphi[m] = a.dphi_mask[M * b_max + m]; }
     }
     if (lane == 0) for (int m = 0; m < M; m++) { o_fest[m] = f_est[m]; o_dphi[m] = dphi[m]; }
+    EST_MARK(14);
 }
 
 // one step of the local oscillator phi *= d on the register pair %0 with temporaries %1, %2 and d = %3; the result goes to LDS at %4 + 8 k.
