@@ -15,6 +15,13 @@
  * A channel that has not delivered a frame for --release-s seconds of stream is ended and free again.
  *
  *     sonde_wideband [--cfreq Hz] [--raster Hz] [--slots N] [--release-s S] [--device D] [-v] - <sr> 16     < cs16 stream
+ *     sonde_wideband --channelize [--chan-M 256] [--chan-D 200] [--chan-P 16] [...] - <sr> 16                 the form for wide streams (BASELINE configs[2])
+ *
+ * --channelize: the stream is not mixed once per raster point and once per sonde; a polyphase channelizer (sonde_chan.h: M channels at sr / D, one pass)
+ * feeds the scanner (`dft_detect --iq --dc` on every channel) and, per sonde type, ONE IF-rate decoder engine whose channels are handed out at run
+ * time: a detection takes a free channel, which is fine-tuned to the offset the scanner measured inside its channelizer channel (cfg.if_tune /
+ * sonde_engine_tune_channel) and fed that channel's samples (sonde_chan_gather) from then on.  Every block costs one channelizer launch, one scanner
+ * step and one launch sequence per sonde type, whatever the number of sondes (python -m radiosonde_auto_rx_amd.wideband --channelize is the same loop).
  *
  * Same arguments as `python -m radiosonde_auto_rx_amd.wideband`; -v logs detections and releases on stderr.  Exit 0 at EOF, 255 on error
  * (no GPU, bad arguments).  The generic-family types (LMS6, iMet-54, Meisei, MRZ, MTS01) are listed on stderr when detected; their decoders are
@@ -27,6 +34,7 @@
 #include <string.h>
 #include "sonde_hip.h"
 #include "sonde_scan.h"
+#include "sonde_chan.h"
 #include "sonde_rs41.h"
 #include "sonde_dfm.h"
 #include "sonde_m10.h"
@@ -37,13 +45,14 @@ static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20" };
 
 typedef struct {
     int used, type, slot;
-    double fq;                           /* carrier / sample rate, snapped to the mixer raster */
+    int chan;                            /* --channelize: the channelizer channel it sits in */
+    double fq;                           /* carrier / sample rate, snapped to the mixer raster (--channelize: carrier in Hz relative to the stream centre / stream rate) */
     int khz;
     void *dec;                           /* sonde_<type>_dec_t */
     long frames; int64_t last_frame_at;  /* stream position (samples) of the last frame delivered */
 } sonde_t;
 
-typedef struct { sonde_engine_t *eng; int *owner; } group_t;       /* owner[slot] = index into g_sondes or -1 */
+typedef struct { sonde_engine_t *eng; int *owner; void *d_rows; int32_t *rows; long calls; } group_t;       /* owner[slot] = index into g_sondes or -1; --channelize: the engine's input rows */
 
 static int g_sr = 0, g_slots = 8, g_device = 0, g_verbose = 0;
 static long long g_cfreq = 0; static int g_raster = 10000; static double g_release_s = 20.0;
@@ -52,6 +61,10 @@ static sonde_t *g_sondes = NULL; static int g_nsondes = 0, g_capsondes = 0;
 static int64_t g_pos = 0;                                            /* samples consumed */
 static int g_chunk = 0;
 static char g_version[32] = "sonde_hip";
+/* --channelize */
+static int g_channelize = 0, g_M = 256, g_D = 200, g_P = 16, g_if_sr = 0, g_nmax = 0;
+static sonde_chan_t *g_chan = NULL;
+static double g_spacing = 0.0;
 
 static double snap_fq(double fq, int sr) { return (double)(long long)llround(fq * sr / 16.0) * 16.0 / sr; }      /* demod_mod.c:1265-1288 where 16 divides sr */
 
@@ -63,6 +76,9 @@ static int group_engine(int type) {
     c.sonde_type = type == T_RS41 ? SONDE_RS41 : type == T_DFM ? SONDE_DFM09 : type == T_M10 ? SONDE_M10 : SONDE_M20;
     c.opt_lp = SONDE_LP_IQ; c.ecc_level = type == T_DFM ? 1 : 2; c.opt_auto = type == T_DFM;
     c.max_chunk = g_chunk; c.max_frames = 16 * g_slots; c.input = SONDE_IN_IQ;
+    if (g_channelize) {                                             /* IF-rate float32 IQ from the channelizer, fine-tuned per channel */
+        c.sample_rate = g_if_sr; c.bits = 32; c.input = SONDE_IN_IFIQ3; c.if_tune = 1; c.max_chunk = g_nmax; c.max_frames = 8 * g_slots;
+    }
     double *fq = (double *)calloc((size_t)g_slots, sizeof(double));
     if (!fq) return SONDE_E_NOMEM;
     const int rc = sonde_engine_create(&c, fq, &g->eng);
@@ -71,6 +87,12 @@ static int group_engine(int type) {
     g->owner = (int *)malloc(sizeof(int) * (size_t)g_slots);
     if (!g->owner) return SONDE_E_NOMEM;
     for (int s = 0; s < g_slots; s++) g->owner[s] = -1;
+    if (g_channelize) {
+        g->rows = (int32_t *)malloc(sizeof(int32_t) * (size_t)g_slots);
+        if (!g->rows) return SONDE_E_NOMEM;
+        const int rc2 = sonde_chan_rows_alloc(g_chan, g_slots, &g->d_rows);
+        if (rc2 < 0) return rc2;
+    }
     return 0;
 }
 
@@ -130,6 +152,38 @@ static void start_sonde(int type, double fq_found) {
     if (!s->dec) { s->used = 0; return; }
     g->owner[slot] = idx;
     if (g_verbose) fprintf(stderr, "detected: %s %+.0f Hz (%d kHz) -> channel %d\n", kTypeName[type], fq * g_sr, s->khz, slot);
+}
+
+/* --channelize: a detection in channelizer channel k, df cycles per IF sample off its centre */
+static void start_sonde_chan(int type, int k, double df) {
+    const double f_hz = (double)(k < g_M / 2 ? k : k - g_M) * g_spacing + df * g_if_sr;
+    const double sep = (type == T_M10 || type == T_M20) ? 20000.0 : 8000.0;               /* the neighbouring channel sees a strong signal too */
+    for (int i = 0; i < g_nsondes; i++) if (g_sondes[i].used && g_sondes[i].type == type && fabs(g_sondes[i].fq * g_sr - f_hz) < sep) return;
+    if (group_engine(type) < 0) { fprintf(stderr, "sonde_wideband: no engine for %s\n", kTypeName[type]); return; }
+    group_t *g = &g_gr[type];
+    int slot = -1;
+    for (int s = 0; s < g_slots; s++) if (g->owner[s] < 0) { slot = s; break; }
+    if (slot < 0) { if (g_verbose) fprintf(stderr, "no free channel: %s %+.0f Hz\n", kTypeName[type], f_hz); return; }
+    if ((g->calls && sonde_engine_restart_channel(g->eng, slot) < 0) || sonde_engine_tune_channel(g->eng, slot, df) < 0) { fprintf(stderr, "sonde_wideband: channel set-up failed\n"); return; }
+    int idx = -1;
+    for (int i = 0; i < g_nsondes; i++) if (!g_sondes[i].used) { idx = i; break; }
+    if (idx < 0) {
+        if (g_nsondes == g_capsondes) {
+            const int cap = g_capsondes ? 2 * g_capsondes : 32;
+            sonde_t *p = (sonde_t *)realloc(g_sondes, sizeof(sonde_t) * (size_t)cap);
+            if (!p) return;
+            g_sondes = p; g_capsondes = cap;
+        }
+        idx = g_nsondes++;
+    }
+    sonde_t *s = &g_sondes[idx];
+    memset(s, 0, sizeof *s);
+    s->used = 1; s->type = type; s->slot = slot; s->chan = k; s->fq = f_hz / g_sr; s->last_frame_at = g_pos;
+    s->khz = g_cfreq ? (int)llround((g_cfreq + f_hz) / 1000.0) : 0;
+    s->dec = make_decoder(type, s->khz);
+    if (!s->dec) { s->used = 0; return; }
+    g->owner[slot] = idx;
+    if (g_verbose) fprintf(stderr, "detected: %s %+.0f Hz (%d kHz) in channel %d -> decoder channel %d\n", kTypeName[type], f_hz, s->khz, k, slot);
 }
 
 static void release_sonde(int idx) {
@@ -196,6 +250,94 @@ static void drain(int type, int finish) {
     fflush(stdout);
 }
 
+static void on_detection(const sonde_detection_t *d, int channelized, const double *raster) {
+    const double fq = channelized ? 0.0 : raster[d->channel] + d->df;
+    int type = -1;
+    if (!strcmp(d->type, "RS41")) { if (d->score > 0) type = T_RS41; else return; }
+    else if (!strcmp(d->type, "DFM9")) type = T_DFM;                 /* either polarity: the decoder runs with --auto */
+    else if (!strcmp(d->type, "M10")) type = T_M10;                  /* differential code: polarity does not matter */
+    else if (!strcmp(d->type, "M20")) type = T_M20;
+    if (type < 0) { if (g_verbose) fprintf(stderr, "seen: %s %.4f in %s %d (decoder: the type's stand-alone front end)\n", d->type, d->score, channelized ? "channel" : "raster point", d->channel); return; }
+    if (channelized) start_sonde_chan(type, d->channel, d->df); else start_sonde(type, fq);
+}
+
+/* --channelize: channelizer -> scanner on every channel -> per type one IF-rate engine with run-time channels */
+static int run_channelized(void) {
+    sonde_chan_cfg_t cc; memset(&cc, 0, sizeof cc);
+    cc.abi_version = SONDE_ABI_VERSION; cc.device = g_device; cc.sample_rate = g_sr; cc.M = g_M; cc.D = g_D; cc.P = g_P;
+    g_chunk = g_sr / 4; g_chunk -= g_chunk % g_D;
+    cc.max_chunk = g_chunk;
+    int rc = sonde_chan_create(&cc, &g_chan);
+    if (rc < 0) { fprintf(stderr, "sonde_wideband: channelizer: %s\n", sonde_strerror(rc)); return 255; }
+    sonde_chan_info_t ci; sonde_chan_info(g_chan, &ci);
+    if (ci.out_rate_den < 1 || ci.out_rate_num % ci.out_rate_den) { fprintf(stderr, "sonde_wideband: sr / D must be an integer rate\n"); return 255; }
+    g_if_sr = ci.out_rate_num / ci.out_rate_den; g_nmax = ci.max_frames; g_spacing = (double)g_sr / g_M;
+    void *d_out = NULL; int64_t stride = 0;
+    if (sonde_chan_output(g_chan, &d_out, &stride) < 0) return 255;
+    sonde_scan_cfg_t sc; memset(&sc, 0, sizeof sc);
+    sc.abi_version = SONDE_ABI_VERSION; sc.device = g_device; sc.n_channels = g_M; sc.sample_rate = g_if_sr; sc.bits = 32; sc.iq_mode = SONDE_SCAN_IFIQ;
+    sc.opt_dc = 1; sc.opt_cont = 1; sc.audio_channels = 1; sc.max_chunk = g_nmax;
+    double *zero = (double *)calloc((size_t)g_M, sizeof(double));
+    sonde_scan_t *scan = NULL;
+    rc = zero ? sonde_scan_create(&sc, zero, &scan) : SONDE_E_NOMEM;
+    free(zero);
+    if (rc < 0) { fprintf(stderr, "sonde_wideband: scanner: %s\n", sonde_strerror(rc)); return 255; }
+    int16_t *buf = (int16_t *)malloc((size_t)g_chunk * 4);
+    if (!buf) return 255;
+    size_t have = 0;
+    int eof = 0;
+    while (!eof) {
+        while (have < (size_t)g_chunk * 4) {
+            const size_t k = fread((char *)buf + have, 1, (size_t)g_chunk * 4 - have, stdin);
+            if (!k) { eof = 1; break; }
+            have += k;
+        }
+        int n = (int)(have / 4); n -= n % g_D;
+        if (n > 0) {
+            const int m = sonde_chan_process_host(g_chan, buf, n, d_out, stride);            /* m IF samples per channel */
+            if (m < 0 || sonde_chan_sync(g_chan) < 0) { fprintf(stderr, "sonde_wideband: channelizer: %s\n", sonde_strerror(m < 0 ? m : SONDE_E_NOGPU)); return 255; }
+            if (m > 0) {
+                rc = sonde_scan_process_device(scan, d_out, stride, m);
+                if (rc < 0) { fprintf(stderr, "sonde_wideband: scanner: %s\n", sonde_strerror(rc)); return 255; }
+                sonde_detection_t det[64];
+                for (;;) {
+                    const int k = sonde_scan_fetch(scan, det, 64);
+                    for (int i = 0; i < k; i++) on_detection(&det[i], 1, NULL);
+                    if (k < 64) break;
+                }
+                for (int t = 0; t < T_N; t++) {                      /* every decoder channel gets its channelizer channel's samples of this block */
+                    group_t *g = &g_gr[t];
+                    if (!g->eng) continue;
+                    for (int sl = 0; sl < g_slots; sl++) g->rows[sl] = g->owner[sl] >= 0 ? g_sondes[g->owner[sl]].chan : -1;
+                    if (sonde_chan_gather(g_chan, d_out, stride, g->rows, g_slots, m, g->d_rows) < 0) { fprintf(stderr, "sonde_wideband: gather failed\n"); return 255; }
+                }
+                if (sonde_chan_sync(g_chan) < 0) return 255;           /* the copies ran on the channelizer's stream, the engines have their own */
+                for (int t = 0; t < T_N; t++) {
+                    group_t *g = &g_gr[t];
+                    if (!g->eng) continue;
+                    rc = sonde_engine_process_device(g->eng, g->d_rows, g_nmax, m);
+                    if (rc < 0) { fprintf(stderr, "sonde_wideband: %s engine: %s\n", kTypeName[t], sonde_strerror(rc)); return 255; }
+                    g->calls++;
+                }
+                g_pos += m;
+                for (int t = 0; t < T_N; t++) drain(t, 0);
+                for (int i = 0; i < g_nsondes; i++)
+                    if (g_sondes[i].used && g_release_s > 0 && (double)(g_pos - g_sondes[i].last_frame_at) > g_release_s * g_if_sr) release_sonde(i);
+            }
+        }
+        const size_t rest = have - (size_t)n * 4;
+        memmove(buf, (char *)buf + (size_t)n * 4, rest);
+        have = rest;
+    }
+    for (int t = 0; t < T_N; t++) drain(t, 1);
+    for (int i = 0; i < g_nsondes; i++) if (g_sondes[i].used) free_decoder(g_sondes[i].type, g_sondes[i].dec);
+    for (int t = 0; t < T_N; t++) { if (g_gr[t].eng) sonde_engine_destroy(g_gr[t].eng); free(g_gr[t].owner); free(g_gr[t].rows); }
+    sonde_scan_destroy(scan);
+    sonde_chan_destroy(g_chan);
+    free(buf); free(g_sondes);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     int ai = 1;
     for (; ai < argc; ai++) {
@@ -205,14 +347,19 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "--release-s") && ai + 1 < argc) g_release_s = atof(argv[++ai]);
         else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) g_device = atoi(argv[++ai]);
         else if (!strcmp(argv[ai], "-v")) g_verbose = 1;
+        else if (!strcmp(argv[ai], "--channelize")) g_channelize = 1;
+        else if (!strcmp(argv[ai], "--chan-M") && ai + 1 < argc) g_M = atoi(argv[++ai]);
+        else if (!strcmp(argv[ai], "--chan-D") && ai + 1 < argc) g_D = atoi(argv[++ai]);
+        else if (!strcmp(argv[ai], "--chan-P") && ai + 1 < argc) g_P = atoi(argv[++ai]);
         else break;
     }
     if (argc - ai != 3 || strcmp(argv[ai], "-") || atoi(argv[ai + 2]) != 16 || atoi(argv[ai + 1]) < 48000 || g_raster < 100 || g_slots < 1 || g_slots > 256) {
-        fprintf(stderr, "usage: %s [--cfreq Hz] [--raster Hz] [--slots N] [--release-s S] [--device D] [-v] - <sr> 16   (cs16 on stdin)\n", argv[0]);
+        fprintf(stderr, "usage: %s [--channelize [--chan-M 256] [--chan-D 200] [--chan-P 16]] [--cfreq Hz] [--raster Hz] [--slots N] [--release-s S] [--device D] [-v] - <sr> 16   (cs16 on stdin)\n", argv[0]);
         return 255;
     }
     g_sr = atoi(argv[ai + 1]);
     if (getenv("SONDE_JSN_VERSION")) snprintf(g_version, sizeof g_version, "%s", getenv("SONDE_JSN_VERSION"));
+    if (g_channelize) return run_channelized();
     /* raster of the scanner: every `raster` Hz over +-0.45 of the sample rate, snapped like an --IQ argument */
     const int kmax = (int)(0.45 * g_sr / g_raster), nr = 2 * kmax + 1;
     double *raster = (double *)malloc(sizeof(double) * (size_t)nr);
@@ -251,14 +398,7 @@ int main(int argc, char **argv) {
             sonde_detection_t det[64];
             for (;;) {
                 const int k = sonde_scan_fetch(scan, det, 64);
-                for (int i = 0; i < k; i++) {
-                    const double fq = raster[det[i].channel] + det[i].df;
-                    if (!strcmp(det[i].type, "RS41")) { if (det[i].score > 0) start_sonde(T_RS41, fq); }
-                    else if (!strcmp(det[i].type, "DFM9")) start_sonde(T_DFM, fq);                 /* either polarity: the decoder runs with --auto */
-                    else if (!strcmp(det[i].type, "M10")) start_sonde(T_M10, fq);                  /* differential code: polarity does not matter */
-                    else if (!strcmp(det[i].type, "M20")) start_sonde(T_M20, fq);
-                    else if (g_verbose) fprintf(stderr, "seen: %s %.4f %+.0f Hz (decoder: the type's stand-alone front end)\n", det[i].type, det[i].score, fq * g_sr);
-                }
+                for (int i = 0; i < k; i++) on_detection(&det[i], 0, raster);
                 if (k < 64) break;
             }
             for (int t = 0; t < T_N; t++) {

@@ -55,6 +55,16 @@ int  sonde_chan_process_host(sonde_chan_t *c, const void *h_iq, int32_t n_sample
 int  sonde_chan_sync(sonde_chan_t *c);
 void *sonde_chan_stream(sonde_chan_t *c);
 int  sonde_chan_kernel_ms(sonde_chan_t *c, double *avg_ms, int64_t *launches);
+/* For callers without a device allocator of their own (host/sonde_wideband.c --channelize; the Python receiver uses torch tensors):
+ *   sonde_chan_output      an output array [M][max_frames] complex float32 owned by the channelizer (freed with it)
+ *   sonde_chan_rows_alloc  a zeroed array [n_rows][max_frames] complex float32 for a decoder engine's channels (freed with the channelizer)
+ *   sonde_chan_gather      rows r = 0 .. n_rows-1 of d_rows <- the first n_frames samples of channel channels[r] of d_out (channels[r] < 0: row left
+ *                          alone); queued on the channelizer's stream, i.e. behind the process call that produced them — sonde_chan_sync() before an
+ *                          engine on another stream reads d_rows.  This is what auto_rx does per sonde with one rtl_fm / ss_iq process each
+ *                          (sdr_wrappers.py:270-371): here it is a row copy. */
+int  sonde_chan_output(sonde_chan_t *c, void **d_out, int64_t *out_stride);
+int  sonde_chan_rows_alloc(sonde_chan_t *c, int32_t n_rows, void **d_rows);
+int  sonde_chan_gather(sonde_chan_t *c, const void *d_out, int64_t out_stride, const int32_t *channels, int32_t n_rows, int32_t n_frames, void *d_rows);
 
 #ifdef __cplusplus
 }

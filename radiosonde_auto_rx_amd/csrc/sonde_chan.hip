@@ -107,6 +107,8 @@ struct sonde_chan {
     sonde_chan_info_t info{};
     hipStream_t stream = nullptr;
     uint32_t *d_x = nullptr; float *d_h = nullptr; float2 *d_tw = nullptr; void *d_stage = nullptr;
+    float2 *d_own = nullptr;            // sonde_chan_output(): [M][max_frames] owned by the channelizer (callers without a device allocator of their own)
+    std::vector<void *> rows;           // sonde_chan_rows_alloc()
     int T = 0, log2M = 0, hist = 0;
     long long n_in = 0, m_out = 0;      // stream samples consumed, output samples produced (per channel)
     double ms = 0; int64_t launches = 0;
@@ -165,7 +167,8 @@ void sonde_chan_destroy(sonde_chan_t *c) {
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (c->ev_a) hipEventDestroy(c->ev_a);
     if (c->ev_b) hipEventDestroy(c->ev_b);
-    for (void *p : { (void *)c->d_x, (void *)c->d_h, (void *)c->d_tw, c->d_stage }) if (p) hipFree(p);
+    for (void *p : { (void *)c->d_x, (void *)c->d_h, (void *)c->d_tw, c->d_stage, (void *)c->d_own }) if (p) hipFree(p);
+    for (void *p : c->rows) if (p) hipFree(p);
     delete c;
 }
 
@@ -227,6 +230,37 @@ int sonde_chan_sync(sonde_chan_t *c) {
 }
 
 void *sonde_chan_stream(sonde_chan_t *c) { return c ? (void *)c->stream : nullptr; }
+
+// For callers that have no device allocator (the C receiver host/sonde_wideband.c): an output array owned by the channelizer, row buffers for
+// the decoder engines, and the copy of chosen channel rows into such a buffer (on the channelizer's stream, behind the call that produced them).
+int sonde_chan_output(sonde_chan_t *c, void **d_out, int64_t *out_stride) {
+    if (!c || !d_out || !out_stride) return SONDE_E_ARG;
+    if (!c->d_own) {
+        HIPCHK(hipMalloc((void **)&c->d_own, (size_t)c->cfg.M * c->info.max_frames * sizeof(float2)));
+        HIPCHK(hipMemset(c->d_own, 0, (size_t)c->cfg.M * c->info.max_frames * sizeof(float2)));
+    }
+    *d_out = c->d_own; *out_stride = c->info.max_frames;
+    return 0;
+}
+int sonde_chan_rows_alloc(sonde_chan_t *c, int32_t n_rows, void **d_rows) {
+    if (!c || !d_rows || n_rows < 1) return SONDE_E_ARG;
+    void *p = nullptr;
+    if (hipMalloc(&p, (size_t)n_rows * c->info.max_frames * sizeof(float2)) != hipSuccess) return SONDE_E_NOMEM;
+    HIPCHK(hipMemset(p, 0, (size_t)n_rows * c->info.max_frames * sizeof(float2)));
+    c->rows.push_back(p);
+    *d_rows = p;
+    return 0;
+}
+int sonde_chan_gather(sonde_chan_t *c, const void *d_out, int64_t out_stride, const int32_t *channels, int32_t n_rows, int32_t n_frames, void *d_rows) {
+    if (!c || !d_out || !channels || !d_rows || n_rows < 0 || n_frames < 0 || n_frames > c->info.max_frames) return SONDE_E_ARG;
+    for (int r = 0; r < n_rows; r++) {
+        if (channels[r] < 0) continue;                            // row not in use
+        if (channels[r] >= c->cfg.M) return SONDE_E_RANGE;
+        HIPCHK(hipMemcpyAsync((float2 *)d_rows + (size_t)r * c->info.max_frames, (const float2 *)d_out + (size_t)channels[r] * out_stride,
+                              (size_t)n_frames * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+    }
+    return 0;
+}
 
 int sonde_chan_kernel_ms(sonde_chan_t *c, double *avg_ms, int64_t *launches) {
     if (!c) return SONDE_E_ARG;

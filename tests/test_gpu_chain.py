@@ -464,3 +464,49 @@ def test_wideband_receiver_gives_a_silent_sondes_decoder_back():
     assert kinds[-1] == "detected" or kinds[-1] == "released", ev
     nos = sorted(o["frame"] for o in out if o.get("id") == "A1111111")
     assert any(f < 150 for f in nos) and any(f >= 200 for f in nos), nos       # frames of both transmissions came out
+
+
+def test_wideband_c_entry_channelized_equals_the_python_receiver():
+    """host/bin/sonde_wideband --channelize (C; BASELINE configs[2]): one 10 Msps stream -> 256-channel polyphase channelizer -> scanner on every channel ->
+    run-time decoder channels -> JSON.  The Python ChannelizedReceiver is the same loop over the same C ABI (and its objects are checked against the
+    reference decoders in test_channelized_receiver_assigns_decoder_channels_at_run_time): both must print the same objects for the same stream."""
+    import json
+    from tools import synth
+    from radiosonde_auto_rx_amd.wideband import ChannelizedReceiver
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sr, M, D = 10_000_000, 256, 200
+    spacing = sr / M
+    secs = 4.4
+    n = int(sr * secs)
+    ecef = (418833319, 85974133, 473346430)
+    sondes = [("rs41", 31 * spacing + 1500.0, dict(sonde_id="K1111111", first_frame_no=300, t_first=0.15, n_frames=4, frame_kw=dict(ecef_cm=ecef))),
+              ("rs41", -80 * spacing - 2600.0, dict(sonde_id="L2222222", first_frame_no=700, t_first=0.45, n_frames=4, frame_kw=dict(ecef_cm=ecef))),
+              ("m10", 90 * spacing + 400.0, dict(frame_fn=lambda j: synth.m10_frame(j, rng=np.random.default_rng(40 + j))))]
+    acc = np.zeros(2 * n, np.float64)
+    for i, (kind, f_hz, kw) in enumerate(sondes):
+        x = (synth.rs41_capture if kind == "rs41" else synth.m10_capture)(sr=sr, seconds=secs, fq=f_hz / sr, seed=50 + i, noise_sigma=0.0, amp=0.2, **kw)
+        acc[:len(x)] += x[:2 * n]
+    acc += np.random.default_rng(98).normal(0.0, 60.0, size=2 * n)
+    iq = np.clip(np.round(acc), -32768, 32767).astype(np.int16)
+    del acc
+    cf = 403_000_000
+    rx = ChannelizedReceiver(sr, M=M, D=D, cfreq_hz=cf, slots=4, version="oracle")
+    want = []
+    for s0 in range(0, n, rx.chunk):
+        want += rx.push(iq[2 * s0:2 * min(n, s0 + rx.chunk)], finish=(s0 + rx.chunk >= n))
+    found = sorted((s["type"], s["chan"]) for s in rx.sondes)
+    rx.close()
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    r = subprocess.run([os.path.join(BIN, "sonde_wideband"), "--channelize", "-v", "--slots", "4", "--cfreq", str(cf), "-", str(sr), "16"],
+                       input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    got = [json.loads(l) for l in r.stdout.decode().splitlines()]
+    det = sorted((l.split()[1], int(l.split("in channel ")[1].split()[0])) for l in r.stderr.decode().splitlines() if l.startswith("detected: "))
+    assert det == found and len(found) == 3, (det, found)
+
+    def key(o):
+        return (o["type"], o.get("id", ""), o["frame"])
+    a, b = sorted(want, key=key), sorted(got, key=key)
+    assert len(a) >= 8 and [key(o) for o in a] == [key(o) for o in b]
+    for x, y in zip(a, b):
+        assert x == y, (x, y)
