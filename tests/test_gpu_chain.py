@@ -376,7 +376,8 @@ def test_channelized_receiver_assigns_decoder_channels_at_run_time():
 def test_channelized_receiver_decodes_the_generic_family():
     """the same receiver with sondes of the generic family in the 10 Msps stream: the scanner names LMS6 / IMET5 / MEISEI, each type gets one
     generic-description engine whose channels are handed out at run time, and every header hit goes through that sonde's own bit-rate tier
-    (radiosonde_auto_rx_amd/family.py) — ids, positions and frame counts as sent"""
+    (radiosonde_auto_rx_amd/family.py) — ids, positions and frame counts as sent, and the LMS6 / iMet-54 objects against the reference decoders run on
+    the same channel samples"""
     from tools import synth
     from radiosonde_auto_rx_amd.wideband import ChannelizedReceiver
     sr, M, D = 10_000_000, 256, 200
@@ -408,6 +409,37 @@ def test_channelized_receiver_decodes_the_generic_family():
     assert len(im) >= 2 and all(j["id"] == "IMET5-54012345" and abs(j["lat"] - 52.1236) < 1e-3 for j in im), im[:1]
     me = [j for j in out if j["type"] == "MEISEI"]
     assert len(me) >= 1 and all(j["subtype"] == "IMS100" and abs(j["lat"] - 35.2058) < 1e-3 for j in me), me[:1]      # one object per second once a frame pair is in
+    # the reference decoders on the same channel samples (`lms6Xmod / imet54mod --json --IQ <offset> --lpIQ - 50000 32`): position and time fields of
+    # every frame both decoded are equal
+    if not os.path.exists(os.path.join(REF, "lms6Xmod")):
+        return
+    import json
+    import torch
+    from radiosonde_auto_rx_amd.chan import Channelizer
+    ch = Channelizer(sr, M, D, 16, max_chunk=sr)
+    buf = torch.zeros(M, 5 * ch.max_frames, 2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    got = 0
+    for pos in range(0, n, sr):
+        take = min(sr, n - pos)
+        got += ch.process_host(iq[2 * pos:2 * (pos + take)], buf.data_ptr() + 8 * got, 5 * ch.max_frames)
+    ch.sync()
+    if_sr = int(ch.out_rate)
+    for typ, name, binary, args, mine in (("LMS6", "LMS", "lms6Xmod", ["--json", "--ecc", "--vit2"], lms), ("IMET5", "IMET5", "imet54mod", ["--json", "--ecc", "--ptu"], im)):
+        f = [f for t, f in found if t == typ][0]
+        k = ch.nearest_channel(f)
+        y = np.ascontiguousarray(buf[k, :got].cpu().numpy()).astype(np.float32).tobytes()
+        resid = (f - ch.channel_freq(k)) / if_sr
+        r = subprocess.run([os.path.join(REF, binary)] + args + ["--IQ", repr(resid), "--lpIQ", "-", str(if_sr), "32"], input=y, capture_output=True, timeout=120)
+        want = {o["frame"]: o for o in (json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{"))}
+        both = [j for j in mine if j["frame"] in want]
+        assert len(both) >= 2, (typ, sorted(want), [j["frame"] for j in mine])
+        for j in both:
+            w = want[j["frame"]]
+            for key in ("id", "datetime", "lat", "lon", "alt", "vel_h", "heading", "vel_v", "temp", "humidity", "subtype"):
+                if key in w:
+                    assert j.get(key) == w[key], (typ, key, j, w)
+    ch.close()
 
 
 def test_wideband_receiver_decodes_the_generic_family():
@@ -431,6 +463,23 @@ def test_wideband_receiver_decodes_the_generic_family():
     im = [j for j in out if j["type"] == "IMET5"]
     assert len(lms) >= 2 and all(j["id"] == "LMS6-8123456" and abs(j["freq"] - 403_300) <= 3 for j in lms), lms[:1]
     assert len(im) >= 2 and all(j["id"] == "IMET5-54012345" and abs(j["freq"] - 402_520) <= 3 for j in im), im[:1]
+    # ... and against the REFERENCE decoders started by hand on the same stream with the carrier the receiver found (what auto_rx would have
+    # started): every object they print for a frame the receiver also decoded (its decoders start at the detection) agrees field by field
+    if not os.path.exists(os.path.join(REF, "lms6Xmod")):
+        return
+    import json
+    det = {e["type"]: e["fq"] for e in log if e["event"] == "detected"}
+    for typ, name, binary, args, mine in (("LMS6", "LMS", "lms6Xmod", ["--json", "--ecc", "--vit2"], lms), ("IMET5", "IMET5", "imet54mod", ["--json", "--ecc", "--ptu"], im)):
+        r = subprocess.run([os.path.join(REF, binary)] + args + ["--jsn_cfq", str(cf), "--IQ", repr(det[typ]), "--lpIQ", "-", str(sr), "16"],
+                           input=iq.tobytes(), capture_output=True, timeout=600)
+        want = {o["frame"]: o for o in (json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{"))}
+        got = {o["frame"]: o for o in mine}
+        common = sorted(set(want) & set(got))
+        assert len(common) >= 2, (typ, sorted(want), sorted(got))
+        for f in common:
+            w, g = dict(want[f]), dict(got[f])
+            w.pop("version", None); g.pop("version", None)
+            assert w == g, (typ, f, w, g)
 
 
 def test_wideband_receiver_gives_a_silent_sondes_decoder_back():
