@@ -24,8 +24,8 @@
  * step and one launch sequence per sonde type, whatever the number of sondes (python -m radiosonde_auto_rx_amd.wideband --channelize is the same loop).
  *
  * Same arguments as `python -m radiosonde_auto_rx_amd.wideband`; -v logs detections and releases on stderr.  Exit 0 at EOF, 255 on error
- * (no GPU, bad arguments).  The generic-family types (LMS6, iMet-54, Meisei, MRZ, MTS01) are listed on stderr when detected; their decoders are
- * the stand-alone front ends (host/lms6Xmod.c ...).
+ * (no GPU, bad arguments).  The generic-family types (LMS6, iMet-54, Meisei, MRZ, MTS01) get a generic-description engine per type and their own
+ * bit-rate tiers (sonde_lms6.h ...): header hits + soft bits -> the JSON `lms6Xmod --json --ecc --vit2` / `imet54mod --json --ecc --ptu` / ... print.
  */
 #include <math.h>
 #include <stdint.h>
@@ -39,9 +39,26 @@
 #include "sonde_dfm.h"
 #include "sonde_m10.h"
 #include "sonde_m20.h"
+#include "sonde_lms6.h"
+#include "sonde_meisei.h"
+#include "sonde_imet54.h"
+#include "sonde_mrz.h"
+#include "sonde_mts01.h"
 
-enum { T_RS41, T_DFM, T_M10, T_M20, T_N };
-static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20" };
+enum { T_RS41, T_DFM, T_M10, T_M20, T_LMS6, T_MEISEI, T_IMET5, T_MRZ, T_MTS01, T_N };
+static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20", "LMS6", "MEISEI", "IMET5", "MRZ", "MTS01" };
+#define IS_FAMILY(t) ((t) >= T_LMS6)
+/* The generic family: what each decoder of the reference puts into dsp_t and passes to find_header() (sonde_generic_t, the same numbers as the
+ * stand-alone front ends host/lms6Xmod.c ... and radiosonde_auto_rx_amd/family.py), the header threshold, whether either polarity is taken, whether
+ * the decoder wants the bits as sent (raw) or in the polarity in effect, and how far apart two sondes of the type must be. */
+typedef struct { const char *header; float baud, bt, h; int symlen, symhd, hdmax, bitofs, nbits; float l_win; int lpiq_bw, lpfm_bw; float thres; int aut, raw_pol; double sep_hz; } family_t;
+static const family_t kFamily[T_N] = {
+    [T_LMS6]   = { "0101011000001000" "0001110010010111" "0001101010100111" "0011110100111110", 4800.0f, 1.2f, 0.9f, 1, 1, 10, 0, 261 * 16 - 80, -1.0f, 16000, 6000, 0.65f, 1, 1, 8000.0 },
+    [T_MEISEI] = { "101010101011010100101011001101001100101011001101", 2400.0f, 1.2f, 2.4f, 1, 1, 1, 0, 1152, -1.0f, 16000, 4000, 0.7f, 1, 0, 12000.0 },
+    [T_IMET5]  = { "0000000001" "0101010101" "0001001001" "0001001001", 4798.0f, 1.0f, 0.8f, 1, 1, 4, 1, 2200, 2.0f, 7400, 6000, 0.7f, 0, 0, 8000.0 },
+    [T_MRZ]    = { "100110011001100110011001100110011001" "10101010", 2399.0f, 1.0f, 2.0f, 2, 2, 2, 2, 386, 2.0f, 9000, 6000, 0.76f, 0, 0, 10000.0 },
+    [T_MTS01]  = { "10101010" "10101010" "10110100" "00101011", 1200.0f, 1.5f, 0.9f, 1, 1, 2, 0, 1048, 2.0f, 4000, 4000, 0.76f, 1, 1, 6000.0 },
+};
 
 typedef struct {
     int used, type, slot;
@@ -50,6 +67,7 @@ typedef struct {
     int khz;
     void *dec;                           /* sonde_<type>_dec_t */
     long frames; int64_t last_frame_at;  /* stream position (samples) of the last frame delivered */
+    uint32_t last_pos;                   /* LMS6: header position of the previous block (frame rate) */
 } sonde_t;
 
 typedef struct { sonde_engine_t *eng; int *owner; void *d_rows; int32_t *rows; long calls; } group_t;       /* owner[slot] = index into g_sondes or -1; --channelize: the engine's input rows */
@@ -61,6 +79,7 @@ static sonde_t *g_sondes = NULL; static int g_nsondes = 0, g_capsondes = 0;
 static int64_t g_pos = 0;                                            /* samples consumed */
 static int g_chunk = 0;
 static char g_version[32] = "sonde_hip";
+static int g_fam_if_sr = 48000;                                      /* IF rate of the base-rate engines (raster form) */
 /* --channelize */
 static int g_channelize = 0, g_M = 256, g_D = 200, g_P = 16, g_if_sr = 0, g_nmax = 0;
 static sonde_chan_t *g_chan = NULL;
@@ -81,7 +100,16 @@ static int group_engine(int type) {
     }
     double *fq = (double *)calloc((size_t)g_slots, sizeof(double));
     if (!fq) return SONDE_E_NOMEM;
-    const int rc = sonde_engine_create(&c, fq, &g->eng);
+    int rc;
+    if (IS_FAMILY(type)) {                                          /* header hits + soft bits; the type's bit-rate tier decodes them */
+        const family_t *f = &kFamily[type];
+        sonde_generic_t gd; memset(&gd, 0, sizeof gd);
+        snprintf(gd.header, sizeof gd.header, "%s", f->header);
+        gd.baud = f->baud; gd.bt = f->bt; gd.h = f->h; gd.symlen = f->symlen; gd.symhd = f->symhd; gd.hdmax = f->hdmax; gd.bitofs = f->bitofs;
+        gd.nbits = f->nbits; gd.l_win = f->l_win; gd.lpiq_bw = f->lpiq_bw; gd.lpfm_bw = f->lpfm_bw;
+        c.sonde_type = SONDE_GENERIC; c.keep_soft = 1; c.thres = f->thres; c.opt_auto = f->aut; c.ecc_level = 0; c.max_frames = 8 * g_slots;
+        rc = sonde_engine_create_generic(&c, fq, &gd, &g->eng);
+    } else rc = sonde_engine_create(&c, fq, &g->eng);
     free(fq);
     if (rc < 0) return rc;
     g->owner = (int *)malloc(sizeof(int) * (size_t)g_slots);
@@ -104,14 +132,27 @@ static void *make_decoder(int type, int khz) {
                               snprintf(o.version, sizeof o.version, "%s", g_version); if (sonde_dfm_dec_create(&o, (sonde_dfm_dec_t **)&d) < 0) return NULL; }
     else if (type == T_M10) { sonde_m10_opts_t o; memset(&o, 0, sizeof o); o.verbose = 1; o.ptu = 1; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
                               if (sonde_m10_dec_create(&o, (sonde_m10_dec_t **)&d) < 0) return NULL; }
-    else { sonde_m20_opts_t o; memset(&o, 0, sizeof o); o.verbose = 1; o.ptu = 1; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+    else if (type == T_M20) { sonde_m20_opts_t o; memset(&o, 0, sizeof o); o.verbose = 1; o.ptu = 1; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
            if (sonde_m20_dec_create(&o, (sonde_m20_dec_t **)&d) < 0) return NULL; }
+    else if (type == T_LMS6) { sonde_lms6_opts_t o; memset(&o, 0, sizeof o); o.ecc = 1; o.vit = 2; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+           if (sonde_lms6_dec_create(&o, (sonde_lms6_dec_t **)&d) < 0) return NULL; }
+    else if (type == T_MEISEI) { sonde_meisei_opts_t o; memset(&o, 0, sizeof o); o.ecc = 1; o.json = 1; o.ptu = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+           if (sonde_meisei_dec_create(&o, (sonde_meisei_dec_t **)&d) < 0) return NULL; }
+    else if (type == T_IMET5) { sonde_imet54_opts_t o; memset(&o, 0, sizeof o); o.ecc = 1; o.json = 1; o.ptu = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+           if (sonde_imet54_dec_create(&o, (sonde_imet54_dec_t **)&d) < 0) return NULL; }
+    else if (type == T_MRZ) { sonde_mrz_opts_t o; memset(&o, 0, sizeof o); o.json = 1; o.ptu = 1; o.uniq = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+           if (sonde_mrz_dec_create(&o, (sonde_mrz_dec_t **)&d) < 0) return NULL; }
+    else { sonde_mts01_opts_t o; memset(&o, 0, sizeof o); o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+           if (sonde_mts01_dec_create(&o, (sonde_mts01_dec_t **)&d) < 0) return NULL; }
     return d;
 }
 static void free_decoder(int type, void *d) {
     if (!d) return;
     if (type == T_RS41) sonde_rs41_dec_destroy((sonde_rs41_dec_t *)d); else if (type == T_DFM) sonde_dfm_dec_destroy((sonde_dfm_dec_t *)d);
-    else if (type == T_M10) sonde_m10_dec_destroy((sonde_m10_dec_t *)d); else sonde_m20_dec_destroy((sonde_m20_dec_t *)d);
+    else if (type == T_M10) sonde_m10_dec_destroy((sonde_m10_dec_t *)d); else if (type == T_M20) sonde_m20_dec_destroy((sonde_m20_dec_t *)d);
+    else if (type == T_LMS6) sonde_lms6_dec_destroy((sonde_lms6_dec_t *)d); else if (type == T_MEISEI) sonde_meisei_dec_destroy((sonde_meisei_dec_t *)d);
+    else if (type == T_IMET5) sonde_imet54_dec_destroy((sonde_imet54_dec_t *)d); else if (type == T_MRZ) sonde_mrz_dec_destroy((sonde_mrz_dec_t *)d);
+    else sonde_mts01_dec_destroy((sonde_mts01_dec_t *)d);
 }
 
 /* the JSON lines of a decoder's output text (it may also hold the decoder's text line) */
@@ -125,6 +166,7 @@ static void print_json_lines(const char *tx) {
 
 static void start_sonde(int type, double fq_found) {
     const double merge_hz = 6000.0 * ((type == T_M10 || type == T_M20) ? 3.0 : 1.0);       /* 9.6 kBd: seen from neighbouring raster points too */
+    if (IS_FAMILY(type) && g_gr[type].eng == NULL && g_verbose) fprintf(stderr, "engine: %s (generic description)\n", kTypeName[type]);
     for (int i = 0; i < g_nsondes; i++) if (g_sondes[i].used && fabs(g_sondes[i].fq - fq_found) * g_sr < merge_hz) return;
     const double fq = snap_fq(fq_found, g_sr);
     if (group_engine(type) < 0) { fprintf(stderr, "sonde_wideband: no engine for %s\n", kTypeName[type]); return; }
@@ -157,7 +199,7 @@ static void start_sonde(int type, double fq_found) {
 /* --channelize: a detection in channelizer channel k, df cycles per IF sample off its centre */
 static void start_sonde_chan(int type, int k, double df) {
     const double f_hz = (double)(k < g_M / 2 ? k : k - g_M) * g_spacing + df * g_if_sr;
-    const double sep = (type == T_M10 || type == T_M20) ? 20000.0 : 8000.0;               /* the neighbouring channel sees a strong signal too */
+    const double sep = IS_FAMILY(type) ? kFamily[type].sep_hz : (type == T_M10 || type == T_M20) ? 20000.0 : 8000.0;     /* the neighbouring channel sees a strong signal too */
     for (int i = 0; i < g_nsondes; i++) if (g_sondes[i].used && g_sondes[i].type == type && fabs(g_sondes[i].fq * g_sr - f_hz) < sep) return;
     if (group_engine(type) < 0) { fprintf(stderr, "sonde_wideband: no engine for %s\n", kTypeName[type]); return; }
     group_t *g = &g_gr[type];
@@ -200,7 +242,44 @@ static void release_sonde(int idx) {
 static void drain(int type, int finish) {
     group_t *g = &g_gr[type];
     if (!g->eng) return;
-    static char tx[8192];
+    static char tx[1 << 16];
+    if (IS_FAMILY(type)) {                                          /* header hits -> the type's bit-rate tier, one decoder object per sonde */
+        const family_t *f = &kFamily[type];
+        const int if_sr = g_channelize ? g_if_sr : g_fam_if_sr;
+        static sonde_hit_t hits[64];
+        static float *soft = NULL; static size_t soft_cap = 0;
+        for (;;) {
+            const int k = sonde_engine_fetch_hits(g->eng, hits, 64, finish);
+            finish = 0;
+            if (k <= 0) break;
+            if ((size_t)k * (size_t)f->nbits > soft_cap) { float *p = (float *)realloc(soft, sizeof(float) * (size_t)k * (size_t)f->nbits); if (!p) return; soft = p; soft_cap = (size_t)k * (size_t)f->nbits; }
+            if (sonde_engine_fetch_soft(g->eng, soft, k) < 0) return;
+            for (int i = 0; i < k; i++) {
+                const int o = (hits[i].channel >= 0 && hits[i].channel < g_slots) ? g->owner[hits[i].channel] : -1;
+                if (o < 0) continue;
+                sonde_t *sn = &g_sondes[o];
+                float *b = soft + (size_t)i * (size_t)f->nbits;
+                int n = hits[i].nbits;
+                if (f->raw_pol && hits[i].mv < 0.f) for (int j = 0; j < n; j++) b[j] = -b[j];      /* stored in the polarity in effect; this decoder reads the bits as sent */
+                int m = 0;
+                if (type == T_LMS6) {
+                    const int want = sonde_lms6_dec_block_bits((sonde_lms6_dec_t *)sn->dec); if (n > want) n = want;
+                    const uint32_t d = hits[i].mv_pos - sn->last_pos;
+                    const float rate = d ? (float)(4800.0 * if_sr / (double)d) : INFINITY;
+                    sn->last_pos = hits[i].mv_pos;
+                    m = sonde_lms6_dec_block((sonde_lms6_dec_t *)sn->dec, b, NULL, n, hits[i].mv, rate, ((double)hits[i].mv_pos + n * (double)if_sr / 4800.0) / if_sr, tx, sizeof tx);
+                }
+                else if (type == T_MEISEI) m = sonde_meisei_dec_frame((sonde_meisei_dec_t *)sn->dec, b, n, tx, sizeof tx);
+                else if (type == T_IMET5) m = sonde_imet54_dec_frame((sonde_imet54_dec_t *)sn->dec, b, n, tx, sizeof tx);
+                else if (type == T_MRZ) { const int want = sonde_mrz_dec_frame_bits((sonde_mrz_dec_t *)sn->dec); if (n > want) n = want; m = sonde_mrz_dec_frame((sonde_mrz_dec_t *)sn->dec, b, n, tx, sizeof tx); }
+                else m = sonde_mts01_dec_frame((sonde_mts01_dec_t *)sn->dec, b, n, tx, sizeof tx);
+                if (m > 0) { if ((size_t)m < sizeof tx) tx[m] = 0; else tx[sizeof tx - 1] = 0; print_json_lines(tx); }
+                sn->frames++; sn->last_frame_at = g_pos;
+            }
+        }
+        fflush(stdout);
+        return;
+    }
     for (;;) {
         int k = 0;
         if (type == T_RS41) {
@@ -257,6 +336,10 @@ static void on_detection(const sonde_detection_t *d, int channelized, const doub
     else if (!strcmp(d->type, "DFM9")) type = T_DFM;                 /* either polarity: the decoder runs with --auto */
     else if (!strcmp(d->type, "M10")) type = T_M10;                  /* differential code: polarity does not matter */
     else if (!strcmp(d->type, "M20")) type = T_M20;
+    else {                                                            /* the generic family: positive score, or either polarity where the decoder takes both */
+        static const struct { const char *name; int t; } fam[] = { { "LMS6", T_LMS6 }, { "MEISEI", T_MEISEI }, { "IMET5", T_IMET5 }, { "MRZ", T_MRZ }, { "MTS01", T_MTS01 } };
+        for (unsigned i = 0; i < sizeof fam / sizeof fam[0]; i++) if (!strcmp(d->type, fam[i].name)) { if (d->score > 0 || kFamily[fam[i].t].aut) type = fam[i].t; else return; }
+    }
     if (type < 0) { if (g_verbose) fprintf(stderr, "seen: %s %.4f in %s %d (decoder: the type's stand-alone front end)\n", d->type, d->score, channelized ? "channel" : "raster point", d->channel); return; }
     if (channelized) start_sonde_chan(type, d->channel, d->df); else start_sonde(type, fq);
 }
@@ -376,6 +459,7 @@ int main(int argc, char **argv) {
     /* calls are cut at multiples of the scanner's and the decoders' decimation factors (the decoders decimate to the reference's IF rate: 48 kHz,
      * raised until it divides the sample rate, demod_mod.c:1229-1236); what is left of a read waits for the next one */
     int if_sr = g_sr < 48000 ? g_sr : 48000; while (g_sr % if_sr) if_sr++;
+    g_fam_if_sr = if_sr;
     const int d1 = si.decM, d2 = g_sr / if_sr;
     int a = d1, b = d2; while (b) { const int t = a % b; a = b; b = t; }
     const int align = d1 / a * d2;

@@ -559,3 +559,59 @@ def test_wideband_c_entry_channelized_equals_the_python_receiver():
     assert len(a) >= 8 and [key(o) for o in a] == [key(o) for o in b]
     for x, y in zip(a, b):
         assert x == y, (x, y)
+
+
+@pytest.mark.parametrize("form", ["raster", "channelize"])
+def test_wideband_c_entry_generic_family_equals_the_python_receiver(form):
+    """The C receiver with sondes of the generic family (LMS6, iMet-54, Meisei: a generic-description engine per type, header hits + soft bits into the
+    type's bit-rate tier) prints the objects the Python receiver returns for the same stream — whose LMS6 / iMet-54 objects are checked against the
+    reference decoders in the two tests above."""
+    import json
+    from tools import synth
+    from radiosonde_auto_rx_amd.wideband import ChannelizedReceiver, WidebandReceiver
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    cf = 403_000_000
+    if form == "raster":
+        sr, secs = 2_400_000, 4.4
+        n = int(sr * secs)
+        fa, fb = synth.snap_fq(0.125, sr), synth.snap_fq(-0.2, sr)
+        acc = synth.lms6_capture(sr=sr, seconds=secs, fq=fa, noise_sigma=0.0, amp=0.25, seed=95).astype(np.float64)[:2 * n]
+        acc = acc + synth.imet54_capture(sr=sr, seconds=secs, fq=fb, noise_sigma=0.0, amp=0.25, seed=96).astype(np.float64)[:2 * n]
+        acc += np.random.default_rng(94).normal(0.0, 80.0, size=2 * n)
+        iq = np.clip(np.round(acc), -32768, 32767).astype(np.int16)
+        rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000, version="oracle")
+        want = rx.push(iq, finish=True)
+        args = []
+    else:
+        sr, M, D, secs = 10_000_000, 256, 200, 4.6
+        spacing = sr / M
+        n = int(sr * secs)
+        acc = np.zeros(2 * n, np.float64)
+        for f_hz, make in ((40 * spacing + 900.0, lambda fq: synth.lms6_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.0, amp=0.2, seed=91)),
+                           (-60 * spacing - 1200.0, lambda fq: synth.imet54_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.0, amp=0.2, seed=92)),
+                           (100 * spacing + 300.0, lambda fq: synth.meisei_capture(sr=sr, seconds=secs, fq=fq, noise_sigma=0.0, amp=0.2, seed=93))):
+            x = make(f_hz / sr)
+            acc[:len(x)] += x[:2 * n]
+        acc += np.random.default_rng(97).normal(0.0, 60.0, size=2 * n)
+        iq = np.clip(np.round(acc), -32768, 32767).astype(np.int16)
+        del acc
+        rx = ChannelizedReceiver(sr, M=M, D=D, cfreq_hz=cf, slots=2, version="oracle")
+        want = []
+        for s0 in range(0, n, rx.chunk):
+            want += rx.push(iq[2 * s0:2 * min(n, s0 + rx.chunk)], finish=(s0 + rx.chunk >= n))
+        args = ["--channelize", "--slots", "2"]
+    kinds = sorted(s["type"] for s in rx.sondes)
+    rx.close()
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    r = subprocess.run([os.path.join(BIN, "sonde_wideband")] + args + ["-v", "--cfreq", str(cf), "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    got = [json.loads(l) for l in r.stdout.decode().splitlines()]
+    det = sorted(l.split()[1] for l in r.stderr.decode().splitlines() if l.startswith("detected: "))
+    assert det == kinds and len(kinds) >= 2, (det, kinds)
+
+    def key(o):
+        return (o["type"], o.get("id", ""), o["frame"], o.get("datetime", ""))
+    a, b = sorted(want, key=key), sorted(got, key=key)
+    assert len(a) >= 4 and [key(o) for o in a] == [key(o) for o in b], ([key(o) for o in a], [key(o) for o in b])
+    for x, y in zip(a, b):
+        assert x == y, (x, y)
