@@ -23,7 +23,8 @@
  * caller's dsp_t, rs92mod, imet54mod, mp3h1mod, mts01mod, meisei100mod, lms6Xmod (kFamily below).  lms6Xmod rewrites dsp.br / dsp.sps after
  * init_buffers() (lms6Xmod.c:1336-1348 for --lms6 / --lmsX): the seam picks the value up at the first find_header() call and re-creates the engine with that
  * symbol rate for the bit clock and slicers (sonde_generic_t.slice_baud), 4096 raw bits per block for LMS6, 4720 for LMS-X.  A change of dsp.sps later in the
- * stream (auto detection switching between LMS6 and LMS-X, :1436-1462) ends the program with a message: samples already demodulated would need another scale.
+ * stream (auto detection switching between LMS6 and LMS-X, :1436-1462) sets the engine up again the same way, fed from the input history (3 s) starting
+ * 64 bits before the end of the block handed out last; hits before that block's end are dropped, mv_pos stays a position in the whole stream.
  *
  * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs are
  * taken from the first find_header call; a header of the wrong polarity that the
@@ -50,7 +51,10 @@ static struct {
     int nbits;                  /* soft bits per hit of this sonde type */
     size_t unit;                /* bytes per input sample */
     int chunk;
-    char *buf; size_t have;
+    /* input history: the samples since hist0 (an input sample index, multiple of decM), ~3 s — enough to set the engine up again from the end of a
+     * block when the caller changes the bit clock in mid-stream (lms6Xmod.c:1436-1462: LMS6 <-> LMS-X) */
+    char *hist; size_t cap; int64_t hist0, hist_n, fed, eng0, skip_before, keep;
+    int64_t last_gpos;          /* IF-rate position (whole stream) of the hit handed out last */
     int eof, started;
     sonde_hit_t hit[SEAM_MAXHITS];
     float *soft, *soft1;
@@ -152,19 +156,22 @@ int init_buffers(dsp_t *dsp) {
     S.chunk = cfg.sample_rate / 10;
     S.chunk -= S.chunk % S.info.decM;
     if (S.chunk < S.info.decM) S.chunk = S.info.decM;
-    S.buf = (char *)malloc((size_t)S.chunk * S.unit);
+    S.keep = (int64_t)cfg.sample_rate * 3;
+    S.cap = (size_t)(S.keep + 2 * (int64_t)S.chunk) * S.unit;
+    S.hist = (char *)malloc(S.cap);
     S.soft = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
     S.soft1 = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
-    S.have = 0; S.eof = 0; S.started = 0; S.qn = S.qi = 0; S.cur = NULL; S.cur_nbits = 0;
+    S.hist0 = S.hist_n = S.fed = S.eng0 = S.skip_before = 0; S.last_gpos = 0;
+    S.eof = 0; S.started = 0; S.qn = S.qi = 0; S.cur = NULL; S.cur_nbits = 0;
     S.sps_cur = dsp->sps; S.fam = fam;
-    if (!S.buf || !S.soft || !S.soft1) return -1;
+    if (!S.hist || !S.soft || !S.soft1) return -1;
     return S.info.K;
 }
 
 int free_buffers(dsp_t *dsp) {
     (void)dsp;
     if (S.eng) sonde_engine_destroy(S.eng);
-    free(S.buf); free(S.soft); free(S.soft1);
+    free(S.hist); free(S.soft); free(S.soft1);
     memset(&S, 0, sizeof S);
     return 0;
 }
@@ -172,11 +179,16 @@ int free_buffers(dsp_t *dsp) {
 int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
     (void)opt_dc;
     if (!S.eng) return EOF;
-    if (!S.started && S.generic && dsp->sps != S.sps_cur) {
-        /* the caller changed dsp.br / dsp.sps after init_buffers() (lms6Xmod.c:1336-1348): same filters and header template, new bit clock */
+    if (S.generic && dsp->sps != S.sps_cur) {
+        /* the caller changed dsp.br / dsp.sps: after init_buffers() and before the first search (lms6Xmod.c:1336-1348), or in mid-stream behind the block
+         * that showed the other type (:1436-1462).  Same filters and header template, new bit clock: the engine is set up again — in mid-stream from 64
+         * bits before the end of that block, out of the input history (the reference carries its filter state over that point; the same frames follow) */
+        const int midstream = S.started;
+        const double sps_old = S.sps_cur;
+        const int64_t block_end = S.last_gpos + (int64_t)((double)S.cur_nbits * sps_old);
         sonde_engine_destroy(S.eng); S.eng = NULL;
         S.gen.slice_baud = dsp->br;
-        if (S.fam >= 0 && kFamily[S.fam].hdr16 && !(dsp->br > 4799.9f && dsp->br < 4800.1f)) S.gen.nbits = 300 * 16 - 80;      /* LMS-X: RAWBITBLOCK_LEN - BLOCKSTART */
+        if (S.fam >= 0 && kFamily[S.fam].hdr16) S.gen.nbits = (dsp->br > 4799.9f && dsp->br < 4800.1f) ? kFamily[S.fam].nbits : 300 * 16 - 80;      /* LMS-X: RAWBITBLOCK_LEN - BLOCKSTART */
         double fq = S.fq;
         const int rc = sonde_engine_create_generic(&S.cfg, &fq, &S.gen, &S.eng);
         if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); S.eng = NULL; return EOF; }
@@ -185,9 +197,19 @@ int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
         S.soft = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
         S.soft1 = (float *)malloc((size_t)SEAM_MAXHITS * S.nbits * sizeof(float));
         if (!S.soft || !S.soft1) return EOF;
+        if (midstream) {
+            int64_t from = (block_end - (int64_t)(64 * sps_old)) * S.info.decM;
+            from -= from % S.info.decM;
+            if (from < S.hist0) from = S.hist0;
+            if (from > S.fed) from = S.fed;
+            S.eng0 = from; S.fed = from; S.skip_before = block_end;
+            S.qn = S.qi = 0; S.cur = S.cur1 = NULL; S.cur_nbits = 0;
+            if (S.eof) S.eof = 1;
+            S.started = 0;                          /* threshold / sync arguments are applied to the new engine below */
+        }
     }
-    if (dsp->sps != S.sps_cur) {
-        fprintf(stderr, "demod_mod_hip: dsp.sps changed from %g to %g in mid-stream; the engine cannot re-scale samples it has already demodulated\n", S.sps_cur, dsp->sps);
+    else if (dsp->sps != S.sps_cur) {
+        fprintf(stderr, "demod_mod_hip: dsp.sps changed from %g to %g in mid-stream; only the generic family follows that\n", S.sps_cur, dsp->sps);
         exit(2);
     }
     if (!S.started) {                                  /* the caller's threshold, accepted header errors and bit offset (e.g. -d <shift>) */
@@ -197,31 +219,45 @@ int find_header(dsp_t *dsp, float thres, int hdmax, int bitofs, int opt_dc) {
         S.started = 1;
     }
     for (;;) {
-        if (S.qi < S.qn) {
-            const sonde_hit_t *h = &S.hit[S.qi];
-            S.cur = S.soft + (size_t)S.qi * S.nbits; S.cur1 = S.soft1 + (size_t)S.qi * S.nbits;
+        while (S.qi < S.qn) {
+            const int idx = S.qi++;
+            const sonde_hit_t *h = &S.hit[idx];
+            const int64_t gpos = S.eng0 / S.info.decM + (int64_t)h->mv_pos;       /* IF-rate position in the whole stream */
+            if (gpos < S.skip_before) continue;                                      /* belongs to a block already handed out before a restart */
+            S.cur = S.soft + (size_t)idx * S.nbits; S.cur1 = S.soft1 + (size_t)idx * S.nbits;
             S.cur_nbits = h->nbits; S.cur_inv = h->mv < 0.f;
-            S.qi++;
-            dsp->mv = h->mv; dsp->mv_pos = h->mv_pos;
+            S.last_gpos = gpos;
+            dsp->mv = h->mv; dsp->mv_pos = (ui32_t)gpos;
             return 1;
         }
         S.cur = S.cur1 = NULL; S.cur_nbits = 0;
-        if (S.eof) return EOF;
-        size_t got = fread(S.buf + S.have, 1, (size_t)S.chunk * S.unit - S.have, dsp->fp);
-        S.have += got;
-        int n = (int)(S.have / S.unit);
+        if (S.eof == 2) return EOF;                                                 /* the stream's last hits have been handed out */
+        if (!S.eof && S.hist0 + S.hist_n - S.fed < S.chunk) {          /* (after a restart: first catch up with what is held) */
+            if ((size_t)(S.hist_n + S.chunk) * S.unit > S.cap) {                        /* drop what is older than `keep` */
+                int64_t drop = S.hist_n - S.keep;
+                drop -= drop % S.info.decM;
+                if (drop > S.fed - S.hist0) drop = S.fed - S.hist0;
+                if (drop > 0) { memmove(S.hist, S.hist + (size_t)drop * S.unit, (size_t)(S.hist_n - drop) * S.unit); S.hist0 += drop; S.hist_n -= drop; }
+            }
+            const size_t got = fread(S.hist + (size_t)S.hist_n * S.unit, S.unit, (size_t)S.chunk, dsp->fp);
+            S.hist_n += (int64_t)got;
+            if (got == 0) S.eof = 1;
+        }
+        int64_t n = S.hist0 + S.hist_n - S.fed;
+        if (n > S.chunk) n = S.chunk;
         n -= n % S.info.decM;
         if (n > 0) {
-            int rc = sonde_engine_process_host(S.eng, S.buf, n, n);
+            const int rc = sonde_engine_process_host(S.eng, S.hist + (size_t)(S.fed - S.hist0) * S.unit, n, (int32_t)n);
             if (rc < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(rc)); return EOF; }
-            memmove(S.buf, S.buf + (size_t)n * S.unit, S.have - (size_t)n * S.unit);
-            S.have -= (size_t)n * S.unit;
+            S.fed += n;
         }
-        if (got == 0) S.eof = 1;
-        S.qn = sonde_engine_fetch_hits(S.eng, S.hit, SEAM_MAXHITS, S.eof);
+        const int at_end = S.eof && S.hist0 + S.hist_n - S.fed < S.info.decM;
+        if (n <= 0 && !at_end) continue;
+        S.qn = sonde_engine_fetch_hits(S.eng, S.hit, SEAM_MAXHITS, at_end);
         if (S.qn < 0) { fprintf(stderr, "demod_mod_hip: %s\n", sonde_strerror(S.qn)); S.qn = 0; return EOF; }
         if (S.qn > 0) { sonde_engine_fetch_soft(S.eng, S.soft, S.qn); sonde_engine_fetch_soft1(S.eng, S.soft1, S.qn); }
         S.qi = 0;
+        if (at_end) { if (S.qn == 0) return EOF; S.eof = 2; }             /* the stream's last hits are handed out, then EOF */
     }
 }
 

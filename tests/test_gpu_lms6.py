@@ -1,6 +1,6 @@
 """Native `lms6Xmod` (host/lms6Xmod.c: the engine's generic sonde description + include/sonde_lms6.h) on samples: stdout against the compiled
 reference decoder on the same captures — IQ at SDR rate, IF-rate IQ, FM audio; LMS6, forced LMS-X, and the auto detection's change of
-symbol rate in mid-stream (which the function-level seam refuses, tests/test_gpu_seam.py)."""
+symbol rate in mid-stream (the function-level seam follows it the same way, tests/test_gpu_seam.py)."""
 import io
 import os
 import subprocess
