@@ -170,7 +170,8 @@ int main(int argc, char **argv) {
     sonde_generic_t g;
     memset(&g, 0, sizeof g);
     strcpy(g.header, kHeader);
-    g.baud = 4800.0f; g.bt = 0.5f; g.h = ngp0 ? 3.8f : 0.8f; g.symlen = 2; g.symhd = 2;                  /* rs92mod.c:1914-1943 */
+    g.baud = 4800.0f; g.bt = 0.5f; g.h = 0.8f; g.symlen = 2; g.symhd = 2;                                /* rs92mod.c:1914-1943 */
+    if (ngp0) g.h = 3.8f;                                                                              /* 1680 MHz RS92-NGP: 4.2 times the deviation */
     g.hdmax = 3; g.bitofs = 2 + shift;                                                                /* :1619,1957,1992 */
     g.nbits = SONDE_RS92_FRAME_BITS;
     g.l_win = 4.0f;                                                                                    /* bl = 4.0 for opt_iq > 2, whole bits else (:2026-2028) */

@@ -44,9 +44,10 @@
 #include "sonde_imet54.h"
 #include "sonde_mrz.h"
 #include "sonde_mts01.h"
+#include "sonde_rs92.h"
 
-enum { T_RS41, T_DFM, T_M10, T_M20, T_LMS6, T_MEISEI, T_IMET5, T_MRZ, T_MTS01, T_N };
-static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20", "LMS6", "MEISEI", "IMET5", "MRZ", "MTS01" };
+enum { T_RS41, T_DFM, T_M10, T_M20, T_LMS6, T_MEISEI, T_IMET5, T_MRZ, T_MTS01, T_RS92, T_N };
+static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20", "LMS6", "MEISEI", "IMET5", "MRZ", "MTS01", "RS92" };
 #define IS_FAMILY(t) ((t) >= T_LMS6)
 /* The generic family: what each decoder of the reference puts into dsp_t and passes to find_header() (sonde_generic_t, the same numbers as the
  * stand-alone front ends host/lms6Xmod.c ... and radiosonde_auto_rx_amd/family.py), the header threshold, whether either polarity is taken, whether
@@ -58,6 +59,7 @@ static const family_t kFamily[T_N] = {
     [T_IMET5]  = { "0000000001" "0101010101" "0001001001" "0001001001", 4798.0f, 1.0f, 0.8f, 1, 1, 4, 1, 2200, 2.0f, 7400, 6000, 0.7f, 0, 0, 8000.0 },
     [T_MRZ]    = { "100110011001100110011001100110011001" "10101010", 2399.0f, 1.0f, 2.0f, 2, 2, 2, 2, 386, 2.0f, 9000, 6000, 0.76f, 0, 0, 10000.0 },
     [T_MTS01]  = { "10101010" "10101010" "10110100" "00101011", 1200.0f, 1.5f, 0.9f, 1, 1, 2, 0, 1048, 2.0f, 4000, 4000, 0.76f, 1, 1, 6000.0 },
+    [T_RS92]   = { "10100110011001101001" "1010011001100110100110101010100110101001", 4800.0f, 0.5f, 0.8f, 2, 2, 3, 2, SONDE_RS92_FRAME_BITS, 4.0f, 8000, 6000, 0.7f, 0, 0, 8000.0 },
 };
 
 typedef struct {
@@ -79,6 +81,7 @@ static sonde_t *g_sondes = NULL; static int g_nsondes = 0, g_capsondes = 0;
 static int64_t g_pos = 0;                                            /* samples consumed */
 static int g_chunk = 0;
 static char g_version[32] = "sonde_hip";
+static const char *g_rs92_eph = NULL, *g_rs92_alm = NULL;        /* orbit data for RS92 positions (rs92mod -e / -a) */
 static int g_fam_if_sr = 48000;                                      /* IF rate of the base-rate engines (raster form) */
 /* --channelize */
 static int g_channelize = 0, g_M = 256, g_D = 200, g_P = 16, g_if_sr = 0, g_nmax = 0;
@@ -142,6 +145,11 @@ static void *make_decoder(int type, int khz) {
            if (sonde_imet54_dec_create(&o, (sonde_imet54_dec_t **)&d) < 0) return NULL; }
     else if (type == T_MRZ) { sonde_mrz_opts_t o; memset(&o, 0, sizeof o); o.json = 1; o.ptu = 1; o.uniq = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
            if (sonde_mrz_dec_create(&o, (sonde_mrz_dec_t **)&d) < 0) return NULL; }
+    else if (type == T_RS92) { sonde_rs92_opts_t o; memset(&o, 0, sizeof o); o.verbose = 1; o.aux = 1; o.ecc = 2; o.gps_vel = 4; o.json = 1; o.gpsepoch = -1; o.jsn_freq_khz = khz;     /* rs92mod -vx -v --crc --ecc --vel --json (decode.py:484) */
+           snprintf(o.version, sizeof o.version, "%s", g_version);
+           if (sonde_rs92_dec_create(&o, (sonde_rs92_dec_t **)&d) < 0) return NULL;
+           if (g_rs92_alm && sonde_rs92_dec_load_almanac((sonde_rs92_dec_t *)d, g_rs92_alm) < 0) fprintf(stderr, "rs92: almanac %s not readable as such\n", g_rs92_alm);
+           if (g_rs92_eph && sonde_rs92_dec_load_ephemeris((sonde_rs92_dec_t *)d, g_rs92_eph) < 0) fprintf(stderr, "rs92: ephemeris %s not readable as such\n", g_rs92_eph); }
     else { sonde_mts01_opts_t o; memset(&o, 0, sizeof o); o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
            if (sonde_mts01_dec_create(&o, (sonde_mts01_dec_t **)&d) < 0) return NULL; }
     return d;
@@ -152,6 +160,7 @@ static void free_decoder(int type, void *d) {
     else if (type == T_M10) sonde_m10_dec_destroy((sonde_m10_dec_t *)d); else if (type == T_M20) sonde_m20_dec_destroy((sonde_m20_dec_t *)d);
     else if (type == T_LMS6) sonde_lms6_dec_destroy((sonde_lms6_dec_t *)d); else if (type == T_MEISEI) sonde_meisei_dec_destroy((sonde_meisei_dec_t *)d);
     else if (type == T_IMET5) sonde_imet54_dec_destroy((sonde_imet54_dec_t *)d); else if (type == T_MRZ) sonde_mrz_dec_destroy((sonde_mrz_dec_t *)d);
+    else if (type == T_RS92) sonde_rs92_dec_destroy((sonde_rs92_dec_t *)d);
     else sonde_mts01_dec_destroy((sonde_mts01_dec_t *)d);
 }
 
@@ -272,6 +281,7 @@ static void drain(int type, int finish) {
                 else if (type == T_MEISEI) m = sonde_meisei_dec_frame((sonde_meisei_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 else if (type == T_IMET5) m = sonde_imet54_dec_frame((sonde_imet54_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 else if (type == T_MRZ) { const int want = sonde_mrz_dec_frame_bits((sonde_mrz_dec_t *)sn->dec); if (n > want) n = want; m = sonde_mrz_dec_frame((sonde_mrz_dec_t *)sn->dec, b, n, tx, sizeof tx); }
+                else if (type == T_RS92) m = sonde_rs92_dec_frame((sonde_rs92_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 else m = sonde_mts01_dec_frame((sonde_mts01_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 if (m > 0) { if ((size_t)m < sizeof tx) tx[m] = 0; else tx[sizeof tx - 1] = 0; print_json_lines(tx); }
                 sn->frames++; sn->last_frame_at = g_pos;
@@ -337,7 +347,7 @@ static void on_detection(const sonde_detection_t *d, int channelized, const doub
     else if (!strcmp(d->type, "M10")) type = T_M10;                  /* differential code: polarity does not matter */
     else if (!strcmp(d->type, "M20")) type = T_M20;
     else {                                                            /* the generic family: positive score, or either polarity where the decoder takes both */
-        static const struct { const char *name; int t; } fam[] = { { "LMS6", T_LMS6 }, { "MEISEI", T_MEISEI }, { "IMET5", T_IMET5 }, { "MRZ", T_MRZ }, { "MTS01", T_MTS01 } };
+        static const struct { const char *name; int t; } fam[] = { { "LMS6", T_LMS6 }, { "MEISEI", T_MEISEI }, { "IMET5", T_IMET5 }, { "MRZ", T_MRZ }, { "MTS01", T_MTS01 }, { "RS92", T_RS92 } };
         for (unsigned i = 0; i < sizeof fam / sizeof fam[0]; i++) if (!strcmp(d->type, fam[i].name)) { if (d->score > 0 || kFamily[fam[i].t].aut) type = fam[i].t; else return; }
     }
     if (type < 0) { if (g_verbose) fprintf(stderr, "seen: %s %.4f in %s %d (decoder: the type's stand-alone front end)\n", d->type, d->score, channelized ? "channel" : "raster point", d->channel); return; }
@@ -431,13 +441,15 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[ai], "--device") && ai + 1 < argc) g_device = atoi(argv[++ai]);
         else if (!strcmp(argv[ai], "-v")) g_verbose = 1;
         else if (!strcmp(argv[ai], "--channelize")) g_channelize = 1;
+        else if (!strcmp(argv[ai], "--rs92-ephem") && ai + 1 < argc) g_rs92_eph = argv[++ai];
+        else if (!strcmp(argv[ai], "--rs92-alm") && ai + 1 < argc) g_rs92_alm = argv[++ai];
         else if (!strcmp(argv[ai], "--chan-M") && ai + 1 < argc) g_M = atoi(argv[++ai]);
         else if (!strcmp(argv[ai], "--chan-D") && ai + 1 < argc) g_D = atoi(argv[++ai]);
         else if (!strcmp(argv[ai], "--chan-P") && ai + 1 < argc) g_P = atoi(argv[++ai]);
         else break;
     }
     if (argc - ai != 3 || strcmp(argv[ai], "-") || atoi(argv[ai + 2]) != 16 || atoi(argv[ai + 1]) < 48000 || g_raster < 100 || g_slots < 1 || g_slots > 256) {
-        fprintf(stderr, "usage: %s [--channelize [--chan-M 256] [--chan-D 200] [--chan-P 16]] [--cfreq Hz] [--raster Hz] [--slots N] [--release-s S] [--device D] [-v] - <sr> 16   (cs16 on stdin)\n", argv[0]);
+        fprintf(stderr, "usage: %s [--channelize [--chan-M 256] [--chan-D 200] [--chan-P 16]] [--cfreq Hz] [--raster Hz] [--slots N] [--release-s S] [--rs92-ephem rinex_nav] [--rs92-alm sem_almanac] [--device D] [-v] - <sr> 16   (cs16 on stdin)\n", argv[0]);
         return 255;
     }
     g_sr = atoi(argv[ai + 1]);

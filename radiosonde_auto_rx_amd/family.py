@@ -1,6 +1,6 @@
 """The rest of the decoder family behind the engine's generic sonde description: descriptors (what the reference's decoders put into dsp_t and pass to
 find_header / read_softbit*) and ctypes bindings of their bit-rate tiers (include/sonde_lms6.h, sonde_meisei.h, sonde_imet54.h, sonde_mrz.h,
-sonde_mts01.h).  Host-side; `FamilyDecoder.hit(h)` takes one dict of Engine(sonde="generic").fetch_hits() and returns the characters the
+sonde_mts01.h, sonde_rs92.h).  Host-side; `FamilyDecoder.hit(h)` takes one dict of Engine(sonde="generic").fetch_hits() and returns the characters the
 reference decoder prints for that header hit; `.json_objects(text)` picks the JSON lines out of them.
 
 The scanner's type names (dft_detect.c:172-191) are the keys."""
@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 
 import numpy as np
 
@@ -41,6 +42,19 @@ class Mts01Opts(C.Structure):
     _fields_ = _opts(("raw", "verbose", "json", "jsn_freq_khz"))
 
 
+class Rs92Opts(C.Structure):
+    _fields_ = [(n, _I) for n in ("raw", "verbose", "aux", "ecc", "ptu", "inv", "ngp", "dbg", "json", "gps_verbose", "gps_iter", "gps_vel", "exsat", "gpsepoch")] + \
+               [("dop_limit", C.c_float), ("d_err", C.c_float), ("jsn_freq_khz", _I), ("version", C.c_char * 32), ("reserved", _I * 4)]
+
+
+# RS92 sends raw GPS ranges: its decoder needs orbit data (auto_rx downloads a RINEX navigation file per flight, decode.py:423-446)
+RS92_ORBITS = {"ephemeris": None, "almanac": None}
+
+
+def set_rs92_orbits(ephemeris: str | None = None, almanac: str | None = None):
+    RS92_ORBITS.update(ephemeris=ephemeris, almanac=almanac)
+
+
 # generic = sonde_generic_t; thres / keep_soft / auto = engine configuration; pol: what the decoder wants — "raw" (un-flip the engine's bits when the
 # header score is negative), "engine" (bits in the polarity in effect, as stored)
 FAMILY = {
@@ -56,6 +70,9 @@ FAMILY = {
     "MRZ": dict(generic=dict(header="100110011001100110011001100110011001" "10101010", baud=2399.0, bt=1.0, h=2.0, symlen=2, symhd=2,
                              hdmax=2, bitofs=2, nbits=386, l_win=2.0, lpiq_bw=9000, lpfm_bw=6000),                     # mp3h1mod.c:117,1112-1131,1181
                 thres=0.76, auto=False, pol="engine", prefix="mrz", opts=MrzOpts, kw=dict(json=1, ptu=1, uniq=1), sep_hz=10000.0),
+    "RS92": dict(generic=dict(header="10100110011001101001" "1010011001100110100110101010100110101001", baud=4800.0, bt=0.5, h=0.8, symlen=2, symhd=2,
+                              hdmax=3, bitofs=2, nbits=2340, l_win=4.0, lpiq_bw=8000, lpfm_bw=6000),                   # rs92mod.c:88-92,1914-1943,1992
+                 thres=0.7, auto=False, pol="engine", prefix="rs92", opts=Rs92Opts, kw=dict(verbose=1, aux=1, ecc=2, gps_vel=4, json=1, gpsepoch=-1), sep_hz=8000.0),
     "MTS01": dict(generic=dict(header="10101010" "10101010" "10110100" "00101011", baud=1200.0, bt=1.5, h=0.9, symlen=1, symhd=1,
                                hdmax=2, bitofs=0, nbits=1048, l_win=2.0, lpiq_bw=4000, lpfm_bw=4000),                  # mts01mod.c:47-48,514-533,575
                   thres=0.76, auto=True, pol="raw", prefix="mts01", opts=Mts01Opts, kw=dict(json=1), sep_hz=6000.0),
@@ -72,7 +89,8 @@ class FamilyDecoder:
         self._create, self._destroy = getattr(L, f"sonde_{p}_dec_create"), getattr(L, f"sonde_{p}_dec_destroy")
         self._create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         self._destroy.argtypes = [C.c_void_p]
-        o = self.f["opts"](**{**self.f["kw"], **kw}, jsn_freq_khz=freq_khz, version=version.encode())
+        okw = {k: v for k, v in kw.items() if k not in ("ephemeris", "almanac")}
+        o = self.f["opts"](**{**self.f["kw"], **okw}, jsn_freq_khz=freq_khz, version=version.encode())
         self._h = C.c_void_p()
         if self._create(C.byref(o), C.byref(self._h)) < 0:
             raise SondeError(f"sonde_{p}_dec_create: unsupported options")
@@ -87,6 +105,13 @@ class FamilyDecoder:
             self._fn.argtypes = [C.c_void_p, C.c_void_p, _I, C.c_char_p, C.c_size_t]
         if typ == "MRZ":
             L.sonde_mrz_dec_frame_bits.argtypes = [C.c_void_p]
+        if typ == "RS92":                                              # without orbit data: frames and JSON-less text only, as `rs92mod` without -e / -a
+            for kind in ("almanac", "ephemeris"):
+                path = kw.get(kind) or RS92_ORBITS[kind]
+                fn = getattr(L, f"sonde_rs92_dec_load_{kind}")
+                fn.argtypes = [C.c_void_p, C.c_char_p]
+                if path and fn(self._h, os.fsencode(path)) < 0:
+                    raise SondeError(f"RS92: {kind} file {path} not readable as such")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -140,7 +140,7 @@ class ChannelizedReceiver:
     Every block costs one channelizer launch, one scanner step and one launch sequence per sonde type, whatever the number of sondes."""
 
     TYPES = {"RS41": ("rs41", Rs41Telemetry), "DFM": ("dfm", DfmTelemetry), "M10": ("m10", M10Telemetry), "M20": ("m20", M20Telemetry)}
-    # + the scanner's LMS6 / MEISEI / IMET5 / MRZ / MTS01: generic sonde descriptions and the bit-rate tiers of family.py
+    # + the scanner's RS92 / LMS6 / MEISEI / IMET5 / MRZ / MTS01: generic sonde descriptions and the bit-rate tiers of family.py
 
     def __init__(self, sample_rate: int, *, M: int = 256, D: int = 200, P: int = 16, cfreq_hz: int = 0, slots: int = 16, chunk: int | None = None,
                  version: str = "sonde_hip", device: int = 0, idle_s: float = 30.0):
@@ -287,8 +287,13 @@ def main(argv=None):
     ap.add_argument("--cfreq", type=int, default=0, help="centre frequency of the stream in Hz (for the JSON freq field)")
     ap.add_argument("--raster", type=int, default=10_000, help="scanner raster in Hz")
     ap.add_argument("--channelize", action="store_true", help="polyphase channelizer front end (256 channels at sr / 200): for streams of several Msps")
+    ap.add_argument("--rs92-ephem", help="RINEX navigation file for RS92 positions (rs92mod -e)")
+    ap.add_argument("--rs92-alm", help="SEM almanac for RS92 positions (rs92mod -a)")
     ap.add_argument("dash"); ap.add_argument("sr", type=int); ap.add_argument("bits", type=int)
     a = ap.parse_args(argv)
+    if a.rs92_ephem or a.rs92_alm:
+        from .family import set_rs92_orbits
+        set_rs92_orbits(ephemeris=a.rs92_ephem, almanac=a.rs92_alm)
     if a.dash != "-" or a.bits != 16:
         ap.error("input is `- <sr> 16` (cs16 on stdin)")
     rx = ChannelizedReceiver(a.sr, cfreq_hz=a.cfreq) if a.channelize else WidebandReceiver(a.sr, cfreq_hz=a.cfreq, raster_hz=a.raster)

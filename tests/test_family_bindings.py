@@ -1,4 +1,4 @@
-"""radiosonde_auto_rx_amd/family.py on the CPU: the ctypes bindings of the five bit-rate tiers take one fetch_hits() dict each (soft bits in the
+"""radiosonde_auto_rx_amd/family.py on the CPU: the ctypes bindings of the bit-rate tiers take one fetch_hits() dict each (soft bits in the
 engine's conventions) and return the reference's text; descriptors agree with the C front ends."""
 import os
 import re
@@ -39,9 +39,25 @@ def test_decoders_on_clean_hits():
     assert "[OK]" in d.hit(dict(soft=-_soft(bb), mv=0.9, mv_pos=0))                                     # engine convention: second half symbol minus first
 
 
+def test_rs92_decoder_solves_the_position(tmp_path):
+    from tools import synth_rs92 as R
+    eph = R.constellation()
+    E = tmp_path / "brdc.nav"
+    E.write_bytes(R.rinex_nav(eph))
+    d = F.FamilyDecoder("RS92", version="x", freq_khz=402500, ephemeris=str(E))
+    fr = R.flight(2, eph)
+    for k, f in enumerate(fr):
+        sym = R.frame_symbols(f)[2 * 10 * 6:]                                            # behind the header bytes; one value per Manchester pair: second minus first
+        t = d.hit(dict(soft=(sym[1::2].astype(np.float32) - sym[0::2].astype(np.float32)), mv=0.9, mv_pos=0))
+        js = d.json_objects(t)
+        assert len(js) == 1 and js[0]["id"] == "K1234567" and js[0]["frame"] == 2000 + k and abs(js[0]["lat"] - 47.7123) < 3e-4 and abs(js[0]["alt"] - 14321.0) < 30.0
+    d.close()
+    assert "lat" not in F.FamilyDecoder("RS92").hit(dict(soft=(sym[1::2].astype(np.float32) - sym[0::2].astype(np.float32)), mv=0.9, mv_pos=0))     # no orbit data: no position
+
+
 def test_descriptors_match_the_c_front_ends():
     """header, baud, BT, h, hdmax, frame bits, filter bandwidths: the same numbers as host/<decoder>.c"""
-    files = {"LMS6": "lms6Xmod.c", "MEISEI": "meisei100mod.c", "IMET5": "imet54mod.c", "MRZ": "mp3h1mod.c", "MTS01": "mts01mod.c"}
+    files = {"LMS6": "lms6Xmod.c", "MEISEI": "meisei100mod.c", "IMET5": "imet54mod.c", "MRZ": "mp3h1mod.c", "MTS01": "mts01mod.c", "RS92": "rs92mod.c"}
     for typ, fn in files.items():
         src = open(os.path.join(ROOT, "host", fn)).read()
         g = F.FAMILY[typ]["generic"]

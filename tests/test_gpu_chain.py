@@ -615,3 +615,43 @@ def test_wideband_c_entry_generic_family_equals_the_python_receiver(form):
     assert len(a) >= 4 and [key(o) for o in a] == [key(o) for o in b], ([key(o) for o in a], [key(o) for o in b])
     for x, y in zip(a, b):
         assert x == y, (x, y)
+
+
+def test_wideband_receivers_decode_an_rs92(tmp_path):
+    """An RS92 in a 2.4 Msps stream: the scanner's RS92 detection starts the generic-description engine and the RS92 bit-rate tier with the orbit
+    data the receiver was given; the objects equal what the reference `rs92mod` prints when started by hand with the carrier found (what auto_rx
+    does, decode.py:484), and the C receiver prints the same objects as the Python one."""
+    import json
+    from tools import synth, synth_rs92 as R
+    from radiosonde_auto_rx_amd import family
+    from radiosonde_auto_rx_amd.wideband import WidebandReceiver
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sr, cf = 2_400_000, 403_000_000
+    eph = R.constellation()
+    E = tmp_path / "brdc.nav"
+    E.write_bytes(R.rinex_nav(eph))
+    fq = synth.snap_fq(-0.15, sr)
+    iq = R.rs92_capture(R.flight(5, eph), sr=sr, fq=fq, noise_sigma=0.004, amp=0.25, seed=98)
+    family.set_rs92_orbits(ephemeris=str(E))
+    try:
+        rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000, version="oracle")
+        want = rx.push(iq, finish=True)
+        log = list(rx.log)
+        rx.close()
+    finally:
+        family.set_rs92_orbits()
+    det = [e for e in log if e["event"] == "detected"]
+    assert [e["type"] for e in det] == ["RS92"], log
+    assert len(want) >= 3 and all(j["type"] == "RS92" and j["id"] == "K1234567" and abs(j["lat"] - 47.712) < 1e-3 and abs(j["freq"] - 402_640) <= 3 for j in want), want[:1]
+    if os.path.exists(os.path.join(REF, "rs92mod")):
+        r = subprocess.run([os.path.join(REF, "rs92mod"), "-vx", "-v", "--crc", "--ecc", "--vel", "--json", "-e", str(E), "--jsn_cfq", str(cf), "--IQ", repr(det[0]["fq"]),
+                            "--lpIQ", "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600)
+        ref = {o["frame"]: o for o in (json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{"))}
+        common = [o for o in want if o["frame"] in ref]
+        assert len(common) >= 3, (sorted(ref), [o["frame"] for o in want])
+        for o in common:
+            assert o == ref[o["frame"]], (o, ref[o["frame"]])
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    c = subprocess.run([os.path.join(BIN, "sonde_wideband"), "-v", "--rs92-ephem", str(E), "--cfreq", str(cf), "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert c.returncode == 0, c.stderr[-500:]
+    assert [json.loads(l) for l in c.stdout.decode().splitlines()] == want
