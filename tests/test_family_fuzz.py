@@ -1,4 +1,4 @@
-"""A fixed-seed slice of tools/fuzz_family.py in the CPU suite: the five native bit-rate tiers against the compiled reference decoders on damaged
+"""A fixed-seed slice of tools/fuzz_family.py in the CPU suite: the native bit-rate tiers (RS92 with its position solver among them) against the compiled reference decoders on damaged
 soft-bit streams with random option sets (noise, bursts, scaling, zeros, inversion, truncation).  `python tools/fuzz_family.py <seed> <n>` runs more."""
 import os
 import subprocess

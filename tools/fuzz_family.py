@@ -1,4 +1,4 @@
-"""Differential fuzzing of the five native bit-rate tiers against the compiled reference decoders (oracle/_ref): random frame streams from tools/synth.py,
+"""Differential fuzzing of the native bit-rate tiers against the compiled reference decoders (oracle/_ref): random frame streams from tools/synth.py,
 damaged in random ways (noise, sign bursts, scaling, zeros, inversion, truncation, a torn last float), random option sets, soft-bit input.
     python tools/fuzz_family.py <seed> <iterations>       -> prints every mismatch, exit code = number of mismatches (capped at 255)"""
 import os
@@ -62,6 +62,37 @@ def _mxx_stream(m20):
     return np.concatenate(out)
 
 
+_RS92 = {}
+
+
+def _rs92_orbits():
+    """constellation + RINEX / SEM files for the RS92 cases (written once per process)"""
+    if not _RS92:
+        import tempfile
+        from tools import synth_rs92 as R
+        d = tempfile.mkdtemp(prefix="fuzz_rs92_")
+        eph = R.constellation()
+        open(os.path.join(d, "brdc.nav"), "wb").write(R.rinex_nav(eph, extra_toe=(-7200.0,)))
+        open(os.path.join(d, "alm.sem"), "wb").write(R.sem_almanac(eph, 2100))
+        _RS92.update(R=R, eph=eph, E=os.path.join(d, "brdc.nav"), A=os.path.join(d, "alm.sem"))
+    return _RS92
+
+
+def _rs92_stream():
+    """a few frames of one ascent: random place / velocity / time, sometimes an RS92-NGP, a spoiled range, few satellites, PRN 32 somewhere"""
+    o = _rs92_orbits()
+    R = o["R"]
+    ngp = bool(rng.integers(4) == 0)
+    cal = R.cal_rows(seed=int(rng.integers(1, 1000)), freq_khz=1680500 if ngp else 402500, ngp_key=bytes(rng.integers(0, 256, 16).astype(np.uint8)) if ngp else None)
+    kw = dict(lat=float(rng.uniform(-70, 70)), lon=float(rng.uniform(-180, 180)), alt=float(rng.uniform(0, 33000)), tow_ms=int(rng.integers(295200_000, 309600_000)),
+              vel_enu=tuple(float(v) for v in rng.normal(0, 15, 3)), seed=int(rng.integers(1 << 20)), min_elev_deg=float([7.0, 7.0, 30.0, 50.0, -90.0][rng.integers(5)]))
+    if rng.integers(3) == 0:
+        kw["spoil"] = {int(rng.integers(1, 33)): float(rng.normal(0, 20000))}
+    fr = R.flight(int(rng.integers(1, 5)), o["eph"], cal=cal, ngp=ngp, aux=tuple(int(v) for v in (rng.integers(0, 3, 4) > 0) * rng.integers(0, 65536, 4)),
+                  frame0=int(rng.integers(0, 60000)), **kw)
+    return R.onair_symbols(fr, lead=int(rng.integers(0, 100)) * 2, gap=int(rng.integers(0, 2)) * int(rng.integers(0, 50)) * 2)
+
+
 streams = {
  "rs41mod": _rs41_stream,
  "dfm09mod": _dfm_stream,
@@ -72,8 +103,9 @@ streams = {
  "imet54mod": lambda: synth.imet54_onair_bits(int(rng.integers(1, 4)), check=["std", "cont", "none"][rng.integers(3)], imet50=bool(rng.integers(2))),
  "mp3h1mod": lambda: synth.mrz_symbols(int(rng.integers(2, 20)), latlon=bool(rng.integers(2))),
  "mts01mod": lambda: synth.mts01_onair_bits(int(rng.integers(1, 5))),
+ "rs92mod": _rs92_stream,
 }
-HEXIN = {"dfm09mod": ["--rawecc", "--auto"], "rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
+HEXIN = {"dfm09mod": ["--rawecc", "--auto"], "rs41mod": ["-r"], "m10mod": ["-r"], "m20mod": ["-r"], "imet54mod": ["-r"], "mp3h1mod": ["-r"], "rs92mod": ["-r"]}      # decoders with --rawhex and how to get lines for it
 opts = {
  "rs41mod": [["-r"], ["-r", "--ecc"], ["-r", "--ecc2", "--crc"], ["--ecc2", "--crc", "--json", "--ptu2", "--jsnsubfrm1"], ["-v", "--ptu", "--ecc"], ["--ecc3", "-r"], ["--ecc4", "-r"], ["-i", "-r", "--ecc2"],
              ["--auto", "--ecc2", "--json"], ["-v", "--ecc2", "--sat"], ["--sat", "--ptu", "--ecc"], ["-vv", "--ecc2", "--ptu"], ["-vx", "--ecc"], ["-vv", "--json"], ["--aux", "--ecc2"], ["--aux", "--json", "--ptu"], ["--json", "--jsn_cfq", "402000000", "--ecc"], ["--ptu", "--dewp", "--ecc2"]],
@@ -85,6 +117,9 @@ opts = {
  "imet54mod": [[], ["-r"], ["--ecc"], ["--ecc", "-v", "--ptu"], ["--json", "--ptu"], ["-r4", "--ecc"], ["--auto", "--ecc"], ["-i", "--ecc"], ["-r", "--json"], ["--silent", "--json"]],
  "mp3h1mod": [[], ["-r"], ["-R"], ["-v"], ["-vv", "--ptu", "--dbg"], ["--json", "--ptu"], ["--auto", "--json"], ["-i"], ["--uniq", "--json"], ["-c"], ["--ofs", "9"], ["--ofs", "0", "-r"]],
  "mts01mod": [[], ["-r"], ["-R"], ["-v"], ["--json"], ["-v", "--json"]],
+ "rs92mod": [["-r"], ["-r", "-v"], ["-v", "EPH"], ["-vx", "-v", "--crc", "--ecc", "--vel", "--json", "EPH"], ["-i", "-vx", "-v", "--crc", "--ecc", "--vel", "--json", "EPH"], ["--json", "--ptu", "ALM", "--gpsepoch", "2"],
+             ["-g2", "--vel2", "-v", "EPH"], ["-g2", "--vel1", "--iter", "ALM"], ["-gg", "--vel", "EPH"], ["-gg", "--vel1", "--dop", "4", "ALM"], ["-vv", "-vx", "--ptu", "--ecc2"], ["--ngp", "--ptu", "--json", "EPH"],
+             ["--der", "50", "-g2", "-v", "EPH"], ["--exsat", "11", "-g1", "EPH"], ["--dbg", "--ptu"], ["ALM", "EPH", "-v", "--vel2"]],
 }
 
 
@@ -106,7 +141,8 @@ def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
     rng = np.random.default_rng(seed)
     bad = 0
     for it in range(iterations):
-        dec = list(streams)[it % len(streams)]
+        only = [d for d in os.environ.get("FUZZ_ONLY", "").split(",") if d in streams] or list(streams)      # FUZZ_ONLY=rs92mod,lms6Xmod: these decoders only
+        dec = only[it % len(only)]
         s = 2.0 * streams[dec]().astype(np.float64) - 1.0
         lead = 2.0 * rng.integers(0, 2, int(rng.integers(0, 200))) - 1.0
         s = np.concatenate([lead, s])
@@ -128,6 +164,8 @@ def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
         if rng.integers(8) == 0:
             data = data[:-int(rng.integers(1, 4))]
         a = opts[dec][rng.integers(len(opts[dec]))]
+        if dec == "rs92mod":                                 # orbit data: the files of _rs92_orbits()
+            a = [y for x in a for y in (["-e", _RS92["E"]] if x == "EPH" else ["-a", _RS92["A"]] if x == "ALM" else [x])]
         args = ["--softinv" if rng.integers(4) == 0 else "--softin"] + a
         form = rng.integers(4)
         if form == 0 and dec in HEXIN:                     # hex-line input: the reference's own -r output of this stream, then damaged as text
