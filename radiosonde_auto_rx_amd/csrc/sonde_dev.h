@@ -62,6 +62,9 @@ struct MixF32Args {
     float2 *z; uint32_t zmask; uint64_t n0;                     // ring [n_ch][zmask+1], absolute base-rate index of the first sample
     int mix;                                                    // 0: no mixer (IF-rate input, --iq0/2/3): z = x - avg
     const uint32_t *epoch;                                      // phase_f64 with IF-rate input (if_tune): per-channel stream start the phase counts from; nullptr = 0
+    // a launch that spans several IQ-DC windows (the scanner's 1/32 s windows): sample i runs under dc_seg[ch][(dc_seg_off + i) / dc_seg_len] and the
+    // sums are not accumulated here (sonde_launch_dc_segments_f32 has done both); nullptr = one window per launch as above
+    const float2 *dc_seg; int dc_seg_n; uint32_t dc_seg_off, dc_seg_len;
 };
 struct DecF32Args {
     const float2 *z; uint32_t zmask; uint64_t n0;               // ring and the absolute index of the first input sample of output 0
@@ -181,6 +184,8 @@ void sonde_launch_dc_update_pcs(int n_ch, long long *sums, float2 *avg, float2 *
 void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s);
+void sonde_launch_dc_segments_f32(const float2 *x, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,
+                                  double *seg_sums, double *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n, hipStream_t s);
 void sonde_launch_decimate_f32(const DecF32Args *a, hipStream_t s);
 void sonde_launch_dc_update_f64(int n_ch, double *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_afc_rotate(const AfcRotArgs *a, hipStream_t s, int n_max);

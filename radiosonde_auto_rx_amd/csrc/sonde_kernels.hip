@@ -762,13 +762,15 @@ void k_mix_f32(const MixF32Args a) {
     const int ch = blockIdx.y;
     const float2 *x = a.x + (size_t)ch * a.ch_stride;
     float2 *z = a.z + (size_t)ch * ((size_t)a.zmask + 1);
-    const float2 avg = a.dc_avg[ch];
+    float2 avg = a.dc_avg[ch];
+    const float2 *seg = a.dc_seg ? a.dc_seg + (size_t)ch * a.dc_seg_n : nullptr;
     const double f0 = a.mix ? a.chan_f0[ch] : 0.0;
     const uint32_t L = (uint32_t)a.lut_len;
     double sx = 0.0, sy = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
         const float2 v = x[i];
         sx += (double)v.x; sy += (double)v.y;
+        if (seg) avg = seg[(a.dc_seg_off + (uint32_t)i) / a.dc_seg_len];
         float2 u = make_float2(v.x - avg.x, v.y - avg.y);
         if (a.mix) {
             const uint32_t k = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)i) % L);         // table index (demod_mod.c:746)
@@ -781,8 +783,45 @@ void k_mix_f32(const MixF32Args a) {
         }
         z[(uint32_t)(a.n0 + (uint64_t)i) & a.zmask] = u;
     }
+    if (seg) return;                                           // the windows' sums were taken by k_dc_seg_sums_f32
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(a.dc_sums + 2 * (size_t)ch, sx); atomicAdd(a.dc_sums + 2 * (size_t)ch + 1, sy); }
+}
+
+// float32 form of k_dc_seg_sums / k_dc_seg_means: the IQ-DC windows a call touches, summed in double (one workgroup per window and channel),
+// then per channel the table of means — window k under the mean of window k-1, the window in progress carried over in dc_sums.
+__global__ __launch_bounds__(256)
+void k_dc_seg_sums_f32(const float2 *x, long long ch_stride, int n_samples, unsigned dc_cnt0, unsigned dc_max, double *seg_sums, int nseg) {
+    const int k = blockIdx.x, ch = blockIdx.y;
+    const long long lo = (long long)k * dc_max - dc_cnt0, hi = lo + dc_max;
+    const int s0 = (int)(lo < 0 ? 0 : lo), s1 = (int)(hi > n_samples ? n_samples : hi);
+    const float2 *p = x + (size_t)ch * ch_stride;
+    double sx = 0.0, sy = 0.0;
+    for (int i = s0 + (int)threadIdx.x; i < s1; i += 256) { const float2 v = p[i]; sx += (double)v.x; sy += (double)v.y; }
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
+    __shared__ double s_d[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_d[2 * wave] = sx; s_d[2 * wave + 1] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tx = 0.0, ty = 0.0;
+        for (int w = 0; w < 4; w++) { tx += s_d[2 * w]; ty += s_d[2 * w + 1]; }
+        seg_sums[((size_t)ch * nseg + k) * 2] = tx; seg_sums[((size_t)ch * nseg + k) * 2 + 1] = ty;
+    }
+}
+
+__global__ void k_dc_seg_means_f32(int n_ch, int nseg, int ncomplete, float maxcnt, const double *seg_sums, double *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_ch) return;
+    float2 mean = dc_avg[c];
+    double cx = dc_sums[2 * c], cy = dc_sums[2 * c + 1];       // what the window in progress had collected before this call
+    for (int k = 0; k < dc_seg_n; k++) {
+        dc_seg[(size_t)c * dc_seg_n + k] = mean;
+        if (k >= nseg) continue;
+        cx += seg_sums[((size_t)c * nseg + k) * 2]; cy += seg_sums[((size_t)c * nseg + k) * 2 + 1];
+        if (k < ncomplete) { mean = make_float2((float)(cx / (double)maxcnt), (float)(cy / (double)maxcnt)); cx = 0.0; cy = 0.0; }      // k_dc_update_f64
+    }
+    dc_avg[c] = mean; dc_sums[2 * c] = cx; dc_sums[2 * c + 1] = cy;
 }
 
 __global__ __launch_bounds__(256)
@@ -1895,6 +1934,13 @@ extern "C" void sonde_launch_dc_segments(const int16_t *iq, long long ch_stride,
     const int ncomplete = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples) / dc_max);
     hipLaunchKernelGGL(k_dc_seg_sums, dim3(nseg, n_ch), dim3(256), 0, s, iq, ch_stride, n_samples, dc_cnt0, dc_max, seg_sums, nseg);
     hipLaunchKernelGGL(k_dc_seg_means, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, (float)dc_max, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n);
+}
+extern "C" void sonde_launch_dc_segments_f32(const float2 *x, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,
+                                             double *seg_sums, double *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
+    const int nseg = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples + dc_max - 1) / dc_max);
+    const int ncomplete = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples) / dc_max);
+    hipLaunchKernelGGL(k_dc_seg_sums_f32, dim3(nseg, n_ch), dim3(256), 0, s, x, ch_stride, n_samples, dc_cnt0, dc_max, seg_sums, nseg);
+    hipLaunchKernelGGL(k_dc_seg_means_f32, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, (float)dc_max, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n);
 }
 extern "C" void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, (float2 *)nullptr, maxcnt);

@@ -779,6 +779,26 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
             s->dc_cnt = (uint32_t)(((uint64_t)s->dc_cnt + (uint64_t)n_samples) % s->dc_max);
             done = n_samples;
         }
+        // float32 IF-rate input (the channelizer's output: 256 channels at 50 kHz): the same table of window means, one k_mix_f32 launch for the call
+        // instead of a mixer launch and a mean update per 1/32 s window (63 launches of 4-9 us per second of signal: 0.4 of scan_wide's 2.5 ms)
+        if (mode != SONDE_SCAN_BBIQ && f32in && !no_segtab && n_samples > 0) {
+            const int nseg_cap = s->cfg.max_chunk / (int)s->dc_max + 2;
+            if (!s->d_dcsums_f) { HIPCHK(hipMalloc((void **)&s->d_dcsums_f, 2 * (size_t)C * sizeof(double))); HIPCHK(hipMemset(s->d_dcsums_f, 0, 2 * (size_t)C * sizeof(double))); }
+            if (!s->d_segsums) {
+                HIPCHK(hipMalloc((void **)&s->d_segsums, (size_t)C * nseg_cap * 2 * sizeof(double)));
+                HIPCHK(hipMalloc((void **)&s->d_dcseg, (size_t)C * (nseg_cap + 1) * sizeof(float2)));
+            }
+            sonde_launch_dc_segments_f32((const float2 *)d_in, ch_stride, C, n_samples, s->dc_cnt, s->dc_max, (double *)s->d_segsums, s->d_dcsums_f, s->d_dcavg,
+                                         s->d_dcseg, nseg_cap + 1, s->stream);
+            MixF32Args a{}; a.x = (const float2 *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.n = n_samples;
+            a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len; a.lut_phase = 0; a.phase_f64 = 1; a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums_f;
+            a.mix = 0; a.z = s->d_y; a.zmask = (uint32_t)s->ring_len - 1; a.n0 = s->m_out;
+            a.dc_seg = s->d_dcseg; a.dc_seg_n = nseg_cap + 1; a.dc_seg_off = s->dc_cnt; a.dc_seg_len = s->dc_max;
+            sonde_launch_mix_f32(&a, s->stream);
+            s->samples_in += (uint64_t)n_samples; s->m_out += (uint32_t)(n_samples / D);
+            s->dc_cnt = (uint32_t)(((uint64_t)s->dc_cnt + (uint64_t)n_samples) % s->dc_max);
+            done = n_samples;
+        }
         while (done < n_samples) {
             const int take = (int)std::min<uint32_t>((uint32_t)(n_samples - done), s->dc_max - s->dc_cnt);
             if (f32in) {                                     // float32 IQ (or the wide-IF copy): plain mixer / FIR kernels, IQ-DC sums in double
