@@ -7,6 +7,11 @@ import pytest
 
 from tools import synth
 
+def _rs92_capture():
+    from tools import synth_rs92 as R
+    return R.rs92_capture(R.flight(4, R.constellation()), sr=48_000, noise_sigma=0.08, seed=81)
+
+
 FAM = {
     "mrz": dict(cap=lambda: synth.mrz_capture(sr=48_000, seconds=18.5, noise_sigma=0.05, seed=71)[:2 * 48_000 * 7],
                 kw=dict(baud=2399.0, bt=1.0, h=2.0, lpiq_bw=9000, lpfm_bw=6000, hdr=b"100110011001100110011001100110011001" b"10101010", symlen=2, symhd=2,
@@ -20,6 +25,9 @@ FAM = {
     "meisei": dict(cap=lambda: synth.meisei_capture(sr=48_000, seconds=5.0, noise_sigma=0.1, seed=41),
                    kw=dict(baud=2400.0, bt=1.2, h=2.4, lpiq_bw=16000, lpfm_bw=4000, hdr=b"101010101011010100101011001101001100101011001101", symlen=1, symhd=1,
                            thres=0.7, hdmax=1, bitofs=0, l=-1.0, nbits=1152)),
+    "rs92": dict(cap=lambda: _rs92_capture(),
+                 kw=dict(baud=4800.0, bt=0.5, h=0.8, lpiq_bw=8000, lpfm_bw=6000, hdr=b"10100110011001101001" b"1010011001100110100110101010100110101001", symlen=2, symhd=2,
+                         thres=0.7, hdmax=3, bitofs=2, l=4.0, nbits=2340)),
     "mts01": dict(cap=lambda: synth.mts01_capture(sr=48_000, seconds=5.5, noise_sigma=0.1, seed=51),
                   kw=dict(baud=1200.0, bt=1.5, h=0.9, lpiq_bw=4000, lpfm_bw=4000, hdr=b"10101010" b"10101010" b"10110100" b"00101011", symlen=1, symhd=1,
                           thres=0.76, hdmax=2, bitofs=0, l=2.0, nbits=1048)),
