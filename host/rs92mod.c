@@ -48,23 +48,11 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
         if (!strcmp(a, "-h") || !strcmp(a, "--help")) {
-            fprintf(stderr, "%s [options] <file>\n", argv[0]);
-            fprintf(stderr, "  file: audio.wav or raw_data\n");
-            fprintf(stderr, "  options:\n");
-            fprintf(stderr, "       --vel; --vel1, --vel2 (-g2)\n");
-            fprintf(stderr, "       -v, -vx, -vv\n");
-            fprintf(stderr, "       -r, --raw\n");
-            fprintf(stderr, "       -i, --invert\n");
-            fprintf(stderr, "       -e, --ephem    <ephemperisRinex>\n");
-            fprintf(stderr, "       -a, --almanac  <almanacSEM>\n");
-            fprintf(stderr, "           --gpsepoch <n> (2019-04-07: n=2)\n");
-            fprintf(stderr, "       -g1          (verbose GPS:   4 sats)\n");
-            fprintf(stderr, "       -g2          (verbose GPS: all sats)\n");
-            fprintf(stderr, "       -gg          (vverbose GPS)\n");
-            fprintf(stderr, "       --crc        (CRC check GPS)\n");
-            fprintf(stderr, "       --ecc        (Reed-Solomon)\n");
-            fprintf(stderr, "       --ths <x>    (peak threshold; default=%.1f)\n", thres);
-            fprintf(stderr, "       --json       (JSON output)\n");
+            fprintf(stderr, "%s [options] ( file.wav | --IQ <fq> - <sr> <bits> | --softin | --rawhex )\n", argv[0]);
+            fprintf(stderr, "  orbit data:  -e <rinex nav file> | -a <SEM almanac> [--gpsepoch n]\n");
+            fprintf(stderr, "  solution:    --vel | --vel1 | --vel2, --iter, -g1 | -g2 | -gg, --dop x, --der x, --exsat prn\n");
+            fprintf(stderr, "  output:      -v | -vv, -vx, -r, --ptu, --ecc | --ecc2, --json [--jsn_cfq hz]\n");
+            fprintf(stderr, "  signal:      -i, --ngp, --ths x (default %.1f), -d shift\n", thres);
             return 0;
         }
         else if (!strcmp(a, "--vel")) o.gps_vel = 4;
