@@ -655,3 +655,38 @@ def test_wideband_receivers_decode_an_rs92(tmp_path):
     c = subprocess.run([os.path.join(BIN, "sonde_wideband"), "-v", "--rs92-ephem", str(E), "--cfreq", str(cf), "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600, env=env)
     assert c.returncode == 0, c.stderr[-500:]
     assert [json.loads(l) for l in c.stdout.decode().splitlines()] == want
+
+
+def test_channelized_receivers_decode_an_rs92(tmp_path):
+    """The same RS92 path behind the channelizer (10 Msps -> 256 channels at 50 kHz, the type's engine tuned to the channel's residual offset): positions as
+    sent, and the C receiver (`sonde_wideband --channelize --rs92-ephem`) prints the objects the Python receiver returns."""
+    import json
+    from tools import synth_rs92 as R
+    from radiosonde_auto_rx_amd import family
+    from radiosonde_auto_rx_amd.wideband import ChannelizedReceiver
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sr, M, D, cf = 10_000_000, 256, 200, 403_000_000
+    f_hz = 25 * sr / M + 700.0
+    eph = R.constellation()
+    E = tmp_path / "brdc.nav"
+    E.write_bytes(R.rinex_nav(eph))
+    iq = R.rs92_capture(R.flight(5, eph), sr=sr, fq=f_hz / sr, noise_sigma=0.002, amp=0.2, seed=99)
+    n = len(iq) // 2
+    family.set_rs92_orbits(ephemeris=str(E))
+    try:
+        rx = ChannelizedReceiver(sr, M=M, D=D, cfreq_hz=cf, slots=2, version="oracle")
+        want = []
+        for s0 in range(0, n, rx.chunk):
+            want += rx.push(iq[2 * s0:2 * min(n, s0 + rx.chunk)], finish=(s0 + rx.chunk >= n))
+        log = list(rx.log)
+        found = [(s["type"], s["f_hz"]) for s in rx.sondes]
+        rx.close()
+    finally:
+        family.set_rs92_orbits()
+    assert len(found) == 1 and found[0][0] == "RS92" and abs(found[0][1] - f_hz) < 800.0, (found, log)
+    assert len(want) >= 3 and all(j["type"] == "RS92" and j["id"] == "K1234567" and abs(j["lat"] - 47.712) < 1e-3 and abs(j["alt"] - 14330.0) < 60.0 for j in want), want[:1]
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+    c = subprocess.run([os.path.join(BIN, "sonde_wideband"), "--channelize", "--slots", "2", "-v", "--rs92-ephem", str(E), "--cfreq", str(cf), "-", str(sr), "16"],
+                       input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert c.returncode == 0, c.stderr[-500:]
+    assert [json.loads(l) for l in c.stdout.decode().splitlines()] == want
