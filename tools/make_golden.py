@@ -768,6 +768,55 @@ def gen_m20_fields(outdir):
     np.savez_compressed(os.path.join(outdir, "m20_fields.npz"), **d)
 
 
+# RS92 text / JSON (print_position, rs92mod.c:1389-1544) incl. the GPS solution from the raw ranges: soft-symbol streams of tools/synth_rs92.py through
+# `rs92mod <args> -e <rinex> | -a <sem> --softin`; the orbit files are re-created from the same seeds at test time (E / A stand for their paths)
+RS92_FIELD_SCENARIOS = {
+    "rs92f_sgp_36": dict(n=36),
+    "rs92f_ngp_36": dict(n=36, ngp=True, aux=(0x1234, 0, 0xBEEF, 7)),
+    "rs92f_spoiled_8": dict(n=8, spoil={17: 30000.0}),
+    "rs92f_prn32_6": dict(n=6, order=[17, 32, 11, 6, 28, 1, 13, 19, 24, 30, 3, 9], min_elev_deg=-90.0),
+    "rs92f_noisy_12": dict(n=12, sigma=0.5),
+}
+RS92_FIELD_ARGS = [["-vx", "-v", "--crc", "--ecc", "--vel", "--json", "--ptu", "E"], ["-v", "--vel", "E"], ["-g2", "--vel2", "-v", "E"], ["--vel1", "--iter", "-v", "E"],
+                   ["-vv", "-vx", "--ptu", "--ecc2", "E"], ["-v", "--vel", "A", "--gpsepoch", "2"], ["-g2", "--vel2", "-v", "A"], ["-r", "-v"], ["--ngp", "--ptu", "--json", "E"]]
+
+
+def rs92_orbit_files(dirname):
+    from tools import synth_rs92 as R
+    eph = R.constellation()
+    E, A = os.path.join(dirname, "brdc.nav"), os.path.join(dirname, "alm.sem")
+    open(E, "wb").write(R.rinex_nav(eph, extra_toe=(-7200.0,)))
+    open(A, "wb").write(R.sem_almanac(eph, 2100))
+    return eph, E, A
+
+
+def rs92_field_symbols(sc, eph):
+    from tools import synth_rs92 as R
+    kw = {k: v for k, v in sc.items() if k not in ("n", "ngp", "aux", "sigma")}
+    cal = R.cal_rows(seed=5, freq_khz=1680500, ngp_key=bytes(range(0x31, 0x41))) if sc.get("ngp") else None
+    sym = R.onair_symbols(R.flight(sc["n"], eph, cal=cal, ngp=bool(sc.get("ngp")), aux=sc.get("aux", (0, 0, 0, 0)), **kw))
+    rng = np.random.default_rng(4)
+    return (2.0 * sym - 1.0 + rng.normal(0.0, sc.get("sigma", 0.05), len(sym))).astype("<f4")
+
+
+def rs92_field_args(args, E, A):
+    return [y for x in args for y in (["-e", E] if x == "E" else ["-a", A] if x == "A" else [x])]
+
+
+def gen_rs92_fields(outdir):
+    import tempfile
+    d = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        eph, E, A = rs92_orbit_files(tmp)
+        for name, sc in RS92_FIELD_SCENARIOS.items():
+            soft = rs92_field_symbols(sc, eph)
+            for k, args in enumerate(RS92_FIELD_ARGS):
+                out, err, rc = bind.ref_run("rs92mod", rs92_field_args(args, E, A) + ["--softin"], soft.tobytes())
+                d["%s|%d" % (name, k)] = np.frombuffer(out.encode(), np.uint8)
+            print(name, len(soft), [len(d["%s|%d" % (name, k)]) for k in range(len(RS92_FIELD_ARGS))])
+    np.savez_compressed(os.path.join(outdir, "rs92_fields.npz"), **d)
+
+
 def gen_rawhex(outdir):
     """--rawhex: frames as hex lines (clean, correctable, uncorrectable, short, truncated) through the reference's rs41mod"""
     lines = [str(l).split(" ")[0] for l in np.load(os.path.join(outdir, "fsk_rs41_48k_mask.npz"))["rs41_lines"]]
@@ -848,6 +897,7 @@ def main():
     gen_dfm_fields(outdir)
     gen_m10_fields(outdir)
     gen_m20_fields(outdir)
+    gen_rs92_fields(outdir)
     gen_cli_cases(F32_CASES, f32_capture, outdir)
     gen_cli_cases({k: dict(v, binary="m10mod") for k, v in M10_CASES.items()}, m10_capture_cli, outdir)
     gen_cli_cases({k: dict(v, binary="m20mod") for k, v in M20_CASES.items()}, m10_capture_cli, outdir)
