@@ -46,19 +46,21 @@
 #include "sonde_mts01.h"
 #include "sonde_rs92.h"
 
-enum { T_RS41, T_DFM, T_M10, T_M20, T_LMS6, T_MEISEI, T_IMET5, T_MRZ, T_MTS01, T_RS92, T_N };
-static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20", "LMS6", "MEISEI", "IMET5", "MRZ", "MTS01", "RS92" };
+enum { T_RS41, T_DFM, T_M10, T_M20, T_LMS6, T_MEISEI, T_IMET5, T_MRZ, T_MTS01, T_RS92, T_LMSX, T_N };
+static const char *kTypeName[T_N] = { "RS41", "DFM", "M10", "M20", "LMS6", "MEISEI", "IMET5", "MRZ", "MTS01", "RS92", "LMSX" };
 #define IS_FAMILY(t) ((t) >= T_LMS6)
 /* The generic family: what each decoder of the reference puts into dsp_t and passes to find_header() (sonde_generic_t, the same numbers as the
  * stand-alone front ends host/lms6Xmod.c ... and radiosonde_auto_rx_amd/family.py), the header threshold, whether either polarity is taken, whether
  * the decoder wants the bits as sent (raw) or in the polarity in effect, and how far apart two sondes of the type must be. */
-typedef struct { const char *header; float baud, bt, h; int symlen, symhd, hdmax, bitofs, nbits; float l_win; int lpiq_bw, lpfm_bw; float thres; int aut, raw_pol; double sep_hz; } family_t;
+typedef struct { const char *header; float baud, bt, h; int symlen, symhd, hdmax, bitofs, nbits; float l_win; int lpiq_bw, lpfm_bw; float thres; int aut, raw_pol; double sep_hz; float slice_baud; } family_t;
 static const family_t kFamily[T_N] = {
     [T_LMS6]   = { "0101011000001000" "0001110010010111" "0001101010100111" "0011110100111110", 4800.0f, 1.2f, 0.9f, 1, 1, 10, 0, 261 * 16 - 80, -1.0f, 16000, 6000, 0.65f, 1, 1, 8000.0 },
     [T_MEISEI] = { "101010101011010100101011001101001100101011001101", 2400.0f, 1.2f, 2.4f, 1, 1, 1, 0, 1152, -1.0f, 16000, 4000, 0.7f, 1, 0, 12000.0 },
     [T_IMET5]  = { "0000000001" "0101010101" "0001001001" "0001001001", 4798.0f, 1.0f, 0.8f, 1, 1, 4, 1, 2200, 2.0f, 7400, 6000, 0.7f, 0, 0, 8000.0 },
     [T_MRZ]    = { "100110011001100110011001100110011001" "10101010", 2399.0f, 1.0f, 2.0f, 2, 2, 2, 2, 386, 2.0f, 9000, 6000, 0.76f, 0, 0, 10000.0 },
     [T_MTS01]  = { "10101010" "10101010" "10110100" "00101011", 1200.0f, 1.5f, 0.9f, 1, 1, 2, 0, 1048, 2.0f, 4000, 4000, 0.76f, 1, 1, 6000.0 },
+    /* not a scanner type: an LMS6 whose blocks turn out to be LMS-X (lms6Xmod.c:1436-1462) moves here — same filters and header, 4797.8 Bd bit clock, 4720 bits per block */
+    [T_LMSX]   = { "0101011000001000" "0001110010010111" "0001101010100111" "0011110100111110", 4800.0f, 1.2f, 0.9f, 1, 1, 10, 0, 300 * 16 - 80, -1.0f, 16000, 6000, 0.65f, 1, 1, 8000.0, 4797.8f },
     [T_RS92]   = { "10100110011001101001" "1010011001100110100110101010100110101001", 4800.0f, 0.5f, 0.8f, 2, 2, 3, 2, SONDE_RS92_FRAME_BITS, 4.0f, 8000, 6000, 0.7f, 0, 0, 8000.0 },
 };
 
@@ -70,6 +72,9 @@ typedef struct {
     void *dec;                           /* sonde_<type>_dec_t */
     long frames; int64_t last_frame_at;  /* stream position (samples) of the last frame delivered */
     uint32_t last_pos;                   /* LMS6: header position of the previous block (frame rate) */
+    int move_to;                         /* LMS6 / LMSX: 1 + the type whose engine it moves to at the end of this block of samples; 0 = stays */
+    int moved;                           /* its first block on the new engine: no header position to take the frame rate from */
+    double df;                           /* --channelize: offset from the channel centre, cycles per IF sample */
 } sonde_t;
 
 typedef struct { sonde_engine_t *eng; int *owner; void *d_rows; int32_t *rows; long calls; } group_t;       /* owner[slot] = index into g_sondes or -1; --channelize: the engine's input rows */
@@ -109,7 +114,7 @@ static int group_engine(int type) {
         sonde_generic_t gd; memset(&gd, 0, sizeof gd);
         snprintf(gd.header, sizeof gd.header, "%s", f->header);
         gd.baud = f->baud; gd.bt = f->bt; gd.h = f->h; gd.symlen = f->symlen; gd.symhd = f->symhd; gd.hdmax = f->hdmax; gd.bitofs = f->bitofs;
-        gd.nbits = f->nbits; gd.l_win = f->l_win; gd.lpiq_bw = f->lpiq_bw; gd.lpfm_bw = f->lpfm_bw;
+        gd.nbits = f->nbits; gd.l_win = f->l_win; gd.lpiq_bw = f->lpiq_bw; gd.lpfm_bw = f->lpfm_bw; gd.slice_baud = f->slice_baud;
         c.sonde_type = SONDE_GENERIC; c.keep_soft = 1; c.thres = f->thres; c.opt_auto = f->aut; c.ecc_level = 0; c.max_frames = 8 * g_slots;
         rc = sonde_engine_create_generic(&c, fq, &gd, &g->eng);
     } else rc = sonde_engine_create(&c, fq, &g->eng);
@@ -137,7 +142,7 @@ static void *make_decoder(int type, int khz) {
                               if (sonde_m10_dec_create(&o, (sonde_m10_dec_t **)&d) < 0) return NULL; }
     else if (type == T_M20) { sonde_m20_opts_t o; memset(&o, 0, sizeof o); o.verbose = 1; o.ptu = 1; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
            if (sonde_m20_dec_create(&o, (sonde_m20_dec_t **)&d) < 0) return NULL; }
-    else if (type == T_LMS6) { sonde_lms6_opts_t o; memset(&o, 0, sizeof o); o.ecc = 1; o.vit = 2; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
+    else if (type == T_LMS6 || type == T_LMSX) { sonde_lms6_opts_t o; memset(&o, 0, sizeof o); o.ecc = 1; o.vit = 2; o.json = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
            if (sonde_lms6_dec_create(&o, (sonde_lms6_dec_t **)&d) < 0) return NULL; }
     else if (type == T_MEISEI) { sonde_meisei_opts_t o; memset(&o, 0, sizeof o); o.ecc = 1; o.json = 1; o.ptu = 1; o.jsn_freq_khz = khz; snprintf(o.version, sizeof o.version, "%s", g_version);
            if (sonde_meisei_dec_create(&o, (sonde_meisei_dec_t **)&d) < 0) return NULL; }
@@ -158,7 +163,7 @@ static void free_decoder(int type, void *d) {
     if (!d) return;
     if (type == T_RS41) sonde_rs41_dec_destroy((sonde_rs41_dec_t *)d); else if (type == T_DFM) sonde_dfm_dec_destroy((sonde_dfm_dec_t *)d);
     else if (type == T_M10) sonde_m10_dec_destroy((sonde_m10_dec_t *)d); else if (type == T_M20) sonde_m20_dec_destroy((sonde_m20_dec_t *)d);
-    else if (type == T_LMS6) sonde_lms6_dec_destroy((sonde_lms6_dec_t *)d); else if (type == T_MEISEI) sonde_meisei_dec_destroy((sonde_meisei_dec_t *)d);
+    else if (type == T_LMS6 || type == T_LMSX) sonde_lms6_dec_destroy((sonde_lms6_dec_t *)d); else if (type == T_MEISEI) sonde_meisei_dec_destroy((sonde_meisei_dec_t *)d);
     else if (type == T_IMET5) sonde_imet54_dec_destroy((sonde_imet54_dec_t *)d); else if (type == T_MRZ) sonde_mrz_dec_destroy((sonde_mrz_dec_t *)d);
     else if (type == T_RS92) sonde_rs92_dec_destroy((sonde_rs92_dec_t *)d);
     else sonde_mts01_dec_destroy((sonde_mts01_dec_t *)d);
@@ -209,7 +214,7 @@ static void start_sonde(int type, double fq_found) {
 static void start_sonde_chan(int type, int k, double df) {
     const double f_hz = (double)(k < g_M / 2 ? k : k - g_M) * g_spacing + df * g_if_sr;
     const double sep = IS_FAMILY(type) ? kFamily[type].sep_hz : (type == T_M10 || type == T_M20) ? 20000.0 : 8000.0;     /* the neighbouring channel sees a strong signal too */
-    for (int i = 0; i < g_nsondes; i++) if (g_sondes[i].used && g_sondes[i].type == type && fabs(g_sondes[i].fq * g_sr - f_hz) < sep) return;
+    for (int i = 0; i < g_nsondes; i++) if (g_sondes[i].used && (g_sondes[i].type == T_LMSX ? T_LMS6 : g_sondes[i].type) == type && fabs(g_sondes[i].fq * g_sr - f_hz) < sep) return;
     if (group_engine(type) < 0) { fprintf(stderr, "sonde_wideband: no engine for %s\n", kTypeName[type]); return; }
     group_t *g = &g_gr[type];
     int slot = -1;
@@ -229,7 +234,7 @@ static void start_sonde_chan(int type, int k, double df) {
     }
     sonde_t *s = &g_sondes[idx];
     memset(s, 0, sizeof *s);
-    s->used = 1; s->type = type; s->slot = slot; s->chan = k; s->fq = f_hz / g_sr; s->last_frame_at = g_pos;
+    s->used = 1; s->type = type; s->slot = slot; s->chan = k; s->df = df; s->fq = f_hz / g_sr; s->last_frame_at = g_pos;
     s->khz = g_cfreq ? (int)llround((g_cfreq + f_hz) / 1000.0) : 0;
     s->dec = make_decoder(type, s->khz);
     if (!s->dec) { s->used = 0; return; }
@@ -245,6 +250,34 @@ static void release_sonde(int idx) {
     if (g_verbose) fprintf(stderr, "released: %s %d kHz channel %d after %ld frames\n", kTypeName[s->type], s->khz, s->slot, s->frames);
     free_decoder(s->type, s->dec);
     s->used = 0; s->dec = NULL;
+}
+
+/* an LMS6 whose decoder found LMS-X blocks (or the reverse): the sonde moves to a channel of the engine of the other description, decoder object and all;
+ * the next block of samples is the first it sees there (the stand-alone decoder replays its input from the end of the block instead, host/lms6Xmod.c) */
+static void move_sondes(void) {
+    for (int i = 0; i < g_nsondes; i++) {
+        sonde_t *s = &g_sondes[i];
+        if (!s->used || !s->move_to) continue;
+        const int want = s->move_to - 1;
+        s->move_to = 0;
+        group_t *g0 = &g_gr[s->type];
+        sonde_engine_finish_channel(g0->eng, s->slot);
+        g0->owner[s->slot] = -1;
+        int slot = -1;
+        if (group_engine(want) == 0) for (int k = 0; k < g_slots; k++) if (g_gr[want].owner[k] < 0) { slot = k; break; }
+        group_t *g = &g_gr[want];
+        int ok = slot >= 0;
+        if (ok && g_channelize) ok = !(g->calls && sonde_engine_restart_channel(g->eng, slot) < 0) && sonde_engine_tune_channel(g->eng, slot, s->df) >= 0;
+        else if (ok) ok = sonde_engine_tune_channel(g->eng, slot, s->fq) >= 0 && sonde_engine_restart_channel(g->eng, slot) >= 0;
+        if (!ok) {
+            if (g_verbose) fprintf(stderr, "no free channel: %s %d kHz\n", kTypeName[want], s->khz);
+            free_decoder(s->type, s->dec); s->used = 0; s->dec = NULL;
+            continue;
+        }
+        if (g_verbose) fprintf(stderr, "retuned: %s -> %s %d kHz -> channel %d\n", kTypeName[s->type], kTypeName[want], s->khz, slot);
+        s->type = want; s->slot = slot; s->moved = 1;
+        g->owner[slot] = i;
+    }
 }
 
 /* frames the engine of one type has ready -> the decoders of the sondes that own the channels */
@@ -271,12 +304,16 @@ static void drain(int type, int finish) {
                 int n = hits[i].nbits;
                 if (f->raw_pol && hits[i].mv < 0.f) for (int j = 0; j < n; j++) b[j] = -b[j];      /* stored in the polarity in effect; this decoder reads the bits as sent */
                 int m = 0;
-                if (type == T_LMS6) {
+                if (type == T_LMS6 || type == T_LMSX) {
                     const int want = sonde_lms6_dec_block_bits((sonde_lms6_dec_t *)sn->dec); if (n > want) n = want;
                     const uint32_t d = hits[i].mv_pos - sn->last_pos;
-                    const float rate = d ? (float)(4800.0 * if_sr / (double)d) : INFINITY;
+                    float rate = d ? (float)(4800.0 * if_sr / (double)d) : INFINITY;
+                    if (sn->moved) { rate = 4800.0f; sn->moved = 0; }                  /* first block after the change of engine: the nominal rate (a rate outside 4000..5000 would send the decoder back, lms6Xmod.c:959) */
                     sn->last_pos = hits[i].mv_pos;
                     m = sonde_lms6_dec_block((sonde_lms6_dec_t *)sn->dec, b, NULL, n, hits[i].mv, rate, ((double)hits[i].mv_pos + n * (double)if_sr / 4800.0) / if_sr, tx, sizeof tx);
+                    int32_t changed = 0;
+                    const int now = (sonde_lms6_dec_type((sonde_lms6_dec_t *)sn->dec, &changed) & 0xFF) == 10 ? T_LMSX : T_LMS6;
+                    if (changed && now != type) sn->move_to = 1 + now;                              /* at the end of this block of samples (move_sondes) */
                 }
                 else if (type == T_MEISEI) m = sonde_meisei_dec_frame((sonde_meisei_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 else if (type == T_IMET5) m = sonde_imet54_dec_frame((sonde_imet54_dec_t *)sn->dec, b, n, tx, sizeof tx);
@@ -414,6 +451,7 @@ static int run_channelized(void) {
                 }
                 g_pos += m;
                 for (int t = 0; t < T_N; t++) drain(t, 0);
+                move_sondes();
                 for (int i = 0; i < g_nsondes; i++)
                     if (g_sondes[i].used && g_release_s > 0 && (double)(g_pos - g_sondes[i].last_frame_at) > g_release_s * g_if_sr) release_sonde(i);
             }
@@ -504,6 +542,7 @@ int main(int argc, char **argv) {
             }
             g_pos += n;
             for (int t = 0; t < T_N; t++) drain(t, 0);
+            move_sondes();
             for (int i = 0; i < g_nsondes; i++)
                 if (g_sondes[i].used && g_release_s > 0 && (double)(g_pos - g_sondes[i].last_frame_at) > g_release_s * g_sr) release_sonde(i);
         }

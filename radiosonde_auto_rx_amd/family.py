@@ -79,6 +79,12 @@ FAMILY = {
 }
 
 
+# An LMS6 whose blocks turn out to be LMS-X (lms6Xmod.c:1436-1462): same filters and header, bit clock 4797.8 Bd and 4720 bits per block.  Not a scanner type:
+# the receivers move a sonde to an engine of this description when its decoder object reports the change (FamilyDecoder.lms_type), and back.
+FAMILY["LMSX"] = dict(FAMILY["LMS6"], generic=dict(FAMILY["LMS6"]["generic"], slice_baud=4797.8, nbits=300 * 16 - 80))
+LMS_BASE = {"LMSX": "LMS6"}                      # receiver bookkeeping: the scanner's name of a sonde's type
+
+
 class FamilyDecoder:
     """one decoder object of type `typ` (a key of FAMILY): state lives across hits like the reference's gpx_t"""
 
@@ -129,6 +135,8 @@ class FamilyDecoder:
             n = min(n, lib().sonde_lms6_dec_block_bits(self._h))           # a decoder that went over to LMS-X wants more bits than a fixed description slices
             d = (int(h["mv_pos"]) - self._last_pos) & 0xFFFFFFFF
             rate = 4800.0 * if_sr / d if d else float("inf")
+            if getattr(self, "moved", False):                              # first block on another engine (receivers, LMS6 <-> LMS-X): no header position to take the
+                rate, self.moved = 4800.0, False                          # frame rate from; a rate outside 4000..5000 would send the decoder back (lms6Xmod.c:959)
             self._last_pos = int(h["mv_pos"])
             k = self._fn(self._h, soft.ctypes.data, None, n, h["mv"], rate, (h["mv_pos"] + n * if_sr / 4800.0) / if_sr, self._buf, len(self._buf))
         else:
@@ -138,6 +146,14 @@ class FamilyDecoder:
         if k < 0:
             raise SondeError(f"{self.typ}: decoder call failed ({k})")
         return self._buf.raw[:k].decode(errors="replace")
+
+    def lms_type(self):
+        """LMS6 only: ("LMS6" | "LMSX" = the description the decoder wants its demodulator on, whether the last block made it change)"""
+        ch = _I(0)
+        L = lib()
+        L.sonde_lms6_dec_type.argtypes = [C.c_void_p, C.POINTER(_I)]
+        t = L.sonde_lms6_dec_type(self._h, C.byref(ch))
+        return ("LMSX" if (t & 0xFF) == 10 else "LMS6"), bool(ch.value)
 
     @staticmethod
     def json_objects(text: str):

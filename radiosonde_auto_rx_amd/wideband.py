@@ -19,7 +19,7 @@ import numpy as np
 
 from .engine import Engine, snap_fq
 from .scan import Scanner
-from .family import FAMILY, FamilyDecoder
+from .family import FAMILY, LMS_BASE, FamilyDecoder
 from .telemetry import DfmTelemetry, M10Telemetry, M20Telemetry, Rs41Telemetry
 
 
@@ -52,9 +52,7 @@ class WidebandReceiver:
         fq = snap_fq(fq, self.sr)
         khz = int(round((self.cfreq + fq * self.sr) / 1000.0)) if self.cfreq else 0
         if typ in FAMILY:                                      # generic sonde description + the type's bit-rate tier (family.py)
-            f = FAMILY[typ]
-            eng = Engine([fq], self.sr, sonde="generic", generic=f["generic"], thres=f["thres"], auto=f["auto"], keep_soft=True, lp_iq=True,
-                         max_chunk=self.chunk, max_frames=8)
+            eng = self._family_engine(typ, fq)
             tel = FamilyDecoder(typ, freq_khz=khz, version=self.version)
         elif typ == "DFM":
             eng = Engine([fq], self.sr, sonde="dfm", ecc=1, auto=True, max_chunk=self.chunk, max_frames=8)
@@ -67,6 +65,21 @@ class WidebandReceiver:
             tel = Rs41Telemetry(freq_khz=khz, version=self.version)
         self.sondes.append(dict(fq=fq, type=typ, engine=eng, telemetry=tel, frames=0, khz=khz, t_last=self.t))
         self.log.append(dict(event="detected", type=typ, fq=fq, freq_khz=khz))
+
+    def _family_engine(self, typ: str, fq: float):
+        f = FAMILY[typ]
+        return Engine([fq], self.sr, sonde="generic", generic=f["generic"], thres=f["thres"], auto=f["auto"], keep_soft=True, lp_iq=True,
+                      max_chunk=self.chunk, max_frames=8)
+
+    def _follow_lms(self, s):
+        """an LMS6 whose decoder found LMS-X blocks (or the reverse): from the next chunk on its samples go through an engine of the other description
+        (the stand-alone decoder replays its input from the end of the block instead, host/lms6Xmod.c; here the stream is live and that block's successor is lost)"""
+        want, changed = s["telemetry"].lms_type()
+        if changed and want != s["type"]:
+            s["engine"].close()
+            s["engine"] = self._family_engine(want, s["fq"])
+            self.log.append(dict(event="retuned", type=want, was=s["type"], fq=s["fq"], freq_khz=s["khz"]))
+            s["type"], s["telemetry"].moved = want, True
 
     def push(self, iq: np.ndarray, finish: bool = False):
         """iq: interleaved int16 I/Q, a whole number of chunks is not required; returns the JSON objects of this call."""
@@ -95,6 +108,8 @@ class WidebandReceiver:
                 out += self._drain(s, False)
                 if s["frames"] != before:
                     s["t_last"] = self.t
+                    if s["type"] in ("LMS6", "LMSX"):
+                        self._follow_lms(s)
                 elif self.t - s["t_last"] > self.idle_s:      # silent for too long: give the engine back
                     out += self._drain(s, True)
                     s["engine"].close(); s["telemetry"].close()
@@ -184,7 +199,7 @@ class ChannelizedReceiver:
     def _start(self, k: int, typ: str, df: float):
         f_hz = self.ch.channel_freq(k) + df * self.if_sr
         for s in self.sondes:                                    # the neighbouring channel sees a strong signal too
-            if s["type"] == typ and abs(s["f_hz"] - f_hz) < (FAMILY[typ]["sep_hz"] if typ in FAMILY else 20_000.0 if typ in ("M10", "M20") else 8_000.0):
+            if LMS_BASE.get(s["type"], s["type"]) == typ and abs(s["f_hz"] - f_hz) < (FAMILY[typ]["sep_hz"] if typ in FAMILY else 20_000.0 if typ in ("M10", "M20") else 8_000.0):
                 return
         g = self._group(typ)
         if None not in g["owner"]:
@@ -224,7 +239,7 @@ class ChannelizedReceiver:
                     self._start(d["channel"], d["type"], d["df"])
                 elif d["type"] in FAMILY and (d["score"] > 0 or FAMILY[d["type"]]["auto"]):
                     self._start(d["channel"], d["type"], d["df"])
-            for typ, g in self.groups.items():
+            for typ, g in list(self.groups.items()):
                 for slot, s in enumerate(g["owner"]):
                     if s is not None:
                         g["stage"][slot, :m] = self.out[s["chan"], :m]
@@ -244,11 +259,36 @@ class ChannelizedReceiver:
                         s["telemetry"].close()
                         self.sondes.remove(s)
                         self.log.append(dict(event="released", type=typ, f_hz=s["f_hz"], slot=slot, frames=s["frames"]))
+            for s in [s for s in self.sondes if s["type"] in ("LMS6", "LMSX")]:     # after every engine has had this block: sondes whose decoder changed type
+                self._follow_lms(s)
             self.t += m / self.if_sr
         if finish:
             for typ, g in self.groups.items():
                 out += self._drain(typ, g, True)
         return out
+
+    def _follow_lms(self, s):
+        """an LMS6 whose decoder found LMS-X blocks (or the reverse): the sonde moves to a channel of the engine of the other description, decoder object and
+        all; the next block of samples is the first it sees there"""
+        want, changed = s["telemetry"].lms_type()
+        if not changed or want == s["type"]:
+            return
+        g0 = self.groups[s["type"]]
+        g0["engine"].finish_channel(s["slot"])
+        g0["owner"][s["slot"]] = None
+        g = self._group(want)
+        if None not in g["owner"]:
+            s["telemetry"].close()
+            self.sondes.remove(s)
+            self.log.append(dict(event="no free channel", type=want, f_hz=s["f_hz"]))
+            return
+        slot = g["owner"].index(None)
+        if g["calls"]:
+            g["engine"].restart_channel(slot)
+        g["engine"].tune_channel(slot, (s["f_hz"] - self.ch.channel_freq(s["chan"])) / self.if_sr)
+        self.log.append(dict(event="retuned", type=want, was=s["type"], f_hz=s["f_hz"], slot=slot))
+        s["type"], s["slot"], s["telemetry"].moved = want, slot, True
+        g["owner"][slot] = s
 
     def _drain(self, typ, g, finish):
         e = g["engine"]

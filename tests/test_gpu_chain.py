@@ -690,3 +690,41 @@ def test_channelized_receivers_decode_an_rs92(tmp_path):
                        input=iq.tobytes(), capture_output=True, timeout=600, env=env)
     assert c.returncode == 0, c.stderr[-500:]
     assert [json.loads(l) for l in c.stdout.decode().splitlines()] == want
+
+
+def test_receivers_follow_an_lms6_that_turns_out_to_be_lmsx():
+    """The scanner knows one LMS6 template; an LMS-X (300-byte blocks at 4797.8 Bd) is detected as LMS6, its first block tells the decoder object
+    (sonde_lms6_dec_type), and the receivers move the sonde to an engine of the LMS-X description — raster and channelized form, Python and C, the C
+    receivers printing what the Python ones return."""
+    import json
+    from tools import synth
+    from radiosonde_auto_rx_amd.wideband import ChannelizedReceiver, WidebandReceiver
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sr, cf, M, D, P = 2_400_000, 403_000_000, 64, 48, 8
+    fq = synth.snap_fq((8 * sr / M + 900.0) / sr, sr)          # 300.9 kHz: next to a raster point and inside channelizer channel 8
+    iq = synth.lms6_capture(sr=sr, seconds=9.0, fq=fq, noise_sigma=0.004, amp=0.25, seed=31, baud=4797.8, lmsx=True)
+    n = len(iq) // 2
+    env = dict(os.environ, SONDE_JSN_VERSION="oracle")
+
+    rx = WidebandReceiver(sr, cfreq_hz=cf, raster_hz=10_000, version="oracle")
+    want = rx.push(iq, finish=True)
+    log = list(rx.log)
+    rx.close()
+    assert [e["type"] for e in log if e["event"] == "retuned"] == ["LMSX"], log
+    assert sum(j["id"] == "LMSX-8123456" for j in want) >= 3, ([j["id"] for j in want], log)
+    c = subprocess.run([os.path.join(BIN, "sonde_wideband"), "-v", "--cfreq", str(cf), "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert c.returncode == 0 and b"retuned: LMS6 -> LMSX" in c.stderr, c.stderr[-500:]
+    assert [json.loads(l) for l in c.stdout.decode().splitlines()] == want
+
+    rx = ChannelizedReceiver(sr, M=M, D=D, P=P, cfreq_hz=cf, slots=2, version="oracle")
+    want = []
+    for s0 in range(0, n, rx.chunk):
+        want += rx.push(iq[2 * s0:2 * min(n, s0 + rx.chunk)], finish=(s0 + rx.chunk >= n))
+    log = list(rx.log)
+    rx.close()
+    assert [e["type"] for e in log if e["event"] == "retuned"] == ["LMSX"], log
+    assert sum(j["id"] == "LMSX-8123456" for j in want) >= 3, ([j["id"] for j in want], log)
+    c = subprocess.run([os.path.join(BIN, "sonde_wideband"), "--channelize", "--chan-M", str(M), "--chan-D", str(D), "--chan-P", str(P), "--slots", "2", "-v", "--cfreq", str(cf),
+                        "-", str(sr), "16"], input=iq.tobytes(), capture_output=True, timeout=600, env=env)
+    assert c.returncode == 0 and b"retuned: LMS6 -> LMSX" in c.stderr, c.stderr[-500:]
+    assert [json.loads(l) for l in c.stdout.decode().splitlines()] == want
