@@ -91,6 +91,7 @@ float vaporSatP(float Tc) {                             // Hyland and Wexler
 }  // namespace
 
 struct sonde_imet54_dec {
+    unsigned char hexbyte = 0;                               // --rawhex: the byte a pair that is not hex leaves in place
     sonde_imet54_opts_t o{};
     uint32_t SNu32 = 0;
     int timems = 0, std_ = 0, min_ = 0;
@@ -290,7 +291,7 @@ int sonde_imet54_dec_rawhex(sonde_imet54_dec_t *d, const char *line, char *out, 
     if (sp) *sp = '\0';
     const int len = (int)strlen(buf) / 2;
     if (len > 20) {
-        unsigned char b = 0;
+        unsigned char &b = d->hexbyte;                           // keeps its value from line to line, as the reference's variable does
         for (int i = 0; i < len; i++) { sscanf(buf + 2 * i, "%2hhx", &b); d->frame[i] = b; }          // a pair that is not hex keeps the previous byte (:1104-1107)
         d->print_frame(w, len * 16, 0);
     }

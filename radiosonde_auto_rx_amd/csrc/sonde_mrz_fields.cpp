@@ -32,6 +32,7 @@ float f32(uint32_t w) { float f; memcpy(&f, &w, 4); return f; }
 }  // namespace
 
 struct sonde_mrz_dec {
+    unsigned char hexbyte = 0;                               // --rawhex: the byte a pair that is not hex leaves in place
     sonde_mrz_opts_t o{};
     int bits_ofs = 8;
     uint8_t subcnt1 = 0, subcnt2 = 0, numSats = 0, cfg_ntc = 0, cfg_T = 0, cfg_H = 0, crcOK = 0;
@@ -329,7 +330,7 @@ int sonde_mrz_dec_rawhex(sonde_mrz_dec_t *d, const char *line, char *out, size_t
     if (sp) *sp = '\0';
     const int len = (int)strlen(buf) / 3;
     if (len > 20) {
-        unsigned char b = 0;
+        unsigned char &b = d->hexbyte;                           // keeps its value from line to line, as the reference's variable does
         for (int i = 0; i < len; i++) { sscanf(buf + 3 * i, "%2hhx", &b); d->frame[i] = b; }
         d->print_frame(w, len, 0);
     }
