@@ -59,7 +59,8 @@ int inverse_diagonal4(const double m[4][4], double diag[4]) {
 
 inline double lorentz(const double a[4], const double b[4]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] - a[3] * b[3]; }
 
-// left inverse of the N x 4 matrix B: B^-1 for N = 4, (B^T B)^-1 B^T above (:1102-1123)
+// left inverse of the N x 4 matrix B: B^-1 for N = 4, (B^T B)^-1 B^T above (:1102-1123).  Where the 4x4 inverse fails (|det| < 1e-4) the reference goes on with an
+// uninitialised matrix (its matrix_invert returns before writing); here that matrix is zero: no correction, no velocity.
 void left_inverse(int N, const double B[][4], double Binv[4][12]) {
     double sq[4][4], sqinv[4][4];
     memset(sqinv, 0, sizeof sqinv);

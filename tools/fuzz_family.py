@@ -194,6 +194,13 @@ def run(seed: int, iterations: int, keep_dir: str | None = None) -> int:
             data = hard.tobytes()
             args = ["--bin"] + [x for x in a if x not in ("--ecc3", "--ecc4")]
         ok, ra, rb = both(dec, args, data)
+        if not ok and dec == "rs92mod" and os.path.exists("oracle/_ref/rs92mod_msan"):
+            # a GPS solution whose 4x4 inverse fails (|det| < 1e-4): the reference goes on with uninitialised memory (MemorySanitizer: rs92mod.c:1238,1240); the
+            # native tier uses a zero matrix there.  Such frames are not comparable: ask the sanitizer build of the reference whether this is one
+            rm = subprocess.run(["oracle/_ref/rs92mod_msan"] + args, input=data, capture_output=True, timeout=120)
+            if b"use-of-uninitialized-value" in rm.stderr and ra.returncode == rb.returncode:
+                print("  (rs92mod: the reference reads uninitialised memory on this input, not compared)", args[:3])
+                ok = True
         if not ok:
             bad += 1
             _report(dec, args, data, ra, rb, keep_dir, f"{seed}_{it}.bin")
