@@ -32,8 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SR = 2_400_000
-BANK = 8                 # unique synthetic captures tiled over the channels
-PROFILE_TAG = "r3"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
+BANK = 20                # unique synthetic captures tiled over the channels
+# on-air bit flips per frame of each capture (tools/synth.rs41_capture bit_errors; the flips fall on both interleaved RS(255,231) codewords):
+# 50 % of the channels clean, 30 % with 3 .. 10 symbol errors, 15 % at the code's limit (t = 12 per codeword: some frames need the 2nd pass
+# of --ecc2, some fail), 5 % beyond it.  What the decoder makes of each class is reported in config.error_mix.
+ERROR_MIX = [0] * 10 + [3, 4, 5, 6, 8, 10] + [20, 22, 24] + [48]
+ERROR_CLASSES = ["clean"] * 10 + ["3-10 symbol errors"] * 6 + ["near t = 12 per codeword"] * 3 + ["uncorrectable"]
+PROFILE_TAG = "r4"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
 
 
 def make_bank(seconds: float = 1.0):
@@ -43,7 +48,7 @@ def make_bank(seconds: float = 1.0):
     for b in range(BANK):
         fq = synth.snap_fq(float(rng.uniform(-0.4, 0.4)), SR)
         caps.append(synth.rs41_capture(sr=SR, seconds=seconds, fq=fq, n_frames=1, t_first=0.15, seed=100 + b,
-                                       first_frame_no=1000 * (b + 1), sonde_id="T%07d" % b, noise_sigma=0.01))
+                                       first_frame_no=1000 * (b + 1), sonde_id="T%07d" % b, noise_sigma=0.01, bit_errors=ERROR_MIX[b]))
         fqs.append(fq)
     return fqs, caps
 
@@ -234,34 +239,47 @@ def bench_demod(args, D: Dist):
                 shard.gather_summaries(D.dist, src, D.world, gathered)
         return frames
 
-    t_w = time.perf_counter()
     for _ in range(warmup):
         step()
     eng.fetch_frames_np(lag=0)
-    t_w = (time.perf_counter() - t_w) / max(1, warmup)
-    # at least ~1.2 s of timed work whatever K is (the driver's GPU-busy sampler needs to see the run): the K steps are repeated R times
-    # and every figure below is over all K x R steps
-    est = max(t_w, 1e-4)
-    repeats = 1 if os.environ.get("SONDE_BENCH_NO_REPEAT") else max(1, int(np.ceil(1.2 / (est * steps))))
+    # at least 2 s of timed work whatever K is (the driver's GPU-busy sampler needs to see the run): the K steps are repeated R times and
+    # every figure below is over all K x R steps.  R comes from a steady-state probe (the warm-up itself carries first-call costs)
+    eng.sync(); torch.cuda.synchronize()
+    t_p = time.perf_counter()
+    for _ in range(10):
+        step()
+    eng.fetch_frames_np(lag=0)
+    eng.sync(); torch.cuda.synchronize()
+    est = max((time.perf_counter() - t_p) / 10, 1e-4)
+    repeats = 1 if os.environ.get("SONDE_BENCH_NO_REPEAT") else max(1, int(np.ceil(2.0 / (est * steps))))
     total_steps = steps * repeats
     eng.profile(1)                      # timed region: HIP events around the dominant kernel only (2 events per step)
     D.barrier()
     t0 = time.perf_counter()
-    nframes, nok = 0, 0
+    nframes, nok, nfixed, nsym = 0, 0, 0, 0
+    host_ecc0 = eng.host_ecc_frames()
     fr_tail = [None, None, None]                                          # the last fetches (every channel ends a frame once per step)
+
+    def tally(fr):
+        nonlocal nframes, nok, nfixed, nsym
+        e = fr["ecc"]
+        nframes += len(fr)
+        nok += int((e >= 0).sum())
+        nfixed += int((e > 0).sum())
+        nsym += int(e[e > 0].sum())
+
     for k in range(total_steps):
         fr = step()
         fr_tail[k % 3] = fr
-        nframes += len(fr)
-        nok += int((fr["ecc"] >= 0).sum())
+        tally(fr)
     fr_tail = [fr_tail[(total_steps + i) % 3] for i in range(3)] + [eng.fetch_frames_np(lag=0)]     # oldest first; drain: all work is inside the timed region
-    nframes += len(fr_tail[-1])
-    nok += int((fr_tail[-1]["ecc"] >= 0).sum())
+    tally(fr_tail[-1])
     eng.sync()
     D.barrier()
     dt_local = time.perf_counter() - t0
     dt, per_rank = D.finish_times(dt_local)
-    nframes, nok = D.sum_ints(nframes, nok)
+    host_ecc = eng.host_ecc_frames() - host_ecc0
+    nframes, nok, nfixed, nsym, host_ecc = D.sum_ints(nframes, nok, nfixed, nsym, host_ecc)
     md_ms, md_n = eng.kernel_ms("mix_decimate")
 
     # untimed: every channel's last frame against the CPU oracle's last frame of the same stream (frame bytes, length, ECC verdict)
@@ -275,15 +293,42 @@ def bench_demod(args, D: Dist):
             f, w = last.get(c), want[ch_bank[c]]
             ok = f is not None and w is not None and int(f["len"]) == w[1] and int(f["ecc"]) == w[2] and bytes(f["frame"][:w[1]]) == w[0][:w[1]]
             verified += int(ok)
+
             if not ok and len(mismatched) < 8:
                 mismatched.append(c)
         verified, = D.sum_ints(verified)
 
+    error_mix = {"bit_flips_per_frame_by_capture": ERROR_MIX, "classes": {k: ERROR_CLASSES.count(k) / BANK for k in dict.fromkeys(ERROR_CLASSES)},
+                 "rs41_ecc_value_by_capture": [(want[b][2] if want is not None and want[b] is not None else None) for b in range(BANK)],
+                 "note": "channel c decodes capture (c + rank) mod %d; rs41_ecc value = repaired symbols of both codewords, negative = codeword 1 / 2 / both "
+                         "unrepairable (CPU oracle's verdict; every channel's device result is compared with it: verified_channels)" % BANK}
+    # untimed: the same steps with the Reed-Solomon decoder on the host (the round-3 arrangement: k_framesync leaves first-pass syndromes, the
+    # fetch runs rs41_ecc on one host thread) — what the device decoder replaces
+    ab = None
+    if D.world == 1 and not args.no_extras:
+        eng.set_device_ecc(False)
+        for _ in range(3):
+            step()
+        eng.fetch_frames_np(lag=0); eng.sync()
+        h0, t_ab, n_ab = eng.host_ecc_frames(), time.perf_counter(), 60
+        for _ in range(n_ab):
+            step()
+        eng.fetch_frames_np(lag=0); eng.sync()
+        t_ab = (time.perf_counter() - t_ab) / n_ab
+        ab = dict(ms_per_step=round(t_ab * 1e3, 3), frames_decoded_by_host_rs_per_step=round((eng.host_ecc_frames() - h0) / n_ab, 1), steps=n_ab,
+                  note="SONDE_HOST_ECC form: syndromes on the device, rs_decode of every damaged codeword on one host thread inside the fetch")
+        eng.set_device_ecc(True)
+        for _ in range(3):
+            step()
+        eng.fetch_frames_np(lag=0); eng.sync()
+
     # untimed: per-kernel table of a step (events around every kernel cost ~0.1 ms of host time per step, so not in the timed region)
+    # pipelined like the timed loop (a step that waits for its own frames lets the clocks drop between steps and reads 10 % slow)
     eng.profile(2)
-    nprof = 5
+    nprof = 20
     for _ in range(nprof):
-        step(lag=0)
+        step()
+    eng.fetch_frames_np(lag=0)
     kern = {}
     for k in ("mix_decimate", "if_chain", "header_corr", "framesync"):
         ms, n = eng.kernel_ms(k)
@@ -309,7 +354,11 @@ def bench_demod(args, D: Dist):
                        "channels_per_gpu": C, "samples_per_channel_per_step": SR, "realtime_channels": round(value / 2.4, 1),
                        "repeats": repeats, "timed_steps": total_steps, "timed_seconds": round(dt, 3),
                        "frame_fetch_lag": lag, "two_streams": bool(lag > 0 and args.two_streams),
-                       "frames_decoded": nframes, "frames_ecc_ok": nok,
+                       "frames_decoded": nframes, "frames_ecc_ok": nok, "frames_ecc_failed": nframes - nok, "frames_repaired": nfixed,
+                       "symbols_repaired": nsym, "frames_decoded_by_host_rs": host_ecc,
+                       "ecc": "rs41_ecc (--ecc2: RS(255,231) Euclid / Chien / Forney per codeword, 2nd pass with the known block ids) inside k_framesync on the "
+                              "device for every frame with non-zero syndromes; the host formats only (frames_decoded_by_host_rs = 0)",
+                       "error_mix": error_mix,
                        "verified_channels": verified if want is not None else None, "verify_mismatch_channels": mismatched,
                        "verify_note": "untimed, after the loop: the last frame of every channel (bytes, length, ECC verdict) equals the CPU oracle's last frame "
                                       "of the stream that channel saw (oracle/ora_rs41_decode on lead-in + 4 s of its capture)",
@@ -328,7 +377,11 @@ def bench_demod(args, D: Dist):
             out["config"]["verify_failed"] = True
     # ---- extras on one GPU (never part of `value`)
     if D.world == 1 and not args.no_extras:
+        out["host_ecc_ab"] = ab
         out["detect_in_step"] = detect_in_step_extra(D, eng, iq, ch_fq, C, STRIDE, lag)
+        if not args.no_configs:                                       # the same at higher scan duties (BASELINE configs[4] "full detect" = duty 1)
+            out["detect_in_step"]["duty_1_4"] = detect_in_step_extra(D, eng, iq, ch_fq, C, STRIDE, lag, groups=4)
+            out["detect_in_step"]["duty_1_1"] = detect_in_step_extra(D, eng, iq, ch_fq, C, STRIDE, lag, groups=1)
         out["pcie_inclusive"] = pcie_extra(D, eng, iq, C)
     eng.set_summary(0)
     eng.close()
@@ -348,7 +401,7 @@ def bench_demod(args, D: Dist):
     return out
 
 
-def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
+def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag, groups=16):
     """BASELINE configs[4] "full detect -> demod -> ECC" as one step: the demodulator step over all C channels with the dft_detect scanner
     (`--IQ fq --dc`, front end + 14 templates) re-scanning a rotating 1/16 of the channels over the same second, inside the step — the
     auto_rx duty cycle: decoders run on the channels that were found while the scanner keeps sweeping (scan.py:948, decode.py:869-913).
@@ -356,7 +409,6 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
     engine's frames of the previous call AND the scanner's detections of this one have been fetched.  Not part of `value`."""
     torch = D.torch
     from radiosonde_auto_rx_amd.scan import Scanner
-    groups = 16
     per = max(1, C // groups)
     scs = [Scanner(SR, fq=ch_fq[g * per:(g + 1) * per], dc=True, cont=True, max_chunk=SR, device=D.local_rank) for g in range(groups)]
     found = [0]
@@ -376,12 +428,12 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
         found[0] += job.result()                                                    # the step is over when both are
         return fr
 
-    for k in range(groups):                                               # every scanner has seen a second (allocations, first windows)
+    for k in range(max(groups, 3)):                                       # every scanner has seen a second (allocations, first windows)
         step(k)
     eng.fetch_frames_np(lag=0)
     torch.cuda.synchronize()
     found[0] = 0
-    n = 4 * groups
+    n = max(12, 4 * groups)
     t0 = time.perf_counter()
     for k in range(n):
         step(k)
@@ -393,9 +445,9 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag):
     for sc in scs:
         sc.close()
     return dict(ms_per_step=round(dt * 1e3, 3), value=round(C * SR / dt / 1e6, 1), unit="Msamples/s", realtime_channels=round(C * SR / dt / 2.4e6, 1),
-                channels_scanned_per_step=per, scan_duty="1/%d of the channels per step, rotating" % groups, steps=n,
+                channels_scanned_per_step=per, scan_duty=("1/%d of the channels per step, rotating" % groups) if groups > 1 else "every channel every step", steps=n,
                 rs41_detections_per_scanned_channel=round(found[0] / float(n * per), 3),
-                note="demodulator step over all channels + dft_detect scanner (front end, 14 templates) over 1 s of a rotating 1/16 of them, inside the step")
+                note="demodulator step over all channels + dft_detect scanner (front end, 14 templates) over 1 s of %s, inside the step" % (("a rotating 1/%d of them" % groups) if groups > 1 else "all of them"))
 
 
 def pcie_extra(D: Dist, eng, iq, C):

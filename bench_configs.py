@@ -134,10 +134,15 @@ def bench_fsk_mixed(args, D, short=False):
     C = args.channels or 1024
     steps = args.steps or (25 if short else 100)
     warmup = 2 if args.warmup is None else args.warmup
-    groups = [("rs41", 48000, 4800, 5), ("dfm", 50000, 2500, 5), ("m10", 48080, 9616, 5)]
+    # auto_rx's own argument sets (auto_rx/autorx/decode.py): RS41 :869-907 `-b -5000 -u 5000 --mask 5000 --nsym=300 -p 5`; DFM :1036-1067
+    # `-b -5000 -u 5000` with fsk_demod's defaults P = 10 (utils/fsk_demod.c:71), nsym = 50 (fsk.h:46); M10 :1085-1122 `-b -10000 -u 10000 -p 5`
+    groups = [("rs41", 48000, 4800, 5, 300, 5000, 5000), ("dfm", 50000, 2500, 10, 50, 0, 5000), ("m10", 48080, 9616, 5, 50, 0, 10000)]
+
+    def ref_args(P, nsym, mask, lim):
+        return ["--cs16", "-b", str(-lim), "-u", str(lim), "-s"] + (["--mask", str(mask)] if mask else []) + ["--nsym=%d" % nsym, "-p", str(P)]
     engines = []
     total_samples = 0
-    for gi, (kind, Fs, Rs, P) in enumerate(groups):
+    for gi, (kind, Fs, Rs, P, nsym, mask, lim) in enumerate(groups):
         n = C // 3 + (1 if gi < C % 3 else 0)
         caps = []
         for s in range(4):
@@ -149,9 +154,8 @@ def bench_fsk_mixed(args, D, short=False):
                 caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=20 + s, baud=float(Rs)))
         L = min(len(c) for c in caps)
         X = torch.from_numpy(np.stack([caps[c % 4][:L] for c in range(n)])).to(D.dev)
-        md = FskModem(Fs, Rs, n_channels=n, P=P, nsym=300 if kind == "rs41" else 150, mask=5000 if kind == "rs41" else 0,
-                      lower=-20000, upper=20000, max_chunk=Fs, device=D.local_rank)
-        engines.append((kind, Fs, Rs, n, X, md, caps[0]))
+        md = FskModem(Fs, Rs, n_channels=n, P=P, nsym=nsym, mask=mask, lower=-lim, upper=lim, max_chunk=Fs, device=D.local_rank)
+        engines.append((kind, Fs, Rs, n, X, md, caps[0], ref_args(P, nsym, mask, lim)))
         total_samples += n * (L // 2)
 
     # untimed, before anything else: the first second of every channel against the compiled reference modem (oracle/_ref/fsk_demod, test infrastructure) —
@@ -162,7 +166,7 @@ def bench_fsk_mixed(args, D, short=False):
         have_ref = bind.have_ref()
     except Exception:
         have_ref = False
-    for kind, Fs, Rs, n, X, md, _cap in engines:
+    for kind, Fs, Rs, n, X, md, _cap, rargs in engines:
         md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
         sds = [md.fetch(c)[0] for c in range(n)]
         refs = {}
@@ -170,7 +174,7 @@ def bench_fsk_mixed(args, D, short=False):
             import subprocess
             exe = os.path.join(bind.REFDIR, "fsk_demod")
             for b in range(min(4, n)):
-                argv = [exe, "--cs16", "-b", "-20000", "-u", "20000", "-s"] + (["--mask", "5000", "--nsym=300"] if kind == "rs41" else ["--nsym=150"]) + ["-p", "5", "2", str(Fs), str(Rs), "-", "-"]
+                argv = [exe] + rargs + ["2", str(Fs), str(Rs), "-", "-"]
                 r = subprocess.run(argv, input=X[b].cpu().numpy().tobytes(), capture_output=True, timeout=120)
                 refs[b] = np.frombuffer(r.stdout, np.float32)
             vnote = "first second of every channel: soft decisions equal to channel (c mod 4) bit for bit, and that channel's to oracle/_ref/fsk_demod -s within 1e-6 of the RMS, same signs"
@@ -190,7 +194,7 @@ def bench_fsk_mixed(args, D, short=False):
     pool = ThreadPoolExecutor(max_workers=len(engines))
 
     def one(e):
-        kind, Fs, Rs, n, X, md, _ = e
+        kind, Fs, Rs, n, X, md, _, _ = e
         md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
 
     def step():
@@ -199,7 +203,7 @@ def bench_fsk_mixed(args, D, short=False):
 
     dt, per = _timed_steps(D, step, steps, warmup)
     value = D.world * total_samples * steps / dt / 1e6
-    kern = {kind: md.kernel_ms() for kind, _, _, _, _, md, _ in engines}
+    kern = {kind: md.kernel_ms() for kind, _, _, _, _, md, _, _ in engines}
     # dominant kernel k_fsk_stream: algorithmic bytes = 4 B per complex cs16 input sample (soft decisions out: 4 B per symbol)
     # the three launches overlap: the rate follows from the step time, not from the sum of the kernels' own durations
     achieved = total_samples * 4 / (dt / steps) / 1e9
@@ -210,7 +214,9 @@ def bench_fsk_mixed(args, D, short=False):
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: %d channels per GPU, RS41 48000/4800, DFM09 50000/2500, M10 48080/9616 in equal parts, "
-                                   "fsk_demod --cs16 -s (mask estimator for RS41), 1 s per channel per step" % C,
+                                   "fsk_demod --cs16 -s with auto_rx's argument sets (decode.py:901 RS41 `-b -5000 -u 5000 --mask 5000 --nsym=300 -p 5`; :1048 DFM "
+                                   "`-b -5000 -u 5000`, defaults P 10 / nsym 50; :1120 M10 `-b -10000 -u 10000 -p 5`, nsym 50), 1 s per channel per step" % C,
+                       "fsk_demod_args": {g[0]: " ".join(ref_args(*g[3:])) for g in groups},
                        "channels_per_gpu": C, "realtime_channels": round(value * 1e6 / D.world / (total_samples / C), 1) if total_samples else 0,
                        "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per],
                        "kernel_ms_per_launch": {k: round(v[0], 4) for k, v in kern.items()},
@@ -228,13 +234,12 @@ def bench_fsk_mixed(args, D, short=False):
                     cmds, inputs, units = [], [], 0
                     exe = os.path.join(bind.REFDIR, "fsk_demod")
                     for k in range(ncores):
-                        kind, Fs, Rs, n, X, md, cap = engines[k % 3]
+                        kind, Fs, Rs, n, X, md, cap, rargs = engines[k % 3]
                         p = os.path.join(td, f"{kind}{k}.cs16")
                         with open(p, "wb") as f:
                             for _ in range(20):
                                 f.write(cap.tobytes())
-                        cmds.append([exe, "--cs16", "-b", "-20000", "-u", "20000", "-s"] + (["--mask", "5000", "--nsym=300"] if kind == "rs41" else ["--nsym=150"]) +
-                                    ["-p", "5", "2", str(Fs), str(Rs), "-", "-"])
+                        cmds.append([exe] + rargs + ["2", str(Fs), str(Rs), "-", "-"])
                         inputs.append(p); units += 20 * (len(cap) // 2)
                     r = _time_reference(cmds, inputs, units / ncores, "Msamples/s", "fsk_demod processes (RS41 / DFM / M10 settings in turn) over 20 s of IF-rate cs16", getattr(args, "cpu_budget", 12.0))
                 out["cpu_baseline"] = r

@@ -183,15 +183,17 @@ int64_t sonde_engine_samples_to_dc_boundary(const sonde_engine_t *e);
 /* wait for all enqueued work */
 int  sonde_engine_sync(sonde_engine_t *e);
 
-/* Collect frames completed so far (syncs).  Runs the RS(255,231) pass(es) of rs41_ecc()
- * (rs41mod.c:1703-1769) on the host for frames whose device-computed syndromes are non-zero.
+/* Collect frames completed so far (syncs).  The RS(255,231) passes of rs41_ecc() (rs41mod.c:1703-1769) have run on the device for
+ * whole frames (k_framesync: syndromes, and for non-zero ones the Euclid / Chien / Forney decoder of bch_ecc_mod.c:877-960 on a wavefront
+ * per codeword, the 2nd pass of --ecc2 included); only a frame cut short by the end of the stream is decoded on the host, because its
+ * missing bytes come from the previous frame (rs41mod.c:2479-2490).
  * Returns the number of frames written (<= max).  Frames of one channel come in stream order; the order between
  * channels that completed a frame in the same process call is unspecified (sonde_frame_t.channel tells them apart). */
 /* Per-channel detection summary: the ONLY data that crosses GPUs when channels are sharded over a node — 32 bytes per
  * channel, written by the frame-sync kernel at every frame it emits and left in device memory, so the all_gather (RCCL over xGMI) runs
  * on the device buffer without a host round trip.  sample_pos = IF-rate sample index of the header's last sample (64 bit).  frames /
- * frames_clean are cumulative: frames emitted and, of those, frames whose RS syndromes were all zero on the device (no host ECC
- * needed; RS41 only).  reference: the per-sonde process of auto_rx prints this information per frame (rs41mod.c:2530-2545). */
+ * frames_clean are cumulative: frames emitted and, of those, frames whose RS syndromes were all zero (nothing to
+ * correct; RS41 only).  reference: the per-sonde process of auto_rx prints this information per frame (rs41mod.c:2530-2545). */
 typedef struct {
     uint32_t channel_id;     /* global channel number: summary_base + channel within the engine                  */
     uint8_t  type;           /* SONDE_RS41 / SONDE_DFM09 / ... (cfg.sonde_type)                                   */
@@ -217,6 +219,13 @@ int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t ma
 /* 1 if the device-side frame queue (cfg.max_frames) overflowed since the last call of this function — the oldest frames were then
  * overwritten before a fetch could read them; the fetch functions themselves return the number of frames they delivered. */
 int  sonde_engine_overflowed(sonde_engine_t *e);
+/* RS41 frames whose Reed-Solomon decoder ran on the host in sonde_engine_fetch_frames* so far: frames cut short by the end of the stream,
+ * and every frame with non-zero syndromes when SONDE_HOST_ECC=1 is set in the environment (the A/B switch).  Whole frames are decoded by
+ * k_framesync on the device (rs41_ecc, rs41mod.c:1703-1769; rs_decode_ErrEra, bch_ecc_mod.c:877-960). */
+long long sonde_engine_host_ecc_frames(sonde_engine_t *e);
+/* on = 0: frames of the following calls leave k_framesync with their first-pass syndromes only and are decoded on the host when fetched (the
+ * round-3 arrangement; A/B measurements and tests); on = 1 (default): device decoder. */
+int  sonde_engine_set_device_ecc(sonde_engine_t *e, int32_t on);
 /* Pipelined variant: return only the frames of process calls issued at least `lag` calls ago and wait only for those.
  * With lag = 1 the IF-rate kernels of call k (stream B) overlap the decimator of call k+1 (stream A); lag = 0 is
  * sonde_engine_fetch_frames().  Frames are never lost: what is not returned stays queued. */
@@ -365,6 +374,13 @@ int  sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen);
 /* RS(255,231) codec of bch_ecc_mod.c (rs_encode :860, rs_decode :962) — exposed for tests/tools */
 int  sonde_rs255_encode(uint8_t cw[255]);
 int  sonde_rs255_decode(uint8_t cw[255]);
+/* rs41_ecc() (rs41mod.c:1703-1769, ecc level 1 = --ecc, 2 = --ecc2) over n de-whitened RS41 frames of 518 bytes each ON THE DEVICE, one
+ * workgroup per frame — the decoder k_framesync runs behind its slicer (syndromes on 16 wavefronts, rs_decode_ErrEra of
+ * bch_ecc_mod.c:877-960 with no erasures on one wavefront per codeword, the 2nd pass with the known block ids).  Host pointers; frames are
+ * repaired in place exactly as the reference leaves gpx->frame (bytes from flen[i] on count as zero, :1727).  ecc[i] = rs41_ecc's value;
+ * codes (nullable) = [n][2] the two rs_decode() values of the last pass; synd (nullable) = [n][48] first-pass syndromes.
+ * Returns 0 or a SONDE_E_* code (SONDE_E_NOGPU without a device: there is no CPU fallback). */
+int  sonde_rs41_ecc_device(uint8_t *frames, const int32_t *flen, int32_t n, int32_t level, int32_t *ecc, int32_t *codes, uint8_t *synd);
 /* CRC-16/CCITT-FALSE of rs41mod.c:284 */
 int  sonde_crc16(const uint8_t *data, int len);
 

@@ -143,6 +143,7 @@ struct CorrArgs {
 
 struct FrameRec {
     int32_t channel, len, nbytes; uint32_t mv_pos; float mv;
+    int32_t ecc, ecc_done;    // ecc_done != 0: rs41_ecc() ran on the device (k_framesync), ecc = its value and frame[] what it leaves in gpx->frame
     uint8_t synd[48];
     uint8_t frame[520];
 };
@@ -157,6 +158,7 @@ struct SyncArgs {
     int K, L, delay, hdrlen, symhd, symlen, hdmax, bitofs, nbits; uint32_t frame_samples;
     float sps, thres, l_win;
     int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
+    int ecc_level;            // rs41: 1 / 2 = rs41_ecc() of whole frames on the device (--ecc / --ecc2); 0 = first-pass syndromes only
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
     int eof_ch;               // with eof: only this channel (-1 = all)
     const uint32_t *epoch;    // per-channel stream start, nullptr = 0

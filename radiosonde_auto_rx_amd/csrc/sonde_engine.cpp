@@ -92,6 +92,8 @@ struct sonde_engine {
     std::vector<uint8_t> last_frame;
     std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
+    bool dev_ecc = true;               // rs41_ecc() of whole frames in k_framesync (SONDE_HOST_ECC=1: on the host from the device syndromes, the A/B switch)
+    long long host_ecc_frames = 0;     // frames whose RS decoder ran on the host (fetch_rs41)
     bool m10_chk3 = false;                         // m10mod --chk3 (sonde_engine_set_m10_chk3)
     // channels restarted in mid-stream (sonde_engine_restart_channel): per-channel stream start in IF samples
     std::vector<uint32_t> epoch; uint32_t *d_epoch = nullptr; int eof_ch = -1;
@@ -183,6 +185,31 @@ const char *sonde_strerror(int code) {
         case SONDE_E_OVERFLOW: return "frame queue overflow";
         default: return "unknown error";
     }
+}
+
+extern "C" void sonde_launch_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int n, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
+                                            const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
+
+int sonde_rs41_ecc_device(uint8_t *frames, const int32_t *flen, int32_t n, int32_t level, int32_t *ecc, int32_t *codes, uint8_t *synd) {
+    if (!frames || !flen || !ecc || n < 0 || level < 1 || level > 2) return SONDE_E_ARG;
+    if (n == 0) return 0;
+    for (int i = 0; i < n; i++) if (flen[i] < 0 || flen[i] > 518) return SONDE_E_ARG;
+    uint8_t *d_fr = nullptr, *d_syn = nullptr, *d_gf = nullptr; int32_t *d_len = nullptr, *d_ecc = nullptr, *d_codes = nullptr;
+    int rc = 0;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == 0) { fprintf(stderr, "libsonde_hip: sonde_rs41_ecc_device: %s\n", hipGetErrorString(e)); rc = SONDE_E_NOGPU; } return rc == 0; };
+    if (ok(hipMalloc((void **)&d_fr, (size_t)n * 518)) && ok(hipMalloc((void **)&d_syn, (size_t)n * 48)) && ok(hipMalloc((void **)&d_gf, 768))
+        && ok(hipMalloc((void **)&d_len, (size_t)n * 4)) && ok(hipMalloc((void **)&d_ecc, (size_t)n * 4)) && ok(hipMalloc((void **)&d_codes, (size_t)n * 8))
+        && ok(hipMemcpy(d_fr, frames, (size_t)n * 518, hipMemcpyHostToDevice)) && ok(hipMemcpy(d_len, flen, (size_t)n * 4, hipMemcpyHostToDevice))
+        && ok(hipMemcpy(d_gf, gf_exp_table(), 512, hipMemcpyHostToDevice)) && ok(hipMemcpy(d_gf + 512, gf_log_table(), 256, hipMemcpyHostToDevice))) {
+        sonde_launch_rs41_ecc_batch(d_fr, d_len, n, level, d_ecc, d_codes, d_syn, d_gf, d_gf + 512, nullptr);
+        ok(hipGetLastError());
+        ok(hipMemcpy(frames, d_fr, (size_t)n * 518, hipMemcpyDeviceToHost));
+        ok(hipMemcpy(ecc, d_ecc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (codes) ok(hipMemcpy(codes, d_codes, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (synd) ok(hipMemcpy(synd, d_syn, (size_t)n * 48, hipMemcpyDeviceToHost));
+    }
+    hipFree(d_fr); hipFree(d_syn); hipFree(d_gf); hipFree(d_len); hipFree(d_ecc); hipFree(d_codes);
+    return rc;
 }
 
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) { return sonde_engine_create_generic(cfg, fq, nullptr, out); }
@@ -360,6 +387,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     bad |= dalloc(&e->d_consts, 1024, true);
     if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
     HIPCHK(hipMemcpy(e->d_match, e->match.data(), L * sizeof(float), hipMemcpyHostToDevice));
+    e->dev_ecc = getenv("SONDE_HOST_ECC") == nullptr;
     {   // Fm = rdft(time-reversed match) with the reference's transform (init_buffers, demod_mod.c:1446-1449); N = 8192 only
         static const bool no_fft = getenv("SONDE_NO_FFTSYNC") != nullptr;        // A/B aid: time-domain correlation ring
         if (!cfg->opt_dc && M == 8192 && K + L <= M && !no_fft) {
@@ -476,7 +504,15 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     // pipeline: stream A (staging, decimator) may run ONE call ahead of stream B (IF-rate kernels); the rings hold that (see
     // process_device).  The FM-audio path writes the rings B reads from on stream A, so it does not pipeline.
     if (cfg->pipeline && audio) { sonde_engine_destroy(e); return SONDE_E_ARG; }
-    if (cfg->pipeline) HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+    if (cfg->pipeline) {
+        // the IF-rate tail of call k runs beside the decimator of call k+1: few, latency-bound workgroups against thousands of bandwidth-bound
+        // ones — B gets the higher dispatch priority so that its workgroups take the next free CU slot instead of queueing behind the decimator's
+        int lo = 0, hi = 0;
+        const char *pr = getenv("SONDE_B_PRIO");                    // A/B aid: 0 = default priority, 1 (default) = highest
+        if ((!pr || atoi(pr) != 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+            HIPCHK(hipStreamCreateWithPriority(&e->stream_b, hipStreamNonBlocking, hi));
+        else HIPCHK(hipStreamCreateWithFlags(&e->stream_b, hipStreamNonBlocking));
+    }
     else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
     HIPCHK(hipStreamCreateWithFlags(&e->stream_c, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
@@ -765,7 +801,7 @@ static void sync_round(sonde_engine *e, int W) {
 static void launch_framesync_impl(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
-    s.eof = eof; s.eof_ch = e->eof_ch; s.epoch = e->d_epoch; s.rs41 = (e->cfg.sonde_type == SONDE_RS41);
+    s.eof = eof; s.eof_ch = e->eof_ch; s.epoch = e->d_epoch; s.rs41 = (e->cfg.sonde_type == SONDE_RS41); s.ecc_level = (s.rs41 && e->dev_ecc && e->cfg.ecc_level >= 1 && e->cfg.ecc_level <= 2) ? e->cfg.ecc_level : 0;
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft; s.soft1 = e->d_soft1;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
@@ -828,8 +864,9 @@ static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int la
             if (e->cfg.ecc_level > 0) {
                 bool clean = true;
                 for (int k = 0; k < 48; k++) clean &= (r.synd[k] == 0);
-                if (clean) { for (int k = f.len; k < 518; k++) f.frame[k] = 0; }
-                else f.ecc = rs41_ecc(f.frame, f.len, e->cfg.ecc_level, r.synd);
+                if (r.ecc_done) f.ecc = r.ecc;                       // rs41_ecc() ran in k_framesync: corrected bytes, zero tail, its return value
+                else if (clean) { for (int k = f.len; k < 518; k++) f.frame[k] = 0; }
+                else { f.ecc = rs41_ecc(f.frame, f.len, e->cfg.ecc_level, r.synd); e->host_ecc_frames++; }
             }
         } else {
             // end-of-stream frame: bytes not read keep the previous frame's content unless fewer than
@@ -857,6 +894,9 @@ int sonde_engine_set_summary_snapshots(sonde_engine_t *e, void *d_snap) {
     e->d_summary_snap = (sonde_summary_t *)d_snap;
     return (int)(e->call & 1);
 }
+
+long long sonde_engine_host_ecc_frames(sonde_engine_t *e) { return e ? e->host_ecc_frames : SONDE_E_ARG; }
+int sonde_engine_set_device_ecc(sonde_engine_t *e, int32_t on) { if (!e) return SONDE_E_ARG; e->dev_ecc = on != 0; return 0; }
 
 int sonde_engine_overflowed(sonde_engine_t *e) {
     if (!e) return SONDE_E_ARG;

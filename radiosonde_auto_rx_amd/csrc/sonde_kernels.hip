@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include "sonde_dev.h"
 #include "md_fast_gen.h"
+#include "sonde_rs_dev.h"
 #include <cstdlib>
 
 typedef short  short2v __attribute__((ext_vector_type(2)));
@@ -1408,6 +1409,10 @@ void k_framesync(const SyncArgs a) {
     __shared__ int s_cnt[2];
     __shared__ unsigned s_slot;
     __shared__ uint8_t s_syn[FS_WAVES][48];
+    __shared__ uint8_t s_S[48];                // first-pass syndromes of the frame in hand
+    __shared__ uint8_t s_cw[2][256];           // device ECC (sonde_rs_dev.h): the two codewords, per-wave scratch, results
+    __shared__ uint8_t s_scr[2][64];
+    __shared__ int s_res[4];
     __shared__ double s_rd[FS_WAVES];
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= a.n_ch) return;
@@ -1614,32 +1619,49 @@ void k_framesync(const SyncArgs a) {
             // frame length from the type byte (rs41mod.c:407-415,2488-2490)
             int ft = 0; { const uint8_t b = s_frame[0x38]; for (int q = 0; q < 4; q++) ft += ((b >> q) & 1) - ((b >> (q + 4)) & 1); }
             const int flen = (ft >= 0) ? 320 : 518;
-            // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732):
-            // wave c evaluates coefficients 16c..16c+15 by Horner and scales by alpha^(16 c j); XOR over the waves
-            if (a.rs41 && lane < 48) {
-                const int cw = lane / 24, jx = lane % 24;
-                const uint8_t x = s_exp[jx];
-                uint8_t hsum = 0;
-                for (int i = 15; i >= 0; i--) {
-                    const int n = 16 * wave + i;
-                    uint8_t v = 0;
-                    if (n < 255) {
-                        const int fi = (n >= 24) ? 56 + 2 * (n - 24) + cw : 8 + 24 * cw + n;
-                        v = (fi < flen) ? s_frame[fi] : 0;
+            // RS(255,231), two interleaved codewords (rs41mod.c:1729-1732).  Whole frames of an engine with --ecc / --ecc2: rs41_ecc() right
+            // here — syndromes by all 16 waves, the Euclid / Chien / Forney decoder on waves 0 and 1 when they are not zero, the 2nd pass with
+            // the known block ids (sonde_rs_dev.h); the host only formats.  Otherwise (no ECC asked for, or a frame cut short by the end of the
+            // stream, whose missing bytes the host fills from the previous frame, rs41mod.c:2479-2490): first-pass syndromes only.
+            int ecc_ret = 0, ecc_done = 0;
+            if (a.rs41 && a.ecc_level > 0 && 8 + nbytes_ok >= 518) {
+                if (tid >= flen && tid < 518) s_frame[tid] = 0;
+                __syncthreads();
+                const RsGf gf{s_exp, s_log};
+                ecc_ret = rs41_ecc_wg(s_frame, a.ecc_level, s_cw, s_syn, s_res, s_scr, s_S, gf, tid);
+                ecc_done = 1;
+            } else if (a.rs41) {
+                // wave c evaluates coefficients 16c..16c+15 by Horner and scales by alpha^(16 c j); XOR over the waves
+                if (lane < 48) {
+                    const int cw = lane / 24, jx = lane % 24;
+                    const uint8_t x = s_exp[jx];
+                    uint8_t hsum = 0;
+                    for (int i = 15; i >= 0; i--) {
+                        const int n = 16 * wave + i;
+                        uint8_t v = 0;
+                        if (n < 255) {
+                            const int fi = (n >= 24) ? 56 + 2 * (n - 24) + cw : 8 + 24 * cw + n;
+                            v = (fi < flen) ? s_frame[fi] : 0;
+                        }
+                        const uint8_t prod = (hsum && x) ? s_exp[s_log[hsum] + s_log[x]] : 0;
+                        hsum = prod ^ v;
                     }
-                    const uint8_t prod = (hsum && x) ? s_exp[s_log[hsum] + s_log[x]] : 0;
-                    hsum = prod ^ v;
+                    const int sh = (jx * 16 * wave) % 255;                 // alpha^(j*16c)
+                    s_syn[wave][lane] = hsum ? s_exp[(s_log[hsum] + sh) % 255] : 0;
                 }
-                const int sh = (jx * 16 * wave) % 255;                 // alpha^(j*16c)
-                s_syn[wave][lane] = hsum ? s_exp[(s_log[hsum] + sh) % 255] : 0;
+                __syncthreads();
+                if (tid < 48) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][tid]; s_S[tid] = syn; }
             }
             __syncthreads();
             if (tid < 518) rec->frame[tid] = s_frame[tid];
-            if (a.rs41 && tid < 48) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][tid]; rec->synd[tid] = syn; }
-            if (tid == 0) { rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok; }
+            if (a.rs41 && tid < 48) rec->synd[tid] = s_S[tid];
+            if (tid == 0) {
+                rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok;
+                rec->ecc = ecc_ret; rec->ecc_done = ecc_done;
+            }
             if (a.summary && tid == 0) {                              // per-channel detection summary, stays on the device
                 bool clean = a.rs41 != 0;
-                if (a.rs41) for (int k = 0; k < 48; k++) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][k]; clean &= (syn == 0); }
+                if (a.rs41) for (int k = 0; k < 48; k++) clean &= (s_S[k] == 0);
                 sonde_summary_t *sm = a.summary + ch;
                 sm->channel_id = a.summary_base + (uint32_t)ch; sm->type = (uint8_t)a.summary_type; sm->inverted = (uint8_t)(st.mv < 0.f);
                 sm->score = st.mv; sm->freq_offset_hz = DC ? (float)af.Df : 0.f;
@@ -2009,6 +2031,28 @@ extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s)
     int grid = a->W * a->n_ch; if (grid > 512) grid = 512;      // two waves of workgroups on 256 CUs at most; the kernel strides over the list
     hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(WF_THREADS), lds, s, *a);
 }
+// rs41_ecc() over a batch of de-whitened 518-byte frames, one workgroup per frame: the decoder of k_framesync on frames that come from
+// somewhere else (tests: word-by-word parity with the compiled reference; callers with frames from --softin or a file)
+__global__ __launch_bounds__(FS_THREADS)
+void k_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int level, int32_t *ecc, int32_t *codes, uint8_t *synd, const uint8_t *gf_exp, const uint8_t *gf_log) {
+    __shared__ uint8_t s_frame[520], s_exp[512], s_log[256], s_cw[2][256], s_part[FS_WAVES][48], s_scr[2][64], s_S[48];
+    __shared__ int s_res[4];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (tid < 512) s_exp[tid] = gf_exp[tid];
+    if (tid < 256) s_log[tid] = gf_log[tid];
+    if (tid < 518) s_frame[tid] = tid < flen[f] ? frames[(size_t)f * 518 + tid] : 0;      // rs41mod.c:1727
+    __syncthreads();
+    const RsGf gf{s_exp, s_log};
+    const int r = rs41_ecc_wg(s_frame, level, s_cw, s_part, s_res, s_scr, s_S, gf, tid);
+    if (tid < 518) frames[(size_t)f * 518 + tid] = s_frame[tid];
+    if (tid < 48) synd[(size_t)f * 48 + tid] = s_S[tid];
+    if (tid == 0) { ecc[f] = r; codes[2 * f] = s_res[0]; codes[2 * f + 1] = s_res[1]; }
+}
+extern "C" void sonde_launch_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int n, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
+                                            const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s) {
+    hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(n), dim3(FS_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log);
+}
+
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
     if (a->opt_dc) hipLaunchKernelGGL(k_framesync<true>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
     else hipLaunchKernelGGL(k_framesync<false>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);

@@ -113,8 +113,23 @@ def lib() -> C.CDLL:
         L.sonde_engine_kernel_ms.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.sonde_engine_stream.argtypes = [C.c_void_p]
         L.sonde_rs41_rawline.argtypes = [C.POINTER(SondeFrame), C.c_char_p, C.c_size_t]
+        L.sonde_engine_host_ecc_frames.argtypes = [C.c_void_p]
+        L.sonde_engine_host_ecc_frames.restype = C.c_longlong
+        L.sonde_engine_set_device_ecc.argtypes = [C.c_void_p, C.c_int32]
+        L.sonde_rs41_ecc_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+def rs41_ecc_device(frames: np.ndarray, flen, level: int = 2):
+    """rs41_ecc() of a batch of de-whitened 518-byte RS41 frames on the device (sonde_rs41_ecc_device, include/sonde_hip.h).
+    -> (repaired frames [n, 518] u8, ecc [n] i32, codes [n, 2] i32 = the two rs_decode values, syndromes [n, 48] u8 of the first pass)"""
+    fr = np.ascontiguousarray(frames, dtype=np.uint8).reshape(-1, 518).copy()
+    n = fr.shape[0]
+    fl = np.ascontiguousarray(np.broadcast_to(np.asarray(flen, dtype=np.int32), (n,)))
+    ecc, codes, synd = np.zeros(n, np.int32), np.zeros((n, 2), np.int32), np.zeros((n, 48), np.uint8)
+    _chk(lib().sonde_rs41_ecc_device(fr.ctypes.data, fl.ctypes.data, n, level, ecc.ctypes.data, codes.ctypes.data, synd.ctypes.data))
+    return fr, ecc, codes, synd
 
 
 class SondeError(RuntimeError):
@@ -226,6 +241,13 @@ class Engine:
         """True if the device-side frame queue overflowed since the last call (oldest frames overwritten before a fetch read them);
         the fetch_* methods return what they could read either way"""
         return bool(_chk(lib().sonde_engine_overflowed(self._h)))
+
+    def host_ecc_frames(self) -> int:
+        """RS41 frames whose Reed-Solomon decoder ran on the host so far (whole frames are decoded in k_framesync; include/sonde_hip.h)"""
+        return int(lib().sonde_engine_host_ecc_frames(self._h))
+
+    def set_device_ecc(self, on: bool):
+        _chk(lib().sonde_engine_set_device_ecc(self._h, 1 if on else 0))
 
     def fetch_frames(self, max_frames: int | None = None, with_soft: bool = False, finish: bool = False):
         """Frames completed so far; finish=True = end of input (also emits the frame in progress, like the reference at EOF)."""
