@@ -330,7 +330,7 @@ def bench_demod(args, D: Dist):
         step()
     eng.fetch_frames_np(lag=0)
     kern = {}
-    for k in ("mix_decimate", "if_chain", "header_corr", "framesync"):
+    for k in ("mix_decimate", "if_chain", "header_corr", "framesync", "rs_ecc"):
         ms, n = eng.kernel_ms(k)
         kern[k] = dict(ms_per_step=round(ms * n / nprof, 4), launches_per_step=n / nprof)
     eng.profile(0)
@@ -483,8 +483,10 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="demod: skip the scan_wide / fsk_mixed objects")
     ap.add_argument("--no-verify", action="store_true", help="demod: skip the oracle check of every channel's last frame")
     ap.add_argument("--lag", type=int, default=1, help="demod: 1 = frame fetch one step behind (default), 0 = every step waits for its own frames")
-    ap.add_argument("--two-streams", action="store_true", help="demod, with --lag 1: IF-rate kernels on a second HIP stream")
+    ap.add_argument("--two-streams", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--one-stream", action="store_true", help="demod: decimator and IF-rate kernels on ONE in-order stream (the round-3 default; the A/B switch)")
     args = ap.parse_args()
+    args.two_streams = not args.one_stream
     D = Dist()
     if args.config == "demod":
         out = bench_demod(args, D)

@@ -143,7 +143,8 @@ struct CorrArgs {
 
 struct FrameRec {
     int32_t channel, len, nbytes; uint32_t mv_pos; float mv;
-    int32_t ecc, ecc_done;    // ecc_done != 0: rs41_ecc() ran on the device (k_framesync), ecc = its value and frame[] what it leaves in gpx->frame
+    int32_t ecc, ecc_done;    // ecc_done 1: rs41_ecc() is done on the device (ecc = its value, frame[] what it leaves in gpx->frame); 2: on the work list of
+                              // k_rs41_ecc_frames, not decoded yet; 0: syndromes only, the host decodes
     uint8_t synd[48];
     uint8_t frame[520];
 };
@@ -159,6 +160,7 @@ struct SyncArgs {
     float sps, thres, l_win;
     int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
     int ecc_level;            // rs41: 1 / 2 = rs41_ecc() of whole frames on the device (--ecc / --ecc2); 0 = first-pass syndromes only
+    uint32_t *ecc_list; unsigned *ecc_count;       // work list of k_rs41_ecc_frames (record slots), nullptr = none (damaged frames are decoded by the host)
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
     int eof_ch;               // with eof: only this channel (-1 = all)
     const uint32_t *epoch;    // per-channel stream start, nullptr = 0

@@ -36,7 +36,10 @@ struct sonde_engine {
     hipStream_t stream_b = nullptr;    // B: IF chain, header correlation, framesync (may overlap the next call's A work)
     unsigned long long *d_wfprof = nullptr;        // SONDE_WF_PROF
     hipStream_t stream_c = nullptr;    // C: record copies of a lagged fetch (on B they would queue behind the call that is still running)
-    hipEvent_t ev_a[4] = {}, ev_b[4] = {};
+    hipStream_t stream_e = nullptr;    // E: k_rs41_ecc_frames + the frame-counter publish of a call, beside the next call's decimator (RS41 engines with ECC)
+    hipEvent_t ev_s = nullptr;         // B -> E hand-over
+    uint32_t *d_ecc_list = nullptr; unsigned *d_ecc_cnt = nullptr;     // two work lists of max_frames record slots, alternating per call; {count[2], done[2]}
+    hipEvent_t ev_a[4] = {}, ev_b[4] = {}, ev_if[4] = {};      // per call: decimator done (A), records complete (B / E), y ring read (B: IF chain done)
     unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
     unsigned *h_count_dev = nullptr;   // the same words as the device addresses them (k_publish_u32 writes them)
     FrameRec *h_recs = nullptr;        // pinned staging for record fetches
@@ -92,6 +95,7 @@ struct sonde_engine {
     std::vector<uint8_t> last_frame;
     std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
+    bool in_call = false, ecc_listed = false;   // inside sonde_engine_process_device; a frame sync of this call was given a work list
     bool dev_ecc = true;               // rs41_ecc() of whole frames in k_framesync (SONDE_HOST_ECC=1: on the host from the device syndromes, the A/B switch)
     long long host_ecc_frames = 0;     // frames whose RS decoder ran on the host (fetch_rs41)
     bool m10_chk3 = false;                         // m10mod --chk3 (sonde_engine_set_m10_chk3)
@@ -136,6 +140,7 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
         count = e->h_count[target & 3];
     } else {
         if (hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        if (e->stream_e && hipStreamSynchronize(e->stream_e) != hipSuccess) return SONDE_E_NOGPU;
         if (e->call > 0 && !e->eof_pending) count = e->h_count[(e->call - 1) & 3];       // snapshot taken by the last process call
         else if (hipMemcpy(&count, e->d_fcount, sizeof count, hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
         e->eof_pending = false;
@@ -187,6 +192,8 @@ const char *sonde_strerror(int code) {
     }
 }
 
+extern "C" void sonde_launch_rs41_ecc_frames(FrameRec *frames, const uint32_t *list, unsigned *count, unsigned *done, int max_frames, int level,
+                                             const uint8_t *gf_exp, const uint8_t *gf_log, int grid, hipStream_t s);
 extern "C" void sonde_launch_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int n, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                             const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
 
@@ -515,7 +522,20 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     }
     else e->stream_b = e->stream;              // one in-order stream: no cross-stream events needed
     HIPCHK(hipStreamCreateWithFlags(&e->stream_c, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); }
+    if (cfg->sonde_type == SONDE_RS41 && cfg->ecc_level >= 1 && cfg->ecc_level <= 2 && getenv("SONDE_ECC_INLINE") == nullptr) {
+        // the Reed-Solomon decoder of a call's damaged frames runs on a stream of its own (highest priority: a few hundred four-wave workgroups that
+        // should take the next free slot) so that it overlaps the next call's decimator; SONDE_ECC_INLINE=1 keeps it on stream B (A/B aid)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) HIPCHK(hipStreamCreateWithPriority(&e->stream_e, hipStreamNonBlocking, hi));
+        else HIPCHK(hipStreamCreateWithFlags(&e->stream_e, hipStreamNonBlocking));
+    }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_s, hipEventDisableTiming));
+    if (cfg->sonde_type == SONDE_RS41) {
+        HIPCHK(hipMalloc((void **)&e->d_ecc_list, 2 * (size_t)e->max_frames * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&e->d_ecc_cnt, 4 * sizeof(unsigned)));
+        HIPCHK(hipMemset(e->d_ecc_cnt, 0, 4 * sizeof(unsigned)));
+    }
+    for (int i = 0; i < 4; i++) { HIPCHK(hipEventCreateWithFlags(&e->ev_a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_b[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->ev_if[i], hipEventDisableTiming)); }
     HIPCHK(hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming));
     HIPCHK(hipHostMalloc((void **)&e->h_count, 4 * sizeof(unsigned), hipHostMallocMapped));
     memset(e->h_count, 0, 4 * sizeof(unsigned));
@@ -529,6 +549,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (!e) return;
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_b) hipStreamSynchronize(e->stream_b);
+    if (e->stream_e) hipStreamSynchronize(e->stream_e);
     prof_collect(e);
     if (e->d_wfprof) {
         unsigned long long h[32] = {0};
@@ -551,7 +572,10 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     { hipStream_t sa = e->stream; if (sa) hipStreamDestroy(sa); }
     if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
     if (e->stream_c) hipStreamDestroy(e->stream_c);
-    for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); }
+    if (e->stream_e) hipStreamDestroy(e->stream_e);
+    if (e->ev_s) hipEventDestroy(e->ev_s);
+    hipFree(e->d_ecc_list); hipFree(e->d_ecc_cnt);
+    for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); if (e->ev_if[i]) hipEventDestroy(e->ev_if[i]); }
     if (e->ev_copy) hipEventDestroy(e->ev_copy);
     if (e->h_pending) hipHostFree(e->h_pending);
     if (e->h_count) hipHostFree(e->h_count);
@@ -596,9 +620,14 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     }
     const uint32_t m_first = e->m_out;
     int done = 0;
-    // two streams: this call's decimator overwrites the part of the y ring that call-2 occupied (ring_len >= 2 * max_if + history),
-    // so it must not start before the IF-rate kernels of call-2 have read it; one call of overlap remains
-    if (e->stream_b != e->stream && e->call >= 2) hipStreamWaitEvent(e->stream, e->ev_b[(e->call - 2) & 3], 0);
+    e->in_call = true; e->ecc_listed = false;
+    // this call's frame syncs append to the work list call-2 used: its decoder kernel (stream E) must be through
+    if (e->stream_e && e->call >= 2) hipStreamWaitEvent(e->stream_b, e->ev_b[(e->call - 2) & 3], 0);
+    // two streams: this call's decimator overwrites the part of the y ring that call-2 occupied (ring_len >= 2 * max_if + history), so it must
+    // not start before the IF chain of call-2 has read it.  Only the IF chain reads y: the header search and the frame sync behind it work on
+    // rings stream B writes itself, so however late they run (they wait for CU slots the decimator frees) the decimators stay back to back.
+    static const bool wait_tail = getenv("SONDE_A_WAITS_TAIL") != nullptr;       // A/B aid: the round-3 dependency on the whole tail of call-2
+    if (e->stream_b != e->stream && e->call >= 2) hipStreamWaitEvent(e->stream, wait_tail ? e->ev_b[(e->call - 2) & 3] : e->ev_if[(e->call - 2) & 3], 0);
     if (e->cfg.input == SONDE_IN_AUDIO) {
         // f32read_sample (demod_mod.c:379-405): b/128/256 of the selected channel; then FM low-pass / bufs
         AudioConvArgs c0{}; c0.pcm = (const int16_t *)d_iq; c0.ch_stride = ch_stride; c0.n_ch = C; c0.n = n_samples;
@@ -742,8 +771,10 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
             HIPCHK(hipStreamSynchronize(sb));
             if (*e->h_pending == 0) break;
         }
+        if (e->stream_b != e->stream) hipEventRecord(e->ev_if[slot], e->stream_b);
     } else {
         if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
+        if (e->stream_b != e->stream) hipEventRecord(e->ev_if[slot], e->stream_b);
         if (!fe && e->d_win) {
             // header search with the reference's own transform: rounds of plan -> evaluate -> sync; the sync stops where the planned
             // windows end and the next round plans from the state it left.  First round: the two windows a received sonde needs.
@@ -768,10 +799,21 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
             launch_framesync(e, 0);
         }
     }
-    sonde_launch_publish_u32(e->d_fcount, e->h_count_dev + slot, e->stream_b);
     if (e->d_summary && e->d_summary_snap)
         hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
-    hipEventRecord(e->ev_b[slot], e->stream_b);
+    // the call's records are complete (ev_b) once its damaged frames are decoded and the counter is published
+    hipStream_t se = e->stream_b;
+    if (e->ecc_listed) {
+        if (e->stream_e) { hipEventRecord(e->ev_s, e->stream_b); hipStreamWaitEvent(e->stream_e, e->ev_s, 0); se = e->stream_e; }
+        const int par = (int)(e->call & 1);
+        prof_begin(e, "rs_ecc", se);
+        sonde_launch_rs41_ecc_frames(e->d_frames, e->d_ecc_list + (size_t)par * e->max_frames, e->d_ecc_cnt + par, e->d_ecc_cnt + 2 + par, e->max_frames,
+                                     e->cfg.ecc_level, e->d_consts + 136, e->d_consts + 648, std::min(512, std::max(1, C)), se);
+        prof_end(e, se);
+    }
+    sonde_launch_publish_u32(e->d_fcount, e->h_count_dev + slot, se);
+    hipEventRecord(e->ev_b[slot], se);
+    e->in_call = false;
     e->call += 1;
     if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
     return 0;
@@ -802,6 +844,8 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
     s.eof = eof; s.eof_ch = e->eof_ch; s.epoch = e->d_epoch; s.rs41 = (e->cfg.sonde_type == SONDE_RS41); s.ecc_level = (s.rs41 && e->dev_ecc && e->cfg.ecc_level >= 1 && e->cfg.ecc_level <= 2) ? e->cfg.ecc_level : 0;
+    // damaged frames of a process call go on that call's work list (k_rs41_ecc_frames at the end of the call); end-of-stream launches have none
+    if (s.ecc_level && !eof && e->in_call && e->d_ecc_list) { s.ecc_list = e->d_ecc_list + (size_t)(e->call & 1) * e->max_frames; s.ecc_count = e->d_ecc_cnt + (e->call & 1); e->ecc_listed = true; }
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft; s.soft1 = e->d_soft1;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
@@ -843,6 +887,7 @@ int sonde_engine_sync(sonde_engine_t *e) {
     if (!e) return SONDE_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
+    if (e->stream_e) HIPCHK(hipStreamSynchronize(e->stream_e));
     prof_collect(e);
     return 0;
 }
@@ -864,7 +909,7 @@ static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int la
             if (e->cfg.ecc_level > 0) {
                 bool clean = true;
                 for (int k = 0; k < 48; k++) clean &= (r.synd[k] == 0);
-                if (r.ecc_done) f.ecc = r.ecc;                       // rs41_ecc() ran in k_framesync: corrected bytes, zero tail, its return value
+                if (r.ecc_done == 1) f.ecc = r.ecc;                  // rs41_ecc() is done on the device: corrected bytes, zero tail, its return value
                 else if (clean) { for (int k = f.len; k < 518; k++) f.frame[k] = 0; }
                 else { f.ecc = rs41_ecc(f.frame, f.len, e->cfg.ecc_level, r.synd); e->host_ecc_frames++; }
             }
@@ -1082,6 +1127,7 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
     if (base && (e->cfg.bits == 32 || e->cfg.opt_nolut || e->lut_len <= 0 || e->lut_len % e->info.decM)) return SONDE_E_ARG;   // int16 / uint8 input through the mixer table only
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
+    if (e->stream_e) HIPCHK(hipStreamSynchronize(e->stream_e));
     const int C = e->cfg.n_channels;
     if (base) {
         // the channel's own sample clock starts here: mixer table phase 0, IQ-DC mean 0 with the first (shortest) segment, empty decimator history
@@ -1168,6 +1214,7 @@ int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64
     if (!e || !out || channel < 0 || channel >= e->cfg.n_channels || count < 0 || count > e->ring_len || first < 0) return SONDE_E_ARG;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
+    if (e->stream_e) HIPCHK(hipStreamSynchronize(e->stream_e));
     prof_collect(e);
     const void *base; size_t esz;
     switch (tap) {
@@ -1192,14 +1239,14 @@ int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64
 
 int sonde_engine_profile(sonde_engine_t *e, int enable) {
     if (!e) return SONDE_E_ARG;
-    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); prof_collect(e);
+    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); if (e->stream_e) (void)hipStreamSynchronize(e->stream_e); prof_collect(e);
     e->prof = enable != 0; e->prof_level = enable == 1 ? 1 : 2; e->stats.clear();    // 1: dominant kernel only (2 events per launch), 2: every kernel
     return 0;
 }
 
 int sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches) {
     if (!e || !kernel) return SONDE_E_ARG;
-    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); prof_collect(e);
+    (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); if (e->stream_e) (void)hipStreamSynchronize(e->stream_e); prof_collect(e);
     auto it = e->stats.find(kernel);
     if (it == e->stats.end() || it->second.n == 0) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return 0; }
     if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;

@@ -1410,9 +1410,6 @@ void k_framesync(const SyncArgs a) {
     __shared__ unsigned s_slot;
     __shared__ uint8_t s_syn[FS_WAVES][48];
     __shared__ uint8_t s_S[48];                // first-pass syndromes of the frame in hand
-    __shared__ uint8_t s_cw[2][256];           // device ECC (sonde_rs_dev.h): the two codewords, per-wave scratch, results
-    __shared__ uint8_t s_scr[2][64];
-    __shared__ int s_res[4];
     __shared__ double s_rd[FS_WAVES];
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= a.n_ch) return;
@@ -1619,19 +1616,14 @@ void k_framesync(const SyncArgs a) {
             // frame length from the type byte (rs41mod.c:407-415,2488-2490)
             int ft = 0; { const uint8_t b = s_frame[0x38]; for (int q = 0; q < 4; q++) ft += ((b >> q) & 1) - ((b >> (q + 4)) & 1); }
             const int flen = (ft >= 0) ? 320 : 518;
-            // RS(255,231), two interleaved codewords (rs41mod.c:1729-1732).  Whole frames of an engine with --ecc / --ecc2: rs41_ecc() right
-            // here — syndromes by all 16 waves, the Euclid / Chien / Forney decoder on waves 0 and 1 when they are not zero, the 2nd pass with
-            // the known block ids (sonde_rs_dev.h); the host only formats.  Otherwise (no ECC asked for, or a frame cut short by the end of the
-            // stream, whose missing bytes the host fills from the previous frame, rs41mod.c:2479-2490): first-pass syndromes only.
-            int ecc_ret = 0, ecc_done = 0;
-            if (a.rs41 && a.ecc_level > 0 && 8 + nbytes_ok >= 518) {
-                if (tid >= flen && tid < 518) s_frame[tid] = 0;
-                __syncthreads();
-                const RsGf gf{s_exp, s_log};
-                ecc_ret = rs41_ecc_wg(s_frame, a.ecc_level, s_cw, s_syn, s_res, s_scr, s_S, gf, tid);
-                ecc_done = 1;
-            } else if (a.rs41) {
-                // wave c evaluates coefficients 16c..16c+15 by Horner and scales by alpha^(16 c j); XOR over the waves
+            // RS(255,231) syndromes S_j = cw(alpha^j), j = 0..23, two interleaved codewords (rs41mod.c:1729-1732): wave c evaluates coefficients
+            // 16c..16c+15 by Horner and scales by alpha^(16 c j); XOR over the waves.  Bytes from flen on count as zero (:1727).
+            // Whole frames of an engine with --ecc / --ecc2: a clean frame is final here (tail zeroed like rs41_ecc leaves it); a damaged one goes on
+            // the work list of k_rs41_ecc_frames (Euclid / Chien / Forney on a wavefront per codeword, 2nd pass; sonde_rs_dev.h), which runs on its
+            // own stream beside the next call's decimator.  Without a list (end-of-stream launches, a frame cut short whose missing bytes the host
+            // fills from the previous frame, rs41mod.c:2479-2490) the record carries the syndromes and the host decodes it when it is fetched.
+            int ecc_done = 0;
+            if (a.rs41) {
                 if (lane < 48) {
                     const int cw = lane / 24, jx = lane % 24;
                     const uint8_t x = s_exp[jx];
@@ -1651,13 +1643,20 @@ void k_framesync(const SyncArgs a) {
                 }
                 __syncthreads();
                 if (tid < 48) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][tid]; s_S[tid] = syn; }
+                __syncthreads();
+                if (a.ecc_level > 0 && 8 + nbytes_ok >= 518) {
+                    bool clean = true;
+                    for (int k = 0; k < 48; k++) clean &= (s_S[k] == 0);
+                    if (clean) { ecc_done = 1; if (tid >= flen && tid < 518) s_frame[tid] = 0; }
+                    else if (a.ecc_list) { ecc_done = 2; if (tid == 0) a.ecc_list[atomicAdd(a.ecc_count, 1u) % (unsigned)a.max_frames] = slot; }
+                }
             }
             __syncthreads();
             if (tid < 518) rec->frame[tid] = s_frame[tid];
             if (a.rs41 && tid < 48) rec->synd[tid] = s_S[tid];
             if (tid == 0) {
                 rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok;
-                rec->ecc = ecc_ret; rec->ecc_done = ecc_done;
+                rec->ecc = 0; rec->ecc_done = ecc_done;
             }
             if (a.summary && tid == 0) {                              // per-channel detection summary, stays on the device
                 bool clean = a.rs41 != 0;
@@ -2031,26 +2030,74 @@ extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s)
     int grid = a->W * a->n_ch; if (grid > 512) grid = 512;      // two waves of workgroups on 256 CUs at most; the kernel strides over the list
     hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(WF_THREADS), lds, s, *a);
 }
-// rs41_ecc() over a batch of de-whitened 518-byte frames, one workgroup per frame: the decoder of k_framesync on frames that come from
-// somewhere else (tests: word-by-word parity with the compiled reference; callers with frames from --softin or a file)
-__global__ __launch_bounds__(FS_THREADS)
-void k_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int level, int32_t *ecc, int32_t *codes, uint8_t *synd, const uint8_t *gf_exp, const uint8_t *gf_log) {
-    __shared__ uint8_t s_frame[520], s_exp[512], s_log[256], s_cw[2][256], s_part[FS_WAVES][48], s_scr[2][64], s_S[48];
-    __shared__ int s_res[4];
-    const int tid = threadIdx.x, f = blockIdx.x;
-    if (tid < 512) s_exp[tid] = gf_exp[tid];
-    if (tid < 256) s_log[tid] = gf_log[tid];
-    if (tid < 518) s_frame[tid] = tid < flen[f] ? frames[(size_t)f * 518 + tid] : 0;      // rs41mod.c:1727
+// rs41_ecc() of the frames k_framesync put on its work list (records with ecc_done == 2): one workgroup of four waves per frame — small enough
+// to take the place of ONE decimator workgroup (51 KB of LDS, a wave per SIMD), so that on its own stream it runs in the slots the next call's
+// decimator frees instead of waiting for a whole CU.  Waves 0 / 1 decode a codeword each from the first-pass syndromes in the record; a 2nd
+// pass (--ecc2) recomputes them with all four waves.  The list counter is reset by the last workgroup to finish.
+#define RSK_THREADS 256
+struct RsEccLds { uint8_t frame[520], exp[512], log[256], cw[2][256], part[RSK_THREADS / 64][48], scr[2][64], S[48]; int res[4]; };
+__device__ __forceinline__ void rs_ecc_tables(RsEccLds &L, const uint8_t *gf_exp, const uint8_t *gf_log, int tid) {
+    for (int i = tid; i < 512; i += RSK_THREADS) L.exp[i] = gf_exp[i];
+    if (tid < 256) L.log[tid] = gf_log[tid];
+}
+__global__ __launch_bounds__(RSK_THREADS)
+void k_rs41_ecc_frames(FrameRec *frames, const uint32_t *list, unsigned *count, unsigned *done, int max_frames, int level,
+                       const uint8_t *gf_exp, const uint8_t *gf_log) {
+    __shared__ RsEccLds L;
+    __shared__ unsigned s_last;
+    const int tid = threadIdx.x;
+    const unsigned n = min(*count, (unsigned)max_frames);
+    if (n) rs_ecc_tables(L, gf_exp, gf_log, tid);
+    for (unsigned w = blockIdx.x; w < n; w += gridDim.x) {
+        FrameRec *rec = frames + list[w];
+        __syncthreads();
+        if (rec->ecc_done != 2) continue;                                  // (uniform: every thread reads the same word)
+        const int flen = rec->len;
+        for (int i = tid; i < 518; i += RSK_THREADS) L.frame[i] = i < flen ? rec->frame[i] : 0;      // rs41mod.c:1727
+        if (tid < 48) L.S[tid] = rec->synd[tid];
+        __syncthreads();
+        const RsGf gf{L.exp, L.log};
+        const int r = rs41_ecc_wg(L.frame, level, L.cw, L.part, L.res, L.scr, L.S, gf, tid, RSK_THREADS);
+        for (int i = tid; i < 518; i += RSK_THREADS) rec->frame[i] = L.frame[i];
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) { rec->ecc = r; rec->ecc_done = 1; }
+    }
+    // the last workgroup out clears the list for the call after next (two lists alternate)
     __syncthreads();
-    const RsGf gf{s_exp, s_log};
-    const int r = rs41_ecc_wg(s_frame, level, s_cw, s_part, s_res, s_scr, s_S, gf, tid);
-    if (tid < 518) frames[(size_t)f * 518 + tid] = s_frame[tid];
-    if (tid < 48) synd[(size_t)f * 48 + tid] = s_S[tid];
-    if (tid == 0) { ecc[f] = r; codes[2 * f] = s_res[0]; codes[2 * f + 1] = s_res[1]; }
+    if (tid == 0) { __threadfence(); s_last = atomicAdd(done, 1u); }
+    __syncthreads();
+    if (s_last == gridDim.x - 1 && tid == 0) { *count = 0; *done = 0; }
+}
+extern "C" void sonde_launch_rs41_ecc_frames(FrameRec *frames, const uint32_t *list, unsigned *count, unsigned *done, int max_frames, int level,
+                                             const uint8_t *gf_exp, const uint8_t *gf_log, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_rs41_ecc_frames, dim3(grid), dim3(RSK_THREADS), 0, s, frames, list, count, done, max_frames, level, gf_exp, gf_log);
+}
+
+// rs41_ecc() over a batch of de-whitened 518-byte frames, one workgroup per frame: the same workgroup function on frames that come from
+// somewhere else (tests: word-by-word parity with the compiled reference; callers with frames from --softin or a file); syndromes computed here
+__global__ __launch_bounds__(RSK_THREADS)
+void k_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int level, int32_t *ecc, int32_t *codes, uint8_t *synd, const uint8_t *gf_exp, const uint8_t *gf_log) {
+    __shared__ RsEccLds L;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    rs_ecc_tables(L, gf_exp, gf_log, tid);
+    for (int i = tid; i < 518; i += RSK_THREADS) L.frame[i] = i < flen[f] ? frames[(size_t)f * 518 + i] : 0;      // rs41mod.c:1727
+    __syncthreads();
+    const RsGf gf{L.exp, L.log};
+    // first-pass syndromes for the caller, then the decoder as k_rs41_ecc_frames runs it (syndromes handed in)
+    for (int i = tid; i < 510; i += RSK_THREADS) { const int c = i / 255, n = i % 255; L.cw[c][n] = n < 24 ? L.frame[8 + 24 * c + n] : L.frame[56 + 2 * (n - 24) + c]; }
+    __syncthreads();
+    rs41_syndrome_partials(L.cw, L.part, gf, tid & 63, tid >> 6, RSK_THREADS / 64);
+    __syncthreads();
+    if (tid < 48) { uint8_t sy = 0; for (int w = 0; w < RSK_THREADS / 64; w++) sy ^= L.part[w][tid]; L.S[tid] = sy; synd[(size_t)f * 48 + tid] = sy; }
+    __syncthreads();
+    const int r = rs41_ecc_wg(L.frame, level, L.cw, L.part, L.res, L.scr, (f & 1) ? L.S : (const uint8_t *)nullptr, gf, tid, RSK_THREADS);
+    for (int i = tid; i < 518; i += RSK_THREADS) frames[(size_t)f * 518 + i] = L.frame[i];
+    if (tid == 0) { ecc[f] = r; codes[2 * f] = L.res[0]; codes[2 * f + 1] = L.res[1]; }
 }
 extern "C" void sonde_launch_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int n, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                             const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s) {
-    hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(n), dim3(FS_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log);
+    hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(n), dim3(RSK_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log);
 }
 
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {

@@ -1,11 +1,11 @@
 // sonde_rs_dev.h — RS(255,231) on the device: the errors-only decoder on ONE wavefront (a polynomial coefficient per lane) and the
-// two passes of rs41_ecc() on the frame-sync workgroup.  Behaviour reproduced (not code): bch_ecc_mod.c rs_decode_ErrEra :877-960 with
+// two passes of rs41_ecc() on a workgroup of four wavefronts (k_rs41_ecc_frames).  Behaviour reproduced (not code): bch_ecc_mod.c rs_decode_ErrEra :877-960 with
 // nera = 0 (polyGF_lfsr :547-578, poly_divmod :410-454, poly_mul :469-490, Chien loop :926-940, forney :596-612) and rs41mod.c
 // rs41_ecc :1703-1769, :1955-1974.  The key equation is solved by the same extended Euclid on (S, x^24) with the same stop rule and the
 // same acceptance tests, so a word the reference cannot repair fails here with the same code, and a word it miscorrects is miscorrected
 // into the same bytes.
 //
-// The file is compiled twice: by hipcc into k_framesync (sonde_kernels.hip), and by g++ under tests/emu/wave_emu.h, which runs every
+// The file is compiled twice: by hipcc into k_rs41_ecc_frames / k_rs41_ecc_batch (sonde_kernels.hip), and by g++ under tests/emu/wave_emu.h, which runs every
 // thread of a workgroup as a fiber and turns the cross-lane operations below into rendezvous points (tests/test_rs_dev_emu.py: the
 // device code against the compiled reference without a GPU).  Control flow around every rsw_* call is wave-uniform.
 #ifndef SONDE_RS_DEV_H
@@ -102,40 +102,41 @@ static RSW_DEV int rs255_wave_decode(uint8_t *cw, int syn, uint8_t *scr, const R
     return nroots;
 }
 
-// Horner partial sums of the 48 syndromes of both codewords: wave c of `nwaves` (16) covers coefficients 16c .. 16c+15 and scales by
-// alpha^(16 c j); the XOR over the waves is S_j = cw(alpha^j), j < 24 (syndromes :638, rs41mod.c:1729-1732).  All threads call it.
-static RSW_DEV void rs41_syndrome_partials(const uint8_t (*cw)[256], uint8_t (*part)[48], const RsGf g, int lane, int wave) {
+// Horner partial sums of the 48 syndromes of both codewords by a workgroup of nw waves (nw divides 256): wave c covers the 256 / nw
+// coefficients from (256 / nw) c on and scales by alpha^(j c 256 / nw); the XOR over the waves is S_j = cw(alpha^j), j < 24 (syndromes :638,
+// rs41mod.c:1729-1732).  All threads call it.
+static RSW_DEV void rs41_syndrome_partials(const uint8_t (*cw)[256], uint8_t (*part)[48], const RsGf g, int lane, int wave, int nw) {
     if (lane < 48) {
-        const int c = lane / 24, jx = lane % 24;
+        const int c = lane / 24, jx = lane % 24, ch = 256 / nw;
         int h = 0;
-        for (int i = 15; i >= 0; i--) {
-            const int n = 16 * wave + i;
+        for (int i = ch - 1; i >= 0; i--) {
+            const int n = ch * wave + i;
             h = rs_gf_mul_l(g, h, jx) ^ (n < 255 ? cw[c][n] : 0);     // x = alpha^jx, log x = jx
         }
-        part[wave][lane] = (uint8_t)(h ? g.exp[(g.log[h] + (jx * 16 * wave) % 255) % 255] : 0);
+        part[wave][lane] = (uint8_t)(h ? g.exp[(g.log[h] + (jx * ch * wave) % 255) % 255] : 0);
     }
 }
 
-// rs41_ecc() for ecc levels 1 / 2 on a full frame, by the 1024 threads of the frame-sync workgroup.  frame = 518 bytes in LDS, de-whitened,
-// bytes from flen on are zero already (rs41mod.c:1727); cw = [2][256], part = [16][48], res = int[4], scr = [2][64]: LDS scratch.
-// On return frame holds the bytes rs41_ecc leaves in gpx->frame, synd_out (48 bytes, global or LDS, written by threads 0..47) the syndromes
-// of the first pass.  Returns rs41_ecc's value: corrected symbols of both codewords, or -1 / -2 / -3 = codeword 1 / 2 / both failed.
+// rs41_ecc() for ecc levels 1 / 2 on a full frame, by a workgroup of nt threads (nt / 64 divides 256; the product uses 256).
+// frame = 518 bytes in LDS, de-whitened, bytes from flen on zero already (rs41mod.c:1727); cw = [2][256], part = [nt / 64][48], res = int[4],
+// scr = [2][64]: LDS scratch.  synd_in = the 48 first-pass syndromes when the caller has them (k_framesync computes them for every frame), else
+// nullptr: computed here.  On return frame holds the bytes rs41_ecc leaves in gpx->frame and res[0..1] the two rs_decode values of the last
+// pass.  Returns rs41_ecc's value: corrected symbols of both codewords, or -1 / -2 / -3 = codeword 1 / 2 / both failed.
 static RSW_DEV int rs41_ecc_wg(uint8_t *frame, int level, uint8_t (*cw)[256], uint8_t (*part)[48], int *res, uint8_t (*scr)[64],
-                               uint8_t *synd_out, const RsGf g, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    if (tid < 510) {                                                  // two interleaved codewords: 24 parity bytes each, then the message (:1730-1733)
-        const int c = tid / 255, n = tid % 255;
+                               const uint8_t *synd_in, const RsGf g, int tid, int nt) {
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int i = tid; i < 510; i += nt) {                             // two interleaved codewords: 24 parity bytes each, then the message (:1730-1733)
+        const int c = i / 255, n = i % 255;
         cw[c][n] = n < 24 ? frame[8 + 24 * c + n] : frame[56 + 2 * (n - 24) + c];
     }
     if (tid < 4) res[tid] = 0;
     rsw_syncthreads();
     for (int pass = 0; pass < 2; pass++) {
-        rs41_syndrome_partials(cw, part, g, lane, wave);
-        rsw_syncthreads();
+        const bool given = pass == 0 && synd_in != nullptr;
+        if (!given) { rs41_syndrome_partials(cw, part, g, lane, wave, nw); rsw_syncthreads(); }
         if (wave < 2) {
             int s = 0;
-            if (lane < 24) for (int w = 0; w < 16; w++) s ^= part[w][24 * wave + lane];
-            if (pass == 0 && lane < 24) synd_out[24 * wave + lane] = (uint8_t)s;
+            if (lane < 24) { if (given) s = synd_in[24 * wave + lane]; else for (int w = 0; w < nw; w++) s ^= part[w][24 * wave + lane]; }
             const int e = rs255_wave_decode(cw[wave], s, scr[wave], g, lane);
             if (lane == 0) res[wave] = e;
         }
@@ -144,16 +145,17 @@ static RSW_DEV int rs41_ecc_wg(uint8_t *frame, int level, uint8_t (*cw)[256], ui
         // 2nd pass (:1739-1769): the block ids every RS41 frame has, and the zero tail; message bytes re-read from the frame, parity as the
         // first pass left it
         int ft = 0; { const int b = frame[0x38]; for (int q = 0; q < 4; q++) ft += ((b >> q) & 1) - ((b >> (q + 4)) & 1); }
-        if (tid < 518) {
-            int v = frame[tid];
-            if (ft < -2) { if (tid >= 320 + 7 && tid < 518 - 2) v = 0; }
+        rsw_syncthreads();
+        for (int i = tid; i < 518; i += nt) {
+            int v = frame[i];
+            if (ft < -2) { if (i >= 320 + 7 && i < 518 - 2) v = 0; }
             else {
-                if (tid >= 320) v = 0;
-                if (tid >= 0x12D && tid < 318) v = 0;
-                if (tid == 0x12B) v = 0x76; if (tid == 0x12C) v = 0x11;
-                if (tid == 318) v = 0xEC; if (tid == 319) v = 0xC7;
+                if (i >= 320) v = 0;
+                if (i >= 0x12D && i < 318) v = 0;
+                if (i == 0x12B) v = 0x76; if (i == 0x12C) v = 0x11;
+                if (i == 318) v = 0xEC; if (i == 319) v = 0xC7;
             }
-            switch (tid) {
+            switch (i) {
                 case 0x039: v = 0x79; break; case 0x03A: v = 0x28; break;
                 case 0x065: v = 0x7A; break; case 0x066: v = 0x2A; break;
                 case 0x093: v = 0x7C; break; case 0x094: v = 0x1E; break;
@@ -161,14 +163,14 @@ static RSW_DEV int rs41_ecc_wg(uint8_t *frame, int level, uint8_t (*cw)[256], ui
                 case 0x112: v = 0x7B; break; case 0x113: v = 0x15; break;
                 default: break;
             }
-            frame[tid] = (uint8_t)v;
+            frame[i] = (uint8_t)v;
         }
         rsw_syncthreads();
-        if (tid < 510) { const int c = tid / 255, n = tid % 255; if (n >= 24) cw[c][n] = frame[56 + 2 * (n - 24) + c]; }
+        for (int i = tid; i < 510; i += nt) { const int c = i / 255, n = i % 255; if (n >= 24) cw[c][n] = frame[56 + 2 * (n - 24) + c]; }
         rsw_syncthreads();
     }
-    if (tid < 510) {                                                  // (:1955-1958)
-        const int c = tid / 255, n = tid % 255;
+    for (int i = tid; i < 510; i += nt) {                             // (:1955-1958)
+        const int c = i / 255, n = i % 255;
         if (n < 24) frame[8 + 24 * c + n] = cw[c][n]; else frame[56 + 2 * (n - 24) + c] = cw[c][n];
     }
     const int e1 = res[0], e2 = res[1];

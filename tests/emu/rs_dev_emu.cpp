@@ -1,6 +1,6 @@
 // rs_dev_emu.cpp — test infrastructure: the device RS(255,231) decoder (csrc/sonde_rs_dev.h) compiled for the CPU under wave_emu.h.
 //   emu_rs255_decode(cw[255])                      one wave, as k_framesync's waves 0 / 1 run it
-//   emu_rs41_ecc(frame[518], flen, level, synd[48]) the 1024-thread workgroup form
+//   emu_rs41_ecc(frame[518], flen, level, synd_in[48] | null, nthreads)  the workgroup form (the product runs 256 threads)
 #include "wave_emu.h"
 #include "../../radiosonde_auto_rx_amd/csrc/sonde_rs_dev.h"
 #include <cstring>
@@ -31,14 +31,15 @@ extern "C" int emu_rs255_decode(uint8_t *cw_io) {
     return ret;
 }
 
-extern "C" int emu_rs41_ecc(uint8_t *frame_io, int flen, int level, uint8_t *synd) {
+// synd_in: 48 first-pass syndromes (as k_framesync leaves them in the record) or nullptr = computed by the workgroup itself
+extern "C" int emu_rs41_ecc(uint8_t *frame_io, int flen, int level, const uint8_t *synd_in, int nthreads) {
     gf_init();
     const RsGf g{g_exp, g_log};
     uint8_t frame[520]; memcpy(frame, frame_io, 518);
     for (int i = flen; i < 518; i++) frame[i] = 0;
     static uint8_t cw[2][256], part[16][48], scr[2][64]; int res[4], ret = 0;
-    emu::run_workgroup(1024, [&](int tid) {
-        const int e = rs41_ecc_wg(frame, level, cw, part, res, scr, synd, g, tid);
+    emu::run_workgroup(nthreads, [&](int tid) {
+        const int e = rs41_ecc_wg(frame, level, cw, part, res, scr, synd_in, g, tid, nthreads);
         if (tid == 0) ret = e;
     });
     memcpy(frame_io, frame, 518);

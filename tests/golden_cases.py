@@ -93,3 +93,16 @@ def load_iqdec(name):
     g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
     g["stderr"] = str(g["stderr"])
     return g
+
+
+def need_ref() -> bool:
+    """True when the compiled reference (oracle/_ref) is there.  When it is not: fail, unless SONDE_ALLOW_NO_REF=1 says the run knowingly does
+    without (then False: the caller leaves that comparison out).  Replaces silent `if have_ref():` gates inside tests."""
+    import os
+    import pytest
+    from oracle import bind
+    if bind.have_ref():
+        return True
+    if os.environ.get("SONDE_ALLOW_NO_REF") == "1":
+        return False
+    pytest.fail("oracle/_ref (compiled reference) is missing: build it where /root/reference exists (make -C oracle ref) or set SONDE_ALLOW_NO_REF=1")

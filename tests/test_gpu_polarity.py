@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import make_golden  # noqa: E402
+from golden_cases import need_ref  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -54,7 +55,7 @@ def test_engine_polarity_is_per_channel():
     assert len(by[0]) == 2 and len(by[1]) == 2
     assert [f["line"] for f in by[0]] == [f["line"] for f in by[1]]
     assert all(f["mv"] > 0 for f in by[0]) and all(f["mv"] < 0 for f in by[1])
-    if bind.have_ref():
+    if need_ref():
         for c, (cap, f0) in enumerate(((x, fq), (xm, -fq))):
             out, _, rc = bind.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "--auto", "--IQ", repr(f0), "--lpIQ", "-", str(sr), "16"], cap)
             assert rc == 0 and [l.rstrip() for l in out.splitlines()] == [f["line"].rstrip() for f in by[c]], c
@@ -70,6 +71,6 @@ def test_engine_polarity_is_per_channel():
     assert len(fi) == 2
     for a, b in zip(by[1], fi):
         assert a["mv_pos"] == b["mv_pos"] and np.array_equal(a["soft"], b["soft"])
-    if bind.have_ref():
+    if need_ref():
         out, _, rc = bind.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "-i", "--IQ", repr(-fq), "--lpIQ", "-", str(sr), "16"], xm)
         assert rc == 0 and [l.rstrip() for l in out.splitlines()] == [f["line"].rstrip() for f in fi]

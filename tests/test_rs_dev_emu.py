@@ -73,6 +73,29 @@ def test_wave_decoder_low_degree_syndromes_and_single_symbols(emu):
         assert (a == b).all(), i
 
 
+def _syndromes(frame, flen):
+    """S_j = cw(alpha^j) of both codewords with the bytes from flen on taken as zero (what k_framesync leaves in FrameRec.synd)"""
+    exp, log = np.zeros(512, np.int64), np.zeros(256, np.int64)
+    x = 1
+    for i in range(255):
+        exp[i] = x; log[x] = i
+        x <<= 1
+        if x & 0x100:
+            x ^= 0x11D
+    exp[255:510] = exp[:255]
+    f = frame.astype(np.int64).copy()
+    f[flen:] = 0
+    out = np.zeros(48, np.uint8)
+    for c in range(2):
+        cw = np.concatenate([f[8 + 24 * c:32 + 24 * c], f[56 + c:518:2]])
+        for j in range(24):
+            y = 0
+            for n in range(254, -1, -1):
+                y = (exp[log[y] + j] if y else 0) ^ int(cw[n])
+            out[24 * c + j] = y
+    return out
+
+
 def test_workgroup_rs41_ecc_matches_oracle(emu):
     from oracle import bind
     L = bind.lib()
@@ -92,9 +115,11 @@ def test_workgroup_rs41_ecc_matches_oracle(emu):
         for level in (1, 2):
             d, o = a.copy(), np.zeros(520, np.uint8)
             o[:518] = a
-            synd = np.zeros(48, np.uint8)
             flen_a = _flen(a)
-            r_dev = emu.emu_rs41_ecc(_u8(d), flen_a, level, _u8(synd))
+            # the product form: 256 threads with the first-pass syndromes handed in (k_framesync has them); every third case computes them
+            # itself, every fifth runs as 1024 threads
+            synd = _syndromes(a, flen_a)
+            r_dev = emu.emu_rs41_ecc(_u8(d), flen_a, level, _u8(synd) if trial % 3 else None, 1024 if trial % 5 == 0 else 256)
             r_ora = L.ora_rs41_ecc(_u8(o), flen_a, level)
             assert r_dev == r_ora, (trial, nerr, level, r_dev, r_ora)
             assert (d == o[:518]).all(), (trial, nerr, level)
