@@ -151,7 +151,7 @@ def bench_fsk_mixed(args, D, short=False):
             elif kind == "dfm":
                 caps.append(synth.dfm_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=10 + s))
             else:
-                caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=20 + s, baud=float(Rs)))
+                caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=20 + s, baud=float(Rs), dev_hz=Rs / 2.0))     # tones Rs apart, as fsk_demod's estimator assumes
         L = min(len(c) for c in caps)
         X = torch.from_numpy(np.stack([caps[c % 4][:L] for c in range(n)])).to(D.dev)
         md = FskModem(Fs, Rs, n_channels=n, P=P, nsym=nsym, mask=mask, lower=-lim, upper=lim, max_chunk=Fs, device=D.local_rank)

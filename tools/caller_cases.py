@@ -15,17 +15,41 @@ from tools import synth
 ECEF = (418833319, 85974133, 473346430)          # a position the decoders accept (48.1 N 11.6 E 12300 m)
 
 
+def _iq16(x, noise_sigma, seed):
+    rng = np.random.default_rng(seed)
+    x = x + noise_sigma * (rng.standard_normal(len(x)) + 1j * rng.standard_normal(len(x)))
+    out = np.empty(2 * len(x), dtype=np.int16)
+    out[0::2] = np.clip(np.round(x.real * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.round(x.imag * 32767 * 0.9), -32768, 32767).astype(np.int16)
+    return out
+
+
+def _dfm_telemetry(sr, seed):
+    """a DFM09 that sends real telemetry (configuration cycle with its serial number, GPS packets 0..8: tools/make_golden.dfm_field_symbols),
+    as GFSK: the random payload of synth.dfm_capture never gets past dfm09mod --dist / --json"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import make_golden
+    sym = (make_golden.dfm_field_symbols(make_golden.DFM_FIELD_SCENARIOS["dfmf_09_40"]) > 0).astype(np.uint8)
+    burst = synth.gfsk_baseband(sym, sr, 2500.0, 2400.0, bt=0.5)
+    x = np.zeros(len(burst) + sr // 5, np.complex128)
+    x[sr // 10:sr // 10 + len(burst)] = 0.5 * burst
+    return _iq16(x, 0.02, seed)
+
+
 def capture(name):
     if name == "rs41":
         return synth.rs41_capture(sr=48000, seconds=5.3, fq=0.0, seed=41, noise_sigma=0.02, f_offset_hz=350.0, frame_kw=dict(ecef_cm=ECEF))
     if name == "rs41_weak":
         return synth.rs41_capture(sr=48000, seconds=4.3, fq=0.0, seed=42, noise_sigma=0.12, f_offset_hz=-800.0, bit_errors=5, frame_kw=dict(ecef_cm=ECEF))
     if name == "dfm":
-        return synth.dfm_capture(sr=50000, seconds=5.0, fq=0.0, noise_sigma=0.02, seed=43)
+        return _dfm_telemetry(50000, 43)
     if name == "dfm48":
         return synth.dfm_capture(sr=48000, seconds=4.0, fq=0.0, noise_sigma=0.02, seed=44)
     if name == "m10":
-        return synth.m10_capture(sr=48080, seconds=4.0, fq=0.0, noise_sigma=0.02, seed=45, baud=9616.0)
+        return synth.m10_capture(sr=48080, seconds=5.0, fq=0.0, noise_sigma=0.02, seed=45, baud=9616.0, dev_hz=4808.0,     # tone spacing = Rs: what fsk_demod's peak estimator assumes (utils/fsk.c:478-520)
+                                 frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(900 + k)))
     if name == "m10_48":
         return synth.m10_capture(sr=48000, seconds=4.0, fq=0.0, noise_sigma=0.02, seed=46)
     if name == "noise":
