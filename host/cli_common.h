@@ -25,6 +25,7 @@ typedef struct {
     int nch;              /* channels of the WAV file */
     int lpiq_bw;          /* IF low-pass bandwidth in Hz (--lpbw kHz inside (4.6, lpbw_max)), the decoder's default otherwise */
     double lpbw_max;
+    int have_lpbw;        /* --lpbw was given with a value inside its range (the reference's set_lpIQbw > 0) */
 } cli_in_t;
 
 static inline void cli_in_init(cli_in_t *in, int lpiq_bw_default, double lpbw_max) {
@@ -54,7 +55,7 @@ static inline int cli_input_option(int argc, char **argv, int *pi, sonde_cfg_t *
     else if (!strcmp(a, "--lpbw")) {
         if (++*pi >= argc) return -1;
         const double bw = atof(argv[*pi]);
-        if (bw > 4.6 && bw < in->lpbw_max) in->lpiq_bw = (int)(bw * 1e3);
+        if (bw > 4.6 && bw < in->lpbw_max) { in->lpiq_bw = (int)(bw * 1e3); in->have_lpbw = 1; }
         cfg->opt_lp |= SONDE_LP_IQ;
     }
     else if (!strcmp(a, "--min")) cfg->opt_min = 1;

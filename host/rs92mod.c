@@ -163,7 +163,7 @@ int main(int argc, char **argv) {
     g.hdmax = 3; g.bitofs = 2 + shift;                                                                /* :1619,1957,1992 */
     g.nbits = SONDE_RS92_FRAME_BITS;
     g.l_win = 4.0f;                                                                                    /* bl = 4.0 for opt_iq > 2, whole bits else (:2026-2028) */
-    g.lpiq_bw = (in.lpiq_bw == 8000 && ngp0) ? 32000 : in.lpiq_bw; g.lpfm_bw = 6000;
+    g.lpiq_bw = (!in.have_lpbw && ngp0) ? 32000 : in.lpiq_bw; g.lpfm_bw = 6000;      /* --ngp default 32 kHz, an explicit --lpbw wins (rs92mod.c:1940-1944) */
     sonde_engine_t *eng = NULL;
     int rc = sonde_engine_create_generic(&cfg, &in.fq, &g, &eng);
     if (rc >= 0) rc = sonde_engine_set_threshold(eng, thres);

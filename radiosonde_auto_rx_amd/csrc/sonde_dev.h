@@ -160,6 +160,7 @@ struct SyncArgs {
     float sps, thres, l_win;
     int rs41;                 // RS41 byte framing + syndromes on the device; else packed hard bits + soft bits
     int ecc_level;            // rs41: 1 / 2 = rs41_ecc() of whole frames on the device (--ecc / --ecc2); 0 = first-pass syndromes only
+    int small_wg;             // 256-thread workgroups (fit the slot one decimator workgroup frees) instead of 1024
     uint32_t *ecc_list; unsigned *ecc_count;       // work list of k_rs41_ecc_frames (record slots), nullptr = none (damaged frames are decoded by the host)
     int eof;                  // end of stream: emit the frame in progress with the bits that exist
     int eof_ch;               // with eof: only this channel (-1 = all)

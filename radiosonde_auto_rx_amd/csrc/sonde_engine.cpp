@@ -849,6 +849,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft; s.soft1 = e->d_soft1;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
+    { static const bool small = getenv("SONDE_FS_SMALL") != nullptr; s.small_wg = small && !e->cfg.opt_dc; }      // A/B aid
     s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;

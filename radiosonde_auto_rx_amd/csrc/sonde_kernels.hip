@@ -1311,22 +1311,22 @@ __device__ __forceinline__ double window_sum(const float *bufs, uint32_t base, u
     return sum;
 }
 
-#define FS_THREADS 1024
-#define FS_WAVES (FS_THREADS / WAVE)
+#define FS_THREADS 1024           // default workgroup of k_framesync; FS_THREADS_SMALL = the form that fits the slot of one decimator workgroup
+#define FS_THREADS_SMALL 256
 
 // One correlation window of getCorrDFT (demod_mod.c:148-225) evaluated from the precomputed correlation ring: arg-max of
 // c^2 over the K+1 end positions p = pos-K .. pos (first maximum wins), edge rejection, L-sample norm.
 // DC (--dc, :174-188): the reference zeroes bin 0 of the zero-padded N-point transform, i.e. subtracts mu = sum(window)/N
 // from every sample including the padding; the circular correlation then drops by mu * sum(match) at every lag and
 // the norm runs over (x - mu).  Returns the peak index 0..K, or -4 (edge / empty window); mv, mpos only when >= 0.
-template <bool DC>
+template <bool DC, int NT>
 __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint32_t mask, uint32_t pos, int K, int L, int N,
                                          float match_sum, int tid, int lane, int wave, float *s_rf, int *s_ri,
                                          float &mv, uint32_t &mpos) {
     float mu = 0.f;
     if (DC) {
         float s = 0.f;
-        for (int t = tid; t < K + L; t += FS_THREADS) {
+        for (int t = tid; t < K + L; t += NT) {
             const int64_t p = (int64_t)pos - (K + L - 1) + t;
             if (p >= 0) s += x[(uint32_t)p & mask];
         }
@@ -1334,7 +1334,7 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
         if (lane == 0) s_rf[wave] = s;
         __syncthreads();
         s = 0.f;
-        for (int w = 0; w < FS_WAVES; w++) s += s_rf[w];
+        for (int w = 0; w < (NT / WAVE); w++) s += s_rf[w];
         __syncthreads();
         mu = s / (float)N;
     }
@@ -1344,7 +1344,7 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
         float cv[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int t = tid + u * FS_THREADS;
+            const int t = tid + u * NT;
             const int64_t p = (int64_t)pos - K + t;
             cv[u] = (t <= K && p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
             if (DC) cv[u] = (t <= K) ? cv[u] - off : 0.f;
@@ -1352,9 +1352,9 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const float c2 = cv[u] * cv[u];
-            if (c2 > best) { best = c2; bidx = tid + u * FS_THREADS; }
+            if (c2 > best) { best = c2; bidx = tid + u * NT; }
         }
-        for (int t = tid + 8 * FS_THREADS; t <= K; t += FS_THREADS) {      // K > 8191 only
+        for (int t = tid + 8 * NT; t <= K; t += NT) {      // K > 8191 only
             const int64_t p = (int64_t)pos - K + t;
             float c = (p >= 0) ? corr[(uint32_t)p & mask] : 0.f;
             if (DC) c -= off;
@@ -1368,7 +1368,7 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
     if (lane == 0) { s_rf[wave] = best; s_ri[wave] = bidx; }
     __syncthreads();
     best = 0.f; bidx = -1;
-    for (int w = 0; w < FS_WAVES; w++) {
+    for (int w = 0; w < (NT / WAVE); w++) {
         const float ob = s_rf[w]; const int oi = s_ri[w];
         if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
     }
@@ -1376,7 +1376,7 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
     if (bidx <= 0 || bidx == K) return -4;                         // edge value -> -4 (mv stays 0)
     mpos = pos - (uint32_t)K + (uint32_t)bidx;
     float e = 0.f;
-    for (int t = tid; t < L; t += FS_THREADS) {
+    for (int t = tid; t < L; t += NT) {
         const int64_t p = (int64_t)mpos - t;
         float v = (p >= 0) ? x[(uint32_t)p & mask] : 0.f;
         if (DC) v -= mu;
@@ -1386,7 +1386,7 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
     if (lane == 0) s_rf[wave] = e;
     __syncthreads();
     e = 0.f;
-    for (int w = 0; w < FS_WAVES; w++) e += s_rf[w];
+    for (int w = 0; w < (NT / WAVE); w++) e += s_rf[w];
     __syncthreads();
     float c = corr[mpos & mask];
     if (DC) c -= off;
@@ -1398,19 +1398,19 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
 // decisions depend only on workgroup-uniform values); the data-parallel parts — window arg-max (K+1 candidates),
 // L-sample energy, header bit check, the nbits soft bits, RS syndromes — are spread over the 1024 threads so that
 // each phase costs about one memory round trip instead of a chain of them.
-template <bool DC>
-__global__ __launch_bounds__(FS_THREADS)
+template <bool DC, int NT>
+__global__ __launch_bounds__(NT, (NT == 1024 ? 4 : 3))      // small form: at most 168 registers, a wave per SIMD
 void k_framesync(const SyncArgs a) {
     __shared__ uint8_t s_frame[520];
     __shared__ uint8_t s_exp[512];
     __shared__ uint8_t s_log[256];
-    __shared__ float s_rf[FS_WAVES];
-    __shared__ int s_ri[FS_WAVES];
+    __shared__ float s_rf[(NT / WAVE)];
+    __shared__ int s_ri[(NT / WAVE)];
     __shared__ int s_cnt[2];
     __shared__ unsigned s_slot;
-    __shared__ uint8_t s_syn[FS_WAVES][48];
+    __shared__ uint8_t s_syn[(NT / WAVE)][48];
     __shared__ uint8_t s_S[48];                // first-pass syndromes of the frame in hand
-    __shared__ double s_rd[FS_WAVES];
+    __shared__ double s_rd[(NT / WAVE)];
     const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= a.n_ch) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
@@ -1427,8 +1427,8 @@ void k_framesync(const SyncArgs a) {
     // profiling aid (SONDE_WF_PROF): thread 0 of channel 0 adds the shader-clock cycles since the previous mark to phase k
 #define FS_MARK(k) do { if (a.prof && ch == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
     unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
-    if (tid < 512) s_exp[tid] = a.gf_exp[tid];
-    if (tid < 256) s_log[tid] = a.gf_log[tid];
+    for (int i = tid; i < 512; i += NT) s_exp[i] = a.gf_exp[i];
+    for (int i = tid; i < 256; i += NT) s_log[i] = a.gf_log[i];
     __syncthreads();
     FS_MARK(0);
     // pass 1 of two: the correlation ring is valid below this end position only (corr_tile_unused with the same state and limit)
@@ -1454,7 +1454,7 @@ void k_framesync(const SyncArgs a) {
             if (pos - ep < (uint32_t)L) continue;                      // getCorrDFT returns -2 (position counted from the channel's stream start)
             float mv; uint32_t mpos;
             if (wi) { if (wi->rc < 0) continue; mv = wi->mv; mpos = wi->mpos; }
-            else if (fs_window<DC>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
+            else if (fs_window<DC, NT>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
             const uint32_t prev = st.mv_pos;
             st.mv = mv; st.mv_pos = mpos;
             if (DC) {
@@ -1464,19 +1464,19 @@ void k_framesync(const SyncArgs a) {
                 uint32_t dpos = mpos, mv2_pos = 0;
                 if (a.opt_iq >= 2 && fabsf(mv) < a.thres) {
                     float mv2; uint32_t mpos2;
-                    if (fs_window<true>(fm, a.corr2 + (size_t)ch * a.ring_len, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv2, mpos2) < 0) continue;
+                    if (fs_window<true, NT>(fm, a.corr2 + (size_t)ch * a.ring_len, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv2, mpos2) < 0) continue;
                     mv2_pos = (uint32_t)((float)mpos2 - hofs);
                     dpos = mpos2;
                     if (mv2 > a.thres || mv2 < -a.thres) { st.mv = mv2; st.mv_pos = mv2_pos; }
                 }
                 const int mp_ofs = (a.opt_iq >= 2 && mv2_pos == 0) ? (int)hofs : 0;
                 double dsum = 0.0;
-                for (int t = tid; t < L; t += FS_THREADS) dsum += (double)fm[((uint32_t)mp_ofs + dpos - (uint32_t)t) & mask];
+                for (int t = tid; t < L; t += NT) dsum += (double)fm[((uint32_t)mp_ofs + dpos - (uint32_t)t) & mask];
                 for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
                 if (lane == 0) s_rd[wave] = dsum;
                 __syncthreads();
                 dsum = 0.0;
-                for (int w = 0; w < FS_WAVES; w++) dsum += s_rd[w];
+                for (int w = 0; w < (NT / WAVE); w++) dsum += s_rd[w];
                 __syncthreads();
                 af.dc = dsum / (double)(float)L;
                 mv = st.mv; mpos = st.mv_pos;
@@ -1512,7 +1512,7 @@ void k_framesync(const SyncArgs a) {
             const int nsym = a.hdrlen / a.symhd;
             const uint32_t mvp = mpos + 1 - (uint32_t)L;
             const double hdc = (DC && a.opt_iq < 2) ? af.dc : 0.0;     // read_bufbit: bufs - dc for the FM-sliced forms (demod_mod.c:879)
-            for (int p = tid; p < nsym; p += FS_THREADS) {
+            for (int p = tid; p < nsym; p += NT) {
                 double edge = (double)((float)(p * a.symhd) * a.sps);
                 uint32_t cnt = (uint32_t)ceil(edge);
                 double sum = 0.0;
@@ -1539,7 +1539,7 @@ void k_framesync(const SyncArgs a) {
             if (lane == 0) s_ri[wave] = errs;
             __syncthreads();
             errs = 0;
-            for (int w = 0; w < FS_WAVES; w++) errs += s_ri[w];
+            for (int w = 0; w < (NT / WAVE); w++) errs += s_ri[w];
             __syncthreads();
             FS_MARK(2);
             if (errs > a.hdmax) continue;
@@ -1558,12 +1558,12 @@ void k_framesync(const SyncArgs a) {
             const int32_t q_lim = enough ? (int32_t)a.frame_samples : (int32_t)(avail - (st.mv_pos + (uint32_t)a.delay + 1));
             const uint32_t base = st.mv_pos + 1 + (uint32_t)a.bitofs;
             if (tid == 0) { s_slot = atomicAdd(a.frame_count, 1u) % (unsigned)a.max_frames; s_cnt[0] = 0; s_cnt[1] = 0; }
-            if (tid < 520) s_frame[tid] = (a.rs41 && tid < 8) ? a.hdr_bytes[tid] : 0;
+            for (int i = tid; i < 520; i += NT) s_frame[i] = (a.rs41 && i < 8) ? a.hdr_bytes[i] : 0;
             __syncthreads();
             const unsigned slot = s_slot;                              // monotonic counter, ring of records
             FrameRec *rec = a.frames + slot;
             FS_MARK(3);
-            for (int p0 = 0; p0 < a.nbits; p0 += FS_THREADS) {
+            for (int p0 = 0; p0 < a.nbits; p0 += NT) {
                 const int bp = p0 + tid;
                 double sum = 0.0;
                 bool valid = bp < a.nbits;
@@ -1628,8 +1628,9 @@ void k_framesync(const SyncArgs a) {
                     const int cw = lane / 24, jx = lane % 24;
                     const uint8_t x = s_exp[jx];
                     uint8_t hsum = 0;
-                    for (int i = 15; i >= 0; i--) {
-                        const int n = 16 * wave + i;
+                    constexpr int CH = 256 / (NT / WAVE);                  // coefficients per wave
+                    for (int i = CH - 1; i >= 0; i--) {
+                        const int n = CH * wave + i;
                         uint8_t v = 0;
                         if (n < 255) {
                             const int fi = (n >= 24) ? 56 + 2 * (n - 24) + cw : 8 + 24 * cw + n;
@@ -1638,21 +1639,21 @@ void k_framesync(const SyncArgs a) {
                         const uint8_t prod = (hsum && x) ? s_exp[s_log[hsum] + s_log[x]] : 0;
                         hsum = prod ^ v;
                     }
-                    const int sh = (jx * 16 * wave) % 255;                 // alpha^(j*16c)
+                    const int sh = (jx * CH * wave) % 255;                 // alpha^(j * CH * c)
                     s_syn[wave][lane] = hsum ? s_exp[(s_log[hsum] + sh) % 255] : 0;
                 }
                 __syncthreads();
-                if (tid < 48) { uint8_t syn = 0; for (int w = 0; w < FS_WAVES; w++) syn ^= s_syn[w][tid]; s_S[tid] = syn; }
+                if (tid < 48) { uint8_t syn = 0; for (int w = 0; w < (NT / WAVE); w++) syn ^= s_syn[w][tid]; s_S[tid] = syn; }
                 __syncthreads();
                 if (a.ecc_level > 0 && 8 + nbytes_ok >= 518) {
                     bool clean = true;
                     for (int k = 0; k < 48; k++) clean &= (s_S[k] == 0);
-                    if (clean) { ecc_done = 1; if (tid >= flen && tid < 518) s_frame[tid] = 0; }
+                    if (clean) { ecc_done = 1; for (int i = flen + tid; i < 518; i += NT) s_frame[i] = 0; }
                     else if (a.ecc_list) { ecc_done = 2; if (tid == 0) a.ecc_list[atomicAdd(a.ecc_count, 1u) % (unsigned)a.max_frames] = slot; }
                 }
             }
             __syncthreads();
-            if (tid < 518) rec->frame[tid] = s_frame[tid];
+            for (int i = tid; i < 518; i += NT) rec->frame[i] = s_frame[i];
             if (a.rs41 && tid < 48) rec->synd[tid] = s_S[tid];
             if (tid == 0) {
                 rec->channel = ch; rec->mv = st.mv; rec->mv_pos = st.mv_pos; rec->len = a.rs41 ? flen : a.nbits; rec->nbytes = a.rs41 ? 8 + nbytes_ok : nbits_ok;
@@ -2101,6 +2102,7 @@ extern "C" void sonde_launch_rs41_ecc_batch(uint8_t *frames, const int32_t *flen
 }
 
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
-    if (a->opt_dc) hipLaunchKernelGGL(k_framesync<true>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
-    else hipLaunchKernelGGL(k_framesync<false>, dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
+    if (a->opt_dc) hipLaunchKernelGGL((k_framesync<true, FS_THREADS>), dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
+    else if (a->small_wg) hipLaunchKernelGGL((k_framesync<false, FS_THREADS_SMALL>), dim3(a->n_ch), dim3(FS_THREADS_SMALL), 0, s, *a);
+    else hipLaunchKernelGGL((k_framesync<false, FS_THREADS>), dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
 }
