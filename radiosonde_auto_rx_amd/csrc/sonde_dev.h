@@ -24,6 +24,7 @@ struct MixDecArgs {
     int ring_len;
     uint32_t m0;              // IF index of the chunk's first output
     const float *wtab_g;      // D > 64: [D][8] tap table in global memory, and the piece length DS (divides D, <= 64)
+    int wtab_scaled;          // wtab_g holds a second table behind the first 64 rows: the tap rows * 2^-15 (the generated D = 50 kernels read it)
     int DS;
     int phase_f64;            // mixer phase f0*n kept in double (dft_detect.c:1090) instead of the float of demod_mod.c:1290
     double nd_base;           // --noLUT: absolute index of the launch's first sample (phase = f0 * absolute index, no table period); else 0

@@ -144,6 +144,15 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
 __device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, float2v msk, float2v (&acc)[7], float2v &dcs) {
     MD_FAST_ASM(MD_FAST_BODY_1);
 }
+// the scanner's form (MD_FAST_BODY_S): double mixer phase; navg = -32768 * the IQ-DC mean of the lane's row, taken off every sample
+__device__ __forceinline__ void md_fast_tile_s(uint32_t row_lds, const float *wt, double f0, double T, float2v navg, float2v (&acc)[7]) {
+    float2v dcs = navg;
+    asm volatile(MD_FAST_BODY_S
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
+          [a6] "+v"(acc[6]), [T] "+v"(T)
+        : [row] "v"(row_lds), [f0] "s"(f0), [dcs] "v"(dcs), [wt] "s"(wt)
+        : MD_FAST_CLOBBERS);
+}
 // y -= avg * E (complex)
 __device__ __forceinline__ float2v md_dc_correct(float2v y, float2 avg, float2 E) {
     y.x = fmaf(-avg.x, E.x, y.x); y.y = fmaf(-avg.x, E.y, y.y);
@@ -359,6 +368,110 @@ void k_mix_decimate50(const MixDecArgs a) {
     }
 }
 
+// k_mix_decimate50s: the same generated tile loop for the SCANNER's front end (scan/dft_detect.c:1085-1101 mixer table from a double phase,
+// :539-588 IQ-DC over 1/32 s windows): MD50_LOOP_S keeps the phase in double and takes the mean of the row's window off every sample (the
+// launch spans many windows: MixDecArgs.dc_seg, filled by k_dc_seg_sums / k_dc_seg_means, which also own the sums).  The P rows therefore
+// hold what the generic k_mix_decimate<7, true, 50, 0> holds, and the two can follow each other between calls (P tail).
+#define MD50S_ASM(BODY) asm volatile(BODY \
+        : [o0] "=v"(acc[0]), [o1] "=v"(acc[1]), [o2] "=v"(acc[2]), [o3] "=v"(acc[3]), [o4] "=v"(acc[4]), [o5] "=v"(acc[5]), [o6] "=v"(acc[6]), \
+          [carry] "+v"(carry), [e] "+v"(eidx), [jrow] "+v"(jrow) \
+        : [row] "v"(row_lds), [voff16] "v"(voff16), [voff8] "v"(voff8), [ldsw16] "v"(ldsw16), [ldsw8] "v"(ldsw8), [lane4] "v"(lane4), \
+          [tb] "s"(tb), [f0] "s"(f0), [wt] "s"(wt_s), [yout] "s"(yout), [jm] "s"(jm), [rmask] "s"(rmask), [P] "s"(P), \
+          [nfull] "s"(nfull), [outmask] "s"(outmask), [navg0] "v"(navg0), [dcseg] "s"(dcseg), [segoff64] "s"(segoff64), [rcpB] "s"(rcpB), [segmax] "s"(segmax) \
+        : MD50_CLOBBERS)
+__device__ __forceinline__ float2v md_seg_navg(const float2 *dcseg, int j, int off, int B, int nmax) {
+    int k = (j + off) / B; k = k < nmax ? k : nmax;
+    const float2 m = dcseg[k];
+    return (float2v){-32768.f * m.x, -32768.f * m.y};
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_mix_decimate50s(const MixDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
+    constexpr int Q_T = 7, H = 6, D = 50, TILE_DW = MD_ROWS * D;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *sRaw = smem_u + wave * (TILE_DW + 4);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(sRaw);
+    const uint32_t row_lds = lds0 + 4u * D * lane, ldsw16 = lds0 + 16u * lane, ldsw8 = lds0 + 8u * lane;
+    const uint32_t voff16 = 16u * lane, voff8 = 8u * lane, lane4 = 4u * lane;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
+    const int wg = slot % a.wgs_per_ch;
+    if (ch >= a.n_ch) return;
+    const int seg = wg * 4 + wave;
+    const int rows_per_seg = MD_ROWS * a.G - H;
+    const int jb = seg * rows_per_seg;
+    if (jb >= a.nblocks) return;
+    const int je = min(a.nblocks, jb + rows_per_seg);
+    const int jt0 = (seg == 0) ? jb : jb - H;
+    const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
+    const int nfull = min(ntiles, (a.nblocks - jt0) / MD_ROWS);
+
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const double f0 = a.chan_f0[ch];
+    float2 *yout = a.y + (size_t)ch * a.ring_len;
+    const float *wt_s = a.wtab_g + 64 * 8;                     // tap rows * 2^-15
+    const uint32_t rmask = (uint32_t)a.ring_len - 1;
+    const uint32_t P = (uint32_t)(a.lut_len / D);              // blocks per period of the mixer table
+    const float2 *dcseg = a.dc_seg + (size_t)ch * a.dc_seg_n;
+    const uint32_t segoff64 = (uint32_t)a.dc_seg_off + 64u, segmax = (uint32_t)a.dc_seg_n - 1u;
+    const float rcpB = 1.0f / (float)a.dc_seg_blocks;
+
+    // carry: what the P rows before this tile add to its first H outputs (lane l < H: sum over q of P[l-(H-q)][q], rows < 0)
+    float2v carry = {0.f, 0.f};
+    if (seg == 0 && lane < H) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int i = lane + q;
+            if (i < H) { const float2 v = a.ptail_in[((size_t)ch * 8 + i) * 8 + q]; carry += (float2v){v.x, v.y}; }
+        }
+    }
+    uint32_t eidx = (uint32_t)(((uint64_t)(a.lut_phase / D) + (uint64_t)(jt0 + lane)) % P);
+    uint32_t jrow = (uint32_t)(jt0 + lane);
+    float2v acc[Q_T];
+
+    if (nfull > 0) {
+        const uint32_t *tb = iq + (size_t)jt0 * D;
+        const uint32_t jm = a.m0 + (uint32_t)jt0;
+        const uint64_t outmask = (seg == 0) ? ~0ull : ~0ull << H;
+        const float2v navg0 = md_seg_navg(dcseg, jt0 + lane, a.dc_seg_off, a.dc_seg_blocks, (int)segmax);
+        MD50S_ASM(MD50_LOOP_S);
+        const int j = jt0 + (nfull - 1) * MD_ROWS + lane;
+        if (j >= a.nblocks - H && j < a.nblocks) {
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+    }
+    if (ntiles > nfull) {                                     // the wave's last tile sticks out of the chunk: checked loads, no staging
+        const int jt = jt0 + nfull * MD_ROWS, total_dw = a.nblocks * D;
+#pragma unroll 1
+        for (int v = 0; v < 13; v++) {
+            const int c = 64 * v + lane, off = jt * D + 4 * c;
+            u32x4_u w = {0u, 0u, 0u, 0u};
+            if (4 * c < TILE_DW && off + 4 <= total_dw) w = *reinterpret_cast<const u32x4_u *>(iq + off);
+            if (4 * c < TILE_DW) *reinterpret_cast<uint4 *>(sRaw + 4 * c) = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        const int j = jt + lane;
+        const bool outrow = j >= jb && j < je;
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
+        md_fast_tile_s(row_lds, wt_s, f0, f0 * (double)(eidx * (uint32_t)D), md_seg_navg(dcseg, j, a.dc_seg_off, a.dc_seg_blocks, (int)segmax), acc);
+        float2v y = acc[H] + carry;
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int k = H - q, src = (lane - k) & 63;
+            const float2v r = { __shfl(acc[q].x, src), __shfl(acc[q].y, src) };
+            if (lane >= k) y += r;
+        }
+        if (outrow) yout[(a.m0 + (uint32_t)j) & rmask] = make_float2(y.x, y.y);
+        if (j >= a.nblocks - H && j < a.nblocks) {
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+    }
+}
+
 template <int Q_T, bool PH64, int D_T, int FAST>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
@@ -528,7 +641,10 @@ void k_dc_seg_sums(const int16_t *iq, long long ch_stride, int n_samples, unsign
     long long lx = 0, ly = 0;
     // 16-byte loads over the part of the window that is 16-byte aligned (the channel rows are), four of them in flight per thread; the few
     // samples in front of and behind it one by one.  An int accumulates at most 2^15 samples of 16 bits before it is folded into the long sums.
-    const int a0 = min(s1, (s0 + 3) & ~3), a1 = max(a0, s1 & ~3);
+    // (aligned by ADDRESS, not by sample index: a caller's rows need not start on 16 bytes — converted 8-bit input with a row stride of
+    // n_samples, a d_in offset)
+    const int mis = (int)((reinterpret_cast<uintptr_t>(p) >> 2) & 3u);                   // samples the row start lies behind a 16-byte boundary
+    const int a0 = min(s1, ((s0 + mis + 3) & ~3) - mis), a1 = max(a0, ((s1 + mis) & ~3) - mis);
     for (int i = s0 + (int)threadIdx.x; i < a0; i += 256) { const uint32_t raw = p[i]; lx += (int)(short)(raw & 0xffffu); ly += ((int)raw) >> 16; }
     for (int i = a1 + (int)threadIdx.x; i < s1; i += 256) { const uint32_t raw = p[i]; lx += (int)(short)(raw & 0xffffu); ly += ((int)raw) >> 16; }
     {
@@ -1933,6 +2049,9 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
             else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, 1>), grid, blk, lds, s, b);
         }
         else if (a->etab) return -1;                          // a fold-mode engine must never fall back to sums with the IQ-DC term
+        else if (a->phase_f64 && a->dc_seg && a->nd_base == 0.0 && !a->epoch_phase && a->lut_len % 50 == 0 && a->lut_phase % 50 == 0 && a->dc_seg_blocks > 0
+                 && a->nblocks >= 64 && a->nblocks % 2 == 0 && !no_k50 && a->wtab_scaled)
+            hipLaunchKernelGGL(k_mix_decimate50s, grid, blk, lds, s, b);      // the scanner's front end on the generated tile loop
         else if (a->phase_f64) hipLaunchKernelGGL((k_mix_decimate<7, true, 50, 0>), grid, blk, lds, s, b);
         else hipLaunchKernelGGL((k_mix_decimate<7, false, 50, 0>), grid, blk, lds, s, b);
         return 0;

@@ -213,17 +213,18 @@ template <class T> static int dupload(T **p, const std::vector<T> &v) {
 
 // ---- prefilter tables (k_scan_pre, sonde_scan_pre.hip)
 static uint16_t f16_bits(float x) { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, sizeof u); return u; }
-// A fragments of the Toeplitz product out[i] = sum_u h[u] x[i+u].  With i = 16 a + b and u = 16 c + d, d in [0, 16):
-//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] x[16 (a+c) + e],   A_c[b][e] = h[16 c + (e - b)] where 0 <= e - b < 16, else 0
-// (each tap belongs to exactly one step c; half of every 16x32 fragment is zero).  Fragment element: step c, lane (b = lane & 15, g = lane >> 4),
-// r < 8  <-  A_c[b][8 g + r].
+// A fragments of the Toeplitz product out[i] = sum_u h[u] x[i+u].  With i = 16 a + b and u = 32 c + e - b (e < 32, so e - b in (-16, 32)):
+//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] x[16 a + 32 c + e],   A_c[b][e] = h[32 c + e - b]   (0 outside [0, U))
+// For a fixed row b a step covers 32 consecutive taps and the next step the next 32: every tap in exactly one step and no structural zeros
+// in a fragment (round 3 advanced by 16 taps per step with e - b restricted to [0, 16): half of every fragment was zero, twice the MFMAs and
+// twice the LDS reads).  Fragment element: step c, lane (b = lane & 15, g = lane >> 4), r < 8  <-  A_c[b][8 g + r].
 static int toeplitz_frags(const std::vector<float> &h, std::vector<uint16_t> &out) {
-    const int U = (int)h.size(), nc = ((U + 15) / 16 + 3) & ~3;      // whole blocks of 4 steps (k_scan_pre prefetches the fragments block-wise); the padding is zeros
+    const int U = (int)h.size(), nc = ((U + 15 + 31) / 32 + 1) & ~1;   // whole blocks of 2 steps (k_scan_pre prefetches the fragments block-wise); the padding is zeros
     for (int c = 0; c < nc; c++)
         for (int lane = 0; lane < 64; lane++)
             for (int r = 0; r < 8; r++) {
-                const int d = 8 * (lane >> 4) + r - (lane & 15), u = 16 * c + d;
-                out.push_back((d >= 0 && d < 16 && u < U) ? f16_bits(h[u]) : (uint16_t)0);
+                const int d = 8 * (lane >> 4) + r - (lane & 15), u = 32 * c + d;          // d in (-16, 32): every element of the fragment is a tap
+                out.push_back((u >= 0 && u < U) ? f16_bits(h[u]) : (uint16_t)0);
             }
     return nc;
 }
@@ -270,6 +271,10 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
             for (int k = 64; k >= 4; k--) if (D % k == 0) { s->DS = k; break; }
             if (!s->DS || s->Q < 5) { delete s; return SONDE_E_ARG; }
             if (dupload(&s->d_wtab, s->wtab)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
+        } else if (!s->wide_fe) {                                            // the generated D = 50 kernel reads the tap rows * 2^-15 behind the table
+            std::vector<float> both(s->wtab);
+            for (size_t i = 0; i < s->wtab.size(); i++) both.push_back(s->wtab[i] * 3.0517578125e-05f);
+            if (dupload(&s->d_wtab, both)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
         }
         std::vector<double> f0s(C);
         for (int c = 0; c < C; c++) {
@@ -766,7 +771,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
                                      s->d_dcseg, nseg_cap + 1, s->stream);
             MixDecArgs a{};
             a.iq = (const int16_t *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = n_samples / D;
-            a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.DS = s->DS; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
+            a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.wtab_scaled = (D <= 64 && !s->wide_fe); a.DS = s->DS; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
             a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
             a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums;
             a.dc_seg = s->d_dcseg; a.dc_seg_n = nseg_cap + 1; a.dc_seg_off = (int)(s->dc_cnt / (uint32_t)D); a.dc_seg_blocks = (int)(s->dc_max / (uint32_t)D);
@@ -830,7 +835,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
             if (mode == SONDE_SCAN_BBIQ) {
                 MixDecArgs a{};
                 a.iq = (const int16_t *)d_in + 2 * (size_t)done; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = take / D;
-                a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.DS = s->DS; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
+                a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.wtab_scaled = (D <= 64 && !s->wide_fe); a.DS = s->DS; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
                 a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
                 a.dc_avg = s->d_dcavg; a.dc_sums = s->d_dcsums;
                 a.ptail_in = s->d_ptail[s->ptail_cur]; a.ptail_out = s->d_ptail[s->ptail_cur ^ 1];

@@ -10,10 +10,10 @@
 // are handed to the exact kernel, together with the same template's window before them (its exact peak position feeds the reference's
 // `mv_pos > mv0_pos` test).  Decisions, printed scores and positions therefore still come from the reference's own transform network.
 //
-// Both the low-pass and the correlation are Toeplitz products out[i] = sum_u h[u] x[i+u]; with i = 16 a + b, u = 16 c + e - b:
-//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] X[e][a + c],   A_c[b][e] = h[16 c + e - b] for 0 <= e - b < 16 (else 0),  X[e][a'] = x[16 a' + e]
-// i.e. per step c (16 taps) one 16x16x32 MFMA: A_c is a constant fragment (tabulated by the host, 1 KB per step), the B fragment of lane (n = lane & 15,
-// g = lane >> 4) is the 8 consecutive halves x[16 (a0+n+c) + 8 g ...] — one 16-byte LDS read.  The D fragment of a lane is out[16 (a0+n) + 4 g + r],
+// Both the low-pass and the correlation are Toeplitz products out[i] = sum_u h[u] x[i+u]; with i = 16 a + b, u = 32 c + e - b:
+//     out[16 a + b] = sum_c sum_{e<32} A_c[b][e] x[16 a + 32 c + e],   A_c[b][e] = h[32 c + e - b]
+// i.e. per step c (32 taps, no zero half in the fragment) one 16x16x32 MFMA: A_c is a constant fragment (tabulated by the host, 1 KB per step), the B
+// fragment of lane (n = lane & 15, g = lane >> 4) is the 8 consecutive halves x[16 (a0+n) + 32 c + 8 g ...] — one 16-byte LDS read.  The D fragment of a lane is out[16 (a0+n) + 4 g + r],
 // r < 4.  (A and B use the same k order within a lane, so the products pair up whatever the hardware's internal k numbering is.)
 // One workgroup (8 waves) = one (window, template); LDS: window f16 + filtered window f16 + prefix sums of its squares = 69 KB, two per CU.
 #include <hip/hip_runtime.h>
@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SP_THREADS 512
 #define SP_WAVES 8
 #define SP_MAXT 4                      // 256-sample tiles per wave (8192 samples / 256 / 8 waves)
-#define SP_CK 4                        // Toeplitz steps per block of prefetched A fragments (the host pads every table to a multiple)
+#define SP_CK 2                        // Toeplitz steps per block of prefetched A fragments (the host pads every table to a multiple)
 #define SP_CH 16                       // samples per thread in the load and prefix phases (8192 / 512)
 #define SP_PI(i) ((i) + ((i) >> 4))    // prefix sums are stored with one pad word per 16: a thread's run of 16 stays off its neighbours' banks
 
@@ -44,7 +44,7 @@ __device__ __forceinline__ void sp_toeplitz_nt(const _Float16 *x, const uint16_t
 #pragma unroll
     for (int t = 0; t < NT; t++) r[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const half8 *af = reinterpret_cast<const half8 *>(afrag) + lane;
-    const _Float16 *xb = x + 16 * (16 * wave + n) + 8 * g;           // tile t adds 16 * 16 * SP_WAVES * t halves, step c adds 16
+    const _Float16 *xb = x + 16 * (16 * wave + n) + 8 * g;           // tile t adds 16 * 16 * SP_WAVES * t halves, step c adds 32
     // nc is a multiple of SP_CK (the host pads the table with zero steps).  The A fragments of the NEXT block of SP_CK steps are requested before
     // the MFMAs of the current block (the scheduling barrier keeps the requests there), so one global-memory latency is paid per wave, not per step.
     half8 cur[SP_CK], nxt[SP_CK];
@@ -59,11 +59,11 @@ __device__ __forceinline__ void sp_toeplitz_nt(const _Float16 *x, const uint16_t
         for (int k = 0; k < SP_CK; k++) {
             half8 B[NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) B[t] = *reinterpret_cast<const half8 *>(xb + 256 * SP_WAVES * t + 16 * k);
+            for (int t = 0; t < NT; t++) B[t] = *reinterpret_cast<const half8 *>(xb + 256 * SP_WAVES * t + 32 * k);
 #pragma unroll
             for (int t = 0; t < NT; t++) r[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[k], B[t], r[t], 0, 0, 0);
         }
-        xb += 16 * SP_CK;
+        xb += 32 * SP_CK;
 #pragma unroll
         for (int k = 0; k < SP_CK; k++) cur[k] = nxt[k];
     }
@@ -95,8 +95,8 @@ void k_scan_pre(const ScanPreArgs a) {
     const int nT1 = (wl + 255) >> 8, nT2 = (K + 1 + 255) >> 8, nc2 = a.nc2[j];
     const int padL = a.opt_iq ? a.ws_pad : 0;
     // LDS carve-up (halves / floats); every array starts on a 16-byte boundary
-    const int NXH = (256 * nT1 + 16 * a.nc1 + 48 + 7) & ~7;
-    int NXF = 256 * nT2 + 16 * nc2 + 48; if (NXF < 256 * nT1) NXF = 256 * nT1; NXF = (NXF + 7) & ~7;
+    const int NXH = (256 * nT1 + 32 * a.nc1 + 48 + 7) & ~7;
+    int NXF = 256 * nT2 + 32 * nc2 + 48; if (NXF < 256 * nT1) NXF = 256 * nT1; NXF = (NXF + 7) & ~7;
     _Float16 *xh = reinterpret_cast<_Float16 *>(sp_smem);                 // padL zeros, the window minus 0.98 dc, zeros
     _Float16 *xfh = xh + (a.opt_iq ? NXH : 0);                             // the filtered window, zeros behind it
     float *P = reinterpret_cast<float *>(xfh + NXF);                       // P[SP_PI(i)] = sum_{q<i} xf[q]^2, i <= 256 nT1
@@ -127,12 +127,27 @@ void k_scan_pre(const ScanPreArgs a) {
         dc = s_dc;
     }
     const float dcs = 0.98f * dc;
+    // The score c / sqrt(e) does not depend on the scale of the window, the f16 operands do: a window of a few LSB of FM audio (1 / 32768 = 3e-5) would
+    // sit in f16's subnormals.  The window is therefore brought to [0.5, 1) by a power of two (exact) before the conversion, so that the rounding — and
+    // with it the margin of the bound — is the same whatever the input level.
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < SP_CH; r++) { const int i = tid + SP_THREADS * r; if (i < wl) amax = fmaxf(amax, fabsf(v[r] - dcs)); }
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    __shared__ float s_amax[SP_WAVES];
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    amax = 0.f;
+    for (int w = 0; w < SP_WAVES; w++) amax = fmaxf(amax, s_amax[w]);
+    int ex = 0;
+    if (amax > 0.f) { (void)frexpf(amax, &ex); ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex); }
+    const float wscale = ldexpf(1.0f, -ex);
     _Float16 *dst = a.opt_iq ? xh + padL : xfh;
     const int ndst = (a.opt_iq ? NXH - padL : NXF);
 #pragma unroll
     for (int r = 0; r < SP_CH; r++) {
         const int i = tid + SP_THREADS * r;
-        if (i < ndst) dst[i] = (_Float16)((i < wl) ? v[r] - dcs : 0.f);
+        if (i < ndst) dst[i] = (_Float16)((i < wl) ? (v[r] - dcs) * wscale : 0.f);
     }
     for (int i = SP_CH * SP_THREADS + tid; i < ndst; i += SP_THREADS) dst[i] = (_Float16)0.f;
     if (a.opt_iq) for (int i = tid; i < padL; i += SP_THREADS) xh[i] = (_Float16)0.f;
@@ -155,7 +170,7 @@ void k_scan_pre(const ScanPreArgs a) {
                 for (int r = 0; r < 4; r++) {
                     const int i = i0 + r;
                     float x = acc[t][r];
-                    if (i < a.taps - 1) x -= dcs * tail[i];
+                    if (i < a.taps - 1) x -= dcs * wscale * tail[i];
                     h[r] = (_Float16)((i < wl) ? x : 0.f);
                 }
                 *reinterpret_cast<half4 *>(xfh + i0) = h;
@@ -246,8 +261,8 @@ extern "C" int sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s) {
     for (int j = 0; j < SC_NTPL; j++) if (a->tpl[j].active) { if (a->tpl[j].L > maxL) maxL = a->tpl[j].L; if (a->nc2[j] > maxc2) maxc2 = a->nc2[j]; }
     const int wl = a->K + maxL, nT1 = (wl + 255) >> 8, nT2 = (a->K + 1 + 255) >> 8;
     if (nT1 > SP_WAVES * SP_MAXT || 256 * nT1 > SP_CH * SP_THREADS) return -1;       // window longer than 8192 samples
-    const size_t nxh = a->opt_iq ? (size_t)((256 * nT1 + 16 * a->nc1 + 48 + 7) & ~7) : 0;
-    size_t nxf = (size_t)256 * nT2 + 16 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1) nxf = (size_t)256 * nT1; nxf = (nxf + 7) & ~(size_t)7;
+    const size_t nxh = a->opt_iq ? (size_t)((256 * nT1 + 32 * a->nc1 + 48 + 7) & ~7) : 0;
+    size_t nxf = (size_t)256 * nT2 + 32 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1) nxf = (size_t)256 * nT1; nxf = (nxf + 7) & ~(size_t)7;
     const size_t lds = 2 * (nxh + nxf) + 4 * (size_t)(SP_PI(256 * nT1) + 8);
     static size_t attr = 0;
     if (lds > attr) {

@@ -63,6 +63,10 @@ class Regs:
 
 
 EXP = ""      # experiment variants (tools/ab_variants.sh): timing only, results are garbage
+SCAN = False  # the scanner's front end (scan/dft_detect.c): mixer phase kept in DOUBLE (t = f0 * n, :1090-1093: fract in f64, then one rounding to f32)
+              # and the IQ-DC mean of the row's 1/32 s window taken off every sample ((x - avg) ex, :579-588; the means come from a table, a
+              # launch spans many windows) instead of folded out per output — same instruction count: the subtraction takes the slot of the
+              # IQ-DC sum, which k_dc_seg_sums owns in that mode
 
 
 def tap_fma(R, q, row, init=False):
@@ -95,12 +99,16 @@ def block(R, r, init=False):
         I["cvt64"] = f"v_cvt_f32_f64 {R.TP}, {R.T}"
         I["add64"] = f"v_add_f64 {R.T}, {R.T}, {R.f0}"
         I["fract"] = f"v_fract_f32 {R.TP}, {R.TP}"
+        if SCAN:      # Z is free between the last tap FMA of the previous block and this block's `z`
+            I["cvt64"] = f"v_fract_f64 {R.Z}, {R.T}"
+            I["fract"] = f"v_cvt_f32_f64 {R.TP}, {R.Z}"
         I["xr"] = f"v_cvt_f32_i32_sdwa {R.XR[e]}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
         I["xi"] = f"v_cvt_f32_i32_sdwa {R.XI[e]}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
         I["cos"] = f"v_cos_f32 {R.C[e]}, {R.TP}"
         I["sin"] = f"v_sin_f32 {R.S[e]}, {R.TP}"
         I["dcs"] = f"v_pk_fma_f32 {R.dcs}, {R.X[e]}, {R.msk}, {R.dcs}" if R.msk else f"v_pk_add_f32 {R.dcs}, {R.X[e]}, {R.dcs}"
         if init and r == 0: I["dcs"] = f"v_mov_b64 {R.dcs}, {R.X[e]}"
+        if SCAN: I["dcs"] = f"v_pk_add_f32 {R.X[e]}, {R.X[e]}, {R.dcs}"      # R.dcs holds -32768 * mean of the row's window
     if s2:
         I["tt"] = f"v_pk_mul_f32 {R.TT}, {R.X[o]}, {R.CS[o]} op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]"
         I["z"] = f"v_pk_fma_f32 {R.Z}, {R.X[o]}, {R.CS[o]}, {R.TT} op_sel_hi:[0,1,1]"
@@ -139,7 +147,7 @@ def walk(R, init=False, hook=()):
 
 # ---- the operand form (md_fast_tile in sonde_kernels.hip) -----------------------------------------------------------------
 def body_operands():
-    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[wt]", msk="%[msk]")
+    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[wt]", msk=None if SCAN else "%[msk]")
     return walk(R)
 
 
@@ -202,10 +210,11 @@ def diag_finish(rb):
         L += [f"s_mov_b32 exec_lo, 0x{(0xffffffff << (H - q)) & 0xffffffff:x}", f"v_pk_add_f32 {pair(Y)}, {pair(Y)}, {pair(rb + 2 * q)}"]
     for q in range(H):
         L += [f"s_mov_b64 exec, {(1 << (H - q)) - 1}", f"v_pk_add_f32 {pair(CARRY)}, {pair(CARRY)}, {pair(rb + 2 * q)}"]
-    L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]",
-          f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel_hi:[1,0,1]",
-          f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]",
-          f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
+    L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]"]
+    if not SCAN:
+        L += [f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel_hi:[1,0,1]",
+              f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"]
+    L += [f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
           "s_mov_b64 exec, -1", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], -1"]
     if "nostore" in EXP: L = [l for l in L if not l.startswith("global_store")]
     if "sc1store" in EXP: L = [l + " sc1" if l.startswith("global_store") else l for l in L]
@@ -218,6 +227,7 @@ def gen_loop():
     T1, A, B = SCR + 14, SCR + 15, SCR + 16
     L = [f"s_mov_b64 s[{S_TB}:{S_TB + 1}], %[tb]", f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[outmask]", f"s_mov_b32 s{S_JM}, %[jm]",
          f"s_mov_b32 s{S_T}, 0", f"v_mov_b64 {pair(CARRY)}, %[carry]"]
+    if SCAN: L.append(f"v_mov_b64 {pair(DCS)}, %[navg0]")        # -32768 * mean of the window of the lane's row in the first tile
     # tile 0 -> LDS (the wave's only exposed load latency); tile 1 on its way
     L += fetch(STAGE[0])
     L += ["s_cmp_gt_i32 %[nfull], 1", "s_cbranch_scc0 10f"]
@@ -235,22 +245,31 @@ def gen_loop():
                 f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 5}f",
                 "s_waitcnt vmcnt(13)", f"s_branch {lab + 6}f", f"{lab + 5}:", "s_waitcnt vmcnt(0)", f"{lab + 6}:"]
         hook += diag_finish(STAGE[h]) + [f"{lab + 1}:"]
-        if "noE" not in EXP: hook += [f"v_lshlrev_b32 v{T1}, 3, %[e]", f"global_load_dwordx2 {pair(EREG)}, v{T1}, %[etab]"]
+        if SCAN:
+            # the mean for the lane's row in the NEXT tile (row + 64): window k = (row + 64 + off) / B through a float reciprocal — row + off < 2^24 is
+            # exact in f32 and (n + 0.5) / B is at least 0.5 / B away from an integer, far more than the rounding of the product — clamped to the table
+            hook += [f"v_add_u32 v{T1}, %[segoff64], %[jrow]", f"v_cvt_f32_u32 v{T1}, v{T1}", f"v_add_f32 v{T1}, 0.5, v{T1}", f"v_mul_f32 v{T1}, %[rcpB], v{T1}",
+                     f"v_cvt_u32_f32 v{T1}, v{T1}", f"v_min_u32 v{T1}, %[segmax], v{T1}", f"v_lshlrev_b32 v{T1}, 3, v{T1}",
+                     f"global_load_dwordx2 {pair(EREG)}, v{T1}, %[dcseg]"]
+        elif "noE" not in EXP: hook += [f"v_lshlrev_b32 v{T1}, 3, %[e]", f"global_load_dwordx2 {pair(EREG)}, v{T1}, %[etab]"]
         fe = [f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f"] + fetch(STAGE[h]) + [f"{lab + 2}:"]
         if "latefetch" not in EXP: hook += fe
         L += [f"{lab}:", f"v_mul_u32_u24 v{T1}, 50, %[e]", f"v_cvt_f64_u32 {pair(TREG)}, v{T1}", f"v_mul_f64 {pair(TREG)}, {pair(TREG)}, %[f0]"]
         L += walk(R, init=True, hook=hook)
         if "latefetch" in EXP: L += fe
         # the lane's block in the next tile: e = (e + 64) mod P; IQ-DC sums of the rows that count
-        L += [f"v_add_u32 %[e], 64, %[e]", f"v_subrev_u32 v{T1}, %[P], %[e]", f"v_min_u32 %[e], v{T1}, %[e]",
-              f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
-              f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1"]
+        L += [f"v_add_u32 %[e], 64, %[e]", f"v_subrev_u32 v{T1}, %[P], %[e]", f"v_min_u32 %[e], v{T1}, %[e]"]
+        if SCAN: L += [f"v_add_u32 %[jrow], 64, %[jrow]"]
+        else: L += [f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
+                    f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1"]
         L += [f"s_add_i32 s{S_T}, s{S_T}, 1", f"s_cmp_ge_i32 s{S_T}, %[nfull]", "s_cbranch_scc1 90f"]
         # tile t+1: its loads are followed by this tile's E load and 13 loads of tile t+2 (if requested)
         L += [f"s_add_i32 s{S_TMP}, s{S_T}, 1", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 3}f",
               "s_waitcnt vmcnt(13)", f"s_branch {lab + 4}f", f"{lab + 3}:", "s_waitcnt vmcnt(0)", f"{lab + 4}:"]
         L += park(STAGE[1 - h])
         L += diag_issue(STAGE[1 - h])
+        if SCAN:      # the next tile's means have landed (they are older than the loads the last wait left outstanding)
+            L += [f"v_mul_f32 v{DCS}, 0xc7000000, v{EREG}", f"v_mul_f32 v{DCS + 1}, 0xc7000000, v{EREG + 1}"]
     L += ["s_branch 20b", "90:"]
     # the wave's last full tile: nothing follows, the walk's scratch registers take the rotations
     L += diag_issue(SCR) + ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + diag_finish(SCR)
@@ -267,6 +286,11 @@ def main():
     global EXP
     text = "// generated by tools/gen_md_fast.py — do not edit (tests/test_generated_sources.py checks it is in sync)\n"
     text += as_macro("MD_FAST_BODY_1", body_operands()) + as_macro("MD50_LOOP_1", gen_loop())
+    global SCAN
+    SCAN = True
+    text += "// the scanner's front end: double mixer phase, IQ-DC mean of the row's window off every sample (SCAN in tools/gen_md_fast.py)\n"
+    text += as_macro("MD_FAST_BODY_S", body_operands()) + as_macro("MD50_LOOP_S", gen_loop())
+    SCAN = False
     if len(sys.argv) > 1 and sys.argv[1] == "--experiments":
         for k, e in enumerate(sys.argv[2:], 2):
             EXP = e
