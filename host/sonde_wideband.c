@@ -321,7 +321,7 @@ static void drain(int type, int finish) {
                 else if (type == T_RS92) m = sonde_rs92_dec_frame((sonde_rs92_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 else m = sonde_mts01_dec_frame((sonde_mts01_dec_t *)sn->dec, b, n, tx, sizeof tx);
                 if (m > 0) { if ((size_t)m < sizeof tx) tx[m] = 0; else tx[sizeof tx - 1] = 0; print_json_lines(tx); }
-                sn->frames++; sn->last_frame_at = g_pos;
+                sn->frames++; if (m > 0) sn->last_frame_at = g_pos;       /* only a frame the decoder accepted counts as a sign of life */
             }
         }
         fflush(stdout);
@@ -337,7 +337,7 @@ static void drain(int type, int finish) {
                 if (o < 0) continue;
                 fr[i].channel = 0;
                 if (sonde_rs41_dec_frame((sonde_rs41_dec_t *)g_sondes[o].dec, &fr[i], tx, sizeof tx) > 0) print_json_lines(tx);
-                g_sondes[o].frames++; g_sondes[o].last_frame_at = g_pos;
+                g_sondes[o].frames++; if (fr[i].ecc >= 0) g_sondes[o].last_frame_at = g_pos;      /* the Reed-Solomon code accepts the frame */
             }
         } else if (type == T_DFM) {
             static sonde_dfm_frame_t fr[64];
@@ -347,7 +347,7 @@ static void drain(int type, int finish) {
                 if (o < 0) continue;
                 fr[i].channel = 0;
                 if (sonde_dfm_dec_frame((sonde_dfm_dec_t *)g_sondes[o].dec, &fr[i], tx, sizeof tx) > 0) print_json_lines(tx);
-                g_sondes[o].frames++; g_sondes[o].last_frame_at = g_pos;
+                g_sondes[o].frames++; if (fr[i].ecc[0] >= 0 && fr[i].ecc[1] >= 0 && fr[i].ecc[2] >= 0) g_sondes[o].last_frame_at = g_pos;   /* all three Hamming blocks */
             }
         } else if (type == T_M10) {
             static sonde_m10_frame_t fr[64];

@@ -189,6 +189,7 @@ struct sonde_scan {
     int ring_len = 0;
     // stream position
     uint64_t samples_in = 0; uint32_t m_out = 0; uint32_t dc_cnt = 0, dc_max = 0;
+    unsigned long long *d_spprof = nullptr;
     long long *d_segsums = nullptr; float2 *d_dcseg = nullptr;      // IQ-DC windows of a call: sums, table of means (MixDecArgs.dc_seg)
     std::vector<Chan> chan;
     std::vector<sonde_detection_t> queue;
@@ -414,6 +415,13 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
 void sonde_scan_destroy(sonde_scan_t *s) {
     if (!s) return;
     if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    if (s->d_spprof) {
+        unsigned long long h[8] = {0};
+        if (hipMemcpy(h, s->d_spprof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[7])
+            fprintf(stderr, "scan_pre prof (template 1, %llu workgroups, mean shader cycles): load+dc %llu  convert+stage %llu  fm-lowpass %llu  prefix %llu  correlation %llu  reduce %llu\n",
+                    h[7], h[0] / h[7], h[1] / h[7], h[2] / h[7], h[3] / h[7], h[4] / h[7], h[5] / h[7]);
+        hipFree(s->d_spprof);
+    }
     if (s->h_items) hipHostFree(s->h_items);
     if (s->h_res) hipHostFree(s->h_res);
     if (s->h_pre) hipHostFree(s->h_pre);
@@ -653,6 +661,11 @@ static int run_windows(sonde_scan *s) {
             pa.K = s->K; pa.opt_dc = s->cfg.opt_dc; pa.opt_iq = a.opt_iq; pa.lpfm_taps = s->lpfm_taps; pa.out = s->d_pre;
             hipEventRecord(e0, s->stream);
             HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
+            {   // profiling aid: cycles per phase of k_scan_pre, printed when the scanner is destroyed
+                static const bool want = getenv("SONDE_SP_PROF") != nullptr;
+                if (want && !s->d_spprof) { if (hipMalloc((void **)&s->d_spprof, 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(s->d_spprof, 0, 8 * sizeof(unsigned long long)); }
+                pa.prof = s->d_spprof;
+            }
             if (sonde_launch_scan_pre(&pa, s->stream) < 0) return SONDE_E_NOGPU;
             HIPCHK(hipMemcpyAsync(s->h_pre, s->d_pre, (size_t)n_items * SC_NTPL * sizeof(ScanPre), hipMemcpyDeviceToHost, s->stream));
             hipEventRecord(e1, s->stream);

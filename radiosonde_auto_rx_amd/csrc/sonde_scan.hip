@@ -59,11 +59,17 @@ void k_audio_convert(const AudioConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_scan_if: 256 IF samples of one channel per workgroup
+// k_scan_if: 1024 IF samples of one channel per workgroup, four consecutive outputs per thread
 // ------------------------------------------------------------------------------------------------
-#define SI_TILE 256
+// Round 4: a thread keeps a sliding window of four y samples in registers and advances it by ONE LDS read per tap (round 3: one read per tap and
+// OUTPUT, and three tap reads beside it — the kernel was bound by LDS instruction issue at 4 LDS operations per 3 packed multiply-adds; now 1.75
+// per 12).  Per output and filter the multiply-adds are the same fmaf chain in the same tap order: streams unchanged to the bit.
+#define SI_TILE 1024
+#define SI_THREADS 256
+#define SI_PER 4
+typedef float si_f2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(SI_TILE)
+__global__ __launch_bounds__(SI_THREADS)
 void k_scan_if(const ScanIfArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem2[];
     const int ch = blockIdx.y, T = a.taps, tid = threadIdx.x;
@@ -71,44 +77,73 @@ void k_scan_if(const ScanIfArgs a) {
     const int nout = min(SI_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
     if (nout <= 0) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
-    float2 *sy = smem2;                          // y[t0 - T + k], k < SI_TILE + T   (one sample more than the FIR history: z[t0-1])
-    float2 *sz = sy + SI_TILE + T;               // [3][SI_TILE + 1] z_b[t0 - 1 + k]
-    float  *sw = reinterpret_cast<float *>(sz + 3 * (SI_TILE + 1));   // [nfilt][T]
+    const int T4 = (T + 3) & ~3;
+    float2 *sy = smem2;                          // y[t0 - T + k], k < SI_TILE + T + 4   (one sample more than the FIR history: z[t0-1])
+    float2 *sz = sy + SI_TILE + T4 + 4;          // [3][SI_TILE + 4] z_b[t0 - 1 + k]   (an even number of float2 in front: the tap rows behind stay 16-byte aligned)
+    float  *sw = reinterpret_cast<float *>(sz + 3 * (SI_TILE + 4));   // [nfilt][T4], zero padded: 16-byte rows
     const float2 *yr = a.y + (size_t)ch * a.ring_len;
-    for (int k = tid; k < SI_TILE + T; k += SI_TILE) {
+    for (int k = tid; k < SI_TILE + T + 4; k += SI_THREADS) {
         const int64_t m = (int64_t)t0 - T + k;
         sy[k] = (m >= 0 && k < nout + T) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
     }
-    for (int k = tid; k < a.nfilt * T; k += SI_TILE) sw[k] = a.w[k];
+    for (int k = tid; k < a.nfilt * T4; k += SI_THREADS) { const int bq = k / T4, kk = k % T4; sw[k] = kk < T ? a.w[bq * T + kk] : 0.f; }
     __syncthreads();
-    // z_b[m] = sum_k w_b[k] * y[m-(T-1)+k] for m = t0-1 .. t0+nout-1 (oldest sample pairs with tap 0, dft_detect.c:696-705)
-    for (int o = tid; o < nout + 1; o += SI_TILE) {
-        float2 acc[3] = { {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f} };
-        const float2 *yy = sy + o;               // y[t0 - 1 + o - (T-1)] = sy[o]
-        for (int k = 0; k < T; k++) {
-            const float2 v = yy[k];
+    // z_b[m] = sum_k w_b[k] * y[m-(T-1)+k] for m = t0-1 .. t0+nout-1 (oldest sample pairs with tap 0, dft_detect.c:696-705): outputs o = 4 tid .. 4 tid + 3
+    // of the nout + 1; the last thread's window runs into the zero padding behind the tile
+    for (int o0 = SI_PER * tid; o0 < nout + 1; o0 += SI_PER * SI_THREADS) {
+        si_f2 acc[3][SI_PER];
 #pragma unroll
-            for (int b = 0; b < 3; b++) if (b < a.nfilt) {
-                const float w = sw[b * T + k];
-                acc[b].x = fmaf(w, v.x, acc[b].x); acc[b].y = fmaf(w, v.y, acc[b].y);
+        for (int bq = 0; bq < 3; bq++)
+#pragma unroll
+            for (int u = 0; u < SI_PER; u++) acc[bq][u] = (si_f2){0.f, 0.f};
+        const float2 *yy = sy + o0;              // y[t0 - 1 + o0 - (T-1)] = sy[o0]
+        si_f2 win[SI_PER];
+#pragma unroll
+        for (int u = 0; u < SI_PER - 1; u++) { const float2 v = yy[u]; win[u + 1] = (si_f2){v.x, v.y}; }
+        for (int k0 = 0; k0 < T; k0 += 4) {
+            float4 w4[3];
+#pragma unroll
+            for (int bq = 0; bq < 3; bq++) w4[bq] = bq < a.nfilt ? *reinterpret_cast<const float4 *>(sw + bq * T4 + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int k = k0 + kk;
+                if (k < T) {
+#pragma unroll
+                    for (int u = 0; u < SI_PER - 1; u++) win[u] = win[u + 1];
+                    const float2 v = yy[k + SI_PER - 1];
+                    win[SI_PER - 1] = (si_f2){v.x, v.y};
+#pragma unroll
+                    for (int bq = 0; bq < 3; bq++) if (bq < a.nfilt) {
+                        const float w = kk == 0 ? w4[bq].x : kk == 1 ? w4[bq].y : kk == 2 ? w4[bq].z : w4[bq].w;
+                        const si_f2 wq = {w, w};
+#pragma unroll
+                        for (int u = 0; u < SI_PER; u++) acc[bq][u] = __builtin_elementwise_fma(wq, win[u], acc[bq][u]);
+                    }
+                }
             }
         }
-        const bool before = (int64_t)t0 - 1 + o < 0;          // z[-1] = 0: static z0 of f32buf_sample starts at 0
 #pragma unroll
-        for (int b = 0; b < 3; b++) if (b < a.nfilt) sz[b * (SI_TILE + 1) + o] = before ? make_float2(0.f, 0.f) : acc[b];
+        for (int u = 0; u < SI_PER; u++) {
+            const int o = o0 + u;
+            if (o < nout + 1) {
+                const bool before = (int64_t)t0 - 1 + o < 0;  // z[-1] = 0: static z0 of f32buf_sample starts at 0
+#pragma unroll
+                for (int bq = 0; bq < 3; bq++) if (bq < a.nfilt) sz[bq * (SI_TILE + 4) + o] = before ? make_float2(0.f, 0.f) : make_float2(acc[bq][u].x, acc[bq][u].y);
+            }
+        }
     }
     __syncthreads();
-    if (tid < nout) {
-        const uint32_t m = (t0 + (uint32_t)tid) & mask;
+    for (int i = tid; i < nout; i += SI_THREADS) {
+        const uint32_t m = (t0 + (uint32_t)i) & mask;
         const size_t cs = (size_t)a.n_ch * a.ring_len, co = (size_t)ch * a.ring_len + m;
         // s = 0.8 * carg(z * conj(z_prev)) / pi   (dft_detect.c:776-803)
 #pragma unroll
-        for (int b = 0; b < 3; b++) if (b < a.nfilt) {
-            const float2 z1 = sz[b * (SI_TILE + 1) + tid + 1], z0 = sz[b * (SI_TILE + 1) + tid];
+        for (int bq = 0; bq < 3; bq++) if (bq < a.nfilt) {
+            const float2 z1 = sz[bq * (SI_TILE + 4) + i + 1], z0 = sz[bq * (SI_TILE + 4) + i];
             const float2 w = cmulc(z1, z0);
-            a.fm[(size_t)a.filt_stream[b] * cs + co] = (float)(0.8 * (double)atan2f(w.y, w.x) / 3.14159265358979323846);
+            a.fm[(size_t)a.filt_stream[bq] * cs + co] = (float)(0.8 * (double)atan2f(w.y, w.x) / 3.14159265358979323846);
         }
-        const float2 y1 = sy[T + tid], y0 = ((int64_t)t0 + tid - 1 < 0) ? make_float2(0.f, 0.f) : sy[T + tid - 1];
+        const float2 y1 = sy[T + i], y0 = ((int64_t)t0 + i - 1 < 0) ? make_float2(0.f, 0.f) : sy[T + i - 1];
         const float2 w = cmulc(y1, y0);
         a.fm[(size_t)a.raw_stream * cs + co] = (float)(0.8 * (double)atan2f(w.y, w.x) / 3.14159265358979323846);
     }
@@ -309,8 +344,8 @@ void k_scan_corr_t(const ScanCorrArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 extern "C" void sonde_launch_scan_if(const ScanIfArgs *a, hipStream_t s) {
-    const size_t lds = (size_t)(SI_TILE + a->taps + 3 * (SI_TILE + 1)) * sizeof(float2) + (size_t)a->nfilt * a->taps * sizeof(float);
-    hipLaunchKernelGGL(k_scan_if, dim3((a->n + SI_TILE - 1) / SI_TILE, a->n_ch), dim3(SI_TILE), lds, s, *a);
+    const size_t lds = (size_t)(SI_TILE + ((a->taps + 3) & ~3) + 4 + 3 * (SI_TILE + 4)) * sizeof(float2) + (size_t)a->nfilt * ((a->taps + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL(k_scan_if, dim3((a->n + SI_TILE - 1) / SI_TILE, a->n_ch), dim3(SI_THREADS), lds, s, *a);
 }
 extern "C" int sonde_launch_scan_corr(const ScanCorrArgs *a, hipStream_t s) {
     static bool attr_set = false;

@@ -63,6 +63,7 @@ struct ScanPreArgs {
     const float *ws_tail;     // [2][taps]: sum of the taps behind tap i (what a constant loses in the filter's first taps-1 outputs)
     int K, opt_dc, opt_iq, lpfm_taps;
     ScanPre *out;             // [n_items][SC_NTPL]
+    unsigned long long *prof; // SONDE_SP_PROF: shader cycles per phase of the workgroups of template 1 (RS41), [8]; nullptr = off
 };
 struct ScanIfArgs {
     const float2 *y;          // [n_ch][ring_len] IF-rate IQ

@@ -15,7 +15,8 @@
 // i.e. per step c (32 taps, no zero half in the fragment) one 16x16x32 MFMA: A_c is a constant fragment (tabulated by the host, 1 KB per step), the B
 // fragment of lane (n = lane & 15, g = lane >> 4) is the 8 consecutive halves x[16 (a0+n) + 32 c + 8 g ...] — one 16-byte LDS read.  The D fragment of a lane is out[16 (a0+n) + 4 g + r],
 // r < 4.  (A and B use the same k order within a lane, so the products pair up whatever the hardware's internal k numbering is.)
-// One workgroup (8 waves) = one (window, template); LDS: window f16 + filtered window f16 + prefix sums of its squares = 69 KB, two per CU.
+// One workgroup (8 waves) = one (window, template); LDS: window f16 (17 KB) + filtered window f16 (19 KB) + every fourth prefix sum of its squares (8 KB)
+// + the A fragments of the low-pass and of the template (1 KB per 32 taps, at most 32 KB at a time) <= 77 KB, two per CU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sonde_scan_dev.h"
@@ -29,49 +30,46 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SP_MAXT 4                      // 256-sample tiles per wave (8192 samples / 256 / 8 waves)
 #define SP_CK 2                        // Toeplitz steps per block of prefetched A fragments (the host pads every table to a multiple)
 #define SP_CH 16                       // samples per thread in the load and prefix phases (8192 / 512)
-#define SP_PI(i) ((i) + ((i) >> 4))    // prefix sums are stored with one pad word per 16: a thread's run of 16 stays off its neighbours' banks
+#define SP_ACAP 32                     // A-fragment steps (1 KB each) the LDS holds at a time: 4 x 16 bytes per thread; longer templates reload
 
+// S(i) = sum_{q<i} xf[q]^2 from the sums kept for every fourth i and the squares between
+__device__ __forceinline__ float sp_S(const float *P, const _Float16 *xf, int i) {
+    float s = P[i >> 2];
+    for (int q = i & ~3; q < i; q++) { const float x = (float)xf[q]; s += x * x; }
+    return s;
+}
 __device__ __forceinline__ float sp_wsum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
 // acc[t] = sum_c A_c x B(tile t, step c) for the NT tiles of this wave (tile = wave + SP_WAVES t); x: f16 array in LDS whose element 0 pairs with
 // h[0] of output 0.  NT is a template parameter so that the step loop has no branches: the B fragments of a step are NT independent 16-byte
-// LDS reads at a fixed distance, followed by NT MFMAs.  A_c comes from global memory (the tables of all templates do not fit beside the
-// window in LDS); the fragment of step c+1 is requested before the MFMAs of step c so that its latency is covered.
+// LDS reads at a fixed distance, followed by NT MFMAs.  The A fragments of ALL steps are in LDS (afrag, 1 KB per step, staged once per workgroup
+// while the window is on its way): round 3 streamed them from global memory inside this loop, one block of steps ahead — every block then waited
+// a global-memory round trip of ~1 us for ~0.1 us of MFMAs, and all eight waves fetched the same bytes.
 template <int NT>
-__device__ __forceinline__ void sp_toeplitz_nt(const _Float16 *x, const uint16_t *afrag, int nc, int wave, int lane, f32x4 *acc) {
+__device__ __forceinline__ void sp_toeplitz_nt(const _Float16 *x, const _Float16 *afrag, int nc, int wave, int lane, f32x4 *acc) {
     const int n = lane & 15, g = lane >> 4;
     f32x4 r[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) r[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; t++) r[t] = acc[t];                       // continues what earlier chunks of steps added up (the caller zeroes acc)
     const half8 *af = reinterpret_cast<const half8 *>(afrag) + lane;
     const _Float16 *xb = x + 16 * (16 * wave + n) + 8 * g;           // tile t adds 16 * 16 * SP_WAVES * t halves, step c adds 32
-    // nc is a multiple of SP_CK (the host pads the table with zero steps).  The A fragments of the NEXT block of SP_CK steps are requested before
-    // the MFMAs of the current block (the scheduling barrier keeps the requests there), so one global-memory latency is paid per wave, not per step.
-    half8 cur[SP_CK], nxt[SP_CK];
-#pragma unroll
-    for (int k = 0; k < SP_CK; k++) cur[k] = af[(size_t)64 * k];
-    for (int c0 = 0; c0 < nc; c0 += SP_CK) {
-        const int cn = c0 + SP_CK < nc ? c0 + SP_CK : c0;             // the last block re-reads itself (unused)
-#pragma unroll
-        for (int k = 0; k < SP_CK; k++) nxt[k] = af[(size_t)64 * (cn + k)];
-        __builtin_amdgcn_sched_barrier(0);
+    for (int c0 = 0; c0 < nc; c0 += SP_CK) {                          // nc is a multiple of SP_CK (the host pads the table with zero steps)
 #pragma unroll
         for (int k = 0; k < SP_CK; k++) {
+            const half8 A = af[(size_t)64 * (c0 + k)];
             half8 B[NT];
 #pragma unroll
             for (int t = 0; t < NT; t++) B[t] = *reinterpret_cast<const half8 *>(xb + 256 * SP_WAVES * t + 32 * k);
 #pragma unroll
-            for (int t = 0; t < NT; t++) r[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[k], B[t], r[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) r[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B[t], r[t], 0, 0, 0);
         }
         xb += 32 * SP_CK;
-#pragma unroll
-        for (int k = 0; k < SP_CK; k++) cur[k] = nxt[k];
     }
 #pragma unroll
     for (int t = 0; t < NT; t++) acc[t] = r[t];
 }
 // number of tiles of this wave (wave-uniform) and the dispatch on it
-__device__ __forceinline__ int sp_toeplitz(const _Float16 *x, const uint16_t *afrag, int nc, int wave, int ntiles, int lane, f32x4 (&acc)[SP_MAXT]) {
+__device__ __forceinline__ int sp_toeplitz(const _Float16 *x, const _Float16 *afrag, int nc, int wave, int ntiles, int lane, f32x4 (&acc)[SP_MAXT]) {
     const int cnt = ntiles > wave ? (ntiles - wave + SP_WAVES - 1) / SP_WAVES : 0;
     switch (cnt) {
         case 1: sp_toeplitz_nt<1>(x, afrag, nc, wave, lane, acc); break;
@@ -89,6 +87,9 @@ void k_scan_pre(const ScanPreArgs a) {
     const int item = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ScanTpl tp = a.tpl[j];
     ScanPre *out = a.out + (size_t)item * SC_NTPL + j;
+    // profiling aid (SONDE_SP_PROF): thread 0 of template 1's workgroups adds the cycles since the previous mark to phase k
+#define SP_MARK(k) do { if (a.prof && j == 1 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(a.prof + (k), t_ - t_prev); t_prev = t_; } } while (0)
+    unsigned long long t_prev = a.prof ? __builtin_readcyclecounter() : 0ull;
     if (!tp.active) { if (tid == 0) *out = ScanPre{0.f, 0.f, 0, 0u, 0.f, 0}; return; }
     const ScanItem it = a.items[item];
     const int K = a.K, L = tp.L, wl = K + L;
@@ -96,10 +97,12 @@ void k_scan_pre(const ScanPreArgs a) {
     const int padL = a.opt_iq ? a.ws_pad : 0;
     // LDS carve-up (halves / floats); every array starts on a 16-byte boundary
     const int NXH = (256 * nT1 + 32 * a.nc1 + 48 + 7) & ~7;
-    int NXF = 256 * nT2 + 32 * nc2 + 48; if (NXF < 256 * nT1) NXF = 256 * nT1; NXF = (NXF + 7) & ~7;
+    int NXF = 256 * nT2 + 32 * nc2 + 48; if (NXF < 256 * nT1 + 8) NXF = 256 * nT1 + 8; NXF = (NXF + 7) & ~7;
     _Float16 *xh = reinterpret_cast<_Float16 *>(sp_smem);                 // padL zeros, the window minus 0.98 dc, zeros
     _Float16 *xfh = xh + (a.opt_iq ? NXH : 0);                             // the filtered window, zeros behind it
-    float *P = reinterpret_cast<float *>(xfh + NXF);                       // P[SP_PI(i)] = sum_{q<i} xf[q]^2, i <= 256 nT1
+    float *P = reinterpret_cast<float *>(xfh + NXF);                       // P[i / 4] = sum_{q<i} xf[q]^2 for i = 0, 4, 8, .. 256 nT1 (the up to three squares between come from xfh)
+    const int NP4 = ((64 * nT1 + 1) + 3) & ~3;
+    _Float16 *sA = reinterpret_cast<_Float16 *>(P + NP4);                  // A fragments: the FM low-pass's nc1 steps, then the template's nc2 steps
     __shared__ float s_f[2 * SP_WAVES];
     __shared__ int s_i[SP_WAVES];
     __shared__ float s_dc;
@@ -117,6 +120,21 @@ void k_scan_pre(const ScanPreArgs a) {
         v[r] = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
         if (i >= K - L && i < wl) dcp += v[r];
     }
+    // A fragments -> registers now (their latency overlaps the window's), -> LDS behind the window
+    const int ncl = a.opt_iq ? a.nc1 : 0;                                 // steps of the FM low-pass, in front of the template's
+    const int nA = min(ncl + nc2, SP_ACAP);                               // steps of 1 KB = 64 uint4 staged now; a longer template reloads (below)
+    uint4 areg[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + SP_THREADS * q;                             // uint4 index into the concatenated fragment list
+        const int stp = idx >> 6;
+        areg[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (stp < nA) {
+            const bool lp = a.opt_iq && stp < a.nc1;
+            const uint16_t *src = lp ? a.a_ws + (size_t)tp.lpfm * a.nc1 * 512 + (size_t)stp * 512 : a.a_match + a.a_off[j] + (size_t)(stp - (a.opt_iq ? a.nc1 : 0)) * 512;
+            areg[q] = reinterpret_cast<const uint4 *>(src)[idx & 63];
+        }
+    }
     float dc = 0.f;
     if (a.opt_dc) {
         const float sw = sp_wsum(dcp);
@@ -126,6 +144,7 @@ void k_scan_pre(const ScanPreArgs a) {
         __syncthreads();
         dc = s_dc;
     }
+    SP_MARK(0);                                                           // window + A fragments requested, dc known
     const float dcs = 0.98f * dc;
     // The score c / sqrt(e) does not depend on the scale of the window, the f16 operands do: a window of a few LSB of FM audio (1 / 32768 = 3e-5) would
     // sit in f16's subnormals.  The window is therefore brought to [0.5, 1) by a power of two (exact) before the conversion, so that the rounding — and
@@ -151,14 +170,19 @@ void k_scan_pre(const ScanPreArgs a) {
     }
     for (int i = SP_CH * SP_THREADS + tid; i < ndst; i += SP_THREADS) dst[i] = (_Float16)0.f;
     if (a.opt_iq) for (int i = tid; i < padL; i += SP_THREADS) xh[i] = (_Float16)0.f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int idx = tid + SP_THREADS * q; if ((idx >> 6) < nA) reinterpret_cast<uint4 *>(sA)[idx] = areg[q]; }
     __syncthreads();
 
+    SP_MARK(1);                                                           // window scaled, converted, stored; A fragments stored
     const int n = lane & 15, g = lane >> 4;
     // ---- FM low-pass (X *= WS[lpFM], dft_detect.c:396-399): xf[i] = sum_t ws[t] xn'[i-t]; the constant -0.98 dc reaches every sample of the
     // reference's (circular, zero padded) array, so the first taps-1 outputs get the part of it the filter has not seen yet (ws_tail)
     if (a.opt_iq) {
         f32x4 acc[SP_MAXT];
-        sp_toeplitz(xh, a.a_ws + (size_t)tp.lpfm * a.nc1 * 512, a.nc1, wave, nT1, lane, acc);
+#pragma unroll
+        for (int t = 0; t < SP_MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sp_toeplitz(xh, sA, a.nc1, wave, nT1, lane, acc);
         const float *tail = a.ws_tail + tp.lpfm * a.taps;
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) {
@@ -180,6 +204,7 @@ void k_scan_pre(const ScanPreArgs a) {
         __syncthreads();
     }
 
+    SP_MARK(2);                                                           // FM low-pass
     // ---- prefix sums of xf^2 (the 2-norm under the template, dft_detect.c:431-433): thread t owns samples [16 t, 16 t + 16)
     {
         float run[SP_CH];
@@ -198,27 +223,50 @@ void k_scan_pre(const ScanPreArgs a) {
         float base = inc - s;
         for (int w = 0; w < wave; w++) base += s_f[SP_WAVES + w];
 #pragma unroll
-        for (int q = 0; q < SP_CH; q++) if (SP_CH * tid + q <= 256 * nT1) P[SP_PI(SP_CH * tid + q)] = base + run[q];     // P holds 256 nT1 + 1 sums
-        if (tid == SP_THREADS - 1 && 256 * nT1 == SP_CH * SP_THREADS) P[SP_PI(SP_CH * SP_THREADS)] = base + s;
+        for (int q = 0; q < SP_CH; q += 4) if (SP_CH * tid + q <= 256 * nT1) P[(SP_CH * tid + q) >> 2] = base + run[q];     // P holds 64 nT1 + 1 sums
+        if (tid == SP_THREADS - 1 && 256 * nT1 == SP_CH * SP_THREADS) P[(SP_CH * SP_THREADS) >> 2] = base + s;
         __syncthreads();
     }
 
+    SP_MARK(3);                                                           // prefix sums
     // ---- header correlation c'[p'] = sum_k match[k] xf[p'+k], p' = p - (L-1) in [0, K] (Z = X Fm, Nidft; arg-max range dft_detect.c:415)
     float bc = -1.f, bs = 0.f; int bp = 0x7fffffff; float bcv = 0.f;
     {
         f32x4 acc[SP_MAXT];
-        sp_toeplitz(xfh, a.a_match + a.a_off[j], nc2, wave, nT2, lane, acc);
+#pragma unroll
+        for (int t = 0; t < SP_MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int done = min(nc2, SP_ACAP - ncl);                             // steps staged at the start (SP_ACAP - ncl is even: both are)
+        sp_toeplitz(xfh, sA + (size_t)ncl * 512, done, wave, nT2, lane, acc);
+        while (done < nc2) {                                            // a template of more than ~900 taps: the next steps, one more round trip each time
+            const int take = min(nc2 - done, SP_ACAP);
+            __syncthreads();
+            for (int idx = tid; idx < 64 * take; idx += SP_THREADS)
+                reinterpret_cast<uint4 *>(sA)[idx] = reinterpret_cast<const uint4 *>(a.a_match + a.a_off[j] + (size_t)done * 512)[idx];
+            __syncthreads();
+            sp_toeplitz(xfh + 32 * done, sA, take, wave, nT2, lane, acc);
+            done += take;
+        }
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) {
             const int tile = wave + SP_WAVES * t;
             if (tile < nT2) {
-                const int p0 = 256 * tile + 16 * n + 4 * g;
+                const int p0 = 256 * tile + 16 * n + 4 * g;            // a multiple of 4: S(p0 + r) and S(p0 + L + r) from three 8-byte reads of xf
+                const int hb = (p0 + L) & ~3, ho = (p0 + L) & 3;
+                const half4 lo = *reinterpret_cast<const half4 *>(xfh + p0), h0 = *reinterpret_cast<const half4 *>(xfh + hb), h1 = *reinterpret_cast<const half4 *>(xfh + hb + 4);
+                float slo = P[p0 >> 2], shi = P[hb >> 2], sq[8];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const float u0 = (float)h0[q], u1 = (float)h1[q]; sq[q] = u0 * u0; sq[4 + q] = u1 * u1; }
+#pragma unroll
+                for (int q = 0; q < 3; q++) if (q < ho) shi += sq[q];      // S(p0 + L)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int p = p0 + r;
+                    const float e = shi - slo;
+                    { const float u = (float)lo[r]; slo += u * u; }
+#pragma unroll
+                    for (int q = 0; q < 7; q++) if (q == ho + r) shi += sq[q];
                     if (p <= K) {
                         const float c = acc[t][r], ac = fabsf(c);
-                        const float e = P[SP_PI(p + L)] - P[SP_PI(p)];
                         const float sc = e > 0.f ? ac * __builtin_amdgcn_rsqf(e) : 0.f;
                         if (sc > bs) bs = sc;
                         if (ac > bc || (ac == bc && p < bp)) { bc = ac; bp = p; bcv = c; }
@@ -227,6 +275,7 @@ void k_scan_pre(const ScanPreArgs a) {
             }
         }
     }
+    SP_MARK(4);                                                           // correlation, scores
     for (int off = 32; off > 0; off >>= 1) {
         const float oc = __shfl_xor(bc, off), ov = __shfl_xor(bcv, off), os = __shfl_xor(bs, off); const int op = __shfl_xor(bp, off);
         if (oc > bc || (oc == bc && op < bp)) { bc = oc; bp = op; bcv = ov; }
@@ -244,7 +293,7 @@ void k_scan_pre(const ScanPreArgs a) {
         }
         ScanPre r{bs, 0.f, -1, 0u, dc, 0};
         if (bp <= K && bc >= 0.f) {
-            const float e = P[SP_PI(bp + L)] - P[SP_PI(bp)];
+            const float e = sp_S(P, xfh, bp + L) - sp_S(P, xfh, bp);
             r.mv = e > 0.f ? bcv / sqrtf(e) : 0.f;
             const int mp = bp + L - 1;
             r.mp = (bp == 0 || bp == K) ? -4 : mp;                                 // edge value (dft_detect.c:424)
@@ -253,6 +302,8 @@ void k_scan_pre(const ScanPreArgs a) {
         }
         *out = r;
     }
+    SP_MARK(5);
+    if (a.prof && j == 1 && tid == 0) atomicAdd(a.prof + 7, 1ull);
 }
 
 extern "C" int sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s) {
@@ -262,8 +313,9 @@ extern "C" int sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s) {
     const int wl = a->K + maxL, nT1 = (wl + 255) >> 8, nT2 = (a->K + 1 + 255) >> 8;
     if (nT1 > SP_WAVES * SP_MAXT || 256 * nT1 > SP_CH * SP_THREADS) return -1;       // window longer than 8192 samples
     const size_t nxh = a->opt_iq ? (size_t)((256 * nT1 + 32 * a->nc1 + 48 + 7) & ~7) : 0;
-    size_t nxf = (size_t)256 * nT2 + 32 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1) nxf = (size_t)256 * nT1; nxf = (nxf + 7) & ~(size_t)7;
-    const size_t lds = 2 * (nxh + nxf) + 4 * (size_t)(SP_PI(256 * nT1) + 8);
+    size_t nxf = (size_t)256 * nT2 + 32 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1 + 8) nxf = (size_t)256 * nT1 + 8; nxf = (nxf + 7) & ~(size_t)7;
+    const size_t np4 = (size_t)(((64 * nT1 + 1) + 3) & ~3);
+    const size_t lds = 2 * (nxh + nxf) + 4 * np4 + 1024 * (size_t)SP_ACAP;
     static size_t attr = 0;
     if (lds > attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pre), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;

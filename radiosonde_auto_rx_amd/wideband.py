@@ -104,9 +104,9 @@ class WidebandReceiver:
             self.t += (len(x) // 2) / self.sr
             for s in list(self.sondes):
                 s["engine"].process_host(x)
-                before = s["frames"]
+                before = s.get("good", 0)
                 out += self._drain(s, False)
-                if s["frames"] != before:
+                if s.get("good", 0) != before:      # only frames that passed their check keep a channel alive
                     s["t_last"] = self.t
                     if s["type"] in ("LMS6", "LMSX"):
                         self._follow_lms(s)
@@ -127,13 +127,16 @@ class WidebandReceiver:
             out = []
             for h in e.fetch_hits(finish=finish):
                 s["frames"] += 1
-                out += FamilyDecoder.json_objects(s["telemetry"].hit(h, e.info["if_sr"]))
+                js = FamilyDecoder.json_objects(s["telemetry"].hit(h, e.info["if_sr"]))
+                s["good"] = s.get("good", 0) + (1 if js else 0)
+                out += js
             return out
         frames = e.fetch_dfm(finish=finish) if s["type"] == "DFM" else e.fetch_mxx(finish=finish) if s["type"] in ("M10", "M20") else e.fetch_frames(finish=finish)
         out = []
         for fr in frames:
             js = s["telemetry"].json(fr)
             s["frames"] += 1
+            s["good"] = s.get("good", 0) + int(_frame_valid(s["type"], fr))
             if js is not None:
                 out.append(js)
         return out
@@ -142,6 +145,18 @@ class WidebandReceiver:
         self.scanner.close()
         for s in self.sondes:
             s["engine"].close(); s["telemetry"].close()
+
+
+
+def _frame_valid(typ, fr):
+    """a frame that passed its own check — the Reed-Solomon code (RS41), all three Hamming blocks (DFM), the checksum (M10 / M20): only such
+    frames count as a sign of life when a receiver decides whether a channel has gone silent (the reference's decoders time out on the absence
+    of VALID telemetry; a false detection that keeps producing garbage hits must not hold a channel)"""
+    if typ == "DFM":
+        return all(e >= 0 for e in fr["ecc"])
+    if typ in ("M10", "M20"):
+        return bool(fr["cs_ok"])
+    return fr["ecc"] >= 0
 
 
 class ChannelizedReceiver:
@@ -250,8 +265,8 @@ class ChannelizedReceiver:
                 for slot, s in enumerate(g["owner"]):                             # channels that have gone silent go back to the pool
                     if s is None:
                         continue
-                    if s["frames"] != s["seen"]:
-                        s["seen"], s["t_last"] = s["frames"], self.t
+                    if s.get("good", 0) != s["seen"]:                              # only frames that passed their check keep a channel
+                        s["seen"], s["t_last"] = s.get("good", 0), self.t
                     elif self.t - s["t_last"] > self.idle_s:
                         g["engine"].finish_channel(slot)
                         out += self._drain(typ, g, False)                         # what the end of its stream still gave
@@ -299,7 +314,9 @@ class ChannelizedReceiver:
                 if s is None:
                     continue
                 s["frames"] += 1
-                out += FamilyDecoder.json_objects(s["telemetry"].hit(h, self.if_sr))
+                js = FamilyDecoder.json_objects(s["telemetry"].hit(h, self.if_sr))
+                s["good"] = s.get("good", 0) + (1 if js else 0)
+                out += js
             return out
         frames = e.fetch_dfm(finish=finish) if typ == "DFM" else e.fetch_mxx(finish=finish) if typ in ("M10", "M20") else e.fetch_frames(finish=finish)
         out = []
@@ -309,6 +326,7 @@ class ChannelizedReceiver:
                 continue
             js = s["telemetry"].json(fr)
             s["frames"] += 1
+            s["good"] = s.get("good", 0) + int(_frame_valid(typ, fr))
             if js is not None:
                 out.append(js)
         return out

@@ -291,24 +291,24 @@ def test_scan_imet_afsk_check(name):
     assert sc.result(0) % 256 == g["rc"]
 
 
-@pytest.mark.parametrize("variant", ["lsb", "lsb_dc", "big_offset"])
+@pytest.mark.parametrize("variant", ["tiny", "tiny_dc", "big_offset"])
 def test_scan_prefilter_at_extreme_input_levels(variant):
-    """FM audio a few LSB strong (1 / 32768 = 3e-5: f16 subnormals unless the prefilter scales its window), the same with --dc, and normal audio on
-    an offset of a third of full scale without --dc: the default mode finds exactly what the exact mode finds, and what it prints for a detection is
-    the exact kernel's value"""
+    """FM audio a millionth of full scale (float32 WAV samples of 1e-6: f16 subnormals unless the prefilter scales its window), the same with --dc, and
+    16-bit audio on an offset of a third of full scale without --dc: the default mode finds exactly what the exact mode finds, and what it prints for
+    a detection is the exact kernel's value (the reference's score is normalised: the level does not matter to it either)"""
     x, fq, _, case = scan_capture("scan_rs41_audio")
-    a = x.astype(np.float64)
-    if variant.startswith("lsb"):
-        a = np.round(a * (3.2 / np.abs(a).max()))                      # +-3 LSB
+    kw = {}
+    if variant.startswith("tiny"):
+        a = (x.astype(np.float32) / 32768.0 * 1e-6).astype(np.float32)
+        kw["bits"] = 32
     else:
-        a = a * 0.3 + 11000.0
-    a = np.clip(a, -32768, 32767).astype(np.int16)
-    case = dict(case, dc=(variant == "lsb_dc"))
+        a = np.clip(x.astype(np.float64) * 0.3 + 11000.0, -32768, 32767).astype(np.int16)
+    case = dict(case, dc=(variant == "tiny_dc"))
     out = {}
     for exact in (True, False):
-        sc = _scanner(case, fq, max_chunk=48000, exact=exact)
+        sc = _scanner(case, fq, max_chunk=48000, exact=exact, **kw)
         wins, dets = _feed(sc, a, 24000, 1)
         out[exact] = ([(d["type"], d["sample"], d["line"]) for d in dets], sc.result(0), len(wins))
     assert out[True] == out[False]
     if variant != "big_offset":
-        assert any(t == "RS41" for t, _, _ in out[True][0])             # the level does not matter to the reference's normalised score either
+        assert any(t == "RS41" for t, _, _ in out[True][0])

@@ -1,6 +1,7 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools import synth
 from radiosonde_auto_rx_amd.scan import Scanner
 SR = 2_400_000
