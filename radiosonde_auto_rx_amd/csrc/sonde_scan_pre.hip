@@ -135,6 +135,13 @@ void k_scan_pre(const ScanPreArgs a) {
             areg[q] = reinterpret_cast<const uint4 *>(src)[idx & 63];
         }
     }
+    // what the -0.98 dc constant loses in the filter's first taps-1 outputs (tile 0): requested now, used behind the low-pass
+    float tl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.opt_iq && wave == 0) {
+        const float *tail = a.ws_tail + tp.lpfm * a.taps;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int i = 16 * (lane & 15) + 4 * (lane >> 4) + r; if (i < a.taps - 1) tl[r] = tail[i]; }
+    }
     float dc = 0.f;
     if (a.opt_dc) {
         const float sw = sp_wsum(dcp);
@@ -183,7 +190,6 @@ void k_scan_pre(const ScanPreArgs a) {
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         sp_toeplitz(xh, sA, a.nc1, wave, nT1, lane, acc);
-        const float *tail = a.ws_tail + tp.lpfm * a.taps;
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) {
             const int tile = wave + SP_WAVES * t;
@@ -194,7 +200,7 @@ void k_scan_pre(const ScanPreArgs a) {
                 for (int r = 0; r < 4; r++) {
                     const int i = i0 + r;
                     float x = acc[t][r];
-                    if (i < a.taps - 1) x -= dcs * wscale * tail[i];
+                    if (t == 0 && wave == 0) x -= dcs * wscale * tl[r];      // (taps - 1 <= 256: tile 0 only; tl is 0 from taps - 1 on)
                     h[r] = (_Float16)((i < wl) ? x : 0.f);
                 }
                 *reinterpret_cast<half4 *>(xfh + i0) = h;
