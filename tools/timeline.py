@@ -8,7 +8,21 @@ import sqlite3
 import sys
 
 
+def dump_tail(path, n):
+    """the last n dispatches with start / end relative to the first of them (any kernels: `timeline.py <db> --tail N`)"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else "0"
+    rows = list(db.execute(f"select name, start, end, {qcol}, grid_x from kernels order by start"))[-n:]
+    t0 = rows[0][1]
+    print(f"{'start':>9s} {'end':>9s} {'dur':>8s} {'queue':>6s}  kernel")
+    for r in rows:
+        print(f"{(r[1] - t0) / 1e3:9.1f} {(r[2] - t0) / 1e3:9.1f} {(r[2] - r[1]) / 1e3:8.1f} {str(r[3]):>6s}  {r[0].split('(')[0].replace('void ', '')[:40]} grid={r[4]}")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[2] == "--tail":
+        return dump_tail(sys.argv[1], int(sys.argv[3]))
     db = sqlite3.connect(sys.argv[1])
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     count = int(sys.argv[3]) if len(sys.argv) > 3 else 4
