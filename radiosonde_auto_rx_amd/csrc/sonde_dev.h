@@ -126,7 +126,10 @@ struct WinFftArgs {
     int n_ch, stride, W, K, L, ring_len;
     const uint32_t *work, *work_count; int round_parity;
     unsigned long long *prof; // SONDE_WF_PROF: cycles per phase of workgroup 0 (nullptr = off)
+    int small_wg;             // the half-array form of the transform (39 KB of LDS, 256 threads): fits the slot of one decimator workgroup
+    float2 *park;             // small_wg: [SONDE_WFH_MAXGRID][8192] per-workgroup parking array in global memory (L2-resident): the half that waits
 };
+#define SONDE_WFH_MAXGRID 768
 
 struct CorrArgs {
     const float *bufs; float *corr; const float *match;

@@ -96,6 +96,8 @@ struct sonde_engine {
     std::vector<char> m10_bits;                    // M10: gpx.frame_bits per channel (persists between frames like the reference's)   // [n_ch][518] gpx.frame of the reference persists across frames
     bool overflow = false;
     bool in_call = false, ecc_listed = false;   // inside sonde_engine_process_device; a frame sync of this call was given a work list
+    float2 *d_park = nullptr;          // parking arrays of k_sync_window_fft_h
+    bool small_tail = false;           // header search and frame sync in workgroups that fit the slot of one decimator workgroup (two-stream engines)
     bool dev_ecc = true;               // rs41_ecc() of whole frames in k_framesync (SONDE_HOST_ECC=1: on the host from the device syndromes, the A/B switch)
     long long host_ecc_frames = 0;     // frames whose RS decoder ran on the host (fetch_rs41)
     bool m10_chk3 = false;                         // m10mod --chk3 (sonde_engine_set_m10_chk3)
@@ -395,6 +397,12 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     if (bad) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
     HIPCHK(hipMemcpy(e->d_match, e->match.data(), L * sizeof(float), hipMemcpyHostToDevice));
     e->dev_ecc = getenv("SONDE_HOST_ECC") == nullptr;
+    {   // SONDE_SMALL_TAIL=1: header search and frame sync in workgroups of the size of one decimator workgroup (k_sync_window_fft_h, k_framesync<.., 256>).
+        // With them the whole IF-rate tail does run beside the next call's decimator — and the decimator slows down by as much as the tail takes
+        // (profiles/r4k_*: 1.35 ms per step either way), so the plain forms stay the default; kept as the measurement's other arm, parity-tested
+        const char *st = getenv("SONDE_SMALL_TAIL");
+        e->small_tail = st && atoi(st) != 0;
+    }
     {   // Fm = rdft(time-reversed match) with the reference's transform (init_buffers, demod_mod.c:1446-1449); N = 8192 only
         static const bool no_fft = getenv("SONDE_NO_FFTSYNC") != nullptr;        // A/B aid: time-domain correlation ring
         if (!cfg->opt_dc && M == 8192 && K + L <= M && !no_fft) {
@@ -574,7 +582,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->stream_c) hipStreamDestroy(e->stream_c);
     if (e->stream_e) hipStreamDestroy(e->stream_e);
     if (e->ev_s) hipEventDestroy(e->ev_s);
-    hipFree(e->d_ecc_list); hipFree(e->d_ecc_cnt);
+    hipFree(e->d_ecc_list); hipFree(e->d_ecc_cnt); hipFree(e->d_park);
     for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); if (e->ev_if[i]) hipEventDestroy(e->ev_if[i]); }
     if (e->ev_copy) hipEventDestroy(e->ev_copy);
     if (e->h_pending) hipHostFree(e->h_pending);
@@ -828,7 +836,8 @@ static void sync_round(sonde_engine *e, int W) {
     p.work = e->d_work; p.work_count = e->d_work_count; p.round_parity = e->sync_rounds & 1;
     WinFftArgs f{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
     f.K = e->info.K; f.L = e->info.L; f.ring_len = e->ring_len;
-    f.work = e->d_work; f.work_count = e->d_work_count; f.round_parity = e->sync_rounds & 1;
+    f.work = e->d_work; f.work_count = e->d_work_count; f.round_parity = e->sync_rounds & 1; f.small_wg = e->small_tail; f.park = e->d_park;
+    if (f.small_wg && !e->d_park) { if (hipMalloc((void **)&e->d_park, (size_t)SONDE_WFH_MAXGRID * 8192 * sizeof(float2)) != hipSuccess) f.small_wg = 0; f.park = e->d_park; }
     static const bool want_prof = getenv("SONDE_WF_PROF") != nullptr;          // profiling aid: cycles per phase of workgroup 0, printed when the engine is destroyed
     if (want_prof && !e->d_wfprof) { if (hipMalloc((void **)&e->d_wfprof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(e->d_wfprof, 0, 32 * sizeof(unsigned long long)); }
     f.prof = e->d_wfprof;
@@ -849,7 +858,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.bufs = e->d_bufs; s.corr = e->d_corr; s.state = e->d_state; s.frames = e->d_frames; s.frame_count = e->d_fcount; s.soft = e->d_soft; s.soft1 = e->d_soft1;
     s.hdr = e->d_consts; s.hdr_bytes = e->d_consts + 64; s.mask = e->d_consts + 72; s.gf_exp = e->d_consts + 136; s.gf_log = e->d_consts + 648;
     s.bitwin = e->d_bitwin; s.bitend = e->d_bitend;
-    { static const bool small = getenv("SONDE_FS_SMALL") != nullptr; s.small_wg = small && !e->cfg.opt_dc; }      // A/B aid
+    s.small_wg = e->small_tail && !e->cfg.opt_dc;
     s.n_ch = C; s.ring_len = e->ring_len; s.max_frames = e->max_frames; s.avail = e->m_out;
     s.K = e->info.K; s.L = e->info.L; s.delay = e->info.delay; s.hdrlen = e->hdrlen; s.symhd = e->symhd; s.symlen = e->symlen;
     s.hdmax = e->hdmax; s.bitofs = e->bitofs; s.nbits = e->nbits; s.frame_samples = e->frame_samples;

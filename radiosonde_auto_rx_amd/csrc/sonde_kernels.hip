@@ -1994,6 +1994,193 @@ void k_sync_window_fft(const WinFftArgs a) {
         sync_eval_window(a, (int)(item / (uint32_t)a.stride), a.items + item, x, tws, s_rf, s_ri);
     }
 }
+// ---- the same window transform in HALF the LDS (round 4): a decimation-in-time network on bit-reversed input never mixes the two halves of its
+// array before the last stage (stage s pairs i with i + 2^s inside blocks of 2^(s+1) <= 4096 for s <= 11).  So the half [0, 4096) — the EVEN window
+// samples — goes through stages 0..11 in a 4096-point array, its results wait in registers (8 per thread), the half [4096, 8192) — the odd samples —
+// follows in the same array, and the last stage combines registers with LDS.  35 KB + 4 KB of twiddles instead of 74 KB; with 256 threads (sixteen butterflies of the last
+// stage each, <= 168 registers) the workgroup fits the slot ONE decimator workgroup frees (51 KB, a wave per SIMD), which is what lets the header
+// search run beside the next call's decimator instead of waiting for it to drain.  Every butterfly is the same cmul / add / sub on
+// the same operands with the same twiddle as in dft_ref: scores and positions identical to the bit.
+#define WFH_THREADS 256               // four waves, one per SIMD at <= 168 registers: exactly the slot of one decimator workgroup
+#define SCH_N (SC_N / 2)
+#define SCH_XN (SCH_N + SCH_N / 16 + SCH_N / 256)
+template <int R>
+__device__ __forceinline__ void dit_pass_h(float2 *x, const float2 *tws, const int t0, const int tid) {
+    constexpr int E = 1 << R;
+    const int p_lo = t0;
+#pragma unroll 1
+    for (int g = tid; g < (SCH_N >> R); g += WFH_THREADS) {
+        const int low = g & ((1 << p_lo) - 1), high = g >> p_lo;
+        const int base = (high << (p_lo + R)) | low;
+        float2 v[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) v[e] = x[XI(base + (e << p_lo))];
+#pragma unroll
+        for (int s2 = 0; s2 < R; s2++) {
+            const int t = t0 + s2, bit = 1 << s2;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (e & bit) continue;
+                const int idx = base + (e << p_lo);
+                const float2 w = tws[((1 << t) - 1) + (idx & ((1 << t) - 1))];
+                const float2 p = v[e], r = cmul(v[e | bit], w);
+                v[e] = make_float2(p.x + r.x, p.y + r.y);
+                v[e | bit] = make_float2(p.x - r.x, p.y - r.y);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; e++) x[XI(base + (e << p_lo))] = v[e];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void dft_half(float2 *x, const float2 *tws, const float2 *tws_g, const int tid) {      // stages 0..11 of one half
+    dit_pass_h<3>(x, tws, 0, tid);
+    dit_pass_h<3>(x, tws, 3, tid);
+    dit_pass_h<3>(x, tws, 6, tid);
+    dit_pass_h<3>(x, tws_g, 9, tid);
+}
+__device__ __forceinline__ int brev12(int k) { return (int)(__brev((unsigned)k) >> 20); }
+
+// the parking array is written by one thread and read by another of the same workgroup (and re-used window after window): device-scope accesses,
+// so that a read never hits a line an earlier window left in the CU's L1
+__device__ __forceinline__ float2 park_ld(const float2 *p) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ __forceinline__ void park_st(float2 *p, const float2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sync_eval_window_h(const WinFftArgs &a, const int ch, WinItem *it, float2 *x, float2 *tws, float *s_rf, int *s_ri, float2 *park) {
+    constexpr int NU = SCH_N / WFH_THREADS;      // 16: butterflies of the last stage per thread, g = tid + WFH_THREADS u
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (it->state != 1) return;
+    const int K = a.K, L = a.L, N = SC_N, wl = K + L;
+    const uint32_t pos = it->pos, mask = (uint32_t)a.ring_len - 1;
+    const float *bufs = a.bufs + (size_t)ch * a.ring_len;
+    const int64_t start = (int64_t)pos - (wl - 1);
+    // xn[i] = bufs[pos - (K+L-1) + i], i < K+L, zero padded (:168-169).  Slot brev12(k) of the even half holds xn[2k], of the odd half xn[2k+1].
+    for (int par = 0; par < 2; par++) {
+        float v[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int i = 2 * (tid + WFH_THREADS * u) + par;
+            const int64_t p = start + i;
+            v[u] = (i < wl && p >= 0) ? bufs[(uint32_t)p & mask] : 0.f;
+        }
+        if (par == 1) {                                                  // the even half's results wait in the parking array while the odd half uses the LDS
+#pragma unroll 4
+            for (int u = 0; u < NU; u++) park_st(park + tid + WFH_THREADS * u, x[XI(tid + WFH_THREADS * u)]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) x[XI(brev12(tid + WFH_THREADS * u))] = make_float2(v[u], 0.f);
+        __syncthreads();
+        dft_half(x, tws, a.tws, tid);
+    }
+    // last stage of X = rdft(xn), then Z = X * Fm (:190) and conj(Z) as the natural-order input of Nidft's transform (:78-80), parked in natural order:
+    // park[n] = conj(Z[n]); element n goes to slot brev13(n) of that transform: even n to its even half (slot brev12(n / 2)), odd n to its odd half
+#pragma unroll 2
+    for (int u = 0; u < NU; u++) {
+        const int g = tid + WFH_THREADS * u;
+        const float2 w = a.tws[((1 << 12) - 1) + g];
+        const float2 p = park_ld(park + g), r = cmul(x[XI(g)], w);
+        const float2 x0 = make_float2(p.x + r.x, p.y + r.y), x1 = make_float2(p.x - r.x, p.y - r.y);
+        const float2 q0 = cmul(x0, a.Fm[g]), q1 = cmul(x1, a.Fm[g + SCH_N]);
+        park_st(park + g, make_float2(q0.x, -q0.y)); park_st(park + g + SCH_N, make_float2(q1.x, -q1.y));       // (g is read and written by this thread only)
+    }
+    __syncthreads();
+    for (int par = 0; par < 2; par++) {
+        if (par == 1) {
+            // the even half's results: into the (now free) even-n places of the parking array
+            float2 t[4];
+#pragma unroll 1
+            for (int u0 = 0; u0 < NU; u0 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) t[q] = x[XI(tid + WFH_THREADS * (u0 + q))];
+#pragma unroll
+                for (int q = 0; q < 4; q++) park_st(park + 2 * (tid + WFH_THREADS * (u0 + q)), t[q]);
+            }
+            __syncthreads();
+        }
+        float2 v2[4];
+#pragma unroll 1
+        for (int u0 = 0; u0 < NU; u0 += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) v2[q] = park_ld(park + 2 * (tid + WFH_THREADS * (u0 + q)) + par);
+#pragma unroll
+            for (int q = 0; q < 4; q++) x[XI(brev12(tid + WFH_THREADS * (u0 + q)))] = v2[q];
+        }
+        __syncthreads();
+        dft_half(x, tws, a.tws, tid);
+    }
+    // last stage in registers: only re(cx) is looked at — the arg-max of re(cx)^2 over i in [L-1, K+L), first maximum wins (:200-207)
+    float best = 0.f, bestc = 0.f; int bidx = -1;
+#pragma unroll 4
+    for (int u = 0; u < NU; u++) {
+        const int g = tid + u * WFH_THREADS;
+        const float2 w = a.tws[((1 << 12) - 1) + g];
+        const float2 p = park_ld(park + 2 * g), r = cmul(x[XI(g)], w);
+        const float c0 = p.x + r.x, c1 = p.x - r.x;
+        const int i0 = g, i1 = g + (1 << 12);
+        if (i0 >= L - 1 && i0 < wl) { const float c2 = c0 * c0; if (c2 > best || (c2 == best && bidx >= 0 && i0 < bidx)) { best = c2; bidx = i0; bestc = c0; } }
+        if (i1 >= L - 1 && i1 < wl) { const float c2 = c1 * c1; if (c2 > best || (c2 == best && bidx >= 0 && i1 < bidx)) { best = c2; bidx = i1; bestc = c1; } }
+    }
+    {
+        float rb = best; int ri = bidx;
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(rb, off); const int oi = __shfl_xor(ri, off);
+            if (ob > rb || (ob == rb && oi >= 0 && (ri < 0 || oi < ri))) { rb = ob; ri = oi; }
+        }
+        if (lane == 0) { s_rf[wave] = rb; s_ri[wave] = ri; }
+    }
+    __syncthreads();
+    int mp = -1;
+    {
+        float b = 0.f;
+        for (int w = 0; w < WFH_THREADS / WAVE; w++) {
+            const float ob = s_rf[w]; const int oi = s_ri[w];
+            if (ob > b || (ob == b && oi >= 0 && (mp < 0 || oi < mp))) { b = ob; mp = oi; }
+        }
+    }
+    __syncthreads();
+    if (mp < 0 || mp == L - 1 || mp == wl - 1) {                          // nothing above zero / edge value: -4 (:208)
+        if (tid == 0) { it->rc = -4; it->mv = 0.f; it->mpos = 0; __threadfence(); it->state = 2; }
+        return;
+    }
+    float e = 0.f;
+    for (int k = tid; k < L; k += WFH_THREADS) {                          // xnorm = sqrt(sum_{i<L} xn[mp-i]^2) (:215-217)
+        const int i = mp - k; const int64_t p2 = start + i;
+        const float v = (i < wl && p2 >= 0) ? bufs[(uint32_t)p2 & mask] : 0.f;
+        e += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+    if (lane == 0) s_rf[wave] = e;
+    if (bidx == mp) s_rf[WFH_THREADS / WAVE] = bestc;
+    __syncthreads();
+    if (tid == 0) {
+        float es = 0.f;
+        for (int w = 0; w < WFH_THREADS / WAVE; w++) es += s_rf[w];
+        const float xnorm = sqrtf(es);
+        it->rc = mp; it->mv = s_rf[WFH_THREADS / WAVE] / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
+        __threadfence(); it->state = 2;
+    }
+}
+__global__ __launch_bounds__(WFH_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_sync_window_fft_h(const WinFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem2[];
+    float2 *x = smem2;                           // [SCH_XN] padded (XI): one half of the transform's array at a time
+    float2 *tws = smem2 + SCH_XN;                // [SC_TW_LDS + 1] twiddles of stages 0..8
+    __shared__ float s_rf[WFH_THREADS / WAVE + 1];
+    __shared__ int s_ri[WFH_THREADS / WAVE];
+    const uint32_t count = a.work_count[a.round_parity];
+    if (blockIdx.x >= count) return;
+    for (int k = threadIdx.x; k < SC_TW_LDS; k += WFH_THREADS) tws[k] = a.tws[k];
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint32_t item = a.work[w];
+        __syncthreads();
+        sync_eval_window_h(a, (int)(item / (uint32_t)a.stride), a.items + item, x, tws, s_rf, s_ri, a.park + (size_t)blockIdx.x * SC_N);
+    }
+}
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------------------
@@ -2147,7 +2334,13 @@ extern "C" void sonde_launch_sync_plan(const WinPlanArgs *a, hipStream_t s) {
 }
 extern "C" void sonde_launch_sync_window_fft(const WinFftArgs *a, hipStream_t s) {
     const size_t lds = (size_t)(SC_XN + SC_TW_LDS + 1) * sizeof(float2);
-    int grid = a->W * a->n_ch; if (grid > 512) grid = 512;      // two waves of workgroups on 256 CUs at most; the kernel strides over the list
+    int grid = a->W * a->n_ch;
+    if (a->small_wg) {                                          // the half-array form: fits the slot of one decimator workgroup (three per CU)
+        if (grid > SONDE_WFH_MAXGRID) grid = SONDE_WFH_MAXGRID;
+        hipLaunchKernelGGL(k_sync_window_fft_h, dim3(grid), dim3(WFH_THREADS), (size_t)(SCH_XN + SC_TW_LDS + 1) * sizeof(float2), s, *a);
+        return;
+    }
+    if (grid > 512) grid = 512;                                 // two waves of workgroups on 256 CUs at most; the kernel strides over the list
     hipLaunchKernelGGL(k_sync_window_fft, dim3(grid), dim3(WF_THREADS), lds, s, *a);
 }
 // rs41_ecc() of the frames k_framesync put on its work list (records with ecc_done == 2): one workgroup of four waves per frame — small enough

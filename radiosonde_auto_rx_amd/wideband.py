@@ -104,12 +104,12 @@ class WidebandReceiver:
             self.t += (len(x) // 2) / self.sr
             for s in list(self.sondes):
                 s["engine"].process_host(x)
-                before = s.get("good", 0)
+                before, hits = s.get("good", 0), s["frames"]
                 out += self._drain(s, False)
+                if s["frames"] != hits and s["type"] in ("LMS6", "LMSX"):     # any block tells what the sonde is, accepted or not
+                    self._follow_lms(s)
                 if s.get("good", 0) != before:      # only frames that passed their check keep a channel alive
                     s["t_last"] = self.t
-                    if s["type"] in ("LMS6", "LMSX"):
-                        self._follow_lms(s)
                 elif self.t - s["t_last"] > self.idle_s:      # silent for too long: give the engine back
                     out += self._drain(s, True)
                     s["engine"].close(); s["telemetry"].close()
