@@ -323,3 +323,34 @@ def test_fetching_again_behind_an_ended_channel_returns_nothing():
     assert eng.fetch_frames() == [] and eng.fetch_frames() == []
     assert eng.overflowed() is False
     eng.close()
+
+
+def test_slot_sized_sync_kernels_give_identical_frames(monkeypatch):
+    """SONDE_SMALL_TAIL=1: the header search's window transform in half the LDS (two 4096-point halves, the waiting half parked in global memory) and the
+    256-thread frame sync — same butterflies on the same operands: header scores, positions, soft bits and frames identical to the bit"""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    sr = 480_000
+    fqs = [synth.snap_fq(f, sr) for f in (-0.21, 0.07, 0.33)]
+    caps = [synth.rs41_capture(sr=sr, seconds=3.3, fq=fq, seed=70 + k, noise_sigma=0.05 + 0.1 * k, bit_errors=5 * k, t_first=0.1 + 0.23 * k) for k, fq in enumerate(fqs)]
+    n = min(len(c) for c in caps) // 2 // 10 * 10
+    x = np.stack([c[:2 * n] for c in caps])
+
+    def run():
+        eng = Engine(fqs, sr, ecc=2, max_chunk=sr, keep_soft=True)
+        out = []
+        for pos in range(0, n, sr):
+            take = min(sr, n - pos) // 10 * 10
+            eng.process_host(np.ascontiguousarray(x[:, 2 * pos:2 * (pos + take)]))
+            out += eng.fetch_frames(with_soft=True)
+        out += eng.fetch_frames(with_soft=True, finish=True)
+        eng.close()
+        return sorted(out, key=lambda f: (f["channel"], f["mv_pos"]))
+
+    a = run()
+    monkeypatch.setenv("SONDE_SMALL_TAIL", "1")
+    b = run()
+    assert len(a) == len(b) >= 9
+    for fa, fb in zip(a, b):
+        assert (fa["channel"], fa["mv_pos"], fa["line"], fa["ecc"]) == (fb["channel"], fb["mv_pos"], fb["line"], fb["ecc"])
+        assert fa["mv"] == fb["mv"] and np.array_equal(fa["soft"], fb["soft"])
