@@ -998,7 +998,7 @@ int sonde_scan_toeplitz_model(const float *h, int32_t n_taps, const float *x, in
         for (int c = 0; c < nc; c++)
             for (int g = 0; g < 4; g++)
                 for (int r = 0; r < 8; r++) {                       // D[b][n] += A[b][k] B[k][n], k = 8 g + r, lane of A = b + 16 g
-                    const int idx = 16 * (a + c) + 8 * g + r;
+                    const int idx = 16 * a + 32 * c + 8 * g + r;             // A_c[b][e] = h[32 c + e - b], e = 8 g + r: x index = 16 a + b + u
                     const float xv = idx < n_x ? (float)(_Float16)x[idx] : 0.f;
                     acc += f16(fr[((size_t)c * 64 + (size_t)(b + 16 * g)) * 8 + r]) * xv;
                 }

@@ -68,7 +68,7 @@ def test_toeplitz_fragment_tables(n_taps, n_out):
     x = rng.standard_normal(n_out + n_taps + 40).astype(np.float32)
     out = np.zeros(n_out, np.float32)
     nc = L.sonde_scan_toeplitz_model(h.ctypes.data, n_taps, x.ctypes.data, len(x), out.ctypes.data, n_out)
-    assert nc == ((n_taps + 15) // 16 + 3) // 4 * 4           # whole blocks of 4 steps, zero padded
+    assert nc == (((n_taps + 15 + 31) // 32 + 1) & ~1)        # full fragments (32 taps a step), whole blocks of 2 steps, zero padded
     h16, x16 = h.astype(np.float16).astype(np.float64), x.astype(np.float16).astype(np.float64)
     want = np.array([np.dot(h16, x16[i:i + n_taps]) for i in range(n_out)])
     assert np.abs(out - want).max() < 2e-5 * max(1.0, np.abs(want).max())
