@@ -2310,21 +2310,29 @@ __device__ __forceinline__ void sync_eval_window_h(const WinFftArgs &a, const in
         if (tid == 0) { it->rc = -4; it->mv = 0.f; it->mpos = 0; __threadfence(); it->state = 2; }
         return;
     }
-    float e = 0.f;
-    for (int k = tid; k < L; k += WFH_THREADS) {                          // xnorm = sqrt(sum_{i<L} xn[mp-i]^2) (:215-217)
-        const int i = mp - k; const int64_t p2 = start + i;
-        const float v = (i < wl && p2 >= 0) ? bufs[(uint32_t)p2 & mask] : 0.f;
-        e += v * v;
+    // xnorm = sqrt(sum_{i<L} xn[mp-i]^2) (:215-217), added up in k_sync_window_fft's order so that the header score is the same float: a thread keeps the
+    // partial sums of the WF_THREADS / WFH_THREADS threads of that kernel it stands for (same lane, waves wave + 4 j) apart
+    constexpr int NV = WF_THREADS / WFH_THREADS;
+    static_assert(WF_THREADS % WFH_THREADS == 0, "the energy sum follows k_sync_window_fft's partition");
+    float e[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        e[j] = 0.f;
+        for (int k = tid + j * WFH_THREADS; k < L; k += WF_THREADS) {
+            const int i = mp - k; const int64_t p2 = start + i;
+            const float v = (i < wl && p2 >= 0) ? bufs[(uint32_t)p2 & mask] : 0.f;
+            e[j] += v * v;
+        }
+        for (int off = 32; off > 0; off >>= 1) e[j] += __shfl_xor(e[j], off);
+        if (lane == 0) s_rf[wave + j * (WFH_THREADS / WAVE)] = e[j];
     }
-    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
-    if (lane == 0) s_rf[wave] = e;
-    if (bidx == mp) s_rf[WFH_THREADS / WAVE] = bestc;
+    if (bidx == mp) s_rf[WF_THREADS / WAVE] = bestc;
     __syncthreads();
     if (tid == 0) {
         float es = 0.f;
-        for (int w = 0; w < WFH_THREADS / WAVE; w++) es += s_rf[w];
+        for (int w = 0; w < WF_THREADS / WAVE; w++) es += s_rf[w];
         const float xnorm = sqrtf(es);
-        it->rc = mp; it->mv = s_rf[WFH_THREADS / WAVE] / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
+        it->rc = mp; it->mv = s_rf[WF_THREADS / WAVE] / (xnorm * (float)N); it->mpos = pos - (uint32_t)(wl - 1) + (uint32_t)mp;
         __threadfence(); it->state = 2;
     }
 }
@@ -2333,7 +2341,7 @@ void k_sync_window_fft_h(const WinFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 smem2[];
     float2 *x = smem2;                           // [SCH_XN] padded (XI): one half of the transform's array at a time
     float2 *tws = smem2 + SCH_XN;                // [SC_TW_LDS + 1] twiddles of stages 0..8
-    __shared__ float s_rf[WFH_THREADS / WAVE + 1];
+    __shared__ float s_rf[WF_THREADS / WAVE + 1];
     __shared__ int s_ri[WFH_THREADS / WAVE];
     const uint32_t count = a.work_count[a.round_parity];
     if (blockIdx.x >= count) return;

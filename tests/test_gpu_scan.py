@@ -326,4 +326,4 @@ def test_scan_one_pass_front_end_equals_two_pass(monkeypatch):
         sc = _scanner(case, fq, max_chunk=2_400_000, exact=True)
         wins, dets = _feed(sc, x, chunk, 2)
         _check_windows(wins, g)
-        assert "".join(d["line"] + "\\n" for d in dets) == g["stdout"]
+        assert "".join(d["line"] + "\n" for d in dets) == g["stdout"]
