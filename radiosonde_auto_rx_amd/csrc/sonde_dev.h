@@ -24,9 +24,6 @@ struct MixDecArgs {
     int ring_len;
     uint32_t m0;              // IF index of the chunk's first output
     const float *wtab_g;      // D > 64: [D][8] tap table in global memory, and the piece length DS (divides D, <= 64)
-    // k_mix_decimate50w (one workgroup per channel walks the IQ-DC windows of the call in order): dc_seg_off / dc_seg_blocks say where the windows lie,
-    // dc_avg / dc_avg_prev / dc_sums / dc_since carry the state in, dc_avg_w / dc_avg_prev_w / dc_sums carry it out
-    float dc_maxcnt; float2 *dc_avg_w, *dc_avg_prev_w; int per_channel_windows;
     int wtab_scaled;          // wtab_g holds a second table behind the first 64 rows: the tap rows * 2^-15 (the generated D = 50 kernels read it)
     int DS;
     int phase_f64;            // mixer phase f0*n kept in double (dft_detect.c:1090) instead of the float of demod_mod.c:1290
@@ -194,8 +191,6 @@ void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapped, hipStre
 void sonde_launch_dc_update_pcs(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, uint32_t *cnt, uint32_t *max, uint32_t lim, int32_t *since,
                                 uint32_t n_samples, int nblocks, hipStream_t s);
 void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);
-void sonde_launch_md_etable64(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);      // double-phase table (the scanner's)
-int  sonde_launch_mix_decimate50w(const MixDecArgs *a, hipStream_t s);
 void sonde_launch_if_chain(const IfArgs *a, hipStream_t s);
 void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s);
 void sonde_launch_dc_segments_f32(const float2 *x, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,

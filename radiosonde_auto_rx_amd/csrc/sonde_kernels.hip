@@ -144,10 +144,6 @@ __device__ __forceinline__ void md_rows(const uint32_t *row, int D, const float 
 __device__ __forceinline__ void md_fast_tile(uint32_t row_lds, const float *wt, double f0, double T, float2v msk, float2v (&acc)[7], float2v &dcs) {
     MD_FAST_ASM(MD_FAST_BODY_1);
 }
-// MD_FAST_BODY_P: md_fast_tile with the mixer phase kept in double (dft_detect.c:1090-1093), IQ-DC folded out per output
-__device__ __forceinline__ void md_fast_tile_p(uint32_t row_lds, const float *wt, double f0, double T, float2v msk, float2v (&acc)[7], float2v &dcs) {
-    MD_FAST_ASM(MD_FAST_BODY_P);
-}
 // the scanner's form (MD_FAST_BODY_S): double mixer phase; navg = -32768 * the IQ-DC mean of the lane's row, taken off every sample
 __device__ __forceinline__ void md_fast_tile_s(uint32_t row_lds, const float *wt, double f0, double T, float2v navg, float2v (&acc)[7]) {
     float2v dcs = navg;
@@ -175,11 +171,6 @@ __device__ __forceinline__ float2 md_phasor(double f0, uint32_t n) {
     const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
     return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
 }
-// the scanner's table: ex[n] = cexp(2 pi i f0 n) with the phase in double, reduced before the single rounding (dft_detect.c:1090-1093)
-__device__ __forceinline__ float2 md_phasor64(double f0, uint32_t n) {
-    const float fr = (float)__builtin_amdgcn_fract(f0 * (double)n);
-    return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
-}
 // table index of the launch's first sample / blocks since the last change of the IQ-DC mean, for a channel that may have been restarted at run time
 __device__ __forceinline__ uint32_t md_lut_phase(const MixDecArgs &a, int ch) {
     if (!a.epoch_phase) return a.lut_phase;
@@ -191,7 +182,7 @@ __device__ __forceinline__ int md_dc_since(const MixDecArgs &a, int ch) { return
 // k_md_etable: E[ch][i] = sum_{q<Q} sum_{r<D} W_q[r] ex[D ((i-(Q-1)+q) mod P) + r], i < P = lut_len / D: the decimator's output for
 // the input x = 1 when the block that completes the output is block i of the mixer table's period.  Once per engine.
 __global__ __launch_bounds__(256)
-void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, float2 *etab, int ph64) {
+void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, float2 *etab) {
     const int ch = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const double f0 = chan_f0[ch];
@@ -199,7 +190,7 @@ void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, 
     for (int q = 0; q < Q; q++) {
         const uint32_t n0 = (uint32_t)D * (uint32_t)((i - (Q - 1) + q + P) % P);
         for (int r = 0; r < D; r++) {
-            const float2 e = ph64 ? md_phasor64(f0, n0 + (uint32_t)r) : md_phasor(f0, n0 + (uint32_t)r);
+            const float2 e = md_phasor(f0, n0 + (uint32_t)r);
             const float w = wtab[8 * r + q];
             er = fmaf(w, e.x, er); ei = fmaf(w, e.y, ei);
         }
@@ -478,160 +469,6 @@ void k_mix_decimate50s(const MixDecArgs a) {
 #pragma unroll
             for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
         }
-    }
-}
-
-// k_mix_decimate50w — the scanner's base-rate front end in ONE pass over the input (round 4).  dft_detect takes the mean of the PREVIOUS 1/32 s window off
-// every sample (dft_detect.c:539-588), so inside one launch window k+1 cannot be mixed before window k has been summed up: k_mix_decimate50s runs behind a pass
-// of its own that does nothing but add (k_dc_seg_sums: the input is read twice).  Here ONE workgroup owns a channel and walks its windows in order — four waves
-// share a window's 1500 blocks — with the IQ-DC folded out per OUTPUT like the demodulator's decimator (y -= mean * E, E from the double-phase table; the first
-// Q-1 outputs of a window mix two means: md_dc_boundary_w), so the sample loop needs no mean at all and adds the window's sums as it goes (MD50_LOOP_P);
-// at the end of a window the waves meet, the sums become the next window's mean (the arithmetic of k_dc_seg_means / k_dc_update), and on they go.
-// 512 channels = 512 workgroups of 768 slots: two waves per SIMD instead of three — measured against the two-pass form in profiles/r4*_scan_front_end*.
-#define MD50W_ASM(BODY) asm volatile(BODY \
-        : [o0] "=v"(acc[0]), [o1] "=v"(acc[1]), [o2] "=v"(acc[2]), [o3] "=v"(acc[3]), [o4] "=v"(acc[4]), [o5] "=v"(acc[5]), [o6] "=v"(acc[6]), \
-          [carry] "+v"(carry), [e] "+v"(eidx), [sx] "+v"(sx), [sy] "+v"(sy), [jrow] "+v"(jrow) \
-        : [row] "v"(row_lds), [voff16] "v"(voff16), [voff8] "v"(voff8), [ldsw16] "v"(ldsw16), [ldsw8] "v"(ldsw8), [lane4] "v"(lane4), \
-          [tb] "s"(tb), [f0] "s"(f0), [navg] "s"(navg), [wt] "s"(wt_s), [yout] "s"(yout), [jm] "s"(jm), [rmask] "s"(rmask), [P] "s"(P), \
-          [etab] "s"(etab), [nfull] "s"(nfull), [outmask] "s"(outmask), [jend] "s"(jend) \
-        : MD50_CLOBBERS)
-// what the change of the mean (avg_old -> avg_new) at block b0 adds to output j = b0 + i, i < Q-1-since: (avg_new - avg_old) * sum over the blocks before the
-// change that reach into it (md_dc_boundary with explicit operands and the double-phase table)
-__device__ __forceinline__ float2v md_dc_boundary_w(const MixDecArgs &a, double f0, int i, int since, uint32_t e_b0, float2 an, float2 ao) {
-    float2v t = {0.f, 0.f};
-    const int H = a.Q - 1, P = a.etab_len;
-    if (i < H - since) {
-        float sr = 0.f, si = 0.f;
-        for (int q = 0; q < H - i - since; q++) {             // block b0 + i - (H - q) lies before the change
-            const uint32_t n0 = (uint32_t)a.D * (uint32_t)(((int)e_b0 + i - (H - q) + 2 * P) % P);
-            for (int r = 0; r < a.D; r++) {
-                const float2 e = md_phasor64(f0, n0 + (uint32_t)r);
-                const float w = a.wtab_g[8 * r + q];
-                sr = fmaf(w, e.x, sr); si = fmaf(w, e.y, si);
-            }
-        }
-        const float dx = an.x - ao.x, dy = an.y - ao.y;
-        t = (float2v){dx * sr - dy * si, dx * si + dy * sr};
-    }
-    return t;
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // a workgroup per channel: 512 channels are two waves per SIMD anyway; no spills at 256 registers
-void k_mix_decimate50w(const MixDecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
-    __shared__ long long s_sum[2];
-    constexpr int Q_T = 7, H = 6, D = 50, TILE_DW = MD_ROWS * D;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *sRaw = smem_u + wave * (TILE_DW + 4);
-    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(sRaw);
-    const uint32_t row_lds = lds0 + 4u * D * lane, ldsw16 = lds0 + 16u * lane, ldsw8 = lds0 + 8u * lane;
-    const uint32_t voff16 = 16u * lane, voff8 = 8u * lane, lane4 = 4u * lane;
-    const int ch = blockIdx.x;
-    if (ch >= a.n_ch) return;
-    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
-    const double f0 = a.chan_f0[ch];
-    float2 *yout = a.y + (size_t)ch * a.ring_len;
-    const float *wt_s = a.wtab_g + 64 * 8;
-    const uint32_t rmask = (uint32_t)a.ring_len - 1;
-    const uint32_t P = (uint32_t)a.etab_len;
-    const float2 *etab = a.etab + (size_t)ch * P;
-    const uint32_t e_call = (uint32_t)((a.lut_phase / D) % P);             // table block of the call's first block
-    const int B = a.dc_seg_blocks;                                        // blocks per IQ-DC window
-    float2 avg_cur = a.dc_avg[ch], avg_prev = a.dc_avg_prev[ch];
-    long long cx = a.dc_sums[2 * (size_t)ch], cy = a.dc_sums[2 * (size_t)ch + 1];     // what the window in progress collected before this call
-    int since = a.dc_since;                                               // blocks between the last change of the mean and the piece in hand
-    if (threadIdx.x == 0) { s_sum[0] = 0; s_sum[1] = 0; }
-    __syncthreads();
-
-    for (int pb = 0, off = a.dc_seg_off; pb < a.nblocks; ) {              // pieces: the rest of the window in progress, then window after window
-        const int pn = min(a.nblocks - pb, B - off);
-        // four segments of whole tiles: 64 G - H rows each (the first of the call has no halo in front of it: its history is the P tail)
-        const int G = ((pn + 3) / 4 + H + MD_ROWS - 1) / MD_ROWS, rps = MD_ROWS * G - H;
-        const int jb = pb + wave * rps, je = min(pb + pn, jb + rps);
-        int sx = 0, sy = 0;
-        if (jb < pb + pn) {
-            const bool first = (pb == 0 && wave == 0);
-            const int jt0 = first ? jb : jb - H;
-            const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
-            const int nfull = min(ntiles, (a.nblocks - jt0) / MD_ROWS);
-            const uint64_t navg = md_navg_sgpr(avg_cur);
-            float2v carry = {0.f, 0.f};
-            if (first && lane < H) {
-#pragma unroll
-                for (int q = 0; q < H; q++) {
-                    const int i = lane + q;
-                    if (i < H) { const float2 v = a.ptail_in[((size_t)ch * 8 + i) * 8 + q]; carry += (float2v){v.x, v.y}; }
-                }
-            }
-            // the first Q-1 outputs of the piece reach into blocks mixed under the previous mean: they sit in wave 0's first tile, behind its halo
-            if (wave == 0) {
-                const int i = lane - (jb - jt0);
-                if (i >= 0 && i < H) carry += md_dc_boundary_w(a, f0, i, since, (e_call + (uint32_t)pb) % P, avg_cur, avg_prev);
-            }
-            uint32_t eidx = (uint32_t)(((uint64_t)e_call + (uint64_t)(jt0 + lane)) % P);
-            uint32_t jrow = (uint32_t)(jt0 + lane);
-            const uint32_t jend = (uint32_t)je;
-            float2v acc[Q_T];
-            if (nfull > 0) {
-                const uint32_t *tb = iq + (size_t)jt0 * D;
-                const uint32_t jm = a.m0 + (uint32_t)jt0;
-                const uint64_t outmask = first ? ~0ull : ~0ull << H;
-                MD50W_ASM(MD50_LOOP_P);
-                const int j = jt0 + (nfull - 1) * MD_ROWS + lane;
-                if (j >= a.nblocks - H && j < a.nblocks) {
-#pragma unroll
-                    for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
-                }
-            }
-            if (ntiles > nfull) {                             // the wave's last tile sticks out of the CALL: checked loads, no staging
-                const int jt = jt0 + nfull * MD_ROWS, total_dw = a.nblocks * D;
-#pragma unroll 1
-                for (int v = 0; v < 13; v++) {
-                    const int c = 64 * v + lane, o2 = jt * D + 4 * c;
-                    u32x4_u w = {0u, 0u, 0u, 0u};
-                    if (4 * c < TILE_DW && o2 + 4 <= total_dw) w = *reinterpret_cast<const u32x4_u *>(iq + o2);
-                    if (4 * c < TILE_DW) *reinterpret_cast<uint4 *>(sRaw + 4 * c) = make_uint4(w.x, w.y, w.z, w.w);
-                }
-                const int j = jt + lane;
-                const bool outrow = j >= jb && j < je;
-#pragma unroll
-                for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
-                float2v dcs = {0.f, 0.f};
-                const float m = outrow ? 1.f : 0.f;
-                md_fast_tile_p(row_lds, wt_s, f0, f0 * (double)(eidx * (uint32_t)D), (float2v){m, m}, acc, dcs);
-                sx += (int)dcs.x; sy += (int)dcs.y;
-                float2v y = acc[H] + carry;
-#pragma unroll
-                for (int q = 0; q < H; q++) {
-                    const int k = H - q, src = (lane - k) & 63;
-                    const float2v r = { __shfl(acc[q].x, src), __shfl(acc[q].y, src) };
-                    if (lane >= k) y += r;
-                }
-                y = md_dc_correct(y, avg_cur, etab[eidx]);
-                if (outrow) yout[(a.m0 + (uint32_t)j) & rmask] = make_float2(y.x, y.y);
-                if (j >= a.nblocks - H && j < a.nblocks) {
-#pragma unroll
-                    for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
-                }
-            }
-        }
-        for (int o2 = 32; o2 > 0; o2 >>= 1) { sx += __shfl_down(sx, o2); sy += __shfl_down(sy, o2); }
-        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(&s_sum[0]), (unsigned long long)(long long)sx); atomicAdd(reinterpret_cast<unsigned long long *>(&s_sum[1]), (unsigned long long)(long long)sy); }
-        __syncthreads();                                      // the piece is through: its outputs written, its sums complete
-        cx += s_sum[0]; cy += s_sum[1];
-        since += pn;
-        if (off + pn == B) {                                  // the window is complete: its mean is in effect from the next block on (dft_detect.c:579-588; k_dc_seg_means)
-            avg_prev = avg_cur;
-            avg_cur = make_float2((float)(((double)cx / 32768.0) / (double)a.dc_maxcnt), (float)(((double)cy / 32768.0) / (double)a.dc_maxcnt));
-            cx = 0; cy = 0; since = 0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { s_sum[0] = 0; s_sum[1] = 0; }
-        __syncthreads();
-        pb += pn; off = 0;
-    }
-    if (threadIdx.x == 0) {
-        a.dc_avg_w[ch] = avg_cur; a.dc_avg_prev_w[ch] = avg_prev;
-        a.dc_sums[2 * (size_t)ch] = cx; a.dc_sums[2 * (size_t)ch + 1] = cy;
     }
 }
 
@@ -2427,13 +2264,6 @@ extern "C" int sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s) {
 #undef MD_LAUNCH
     return 0;
 }
-extern "C" int sonde_launch_mix_decimate50w(const MixDecArgs *a, hipStream_t s) {
-    if (a->D != 50 || a->Q != 7 || !a->etab || a->etab_len < 1 || a->lut_len % 50 || a->lut_phase % 50 || !a->dc_avg_prev || !a->dc_avg_w || !a->dc_avg_prev_w
-        || a->dc_seg_blocks < 1 || a->dc_seg_off < 0 || a->dc_seg_off >= a->dc_seg_blocks || !a->wtab_scaled) return -1;
-    const size_t lds = (size_t)4 * (MD_ROWS * a->D + 4) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_mix_decimate50w, dim3(a->n_ch), dim3(256), lds, s, *a);
-    return 0;
-}
 extern "C" void sonde_launch_dc_segments(const int16_t *iq, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,
                                          long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
     const int nseg = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples + dc_max - 1) / dc_max);
@@ -2462,10 +2292,7 @@ extern "C" void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapp
     hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(64), 0, s, src, dst_mapped);
 }
 extern "C" void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s) {
-    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab, 0);
-}
-extern "C" void sonde_launch_md_etable64(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s) {
-    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab, 1);
+    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab);
 }
 extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s) {
     int gx = (n_bytes / 4 + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;

@@ -190,8 +190,6 @@ struct sonde_scan {
     // stream position
     uint64_t samples_in = 0; uint32_t m_out = 0; uint32_t dc_cnt = 0, dc_max = 0;
     unsigned long long *d_spprof = nullptr;
-    float2 *d_etab64 = nullptr, *d_dcavg_prev = nullptr; int etab_len = 0; int dc_since = 1 << 20;      // one-pass front end (k_mix_decimate50w)
-    int one_pass_sticky = -1;          // decided at the first call (the two forms keep different things in the P tail between calls)
     long long *d_segsums = nullptr; float2 *d_dcseg = nullptr;      // IQ-DC windows of a call: sums, table of means (MixDecArgs.dc_seg)
     std::vector<Chan> chan;
     std::vector<sonde_detection_t> queue;
@@ -280,19 +278,11 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
             if (dupload(&s->d_wtab, both)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
         }
         std::vector<double> f0s(C);
-        const bool onepass_ok = !s->wide_fe && D == 50 && s->Q == 7 && cfg->bits != 32;       // the generated D = 50, Q = 7 tile loop
         for (int c = 0; c < C; c++) {
             const Mixer m = design_mixer(-std::max(-0.5, std::min(0.5, fq[c])), cfg->sample_rate);
             f0s[c] = m.f0; s->lut_len = m.lut_len;
         }
         if (dupload(&s->d_chanf0, f0s)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
-        if (onepass_ok && s->lut_len % D == 0 && s->d_wtab) {
-            // E[ch][i]: the decimator's response to the bare (double-phase) mixer table when block i of the table's period completes the output
-            s->etab_len = s->lut_len / D;
-            if (dalloc(&s->d_etab64, (size_t)C * s->etab_len, false) || dalloc(&s->d_dcavg_prev, (size_t)C, true)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
-            sonde_launch_md_etable64(s->d_chanf0, s->d_wtab, D, s->Q, s->etab_len, C, s->d_etab64, nullptr);
-            HIPCHK(hipDeviceSynchronize());
-        }
     }
     std::vector<float> w_iq, w_lp;
     if (iq) {
@@ -437,7 +427,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_pre) hipHostFree(s->h_pre);
     if (s->h_work) hipHostFree(s->h_work);
     void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_scratch, s->d_f32in, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg, s->d_etab64, s->d_dcavg_prev };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -784,32 +774,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         // windows it spans (1/32 s each: 32 per second of signal) handled by a table of means (MixDecArgs.dc_seg) that two small kernels fill first —
         // a launch per window made the front end launch-bound (64 launches of ~9 us per second of signal)
         static const bool no_segtab = getenv("SONDE_SCAN_NO_SEGTAB") != nullptr;      // A/B aid
-        // SONDE_SCAN_ONE_PASS=1: a workgroup per channel walks the call's IQ-DC windows in order, sums and mixes as it goes (k_mix_decimate50w) instead of the
-        // two passes below.  Measured (profiles/r4l_scan_one_pass.txt): a channel's 32 windows one after the other take 1.27 ms however few channels there
-        // are (four waves, one per SIMD, each alone with its latencies), so it ties at 512 channels (1.84 vs 1.82 ms) and loses below — the other arm of the
-        // measurement, same results (tests/test_gpu_scan.py::test_scan_one_pass_front_end_equals_two_pass), not the default
-        if (s->one_pass_sticky < 0) s->one_pass_sticky = getenv("SONDE_SCAN_ONE_PASS") != nullptr ? 1 : 0;
-        const bool one_pass = s->one_pass_sticky == 1;
-        if (mode == SONDE_SCAN_BBIQ && !f32in && s->d_etab64 && n_samples % D == 0 && s->dc_cnt % (uint32_t)D == 0 && !no_segtab && one_pass && ch_stride != 0) {
-            MixDecArgs a{};
-            a.iq = (const int16_t *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = n_samples / D;
-            a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.wtab_scaled = 1; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
-            a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
-            a.dc_avg = s->d_dcavg; a.dc_avg_prev = s->d_dcavg_prev; a.dc_avg_w = s->d_dcavg; a.dc_avg_prev_w = s->d_dcavg_prev; a.dc_sums = s->d_dcsums;
-            a.dc_since = s->dc_since; a.dc_maxcnt = (float)s->dc_max; a.dc_seg_off = (int)(s->dc_cnt / (uint32_t)D); a.dc_seg_blocks = (int)(s->dc_max / (uint32_t)D);
-            a.etab = s->d_etab64; a.etab_len = s->etab_len;
-            a.ptail_in = s->d_ptail[s->ptail_cur]; a.ptail_out = s->d_ptail[s->ptail_cur ^ 1];
-            a.y = s->d_y; a.ring_len = s->ring_len; a.m0 = s->m_out; a.phase_f64 = 1;
-            if (sonde_launch_mix_decimate50w(&a, s->stream) < 0) return SONDE_E_ARG;
-            s->ptail_cur ^= 1;
-            const uint64_t end = (uint64_t)s->dc_cnt + (uint64_t)n_samples;
-            if (end >= s->dc_max) s->dc_since = (int)((end % s->dc_max) / (uint32_t)D);
-            else if (s->dc_since < (1 << 20)) s->dc_since += n_samples / D;
-            s->samples_in += (uint64_t)n_samples; s->m_out += (uint32_t)(n_samples / D);
-            s->dc_cnt = (uint32_t)(end % s->dc_max);
-            done = n_samples;
-        }
-        if (done < n_samples && mode == SONDE_SCAN_BBIQ && !f32in && D <= 64 && n_samples % D == 0 && s->dc_cnt % (uint32_t)D == 0 && !no_segtab) {
+        if (mode == SONDE_SCAN_BBIQ && !f32in && D <= 64 && n_samples % D == 0 && s->dc_cnt % (uint32_t)D == 0 && !no_segtab) {
             const int nseg_cap = s->cfg.max_chunk / (int)s->dc_max + 2;
             if (!s->d_segsums) {
                 HIPCHK(hipMalloc((void **)&s->d_segsums, (size_t)C * nseg_cap * 2 * sizeof(long long)));

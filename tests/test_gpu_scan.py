@@ -312,18 +312,3 @@ def test_scan_prefilter_at_extreme_input_levels(variant):
     assert out[True] == out[False]
     if variant != "big_offset":
         assert any(t == "RS41" for t, _, _ in out[True][0])
-
-
-def test_scan_one_pass_front_end_equals_two_pass(monkeypatch):
-    """SONDE_SCAN_ONE_PASS=1: the base-rate front end as one workgroup per channel walking the IQ-DC windows in order, the mean folded out per output
-    (k_mix_decimate50w) — against the default (window sums in a pass of their own, the mean off every sample): same windows, scores within 2e-5,
-    same lines, also with odd chunk sizes (windows and calls straddle)"""
-    name = "scan_rs41_2400k_dc"
-    g = load_scan(name)
-    x, fq, _, case = scan_capture(name)
-    monkeypatch.setenv("SONDE_SCAN_ONE_PASS", "1")
-    for chunk in (2_400_000 // 2, 350 * 50 * 7, 2_400_000 // 5 + 50 * 13):
-        sc = _scanner(case, fq, max_chunk=2_400_000, exact=True)
-        wins, dets = _feed(sc, x, chunk, 2)
-        _check_windows(wins, g)
-        assert "".join(d["line"] + "\n" for d in dets) == g["stdout"]

@@ -63,7 +63,6 @@ class Regs:
 
 
 EXP = ""      # experiment variants (tools/ab_variants.sh): timing only, results are garbage
-PH64 = False  # mixer phase kept in DOUBLE (dft_detect.c:1090-1093): v_fract_f64, then one rounding to f32 — otherwise the demodulator's stream (fold mode)
 SCAN = False  # the scanner's front end (scan/dft_detect.c): mixer phase kept in DOUBLE (t = f0 * n, :1090-1093: fract in f64, then one rounding to f32)
               # and the IQ-DC mean of the row's 1/32 s window taken off every sample ((x - avg) ex, :579-588; the means come from a table, a
               # launch spans many windows) instead of folded out per output — same instruction count: the subtraction takes the slot of the
@@ -100,7 +99,7 @@ def block(R, r, init=False):
         I["cvt64"] = f"v_cvt_f32_f64 {R.TP}, {R.T}"
         I["add64"] = f"v_add_f64 {R.T}, {R.T}, {R.f0}"
         I["fract"] = f"v_fract_f32 {R.TP}, {R.TP}"
-        if SCAN or PH64:      # Z is free between the last tap FMA of the previous block and this block's `z`
+        if SCAN:      # Z is free between the last tap FMA of the previous block and this block's `z`
             I["cvt64"] = f"v_fract_f64 {R.Z}, {R.T}"
             I["fract"] = f"v_cvt_f32_f64 {R.TP}, {R.Z}"
         I["xr"] = f"v_cvt_f32_i32_sdwa {R.XR[e]}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
@@ -261,10 +260,6 @@ def gen_loop():
         # the lane's block in the next tile: e = (e + 64) mod P; IQ-DC sums of the rows that count
         L += [f"v_add_u32 %[e], 64, %[e]", f"v_subrev_u32 v{T1}, %[P], %[e]", f"v_min_u32 %[e], v{T1}, %[e]"]
         if SCAN: L += [f"v_add_u32 %[jrow], 64, %[jrow]"]
-        elif PH64:    # a wave's last tile may run past the end of its piece (the rows of the next IQ-DC window): they do not count for this window's sums
-            L += [f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
-                  f"v_cmp_gt_u32 vcc, %[jend], %[jrow]", f"s_and_b64 exec, vcc, s[{S_OUT}:{S_OUT + 1}]",
-                  f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1", f"v_add_u32 %[jrow], 64, %[jrow]"]
         else: L += [f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
                     f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1"]
         L += [f"s_add_i32 s{S_T}, s{S_T}, 1", f"s_cmp_ge_i32 s{S_T}, %[nfull]", "s_cbranch_scc1 90f"]
@@ -296,11 +291,6 @@ def main():
     text += "// the scanner's front end: double mixer phase, IQ-DC mean of the row's window off every sample (SCAN in tools/gen_md_fast.py)\n"
     text += as_macro("MD_FAST_BODY_S", body_operands()) + as_macro("MD50_LOOP_S", gen_loop())
     SCAN = False
-    global PH64
-    PH64 = True
-    text += "// double mixer phase, IQ-DC folded out per output like the demodulator's: the scanner's per-channel form (k_mix_decimate50w)\n"
-    text += as_macro("MD_FAST_BODY_P", body_operands()) + as_macro("MD50_LOOP_P", gen_loop())
-    PH64 = False
     if len(sys.argv) > 1 and sys.argv[1] == "--experiments":
         for k, e in enumerate(sys.argv[2:], 2):
             EXP = e
