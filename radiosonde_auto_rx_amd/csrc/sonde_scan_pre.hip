@@ -30,7 +30,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SP_MAXT 4                      // 256-sample tiles per wave (8192 samples / 256 / 8 waves)
 #define SP_CK 2                        // Toeplitz steps per block of prefetched A fragments (the host pads every table to a multiple)
 #define SP_CH 16                       // samples per thread in the load and prefix phases (8192 / 512)
-#define SP_ACAP 32                     // A-fragment steps (1 KB each) the LDS holds at a time: 4 x 16 bytes per thread; longer templates reload
+#ifndef SP_ACAP
+#define SP_ACAP 16                     // A-fragment steps (1 KB each) the LDS holds at a time: SP_AQ x 16 bytes per thread; longer templates reload
+#endif
+#define SP_AQ (SP_ACAP * 64 / SP_THREADS)
 
 // S(i) = sum_{q<i} xf[q]^2 from the sums kept for every fourth i and the squares between
 __device__ __forceinline__ float sp_S(const float *P, const _Float16 *xf, int i) {
@@ -81,7 +84,46 @@ __device__ __forceinline__ int sp_toeplitz(const _Float16 *x, const _Float16 *af
     return cnt;
 }
 
-__global__ __launch_bounds__(SP_THREADS, 4)
+// Scores of a wave's correlation tiles: e[p] = S(p + L) - S(p) from the kept sums and the squares between, |c[p]| / sqrt(e[p]) and the arg-max of |c|.
+// HO = (p0 + L) & 3 = L & 3 for every lane (p0 is a multiple of 4), so which of the eight squares read at p0 + L joins the upper sum at step r is known
+// at compile time — round 3's form selected it per sample with seven compares.  Within a lane p only grows (r, then the tiles in order), so a later
+// equal |c| never replaces an earlier one: first maximum wins without comparing positions.
+template <int HO>
+__device__ __forceinline__ void sp_scores(const _Float16 *xfh, const float *P, const f32x4 (&acc)[SP_MAXT], int wave, int nT2, int n, int g, int L, int K,
+                                          float &bs, float &bc, float &bcv, int &bp) {
+#pragma unroll
+    for (int t = 0; t < SP_MAXT; t++) {
+        const int tile = wave + SP_WAVES * t;
+        if (tile < nT2) {
+            const int p0 = 256 * tile + 16 * n + 4 * g, hb = p0 + L - HO;   // hb: a multiple of 4 — S(p0 + r) and S(p0 + L + r) from three 8-byte reads of xf
+            const half4 lo = *reinterpret_cast<const half4 *>(xfh + p0), h0 = *reinterpret_cast<const half4 *>(xfh + hb), h1 = *reinterpret_cast<const half4 *>(xfh + hb + 4);
+            float slo = P[p0 >> 2], shi = P[hb >> 2], sq[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const float u0 = (float)h0[q], u1 = (float)h1[q]; sq[q] = u0 * u0; sq[4 + q] = u1 * u1; }
+#pragma unroll
+            for (int q = 0; q < HO; q++) shi += sq[q];                     // S(p0 + L)
+            const bool edge = 256 * tile + 255 > K;                         // (uniform) the tile the arg-max range ends in
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int p = p0 + r;
+                const float e = shi - slo;
+                { const float u = (float)lo[r]; slo += u * u; }
+                shi += sq[HO + r];
+                if (!edge || p <= K) {
+                    const float c = acc[t][r], ac = fabsf(c);
+                    const float sc = e > 0.f ? ac * __builtin_amdgcn_rsqf(e) : 0.f;
+                    bs = fmaxf(bs, sc);
+                    if (ac > bc) { bc = ac; bp = p; bcv = c; }
+                }
+            }
+        }
+    }
+}
+
+#ifndef SP_MINW
+#define SP_MINW 6                      // waves per SIMD the register allocation leaves room for
+#endif
+__global__ __launch_bounds__(SP_THREADS, SP_MINW)
 void k_scan_pre(const ScanPreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     const int item = blockIdx.x, j = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,34 +140,42 @@ void k_scan_pre(const ScanPreArgs a) {
     // LDS carve-up (halves / floats); every array starts on a 16-byte boundary
     const int NXH = (256 * nT1 + 32 * a.nc1 + 48 + 7) & ~7;
     int NXF = 256 * nT2 + 32 * nc2 + 48; if (NXF < 256 * nT1 + 8) NXF = 256 * nT1 + 8; NXF = (NXF + 7) & ~7;
+    const int NB = (a.opt_iq && NXH > NXF) ? NXH : NXF;
     _Float16 *xh = reinterpret_cast<_Float16 *>(sp_smem);                 // padL zeros, the window minus 0.98 dc, zeros
-    _Float16 *xfh = xh + (a.opt_iq ? NXH : 0);                             // the filtered window, zeros behind it
-    float *P = reinterpret_cast<float *>(xfh + NXF);                       // P[i / 4] = sum_{q<i} xf[q]^2 for i = 0, 4, 8, .. 256 nT1 (the up to three squares between come from xfh)
+    _Float16 *xfh = xh;                                                    // the filtered window, zeros behind it — IN PLACE of the unfiltered one: every output of the
+                                                                           // low-pass is in an accumulator register before the first is stored (a barrier between)
+    float *P = reinterpret_cast<float *>(xfh + NB);                        // P[i / 4] = sum_{q<i} xf[q]^2 for i = 0, 4, 8, .. 256 nT1 (the up to three squares between come from xfh)
     const int NP4 = ((64 * nT1 + 1) + 3) & ~3;
     _Float16 *sA = reinterpret_cast<_Float16 *>(P + NP4);                  // A fragments: the FM low-pass's nc1 steps, then the template's nc2 steps
-    __shared__ float s_f[2 * SP_WAVES];
+    __shared__ float s_f[2 * SP_WAVES], s_mx[SP_WAVES], s_mn[SP_WAVES], s_rc[SP_WAVES], s_rs[SP_WAVES], s_cv[SP_WAVES];
     __shared__ int s_i[SP_WAVES];
-    __shared__ float s_dc;
 
-    // ---- the window: xn[i] = stream[pos - (K+L-1) + i], i < K+L (dft_detect.c:378-379); dc over its last 2L samples (:389-391)
+    // ---- the window: xn[i] = stream[pos - (K+L-1) + i], i < K+L (dft_detect.c:378-379); dc over its last 2L samples (:389-391).
+    // A thread owns the pairs i = 2 tid + 1024 r + {0, 1}: ring index and byte offset in 32 bits (the ring length is a power of two, so the window's start
+    // may wrap modulo 2^32), and everything that depends on where the window or the dc range ends is decided per r on wave-uniform values — the
+    // per-sample compares of round 3's form were a third of this kernel's vector instructions
     const uint32_t mask = (uint32_t)a.ring_len - 1;
-    const float *str = a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len;
-    const int64_t start = (int64_t)it.pos - (wl - 1);
+    const char *str = reinterpret_cast<const char *>(a.fm + ((size_t)tp.stream * a.n_ch + it.ch) * a.ring_len);
+    const uint32_t s32 = it.pos - (uint32_t)(wl - 1);
+    const int first = it.pos >= (uint32_t)(wl - 1) ? 0 : (wl - 1) - (int)it.pos;      // samples in front of the stream's first one are zeros
     float v[SP_CH];
-    float dcp = 0.f;
 #pragma unroll
-    for (int r = 0; r < SP_CH; r++) {
-        const int i = tid + SP_THREADS * r;
-        const int64_t p = start + i;
-        v[r] = (i < wl && p >= 0) ? str[(uint32_t)p & mask] : 0.f;
-        if (i >= K - L && i < wl) dcp += v[r];
+    for (int r = 0; r < SP_CH / 2; r++) {
+        const int i0 = 2 * tid + 2 * SP_THREADS * r;
+        const uint32_t x0 = (s32 + (uint32_t)i0) & mask, x1 = (x0 + 1u) & mask;
+        if (first == 0 && 2 * SP_THREADS * (r + 1) <= wl) {              // (uniform) the whole row is inside the window
+            v[2 * r] = *reinterpret_cast<const float *>(str + (x0 << 2)); v[2 * r + 1] = *reinterpret_cast<const float *>(str + (x1 << 2));
+        } else {
+            v[2 * r]     = (i0 >= first && i0 < wl) ? *reinterpret_cast<const float *>(str + (x0 << 2)) : 0.f;
+            v[2 * r + 1] = (i0 + 1 >= first && i0 + 1 < wl) ? *reinterpret_cast<const float *>(str + (x1 << 2)) : 0.f;
+        }
     }
     // A fragments -> registers now (their latency overlaps the window's), -> LDS behind the window
     const int ncl = a.opt_iq ? a.nc1 : 0;                                 // steps of the FM low-pass, in front of the template's
     const int nA = min(ncl + nc2, SP_ACAP);                               // steps of 1 KB = 64 uint4 staged now; a longer template reloads (below)
-    uint4 areg[4];
+    uint4 areg[SP_AQ];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < SP_AQ; q++) {
         const int idx = tid + SP_THREADS * q;                             // uint4 index into the concatenated fragment list
         const int stp = idx >> 6;
         areg[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -142,43 +192,56 @@ void k_scan_pre(const ScanPreArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; r++) { const int i = 16 * (lane & 15) + 4 * (lane >> 4) + r; if (i < a.taps - 1) tl[r] = tail[i]; }
     }
-    float dc = 0.f;
-    if (a.opt_dc) {
-        const float sw = sp_wsum(dcp);
-        if (lane == 0) s_f[wave] = sw;
-        __syncthreads();
-        if (tid == 0) { float s = 0.f; for (int w = 0; w < SP_WAVES; w++) s += s_f[w]; s_dc = (float)((double)s / (2.0 * (double)(float)L)); }
-        __syncthreads();
-        dc = s_dc;
+    // one reduction for everything the conversion needs: the dc sum and the window's extremes — max_i |v[i] - c| = max(vmax - c, c - vmin) to the bit
+    // (the rounded difference is monotonic in v), so the level of the window is known without a second pass behind the dc
+    float dcp = 0.f, vmx = -3.0e38f, vmn = 3.0e38f;
+#pragma unroll
+    for (int r = 0; r < SP_CH / 2; r++) {
+        const int lo_r = 2 * SP_THREADS * r, hi_r = lo_r + 2 * SP_THREADS, i0 = 2 * tid + lo_r;
+        if (hi_r <= wl) { vmx = fmaxf(vmx, fmaxf(v[2 * r], v[2 * r + 1])); vmn = fminf(vmn, fminf(v[2 * r], v[2 * r + 1])); }
+        else if (lo_r < wl) {
+            if (i0 < wl) { vmx = fmaxf(vmx, v[2 * r]); vmn = fminf(vmn, v[2 * r]); }
+            if (i0 + 1 < wl) { vmx = fmaxf(vmx, v[2 * r + 1]); vmn = fminf(vmn, v[2 * r + 1]); }
+        }
+        if (lo_r >= K - L && hi_r <= wl) dcp += v[2 * r] + v[2 * r + 1];
+        else if (hi_r > K - L && lo_r < wl) {                            // (samples behind the window are zeros: only the range's start needs a test)
+            if (i0 >= K - L) dcp += v[2 * r];
+            if (i0 + 1 >= K - L) dcp += v[2 * r + 1];
+        }
     }
-    SP_MARK(0);                                                           // window + A fragments requested, dc known
+    dcp = sp_wsum(dcp);
+    for (int off = 32; off > 0; off >>= 1) { vmx = fmaxf(vmx, __shfl_xor(vmx, off)); vmn = fminf(vmn, __shfl_xor(vmn, off)); }
+    if (lane == 0) { s_f[wave] = dcp; s_mx[wave] = vmx; s_mn[wave] = vmn; }
+    __syncthreads();
+    float dc = 0.f;
+    if (a.opt_dc) { float sm = 0.f; for (int w = 0; w < SP_WAVES; w++) sm += s_f[w]; dc = (float)((double)sm / (2.0 * (double)(float)L)); }
+    for (int w = 0; w < SP_WAVES; w++) { vmx = fmaxf(vmx, s_mx[w]); vmn = fminf(vmn, s_mn[w]); }
+    SP_MARK(0);                                                           // window + A fragments requested, dc and level known
     const float dcs = 0.98f * dc;
     // The score c / sqrt(e) does not depend on the scale of the window, the f16 operands do: a window of a few LSB of FM audio (1 / 32768 = 3e-5) would
     // sit in f16's subnormals.  The window is therefore brought to [0.5, 1) by a power of two (exact) before the conversion, so that the rounding — and
     // with it the margin of the bound — is the same whatever the input level.
-    float amax = 0.f;
-#pragma unroll
-    for (int r = 0; r < SP_CH; r++) { const int i = tid + SP_THREADS * r; if (i < wl) amax = fmaxf(amax, fabsf(v[r] - dcs)); }
-    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-    __shared__ float s_amax[SP_WAVES];
-    if (lane == 0) s_amax[wave] = amax;
-    __syncthreads();
-    amax = 0.f;
-    for (int w = 0; w < SP_WAVES; w++) amax = fmaxf(amax, s_amax[w]);
+    const float amax = fmaxf(fmaxf(vmx - dcs, dcs - vmn), 0.f);
     int ex = 0;
     if (amax > 0.f) { (void)frexpf(amax, &ex); ex = ex > 120 ? 120 : (ex < -120 ? -120 : ex); }
     const float wscale = ldexpf(1.0f, -ex);
-    _Float16 *dst = a.opt_iq ? xh + padL : xfh;
-    const int ndst = (a.opt_iq ? NXH - padL : NXF);
+    _Float16 *dst = a.opt_iq ? xh + padL : xfh;                          // (padL is a multiple of 8: pairs are 4-byte aligned)
+    const int ndst = NB - (a.opt_iq ? padL : 0);
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int r = 0; r < SP_CH; r++) {
-        const int i = tid + SP_THREADS * r;
-        if (i < ndst) dst[i] = (_Float16)((i < wl) ? (v[r] - dcs) * wscale : 0.f);
+    for (int r = 0; r < SP_CH / 2; r++) {
+        const int i0 = 2 * tid + 2 * SP_THREADS * r;
+        half2v h = { (_Float16)((v[2 * r] - dcs) * wscale), (_Float16)((v[2 * r + 1] - dcs) * wscale) };
+        if (2 * SP_THREADS * (r + 1) > wl) {                              // (uniform) the row the window ends in, and the rows behind it
+            if (i0 >= wl) h[0] = (_Float16)0.f;
+            if (i0 + 1 >= wl) h[1] = (_Float16)0.f;
+        }
+        if (i0 < ndst) *reinterpret_cast<half2v *>(dst + i0) = h;        // (ndst is even)
     }
-    for (int i = SP_CH * SP_THREADS + tid; i < ndst; i += SP_THREADS) dst[i] = (_Float16)0.f;
+    for (int i = SP_CH * SP_THREADS + 2 * tid; i < ndst; i += 2 * SP_THREADS) *reinterpret_cast<half2v *>(dst + i) = half2v{ (_Float16)0.f, (_Float16)0.f };
     if (a.opt_iq) for (int i = tid; i < padL; i += SP_THREADS) xh[i] = (_Float16)0.f;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int idx = tid + SP_THREADS * q; if ((idx >> 6) < nA) reinterpret_cast<uint4 *>(sA)[idx] = areg[q]; }
+    for (int q = 0; q < SP_AQ; q++) { const int idx = tid + SP_THREADS * q; if ((idx >> 6) < nA) reinterpret_cast<uint4 *>(sA)[idx] = areg[q]; }
     __syncthreads();
 
     SP_MARK(1);                                                           // window scaled, converted, stored; A fragments stored
@@ -190,6 +253,7 @@ void k_scan_pre(const ScanPreArgs a) {
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         sp_toeplitz(xh, sA, a.nc1, wave, nT1, lane, acc);
+        __syncthreads();                                                  // every wave has read what it needs of the unfiltered window: the outputs take its place
 #pragma unroll
         for (int t = 0; t < SP_MAXT; t++) {
             const int tile = wave + SP_WAVES * t;
@@ -198,15 +262,18 @@ void k_scan_pre(const ScanPreArgs a) {
                 half4 h;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int i = i0 + r;
                     float x = acc[t][r];
                     if (t == 0 && wave == 0) x -= dcs * wscale * tl[r];      // (taps - 1 <= 256: tile 0 only; tl is 0 from taps - 1 on)
-                    h[r] = (_Float16)((i < wl) ? x : 0.f);
+                    h[r] = (_Float16)x;
+                }
+                if (256 * (tile + 1) > wl) {                                  // (uniform) the tile the window ends in
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (i0 + r >= wl) h[r] = (_Float16)0.f;
                 }
                 *reinterpret_cast<half4 *>(xfh + i0) = h;
             }
         }
-        for (int i = 256 * nT1 + tid; i < NXF; i += SP_THREADS) xfh[i] = (_Float16)0.f;
+        for (int i = 256 * nT1 + tid; i < NB; i += SP_THREADS) xfh[i] = (_Float16)0.f;
         __syncthreads();
     }
 
@@ -252,33 +319,11 @@ void k_scan_pre(const ScanPreArgs a) {
             sp_toeplitz(xfh + 32 * done, sA, take, wave, nT2, lane, acc);
             done += take;
         }
-#pragma unroll
-        for (int t = 0; t < SP_MAXT; t++) {
-            const int tile = wave + SP_WAVES * t;
-            if (tile < nT2) {
-                const int p0 = 256 * tile + 16 * n + 4 * g;            // a multiple of 4: S(p0 + r) and S(p0 + L + r) from three 8-byte reads of xf
-                const int hb = (p0 + L) & ~3, ho = (p0 + L) & 3;
-                const half4 lo = *reinterpret_cast<const half4 *>(xfh + p0), h0 = *reinterpret_cast<const half4 *>(xfh + hb), h1 = *reinterpret_cast<const half4 *>(xfh + hb + 4);
-                float slo = P[p0 >> 2], shi = P[hb >> 2], sq[8];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const float u0 = (float)h0[q], u1 = (float)h1[q]; sq[q] = u0 * u0; sq[4 + q] = u1 * u1; }
-#pragma unroll
-                for (int q = 0; q < 3; q++) if (q < ho) shi += sq[q];      // S(p0 + L)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int p = p0 + r;
-                    const float e = shi - slo;
-                    { const float u = (float)lo[r]; slo += u * u; }
-#pragma unroll
-                    for (int q = 0; q < 7; q++) if (q == ho + r) shi += sq[q];
-                    if (p <= K) {
-                        const float c = acc[t][r], ac = fabsf(c);
-                        const float sc = e > 0.f ? ac * __builtin_amdgcn_rsqf(e) : 0.f;
-                        if (sc > bs) bs = sc;
-                        if (ac > bc || (ac == bc && p < bp)) { bc = ac; bp = p; bcv = c; }
-                    }
-                }
-            }
+        switch (L & 3) {                                                 // (p0 is a multiple of 4: where S(p0 + L) sits between the kept sums is the template's own)
+            case 0: sp_scores<0>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
+            case 1: sp_scores<1>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
+            case 2: sp_scores<2>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
+            default: sp_scores<3>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
         }
     }
     SP_MARK(4);                                                           // correlation, scores
@@ -287,15 +332,12 @@ void k_scan_pre(const ScanPreArgs a) {
         if (oc > bc || (oc == bc && op < bp)) { bc = oc; bp = op; bcv = ov; }
         if (os > bs) bs = os;
     }
-    __syncthreads();
-    if (lane == 0) { s_f[wave] = bc; s_f[SP_WAVES + wave] = bs; s_i[wave] = bp; }
-    __shared__ float s_cv[SP_WAVES];
-    if (lane == 0) s_cv[wave] = bcv;
+    if (lane == 0) { s_rc[wave] = bc; s_rs[wave] = bs; s_i[wave] = bp; s_cv[wave] = bcv; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < SP_WAVES; w++) {
-            if (s_f[w] > bc || (s_f[w] == bc && s_i[w] < bp)) { bc = s_f[w]; bp = s_i[w]; bcv = s_cv[w]; }
-            if (s_f[SP_WAVES + w] > bs) bs = s_f[SP_WAVES + w];
+            if (s_rc[w] > bc || (s_rc[w] == bc && s_i[w] < bp)) { bc = s_rc[w]; bp = s_i[w]; bcv = s_cv[w]; }
+            if (s_rs[w] > bs) bs = s_rs[w];
         }
         ScanPre r{bs, 0.f, -1, 0u, dc, 0};
         if (bp <= K && bc >= 0.f) {
@@ -321,7 +363,7 @@ extern "C" int sonde_launch_scan_pre(const ScanPreArgs *a, hipStream_t s) {
     const size_t nxh = a->opt_iq ? (size_t)((256 * nT1 + 32 * a->nc1 + 48 + 7) & ~7) : 0;
     size_t nxf = (size_t)256 * nT2 + 32 * (size_t)maxc2 + 48; if (nxf < (size_t)256 * nT1 + 8) nxf = (size_t)256 * nT1 + 8; nxf = (nxf + 7) & ~(size_t)7;
     const size_t np4 = (size_t)(((64 * nT1 + 1) + 3) & ~3);
-    const size_t lds = 2 * (nxh + nxf) + 4 * np4 + 1024 * (size_t)SP_ACAP;
+    const size_t lds = 2 * (nxh > nxf ? nxh : nxf) + 4 * np4 + 1024 * (size_t)SP_ACAP;
     static size_t attr = 0;
     if (lds > attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_pre), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;

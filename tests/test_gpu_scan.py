@@ -46,7 +46,7 @@ def _feed(sc, x, chunk, per):
     return wins, dets
 
 
-def _check_windows(wins, g, upto=None, tol_first=2e-5):
+def _check_windows(wins, g, upto=None, tol_first=2e-5, tol=2e-5):
     n = len(wins) if upto is None else upto
     assert n <= len(g["pos"])
     for w in range(n):
@@ -55,7 +55,7 @@ def _check_windows(wins, g, upto=None, tol_first=2e-5):
         assert np.array_equal(r["mp"], g["mp"][w]), (w, r["mp"], g["mp"][w])
         ok = g["mp"][w] > 0
         assert np.array_equal(r["mpos"][ok], g["mpos"][w][ok]), w
-        assert np.abs(r["mv"][ok] - g["mv"][w][ok]).max() < (tol_first if w == 0 else 2e-5), (w, r["mv"], g["mv"][w])
+        assert np.abs(r["mv"][ok] - g["mv"][w][ok]).max() < (tol_first if w == 0 else tol), (w, r["mv"], g["mv"][w])
         assert np.abs(r["dc"] - g["dc"][w]).max() < 1e-6
         assert np.array_equal(r["herrs"][ok], g["herrs"][w][ok]), (w, r["herrs"], g["herrs"][w])
         assert np.array_equal(r["m10"][ok], g["m10"][w][ok])
