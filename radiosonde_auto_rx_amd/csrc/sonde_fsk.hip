@@ -123,13 +123,14 @@ __device__ __forceinline__ void fsk_stage(float2 *buf, const float2 *tw, const i
 // barrier of the `n` estimator waves only (wave 0 is inside the oscillator walk and takes no part): a counter in LDS that only grows —
 // every wave adds one and waits until the count says all have arrived for this `phase` (1, 2, ...).  DS operations of a wave execute in
 // order, so what a wave wrote before its add is visible to whoever sees the count; all waves of a workgroup are resident, so the wait ends.
-__device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned n, unsigned &phase, const int lane) {
+__device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned n, unsigned &phase, const int lane, unsigned *abort_flag = nullptr) {
     phase++;
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         atomicAdd(cnt, 1u);
-        unsigned spins = 0;                                       // a wait that long means a bug: give up instead of hanging the device
+        unsigned spins = 0;                                       // a wait that long means a bug: give up instead of hanging the device —
         while (*reinterpret_cast<volatile unsigned *>(cnt) < n * phase && ++spins < FSK_SPIN_MAX) __builtin_amdgcn_s_sleep(FSK_NAP);
+        if (spins >= FSK_SPIN_MAX && abort_flag) __atomic_store_n(abort_flag, 1u, __ATOMIC_RELAXED);     // — and say so: the channel reports frames = -1, nobody goes on with half an estimate
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -142,7 +143,7 @@ __device__ __forceinline__ void fsk_group_barrier(unsigned *cnt, const unsigned 
 template <int M>
 __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_t rd, const int numffts, float2 *s_fb, const float2 *s_tw,
                                    float *s_Sf, float *s_Sc, float *Sf_g, float *o_fest, float2 *o_dphi, const int gw, const int NG, const int lane,
-                                   unsigned *s_bar, unsigned &phase) {
+                                   unsigned *s_bar, unsigned &phase, unsigned *abort_flag = nullptr) {
     const int Ndft = a.Ndft;
     const float tc = a.tc, omt = 1 - tc;
     // a wave takes BPW blocks at a time, one per group of GL lanes, FSK_AE transform elements per lane: short transforms (Ndft 64 / 128) would
@@ -191,7 +192,7 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
             for (int e = 0; e < FSK_AE; e++) if (e < EPL) mag[(lt + e * GL + Ndft / 2) & (Ndft - 1)] = mg[e];
         }
         EST_MARK(12);
-        fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
+        fsk_group_barrier(s_bar, (unsigned)NG, phase, lane, abort_flag);
         EST_MARK(13);
         const int nb = min(RB, numffts - j0);
         for (int k = gt; k < Ndft; k += GT) {                  // Sf = Sf (1 - tc) + |X| tc, block after block (fsk.c:497-503)
@@ -200,7 +201,7 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
             s_Sf[k] = sf;
         }
         EST_MARK(12);
-        fsk_group_barrier(s_bar, (unsigned)NG, phase, lane);
+        fsk_group_barrier(s_bar, (unsigned)NG, phase, lane, abort_flag);
         EST_MARK(13);
     }
     if (gw != 0) return;
@@ -738,7 +739,7 @@ void k_fsk_stream(const FskArgs a) {
                 numffts = nin / (Ndft / 2) - 1;
             }
             if (gw == 0) PIPE_ADD(9, tw0);
-            fsk_estimate_ahead<M>(a, ch, rd0 + S, numffts, s_fb, s_tw, s_Sf, s_Sc, Sf_g, pp.f_est[k & 1], pp.dphi[k & 1], gw, 2, lane, &pp.bar, phase);
+            fsk_estimate_ahead<M>(a, ch, rd0 + S, numffts, s_fb, s_tw, s_Sf, s_Sc, Sf_g, pp.f_est[k & 1], pp.dphi[k & 1], gw, 2, lane, &pp.bar, phase, &pp.abort);
             if (pipe_ld(&pp.abort)) break;
             if (gw == 0 && lane == 0) pipe_publish(&pp.est_seq, (unsigned)(k + 1));
         }

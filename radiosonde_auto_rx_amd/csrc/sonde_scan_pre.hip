@@ -41,7 +41,6 @@ __device__ __forceinline__ float sp_S(const float *P, const _Float16 *xf, int i)
     for (int q = i & ~3; q < i; q++) { const float x = (float)xf[q]; s += x * x; }
     return s;
 }
-__device__ __forceinline__ float sp_wsum(float v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off); return v; }
 
 // acc[t] = sum_c A_c x B(tile t, step c) for the NT tiles of this wave (tile = wave + SP_WAVES t); x: f16 array in LDS whose element 0 pairs with
 // h[0] of output 0.  NT is a template parameter so that the step loop has no branches: the B fragments of a step are NT independent 16-byte
@@ -84,38 +83,69 @@ __device__ __forceinline__ int sp_toeplitz(const _Float16 *x, const _Float16 *af
     return cnt;
 }
 
-// Scores of a wave's correlation tiles: e[p] = S(p + L) - S(p) from the kept sums and the squares between, |c[p]| / sqrt(e[p]) and the arg-max of |c|.
+// Wave-wide maximum of a 32-bit unsigned value (non-negative floats order like their bit patterns), every lane's copy in an SGPR: the row-shift /
+// row-broadcast DPP scan of gfx9 (shifts by 1, 2, 4, 8 inside a row of 16, then the last lane of rows 0 / 2 into rows 1 / 3 and of row 1 into rows 2-3) —
+// six vector instructions and no LDS, where six __shfl_xor steps are six ds_bpermute round trips.  Lanes without a source keep 0, the identity.
+__device__ __forceinline__ uint32_t sp_wave_umax(uint32_t v) {
+    int x = (int)v;
+#define SP_DPP_MAX(ctrl, rmask) { const int y = __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false); x = (int)max((uint32_t)x, (uint32_t)y); }
+    SP_DPP_MAX(0x111, 0xf) SP_DPP_MAX(0x112, 0xf) SP_DPP_MAX(0x114, 0xf) SP_DPP_MAX(0x118, 0xf)     // row_shr:1, 2, 4, 8
+    SP_DPP_MAX(0x142, 0xa) SP_DPP_MAX(0x143, 0xc)                                                      // row_bcast:15 (rows 1, 3), row_bcast:31 (rows 2, 3)
+#undef SP_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ float sp_hwmax(float a, float b) {      // v_max_f32 as the hardware does it: a NaN operand loses (no canonicalisation in front)
+    float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ float sp_hwmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the same scan for floats: inclusive prefix of OP over the wave's lanes (lane 63: the whole wave); IDENT (as bits) is what a lane without a source combines with
+#define SP_DPP_SCAN(x, OP, IDENT) do { \
+    x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(IDENT, __float_as_int(x), 0x111, 0xf, 0xf, false))); \
+    x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(IDENT, __float_as_int(x), 0x112, 0xf, 0xf, false))); \
+    x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(IDENT, __float_as_int(x), 0x114, 0xf, 0xf, false))); \
+    x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(IDENT, __float_as_int(x), 0x118, 0xf, 0xf, false))); \
+    x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(IDENT, __float_as_int(x), 0x142, 0xa, 0xf, false))); \
+    x = OP(x, __int_as_float(__builtin_amdgcn_update_dpp(IDENT, __float_as_int(x), 0x143, 0xc, 0xf, false))); } while (0)
+__device__ __forceinline__ float sp_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float sp_last(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
+
+// Scores of one correlation tile: e[p] = S(p + L) - S(p) from the kept sums and the squares between, |c[p]| / sqrt(e[p]) and the arg-max of |c|.
 // HO = (p0 + L) & 3 = L & 3 for every lane (p0 is a multiple of 4), so which of the eight squares read at p0 + L joins the upper sum at step r is known
-// at compile time — round 3's form selected it per sample with seven compares.  Within a lane p only grows (r, then the tiles in order), so a later
-// equal |c| never replaces an earlier one: first maximum wins without comparing positions.
+// at compile time.  No branches: a position outside the arg-max range (EDGE tiles only) gets |c| = -1, which neither the score (negative) nor the
+// arg-max (never above what is held) takes; e < 0 (rounding of the difference where the window is empty) makes the score a NaN that v_max_f32 drops,
+// e = 0 with c != 0 makes it +inf: the pair goes to the exact kernel.  Within a lane p only grows (r, then the tiles in order), so a later equal |c| never
+// replaces an earlier one — first maximum wins — and what is kept is bidx = 4 t + r: position and c are looked up once, behind the loop.
+template <int HO, bool EDGE>
+__device__ __forceinline__ void sp_tile_scores(const _Float16 *xfh, const float *P, const f32x4 c4, const int p0, const int L, const int K, const int code0,
+                                               float &bs, float &bc, int &bidx) {
+    const int hb = p0 + L - HO;                                          // a multiple of 4 — S(p0 + r) and S(p0 + L + r) from three 8-byte reads of xf
+    const half4 lo = *reinterpret_cast<const half4 *>(xfh + p0), h0 = *reinterpret_cast<const half4 *>(xfh + hb), h1 = *reinterpret_cast<const half4 *>(xfh + hb + 4);
+    const _Float16 hh[8] = { h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3] };
+    float slo = P[p0 >> 2], shi = P[hb >> 2];
+#pragma unroll
+    for (int q = 0; q < HO; q++) shi += (float)hh[q] * (float)hh[q];   // S(p0 + L)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float e = shi - slo;
+        slo += (float)lo[r] * (float)lo[r];
+        shi += (float)hh[HO + r] * (float)hh[HO + r];
+        float ac = fabsf(c4[r]);
+        if (EDGE) ac = (p0 + r <= K) ? ac : -1.f;
+        bs = sp_hwmax(bs, ac * __builtin_amdgcn_rsqf(e));
+        const bool up = ac > bc;
+        bc = up ? ac : bc; bidx = up ? code0 + r : bidx;
+    }
+}
 template <int HO>
 __device__ __forceinline__ void sp_scores(const _Float16 *xfh, const float *P, const f32x4 (&acc)[SP_MAXT], int wave, int nT2, int n, int g, int L, int K,
-                                          float &bs, float &bc, float &bcv, int &bp) {
+                                          float &bs, float &bc, int &bidx) {
 #pragma unroll
     for (int t = 0; t < SP_MAXT; t++) {
         const int tile = wave + SP_WAVES * t;
         if (tile < nT2) {
-            const int p0 = 256 * tile + 16 * n + 4 * g, hb = p0 + L - HO;   // hb: a multiple of 4 — S(p0 + r) and S(p0 + L + r) from three 8-byte reads of xf
-            const half4 lo = *reinterpret_cast<const half4 *>(xfh + p0), h0 = *reinterpret_cast<const half4 *>(xfh + hb), h1 = *reinterpret_cast<const half4 *>(xfh + hb + 4);
-            float slo = P[p0 >> 2], shi = P[hb >> 2], sq[8];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const float u0 = (float)h0[q], u1 = (float)h1[q]; sq[q] = u0 * u0; sq[4 + q] = u1 * u1; }
-#pragma unroll
-            for (int q = 0; q < HO; q++) shi += sq[q];                     // S(p0 + L)
-            const bool edge = 256 * tile + 255 > K;                         // (uniform) the tile the arg-max range ends in
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int p = p0 + r;
-                const float e = shi - slo;
-                { const float u = (float)lo[r]; slo += u * u; }
-                shi += sq[HO + r];
-                if (!edge || p <= K) {
-                    const float c = acc[t][r], ac = fabsf(c);
-                    const float sc = e > 0.f ? ac * __builtin_amdgcn_rsqf(e) : 0.f;
-                    bs = fmaxf(bs, sc);
-                    if (ac > bc) { bc = ac; bp = p; bcv = c; }
-                }
-            }
+            const int p0 = 256 * tile + 16 * n + 4 * g;
+            if (256 * tile + 255 > K) sp_tile_scores<HO, true>(xfh, P, acc[t], p0, L, K, 4 * t, bs, bc, bidx);       // (uniform) the tile the arg-max range ends in
+            else sp_tile_scores<HO, false>(xfh, P, acc[t], p0, L, K, 4 * t, bs, bc, bidx);
         }
     }
 }
@@ -209,12 +239,13 @@ void k_scan_pre(const ScanPreArgs a) {
             if (i0 + 1 >= K - L) dcp += v[2 * r + 1];
         }
     }
-    dcp = sp_wsum(dcp);
-    for (int off = 32; off > 0; off >>= 1) { vmx = fmaxf(vmx, __shfl_xor(vmx, off)); vmn = fminf(vmn, __shfl_xor(vmn, off)); }
-    if (lane == 0) { s_f[wave] = dcp; s_mx[wave] = vmx; s_mn[wave] = vmn; }
+    SP_DPP_SCAN(dcp, sp_addf, 0);
+    SP_DPP_SCAN(vmx, sp_hwmax, (int)0xff7fffffu);                        // -FLT_MAX
+    SP_DPP_SCAN(vmn, sp_hwmin, 0x7f7fffff);                              // +FLT_MAX
+    if (lane == 63) { s_f[wave] = dcp; s_mx[wave] = vmx; s_mn[wave] = vmn; }
     __syncthreads();
     float dc = 0.f;
-    if (a.opt_dc) { float sm = 0.f; for (int w = 0; w < SP_WAVES; w++) sm += s_f[w]; dc = (float)((double)sm / (2.0 * (double)(float)L)); }
+    if (a.opt_dc) { float sm = 0.f; for (int w = 0; w < SP_WAVES; w++) sm += s_f[w]; dc = sm * __builtin_amdgcn_rcpf(2.0f * (float)L); }      // (a bound's dc: 1 ulp of the mean is 1e-7 of the window)
     for (int w = 0; w < SP_WAVES; w++) { vmx = fmaxf(vmx, s_mx[w]); vmn = fminf(vmn, s_mn[w]); }
     SP_MARK(0);                                                           // window + A fragments requested, dc and level known
     const float dcs = 0.98f * dc;
@@ -290,7 +321,7 @@ void k_scan_pre(const ScanPreArgs a) {
             for (int r = 0; r < 8; r++) { run[8 * q + r] = s; const float x = (float)h[r]; s += x * x; }
         }
         float inc = s;                                            // inclusive scan of the per-thread totals
-        for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        SP_DPP_SCAN(inc, sp_addf, 0);
         if (lane == 63) s_f[SP_WAVES + wave] = inc;
         __syncthreads();
         float base = inc - s;
@@ -303,7 +334,8 @@ void k_scan_pre(const ScanPreArgs a) {
 
     SP_MARK(3);                                                           // prefix sums
     // ---- header correlation c'[p'] = sum_k match[k] xf[p'+k], p' = p - (L-1) in [0, K] (Z = X Fm, Nidft; arg-max range dft_detect.c:415)
-    float bc = -1.f, bs = 0.f; int bp = 0x7fffffff; float bcv = 0.f;
+    float bc = -1.f, bs = 0.f; int bidx = -1;
+    int bp = 0x7fffffff; float bcv = 0.f;
     {
         f32x4 acc[SP_MAXT];
 #pragma unroll
@@ -320,17 +352,30 @@ void k_scan_pre(const ScanPreArgs a) {
             done += take;
         }
         switch (L & 3) {                                                 // (p0 is a multiple of 4: where S(p0 + L) sits between the kept sums is the template's own)
-            case 0: sp_scores<0>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
-            case 1: sp_scores<1>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
-            case 2: sp_scores<2>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
-            default: sp_scores<3>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bcv, bp); break;
+            case 0: sp_scores<0>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
+            case 1: sp_scores<1>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
+            case 2: sp_scores<2>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
+            default: sp_scores<3>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
         }
+        // the lane's best position and its c, from bidx = 4 t + r
+        f32x4 sel = acc[0];
+#pragma unroll
+        for (int t = 1; t < SP_MAXT; t++) if ((bidx >> 2) == t) sel = acc[t];
+        bcv = sel[0];
+#pragma unroll
+        for (int r = 1; r < 4; r++) if ((bidx & 3) == r) bcv = sel[r];
+        if (bidx >= 0) bp = 256 * (wave + SP_WAVES * (bidx >> 2)) + 16 * n + 4 * g + (bidx & 3);
     }
     SP_MARK(4);                                                           // correlation, scores
-    for (int off = 32; off > 0; off >>= 1) {
-        const float oc = __shfl_xor(bc, off), ov = __shfl_xor(bcv, off), os = __shfl_xor(bs, off); const int op = __shfl_xor(bp, off);
-        if (oc > bc || (oc == bc && op < bp)) { bc = oc; bp = op; bcv = ov; }
-        if (os > bs) bs = os;
+    {   // the wave's largest |c| (first position wins), the c there, and the largest score
+        const uint32_t kc = __float_as_uint(fmaxf(bc, 0.f));
+        const uint32_t wc = sp_wave_umax(kc);
+        const bool mine = bidx >= 0 && kc == wc;
+        const uint32_t wp = ~sp_wave_umax(mine ? ~(uint32_t)bp : 0u);        // the smallest position among the lanes that hold it (0xffffffff: none)
+        const unsigned long long own = __ballot(mine && (uint32_t)bp == wp);
+        const float wv = own ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bcv), (int)__builtin_ctzll(own))) : 0.f;
+        bs = __uint_as_float(sp_wave_umax(__float_as_uint(bs)));
+        bc = own ? __uint_as_float(wc) : -1.f; bp = own ? (int)wp : 0x7fffffff; bcv = wv;
     }
     if (lane == 0) { s_rc[wave] = bc; s_rs[wave] = bs; s_i[wave] = bp; s_cv[wave] = bcv; }
     __syncthreads();
