@@ -51,21 +51,38 @@ def bench_scan_wide(args, D, short=False):
     wb = torch.from_numpy(x).to(D.dev)
     ch = Channelizer(sr, M, Dd, P, max_chunk=sr, device=D.local_rank)
     if_sr = int(ch.out_rate)
-    out = torch.zeros(M, ch.max_frames, 2, dtype=torch.float32, device=D.dev)
+    outs = [torch.zeros(M, ch.max_frames, 2, dtype=torch.float32, device=D.dev) for _ in range(2)]
     torch.cuda.synchronize()                     # torch's fill must be over before another stream writes the buffer
     sc = Scanner(if_sr, n_channels=M, iq_mode=IFIQ, dc=True, cont=True, max_chunk=ch.max_frames, device=D.local_rank, bits=32)
     found = []
+    ch_stream = ch.stream()
+    # Two stages on two streams, one step apart: while the scanner works on the channels of the stream second before (and its call waits for the
+    # prefilter's and the exact kernel's results on the host), the channelizer already produces this second's.  A step is still one pass of each stage
+    # over one second of stream; the channelizer's output alternates between two buffers.  SONDE_SCAN_WIDE_SERIAL=1: the stages one after the other.
+    serial = os.environ.get("SONDE_SCAN_WIDE_SERIAL") is not None
+    state = {"k": 0, "n": 0}
 
     def step():
-        n = ch.process_device(wb.data_ptr(), sr, out.data_ptr(), ch.max_frames)
-        ch.sync()                                             # the scanner runs on its own stream
-        sc.process_device(out.data_ptr(), ch.max_frames, n)
-        found.append(sc.fetch())
+        k = state["k"]
+        if serial:
+            n = ch.process_device(wb.data_ptr(), sr, outs[0].data_ptr(), ch.max_frames)
+            sc.wait_stream(ch_stream)                         # the scanner runs on its own stream: ordered behind the channelizer on the device, no host wait
+            sc.process_device(outs[0].data_ptr(), ch.max_frames, n)
+            found.append(sc.fetch())
+            return
+        sc.wait_stream(ch_stream)                             # everything the channelizer has queued so far: the buffer the scanner is about to read
+        n_prev = state["n"]
+        state["n"] = ch.process_device(wb.data_ptr(), sr, outs[k & 1].data_ptr(), ch.max_frames)       # (queued; its own stream)
+        if n_prev > 0:
+            sc.process_device(outs[(k - 1) & 1].data_ptr(), ch.max_frames, n_prev)     # returns when its detections are on the host
+            found.append(sc.fetch())
+        state["k"] = k + 1
 
     dt, per = _timed_steps(D, step, steps, warmup)
     det = found[-1]
     kern = {k: sc.kernel_ms(k) for k in ("front_end", "scan_if", "scan_pre", "scan_corr")}
     pre_pairs, exact_pairs = sc.kernel_ms("pre_pairs")[0], sc.kernel_ms("exact_pairs")[0]
+    ch.sync()                                                 # (reads the last launch's events)
     ch_ms, ch_n = ch.kernel_ms()
     value = D.world * sr * steps / dt / 1e6
     # dominant kernel: the prefilter k_scan_pre (matrix cores, f16 in / f32 accumulate).  Algorithmic flops per launch = 2 x the multiply-adds of
@@ -95,7 +112,9 @@ def bench_scan_wide(args, D, short=False):
             "metric": "wideband IQ Msamples/s channelized (256 ch polyphase) and scanned (dft_detect, 14 templates per channel)",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": D.world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: one 10 Msps cs16 stream -> 256 x 50 kHz polyphase channels -> dft_detect scan, 1 s of stream per step",
+            "config": {"workload": "BASELINE configs[2]: one 10 Msps cs16 stream -> 256 x 50 kHz polyphase channels -> dft_detect scan, 1 s of stream per step"
+                                   + ("" if serial else "; the two stages run one step apart on two streams (the scanner on the channels of the second before)"),
+                       "stages": "serial" if serial else "pipelined",
                        "stream_rate": sr, "channels": M, "if_rate": if_sr, "realtime_factor": round(value * 1e6 / D.world / sr, 2),
                        "detections_last_step": sorted({(d["channel"], d["type"]) for d in det if d["printed"] or d["score"] != 0})[:24],
                        "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per],
@@ -105,8 +124,9 @@ def bench_scan_wide(args, D, short=False):
             "roofline": {"bound": "mfma", "kernel": "k_scan_pre", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": round(achieved / 2500.0, 4), "traffic": None, "avg_launch_ms": round(pre_ms, 4),
                          "pairs_per_launch": round(pre_pairs, 1), "exact_pairs_per_launch": round(exact_pairs, 1),
-                         "note": "dense f16 MFMA peak; useful multiply-adds only (FM low-pass + header correlation of every (window, template)); the Toeplitz "
-                                 "fragments are half zeros, so the matrix pipe does twice this work, fed by one 16-byte LDS read per MFMA.  Pairs within 0.03 "
+                         "note": "dense f16 MFMA peak; useful multiply-adds only (FM low-pass + header correlation of every (window, template)); full Toeplitz "
+                                 "fragments (32 taps per MFMA), one 16-byte LDS read per MFMA.  The kernel is bound by the vector instructions AROUND the "
+                                 "MFMAs (conversion, prefix sums, scores, reductions: ~12 per MFMA), see DESIGN 4.6a.  Pairs within 0.03 "
                                  "of their threshold go on to the reference's own transform network (k_scan_corr: exact_pairs_per_launch)"},
         }
         if D.world == 1 and not args.no_cpu_baseline:

@@ -99,6 +99,10 @@ int  sonde_scan_info(const sonde_scan_t *s, sonde_scan_info_t *info);
  * ch_stride == 0: one wideband stream shared by all channels (each mixes its own fq out of it) — the channelizer form. */
 int  sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stride, int32_t n_samples);
+/* The scanner's stream waits for everything queued so far on `stream` (a hipStream_t: sonde_chan_stream(), an engine's, the caller's own) —
+ * the producer of d_in then needs no host synchronisation in front of sonde_scan_process_device.  (The reference has no such seam: its
+ * scanner reads a pipe; this is the device-side equivalent of the pipe's ordering.) */
+int  sonde_scan_wait_stream(sonde_scan_t *s, void *stream);
 
 /* End of input: a channel parked in the IMET AFSK check (one more second of samples, dft_detect.c:1533-1607) is decided
  * with the samples that exist, like the reference at EOF. */

@@ -32,6 +32,7 @@ def _lib():
         L.sonde_chan_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.sonde_chan_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         L.sonde_chan_sync.argtypes = [C.c_void_p]
+        L.sonde_chan_stream.argtypes = [C.c_void_p]; L.sonde_chan_stream.restype = C.c_void_p
         L.sonde_chan_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         _proto = True
     return L
@@ -65,6 +66,10 @@ class Channelizer:
 
     def sync(self):
         _chk(_lib().sonde_chan_sync(self._h))
+
+    def stream(self) -> int:
+        """The hipStream_t the channelizer queues its work on (for Scanner.wait_stream / an engine's wait)."""
+        return int(_lib().sonde_chan_stream(self._h) or 0)
 
     def kernel_ms(self):
         ms, n = C.c_double(), C.c_int64()

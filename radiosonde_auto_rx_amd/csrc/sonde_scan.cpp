@@ -167,6 +167,9 @@ struct sonde_scan {
     sonde_scan_cfg_t cfg{};
     sonde_scan_info_t info{};
     hipStream_t stream = nullptr;
+    hipEvent_t ev_fe[3] = { nullptr, nullptr, nullptr }; bool fe_pending = false, fe_timed = false;      // front end / scan_if timing of the call in flight (read at its first host wait)
+    hipEvent_t ev_rw[3] = { nullptr, nullptr, nullptr };                  // run_windows' timing events
+    hipEvent_t ev_wait = nullptr;                                       // sonde_scan_wait_stream
     // design
     Decimator dec; int Q = 0; int lut_len = 1; int DS = 0; float *d_wtab = nullptr;
     std::vector<float> wtab;
@@ -199,6 +202,13 @@ struct sonde_scan {
 
 static void timed(sonde_scan *s, const char *name, hipEvent_t a, hipEvent_t b) {
     float ms = 0; if (hipEventElapsedTime(&ms, a, b) == hipSuccess) { auto &k = s->stats[name]; k.ms += ms; k.n += 1; }
+}
+
+// the events around the front end and k_scan_if are read at the call's first host wait (behind the prefilter): the call does not stop for them
+static void flush_front_timing(sonde_scan *s) {
+    if (!s->fe_pending) return;
+    s->fe_pending = false;
+    if (s->fe_timed) { timed(s, "front_end", s->ev_fe[0], s->ev_fe[1]); timed(s, "scan_if", s->ev_fe[1], s->ev_fe[2]); }
 }
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
@@ -415,6 +425,9 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
 void sonde_scan_destroy(sonde_scan_t *s) {
     if (!s) return;
     if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    for (auto &e : s->ev_fe) if (e) hipEventDestroy(e);
+    for (auto &e : s->ev_rw) if (e) hipEventDestroy(e);
+    if (s->ev_wait) hipEventDestroy(s->ev_wait);
     if (s->d_spprof) {
         unsigned long long h[8] = {0};
         if (hipMemcpy(h, s->d_spprof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[7])
@@ -606,7 +619,8 @@ static int run_windows(sonde_scan *s) {
         }
         first_item[C] = n_items;
         if (!n_items) break;
-        hipEvent_t e0, e1, e2; hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+        for (auto &e : s->ev_rw) if (!e) HIPCHK(hipEventCreate(&e));
+        hipEvent_t e0 = s->ev_rw[0], e1 = s->ev_rw[1], e2 = s->ev_rw[2];
         ScanCorrArgs a{};
         a.fm = s->d_fm; a.n_ch = C; a.ring_len = s->ring_len; a.items = s->d_items; a.n_items = n_items;
         memcpy(a.tpl, s->tpl, sizeof a.tpl);
@@ -637,7 +651,7 @@ static int run_windows(sonde_scan *s) {
             std::vector<ScanRes> keep(s->h_res, s->h_res + (size_t)n_items * SC_NTPL);
             HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
             hipEventRecord(e2, s->stream);
-            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream)); flush_front_timing(s);
             for (int i = 0; i < n_items; i++) for (int j = 0; j < SC_NTPL; j++) if (!s->tpl[j].active) s->h_res[(size_t)i * SC_NTPL + j] = keep[(size_t)i * SC_NTPL + j];
             timed(s, "scan_corr", e1, e2);
             for (int i = 0; i < n_items; i++) exact[i] = 0xffffu;
@@ -648,7 +662,7 @@ static int run_windows(sonde_scan *s) {
             if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
             HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_items * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
             hipEventRecord(e2, s->stream);
-            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream)); flush_front_timing(s);
             timed(s, "scan_corr", e1, e2);
             for (int i = 0; i < n_items; i++) exact[i] = 0xffffu;
         } else {
@@ -669,7 +683,7 @@ static int run_windows(sonde_scan *s) {
             if (sonde_launch_scan_pre(&pa, s->stream) < 0) return SONDE_E_NOGPU;
             HIPCHK(hipMemcpyAsync(s->h_pre, s->d_pre, (size_t)n_items * SC_NTPL * sizeof(ScanPre), hipMemcpyDeviceToHost, s->stream));
             hipEventRecord(e1, s->stream);
-            HIPCHK(hipStreamSynchronize(s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream)); flush_front_timing(s);
             timed(s, "scan_pre", e0, e1);
             // candidates, and for each the same template in the window before it (this call's, or the last one of the previous call)
             int n_work = 0;
@@ -698,7 +712,7 @@ static int run_windows(sonde_scan *s) {
                 if (sonde_launch_scan_corr(&a, s->stream) < 0) return SONDE_E_NOGPU;
                 HIPCHK(hipMemcpyAsync(s->h_res, s->d_res, (size_t)n_all * SC_NTPL * sizeof(ScanRes), hipMemcpyDeviceToHost, s->stream));
                 hipEventRecord(e2, s->stream);
-                HIPCHK(hipStreamSynchronize(s->stream));
+                HIPCHK(hipStreamSynchronize(s->stream)); flush_front_timing(s);
                 timed(s, "scan_corr", e1, e2);
             }
             // everything else keeps the prefilter's values: below the threshold by more than the margin, header not compared (herrs = -2)
@@ -720,7 +734,6 @@ static int run_windows(sonde_scan *s) {
                 }
             }
         }
-        hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
         for (int c = 0; c < C; c++) {
             Chan &cs = s->chan[c];
             for (int i = first_item[c]; i < first_item[c + 1]; i++) {
@@ -759,7 +772,8 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         d_in = s->d_f32in; if (ch_stride != 0) ch_stride = n_samples;
         f32in = true;
     }
-    hipEvent_t ev[4]; for (auto &e : ev) hipEventCreate(&e);
+    hipEvent_t *ev = s->ev_fe;
+    for (int k = 0; k < 3; k++) if (!ev[k]) HIPCHK(hipEventCreate(&ev[k]));
     const uint32_t m_first = s->m_out;
     hipEventRecord(ev[0], s->stream);
     if (mode == SONDE_SCAN_AUDIO) {
@@ -873,13 +887,27 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         sonde_launch_scan_if(&b, s->stream);
     }
     hipEventRecord(ev[2], s->stream);
-
-    hipEventRecord(ev[3], s->stream);
-    HIPCHK(hipStreamSynchronize(s->stream));
-    if (mode != SONDE_SCAN_AUDIO) { timed(s, "front_end", ev[0], ev[1]); timed(s, "scan_if", ev[1], ev[2]); }
-    for (auto &e : ev) hipEventDestroy(e);
+    // no host wait here: the windows that are due follow from the sample counts alone, so the prefilter is queued straight behind k_scan_if
+    // (round 3 stopped for the stream at this point: one host round trip per call for two timing figures).  A channel parked by the IMET check
+    // re-reads its ring on the host: then the stream is drained first.
+    s->fe_pending = true; s->fe_timed = mode != SONDE_SCAN_AUDIO;
+    bool parked = false;
+    for (int c = 0; c < C; c++) parked |= s->chan[c].imet_hold && !s->chan[c].done;
+    if (parked) { HIPCHK(hipStreamSynchronize(s->stream)); flush_front_timing(s); }
     s->last_windows.clear();
-    return run_windows(s);
+    const int rc = run_windows(s);
+    if (s->fe_pending) { HIPCHK(hipStreamSynchronize(s->stream)); flush_front_timing(s); }      // (no window was due: nothing waited yet)
+    return rc;
+}
+
+/* The scanner's stream waits for everything queued so far on `stream` (a channelizer's, an engine's): the producer of d_in needs no host
+ * synchronisation in front of sonde_scan_process_device. */
+int sonde_scan_wait_stream(sonde_scan_t *s, void *stream) {
+    if (!s) return SONDE_E_ARG;
+    if (!s->ev_wait) HIPCHK(hipEventCreateWithFlags(&s->ev_wait, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(s->ev_wait, (hipStream_t)stream));
+    HIPCHK(hipStreamWaitEvent(s->stream, s->ev_wait, 0));
+    return 0;
 }
 
 int sonde_scan_process_host(sonde_scan_t *s, const void *h_in, int64_t ch_stride, int32_t n_samples) {

@@ -53,6 +53,7 @@ def _lib():
         L.sonde_scan_info.argtypes = [C.c_void_p, C.POINTER(ScanInfo)]
         L.sonde_scan_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_scan_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_scan_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.sonde_scan_finish.argtypes = [C.c_void_p]
         L.sonde_scan_fetch.argtypes = [C.c_void_p, C.POINTER(Detection), C.c_int32]
         L.sonde_scan_channel_done.argtypes = [C.c_void_p, C.c_int32]
@@ -112,6 +113,10 @@ class Scanner:
 
     def process_device(self, ptr: int, ch_stride: int, n: int):
         _chk(_lib().sonde_scan_process_device(self._h, C.c_void_p(ptr), ch_stride, n))
+
+    def wait_stream(self, stream: int):
+        """The scanner's stream waits for what is queued on `stream` (Channelizer.stream(), a torch stream's cuda_stream): no host wait in between."""
+        _chk(_lib().sonde_scan_wait_stream(self._h, C.c_void_p(stream)))
 
     def finish(self):
         """End of input: decide a pending IMET check with the samples that exist."""

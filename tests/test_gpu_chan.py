@@ -127,3 +127,43 @@ def test_wideband_stream_channels_detect_and_decode_like_reference():
     lines = a.stdout.decode().splitlines()
     assert len(lines) >= 2 and all("[OK]" in l for l in lines)
     ch.close()
+
+
+def test_scanner_ordered_behind_the_channelizer_on_the_device():
+    """sonde_scan_wait_stream: the scanner's stream waits for the channelizer's instead of the host waiting in between (what bench.py's scan_wide step
+    does) — same detections, chunk by chunk, as with sonde_chan_sync() in front of every scanner call"""
+    import torch
+    from tools import synth
+    from radiosonde_auto_rx_amd.chan import Channelizer
+    from radiosonde_auto_rx_amd.scan import Scanner, IFIQ
+    sr, M, D, P = 2_400_000, 64, 48, 8
+    spacing = sr / M
+    k_rs41, k_dfm = 9, 52
+    sig = [dict(kind="rs41", fq=(k_rs41 * spacing + 1500.0) / sr, t_first=0.05, amp=0.08),
+           dict(kind="dfm", fq=((k_dfm - M) * spacing - 2000.0) / sr, t_first=0.1, amp=0.08)]
+    x = synth.wideband_capture(sr, 1.6, sig, noise_sigma=0.01, seed=5)
+    n_tot = len(x) // 2 // D * D
+    wb = torch.from_numpy(x).to("cuda")
+    chunk = sr // 4
+    got = {}
+    for ordered in (False, True):
+        ch = Channelizer(sr, M, D, P, max_chunk=chunk)
+        out = torch.zeros(M, ch.max_frames, 2, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        sc = Scanner(sr // D, n_channels=M, iq_mode=IFIQ, dc=True, cont=True, max_chunk=ch.max_frames, bits=32)
+        dets = []
+        for s0 in range(0, n_tot, chunk):
+            take = min(chunk, n_tot - s0)
+            nf = ch.process_device(wb.data_ptr() + 4 * s0, take, out.data_ptr(), ch.max_frames)
+            if ordered:
+                sc.wait_stream(ch.stream())
+            else:
+                ch.sync()
+            if nf > 0:
+                sc.process_device(out.data_ptr(), ch.max_frames, nf)
+                dets += [(d["channel"], d["type"], d["sample"], d["line"]) for d in sc.fetch(verbose=True)]
+            ch.sync()                                   # `out` is rewritten by the next channelizer call: the scanner call above has returned (it ends with a host wait)
+        sc.close(); ch.close()
+        got[ordered] = dets
+    assert got[True] == got[False]
+    assert {(c, t) for c, t, _, _ in got[True]} >= {(k_rs41, "RS41"), (k_dfm, "DFM9")}
