@@ -153,6 +153,14 @@ __device__ __forceinline__ void md_fast_tile_s(uint32_t row_lds, const float *wt
         : [row] "v"(row_lds), [f0] "s"(f0), [dcs] "v"(dcs), [wt] "s"(wt)
         : MD_FAST_CLOBBERS);
 }
+// the one-pass form (MD_FAST_BODY_R): double mixer phase, no mean; dcs += the row's raw samples
+__device__ __forceinline__ void md_fast_tile_r(uint32_t row_lds, const float *wt, double f0, double T, float2v (&acc)[7], float2v &dcs) {
+    asm volatile(MD_FAST_BODY_R
+        : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [a2] "+v"(acc[2]), [a3] "+v"(acc[3]), [a4] "+v"(acc[4]), [a5] "+v"(acc[5]),
+          [a6] "+v"(acc[6]), [dcs] "+v"(dcs), [T] "+v"(T)
+        : [row] "v"(row_lds), [f0] "s"(f0), [wt] "s"(wt)
+        : MD_FAST_CLOBBERS);
+}
 // y -= avg * E (complex)
 __device__ __forceinline__ float2v md_dc_correct(float2v y, float2 avg, float2 E) {
     y.x = fmaf(-avg.x, E.x, y.x); y.y = fmaf(-avg.x, E.y, y.y);
@@ -171,6 +179,11 @@ __device__ __forceinline__ float2 md_phasor(double f0, uint32_t n) {
     const float fr = __builtin_amdgcn_fractf((float)(f0 * (double)n));
     return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
 }
+// the scanner's table: ex[n] = cexp(2 pi i f0 n) with the phase in double, reduced before the single rounding (dft_detect.c:1090-1093)
+__device__ __forceinline__ float2 md_phasor64(double f0, uint32_t n) {
+    const float fr = (float)__builtin_amdgcn_fract(f0 * (double)n);
+    return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
+}
 // table index of the launch's first sample / blocks since the last change of the IQ-DC mean, for a channel that may have been restarted at run time
 __device__ __forceinline__ uint32_t md_lut_phase(const MixDecArgs &a, int ch) {
     if (!a.epoch_phase) return a.lut_phase;
@@ -182,7 +195,7 @@ __device__ __forceinline__ int md_dc_since(const MixDecArgs &a, int ch) { return
 // k_md_etable: E[ch][i] = sum_{q<Q} sum_{r<D} W_q[r] ex[D ((i-(Q-1)+q) mod P) + r], i < P = lut_len / D: the decimator's output for
 // the input x = 1 when the block that completes the output is block i of the mixer table's period.  Once per engine.
 __global__ __launch_bounds__(256)
-void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, float2 *etab) {
+void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, float2 *etab, int ph64) {
     const int ch = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const double f0 = chan_f0[ch];
@@ -190,7 +203,7 @@ void k_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, 
     for (int q = 0; q < Q; q++) {
         const uint32_t n0 = (uint32_t)D * (uint32_t)((i - (Q - 1) + q + P) % P);
         for (int r = 0; r < D; r++) {
-            const float2 e = md_phasor(f0, n0 + (uint32_t)r);
+            const float2 e = ph64 ? md_phasor64(f0, n0 + (uint32_t)r) : md_phasor(f0, n0 + (uint32_t)r);
             const float w = wtab[8 * r + q];
             er = fmaf(w, e.x, er); ei = fmaf(w, e.y, ei);
         }
@@ -472,6 +485,181 @@ void k_mix_decimate50s(const MixDecArgs a) {
     }
 }
 
+// k_mix_decimate50r — the scanner's base-rate front end in ONE pass over the input (round 4).  dft_detect takes the mean of the PREVIOUS 1/32 s window off
+// every sample (dft_detect.c:539-588): k_mix_decimate50s therefore runs behind a pass of its own that does nothing but add (k_dc_seg_sums — the input is
+// read twice, and the two passes together are HBM-bound).  The filter is linear: y = sum W (x - mean) ex = sum W x ex - sum over the blocks of mean(block) *
+// (the block's part of E).  So the sample loop here needs no mean at all (MD50_LOOP_R: the raw sum, and every block's sum of raw samples to bsum — 8 bytes
+// per 200 of input), every window is mixed in parallel, and what depends on the means happens at the IF rate, on 1/50 of the bytes: k_dc_rows_to_segments adds
+// the block sums up per window, k_dc_seg_means makes the table of means (unchanged), k_scan_dc_edges tabulates what the Q-1 outputs behind a change of the
+// mean need on top, and k_scan_if subtracts mean * E from every output AS IT LOADS IT (ScanFold; a pass of its own over y cost 0.27 ms per 512 channel-seconds).
+// The P tail between calls holds raw partial sums; the ring y holds raw outputs (k_scan_if keeps the folded history it needs).  Rounding: y - mean * E rounds relative to |mean|, not to |x - mean| — 1e-8 of the offset, as in the demodulator's decimator.
+#define MD50R_ASM(BODY) asm volatile(BODY \
+        : [o0] "=v"(acc[0]), [o1] "=v"(acc[1]), [o2] "=v"(acc[2]), [o3] "=v"(acc[3]), [o4] "=v"(acc[4]), [o5] "=v"(acc[5]), [o6] "=v"(acc[6]), \
+          [carry] "+v"(carry), [e] "+v"(eidx), [jrow] "+v"(jrow) \
+        : [row] "v"(row_lds), [voff16] "v"(voff16), [voff8] "v"(voff8), [ldsw16] "v"(ldsw16), [ldsw8] "v"(ldsw8), [lane4] "v"(lane4), \
+          [tb] "s"(tb), [f0] "s"(f0), [wt] "s"(wt_s), [yout] "s"(yout), [jm] "s"(jm), [rmask] "s"(rmask), [P] "s"(P), \
+          [nfull] "s"(nfull), [outmask] "s"(outmask), [bsum] "s"(bsum) \
+        : MD50_CLOBBERS)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_mix_decimate50r(const MixDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
+    constexpr int Q_T = 7, H = 6, D = 50, TILE_DW = MD_ROWS * D;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *sRaw = smem_u + wave * (TILE_DW + 4);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(sRaw);
+    const uint32_t row_lds = lds0 + 4u * D * lane, ldsw16 = lds0 + 16u * lane, ldsw8 = lds0 + 8u * lane;
+    const uint32_t voff16 = 16u * lane, voff8 = 8u * lane, lane4 = 4u * lane;
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int ch = (slot / a.wgs_per_ch) * 8 + xcd;
+    const int wg = slot % a.wgs_per_ch;
+    if (ch >= a.n_ch) return;
+    const int seg = wg * 4 + wave;
+    const int rows_per_seg = MD_ROWS * a.G - H;
+    const int jb = seg * rows_per_seg;
+    if (jb >= a.nblocks) return;
+    const int je = min(a.nblocks, jb + rows_per_seg);
+    const int jt0 = (seg == 0) ? jb : jb - H;
+    const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
+    const int nfull = (a.nblocks & 1) ? 0 : min(ntiles, (a.nblocks - jt0) / MD_ROWS);      // (odd launches: channel rows need not sit on the 16-byte grid)
+
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const double f0 = a.chan_f0[ch];
+    float2 *yout = a.y + (size_t)ch * a.ring_len;
+    const float *wt_s = a.wtab_g + 64 * 8;                     // tap rows * 2^-15
+    const uint32_t rmask = (uint32_t)a.ring_len - 1;
+    const uint32_t P = (uint32_t)(a.lut_len / D);              // blocks per period of the mixer table
+    int2 *bsum = a.bsum + (size_t)ch * a.bsum_stride;
+
+    // carry: what the P rows before this tile add to its first H outputs (lane l < H: sum over q of P[l-(H-q)][q], rows < 0)
+    float2v carry = {0.f, 0.f};
+    if (seg == 0 && lane < H) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int i = lane + q;
+            if (i < H) { const float2 v = a.ptail_in[((size_t)ch * 8 + i) * 8 + q]; carry += (float2v){v.x, v.y}; }
+        }
+    }
+    uint32_t eidx = (uint32_t)(((uint64_t)(a.lut_phase / D) + (uint64_t)(jt0 + lane)) % P);
+    uint32_t jrow = (uint32_t)(jt0 + lane);
+    float2v acc[Q_T];
+
+    if (nfull > 0) {
+        const uint32_t *tb = iq + (size_t)jt0 * D;
+        const uint32_t jm = a.m0 + (uint32_t)jt0;
+        const uint64_t outmask = (seg == 0) ? ~0ull : ~0ull << H;
+        MD50R_ASM(MD50_LOOP_R);
+        const int j = jt0 + (nfull - 1) * MD_ROWS + lane;
+        if (j >= a.nblocks - H && j < a.nblocks) {
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+    }
+    // tiles the generated loop does not take — the one that sticks out of the chunk, every tile of a launch with an odd number of blocks (channel rows off the
+    // 16-byte grid) or of fewer than 64: checked loads, one tile at a time, the carry handed on in C++
+#pragma unroll 1
+    for (int t = nfull; t < ntiles; t++) {
+        const int jt = jt0 + t * MD_ROWS, total_dw = a.nblocks * D;
+#pragma unroll 1
+        for (int v = 0; v < 13; v++) {
+            const int c = 64 * v + lane, off = jt * D + 4 * c;
+            u32x4_u w = {0u, 0u, 0u, 0u};
+            if (4 * c < TILE_DW && off + 4 <= total_dw) w = *reinterpret_cast<const u32x4_u *>(iq + off);
+            else if (4 * c < TILE_DW) { if (off < total_dw) w.x = iq[off]; if (off + 1 < total_dw) w.y = iq[off + 1]; if (off + 2 < total_dw) w.z = iq[off + 2]; }      // (an odd launch ends inside a quad)
+            if (4 * c < TILE_DW) *reinterpret_cast<uint4 *>(sRaw + 4 * c) = make_uint4(w.x, w.y, w.z, w.w);
+        }
+        const int j = jt + lane;
+        const bool outrow = j >= jb && j < je;
+#pragma unroll
+        for (int q = 0; q < Q_T; q++) acc[q] = (float2v){0.f, 0.f};
+        float2v dcs = {0.f, 0.f};
+        md_fast_tile_r(row_lds, wt_s, f0, f0 * (double)(eidx * (uint32_t)D), acc, dcs);
+        if (outrow) bsum[j] = make_int2((int)dcs.x, (int)dcs.y);
+        float2v y = acc[H] + carry, cnext = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int k = H - q, src = (lane - k) & 63;
+            const float2v r = { __shfl(acc[q].x, src), __shfl(acc[q].y, src) };
+            if (lane >= k) y += r; else cnext += r;           // lanes < k hold rows 64 - k + lane of this tile: the next tile's carry
+        }
+        carry = cnext;
+        if (outrow) yout[(a.m0 + (uint32_t)j) & rmask] = make_float2(y.x, y.y);
+        if (j >= a.nblocks - H && j < a.nblocks) {
+#pragma unroll
+            for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + (j - (a.nblocks - H))) * 8 + q] = make_float2(acc[q].x, acc[q].y);
+        }
+        eidx += 64u; eidx = eidx >= P ? eidx - P : eidx;
+    }
+}
+
+
+// block sums -> window sums: window k of the launch covers blocks [k B - off, (k + 1) B - off) of it (k_dc_seg_sums' output, from 1/25 of its input)
+__global__ __launch_bounds__(256)
+void k_dc_rows_to_segments(const int2 *bsum, long long bsum_stride, int nblocks, int seg_off, int seg_blocks, long long *seg_sums, int nseg) {
+    const int k = blockIdx.x, ch = blockIdx.y;
+    const long long lo = (long long)k * seg_blocks - seg_off, hi = lo + seg_blocks;
+    const int j0 = (int)(lo < 0 ? 0 : lo), j1 = (int)(hi > nblocks ? nblocks : hi);
+    const int2 *p = bsum + (size_t)ch * bsum_stride;
+    long long lx = 0, ly = 0;
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += 256) { const int2 v = p[j]; lx += v.x; ly += v.y; }
+    for (int off = 32; off > 0; off >>= 1) { lx += __shfl_down(lx, off); ly += __shfl_down(ly, off); }
+    __shared__ long long s_l[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_l[2 * wave] = lx; s_l[2 * wave + 1] = ly; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tx = 0, ty = 0;
+        for (int w = 0; w < 4; w++) { tx += s_l[2 * w]; ty += s_l[2 * w + 1]; }
+        seg_sums[((size_t)ch * nseg + k) * 2] = tx; seg_sums[((size_t)ch * nseg + k) * 2 + 1] = ty;
+    }
+}
+// The Q-1 outputs behind a change of the IQ-DC mean: output m = (start of window k) + i, i < Q-1, sums Q blocks of which the first Q-1-i still ran under
+// the mean of window k-1.  k_scan_if takes mean(k) * E[e] off every output (E = sum over the Q blocks' parts, k_md_etable); what is missing for these is
+// corr[ch][k][i] = -(mean(k-1) - mean(k)) * sum_{q < Q-1-i} Eblk(e, q),  Eblk(e, q) = sum_r W_q[r] ex[D ((e - (Q-1) + q) mod P) + r]  (k_md_etable's order).
+// A window that began before the launch (k = 0 with dc_seg_off > 0) has its first outputs in the launch before; mean(-1) travels in dc_prev.
+// (Eblk(e + i, q) is the tap column q over table block e - (Q-1) + t, t = i + q: 21 (t, q) pairs of D terms for Q = 7.  A lane takes one pair and a third of
+// its D terms — one lane per output walked 300 dependent sincos and the launch took 0.115 ms.)
+__global__ __launch_bounds__(64)
+void k_scan_dc_edges(const ScanEdgeArgs a) {
+    const int k = blockIdx.x, ch = blockIdx.y, lane = threadIdx.x;
+    const int H = a.Q - 1, P = a.etab_len;
+    if (k >= a.nseg) return;
+    __shared__ float2 s_part[64];
+    const int m0w = k * a.dc_seg_blocks - a.dc_seg_off;                 // the window's first block, as a block of this launch (negative: it began before)
+    const uint32_t e0w = (uint32_t)((((long long)a.e0 + (long long)m0w) % P + P) % P);      // its table block
+    const double f0 = a.chan_f0[ch];
+    // pair p < H (H + 1) / 2: t = row of the triangle, q <= t; lanes p, p + 21, p + 42 share its D terms
+    const int np = H * (H + 1) / 2;
+    const int p = lane % np, part = lane / np, nparts = 64 / np;
+    float er = 0.f, ei = 0.f;
+    if (part < nparts) {
+        int t = 0, q = p; while (q > t) { q -= t + 1; t++; }             // p = t (t + 1) / 2 + q
+        const uint32_t n0 = (uint32_t)a.D * (uint32_t)(((long long)e0w - H + t + 2LL * P) % P);
+        const int per = (a.D + nparts - 1) / nparts, r0 = part * per, r1 = min(a.D, r0 + per);
+        for (int r = r0; r < r1; r++) {
+            const float2 ex = md_phasor64(f0, n0 + (uint32_t)r);
+            const float w = a.wtab[8 * r + q];
+            er = fmaf(w, ex.x, er); ei = fmaf(w, ex.y, ei);
+        }
+    }
+    s_part[lane] = make_float2(er, ei);
+    __syncthreads();
+    if (lane < H) {
+        const int i = lane, m = m0w + i;
+        float2 *out = a.corr + ((size_t)ch * a.dc_seg_n + k) * 8 + i;
+        if (m < 0 || m >= a.nblocks) { *out = make_float2(0.f, 0.f); return; }
+        float sr = 0.f, si = 0.f;
+        for (int q = 0; q < H - i; q++) {                               // blocks of output i that lie before the change: tap columns q < H - i, table row t = i + q
+            const int t = i + q, pp = t * (t + 1) / 2 + q;
+            for (int c = 0; c < nparts; c++) { const float2 v = s_part[pp + c * np]; sr += v.x; si += v.y; }
+        }
+        const float2 mn = a.dc_seg[(size_t)ch * a.dc_seg_n + k], mo = k > 0 ? a.dc_seg[(size_t)ch * a.dc_seg_n + k - 1] : a.dc_prev[ch];
+        const float dx = mn.x - mo.x, dy = mn.y - mo.y;                 // -(mo - mn)
+        *out = make_float2(dx * sr - dy * si, dx * si + dy * sr);
+    }
+}
+
 template <int Q_T, bool PH64, int D_T, int FAST>
 __global__ __launch_bounds__(256)
 void k_mix_decimate(const MixDecArgs a) {
@@ -675,21 +863,24 @@ void k_dc_seg_sums(const int16_t *iq, long long ch_stride, int n_samples, unsign
         seg_sums[((size_t)ch * nseg + k) * 2] = tx; seg_sums[((size_t)ch * nseg + k) * 2 + 1] = ty;
     }
 }
-__global__ void k_dc_seg_means(int n_ch, int nseg, int ncomplete, float maxcnt, const long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n) {
+__global__ void k_dc_seg_means(int n_ch, int nseg, int ncomplete, float maxcnt, const long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n,
+                               float2 *dc_prev = nullptr) {      // dc_prev (optional): keeps the mean of the window before the one in progress (k_scan_dc_edges)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_ch) return;
-    float2 mean = dc_avg[c];
+    float2 mean = dc_avg[c], prev = dc_prev ? dc_prev[c] : mean;
     long long cx = dc_sums[2 * c], cy = dc_sums[2 * c + 1];   // what the window in progress had collected before this call
     for (int k = 0; k < dc_seg_n; k++) {
         dc_seg[(size_t)c * dc_seg_n + k] = mean;
         if (k >= nseg) continue;
         cx += seg_sums[((size_t)c * nseg + k) * 2]; cy += seg_sums[((size_t)c * nseg + k) * 2 + 1];
         if (k < ncomplete) {                                  // avg = (float)(sum / (float)maxcnt), sum = S / 32768 exact in double (k_dc_update)
+            prev = mean;
             mean = make_float2((float)(((double)cx / 32768.0) / (double)maxcnt), (float)(((double)cy / 32768.0) / (double)maxcnt));
             cx = 0; cy = 0;
         }
     }
     dc_avg[c] = mean; dc_sums[2 * c] = cx; dc_sums[2 * c + 1] = cy;
+    if (dc_prev) dc_prev[c] = prev;
 }
 
 // Decimation factors above 64 (input rates above ~3 Msps, e.g. a 10 Msps wideband stream): same lane-per-block scheme,
@@ -2271,6 +2462,30 @@ extern "C" void sonde_launch_dc_segments(const int16_t *iq, long long ch_stride,
     hipLaunchKernelGGL(k_dc_seg_sums, dim3(nseg, n_ch), dim3(256), 0, s, iq, ch_stride, n_samples, dc_cnt0, dc_max, seg_sums, nseg);
     hipLaunchKernelGGL(k_dc_seg_means, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, (float)dc_max, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n);
 }
+extern "C" int sonde_launch_mix_decimate50r(const MixDecArgs *a, hipStream_t s) {
+    if (a->D != 50 || a->Q != 7 || a->lut_len % 50 || a->lut_phase % 50 || !a->wtab_scaled || !a->bsum || a->bsum_stride < a->nblocks || a->dc_seg) return -1;
+    MixDecArgs b = *a;
+    const int H = b.Q - 1, rps = 64 * b.G - H;
+    if (b.G < 1 || rps < 1) return -1;
+    const int segs = (b.nblocks + rps - 1) / rps;
+    b.wgs_per_ch = (segs + 3) / 4;
+    const int ch8 = (b.n_ch + 7) / 8;
+    const size_t lds = (size_t)4 * (64 * b.D + 4) * sizeof(uint32_t);
+    static bool attr = false;
+    if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_mix_decimate50r), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; attr = true; }
+    hipLaunchKernelGGL(k_mix_decimate50r, dim3((unsigned)(ch8 * b.wgs_per_ch * 8)), dim3(256), lds, s, b);
+    return 0;
+}
+extern "C" void sonde_launch_dc_rows_to_segments(const int2 *bsum, long long bsum_stride, int n_ch, int nblocks, int seg_off, int seg_blocks, float maxcnt,
+                                                 long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_prev, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
+    const int nseg = (seg_off + nblocks + seg_blocks - 1) / seg_blocks, ncomplete = (seg_off + nblocks) / seg_blocks;
+    hipLaunchKernelGGL(k_dc_rows_to_segments, dim3(nseg, n_ch), dim3(256), 0, s, bsum, bsum_stride, nblocks, seg_off, seg_blocks, seg_sums, nseg);
+    hipLaunchKernelGGL(k_dc_seg_means, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, maxcnt, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n, dc_prev);
+}
+extern "C" void sonde_launch_scan_dc_edges(const ScanEdgeArgs *a, hipStream_t s) {
+    if (a->nseg <= 0) return;
+    hipLaunchKernelGGL(k_scan_dc_edges, dim3(a->nseg, a->n_ch), dim3(64), 0, s, *a);
+}
 extern "C" void sonde_launch_dc_segments_f32(const float2 *x, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,
                                              double *seg_sums, double *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
     const int nseg = (int)(((unsigned long long)dc_cnt0 + (unsigned)n_samples + dc_max - 1) / dc_max);
@@ -2292,7 +2507,10 @@ extern "C" void sonde_launch_publish_u32(const unsigned *src, unsigned *dst_mapp
     hipLaunchKernelGGL(k_publish_u32, dim3(1), dim3(64), 0, s, src, dst_mapped);
 }
 extern "C" void sonde_launch_md_etable(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s) {
-    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab);
+    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab, 0);
+}
+extern "C" void sonde_launch_md_etable64(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s) {
+    hipLaunchKernelGGL(k_md_etable, dim3((P + 255) / 256, n_ch), dim3(256), 0, s, chan_f0, wtab, D, Q, P, etab, 1);
 }
 extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, int16_t *out, long long out_stride, int n_ch, int n_bytes, hipStream_t s) {
     int gx = (n_bytes / 4 + 255) / 256; if (gx > 1024) gx = 1024; if (gx < 1) gx = 1;

@@ -168,6 +168,8 @@ struct sonde_scan {
     sonde_scan_info_t info{};
     hipStream_t stream = nullptr;
     hipEvent_t ev_fe[3] = { nullptr, nullptr, nullptr }; bool fe_pending = false, fe_timed = false;      // front end / scan_if timing of the call in flight (read at its first host wait)
+    // one-pass front end (k_mix_decimate50r): decided when the scanner is made — the P tail between calls holds raw sums in this form
+    bool front_raw = false; float2 *d_etab64 = nullptr; int etab_len = 0; int2 *d_bsum = nullptr; long long bsum_stride = 0; float2 *d_corr = nullptr, *d_dcprev = nullptr, *d_hist[2] = { nullptr, nullptr }; int hist_cur = 0; bool fold_pending = false; ScanFold fold{};
     hipEvent_t ev_rw[3] = { nullptr, nullptr, nullptr };                  // run_windows' timing events
     hipEvent_t ev_wait = nullptr;                                       // sonde_scan_wait_stream
     // design
@@ -413,6 +415,21 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
     // IQ-DC: always on, fixed window (dft_detect.c:1152-1156)
     s->dc_max = (uint32_t)(sr / 32); if (D > 1) s->dc_max *= (uint32_t)D;
     if (iq && (s->dc_max == 0 || s->dc_max % D)) { sonde_scan_destroy(s); return SONDE_E_ARG; }
+    {   // int16 / 8-bit base-rate input at the generated decimator's geometry (D = 50, Q = 7, a mixer table whose period is whole blocks): the front end reads its
+        // input ONCE (k_mix_decimate50r + the fold at the IF rate) instead of a summing pass and a mixing pass.  SONDE_SCAN_TWO_PASS=1: the two-pass form (A/B)
+        const bool two_pass = getenv("SONDE_SCAN_TWO_PASS") != nullptr;
+        if (cfg->iq_mode == SONDE_SCAN_BBIQ && cfg->bits != 32 && !s->wide_fe && D == 50 && s->Q == 7 && s->lut_len % D == 0 && s->d_wtab && !two_pass) {
+            s->etab_len = s->lut_len / D;
+            s->bsum_stride = (cfg->max_chunk + D - 1) / D;
+            const int nseg_cap = cfg->max_chunk / (int)s->dc_max + 2;
+            if (dalloc(&s->d_etab64, (size_t)C * s->etab_len, false) || dalloc(&s->d_bsum, (size_t)C * s->bsum_stride, false)
+                || dalloc(&s->d_corr, (size_t)C * (nseg_cap + 1) * 8) || dalloc(&s->d_dcprev, (size_t)C)
+                || dalloc(&s->d_hist[0], (size_t)C * s->lpiq_taps) || dalloc(&s->d_hist[1], (size_t)C * s->lpiq_taps)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
+            sonde_launch_md_etable64(s->d_chanf0, s->d_wtab, D, s->Q, s->etab_len, C, s->d_etab64, nullptr);      // E of the double-phase mixer table, once
+            HIPCHK(hipDeviceSynchronize());
+            s->front_raw = true;
+        }
+    }
     s->chan.resize(C);
     for (auto &c : s->chan) {
         for (int j = 0; j < kNrs; j++) { c.mv[j] = 0; c.mv_pos[j] = 0; c.mv0_pos[j] = 0; c.mp[j] = 0; c.dc[j] = 0; c.df[j] = 0; c.type[j] = kTpl[j].type; c.tn[j] = kTpl[j].tn; c.detect2[j] = 0; }
@@ -440,7 +457,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_pre) hipHostFree(s->h_pre);
     if (s->h_work) hipHostFree(s->h_work);
     void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_scratch, s->d_f32in, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg, s->d_etab64, s->d_bsum, s->d_corr, s->d_dcprev, s->d_hist[0], s->d_hist[1] };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -788,7 +805,44 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         // windows it spans (1/32 s each: 32 per second of signal) handled by a table of means (MixDecArgs.dc_seg) that two small kernels fill first —
         // a launch per window made the front end launch-bound (64 launches of ~9 us per second of signal)
         static const bool no_segtab = getenv("SONDE_SCAN_NO_SEGTAB") != nullptr;      // A/B aid
-        if (mode == SONDE_SCAN_BBIQ && !f32in && D <= 64 && n_samples % D == 0 && s->dc_cnt % (uint32_t)D == 0 && !no_segtab) {
+        if (s->front_raw) {
+            // one pass over the input: raw mix + block sums, then window sums -> means -> y -= mean * E at the IF rate
+            if (mode != SONDE_SCAN_BBIQ || f32in || n_samples % D || s->dc_cnt % (uint32_t)D) return SONDE_E_ARG;      // (cannot happen: whole blocks per call)
+            const int nseg_cap = s->cfg.max_chunk / (int)s->dc_max + 2;
+            if (!s->d_segsums) {
+                HIPCHK(hipMalloc((void **)&s->d_segsums, (size_t)C * nseg_cap * 2 * sizeof(long long)));
+                HIPCHK(hipMalloc((void **)&s->d_dcseg, (size_t)C * (nseg_cap + 1) * sizeof(float2)));
+            }
+            const int nb = n_samples / D, seg_off = (int)(s->dc_cnt / (uint32_t)D), seg_blocks = (int)(s->dc_max / (uint32_t)D);
+            MixDecArgs a{};
+            a.iq = (const int16_t *)d_in; a.ch_stride = ch_stride; a.n_ch = C; a.nblocks = nb;
+            a.D = D; a.Q = s->Q; memcpy(a.wtab, s->wtab.data(), sizeof a.wtab); a.wtab_g = s->d_wtab; a.wtab_scaled = 1; a.chan_f0 = s->d_chanf0; a.lut_len = s->lut_len;
+            a.lut_phase = (uint32_t)(s->samples_in % (uint64_t)s->lut_len);
+            a.ptail_in = s->d_ptail[s->ptail_cur]; a.ptail_out = s->d_ptail[s->ptail_cur ^ 1];
+            a.y = s->d_y; a.ring_len = s->ring_len; a.m0 = s->m_out; a.phase_f64 = 1;
+            a.bsum = s->d_bsum; a.bsum_stride = s->bsum_stride;
+            { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
+            if (sonde_launch_mix_decimate50r(&a, s->stream) < 0) return SONDE_E_ARG;
+            sonde_launch_dc_rows_to_segments(s->d_bsum, s->bsum_stride, C, nb, seg_off, seg_blocks, (float)s->dc_max, s->d_segsums, s->d_dcsums, s->d_dcavg,
+                                             s->d_dcprev, s->d_dcseg, nseg_cap + 1, s->stream);
+            ScanEdgeArgs g{};
+            g.n_ch = C; g.nblocks = nb; g.D = D; g.Q = s->Q; g.nseg = (seg_off + nb + seg_blocks - 1) / seg_blocks;
+            g.dc_seg = s->d_dcseg; g.dc_seg_n = nseg_cap + 1; g.dc_seg_off = seg_off; g.dc_seg_blocks = seg_blocks; g.dc_prev = s->d_dcprev;
+            g.etab_len = s->etab_len; g.e0 = (uint32_t)((a.lut_phase / (uint32_t)D) % (uint32_t)s->etab_len);
+            g.chan_f0 = s->d_chanf0; g.wtab = s->d_wtab; g.corr = s->d_corr;
+            sonde_launch_scan_dc_edges(&g, s->stream);
+            ScanFold &f = s->fold;                              // what k_scan_if (below) folds with
+            f.etab = s->d_etab64; f.etab_len = s->etab_len; f.e0 = g.e0; f.m0 = s->m_out; f.nblocks = nb;
+            f.dc_seg = s->d_dcseg; f.dc_seg_n = nseg_cap + 1; f.dc_seg_off = seg_off; f.dc_seg_blocks = seg_blocks;
+            f.corr = s->d_corr; f.edge_n = s->Q - 1;
+            f.hist_in = s->d_hist[s->hist_cur]; f.hist_out = s->d_hist[s->hist_cur ^ 1]; f.hist_n = s->lpiq_taps;
+            s->fold_pending = true;
+            s->ptail_cur ^= 1; s->hist_cur ^= 1;
+            s->samples_in += (uint64_t)n_samples; s->m_out += (uint32_t)nb;
+            s->dc_cnt = (uint32_t)(((uint64_t)s->dc_cnt + (uint64_t)n_samples) % s->dc_max);
+            done = n_samples;
+        }
+        if (done < n_samples && mode == SONDE_SCAN_BBIQ && !f32in && D <= 64 && n_samples % D == 0 && s->dc_cnt % (uint32_t)D == 0 && !no_segtab) {
             const int nseg_cap = s->cfg.max_chunk / (int)s->dc_max + 2;
             if (!s->d_segsums) {
                 HIPCHK(hipMalloc((void **)&s->d_segsums, (size_t)C * nseg_cap * 2 * sizeof(long long)));
@@ -884,6 +938,7 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
         b.taps = s->lpiq_taps; b.nfilt = s->nfilt; b.w = s->d_wiq;
         for (int k = 0; k < 3; k++) b.filt_stream[k] = s->filt_stream[k];
         b.raw_stream = s->raw_stream;
+        if (s->fold_pending) { b.fold = s->fold; s->fold_pending = false; }      // one-pass front end: y holds raw sums, the means come off as k_scan_if loads
         sonde_launch_scan_if(&b, s->stream);
     }
     hipEventRecord(ev[2], s->stream);

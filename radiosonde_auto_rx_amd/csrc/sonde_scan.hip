@@ -82,12 +82,42 @@ void k_scan_if(const ScanIfArgs a) {
     float2 *sz = sy + SI_TILE + T4 + 4;          // [3][SI_TILE + 4] z_b[t0 - 1 + k]   (an even number of float2 in front: the tap rows behind stay 16-byte aligned)
     float  *sw = reinterpret_cast<float *>(sz + 3 * (SI_TILE + 4));   // [nfilt][T4], zero padded: 16-byte rows
     const float2 *yr = a.y + (size_t)ch * a.ring_len;
+    const ScanFold &fo = a.fold;
     for (int k = tid; k < SI_TILE + T + 4; k += SI_THREADS) {
         const int64_t m = (int64_t)t0 - T + k;
-        sy[k] = (m >= 0 && k < nout + T) ? yr[(uint32_t)m & mask] : make_float2(0.f, 0.f);
+        float2 v = make_float2(0.f, 0.f);
+        if (m >= 0 && k < nout + T) {
+            if (!fo.etab) v = yr[(uint32_t)m & mask];
+            else {
+                // y holds the raw sums of k_mix_decimate50r: the IQ-DC mean of the block's window comes off here, y -= mean * E (+ what the first Q-1 outputs of a
+                // window need on top, k_scan_dc_edges).  Samples of earlier launches: the folded history the launch before left (their means are gone)
+                const int32_t j = (int32_t)((uint32_t)m - fo.m0);
+                if (j >= 0) {
+                    v = yr[(uint32_t)m & mask];
+                    const uint32_t jo = (uint32_t)j + (uint32_t)fo.dc_seg_off, B = (uint32_t)fo.dc_seg_blocks;
+                    uint32_t kw = jo / B; const uint32_t rem = jo - kw * B;
+                    kw = kw < (uint32_t)fo.dc_seg_n - 1u ? kw : (uint32_t)fo.dc_seg_n - 1u;
+                    const uint32_t e = (fo.e0 + (uint32_t)j) % (uint32_t)fo.etab_len;
+                    const float2 mean = fo.dc_seg[(size_t)ch * fo.dc_seg_n + kw], E = fo.etab[(size_t)ch * fo.etab_len + e];
+                    v.x = fmaf(-mean.x, E.x, v.x); v.y = fmaf(-mean.x, E.y, v.y);
+                    v.x = fmaf(mean.y, E.y, v.x);  v.y = fmaf(-mean.y, E.x, v.y);
+                    if (rem < (uint32_t)fo.edge_n) { const float2 c = fo.corr[((size_t)ch * fo.dc_seg_n + kw) * 8 + rem]; v.x += c.x; v.y += c.y; }
+                } else if (-j <= fo.hist_n) v = fo.hist_in[(size_t)ch * fo.hist_n + (fo.hist_n + j)];
+            }
+        }
+        sy[k] = v;
     }
     for (int k = tid; k < a.nfilt * T4; k += SI_THREADS) { const int bq = k / T4, kk = k % T4; sw[k] = kk < T ? a.w[bq * T + kk] : 0.f; }
     __syncthreads();
+    if (fo.etab) {
+        // the folded outputs the next launch's first tile needs as its history: the last hist_n of this launch (a launch shorter than that: the older ones move up)
+        const uint32_t m_end = fo.m0 + (uint32_t)fo.nblocks;
+        for (int i = tid; i < nout; i += SI_THREADS) {
+            const uint32_t back = m_end - (t0 + (uint32_t)i);                  // 1 = the launch's last output
+            if (back <= (uint32_t)fo.hist_n) fo.hist_out[(size_t)ch * fo.hist_n + (fo.hist_n - (int)back)] = sy[T + i];
+        }
+        if (blockIdx.x == 0) for (int i = tid; i < fo.hist_n - fo.nblocks; i += SI_THREADS) fo.hist_out[(size_t)ch * fo.hist_n + i] = fo.hist_in[(size_t)ch * fo.hist_n + i + fo.nblocks];
+    }
     // z_b[m] = sum_k w_b[k] * y[m-(T-1)+k] for m = t0-1 .. t0+nout-1 (oldest sample pairs with tap 0, dft_detect.c:696-705): outputs o = 4 tid .. 4 tid + 3
     // of the nout + 1; the last thread's window runs into the zero padding behind the tile
     for (int o0 = SI_PER * tid; o0 < nout + 1; o0 += SI_PER * SI_THREADS) {

@@ -65,6 +65,15 @@ struct ScanPreArgs {
     ScanPre *out;             // [n_items][SC_NTPL]
     unsigned long long *prof; // SONDE_SP_PROF: shader cycles per phase of the workgroups of template 1 (RS41), [8]; nullptr = off
 };
+// What k_scan_if needs to take the IQ-DC means off the raw outputs of k_mix_decimate50r as it loads them: y -= mean(window of the block) * E, and for
+// the Q-1 outputs behind a change of the mean the correction k_scan_dc_edges tabulated (the blocks of the window before ran under the other mean).
+struct ScanFold {
+    const float2 *etab; int etab_len; uint32_t e0; // E[ch][etab_len] (double-phase mixer table, k_md_etable); table block of the launch's first block.  etab == nullptr: no fold
+    uint32_t m0; int nblocks;                       // the launch's outputs are IF samples m0 .. m0 + nblocks - 1
+    const float2 *dc_seg; int dc_seg_n, dc_seg_off, dc_seg_blocks;   // as in MixDecArgs: the mean in effect for the k-th window the launch touches
+    const float2 *corr; int edge_n;                 // [n_ch][dc_seg_n][8]: what output i < edge_n = Q-1 of window k gets on top (k_scan_dc_edges)
+    const float2 *hist_in; float2 *hist_out; int hist_n;             // [n_ch][hist_n]: the last hist_n folded outputs of the previous / of this launch (the FIR's history)
+};
 struct ScanIfArgs {
     const float2 *y;          // [n_ch][ring_len] IF-rate IQ
     float *fm;                // [streams][n_ch][ring_len]
@@ -73,6 +82,7 @@ struct ScanIfArgs {
     const float *w;           // [nfilt][taps]
     int filt_stream[3];       // physical stream of filter b
     int raw_stream;           // physical stream of the unfiltered discriminator
+    ScanFold fold;            // y holds the raw outputs of k_mix_decimate50r: the IQ-DC means come off as the tile is loaded (fold.etab == nullptr: y is final)
 };
 
 struct IqConvArgs {           // --iq: IF-rate IQ in, IQ-DC removed (f32read_csample, dft_detect.c:539-573)

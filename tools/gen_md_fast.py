@@ -62,6 +62,9 @@ class Regs:
         self.acc, self.dcs, self.T, self.row, self.f0, self.wt, self.msk = acc, dcs, T, row, f0, wt, msk
 
 
+RAW = False   # the scanner's front end in ONE pass over the input (round 4): double mixer phase like SCAN, NO mean anywhere in the loop — the outputs are the
+              # raw sum W x ex, and every row's sum of raw samples (the IQ-DC sum of its D samples, exact integers) goes to a side array; the means of the
+              # 1/32 s windows and y -= mean * E follow at the IF rate (k_dc_rows_to_segments, k_scan_dc_fold), where the input is 1/50 of the bytes
 EXP = ""      # experiment variants (tools/ab_variants.sh): timing only, results are garbage
 SCAN = False  # the scanner's front end (scan/dft_detect.c): mixer phase kept in DOUBLE (t = f0 * n, :1090-1093: fract in f64, then one rounding to f32)
               # and the IQ-DC mean of the row's 1/32 s window taken off every sample ((x - avg) ex, :579-588; the means come from a table, a
@@ -99,7 +102,7 @@ def block(R, r, init=False):
         I["cvt64"] = f"v_cvt_f32_f64 {R.TP}, {R.T}"
         I["add64"] = f"v_add_f64 {R.T}, {R.T}, {R.f0}"
         I["fract"] = f"v_fract_f32 {R.TP}, {R.TP}"
-        if SCAN:      # Z is free between the last tap FMA of the previous block and this block's `z`
+        if SCAN or RAW:      # Z is free between the last tap FMA of the previous block and this block's `z`
             I["cvt64"] = f"v_fract_f64 {R.Z}, {R.T}"
             I["fract"] = f"v_cvt_f32_f64 {R.TP}, {R.Z}"
         I["xr"] = f"v_cvt_f32_i32_sdwa {R.XR[e]}, sext({raw}) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
@@ -147,7 +150,7 @@ def walk(R, init=False, hook=()):
 
 # ---- the operand form (md_fast_tile in sonde_kernels.hip) -----------------------------------------------------------------
 def body_operands():
-    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[wt]", msk=None if SCAN else "%[msk]")
+    R = Regs(100, [f"%[a{q}]" for q in range(Q)], "%[dcs]", "%[T]", "%[row]", "%[f0]", "%[wt]", msk=None if (SCAN or RAW) else "%[msk]")
     return walk(R)
 
 
@@ -211,7 +214,7 @@ def diag_finish(rb):
     for q in range(H):
         L += [f"s_mov_b64 exec, {(1 << (H - q)) - 1}", f"v_pk_add_f32 {pair(CARRY)}, {pair(CARRY)}, {pair(rb + 2 * q)}"]
     L += [f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]"]
-    if not SCAN:
+    if not (SCAN or RAW):
         L += [f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel_hi:[1,0,1]",
               f"v_pk_fma_f32 {pair(Y)}, {pair(EREG)}, %[navg], {pair(Y)} op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"]
     L += [f"global_store_dwordx2 v{T1}, {pair(Y)}, %[yout]",
@@ -251,6 +254,7 @@ def gen_loop():
             hook += [f"v_add_u32 v{T1}, %[segoff64], %[jrow]", f"v_cvt_f32_u32 v{T1}, v{T1}", f"v_add_f32 v{T1}, 0.5, v{T1}", f"v_mul_f32 v{T1}, %[rcpB], v{T1}",
                      f"v_cvt_u32_f32 v{T1}, v{T1}", f"v_min_u32 v{T1}, %[segmax], v{T1}", f"v_lshlrev_b32 v{T1}, 3, v{T1}",
                      f"global_load_dwordx2 {pair(EREG)}, v{T1}, %[dcseg]"]
+        elif RAW: pass                                        # neither a mean nor E: the fold happens at the IF rate
         elif "noE" not in EXP: hook += [f"v_lshlrev_b32 v{T1}, 3, %[e]", f"global_load_dwordx2 {pair(EREG)}, v{T1}, %[etab]"]
         fe = [f"s_add_i32 s{S_TMP}, s{S_T}, 2", f"s_cmp_lt_i32 s{S_TMP}, %[nfull]", f"s_cbranch_scc0 {lab + 2}f"] + fetch(STAGE[h]) + [f"{lab + 2}:"]
         if "latefetch" not in EXP: hook += fe
@@ -260,6 +264,13 @@ def gen_loop():
         # the lane's block in the next tile: e = (e + 64) mod P; IQ-DC sums of the rows that count
         L += [f"v_add_u32 %[e], 64, %[e]", f"v_subrev_u32 v{T1}, %[P], %[e]", f"v_min_u32 %[e], v{T1}, %[e]"]
         if SCAN: L += [f"v_add_u32 %[jrow], 64, %[jrow]"]
+        elif RAW:
+            # the rows' sums (re, im; sums of 50 int16: exact in f32 and in i32) -> bsum[jrow], for the rows whose outputs count (a halo row is the
+            # previous segment's).  One store more in flight than the vmcnt(13) waits were counted for: they then also wait for the first load of tile
+            # t + 2 — harmless
+            L += [f"v_cvt_i32_f32 v{SCR + 12}, v{DCS}", f"v_cvt_i32_f32 v{SCR + 13}, v{DCS + 1}", f"v_lshlrev_b32 v{T1}, 3, %[jrow]",
+                  f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"global_store_dwordx2 v{T1}, {pair(SCR + 12)}, %[bsum]", "s_mov_b64 exec, -1",
+                  f"v_add_u32 %[jrow], 64, %[jrow]"]
         else: L += [f"v_cvt_i32_f32 v{A}, v{DCS}", f"v_cvt_i32_f32 v{B}, v{DCS + 1}",
                     f"s_mov_b64 exec, s[{S_OUT}:{S_OUT + 1}]", f"v_add_u32 %[sx], %[sx], v{A}", f"v_add_u32 %[sy], %[sy], v{B}", "s_mov_b64 exec, -1"]
         L += [f"s_add_i32 s{S_T}, s{S_T}, 1", f"s_cmp_ge_i32 s{S_T}, %[nfull]", "s_cbranch_scc1 90f"]
@@ -291,6 +302,11 @@ def main():
     text += "// the scanner's front end: double mixer phase, IQ-DC mean of the row's window off every sample (SCAN in tools/gen_md_fast.py)\n"
     text += as_macro("MD_FAST_BODY_S", body_operands()) + as_macro("MD50_LOOP_S", gen_loop())
     SCAN = False
+    global RAW
+    RAW = True
+    text += "// the scanner's front end in one pass: double mixer phase, no mean in the loop, the rows' raw sums to a side array (RAW in tools/gen_md_fast.py)\n"
+    text += as_macro("MD_FAST_BODY_R", body_operands()) + as_macro("MD50_LOOP_R", gen_loop())
+    RAW = False
     if len(sys.argv) > 1 and sys.argv[1] == "--experiments":
         for k, e in enumerate(sys.argv[2:], 2):
             EXP = e
