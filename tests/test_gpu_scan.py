@@ -312,3 +312,29 @@ def test_scan_prefilter_at_extreme_input_levels(variant):
     assert out[True] == out[False]
     if variant != "big_offset":
         assert any(t == "RS41" for t, _, _ in out[True][0])
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_scan_front_end_ragged_calls(two_pass, monkeypatch):
+    """The base-rate front end fed in calls of every awkward length — fewer blocks than the decimator's history (Q-1 = 6), fewer than the IF filter's, an odd
+    number of blocks (channel rows off the 16-byte grid: the checked-load path), one block, 64 / 65 / 127 blocks (one tile and a bit), calls that end on an
+    IQ-DC window boundary (1500 blocks) and just behind one — gives the reference's windows and lines.  Both forms: one pass over the input (raw mix + block
+    sums, the means folded out inside k_scan_if; the default) and two passes (SONDE_SCAN_TWO_PASS=1: window sums first, the mean off every sample)."""
+    if two_pass:
+        monkeypatch.setenv("SONDE_SCAN_TWO_PASS", "1")
+    name = "scan_rs41_2400k_dc"
+    g = load_scan(name)
+    x, fq, _, case = scan_capture(name)
+    sc = _scanner(case, fq, max_chunk=2_400_000, exact=True)
+    D = sc.info["decM"]
+    n = len(x) // 2 // D * D
+    pattern = [3, 1, 2, 65, 127, 64, 1500 - 262, 1500, 1, 5, 1499, 7, 4001, 33, 12001]       # blocks per call; repeated until the capture is used up
+    wins, dets, pos, k = [], [], 0, 0
+    while pos < n:
+        take = min(pattern[k % len(pattern)] * D, n - pos); k += 1
+        sc.process_host(x[2 * pos:2 * (pos + take)])
+        wins += sc.last_windows(); dets += sc.fetch(verbose=True)
+        pos += take
+    _check_windows(wins, g)
+    assert len(wins) == len(g["pos"])
+    assert "".join(d["line"] + "\n" for d in dets) == g["stdout"]
