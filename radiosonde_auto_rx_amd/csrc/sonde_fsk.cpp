@@ -30,6 +30,8 @@ struct sonde_fsk {
     uint32_t wr = 0;
     std::vector<uint32_t> wr_ch; uint32_t *d_wr = nullptr;    // per-channel write positions once sonde_fsk_process_host_var is used
     double ms = 0; int64_t launches = 0;
+    // what a repeat of single channels needs (a pipeline that gave up, launch_and_collect): Sf and the tone tails as they were before the launch, the list
+    float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
 };
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
@@ -188,7 +190,7 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         hipFree(f->d_prof);
     }
     if (!f->h_sd.empty()) { hipHostUnregister(f->h_sd.data()); hipHostUnregister(f->h_hb.data()); hipHostUnregister(f->h_recs.data()); hipHostUnregister(f->h_chan.data()); (void)hipGetLastError(); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_wr };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -199,9 +201,30 @@ int sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info) {
     return 0;
 }
 
+static int collect(sonde_fsk_t *f) {
+    const int C = f->cfg.n_channels;
+    HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_hb.data(), f->d_hb, f->h_hb.size(), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    return 0;
+}
 static int launch_and_collect(sonde_fsk_t *f) {
     const int C = f->cfg.n_channels;
     FskArgs &a = f->args;
+    // The pipelined kernel's waves wait for each other with a bound (FSK_SPIN_MAX); a wait that runs out — a bug, or a device slowed to a crawl under a profiler —
+    // ends that channel's launch with frames = -1.  Such channels are repeated with the frame-at-a-time kernel (same arithmetic, no waits between waves) from the
+    // state they had before the launch: the channel records are still on the host, Sf and the tone tails are copied aside first (two small device copies).
+    const int Ndft = f->info.Ndft;
+    if (!f->d_Sf_bak) {
+        if (dalloc(&f->d_Sf_bak, (size_t)C * Ndft, false) || dalloc(&f->d_tail_bak, (size_t)C * a.M * a.NT, false) || dalloc(&f->d_chlist, (size_t)C, false)) return SONDE_E_NOMEM;
+    }
+    f->h_chan_prev = f->h_chan;
+    HIPCHK(hipMemcpyAsync(f->d_Sf_bak, f->d_Sf, (size_t)C * Ndft * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_tail_bak, f->d_tail, (size_t)C * a.M * a.NT * sizeof(float2), hipMemcpyDeviceToDevice, f->stream));
+    { const char *t = getenv("SONDE_FSK_TEST_ABORT"); a.test_abort_ch = t ? atoi(t) : -1; }
+    a.ch_list = nullptr; a.force_demod = 0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, f->stream);
     static const bool want_prof = getenv("SONDE_FSK_PROF") != nullptr;            // profiling aid: cycles per phase of channel 0, printed when the modem is destroyed
@@ -210,14 +233,27 @@ static int launch_and_collect(sonde_fsk_t *f) {
     const int lrc = sonde_launch_fsk(&a, f->stream);
     hipEventRecord(e1, f->stream);
     if (lrc < 0) { hipEventDestroy(e0); hipEventDestroy(e1); return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU; }
-    HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->h_hb.data(), f->d_hb, f->h_hb.size(), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipStreamSynchronize(f->stream));
+    { const int rc = collect(f); if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; } }
     float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { f->ms += ms; f->launches++; }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) { fprintf(stderr, "libsonde_hip: fsk modem pipeline of channel %d stalled\n", c); return SONDE_E_NOGPU; }
+    std::vector<int> bad;
+    for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) bad.push_back(c);
+    if (bad.empty()) return 0;
+    fprintf(stderr, "libsonde_hip: fsk modem pipeline gave up on %zu channel(s) (first: %d): repeating them frame by frame\n", bad.size(), bad[0]);
+    for (int c : bad) {
+        HIPCHK(hipMemcpyAsync(f->d_chan + c, &f->h_chan_prev[c], sizeof(FskChan), hipMemcpyHostToDevice, f->stream));
+        HIPCHK(hipMemcpyAsync(f->d_Sf + (size_t)c * Ndft, f->d_Sf_bak + (size_t)c * Ndft, (size_t)Ndft * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+        HIPCHK(hipMemcpyAsync(f->d_tail + (size_t)c * a.M * a.NT, f->d_tail_bak + (size_t)c * a.M * a.NT, (size_t)a.M * a.NT * sizeof(float2), hipMemcpyDeviceToDevice, f->stream));
+    }
+    HIPCHK(hipMemcpyAsync(f->d_chlist, bad.data(), bad.size() * sizeof(int), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));               // (the copies read host vectors)
+    FskArgs b = a;
+    b.ch_list = f->d_chlist; b.n_ch = (int)bad.size(); b.force_demod = 1; b.test_abort_ch = -1; b.prof = nullptr;
+    const int lrc2 = sonde_launch_fsk(&b, f->stream);
+    if (lrc2 < 0) return lrc2 == -1 ? SONDE_E_ARG : SONDE_E_NOGPU;
+    { const int rc = collect(f); if (rc) return rc; }
+    f->repeats += (int64_t)bad.size();
+    for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) { fprintf(stderr, "libsonde_hip: fsk modem: channel %d failed again\n", c); return SONDE_E_NOGPU; }
     return 0;
 }
 

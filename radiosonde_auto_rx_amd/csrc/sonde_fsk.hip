@@ -255,7 +255,7 @@ void k_fsk_demod(const FskArgs a) {
     __shared__ float2 s_phi[4]; __shared__ float s_tc[2], s_eb[2];
     __shared__ float s_nfest[4]; __shared__ float2 s_ndphi[4];            // the next frame's estimate, when it was made ahead
     __shared__ unsigned s_bar;                                              // arrival count of the estimator waves (fsk_group_barrier)
-    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = a.ch_list ? a.ch_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT;
     const int W = (nsym + 1) * P;
     const int n_in = max(N + Ts / 2, W);
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(FSK_THREADS) __attribute__((amdgpu_waves_per_eu(FSK
 void k_fsk_stream(const FskArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ FskPipe pp;
-    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ch = a.ch_list ? a.ch_list[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Ndft = a.Ndft, Nmem = a.Nmem, NT = a.NT, R = a.R;
     const int W = (nsym + 1) * P, step = Ts / P;
     float2 *s_ring = reinterpret_cast<float2 *>(lds);                      // [M][R]
@@ -940,6 +940,7 @@ void k_fsk_stream(const FskArgs a) {
             frames++;
             S = E; E_last = E;
             nin = more ? nin_next : 0;
+            if (a.test_abort_ch == ch && frames == 1 && lane == 0) __atomic_store_n(&pp.abort, 1u, __ATOMIC_RELAXED);      // (test hook: as if a wait had run out)
         }
         PIPE_ADD(4, tc0_);
         if (a.prof && ch == 0 && lane == 0) a.prof[15] = 1;             // (this kernel's slots, not k_fsk_demod's phases)
@@ -979,7 +980,7 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
             for (int cand = 2 * Rmin; cand > Rmin; cand >>= 1) if (total(cand, bpw_max) <= bracket) { R = cand; break; }
         }
         const size_t lds_s = total(R, bpw);
-        if (!(st_env && atoi(st_env) == 0) && a->Ndft <= FSK_AE * 64 && a->Ndft >= FSK_AE && a->P >= 1 && a->Ts % a->P == 0 && lds_s <= 150 * 1024) {
+        if (!(st_env && atoi(st_env) == 0) && !a->force_demod && a->Ndft <= FSK_AE * 64 && a->Ndft >= FSK_AE && a->P >= 1 && a->Ts % a->P == 0 && lds_s <= 150 * 1024) {
             static size_t attr_s[2] = { 0, 0 };
             const void *fn = M == 2 ? reinterpret_cast<const void *>(k_fsk_stream<2>) : reinterpret_cast<const void *>(k_fsk_stream<4>);
             if (lds_s > attr_s[M == 4]) {

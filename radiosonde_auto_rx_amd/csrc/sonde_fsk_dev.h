@@ -49,7 +49,10 @@ struct FskArgs {
     int R;                            // set by the launcher: ring length (samples per tone) of the pipelined kernel, a power of two
     int est_bpw;                      // set by the launcher: transform blocks a wave of the ahead-estimator takes at a time (0 = as many as its lanes hold)
     int est_waves;                    // set by the launcher: waves that estimate the next frame while the oscillator of the current one runs (0..3)
-    unsigned long long *prof;         // profiling aid (SONDE_FSK_PROF): [16] shader-clock cycles per phase of channel 0's frames, summed; nullptr = off
+    unsigned long long *prof;         // profiling aid (SONDE_FSK_PROF): [16] shader-clock cycles per phase of channel 0's frames, summed; nullptr = off    // a launch over a LIST of channels with the frame-at-a-time kernel: how the host repeats the channels whose pipeline gave up (sonde_fsk.cpp launch_and_collect)
+    const int *ch_list;               // [n_ch] channel of workgroup b (nullptr: b)
+    int force_demod;                  // 1: k_fsk_demod even where the pipelined kernel applies
+    int test_abort_ch;                // test hook (SONDE_FSK_TEST_ABORT=<channel>): that channel's pipeline gives up behind its first frame; -1 = off
 };
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s);

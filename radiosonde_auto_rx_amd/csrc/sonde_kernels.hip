@@ -541,6 +541,9 @@ void k_mix_decimate50r(const MixDecArgs a) {
             if (i < H) { const float2 v = a.ptail_in[((size_t)ch * 8 + i) * 8 + q]; carry += (float2v){v.x, v.y}; }
         }
     }
+    if (seg == 0 && a.nblocks < H && lane < H - a.nblocks) {  // a launch shorter than the history: the older tail rows move up
+        for (int q = 0; q < Q_T; q++) a.ptail_out[((size_t)ch * 8 + lane) * 8 + q] = a.ptail_in[((size_t)ch * 8 + lane + a.nblocks) * 8 + q];
+    }
     uint32_t eidx = (uint32_t)(((uint64_t)(a.lut_phase / D) + (uint64_t)(jt0 + lane)) % P);
     uint32_t jrow = (uint32_t)(jt0 + lane);
     float2v acc[Q_T];

@@ -330,3 +330,37 @@ def test_testframes_ber_lines_match_reference():
         for a, b in zip(got, want):
             a, b = json.loads(a), json.loads(b)
             assert all(a[f] == b[f] for f in ("samples", "frames", "bits", "errs", "ppm", "f1_est", "f2_est")) and "eye_diagram" not in a
+
+
+def test_fsk_pipeline_that_gives_up_is_repeated_frame_by_frame(monkeypatch, capfd):
+    """A channel whose pipelined launch ends with frames = -1 (a wait between its waves ran out; here: the test hook SONDE_FSK_TEST_ABORT) is run again by the
+    frame-at-a-time kernel from the state it had before the launch — the call succeeds, every channel's frames are the reference's, the other channels are untouched
+    (a spurious expiry must not fail the whole batch)"""
+    name = "fsk_rs41_48k_mask"
+    g = load_fsk(name)
+    x, case = fsk_capture(name)
+    per = 1 if case["fmt"] == 1 else 2
+    n = x.shape[-1] // per
+    X = np.stack([x, x, x])
+    chunk = case["cap"]["sr"] // 3 + 7
+
+    def run():
+        md = _modem(case, n_channels=3, max_chunk=chunk)
+        out = [([], []) for _ in range(3)]
+        for s0 in range(0, n, chunk):
+            md.process_host(X[:, per * s0:per * min(n, s0 + chunk)])
+            for c in range(3):
+                sd, rc = md.fetch(c)
+                out[c][0].append(sd); out[c][1].extend(rc)
+        md.close()
+        return [(np.concatenate(a), b) for a, b in out]
+
+    plain = run()
+    capfd.readouterr()
+    monkeypatch.setenv("SONDE_FSK_TEST_ABORT", "1")
+    again = run()
+    err = capfd.readouterr().err
+    assert "repeating them frame by frame" in err
+    for c in range(3):
+        _check(again[c][0], again[c][1], g)
+        assert np.array_equal(again[c][0], plain[c][0]) and again[c][1] == plain[c][1]
