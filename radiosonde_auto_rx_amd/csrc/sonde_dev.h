@@ -49,14 +49,14 @@ struct MixDecArgs {
 struct ScanEdgeArgs {
     int n_ch, nblocks, D, Q, nseg;
     const float2 *dc_seg; int dc_seg_n, dc_seg_off, dc_seg_blocks;
-    const float2 *dc_prev;                          // [n_ch] the mean of the window before the one dc_seg[ch][0] belongs to
+    const float2 *dc_prev;                          // [n_ch] the mean of the window before the one dc_seg[ch][0] belongs to (its value at the START of the call)
     int etab_len; uint32_t e0;
     const double *chan_f0; const float *wtab;
     float2 *corr;
 };
 extern "C" int  sonde_launch_mix_decimate50r(const MixDecArgs *a, hipStream_t s);
 extern "C" void sonde_launch_dc_rows_to_segments(const int2 *bsum, long long bsum_stride, int n_ch, int nblocks, int seg_off, int seg_blocks, float maxcnt,
-                                                 long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_prev, float2 *dc_seg, int dc_seg_n, hipStream_t s);
+                                                 long long *seg_sums, long long *dc_sums, float2 *dc_avg, const float2 *dc_prev, float2 *dc_prev_out, float2 *dc_seg, int dc_seg_n, hipStream_t s);
 extern "C" void sonde_launch_scan_dc_edges(const ScanEdgeArgs *a, hipStream_t s);
 extern "C" void sonde_launch_md_etable64(const double *chan_f0, const float *wtab, int D, int Q, int P, int n_ch, float2 *etab, hipStream_t s);
 extern "C" void sonde_launch_dc_segments(const int16_t *iq, long long ch_stride, int n_ch, int n_samples, unsigned dc_cnt0, unsigned dc_max,

@@ -867,7 +867,9 @@ void k_dc_seg_sums(const int16_t *iq, long long ch_stride, int n_samples, unsign
     }
 }
 __global__ void k_dc_seg_means(int n_ch, int nseg, int ncomplete, float maxcnt, const long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_seg, int dc_seg_n,
-                               float2 *dc_prev = nullptr) {      // dc_prev (optional): keeps the mean of the window before the one in progress (k_scan_dc_edges)
+                               const float2 *dc_prev = nullptr, float2 *dc_prev_out = nullptr) {
+    // dc_prev / dc_prev_out (optional): the mean of the window before the one in progress, at the start / at the end of this call — two arrays, because
+    // k_scan_dc_edges, behind this kernel, needs the value of the call's START (the mean the blocks in front of the call's first window ran under)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_ch) return;
     float2 mean = dc_avg[c], prev = dc_prev ? dc_prev[c] : mean;
@@ -883,7 +885,7 @@ __global__ void k_dc_seg_means(int n_ch, int nseg, int ncomplete, float maxcnt, 
         }
     }
     dc_avg[c] = mean; dc_sums[2 * c] = cx; dc_sums[2 * c + 1] = cy;
-    if (dc_prev) dc_prev[c] = prev;
+    if (dc_prev_out) dc_prev_out[c] = prev;
 }
 
 // Decimation factors above 64 (input rates above ~3 Msps, e.g. a 10 Msps wideband stream): same lane-per-block scheme,
@@ -2480,10 +2482,10 @@ extern "C" int sonde_launch_mix_decimate50r(const MixDecArgs *a, hipStream_t s) 
     return 0;
 }
 extern "C" void sonde_launch_dc_rows_to_segments(const int2 *bsum, long long bsum_stride, int n_ch, int nblocks, int seg_off, int seg_blocks, float maxcnt,
-                                                 long long *seg_sums, long long *dc_sums, float2 *dc_avg, float2 *dc_prev, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
+                                                 long long *seg_sums, long long *dc_sums, float2 *dc_avg, const float2 *dc_prev, float2 *dc_prev_out, float2 *dc_seg, int dc_seg_n, hipStream_t s) {
     const int nseg = (seg_off + nblocks + seg_blocks - 1) / seg_blocks, ncomplete = (seg_off + nblocks) / seg_blocks;
     hipLaunchKernelGGL(k_dc_rows_to_segments, dim3(nseg, n_ch), dim3(256), 0, s, bsum, bsum_stride, nblocks, seg_off, seg_blocks, seg_sums, nseg);
-    hipLaunchKernelGGL(k_dc_seg_means, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, maxcnt, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n, dc_prev);
+    hipLaunchKernelGGL(k_dc_seg_means, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, nseg, ncomplete, maxcnt, seg_sums, dc_sums, dc_avg, dc_seg, dc_seg_n, dc_prev, dc_prev_out);
 }
 extern "C" void sonde_launch_scan_dc_edges(const ScanEdgeArgs *a, hipStream_t s) {
     if (a->nseg <= 0) return;

@@ -169,7 +169,7 @@ struct sonde_scan {
     hipStream_t stream = nullptr;
     hipEvent_t ev_fe[3] = { nullptr, nullptr, nullptr }; bool fe_pending = false, fe_timed = false;      // front end / scan_if timing of the call in flight (read at its first host wait)
     // one-pass front end (k_mix_decimate50r): decided when the scanner is made — the P tail between calls holds raw sums in this form
-    bool front_raw = false; float2 *d_etab64 = nullptr; int etab_len = 0; int2 *d_bsum = nullptr; long long bsum_stride = 0; float2 *d_corr = nullptr, *d_dcprev = nullptr, *d_hist[2] = { nullptr, nullptr }; int hist_cur = 0; bool fold_pending = false; ScanFold fold{};
+    bool front_raw = false; float2 *d_etab64 = nullptr; int etab_len = 0; int2 *d_bsum = nullptr; long long bsum_stride = 0; float2 *d_corr = nullptr, *d_dcprev[2] = { nullptr, nullptr }, *d_hist[2] = { nullptr, nullptr }; int hist_cur = 0; bool fold_pending = false; ScanFold fold{};
     hipEvent_t ev_rw[3] = { nullptr, nullptr, nullptr };                  // run_windows' timing events
     hipEvent_t ev_wait = nullptr;                                       // sonde_scan_wait_stream
     // design
@@ -423,7 +423,7 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
             s->bsum_stride = (cfg->max_chunk + D - 1) / D;
             const int nseg_cap = cfg->max_chunk / (int)s->dc_max + 2;
             if (dalloc(&s->d_etab64, (size_t)C * s->etab_len, false) || dalloc(&s->d_bsum, (size_t)C * s->bsum_stride, false)
-                || dalloc(&s->d_corr, (size_t)C * (nseg_cap + 1) * 8) || dalloc(&s->d_dcprev, (size_t)C)
+                || dalloc(&s->d_corr, (size_t)C * (nseg_cap + 1) * 8) || dalloc(&s->d_dcprev[0], (size_t)C) || dalloc(&s->d_dcprev[1], (size_t)C)
                 || dalloc(&s->d_hist[0], (size_t)C * s->lpiq_taps) || dalloc(&s->d_hist[1], (size_t)C * s->lpiq_taps)) { sonde_scan_destroy(s); return SONDE_E_NOMEM; }
             sonde_launch_md_etable64(s->d_chanf0, s->d_wtab, D, s->Q, s->etab_len, C, s->d_etab64, nullptr);      // E of the double-phase mixer table, once
             HIPCHK(hipDeviceSynchronize());
@@ -457,7 +457,7 @@ void sonde_scan_destroy(sonde_scan_t *s) {
     if (s->h_pre) hipHostFree(s->h_pre);
     if (s->h_work) hipHostFree(s->h_work);
     void *ptrs[] = { s->d_amatch, s->d_aws, s->d_wstail, s->d_pre, s->d_work, s->d_scratch, s->d_f32in, s->d_chanf0, s->d_dcavg, s->d_dcsums, s->d_ptail[0], s->d_ptail[1], s->d_y, s->d_fm, s->d_wiq, s->d_WS, s->d_G, s->d_tw,
-                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg, s->d_etab64, s->d_bsum, s->d_corr, s->d_dcprev, s->d_hist[0], s->d_hist[1] };
+                     s->d_hdr, s->d_bnd, s->d_items, s->d_res, s->d_stage, s->d_wtab, s->d_conv, s->d_dcsums_f, s->d_zring, s->d_taps_f, s->d_segsums, s->d_dcseg, s->d_etab64, s->d_bsum, s->d_corr, s->d_dcprev[0], s->d_dcprev[1], s->d_hist[0], s->d_hist[1] };
     for (void *p : ptrs) if (p) hipFree(p);
     delete s;
 }
@@ -824,10 +824,10 @@ int sonde_scan_process_device(sonde_scan_t *s, const void *d_in, int64_t ch_stri
             { long long tiles = (long long)C * ((a.nblocks + 63) / 64); int G = (int)(tiles / 12288); a.G = G < 1 ? 1 : (G > 16 ? 16 : G); }
             if (sonde_launch_mix_decimate50r(&a, s->stream) < 0) return SONDE_E_ARG;
             sonde_launch_dc_rows_to_segments(s->d_bsum, s->bsum_stride, C, nb, seg_off, seg_blocks, (float)s->dc_max, s->d_segsums, s->d_dcsums, s->d_dcavg,
-                                             s->d_dcprev, s->d_dcseg, nseg_cap + 1, s->stream);
+                                             s->d_dcprev[s->hist_cur], s->d_dcprev[s->hist_cur ^ 1], s->d_dcseg, nseg_cap + 1, s->stream);
             ScanEdgeArgs g{};
             g.n_ch = C; g.nblocks = nb; g.D = D; g.Q = s->Q; g.nseg = (seg_off + nb + seg_blocks - 1) / seg_blocks;
-            g.dc_seg = s->d_dcseg; g.dc_seg_n = nseg_cap + 1; g.dc_seg_off = seg_off; g.dc_seg_blocks = seg_blocks; g.dc_prev = s->d_dcprev;
+            g.dc_seg = s->d_dcseg; g.dc_seg_n = nseg_cap + 1; g.dc_seg_off = seg_off; g.dc_seg_blocks = seg_blocks; g.dc_prev = s->d_dcprev[s->hist_cur];      // (the call-start value: k_dc_seg_means wrote the end-of-call one to the other array)
             g.etab_len = s->etab_len; g.e0 = (uint32_t)((a.lut_phase / (uint32_t)D) % (uint32_t)s->etab_len);
             g.chan_f0 = s->d_chanf0; g.wtab = s->d_wtab; g.corr = s->d_corr;
             sonde_launch_scan_dc_edges(&g, s->stream);

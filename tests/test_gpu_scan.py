@@ -338,3 +338,40 @@ def test_scan_front_end_ragged_calls(two_pass, monkeypatch):
     _check_windows(wins, g)
     assert len(wins) == len(g["pos"])
     assert "".join(d["line"] + "\n" for d in dets) == g["stdout"]
+
+
+def test_scan_one_pass_front_end_with_a_moving_offset_in_the_passband(monkeypatch):
+    """Where the one-pass front end's fold is actually exercised: a channel at the stream's centre (the IQ offset lands in the decimator's PASSBAND, E ~ 1) and an
+    offset that drifts from window to window (every 1/32 s another mean; the Q-1 outputs behind each change mix two of them).  Calls of whole windows (every call
+    starts ON a change of the mean: the blocks in front of it ran under the previous call's last mean) and of odd lengths.  The four FM streams equal those of the
+    two-pass form (the mean off every sample, as the reference does it) to 2e-4 of their +-0.8 range — a wrong mean at one edge shows as 1e-1 on six samples."""
+    from tools import synth
+    from radiosonde_auto_rx_amd.scan import Scanner, BBIQ
+    sr, D = 2_400_000, 50
+    x = synth.rs41_capture(sr=sr, seconds=1.5, fq=0.0, f_offset_hz=900.0, amp=0.05, noise_sigma=0.004, t_first=0.1, seed=77).astype(np.float64)
+    n = len(x) // 2 // D * D
+    t = np.arange(n) / sr
+    x[0:2 * n:2] += 32768 * (0.10 + 0.12 * np.sin(2 * np.pi * 1.7 * t))          # I offset: 10 % of full scale, moving by +-12 % at 1.7 Hz
+    x[1:2 * n:2] += 32768 * (-0.07 + 0.05 * t)                                     # Q offset: a ramp
+    x = np.clip(np.round(x[:2 * n]), -32768, 32767).astype(np.int16)
+    B = sr // 32                                                                    # samples per IQ-DC window
+
+    def run(chunks):
+        sc = Scanner(sr, fq=[0.0], iq_mode=BBIQ, dc=True, cont=True, max_chunk=n)
+        pos, k = 0, 0
+        while pos < n:
+            take = min(chunks[k % len(chunks)], n - pos); k += 1
+            sc.process_host(x[2 * pos:2 * (pos + take)])
+            pos += take
+        m = n // D
+        out = [sc.read_fm(0, st, m - 40000, 40000) for st in range(4)]
+        sc.close()
+        return out
+
+    for chunks in ([4 * B], [B, 3 * B], [7 * D * 331, 2 * B + 5 * D, 3 * D]):
+        monkeypatch.delenv("SONDE_SCAN_TWO_PASS", raising=False)
+        one = run(chunks)
+        monkeypatch.setenv("SONDE_SCAN_TWO_PASS", "1")
+        two = run(chunks)
+        for st in range(4):
+            assert np.abs(one[st] - two[st]).max() < 2e-4, (chunks, st, np.abs(one[st] - two[st]).max())
