@@ -36,3 +36,30 @@ def test_bench_two_ranks_on_one_device(lag):
     assert cfg["verified_channels"] == 80 and not cfg.get("verify_failed")                                # both ranks' channels against the oracle
     assert cfg["frame_fetch_lag"] == lag
     assert "cpu_baseline" not in d and "detect_in_step" not in d                                          # single-GPU extras stay out of N > 1 lines
+
+
+@pytest.mark.parametrize("config", ["scan_wide", "fsk_mixed"])
+def test_other_configs_two_ranks_on_one_device(config):
+    """BASELINE configs[2] and [3] the way the driver would launch them on N GPUs (configs[3] is quoted on four): the N-rank line executes, every rank does its own
+    full workload (weak scaling: independent streams / channels per GPU, no data-path collective), rank 0 prints one line with the job's aggregate"""
+    env = dict(os.environ, SONDE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29300 + (os.getpid() + len(config)) % 300
+    extra = ["--channels", "48"] if config == "fsk_mixed" else []
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--config", config, "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(cfg["rank_ms_per_step"]) == 2 and all(t > 0 for t in cfg["rank_ms_per_step"])
+    assert abs(d["ms_per_step"] - max(cfg["rank_ms_per_step"])) < 1e-3
+    assert "cpu_baseline" not in d
+    if config == "fsk_mixed":
+        assert cfg["channels_per_gpu"] == 48 and cfg["checked_channels"] == 48 and cfg["verified_channels"] == 48          # rank 0's channels against the reference modem
+        assert abs(d["value"] - 2 * (16 * 48000 + 16 * 50000 + 16 * 48080) / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]
+    else:
+        assert cfg["channels"] == 256 and len(cfg["detections_last_step"]) >= 10                                           # the dozen planted sondes
+        assert abs(d["value"] - 2 * 10e6 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]

@@ -351,20 +351,26 @@ def test_scan_one_pass_front_end_with_a_moving_offset_in_the_passband(monkeypatc
     x = synth.rs41_capture(sr=sr, seconds=1.5, fq=0.0, f_offset_hz=900.0, amp=0.05, noise_sigma=0.004, t_first=0.1, seed=77).astype(np.float64)
     n = len(x) // 2 // D * D
     t = np.arange(n) / sr
-    x[0:2 * n:2] += 32768 * (0.10 + 0.12 * np.sin(2 * np.pi * 1.7 * t))          # I offset: 10 % of full scale, moving by +-12 % at 1.7 Hz
-    x[1:2 * n:2] += 32768 * (-0.07 + 0.05 * t)                                     # Q offset: a ramp
-    x = np.clip(np.round(x[:2 * n]), -32768, 32767).astype(np.int16)
+    # three channels (per-channel tables, means, corrections, histories): the same signal under three different moving offsets, three carriers in the passband
+    X = []
+    for a_i, a_q, ph in ((0.10, -0.07, 0.0), (-0.05, 0.12, 1.0), (0.02, 0.03, 2.0)):
+        y = x[:2 * n].copy()
+        y[0::2] += 32768 * (a_i + 0.12 * np.sin(2 * np.pi * 1.7 * t + ph))          # I offset: moving by +-12 % of full scale at 1.7 Hz
+        y[1::2] += 32768 * (a_q + 0.05 * t)                                        # Q offset: a ramp
+        X.append(np.clip(np.round(y), -32768, 32767).astype(np.int16))
+    X = np.stack(X)
+    fqs = [0.0, synth.snap_fq(0.0004, sr), synth.snap_fq(-0.0003, sr)]
     B = sr // 32                                                                    # samples per IQ-DC window
 
     def run(chunks):
-        sc = Scanner(sr, fq=[0.0], iq_mode=BBIQ, dc=True, cont=True, max_chunk=n)
+        sc = Scanner(sr, fq=fqs, iq_mode=BBIQ, dc=True, cont=True, max_chunk=n)
         pos, k = 0, 0
         while pos < n:
             take = min(chunks[k % len(chunks)], n - pos); k += 1
-            sc.process_host(x[2 * pos:2 * (pos + take)])
+            sc.process_host(X[:, 2 * pos:2 * (pos + take)])
             pos += take
         m = n // D
-        out = [sc.read_fm(0, st, m - 40000, 40000) for st in range(4)]
+        out = [sc.read_fm(c, st, m - 40000, 40000) for c in range(3) for st in range(4)]
         sc.close()
         return out
 
@@ -373,5 +379,5 @@ def test_scan_one_pass_front_end_with_a_moving_offset_in_the_passband(monkeypatc
         one = run(chunks)
         monkeypatch.setenv("SONDE_SCAN_TWO_PASS", "1")
         two = run(chunks)
-        for st in range(4):
+        for st in range(12):
             assert np.abs(one[st] - two[st]).max() < 2e-4, (chunks, st, np.abs(one[st] - two[st]).max())
