@@ -322,6 +322,28 @@ def bench_demod(args, D: Dist):
             step()
         eng.fetch_frames_np(lag=0); eng.sync()
 
+    # untimed: the dominant kernel on a stream of its own order — a second engine with ONE stream (every kernel of a call behind the other), same channels, same
+    # input: what k_mix_decimate50 does when no IF-rate kernel of the call before holds CU slots beside it.  `roofline.frac` above is the timed run's figure
+    # (two streams: the tail runs beside the decimator and stretches it); this one goes beside it as `frac_kernel_alone`
+    alone = None
+    if D.world == 1 and not args.no_extras and lag > 0 and args.two_streams:
+        e1 = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=False)
+        _lead_in(e1, iq.data_ptr(), STRIDE)
+        for _ in range(5):
+            e1.process_device(iq.data_ptr(), STRIDE, SR); e1.fetch_frames_np(lag=lag)
+        e1.fetch_frames_np(lag=0); e1.sync()
+        e1.profile(1)
+        n1, t1 = 80, time.perf_counter()
+        for _ in range(n1):
+            e1.process_device(iq.data_ptr(), STRIDE, SR); e1.fetch_frames_np(lag=lag)
+        e1.fetch_frames_np(lag=0); e1.sync()
+        t1 = (time.perf_counter() - t1) / n1
+        ms1, k1 = e1.kernel_ms("mix_decimate")
+        if ms1 > 0 and k1 > 0:
+            alone = dict(avg_launch_ms=round(ms1, 4), frac=round(C * SR * 4 / (ms1 * 1e-3) / 1e9 / 8000.0, 4), launches=int(k1), ms_per_step_one_stream=round(t1 * 1e3, 3))
+        e1.profile(0)
+        e1.close()
+
     # untimed: per-kernel table of a step (events around every kernel cost ~0.1 ms of host time per step, so not in the timed region)
     # pipelined like the timed loop (a step that waits for its own frames lets the clocks drop between steps and reads 10 % slow)
     eng.profile(2)
@@ -369,11 +391,13 @@ def bench_demod(args, D: Dist):
                        "kernels_note": "HIP events around every kernel over 20 untimed pipelined steps; with two streams a kernel's time includes its wait for the CU "
                                        "slots the other stream's kernels hold (header search / frame sync beside the decimator), so the column does not add up to the step"},
             "roofline": {"bound": "hbm", "kernel": "k_mix_decimate50", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_note": traffic_src,
+                         "frac": round(achieved / 8000.0, 4), "frac_kernel_alone": alone["frac"] if alone else None, "kernel_alone": alone,
+                         "traffic": traffic, "traffic_note": traffic_src,
                          "algorithmic_gb_per_launch": round(C * SR * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4), "launches": md_n,
                          "step_frac": round(C * SR * 4 / (dt / total_steps) / 8e12, 4),
                          "note": "achieved = 4 B x complex samples of all timed k_mix_decimate50 launches / their HIP-event time on the engine stream; "
-                                 "step_frac = the same bytes over the whole step time (all kernels + host)"},
+                                 "step_frac = the same bytes over the whole step time (all kernels + host); frac_kernel_alone = the same kernel on a one-stream engine "
+                                 "(no IF-rate kernel beside it), untimed A/B in the same process: kernel_alone"},
         }
         if want is not None and verified != D.world * C:
             out["config"]["verify_failed"] = True
