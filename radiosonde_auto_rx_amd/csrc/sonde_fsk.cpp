@@ -30,6 +30,7 @@ struct sonde_fsk {
     uint32_t wr = 0;
     std::vector<uint32_t> wr_ch; uint32_t *d_wr = nullptr;    // per-channel write positions once sonde_fsk_process_host_var is used
     double ms = 0; int64_t launches = 0;
+    bool hb_on_host = false;                       // h_hb holds the last launch's hard bits (copied on the first sonde_fsk_fetch_bits behind a launch)
     // what a repeat of single channels needs (a pipeline that gave up, launch_and_collect): Sf and the tone tails as they were before the launch, the list
     float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
 };
@@ -205,7 +206,7 @@ static int collect(sonde_fsk_t *f) {
     const int C = f->cfg.n_channels;
     HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->h_hb.data(), f->d_hb, f->h_hb.size(), hipMemcpyDeviceToHost, f->stream));
+    f->hb_on_host = false;                                    // the hard bits follow when somebody asks for them (sonde_fsk_fetch_bits): auto_rx's pipelines read the soft decisions
     HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
     return 0;
@@ -346,6 +347,11 @@ int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, son
 
 int sonde_fsk_fetch_bits(sonde_fsk_t *f, int32_t channel, uint8_t *bits, int32_t max) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels || (!bits && max > 0)) return SONDE_E_ARG;
+    if (!f->hb_on_host) {
+        HIPCHK(hipMemcpyAsync(f->h_hb.data(), f->d_hb, f->h_hb.size(), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+        f->hb_on_host = true;
+    }
     const int nb = std::min<int>(f->h_chan[channel].frames * f->info.Nbits, max);
     if (nb > 0) memcpy(bits, f->h_hb.data() + (size_t)channel * f->args.sd_cap, (size_t)nb);
     return nb;
