@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SP_CK 2                        // Toeplitz steps per block of prefetched A fragments (the host pads every table to a multiple)
 #define SP_CH 16                       // samples per thread in the load and prefix phases (8192 / 512)
 #ifndef SP_ACAP
-#define SP_ACAP 16                     // A-fragment steps (1 KB each) the LDS holds at a time: SP_AQ x 16 bytes per thread; longer templates reload
+#define SP_ACAP 8                      // A-fragment steps (1 KB each) the LDS holds at a time: SP_AQ x 16 bytes per thread; longer templates reload
 #endif
 #define SP_AQ (SP_ACAP * 64 / SP_THREADS)
 
@@ -151,7 +151,7 @@ __device__ __forceinline__ void sp_scores(const _Float16 *xfh, const float *P, c
 }
 
 #ifndef SP_MINW
-#define SP_MINW 6                      // waves per SIMD the register allocation leaves room for
+#define SP_MINW 8                      // waves per SIMD the register allocation leaves room for
 #endif
 __global__ __launch_bounds__(SP_THREADS, SP_MINW)
 void k_scan_pre(const ScanPreArgs a) {
