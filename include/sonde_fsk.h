@@ -95,6 +95,25 @@ int  sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr,
 int  sonde_fsk_clear_estimators(sonde_fsk_t *f);                          /* fsk_clear_estimators (fsk.c:981)     */
 int  sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches);
 
+/* ---- the consumer of the soft decisions on the device: `rs41mod --softin [-i] [--ecc|--ecc2]` for every channel of a modem engine
+ * (auto_rx's pipe `fsk_demod ... | rs41mod --softin -i`, auto_rx/autorx/decode.py:901-909).  find_softbinhead / corr_softhdb
+ * (demod/mod/demod_mod.c:1692-1762, threshold 0.7), the bit loop and de-whitening of rs41mod.c:2893-2962 and rs41_ecc() (:1703-1769) run in
+ * device memory; only completed frames (518 bytes each) come to the host.  invert_stream = --softinv, opt_inv = -i, opt_auto = --auto.
+ * sonde_type: SONDE_RS41.  No CPU fallback. */
+typedef struct sonde_softin_dev sonde_softin_dev_t;
+int  sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto,
+                             sonde_softin_dev_t **out);
+void sonde_softin_dev_destroy(sonde_softin_dev_t *s);
+/* consume the soft decisions the modem's last process call left in device memory (every channel; n_channels must match).  Synchronous. */
+int  sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
+/* the same over any soft-bit streams in device memory: channel c at d_soft + c * ch_stride, n_bits each */
+int  sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, int64_t ch_stride, int32_t n_bits);
+/* frames completed by the push calls since the last fetch (all channels, in completion order per call; channel / len / ecc / mv / mv_pos = the header's
+ * bit index in the channel's stream); returns the count (<= max) */
+int  sonde_softin_dev_fetch(sonde_softin_dev_t *s, sonde_frame_t *out, int32_t max);
+/* tallies since creation: frames completed, frames rs41_ecc() accepted (ecc >= 0), frames it repaired (ecc > 0), symbols repaired, frames lost to a full buffer */
+int  sonde_softin_dev_counts(sonde_softin_dev_t *s, int64_t *frames, int64_t *ecc_ok, int64_t *repaired, int64_t *symbols, int64_t *dropped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 // two estimators can return (fsk.c:643), and the timing oscillator's float recurrence (fsk.c:682-703).
 #include "../../include/sonde_fsk.h"
 #include "sonde_fsk_dev.h"
+#include "sonde_fsk_tables.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -21,7 +22,7 @@ struct sonde_fsk {
     hipStream_t stream = nullptr;
     void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr, *d_eye = nullptr;
     unsigned long long *d_prof = nullptr;          // SONDE_FSK_PROF
-    uint16_t *d_perm = nullptr;
+    uint16_t *d_perm = nullptr, *d_iperm = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
     FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; std::vector<uint8_t> h_hb;
     std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
@@ -30,6 +31,7 @@ struct sonde_fsk {
     uint32_t wr = 0;
     std::vector<uint32_t> wr_ch; uint32_t *d_wr = nullptr;    // per-channel write positions once sonde_fsk_process_host_var is used
     double ms = 0; int64_t launches = 0;
+    bool sd_on_host = false;                       // h_sd holds the last launch's soft decisions (copied on the first sonde_fsk_fetch behind a launch)
     bool hb_on_host = false;                       // h_hb holds the last launch's hard bits (copied on the first sonde_fsk_fetch_bits behind a launch)
     // what a repeat of single channels needs (a pipeline that gave up, launch_and_collect): Sf and the tone tails as they were before the launch, the list
     float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
@@ -46,7 +48,7 @@ template <class T> static int dupload(T **p, const std::vector<T> &v) {
     return 0;
 }
 
-static float2 exp_j(float phi) { return make_float2(cosf(phi), sinf(phi)); }       // comp_exp_j (comp_prim.h:95)
+static float2 exp_j(float phi) { return fsk_exp_j(phi); }
 
 extern "C" {
 
@@ -65,78 +67,19 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     HIPCHK(hipSetDevice(cfg->device));
     sonde_fsk *f = new sonde_fsk();
     f->cfg = *cfg;
-    const int C = cfg->n_channels, Fs = cfg->Fs, Rs = cfg->Rs, P = cfg->P, nsym = cfg->nsym, M = cfg->M;
+    const int C = cfg->n_channels, nsym = cfg->nsym, M = cfg->M;
 
-    // ---- fsk_create_core (fsk.c:114-201)
-    const float bin_width_Hz = 0.1 * Rs;
-    float Ndft_f = (float)Fs / bin_width_Hz;
-    Ndft_f = pow(2.0, ceil(log2(Ndft_f)));
-    const int Ndft = (int)Ndft_f, Ts = Fs / Rs, N = Ts * nsym, Nmem = N + 2 * Ts;
-    int lg = 0; while ((1 << lg) < Ndft) lg++;
-    if (Ndft > 1024 || Ndft < 8 || (1 << lg) != Ndft) { delete f; return SONDE_E_ARG; }
+    // ---- fsk_create_core's constants and every data-independent table (sonde_fsk_tables.h)
+    FskTables T;
+    if (fsk_build_tables(*cfg, T)) { delete f; return SONDE_E_ARG; }
+    const int Ndft = T.Ndft, Ts = T.Ts, N = T.N;
     FskArgs &a = f->args;
-    a.format = cfg->format; a.M = M; a.burst = cfg->burst_mode ? 1 : 0; a.n_ch = C; a.Fs = Fs; a.Rs = Rs; a.Ts = Ts; a.P = P; a.nsym = nsym; a.N = N; a.Ndft = Ndft; a.log2Ndft = lg;
-    a.Nmem = Nmem; a.NT = 2 * Ts + Ts / 2;
-    a.tc = 0.95 * Ndft_f / Fs;
-    const int est_space = 0.75 * Rs, fs_tx = cfg->mask ? cfg->tone_spacing : 100;
-    a.fs_tx = fs_tx; a.est_type = cfg->mask ? 1 : 0;
-    // fsk_demod_freq_est's bin limits (fsk.c:464-469), integer arithmetic
-    a.st = (cfg->fsk_lower * Ndft) / Fs + Ndft / 2; if (a.st < 0) a.st = 0;
-    a.en = (cfg->fsk_upper * Ndft) / Fs + Ndft / 2; if (a.en > Ndft) a.en = Ndft;
-    a.f_zero = (est_space * Ndft) / Fs;
-    {   // mask of the second estimator (fsk.c:553-560): ones at 0..2 and at bin_m..bin_m+2, bin_m = round(m fs_tx Ndft / Fs) - 1, m = 1..M-1
-        std::vector<char> mask(Ndft + 8, 0);
-        for (int i = 0; i < 3; i++) mask[i] = 1;
-        int bin = 0; bool fits = true;
-        for (int m = 1; m <= M - 1; m++) {
-            bin = (int)round((float)m * fs_tx * Ndft / Fs) - 1;
-            if (bin < 0 || bin + 2 >= Ndft) { fits = false; break; }
-            for (int i = bin; i <= bin + 2; i++) mask[i] = 1;
-        }
-        if (!fits && cfg->mask) { delete f; return SONDE_E_ARG; }
-        a.len_mask = bin + 2 + 1; a.n_mask = 0;
-        for (int i = 0; i < Ndft && a.n_mask < 12; i++) if (mask[i]) a.mask_idx[a.n_mask++] = i;
-    }
-    f->info.Ts = Ts; f->info.N = N; f->info.Ndft = Ndft; f->info.Nmem = Nmem; f->info.Nbits = nsym * (M / 2); f->info.tc = a.tc;
-    a.max_fft = (N + Ts / 2) / (Ndft / 2) - 1; if (a.max_fft < 1) a.max_fft = 1;
-
-    // ---- tables
-    std::vector<float> hann(Ndft), fmask((size_t)Ndft * M);
-    std::vector<float2> tw(Ndft), dpeak(Ndft), dmask((size_t)Ndft * M), phift((size_t)(nsym + 1) * P);
-    for (int i = 0; i < Ndft; i++) hann[i] = 0.5 - 0.5 * cosf(2.0 * M_PI * (float)i / (float)(Ndft - 1));
-    std::vector<uint16_t> perm(Ndft);
-    {   // kiss_fft_alloc / kf_factor / kf_work (kiss_fft.c:340-366, :304-331, :238-300): twiddles from cosf / sinf of the float phase,
-        // factors 4,4,..(,2); output slot sum_s k_s m_s holds input sum_s k_s fstride_s; stages run innermost first
-        for (int k = 0; k < Ndft; k++) {
-            const double pi = 3.141592653589793238462643383279502884197169399375105820974944;
-            const double phase = -2 * pi * k / Ndft;
-            tw[k] = make_float2(cosf(phase), sinf(phase));
-        }
-        int fp[8], fm[8], ffs[8], L = 0, n = Ndft, stride = 1;
-        while (n > 1) { const int p = (n % 4 == 0) ? 4 : 2; n /= p; fp[L] = p; fm[L] = n; ffs[L] = stride; stride *= p; L++; }
-        for (int o = 0; o < Ndft; o++) {
-            int rem = o, in = 0;
-            for (int s = 0; s < L; s++) { const int k = rem / fm[s]; rem -= k * fm[s]; in += k * ffs[s]; }
-            perm[in] = (uint16_t)o;
-        }
-        a.n_stage = L;
-        for (int s = 0; s < L; s++) { a.st_p[s] = fp[L - 1 - s]; a.st_m[s] = fm[L - 1 - s]; a.st_fs[s] = ffs[L - 1 - s]; }
-    }
-    for (int k = 0; k < Ndft; k++) {
-        const float fp = (float)(k - Ndft / 2) * ((float)Fs / (float)Ndft);             // peak estimator (fsk.c:544-546)
-        dpeak[k] = exp_j(2 * M_PI * ((fp) / (float)(Fs)));
-        const float foff = (k - Ndft / 2) * Fs / Ndft;                                  // mask estimator (fsk.c:575-578), integer division
-        for (int m = 0; m < M; m++) { const float fm = foff + m * fs_tx; fmask[M * k + m] = fm; dmask[M * k + m] = exp_j(2 * M_PI * ((fm) / (float)(Fs))); }
-    }
-    {   // timing oscillator: phi_ft = 1; used, then phi_ft *= dphift (fsk.c:682-703)
-        const float2 d = exp_j(2 * M_PI * ((float)(Rs) / (float)(P * Rs)));
-        float2 ph = make_float2(1.f, 0.f);
-        for (size_t i = 0; i < phift.size(); i++) {
-            phift[i] = ph;
-            const float nr = ph.x * d.x - ph.y * d.y, ni = ph.x * d.y + ph.y * d.x;
-            ph = make_float2(nr, ni);
-        }
-    }
+    fsk_tables_to_args(*cfg, T, a);
+    a.n_ch = C;
+    f->info.Ts = Ts; f->info.N = N; f->info.Ndft = Ndft; f->info.Nmem = T.Nmem; f->info.Nbits = nsym * (M / 2); f->info.tc = a.tc;
+    const std::vector<float> &hann = T.hann, &fmask = T.fmask;
+    const std::vector<float2> &tw = T.tw, &dpeak = T.dpeak, &dmask = T.dmask, &phift = T.phift;
+    const std::vector<uint16_t> &perm = T.perm, &iperm = T.iperm;
     const int max_frames = cfg->max_chunk / std::max(1, N - Ts / 2) + 2;
     a.rec_cap = max_frames; a.sd_cap = max_frames * nsym * (M / 2);
     uint32_t ring = 1; while (ring < (uint32_t)(cfg->max_chunk + N + Ts + 16)) ring <<= 1;
@@ -144,7 +87,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     f->unit = cfg->format == SONDE_FSK_CF32 ? 8 : cfg->format == SONDE_FSK_CS16 ? 4 : 2;
     int bad = 0;
     bad |= dalloc((char **)&f->d_in, (size_t)C * ring * f->unit);
-    bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_perm, perm); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
+    bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_perm, perm); bad |= dupload(&f->d_iperm, iperm); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
     bad |= dupload(&f->d_fmask, fmask); bad |= dupload(&f->d_phift, phift);
     bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * M * a.NT);
     bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_hb, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
@@ -152,7 +95,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     f->h_chan.resize(C);
     for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); for (int m = 0; m < 4; m++) c.phi_c[m] = exp_j(0); c.nin = N; }
     HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
-    a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.perm = f->d_perm; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
+    a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.perm = f->d_perm; a.iperm = f->d_iperm; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
     a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.hb = f->d_hb; a.recs = f->d_recs;
     f->h_sd.resize((size_t)C * a.sd_cap); f->h_hb.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
     // the per-launch results come back into these (never resized again): page-locked, so that the copies are real asynchronous DMA and not staged through
@@ -171,10 +114,21 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
     if (f->d_prof) {
-        unsigned long long h[16];
+        unsigned long long h[32];
         if (hipMemcpy(h, f->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
             static const char *nm[9] = { "input", "fft", "Sf+estimators", "oscillator", "downconv+tail", "integrate", "timing", "soft", "ebno+record" };
-            if (h[15]) {          // the pipelined kernel: cycles of channel 0's waves, all of it and what they spent waiting
+            if (h[15] >= 2) {     // the wave form (sonde_fsk_wave.h): cycles of channel 0's worker (and walker) by what they were doing
+                const double tw = (double)(h[0] + h[1] + h[2] + h[3] + h[4]), tk = (double)(h[5] + h[6] + h[7]);
+                fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, wave form, %s): worker %.0f kcycles: barriers / waiting %.1f%% estimator %.1f%% down-conversion %.1f%% "
+                                "integrators + timing sum %.1f%% frame end %.1f%%", f->cfg.Rs, f->cfg.nsym, h[15] == 3 ? "walker + worker" : "one wave", tw / 1e3,
+                        100.0 * h[0] / std::max(1.0, tw), 100.0 * h[1] / std::max(1.0, tw), 100.0 * h[2] / std::max(1.0, tw), 100.0 * h[3] / std::max(1.0, tw), 100.0 * h[4] / std::max(1.0, tw));
+                if (h[15] == 3) fprintf(stderr, "; walker %.0f kcycles: oscillator %.1f%% barriers / waiting %.1f%% other %.1f%%; estimator: transforms + searches %.1f%% barriers / waiting %.1f%%", tk / 1e3, 100.0 * h[5] / std::max(1.0, tk), 100.0 * h[7] / std::max(1.0, tk), 100.0 * h[6] / std::max(1.0, tk),
+                                        100.0 * h[8] / std::max(1.0, (double)(h[8] + h[9])), 100.0 * h[9] / std::max(1.0, (double)(h[8] + h[9])));
+                else fprintf(stderr, " (oscillator %.1f%% of it)", 100.0 * h[5] / std::max(1.0, tw + (double)h[5]));
+                fprintf(stderr, "\n");
+                fprintf(stderr, "fsk prof   raw kcycles:"); for (int k = 0; k < 32; k++) if (k != 15 && k != 16 && k != 17) fprintf(stderr, " [%d] %.0f", k, h[k] / 1e3);
+                fprintf(stderr, "  slots %llu frames %llu\n", h[16], h[17]);
+            } else if (h[15]) {   // the pipelined kernel: cycles of channel 0's waves, all of it and what they spent waiting
                 fprintf(stderr, "fsk prof (Rs %d, nsym %d, channel 0, pipelined kernel): producer %.0f kcycles (waits: estimate %.1f%% ring %.1f%% length %.1f%%), "
                                 "consumer %.0f (waits for samples %.1f%%, frame tail %.1f%%), estimators %.0f (waits %.1f%%)\n", f->cfg.Rs, f->cfg.nsym,
                         h[0] / 1e3, 100.0 * h[1] / std::max(1ull, h[0]), 100.0 * h[2] / std::max(1ull, h[0]), 100.0 * h[3] / std::max(1ull, h[0]),
@@ -191,7 +145,7 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         hipFree(f->d_prof);
     }
     if (!f->h_sd.empty()) { hipHostUnregister(f->h_sd.data()); hipHostUnregister(f->h_hb.data()); hipHostUnregister(f->h_recs.data()); hipHostUnregister(f->h_chan.data()); (void)hipGetLastError(); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_iperm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -205,7 +159,7 @@ int sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info) {
 static int collect(sonde_fsk_t *f) {
     const int C = f->cfg.n_channels;
     HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+    f->sd_on_host = false;                                    // the soft decisions follow when somebody asks for them (sonde_fsk_fetch): a consumer on the device (sonde_softin_dev.h) never does
     f->hb_on_host = false;                                    // the hard bits follow when somebody asks for them (sonde_fsk_fetch_bits): auto_rx's pipelines read the soft decisions
     HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));
@@ -229,7 +183,7 @@ static int launch_and_collect(sonde_fsk_t *f) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, f->stream);
     static const bool want_prof = getenv("SONDE_FSK_PROF") != nullptr;            // profiling aid: cycles per phase of channel 0, printed when the modem is destroyed
-    if (want_prof && !f->d_prof) { if (hipMalloc((void **)&f->d_prof, 16 * sizeof(unsigned long long)) == hipSuccess) hipMemset(f->d_prof, 0, 16 * sizeof(unsigned long long)); }
+    if (want_prof && !f->d_prof) { if (hipMalloc((void **)&f->d_prof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(f->d_prof, 0, 32 * sizeof(unsigned long long)); }
     a.prof = f->d_prof;
     const int lrc = sonde_launch_fsk(&a, f->stream);
     hipEventRecord(e1, f->stream);
@@ -332,6 +286,11 @@ int sonde_fsk_reset_channel(sonde_fsk_t *f, int32_t channel) {
 
 int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames, int32_t *n_frames) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels || (!sd && max > 0)) return SONDE_E_ARG;
+    if (!f->sd_on_host) {
+        HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+        f->sd_on_host = true;
+    }
     const FskChan &c = f->h_chan[channel];
     const int nf = c.frames, nb = std::min<int>(nf * f->info.Nbits, max);
     if (nb > 0) memcpy(sd, f->h_sd.data() + (size_t)channel * f->args.sd_cap, (size_t)nb * sizeof(float));
@@ -395,6 +354,13 @@ int sonde_fsk_clear_estimators(sonde_fsk_t *f) {               // fsk_clear_esti
     HIPCHK(hipMemcpy(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost));
     for (auto &c : f->h_chan) c.nin = f->info.N;
     HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// what a consumer on the device needs of the last launch (sonde_softin_dev.hip): the soft decisions where they lie, the per-channel frame counts, the stream they were made on
+int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream) {
+    if (!f) return SONDE_E_ARG;
+    *d_sd = f->d_sd; *sd_cap = f->args.sd_cap; *d_chan = f->d_chan; *bits_per_frame = f->info.Nbits; *n_ch = f->cfg.n_channels; *stream = f->stream;
     return 0;
 }
 

@@ -18,8 +18,11 @@
 // and the serial sums keep its order, so f_dc / f_int / soft decisions reproduce it up to libm (atan2f, log10f).
 #pragma clang fp contract(off)
 #include "sonde_fsk_dev.h"
+#include "sonde_fsk_wave.h"
 #include <limits.h>
 #include <cstdlib>
+#include <cstring>
+extern "C" int sonde_launch_fsk_old(const FskArgs *a, hipStream_t s);
 
 #define WAVE 64
 #define FMT_S16  1
@@ -957,7 +960,64 @@ void k_fsk_stream(const FskArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fsk_wave: walker + worker wavefronts meeting at barriers (sonde_fsk_wave.h) — the form that runs for every sonde configuration
+// ------------------------------------------------------------------------------------------------
+template <int M, int LOG2N, bool SPLIT, int FMT>
+__global__ __launch_bounds__(SPLIT ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SPLIT ? 4 : 2, 8)))
+void k_fsk_wave(const FskArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ FwCtl ctl;
+    const int ch = a.ch_list ? a.ch_list[blockIdx.x] : (int)blockIdx.x;
+    fsk_wave_channel<M, LOG2N, SPLIT, FMT>(a, ch, (int)threadIdx.x, lds, ctl);
+}
+
+template <int M, int LOG2N, bool SPLIT, int FMT>
+static int launch_wave_f(const FskArgs &b, const size_t lds_bytes, hipStream_t s) {
+    static size_t attr = 0;
+    if (lds_bytes > attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fsk_wave<M, LOG2N, SPLIT, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
+        attr = lds_bytes;
+    }
+    hipLaunchKernelGGL((k_fsk_wave<M, LOG2N, SPLIT, FMT>), dim3(b.n_ch), dim3(SPLIT ? (b.fin ? 256 : 192) : 64), lds_bytes, s, b);
+    return 0;
+}
+// (cs16 — what auto_rx pipes in — gets a kernel of its own: with the format a constant there are no branches around the sample loads)
+template <int M, int LOG2N, bool SPLIT>
+static int launch_wave(const FskArgs &b, const size_t lds_bytes, hipStream_t s) {
+    return b.format == FMT_CS16 ? launch_wave_f<M, LOG2N, SPLIT, FMT_CS16>(b, lds_bytes, s) : launch_wave_f<M, LOG2N, SPLIT, 0>(b, lds_bytes, s);
+}
+template <int M, bool SPLIT>
+static int launch_wave_n(const FskArgs &b, const size_t lds_bytes, hipStream_t s) {
+    return b.Ndft == 64 ? launch_wave<M, 6, SPLIT>(b, lds_bytes, s) : b.Ndft == 128 ? launch_wave<M, 7, SPLIT>(b, lds_bytes, s) : launch_wave<M, 8, SPLIT>(b, lds_bytes, s);
+}
+
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
+    const int M = a->M, W = (a->nsym + 1) * a->P;
+    if (a->M != 2 && a->M != 4) return -1;
+    {   // the wave form (Ndft 64 / 128 / 256: every sonde configuration).  SONDE_FSK_KERNEL = wave2 (walker + worker, the default) | wave1 (one wave per channel) |
+        // stream (round 3's pipeline of four waves) | demod (frame at a time) — an A/B aid
+        static const char *k_env = getenv("SONDE_FSK_KERNEL");
+        int mode = 2; bool demod_env = false;
+        if (k_env) { mode = !strcmp(k_env, "wave1") ? 1 : !strcmp(k_env, "wave2") ? 2 : 0; demod_env = !strcmp(k_env, "demod"); }
+        static const char *st_env0 = getenv("SONDE_FSK_STREAM");
+        if (st_env0) mode = 0;                                                  // (the older switch between the two older kernels implies one of them)
+        const int R = fw_ring_len(a->NT, a->Ts / a->P);
+        // the finisher (a fourth wave: soft decisions, Eb/N0 and record of a frame while the worker is in the next) where f_int fits twice: the short frames of DFM / M10
+        const int fin = 2 * (size_t)M * W * sizeof(float2) <= 16384 ? 1 : 0;
+        const size_t lds_w = fw_lds_floats(M, a->nsym, a->P, R, a->Ndft, fin) * sizeof(float);
+        const bool fits = (a->Ndft == 64 || a->Ndft == 128 || a->Ndft == 256) && a->P >= 1 && a->Ts % a->P == 0 && lds_w + sizeof(FwCtl) + 64 <= 160 * 1024 && a->iperm;
+        if (mode && !a->force_demod && fits) {
+            FskArgs b = *a; b.R = R; b.wave_mode = mode; b.fin = fin;
+            if (mode == 2) return M == 2 ? launch_wave_n<2, true>(b, lds_w, s) : launch_wave_n<4, true>(b, lds_w, s);
+            return M == 2 ? launch_wave_n<2, false>(b, lds_w, s) : launch_wave_n<4, false>(b, lds_w, s);
+        }
+        if (demod_env) { FskArgs b = *a; b.force_demod = 1; return sonde_launch_fsk_old(&b, s); }
+    }
+    return sonde_launch_fsk_old(a, s);
+}
+
+extern "C" int sonde_launch_fsk_old(const FskArgs *a, hipStream_t s) {
     const int W = (a->nsym + 1) * a->P, M = a->M;
     if (a->M != 2 && a->M != 4) return -1;
     {   // the pipelined kernel, where its estimator fits (Ndft <= 256: every sonde configuration)

@@ -1,8 +1,16 @@
 // sonde_fsk_dev.h — structs shared by the 2-/4-FSK modem kernel (sonde_fsk.hip) and its host engine (sonde_fsk.cpp).
 #ifndef SONDE_FSK_DEV_H
 #define SONDE_FSK_DEV_H
+#ifdef SONDE_FSK_EMU                  // tests/emu: the wave form of the modem compiled for the host (test infrastructure) — no HIP headers
+#include <stdint.h>
+#include <stddef.h>
+struct float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { float2 v; v.x = x; v.y = y; return v; }
+typedef void *hipStream_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #define FSK_THREADS 256
 
@@ -33,6 +41,7 @@ struct FskArgs {
     const float *hann;                // [Ndft]
     const float2 *tw;                 // [Ndft] kiss_fft's twiddles: (cosf, sinf) of (float)(-2 pi k / Ndft) (kiss_fft.c:356-362)
     const uint16_t *perm;             // [Ndft] where input sample i sits before the first butterfly stage (kf_work's decimation)
+    const uint16_t *iperm;            // [Ndft] its inverse: the input sample that sits at position o
     int n_stage, st_p[8], st_m[8], st_fs[8];   // butterfly stages in execution order: radix, sub-transform length, twiddle stride
     const float2 *dphi_peak;          // [Ndft]    comp_exp_j(2 pi f/Fs) for f = (k - Ndft/2) Fs/Ndft
     const float2 *dphi_mask;          // [Ndft][M] same for the mask estimator's f2_est
@@ -52,6 +61,8 @@ struct FskArgs {
     unsigned long long *prof;         // profiling aid (SONDE_FSK_PROF): [16] shader-clock cycles per phase of channel 0's frames, summed; nullptr = off    // a launch over a LIST of channels with the frame-at-a-time kernel: how the host repeats the channels whose pipeline gave up (sonde_fsk.cpp launch_and_collect)
     const int *ch_list;               // [n_ch] channel of workgroup b (nullptr: b)
     int force_demod;                  // 1: k_fsk_demod even where the pipelined kernel applies
+    int fin;                          // set by the launcher: the wave form's finisher is on (f_int twice in LDS)
+    int wave_mode;                    // set by the launcher: 0 = k_fsk_stream / k_fsk_demod, 1 = k_fsk_wave one wave per channel, 2 = k_fsk_wave walker + worker (sonde_fsk_wave.h)
     int test_abort_ch;                // test hook (SONDE_FSK_TEST_ABORT=<channel>): that channel's pipeline gives up behind its first frame; -1 = off
 };
 

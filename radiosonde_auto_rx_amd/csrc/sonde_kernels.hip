@@ -2621,9 +2621,10 @@ extern "C" void sonde_launch_rs41_ecc_frames(FrameRec *frames, const uint32_t *l
 // rs41_ecc() over a batch of de-whitened 518-byte frames, one workgroup per frame: the same workgroup function on frames that come from
 // somewhere else (tests: word-by-word parity with the compiled reference; callers with frames from --softin or a file); syndromes computed here
 __global__ __launch_bounds__(RSK_THREADS)
-void k_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int level, int32_t *ecc, int32_t *codes, uint8_t *synd, const uint8_t *gf_exp, const uint8_t *gf_log) {
+void k_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int level, int32_t *ecc, int32_t *codes, uint8_t *synd, const uint8_t *gf_exp, const uint8_t *gf_log, const unsigned *count) {
     __shared__ RsEccLds L;
     const int tid = threadIdx.x, f = blockIdx.x;
+    if (count && (unsigned)f >= *count) return;                           // (a batch whose size only the device knows: the soft-bit framer's frames of this call)
     rs_ecc_tables(L, gf_exp, gf_log, tid);
     for (int i = tid; i < 518; i += RSK_THREADS) L.frame[i] = i < flen[f] ? frames[(size_t)f * 518 + i] : 0;      // rs41mod.c:1727
     __syncthreads();
@@ -2641,7 +2642,11 @@ void k_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int level, int32_t *
 }
 extern "C" void sonde_launch_rs41_ecc_batch(uint8_t *frames, const int32_t *flen, int n, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                             const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s) {
-    hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(n), dim3(RSK_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log);
+    hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(n), dim3(RSK_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log, (const unsigned *)nullptr);
+}
+extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *flen, const unsigned *count, int cap, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
+                                              const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s) {
+    hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(cap), dim3(RSK_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log, count);
 }
 
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {

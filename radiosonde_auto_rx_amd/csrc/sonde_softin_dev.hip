@@ -1,0 +1,287 @@
+// sonde_softin_dev.hip — `rs41mod --softin [-i]` for MANY channels on the device, fed from the modem's soft decisions where they lie
+// (include/sonde_fsk.h sonde_softin_dev_*): the consumer half of auto_rx's production pipe `fsk_demod ... | rs41mod --softin -i`
+// (auto_rx/autorx/decode.py:901-909), so that BASELINE configs[3] ends at decoded, repaired frames without a device-to-host copy of the
+// soft-decision stream.
+//   find_softbinhead / corr_softhdb (demod/mod/demod_mod.c:1692-1762): the last 64 soft bits against the +-1 header, normalised, in double,
+//     |mv| > 0.7 — one lane per bit position, 64 positions at a time; the polarity rule of rs41mod.c:2886-2890 (-i / --auto) on the first hit
+//   the bit loop (rs41mod.c:2893-2962): 510 x 8 hard decisions, LSB first, de-whitened — one lane per byte
+//   rs41_ecc (rs41mod.c:1703-1769): k_rs41_ecc_batch (sonde_kernels.hip), one workgroup per completed frame
+// A wavefront per channel; the state that survives a call (search ring, frame in progress, pending bits of a byte, polarity) lives in
+// device memory.  The ring is only advanced while SEARCHING — the reference's frame loop does not touch hdb.sbuf — so a search behind a
+// frame starts from the ring as the header left it.  Arithmetic as the reference's (float products, double sums, in order): frames are
+// bit-identical for identical soft bits (tests/test_gpu_softin_dev.py against oracle/_ref/fsk_demod | oracle/_ref/rs41mod --softin).
+#include "../../include/sonde_fsk.h"
+#include "sonde_fsk_dev.h"
+#include "sonde_host.h"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libsonde_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return SONDE_E_NOGPU; } } while (0)
+
+struct SoftinChan {
+    int   mode;                    // 0 searching, 1 inside a frame
+    int   inv;                     // gpx.option.inv as it stands (--auto may flip it)
+    int   body_done;               // frame bits consumed (0 .. 4080)
+    int   carry_n;                 // soft bits of an unfinished byte
+    float carry[8];
+    float hist[64];                // the last 64 soft bits seen while searching, oldest first (hdb.sbuf)
+    float mv;                      // score of the header in front of the frame in progress
+    unsigned long long bits_in, hdr_bit;
+    unsigned char frame[520];
+};
+struct SoftinMeta { int channel, len, nbytes; float mv; unsigned long long hdr_bit; };
+
+struct SoftinArgs {
+    const float *sd; long long ch_stride;          // soft decisions of channel c at sd + c * ch_stride
+    const int *nbits_ch; int nbits;                // per channel (device) or one count for all
+    const FskChan *fsk_chan; int bits_per_frame;   // or: frames of the modem's last launch x bits per frame
+    int n_ch, inv_in, opt_auto; float ths;
+    SoftinChan *chan;
+    unsigned char *frames; int *flen; SoftinMeta *meta; unsigned *count; int cap;
+    const unsigned char *hdr;                      // 64 header bits ('0'/'1'), 8 header bytes, 64 mask bytes
+};
+
+__global__ __launch_bounds__(64)
+void k_softin_rs41(const SoftinArgs a) {
+    __shared__ float s_hist[64];
+    __shared__ unsigned char s_frame[520];
+    __shared__ float s_carry[8];
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= a.n_ch) return;
+    SoftinChan *st = a.chan + ch;
+    int nb = a.nbits;
+    if (a.fsk_chan) { const int fr = a.fsk_chan[ch].frames; nb = fr > 0 ? fr * a.bits_per_frame : 0; }
+    else if (a.nbits_ch) nb = a.nbits_ch[ch];
+    const float *x = a.sd + (size_t)ch * a.ch_stride;
+    int mode = st->mode, inv = st->inv, body_done = st->body_done, carry_n = st->carry_n;
+    float mv_hdr = st->mv; unsigned long long hdr_bit = st->hdr_bit; const unsigned long long bits0 = st->bits_in;
+    s_hist[lane] = st->hist[lane];
+    for (int i = lane; i < 520; i += 64) s_frame[i] = st->frame[i];
+    if (lane < 8) s_carry[lane] = st->carry[lane];
+    // the header as +-1, one element per lane (for the dot products every lane needs all 64: from LDS-free registers via the constant array)
+    __builtin_amdgcn_wave_barrier();
+    const float sgn = a.inv_in ? -1.f : 1.f;
+    int cur = 0;
+    while (cur < nb) {
+        if (mode == 0) {
+            // ---- find_softbinhead: position q of the call = stream element 64 + (q - cur) of hist ++ x[cur ..]
+            bool found = false;
+            int base = cur;
+            for (; base < nb && !found; base += 64) {
+                const int q = base + lane;
+                float mv = 0.f;
+                if (q < nb) {
+                    double sum = 0.0, normx = 0.0;
+                    const int e = 64 + (q - cur);                       // window = elements e-63 .. e
+                    for (int i = 0; i < 64; i++) {
+                        const int k = e - 63 + i;
+                        const float v = k < 64 ? s_hist[k] : sgn * x[cur + (k - 64)];
+                        const float y = (a.hdr[i] & 1) ? 1.f : -1.f;
+                        sum += (double)(y * v);
+                        normx += (double)(v * v);
+                    }
+                    sum /= sqrt(normx * 64.0);
+                    mv = (float)sum;
+                }
+                unsigned long long hits = __ballot(q < nb && fabsf(mv) > a.ths);
+                while (hits) {
+                    const int l = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const float mvl = __shfl(mv, l);
+                    // the polarity rule (rs41mod.c:2886-2890): a header of the other sign is skipped, or with --auto flips the option
+                    if ((double)mvl * (0.5 - inv) < 0) { if (!a.opt_auto) continue; inv ^= 1; }
+                    found = true;
+                    const int qs = base + l;
+                    // the ring as the header leaves it: the 64 elements up to the hit
+                    const int e = 64 + (qs - cur), k = e - 63 + lane;
+                    const float v = k < 64 ? s_hist[k] : sgn * x[cur + (k - 64)];
+                    __builtin_amdgcn_wave_barrier();
+                    s_hist[lane] = v;
+                    __builtin_amdgcn_wave_barrier();
+                    mode = 1; body_done = 0; carry_n = 0; mv_hdr = mvl; hdr_bit = bits0 + (unsigned long long)qs + 1ull;
+                    cur = qs + 1;
+                    break;
+                }
+            }
+            if (!found) {
+                const int e = 64 + (nb - 1 - cur), k = e - 63 + lane;
+                const float v = k < 64 ? s_hist[k] : sgn * x[cur + (k - 64)];
+                __builtin_amdgcn_wave_barrier();
+                s_hist[lane] = v;
+                __builtin_amdgcn_wave_barrier();
+                cur = nb;
+            }
+        } else {
+            // ---- the bit loop: bytes from the pending bits of the last call and the new ones
+            const int take = min(nb - cur, 4080 - body_done);
+            const int tot = carry_n + take, nbytes = tot / 8, byte0 = 8 + (body_done - carry_n) / 8;
+            for (int j = lane; j < nbytes; j += 64) {
+                unsigned byte = 0;
+                for (int b = 0; b < 8; b++) {
+                    const int k = 8 * j + b;
+                    const float v = k < carry_n ? s_carry[k] : sgn * x[cur + (k - carry_n)];
+                    int bit = v >= 0.0f;
+                    if (inv) bit ^= 1;
+                    byte |= (unsigned)bit << b;                         // bits2byte: LSB first (rs41mod.c:224)
+                }
+                const int bc = byte0 + j;
+                s_frame[bc] = (unsigned char)(byte ^ a.hdr[72 + (bc & 63)]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int rest = tot - 8 * nbytes;
+            float cv = 0.f;
+            if (lane < rest) { const int k = 8 * nbytes + lane; cv = k < carry_n ? s_carry[k] : sgn * x[cur + (k - carry_n)]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 8) s_carry[lane] = cv;
+            __builtin_amdgcn_wave_barrier();
+            carry_n = rest; body_done += take; cur += take;
+            if (body_done == 4080) {
+                // print_frame(): the frame goes out (header bytes in front), rs41_ecc() follows in k_rs41_ecc_batch
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(a.count, 1u);
+                slot = __shfl(slot, 0);
+                if ((int)slot < a.cap) {
+                    unsigned char *o = a.frames + (size_t)slot * 518;
+                    for (int i = lane; i < 518; i += 64) o[i] = i < 8 ? a.hdr[64 + i] : s_frame[i];
+                    if (lane == 0) {
+                        int ft = 0; const unsigned char b = s_frame[0x38];
+                        for (int i = 0; i < 4; i++) ft += ((b >> i) & 1) - ((b >> (i + 4)) & 1);        // frametype (rs41mod.c:407-415)
+                        a.flen[slot] = ft >= 0 ? 320 : 518;
+                        SoftinMeta m; m.channel = ch; m.len = ft >= 0 ? 320 : 518; m.nbytes = 518; m.mv = mv_hdr; m.hdr_bit = hdr_bit;
+                        a.meta[slot] = m;
+                    }
+                }
+                mode = 0; body_done = 0; carry_n = 0;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    st->hist[lane] = s_hist[lane];
+    for (int i = lane; i < 520; i += 64) st->frame[i] = s_frame[i];
+    if (lane < 8) st->carry[lane] = s_carry[lane];
+    if (lane == 0) { st->mode = mode; st->inv = inv; st->body_done = body_done; st->carry_n = carry_n; st->mv = mv_hdr; st->hdr_bit = hdr_bit; st->bits_in = bits0 + (unsigned long long)nb; }
+}
+
+extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *flen, const unsigned *count, int cap, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
+                                              const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
+extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream);
+
+struct sonde_softin_dev {
+    int C = 0, ecc_level = 0, cap = 0;
+    SoftinArgs args{};
+    hipStream_t stream = nullptr; bool own_stream = false;
+    SoftinChan *d_chan = nullptr; unsigned char *d_frames = nullptr, *d_hdr = nullptr, *d_gf = nullptr, *d_synd = nullptr;
+    int *d_flen = nullptr, *d_ecc = nullptr, *d_codes = nullptr; SoftinMeta *d_meta = nullptr; unsigned *d_count = nullptr;
+    std::vector<sonde_frame_t> queue;
+    long long frames_total = 0, ecc_ok_total = 0, repaired_total = 0, symbols_total = 0, dropped = 0;
+    std::vector<int> h_flen, h_ecc; std::vector<SoftinMeta> h_meta; std::vector<unsigned char> h_frames;
+};
+
+extern "C" {
+
+int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto, sonde_softin_dev_t **out) {
+    if (!out || n_channels < 1 || sonde_type != SONDE_RS41 || ecc_level < 0 || ecc_level > 2) return SONDE_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "libsonde_hip: no usable HIP device (the batched soft-bit framer has no CPU fallback)\n"); return SONDE_E_NOGPU; }
+    sonde_softin_dev *s = new sonde_softin_dev();
+    s->C = n_channels; s->ecc_level = ecc_level; s->cap = 2 * n_channels + 16;          // a call of one second completes at most two frames per channel
+    const size_t C = (size_t)n_channels, cap = (size_t)s->cap;
+    std::vector<SoftinChan> init(C);
+    memset(init.data(), 0, C * sizeof(SoftinChan));
+    for (auto &c : init) { c.inv = opt_inv ? 1 : 0; memcpy(c.frame, sonde::kRs41HeaderBytes, 8); }
+    unsigned char hdr[136];
+    memcpy(hdr, sonde::kRs41Header, 64); memcpy(hdr + 64, sonde::kRs41HeaderBytes, 8); memcpy(hdr + 72, sonde::kRs41Mask, 64);
+    bool ok = hipMalloc((void **)&s->d_chan, C * sizeof(SoftinChan)) == hipSuccess && hipMalloc((void **)&s->d_frames, cap * 518) == hipSuccess
+           && hipMalloc((void **)&s->d_hdr, sizeof hdr) == hipSuccess && hipMalloc((void **)&s->d_gf, 768) == hipSuccess && hipMalloc((void **)&s->d_synd, cap * 48) == hipSuccess
+           && hipMalloc((void **)&s->d_flen, cap * 4) == hipSuccess && hipMalloc((void **)&s->d_ecc, cap * 4) == hipSuccess && hipMalloc((void **)&s->d_codes, cap * 8) == hipSuccess
+           && hipMalloc((void **)&s->d_meta, cap * sizeof(SoftinMeta)) == hipSuccess && hipMalloc((void **)&s->d_count, 4) == hipSuccess;
+    ok = ok && hipMemcpy(s->d_chan, init.data(), C * sizeof(SoftinChan), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice) == hipSuccess
+            && hipMemcpy(s->d_gf, sonde::gf_exp_table(), 512, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->d_gf + 512, sonde::gf_log_table(), 256, hipMemcpyHostToDevice) == hipSuccess
+            && hipMemset(s->d_ecc, 0, cap * 4) == hipSuccess;
+    if (!ok) { sonde_softin_dev_destroy(s); return SONDE_E_NOMEM; }
+    SoftinArgs &a = s->args;
+    a.n_ch = n_channels; a.inv_in = invert_stream ? 1 : 0; a.opt_auto = opt_auto ? 1 : 0; a.ths = 0.7f;
+    a.chan = s->d_chan; a.frames = s->d_frames; a.flen = s->d_flen; a.meta = s->d_meta; a.count = s->d_count; a.cap = s->cap; a.hdr = s->d_hdr;
+    s->h_flen.resize(cap); s->h_ecc.resize(cap); s->h_meta.resize(cap); s->h_frames.resize(cap * 518);
+    *out = s;
+    return 0;
+}
+
+void sonde_softin_dev_destroy(sonde_softin_dev_t *s) {
+    if (!s) return;
+    if (s->own_stream && s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    void *p[] = { s->d_chan, s->d_frames, s->d_hdr, s->d_gf, s->d_synd, s->d_flen, s->d_ecc, s->d_codes, s->d_meta, s->d_count };
+    for (void *q : p) if (q) hipFree(q);
+    delete s;
+}
+
+// the framer over what args.sd / nbits describe, then rs41_ecc() over the frames it completed; tallies and the records of the call come to the host
+static int softin_run(sonde_softin_dev *s, hipStream_t st) {
+    SoftinArgs &a = s->args;
+    HIPCHK(hipMemsetAsync(s->d_count, 0, 4, st));
+    hipLaunchKernelGGL(k_softin_rs41, dim3(s->C), dim3(64), 0, st, a);
+    if (s->ecc_level > 0)
+        sonde_launch_rs41_ecc_batch_n(s->d_frames, s->d_flen, s->d_count, s->cap, s->ecc_level, s->d_ecc, s->d_codes, s->d_synd, s->d_gf, s->d_gf + 512, st);
+    HIPCHK(hipGetLastError());
+    unsigned n = 0;
+    HIPCHK(hipMemcpyAsync(&n, s->d_count, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if ((int)n > s->cap) { s->dropped += (long long)n - s->cap; n = (unsigned)s->cap; }
+    if (n == 0) return 0;
+    HIPCHK(hipMemcpyAsync(s->h_meta.data(), s->d_meta, (size_t)n * sizeof(SoftinMeta), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_ecc.data(), s->d_ecc, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_frames.data(), s->d_frames, (size_t)n * 518, hipMemcpyDeviceToHost, st));       // 518 bytes per frame and second: not the soft decisions
+    HIPCHK(hipStreamSynchronize(st));
+    for (unsigned i = 0; i < n; i++) {
+        sonde_frame_t f; memset(&f, 0, sizeof f);
+        const SoftinMeta &m = s->h_meta[i];
+        f.channel = m.channel; f.len = m.len; f.nbytes = m.nbytes; f.mv = m.mv; f.mv_pos = (uint32_t)m.hdr_bit;
+        f.ecc = s->ecc_level > 0 ? s->h_ecc[i] : 0;
+        memcpy(f.frame, s->h_frames.data() + (size_t)i * 518, 518);
+        s->queue.push_back(f);
+        s->frames_total++;
+        if (f.ecc >= 0) s->ecc_ok_total++;
+        if (f.ecc > 0) { s->repaired_total++; s->symbols_total += f.ecc; }
+    }
+    return 0;
+}
+
+int sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
+    if (!s || !modem) return SONDE_E_ARG;
+    const float *d_sd = nullptr; long long cap = 0; const FskChan *d_chan = nullptr; int bpf = 0, nch = 0; hipStream_t st = nullptr;
+    const int rc = sonde_fsk_dev_view(modem, &d_sd, &cap, &d_chan, &bpf, &nch, &st);
+    if (rc) return rc;
+    if (nch != s->C) return SONDE_E_ARG;
+    SoftinArgs &a = s->args;
+    a.sd = d_sd; a.ch_stride = cap; a.fsk_chan = d_chan; a.bits_per_frame = bpf; a.nbits_ch = nullptr; a.nbits = 0;
+    return softin_run(s, st);
+}
+
+int sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, int64_t ch_stride, int32_t n_bits) {
+    if (!s || !d_soft || n_bits < 0 || ch_stride < n_bits) return SONDE_E_ARG;
+    if (!s->stream) { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+    SoftinArgs &a = s->args;
+    a.sd = d_soft; a.ch_stride = ch_stride; a.fsk_chan = nullptr; a.nbits_ch = nullptr; a.nbits = n_bits;
+    return softin_run(s, s->stream);
+}
+
+int sonde_softin_dev_fetch(sonde_softin_dev_t *s, sonde_frame_t *out, int32_t max) {
+    if (!s || (!out && max > 0)) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->queue.size(), (size_t)(max < 0 ? 0 : max));
+    for (int i = 0; i < n; i++) out[i] = s->queue[i];
+    s->queue.erase(s->queue.begin(), s->queue.begin() + n);
+    return n;
+}
+
+int sonde_softin_dev_counts(sonde_softin_dev_t *s, int64_t *frames, int64_t *ecc_ok, int64_t *repaired, int64_t *symbols, int64_t *dropped) {
+    if (!s) return SONDE_E_ARG;
+    if (frames) *frames = s->frames_total;
+    if (ecc_ok) *ecc_ok = s->ecc_ok_total;
+    if (repaired) *repaired = s->repaired_total;
+    if (symbols) *symbols = s->symbols_total;
+    if (dropped) *dropped = s->dropped;
+    return 0;
+}
+
+}  // extern "C"

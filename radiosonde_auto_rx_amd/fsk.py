@@ -48,6 +48,12 @@ def _lib():
         L.sonde_fsk_process_host_var.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
         L.sonde_fsk_reset_channel.argtypes = [C.c_void_p, C.c_int32]
         L.sonde_fsk_fetch_bits.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.sonde_softin_dev_create.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_void_p)]
+        L.sonde_softin_dev_destroy.argtypes = [C.c_void_p]
+        L.sonde_softin_dev_push_fsk.argtypes = [C.c_void_p, C.c_void_p]
+        L.sonde_softin_dev_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_softin_dev_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.sonde_softin_dev_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 5
         _proto = True
     return L
 
@@ -140,3 +146,47 @@ class FskModem:
         ms, n = C.c_double(0), C.c_int64(0)
         _chk(_lib().sonde_fsk_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class SoftinDev:
+    """Batched `rs41mod --softin [-i] [--ecc|--ecc2]` on the device (include/sonde_fsk.h sonde_softin_dev_*): the consumer of a modem
+    engine's soft decisions where they lie — auto_rx's pipe `fsk_demod ... | rs41mod --softin -i` (auto_rx/autorx/decode.py:901-909)
+    without the soft-decision stream crossing to the host.  No CPU fallback."""
+
+    def __init__(self, n_channels: int, *, ecc: int = 2, softinv: bool = False, inv: bool = True, auto: bool = False):
+        from .engine import SONDE_RS41
+        h = C.c_void_p()
+        _chk(_lib().sonde_softin_dev_create(n_channels, SONDE_RS41, ecc, int(softinv), int(inv), int(auto), C.byref(h)))
+        self._h, self.n_channels = h, n_channels
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib().sonde_softin_dev_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def push_fsk(self, modem: "FskModem"):
+        """consume what the modem's last process call left in device memory"""
+        _chk(_lib().sonde_softin_dev_push_fsk(self._h, modem._h))
+
+    def push_device(self, ptr: int, ch_stride: int, n_bits: int):
+        _chk(_lib().sonde_softin_dev_push_device(self._h, C.c_void_p(ptr), ch_stride, n_bits))
+
+    def fetch(self, max_frames: int = 4096):
+        """-> list of dicts (channel, len, ecc, mv, mv_pos, frame bytes, line = the `rs41mod -r` text) of the frames completed since the last fetch"""
+        from .engine import SondeFrame, lib
+        buf = (SondeFrame * max_frames)()
+        n = _chk(_lib().sonde_softin_dev_fetch(self._h, buf, max_frames))
+        out = []
+        line = C.create_string_buffer(1200)
+        for i in range(n):
+            f = buf[i]
+            ll = lib().sonde_rs41_rawline(C.byref(f), line, 1200)
+            out.append(dict(channel=f.channel, len=f.len, ecc=f.ecc, mv=f.mv, mv_pos=f.mv_pos, nbytes=f.nbytes, frame=bytes(f.frame), line=line.raw[:ll].decode()))
+        return out
+
+    def counts(self):
+        v = [C.c_int64(0) for _ in range(5)]
+        _chk(_lib().sonde_softin_dev_counts(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("frames", "ecc_ok", "repaired", "symbols", "dropped"), [x.value for x in v]))
