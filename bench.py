@@ -38,7 +38,7 @@ BANK = 20                # unique synthetic captures tiled over the channels
 # of --ecc2, some fail), 5 % beyond it.  What the decoder makes of each class is reported in config.error_mix.
 ERROR_MIX = [0] * 10 + [3, 4, 5, 6, 8, 10] + [20, 22, 24] + [48]
 ERROR_CLASSES = ["clean"] * 10 + ["3-10 symbol errors"] * 6 + ["near t = 12 per codeword"] * 3 + ["uncorrectable"]
-PROFILE_TAG = "r4"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
+PROFILE_TAG = "r5"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
 
 
 def make_bank(seconds: float = 1.0):
@@ -253,6 +253,9 @@ def bench_demod(args, D: Dist):
     est = max((time.perf_counter() - t_p) / 10, 1e-4)
     repeats = 1 if os.environ.get("SONDE_BENCH_NO_REPEAT") else max(1, int(np.ceil(2.2 / (est * steps))))
     total_steps = steps * repeats
+    # what this box's HBM gives a plain read stream over the very buffer the decimator reads (best of five passes), and the clocks around the timed loop
+    stream_gbps = _stream_probe(iq.data_ptr(), int(iq.numel()) * iq.element_size())
+    clocks0 = _device_clocks()
     eng.profile(1)                      # timed region: HIP events around the dominant kernel only (2 events per step)
     D.barrier()
     t0 = time.perf_counter()
@@ -277,6 +280,7 @@ def bench_demod(args, D: Dist):
     eng.sync()
     D.barrier()
     dt_local = time.perf_counter() - t0
+    clocks1 = _device_clocks()
     dt, per_rank = D.finish_times(dt_local)
     host_ecc = eng.host_ecc_frames() - host_ecc0
     nframes, nok, nfixed, nsym, host_ecc = D.sum_ints(nframes, nok, nfixed, nsym, host_ecc)
@@ -392,6 +396,11 @@ def bench_demod(args, D: Dist):
                                        "slots the other stream's kernels hold (header search / frame sync beside the decimator), so the column does not add up to the step"},
             "roofline": {"bound": "hbm", "kernel": "k_mix_decimate50", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "frac_kernel_alone": alone["frac"] if alone else None, "kernel_alone": alone,
+                         "measured_stream_GBps": round(stream_gbps, 1) if stream_gbps else None,
+                         "frac_of_measured": round(achieved / stream_gbps, 4) if stream_gbps else None,
+                         "measured_note": "a plain read stream over the same 4.9 GB buffer in this process just before the timed loop (16 B per lane, non-temporal, no arithmetic; "
+                                          "best of five passes): what THIS box's HBM delivers — boxes of the pool differ by several per cent",
+                         "clocks_mhz": {"before": clocks0, "after": clocks1},
                          "traffic": traffic, "traffic_note": traffic_src,
                          "algorithmic_gb_per_launch": round(C * SR * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4), "launches": md_n,
                          "step_frac": round(C * SR * 4 / (dt / total_steps) / 8e12, 4),
@@ -493,8 +502,58 @@ def pcie_extra(D: Dist, eng, iq, C):
         eng.fetch_frames_np()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return dict(value=round(nch * SR / dt / 1e6, 1), unit="Msamples/s", ms_per_step=round(dt * 1e3, 3), realtime_channels=round(nch * SR / dt / 2.4e6, 1),
-                note="process_host from pinned memory, copy and kernels of one call in sequence (no double buffering)")
+    # double-buffered: the copy of second k+1 (its own stream, pinned source) runs while the kernels of second k do
+    bufs = [torch.empty_like(iq[:nch]), torch.empty_like(iq[:nch])]
+    cs = torch.cuda.Stream()
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    with torch.cuda.stream(cs):
+        bufs[0].copy_(host, non_blocking=True); evs[0].record(cs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps2 = 4
+    for k in range(reps2):
+        with torch.cuda.stream(cs):
+            bufs[(k + 1) & 1].copy_(host, non_blocking=True); evs[(k + 1) & 1].record(cs)
+        evs[k & 1].synchronize()
+        eng.process_device(bufs[k & 1].data_ptr(), iq.shape[1] // 2, SR)
+        eng.fetch_frames_np()
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / reps2
+    del bufs
+    return dict(value=round(nch * SR / dt2 / 1e6, 1), unit="Msamples/s", ms_per_step=round(dt2 * 1e3, 3), realtime_channels=round(nch * SR / dt2 / 2.4e6, 1),
+                host_to_device_GBps=round(nch * SR * 4 / dt2 / 1e9, 1),
+                sequential=dict(value=round(nch * SR / dt / 1e6, 1), ms_per_step=round(dt * 1e3, 3)),
+                note="samples arrive in pinned host memory; double-buffered: the host-to-device copy of second k+1 on its own stream beside the kernels of second k "
+                     "(process_device on the buffer that has landed) — bounded by the link, never `value`; `sequential` = process_host, copy and kernels in turn")
+
+
+def _device_clocks(index=0):
+    """current shader / memory clock of the device in MHz from sysfs (the line pp_dpm_* marks with '*'), or None where the box does not expose them"""
+    import glob
+    out = {}
+    for name, key in (("pp_dpm_sclk", "sclk_mhz"), ("pp_dpm_mclk", "mclk_mhz")):
+        val = None
+        for path in sorted(glob.glob("/sys/class/drm/card*/device/" + name)):
+            try:
+                for line in open(path).read().splitlines():
+                    if line.rstrip().endswith("*"):
+                        val = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                break
+            except Exception:
+                continue
+        out[key] = val
+    return out if any(v is not None for v in out.values()) else None
+
+
+def _stream_probe(ptr, nbytes):
+    """GB/s of a plain read stream over `nbytes` of device memory on this box, now (libsonde_hip sonde_probe_read_gbps): the measured figure beside the nominal peak"""
+    import ctypes as C
+    from radiosonde_auto_rx_amd.engine import lib
+    L = lib()
+    L.sonde_probe_read_gbps.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
+    g = C.c_double(0)
+    rc = L.sonde_probe_read_gbps(C.c_void_p(ptr), C.c_size_t(nbytes), 5, C.byref(g))
+    return float(g.value) if rc == 0 and g.value > 0 else None
 
 
 def main():

@@ -22,16 +22,26 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def _timed_steps(D, step, steps, warmup):
+def _timed_steps(D, step, steps, warmup, min_seconds=0.0):
+    """-> (seconds, per-rank seconds, steps timed).  min_seconds: the step count is raised (from a probe of three untimed steps, the same count on every rank) until
+    the timed region is at least that long — the sub-configurations of the default line are timed over >= 1 s like the headline, not over a few milliseconds."""
     for _ in range(warmup):
         step()
+    if min_seconds > 0:
+        D.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        D.barrier()
+        probe, _ = D.finish_times(time.perf_counter() - t0)
+        steps = max(steps, int(min_seconds / max(probe / 3, 1e-6)) + 1)
     D.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     D.barrier()
     dt, per = D.finish_times(time.perf_counter() - t0)
-    return dt, per
+    return dt, per, steps
 
 
 def bench_scan_wide(args, D, short=False):
@@ -78,7 +88,7 @@ def bench_scan_wide(args, D, short=False):
             found.append(sc.fetch())
         state["k"] = k + 1
 
-    dt, per = _timed_steps(D, step, steps, warmup)
+    dt, per, steps = _timed_steps(D, step, steps, warmup, 1.0 if not args.steps else 0.0)
     det = found[-1]
     kern = {k: sc.kernel_ms(k) for k in ("front_end", "scan_if", "scan_pre", "scan_corr")}
     pre_pairs, exact_pairs = sc.kernel_ms("pre_pairs")[0], sc.kernel_ms("exact_pairs")[0]
@@ -162,12 +172,14 @@ def bench_fsk_mixed(args, D, short=False):
         return ["--cs16", "-b", str(-lim), "-u", str(lim), "-s"] + (["--mask", str(mask)] if mask else []) + ["--nsym=%d" % nsym, "-p", str(P)]
     engines = []
     total_samples = 0
+    softin, rs41_caps = None, None
     for gi, (kind, Fs, Rs, P, nsym, mask, lim) in enumerate(groups):
         n = C // 3 + (1 if gi < C % 3 else 0)
         caps = []
         for s in range(4):
             if kind == "rs41":
-                caps.append(synth.rs41_capture(sr=Fs, seconds=1.0, fq=0.0, n_frames=1, t_first=0.05, noise_sigma=0.02, seed=s, f_offset_hz=150.0 * s))
+                # (captures 1..3 carry 4 / 8 / 12 bit errors in the frame: the consumer's Reed-Solomon stage has symbols to repair)
+                caps.append(synth.rs41_capture(sr=Fs, seconds=1.0, fq=0.0, n_frames=1, t_first=0.05, noise_sigma=0.02, seed=s, f_offset_hz=150.0 * s, bit_errors=4 * s))
             elif kind == "dfm":
                 caps.append(synth.dfm_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=10 + s))
             else:
@@ -176,6 +188,11 @@ def bench_fsk_mixed(args, D, short=False):
         X = torch.from_numpy(np.stack([caps[c % 4][:L] for c in range(n)])).to(D.dev)
         md = FskModem(Fs, Rs, n_channels=n, P=P, nsym=nsym, mask=mask, lower=-lim, upper=lim, max_chunk=Fs, device=D.local_rank)
         engines.append((kind, Fs, Rs, n, X, md, caps[0], ref_args(P, nsym, mask, lim)))
+        if kind == "rs41":
+            # the consumer of auto_rx's pipe (decode.py:901-909 `fsk_demod ... | rs41mod --softin -i`) on the device: header search, bit loop, rs41_ecc --ecc2
+            from radiosonde_auto_rx_amd.fsk import SoftinDev
+            softin = SoftinDev(n, ecc=2, inv=True)
+            rs41_caps = caps
         total_samples += n * (L // 2)
 
     # untimed, before anything else: the first second of every channel against the compiled reference modem (oracle/_ref/fsk_demod, test infrastructure) —
@@ -186,6 +203,7 @@ def bench_fsk_mixed(args, D, short=False):
         have_ref = bind.have_ref()
     except Exception:
         have_ref = False
+    frames_ok, frames_checked, fnote = 0, 0, "compiled reference not present"
     for kind, Fs, Rs, n, X, md, _cap, rargs in engines:
         md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
         sds = [md.fetch(c)[0] for c in range(n)]
@@ -207,23 +225,52 @@ def bench_fsk_mixed(args, D, short=False):
                 rms = float(np.sqrt(np.mean(w.astype(np.float64) ** 2))) or 1.0
                 ok = len(w) == len(ac) and len(ac) > 0 and float(np.sqrt(np.mean((ac.astype(np.float64) - w) ** 2))) < 1e-6 * rms and np.array_equal(ac < 0, w < 0)
             verified += int(ok and have_ref)
+        if kind == "rs41" and softin is not None:
+            # the frames the device consumer completes in the first THREE seconds (the capture three times: a frame spans 0.86 s and starts 0.13 s into each second) against
+            # the reference's own pipe on the same samples
+            softin.push_fsk(md)
+            for _ in range(2):
+                md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
+                softin.push_fsk(md)
+            got = {}
+            for f in softin.fetch(4 * n):
+                got.setdefault(f["channel"], []).append(f["line"])
+            want = {}
+            if have_ref:
+                import subprocess
+                for b in range(min(4, n)):
+                    p1 = subprocess.run([os.path.join(bind.REFDIR, "fsk_demod")] + rargs + ["2", str(Fs), str(Rs), "-", "-"], input=rs41_caps[b][:X.shape[1]].tobytes() * 3, capture_output=True, timeout=120)
+                    p2 = subprocess.run([os.path.join(bind.REFDIR, "rs41mod"), "--softin", "-i", "-r", "--ecc2"], input=p1.stdout, capture_output=True, timeout=120)
+                    want[b] = p2.stdout.decode().splitlines()
+                fnote = "first three seconds of every RS41 channel: the frames of the device consumer equal `oracle/_ref/fsk_demod ... | oracle/_ref/rs41mod --softin -i -r --ecc2` on the same capture, line for line (the frame in progress at the end is the next call's)"
+            for c in range(n):
+                frames_checked += 1
+                g = got.get(c, [])
+                frames_ok += int(have_ref and len(g) >= 1 and g == want[c % 4][:len(g)])
 
     # the three modem configurations are three engines with a stream each: driven from three host threads (the C calls release the GIL) their
-    # launches overlap on the GPU — one workgroup per channel (23-37 KB of LDS), four to five of them resident per CU
+    # launches overlap on the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS)
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=len(engines))
 
     def one(e):
         kind, Fs, Rs, n, X, md, _, _ = e
         md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
+        if kind == "rs41" and softin is not None:
+            softin.push_fsk(md)                               # soft decisions -> frames -> rs41_ecc, all in device memory; 518 bytes per frame come back
+
+    cnt0 = softin.counts() if softin is not None else None
 
     def step():
         list(pool.map(one, engines))
         torch.cuda.synchronize()
 
-    dt, per = _timed_steps(D, step, steps, warmup)
+    dt, per, steps = _timed_steps(D, step, steps, warmup, 1.0 if not args.steps else 0.0)
     value = D.world * total_samples * steps / dt / 1e6
     kern = {kind: md.kernel_ms() for kind, _, _, _, _, md, _, _ in engines}
+    cnt1 = softin.counts() if softin is not None else None
+    if softin is not None:
+        softin.fetch(1 << 20)                                 # (drop the queued records)
     # dominant kernel k_fsk_stream: algorithmic bytes = 4 B per complex cs16 input sample (soft decisions out: 4 B per symbol)
     # the three launches overlap: the rate follows from the step time, not from the sum of the kernels' own durations
     achieved = total_samples * 4 / (dt / steps) / 1e9
@@ -240,11 +287,18 @@ def bench_fsk_mixed(args, D, short=False):
                        "channels_per_gpu": C, "realtime_channels": round(value * 1e6 / D.world / (total_samples / C), 1) if total_samples else 0,
                        "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per],
                        "kernel_ms_per_launch": {k: round(v[0], 4) for k, v in kern.items()},
-                       "verified_channels": verified, "checked_channels": checked, "verify_note": vnote},
-            "roofline": {"bound": "hbm", "kernel": "k_fsk_stream", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                         "traffic": None, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel, its four waves a pipeline around the "
-                                                  "serial oscillator recurrence (one dependent complex multiply per sample, as in the reference): bound by that chain and by "
-                                                  "instruction issue, not by memory, see DESIGN.md"},
+                       "verified_channels": verified, "checked_channels": checked, "verify_note": vnote,
+                       "rs41_consumer": None if cnt1 is None else {
+                           "what": "rs41mod --softin -i --ecc2 on the device behind the modem (sonde_softin_dev_*): header search, bit loop, rs41_ecc; inside the timed step",
+                           "frames_decoded": cnt1["frames"] - cnt0["frames"], "frames_ecc_ok": cnt1["ecc_ok"] - cnt0["ecc_ok"], "frames_repaired": cnt1["repaired"] - cnt0["repaired"],
+                           "symbols_repaired": cnt1["symbols"] - cnt0["symbols"], "frames_dropped": cnt1["dropped"] - cnt0["dropped"],
+                           "verified_channels": frames_ok, "checked_channels": frames_checked, "verify_note": fnote},
+                       "soft_decisions": "stay in device memory (copied to the host only when sonde_fsk_fetch asks for them); the DFM and M10 thirds have no consumer on the device yet"},
+            "roofline": {"bound": "hbm", "kernel": "k_fsk_wave", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+                         "traffic": None, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel: a walker wave on the serial "
+                                                  "oscillator recurrence (one dependent complex multiply per sample, as in the reference: ~31 cycles per sample, 0.6 ms per second of "
+                                                  "signal whatever the channel count), worker / estimator / finisher waves beside it, one barrier per 128-sample piece: bound by that "
+                                                  "chain and by the waves' own instruction latency, not by memory — see DESIGN.md 4.7 and profiles/r5*"},
         }
         if D.world == 1 and not args.no_cpu_baseline:
             from oracle import bind
@@ -264,6 +318,8 @@ def bench_fsk_mixed(args, D, short=False):
                     r = _time_reference(cmds, inputs, units / ncores, "Msamples/s", "fsk_demod processes (RS41 / DFM / M10 settings in turn) over 20 s of IF-rate cs16", getattr(args, "cpu_budget", 12.0))
                 out["cpu_baseline"] = r
     pool.shutdown()
+    if softin is not None:
+        softin.close()
     for e in engines:
         e[5].close()
     return out

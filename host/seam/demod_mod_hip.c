@@ -28,7 +28,7 @@
  *
  * Differences to demod_mod.c a caller can see: one dsp_t at a time (the reference keeps file-static state too); thres / hdmax / bitofs are
  * taken from the first find_header call; a header of the wrong polarity that the
- * caller skips still has its frame consumed; f32buf_sample() is not available (EOF).
+ * caller skips still has its frame consumed; f32buf_sample() is not part of the seam (a call ends the program with a message).
  * The bit readers take per-call arguments the batched engine fixed when the hit was sliced: `ofs` must be the bitofs given to find_header() and
  * `l` the window this decoder always passes (-1, or its centre window for opt_iq > 2) — every decoder of the family does exactly that; any other
  * value, and spike != 0, ends the program with a message instead of returning bits that were sliced differently.  (spike: the reference's
@@ -301,7 +301,13 @@ int read_slbit(dsp_t *dsp, int *bit, int inv, int ofs, int pos, float l, int spi
     return 0;
 }
 
-int f32buf_sample(dsp_t *dsp, int inv) { (void)dsp; (void)inv; return EOF; }
+/* The per-sample pull of the reference (demod_mod.c:722): none of its decoders calls it directly — they go through find_header() / read_softbit2p() — and a
+ * batched engine has no "next sample" to hand out.  A caller that does call it is told so instead of reading a silent EOF. */
+int f32buf_sample(dsp_t *dsp, int inv) {
+    (void)dsp; (void)inv;
+    fprintf(stderr, "demod_mod_hip: f32buf_sample() is not part of this seam (samples are consumed inside find_header / read_softbit2p); the decoders of the reference do not call it\n");
+    exit(70);
+}
 
 /* ---------------------------------------------------------------- host-only helpers of demod_mod.c the decoders link against */
 

@@ -99,7 +99,9 @@ int  sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches);
  * (auto_rx's pipe `fsk_demod ... | rs41mod --softin -i`, auto_rx/autorx/decode.py:901-909).  find_softbinhead / corr_softhdb
  * (demod/mod/demod_mod.c:1692-1762, threshold 0.7), the bit loop and de-whitening of rs41mod.c:2893-2962 and rs41_ecc() (:1703-1769) run in
  * device memory; only completed frames (518 bytes each) come to the host.  invert_stream = --softinv, opt_inv = -i, opt_auto = --auto.
- * sonde_type: SONDE_RS41.  No CPU fallback. */
+ * sonde_type: SONDE_RS41; SONDE_DFM09 = `dfm09mod --softin [-i] [--ecc|--ecc2]` (dfm09mod.c:1604-1720: 32 raw header symbols, two soft symbols per bit, eight frames
+ * per header hit, de-interleave + Hamming(8,4) incl. the soft 2-bit pass :231-345 on a lane per codeword); SONDE_M10 = `m10mod --softin` (m10mod.c:1405-1510: header
+ * threshold 0.8 in either polarity, differential decoding, the rest of the second skipped, checkM10 :594-628).  No CPU fallback. */
 typedef struct sonde_softin_dev sonde_softin_dev_t;
 int  sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto,
                              sonde_softin_dev_t **out);
@@ -111,7 +113,10 @@ int  sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, in
 /* frames completed by the push calls since the last fetch (all channels, in completion order per call; channel / len / ecc / mv / mv_pos = the header's
  * bit index in the channel's stream); returns the count (<= max) */
 int  sonde_softin_dev_fetch(sonde_softin_dev_t *s, sonde_frame_t *out, int32_t max);
-/* tallies since creation: frames completed, frames rs41_ecc() accepted (ecc >= 0), frames it repaired (ecc > 0), symbols repaired, frames lost to a full buffer */
+/* SONDE_DFM09 / SONDE_M10 consumers: their frames (ecc[3] = hamming()'s value per block; cs_ok / cs_calc = the frame checksum) */
+int  sonde_softin_dev_fetch_dfm(sonde_softin_dev_t *s, sonde_dfm_frame_t *out, int32_t max);
+int  sonde_softin_dev_fetch_m10(sonde_softin_dev_t *s, sonde_m10_frame_t *out, int32_t max);
+/* tallies since creation: frames completed, frames accepted (RS41: rs41_ecc() >= 0; DFM: no block uncorrectable; M10: checksum good), frames repaired, symbols / codewords repaired, frames lost to a full buffer */
 int  sonde_softin_dev_counts(sonde_softin_dev_t *s, int64_t *frames, int64_t *ecc_ok, int64_t *repaired, int64_t *symbols, int64_t *dropped);
 
 #ifdef __cplusplus

@@ -185,8 +185,9 @@ int  sonde_engine_sync(sonde_engine_t *e);
 
 /* Collect frames completed so far (syncs).  The RS(255,231) passes of rs41_ecc() (rs41mod.c:1703-1769) have run on the device for
  * whole frames (k_framesync: syndromes, and for non-zero ones the Euclid / Chien / Forney decoder of bch_ecc_mod.c:877-960 on a wavefront
- * per codeword, the 2nd pass of --ecc2 included); only a frame cut short by the end of the stream is decoded on the host, because its
- * missing bytes come from the previous frame (rs41mod.c:2479-2490).
+ * per codeword, the 2nd pass of --ecc2 included).  Decoded on the host when they are fetched: a frame cut short by the end of the stream
+ * (its missing bytes come from the previous frame, rs41mod.c:2479-2490), and the damaged frames the end-of-stream frame syncs of
+ * sonde_engine_finish / _finish_channel emit (those launches have no decoder work list) — sonde_engine_host_ecc_frames() counts both.
  * Returns the number of frames written (<= max).  Frames of one channel come in stream order; the order between
  * channels that completed a frame in the same process call is unspecified (sonde_frame_t.channel tells them apart). */
 /* Per-channel detection summary: the ONLY data that crosses GPUs when channels are sharded over a node — 32 bytes per
@@ -220,7 +221,7 @@ int  sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t ma
  * overwritten before a fetch could read them; the fetch functions themselves return the number of frames they delivered. */
 int  sonde_engine_overflowed(sonde_engine_t *e);
 /* RS41 frames whose Reed-Solomon decoder ran on the host in sonde_engine_fetch_frames* so far: frames cut short by the end of the stream,
- * and every frame with non-zero syndromes when SONDE_HOST_ECC=1 is set in the environment (the A/B switch).  Whole frames are decoded by
+ * damaged frames emitted by the end-of-stream frame syncs (finish / finish_channel), and every frame with non-zero syndromes when SONDE_HOST_ECC=1 is set in the environment (the A/B switch).  Whole frames are decoded by
  * k_framesync on the device (rs41_ecc, rs41mod.c:1703-1769; rs_decode_ErrEra, bch_ecc_mod.c:877-960). */
 long long sonde_engine_host_ecc_frames(sonde_engine_t *e);
 /* on = 0: frames of the following calls leave k_framesync with their first-pass syndromes only and are decoded on the host when fetched (the
@@ -375,7 +376,7 @@ int  sonde_rs41_rawline(const sonde_frame_t *f, char *buf, size_t buflen);
 int  sonde_rs255_encode(uint8_t cw[255]);
 int  sonde_rs255_decode(uint8_t cw[255]);
 /* rs41_ecc() (rs41mod.c:1703-1769, ecc level 1 = --ecc, 2 = --ecc2) over n de-whitened RS41 frames of 518 bytes each ON THE DEVICE, one
- * workgroup per frame — the decoder k_framesync runs behind its slicer (syndromes on 16 wavefronts, rs_decode_ErrEra of
+ * workgroup per frame — the decoder k_framesync runs behind its slicer (syndromes on the workgroup's four wavefronts, rs_decode_ErrEra of
  * bch_ecc_mod.c:877-960 with no erasures on one wavefront per codeword, the 2nd pass with the known block ids).  Host pointers; frames are
  * repaired in place exactly as the reference leaves gpx->frame (bytes from flen[i] on count as zero, :1727).  ecc[i] = rs41_ecc's value;
  * codes (nullable) = [n][2] the two rs_decode() values of the last pass; synd (nullable) = [n][48] first-pass syndromes.
@@ -383,6 +384,11 @@ int  sonde_rs255_decode(uint8_t cw[255]);
 int  sonde_rs41_ecc_device(uint8_t *frames, const int32_t *flen, int32_t n, int32_t level, int32_t *ecc, int32_t *codes, uint8_t *synd);
 /* CRC-16/CCITT-FALSE of rs41mod.c:284 */
 int  sonde_crc16(const uint8_t *data, int len);
+
+/* What this device's HBM delivers to a plain read stream right now: `bytes` of device memory at d_buf read once per repetition, 16 bytes per lane,
+ * non-temporal (the decimator's access pattern without its arithmetic); *gbps = the best of `reps` passes in GB/s.  bench.py puts it beside the
+ * roofline's nominal peak (the measured stream figure of the same run). */
+int  sonde_probe_read_gbps(const void *d_buf, size_t bytes, int32_t reps, double *gbps);
 
 const char *sonde_strerror(int code);
 

@@ -387,7 +387,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     if (audio) bad |= dalloc(&e->d_raw, (size_t)C * ring);
     else { bad |= dalloc(&e->d_y, (size_t)C * ring); bad |= dalloc(&e->d_ifiq, (size_t)C * ring); }
     bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring);
-    bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1);
+    bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1 + 4);      // the counter, and its value behind each of the last four calls (what a call publishes)
     if (cfg->keep_soft || cfg->sonde_type != SONDE_RS41) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
     if (cfg->keep_soft == 2) bad |= dalloc(&e->d_soft1, (size_t)e->max_frames * e->nbits);
     bad |= dalloc(&e->d_match, L, false);
@@ -631,6 +631,8 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     e->in_call = true; e->ecc_listed = false;
     // this call's frame syncs append to the work list call-2 used: its decoder kernel (stream E) must be through
     if (e->stream_e && e->call >= 2) hipStreamWaitEvent(e->stream_b, e->ev_b[(e->call - 2) & 3], 0);
+    // ... and the list starts empty whatever that call left (a call that failed half way never ran the decoder that clears it: ADVICE round 4)
+    if (e->d_ecc_cnt) { hipMemsetAsync(e->d_ecc_cnt + (e->call & 1), 0, sizeof(unsigned), e->stream_b); hipMemsetAsync(e->d_ecc_cnt + 2 + (e->call & 1), 0, sizeof(unsigned), e->stream_b); }
     // two streams: this call's decimator overwrites the part of the y ring that call-2 occupied (ring_len >= 2 * max_if + history), so it must
     // not start before the IF chain of call-2 has read it.  Only the IF chain reads y: the header search and the frame sync behind it work on
     // rings stream B writes itself, so however late they run (they wait for CU slots the decimator frees) the decimators stay back to back.
@@ -720,7 +722,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         if (e->dc_since < (1 << 20)) e->dc_since += take / D;
         if (e->pcs) { a.epoch_phase = e->d_epoch_phase; a.dc_since_ch = e->d_pcs_since; a.dc_avg_prev = e->d_etab ? e->d_dcavg_prev : nullptr; }
         prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);
-        if (lrc < 0) return SONDE_E_ARG;
+        if (lrc < 0) { e->in_call = false; e->ecc_listed = false; return SONDE_E_ARG; }
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
         if (e->pcs) {                                    // per-channel segment edges: the device keeps the counters, the host mirrors them
@@ -811,6 +813,10 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
     // the call's records are complete (ev_b) once its damaged frames are decoded and the counter is published
     hipStream_t se = e->stream_b;
+    // the counter as THIS call's last frame sync leaves it, taken on the frame sync's own stream: what the call publishes.  (Published from the live counter
+    // behind the decoder on stream E it could already include slots the NEXT call's frame sync — which only waits for the call before last — has counted but not
+    // written yet: ADVICE round 4.)
+    hipMemcpyAsync(e->d_fcount + 1 + slot, e->d_fcount, sizeof(unsigned), hipMemcpyDeviceToDevice, e->stream_b);
     if (e->ecc_listed) {
         if (e->stream_e) { hipEventRecord(e->ev_s, e->stream_b); hipStreamWaitEvent(e->stream_e, e->ev_s, 0); se = e->stream_e; }
         const int par = (int)(e->call & 1);
@@ -819,7 +825,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
                                      e->cfg.ecc_level, e->d_consts + 136, e->d_consts + 648, std::min(512, std::max(1, C)), se);
         prof_end(e, se);
     }
-    sonde_launch_publish_u32(e->d_fcount, e->h_count_dev + slot, se);
+    sonde_launch_publish_u32(e->d_fcount + 1 + slot, e->h_count_dev + slot, se);
     hipEventRecord(e->ev_b[slot], se);
     e->in_call = false;
     e->call += 1;

@@ -42,6 +42,15 @@ static inline int fw_shfl_xor_i(int v, int mask) {
     emu::Wave &w = emu::my_wave(); const int l = emu::tid() & 63; int *b = reinterpret_cast<int *>(w.buf);
     b[l] = v; emu::wave_rendezvous(); const int r = b[l ^ mask]; emu::wave_rendezvous(); return r;
 }
+static inline unsigned fw_wave_umax(unsigned v) {
+    emu::Wave &w = emu::my_wave(); const int l = emu::tid() & 63; unsigned *b = reinterpret_cast<unsigned *>(w.buf);
+    b[l] = v; emu::wave_rendezvous(); unsigned r = 0; for (int i = 0; i < 64; i++) r = b[i] > r ? b[i] : r; emu::wave_rendezvous(); return r;
+}
+static inline unsigned fw_wave_umin(unsigned v) {
+    emu::Wave &w = emu::my_wave(); const int l = emu::tid() & 63; unsigned *b = reinterpret_cast<unsigned *>(w.buf);
+    b[l] = v; emu::wave_rendezvous(); unsigned r = 0xFFFFFFFFu; for (int i = 0; i < 64; i++) r = b[i] < r ? b[i] : r; emu::wave_rendezvous(); return r;
+}
+static inline unsigned fw_float_bits(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }
 static inline unsigned long long fw_clock() { return 0ull; }
 #else
 #define FW_DEV __device__ __forceinline__
@@ -51,6 +60,24 @@ FW_DEV void fw_barrier() { __syncthreads(); }
 FW_DEV float fw_shfl_xor_f(float v, int mask) { return __shfl_xor(v, mask); }
 FW_DEV int fw_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask); }
 FW_DEV unsigned long long fw_clock() { return __builtin_readcyclecounter(); }
+// wave-wide unsigned max / min in seven DPP steps (row shifts, then the row broadcasts; lanes a step does not reach keep their value), the result from lane 63 —
+// a butterfly of `ds_bpermute` exchanges costs an LDS round trip per step, and the estimator's searches were a third of its time for short frames
+#define FW_DPP_STEP(OP, ID, ctrl, rm, bm) do { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp((int)(ID), (int)v, ctrl, rm, bm, false); v = OP(v, o_); } while (0)
+FW_DEV unsigned fw_umax2(unsigned a, unsigned b) { return a > b ? a : b; }
+FW_DEV unsigned fw_umin2(unsigned a, unsigned b) { return a < b ? a : b; }
+FW_DEV unsigned fw_wave_umax(unsigned v) {
+    FW_DPP_STEP(fw_umax2, 0u, 0x111, 0xf, 0xf); FW_DPP_STEP(fw_umax2, 0u, 0x112, 0xf, 0xf); FW_DPP_STEP(fw_umax2, 0u, 0x113, 0xf, 0xf);
+    FW_DPP_STEP(fw_umax2, 0u, 0x114, 0xf, 0xe); FW_DPP_STEP(fw_umax2, 0u, 0x118, 0xf, 0xc);
+    FW_DPP_STEP(fw_umax2, 0u, 0x142, 0xa, 0xf); FW_DPP_STEP(fw_umax2, 0u, 0x143, 0xc, 0xf);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+FW_DEV unsigned fw_wave_umin(unsigned v) {
+    FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x111, 0xf, 0xf); FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x112, 0xf, 0xf); FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x113, 0xf, 0xf);
+    FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x114, 0xf, 0xe); FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x118, 0xf, 0xc);
+    FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x142, 0xa, 0xf); FW_DPP_STEP(fw_umin2, 0xFFFFFFFFu, 0x143, 0xc, 0xf);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+FW_DEV unsigned fw_float_bits(float f) { return __float_as_uint(f); }
 #endif
 
 #define FW_FMT_S16  1
@@ -111,11 +138,10 @@ FW_DEV float2 fw_convert(const int format, const FwRaw r) {
 FW_DEV int fw_argmax(const float *v, const int lo, const int hi, const int dflt, const int lane) {
     float best = 0.f; int bi = INT_MAX;
     for (int i = lo + lane; i < hi; i += 64) { const float x = v[i]; if (x > best) { best = x; bi = i; } }
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ob = fw_shfl_xor_f(best, off); const int oi = fw_shfl_xor_i(bi, off);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    return bi == INT_MAX ? dflt : bi;
+    // the largest value (the bit patterns of non-negative floats order like the floats), then the smallest index that holds it
+    const unsigned bits = fw_float_bits(best), mx = fw_wave_umax(bits);
+    const unsigned mi = fw_wave_umin((bits == mx && bi != INT_MAX) ? (unsigned)bi : 0xFFFFFFFFu);
+    return mi == 0xFFFFFFFFu ? dflt : (int)mi;
 }
 
 // kiss_fft's radix-4 butterfly (kf_bfly4, forward): separately rounded products and sums in its order
@@ -655,15 +681,11 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                                 for (int u = 0; u < 32; u++) t_sum = t_sum + vv[u];
                             }
                         } else {
+                            // a batch cut short by the frame's end: groups of 32, 16, 8, 4, 2, 1 terms, each requested as a whole before its adds
                             int q = 0;
-                            for (; q + 16 <= nb; q += 16) {
-                                float vv[16];
-#pragma unroll
-                                for (int u = 0; u < 16; u++) vv[u] = pq[2 * (q + u)];
-#pragma unroll
-                                for (int u = 0; u < 16; u++) t_sum = t_sum + vv[u];
-                            }
-                            for (; q < nb; q++) t_sum = t_sum + pq[2 * q];
+#define FW_SUM_GROUP(n) if (nb - q >= (n)) { float vv[n]; _Pragma("unroll") for (int u = 0; u < (n); u++) vv[u] = pq[2 * (q + u)]; _Pragma("unroll") for (int u = 0; u < (n); u++) t_sum = t_sum + vv[u]; q += (n); }
+                            FW_SUM_GROUP(32) FW_SUM_GROUP(16) FW_SUM_GROUP(8) FW_SUM_GROUP(4) FW_SUM_GROUP(2) FW_SUM_GROUP(1)
+#undef FW_SUM_GROUP
                         }
                     }
                     FW_MARK(SPLIT ? 25 : -1);

@@ -163,12 +163,325 @@ void k_softin_rs41(const SoftinArgs a) {
     if (lane == 0) { st->mode = mode; st->inv = inv; st->body_done = body_done; st->carry_n = carry_n; st->mv = mv_hdr; st->hdr_bit = hdr_bit; st->bits_in = bits0 + (unsigned long long)nb; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// DFM09: dfm09mod --softin (dfm09mod.c:1604-1720) — 32 raw header symbols at 0.7, then two soft symbols per bit (s2 - s1), 8 frames of 280 bits per hit
+// (the first one starts behind its 16 header bits), de-interleave + Hamming(8,4) with the soft 2-bit pass of --ecc2 (:231-345) on a lane per codeword
+// ------------------------------------------------------------------------------------------------
+struct SoftinDfmChan {
+    int   mode, inv, dpos, dfrm, dhalf;
+    float ds1;
+    unsigned hdrcnt;
+    float hist[32];
+    float mv;
+    unsigned long long bits_in, hdr_bit;
+    unsigned char dhb[280];
+    float dsf[280];
+};
+// one 8-bit codeword (dfm09mod.c:240-307): 0 clean, j + 1 = bit j fixed, -1 uncorrectable (level 2: the codeword at distance 2 that correlates best with the soft bits)
+__device__ __forceinline__ void dfm_dev_codeword(int n, unsigned char *c) {
+    const unsigned char d0 = (n >> 3) & 1, d1 = (n >> 2) & 1, d2 = (n >> 1) & 1, d3 = n & 1;
+    c[0] = d0; c[1] = d1; c[2] = d2; c[3] = d3; c[4] = d1 ^ d2 ^ d3; c[5] = d0 ^ d2 ^ d3; c[6] = d0 ^ d1 ^ d3; c[7] = d0 ^ d1 ^ d2;
+}
+__device__ int dfm_dev_check(int level, unsigned char hb[8], const float sb[8]) {
+    const unsigned char Hm[4][8] = { {0,1,1,1,1,0,0,0}, {1,0,1,1,0,1,0,0}, {1,1,0,1,0,0,1,0}, {1,1,1,0,0,0,0,1} };
+    const unsigned char He[8] = { 0x7, 0xB, 0xD, 0xE, 0x8, 0x4, 0x2, 0x1 };
+    unsigned syn = 0;
+    for (int i = 0; i < 4; i++) { unsigned char s = 0; for (int j = 0; j < 8; j++) s ^= Hm[i][j] & hb[j]; syn = (syn << 1) | s; }
+    if (!syn) return 0;
+    for (int j = 0; j < 8; j++) if (syn == He[j]) { hb[j] ^= 1; return j + 1; }
+    if (level == 2) {
+        int best = -1; float bestsum = 0.0f;
+        for (int n = 0; n < 16; n++) {
+            unsigned char c[8]; int d = 0;
+            dfm_dev_codeword(n, c);
+            for (int i = 0; i < 8; i++) d += (hb[i] != c[i]);
+            if (d != 2) continue;
+            float sum = 0.0f;
+            for (int i = 0; i < 8; i++) sum += (2 * c[i] - 1) * sb[i];
+            if (sum >= bestsum) { bestsum = sum; best = n; }
+        }
+        if (best >= 0) dfm_dev_codeword(best, hb);
+    }
+    return -1;
+}
+
+struct SoftinDfmArgs {
+    SoftinArgs base;                       // sd / counts / n_ch / inv_in / opt_auto / ths / count / cap / hdr (32 raw header symbols)
+    SoftinDfmChan *chan;
+    sonde_dfm_frame_t *out;
+    int ecc_level;
+};
+
+__global__ __launch_bounds__(64)
+void k_softin_dfm(const SoftinDfmArgs A) {
+    const SoftinArgs &a = A.base;
+    __shared__ float s_hist[32];
+    __shared__ unsigned char s_hb[280];
+    __shared__ float s_sf[280];
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= a.n_ch) return;
+    SoftinDfmChan *st = A.chan + ch;
+    int nb = a.nbits;
+    if (a.fsk_chan) { const int fr = a.fsk_chan[ch].frames; nb = fr > 0 ? fr * a.bits_per_frame : 0; }
+    const float *x = a.sd + (size_t)ch * a.ch_stride;
+    int mode = st->mode, inv = st->inv, dpos = st->dpos, dfrm = st->dfrm, dhalf = st->dhalf;
+    float ds1 = st->ds1, mv_hdr = st->mv; unsigned hdrcnt = st->hdrcnt; unsigned long long hdr_bit = st->hdr_bit; const unsigned long long bits0 = st->bits_in;
+    if (lane < 32) s_hist[lane] = st->hist[lane];
+    for (int i = lane; i < 280; i += 64) { s_hb[i] = st->dhb[i]; s_sf[i] = st->dsf[i]; }
+    __builtin_amdgcn_wave_barrier();
+    const float sgn = a.inv_in ? -1.f : 1.f;
+    int cur = 0;
+    while (cur < nb) {
+        if (mode == 0) {
+            bool found = false;
+            for (int base = cur; base < nb && !found; base += 64) {
+                const int q = base + lane;
+                float mv = 0.f;
+                if (q < nb) {
+                    double sum = 0.0, normx = 0.0;
+                    const int e = 32 + (q - cur);
+                    for (int i = 0; i < 32; i++) {
+                        const int k = e - 31 + i;
+                        const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                        const float y = (a.hdr[i] & 1) ? 1.f : -1.f;
+                        sum += (double)(y * v);
+                        normx += (double)(v * v);
+                    }
+                    sum /= sqrt(normx * 32.0);
+                    mv = (float)sum;
+                }
+                unsigned long long hits = __ballot(q < nb && fabsf(mv) > a.ths);
+                while (hits) {
+                    const int l = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const float mvl = __shfl(mv, l);
+                    hdrcnt += 8;                                        // every header seen counts (dfm09mod.c:1628,1632), accepted or not
+                    if ((double)mvl * (0.5 - inv) < 0) { if (!a.opt_auto) continue; inv ^= 1; }
+                    found = true;
+                    const int qs = base + l, e = 32 + (qs - cur), k = e - 31 + (lane & 31);
+                    const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 32) s_hist[lane] = v;
+                    __builtin_amdgcn_wave_barrier();
+                    mode = 1; dpos = 16; dfrm = 0; dhalf = 0; mv_hdr = mvl; hdr_bit = bits0 + (unsigned long long)qs + 1ull;
+                    cur = qs + 1;
+                    break;
+                }
+            }
+            if (!found) {
+                const int e = 32 + (nb - 1 - cur), k = e - 31 + (lane & 31);
+                const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) s_hist[lane] = v;
+                __builtin_amdgcn_wave_barrier();
+                cur = nb;
+            }
+        } else {
+            // ---- frame bits: two symbols each (the first of a pair may be left over from the last call)
+            const int need = 280 - dpos, take = min(nb - cur, 2 * need - dhalf), nbits = (dhalf + take) / 2;
+            for (int j = lane; j < nbits; j += 64) {
+                const float s1 = (j == 0 && dhalf) ? ds1 : sgn * x[cur + 2 * j - dhalf], s2 = sgn * x[cur + 2 * j + 1 - dhalf];
+                float v = s2 - s1;                                      // integrate both Manchester symbols (dfm09mod.c:1684)
+                int hb = v >= 0.0f;
+                if (inv) { hb ^= 1; v = -v; }
+                s_hb[dpos + j] = (unsigned char)hb; s_sf[dpos + j] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((dhalf + take) & 1) { ds1 = sgn * x[cur + take - 1]; dhalf = 1; } else dhalf = 0;
+            dpos += nbits; cur += take;
+            if (dpos == 280) {
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(a.count, 1u);
+                slot = __shfl(slot, 0);
+                // de-interleave + Hamming: lanes 0..6 conf (block at bit 16, 7 codewords), 7..19 dat1 (72, 13), 20..32 dat2 (176, 13)
+                int e = 0; unsigned char nib = 0;
+                const int blk = lane < 7 ? 0 : lane < 20 ? 1 : 2, i = lane < 7 ? lane : lane < 20 ? lane - 7 : lane - 20;
+                const int L = blk == 0 ? 7 : 13, off = blk == 0 ? 16 : blk == 1 ? 72 : 176;
+                if (lane < 33) {
+                    unsigned char c[8]; float sb[8];
+                    for (int j = 0; j < 8; j++) { c[j] = s_hb[off + L * j + i]; sb[j] = s_sf[off + L * j + i]; }
+                    if (A.ecc_level) e = dfm_dev_check(A.ecc_level, c, sb);
+                    nib = (unsigned char)((c[0] << 3) | (c[1] << 2) | (c[2] << 1) | c[3]);
+                }
+                const unsigned long long fixed = __ballot(lane < 33 && e > 0), bad = __ballot(lane < 33 && e < 0);
+                if ((int)slot < a.cap) {
+                    sonde_dfm_frame_t *o = A.out + slot;
+                    if (lane < 7) o->conf[i] = nib; else if (lane < 20) o->dat1[i] = nib; else if (lane < 33) o->dat2[i] = nib;
+                    if (lane < 35) { unsigned char rb = 0; for (int b = 0; b < 8; b++) rb |= (unsigned char)((s_hb[8 * lane + b] & 1) << b); o->rawbits[lane] = rb; }
+                    if (lane == 0) {
+                        o->channel = ch; o->frame_in_hit = dfrm; o->mv = mv_hdr; o->mv_pos = (uint32_t)hdr_bit;
+                        o->frm_count = (float)(hdrcnt + (unsigned)dfrm); o->inv = inv; o->pad[0] = o->pad[1] = o->pad[2] = 0; o->pad2 = 0;
+                        // hamming()'s return per block: a bit per fixed codeword, or'ed with -1 for an uncorrectable one
+                        o->ecc[0] = ((bad & 0x7Full) ? -1 : 0) | (int)(fixed & 0x7Full);
+                        o->ecc[1] = (((bad >> 7) & 0x1FFFull) ? -1 : 0) | (int)((fixed >> 7) & 0x1FFFull);
+                        o->ecc[2] = (((bad >> 20) & 0x1FFFull) ? -1 : 0) | (int)((fixed >> 20) & 0x1FFFull);
+                    }
+                }
+                dpos = 0;
+                if (++dfrm == 8) mode = 0;                              // nfrms frames per header hit, then search again (:1656,1718)
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) st->hist[lane] = s_hist[lane];
+    for (int i = lane; i < 280; i += 64) { st->dhb[i] = s_hb[i]; st->dsf[i] = s_sf[i]; }
+    if (lane == 0) { st->mode = mode; st->inv = inv; st->dpos = dpos; st->dfrm = dfrm; st->dhalf = dhalf; st->ds1 = ds1; st->hdrcnt = hdrcnt; st->mv = mv_hdr; st->hdr_bit = hdr_bit; st->bits_in = bits0 + (unsigned long long)nb; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// M10: m10mod --softin (m10mod.c:1405-1510) — 32 raw header symbols at 0.8 in either polarity, two soft symbols per bit (s2 - s1), differential decoding,
+// 968 bits, then one symbol per counted bit dropped up to 5 x 808; the frame checksum (m10mod.c:594-628) on the device
+// ------------------------------------------------------------------------------------------------
+struct SoftinM10Chan {
+    int   mode, inv, mpos, mhalf, mbit0, mskip;
+    float ms1;
+    float hist[32];
+    float mv;
+    unsigned long long bits_in, hdr_bit;
+    char  mbits[976];
+};
+struct SoftinM10Args { SoftinArgs base; SoftinM10Chan *chan; sonde_m10_frame_t *out; };
+
+__global__ __launch_bounds__(64)
+void k_softin_m10(const SoftinM10Args A) {
+    const SoftinArgs &a = A.base;
+    __shared__ float s_hist[32];
+    __shared__ char s_mb[976];
+    __shared__ unsigned char s_fr[124];
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= a.n_ch) return;
+    SoftinM10Chan *st = A.chan + ch;
+    int nb = a.nbits;
+    if (a.fsk_chan) { const int fr = a.fsk_chan[ch].frames; nb = fr > 0 ? fr * a.bits_per_frame : 0; }
+    const float *x = a.sd + (size_t)ch * a.ch_stride;
+    constexpr int NBITS = 121 * 8;
+    int mode = st->mode, inv = st->inv, mpos = st->mpos, mhalf = st->mhalf, mbit0 = st->mbit0, mskip = st->mskip;
+    float ms1 = st->ms1, mv_hdr = st->mv; unsigned long long hdr_bit = st->hdr_bit; const unsigned long long bits0 = st->bits_in;
+    if (lane < 32) s_hist[lane] = st->hist[lane];
+    for (int i = lane; i < 976; i += 64) s_mb[i] = st->mbits[i];
+    __builtin_amdgcn_wave_barrier();
+    const float sgn = a.inv_in ? -1.f : 1.f;
+    int cur = 0;
+    while (cur < nb) {
+        if (mode == 0) {
+            bool found = false;
+            for (int base = cur; base < nb && !found; base += 64) {
+                const int q = base + lane;
+                float mv = 0.f;
+                if (q < nb) {
+                    double sum = 0.0, normx = 0.0;
+                    const int e = 32 + (q - cur);
+                    for (int i = 0; i < 32; i++) {
+                        const int k = e - 31 + i;
+                        const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                        const float y = (a.hdr[i] & 1) ? 1.f : -1.f;
+                        sum += (double)(y * v);
+                        normx += (double)(v * v);
+                    }
+                    sum /= sqrt(normx * 32.0);
+                    mv = (float)sum;
+                }
+                const unsigned long long hits = __ballot(q < nb && fabsf(mv) > a.ths);
+                if (hits) {
+                    const int l = __builtin_ctzll(hits);
+                    const float mvl = __shfl(mv, l);
+                    if ((double)mvl * (0.5 - inv) < 0) inv ^= 1;            // irrelevant for the differential code (m10mod.c:1447)
+                    found = true;
+                    const int qs = base + l, e = 32 + (qs - cur), k = e - 31 + (lane & 31);
+                    const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 32) s_hist[lane] = v;
+                    __builtin_amdgcn_wave_barrier();
+                    mode = 1; mpos = 0; mhalf = 0; mbit0 = '0'; mv_hdr = mvl; hdr_bit = bits0 + (unsigned long long)qs + 1ull;
+                    cur = qs + 1;
+                }
+            }
+            if (!found) {
+                const int e = 32 + (nb - 1 - cur), k = e - 31 + (lane & 31);
+                const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 32) s_hist[lane] = v;
+                __builtin_amdgcn_wave_barrier();
+                cur = nb;
+            }
+        } else if (mode == 1) {
+            const int need = NBITS - mpos, take = min(nb - cur, 2 * need - mhalf), nbits = (mhalf + take) / 2;
+            // bit j of this call and the one before it (the differential code): out = 0x31 ^ (previous ^ bit); the previous of the frame's first bit is '0' (0x30),
+            // which leaves that character outside '0' / '1' — the reference's own quirk, kept
+            int last_bit = mbit0;
+            for (int j0 = 0; j0 < nbits; j0 += 64) {
+                const int j = j0 + lane;
+                int bit = 0, prev = 0;
+                if (j < nbits) {
+                    const float s1 = (j == 0 && mhalf) ? ms1 : sgn * x[cur + 2 * j - mhalf], s2 = sgn * x[cur + 2 * j + 1 - mhalf];
+                    bit = (s2 - s1) >= 0.0f;
+                }
+                prev = __shfl_up(bit, 1);
+                if (lane == 0) prev = last_bit;
+                if (j < nbits) s_mb[mpos + j] = (char)(0x31 ^ (prev ^ bit));
+                const int cnt = min(64, nbits - j0);
+                last_bit = __shfl(bit, cnt - 1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (nbits > 0) mbit0 = last_bit;
+            if ((mhalf + take) & 1) { ms1 = sgn * x[cur + take - 1]; mhalf = 1; } else mhalf = 0;
+            mpos += nbits; cur += take;
+            if (mpos == NBITS) {
+                unsigned slot = 0;
+                if (lane == 0) slot = atomicAdd(a.count, 1u);
+                slot = __shfl(slot, 0);
+                for (int i = lane; i < 124; i += 64) {
+                    unsigned v = 0;
+                    if (i < 121) for (int k = 0; k < 8; k++) if (s_mb[8 * i + 7 - k] == '1') v |= 1u << k;
+                    s_fr[i] = (unsigned char)v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if ((int)slot < a.cap) {
+                    sonde_m10_frame_t *o = A.out + slot;
+                    for (int i = lane; i < 124; i += 64) o->frame[i] = s_fr[i];
+                    if (lane == 0) {
+                        int aux = s_fr[0] - 0x64;
+                        if (aux < 0 || aux > 20) aux = 0;
+                        int c = 0;
+                        for (int i = 0; i < 99 + aux; i++) {                 // checkM10 (m10mod.c:594-628)
+                            unsigned char b = s_fr[i];
+                            b = (unsigned char)((b >> 1) | ((b & 1) << 7));
+                            b ^= (b >> 2) & 0xFF;
+                            const int t6 = (c & 1) ^ ((c >> 2) & 1) ^ ((c >> 4) & 1), t7 = ((c >> 1) & 1) ^ ((c >> 3) & 1) ^ ((c >> 5) & 1);
+                            const int t = (c & 0x3F) | (t6 << 6) | (t7 << 7);
+                            int sreg = (c >> 7) & 0xFF;
+                            sreg ^= (sreg >> 2) & 0xFF;
+                            c = (((c & 0xFF) << 8) | ((b ^ t ^ sreg) & 0xFF)) & 0xFFFF;
+                        }
+                        o->channel = ch; o->nbits = NBITS; o->len = 101 + aux; o->cs_calc = (uint32_t)c;
+                        o->cs_ok = ((uint32_t)((s_fr[99 + aux] << 8) | s_fr[100 + aux]) == (uint32_t)c);
+                        o->mv = mv_hdr; o->mv_pos = (uint32_t)hdr_bit;
+                    }
+                }
+                mode = 2; mskip = NBITS;
+            }
+        } else {
+            // the rest of the second: one symbol per counted bit up to 5 x 808 (m10mod.c:1494-1506)
+            const int take = min(nb - cur, 5 * 808 - mskip);
+            mskip += take; cur += take;
+            if (mskip >= 5 * 808) mode = 0;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) st->hist[lane] = s_hist[lane];
+    for (int i = lane; i < 976; i += 64) st->mbits[i] = s_mb[i];
+    if (lane == 0) { st->mode = mode; st->inv = inv; st->mpos = mpos; st->mhalf = mhalf; st->mbit0 = mbit0; st->mskip = mskip; st->ms1 = ms1; st->mv = mv_hdr; st->hdr_bit = hdr_bit; st->bits_in = bits0 + (unsigned long long)nb; }
+}
+
 extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *flen, const unsigned *count, int cap, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                               const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
 extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream);
 
 struct sonde_softin_dev {
-    int C = 0, ecc_level = 0, cap = 0;
+    int C = 0, ecc_level = 0, cap = 0, type = SONDE_RS41;
+    SoftinDfmChan *d_dfm_chan = nullptr; sonde_dfm_frame_t *d_dfm_out = nullptr; std::vector<sonde_dfm_frame_t> qdfm, h_dfm;
+    SoftinM10Chan *d_m10_chan = nullptr; sonde_m10_frame_t *d_m10_out = nullptr; std::vector<sonde_m10_frame_t> qm10, h_m10;
     SoftinArgs args{};
     hipStream_t stream = nullptr; bool own_stream = false;
     SoftinChan *d_chan = nullptr; unsigned char *d_frames = nullptr, *d_hdr = nullptr, *d_gf = nullptr, *d_synd = nullptr;
@@ -181,17 +494,21 @@ struct sonde_softin_dev {
 extern "C" {
 
 int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_level, int32_t invert_stream, int32_t opt_inv, int32_t opt_auto, sonde_softin_dev_t **out) {
-    if (!out || n_channels < 1 || sonde_type != SONDE_RS41 || ecc_level < 0 || ecc_level > 2) return SONDE_E_ARG;
+    if (!out || n_channels < 1 || (sonde_type != SONDE_RS41 && sonde_type != SONDE_DFM09 && sonde_type != SONDE_M10) || ecc_level < 0 || ecc_level > 2) return SONDE_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "libsonde_hip: no usable HIP device (the batched soft-bit framer has no CPU fallback)\n"); return SONDE_E_NOGPU; }
     sonde_softin_dev *s = new sonde_softin_dev();
-    s->C = n_channels; s->ecc_level = ecc_level; s->cap = 2 * n_channels + 16;          // a call of one second completes at most two frames per channel
+    s->C = n_channels; s->ecc_level = ecc_level; s->type = sonde_type;
+    // frames a call of about a second can complete per channel: RS41 two, DFM09 six (280 bits at 1250 b/s), M10 two (one per second; the rest of the second is skipped)
+    s->cap = (sonde_type == SONDE_DFM09 ? 8 : 2) * n_channels + 16;
     const size_t C = (size_t)n_channels, cap = (size_t)s->cap;
     std::vector<SoftinChan> init(C);
     memset(init.data(), 0, C * sizeof(SoftinChan));
     for (auto &c : init) { c.inv = opt_inv ? 1 : 0; memcpy(c.frame, sonde::kRs41HeaderBytes, 8); }
     unsigned char hdr[136];
-    memcpy(hdr, sonde::kRs41Header, 64); memcpy(hdr + 64, sonde::kRs41HeaderBytes, 8); memcpy(hdr + 72, sonde::kRs41Mask, 64);
+    memset(hdr, 0, sizeof hdr);
+    if (sonde_type == SONDE_RS41) { memcpy(hdr, sonde::kRs41Header, 64); memcpy(hdr + 64, sonde::kRs41HeaderBytes, 8); memcpy(hdr + 72, sonde::kRs41Mask, 64); }
+    else memcpy(hdr, sonde_type == SONDE_DFM09 ? sonde::kDfmRawHeader : sonde::kM10RawHeader, 32);
     bool ok = hipMalloc((void **)&s->d_chan, C * sizeof(SoftinChan)) == hipSuccess && hipMalloc((void **)&s->d_frames, cap * 518) == hipSuccess
            && hipMalloc((void **)&s->d_hdr, sizeof hdr) == hipSuccess && hipMalloc((void **)&s->d_gf, 768) == hipSuccess && hipMalloc((void **)&s->d_synd, cap * 48) == hipSuccess
            && hipMalloc((void **)&s->d_flen, cap * 4) == hipSuccess && hipMalloc((void **)&s->d_ecc, cap * 4) == hipSuccess && hipMalloc((void **)&s->d_codes, cap * 8) == hipSuccess
@@ -199,9 +516,26 @@ int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_
     ok = ok && hipMemcpy(s->d_chan, init.data(), C * sizeof(SoftinChan), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice) == hipSuccess
             && hipMemcpy(s->d_gf, sonde::gf_exp_table(), 512, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->d_gf + 512, sonde::gf_log_table(), 256, hipMemcpyHostToDevice) == hipSuccess
             && hipMemset(s->d_ecc, 0, cap * 4) == hipSuccess;
+    if (ok && sonde_type == SONDE_DFM09) {
+        std::vector<SoftinDfmChan> di(C);
+        memset(di.data(), 0, C * sizeof(SoftinDfmChan));
+        static const char kDfmHdr[] = "0100010111001111";                                 // dfm09mod.c:1503-1506: the header's 16 bits in front of the first frame of a hit
+        for (auto &c : di) { c.inv = opt_inv ? 1 : 0; c.dpos = 16; for (int i = 0; i < 16; i++) c.dhb[i] = (unsigned char)(kDfmHdr[i] & 1); }
+        ok = hipMalloc((void **)&s->d_dfm_chan, C * sizeof(SoftinDfmChan)) == hipSuccess && hipMalloc((void **)&s->d_dfm_out, cap * sizeof(sonde_dfm_frame_t)) == hipSuccess
+          && hipMemcpy(s->d_dfm_chan, di.data(), C * sizeof(SoftinDfmChan), hipMemcpyHostToDevice) == hipSuccess;
+        s->h_dfm.resize(cap);
+    }
+    if (ok && sonde_type == SONDE_M10) {
+        std::vector<SoftinM10Chan> mi(C);
+        memset(mi.data(), 0, C * sizeof(SoftinM10Chan));
+        for (auto &c : mi) { c.inv = opt_inv ? 1 : 0; c.mbit0 = '0'; }
+        ok = hipMalloc((void **)&s->d_m10_chan, C * sizeof(SoftinM10Chan)) == hipSuccess && hipMalloc((void **)&s->d_m10_out, cap * sizeof(sonde_m10_frame_t)) == hipSuccess
+          && hipMemcpy(s->d_m10_chan, mi.data(), C * sizeof(SoftinM10Chan), hipMemcpyHostToDevice) == hipSuccess;
+        s->h_m10.resize(cap);
+    }
     if (!ok) { sonde_softin_dev_destroy(s); return SONDE_E_NOMEM; }
     SoftinArgs &a = s->args;
-    a.n_ch = n_channels; a.inv_in = invert_stream ? 1 : 0; a.opt_auto = opt_auto ? 1 : 0; a.ths = 0.7f;
+    a.n_ch = n_channels; a.inv_in = invert_stream ? 1 : 0; a.opt_auto = opt_auto ? 1 : 0; a.ths = sonde_type == SONDE_M10 ? 0.8f : 0.7f;
     a.chan = s->d_chan; a.frames = s->d_frames; a.flen = s->d_flen; a.meta = s->d_meta; a.count = s->d_count; a.cap = s->cap; a.hdr = s->d_hdr;
     s->h_flen.resize(cap); s->h_ecc.resize(cap); s->h_meta.resize(cap); s->h_frames.resize(cap * 518);
     *out = s;
@@ -211,7 +545,7 @@ int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_
 void sonde_softin_dev_destroy(sonde_softin_dev_t *s) {
     if (!s) return;
     if (s->own_stream && s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
-    void *p[] = { s->d_chan, s->d_frames, s->d_hdr, s->d_gf, s->d_synd, s->d_flen, s->d_ecc, s->d_codes, s->d_meta, s->d_count };
+    void *p[] = { s->d_chan, s->d_frames, s->d_hdr, s->d_gf, s->d_synd, s->d_flen, s->d_ecc, s->d_codes, s->d_meta, s->d_count, s->d_dfm_chan, s->d_dfm_out, s->d_m10_chan, s->d_m10_out };
     for (void *q : p) if (q) hipFree(q);
     delete s;
 }
@@ -220,6 +554,33 @@ void sonde_softin_dev_destroy(sonde_softin_dev_t *s) {
 static int softin_run(sonde_softin_dev *s, hipStream_t st) {
     SoftinArgs &a = s->args;
     HIPCHK(hipMemsetAsync(s->d_count, 0, 4, st));
+    if (s->type != SONDE_RS41) {
+        if (s->type == SONDE_DFM09) { SoftinDfmArgs d{a, s->d_dfm_chan, s->d_dfm_out, s->ecc_level}; hipLaunchKernelGGL(k_softin_dfm, dim3(s->C), dim3(64), 0, st, d); }
+        else { SoftinM10Args m{a, s->d_m10_chan, s->d_m10_out}; hipLaunchKernelGGL(k_softin_m10, dim3(s->C), dim3(64), 0, st, m); }
+        HIPCHK(hipGetLastError());
+        unsigned n = 0;
+        HIPCHK(hipMemcpyAsync(&n, s->d_count, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if ((int)n > s->cap) { s->dropped += (long long)n - s->cap; n = (unsigned)s->cap; }
+        if (n == 0) return 0;
+        if (s->type == SONDE_DFM09) {
+            HIPCHK(hipMemcpyAsync(s->h_dfm.data(), s->d_dfm_out, (size_t)n * sizeof(sonde_dfm_frame_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            // (frames of one channel in order: the slots of a call are handed out in completion order per channel, channels interleave)
+            for (unsigned i = 0; i < n; i++) {
+                const sonde_dfm_frame_t &f = s->h_dfm[i];
+                s->qdfm.push_back(f); s->frames_total++;
+                const bool okf = f.ecc[0] >= 0 && f.ecc[1] >= 0 && f.ecc[2] >= 0;
+                if (okf) s->ecc_ok_total++;
+                if (okf && (f.ecc[0] > 0 || f.ecc[1] > 0 || f.ecc[2] > 0)) { s->repaired_total++; s->symbols_total += __builtin_popcount((unsigned)f.ecc[0]) + __builtin_popcount((unsigned)f.ecc[1]) + __builtin_popcount((unsigned)f.ecc[2]); }
+            }
+        } else {
+            HIPCHK(hipMemcpyAsync(s->h_m10.data(), s->d_m10_out, (size_t)n * sizeof(sonde_m10_frame_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (unsigned i = 0; i < n; i++) { s->qm10.push_back(s->h_m10[i]); s->frames_total++; if (s->h_m10[i].cs_ok) s->ecc_ok_total++; }
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(k_softin_rs41, dim3(s->C), dim3(64), 0, st, a);
     if (s->ecc_level > 0)
         sonde_launch_rs41_ecc_batch_n(s->d_frames, s->d_flen, s->d_count, s->cap, s->ecc_level, s->d_ecc, s->d_codes, s->d_synd, s->d_gf, s->d_gf + 512, st);
@@ -271,6 +632,22 @@ int sonde_softin_dev_fetch(sonde_softin_dev_t *s, sonde_frame_t *out, int32_t ma
     const int n = (int)std::min<size_t>(s->queue.size(), (size_t)(max < 0 ? 0 : max));
     for (int i = 0; i < n; i++) out[i] = s->queue[i];
     s->queue.erase(s->queue.begin(), s->queue.begin() + n);
+    return n;
+}
+
+int sonde_softin_dev_fetch_dfm(sonde_softin_dev_t *s, sonde_dfm_frame_t *out, int32_t max) {
+    if (!s || (!out && max > 0)) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->qdfm.size(), (size_t)(max < 0 ? 0 : max));
+    for (int i = 0; i < n; i++) out[i] = s->qdfm[i];
+    s->qdfm.erase(s->qdfm.begin(), s->qdfm.begin() + n);
+    return n;
+}
+
+int sonde_softin_dev_fetch_m10(sonde_softin_dev_t *s, sonde_m10_frame_t *out, int32_t max) {
+    if (!s || (!out && max > 0)) return SONDE_E_ARG;
+    const int n = (int)std::min<size_t>(s->qm10.size(), (size_t)(max < 0 ? 0 : max));
+    for (int i = 0; i < n; i++) out[i] = s->qm10[i];
+    s->qm10.erase(s->qm10.begin(), s->qm10.begin() + n);
     return n;
 }
 

@@ -155,3 +155,37 @@ def test_version_gate_rejects_a_decoder_of_another_version(autorx, sides, monkey
     for out in (ours_out, ref_out):
         sink, rets, d = _telemetry(autorx, monkeypatch, sides["ours"][name + ".stderr"], out, typ)
         assert sink == [] and False in rets and d.exit_state == "Decoder Version Mismatch" and d.decoder_running is False
+
+
+def test_batch_scanner_binding_equals_auto_rx_scanning_the_peaks_one_by_one(autorx, sides, monkeypatch, tmp_path):
+    """§8f-3: auto_rx's OWN scan_peaks_concurrent (autorx/scan_async.py:298-378: one `dft_detect --iq` process per peak on a 48 kHz channel of the band —
+    here cut out of the band by the reference's own iq_dec, the role the KA9Q server plays) against radiosonde_auto_rx_amd/scan_batch.py on the output of
+    ONE batch process `dft_detect --IQ fq1,fq2,fq3,fq4` over the same band (recorded on the MI355X: tests/golden/cli_ours.npz `batch_band`, kept honest by
+    tests/test_gpu_cli_recorded.py), every channel's lines parsed by auto_rx's own parse_dft_detect_output: the same [(frequency, type)] list."""
+    import asyncio
+    import autorx.scan_async as sa
+    import autorx.sdr_wrappers as sw
+    from tools import caller_cases as cc
+    from radiosonde_auto_rx_amd import scan_batch as sb
+    band = tmp_path / "band.cs16"
+    band.write_bytes(cc.capture("band").tobytes())
+
+    def iq_cmd(sdr_type=None, frequency=None, sample_rate=None, **kw):          # get_sdr_iq_cmd: "a pipeline that ends in | and delivers cs16 IQ of that channel"
+        fq = (float(frequency) - cc.BATCH_CENTER) / cc.BATCH_SR
+        assert sample_rate == 48000
+        return "cat %s | %s --bo 16 --iq %.9f - %d 16 2>/dev/null |" % (band, os.path.join(REF, "iq_dec"), fq, cc.BATCH_SR)
+    monkeypatch.setattr(sw, "get_sdr_iq_cmd", iq_cmd)
+    monkeypatch.setattr(sw, "get_sdr_name", lambda *a, **k: "test")
+    monkeypatch.setattr(sw, "shutdown_sdr", lambda *a, **k: None)
+    ref = asyncio.run(sa.scan_peaks_concurrent(cc.BATCH_PEAKS, max_concurrent=2, rs_path=REF + "/", dwell_time=cc.BATCH_DWELL, sdr_type="KA9Q"))
+
+    async def recorded(cmd):                                                     # the one batch process, as it ran on the GPU
+        assert "--IQ " + cc.BATCH["batch_band"][1][3] in cmd and "-t %d" % cc.BATCH_DWELL in cmd
+        return sides["ours"]["batch_band.stdout"], sides["ours"]["batch_band.rc"]
+    ours = asyncio.run(sb.scan_peaks_batch(cc.BATCH_PEAKS, center_frequency=cc.BATCH_CENTER, sample_rate=cc.BATCH_SR, iq_cmd="cat %s |" % band,
+                                           rs_path=BIN, dwell_time=cc.BATCH_DWELL, parse=autorx.scan.parse_dft_detect_output, sdr_name="test", run=recorded))
+    assert sorted(ours) == sorted(ref) and len(ref) == 3
+    assert {t for _, t in ref} == {"RS41", "DFM", "M10"}
+    # and the synchronous wrapper (the counterpart of run_async_scan) on the same recording
+    assert sorted(sb.run_batch_scan(cc.BATCH_PEAKS, center_frequency=cc.BATCH_CENTER, sample_rate=cc.BATCH_SR, iq_cmd="cat %s |" % band, rs_path=BIN,
+                                    dwell_time=cc.BATCH_DWELL, parse=autorx.scan.parse_dft_detect_output, run=recorded)) == sorted(ref)

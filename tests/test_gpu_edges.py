@@ -117,6 +117,37 @@ def test_two_stream_pipeline_matches_single_stream():
         Engine([0.0], 48000, audio=True, pipeline=True)
 
 
+def test_lagged_fetch_behind_a_long_running_decoder_sees_only_its_own_calls_frames():
+    """Many channels, every frame damaged (the Reed-Solomon decoder on stream E takes its time), two streams, every fetch one call late, calls short enough that the
+    next call's frame sync runs while the decoder of this one is still busy: what a call publishes is the frame counter as ITS last frame sync left it (taken on the
+    frame sync's stream), not the live counter behind the decoder — which may already include slots the next call has counted but not written.
+    The lagged run must deliver the frames of the plain run: same records, nothing stale, nothing skipped."""
+    from radiosonde_auto_rx_amd.engine import Engine
+    from tools import synth
+    sr = 480_000
+    C = 48
+    fqs = [synth.snap_fq(0.004 * (k - C / 2), sr) for k in range(C)]
+    caps = [synth.rs41_capture(sr=sr, seconds=2.4, fq=fq, seed=300 + k, noise_sigma=0.03, bit_errors=18 + (k % 7), t_first=0.05 + 0.013 * (k % 9)) for k, fq in enumerate(fqs)]
+    n = min(len(c) for c in caps) // 2 // 10 * 10
+    xb = np.stack([c[:2 * n] for c in caps])
+    out = {}
+    for pipe in (False, True):
+        eng = Engine(fqs, sr, ecc=2, max_chunk=48_000, keep_soft=False, pipeline=pipe, max_frames=8 * C)
+        frames = []
+        for pos in range(0, n, 48_000):
+            take = min(48_000, n - pos)
+            eng.process_host(np.ascontiguousarray(xb[:, 2 * pos:2 * (pos + take)]))
+            fr = eng.fetch_frames_np(lag=1 if pipe else 0)
+            frames += [(int(f["channel"]), int(f["mv_pos"]), int(f["ecc"]), bytes(f["frame"])) for f in fr]
+        fr = eng.fetch_frames_np(lag=0)
+        frames += [(int(f["channel"]), int(f["mv_pos"]), int(f["ecc"]), bytes(f["frame"])) for f in fr]
+        assert eng.host_ecc_frames() == 0
+        out[pipe] = sorted(frames)
+        eng.close()
+    assert len(out[False]) >= C and out[True] == out[False]
+    assert sum(1 for f in out[False] if f[2] > 0) >= C // 2                 # the decoder had work
+
+
 def test_long_chunk_is_fully_consumed():
     """A call much longer than 64 correlation windows (K - 4 = 7508 IF samples each): the frame sync keeps going until the samples
     are used up — all frames of a 12 s capture come out of ONE call."""

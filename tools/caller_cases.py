@@ -52,6 +52,9 @@ def capture(name):
                                  frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(900 + k)))
     if name == "m10_48":
         return synth.m10_capture(sr=48000, seconds=4.0, fq=0.0, noise_sigma=0.02, seed=46)
+    if name == "band":
+        sig = [dict(kind=k, fq=(f - BATCH_CENTER) / BATCH_SR, t_first=0.15 + 0.1 * i, amp=0.06) for i, (k, f) in enumerate(BATCH_TRUE)]
+        return synth.wideband_capture(BATCH_SR, 3.6, sig, noise_sigma=0.01, seed=48)
     if name == "noise":
         rng = np.random.default_rng(47)
         return np.clip(np.round(rng.standard_normal(2 * 48000 * 3) * 900), -32768, 32767).astype(np.int16)
@@ -64,6 +67,11 @@ DETECT = {  # case -> (capture, argv behind the binary's name)
     "detect_m10": ("m10_48", ["-t", "10", "--iq", "--bw", "15", "--dc", "-", "48000", "16"]),
     "detect_noise": ("noise", ["-t", "2", "--iq", "--bw", "15", "--dc", "-", "48000", "16"]),
 }
+# one band, several sondes: the batch form `dft_detect --IQ fq1,fq2,...` (radiosonde_auto_rx_amd/scan_batch.py) against auto_rx's per-peak scan
+BATCH_SR, BATCH_CENTER, BATCH_DWELL = 960_000, 403_000_000, 4
+BATCH_PEAKS = [403_120_000, 402_800_000, 403_310_000, 402_950_000]        # what the spectrum peak search hands to the detector (the last one is empty)
+BATCH_TRUE = [("rs41", 403_120_300), ("dfm", 402_799_600), ("m10", 403_310_450)]        # where the sondes really are (a few hundred Hz off their peaks)
+BATCH = {"batch_band": ("band", ["-t", str(BATCH_DWELL), "--IQ", ",".join("%.9f" % ((f - BATCH_CENTER) / BATCH_SR) for f in BATCH_PEAKS), "--bw", "15", "--dc", "-", str(BATCH_SR), "16"])}
 FSK = {     # case -> (capture, fsk_demod argv, decoder binary, decoder argv, auto_rx sonde type)
     "fsk_rs41": ("rs41", ["--cs16", "-b", "-5000", "-u", "5000", "-s", "--mask", "5000", "--nsym=300", "-p", "5", "--stats=5", "2", "48000", "4800", "-", "-"],
                  "rs41mod", ["--ptu2", "--json", "--jsnsubfrm1", "--softin", "-i"], "RS41"),

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round profile refresh, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh [tag]   (default tag r4)
+# Round profile refresh, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh [tag]   (default tag r5)
 #   demod     bench line as the driver runs it; rocprofv3 --kernel-trace --stats of the same command; FETCH_SIZE / WRITE_SIZE and SQ
 #             counter passes (separate, kernel trace + PMC only) -> traffic json of the dominant kernel
 #   scan_wide, fsk_mixed   bench line + kernel trace each
 # everything lands in gpurun_out/prof/ as <tag>_*; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"

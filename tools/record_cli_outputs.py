@@ -23,6 +23,9 @@ def run_all(bindir=BIN, env_extra=None):
     for name, (cap, argv) in cc.DETECT.items():
         r = subprocess.run([os.path.join(bindir, "dft_detect")] + argv, input=cc.capture(cap).tobytes(), capture_output=True, env=env, timeout=300)
         out[name + ".stdout"], out[name + ".stderr"], out[name + ".rc"] = r.stdout, r.stderr, r.returncode
+    for name, (cap, argv) in cc.BATCH.items():
+        r = subprocess.run([os.path.join(bindir, "dft_detect")] + argv, input=cc.capture(cap).tobytes(), capture_output=True, env=env, timeout=300)
+        out[name + ".stdout"], out[name + ".stderr"], out[name + ".rc"] = r.stdout, r.stderr, r.returncode
     for name, (cap, fargv, _dec, _dargv, _typ) in cc.FSK.items():
         r = subprocess.run([os.path.join(bindir, "fsk_demod")] + fargv, input=cc.capture(cap).tobytes(), capture_output=True, env=env, timeout=300)
         out[name + ".stdout"], out[name + ".stderr"], out[name + ".rc"] = r.stdout, r.stderr, r.returncode
