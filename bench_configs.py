@@ -172,7 +172,7 @@ def bench_fsk_mixed(args, D, short=False):
         return ["--cs16", "-b", str(-lim), "-u", str(lim), "-s"] + (["--mask", str(mask)] if mask else []) + ["--nsym=%d" % nsym, "-p", str(P)]
     engines = []
     total_samples = 0
-    softin, rs41_caps = None, None
+    consumers = {}
     for gi, (kind, Fs, Rs, P, nsym, mask, lim) in enumerate(groups):
         n = C // 3 + (1 if gi < C % 3 else 0)
         caps = []
@@ -183,16 +183,19 @@ def bench_fsk_mixed(args, D, short=False):
             elif kind == "dfm":
                 caps.append(synth.dfm_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=10 + s))
             else:
-                caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=20 + s, baud=float(Rs), dev_hz=Rs / 2.0))     # tones Rs apart, as fsk_demod's estimator assumes
+                caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=20 + s, baud=float(Rs), dev_hz=Rs / 2.0,     # tones Rs apart, as fsk_demod's estimator assumes
+                                              frame_fn=lambda k, s=s: synth.m10_frame(k, rng=np.random.default_rng(900 + 10 * s + k))))          # real frames: the checksum stage has something to accept
         L = min(len(c) for c in caps)
         X = torch.from_numpy(np.stack([caps[c % 4][:L] for c in range(n)])).to(D.dev)
         md = FskModem(Fs, Rs, n_channels=n, P=P, nsym=nsym, mask=mask, lower=-lim, upper=lim, max_chunk=Fs, device=D.local_rank)
         engines.append((kind, Fs, Rs, n, X, md, caps[0], ref_args(P, nsym, mask, lim)))
-        if kind == "rs41":
-            # the consumer of auto_rx's pipe (decode.py:901-909 `fsk_demod ... | rs41mod --softin -i`) on the device: header search, bit loop, rs41_ecc --ecc2
-            from radiosonde_auto_rx_amd.fsk import SoftinDev
-            softin = SoftinDev(n, ecc=2, inv=True)
-            rs41_caps = caps
+        # the consumers of auto_rx's pipes on the device (sonde_softin_dev_*): decode.py:901-909 `fsk_demod ... | rs41mod --softin -i` (header search, bit loop, rs41_ecc --ecc2),
+        # :1067 `... | dfm09mod --ecc --auto --softin` (two symbols per bit, eight frames per hit, Hamming(8,4)), :1120 `... | m10mod --softin -i` (differential code, checksum)
+        from radiosonde_auto_rx_amd.fsk import SoftinDev
+        consumers[kind] = dict(sf=SoftinDev(n, ecc=2, inv=True) if kind == "rs41" else SoftinDev(n, kind="dfm", ecc=1, inv=False, auto=True) if kind == "dfm" else SoftinDev(n, kind="m10", ecc=0, inv=True),
+                               caps=caps, binary={"rs41": "rs41mod", "dfm": "dfm09mod", "m10": "m10mod"}[kind],
+                               args={"rs41": ["--softin", "-i", "-r", "--ecc2"], "dfm": ["--softin", "-r", "--ecc", "--auto"], "m10": ["--softin", "-i", "-r", "-v"]}[kind],
+                               fetch={"rs41": "fetch", "dfm": "fetch_dfm", "m10": "fetch_m10"}[kind], ok=0, checked=0)
         total_samples += n * (L // 2)
 
     # untimed, before anything else: the first second of every channel against the compiled reference modem (oracle/_ref/fsk_demod, test infrastructure) —
@@ -203,7 +206,7 @@ def bench_fsk_mixed(args, D, short=False):
         have_ref = bind.have_ref()
     except Exception:
         have_ref = False
-    frames_ok, frames_checked, fnote = 0, 0, "compiled reference not present"
+    fnote = "compiled reference not present"
     for kind, Fs, Rs, n, X, md, _cap, rargs in engines:
         md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
         sds = [md.fetch(c)[0] for c in range(n)]
@@ -225,28 +228,30 @@ def bench_fsk_mixed(args, D, short=False):
                 rms = float(np.sqrt(np.mean(w.astype(np.float64) ** 2))) or 1.0
                 ok = len(w) == len(ac) and len(ac) > 0 and float(np.sqrt(np.mean((ac.astype(np.float64) - w) ** 2))) < 1e-6 * rms and np.array_equal(ac < 0, w < 0)
             verified += int(ok and have_ref)
-        if kind == "rs41" and softin is not None:
-            # the frames the device consumer completes in the first THREE seconds (the capture three times: a frame spans 0.86 s and starts 0.13 s into each second) against
-            # the reference's own pipe on the same samples
-            softin.push_fsk(md)
+        cons = consumers.get(kind)
+        if cons is not None:
+            # the frames the device consumer completes in the first THREE seconds (the capture three times) against the reference's own pipe on the same samples
+            sf = cons["sf"]
+            sf.push_fsk(md)
             for _ in range(2):
                 md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
-                softin.push_fsk(md)
+                sf.push_fsk(md)
             got = {}
-            for f in softin.fetch(4 * n):
-                got.setdefault(f["channel"], []).append(f["line"])
+            for f in getattr(sf, cons["fetch"])(16 * n):
+                got.setdefault(f["channel"], []).append(f["line"].rstrip())
             want = {}
             if have_ref:
                 import subprocess
                 for b in range(min(4, n)):
-                    p1 = subprocess.run([os.path.join(bind.REFDIR, "fsk_demod")] + rargs + ["2", str(Fs), str(Rs), "-", "-"], input=rs41_caps[b][:X.shape[1]].tobytes() * 3, capture_output=True, timeout=120)
-                    p2 = subprocess.run([os.path.join(bind.REFDIR, "rs41mod"), "--softin", "-i", "-r", "--ecc2"], input=p1.stdout, capture_output=True, timeout=120)
-                    want[b] = p2.stdout.decode().splitlines()
-                fnote = "first three seconds of every RS41 channel: the frames of the device consumer equal `oracle/_ref/fsk_demod ... | oracle/_ref/rs41mod --softin -i -r --ecc2` on the same capture, line for line (the frame in progress at the end is the next call's)"
+                    p1 = subprocess.run([os.path.join(bind.REFDIR, "fsk_demod")] + rargs + ["2", str(Fs), str(Rs), "-", "-"], input=cons["caps"][b][:X.shape[1]].tobytes() * 3, capture_output=True, timeout=120)
+                    p2 = subprocess.run([os.path.join(bind.REFDIR, cons["binary"])] + cons["args"], input=p1.stdout, capture_output=True, timeout=120)
+                    want[b] = [l.rstrip() for l in p2.stdout.decode().splitlines()]
+                fnote = ("first three seconds of every channel: the frames of the device consumers equal `oracle/_ref/fsk_demod ... | oracle/_ref/{rs41mod --softin -i -r --ecc2, "
+                         "dfm09mod --softin -r --ecc --auto, m10mod --softin -i -r -v}` on the same capture, line for line (the frame in progress at the end is the next call's)")
             for c in range(n):
-                frames_checked += 1
+                cons["checked"] += 1
                 g = got.get(c, [])
-                frames_ok += int(have_ref and len(g) >= 1 and g == want[c % 4][:len(g)])
+                cons["ok"] += int(have_ref and len(g) >= 1 and g == want[c % 4][:len(g)])
 
     # the three modem configurations are three engines with a stream each: driven from three host threads (the C calls release the GIL) their
     # launches overlap on the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS)
@@ -256,10 +261,10 @@ def bench_fsk_mixed(args, D, short=False):
     def one(e):
         kind, Fs, Rs, n, X, md, _, _ = e
         md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
-        if kind == "rs41" and softin is not None:
-            softin.push_fsk(md)                               # soft decisions -> frames -> rs41_ecc, all in device memory; 518 bytes per frame come back
+        if kind in consumers:
+            consumers[kind]["sf"].push_fsk(md)                # soft decisions -> frames -> block codes, all in device memory; only the frames come back
 
-    cnt0 = softin.counts() if softin is not None else None
+    cnt0 = {k: c["sf"].counts() for k, c in consumers.items()}
 
     def step():
         list(pool.map(one, engines))
@@ -268,9 +273,9 @@ def bench_fsk_mixed(args, D, short=False):
     dt, per, steps = _timed_steps(D, step, steps, warmup, 1.0 if not args.steps else 0.0)
     value = D.world * total_samples * steps / dt / 1e6
     kern = {kind: md.kernel_ms() for kind, _, _, _, _, md, _, _ in engines}
-    cnt1 = softin.counts() if softin is not None else None
-    if softin is not None:
-        softin.fetch(1 << 20)                                 # (drop the queued records)
+    cnt1 = {k: c["sf"].counts() for k, c in consumers.items()}
+    for k, c in consumers.items():
+        getattr(c["sf"], c["fetch"])(1 << 20)                 # (drop the queued records)
     # dominant kernel k_fsk_stream: algorithmic bytes = 4 B per complex cs16 input sample (soft decisions out: 4 B per symbol)
     # the three launches overlap: the rate follows from the step time, not from the sum of the kernels' own durations
     achieved = total_samples * 4 / (dt / steps) / 1e9
@@ -288,12 +293,15 @@ def bench_fsk_mixed(args, D, short=False):
                        "rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per],
                        "kernel_ms_per_launch": {k: round(v[0], 4) for k, v in kern.items()},
                        "verified_channels": verified, "checked_channels": checked, "verify_note": vnote,
-                       "rs41_consumer": None if cnt1 is None else {
-                           "what": "rs41mod --softin -i --ecc2 on the device behind the modem (sonde_softin_dev_*): header search, bit loop, rs41_ecc; inside the timed step",
-                           "frames_decoded": cnt1["frames"] - cnt0["frames"], "frames_ecc_ok": cnt1["ecc_ok"] - cnt0["ecc_ok"], "frames_repaired": cnt1["repaired"] - cnt0["repaired"],
-                           "symbols_repaired": cnt1["symbols"] - cnt0["symbols"], "frames_dropped": cnt1["dropped"] - cnt0["dropped"],
-                           "verified_channels": frames_ok, "checked_channels": frames_checked, "verify_note": fnote},
-                       "soft_decisions": "stay in device memory (copied to the host only when sonde_fsk_fetch asks for them); the DFM and M10 thirds have no consumer on the device yet"},
+                       "consumers": {
+                           "what": "the decoders behind the modem on the device, inside the timed step (sonde_softin_dev_*): rs41mod --softin -i --ecc2 (header search, bit loop, rs41_ecc), "
+                                   "dfm09mod --softin --ecc --auto (two symbols per bit, eight frames per hit, Hamming(8,4)), m10mod --softin -i (differential code, checkM10); "
+                                   "frames_ok = accepted by the block code / checksum",
+                           **{k: {"frames_decoded": cnt1[k]["frames"] - cnt0[k]["frames"], "frames_ok": cnt1[k]["ecc_ok"] - cnt0[k]["ecc_ok"],
+                                  "frames_repaired": cnt1[k]["repaired"] - cnt0[k]["repaired"], "symbols_or_codewords_repaired": cnt1[k]["symbols"] - cnt0[k]["symbols"],
+                                  "frames_dropped": cnt1[k]["dropped"] - cnt0[k]["dropped"], "verified_channels": consumers[k]["ok"], "checked_channels": consumers[k]["checked"]} for k in consumers},
+                           "verify_note": fnote},
+                       "soft_decisions": "stay in device memory (copied to the host only when sonde_fsk_fetch asks for them): the consumers read them there"},
             "roofline": {"bound": "hbm", "kernel": "k_fsk_wave", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
                          "traffic": None, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel: a walker wave on the serial "
                                                   "oscillator recurrence (one dependent complex multiply per sample, as in the reference: ~31 cycles per sample, 0.6 ms per second of "
@@ -318,8 +326,8 @@ def bench_fsk_mixed(args, D, short=False):
                     r = _time_reference(cmds, inputs, units / ncores, "Msamples/s", "fsk_demod processes (RS41 / DFM / M10 settings in turn) over 20 s of IF-rate cs16", getattr(args, "cpu_budget", 12.0))
                 out["cpu_baseline"] = r
     pool.shutdown()
-    if softin is not None:
-        softin.close()
+    for c in consumers.values():
+        c["sf"].close()
     for e in engines:
         e[5].close()
     return out

@@ -10,6 +10,8 @@
 // device memory.  The ring is only advanced while SEARCHING — the reference's frame loop does not touch hdb.sbuf — so a search behind a
 // frame starts from the ring as the header left it.  Arithmetic as the reference's (float products, double sums, in order): frames are
 // bit-identical for identical soft bits (tests/test_gpu_softin_dev.py against oracle/_ref/fsk_demod | oracle/_ref/rs41mod --softin).
+// (no contraction: the reference is plain C on x86-64 — every product and sum rounded on its own)
+#pragma clang fp contract(off)
 #include "../../include/sonde_fsk.h"
 #include "sonde_fsk_dev.h"
 #include "sonde_host.h"

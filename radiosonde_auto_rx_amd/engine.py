@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("SONDE_HIP_LIB", os.path.join(_HERE, "libsonde_hip.so"
 
 SONDE_RS41 = 41
 SONDE_DFM09 = 9
+SONDE_M10 = 10
+SONDE_M20 = 20
 LP_IQ, LP_FM = 1, 2
 TAP_DECIM, TAP_IFIQ, TAP_FM, TAP_BUFS, TAP_CORR = range(5)
 ABI_VERSION = 3

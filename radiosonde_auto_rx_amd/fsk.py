@@ -54,6 +54,8 @@ def _lib():
         L.sonde_softin_dev_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_softin_dev_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_softin_dev_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 5
+        L.sonde_softin_dev_fetch_dfm.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.sonde_softin_dev_fetch_m10.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         _proto = True
     return L
 
@@ -153,10 +155,12 @@ class SoftinDev:
     engine's soft decisions where they lie — auto_rx's pipe `fsk_demod ... | rs41mod --softin -i` (auto_rx/autorx/decode.py:901-909)
     without the soft-decision stream crossing to the host.  No CPU fallback."""
 
-    def __init__(self, n_channels: int, *, ecc: int = 2, softinv: bool = False, inv: bool = True, auto: bool = False):
-        from .engine import SONDE_RS41
+    def __init__(self, n_channels: int, *, ecc: int = 2, softinv: bool = False, inv: bool = True, auto: bool = False, kind: str = "rs41"):
+        """kind: "rs41" (rs41mod --softin), "dfm" (dfm09mod --softin: ecc 0 / 1 = --ecc / 2 = --ecc2) or "m10" (m10mod --softin)"""
+        from .engine import SONDE_RS41, SONDE_DFM09, SONDE_M10
         h = C.c_void_p()
-        _chk(_lib().sonde_softin_dev_create(n_channels, SONDE_RS41, ecc, int(softinv), int(inv), int(auto), C.byref(h)))
+        self.kind, self.ecc = kind, ecc
+        _chk(_lib().sonde_softin_dev_create(n_channels, {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "m10": SONDE_M10}[kind], ecc, int(softinv), int(inv), int(auto), C.byref(h)))
         self._h, self.n_channels = h, n_channels
 
     def close(self):
@@ -184,6 +188,33 @@ class SoftinDev:
             f = buf[i]
             ll = lib().sonde_rs41_rawline(C.byref(f), line, 1200)
             out.append(dict(channel=f.channel, len=f.len, ecc=f.ecc, mv=f.mv, mv_pos=f.mv_pos, nbytes=f.nbytes, frame=bytes(f.frame), line=line.raw[:ll].decode()))
+        return out
+
+    def fetch_dfm(self, max_frames: int = 8192):
+        """DFM consumers: dicts with ecc (per block), conf / dat1 / dat2 nibbles, frame_in_hit, frm_count, inv, line = the `dfm09mod -r [--ecc]` text"""
+        from .engine import SondeDfmFrame, lib
+        buf = (SondeDfmFrame * max_frames)()
+        n = _chk(_lib().sonde_softin_dev_fetch_dfm(self._h, buf, max_frames))
+        out = []
+        line = C.create_string_buffer(160)
+        for i in range(n):
+            f = buf[i]
+            ll = lib().sonde_dfm_rawline(C.byref(f), self.ecc, line, 128)
+            out.append(dict(channel=f.channel, frame_in_hit=f.frame_in_hit, ecc=tuple(f.ecc), mv=f.mv, mv_pos=f.mv_pos, frm_count=f.frm_count, inv=f.inv,
+                            conf=bytes(f.conf), dat1=bytes(f.dat1), dat2=bytes(f.dat2), rawbits=bytes(f.rawbits), line=line.raw[:ll].decode()))
+        return out
+
+    def fetch_m10(self, max_frames: int = 4096, verbose: int = 1):
+        """M10 consumers: dicts with len, cs_ok, cs_calc, frame bytes, line = the `m10mod -r [-v]` text"""
+        from .engine import SondeM10Frame, lib
+        buf = (SondeM10Frame * max_frames)()
+        n = _chk(_lib().sonde_softin_dev_fetch_m10(self._h, buf, max_frames))
+        out = []
+        line = C.create_string_buffer(420)
+        for i in range(n):
+            f = buf[i]
+            ll = lib().sonde_m10_rawline(C.byref(f), verbose, line, 420)
+            out.append(dict(channel=f.channel, nbits=f.nbits, len=f.len, cs_ok=f.cs_ok, cs_calc=f.cs_calc, mv=f.mv, mv_pos=f.mv_pos, frame=bytes(f.frame), line=line.raw[:ll].decode()))
         return out
 
     def counts(self):

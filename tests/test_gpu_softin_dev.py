@@ -107,3 +107,154 @@ def test_soft_streams_in_device_memory_equal_reference_rs41mod(case):
     if case == "damaged":
         assert cnt["repaired"] > 0 and cnt["ecc_ok"] < cnt["frames"]          # 120+ flipped bits are beyond the code
     sf.close()
+
+
+# ---------------------------------------------------------------- DFM09 and M10: the other two thirds of BASELINE configs[3]
+
+def _ref(binary, soft, args):
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", binary)] + args, input=np.ascontiguousarray(soft, np.float32).tobytes(), capture_output=True, timeout=120)
+    return [l.rstrip() for l in r.stdout.decode().splitlines()]
+
+
+@pytest.mark.parametrize("inv,key", [(True, "dfm_lines"), (False, "dfm_lines_noinv")])
+def test_dfm_modem_to_frames_on_the_device_equals_the_reference_pipe(inv, key):
+    """fsk_demod | dfm09mod --softin [-i] -r --ecc with both halves on the device: the recorded lines of the reference's own pipe (tests/golden/fsk_dfm_50k.npz)"""
+    from radiosonde_auto_rx_amd.fsk import SoftinDev
+    name = "fsk_dfm_50k"
+    g = load_fsk(name)
+    x, case = fsk_capture(name)
+    sr = case["cap"]["sr"]
+    X = np.stack([x, x])
+    md = _modem(case, n_channels=2)
+    sf = SoftinDev(2, kind="dfm", ecc=1, inv=inv)
+    lines = {0: [], 1: []}
+    for s0 in range(0, X.shape[1] // 2, sr):
+        md.process_host(X[:, 2 * s0:2 * (s0 + sr)])
+        sf.push_fsk(md)
+        for f in sf.fetch_dfm():
+            lines[f["channel"]].append(f["line"].rstrip())
+    want = [str(l).rstrip() for l in g[key]]
+    n = len(lines[0])
+    assert n >= 4 and lines[0] == want[:n] and lines[1] == lines[0] and len(want) - n <= 1          # (the reference drops a partial frame at EOF: at most the one in progress is missing)
+    md.close(); sf.close()
+
+
+def _dfm_soft_stream(rng, nhits, flips, invert=False):
+    """soft SYMBOLS of DFM frames (Manchester halves, 2 per bit) as fsk_demod -s delivers them: random conf / dat blocks with valid Hamming codewords, `flips` symbols negated per frame"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    out = [rng.normal(0, 0.3, 150).astype(np.float32)]
+    for h in range(nhits):
+        nfr = 9                                                                    # a header hit takes eight frames; the ninth needs the next search
+        fb = np.concatenate([synth.dfm_frame_bits([int(v) for v in rng.integers(0, 16, 7)], [int(v) for v in rng.integers(0, 16, 13)], [int(v) for v in rng.integers(0, 16, 13)]) for _ in range(nfr)])
+        sym = np.empty(2 * len(fb), np.float32); sym[0::2] = 1.0 - 2.0 * fb; sym[1::2] = 2.0 * fb - 1.0          # bit b -> halves (not b, b)
+        sym *= rng.uniform(0.6, 1.4, len(sym)).astype(np.float32)
+        for f in range(nfr):
+            idx = 560 * f + 40 + rng.choice(500, size=flips, replace=False)
+            sym[idx] = -sym[idx] * 0.3
+        out += [sym, rng.normal(0, 0.3, 333).astype(np.float32)]
+    v = np.concatenate(out)
+    return -v if invert else v
+
+
+@pytest.mark.parametrize("ecc,flips,invert", [(1, 0, False), (1, 6, False), (2, 14, False), (2, 10, True), (0, 3, False)])
+def test_dfm_soft_streams_in_device_memory_equal_reference_dfm09mod(ecc, flips, invert):
+    need_ref()
+    import torch
+    from radiosonde_auto_rx_amd.fsk import SoftinDev
+    rng = np.random.default_rng(700 + 10 * ecc + flips)
+    C = 4
+    streams = [_dfm_soft_stream(rng, 3, flips + c, invert) for c in range(C)]
+    n = min(len(s) for s in streams)
+    S = np.stack([s[:n] for s in streams])
+    eargs = {0: [], 1: ["--ecc"], 2: ["--ecc2"]}[ecc]
+    sf = SoftinDev(C, kind="dfm", ecc=ecc, inv=False, auto=invert)
+    d = torch.from_numpy(S).cuda()
+    got = {c: [] for c in range(C)}
+    pos = 0
+    while pos < n:
+        k = min(int(rng.choice([2500, 1111, 63, 5000, 560])), n - pos)
+        chunk = d[:, pos:pos + k].contiguous()
+        sf.push_device(chunk.data_ptr(), k, k)
+        for f in sf.fetch_dfm():
+            got[f["channel"]].append(f["line"].rstrip())
+        pos += k
+    for c in range(C):
+        ref = _ref("dfm09mod", S[c], ["--softin", "-r"] + eargs + (["--auto"] if invert else []))
+        assert len(got[c]) >= 16 and got[c] == ref[:len(got[c])] and len(ref) - len(got[c]) <= 1, (ecc, flips, c, got[c][:3], ref[:3])
+    cnt = sf.counts()
+    assert cnt["frames"] == sum(len(v) for v in got.values())
+    if ecc and flips:
+        assert cnt["repaired"] > 0
+    sf.close()
+
+
+def test_m10_modem_to_frames_on_the_device_equals_the_reference_pipe():
+    """auto_rx's M10 pipe (decode.py:1120 `fsk_demod --cs16 -b -10000 -u 10000 -s -p 5 2 48080 9616 - - | m10mod --softin ...`), both halves on the device, against
+    both halves of the compiled reference on the same capture (tools/caller_cases.py "m10": tones a symbol rate apart, as the modem's estimator assumes)"""
+    need_ref()
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import caller_cases as cc
+    from radiosonde_auto_rx_amd.fsk import FskModem, SoftinDev
+    x = cc.capture("m10")
+    sr = 48080
+    p1 = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fsk_demod"), "--cs16", "-b", "-10000", "-u", "10000", "-s", "-p", "5", "2", "48080", "9616", "-", "-"],
+                        input=x.tobytes(), capture_output=True, timeout=300)
+    want = _ref("m10mod", np.frombuffer(p1.stdout, np.float32), ["--softin", "-r", "-v"])
+    assert len(want) >= 3
+    md = FskModem(sr, 9616, n_channels=2, P=5, nsym=50, lower=-10000, upper=10000, max_chunk=sr)
+    sf = SoftinDev(2, kind="m10", ecc=0, inv=False)
+    X = np.stack([x, x])
+    lines = {0: [], 1: []}
+    for s0 in range(0, X.shape[1] // 2, sr):
+        md.process_host(X[:, 2 * s0:2 * (s0 + sr)])
+        sf.push_fsk(md)
+        for f in sf.fetch_m10():
+            lines[f["channel"]].append(f["line"].rstrip())
+    n = len(lines[0])
+    assert n >= 3 and lines[0] == want[:n] and lines[1] == lines[0] and len(want) - n <= 1
+    assert sf.counts()["ecc_ok"] >= 2 * (n - 1)
+    md.close(); sf.close()
+
+
+@pytest.mark.parametrize("invert", [False, True])
+def test_m10_soft_streams_in_device_memory_equal_reference_m10mod(invert):
+    need_ref()
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    from radiosonde_auto_rx_amd.fsk import SoftinDev
+    rng = np.random.default_rng(900 + int(invert))
+    C = 3
+    streams = []
+    for c in range(C):
+        parts = [rng.normal(0, 0.3, 100 + 7 * c).astype(np.float32)]
+        for k in range(3):
+            sym = synth.m10_symbols(rng=np.random.default_rng(50 * c + k), data=synth.m10_frame(k, rng=np.random.default_rng(60 * c + k)))
+            s = (2.0 * sym.astype(np.float32) - 1.0) * rng.uniform(0.6, 1.4, len(sym)).astype(np.float32)
+            if k == 1:
+                idx = 80 + rng.choice(len(s) - 100, size=4 + c, replace=False); s[idx] = -s[idx]              # a damaged frame: checksum [NO]
+            parts += [s, rng.normal(0, 0.3, 2600 + 11 * k).astype(np.float32)]                                  # the skipped rest of the second and a bit more
+        streams.append(np.concatenate(parts))
+    n = min(len(s) for s in streams)
+    S = np.stack([s[:n] for s in streams])
+    if invert:
+        S = -S
+    sf = SoftinDev(C, kind="m10", ecc=0, inv=False)
+    d = torch.from_numpy(np.ascontiguousarray(S)).cuda()
+    got = {c: [] for c in range(C)}
+    pos = 0
+    while pos < n:
+        k = min(int(rng.choice([9616, 1000, 251, 4808])), n - pos)
+        chunk = d[:, pos:pos + k].contiguous()
+        sf.push_device(chunk.data_ptr(), k, k)
+        for f in sf.fetch_m10():
+            got[f["channel"]].append(f["line"].rstrip())
+        pos += k
+    for c in range(C):
+        ref = _ref("m10mod", S[c], ["--softin", "-r", "-v"])
+        assert len(got[c]) >= 2 and got[c] == ref[:len(got[c])] and len(ref) - len(got[c]) <= 1, (c, got[c][:2], ref[:2])
+    sf.close()
