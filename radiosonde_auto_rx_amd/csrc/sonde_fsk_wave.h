@@ -29,6 +29,13 @@
 #include "sonde_fsk_dev.h"
 #include <limits.h>
 #include <math.h>
+// (tests/test_fsk_wave_emu.py builds the emulator once with this set: every guessed frame start of the estimator wrong, see est_slot)
+#ifndef SPEC_TEST_WRONG
+#define SPEC_TEST_WRONG 0
+#endif
+#ifndef FW_EST_SPEC
+#define FW_EST_SPEC 1          // (0: A/B builds without the estimator's guessed starts)
+#endif
 
 #ifdef SONDE_FSK_EMU
 #define FW_DEV static inline
@@ -307,14 +314,14 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
 
     // ---- estimator state: frame being estimated, its start, rounds done / to do; registers of the transform
     int ke = 0; bool e_done = false;
-    uint32_t est_S = 0; int est_round = 0, est_rounds = 0, est_numffts = 0; bool est_active = false;
+    uint32_t est_S = 0, spec_S = 0; int est_round = 0, est_rounds = 0, est_numffts = 0; bool est_active = false, est_spec = false, est_hold = false;
     const bool same_blocks = a.burst || ((N - Ts / 2) / (NDFT / 2) == (N + Ts / 2) / (NDFT / 2));
     // rounds per slot: a frame's rounds (and the searches behind them) spread over the slots its pieces take
     // (the estimator may be a frame ahead, so the average is what has to fit: rounded, not rounded up)
     const int est_steps = (Nmax / (NDFT / 2) - 1 + BPW - 1) / BPW + 1, est_slots = (Nmin + FW_L - 1) / FW_L;
     const int est_per_slot = (2 * est_steps + est_slots) / (2 * est_slots) > 0 ? (2 * est_steps + est_slots) / (2 * est_slots) : 1;
     const int sub = lane / GL, lt = lane - sub * GL;
-    float hn[4]; int ip[4]; float2 tw1[NS > 0 ? NS : 1], tw2[NS > 0 ? NS : 1], tw3[NS > 0 ? NS : 1]; float sf[SPL] = {0.f};
+    float hn[4]; int ip[4]; float2 tw1[NS > 0 ? NS : 1], tw2[NS > 0 ? NS : 1], tw3[NS > 0 ? NS : 1]; float sf[SPL] = {0.f}, sf_bak[SPL] = {0.f};
     FwRaw xs[4];
     const float tc = a.tc, omt = 1 - tc;
     if (is_est) {
@@ -392,12 +399,13 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
         FW_MARK(SPLIT ? 23 : -1);
         est_round++;
     };
-    // behind the last round: the searches (fsk.c:508-581) -> ctl.f_est[ke & 3], ctl.dphi[ke & 1], est_seq
+    // behind the last round: the searches (fsk.c:508-581) -> pend_dphi / pend_fest (registers), published as ctl.f_est[ke & 3], ctl.dphi[ke & 1] by est_publish
+    float2 pend_dphi[4] = {}; float pend_fest[4] = {};
     auto est_finish = [&]() {
 #pragma unroll
         for (int r = 0; r < SPL; r++) { s_Sf[lane + 64 * r] = sf[r]; s_Sc[lane + 64 * r] = sf[r]; }
         fw_sync();
-        float2 dphi[4]; float f_est[4];
+        float2 (&dphi)[4] = pend_dphi; float (&f_est)[4] = pend_fest;
         {
             int freqi[4];
             for (int m = 0; m < M; m++) {
@@ -422,10 +430,12 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
             const int b_max = fw_argmax(s_Sc, a.st, a.en - a.len_mask, a.st, lane);
             for (int m = 0; m < M; m++) { f_est[m] = a.f_mask[M * b_max + m]; dphi[m] = a.dphi_mask[M * b_max + m]; }
         }
-        if (lane == 0) {
-            for (int m = 0; m < M; m++) { ctl.dphi[ke & 1][m] = dphi[m]; ctl.f_est[ke & 3][m] = f_est[m]; }
-        }
         est_active = false;
+    };
+    auto est_publish = [&]() {
+        if (lane == 0) {
+            for (int m = 0; m < M; m++) { ctl.dphi[ke & 1][m] = pend_dphi[m]; ctl.f_est[ke & 3][m] = pend_fest[m]; }
+        }
     };
 
     // prefetched raw samples of the worker's next piece (positions cc + lane, cc + 64 + lane, ...) and the timing phasor of its next batch of windows
@@ -530,13 +540,38 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     auto est_slot = [&]() {
         // =========================================================== estimator: the frequency estimate of every frame, as early as its start is known
         if (is_est && !e_done) {
-            if (!est_active) {
+            // a speculative estimate (below) whose guess has been settled meanwhile
+            if (est_spec && sn_nin > (unsigned)(ke - 1) && (uint32_t)ctl.E[(ke - 1) & 3] != spec_S) {
+                // the frame before this one did not come out at its nominal length (one in twenty): Sf back to where it was, the estimate again from the real start
+#pragma unroll
+                for (int r = 0; r < SPL; r++) sf[r] = sf_bak[r];
+                est_active = false; est_spec = false; est_hold = false;
+            }
+            if (sn_stop <= ke && (est_active || est_hold) && est_spec) {                       // (the guessed frame does not exist after all: nothing of it may stay in Sf)
+#pragma unroll
+                for (int r = 0; r < SPL; r++) sf[r] = sf_bak[r];
+                est_active = false; est_spec = false; est_hold = false;
+            }
+            if (!est_active && !est_hold) {
                 if (sn_stop <= ke) e_done = true;
                 else if (ke == 0 || sn_nin > (unsigned)(ke - 1)) {
                     const uint32_t S = ke == 0 ? 0u : (uint32_t)ctl.E[(ke - 1) & 3];
+                    est_spec = false;
                     if (sn_nin > (unsigned)ke) est_begin(S, (int)((uint32_t)ctl.E[ke & 3] - S) / (NDFT / 2) - 1);
                     // ahead of the frame's length: when it is certain to be demodulated by this launch whatever length the timing gives it, and its blocks are the same for all three
                     else if (same_blocks && frame_fits(ke, S, Nmax)) est_begin(S, N / (NDFT / 2) - 1);
+                } else if (FW_EST_SPEC && same_blocks && !a.burst && (ke == 1 || sn_nin > (unsigned)(ke - 2))) {
+                    // ahead of the frame's START too: the frame before it is known to start at S1 and nineteen frames in twenty are N samples long — the estimate of
+                    // frame ke from S1 + N now, kept if that frame's length comes out as N (checked before anything is published), redone otherwise.  This takes the
+                    // estimate off the chain timing(k-1) -> start(k+1) -> estimate(k+1) -> walk(k+1) that bounds short frames.  Only where both
+                    // frames are certain to be demodulated by this launch whatever their lengths.
+                    const uint32_t S1 = ke == 1 ? 0u : (uint32_t)ctl.E[(ke - 2) & 3];
+                    if (frame_fits(ke, S1 + (uint32_t)Nmax, Nmax)) {
+#pragma unroll
+                        for (int r = 0; r < SPL; r++) sf_bak[r] = sf[r];
+                        spec_S = S1 + (uint32_t)N + (SPEC_TEST_WRONG ? Ts / 2 : 0); est_spec = true;
+                        est_begin(spec_S, N / (NDFT / 2) - 1);
+                    }
                 }
             }
             if (est_active) {
@@ -545,7 +580,12 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                 int r = 0;
                 for (; r < cnt && est_round < est_rounds; r++) est_round_do();
                 FW_MARK(SPLIT ? 8 : 1);
-                if (r < cnt && est_round >= est_rounds) { est_finish(); ke++; FW_MARK(SPLIT ? 13 : 1); }
+                // behind the last round the searches, into registers
+                if (r < cnt && est_round >= est_rounds) { est_finish(); est_hold = true; FW_MARK(SPLIT ? 13 : 1); }
+            }
+            if (est_hold && (!est_spec || sn_nin > (unsigned)(ke - 1))) {
+                // the estimate is published — a guessed one only once the guess is known to hold (a wrong one was thrown away above)
+                est_publish(); est_hold = false; est_spec = false; ke++;
             }
         }
         if (is_est && lane == 0) {

@@ -25,15 +25,26 @@ class Rec(C.Structure):
                 ("EbNodB", C.c_float), ("snr_est", C.c_float)]
 
 
-@pytest.fixture(scope="module")
-def emu():
-    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
-        tmp = SO + ".%d.tmp" % os.getpid()
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wno-unknown-pragmas", "-shared", "-fPIC", "-o", tmp, SRC])
-        os.replace(tmp, SO)
-    L = C.CDLL(SO)
+def _build(so, defs=()):
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in DEPS):
+        tmp = so + ".%d.tmp" % os.getpid()
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wno-unknown-pragmas", "-shared", "-fPIC", *defs, "-o", tmp, SRC])
+        os.replace(tmp, so)
+    L = C.CDLL(so)
     L.emu_fsk_run.argtypes = [C.c_int] * 13 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     return L
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return _build(SO)
+
+
+@pytest.fixture(scope="module")
+def emu_wrong_guess():
+    """the same source with the estimator's guess of the next frame's start made wrong for every nominal-length frame (SPEC_TEST_WRONG): every
+    speculative estimate is thrown away, Sf restored and the estimate redone — results must not move"""
+    return _build(SO.replace(".so", "_wrong.so"), ("-DSPEC_TEST_WRONG=1",))
 
 
 def run(emu, name, frames, chunk, split, M=2, fin=None):
@@ -72,6 +83,13 @@ def check(g, n, sd, recs, frames, nsym):
     assert np.abs(np.array([recs[i].ppm for i in range(n)]) - g["ppm"][:n]).max() < 1e-3
     assert np.abs(np.array([recs[i].EbNodB for i in range(n)]) - g["EbNodB"][:n]).max() < 5e-3
     assert np.abs(np.array([recs[i].snr_est for i in range(n)]) - g["snr_est"][:n]).max() < 5e-3
+
+
+def test_wave_modem_with_every_guessed_frame_start_wrong(emu_wrong_guess):
+    for name, frames in (("fsk_dfm_50k", 40), ("fsk_m10_48080", 120), ("fsk_rs41_48k_peak", 40)):
+        _, case = fsk_capture(name)
+        g, n, sd, recs, Sf, ns = run(emu_wrong_guess, name, frames, case["cap"]["sr"], True)
+        check(g, n, sd, recs, frames, case["nsym"])
 
 
 CASES = [("fsk_rs41_48k_mask", 5), ("fsk_dfm_50k", 12), ("fsk_m10_48080", 40), ("fsk_rs41_48k_cu8", 4), ("fsk_rs41_48k_real", 12), ("fsk_rs41_48k_peak", 12)]
