@@ -253,21 +253,21 @@ def bench_fsk_mixed(args, D, short=False):
                 g = got.get(c, [])
                 cons["ok"] += int(have_ref and len(g) >= 1 and g == want[c % 4][:len(g)])
 
-    # the three modem configurations are three engines with a stream each: driven from three host threads (the C calls release the GIL) their
-    # launches overlap on the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS)
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=len(engines))
-
-    def one(e):
-        kind, Fs, Rs, n, X, md, _, _ = e
-        md.process_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
-        if kind in consumers:
-            consumers[kind]["sf"].push_fsk(md)                # soft decisions -> frames -> block codes, all in device memory; only the frames come back
+    # the three modem configurations are three engines with a stream each: a step submits all three (sonde_fsk_submit_device: ring copy, launch, the channel
+    # records' way back — nothing waits), puts each family's consumer behind its modem on the same stream (sonde_softin_dev_submit_fsk: soft decisions ->
+    # frames -> block codes, all in device memory; only the frames come back), then collects.  One host thread, one wait per engine; the launches overlap on
+    # the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS).  The family with the longest chain per second of signal (M10) goes first.
+    _ord = os.environ.get("SONDE_BENCH_ORDER", "m10,dfm,rs41").split(",")
+    order = sorted(engines, key=lambda e: _ord.index(e[0]))
 
     cnt0 = {k: c["sf"].counts() for k, c in consumers.items()}
 
     def step():
-        list(pool.map(one, engines))
+        for kind, Fs, Rs, n, X, md, _, _ in order:
+            md.submit_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
+            consumers[kind]["sf"].submit_fsk(md)
+        for kind, Fs, Rs, n, X, md, _, _ in order:
+            consumers[kind]["sf"].collect()
         torch.cuda.synchronize()
 
     dt, per, steps = _timed_steps(D, step, steps, warmup, 1.0 if not args.steps else 0.0)
@@ -325,7 +325,6 @@ def bench_fsk_mixed(args, D, short=False):
                         inputs.append(p); units += 20 * (len(cap) // 2)
                     r = _time_reference(cmds, inputs, units / ncores, "Msamples/s", "fsk_demod processes (RS41 / DFM / M10 settings in turn) over 20 s of IF-rate cs16", getattr(args, "cpu_budget", 12.0))
                 out["cpu_baseline"] = r
-    pool.shutdown()
     for c in consumers.values():
         c["sf"].close()
     for e in engines:

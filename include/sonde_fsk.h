@@ -70,6 +70,11 @@ int  sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info);
  * queued.  Synchronous. */
 int  sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
+/* sonde_fsk_process_device in two halves: submit enqueues everything on the engine's stream and returns, wait blocks until the launch is through.
+ * Between the two the host is free: the other engines of a mixed batch can be submitted (their launches overlap on the GPU without a host thread
+ * each), and a consumer on the device can be put behind this launch (sonde_softin_dev_submit_fsk).  Any other call of the engine waits first. */
+int  sonde_fsk_submit_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
+int  sonde_fsk_wait(sonde_fsk_t *f);
 
 /* Channels fed independently (the resident broker, host/sonde_broker.c: every client reads exactly fsk_nin() samples of its own
  * stream per frame, and nin differs between channels): channel c gets n_samples[c] samples from h_in[c] (0 = nothing this time).
@@ -108,6 +113,10 @@ int  sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc
 void sonde_softin_dev_destroy(sonde_softin_dev_t *s);
 /* consume the soft decisions the modem's last process call left in device memory (every channel; n_channels must match).  Synchronous. */
 int  sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
+/* sonde_softin_dev_push_fsk in two halves: submit puts the consumer's kernels and the copies of its frames on the modem's stream behind the launch
+ * the modem has submitted (sonde_fsk_submit_device) — no host round trip between modem and consumer; collect waits for both (it calls sonde_fsk_wait). */
+int  sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
+int  sonde_softin_dev_collect(sonde_softin_dev_t *s);
 /* the same over any soft-bit streams in device memory: channel c at d_soft + c * ch_stride, n_bits each */
 int  sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, int64_t ch_stride, int32_t n_bits);
 /* frames completed by the push calls since the last fetch (all channels, in completion order per call; channel / len / ecc / mv / mv_pos = the header's

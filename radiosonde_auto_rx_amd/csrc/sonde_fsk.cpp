@@ -32,9 +32,12 @@ struct sonde_fsk {
     std::vector<uint32_t> wr_ch; uint32_t *d_wr = nullptr;    // per-channel write positions once sonde_fsk_process_host_var is used
     double ms = 0; int64_t launches = 0;
     bool sd_on_host = false;                       // h_sd holds the last launch's soft decisions (copied on the first sonde_fsk_fetch behind a launch)
+    bool recs_on_host = false;                     // h_recs holds the last launch's frame records (copied with the soft decisions)
     bool hb_on_host = false;                       // h_hb holds the last launch's hard bits (copied on the first sonde_fsk_fetch_bits behind a launch)
-    // what a repeat of single channels needs (a pipeline that gave up, launch_and_collect): Sf and the tone tails as they were before the launch, the list
+    // what a repeat of single channels needs (a pipeline that gave up, launch_wait): Sf and the tone tails as they were before the launch, the list
     float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
+    // a launch that was submitted and not yet waited for (sonde_fsk_submit_device / sonde_fsk_wait); the channels the last wait had to repeat
+    bool pending = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; int last_repeated = 0;
 };
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
@@ -113,6 +116,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
 void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
+    if (f->ev0) { hipEventDestroy(f->ev0); hipEventDestroy(f->ev1); }
     if (f->d_prof) {
         unsigned long long h[32];
         if (hipMemcpy(h, f->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -156,41 +160,50 @@ int sonde_fsk_info(const sonde_fsk_t *f, sonde_fsk_info_t *info) {
     return 0;
 }
 
-static int collect(sonde_fsk_t *f) {
+// enqueue: the channels' records back to the host behind the launch (the soft decisions, hard bits and frame records stay on the device until somebody asks)
+static int collect_enqueue(sonde_fsk_t *f) {
     const int C = f->cfg.n_channels;
     HIPCHK(hipMemcpyAsync(f->h_chan.data(), f->d_chan, (size_t)C * sizeof(FskChan), hipMemcpyDeviceToHost, f->stream));
     f->sd_on_host = false;                                    // the soft decisions follow when somebody asks for them (sonde_fsk_fetch): a consumer on the device (sonde_softin_dev.h) never does
     f->hb_on_host = false;                                    // the hard bits follow when somebody asks for them (sonde_fsk_fetch_bits): auto_rx's pipelines read the soft decisions
-    HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
-    HIPCHK(hipStreamSynchronize(f->stream));
+    f->recs_on_host = false;                                  // the frame records (timing, Eb/N0, tone estimates per frame) too: up to 40 bytes x 200 frames x channels a second
     return 0;
 }
-static int launch_and_collect(sonde_fsk_t *f) {
+static int launch_enqueue(sonde_fsk_t *f) {
     const int C = f->cfg.n_channels;
     FskArgs &a = f->args;
-    // The pipelined kernel's waves wait for each other with a bound (FSK_SPIN_MAX); a wait that runs out — a bug, or a device slowed to a crawl under a profiler —
-    // ends that channel's launch with frames = -1.  Such channels are repeated with the frame-at-a-time kernel (same arithmetic, no waits between waves) from the
-    // state they had before the launch: the channel records are still on the host, Sf and the tone tails are copied aside first (two small device copies).
+    // A launch whose waves run out of slots — a bug, or a device slowed to a crawl under a profiler — ends that channel's launch with frames = -1.  Such
+    // channels are repeated with the frame-at-a-time kernel (same arithmetic, no waits between waves) from the state they had before the launch: the channel
+    // records are still on the host, Sf and the tone tails are copied aside first (two small device copies).
     const int Ndft = f->info.Ndft;
     if (!f->d_Sf_bak) {
         if (dalloc(&f->d_Sf_bak, (size_t)C * Ndft, false) || dalloc(&f->d_tail_bak, (size_t)C * a.M * a.NT, false) || dalloc(&f->d_chlist, (size_t)C, false)) return SONDE_E_NOMEM;
     }
+    if (!f->ev0) { HIPCHK(hipEventCreate(&f->ev0)); HIPCHK(hipEventCreate(&f->ev1)); }
     f->h_chan_prev = f->h_chan;
     HIPCHK(hipMemcpyAsync(f->d_Sf_bak, f->d_Sf, (size_t)C * Ndft * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
     HIPCHK(hipMemcpyAsync(f->d_tail_bak, f->d_tail, (size_t)C * a.M * a.NT * sizeof(float2), hipMemcpyDeviceToDevice, f->stream));
     { const char *t = getenv("SONDE_FSK_TEST_ABORT"); a.test_abort_ch = t ? atoi(t) : -1; }
     a.ch_list = nullptr; a.force_demod = 0;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, f->stream);
+    hipEventRecord(f->ev0, f->stream);
     static const bool want_prof = getenv("SONDE_FSK_PROF") != nullptr;            // profiling aid: cycles per phase of channel 0, printed when the modem is destroyed
     if (want_prof && !f->d_prof) { if (hipMalloc((void **)&f->d_prof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(f->d_prof, 0, 32 * sizeof(unsigned long long)); }
     a.prof = f->d_prof;
     const int lrc = sonde_launch_fsk(&a, f->stream);
-    hipEventRecord(e1, f->stream);
-    if (lrc < 0) { hipEventDestroy(e0); hipEventDestroy(e1); return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU; }
-    { const int rc = collect(f); if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; } }
-    float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { f->ms += ms; f->launches++; }
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipEventRecord(f->ev1, f->stream);
+    if (lrc < 0) return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU;
+    f->pending = true; f->last_repeated = 0;
+    return collect_enqueue(f);
+}
+// the other half: wait for the launch, repeat the channels it gave up on
+static int launch_wait(sonde_fsk_t *f) {
+    if (!f->pending) return 0;
+    const int C = f->cfg.n_channels;
+    FskArgs &a = f->args;
+    const int Ndft = f->info.Ndft;
+    f->pending = false;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    float ms = 0; if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) { f->ms += ms; f->launches++; }
     std::vector<int> bad;
     for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) bad.push_back(c);
     if (bad.empty()) return 0;
@@ -206,8 +219,10 @@ static int launch_and_collect(sonde_fsk_t *f) {
     b.ch_list = f->d_chlist; b.n_ch = (int)bad.size(); b.force_demod = 1; b.test_abort_ch = -1; b.prof = nullptr;
     const int lrc2 = sonde_launch_fsk(&b, f->stream);
     if (lrc2 < 0) return lrc2 == -1 ? SONDE_E_ARG : SONDE_E_NOGPU;
-    { const int rc = collect(f); if (rc) return rc; }
+    { const int rc = collect_enqueue(f); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(f->stream));
     f->repeats += (int64_t)bad.size();
+    f->last_repeated = (int)bad.size();
     for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) { fprintf(stderr, "libsonde_hip: fsk modem: channel %d failed again\n", c); return SONDE_E_NOGPU; }
     return 0;
 }
@@ -222,8 +237,9 @@ static int ring_write(sonde_fsk_t *f, int ch, uint32_t w, const char *src, int32
     return 0;
 }
 
-static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hipMemcpyKind kind) {
+static int submit(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hipMemcpyKind kind) {
     const int C = f->cfg.n_channels;
+    if (f->pending) { const int rc = launch_wait(f); if (rc) return rc; }
     if (n <= 0 || n > f->cfg.max_chunk || ch_stride < n) return SONDE_E_RANGE;
     if (!f->wr_ch.empty()) return SONDE_E_ARG;                  // the engine was switched to per-channel feeding
     FskArgs &a = f->args;
@@ -237,7 +253,11 @@ static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hi
                                 (size_t)(n - first) * f->unit, C, kind, f->stream));
     f->wr += (uint32_t)n;
     a.wr = f->wr;
-    return launch_and_collect(f);
+    return launch_enqueue(f);
+}
+static int run(sonde_fsk_t *f, const void *src, int64_t ch_stride, int32_t n, hipMemcpyKind kind) {
+    const int rc = submit(f, src, ch_stride, n, kind);
+    return rc ? rc : launch_wait(f);
 }
 
 int sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride, int32_t n_samples) {
@@ -248,9 +268,27 @@ int sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride
     if (!f || !d_in) return SONDE_E_ARG;
     return run(f, d_in, ch_stride, n_samples, hipMemcpyDeviceToDevice);
 }
+// the same in two halves: everything of sonde_fsk_process_device is enqueued on the engine's stream and the call returns; sonde_fsk_wait blocks until it is
+// through (and repeats what has to be repeated).  Between the two the host is free — e.g. to submit the other engines of a mixed batch, or a consumer on
+// the device behind this launch (sonde_softin_dev_submit_fsk).  Every other call of this engine waits first.
+int sonde_fsk_submit_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples) {
+    if (!f || !d_in) return SONDE_E_ARG;
+    return submit(f, d_in, ch_stride, n_samples, hipMemcpyDeviceToDevice);
+}
+int sonde_fsk_wait(sonde_fsk_t *f) {
+    if (!f) return SONDE_E_ARG;
+    return launch_wait(f);
+}
+// (for sonde_softin_dev: the channels the last wait repeated — their list on the device)
+int sonde_fsk_last_repeats(sonde_fsk_t *f, const int **d_list, int *n) {
+    if (!f || !d_list || !n) return SONDE_E_ARG;
+    *d_list = f->d_chlist; *n = f->last_repeated;
+    return 0;
+}
 
 int sonde_fsk_process_host_var(sonde_fsk_t *f, const void *const *h_in, const int32_t *n_samples) {
     if (!f || !h_in || !n_samples) return SONDE_E_ARG;
+    if (f->pending) { const int rc = launch_wait(f); if (rc) return rc; }
     const int C = f->cfg.n_channels;
     if (f->wr_ch.empty()) {
         if (f->wr != 0) return SONDE_E_ARG;                     // one feeding mode per engine
@@ -265,11 +303,12 @@ int sonde_fsk_process_host_var(sonde_fsk_t *f, const void *const *h_in, const in
         f->wr_ch[c] += (uint32_t)n_samples[c];
     }
     HIPCHK(hipMemcpyAsync(f->d_wr, f->wr_ch.data(), (size_t)C * sizeof(uint32_t), hipMemcpyHostToDevice, f->stream));
-    return launch_and_collect(f);
+    { const int rc = launch_enqueue(f); return rc ? rc : launch_wait(f); }
 }
 
 int sonde_fsk_reset_channel(sonde_fsk_t *f, int32_t channel) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     HIPCHK(hipStreamSynchronize(f->stream));
     const FskArgs &a = f->args;
     FskChan c; memset(&c, 0, sizeof c);
@@ -286,10 +325,16 @@ int sonde_fsk_reset_channel(sonde_fsk_t *f, int32_t channel) {
 
 int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, sonde_fsk_frame_t *frames, int32_t max_frames, int32_t *n_frames) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels || (!sd && max > 0)) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     if (!f->sd_on_host) {
         HIPCHK(hipMemcpyAsync(f->h_sd.data(), f->d_sd, f->h_sd.size() * sizeof(float), hipMemcpyDeviceToHost, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
         f->sd_on_host = true;
+    }
+    if (frames && !f->recs_on_host) {
+        HIPCHK(hipMemcpyAsync(f->h_recs.data(), f->d_recs, f->h_recs.size() * sizeof(FskFrameRec), hipMemcpyDeviceToHost, f->stream));
+        HIPCHK(hipStreamSynchronize(f->stream));
+        f->recs_on_host = true;
     }
     const FskChan &c = f->h_chan[channel];
     const int nf = c.frames, nb = std::min<int>(nf * f->info.Nbits, max);
@@ -306,6 +351,7 @@ int sonde_fsk_fetch(sonde_fsk_t *f, int32_t channel, float *sd, int32_t max, son
 
 int sonde_fsk_fetch_bits(sonde_fsk_t *f, int32_t channel, uint8_t *bits, int32_t max) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels || (!bits && max > 0)) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     if (!f->hb_on_host) {
         HIPCHK(hipMemcpyAsync(f->h_hb.data(), f->d_hb, f->h_hb.size(), hipMemcpyDeviceToHost, f->stream));
         HIPCHK(hipStreamSynchronize(f->stream));
@@ -318,6 +364,7 @@ int sonde_fsk_fetch_bits(sonde_fsk_t *f, int32_t channel, uint8_t *bits, int32_t
 
 int sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, float *Sf, int64_t *samples) {
     if (!f || channel < 0 || channel >= f->cfg.n_channels) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     const FskChan &c = f->h_chan[channel];
     if (last) {
         memset(last, 0, sizeof *last);
@@ -331,6 +378,7 @@ int sonde_fsk_stats(sonde_fsk_t *f, int32_t channel, sonde_fsk_frame_t *last, fl
 
 int sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr, int32_t *neyesamp) {
     if (!f || !eye || channel < 0 || channel >= f->cfg.n_channels) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     const int P = f->cfg.P;
     const int dec = (int)ceil(((float)P * 2) / 160.0f), nes = (P * 2) / dec, ntr = 8;      // MODEM_STATS_EYE_IND_MAX 160, ET_MAX 8
     std::vector<float> raw(8 * 160);
@@ -348,6 +396,7 @@ int sonde_fsk_eye(sonde_fsk_t *f, int32_t channel, float *eye, int32_t *neyetr, 
 
 int sonde_fsk_clear_estimators(sonde_fsk_t *f) {               // fsk_clear_estimators (fsk.c:981-989): Sf = 0, nin = N
     if (!f) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     const int C = f->cfg.n_channels;
     HIPCHK(hipStreamSynchronize(f->stream));
     HIPCHK(hipMemset(f->d_Sf, 0, (size_t)C * f->info.Ndft * sizeof(float)));
@@ -366,6 +415,7 @@ int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, co
 
 int sonde_fsk_kernel_ms(sonde_fsk_t *f, double *avg_ms, int64_t *launches) {
     if (!f) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
     if (avg_ms) *avg_ms = f->launches ? f->ms / (double)f->launches : 0.0;
     if (launches) *launches = f->launches;
     return 0;

@@ -452,7 +452,7 @@ void k_fsk_demod(const FskArgs a) {
             s_tc[lane] = t;
         }
         __syncthreads();
-        const float norm_rx_timing = (float)((double)(float)atan2((double)s_tc[1], (double)s_tc[0]) / (2 * 3.14159265358979323846));
+        const float norm_rx_timing = (float)((double)fsk_atan2f(s_tc[1], s_tc[0]) / (2 * 3.14159265358979323846));
         const float rx_timing = norm_rx_timing * (float)P;
         const float d_norm = norm_rx_timing - st.norm_rx_timing;
         st.norm_rx_timing = norm_rx_timing;
@@ -849,7 +849,7 @@ void k_fsk_stream(const FskArgs a) {
             if (lane < 2) pp.tc[lane] = t;
             __builtin_amdgcn_wave_barrier();
             const float tc0 = pp.tc[0], tc1 = pp.tc[1];
-            const float norm_rx_timing = (float)((double)(float)atan2((double)tc1, (double)tc0) / (2 * 3.14159265358979323846));
+            const float norm_rx_timing = (float)((double)fsk_atan2f(tc1, tc0) / (2 * 3.14159265358979323846));
             const float rx_timing = norm_rx_timing * (float)P;
             const float d_norm = norm_rx_timing - st.norm_rx_timing;
             st.norm_rx_timing = norm_rx_timing;
@@ -963,8 +963,13 @@ void k_fsk_stream(const FskArgs a) {
 // ------------------------------------------------------------------------------------------------
 // k_fsk_wave: walker + worker wavefronts meeting at barriers (sonde_fsk_wave.h) — the form that runs for every sonde configuration
 // ------------------------------------------------------------------------------------------------
+// Register budget: 96 vector registers (five wavefronts per SIMD, twenty per CU = five channels of four roles).  With the 128 the code would take if left alone a CU
+// holds four channels, and a launch of more channels than that runs in rounds: 1026 channels of three configurations 2.2 ms at 128, 1.75 ms at 96; one
+// configuration's 342 the same 1.0-1.2 ms at either (profiles/r5e_fsk_registers_ab.txt).  At 80 and below the worker's sums spill.  What made 96 possible without
+// spills: the channel record outside the registers, the estimator's Sf backup in LDS, each role's loads behind the role dispatch, uniform bookkeeping in scalar
+// registers (fw_uni) and the timing angle's arctangent as one dependent chain (fsk_atan2f).
 template <int M, int LOG2N, bool SPLIT, int FMT>
-__global__ __launch_bounds__(SPLIT ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SPLIT ? 4 : 2, 8)))
+__global__ __launch_bounds__(SPLIT ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SPLIT ? 5 : 2, 8)))
 void k_fsk_wave(const FskArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ FwCtl ctl;
@@ -1009,6 +1014,8 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
         const bool fits = (a->Ndft == 64 || a->Ndft == 128 || a->Ndft == 256) && a->P >= 1 && a->Ts % a->P == 0 && lds_w + sizeof(FwCtl) + 64 <= 160 * 1024 && a->iperm;
         if (mode && !a->force_demod && fits) {
             FskArgs b = *a; b.R = R; b.wave_mode = mode; b.fin = fin;
+            static const char *rot_env = getenv("SONDE_FSK_ROT");
+            b.role_rot = rot_env ? atoi(rot_env) : 1;
             if (mode == 2) return M == 2 ? launch_wave_n<2, true>(b, lds_w, s) : launch_wave_n<4, true>(b, lds_w, s);
             return M == 2 ? launch_wave_n<2, false>(b, lds_w, s) : launch_wave_n<4, false>(b, lds_w, s);
         }

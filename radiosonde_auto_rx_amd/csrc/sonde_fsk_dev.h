@@ -62,9 +62,67 @@ struct FskArgs {
     const int *ch_list;               // [n_ch] channel of workgroup b (nullptr: b)
     int force_demod;                  // 1: k_fsk_demod even where the pipelined kernel applies
     int fin;                          // set by the launcher: the wave form's finisher is on (f_int twice in LDS)
+    int role_rot;                     // set by the launcher: 0: roles in wavefront order; k > 0: the channel's roles start at wavefront (channel + k - 1) mod waves (sonde_fsk_wave.h)
     int wave_mode;                    // set by the launcher: 0 = k_fsk_stream / k_fsk_demod, 1 = k_fsk_wave one wave per channel, 2 = k_fsk_wave walker + worker (sonde_fsk_wave.h)
     int test_abort_ch;                // test hook (SONDE_FSK_TEST_ABORT=<channel>): that channel's pipeline gives up behind its first frame; -1 = off
 };
+
+// atan2 of two floats for the fine-timing angle (fsk.c:705): worked out in double and rounded to float once.  One short dependent chain — the odd series of atan
+// on |t| <= tan(pi/8) by Horner's rule, two divisions — instead of the math library's wide evaluation: that one needs some forty vector registers at the spot
+// where a channel's whole state is live, which costs the modem kernel a fifth of the channels a CU can hold (sonde_fsk_wave.h).  Error ~2e-16, far below the
+// float it is rounded to; the same code on the device and in the emulator (fma and division are IEEE operations on both).
+#ifdef SONDE_FSK_EMU
+static inline
+#else
+__host__ __device__ __forceinline__
+#endif
+float fsk_atan2f(const float yf, const float xf) {
+    const double y = (double)yf, x = (double)xf;
+    const double ay = __builtin_fabs(y), ax = __builtin_fabs(x);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    double r = 0.0;
+    if (mx != 0.0) {
+        double t = mn / mx;                                     // [0, 1]
+        const bool upper = t > 0.41421356237309503;
+        if (upper) t = (t - 1.0) / (t + 1.0);                   // atan t = pi/4 + atan((t - 1) / (t + 1)), the argument in [-tan(pi/8), 0]
+        const double z = t * t;                                 // <= 0.1716: the term behind the last one kept is below 1e-19
+        // (each coefficient is made where it is used: left to itself the compiler keeps all 22 in vector registers across the channel's whole loop — and spills them)
+#if defined(SONDE_FSK_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#define FSK_AT_STEP(c) p = __builtin_fma(p, z, (c));
+#else
+#define FSK_AT_STEP(c) { double c_ = (c); asm volatile("" : "+s"(c_)); p = __builtin_fma(p, z, c_); }
+#endif
+        double p = 1.0 / 45.0;
+        FSK_AT_STEP(-1.0 / 43.0)
+        FSK_AT_STEP(1.0 / 41.0)
+        FSK_AT_STEP(-1.0 / 39.0)
+        FSK_AT_STEP(1.0 / 37.0)
+        FSK_AT_STEP(-1.0 / 35.0)
+        FSK_AT_STEP(1.0 / 33.0)
+        FSK_AT_STEP(-1.0 / 31.0)
+        FSK_AT_STEP(1.0 / 29.0)
+        FSK_AT_STEP(-1.0 / 27.0)
+        FSK_AT_STEP(1.0 / 25.0)
+        FSK_AT_STEP(-1.0 / 23.0)
+        FSK_AT_STEP(1.0 / 21.0)
+        FSK_AT_STEP(-1.0 / 19.0)
+        FSK_AT_STEP(1.0 / 17.0)
+        FSK_AT_STEP(-1.0 / 15.0)
+        FSK_AT_STEP(1.0 / 13.0)
+        FSK_AT_STEP(-1.0 / 11.0)
+        FSK_AT_STEP(1.0 / 9.0)
+        FSK_AT_STEP(-1.0 / 7.0)
+        FSK_AT_STEP(1.0 / 5.0)
+        FSK_AT_STEP(-1.0 / 3.0)
+        FSK_AT_STEP(1.0 / 1.0)
+#undef FSK_AT_STEP
+        r = t * p;
+        if (upper) r += 0.78539816339744830962;
+        if (ay > ax) r = 1.57079632679489661923 - r;
+    }
+    if (__builtin_signbit(x)) r = 3.14159265358979323846 - r;
+    return __builtin_copysignf((float)r, yf);
+}
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s);
 #endif

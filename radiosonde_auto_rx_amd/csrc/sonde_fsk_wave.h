@@ -59,6 +59,7 @@ static inline unsigned fw_wave_umin(unsigned v) {
 }
 static inline unsigned fw_float_bits(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); return u; }
 static inline unsigned long long fw_clock() { return 0ull; }
+static inline int fw_uni(int v) { return v; }
 #else
 #define FW_DEV __device__ __forceinline__
 // lanes of ONE wave exchanging data through LDS: its DS operations execute in order, so all that is needed is that the compiler keeps them in order
@@ -67,6 +68,8 @@ FW_DEV void fw_barrier() { __syncthreads(); }
 FW_DEV float fw_shfl_xor_f(float v, int mask) { return __shfl_xor(v, mask); }
 FW_DEV int fw_shfl_xor_i(int v, int mask) { return __shfl_xor(v, mask); }
 FW_DEV unsigned long long fw_clock() { return __builtin_readcyclecounter(); }
+// a value every lane of the wave holds alike: into a scalar register (the channel's bookkeeping is all of this kind, and vector registers decide how many channels a CU holds)
+FW_DEV int fw_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // wave-wide unsigned max / min in seven DPP steps (row shifts, then the row broadcasts; lanes a step does not reach keep their value), the result from lane 63 —
 // a butterfly of `ds_bpermute` exchanges costs an LDS round trip per step, and the estimator's searches were a third of its time for short frames
 #define FW_DPP_STEP(OP, ID, ctrl, rm, bm) do { const unsigned o_ = (unsigned)__builtin_amdgcn_update_dpp((int)(ID), (int)v, ctrl, rm, bm, false); v = OP(v, o_); } while (0)
@@ -102,6 +105,7 @@ struct FwCtl {
     float    f_est[4][4];              // the estimates, for the frame records
     float2   phi_end[2][4];            // the oscillators behind frame k, normalised (fsk.c:654-656)
     struct { float rx_timing, norm_rx_timing, ppm; int nin, nin_next; } fe[2];   // a frame's timing results, for the finisher
+    float2   pend_dphi[4]; float pend_fest[4];   // the estimator's result of a frame between its searches and its publication (est_slot)
     float    fin_state[6];             // EbNodB, snr_est, f_est[4] behind the finisher's last frame, for the channel record
     unsigned pacc[32];                 // profiling aid (SONDE_FSK_PROF): cycles per phase of channel 0's waves (each phase belongs to one role)
 };
@@ -179,7 +183,7 @@ template <int LOG2N> struct FwN {
 // LDS of a channel, in floats (the launcher and the emulator harness size the allocation with this)
 static inline size_t fw_lds_floats(const int M, const int nsym, const int P, const int R, const int Ndft, const int fin) {
     const size_t W = (size_t)(nsym + 1) * P;
-    return 2 * (size_t)M * W * (fin ? 2 : 1) + 2 * (size_t)M * R + (size_t)((2 * nsym + 1) & ~1) + 2 * 2 * 64 + 2 * (size_t)Ndft + 2 * 256 + 256;
+    return 2 * (size_t)M * W * (fin ? 2 : 1) + 2 * (size_t)M * R + (size_t)((2 * nsym + 1) & ~1) + 2 * 2 * 64 + 3 * (size_t)Ndft + 2 * 256 + 256;
 }
 // the ring: two pieces (the walker's lead), the history a frame starts with, the samples of up to 63 windows left over for the next piece
 static inline int fw_ring_len(const int NT, const int step) { int R = 256; while (R < 2 * FW_L + NT + 64 * step + 8) R <<= 1; return R; }
@@ -255,7 +259,11 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     const int lane = tid & 63;
     // (FMT: the input format when the kernel is compiled for one — no branches around the sample loads, which then stay in flight across a slot — or 0: a.format)
     const int format = FMT ? FMT : a.format;
-    const bool is_worker = !SPLIT || (tid >> 6) == 0, is_walker = !SPLIT || (tid >> 6) == 1, is_est = !SPLIT || (tid >> 6) == 2, is_fin = !SPLIT || (tid >> 6) == 3;
+    // which wavefront plays which role: the hardware puts wavefront w of every workgroup of a CU on the same SIMD, so with the roles in the same order everywhere the
+    // four oscillator walks of a CU's four channels share one SIMD's issue slots while the SIMD of the estimators idles — role_rot turns the order by the channel number
+    const int nwv = a.fin ? 4 : 3;
+    const int role = SPLIT ? (((tid >> 6) + (a.role_rot ? (ch + a.role_rot - 1) % nwv : 0)) % nwv) : 0;
+    const bool is_worker = !SPLIT || role == 0, is_walker = !SPLIT || role == 1, is_est = !SPLIT || role == 2, is_fin = !SPLIT || role == 3;
     const int Ts = a.Ts, P = a.P, nsym = a.nsym, N = a.N, Nmem = a.Nmem, NT = a.NT, R = a.R;
     const int W = (nsym + 1) * P, step = Ts / P;
     const uint32_t rmask = (uint32_t)R - 1;
@@ -268,7 +276,10 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     float  *s_Sf   = reinterpret_cast<float *>(s_ftp + 2 * 64), *s_Sc = s_Sf + NDFT;
     float2 *s_fb   = reinterpret_cast<float2 *>(s_Sc + NDFT);                      // [256] transform scratch
     float  *s_mag  = reinterpret_cast<float *>(s_fb + 256);                        // [256] the round's magnitudes, fftshifted, block after block
-    FskChan st = a.chan[ch];
+    float  *s_sfbak = s_mag + 256;                                                 // [NDFT] Sf as it was before a guessed estimate (est_slot)
+    // (of the channel's record only what changes from frame to frame stays in registers; the rest is put together when the launch ends)
+    struct FwSt { int nin; float norm_rx_timing, ppm, EbNodB, snr_est; uint32_t rd; } st;
+    { const FskChan &g = a.chan[ch]; st.nin = g.nin; st.norm_rx_timing = g.norm_rx_timing; st.ppm = g.ppm; st.EbNodB = g.EbNodB; st.snr_est = g.snr_est; st.rd = g.rd; }
     float *Sf_g = a.Sf + (size_t)ch * NDFT;
     float2 *tail_g = a.tail + (size_t)ch * M * NT;
     const uint32_t wr = a.wr_ch ? a.wr_ch[ch] : a.wr, rd0 = st.rd;
@@ -302,7 +313,8 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     // ---- walker state
     int kw = 0; uint32_t cw = 0, Sw = 0; bool w_done = false, w_have_d = false;
     float wx = 0.f, wc1 = 0.f, wc2 = 0.f;
-    if (is_walker && lane < 2 * M) { const float2 p = st.phi_c[lane >> 1]; wx = (lane & 1) ? p.y : p.x; }
+    // (each role's own loads are made where its loop starts, not here: what is loaded here stays in registers through every other role's set-up)
+    auto walker_setup = [&]() { if (is_walker && lane < 2 * M) { const float2 p = a.chan[ch].phi_c[lane >> 1]; wx = (lane & 1) ? p.y : p.x; } };
 
     // ---- worker state
     const bool frame0 = frame_fits(0, 0u, st.nin);
@@ -321,10 +333,11 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     const int est_steps = (Nmax / (NDFT / 2) - 1 + BPW - 1) / BPW + 1, est_slots = (Nmin + FW_L - 1) / FW_L;
     const int est_per_slot = (2 * est_steps + est_slots) / (2 * est_slots) > 0 ? (2 * est_steps + est_slots) / (2 * est_slots) : 1;
     const int sub = lane / GL, lt = lane - sub * GL;
-    float hn[4]; int ip[4]; float2 tw1[NS > 0 ? NS : 1], tw2[NS > 0 ? NS : 1], tw3[NS > 0 ? NS : 1]; float sf[SPL] = {0.f}, sf_bak[SPL] = {0.f};
+    float hn[4]; int ip[4]; float2 tw1[NS > 0 ? NS : 1], tw2[NS > 0 ? NS : 1], tw3[NS > 0 ? NS : 1]; float sf[SPL] = {0.f};
     FwRaw xs[4];
     const float tc = a.tc, omt = 1 - tc;
-    if (is_est) {
+    auto est_setup = [&]() {
+      if (is_est) {
 #pragma unroll
         for (int q = 0; q < 4; q++) { ip[q] = a.iperm[4 * lt + q]; hn[q] = a.hann[ip[q]]; xs[q].lo = 0; xs[q].hi = 0; }
 #pragma unroll
@@ -334,7 +347,8 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
         }
 #pragma unroll
         for (int r = 0; r < SPL; r++) sf[r] = Sf_g[lane + 64 * r];
-    }
+      }
+    };
     auto est_fetch = [&](const int j0) {                        // the raw samples of round j0's blocks (one block per group of GL lanes)
         const int j = j0 + sub;
         if (j < est_numffts) {
@@ -400,12 +414,11 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
         est_round++;
     };
     // behind the last round: the searches (fsk.c:508-581) -> pend_dphi / pend_fest (registers), published as ctl.f_est[ke & 3], ctl.dphi[ke & 1] by est_publish
-    float2 pend_dphi[4] = {}; float pend_fest[4] = {};
     auto est_finish = [&]() {
 #pragma unroll
         for (int r = 0; r < SPL; r++) { s_Sf[lane + 64 * r] = sf[r]; s_Sc[lane + 64 * r] = sf[r]; }
         fw_sync();
-        float2 (&dphi)[4] = pend_dphi; float (&f_est)[4] = pend_fest;
+        float2 dphi[4]; float f_est[4];
         {
             int freqi[4];
             for (int m = 0; m < M; m++) {
@@ -430,11 +443,14 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
             const int b_max = fw_argmax(s_Sc, a.st, a.en - a.len_mask, a.st, lane);
             for (int m = 0; m < M; m++) { f_est[m] = a.f_mask[M * b_max + m]; dphi[m] = a.dphi_mask[M * b_max + m]; }
         }
+        if (lane == 0) {
+            for (int m = 0; m < M; m++) { ctl.pend_dphi[m] = dphi[m]; ctl.pend_fest[m] = f_est[m]; }
+        }
         est_active = false;
     };
     auto est_publish = [&]() {
         if (lane == 0) {
-            for (int m = 0; m < M; m++) { ctl.dphi[ke & 1][m] = pend_dphi[m]; ctl.f_est[ke & 3][m] = pend_fest[m]; }
+            for (int m = 0; m < M; m++) { ctl.dphi[ke & 1][m] = ctl.pend_dphi[m]; ctl.f_est[ke & 3][m] = ctl.pend_fest[m]; }
         }
     };
 
@@ -446,17 +462,20 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     };
     int ftp_par = 0;
     float2 ph_next = make_float2(1.f, 0.f);
-    if (is_worker) {
-        if (frame0) { piece_fetch(0u); if (lane < W) ph_next = a.phi_ft[lane]; }
-        else k_done = true;
-    }
+    auto worker_setup = [&]() {
+        if (is_worker) {
+            if (frame0) { piece_fetch(0u); if (lane < W) ph_next = a.phi_ft[lane]; }
+            else k_done = true;
+        }
+    };
     // snapshot of the control block (taken between the barriers)
     int sn_walk = 0, sn_work = 0, sn_fe = 0, sn_fedone = 0; unsigned sn_est = 0, sn_nin = 0; int sn_stop = INT_MAX;
     int all_done = 0;
     auto snapshot = [&](const int q) {
         const int *c = ctl.c[q];
-        sn_walk = c[FW_C_WALK]; sn_work = c[FW_C_WORK]; sn_est = (unsigned)c[FW_C_EST]; sn_nin = (unsigned)c[FW_C_NIN]; sn_stop = c[FW_C_STOP]; sn_fe = c[FW_C_FE]; sn_fedone = c[FW_C_FEDONE];
-        all_done = (c[FW_C_WDONE] && c[FW_C_KDONE] && c[FW_C_EDONE] && c[FW_C_FDONE]) ? 1 : 0;
+        sn_walk = fw_uni(c[FW_C_WALK]); sn_work = fw_uni(c[FW_C_WORK]); sn_est = (unsigned)fw_uni(c[FW_C_EST]); sn_nin = (unsigned)fw_uni(c[FW_C_NIN]); sn_stop = fw_uni(c[FW_C_STOP]);
+        sn_fe = fw_uni(c[FW_C_FE]); sn_fedone = fw_uni(c[FW_C_FEDONE]);
+        all_done = fw_uni((c[FW_C_WDONE] && c[FW_C_KDONE] && c[FW_C_EDONE] && c[FW_C_FDONE]) ? 1 : 0);
     };
     if (SPLIT) fw_barrier(); else fw_sync();
     snapshot(0);
@@ -465,7 +484,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     // (every slot walks or works a piece, finishes a frame or part of an estimate, or is the one slot a role waits for another's publication: the bound is generous)
     const int max_slots = 8 * ((int)((wr - rd0) / FW_L) + 4 * a.rec_cap + 16);
     // ---- the second half of a frame's end: soft decisions, eye, Eb/N0, the record — by the worker itself, or by the finisher while the worker is in the next frame
-    auto frame_finish = [&](const int k, const float2 *fint, const float rx_timing, const float norm_rx_timing, const float ppm, const int nin, const int nin_next, FskChan &cs) {
+    auto frame_finish = [&](const int k, const float2 *fint, const float rx_timing, const float norm_rx_timing, const float ppm, const int nin, const int nin_next, FwSt &cs) {
         // ---- soft decisions: integrators resampled by linear interpolation (fsk.c:733-805)
         const int low = (int)floorf(rx_timing), high = (int)ceilf(rx_timing);
         const float fract = rx_timing - (float)low, omf = 1 - fract;
@@ -530,7 +549,6 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
             cs.EbNodB = -6 + (20 * log10f((float)((1e-6 + meanebno) / (1e-6 + stdebno))));
             cs.snr_est = (float)(.5 * cs.snr_est + .5 * cs.EbNodB);
         }
-        for (int m = 0; m < M; m++) cs.f_est[m] = f_est_cur[m];
         if (lane == 0) {
             FskFrameRec r; r.nin = nin; r.nin_next = nin_next; for (int m = 0; m < 4; m++) r.f_est[m] = m < M ? f_est_cur[m] : 0.f;
             r.norm_rx_timing = norm_rx_timing; r.ppm = ppm; r.EbNodB = cs.EbNodB; r.snr_est = cs.snr_est;
@@ -544,12 +562,12 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
             if (est_spec && sn_nin > (unsigned)(ke - 1) && (uint32_t)ctl.E[(ke - 1) & 3] != spec_S) {
                 // the frame before this one did not come out at its nominal length (one in twenty): Sf back to where it was, the estimate again from the real start
 #pragma unroll
-                for (int r = 0; r < SPL; r++) sf[r] = sf_bak[r];
+                for (int r = 0; r < SPL; r++) sf[r] = s_sfbak[lane + 64 * r];
                 est_active = false; est_spec = false; est_hold = false;
             }
             if (sn_stop <= ke && (est_active || est_hold) && est_spec) {                       // (the guessed frame does not exist after all: nothing of it may stay in Sf)
 #pragma unroll
-                for (int r = 0; r < SPL; r++) sf[r] = sf_bak[r];
+                for (int r = 0; r < SPL; r++) sf[r] = s_sfbak[lane + 64 * r];
                 est_active = false; est_spec = false; est_hold = false;
             }
             if (!est_active && !est_hold) {
@@ -568,7 +586,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                     const uint32_t S1 = ke == 1 ? 0u : (uint32_t)ctl.E[(ke - 2) & 3];
                     if (frame_fits(ke, S1 + (uint32_t)Nmax, Nmax)) {
 #pragma unroll
-                        for (int r = 0; r < SPL; r++) sf_bak[r] = sf[r];
+                        for (int r = 0; r < SPL; r++) s_sfbak[lane + 64 * r] = sf[r];
                         spec_S = S1 + (uint32_t)N + (SPEC_TEST_WRONG ? Ts / 2 : 0); est_spec = true;
                         est_begin(spec_S, N / (NDFT / 2) - 1);
                     }
@@ -708,23 +726,23 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                     }
                     fw_sync();
                     const int nb = i_new - ib < 64 ? i_new - ib : 64;
-                    {   // the serial sum in window order; every lane carries component (lane & 1).  Half of a full batch's terms are requested before
-                        // the first add, so the LDS latency is paid twice per batch and not per small group of adds
+                    {   // the serial sum in window order; every lane carries component (lane & 1).  A quarter of a full batch's terms are requested before
+                        // the first add (sixteen registers: the kernel's register budget is what decides how many channels a CU holds)
                         const float *pq = reinterpret_cast<const float *>(s_ftp + ftp_par * 64) + (lane & 1);
                         if (nb == 64) {
 #pragma unroll
-                            for (int q = 0; q < 64; q += 32) {
-                                float vv[32];
+                            for (int q = 0; q < 64; q += 16) {
+                                float vv[16];
 #pragma unroll
-                                for (int u = 0; u < 32; u++) vv[u] = pq[2 * (q + u)];
+                                for (int u = 0; u < 16; u++) vv[u] = pq[2 * (q + u)];
 #pragma unroll
-                                for (int u = 0; u < 32; u++) t_sum = t_sum + vv[u];
+                                for (int u = 0; u < 16; u++) t_sum = t_sum + vv[u];
                             }
                         } else {
-                            // a batch cut short by the frame's end: groups of 32, 16, 8, 4, 2, 1 terms, each requested as a whole before its adds
+                            // a batch cut short by the frame's end: groups of 16, 8, 4, 2, 1 terms, each requested as a whole before its adds
                             int q = 0;
 #define FW_SUM_GROUP(n) if (nb - q >= (n)) { float vv[n]; _Pragma("unroll") for (int u = 0; u < (n); u++) vv[u] = pq[2 * (q + u)]; _Pragma("unroll") for (int u = 0; u < (n); u++) t_sum = t_sum + vv[u]; q += (n); }
-                            FW_SUM_GROUP(32) FW_SUM_GROUP(16) FW_SUM_GROUP(8) FW_SUM_GROUP(4) FW_SUM_GROUP(2) FW_SUM_GROUP(1)
+                            FW_SUM_GROUP(16) FW_SUM_GROUP(16) FW_SUM_GROUP(16) FW_SUM_GROUP(8) FW_SUM_GROUP(4) FW_SUM_GROUP(2) FW_SUM_GROUP(1)
 #undef FW_SUM_GROUP
                         }
                     }
@@ -742,7 +760,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                     // ================================================ the frame's last piece is in: timing, the next frame's length
                     const float tc0 = fw_shfl_xor_f(t_sum, 1);
                     const float tre = (lane & 1) ? tc0 : t_sum, tim = (lane & 1) ? t_sum : tc0;
-                    const float norm_rx_timing = (float)((double)(float)atan2((double)tim, (double)tre) / (2 * 3.14159265358979323846));
+                    const float norm_rx_timing = (float)((double)fsk_atan2f(tim, tre) / (2 * 3.14159265358979323846));
                     const float rx_timing = norm_rx_timing * (float)P;
                     const float d_norm = norm_rx_timing - st.norm_rx_timing;
                     st.norm_rx_timing = norm_rx_timing;
@@ -755,6 +773,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                         if (norm_rx_timing > 0.25) nin_next = N + Ts / 2;
                         else if (norm_rx_timing < -0.25) nin_next = N - Ts / 2;
                     }
+                    nin_next = fw_uni(nin_next);
                     const bool more = frame_fits(kk + 1, Ek, nin_next);
                     if (more) { if (lane == 0) ctl.E[(kk + 1) & 3] = (int)(Ek + (uint32_t)nin_next); my_nin_seq = kk + 2; }
                     else my_stop = kk + 1;
@@ -766,7 +785,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                         my_fe = kk + 1;
                     }
                     fw_sync();                                                  // s_fint / s_ebv are rewritten by the next frame
-                    st.rd += (uint32_t)nin; st.samples += nin; st.nin = nin_next;
+                    st.nin = nin_next;
                     frames++;
                     if (fin_on) s_fint = s_fint0 + (frames & 1) * M * W;
                     E_last = Ek;
@@ -785,7 +804,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     };
     // =========================================================== finisher (a.fin): soft decisions, Eb/N0 and record of the frames the worker hands over
     int kf = 0; bool f_done = !fin_on;
-    FskChan stf = st;
+    FwSt stf = st;
     auto fin_slot = [&]() {
         if (is_fin && !f_done) {
             if (sn_fe > kf) {
@@ -797,7 +816,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
                 FW_MARK(SPLIT ? 27 : -1);
             } else if (sn_stop <= kf) {
                 f_done = true;
-                if (lane == 0) { ctl.fin_state[0] = stf.EbNodB; ctl.fin_state[1] = stf.snr_est; for (int m = 0; m < 4; m++) ctl.fin_state[2 + m] = stf.f_est[m]; }
+                if (lane == 0) { ctl.fin_state[0] = stf.EbNodB; ctl.fin_state[1] = stf.snr_est; }
             }
         }
         if (is_fin && fin_on && lane == 0) {
@@ -815,12 +834,12 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     int slot = 0;
     if (SPLIT) {
         // a loop per role, so that a wave holds only its own role's registers (the barriers pair up across the three loops)
-        const int role = tid >> 6;
         if (role == 3)      for (; !all_done && slot < max_slots; slot++) { fin_slot(); slot_end(28); }
-        else if (role == 2) for (; !all_done && slot < max_slots; slot++) { est_slot(); slot_end(9); }
-        else if (role == 1) for (; !all_done && slot < max_slots; slot++) { walker_slot(); slot_end(7); }
-        else                for (; !all_done && slot < max_slots; slot++) { worker_slot(); slot_end(0); }
+        else if (role == 2) { est_setup(); for (; !all_done && slot < max_slots; slot++) { est_slot(); slot_end(9); } }
+        else if (role == 1) { walker_setup(); for (; !all_done && slot < max_slots; slot++) { walker_slot(); slot_end(7); } }
+        else                { worker_setup(); for (; !all_done && slot < max_slots; slot++) { worker_slot(); slot_end(0); } }
     } else {
+        est_setup(); walker_setup(); worker_setup();
         for (; !all_done && slot < max_slots; slot++) {
             est_slot(); fw_sync(); snapshot(par);
             walker_slot(); fw_sync(); snapshot(par);
@@ -841,11 +860,20 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
     }
     if (is_worker) {
         if (frames > 0) {
-            for (int m = 0; m < M; m++) st.phi_c[m] = ctl.phi_end[(frames - 1) & 1][m];
             for (int m = 0; m < M; m++) for (int i = lane; i < NT; i += 64) tail_g[m * NT + i] = s_ring[m * R + ((E_last - (uint32_t)NT + (uint32_t)i) & rmask)];
         }
-        if (fin_on && frames > 0) { st.EbNodB = ctl.fin_state[0]; st.snr_est = ctl.fin_state[1]; for (int m = 0; m < 4; m++) st.f_est[m] = ctl.fin_state[2 + m]; }
-        if (lane == 0) { st.frames = (all_done && !gave_up) ? frames : -1; a.chan[ch] = st; }
+        if (lane == 0) {
+            FskChan &g = a.chan[ch];
+            if (frames > 0) {
+                // the oscillators where the last frame left them, the estimates it used (still in place: the estimator publishes only frames this launch demodulates)
+                for (int m = 0; m < M; m++) { g.phi_c[m] = ctl.phi_end[(frames - 1) & 1][m]; g.f_est[m] = ctl.f_est[(frames - 1) & 3][m]; }
+            }
+            const bool from_fin = fin_on && frames > 0;
+            g.nin = st.nin; g.norm_rx_timing = st.norm_rx_timing; g.ppm = st.ppm;
+            g.EbNodB = from_fin ? ctl.fin_state[0] : st.EbNodB; g.snr_est = from_fin ? ctl.fin_state[1] : st.snr_est;
+            g.rd = rd0 + E_last; g.samples += (long long)E_last;              // (E_last: the samples the launch's frames took)
+            g.frames = (all_done && !gave_up) ? frames : -1;
+        }
     }
     (void)Sk;
 #undef FW_MARK

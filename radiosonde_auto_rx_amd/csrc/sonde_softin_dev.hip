@@ -38,6 +38,7 @@ struct SoftinArgs {
     const float *sd; long long ch_stride;          // soft decisions of channel c at sd + c * ch_stride
     const int *nbits_ch; int nbits;                // per channel (device) or one count for all
     const FskChan *fsk_chan; int bits_per_frame;   // or: frames of the modem's last launch x bits per frame
+    const int *ch_list;                            // the channels of this launch (one workgroup each); null: all of them
     int n_ch, inv_in, opt_auto; float ths;
     SoftinChan *chan;
     unsigned char *frames; int *flen; SoftinMeta *meta; unsigned *count; int cap;
@@ -49,7 +50,7 @@ void k_softin_rs41(const SoftinArgs a) {
     __shared__ float s_hist[64];
     __shared__ unsigned char s_frame[520];
     __shared__ float s_carry[8];
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    const int ch = a.ch_list ? a.ch_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     if (ch >= a.n_ch) return;
     SoftinChan *st = a.chan + ch;
     int nb = a.nbits;
@@ -221,7 +222,7 @@ void k_softin_dfm(const SoftinDfmArgs A) {
     __shared__ float s_hist[32];
     __shared__ unsigned char s_hb[280];
     __shared__ float s_sf[280];
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    const int ch = a.ch_list ? a.ch_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     if (ch >= a.n_ch) return;
     SoftinDfmChan *st = A.chan + ch;
     int nb = a.nbits;
@@ -351,7 +352,7 @@ void k_softin_m10(const SoftinM10Args A) {
     __shared__ float s_hist[32];
     __shared__ char s_mb[976];
     __shared__ unsigned char s_fr[124];
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    const int ch = a.ch_list ? a.ch_list[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     if (ch >= a.n_ch) return;
     SoftinM10Chan *st = A.chan + ch;
     int nb = a.nbits;
@@ -478,6 +479,8 @@ void k_softin_m10(const SoftinM10Args A) {
 
 extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *flen, const unsigned *count, int cap, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                               const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
+extern "C" int sonde_fsk_wait(sonde_fsk_t *f);
+extern "C" int sonde_fsk_last_repeats(sonde_fsk_t *f, const int **d_list, int *n);
 extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream);
 
 struct sonde_softin_dev {
@@ -491,6 +494,9 @@ struct sonde_softin_dev {
     std::vector<sonde_frame_t> queue;
     long long frames_total = 0, ecc_ok_total = 0, repaired_total = 0, symbols_total = 0, dropped = 0;
     std::vector<int> h_flen, h_ecc; std::vector<SoftinMeta> h_meta; std::vector<unsigned char> h_frames;
+    unsigned *h_count = nullptr;                   // pinned: the counters of a call's two passes
+    int head = 0;                                  // records copied to the host without asking how many there are (what a call of a second normally completes)
+    bool pending = false; hipStream_t pend_stream = nullptr; sonde_fsk_t *pend_modem = nullptr; bool registered = false;
 };
 
 extern "C" {
@@ -514,7 +520,7 @@ int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_
     bool ok = hipMalloc((void **)&s->d_chan, C * sizeof(SoftinChan)) == hipSuccess && hipMalloc((void **)&s->d_frames, cap * 518) == hipSuccess
            && hipMalloc((void **)&s->d_hdr, sizeof hdr) == hipSuccess && hipMalloc((void **)&s->d_gf, 768) == hipSuccess && hipMalloc((void **)&s->d_synd, cap * 48) == hipSuccess
            && hipMalloc((void **)&s->d_flen, cap * 4) == hipSuccess && hipMalloc((void **)&s->d_ecc, cap * 4) == hipSuccess && hipMalloc((void **)&s->d_codes, cap * 8) == hipSuccess
-           && hipMalloc((void **)&s->d_meta, cap * sizeof(SoftinMeta)) == hipSuccess && hipMalloc((void **)&s->d_count, 4) == hipSuccess;
+           && hipMalloc((void **)&s->d_meta, cap * sizeof(SoftinMeta)) == hipSuccess && hipMalloc((void **)&s->d_count, 8) == hipSuccess && hipHostMalloc((void **)&s->h_count, 8) == hipSuccess;
     ok = ok && hipMemcpy(s->d_chan, init.data(), C * sizeof(SoftinChan), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->d_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice) == hipSuccess
             && hipMemcpy(s->d_gf, sonde::gf_exp_table(), 512, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->d_gf + 512, sonde::gf_log_table(), 256, hipMemcpyHostToDevice) == hipSuccess
             && hipMemset(s->d_ecc, 0, cap * 4) == hipSuccess;
@@ -540,96 +546,163 @@ int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_
     a.n_ch = n_channels; a.inv_in = invert_stream ? 1 : 0; a.opt_auto = opt_auto ? 1 : 0; a.ths = sonde_type == SONDE_M10 ? 0.8f : 0.7f;
     a.chan = s->d_chan; a.frames = s->d_frames; a.flen = s->d_flen; a.meta = s->d_meta; a.count = s->d_count; a.cap = s->cap; a.hdr = s->d_hdr;
     s->h_flen.resize(cap); s->h_ecc.resize(cap); s->h_meta.resize(cap); s->h_frames.resize(cap * 518);
+    s->head = std::min(s->cap, (sonde_type == SONDE_DFM09 ? 5 : 1) * n_channels + 16);
+    // (pinned, so that the copies behind the kernels really are asynchronous; not fatal when the registration fails)
+    s->registered = hipHostRegister(s->h_ecc.data(), cap * 4, hipHostRegisterDefault) == hipSuccess && hipHostRegister(s->h_meta.data(), cap * sizeof(SoftinMeta), hipHostRegisterDefault) == hipSuccess
+                 && hipHostRegister(s->h_frames.data(), cap * 518, hipHostRegisterDefault) == hipSuccess
+                 && (s->h_dfm.empty() || hipHostRegister(s->h_dfm.data(), cap * sizeof(sonde_dfm_frame_t), hipHostRegisterDefault) == hipSuccess)
+                 && (s->h_m10.empty() || hipHostRegister(s->h_m10.data(), cap * sizeof(sonde_m10_frame_t), hipHostRegisterDefault) == hipSuccess);
+    (void)hipGetLastError();
     *out = s;
     return 0;
 }
 
 void sonde_softin_dev_destroy(sonde_softin_dev_t *s) {
     if (!s) return;
+    if (s->pending && s->pend_stream) (void)hipStreamSynchronize(s->pend_stream);
     if (s->own_stream && s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    if (!s->h_ecc.empty()) { hipHostUnregister(s->h_ecc.data()); hipHostUnregister(s->h_meta.data()); hipHostUnregister(s->h_frames.data()); }
+    if (!s->h_dfm.empty()) hipHostUnregister(s->h_dfm.data());
+    if (!s->h_m10.empty()) hipHostUnregister(s->h_m10.data());
+    if (s->h_count) hipHostFree(s->h_count);
+    (void)hipGetLastError();
     void *p[] = { s->d_chan, s->d_frames, s->d_hdr, s->d_gf, s->d_synd, s->d_flen, s->d_ecc, s->d_codes, s->d_meta, s->d_count, s->d_dfm_chan, s->d_dfm_out, s->d_m10_chan, s->d_m10_out };
     for (void *q : p) if (q) hipFree(q);
     delete s;
 }
 
-// the framer over what args.sd / nbits describe, then rs41_ecc() over the frames it completed; tallies and the records of the call come to the host
-static int softin_run(sonde_softin_dev *s, hipStream_t st) {
-    SoftinArgs &a = s->args;
-    HIPCHK(hipMemsetAsync(s->d_count, 0, 4, st));
-    if (s->type != SONDE_RS41) {
-        if (s->type == SONDE_DFM09) { SoftinDfmArgs d{a, s->d_dfm_chan, s->d_dfm_out, s->ecc_level}; hipLaunchKernelGGL(k_softin_dfm, dim3(s->C), dim3(64), 0, st, d); }
-        else { SoftinM10Args m{a, s->d_m10_chan, s->d_m10_out}; hipLaunchKernelGGL(k_softin_m10, dim3(s->C), dim3(64), 0, st, m); }
-        HIPCHK(hipGetLastError());
-        unsigned n = 0;
-        HIPCHK(hipMemcpyAsync(&n, s->d_count, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if ((int)n > s->cap) { s->dropped += (long long)n - s->cap; n = (unsigned)s->cap; }
-        if (n == 0) return 0;
-        if (s->type == SONDE_DFM09) {
-            HIPCHK(hipMemcpyAsync(s->h_dfm.data(), s->d_dfm_out, (size_t)n * sizeof(sonde_dfm_frame_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            // (frames of one channel in order: the slots of a call are handed out in completion order per channel, channels interleave)
-            for (unsigned i = 0; i < n; i++) {
-                const sonde_dfm_frame_t &f = s->h_dfm[i];
-                s->qdfm.push_back(f); s->frames_total++;
-                const bool okf = f.ecc[0] >= 0 && f.ecc[1] >= 0 && f.ecc[2] >= 0;
-                if (okf) s->ecc_ok_total++;
-                if (okf && (f.ecc[0] > 0 || f.ecc[1] > 0 || f.ecc[2] > 0)) { s->repaired_total++; s->symbols_total += __builtin_popcount((unsigned)f.ecc[0]) + __builtin_popcount((unsigned)f.ecc[1]) + __builtin_popcount((unsigned)f.ecc[2]); }
-            }
-        } else {
-            HIPCHK(hipMemcpyAsync(s->h_m10.data(), s->d_m10_out, (size_t)n * sizeof(sonde_m10_frame_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            for (unsigned i = 0; i < n; i++) { s->qm10.push_back(s->h_m10[i]); s->frames_total++; if (s->h_m10[i].cs_ok) s->ecc_ok_total++; }
-        }
-        return 0;
+// one pass of the framer (and rs41_ecc() over the frames it completes) over the channels of ch_list (null: all), its records behind the `off` records the
+// call already has; counter `which` of d_count
+static int softin_pass(sonde_softin_dev *s, hipStream_t st, const int off, const int nblocks, const int *ch_list, const int which) {
+    SoftinArgs a = s->args;
+    a.frames += (size_t)off * 518; a.flen += off; a.meta += off; a.cap = s->cap - off; a.count = s->d_count + which; a.ch_list = ch_list;
+    HIPCHK(hipMemsetAsync(a.count, 0, 4, st));
+    if (s->type == SONDE_DFM09) { SoftinDfmArgs d{a, s->d_dfm_chan, s->d_dfm_out + off, s->ecc_level}; hipLaunchKernelGGL(k_softin_dfm, dim3(nblocks), dim3(64), 0, st, d); }
+    else if (s->type == SONDE_M10) { SoftinM10Args m{a, s->d_m10_chan, s->d_m10_out + off}; hipLaunchKernelGGL(k_softin_m10, dim3(nblocks), dim3(64), 0, st, m); }
+    else {
+        hipLaunchKernelGGL(k_softin_rs41, dim3(nblocks), dim3(64), 0, st, a);
+        if (s->ecc_level > 0)
+            sonde_launch_rs41_ecc_batch_n(a.frames, a.flen, a.count, a.cap, s->ecc_level, s->d_ecc + off, s->d_codes + 2 * (size_t)off, s->d_synd + 48 * (size_t)off, s->d_gf, s->d_gf + 512, st);
     }
-    hipLaunchKernelGGL(k_softin_rs41, dim3(s->C), dim3(64), 0, st, a);
-    if (s->ecc_level > 0)
-        sonde_launch_rs41_ecc_batch_n(s->d_frames, s->d_flen, s->d_count, s->cap, s->ecc_level, s->d_ecc, s->d_codes, s->d_synd, s->d_gf, s->d_gf + 512, st);
     HIPCHK(hipGetLastError());
-    unsigned n = 0;
-    HIPCHK(hipMemcpyAsync(&n, s->d_count, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->h_count + which, a.count, 4, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+// records [from, to) of the call to the host
+static int softin_copy(sonde_softin_dev *s, hipStream_t st, const int from, const int to) {
+    if (to <= from) return 0;
+    const size_t n = (size_t)(to - from);
+    if (s->type == SONDE_DFM09) HIPCHK(hipMemcpyAsync(s->h_dfm.data() + from, s->d_dfm_out + from, n * sizeof(sonde_dfm_frame_t), hipMemcpyDeviceToHost, st));
+    else if (s->type == SONDE_M10) HIPCHK(hipMemcpyAsync(s->h_m10.data() + from, s->d_m10_out + from, n * sizeof(sonde_m10_frame_t), hipMemcpyDeviceToHost, st));
+    else {
+        HIPCHK(hipMemcpyAsync(s->h_meta.data() + from, s->d_meta + from, n * sizeof(SoftinMeta), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s->h_ecc.data() + from, s->d_ecc + from, n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(s->h_frames.data() + (size_t)from * 518, s->d_frames + (size_t)from * 518, n * 518, hipMemcpyDeviceToHost, st));   // 518 bytes per frame and second: not the soft decisions
+    }
+    return 0;
+}
+// enqueue a call: the framer over what args.sd / nbits describe, the block code, the counter and the records a call normally completes (`head`) on their way to the host
+static int softin_enqueue(sonde_softin_dev *s, hipStream_t st, sonde_fsk_t *modem) {
+    if (s->pending) return SONDE_E_ARG;
+    { const int rc = softin_pass(s, st, 0, s->C, nullptr, 0); if (rc) return rc; }
+    { const int rc = softin_copy(s, st, 0, s->head); if (rc) return rc; }
+    s->pending = true; s->pend_stream = st; s->pend_modem = modem;
+    return 0;
+}
+// the other half: wait, take what the head did not cover, queue the frames and add up the tallies
+static int softin_finish(sonde_softin_dev *s) {
+    if (!s->pending) return 0;
+    hipStream_t st = s->pend_stream;
+    s->pending = false;
+    int nrep = 0; const int *d_rep = nullptr;
+    if (s->pend_modem) {
+        // (the modem's wait is the stream's: the consumer's work sits behind the modem's launch.  Channels the modem had to repeat gave this call no bits
+        // — frames = -1 at the time, k_softin_* take nothing then — and get a pass of their own now, over the repeated launch's soft decisions)
+        const int rc = sonde_fsk_wait(s->pend_modem); if (rc) return rc;
+        sonde_fsk_last_repeats(s->pend_modem, &d_rep, &nrep);
+    }
     HIPCHK(hipStreamSynchronize(st));
-    if ((int)n > s->cap) { s->dropped += (long long)n - s->cap; n = (unsigned)s->cap; }
-    if (n == 0) return 0;
-    HIPCHK(hipMemcpyAsync(s->h_meta.data(), s->d_meta, (size_t)n * sizeof(SoftinMeta), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(s->h_ecc.data(), s->d_ecc, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(s->h_frames.data(), s->d_frames, (size_t)n * 518, hipMemcpyDeviceToHost, st));       // 518 bytes per frame and second: not the soft decisions
-    HIPCHK(hipStreamSynchronize(st));
-    for (unsigned i = 0; i < n; i++) {
-        sonde_frame_t f; memset(&f, 0, sizeof f);
-        const SoftinMeta &m = s->h_meta[i];
-        f.channel = m.channel; f.len = m.len; f.nbytes = m.nbytes; f.mv = m.mv; f.mv_pos = (uint32_t)m.hdr_bit;
-        f.ecc = s->ecc_level > 0 ? s->h_ecc[i] : 0;
-        memcpy(f.frame, s->h_frames.data() + (size_t)i * 518, 518);
-        s->queue.push_back(f);
-        s->frames_total++;
-        if (f.ecc >= 0) s->ecc_ok_total++;
-        if (f.ecc > 0) { s->repaired_total++; s->symbols_total += f.ecc; }
+    long long n = s->h_count[0];
+    if (n > s->cap) { s->dropped += n - s->cap; n = s->cap; }
+    int have = (int)std::min<long long>(n, s->head);
+    if (nrep > 0 && n < s->cap) {
+        { const int rc = softin_pass(s, st, (int)n, nrep, d_rep, 1); if (rc) return rc; }
+        HIPCHK(hipStreamSynchronize(st));
+        long long n2 = s->h_count[1];
+        if (n + n2 > s->cap) { s->dropped += n + n2 - s->cap; n2 = s->cap - n; }
+        n += n2;
+    }
+    if (n > have) { const int rc = softin_copy(s, st, have, (int)n); if (rc) return rc; HIPCHK(hipStreamSynchronize(st)); }
+    if (s->type == SONDE_DFM09) {
+        // (frames of one channel in order: the slots of a call are handed out in completion order per channel, channels interleave)
+        for (long long i = 0; i < n; i++) {
+            const sonde_dfm_frame_t &f = s->h_dfm[i];
+            s->qdfm.push_back(f); s->frames_total++;
+            const bool okf = f.ecc[0] >= 0 && f.ecc[1] >= 0 && f.ecc[2] >= 0;
+            if (okf) s->ecc_ok_total++;
+            if (okf && (f.ecc[0] > 0 || f.ecc[1] > 0 || f.ecc[2] > 0)) { s->repaired_total++; s->symbols_total += __builtin_popcount((unsigned)f.ecc[0]) + __builtin_popcount((unsigned)f.ecc[1]) + __builtin_popcount((unsigned)f.ecc[2]); }
+        }
+    } else if (s->type == SONDE_M10) {
+        for (long long i = 0; i < n; i++) { s->qm10.push_back(s->h_m10[i]); s->frames_total++; if (s->h_m10[i].cs_ok) s->ecc_ok_total++; }
+    } else {
+        for (long long i = 0; i < n; i++) {
+            sonde_frame_t f; memset(&f, 0, sizeof f);
+            const SoftinMeta &m = s->h_meta[i];
+            f.channel = m.channel; f.len = m.len; f.nbytes = m.nbytes; f.mv = m.mv; f.mv_pos = (uint32_t)m.hdr_bit;
+            f.ecc = s->ecc_level > 0 ? s->h_ecc[i] : 0;
+            memcpy(f.frame, s->h_frames.data() + (size_t)i * 518, 518);
+            s->queue.push_back(f);
+            s->frames_total++;
+            if (f.ecc >= 0) s->ecc_ok_total++;
+            if (f.ecc > 0) { s->repaired_total++; s->symbols_total += f.ecc; }
+        }
     }
     return 0;
 }
 
-int sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
-    if (!s || !modem) return SONDE_E_ARG;
-    const float *d_sd = nullptr; long long cap = 0; const FskChan *d_chan = nullptr; int bpf = 0, nch = 0; hipStream_t st = nullptr;
-    const int rc = sonde_fsk_dev_view(modem, &d_sd, &cap, &d_chan, &bpf, &nch, &st);
+static int softin_bind_fsk(sonde_softin_dev *s, sonde_fsk_t *modem, hipStream_t *st) {
+    const float *d_sd = nullptr; long long cap = 0; const FskChan *d_chan = nullptr; int bpf = 0, nch = 0;
+    const int rc = sonde_fsk_dev_view(modem, &d_sd, &cap, &d_chan, &bpf, &nch, st);
     if (rc) return rc;
     if (nch != s->C) return SONDE_E_ARG;
     SoftinArgs &a = s->args;
     a.sd = d_sd; a.ch_stride = cap; a.fsk_chan = d_chan; a.bits_per_frame = bpf; a.nbits_ch = nullptr; a.nbits = 0;
-    return softin_run(s, st);
+    return 0;
+}
+int sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
+    if (!s || !modem) return SONDE_E_ARG;
+    { const int rc = softin_finish(s); if (rc) return rc; }
+    hipStream_t st = nullptr;
+    { const int rc = softin_bind_fsk(s, modem, &st); if (rc) return rc; }
+    { const int rc = softin_enqueue(s, st, modem); if (rc) return rc; }
+    return softin_finish(s);
+}
+// the same in two halves (as sonde_fsk_submit_device / sonde_fsk_wait): the consumer's kernels and copies are enqueued on the modem's stream BEHIND the launch
+// the modem has submitted — no host round trip between the two — and sonde_softin_dev_collect waits for both (it calls sonde_fsk_wait).
+int sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
+    if (!s || !modem) return SONDE_E_ARG;
+    { const int rc = softin_finish(s); if (rc) return rc; }
+    hipStream_t st = nullptr;
+    { const int rc = softin_bind_fsk(s, modem, &st); if (rc) return rc; }
+    return softin_enqueue(s, st, modem);
+}
+int sonde_softin_dev_collect(sonde_softin_dev_t *s) {
+    if (!s) return SONDE_E_ARG;
+    return softin_finish(s);
 }
 
 int sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, int64_t ch_stride, int32_t n_bits) {
     if (!s || !d_soft || n_bits < 0 || ch_stride < n_bits) return SONDE_E_ARG;
+    { const int rc = softin_finish(s); if (rc) return rc; }
     if (!s->stream) { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     SoftinArgs &a = s->args;
     a.sd = d_soft; a.ch_stride = ch_stride; a.fsk_chan = nullptr; a.nbits_ch = nullptr; a.nbits = n_bits;
-    return softin_run(s, s->stream);
+    { const int rc = softin_enqueue(s, s->stream, nullptr); if (rc) return rc; }
+    return softin_finish(s);
 }
 
 int sonde_softin_dev_fetch(sonde_softin_dev_t *s, sonde_frame_t *out, int32_t max) {
+    if (s && s->pending) { const int rc_ = softin_finish(s); if (rc_) return rc_; }
     if (!s || (!out && max > 0)) return SONDE_E_ARG;
     const int n = (int)std::min<size_t>(s->queue.size(), (size_t)(max < 0 ? 0 : max));
     for (int i = 0; i < n; i++) out[i] = s->queue[i];
@@ -638,6 +711,7 @@ int sonde_softin_dev_fetch(sonde_softin_dev_t *s, sonde_frame_t *out, int32_t ma
 }
 
 int sonde_softin_dev_fetch_dfm(sonde_softin_dev_t *s, sonde_dfm_frame_t *out, int32_t max) {
+    if (s && s->pending) { const int rc_ = softin_finish(s); if (rc_) return rc_; }
     if (!s || (!out && max > 0)) return SONDE_E_ARG;
     const int n = (int)std::min<size_t>(s->qdfm.size(), (size_t)(max < 0 ? 0 : max));
     for (int i = 0; i < n; i++) out[i] = s->qdfm[i];
@@ -646,6 +720,7 @@ int sonde_softin_dev_fetch_dfm(sonde_softin_dev_t *s, sonde_dfm_frame_t *out, in
 }
 
 int sonde_softin_dev_fetch_m10(sonde_softin_dev_t *s, sonde_m10_frame_t *out, int32_t max) {
+    if (s && s->pending) { const int rc_ = softin_finish(s); if (rc_) return rc_; }
     if (!s || (!out && max > 0)) return SONDE_E_ARG;
     const int n = (int)std::min<size_t>(s->qm10.size(), (size_t)(max < 0 ? 0 : max));
     for (int i = 0; i < n; i++) out[i] = s->qm10[i];
@@ -654,6 +729,7 @@ int sonde_softin_dev_fetch_m10(sonde_softin_dev_t *s, sonde_m10_frame_t *out, in
 }
 
 int sonde_softin_dev_counts(sonde_softin_dev_t *s, int64_t *frames, int64_t *ecc_ok, int64_t *repaired, int64_t *symbols, int64_t *dropped) {
+    if (s && s->pending) { const int rc_ = softin_finish(s); if (rc_) return rc_; }
     if (!s) return SONDE_E_ARG;
     if (frames) *frames = s->frames_total;
     if (ecc_ok) *ecc_ok = s->ecc_ok_total;

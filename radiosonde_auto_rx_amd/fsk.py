@@ -41,6 +41,8 @@ def _lib():
         L.sonde_fsk_info.argtypes = [C.c_void_p, C.POINTER(FskInfo)]
         L.sonde_fsk_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_fsk_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_fsk_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+        L.sonde_fsk_wait.argtypes = [C.c_void_p]
         L.sonde_fsk_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_int32, C.POINTER(C.c_int32)]
         L.sonde_fsk_stats.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FskFrame), C.c_void_p, C.POINTER(C.c_int64)]
         L.sonde_fsk_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -51,6 +53,8 @@ def _lib():
         L.sonde_softin_dev_create.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_void_p)]
         L.sonde_softin_dev_destroy.argtypes = [C.c_void_p]
         L.sonde_softin_dev_push_fsk.argtypes = [C.c_void_p, C.c_void_p]
+        L.sonde_softin_dev_submit_fsk.argtypes = [C.c_void_p, C.c_void_p]
+        L.sonde_softin_dev_collect.argtypes = [C.c_void_p]
         L.sonde_softin_dev_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_softin_dev_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.sonde_softin_dev_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int64)] * 5
@@ -117,6 +121,13 @@ class FskModem:
     def process_device(self, ptr: int, ch_stride: int, n: int):
         _chk(_lib().sonde_fsk_process_device(self._h, C.c_void_p(ptr), ch_stride, n))
 
+    def submit_device(self, ptr: int, ch_stride: int, n: int):
+        """process_device in two halves: everything enqueued on the engine's stream, no waiting; wait() (or any other call) blocks until it is through"""
+        _chk(_lib().sonde_fsk_submit_device(self._h, C.c_void_p(ptr), ch_stride, n))
+
+    def wait(self):
+        _chk(_lib().sonde_fsk_wait(self._h))
+
     def fetch(self, ch: int = 0):
         """-> (soft decisions [frames, Nbits], list of per-frame dicts) of the last process call."""
         cap = 4096
@@ -173,6 +184,13 @@ class SoftinDev:
     def push_fsk(self, modem: "FskModem"):
         """consume what the modem's last process call left in device memory"""
         _chk(_lib().sonde_softin_dev_push_fsk(self._h, modem._h))
+
+    def submit_fsk(self, modem: "FskModem"):
+        """push_fsk without waiting: the consumer's kernels and frame copies go on the modem's stream behind the launch it has submitted; collect() waits for both"""
+        _chk(_lib().sonde_softin_dev_submit_fsk(self._h, modem._h))
+
+    def collect(self):
+        _chk(_lib().sonde_softin_dev_collect(self._h))
 
     def push_device(self, ptr: int, ch_stride: int, n_bits: int):
         _chk(_lib().sonde_softin_dev_push_device(self._h, C.c_void_p(ptr), ch_stride, n_bits))

@@ -52,6 +52,7 @@ extern "C" int emu_fsk_run(int Fs, int Rs, int M, int P, int nsym, int format, i
     a.dphi_mask = T.dmask.data(); a.f_mask = T.fmask.data(); a.phi_ft = T.phift.data(); a.chan = &chan; a.Sf = Sf.data(); a.eye = eye.data();
     a.tail = tail.data(); a.sd = sd.data(); a.hb = hb.data(); a.recs = recs.data();
     a.R = fw_ring_len(T.NT, T.Ts / P); a.test_abort_ch = -1; a.fin = fin;
+    { const char *e = getenv("EMU_ROLE_ROT"); a.role_rot = e ? atoi(e) : 0; }       // (which wavefront plays which role, sonde_fsk_wave.h)
     std::vector<float> lds(fw_lds_floats(M, nsym, P, a.R, T.Ndft, fin) + 64, 0.f);
     FwCtl ctl; memset(&ctl, 0, sizeof ctl);
     uint32_t wr = 0;

@@ -85,6 +85,16 @@ def check(g, n, sd, recs, frames, nsym):
     assert np.abs(np.array([recs[i].snr_est for i in range(n)]) - g["snr_est"][:n]).max() < 5e-3
 
 
+@pytest.mark.parametrize("rot", [2, 3, 4])
+def test_wave_modem_with_the_roles_on_other_wavefronts(emu, monkeypatch, rot):
+    """role_rot: the launcher turns the order of worker / walker / estimator / finisher by the channel number (SIMD balance); results must not depend on it"""
+    monkeypatch.setenv("EMU_ROLE_ROT", str(rot))
+    for name, frames in (("fsk_dfm_50k", 12), ("fsk_m10_48080", 40), ("fsk_rs41_48k_mask", 3)):
+        _, case = fsk_capture(name)
+        g, n, sd, recs, Sf, ns = run(emu, name, frames, case["cap"]["sr"], True)
+        check(g, n, sd, recs, frames, case["nsym"])
+
+
 def test_wave_modem_with_every_guessed_frame_start_wrong(emu_wrong_guess):
     for name, frames in (("fsk_dfm_50k", 40), ("fsk_m10_48080", 120), ("fsk_rs41_48k_peak", 40)):
         _, case = fsk_capture(name)

@@ -258,3 +258,83 @@ def test_m10_soft_streams_in_device_memory_equal_reference_m10mod(invert):
         ref = _ref("m10mod", S[c], ["--softin", "-r", "-v"])
         assert len(got[c]) >= 2 and got[c] == ref[:len(got[c])] and len(ref) - len(got[c]) <= 1, (c, got[c][:2], ref[:2])
     sf.close()
+
+
+def _pipe_case(kind):
+    """(capture as cs16 int16 pairs, sample rate, modem factory, consumer factory, fetch method) of auto_rx's pipe for one family"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from radiosonde_auto_rx_amd.fsk import FskModem, SoftinDev
+    if kind == "m10":
+        from tools import caller_cases as cc
+        x, sr = cc.capture("m10"), 48080
+        return (x, sr, lambda n: FskModem(sr, 9616, n_channels=n, P=5, nsym=50, lower=-10000, upper=10000, max_chunk=sr),
+                lambda n: SoftinDev(n, kind="m10", ecc=0, inv=False), "fetch_m10")
+    name = {"rs41": "fsk_rs41_48k_mask", "dfm": "fsk_dfm_50k"}[kind]
+    x, case = fsk_capture(name)
+    assert case["fmt"] != 1
+    return (x, case["cap"]["sr"], lambda n: _modem(case, n_channels=n),
+            (lambda n: SoftinDev(n, ecc=2, inv=True)) if kind == "rs41" else (lambda n: SoftinDev(n, kind="dfm", ecc=1, inv=True)), "fetch" if kind == "rs41" else "fetch_dfm")
+
+
+@pytest.mark.parametrize("abort", [False, True])
+@pytest.mark.parametrize("kind", ["rs41", "dfm", "m10"])
+def test_submit_and_collect_give_the_frames_of_the_synchronous_calls(monkeypatch, capfd, kind, abort):
+    """sonde_fsk_submit_device + sonde_softin_dev_submit_fsk, then sonde_softin_dev_collect: the consumer's kernels sit on the modem's stream behind its launch, no
+    host round trip between the two, one wait for both.  Same frames, same order per channel, same tallies as process + push; also when the modem has to repeat a
+    channel (test hook SONDE_FSK_TEST_ABORT: channel 1 gives up in every launch) — the consumer then takes that channel's bits in a pass of its own."""
+    import torch
+    x, sr, mk_modem, mk_cons, fetch = _pipe_case(kind)
+    X = torch.from_numpy(np.stack([x, x, x])).cuda()
+    n = X.shape[1] // 2
+
+    def run(two_halves):
+        md, sf = mk_modem(3), mk_cons(3)
+        lines = {0: [], 1: [], 2: []}
+        for s0 in range(0, n, sr):
+            m = min(sr, n - s0)
+            ptr = X.data_ptr() + 2 * s0 * X.element_size()
+            if two_halves:
+                md.submit_device(ptr, n, m)
+                sf.submit_fsk(md)
+                sf.collect()
+            else:
+                md.process_device(ptr, n, m)
+                sf.push_fsk(md)
+            for f in getattr(sf, fetch)():
+                lines[f["channel"]].append(f["line"].rstrip())
+        c = sf.counts()
+        sd = [md.fetch(k)[0] for k in range(3)]
+        md.close(); sf.close()
+        return lines, c, sd
+
+    plain = run(False)
+    capfd.readouterr()
+    if abort:
+        monkeypatch.setenv("SONDE_FSK_TEST_ABORT", "1")
+    got = run(True)
+    err = capfd.readouterr().err
+    assert ("repeating them frame by frame" in err) == abort
+    assert len(plain[0][0]) >= 1 and plain[0][1] == plain[0][0] and plain[0][2] == plain[0][0]
+    assert got[0] == plain[0] and got[1] == plain[1]
+    for k in range(3):
+        assert np.array_equal(got[2][k], plain[2][k])
+
+
+def test_submit_without_wait_is_waited_for_by_the_next_call():
+    """any call of an engine with a launch in flight waits for it first: fetch right after submit returns that launch's soft decisions"""
+    import torch
+    x, sr, mk_modem, _mk, _f = _pipe_case("rs41")
+    X = torch.from_numpy(np.stack([x, x])).cuda()
+    a, b = mk_modem(2), mk_modem(2)
+    a.process_device(X.data_ptr(), X.shape[1] // 2, sr)
+    b.submit_device(X.data_ptr(), X.shape[1] // 2, sr)
+    for k in range(2):
+        sa, ra = a.fetch(k); sb, rb = b.fetch(k)
+        assert len(sa) > 0 and np.array_equal(sa, sb) and ra == rb
+    b.submit_device(X.data_ptr() + 2 * sr * X.element_size(), X.shape[1] // 2, sr)       # (a second submit waits for the first)
+    b.submit_device(X.data_ptr() + 4 * sr * X.element_size(), X.shape[1] // 2, sr)
+    a.process_device(X.data_ptr() + 2 * sr * X.element_size(), X.shape[1] // 2, sr)
+    a.process_device(X.data_ptr() + 4 * sr * X.element_size(), X.shape[1] // 2, sr)
+    assert np.array_equal(a.fetch(1)[0], b.fetch(1)[0])
+    a.close(); b.close()
