@@ -256,8 +256,10 @@ def bench_fsk_mixed(args, D, short=False):
     # the three modem configurations are three engines with a stream each: a step submits all three (sonde_fsk_submit_device: ring copy, launch, the channel
     # records' way back — nothing waits), puts each family's consumer behind its modem on the same stream (sonde_softin_dev_submit_fsk: soft decisions ->
     # frames -> block codes, all in device memory; only the frames come back), then collects.  One host thread, one wait per engine; the launches overlap on
-    # the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS).  The family with the longest chain per second of signal (M10) goes first.
-    _ord = os.environ.get("SONDE_BENCH_ORDER", "m10,dfm,rs41").split(",")
+    # the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS).  
+    # (measured, profiles/r5f_fsk_mixed_order.txt: up to ~2000 channels the launches do not fill the GPU and the step ends with the last one submitted — the cheapest
+    # consumer (DFM) goes last; beyond, the CUs' LDS is what is contended and the largest footprint (RS41, 40 KB a channel) is best placed first)
+    _ord = os.environ.get("SONDE_BENCH_ORDER", "m10,rs41,dfm" if C <= 2048 else "rs41,m10,dfm").split(",")
     order = sorted(engines, key=lambda e: _ord.index(e[0]))
 
     cnt0 = {k: c["sf"].counts() for k, c in consumers.items()}

@@ -225,7 +225,8 @@ int  sonde_engine_overflowed(sonde_engine_t *e);
  * k_framesync on the device (rs41_ecc, rs41mod.c:1703-1769; rs_decode_ErrEra, bch_ecc_mod.c:877-960). */
 long long sonde_engine_host_ecc_frames(sonde_engine_t *e);
 /* on = 0: frames of the following calls leave k_framesync with their first-pass syndromes only and are decoded on the host when fetched (the
- * round-3 arrangement; A/B measurements and tests); on = 1 (default): device decoder. */
+ * round-3 arrangement; A/B measurements and tests); on = 1 (default): device decoder.  DFM09 / M10 engines: the same switch for their block codes
+ * (Hamming(8,4) of the sliced frames / differential decoding + checkM10): on the device behind the frame sync, or on the host inside the fetch. */
 int  sonde_engine_set_device_ecc(sonde_engine_t *e, int32_t on);
 /* Pipelined variant: return only the frames of process calls issued at least `lag` calls ago and wait only for those.
  * With lag = 1 the IF-rate kernels of call k (stream B) overlap the decimator of call k+1 (stream A); lag = 0 is
@@ -252,7 +253,8 @@ int  sonde_engine_fetch_soft1(sonde_engine_t *e, float *soft, int32_t max_frames
 /* find_header()'s threshold argument (demod_mod.c:1533) for the following process calls */
 int  sonde_engine_set_threshold(sonde_engine_t *e, float thres);
 
-/* DFM engines: frames completed so far (syncs; Hamming decode of dfm09mod.c:240-345 on the host).  cfg.ecc_level 0/1/2
+/* DFM engines: frames completed so far (syncs).  The hits are sliced into frames and Hamming-decoded (dfm09mod.c:240-345) on the device behind the frame sync
+ * (k_dfm_hits; the host decode remains as the A/B path, sonde_engine_set_device_ecc(e, 0)); only decoded frames come to the host, the soft bits on request.  cfg.ecc_level 0/1/2
  * = none / --ecc / --ecc2 (soft 2-bit pass).  finish != 0: end of input, also emits the complete frames of a hit
  * in progress (a partial frame is dropped like dfm09mod.c:1713). */
 int  sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish);

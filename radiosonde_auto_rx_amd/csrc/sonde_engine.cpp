@@ -38,6 +38,9 @@ struct sonde_engine {
     hipStream_t stream_c = nullptr;    // C: record copies of a lagged fetch (on B they would queue behind the call that is still running)
     hipStream_t stream_e = nullptr;    // E: k_rs41_ecc_frames + the frame-counter publish of a call, beside the next call's decimator (RS41 engines with ECC)
     hipEvent_t ev_s = nullptr;         // B -> E hand-over
+    // DFM / M10 block codes of the hits on the device (k_dfm_hits / k_m10_hits, sonde_softin_dev.hip): decoded frames per ring slot, {done, ticket}, M10's bit characters per channel
+    sonde_dfm_frame_t *d_dfm_out = nullptr; sonde_m10_frame_t *d_m10_out = nullptr; unsigned *d_blk_done = nullptr; char *d_m10_bits = nullptr;
+    std::vector<sonde_dfm_frame_t> h_dfm; std::vector<sonde_m10_frame_t> h_m10; bool soft_lazy = false; unsigned soft_lazy_start = 0;
     uint32_t *d_ecc_list = nullptr; unsigned *d_ecc_cnt = nullptr;     // two work lists of max_frames record slots, alternating per call; {count[2], done[2]}
     hipEvent_t ev_a[4] = {}, ev_b[4] = {}, ev_if[4] = {};      // per call: decimator done (A), records complete (B / E), y ring read (B: IF chain done)
     unsigned *h_count = nullptr;       // pinned: frame counter snapshot after each call's framesync
@@ -177,8 +180,39 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
 static void launch_framesync_impl(sonde_engine *e, int eof);
 // header position as the caller's stream counts it: from the channel's own start
 static inline uint32_t rel_pos(const sonde_engine *e, const FrameRec &r) { return e->epoch.empty() ? r.mv_pos : r.mv_pos - e->epoch[r.channel]; }
-static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); if (eof) e->eof_pending = true; }
+extern "C" void sonde_launch_dfm_hits(const FrameRec *frames, const float *soft, int nbits, int max_frames, const unsigned *fcount, unsigned *done, sonde_dfm_frame_t *out,
+                                      int ecc_level, int grid, hipStream_t s);
+extern "C" void sonde_launch_m10_hits(const FrameRec *frames, const float *soft, const float *soft1, int chk3, int nbits, int max_frames, const unsigned *fcount, unsigned *done,
+                                      char *chan_bits, sonde_m10_frame_t *out, int grid, hipStream_t s);
+static bool blockcodes_on_device(const sonde_engine *e);
+// behind every frame-sync launch: the block codes of the hits it has queued (DFM Hamming(8,4), M10 checksum), on the same stream
+static void launch_blockcodes(sonde_engine *e) {
+    if (!blockcodes_on_device(e)) return;
+    const int grid = std::max(1, std::min(e->cfg.n_channels, 1024));
+    if (e->cfg.sonde_type == SONDE_DFM09)
+        sonde_launch_dfm_hits(e->d_frames, e->d_soft, e->nbits, e->max_frames, e->d_fcount, e->d_blk_done, e->d_dfm_out, e->cfg.ecc_level, grid, e->stream_b);
+    else
+        sonde_launch_m10_hits(e->d_frames, e->d_soft, e->d_soft1, e->m10_chk3 ? 1 : 0, e->nbits, e->max_frames, e->d_fcount, e->d_blk_done, e->d_m10_bits, e->d_m10_out, grid, e->stream_b);
+}
+static void launch_framesync(sonde_engine *e, int eof) { launch_framesync_impl(e, eof); launch_blockcodes(e); if (eof) e->eof_pending = true; }
 static void sync_round(sonde_engine *e, int W);
+
+static bool blockcodes_on_device(const sonde_engine *e) {
+    return e->dev_ecc && e->d_soft && e->d_blk_done && ((e->cfg.sonde_type == SONDE_DFM09 && e->d_dfm_out) || (e->cfg.sonde_type == SONDE_M10 && e->d_m10_out));
+}
+// the decoded frames of the n records a fetch has just taken (ring slots from `start` on) -> host
+template <class T> static int copy_decoded(sonde_engine *e, const T *d_out, std::vector<T> &h, unsigned start, int n, int per) {
+    h.resize((size_t)n * per);
+    unsigned done = 0;
+    while (done < (unsigned)n) {
+        const unsigned idx = (start + done) % (unsigned)e->max_frames;
+        const unsigned run = std::min<unsigned>((unsigned)n - done, (unsigned)e->max_frames - idx);
+        if (hipMemcpyAsync(h.data() + (size_t)done * per, d_out + (size_t)idx * per, (size_t)run * per * sizeof(T), hipMemcpyDeviceToHost, e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        done += run;
+    }
+    if (n && hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+    return 0;
+}
 
 extern "C" {
 
@@ -390,6 +424,8 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1 + 4);      // the counter, and its value behind each of the last four calls (what a call publishes)
     if (cfg->keep_soft || cfg->sonde_type != SONDE_RS41) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
     if (cfg->keep_soft == 2) bad |= dalloc(&e->d_soft1, (size_t)e->max_frames * e->nbits);
+    if (cfg->sonde_type == SONDE_DFM09) { bad |= dalloc(&e->d_dfm_out, (size_t)e->max_frames * 8); bad |= dalloc(&e->d_blk_done, 2); }
+    if (cfg->sonde_type == SONDE_M10) { bad |= dalloc(&e->d_m10_out, (size_t)e->max_frames); bad |= dalloc(&e->d_blk_done, 2); bad |= dalloc(&e->d_m10_bits, (size_t)C * ((101 + 20) * 8 + 8)); }
     bad |= dalloc(&e->d_match, L, false);
     if (!e->w_iq.empty()) bad |= dalloc(&e->d_wiq, e->w_iq.size(), false);
     if (!e->w_fm.empty()) bad |= dalloc(&e->d_wfm, e->w_fm.size(), false);
@@ -582,6 +618,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->stream_c) hipStreamDestroy(e->stream_c);
     if (e->stream_e) hipStreamDestroy(e->stream_e);
     if (e->ev_s) hipEventDestroy(e->ev_s);
+    hipFree(e->d_dfm_out); hipFree(e->d_m10_out); hipFree(e->d_blk_done); hipFree(e->d_m10_bits);
     hipFree(e->d_ecc_list); hipFree(e->d_ecc_cnt); hipFree(e->d_park);
     for (int i = 0; i < 4; i++) { if (e->ev_a[i]) hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) hipEventDestroy(e->ev_b[i]); if (e->ev_if[i]) hipEventDestroy(e->ev_if[i]); }
     if (e->ev_copy) hipEventDestroy(e->ev_copy);
@@ -976,9 +1013,31 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
     if (finish) launch_framesync(e, 1);
     std::vector<FrameRec> recs;
     std::vector<float> soft;
-    const int nh = collect_records(e, 0, recs, &soft, max / 8);
+    const bool on_dev = blockcodes_on_device(e);
+    const int nh = collect_records(e, 0, recs, on_dev ? nullptr : &soft, max / 8);
     if (nh < 0) return nh;
-    e->last_soft = soft; e->last_n = nh;
+    e->last_n = nh;
+    if (on_dev) {
+        // the frames were sliced and decoded on the device behind the frame sync (k_dfm_hits): only they come over — the soft bits stay where they are until
+        // sonde_engine_fetch_soft asks for them
+        const unsigned start = e->read_idx - (unsigned)nh;
+        e->soft_lazy = true; e->soft_lazy_start = start;
+        if (copy_decoded(e, e->d_dfm_out, e->h_dfm, start, nh, 8)) return SONDE_E_NOGPU;
+        int n = 0;
+        for (int h = 0; h < nh; h++) {
+            const FrameRec &r = recs[h];
+            for (int f = 0; f < 8 && n < max; f++) {
+                const sonde_dfm_frame_t &d = e->h_dfm[(size_t)h * 8 + f];
+                if (d.frame_in_hit != f) break;                            // (-1: the hit ends before this frame)
+                sonde_dfm_frame_t &o = out[n++];
+                o = d;
+                o.mv_pos = rel_pos(e, r);
+                o.frm_count = (float)(rel_pos(e, r) / (2.0 * e->sps * 280) + f);   // gpx._frmcnt (dfm09mod.c:1662)
+            }
+        }
+        return n;
+    }
+    e->last_soft = soft; e->soft_lazy = false;
     int n = 0;
     for (int h = 0; h < nh; h++) {
         const FrameRec &r = recs[h];
@@ -1032,7 +1091,7 @@ int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t ma
     std::vector<float> soft;
     const int n = collect_records(e, 0, recs, &soft, max);
     if (n < 0) return n;
-    e->last_soft = soft; e->last_n = n;
+    e->last_soft = soft; e->last_n = n; e->soft_lazy = false;
     for (int h = 0; h < n; h++) {
         const FrameRec &r = recs[h];
         sonde_m20_frame_t &o = out[h];
@@ -1049,9 +1108,19 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
     if (finish) launch_framesync(e, 1);
     std::vector<FrameRec> recs;
     std::vector<float> soft;
-    const int n = collect_records(e, 0, recs, &soft, max);
+    const bool on_dev = blockcodes_on_device(e);
+    const int n = collect_records(e, 0, recs, on_dev ? nullptr : &soft, max);
     if (n < 0) return n;
-    e->last_soft = soft; e->last_n = n;
+    e->last_n = n;
+    if (on_dev) {
+        // differential decoding, bytes and checkM10 were done on the device behind the frame sync (k_m10_hits)
+        const unsigned start = e->read_idx - (unsigned)n;
+        e->soft_lazy = true; e->soft_lazy_start = start;
+        if (copy_decoded(e, e->d_m10_out, e->h_m10, start, n, 1)) return SONDE_E_NOGPU;
+        for (int h = 0; h < n; h++) { out[h] = e->h_m10[h]; out[h].mv_pos = rel_pos(e, recs[h]); }
+        return n;
+    }
+    e->last_soft = soft; e->soft_lazy = false;
     if (e->m10_chk3 && e->d_soft1 && !soft.empty()) {
         // --chk3 (m10mod.c:1476-1479): the bit is re-decided from both soft values of read_softbit2p, (sb + 0.25 sb1) >= 0, before the differential decoding
         const unsigned start = e->read_idx - (unsigned)n;
@@ -1085,7 +1154,7 @@ int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, in
     std::vector<float> soft;
     const int n = collect_records(e, 0, recs, &soft, max);
     if (n < 0) return n;
-    e->last_soft = soft; e->last_n = n;
+    e->last_soft = soft; e->last_n = n; e->soft_lazy = false;
     if (e->d_soft1) {                                          // the same ring slots of the second soft-bit array
         const unsigned start = e->read_idx - (unsigned)n;       // first ring slot of the records just taken (read_idx is already behind them)
         e->last_soft1.resize((size_t)n * e->nbits);
@@ -1187,6 +1256,7 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
     HIPCHK(hipMemcpy(e->d_state + channel, &st, sizeof st, hipMemcpyHostToDevice));
     if (!e->last_frame.empty()) { memset(e->last_frame.data() + (size_t)channel * 518, 0, 518); memcpy(e->last_frame.data() + (size_t)channel * 518, kRs41HeaderBytes, 8); }
     if (!e->m10_bits.empty()) { const size_t per = e->m10_bits.size() / (size_t)C; memset(e->m10_bits.data() + (size_t)channel * per, 0, per); }
+    if (e->d_m10_bits) { const size_t per = (101 + 20) * 8 + 8; HIPCHK(hipStreamSynchronize(e->stream_b)); HIPCHK(hipMemset(e->d_m10_bits + (size_t)channel * per, 0, per)); }
     return 0;
 }
 
@@ -1215,6 +1285,14 @@ int sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq) {
 int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) {
     if (!e || !soft || !e->d_soft) return SONDE_E_ARG;
     const int n = std::min(e->last_n, (int)max_frames);
+    if (e->soft_lazy) {
+        // the last fetch left the soft bits on the device (block codes decoded there): their ring slots now
+        for (int i = 0; i < n; i++) {
+            const unsigned idx = (e->soft_lazy_start + (unsigned)i) % (unsigned)e->max_frames;
+            if (hipMemcpy(soft + (size_t)i * e->nbits, e->d_soft + (size_t)idx * e->nbits, (size_t)e->nbits * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        }
+        return n;
+    }
     memcpy(soft, e->last_soft.data(), (size_t)n * e->nbits * sizeof(float));
     return n;
 }

@@ -477,6 +477,131 @@ void k_softin_m10(const SoftinM10Args A) {
     if (lane == 0) { st->mode = mode; st->inv = inv; st->mpos = mpos; st->mhalf = mhalf; st->mbit0 = mbit0; st->mskip = mskip; st->ms1 = ms1; st->mv = mv_hdr; st->hdr_bit = hdr_bit; st->bits_in = bits0 + (unsigned long long)nb; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same block codes for the BASE-RATE engine's hits (sonde_engine.cpp): what sonde_engine_fetch_dfm / _m10 used to do per frame on one host thread
+// now runs over the records a process call has queued, behind its frame-sync kernel on the same stream.  Only decoded frames come to the host (DFM: 8 x 104 bytes
+// a hit instead of 2224 soft bits).
+//   DFM (dfm09mod.c:1652-1717, :231-345): a hit = frame 0 (bits 16..279, the header went to the correlator) + 7 x 280 bits; de-interleave, Hamming(8,4) per
+//        codeword on a lane (hard, or --ecc2's soft 2-bit pass), block status by ballot
+//   M10 (m10mod.c:1484, :141-166, :594-628): differential decoding into the channel's persistent bit characters, bits2bytes, checkM10
+// Records [*done, *fcount) of the ring; the last workgroup to finish moves *done up (done[1] is its ticket counter).
+// ------------------------------------------------------------------------------------------------
+#include "sonde_dev.h"
+__global__ __launch_bounds__(64)
+void k_dfm_hits(const FrameRec *frames, const float *soft, const int nbits, const int max_frames, const unsigned *fcount, unsigned *done, sonde_dfm_frame_t *out, const int ecc_level) {
+    __shared__ unsigned char s_hb[280];
+    __shared__ float s_sf[280];
+    const int lane = threadIdx.x;
+    const unsigned end = *fcount; unsigned start = done[0];
+    if ((int)(end - start) > max_frames) start = end - (unsigned)max_frames;       // (what the ring no longer holds)
+    for (unsigned i = start + blockIdx.x; (int)(end - i) > 0; i += gridDim.x) {
+        const unsigned idx = i % (unsigned)max_frames;
+        const FrameRec &r = frames[idx];
+        const float *sb = soft + (size_t)idx * nbits;
+        for (int f = 0; f < 8; f++) {
+            const int first = f == 0 ? 0 : 264 + 280 * (f - 1), skip = f == 0 ? 16 : 0;
+            sonde_dfm_frame_t *o = out + (size_t)idx * 8 + f;
+            if (first + (280 - skip) > r.nbytes) { if (lane == 0) o->frame_in_hit = -1; continue; }       // nbytes = valid bits of the hit; a partial frame is dropped
+            for (int k = lane; k < 280; k += 64) {
+                const int b = first + k - skip;
+                s_hb[k] = k < skip ? 0 : (unsigned char)((r.frame[b >> 3] >> (b & 7)) & 1);
+                s_sf[k] = k < skip ? 0.f : sb[b];
+            }
+            __builtin_amdgcn_wave_barrier();
+            int e = 0; unsigned char nib = 0;
+            const int blk = lane < 7 ? 0 : lane < 20 ? 1 : 2, ci = lane < 7 ? lane : lane < 20 ? lane - 7 : lane - 20;
+            const int L = blk == 0 ? 7 : 13, off = blk == 0 ? 16 : blk == 1 ? 72 : 176;
+            if (lane < 33) {
+                unsigned char c[8]; float sv[8];
+                for (int j = 0; j < 8; j++) { c[j] = s_hb[off + L * j + ci]; sv[j] = s_sf[off + L * j + ci]; }
+                if (ecc_level) e = dfm_dev_check(ecc_level, c, sv);
+                nib = (unsigned char)((c[0] << 3) | (c[1] << 2) | (c[2] << 1) | c[3]);
+            }
+            const unsigned long long fixed = __ballot(lane < 33 && e > 0), bad = __ballot(lane < 33 && e < 0);
+            if (lane < 7) o->conf[ci] = nib; else if (lane < 20) o->dat1[ci] = nib; else if (lane < 33) o->dat2[ci] = nib;
+            if (lane < 35) { unsigned char rb = 0; for (int b = 0; b < 8; b++) rb |= (unsigned char)((s_hb[8 * lane + b] & 1) << b); o->rawbits[lane] = rb; }
+            if (lane == 0) {
+                o->channel = r.channel; o->frame_in_hit = f; o->mv = r.mv; o->mv_pos = r.mv_pos; o->frm_count = 0.f;     // (positions relative to the channel's start: the host, which knows it)
+                o->inv = r.mv < 0.f; o->pad[0] = o->pad[1] = o->pad[2] = 0; o->pad2 = 0;
+                o->ecc[0] = ((bad & 0x7Full) ? -1 : 0) | (int)(fixed & 0x7Full);
+                o->ecc[1] = (((bad >> 7) & 0x1FFFull) ? -1 : 0) | (int)((fixed >> 7) & 0x1FFFull);
+                o->ecc[2] = (((bad >> 20) & 0x1FFFull) ? -1 : 0) | (int)((fixed >> 20) & 0x1FFFull);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __threadfence();
+    if (lane == 0 && atomicAdd(&done[1], 1u) == gridDim.x - 1) { done[1] = 0; done[0] = end; }
+}
+
+__global__ __launch_bounds__(64)
+void k_m10_hits(const FrameRec *frames, const float *soft, const float *soft1, const int chk3, const int nbits, const int max_frames, const unsigned *fcount, unsigned *done,
+                char *chan_bits, sonde_m10_frame_t *out) {
+    constexpr int NBYTES = 101 + 20, NB = NBYTES * 8;
+    __shared__ unsigned char s_fr[124];
+    const int lane = threadIdx.x;
+    const unsigned end = *fcount; unsigned start = done[0];
+    if ((int)(end - start) > max_frames) start = end - (unsigned)max_frames;
+    for (unsigned i = start; (int)(end - i) > 0; i++) {
+        const unsigned idx = i % (unsigned)max_frames;
+        const FrameRec &r = frames[idx];
+        if ((unsigned)r.channel % gridDim.x != blockIdx.x) continue;          // a channel's records in order, by one workgroup: its bit characters persist from frame to frame
+        char *fb = chan_bits + (size_t)r.channel * (NB + 8);
+        const int nv = r.nbytes < NB ? r.nbytes : NB;                          // nbytes = valid bits of the hit
+        const float *sb = soft + (size_t)idx * nbits, *sb1 = soft1 ? soft1 + (size_t)idx * nbits : nullptr;
+        auto bit_at = [&](const int p) -> int {
+            // --chk3 (m10mod.c:1476-1479): the bit from both soft values of read_softbit2p, (sb + 0.25 sb1) >= 0
+            if (chk3 && sb1) return ((double)sb[p] + 0.25 * (double)sb1[p]) >= 0.0;
+            return (r.frame[p >> 3] >> (p & 7)) & 1;
+        };
+        for (int p = lane; p < nv; p += 64) {
+            const int bit = bit_at(p), prev = p == 0 ? 0x30 : bit_at(p - 1);  // differential decoding: 1 = same as the previous bit; the first against '0' (m10mod.c:1484)
+            fb[p] = (char)(0x31 ^ (prev ^ bit));
+        }
+        if (lane == 0) fb[nv] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int k = lane; k < 124; k += 64) {
+            unsigned v = 0;
+            if (k < NBYTES) for (int q = 0; q < 8; q++) if (fb[8 * k + 7 - q] == '1') v |= 1u << q;       // bits2bytes, big endian; anything but '1' counts as 0
+            s_fr[k] = (unsigned char)v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        sonde_m10_frame_t *o = out + idx;
+        for (int k = lane; k < 124; k += 64) o->frame[k] = s_fr[k];
+        if (lane == 0) {
+            int aux = s_fr[0] - 0x64;
+            if (aux < 0 || aux > 20) aux = 0;
+            int c = 0;
+            for (int k = 0; k < 99 + aux; k++) {                            // checkM10 (m10mod.c:594-628)
+                unsigned char b = s_fr[k];
+                b = (unsigned char)((b >> 1) | ((b & 1) << 7));
+                b ^= (b >> 2) & 0xFF;
+                const int t6 = (c & 1) ^ ((c >> 2) & 1) ^ ((c >> 4) & 1), t7 = ((c >> 1) & 1) ^ ((c >> 3) & 1) ^ ((c >> 5) & 1);
+                const int t = (c & 0x3F) | (t6 << 6) | (t7 << 7);
+                int sreg = (c >> 7) & 0xFF;
+                sreg ^= (sreg >> 2) & 0xFF;
+                c = (((c & 0xFF) << 8) | ((b ^ t ^ sreg) & 0xFF)) & 0xFFFF;
+            }
+            o->channel = r.channel; o->nbits = nv; o->len = 101 + aux; o->cs_calc = (uint32_t)c;
+            o->cs_ok = ((uint32_t)((s_fr[99 + aux] << 8) | s_fr[100 + aux]) == (uint32_t)c);
+            o->mv = r.mv; o->mv_pos = r.mv_pos;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __threadfence();
+    if (lane == 0 && atomicAdd(&done[1], 1u) == gridDim.x - 1) { done[1] = 0; done[0] = end; }
+}
+
+extern "C" void sonde_launch_dfm_hits(const FrameRec *frames, const float *soft, int nbits, int max_frames, const unsigned *fcount, unsigned *done, sonde_dfm_frame_t *out,
+                                      int ecc_level, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_dfm_hits, dim3(grid), dim3(64), 0, s, frames, soft, nbits, max_frames, fcount, done, out, ecc_level);
+}
+extern "C" void sonde_launch_m10_hits(const FrameRec *frames, const float *soft, const float *soft1, int chk3, int nbits, int max_frames, const unsigned *fcount, unsigned *done,
+                                      char *chan_bits, sonde_m10_frame_t *out, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(k_m10_hits, dim3(grid), dim3(64), 0, s, frames, soft, soft1, chk3, nbits, max_frames, fcount, done, chan_bits, out);
+}
+
 extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *flen, const unsigned *count, int cap, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                               const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
 extern "C" int sonde_fsk_wait(sonde_fsk_t *f);
