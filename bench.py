@@ -12,6 +12,7 @@
       configs[3], each with its own ms_per_step / roofline / cpu_baseline — the objects `--config scan_wide|fsk_mixed` print on their own).
   --config scan_wide (BASELINE configs[2]): 256 channels out of ONE 10 Msps stream -> dft_detect scanner, per 0.2 s of stream.
   --config fsk_mixed (BASELINE configs[3]): 1024 mixed RS41 / DFM09 / M10 channels through the 2-FSK modem (fsk_demod path).
+  --config mixed_2400k (BASELINE configs[4] at configs[3]'s type mix): 512 channels at 2.4 Msps, 50 % RS41 / 30 % DFM09 / 20 % M10, demodulated and block-decoded on the device.
 
   python bench.py --gpus 1 [--config demod] [--steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -426,7 +427,7 @@ def bench_demod(args, D: Dist):
         out["cpu_baseline"] = cpu_baseline_demod(fqs, caps)
     if D.world == 1 and not args.no_extras and not args.no_configs:
         import bench_configs
-        for name in ("scan_wide", "fsk_mixed"):                           # BASELINE configs[2] and [3] in the same line (short runs)
+        for name in ("scan_wide", "fsk_mixed", "mixed_2400k"):            # BASELINE configs[2], [3] and [4] at [3]'s type mix in the same line (short runs)
             sub = argparse.Namespace(**vars(args))
             sub.config, sub.steps, sub.warmup, sub.channels, sub.cpu_budget = name, None, None, 0, 6.0
             try:
@@ -561,7 +562,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="demod", choices=["demod", "scan_wide", "fsk_mixed"])
+    ap.add_argument("--config", default="demod", choices=["demod", "scan_wide", "fsk_mixed", "mixed_2400k"])
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (0 = the configuration's own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="demod: skip the detect / PCIe-inclusive extras")

@@ -334,6 +334,143 @@ def bench_fsk_mixed(args, D, short=False):
     return out
 
 
+def bench_mixed_2400k(args, D, short=False):
+    """BASELINE configs[4] with the sonde types of configs[3]: channels at the base rate (2.4 Msps IQ each) through mix -> decimate -> FM -> header search -> frame
+    sync -> block code, half of them RS41 (Reed-Solomon (255,231) x 2), 30 % DFM09 (Hamming(8,4), eight frames per hit) and 20 % M10 (differential code, checksum),
+    one engine per type on its own streams, every block code on the device.  A step = one second of every channel; only decoded frames cross to the host.
+    Untimed, first: two seconds of every channel against the compiled reference decoders on the same samples (oracle/_ref, test infrastructure), line for line.
+    `host_decode_ab`: the same steps with the block codes on the host inside the fetch (what the device kernels replace)."""
+    torch = D.torch
+    import subprocess
+    from tools import synth
+    from radiosonde_auto_rx_amd.engine import Engine
+    SR = 2_400_000
+    C = args.channels or 512
+    n_dfm, n_m10 = (3 * C) // 10, C // 5
+    n_rs = C - n_dfm - n_m10
+    rng = np.random.default_rng(4242)
+    kinds = {}
+    for kind, n in (("rs41", n_rs), ("dfm", n_dfm), ("m10", n_m10)):
+        fqs, caps = [], []
+        for b in range(4):
+            fq = synth.snap_fq(float(rng.uniform(-0.4, 0.4)), SR)
+            if kind == "rs41":
+                cap = synth.rs41_capture(sr=SR, seconds=1.0, fq=fq, n_frames=1, t_first=0.15, seed=300 + b, noise_sigma=0.01, bit_errors=(0, 6, 14, 30)[b])
+            elif kind == "dfm":
+                cap = synth.dfm_capture(sr=SR, seconds=1.0, fq=fq, noise_sigma=0.02, seed=310 + b, bit_errors_per_frame=b % 3, t_first=0.02)
+            else:
+                cap = synth.m10_capture(sr=SR, seconds=1.0, fq=fq, noise_sigma=0.02, seed=320 + b, t_first=0.3,
+                                        frame_fn=lambda k, b=b: synth.m10_frame(k, rng=np.random.default_rng(500 + 10 * b + k), good_checksum=(k + b) % 4 != 3))
+            fqs.append(fq); caps.append(cap)
+        bank = [c % 4 for c in range(n)]
+        X = torch.from_numpy(np.stack(caps)).to(D.dev).index_select(0, torch.tensor(bank, device=D.dev)).contiguous()
+        kinds[kind] = dict(n=n, fqs=fqs, caps=caps, bank=bank, X=X)
+
+    def make(kind):
+        k = kinds[kind]
+        ch_fq = [k["fqs"][b] for b in k["bank"]]
+        if kind == "rs41":
+            return Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * k["n"])
+        return Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, sonde=kind, ecc=1 if kind == "dfm" else 0, max_chunk=SR, max_frames=4 * k["n"])
+
+    # ---- untimed: two seconds of every channel against the reference decoders
+    ref_bin = {"rs41": ("rs41mod", ["-r", "--ecc2"]), "dfm": ("dfm09mod", ["-r", "--ecc"]), "m10": ("m10mod", ["-r", "-v"])}
+    try:
+        from oracle import bind
+        have_ref = bind.have_ref()
+    except Exception:
+        have_ref = False
+    verified = {k: 0 for k in kinds}
+    vnote = "compiled reference not present"
+    for kind, k in kinds.items():
+        eng = make(kind)
+        got = {}
+        for sec in range(2):
+            eng.process_device(k["X"].data_ptr(), SR, SR)
+            fin = sec == 1
+            frames = eng.fetch_frames(finish=fin) if kind == "rs41" else eng.fetch_dfm(finish=fin) if kind == "dfm" else eng.fetch_mxx(finish=fin)
+            for f in frames:
+                got.setdefault(f["channel"], []).append(f["line"].rstrip())
+        eng.close()
+        if have_ref:
+            want = {}
+            for b in range(4):
+                exe, a = ref_bin[kind]
+                r = subprocess.run([os.path.join(bind.REFDIR, exe)] + a + ["--IQ", repr(k["fqs"][b]), "--lpIQ", "-", str(SR), "16"], input=k["caps"][b].tobytes() * 2,
+                                   capture_output=True, timeout=300)
+                want[b] = [l.rstrip() for l in r.stdout.decode().splitlines()]
+            verified[kind] = sum(int(len(want[k["bank"][c]]) >= 1 and got.get(c, []) == want[k["bank"][c]]) for c in range(k["n"]))
+            vnote = ("two seconds of every channel (the capture twice, end of input behind them): the text lines of our frames equal the stdout of oracle/_ref/{rs41mod -r --ecc2, "
+                     "dfm09mod -r --ecc, m10mod -r -v} --IQ fq --lpIQ - 2400000 16 on the same samples")
+
+    # ---- timed
+    engs = {kind: make(kind) for kind in kinds}
+    order = ["rs41", "dfm", "m10"]
+    tallies = {k: [0, 0] for k in kinds}
+
+    def step(count=True):
+        for kind in order:
+            engs[kind].process_device(kinds[kind]["X"].data_ptr(), SR, SR)
+        fr = engs["rs41"].fetch_frames_np()
+        buf_d, n_d = engs["dfm"].fetch_dfm_raw()
+        buf_m, n_m = engs["m10"].fetch_m10_raw()
+        if count:
+            tallies["rs41"][0] += len(fr); tallies["rs41"][1] += int((fr["ecc"] >= 0).sum())
+            if n_d:
+                a = np.frombuffer(buf_d, np.dtype([("h", "<i4", (2,)), ("ecc", "<i4", (3,)), ("rest", "u1", (88,))]), n_d)
+                tallies["dfm"][0] += n_d; tallies["dfm"][1] += int((a["ecc"] >= 0).all(axis=1).sum())
+            if n_m:
+                a = np.frombuffer(buf_m, np.dtype([("h", "<i4", (3,)), ("cs_ok", "<i4"), ("rest", "u1", (136,))]), n_m)
+                tallies["m10"][0] += n_m; tallies["m10"][1] += int((a["cs_ok"] != 0).sum())
+
+    def timed(min_seconds):
+        for _ in range(3):
+            step(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            step()
+            n += 1
+            if n >= 8 and time.perf_counter() - t0 >= min_seconds:
+                break
+        for e in engs.values():
+            e.sync()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, n
+
+    for v in tallies.values():
+        v[0] = v[1] = 0
+    per, nsteps = timed(1.0)
+    counts = {k: (v[0] / nsteps, v[1] / nsteps) for k, v in tallies.items()}
+    # A/B: the block codes on the host inside the fetch
+    for e in engs.values():
+        e.set_device_ecc(False)
+    per_host, nh = timed(1.0)
+    for e in engs.values():
+        e.set_device_ecc(True); e.close()
+    total = C * SR
+    out = None
+    if D.rank == 0:
+        out = {
+            "metric": "IQ Msamples/s demodulated + block-decoded, mixed RS41 / DFM09 / M10 channels at the base rate", "value": round(D.world * total / per / 1e6, 1), "unit": "Msamples/s",
+            "n_gpus": D.world, "steps": nsteps, "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] at configs[3]'s type mix: %d channels x 2.4 Msps cs16 IQ per GPU — %d RS41 (rs41mod --ecc2), %d DFM09 (dfm09mod --ecc), %d M10 — "
+                                   "mix -> decimate -> FM -> header search -> frame sync -> block code on the device, one engine per type; 1 s per channel per step" % (C, n_rs, n_dfm, n_m10),
+                       "channels": {"rs41": n_rs, "dfm": n_dfm, "m10": n_m10}, "realtime_channels": round(total / per / SR, 1),
+                       "frames_per_step": {k: round(v[0], 1) for k, v in counts.items()},
+                       "frames_ok_per_step": {k: round(v[1], 1) for k, v in counts.items()},
+                       "frames_ok_means": "rs41: rs41_ecc() >= 0; dfm: hamming() >= 0 in all three blocks; m10: checksum equal",
+                       "verified_channels": verified, "checked_channels": {k: v["n"] for k, v in kinds.items()}, "verify_note": vnote},
+            "host_decode_ab": {"ms_per_step": round(per_host * 1e3, 3), "steps": nh,
+                               "note": "sonde_engine_set_device_ecc(0) on all three engines: Reed-Solomon from the device syndromes, Hamming(8,4) and the M10 differential "
+                                       "decoding + checksum on one host thread inside the fetch, soft bits of every DFM / M10 hit copied to the host"},
+        }
+    return out
+
+
 def run(args, D, short=False):
     """short: the reduced runs the default `bench.py` line carries as its `scan_wide` / `fsk_mixed` objects"""
+    if args.config == "mixed_2400k":
+        return bench_mixed_2400k(args, D, short)
     return bench_scan_wide(args, D, short) if args.config == "scan_wide" else bench_fsk_mixed(args, D, short)

@@ -290,6 +290,20 @@ class Engine:
             return frames, soft[:nh]
         return frames
 
+    def fetch_dfm_raw(self, finish: bool = False):
+        """DFM engines: the decoded frames as a ctypes array of sonde_dfm_frame_t and their count — no per-frame Python work (the batch caller's form)."""
+        n = 8 * self._max_frames
+        if getattr(self, "_dfmbuf", None) is None:
+            self._dfmbuf = (SondeDfmFrame * n)()
+        return self._dfmbuf, _chk(lib().sonde_engine_fetch_dfm(self._h, self._dfmbuf, n, int(finish)))
+
+    def fetch_m10_raw(self, finish: bool = False):
+        """M10 engines: the frames as a ctypes array of sonde_m10_frame_t and their count — no per-frame Python work."""
+        n = 4 * self._max_frames
+        if getattr(self, "_m10buf", None) is None:
+            self._m10buf = (SondeM10Frame * n)()
+        return self._m10buf, _chk(lib().sonde_engine_fetch_m10(self._h, self._m10buf, n, int(finish)))
+
     def fetch_hits(self, finish: bool = False):
         """Function-level seam: header hits (score, position, polarity) with their soft bits, any sonde type (needs keep_soft)."""
         n = self._max_frames
