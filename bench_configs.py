@@ -22,23 +22,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def _timed_steps(D, step, steps, warmup, min_seconds=0.0):
+def _timed_steps(D, step, steps, warmup, min_seconds=0.0, drain=None, run_n=None):
     """-> (seconds, per-rank seconds, steps timed).  min_seconds: the step count is raised (from a probe of three untimed steps, the same count on every rank) until
-    the timed region is at least that long — the sub-configurations of the default line are timed over >= 1 s like the headline, not over a few milliseconds."""
-    for _ in range(warmup):
-        step()
+    the timed region is at least that long — the sub-configurations of the default line are timed over >= 1 s like the headline, not over a few milliseconds.
+    drain: called behind the last step of every group of steps, inside the timed region — completes what a pipelined step leaves in flight.
+    run_n: instead of `step` / `drain`: run_n(n) does n steps and completes them (a configuration whose steps are driven from several host threads)."""
+    drain = drain or (lambda: None)
+    if run_n is None:
+        def run_n(n):
+            for _ in range(n):
+                step()
+            drain()
+    run_n(warmup)
     if min_seconds > 0:
         D.barrier()
         t0 = time.perf_counter()
-        for _ in range(3):
-            step()
+        run_n(3)
         D.barrier()
         probe, _ = D.finish_times(time.perf_counter() - t0)
         steps = max(steps, int(min_seconds / max(probe / 3, 1e-6)) + 1)
     D.barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run_n(steps)
     D.barrier()
     dt, per = D.finish_times(time.perf_counter() - t0)
     return dt, per, steps
@@ -253,26 +258,54 @@ def bench_fsk_mixed(args, D, short=False):
                 g = got.get(c, [])
                 cons["ok"] += int(have_ref and len(g) >= 1 and g == want[c % 4][:len(g)])
 
-    # the three modem configurations are three engines with a stream each: a step submits all three (sonde_fsk_submit_device: ring copy, launch, the channel
-    # records' way back — nothing waits), puts each family's consumer behind its modem on the same stream (sonde_softin_dev_submit_fsk: soft decisions ->
-    # frames -> block codes, all in device memory; only the frames come back), then collects.  One host thread, one wait per engine; the launches overlap on
-    # the GPU — one workgroup per channel (three or four waves, 17-45 KB of LDS).  
-    # (measured, profiles/r5f_fsk_mixed_order.txt: up to ~2000 channels the launches do not fill the GPU and the step ends with the last one submitted — the cheapest
-    # consumer (DFM) goes last; beyond, the CUs' LDS is what is contended and the largest footprint (RS41, 40 KB a channel) is best placed first)
+    # The three modem configurations are three engines with a stream each, driven by one host thread through the two-halves calls.  Per family and second k:
+    #   sonde_fsk_wait (k - 1)              the modem's launch of the second before is through (its channel records on the host)
+    #   sonde_softin_dev_collect (k - 2)    the frames of the consumer call that ran beside it
+    #   sonde_softin_dev_submit_fsk (k - 1) the consumer over launch k - 1's soft decisions, on the consumer's own stream: soft decisions -> frames -> block codes, all in
+    #                                       device memory; only the frames come back
+    #   sonde_fsk_submit_device (k)         ring copy, launch, the channel records' way back — nothing waits; it runs beside the consumer of k - 1 (the modem keeps the
+    #                                       soft decisions of two launches)
+    # The families are independent receivers: none waits for another's second.  A step = one second of all channels submitted; everything in flight — the last modem
+    # launches and both consumer calls behind them — is completed inside the timed region (`drain`).  One workgroup per channel (three or four waves, 17-41 KB of LDS).
+    # (a host thread per family was tried and is slower — 2.17 against 2.03 ms at 1024 channels: the HIP calls of the threads serialise — profiles/r5g_fsk_mixed_host_loop.txt;
+    # submission order, profiles/r5f_fsk_mixed_order.txt: up to ~2000 channels the launches do not fill the GPU; beyond, the CUs' LDS is what is contended and the
+    # largest footprint (RS41, 40 KB a channel) is best placed first)
     _ord = os.environ.get("SONDE_BENCH_ORDER", "m10,rs41,dfm" if C <= 2048 else "rs41,m10,dfm").split(",")
     order = sorted(engines, key=lambda e: _ord.index(e[0]))
+    barrier_every_step = bool(os.environ.get("SONDE_BENCH_FSK_BARRIER"))          # A/B: everything of a step completed before the next one starts
 
     cnt0 = {k: c["sf"].counts() for k, c in consumers.items()}
+    launched, consuming = set(), set()
+
+    def drain():
+        for kind, Fs, Rs, n, X, md, _, _ in order:
+            sf = consumers[kind]["sf"]
+            if kind in launched:
+                md.wait()
+            if kind in consuming:
+                sf.collect()
+            if kind in launched:
+                sf.submit_fsk(md)
+                sf.collect()
+        launched.clear(); consuming.clear()
+        torch.cuda.synchronize()
 
     def step():
         for kind, Fs, Rs, n, X, md, _, _ in order:
+            sf = consumers[kind]["sf"]
+            if kind in launched:
+                md.wait()
+            if kind in consuming:
+                sf.collect()
+            if kind in launched:
+                sf.submit_fsk(md)
+                consuming.add(kind)
             md.submit_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
-            consumers[kind]["sf"].submit_fsk(md)
-        for kind, Fs, Rs, n, X, md, _, _ in order:
-            consumers[kind]["sf"].collect()
-        torch.cuda.synchronize()
+            launched.add(kind)
+        if barrier_every_step:
+            drain()
 
-    dt, per, steps = _timed_steps(D, step, steps, warmup, 1.0 if not args.steps else 0.0)
+    dt, per, steps = _timed_steps(D, step, steps, warmup, 1.0 if not args.steps else 0.0, drain=drain)
     value = D.world * total_samples * steps / dt / 1e6
     kern = {kind: md.kernel_ms() for kind, _, _, _, _, md, _, _ in engines}
     cnt1 = {k: c["sf"].counts() for k, c in consumers.items()}
@@ -303,6 +336,10 @@ def bench_fsk_mixed(args, D, short=False):
                                   "frames_repaired": cnt1[k]["repaired"] - cnt0[k]["repaired"], "symbols_or_codewords_repaired": cnt1[k]["symbols"] - cnt0[k]["symbols"],
                                   "frames_dropped": cnt1[k]["dropped"] - cnt0[k]["dropped"], "verified_channels": consumers[k]["ok"], "checked_channels": consumers[k]["checked"]} for k in consumers},
                            "verify_note": fnote},
+                       "step": ("one second of all channels submitted; the three families are independent receivers — a family's consumer call over second k - 1 runs beside its "
+                                "modem launch of second k (own stream; the modem keeps two launches' soft decisions), no family waits for another's; all work in flight is "
+                                "completed inside the timed region" if not barrier_every_step else
+                                "one second of all channels, every family's modem and consumer completed before the next step starts (SONDE_BENCH_FSK_BARRIER)"),
                        "soft_decisions": "stay in device memory (copied to the host only when sonde_fsk_fetch asks for them): the consumers read them there"},
             "roofline": {"bound": "hbm", "kernel": "k_fsk_wave", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
                          "traffic": None, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel: a walker wave on the serial "

@@ -21,6 +21,8 @@ struct sonde_fsk {
     FskArgs args{};
     hipStream_t stream = nullptr;
     void *d_in = nullptr; float *d_hann = nullptr, *d_fmask = nullptr, *d_Sf = nullptr, *d_sd = nullptr, *d_eye = nullptr;
+    float *d_sd_alt = nullptr;                     // the soft decisions of the launch before the last: d_sd and d_sd_alt swap at every launch, so a consumer on the device
+                                                   // (sonde_softin_dev_submit_fsk) can still read launch k's while launch k + 1 runs
     unsigned long long *d_prof = nullptr;          // SONDE_FSK_PROF
     uint16_t *d_perm = nullptr, *d_iperm = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
@@ -93,7 +95,7 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     bad |= dupload(&f->d_hann, hann); bad |= dupload(&f->d_tw, tw); bad |= dupload(&f->d_perm, perm); bad |= dupload(&f->d_iperm, iperm); bad |= dupload(&f->d_dpeak, dpeak); bad |= dupload(&f->d_dmask, dmask);
     bad |= dupload(&f->d_fmask, fmask); bad |= dupload(&f->d_phift, phift);
     bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * M * a.NT);
-    bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_hb, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
+    bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_sd_alt, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_hb, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
     if (bad) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
     f->h_chan.resize(C);
     for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); for (int m = 0; m < 4; m++) c.phi_c[m] = exp_j(0); c.nin = N; }
@@ -149,7 +151,7 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         hipFree(f->d_prof);
     }
     if (!f->h_sd.empty()) { hipHostUnregister(f->h_sd.data()); hipHostUnregister(f->h_hb.data()); hipHostUnregister(f->h_recs.data()); hipHostUnregister(f->h_chan.data()); (void)hipGetLastError(); }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_iperm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_iperm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist, f->d_sd_alt };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -181,10 +183,16 @@ static int launch_enqueue(sonde_fsk_t *f) {
     }
     if (!f->ev0) { HIPCHK(hipEventCreate(&f->ev0)); HIPCHK(hipEventCreate(&f->ev1)); }
     f->h_chan_prev = f->h_chan;
-    HIPCHK(hipMemcpyAsync(f->d_Sf_bak, f->d_Sf, (size_t)C * Ndft * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
-    HIPCHK(hipMemcpyAsync(f->d_tail_bak, f->d_tail, (size_t)C * a.M * a.NT * sizeof(float2), hipMemcpyDeviceToDevice, f->stream));
+    // (the wave form of the modem keeps these two copies itself as it loads the state; the older kernels — SONDE_FSK_KERNEL, an A/B aid — get them from here)
+    static const bool old_kernel = getenv("SONDE_FSK_KERNEL") != nullptr || getenv("SONDE_FSK_STREAM") != nullptr;
+    if (old_kernel) {
+        HIPCHK(hipMemcpyAsync(f->d_Sf_bak, f->d_Sf, (size_t)C * Ndft * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
+        HIPCHK(hipMemcpyAsync(f->d_tail_bak, f->d_tail, (size_t)C * a.M * a.NT * sizeof(float2), hipMemcpyDeviceToDevice, f->stream));
+        a.Sf_bak = nullptr; a.tail_bak = nullptr;
+    } else { a.Sf_bak = f->d_Sf_bak; a.tail_bak = f->d_tail_bak; }
     { const char *t = getenv("SONDE_FSK_TEST_ABORT"); a.test_abort_ch = t ? atoi(t) : -1; }
     a.ch_list = nullptr; a.force_demod = 0;
+    std::swap(f->d_sd, f->d_sd_alt); a.sd = f->d_sd;
     hipEventRecord(f->ev0, f->stream);
     static const bool want_prof = getenv("SONDE_FSK_PROF") != nullptr;            // profiling aid: cycles per phase of channel 0, printed when the modem is destroyed
     if (want_prof && !f->d_prof) { if (hipMalloc((void **)&f->d_prof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(f->d_prof, 0, 32 * sizeof(unsigned long long)); }
@@ -216,7 +224,7 @@ static int launch_wait(sonde_fsk_t *f) {
     HIPCHK(hipMemcpyAsync(f->d_chlist, bad.data(), bad.size() * sizeof(int), hipMemcpyHostToDevice, f->stream));
     HIPCHK(hipStreamSynchronize(f->stream));               // (the copies read host vectors)
     FskArgs b = a;
-    b.ch_list = f->d_chlist; b.n_ch = (int)bad.size(); b.force_demod = 1; b.test_abort_ch = -1; b.prof = nullptr;
+    b.ch_list = f->d_chlist; b.n_ch = (int)bad.size(); b.force_demod = 1; b.test_abort_ch = -1; b.prof = nullptr; b.Sf_bak = nullptr; b.tail_bak = nullptr;
     const int lrc2 = sonde_launch_fsk(&b, f->stream);
     if (lrc2 < 0) return lrc2 == -1 ? SONDE_E_ARG : SONDE_E_NOGPU;
     { const int rc = collect_enqueue(f); if (rc) return rc; }
@@ -279,10 +287,11 @@ int sonde_fsk_wait(sonde_fsk_t *f) {
     if (!f) return SONDE_E_ARG;
     return launch_wait(f);
 }
-// (for sonde_softin_dev: the channels the last wait repeated — their list on the device)
-int sonde_fsk_last_repeats(sonde_fsk_t *f, const int **d_list, int *n) {
-    if (!f || !d_list || !n) return SONDE_E_ARG;
-    *d_list = f->d_chlist; *n = f->last_repeated;
+// (for sonde_softin_dev: frames per channel of the last launch, from the host's copy of the channel records — waits for a launch in flight)
+int sonde_fsk_host_frames(sonde_fsk_t *f, int32_t *out) {
+    if (!f || !out) return SONDE_E_ARG;
+    if (f->pending) { const int rc_ = launch_wait(f); if (rc_) return rc_; }
+    for (int c = 0; c < f->cfg.n_channels; c++) out[c] = f->h_chan[c].frames;
     return 0;
 }
 

@@ -61,6 +61,7 @@ struct FskArgs {
     unsigned long long *prof;         // profiling aid (SONDE_FSK_PROF): [16] shader-clock cycles per phase of channel 0's frames, summed; nullptr = off    // a launch over a LIST of channels with the frame-at-a-time kernel: how the host repeats the channels whose pipeline gave up (sonde_fsk.cpp launch_and_collect)
     const int *ch_list;               // [n_ch] channel of workgroup b (nullptr: b)
     int force_demod;                  // 1: k_fsk_demod even where the pipelined kernel applies
+    float *Sf_bak; float2 *tail_bak;  // where the wave form keeps Sf / the tone tails as they were before the launch (for the host's repeat of a channel that gave up); nullptr: the host copies
     int fin;                          // set by the launcher: the wave form's finisher is on (f_int twice in LDS)
     int role_rot;                     // set by the launcher: 0: roles in wavefront order; k > 0: the channel's roles start at wavefront (channel + k - 1) mod waves (sonde_fsk_wave.h)
     int wave_mode;                    // set by the launcher: 0 = k_fsk_stream / k_fsk_demod, 1 = k_fsk_wave one wave per channel, 2 = k_fsk_wave walker + worker (sonde_fsk_wave.h)

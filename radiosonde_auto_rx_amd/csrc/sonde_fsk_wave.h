@@ -296,7 +296,8 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
 
     // ---- set-up: the last NT f_dc samples of the previous launch in front of stream position 0, the control block
     if (is_worker) {
-        for (int m = 0; m < M; m++) for (int i = lane; i < NT; i += 64) s_ring[m * R + ((uint32_t)(i - NT) & rmask)] = tail_g[m * NT + i];
+        // (and aside, for the host's repeat of a channel whose launch gives up: a.tail_bak / a.Sf_bak — two copies the host would otherwise enqueue in front of every launch)
+        for (int m = 0; m < M; m++) for (int i = lane; i < NT; i += 64) { const float2 v = tail_g[m * NT + i]; s_ring[m * R + ((uint32_t)(i - NT) & rmask)] = v; if (a.tail_bak) a.tail_bak[(size_t)ch * M * NT + m * NT + i] = v; }
         if (lane == 0) {
             const bool f0 = frame_fits(0, 0u, st.nin);
             for (int q = 0; q < 2; q++) {
@@ -346,7 +347,7 @@ FW_DEV void fsk_wave_channel(const FskArgs &a, const int ch, const int tid, floa
             tw1[r] = a.tw[u * fs]; tw2[r] = a.tw[2 * u * fs]; tw3[r] = a.tw[3 * u * fs];
         }
 #pragma unroll
-        for (int r = 0; r < SPL; r++) sf[r] = Sf_g[lane + 64 * r];
+        for (int r = 0; r < SPL; r++) { sf[r] = Sf_g[lane + 64 * r]; if (a.Sf_bak) a.Sf_bak[(size_t)ch * NDFT + lane + 64 * r] = sf[r]; }
       }
     };
     auto est_fetch = [&](const int j0) {                        // the raw samples of round j0's blocks (one block per group of GL lanes)

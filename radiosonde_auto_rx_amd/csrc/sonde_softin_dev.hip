@@ -227,6 +227,7 @@ void k_softin_dfm(const SoftinDfmArgs A) {
     SoftinDfmChan *st = A.chan + ch;
     int nb = a.nbits;
     if (a.fsk_chan) { const int fr = a.fsk_chan[ch].frames; nb = fr > 0 ? fr * a.bits_per_frame : 0; }
+    else if (a.nbits_ch) nb = a.nbits_ch[ch];
     const float *x = a.sd + (size_t)ch * a.ch_stride;
     int mode = st->mode, inv = st->inv, dpos = st->dpos, dfrm = st->dfrm, dhalf = st->dhalf;
     float ds1 = st->ds1, mv_hdr = st->mv; unsigned hdrcnt = st->hdrcnt; unsigned long long hdr_bit = st->hdr_bit; const unsigned long long bits0 = st->bits_in;
@@ -357,6 +358,7 @@ void k_softin_m10(const SoftinM10Args A) {
     SoftinM10Chan *st = A.chan + ch;
     int nb = a.nbits;
     if (a.fsk_chan) { const int fr = a.fsk_chan[ch].frames; nb = fr > 0 ? fr * a.bits_per_frame : 0; }
+    else if (a.nbits_ch) nb = a.nbits_ch[ch];
     const float *x = a.sd + (size_t)ch * a.ch_stride;
     constexpr int NBITS = 121 * 8;
     int mode = st->mode, inv = st->inv, mpos = st->mpos, mhalf = st->mhalf, mbit0 = st->mbit0, mskip = st->mskip;
@@ -605,7 +607,7 @@ extern "C" void sonde_launch_m10_hits(const FrameRec *frames, const float *soft,
 extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *flen, const unsigned *count, int cap, int level, int32_t *ecc, int32_t *codes, uint8_t *synd,
                                               const uint8_t *gf_exp, const uint8_t *gf_log, hipStream_t s);
 extern "C" int sonde_fsk_wait(sonde_fsk_t *f);
-extern "C" int sonde_fsk_last_repeats(sonde_fsk_t *f, const int **d_list, int *n);
+extern "C" int sonde_fsk_host_frames(sonde_fsk_t *f, int32_t *out);
 extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream);
 
 struct sonde_softin_dev {
@@ -621,7 +623,8 @@ struct sonde_softin_dev {
     std::vector<int> h_flen, h_ecc; std::vector<SoftinMeta> h_meta; std::vector<unsigned char> h_frames;
     unsigned *h_count = nullptr;                   // pinned: the counters of a call's two passes
     int head = 0;                                  // records copied to the host without asking how many there are (what a call of a second normally completes)
-    bool pending = false; hipStream_t pend_stream = nullptr; sonde_fsk_t *pend_modem = nullptr; bool registered = false;
+    bool pending = false; hipStream_t pend_stream = nullptr; bool registered = false;
+    int *h_nbits = nullptr, *d_nbits = nullptr;    // bits per channel of the modem launch a call consumes (pinned host copy, device copy)
 };
 
 extern "C" {
@@ -690,6 +693,8 @@ void sonde_softin_dev_destroy(sonde_softin_dev_t *s) {
     if (!s->h_dfm.empty()) hipHostUnregister(s->h_dfm.data());
     if (!s->h_m10.empty()) hipHostUnregister(s->h_m10.data());
     if (s->h_count) hipHostFree(s->h_count);
+    if (s->h_nbits) hipHostFree(s->h_nbits);
+    if (s->d_nbits) hipFree(s->d_nbits);
     (void)hipGetLastError();
     void *p[] = { s->d_chan, s->d_frames, s->d_hdr, s->d_gf, s->d_synd, s->d_flen, s->d_ecc, s->d_codes, s->d_meta, s->d_count, s->d_dfm_chan, s->d_dfm_out, s->d_m10_chan, s->d_m10_out };
     for (void *q : p) if (q) hipFree(q);
@@ -727,11 +732,11 @@ static int softin_copy(sonde_softin_dev *s, hipStream_t st, const int from, cons
     return 0;
 }
 // enqueue a call: the framer over what args.sd / nbits describe, the block code, the counter and the records a call normally completes (`head`) on their way to the host
-static int softin_enqueue(sonde_softin_dev *s, hipStream_t st, sonde_fsk_t *modem) {
+static int softin_enqueue(sonde_softin_dev *s, hipStream_t st) {
     if (s->pending) return SONDE_E_ARG;
     { const int rc = softin_pass(s, st, 0, s->C, nullptr, 0); if (rc) return rc; }
     { const int rc = softin_copy(s, st, 0, s->head); if (rc) return rc; }
-    s->pending = true; s->pend_stream = st; s->pend_modem = modem;
+    s->pending = true; s->pend_stream = st;
     return 0;
 }
 // the other half: wait, take what the head did not cover, queue the frames and add up the tallies
@@ -739,24 +744,10 @@ static int softin_finish(sonde_softin_dev *s) {
     if (!s->pending) return 0;
     hipStream_t st = s->pend_stream;
     s->pending = false;
-    int nrep = 0; const int *d_rep = nullptr;
-    if (s->pend_modem) {
-        // (the modem's wait is the stream's: the consumer's work sits behind the modem's launch.  Channels the modem had to repeat gave this call no bits
-        // — frames = -1 at the time, k_softin_* take nothing then — and get a pass of their own now, over the repeated launch's soft decisions)
-        const int rc = sonde_fsk_wait(s->pend_modem); if (rc) return rc;
-        sonde_fsk_last_repeats(s->pend_modem, &d_rep, &nrep);
-    }
     HIPCHK(hipStreamSynchronize(st));
     long long n = s->h_count[0];
     if (n > s->cap) { s->dropped += n - s->cap; n = s->cap; }
-    int have = (int)std::min<long long>(n, s->head);
-    if (nrep > 0 && n < s->cap) {
-        { const int rc = softin_pass(s, st, (int)n, nrep, d_rep, 1); if (rc) return rc; }
-        HIPCHK(hipStreamSynchronize(st));
-        long long n2 = s->h_count[1];
-        if (n + n2 > s->cap) { s->dropped += n + n2 - s->cap; n2 = s->cap - n; }
-        n += n2;
-    }
+    const int have = (int)std::min<long long>(n, s->head);
     if (n > have) { const int rc = softin_copy(s, st, have, (int)n); if (rc) return rc; HIPCHK(hipStreamSynchronize(st)); }
     if (s->type == SONDE_DFM09) {
         // (frames of one channel in order: the slots of a call are handed out in completion order per channel, channels interleave)
@@ -785,31 +776,45 @@ static int softin_finish(sonde_softin_dev *s) {
     return 0;
 }
 
-static int softin_bind_fsk(sonde_softin_dev *s, sonde_fsk_t *modem, hipStream_t *st) {
-    const float *d_sd = nullptr; long long cap = 0; const FskChan *d_chan = nullptr; int bpf = 0, nch = 0;
-    const int rc = sonde_fsk_dev_view(modem, &d_sd, &cap, &d_chan, &bpf, &nch, st);
+// the modem's last launch (waited for first: its channels' frame counts come from the host's copy of the records, and whatever the modem had to repeat is repeated by
+// then) as this call's input: the soft decisions where that launch left them, the bits per channel uploaded
+static int softin_bind_fsk(sonde_softin_dev *s, sonde_fsk_t *modem, hipStream_t st) {
+    const float *d_sd = nullptr; long long cap = 0; const FskChan *d_chan = nullptr; int bpf = 0, nch = 0; hipStream_t ms = nullptr;
+    { const int rc = sonde_fsk_wait(modem); if (rc) return rc; }
+    const int rc = sonde_fsk_dev_view(modem, &d_sd, &cap, &d_chan, &bpf, &nch, &ms);
     if (rc) return rc;
     if (nch != s->C) return SONDE_E_ARG;
+    if (!s->h_nbits) {
+        if (hipHostMalloc((void **)&s->h_nbits, (size_t)s->C * sizeof(int)) != hipSuccess || hipMalloc((void **)&s->d_nbits, (size_t)s->C * sizeof(int)) != hipSuccess) return SONDE_E_NOMEM;
+    }
+    { const int rc2 = sonde_fsk_host_frames(modem, s->h_nbits); if (rc2) return rc2; }
+    for (int c = 0; c < s->C; c++) s->h_nbits[c] = s->h_nbits[c] > 0 ? s->h_nbits[c] * bpf : 0;
+    HIPCHK(hipMemcpyAsync(s->d_nbits, s->h_nbits, (size_t)s->C * sizeof(int), hipMemcpyHostToDevice, st));
     SoftinArgs &a = s->args;
-    a.sd = d_sd; a.ch_stride = cap; a.fsk_chan = d_chan; a.bits_per_frame = bpf; a.nbits_ch = nullptr; a.nbits = 0;
+    a.sd = d_sd; a.ch_stride = cap; a.fsk_chan = nullptr; a.bits_per_frame = bpf; a.nbits_ch = s->d_nbits; a.nbits = 0;
+    return 0;
+}
+static int softin_own_stream(sonde_softin_dev *s) {
+    if (!s->stream) { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     return 0;
 }
 int sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
     if (!s || !modem) return SONDE_E_ARG;
     { const int rc = softin_finish(s); if (rc) return rc; }
-    hipStream_t st = nullptr;
-    { const int rc = softin_bind_fsk(s, modem, &st); if (rc) return rc; }
-    { const int rc = softin_enqueue(s, st, modem); if (rc) return rc; }
+    { const int rc = softin_own_stream(s); if (rc) return rc; }
+    { const int rc = softin_bind_fsk(s, modem, s->stream); if (rc) return rc; }
+    { const int rc = softin_enqueue(s, s->stream); if (rc) return rc; }
     return softin_finish(s);
 }
-// the same in two halves (as sonde_fsk_submit_device / sonde_fsk_wait): the consumer's kernels and copies are enqueued on the modem's stream BEHIND the launch
-// the modem has submitted — no host round trip between the two — and sonde_softin_dev_collect waits for both (it calls sonde_fsk_wait).
+// the same in two halves: submit waits for the modem's launch (sonde_fsk_wait), then enqueues the consumer's kernels and the copies of its frames on the consumer's OWN
+// stream and returns; collect waits for them.  In between the modem can be given its next second (sonde_fsk_submit_device): the modem keeps the soft decisions of two
+// launches (they alternate between two buffers), so the consumer of second k runs beside the modem of second k + 1.  Collect before the modem's launch after that.
 int sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
     if (!s || !modem) return SONDE_E_ARG;
     { const int rc = softin_finish(s); if (rc) return rc; }
-    hipStream_t st = nullptr;
-    { const int rc = softin_bind_fsk(s, modem, &st); if (rc) return rc; }
-    return softin_enqueue(s, st, modem);
+    { const int rc = softin_own_stream(s); if (rc) return rc; }
+    { const int rc = softin_bind_fsk(s, modem, s->stream); if (rc) return rc; }
+    return softin_enqueue(s, s->stream);
 }
 int sonde_softin_dev_collect(sonde_softin_dev_t *s) {
     if (!s) return SONDE_E_ARG;
@@ -822,7 +827,7 @@ int sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, int
     if (!s->stream) { HIPCHK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
     SoftinArgs &a = s->args;
     a.sd = d_soft; a.ch_stride = ch_stride; a.fsk_chan = nullptr; a.nbits_ch = nullptr; a.nbits = n_bits;
-    { const int rc = softin_enqueue(s, s->stream, nullptr); if (rc) return rc; }
+    { const int rc = softin_enqueue(s, s->stream); if (rc) return rc; }
     return softin_finish(s);
 }
 

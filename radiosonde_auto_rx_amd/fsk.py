@@ -186,7 +186,8 @@ class SoftinDev:
         _chk(_lib().sonde_softin_dev_push_fsk(self._h, modem._h))
 
     def submit_fsk(self, modem: "FskModem"):
-        """push_fsk without waiting: the consumer's kernels and frame copies go on the modem's stream behind the launch it has submitted; collect() waits for both"""
+        """push_fsk without waiting for the result: waits for the modem's launch, then enqueues the consumer on its own stream; the modem can be given its next second
+        (submit_device) before collect() — it keeps the soft decisions of two launches"""
         _chk(_lib().sonde_softin_dev_submit_fsk(self._h, modem._h))
 
     def collect(self):

@@ -280,9 +280,9 @@ def _pipe_case(kind):
 @pytest.mark.parametrize("abort", [False, True])
 @pytest.mark.parametrize("kind", ["rs41", "dfm", "m10"])
 def test_submit_and_collect_give_the_frames_of_the_synchronous_calls(monkeypatch, capfd, kind, abort):
-    """sonde_fsk_submit_device + sonde_softin_dev_submit_fsk, then sonde_softin_dev_collect: the consumer's kernels sit on the modem's stream behind its launch, no
-    host round trip between the two, one wait for both.  Same frames, same order per channel, same tallies as process + push; also when the modem has to repeat a
-    channel (test hook SONDE_FSK_TEST_ABORT: channel 1 gives up in every launch) — the consumer then takes that channel's bits in a pass of its own."""
+    """The two-halves calls in the order a pipelined caller uses them — wait (k - 1), collect (k - 2), submit_fsk (k - 1), submit_device (k): the consumer of a second runs
+    on its own stream beside the modem's next launch (the modem keeps two launches' soft decisions).  Same frames, same order per channel, same tallies as process + push;
+    also when the modem has to repeat a channel (test hook SONDE_FSK_TEST_ABORT: channel 1 gives up in every launch) — the wait repeats it before the consumer reads."""
     import torch
     x, sr, mk_modem, mk_cons, fetch = _pipe_case(kind)
     X = torch.from_numpy(np.stack([x, x, x])).cuda()
@@ -295,12 +295,18 @@ def test_submit_and_collect_give_the_frames_of_the_synchronous_calls(monkeypatch
             m = min(sr, n - s0)
             ptr = X.data_ptr() + 2 * s0 * X.element_size()
             if two_halves:
-                md.submit_device(ptr, n, m)
-                sf.submit_fsk(md)
-                sf.collect()
+                if s0 > 0:
+                    md.wait()
+                    sf.collect()
+                    sf.submit_fsk(md)               # the consumer over the launch before ...
+                md.submit_device(ptr, n, m)         # ... beside this one
             else:
                 md.process_device(ptr, n, m)
                 sf.push_fsk(md)
+            for f in getattr(sf, fetch)():
+                lines[f["channel"]].append(f["line"].rstrip())
+        if two_halves:
+            md.wait(); sf.collect(); sf.submit_fsk(md); sf.collect()
             for f in getattr(sf, fetch)():
                 lines[f["channel"]].append(f["line"].rstrip())
         c = sf.counts()
