@@ -314,6 +314,12 @@ def bench_fsk_mixed(args, D, short=False):
     # dominant kernel k_fsk_stream: algorithmic bytes = 4 B per complex cs16 input sample (soft decisions out: 4 B per symbol)
     # the three launches overlap: the rate follows from the step time, not from the sum of the kernels' own durations
     achieved = total_samples * 4 / (dt / steps) / 1e9
+    # HBM bytes of the three launches of a step from the committed counter passes of this command (tools/profile_round.sh), when taken on these launch geometries
+    from bench import _traffic
+    parts = [_traffic("fsk_" + kind, n * (X.shape[1] // 2) * 4) for kind, Fs, Rs, n, X, md, _, _ in engines]
+    traffic = round(sum(p[0] for p in parts), 4) if all(p[0] is not None for p in parts) else None
+    traffic_note = ("GB per step over the three launches (4 B per lane loads: FETCH_SIZE taken x 2 as for a wide stream — uncalibrated for this width, an upper bound; the raw "
+                    "counters are in profiles/%s_fsk_{rs41,dfm,m10}_traffic.json): the input is read once, the soft decisions written once" % __import__("bench").PROFILE_TAG) if traffic is not None else None
     out = None
     if D.rank == 0:
         out = {
@@ -342,7 +348,7 @@ def bench_fsk_mixed(args, D, short=False):
                                 "one second of all channels, every family's modem and consumer completed before the next step starts (SONDE_BENCH_FSK_BARRIER)"),
                        "soft_decisions": "stay in device memory (copied to the host only when sonde_fsk_fetch asks for them): the consumers read them there"},
             "roofline": {"bound": "hbm", "kernel": "k_fsk_wave", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                         "traffic": None, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel: a walker wave on the serial "
+                         "traffic": traffic, "traffic_note": traffic_note, "note": "4 B per complex input sample over the three (overlapping) launches; one workgroup per channel: a walker wave on the serial "
                                                   "oscillator recurrence (one dependent complex multiply per sample, as in the reference: ~31 cycles per sample, 0.6 ms per second of "
                                                   "signal whatever the channel count), worker / estimator / finisher waves beside it, one barrier per 128-sample piece: bound by that "
                                                   "chain and by the waves' own instruction latency, not by memory — see DESIGN.md 4.7 and profiles/r5*"},
