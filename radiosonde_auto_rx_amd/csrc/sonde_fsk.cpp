@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include "sonde_pinned.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "libsonde_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return SONDE_E_NOGPU; } } while (0)
 
@@ -26,8 +27,8 @@ struct sonde_fsk {
     unsigned long long *d_prof = nullptr;          // SONDE_FSK_PROF
     uint16_t *d_perm = nullptr, *d_iperm = nullptr;
     float2 *d_tw = nullptr, *d_dpeak = nullptr, *d_dmask = nullptr, *d_phift = nullptr, *d_tail = nullptr;
-    FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; std::vector<uint8_t> h_hb;
-    std::vector<FskChan> h_chan; std::vector<float> h_sd; std::vector<FskFrameRec> h_recs;
+    FskChan *d_chan = nullptr; FskFrameRec *d_recs = nullptr; uint8_t *d_hb = nullptr; Pinned<uint8_t> h_hb;
+    Pinned<FskChan> h_chan; Pinned<float> h_sd; Pinned<FskFrameRec> h_recs;          // page-locked landing buffers (sonde_pinned.h)
     bool pinned = false;
     size_t unit = 4;
     uint32_t wr = 0;
@@ -97,19 +98,15 @@ int sonde_fsk_create(const sonde_fsk_cfg_t *cfg, sonde_fsk_t **out) {
     bad |= dalloc(&f->d_eye, (size_t)C * 8 * 160); bad |= dalloc(&f->d_Sf, (size_t)C * Ndft); bad |= dalloc(&f->d_tail, (size_t)C * M * a.NT);
     bad |= dalloc(&f->d_sd, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_sd_alt, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_hb, (size_t)C * a.sd_cap); bad |= dalloc(&f->d_recs, (size_t)C * a.rec_cap); bad |= dalloc(&f->d_chan, (size_t)C, false);
     if (bad) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
-    f->h_chan.resize(C);
+    if (!f->h_chan.alloc(C)) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
     for (auto &c : f->h_chan) { memset(&c, 0, sizeof c); for (int m = 0; m < 4; m++) c.phi_c[m] = exp_j(0); c.nin = N; }
     HIPCHK(hipMemcpy(f->d_chan, f->h_chan.data(), (size_t)C * sizeof(FskChan), hipMemcpyHostToDevice));
     a.in = f->d_in; a.hann = f->d_hann; a.tw = f->d_tw; a.perm = f->d_perm; a.iperm = f->d_iperm; a.dphi_peak = f->d_dpeak; a.dphi_mask = f->d_dmask; a.f_mask = f->d_fmask;
     a.phi_ft = f->d_phift; a.chan = f->d_chan; a.Sf = f->d_Sf; a.eye = f->d_eye; a.tail = f->d_tail; a.sd = f->d_sd; a.hb = f->d_hb; a.recs = f->d_recs;
-    f->h_sd.resize((size_t)C * a.sd_cap); f->h_hb.resize((size_t)C * a.sd_cap); f->h_recs.resize((size_t)C * a.rec_cap);
+    if (!f->h_sd.alloc((size_t)C * a.sd_cap) || !f->h_hb.alloc((size_t)C * a.sd_cap) || !f->h_recs.alloc((size_t)C * a.rec_cap)) { sonde_fsk_destroy(f); return SONDE_E_NOMEM; }
     // the per-launch results come back into these (never resized again): page-locked, so that the copies are real asynchronous DMA and not staged through
     // a bounce buffer — with the pipelined kernel the copies of a thousand channels were a fifth of a step
-    f->pinned = hipHostRegister(f->h_sd.data(), f->h_sd.size() * sizeof(float), hipHostRegisterDefault) == hipSuccess
-             && hipHostRegister(f->h_hb.data(), f->h_hb.size(), hipHostRegisterDefault) == hipSuccess
-             && hipHostRegister(f->h_recs.data(), f->h_recs.size() * sizeof(FskFrameRec), hipHostRegisterDefault) == hipSuccess
-             && hipHostRegister(f->h_chan.data(), f->h_chan.size() * sizeof(FskChan), hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();                          // (registration is an optimisation: pageable buffers work too)
+    f->pinned = true;
     HIPCHK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     *out = f;
     return 0;
@@ -150,7 +147,6 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         }
         hipFree(f->d_prof);
     }
-    if (!f->h_sd.empty()) { hipHostUnregister(f->h_sd.data()); hipHostUnregister(f->h_hb.data()); hipHostUnregister(f->h_recs.data()); hipHostUnregister(f->h_chan.data()); (void)hipGetLastError(); }
     void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_iperm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist, f->d_sd_alt };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
@@ -182,7 +178,7 @@ static int launch_enqueue(sonde_fsk_t *f) {
         if (dalloc(&f->d_Sf_bak, (size_t)C * Ndft, false) || dalloc(&f->d_tail_bak, (size_t)C * a.M * a.NT, false) || dalloc(&f->d_chlist, (size_t)C, false)) return SONDE_E_NOMEM;
     }
     if (!f->ev0) { HIPCHK(hipEventCreate(&f->ev0)); HIPCHK(hipEventCreate(&f->ev1)); }
-    f->h_chan_prev = f->h_chan;
+    f->h_chan_prev.assign(f->h_chan.begin(), f->h_chan.end());
     // (the wave form of the modem keeps these two copies itself as it loads the state; the older kernels — SONDE_FSK_KERNEL, an A/B aid — get them from here)
     static const bool old_kernel = getenv("SONDE_FSK_KERNEL") != nullptr || getenv("SONDE_FSK_STREAM") != nullptr;
     if (old_kernel) {

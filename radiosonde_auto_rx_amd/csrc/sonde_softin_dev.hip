@@ -15,6 +15,7 @@
 #include "../../include/sonde_fsk.h"
 #include "sonde_fsk_dev.h"
 #include "sonde_host.h"
+#include "sonde_pinned.h"
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -612,18 +613,18 @@ extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long 
 
 struct sonde_softin_dev {
     int C = 0, ecc_level = 0, cap = 0, type = SONDE_RS41;
-    SoftinDfmChan *d_dfm_chan = nullptr; sonde_dfm_frame_t *d_dfm_out = nullptr; std::vector<sonde_dfm_frame_t> qdfm, h_dfm;
-    SoftinM10Chan *d_m10_chan = nullptr; sonde_m10_frame_t *d_m10_out = nullptr; std::vector<sonde_m10_frame_t> qm10, h_m10;
+    SoftinDfmChan *d_dfm_chan = nullptr; sonde_dfm_frame_t *d_dfm_out = nullptr; std::vector<sonde_dfm_frame_t> qdfm; Pinned<sonde_dfm_frame_t> h_dfm;
+    SoftinM10Chan *d_m10_chan = nullptr; sonde_m10_frame_t *d_m10_out = nullptr; std::vector<sonde_m10_frame_t> qm10; Pinned<sonde_m10_frame_t> h_m10;
     SoftinArgs args{};
     hipStream_t stream = nullptr; bool own_stream = false;
     SoftinChan *d_chan = nullptr; unsigned char *d_frames = nullptr, *d_hdr = nullptr, *d_gf = nullptr, *d_synd = nullptr;
     int *d_flen = nullptr, *d_ecc = nullptr, *d_codes = nullptr; SoftinMeta *d_meta = nullptr; unsigned *d_count = nullptr;
     std::vector<sonde_frame_t> queue;
     long long frames_total = 0, ecc_ok_total = 0, repaired_total = 0, symbols_total = 0, dropped = 0;
-    std::vector<int> h_flen, h_ecc; std::vector<SoftinMeta> h_meta; std::vector<unsigned char> h_frames;
+    Pinned<int> h_ecc; Pinned<SoftinMeta> h_meta; Pinned<unsigned char> h_frames;       // page-locked landing buffers of a call's records (sonde_pinned.h)
     unsigned *h_count = nullptr;                   // pinned: the counters of a call's two passes
     int head = 0;                                  // records copied to the host without asking how many there are (what a call of a second normally completes)
-    bool pending = false; hipStream_t pend_stream = nullptr; bool registered = false;
+    bool pending = false; hipStream_t pend_stream = nullptr;
     int *h_nbits = nullptr, *d_nbits = nullptr;    // bits per channel of the modem launch a call consumes (pinned host copy, device copy)
 };
 
@@ -659,7 +660,7 @@ int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_
         for (auto &c : di) { c.inv = opt_inv ? 1 : 0; c.dpos = 16; for (int i = 0; i < 16; i++) c.dhb[i] = (unsigned char)(kDfmHdr[i] & 1); }
         ok = hipMalloc((void **)&s->d_dfm_chan, C * sizeof(SoftinDfmChan)) == hipSuccess && hipMalloc((void **)&s->d_dfm_out, cap * sizeof(sonde_dfm_frame_t)) == hipSuccess
           && hipMemcpy(s->d_dfm_chan, di.data(), C * sizeof(SoftinDfmChan), hipMemcpyHostToDevice) == hipSuccess;
-        s->h_dfm.resize(cap);
+        ok = ok && s->h_dfm.alloc(cap);
     }
     if (ok && sonde_type == SONDE_M10) {
         std::vector<SoftinM10Chan> mi(C);
@@ -667,19 +668,14 @@ int sonde_softin_dev_create(int32_t n_channels, int32_t sonde_type, int32_t ecc_
         for (auto &c : mi) { c.inv = opt_inv ? 1 : 0; c.mbit0 = '0'; }
         ok = hipMalloc((void **)&s->d_m10_chan, C * sizeof(SoftinM10Chan)) == hipSuccess && hipMalloc((void **)&s->d_m10_out, cap * sizeof(sonde_m10_frame_t)) == hipSuccess
           && hipMemcpy(s->d_m10_chan, mi.data(), C * sizeof(SoftinM10Chan), hipMemcpyHostToDevice) == hipSuccess;
-        s->h_m10.resize(cap);
+        ok = ok && s->h_m10.alloc(cap);
     }
     if (!ok) { sonde_softin_dev_destroy(s); return SONDE_E_NOMEM; }
     SoftinArgs &a = s->args;
     a.n_ch = n_channels; a.inv_in = invert_stream ? 1 : 0; a.opt_auto = opt_auto ? 1 : 0; a.ths = sonde_type == SONDE_M10 ? 0.8f : 0.7f;
     a.chan = s->d_chan; a.frames = s->d_frames; a.flen = s->d_flen; a.meta = s->d_meta; a.count = s->d_count; a.cap = s->cap; a.hdr = s->d_hdr;
-    s->h_flen.resize(cap); s->h_ecc.resize(cap); s->h_meta.resize(cap); s->h_frames.resize(cap * 518);
+    if (!s->h_ecc.alloc(cap) || !s->h_meta.alloc(cap) || !s->h_frames.alloc(cap * 518)) { sonde_softin_dev_destroy(s); return SONDE_E_NOMEM; }
     s->head = std::min(s->cap, (sonde_type == SONDE_DFM09 ? 5 : 1) * n_channels + 16);
-    // (pinned, so that the copies behind the kernels really are asynchronous; not fatal when the registration fails)
-    s->registered = hipHostRegister(s->h_ecc.data(), cap * 4, hipHostRegisterDefault) == hipSuccess && hipHostRegister(s->h_meta.data(), cap * sizeof(SoftinMeta), hipHostRegisterDefault) == hipSuccess
-                 && hipHostRegister(s->h_frames.data(), cap * 518, hipHostRegisterDefault) == hipSuccess
-                 && (s->h_dfm.empty() || hipHostRegister(s->h_dfm.data(), cap * sizeof(sonde_dfm_frame_t), hipHostRegisterDefault) == hipSuccess)
-                 && (s->h_m10.empty() || hipHostRegister(s->h_m10.data(), cap * sizeof(sonde_m10_frame_t), hipHostRegisterDefault) == hipSuccess);
     (void)hipGetLastError();
     *out = s;
     return 0;
@@ -689,9 +685,6 @@ void sonde_softin_dev_destroy(sonde_softin_dev_t *s) {
     if (!s) return;
     if (s->pending && s->pend_stream) (void)hipStreamSynchronize(s->pend_stream);
     if (s->own_stream && s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
-    if (!s->h_ecc.empty()) { hipHostUnregister(s->h_ecc.data()); hipHostUnregister(s->h_meta.data()); hipHostUnregister(s->h_frames.data()); }
-    if (!s->h_dfm.empty()) hipHostUnregister(s->h_dfm.data());
-    if (!s->h_m10.empty()) hipHostUnregister(s->h_m10.data());
     if (s->h_count) hipHostFree(s->h_count);
     if (s->h_nbits) hipHostFree(s->h_nbits);
     if (s->d_nbits) hipFree(s->d_nbits);

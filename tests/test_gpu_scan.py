@@ -381,3 +381,32 @@ def test_scan_one_pass_front_end_with_a_moving_offset_in_the_passband(monkeypatc
         two = run(chunks)
         for st in range(12):
             assert np.abs(one[st] - two[st]).max() < 2e-4, (chunks, st, np.abs(one[st] - two[st]).max())
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_cli_dft_detect_with_a_large_iq_offset_and_a_weak_signal_matches_the_compiled_reference(two_pass):
+    """The scanner's base-rate front end under the condition its one-pass form is most exposed to: an IQ offset of 15 % / -11 % of full scale, moving,
+    over a signal of 3 % of full scale.  `dft_detect -v --IQ fq --dc` on the 2.4 Msps stream: stdout (type, score to four places, offset) and the exit code of
+    host/bin/dft_detect equal those of the compiled reference (oracle/_ref/dft_detect) run here on the same bytes, in the one-pass form (default) and the two-pass form."""
+    from golden_cases import need_ref
+    need_ref()
+    from tools import synth
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    sr = 2_400_000
+    fq = synth.snap_fq(0.0003, sr)                                                   # in the decimator's passband next to DC: the offset is not filtered away
+    x = synth.rs41_capture(sr=sr, seconds=2.2, fq=fq, f_offset_hz=600.0, amp=0.03, noise_sigma=0.003, t_first=0.15, seed=91).astype(np.float64)
+    n = len(x) // 2
+    t = np.arange(n) / sr
+    x[0::2] += 32768 * (0.15 + 0.03 * np.sin(2 * np.pi * 2.3 * t))
+    x[1::2] += 32768 * (-0.11 + 0.02 * t)
+    raw = np.clip(np.round(x), -32768, 32767).astype(np.int16).tobytes()
+    args = ["-v", "--IQ", repr(fq), "--dc", "-", str(sr), "16"]
+    want = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "dft_detect")] + args, input=raw, capture_output=True, timeout=300)
+    env = dict(os.environ)
+    env.pop("SONDE_SCAN_TWO_PASS", None)
+    if two_pass:
+        env["SONDE_SCAN_TWO_PASS"] = "1"
+    got = subprocess.run([os.path.join(ROOT, "host", "bin", "dft_detect")] + args, input=raw, capture_output=True, timeout=300, env=env)
+    assert want.stdout.decode().strip() != "" and "RS41" in want.stdout.decode()
+    assert got.stdout.decode() == want.stdout.decode(), got.stderr.decode()
+    assert got.returncode == want.returncode
