@@ -137,3 +137,11 @@ def test_wave_modem_spectrum_is_the_references_bit_for_bit(emu):
     g, n, sd, recs, Sf, ns = run(emu, name, frames, case["cap"]["sr"], True)
     check(g, n, sd, recs, frames, case["nsym"])
     assert np.array_equal(Sf, g["Sf"])
+
+
+@pytest.mark.parametrize("name,frames,fin", [("fsk_dfm_50k", 12, 0), ("fsk_m10_48080", 40, 0), ("fsk_rs41_48k_real", 12, 0), ("fsk_rs41_48k_mask", 3, 1)])
+def test_wave_modem_with_the_finisher_forced_on_or_off(emu, name, frames, fin):
+    """the launcher turns the finisher wave on where f_int fits into LDS twice (short frames); either way the worker / finisher split must not show in the results"""
+    _, case = fsk_capture(name)
+    g, n, sd, recs, Sf, ns = run(emu, name, frames, case["cap"]["sr"], True, fin=fin)
+    check(g, n, sd, recs, frames, case["nsym"])
