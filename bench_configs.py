@@ -466,30 +466,38 @@ def bench_mixed_2400k(args, D, short=False):
                 a = np.frombuffer(buf_m, np.dtype([("h", "<i4", (3,)), ("cs_ok", "<i4"), ("rest", "u1", (136,))]), n_m)
                 tallies["m10"][0] += n_m; tallies["m10"][1] += int((a["cs_ok"] != 0).sum())
 
-    def timed(min_seconds):
-        for _ in range(3):
-            step(False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            step()
-            n += 1
-            if n >= 8 and time.perf_counter() - t0 >= min_seconds:
-                break
+    def drain():
         for e in engs.values():
             e.sync()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n, n
 
+    steps0 = args.steps or 8
     for v in tallies.values():
         v[0] = v[1] = 0
-    per, nsteps = timed(1.0)
-    counts = {k: (v[0] / nsteps, v[1] / nsteps) for k, v in tallies.items()}
+    warm = 3 if args.warmup is None else args.warmup
+    counting = [False]
+    _step = step
+
+    def step():                                           # (the warm-up and probe steps do not count frames)
+        _step(counting[0])
+
+    for _ in range(warm):
+        step()
+    drain()
+    counting[0] = True
+    dt, per_rank, nsteps = _timed_steps(D, step, steps0, 0, 1.0 if not args.steps else 0.0, drain=drain)
+    counting[0] = False
+    per = dt / nsteps
+    probe_steps = 3 if not args.steps else 0             # (_timed_steps' probe steps ran with the counters on)
+    counts = {k: (v[0] / (nsteps + probe_steps), v[1] / (nsteps + probe_steps)) for k, v in tallies.items()}
     # A/B: the block codes on the host inside the fetch
     for e in engs.values():
         e.set_device_ecc(False)
-    per_host, nh = timed(1.0)
+    for _ in range(3):
+        step()
+    drain()
+    dth, _, nh = _timed_steps(D, step, steps0, 0, 1.0 if not args.steps else 0.0, drain=drain)
+    per_host = dth / nh
     for e in engs.values():
         e.set_device_ecc(True); e.close()
     total = C * SR
@@ -501,6 +509,7 @@ def bench_mixed_2400k(args, D, short=False):
             "config": {"workload": "BASELINE configs[4] at configs[3]'s type mix: %d channels x 2.4 Msps cs16 IQ per GPU — %d RS41 (rs41mod --ecc2), %d DFM09 (dfm09mod --ecc), %d M10 — "
                                    "mix -> decimate -> FM -> header search -> frame sync -> block code on the device, one engine per type; 1 s per channel per step" % (C, n_rs, n_dfm, n_m10),
                        "channels": {"rs41": n_rs, "dfm": n_dfm, "m10": n_m10}, "realtime_channels": round(total / per / SR, 1),
+                       "rank_ms_per_step": [round(t / nsteps * 1e3, 3) for t in per_rank],
                        "frames_per_step": {k: round(v[0], 1) for k, v in counts.items()},
                        "frames_ok_per_step": {k: round(v[1], 1) for k, v in counts.items()},
                        "frames_ok_means": "rs41: rs41_ecc() >= 0; dfm: hamming() >= 0 in all three blocks; m10: checksum equal",

@@ -38,13 +38,13 @@ def test_bench_two_ranks_on_one_device(lag):
     assert "cpu_baseline" not in d and "detect_in_step" not in d                                          # single-GPU extras stay out of N > 1 lines
 
 
-@pytest.mark.parametrize("config", ["scan_wide", "fsk_mixed"])
+@pytest.mark.parametrize("config", ["scan_wide", "fsk_mixed", "mixed_2400k"])
 def test_other_configs_two_ranks_on_one_device(config):
     """BASELINE configs[2] and [3] the way the driver would launch them on N GPUs (configs[3] is quoted on four): the N-rank line executes, every rank does its own
     full workload (weak scaling: independent streams / channels per GPU, no data-path collective), rank 0 prints one line with the job's aggregate"""
     env = dict(os.environ, SONDE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = 29300 + (os.getpid() + len(config)) % 300
-    extra = ["--channels", "48"] if config == "fsk_mixed" else []
+    extra = ["--channels", "48"] if config == "fsk_mixed" else ["--channels", "20"] if config == "mixed_2400k" else []
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--config", config, "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, capture_output=True, timeout=900, env=env, cwd=ROOT)
@@ -60,6 +60,10 @@ def test_other_configs_two_ranks_on_one_device(config):
     if config == "fsk_mixed":
         assert cfg["channels_per_gpu"] == 48 and cfg["checked_channels"] == 48 and cfg["verified_channels"] == 48          # rank 0's channels against the reference modem
         assert abs(d["value"] - 2 * (16 * 48000 + 16 * 50000 + 16 * 48080) / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]
+    elif config == "mixed_2400k":
+        assert cfg["channels"] == {"rs41": 10, "dfm": 6, "m10": 4} and cfg["verified_channels"] == cfg["checked_channels"] == cfg["channels"]     # rank 0's channels against the reference decoders
+        assert abs(d["value"] - 2 * 20 * 2.4e6 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]
+        assert d["host_decode_ab"]["ms_per_step"] > 0
     else:
         assert cfg["channels"] == 256 and len(cfg["detections_last_step"]) >= 10                                           # the dozen planted sondes
         assert abs(d["value"] - 2 * 10e6 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.02 * d["value"]
