@@ -40,7 +40,7 @@ struct sonde_fsk {
     // what a repeat of single channels needs (a pipeline that gave up, launch_wait): Sf and the tone tails as they were before the launch, the list
     float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
     // a launch that was submitted and not yet waited for (sonde_fsk_submit_device / sonde_fsk_wait); the channels the last wait had to repeat
-    bool pending = false; hipEvent_t ev0 = nullptr, ev1 = nullptr; int last_repeated = 0;
+    bool pending = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
@@ -196,7 +196,7 @@ static int launch_enqueue(sonde_fsk_t *f) {
     const int lrc = sonde_launch_fsk(&a, f->stream);
     hipEventRecord(f->ev1, f->stream);
     if (lrc < 0) return lrc == -1 ? SONDE_E_ARG : SONDE_E_NOGPU;
-    f->pending = true; f->last_repeated = 0;
+    f->pending = true;
     return collect_enqueue(f);
 }
 // the other half: wait for the launch, repeat the channels it gave up on
@@ -226,7 +226,6 @@ static int launch_wait(sonde_fsk_t *f) {
     { const int rc = collect_enqueue(f); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(f->stream));
     f->repeats += (int64_t)bad.size();
-    f->last_repeated = (int)bad.size();
     for (int c = 0; c < C; c++) if (f->h_chan[c].frames < 0) { fprintf(stderr, "libsonde_hip: fsk modem: channel %d failed again\n", c); return SONDE_E_NOGPU; }
     return 0;
 }
@@ -273,8 +272,9 @@ int sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride
     return run(f, d_in, ch_stride, n_samples, hipMemcpyDeviceToDevice);
 }
 // the same in two halves: everything of sonde_fsk_process_device is enqueued on the engine's stream and the call returns; sonde_fsk_wait blocks until it is
-// through (and repeats what has to be repeated).  Between the two the host is free — e.g. to submit the other engines of a mixed batch, or a consumer on
-// the device behind this launch (sonde_softin_dev_submit_fsk).  Every other call of this engine waits first.
+// through (and repeats what has to be repeated).  Between the two the host is free — e.g. to submit the other engines of a mixed batch, or to run a consumer on the
+// device over the launch BEFORE this one on its own stream (sonde_softin_dev_submit_fsk: the soft decisions of the last two launches are kept, d_sd / d_sd_alt).
+// Every other call of this engine waits first.
 int sonde_fsk_submit_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples) {
     if (!f || !d_in) return SONDE_E_ARG;
     return submit(f, d_in, ch_stride, n_samples, hipMemcpyDeviceToDevice);
