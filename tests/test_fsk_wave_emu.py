@@ -145,3 +145,35 @@ def test_wave_modem_with_the_finisher_forced_on_or_off(emu, name, frames, fin):
     _, case = fsk_capture(name)
     g, n, sd, recs, Sf, ns = run(emu, name, frames, case["cap"]["sr"], True, fin=fin)
     check(g, n, sd, recs, frames, case["nsym"])
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_wave_modem_4fsk_matches_the_compiled_reference(emu, split):
+    """M = 4 (fsk.c: four tone estimates, four down-converters / integrators, two soft decisions per symbol :793-802) through the same source, against
+    `oracle/_ref/fsk_demod --cs16 -p 5 -s 4 48000 2400` run here on the same synthetic four-tone signal"""
+    from golden_cases import need_ref
+    need_ref()
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    rng = np.random.default_rng(4)
+    bits = rng.integers(0, 2, 2 * 50 * 60)
+    x = synth.mfsk_capture(bits, 48000, 2400, 4, f_low=-3600.0, shift=2400.0, noise_sigma=0.12, seed=9)
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fsk_demod"), "--cs16", "-p", "5", "-s", "4", "48000", "2400", "-", "-"], input=x.tobytes(), capture_output=True, timeout=120)
+    ref = np.frombuffer(r.stdout, np.float32)
+    nsym, M = 50, 4
+    frames = len(ref) // (nsym * 2)
+    assert frames >= 20
+    n = len(x) // 2
+    sd = np.zeros(frames * nsym * 2 + 64, np.float32)
+    recs = (Rec * (frames + 8))()
+    Sf = np.zeros(1024, np.float32)
+    ns = C.c_longlong(0)
+    fin = 1 if 2 * M * (nsym + 1) * 5 * 8 <= 16384 else 0
+    got_frames = emu.emu_fsk_run(48000, 2400, M, 5, nsym, 2, -24000, 24000, 0, 100, 0, 1 if split else 0, fin,
+                                 np.ascontiguousarray(x).ctypes.data, n, 48000, sd.ctypes.data, len(sd), C.addressof(recs), len(recs), Sf.ctypes.data, C.byref(ns))
+    assert got_frames == frames
+    got = sd[:frames * nsym * 2]
+    rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    d = got.astype(np.float64) - ref[:len(got)]
+    assert np.sqrt(np.mean(d ** 2)) < 1e-6 * rms and np.array_equal(got < 0, ref[:len(got)] < 0)
