@@ -42,6 +42,7 @@ extern "C" {
                                  * second (5 x 808 bits) is skipped; either polarity */
 #define SONDE_M20    20         /* m20mod.c:60,86,1034-1040,1238-1251,1321-1365: as M10 with 9600 Bd and up to 64 aux bytes (1320 bits) */
 
+#define SONDE_MIXED  100        /* cfg.sonde_type of sonde_engine_create_mixed: the type is a property of the channel (its group), not of the engine */
 #define SONDE_GENERIC 99        /* any other 2-FSK sonde of the reference's demod/mod family, described by a sonde_generic_t given to sonde_engine_create_generic;
                                  * header hits + soft bits only (sonde_engine_fetch_hits), framing stays with the caller */
 
@@ -164,6 +165,27 @@ typedef struct {
 int  sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out);
 /* With a preset type in cfg (SONDE_RS41 / DFM09 / M10 / M20) a non-NULL `gen` carries one thing only: gen->baud replaces the preset's symbol
  * rate before the design — the decoders' --br option (dfm09mod.c:1436-1443,1590-1594; m20mod.c:1082-1089).  Everything else of `gen` is ignored. */
+/* Mixed-type engine (BASELINE configs[3] / [4]: RS41, DFM09, M10 ... channels side by side on one GPU).  Nothing in front of the IF rate depends on the sonde
+ * type — IF_sr, decM and the decimator taps follow from the sample rate and --min alone (demod_mod.c:1222-1249), the mixer table from fq (:1262-1296), the
+ * IQ-DC from the samples (:495-504) — so ONE decimator launch per call serves every channel, whatever it carries; the IF-rate stages (IF low-pass, tone
+ * correlator, header search, frame sync, block code) run per group with the group's preset, each group on streams of its own behind that launch.
+ * A group = what one decoder command line of the reference fixes: the decoder (sonde_type: SONDE_RS41 / DFM09 / M10 / M20) and its options.
+ * cfg: sonde_type = SONDE_MIXED; device, n_channels, sample_rate, bits (16 / 8), opt_lp, opt_min, max_chunk, max_frames (shared out among the groups by
+ * channel count), input = SONDE_IN_IQ are common to all channels; ecc_level / thres / lpiq_bw / opt_inv / opt_auto / m10_noskip come from the group.
+ * Not here: --dc, --noLUT, float32 input, keep_soft (SONDE_E_ARG).  group_of_channel[c] = index into groups[] of channel c; channel numbers in every
+ * result are the caller's.  Results: sonde_engine_fetch_frames[_lagged] / _finish return the frames of the RS41 channels, sonde_engine_fetch_dfm[_lagged] /
+ * _m10[_lagged] / _m20 those of their types; process / sync / set_summary[_snapshots] / set_device_ecc / overflowed / samples_to_dc_boundary / read_tap /
+ * finish_channel work as on a single-type engine. */
+typedef struct {
+    int32_t sonde_type;      /* SONDE_RS41, SONDE_DFM09, SONDE_M10, SONDE_M20 */
+    int32_t ecc_level;       /* as sonde_cfg_t.ecc_level */
+    int32_t lpiq_bw, opt_inv, opt_auto, m10_noskip;
+    float   thres;           /* 0 = type default */
+    int32_t reserved;
+} sonde_group_t;
+int  sonde_engine_create_mixed(const sonde_cfg_t *cfg, const double *fq, const sonde_group_t *groups, int32_t n_groups, const int32_t *group_of_channel, sonde_engine_t **out);
+/* the sonde type and the derived constants (init_buffers) of the group channel `channel` belongs to; a single-type engine answers with its own */
+int  sonde_engine_group_info(const sonde_engine_t *e, int32_t channel, int32_t *sonde_type, sonde_info_t *info);
 /* replaces free_buffers() (demod_mod.c:1476) */
 void sonde_engine_destroy(sonde_engine_t *e);
 int  sonde_engine_info(const sonde_engine_t *e, sonde_info_t *info);
@@ -226,7 +248,8 @@ int  sonde_engine_overflowed(sonde_engine_t *e);
 long long sonde_engine_host_ecc_frames(sonde_engine_t *e);
 /* on = 0: frames of the following calls leave k_framesync with their first-pass syndromes only and are decoded on the host when fetched (the
  * round-3 arrangement; A/B measurements and tests); on = 1 (default): device decoder.  DFM09 / M10 engines: the same switch for their block codes
- * (Hamming(8,4) of the sliced frames / differential decoding + checkM10): on the device behind the frame sync, or on the host inside the fetch. */
+ * (Hamming(8,4) of the sliced frames / differential decoding + checkM10): on the device behind the frame sync, or on the host inside the fetch; there the
+ * switch takes effect between records only — everything queued must have been fetched (SONDE_E_ARG otherwise). */
 int  sonde_engine_set_device_ecc(sonde_engine_t *e, int32_t on);
 /* Pipelined variant: return only the frames of process calls issued at least `lag` calls ago and wait only for those.
  * With lag = 1 the IF-rate kernels of call k (stream B) overlap the decimator of call k+1 (stream A); lag = 0 is
@@ -258,6 +281,8 @@ int  sonde_engine_set_threshold(sonde_engine_t *e, float thres);
  * = none / --ecc / --ecc2 (soft 2-bit pass).  finish != 0: end of input, also emits the complete frames of a hit
  * in progress (a partial frame is dropped like dfm09mod.c:1713). */
 int  sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish);
+/* pipelined form (as sonde_engine_fetch_frames_lagged): only the frames of process calls issued at least `lag` calls ago, waiting only for those */
+int  sonde_engine_fetch_dfm_lagged(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t lag);
 /* One M10 / M10+ / M2K2 frame = what m10mod's print_frame() sees after differential decoding (m10mod.c:1049-1070,1484). */
 typedef struct {
     int32_t  channel;
@@ -272,6 +297,7 @@ typedef struct {
 /* SONDE_M10 engines: frames completed so far; finish != 0 = end of input (a frame in progress is emitted with the bits that
  * exist, m10mod.c:1486-1490). */
 int  sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish);
+int  sonde_engine_fetch_m10_lagged(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t lag);
 /* m10mod --chk3 (m10mod.c:1233,1476-1479; IQ input forms): every bit is re-decided from both soft values of read_softbit2p, (sb + 0.25 sb1) >= 0.
  * Needs cfg.keep_soft = 2 (the engine then keeps the second soft value per bit); SONDE_E_ARG otherwise. */
 int  sonde_engine_set_m10_chk3(sonde_engine_t *e, int32_t on);

@@ -44,6 +44,7 @@ struct MixDecArgs {
     // k_mix_decimate50r (the scanner's front end in one pass over the input): no mean at all in the sample loop — y receives the raw sum W x ex,
     // bsum[ch][j] the sum of the raw samples of block j (re, im: exact integers); k_dc_rows_to_segments / k_dc_seg_means / k_scan_dc_edges follow at the IF rate, k_scan_if folds as it loads
     int2 *bsum; long long bsum_stride;
+    const int32_t *in_row;    // nullable: [n_ch] row of `iq` channel ch reads (mixed engines: channels grouped by type inside, the caller's order outside)
 };
 // (ScanFold, what k_scan_if folds with, is in sonde_scan_dev.h)
 struct ScanEdgeArgs {
@@ -193,6 +194,7 @@ struct SyncArgs {
     const float *fm, *corr2; float2 *ifiq;
     AfcState *afc; uint32_t *start; unsigned *pending;
     sonde_summary_t *summary; uint32_t summary_base; int summary_type; uint64_t summary_epoch;      // nullable: per-channel summary records
+    const int32_t *summary_map;                               // nullable: [n_ch] record index / channel number of channel ch (groups of a mixed engine)
     const WinItem *win; int win_W;                             // != nullptr: header windows precomputed by k_sync_window_fft (W per channel)
     uint32_t corr_limit;      // != 0: pass 1 of two — `corr` holds CorrArgs.limit end positions behind the state's first one; stop there
     unsigned long long *prof; // SONDE_WF_PROF: cycles per phase of channel 0 (nullptr = off)

@@ -108,7 +108,18 @@ struct sonde_engine {
     std::vector<uint32_t> epoch; uint32_t *d_epoch = nullptr; int eof_ch = -1;
     // profiling
     bool prof = false, prof_skip = false; int prof_level = 2; std::map<std::string, KernelStat> stats; std::vector<PendingEvt> pend;
+    // Mixed engines (sonde_engine_create_mixed).  Nothing in front of the IF rate depends on the sonde type (demod_mod.c:1222-1249: IF_sr, decM and the
+    // decimator taps follow from the sample rate and --min only; mixer table and IQ-DC likewise), so ONE object owns mixer / decimator / IQ-DC of all
+    // channels — `front_only`: no IF-rate state of its own — and keeps the channels grouped by type inside: `groups` are engines of one type each whose
+    // IF chain reads their rows of the owner's y ring.  grp_of_ch / row_of_ch: caller's channel -> group, row; ch_of_grp[g][i]: channel i of group g ->
+    // caller's channel; d_in_row: row -> caller's channel (what the decimator reads for that row).
+    std::vector<sonde_engine *> groups; std::vector<int32_t> grp_of_ch, row_of_ch; std::vector<std::vector<int32_t>> ch_of_grp; int32_t *d_in_row = nullptr;
+    bool front_only = false; int64_t snap_calls = 0;       // snap_calls: calls up to which the owner has enqueued a summary snapshot copy (ev_b of the owner)
+    // a group of a mixed engine: who owns its front end, the first of the owner's rows that is this group's, its channels' numbers at the caller (summary records)
+    sonde_engine *front = nullptr; int front_row = 0; int32_t *d_sum_map = nullptr; bool is_group = false;
 };
+// how sonde_engine_create_mixed creates its parts
+struct CreateLink { bool is_group, front_only; int min_ring; };
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
     HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
@@ -201,17 +212,37 @@ static bool blockcodes_on_device(const sonde_engine *e) {
     return e->dev_ecc && e->d_soft && e->d_blk_done && ((e->cfg.sonde_type == SONDE_DFM09 && e->d_dfm_out) || (e->cfg.sonde_type == SONDE_M10 && e->d_m10_out));
 }
 // the decoded frames of the n records a fetch has just taken (ring slots from `start` on) -> host
-template <class T> static int copy_decoded(sonde_engine *e, const T *d_out, std::vector<T> &h, unsigned start, int n, int per) {
+template <class T> static int copy_decoded(sonde_engine *e, const T *d_out, std::vector<T> &h, unsigned start, int n, int per, int lag = 0) {
     h.resize((size_t)n * per);
+    hipStream_t cs = (lag > 0 && e->stream_c) ? e->stream_c : e->stream_b;      // a lagged fetch must not queue behind the call that is still running (collect_records)
     unsigned done = 0;
     while (done < (unsigned)n) {
         const unsigned idx = (start + done) % (unsigned)e->max_frames;
         const unsigned run = std::min<unsigned>((unsigned)n - done, (unsigned)e->max_frames - idx);
-        if (hipMemcpyAsync(h.data() + (size_t)done * per, d_out + (size_t)idx * per, (size_t)run * per * sizeof(T), hipMemcpyDeviceToHost, e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        if (hipMemcpyAsync(h.data() + (size_t)done * per, d_out + (size_t)idx * per, (size_t)run * per * sizeof(T), hipMemcpyDeviceToHost, cs) != hipSuccess) return SONDE_E_NOGPU;
         done += run;
     }
-    if (n && hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+    if (n && hipStreamSynchronize(cs) != hipSuccess) return SONDE_E_NOGPU;
     return 0;
+}
+
+// mixed engines: the same fetch on every group of the wanted type, channel numbers translated to the caller's
+template <class F, class FN> static int mixed_fetch(sonde_engine *e, int type, F *out, int32_t max, int lag, FN fn) {
+    if (!e || !out || max < 0) return SONDE_E_ARG;
+    if (lag > 0 && e->snap_calls > 0) {                        // the summary snapshot of the call the fetch reaches back to is complete as well
+        const int64_t target = e->call - 1 - lag;
+        if (target >= 0 && target < e->snap_calls && hipEventSynchronize(e->ev_b[target & 3]) != hipSuccess) return SONDE_E_NOGPU;
+    }
+    int n = 0;
+    for (size_t gi = 0; gi < e->groups.size(); gi++) {
+        sonde_engine *g = e->groups[gi];
+        if (g->cfg.sonde_type != type) continue;
+        const int k = fn(g, out + n, max - n);
+        if (k < 0) return k;
+        for (int i = 0; i < k; i++) out[n + i].channel = e->ch_of_grp[gi][(size_t)out[n + i].channel];
+        n += k;
+    }
+    return n;
 }
 
 extern "C" {
@@ -257,7 +288,14 @@ int sonde_rs41_ecc_device(uint8_t *frames, const int32_t *flen, int32_t n, int32
 
 int sonde_engine_create(const sonde_cfg_t *cfg, const double *fq, sonde_engine_t **out) { return sonde_engine_create_generic(cfg, fq, nullptr, out); }
 
-int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out) {
+static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, const CreateLink *lk, sonde_engine_t **out);
+static int fetch_dfm_impl(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish, int lag);
+static int fetch_m10_impl(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish, int lag);
+int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, sonde_engine_t **out) { return create_impl(cfg, fq, gen, nullptr, out); }
+
+}  // extern "C"
+
+static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_generic_t *gen, const CreateLink *lk, sonde_engine_t **out) {
     if (!cfg || !fq || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
     if (cfg->sonde_type == SONDE_GENERIC && !gen) return SONDE_E_ARG;
     // a description next to a PRESET type (DFM09 / M10 / M20 / RS41): only its baud is read — the decoders' --br option (dfm09mod.c:1436-1443,
@@ -285,6 +323,8 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     sonde_engine *e = new sonde_engine();
     e->cfg = *cfg;
     const int C = cfg->n_channels;
+    const bool is_group = lk && lk->is_group, front_only = lk && lk->front_only;
+    e->is_group = is_group; e->front_only = front_only;
 
     // ---- sonde preset (rs41mod.c:2591-2597,2812-2836,2882,2920-2923)
     std::string header;
@@ -364,6 +404,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
 
     const int max_if = (cfg->max_chunk + D - 1) / D;
     int ring = 1; while (ring < max_if + (int)e->frame_samples + 2 * M + 4096 || ring < 4 * M || (cfg->pipeline && ring < 2 * max_if + 4096)) ring <<= 1;
+    if (lk && ring < lk->min_ring) ring = lk->min_ring;        // the parts of a mixed engine share one ring length (the y ring is the owner's)
     e->ring_len = ring;
     e->max_frames = cfg->max_frames > 0 ? cfg->max_frames : 4 * C;
 
@@ -408,7 +449,7 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     {
         static const bool no_fast = getenv("SONDE_MD_NOFAST") != nullptr;       // A/B aid: the compiler-scheduled kernels
         if (D == 50 && e->Q == 7 && !audio && cfg->bits != 32 && cfg->sonde_type != SONDE_FRONTEND && !cfg->opt_nolut && e->lut_len % D == 0 && !no_fast
-            && cfg->input == SONDE_IN_IQ) {
+            && cfg->input == SONDE_IN_IQ && !is_group) {
             e->etab_len = e->lut_len / D;
             if (dalloc(&e->d_etab, (size_t)C * e->etab_len, false) || dalloc(&e->d_dcavg_prev, C)) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
             sonde_launch_md_etable(e->d_chanf0, e->d_wtab, D, e->Q, e->etab_len, C, e->d_etab, nullptr);
@@ -419,8 +460,8 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     bad |= dalloc(&e->d_dcavg, C); bad |= dalloc(&e->d_dcsums, 2 * (size_t)C);
     bad |= dalloc(&e->d_ptail[0], (size_t)C * 64); bad |= dalloc(&e->d_ptail[1], (size_t)C * 64);
     if (audio) bad |= dalloc(&e->d_raw, (size_t)C * ring);
-    else { bad |= dalloc(&e->d_y, (size_t)C * ring); bad |= dalloc(&e->d_ifiq, (size_t)C * ring); }
-    bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring);
+    else { if (!is_group) bad |= dalloc(&e->d_y, (size_t)C * ring); if (!front_only) bad |= dalloc(&e->d_ifiq, (size_t)C * ring); }
+    if (!front_only) { bad |= dalloc(&e->d_fm, (size_t)C * ring); bad |= dalloc(&e->d_bufs, (size_t)C * ring); bad |= dalloc(&e->d_corr, (size_t)C * ring); }
     bad |= dalloc(&e->d_state, C); bad |= dalloc(&e->d_frames, e->max_frames); bad |= dalloc(&e->d_fcount, 1 + 4);      // the counter, and its value behind each of the last four calls (what a call publishes)
     if (cfg->keep_soft || cfg->sonde_type != SONDE_RS41) bad |= dalloc(&e->d_soft, (size_t)e->max_frames * e->nbits);
     if (cfg->keep_soft == 2) bad |= dalloc(&e->d_soft1, (size_t)e->max_frames * e->nbits);
@@ -589,8 +630,13 @@ int sonde_engine_create_generic(const sonde_cfg_t *cfg, const double *fq, const 
     return 0;
 }
 
+extern "C" {
+
 void sonde_engine_destroy(sonde_engine_t *e) {
     if (!e) return;
+    for (sonde_engine *g : e->groups) sonde_engine_destroy(g);      // (they borrow rows of this object's y ring)
+    e->groups.clear();
+    if (e->is_group) e->d_y = nullptr;
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_b) hipStreamSynchronize(e->stream_b);
     if (e->stream_e) hipStreamSynchronize(e->stream_e);
@@ -629,7 +675,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
                      e->d_epoch, e->d_work, e->d_work_count, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
-                     e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws, e->d_epoch_phase, e->d_pcs_cnt, e->d_pcs_max, e->d_pcs_since };
+                     e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws, e->d_epoch_phase, e->d_pcs_cnt, e->d_pcs_max, e->d_pcs_since, e->d_in_row, e->d_sum_map };
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -652,8 +698,28 @@ int64_t sonde_engine_samples_to_dc_boundary(const sonde_engine_t *e) {
 
 void *sonde_engine_stream(sonde_engine_t *e) { return e ? (void *)e->stream : nullptr; }
 
+}  // extern "C"
+
+// What a process call does before its first kernel, for every engine `t` that runs an IF-rate tail in it (the engine itself, or each group of a mixed
+// engine); fs = the stream the call's decimator runs on.
+static void tail_begin(sonde_engine *t, hipStream_t fs) {
+    t->in_call = true; t->ecc_listed = false;
+    // this call's frame syncs append to the work list call-2 used: its decoder kernel (stream E) must be through
+    if (t->stream_e && t->call >= 2) hipStreamWaitEvent(t->stream_b, t->ev_b[(t->call - 2) & 3], 0);
+    // ... and the list starts empty whatever that call left (a call that failed half way never ran the decoder that clears it: ADVICE round 4)
+    if (t->d_ecc_cnt) { hipMemsetAsync(t->d_ecc_cnt + (t->call & 1), 0, sizeof(unsigned), t->stream_b); hipMemsetAsync(t->d_ecc_cnt + 2 + (t->call & 1), 0, sizeof(unsigned), t->stream_b); }
+    // two streams: this call's decimator overwrites the part of the y ring that call-2 occupied (ring_len >= 2 * max_if + history), so it must
+    // not start before the IF chain of call-2 has read it.  Only the IF chain reads y: the header search and the frame sync behind it work on
+    // rings stream B writes itself, so however late they run (they wait for CU slots the decimator frees) the decimators stay back to back.
+    static const bool wait_tail = getenv("SONDE_A_WAITS_TAIL") != nullptr;       // A/B aid: the round-3 dependency on the whole tail of call-2
+    if (t->stream_b != fs && t->call >= 2) hipStreamWaitEvent(fs, wait_tail ? t->ev_b[(t->call - 2) & 3] : t->ev_if[(t->call - 2) & 3], 0);
+}
+static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hipStream_t fs, hipEvent_t front_done);
+
+extern "C" {
+
 int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_stride, int32_t n_samples) {
-    if (!e || !d_iq) return SONDE_E_ARG;
+    if (!e || !d_iq || e->is_group) return SONDE_E_ARG;        // (a group of a mixed engine is driven by its owner)
     const int D = e->info.decM, C = e->cfg.n_channels;
     // ch_stride == 0: one wideband stream shared by all channels (each mixes its own fq out of it)
     if (n_samples <= 0 || n_samples > e->cfg.max_chunk || n_samples % D || (ch_stride != 0 && ch_stride < n_samples)) return SONDE_E_RANGE;
@@ -665,16 +731,9 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     }
     const uint32_t m_first = e->m_out;
     int done = 0;
-    e->in_call = true; e->ecc_listed = false;
-    // this call's frame syncs append to the work list call-2 used: its decoder kernel (stream E) must be through
-    if (e->stream_e && e->call >= 2) hipStreamWaitEvent(e->stream_b, e->ev_b[(e->call - 2) & 3], 0);
-    // ... and the list starts empty whatever that call left (a call that failed half way never ran the decoder that clears it: ADVICE round 4)
-    if (e->d_ecc_cnt) { hipMemsetAsync(e->d_ecc_cnt + (e->call & 1), 0, sizeof(unsigned), e->stream_b); hipMemsetAsync(e->d_ecc_cnt + 2 + (e->call & 1), 0, sizeof(unsigned), e->stream_b); }
-    // two streams: this call's decimator overwrites the part of the y ring that call-2 occupied (ring_len >= 2 * max_if + history), so it must
-    // not start before the IF chain of call-2 has read it.  Only the IF chain reads y: the header search and the frame sync behind it work on
-    // rings stream B writes itself, so however late they run (they wait for CU slots the decimator frees) the decimators stay back to back.
-    static const bool wait_tail = getenv("SONDE_A_WAITS_TAIL") != nullptr;       // A/B aid: the round-3 dependency on the whole tail of call-2
-    if (e->stream_b != e->stream && e->call >= 2) hipStreamWaitEvent(e->stream, wait_tail ? e->ev_b[(e->call - 2) & 3] : e->ev_if[(e->call - 2) & 3], 0);
+    const bool mixed = !e->groups.empty();
+    if (mixed) { for (sonde_engine *g : e->groups) tail_begin(g, e->stream); }
+    else tail_begin(e, e->stream);
     if (e->cfg.input == SONDE_IN_AUDIO) {
         // f32read_sample (demod_mod.c:379-405): b/128/256 of the selected channel; then FM low-pass / bufs
         AudioConvArgs c0{}; c0.pcm = (const int16_t *)d_iq; c0.ch_stride = ch_stride; c0.n_ch = C; c0.n = n_samples;
@@ -754,12 +813,12 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         {   // test aid: tiles per wave of a large batch (512 channels x 1 s: G = 16) on a batch small enough for a parity test (tests/test_gpu_batch.py)
             const char *g = getenv("SONDE_MD_G"); const int gv = g ? atoi(g) : 0; if (gv >= 1 && gv <= 16) a.G = gv;
         }
-        a.etab = e->d_etab; a.etab_len = e->etab_len;
+        a.etab = e->d_etab; a.etab_len = e->etab_len; a.in_row = e->d_in_row;
         a.dc_avg_prev = (e->d_etab && e->dc_since < e->Q - 1) ? e->d_dcavg_prev : nullptr; a.dc_since = e->dc_since;
         if (e->dc_since < (1 << 20)) e->dc_since += take / D;
         if (e->pcs) { a.epoch_phase = e->d_epoch_phase; a.dc_since_ch = e->d_pcs_since; a.dc_avg_prev = e->d_etab ? e->d_dcavg_prev : nullptr; }
         prof_begin(e, "mix_decimate", e->stream); const int lrc = sonde_launch_mix_decimate(&a, e->stream); prof_end(e, e->stream);
-        if (lrc < 0) { e->in_call = false; e->ecc_listed = false; return SONDE_E_ARG; }
+        if (lrc < 0) { e->in_call = false; e->ecc_listed = false; for (sonde_engine *g : e->groups) { g->in_call = false; g->ecc_listed = false; } return SONDE_E_ARG; }
         e->ptail_cur ^= 1;
         e->samples_in += (uint64_t)take; e->m_out += (uint32_t)(take / D); e->dc_cnt += (uint32_t)take; done += take;
         if (e->pcs) {                                    // per-channel segment edges: the device keeps the counters, the host mirrors them
@@ -778,6 +837,38 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
             if (e->dc_max < e->dc_lim) e->dc_max *= 2;
         }
     }
+    // the IF-rate work of the call: behind this call's decimator, on the stream(s) B of the engine — or of every group of a mixed engine
+    const int slot = (int)(e->call & 3);
+    int rc = 0;
+    if (mixed) {
+        hipEventRecord(e->ev_a[slot], e->stream);
+        for (sonde_engine *g : e->groups) {
+            g->samples_in = e->samples_in; g->m_out = e->m_out;
+            const int r2 = tail_enqueue(g, n_samples, m_first, e->stream, e->ev_a[slot]);
+            if (r2 && !rc) rc = r2;
+        }
+        if (e->d_summary && e->d_summary_snap) {
+            // the summary records of all groups as this call leaves them: behind every group's last frame sync, on the owner's stream B; a lagged fetch waits for it
+            for (sonde_engine *g : e->groups) hipStreamWaitEvent(e->stream_b, g->ev_b[slot], 0);
+            hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
+            hipEventRecord(e->ev_b[slot], e->stream_b);
+            e->snap_calls = e->call + 1;
+        }
+        e->call += 1;
+    } else {
+        if (e->stream_b != e->stream) hipEventRecord(e->ev_a[slot], e->stream);
+        rc = tail_enqueue(e, n_samples, m_first, e->stream, e->ev_a[slot]);
+    }
+    return rc;
+}
+
+}  // extern "C"
+
+// The IF-rate part of a process call: IF chain, header search rounds, frame sync (+ block codes), decoder, counter publish — everything behind the decimator.
+// `e` is an engine that runs such a tail: a plain engine, or one group of a mixed engine; fs = the stream the decimator of the call ran on, front_done = the
+// event recorded behind it there (stream B waits for it unless it IS that stream); n_samples / m_first: the call's input samples per channel and the IF index of its first output.
+static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hipStream_t fs, hipEvent_t front_done) {
+    const int D = e->info.decM, C = e->cfg.n_channels;
     const int n_if = n_samples / D;
     IfArgs b{};
     const bool fe = e->cfg.sonde_type == SONDE_FRONTEND;
@@ -789,10 +880,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps; b.epoch = e->d_epoch;
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);
-    if (e->stream_b != e->stream) {
-        hipEventRecord(e->ev_a[slot], e->stream);
-        hipStreamWaitEvent(e->stream_b, e->ev_a[slot], 0);
-    }
+    if (e->stream_b != fs) hipStreamWaitEvent(e->stream_b, front_done, 0);
     CorrArgs c{};
     c.bufs = e->d_bufs; c.corr = e->d_corr; c.match = e->d_match; c.n_ch = C; c.ring_len = e->ring_len; c.n = n_if; c.L = e->info.L; c.m0 = m_first;
     c.state = e->d_state; c.delay = e->info.delay; c.frame_samples = e->frame_samples;
@@ -818,10 +906,10 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
             HIPCHK(hipStreamSynchronize(sb));
             if (*e->h_pending == 0) break;
         }
-        if (e->stream_b != e->stream) hipEventRecord(e->ev_if[slot], e->stream_b);
+        if (e->stream_b != fs) hipEventRecord(e->ev_if[slot], e->stream_b);
     } else {
         if (e->cfg.input != SONDE_IN_AUDIO) { prof_begin(e, "if_chain", e->stream_b); sonde_launch_if_chain(&b, e->stream_b); prof_end(e, e->stream_b); }
-        if (e->stream_b != e->stream) hipEventRecord(e->ev_if[slot], e->stream_b);
+        if (e->stream_b != fs) hipEventRecord(e->ev_if[slot], e->stream_b);
         if (!fe && e->d_win) {
             // header search with the reference's own transform: rounds of plan -> evaluate -> sync; the sync stops where the planned
             // windows end and the next round plans from the state it left.  First round: the two windows a received sonde needs.
@@ -846,7 +934,7 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
             launch_framesync(e, 0);
         }
     }
-    if (e->d_summary && e->d_summary_snap)
+    if (e->d_summary && e->d_summary_snap && !e->is_group)         // (a mixed engine copies once, behind all its groups: sonde_engine_process_device)
         hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
     // the call's records are complete (ev_b) once its damaged frames are decoded and the counter is published
     hipStream_t se = e->stream_b;
@@ -869,6 +957,9 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     if (hipPeekAtLastError() != hipSuccess) { fprintf(stderr, "libsonde_hip: launch failed: %s\n", hipGetErrorString(hipGetLastError())); return SONDE_E_NOGPU; }
     return 0;
 }
+
+
+extern "C" {
 
 static void sync_round(sonde_engine *e, int W) {
     // the item table has win_W slots per channel; this round plans and evaluates the first W of them (the others are cleared)
@@ -912,7 +1003,7 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.corr_limit = e->corr_limit;
     s.win = e->d_win; s.win_W = e->win_W;
     s.prof = e->d_wfprof ? e->d_wfprof + 16 : nullptr;
-    s.summary = e->d_summary; s.summary_base = e->summary_base; s.summary_type = e->cfg.sonde_type; s.summary_epoch = e->samples_in / (uint64_t)std::max(1, e->info.decM);     // IF samples produced so far, 64 bit
+    s.summary = e->d_summary; s.summary_base = e->summary_base; s.summary_map = e->d_sum_map; s.summary_type = e->cfg.sonde_type; s.summary_epoch = e->samples_in / (uint64_t)std::max(1, e->info.decM);     // IF samples produced so far, 64 bit
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }
 
@@ -938,6 +1029,7 @@ int sonde_engine_process_host(sonde_engine_t *e, const void *h_iq, int64_t ch_st
 
 int sonde_engine_sync(sonde_engine_t *e) {
     if (!e) return SONDE_E_ARG;
+    for (sonde_engine *g : e->groups) { const int rc = sonde_engine_sync(g); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
     if (e->stream_e) HIPCHK(hipStreamSynchronize(e->stream_e));
@@ -984,6 +1076,7 @@ static int fetch_rs41(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int la
 int sonde_engine_set_summary(sonde_engine_t *e, void *d_summary, uint32_t channel_base) {
     if (!e) return SONDE_E_ARG;
     e->d_summary = (sonde_summary_t *)d_summary; e->summary_base = channel_base;
+    for (sonde_engine *g : e->groups) { g->d_summary = e->d_summary; g->summary_base = channel_base; }     // (each group writes its channels' records: d_sum_map)
     return 0;
 }
 
@@ -993,28 +1086,72 @@ int sonde_engine_set_summary_snapshots(sonde_engine_t *e, void *d_snap) {
     return (int)(e->call & 1);
 }
 
-long long sonde_engine_host_ecc_frames(sonde_engine_t *e) { return e ? e->host_ecc_frames : SONDE_E_ARG; }
-int sonde_engine_set_device_ecc(sonde_engine_t *e, int32_t on) { if (!e) return SONDE_E_ARG; e->dev_ecc = on != 0; return 0; }
+long long sonde_engine_host_ecc_frames(sonde_engine_t *e) {
+    if (!e) return SONDE_E_ARG;
+    long long n = e->host_ecc_frames;
+    for (sonde_engine *g : e->groups) n += g->host_ecc_frames;
+    return n;
+}
+int sonde_engine_set_device_ecc(sonde_engine_t *e, int32_t on) {
+    if (!e) return SONDE_E_ARG;
+    for (sonde_engine *g : e->groups) { const int rc = sonde_engine_set_device_ecc(g, on); if (rc) return rc; }
+    if ((on != 0) == e->dev_ecc) return 0;
+    if (e->d_blk_done) {
+        // DFM / M10 engines decide per record range where its block codes run: k_dfm_hits / k_m10_hits behind the frame sync that queued it, or the host inside
+        // the fetch.  A switch therefore takes effect between records only: everything queued so far must have been fetched (SONDE_E_ARG otherwise — fetch first),
+        // and the device decoder then starts at the record the next frame sync queues (a toggle between a call and its fetch read slots never decoded).
+        if (hipStreamSynchronize(e->stream_b) != hipSuccess) return SONDE_E_NOGPU;
+        unsigned count = 0;
+        if (hipMemcpy(&count, e->d_fcount, sizeof count, hipMemcpyDeviceToHost) != hipSuccess) return SONDE_E_NOGPU;
+        if (count != e->read_idx) return SONDE_E_ARG;
+        const unsigned dn[2] = { count, 0u };
+        if (on && hipMemcpy(e->d_blk_done, dn, sizeof dn, hipMemcpyHostToDevice) != hipSuccess) return SONDE_E_NOGPU;
+    }
+    e->dev_ecc = on != 0;
+    return 0;
+}
 
 int sonde_engine_overflowed(sonde_engine_t *e) {
     if (!e) return SONDE_E_ARG;
-    const bool ovf = e->overflow; e->overflow = false;
+    bool ovf = e->overflow; e->overflow = false;
+    for (sonde_engine *g : e->groups) { ovf |= g->overflow; g->overflow = false; }
     return ovf ? 1 : 0;
 }
 
-int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) { return fetch_rs41(e, out, max, 0); }
+int sonde_engine_fetch_frames(sonde_engine_t *e, sonde_frame_t *out, int32_t max) { return sonde_engine_fetch_frames_lagged(e, out, max, 0); }
 
 int sonde_engine_fetch_frames_lagged(sonde_engine_t *e, sonde_frame_t *out, int32_t max, int32_t lag) {
-    return fetch_rs41(e, out, max, lag < 0 ? 0 : lag);
+    if (lag < 0) lag = 0;
+    if (e && !e->groups.empty()) return mixed_fetch(e, SONDE_RS41, out, max, lag, [lag](sonde_engine *g, sonde_frame_t *o, int32_t m) { return fetch_rs41(g, o, m, lag); });
+    return fetch_rs41(e, out, max, lag);
 }
 
 int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish) {
+    if (e && !e->groups.empty()) return mixed_fetch(e, SONDE_DFM09, out, max, 0, [finish](sonde_engine *g, sonde_dfm_frame_t *o, int32_t m) { return fetch_dfm_impl(g, o, m, finish, 0); });
+    return fetch_dfm_impl(e, out, max, finish, 0);
+}
+int sonde_engine_fetch_dfm_lagged(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t lag) {
+    if (lag < 0) lag = 0;
+    if (e && !e->groups.empty()) return mixed_fetch(e, SONDE_DFM09, out, max, lag, [lag](sonde_engine *g, sonde_dfm_frame_t *o, int32_t m) { return fetch_dfm_impl(g, o, m, 0, lag); });
+    return fetch_dfm_impl(e, out, max, 0, lag);
+}
+int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish) {
+    if (e && !e->groups.empty()) return mixed_fetch(e, SONDE_M10, out, max, 0, [finish](sonde_engine *g, sonde_m10_frame_t *o, int32_t m) { return fetch_m10_impl(g, o, m, finish, 0); });
+    return fetch_m10_impl(e, out, max, finish, 0);
+}
+int sonde_engine_fetch_m10_lagged(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t lag) {
+    if (lag < 0) lag = 0;
+    if (e && !e->groups.empty()) return mixed_fetch(e, SONDE_M10, out, max, lag, [lag](sonde_engine *g, sonde_m10_frame_t *o, int32_t m) { return fetch_m10_impl(g, o, m, 0, lag); });
+    return fetch_m10_impl(e, out, max, 0, lag);
+}
+
+static int fetch_dfm_impl(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t max, int32_t finish, int lag) {
     if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_DFM09) return SONDE_E_ARG;
-    if (finish) launch_framesync(e, 1);
+    if (finish) { launch_framesync(e, 1); lag = 0; }
     std::vector<FrameRec> recs;
     std::vector<float> soft;
     const bool on_dev = blockcodes_on_device(e);
-    const int nh = collect_records(e, 0, recs, on_dev ? nullptr : &soft, max / 8);
+    const int nh = collect_records(e, lag, recs, on_dev ? nullptr : &soft, max / 8);
     if (nh < 0) return nh;
     e->last_n = nh;
     if (on_dev) {
@@ -1022,7 +1159,7 @@ int sonde_engine_fetch_dfm(sonde_engine_t *e, sonde_dfm_frame_t *out, int32_t ma
         // sonde_engine_fetch_soft asks for them
         const unsigned start = e->read_idx - (unsigned)nh;
         e->soft_lazy = true; e->soft_lazy_start = start;
-        if (copy_decoded(e, e->d_dfm_out, e->h_dfm, start, nh, 8)) return SONDE_E_NOGPU;
+        if (copy_decoded(e, e->d_dfm_out, e->h_dfm, start, nh, 8, lag)) return SONDE_E_NOGPU;
         int n = 0;
         for (int h = 0; h < nh; h++) {
             const FrameRec &r = recs[h];
@@ -1085,6 +1222,7 @@ static int mxx_bytes(sonde_engine *e, const FrameRec &r, int nbytes_max, uint8_t
 }
 
 int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t max, int32_t finish) {
+    if (e && !e->groups.empty()) return mixed_fetch(e, SONDE_M20, out, max, 0, [finish](sonde_engine *g, sonde_m20_frame_t *o, int32_t m) { return sonde_engine_fetch_m20(g, o, m, finish); });
     if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_M20) return SONDE_E_ARG;
     if (finish) launch_framesync(e, 1);
     std::vector<FrameRec> recs;
@@ -1103,20 +1241,20 @@ int sonde_engine_fetch_m20(sonde_engine_t *e, sonde_m20_frame_t *out, int32_t ma
     return n;                                  // frames dropped by a full queue: sonde_engine_overflowed()
 }
 
-int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish) {
+static int fetch_m10_impl(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t max, int32_t finish, int lag) {
     if (!e || !out || max < 0 || e->cfg.sonde_type != SONDE_M10) return SONDE_E_ARG;
-    if (finish) launch_framesync(e, 1);
+    if (finish) { launch_framesync(e, 1); lag = 0; }
     std::vector<FrameRec> recs;
     std::vector<float> soft;
     const bool on_dev = blockcodes_on_device(e);
-    const int n = collect_records(e, 0, recs, on_dev ? nullptr : &soft, max);
+    const int n = collect_records(e, lag, recs, on_dev ? nullptr : &soft, max);
     if (n < 0) return n;
     e->last_n = n;
     if (on_dev) {
         // differential decoding, bytes and checkM10 were done on the device behind the frame sync (k_m10_hits)
         const unsigned start = e->read_idx - (unsigned)n;
         e->soft_lazy = true; e->soft_lazy_start = start;
-        if (copy_decoded(e, e->d_m10_out, e->h_m10, start, n, 1)) return SONDE_E_NOGPU;
+        if (copy_decoded(e, e->d_m10_out, e->h_m10, start, n, 1, lag)) return SONDE_E_NOGPU;
         for (int h = 0; h < n; h++) { out[h] = e->h_m10[h]; out[h].mv_pos = rel_pos(e, recs[h]); }
         return n;
     }
@@ -1148,7 +1286,7 @@ int sonde_engine_fetch_m10(sonde_engine_t *e, sonde_m10_frame_t *out, int32_t ma
 }
 
 int sonde_engine_fetch_hits(sonde_engine_t *e, sonde_hit_t *out, int32_t max, int32_t finish) {
-    if (!e || !out || max < 0 || !e->d_soft || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
+    if (!e || !e->groups.empty() || !out || max < 0 || !e->d_soft || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (finish) launch_framesync(e, 1);
     std::vector<FrameRec> recs;
     std::vector<float> soft;
@@ -1178,25 +1316,28 @@ int sonde_engine_set_m10_chk3(sonde_engine_t *e, int32_t on) {
 }
 
 int sonde_engine_set_sync(sonde_engine_t *e, int32_t hdmax, int32_t bitofs) {
-    if (!e || hdmax < 0 || hdmax > 64 || bitofs < -8 || bitofs > 64 || e->call > 0) return SONDE_E_ARG;      // before the first process call only
+    if (!e || !e->groups.empty() || hdmax < 0 || hdmax > 64 || bitofs < -8 || bitofs > 64 || e->call > 0) return SONDE_E_ARG;      // before the first process call only
     e->hdmax = hdmax; e->bitofs = bitofs;
     return 0;
 }
 
 int sonde_engine_set_threshold(sonde_engine_t *e, float thres) {
-    if (!e || !(thres > 0.f) || thres >= 1.f) return SONDE_E_ARG;
+    if (!e || !e->groups.empty() || !(thres > 0.f) || thres >= 1.f) return SONDE_E_ARG;
     e->thres = thres;
     return 0;
 }
 
 int sonde_engine_finish(sonde_engine_t *e, sonde_frame_t *out, int32_t max) {
     if (!e || !out) return SONDE_E_ARG;
+    if (!e->groups.empty())       // mixed: the RS41 groups end here; the other types with their own fetch (finish != 0)
+        return mixed_fetch(e, SONDE_RS41, out, max, 0, [](sonde_engine *g, sonde_frame_t *o, int32_t m) { return sonde_engine_finish(g, o, m); });
     launch_framesync(e, 1);
     return sonde_engine_fetch_frames(e, out, max);
 }
 
 int sonde_engine_finish_channel(sonde_engine_t *e, int32_t channel) {
     if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
+    if (!e->groups.empty()) { const int gi = e->grp_of_ch[(size_t)channel]; return sonde_engine_finish_channel(e->groups[(size_t)gi], e->row_of_ch[(size_t)channel] - e->groups[(size_t)gi]->front_row); }
     e->eof_ch = channel;
     launch_framesync(e, 1);
     e->eof_ch = -1;
@@ -1204,7 +1345,7 @@ int sonde_engine_finish_channel(sonde_engine_t *e, int32_t channel) {
 }
 
 int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
-    if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
+    if (!e || !e->groups.empty() || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
     // channels of an engine share the base-rate sample clock (mixer table phase, IQ-DC segment schedule): only engines without that
     // front end can give one channel a new origin; the AFC loop of --dc and the pipelined streams are left out as well
     const bool base = e->cfg.input == SONDE_IN_IQ;            // --IQ fq: mixer + decimator in front of the IF-rate chain
@@ -1261,7 +1402,7 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
 }
 
 int sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq) {
-    if (!e || channel < 0 || channel >= e->cfg.n_channels || !(fq >= -0.5 && fq <= 0.5)) return SONDE_E_ARG;
+    if (!e || !e->groups.empty() || channel < 0 || channel >= e->cfg.n_channels || !(fq >= -0.5 && fq <= 0.5)) return SONDE_E_ARG;
     if (e->cfg.input == SONDE_IN_IQ && !e->ifiq && e->cfg.bits != 32 && !e->cfg.opt_nolut) {
         // base-rate engine: the channel's mixer table is that of `--IQ fq` (carrier snapped to the table's raster, demod_mod.c:1265-1288) and, in fold
         // mode, its row of the E table; meant to be followed by sonde_engine_restart_channel() — the samples the channel has seen were mixed with the old carrier
@@ -1283,7 +1424,7 @@ int sonde_engine_tune_channel(sonde_engine_t *e, int32_t channel, double fq) {
 }
 
 int sonde_engine_fetch_soft(sonde_engine_t *e, float *soft, int32_t max_frames) {
-    if (!e || !soft || !e->d_soft) return SONDE_E_ARG;
+    if (!e || !e->groups.empty() || !soft || !e->d_soft) return SONDE_E_ARG;
     const int n = std::min(e->last_n, (int)max_frames);
     if (e->soft_lazy) {
         // the last fetch left the soft bits on the device (block codes decoded there): their ring slots now
@@ -1306,6 +1447,11 @@ int sonde_engine_fetch_soft1(sonde_engine_t *e, float *soft, int32_t max_frames)
 
 int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64_t first, int32_t count, float *out) {
     if (!e || !out || channel < 0 || channel >= e->cfg.n_channels || count < 0 || count > e->ring_len || first < 0) return SONDE_E_ARG;
+    if (!e->groups.empty()) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const int gi = e->grp_of_ch[(size_t)channel];
+        return sonde_engine_read_tap(e->groups[(size_t)gi], e->row_of_ch[(size_t)channel] - e->groups[(size_t)gi]->front_row, tap, first, count, out);
+    }
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
     if (e->stream_e) HIPCHK(hipStreamSynchronize(e->stream_e));
@@ -1333,6 +1479,7 @@ int sonde_engine_read_tap(sonde_engine_t *e, int32_t channel, int32_t tap, int64
 
 int sonde_engine_profile(sonde_engine_t *e, int enable) {
     if (!e) return SONDE_E_ARG;
+    for (sonde_engine *g : e->groups) sonde_engine_profile(g, enable);
     (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); if (e->stream_e) (void)hipStreamSynchronize(e->stream_e); prof_collect(e);
     e->prof = enable != 0; e->prof_level = enable == 1 ? 1 : 2; e->stats.clear();    // 1: dominant kernel only (2 events per launch), 2: every kernel
     return 0;
@@ -1341,10 +1488,99 @@ int sonde_engine_profile(sonde_engine_t *e, int enable) {
 int sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms, int64_t *launches) {
     if (!e || !kernel) return SONDE_E_ARG;
     (void)hipStreamSynchronize(e->stream); (void)hipStreamSynchronize(e->stream_b); if (e->stream_e) (void)hipStreamSynchronize(e->stream_e); prof_collect(e);
+    if (!e->groups.empty() && strcmp(kernel, "mix_decimate") != 0) {
+        // IF-rate kernels of a mixed engine: the groups' launches together (average per launch over all of them)
+        double ms = 0; int64_t n = 0;
+        for (sonde_engine *g : e->groups) { double m1 = 0; int64_t n1 = 0; sonde_engine_kernel_ms(g, kernel, &m1, &n1); ms += m1 * (double)n1; n += n1; }
+        if (avg_ms) *avg_ms = n ? ms / (double)n : 0; if (launches) *launches = n;
+        return 0;
+    }
     auto it = e->stats.find(kernel);
     if (it == e->stats.end() || it->second.n == 0) { if (avg_ms) *avg_ms = 0; if (launches) *launches = 0; return 0; }
     if (avg_ms) *avg_ms = it->second.ms / (double)it->second.n;
     if (launches) *launches = it->second.n;
+    return 0;
+}
+
+// ---- mixed engines ---------------------------------------------------------------------------------------------------------------
+int sonde_engine_create_mixed(const sonde_cfg_t *cfg, const double *fq, const sonde_group_t *groups, int32_t n_groups, const int32_t *group_of_channel, sonde_engine_t **out) {
+    if (!cfg || !fq || !groups || !group_of_channel || !out || cfg->abi_version != SONDE_ABI_VERSION) return SONDE_E_ARG;
+    if (cfg->sonde_type != SONDE_MIXED || n_groups < 1 || n_groups > 64 || cfg->n_channels < 1) return SONDE_E_ARG;
+    // the shared front end is the base-rate `--IQ fq` one through the mixer table; what couples the sync back into it (--dc), other input forms and the
+    // per-hit soft-bit interface stay with the single-type engines
+    if (cfg->input != SONDE_IN_IQ || (cfg->bits != 16 && cfg->bits != 8) || cfg->opt_dc || cfg->opt_nolut || cfg->if_tune || cfg->keep_soft || cfg->opt_iqdc) return SONDE_E_ARG;
+    const int C = cfg->n_channels;
+    std::vector<std::vector<int32_t>> ch_of((size_t)n_groups);
+    for (int c = 0; c < C; c++) {
+        if (group_of_channel[c] < 0 || group_of_channel[c] >= n_groups) return SONDE_E_ARG;
+        ch_of[(size_t)group_of_channel[c]].push_back(c);
+    }
+    for (int g = 0; g < n_groups; g++) {
+        const int t = groups[g].sonde_type;
+        if (t != SONDE_RS41 && t != SONDE_DFM09 && t != SONDE_M10 && t != SONDE_M20) return SONDE_E_ARG;
+    }
+    // groups first (their rings tell how long the shared y ring must be), then the owner of the front end
+    std::vector<sonde_engine *> parts; std::vector<int> part_grp;
+    auto drop = [&]() { for (sonde_engine *g : parts) sonde_engine_destroy(g); parts.clear(); part_grp.clear(); };
+    int min_ring = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int ring = 0; bool same = true;
+        for (int g = 0; g < n_groups; g++) {
+            const std::vector<int32_t> &chs = ch_of[(size_t)g];
+            if (chs.empty()) continue;
+            sonde_cfg_t c2 = *cfg;
+            c2.n_channels = (int32_t)chs.size(); c2.sonde_type = groups[g].sonde_type; c2.ecc_level = groups[g].ecc_level; c2.thres = groups[g].thres;
+            c2.lpiq_bw = groups[g].lpiq_bw; c2.opt_inv = groups[g].opt_inv; c2.opt_auto = groups[g].opt_auto; c2.m10_noskip = groups[g].m10_noskip;
+            c2.pipeline = 1;                                          // every group has its own stream B (+ E): the tails of the types run beside each other
+            c2.max_frames = cfg->max_frames > 0 ? std::max(16, (int)(((long long)cfg->max_frames * (long long)chs.size() + C - 1) / C)) : 0;
+            std::vector<double> f2(chs.size());
+            for (size_t i = 0; i < chs.size(); i++) f2[i] = fq[chs[i]];
+            const CreateLink lk{ true, false, min_ring };
+            sonde_engine *ge = nullptr;
+            const int rc = create_impl(&c2, f2.data(), nullptr, &lk, &ge);
+            if (rc) { drop(); return rc; }
+            parts.push_back(ge); part_grp.push_back(g);
+            if (ring && ge->ring_len != ring) same = false;
+            ring = std::max(ring, ge->ring_len);
+        }
+        if (parts.empty()) return SONDE_E_ARG;
+        min_ring = ring;
+        if (same) break;
+        if (pass == 0) drop();                                        // once more, every part at the longest ring
+    }
+    // the owner: channels in row order = group after group
+    std::vector<int32_t> in_row; std::vector<double> f_rows;
+    for (size_t k = 0; k < parts.size(); k++) for (int32_t c : ch_of[(size_t)part_grp[k]]) { in_row.push_back(c); f_rows.push_back(fq[c]); }
+    sonde_cfg_t cf = *cfg;
+    cf.sonde_type = SONDE_RS41; cf.ecc_level = 0; cf.pipeline = 1; cf.max_frames = 16; cf.thres = 0.f; cf.lpiq_bw = 0; cf.opt_inv = 0; cf.opt_auto = 0;      // (the preset is never used: front_only)
+    const CreateLink lf{ false, true, min_ring };
+    sonde_engine *e = nullptr;
+    const int rc = create_impl(&cf, f_rows.data(), nullptr, &lf, &e);
+    if (rc) { drop(); return rc; }
+    e->cfg.sonde_type = SONDE_MIXED;
+    e->groups = parts; e->ch_of_grp.resize(parts.size());
+    e->grp_of_ch.assign((size_t)C, 0); e->row_of_ch.assign((size_t)C, 0);
+    int row = 0;
+    for (size_t k = 0; k < parts.size(); k++) {
+        sonde_engine *g = parts[k];
+        g->front = e; g->front_row = row; g->d_y = e->d_y + (size_t)row * e->ring_len;
+        e->ch_of_grp[k] = ch_of[(size_t)part_grp[k]];
+        for (size_t i = 0; i < e->ch_of_grp[k].size(); i++) { e->grp_of_ch[(size_t)e->ch_of_grp[k][i]] = (int32_t)k; e->row_of_ch[(size_t)e->ch_of_grp[k][i]] = row + (int32_t)i; }
+        if (dalloc(&g->d_sum_map, e->ch_of_grp[k].size(), false) ||
+            hipMemcpy(g->d_sum_map, e->ch_of_grp[k].data(), e->ch_of_grp[k].size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+        row += g->cfg.n_channels;
+    }
+    if (e->ring_len != min_ring || dalloc(&e->d_in_row, in_row.size(), false) ||
+        hipMemcpy(e->d_in_row, in_row.data(), in_row.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { sonde_engine_destroy(e); return SONDE_E_NOMEM; }
+    *out = e;
+    return 0;
+}
+
+int sonde_engine_group_info(const sonde_engine_t *e, int32_t channel, int32_t *sonde_type, sonde_info_t *info) {
+    if (!e || channel < 0 || channel >= e->cfg.n_channels) return SONDE_E_ARG;
+    const sonde_engine *g = e->groups.empty() ? e : e->groups[(size_t)e->grp_of_ch[(size_t)channel]];
+    if (sonde_type) *sonde_type = g->cfg.sonde_type;
+    if (info) *info = g->info;
     return 0;
 }
 

@@ -185,6 +185,8 @@ __device__ __forceinline__ float2 md_phasor64(double f0, uint32_t n) {
     return make_float2(__builtin_amdgcn_cosf(fr), __builtin_amdgcn_sinf(fr));
 }
 // table index of the launch's first sample / blocks since the last change of the IQ-DC mean, for a channel that may have been restarted at run time
+// mixed engines (sonde_engine_create_mixed) keep their channels grouped by sonde type: channel ch of the engine reads row in_row[ch] of the caller's buffer
+__device__ __forceinline__ int md_in_row(const MixDecArgs &a, int ch) { return a.in_row ? a.in_row[ch] : ch; }
 __device__ __forceinline__ uint32_t md_lut_phase(const MixDecArgs &a, int ch) {
     if (!a.epoch_phase) return a.lut_phase;
     const uint32_t L = (uint32_t)a.lut_len;
@@ -294,7 +296,7 @@ void k_mix_decimate50(const MixDecArgs a) {
     const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
     const int nfull = min(ntiles, (a.nblocks - jt0) / MD_ROWS);        // leading tiles that lie completely inside the chunk
 
-    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)md_in_row(a, ch) * a.ch_stride;
     const float2 avg = a.dc_avg[ch];
     const uint64_t navg = md_navg_sgpr(avg);
     const double f0 = a.chan_f0[ch];
@@ -421,7 +423,7 @@ void k_mix_decimate50s(const MixDecArgs a) {
     const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
     const int nfull = min(ntiles, (a.nblocks - jt0) / MD_ROWS);
 
-    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)md_in_row(a, ch) * a.ch_stride;
     const double f0 = a.chan_f0[ch];
     float2 *yout = a.y + (size_t)ch * a.ring_len;
     const float *wt_s = a.wtab_g + 64 * 8;                     // tap rows * 2^-15
@@ -524,7 +526,7 @@ void k_mix_decimate50r(const MixDecArgs a) {
     const int ntiles = (je - jt0 + MD_ROWS - 1) / MD_ROWS;
     const int nfull = (a.nblocks & 1) ? 0 : min(ntiles, (a.nblocks - jt0) / MD_ROWS);      // (odd launches: channel rows need not sit on the 16-byte grid)
 
-    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)md_in_row(a, ch) * a.ch_stride;
     const double f0 = a.chan_f0[ch];
     float2 *yout = a.y + (size_t)ch * a.ring_len;
     const float *wt_s = a.wtab_g + 64 * 8;                     // tap rows * 2^-15
@@ -687,7 +689,7 @@ void k_mix_decimate(const MixDecArgs a) {
     if (jb >= a.nblocks) return;
     const int je = min(a.nblocks, jb + rows_per_seg);
 
-    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)md_in_row(a, ch) * a.ch_stride;
     const float2 avg = a.dc_avg[ch];
     const double f0 = a.chan_f0[ch];
     const uint32_t L = (uint32_t)a.lut_len;
@@ -912,7 +914,7 @@ void k_mix_decimate_wide(const MixDecArgs a) {
     if (jb >= a.nblocks) return;
     const int je = min(a.nblocks, jb + rows_per_seg);
 
-    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)ch * a.ch_stride;
+    const uint32_t *iq = reinterpret_cast<const uint32_t *>(a.iq) + (size_t)md_in_row(a, ch) * a.ch_stride;
     const float2 avg = a.dc_avg[ch];
     const double f0 = a.chan_f0[ch];
     const uint32_t L = (uint32_t)a.lut_len;
@@ -1974,8 +1976,9 @@ void k_framesync(const SyncArgs a) {
             if (a.summary && tid == 0) {                              // per-channel detection summary, stays on the device
                 bool clean = a.rs41 != 0;
                 if (a.rs41) for (int k = 0; k < 48; k++) clean &= (s_S[k] == 0);
-                sonde_summary_t *sm = a.summary + ch;
-                sm->channel_id = a.summary_base + (uint32_t)ch; sm->type = (uint8_t)a.summary_type; sm->inverted = (uint8_t)(st.mv < 0.f);
+                const uint32_t gch = a.summary_map ? (uint32_t)a.summary_map[ch] : (uint32_t)ch;      // mixed engines: the caller's channel number
+                sonde_summary_t *sm = a.summary + gch;
+                sm->channel_id = a.summary_base + gch; sm->type = (uint8_t)a.summary_type; sm->inverted = (uint8_t)(st.mv < 0.f);
                 sm->score = st.mv; sm->freq_offset_hz = DC ? (float)af.Df : 0.f;
                 sm->sample_pos = a.summary_epoch - (uint64_t)(uint32_t)((uint32_t)a.summary_epoch - st.mv_pos);     // mv_pos is the low half of a 64-bit index
                 sm->frames += 1; sm->frames_clean += clean ? 1u : 0u;

@@ -62,6 +62,12 @@ class SondeGeneric(C.Structure):
                 ("lpiq_bw", C.c_int32), ("lpfm_bw", C.c_int32), ("slice_baud", C.c_float), ("reserved", C.c_int32 * 3)]
 
 
+class SondeGroup(C.Structure):
+    """sonde_group_t: one decoder command line of a mixed engine (include/sonde_hip.h)"""
+    _fields_ = [("sonde_type", C.c_int32), ("ecc_level", C.c_int32), ("lpiq_bw", C.c_int32), ("opt_inv", C.c_int32), ("opt_auto", C.c_int32),
+                ("m10_noskip", C.c_int32), ("thres", C.c_float), ("reserved", C.c_int32)]
+
+
 class SondeInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("if_sr", "decM", "dectaps", "lut_len", "lpiq_taps", "lpfm_taps",
                                          "L", "M", "K", "N", "delay")] + \
@@ -73,7 +79,7 @@ def build_library(force: bool = False) -> str:
     src = os.path.join(_HERE, "csrc")
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
-    subprocess.check_call(["make", "-s", "-C", src])
+    subprocess.check_call(["make", "-s", "-j8", "-C", src])
     return LIB_PATH
 
 
@@ -102,6 +108,10 @@ def lib() -> C.CDLL:
         L.sonde_engine_fetch_hits.argtypes = [C.c_void_p, C.POINTER(SondeHit), C.c_int32, C.c_int32]
         L.sonde_engine_set_threshold.argtypes = [C.c_void_p, C.c_float]
         L.sonde_engine_fetch_m10.argtypes = [C.c_void_p, C.POINTER(SondeM10Frame), C.c_int32, C.c_int32]
+        L.sonde_engine_fetch_m10_lagged.argtypes = [C.c_void_p, C.POINTER(SondeM10Frame), C.c_int32, C.c_int32]
+        L.sonde_engine_fetch_dfm_lagged.argtypes = [C.c_void_p, C.POINTER(SondeDfmFrame), C.c_int32, C.c_int32]
+        L.sonde_engine_create_mixed.argtypes = [C.POINTER(SondeCfg), C.POINTER(C.c_double), C.POINTER(SondeGroup), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        L.sonde_engine_group_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(SondeInfo)]
         L.sonde_engine_fetch_m20.argtypes = [C.c_void_p, C.POINTER(SondeM20Frame), C.c_int32, C.c_int32]
         L.sonde_m10_rawline.argtypes = [C.POINTER(SondeM10Frame), C.c_int, C.c_char_p, C.c_size_t]
         L.sonde_m20_rawline.argtypes = [C.POINTER(SondeM20Frame), C.c_int, C.c_char_p, C.c_size_t]
@@ -290,18 +300,23 @@ class Engine:
             return frames, soft[:nh]
         return frames
 
-    def fetch_dfm_raw(self, finish: bool = False):
-        """DFM engines: the decoded frames as a ctypes array of sonde_dfm_frame_t and their count — no per-frame Python work (the batch caller's form)."""
+    def fetch_dfm_raw(self, finish: bool = False, lag: int = 0):
+        """DFM engines: the decoded frames as a ctypes array of sonde_dfm_frame_t and their count — no per-frame Python work (the batch caller's form).
+        lag = 1: only frames of calls before the latest one (sonde_engine_fetch_dfm_lagged)."""
         n = 8 * self._max_frames
         if getattr(self, "_dfmbuf", None) is None:
             self._dfmbuf = (SondeDfmFrame * n)()
+        if lag and not finish:
+            return self._dfmbuf, _chk(lib().sonde_engine_fetch_dfm_lagged(self._h, self._dfmbuf, n, lag))
         return self._dfmbuf, _chk(lib().sonde_engine_fetch_dfm(self._h, self._dfmbuf, n, int(finish)))
 
-    def fetch_m10_raw(self, finish: bool = False):
+    def fetch_m10_raw(self, finish: bool = False, lag: int = 0):
         """M10 engines: the frames as a ctypes array of sonde_m10_frame_t and their count — no per-frame Python work."""
         n = 4 * self._max_frames
         if getattr(self, "_m10buf", None) is None:
             self._m10buf = (SondeM10Frame * n)()
+        if lag and not finish:
+            return self._m10buf, _chk(lib().sonde_engine_fetch_m10_lagged(self._h, self._m10buf, n, lag))
         return self._m10buf, _chk(lib().sonde_engine_fetch_m10(self._h, self._m10buf, n, int(finish)))
 
     def fetch_hits(self, finish: bool = False):
@@ -364,3 +379,57 @@ class Engine:
     @property
     def stream(self) -> int:
         return lib().sonde_engine_stream(self._h)
+
+
+_KIND = {"rs41": SONDE_RS41, "dfm": SONDE_DFM09, "m10": SONDE_M10, "m20": SONDE_M20}
+SONDE_MIXED = 100
+
+
+class MixedEngine(Engine):
+    """Mixed-type engine (sonde_engine_create_mixed): channel c carries a sonde of type kinds[c] ("rs41" / "dfm" / "m10" / "m20"); ONE decimator launch per call
+    serves all channels, the IF-rate stages run per type.  ecc = {kind: level} (rs41mod --ecc2 = 2, dfm09mod --ecc = 1).  Frames come back per type:
+    fetch_frames* (RS41), fetch_dfm* (DFM), fetch_m10* / fetch_mxx (M10 / M20), channel numbers are the caller's."""
+
+    def __init__(self, fq, kinds, sample_rate: int, *, device: int = 0, lp_iq: bool = True, ecc: dict | None = None, thres: dict | None = None,
+                 max_chunk: int | None = None, max_frames: int = 0, opt_min: bool = False, bits: int = 16, pipeline: bool = True):
+        fq = np.atleast_1d(np.asarray(fq, dtype=np.float64))
+        kinds = list(kinds)
+        assert len(kinds) == len(fq)
+        ecc = {"rs41": 2, "dfm": 1, "m10": 0, "m20": 0, **(ecc or {})}
+        thres = thres or {}
+        self.kinds = kinds
+        self.group_kinds = list(dict.fromkeys(kinds))              # groups in order of first appearance
+        self.n_channels = len(fq)
+        self.sample_rate = sample_rate
+        self.sonde = "mixed"
+        self.ecc = ecc["dfm"]                                      # (Engine.fetch_dfm prints the raw line with it)
+        self._ecc = ecc
+        self._per_sample = 2
+        self._dtype = {8: np.uint8}.get(bits, np.int16)
+        cfg = SondeCfg(ABI_VERSION, device, self.n_channels, sample_rate, bits, SONDE_MIXED, LP_IQ if lp_iq else 0, 0, int(opt_min), 0, 0,
+                       0.0, max_chunk or sample_rate, max_frames, 0, int(pipeline), 0, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+        groups = (SondeGroup * len(self.group_kinds))()
+        for i, k in enumerate(self.group_kinds):
+            groups[i] = SondeGroup(_KIND[k], ecc[k], 0, 0, 0, 0, float(thres.get(k, 0.0)), 0)
+        gof = np.asarray([self.group_kinds.index(k) for k in kinds], dtype=np.int32)
+        h = C.c_void_p()
+        _chk(lib().sonde_engine_create_mixed(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), groups, len(self.group_kinds),
+                                              gof.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h)))
+        self._h = h
+        info = SondeInfo()
+        _chk(lib().sonde_engine_info(h, C.byref(info)))
+        self.info = {n: getattr(info, n) for n, _ in SondeInfo._fields_ if n != "reserved"}
+        self.nbits = 4080
+        self._max_frames = max_frames or 4 * self.n_channels
+
+    def group_info(self, channel: int):
+        t, info = C.c_int32(), SondeInfo()
+        _chk(lib().sonde_engine_group_info(self._h, channel, C.byref(t), C.byref(info)))
+        return t.value, {n: getattr(info, n) for n, _ in SondeInfo._fields_ if n != "reserved"}
+
+    def fetch_mxx(self, finish: bool = False, verbose: int = 1, m20: bool = False):
+        self.sonde = "m20" if m20 else "m10"
+        try:
+            return Engine.fetch_mxx(self, finish=finish, verbose=verbose)
+        finally:
+            self.sonde = "mixed"
