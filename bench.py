@@ -427,6 +427,10 @@ def bench_demod(args, D: Dist):
         out["cpu_baseline"] = cpu_baseline_demod(fqs, caps)
     if D.world == 1 and not args.no_extras and not args.no_configs:
         import bench_configs
+        try:
+            out["side_paths"] = bench_configs.side_paths(D, caps, fqs)
+        except Exception as exc:
+            out["side_paths"] = {"error": repr(exc)}
         for name in ("scan_wide", "fsk_mixed", "mixed_2400k"):            # BASELINE configs[2], [3] and [4] at [3]'s type mix in the same line (short runs)
             sub = argparse.Namespace(**vars(args))
             sub.config, sub.steps, sub.warmup, sub.channels, sub.cpu_budget = name, None, None, 0, 6.0
@@ -437,7 +441,7 @@ def bench_demod(args, D: Dist):
     return out
 
 
-def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag, groups=16):
+def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag, groups=16, engine_step=None, engine_drain=None):
     """BASELINE configs[4] "full detect -> demod -> ECC" as one step: the demodulator step over all C channels with the dft_detect scanner
     (`--IQ fq --dc`, front end + 14 templates) re-scanning a rotating 1/16 of the channels over the same second, inside the step — the
     auto_rx duty cycle: decoders run on the channels that were found while the scanner keeps sweeping (scan.py:948, decode.py:869-913).
@@ -445,6 +449,14 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag, groups=16):
     engine's frames of the previous call AND the scanner's detections of this one have been fetched.  Not part of `value`."""
     torch = D.torch
     from radiosonde_auto_rx_amd.scan import Scanner
+    if engine_step is None:                                               # (another engine's step / drain: the mixed-type configuration, bench_configs.py)
+        def engine_step():
+            eng.process_device(iq.data_ptr(), STRIDE, SR)                          # asynchronous on the engine's stream(s)
+            return eng.fetch_frames_np(lag=lag)
+
+        def engine_drain():
+            eng.fetch_frames_np(lag=0)
+            eng.sync()
     per = max(1, C // groups)
     scs = [Scanner(SR, fq=ch_fq[g * per:(g + 1) * per], dc=True, cont=True, max_chunk=SR, device=D.local_rank) for g in range(groups)]
     found = [0]
@@ -455,26 +467,24 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag, groups=16):
     def scan(g):                                                          # on a host thread of its own (the C call releases the GIL): the scanner's
         sc = scs[g]                                                       # call waits for its kernels between stages, on its own high-priority stream
         sc.process_device(iq.data_ptr() + 4 * STRIDE * g * per, STRIDE, SR)
-        return sum(1 for d in sc.fetch() if d["type"] == "RS41")
+        return sum(1 for d in sc.fetch() if d["type"] in ("RS41", "DFM9", "M10", "M20"))
 
     def step(k):
         job = pool.submit(scan, k % groups)
-        eng.process_device(iq.data_ptr(), STRIDE, SR)                              # asynchronous on the engine's stream(s)
-        fr = eng.fetch_frames_np(lag=lag)
+        fr = engine_step()
         found[0] += job.result()                                                    # the step is over when both are
         return fr
 
     for k in range(max(groups, 3)):                                       # every scanner has seen a second (allocations, first windows)
         step(k)
-    eng.fetch_frames_np(lag=0)
+    engine_drain()
     torch.cuda.synchronize()
     found[0] = 0
     n = max(12, 4 * groups)
     t0 = time.perf_counter()
     for k in range(n):
         step(k)
-    eng.fetch_frames_np(lag=0)
-    eng.sync()
+    engine_drain()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     pool.shutdown()
@@ -482,7 +492,7 @@ def detect_in_step_extra(D: Dist, eng, iq, ch_fq, C, STRIDE, lag, groups=16):
         sc.close()
     return dict(ms_per_step=round(dt * 1e3, 3), value=round(C * SR / dt / 1e6, 1), unit="Msamples/s", realtime_channels=round(C * SR / dt / 2.4e6, 1),
                 channels_scanned_per_step=per, scan_duty=("1/%d of the channels per step, rotating" % groups) if groups > 1 else "every channel every step", steps=n,
-                rs41_detections_per_scanned_channel=round(found[0] / float(n * per), 3),
+                detections_per_scanned_channel=round(found[0] / float(n * per), 3),
                 note="demodulator step over all channels + dft_detect scanner (front end, 14 templates) over 1 s of %s, inside the step" % (("a rotating 1/%d of them" % groups) if groups > 1 else "all of them"))
 
 
@@ -557,6 +567,65 @@ def _stream_probe(ptr, nbytes):
     return float(g.value) if rc == 0 and g.value > 0 else None
 
 
+# ---- the printed line.  The driver keeps the last ~8 KB of stdout: the line must fit with every object in it.  What is printed is the numbers; the prose
+# (notes, method descriptions) stays in the full object, written next to it (gpurun_out/bench_full.json, or $SONDE_BENCH_FULL), and in DESIGN.md §5 / INTEGRATION.md.
+_DROP_KEYS = {"ecc", "error_mix", "frames_ok_means", "kernel_alone", "clocks_mhz", "rank_ms_per_step", "verify_mismatch_channels", "stdout_bytes", "per_core",
+              "samples_per_channel_per_step", "repeats", "scan_duty", "sequential", "summary_records", "algorithmic_gb_per_launch", "launches", "unique_captures_per_family",
+              "timed_seconds", "two_streams", "frame_fetch_lag", "fsk_demod_args", "what", "step", "soft_decisions", "detections_last_step", "stages", "stream_rate",
+              "frames_dropped", "symbols_or_codewords_repaired", "per_type", "launches_per_step"}
+_KEEP_LONG = {"workload": 230, "sample": 170, "metric": 130}
+LINE_LIMIT = 7600
+
+
+def compact(obj, top=True, head=True):
+    """the object as it is printed: no notes, no long strings, sub-objects reduced to their figures"""
+    if isinstance(obj, dict):
+        out = {}
+        for k, v in obj.items():
+            if k.endswith("note") or k.endswith("notes") or k in _DROP_KEYS:
+                continue
+            if not top and k in ("higher_is_better", "scaling", "vs_baseline", "data", "n_gpus", "warmup"):     # (said once, by the headline)
+                continue
+            if isinstance(v, str):
+                lim = _KEEP_LONG.get(k, 90) if head or k not in ("workload", "metric") else {"workload": 130, "metric": 70}[k]
+                v = v if len(v) <= lim else v[:lim - 3] + "..."
+            else:
+                v = compact(v, False, head and (not top or k in ("config", "roofline", "cpu_baseline")))
+            out[k] = v
+        return out
+    if isinstance(obj, list):
+        return [compact(v, False, head) for v in obj] if len(obj) <= 24 else None
+    if isinstance(obj, float):
+        return float("%.5g" % obj)
+    return obj
+
+
+def emit(out):
+    full = os.environ.get("SONDE_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        with open(full, "w") as f:
+            json.dump(out, f)
+    except OSError:
+        pass
+    if os.environ.get("SONDE_BENCH_VERBOSE"):
+        print(json.dumps(out), flush=True)
+        return
+    c = compact(out)
+    line = json.dumps(c, separators=(",", ":"))
+    # should an object have grown: shed tables until the line fits the driver's tail, the figures of every object stay
+    for path in (("fsk_mixed", "config", "consumers"), ("scan_wide", "config", "brute_force"), ("mixed_2400k", "kernels"), ("config", "kernels"), ("scan_wide", "config", "kernels_ms_per_launch"),
+                 ("detect_in_step", "duty_1_4"), ("mixed_2400k", "config", "frames_ok_per_step")):
+        if len(line) <= LINE_LIMIT:
+            break
+        d = c
+        for k in path[:-1]:
+            d = d.get(k, {}) if isinstance(d, dict) else {}
+        if isinstance(d, dict) and d.pop(path[-1], None) is not None:
+            line = json.dumps(c, separators=(",", ":"))
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -580,7 +649,7 @@ def main():
         import bench_configs
         out = bench_configs.run(args, D)
     if D.rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     D.close()
 
 

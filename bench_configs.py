@@ -172,6 +172,7 @@ def bench_fsk_mixed(args, D, short=False):
     # auto_rx's own argument sets (auto_rx/autorx/decode.py): RS41 :869-907 `-b -5000 -u 5000 --mask 5000 --nsym=300 -p 5`; DFM :1036-1067
     # `-b -5000 -u 5000` with fsk_demod's defaults P = 10 (utils/fsk_demod.c:71), nsym = 50 (fsk.h:46); M10 :1085-1122 `-b -10000 -u 10000 -p 5`
     groups = [("rs41", 48000, 4800, 5, 300, 5000, 5000), ("dfm", 50000, 2500, 10, 50, 0, 5000), ("m10", 48080, 9616, 5, 50, 0, 10000)]
+    NB = 16
 
     def ref_args(P, nsym, mask, lim):
         return ["--cs16", "-b", str(-lim), "-u", str(lim), "-s"] + (["--mask", str(mask)] if mask else []) + ["--nsym=%d" % nsym, "-p", str(P)]
@@ -181,17 +182,19 @@ def bench_fsk_mixed(args, D, short=False):
     for gi, (kind, Fs, Rs, P, nsym, mask, lim) in enumerate(groups):
         n = C // 3 + (1 if gi < C % 3 else 0)
         caps = []
-        for s in range(4):
+        for s in range(NB):                                   # NB unique captures per family: frame phase, carrier offset, noise and error count differ, so the channels of a launch do not move in lock step
             if kind == "rs41":
-                # (captures 1..3 carry 4 / 8 / 12 bit errors in the frame: the consumer's Reed-Solomon stage has symbols to repair)
-                caps.append(synth.rs41_capture(sr=Fs, seconds=1.0, fq=0.0, n_frames=1, t_first=0.05, noise_sigma=0.02, seed=s, f_offset_hz=150.0 * s, bit_errors=4 * s))
+                # (most captures carry bit errors in the frame: the consumer's Reed-Solomon stage has symbols to repair)
+                caps.append(synth.rs41_capture(sr=Fs, seconds=1.0, fq=0.0, n_frames=1, t_first=0.03 + 0.023 * s, noise_sigma=0.02 + 0.003 * (s % 4), seed=s, f_offset_hz=150.0 * (s % 4) - 40.0 * (s // 4),
+                                               bit_errors=4 * (s % 4)))
             elif kind == "dfm":
-                caps.append(synth.dfm_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=10 + s))
+                caps.append(synth.dfm_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02 + 0.004 * (s % 3), seed=10 + s, t_first=0.1 + 0.0119 * s))
             else:
-                caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02, seed=20 + s, baud=float(Rs), dev_hz=Rs / 2.0,     # tones Rs apart, as fsk_demod's estimator assumes
+                caps.append(synth.m10_capture(sr=Fs, seconds=1.0, fq=0.0, noise_sigma=0.02 + 0.004 * (s % 3), seed=20 + s, baud=float(Rs), dev_hz=Rs / 2.0,     # tones Rs apart, as fsk_demod's estimator assumes
+                                              t_first=0.35 + 0.017 * s,
                                               frame_fn=lambda k, s=s: synth.m10_frame(k, rng=np.random.default_rng(900 + 10 * s + k))))          # real frames: the checksum stage has something to accept
         L = min(len(c) for c in caps)
-        X = torch.from_numpy(np.stack([caps[c % 4][:L] for c in range(n)])).to(D.dev)
+        X = torch.from_numpy(np.stack([caps[c % NB][:L] for c in range(n)])).to(D.dev)
         md = FskModem(Fs, Rs, n_channels=n, P=P, nsym=nsym, mask=mask, lower=-lim, upper=lim, max_chunk=Fs, device=D.local_rank)
         engines.append((kind, Fs, Rs, n, X, md, caps[0], ref_args(P, nsym, mask, lim)))
         # the consumers of auto_rx's pipes on the device (sonde_softin_dev_*): decode.py:901-909 `fsk_demod ... | rs41mod --softin -i` (header search, bit loop, rs41_ecc --ecc2),
@@ -219,17 +222,17 @@ def bench_fsk_mixed(args, D, short=False):
         if have_ref:
             import subprocess
             exe = os.path.join(bind.REFDIR, "fsk_demod")
-            for b in range(min(4, n)):
+            for b in range(min(NB, n)):
                 argv = [exe] + rargs + ["2", str(Fs), str(Rs), "-", "-"]
                 r = subprocess.run(argv, input=X[b].cpu().numpy().tobytes(), capture_output=True, timeout=120)
                 refs[b] = np.frombuffer(r.stdout, np.float32)
-            vnote = "first second of every channel: soft decisions equal to channel (c mod 4) bit for bit, and that channel's to oracle/_ref/fsk_demod -s within 1e-6 of the RMS, same signs"
+            vnote = "first second of every channel: soft decisions equal to channel (c mod %d) bit for bit, and that channel's to oracle/_ref/fsk_demod -s within 1e-6 of the RMS, same signs" % NB
         for c in range(n):
             checked += 1
-            a0 = sds[c % 4].ravel(); ac = sds[c].ravel()
+            a0 = sds[c % NB].ravel(); ac = sds[c].ravel()
             ok = ac.shape == a0.shape and np.array_equal(ac, a0)
             if ok and have_ref:
-                w = refs[c % 4][:len(ac)]
+                w = refs[c % NB][:len(ac)]
                 rms = float(np.sqrt(np.mean(w.astype(np.float64) ** 2))) or 1.0
                 ok = len(w) == len(ac) and len(ac) > 0 and float(np.sqrt(np.mean((ac.astype(np.float64) - w) ** 2))) < 1e-6 * rms and np.array_equal(ac < 0, w < 0)
             verified += int(ok and have_ref)
@@ -247,7 +250,7 @@ def bench_fsk_mixed(args, D, short=False):
             want = {}
             if have_ref:
                 import subprocess
-                for b in range(min(4, n)):
+                for b in range(min(NB, n)):
                     p1 = subprocess.run([os.path.join(bind.REFDIR, "fsk_demod")] + rargs + ["2", str(Fs), str(Rs), "-", "-"], input=cons["caps"][b][:X.shape[1]].tobytes() * 3, capture_output=True, timeout=120)
                     p2 = subprocess.run([os.path.join(bind.REFDIR, cons["binary"])] + cons["args"], input=p1.stdout, capture_output=True, timeout=120)
                     want[b] = [l.rstrip() for l in p2.stdout.decode().splitlines()]
@@ -256,7 +259,9 @@ def bench_fsk_mixed(args, D, short=False):
             for c in range(n):
                 cons["checked"] += 1
                 g = got.get(c, [])
-                cons["ok"] += int(have_ref and len(g) >= 1 and g == want[c % 4][:len(g)])
+                w = want.get(c % NB, [])
+                # every frame the reference prints, in order — only the frame in progress at the end of the third second may still be missing (it is the next call's)
+                cons["ok"] += int(have_ref and len(g) >= max(1, len(w) - 1) and g == w[:len(g)])
 
     # The three modem configurations are three engines with a stream each, driven by one host thread through the two-halves calls.  Per family and second k:
     #   sonde_fsk_wait (k - 1)              the modem's launch of the second before is through (its channel records on the host)
@@ -377,147 +382,360 @@ def bench_fsk_mixed(args, D, short=False):
     return out
 
 
+MIX_PATTERN = ("rs41", "dfm", "rs41", "m10", "rs41", "dfm", "rs41", "m10", "dfm", "rs41")      # 50 % RS41, 30 % DFM09, 20 % M10, interleaved: the type is a property of the channel
+MIX_BANK = 16                # unique captures per family (carrier, frame phase, carrier offset, noise and error count differ: channels of a launch do not move in lock step)
+MIX_REF = {"rs41": ("rs41mod", ["-r", "--ecc2"]), "dfm": ("dfm09mod", ["-r", "--ecc"]), "m10": ("m10mod", ["-r", "-v"])}
+
+
+def mixed_bank(SR=2_400_000, n=MIX_BANK):
+    """-> {kind: (fqs, captures)}: n one-second captures per family at 2.4 Msps, seeded"""
+    from concurrent.futures import ThreadPoolExecutor
+    from tools import synth
+    rng = np.random.default_rng(4242)
+    jobs = []
+    for kind in ("rs41", "dfm", "m10"):
+        for b in range(n):
+            fq = synth.snap_fq(float(rng.uniform(-0.4, 0.4)), SR)
+            jobs.append((kind, b, fq))
+
+    def make(job):
+        kind, b, fq = job
+        if kind == "rs41":
+            return synth.rs41_capture(sr=SR, seconds=1.0, fq=fq, n_frames=1, t_first=0.05 + 0.021 * b, seed=300 + b, noise_sigma=0.01 + 0.004 * (b % 5),
+                                      bit_errors=(0, 0, 6, 14, 0, 3, 30, 0)[b % 8], f_offset_hz=60.0 * (b % 7 - 3))
+        if kind == "dfm":
+            return synth.dfm_capture(sr=SR, seconds=1.0, fq=fq, noise_sigma=0.02 + 0.01 * (b % 4), seed=310 + b, bit_errors_per_frame=b % 3, t_first=0.02 + 0.0137 * b)
+        return synth.m10_capture(sr=SR, seconds=1.0, fq=fq, noise_sigma=0.02 + 0.01 * (b % 4), seed=320 + b, t_first=0.1 + 0.027 * b, f_offset_hz=80.0 * (b % 5 - 2),
+                                 frame_fn=lambda k, b=b: synth.m10_frame(k, rng=np.random.default_rng(500 + 10 * b + k), good_checksum=(k + b) % 4 != 3))
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        caps = list(ex.map(make, jobs))
+    out = {}
+    for (kind, b, fq), cap in zip(jobs, caps):
+        out.setdefault(kind, ([], []))
+        out[kind][0].append(fq); out[kind][1].append(cap)
+    return out
+
+
+def _dfm_undecodable(line):
+    """a `dfm09mod -r --ecc` line whose three blocks all failed the Hamming check"""
+    return line.count("[NO]") == 3 and "[OK]" not in line and "[KO]" not in line
+
+
+def cpu_baseline_mixed(bank, shares, SR, budget_s=9.0):
+    """The reference decoders on this host's cores at the bench's type mix: every type timed by itself on all cores (N concurrent processes over the same
+    captures), combined for the mix — a second of the mix costs sum(share_t / rate_t) seconds of the cores."""
+    from bench import _time_reference
+    from oracle import bind
+    if not bind.have_ref():
+        return None
+    ncores = max(1, min(os.cpu_count() or 1, 8))
+    secs = 6
+    rates, samples = {}, []
+    with tempfile.TemporaryDirectory() as td:
+        for kind, (fqs, caps) in bank.items():
+            paths = []
+            for b in range(min(len(caps), ncores)):
+                p = os.path.join(td, "%s%d.cs16" % (kind, b))
+                with open(p, "wb") as f:
+                    for _ in range(secs):
+                        f.write(caps[b].tobytes())
+                paths.append(p)
+            exe, a = MIX_REF[kind]
+            cmds = [[os.path.join(bind.REFDIR, exe)] + a + ["--IQ", repr(fqs[k % len(paths)]), "--lpIQ", "-", str(SR), "16"] for k in range(ncores)]
+            r = _time_reference(cmds, [paths[k % len(paths)] for k in range(ncores)], secs * SR, "Msamples/s", "%s processes" % exe, budget_s / 3)
+            rates[kind] = r["value"]; samples.append(r["sample"])
+            for p in paths:
+                os.remove(p)
+    mix = 1.0 / sum(shares[k] / rates[k] for k in rates)
+    return dict(value=round(mix, 1), unit="Msamples/s", cores=ncores, kind="reference", per_type={k: round(v, 1) for k, v in rates.items()},
+                sample="%d concurrent oracle/_ref processes per type over %d s of the bench's own 2.4 Msps captures (%s); combined at the channel shares %s"
+                       % (ncores, secs, "; ".join(samples), {k: round(v, 3) for k, v in shares.items()}))
+
+
 def bench_mixed_2400k(args, D, short=False):
-    """BASELINE configs[4] with the sonde types of configs[3]: channels at the base rate (2.4 Msps IQ each) through mix -> decimate -> FM -> header search -> frame
-    sync -> block code, half of them RS41 (Reed-Solomon (255,231) x 2), 30 % DFM09 (Hamming(8,4), eight frames per hit) and 20 % M10 (differential code, checksum),
-    one engine per type on its own streams, every block code on the device.  A step = one second of every channel; only decoded frames cross to the host.
+    """BASELINE configs[4] at the sonde types of configs[3]: channels at the base rate (2.4 Msps IQ each), half of them RS41 (Reed-Solomon (255,231) x 2), 30 % DFM09
+    (Hamming(8,4), eight frames per hit), 20 % M10 (differential code, checksum), interleaved, on ONE mixed-type engine (sonde_engine_create_mixed): one decimator launch
+    per step over all channels, the IF-rate stages per type on their own streams, every block code on the device, frames fetched one step behind.  A step = one second
+    of every channel.  Ranks own contiguous channel blocks; the 32-byte detection summaries are all_gathered from device memory once per step.
     Untimed, first: two seconds of every channel against the compiled reference decoders on the same samples (oracle/_ref, test infrastructure), line for line.
-    `host_decode_ab`: the same steps with the block codes on the host inside the fetch (what the device kernels replace)."""
+    Extra objects on one GPU: `detect_in_step` (the dft_detect scanner re-scanning a rotating 1/16 of the channels inside every step), `host_decode_ab` (block codes on the
+    host inside the fetch), `three_engines_ab` (one engine per type: the round-5 arrangement, three decimator launches per step)."""
     torch = D.torch
     import subprocess
-    from tools import synth
-    from radiosonde_auto_rx_amd.engine import Engine
+    from radiosonde_auto_rx_amd.engine import Engine, MixedEngine
+    from radiosonde_auto_rx_amd import shard
+    from bench import _traffic, _stream_probe, _device_clocks, detect_in_step_extra
     SR = 2_400_000
     C = args.channels or 512
-    n_dfm, n_m10 = (3 * C) // 10, C // 5
-    n_rs = C - n_dfm - n_m10
-    rng = np.random.default_rng(4242)
-    kinds = {}
-    for kind, n in (("rs41", n_rs), ("dfm", n_dfm), ("m10", n_m10)):
-        fqs, caps = [], []
-        for b in range(4):
-            fq = synth.snap_fq(float(rng.uniform(-0.4, 0.4)), SR)
-            if kind == "rs41":
-                cap = synth.rs41_capture(sr=SR, seconds=1.0, fq=fq, n_frames=1, t_first=0.15, seed=300 + b, noise_sigma=0.01, bit_errors=(0, 6, 14, 30)[b])
-            elif kind == "dfm":
-                cap = synth.dfm_capture(sr=SR, seconds=1.0, fq=fq, noise_sigma=0.02, seed=310 + b, bit_errors_per_frame=b % 3, t_first=0.02)
-            else:
-                cap = synth.m10_capture(sr=SR, seconds=1.0, fq=fq, noise_sigma=0.02, seed=320 + b, t_first=0.3,
-                                        frame_fn=lambda k, b=b: synth.m10_frame(k, rng=np.random.default_rng(500 + 10 * b + k), good_checksum=(k + b) % 4 != 3))
-            fqs.append(fq); caps.append(cap)
-        bank = [c % 4 for c in range(n)]
-        X = torch.from_numpy(np.stack(caps)).to(D.dev).index_select(0, torch.tensor(bank, device=D.dev)).contiguous()
-        kinds[kind] = dict(n=n, fqs=fqs, caps=caps, bank=bank, X=X)
+    kinds = [MIX_PATTERN[(c + D.rank) % len(MIX_PATTERN)] for c in range(C)]
+    bank = mixed_bank(SR)
+    seen = {k: 0 for k in bank}
+    ch_bank = []
+    for kd in kinds:                                                   # the b-th channel of a family decodes capture (b + rank) mod 16
+        ch_bank.append((seen[kd] + D.rank) % MIX_BANK); seen[kd] += 1
+    ch_fq = [bank[kd][0][b] for kd, b in zip(kinds, ch_bank)]
+    n_of = {k: kinds.count(k) for k in bank}
+    # resident input [C][2 * SR] int16, rows in the caller's channel order
+    order = {"rs41": 0, "dfm": 1, "m10": 2}
+    all_caps = torch.from_numpy(np.stack([cap for k in ("rs41", "dfm", "m10") for cap in bank[k][1]])).to(D.dev)
+    X = all_caps.index_select(0, torch.tensor([order[kd] * MIX_BANK + b for kd, b in zip(kinds, ch_bank)], device=D.dev)).contiguous()
+    del all_caps
+    torch.cuda.synchronize()
 
-    def make(kind):
-        k = kinds[kind]
-        ch_fq = [k["fqs"][b] for b in k["bank"]]
-        if kind == "rs41":
-            return Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * k["n"])
-        return Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, sonde=kind, ecc=1 if kind == "dfm" else 0, max_chunk=SR, max_frames=4 * k["n"])
+    def make():
+        return MixedEngine(ch_fq, kinds, SR, device=D.local_rank, lp_iq=True, ecc={"rs41": 2, "dfm": 1, "m10": 0}, max_chunk=SR, max_frames=8 * C)
+
+    def lines_of(eng, fin):
+        got = {}
+        for f in eng.fetch_frames(finish=fin) + eng.fetch_dfm(finish=fin) + eng.fetch_mxx(finish=fin):
+            got.setdefault(f["channel"], []).append(f["line"].rstrip())
+        return got
 
     # ---- untimed: two seconds of every channel against the reference decoders
-    ref_bin = {"rs41": ("rs41mod", ["-r", "--ecc2"]), "dfm": ("dfm09mod", ["-r", "--ecc"]), "m10": ("m10mod", ["-r", "-v"])}
     try:
         from oracle import bind
         have_ref = bind.have_ref()
     except Exception:
         have_ref = False
-    verified = {k: 0 for k in kinds}
+    verified = {k: 0 for k in bank}
+    exact = {k: 0 for k in bank}
     vnote = "compiled reference not present"
-    for kind, k in kinds.items():
-        eng = make(kind)
+    if not getattr(args, "no_verify", False):
+        eng = make()
         got = {}
         for sec in range(2):
-            eng.process_device(k["X"].data_ptr(), SR, SR)
-            fin = sec == 1
-            frames = eng.fetch_frames(finish=fin) if kind == "rs41" else eng.fetch_dfm(finish=fin) if kind == "dfm" else eng.fetch_mxx(finish=fin)
-            for f in frames:
-                got.setdefault(f["channel"], []).append(f["line"].rstrip())
+            eng.process_device(X.data_ptr(), SR, SR)
+            for c, ls in lines_of(eng, sec == 1).items():
+                got.setdefault(c, []).extend(ls)
         eng.close()
         if have_ref:
             want = {}
-            for b in range(4):
-                exe, a = ref_bin[kind]
-                r = subprocess.run([os.path.join(bind.REFDIR, exe)] + a + ["--IQ", repr(k["fqs"][b]), "--lpIQ", "-", str(SR), "16"], input=k["caps"][b].tobytes() * 2,
-                                   capture_output=True, timeout=300)
-                want[b] = [l.rstrip() for l in r.stdout.decode().splitlines()]
-            verified[kind] = sum(int(len(want[k["bank"][c]]) >= 1 and got.get(c, []) == want[k["bank"][c]]) for c in range(k["n"]))
-            vnote = ("two seconds of every channel (the capture twice, end of input behind them): the text lines of our frames equal the stdout of oracle/_ref/{rs41mod -r --ecc2, "
-                     "dfm09mod -r --ecc, m10mod -r -v} --IQ fq --lpIQ - 2400000 16 on the same samples")
+            for kind, (fqs, caps) in bank.items():
+                exe, a = MIX_REF[kind]
+                for b in range(MIX_BANK):
+                    r = subprocess.run([os.path.join(bind.REFDIR, exe)] + a + ["--IQ", repr(fqs[b]), "--lpIQ", "-", str(SR), "16"], input=caps[b].tobytes() * 2,
+                                       capture_output=True, timeout=300)
+                    want[kind, b] = [ln.rstrip() for ln in r.stdout.decode().splitlines()]
+            for c, (kd, b) in enumerate(zip(kinds, ch_bank)):
+                w, g = want[kd, b], got.get(c, [])
+                exact[kd] += int(len(w) >= 1 and g == w)
+                verified[kd] += int(len(w) >= 1 and len(g) == len(w) and all(a == q or (kd == "dfm" and _dfm_undecodable(a) and _dfm_undecodable(q)) for a, q in zip(w, g)))
+            vnote = ("2 s of every channel + end of input: our text lines == stdout of oracle/_ref/{rs41mod -r --ecc2, dfm09mod -r --ecc, m10mod -r -v} --IQ fq --lpIQ - 2400000 16; "
+                     "exact_channels: every line equal; verified_channels: every line equal except DFM lines BOTH sides print with all three blocks [NO] — slices of the gap "
+                     "between two transmissions of the 1 s loop (a DFM hit is eight frames = 1.79 s), noise only, where a soft bit at the float noise floor decides a nibble")
+        verified = dict(zip(verified, D.sum_ints(*verified.values())))
+        exact = dict(zip(exact, D.sum_ints(*exact.values())))
 
     # ---- timed
-    engs = {kind: make(kind) for kind in kinds}
-    order = ["rs41", "dfm", "m10"]
-    tallies = {k: [0, 0] for k in kinds}
+    eng = make()
+    summary = shard.summary_buffer(C, D.dev)
+    eng.set_summary(summary.data_ptr(), D.rank * C)
+    snaps = shard.summary_buffer(2 * C, D.dev).view(2, C, shard.SUMMARY_BYTES) if D.dist else None
+    snap_next = eng.set_summary_snapshots(snaps.data_ptr()) if snaps is not None else 0
+    gathered = [torch.empty_like(summary) for _ in range(D.world)] if D.dist else None
+    while eng.samples_to_dc_boundary() < SR:                           # untimed lead-in: from here on every 1 s step is one IQ-DC segment = one decimator launch
+        eng.process_device(X.data_ptr(), SR, eng.samples_to_dc_boundary())
+    tallies = {k: [0, 0] for k in bank}
+    dfm_dt = np.dtype([("h", "<i4", (2,)), ("ecc", "<i4", (3,)), ("rest", "u1", (88,))])
+    m10_dt = np.dtype([("h", "<i4", (3,)), ("cs_ok", "<i4"), ("rest", "u1", (136,))])
+    state = {"count": False, "calls": 0}
 
-    def step(count=True):
-        for kind in order:
-            engs[kind].process_device(kinds[kind]["X"].data_ptr(), SR, SR)
-        fr = engs["rs41"].fetch_frames_np()
-        buf_d, n_d = engs["dfm"].fetch_dfm_raw()
-        buf_m, n_m = engs["m10"].fetch_m10_raw()
-        if count:
+    def fetch(lag):
+        fr = eng.fetch_frames_np(lag=lag)
+        buf_d, n_d = eng.fetch_dfm_raw(lag=lag)
+        buf_m, n_m = eng.fetch_m10_raw(lag=lag)
+        if state["count"]:
             tallies["rs41"][0] += len(fr); tallies["rs41"][1] += int((fr["ecc"] >= 0).sum())
             if n_d:
-                a = np.frombuffer(buf_d, np.dtype([("h", "<i4", (2,)), ("ecc", "<i4", (3,)), ("rest", "u1", (88,))]), n_d)
+                a = np.frombuffer(buf_d, dfm_dt, n_d)
                 tallies["dfm"][0] += n_d; tallies["dfm"][1] += int((a["ecc"] >= 0).all(axis=1).sum())
             if n_m:
-                a = np.frombuffer(buf_m, np.dtype([("h", "<i4", (3,)), ("cs_ok", "<i4"), ("rest", "u1", (136,))]), n_m)
+                a = np.frombuffer(buf_m, m10_dt, n_m)
                 tallies["m10"][0] += n_m; tallies["m10"][1] += int((a["cs_ok"] != 0).sum())
+        return fr
+
+    # frames are fetched one step behind, like the headline's (two steps behind is slower with the groups' stages in shared launches, faster with a stream per
+    # group: profiles/r6a_mixed_lag_ab.txt; and the engine keeps two summary snapshot halves, so ranks that gather them cannot go further back than one)
+    LAG = int(os.environ.get("SONDE_MIXED_LAG", "1"))
+
+    def step():
+        eng.process_device(X.data_ptr(), SR, SR)
+        state["calls"] += 1
+        fr = fetch(LAG)
+        if D.dist and state["calls"] >= 2:                             # 32 B per channel over RCCL, device to device: the snapshot call k-1 left while call k runs
+            shard.gather_summaries(D.dist, snaps[(snap_next + state["calls"] - 2) & 1], D.world, gathered)
+        return fr
 
     def drain():
-        for e in engs.values():
-            e.sync()
+        fetch(0)
+        eng.sync()
         torch.cuda.synchronize()
 
     steps0 = args.steps or 8
-    for v in tallies.values():
-        v[0] = v[1] = 0
     warm = 3 if args.warmup is None else args.warmup
-    counting = [False]
-    _step = step
-
-    def step():                                           # (the warm-up and probe steps do not count frames)
-        _step(counting[0])
-
     for _ in range(warm):
         step()
     drain()
-    counting[0] = True
-    dt, per_rank, nsteps = _timed_steps(D, step, steps0, 0, 1.0 if not args.steps else 0.0, drain=drain)
-    counting[0] = False
+    stream_gbps = _stream_probe(X.data_ptr(), int(X.numel()) * X.element_size())
+    clocks0 = _device_clocks()
+    eng.profile(1)                                                     # HIP events around the decimator only (2 per step), on the stream it runs on
+    min_s = 1.0 if not args.steps else 0.0
+    if min_s:                                                          # probe (untimed, uncounted): how many steps make a second
+        D.barrier(); t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        drain(); D.barrier()
+        probe, _ = D.finish_times(time.perf_counter() - t0)
+        steps0 = max(steps0, int(min_s / max(probe / 3, 1e-6)) + 1)
+    state["count"] = True
+    dt, per_rank, nsteps = _timed_steps(D, step, steps0, 0, 0.0, drain=drain)
+    state["count"] = False
+    clocks1 = _device_clocks()
     per = dt / nsteps
-    probe_steps = 3 if not args.steps else 0             # (_timed_steps' probe steps ran with the counters on)
-    counts = {k: (v[0] / (nsteps + probe_steps), v[1] / (nsteps + probe_steps)) for k, v in tallies.items()}
-    # A/B: the block codes on the host inside the fetch
-    for e in engs.values():
-        e.set_device_ecc(False)
-    for _ in range(3):
-        step()
-    drain()
-    dth, _, nh = _timed_steps(D, step, steps0, 0, 1.0 if not args.steps else 0.0, drain=drain)
-    per_host = dth / nh
-    for e in engs.values():
-        e.set_device_ecc(True); e.close()
+    md_ms, md_n = eng.kernel_ms("mix_decimate")
+    eng.profile(0)
+    counts = {k: (v[0] / nsteps, v[1] / nsteps) for k, v in tallies.items()}
+    rec = shard.decode_summaries(summary)
+
+    extras = {}
+    if D.world == 1 and not getattr(args, "no_extras", False):
+        # per-kernel table (untimed, events around every kernel)
+        eng.profile(2)
+        for _ in range(10):
+            step()
+        drain()
+        kern = {}
+        for k in ("mix_decimate", "if_chain", "header_corr", "framesync", "rs_ecc"):
+            ms, n = eng.kernel_ms(k)
+            kern[k] = dict(ms_per_step=round(ms * n / 10, 4), launches_per_step=n / 10)
+        eng.profile(0)
+        extras["kernels"] = kern
+
+        def eng_step():
+            eng.process_device(X.data_ptr(), SR, SR)
+            return fetch(LAG)
+        extras["detect_in_step"] = detect_in_step_extra(D, None, X, ch_fq, C, SR, 1, groups=16, engine_step=eng_step, engine_drain=drain)
+        # A/B: the block codes on the host inside the fetch
+        drain()
+        eng.set_device_ecc(False)
+        for _ in range(3):
+            step()
+        drain()
+        dth, _, nh = _timed_steps(D, step, 8, 0, 0.5 if not args.steps else 0.0, drain=drain)
+        extras["host_decode_ab"] = {"ms_per_step": round(dth / nh * 1e3, 3), "steps": nh}
+        eng.set_device_ecc(True)
+    eng.set_summary(0)
+    eng.close()
+    if D.world == 1 and not getattr(args, "no_extras", False):
+        # A/B: one engine per type (round 5): three decimator launches per step
+        idx = {k: [c for c, kd in enumerate(kinds) if kd == k] for k in bank}
+        Xs = {k: X.index_select(0, torch.tensor(v, device=D.dev)).contiguous() for k, v in idx.items()}
+        torch.cuda.synchronize()
+        e3 = {k: Engine([ch_fq[c] for c in idx[k]], SR, device=D.local_rank, lp_iq=True, sonde=k, ecc={"rs41": 2, "dfm": 1, "m10": 0}[k], max_chunk=SR, max_frames=8 * len(idx[k]))
+              for k in bank}
+
+        def step3():
+            for k in ("rs41", "dfm", "m10"):
+                e3[k].process_device(Xs[k].data_ptr(), SR, SR)
+            e3["rs41"].fetch_frames_np(); e3["dfm"].fetch_dfm_raw(); e3["m10"].fetch_m10_raw()
+
+        def drain3():
+            for e in e3.values():
+                e.sync()
+            torch.cuda.synchronize()
+        for _ in range(3):
+            step3()
+        drain3()
+        dt3, _, n3 = _timed_steps(D, step3, 8, 0, 0.5 if not args.steps else 0.0, drain=drain3)
+        extras["three_engines_ab"] = {"ms_per_step": round(dt3 / n3 * 1e3, 3), "steps": n3}
+        for e in e3.values():
+            e.close()
+        del Xs
     total = C * SR
+    achieved = (total * 4 * md_n) / (md_ms * md_n / 1e3) / 1e9 if md_ms > 0 and md_n > 0 else 0.0
+    traffic, traffic_src = _traffic("mix_decimate", total * 4)
     out = None
     if D.rank == 0:
         out = {
             "metric": "IQ Msamples/s demodulated + block-decoded, mixed RS41 / DFM09 / M10 channels at the base rate", "value": round(D.world * total / per / 1e6, 1), "unit": "Msamples/s",
             "n_gpus": D.world, "steps": nsteps, "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[4] at configs[3]'s type mix: %d channels x 2.4 Msps cs16 IQ per GPU — %d RS41 (rs41mod --ecc2), %d DFM09 (dfm09mod --ecc), %d M10 — "
-                                   "mix -> decimate -> FM -> header search -> frame sync -> block code on the device, one engine per type; 1 s per channel per step" % (C, n_rs, n_dfm, n_m10),
-                       "channels": {"rs41": n_rs, "dfm": n_dfm, "m10": n_m10}, "realtime_channels": round(total / per / SR, 1),
+            "config": {"workload": "BASELINE configs[4] at configs[3]'s type mix: %d channels x 2.4 Msps cs16 IQ per GPU on ONE mixed-type engine — %d RS41 (rs41mod --ecc2), %d DFM09 "
+                                   "(dfm09mod --ecc), %d M10, interleaved — one decimator launch per step, IF-rate stages per type, block codes on the device; 1 s per channel per step"
+                                   % (C, n_of["rs41"], n_of["dfm"], n_of["m10"]),
+                       "channels": n_of, "unique_captures_per_family": MIX_BANK, "realtime_channels": round(D.world * total / per / SR, 1), "timed_seconds": round(dt, 3), "frame_fetch_lag": LAG,
                        "rank_ms_per_step": [round(t / nsteps * 1e3, 3) for t in per_rank],
                        "frames_per_step": {k: round(v[0], 1) for k, v in counts.items()},
                        "frames_ok_per_step": {k: round(v[1], 1) for k, v in counts.items()},
                        "frames_ok_means": "rs41: rs41_ecc() >= 0; dfm: hamming() >= 0 in all three blocks; m10: checksum equal",
-                       "verified_channels": verified, "checked_channels": {k: v["n"] for k, v in kinds.items()}, "verify_note": vnote},
-            "host_decode_ab": {"ms_per_step": round(per_host * 1e3, 3), "steps": nh,
-                               "note": "sonde_engine_set_device_ecc(0) on all three engines: Reed-Solomon from the device syndromes, Hamming(8,4) and the M10 differential "
-                                       "decoding + checksum on one host thread inside the fetch, soft bits of every DFM / M10 hit copied to the host"},
+                       "summary_records": {"channels_with_frames": int((rec["frames"] > 0).sum())},
+                       "verified_channels": verified, "exact_channels": exact, "checked_channels": {k: D.world * v for k, v in n_of.items()}, "verify_note": vnote},
+            "roofline": {"bound": "hbm", "kernel": "k_mix_decimate50", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
+                         "measured_stream_GBps": round(stream_gbps, 1) if stream_gbps else None, "frac_of_measured": round(achieved / stream_gbps, 4) if stream_gbps else None,
+                         "traffic": traffic, "traffic_note": traffic_src, "algorithmic_gb_per_launch": round(total * 4 / 1e9, 3), "avg_launch_ms": round(md_ms, 4), "launches": md_n,
+                         "step_frac": round(total * 4 / per / 8e12, 4), "clocks_mhz": {"before": clocks0, "after": clocks1},
+                         "note": "ONE k_mix_decimate50 launch per step over all channels of all types (the same kernel and launch geometry as the headline's); achieved = 4 B x complex "
+                                 "samples of the timed launches / their HIP-event time on the stream they ran on; step_frac = the same bytes over the whole step"},
         }
+        out.update(extras)
+    if D.world == 1 and not getattr(args, "no_cpu_baseline", False):
+        cb = cpu_baseline_mixed(bank, {k: n_of[k] / C for k in n_of}, SR, getattr(args, "cpu_budget", None) or 9.0)
+        if cb:
+            out["cpu_baseline"] = cb
+    del X
+    torch.cuda.empty_cache()
+    return out
+
+
+def side_paths(D, caps, fqs, C=64, steps=12):
+    """What the input forms and options beside the headline's cost (verdict round 5, weak #6): the same RS41 step over C channels x 1 s with float32 samples (k_mix_f32 /
+    k_decimate_f32), unsigned 8-bit samples (k_u8_to_s16 in front of the cs16 kernels), --dc (AFC feedback: the host synchronises once per repair round) and with the C
+    channels mixed out of ONE 10 Msps stream (channel stride 0, k_mix_decimate_wide, D = 200) — each in ms per channel-second beside the cs16 path at the same C."""
+    torch = D.torch
+    from tools import synth
+    from radiosonde_auto_rx_amd.engine import Engine
+    SR = 2_400_000
+    nb = len(caps)
+    x16 = torch.from_numpy(np.stack([caps[c % nb] for c in range(C)])).to(D.dev)
+    ch_fq = [fqs[c % nb] for c in range(C)]
+    out = {"channels": C}
+
+    def timed(eng, ptr, stride, n):
+        for _ in range(3):
+            eng.process_device(ptr, stride, n); eng.fetch_frames_np()
+        eng.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = 0
+        for _ in range(steps):
+            eng.process_device(ptr, stride, n); got += len(eng.fetch_frames_np())
+        eng.sync(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        eng.close()
+        return dt, got / steps
+
+    def entry(dt, frames, seconds=1.0):
+        return {"ms_per_channel_second": round(dt * 1e3 / (C * seconds), 5), "ms_per_step": round(dt * 1e3, 3), "frames_per_step": round(frames, 1)}
+    base, fr = timed(Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C), x16.data_ptr(), SR, SR)
+    out["cs16"] = entry(base, fr)
+    xf = (x16.to(torch.float32) / 32768.0).contiguous()
+    dt, fr = timed(Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, bits=32), xf.data_ptr(), SR, SR)
+    out["f32"] = entry(dt, fr); del xf
+    x8 = ((x16.to(torch.int32) >> 8) + 128).to(torch.uint8).contiguous()
+    dt, fr = timed(Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, bits=8), x8.data_ptr(), SR, SR)
+    out["u8"] = entry(dt, fr); del x8
+    dt, fr = timed(Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, opt_dc=True), x16.data_ptr(), SR, SR)
+    out["dc"] = entry(dt, fr)
+    del x16
+    wsr = 10_000_000
+    sig = [dict(kind="rs41", fq=(-0.3 + 0.6 * i / 11), t_first=0.03 + 0.02 * i, amp=0.05) for i in range(12)]
+    wb = torch.from_numpy(synth.wideband_capture(wsr, 1.0, sig, noise_sigma=0.01, seed=5)).to(D.dev)
+    wfq = [synth.snap_fq(sig[c % 12]["fq"], wsr) for c in range(C)]
+    dt, fr = timed(Engine(wfq, wsr, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=2_000_000, max_frames=4 * C), wb.data_ptr(), 0, 2_000_000)
+    out["wide_d200"] = entry(dt, fr, seconds=0.2); out["wide_d200"]["what"] = "%d channels out of ONE 10 Msps stream, 0.2 s per step" % C
+    for k in ("f32", "u8", "dc", "wide_d200"):
+        out[k]["x_cs16"] = round(out[k]["ms_per_channel_second"] / out["cs16"]["ms_per_channel_second"], 2)
+    del wb
+    torch.cuda.empty_cache()
     return out
 
 

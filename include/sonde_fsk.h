@@ -72,7 +72,8 @@ int  sonde_fsk_process_host(sonde_fsk_t *f, const void *h_in, int64_t ch_stride,
 int  sonde_fsk_process_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
 /* sonde_fsk_process_device in two halves: submit enqueues everything on the engine's stream and returns, wait blocks until the launch is through.
  * Between the two the host is free: the other engines of a mixed batch can be submitted (their launches overlap on the GPU without a host thread
- * each).  Any other call of the engine waits first. */
+ * each).  Any other call of the engine waits first.  d_in is read by a copy that is only ENQUEUED when submit returns: it must stay untouched until
+ * sonde_fsk_wait (or any other call of the engine) has returned. */
 int  sonde_fsk_submit_device(sonde_fsk_t *f, const void *d_in, int64_t ch_stride, int32_t n_samples);
 int  sonde_fsk_wait(sonde_fsk_t *f);
 
@@ -116,7 +117,8 @@ int  sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
 /* sonde_softin_dev_push_fsk in two halves: submit waits for the modem's launch (sonde_fsk_wait), then puts the consumer's kernels and the copies of its frames on the
  * consumer's OWN stream and returns; collect waits for them.  In between the modem can be given its next second (sonde_fsk_submit_device): the modem keeps the soft
  * decisions of its last two launches, so the consumer of second k runs beside the modem of second k + 1.  Order per second: sonde_fsk_wait(k - 1), collect (k - 2),
- * submit_fsk (k - 1), sonde_fsk_submit_device (k). */
+ * submit_fsk (k - 1), sonde_fsk_submit_device (k).  The modem's launch that overwrites a buffer of soft decisions waits (on the device) for the consumer that was
+ * given that buffer, so another order costs overlap, never frames. */
 int  sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
 int  sonde_softin_dev_collect(sonde_softin_dev_t *s);
 /* the same over any soft-bit streams in device memory: channel c at d_soft + c * ch_stride, n_bits each */

@@ -200,7 +200,12 @@ struct SyncArgs {
     unsigned long long *prof; // SONDE_WF_PROF: cycles per phase of channel 0 (nullptr = off)
 };
 
+#define SONDE_MAX_GROUPS 6      // groups of a mixed engine whose IF-rate stages share a launch (the argument structs of all groups travel in the kernel argument segment: 4 KB)
 extern "C" {
+int  sonde_launch_if_chain_multi(const IfArgs *a, int n_groups, hipStream_t s);
+int  sonde_launch_sync_plan_multi(const WinPlanArgs *a, int n_groups, hipStream_t s);
+int  sonde_launch_sync_window_fft_multi(const WinFftArgs *a, int n_groups, hipStream_t s);
+int  sonde_launch_framesync_multi(const SyncArgs *a, int n_groups, hipStream_t s);
 int  sonde_launch_mix_decimate(const MixDecArgs *a, hipStream_t s);   // -1: decimation factor not instantiated
 void sonde_launch_dc_update(int n_ch, long long *sums, float2 *avg, float maxcnt, hipStream_t s);
 void sonde_launch_dc_update_keep(int n_ch, long long *sums, float2 *avg, float2 *avg_prev, float maxcnt, hipStream_t s);

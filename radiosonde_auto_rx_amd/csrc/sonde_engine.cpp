@@ -117,9 +117,10 @@ struct sonde_engine {
     bool front_only = false; int64_t snap_calls = 0;       // snap_calls: calls up to which the owner has enqueued a summary snapshot copy (ev_b of the owner)
     // a group of a mixed engine: who owns its front end, the first of the owner's rows that is this group's, its channels' numbers at the caller (summary records)
     sonde_engine *front = nullptr; int front_row = 0; int32_t *d_sum_map = nullptr; bool is_group = false;
+    bool merged = false, borrowed_b = false;     // merged (owner): one launch per IF-rate stage for all groups, on the one stream B they share; borrowed_b (group): stream_b is the owner's
 };
 // how sonde_engine_create_mixed creates its parts
-struct CreateLink { bool is_group, front_only; int min_ring; };
+struct CreateLink { bool is_group, front_only; int min_ring; hipStream_t shared_b; };     // shared_b: the ONE stream B of a mixed engine whose groups' IF-rate stages share launches (nullptr: a stream B per part)
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
     HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
@@ -189,6 +190,8 @@ static int collect_records(sonde_engine *e, int lag, std::vector<FrameRec> &recs
 }
 
 static void launch_framesync_impl(sonde_engine *e, int eof);
+static SyncArgs fill_sync(sonde_engine *e, int eof);
+static void fill_round(sonde_engine *e, int W, WinPlanArgs &p, WinFftArgs &f);
 // header position as the caller's stream counts it: from the channel's own start
 static inline uint32_t rel_pos(const sonde_engine *e, const FrameRec &r) { return e->epoch.empty() ? r.mv_pos : r.mv_pos - e->epoch[r.channel]; }
 extern "C" void sonde_launch_dfm_hits(const FrameRec *frames, const float *soft, int nbits, int max_frames, const unsigned *fcount, unsigned *done, sonde_dfm_frame_t *out,
@@ -596,7 +599,8 @@ static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_gen
     // pipeline: stream A (staging, decimator) may run ONE call ahead of stream B (IF-rate kernels); the rings hold that (see
     // process_device).  The FM-audio path writes the rings B reads from on stream A, so it does not pipeline.
     if (cfg->pipeline && audio) { sonde_engine_destroy(e); return SONDE_E_ARG; }
-    if (cfg->pipeline) {
+    if (lk && lk->shared_b) { e->stream_b = lk->shared_b; e->borrowed_b = is_group; }
+    else if (cfg->pipeline) {
         // the IF-rate tail of call k runs beside the decimator of call k+1: few, latency-bound workgroups against thousands of bandwidth-bound
         // ones — B gets the higher dispatch priority so that its workgroups take the next free CU slot instead of queueing behind the decimator's
         int lo = 0, hi = 0;
@@ -660,7 +664,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
         hipFree(e->d_wfprof);
     }
     { hipStream_t sa = e->stream; if (sa) hipStreamDestroy(sa); }
-    if (e->stream_b && e->stream_b != e->stream) hipStreamDestroy(e->stream_b);
+    if (e->stream_b && e->stream_b != e->stream && !e->borrowed_b) hipStreamDestroy(e->stream_b);
     if (e->stream_c) hipStreamDestroy(e->stream_c);
     if (e->stream_e) hipStreamDestroy(e->stream_e);
     if (e->ev_s) hipEventDestroy(e->ev_s);
@@ -715,6 +719,10 @@ static void tail_begin(sonde_engine *t, hipStream_t fs) {
     if (t->stream_b != fs && t->call >= 2) hipStreamWaitEvent(fs, wait_tail ? t->ev_b[(t->call - 2) & 3] : t->ev_if[(t->call - 2) & 3], 0);
 }
 static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hipStream_t fs, hipEvent_t front_done);
+static int tail_enqueue_merged(sonde_engine *e, int32_t n_samples, uint32_t m_first);
+static int tail_finish(sonde_engine *e);
+static int sync_rounds_of(const sonde_engine *e, int n_if);
+static IfArgs fill_if(sonde_engine *e, int n_if, uint32_t m_first);
 
 extern "C" {
 
@@ -842,8 +850,9 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
     int rc = 0;
     if (mixed) {
         hipEventRecord(e->ev_a[slot], e->stream);
-        for (sonde_engine *g : e->groups) {
-            g->samples_in = e->samples_in; g->m_out = e->m_out;
+        for (sonde_engine *g : e->groups) { g->samples_in = e->samples_in; g->m_out = e->m_out; }
+        if (e->merged) rc = tail_enqueue_merged(e, n_samples, m_first);
+        else for (sonde_engine *g : e->groups) {
             const int r2 = tail_enqueue(g, n_samples, m_first, e->stream, e->ev_a[slot]);
             if (r2 && !rc) rc = r2;
         }
@@ -864,20 +873,26 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
 
 }  // extern "C"
 
+// arguments of the IF chain of one call (k_if_chain): n_if IF samples per channel from IF index m_first on
+static IfArgs fill_if(sonde_engine *e, int n_if, uint32_t m_first) {
+    IfArgs b{};
+    const bool fe = e->cfg.sonde_type == SONDE_FRONTEND;
+    b.y = e->d_y; b.tap_ifiq = (e->cfg.keep_soft || fe) ? e->d_ifiq : nullptr; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = e->cfg.n_channels; b.ring_len = e->ring_len;
+    b.n = n_if; b.m0 = m_first;
+    b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
+    b.tone_on = (e->cfg.input != SONDE_IN_IFIQ0); b.nwin = (int)e->sps;           // --iq0 slices the FM stream (opt_iq = 1)
+    b.fm_on = (e->cfg.keep_soft || fe || !e->w_fm.empty() || !b.tone_on) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
+    b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps; b.epoch = e->d_epoch;
+    return b;
+}
 // The IF-rate part of a process call: IF chain, header search rounds, frame sync (+ block codes), decoder, counter publish — everything behind the decimator.
 // `e` is an engine that runs such a tail: a plain engine, or one group of a mixed engine; fs = the stream the decimator of the call ran on, front_done = the
 // event recorded behind it there (stream B waits for it unless it IS that stream); n_samples / m_first: the call's input samples per channel and the IF index of its first output.
 static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hipStream_t fs, hipEvent_t front_done) {
     const int D = e->info.decM, C = e->cfg.n_channels;
     const int n_if = n_samples / D;
-    IfArgs b{};
     const bool fe = e->cfg.sonde_type == SONDE_FRONTEND;
-    b.y = e->d_y; b.tap_ifiq = (e->cfg.keep_soft || fe) ? e->d_ifiq : nullptr; b.fm = e->d_fm; b.bufs = e->d_bufs; b.n_ch = C; b.ring_len = e->ring_len;
-    b.n = n_if; b.m0 = m_first;
-    b.lpiq_on = !e->w_iq.empty(); b.lpiq_taps = (int)e->w_iq.size(); b.lpfm_on = !e->w_fm.empty(); b.lpfm_taps = (int)e->w_fm.size();
-    b.tone_on = (e->cfg.input != SONDE_IN_IFIQ0); b.nwin = (int)e->sps;           // --iq0 slices the FM stream (opt_iq = 1)
-    b.fm_on = (e->cfg.keep_soft || fe || !e->w_fm.empty() || !b.tone_on) ? 1 : 0;   // fm_buffer feeds only --dc/--lpFM and the parity taps
-    b.w_iq = e->d_wiq; b.w_fm = e->d_wfm; b.rho = e->rho; b.sps = e->sps; b.epoch = e->d_epoch;
+    IfArgs b = fill_if(e, n_if, m_first);
     // IF-rate work goes to stream B behind this call's decimator; the next call's decimator may overlap it
     const int slot = (int)(e->call & 3);
     if (e->stream_b != fs) hipStreamWaitEvent(e->stream_b, front_done, 0);
@@ -916,8 +931,7 @@ static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hi
             // A round ends when the planned windows are used up or a hit's frame has been sliced (the search then resumes at a place the
             // plan could not know), so it covers at least min(W windows, one window + one frame) samples: two rounds for a call of up to
             // about a second, more for longer ones.
-            const int kw = std::max(1, e->info.K - 4);
-            const int rounds = 2 + n_if / (kw + (int)e->frame_samples) + n_if / (e->win_W * kw);
+            const int rounds = sync_rounds_of(e, n_if);
             for (int round = 0; round < rounds; round++) sync_round(e, round == 0 ? 2 : e->win_W);
         } else if (!fe) {
             // two passes (corr_tile_unused in sonde_kernels.hip): correlate what two search windows can reach, sync up to there, then the
@@ -936,6 +950,48 @@ static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hi
     }
     if (e->d_summary && e->d_summary_snap && !e->is_group)         // (a mixed engine copies once, behind all its groups: sonde_engine_process_device)
         hipMemcpyAsync(e->d_summary_snap + (size_t)(e->call & 1) * C, e->d_summary, (size_t)C * sizeof(sonde_summary_t), hipMemcpyDeviceToDevice, e->stream_b);
+    return tail_finish(e);
+}
+
+// The tail of a call of a mixed engine whose groups share launches: ONE IF chain, and per header-search round ONE plan, ONE window transform and ONE frame sync
+// over all rows (k_*_multi: the row's group brings its arguments), on the one stream B the groups share; behind each frame sync the block codes of the DFM / M10
+// groups, at the end every group's own finish (counter snapshot, RS41 decoder on its stream E, publish, ev_b).
+static int tail_enqueue_merged(sonde_engine *e, int32_t n_samples, uint32_t m_first) {
+    const int n_if = n_samples / e->info.decM, G = (int)e->groups.size();
+    hipStream_t sb = e->stream_b;
+    const int slot = (int)(e->call & 3);
+    hipStreamWaitEvent(sb, e->ev_a[slot], 0);
+    IfArgs ia[SONDE_MAX_GROUPS]; WinPlanArgs pa[SONDE_MAX_GROUPS]; WinFftArgs fa[SONDE_MAX_GROUPS]; SyncArgs sa[SONDE_MAX_GROUPS];
+    for (int g = 0; g < G; g++) ia[g] = fill_if(e->groups[(size_t)g], n_if, m_first);
+    prof_begin(e, "if_chain", sb); sonde_launch_if_chain_multi(ia, G, sb); prof_end(e, sb);
+    for (sonde_engine *g : e->groups) hipEventRecord(g->ev_if[slot], sb);         // (what tail_begin makes the next-but-one decimator wait for)
+    int rounds = 0;
+    for (sonde_engine *g : e->groups) rounds = std::max(rounds, sync_rounds_of(g, n_if));
+    for (int round = 0; round < rounds; round++) {
+        for (int g = 0; g < G; g++) fill_round(e->groups[(size_t)g], round == 0 ? 2 : e->groups[(size_t)g]->win_W, pa[g], fa[g]);
+        prof_begin(e, "header_corr", sb);
+        sonde_launch_sync_plan_multi(pa, G, sb);
+        sonde_launch_sync_window_fft_multi(fa, G, sb);
+        prof_end(e, sb);
+        for (int g = 0; g < G; g++) sa[g] = fill_sync(e->groups[(size_t)g], 0);
+        prof_begin(e, "framesync", sb); sonde_launch_framesync_multi(sa, G, sb); prof_end(e, sb);
+        for (sonde_engine *g : e->groups) launch_blockcodes(g);
+    }
+    int rc = 0;
+    for (sonde_engine *g : e->groups) { const int r2 = tail_finish(g); if (r2 && !rc) rc = r2; }
+    return rc;
+}
+
+// header-search rounds of a call of n_if IF samples: a round ends when the planned windows are used up or a hit's frame has been sliced
+static int sync_rounds_of(const sonde_engine *e, int n_if) {
+    const int kw = std::max(1, e->info.K - 4);
+    return 2 + n_if / (kw + (int)e->frame_samples) + n_if / (e->win_W * kw);
+}
+
+// the end of a call's tail, behind its last frame sync on stream B: frame counter snapshot, the decoder of the damaged RS41 frames (stream E), counter publish, ev_b
+static int tail_finish(sonde_engine *e) {
+    const int C = e->cfg.n_channels;
+    const int slot = (int)(e->call & 3);
     // the call's records are complete (ev_b) once its damaged frames are decoded and the counter is published
     hipStream_t se = e->stream_b;
     // the counter as THIS call's last frame sync leaves it, taken on the frame sync's own stream: what the call publishes.  (Published from the live counter
@@ -961,14 +1017,14 @@ static int tail_enqueue(sonde_engine *e, int32_t n_samples, uint32_t m_first, hi
 
 extern "C" {
 
-static void sync_round(sonde_engine *e, int W) {
+// arguments of one header-search round (k_sync_plan + k_sync_window_fft); advances the round counter
+static void fill_round(sonde_engine *e, int W, WinPlanArgs &p, WinFftArgs &f) {
     // the item table has win_W slots per channel; this round plans and evaluates the first W of them (the others are cleared)
     const int C = e->cfg.n_channels;
-    hipStream_t sb = e->stream_b;
-    WinPlanArgs p{}; p.state = e->d_state; p.items = e->d_win; p.n_ch = C; p.stride = e->win_W; p.W = W; p.K = e->info.K; p.L = e->info.L;
+    p = WinPlanArgs{}; p.state = e->d_state; p.items = e->d_win; p.n_ch = C; p.stride = e->win_W; p.W = W; p.K = e->info.K; p.L = e->info.L;
     p.delay = e->info.delay; p.frame_samples = e->frame_samples; p.avail = e->m_out; p.epoch = e->d_epoch;
     p.work = e->d_work; p.work_count = e->d_work_count; p.round_parity = e->sync_rounds & 1;
-    WinFftArgs f{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
+    f = WinFftArgs{}; f.bufs = e->d_bufs; f.items = e->d_win; f.Fm = e->d_Fm; f.tws = e->d_tws; f.n_ch = C; f.stride = e->win_W; f.W = W;
     f.K = e->info.K; f.L = e->info.L; f.ring_len = e->ring_len;
     f.work = e->d_work; f.work_count = e->d_work_count; f.round_parity = e->sync_rounds & 1; f.small_wg = e->small_tail; f.park = e->d_park;
     if (f.small_wg && !e->d_park) { if (hipMalloc((void **)&e->d_park, (size_t)SONDE_WFH_MAXGRID * 8192 * sizeof(float2)) != hipSuccess) f.small_wg = 0; f.park = e->d_park; }
@@ -976,6 +1032,11 @@ static void sync_round(sonde_engine *e, int W) {
     if (want_prof && !e->d_wfprof) { if (hipMalloc((void **)&e->d_wfprof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(e->d_wfprof, 0, 32 * sizeof(unsigned long long)); }
     f.prof = e->d_wfprof;
     e->sync_rounds++;
+}
+static void sync_round(sonde_engine *e, int W) {
+    hipStream_t sb = e->stream_b;
+    WinPlanArgs p; WinFftArgs f;
+    fill_round(e, W, p, f);
     prof_begin(e, "header_corr", sb);
     sonde_launch_sync_plan(&p, sb);
     sonde_launch_sync_window_fft(&f, sb);
@@ -983,7 +1044,8 @@ static void sync_round(sonde_engine *e, int W) {
     launch_framesync(e, 0);
 }
 
-static void launch_framesync_impl(sonde_engine *e, int eof) {
+// arguments of a frame-sync launch (k_framesync); a launch inside a process call of an engine with the device decoder claims the call's work list
+static SyncArgs fill_sync(sonde_engine *e, int eof) {
     const int C = e->cfg.n_channels;
     SyncArgs s{};
     s.eof = eof; s.eof_ch = e->eof_ch; s.epoch = e->d_epoch; s.rs41 = (e->cfg.sonde_type == SONDE_RS41); s.ecc_level = (s.rs41 && e->dev_ecc && e->cfg.ecc_level >= 1 && e->cfg.ecc_level <= 2) ? e->cfg.ecc_level : 0;
@@ -1004,6 +1066,10 @@ static void launch_framesync_impl(sonde_engine *e, int eof) {
     s.win = e->d_win; s.win_W = e->win_W;
     s.prof = e->d_wfprof ? e->d_wfprof + 16 : nullptr;
     s.summary = e->d_summary; s.summary_base = e->summary_base; s.summary_map = e->d_sum_map; s.summary_type = e->cfg.sonde_type; s.summary_epoch = e->samples_in / (uint64_t)std::max(1, e->info.decM);     // IF samples produced so far, 64 bit
+    return s;
+}
+static void launch_framesync_impl(sonde_engine *e, int eof) {
+    const SyncArgs s = fill_sync(e, eof);
     prof_begin(e, "framesync", e->stream_b); sonde_launch_framesync(&s, e->stream_b); prof_end(e, e->stream_b);
 }
 
@@ -1491,6 +1557,7 @@ int sonde_engine_kernel_ms(sonde_engine_t *e, const char *kernel, double *avg_ms
     if (!e->groups.empty() && strcmp(kernel, "mix_decimate") != 0) {
         // IF-rate kernels of a mixed engine: the groups' launches together (average per launch over all of them)
         double ms = 0; int64_t n = 0;
+        { auto it = e->stats.find(kernel); if (it != e->stats.end()) { ms += it->second.ms; n += it->second.n; } }      // (launches the groups share are booked here)
         for (sonde_engine *g : e->groups) { double m1 = 0; int64_t n1 = 0; sonde_engine_kernel_ms(g, kernel, &m1, &n1); ms += m1 * (double)n1; n += n1; }
         if (avg_ms) *avg_ms = n ? ms / (double)n : 0; if (launches) *launches = n;
         return 0;
@@ -1519,6 +1586,19 @@ int sonde_engine_create_mixed(const sonde_cfg_t *cfg, const double *fq, const so
         const int t = groups[g].sonde_type;
         if (t != SONDE_RS41 && t != SONDE_DFM09 && t != SONDE_M10 && t != SONDE_M20) return SONDE_E_ARG;
     }
+    // One stream B for all groups when their IF-rate stages share launches (k_*_multi: one IF chain, one plan / window transform / frame sync per round over all rows) —
+    // the default for up to SONDE_MAX_GROUPS groups; SONDE_MIXED_SPLIT=1: every group enqueues its own kernels on its own stream B (the A/B arm)
+    static const bool split = getenv("SONDE_MIXED_SPLIT") != nullptr;
+    int n_used = 0;
+    for (int g = 0; g < n_groups; g++) n_used += ch_of[(size_t)g].empty() ? 0 : 1;
+    const bool merged = !split && n_used <= SONDE_MAX_GROUPS;
+    hipStream_t shared_b = nullptr;
+    if (merged) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipSetDevice(cfg->device));
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) HIPCHK(hipStreamCreateWithPriority(&shared_b, hipStreamNonBlocking, hi));
+        else HIPCHK(hipStreamCreateWithFlags(&shared_b, hipStreamNonBlocking));
+    }
     // groups first (their rings tell how long the shared y ring must be), then the owner of the front end
     std::vector<sonde_engine *> parts; std::vector<int> part_grp;
     auto drop = [&]() { for (sonde_engine *g : parts) sonde_engine_destroy(g); parts.clear(); part_grp.clear(); };
@@ -1535,15 +1615,15 @@ int sonde_engine_create_mixed(const sonde_cfg_t *cfg, const double *fq, const so
             c2.max_frames = cfg->max_frames > 0 ? std::max(16, (int)(((long long)cfg->max_frames * (long long)chs.size() + C - 1) / C)) : 0;
             std::vector<double> f2(chs.size());
             for (size_t i = 0; i < chs.size(); i++) f2[i] = fq[chs[i]];
-            const CreateLink lk{ true, false, min_ring };
+            const CreateLink lk{ true, false, min_ring, shared_b };
             sonde_engine *ge = nullptr;
             const int rc = create_impl(&c2, f2.data(), nullptr, &lk, &ge);
-            if (rc) { drop(); return rc; }
+            if (rc) { drop(); if (shared_b) hipStreamDestroy(shared_b); return rc; }
             parts.push_back(ge); part_grp.push_back(g);
             if (ring && ge->ring_len != ring) same = false;
             ring = std::max(ring, ge->ring_len);
         }
-        if (parts.empty()) return SONDE_E_ARG;
+        if (parts.empty()) { if (shared_b) hipStreamDestroy(shared_b); return SONDE_E_ARG; }
         min_ring = ring;
         if (same) break;
         if (pass == 0) drop();                                        // once more, every part at the longest ring
@@ -1553,11 +1633,12 @@ int sonde_engine_create_mixed(const sonde_cfg_t *cfg, const double *fq, const so
     for (size_t k = 0; k < parts.size(); k++) for (int32_t c : ch_of[(size_t)part_grp[k]]) { in_row.push_back(c); f_rows.push_back(fq[c]); }
     sonde_cfg_t cf = *cfg;
     cf.sonde_type = SONDE_RS41; cf.ecc_level = 0; cf.pipeline = 1; cf.max_frames = 16; cf.thres = 0.f; cf.lpiq_bw = 0; cf.opt_inv = 0; cf.opt_auto = 0;      // (the preset is never used: front_only)
-    const CreateLink lf{ false, true, min_ring };
+    const CreateLink lf{ false, true, min_ring, shared_b };
     sonde_engine *e = nullptr;
     const int rc = create_impl(&cf, f_rows.data(), nullptr, &lf, &e);
-    if (rc) { drop(); return rc; }
-    e->cfg.sonde_type = SONDE_MIXED;
+    if (rc) { drop(); if (shared_b) hipStreamDestroy(shared_b); return rc; }
+    e->cfg.sonde_type = SONDE_MIXED; e->merged = merged;
+    for (sonde_engine *g : parts) if (merged && (!g->d_win || g->small_tail)) e->merged = false;      // (every group must be on the window-transform search, plain forms)
     e->groups = parts; e->ch_of_grp.resize(parts.size());
     e->grp_of_ch.assign((size_t)C, 0); e->row_of_ch.assign((size_t)C, 0);
     int row = 0;

@@ -41,6 +41,9 @@ struct sonde_fsk {
     float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
     // a launch that was submitted and not yet waited for (sonde_fsk_submit_device / sonde_fsk_wait); the channels the last wait had to repeat
     bool pending = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // consumers on the device read d_sd / d_sd_alt on streams of their own (sonde_softin_dev_submit_fsk): each of the two buffers remembers the last reader's end
+    // (sonde_fsk_dev_reader_done) and the launch that is about to overwrite it waits for that event — whatever order the caller submits things in
+    hipEvent_t ev_rd[2] = { nullptr, nullptr }; bool rd_set[2] = { false, false }; int sd_idx = 0;
 };
 
 template <class T> static int dalloc(T **p, size_t n, bool zero = true) {
@@ -116,6 +119,7 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
     if (!f) return;
     if (f->stream) { hipStreamSynchronize(f->stream); hipStreamDestroy(f->stream); }
     if (f->ev0) { hipEventDestroy(f->ev0); hipEventDestroy(f->ev1); }
+    for (hipEvent_t ev : f->ev_rd) if (ev) hipEventDestroy(ev);
     if (f->d_prof) {
         unsigned long long h[32];
         if (hipMemcpy(h, f->d_prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -180,7 +184,9 @@ static int launch_enqueue(sonde_fsk_t *f) {
     if (!f->ev0) { HIPCHK(hipEventCreate(&f->ev0)); HIPCHK(hipEventCreate(&f->ev1)); }
     f->h_chan_prev.assign(f->h_chan.begin(), f->h_chan.end());
     // (the wave form of the modem keeps these two copies itself as it loads the state; the older kernels — SONDE_FSK_KERNEL, an A/B aid — get them from here)
-    static const bool old_kernel = getenv("SONDE_FSK_KERNEL") != nullptr || getenv("SONDE_FSK_STREAM") != nullptr;
+    // (asked of the launcher itself: it also falls back to them where the wave form does not fit — Ndft < 64 or > 256, Ts % P != 0, more LDS than a CU has)
+    a.ch_list = nullptr; a.force_demod = 0;
+    const bool old_kernel = !sonde_fsk_wave_selected(&a);
     if (old_kernel) {
         HIPCHK(hipMemcpyAsync(f->d_Sf_bak, f->d_Sf, (size_t)C * Ndft * sizeof(float), hipMemcpyDeviceToDevice, f->stream));
         HIPCHK(hipMemcpyAsync(f->d_tail_bak, f->d_tail, (size_t)C * a.M * a.NT * sizeof(float2), hipMemcpyDeviceToDevice, f->stream));
@@ -188,7 +194,8 @@ static int launch_enqueue(sonde_fsk_t *f) {
     } else { a.Sf_bak = f->d_Sf_bak; a.tail_bak = f->d_tail_bak; }
     { const char *t = getenv("SONDE_FSK_TEST_ABORT"); a.test_abort_ch = t ? atoi(t) : -1; }
     a.ch_list = nullptr; a.force_demod = 0;
-    std::swap(f->d_sd, f->d_sd_alt); a.sd = f->d_sd;
+    std::swap(f->d_sd, f->d_sd_alt); a.sd = f->d_sd; f->sd_idx ^= 1;
+    if (f->rd_set[f->sd_idx]) { HIPCHK(hipStreamWaitEvent(f->stream, f->ev_rd[f->sd_idx], 0)); f->rd_set[f->sd_idx] = false; }     // a consumer of the launch before last may still be reading this buffer
     hipEventRecord(f->ev0, f->stream);
     static const bool want_prof = getenv("SONDE_FSK_PROF") != nullptr;            // profiling aid: cycles per phase of channel 0, printed when the modem is destroyed
     if (want_prof && !f->d_prof) { if (hipMalloc((void **)&f->d_prof, 32 * sizeof(unsigned long long)) == hipSuccess) hipMemset(f->d_prof, 0, 32 * sizeof(unsigned long long)); }
@@ -415,6 +422,17 @@ int sonde_fsk_clear_estimators(sonde_fsk_t *f) {               // fsk_clear_esti
 int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream) {
     if (!f) return SONDE_E_ARG;
     *d_sd = f->d_sd; *sd_cap = f->args.sd_cap; *d_chan = f->d_chan; *bits_per_frame = f->info.Nbits; *n_ch = f->cfg.n_channels; *stream = f->stream;
+    return 0;
+}
+
+// a consumer that has enqueued its reads of the buffer sonde_fsk_dev_view showed (the last launch's soft decisions) on `consumer_stream` says so: the launch that
+// will overwrite that buffer — the next but one — waits for this point of the consumer's stream
+int sonde_fsk_dev_reader_done(sonde_fsk_t *f, hipStream_t consumer_stream) {
+    if (!f) return SONDE_E_ARG;
+    const int i = f->sd_idx;
+    if (!f->ev_rd[i]) HIPCHK(hipEventCreateWithFlags(&f->ev_rd[i], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(f->ev_rd[i], consumer_stream));
+    f->rd_set[i] = true;
     return 0;
 }
 

@@ -977,12 +977,17 @@ void k_fsk_wave(const FskArgs a) {
     fsk_wave_channel<M, LOG2N, SPLIT, FMT>(a, ch, (int)threadIdx.x, lds, ctl);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of (function, device): the launchers remember what each device has been given
+#define FSK_MAX_DEV 16
+static int fsk_cur_dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0; return d % FSK_MAX_DEV; }
+
 template <int M, int LOG2N, bool SPLIT, int FMT>
 static int launch_wave_f(const FskArgs &b, const size_t lds_bytes, hipStream_t s) {
-    static size_t attr = 0;
-    if (lds_bytes > attr) {
+    static size_t attr[FSK_MAX_DEV] = {};                     // (the attribute is per device: one high-water mark each)
+    size_t &hw = attr[fsk_cur_dev()];
+    if (lds_bytes > hw) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fsk_wave<M, LOG2N, SPLIT, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
-        attr = lds_bytes;
+        hw = lds_bytes;
     }
     hipLaunchKernelGGL((k_fsk_wave<M, LOG2N, SPLIT, FMT>), dim3(b.n_ch), dim3(SPLIT ? (b.fin ? 256 : 192) : 64), lds_bytes, s, b);
     return 0;
@@ -997,22 +1002,35 @@ static int launch_wave_n(const FskArgs &b, const size_t lds_bytes, hipStream_t s
     return b.Ndft == 64 ? launch_wave<M, 6, SPLIT>(b, lds_bytes, s) : b.Ndft == 128 ? launch_wave<M, 7, SPLIT>(b, lds_bytes, s) : launch_wave<M, 8, SPLIT>(b, lds_bytes, s);
 }
 
-extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
+// which kernel a launch with these arguments gets: the wave form (mode 1 / 2; Ndft 64 / 128 / 256: every sonde configuration) or one of the older kernels (mode 0).
+// SONDE_FSK_KERNEL = wave2 (walker + worker, the default) | wave1 (one wave per channel) | stream (round 3's pipeline of four waves) | demod (frame at a time) — an A/B aid
+static int fsk_wave_plan(const FskArgs *a, int &R, int &fin, size_t &lds_w, bool &demod_env) {
     const int M = a->M, W = (a->nsym + 1) * a->P;
+    static const char *k_env = getenv("SONDE_FSK_KERNEL");
+    int mode = 2; demod_env = false;
+    if (k_env) { mode = !strcmp(k_env, "wave1") ? 1 : !strcmp(k_env, "wave2") ? 2 : 0; demod_env = !strcmp(k_env, "demod"); }
+    static const char *st_env0 = getenv("SONDE_FSK_STREAM");
+    if (st_env0) mode = 0;                                                  // (the older switch between the two older kernels implies one of them)
+    R = fw_ring_len(a->NT, a->Ts / a->P);
+    // the finisher (a fourth wave: soft decisions, Eb/N0 and record of a frame while the worker is in the next) where f_int fits twice: the short frames of DFM / M10
+    fin = 2 * (size_t)M * W * sizeof(float2) <= 16384 ? 1 : 0;
+    lds_w = fw_lds_floats(M, a->nsym, a->P, R, a->Ndft, fin) * sizeof(float);
+    const bool fits = (a->Ndft == 64 || a->Ndft == 128 || a->Ndft == 256) && a->P >= 1 && a->Ts % a->P == 0 && lds_w + sizeof(FwCtl) + 64 <= 160 * 1024 && a->iperm;
+    return (mode && !a->force_demod && fits) ? mode : 0;
+}
+// 1: sonde_launch_fsk will run the wave form, which keeps the Sf / tone-tail backups a repeat needs itself; 0: an older kernel, which does not (the host copies them)
+extern "C" int sonde_fsk_wave_selected(const FskArgs *a) {
+    int R, fin; size_t lds_w; bool demod_env;
+    return (a->M == 2 || a->M == 4) && fsk_wave_plan(a, R, fin, lds_w, demod_env) != 0;
+}
+
+extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
+    const int M = a->M;
     if (a->M != 2 && a->M != 4) return -1;
-    {   // the wave form (Ndft 64 / 128 / 256: every sonde configuration).  SONDE_FSK_KERNEL = wave2 (walker + worker, the default) | wave1 (one wave per channel) |
-        // stream (round 3's pipeline of four waves) | demod (frame at a time) — an A/B aid
-        static const char *k_env = getenv("SONDE_FSK_KERNEL");
-        int mode = 2; bool demod_env = false;
-        if (k_env) { mode = !strcmp(k_env, "wave1") ? 1 : !strcmp(k_env, "wave2") ? 2 : 0; demod_env = !strcmp(k_env, "demod"); }
-        static const char *st_env0 = getenv("SONDE_FSK_STREAM");
-        if (st_env0) mode = 0;                                                  // (the older switch between the two older kernels implies one of them)
-        const int R = fw_ring_len(a->NT, a->Ts / a->P);
-        // the finisher (a fourth wave: soft decisions, Eb/N0 and record of a frame while the worker is in the next) where f_int fits twice: the short frames of DFM / M10
-        const int fin = 2 * (size_t)M * W * sizeof(float2) <= 16384 ? 1 : 0;
-        const size_t lds_w = fw_lds_floats(M, a->nsym, a->P, R, a->Ndft, fin) * sizeof(float);
-        const bool fits = (a->Ndft == 64 || a->Ndft == 128 || a->Ndft == 256) && a->P >= 1 && a->Ts % a->P == 0 && lds_w + sizeof(FwCtl) + 64 <= 160 * 1024 && a->iperm;
-        if (mode && !a->force_demod && fits) {
+    {
+        int R, fin; size_t lds_w; bool demod_env;
+        const int mode = fsk_wave_plan(a, R, fin, lds_w, demod_env);
+        if (mode) {
             FskArgs b = *a; b.R = R; b.wave_mode = mode; b.fin = fin;
             static const char *rot_env = getenv("SONDE_FSK_ROT");
             b.role_rot = rot_env ? atoi(rot_env) : 1;
@@ -1048,11 +1066,12 @@ extern "C" int sonde_launch_fsk_old(const FskArgs *a, hipStream_t s) {
         }
         const size_t lds_s = total(R, bpw);
         if (!(st_env && atoi(st_env) == 0) && !a->force_demod && a->Ndft <= FSK_AE * 64 && a->Ndft >= FSK_AE && a->P >= 1 && a->Ts % a->P == 0 && lds_s <= 150 * 1024) {
-            static size_t attr_s[2] = { 0, 0 };
+            static size_t attr_s[FSK_MAX_DEV][2] = {};
             const void *fn = M == 2 ? reinterpret_cast<const void *>(k_fsk_stream<2>) : reinterpret_cast<const void *>(k_fsk_stream<4>);
-            if (lds_s > attr_s[M == 4]) {
+            size_t &hw = attr_s[fsk_cur_dev()][M == 4];
+            if (lds_s > hw) {
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess) return -2;
-                attr_s[M == 4] = lds_s;
+                hw = lds_s;
             }
             FskArgs b = *a; b.R = R; b.est_bpw = bpw;
             if (M == 2) hipLaunchKernelGGL(k_fsk_stream<2>, dim3(a->n_ch), dim3(FSK_THREADS), lds_s, s, b);
@@ -1079,11 +1098,12 @@ extern "C" int sonde_launch_fsk_old(const FskArgs *a, hipStream_t s) {
     if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
     FskArgs b = *a; b.est_waves = ng; b.est_bpw = 0; a = &b;
     if (a->M != 2 && a->M != 4) return -1;
-    static size_t attr[2] = { 0, 0 };
+    static size_t attr[FSK_MAX_DEV][2] = {};
     const void *fn = a->M == 2 ? reinterpret_cast<const void *>(k_fsk_demod<2>) : reinterpret_cast<const void *>(k_fsk_demod<4>);
-    if (lds > attr[a->M == 4]) {
+    size_t &hw = attr[fsk_cur_dev()][a->M == 4];
+    if (lds > hw) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-        attr[a->M == 4] = lds;
+        hw = lds;
     }
     if (a->M == 2) hipLaunchKernelGGL(k_fsk_demod<2>, dim3(a->n_ch), dim3(FSK_THREADS), lds, s, *a);
     else           hipLaunchKernelGGL(k_fsk_demod<4>, dim3(a->n_ch), dim3(FSK_THREADS), lds, s, *a);

@@ -126,4 +126,5 @@ float fsk_atan2f(const float yf, const float xf) {
 }
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s);
+extern "C" int sonde_fsk_wave_selected(const FskArgs *a);      // 1: that launch runs the wave form (which keeps the Sf / tail backups itself)
 #endif

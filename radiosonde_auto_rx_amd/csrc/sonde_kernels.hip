@@ -1217,11 +1217,10 @@ __global__ void k_fill_u32(uint32_t *p, uint32_t v, int n) {
 #define IF_LD 5
 #endif
 
-__global__ __launch_bounds__(IF_THREADS)
-void k_if_chain(const IfArgs a) {
+// (the body serves two kernels: k_if_chain — one sonde type, arguments in the kernel argument segment — and k_if_chain_multi, the channel groups of a mixed engine in one launch)
+__device__ __forceinline__ void if_chain_body(const IfArgs &a, const int ch, const int bx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int ch = blockIdx.y;
-    const uint32_t t0 = a.m0 + (uint32_t)blockIdx.x * IF_TILE;        // first output sample (absolute)
+    const uint32_t t0 = a.m0 + (uint32_t)bx * IF_TILE;        // first output sample (absolute)
     const int nout = min(IF_TILE, (int)(a.m0 + (uint32_t)a.n - t0));
     if (nout <= 0) return;
     const bool afc = a.afc != nullptr;
@@ -1343,7 +1342,10 @@ void k_if_chain(const IfArgs a) {
                 const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);   // revolutions in, abs error ~2e-7
 #endif
                 // X1 = z * e^{+i 2pi fr}; X2 = z * e^{-i 2pi fr}  (iw1 = 2 pi i f1, f1 < 0, demod_mod.c:796-803,1467-1470); stored side by side
-                sx4[k] = make_float4(re * cs - im * sn, re * sn + im * cs, re * cs + im * sn, im * cs - re * sn);
+                // (which product of a*b + c*d is rounded before the fused multiply-add is the compiler's choice under contraction, and it chose differently in the
+                // two kernels that share this body — one ulp apart; spelled out: the cosine products are rounded, the sine products fused)
+                const float rc = re * cs, ic = im * cs;
+                sx4[k] = make_float4(__builtin_fmaf(-sn, im, rc), __builtin_fmaf(sn, re, ic), __builtin_fmaf(sn, im, rc), __builtin_fmaf(-sn, re, ic));
             }
             if (a.tap_ifiq && m >= (int64_t)t0 && (int32_t)((uint32_t)m - start) >= 0)
                 a.tap_ifiq[(size_t)ch * a.ring_len + ((uint32_t)m & mask)] = make_float2(re, im);
@@ -1425,6 +1427,21 @@ void k_if_chain(const IfArgs a) {
             if (a.fm_on) *reinterpret_cast<float4 *>(fmb + mi) = make_float4(sfm[0], sfm[1], sfm[2], sfm[3]);
         }
     }
+}
+
+__global__ __launch_bounds__(IF_THREADS)
+void k_if_chain(const IfArgs a) { if_chain_body(a, blockIdx.y, blockIdx.x); }
+// Mixed engines: the groups (one sonde type each: own taps, tone spacing, window) side by side in ONE launch; blockIdx.y = row of the engine, rows grouped by type
+template <class A> struct MultiArgs { A g[SONDE_MAX_GROUPS]; int row0[SONDE_MAX_GROUPS + 1]; int n_groups; };
+template <class A> __device__ __forceinline__ int multi_group(const MultiArgs<A> &m, const int row) {
+    int g = 0;
+    while (g + 1 < m.n_groups && row >= m.row0[g + 1]) g++;
+    return __builtin_amdgcn_readfirstlane(g);
+}
+__global__ __launch_bounds__(IF_THREADS)
+void k_if_chain_multi(const MultiArgs<IfArgs> m) {
+    const int g = multi_group(m, (int)blockIdx.y);
+    if_chain_body(m.g[g], (int)blockIdx.y - m.row0[g], blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1713,8 +1730,7 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
 // L-sample energy, header bit check, the nbits soft bits, RS syndromes — are spread over the 1024 threads so that
 // each phase costs about one memory round trip instead of a chain of them.
 template <bool DC, int NT>
-__global__ __launch_bounds__(NT, (NT == 1024 ? 4 : 3))      // small form: at most 168 registers, a wave per SIMD
-void k_framesync(const SyncArgs a) {
+__device__ __forceinline__ void framesync_body(const SyncArgs &a, const int ch) {
     __shared__ uint8_t s_frame[520];
     __shared__ uint8_t s_exp[512];
     __shared__ uint8_t s_log[256];
@@ -1725,7 +1741,7 @@ void k_framesync(const SyncArgs a) {
     __shared__ uint8_t s_syn[(NT / WAVE)][48];
     __shared__ uint8_t s_S[48];                // first-pass syndromes of the frame in hand
     __shared__ double s_rd[(NT / WAVE)];
-    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (ch >= a.n_ch) return;
     const uint32_t mask = (uint32_t)a.ring_len - 1;
     const float *bufs = a.bufs + (size_t)ch * a.ring_len;
@@ -2000,12 +2016,21 @@ void k_framesync(const SyncArgs a) {
     }
 }
 
+template <bool DC, int NT>
+__global__ __launch_bounds__(NT, (NT == 1024 ? 4 : 3))      // small form: at most 168 registers, a wave per SIMD
+void k_framesync(const SyncArgs a) { framesync_body<DC, NT>(a, (int)blockIdx.x); }
+// mixed engines: one workgroup per row of the engine, the row's group brings its preset (header, bit clock, frame length, thresholds, record queue)
+__global__ __launch_bounds__(1024, 4)
+void k_framesync_multi(const MultiArgs<SyncArgs> m) {
+    const int g = multi_group(m, (int)blockIdx.x);
+    framesync_body<false, 1024>(m.g[g], (int)blockIdx.x - m.row0[g]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_sync_plan / k_sync_window_fft: the header search of find_header with the reference's transform (WinItem in sonde_dev.h)
 // ------------------------------------------------------------------------------------------------
 // the windows the frame sync will ask for, in order, assuming none of them finds a header (those behind a hit are not consumed)
-__global__ void k_sync_plan(const WinPlanArgs a) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void sync_plan_body(const WinPlanArgs &a, const int ch, const bool first_thread) {
     if (ch >= a.n_ch) return;
     const SyncState st = a.state[ch];
     WinItem *it = a.items + (size_t)ch * a.stride;
@@ -2028,8 +2053,19 @@ __global__ void k_sync_plan(const WinPlanArgs a) {
         const uint32_t at = atomicAdd(a.work_count + a.round_parity, (uint32_t)n);
         for (int i = 0; i < n; i++) a.work[at + (uint32_t)i] = (uint32_t)(ch * a.stride + i);
     }
-    if (a.work && ch == 0) a.work_count[a.round_parity ^ 1] = 0;            // the other round's counter: its consumer ran before this kernel
+    if (a.work && first_thread) a.work_count[a.round_parity ^ 1] = 0;       // the other round's counter: its consumer ran before this kernel
     for (; n < a.stride; n++) { it[n].pos = 0xffffffffu; it[n].state = 0; }
+}
+__global__ void k_sync_plan(const WinPlanArgs a) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    sync_plan_body(a, ch, ch == 0);
+}
+__global__ void k_sync_plan_multi(const MultiArgs<WinPlanArgs> m) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m.row0[m.n_groups]) return;
+    int g = 0;
+    while (g + 1 < m.n_groups && row >= m.row0[g + 1]) g++;
+    sync_plan_body(m.g[g], row - m.row0[g], row == m.row0[g]);
 }
 
 // The reference is plain C on x86-64: separately rounded multiplies and adds (no fused multiply-add) in the butterflies and products.
@@ -2177,21 +2213,28 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
 #else
 #define WF_WAVES_ATTR
 #endif
-__global__ __launch_bounds__(WF_THREADS) WF_WAVES_ATTR
-void k_sync_window_fft(const WinFftArgs a) {
+__device__ __forceinline__ void sync_window_fft_body(const WinFftArgs &a, const uint32_t b, const uint32_t nb) {      // workgroup b of the nb that share a's list
     extern __shared__ __attribute__((aligned(16))) float2 smem2[];
     float2 *x = smem2;                           // [SC_XN] padded (XI)
     float2 *tws = smem2 + SC_XN;       // [SC_TW_LDS + 1] twiddles of stages 0..8
     __shared__ float s_rf[WF_THREADS / WAVE + 1];
     __shared__ int s_ri[WF_THREADS / WAVE];
     const uint32_t count = a.work_count[a.round_parity];
-    if (blockIdx.x >= count) return;
+    if (b >= count) return;
     for (int k = threadIdx.x; k < SC_TW_LDS; k += WF_THREADS) tws[k] = a.tws[k];
-    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+    for (uint32_t w = b; w < count; w += nb) {
         const uint32_t item = a.work[w];
         __syncthreads();                         // the previous window's last reads of x / s_rf are over
         sync_eval_window(a, (int)(item / (uint32_t)a.stride), a.items + item, x, tws, s_rf, s_ri);
     }
+}
+__global__ __launch_bounds__(WF_THREADS) WF_WAVES_ATTR
+void k_sync_window_fft(const WinFftArgs a) { sync_window_fft_body(a, blockIdx.x, gridDim.x); }
+// mixed engines: row0[] counts WORKGROUPS here — group g's windows (its own template spectrum, K, L, list) are walked by workgroups row0[g] .. row0[g + 1] - 1
+__global__ __launch_bounds__(WF_THREADS) WF_WAVES_ATTR
+void k_sync_window_fft_multi(const MultiArgs<WinFftArgs> m) {
+    const int g = multi_group(m, (int)blockIdx.x);
+    sync_window_fft_body(m.g[g], blockIdx.x - (uint32_t)m.row0[g], (uint32_t)(m.row0[g + 1] - m.row0[g]));
 }
 // ---- the same window transform in HALF the LDS (round 4): a decimation-in-time network on bit-reversed input never mixes the two halves of its
 // array before the last stage (stage s pairs i with i + 2^s inside blocks of 2^(s+1) <= 4096 for s <= 11).  So the half [0, 4096) — the EVEN window
@@ -2553,6 +2596,48 @@ extern "C" void sonde_launch_if_chain(const IfArgs *a, hipStream_t s) {
     const size_t lds = (size_t)((ny + 2 * IF_NB + 1) & ~1) * 8 + (size_t)(a->fm_on ? nz + 1 : 0) * 8 + (size_t)(a->tone_on ? nz : 0) * 16 + (size_t)(a->fm_on ? T2 - 1 + IF_TILE : 0) * 4 + (size_t)(T1 + T2) * 4 + 32;
     hipLaunchKernelGGL(k_if_chain, dim3((a->n + IF_TILE - 1) / IF_TILE, a->n_ch), dim3(IF_THREADS), lds, s, *a);
 }
+// the groups of a mixed engine in one launch each (rows = channels in the engine's order, group after group)
+template <class A> static MultiArgs<A> multi_pack(const A *a, const int *rows, int n_groups) {
+    MultiArgs<A> m{};
+    m.n_groups = n_groups; m.row0[0] = 0;
+    for (int g = 0; g < n_groups; g++) { m.g[g] = a[g]; m.row0[g + 1] = m.row0[g] + rows[g]; }
+    return m;
+}
+extern "C" int sonde_launch_if_chain_multi(const IfArgs *a, int n_groups, hipStream_t s) {
+    if (n_groups < 1 || n_groups > SONDE_MAX_GROUPS) return -1;
+    size_t lds = 0; int rows[SONDE_MAX_GROUPS], n = a[0].n;
+    for (int g = 0; g < n_groups; g++) {
+        const int T1 = a[g].lpiq_on ? a[g].lpiq_taps : 1, T2 = a[g].lpfm_on ? a[g].lpfm_taps : 1;
+        const int hz = (T2 - 1) + (a[g].nwin - 1 > 1 ? a[g].nwin - 1 : 1);
+        const int nz = hz + IF_TILE, ny = nz + T1 - 1;
+        const size_t l = (size_t)((ny + 2 * IF_NB + 1) & ~1) * 8 + (size_t)(a[g].fm_on ? nz + 1 : 0) * 8 + (size_t)(a[g].tone_on ? nz : 0) * 16 + (size_t)(a[g].fm_on ? T2 - 1 + IF_TILE : 0) * 4 + (size_t)(T1 + T2) * 4 + 32;
+        if (l > lds) lds = l;
+        rows[g] = a[g].n_ch;
+        if (a[g].n != n) return -1;                              // (one call = the same samples for every channel)
+    }
+    const MultiArgs<IfArgs> m = multi_pack(a, rows, n_groups);
+    hipLaunchKernelGGL(k_if_chain_multi, dim3((n + IF_TILE - 1) / IF_TILE, m.row0[n_groups]), dim3(IF_THREADS), lds, s, m);
+    return 0;
+}
+extern "C" int sonde_launch_sync_plan_multi(const WinPlanArgs *a, int n_groups, hipStream_t s) {
+    if (n_groups < 1 || n_groups > SONDE_MAX_GROUPS) return -1;
+    int rows[SONDE_MAX_GROUPS];
+    for (int g = 0; g < n_groups; g++) rows[g] = a[g].n_ch;
+    const MultiArgs<WinPlanArgs> m = multi_pack(a, rows, n_groups);
+    hipLaunchKernelGGL(k_sync_plan_multi, dim3((m.row0[n_groups] + 255) / 256), dim3(256), 0, s, m);
+    return 0;
+}
+extern "C" int sonde_launch_sync_window_fft_multi(const WinFftArgs *a, int n_groups, hipStream_t s) {
+    if (n_groups < 1 || n_groups > SONDE_MAX_GROUPS) return -1;
+    // two waves of workgroups on 256 CUs at most, shared out by the windows a group can have planned (W per channel)
+    long long tot = 0; int rows[SONDE_MAX_GROUPS];
+    for (int g = 0; g < n_groups; g++) tot += (long long)a[g].W * a[g].n_ch;
+    const long long cap = tot > 512 ? 512 : tot;
+    for (int g = 0; g < n_groups; g++) { const long long w = (long long)a[g].W * a[g].n_ch; rows[g] = (int)((w * cap + tot - 1) / tot); if (rows[g] < 1) rows[g] = 1; }
+    const MultiArgs<WinFftArgs> m = multi_pack(a, rows, n_groups);
+    hipLaunchKernelGGL(k_sync_window_fft_multi, dim3(m.row0[n_groups]), dim3(WF_THREADS), (size_t)(SC_XN + SC_TW_LDS + 1) * sizeof(float2), s, m);
+    return 0;
+}
 extern "C" void sonde_launch_header_corr(const CorrArgs *a, hipStream_t s) {
     if (a->ntypes > 0) {
         const int nf = (HCF_TILE + a->isps * (a->nsym - 1) + 3) & ~3, nxp = (nf + a->isps + 3 + 3) & ~3;
@@ -2652,6 +2737,14 @@ extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *fl
     hipLaunchKernelGGL(k_rs41_ecc_batch, dim3(cap), dim3(RSK_THREADS), 0, s, frames, flen, level, ecc, codes, synd, gf_exp, gf_log, count);
 }
 
+extern "C" int sonde_launch_framesync_multi(const SyncArgs *a, int n_groups, hipStream_t s) {
+    if (n_groups < 1 || n_groups > SONDE_MAX_GROUPS) return -1;
+    int rows[SONDE_MAX_GROUPS];
+    for (int g = 0; g < n_groups; g++) { rows[g] = a[g].n_ch; if (a[g].opt_dc) return -1; }
+    const MultiArgs<SyncArgs> m = multi_pack(a, rows, n_groups);
+    hipLaunchKernelGGL(k_framesync_multi, dim3(m.row0[n_groups]), dim3(1024), 0, s, m);
+    return 0;
+}
 extern "C" void sonde_launch_framesync(const SyncArgs *a, hipStream_t s) {
     if (a->opt_dc) hipLaunchKernelGGL((k_framesync<true, FS_THREADS>), dim3(a->n_ch), dim3(FS_THREADS), 0, s, *a);
     else if (a->small_wg) hipLaunchKernelGGL((k_framesync<false, FS_THREADS_SMALL>), dim3(a->n_ch), dim3(FS_THREADS_SMALL), 0, s, *a);

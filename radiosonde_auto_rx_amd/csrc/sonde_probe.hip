@@ -24,8 +24,8 @@ extern "C" int sonde_probe_read_gbps(const void *d_buf, size_t bytes, int32_t re
     if (!d_buf || !gbps || bytes < (1u << 20) || reps < 1) return SONDE_E_ARG;
     unsigned *sink = nullptr;
     if (hipMalloc((void **)&sink, 4) != hipSuccess) return SONDE_E_NOGPU;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) hipEventDestroy(e0); hipFree(sink); return SONDE_E_NOGPU; }
     const size_t n16 = bytes / 16;
     const int grid = 256 * 16;                                 // 16 workgroups per CU
     hipLaunchKernelGGL(k_probe_read, dim3(grid), dim3(256), 0, 0, (const v4u *)d_buf, n16, sink);       // warm-up (clocks, TLB)
@@ -34,7 +34,7 @@ extern "C" int sonde_probe_read_gbps(const void *d_buf, size_t bytes, int32_t re
         hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k_probe_read, dim3(grid), dim3(256), 0, 0, (const v4u *)d_buf, n16, sink);
         hipEventRecord(e1, 0);
-        if (hipEventSynchronize(e1) != hipSuccess) { hipFree(sink); return SONDE_E_NOGPU; }
+        if (hipEventSynchronize(e1) != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); hipFree(sink); return SONDE_E_NOGPU; }
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
         if (ms > 0.f) { const double g = (double)n16 * 16.0 / (ms * 1e-3) / 1e9; if (g > best) best = g; }
     }

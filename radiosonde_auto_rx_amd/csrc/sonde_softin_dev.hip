@@ -610,6 +610,7 @@ extern "C" void sonde_launch_rs41_ecc_batch_n(uint8_t *frames, const int32_t *fl
 extern "C" int sonde_fsk_wait(sonde_fsk_t *f);
 extern "C" int sonde_fsk_host_frames(sonde_fsk_t *f, int32_t *out);
 extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream);
+extern "C" int sonde_fsk_dev_reader_done(sonde_fsk_t *f, hipStream_t consumer_stream);
 
 struct sonde_softin_dev {
     int C = 0, ecc_level = 0, cap = 0, type = SONDE_RS41;
@@ -797,6 +798,7 @@ int sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
     { const int rc = softin_own_stream(s); if (rc) return rc; }
     { const int rc = softin_bind_fsk(s, modem, s->stream); if (rc) return rc; }
     { const int rc = softin_enqueue(s, s->stream); if (rc) return rc; }
+    { const int rc = sonde_fsk_dev_reader_done(modem, s->stream); if (rc) return rc; }
     return softin_finish(s);
 }
 // the same in two halves: submit waits for the modem's launch (sonde_fsk_wait), then enqueues the consumer's kernels and the copies of its frames on the consumer's OWN
@@ -807,7 +809,10 @@ int sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
     { const int rc = softin_finish(s); if (rc) return rc; }
     { const int rc = softin_own_stream(s); if (rc) return rc; }
     { const int rc = softin_bind_fsk(s, modem, s->stream); if (rc) return rc; }
-    return softin_enqueue(s, s->stream);
+    { const int rc = softin_enqueue(s, s->stream); if (rc) return rc; }
+    // the modem's launch that reuses this buffer of soft decisions (the next but one) waits for the consumer's kernels: submitting the modem twice before
+    // sonde_softin_dev_collect is slower, not wrong
+    return sonde_fsk_dev_reader_done(modem, s->stream);
 }
 int sonde_softin_dev_collect(sonde_softin_dev_t *s) {
     if (!s) return SONDE_E_ARG;

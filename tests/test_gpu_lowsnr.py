@@ -116,3 +116,79 @@ def test_fsk_softin_chain_matches_reference_over_ebno():
         b = _run(dec, _run([os.path.join(REF, fsk[0])] + fsk[1:], data))
         n.append(assert_same_output(a, b, ("softin", ebno)))
     assert n[-1] >= 55, n
+
+
+# ---- the DEVICE consumer chain: FskModem -> SoftinDev (k_fsk_wave -> k_softin_rs41 / _dfm / _m10), nothing of it on the host
+DEV_CASES = {
+    # auto_rx's own argument sets (auto_rx/autorx/decode.py:901-909, 1036-1067, 1085-1122): (Fs, Rs, P, nsym, mask, limit, decoder, decoder arguments)
+    "rs41": (48000, 4800, 5, 300, 5000, 5000, "rs41mod", ["--softin", "-i", "-r", "--ecc2"]),
+    "dfm": (50000, 2500, 10, 50, 0, 5000, "dfm09mod", ["--softin", "-r", "--ecc", "--auto"]),
+    "m10": (48080, 9616, 5, 50, 0, 10000, "m10mod", ["--softin", "-i", "-r", "-v"]),
+}
+
+
+def _lines_equal_modulo_undecodable(got, want, what):
+    """the CLI sweep's rule, line by line: equal — or the reference's line carries no [OK] mark (a frame the block code could not repair, printed with its raw bits), ours
+    has the same tail and differs in at most MAX_RAW_BITS payload bits.  Returns the number of such lines."""
+    soft = 0
+    for la, lb in zip(got, want):
+        if la == lb:
+            continue
+        ha, ta = la.split(" ", 1) if " " in la else (la, "")
+        hb, tb = lb.split(" ", 1) if " " in lb else (lb, "")
+        ok_tail = ta == tb or ("[OK]" not in ta and "[OK]" not in tb and ta.count("[") == tb.count("["))
+        assert ok_tail and "[OK]" not in lb and len(ha) == len(hb), (what, la[-60:], lb[-60:])
+        try:
+            bits = bin(int(ha.replace(" ", ""), 16) ^ int(hb.replace(" ", ""), 16)).count("1")
+        except ValueError:                                           # (DFM lines are three hex groups with marks between them: compare the hex digits only)
+            xa = "".join(ch for ch in la if ch in "0123456789ABCDEFabcdef"); xb = "".join(ch for ch in lb if ch in "0123456789ABCDEFabcdef")
+            assert len(xa) == len(xb), (what, la, lb)
+            bits = bin(int(xa, 16) ^ int(xb, 16)).count("1")
+        assert bits <= MAX_RAW_BITS, (what, bits)
+        soft += 1
+    return soft
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "rs41mod")), reason="compiled reference not present")
+@pytest.mark.parametrize("kind", list(DEV_CASES))
+def test_device_consumer_chain_matches_reference_over_ebno(kind):
+    """Eb/N0 6 .. 14 dB through the modem AND its consumer on the device — the nine noise levels are the nine channels of one modem / one consumer, second by second —
+    against `oracle/_ref/fsk_demod -s ... | oracle/_ref/{rs41mod, dfm09mod, m10mod} --softin` on the same noisy captures.  At these levels a soft decision 1e-6 away
+    from the reference's can tip a sign; what that may change is bounded exactly as in the CLI sweep above: only lines of frames the block code could not repair,
+    in a few raw bits, in under 1 % of the lines.  Frame count, order, positions and every repaired frame are equal without exception (the consumer keeps the frame in
+    progress at the end of the stream: the reference's last line may be missing)."""
+    from tools import synth
+    from radiosonde_auto_rx_amd.fsk import FskModem, SoftinDev
+    fs, rs, P, nsym, mask, lim, binary, dargs = DEV_CASES[kind]
+    if kind == "rs41":
+        x = synth.rs41_capture(sr=fs, seconds=40.3, fq=0.0, n_frames=40, t_first=0.2, noise_sigma=0.0, seed=31)
+    elif kind == "dfm":
+        x = synth.dfm_capture(sr=fs, seconds=12.0, fq=0.0, noise_sigma=0.0, seed=32)
+    else:
+        x = synth.m10_capture(sr=fs, seconds=40.5, fq=0.0, noise_sigma=0.0, seed=33, baud=float(rs), dev_hz=rs / 2.0,
+                              frame_fn=lambda k: synth.m10_frame(k, rng=np.random.default_rng(4000 + k)))
+    noisy = [add_noise(x, float(rs) * FS / fs, ebno, 3000 + k) for k, ebno in enumerate(EBNO)]      # (add_noise scales by FS / baud: pass baud * FS / fs for this rate)
+    X = np.stack(noisy)
+    n = X.shape[1] // 2
+    md = FskModem(fs, rs, n_channels=len(EBNO), P=P, nsym=nsym, mask=mask, lower=-lim, upper=lim, max_chunk=fs)
+    sf = SoftinDev(len(EBNO), ecc=2, inv=True) if kind == "rs41" else SoftinDev(len(EBNO), kind="dfm", ecc=1, inv=False, auto=True) if kind == "dfm" else SoftinDev(len(EBNO), kind="m10", ecc=0, inv=True)
+    fetch = {"rs41": "fetch", "dfm": "fetch_dfm", "m10": "fetch_m10"}[kind]
+    got = {c: [] for c in range(len(EBNO))}
+    for s0 in range(0, n, fs):
+        m = min(fs, n - s0)
+        md.process_host(np.ascontiguousarray(X[:, 2 * s0:2 * (s0 + m)]))
+        sf.push_fsk(md)
+        for f in getattr(sf, fetch)(1 << 14):
+            got[f["channel"]].append(f["line"].rstrip())
+    md.close(); sf.close()
+    fsk = [os.path.join(REF, "fsk_demod"), "--cs16", "-b", str(-lim), "-u", str(lim), "-s"] + (["--mask", str(mask)] if mask else []) + ["--nsym=%d" % nsym, "-p", str(P), "2", str(fs), str(rs), "-", "-"]
+    total = soft = 0
+    counts = []
+    for c, ebno in enumerate(EBNO):
+        want = [ln.rstrip() for ln in _run([os.path.join(REF, binary)] + dargs, _run(fsk, noisy[c].tobytes())).decode().splitlines()]
+        g = got[c]
+        assert 0 <= len(want) - len(g) <= 1, (kind, ebno, len(g), len(want))
+        soft += _lines_equal_modulo_undecodable(g, want[:len(g)], (kind, ebno))
+        total += len(g); counts.append(len(want))
+    assert soft <= max(1, total // 100), (kind, soft, total)
+    assert counts[-1] >= (38 if kind != "dfm" else 40), counts          # at 14 dB everything is there

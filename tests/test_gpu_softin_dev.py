@@ -344,3 +344,41 @@ def test_submit_without_wait_is_waited_for_by_the_next_call():
     a.process_device(X.data_ptr() + 4 * sr * X.element_size(), X.shape[1] // 2, sr)
     assert np.array_equal(a.fetch(1)[0], b.fetch(1)[0])
     a.close(); b.close()
+
+
+def test_modem_submitted_twice_before_collect_waits_for_the_consumer():
+    """A caller that leaves the order of include/sonde_fsk.h — the modem submitted twice while a consumer call is still in flight: the second of those launches writes the
+    very buffer of soft decisions the consumer was given.  The launch waits for the consumer on the device (sonde_fsk_dev_reader_done): the frames are
+    those of the synchronous calls over the same seconds (the consumer is given seconds 0 and 2, not 1, in both runs)."""
+    import torch
+    x, sr, mk_modem, mk_cons, fetch = _pipe_case("rs41")
+    nch = 48                                                   # (enough channels that the consumer's kernels take a while)
+    X = torch.from_numpy(np.stack([x] * nch)).cuda()
+    n = X.shape[1] // 2
+    assert n >= 3 * sr
+    ptr = lambda k: X.data_ptr() + 2 * k * sr * X.element_size()
+
+    def lines_of(sf):
+        out = {}
+        for f in getattr(sf, fetch)(16 * nch):
+            out.setdefault(f["channel"], []).append(f["line"].rstrip())
+        return out
+
+    md, sf = mk_modem(nch), mk_cons(nch)
+    md.process_device(ptr(0), n, sr); sf.push_fsk(md)
+    md.process_device(ptr(1), n, sr)
+    md.process_device(ptr(2), n, sr); sf.push_fsk(md)
+    want = lines_of(sf)
+    md.close(); sf.close()
+
+    md, sf = mk_modem(nch), mk_cons(nch)
+    md.submit_device(ptr(0), n, sr); md.wait()
+    sf.submit_fsk(md)                                          # the consumer of second 0 on its own stream ...
+    md.submit_device(ptr(1), n, sr); md.wait()                 # ... the modem's next launch (the other buffer) ...
+    md.submit_device(ptr(2), n, sr); md.wait()                 # ... and the one after it, which overwrites what the consumer reads — before any collect
+    sf.collect()
+    sf.submit_fsk(md); sf.collect()
+    got = lines_of(sf)
+    md.close(); sf.close()
+    assert sorted(want) == list(range(nch)) and all(len(v) >= 1 for v in want.values())
+    assert got == want
