@@ -330,7 +330,7 @@ def bench_demod(args, D: Dist):
     # untimed: the dominant kernel on a stream of its own order — a second engine with ONE stream (every kernel of a call behind the other), same channels, same
     # input: what k_mix_decimate50 does when no IF-rate kernel of the call before holds CU slots beside it.  `roofline.frac` above is the timed run's figure
     # (two streams: the tail runs beside the decimator and stretches it); this one goes beside it as `frac_kernel_alone`
-    alone = None
+    alone, kern_serial = None, None
     if D.world == 1 and not args.no_extras and lag > 0 and args.two_streams:
         e1 = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=False)
         _lead_in(e1, iq.data_ptr(), STRIDE)
@@ -346,6 +346,17 @@ def bench_demod(args, D: Dist):
         ms1, k1 = e1.kernel_ms("mix_decimate")
         if ms1 > 0 and k1 > 0:
             alone = dict(avg_launch_ms=round(ms1, 4), frac=round(C * SR * 4 / (ms1 * 1e-3) / 1e9 / 8000.0, 4), launches=int(k1), ms_per_step_one_stream=round(t1 * 1e3, 3))
+        # the per-kernel table of a step as EXECUTION times: on this one-stream engine every kernel of a call runs behind the other, so the HIP events around a kernel
+        # bracket its work and nothing else (on the two-stream engine of the timed loop they also bracket its wait for CU slots the decimator holds: kernels_two_streams)
+        e1.profile(2)
+        nser = 20
+        for _ in range(nser):
+            e1.process_device(iq.data_ptr(), STRIDE, SR); e1.fetch_frames_np(lag=lag)
+        e1.fetch_frames_np(lag=0); e1.sync()
+        kern_serial = {}
+        for k in ("mix_decimate", "if_chain", "header_corr", "framesync", "rs_ecc"):
+            ms, n = e1.kernel_ms(k)
+            kern_serial[k] = dict(ms_per_step=round(ms * n / nser, 4), launches_per_step=n / nser)
         e1.profile(0)
         e1.close()
 
@@ -392,9 +403,10 @@ def bench_demod(args, D: Dist):
                        "rank_ms_per_step": [round(t / total_steps * 1e3, 3) for t in per_rank],
                        "summary_records": {"bytes_per_channel": shard.SUMMARY_BYTES, "channels_with_frames": int((rec["frames"] > 0).sum()),
                                            "frames_clean_on_device": int(rec["frames_clean"].sum())},
-                       "kernels": kern,
-                       "kernels_note": "HIP events around every kernel over 20 untimed pipelined steps; with two streams a kernel's time includes its wait for the CU "
-                                       "slots the other stream's kernels hold (header search / frame sync beside the decimator), so the column does not add up to the step"},
+                       "kernels": kern_serial if kern_serial else kern, "kernels_two_streams": kern if kern_serial else None,
+                       "kernels_note": "kernels: execution time per step of every kernel, HIP events on a ONE-stream engine (same channels, same input; untimed, 20 steps) — each "
+                                       "kernel runs alone behind the one before, so the column adds up to that engine's step; kernels_two_streams: the same events on the timed "
+                                       "engine, where a kernel's span includes its wait for CU slots the decimator on the other stream holds"},
             "roofline": {"bound": "hbm", "kernel": "k_mix_decimate50", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "frac_kernel_alone": alone["frac"] if alone else None, "kernel_alone": alone,
                          "measured_stream_GBps": round(stream_gbps, 1) if stream_gbps else None,
@@ -569,7 +581,7 @@ def _stream_probe(ptr, nbytes):
 
 # ---- the printed line.  The driver keeps the last ~8 KB of stdout: the line must fit with every object in it.  What is printed is the numbers; the prose
 # (notes, method descriptions) stays in the full object, written next to it (gpurun_out/bench_full.json, or $SONDE_BENCH_FULL), and in DESIGN.md §5 / INTEGRATION.md.
-_DROP_KEYS = {"ecc", "error_mix", "frames_ok_means", "kernel_alone", "clocks_mhz", "rank_ms_per_step", "verify_mismatch_channels", "stdout_bytes", "per_core",
+_DROP_KEYS = {"kernels_two_streams", "ecc", "error_mix", "frames_ok_means", "kernel_alone", "clocks_mhz", "rank_ms_per_step", "verify_mismatch_channels", "stdout_bytes", "per_core",
               "samples_per_channel_per_step", "repeats", "scan_duty", "sequential", "summary_records", "algorithmic_gb_per_launch", "launches", "unique_captures_per_family",
               "timed_seconds", "two_streams", "frame_fetch_lag", "fsk_demod_args", "what", "step", "soft_decisions", "detections_last_step", "stages", "stream_rate",
               "frames_dropped", "symbols_or_codewords_repaired", "per_type", "launches_per_step"}
