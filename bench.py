@@ -31,6 +31,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue wait for each other's kernels.  The mixed
+# configurations drive 6 - 8 streams (three modems + their three device decoders; decimator, IF-rate stages, decoder, record copies): with four queues a modem's launch
+# sat behind another family's decoder kernel (profiles/r6c_fsk_mixed_hw_queues.txt: fsk_mixed 1.80 -> 1.63 ms).  Read once, when the runtime initialises; a
+# deployment knob like any other, left alone if the caller has set it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 SR = 2_400_000
 BANK = 20                # unique synthetic captures tiled over the channels

@@ -346,11 +346,17 @@ struct SoftinM10Chan {
     unsigned long long bits_in, hdr_bit;
     char  mbits[976];
 };
-struct SoftinM10Args { SoftinArgs base; SoftinM10Chan *chan; sonde_m10_frame_t *out; };
+struct SoftinM10Args { SoftinArgs base; SoftinM10Chan *chan; sonde_m10_frame_t *out; int stage_cap; };
+#define M10_STAGE_MAX 12288            // soft decisions of a call the kernel keeps in LDS (48 KB); longer calls read them from global memory
 
+// The header search (find_softbinhead / corr_softhdb, demod_mod.c:1692-1762) evaluates at EVERY symbol the normalised correlation of the last 32 with the header, in
+// double.  Round 5 did exactly that on a lane per position — 64 dependent double adds and 32 global loads each, 0.37 ms for 341 channels.  Now the call's soft decisions
+// are staged in LDS once and every position gets the same quantity in float first (error < 1e-5); only a position whose float value comes within 1e-3 of the
+// threshold — a header, a few per second — is evaluated again the reference's way (same operands, same order, double), and that value decides and is recorded.
 __global__ __launch_bounds__(64)
 void k_softin_m10(const SoftinM10Args A) {
     const SoftinArgs &a = A.base;
+    extern __shared__ float s_x[];                     // [stage_cap] sgn * x of this call (staged: nb <= stage_cap)
     __shared__ float s_hist[32];
     __shared__ char s_mb[976];
     __shared__ unsigned char s_fr[124];
@@ -366,8 +372,13 @@ void k_softin_m10(const SoftinM10Args A) {
     float ms1 = st->ms1, mv_hdr = st->mv; unsigned long long hdr_bit = st->hdr_bit; const unsigned long long bits0 = st->bits_in;
     if (lane < 32) s_hist[lane] = st->hist[lane];
     for (int i = lane; i < 976; i += 64) s_mb[i] = st->mbits[i];
-    __builtin_amdgcn_wave_barrier();
     const float sgn = a.inv_in ? -1.f : 1.f;
+    const bool staged = nb <= A.stage_cap;
+    if (staged) for (int i = lane; i < nb; i += 64) s_x[i] = sgn * x[i];
+    __builtin_amdgcn_wave_barrier();
+    auto X = [&](int p) -> float { return staged ? s_x[p] : sgn * x[p]; };       // soft decision p of this call, in the polarity in effect
+    unsigned hbits = 0;                                                          // the 32 header symbols as a bit mask
+    for (int i = 0; i < 32; i++) hbits |= (unsigned)(a.hdr[i] & 1) << i;
     int cur = 0;
     while (cur < nb) {
         if (mode == 0) {
@@ -376,17 +387,27 @@ void k_softin_m10(const SoftinM10Args A) {
                 const int q = base + lane;
                 float mv = 0.f;
                 if (q < nb) {
-                    double sum = 0.0, normx = 0.0;
                     const int e = 32 + (q - cur);
+                    float fs = 0.f, fn = 0.f;
                     for (int i = 0; i < 32; i++) {
                         const int k = e - 31 + i;
-                        const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
-                        const float y = (a.hdr[i] & 1) ? 1.f : -1.f;
-                        sum += (double)(y * v);
-                        normx += (double)(v * v);
+                        const float v = k < 32 ? s_hist[k] : X(cur + (k - 32));
+                        fs += ((hbits >> i) & 1u) ? v : -v;
+                        fn = fmaf(v, v, fn);
                     }
-                    sum /= sqrt(normx * 32.0);
-                    mv = (float)sum;
+                    mv = fs * __builtin_amdgcn_rsqf(fn * 32.0f);
+                    if (!(fabsf(mv) < a.ths - 1e-3f)) {                   // (also NaN: an all-zero window is the reference's 0 / 0)
+                        double sum = 0.0, normx = 0.0;
+                        for (int i = 0; i < 32; i++) {
+                            const int k = e - 31 + i;
+                            const float v = k < 32 ? s_hist[k] : X(cur + (k - 32));
+                            const float y = ((hbits >> i) & 1u) ? 1.f : -1.f;
+                            sum += (double)(y * v);
+                            normx += (double)(v * v);
+                        }
+                        sum /= sqrt(normx * 32.0);
+                        mv = (float)sum;
+                    }
                 }
                 const unsigned long long hits = __ballot(q < nb && fabsf(mv) > a.ths);
                 if (hits) {
@@ -395,7 +416,7 @@ void k_softin_m10(const SoftinM10Args A) {
                     if ((double)mvl * (0.5 - inv) < 0) inv ^= 1;            // irrelevant for the differential code (m10mod.c:1447)
                     found = true;
                     const int qs = base + l, e = 32 + (qs - cur), k = e - 31 + (lane & 31);
-                    const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                    const float v = k < 32 ? s_hist[k] : X(cur + (k - 32));
                     __builtin_amdgcn_wave_barrier();
                     if (lane < 32) s_hist[lane] = v;
                     __builtin_amdgcn_wave_barrier();
@@ -405,7 +426,7 @@ void k_softin_m10(const SoftinM10Args A) {
             }
             if (!found) {
                 const int e = 32 + (nb - 1 - cur), k = e - 31 + (lane & 31);
-                const float v = k < 32 ? s_hist[k] : sgn * x[cur + (k - 32)];
+                const float v = k < 32 ? s_hist[k] : X(cur + (k - 32));
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32) s_hist[lane] = v;
                 __builtin_amdgcn_wave_barrier();
@@ -420,7 +441,7 @@ void k_softin_m10(const SoftinM10Args A) {
                 const int j = j0 + lane;
                 int bit = 0, prev = 0;
                 if (j < nbits) {
-                    const float s1 = (j == 0 && mhalf) ? ms1 : sgn * x[cur + 2 * j - mhalf], s2 = sgn * x[cur + 2 * j + 1 - mhalf];
+                    const float s1 = (j == 0 && mhalf) ? ms1 : X(cur + 2 * j - mhalf), s2 = X(cur + 2 * j + 1 - mhalf);
                     bit = (s2 - s1) >= 0.0f;
                 }
                 prev = __shfl_up(bit, 1);
@@ -431,7 +452,7 @@ void k_softin_m10(const SoftinM10Args A) {
             }
             __builtin_amdgcn_wave_barrier();
             if (nbits > 0) mbit0 = last_bit;
-            if ((mhalf + take) & 1) { ms1 = sgn * x[cur + take - 1]; mhalf = 1; } else mhalf = 0;
+            if ((mhalf + take) & 1) { ms1 = X(cur + take - 1); mhalf = 1; } else mhalf = 0;
             mpos += nbits; cur += take;
             if (mpos == NBITS) {
                 unsigned slot = 0;
@@ -702,7 +723,16 @@ static int softin_pass(sonde_softin_dev *s, hipStream_t st, const int off, const
     a.frames += (size_t)off * 518; a.flen += off; a.meta += off; a.cap = s->cap - off; a.count = s->d_count + which; a.ch_list = ch_list;
     HIPCHK(hipMemsetAsync(a.count, 0, 4, st));
     if (s->type == SONDE_DFM09) { SoftinDfmArgs d{a, s->d_dfm_chan, s->d_dfm_out + off, s->ecc_level}; hipLaunchKernelGGL(k_softin_dfm, dim3(nblocks), dim3(64), 0, st, d); }
-    else if (s->type == SONDE_M10) { SoftinM10Args m{a, s->d_m10_chan, s->d_m10_out + off}; hipLaunchKernelGGL(k_softin_m10, dim3(nblocks), dim3(64), 0, st, m); }
+    else if (s->type == SONDE_M10) {
+        // LDS for the call's soft decisions: what a call can hold (a modem launch: its capacity; a pushed stream: its length), up to M10_STAGE_MAX
+        long long need = a.fsk_chan || a.nbits_ch ? a.ch_stride : a.nbits;
+        if (need > M10_STAGE_MAX || need < 0) need = 0;
+        SoftinM10Args m{a, s->d_m10_chan, s->d_m10_out + off, (int)need};
+        static size_t attr = 0;
+        const size_t lds = (size_t)need * sizeof(float);
+        if (lds > attr) { if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_softin_m10), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr = lds; else m.stage_cap = 0; }
+        hipLaunchKernelGGL(k_softin_m10, dim3(nblocks), dim3(64), m.stage_cap ? lds : 0, st, m);
+    }
     else {
         hipLaunchKernelGGL(k_softin_rs41, dim3(nblocks), dim3(64), 0, st, a);
         if (s->ecc_level > 0)
