@@ -1072,6 +1072,10 @@ void k_audio_chain(const AudioChainArgs a) {
 // float32 input: k_mix_f32 / k_decimate_f32 / k_dc_update_f64 (see MixF32Args).  Correct-by-construction, not tuned: cf32 is
 // 8 B per sample and rare (the reference's usual sources are cs16 and cu8).
 // ------------------------------------------------------------------------------------------------
+// Round 6: a workgroup takes MF32_CHUNK consecutive samples of one channel (coalesced, 32 per thread), keeps the mixer-table index by addition instead of a 64-bit
+// modulo per sample, and adds its IQ-DC sums with ONE pair of double atomics (round 1..5: a pair per wave, 8192 per channel and launch on two addresses — the kernel
+// took 4 ms for 64 channels x 1 s, bench side_paths).
+#define MF32_CHUNK 8192
 __global__ __launch_bounds__(256)
 void k_mix_f32(const MixF32Args a) {
     const int ch = blockIdx.y;
@@ -1081,26 +1085,38 @@ void k_mix_f32(const MixF32Args a) {
     const float2 *seg = a.dc_seg ? a.dc_seg + (size_t)ch * a.dc_seg_n : nullptr;
     const double f0 = a.mix ? a.chan_f0[ch] : 0.0;
     const uint32_t L = (uint32_t)a.lut_len;
+    const double nd0 = a.nd_base - (a.epoch ? (double)a.epoch[ch] : 0.0);
     double sx = 0.0, sy = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
+    const int i_first = blockIdx.x * MF32_CHUNK + threadIdx.x, i_end = min(a.n, (int)(blockIdx.x + 1) * MF32_CHUNK);
+    uint32_t k = i_first < a.n ? (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)i_first) % L) : 0u;      // table index (demod_mod.c:746), advanced by 256 per step
+    const uint32_t kstep = 256u % L;
+    for (int i = i_first; i < i_end; i += 256) {
         const float2 v = x[i];
         sx += (double)v.x; sy += (double)v.y;
         if (seg) avg = seg[(a.dc_seg_off + (uint32_t)i) / a.dc_seg_len];
         float2 u = make_float2(v.x - avg.x, v.y - avg.y);
         if (a.mix) {
-            const uint32_t k = (uint32_t)(((uint64_t)a.lut_phase + (uint64_t)i) % L);         // table index (demod_mod.c:746)
-            const double nd = (double)k + a.nd_base - (a.epoch ? (double)a.epoch[ch] : 0.0);
+            const double nd = (double)k + nd0;
             float fr;
             if (a.phase_f64) fr = (float)__builtin_amdgcn_fract(f0 * nd);
             else             fr = __builtin_amdgcn_fractf((float)(f0 * nd));
             const float c = __builtin_amdgcn_cosf(fr), s = __builtin_amdgcn_sinf(fr);
             u = make_float2(u.x * c - u.y * s, u.x * s + u.y * c);
+            k += kstep; if (k >= L) k -= L;
         }
         z[(uint32_t)(a.n0 + (uint64_t)i) & a.zmask] = u;
     }
     if (seg) return;                                           // the windows' sums were taken by k_dc_seg_sums_f32
     for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(a.dc_sums + 2 * (size_t)ch, sx); atomicAdd(a.dc_sums + 2 * (size_t)ch + 1, sy); }
+    __shared__ double s_d[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_d[2 * wave] = sx; s_d[2 * wave + 1] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tx = 0.0, ty = 0.0;
+        for (int w = 0; w < 4; w++) { tx += s_d[2 * w]; ty += s_d[2 * w + 1]; }
+        atomicAdd(a.dc_sums + 2 * (size_t)ch, tx); atomicAdd(a.dc_sums + 2 * (size_t)ch + 1, ty);
+    }
 }
 
 // float32 form of k_dc_seg_sums / k_dc_seg_means: the IQ-DC windows a call touches, summed in double (one workgroup per window and channel),
@@ -1139,13 +1155,16 @@ __global__ void k_dc_seg_means_f32(int n_ch, int nseg, int ncomplete, float maxc
     dc_avg[c] = mean; dc_sums[2 * c] = cx; dc_sums[2 * c + 1] = cy;
 }
 
+// Round 6: DF32_J consecutive outputs per workgroup, their D (DF32_J - 1) + T input samples staged in LDS with coalesced loads (round 1..5: every thread walked its T taps
+// through global memory at a stride of D samples between lanes — 64 cache lines per load, 24 x the cs16 path per channel-second, bench side_paths).  One thread per
+// output and the taps in ascending order, as before: the same fused multiply-adds on the same operands, results unchanged to the bit.
+#define DF32_J 128
 __global__ __launch_bounds__(256)
-void k_decimate_f32(const DecF32Args a) {
+void k_decimate_f32_global(const DecF32Args a) {                          // (decimation factors whose tile does not fit the LDS: wide IF rates, rare)
     const int ch = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.nblocks) return;
     const float2 *z = a.z + (size_t)ch * ((size_t)a.zmask + 1);
-    // y[m] = sum_k w[k] z[D (m+1) - T + k]; samples before the stream are zero (calloc'ed delay line)
     const int64_t first = (int64_t)a.n0 + (int64_t)a.D * (j + 1) - a.T;
     float re = 0.f, im = 0.f;
     for (int k = 0; k < a.T; k++) {
@@ -1156,6 +1175,41 @@ void k_decimate_f32(const DecF32Args a) {
         re = fmaf(w, v.x, re); im = fmaf(w, v.y, im);
     }
     a.y[(size_t)ch * a.ring_len + ((a.m0 + (uint32_t)j) & ((uint32_t)a.ring_len - 1))] = make_float2(re, im);
+}
+__global__ __launch_bounds__(DF32_J)
+void k_decimate_f32(const DecF32Args a, const int jper) {                 // jper <= DF32_J outputs per workgroup (what fits the LDS)
+    extern __shared__ __attribute__((aligned(16))) float2 s_z[];          // [D (jper - 1) + T] samples first(j0) ..., then [T] taps as floats
+    const int ch = blockIdx.y, j0 = blockIdx.x * jper, tid = threadIdx.x;
+    const int nj = min(jper, a.nblocks - j0);
+    if (nj <= 0) return;
+    const float2 *z = a.z + (size_t)ch * ((size_t)a.zmask + 1);
+    // y[m] = sum_k w[k] z[D (m+1) - T + k]; samples before the stream are zero (calloc'ed delay line)
+    const int64_t first0 = (int64_t)a.n0 + (int64_t)a.D * (j0 + 1) - a.T;
+    const int nz = a.D * (nj - 1) + a.T;
+    float *s_w = reinterpret_cast<float *>(s_z + a.D * (jper - 1) + a.T);
+    for (int i = tid; i < nz; i += DF32_J) { const int64_t n = first0 + i; s_z[i] = n < 0 ? make_float2(0.f, 0.f) : z[(uint32_t)n & a.zmask]; }
+    for (int k = tid; k < a.T; k += DF32_J) s_w[k] = a.taps[k];
+    __syncthreads();
+    if (tid >= nj) return;
+    const int64_t first = first0 + (int64_t)a.D * tid;
+    const float2 *p = s_z + a.D * tid;
+    float re = 0.f, im = 0.f;
+    int k = first < 0 ? (int)min((int64_t)a.T, -first) : 0;            // (taps that would pair with samples before the stream are skipped, not multiplied by zero: as before)
+    // eight taps at a time: their LDS reads are in flight together, the multiply-adds follow in tap order (a loop of one read and one dependent FMA pair per
+    // iteration waited a full LDS round trip per tap)
+    for (; k + 8 <= a.T; k += 8) {
+        float2 v[8]; float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { v[u] = p[k + u]; w[u] = s_w[k + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { re = fmaf(w[u], v[u].x, re); im = fmaf(w[u], v[u].y, im); }
+    }
+    for (; k < a.T; k++) {
+        const float2 v = p[k];
+        const float w = s_w[k];
+        re = fmaf(w, v.x, re); im = fmaf(w, v.y, im);
+    }
+    a.y[(size_t)ch * a.ring_len + ((a.m0 + (uint32_t)(j0 + tid)) & ((uint32_t)a.ring_len - 1))] = make_float2(re, im);
 }
 
 __global__ void k_dc_update_f64(int n_ch, double *dc_sums, float2 *dc_avg, float maxcnt) {
@@ -2568,12 +2622,17 @@ extern "C" void sonde_launch_u8_to_s16(const uint8_t *in, long long in_stride, i
     hipLaunchKernelGGL(k_u8_to_s16, dim3(gx, n_ch), dim3(256), 0, s, in, in_stride, out, out_stride, n_bytes);
 }
 extern "C" void sonde_launch_mix_f32(const MixF32Args *a, hipStream_t s) {
-    int gx = (a->n + 255) / 256; if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+    const int gx = (a->n + MF32_CHUNK - 1) / MF32_CHUNK;
+    if (gx < 1) return;
     hipLaunchKernelGGL(k_mix_f32, dim3(gx, a->n_ch), dim3(256), 0, s, *a);
 }
 extern "C" void sonde_launch_decimate_f32(const DecF32Args *a, hipStream_t s) {
     if (a->nblocks <= 0) return;
-    hipLaunchKernelGGL(k_decimate_f32, dim3((a->nblocks + 255) / 256, a->n_ch), dim3(256), 0, s, *a);
+    int jper = DF32_J;
+    auto lds_of = [&](int j) { return (size_t)(a->D * (j - 1) + a->T) * sizeof(float2) + (size_t)a->T * sizeof(float); };
+    while (jper > 8 && lds_of(jper) > 64 * 1024) jper >>= 1;
+    if (lds_of(jper) > 64 * 1024) { hipLaunchKernelGGL(k_decimate_f32_global, dim3((a->nblocks + 255) / 256, a->n_ch), dim3(256), 0, s, *a); return; }
+    hipLaunchKernelGGL(k_decimate_f32, dim3((a->nblocks + jper - 1) / jper, a->n_ch), dim3(DF32_J), lds_of(jper), s, *a, jper);
 }
 extern "C" void sonde_launch_dc_update_f64(int n_ch, double *sums, float2 *avg, float maxcnt, hipStream_t s) {
     hipLaunchKernelGGL(k_dc_update_f64, dim3((n_ch + 255) / 256), dim3(256), 0, s, n_ch, sums, avg, maxcnt);
