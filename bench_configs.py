@@ -278,6 +278,7 @@ def bench_fsk_mixed(args, D, short=False):
     _ord = os.environ.get("SONDE_BENCH_ORDER", "m10,rs41,dfm" if C <= 2048 else "rs41,m10,dfm").split(",")
     order = sorted(engines, key=lambda e: _ord.index(e[0]))
     barrier_every_step = bool(os.environ.get("SONDE_BENCH_FSK_BARRIER"))          # A/B: everything of a step completed before the next one starts
+    modem_first = not os.environ.get("SONDE_BENCH_FSK_DECODER_FIRST")             # A/B: round 5's order (decoder of k - 1 submitted before the modem's second k)
 
     cnt0 = {k: c["sf"].counts() for k, c in consumers.items()}
     launched, consuming = set(), set()
@@ -298,14 +299,18 @@ def bench_fsk_mixed(args, D, short=False):
     def step():
         for kind, Fs, Rs, n, X, md, _, _ in order:
             sf = consumers[kind]["sf"]
-            if kind in launched:
+            was = kind in launched
+            if was:
                 md.wait()
+            if modem_first:                                   # the modem's next second first: its stream does not wait for the decoder's bookkeeping on the host
+                md.submit_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
             if kind in consuming:
                 sf.collect()
-            if kind in launched:
-                sf.submit_fsk(md)
+            if was:
+                (sf.submit_fsk_behind if modem_first else sf.submit_fsk)(md)
                 consuming.add(kind)
-            md.submit_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
+            if not modem_first:
+                md.submit_device(X.data_ptr(), X.shape[1] // 2, X.shape[1] // 2)
             launched.add(kind)
         if barrier_every_step:
             drain()

@@ -120,6 +120,10 @@ int  sonde_softin_dev_push_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
  * submit_fsk (k - 1), sonde_fsk_submit_device (k).  The modem's launch that overwrites a buffer of soft decisions waits (on the device) for the consumer that was
  * given that buffer, so another order costs overlap, never frames. */
 int  sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem);
+/* the same over the modem's launch BEFORE the one in flight — for the order sonde_fsk_wait (k - 1), sonde_fsk_submit_device (k), collect (k - 2), submit_fsk_behind (k - 1):
+ * the modem gets its next second before the host does the decoder's bookkeeping, and nothing here waits for the launch in flight.  With no launch in flight:
+ * sonde_softin_dev_submit_fsk. */
+int  sonde_softin_dev_submit_fsk_behind(sonde_softin_dev_t *s, sonde_fsk_t *modem);
 int  sonde_softin_dev_collect(sonde_softin_dev_t *s);
 /* the same over any soft-bit streams in device memory: channel c at d_soft + c * ch_stride, n_bits each */
 int  sonde_softin_dev_push_device(sonde_softin_dev_t *s, const float *d_soft, int64_t ch_stride, int32_t n_bits);

@@ -425,6 +425,24 @@ int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, co
     return 0;
 }
 
+// the same for the launch BEFORE the one in flight (sonde_softin_dev_submit_fsk_behind): its soft decisions sit in the other buffer, its frame counts are the host's copy
+// from before the launch in flight was submitted; 1 = there is such a pair (a launch in flight and one before it), 0 = no launch in flight (use sonde_fsk_dev_view)
+int sonde_fsk_dev_view_prev(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, int *bits_per_frame, int *n_ch, int32_t *frames_out) {
+    if (!f) return SONDE_E_ARG;
+    if (!f->pending || f->h_chan_prev.size() != (size_t)f->cfg.n_channels) return 0;
+    *d_sd = f->d_sd_alt; *sd_cap = f->args.sd_cap; *bits_per_frame = f->info.Nbits; *n_ch = f->cfg.n_channels;
+    for (int c = 0; c < f->cfg.n_channels; c++) frames_out[c] = f->h_chan_prev[(size_t)c].frames;
+    return 1;
+}
+int sonde_fsk_dev_reader_done_prev(sonde_fsk_t *f, hipStream_t consumer_stream) {
+    if (!f) return SONDE_E_ARG;
+    const int i = f->sd_idx ^ 1;
+    if (!f->ev_rd[i]) HIPCHK(hipEventCreateWithFlags(&f->ev_rd[i], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(f->ev_rd[i], consumer_stream));
+    f->rd_set[i] = true;
+    return 0;
+}
+
 // a consumer that has enqueued its reads of the buffer sonde_fsk_dev_view showed (the last launch's soft decisions) on `consumer_stream` says so: the launch that
 // will overwrite that buffer — the next but one — waits for this point of the consumer's stream
 int sonde_fsk_dev_reader_done(sonde_fsk_t *f, hipStream_t consumer_stream) {

@@ -632,6 +632,8 @@ extern "C" int sonde_fsk_wait(sonde_fsk_t *f);
 extern "C" int sonde_fsk_host_frames(sonde_fsk_t *f, int32_t *out);
 extern "C" int sonde_fsk_dev_view(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, const FskChan **d_chan, int *bits_per_frame, int *n_ch, hipStream_t *stream);
 extern "C" int sonde_fsk_dev_reader_done(sonde_fsk_t *f, hipStream_t consumer_stream);
+extern "C" int sonde_fsk_dev_view_prev(sonde_fsk_t *f, const float **d_sd, long long *sd_cap, int *bits_per_frame, int *n_ch, int32_t *frames_out);
+extern "C" int sonde_fsk_dev_reader_done_prev(sonde_fsk_t *f, hipStream_t consumer_stream);
 
 struct sonde_softin_dev {
     int C = 0, ecc_level = 0, cap = 0, type = SONDE_RS41;
@@ -843,6 +845,28 @@ int sonde_softin_dev_submit_fsk(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
     // the modem's launch that reuses this buffer of soft decisions (the next but one) waits for the consumer's kernels: submitting the modem twice before
     // sonde_softin_dev_collect is slower, not wrong
     return sonde_fsk_dev_reader_done(modem, s->stream);
+}
+// The consumer over the launch BEFORE the one the modem has in flight: for a caller that hands the modem its next second first (sonde_fsk_wait (k - 1),
+// sonde_fsk_submit_device (k), then this for k - 1) — the modem's stream never waits for the host's decoder bookkeeping.  Nothing waits here; with no launch in
+// flight this is sonde_softin_dev_submit_fsk.
+int sonde_softin_dev_submit_fsk_behind(sonde_softin_dev_t *s, sonde_fsk_t *modem) {
+    if (!s || !modem) return SONDE_E_ARG;
+    { const int rc = softin_finish(s); if (rc) return rc; }
+    { const int rc = softin_own_stream(s); if (rc) return rc; }
+    if (!s->h_nbits) {
+        if (hipHostMalloc((void **)&s->h_nbits, (size_t)s->C * sizeof(int)) != hipSuccess || hipMalloc((void **)&s->d_nbits, (size_t)s->C * sizeof(int)) != hipSuccess) return SONDE_E_NOMEM;
+    }
+    const float *d_sd = nullptr; long long cap = 0; int bpf = 0, nch = s->C;
+    const int have = sonde_fsk_dev_view_prev(modem, &d_sd, &cap, &bpf, &nch, s->h_nbits);
+    if (have < 0) return have;
+    if (have == 0) return sonde_softin_dev_submit_fsk(s, modem);
+    if (nch != s->C) return SONDE_E_ARG;
+    for (int c = 0; c < s->C; c++) s->h_nbits[c] = s->h_nbits[c] > 0 ? s->h_nbits[c] * bpf : 0;
+    HIPCHK(hipMemcpyAsync(s->d_nbits, s->h_nbits, (size_t)s->C * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    SoftinArgs &a = s->args;
+    a.sd = d_sd; a.ch_stride = cap; a.fsk_chan = nullptr; a.bits_per_frame = bpf; a.nbits_ch = s->d_nbits; a.nbits = 0;
+    { const int rc = softin_enqueue(s, s->stream); if (rc) return rc; }
+    return sonde_fsk_dev_reader_done_prev(modem, s->stream);
 }
 int sonde_softin_dev_collect(sonde_softin_dev_t *s) {
     if (!s) return SONDE_E_ARG;

@@ -54,6 +54,7 @@ def _lib():
         L.sonde_softin_dev_destroy.argtypes = [C.c_void_p]
         L.sonde_softin_dev_push_fsk.argtypes = [C.c_void_p, C.c_void_p]
         L.sonde_softin_dev_submit_fsk.argtypes = [C.c_void_p, C.c_void_p]
+        L.sonde_softin_dev_submit_fsk_behind.argtypes = [C.c_void_p, C.c_void_p]
         L.sonde_softin_dev_collect.argtypes = [C.c_void_p]
         L.sonde_softin_dev_push_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
         L.sonde_softin_dev_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -189,6 +190,10 @@ class SoftinDev:
         """push_fsk without waiting for the result: waits for the modem's launch, then enqueues the consumer on its own stream; the modem can be given its next second
         (submit_device) before collect() — it keeps the soft decisions of two launches"""
         _chk(_lib().sonde_softin_dev_submit_fsk(self._h, modem._h))
+
+    def submit_fsk_behind(self, modem: "FskModem"):
+        """the consumer over the modem's launch BEFORE the one in flight (order: wait, submit_device, collect, submit_fsk_behind): nothing waits"""
+        _chk(_lib().sonde_softin_dev_submit_fsk_behind(self._h, modem._h))
 
     def collect(self):
         _chk(_lib().sonde_softin_dev_collect(self._h))

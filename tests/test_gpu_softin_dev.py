@@ -382,3 +382,47 @@ def test_modem_submitted_twice_before_collect_waits_for_the_consumer():
     md.close(); sf.close()
     assert sorted(want) == list(range(nch)) and all(len(v) >= 1 for v in want.values())
     assert got == want
+
+
+@pytest.mark.parametrize("kind", ["rs41", "dfm", "m10"])
+def test_decoder_submitted_behind_the_modems_next_second_gives_the_same_frames(kind):
+    """The order that keeps the modem's stream busiest — wait (k - 1), submit_device (k), collect (k - 2), submit_fsk_behind (k - 1): the decoder reads the launch BEFORE
+    the one in flight (the modem's other buffer of soft decisions, the host's frame counts from before that launch was submitted), nothing waits for the launch in flight.
+    Same frames, same order per channel, same soft decisions as process + push."""
+    import torch
+    x, sr, mk_modem, mk_cons, fetch = _pipe_case(kind)
+    X = torch.from_numpy(np.stack([x, x, x])).cuda()
+    n = X.shape[1] // 2
+
+    def run(behind):
+        md, sf = mk_modem(3), mk_cons(3)
+        lines = {0: [], 1: [], 2: []}
+        for s0 in range(0, n, sr):
+            m = min(sr, n - s0)
+            ptr = X.data_ptr() + 2 * s0 * X.element_size()
+            if behind:
+                if s0 > 0:
+                    md.wait()
+                md.submit_device(ptr, n, m)         # the modem's next second first ...
+                if s0 > 0:
+                    sf.collect()
+                    sf.submit_fsk_behind(md)        # ... then the decoder over the second before it
+            else:
+                md.process_device(ptr, n, m)
+                sf.push_fsk(md)
+            for f in getattr(sf, fetch)():
+                lines[f["channel"]].append(f["line"].rstrip())
+        if behind:
+            md.wait(); sf.collect(); sf.submit_fsk_behind(md); sf.collect()      # (no launch in flight: the last one's soft decisions)
+            for f in getattr(sf, fetch)():
+                lines[f["channel"]].append(f["line"].rstrip())
+        c = sf.counts()
+        sd = [md.fetch(k)[0] for k in range(3)]
+        md.close(); sf.close()
+        return lines, c, sd
+
+    plain, got = run(False), run(True)
+    assert len(plain[0][0]) >= 1 and plain[0][1] == plain[0][0] and plain[0][2] == plain[0][0]
+    assert got[0] == plain[0] and got[1] == plain[1]
+    for k in range(3):
+        assert np.array_equal(got[2][k], plain[2][k])
