@@ -187,6 +187,7 @@ struct sonde_scan {
     ScanItem *h_items = nullptr; ScanRes *h_res = nullptr; int item_cap = 0;
     // prefilter (k_scan_pre): A fragments of the templates / FM low-passes, per-pair results, work list of the exact kernel
     uint16_t *d_amatch = nullptr, *d_aws = nullptr; float *d_wstail = nullptr; int a_off[SC_NTPL] = {0}, nc2[SC_NTPL] = {0}, nc1 = 0, ws_pad = 0;
+    float kap[SC_NTPL] = {0};
     ScanPre *d_pre = nullptr, *h_pre = nullptr; ScanWork *d_work = nullptr, *h_work = nullptr; bool use_pre = false;
     void *d_stage = nullptr; size_t stage_bytes = 0;
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy
@@ -241,7 +242,10 @@ static int toeplitz_frags(const std::vector<float> &h, std::vector<uint16_t> &ou
             }
     return nc;
 }
-static const float kPreMargin = 0.03f;      // candidates: smax > thres - margin; the prefilter's own error is ~1e-4 (tests/test_scan_prefilter_model.py)
+// candidates: smax > thres - margin, where smax already carries the part of the rounding bound that scales with the signal (ScanPreArgs.kap, added per position by the
+// kernel) and the margin is what does not: 3 u + L 2^-24 + the reference's own distance from exact arithmetic (3e-4, its drifting twiddles) — DESIGN.md §4.6b,
+// tests/test_scan_prefilter_model.py::test_prefilter_error_stays_inside_the_derived_bound.  (Rounds 3-5: a flat 0.03 on the bare score, argued not derived.)
+static const float kPreMargin = 0.003f;
 
 extern "C" {
 
@@ -378,6 +382,12 @@ int sonde_scan_create(const sonde_scan_cfg_t *cfg, const double *fq, sonde_scan_
             s->nc1 = toeplitz_frags(h, a_ws);
             for (int i = 0; i < taps; i++) { double acc = 0; for (int t = i + 1; t < taps; t++) acc += (double)w_lp[(size_t)lp * taps + t]; ws_tail.push_back((float)acc); }
         }
+    }
+    for (int j = 0; j < SC_NTPL; j++) {        // ScanPreArgs.kap: 4.02 u ||ws||_1 sqrt(L) with the taps as the kernel has them (f16)
+        s->kap[j] = 0.f;
+        if (!iq || !s->tpl[j].active) continue;
+        double w1 = 0; for (int t = 0; t < s->lpfm_taps; t++) { const uint16_t hb = f16_bits(w_lp[(size_t)s->tpl[j].lpfm * s->lpfm_taps + t]); _Float16 hv; memcpy(&hv, &hb, sizeof hv); w1 += fabs((double)(float)hv); }
+        s->kap[j] = (float)(4.02 * 4.8828125e-4 * w1 * sqrt((double)s->tpl[j].L));
     }
     s->use_pre = cfg->opt_exact == 0 && N == SC_N;             // windows beyond 8192 samples: the exact kernel for every pair (rare: wide --bw / wide --iq input)
 
@@ -690,6 +700,7 @@ static int run_windows(sonde_scan *s) {
             pa.a_match = s->d_amatch; memcpy(pa.a_off, s->a_off, sizeof pa.a_off); memcpy(pa.nc2, s->nc2, sizeof pa.nc2);
             pa.a_ws = s->d_aws; pa.nc1 = s->nc1; pa.taps = s->lpfm_taps; pa.ws_pad = s->ws_pad; pa.ws_tail = s->d_wstail;
             pa.K = s->K; pa.opt_dc = s->cfg.opt_dc; pa.opt_iq = a.opt_iq; pa.lpfm_taps = s->lpfm_taps; pa.out = s->d_pre;
+            memcpy(pa.kap, s->kap, sizeof pa.kap);
             hipEventRecord(e0, s->stream);
             HIPCHK(hipMemcpyAsync(s->d_items, s->h_items, (size_t)n_items * sizeof(ScanItem), hipMemcpyHostToDevice, s->stream));
             {   // profiling aid: cycles per phase of k_scan_pre, printed when the scanner is destroyed

@@ -51,7 +51,7 @@ struct ScanWork { int item, tpl; };
 // f32 accumulation) — FM low-pass and header correlation as Toeplitz products, energy under the template from prefix sums.  smax is an UPPER
 // bound (up to the f16 rounding, ~1e-4) of |mv| as getCorrDFT would return it: the reference normalises the correlation at its arg-max, smax
 // takes the maximum of the normalised value over all positions.  Only pairs with smax > thres - margin go to the exact transform network.
-struct ScanPre { float smax; float mv; int mp; uint32_t mpos; float dc; int pad; };
+struct ScanPre { float smax; float mv; int mp; uint32_t mpos; float dc; int pad; };      // smax: the maximum over all positions of (score + its rounding bound)
 struct ScanPreArgs {
     const float *fm; int n_ch, ring_len;
     const ScanItem *items; int n_items;
@@ -62,6 +62,8 @@ struct ScanPreArgs {
     int nc1, taps, ws_pad;    // ws_pad = taps - 1 + front padding of the tap vector, a multiple of 8 (16-byte aligned LDS reads)
     const float *ws_tail;     // [2][taps]: sum of the taps behind tap i (what a constant loses in the filter's first taps-1 outputs)
     int K, opt_dc, opt_iq, lpfm_taps;
+    float kap[SC_NTPL];       // kappa_j = 4.02 u ||ws||_1 sqrt(L_j) (u = 2^-11; 0 for FM-audio input, which has no low-pass): the part of the score's rounding bound that scales with
+                              // (window maximum) / (rms under the template) — added per position inside the kernel
     ScanPre *out;             // [n_items][SC_NTPL]
     unsigned long long *prof; // SONDE_SP_PROF: shader cycles per phase of the workgroups of template 1 (RS41), [8]; nullptr = off
 };

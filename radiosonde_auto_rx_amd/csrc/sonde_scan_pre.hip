@@ -34,6 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SP_ACAP 8                      // A-fragment steps (1 KB each) the LDS holds at a time: SP_AQ x 16 bytes per thread; longer templates reload
 #endif
 #define SP_AQ (SP_ACAP * 64 / SP_THREADS)
+#define SP_CP 1.9073486e-6f            // 32 x 2^-24: the float32 rounding of a prefix sum that is built in three short levels (16 per thread, the wave's scan, the waves), DESIGN.md §4.6b
 
 // S(i) = sum_{q<i} xf[q]^2 from the sums kept for every fourth i and the squares between
 __device__ __forceinline__ float sp_S(const float *P, const _Float16 *xf, int i) {
@@ -115,9 +116,13 @@ __device__ __forceinline__ float sp_last(float x) { return __int_as_float(__buil
 // arg-max (never above what is held) takes; e < 0 (rounding of the difference where the window is empty) makes the score a NaN that v_max_f32 drops,
 // e = 0 with c != 0 makes it +inf: the pair goes to the exact kernel.  Within a lane p only grows (r, then the tiles in order), so a later equal |c| never
 // replaces an earlier one — first maximum wins — and what is kept is bidx = 4 t + r: position and c are looked up once, behind the loop.
+// Round 6: what is maximised is not |c| / sqrt(e) but that value plus the bound of its own rounding error at the position:
+//     (|c[p]| + kx) / sqrt(e[p]) + be / e[p],   kx = kappa_j X (f16 roundings of window, taps and filtered window; X = the window's maximum), be = C_P E_win (prefix sums)
+// so that "the maximum is below thres - margin" rules a pair out whatever the signal looks like — a quiet span beside a loud one gets a wide bound and goes to the
+// exact kernel instead of being trusted to a flat margin.
 template <int HO, bool EDGE>
 __device__ __forceinline__ void sp_tile_scores(const _Float16 *xfh, const float *P, const f32x4 c4, const int p0, const int L, const int K, const int code0,
-                                               float &bs, float &bc, int &bidx) {
+                                               const float kx, const float be, float &bs, float &bc, int &bidx) {
     const int hb = p0 + L - HO;                                          // a multiple of 4 — S(p0 + r) and S(p0 + L + r) from three 8-byte reads of xf
     const half4 lo = *reinterpret_cast<const half4 *>(xfh + p0), h0 = *reinterpret_cast<const half4 *>(xfh + hb), h1 = *reinterpret_cast<const half4 *>(xfh + hb + 4);
     const _Float16 hh[8] = { h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3] };
@@ -130,22 +135,24 @@ __device__ __forceinline__ void sp_tile_scores(const _Float16 *xfh, const float 
         slo += (float)lo[r] * (float)lo[r];
         shi += (float)hh[HO + r] * (float)hh[HO + r];
         float ac = fabsf(c4[r]);
-        if (EDGE) ac = (p0 + r <= K) ? ac : -1.f;
-        bs = sp_hwmax(bs, ac * __builtin_amdgcn_rsqf(e));
+        const float rs = __builtin_amdgcn_rsqf(e);
+        float sc = __builtin_fmaf(be * rs, rs, (ac + kx) * rs);
+        if (EDGE) { const bool in = p0 + r <= K; ac = in ? ac : -1.f; sc = in ? sc : 0.f; }
+        bs = sp_hwmax(bs, sc);
         const bool up = ac > bc;
         bc = up ? ac : bc; bidx = up ? code0 + r : bidx;
     }
 }
 template <int HO>
 __device__ __forceinline__ void sp_scores(const _Float16 *xfh, const float *P, const f32x4 (&acc)[SP_MAXT], int wave, int nT2, int n, int g, int L, int K,
-                                          float &bs, float &bc, int &bidx) {
+                                          const float kx, const float be, float &bs, float &bc, int &bidx) {
 #pragma unroll
     for (int t = 0; t < SP_MAXT; t++) {
         const int tile = wave + SP_WAVES * t;
         if (tile < nT2) {
             const int p0 = 256 * tile + 16 * n + 4 * g;
-            if (256 * tile + 255 > K) sp_tile_scores<HO, true>(xfh, P, acc[t], p0, L, K, 4 * t, bs, bc, bidx);       // (uniform) the tile the arg-max range ends in
-            else sp_tile_scores<HO, false>(xfh, P, acc[t], p0, L, K, 4 * t, bs, bc, bidx);
+            if (256 * tile + 255 > K) sp_tile_scores<HO, true>(xfh, P, acc[t], p0, L, K, 4 * t, kx, be, bs, bc, bidx);       // (uniform) the tile the arg-max range ends in
+            else sp_tile_scores<HO, false>(xfh, P, acc[t], p0, L, K, 4 * t, kx, be, bs, bc, bidx);
         }
     }
 }
@@ -351,11 +358,13 @@ void k_scan_pre(const ScanPreArgs a) {
             sp_toeplitz(xfh + 32 * done, sA, take, wave, nT2, lane, acc);
             done += take;
         }
+        const float kx = a.kap[j] * (amax * wscale);                     // kappa_j X in the window's scaled units (X in [0.5, 1))
+        const float be = SP_CP * P[64 * nT1];                            // C_P E_win: P's last entry is the sum over the whole array
         switch (L & 3) {                                                 // (p0 is a multiple of 4: where S(p0 + L) sits between the kept sums is the template's own)
-            case 0: sp_scores<0>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
-            case 1: sp_scores<1>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
-            case 2: sp_scores<2>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
-            default: sp_scores<3>(xfh, P, acc, wave, nT2, n, g, L, K, bs, bc, bidx); break;
+            case 0: sp_scores<0>(xfh, P, acc, wave, nT2, n, g, L, K, kx, be, bs, bc, bidx); break;
+            case 1: sp_scores<1>(xfh, P, acc, wave, nT2, n, g, L, K, kx, be, bs, bc, bidx); break;
+            case 2: sp_scores<2>(xfh, P, acc, wave, nT2, n, g, L, K, kx, be, bs, bc, bidx); break;
+            default: sp_scores<3>(xfh, P, acc, wave, nT2, n, g, L, K, kx, be, bs, bc, bidx); break;
         }
         // the lane's best position and its c, from bidx = 4 t + r
         f32x4 sel = acc[0];
