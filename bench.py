@@ -44,7 +44,7 @@ BANK = 20                # unique synthetic captures tiled over the channels
 # of --ecc2, some fail), 5 % beyond it.  What the decoder makes of each class is reported in config.error_mix.
 ERROR_MIX = [0] * 10 + [3, 4, 5, 6, 8, 10] + [20, 22, 24] + [48]
 ERROR_CLASSES = ["clean"] * 10 + ["3-10 symbol errors"] * 6 + ["near t = 12 per codeword"] * 3 + ["uncorrectable"]
-PROFILE_TAG = "r5"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
+PROFILE_TAG = "r6"       # profiles/<tag>_*_traffic.json: HBM traffic of the dominant kernel from rocprofv3 --pmc passes of this command
 
 
 def make_bank(seconds: float = 1.0):

@@ -1,15 +1,16 @@
 #!/bin/bash
-# Round profile refresh, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh [tag]   (default tag r5)
+# Round profile refresh, run on the GPU box from the repo root (gpurun):  bash tools/profile_round.sh [tag]   (default tag r6)
 #   demod     bench line as the driver runs it; rocprofv3 --kernel-trace --stats of the same command; FETCH_SIZE / WRITE_SIZE and SQ
 #             counter passes (separate, kernel trace + PMC only) -> traffic json of the dominant kernel
 #   scan_wide, fsk_mixed, mixed_2400k   bench line + kernel trace each; fsk: phase counters, SQ counters of k_fsk_wave (tools/fsk_multi.py)
 # everything lands in gpurun_out/prof/ as <tag>_*; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
+export SONDE_BENCH_VERBOSE=1      # the full objects (bench.py prints the compact line by default)
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench.json"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/t" -o t -- python "$ROOT/bench.py" --steps 200 --no-cpu-baseline --no-extras --no-verify 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
@@ -30,7 +31,7 @@ for cfg in scan_wide fsk_mixed mixed_2400k; do
   timeout 300 python bench.py --config $cfg 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_${cfg}.json"
   if [ $cfg = fsk_mixed ]; then      # the phase counters slow the kernel down: a run of their own, not the bench line's
     SONDE_FSK_PROF=1 timeout 300 python bench.py --config $cfg --steps 5 --no-cpu-baseline 2>&1 >/dev/null | grep "fsk prof" > "$OUT/${TAG}_fsk_phases.txt"
-    timeout 300 python bench.py --config $cfg --channels 4096 --steps 5 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_${cfg}_4096.json"
+    timeout 300 python bench.py --config $cfg --channels 4096 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_${cfg}_4096.json"
   fi
   cd /tmp
   timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/k_$cfg" -o k -- python "$ROOT/bench.py" --config $cfg --steps 5 --no-cpu-baseline > /dev/null 2>&1
