@@ -1317,6 +1317,8 @@ __device__ __forceinline__ void if_chain_body(const IfArgs &a, const int ch, con
     const float *w_iq = acq ? a.w_iq0 : a.w_iq;
     for (int k = threadIdx.x; k < T2; k += IF_THREADS) wf[k] = a.lpfm_on ? a.w_fm[k] : 1.0f;
     for (int k = threadIdx.x; k < T1; k += IF_THREADS) wq[k] = a.lpiq_on ? w_iq[k] : 1.0f;
+    typedef const float __attribute__((address_space(4))) *cfptr;
+    const cfptr wtaps = (cfptr)(uintptr_t)w_iq;        // the taps of the 4-tap loop come through the scalar cache (that loop only runs with a filter: T1 >= 4); the tail loops read the LDS copy
     __syncthreads();
 
     // IF low-pass: z'[m] = sum_k w[k] * y[m-(T1-1)+k]   (oldest sample pairs with tap 0, demod_mod.c:639-648).
@@ -1340,7 +1342,7 @@ __device__ __forceinline__ void if_chain_body(const IfArgs &a, const int ch, con
 #endif
         for (; t + 3 < T1; t += 4) {                                   // 4 taps: two 16-byte sample reads, one 16-byte (broadcast) tap read
             const float4 n0 = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB), n1 = *reinterpret_cast<const float4 *>(sy + k0 + t + IF_NB + 2);
-            const float4 w4 = *reinterpret_cast<const float4 *>(wq + t);
+            const float4 w4 = make_float4(wtaps[t], wtaps[t + 1], wtaps[t + 2], wtaps[t + 3]);      // wave-uniform, constant address space: one scalar load instead of a (broadcast) LDS read — round 6, -2.5 %
             win[IF_NB] = v2f{n0.x, n0.y}; win[IF_NB + 1] = v2f{n0.z, n0.w};
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) {
