@@ -245,3 +245,98 @@ def test_mixed_engine_rejects_what_it_does_not_do():
     assert lib().sonde_engine_restart_channel(eng._h, 0) < 0
     assert lib().sonde_engine_set_threshold(eng._h, C.c_float(0.5)) < 0
     eng.close()
+
+
+def test_mixed_engine_with_m20_and_a_single_group():
+    """M20 next to M10 and RS41 (sr 480 kHz), and an engine whose channels all carry the same type: one group, the shared launches with a single set of arguments"""
+    from tools import synth
+    from radiosonde_auto_rx_amd.engine import Engine, MixedEngine
+    sr = 480_000
+    kinds = ["m20", "rs41", "m10", "m20"]
+    rng = np.random.default_rng(5)
+    fqs = [synth.snap_fq(float(rng.uniform(-0.3, 0.3)), sr) for _ in kinds]
+    caps = []
+    for k, kd in enumerate(kinds):
+        if kd == "m20":
+            caps.append(synth.m10_capture(sr=sr, seconds=3.3, fq=fqs[k], noise_sigma=0.03, seed=40 + k, baud=9600.0, t_first=0.3 + 0.1 * k,
+                                          frame_fn=lambda i, k=k: synth.m20_frame(i, fw=8, rng=np.random.default_rng(800 + 10 * k + i), good_checksum=(i != 1))))
+        else:
+            caps.append(_capture(kd, k, sr, 3.3, fqs[k]))
+    x = np.stack(caps)
+
+    def lines(eng, m20):
+        out = {}
+        for s0 in range(0, x.shape[1] // 2, sr):
+            m = min(sr, x.shape[1] // 2 - s0) // 10 * 10
+            eng.process_host(x[:, 2 * s0:2 * (s0 + m)] if isinstance(eng, MixedEngine) else x[sel][:, 2 * s0:2 * (s0 + m)])
+        fin = True
+        fr = eng.fetch_mxx(finish=fin, m20=True) if isinstance(eng, MixedEngine) else eng.fetch_mxx(finish=fin)
+        for f in fr:
+            out.setdefault(f["channel"], []).append((f["line"].rstrip(), f["mv_pos"], f.get("blk_ok")))
+        return out
+    eng = MixedEngine(fqs, kinds, sr, max_chunk=sr, max_frames=64)
+    got = lines(eng, True)
+    assert eng.group_info(0)[0] == 20 and eng.group_info(2)[0] == 10
+    eng.close()
+    sel = [0, 3]
+    e1 = Engine([fqs[c] for c in sel], sr, sonde="m20", ecc=0, max_chunk=sr, max_frames=64)
+    want = lines(e1, True)
+    e1.close()
+    assert sorted(got) == [0, 3] and {sel[c]: v for c, v in want.items()} == got and all(len(v) >= 2 for v in got.values())
+    # one group only
+    sel = [1]
+    a = _per_channel(_run_mixed([fqs[1]] * 3, ["rs41"] * 3, np.ascontiguousarray(x[[1, 1, 1]]), sr, sr))
+    b = _per_channel(_run_single([fqs[1]] * 3, ["rs41"] * 3, np.ascontiguousarray(x[[1, 1, 1]]), sr, sr))
+    assert a == b and sorted(a) == [0, 1, 2] and a[0] == a[1] == a[2]
+
+
+def test_mixed_engine_groups_of_one_type_with_different_options_taps_overflow_and_channel_end(bank24):
+    """The C ABI directly: two RS41 groups (--ecc and --ecc2) beside a DFM group; read_tap and finish_channel go to the channel's group; a frame queue too small says so."""
+    import ctypes as C
+    from radiosonde_auto_rx_amd.engine import (lib, SondeCfg, SondeGroup, SondeFrame, SondeInfo, ABI_VERSION, SONDE_MIXED, LP_IQ, Engine, TAP_DECIM, TAP_BUFS, _chk)
+    sr, fqs, x = bank24
+    idx = [0, 4, 1, 6]                                             # rs41, rs41, dfm, rs41 of the bank
+    kinds = [KINDS[i] for i in idx]
+    assert kinds == ["rs41", "rs41", "dfm", "rs41"]
+    fq = np.asarray([fqs[i] for i in idx], np.float64)
+    xs = np.ascontiguousarray(x[idx][:, :4 * sr])
+    L = lib()
+    cfg = SondeCfg(ABI_VERSION, 0, 4, sr, 16, SONDE_MIXED, LP_IQ, 0, 0, 0, 0, 0.0, sr, 64, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+    groups = (SondeGroup * 3)(SondeGroup(41, 1, 0, 0, 0, 0, 0.0, 0), SondeGroup(9, 1, 0, 0, 0, 0, 0.0, 0), SondeGroup(41, 2, 0, 0, 0, 0, 0.0, 0))
+    gof = np.asarray([0, 2, 1, 2], np.int32)                        # channel 0: rs41 --ecc; channels 1, 3: rs41 --ecc2; channel 2: dfm
+    h = C.c_void_p()
+    _chk(L.sonde_engine_create_mixed(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), groups, 3, gof.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h)))
+    buf = (SondeFrame * 64)()
+    got = {}
+    for k in range(2):
+        _chk(L.sonde_engine_process_host(h, np.ascontiguousarray(xs[:, 2 * k * sr:2 * (k + 1) * sr]).ctypes.data_as(C.c_void_p), sr, sr))
+        n = _chk(L.sonde_engine_fetch_frames(h, buf, 64))
+        for i in range(n):
+            got.setdefault(buf[i].channel, []).append((buf[i].ecc, buf[i].mv_pos, bytes(buf[i].frame)))
+    # the same channels on single-type engines with the group's ecc level
+    for c, ecc in ((0, 1), (1, 2), (3, 2)):
+        e = Engine([fq[c]], sr, ecc=ecc, max_chunk=sr, max_frames=16)
+        fr = []
+        for k in range(2):
+            e.process_host(xs[c:c + 1, 2 * k * sr:2 * (k + 1) * sr])
+            fr += e.fetch_frames()
+        tap_want = e.read_tap(0, TAP_BUFS, 90000, 4000)
+        e.close()
+        assert len(fr) >= 1 and got.get(c) == [(f["ecc"], f["mv_pos"], f["frame"]) for f in fr], c
+        out = np.zeros(4000, np.float32)
+        _chk(L.sonde_engine_read_tap(h, c, TAP_BUFS, 90000, 4000, out.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(out, tap_want)                          # (read_tap reaches the channel's group: the same sliced stream to the bit)
+    # end of one channel's stream: the DFM hit in progress on channel 2 is cut where the samples end
+    _chk(L.sonde_engine_finish_channel(h, 2))
+    from radiosonde_auto_rx_amd.engine import SondeDfmFrame
+    dbuf = (SondeDfmFrame * 64)()
+    nd = _chk(L.sonde_engine_fetch_dfm(h, dbuf, 64, 0))
+    assert nd >= 1 and all(dbuf[i].channel == 2 for i in range(nd))
+    assert L.sonde_engine_overflowed(h) == 0
+    L.sonde_engine_destroy(h)
+    # bad arguments
+    h2 = C.c_void_p()
+    bad = np.asarray([0, 3, 1, 2], np.int32)
+    assert L.sonde_engine_create_mixed(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), groups, 3, bad.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h2)) < 0
+    cfg.keep_soft = 1
+    assert L.sonde_engine_create_mixed(C.byref(cfg), fq.ctypes.data_as(C.POINTER(C.c_double)), groups, 3, gof.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h2)) < 0
