@@ -337,7 +337,14 @@ def bench_demod(args, D: Dist):
     # (two streams: the tail runs beside the decimator and stretches it); this one goes beside it as `frac_kernel_alone`
     alone, kern_serial = None, None
     if D.world == 1 and not args.no_extras and lag > 0 and args.two_streams:
-        e1 = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=False)
+        # (the Reed-Solomon kernel too: on the timed engine it has a stream of its own beside the next call's decimator; SONDE_ECC_INLINE is read when an engine is made)
+        had_inline = os.environ.get("SONDE_ECC_INLINE")
+        os.environ["SONDE_ECC_INLINE"] = "1"
+        try:
+            e1 = Engine(ch_fq, SR, device=D.local_rank, lp_iq=True, ecc=2, max_chunk=SR, max_frames=4 * C, pipeline=False)
+        finally:
+            if had_inline is None:
+                del os.environ["SONDE_ECC_INLINE"]
         _lead_in(e1, iq.data_ptr(), STRIDE)
         for _ in range(5):
             e1.process_device(iq.data_ptr(), STRIDE, SR); e1.fetch_frames_np(lag=lag)
