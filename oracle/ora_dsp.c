@@ -387,6 +387,10 @@ static int peak_of(const ora_dsp *d, float *mx_out) {
 }
 static float norm_at(const ora_dsp *d, int mp) {
     float a = 0;
+    /* mp = -1 (no correlation value above zero: a window of digital silence): the reference reads xn[-1 - i] here — in front of its array — and divides 0 by it;
+       whatever it finds, the score stays below every threshold, and the wrapped mv_pos = pos - (K + L - 1) - 1 it goes on to store is what matters (find_header's
+       `mv_pos > mvpos0` fails for the next window's header).  Restated with a norm of 1 instead of the out-of-bounds read. */
+    if (mp < 0) return 1.0f;
     for (int i = 0; i < d->L; i++) a += d->xn[mp - i] * d->xn[mp - i];
     return (float)sqrt(a);
 }

@@ -176,6 +176,10 @@ class ScanDesign:
             xn = (dft_ref(np.conj(X)).real / F(N)).astype(F)
         cx = dft_ref(np.conj(_cmul(X, self.Fm[j]))).real.astype(F)
         seg = cx[L - 1:K + L]
+        if not np.any(seg * seg > 0):
+            # digital silence: the reference's loop (`re_cx*re_cx > mx2`, dft_detect.c:417) leaves mp = -1, which is no edge value — it goes on, stores 0 / (a norm
+            # read in front of the array) and the WRAPPED position, and `mv_pos > mv0_pos` (:1521) then fails for the next window's hit
+            return dict(mp=-1, mv=0.0, mpos=(pos - (K + L - 1) - 1 - (self.lpfm_taps // 2 if self.iq else 0)) & 0xFFFFFFFF, dc=float(dc))
         mp = L - 1 + int(np.argmax(seg * seg))
         if mp == L - 1 or mp == K + L - 1:
             return dict(mp=-4, dc=float(dc))

@@ -1760,7 +1760,8 @@ __device__ __forceinline__ int fs_window(const float *x, const float *corr, uint
         if (ob > best || (ob == best && oi >= 0 && (bidx < 0 || oi < bidx))) { best = ob; bidx = oi; }
     }
     __syncthreads();
-    if (bidx <= 0 || bidx == K) return -4;                         // edge value -> -4 (mv stays 0)
+    if (bidx < 0) { mpos = pos - (uint32_t)(K + L); mv = 0.f; return -5; }       // nothing above zero: the reference's mp = -1 (see k_sync_window_fft)
+    if (bidx == 0 || bidx == K) return -4;                         // edge value -> -4 (mv stays 0)
     mpos = pos - (uint32_t)K + (uint32_t)bidx;
     float e = 0.f;
     for (int t = tid; t < L; t += NT) {
@@ -1839,8 +1840,12 @@ __device__ __forceinline__ void framesync_body(const SyncArgs &a, const int ch) 
             st.s_in = s_in_w; st.k = 0; st.mv = 0.f;
             if (pos - ep < (uint32_t)L) continue;                      // getCorrDFT returns -2 (position counted from the channel's stream start)
             float mv; uint32_t mpos;
-            if (wi) { if (wi->rc < 0) continue; mv = wi->mv; mpos = wi->mpos; }
-            else if (fs_window<DC, NT>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos) < 0) continue;
+            if (wi) { if (wi->rc < 0) { if (wi->rc == -5) st.mv_pos = wi->mpos; continue; } mv = wi->mv; mpos = wi->mpos; }
+            else {
+                const int rc = fs_window<DC, NT>(bufs, corr, mask, pos, K, L, a.N, a.match_sum, tid, lane, wave, s_rf, s_ri, mv, mpos);
+                if (rc == -5) { st.mv_pos = mpos; if (DC) af.dc = 0.0; }       // an all-zero window: position taken, nothing found (getCorrDFT with mp = -1)
+                if (rc < 0) continue;
+            }
             const uint32_t prev = st.mv_pos;
             st.mv = mv; st.mv_pos = mpos;
             if (DC) {
@@ -1891,7 +1896,7 @@ __device__ __forceinline__ void framesync_body(const SyncArgs &a, const int ch) 
                 else { if (!af.locked) { af.locked = 1; ev |= (a.lpiq_on != 0); } }
                 if (ev) { afc_event = true; avail = st.s_in; }
             }
-            if (!(mpos > prev)) continue;
+            if (!(mpos - ep > prev - ep)) continue;                    // positions as the reference counts them: from the channel's stream start (an all-zero first window leaves a wrapped one)
             FS_MARK(1);
             // ---- headcmp (demod_mod.c:870-938): hard-slice the header from the ring, count mismatches
             int errs = 0;
@@ -2234,7 +2239,14 @@ __device__ __forceinline__ void sync_eval_window(const WinFftArgs &a, const int 
     }
     __syncthreads();
     WF_MARK(4);
-    if (mp < 0 || mp == L - 1 || mp == wl - 1) {                          // nothing above zero / edge value: -4 (:208)
+    if (mp < 0) {
+        // not one correlation value above zero — a stream that begins with digital silence.  The reference's loop leaves mp = -1 (:200-207), which is no edge value:
+        // getCorrDFT runs on and sets mv = 0 / (a norm read in front of the array) and mv_pos = pos - (K + L - 1) - 1, which wraps in the first window of a stream —
+        // and `mv_pos > mvpos0` (find_header, :1603) then fails for the header the NEXT window finds.  Handed on as rc = -5 (k_framesync takes the position)
+        if (tid == 0) { it->rc = -5; it->mv = 0.f; it->mpos = pos - (uint32_t)(wl - 1) - 1u; __threadfence(); it->state = 2; }
+        return;
+    }
+    if (mp == L - 1 || mp == wl - 1) {                                    // edge value: -4 (:208)
         if (tid == 0) { it->rc = -4; it->mv = 0.f; it->mpos = 0; __threadfence(); it->state = 2; }
         return;
     }
@@ -2441,7 +2453,14 @@ __device__ __forceinline__ void sync_eval_window_h(const WinFftArgs &a, const in
         }
     }
     __syncthreads();
-    if (mp < 0 || mp == L - 1 || mp == wl - 1) {                          // nothing above zero / edge value: -4 (:208)
+    if (mp < 0) {
+        // not one correlation value above zero — a stream that begins with digital silence.  The reference's loop leaves mp = -1 (:200-207), which is no edge value:
+        // getCorrDFT runs on and sets mv = 0 / (a norm read in front of the array) and mv_pos = pos - (K + L - 1) - 1, which wraps in the first window of a stream —
+        // and `mv_pos > mvpos0` (find_header, :1603) then fails for the header the NEXT window finds.  Handed on as rc = -5 (k_framesync takes the position)
+        if (tid == 0) { it->rc = -5; it->mv = 0.f; it->mpos = pos - (uint32_t)(wl - 1) - 1u; __threadfence(); it->state = 2; }
+        return;
+    }
+    if (mp == L - 1 || mp == wl - 1) {                                    // edge value: -4 (:208)
         if (tid == 0) { it->rc = -4; it->mv = 0.f; it->mpos = 0; __threadfence(); it->state = 2; }
         return;
     }

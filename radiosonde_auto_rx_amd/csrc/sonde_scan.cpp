@@ -532,7 +532,7 @@ static void decide(sonde_scan *s, int ch, const ScanRes *res, uint32_t win_sin) 
         c.mv0_pos[j] = c.mv_pos[j];
         c.mp[j] = res[j].mp;
         c.dc[j] = res[j].dc;
-        if (res[j].mp > 0) {                                   // getCorrDFT ran to its end
+        if (res[j].mp > 0 || res[j].mp == -1) {                // getCorrDFT ran to its end (-1: an all-zero window, its wrapped position blocks the next window's hit — k_scan_corr)
             c.mv[j] = res[j].mv; c.mv_pos[j] = res[j].mpos;
             if (s->cfg.opt_dc) c.df[j] = (float)(c.dc[j] / (2.0 * 0.8 * s->info.decM));
         }
@@ -758,7 +758,7 @@ static int run_windows(sonde_scan *s) {
                 for (int j = 0; j < SC_NTPL; j++) {
                     if (!((exact[aux_of[c]] >> j) & 1u)) continue;
                     const ScanRes &r = s->h_res[(size_t)aux_of[c] * SC_NTPL + j];
-                    cs.mv_pos[j] = (r.mp > 0) ? r.mpos : cs.mv0_pos[j];
+                    cs.mv_pos[j] = (r.mp > 0 || r.mp == -1) ? r.mpos : cs.mv0_pos[j];
                 }
             }
         }

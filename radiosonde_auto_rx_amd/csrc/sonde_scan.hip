@@ -319,7 +319,14 @@ void k_scan_corr_t(const ScanCorrArgs a) {
 
     if (wave == 0) {
         ScanRes r{ 0, 0.f, 0u, dc, -1, 0u };
-        if (mp < 0) r.mp = -1;
+        if (mp < 0) {
+            // a window without a single non-zero correlation value (a stream that begins with digital silence): the reference's loop leaves mp = -1, which is
+            // no edge value, so getCorrDFT runs on and hands back mpos = pos - (K + L - 1) - 1 (- the low-pass delay), wrapped — and `mv_pos > mv0_pos`
+            // (dft_detect.c:1521) then fails for whatever the NEXT window finds.  Mirrored: the score there is 0 / (a norm read in front of the array)
+            r.mp = -1;
+            r.mpos = it.pos - (uint32_t)(K + L - 1) - 1u;
+            if (a.opt_iq) r.mpos -= (uint32_t)(a.lpfm_taps / 2);
+        }
         else if (mp == L - 1 || mp == K + L - 1) r.mp = -4;                          // edge value
         else {
             double e = 0.0;
