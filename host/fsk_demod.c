@@ -240,6 +240,7 @@ int main(int argc, char *argv[]) {
     const sonde_fsk_info_t info = modem.info;
     size_t nin = (size_t)info.N;                                /* fsk_nin() before the first frame */
     int every = 0, countdown = 0;                               /* stats line every `every` frames */
+    int failed = 0;                                             /* the engine refused or lost a frame: exit 255, never a silent 0 */
     if (job.stats) every = (int)(1 / (job.stats_rate * ((float)nin / (float)c->Fs)));
     unsigned char *raw = (unsigned char *)malloc((size_t)job.sample_bytes * (size_t)(info.N + 2 * info.Ts));
     float *soft = (float *)malloc(sizeof(float) * (size_t)info.Nbits);
@@ -254,7 +255,10 @@ int main(int argc, char *argv[]) {
         sonde_fsk_frame_t fr;
         /* the eye and the spectrum are only printed without --testframes, and then exactly when the countdown has run out */
         const int want = job.stats && !job.testframes && countdown < 0;
-        if (modem_frame(&modem, raw, nin, (size_t)job.sample_bytes, want, soft, hard, &fr, &fst)) break;
+        if (modem_frame(&modem, raw, nin, (size_t)job.sample_bytes, want, soft, hard, &fr, &fst)) {
+            fprintf(stderr, "fsk_demod: the modem engine failed on a frame of %zu samples (unsupported geometry or device error)\n", nin);
+            failed = 1; break;
+        }
         nin = (size_t)fr.nin_next;
         int aligned = 0;
         if (job.testframes)
@@ -277,5 +281,5 @@ int main(int argc, char *argv[]) {
     free(raw); free(soft); free(hard); free(fst.Sf);
     fclose(fin); fclose(fout);
     modem_close(&modem);
-    return 0;
+    return failed ? -1 : 0;
 }

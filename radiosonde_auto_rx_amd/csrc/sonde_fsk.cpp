@@ -38,7 +38,7 @@ struct sonde_fsk {
     bool recs_on_host = false;                     // h_recs holds the last launch's frame records (copied with the soft decisions)
     bool hb_on_host = false;                       // h_hb holds the last launch's hard bits (copied on the first sonde_fsk_fetch_bits behind a launch)
     // what a repeat of single channels needs (a pipeline that gave up, launch_wait): Sf and the tone tails as they were before the launch, the list
-    float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
+    float *d_Sf_bak = nullptr; float2 *d_tail_bak = nullptr; int *d_chlist = nullptr; float *d_scratch = nullptr; std::vector<FskChan> h_chan_prev; int64_t repeats = 0;
     // a launch that was submitted and not yet waited for (sonde_fsk_submit_device / sonde_fsk_wait); the channels the last wait had to repeat
     bool pending = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // consumers on the device read d_sd / d_sd_alt on streams of their own (sonde_softin_dev_submit_fsk): each of the two buffers remembers the last reader's end
@@ -151,7 +151,7 @@ void sonde_fsk_destroy(sonde_fsk_t *f) {
         }
         hipFree(f->d_prof);
     }
-    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_iperm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist, f->d_sd_alt };
+    void *ptrs[] = { f->d_in, f->d_hann, f->d_fmask, f->d_Sf, f->d_sd, f->d_tw, f->d_dpeak, f->d_dmask, f->d_phift, f->d_tail, f->d_chan, f->d_recs, f->d_eye, f->d_hb, f->d_perm, f->d_iperm, f->d_wr, f->d_Sf_bak, f->d_tail_bak, f->d_chlist, f->d_sd_alt, f->d_scratch };
     for (void *p : ptrs) if (p) hipFree(p);
     delete f;
 }
@@ -180,6 +180,10 @@ static int launch_enqueue(sonde_fsk_t *f) {
     const int Ndft = f->info.Ndft;
     if (!f->d_Sf_bak) {
         if (dalloc(&f->d_Sf_bak, (size_t)C * Ndft, false) || dalloc(&f->d_tail_bak, (size_t)C * a.M * a.NT, false) || dalloc(&f->d_chlist, (size_t)C, false)) return SONDE_E_NOMEM;
+    }
+    if (!f->d_scratch) {                                       // frames longer than a CU's LDS holds: k_fsk_demod's regions in global memory (sonde_fsk.hip)
+        const long long nf = sonde_fsk_scratch_floats(&a);
+        if (nf > 0) { if (dalloc(&f->d_scratch, (size_t)C * (size_t)nf, false)) return SONDE_E_NOMEM; a.scratch = f->d_scratch; a.scratch_stride = nf; }
     }
     if (!f->ev0) { HIPCHK(hipEventCreate(&f->ev0)); HIPCHK(hipEventCreate(&f->ev1)); }
     f->h_chan_prev.assign(f->h_chan.begin(), f->h_chan.end());

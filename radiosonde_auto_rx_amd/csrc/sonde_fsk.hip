@@ -250,10 +250,15 @@ __device__ void fsk_estimate_ahead(const FskArgs &a, const int ch, const uint32_
 // profiling aid: thread 0 of channel 0 adds the shader-clock cycles since the previous mark to phase k
 #define FSK_MARK(k) do { if (a.prof && ch == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); a.prof[k] += t_ - t_prev; t_prev = t_; } } while (0)
 
-template <int M>
+// BIG: the regions live in global memory (a.scratch, one slice per workgroup) instead of LDS — frames of more samples than a CU's LDS holds (fsk_demod takes any
+// Fs / Rs / nsym; the sondes' own configurations all fit).  Same code, same barriers: a workgroup's wavefronts share their CU's vector cache, so what one has
+// written before a barrier the others read behind it.  est_waves is 0 there (no estimator running ahead: its hand-over counts on LDS ordering).
+template <int M, bool BIG = false>
 __global__ __launch_bounds__(FSK_THREADS)
 void k_fsk_demod(const FskArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // 16-byte base whatever the static arrays in front of it add up to (float2 / b64 accesses everywhere)
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];      // 16-byte base whatever the static arrays in front of it add up to (float2 / b64 accesses everywhere)
+    float *lds;
+    if constexpr (BIG) lds = a.scratch + (size_t)blockIdx.x * (size_t)a.scratch_stride; else lds = lds_dyn;
     __shared__ float s_rf[FSK_THREADS / WAVE]; __shared__ int s_ri[FSK_THREADS / WAVE];
     __shared__ float2 s_phi[4]; __shared__ float s_tc[2], s_eb[2];
     __shared__ float s_nfest[4]; __shared__ float2 s_ndphi[4];            // the next frame's estimate, when it was made ahead
@@ -385,10 +390,12 @@ void k_fsk_demod(const FskArgs a) {
             const v2f dd = {d.x, d.y};
             uint32_t oaddr = (uint32_t)reinterpret_cast<uintptr_t>(o);
             int j = 0;
-            for (; j + 8 <= nin; j += 8) {
-                v2f ta, tb;
-                asm volatile(FSK_OSC8 : "+v"(ph), "=&v"(ta), "=&v"(tb) : "v"(dd), "v"(oaddr) : "memory");
-                oaddr += 64;
+            if constexpr (!BIG) {                                   // (the statement writes through LDS addresses; the global-memory form walks in C++: the same products and sums)
+                for (; j + 8 <= nin; j += 8) {
+                    v2f ta, tb;
+                    asm volatile(FSK_OSC8 : "+v"(ph), "=&v"(ta), "=&v"(tb) : "v"(dd), "v"(oaddr) : "memory");
+                    oaddr += 64;
+                }
             }
             const float pr = ph.x, pi = ph.y;
             phi = make_float2(pr, pi);
@@ -1042,6 +1049,19 @@ extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s) {
     return sonde_launch_fsk_old(a, s);
 }
 
+// floats of global scratch per workgroup k_fsk_demod<M, true> needs for this configuration; 0 where a frame fits into LDS (every kernel form)
+extern "C" long long sonde_fsk_scratch_floats(const FskArgs *a) {
+    const int W = (a->nsym + 1) * a->P, M = a->M;
+    const int n_in = (a->N + a->Ts / 2) > W ? (a->N + a->Ts / 2) : W;
+    const int nA = n_in > M * W + (a->nsym + 1) ? n_in : M * W + (a->nsym + 1);
+    int nB = M * a->Nmem;
+    if (4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2 > nB) nB = 4 * a->Ndft + (a->max_fft * a->Ndft + 1) / 2;
+    if (W > nB) nB = W;
+    const size_t base = (size_t)(nA + nB) * sizeof(float2) + (size_t)2 * a->Ndft * sizeof(float) + (size_t)a->Ndft * sizeof(float2);
+    if (base <= 150 * 1024) return 0;
+    return (long long)((base / sizeof(float) + 63) & ~(size_t)63);
+}
+
 extern "C" int sonde_launch_fsk_old(const FskArgs *a, hipStream_t s) {
     const int W = (a->nsym + 1) * a->P, M = a->M;
     if (a->M != 2 && a->M != 4) return -1;
@@ -1095,7 +1115,14 @@ extern "C" int sonde_launch_fsk_old(const FskArgs *a, hipStream_t s) {
     while (ng > 0 && base + (size_t)ng * per_wave > cap) ng--;
     if (a->Ndft > FSK_AE * 64 || a->Ndft < FSK_AE) ng = 0;                // a lane holds FSK_AE elements of its block
     const size_t lds = base + (size_t)ng * per_wave;
-    if (lds > 150 * 1024 || a->Ndft > 1024) return -1;
+    if (a->Ndft > 1024) return -1;
+    if (lds > 150 * 1024) {                                              // a frame that no CU's LDS holds: the same kernel on a slice of global memory per workgroup
+        if (!a->scratch || (size_t)a->scratch_stride * sizeof(float) < base) return -1;
+        FskArgs b = *a; b.est_waves = 0; b.est_bpw = 0;
+        if (a->M == 2) hipLaunchKernelGGL((k_fsk_demod<2, true>), dim3(a->n_ch), dim3(FSK_THREADS), 0, s, b);
+        else           hipLaunchKernelGGL((k_fsk_demod<4, true>), dim3(a->n_ch), dim3(FSK_THREADS), 0, s, b);
+        return 0;
+    }
     FskArgs b = *a; b.est_waves = ng; b.est_bpw = 0; a = &b;
     if (a->M != 2 && a->M != 4) return -1;
     static size_t attr[FSK_MAX_DEV][2] = {};

@@ -66,6 +66,7 @@ struct FskArgs {
     int role_rot;                     // set by the launcher: 0: roles in wavefront order; k > 0: the channel's roles start at wavefront (channel + k - 1) mod waves (sonde_fsk_wave.h)
     int wave_mode;                    // set by the launcher: 0 = k_fsk_stream / k_fsk_demod, 1 = k_fsk_wave one wave per channel, 2 = k_fsk_wave walker + worker (sonde_fsk_wave.h)
     int test_abort_ch;                // test hook (SONDE_FSK_TEST_ABORT=<channel>): that channel's pipeline gives up behind its first frame; -1 = off
+    float *scratch; long long scratch_stride;   // frames too long for a CU's LDS (N * (M + 1) beyond ~19000 samples): k_fsk_demod's regions in global memory, scratch_stride floats per workgroup; nullptr: none
 };
 
 // atan2 of two floats for the fine-timing angle (fsk.c:705): worked out in double and rounded to float once.  One short dependent chain — the odd series of atan
@@ -127,4 +128,5 @@ float fsk_atan2f(const float yf, const float xf) {
 
 extern "C" int sonde_launch_fsk(const FskArgs *a, hipStream_t s);
 extern "C" int sonde_fsk_wave_selected(const FskArgs *a);      // 1: that launch runs the wave form (which keeps the Sf / tail backups itself)
+extern "C" long long sonde_fsk_scratch_floats(const FskArgs *a);      // floats of global scratch per workgroup where a frame does not fit into LDS (k_fsk_demod<M, true>); 0: fits
 #endif

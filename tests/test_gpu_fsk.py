@@ -364,3 +364,33 @@ def test_fsk_pipeline_that_gives_up_is_repeated_frame_by_frame(monkeypatch, capf
     for c in range(3):
         _check(again[c][0], again[c][1], g)
         assert np.array_equal(again[c][0], plain[c][0]) and again[c][1] == plain[c][1]
+
+
+LONG_FRAMES = {
+    # modem frames that no CU's LDS holds (N (M + 1) samples beyond ~19000): k_fsk_demod<M, true> on a slice of global memory per workgroup — found missing by
+    # tools/fuzz_fsk.py (the CLI used to end with exit code 0 and no output)
+    "2fsk_ts40_nsym300": (2, 100_000, 2500, 20, 300, 2, ["--cs16", "-s"]),
+    "4fsk_ts40_nsym100_hard": (4, 192_000, 4800, 40, 100, 2, ["--cs16"]),
+    "4fsk_ts16_nsym300_cu8_mask": (4, 76_800, 4800, 16, 300, 3, ["--cu8", "-s", "--mask", "4800"]),
+    "2fsk_ts40_real_limits": (2, 48_000, 1200, 40, 300, 1, ["-s", "-b", "3000", "-u", "16000"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LONG_FRAMES))
+def test_cli_fsk_demod_frames_longer_than_lds_match_the_reference(name):
+    from tools import synth
+    M, Fs, Rs, P, nsym, fmt, opts = LONG_FRAMES[name]
+    if not os.path.exists(REFBIN):
+        pytest.fail("oracle/_ref/fsk_demod missing: run __graft_entry__.build() where /root/reference exists")
+    bits = np.random.default_rng(5).integers(0, 2, 6 * nsym * (M // 2) + 40)
+    x = synth.mfsk_capture(bits, Fs, Rs, M, f_low=6000.0, shift=float(Rs * (2 if name.startswith("2fsk_ts40_real") else 1)), amp=0.4, noise_sigma=0.04, seed=9)
+    data = synth.to_u8(x).tobytes() if fmt == 3 else np.ascontiguousarray(x[0::2]).tobytes() if fmt == 1 else x.tobytes()
+    args = opts + ["--nsym=%d" % nsym, "-p", str(P), str(M), str(Fs), str(Rs), "-", "-"]
+    a = subprocess.run([NATIVE] + args, input=data, capture_output=True, timeout=300)
+    b = subprocess.run([REFBIN] + args, input=data, capture_output=True, timeout=300)
+    assert a.returncode == b.returncode == 0 and len(a.stdout) == len(b.stdout) > 0, (a.returncode, b.returncode, len(a.stdout), len(b.stdout), a.stderr[-200:])
+    if "-s" in opts:
+        fa, fb = np.frombuffer(a.stdout, np.float32), np.frombuffer(b.stdout, np.float32)
+        assert np.max(np.abs(fa.astype(np.float64) - fb)) <= 2e-6 * np.sqrt(np.mean(np.square(fb.astype(np.float64))))
+    else:
+        assert a.stdout == b.stdout
