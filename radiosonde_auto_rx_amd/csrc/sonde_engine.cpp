@@ -84,6 +84,7 @@ struct sonde_engine {
     double *d_dcsums_f = nullptr; float2 *d_zring = nullptr; float *d_taps_f = nullptr; uint32_t zmask = 0;
     hipEvent_t ev_copy = nullptr;                  // end of the host -> staging copy of process_host
     int16_t *d_conv = nullptr;                     // cu8 input: converted int16 copy [C][max_chunk]
+    float2 *d_conv32 = nullptr; bool f32_path = false, conv32 = false;   // f32_path: the plain float32 mixer / FIR kernels (cf32 input, or a decimator of more than 8 tap columns); conv32: 16- / 8-bit input converted for them [C][max_chunk] float2
     int ring_len = 0, max_frames = 0;
     // stream position
     uint64_t samples_in = 0;       // base-rate samples consumed per channel
@@ -372,7 +373,11 @@ static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_gen
     e->sps = (float)cfg->sample_rate / e->baud;
     e->sps /= (float)D;
     e->Q = (T + D - 1) / D;
-    if (e->Q > 8 || D > 1024) { delete e; return SONDE_E_ARG; }
+    // more tap columns than the packed kernels hold (a narrow transition band at a high decimation, e.g. `iq_dec --IFbw 32` at 960 kHz: 321 taps, D = 30): the plain
+    // float32 mixer / FIR kernels take any length; 16- / 8-bit samples are converted for them first (x / 32768, what f32read_cblock does)
+    const bool wide = e->Q > 8;
+    if (D > 1024 || (wide && (audio || ifiq || lk || cfg->input != SONDE_IN_IQ))) { delete e; return SONDE_E_ARG; }
+    e->f32_path = cfg->bits == 32 || wide; e->conv32 = wide && cfg->bits != 32;
     if ((cfg->opt_lp & SONDE_LP_IQ) && !audio) {
         float f_lp = (float)(24e3 / (float)sr / 2.0);
         if (lpiq_bw) f_lp = (float)(lpiq_bw / (float)sr / 2.0);
@@ -416,7 +421,8 @@ static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_gen
     I.L = L; I.M = M; I.K = K; I.N = M; I.delay = delay; I.sps = e->sps_design; I.ring_len = ring;
 
     // ---- decimator taps, front-padded to Q*D and laid out [r][q] so that step r loads its Q taps with one scalar load
-    {
+    if (wide) e->wtab.assign((size_t)std::max(64, D) * 8, 0.f);      // (not used: the float32 kernels read the taps as they are, d_taps_f)
+    else {
         const int pad = e->Q * D - T;
         std::vector<float> wpad((size_t)e->Q * D, 0.f);
         for (int k = 0; k < T; k++) wpad[pad + k] = e->dec.taps[k];
@@ -567,8 +573,9 @@ static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_gen
     if (e->dc_max == 0 || e->dc_max % D) { sonde_engine_destroy(e); return SONDE_E_ARG; }
     e->dc_max0 = e->dc_max;
     e->ifiq = ifiq;
-    if (cfg->bits == 32) {
+    if (e->f32_path) {
         bad = dalloc(&e->d_dcsums_f, 2 * (size_t)C);
+        if (e->conv32) bad |= dalloc(&e->d_conv32, (size_t)C * (size_t)cfg->max_chunk, false);
         if (!audio && !ifiq) {
             uint32_t zl = 1; while (zl < (uint32_t)cfg->max_chunk + (uint32_t)T + (uint32_t)D + 64u) zl <<= 1;
             e->zmask = zl - 1;
@@ -677,7 +684,7 @@ void sonde_engine_destroy(sonde_engine_t *e) {
     if (e->h_recs) hipHostFree(e->h_recs);
     void *ptrs[] = { e->d_Bop, e->d_chanf0, e->d_dcavg, e->d_dcsums, e->d_ptail[0], e->d_ptail[1], e->d_y, e->d_ifiq, e->d_fm,
                      e->d_bufs, e->d_corr, e->d_wiq, e->d_wfm, e->d_match, e->d_state, e->d_frames, e->d_fcount, e->d_soft, e->d_soft1,
-                     e->d_epoch, e->d_work, e->d_work_count, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv,
+                     e->d_epoch, e->d_work, e->d_work_count, e->d_consts, e->d_stage, e->d_shapes, e->d_symtype, e->d_symsign, e->d_bitwin, e->d_bitend, e->d_raw, e->d_wtab, e->d_conv, e->d_conv32,
                      e->d_dcsums_f, e->d_zring, e->d_taps_f, e->d_wiq0, e->d_yrot, e->d_fmraw, e->d_corr2, e->d_afc, e->d_start, e->d_pending,
                      e->d_etab, e->d_dcavg_prev, e->d_win, e->d_Fm, e->d_tws, e->d_epoch_phase, e->d_pcs_cnt, e->d_pcs_max, e->d_pcs_since, e->d_in_row, e->d_sum_map };
     for (void *p : ptrs) if (p) hipFree(p);
@@ -753,7 +760,11 @@ int sonde_engine_process_device(sonde_engine_t *e, const void *d_iq, int64_t ch_
         prof_begin(e, "if_chain", e->stream); sonde_launch_audio_chain(&c1, e->stream); prof_end(e, e->stream);
         e->samples_in += (uint64_t)n_samples; e->m_out += (uint32_t)n_samples; done = n_samples;
     }
-    while (done < n_samples && e->cfg.bits == 32 && e->cfg.input != SONDE_IN_AUDIO) {
+    if (e->conv32) {
+        sonde_launch_s16_to_f32((const int16_t *)d_iq, ch_stride, e->d_conv32, (long long)n_samples, ch_stride == 0 ? 1 : C, n_samples, e->stream);
+        d_iq = e->d_conv32; if (ch_stride != 0) ch_stride = n_samples;
+    }
+    while (done < n_samples && e->f32_path && e->cfg.input != SONDE_IN_AUDIO) {
         // float32 IQ (cf32): plain mixer + FIR kernels (MixF32Args); the IQ-DC schedule is the same, sums in double like the reference
         const bool dc = !e->ifiq || e->cfg.opt_iqdc != 0;
         const int take = dc ? (int)std::min<uint32_t>((uint32_t)(n_samples - done), e->dc_max - e->dc_cnt) : n_samples - done;
@@ -1416,7 +1427,7 @@ int sonde_engine_restart_channel(sonde_engine_t *e, int32_t channel) {
     // front end can give one channel a new origin; the AFC loop of --dc and the pipelined streams are left out as well
     const bool base = e->cfg.input == SONDE_IN_IQ;            // --IQ fq: mixer + decimator in front of the IF-rate chain
     if ((!base && e->info.decM != 1) || e->cfg.opt_dc || e->cfg.opt_iqdc || e->cfg.pipeline || e->cfg.sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
-    if (base && (e->cfg.bits == 32 || e->cfg.opt_nolut || e->lut_len <= 0 || e->lut_len % e->info.decM)) return SONDE_E_ARG;   // int16 / uint8 input through the mixer table only
+    if (base && (e->f32_path || e->cfg.opt_nolut || e->lut_len <= 0 || e->lut_len % e->info.decM)) return SONDE_E_ARG;   // int16 / uint8 input through the mixer table only
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->stream_b));
     if (e->stream_e) HIPCHK(hipStreamSynchronize(e->stream_e));

@@ -385,3 +385,25 @@ def test_slot_sized_sync_kernels_give_identical_frames(monkeypatch):
     for fa, fb in zip(a, b):
         assert (fa["channel"], fa["mv_pos"], fa["line"], fa["ecc"]) == (fb["channel"], fb["mv_pos"], fb["line"], fb["ecc"])
         assert fa["mv"] == fb["mv"] and np.array_equal(fa["soft"], fb["soft"])
+
+
+@pytest.mark.parametrize("bits", [16, 8])
+def test_iq_dec_with_a_decimator_of_more_than_eight_tap_columns_matches_the_reference(bits):
+    """`iq_dec --IFbw 32` (the narrowest IF the reference accepts, iq_dec.c:993-1000) at 960 kHz: 321 taps at a decimation of 30 are 11 tap columns — more than the
+    packed decimator kernels hold.  Such configurations run through the plain float32 mixer / FIR kernels behind a conversion of the 16- / 8-bit samples
+    (found missing by tools/fuzz_iqdec.py: the CLI used to end with 255).  IQ and FM output against the compiled reference on the same bytes."""
+    from tools import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "iq_dec")
+    if not os.path.exists(ref):
+        pytest.fail("oracle/_ref/iq_dec missing: run __graft_entry__.build() where /root/reference exists")
+    sr = 960_000
+    fq = synth.snap_fq(-0.21, sr)
+    x = synth.rs41_capture(sr=sr, seconds=1.2, fq=fq, seed=4, noise_sigma=0.03, t_first=0.05)
+    data = (x if bits == 16 else synth.to_u8(x)).tobytes()
+    for opts, dt, tol in ((["--bo", "32", "--iq", repr(fq), "--IFbw", "32"], np.float32, 2e-6), (["--bo", "16", "--iq", repr(fq), "--IFbw", "32", "--FM", "--lpFM"], np.int16, 0.5)):
+        a = subprocess.run([os.path.join(BIN, "iq_dec")] + opts + ["-", str(sr), str(bits)], input=data, capture_output=True, timeout=120)
+        b = subprocess.run([ref] + opts + ["-", str(sr), str(bits)], input=data, capture_output=True, timeout=120)
+        assert a.returncode == b.returncode == 0 and len(a.stdout) == len(b.stdout) > 0, (opts, a.returncode, a.stderr[-200:])
+        assert a.stderr.decode().splitlines()[:2] == b.stderr.decode().splitlines()[:2] == ["IF: 32000", "dec: 30"]
+        pa, pb = np.frombuffer(a.stdout, dt).astype(np.float64), np.frombuffer(b.stdout, dt).astype(np.float64)
+        assert np.sqrt(np.mean(np.square(pa - pb))) <= tol, (opts, float(np.sqrt(np.mean(np.square(pa - pb)))))
