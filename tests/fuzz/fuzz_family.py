@@ -1,13 +1,13 @@
 """Differential fuzzing of the native bit-rate tiers against the compiled reference decoders (oracle/_ref): random frame streams from tools/synth.py,
 damaged in random ways (noise, sign bursts, scaling, zeros, inversion, truncation, a torn last float), random option sets, soft-bit input.
-    python tools/fuzz_family.py <seed> <iterations>       -> prints every mismatch, exit code = number of mismatches (capped at 255)"""
+    python tests/fuzz/fuzz_family.py <seed> <iterations>       -> prints every mismatch, exit code = number of mismatches (capped at 255)"""
 import os
 import subprocess
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402

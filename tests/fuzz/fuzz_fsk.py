@@ -3,7 +3,7 @@ geometry (symbol rate, samples per symbol 5 .. 40, oversampling P, frame length)
 real s16), amplitude from clipping down to a few LSB, noise, a stretch of digital silence in front or in the middle, hard or soft output, -i.
 Hard decisions must be the same bytes; soft decisions the same count and within 2e-6 of their RMS (tests/test_gpu_fsk.py's tolerance: the timing estimate's
 atan2f), NaNs in the same places.
-    python tools/fuzz_fsk.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatches (capped at 255)"""
+    python tests/fuzz/fuzz_fsk.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatches (capped at 255)"""
 import os
 import subprocess
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402

@@ -4,7 +4,7 @@ against the compiled reference's iq_dec on an MI355X: random input rate (multipl
 The two outputs must have the same length and header; float streams within 1e-5 RMS (the IF / FM stream tolerance of DESIGN.md §2 is 1e-6 RMS on streams of
 0.3 rms) with no sample grossly off; integer streams within 0.5 steps RMS, no sample more than 32 steps off (the discriminator's angle where the IF amplitude
 dips); a step of 2 * 0.8 where the angle sits at +-pi is the same angle.
-    python tools/fuzz_iqdec.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatches (capped at 255)"""
+    python tests/fuzz/fuzz_iqdec.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatches (capped at 255)"""
 import os
 import subprocess
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402

@@ -3,7 +3,7 @@ channels with random types in random order, random sample rate (2.4 Msps = the h
 samples, random noise / bit errors / frame phases / tuning, calls of random lengths (any multiple of the decimation, IQ-DC segment edges inside calls),
 fetches 0 / 1 / 2 calls behind.  Every channel's text lines must be the stdout of oracle/_ref/{rs41mod -r --ecc2, dfm09mod -r --ecc, m10mod -r -v} on the
 same bytes, line for line.
-    python tools/fuzz_mixed.py <seed> <seconds of wall clock>         -> prints every mismatch; exit code = number of mismatching channels (capped at 255)"""
+    python tests/fuzz/fuzz_mixed.py <seed> <seconds of wall clock>         -> prints every mismatch; exit code = number of mismatching channels (capped at 255)"""
 import os
 import subprocess
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402

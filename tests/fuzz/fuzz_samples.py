@@ -1,7 +1,7 @@
 """Differential fuzzing of the SAMPLE forms of the nine decoder front ends against the compiled reference decoders on an MI355X: random decoder, random
 input form (--IQ fq at several rates, --iq0/2/3, FM audio in a WAV; 16 / 8 / 32 bit), random filter / AFC / shift / threshold options, random noise,
 frequency offset, polarity.  Every case = the same bytes and arguments into host/bin/<dec> and oracle/_ref/<dec>; stdout and exit code must agree.
-    python tools/fuzz_samples.py <seed> <seconds of wall clock> [keep_dir]"""
+    python tests/fuzz/fuzz_samples.py <seed> <seconds of wall clock> [keep_dir]"""
 import os
 import subprocess
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402

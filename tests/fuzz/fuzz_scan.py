@@ -2,7 +2,7 @@
 compiled reference's dft_detect on an MI355X: random sonde type, input form (--iq at 48 / 96 kHz, --IQ fq at 0.48 / 2.4 Msps, FM audio in a WAV), random
 amplitude (down to 2 % of full scale) and noise (scores on both sides of the thresholds), frequency offset, polarity, a quiet or loud stretch beside the
 signal, random options (--bw, --dc, -t, -d2, -c, -v, -L, --min, --ths).  stdout and exit code must agree.
-    python tools/fuzz_scan.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatches (capped at 255)"""
+    python tests/fuzz/fuzz_scan.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatches (capped at 255)"""
 import os
 import subprocess
 import sys
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 from tools import synth  # noqa: E402

@@ -391,7 +391,7 @@ def test_slot_sized_sync_kernels_give_identical_frames(monkeypatch):
 def test_iq_dec_with_a_decimator_of_more_than_eight_tap_columns_matches_the_reference(bits):
     """`iq_dec --IFbw 32` (the narrowest IF the reference accepts, iq_dec.c:993-1000) at 960 kHz: 321 taps at a decimation of 30 are 11 tap columns — more than the
     packed decimator kernels hold.  Such configurations run through the plain float32 mixer / FIR kernels behind a conversion of the 16- / 8-bit samples
-    (found missing by tools/fuzz_iqdec.py: the CLI used to end with 255).  IQ and FM output against the compiled reference on the same bytes."""
+    (found missing by tests/fuzz/fuzz_iqdec.py: the CLI used to end with 255).  IQ and FM output against the compiled reference on the same bytes."""
     from tools import synth
     ref = os.path.join(ROOT, "oracle", "_ref", "iq_dec")
     if not os.path.exists(ref):

@@ -368,7 +368,7 @@ def test_fsk_pipeline_that_gives_up_is_repeated_frame_by_frame(monkeypatch, capf
 
 LONG_FRAMES = {
     # modem frames that no CU's LDS holds (N (M + 1) samples beyond ~19000): k_fsk_demod<M, true> on a slice of global memory per workgroup — found missing by
-    # tools/fuzz_fsk.py (the CLI used to end with exit code 0 and no output)
+    # tests/fuzz/fuzz_fsk.py (the CLI used to end with exit code 0 and no output)
     "2fsk_ts40_nsym300": (2, 100_000, 2500, 20, 300, 2, ["--cs16", "-s"]),
     "4fsk_ts40_nsym100_hard": (4, 192_000, 4800, 40, 100, 2, ["--cs16"]),
     "4fsk_ts16_nsym300_cu8_mask": (4, 76_800, 4800, 16, 300, 3, ["--cu8", "-s", "--mask", "4800"]),

@@ -1,4 +1,4 @@
-"""A stream that BEGINS WITH DIGITAL SILENCE (exact zeros: a squelched or not yet started source) — found by tools/fuzz_scan.py in round 6.
+"""A stream that BEGINS WITH DIGITAL SILENCE (exact zeros: a squelched or not yet started source) — found by tests/fuzz/fuzz_scan.py in round 6.
 
 In a window without a single non-zero correlation value the reference's arg-max loop leaves `mp = -1` (scan/dft_detect.c:415-423, demod/mod/demod_mod.c:200-207).
 That is not one of the two edge values it rejects, so getCorrDFT runs on: the score becomes 0 / (a norm read in front of the array) and the stored position

@@ -100,7 +100,7 @@ def _ref_or_skip(name):
 def test_rs41_sat_and_argument_order_match_reference():
     """`--sat` (raw GPS block contents incl. the newer GNSS block, no PTU then: rs41mod.c:2052-2111,1221-1260,2279), `-vx` / `-vv` (xdata text, battery,
     week, sats, subframe bytes, QFE: :1565-1578,1981,2018,2029,1492-1506), `--aux` (ECC / OIF411 / CFH instrument records in the xdata text, :1280-1452) and the order dependence of `--json` / `--ecc` (`--json` sets ecc = 2
-    where it stands, a later `--ecc` wins, :2703-2707; `--jsnsubfrm1` forces 2 afterwards, :2769-2773) — found by tools/fuzz_family.py"""
+    where it stands, a later `--ecc` wins, :2703-2707; `--jsnsubfrm1` forces 2 afterwards, :2769-2773) — found by tests/fuzz/fuzz_family.py"""
     import sys
     sys.path.insert(0, ROOT)
     from tools import synth
@@ -130,7 +130,7 @@ def test_rs41_sat_and_argument_order_match_reference():
 @pytest.mark.parametrize("dec,opts", [("rs41mod", ["-r", "--ecc2"]), ("rs41mod", ["--xorhex", "-r", "--ecc"]), ("m10mod", ["-r", "-v"]), ("m20mod", ["-vv"])])
 def test_rawhex_lines_with_non_hex_characters(dec, opts):
     """a pair of characters that is not hex keeps the previous byte (the reference's sscanf leaves its variable alone, rs41mod.c:2995, m10mod.c:1539,
-    m20mod.c:1405), also across lines; odd lengths, blanks, text behind the frame — found by tools/fuzz_family.py"""
+    m20mod.c:1405), also across lines; odd lengths, blanks, text behind the frame — found by tests/fuzz/fuzz_family.py"""
     import sys
     sys.path.insert(0, ROOT)
     from tools import synth

@@ -1,6 +1,6 @@
 #!/bin/bash
 # AddressSanitizer + UBSan build of the host-only half of the library (block codes, framers, telemetry and the bit-rate tiers: everything
-# that parses bytes received over RF) and of the ten decoder front ends, then tools/fuzz_family.py against the compiled reference with them.
+# that parses bytes received over RF) and of the ten decoder front ends, then tests/fuzz/fuzz_family.py against the compiled reference with them.
 # No GPU and no HIP runtime involved: the soft-bit / hex-line / hard-bit input forms never create an engine.
 #     tools/asan_fuzz.sh [seed] [iterations]
 set -e
@@ -14,4 +14,4 @@ g++ -shared -fsanitize=address,undefined -o $OUT/libsonde_hip.so $OUT/*.o
 for c in rs41mod dfm09mod m10mod m20mod lms6Xmod meisei100mod imet54mod mp3h1mod mts01mod rs92mod; do
     gcc $FLAGS -Iinclude -Ihost -o $OUT/$c host/$c.c -L$OUT -lsonde_hip -Wl,-rpath,'$ORIGIN' -Wl,--unresolved-symbols=ignore-all -lm
 done
-FUZZ_BIN_DIR=$OUT python tools/fuzz_family.py "${1:-1}" "${2:-270}"
+FUZZ_BIN_DIR=$OUT python tests/fuzz/fuzz_family.py "${1:-1}" "${2:-270}"
