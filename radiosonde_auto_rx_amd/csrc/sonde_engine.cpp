@@ -9,7 +9,8 @@
 //   mixer table position (sample_decM)                 lut_phase (host counter, same for all channels)
 //   find_header / read_softbit2p counters              SyncState per channel in HBM
 //   AFC of --dc (dsp.Df / locked / dc, demod_mod.c:1553-1600)   AfcState per channel; optimistic chunk + per-channel restart loop (process_device)
-// Returns SONDE_E_ARG for what is not mirrored: --ecc3/4, --noLUT together with --dc, decimation factors whose tap count needs Q > 8.
+// Returns SONDE_E_ARG for what is not mirrored: --ecc3/4, --noLUT together with --dc, decimators of more than 8 tap columns on a mixed engine (single-type engines run
+// those through the float32 mixer / FIR kernels, create_impl).
 #include "../../include/sonde_hip.h"
 #include "sonde_dev.h"
 #include "sonde_host.h"
