@@ -76,7 +76,7 @@ typedef struct {
     int32_t bits;            /* 16 (cs16 / s16), 8 (unsigned: rtl_sdr cu8, 8-bit WAV) or 32 (float32: cf32 / float WAV) */
     int32_t sonde_type;      /* SONDE_RS41, SONDE_DFM09, SONDE_M10, SONDE_M20, SONDE_FRONTEND, SONDE_GENERIC */
     int32_t opt_lp;          /* SONDE_LP_IQ (--lpIQ) | SONDE_LP_FM (--lpFM)                    */
-    int32_t opt_dc;          /* --dc: zero-mean correlation windows, header dc, AFC feedback   */
+    int32_t opt_dc;          /* --dc: zero-mean correlation windows, header dc, AFC feedback; with input = SONDE_IN_IQ the engine turns SONDE_LP_FM on as every decoder does (rs41mod.c:2747) */
     int32_t opt_min;         /* --min (IF 32 kHz)                                             */
     int32_t lpiq_bw;         /* --lpbw in Hz, 0 = type default (7400 for RS41)                */
     int32_t ecc_level;       /* 0 none, 1 --ecc, 2 --ecc2                                     */

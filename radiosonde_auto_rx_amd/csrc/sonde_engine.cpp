@@ -313,6 +313,11 @@ static int create_impl(const sonde_cfg_t *cfg, const double *fq, const sonde_gen
             hl % gen->symhd || gen->hdmax < 0 || gen->bitofs < -8 || gen->bitofs > 64 || gen->nbits < 1 || gen->nbits > 8192 || gen->skip_bits < 0 || gen->slice_baud < 0.f) return SONDE_E_ARG;
     }
     if (cfg->n_channels < 1 || cfg->sample_rate < 1 || (cfg->bits != 16 && cfg->bits != 8 && cfg->bits != 32)) return SONDE_E_ARG;
+    // every decoder of the reference turns the FM low-pass on when it runs `--IQ fq` with `--dc` (rs41mod.c:2747, dfm09mod.c:1475, m10mod.c:1320, ... — all eleven
+    // have the line): an engine that stands for such a decoder does the same, whether its caller remembered or not
+    sonde_cfg_t cfg_own = *cfg;
+    if (cfg->input == SONDE_IN_IQ && cfg->opt_dc && cfg->sonde_type != SONDE_FRONTEND) cfg_own.opt_lp |= SONDE_LP_FM;
+    cfg = &cfg_own;
     if ((cfg->sonde_type != SONDE_RS41 && cfg->sonde_type != SONDE_DFM09 && cfg->sonde_type != SONDE_M10 && cfg->sonde_type != SONDE_M20 && cfg->sonde_type != SONDE_FRONTEND && cfg->sonde_type != SONDE_GENERIC) ) return SONDE_E_ARG;
     if (cfg->opt_dc && cfg->sonde_type == SONDE_FRONTEND) return SONDE_E_ARG;
     if (cfg->opt_nolut && (cfg->opt_dc || cfg->input != SONDE_IN_IQ)) return SONDE_E_ARG;     // --noLUT folds Df into the base-rate mixer: not with --dc here

@@ -1372,7 +1372,14 @@ __device__ __forceinline__ void if_chain_body(const IfArgs &a, const int ch, con
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) win[j] = win[j + 2];
         }
-        if (T1 & 1) {
+        if (T1 == 1) {
+            // no IF low-pass (or a one-tap one): the sample times its weight, NOT 0 + sample * 1 — the sum would turn a -0 into +0, and the discriminator below
+            // tells them apart (atan2(+-0, +-0) = 0 / pi / -pi / -0): exactly-zero samples (8-bit input at 128 / 128) behind the AFC rotation carry signed zeros, and
+            // the reference's discriminator sees them (found by tests/fuzz/fuzz_chunks.py: 0.8 instead of 0 in 1.4 % of the noise samples moved a header-search arg-max)
+            const float w0 = wq[0];
+#pragma unroll
+            for (int j = 0; j < IF_NB; j++) acc[j] = win[j] * v2f{w0, w0};
+        } else if (T1 & 1) {
             const float w0 = wq[T1 - 1];
 #pragma unroll
             for (int j = 0; j < IF_NB; j++) acc[j] = __builtin_elementwise_fma(win[j], v2f{w0, w0}, acc[j]);

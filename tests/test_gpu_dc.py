@@ -99,3 +99,31 @@ def test_cli_dc_matches_reference(name):
     assert r.returncode == int(g["rc"]), r.stderr
     assert r.stderr.decode() == str(g["stderr"])
     assert [l.rstrip() for l in r.stdout.decode().splitlines()] == [l.rstrip() for l in g["lines"]]
+
+
+def test_engine_with_dc_turns_the_fm_lowpass_on_like_every_decoder():
+    """`--IQ fq` with `--dc`: every decoder of the reference sets LP_FM itself (rs41mod.c:2747, dfm09mod.c:1475, m10mod.c:1320).  An engine created with opt_dc and
+    WITHOUT SONDE_LP_FM must give the reference decoder's lines — found by tests/fuzz/fuzz_chunks.py (the CLIs set the flag, a library caller may not): the
+    repaired-symbol counts of noisy frames are what tells the two filters apart."""
+    sys.path.insert(0, ROOT)
+    from tools import synth
+    from radiosonde_auto_rx_amd.engine import Engine
+    ref = os.path.join(ROOT, "oracle", "_ref", "rs41mod")
+    if not os.path.exists(ref):
+        pytest.fail("oracle/_ref/rs41mod missing: run __graft_entry__.build() where /root/reference exists")
+    sr = 480_000
+    fq = synth.snap_fq(-0.23, sr)
+    x = synth.rs41_capture(sr=sr, seconds=4.3, fq=fq, seed=77, noise_sigma=0.08, bit_errors=12, t_first=0.4, f_offset_hz=-1452.0)
+    want = [ln.rstrip() for ln in subprocess.run([ref, "-r", "--ecc2", "--IQ", repr(fq), "--lpIQ", "--dc", "-", str(sr), "16"], input=x.tobytes(),
+                                                 capture_output=True, timeout=120).stdout.decode().splitlines()]
+    assert len(want) >= 3
+    for lp_fm in (False, True):
+        eng = Engine([fq], sr, sonde="rs41", ecc=2, lp_iq=True, lp_fm=lp_fm, opt_dc=True, max_chunk=sr, max_frames=32)
+        got = []
+        for s0 in range(0, len(x) // 2, sr):
+            m = min(sr, len(x) // 2 - s0) // 10 * 10
+            eng.process_host(x[None, 2 * s0:2 * (s0 + m)])
+            got += [f["line"].rstrip() for f in eng.fetch_frames()]
+        got += [f["line"].rstrip() for f in eng.fetch_frames(finish=True)]
+        eng.close()
+        assert got == want, (lp_fm, [g[-14:] for g in got], [w[-14:] for w in want])
