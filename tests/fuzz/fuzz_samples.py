@@ -76,12 +76,12 @@ def one(rng, it, keep_dir):
     ns = float([0.01, 0.03, 0.08, 0.15][rng.integers(4)])
     sd = int(rng.integers(1, 1 << 20))
     x = D["cap"](sr, fq, ns, sd)
-    if form != "IQ" and rng.integers(3) == 0:                       # a residual offset the IF-rate forms have to live with
-        z = (x[0::2] + 1j * x[1::2]) * np.exp(2j * np.pi * float(rng.uniform(-600, 600)) / sr * np.arange(len(x) // 2))
+    if rng.integers(3) == 0:                                        # a residual offset (the AFC of --dc unlocks beyond 1 kHz, demod_mod.c:1586-1599)
+        z = (x[0::2] + 1j * x[1::2]) * np.exp(2j * np.pi * float(rng.uniform(-1500, 1500) if rng.integers(2) else rng.uniform(-600, 600)) / sr * np.arange(len(x) // 2))
         x = np.empty_like(x); x[0::2] = np.clip(np.round(z.real), -32768, 32767); x[1::2] = np.clip(np.round(z.imag), -32768, 32767)
     if rng.integers(5) == 0:
         x = x.copy(); x[1::2] = -x[1::2]                           # spectrum / polarity inversion
-    k = int(rng.integers(8))
+    anom = k = int(rng.integers(8))
     if k == 0:                                                     # digital silence in front (the reference's mp = -1 path, tests/test_gpu_silence.py)
         x = np.concatenate([np.zeros(2 * int(sr * float(rng.uniform(0.05, 0.4))), np.int16), x])
     elif k == 1:                                                   # ... in the middle
@@ -135,10 +135,10 @@ def one(rng, it, keep_dir):
     ra = subprocess.run(["host/bin/" + dec] + args, input=data, capture_output=True, env=env, timeout=120)
     rb = subprocess.run(["oracle/_ref/" + dec] + args, input=data, capture_output=True, timeout=120)
     ok = ra.returncode == rb.returncode and ra.stdout == rb.stdout
-    if not ok and k < 4 and ra.returncode == rb.returncode and degenerate_only(ra.stdout, rb.stdout):
+    if not ok and anom < 4 and ra.returncode == rb.returncode and degenerate_only(ra.stdout, rb.stdout):
         return True, dec, -1                                      # (counted apart: raw bits of frames no block code accepts, on degenerate input)
     if not ok:
-        print("MISMATCH", dec, " ".join(args), "seed", sd, "noise", ns, "anomaly", {0: "silence in front", 1: "silence inside", 2: "offset", 3: "clipping"}.get(k, "none"), "rc", ra.returncode, rb.returncode, flush=True)
+        print("MISMATCH", dec, " ".join(args), "seed", sd, "noise", ns, "anomaly", {0: "silence in front", 1: "silence inside", 2: "offset", 3: "clipping"}.get(anom, "none"), "rc", ra.returncode, rb.returncode, flush=True)
         la, lb = ra.stdout.splitlines(), rb.stdout.splitlines()
         for u, v in zip(la, lb):
             if u != v:
@@ -150,7 +150,7 @@ def one(rng, it, keep_dir):
             os.makedirs(keep_dir, exist_ok=True)
             open(os.path.join(keep_dir, f"fail_{dec}_{it}.ours"), "wb").write(ra.stdout)
             open(os.path.join(keep_dir, f"fail_{dec}_{it}.ref"), "wb").write(rb.stdout)
-        if keep_dir and len(data) < (4 << 20):
+        if keep_dir and len(data) < (20 << 20):
             open(os.path.join(keep_dir, f"fail_{dec}_{it}.bin"), "wb").write(data)
             open(os.path.join(keep_dir, f"fail_{dec}_{it}.args"), "w").write(" ".join(args))
     return ok, dec, len(ra.stdout)
