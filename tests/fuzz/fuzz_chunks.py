@@ -1,6 +1,6 @@
 """Differential fuzzing of the single-type ENGINE (sonde_engine_create through engine.py) under the calls a library user makes — calls of any length, several channels
-with different options shared, --dc (the AFC loop restarts channels inside a call), --iqdc, --min, --lpbw, 8- / 16- / 32-bit samples, IF-rate input forms, pipelined or
-not — against the compiled reference decoder's stdout on every channel's bytes.  (The CLIs feed fixed calls; tests/fuzz/fuzz_mixed.py does this for the mixed engine.)
+with different options shared, --dc (the AFC loop restarts channels inside a call), --iqdc, --min, --lpbw, 8- / 16- / 32-bit samples, IF-rate input forms, FM audio,
+pipelined or not — against the compiled reference decoder's stdout on every channel's bytes.  (The CLIs feed fixed calls; tests/fuzz/fuzz_mixed.py does this for the mixed engine.)
     python tests/fuzz/fuzz_chunks.py <seed> <seconds of wall clock>     -> prints every mismatch; exit code = number of mismatching channels (capped at 255)"""
 import os
 import subprocess
@@ -20,7 +20,7 @@ REF = {"rs41": "rs41mod", "dfm": "dfm09mod", "m10": "m10mod"}
 def one(rng, it):
     from radiosonde_auto_rx_amd.engine import Engine
     kind = str(rng.choice(["rs41", "dfm", "m10"]))
-    form = str(rng.choice(["IQ", "IQ", "IQ", "iq0", "iq2", "iq3"]))
+    form = str(rng.choice(["IQ", "IQ", "IQ", "iq0", "iq2", "iq3", "audio"]))
     sr = int(rng.choice([480_000, 480_000, 960_000, 240_000, 2_400_000])) if form == "IQ" else 48_000
     C = int(rng.integers(1, 5 if sr > 1_000_000 else 9))
     dc = bool(rng.integers(3) == 0)
@@ -31,6 +31,8 @@ def one(rng, it):
     lp_fm = bool(rng.integers(5) == 0)
     eng_lp_fm = lp_fm or (form == "IQ" and dc)                  # the decoders' own rule (rs41mod.c:2747, dfm09mod.c:1475, m10mod.c:1320): --IQ with --dc turns the FM low-pass on
     bits = int(rng.choice([16, 16, 8, 32]))
+    if form == "audio":
+        bits = int(rng.choice([16, 16, 8])); iqdc = False; opt_min = False; lpbw = 0.0; lp_iq = False
     ecc = {"rs41": int(rng.choice([1, 1, 2])), "dfm": int(rng.choice([0, 1, 2])), "m10": 0}[kind]      # (rs41mod never runs without its decoder: rs41mod.c:2756 raises 0 to 1)
     seconds = float(rng.uniform(1.8, 3.3))
     fqs = [synth.snap_fq(float(rng.uniform(-0.4, 0.4)), sr) if form == "IQ" else 0.0 for _ in range(C)]
@@ -46,11 +48,21 @@ def one(rng, it):
                                           frame_fn=lambda i, sd=sd: synth.m10_frame(i, rng=np.random.default_rng(sd + i), good_checksum=(i + sd) % 4 != 3)))
     n = min(len(c) for c in caps) // 2
     x = np.stack([c[:2 * n] for c in caps])
-    xin = x if bits == 16 else synth.to_u8(x.reshape(-1)).reshape(x.shape) if bits == 8 else synth.to_f32(x.reshape(-1)).reshape(x.shape)
+    if form == "audio":                                           # FM audio (a WAV for the decoder, the PCM for the engine), one audio channel
+        pcm = np.stack([synth.fm_audio(c, gain=float(rng.uniform(0.15, 0.45))) for c in x])
+        x = pcm; n = pcm.shape[1]
+        xin = pcm if bits == 16 else synth.to_u8(pcm.reshape(-1)).reshape(pcm.shape)
+    else:
+        xin = x if bits == 16 else synth.to_u8(x.reshape(-1)).reshape(x.shape) if bits == 8 else synth.to_f32(x.reshape(-1)).reshape(x.shape)
+    per = 1 if form == "audio" else 2
     max_chunk = int(rng.choice([sr, sr // 2, 2 * sr]))
-    pipeline = bool(rng.integers(2)) and not dc
-    eng = Engine(fqs, sr, sonde=kind, ecc=ecc, lp_iq=lp_iq, lp_fm=eng_lp_fm, lpiq_bw=int(round(lpbw * 1e3)), opt_dc=dc, opt_min=opt_min, bits=bits, iqdc=iqdc,
-                 iq_mode={"IQ": 5, "iq0": 1, "iq2": 2, "iq3": 3}[form], max_chunk=max_chunk, max_frames=64 * C, pipeline=pipeline)
+    pipeline = bool(rng.integers(2)) and not dc and form != "audio"      # (the pipelined form is the base-rate / IF-rate engines'; an FM-audio engine refuses it)
+    try:
+      eng = Engine(fqs, sr, sonde=kind, ecc=ecc, lp_iq=lp_iq, lp_fm=eng_lp_fm, lpiq_bw=int(round(lpbw * 1e3)), opt_dc=dc, opt_min=opt_min, bits=bits, iqdc=iqdc,
+                 iq_mode={"IQ": 5, "iq0": 1, "iq2": 2, "iq3": 3, "audio": 5}[form], audio=(form == "audio"), max_chunk=max_chunk, max_frames=64 * C, pipeline=pipeline)
+    except Exception as ex:
+        print(f"REFUSED it {it}: {kind} {form} sr {sr} bits {bits} dc {dc} iqdc {iqdc} min {opt_min} lpbw {lpbw} lp_iq {lp_iq} lp_fm {lp_fm} pipeline {pipeline}: {ex}", flush=True)
+        return 0, 0, 0
     D = eng.info["decM"]
     fetch = {"rs41": lambda fin: eng.fetch_frames(finish=fin), "dfm": lambda fin: eng.fetch_dfm(finish=fin), "m10": lambda fin: eng.fetch_mxx(finish=fin)}[kind]
     pos, lines, calls = 0, {}, []
@@ -58,7 +70,7 @@ def one(rng, it):
         take = min(int(rng.choice([max_chunk, max_chunk, int(rng.integers(D, max_chunk + 1)), int(rng.integers(D, 60 * D))])), n - pos) // D * D
         if take <= 0:
             break
-        eng.process_host(xin[:, 2 * pos:2 * (pos + take)])
+        eng.process_host(xin[:, per * pos:per * (pos + take)])
         pos += take; calls.append(take)
         for f in fetch(False):
             lines.setdefault(f["channel"], []).append(f["line"].rstrip())
@@ -70,6 +82,24 @@ def one(rng, it):
     bad = 0
     for c in range(C):
         a = list(args)
+        if form == "audio":
+            if lp_fm:
+                a.append("--lpFM")
+            if dc:
+                a.append("--dc")
+            data = synth.wav_bytes(np.ascontiguousarray(xin[c, :pos]), sr, 1, bits)
+            r = subprocess.run([os.path.join("oracle", "_ref", REF[kind])] + a, input=data, capture_output=True, timeout=600)
+            want = [ln.rstrip() for ln in r.stdout.decode().splitlines()]
+            have = lines.get(c, [])
+            if have != want or over:
+                bad += 1
+                k = next((i for i in range(min(len(have), len(want))) if have[i] != want[i]), min(len(have), len(want)))
+                print(f"MISMATCH it {it} channel {c}/{C}: {REF[kind]} {' '.join(a)} <WAV {sr} Hz {bits} bit>  pipeline {pipeline} calls {calls[:10]} overflow {over}: {len(have)} lines against {len(want)}, first difference at line {k}", flush=True)
+                if k < len(have):
+                    print("   ours:", have[k][:160])
+                if k < len(want):
+                    print("   ref: ", want[k][:160])
+            continue
         a += ["--IQ", repr(fqs[c])] if form == "IQ" else ["--" + form]
         if opt_min:
             a.append("--min")
