@@ -174,7 +174,7 @@ int main(int argc, char **argv) {
         got -= got % (size_t)info.decM;
         if (got == 0) break;
         rc = sonde_scan_process_host(sc, buf, batch ? 0 : (int64_t)got, (int32_t)got);      /* stride 0: all channels read the one stream */
-        if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); break; }
+        if (rc < 0) { fprintf(stderr, "error: %s\n", sonde_strerror(rc)); sonde_scan_destroy(sc); free(buf); return -50; }      /* the reference's error code (dft_detect.c:1446-1455), not a detection result */
         print_detections(sc, verbose, silent, batch, fqs);
         int all_done = 1;
         for (int c = 0; c < cfg.n_channels; c++) all_done &= sonde_scan_channel_done(sc, c) == 1;

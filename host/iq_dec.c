@@ -101,14 +101,16 @@ int main(int argc, char **argv) {
     int16_t *buf = (int16_t *)malloc((size_t)chunk * unit);
     float *out = (float *)malloc((size_t)(chunk / info.decM + 8) * 8);
     int64_t m_done = 0;                                   /* IF samples written so far */
+    int failed = 0;
     const int tap = opt_fm ? SONDE_TAP_FM : ((cfg.opt_lp & SONDE_LP_IQ) ? SONDE_TAP_IFIQ : SONDE_TAP_DECIM);
     for (;;) {
         size_t got = fread(buf, unit, (size_t)chunk, fp);
         got -= got % (size_t)(info.decM * decFM);                      /* whole output samples only (if_fm returns EOF mid-block) */
         if (got == 0) break;
-        if (sonde_engine_process_host(eng, buf, (int64_t)got, (int32_t)got) < 0) break;
+        int erc = sonde_engine_process_host(eng, buf, (int64_t)got, (int32_t)got);
         const int n_if = (int)(got / (size_t)info.decM);
-        if (sonde_engine_read_tap(eng, 0, tap, m_done, n_if, out) < 0) break;
+        if (erc >= 0) erc = sonde_engine_read_tap(eng, 0, tap, m_done, n_if, out);
+        if (erc < 0) { fprintf(stderr, "iq_dec: the engine failed (%s)\n", sonde_strerror(erc)); failed = 1; break; }     /* never a silent 0 */
         if (opt_fm) {
             int k = 0;
             for (int m = decFM - 1; m < n_if; m += decFM) out[k++] = out[m];       /* s_fm of the last sub-sample (iq_dec.c:551-618) */
@@ -119,5 +121,5 @@ int main(int argc, char **argv) {
     }
     sonde_engine_destroy(eng);
     free(buf); free(out);
-    return 0;
+    return failed ? -1 : 0;
 }
