@@ -49,6 +49,26 @@ def test_oracle_vs_live_reference(oracle):
         assert rms(so[k] - ss[k]) < 1e-7, k
 
 
+def test_oracle_behind_digital_silence_vs_live_reference(oracle):
+    """A stream that begins with exact zeros: the reference's arg-max leaves mp = -1 in the all-zero first window, stores the WRAPPED position and misses the header the
+    second window finds (demod_mod.c:200-215,1603; scan/dft_detect.c:415-443,1521).  Both restatements follow it (ora_dsp.c norm_at / corr_window, ora_scan.py window):
+    pinned here against the compiled reference on the CPU — the product's side is tests/test_gpu_silence.py."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    from tools import synth
+    sr = 480_000
+    fq = synth.snap_fq(0.13, sr)
+    x = synth.rs41_capture(sr=sr, seconds=3.3, fq=fq, noise_sigma=0.02, seed=11, n_frames=3, t_first=0.005)
+    for lsb in (False, True):
+        head = np.zeros(2 * int(0.17 * sr), np.int16)
+        if lsb:
+            head[:] = np.random.default_rng(3).integers(-1, 2, len(head))
+        xs = np.concatenate([head, x])
+        o = oracle.ora_rs41_decode(xs, sr, fq=fq)
+        out, _, rc = oracle.ref_run("rs41mod", ["-r", "--ecc2", "--crc", "--IQ", repr(fq), "--lpIQ", "-", str(sr), "16"], xs)
+        assert rc == 0 and out.splitlines() == o["lines"] and o["n"] == (3 if lsb else 2), (lsb, o["n"], len(out.splitlines()))
+
+
 def test_rs_decoder_vs_reference(oracle):
     """RS(255,231): restated Euclid decoder == reference decoder incl. failures/miscorrections."""
     import ctypes as C

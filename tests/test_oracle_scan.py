@@ -60,3 +60,26 @@ def test_corr_window_matches_reference(design, name):
                 assert e == g["herrs"][w][j]
         checked += 1
     assert checked >= 3 and g["herrs"][w][jhit] >= 0
+
+
+def test_all_zero_first_window_is_the_references_mp_minus_one(design):
+    """A stream that begins with digital silence: in the all-zero first window the reference's arg-max leaves mp = -1 and getCorrDFT goes on to store the WRAPPED position
+    pos - (K + L - 1) - 1 - lpFMtaps / 2 (dft_detect.c:415-438) — what makes `mv_pos > mv0_pos` (:1521) fail for the header the second window finds.  The restatement's
+    window function says the same as the live harness (oracle/_ref/libref_scan.so), template by template."""
+    from oracle import bind
+    if not bind.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    from tools import synth
+    sr = 48_000
+    x = np.concatenate([np.zeros(2 * 6000, np.int16), synth.rs41_capture(sr=sr, seconds=1.2, fq=0.0, noise_sigma=0.03, seed=7, t_first=0.005)])
+    r = bind.ref_scan_windows(x, sr, iq_mode=1, dc=False, max_win=8)
+    assert r["n"] >= 2
+    pos0 = int(r["pos"][0])
+    zeros = np.zeros(pos0 + 1, np.float32)
+    checked = 0
+    for j in design.active:
+        assert int(r["mp"][0][j]) == -1, (j, r["mp"][0][j])
+        o = design.corr(j, zeros, pos0, False)
+        assert o["mp"] == -1 and o["mpos"] == int(r["mpos"][0][j]) and o["mpos"] > 0xFFFF0000, (j, o, int(r["mpos"][0][j]))
+        checked += 1
+    assert checked >= 10
